@@ -1,0 +1,70 @@
+"""ctypes binding of libfqhip.so (C ABI declared in include/fqhip.h).
+
+There is NO fallback: if the shared library is missing or fails to load, importing this module raises, and
+every op in the package is unusable.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C flatquant_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfqhip.so")
+
+# flags (include/fqhip.h)
+FQ_OUT_PACKED = 0x01
+FQ_OUT_FAKEQUANT = 0x02
+FQ_OUT_TRANSFORM = 0x04
+FQ_ROUND_Y_F16 = 0x08
+FQ_NO_CLAMP0 = 0x10
+FQ_QUANT_F16 = 0x20
+FQ_MAX_CLIPS = 4
+
+FQ_OK, FQ_EINVAL, FQ_EUNSUPPORTED, FQ_ELAUNCH = 0, -1, -2, -3
+
+# every symbol include/fqhip.h declares: (name, restype, argtypes)
+_vp, _i64, _i, _f = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+_fp = ctypes.POINTER(ctypes.c_float)
+_vpp = ctypes.POINTER(ctypes.c_void_p)
+SYMBOLS = {
+    "fq_kron_quant_f16": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp]),
+    "fq_block_quant_f16": (_i, [_vp, _vp, _i64, _i, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp]),
+    "fq_hadamard_f16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _f, _vp]),
+    "fq_rowquant_f16": (_i, [_vp, _i64, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp]),
+    "fq_sym_quant_f16": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    "fq_sym_dequant_i32_f16": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
+    "fq_probe_mfma_32x32x16_f16": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "fq_last_error": (ctypes.c_char_p, []),
+    "fq_version": (_i, []),
+}
+
+
+class FqError(RuntimeError):
+    """A libfqhip entry point returned a negative code (mirrors torch::check* -> RuntimeError in the
+    reference's bindings.cpp:11-16,29-34)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libfqhip error {code}: {msg}")
+        self.code = code
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `make -C flatquant_amd/csrc` "
+            "(needs hipcc, --offload-arch=gfx950). flatquant_amd has no CPU or PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(code: int) -> None:
+    if code != FQ_OK:
+        raise FqError(code, lib.fq_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,200 @@
+// fq_capi.hip — the C ABI of libfqhip.so (include/fqhip.h). Argument validation + dispatch only.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "fq_common.hpp"
+
+// launchers defined in the kernel translation units
+int fq_launch_kron64(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
+                     int64_t rows, const FqQuantOut& out, int n_cu, hipStream_t stream);
+int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
+                           int64_t rows, int M, int N, const FqQuantOut& out, int n_cu,
+                           hipStream_t stream);
+int fq_launch_block(int flags, const f16* x, const f16* P, int64_t rows, int R, int C, int transpose_out,
+                    const FqQuantOut& out, int n_cu, hipStream_t stream);
+int fq_launch_hadamard(const f16* x, f16* y, int64_t rows, int n, int K, const f16* hadK, float scale,
+                       int n_cu, hipStream_t stream);
+int fq_launch_rowquant(int flags, const f16* x, int64_t rows, int cols, const FqQuantOut& out, int n_cu,
+                       hipStream_t stream);
+int fq_launch_sym_quant(const f16* x, const f16* scale, int64_t rows, int cols, uint8_t* q, int n_cu,
+                        hipStream_t stream);
+int fq_launch_sym_dequant(const int32_t* q, const f16* srow, const f16* scol, int64_t rows, int cols,
+                          f16* x, int n_cu, hipStream_t stream);
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        return 256;
+    return n;
+}
+
+int check_launch(int rc, const char* what) {
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "%s: flag combination / shape has no compiled kernel", what);
+    if (rc != 0) return fail(FQ_ELAUNCH, "%s: HIP launch failed: %s", what, hipGetErrorString((hipError_t)rc));
+    return FQ_OK;
+}
+
+// Fill FqQuantOut from the C-ABI arguments; validates the pointers the flags require.
+int fill_out(const char* what, FqQuantOut& o, const float* sig_max, const float* sig_min, int n_clips,
+             int flags, void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out) {
+    memset(&o, 0, sizeof(o));
+    const int outs = flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM);
+    if (outs == 0) return fail(FQ_EINVAL, "%s: flags select no output", what);
+    if (flags & ~(FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_ROUND_Y_F16 | FQ_NO_CLAMP0 |
+                  FQ_QUANT_F16))
+        return fail(FQ_EINVAL, "%s: unknown flag bits 0x%x", what, flags);
+    if (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) {
+        if (n_clips < 1 || n_clips > FQ_MAX_CLIPS)
+            return fail(FQ_EINVAL, "%s: n_clips=%d out of [1,%d]", what, n_clips, FQ_MAX_CLIPS);
+        if (!sig_max || !sig_min) return fail(FQ_EINVAL, "%s: sig_max/sig_min is NULL", what);
+        o.n_clips = n_clips;
+        for (int i = 0; i < n_clips; ++i) {
+            o.sig_max[i] = sig_max[i];
+            o.sig_min[i] = sig_min[i];
+            if (flags & FQ_OUT_PACKED) {
+                if (!q_out || !scale_out || !q_out[i] || !scale_out[i])
+                    return fail(FQ_EINVAL, "%s: FQ_OUT_PACKED needs q_out[%d] and scale_out[%d]", what, i, i);
+                o.q[i] = (uint8_t*)q_out[i];
+                o.scale[i] = (f16*)scale_out[i];
+            }
+            if (flags & FQ_OUT_FAKEQUANT) {
+                if (!fq_out || !fq_out[i]) return fail(FQ_EINVAL, "%s: FQ_OUT_FAKEQUANT needs fq_out[%d]", what, i);
+                o.fq[i] = (f16*)fq_out[i];
+            }
+        }
+    }
+    if (flags & FQ_OUT_TRANSFORM) {
+        if (!y_out) return fail(FQ_EINVAL, "%s: FQ_OUT_TRANSFORM needs y_out", what);
+        o.y = (f16*)y_out;
+    }
+    return FQ_OK;
+}
+
+__global__ void fq_probe_mfma_kernel(const f16* __restrict__ A, const f16* __restrict__ B,
+                                     const float* __restrict__ C, float* __restrict__ D) {
+    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+    f16x8 a, b;
+    f32x16 acc;
+    for (int j = 0; j < 8; ++j) {
+        a[j] = A[c * 16 + h * 8 + j];        // A[i = c][k = 8h + j]
+        b[j] = B[(h * 8 + j) * 32 + c];      // B[k = 8h + j][col = c]
+    }
+    for (int r = 0; r < 16; ++r) acc[r] = C[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + c];
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + c] = acc[r];
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fq_last_error(void) { return g_err; }
+int fq_version(void) { return 100; }
+
+int fq_kron_quant_f16(const void* x, const void* left, const void* right, const void* diag, int64_t rows,
+                      int M, int N, const float* sig_max, const float* sig_min, int n_clips, int flags,
+                      void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                      void* stream) {
+    if (!x || !left || !right) return fail(FQ_EINVAL, "fq_kron_quant_f16: x/left/right is NULL");
+    if (rows < 0 || M <= 0 || N <= 0) return fail(FQ_EINVAL, "fq_kron_quant_f16: bad sizes rows=%lld M=%d N=%d", (long long)rows, M, N);
+    if (N & 1) return fail(FQ_EINVAL, "fq_kron_quant_f16: N=%d must be even (two INT4 per byte)", N);
+    FqQuantOut o;
+    int rc = fill_out("fq_kron_quant_f16", o, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out, y_out);
+    if (rc != FQ_OK) return rc;
+    if (rows == 0) return FQ_OK;
+    const int n_cu = cu_count();
+    if (M == 64 && N == 64) {
+        rc = fq_launch_kron64(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag,
+                              rows, o, n_cu, (hipStream_t)stream);
+        if (rc != -1000) return check_launch(rc, "fq_kron_quant_f16[64x64]");
+    }
+    rc = fq_launch_kron_generic(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag,
+                                rows, M, N, o, n_cu, (hipStream_t)stream);
+    return check_launch(rc, "fq_kron_quant_f16[generic]");
+}
+
+int fq_block_quant_f16(const void* x, const void* P, int64_t rows, int R, int C, int transpose_out,
+                       const float* sig_max, const float* sig_min, int n_clips, int flags,
+                       void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                       void* stream) {
+    if (!x || !P) return fail(FQ_EINVAL, "fq_block_quant_f16: x/P is NULL");
+    if (rows < 0 || R <= 0 || C <= 0) return fail(FQ_EINVAL, "fq_block_quant_f16: bad sizes");
+    FqQuantOut o;
+    int rc = fill_out("fq_block_quant_f16", o, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out, y_out);
+    if (rc != FQ_OK) return rc;
+    if (rows == 0) return FQ_OK;
+    rc = fq_launch_block(flags, (const f16*)x, (const f16*)P, rows, R, C, transpose_out, o, cu_count(),
+                         (hipStream_t)stream);
+    return check_launch(rc, "fq_block_quant_f16");
+}
+
+int fq_hadamard_f16(const void* x, void* y, int64_t rows, int n, int K, const void* hadK, float scale,
+                    void* stream) {
+    if (!x || !y) return fail(FQ_EINVAL, "fq_hadamard_f16: x/y is NULL");
+    if (rows < 0 || n <= 0 || K <= 0 || n % K) return fail(FQ_EINVAL, "fq_hadamard_f16: bad sizes n=%d K=%d", n, K);
+    const int p2 = n / K;
+    if (p2 & (p2 - 1)) return fail(FQ_EINVAL, "fq_hadamard_f16: n/K=%d is not a power of two", p2);
+    if (K > 1 && !hadK) return fail(FQ_EINVAL, "fq_hadamard_f16: hadK is NULL with K=%d", K);
+    if (rows == 0) return FQ_OK;
+    int rc = fq_launch_hadamard((const f16*)x, (f16*)y, rows, n, K, (const f16*)hadK, scale, cu_count(),
+                                (hipStream_t)stream);
+    return check_launch(rc, "fq_hadamard_f16");
+}
+
+int fq_rowquant_f16(const void* x, int64_t rows, int cols, const float* sig_max, const float* sig_min,
+                    int n_clips, int flags, void* const* q_out, void* const* scale_out,
+                    void* const* fq_out, void* stream) {
+    if (!x) return fail(FQ_EINVAL, "fq_rowquant_f16: x is NULL");
+    if (rows < 0 || cols <= 0) return fail(FQ_EINVAL, "fq_rowquant_f16: bad sizes");
+    if (cols & 7) return fail(FQ_EUNSUPPORTED, "fq_rowquant_f16: cols=%d must be a multiple of 8", cols);
+    if (cols > 32768) return fail(FQ_EUNSUPPORTED, "fq_rowquant_f16: cols=%d > 32768", cols);
+    if (flags & FQ_OUT_TRANSFORM) return fail(FQ_EINVAL, "fq_rowquant_f16: FQ_OUT_TRANSFORM is meaningless here");
+    FqQuantOut o;
+    int rc = fill_out("fq_rowquant_f16", o, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out, nullptr);
+    if (rc != FQ_OK) return rc;
+    if (rows == 0) return FQ_OK;
+    rc = fq_launch_rowquant(flags, (const f16*)x, rows, cols, o, cu_count(), (hipStream_t)stream);
+    return check_launch(rc, "fq_rowquant_f16");
+}
+
+int fq_sym_quant_f16(const void* x, const void* scale, int64_t rows, int cols, void* q, void* stream) {
+    if (!x || !scale || !q) return fail(FQ_EINVAL, "fq_sym_quant_f16: NULL pointer");
+    if (rows < 0 || cols <= 0) return fail(FQ_EINVAL, "fq_sym_quant_f16: bad sizes");
+    if (rows == 0) return FQ_OK;
+    return check_launch(fq_launch_sym_quant((const f16*)x, (const f16*)scale, rows, cols, (uint8_t*)q,
+                                            cu_count(), (hipStream_t)stream),
+                        "fq_sym_quant_f16");
+}
+
+int fq_sym_dequant_i32_f16(const void* q, const void* scale_row, const void* scale_col, int64_t rows,
+                           int cols, void* x, void* stream) {
+    if (!q || !scale_row || !scale_col || !x) return fail(FQ_EINVAL, "fq_sym_dequant_i32_f16: NULL pointer");
+    if (rows < 0 || cols <= 0) return fail(FQ_EINVAL, "fq_sym_dequant_i32_f16: bad sizes");
+    if (rows == 0) return FQ_OK;
+    return check_launch(fq_launch_sym_dequant((const int32_t*)q, (const f16*)scale_row, (const f16*)scale_col,
+                                              rows, cols, (f16*)x, cu_count(), (hipStream_t)stream),
+                        "fq_sym_dequant_i32_f16");
+}
+
+int fq_probe_mfma_32x32x16_f16(const void* A, const void* B, const void* C, void* D, void* stream) {
+    if (!A || !B || !C || !D) return fail(FQ_EINVAL, "fq_probe_mfma: NULL pointer");
+    hipLaunchKernelGGL(fq_probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const f16*)A,
+                       (const f16*)B, (const float*)C, (float*)D);
+    return check_launch((int)hipGetLastError(), "fq_probe_mfma");
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+// fq_common.hpp — shared device helpers for the gfx950 kernels of libfqhip.
+//
+// Arithmetic pinned here (and restated on the CPU in oracle/):
+//   * per-token statistics, scale = m/7 and x/scale are IEEE fp32 (round-to-nearest-even, correctly
+//     rounded division), mirroring flatquant/quant_utils.py:85-107 when `lac` promotes to fp32 and
+//     deploy/kernels/kron_matmul.py:91-107;
+//   * rint is round-half-to-even (torch.round / llrint / __half2int_rn);
+//   * nibble order: even element -> low nibble (deploy/functional/quantization.py:49-56).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/fqhip.h"
+
+typedef _Float16 f16;
+typedef f16   f16x2  __attribute__((ext_vector_type(2)));
+typedef f16   f16x4  __attribute__((ext_vector_type(4)));
+typedef f16   f16x8  __attribute__((ext_vector_type(8)));
+typedef float f32x4  __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Per-launch output description, passed by value as a kernel argument.
+struct FqQuantOut {
+    float    sig_max[FQ_MAX_CLIPS];
+    float    sig_min[FQ_MAX_CLIPS];
+    uint8_t* q[FQ_MAX_CLIPS];      // packed INT4, or nullptr
+    f16*     scale[FQ_MAX_CLIPS];  // fp16 scales, or nullptr
+    f16*     fq[FQ_MAX_CLIPS];     // fake-quant fp16, or nullptr
+    f16*     y;                    // transformed fp16, or nullptr
+    int      n_clips;
+};
+
+__device__ __forceinline__ float fq_wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float fq_wave_min(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// scale from (xmax, xmin) of one token and one clip set; see header comment for the pinned arithmetic.
+template <int FLAGS>
+__device__ __forceinline__ float fq_token_scale(float xmax, float xmin, float sig_max, float sig_min) {
+    if (!(FLAGS & FQ_NO_CLAMP0)) {
+        xmax = fmaxf(xmax, 0.0f);
+        xmin = fminf(xmin, 0.0f);
+    }
+    xmax = xmax * sig_max;
+    xmin = xmin * sig_min;
+    float m = fmaxf(fabsf(xmin), xmax);
+    float scale;
+    if (FLAGS & FQ_QUANT_F16) {
+        // fp16 scale: (m/7).to(fp16) as deploy/nn/quantization.py:25-30 and quant_utils.py:103 (fp16
+        // tensors; with sig == 1 m is itself an fp16 value, so fp16(m/7) is the fp16 division).
+        scale = (float)(f16)(m / 7.0f);
+        if (m == 0.0f) scale = 1.0f;
+    } else {
+        scale = m / 7.0f;
+        if (m == 0.0f) scale = 1.0f;
+    }
+    return scale;
+}
+
+// clamp(rint(y/scale), -8, 7) as an integer in [-8, 7].
+template <int FLAGS>
+__device__ __forceinline__ int fq_quant1(float y, float scale) {
+    float t = y / scale;                       // correctly rounded fp32 division
+    if (FLAGS & FQ_QUANT_F16) t = (float)(f16)t;  // fp16 quotient (== __hdiv, no double-rounding issue)
+    t = __builtin_rintf(t);
+    t = fminf(fmaxf(t, -8.0f), 7.0f);
+    return (int)t;
+}
+
+template <int FLAGS>
+__device__ __forceinline__ f16 fq_dequant1(int q, float scale) {
+    if (FLAGS & FQ_QUANT_F16) return (f16)((float)(f16)scale * (float)q);  // fp16 product, one rounding
+    return (f16)(scale * (float)q);
+}

@@ -1,0 +1,220 @@
+// fq_quant.hip — standalone quantisation kernels (HBM-bound byte work, no MFMA).
+//
+//   fq_rowquant_kernel      deploy/nn/quantization.py:13-36 (Quantizer.forward: 5-8 torch launches + the
+//                           CUDA pack kernel) and flatquant/quant_utils.py:77-119 in ONE pass: a row is
+//                           read once into registers, reduced, quantised, packed, written.
+//   fq_sym_quant_kernel     deploy/kernels/quant.cu:13-47  (fp16 division, rn, clamp, low nibble first)
+//   fq_sym_dequant_kernel   deploy/kernels/quant.cu:66-85
+#include "fq_common.hpp"
+
+namespace {
+
+constexpr int RQ_THREADS = 256;
+constexpr int RQ_MAXCH = 16;  // 16-byte chunks per thread: cols <= 256 * 16 * 8 = 32768
+
+// One workgroup per row; each thread keeps its 16-byte chunks (8 fp16) in registers.
+template <int FLAGS, int NCH>
+__global__ __launch_bounds__(RQ_THREADS) void fq_rowquant_kernel(const f16* __restrict__ x, int64_t rows,
+                                                                 int cols, FqQuantOut out) {
+    __shared__ float red[2][RQ_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int nchunks = cols >> 3;  // cols % 8 == 0 enforced by the host
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const uint4* xp = reinterpret_cast<const uint4*>(x + row * (int64_t)cols);
+        f16x8 v[NCH];
+        float vmax = -INFINITY, vmin = INFINITY;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = tid + k * RQ_THREADS;
+            if (ch < nchunks) {
+                v[k] = __builtin_bit_cast(f16x8, xp[ch]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    vmax = fmaxf(vmax, (float)v[k][e]);
+                    vmin = fminf(vmin, (float)v[k][e]);
+                }
+            }
+        }
+        vmax = fq_wave_max(vmax);
+        vmin = fq_wave_min(vmin);
+        __syncthreads();  // protect `red` against the previous iteration's readers
+        if ((tid & 63) == 0) {
+            red[0][tid >> 6] = vmax;
+            red[1][tid >> 6] = vmin;
+        }
+        __syncthreads();
+        vmax = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        vmin = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
+
+        for (int ci = 0; ci < out.n_clips; ++ci) {
+            const float scale = fq_token_scale<FLAGS>(vmax, vmin, out.sig_max[ci], out.sig_min[ci]);
+            if (FLAGS & FQ_OUT_PACKED) {
+                if (tid == 0) out.scale[ci][row] = (f16)scale;
+                uint32_t* qp = reinterpret_cast<uint32_t*>(out.q[ci] + row * (int64_t)(cols >> 1));
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const int ch = tid + k * RQ_THREADS;
+                    if (ch < nchunks) {
+                        uint32_t d = 0;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            d |= (uint32_t)(fq_quant1<FLAGS>((float)v[k][e], scale) & 15) << (4 * e);
+                        qp[ch] = d;
+                    }
+                }
+            }
+            if (FLAGS & FQ_OUT_FAKEQUANT) {
+                uint4* fp = reinterpret_cast<uint4*>(out.fq[ci] + row * (int64_t)cols);
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const int ch = tid + k * RQ_THREADS;
+                    if (ch < nchunks) {
+                        f16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            o[e] = fq_dequant1<FLAGS>(fq_quant1<FLAGS>((float)v[k][e], scale), scale);
+                        fp[ch] = __builtin_bit_cast(uint4, o);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// q = clamp(rn(x /h scale[row])) — fp16 division exactly as __hdiv (quant.cu:40): the fp32 quotient of
+// two fp16 values rounded to fp16 is the correctly rounded fp16 quotient (24 >= 2*11+2).
+__device__ __forceinline__ int symq1(f16 x, f16 s) {
+    f16 d = (f16)((float)x / (float)s);
+    float t = __builtin_rintf((float)d);
+    t = fminf(fmaxf(t, -8.0f), 7.0f);
+    return (int)t;
+}
+
+// Fast path: cols % 8 == 0. One thread packs 8 values (16-byte load, 4-byte store).
+__global__ __launch_bounds__(256) void fq_sym_quant_vec_kernel(const f16* __restrict__ x,
+                                                               const f16* __restrict__ scale,
+                                                               int64_t rows, int cols,
+                                                               uint8_t* __restrict__ q) {
+    const int cpr = cols >> 3;  // chunks per row
+    const int64_t total = rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cpr;
+        const f16 s = scale[row];
+        const f16x8 v = __builtin_bit_cast(f16x8, reinterpret_cast<const uint4*>(x)[i]);
+        uint32_t d = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d |= (uint32_t)(symq1(v[e], s) & 15) << (4 * e);
+        reinterpret_cast<uint32_t*>(q)[i] = d;
+    }
+}
+
+// General path: any cols (odd tail -> high nibble 0, as quant.cu:27-46 memset + `safe`).
+__global__ __launch_bounds__(256) void fq_sym_quant_gen_kernel(const f16* __restrict__ x,
+                                                               const f16* __restrict__ scale,
+                                                               int64_t rows, int cols, int cols_dst,
+                                                               uint8_t* __restrict__ q) {
+    const int64_t total = rows * cols_dst;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cols_dst;
+        const int cd = (int)(i - row * cols_dst);
+        const f16 s = scale[row];
+        const f16* xr = x + row * (int64_t)cols;
+        uint32_t b = (uint32_t)(symq1(xr[2 * cd], s) & 15);
+        if (2 * cd + 1 < cols) b |= (uint32_t)(symq1(xr[2 * cd + 1], s) & 15) << 4;
+        q[i] = (uint8_t)b;
+    }
+}
+
+// x = scale_row[r] * scale_col[c] * half(int(q / 10.0f) clamped to +-65176) * half(10), every product
+// rounded to fp16 left-to-right (quant.cu:5-10, 83-84).
+__global__ __launch_bounds__(256) void fq_sym_dequant_kernel(const int32_t* __restrict__ q,
+                                                             const f16* __restrict__ srow,
+                                                             const f16* __restrict__ scol, int64_t rows,
+                                                             int cols, f16* __restrict__ x) {
+    const int64_t total = rows * (int64_t)cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cols;
+        const int col = (int)(i - row * cols);
+        int iv = (int)((float)q[i] / 10.0f);  // C truncation toward zero
+        iv = max(-65176, min(65176, iv));
+        const f16 xe = (f16)iv;  // __int2half_rn
+        f16 r = srow[row] * scol[col];
+        r = r * xe;
+        r = r * (f16)10.0f;
+        x[i] = r;
+    }
+}
+
+template <int FLAGS>
+int launch_rowquant(const f16* x, int64_t rows, int cols, const FqQuantOut& out, int n_cu,
+                    hipStream_t stream) {
+    const int nch = ((cols >> 3) + RQ_THREADS - 1) / RQ_THREADS;
+    int64_t blocks = rows;
+    const int64_t cap = (int64_t)n_cu * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    dim3 g((unsigned)blocks), b(RQ_THREADS);
+#define FQ_RQ(N)                                                                                 \
+    if (nch <= (N)) {                                                                            \
+        hipLaunchKernelGGL((fq_rowquant_kernel<FLAGS, (N)>), g, b, 0, stream, x, rows, cols, out); \
+        return (int)hipGetLastError();                                                           \
+    }
+    FQ_RQ(2) FQ_RQ(4) FQ_RQ(8) FQ_RQ(RQ_MAXCH)
+#undef FQ_RQ
+    return -1000;
+}
+
+}  // namespace
+
+int fq_launch_rowquant(int flags, const f16* x, int64_t rows, int cols, const FqQuantOut& out, int n_cu,
+                       hipStream_t stream) {
+#define FQ_CASE(F) \
+    case (F):      \
+        return launch_rowquant<(F)>(x, rows, cols, out, n_cu, stream);
+    switch (flags) {
+        FQ_CASE(FQ_OUT_PACKED)
+        FQ_CASE(FQ_OUT_PACKED | FQ_NO_CLAMP0)
+        FQ_CASE(FQ_OUT_PACKED | FQ_QUANT_F16)
+        FQ_CASE(FQ_OUT_FAKEQUANT)
+        FQ_CASE(FQ_OUT_FAKEQUANT | FQ_QUANT_F16)
+        FQ_CASE(FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)
+        default:
+            return -1000;
+    }
+#undef FQ_CASE
+}
+
+int fq_launch_sym_quant(const f16* x, const f16* scale, int64_t rows, int cols, uint8_t* q, int n_cu,
+                        hipStream_t stream) {
+    if ((cols & 7) == 0) {
+        const int64_t total = rows * (cols >> 3);
+        int64_t blocks = (total + 255) / 256;
+        if (blocks > (int64_t)n_cu * 16) blocks = (int64_t)n_cu * 16;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(fq_sym_quant_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, scale,
+                           rows, cols, q);
+    } else {
+        const int cols_dst = (cols + 1) / 2;
+        const int64_t total = rows * cols_dst;
+        int64_t blocks = (total + 255) / 256;
+        if (blocks > (int64_t)n_cu * 16) blocks = (int64_t)n_cu * 16;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(fq_sym_quant_gen_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, scale,
+                           rows, cols, cols_dst, q);
+    }
+    return (int)hipGetLastError();
+}
+
+int fq_launch_sym_dequant(const int32_t* q, const f16* srow, const f16* scol, int64_t rows, int cols,
+                          f16* x, int n_cu, hipStream_t stream) {
+    const int64_t total = rows * (int64_t)cols;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > (int64_t)n_cu * 16) blocks = (int64_t)n_cu * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fq_sym_dequant_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q, srow, scol,
+                       rows, cols, x);
+    return (int)hipGetLastError();
+}

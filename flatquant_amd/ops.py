@@ -1,0 +1,197 @@
+"""Tensor-level entry points: torch device memory + streams in, libfqhip C-ABI calls out.
+
+PyTorch is plumbing here (allocation, current stream, device guard); all arithmetic happens in the HIP
+kernels.  Inputs must be CUDA (ROCm) fp16 contiguous tensors — violations raise, as the reference's
+``torch::check*`` / ``assert`` do (deploy/kernels/bindings.cpp:11-16,29-34; kron_matmul.py:195-199).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (FQ_MAX_CLIPS, FQ_NO_CLAMP0, FQ_OUT_FAKEQUANT, FQ_OUT_PACKED, FQ_OUT_TRANSFORM,
+                   FQ_QUANT_F16, FQ_ROUND_Y_F16, check, lib)
+
+Sig = Tuple[float, float]  # (sigmoid(clip_factor_a_max), sigmoid(clip_factor_a_min)); (1.0, 1.0) = no clip
+
+
+def sigmoid_pair(clip_max, clip_min) -> Sig:
+    """fp32 sigmoid of the raw (pre-sigmoid) learnable clipping factors, evaluated by torch on the host —
+    the value the reference multiplies the row extrema with (quant_utils.py:96-97, kron_matmul.py:93-94)."""
+    t = torch.sigmoid(torch.tensor([float(clip_max), float(clip_min)], dtype=torch.float32))
+    return float(t[0]), float(t[1])
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float16) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA/ROCm tensor (flatquant_amd has no CPU path); got {t.device}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _ptr_array(ts: Sequence[Optional[torch.Tensor]]):
+    arr = (ctypes.c_void_p * FQ_MAX_CLIPS)()
+    for i, t in enumerate(ts):
+        arr[i] = 0 if t is None else t.data_ptr()
+    return arr
+
+
+def _sig_arrays(sigs: Sequence[Sig]):
+    n = len(sigs)
+    if not 1 <= n <= FQ_MAX_CLIPS:
+        raise ValueError(f"between 1 and {FQ_MAX_CLIPS} clip sets are supported, got {n}")
+    smax = (ctypes.c_float * FQ_MAX_CLIPS)(*[float(s[0]) for s in sigs])
+    smin = (ctypes.c_float * FQ_MAX_CLIPS)(*[float(s[1]) for s in sigs])
+    return smax, smin, n
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+class FusedOutputs:
+    """Outputs of one fused transform+quant launch (lists are indexed by clip set)."""
+
+    def __init__(self):
+        self.q: List[torch.Tensor] = []       # uint8 [..., d/2]
+        self.scale: List[torch.Tensor] = []   # fp16 [rows]
+        self.fq: List[torch.Tensor] = []      # fp16 [..., d]
+        self.y: Optional[torch.Tensor] = None  # fp16 [..., d]
+
+
+def _alloc_outputs(x: torch.Tensor, rows: int, d: int, n_clips: int, flags: int, q_shape, y_shape):
+    o = FusedOutputs()
+    for _ in range(n_clips if flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT) else 0):
+        if flags & FQ_OUT_PACKED:
+            o.q.append(torch.empty(q_shape, dtype=torch.uint8, device=x.device))
+            o.scale.append(torch.empty((rows,), dtype=torch.float16, device=x.device))
+        if flags & FQ_OUT_FAKEQUANT:
+            o.fq.append(torch.empty(y_shape, dtype=torch.float16, device=x.device))
+    if flags & FQ_OUT_TRANSFORM:
+        o.y = torch.empty(y_shape, dtype=torch.float16, device=x.device)
+    return o
+
+
+def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),),
+               flags: int = FQ_OUT_PACKED, diag: Optional[torch.Tensor] = None) -> FusedOutputs:
+    """y = x @ kron(left, right) fused with per-token INT4 quantisation (fq_kron_quant_f16)."""
+    _chk(x, "x"), _chk(left, "left"), _chk(right, "right")
+    M, N = left.shape[0], right.shape[0]
+    if left.shape != (M, M) or right.shape != (N, N):
+        raise ValueError("left/right must be square")
+    d = M * N
+    if x.shape[-1] != d:
+        raise ValueError(f"x.shape[-1]={x.shape[-1]} != {M}*{N}")
+    if diag is not None:
+        _chk(diag, "diag")
+        if diag.numel() != d:
+            raise ValueError("diag must have M*N elements")
+    rows = x.numel() // d
+    smax, smin, n = _sig_arrays(sigs)
+    o = _alloc_outputs(x, rows, d, n, flags, x.shape[:-1] + (d // 2,), x.shape)
+    with torch.cuda.device(x.device):
+        check(lib.fq_kron_quant_f16(_ptr(x), _ptr(left), _ptr(right), _ptr(diag), rows, M, N, smax, smin, n,
+                                    flags, _ptr_array(o.q), _ptr_array(o.scale), _ptr_array(o.fq), _ptr(o.y),
+                                    _stream(x)))
+    return o
+
+
+def block_quant(x: torch.Tensor, P: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),),
+                flags: int = FQ_OUT_PACKED | FQ_NO_CLAMP0, transpose_out: bool = True) -> FusedOutputs:
+    """x [..., R, C] @ P [C, C], quantised per [R, C] block (fq_block_quant_f16)."""
+    _chk(x, "x"), _chk(P, "P")
+    R, C = x.shape[-2], x.shape[-1]
+    if P.shape != (C, C):
+        raise ValueError("P must be [C, C] with C = x.shape[-1]")
+    d = R * C
+    rows = x.numel() // d
+    smax, smin, n = _sig_arrays(sigs)
+    yshape = x.shape[:-2] + ((C, R) if transpose_out else (R, C))
+    o = _alloc_outputs(x, rows, d, n, flags, x.shape[:-2] + (d // 2,), yshape)
+    with torch.cuda.device(x.device):
+        check(lib.fq_block_quant_f16(_ptr(x), _ptr(P), rows, R, C, int(transpose_out), smax, smin, n, flags,
+                                     _ptr_array(o.q), _ptr_array(o.scale), _ptr_array(o.fq), _ptr(o.y),
+                                     _stream(x)))
+    return o
+
+
+def rowquant(x: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),), flags: int = FQ_OUT_PACKED) -> FusedOutputs:
+    """Per-token scale + INT4 quantisation of x [..., cols] (fq_rowquant_f16)."""
+    _chk(x, "x")
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    smax, smin, n = _sig_arrays(sigs)
+    o = _alloc_outputs(x, rows, cols, n, flags, x.shape[:-1] + (cols // 2,), x.shape)
+    with torch.cuda.device(x.device):
+        check(lib.fq_rowquant_f16(_ptr(x), rows, cols, smax, smin, n, flags, _ptr_array(o.q),
+                                  _ptr_array(o.scale), _ptr_array(o.fq), _stream(x)))
+    return o
+
+
+def hadamard(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None,
+             scale: Optional[float] = None) -> torch.Tensor:
+    """hadK @ FWHT(x.view(rows, K, n/K)) * scale  (fq_hadamard_f16)."""
+    _chk(x, "x")
+    n = x.shape[-1]
+    if K > 1:
+        if hadK is None:
+            raise ValueError("hadK required when K > 1")
+        _chk(hadK, "hadK")
+        if hadK.shape != (K, K):
+            raise ValueError("hadK must be [K, K]")
+    if scale is None:
+        scale = float(1.0 / torch.tensor(n).sqrt())  # fp32 value, as hadamard_utils.py:135
+    rows = x.numel() // n
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib.fq_hadamard_f16(_ptr(x), _ptr(y), rows, n, K, _ptr(hadK), ctypes.c_float(scale), _stream(x)))
+    return y
+
+
+def sym_quant(x: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """_CUDA.sym_quant (bindings.cpp:27-44): x fp16 [rows, cols], scale fp16 [rows] -> uint8 [rows, ceil(cols/2)]."""
+    _chk(x, "x"), _chk(scale, "scale")
+    if x.dim() != 2:
+        raise RuntimeError("sym_quant: x must be 2-D")
+    rows, cols = x.shape
+    if scale.numel() != rows:
+        raise RuntimeError(f"sym_quant: expected scale to have {rows} elements, got {scale.numel()}")
+    q = torch.empty((rows, (cols + 1) // 2), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.fq_sym_quant_f16(_ptr(x), _ptr(scale), rows, cols, _ptr(q), _stream(x)))
+    return q
+
+
+def sym_dequant(q: torch.Tensor, scale_row: torch.Tensor, scale_col: torch.Tensor) -> torch.Tensor:
+    """_CUDA.sym_dequant (bindings.cpp:47-87), bits = 32."""
+    _chk(q, "q", torch.int32), _chk(scale_row, "scale_row"), _chk(scale_col, "scale_col")
+    if q.dim() != 2:
+        raise RuntimeError("sym_dequant: q must be 2-D")
+    rows, cols = q.shape
+    if scale_row.numel() != rows or scale_col.numel() != cols:
+        raise RuntimeError("sym_dequant: scale sizes do not match q")
+    x = torch.empty((rows, cols), dtype=torch.float16, device=q.device)
+    with torch.cuda.device(q.device):
+        check(lib.fq_sym_dequant_i32_f16(_ptr(q), _ptr(scale_row), _ptr(scale_col), rows, cols, _ptr(x),
+                                         _stream(q)))
+    return x
+
+
+def probe_mfma(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor) -> torch.Tensor:
+    """D = A[32,16] @ B[16,32] + C[32,32] by one v_mfma_f32_32x32x16_f16 (oracle-calibration helper)."""
+    _chk(A, "A"), _chk(B, "B"), _chk(C, "C", torch.float32)
+    D = torch.empty((32, 32), dtype=torch.float32, device=A.device)
+    with torch.cuda.device(A.device):
+        check(lib.fq_probe_mfma_32x32x16_f16(_ptr(A), _ptr(B), _ptr(C), _ptr(D), _stream(A)))
+    return D

@@ -1,0 +1,123 @@
+/*
+ * fqhip.h — C ABI of libfqhip.so: MI355X (gfx950) implementation of FlatQuant's online
+ * transform + INT4 activation-quantisation hot path.
+ *
+ * Every entry point:
+ *   - takes raw DEVICE pointers owned by the caller (no allocation inside),
+ *   - takes the HIP stream to launch on (void* == hipStream_t; NULL = default stream),
+ *   - returns 0 on success or a negative FQ_E* code and never throws;
+ *     fq_last_error() returns a thread-local message for the last failure,
+ *   - is stateless and thread-safe (no global mutable state).
+ *
+ * Reference interfaces replaced (paths relative to the FlatQuant repository):
+ *   fq_kron_quant_f16      deploy/kernels/kron_matmul.py:192-266 (kron_matmul) +
+ *                          flatquant/flat_utils.py:6-17 (kronecker_matmul) +
+ *                          flatquant/quant_utils.py:71-119 (ActivationQuantizer)
+ *   fq_block_quant_f16     deploy/kernels/block_matmul.py:231-311 (block_matmul)
+ *   fq_hadamard_f16        flatquant/hadamard_utils.py:89-110,132-141 (matmul_hadU[_cuda]),
+ *                          deploy/functional/online_trans.py:144-151
+ *   fq_rowquant_f16        deploy/nn/quantization.py:13-36 (Quantizer.forward),
+ *                          flatquant/quant_utils.py:77-119
+ *   fq_sym_quant_f16       deploy/kernels/bindings.cpp:27-44 -> quant.cu:13-63 (sym_quant)
+ *   fq_sym_dequant_i32_f16 deploy/kernels/bindings.cpp:47-87 -> quant.cu:66-101 (sym_dequant)
+ */
+#ifndef FQHIP_H
+#define FQHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes */
+#define FQ_OK            0
+#define FQ_EINVAL       -1   /* bad argument (null pointer, bad size, bad flag combination) */
+#define FQ_EUNSUPPORTED -2   /* shape not supported by any compiled kernel */
+#define FQ_ELAUNCH      -3   /* HIP reported a launch error */
+
+/* flags for the fused transform+quant entry points (bit-or) */
+#define FQ_OUT_PACKED     0x01  /* write packed INT4 bytes + fp16 scales (deploy PackedQuantizedTensor) */
+#define FQ_OUT_FAKEQUANT  0x02  /* write fp16 scale*q (FlatQuantizedLinear._eval_forward contract)      */
+#define FQ_OUT_TRANSFORM  0x04  /* write the fp16 transformed activation (kronecker_matmul contract)    */
+#define FQ_ROUND_Y_F16    0x08  /* round the transformed activation to fp16 BEFORE statistics/quant
+                                   (path-A arithmetic: flat_utils.py:15-16 returns fp16)                */
+#define FQ_NO_CLAMP0      0x10  /* do not clamp xmax>=0 / xmin<=0 (deploy Triton kernels omit the clamp,
+                                   kron_matmul.py:91-100; quant_utils.py:90-91 has it)                   */
+#define FQ_QUANT_F16      0x20  /* scale, x/scale and scale*q evaluated in fp16 (quant_utils.py lac=False
+                                   path and quant.cu:40 __hdiv); default is fp32                         */
+
+#define FQ_MAX_CLIPS 4
+
+/*
+ * Fused Kronecker transform + per-token symmetric INT4 quantisation.
+ *   y[t] = x[t] (as [M,N] row-major) ; U = fp16(x[t] . right) ; Y = left^T . U   (fp32 accumulate)
+ *   == x_flat[t] @ kron(left, right)                         (flat_utils.py:6-17)
+ * then per token and per clip set c:
+ *   xmax = max(Y) (clamped >=0), xmin = min(Y) (clamped <=0)
+ *   m = max(|xmin*sig_min[c]|, xmax*sig_max[c]) ; scale = m/7 (1 if m==0)
+ *   q = clamp(rint(Y/scale), -8, 7) ; byte j = (q[2j+1] << 4) | (q[2j] & 15)
+ * x      [rows, M*N] fp16 contiguous
+ * left   [M, M] fp16 row-major  (hadL / matrix_left / left_matrix)
+ * right  [N, N] fp16 row-major  (hadR / matrix_right / right_matrix)
+ * diag   [M*N] fp16 or NULL: x is multiplied by diag (rounded to fp16) first (trans_utils.py:86-90)
+ * sig_max/sig_min: HOST arrays of n_clips floats = sigmoid(clip_factor_a_max/min) (1.0f = no clipping)
+ * q_out[c]     [rows, M*N/2] uint8   (FQ_OUT_PACKED)
+ * scale_out[c] [rows] fp16           (FQ_OUT_PACKED)
+ * fq_out[c]    [rows, M*N] fp16      (FQ_OUT_FAKEQUANT)
+ * y_out        [rows, M*N] fp16      (FQ_OUT_TRANSFORM)
+ */
+int fq_kron_quant_f16(const void* x, const void* left, const void* right, const void* diag,
+                      int64_t rows, int M, int N,
+                      const float* sig_max, const float* sig_min, int n_clips, int flags,
+                      void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                      void* stream);
+
+/*
+ * Single-matrix transform over the LAST axis of [rows, R, C] blocks (o_proj head transform):
+ *   Y[t] = x[t] ([R,C] row-major) . P ([C,C]);  quantised per token over all R*C values.
+ * Packed output follows block_matmul.py:86-101: the quantised block is TRANSPOSED before packing when
+ * transpose_out != 0 (logical [C, R] per token), natural [R, C] otherwise.
+ */
+int fq_block_quant_f16(const void* x, const void* P, int64_t rows, int R, int C, int transpose_out,
+                       const float* sig_max, const float* sig_min, int n_clips, int flags,
+                       void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                       void* stream);
+
+/*
+ * Normalised Hadamard transform over the last axis, n = K * 2^p:
+ *   y = hadK [K,K] @ FWHT_{n/K}( x.view(rows, K, n/K) ) * scale         (hadamard_utils.py:132-141)
+ * fp32 butterflies, result of the FWHT rounded to fp16 before the K-factor (as the un-vendored
+ * fast_hadamard_transform + fp16 matmul sequence does), output fp16.
+ * hadK may be NULL iff K == 1.  In-place (y == x) is allowed.
+ */
+int fq_hadamard_f16(const void* x, void* y, int64_t rows, int n, int K, const void* hadK, float scale,
+                    void* stream);
+
+/*
+ * Per-token scale + INT4 quantisation of an fp16 matrix (Quantizer.forward / ActivationQuantizer).
+ * Same statistics/flags as fq_kron_quant_f16 with Y = x.  cols even, cols <= 65536.
+ */
+int fq_rowquant_f16(const void* x, int64_t rows, int cols,
+                    const float* sig_max, const float* sig_min, int n_clips, int flags,
+                    void* const* q_out, void* const* scale_out, void* const* fq_out,
+                    void* stream);
+
+/* q = clamp(rn(x /fp16 scale[row]), -8, 7), two per byte, even column -> low nibble (quant.cu:13-47). */
+int fq_sym_quant_f16(const void* x, const void* scale, int64_t rows, int cols, void* q, void* stream);
+
+/* x = scale_row[r] * scale_col[c] * half(q/10) * 10   (quant.cu:66-85) */
+int fq_sym_dequant_i32_f16(const void* q, const void* scale_row, const void* scale_col,
+                           int64_t rows, int cols, void* x, void* stream);
+
+/* MFMA numerics probe (test infrastructure for the oracle's accumulation model):
+ * D[32,32] = A[32,16] . B[16,32] + C with one v_mfma_f32_32x32x16_f16. All row-major, A/B fp16, C/D fp32. */
+int fq_probe_mfma_32x32x16_f16(const void* A, const void* B, const void* C, void* D, void* stream);
+
+const char* fq_last_error(void);
+int fq_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FQHIP_H */

@@ -1,0 +1,302 @@
+"""CPU oracle for the FlatQuant online-transform + INT4-quantisation hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``flatquant_amd/`` imports this module; only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may.  It is the checker, never
+the thing measured or shipped.
+
+It restates, in numpy with explicitly pinned IEEE arithmetic, what the reference computes on the path
+(citations are file:line in the FlatQuant repository):
+
+  get_decompose_dim      flatquant/function_utils.py:11-21
+  pack_i4 / unpack_i4    deploy/functional/quantization.py:49-56 / :60-82
+  kron_transform         flatquant/flat_utils.py:6-17          (x @ hadR -> fp16, hadL.T @ . -> fp32)
+  token_scale/quantize   flatquant/quant_utils.py:85-107, :19-22 ; deploy/kernels/kron_matmul.py:91-123
+  rowquant               deploy/nn/quantization.py:13-36 (Quantizer) ; quant_utils.py:71-119
+  sym_quant              deploy/kernels/quant.cu:13-47   (fp16 division, rn, clamp, low nibble = even col)
+  sym_dequant            deploy/kernels/quant.cu:5-10, :66-85
+  hadamard               flatquant/hadamard_utils.py:89-110 (matmul_hadU), :132-141 (matmul_hadU_cuda)
+  block_quant            deploy/kernels/block_matmul.py:29-104
+
+Parity pinning: ``tests/golden/*.npz`` are produced by ``tools/gen_golden.py`` from the imported
+reference (path A on CPU; path-B Triton kernels under TRITON_INTERPRET=1) and
+``tests/test_oracle_golden.py`` checks this module against them.  Two pieces have no reference artefact
+that can run here and are therefore "parity unpinned" beyond their published algorithm:
+``sym_quant``/``sym_dequant`` (quant.cu needs nvcc + CUTLASS) and the FWHT of the un-vendored third-party
+``fast_hadamard_transform`` (Dao-AILab/fast-hadamard-transform, pin unknown: empty submodule) — for the
+latter ``matmul_hadU`` (in-repo, same mathematics) is the anchor.
+
+Arithmetic pinned (DESIGN.md "Pinned arithmetic"):
+  * GEMMs take fp16 operands, multiply exactly, accumulate in fp32.  The accumulation ORDER is a
+    parameter (`groups`): each group of contraction indices is summed exactly and added to the running
+    fp32 accumulator with one rounding.  ``None`` = one group (exact dot product, rounded once).
+  * intermediate U = x @ hadR is rounded to fp16 (flat_utils.py:15 returns the input dtype).
+  * statistics, scale = m/7 and y/scale in fp32 with correctly rounded division; rint = half-to-even.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import numpy as np
+
+F16 = np.float16
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------------------------------
+# integer helpers
+# --------------------------------------------------------------------------------------------------
+def get_decompose_dim(n: int):
+    """flatquant/function_utils.py:11-21 — closest factor pair (a-b, a+b) with a^2 - n = b^2."""
+    a = int(math.sqrt(n))
+    if a * a < n:
+        a += 1
+    while True:
+        tmp = a * a - n
+        b = int(math.sqrt(tmp))
+        if b * b == tmp:
+            break
+        a += 1
+    return a - b, a + b
+
+
+def pack_i4(q: np.ndarray) -> np.ndarray:
+    """deploy/functional/quantization.py:49-56: two's complement nibbles, even column -> low nibble."""
+    q = np.asarray(q)
+    assert np.issubdtype(q.dtype, np.signedinteger)
+    assert q.min(initial=0) >= -8 and q.max(initial=0) <= 7
+    u = (q.astype(np.int16) & 0xF).astype(np.uint8)
+    return (u[..., 0::2] | (u[..., 1::2] << 4)).astype(np.uint8)
+
+
+def unpack_i4(p: np.ndarray) -> np.ndarray:
+    """deploy/functional/quantization.py:60-82 -> int32, interleaved low/high."""
+    p = np.asarray(p, dtype=np.uint8)
+    lo = (p & 0x0F).astype(np.int32)
+    hi = ((p & 0xF0) >> 4).astype(np.int32)
+    lo[lo >= 8] -= 16
+    hi[hi >= 8] -= 16
+    out = np.empty(p.shape[:-1] + (p.shape[-1] * 2,), dtype=np.int32)
+    out[..., 0::2] = lo
+    out[..., 1::2] = hi
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# fp16-operand / fp32-accumulate GEMM with a pinned accumulation order
+# --------------------------------------------------------------------------------------------------
+def _grouped_matmul(a16: np.ndarray, b16: np.ndarray, groups: Optional[Sequence[Sequence[int]]]):
+    """a16 [..., I, K] @ b16 [K, J] -> fp32 [..., I, J].
+
+    Products of fp16 values are exact in fp32 (22-bit significands) and a sum of <= a few hundred of them is
+    exact in float64 for inputs of moderate dynamic range, so "sum the group exactly" is a float64 sum.
+    """
+    a = a16.astype(np.float64)
+    b = b16.astype(np.float64)
+    K = a.shape[-1]
+    if groups is None:
+        groups = [list(range(K))]
+    acc = np.zeros(a.shape[:-1] + (b.shape[-1],), dtype=F32)
+    for g in groups:
+        g = list(g)
+        part = a[..., g] @ b[g, :]                      # exact group sum in float64
+        acc = (acc.astype(np.float64) + part).astype(F32)   # one fp32 rounding per group
+    return acc
+
+
+def kron_transform(x16, left16, right16, diag16=None, groups1=None, groups2=None, left_first=False):
+    """Y = left^T . fp16(X . right) for every token; returns fp32 [T, M, N].
+
+    left_first=True evaluates the deploy Triton kernel's association instead (kron_matmul.py:63-71):
+    T = fp16(left^T . X), Y = T . right.  The two orders differ by the fp16 rounding of a different
+    intermediate (about 5e-4 of INT4 indices flip by one step on LLM-like data).
+
+    flatquant/flat_utils.py:13-16: ``x = x.reshape(-1, L, R); x = x @ hadR; x = hadL.T @ x`` with fp16
+    tensors (each torch.matmul accumulates in fp32 and returns fp16).  The second rounding to fp16 is the
+    caller's choice here (FQ_ROUND_Y_F16 / round_y_f16) because the deploy kernels quantise the fp32
+    accumulator (kron_matmul.py:71-107).
+    """
+    x16 = np.asarray(x16, dtype=F16)
+    left16 = np.asarray(left16, dtype=F16)
+    right16 = np.asarray(right16, dtype=F16)
+    M, N = left16.shape[0], right16.shape[0]
+    X = x16.reshape(-1, M, N)
+    if diag16 is not None:
+        d = np.asarray(diag16, dtype=F16).reshape(M, N)
+        X = (X.astype(F32) * d.astype(F32)).astype(F16)      # one fp16 multiply
+    if left_first:
+        # T[t, m', n] = sum_m L[m, m'] X[t, m, n]   ->  (X^T)[t, n, m] @ L
+        Tt = _grouped_matmul(np.swapaxes(X, -1, -2), left16, groups1).astype(F16)   # [T, N, M']
+        return _grouped_matmul(np.swapaxes(Tt, -1, -2), right16, groups2)           # [T, M', N']
+    U = _grouped_matmul(X, right16, groups1).astype(F16)       # [T, M, N'] fp16
+    # Y[t, m', n'] = sum_m L[m, m'] U[t, m, n']  ->  (U^T)[t, n', m] @ L[m, m']
+    Yt = _grouped_matmul(np.swapaxes(U, -1, -2), left16, groups2)   # [T, N', M']
+    return np.ascontiguousarray(np.swapaxes(Yt, -1, -2))               # [T, M', N']
+
+
+def single_transform(x16, P16, groups=None):
+    """x [T, R, C] fp16 @ P [C, C] -> fp32 [T, R, C]  (block_matmul.py:59-70; trans_utils.py:21-25)."""
+    return _grouped_matmul(np.asarray(x16, dtype=F16), np.asarray(P16, dtype=F16), groups)
+
+
+# --------------------------------------------------------------------------------------------------
+# per-token symmetric INT4 quantisation
+# --------------------------------------------------------------------------------------------------
+def token_scale(y32, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False):
+    """y32 [T, d] fp32 -> scale fp32 [T].
+
+    quant_utils.py:88-107 (clamp to 0, lac sigmoid factors, m = max(|xmin|, xmax), scale = m/q_max,
+    scale[m == 0] = 1) evaluated in fp32 — what torch's type promotion yields when ``lac`` multiplies the
+    fp16 row extrema by the fp32 sigmoid — and kron_matmul.py:91-104 (no clamp: clamp0=False).
+    quant_f16: the scale is rounded to fp16 ((m/7).to(float16), deploy/nn/quantization.py:25-30).
+    """
+    y32 = np.asarray(y32, dtype=F32)
+    xmax = y32.max(axis=-1)
+    xmin = y32.min(axis=-1)
+    if clamp0:
+        xmax = np.maximum(xmax, F32(0))
+        xmin = np.minimum(xmin, F32(0))
+    xmax = (xmax * F32(sig_max)).astype(F32)
+    xmin = (xmin * F32(sig_min)).astype(F32)
+    m = np.maximum(np.abs(xmin), xmax).astype(F32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        scale = (m / F32(7.0)).astype(F32)
+    if quant_f16:
+        scale = scale.astype(F16).astype(F32)
+    scale = np.where(m == 0, F32(1.0), scale).astype(F32)
+    return scale
+
+
+def quantize(y32, scale, quant_f16=False):
+    """clamp(rint(y/scale), -8, 7) -> int8; division fp32 (fp16-rounded quotient when quant_f16)."""
+    y32 = np.asarray(y32, dtype=F32)
+    s = np.asarray(scale, dtype=F32)[..., None]
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        t = (y32 / s).astype(F32)
+        if quant_f16:
+            t = t.astype(F16).astype(F32)
+    t = np.rint(t)
+    t = np.clip(t, -8, 7)
+    t = np.where(np.isnan(t), 0, t)
+    return t.astype(np.int8)
+
+
+def dequantize(q, scale, quant_f16=False):
+    """(scale * q).to(fp16)  (quant_utils.py:25-26,81)."""
+    s = np.asarray(scale, dtype=F32)[..., None]
+    if quant_f16:
+        s = s.astype(F16).astype(F32)
+    return (s * q.astype(F32)).astype(F16)
+
+
+def quant_outputs(y32, sig_max=1.0, sig_min=1.0, round_y_f16=False, clamp0=True, quant_f16=False):
+    """Everything the fused kernels can emit for one clip set, from the fp32 transformed activation."""
+    y32 = np.asarray(y32, dtype=F32)
+    T = y32.shape[0]
+    y = y32.reshape(T, -1)
+    y16 = y.astype(F16)
+    if round_y_f16:
+        y = y16.astype(F32)
+    scale = token_scale(y, sig_max, sig_min, clamp0, quant_f16)
+    q = quantize(y, scale, quant_f16)
+    return {
+        "y16": y16,
+        "scale": scale,
+        "scale16": scale.astype(F16),
+        "q": q,
+        "packed": pack_i4(q),
+        "fq": dequantize(q, scale, quant_f16),
+    }
+
+
+def kron_quant(x16, left16, right16, sig_max=1.0, sig_min=1.0, diag16=None, round_y_f16=False,
+               clamp0=True, quant_f16=False, groups1=None, groups2=None, left_first=False):
+    y = kron_transform(x16, left16, right16, diag16, groups1, groups2, left_first)
+    return quant_outputs(y, sig_max, sig_min, round_y_f16, clamp0, quant_f16)
+
+
+def rowquant(x16, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False):
+    x16 = np.asarray(x16, dtype=F16)
+    return quant_outputs(x16.astype(F32).reshape(x16.shape[0], -1), sig_max, sig_min, False, clamp0, quant_f16)
+
+
+def block_quant(x16, P16, sig_max=1.0, sig_min=1.0, transpose_out=True, round_y_f16=False, clamp0=False,
+                quant_f16=False, groups=None):
+    """block_matmul.py:29-104: Y = x[t] ([R, C]) @ P; statistics over the whole block; the quantised block
+    is transposed before packing (:86-90) when transpose_out."""
+    y = single_transform(x16, P16, groups)               # [T, R, C]
+    if transpose_out:
+        y = np.ascontiguousarray(np.swapaxes(y, -1, -2))  # [T, C, R]
+    return quant_outputs(y, sig_max, sig_min, round_y_f16, clamp0, quant_f16)
+
+
+# --------------------------------------------------------------------------------------------------
+# quant.cu restatements
+# --------------------------------------------------------------------------------------------------
+def sym_quant(x16, scale16):
+    """quant.cu:13-47: q = clamp(__half2int_rn(__hdiv(x, scale[row])), -8, 7); odd tail -> high nibble 0."""
+    x16 = np.asarray(x16, dtype=F16)
+    s = np.asarray(scale16, dtype=F16).reshape(-1, 1)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        d = (x16.astype(F32) / s.astype(F32)).astype(F16).astype(F32)
+    t = np.clip(np.rint(d), -8, 7)
+    t = np.where(np.isnan(t), 0, t).astype(np.int8)
+    if t.shape[1] & 1:
+        t = np.concatenate([t, np.zeros((t.shape[0], 1), np.int8)], axis=1)
+    return pack_i4(t)
+
+
+def sym_dequant(q32, scale_row16, scale_col16):
+    """quant.cu:5-10,66-85: x = s_row * s_col * half(int(q/10.0f)) * half(10), fp16 products left to right."""
+    q32 = np.asarray(q32, dtype=np.int32)
+    iv = np.trunc(q32.astype(F32) / F32(10.0)).astype(np.int64)
+    iv = np.clip(iv, -65176, 65176)
+    with np.errstate(over="ignore"):
+        xe = iv.astype(F32).astype(F16)
+        sr = np.asarray(scale_row16, dtype=F16).reshape(-1, 1)
+        sc = np.asarray(scale_col16, dtype=F16).reshape(1, -1)
+        r = (sr.astype(F32) * sc.astype(F32)).astype(F16)
+        r = (r.astype(F32) * xe.astype(F32)).astype(F16)
+        r = (r.astype(F32) * F32(10.0)).astype(F16)
+    return r
+
+
+# --------------------------------------------------------------------------------------------------
+# Hadamard
+# --------------------------------------------------------------------------------------------------
+def fwht_f32(v32):
+    """Unnormalised FWHT over the last axis (power of two), fp32, stages from stride 1 upwards — the order
+    of hadamard_utils.py:94-101 (adjacent pairs first) and of the fast_hadamard_transform kernel
+    (in-thread, then warp shuffles, then across warps)."""
+    v = np.array(v32, dtype=F32, copy=True)
+    n = v.shape[-1]
+    assert n & (n - 1) == 0
+    h = 1
+    lead = v.shape[:-1]
+    while h < n:
+        w = v.reshape(lead + (n // (2 * h), 2, h))
+        a = w[..., 0, :].copy()
+        b = w[..., 1, :].copy()
+        w[..., 0, :] = a + b
+        w[..., 1, :] = a - b
+        v = w.reshape(lead + (n,))
+        h *= 2
+    return v
+
+
+def hadamard(x16, K=1, hadK16=None, scale=None, groupsK=None):
+    """matmul_hadU_cuda (hadamard_utils.py:132-141): view [rows, K, n/K]; FWHT over the last axis in fp32
+    times `scale`, rounded to fp16 (fast_hadamard_transform returns the input dtype); then
+    hadK [K,K] @ . with fp32 accumulation, rounded to fp16."""
+    x16 = np.asarray(x16, dtype=F16)
+    rows, n = x16.shape
+    if scale is None:
+        scale = F32(1.0) / np.sqrt(F32(n))
+    v = fwht_f32(x16.astype(F32).reshape(rows, K, n // K))
+    v = (v * F32(scale)).astype(F16)
+    if K == 1:
+        return v.reshape(rows, n)
+    h = np.asarray(hadK16, dtype=F16)
+    # out[r, k', p] = sum_k hadK[k', k] v[r, k, p]   ->  v^T [r, p, k] @ hadK^T [k, k']
+    o = _grouped_matmul(np.swapaxes(v, -1, -2), np.ascontiguousarray(h.T), groupsK)
+    return np.swapaxes(o, -1, -2).astype(F16).reshape(rows, n)

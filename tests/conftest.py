@@ -1,0 +1,43 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests are skipped (not failed) when no device is visible, e.g. `pytest tests/` with no -m."""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:  # pragma: no cover
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + ".npz"))
+    return load
+
+
+def hadk_matrix(K):
+    """Sign matrix of the K x K Hadamard factor shipped in flatquant_amd/data/hadk.npz."""
+    z = np.load(os.path.join(ROOT, "flatquant_amd", "data", "hadk.npz"))
+    bits = np.unpackbits(z[f"had{K}"])[: K * K].reshape(K, K)
+    return (bits.astype(np.float32) * 2 - 1).astype(np.float16)

@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE (ruikangliu/FlatQuant, mounted read-only at
+/root/reference) in this container.  Only data (inputs + the reference's outputs) is written; no reference
+source travels.  Re-run:  python tools/gen_golden.py
+
+Path A  = flatquant/{flat_utils,trans_utils,quant_utils,hadamard_utils}.py on CPU (fp16 and fp32).
+Path B  = deploy/kernels/{kron_matmul,block_matmul}.py Triton kernels under TRITON_INTERPRET=1, with three
+          harness-side accommodations that touch no reference file:
+            1. sys.modules['deploy._CUDA'] / ['fast_hadamard_transform'] = empty stub modules
+               (import-only; the kernels used here never call them),
+            2. the autotuner's config list trimmed to its first entry (it otherwise wants a GPU to benchmark),
+            3. libdevice.llrint replaced by an np.rint wrapper (the intrinsic is GPU-only).
+Also extracts the non-power-of-two Hadamard factor matrices (data tables the reference inherits from
+QuIP#/Sloane's library) into flatquant_amd/data/hadk.npz as bit-packed sign matrices.
+"""
+import os
+import sys
+import types
+
+os.environ["TRITON_INTERPRET"] = "1"
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.modules["fast_hadamard_transform"] = types.ModuleType("fast_hadamard_transform")
+sys.modules["deploy._CUDA"] = types.ModuleType("deploy._CUDA")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import triton.language as tl  # noqa: E402
+import triton.runtime.interpreter as ti  # noqa: E402
+
+import deploy  # noqa: E402,F401
+from deploy.kernels import block_matmul as ref_bm  # noqa: E402
+from deploy.kernels import kron_matmul as ref_km  # noqa: E402
+from flatquant import hadamard_utils as ref_had  # noqa: E402
+from flatquant.flat_utils import kronecker_matmul as ref_kronecker_matmul  # noqa: E402
+from flatquant.function_utils import get_decompose_dim as ref_get_decompose_dim  # noqa: E402
+from flatquant.quant_utils import ActivationQuantizer as RefActQ  # noqa: E402
+from flatquant.trans_utils import InvDecomposeTransMatrix as RefInvDec  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+class _LibdeviceShim:
+    @staticmethod
+    def llrint(x, _semantic=None, **kw):
+        data = np.rint(x.handle.data).astype(np.int64)
+        ty = tl.block_type(tl.int64, list(x.shape)) if len(x.shape) else tl.int64
+        return tl.tensor(ti.TensorHandle(data, tl.int64), ty)
+
+
+for mod in (ref_km, ref_bm):
+    mod.libdevice = _LibdeviceShim
+for k in (ref_km.matmul_kernel, ref_bm.matmul_quant_kernel):
+    k.configs = k.configs[:1]
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic inputs (BASELINE.md section 2 / SURVEY 8d): LLM-like activations, learned-matrix-like factors
+# ------------------------------------------------------------------------------------------------
+def make_x(rows, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, d, generator=g)
+    ch = torch.randperm(d, generator=g)[: max(1, d // 100)]
+    x[:, ch] *= 20.0
+    return x.to(torch.float16)
+
+
+def make_mat(n, seed):
+    """random orthogonal . diag(U[0.5, 2]) — an invertible, non-symmetric 'learned' factor."""
+    rng = np.random.RandomState(seed)
+    q, r = np.linalg.qr(rng.randn(n, n))
+    q = q @ np.diag(np.sign(np.diag(r)))
+    m = q @ np.diag(rng.uniform(0.5, 2.0, n))
+    return torch.from_numpy(m).to(torch.float16)
+
+
+def sig(c):
+    return float(torch.sigmoid(torch.tensor(float(c), dtype=torch.float32)))
+
+
+def path_a(x, L, R, clip_max, clip_min, lac=True, dtype=torch.float16, diag=None):
+    """Reference path A: InvDecomposeTransMatrix (eval mode) -> ActivationQuantizer(4 bit, sym)."""
+    M, N = L.shape[0], R.shape[0]
+    tr = RefInvDec(M, N, add_diag=diag is not None, diag_init_para=None if diag is None else diag.clone())
+    tr.to_eval_mode()
+    tr.matrix_left.data = L.clone()
+    tr.matrix_right.data = R.clone()
+    q = RefActQ(bits=4, sym=True, lac=lac)
+    if lac:
+        q.clip_factor_a_max.data.fill_(clip_max)
+        q.clip_factor_a_min.data.fill_(clip_min)
+    with torch.no_grad():
+        xin = x.to(dtype)
+        y = tr(xin)                                  # flat_utils.kronecker_matmul inside
+        scale, _ = q.get_scale_zero(y)
+        fq = q(y)
+        from flatquant.quant_utils import sym_quant
+        qi, _ = sym_quant(y, scale, q.q_max.to(y))
+    return {
+        "y": y.numpy(),
+        "scale": scale[:, 0].float().numpy(),
+        "scale_dtype": str(scale.dtype),
+        "q": qi.float().numpy().astype(np.int8),
+        "fq": fq.numpy(),
+    }
+
+
+def path_b_kron(x, L, R, clip_max, clip_min, bsz, seq):
+    """Reference path B: deploy.functional.online_trans.kronecker_matmul -> Triton kron_matmul."""
+    from deploy.functional.online_trans import kronecker_matmul
+    d = x.shape[-1]
+    p = kronecker_matmul(x.reshape(bsz, seq, d).clone(), [L.clone(), R.clone()], clip_max, clip_min)
+    return p.quantized_x.numpy().reshape(bsz * seq, -1), p.scales_x.numpy().reshape(-1)
+
+
+def path_b_block(x4, P, clip_max, clip_min):
+    from deploy.functional.online_trans import kronecker_matmul
+    p = kronecker_matmul(x4.clone(), [P.clone()], clip_max, clip_min)
+    bsz, seq = x4.shape[:2]
+    return p.quantized_x.numpy().reshape(bsz * seq, -1), p.scales_x.numpy().reshape(-1)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path} ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_decompose():
+    ns = [4096, 8192, 14336, 28672, 11008, 7168, 2048, 3584, 5120, 13824, 1024, 512, 6912]
+    save("decompose_dim", n=np.array(ns), dims=np.array([ref_get_decompose_dim(n) for n in ns]))
+
+
+def gen_kron_a():
+    shapes = [(64, 64, 8), (64, 128, 4), (112, 128, 4), (128, 224, 2), (86, 128, 2), (64, 112, 4), (32, 64, 8),
+              (56, 64, 4)]
+    clips = [(4.0, 4.0), (2.3, -0.7)]
+    for M, N, rows in shapes:
+        d = M * N
+        x = make_x(rows, d, seed=0)
+        L, R = make_mat(M, 1), make_mat(N, 2)
+        arrays = {"x": x.numpy(), "L": L.numpy(), "R": R.numpy(), "clips": np.array(clips, dtype=np.float32),
+                  "sig": np.array([[sig(a), sig(b)] for a, b in clips], dtype=np.float32)}
+        for ci, (cmax, cmin) in enumerate(clips):
+            a16 = path_a(x, L, R, cmax, cmin, lac=True, dtype=torch.float16)
+            assert a16["scale_dtype"] == "torch.float32", a16["scale_dtype"]  # promotion check
+            for k in ("y", "scale", "q", "fq"):
+                arrays[f"a16_lac{ci}_{k}"] = a16[k]
+        n16 = path_a(x, L, R, 0, 0, lac=False, dtype=torch.float16)
+        assert n16["scale_dtype"] == "torch.float16"
+        for k in ("scale", "q", "fq"):
+            arrays[f"a16_nolac_{k}"] = n16[k]
+        a32 = path_a(x, L, R, clips[0][0], clips[0][1], lac=True, dtype=torch.float32)
+        for k in ("y", "scale", "q"):
+            arrays[f"a32_lac0_{k}"] = a32[k]
+        save(f"kron_A_{M}x{N}", **arrays)
+    # diag_scale variant (trans_utils.py:192-196)
+    M, N, rows = 64, 64, 4
+    x = make_x(rows, M * N, seed=3)
+    L, R = make_mat(M, 4), make_mat(N, 5)
+    diag = (torch.rand(M * N, generator=torch.Generator().manual_seed(6)) + 0.5).to(torch.float16)
+    a = path_a(x, L, R, 4.0, 4.0, lac=True, dtype=torch.float16, diag=diag)
+    save("kron_A_diag_64x64", x=x.numpy(), L=L.numpy(), R=R.numpy(), diag=diag.numpy(),
+         sig=np.array([sig(4.0), sig(4.0)], dtype=np.float32), y=a["y"], scale=a["scale"], q=a["q"], fq=a["fq"])
+
+
+def gen_kron_b():
+    clips = [(1.0, 1.0), (4.0, 4.0), (2.3, -0.7)]
+    for M, N, bsz, seq in [(64, 64, 2, 4), (64, 128, 1, 4), (32, 64, 2, 4), (112, 128, 1, 2)]:
+        d = M * N
+        x = make_x(bsz * seq, d, seed=10)
+        L, R = make_mat(M, 11), make_mat(N, 12)
+        arrays = {"x": x.numpy(), "L": L.numpy(), "R": R.numpy(), "clips": np.array(clips, dtype=np.float32),
+                  "sig": np.array([[sig(a), sig(b)] for a, b in clips], dtype=np.float32),
+                  "bsz_seq": np.array([bsz, seq])}
+        for ci, (cmax, cmin) in enumerate(clips):
+            qx, sx = path_b_kron(x, L, R, cmax, cmin, bsz, seq)
+            arrays[f"b_packed{ci}"] = qx
+            arrays[f"b_scale{ci}"] = sx
+        save(f"kron_B_{M}x{N}", **arrays)
+
+
+def gen_block_b():
+    for hd, H in [(128, 32), (128, 64)]:
+        bsz, seq = 1, 4
+        g = torch.Generator().manual_seed(20)
+        x4 = torch.randn(bsz, seq, hd, H, generator=g).to(torch.float16)   # already [.., head_dim, num_heads]
+        P = make_mat(H, 21)
+        arrays = {"x": x4.numpy(), "P": P.numpy()}
+        for ci, (cmax, cmin) in enumerate([(1.0, 1.0), (4.0, 4.0)]):
+            qx, sx = path_b_block(x4, P, cmax, cmin)
+            arrays[f"b_packed{ci}"] = qx
+            arrays[f"b_scale{ci}"] = sx
+            arrays[f"sig{ci}"] = np.array([sig(cmax), sig(cmin)], dtype=np.float32)
+        save(f"block_B_{hd}x{H}", **arrays)
+
+
+def gen_exact():
+    """Dyadic-grid inputs: every partial sum of both association orders is exactly representable, so path A,
+    path B and any correct implementation must agree BIT FOR BIT (hard parts)."""
+    for M, N, bsz, seq in [(64, 64, 2, 8), (64, 128, 1, 4), (32, 64, 1, 8)]:
+        rng = np.random.RandomState(100 + M + N)
+        rows = bsz * seq
+        k = rng.randint(-16, 17, size=(rows, M * N))
+        x = torch.from_numpy(k / 16.0).to(torch.float16)
+
+        def hadlike(n, seed):
+            r = np.random.RandomState(seed)
+            h = ref_had.get_had_pow2(n, norm=False).numpy()
+            h = h[r.permutation(n)] * r.choice([-1.0, 1.0], size=(1, n))
+            return torch.from_numpy(h / 8.0).to(torch.float16)
+
+        L, R = hadlike(M, 1), hadlike(N, 2)
+        arrays = {"x": x.numpy(), "L": L.numpy(), "R": R.numpy(), "bsz_seq": np.array([bsz, seq])}
+        for ci, (cmax, cmin) in enumerate([(1.0, 1.0), (4.0, 4.0)]):
+            a = path_a(x, L, R, cmax, cmin, lac=True, dtype=torch.float16)
+            qx, sx = path_b_kron(x, L, R, cmax, cmin, bsz, seq)
+            arrays[f"sig{ci}"] = np.array([sig(cmax), sig(cmin)], dtype=np.float32)
+            arrays[f"a_y{ci}"], arrays[f"a_q{ci}"], arrays[f"a_scale{ci}"], arrays[f"a_fq{ci}"] = (
+                a["y"], a["q"], a["scale"], a["fq"])
+            arrays[f"b_packed{ci}"], arrays[f"b_scale{ci}"] = qx, sx
+        save(f"exact_{M}x{N}", **arrays)
+
+
+def gen_edge():
+    """Edge rows for 64x64, run through path A (lac, fp16)."""
+    M = N = 64
+    d = M * N
+    x = make_x(8, d, seed=30)
+    x[0] = 0                                  # all-zero token
+    x[1] = x[1].abs()                         # single-signed input (output is not, but exercises clamp0 rarely)
+    x[2, 5] = 60000.0                         # huge outlier near fp16 max
+    x[3] = 0
+    x[3, 100] = 1.0                           # one-hot token
+    x[4] *= 1e-3                              # tiny magnitudes (fp16 subnormal intermediates)
+    eye_l, eye_r = torch.eye(M, dtype=torch.float16), torch.eye(N, dtype=torch.float16)
+    x[5] = 0
+    x[5, :8] = torch.tensor([7.0, 0.5, 1.5, 2.5, -0.5, -1.5, 3.5, -3.5], dtype=torch.float16)  # .5 ties at scale 1
+    arrays = {"x": x.numpy()}
+    for tag, (L, R) in {"rand": (make_mat(M, 31), make_mat(N, 32)), "eye": (eye_l, eye_r)}.items():
+        a = path_a(x, L, R, 20.0, 20.0, lac=True, dtype=torch.float16)   # sigmoid(20) == 1.0f
+        arrays[f"{tag}_L"], arrays[f"{tag}_R"] = L.numpy(), R.numpy()
+        arrays[f"{tag}_y"], arrays[f"{tag}_q"], arrays[f"{tag}_scale"], arrays[f"{tag}_fq"] = (
+            a["y"], a["q"], a["scale"], a["fq"])
+    arrays["sig"] = np.array([sig(20.0), sig(20.0)], dtype=np.float32)
+    save("edge_64x64", **arrays)
+
+
+def gen_had():
+    arrays = {}
+    for n in [4096, 8192, 14336, 28672, 11008, 1024, 512, 5120]:
+        x = make_x(4, n, seed=40 + n % 7)
+        arrays[f"x_{n}"] = x.numpy()
+        with torch.no_grad():
+            arrays[f"y16_{n}"] = ref_had.matmul_hadU(x).numpy()
+            arrays[f"y64_{n}"] = ref_had.matmul_hadU(x.double()).numpy()
+        _, K = ref_had.get_hadK(n)
+        arrays[f"K_{n}"] = np.array(K)
+    save("had_A", **arrays)
+
+
+def gen_hadk_data():
+    mats = {}
+    for K in [12, 20, 28, 36, 40, 52, 60, 108, 140, 156, 172]:
+        h = getattr(ref_had, f"get_had{K}")().numpy()
+        assert h.shape == (K, K) and np.all(np.abs(h) == 1)
+        mats[f"had{K}"] = np.packbits((h > 0).astype(np.uint8), axis=None)
+    path = os.path.join(ROOT, "flatquant_amd", "data", "hadk.npz")
+    np.savez_compressed(path, **mats)
+    print(f"wrote {path} ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+def gen_pack():
+    from deploy.functional.quantization import pack_i4, unpack_i4
+    q = torch.arange(-8, 8, dtype=torch.int8)
+    grid = torch.stack(torch.meshgrid(q, q, indexing="ij"), -1).reshape(-1, 2)   # all 256 (lo, hi) pairs
+    packed = pack_i4(grid)
+    save("pack_roundtrip", q=grid.numpy(), packed=packed.numpy(), unpacked=unpack_i4(packed).numpy())
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    gen_decompose()
+    gen_pack()
+    gen_hadk_data()
+    gen_had()
+    gen_kron_a()
+    gen_exact()
+    gen_edge()
+    gen_block_b()
+    gen_kron_b()
