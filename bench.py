@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py — Melem/s of the fused Kronecker-transform + INT4-quant hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): Llama-3-8B single linear input, d = 4096 (64 x 64 Kronecker
+factors), bs x seq = 8 x 2048 = 16384 tokens PER GPU (weak scaling: tokens shard, no data-path collective;
+the two 64x64 factor matrices are broadcast once from rank 0 over RCCL).  One step = one launch of
+fq_kron_quant_f16 (packed INT4 + fp16 scales out) over one 128 MiB activation buffer already resident in
+HBM; buffers rotate over > 256 MiB so the Infinity Cache cannot serve the stream.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (HBM, algorithmic bytes / HIP-
+event time per launch) and `cpu_baseline` (torch restatement of the reference's CPU fake-quant path, timed on
+the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D, M, N = 4096, 64, 64
+BSZ, SEQ = 8, 2048
+ROWS = BSZ * SEQ
+BYTES_PER_TOKEN = 2 * D + D // 2 + 2          # fp16 in + packed INT4 out + fp16 scale = 10242
+HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8 TB/s spec
+N_BUF = 4                                     # 4 x 128 MiB inputs + 4 x 32 MiB outputs rotate (> 256 MiB L3)
+
+
+def make_inputs(device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    xs = []
+    for _ in range(N_BUF):
+        x = torch.randn(ROWS, D, generator=g, device=device, dtype=torch.float16)
+        x[:, :: 97] *= 20.0                    # LLM-like outlier channels
+        xs.append(x)
+    return xs
+
+
+def make_matrices(device):
+    """random orthogonal . diag(U[0.5, 2]) in fp64 -> fp16, seeds 1 and 2."""
+    mats = {}
+    for name, n, seed in (("left", M, 1), ("right", N, 2)):
+        g = torch.Generator().manual_seed(seed)
+        q, r = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
+        q = q * torch.sign(torch.diagonal(r))[None, :]
+        m = q * (torch.rand(n, generator=g, dtype=torch.float64) * 1.5 + 0.5)[None, :]
+        mats[name] = m.to(torch.float16).to(device)
+    return mats
+
+
+def cpu_baseline(max_seconds=20.0):
+    """The reference's CPU fake-quant path (flat_utils.py:6-17 + quant_utils.py:71-119), restated in torch by
+    oracle/path_a_torch.py, on a bounded sample: C1-sized batches (2048 x 4096 fp16) for <= ~20 s."""
+    from oracle import path_a_torch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rows = 2048
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(rows, D, generator=g).to(torch.float16)
+    mats = make_matrices("cpu")
+    sig = (float(torch.sigmoid(torch.tensor(4.0))),) * 2
+    path_a_torch.kron_fakequant(x, mats["left"], mats["right"], sig)       # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 10 and time.perf_counter() - t_start < max_seconds:
+        t0 = time.perf_counter()
+        path_a_torch.kron_fakequant(x, mats["left"], mats["right"], sig)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": rows * D / med / 1e6, "unit": "Melem/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} x ({rows} x {D} fp16 tokens), torch {torch.__version__} CPU, median",
+            "ms_per_sample": med * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)   # RCCL
+
+    from flatquant_amd import ops, sharding
+    from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED
+
+    mats = make_matrices(device) if rank == 0 else {
+        "left": torch.empty(M, M, dtype=torch.float16, device=device),
+        "right": torch.empty(N, N, dtype=torch.float16, device=device)}
+    mats = sharding.broadcast_matrices(mats, src=0)         # the only collective on the path (set-up time)
+    left, right = mats["left"].contiguous(), mats["right"].contiguous()
+    sig = [ops.sigmoid_pair(4.0, 4.0)]
+    xs = make_inputs(device, seed=rank)
+    flags = FQ_OUT_PACKED | FQ_NO_CLAMP0                    # deploy OnlineTrans(matmul) contract
+
+    # pre-allocated rotating outputs; the timed region calls the C ABI directly (no allocator in the loop)
+    import ctypes
+    from flatquant_amd._lib import check, lib
+    qs = [torch.empty(ROWS, D // 2, dtype=torch.uint8, device=device) for _ in range(N_BUF)]
+    ss = [torch.empty(ROWS, dtype=torch.float16, device=device) for _ in range(N_BUF)]
+    smax = (ctypes.c_float * 4)(sig[0][0]); smin = (ctypes.c_float * 4)(sig[0][1])
+    stream = torch.cuda.current_stream(device)
+    sp = ctypes.c_void_p(stream.cuda_stream)
+
+    def arr(t):
+        a = (ctypes.c_void_p * 4)()
+        a[0] = t.data_ptr()
+        return a
+    calls = [(ctypes.c_void_p(xs[i].data_ptr()), arr(qs[i]), arr(ss[i])) for i in range(N_BUF)]
+    lp, rp = ctypes.c_void_p(left.data_ptr()), ctypes.c_void_p(right.data_ptr())
+    none4 = (ctypes.c_void_p * 4)()
+
+    def step(i):
+        xp, qa, sa = calls[i % N_BUF]
+        check(lib.fq_kron_quant_f16(xp, lp, rp, None, ROWS, M, N, smax, smin, 1, flags, qa, sa, none4, None, sp))
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)                                       # same stream the kernels are launched on
+    for i in range(args.steps):
+        step(i)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps             # average launch duration from HIP events
+
+    t = torch.tensor([wall, kern_ms], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)             # MAX over ranks
+    wall, kern_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        ms_per_step = wall * 1e3 / args.steps
+        value = world * ROWS * D / (wall / args.steps) / 1e6
+        achieved = ROWS * BYTES_PER_TOKEN / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Melems/s for fused kron-transform+INT4-quant, Llama-3-8B d=4096, bs×seq=8×2048",
+            "value": value, "unit": "Melem/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "C2: Llama-3-8B single linear (q_proj input), d=4096 = 64x64 Kronecker, "
+                                   "8x2048 tokens per GPU, packed INT4 + fp16 scale out",
+                       "rows_per_gpu": ROWS, "d": D, "factors": [M, N], "parallelism": f"rows x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "fq_kron64_kernel", "algorithmic_bytes_per_launch": ROWS * BYTES_PER_TOKEN,
+                         "launch_us": kern_ms * 1e3},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

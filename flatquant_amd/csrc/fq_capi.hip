@@ -81,6 +81,7 @@ int fill_out(const char* what, FqQuantOut& o, const float* sig_max, const float*
         if (!y_out) return fail(FQ_EINVAL, "%s: FQ_OUT_TRANSFORM needs y_out", what);
         o.y = (f16*)y_out;
     }
+    o.rt_flags = flags & (FQ_ROUND_Y_F16 | FQ_NO_CLAMP0);
     return FQ_OK;
 }
 

@@ -27,7 +27,11 @@ struct FqQuantOut {
     f16*     fq[FQ_MAX_CLIPS];     // fake-quant fp16, or nullptr
     f16*     y;                    // transformed fp16, or nullptr
     int      n_clips;
+    int      rt_flags;             // run-time flags: FQ_ROUND_Y_F16, FQ_NO_CLAMP0 (wave-uniform branches)
 };
+
+// Flags that select a compile-time kernel specialisation; the rest travel in FqQuantOut::rt_flags.
+constexpr int FQ_CT_MASK = FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_QUANT_F16;
 
 __device__ __forceinline__ float fq_wave_max(float v) {
 #pragma unroll
@@ -42,8 +46,9 @@ __device__ __forceinline__ float fq_wave_min(float v) {
 
 // scale from (xmax, xmin) of one token and one clip set; see header comment for the pinned arithmetic.
 template <int FLAGS>
-__device__ __forceinline__ float fq_token_scale(float xmax, float xmin, float sig_max, float sig_min) {
-    if (!(FLAGS & FQ_NO_CLAMP0)) {
+__device__ __forceinline__ float fq_token_scale(float xmax, float xmin, float sig_max, float sig_min,
+                                                int rt_flags) {
+    if (!(rt_flags & FQ_NO_CLAMP0)) {
         xmax = fmaxf(xmax, 0.0f);
         xmin = fminf(xmin, 0.0f);
     }

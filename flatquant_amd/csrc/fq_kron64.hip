@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void fq_kron64_kernel(const f16* __restrict
             }
         }
 
-        if (FLAGS & FQ_ROUND_Y_F16) {
+        if (out.rt_flags & FQ_ROUND_Y_F16) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void fq_kron64_kernel(const f16* __restrict
             vmin = fq_wave_min(vmin);
 
             for (int ci = 0; ci < out.n_clips; ++ci) {
-                const float scale = fq_token_scale<FLAGS>(vmax, vmin, out.sig_max[ci], out.sig_min[ci]);
+                const float scale = fq_token_scale<FLAGS>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
                 if (FLAGS & FQ_OUT_PACKED) {
                     if (lane == 0) out.scale[ci][tok] = (f16)scale;
 #pragma unroll
@@ -256,22 +256,22 @@ static int launch_kron64(const f16* x, const f16* left, const f16* right, const 
 
 int fq_launch_kron64(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
                      int64_t rows, const FqQuantOut& out, int n_cu, hipStream_t stream) {
-    // Compile-time specialisations of the output/arithmetics flag set; everything else is rejected
-    // by the caller with FQ_EUNSUPPORTED.
-#define FQ_CASE(F) \
-    case (F):      \
-        return launch_kron64<(F)>(x, left, right, diag, rows, out, n_cu, stream);
-    switch (flags) {
+    // Compile-time specialisations: output set x fp16-quant arithmetic. Everything else is run-time.
+#define FQ_CASE(F)                                                                     \
+    case (F):                                                                          \
+        return launch_kron64<(F)>(x, left, right, diag, rows, out, n_cu, stream);      \
+    case (F) | FQ_QUANT_F16:                                                           \
+        return launch_kron64<(F) | FQ_QUANT_F16>(x, left, right, diag, rows, out, n_cu, stream);
+    switch (flags & FQ_CT_MASK) {
         FQ_CASE(FQ_OUT_PACKED)
-        FQ_CASE(FQ_OUT_PACKED | FQ_NO_CLAMP0)
-        FQ_CASE(FQ_OUT_PACKED | FQ_ROUND_Y_F16)
         FQ_CASE(FQ_OUT_FAKEQUANT)
-        FQ_CASE(FQ_OUT_FAKEQUANT | FQ_ROUND_Y_F16)
-        FQ_CASE(FQ_OUT_FAKEQUANT | FQ_ROUND_Y_F16 | FQ_QUANT_F16)
         FQ_CASE(FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)
-        FQ_CASE(FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_ROUND_Y_F16)
-        FQ_CASE(FQ_OUT_TRANSFORM)
         FQ_CASE(FQ_OUT_TRANSFORM | FQ_OUT_PACKED)
+        FQ_CASE(FQ_OUT_TRANSFORM | FQ_OUT_FAKEQUANT)
+        FQ_CASE(FQ_OUT_TRANSFORM | FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)
+        case FQ_OUT_TRANSFORM:
+        case FQ_OUT_TRANSFORM | FQ_QUANT_F16:
+            return launch_kron64<FQ_OUT_TRANSFORM>(x, left, right, diag, rows, out, n_cu, stream);
         default:
             return -1000;
     }

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(RQ_THREADS) void fq_rowquant_kernel(const f16* __re
         vmin = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
 
         for (int ci = 0; ci < out.n_clips; ++ci) {
-            const float scale = fq_token_scale<FLAGS>(vmax, vmin, out.sig_max[ci], out.sig_min[ci]);
+            const float scale = fq_token_scale<FLAGS>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
             if (FLAGS & FQ_OUT_PACKED) {
                 if (tid == 0) out.scale[ci][row] = (f16)scale;
                 uint32_t* qp = reinterpret_cast<uint32_t*>(out.q[ci] + row * (int64_t)(cols >> 1));
@@ -171,15 +171,14 @@ int launch_rowquant(const f16* x, int64_t rows, int cols, const FqQuantOut& out,
 
 int fq_launch_rowquant(int flags, const f16* x, int64_t rows, int cols, const FqQuantOut& out, int n_cu,
                        hipStream_t stream) {
-#define FQ_CASE(F) \
-    case (F):      \
-        return launch_rowquant<(F)>(x, rows, cols, out, n_cu, stream);
-    switch (flags) {
+#define FQ_CASE(F)                                                              \
+    case (F):                                                                   \
+        return launch_rowquant<(F)>(x, rows, cols, out, n_cu, stream);          \
+    case (F) | FQ_QUANT_F16:                                                    \
+        return launch_rowquant<(F) | FQ_QUANT_F16>(x, rows, cols, out, n_cu, stream);
+    switch (flags & FQ_CT_MASK) {
         FQ_CASE(FQ_OUT_PACKED)
-        FQ_CASE(FQ_OUT_PACKED | FQ_NO_CLAMP0)
-        FQ_CASE(FQ_OUT_PACKED | FQ_QUANT_F16)
         FQ_CASE(FQ_OUT_FAKEQUANT)
-        FQ_CASE(FQ_OUT_FAKEQUANT | FQ_QUANT_F16)
         FQ_CASE(FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)
         default:
             return -1000;

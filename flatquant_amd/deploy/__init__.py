@@ -1,0 +1,56 @@
+"""Mirror of the reference's ``deploy`` package façade (deploy/__init__.py:37-71) over libfqhip."""
+import torch
+
+from .. import ops
+
+
+class PackedQuantizedTensor:
+    """Packed INT4 activation + per-token fp16 scales.  Reference: deploy/__init__.py:55-71."""
+
+    def __init__(self, quantized_x: torch.Tensor, scales_x: torch.Tensor):
+        self.quantized_x = quantized_x
+        self.scales_x = scales_x
+
+    def size(self):
+        return self.quantized_x.size()
+
+    @property
+    def device(self):
+        return self.quantized_x.device
+
+    @property
+    def dtype(self):
+        return self.quantized_x.dtype
+
+
+def flatten_last_dim_and_return_shape(x: torch.Tensor):
+    shape_excl_last = x.shape[:-1]
+    return x.view(-1, x.shape[-1]), shape_excl_last
+
+
+def sym_quant(x, scale):
+    """deploy/__init__.py:43-46 -> _CUDA.sym_quant (quant.cu:13-63): fp16 in, packed uint8 out."""
+    assert x.dtype == scale.dtype == torch.float16
+    x, x_shape_excl_last = flatten_last_dim_and_return_shape(x)
+    return ops.sym_quant(x, scale.view(-1)).view(*x_shape_excl_last, -1)
+
+
+def sym_dequant(q, scale_row, scale_col, bits=32):
+    """deploy/__init__.py:48-52 -> _CUDA.sym_dequant (quant.cu:66-101)."""
+    assert q.dtype == torch.int32
+    assert scale_row.dtype == scale_col.dtype == torch.float16
+    if bits != 32:
+        raise RuntimeError("Unsupported data type")          # bindings.cpp:82
+    q, q_shape_excl_last = flatten_last_dim_and_return_shape(q)
+    return ops.sym_dequant(q, scale_row.view(-1), scale_col.reshape(-1)).view(*q_shape_excl_last, -1)
+
+
+def matmul(A, B):
+    """INT4 x INT4 -> INT32 GEMM (deploy/__init__.py:37-41 -> gemm.cu, CUTLASS): the CONSUMER of the path,
+    SURVEY 8f rank 1 — not built in this round."""
+    raise NotImplementedError("flatquant_amd.deploy.matmul (int4 GEMM) is the next scope row, not built yet")
+
+
+from . import functional, nn  # noqa: E402,F401
+
+__all__ = ["matmul", "sym_quant", "sym_dequant", "PackedQuantizedTensor", "nn", "functional"]

@@ -1,0 +1,2 @@
+from .online_trans import OnlineTrans  # noqa: F401
+from .quantization import Quantizer  # noqa: F401

@@ -1,0 +1,57 @@
+"""Counterpart of deploy/nn/online_trans.py."""
+import torch
+
+from .. import functional
+from ...flatquant.function_utils import get_decompose_dim  # noqa: F401
+
+
+class OnlineTrans(torch.nn.Module):
+    """Online transform in front of a 4-bit linear.  Reference: deploy/nn/online_trans.py:18-67 — same
+    constructor, same buffers (``had_rem_dim`` | ``left_matrix right_matrix diag_scale``;
+    ``clip_factor_a_max/min`` default 1.0) so reference state dicts load unchanged.
+
+      trans="had":    fp16 tensor out (QuaRot baseline), one HIP launch instead of FWHT + bmm.
+      trans="matmul": PackedQuantizedTensor out (transform + INT4 quant fused), one HIP launch.
+    """
+
+    def __init__(self, trans_dim, force_fp32=False, trans="had", decompose=True, lac=False):
+        super().__init__()
+        self.fp32_trans = force_fp32
+        self.trans = trans
+        self.decompose = decompose
+        self.trans_dim = trans_dim
+        if trans == "had":
+            had_rem_dim, self.rem_dim = functional.online_trans.get_hadK(trans_dim)
+            if had_rem_dim is not None:
+                self.register_buffer("had_rem_dim", had_rem_dim)
+                if not self.fp32_trans:
+                    self.had_rem_dim = self.had_rem_dim.to(torch.float16)
+            else:
+                self.had_rem_dim = None
+        elif trans == "matmul":
+            if decompose:
+                left_size, right_size = get_decompose_dim(trans_dim)
+                self.register_buffer("left_matrix", torch.randn([left_size, left_size], dtype=torch.float16))
+                self.register_buffer("right_matrix", torch.randn([right_size, right_size], dtype=torch.float16))
+                self.register_buffer("diag_scale", torch.randn([trans_dim], dtype=torch.float16))
+            else:
+                self.register_buffer("right_matrix", torch.randn([trans_dim, trans_dim], dtype=torch.float16))
+        self.lac = lac
+        self.register_buffer("clip_factor_a_max", torch.tensor(1.0))
+        self.register_buffer("clip_factor_a_min", torch.tensor(1.0))
+
+    def forward(self, x):
+        if self.trans == "had":
+            if self.fp32_trans:
+                # the reference up-casts and returns fp32 (online_trans.py:56-59); the HIP kernel already
+                # runs its butterflies in fp32, so only the result is widened.
+                return functional.matmul_hadU_cuda(x.to(torch.float16), self.had_rem_dim, self.rem_dim).float()
+            return functional.matmul_hadU_cuda(x, self.had_rem_dim, self.rem_dim)
+        if self.trans == "matmul":
+            invs = []
+            if hasattr(self, "left_matrix"):
+                invs.append(self.left_matrix)
+            if hasattr(self, "right_matrix"):
+                invs.append(self.right_matrix)
+            return functional.online_trans.kronecker_matmul(x, invs, self.clip_factor_a_max, self.clip_factor_a_min)
+        return x

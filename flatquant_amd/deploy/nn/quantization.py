@@ -1,0 +1,36 @@
+"""Counterpart of deploy/nn/quantization.py."""
+import torch
+
+from ... import ops
+from ..._lib import FQ_OUT_PACKED, FQ_QUANT_F16
+from .. import PackedQuantizedTensor
+
+
+class Quantizer(torch.nn.Module):
+    """Per-token INT4 activation quantiser; passes an already packed input through.
+    Reference: deploy/nn/quantization.py:5-36 (5-8 torch launches + the CUDA pack kernel) — here one HIP
+    launch reads each row once.  Arithmetic as the reference: fp32 statistics, scale rounded to fp16,
+    x / scale in fp16 (quant.cu:40), round-half-even, clamp, low nibble = even column."""
+
+    def __init__(self, input_clip_ratio=1.0, lac=False):
+        super().__init__()
+        self.input_clip_ratio = input_clip_ratio
+        self.lac = lac
+        self.register_buffer("clip_factor_a_max", torch.tensor(4.0))
+        self.register_buffer("clip_factor_a_min", torch.tensor(4.0))
+
+    def forward(self, x):
+        if isinstance(x, PackedQuantizedTensor):
+            return x
+        if self.lac:
+            sig = ops.sigmoid_pair(float(self.clip_factor_a_max), float(self.clip_factor_a_min))
+        elif self.input_clip_ratio == 1.0:
+            sig = (1.0, 1.0)
+        else:
+            # (max|x|/7).to(fp16) * ratio: keep the reference's exact op order with torch, pack with the kernel
+            from .. import sym_quant
+            scales = (torch.max(torch.abs(x), dim=-1)[0].unsqueeze(1) / 7).to(torch.float16) * self.input_clip_ratio
+            return PackedQuantizedTensor(sym_quant(x, scales), scales)
+        o = ops.rowquant(x.contiguous(), [sig], FQ_OUT_PACKED | FQ_QUANT_F16)
+        lead = x.shape[:-1]
+        return PackedQuantizedTensor(o.q[0], o.scale[0].reshape(*lead, 1) if len(lead) > 1 else o.scale[0].reshape(-1, 1))

@@ -1,0 +1,62 @@
+"""Counterpart of flatquant/quant_utils.py: the per-token activation fake-quantiser."""
+import torch
+
+from .. import ops
+from .._lib import FQ_OUT_FAKEQUANT, FQ_QUANT_F16
+
+
+def get_qmin_qmax(bits, sym):
+    """quant_utils.py:10-16."""
+    if sym:
+        q_max = torch.tensor(2 ** (bits - 1) - 1)
+        q_min = -q_max - 1
+    else:
+        q_max, q_min = torch.tensor(2 ** bits - 1), 0
+    return q_max, q_min
+
+
+class ActivationQuantizer(torch.nn.Module):
+    """Per-token symmetric fake quantisation, one fused HIP pass (row read once, written once).
+
+    Reference: flatquant/quant_utils.py:48-119.  Same constructor, parameters (``clip_factor_a_max/min``,
+    shape (1,), init 4.0 when ``lac``) and attributes (``bits sym lac enable q_max q_min groupsize``).
+    Arithmetic: with ``lac`` the reference's type promotion evaluates scale, x/scale and scale*q in fp32
+    (fp16 extrema x fp32 sigmoid); without it everything stays fp16 — both are reproduced (FQ_QUANT_F16).
+    Only the 4-bit symmetric case is on the hot path; asymmetric raises NotImplementedError.
+    """
+
+    def __init__(self, bits, sym=False, lac=False, groupsize=-1, clip_ratio=None):
+        super().__init__()
+        self.bits = bits
+        self.q_max, self.q_min = get_qmin_qmax(bits, sym)
+        self.sym = sym
+        self.groupsize = groupsize
+        if self.groupsize > 0:
+            raise NotImplementedError("Not support per-group quantization for activation yet.")
+        self.lac = lac
+        self._clip_ratio = clip_ratio
+        if self.lac:
+            init_value = 4.0
+            self.sigmoid = torch.nn.Sigmoid()
+            self.clip_factor_a_max = torch.nn.Parameter(torch.ones((1,)) * init_value, requires_grad=True)
+            self.clip_factor_a_min = torch.nn.Parameter(torch.ones((1,)) * init_value, requires_grad=True)
+        self.enable = True
+
+    def _sig(self):
+        if self.lac:
+            return (float(torch.sigmoid(self.clip_factor_a_max.detach().float().cpu())[0]),
+                    float(torch.sigmoid(self.clip_factor_a_min.detach().float().cpu())[0]))
+        if self._clip_ratio is not None:
+            return float(self._clip_ratio), float(self._clip_ratio)
+        return 1.0, 1.0
+
+    def forward(self, x):
+        if self.bits == 16 or (not self.enable):
+            return x
+        return self.fake_quant(x)
+
+    def fake_quant(self, x):
+        if self.bits != 4 or not self.sym:
+            raise NotImplementedError("flatquant_amd: only 4-bit symmetric activation quantisation is on the hot path")
+        flags = FQ_OUT_FAKEQUANT | (0 if self.lac else FQ_QUANT_F16)
+        return ops.rowquant(x.contiguous(), [self._sig()], flags).fq[0]

@@ -1,0 +1,108 @@
+"""Counterpart of flatquant/trans_utils.py — inference (eval-mode) transforms only.
+
+The reference classes are *training* parametrisations (Cayley-orthogonal SVD factors, trans_utils.py:57-84)
+that ``to_eval_mode()`` collapses into plain matrices.  Calibration is out of scope,
+so these classes are born in eval mode: they own ``matrix_left / matrix_right`` (+ ``*_inv`` = (P^-1)^T) and
+``diag_scale`` with the reference's names, so ``flat_matrices.pth`` / state dicts load unchanged, and their
+``forward`` runs the HIP kernel.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import FQ_OUT_TRANSFORM
+from .flat_utils import kronecker_matmul
+from .function_utils import get_init_weight, get_inverse
+
+
+class _DecomposeTransBase(nn.Module):
+    """Shared eval-mode behaviour of {SVD,Inv}DecomposeTransMatrix (trans_utils.py:85-116, :190-213)."""
+
+    def __init__(self, left_size, right_size, add_diag=False, diag_init_para=None, diag_dtype=None):
+        super().__init__()
+        left = get_init_weight(left_size).to(torch.get_default_dtype())
+        right = get_init_weight(right_size).to(torch.get_default_dtype())
+        self.matrix_left = nn.Parameter(left, requires_grad=False)
+        self.matrix_right = nn.Parameter(right, requires_grad=False)
+        self.matrix_left_inv = nn.Parameter(get_inverse(left).T.contiguous(), requires_grad=False)
+        self.matrix_right_inv = nn.Parameter(get_inverse(right).T.contiguous(), requires_grad=False)
+        self.add_diag = add_diag
+        self.use_diag = True
+        if self.add_diag:
+            if diag_init_para is None:
+                diag_init_para = torch.ones(left_size * right_size, dtype=diag_dtype or torch.get_default_dtype())
+            self.diag_scale = nn.Parameter(diag_init_para, requires_grad=False)
+        self._eval_mode = True
+
+    def to_eval_mode(self):
+        self._eval_mode = True
+
+    def forward(self, inp, inv_t=False):
+        left, right = (self.matrix_left_inv, self.matrix_right_inv) if inv_t else (self.matrix_left, self.matrix_right)
+        use_diag = self.add_diag and self.use_diag
+        if inp.dtype == torch.float16 and inp.is_cuda:
+            diag = None
+            if use_diag:
+                d = self.diag_scale.to(inp)
+                # x / d is evaluated as x * (1/d) would NOT match the reference's fp16 division; divide first.
+                if inv_t:
+                    inp = inp / d
+                else:
+                    diag = d.contiguous()
+            l16 = left.to(device=inp.device, dtype=torch.float16).contiguous()
+            r16 = right.to(device=inp.device, dtype=torch.float16).contiguous()
+            return ops.kron_quant(inp.contiguous(), l16, r16, flags=FQ_OUT_TRANSFORM, diag=diag).y
+        if use_diag:
+            inp = inp / self.diag_scale.to(inp) if inv_t else inp * self.diag_scale.to(inp)
+        return kronecker_matmul(inp, left.to(inp), right.to(inp))
+
+    def __repr__(self):
+        return (f"{type(self).__name__}(_eval_mode=True, matrix.shape={tuple(self.matrix_left.shape)}, "
+                f"matrix_right.shape={tuple(self.matrix_right.shape)})")
+
+
+class SVDDecomposeTransMatrix(_DecomposeTransBase):
+    """trans_utils.py:57-124 (eval mode).  diag_scale is fp32 as in the reference (:78)."""
+
+    def __init__(self, left_size, right_size, add_diag=False, diag_init_para=None):
+        super().__init__(left_size, right_size, add_diag, diag_init_para, diag_dtype=torch.float32)
+
+
+class InvDecomposeTransMatrix(_DecomposeTransBase):
+    """trans_utils.py:170-221 (eval mode)."""
+
+
+class _SingleTransBase(nn.Module):
+    """{SVD,Inv}SingleTransMatrix in eval mode (trans_utils.py:21-46, :136-160): y = x.reshape(-1, n) @ matrix."""
+
+    def __init__(self, size):
+        super().__init__()
+        m = get_init_weight(size).to(torch.get_default_dtype())
+        self.matrix = nn.Parameter(m, requires_grad=False)
+        self.matrix_inv_t = nn.Parameter(get_inverse(m).T.contiguous(), requires_grad=False)
+        self._eval_mode = True
+
+    def to_eval_mode(self):
+        self._eval_mode = True
+
+    def get_matrix(self, inv_t=False):
+        return self.matrix_inv_t if inv_t else self.matrix
+
+    def forward(self, inp, inv_t=False):
+        init_shape = inp.shape
+        matrix = self.get_matrix(inv_t=inv_t).to(inp)
+        n = matrix.shape[0]
+        # a plain [rows, n] x [n, n] library GEMM (rocBLAS through torch), exactly trans_utils.py:21-25; the
+        # fused, quantising form of this transform on the o_proj input is ops.block_quant.
+        return inp.reshape(-1, n).matmul(matrix).reshape(init_shape)
+
+    def __repr__(self):
+        return f"{type(self).__name__}(eval_mode=True, matrix.shape={tuple(self.matrix.shape)})"
+
+
+class SVDSingleTransMatrix(_SingleTransBase):
+    """trans_utils.py:8-54 (eval mode)."""
+
+
+class InvSingleTransMatrix(_SingleTransBase):
+    """trans_utils.py:128-167 (eval mode)."""

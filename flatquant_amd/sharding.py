@@ -1,0 +1,47 @@
+"""Multi-GPU: one process per GPU, rows (tokens) sharded, factor matrices broadcast once over RCCL/xGMI.
+
+The path is embarrassingly parallel over tokens: the only shared state is read-only (left/right/hadK and two
+clip scalars per layer).  So there is NO data-path collective — just a one-time ``broadcast`` of the small
+matrices from rank 0 at set-up.  ``backend='nccl'`` is RCCL on ROCm; tests use ``gloo`` on CPU.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(total_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous [start, stop) block of rows owned by ``rank``; sizes differ by at most one row."""
+    base, rem = divmod(total_rows, world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def broadcast_matrices(mats: Dict[str, torch.Tensor], src: int = 0, group=None) -> Dict[str, torch.Tensor]:
+    """Broadcast every tensor of ``mats`` from ``src`` as ONE flat buffer (one collective for all layers: a few
+    hundred KB to a few MB — latency-bound on xGMI, so fewer, larger messages)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return mats
+    keys = sorted(mats)
+    flat = torch.cat([mats[k].reshape(-1).view(torch.uint8) for k in keys]) if keys else None
+    if flat is not None:
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        out = {}
+        for k in keys:
+            nbytes = mats[k].numel() * mats[k].element_size()
+            out[k] = flat[off:off + nbytes].view(mats[k].dtype).reshape(mats[k].shape).clone()
+            off += nbytes
+        return out
+    return mats
+
+
+def gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
+    """all_gather of row shards (equal sizes) — for tests that compare with the single-GPU result only."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    parts = [torch.empty_like(local) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, local.contiguous(), group=group)
+    return torch.cat(parts, dim=0)

@@ -1,0 +1,205 @@
+"""GPU parity for the fused Kronecker transform + INT4 quantisation at d = 4096 (M = N = 64).
+
+Everything goes through the C ABI (flatquant_amd.ops -> libfqhip.so).  Bars:
+  * dyadic fixtures: packed bytes, scales, fake-quant and transformed output BIT-EXACT vs BOTH reference paths;
+  * quantise/pack stage: BIT-EXACT vs the oracle applied to the kernel's own transformed activation
+    (independent of the order in which the matrix cores add partial products);
+  * transform stage vs the oracle: fp16 outputs equal except isolated 1-ulp roundings (MFMA vs exact-sum
+    accumulation order), <= 1e-3 relative to the token's max — the north-star tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+P, F, T, R16, NC0, Q16 = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+def mismatch(a, b):
+    return float(np.mean(np.asarray(a).reshape(-1) != np.asarray(b).reshape(-1)))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from flatquant_amd import ops as _ops
+    return _ops
+
+
+def test_exact_fixture_bit_exact_vs_both_reference_paths(ops, golden):
+    g = golden("exact_64x64")
+    x, L, Rm = dev(g["x"]), dev(g["L"]), dev(g["R"])
+    rows = x.shape[0]
+    for ci in range(2):
+        sig = [(float(g[f"sig{ci}"][0]), float(g[f"sig{ci}"][1]))]
+        o = ops.kron_quant(x, L, Rm, sig, P | NC0)                       # deploy / path-B contract
+        assert np.array_equal(o.q[0].cpu().numpy(), g[f"b_packed{ci}"])
+        assert np.array_equal(o.scale[0].cpu().numpy(), g[f"b_scale{ci}"])
+        o = ops.kron_quant(x, L, Rm, sig, F | R16)                       # FlatQuantizedLinear / path-A contract
+        assert np.array_equal(o.fq[0].cpu().numpy(), g[f"a_fq{ci}"].reshape(rows, -1))
+        o = ops.kron_quant(x, L, Rm, sig, T)
+        assert np.array_equal(o.y.cpu().numpy(), g[f"a_y{ci}"].reshape(rows, -1))
+
+
+@pytest.mark.parametrize("name", ["kron_A_64x64", "kron_B_64x64", "edge_64x64"])
+def test_quant_stage_bit_exact_given_kernel_transform(ops, golden, name):
+    g = golden(name)
+    Lk, Rk = ("rand_L", "rand_R") if name.startswith("edge") else ("L", "R")
+    x, L, Rm = dev(g["x"]), dev(g[Lk]), dev(g[Rk])
+    sigs = [(0.9820137619972229, 0.9820137619972229), (0.9, 0.33), (1.0, 1.0)]
+    o = ops.kron_quant(x, L, Rm, sigs, T | P | F | R16)
+    y16 = o.y.cpu().numpy()
+    for ci, (smax, smin) in enumerate(sigs):
+        ref = O.quant_outputs(y16.astype(np.float32), smax, smin)
+        assert np.array_equal(o.q[ci].cpu().numpy(), ref["packed"])
+        assert np.array_equal(o.scale[ci].cpu().numpy(), ref["scale16"])
+        assert np.array_equal(o.fq[ci].cpu().numpy(), ref["fq"])
+
+
+@pytest.mark.parametrize("name", ["kron_A_64x64", "kron_B_64x64", "edge_64x64"])
+def test_transform_vs_oracle(ops, golden, name):
+    g = golden(name)
+    Lk, Rk = ("rand_L", "rand_R") if name.startswith("edge") else ("L", "R")
+    x, L, Rm = dev(g["x"]), dev(g[Lk]), dev(g[Rk])
+    y = ops.kron_quant(x, L, Rm, flags=T).y.cpu().numpy()
+    y32 = O.kron_transform(g["x"], g[Lk], g[Rk]).reshape(y.shape)
+    ref = y32.astype(np.float16)
+    finite = np.isfinite(ref.astype(np.float32)).all(axis=1)
+    assert mismatch(y[finite], ref[finite]) <= 5e-3
+    den = np.abs(y32[finite]).max(axis=1, keepdims=True) + 1e-30
+    assert np.max(np.abs(y[finite].astype(np.float32) - y32[finite]) / den) <= 1e-3
+
+
+@pytest.mark.parametrize("name,flags,kw", [
+    ("kron_A_64x64", P, dict()),
+    ("kron_A_64x64", P | R16, dict(round_y_f16=True)),
+    ("kron_B_64x64", P | NC0, dict(clamp0=False)),
+])
+def test_packed_vs_oracle_random(ops, golden, name, flags, kw):
+    g = golden(name)
+    x, L, Rm = dev(g["x"]), dev(g["L"]), dev(g["R"])
+    for ci in range(2):
+        s = (float(g["sig"][ci][0]), float(g["sig"][ci][1]))
+        o = ops.kron_quant(x, L, Rm, [s], flags)
+        ref = O.kron_quant(g["x"], g["L"], g["R"], s[0], s[1], **kw)
+        q = O.unpack_i4(o.q[0].cpu().numpy())
+        assert mismatch(q, ref["q"]) <= 1e-3
+        assert np.max(np.abs(q - ref["q"].astype(np.int32))) <= 1
+        sg = o.scale[0].cpu().numpy().astype(np.float32)
+        assert np.max(np.abs(sg - ref["scale"]) / ref["scale"]) <= 1e-3
+
+
+def test_vs_reference_path_a_and_b_goldens(ops, golden):
+    """Directly against the reference's own outputs (not the oracle): INT4 flip rate <= 1e-3, |dq| <= 1."""
+    g = golden("kron_A_64x64")
+    x, L, Rm = dev(g["x"]), dev(g["L"]), dev(g["R"])
+    for ci in range(2):
+        s = (float(g["sig"][ci][0]), float(g["sig"][ci][1]))
+        o = ops.kron_quant(x, L, Rm, [s], P | F | R16)
+        q = O.unpack_i4(o.q[0].cpu().numpy())
+        qa = g[f"a16_lac{ci}_q"].reshape(q.shape).astype(np.int32)
+        assert mismatch(q, qa) <= 1e-3 and np.max(np.abs(q - qa)) <= 1
+        fq, fa = o.fq[0].cpu().numpy().astype(np.float32), g[f"a16_lac{ci}_fq"].reshape(q.shape).astype(np.float32)
+        assert np.max(np.abs(fq - fa) / (np.abs(fa).max(axis=1, keepdims=True))) <= 0.15  # one INT4 step at most
+        assert np.mean(fq != fa) <= 2e-3
+    g = golden("kron_B_64x64")
+    x, L, Rm = dev(g["x"]), dev(g["L"]), dev(g["R"])
+    for ci in range(3):
+        s = (float(g["sig"][ci][0]), float(g["sig"][ci][1]))
+        o = ops.kron_quant(x, L, Rm, [s], P | NC0)
+        q, qb = O.unpack_i4(o.q[0].cpu().numpy()), O.unpack_i4(g[f"b_packed{ci}"])
+        assert mismatch(q, qb) <= 1e-3 and np.max(np.abs(q - qb)) <= 1
+        sb = g[f"b_scale{ci}"].astype(np.float32)
+        assert np.max(np.abs(o.scale[0].cpu().numpy().astype(np.float32) - sb) / sb) <= 1e-3
+
+
+def test_diag_scale(ops, golden):
+    g = golden("kron_A_diag_64x64")
+    x, L, Rm, d = dev(g["x"]), dev(g["L"]), dev(g["R"]), dev(g["diag"])
+    y = ops.kron_quant(x, L, Rm, flags=T, diag=d).y.cpu().numpy()
+    ref = O.kron_transform(g["x"], g["L"], g["R"], diag16=g["diag"]).reshape(y.shape).astype(np.float16)
+    assert mismatch(y, ref) <= 5e-3
+    assert mismatch(y, g["y"]) <= 1e-2
+
+
+def test_multi_clip_equals_single_clip_launches(ops, golden):
+    g = golden("kron_A_64x64")
+    x, L, Rm = dev(g["x"]), dev(g["L"]), dev(g["R"])
+    sigs = [(0.98, 0.97), (0.5, 0.9), (1.0, 1.0), (0.75, 0.25)]
+    multi = ops.kron_quant(x, L, Rm, sigs, P)
+    for i, s in enumerate(sigs):
+        one = ops.kron_quant(x, L, Rm, [s], P)
+        assert torch.equal(multi.q[i], one.q[0]) and torch.equal(multi.scale[i], one.scale[0])
+
+
+@pytest.mark.parametrize("rows", [0, 1, 3, 4, 5, 1023, 2049])
+def test_ragged_row_counts(ops, rows):
+    gen = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, 4096, generator=gen).half()
+    L = (torch.randn(64, 64, generator=gen) / 8).half()
+    Rm = (torch.randn(64, 64, generator=gen) / 8).half()
+    o = ops.kron_quant(x.cuda(), L.cuda(), Rm.cuda(), [(1.0, 1.0)], T | P | R16)
+    assert o.q[0].shape == (rows, 2048) and o.scale[0].shape == (rows,)
+    if rows:
+        n = min(rows, 6)
+        ref = O.quant_outputs(o.y[-n:].cpu().numpy().astype(np.float32), 1.0, 1.0)
+        assert np.array_equal(o.q[0][-n:].cpu().numpy(), ref["packed"])
+        y32 = O.kron_transform(x[-n:].numpy(), L.numpy(), Rm.numpy()).reshape(n, -1)
+        assert mismatch(o.y[-n:].cpu().numpy(), y32.astype(np.float16)) <= 5e-3
+
+
+def test_full_size_properties(ops):
+    """BASELINE config C2 (8 x 2048 tokens, d = 4096): size-independent properties + sampled oracle check."""
+    rows, d = 8 * 2048, 4096
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(rows, d, generator=gen, device="cuda", dtype=torch.float16)
+    x[:, ::97] *= 20
+    L = (torch.randn(64, 64, generator=gen, device="cuda") / 8).half()
+    Rm = (torch.randn(64, 64, generator=gen, device="cuda") / 8).half()
+    sig = [(0.982, 0.982)]
+    a = ops.kron_quant(x, L, Rm, sig, T | P | R16)
+    b = ops.kron_quant(x, L, Rm, sig, T | P | R16)
+    assert torch.equal(a.q[0], b.q[0]) and torch.equal(a.scale[0], b.scale[0])         # deterministic
+    perm = torch.randperm(rows, device="cuda")
+    c = ops.kron_quant(x[perm].contiguous(), L, Rm, sig, T | P | R16)
+    assert torch.equal(c.q[0], a.q[0][perm]) and torch.equal(c.scale[0], a.scale[0][perm])  # token independence
+    # dequantised INT4 reproduces the transform to within half a step wherever it is not clipped
+    from flatquant_amd.deploy.functional import unpack_i4
+    q = unpack_i4(a.q[0]).float()
+    s = a.scale[0].float()[:, None]
+    y = a.y.float()
+    inside = (y.abs() <= 7 * s)
+    assert bool(((q * s - y).abs()[inside] <= 0.5 * s.expand_as(y)[inside] * 1.002 + 1e-6).all())
+    assert int(q.min()) >= -8 and int(q.max()) <= 7
+    # linearity of the transform: T(2x) == 2 T(x) exactly in fp16 (power-of-two scaling commutes with rounding)
+    y2 = ops.kron_quant((x * 2).contiguous(), L, Rm, flags=T).y
+    ok = torch.isfinite(y2).all(dim=1) & torch.isfinite(a.y).all(dim=1) & (a.y.abs().min(dim=1).values > 1e-3)
+    assert torch.equal(y2[ok], (a.y * 2)[ok])
+    idx = torch.randperm(rows)[:24]
+    ref = O.quant_outputs(a.y[idx.cuda()].cpu().numpy().astype(np.float32), *sig[0])
+    assert np.array_equal(a.q[0][idx.cuda()].cpu().numpy(), ref["packed"])
+    y32 = O.kron_transform(x[idx.cuda()].cpu().numpy(), L.cpu().numpy(), Rm.cpu().numpy()).reshape(24, -1)
+    assert mismatch(a.y[idx.cuda()].cpu().numpy(), y32.astype(np.float16)) <= 5e-3
+
+
+def test_argument_errors(ops):
+    x = torch.randn(4, 4096).half()
+    L = torch.randn(64, 64).half()
+    with pytest.raises(RuntimeError):
+        ops.kron_quant(x, L.cuda(), L.cuda())                       # CPU tensor: no CPU path
+    with pytest.raises(TypeError):
+        ops.kron_quant(x.cuda().float(), L.cuda(), L.cuda())        # wrong dtype
+    with pytest.raises(RuntimeError):
+        ops.kron_quant(x.cuda().t().contiguous().t(), L.cuda(), L.cuda())   # non-contiguous
+    with pytest.raises(ValueError):
+        ops.kron_quant(x.cuda(), L.cuda(), L.cuda(), sigs=[])       # no clip set
+    from flatquant_amd._lib import FqError
+    with pytest.raises(FqError):
+        ops.kron_quant(x.cuda(), L.cuda(), L.cuda(), flags=0)       # no output selected

@@ -1,0 +1,92 @@
+"""GPU parity for the standalone quantisation kernels (bit-exact: byte/integer results of IEEE arithmetic)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fq_oracle as O
+
+pytestmark = pytest.mark.gpu
+P, F, NC0, Q16 = 0x01, 0x02, 0x10, 0x20
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from flatquant_amd import ops as _ops
+    return _ops
+
+
+def rand_x(rows, cols, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, cols, generator=g)
+    x[:, ::53] *= 15
+    return x.half()
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 8), (7, 64), (33, 4096), (16, 14336), (5, 28672), (9, 11008), (3, 2056)])
+@pytest.mark.parametrize("flags,kw", [(P, {}), (P | NC0, dict(clamp0=False)), (P | Q16, dict(quant_f16=True)),
+                                      (F, {}), (F | Q16, dict(quant_f16=True)), (P | F, {})])
+def test_rowquant_bit_exact(ops, rows, cols, flags, kw):
+    x = rand_x(rows, cols, rows * 131 + cols)
+    if rows > 2:
+        x[1] = 0
+        x[2] = x[2].abs()
+    sigs = [(0.982, 0.982), (0.6, 0.9)] if not (flags & Q16) else [(1.0, 1.0), (0.982, 0.95)]
+    o = ops.rowquant(x.cuda(), sigs, flags)
+    for ci, s in enumerate(sigs):
+        ref = O.rowquant(x.numpy(), s[0], s[1], **kw)
+        if flags & P:
+            assert np.array_equal(o.q[ci].cpu().numpy(), ref["packed"])
+            assert np.array_equal(o.scale[ci].cpu().numpy(), ref["scale16"])
+        if flags & F:
+            assert np.array_equal(o.fq[ci].cpu().numpy(), ref["fq"])
+
+
+def test_rowquant_matches_reference_path_a_quantizer(ops, golden):
+    """ActivationQuantizer goldens (reference path A run on its own transformed activation)."""
+    g = golden("kron_A_112x128")
+    rows = g["x"].shape[0]
+    y = torch.from_numpy(g["a16_lac0_y"].reshape(rows, -1)).cuda()
+    for ci in range(2):
+        s = (float(g["sig"][ci][0]), float(g["sig"][ci][1]))
+        o = ops.rowquant(y, [s], F)
+        assert np.array_equal(o.fq[0].cpu().numpy(), g[f"a16_lac{ci}_fq"].reshape(rows, -1))
+    o = ops.rowquant(y, [(1.0, 1.0)], F | Q16)
+    assert np.array_equal(o.fq[0].cpu().numpy(), g["a16_nolac_fq"].reshape(rows, -1))
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 2), (5, 63), (4, 64), (17, 4096), (3, 4097), (64, 14336)])
+def test_sym_quant_bit_exact(ops, rows, cols):
+    x = rand_x(rows, cols, 7 * rows + cols)
+    s = (x.float().abs().amax(dim=1) / 7).half()
+    s[0] = s[0] * 0.5                                    # force clamping on one row
+    q = ops.sym_quant(x.cuda(), s.cuda()).cpu().numpy()
+    assert np.array_equal(q, O.sym_quant(x.numpy(), s.numpy()))
+
+
+def test_sym_dequant_bit_exact(ops):
+    g = torch.Generator().manual_seed(3)
+    q = torch.randint(-200000, 200000, (37, 200), generator=g, dtype=torch.int32)
+    q[0, :4] = torch.tensor([0, 9, -9, 700000])
+    sr = (torch.rand(37, generator=g) * 0.1).half()
+    sc = (torch.rand(200, generator=g) * 0.1).half()
+    x = ops.sym_dequant(q.cuda(), sr.cuda(), sc.cuda()).cpu().numpy()
+    ref = O.sym_dequant(q.numpy(), sr.numpy(), sc.numpy())
+    assert np.array_equal(x.view(np.uint16), ref.view(np.uint16))
+
+
+def test_deploy_api_round_trip(ops):
+    """deploy.nn.Quantizer -> PackedQuantizedTensor -> unpack * scale ~= x (the module-level contract)."""
+    from flatquant_amd import deploy
+    from flatquant_amd.deploy.functional import pack_i4, unpack_i4
+    x = rand_x(64, 4096, 11).cuda()
+    qz = deploy.nn.Quantizer(lac=True).cuda()
+    p = qz(x)
+    assert isinstance(p, deploy.PackedQuantizedTensor) and p.quantized_x.dtype == torch.uint8
+    assert qz(p) is p                                    # already packed: pass-through (quantization.py:14,35)
+    q = unpack_i4(p.quantized_x)
+    assert torch.equal(pack_i4(q.to(torch.int8)), p.quantized_x)
+    ref = O.rowquant(x.cpu().numpy(), *ops.sigmoid_pair(4.0, 4.0), quant_f16=True)
+    assert np.array_equal(p.quantized_x.cpu().numpy(), ref["packed"])
+    assert np.array_equal(p.scales_x.cpu().numpy().reshape(-1), ref["scale16"])
+    again = deploy.sym_quant(x, p.scales_x.reshape(-1))
+    assert torch.equal(again, p.quantized_x)             # Quantizer == scales + sym_quant, as in the reference

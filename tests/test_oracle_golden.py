@@ -199,3 +199,17 @@ def test_sym_dequant_restatement():
     out = O.sym_dequant(q, np.array([0.5], np.float16), np.ones(6, np.float16))
     assert out[0, 0] == 0 and out[0, 1] == 5 and out[0, 2] == -5
     assert out[0, 3] == np.float16(np.float16(np.float16(0.5) * np.float16(1234)) * np.float16(10))
+
+
+def test_path_a_torch_port_matches_reference_goldens(golden):
+    """oracle/path_a_torch.py (the cpu_baseline 'port') reproduces the reference's path A bit for bit: same
+    torch ops in the same order on the same CPU BLAS."""
+    import torch
+    from oracle import path_a_torch
+    g = golden("kron_A_64x64")
+    x, L, R = (torch.from_numpy(g[k]) for k in ("x", "L", "R"))
+    for ci in range(2):
+        fq = path_a_torch.kron_fakequant(x, L, R, (float(g["sig"][ci][0]), float(g["sig"][ci][1])))
+        assert np.array_equal(fq.numpy(), g[f"a16_lac{ci}_fq"])
+    y = path_a_torch.kronecker_matmul(x, L, R)
+    assert np.array_equal(y.numpy(), g["a16_lac0_y"])
