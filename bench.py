@@ -59,25 +59,38 @@ def cpu_baseline(max_seconds=20.0):
     """The reference's CPU fake-quant path (flat_utils.py:6-17 + quant_utils.py:71-119), restated in torch by
     oracle/path_a_torch.py, on a bounded sample: C1-sized batches (2048 x 4096 fp16) for <= ~20 s."""
     from oracle import path_a_torch
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    # torch's CPU GEMM on 64x64 factors scales poorly past a few dozen threads; time a short ladder and report the
+    # best (cores = the thread count actually used for `value`).
     rows = 2048
     g = torch.Generator().manual_seed(0)
     x = torch.randn(rows, D, generator=g).to(torch.float16)
     mats = make_matrices("cpu")
     sig = (float(torch.sigmoid(torch.tensor(4.0))),) * 2
-    path_a_torch.kron_fakequant(x, mats["left"], mats["right"], sig)       # warm-up
-    times = []
+    ncpu = os.cpu_count() or 1
+    ladder = sorted({t for t in (1, 8, 16, 32, 64, ncpu) if t <= ncpu})
+    best = None
+    results = {}
     t_start = time.perf_counter()
-    while len(times) < 10 and time.perf_counter() - t_start < max_seconds:
-        t0 = time.perf_counter()
-        path_a_torch.kron_fakequant(x, mats["left"], mats["right"], sig)
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": rows * D / med / 1e6, "unit": "Melem/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} x ({rows} x {D} fp16 tokens), torch {torch.__version__} CPU, median",
-            "ms_per_sample": med * 1e3}
+    for threads in ladder:
+        torch.set_num_threads(threads)
+        path_a_torch.kron_fakequant(x, mats["left"], mats["right"], sig)   # warm-up
+        times = []
+        t_cfg = time.perf_counter()
+        while len(times) < 5 and time.perf_counter() - t_cfg < max_seconds / len(ladder):
+            t0 = time.perf_counter()
+            path_a_torch.kron_fakequant(x, mats["left"], mats["right"], sig)
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        med = times[len(times) // 2]
+        results[threads] = rows * D / med / 1e6
+        if best is None or results[threads] > results[best]:
+            best = threads
+        if time.perf_counter() - t_start > max_seconds:
+            break
+    return {"value": results[best], "unit": "Melem/s", "cores": best, "kind": "port",
+            "sample": f"median of <=5 x ({rows} x {D} fp16 tokens) per thread count, torch {torch.__version__} CPU; "
+                      f"host has {ncpu} logical CPUs",
+            "by_threads": {str(k): round(v, 2) for k, v in results.items()}}
 
 
 def main():

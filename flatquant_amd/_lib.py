@@ -9,6 +9,10 @@ from __future__ import annotations
 import ctypes
 import os
 
+# torch FIRST: the PyTorch-ROCm wheel bundles its own libamdhip64.so; loading libfqhip.so before it would bind
+# /opt/rocm's copy under the same soname and the two runtimes would disagree about devices and streams.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfqhip.so")
 

@@ -35,6 +35,7 @@ int fail(int code, const char* fmt, ...) {
 }
 
 int cu_count() {
+    (void)hipGetLastError();  // drop any stale error of this thread so the post-launch check is ours
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 256;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
@@ -110,13 +111,13 @@ int fq_kron_quant_f16(const void* x, const void* left, const void* right, const 
                       int M, int N, const float* sig_max, const float* sig_min, int n_clips, int flags,
                       void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
                       void* stream) {
-    if (!x || !left || !right) return fail(FQ_EINVAL, "fq_kron_quant_f16: x/left/right is NULL");
     if (rows < 0 || M <= 0 || N <= 0) return fail(FQ_EINVAL, "fq_kron_quant_f16: bad sizes rows=%lld M=%d N=%d", (long long)rows, M, N);
     if (N & 1) return fail(FQ_EINVAL, "fq_kron_quant_f16: N=%d must be even (two INT4 per byte)", N);
     FqQuantOut o;
     int rc = fill_out("fq_kron_quant_f16", o, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out, y_out);
     if (rc != FQ_OK) return rc;
-    if (rows == 0) return FQ_OK;
+    if (rows == 0) return FQ_OK;  // empty batch: nothing to launch (zero-size tensors have NULL data)
+    if (!x || !left || !right) return fail(FQ_EINVAL, "fq_kron_quant_f16: x/left/right is NULL");
     const int n_cu = cu_count();
     if (M == 64 && N == 64) {
         rc = fq_launch_kron64(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag,

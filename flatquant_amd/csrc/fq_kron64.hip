@@ -19,8 +19,9 @@
 //     once per workgroup; the grid is persistent):
 //       - columns of R are permuted so that, after GEMM 2, lane (h, c) holds for output row m' = c
 //         the 32 CONSECUTIVE columns n' = 32h .. 32h+31 -> one 16-byte store of packed nibbles.
-//   * Prefetch: the next token's 8 KB are loaded into a second register set before the current token's
-//     MFMAs start; 8 waves/CU x 8 KB in flight x 2 = 128 KB per CU of outstanding HBM reads.
+//   * The B-operand fragments of L and R live in LDS in fragment order (16 KB, conflict-free b128 reads),
+//     which keeps the kernel at <= 168 VGPRs -> 3 waves/SIMD = 12 tokens in flight per CU. The next
+//     token's 8 KB are loaded into the X registers as soon as GEMM 1 has consumed them.
 //
 // Algorithmic traffic per token: 8192 B read + 2048 B packed + 2 B scale = 10242 B.
 #include "fq_common.hpp"
@@ -38,19 +39,31 @@ __device__ __forceinline__ int nperm(int nt, int pos) {
     return ((pos >> 2) & 1) * 32 + nt * 16 + (pos & 3) + 4 * (pos >> 3);
 }
 
+// LDS image of the B-operand fragments, built once per workgroup (the grid is persistent):
+//   frag f in [0, 8):  f = nt*4 + s      R[n = 32h + 8s + j][n' = nperm(nt, c)]          (GEMM 1)
+//   frag f in [8,16):  f = 8 + ks*2 + mo L[m = 32(ks>>1) + 16(ks&1) + 8(j>>2) + 4h + (j&3)][m' = 32mo + c]
+// stored as [f][lane] 16-byte records -> conflict-free ds_read_b128, 16 KB.
+// WPS = waves per SIMD the register allocator is asked to fit (3 for the lean output sets, 2 otherwise).
 template <int FLAGS>
-__global__ __launch_bounds__(256, 2) void fq_kron64_kernel(const f16* __restrict__ x,
+constexpr int kron64_wps() {
+    constexpr int outs = ((FLAGS & FQ_OUT_PACKED) ? 1 : 0) + ((FLAGS & FQ_OUT_FAKEQUANT) ? 1 : 0) +
+                         ((FLAGS & FQ_OUT_TRANSFORM) ? 1 : 0);
+    if (FLAGS & FQ_QUANT_F16) return (FLAGS & FQ_OUT_PACKED) ? 2 : (outs <= 2 ? 3 : 2);
+    return (outs == 3 || (FLAGS & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) == (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) ? 2 : 3;
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(256, kron64_wps<FLAGS>()) void fq_kron64_kernel(const f16* __restrict__ x,
                                                            const f16* __restrict__ left,
                                                            const f16* __restrict__ right,
                                                            const f16* __restrict__ diag,
                                                            int64_t rows, FqQuantOut out) {
-    __shared__ __attribute__((aligned(16))) f16 smem[2 * KD];  // [0,KD) = right, [KD,2KD) = left
+    __shared__ __attribute__((aligned(16))) f16 smem[4 * KD];  // [0,2KD) raw right|left, [2KD,4KD) fragments
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int h = lane >> 5;
     const int c = lane & 31;
 
-    // ---- stage the two 64x64 matrices in LDS (coalesced 16-byte loads), gather fragments once ----
     {
         const uint4* gr = reinterpret_cast<const uint4*>(right);
         const uint4* gl = reinterpret_cast<const uint4*>(left);
@@ -62,28 +75,27 @@ __global__ __launch_bounds__(256, 2) void fq_kron64_kernel(const f16* __restrict
         }
     }
     __syncthreads();
-
-    f16x8 Rf[2][4];   // [nt][s]   B operand of GEMM 1: R[n = 32h + 8s + j][n' = nperm(nt, c)]
-    f16x8 Lf[4][2];   // [ks][mt'] B operand of GEMM 2: L[m(ks, h, j)][m' = 32 mt' + c]
+    uint4* frag = reinterpret_cast<uint4*>(smem + 2 * KD);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int np = nperm(nt, c);
+    for (int it = 0; it < 4; ++it) {
+        const int item = tid + it * 256;  // (f, lane') with lane' fastest
+        const int f = item >> 6, ln = item & 63, fh = ln >> 5, fc = ln & 31;
+        f16x8 v;
+        if (f < 8) {
+            const int nt = f >> 2, sk = f & 3, np = nperm(nt, fc);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) Rf[nt][s][j] = smem[(h * 32 + s * 8 + j) * KN + np];
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const int mt = ks >> 1, p = ks & 1;
-#pragma unroll
-        for (int mo = 0; mo < 2; ++mo)
+            for (int j = 0; j < 8; ++j) v[j] = smem[(fh * 32 + sk * 8 + j) * KN + np];
+        } else {
+            const int ks = (f - 8) >> 1, mo = (f - 8) & 1;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int m = mt * 32 + 16 * p + 8 * (j >> 2) + 4 * h + (j & 3);
-                Lf[ks][mo][j] = smem[KD + m * KM + mo * 32 + c];
+                const int m = (ks >> 1) * 32 + 16 * (ks & 1) + 8 * (j >> 2) + 4 * fh + (j & 3);
+                v[j] = smem[KD + m * KM + mo * 32 + fc];
             }
+        }
+        frag[item] = __builtin_bit_cast(uint4, v);
     }
+    __syncthreads();
 
     const int wave = tid >> 6;
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave;
@@ -92,32 +104,22 @@ __global__ __launch_bounds__(256, 2) void fq_kron64_kernel(const f16* __restrict
     // lane's 64 contiguous bytes inside each 32-row half of X: row (mt*32 + c), columns 32h .. 32h+31
     const int lane_off = c * KN + h * 32;
 
-    uint4 Xn[2][4];
+    u32x4 X[2][4];
     int64_t tok = wave_id;
     if (tok < rows) {
-        const uint4* xp = reinterpret_cast<const uint4*>(x + tok * KD + lane_off);
+        const u32x4* xp = reinterpret_cast<const u32x4*>(x + tok * KD + lane_off);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) Xn[mt][s] = xp[mt * (32 * KN / 8) + s];
+            for (int s = 0; s < 4; ++s) X[mt][s] = __builtin_nontemporal_load(xp + mt * (32 * KN / 8) + s);
     }
 
     for (; tok < rows; tok += n_waves) {
-        f16x8 Xc[2][4];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) Xc[mt][s] = __builtin_bit_cast(f16x8, Xn[mt][s]);
-
-        const int64_t nxt = tok + n_waves;
-        if (nxt < rows) {
-            const uint4* xp = reinterpret_cast<const uint4*>(x + nxt * KD + lane_off);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) Xn[mt][s] = xp[mt * (32 * KN / 8) + s];
-        }
-
+        // Launder the lane offset every iteration: otherwise LICM hoists all 16 loop-invariant fragment reads
+        // (64 VGPRs) out of the token loop and the register allocator spills them.
+        int foff = lane;
+        asm volatile("" : "+v"(foff));
+        const uint4* myfrag = frag + foff;
         if (diag != nullptr) {  // x * diag_scale, rounded to fp16 (trans_utils.py:86-90)
             const uint4* dp = reinterpret_cast<const uint4*>(diag + lane_off);
 #pragma unroll
@@ -125,34 +127,57 @@ __global__ __launch_bounds__(256, 2) void fq_kron64_kernel(const f16* __restrict
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     f16x8 dv = __builtin_bit_cast(f16x8, dp[mt * (32 * KN / 8) + s]);
-                    Xc[mt][s] = Xc[mt][s] * dv;
+                    X[mt][s] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8, X[mt][s]) * dv);
                 }
         }
 
-        f32x16 Y[2][2];  // [nt][mt']: Y^T[n' = 32h + 16nt + r][m' = 32mt' + c]
+        // ---- GEMM 1: U[mt][nt] = X(mt,:) . R(:, nt) ----
+        f32x16 U[2][2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            f32x16 U[2];
+            U[0][nt] = f32x16{0};
+            U[1][nt] = f32x16{0};
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                f32x16 acc = {0};
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc = mfma32(Xc[mt][s], Rf[nt][s], acc);
-                U[mt] = acc;
+            for (int s = 0; s < 4; ++s) {
+                const f16x8 b = __builtin_bit_cast(f16x8, myfrag[(nt * 4 + s) * 64]);
+                U[0][nt] = mfma32(__builtin_bit_cast(f16x8, X[0][s]), b, U[0][nt]);
+                U[1][nt] = mfma32(__builtin_bit_cast(f16x8, X[1][s]), b, U[1][nt]);
             }
-            f16x8 Uh[4];
+        }
+
+        // ---- X is dead: prefetch the next token into the same registers ----
+        // (sched_barrier: the scheduler must not hoist these loads above GEMM 1, where X is still live —
+        //  that would need a second 32-VGPR buffer and spill.)
+        __builtin_amdgcn_sched_barrier(0);
+        const int64_t nxt = tok + n_waves;
+        if (nxt < rows) {
+            const u32x4* xp = reinterpret_cast<const u32x4*>(x + nxt * KD + lane_off);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) X[mt][s] = __builtin_nontemporal_load(xp + mt * (32 * KN / 8) + s);
+        }
+
+        // ---- fp16 rounding of U (flat_utils.py:15); C fragment -> A fragment of GEMM 2, no data movement ----
+        f16x8 Uh[2][4];  // [nt][ks]
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) Uh[ks][j] = (f16)U[ks >> 1][(ks & 1) * 8 + j];
+                for (int j = 0; j < 8; ++j) Uh[nt][ks][j] = (f16)U[ks >> 1][nt][(ks & 1) * 8 + j];
+
+        // ---- GEMM 2: Y^T(nt, mo) = U(:, nt)^T . L(:, mo) ----
+        f32x16 Y[2][2];  // [nt][mo]: Y^T[n' = 32h + 16nt + r][m' = 32mo + c]
+        Y[0][0] = f32x16{0}; Y[0][1] = f32x16{0}; Y[1][0] = f32x16{0}; Y[1][1] = f32x16{0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int mo = 0; mo < 2; ++mo) {
-                f32x16 acc = {0};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) acc = mfma32(Uh[ks], Lf[ks][mo], acc);
-                Y[nt][mo] = acc;
+                const f16x8 b = __builtin_bit_cast(f16x8, myfrag[(8 + ks * 2 + mo) * 64]);
+                Y[0][mo] = mfma32(Uh[0][ks], b, Y[0][mo]);
+                Y[1][mo] = mfma32(Uh[1][ks], b, Y[1][mo]);
             }
-        }
 
         if (out.rt_flags & FQ_ROUND_Y_F16) {
 #pragma unroll
@@ -195,45 +220,84 @@ __global__ __launch_bounds__(256, 2) void fq_kron64_kernel(const f16* __restrict
 
             for (int ci = 0; ci < out.n_clips; ++ci) {
                 const float scale = fq_token_scale<FLAGS>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
+                // value of element e (0..7) of dword w (0..3) of output row mo: Y^T[n' = 32h + 8w + e]
+#define FQ_YV(mo, w, e) Y[(w) >> 1][mo][((w) & 1) * 8 + (e)]
                 if (FLAGS & FQ_OUT_PACKED) {
                     if (lane == 0) out.scale[ci][tok] = (f16)scale;
+                    uint32_t pw[2][4];
+                    if (FLAGS & FQ_QUANT_F16) {
 #pragma unroll
-                    for (int mo = 0; mo < 2; ++mo) {
-                        uint4 pk;
-                        uint32_t* pw = reinterpret_cast<uint32_t*>(&pk);
+                        for (int mo = 0; mo < 2; ++mo)
 #pragma unroll
-                        for (int w = 0; w < 4; ++w) {
-                            uint32_t d = 0;
+                            for (int w = 0; w < 4; ++w) {
+                                uint32_t d = 0;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const int q = fq_quant1<FLAGS>(Y[w >> 1][mo][(w & 1) * 8 + e], scale);
-                                d |= (uint32_t)(q & 15) << (4 * e);
+                                for (int e = 0; e < 8; ++e)
+                                    d |= (uint32_t)(fq_quant1<FLAGS>(FQ_YV(mo, w, e), scale) & 15) << (4 * e);
+                                pw[mo][w] = d;
                             }
-                            pw[w] = d;
-                        }
-                        *reinterpret_cast<uint4*>(out.q[ci] + tok * (KD / 2) + (mo * 32 + c) * (KN / 2) +
-                                                  h * 16) = pk;
+                    } else {
+                        const float inv = 1.0f / scale;
+#pragma unroll
+                        for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) {
+                                float dmax = 0.0f;
+                                uint32_t d = fq_pack8(
+                                    fq_qfast(FQ_YV(mo, w, 0), inv, dmax), fq_qfast(FQ_YV(mo, w, 1), inv, dmax),
+                                    fq_qfast(FQ_YV(mo, w, 2), inv, dmax), fq_qfast(FQ_YV(mo, w, 3), inv, dmax),
+                                    fq_qfast(FQ_YV(mo, w, 4), inv, dmax), fq_qfast(FQ_YV(mo, w, 5), inv, dmax),
+                                    fq_qfast(FQ_YV(mo, w, 6), inv, dmax), fq_qfast(FQ_YV(mo, w, 7), inv, dmax));
+                                if (fq_wave_needs_exact(dmax))  // rare (~0.4 % of dwords): a quotient within 4e-6 of a tie
+                                    d = fq_pack8(
+                                        fq_qexact(FQ_YV(mo, w, 0), scale), fq_qexact(FQ_YV(mo, w, 1), scale),
+                                        fq_qexact(FQ_YV(mo, w, 2), scale), fq_qexact(FQ_YV(mo, w, 3), scale),
+                                        fq_qexact(FQ_YV(mo, w, 4), scale), fq_qexact(FQ_YV(mo, w, 5), scale),
+                                        fq_qexact(FQ_YV(mo, w, 6), scale), fq_qexact(FQ_YV(mo, w, 7), scale));
+                                pw[mo][w] = d;
+                            }
                     }
+#pragma unroll
+                    for (int mo = 0; mo < 2; ++mo)
+                        *reinterpret_cast<uint4*>(out.q[ci] + tok * (KD / 2) + (mo * 32 + c) * (KN / 2) +
+                                                  h * 16) = make_uint4(pw[mo][0], pw[mo][1], pw[mo][2], pw[mo][3]);
                 }
                 if (FLAGS & FQ_OUT_FAKEQUANT) {
+                    f16x8 fv[2][4];
+                    if (FLAGS & FQ_QUANT_F16) {
+#pragma unroll
+                        for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+                            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                                for (int e = 0; e < 8; ++e)
+                                    fv[mo][w][e] = fq_dequant1<FLAGS>(fq_quant1<FLAGS>(FQ_YV(mo, w, e), scale), scale);
+                    } else {
+                        const float inv = 1.0f / scale;
+#pragma unroll
+                        for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) {
+                                float dmax = 0.0f;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e)
+                                    fv[mo][w][e] = (f16)(scale * fq_qfast(FQ_YV(mo, w, e), inv, dmax));
+                                if (fq_wave_needs_exact(dmax)) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e)
+                                        fv[mo][w][e] = (f16)(scale * fq_qexact(FQ_YV(mo, w, e), scale));
+                                }
+                            }
+                    }
 #pragma unroll
                     for (int mo = 0; mo < 2; ++mo) {
                         uint4* fp =
                             reinterpret_cast<uint4*>(out.fq[ci] + tok * KD + (mo * 32 + c) * KN + h * 32);
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                            for (int w = 0; w < 2; ++w) {
-                                f16x8 v;
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) {
-                                    const int q = fq_quant1<FLAGS>(Y[nt][mo][w * 8 + e], scale);
-                                    v[e] = fq_dequant1<FLAGS>(q, scale);
-                                }
-                                fp[nt * 2 + w] = __builtin_bit_cast(uint4, v);
-                            }
+                        for (int w = 0; w < 4; ++w) fp[w] = __builtin_bit_cast(uint4, fv[mo][w]);
                     }
                 }
+#undef FQ_YV
             }
         }
     }
@@ -246,7 +310,7 @@ template <int FLAGS>
 static int launch_kron64(const f16* x, const f16* left, const f16* right, const f16* diag, int64_t rows,
                          const FqQuantOut& out, int n_cu, hipStream_t stream) {
     int64_t blocks = (rows + 3) / 4;
-    const int64_t cap = (int64_t)n_cu * 2;
+    const int64_t cap = (int64_t)n_cu * kron64_wps<FLAGS>();
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(fq_kron64_kernel<FLAGS>, dim3((unsigned)blocks), dim3(256), 0, stream, x, left,

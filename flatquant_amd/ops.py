@@ -100,6 +100,8 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
     rows = x.numel() // d
     smax, smin, n = _sig_arrays(sigs)
     o = _alloc_outputs(x, rows, d, n, flags, x.shape[:-1] + (d // 2,), x.shape)
+    if rows == 0:
+        return o
     with torch.cuda.device(x.device):
         check(lib.fq_kron_quant_f16(_ptr(x), _ptr(left), _ptr(right), _ptr(diag), rows, M, N, smax, smin, n,
                                     flags, _ptr_array(o.q), _ptr_array(o.scale), _ptr_array(o.fq), _ptr(o.y),
@@ -119,6 +121,8 @@ def block_quant(x: torch.Tensor, P: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1
     smax, smin, n = _sig_arrays(sigs)
     yshape = x.shape[:-2] + ((C, R) if transpose_out else (R, C))
     o = _alloc_outputs(x, rows, d, n, flags, x.shape[:-2] + (d // 2,), yshape)
+    if rows == 0:
+        return o
     with torch.cuda.device(x.device):
         check(lib.fq_block_quant_f16(_ptr(x), _ptr(P), rows, R, C, int(transpose_out), smax, smin, n, flags,
                                      _ptr_array(o.q), _ptr_array(o.scale), _ptr_array(o.fq), _ptr(o.y),
@@ -133,6 +137,8 @@ def rowquant(x: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),), flags: int = 
     rows = x.numel() // cols
     smax, smin, n = _sig_arrays(sigs)
     o = _alloc_outputs(x, rows, cols, n, flags, x.shape[:-1] + (cols // 2,), x.shape)
+    if rows == 0:
+        return o
     with torch.cuda.device(x.device):
         check(lib.fq_rowquant_f16(_ptr(x), rows, cols, smax, smin, n, flags, _ptr_array(o.q),
                                   _ptr_array(o.scale), _ptr_array(o.fq), _stream(x)))
@@ -154,6 +160,8 @@ def hadamard(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None,
         scale = float(1.0 / torch.tensor(n).sqrt())  # fp32 value, as hadamard_utils.py:135
     rows = x.numel() // n
     y = torch.empty_like(x)
+    if rows == 0:
+        return y
     with torch.cuda.device(x.device):
         check(lib.fq_hadamard_f16(_ptr(x), _ptr(y), rows, n, K, _ptr(hadK), ctypes.c_float(scale), _stream(x)))
     return y
@@ -168,6 +176,8 @@ def sym_quant(x: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
     if scale.numel() != rows:
         raise RuntimeError(f"sym_quant: expected scale to have {rows} elements, got {scale.numel()}")
     q = torch.empty((rows, (cols + 1) // 2), dtype=torch.uint8, device=x.device)
+    if rows == 0:
+        return q
     with torch.cuda.device(x.device):
         check(lib.fq_sym_quant_f16(_ptr(x), _ptr(scale), rows, cols, _ptr(q), _stream(x)))
     return q
@@ -182,6 +192,8 @@ def sym_dequant(q: torch.Tensor, scale_row: torch.Tensor, scale_col: torch.Tenso
     if scale_row.numel() != rows or scale_col.numel() != cols:
         raise RuntimeError("sym_dequant: scale sizes do not match q")
     x = torch.empty((rows, cols), dtype=torch.float16, device=q.device)
+    if rows == 0:
+        return x
     with torch.cuda.device(q.device):
         check(lib.fq_sym_dequant_i32_f16(_ptr(q), _ptr(scale_row), _ptr(scale_col), rows, cols, _ptr(x),
                                          _stream(q)))
