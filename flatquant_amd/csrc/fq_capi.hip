@@ -21,6 +21,8 @@ int fq_launch_sym_quant(const f16* x, const f16* scale, int64_t rows, int cols, 
                         hipStream_t stream);
 int fq_launch_sym_dequant(const int32_t* q, const f16* srow, const f16* scol, int64_t rows, int cols,
                           f16* x, int n_cu, hipStream_t stream);
+int fq_launch_probe_stream(const void* x, int64_t rows, void* q, void* s, int n_cu, int waves_per_simd,
+                           hipStream_t stream);
 
 namespace {
 
@@ -197,6 +199,13 @@ int fq_probe_mfma_32x32x16_f16(const void* A, const void* B, const void* C, void
     hipLaunchKernelGGL(fq_probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const f16*)A,
                        (const f16*)B, (const float*)C, (float*)D);
     return check_launch((int)hipGetLastError(), "fq_probe_mfma");
+}
+
+int fq_probe_stream_4096(const void* x, int64_t rows, void* q, void* s, int waves_per_simd, void* stream) {
+    if (!x || !q || !s) return fail(FQ_EINVAL, "fq_probe_stream_4096: NULL pointer");
+    if (rows <= 0 || waves_per_simd < 1 || waves_per_simd > 8) return fail(FQ_EINVAL, "fq_probe_stream_4096: bad sizes");
+    return check_launch(fq_launch_probe_stream(x, rows, q, s, cu_count(), waves_per_simd, (hipStream_t)stream),
+                        "fq_probe_stream_4096");
 }
 
 }  // extern "C"

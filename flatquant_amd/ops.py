@@ -207,3 +207,11 @@ def probe_mfma(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor) -> torch.Tenso
     with torch.cuda.device(A.device):
         check(lib.fq_probe_mfma_32x32x16_f16(_ptr(A), _ptr(B), _ptr(C), _ptr(D), _stream(A)))
     return D
+
+
+def probe_stream_4096(x: torch.Tensor, q: torch.Tensor, s: torch.Tensor, waves_per_simd: int = 4) -> None:
+    """HBM-floor probe: move the bytes of the d=4096 fused kernel with no arithmetic (measurement aid)."""
+    _chk(x, "x"), _chk(q, "q", torch.uint8), _chk(s, "s")
+    rows = x.numel() // 4096
+    with torch.cuda.device(x.device):
+        check(lib.fq_probe_stream_4096(_ptr(x), rows, _ptr(q), _ptr(s), waves_per_simd, _stream(x)))

@@ -43,6 +43,10 @@ def main():
         "rowquant fakequant": lambda i: ops.rowquant(xs[i % NB], sig, FQ_OUT_FAKEQUANT),
         "torch copy 128MiB": lambda i: ys[i % NB].copy_(xs[(i + 1) % NB]),
     }
+    qb = torch.empty(ROWS, D // 2, dtype=torch.uint8, device="cuda")
+    sb = torch.empty(ROWS, dtype=torch.float16, device="cuda")
+    for w in (2, 3, 4, 8):
+        cases[f"stream probe 8K in/2K out, {w} waves/SIMD"] = (lambda i, w=w: ops.probe_stream_4096(xs[i % NB], qb, sb, w))
     for name, fn in cases.items():
         us = timeit(fn)
         print(f"{name:34s} {us:9.1f} us   {ROWS * D / us:12.0f} Melem/s")
