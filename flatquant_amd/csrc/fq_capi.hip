@@ -21,6 +21,8 @@ int fq_launch_sym_quant(const f16* x, const f16* scale, int64_t rows, int cols, 
                         hipStream_t stream);
 int fq_launch_sym_dequant(const int32_t* q, const f16* srow, const f16* scol, int64_t rows, int cols,
                           f16* x, int n_cu, hipStream_t stream);
+int fq_launch_kron64_trace(const f16* x, const f16* left, const f16* right, int64_t rows, const FqQuantOut& out,
+                           unsigned long long* trace, int n_cu, hipStream_t stream);
 int fq_launch_probe_stream(const void* x, int64_t rows, void* q, void* s, int n_cu, int waves_per_simd,
                            hipStream_t stream);
 
@@ -206,6 +208,17 @@ int fq_probe_stream_4096(const void* x, int64_t rows, void* q, void* s, int wave
     if (rows <= 0 || waves_per_simd < 1 || waves_per_simd > 8) return fail(FQ_EINVAL, "fq_probe_stream_4096: bad sizes");
     return check_launch(fq_launch_probe_stream(x, rows, q, s, cu_count(), waves_per_simd, (hipStream_t)stream),
                         "fq_probe_stream_4096");
+}
+
+/* debug only (not declared in fqhip.h): per-phase cycle accounting of the d=4096 packed kernel */
+int fq_debug_kron64_trace(const void* x, const void* left, const void* right, int64_t rows, void* q, void* scale,
+                          void* trace, void* stream) {
+    FqQuantOut o;
+    memset(&o, 0, sizeof(o));
+    o.n_clips = 1; o.sig_max[0] = 1.0f; o.sig_min[0] = 1.0f; o.q[0] = (uint8_t*)q; o.scale[0] = (f16*)scale;
+    return check_launch(fq_launch_kron64_trace((const f16*)x, (const f16*)left, (const f16*)right, rows, o,
+                                               (unsigned long long*)trace, cu_count(), (hipStream_t)stream),
+                        "fq_debug_kron64_trace");
 }
 
 }  // extern "C"

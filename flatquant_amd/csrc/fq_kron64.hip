@@ -52,12 +52,24 @@ constexpr int kron64_wps() {
     return (outs == 3 || (FLAGS & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) == (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) ? 2 : 3;
 }
 
-template <int FLAGS>
+// TRACE (debug builds of the same kernel, fq_debug_kron64_trace): lane 0 of every wave accumulates s_memtime
+// deltas of the four phases of the token loop into trace[wave*4 .. +3].
+#define FQ_TICK(var)                               \
+    unsigned long long var = 0;                    \
+    if (TRACE) {                                   \
+        __builtin_amdgcn_sched_barrier(0);         \
+        var = __builtin_amdgcn_s_memtime();        \
+        __builtin_amdgcn_sched_barrier(0);         \
+    }
+
+template <int FLAGS, bool TRACE = false>
 __global__ __launch_bounds__(256, kron64_wps<FLAGS>()) void fq_kron64_kernel(const f16* __restrict__ x,
                                                            const f16* __restrict__ left,
                                                            const f16* __restrict__ right,
                                                            const f16* __restrict__ diag,
-                                                           int64_t rows, FqQuantOut out) {
+                                                           int64_t rows, FqQuantOut out,
+                                                           unsigned long long* __restrict__ trace) {
+    unsigned long long tr_wait = 0, tr_g1 = 0, tr_g2 = 0, tr_epi = 0;
     __shared__ __attribute__((aligned(16))) f16 smem[4 * KD];  // [0,2KD) raw right|left, [2KD,4KD) fragments
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -120,6 +132,9 @@ __global__ __launch_bounds__(256, kron64_wps<FLAGS>()) void fq_kron64_kernel(con
         int foff = lane;
         asm volatile("" : "+v"(foff));
         const uint4* myfrag = frag + foff;
+        FQ_TICK(c0)
+        if (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FQ_TICK(c1)
         if (diag != nullptr) {  // x * diag_scale, rounded to fp16 (trans_utils.py:86-90)
             const uint4* dp = reinterpret_cast<const uint4*>(diag + lane_off);
 #pragma unroll
@@ -167,6 +182,7 @@ __global__ __launch_bounds__(256, kron64_wps<FLAGS>()) void fq_kron64_kernel(con
 #pragma unroll
                 for (int j = 0; j < 8; ++j) Uh[nt][ks][j] = (f16)U[ks >> 1][nt][(ks & 1) * 8 + j];
 
+        FQ_TICK(c2)
         // ---- GEMM 2: Y^T(nt, mo) = U(:, nt)^T . L(:, mo) ----
         f32x16 Y[2][2];  // [nt][mo]: Y^T[n' = 32h + 16nt + r][m' = 32mo + c]
         Y[0][0] = f32x16{0}; Y[0][1] = f32x16{0}; Y[1][0] = f32x16{0}; Y[1][1] = f32x16{0};
@@ -217,6 +233,7 @@ __global__ __launch_bounds__(256, kron64_wps<FLAGS>()) void fq_kron64_kernel(con
                     }
             vmax = fq_wave_max(vmax);
             vmin = fq_wave_min(vmin);
+            FQ_TICK(c3)
 
             for (int ci = 0; ci < out.n_clips; ++ci) {
                 const float scale = fq_token_scale<FLAGS>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
@@ -299,7 +316,20 @@ __global__ __launch_bounds__(256, kron64_wps<FLAGS>()) void fq_kron64_kernel(con
                 }
 #undef FQ_YV
             }
+            FQ_TICK(c4)
+            if (TRACE) {
+                tr_wait += c1 - c0;
+                tr_g1 += c2 - c1;
+                tr_g2 += c3 - c2;
+                tr_epi += c4 - c3;
+            }
         }
+    }
+    if (TRACE && lane == 0) {
+        trace[wave_id * 4 + 0] = tr_wait;
+        trace[wave_id * 4 + 1] = tr_g1;
+        trace[wave_id * 4 + 2] = tr_g2;
+        trace[wave_id * 4 + 3] = tr_epi;
     }
 }
 
@@ -313,8 +343,8 @@ static int launch_kron64(const f16* x, const f16* left, const f16* right, const 
     const int64_t cap = (int64_t)n_cu * kron64_wps<FLAGS>();
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(fq_kron64_kernel<FLAGS>, dim3((unsigned)blocks), dim3(256), 0, stream, x, left,
-                       right, diag, rows, out);
+    hipLaunchKernelGGL((fq_kron64_kernel<FLAGS, false>), dim3((unsigned)blocks), dim3(256), 0, stream, x, left,
+                       right, diag, rows, out, (unsigned long long*)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -340,4 +370,16 @@ int fq_launch_kron64(int flags, const f16* x, const f16* left, const f16* right,
             return -1000;
     }
 #undef FQ_CASE
+}
+
+// Debug: the packed kernel with per-phase s_memtime accounting (see FQ_TICK). trace: [n_waves, 4] u64,
+// n_waves = 4 * min(ceil(rows/4), 3 * n_cu).
+int fq_launch_kron64_trace(const f16* x, const f16* left, const f16* right, int64_t rows, const FqQuantOut& out,
+                           unsigned long long* trace, int n_cu, hipStream_t stream) {
+    int64_t blocks = (rows + 3) / 4;
+    const int64_t cap = (int64_t)n_cu * 3;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((fq_kron64_kernel<FQ_OUT_PACKED, true>), dim3((unsigned)blocks), dim3(256), 0, stream, x, left,
+                       right, (const f16*)nullptr, rows, out, trace);
+    return (int)hipGetLastError();
 }
