@@ -34,16 +34,35 @@ struct FqQuantOut {
 // Flags that select a compile-time kernel specialisation; the rest travel in FqQuantOut::rt_flags.
 constexpr int FQ_CT_MASK = FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_QUANT_F16;
 
-__device__ __forceinline__ float fq_wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+// Wave64 all-reduce in registers: four DPP steps inside each 16-lane row, then v_permlane16_swap and
+// v_permlane32_swap (gfx950) across rows. ~6 VALU-latency steps instead of six ds_bpermute round trips
+// through the LDS crossbar. Every lane ends up with the result.
+template <int CTRL>
+__device__ __forceinline__ float fq_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+struct FqMaxOp { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+struct FqMinOp { __device__ __forceinline__ float operator()(float a, float b) const { return fminf(a, b); } };
+template <class Op>
+__device__ __forceinline__ float fq_wave_reduce(float v, Op op) {
+    v = op(v, fq_dpp<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = op(v, fq_dpp<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = op(v, fq_dpp<0x141>(v));  // row_half_mirror: the other quad of each 8
+    v = op(v, fq_dpp<0x140>(v));  // row_mirror: the other half of each row
+    {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = op(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    }
+    {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v = op(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    }
     return v;
 }
-__device__ __forceinline__ float fq_wave_min(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-    return v;
-}
+__device__ __forceinline__ float fq_wave_max(float v) { return fq_wave_reduce(v, FqMaxOp()); }
+__device__ __forceinline__ float fq_wave_min(float v) { return fq_wave_reduce(v, FqMinOp()); }
 
 // scale from (xmax, xmin) of one token and one clip set; see header comment for the pinned arithmetic.
 template <int FLAGS>

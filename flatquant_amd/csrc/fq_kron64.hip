@@ -70,11 +70,30 @@ __global__ __launch_bounds__(256, kron64_wps<FLAGS>()) void fq_kron64_kernel(con
                                                            int64_t rows, FqQuantOut out,
                                                            unsigned long long* __restrict__ trace) {
     unsigned long long tr_wait = 0, tr_g1 = 0, tr_g2 = 0, tr_epi = 0;
+    const unsigned long long tr_start = TRACE ? __builtin_amdgcn_s_memtime() : 0;
     __shared__ __attribute__((aligned(16))) f16 smem[4 * KD];  // [0,2KD) raw right|left, [2KD,4KD) fragments
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int h = lane >> 5;
     const int c = lane & 31;
+
+    const int wave = tid >> 6;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+
+    // lane's 64 contiguous bytes inside each 32-row half of X: row (mt*32 + c), columns 32h .. 32h+31
+    const int lane_off = c * KN + h * 32;
+
+    // First token's HBM load goes out BEFORE the fragment staging below, so its latency hides behind it.
+    u32x4 X[2][4];
+    int64_t tok = wave_id;
+    if (tok < rows) {
+        const u32x4* xp = reinterpret_cast<const u32x4*>(x + tok * KD + lane_off);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) X[mt][s] = __builtin_nontemporal_load(xp + mt * (32 * KN / 8) + s);
+    }
 
     {
         const uint4* gr = reinterpret_cast<const uint4*>(right);
@@ -108,23 +127,6 @@ __global__ __launch_bounds__(256, kron64_wps<FLAGS>()) void fq_kron64_kernel(con
         frag[item] = __builtin_bit_cast(uint4, v);
     }
     __syncthreads();
-
-    const int wave = tid >> 6;
-    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t n_waves = (int64_t)gridDim.x * 4;
-
-    // lane's 64 contiguous bytes inside each 32-row half of X: row (mt*32 + c), columns 32h .. 32h+31
-    const int lane_off = c * KN + h * 32;
-
-    u32x4 X[2][4];
-    int64_t tok = wave_id;
-    if (tok < rows) {
-        const u32x4* xp = reinterpret_cast<const u32x4*>(x + tok * KD + lane_off);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) X[mt][s] = __builtin_nontemporal_load(xp + mt * (32 * KN / 8) + s);
-    }
 
     for (; tok < rows; tok += n_waves) {
         // Launder the lane offset every iteration: otherwise LICM hoists all 16 loop-invariant fragment reads
@@ -221,16 +223,22 @@ __global__ __launch_bounds__(256, kron64_wps<FLAGS>()) void fq_kron64_kernel(con
         }
 
         if (FLAGS & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) {
-            float vmax = Y[0][0][0], vmin = Y[0][0][0];
+            // four independent partial chains each (v_max3/v_min3), then a wave all-reduce
+            float pmax[4], pmin[4];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int k = 0; k < 4; ++k) {
+                const f32x16& t = Y[k >> 1][k & 1];
+                float a = fmaxf(t[0], t[1]), b = fminf(t[0], t[1]);
 #pragma unroll
-                for (int mo = 0; mo < 2; ++mo)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        vmax = fmaxf(vmax, Y[nt][mo][r]);
-                        vmin = fminf(vmin, Y[nt][mo][r]);
-                    }
+                for (int r = 2; r < 16; r += 2) {
+                    a = fmaxf(fmaxf(a, t[r]), t[r + 1]);
+                    b = fminf(fminf(b, t[r]), t[r + 1]);
+                }
+                pmax[k] = a;
+                pmin[k] = b;
+            }
+            float vmax = fmaxf(fmaxf(pmax[0], pmax[1]), fmaxf(pmax[2], pmax[3]));
+            float vmin = fminf(fminf(pmin[0], pmin[1]), fminf(pmin[2], pmin[3]));
             vmax = fq_wave_max(vmax);
             vmin = fq_wave_min(vmin);
             FQ_TICK(c3)
@@ -255,24 +263,31 @@ __global__ __launch_bounds__(256, kron64_wps<FLAGS>()) void fq_kron64_kernel(con
                             }
                     } else {
                         const float inv = 1.0f / scale;
+                        unsigned near = 0;  // bit (4*mo + w): some lane's dword has a quotient within FQ_NEAR of a tie
 #pragma unroll
                         for (int mo = 0; mo < 2; ++mo)
 #pragma unroll
                             for (int w = 0; w < 4; ++w) {
                                 float dmax = 0.0f;
-                                uint32_t d = fq_pack8(
+                                pw[mo][w] = fq_pack8(
                                     fq_qfast(FQ_YV(mo, w, 0), inv, dmax), fq_qfast(FQ_YV(mo, w, 1), inv, dmax),
                                     fq_qfast(FQ_YV(mo, w, 2), inv, dmax), fq_qfast(FQ_YV(mo, w, 3), inv, dmax),
                                     fq_qfast(FQ_YV(mo, w, 4), inv, dmax), fq_qfast(FQ_YV(mo, w, 5), inv, dmax),
                                     fq_qfast(FQ_YV(mo, w, 6), inv, dmax), fq_qfast(FQ_YV(mo, w, 7), inv, dmax));
-                                if (fq_wave_needs_exact(dmax))  // rare (~0.4 % of dwords): a quotient within 4e-6 of a tie
-                                    d = fq_pack8(
-                                        fq_qexact(FQ_YV(mo, w, 0), scale), fq_qexact(FQ_YV(mo, w, 1), scale),
-                                        fq_qexact(FQ_YV(mo, w, 2), scale), fq_qexact(FQ_YV(mo, w, 3), scale),
-                                        fq_qexact(FQ_YV(mo, w, 4), scale), fq_qexact(FQ_YV(mo, w, 5), scale),
-                                        fq_qexact(FQ_YV(mo, w, 6), scale), fq_qexact(FQ_YV(mo, w, 7), scale));
-                                pw[mo][w] = d;
+                                near |= fq_wave_needs_exact(dmax) ? (1u << (4 * mo + w)) : 0u;   // SALU only
                             }
+                        if (near) {  // rare (~3 % of tokens): redo the flagged dwords with the true division
+#pragma unroll
+                            for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+                                for (int w = 0; w < 4; ++w)
+                                    if (near & (1u << (4 * mo + w)))
+                                        pw[mo][w] = fq_pack8(
+                                            fq_qexact(FQ_YV(mo, w, 0), scale), fq_qexact(FQ_YV(mo, w, 1), scale),
+                                            fq_qexact(FQ_YV(mo, w, 2), scale), fq_qexact(FQ_YV(mo, w, 3), scale),
+                                            fq_qexact(FQ_YV(mo, w, 4), scale), fq_qexact(FQ_YV(mo, w, 5), scale),
+                                            fq_qexact(FQ_YV(mo, w, 6), scale), fq_qexact(FQ_YV(mo, w, 7), scale));
+                        }
                     }
 #pragma unroll
                     for (int mo = 0; mo < 2; ++mo)
@@ -326,6 +341,8 @@ __global__ __launch_bounds__(256, kron64_wps<FLAGS>()) void fq_kron64_kernel(con
         }
     }
     if (TRACE && lane == 0) {
+        trace[n_waves * 4 + wave_id * 2 + 0] = tr_start;                       // absolute start / end stamps
+        trace[n_waves * 4 + wave_id * 2 + 1] = __builtin_amdgcn_s_memtime();
         trace[wave_id * 4 + 0] = tr_wait;
         trace[wave_id * 4 + 1] = tr_g1;
         trace[wave_id * 4 + 2] = tr_g2;
