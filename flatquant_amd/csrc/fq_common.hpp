@@ -49,15 +49,19 @@ __device__ __forceinline__ float fq_wave_reduce(float v, Op op) {
     v = op(v, fq_dpp<0x4E>(v));   // quad_perm [2,3,0,1]
     v = op(v, fq_dpp<0x141>(v));  // row_half_mirror: the other quad of each 8
     v = op(v, fq_dpp<0x140>(v));  // row_mirror: the other half of each row
+    // v_permlane16_swap: odd rows of the first register <-> even rows of the second; v_permlane32_swap: upper
+    // half of the first <-> lower half of the second. Written as inline asm on two explicit registers: with
+    // the builtin hipcc (ROCm 7.2) folds the two results into one when both inputs hold the same value.
+    // "s_nop 1" = the 2 wait states a VALU write needs before v_permlane*_swap reads it.
     {
-        const unsigned u = __builtin_bit_cast(unsigned, v);
-        auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-        v = op(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+        float a = v, b = v;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        v = op(a, b);
     }
     {
-        const unsigned u = __builtin_bit_cast(unsigned, v);
-        auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-        v = op(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+        float a = v, b = v;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        v = op(a, b);
     }
     return v;
 }

@@ -4,10 +4,14 @@
 // non-split branch) and the flat_utils.py:6-17 + quant_utils.py:71-119 op sequence.
 //
 // Design (gfx950, wave64):
-//   * ONE WAVE OWNS ONE TOKEN. A token is a 64x64 fp16 matrix X (8 KB). Nothing about a token ever
-//     touches LDS: X is loaded from HBM straight into MFMA A-operand fragments (64 contiguous bytes per
-//     lane), both small GEMMs run on v_mfma_f32_32x32x16_f16, and the fp32 result is quantised and
-//     packed in registers, then stored with 16-byte coalesced stores.
+//   * ONE WAVE OWNS ONE TOKEN (a 64x64 fp16 matrix X, 8 KB); a persistent 16-wave workgroup per CU walks
+//     the tokens, 16 tokens in flight per CU.
+//   * HBM -> LDS by LDS-DMA (global_load_lds_dwordx4), FULL 128-byte lines: each DMA instruction moves
+//     8 whole rows of X (1 KB) — the streaming pattern that reaches ~6 TB/s on this chip. (Loading the
+//     MFMA fragments straight from global touches 64 different half-lines per instruction: measured 2x
+//     slower, address-processing bound.) The LDS image is lane-linear, so the bank-conflict swizzle is
+//     applied to the per-lane SOURCE address (chunk ^= (row>>1)&7 inside a row: same cache line) and
+//     mirrored on the ds_read_b128 side -> conflict-free fragment reads.
 //   * GEMM 1:  U = X . R          (contraction over n, the contiguous axis of X)      32x32x16, K = n
 //     GEMM 2:  Y^T = U^T . L      (contraction over m)                               32x32x16, K = m
 //     The C/D fragment of GEMM 1 (lane holds one column n', 16 rows m) is, after fp16 conversion,
@@ -15,13 +19,13 @@
 //     contraction index inside an MFMA is free as long as A and B agree. So the intermediate never
 //     leaves registers and needs no cross-lane traffic. The fp16 rounding of U is the rounding
 //     flat_utils.py:15 performs (torch.matmul output dtype) — path-A arithmetic.
-//   * The permutations are absorbed into the one-time gather of the L and R fragments (LDS-staged,
-//     once per workgroup; the grid is persistent):
-//       - columns of R are permuted so that, after GEMM 2, lane (h, c) holds for output row m' = c
-//         the 32 CONSECUTIVE columns n' = 32h .. 32h+31 -> one 16-byte store of packed nibbles.
-//   * The B-operand fragments of L and R live in LDS in fragment order (16 KB, conflict-free b128 reads),
-//     which keeps the kernel at <= 168 VGPRs -> 3 waves/SIMD = 12 tokens in flight per CU. The next
-//     token's 8 KB are loaded into the X registers as soon as GEMM 1 has consumed them.
+//   * The permutations are absorbed into the one-time gather of the L and R B-operand fragments (LDS,
+//     fragment order, 16 KB per workgroup, conflict-free b128 reads): columns of R are permuted so that,
+//     after GEMM 2, lane (h, c) holds for output row m' = c the 32 CONSECUTIVE columns n' = 32h..32h+31
+//     -> one 16-byte store of packed nibbles per output row.
+//   * The token's single LDS buffer is refilled (next token) as soon as its fragments are in registers,
+//     i.e. almost a full iteration ahead of use; X occupies VGPRs only during GEMM 1, which keeps the
+//     lean variants under 128 VGPRs -> 4 waves/SIMD.
 //
 // Algorithmic traffic per token: 8192 B read + 2048 B packed + 2 B scale = 10242 B.
 #include "fq_common.hpp"
@@ -29,6 +33,8 @@
 namespace {
 
 constexpr int KM = 64, KN = 64, KD = KM * KN;
+constexpr int FRAG_BYTES = 16 * 64 * 16;  // 16 fragments x 64 lanes x 16 B
+constexpr int TOK_BYTES = KD * 2;         // 8192
 
 __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -39,20 +45,20 @@ __device__ __forceinline__ int nperm(int nt, int pos) {
     return ((pos >> 2) & 1) * 32 + nt * 16 + (pos & 3) + 4 * (pos >> 3);
 }
 
-// LDS image of the B-operand fragments, built once per workgroup (the grid is persistent):
+// LDS image of the B-operand fragments, built once per workgroup:
 //   frag f in [0, 8):  f = nt*4 + s      R[n = 32h + 8s + j][n' = nperm(nt, c)]          (GEMM 1)
 //   frag f in [8,16):  f = 8 + ks*2 + mo L[m = 32(ks>>1) + 16(ks&1) + 8(j>>2) + 4h + (j&3)][m' = 32mo + c]
-// stored as [f][lane] 16-byte records -> conflict-free ds_read_b128, 16 KB.
-// WPS = waves per SIMD the register allocator is asked to fit (3 for the lean output sets, 2 otherwise).
+// stored as [f][lane] 16-byte records.
+//
+// Workgroup size: 1024 threads (4 waves/SIMD, <= 128 VGPRs) for the lean output sets, 512 otherwise.
 template <int FLAGS>
-constexpr int kron64_wps() {
+constexpr int kron64_threads() {
     constexpr int outs = ((FLAGS & FQ_OUT_PACKED) ? 1 : 0) + ((FLAGS & FQ_OUT_FAKEQUANT) ? 1 : 0) +
                          ((FLAGS & FQ_OUT_TRANSFORM) ? 1 : 0);
-    if (FLAGS & FQ_QUANT_F16) return (FLAGS & FQ_OUT_PACKED) ? 2 : (outs <= 2 ? 3 : 2);
-    return (outs == 3 || (FLAGS & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) == (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) ? 2 : 3;
+    return (outs == 1 && !(FLAGS & FQ_QUANT_F16)) ? 1024 : 512;
 }
 
-// TRACE (debug builds of the same kernel, fq_debug_kron64_trace): lane 0 of every wave accumulates s_memtime
+// TRACE (debug build of the same kernel, fq_debug_kron64_trace): lane 0 of every wave accumulates s_memtime
 // deltas of the four phases of the token loop into trace[wave*4 .. +3].
 #define FQ_TICK(var)                               \
     unsigned long long var = 0;                    \
@@ -62,71 +68,91 @@ constexpr int kron64_wps() {
         __builtin_amdgcn_sched_barrier(0);         \
     }
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+// LDS-DMA of one token into the wave's 8 KB buffer: instruction i moves rows 8i..8i+7 (1 KB contiguous in
+// HBM); lane l supplies row 8i + (l>>3), 16-byte chunk (l&7) ^ ((row>>1)&7) and lands in slot 64 i + l.
+// Inline asm on purpose: through the builtin hipcc treats the DMA as a store to the shared array and puts
+// s_waitcnt vmcnt(0) in front of the next ds_read of ANY part of it (the fragment image), i.e. it waits for
+// the prefetch right after issuing it. The asm form is invisible to its counters; completion is waited for by
+// the COUNTED s_waitcnt at the top of the token loop. M0 (LDS base of the DMA) is saved/restored because the
+// compiler owns it.
+__device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok, unsigned lds_base, int lane) {
+    const unsigned char* g = reinterpret_cast<const unsigned char*>(x) + tok * TOK_BYTES + (lane >> 3) * 128;
+    const int l7 = lane & 7, sw0 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int chunk = l7 ^ ((i * 4 + sw0) & 7);
+        const unsigned char* src = g + i * 1024 + chunk * 16;
+        const unsigned dst = lds_base + i * 1024;
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(src), "s"(dst)
+            : "memory");
+    }
+}
+
 template <int FLAGS, bool TRACE = false>
-__global__ __launch_bounds__(256, kron64_wps<FLAGS>()) void fq_kron64_kernel(const f16* __restrict__ x,
+__global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(const f16* __restrict__ x,
                                                            const f16* __restrict__ left,
                                                            const f16* __restrict__ right,
                                                            const f16* __restrict__ diag,
                                                            int64_t rows, FqQuantOut out,
                                                            unsigned long long* __restrict__ trace) {
+    constexpr int THREADS = kron64_threads<FLAGS>();
+    constexpr int WAVES = THREADS / 64;
+    // output stores a single-clip packed token issues after its DMA (2 x 16 B + the scale): lets the top-of-loop
+    // wait be a COUNTED vmcnt that does not also wait for the previous token's stores to reach memory.
+    constexpr bool COUNTED_WAIT = (FLAGS & FQ_CT_MASK) == FQ_OUT_PACKED;
     unsigned long long tr_wait = 0, tr_g1 = 0, tr_g2 = 0, tr_epi = 0;
     const unsigned long long tr_start = TRACE ? __builtin_amdgcn_s_memtime() : 0;
-    __shared__ __attribute__((aligned(16))) f16 smem[4 * KD];  // [0,2KD) raw right|left, [2KD,4KD) fragments
+    __shared__ __attribute__((aligned(16))) unsigned char smem[FRAG_BYTES + WAVES * TOK_BYTES];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int h = lane >> 5;
     const int c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t wave_id = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t n_waves = (int64_t)gridDim.x * WAVES;
+    unsigned char* tokbuf = smem + FRAG_BYTES + wave * TOK_BYTES;  // wave-private, wave-uniform address
+    const unsigned tok_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)tokbuf);
 
-    const int wave = tid >> 6;
-    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t n_waves = (int64_t)gridDim.x * 4;
-
-    // lane's 64 contiguous bytes inside each 32-row half of X: row (mt*32 + c), columns 32h .. 32h+31
-    const int lane_off = c * KN + h * 32;
-
-    // First token's HBM load goes out BEFORE the fragment staging below, so its latency hides behind it.
-    u32x4 X[2][4];
+    // First token's HBM->LDS DMA goes out BEFORE the fragment gather below, so its latency hides behind it.
     int64_t tok = wave_id;
-    if (tok < rows) {
-        const u32x4* xp = reinterpret_cast<const u32x4*>(x + tok * KD + lane_off);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) X[mt][s] = __builtin_nontemporal_load(xp + mt * (32 * KN / 8) + s);
-    }
+    if (tok < rows) dma_token(x, tok, tok_lds, lane);
 
-    {
-        const uint4* gr = reinterpret_cast<const uint4*>(right);
-        const uint4* gl = reinterpret_cast<const uint4*>(left);
-        uint4* s4 = reinterpret_cast<uint4*>(smem);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            s4[tid + i * 256] = gr[tid + i * 256];
-            s4[512 + tid + i * 256] = gl[tid + i * 256];
-        }
-    }
-    __syncthreads();
-    uint4* frag = reinterpret_cast<uint4*>(smem + 2 * KD);
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int item = tid + it * 256;  // (f, lane') with lane' fastest
+    // ---- B-operand fragments of R and L: gathered straight from global (L2-resident 2 x 8 KB), once ----
+    uint4* frag = reinterpret_cast<uint4*>(smem);
+    for (int item = tid; item < 16 * 64; item += THREADS) {  // (f, lane') with lane' fastest
         const int f = item >> 6, ln = item & 63, fh = ln >> 5, fc = ln & 31;
         f16x8 v;
         if (f < 8) {
             const int nt = f >> 2, sk = f & 3, np = nperm(nt, fc);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = smem[(fh * 32 + sk * 8 + j) * KN + np];
+            for (int j = 0; j < 8; ++j) v[j] = right[(fh * 32 + sk * 8 + j) * KN + np];
         } else {
             const int ks = (f - 8) >> 1, mo = (f - 8) & 1;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int m = (ks >> 1) * 32 + 16 * (ks & 1) + 8 * (j >> 2) + 4 * fh + (j & 3);
-                v[j] = smem[KD + m * KM + mo * 32 + fc];
+                v[j] = left[m * KM + mo * 32 + fc];
             }
         }
         frag[item] = __builtin_bit_cast(uint4, v);
     }
     __syncthreads();
+
+    // fragment-read address of this lane inside the token buffer: row (32 mt + c), chunk (4h + s) ^ ((c>>1)&7)
+    const int sw = (c >> 1) & 7;
+    const int lane_off = c * KN + h * 32;  // same element offset in HBM (used by diag and by the outputs)
+    bool first = true;
 
     for (; tok < rows; tok += n_waves) {
         // Launder the lane offset every iteration: otherwise LICM hoists all 16 loop-invariant fragment reads
@@ -135,8 +161,31 @@ __global__ __launch_bounds__(256, kron64_wps<FLAGS>()) void fq_kron64_kernel(con
         asm volatile("" : "+v"(foff));
         const uint4* myfrag = frag + foff;
         FQ_TICK(c0)
-        if (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the DMA of this token was issued an iteration ago (or in the prologue); younger ops = its 3 stores
+        if (COUNTED_WAIT && !first) {
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        first = false;
         FQ_TICK(c1)
+
+        u32x4 X[2][4];
+        {
+            const u32x4* tb = reinterpret_cast<const u32x4*>(tokbuf);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) X[mt][s] = tb[(mt * 32 + c) * 8 + ((h * 4 + s) ^ sw)];
+        }
+        // the buffer is free once those reads have landed: refill it with the next token
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int64_t nxt = tok + n_waves;
+            if (nxt < rows) dma_token(x, nxt, tok_lds, lane);
+        }
+
         if (diag != nullptr) {  // x * diag_scale, rounded to fp16 (trans_utils.py:86-90)
             const uint4* dp = reinterpret_cast<const uint4*>(diag + lane_off);
 #pragma unroll
@@ -148,31 +197,17 @@ __global__ __launch_bounds__(256, kron64_wps<FLAGS>()) void fq_kron64_kernel(con
                 }
         }
 
-        // ---- GEMM 1: U[mt][nt] = X(mt,:) . R(:, nt) ----
+        // ---- GEMM 1: U[mt][nt] = X(mt,:) . R(:, nt); four independent accumulator chains ----
         f32x16 U[2][2];
+        U[0][0] = f32x16{0}; U[0][1] = f32x16{0}; U[1][0] = f32x16{0}; U[1][1] = f32x16{0};
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            U[0][nt] = f32x16{0};
-            U[1][nt] = f32x16{0};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const f16x8 b = __builtin_bit_cast(f16x8, myfrag[(nt * 4 + s) * 64]);
-                U[0][nt] = mfma32(__builtin_bit_cast(f16x8, X[0][s]), b, U[0][nt]);
-                U[1][nt] = mfma32(__builtin_bit_cast(f16x8, X[1][s]), b, U[1][nt]);
-            }
-        }
-
-        // ---- X is dead: prefetch the next token into the same registers ----
-        // (sched_barrier: the scheduler must not hoist these loads above GEMM 1, where X is still live —
-        //  that would need a second 32-VGPR buffer and spill.)
-        __builtin_amdgcn_sched_barrier(0);
-        const int64_t nxt = tok + n_waves;
-        if (nxt < rows) {
-            const u32x4* xp = reinterpret_cast<const u32x4*>(x + nxt * KD + lane_off);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) X[mt][s] = __builtin_nontemporal_load(xp + mt * (32 * KN / 8) + s);
+        for (int s = 0; s < 4; ++s) {
+            const f16x8 b0 = __builtin_bit_cast(f16x8, myfrag[(0 * 4 + s) * 64]);
+            const f16x8 b1 = __builtin_bit_cast(f16x8, myfrag[(1 * 4 + s) * 64]);
+            U[0][0] = mfma32(__builtin_bit_cast(f16x8, X[0][s]), b0, U[0][0]);
+            U[1][0] = mfma32(__builtin_bit_cast(f16x8, X[1][s]), b0, U[1][0]);
+            U[0][1] = mfma32(__builtin_bit_cast(f16x8, X[0][s]), b1, U[0][1]);
+            U[1][1] = mfma32(__builtin_bit_cast(f16x8, X[1][s]), b1, U[1][1]);
         }
 
         // ---- fp16 rounding of U (flat_utils.py:15); C fragment -> A fragment of GEMM 2, no data movement ----
@@ -189,13 +224,14 @@ __global__ __launch_bounds__(256, kron64_wps<FLAGS>()) void fq_kron64_kernel(con
         f32x16 Y[2][2];  // [nt][mo]: Y^T[n' = 32h + 16nt + r][m' = 32mo + c]
         Y[0][0] = f32x16{0}; Y[0][1] = f32x16{0}; Y[1][0] = f32x16{0}; Y[1][1] = f32x16{0};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int mo = 0; mo < 2; ++mo) {
-                const f16x8 b = __builtin_bit_cast(f16x8, myfrag[(8 + ks * 2 + mo) * 64]);
-                Y[0][mo] = mfma32(Uh[0][ks], b, Y[0][mo]);
-                Y[1][mo] = mfma32(Uh[1][ks], b, Y[1][mo]);
-            }
+        for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 b0 = __builtin_bit_cast(f16x8, myfrag[(8 + ks * 2 + 0) * 64]);
+            const f16x8 b1 = __builtin_bit_cast(f16x8, myfrag[(8 + ks * 2 + 1) * 64]);
+            Y[0][0] = mfma32(Uh[0][ks], b0, Y[0][0]);
+            Y[1][0] = mfma32(Uh[1][ks], b0, Y[1][0]);
+            Y[0][1] = mfma32(Uh[0][ks], b1, Y[0][1]);
+            Y[1][1] = mfma32(Uh[1][ks], b1, Y[1][1]);
+        }
 
         if (out.rt_flags & FQ_ROUND_Y_F16) {
 #pragma unroll
@@ -356,11 +392,12 @@ __global__ __launch_bounds__(256, kron64_wps<FLAGS>()) void fq_kron64_kernel(con
 template <int FLAGS>
 static int launch_kron64(const f16* x, const f16* left, const f16* right, const f16* diag, int64_t rows,
                          const FqQuantOut& out, int n_cu, hipStream_t stream) {
-    int64_t blocks = (rows + 3) / 4;
-    const int64_t cap = (int64_t)n_cu * kron64_wps<FLAGS>();
-    if (blocks > cap) blocks = cap;
+    constexpr int THREADS = kron64_threads<FLAGS>();
+    constexpr int WAVES = THREADS / 64;
+    int64_t blocks = (rows + WAVES - 1) / WAVES;
+    if (blocks > n_cu) blocks = n_cu;  // one persistent workgroup per CU (LDS: 16 KB + 8 KB per wave)
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((fq_kron64_kernel<FLAGS, false>), dim3((unsigned)blocks), dim3(256), 0, stream, x, left,
+    hipLaunchKernelGGL((fq_kron64_kernel<FLAGS, false>), dim3((unsigned)blocks), dim3(THREADS), 0, stream, x, left,
                        right, diag, rows, out, (unsigned long long*)nullptr);
     return (int)hipGetLastError();
 }
@@ -390,13 +427,12 @@ int fq_launch_kron64(int flags, const f16* x, const f16* left, const f16* right,
 }
 
 // Debug: the packed kernel with per-phase s_memtime accounting (see FQ_TICK). trace: [n_waves, 4] u64,
-// n_waves = 4 * min(ceil(rows/4), 3 * n_cu).
+// n_waves = 16 * min(ceil(rows/16), n_cu).
 int fq_launch_kron64_trace(const f16* x, const f16* left, const f16* right, int64_t rows, const FqQuantOut& out,
                            unsigned long long* trace, int n_cu, hipStream_t stream) {
-    int64_t blocks = (rows + 3) / 4;
-    const int64_t cap = (int64_t)n_cu * 3;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((fq_kron64_kernel<FQ_OUT_PACKED, true>), dim3((unsigned)blocks), dim3(256), 0, stream, x, left,
+    int64_t blocks = (rows + 15) / 16;
+    if (blocks > n_cu) blocks = n_cu;
+    hipLaunchKernelGGL((fq_kron64_kernel<FQ_OUT_PACKED, true>), dim3((unsigned)blocks), dim3(1024), 0, stream, x, left,
                        right, (const f16*)nullptr, rows, out, trace);
     return (int)hipGetLastError();
 }
