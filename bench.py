@@ -142,7 +142,7 @@ def main():
 
     def step(i):
         xp, qa, sa = calls[i % N_BUF]
-        check(lib.fq_kron_quant_f16(xp, lp, rp, None, ROWS, M, N, smax, smin, 1, flags, qa, sa, none4, None, sp))
+        check(lib.fq_kron_quant_f16(xp, lp, rp, None, ROWS, M, N, smax, smin, 1, flags, qa, sa, none4, None, None, 0, sp))
 
     for i in range(args.warmup):
         step(i)

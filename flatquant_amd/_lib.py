@@ -32,7 +32,9 @@ _vp, _i64, _i, _f = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_floa
 _fp = ctypes.POINTER(ctypes.c_float)
 _vpp = ctypes.POINTER(ctypes.c_void_p)
 SYMBOLS = {
-    "fq_kron_quant_f16": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp]),
+    "fq_kron_quant_f16": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp, _i64,
+                               _vp]),
+    "fq_kron_workspace_bytes": (_i64, [_i, _i]),
     "fq_block_quant_f16": (_i, [_vp, _vp, _i64, _i, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp]),
     "fq_hadamard_f16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _f, _vp]),
     "fq_rowquant_f16": (_i, [_vp, _i64, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp]),

@@ -9,8 +9,9 @@
 int fq_launch_kron64(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
                      int64_t rows, const FqQuantOut& out, int n_cu, hipStream_t stream);
 int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
-                           int64_t rows, int M, int N, const FqQuantOut& out, int n_cu,
-                           hipStream_t stream);
+                           int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
+                           int64_t workspace_bytes, int n_cu, hipStream_t stream);
+int64_t fq_kron_generic_workspace_bytes(int M, int N);
 int fq_launch_block(int flags, const f16* x, const f16* P, int64_t rows, int R, int C, int transpose_out,
                     const FqQuantOut& out, int n_cu, hipStream_t stream);
 int fq_launch_hadamard(const f16* x, f16* y, int64_t rows, int n, int K, const f16* hadK, float scale,
@@ -40,11 +41,15 @@ int fail(int code, const char* fmt, ...) {
 
 int cu_count() {
     (void)hipGetLastError();  // drop any stale error of this thread so the post-launch check is ours
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-        return 256;
-    return n;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    static int cached[64] = {0};  // immutable per device once written; a racy double-write stores the same value
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
 }
 
 int check_launch(int rc, const char* what) {
@@ -114,7 +119,7 @@ int fq_version(void) { return 100; }
 int fq_kron_quant_f16(const void* x, const void* left, const void* right, const void* diag, int64_t rows,
                       int M, int N, const float* sig_max, const float* sig_min, int n_clips, int flags,
                       void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
-                      void* stream) {
+                      void* workspace, int64_t workspace_bytes, void* stream) {
     if (rows < 0 || M <= 0 || N <= 0) return fail(FQ_EINVAL, "fq_kron_quant_f16: bad sizes rows=%lld M=%d N=%d", (long long)rows, M, N);
     if (N & 1) return fail(FQ_EINVAL, "fq_kron_quant_f16: N=%d must be even (two INT4 per byte)", N);
     FqQuantOut o;
@@ -129,8 +134,17 @@ int fq_kron_quant_f16(const void* x, const void* left, const void* right, const 
         if (rc != -1000) return check_launch(rc, "fq_kron_quant_f16[64x64]");
     }
     rc = fq_launch_kron_generic(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag,
-                                rows, M, N, o, n_cu, (hipStream_t)stream);
+                                rows, M, N, o, workspace, workspace_bytes, n_cu, (hipStream_t)stream);
+    if (rc == -1001)
+        return fail(FQ_EINVAL, "fq_kron_quant_f16: workspace of %lld bytes required for M=%d N=%d (got %lld)",
+                    (long long)fq_kron_generic_workspace_bytes(M, N), M, N, (long long)(workspace ? workspace_bytes : 0));
     return check_launch(rc, "fq_kron_quant_f16[generic]");
+}
+
+int64_t fq_kron_workspace_bytes(int M, int N) {
+    if (M == 64 && N == 64) return 0;
+    if ((N & 15) || M < 1 || M > 128 || N < 16 || N > 256 || ((M * N / 2) & 15)) return FQ_EUNSUPPORTED;
+    return fq_kron_generic_workspace_bytes(M, N);
 }
 
 int fq_block_quant_f16(const void* x, const void* P, int64_t rows, int R, int C, int transpose_out,

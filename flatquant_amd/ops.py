@@ -83,6 +83,24 @@ def _alloc_outputs(x: torch.Tensor, rows: int, d: int, n_clips: int, flags: int,
     return o
 
 
+_WORKSPACES = {}
+
+
+def _kron_workspace(device: torch.device, M: int, N: int):
+    """Per-(device, stream, shape) scratch for the fragment re-pack of the generic Kronecker kernel (the C ABI
+    allocates nothing). Keyed by stream too: two streams must not share a buffer the launches rewrite."""
+    nbytes = int(lib.fq_kron_workspace_bytes(M, N))
+    if nbytes < 0:
+        raise _lib.FqError(nbytes, f"no kernel for Kronecker factors ({M}, {N}): need N % 16 == 0, M <= 128, N <= 256")
+    if nbytes == 0:
+        return None, 0
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, M, N)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        ws = _WORKSPACES[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws, nbytes
+
+
 def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),),
                flags: int = FQ_OUT_PACKED, diag: Optional[torch.Tensor] = None) -> FusedOutputs:
     """y = x @ kron(left, right) fused with per-token INT4 quantisation (fq_kron_quant_f16)."""
@@ -103,9 +121,10 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
     if rows == 0:
         return o
     with torch.cuda.device(x.device):
+        ws, ws_bytes = _kron_workspace(x.device, M, N)
         check(lib.fq_kron_quant_f16(_ptr(x), _ptr(left), _ptr(right), _ptr(diag), rows, M, N, smax, smin, n,
                                     flags, _ptr_array(o.q), _ptr_array(o.scale), _ptr_array(o.fq), _ptr(o.y),
-                                    _stream(x)))
+                                    _ptr(ws), ws_bytes, _stream(x)))
     return o
 
 

@@ -66,12 +66,18 @@ extern "C" {
  * scale_out[c] [rows] fp16           (FQ_OUT_PACKED)
  * fq_out[c]    [rows, M*N] fp16      (FQ_OUT_FAKEQUANT)
  * y_out        [rows, M*N] fp16      (FQ_OUT_TRANSFORM)
+ * workspace   device scratch of at least fq_kron_workspace_bytes(M, N) bytes (0 for M = N = 64, where it may be
+ *             NULL): the call re-packs left/right into MFMA fragment order there before the main kernel.
  */
 int fq_kron_quant_f16(const void* x, const void* left, const void* right, const void* diag,
                       int64_t rows, int M, int N,
                       const float* sig_max, const float* sig_min, int n_clips, int flags,
                       void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
-                      void* stream);
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Bytes of device workspace fq_kron_quant_f16 needs for factor sizes (M, N); 0 when none is needed;
+ * negative (FQ_EUNSUPPORTED) when no kernel handles the shape (needs N % 16 == 0, M <= 128, N <= 256). */
+int64_t fq_kron_workspace_bytes(int M, int N);
 
 /*
  * Single-matrix transform over the LAST axis of [rows, R, C] blocks (o_proj head transform):

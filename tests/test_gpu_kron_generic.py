@@ -1,0 +1,134 @@
+"""GPU parity for the generic fused Kronecker kernel (every factor pair of SURVEY 8a other than 64x64).
+
+Same bars as tests/test_gpu_kron64.py: dyadic fixtures bit-exact vs both reference paths; quantise/pack stage
+bit-exact vs the oracle on the kernel's own transformed activation; transform within the north-star tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fq_oracle as O
+
+pytestmark = pytest.mark.gpu
+P, F, T, R16, NC0, Q16 = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
+SHAPES = ["64x128", "112x128", "128x224", "86x128", "64x112", "32x64", "56x64"]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def mismatch(a, b):
+    return float(np.mean(np.asarray(a).reshape(-1) != np.asarray(b).reshape(-1)))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from flatquant_amd import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize("shape", ["64x128", "32x64"])
+def test_exact_fixture_bit_exact_vs_both_reference_paths(ops, golden, shape):
+    g = golden(f"exact_{shape}")
+    x, L, Rm = dev(g["x"]), dev(g["L"]), dev(g["R"])
+    rows = x.shape[0]
+    for ci in range(2):
+        sig = [(float(g[f"sig{ci}"][0]), float(g[f"sig{ci}"][1]))]
+        o = ops.kron_quant(x, L, Rm, sig, P | NC0)
+        assert np.array_equal(o.q[0].cpu().numpy(), g[f"b_packed{ci}"])
+        assert np.array_equal(o.scale[0].cpu().numpy(), g[f"b_scale{ci}"])
+        o = ops.kron_quant(x, L, Rm, sig, F | R16)
+        assert np.array_equal(o.fq[0].cpu().numpy(), g[f"a_fq{ci}"].reshape(rows, -1))
+        o = ops.kron_quant(x, L, Rm, sig, T)
+        assert np.array_equal(o.y.cpu().numpy(), g[f"a_y{ci}"].reshape(rows, -1))
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_quant_stage_bit_exact_given_kernel_transform(ops, golden, shape):
+    g = golden(f"kron_A_{shape}")
+    x, L, Rm = dev(g["x"]), dev(g["L"]), dev(g["R"])
+    sigs = [(0.9820137619972229, 0.9820137619972229), (0.9, 0.33)]
+    o = ops.kron_quant(x, L, Rm, sigs, T | P | F | R16)
+    y16 = o.y.cpu().numpy()
+    for ci, (smax, smin) in enumerate(sigs):
+        ref = O.quant_outputs(y16.astype(np.float32), smax, smin)
+        assert np.array_equal(o.q[ci].cpu().numpy(), ref["packed"])
+        assert np.array_equal(o.scale[ci].cpu().numpy(), ref["scale16"])
+        assert np.array_equal(o.fq[ci].cpu().numpy(), ref["fq"])
+    # fp16-arithmetic quantiser (lac = False path of quant_utils.py) on the same transform
+    o = ops.kron_quant(x, L, Rm, [(1.0, 1.0)], T | F | R16 | Q16)
+    ref = O.quant_outputs(o.y.cpu().numpy().astype(np.float32), 1.0, 1.0, quant_f16=True)
+    assert np.array_equal(o.fq[0].cpu().numpy(), ref["fq"])
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_transform_and_packed_vs_oracle_and_reference(ops, golden, shape):
+    g = golden(f"kron_A_{shape}")
+    x, L, Rm = dev(g["x"]), dev(g["L"]), dev(g["R"])
+    rows = x.shape[0]
+    y = ops.kron_quant(x, L, Rm, flags=T).y.cpu().numpy()
+    y32 = O.kron_transform(g["x"], g["L"], g["R"]).reshape(rows, -1)
+    assert mismatch(y, y32.astype(np.float16)) <= 1e-2
+    den = np.abs(y32).max(axis=1, keepdims=True)
+    assert np.max(np.abs(y.astype(np.float32) - y32) / den) <= 1e-3
+    assert mismatch(y, g["a16_lac0_y"]) <= 2e-2                      # reference path A (torch CPU BLAS order)
+    for ci in range(2):
+        s = (float(g["sig"][ci][0]), float(g["sig"][ci][1]))
+        o = ops.kron_quant(x, L, Rm, [s], P | R16)
+        q = O.unpack_i4(o.q[0].cpu().numpy())
+        ref = O.kron_quant(g["x"], g["L"], g["R"], s[0], s[1], round_y_f16=True)
+        assert mismatch(q, ref["q"]) <= 1e-3 and np.max(np.abs(q - ref["q"].astype(np.int32))) <= 1
+        qa = g[f"a16_lac{ci}_q"].reshape(rows, -1).astype(np.int32)
+        assert mismatch(q, qa) <= 1e-3 and np.max(np.abs(q - qa)) <= 1
+        sg = o.scale[0].cpu().numpy().astype(np.float32)
+        assert np.max(np.abs(sg - ref["scale"]) / ref["scale"]) <= 1e-3
+
+
+@pytest.mark.parametrize("shape", ["64x128", "32x64", "112x128"])
+def test_vs_reference_path_b_packed(ops, golden, shape):
+    g = golden(f"kron_B_{shape}")
+    x, L, Rm = dev(g["x"]), dev(g["L"]), dev(g["R"])
+    for ci in range(3):
+        s = (float(g["sig"][ci][0]), float(g["sig"][ci][1]))
+        o = ops.kron_quant(x, L, Rm, [s], P | NC0)
+        q, qb = O.unpack_i4(o.q[0].cpu().numpy()), O.unpack_i4(g[f"b_packed{ci}"])
+        assert mismatch(q, qb) <= 1e-3 and np.max(np.abs(q - qb)) <= 1
+        sb = g[f"b_scale{ci}"].astype(np.float32)
+        assert np.max(np.abs(o.scale[0].cpu().numpy().astype(np.float32) - sb) / sb) <= 1e-3
+
+
+@pytest.mark.parametrize("M,N,rows", [(64, 128, 0), (64, 128, 1), (112, 128, 3), (128, 224, 5), (32, 64, 1025),
+                                      (64, 80, 7), (128, 128, 9), (96, 96, 4), (128, 256, 3)])
+def test_ragged_rows_and_other_factor_pairs(ops, M, N, rows):
+    gen = torch.Generator().manual_seed(M * 1000 + N + rows)
+    x = torch.randn(rows, M * N, generator=gen).half()
+    L = (torch.randn(M, M, generator=gen) / (M ** 0.5)).half()
+    Rm = (torch.randn(N, N, generator=gen) / (N ** 0.5)).half()
+    o = ops.kron_quant(x.cuda(), L.cuda(), Rm.cuda(), [(0.97, 0.9)], T | P | R16)
+    assert o.q[0].shape == (rows, M * N // 2)
+    if rows:
+        n = min(rows, 4)
+        ref = O.quant_outputs(o.y[-n:].cpu().numpy().astype(np.float32), 0.97, 0.9)
+        assert np.array_equal(o.q[0][-n:].cpu().numpy(), ref["packed"])
+        y32 = O.kron_transform(x[-n:].numpy(), L.numpy(), Rm.numpy()).reshape(n, -1)
+        assert mismatch(o.y[-n:].cpu().numpy(), y32.astype(np.float16)) <= 1e-2
+
+
+def test_single_signed_token_no_clamp_masks_padding(ops):
+    """NO_CLAMP0 statistics must ignore the zero padding of non-multiple-of-32 factors (M = 86, 112)."""
+    M, N = 86, 128
+    x = torch.zeros(2, M * N).half()
+    x[:, :] = 1.0                                             # all-positive token
+    L, Rm = torch.eye(M).half(), torch.eye(N).half()          # identity transform: Y == X > 0 everywhere
+    o = ops.kron_quant(x.cuda(), L.cuda(), Rm.cuda(), [(1.0, 0.5)], P | NC0)
+    ref = O.kron_quant(x.numpy(), L.numpy(), Rm.numpy(), 1.0, 0.5, clamp0=False)
+    assert np.array_equal(o.q[0].cpu().numpy(), ref["packed"])
+    assert np.array_equal(o.scale[0].cpu().numpy(), ref["scale16"])
+
+
+def test_unsupported_shape_raises(ops):
+    from flatquant_amd._lib import FqError
+    x = torch.randn(2, 60 * 63).half().cuda()
+    with pytest.raises(FqError):
+        ops.kron_quant(x, torch.eye(60).half().cuda(), torch.eye(63).half().cuda())

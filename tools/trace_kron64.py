@@ -20,7 +20,7 @@ R = (torch.randn(64, 64, generator=g, device="cuda") / 8).half()
 q = torch.empty(ROWS, 2048, dtype=torch.uint8, device="cuda")
 s = torch.empty(ROWS, dtype=torch.float16, device="cuda")
 n_cu = torch.cuda.get_device_properties(0).multi_processor_count
-n_waves = 4 * min((ROWS + 3) // 4, 3 * n_cu)
+n_waves = 16 * min((ROWS + 15) // 16, n_cu)
 trace = torch.zeros(n_waves * 6, dtype=torch.int64, device="cuda")
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 for i in range(8):
