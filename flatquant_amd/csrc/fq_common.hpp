@@ -102,10 +102,21 @@ __device__ __forceinline__ int fq_quant1(float y, float scale) {
     return (int)t;
 }
 
+// fp16(fp32(a * b)): the fp32 product is ROUNDED TO fp32 FIRST, then to fp16 — what torch does for
+// (scale * q).to(float16) (quant_utils.py:25-26,81). hipcc otherwise selects v_fma_mixlo_f16 for
+// fptrunc(fmul), which rounds the exact product once and differs when the fp32 product lands on an fp16 tie
+// (seen on the GPU: 7 * 3.184152 -> 22.297 instead of 22.281). The empty asm makes the product opaque.
+__device__ __forceinline__ f16 fq_mul_to_f16(float a, float b) {
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return (f16)p;
+}
+
 template <int FLAGS>
 __device__ __forceinline__ f16 fq_dequant1(int q, float scale) {
-    if (FLAGS & FQ_QUANT_F16) return (f16)((float)(f16)scale * (float)q);  // fp16 product, one rounding
-    return (f16)(scale * (float)q);
+    // FQ_QUANT_F16: scale is an fp16 value and |q| <= 8, so the fp32 product is exact and one rounding remains
+    if (FLAGS & FQ_QUANT_F16) return (f16)((float)(f16)scale * (float)q);
+    return fq_mul_to_f16(scale, (float)q);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -349,11 +349,11 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                                 float dmax = 0.0f;
 #pragma unroll
                                 for (int e = 0; e < 8; ++e)
-                                    fv[mo][w][e] = (f16)(scale * fq_qfast(FQ_YV(mo, w, e), inv, dmax));
+                                    fv[mo][w][e] = fq_mul_to_f16(scale, fq_qfast(FQ_YV(mo, w, e), inv, dmax));
                                 if (fq_wave_needs_exact(dmax)) {
 #pragma unroll
                                     for (int e = 0; e < 8; ++e)
-                                        fv[mo][w][e] = (f16)(scale * fq_qexact(FQ_YV(mo, w, e), scale));
+                                        fv[mo][w][e] = fq_mul_to_f16(scale, fq_qexact(FQ_YV(mo, w, e), scale));
                                 }
                             }
                     }

@@ -241,8 +241,8 @@ __global__ __launch_bounds__(256) void fq_kron_generic_kernel(const f16* __restr
                                 v0[e] = fq_dequant1<FQ_QUANT_F16>((int)qv[e], scale);
                                 v1[e] = fq_dequant1<FQ_QUANT_F16>((int)qv[8 + e], scale);
                             } else {
-                                v0[e] = (f16)(scale * qv[e]);
-                                v1[e] = (f16)(scale * qv[8 + e]);
+                                v0[e] = fq_mul_to_f16(scale, qv[e]);
+                                v1[e] = fq_mul_to_f16(scale, qv[8 + e]);
                             }
                         }
                         uint4* sp = reinterpret_cast<uint4*>(stage + (mo * 32 + c) * N + n0);
