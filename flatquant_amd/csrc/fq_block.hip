@@ -1,0 +1,186 @@
+// fq_block.hip — single-matrix transform over the last axis of [R, C] blocks, fused with per-block INT4
+// quantisation: the o_proj input transform across heads.
+//
+// Replaces deploy/kernels/block_matmul.py:29-104 (Triton matmul_quant_kernel: b [B, hd, H] @ c [H, H], the
+// quantised block TRANSPOSED before packing, :86-101) and the path-A op llama_utils.py:275-277.
+//
+//   Y[t] = x[t] ([R, C] row-major, R = head_dim, C = num_heads) . P ([C, C]); statistics over all R*C values;
+//   packed / fp16 outputs in the reference's transposed order [C][R] per token (transpose_out = 1).
+//
+// One wave per token. MFMA 32x32x16: A = 32 rows of x (k = C, contiguous: 16-byte fragment loads straight
+// from HBM), B = P fragments (LDS, fragment order, built once per workgroup). The A rows a lane supplies are
+// PERMUTED (free: each lane picks the row it loads) so that in the C/D fragment lane (h, c') ends up with the
+// 64 consecutive rows r = 64h .. 64h+63 of output column c' — i.e. one contiguous run of the transposed
+// output, stored with 16-byte stores. Supported: R in {32, 64, 96, 128}, C in {32, 64}.
+#include "fq_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// physical row supplied by A-fragment lane index i of row tile rt (RT tiles): see header comment
+__device__ __forceinline__ int rmap(int RT, int rt, int i) {
+    return ((i >> 2) & 1) * (RT * 16) + rt * 16 + (i & 3) + 4 * (i >> 3);
+}
+
+template <int RT, int CT>
+__global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x, const f16* __restrict__ P,
+                                                       int64_t rows, FqQuantOut out, int flags) {
+    constexpr int R = RT * 32, C = CT * 32, KS = C / 16, D = R * C;
+    __shared__ __attribute__((aligned(16))) uint4 pfrag[KS * CT * 64];  // [(s*CT + ct)][lane]
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    for (int item = tid; item < KS * CT * 64; item += 256) {
+        const int f = item >> 6, ln = item & 63, fh = ln >> 5, fc = ln & 31;
+        const int s = f / CT, ct = f - s * CT;
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = P[(s * 16 + fh * 8 + j) * C + ct * 32 + fc];
+        pfrag[item] = __builtin_bit_cast(uint4, v);
+    }
+    __syncthreads();
+
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (tid >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t tok = wave_id; tok < rows; tok += n_waves) {
+        int foff = lane;
+        asm volatile("" : "+v"(foff));  // keep the fragment reads inside the loop (see fq_kron64.hip)
+        const uint4* myp = pfrag + foff;
+
+        f32x16 Y[RT][CT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const uint4* xp = reinterpret_cast<const uint4*>(x + tok * D + (int64_t)rmap(RT, rt, c) * C + h * 8);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) Y[rt][ct] = f32x16{0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const f16x8 a = __builtin_bit_cast(f16x8, __builtin_nontemporal_load(
+                                    reinterpret_cast<const u32x4*>(xp) + s * 2));  // k = 16 s + 8 h .. +8
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    Y[rt][ct] = mfma32(a, __builtin_bit_cast(f16x8, myp[(s * CT + ct) * 64]), Y[rt][ct]);
+            }
+        }
+        // lane (h, c) now holds, for column c' = 32 ct + c, rows r = RT*16*h + 16 rt + reg
+
+        if (flags & FQ_ROUND_Y_F16) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Y[rt][ct][r] = (float)(f16)Y[rt][ct][r];
+        }
+        if (flags & FQ_OUT_TRANSFORM) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                uint4* yp = reinterpret_cast<uint4*>(out.y + tok * D + (int64_t)(ct * 32 + c) * R + h * (RT * 16));
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        f16x8 v;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (f16)Y[rt][ct][w * 8 + e];
+                        yp[rt * 2 + w] = __builtin_bit_cast(uint4, v);
+                    }
+            }
+        }
+        if (!(flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT))) continue;
+
+        float vmax = Y[0][0][0], vmin = Y[0][0][0];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    vmax = fmaxf(fmaxf(vmax, Y[rt][ct][r]), Y[rt][ct][r + 1]);
+                    vmin = fminf(fminf(vmin, Y[rt][ct][r]), Y[rt][ct][r + 1]);
+                }
+        vmax = fq_wave_max(vmax);
+        vmin = fq_wave_min(vmin);
+
+        for (int ci = 0; ci < out.n_clips; ++ci) {
+            float scale;
+            if (flags & FQ_QUANT_F16) scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
+            else scale = fq_token_scale<0>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
+            const float inv = 1.0f / scale;
+            if ((flags & FQ_OUT_PACKED) && lane == 0) out.scale[ci][tok] = (f16)scale;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                uint8_t* qrow = (flags & FQ_OUT_PACKED)
+                                    ? out.q[ci] + tok * (D / 2) + (int64_t)(ct * 32 + c) * (R / 2) + h * (RT * 8)
+                                    : nullptr;
+                f16* frow = (flags & FQ_OUT_FAKEQUANT)
+                                ? out.fq[ci] + tok * D + (int64_t)(ct * 32 + c) * R + h * (RT * 16)
+                                : nullptr;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    float qv[16];
+                    if (flags & FQ_QUANT_F16) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) qv[r] = (float)fq_quant1<FQ_QUANT_F16>(Y[rt][ct][r], scale);
+                    } else {
+                        float dmax = 0.0f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) qv[r] = fq_qfast(Y[rt][ct][r], inv, dmax);
+                        if (fq_wave_needs_exact(dmax)) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) qv[r] = fq_qexact(Y[rt][ct][r], scale);
+                        }
+                    }
+                    if (flags & FQ_OUT_PACKED) {
+                        uint2 pk;
+                        pk.x = fq_pack8(qv[0], qv[1], qv[2], qv[3], qv[4], qv[5], qv[6], qv[7]);
+                        pk.y = fq_pack8(qv[8], qv[9], qv[10], qv[11], qv[12], qv[13], qv[14], qv[15]);
+                        *reinterpret_cast<uint2*>(qrow + rt * 8) = pk;
+                    }
+                    if (flags & FQ_OUT_FAKEQUANT) {
+                        f16x8 v0, v1;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (flags & FQ_QUANT_F16) {
+                                v0[e] = fq_dequant1<FQ_QUANT_F16>((int)qv[e], scale);
+                                v1[e] = fq_dequant1<FQ_QUANT_F16>((int)qv[8 + e], scale);
+                            } else {
+                                v0[e] = fq_mul_to_f16(scale, qv[e]);
+                                v1[e] = fq_mul_to_f16(scale, qv[8 + e]);
+                            }
+                        }
+                        uint4* fp = reinterpret_cast<uint4*>(frow + rt * 16);
+                        fp[0] = __builtin_bit_cast(uint4, v0);
+                        fp[1] = __builtin_bit_cast(uint4, v1);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int RT, int CT>
+int launch_block(int flags, const f16* x, const f16* P, int64_t rows, const FqQuantOut& out, int n_cu,
+                 hipStream_t stream) {
+    int64_t blocks = (rows + 3) / 4;
+    const int64_t cap = (int64_t)n_cu * 2;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((fq_block_kernel<RT, CT>), dim3((unsigned)blocks), dim3(256), 0, stream, x, P, rows, out, flags);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int fq_launch_block(int flags, const f16* x, const f16* P, int64_t rows, int R, int C, int transpose_out,
+                    const FqQuantOut& out, int n_cu, hipStream_t stream) {
+    if (!transpose_out) return -1000;  // natural [R][C] packing is not what the reference emits; not built
+    if ((R & 31) || R < 32 || R > 128 || (C != 32 && C != 64)) return -1000;
+    const int RT = R / 32, CT = C / 32;
+#define FQ_B(RT_, CT_) \
+    if (RT == RT_ && CT == CT_) return launch_block<RT_, CT_>(flags, x, P, rows, out, n_cu, stream);
+    FQ_B(1, 1) FQ_B(2, 1) FQ_B(3, 1) FQ_B(4, 1) FQ_B(1, 2) FQ_B(2, 2) FQ_B(3, 2) FQ_B(4, 2)
+#undef FQ_B
+    return -1000;
+}
