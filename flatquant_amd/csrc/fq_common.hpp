@@ -133,6 +133,41 @@ __device__ __forceinline__ f16 fq_dequant1(int q, float scale) {
 // ---------------------------------------------------------------------------------------------------
 constexpr float FQ_NEAR = 4e-6f;
 
+// Single-instruction 3-input max/min. fmaxf(fmaxf(a,b),c) compiles to v_max3_f32 only after hipcc has inserted
+// a canonicalising v_max_f32 x,x per MFMA-produced operand (one extra VALU per element); NaNs are not part of the
+// contract here, so use the instruction directly.
+__device__ __forceinline__ float fq_max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float fq_min3(float a, float b, float c) {
+    float d;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float fq_max3_abs(float a, float b, float c) {  // max(a, |b|, |c|)
+    float d;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Two elements at once: v_pk_mul_f32 / v_pk_add_f32 process a register pair per instruction on gfx950.
+// Returns the clamped integer-valued pair; dmax accumulates max |t - rint(t)| (see fq_qfast).
+__device__ __forceinline__ f32x2 fq_qfast2(f32x2 y, f32x2 inv2, float& dmax) {
+    const f32x2 t = y * inv2;
+    f32x2 r;
+    r.x = __builtin_rintf(t.x);
+    r.y = __builtin_rintf(t.y);
+    const f32x2 d = t - r;
+    dmax = fq_max3_abs(dmax, d.x, d.y);
+    r.x = __builtin_amdgcn_fmed3f(r.x, -8.0f, 7.0f);
+    r.y = __builtin_amdgcn_fmed3f(r.y, -8.0f, 7.0f);
+    return r;
+}
+
 __device__ __forceinline__ float fq_qfast(float y, float inv, float& dmax) {
     const float t = y * inv;
     const float r = __builtin_rintf(t);

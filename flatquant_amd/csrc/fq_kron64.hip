@@ -78,25 +78,58 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // the prefetch right after issuing it. The asm form is invisible to its counters; completion is waited for by
 // the COUNTED s_waitcnt at the top of the token loop. M0 (LDS base of the DMA) is saved/restored because the
 // compiler owns it.
+#ifndef FQ_DMA_INST_OFFSET
+#define FQ_DMA_INST_OFFSET 1  // 1: the instruction's offset field advances BOTH the global and the LDS address
+#endif
 __device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok, unsigned lds_base, int lane) {
-    const unsigned char* g = reinterpret_cast<const unsigned char*>(x) + tok * TOK_BYTES + (lane >> 3) * 128;
-    const int l7 = lane & 7, sw0 = lane >> 4;
+    // (row>>1)&7 of row 8i + (lane>>3) is (4i + (lane>>4)) & 7 = 4(i&1) + (lane>>4): the chunk swizzle only depends
+    // on the parity of i -> two per-lane offsets, everything else is immediates and scalars.
+    const unsigned ce = ((lane & 7) ^ (lane >> 4)) << 4;
+    const unsigned voff_e = (lane >> 3) * 128 + ce;         // even i
+    const unsigned voff_o = (lane >> 3) * 128 + (ce ^ 64);  // odd i: chunk ^ 4
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(x) + tok * TOK_BYTES;  // wave-uniform
+    // readfirstlane returns int: widen through unsigned or a low half >= 2^31 sign-extends into the high half
+    const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)base);
+    const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((size_t)base >> 32));
+    const unsigned long long sb0 = (unsigned long long)lo32 | ((unsigned long long)hi32 << 32);
+    const unsigned long long sb1 = sb0 + 4096;
+    unsigned keep;
+#if FQ_DMA_INST_OFFSET
+    asm volatile(
+        "s_nop 4\n\t"  // SGPR base / offsets may come straight from v_readfirstlane: 5 wait states before VMEM reads them
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3 nt\n\t"
+        "global_load_lds_dwordx4 %2, %3 offset:1024 nt\n\t"
+        "global_load_lds_dwordx4 %1, %3 offset:2048 nt\n\t"
+        "global_load_lds_dwordx4 %2, %3 offset:3072 nt\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %4 nt\n\t"
+        "global_load_lds_dwordx4 %2, %4 offset:1024 nt\n\t"
+        "global_load_lds_dwordx4 %1, %4 offset:2048 nt\n\t"
+        "global_load_lds_dwordx4 %2, %4 offset:3072 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff_e), "v"(voff_o), "s"(sb0), "s"(sb1), "s"(lds_base), "s"(lds_base + 4096)
+        : "memory");
+#else
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int chunk = l7 ^ ((i * 4 + sw0) & 7);
-        const unsigned char* src = g + i * 1024 + chunk * 16;
-        const unsigned dst = lds_base + i * 1024;
-        unsigned keep;
+        const unsigned voff = ((i & 1) ? voff_o : voff_e) + (i & 3) * 1024;
         asm volatile(
+            "s_nop 4\n\t"
             "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %2\n\t"
+            "s_mov_b32 m0, %3\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, off nt\n\t"
+            "global_load_lds_dwordx4 %1, %2 nt\n\t"
             "s_mov_b32 m0, %0"
             : "=&s"(keep)
-            : "v"(src), "s"(dst)
+            : "v"(voff), "s"(i < 4 ? sb0 : sb1), "s"(lds_base + i * 1024)
             : "memory");
     }
+#endif
 }
 
 template <int FLAGS, bool TRACE = false>
@@ -113,7 +146,8 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     constexpr bool COUNTED_WAIT = (FLAGS & FQ_CT_MASK) == FQ_OUT_PACKED;
     unsigned long long tr_wait = 0, tr_g1 = 0, tr_g2 = 0, tr_epi = 0;
     const unsigned long long tr_start = TRACE ? __builtin_amdgcn_s_memtime() : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[FRAG_BYTES + WAVES * TOK_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[FRAG_BYTES + WAVES * TOK_BYTES + 16];
+    unsigned* next_slot = reinterpret_cast<unsigned*>(smem + FRAG_BYTES + WAVES * TOK_BYTES);  // work counter
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int h = lane >> 5;
@@ -125,8 +159,16 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     const unsigned tok_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)tokbuf);
 
     // First token's HBM->LDS DMA goes out BEFORE the fragment gather below, so its latency hides behind it.
-    int64_t tok = wave_id;
-    if (tok < rows) dma_token(x, tok, tok_lds, lane);
+    // Tokens: workgroup b owns the contiguous range [blk_base, blk_base + blk_cnt); its waves PULL tokens from a
+    // counter in LDS. (A static tok += n_waves split ties the kernel's duration to the slowest wave: the SIMD
+    // arbiter favours older waves, measured 2.8x spread in per-wave loop time.) The first WAVES tokens are handed
+    // out statically so that nothing has to be synchronised before the first DMA.
+    const int64_t tpb = (rows + gridDim.x - 1) / gridDim.x;
+    const int64_t blk_base = (int64_t)blockIdx.x * tpb;
+    const int blk_cnt = (int)(rows - blk_base < tpb ? (rows - blk_base < 0 ? 0 : rows - blk_base) : tpb);
+    if (tid == 0) *next_slot = WAVES;
+    int slot = wave;
+    if (slot < blk_cnt) dma_token(x, blk_base + slot, tok_lds, lane);
 
     // ---- B-operand fragments of R and L: gathered straight from global (L2-resident 2 x 8 KB), once ----
     uint4* frag = reinterpret_cast<uint4*>(smem);
@@ -153,8 +195,10 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     const int sw = (c >> 1) & 7;
     const int lane_off = c * KN + h * 32;  // same element offset in HBM (used by diag and by the outputs)
     bool first = true;
+    int next_pulled = 0;
 
-    for (; tok < rows; tok += n_waves) {
+    while (slot < blk_cnt) {
+        const int64_t tok = blk_base + slot;
         // Launder the lane offset every iteration: otherwise LICM hoists all 16 loop-invariant fragment reads
         // (64 VGPRs) out of the token loop and the register allocator spills them.
         int foff = lane;
@@ -178,14 +222,6 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
 #pragma unroll
                 for (int s = 0; s < 4; ++s) X[mt][s] = tb[(mt * 32 + c) * 8 + ((h * 4 + s) ^ sw)];
         }
-        // the buffer is free once those reads have landed: refill it with the next token
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const int64_t nxt = tok + n_waves;
-            if (nxt < rows) dma_token(x, nxt, tok_lds, lane);
-        }
-
         if (diag != nullptr) {  // x * diag_scale, rounded to fp16 (trans_utils.py:86-90)
             const uint4* dp = reinterpret_cast<const uint4*>(diag + lane_off);
 #pragma unroll
@@ -208,6 +244,18 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
             U[1][0] = mfma32(__builtin_bit_cast(f16x8, X[1][s]), b0, U[1][0]);
             U[0][1] = mfma32(__builtin_bit_cast(f16x8, X[0][s]), b1, U[0][1]);
             U[1][1] = mfma32(__builtin_bit_cast(f16x8, X[1][s]), b1, U[1][1]);
+            if (s == 0) {
+                // All eight X fragments were requested before the first MFMA; once they have landed the token's LDS
+                // buffer is free -> refill it with the next token while the matrix pipe works on the first K-step.
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                int nxt = 0;
+                if (lane == 0) nxt = (int)atomicAdd(next_slot, 1u);
+                nxt = __builtin_amdgcn_readfirstlane(nxt);
+                if (nxt < blk_cnt) dma_token(x, blk_base + nxt, tok_lds, lane);
+                next_pulled = nxt;
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
         // ---- fp16 rounding of U (flat_utils.py:15); C fragment -> A fragment of GEMM 2, no data movement ----
@@ -267,8 +315,8 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                 float a = fmaxf(t[0], t[1]), b = fminf(t[0], t[1]);
 #pragma unroll
                 for (int r = 2; r < 16; r += 2) {
-                    a = fmaxf(fmaxf(a, t[r]), t[r + 1]);
-                    b = fminf(fminf(b, t[r]), t[r + 1]);
+                    a = fq_max3(a, t[r], t[r + 1]);
+                    b = fq_min3(b, t[r], t[r + 1]);
                 }
                 pmax[k] = a;
                 pmin[k] = b;
@@ -305,11 +353,12 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
 #pragma unroll
                             for (int w = 0; w < 4; ++w) {
                                 float dmax = 0.0f;
-                                pw[mo][w] = fq_pack8(
-                                    fq_qfast(FQ_YV(mo, w, 0), inv, dmax), fq_qfast(FQ_YV(mo, w, 1), inv, dmax),
-                                    fq_qfast(FQ_YV(mo, w, 2), inv, dmax), fq_qfast(FQ_YV(mo, w, 3), inv, dmax),
-                                    fq_qfast(FQ_YV(mo, w, 4), inv, dmax), fq_qfast(FQ_YV(mo, w, 5), inv, dmax),
-                                    fq_qfast(FQ_YV(mo, w, 6), inv, dmax), fq_qfast(FQ_YV(mo, w, 7), inv, dmax));
+                                const f32x2 inv2 = {inv, inv};
+                                const f32x2 q01 = fq_qfast2(f32x2{FQ_YV(mo, w, 0), FQ_YV(mo, w, 1)}, inv2, dmax);
+                                const f32x2 q23 = fq_qfast2(f32x2{FQ_YV(mo, w, 2), FQ_YV(mo, w, 3)}, inv2, dmax);
+                                const f32x2 q45 = fq_qfast2(f32x2{FQ_YV(mo, w, 4), FQ_YV(mo, w, 5)}, inv2, dmax);
+                                const f32x2 q67 = fq_qfast2(f32x2{FQ_YV(mo, w, 6), FQ_YV(mo, w, 7)}, inv2, dmax);
+                                pw[mo][w] = fq_pack8(q01.x, q01.y, q23.x, q23.y, q45.x, q45.y, q67.x, q67.y);
                                 near |= fq_wave_needs_exact(dmax) ? (1u << (4 * mo + w)) : 0u;   // SALU only
                             }
                         if (near) {  // rare (~3 % of tokens): redo the flagged dwords with the true division
@@ -375,6 +424,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                 tr_epi += c4 - c3;
             }
         }
+        slot = next_pulled;
     }
     if (TRACE && lane == 0) {
         trace[n_waves * 4 + wave_id * 2 + 0] = tr_start;                       // absolute start / end stamps
