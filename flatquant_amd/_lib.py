@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfqhip.so")
+LIB_PATH = os.environ.get("FQHIP_LIB", os.path.join(_HERE, "lib", "libfqhip.so"))  # FQHIP_LIB: A/B builds
 
 # flags (include/fqhip.h)
 FQ_OUT_PACKED = 0x01

@@ -41,14 +41,45 @@ template <int CTRL>
 __device__ __forceinline__ float fq_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-struct FqMaxOp { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
-struct FqMinOp { __device__ __forceinline__ float operator()(float a, float b) const { return fminf(a, b); } };
+// One instruction per reduction step: v_max/min_f32 with a DPP source. (Through fmaxf + update_dpp hipcc emits a
+// v_mov_dpp, a canonicalising v_max x,x and the v_max: 3 VALU per step.) "s_nop 1": a VALU write needs 2 wait
+// states before a DPP read of the same register.
+#define FQ_DPP_STEP(OPNAME, CTRLSTR)                                                                     \
+    asm("s_nop 1\n\t" OPNAME " %0, %1, %1 " CTRLSTR " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v)); \
+    v = r;
+struct FqMaxOp {
+    __device__ __forceinline__ float operator()(float a, float b) const {
+        float d;
+        asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+        return d;
+    }
+    __device__ __forceinline__ float row(float v) const {
+        float r;
+        FQ_DPP_STEP("v_max_f32_dpp", "quad_perm:[1,0,3,2]")
+        FQ_DPP_STEP("v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+        FQ_DPP_STEP("v_max_f32_dpp", "row_half_mirror")
+        FQ_DPP_STEP("v_max_f32_dpp", "row_mirror")
+        return v;
+    }
+};
+struct FqMinOp {
+    __device__ __forceinline__ float operator()(float a, float b) const {
+        float d;
+        asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+        return d;
+    }
+    __device__ __forceinline__ float row(float v) const {
+        float r;
+        FQ_DPP_STEP("v_min_f32_dpp", "quad_perm:[1,0,3,2]")
+        FQ_DPP_STEP("v_min_f32_dpp", "quad_perm:[2,3,0,1]")
+        FQ_DPP_STEP("v_min_f32_dpp", "row_half_mirror")
+        FQ_DPP_STEP("v_min_f32_dpp", "row_mirror")
+        return v;
+    }
+};
 template <class Op>
 __device__ __forceinline__ float fq_wave_reduce(float v, Op op) {
-    v = op(v, fq_dpp<0xB1>(v));   // quad_perm [1,0,3,2]
-    v = op(v, fq_dpp<0x4E>(v));   // quad_perm [2,3,0,1]
-    v = op(v, fq_dpp<0x141>(v));  // row_half_mirror: the other quad of each 8
-    v = op(v, fq_dpp<0x140>(v));  // row_mirror: the other half of each row
+    v = op.row(v);  // every lane of a 16-lane row now holds the row's result
     // v_permlane16_swap: odd rows of the first register <-> even rows of the second; v_permlane32_swap: upper
     // half of the first <-> lower half of the second. Written as inline asm on two explicit registers: with
     // the builtin hipcc (ROCm 7.2) folds the two results into one when both inputs hold the same value.

@@ -36,8 +36,16 @@ constexpr int KM = 64, KN = 64, KD = KM * KN;
 constexpr int FRAG_BYTES = 16 * 64 * 16;  // 16 fragments x 64 lanes x 16 B
 constexpr int TOK_BYTES = KD * 2;         // 8192
 
+#ifndef FQ_K64_ABLATE
+#define FQ_K64_ABLATE 0  // measurement builds only: bit 0 = no MFMA, bit 1 = no quantiser arithmetic, bit 2 = no DMA
+#endif
 __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+#if FQ_K64_ABLATE & 1
+    c[0] += (float)a[0] + (float)b[0];
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
 }
 
 // physical column n' held at (n-tile nt, tile position pos) of GEMM-1's output / GEMM-2's output rows.
@@ -55,7 +63,10 @@ template <int FLAGS>
 constexpr int kron64_threads() {
     constexpr int outs = ((FLAGS & FQ_OUT_PACKED) ? 1 : 0) + ((FLAGS & FQ_OUT_FAKEQUANT) ? 1 : 0) +
                          ((FLAGS & FQ_OUT_TRANSFORM) ? 1 : 0);
-    return (outs == 1 && !(FLAGS & FQ_QUANT_F16)) ? 1024 : 512;
+#ifndef FQ_K64_THREADS
+#define FQ_K64_THREADS 1024
+#endif
+    return (outs == 1 && !(FLAGS & FQ_QUANT_F16)) ? FQ_K64_THREADS : 512;
 }
 
 // TRACE (debug build of the same kernel, fq_debug_kron64_trace): lane 0 of every wave accumulates s_memtime
@@ -82,6 +93,9 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #define FQ_DMA_INST_OFFSET 1  // 1: the instruction's offset field advances BOTH the global and the LDS address
 #endif
 __device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok, unsigned lds_base, int lane) {
+#if FQ_K64_ABLATE & 4
+    return;  // measurement build: no HBM reads (compute on whatever is in LDS)
+#endif
     // (row>>1)&7 of row 8i + (lane>>3) is (4i + (lane>>4)) & 7 = 4(i&1) + (lane>>4): the chunk swizzle only depends
     // on the parity of i -> two per-lane offsets, everything else is immediates and scalars.
     const unsigned ce = ((lane & 7) ^ (lane >> 4)) << 4;
@@ -196,6 +210,14 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     const int lane_off = c * KN + h * 32;  // same element offset in HBM (used by diag and by the outputs)
     bool first = true;
     int next_pulled = 0;
+#ifndef FQ_K64_REGFRAG
+#define FQ_K64_REGFRAG 0  // 1: keep the 16 B-operand fragments in 64 VGPRs (needs the 512-thread build)
+#endif
+#if FQ_K64_REGFRAG
+    f16x8 FR[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) FR[f] = __builtin_bit_cast(f16x8, frag[f * 64 + lane]);
+#endif
 
     while (slot < blk_cnt) {
         const int64_t tok = blk_base + slot;
@@ -234,12 +256,22 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
         }
 
         // ---- GEMM 1: U[mt][nt] = X(mt,:) . R(:, nt); four independent accumulator chains ----
+        // Matrix phases run at raised priority: an MFMA needs one issue slot per 32 cycles, so letting it win the
+        // arbitration keeps the matrix pipe fed while the other waves' VALU work (quantiser) fills the gaps.
+#ifndef FQ_K64_PRIO
+#define FQ_K64_PRIO 2
+#endif
+        __builtin_amdgcn_s_setprio(FQ_K64_PRIO);
         f32x16 U[2][2];
         U[0][0] = f32x16{0}; U[0][1] = f32x16{0}; U[1][0] = f32x16{0}; U[1][1] = f32x16{0};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+#if FQ_K64_REGFRAG
+            const f16x8 b0 = FR[0 * 4 + s], b1 = FR[1 * 4 + s];
+#else
             const f16x8 b0 = __builtin_bit_cast(f16x8, myfrag[(0 * 4 + s) * 64]);
             const f16x8 b1 = __builtin_bit_cast(f16x8, myfrag[(1 * 4 + s) * 64]);
+#endif
             U[0][0] = mfma32(__builtin_bit_cast(f16x8, X[0][s]), b0, U[0][0]);
             U[1][0] = mfma32(__builtin_bit_cast(f16x8, X[1][s]), b0, U[1][0]);
             U[0][1] = mfma32(__builtin_bit_cast(f16x8, X[0][s]), b1, U[0][1]);
@@ -273,13 +305,18 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
         Y[0][0] = f32x16{0}; Y[0][1] = f32x16{0}; Y[1][0] = f32x16{0}; Y[1][1] = f32x16{0};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+#if FQ_K64_REGFRAG
+            const f16x8 b0 = FR[8 + ks * 2 + 0], b1 = FR[8 + ks * 2 + 1];
+#else
             const f16x8 b0 = __builtin_bit_cast(f16x8, myfrag[(8 + ks * 2 + 0) * 64]);
             const f16x8 b1 = __builtin_bit_cast(f16x8, myfrag[(8 + ks * 2 + 1) * 64]);
+#endif
             Y[0][0] = mfma32(Uh[0][ks], b0, Y[0][0]);
             Y[1][0] = mfma32(Uh[1][ks], b0, Y[1][0]);
             Y[0][1] = mfma32(Uh[0][ks], b1, Y[0][1]);
             Y[1][1] = mfma32(Uh[1][ks], b1, Y[1][1]);
         }
+        __builtin_amdgcn_s_setprio(0);
 
         if (out.rt_flags & FQ_ROUND_Y_F16) {
 #pragma unroll
@@ -312,7 +349,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const f32x16& t = Y[k >> 1][k & 1];
-                float a = fmaxf(t[0], t[1]), b = fminf(t[0], t[1]);
+                float a = FqMaxOp()(t[0], t[1]), b = FqMinOp()(t[0], t[1]);
 #pragma unroll
                 for (int r = 2; r < 16; r += 2) {
                     a = fq_max3(a, t[r], t[r + 1]);
@@ -321,8 +358,8 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                 pmax[k] = a;
                 pmin[k] = b;
             }
-            float vmax = fmaxf(fmaxf(pmax[0], pmax[1]), fmaxf(pmax[2], pmax[3]));
-            float vmin = fminf(fminf(pmin[0], pmin[1]), fminf(pmin[2], pmin[3]));
+            float vmax = fq_max3(pmax[0], pmax[1], FqMaxOp()(pmax[2], pmax[3]));
+            float vmin = fq_min3(pmin[0], pmin[1], FqMinOp()(pmin[2], pmin[3]));
             vmax = fq_wave_max(vmax);
             vmin = fq_wave_min(vmin);
             FQ_TICK(c3)
@@ -353,12 +390,20 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
 #pragma unroll
                             for (int w = 0; w < 4; ++w) {
                                 float dmax = 0.0f;
+#if FQ_K64_ABLATE & 2
+                                pw[mo][w] = __builtin_bit_cast(unsigned, FQ_YV(mo, w, 0)) ^ __builtin_bit_cast(unsigned, FQ_YV(mo, w, 1)) ^
+                                            __builtin_bit_cast(unsigned, FQ_YV(mo, w, 2)) ^ __builtin_bit_cast(unsigned, FQ_YV(mo, w, 3)) ^
+                                            __builtin_bit_cast(unsigned, FQ_YV(mo, w, 4)) ^ __builtin_bit_cast(unsigned, FQ_YV(mo, w, 5)) ^
+                                            __builtin_bit_cast(unsigned, FQ_YV(mo, w, 6)) ^ __builtin_bit_cast(unsigned, FQ_YV(mo, w, 7)) ^
+                                            __builtin_bit_cast(unsigned, inv);
+#else
                                 const f32x2 inv2 = {inv, inv};
                                 const f32x2 q01 = fq_qfast2(f32x2{FQ_YV(mo, w, 0), FQ_YV(mo, w, 1)}, inv2, dmax);
                                 const f32x2 q23 = fq_qfast2(f32x2{FQ_YV(mo, w, 2), FQ_YV(mo, w, 3)}, inv2, dmax);
                                 const f32x2 q45 = fq_qfast2(f32x2{FQ_YV(mo, w, 4), FQ_YV(mo, w, 5)}, inv2, dmax);
                                 const f32x2 q67 = fq_qfast2(f32x2{FQ_YV(mo, w, 6), FQ_YV(mo, w, 7)}, inv2, dmax);
                                 pw[mo][w] = fq_pack8(q01.x, q01.y, q23.x, q23.y, q45.x, q45.y, q67.x, q67.y);
+#endif
                                 near |= fq_wave_needs_exact(dmax) ? (1u << (4 * mo + w)) : 0u;   // SALU only
                             }
                         if (near) {  // rare (~3 % of tokens): redo the flagged dwords with the true division
