@@ -55,6 +55,17 @@ def make_matrices(device):
     return mats
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC run (tools/prof.sh: separate
+    --pmc passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled per the gfx950 correction). None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_kron64_pmc.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(max_seconds=20.0):
     """The reference's CPU fake-quant path (flat_utils.py:6-17 + quant_utils.py:71-119), restated in torch by
     oracle/path_a_torch.py, on a bounded sample: C1-sized batches (2048 x 4096 fp16) for <= ~20 s."""
@@ -163,6 +174,20 @@ def main():
     wall = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps             # average launch duration from HIP events
 
+    # practical HBM floor: the same bytes (8 KB in, 2 KB + 2 B out per token) moved by a no-arithmetic kernel
+    floor_us = None
+    if rank == 0:
+        for i in range(5):
+            ops.probe_stream_4096(xs[i % N_BUF], qs[i % N_BUF], ss[i % N_BUF])
+        torch.cuda.synchronize()
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record(stream)
+        for i in range(50):
+            ops.probe_stream_4096(xs[i % N_BUF], qs[i % N_BUF], ss[i % N_BUF])
+        f1.record(stream)
+        torch.cuda.synchronize()
+        floor_us = f0.elapsed_time(f1) / 50 * 1e3
+
     t = torch.tensor([wall, kern_ms], dtype=torch.float64, device=device)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)             # MAX over ranks
@@ -181,9 +206,10 @@ def main():
                                    "8x2048 tokens per GPU, packed INT4 + fp16 scale out",
                        "rows_per_gpu": ROWS, "d": D, "factors": [M, N], "parallelism": f"rows x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
                          "kernel": "fq_kron64_kernel", "algorithmic_bytes_per_launch": ROWS * BYTES_PER_TOKEN,
-                         "launch_us": kern_ms * 1e3},
+                         "launch_us": kern_ms * 1e3, "hbm_stream_floor_us": floor_us,
+                         "frac_of_stream_floor": (floor_us / (kern_ms * 1e3)) if floor_us else None},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Timing table for the other hot-path rows / BASELINE configs (C3-C5 pieces) on one MI355X.
+Each line: kernel, shape, us per launch (HIP events, 50 launches, buffers rotated), algorithmic GB/s, Melem/s."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from flatquant_amd import ops  # noqa: E402
+from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_FAKEQUANT, FQ_OUT_PACKED, FQ_QUANT_F16, FQ_ROUND_Y_F16  # noqa: E402
+from flatquant_amd.flatquant.function_utils import get_decompose_dim  # noqa: E402
+from flatquant_amd.flatquant.hadamard_utils import get_hadK  # noqa: E402
+
+ROWS = 16384
+NB = 3
+
+
+def timeit(fn, steps=50, warm=5):
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(steps):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps * 1e3
+
+
+def line(name, shape, us, bytes_per_row, d, rows=ROWS):
+    print(f"{name:34s} {shape:22s} {us:9.1f} us  {rows * bytes_per_row / us / 1e3:8.0f} GB/s  {rows * d / us:10.0f} Melem/s")
+
+
+def main():
+    g = torch.Generator(device="cuda").manual_seed(0)
+    sig = [(0.982, 0.982)]
+    for d in (4096, 8192, 14336, 28672, 11008, 7168, 2048):
+        M, N = get_decompose_dim(d)
+        rows = ROWS if d <= 14336 else ROWS // 2
+        xs = [torch.randn(rows, d, generator=g, device="cuda", dtype=torch.float16) for _ in range(NB)]
+        L = (torch.randn(M, M, generator=g, device="cuda") / M ** 0.5).half()
+        R = (torch.randn(N, N, generator=g, device="cuda") / N ** 0.5).half()
+        us = timeit(lambda i: ops.kron_quant(xs[i % NB], L, R, sig, FQ_OUT_PACKED | FQ_NO_CLAMP0))
+        line("kron+quant packed", f"d={d} ({M}x{N}) rows={rows}", us, 2.5 * d + 2, d, rows)
+        if d in (4096, 14336):
+            us = timeit(lambda i: ops.kron_quant(xs[i % NB], L, R, sig, FQ_OUT_FAKEQUANT | FQ_ROUND_Y_F16))
+            line("kron+fake-quant fp16", f"d={d} ({M}x{N}) rows={rows}", us, 4.0 * d, d, rows)
+            us = timeit(lambda i: ops.kron_quant(xs[i % NB], L, R, sig * 3, FQ_OUT_PACKED | FQ_NO_CLAMP0))
+            line("kron+quant packed, 3 clip sets", f"d={d} ({M}x{N}) rows={rows}", us, 2.0 * d + 3 * (0.5 * d + 2), d, rows)
+        if d in (4096, 14336, 28672, 11008):
+            hk, K = get_hadK(d)
+            hk = None if hk is None else hk.half().cuda()
+            us = timeit(lambda i: ops.hadamard(xs[i % NB], K, hk))
+            line("hadamard fp16 out", f"n={d} (K={K}) rows={rows}", us, 4.0 * d, d, rows)
+            us = timeit(lambda i: ops.rowquant(xs[i % NB], sig, FQ_OUT_PACKED | FQ_QUANT_F16))
+            line("rowquant packed (Quantizer)", f"cols={d} rows={rows}", us, 2.5 * d + 2, d, rows)
+        del xs
+    for hd, H in ((128, 32), (128, 64)):
+        xs = [torch.randn(ROWS, hd, H, generator=g, device="cuda", dtype=torch.float16) for _ in range(NB)]
+        P = (torch.randn(H, H, generator=g, device="cuda") / H ** 0.5).half()
+        us = timeit(lambda i: ops.block_quant(xs[i % NB], P, sig, FQ_OUT_PACKED | FQ_NO_CLAMP0, True))
+        line("block (o_proj) + quant packed", f"hd={hd} H={H}", us, 2.5 * hd * H + 2, hd * H)
+        del xs
+
+
+if __name__ == "__main__":
+    main()
