@@ -12,6 +12,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The shared library is a build artefact (git-ignored). Build it once if this checkout does not have it yet and a
+    # hipcc is around (it cross-compiles gfx950 without a GPU); the tests themselves never fall back to anything else.
+    lib = os.path.join(ROOT, "flatquant_amd", "lib", "libfqhip.so")
+    if not os.path.exists(lib):
+        import shutil
+        import subprocess
+        if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+            env = dict(os.environ, PATH=os.environ.get("PATH", "") + ":/opt/rocm/bin")
+            subprocess.run(["make", "-C", os.path.join(ROOT, "flatquant_amd", "csrc"), "-j8"], check=True, env=env)
 
 
 def pytest_collection_modifyitems(config, items):
