@@ -286,7 +286,9 @@ int launch_generic(int flags, const f16* x, const uint4* ws, const f16* diag, in
                                   160 * 1024);
         attr_set = true;
     }
-    const int per_cu = lds <= 80 * 1024 ? 2 : 1;  // workgroups that fit a CU's 160 KB of LDS (cap 2)
+    int per_cu = (int)((160 * 1024) / lds);  // workgroups that fit a CU's 160 KB of LDS: they overlap each other's
+    if (per_cu > 4) per_cu = 4;              // synchronous token load with compute
+    if (per_cu < 1) per_cu = 1;
     int64_t blocks = (int64_t)n_cu * per_cu;
     if (blocks > rows) blocks = rows;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, x, ws, diag, rows, g, out, flags);
