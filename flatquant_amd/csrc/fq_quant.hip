@@ -148,9 +148,114 @@ __global__ __launch_bounds__(256) void fq_sym_dequant_kernel(const int32_t* __re
     }
 }
 
+// Wave-per-row variant for cols <= 64 * 8 * NCH: the whole row sits in one wave's registers (NCH 16-byte chunks per
+// lane, all loads issued back to back), max/min by a register wave all-reduce, no LDS and no workgroup barrier.
+// (The one-workgroup-per-row kernel above keeps only 2 loads per lane in flight and pays two barriers per row:
+// 55 us for 16384 x 4096, where moving the same bytes takes 28 us.) Rows are handed out grid-stride per wave.
+template <int FLAGS, int NCH>
+__global__ __launch_bounds__(256) void fq_rowquant_wave_kernel(const f16* __restrict__ x, int64_t rows, int cols,
+                                                               FqQuantOut out) {
+    const int lane = threadIdx.x & 63;
+    const int nchunks = cols >> 3;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nw) {
+        const u32x4* xp = reinterpret_cast<const u32x4*>(x + row * (int64_t)cols);
+        f16x8 v[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + k * 64;
+            v[k] = (ch < nchunks) ? __builtin_bit_cast(f16x8, __builtin_nontemporal_load(xp + ch)) : f16x8{0};
+        }
+        float vmax = -INFINITY, vmin = INFINITY;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (lane + k * 64 < nchunks) {
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    vmax = fq_max3(vmax, (float)v[k][e], (float)v[k][e + 1]);
+                    vmin = fq_min3(vmin, (float)v[k][e], (float)v[k][e + 1]);
+                }
+            }
+        }
+        vmax = fq_wave_max(vmax);
+        vmin = fq_wave_min(vmin);
+        for (int ci = 0; ci < out.n_clips; ++ci) {
+            const float scale = fq_token_scale<FLAGS>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
+            const float inv = 1.0f / scale;
+            if (FLAGS & FQ_OUT_PACKED) {
+                if (lane == 0) out.scale[ci][row] = (f16)scale;
+                uint32_t* qp = reinterpret_cast<uint32_t*>(out.q[ci] + row * (int64_t)(cols >> 1));
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const int ch = lane + k * 64;
+                    uint32_t d;
+                    if (FLAGS & FQ_QUANT_F16) {
+                        d = 0;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) d |= (uint32_t)(fq_quant1<FLAGS>((float)v[k][e], scale) & 15) << (4 * e);
+                    } else {
+                        float dmax = 0.0f;
+                        const f32x2 inv2 = {inv, inv};
+                        const f32x2 q01 = fq_qfast2(f32x2{(float)v[k][0], (float)v[k][1]}, inv2, dmax);
+                        const f32x2 q23 = fq_qfast2(f32x2{(float)v[k][2], (float)v[k][3]}, inv2, dmax);
+                        const f32x2 q45 = fq_qfast2(f32x2{(float)v[k][4], (float)v[k][5]}, inv2, dmax);
+                        const f32x2 q67 = fq_qfast2(f32x2{(float)v[k][6], (float)v[k][7]}, inv2, dmax);
+                        d = fq_pack8(q01.x, q01.y, q23.x, q23.y, q45.x, q45.y, q67.x, q67.y);
+                        if (fq_wave_needs_exact(dmax))
+                            d = fq_pack8(fq_qexact((float)v[k][0], scale), fq_qexact((float)v[k][1], scale),
+                                         fq_qexact((float)v[k][2], scale), fq_qexact((float)v[k][3], scale),
+                                         fq_qexact((float)v[k][4], scale), fq_qexact((float)v[k][5], scale),
+                                         fq_qexact((float)v[k][6], scale), fq_qexact((float)v[k][7], scale));
+                    }
+                    if (ch < nchunks) qp[ch] = d;
+                }
+            }
+            if (FLAGS & FQ_OUT_FAKEQUANT) {
+                uint4* fp = reinterpret_cast<uint4*>(out.fq[ci] + row * (int64_t)cols);
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const int ch = lane + k * 64;
+                    f16x8 o;
+                    if (FLAGS & FQ_QUANT_F16) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            o[e] = fq_dequant1<FLAGS>(fq_quant1<FLAGS>((float)v[k][e], scale), scale);
+                    } else {
+                        float dmax = 0.0f;
+                        float r[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) r[e] = fq_qfast((float)v[k][e], inv, dmax);
+                        if (fq_wave_needs_exact(dmax)) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) r[e] = fq_qexact((float)v[k][e], scale);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = fq_mul_to_f16(scale, r[e]);
+                    }
+                    if (ch < nchunks) fp[ch] = __builtin_bit_cast(uint4, o);
+                }
+            }
+        }
+    }
+}
+
 template <int FLAGS>
 int launch_rowquant(const f16* x, int64_t rows, int cols, const FqQuantOut& out, int n_cu,
                     hipStream_t stream) {
+    {   // wave-per-row fast path: the row fits one wave's registers (up to 32 chunks of 16 bytes per lane)
+        const int nchw = ((cols >> 3) + 63) / 64;
+        int64_t wb = (rows + 3) / 4;
+        if (wb > (int64_t)n_cu * 8) wb = (int64_t)n_cu * 8;
+        if (wb < 1) wb = 1;
+#define FQ_RW(N)                                                                                                  \
+    if (nchw <= (N)) {                                                                                            \
+        hipLaunchKernelGGL((fq_rowquant_wave_kernel<FLAGS, (N)>), dim3((unsigned)wb), dim3(256), 0, stream, x, rows, \
+                           cols, out);                                                                            \
+        return (int)hipGetLastError();                                                                            \
+    }
+        FQ_RW(4) FQ_RW(8) FQ_RW(16) FQ_RW(24)  // beyond 24 chunks per lane the one-workgroup-per-row kernel measured faster
+#undef FQ_RW
+    }
     const int nch = ((cols >> 3) + RQ_THREADS - 1) / RQ_THREADS;
     int64_t blocks = rows;
     const int64_t cap = (int64_t)n_cu * 8;
