@@ -107,8 +107,8 @@ def cpu_baseline(max_seconds=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

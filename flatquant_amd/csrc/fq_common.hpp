@@ -199,6 +199,49 @@ __device__ __forceinline__ f32x2 fq_qfast2(f32x2 y, f32x2 inv2, float& dmax) {
     return r;
 }
 
+// Cheaper form of the same test (2 VALU per element instead of 2.5, 3 with the clamp): round with the
+// magic-number add instead of v_rndne. u = fma(y, inv, 1.5*2^23) is the EXACT product y*inv rounded to an integer
+// (the ulp of u is 1 for |y*inv| < 2^22), r = u - magic is that integer, e = fma(y, inv, -r) the exact residual
+// rounded once. |e| <= 0.5 - FQ_NEAR proves rint(fl(y/s)) == r by the same argument as above (y*inv differs from
+// y/s, and fl(y/s) from y/s, by <= |t| 2^-24 each). Callers guarantee |y*inv| < 2^21 (fq_magic_ok) and, for
+// CLAMP == false, that every quotient of the token rounds into [-8, 7] (fq_needs_clamp).
+constexpr float FQ_MAGIC = 12582912.0f;
+template <bool CLAMP>
+__device__ __forceinline__ f32x2 fq_qmagic2(f32x2 y, f32x2 inv2, float& dmax) {
+    const f32x2 magic = {FQ_MAGIC, FQ_MAGIC};
+    const f32x2 u = __builtin_elementwise_fma(y, inv2, magic);
+    f32x2 r = u - magic;
+    const f32x2 e = __builtin_elementwise_fma(y, inv2, -r);
+    dmax = fq_max3_abs(dmax, e.x, e.y);
+    if (CLAMP) {
+        r.x = __builtin_amdgcn_fmed3f(r.x, -8.0f, 7.0f);
+        r.y = __builtin_amdgcn_fmed3f(r.y, -8.0f, 7.0f);
+    }
+    return r;
+}
+// token-uniform guards for fq_qmagic2 (vmax / vmin: the token's raw extremes, inv = 1/scale > 0)
+__device__ __forceinline__ bool fq_magic_ok(float vmax, float vmin, float inv) {
+    return fmaxf(vmax, -vmin) * inv < 2097152.0f;
+}
+__device__ __forceinline__ bool fq_needs_clamp(float vmax, float vmin, float inv) {
+    return !(vmax * inv < 7.49f && vmin * inv > -8.49f);
+}
+
+// Eight integer-valued floats in [-8, 7], given as the pairs p_j = (r_2j, r_2j+1), -> one dword of
+// two's-complement nibbles. Two packed fmas build (r0 + 256 r2, r1 + 256 r3) and the same for r4..r7, one fma
+// each interleaves them into a signed 16-bit digit string, and adding 1.5*2^23 + 0x8888 leaves the offset-binary
+// 16-bit value in the low mantissa bits (everything is an integer < 2^24, so every step is exact).
+__device__ __forceinline__ uint32_t fq_pack8p(f32x2 p0, f32x2 p1, f32x2 p2, f32x2 p3) {
+    const f32x2 c256 = {256.0f, 256.0f};
+    const f32x2 lo = __builtin_elementwise_fma(p1, c256, p0);
+    const f32x2 hi = __builtin_elementwise_fma(p3, c256, p2);
+    // (kept as two scalars: with both halves in one f32x2, hipcc 7.2 folds the v_perm_b32 below onto a single source)
+    const float wl = __builtin_fmaf(lo.y, 16.0f, lo.x) + (FQ_MAGIC + 34952.0f);
+    const float wh = __builtin_fmaf(hi.y, 16.0f, hi.x) + (FQ_MAGIC + 34952.0f);
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, wh), __builtin_bit_cast(uint32_t, wl), 0x05040100u) ^
+           0x88888888u;
+}
+
 __device__ __forceinline__ float fq_qfast(float y, float inv, float& dmax) {
     const float t = y * inv;
     const float r = __builtin_rintf(t);

@@ -37,7 +37,7 @@ constexpr int FRAG_BYTES = 16 * 64 * 16;  // 16 fragments x 64 lanes x 16 B
 constexpr int TOK_BYTES = KD * 2;         // 8192
 
 #ifndef FQ_K64_NT_STORE
-#define FQ_K64_NT_STORE 1  // non-temporal packed-output stores (write-once stream; A/B: 41.0 vs 41.9 us)
+#define FQ_K64_NT_STORE 0  // 1: non-temporal packed-output stores. A/B (tools/time_variants.py): plain stores 1.7 us faster
 #endif
 #ifndef FQ_K64_ABLATE
 #define FQ_K64_ABLATE 0  // measurement builds only: bit 0 = no MFMA, bit 1 = no quantiser arithmetic, bit 2 = no DMA
@@ -92,6 +92,14 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // the prefetch right after issuing it. The asm form is invisible to its counters; completion is waited for by
 // the COUNTED s_waitcnt at the top of the token loop. M0 (LDS base of the DMA) is saved/restored because the
 // compiler owns it.
+#ifndef FQ_K64_NT_LOAD
+#define FQ_K64_NT_LOAD 1  // token DMAs carry the nt (streaming) hint: x is read exactly once
+#endif
+#if FQ_K64_NT_LOAD
+#define FQ_DMA_NT "nt"
+#else
+#define FQ_DMA_NT ""
+#endif
 #ifndef FQ_DMA_INST_OFFSET
 #define FQ_DMA_INST_OFFSET 1  // 1: the instruction's offset field advances BOTH the global and the LDS address
 #endif
@@ -117,16 +125,16 @@ __device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %5\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %3 nt\n\t"
-        "global_load_lds_dwordx4 %2, %3 offset:1024 nt\n\t"
-        "global_load_lds_dwordx4 %1, %3 offset:2048 nt\n\t"
-        "global_load_lds_dwordx4 %2, %3 offset:3072 nt\n\t"
+        "global_load_lds_dwordx4 %1, %3 " FQ_DMA_NT "\n\t"
+        "global_load_lds_dwordx4 %2, %3 offset:1024 " FQ_DMA_NT "\n\t"
+        "global_load_lds_dwordx4 %1, %3 offset:2048 " FQ_DMA_NT "\n\t"
+        "global_load_lds_dwordx4 %2, %3 offset:3072 " FQ_DMA_NT "\n\t"
         "s_mov_b32 m0, %6\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %4 nt\n\t"
-        "global_load_lds_dwordx4 %2, %4 offset:1024 nt\n\t"
-        "global_load_lds_dwordx4 %1, %4 offset:2048 nt\n\t"
-        "global_load_lds_dwordx4 %2, %4 offset:3072 nt\n\t"
+        "global_load_lds_dwordx4 %1, %4 " FQ_DMA_NT "\n\t"
+        "global_load_lds_dwordx4 %2, %4 offset:1024 " FQ_DMA_NT "\n\t"
+        "global_load_lds_dwordx4 %1, %4 offset:2048 " FQ_DMA_NT "\n\t"
+        "global_load_lds_dwordx4 %2, %4 offset:3072 " FQ_DMA_NT "\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(voff_e), "v"(voff_o), "s"(sb0), "s"(sb1), "s"(lds_base), "s"(lds_base + 4096)
@@ -149,21 +157,76 @@ __device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok
 #endif
 }
 
+// Fast quantiser over one token's fragment (see fq_qmagic2): fills the 2 x 4 packed dwords this lane stores and
+// returns the mask of dwords (bit 4*mo + w) that some lane of the wave wants redone with the true division.
+template <bool CLAMP>
+__device__ __forceinline__ unsigned quant_pack_token(const f32x16 (&Y)[2][2], float inv, uint32_t (&pw)[2][4]) {
+    const f32x2 inv2 = {inv, inv};
+    unsigned near = 0;
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const f32x16& t = Y[w >> 1][mo];
+            const int b = (w & 1) * 8;
+            float dmax = 0.0f;
+            const f32x2 q01 = fq_qmagic2<CLAMP>(f32x2{t[b + 0], t[b + 1]}, inv2, dmax);
+            const f32x2 q23 = fq_qmagic2<CLAMP>(f32x2{t[b + 2], t[b + 3]}, inv2, dmax);
+            const f32x2 q45 = fq_qmagic2<CLAMP>(f32x2{t[b + 4], t[b + 5]}, inv2, dmax);
+            const f32x2 q67 = fq_qmagic2<CLAMP>(f32x2{t[b + 6], t[b + 7]}, inv2, dmax);
+            pw[mo][w] = fq_pack8p(q01, q23, q45, q67);
+            near |= fq_wave_needs_exact(dmax) ? (1u << (4 * mo + w)) : 0u;  // SALU only
+        }
+    return near;
+}
+
+// Take the next token of the workgroup's range and start its DMA into this wave's (already drained) buffer.
+// FQ_K64_PULL_AT (measurement knob) picks the point of the iteration: 0 = behind GEMM 1's first K-step (all eight
+// X fragments were requested before the first MFMA, so the buffer is free), 1 = after GEMM 1, 2 = after GEMM 2,
+// 3 = after the statistics. Measured round-robin in one process (tools/time_variants.py, C2): 0: 35.7 us (+-0.4),
+// 3: 39.4 us with 4 us of run-to-run spread -- the DMA wants the whole iteration to land.
+#ifndef FQ_K64_PULL_AT
+#define FQ_K64_PULL_AT 0
+#endif
+template <int FLAGS>
+constexpr int kron64_pull_at() {
+    return FQ_K64_PULL_AT;
+}
+#define FQ_PULL_NEXT()                                                       \
+    {                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
+        int nxt = slot + WAVES;                                              \
+        if (!FQ_K64_STATIC) {                                                \
+            if (lane == 0) nxt = (int)atomicAdd(next_slot, 1u);              \
+            nxt = __builtin_amdgcn_readfirstlane(nxt);                       \
+        }                                                                    \
+        if (nxt < blk_cnt) dma_token(x, blk_base + nxt, tok_lds, lane);      \
+        next_pulled = nxt;                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+    }
+
 template <int FLAGS, bool TRACE = false>
 __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(const f16* __restrict__ x,
                                                            const f16* __restrict__ left,
                                                            const f16* __restrict__ right,
                                                            const f16* __restrict__ diag,
-                                                           int64_t rows, FqQuantOut out,
+                                                           int64_t rows, int64_t tpb, FqQuantOut out,
                                                            unsigned long long* __restrict__ trace) {
     constexpr int THREADS = kron64_threads<FLAGS>();
     constexpr int WAVES = THREADS / 64;
+    constexpr int PULL_AT = kron64_pull_at<FLAGS>();
+    static_assert(PULL_AT != 3 || (FLAGS & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)), "no statistics phase to pull behind");
     // output stores a single-clip packed token issues after its DMA (2 x 16 B + the scale): lets the top-of-loop
     // wait be a COUNTED vmcnt that does not also wait for the previous token's stores to reach memory.
     constexpr bool COUNTED_WAIT = (FLAGS & FQ_CT_MASK) == FQ_OUT_PACKED;
     unsigned long long tr_wait = 0, tr_g1 = 0, tr_g2 = 0, tr_epi = 0;
     const unsigned long long tr_start = TRACE ? __builtin_amdgcn_s_memtime() : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[FRAG_BYTES + WAVES * TOK_BYTES + 16];
+    const unsigned long long tr_start_rt = TRACE ? __builtin_amdgcn_s_memrealtime() : 0;  // 100 MHz, chip-wide
+#ifndef FQ_K64_STATIC
+#define FQ_K64_STATIC 0  // 1: waves take tokens wave, wave + WAVES, ... of the workgroup's range (no LDS counter)
+#endif
+    __shared__ __attribute__((aligned(16))) unsigned char smem[FRAG_BYTES + WAVES * TOK_BYTES + (FQ_K64_STATIC ? 0 : 16)];
     unsigned* next_slot = reinterpret_cast<unsigned*>(smem + FRAG_BYTES + WAVES * TOK_BYTES);  // work counter
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -175,43 +238,109 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     unsigned char* tokbuf = smem + FRAG_BYTES + wave * TOK_BYTES;  // wave-private, wave-uniform address
     const unsigned tok_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)tokbuf);
 
-    // First token's HBM->LDS DMA goes out BEFORE the fragment gather below, so its latency hides behind it.
-    // Tokens: workgroup b owns the contiguous range [blk_base, blk_base + blk_cnt); its waves PULL tokens from a
-    // counter in LDS. (A static tok += n_waves split ties the kernel's duration to the slowest wave: the SIMD
-    // arbiter favours older waves, measured 2.8x spread in per-wave loop time.) The first WAVES tokens are handed
-    // out statically so that nothing has to be synchronised before the first DMA.
-    const int64_t tpb = (rows + gridDim.x - 1) / gridDim.x;
+    // Tokens: workgroup b owns the contiguous range [blk_base, blk_base + blk_cnt) (tpb = tokens per workgroup, from
+    // the host: no gridDim / division here, and with the first 16 kernarg dwords preloaded into SGPRs the prologue
+    // below starts without a kernarg round trip); its waves PULL tokens from a counter in LDS. (A static
+    // tok += n_waves split ties the kernel's duration to the slowest wave: the SIMD arbiter favours older waves,
+    // measured 2.8x spread in per-wave loop time.) The first WAVES tokens are handed out statically.
     const int64_t blk_base = (int64_t)blockIdx.x * tpb;
     const int blk_cnt = (int)(rows - blk_base < tpb ? (rows - blk_base < 0 ? 0 : rows - blk_base) : tpb);
-    if (tid == 0) *next_slot = WAVES;
+    if (!FQ_K64_STATIC && tid == 0) *next_slot = WAVES;
     int slot = wave;
-    if (slot < blk_cnt) dma_token(x, blk_base + slot, tok_lds, lane);
 
-    // ---- B-operand fragments of R and L: gathered straight from global (L2-resident 2 x 8 KB), once ----
+    // ---- prologue: B-operand fragments of R and L (gathered straight from the 2 x 8 KB row-major matrices) and the
+    // first token of every wave. The order is what the TRACE build measured as mattering:
+    //  (1) every wave issues its 8 small L/R loads, then a bare s_barrier: all of them are in the CU's memory
+    //      pipeline before the first DMA. (DMAs of 16 waves are 128 KB of misses per CU; a gather load queued
+    //      behind them used to hold the workgroup at the fragment barrier for ~5 us.)
+    //  (2) the first DMAs go out in SIMD-slot order (waves 4g..4g+3 sit on the four SIMDs): group 0 at once,
+    //      group 1 after it has written its fragments, groups 2, 3 after the fragment barrier plus (g-1) *
+    //      FQ_K64_STAGGER * 64 cycles. All 4096 waves asking at once is a 32 MB burst that comes back
+    //      interleaved, i.e. every wave waits ~6 us and the SIMDs then run in lock step; ordered, the first
+    //      quarter computes after ~2 us and the four waves of a SIMD stay out of phase.
+    // The gather loads are inline asm because the compiler cannot see the DMAs in its vmcnt accounting: their
+    // completion is waited for by hand (8 younger VMEM ops = the DMA, for group 0).
+#ifndef FQ_K64_STAGGER
+#define FQ_K64_STAGGER 40
+#endif
     uint4* frag = reinterpret_cast<uint4*>(smem);
-    for (int item = tid; item < 16 * 64; item += THREADS) {  // (f, lane') with lane' fastest
-        const int f = item >> 6, ln = item & 63, fh = ln >> 5, fc = ln & 31;
-        f16x8 v;
-        if (f < 8) {
-            const int nt = f >> 2, sk = f & 3, np = nperm(nt, fc);
+    constexpr int ITEMS = 16 * 64 / THREADS;  // fragment slots (f, lane') this thread fills: 1 or 2
+    static_assert(ITEMS * THREADS == 16 * 64, "fragment image is 1024 x 16 B");
+    unsigned gv[ITEMS][8];
+#ifdef FQ_K64_SKIP_GATHER  // measurement build: what would a free fragment build be worth?
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = right[(fh * 32 + sk * 8 + j) * KN + np];
-        } else {
+    for (int it = 0; it < ITEMS; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[it][j] = 0;
+#else
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int item = tid + it * THREADS;                              // (f, lane') with lane' fastest
+        const int f = __builtin_amdgcn_readfirstlane(item >> 6);          // one fragment per wave and item
+        const int ln = item & 63, fh = ln >> 5, fc = ln & 31;
+#define FQ_LD(j, off) asm volatile("global_load_ushort %0, %1, off offset:" #off : "=v"(gv[it][j]) : "v"(src) : "memory");
+        if (f < 8) {  // element j: row + j of R
+            const int nt = f >> 2, sk = f & 3;
+            const f16* src = right + (fh * 32 + sk * 8) * KN + nperm(nt, fc);
+            FQ_LD(0, 0) FQ_LD(1, 128) FQ_LD(2, 256) FQ_LD(3, 384) FQ_LD(4, 512) FQ_LD(5, 640) FQ_LD(6, 768) FQ_LD(7, 896)
+        } else {      // element j: row + 8 (j>>2) + (j&3) of L
             const int ks = (f - 8) >> 1, mo = (f - 8) & 1;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int m = (ks >> 1) * 32 + 16 * (ks & 1) + 8 * (j >> 2) + 4 * fh + (j & 3);
-                v[j] = left[m * KM + mo * 32 + fc];
-            }
+            const f16* src = left + ((ks >> 1) * 32 + 16 * (ks & 1) + 4 * fh) * KM + mo * 32 + fc;
+            FQ_LD(0, 0) FQ_LD(1, 128) FQ_LD(2, 256) FQ_LD(3, 384) FQ_LD(4, 1024) FQ_LD(5, 1152) FQ_LD(6, 1280) FQ_LD(7, 1408)
         }
-        frag[item] = __builtin_bit_cast(uint4, v);
+#undef FQ_LD
     }
-    __syncthreads();
+#endif
+    const bool have_first = slot < blk_cnt;
+    const int grp = wave >> 2;
+    unsigned long long tr_args = 0, tr_issue = 0;
+    if (TRACE) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_args) : "s"(blk_cnt));  // kernargs are here
+    __builtin_amdgcn_s_barrier();  // (1): no memory wait in front of it, only "all gather loads are issued"
+    if (have_first && grp == 0) dma_token(x, blk_base + slot, tok_lds, lane);
+    if (TRACE) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_issue));  // prologue loads issued (group 0)
+    // the remaining kernel arguments, fetched while the gather is in flight instead of one miss at a time later
+    asm volatile("" : : "s"(out.n_clips), "s"(out.rt_flags), "s"(out.sig_max[0]), "s"(out.sig_min[0]), "s"(out.q[0]),
+                 "s"(out.scale[0]));
+    // gather data has landed once at most the DMA's 8 ops are outstanding; ties the wait to the registers
+#define FQ_GV(it) "+v"(gv[it][0]), "+v"(gv[it][1]), "+v"(gv[it][2]), "+v"(gv[it][3]), "+v"(gv[it][4]), \
+                  "+v"(gv[it][5]), "+v"(gv[it][6]), "+v"(gv[it][7])
+    // ONE asm statement for both cases (only group 0 has a DMA in flight): separate statements in the arms of
+    // an if make the register allocator copy the still-in-flight registers ahead of the wait.
+    const int dma_ops = ((FQ_K64_ABLATE & 4) || !have_first || grp != 0) ? 0 : 8;
+#define FQ_WAIT_GATHER                                                                                      \
+    "s_cmp_eq_u32 %[n], 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(8)\n\ts_branch 2f\n1:\n\ts_waitcnt vmcnt(0)\n2:"
+    if (ITEMS == 1) asm volatile(FQ_WAIT_GATHER : FQ_GV(0) : [n] "s"(dma_ops) : "scc");
+    else asm volatile(FQ_WAIT_GATHER : FQ_GV(0), FQ_GV(ITEMS - 1) : [n] "s"(dma_ops) : "scc");
+#undef FQ_WAIT_GATHER
+#undef FQ_GV
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        uint4 v;
+        v.x = gv[it][0] | (gv[it][1] << 16);  // global_load_ushort zero-extends
+        v.y = gv[it][2] | (gv[it][3] << 16);
+        v.z = gv[it][4] | (gv[it][5] << 16);
+        v.w = gv[it][6] | (gv[it][7] << 16);
+        frag[tid + it * THREADS] = v;
+    }
+    const unsigned long long tr_gather = TRACE ? __builtin_amdgcn_s_memtime() : 0;
+    if (have_first && grp == 1) dma_token(x, blk_base + slot, tok_lds, lane);
+    unsigned long long tr_prebar = 0;
+    if (TRACE) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_prebar) : : "memory");
+    __syncthreads();  // (the compiler knows of no VMEM in flight: this is lgkmcnt(0) + s_barrier, the DMAs stay out)
+    const unsigned long long tr_barrier = TRACE ? __builtin_amdgcn_s_memtime() : 0;
+    if (have_first && grp >= 2) {
+#if FQ_K64_STAGGER
+        for (int g = grp - 1; g > 0; --g) __builtin_amdgcn_s_sleep(FQ_K64_STAGGER);
+#endif
+        dma_token(x, blk_base + slot, tok_lds, lane);
+    }
 
     // fragment-read address of this lane inside the token buffer: row (32 mt + c), chunk (4h + s) ^ ((c>>1)&7)
     const int sw = (c >> 1) & 7;
     const int lane_off = c * KN + h * 32;  // same element offset in HBM (used by diag and by the outputs)
     bool first = true;
+    int prio_rot = 0;
+    (void)prio_rot;
     int next_pulled = 0;
 #ifndef FQ_K64_REGFRAG
 #define FQ_K64_REGFRAG 0  // 1: keep the 16 B-operand fragments in 64 VGPRs (needs the 512-thread build)
@@ -264,7 +393,18 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
 #ifndef FQ_K64_PRIO
 #define FQ_K64_PRIO 2
 #endif
+#ifndef FQ_K64_PRIO_MODE
+#define FQ_K64_PRIO_MODE 0  // 0: raised in the GEMM phases; 1: flat; 2: younger wave groups higher; 3: rotating per token
+#endif
+#if FQ_K64_PRIO_MODE == 0
         __builtin_amdgcn_s_setprio(FQ_K64_PRIO);
+#elif FQ_K64_PRIO_MODE == 2
+        if (first) { switch (wave >> 2) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break;
+                                          case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); } }
+#elif FQ_K64_PRIO_MODE == 3
+        switch (((wave >> 2) + prio_rot++) & 3) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break;
+                                                  case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); }
+#endif
         f32x16 U[2][2];
         U[0][0] = f32x16{0}; U[0][1] = f32x16{0}; U[1][0] = f32x16{0}; U[1][1] = f32x16{0};
 #pragma unroll
@@ -279,18 +419,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
             U[1][0] = mfma32(__builtin_bit_cast(f16x8, X[1][s]), b0, U[1][0]);
             U[0][1] = mfma32(__builtin_bit_cast(f16x8, X[0][s]), b1, U[0][1]);
             U[1][1] = mfma32(__builtin_bit_cast(f16x8, X[1][s]), b1, U[1][1]);
-            if (s == 0) {
-                // All eight X fragments were requested before the first MFMA; once they have landed the token's LDS
-                // buffer is free -> refill it with the next token while the matrix pipe works on the first K-step.
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                int nxt = 0;
-                if (lane == 0) nxt = (int)atomicAdd(next_slot, 1u);
-                nxt = __builtin_amdgcn_readfirstlane(nxt);
-                if (nxt < blk_cnt) dma_token(x, blk_base + nxt, tok_lds, lane);
-                next_pulled = nxt;
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            if (PULL_AT == 0 && s == 0) FQ_PULL_NEXT()  // (all eight X fragments were requested before the first MFMA)
         }
 
         // ---- fp16 rounding of U (flat_utils.py:15); C fragment -> A fragment of GEMM 2, no data movement ----
@@ -302,6 +431,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
 #pragma unroll
                 for (int j = 0; j < 8; ++j) Uh[nt][ks][j] = (f16)U[ks >> 1][nt][(ks & 1) * 8 + j];
 
+        if (PULL_AT == 1) FQ_PULL_NEXT()
         FQ_TICK(c2)
         // ---- GEMM 2: Y^T(nt, mo) = U(:, nt)^T . L(:, mo) ----
         f32x16 Y[2][2];  // [nt][mo]: Y^T[n' = 32h + 16nt + r][m' = 32mo + c]
@@ -319,7 +449,10 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
             Y[0][1] = mfma32(Uh[0][ks], b1, Y[0][1]);
             Y[1][1] = mfma32(Uh[1][ks], b1, Y[1][1]);
         }
+#if FQ_K64_PRIO_MODE == 0
         __builtin_amdgcn_s_setprio(0);
+#endif
+        if (PULL_AT == 2) FQ_PULL_NEXT()
 
         if (out.rt_flags & FQ_ROUND_Y_F16) {
 #pragma unroll
@@ -365,6 +498,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
             float vmin = fq_min3(pmin[0], pmin[1], FqMinOp()(pmin[2], pmin[3]));
             vmax = fq_wave_max(vmax);
             vmin = fq_wave_min(vmin);
+            if (PULL_AT == 3) FQ_PULL_NEXT()
             FQ_TICK(c3)
 
             for (int ci = 0; ci < out.n_clips; ++ci) {
@@ -387,28 +521,28 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                             }
                     } else {
                         const float inv = 1.0f / scale;
-                        unsigned near = 0;  // bit (4*mo + w): some lane's dword has a quotient within FQ_NEAR of a tie
+                        // bit (4*mo + w) of near: some lane's dword has a quotient within FQ_NEAR of a tie
+                        unsigned near;
+#if FQ_K64_ABLATE & 2
+                        near = 0;
 #pragma unroll
                         for (int mo = 0; mo < 2; ++mo)
 #pragma unroll
-                            for (int w = 0; w < 4; ++w) {
-                                float dmax = 0.0f;
-#if FQ_K64_ABLATE & 2
+                            for (int w = 0; w < 4; ++w)
                                 pw[mo][w] = __builtin_bit_cast(unsigned, FQ_YV(mo, w, 0)) ^ __builtin_bit_cast(unsigned, FQ_YV(mo, w, 1)) ^
                                             __builtin_bit_cast(unsigned, FQ_YV(mo, w, 2)) ^ __builtin_bit_cast(unsigned, FQ_YV(mo, w, 3)) ^
                                             __builtin_bit_cast(unsigned, FQ_YV(mo, w, 4)) ^ __builtin_bit_cast(unsigned, FQ_YV(mo, w, 5)) ^
                                             __builtin_bit_cast(unsigned, FQ_YV(mo, w, 6)) ^ __builtin_bit_cast(unsigned, FQ_YV(mo, w, 7)) ^
                                             __builtin_bit_cast(unsigned, inv);
 #else
-                                const f32x2 inv2 = {inv, inv};
-                                const f32x2 q01 = fq_qfast2(f32x2{FQ_YV(mo, w, 0), FQ_YV(mo, w, 1)}, inv2, dmax);
-                                const f32x2 q23 = fq_qfast2(f32x2{FQ_YV(mo, w, 2), FQ_YV(mo, w, 3)}, inv2, dmax);
-                                const f32x2 q45 = fq_qfast2(f32x2{FQ_YV(mo, w, 4), FQ_YV(mo, w, 5)}, inv2, dmax);
-                                const f32x2 q67 = fq_qfast2(f32x2{FQ_YV(mo, w, 6), FQ_YV(mo, w, 7)}, inv2, dmax);
-                                pw[mo][w] = fq_pack8(q01.x, q01.y, q23.x, q23.y, q45.x, q45.y, q67.x, q67.y);
+                        if (!fq_magic_ok(vmax, vmin, inv)) {
+                            near = 0xffu;  // quotients too large for the magic-number rounding: true division throughout
+                        } else if (fq_needs_clamp(vmax, vmin, inv)) {
+                            near = quant_pack_token<true>(Y, inv, pw);
+                        } else {
+                            near = quant_pack_token<false>(Y, inv, pw);
+                        }
 #endif
-                                near |= fq_wave_needs_exact(dmax) ? (1u << (4 * mo + w)) : 0u;   // SALU only
-                            }
                         if (near) {  // rare (~3 % of tokens): redo the flagged dwords with the true division
 #pragma unroll
                             for (int mo = 0; mo < 2; ++mo)
@@ -481,8 +615,15 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
         slot = next_pulled;
     }
     if (TRACE && lane == 0) {
-        trace[n_waves * 4 + wave_id * 2 + 0] = tr_start;                       // absolute start / end stamps
-        trace[n_waves * 4 + wave_id * 2 + 1] = __builtin_amdgcn_s_memtime();
+        trace[n_waves * 4 + wave_id * 10 + 0] = tr_start;                       // absolute stamps: start, end,
+        trace[n_waves * 4 + wave_id * 10 + 1] = __builtin_amdgcn_s_memtime();   // fragment gather done, barrier passed,
+        trace[n_waves * 4 + wave_id * 10 + 2] = tr_gather;                      // start / end on the 100 MHz clock
+        trace[n_waves * 4 + wave_id * 10 + 3] = tr_barrier;
+        trace[n_waves * 4 + wave_id * 10 + 4] = tr_start_rt;
+        trace[n_waves * 4 + wave_id * 10 + 5] = __builtin_amdgcn_s_memrealtime();
+        trace[n_waves * 4 + wave_id * 10 + 6] = tr_args;                        // kernargs loaded / prologue loads issued
+        trace[n_waves * 4 + wave_id * 10 + 7] = tr_issue;
+        trace[n_waves * 4 + wave_id * 10 + 8] = tr_prebar;                      // own fragment writes done, at the barrier
         trace[wave_id * 4 + 0] = tr_wait;
         trace[wave_id * 4 + 1] = tr_g1;
         trace[wave_id * 4 + 2] = tr_g2;
@@ -498,11 +639,18 @@ static int launch_kron64(const f16* x, const f16* left, const f16* right, const 
                          const FqQuantOut& out, int n_cu, hipStream_t stream) {
     constexpr int THREADS = kron64_threads<FLAGS>();
     constexpr int WAVES = THREADS / 64;
+#ifdef FQ_K64_TPW  // measurement builds: small workgroups of WAVES * FQ_K64_TPW tokens, balanced by the dispatcher
+    int64_t blocks = (rows + WAVES * FQ_K64_TPW - 1) / (WAVES * FQ_K64_TPW);
+    if (blocks < 1) blocks = 1;
+    const int64_t tpb = WAVES * FQ_K64_TPW;
+#else
     int64_t blocks = (rows + WAVES - 1) / WAVES;
     if (blocks > n_cu) blocks = n_cu;  // one persistent workgroup per CU (LDS: 16 KB + 8 KB per wave)
     if (blocks < 1) blocks = 1;
+    const int64_t tpb = (rows + blocks - 1) / blocks;
+#endif
     hipLaunchKernelGGL((fq_kron64_kernel<FLAGS, false>), dim3((unsigned)blocks), dim3(THREADS), 0, stream, x, left,
-                       right, diag, rows, out, (unsigned long long*)nullptr);
+                       right, diag, rows, tpb, out, (unsigned long long*)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -536,7 +684,8 @@ int fq_launch_kron64_trace(const f16* x, const f16* left, const f16* right, int6
                            unsigned long long* trace, int n_cu, hipStream_t stream) {
     int64_t blocks = (rows + 15) / 16;
     if (blocks > n_cu) blocks = n_cu;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((fq_kron64_kernel<FQ_OUT_PACKED, true>), dim3((unsigned)blocks), dim3(1024), 0, stream, x, left,
-                       right, (const f16*)nullptr, rows, out, trace);
+                       right, (const f16*)nullptr, rows, (rows + blocks - 1) / blocks, out, trace);
     return (int)hipGetLastError();
 }

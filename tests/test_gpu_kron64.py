@@ -63,6 +63,24 @@ def test_quant_stage_bit_exact_given_kernel_transform(ops, golden, name):
         assert np.array_equal(o.fq[ci].cpu().numpy(), ref["fq"])
 
 
+@pytest.mark.parametrize("sig", [(0.9820137619972229, 0.9820137619972229),   # no clamp needed: the short quantiser
+                                 (0.9, 0.33), (0.5, 0.6),                      # clamping variant
+                                 (1.0, 1.0), (0.94, 0.93),
+                                 (1e-7, 1e-7), (3e-6, 1.0)])                   # quotients beyond the magic-number range
+@pytest.mark.parametrize("name", ["kron_A_64x64", "edge_64x64"])
+def test_packed_only_kernel_quant_stage_bit_exact(ops, golden, name, sig):
+    """The packed-only specialisation (16-wave workgroups) takes three routes through the quantiser (magic-number
+    rounding with / without clamp, true division); each must reproduce the oracle on the kernel's own transform."""
+    g = golden(name)
+    Lk, Rk = ("rand_L", "rand_R") if name.startswith("edge") else ("L", "R")
+    x, L, Rm = dev(g["x"]), dev(g[Lk]), dev(g[Rk])
+    y16 = ops.kron_quant(x, L, Rm, flags=T).y.cpu().numpy()
+    o = ops.kron_quant(x, L, Rm, [sig], P | R16)
+    ref = O.quant_outputs(y16.astype(np.float32), sig[0], sig[1])
+    assert np.array_equal(o.q[0].cpu().numpy(), ref["packed"])
+    assert np.array_equal(o.scale[0].cpu().numpy(), ref["scale16"])
+
+
 @pytest.mark.parametrize("name", ["kron_A_64x64", "kron_B_64x64", "edge_64x64"])
 def test_transform_vs_oracle(ops, golden, name):
     g = golden(name)
