@@ -16,6 +16,7 @@
 // This single pass replaces the reference's split path for M > 64 (kron_matmul.py:213-247), which writes the
 // fp16 intermediate to HBM and re-reads it (+4 B/element).
 #include "fq_common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -272,6 +273,325 @@ __global__ __launch_bounds__(256) void fq_kron_generic_kernel(const f16* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fast variant for the factor pairs real models use (compile-time KS1). Same partition (wave w owns the n'-tiles
+// w, w+4, ...), but the per-token traffic that made the kernel above L2-bound is gone:
+//   * a wave's R fragments never change -> loaded once into registers (TPW x KS1 x 4 VGPRs);
+//   * the L fragments every wave needs in full live in LDS (2 MT^2 KB, copied once per workgroup);
+//   * the next token is fetched into registers (coalesced 16-byte loads) while the current one is being
+//     multiplied, and written to LDS after the barrier that frees the stage: HBM latency is off the critical path;
+//   * the quantiser is the magic-number one of fq_common.hpp.
+// Barriers per token: stage written | statistics exchanged (= stage free) | output stage complete.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MT, int NT, int KS1, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void fq_kron_fast_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
+                                                           const f16* __restrict__ diag, int64_t rows, int M, int /*N*/,
+                                                           FqQuantOut out, int flags) {
+    constexpr int N = KS1 * 16;                    // N % 16 == 0 is a precondition, so KS1 fixes N
+    constexpr int THREADS = WAVES * 64;
+    constexpr int TPW = (NT + WAVES - 1) / WAVES;  // n'-tiles per wave
+    constexpr int PITCH = (KS1 * 2) | 1;           // LDS row pitch of the staged token, in 16-byte chunks (odd)
+    constexpr int XS_CHUNKS = MT * 32 * PITCH;
+    constexpr int NPF = (MT * 32 * KS1 * 2 + THREADS - 1) / THREADS;  // prefetch registers (uint4) per thread, upper bound
+    constexpr int LFR = 2 * MT * MT * 64;          // L fragments, uint4 each
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* lfr = reinterpret_cast<uint4*>(smem);
+    uint4* xs = lfr + LFR;                                             // [MT*32][PITCH]
+    unsigned char* obuf = reinterpret_cast<unsigned char*>(xs + XS_CHUNKS);  // packed output stage: M*N/2 bytes
+    float* red = reinterpret_cast<float*>(obuf + ((M * N / 2 + 15) & ~15));  // [2][WAVES]
+
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int cpr = N >> 3;      // 16-byte chunks per token row
+    const int n_chunks = M * cpr;    // chunks per token
+    const int64_t d = (int64_t)M * N;
+
+    // ---- once per workgroup ----
+    const uint4* lsrc = ws + (size_t)NT * KS1 * 64;
+    for (int i = tid; i < LFR; i += THREADS) lfr[i] = lsrc[i];
+    for (int i = tid; i < XS_CHUNKS; i += THREADS) xs[i] = make_uint4(0, 0, 0, 0);  // padding stays zero
+    f16x8 RF[TPW][KS1];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int nt = wave + WAVES * t;
+#pragma unroll
+        for (int s = 0; s < KS1; ++s)
+            RF[t][s] = nt < NT ? __builtin_bit_cast(f16x8, ws[((size_t)nt * KS1 + s) * 64 + lane]) : f16x8{0};
+    }
+    // LDS slot of prefetch register k of this thread (chunk q = tid + 256 k of the token)
+    u32x4 PF[NPF];
+    int64_t tok = blockIdx.x;
+    if (tok < rows) {
+        const uint4* xp = reinterpret_cast<const uint4*>(x + tok * d);
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int q = tid + THREADS * k;
+            PF[k] = q < n_chunks ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xp) + q) : u32x4{0, 0, 0, 0};
+        }
+    }
+
+    for (; tok < rows; tok += gridDim.x) {
+        // ---- stage the prefetched token (the previous token's readers passed the statistics barrier) ----
+        {
+            const uint4* dp = reinterpret_cast<const uint4*>(diag);
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) {
+                const int q = tid + THREADS * k;
+                if (q < n_chunks) {
+                    uint4 v = __builtin_bit_cast(uint4, PF[k]);
+                    if (diag != nullptr)
+                        v = __builtin_bit_cast(uint4, __builtin_bit_cast(f16x8, v) * __builtin_bit_cast(f16x8, dp[q]));
+                    const int row = q / cpr, ch = q - row * cpr;
+                    xs[row * PITCH + ch] = v;
+                }
+            }
+        }
+        __syncthreads();
+        {   // next token -> registers; lands while this one is multiplied and quantised
+            const int64_t nxt = tok + gridDim.x;
+            if (nxt < rows) {
+                const uint4* xp = reinterpret_cast<const uint4*>(x + nxt * d);
+#pragma unroll
+                for (int k = 0; k < NPF; ++k) {
+                    const int q = tid + THREADS * k;
+                    if (q < n_chunks) PF[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xp) + q);
+                }
+            }
+        }
+
+        int loff = lane;
+        asm volatile("" : "+v"(loff));  // keep the L-fragment reads inside the token loop (see fq_kron64.hip)
+        const uint4* mylfr = lfr + loff;
+        f32x16 Y[TPW][MT];  // Y^T of tile (nt = wave + WAVES t, mo): rows n' = h*NT*16 + nt*16 + r, col m' = 32mo + c
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int nt = wave + WAVES * t;
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo) Y[t][mo] = f32x16{0};
+            if (nt < NT) {
+                // Both GEMMs are software-pipelined by hand, one K-step of LDS fragment reads ahead of the MFMAs,
+                // with a scheduling barrier per step: left alone, hipcc hoists ALL fragment reads of a GEMM (128
+                // VGPRs each) in front of its first MFMA and spills.
+                f32x16 U[MT];
+                f16x8 A[2][MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    U[mt] = f32x16{0};
+                    A[0][mt] = __builtin_bit_cast(f16x8, xs[(mt * 32 + c) * PITCH + h]);
+                }
+#pragma unroll
+                for (int s = 0; s < KS1; ++s) {
+                    if (s + 1 < KS1) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            A[(s + 1) & 1][mt] = __builtin_bit_cast(f16x8, xs[(mt * 32 + c) * PITCH + (s + 1) * 2 + h]);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) U[mt] = mfma32(A[s & 1][mt], RF[t][s], U[mt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                f16x8 Uh[MT][2];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) Uh[mt][p][j] = (f16)U[mt][p * 8 + j];
+                f16x8 B[2][MT];
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo) B[0][mo] = __builtin_bit_cast(f16x8, mylfr[mo * 64]);
+#pragma unroll
+                for (int ks = 0; ks < 2 * MT; ++ks) {
+                    if (ks + 1 < 2 * MT) {
+#pragma unroll
+                        for (int mo = 0; mo < MT; ++mo)
+                            B[(ks + 1) & 1][mo] = __builtin_bit_cast(f16x8, mylfr[((ks + 1) * MT + mo) * 64]);
+                    }
+#pragma unroll
+                    for (int mo = 0; mo < MT; ++mo) Y[t][mo] = mfma32(Uh[ks >> 1][ks & 1], B[ks & 1][mo], Y[t][mo]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (flags & FQ_ROUND_Y_F16) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Y[t][mo][r] = (float)(f16)Y[t][mo][r];
+        }
+
+        // ---- per-token extrema over the VALID entries (padding rows/columns are excluded) ----
+        float vmax = -INFINITY, vmin = INFINITY;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int nt = wave + WAVES * t;
+            const bool col_ok = nt < NT && (h * NT * 16 + nt * 16) < N;  // the lane's 16 columns of this tile
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo) {
+                if (col_ok && (mo * 32 + c) < M) {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        vmax = fq_max3(vmax, Y[t][mo][r], Y[t][mo][r + 1]);
+                        vmin = fq_min3(vmin, Y[t][mo][r], Y[t][mo][r + 1]);
+                    }
+                }
+            }
+        }
+        vmax = fq_wave_max(vmax);
+        vmin = fq_wave_min(vmin);
+        if (lane == 0) {
+            red[wave] = vmax;
+            red[WAVES + wave] = vmin;
+        }
+        __syncthreads();  // also: every wave has finished reading xs -> it may be reused as an output stage
+        vmax = red[0];
+        vmin = red[WAVES];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) {
+            vmax = fmaxf(vmax, red[w]);
+            vmin = fminf(vmin, red[WAVES + w]);
+        }
+
+        // ---- fp16 outputs (transform / fake-quant) are staged dense [M][N] in xs, then streamed out ----
+        f16* stage = reinterpret_cast<f16*>(xs);
+        if (flags & FQ_OUT_TRANSFORM) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int nt = wave + WAVES * t, n0 = h * NT * 16 + nt * 16;
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo)
+                    if (nt < NT && n0 < N && (mo * 32 + c) < M) {
+                        f16x8 v0, v1;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            v0[e] = (f16)Y[t][mo][e];
+                            v1[e] = (f16)Y[t][mo][8 + e];
+                        }
+                        uint4* sp = reinterpret_cast<uint4*>(stage + (mo * 32 + c) * N + n0);
+                        sp[0] = __builtin_bit_cast(uint4, v0);
+                        sp[1] = __builtin_bit_cast(uint4, v1);
+                    }
+            }
+            __syncthreads();
+            uint4* yp = reinterpret_cast<uint4*>(out.y + tok * d);
+            for (int q = tid; q < n_chunks; q += THREADS) yp[q] = reinterpret_cast<const uint4*>(stage)[q];
+            __syncthreads();
+        }
+
+        for (int ci = 0; ci < out.n_clips; ++ci) {
+            if (!(flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT))) break;
+            float scale;
+            if (flags & FQ_QUANT_F16) scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
+            else scale = fq_token_scale<0>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
+            const float inv = 1.0f / scale;
+            const f32x2 inv2 = {inv, inv};
+            const bool magic = !(flags & FQ_QUANT_F16) && fq_magic_ok(vmax, vmin, inv);
+            const bool clampq = fq_needs_clamp(vmax, vmin, inv);
+
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int nt = wave + WAVES * t, n0 = h * NT * 16 + nt * 16;
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo) {
+                    const bool ok = nt < NT && n0 < N && (mo * 32 + c) < M;
+                    const f32x16& yv = Y[t][mo];
+                    f32x2 qp[8];  // integer-valued pairs (r_2j, r_2j+1)
+                    bool exact = !magic;
+                    if (magic) {
+                        float dmax = 0.0f;
+                        if (clampq) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                qp[j] = fq_qmagic2<true>(ok ? f32x2{yv[2 * j], yv[2 * j + 1]} : f32x2{0, 0}, inv2, dmax);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                qp[j] = fq_qmagic2<false>(ok ? f32x2{yv[2 * j], yv[2 * j + 1]} : f32x2{0, 0}, inv2, dmax);
+                        }
+                        exact = fq_wave_needs_exact(dmax);
+                    }
+                    if (exact) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            if (flags & FQ_QUANT_F16)
+                                qp[j] = f32x2{(float)fq_quant1<FQ_QUANT_F16>(yv[2 * j], scale),
+                                              (float)fq_quant1<FQ_QUANT_F16>(yv[2 * j + 1], scale)};
+                            else
+                                qp[j] = f32x2{fq_qexact(yv[2 * j], scale), fq_qexact(yv[2 * j + 1], scale)};
+                        }
+                    }
+                    if (ok && (flags & FQ_OUT_PACKED)) {
+                        uint2 pk;
+                        pk.x = fq_pack8p(qp[0], qp[1], qp[2], qp[3]);
+                        pk.y = fq_pack8p(qp[4], qp[5], qp[6], qp[7]);
+                        *reinterpret_cast<uint2*>(obuf + (mo * 32 + c) * (N >> 1) + (n0 >> 1)) = pk;
+                    }
+                    if (ok && (flags & FQ_OUT_FAKEQUANT)) {
+                        f16x8 v0, v1;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float q0 = (e & 1) ? qp[e >> 1].y : qp[e >> 1].x;
+                            const float q1 = (e & 1) ? qp[4 + (e >> 1)].y : qp[4 + (e >> 1)].x;
+                            if (flags & FQ_QUANT_F16) {
+                                v0[e] = fq_dequant1<FQ_QUANT_F16>((int)q0, scale);
+                                v1[e] = fq_dequant1<FQ_QUANT_F16>((int)q1, scale);
+                            } else {
+                                v0[e] = fq_mul_to_f16(scale, q0);
+                                v1[e] = fq_mul_to_f16(scale, q1);
+                            }
+                        }
+                        uint4* sp = reinterpret_cast<uint4*>(stage + (mo * 32 + c) * N + n0);
+                        sp[0] = __builtin_bit_cast(uint4, v0);
+                        sp[1] = __builtin_bit_cast(uint4, v1);
+                    }
+                }
+            }
+            __syncthreads();
+            if (flags & FQ_OUT_PACKED) {
+                if (tid == 0) out.scale[ci][tok] = (f16)scale;
+                uint4* qp4 = reinterpret_cast<uint4*>(out.q[ci] + tok * (d >> 1));
+                for (int q = tid; q < (n_chunks >> 2); q += THREADS) qp4[q] = reinterpret_cast<const uint4*>(obuf)[q];
+            }
+            if (flags & FQ_OUT_FAKEQUANT) {
+                uint4* fp = reinterpret_cast<uint4*>(out.fq[ci] + tok * d);
+                for (int q = tid; q < n_chunks; q += THREADS) fp[q] = reinterpret_cast<const uint4*>(stage)[q];
+            }
+            if ((flags & FQ_OUT_FAKEQUANT) || ci + 1 < out.n_clips) __syncthreads();  // stage / obuf are rewritten next
+        }
+
+        // the dense output stage lives in xs: restore the zero padding the next token relies on
+        if (flags & (FQ_OUT_TRANSFORM | FQ_OUT_FAKEQUANT)) {
+            for (int i = tid; i < XS_CHUNKS; i += THREADS) xs[i] = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+        }
+    }
+}
+
+template <int MT, int NT, int KS1, int WAVES>
+int launch_fast(int flags, const f16* x, const uint4* ws, const f16* diag, int64_t rows, int M, int N,
+                const FqQuantOut& out, int n_cu, hipStream_t stream) {
+    constexpr int PITCH = (KS1 * 2) | 1;
+    const size_t lds = (size_t)2 * MT * MT * 1024 + (size_t)MT * 32 * PITCH * 16 + (((size_t)M * N / 2 + 15) & ~(size_t)15) + 128;
+    if (lds > 160 * 1024) return -1000;
+    auto kern = fq_kron_fast_kernel<MT, NT, KS1, WAVES>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr_set = true;
+    }
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 8 / WAVES) per_cu = 8 / WAVES;  // 2 waves per SIMD: up to 256 VGPRs each
+    if (per_cu < 1) per_cu = 1;
+    int64_t blocks = (int64_t)n_cu * per_cu;
+    if (blocks > rows) blocks = rows;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), lds, stream, x, ws, diag, rows, M, N, out, flags);
+    return (int)hipGetLastError();
+}
+
 template <int MT, int NT>
 int launch_generic(int flags, const f16* x, const uint4* ws, const f16* diag, int64_t rows, const KronGeom& g,
                    const FqQuantOut& out, int n_cu, hipStream_t stream) {
@@ -321,6 +641,16 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
                        NT, g.KS1, ws);
     int rc = (int)hipGetLastError();
     if (rc != 0) return rc;
+    if (!getenv("FQ_KRON_GENERIC_V1")) {  // (the original kernel stays reachable for A/B runs)
+#define FQ_F(MT_, NT_, KS1_, W_)                                                                         \
+    if (MT == MT_ && NT == NT_ && g.KS1 == KS1_) {                                                       \
+        rc = launch_fast<MT_, NT_, KS1_, W_>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);         \
+        if (rc != -1000) return rc;                                                                      \
+    }
+        FQ_F(2, 4, 8, 4) FQ_F(4, 4, 8, 4) FQ_F(3, 4, 8, 4) FQ_F(4, 7, 14, 8) FQ_F(2, 4, 7, 4) FQ_F(1, 2, 4, 4)
+        FQ_F(2, 2, 4, 4) FQ_F(2, 3, 5, 4)
+#undef FQ_F
+    }
 #define FQ_G(MT_, NT_)                                                                                   \
     if (MT == MT_ && NT == NT_)                                                                          \
         return launch_generic<MT_, NT_>(flags, x, ws, diag, rows, g, out, n_cu, stream);

@@ -44,6 +44,9 @@ def main():
         R = (torch.randn(N, N, generator=g, device="cuda") / N ** 0.5).half()
         us = timeit(lambda i: ops.kron_quant(xs[i % NB], L, R, sig, FQ_OUT_PACKED | FQ_NO_CLAMP0))
         line("kron+quant packed", f"d={d} ({M}x{N}) rows={rows}", us, 2.5 * d + 2, d, rows)
+        if os.environ.get("KRON_ONLY"):
+            del xs
+            continue
         if d in (4096, 14336):
             us = timeit(lambda i: ops.kron_quant(xs[i % NB], L, R, sig, FQ_OUT_FAKEQUANT | FQ_ROUND_Y_F16))
             line("kron+fake-quant fp16", f"d={d} ({M}x{N}) rows={rows}", us, 4.0 * d, d, rows)
@@ -57,6 +60,8 @@ def main():
             us = timeit(lambda i: ops.rowquant(xs[i % NB], sig, FQ_OUT_PACKED | FQ_QUANT_F16))
             line("rowquant packed (Quantizer)", f"cols={d} rows={rows}", us, 2.5 * d + 2, d, rows)
         del xs
+    if os.environ.get("KRON_ONLY"):
+        return
     for hd, H in ((128, 32), (128, 64)):
         xs = [torch.randn(ROWS, hd, H, generator=g, device="cuda", dtype=torch.float16) for _ in range(NB)]
         P = (torch.randn(H, H, generator=g, device="cuda") / H ** 0.5).half()
