@@ -283,8 +283,9 @@ __global__ __launch_bounds__(256) void fq_kron_generic_kernel(const f16* __restr
 //   * the quantiser is the magic-number one of fq_common.hpp.
 // Barriers per token: stage written | statistics exchanged (= stage free) | output stage complete.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MT, int NT, int KS1, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void fq_kron_fast_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
+// OCC = workgroups per CU the register allocation must leave room for (waves per SIMD = OCC * WAVES / 4).
+template <int MT, int NT, int KS1, int WAVES, int OCC>
+__global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fast_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
                                                            const f16* __restrict__ diag, int64_t rows, int M, int /*N*/,
                                                            FqQuantOut out, int flags) {
     constexpr int N = KS1 * 16;                    // N % 16 == 0 is a precondition, so KS1 fixes N
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void fq_kron_fast_kernel(con
 #pragma unroll
                 for (int k = 0; k < NPF; ++k) {
                     const int q = tid + THREADS * k;
-                    if (q < n_chunks) PF[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xp) + q);
+                    if (q < n_chunks && !(flags & 0x4000)) PF[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xp) + q);
                 }
             }
         }
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void fq_kron_fast_kernel(con
             const int nt = wave + WAVES * t;
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo) Y[t][mo] = f32x16{0};
-            if (nt < NT) {
+            if (nt < NT && !(flags & 0x1000)) {
                 // Both GEMMs are software-pipelined by hand, one K-step of LDS fragment reads ahead of the MFMAs,
                 // with a scheduling barrier per step: left alone, hipcc hoists ALL fragment reads of a GEMM (128
                 // VGPRs each) in front of its first MFMA and spills.
@@ -499,7 +500,11 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void fq_kron_fast_kernel(con
                     const f32x16& yv = Y[t][mo];
                     f32x2 qp[8];  // integer-valued pairs (r_2j, r_2j+1)
                     bool exact = !magic;
-                    if (magic) {
+                    if (flags & 0x2000) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) qp[j] = f32x2{yv[2 * j], yv[2 * j + 1]};
+                        exact = false;
+                    } else if (magic) {
                         float dmax = 0.0f;
                         if (clampq) {
 #pragma unroll
@@ -569,13 +574,13 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void fq_kron_fast_kernel(con
     }
 }
 
-template <int MT, int NT, int KS1, int WAVES>
+template <int MT, int NT, int KS1, int WAVES, int OCC>
 int launch_fast(int flags, const f16* x, const uint4* ws, const f16* diag, int64_t rows, int M, int N,
                 const FqQuantOut& out, int n_cu, hipStream_t stream) {
     constexpr int PITCH = (KS1 * 2) | 1;
     const size_t lds = (size_t)2 * MT * MT * 1024 + (size_t)MT * 32 * PITCH * 16 + (((size_t)M * N / 2 + 15) & ~(size_t)15) + 128;
     if (lds > 160 * 1024) return -1000;
-    auto kern = fq_kron_fast_kernel<MT, NT, KS1, WAVES>;
+    auto kern = fq_kron_fast_kernel<MT, NT, KS1, WAVES, OCC>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -583,7 +588,7 @@ int launch_fast(int flags, const f16* x, const uint4* ws, const f16* diag, int64
         attr_set = true;
     }
     int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 8 / WAVES) per_cu = 8 / WAVES;  // 2 waves per SIMD: up to 256 VGPRs each
+    if (per_cu > OCC) per_cu = OCC;
     if (per_cu < 1) per_cu = 1;
     int64_t blocks = (int64_t)n_cu * per_cu;
     if (blocks > rows) blocks = rows;
@@ -617,6 +622,9 @@ int launch_generic(int flags, const f16* x, const uint4* ws, const f16* diag, in
 
 }  // namespace
 
+int fq_launch_kron_wave(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
+                        const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_wave.hip
+
 static inline int tiles32(int n) { return (n + 31) / 32; }
 
 int64_t fq_kron_generic_workspace_bytes(int M, int N) {
@@ -641,14 +649,25 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
                        NT, g.KS1, ws);
     int rc = (int)hipGetLastError();
     if (rc != 0) return rc;
+    if (!getenv("FQ_KRON_NO_WAVE")) {  // one wave per token where a token fits a wave (packed output only)
+        rc = fq_launch_kron_wave(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
+        if (rc != -1000) return rc;
+    }
+    if (const char* dbg = getenv("FQ_KRON_DBG")) flags |= atoi(dbg) & 0x7000;  // measurement: ablation bits of the fast kernel
     if (!getenv("FQ_KRON_GENERIC_V1")) {  // (the original kernel stays reachable for A/B runs)
-#define FQ_F(MT_, NT_, KS1_, W_)                                                                         \
+#define FQ_F(MT_, NT_, KS1_, W_, OCC_)                                                                   \
     if (MT == MT_ && NT == NT_ && g.KS1 == KS1_) {                                                       \
-        rc = launch_fast<MT_, NT_, KS1_, W_>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);         \
+        rc = launch_fast<MT_, NT_, KS1_, W_, OCC_>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);   \
         if (rc != -1000) return rc;                                                                      \
     }
-        FQ_F(2, 4, 8, 4) FQ_F(4, 4, 8, 4) FQ_F(3, 4, 8, 4) FQ_F(4, 7, 14, 8) FQ_F(2, 4, 7, 4) FQ_F(1, 2, 4, 4)
-        FQ_F(2, 2, 4, 4) FQ_F(2, 3, 5, 4)
+#ifndef FQ_GEN_OCC2
+#define FQ_GEN_OCC2 2   // MT = 2 shapes (measurement knobs): workgroups per CU, waves per workgroup
+#endif
+#ifndef FQ_GEN_W2
+#define FQ_GEN_W2 4
+#endif
+        FQ_F(2, 4, 8, FQ_GEN_W2, FQ_GEN_OCC2) FQ_F(4, 4, 8, 4, 2) FQ_F(3, 4, 8, 4, 2) FQ_F(4, 7, 14, 8, 1) FQ_F(2, 4, 7, FQ_GEN_W2, FQ_GEN_OCC2)
+        FQ_F(1, 2, 4, 4, 4) FQ_F(2, 2, 4, 4, FQ_GEN_OCC2) FQ_F(2, 3, 5, 4, FQ_GEN_OCC2)
 #undef FQ_F
     }
 #define FQ_G(MT_, NT_)                                                                                   \

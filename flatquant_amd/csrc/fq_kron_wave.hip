@@ -1,0 +1,325 @@
+// fq_kron_wave.hip — fused Kronecker transform + per-token INT4 quantisation, ONE WAVE PER TOKEN, for factor pairs
+// whose token fits a wave's registers: M <= 64, N in {64, 112, 128} (N/32 rounded up even, <= 4 column tiles):
+// d = 8192 (64x128, Llama-2-70B hidden), 7168 (64x112, DeepSeek-V3 hidden), 3584 (56x64), 2048 (32x64).
+// Packed INT4 + fp16 scale output (the deploy.nn.OnlineTrans contract: deploy/kernels/kron_matmul.py:192-266,
+// functional/online_trans.py:113-122); everything else goes to fq_kron_generic.hip.
+//
+// Why: the workgroup-per-token kernel needs three workgroup barriers per token and spends ~60 % of its wave
+// cycles waiting at them (rocprofv3: SQ_WAIT_ANY / SQ_WAVE_CYCLES). Here a wave owns its token end to end, as in
+// fq_kron64.hip, and nothing is synchronised after the prologue:
+//   * token: HBM -> LDS by DMA (global_load_lds_dwordx4, full 1 KB lines, source-side XOR swizzle so the A-fragment
+//     ds_read_b128 are conflict-free), into a wave-private buffer; the next token's DMA is issued as soon as
+//     GEMM 1 has read the current one, and is waited for with a COUNTED vmcnt at the top of the loop;
+//   * R and L fragments: fragment-ordered image in LDS, shared by the workgroup, copied once from the workspace
+//     that fq_kron_prepare_kernel fills (same layout as the generic kernel's);
+//   * GEMM 1 with the K-step outermost: each A fragment is read once and used for all column tiles
+//     (U: NT x MT accumulators), then fp16 rounding (flat_utils.py:15) turns the C fragments into GEMM 2's A
+//     fragments; GEMM 2 with (ks, mo) outermost: each L fragment is read once and used for all NT tiles;
+//   * statistics, scale, magic-number quantiser and nibble packing on the accumulators in registers; a lane ends
+//     up with NT*16 consecutive n' of an output row = NT*8 contiguous bytes -> 16-byte stores.
+// LDS reads per 64x128 token: 16 (A) + 32 (R) + 8 (L) ds_read_b128 against 96 MFMAs.
+#include "fq_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+// chunk swizzle of row r inside the token buffer (16-byte chunks, CPR per row): 8 consecutive rows must spread over
+// the 16 chunk-aligned bank groups. CPR = 16: rows alias -> XOR the row's low bits; CPR = 8: pairs of rows alias;
+// CPR = 14 (N = 112): the row pitch already rotates by 14 mod 16.
+template <int CPR>
+__device__ __forceinline__ int swz(int r) {
+    return CPR == 16 ? (r & 15) : CPR == 8 ? ((r >> 1) & 7) : 0;
+}
+
+template <int MT, int NT, int KS1, int W>
+struct WaveGeom {
+    static constexpr int N = KS1 * 16;
+    static constexpr int CPR = KS1 * 2;                     // 16-byte chunks per token row
+    static constexpr int TOKBUF = MT * 32 * CPR * 16;       // bytes, rows padded to the tile
+    static constexpr int RFR = NT * KS1 * 64;               // uint4
+    static constexpr int LFR = 2 * MT * MT * 64;            // uint4
+    static constexpr int LDS = (RFR + LFR) * 16 + W * TOKBUF + 16;
+    static constexpr int V1 = N - NT * 16;                  // valid n' in the h = 1 half of a lane's run
+    static constexpr int NPAIR = NT / 2;                    // 16-byte pieces of a lane's packed run
+    static constexpr int STORES = MT * (NPAIR + ((V1 % 32) == 16 ? 1 : 0)) + 1;  // VMEM stores per token and clip
+};
+
+// DMA of one token (n_dma instructions of 1 KB) into the wave's buffer. Instruction i moves the LDS slots
+// [64 i, 64 i + 64) (lane-linear); lane l fetches the global chunk that the swizzle maps to its slot.
+template <int CPR>
+__device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok, int64_t tok_bytes, int n_dma,
+                                          unsigned lds_base, int lane) {
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(x) + tok * tok_bytes;  // wave-uniform
+    const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)base);
+    const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((size_t)base >> 32));
+    const unsigned long long sb = (unsigned long long)lo32 | ((unsigned long long)hi32 << 32);
+    for (int i = 0; i < n_dma; ++i) {
+        const int q = i * 64 + lane;                    // LDS slot
+        const int r = q / CPR, pch = q - r * CPR;       // CPR is a compile-time constant
+        const unsigned voff = (unsigned)((r * CPR + (pch ^ swz<CPR>(r))) * 16 - i * 1024);  // relative to this KB
+        unsigned keep;
+        asm volatile(
+            "s_nop 4\n\t"
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2 nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(sb + (unsigned long long)i * 1024), "s"(lds_base + (unsigned)i * 1024)
+            : "memory");
+    }
+}
+
+template <int MT, int NT, int KS1, int W>
+__global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
+                                                            int64_t rows, int64_t tpb, int M, FqQuantOut out) {
+    typedef WaveGeom<MT, NT, KS1, W> G;
+    constexpr int N = G::N, CPR = G::CPR;
+    static_assert(NT % 2 == 0 && NT <= 4 && MT <= 2, "a token must fit one wave's accumulators");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
+    uint4* rfr = reinterpret_cast<uint4*>(smem);
+    uint4* lfr = rfr + G::RFR;
+    unsigned char* tok0 = smem + (G::RFR + G::LFR) * 16;
+    unsigned* next_slot = reinterpret_cast<unsigned*>(tok0 + W * G::TOKBUF);
+
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* tokbuf = tok0 + wave * G::TOKBUF;
+    const unsigned tok_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)tokbuf);
+    const int64_t tok_bytes = (int64_t)M * N * 2;
+    const int n_dma = (M * CPR) >> 6;  // the launcher guarantees M * CPR % 64 == 0
+
+    const int64_t blk_base = (int64_t)blockIdx.x * tpb;
+    const int blk_cnt = (int)(rows - blk_base < tpb ? (rows - blk_base < 0 ? 0 : rows - blk_base) : tpb);
+    if (tid == 0) *next_slot = W;
+    int slot = wave;
+
+    // ---- once per workgroup: fragment image (coalesced copy), zero rows below the token, first DMA ----
+    for (int i = tid; i < G::RFR + G::LFR; i += W * 64) rfr[i] = ws[i];
+    for (int i = M * CPR + lane; i < MT * 32 * CPR; i += 64) reinterpret_cast<uint4*>(tokbuf)[i] = make_uint4(0, 0, 0, 0);
+    if (slot < blk_cnt) dma_token<CPR>(x, blk_base + slot, tok_bytes, n_dma, tok_lds, lane);
+    __syncthreads();  // (no VMEM the compiler knows of is in flight: lgkmcnt(0) + s_barrier)
+
+    // A-fragment byte offsets of this lane: row (32 mt + c), chunk (2 s + h) ^ swz(row)
+    const int sw = swz<CPR>(c);  // rows 32 mt + c share their low bits with c
+    bool first = true;
+    int next_pulled = 0;
+
+    while (slot < blk_cnt) {
+        const int64_t tok = blk_base + slot;
+        int foff = lane;
+        asm volatile("" : "+v"(foff));  // keep the fragment reads inside the loop (LICM would hoist and spill them)
+        const uint4* myr = rfr + foff;
+        const uint4* myl = lfr + foff;
+        // this token's DMA: issued in the prologue or an iteration ago; younger VMEM ops = that iteration's stores
+        if (!first && out.n_clips == 1) {
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G::STORES) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        first = false;
+
+        // ---- GEMM 1, K-step outermost: U[nt][mt] += X(mt, s) . R(s, nt) ----
+        f32x16 U[NT][MT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) U[nt][mt] = f32x16{0};
+        {
+            const uint4* tb = reinterpret_cast<const uint4*>(tokbuf);
+            f16x8 A[2][MT], B[2][NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) A[0][mt] = __builtin_bit_cast(f16x8, tb[(mt * 32 + c) * CPR + (h ^ sw)]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) B[0][nt] = __builtin_bit_cast(f16x8, myr[(nt * KS1) * 64]);
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) {
+                if (s + 1 < KS1) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        A[(s + 1) & 1][mt] =
+                            __builtin_bit_cast(f16x8, tb[(mt * 32 + c) * CPR + (((s + 1) * 2 + h) ^ sw)]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        B[(s + 1) & 1][nt] = __builtin_bit_cast(f16x8, myr[(nt * KS1 + s + 1) * 64]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) U[nt][mt] = mfma32(A[s & 1][mt], B[s & 1][nt], U[nt][mt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the token buffer has been read: pull the next token and start its DMA
+        {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            int nxt = 0;
+            if (lane == 0) nxt = (int)atomicAdd(next_slot, 1u);
+            nxt = __builtin_amdgcn_readfirstlane(nxt);
+            if (nxt < blk_cnt) dma_token<CPR>(x, blk_base + nxt, tok_bytes, n_dma, tok_lds, lane);
+            next_pulled = nxt;
+        }
+
+        // ---- fp16 rounding of U (flat_utils.py:15): C fragments -> A fragments of GEMM 2, no data movement ----
+        f16x8 Uh[NT][2 * MT];  // [nt][ks]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 2 * MT; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Uh[nt][ks][j] = (f16)U[nt][ks >> 1][(ks & 1) * 8 + j];
+
+        // ---- GEMM 2, (ks, mo) outermost: Y[nt][mo] += U(:, nt)^T(ks) . L(ks, mo) ----
+        f32x16 Y[NT][MT];  // Y^T of tile (nt, mo): rows n' = h*NT*16 + nt*16 + r, col m' = 32 mo + c
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo) Y[nt][mo] = f32x16{0};
+        {
+            f16x8 B[2];
+            B[0] = __builtin_bit_cast(f16x8, myl[0]);
+#pragma unroll
+            for (int i = 0; i < 2 * MT * MT; ++i) {  // i = ks * MT + mo
+                if (i + 1 < 2 * MT * MT) B[(i + 1) & 1] = __builtin_bit_cast(f16x8, myl[(i + 1) * 64]);
+                const int ks = i / MT, mo = i % MT;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) Y[nt][mo] = mfma32(Uh[nt][ks], B[i & 1], Y[nt][mo]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (out.rt_flags & FQ_ROUND_Y_F16) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Y[nt][mo][r] = (float)(f16)Y[nt][mo][r];
+        }
+
+        // ---- per-token extrema over the valid entries ----
+        // (one independent max3 / min3 chain per tile: a single running pair is a 128-deep dependent chain, which a
+        //  CU holding only ~2 waves per SIMD cannot hide)
+        float vmax = -INFINITY, vmin = INFINITY;
+        {
+            float pmax[NT][MT], pmin[NT][MT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo) {
+                    const f32x16& t = Y[nt][mo];
+                    float a = FqMaxOp()(t[0], t[1]), b = FqMinOp()(t[0], t[1]);
+#pragma unroll
+                    for (int r = 2; r < 16; r += 2) {
+                        a = fq_max3(a, t[r], t[r + 1]);
+                        b = fq_min3(b, t[r], t[r + 1]);
+                    }
+                    const bool ok = ((N == NT * 32) || (h * NT * 16 + nt * 16) < N) && (mo * 32 + c) < M;
+                    pmax[nt][mo] = ok ? a : -INFINITY;
+                    pmin[nt][mo] = ok ? b : INFINITY;
+                }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo) {
+                    vmax = fmaxf(vmax, pmax[nt][mo]);
+                    vmin = fminf(vmin, pmin[nt][mo]);
+                }
+        }
+        vmax = fq_wave_max(vmax);
+        vmin = fq_wave_min(vmin);
+
+        for (int ci = 0; ci < out.n_clips; ++ci) {
+            const float scale = fq_token_scale<0>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
+            const float inv = 1.0f / scale;
+            const f32x2 inv2 = {inv, inv};
+            const bool magic = fq_magic_ok(vmax, vmin, inv);
+            const bool clampq = fq_needs_clamp(vmax, vmin, inv);
+            if (lane == 0) out.scale[ci][tok] = (f16)scale;
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo) {
+                uint32_t pw[NT * 2];  // dword nt*2 + w: elements n' = h*NT*16 + nt*16 + 8w .. +8 of row 32 mo + c
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        const f32x16& t = Y[nt][mo];
+                        const int b = w * 8;
+                        f32x2 q[4];
+                        bool exact = !magic;
+                        if (magic) {
+                            float dmax = 0.0f;
+                            if (clampq) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    q[j] = fq_qmagic2<true>(f32x2{t[b + 2 * j], t[b + 2 * j + 1]}, inv2, dmax);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    q[j] = fq_qmagic2<false>(f32x2{t[b + 2 * j], t[b + 2 * j + 1]}, inv2, dmax);
+                            }
+                            exact = fq_wave_needs_exact(dmax);
+                        }
+                        if (exact) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                q[j] = f32x2{fq_qexact(t[b + 2 * j], scale), fq_qexact(t[b + 2 * j + 1], scale)};
+                        }
+                        pw[nt * 2 + w] = fq_pack8p(q[0], q[1], q[2], q[3]);
+                    }
+                // the lane's run of row m' = 32 mo + c starts at n' = h*NT*16: NT*8 bytes, valid up to N
+                if ((mo * 32 + c) < M) {
+                    uint8_t* qrow = out.q[ci] + tok * ((int64_t)M * N / 2) + (int64_t)(mo * 32 + c) * (N / 2) + h * (NT * 8);
+                    const int nvalid = h ? G::V1 : NT * 16;  // valid elements of the run
+#pragma unroll
+                    for (int p = 0; p < G::NPAIR; ++p) {
+                        if (nvalid >= p * 32 + 32)
+                            *reinterpret_cast<uint4*>(qrow + p * 16) =
+                                make_uint4(pw[4 * p], pw[4 * p + 1], pw[4 * p + 2], pw[4 * p + 3]);
+                        else if ((G::V1 % 32) == 16 && nvalid == p * 32 + 16)
+                            *reinterpret_cast<uint2*>(qrow + p * 16) = make_uint2(pw[4 * p], pw[4 * p + 1]);
+                    }
+                }
+            }
+        }
+        slot = next_pulled;
+    }
+}
+
+template <int MT, int NT, int KS1, int W>
+int launch_wave(const f16* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
+    typedef WaveGeom<MT, NT, KS1, W> G;
+    static_assert(G::LDS <= 160 * 1024, "LDS budget");
+    int64_t blocks = (rows + W - 1) / W;
+    if (blocks > n_cu) blocks = n_cu;  // one persistent workgroup per CU
+    if (blocks < 1) blocks = 1;
+    const int64_t tpb = (rows + blocks - 1) / blocks;
+    hipLaunchKernelGGL((fq_kron_wave_kernel<MT, NT, KS1, W>), dim3((unsigned)blocks), dim3(W * 64), 0, stream, x, ws, rows,
+                       tpb, M, out);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// Returns -1000 when the shape / output set is not one this kernel covers (the caller falls back to the generic one).
+// ws: fragment workspace already filled by fq_kron_prepare_kernel (rfrag [NT][KS1][64], lfrag [2MT][MT][64]).
+int fq_launch_kron_wave(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
+                        const FqQuantOut& out, int n_cu, hipStream_t stream) {
+    if ((flags & FQ_CT_MASK) != FQ_OUT_PACKED || diag != nullptr) return -1000;
+    if (M < 1 || M > 64 || (N & 15) || ((M * (N / 8)) & 63)) return -1000;
+    const int MT = (M + 31) / 32, KS1 = N / 16;
+    const uint4* w = reinterpret_cast<const uint4*>(ws);
+#define FQ_W(MT_, NT_, KS1_, W_) \
+    if (MT == MT_ && KS1 == KS1_) return launch_wave<MT_, NT_, KS1_, W_>(x, w, rows, M, out, n_cu, stream);
+    FQ_W(2, 4, 8, 7)    // 64x128
+    FQ_W(2, 4, 7, 8)    // 64x112
+    FQ_W(2, 2, 4, 16)   // 56x64, (64x64 stays with fq_kron64.hip)
+    FQ_W(1, 2, 4, 16)   // 32x64
+#undef FQ_W
+    return -1000;
+}
