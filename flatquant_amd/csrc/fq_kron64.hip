@@ -162,7 +162,7 @@ __device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok
 template <bool CLAMP>
 __device__ __forceinline__ unsigned quant_pack_token(const f32x16 (&Y)[2][2], float inv, uint32_t (&pw)[2][4]) {
     const f32x2 inv2 = {inv, inv};
-    unsigned near = 0;
+    float dm[2][4];
 #pragma unroll
     for (int mo = 0; mo < 2; ++mo)
 #pragma unroll
@@ -175,8 +175,22 @@ __device__ __forceinline__ unsigned quant_pack_token(const f32x16 (&Y)[2][2], fl
             const f32x2 q45 = fq_qmagic2<CLAMP>(f32x2{t[b + 4], t[b + 5]}, inv2, dmax);
             const f32x2 q67 = fq_qmagic2<CLAMP>(f32x2{t[b + 6], t[b + 7]}, inv2, dmax);
             pw[mo][w] = fq_pack8p(q01, q23, q45, q67);
-            near |= fq_wave_needs_exact(dmax) ? (1u << (4 * mo + w)) : 0u;  // SALU only
+            dm[mo][w] = dmax;
         }
+#ifndef FQ_K64_DEFER_NEAR
+#define FQ_K64_DEFER_NEAR 0  // 1: one wave-wide tie test per token, per-dword tests only if it fires. Keeping the eight
+                             // residual maxima alive costs 52 spilled VGPRs at this kernel's 128-register cap: 39 -> 62 us.
+#endif
+    unsigned near = 0;
+#if FQ_K64_DEFER_NEAR
+    const float dall = fq_max3(fq_max3(dm[0][0], dm[0][1], dm[0][2]), fq_max3(dm[0][3], dm[1][0], dm[1][1]),
+                               FqMaxOp()(dm[1][2], dm[1][3]));
+    if (!fq_wave_needs_exact(dall)) return 0;
+#endif
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) near |= fq_wave_needs_exact(dm[mo][w]) ? (1u << (4 * mo + w)) : 0u;  // SALU only
     return near;
 }
 

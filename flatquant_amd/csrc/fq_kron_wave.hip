@@ -50,18 +50,46 @@ struct WaveGeom {
 };
 
 // DMA of one token (n_dma instructions of 1 KB) into the wave's buffer. Instruction i moves the LDS slots
-// [64 i, 64 i + 64) (lane-linear); lane l fetches the global chunk that the swizzle maps to its slot.
+// [64 i, 64 i + 64) (lane-linear); lane l fetches the global chunk that the swizzle maps to its slot. The per-lane
+// byte offset inside the instruction's KB only depends on i & 3 (CPR = 16), i & 1 (CPR = 8) or not at all, so the
+// caller precomputes four of them (dma_offsets); four instructions share one M0 / base pair through the
+// instruction offset field, which advances the global AND the LDS address (see fq_kron64.hip).
+template <int CPR>
+__device__ __forceinline__ void dma_offsets(int lane, unsigned (&voff)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = i * 64 + lane;                    // LDS slot
+        const int r = q / CPR, pch = q - r * CPR;
+        voff[i] = (unsigned)((r * CPR + (pch ^ swz<CPR>(r))) * 16 - i * 1024);  // relative to this instruction's KB
+    }
+}
 template <int CPR>
 __device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok, int64_t tok_bytes, int n_dma,
-                                          unsigned lds_base, int lane) {
+                                          unsigned lds_base, const unsigned (&voff)[4]) {
+    static_assert(CPR == 16 || CPR == 8 || CPR == 14, "offset pattern must repeat every 4 instructions");
     const unsigned char* base = reinterpret_cast<const unsigned char*>(x) + tok * tok_bytes;  // wave-uniform
     const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)base);
     const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((size_t)base >> 32));
     const unsigned long long sb = (unsigned long long)lo32 | ((unsigned long long)hi32 << 32);
-    for (int i = 0; i < n_dma; ++i) {
-        const int q = i * 64 + lane;                    // LDS slot
-        const int r = q / CPR, pch = q - r * CPR;       // CPR is a compile-time constant
-        const unsigned voff = (unsigned)((r * CPR + (pch ^ swz<CPR>(r))) * 16 - i * 1024);  // relative to this KB
+    int g = 0;
+    for (; g + 4 <= n_dma; g += 4) {
+        unsigned keep;
+        asm volatile(
+            "s_nop 4\n\t"
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %6\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %5 nt\n\t"
+            "global_load_lds_dwordx4 %2, %5 offset:1024 nt\n\t"
+            "global_load_lds_dwordx4 %3, %5 offset:2048 nt\n\t"
+            "global_load_lds_dwordx4 %4, %5 offset:3072 nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sb + (unsigned long long)g * 1024),
+              "s"(lds_base + (unsigned)g * 1024)
+            : "memory");
+    }
+    for (int j = 0; g + j < n_dma; ++j) {  // tail (n_dma % 4 instructions)
         unsigned keep;
         asm volatile(
             "s_nop 4\n\t"
@@ -71,8 +99,27 @@ __device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok
             "global_load_lds_dwordx4 %1, %2 nt\n\t"
             "s_mov_b32 m0, %0"
             : "=&s"(keep)
-            : "v"(voff), "s"(sb + (unsigned long long)i * 1024), "s"(lds_base + (unsigned)i * 1024)
+            : "v"(j == 0 ? voff[0] : j == 1 ? voff[1] : voff[2]), "s"(sb + (unsigned long long)(g + j) * 1024),
+              "s"(lds_base + (unsigned)(g + j) * 1024)
             : "memory");
+    }
+}
+
+// Magic-number quantiser over one output row group (mo) of a lane: NT * 2 packed dwords + their residual maxima.
+template <bool CLAMP, int NT, int MT>
+__device__ __forceinline__ void quant_row(const f32x16 (&Y)[NT][MT], int mo, f32x2 inv2, uint32_t (&pw)[NT * 2],
+                                          float (&dm)[NT * 2]) {
+#pragma unroll
+    for (int k = 0; k < NT * 2; ++k) {
+        const f32x16& t = Y[k >> 1][mo];
+        const int b = (k & 1) * 8;
+        float dmax = 0.0f;
+        const f32x2 q0 = fq_qmagic2<CLAMP>(f32x2{t[b + 0], t[b + 1]}, inv2, dmax);
+        const f32x2 q1 = fq_qmagic2<CLAMP>(f32x2{t[b + 2], t[b + 3]}, inv2, dmax);
+        const f32x2 q2 = fq_qmagic2<CLAMP>(f32x2{t[b + 4], t[b + 5]}, inv2, dmax);
+        const f32x2 q3 = fq_qmagic2<CLAMP>(f32x2{t[b + 6], t[b + 7]}, inv2, dmax);
+        pw[k] = fq_pack8p(q0, q1, q2, q3);
+        dm[k] = dmax;
     }
 }
 
@@ -103,7 +150,9 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
     // ---- once per workgroup: fragment image (coalesced copy), zero rows below the token, first DMA ----
     for (int i = tid; i < G::RFR + G::LFR; i += W * 64) rfr[i] = ws[i];
     for (int i = M * CPR + lane; i < MT * 32 * CPR; i += 64) reinterpret_cast<uint4*>(tokbuf)[i] = make_uint4(0, 0, 0, 0);
-    if (slot < blk_cnt) dma_token<CPR>(x, blk_base + slot, tok_bytes, n_dma, tok_lds, lane);
+    unsigned voff[4];
+    dma_offsets<CPR>(lane, voff);
+    if (slot < blk_cnt) dma_token<CPR>(x, blk_base + slot, tok_bytes, n_dma, tok_lds, voff);
     __syncthreads();  // (no VMEM the compiler knows of is in flight: lgkmcnt(0) + s_barrier)
 
     // A-fragment byte offsets of this lane: row (32 mt + c), chunk (2 s + h) ^ swz(row)
@@ -162,7 +211,7 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
             int nxt = 0;
             if (lane == 0) nxt = (int)atomicAdd(next_slot, 1u);
             nxt = __builtin_amdgcn_readfirstlane(nxt);
-            if (nxt < blk_cnt) dma_token<CPR>(x, blk_base + nxt, tok_bytes, n_dma, tok_lds, lane);
+            if (nxt < blk_cnt) dma_token<CPR>(x, blk_base + nxt, tok_bytes, n_dma, tok_lds, voff);
             next_pulled = nxt;
         }
 
@@ -244,34 +293,31 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo) {
                 uint32_t pw[NT * 2];  // dword nt*2 + w: elements n' = h*NT*16 + nt*16 + 8w .. +8 of row 32 mo + c
+                float dm[NT * 2];     // per dword: max |residual| of the magic-number rounding
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int k = 0; k < NT * 2; ++k) dm[k] = 0.0f;
+                if (magic) {
+                    if (clampq) quant_row<true, NT, MT>(Y, mo, inv2, pw, dm);
+                    else quant_row<false, NT, MT>(Y, mo, inv2, pw, dm);
+                }
+                // ONE wave-wide test per output row group instead of one per dword (each costs a VALU -> SALU round
+                // trip); the per-dword tests only run on the rare row that has a quotient within FQ_NEAR of a tie
+                float dall = dm[0];
 #pragma unroll
-                    for (int w = 0; w < 2; ++w) {
-                        const f32x16& t = Y[nt][mo];
-                        const int b = w * 8;
-                        f32x2 q[4];
-                        bool exact = !magic;
-                        if (magic) {
-                            float dmax = 0.0f;
-                            if (clampq) {
+                for (int k = 1; k < NT * 2; k += 2) dall = fq_max3(dall, dm[k], k + 1 < NT * 2 ? dm[k + 1] : dm[k]);
+                if (!magic || fq_wave_needs_exact(dall)) {
 #pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    q[j] = fq_qmagic2<true>(f32x2{t[b + 2 * j], t[b + 2 * j + 1]}, inv2, dmax);
-                            } else {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    q[j] = fq_qmagic2<false>(f32x2{t[b + 2 * j], t[b + 2 * j + 1]}, inv2, dmax);
-                            }
-                            exact = fq_wave_needs_exact(dmax);
+                    for (int k = 0; k < NT * 2; ++k) {
+                        if (!magic || fq_wave_needs_exact(dm[k])) {
+                            const f32x16& t = Y[k >> 1][mo];
+                            const int b = (k & 1) * 8;
+                            pw[k] = fq_pack8p(f32x2{fq_qexact(t[b + 0], scale), fq_qexact(t[b + 1], scale)},
+                                              f32x2{fq_qexact(t[b + 2], scale), fq_qexact(t[b + 3], scale)},
+                                              f32x2{fq_qexact(t[b + 4], scale), fq_qexact(t[b + 5], scale)},
+                                              f32x2{fq_qexact(t[b + 6], scale), fq_qexact(t[b + 7], scale)});
                         }
-                        if (exact) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                q[j] = f32x2{fq_qexact(t[b + 2 * j], scale), fq_qexact(t[b + 2 * j + 1], scale)};
-                        }
-                        pw[nt * 2 + w] = fq_pack8p(q[0], q[1], q[2], q[3]);
                     }
+                }
                 // the lane's run of row m' = 32 mo + c starts at n' = h*NT*16: NT*8 bytes, valid up to N
                 if ((mo * 32 + c) < M) {
                     uint8_t* qrow = out.q[ci] + tok * ((int64_t)M * N / 2) + (int64_t)(mo * 32 + c) * (N / 2) + h * (NT * 8);

@@ -63,6 +63,27 @@ def test_quant_stage_bit_exact_given_kernel_transform(ops, golden, shape):
 
 
 @pytest.mark.parametrize("shape", SHAPES)
+def test_packed_only_kernels_quant_stage_bit_exact(ops, golden, shape):
+    """Packed-only launches take their own kernels (one wave per token where a token fits a wave). Each of their
+    quantiser routes -- magic-number rounding with / without clamp, true division -- and the multi-clip loop must
+    reproduce the oracle on the transform the transform-only launch returns (same MFMA sequence, same bits)."""
+    g = golden(f"kron_A_{shape}")
+    x, L, Rm = dev(g["x"]), dev(g["L"]), dev(g["R"])
+    y16 = ops.kron_quant(x, L, Rm, flags=T).y.cpu().numpy().astype(np.float32)
+    sigs = [(0.9820137619972229, 0.9820137619972229), (0.9, 0.33), (1.0, 1.0), (1e-7, 1e-7)]
+    for sig in sigs:
+        o = ops.kron_quant(x, L, Rm, [sig], P | R16)
+        ref = O.quant_outputs(y16, sig[0], sig[1])
+        assert np.array_equal(o.q[0].cpu().numpy(), ref["packed"]), sig
+        assert np.array_equal(o.scale[0].cpu().numpy(), ref["scale16"]), sig
+    o = ops.kron_quant(x, L, Rm, sigs[:3], P | R16)
+    for ci, sig in enumerate(sigs[:3]):
+        ref = O.quant_outputs(y16, sig[0], sig[1])
+        assert np.array_equal(o.q[ci].cpu().numpy(), ref["packed"]), ("multi", sig)
+        assert np.array_equal(o.scale[ci].cpu().numpy(), ref["scale16"]), ("multi", sig)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
 def test_transform_and_packed_vs_oracle_and_reference(ops, golden, shape):
     g = golden(f"kron_A_{shape}")
     x, L, Rm = dev(g["x"]), dev(g["L"]), dev(g["R"])
