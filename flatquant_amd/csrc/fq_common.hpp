@@ -208,11 +208,27 @@ __device__ __forceinline__ f32x2 fq_qfast2(f32x2 y, f32x2 inv2, float& dmax) {
 constexpr float FQ_MAGIC = 12582912.0f;
 template <bool CLAMP>
 __device__ __forceinline__ f32x2 fq_qmagic2(f32x2 y, f32x2 inv2, float& dmax) {
+#ifndef FQ_SCALAR_QUANT
+#define FQ_SCALAR_QUANT 0  // 1: single-lane-width v_fma/v_add instead of v_pk_*_f32 (build with -fno-slp-vectorize)
+#endif
+#if FQ_SCALAR_QUANT
+    f32x2 r;
+    float ex, ey;
+    {
+        const float ux = __builtin_fmaf(y.x, inv2.x, FQ_MAGIC), uy = __builtin_fmaf(y.y, inv2.y, FQ_MAGIC);
+        r.x = ux - FQ_MAGIC;
+        r.y = uy - FQ_MAGIC;
+        ex = __builtin_fmaf(y.x, inv2.x, -r.x);
+        ey = __builtin_fmaf(y.y, inv2.y, -r.y);
+    }
+    dmax = fq_max3_abs(dmax, ex, ey);
+#else
     const f32x2 magic = {FQ_MAGIC, FQ_MAGIC};
     const f32x2 u = __builtin_elementwise_fma(y, inv2, magic);
     f32x2 r = u - magic;
     const f32x2 e = __builtin_elementwise_fma(y, inv2, -r);
     dmax = fq_max3_abs(dmax, e.x, e.y);
+#endif
     if (CLAMP) {
         r.x = __builtin_amdgcn_fmed3f(r.x, -8.0f, 7.0f);
         r.y = __builtin_amdgcn_fmed3f(r.y, -8.0f, 7.0f);
@@ -232,9 +248,14 @@ __device__ __forceinline__ bool fq_needs_clamp(float vmax, float vmin, float inv
 // each interleaves them into a signed 16-bit digit string, and adding 1.5*2^23 + 0x8888 leaves the offset-binary
 // 16-bit value in the low mantissa bits (everything is an integer < 2^24, so every step is exact).
 __device__ __forceinline__ uint32_t fq_pack8p(f32x2 p0, f32x2 p1, f32x2 p2, f32x2 p3) {
+#if FQ_SCALAR_QUANT
+    const f32x2 lo = {__builtin_fmaf(p1.x, 256.0f, p0.x), __builtin_fmaf(p1.y, 256.0f, p0.y)};
+    const f32x2 hi = {__builtin_fmaf(p3.x, 256.0f, p2.x), __builtin_fmaf(p3.y, 256.0f, p2.y)};
+#else
     const f32x2 c256 = {256.0f, 256.0f};
     const f32x2 lo = __builtin_elementwise_fma(p1, c256, p0);
     const f32x2 hi = __builtin_elementwise_fma(p3, c256, p2);
+#endif
     // (kept as two scalars: with both halves in one f32x2, hipcc 7.2 folds the v_perm_b32 below onto a single source)
     const float wl = __builtin_fmaf(lo.y, 16.0f, lo.x) + (FQ_MAGIC + 34952.0f);
     const float wh = __builtin_fmaf(hi.y, 16.0f, hi.x) + (FQ_MAGIC + 34952.0f);

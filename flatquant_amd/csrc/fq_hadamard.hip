@@ -18,6 +18,7 @@
 //     fp16-in/fp32-accumulate arithmetic of the reference's `hadK @ input` in fp16). The A rows are permuted so
 //     each lane ends with 16 consecutive p of one output row k' -> 32-byte stores.
 #include "fq_common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -213,8 +214,15 @@ __global__ __launch_bounds__(256) void fq_hadamard_kernel(const f16* __restrict_
 
 }  // namespace
 
+int fq_launch_hadamard_reg(const f16* x, f16* y, int64_t rows, int n, int K, const f16* hadK, float scale, int n_cu,
+                           hipStream_t stream);  // fq_hadamard_reg.hip
+
 int fq_launch_hadamard(const f16* x, f16* y, int64_t rows, int n, int K, const f16* hadK, float scale, int n_cu,
                        hipStream_t stream) {
+    if (!getenv("FQ_HADAMARD_LDS")) {  // register FWHT where it applies (P = 512 * 2^q); this file is the general case
+        const int rc = fq_launch_hadamard_reg(x, y, rows, n, K, hadK, scale, n_cu, stream);
+        if (rc != -1000) return rc;
+    }
     HadGeom g;
     g.n = n;
     g.K = K;

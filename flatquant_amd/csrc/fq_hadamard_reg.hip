@@ -1,0 +1,288 @@
+// fq_hadamard_reg.hip — online Hadamard rotation with the FWHT done in REGISTERS (no LDS butterfly passes):
+//     y = hadK [K,K] @ FWHT_P( x.view(rows, K, P) ) * scale,   P = 512 * CH, CH a power of two.
+// Same contract and arithmetic as fq_hadamard.hip (hadamard_utils.py:132-141, deploy/functional/online_trans.py:
+// 144-151), which stays as the fallback for every other shape.
+//
+// A wave transforms one length-P vector. Lane l holds, for each 16-byte chunk j < CH, the 8 consecutive elements
+// j*512 + 8 l .. +7 (one coalesced 1 KB load per chunk), so element-index bits 0-2 are registers of a chunk, bits 3-8
+// are the lane number and bits 9+ are the chunk number. The butterfly stages run in ascending bit order — the order of
+// hadamard_utils.py:94-101 and of the fast_hadamard_transform kernel, so the fp32 results are bit-identical to the
+// oracle's fwht_f32:
+//   bits 0-2  in registers;
+//   bits 3-8  ACROSS LANES, partner = lane ^ 2^s: quad_perm DPP (s = 0, 1), half-mirror + quad reverse (s = 2),
+//             row rotate by 8 (s = 3), v_permlane16_swap / v_permlane32_swap (s = 4, 5). A lane whose bit s is set
+//             needs partner - own: its own value gets the sign bit flipped first (exact), then both kinds of lane add;
+//   bits 9+   in registers, between chunks.
+// K == 1 (n = 512 .. 8192): a wave per row, nothing but registers between the load and the store.
+// K  > 1 (n = K * 512 or K * 1024, e.g. 14336 = 28 x 512, 28672 = 28 x 1024): a 4-wave workgroup per row; wave w
+//   transforms the sub-vectors w, w+4, ... and drops them as fp16 into an LDS image [k][p] with plain 16-byte
+//   writes; the K x K factor then runs on the matrix cores exactly as in fq_hadamard.hip (A = 32 positions x 16 k,
+//   B = hadK^T fragments), its A fragments read k-strided out of the row-major image by ds_read_b64_tr_b16 (the
+//   hardware transpose read: lane i of a 16-lane group receives column i of the 4 x 16 block its group addresses).
+#include "fq_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float flip(float v, unsigned m) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) ^ m);
+}
+
+// sign masks of the six cross-lane stages: 0x80000000 where bit s of the lane number is set
+struct XMask {
+    unsigned m[6];
+    __device__ __forceinline__ explicit XMask(int lane) {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) m[s] = ((lane >> s) & 1) ? 0x80000000u : 0u;
+    }
+};
+
+// the six cross-lane butterfly stages on one register
+__device__ __forceinline__ float xlane(float v, const XMask& k) {
+    v = flip(v, k.m[0]) + dppf<0xB1>(v);                 // lane ^ 1: quad_perm [1,0,3,2]
+    v = flip(v, k.m[1]) + dppf<0x4E>(v);                 // lane ^ 2: quad_perm [2,3,0,1]
+    v = flip(v, k.m[2]) + dppf<0x1B>(dppf<0x141>(v));    // lane ^ 4: row_half_mirror (^7) then quad_perm [3,2,1,0] (^3)
+    v = flip(v, k.m[3]) + dppf<0x128>(v);                // lane ^ 8: row_ror:8
+    {   // lane ^ 16: after the swap, a = value of the lower lane of the pair, b = of the upper one, in BOTH lanes' view:
+        // even rows keep a = own and receive b = partner; odd rows receive a = partner and keep b = own
+        float a = v, b = v;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        v = a + flip(b, k.m[4]);
+    }
+    {   // lane ^ 32: same with the wave's halves
+        float a = v, b = v;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        v = a + flip(b, k.m[5]);
+    }
+    return v;
+}
+
+template <int W>  // radix 2^W butterfly over v[0 .. 2^W), stages in ascending bit order
+__device__ __forceinline__ void bfly8(float (&v)[8]) {
+#pragma unroll
+    for (int b = 0; b < W; ++b) {
+        const int s = 1 << b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (!(i & s)) {
+                const float a = v[i], c = v[i + s];
+                v[i] = a + c;
+                v[i + s] = a - c;
+            }
+    }
+}
+
+// FWHT of a length 512*CH vector held as v[chunk][8] (see the header for the element mapping)
+template <int CH>
+__device__ __forceinline__ void fwht_wave(float (&v)[CH][8], const XMask& k) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) bfly8<3>(v[j]);
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = xlane(v[j][e], k);
+#pragma unroll
+    for (int s = 1; s < CH; s <<= 1)
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (!(j & s)) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = v[j][e], c = v[j + s][e];
+                    v[j][e] = a + c;
+                    v[j + s][e] = a - c;
+                }
+            }
+}
+
+template <int CH>
+__device__ __forceinline__ void load_vec(const f16* __restrict__ p, int lane, float (&v)[CH][8]) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const f16x8 hv = __builtin_bit_cast(
+            f16x8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + j * 512 + lane * 8)));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = (float)hv[e];
+    }
+}
+template <int CH>
+__device__ __forceinline__ void to_f16(const float (&v)[CH][8], float scale, f16x8 (&o)[CH]) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[j][e] = fq_mul_to_f16(v[j][e], scale);
+}
+
+// ---- K == 1: one wave per row ----
+template <int CH>
+__global__ __launch_bounds__(256) void fq_had_pow2_kernel(const f16* __restrict__ x, f16* __restrict__ y, int64_t rows,
+                                                          float scale) {
+    constexpr int n = 512 * CH;
+    const int lane = threadIdx.x & 63;
+    const XMask k(lane);
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t row = wave_id; row < rows; row += n_waves) {
+        float v[CH][8];
+        load_vec<CH>(x + row * n, lane, v);
+        fwht_wave<CH>(v, k);
+        f16x8 o[CH];
+        to_f16<CH>(v, scale, o);
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            *reinterpret_cast<uint4*>(y + row * n + j * 512 + lane * 8) = __builtin_bit_cast(uint4, o[j]);
+    }
+}
+
+// ---- K > 1: a 4-wave workgroup per row, K x K factor on the matrix cores ----
+struct KmixGeom {
+    int K, KP, KT;  // K, K padded to 16, 32-wide output tiles over k'
+};
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <int CH>
+__global__ __launch_bounds__(256) void fq_had_kmix_kernel(const f16* __restrict__ x, f16* __restrict__ y, int64_t rows,
+                                                          KmixGeom g, const f16* __restrict__ hadK, float scale) {
+    constexpr int P = 512 * CH;
+    constexpr int PITCH = P + 8;  // fp16 elements per image row: +16 bytes skews consecutive k rows across the banks
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f16* V = reinterpret_cast<f16*>(smem);                                   // [KP][PITCH]
+    uint4* kfrag = reinterpret_cast<uint4*>(smem + (size_t)g.KP * PITCH * 2);  // [KP/16][KT][64]
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = g.K;
+    const XMask km(lane);
+
+    // once per workgroup: B fragments of hadK^T (frag (s, kt): B[k = 16 s + 8 h + j][k' = 32 kt + c] = hadK[k'][k]),
+    // zero rows K .. KP of the image (their B entries are zero, but 0 * garbage must not be NaN)
+    {
+        const int nfr = (g.KP / 16) * g.KT * 64;
+        for (int item = tid; item < nfr; item += 256) {
+            const int f = item >> 6, ln = item & 63, fh = ln >> 5, fc = ln & 31;
+            const int s = f / g.KT, kt = f - s * g.KT;
+            const int kp = kt * 32 + fc;
+            f16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kk = s * 16 + fh * 8 + j;
+                v[j] = (kk < K && kp < K) ? hadK[kp * K + kk] : (f16)0.0f;
+            }
+            kfrag[item] = __builtin_bit_cast(uint4, v);
+        }
+        for (int i = K * PITCH + tid * 8; i < g.KP * PITCH; i += 256 * 8)
+            *reinterpret_cast<uint4*>(V + i) = make_uint4(0, 0, 0, 0);
+    }
+
+    // transpose-read addressing of this lane (see the header): 16-lane group grp = 2 h + (c >> 4), index i in it
+    const int grp = lane >> 4, i16 = lane & 15;
+    const int q = i16 & 3;  // the 4-column chunk this lane PROVIDES
+    const int pcol = 16 * (q & 1) + 8 * (grp & 1) + 4 * (q >> 1);
+    const int tr_base = (8 * (grp >> 1) + (i16 >> 2)) * PITCH + pcol;  // element offset; + (16 s + 4 rd) PITCH + 32 pt
+
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const f16* xr = x + row * (int64_t)K * P;
+        __syncthreads();  // the previous row's fragment reads are done
+        for (int k = wave; k < K; k += 4) {
+            float v[CH][8];
+            load_vec<CH>(xr + (int64_t)k * P, lane, v);
+            fwht_wave<CH>(v, km);
+            f16x8 o[CH];
+            to_f16<CH>(v, scale, o);
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                *reinterpret_cast<uint4*>(V + k * PITCH + j * 512 + lane * 8) = __builtin_bit_cast(uint4, o[j]);
+        }
+        __syncthreads();
+        // ---- out^T[p][k'] = sum_k V[k][p] hadK[k'][k]; lane (h, .) ends with p = 32 pt + 16 h + reg of row k' ----
+        f16* yp = y + row * (int64_t)K * P;
+        const int ksteps = g.KP >> 4;
+        for (int t = wave; t < (P / 32) * g.KT; t += 4) {
+            const int pt = t / g.KT, kt = t - pt * g.KT;
+            f32x16 acc = {0};
+            for (int s = 0; s < ksteps; ++s) {
+                const f16* ap = V + tr_base + (16 * s) * PITCH + 32 * pt;
+                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap));
+                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + 4 * PITCH));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                const s16x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                acc = mfma32(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, kfrag[(s * g.KT + kt) * 64 + lane]), acc);
+            }
+            const int kp = kt * 32 + c;
+            if (kp < K) {
+                f16x8 v0, v1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v0[e] = (f16)acc[e];
+                    v1[e] = (f16)acc[8 + e];
+                }
+                uint4* op = reinterpret_cast<uint4*>(yp + (int64_t)kp * P + pt * 32 + h * 16);
+                op[0] = __builtin_bit_cast(uint4, v0);
+                op[1] = __builtin_bit_cast(uint4, v1);
+            }
+        }
+    }
+}
+
+template <int CH>
+int launch_pow2(const f16* x, f16* y, int64_t rows, float scale, int n_cu, hipStream_t stream) {
+    int64_t blocks = (rows + 3) / 4;
+    const int64_t cap = (int64_t)n_cu * (CH <= 8 ? 4 : 2);  // 16 / 8 waves per CU
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((fq_had_pow2_kernel<CH>), dim3((unsigned)blocks), dim3(256), 0, stream, x, y, rows, scale);
+    return (int)hipGetLastError();
+}
+
+template <int CH>
+int launch_kmix(const f16* x, f16* y, int64_t rows, int K, const f16* hadK, float scale, int n_cu, hipStream_t stream) {
+    KmixGeom g;
+    g.K = K;
+    g.KP = (K + 15) / 16 * 16;
+    g.KT = (K + 31) / 32;
+    const size_t lds = (size_t)g.KP * (512 * CH + 8) * 2 + (size_t)(g.KP / 16) * g.KT * 1024;
+    if (lds > 160 * 1024) return -1000;
+    auto kern = fq_had_kmix_kernel<CH>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    int64_t blocks = (int64_t)n_cu * per_cu;
+    if (blocks > rows) blocks = rows;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, x, y, rows, g, hadK, scale);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// Returns -1000 for shapes this file does not cover (the caller falls back to fq_hadamard.hip).
+int fq_launch_hadamard_reg(const f16* x, f16* y, int64_t rows, int n, int K, const f16* hadK, float scale, int n_cu,
+                           hipStream_t stream) {
+    if (K < 1 || n % K) return -1000;
+    const int P = n / K;
+    if (K == 1) {
+        switch (P) {
+            case 512: return launch_pow2<1>(x, y, rows, scale, n_cu, stream);
+            case 1024: return launch_pow2<2>(x, y, rows, scale, n_cu, stream);
+            case 2048: return launch_pow2<4>(x, y, rows, scale, n_cu, stream);
+            case 4096: return launch_pow2<8>(x, y, rows, scale, n_cu, stream);
+            case 8192: return launch_pow2<16>(x, y, rows, scale, n_cu, stream);
+            default: return -1000;
+        }
+    }
+    if (K > 192) return -1000;
+    if (P == 512) return launch_kmix<1>(x, y, rows, K, hadK, scale, n_cu, stream);
+    if (P == 1024) return launch_kmix<2>(x, y, rows, K, hadK, scale, n_cu, stream);
+    return -1000;
+}

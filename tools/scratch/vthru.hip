@@ -73,6 +73,22 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, float seed) {
                         acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[c], 0, 0, 0);
                         asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(p[r * 4 + c]) : "v"(q[r * 4 + c]));
                     }
+            } else if (OP >= 13 && OP <= 17) {  // 8 MFMAs, each followed by fillers of one kind
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[c], 0, 0, 0);
+#pragma unroll
+                        for (int z = 0; z < (OP == 13 ? 8 : 4); ++z) {
+                            const int i = (r * 4 + c + z) & 7;
+                            if (OP == 13) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b[z & 7]));
+                            if (OP == 14) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b[z & 7]));
+                            if (OP == 15) asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(a[i]) : "v"(b[z]), "v"(b[z + 1]));
+                            if (OP == 16) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b[z]), "v"(b[z + 1]));
+                            if (OP == 17) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b[z]));
+                        }
+                    }
             } else if (OP == 12) {  // 8 MFMAs, each followed by 4 pk_fma
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
@@ -124,5 +140,10 @@ int main() {
     run<10>("mfma_32x32x16_f16 (4 acc)", d);
     run<11>("mfma + 1 pk_fma each (per pair)", d);
     run<12>("mfma + 4 pk_fma each (per 5)", d);
+    run<13>("mfma + 8 v_fma_f32 each", d);
+    run<14>("mfma + 4 v_fma_f32 each", d);
+    run<15>("mfma + 4 v_max3_f32 each", d);
+    run<16>("mfma + 4 v_med3_f32 each", d);
+    run<17>("mfma + 4 v_cvt_pk_f16_f32 each", d);
     return 0;
 }
