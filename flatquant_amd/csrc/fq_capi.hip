@@ -15,6 +15,7 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream);
 int64_t fq_kron_generic_workspace_bytes(int M, int N);
+int fq_launch_kron_prepare(const f16* left, const f16* right, int M, int N, void* workspace, hipStream_t stream);
 int fq_launch_block(int flags, const f16* x, const f16* P, int64_t rows, int R, int C, int transpose_out,
                     const FqQuantOut& out, int n_cu, hipStream_t stream);
 int fq_launch_hadamard(const f16* x, f16* y, int64_t rows, int n, int K, const f16* hadK, float scale,
@@ -67,7 +68,7 @@ int fill_out(const char* what, FqQuantOut& o, const float* sig_max, const float*
     memset(&o, 0, sizeof(o));
     const int outs = flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM);
     if (outs == 0) return fail(FQ_EINVAL, "%s: flags select no output", what);
-    if (flags & ~(FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_ROUND_Y_F16 | FQ_NO_CLAMP0 |
+    if (flags & ~(FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_ROUND_Y_F16 | FQ_NO_CLAMP0 | FQ_WS_PREPARED |
                   FQ_QUANT_F16))
         return fail(FQ_EINVAL, "%s: unknown flag bits 0x%x", what, flags);
     if (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) {
@@ -149,6 +150,19 @@ int fq_kron_quant_f16(const void* x, const void* left, const void* right, const 
         return fail(FQ_EINVAL, "fq_kron_quant_f16: workspace of %lld bytes required for M=%d N=%d (got %lld)",
                     (long long)fq_kron_generic_workspace_bytes(M, N), M, N, (long long)(workspace ? workspace_bytes : 0));
     return check_launch(rc, "fq_kron_quant_f16[generic]");
+}
+
+int fq_kron_prepare_f16(const void* left, const void* right, int M, int N, void* workspace, int64_t workspace_bytes,
+                        void* stream) {
+    if (M == 64 && N == 64) return FQ_OK;
+    const int64_t need = fq_kron_workspace_bytes(M, N);
+    if (need < 0) return fail(FQ_EUNSUPPORTED, "fq_kron_prepare_f16: no kernel for factors (%d, %d)", M, N);
+    if (!left || !right) return fail(FQ_EINVAL, "fq_kron_prepare_f16: left/right is NULL");
+    if (!workspace || workspace_bytes < need)
+        return fail(FQ_EINVAL, "fq_kron_prepare_f16: workspace of %lld bytes required (got %lld)", (long long)need,
+                    (long long)(workspace ? workspace_bytes : 0));
+    return check_launch(fq_launch_kron_prepare((const f16*)left, (const f16*)right, M, N, workspace, (hipStream_t)stream),
+                        "fq_kron_prepare_f16");
 }
 
 int64_t fq_kron_workspace_bytes(int M, int N) {

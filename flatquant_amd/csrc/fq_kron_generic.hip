@@ -632,6 +632,14 @@ int64_t fq_kron_generic_workspace_bytes(int M, int N) {
     return ((int64_t)NT * KS1 + 2 * (int64_t)MT * MT) * 1024;
 }
 
+int fq_launch_kron_prepare(const f16* left, const f16* right, int M, int N, void* workspace, hipStream_t stream) {
+    const int MT = tiles32(M), NT = tiles32(N), KS1 = (N + 15) / 16;
+    const int items = (NT * KS1 + 2 * MT * MT) * 64;
+    hipLaunchKernelGGL(fq_kron_prepare_kernel, dim3((items + 255) / 256), dim3(256), 0, stream, left, right, M, N, MT,
+                       NT, KS1, reinterpret_cast<uint4*>(workspace));
+    return (int)hipGetLastError();
+}
+
 int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream) {
@@ -644,11 +652,12 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
     g.pitch = (g.KS1 * 2) | 1;
     const int MT = tiles32(M), NT = tiles32(N);
     uint4* ws = reinterpret_cast<uint4*>(workspace);
-    const int items = (NT * g.KS1 + 2 * MT * MT) * 64;
-    hipLaunchKernelGGL(fq_kron_prepare_kernel, dim3((items + 255) / 256), dim3(256), 0, stream, left, right, M, N, MT,
-                       NT, g.KS1, ws);
-    int rc = (int)hipGetLastError();
-    if (rc != 0) return rc;
+    int rc = 0;
+    if (!(flags & FQ_WS_PREPARED)) {
+        rc = fq_launch_kron_prepare(left, right, M, N, workspace, stream);
+        if (rc != 0) return rc;
+    }
+    flags &= ~FQ_WS_PREPARED;
     if (!getenv("FQ_KRON_NO_WAVE")) {  // one wave per token where a token fits a wave (packed output only)
         rc = fq_launch_kron_wave(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;

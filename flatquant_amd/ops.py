@@ -6,6 +6,7 @@ kernels.  Inputs must be CUDA (ROCm) fp16 contiguous tensors — violations rais
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 from typing import List, Optional, Sequence, Tuple
 
@@ -13,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import (FQ_MAX_CLIPS, FQ_NO_CLAMP0, FQ_OUT_FAKEQUANT, FQ_OUT_PACKED, FQ_OUT_TRANSFORM,
-                   FQ_QUANT_F16, FQ_ROUND_Y_F16, check, lib)
+                   FQ_QUANT_F16, FQ_ROUND_Y_F16, FQ_WS_PREPARED, check, lib)
 
 Sig = Tuple[float, float]  # (sigmoid(clip_factor_a_max), sigmoid(clip_factor_a_min)); (1.0, 1.0) = no clip
 
@@ -83,22 +84,35 @@ def _alloc_outputs(x: torch.Tensor, rows: int, d: int, n_clips: int, flags: int,
     return o
 
 
-_WORKSPACES = {}
+# Fragment workspaces of the non-64x64 Kronecker kernels, one per (device, stream, left, right): the launch re-packs
+# left/right into MFMA fragment order there (~5 us); a deployed layer passes the same two buffers every call, so the
+# second call onwards skips the re-pack (FQ_WS_PREPARED). An entry keeps its tensors alive (their addresses cannot be
+# recycled under it) and is keyed by torch's version counters (in-place updates miss). LRU-bounded.
+_WS_LRU: "collections.OrderedDict" = collections.OrderedDict()
+_WS_LRU_MAX = 512
 
 
-def _kron_workspace(device: torch.device, M: int, N: int):
-    """Per-(device, stream, shape) scratch for the fragment re-pack of the generic Kronecker kernel (the C ABI
-    allocates nothing). Keyed by stream too: two streams must not share a buffer the launches rewrite."""
+def _kron_workspace(device: torch.device, M: int, N: int, left: torch.Tensor, right: torch.Tensor):
+    """-> (workspace | None, bytes, prepared, key). Keyed by stream too: two streams must not share a buffer. The
+    caller registers a fresh workspace (_kron_workspace_commit) once the launch that fills it has been accepted."""
     nbytes = int(lib.fq_kron_workspace_bytes(M, N))
     if nbytes < 0:
         raise _lib.FqError(nbytes, f"no kernel for Kronecker factors ({M}, {N}): need N % 16 == 0, M <= 128, N <= 256")
     if nbytes == 0:
-        return None, 0
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, M, N)
-    ws = _WORKSPACES.get(key)
-    if ws is None:
-        ws = _WORKSPACES[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    return ws, nbytes
+        return None, 0, False, None
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, M, N,
+           left.data_ptr(), left._version, right.data_ptr(), right._version)
+    ent = _WS_LRU.get(key)
+    if ent is not None:
+        _WS_LRU.move_to_end(key)
+        return ent[0], nbytes, True, key
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes, False, key
+
+
+def _kron_workspace_commit(key, ws: torch.Tensor, left: torch.Tensor, right: torch.Tensor) -> None:
+    _WS_LRU[key] = (ws, left, right)
+    if len(_WS_LRU) > _WS_LRU_MAX:
+        _WS_LRU.popitem(last=False)
 
 
 def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),),
@@ -121,10 +135,12 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
     if rows == 0:
         return o
     with torch.cuda.device(x.device):
-        ws, ws_bytes = _kron_workspace(x.device, M, N)
+        ws, ws_bytes, prepared, key = _kron_workspace(x.device, M, N, left, right)
         check(lib.fq_kron_quant_f16(_ptr(x), _ptr(left), _ptr(right), _ptr(diag), rows, M, N, smax, smin, n,
-                                    flags, _ptr_array(o.q), _ptr_array(o.scale), _ptr_array(o.fq), _ptr(o.y),
-                                    _ptr(ws), ws_bytes, _stream(x)))
+                                    flags | (FQ_WS_PREPARED if prepared else 0), _ptr_array(o.q), _ptr_array(o.scale),
+                                    _ptr_array(o.fq), _ptr(o.y), _ptr(ws), ws_bytes, _stream(x)))
+        if key is not None and not prepared:
+            _kron_workspace_commit(key, ws, left, right)
     return o
 
 

@@ -47,6 +47,10 @@ extern "C" {
 #define FQ_QUANT_F16      0x20  /* scale, x/scale and scale*q evaluated in fp16 (quant_utils.py lac=False
                                    path and quant.cu:40 __hdiv); default is fp32                         */
 
+#define FQ_WS_PREPARED    0x40  /* `workspace` already holds the fragment image of (left, right), written by
+                                   fq_kron_prepare_f16: skip the re-pack launch (the matrices are constants of a
+                                   deployed layer; the re-pack is ~5 us per call)                          */
+
 #define FQ_MAX_CLIPS 4
 
 /*
@@ -78,6 +82,12 @@ int fq_kron_quant_f16(const void* x, const void* left, const void* right, const 
 /* Bytes of device workspace fq_kron_quant_f16 needs for factor sizes (M, N); 0 when none is needed;
  * negative (FQ_EUNSUPPORTED) when no kernel handles the shape (needs N % 16 == 0, M <= 128, N <= 256). */
 int64_t fq_kron_workspace_bytes(int M, int N);
+
+/* Re-pack left [M,M] / right [N,N] into the MFMA fragment image fq_kron_quant_f16 consumes, once, for callers whose
+ * matrices do not change between calls (deploy/nn/online_trans.py:18-67 keeps them as buffers). Pass the same
+ * workspace with FQ_WS_PREPARED afterwards. A no-op (FQ_OK) for M = N = 64, which needs no workspace. */
+int fq_kron_prepare_f16(const void* left, const void* right, int M, int N, void* workspace, int64_t workspace_bytes,
+                        void* stream);
 
 /*
  * Single-matrix transform over the LAST axis of [rows, R, C] blocks (o_proj head transform):

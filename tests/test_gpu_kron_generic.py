@@ -153,3 +153,38 @@ def test_unsupported_shape_raises(ops):
     x = torch.randn(2, 60 * 63).half().cuda()
     with pytest.raises(FqError):
         ops.kron_quant(x, torch.eye(60).half().cuda(), torch.eye(63).half().cuda())
+
+
+def test_prepared_workspace_reuse_and_invalidation(ops):
+    """The fragment re-pack of (left, right) is skipped when the same two buffers come back (FQ_WS_PREPARED); an
+    in-place update of a matrix must invalidate that, and fq_kron_prepare_f16 + the flag must equal a plain call."""
+    import ctypes
+    from flatquant_amd._lib import FQ_WS_PREPARED, check, lib
+    gen = torch.Generator().manual_seed(5)
+    M, N, rows = 64, 128, 33
+    x = torch.randn(rows, M * N, generator=gen).half().cuda()
+    L = (torch.randn(M, M, generator=gen) / 8).half().cuda()
+    R = (torch.randn(N, N, generator=gen) / 11).half().cuda()
+    sig = [(0.95, 0.9)]
+    a = ops.kron_quant(x, L, R, sig, P)
+    b = ops.kron_quant(x, L, R, sig, P)            # second call: workspace reused
+    assert torch.equal(a.q[0], b.q[0]) and torch.equal(a.scale[0], b.scale[0])
+    L.mul_(-1.0)                                   # in-place: same address, new version
+    c = ops.kron_quant(x, L, R, sig, P)
+    ref = ops.kron_quant(x, L.clone(), R.clone(), sig, P)
+    assert torch.equal(c.q[0], ref.q[0]) and torch.equal(c.scale[0], ref.scale[0])
+    assert not torch.equal(c.q[0], a.q[0])
+    # the C ABI directly: prepare once, then FQ_WS_PREPARED with garbage-proofing (matrix pointers still passed)
+    nbytes = int(lib.fq_kron_workspace_bytes(M, N))
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(lib.fq_kron_prepare_f16(L.data_ptr(), R.data_ptr(), M, N, ws.data_ptr(), nbytes, st))
+    q = torch.empty(rows, M * N // 2, dtype=torch.uint8, device="cuda")
+    s = torch.empty(rows, dtype=torch.float16, device="cuda")
+    qa, sa, none4 = (ctypes.c_void_p * 4)(), (ctypes.c_void_p * 4)(), (ctypes.c_void_p * 4)()
+    qa[0], sa[0] = q.data_ptr(), s.data_ptr()
+    smax, smin = (ctypes.c_float * 4)(sig[0][0]), (ctypes.c_float * 4)(sig[0][1])
+    check(lib.fq_kron_quant_f16(x.data_ptr(), L.data_ptr(), R.data_ptr(), None, rows, M, N, smax, smin, 1,
+                                P | FQ_WS_PREPARED, qa, sa, none4, None, ws.data_ptr(), nbytes, st))
+    assert torch.equal(q, c.q[0]) and torch.equal(s, c.scale[0])
+    assert lib.fq_kron_prepare_f16(L.data_ptr(), R.data_ptr(), M, N, ws.data_ptr(), 16, st) < 0   # too small

@@ -5,8 +5,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
+# kernel trace: the default bench command (1000 steps after 200 warm-up launches), minus the CPU baseline leg
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1
+CMD="python $R/bench.py --steps 200 --warmup 100 --no-cpu-baseline"   # counter passes: fewer launches
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
