@@ -12,7 +12,15 @@
 // PERMUTED (free: each lane picks the row it loads) so that in the C/D fragment lane (h, c') ends up with the
 // 64 consecutive rows r = 64h .. 64h+63 of output column c' — i.e. one contiguous run of the transposed
 // output, stored with 16-byte stores. Supported: R in {32, 64, 96, 128}, C in {32, 64}.
+//
+// C = 32: a row is 64 bytes and the two k-halves of the 32 lanes cover it, so the fragment loads are 2 KB contiguous
+// per instruction. C = 64 (Llama-2-70B: 64 heads): the same loads would take 32 bytes out of each of 32 different
+// 128-byte lines per instruction (4x the address work, measured 150 us against 45 us for the same bytes per
+// element) -> DMA variant: the token goes HBM -> LDS in whole 1 KB pieces (fq_dma.hpp, source-side swizzle) into a
+// wave-private buffer, the A fragments are conflict-free ds_read_b128, and the next token's DMA is issued as soon as
+// the GEMM has read the current one.
 #include "fq_common.hpp"
+#include "fq_dma.hpp"
 
 namespace {
 
@@ -25,11 +33,13 @@ __device__ __forceinline__ int rmap(int RT, int rt, int i) {
     return ((i >> 2) & 1) * (RT * 16) + rt * 16 + (i & 3) + 4 * (i >> 3);
 }
 
-template <int RT, int CT>
+template <int RT, int CT, bool DMA>
 __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x, const f16* __restrict__ P,
                                                        int64_t rows, FqQuantOut out, int flags) {
-    constexpr int R = RT * 32, C = CT * 32, KS = C / 16, D = R * C;
+    constexpr int R = RT * 32, C = CT * 32, KS = C / 16, D = R * C, CPR = C / 8;
+    static_assert(!DMA || CPR == 8, "the DMA variant is the C = 64 one");
     __shared__ __attribute__((aligned(16))) uint4 pfrag[KS * CT * 64];  // [(s*CT + ct)][lane]
+    __shared__ __attribute__((aligned(16))) unsigned char tokmem[DMA ? 4 * D * 2 : 16];  // wave-private token buffers
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     for (int item = tid; item < KS * CT * 64; item += 256) {
         const int f = item >> 6, ln = item & 63, fh = ln >> 5, fc = ln & 31;
@@ -39,11 +49,29 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
         for (int j = 0; j < 8; ++j) v[j] = P[(s * 16 + fh * 8 + j) * C + ct * 32 + fc];
         pfrag[item] = __builtin_bit_cast(uint4, v);
     }
-    __syncthreads();
-
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + (tid >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
+    unsigned char* tokbuf = tokmem + (DMA ? (tid >> 6) * D * 2 : 0);
+    const unsigned tok_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)tokbuf);
+    unsigned voff[4] = {0, 0, 0, 0};
+    if (DMA) {
+        dma_offsets<8>(lane, voff);
+        if (wave_id < rows) dma_token<8>(x, wave_id, (int64_t)D * 2, D * 2 / 1024, tok_lds, voff);
+    }
+    __syncthreads();  // (the compiler knows of no VMEM in flight here: lgkmcnt(0) + s_barrier)
+    // packed-only single-clip launches: the stores a token issues after its successor's DMA are a fixed number, so the
+    // wait for that DMA can leave them in flight
+    constexpr int PACKED_STORES = CT * ((RT + 1) / 2) + 1;
+    const bool counted = DMA && (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM)) == FQ_OUT_PACKED &&
+                         out.n_clips == 1;
+    bool first = true;
+
     for (int64_t tok = wave_id; tok < rows; tok += n_waves) {
+        if (DMA) {
+            if (counted && !first) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PACKED_STORES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            first = false;
+        }
         int foff = lane;
         asm volatile("" : "+v"(foff));  // keep the fragment reads inside the loop (see fq_kron64.hip)
         const uint4* myp = pfrag + foff;
@@ -51,17 +79,25 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
         f32x16 Y[RT][CT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            const uint4* xp = reinterpret_cast<const uint4*>(x + tok * D + (int64_t)rmap(RT, rt, c) * C + h * 8);
+            const int row = rmap(RT, rt, c);
+            const uint4* xp = reinterpret_cast<const uint4*>(x + tok * D + (int64_t)row * C + h * 8);
+            const uint4* lp = reinterpret_cast<const uint4*>(tokbuf) + row * CPR;  // chunk (2 s + h) ^ swz(row)
+            const int sw = DMA ? swz<8>(row) : 0;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) Y[rt][ct] = f32x16{0};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const f16x8 a = __builtin_bit_cast(f16x8, __builtin_nontemporal_load(
-                                    reinterpret_cast<const u32x4*>(xp) + s * 2));  // k = 16 s + 8 h .. +8
+                f16x8 a;  // k = 16 s + 8 h .. +8
+                if (DMA) a = __builtin_bit_cast(f16x8, lp[(s * 2 + h) ^ sw]);
+                else a = __builtin_bit_cast(f16x8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xp) + s * 2));
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
                     Y[rt][ct] = mfma32(a, __builtin_bit_cast(f16x8, myp[(s * CT + ct) * 64]), Y[rt][ct]);
             }
+        }
+        if (DMA) {  // the buffer has been read: fetch this wave's next token while the current one is quantised
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (tok + n_waves < rows) dma_token<8>(x, tok + n_waves, (int64_t)D * 2, D * 2 / 1024, tok_lds, voff);
         }
         // lane (h, c) now holds, for column c' = 32 ct + c, rows r = RT*16*h + 16 rt + reg
 
@@ -117,6 +153,7 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
                 f16* frow = (flags & FQ_OUT_FAKEQUANT)
                                 ? out.fq[ci] + tok * D + (int64_t)(ct * 32 + c) * R + h * (RT * 16)
                                 : nullptr;
+                uint2 pk[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
                     float qv[16];
@@ -132,11 +169,13 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
                             for (int r = 0; r < 16; ++r) qv[r] = fq_qexact(Y[rt][ct][r], scale);
                         }
                     }
-                    if (flags & FQ_OUT_PACKED) {
-                        uint2 pk;
-                        pk.x = fq_pack8(qv[0], qv[1], qv[2], qv[3], qv[4], qv[5], qv[6], qv[7]);
-                        pk.y = fq_pack8(qv[8], qv[9], qv[10], qv[11], qv[12], qv[13], qv[14], qv[15]);
-                        *reinterpret_cast<uint2*>(qrow + rt * 8) = pk;
+                    if (flags & FQ_OUT_PACKED) {  // 8 bytes per row tile; two tiles share one 16-byte store
+                        pk[rt].x = fq_pack8(qv[0], qv[1], qv[2], qv[3], qv[4], qv[5], qv[6], qv[7]);
+                        pk[rt].y = fq_pack8(qv[8], qv[9], qv[10], qv[11], qv[12], qv[13], qv[14], qv[15]);
+                        if (rt & 1)
+                            *reinterpret_cast<uint4*>(qrow + (rt - 1) * 8) = make_uint4(pk[rt - 1].x, pk[rt - 1].y, pk[rt].x, pk[rt].y);
+                        else if (rt == RT - 1)
+                            *reinterpret_cast<uint2*>(qrow + rt * 8) = pk[rt];
                     }
                     if (flags & FQ_OUT_FAKEQUANT) {
                         f16x8 v0, v1;
@@ -163,11 +202,12 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
 template <int RT, int CT>
 int launch_block(int flags, const f16* x, const f16* P, int64_t rows, const FqQuantOut& out, int n_cu,
                  hipStream_t stream) {
+    constexpr bool DMA = CT == 2;  // C = 64: whole-line DMA staging (see the header)
     int64_t blocks = (rows + 3) / 4;
     const int64_t cap = (int64_t)n_cu * 2;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((fq_block_kernel<RT, CT>), dim3((unsigned)blocks), dim3(256), 0, stream, x, P, rows, out, flags);
+    hipLaunchKernelGGL((fq_block_kernel<RT, CT, DMA>), dim3((unsigned)blocks), dim3(256), 0, stream, x, P, rows, out, flags);
     return (int)hipGetLastError();
 }
 

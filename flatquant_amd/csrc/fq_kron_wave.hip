@@ -19,21 +19,12 @@
 //     up with NT*16 consecutive n' of an output row = NT*8 contiguous bytes -> 16-byte stores.
 // LDS reads per 64x128 token: 16 (A) + 32 (R) + 8 (L) ds_read_b128 against 96 MFMAs.
 #include "fq_common.hpp"
+#include "fq_dma.hpp"
 
 namespace {
 
 __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
-typedef __attribute__((address_space(3))) void lds_void;
-
-// chunk swizzle of row r inside the token buffer (16-byte chunks, CPR per row): 8 consecutive rows must spread over
-// the 16 chunk-aligned bank groups. CPR = 16: rows alias -> XOR the row's low bits; CPR = 8: pairs of rows alias;
-// CPR = 14 (N = 112): the row pitch already rotates by 14 mod 16.
-template <int CPR>
-__device__ __forceinline__ int swz(int r) {
-    return CPR == 16 ? (r & 15) : CPR == 8 ? ((r >> 1) & 7) : 0;
 }
 
 template <int MT, int NT, int KS1, int W>
@@ -48,62 +39,6 @@ struct WaveGeom {
     static constexpr int NPAIR = NT / 2;                    // 16-byte pieces of a lane's packed run
     static constexpr int STORES = MT * (NPAIR + ((V1 % 32) == 16 ? 1 : 0)) + 1;  // VMEM stores per token and clip
 };
-
-// DMA of one token (n_dma instructions of 1 KB) into the wave's buffer. Instruction i moves the LDS slots
-// [64 i, 64 i + 64) (lane-linear); lane l fetches the global chunk that the swizzle maps to its slot. The per-lane
-// byte offset inside the instruction's KB only depends on i & 3 (CPR = 16), i & 1 (CPR = 8) or not at all, so the
-// caller precomputes four of them (dma_offsets); four instructions share one M0 / base pair through the
-// instruction offset field, which advances the global AND the LDS address (see fq_kron64.hip).
-template <int CPR>
-__device__ __forceinline__ void dma_offsets(int lane, unsigned (&voff)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = i * 64 + lane;                    // LDS slot
-        const int r = q / CPR, pch = q - r * CPR;
-        voff[i] = (unsigned)((r * CPR + (pch ^ swz<CPR>(r))) * 16 - i * 1024);  // relative to this instruction's KB
-    }
-}
-template <int CPR>
-__device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok, int64_t tok_bytes, int n_dma,
-                                          unsigned lds_base, const unsigned (&voff)[4]) {
-    static_assert(CPR == 16 || CPR == 8 || CPR == 14, "offset pattern must repeat every 4 instructions");
-    const unsigned char* base = reinterpret_cast<const unsigned char*>(x) + tok * tok_bytes;  // wave-uniform
-    const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)base);
-    const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((size_t)base >> 32));
-    const unsigned long long sb = (unsigned long long)lo32 | ((unsigned long long)hi32 << 32);
-    int g = 0;
-    for (; g + 4 <= n_dma; g += 4) {
-        unsigned keep;
-        asm volatile(
-            "s_nop 4\n\t"
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %6\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %5 nt\n\t"
-            "global_load_lds_dwordx4 %2, %5 offset:1024 nt\n\t"
-            "global_load_lds_dwordx4 %3, %5 offset:2048 nt\n\t"
-            "global_load_lds_dwordx4 %4, %5 offset:3072 nt\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sb + (unsigned long long)g * 1024),
-              "s"(lds_base + (unsigned)g * 1024)
-            : "memory");
-    }
-    for (int j = 0; g + j < n_dma; ++j) {  // tail (n_dma % 4 instructions)
-        unsigned keep;
-        asm volatile(
-            "s_nop 4\n\t"
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %3\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2 nt\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(j == 0 ? voff[0] : j == 1 ? voff[1] : voff[2]), "s"(sb + (unsigned long long)(g + j) * 1024),
-              "s"(lds_base + (unsigned)(g + j) * 1024)
-            : "memory");
-    }
-}
 
 // Magic-number quantiser over one output row group (mo) of a lane: NT * 2 packed dwords + their residual maxima.
 template <bool CLAMP, int NT, int MT>

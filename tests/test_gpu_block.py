@@ -60,6 +60,22 @@ def test_quant_stage_bit_exact_and_transform_tolerance(ops, R, C):
     assert np.array_equal(o2.fq[0].cpu().numpy().reshape(9, -1), ref["fq"])
 
 
+@pytest.mark.parametrize("R,C", [(128, 64), (128, 32)])
+def test_many_rows_prefetch_loop_packed_only(ops, R, C):
+    """More tokens than resident waves: every wave loops (C = 64: DMA prefetch of its next token + counted wait).
+    The packed-only launch must equal the oracle's quantiser on the transform-only launch's output."""
+    gen = torch.Generator().manual_seed(R + C)
+    rows = 4500
+    x = torch.randn(rows, R, C, generator=gen).half().cuda()
+    Pm = (torch.randn(C, C, generator=gen) / C ** 0.5).half().cuda()
+    y16 = ops.block_quant(x, Pm, flags=T, transpose_out=True).y.cpu().numpy().reshape(rows, -1).astype(np.float32)
+    for sig in [(0.982, 0.982), (0.6, 0.8)]:
+        o = ops.block_quant(x, Pm, [sig], P_ | R16, transpose_out=True)
+        ref = O.quant_outputs(y16, sig[0], sig[1])
+        assert np.array_equal(o.q[0].cpu().numpy().reshape(rows, -1), ref["packed"])
+        assert np.array_equal(o.scale[0].cpu().numpy().reshape(-1), ref["scale16"].reshape(-1))
+
+
 def test_dyadic_inputs_bit_exact_vs_oracle(ops):
     """Exact arithmetic: every partial sum representable -> independent of the MFMA accumulation order."""
     rng = np.random.RandomState(0)
