@@ -133,6 +133,17 @@ __device__ __forceinline__ int fq_quant1(float y, float scale) {
     return (int)t;
 }
 
+// The fp16-arithmetic quantiser when y itself is an fp16 value (rowquant / sym_quant inputs; quant.cu:40 __hdiv):
+// the native _Float16 division (v_rcp_f32 + two v_fma_mix refinements + v_div_fixup_f16, ~7 VALU with the reciprocal
+// of the per-row scale hoisted) instead of the ~11 of an IEEE fp32 division. tools/scratch/h16div.hip checked on
+// gfx950 that it equals the correctly rounded quotient for ALL 2^32 pairs of finite fp16 values.
+__device__ __forceinline__ int fq_quant1_h(f16 y, f16 s) {
+    const f16 t = y / s;
+    float r = __builtin_rintf((float)t);
+    r = __builtin_amdgcn_fmed3f(r, -8.0f, 7.0f);
+    return (int)r;
+}
+
 // fp16(fp32(a * b)): the fp32 product is ROUNDED TO fp32 FIRST, then to fp16 — what torch does for
 // (scale * q).to(float16) (quant_utils.py:25-26,81). hipcc otherwise selects v_fma_mixlo_f16 for
 // fptrunc(fmul), which rounds the exact product once and differs when the fp32 product lands on an fp16 tie

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(RQ_THREADS) void fq_rowquant_kernel(const f16* __re
                         uint32_t d = 0;
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
-                            d |= (uint32_t)(fq_quant1<FLAGS>((float)v[k][e], scale) & 15) << (4 * e);
+                            d |= (uint32_t)(((FLAGS & FQ_QUANT_F16) ? fq_quant1_h(v[k][e], (f16)scale)
+                                                                    : fq_quant1<FLAGS>((float)v[k][e], scale)) & 15) << (4 * e);
                         qp[ch] = d;
                     }
                 }
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(RQ_THREADS) void fq_rowquant_kernel(const f16* __re
                         f16x8 o;
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
-                            o[e] = fq_dequant1<FLAGS>(fq_quant1<FLAGS>((float)v[k][e], scale), scale);
+                            o[e] = fq_dequant1<FLAGS>((FLAGS & FQ_QUANT_F16) ? fq_quant1_h(v[k][e], (f16)scale)
+                                                                             : fq_quant1<FLAGS>((float)v[k][e], scale), scale);
                         fp[ch] = __builtin_bit_cast(uint4, o);
                     }
                 }
@@ -84,10 +86,7 @@ __global__ __launch_bounds__(RQ_THREADS) void fq_rowquant_kernel(const f16* __re
 // q = clamp(rn(x /h scale[row])) — fp16 division exactly as __hdiv (quant.cu:40): the fp32 quotient of
 // two fp16 values rounded to fp16 is the correctly rounded fp16 quotient (24 >= 2*11+2).
 __device__ __forceinline__ int symq1(f16 x, f16 s) {
-    f16 d = (f16)((float)x / (float)s);
-    float t = __builtin_rintf((float)d);
-    t = fminf(fmaxf(t, -8.0f), 7.0f);
-    return (int)t;
+    return fq_quant1_h(x, s);  // native fp16 division == correctly rounded (fq_common.hpp)
 }
 
 // Fast path: cols % 8 == 0. One thread packs 8 values (16-byte load, 4-byte store).
@@ -192,7 +191,7 @@ __global__ __launch_bounds__(256) void fq_rowquant_wave_kernel(const f16* __rest
                     if (FLAGS & FQ_QUANT_F16) {
                         d = 0;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) d |= (uint32_t)(fq_quant1<FLAGS>((float)v[k][e], scale) & 15) << (4 * e);
+                        for (int e = 0; e < 8; ++e) d |= (uint32_t)(fq_quant1_h(v[k][e], (f16)scale) & 15) << (4 * e);
                     } else {
                         float dmax = 0.0f;
                         const f32x2 inv2 = {inv, inv};
@@ -219,7 +218,7 @@ __global__ __launch_bounds__(256) void fq_rowquant_wave_kernel(const f16* __rest
                     if (FLAGS & FQ_QUANT_F16) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
-                            o[e] = fq_dequant1<FLAGS>(fq_quant1<FLAGS>((float)v[k][e], scale), scale);
+                            o[e] = fq_dequant1<FLAGS>(fq_quant1_h(v[k][e], (f16)scale), scale);
                     } else {
                         float dmax = 0.0f;
                         float r[8];
