@@ -593,27 +593,50 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                                     fv[mo][w][e] = fq_dequant1<FLAGS>(fq_quant1<FLAGS>(FQ_YV(mo, w, e), scale), scale);
                     } else {
                         const float inv = 1.0f / scale;
+                        const f32x2 inv2 = {inv, inv};
+                        const bool magic = fq_magic_ok(vmax, vmin, inv);
+                        const bool clampq = fq_needs_clamp(vmax, vmin, inv);
 #pragma unroll
                         for (int mo = 0; mo < 2; ++mo)
 #pragma unroll
                             for (int w = 0; w < 4; ++w) {
                                 float dmax = 0.0f;
+                                f32x2 q[4];
+                                if (magic && clampq) {
 #pragma unroll
-                                for (int e = 0; e < 8; ++e)
-                                    fv[mo][w][e] = fq_mul_to_f16(scale, fq_qfast(FQ_YV(mo, w, e), inv, dmax));
-                                if (fq_wave_needs_exact(dmax)) {
+                                    for (int j = 0; j < 4; ++j)
+                                        q[j] = fq_qmagic2<true>(f32x2{FQ_YV(mo, w, 2 * j), FQ_YV(mo, w, 2 * j + 1)}, inv2, dmax);
+                                } else if (magic) {
 #pragma unroll
-                                    for (int e = 0; e < 8; ++e)
-                                        fv[mo][w][e] = fq_mul_to_f16(scale, fq_qexact(FQ_YV(mo, w, e), scale));
+                                    for (int j = 0; j < 4; ++j)
+                                        q[j] = fq_qmagic2<false>(f32x2{FQ_YV(mo, w, 2 * j), FQ_YV(mo, w, 2 * j + 1)}, inv2, dmax);
                                 }
+                                if (!magic || fq_wave_needs_exact(dmax)) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j)
+                                        q[j] = f32x2{fq_qexact(FQ_YV(mo, w, 2 * j), scale), fq_qexact(FQ_YV(mo, w, 2 * j + 1), scale)};
+                                }
+                                f16x8 o;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {  // fp16(fp32(scale * q)): two roundings, as torch (fq_mul_to_f16)
+                                    f32x2 pr = q[j] * f32x2{scale, scale};
+                                    asm volatile("" : "+v"(pr));
+                                    o[2 * j] = (f16)pr.x;
+                                    o[2 * j + 1] = (f16)pr.y;
+                                }
+                                // stored at once: keeping all eight chunks of a token costs 32 VGPRs this kernel lacks
+                                reinterpret_cast<uint4*>(out.fq[ci] + tok * KD + (mo * 32 + c) * KN + h * 32)[w] =
+                                    __builtin_bit_cast(uint4, o);
                             }
                     }
+                    if (FLAGS & FQ_QUANT_F16) {
 #pragma unroll
-                    for (int mo = 0; mo < 2; ++mo) {
-                        uint4* fp =
-                            reinterpret_cast<uint4*>(out.fq[ci] + tok * KD + (mo * 32 + c) * KN + h * 32);
+                        for (int mo = 0; mo < 2; ++mo) {
+                            uint4* fp =
+                                reinterpret_cast<uint4*>(out.fq[ci] + tok * KD + (mo * 32 + c) * KN + h * 32);
 #pragma unroll
-                        for (int w = 0; w < 4; ++w) fp[w] = __builtin_bit_cast(uint4, fv[mo][w]);
+                            for (int w = 0; w < 4; ++w) fp[w] = __builtin_bit_cast(uint4, fv[mo][w]);
+                        }
                     }
                 }
 #undef FQ_YV
