@@ -14,6 +14,8 @@ int fq_launch_kron64p(const f16* x, const f16* left, const f16* right, int64_t r
 int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream);
+int fq_launch_hadamard_quant(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max,
+                             float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream);
 int64_t fq_kron_generic_workspace_bytes(int M, int N);
 int fq_launch_kron_prepare(const f16* left, const f16* right, int M, int N, void* workspace, hipStream_t stream);
 int fq_launch_block(int flags, const f16* x, const f16* P, int64_t rows, int R, int C, int transpose_out,
@@ -197,6 +199,20 @@ int fq_hadamard_f16(const void* x, void* y, int64_t rows, int n, int K, const vo
     int rc = fq_launch_hadamard((const f16*)x, (f16*)y, rows, n, K, (const f16*)hadK, scale, cu_count(),
                                 (hipStream_t)stream);
     return check_launch(rc, "fq_hadamard_f16");
+}
+
+int fq_hadamard_quant_f16(const void* x, int64_t rows, int n, int K, const void* hadK, float scale, float sig_max,
+                          float sig_min, void* q_out, void* scale_out, void* stream) {
+    if (!x || !q_out || !scale_out) return fail(FQ_EINVAL, "fq_hadamard_quant_f16: NULL pointer");
+    if (rows < 0 || n <= 0 || K <= 0 || n % K) return fail(FQ_EINVAL, "fq_hadamard_quant_f16: bad sizes n=%d K=%d", n, K);
+    if (K > 1 && !hadK) return fail(FQ_EINVAL, "fq_hadamard_quant_f16: hadK is NULL with K=%d", K);
+    if (!(sig_max > 0.0f) || !(sig_min > 0.0f)) return fail(FQ_EINVAL, "fq_hadamard_quant_f16: sig_max/sig_min must be > 0");
+    if (rows == 0) return FQ_OK;
+    const int rc = fq_launch_hadamard_quant((const f16*)x, rows, n, K, (const f16*)hadK, scale, sig_max, sig_min,
+                                            (uint8_t*)q_out, (f16*)scale_out, cu_count(), (hipStream_t)stream);
+    if (rc == -1000)
+        return fail(FQ_EUNSUPPORTED, "fq_hadamard_quant_f16: no fused kernel for n=%d K=%d (use fq_hadamard_f16 + fq_rowquant_f16)", n, K);
+    return check_launch(rc, "fq_hadamard_quant_f16");
 }
 
 int fq_rowquant_f16(const void* x, int64_t rows, int cols, const float* sig_max, const float* sig_min,

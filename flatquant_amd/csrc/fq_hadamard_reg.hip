@@ -120,10 +120,31 @@ __device__ __forceinline__ void to_f16(const float (&v)[CH][8], float scale, f16
         for (int e = 0; e < 8; ++e) o[j][e] = fq_mul_to_f16(v[j][e], scale);
 }
 
+// Fused deploy.nn.Quantizer (deploy/nn/quantization.py:13-36 on the fp16 Hadamard output, lac clip factors): per-row
+// extrema of the fp16 results, fp16 scale, fp16 division, round-half-even, clamp, pack. `o` holds a lane's fp16 results.
+struct HadQuant {
+    float sig_max, sig_min;
+    uint8_t* q;   // [rows, n/2]
+    f16* scale;   // [rows]
+};
+__device__ __forceinline__ uint32_t quant8_h(f16x8 v, f16 s) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d |= (uint32_t)(fq_quant1_h(v[e], s) & 15) << (4 * e);
+    return d;
+}
+__device__ __forceinline__ void minmax8(f16x8 v, float& mx, float& mn) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        mx = fq_max3(mx, (float)v[e], (float)v[e + 1]);
+        mn = fq_min3(mn, (float)v[e], (float)v[e + 1]);
+    }
+}
+
 // ---- K == 1: one wave per row ----
-template <int CH>
+template <int CH, bool QUANT>
 __global__ __launch_bounds__(256) void fq_had_pow2_kernel(const f16* __restrict__ x, f16* __restrict__ y, int64_t rows,
-                                                          float scale) {
+                                                          float scale, HadQuant hq) {
     constexpr int n = 512 * CH;
     const int lane = threadIdx.x & 63;
     const XMask k(lane);
@@ -134,9 +155,22 @@ __global__ __launch_bounds__(256) void fq_had_pow2_kernel(const f16* __restrict_
         fwht_wave<CH>(v, k);
         f16x8 o[CH];
         to_f16<CH>(v, scale, o);
+        if (!QUANT) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j)
-            *reinterpret_cast<uint4*>(y + row * n + j * 512 + lane * 8) = __builtin_bit_cast(uint4, o[j]);
+            for (int j = 0; j < CH; ++j)
+                *reinterpret_cast<uint4*>(y + row * n + j * 512 + lane * 8) = __builtin_bit_cast(uint4, o[j]);
+        } else {
+            float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) minmax8(o[j], mx, mn);
+            mx = fq_wave_max(mx);
+            mn = fq_wave_min(mn);
+            const float sc = fq_token_scale<FQ_QUANT_F16>(mx, mn, hq.sig_max, hq.sig_min, 0);
+            if (lane == 0) hq.scale[row] = (f16)sc;
+            uint32_t* qp = reinterpret_cast<uint32_t*>(hq.q + row * (n / 2));
+#pragma unroll
+            for (int j = 0; j < CH; ++j) qp[j * 64 + lane] = quant8_h(o[j], (f16)sc);  // 8 nibbles = elements j*512 + 8 lane ..
+        }
     }
 }
 
@@ -147,9 +181,10 @@ struct KmixGeom {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <int CH>
+template <int CH, bool QUANT>
 __global__ __launch_bounds__(256) void fq_had_kmix_kernel(const f16* __restrict__ x, f16* __restrict__ y, int64_t rows,
-                                                          KmixGeom g, const f16* __restrict__ hadK, float scale) {
+                                                          KmixGeom g, const f16* __restrict__ hadK, float scale,
+                                                          HadQuant hq) {
     constexpr int P = 512 * CH;
     constexpr int PITCH = P + 8;  // fp16 elements per image row: +16 bytes skews consecutive k rows across the banks
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -203,7 +238,11 @@ __global__ __launch_bounds__(256) void fq_had_kmix_kernel(const f16* __restrict_
         // ---- out^T[p][k'] = sum_k V[k][p] hadK[k'][k]; lane (h, .) ends with p = 32 pt + 16 h + reg of row k' ----
         f16* yp = y + row * (int64_t)K * P;
         const int ksteps = g.KP >> 4;
-        for (int t = wave; t < (P / 32) * g.KT; t += 4) {
+        constexpr int MAXT = (P / 32) * 2 / 4;  // tiles per wave for KT <= 2 (checked by the launcher for QUANT)
+        const int ntiles = (P / 32) * g.KT;
+        f16x8 res[QUANT ? MAXT : 1][2];
+        float mx = -INFINITY, mn = INFINITY;
+        auto tile = [&](int t, f16x8& v0, f16x8& v1) {  // one 32 (p) x 32 (k') output tile -> 16 fp16 per lane
             const int pt = t / g.KT, kt = t - pt * g.KT;
             f32x16 acc = {0};
             for (int s = 0; s < ksteps; ++s) {
@@ -214,41 +253,88 @@ __global__ __launch_bounds__(256) void fq_had_kmix_kernel(const f16* __restrict_
                 const s16x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                 acc = mfma32(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, kfrag[(s * g.KT + kt) * 64 + lane]), acc);
             }
-            const int kp = kt * 32 + c;
-            if (kp < K) {
-                f16x8 v0, v1;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    v0[e] = (f16)acc[e];
-                    v1[e] = (f16)acc[8 + e];
-                }
-                uint4* op = reinterpret_cast<uint4*>(yp + (int64_t)kp * P + pt * 32 + h * 16);
-                op[0] = __builtin_bit_cast(uint4, v0);
-                op[1] = __builtin_bit_cast(uint4, v1);
+            for (int e = 0; e < 8; ++e) {
+                v0[e] = (f16)acc[e];
+                v1[e] = (f16)acc[8 + e];
             }
+        };
+        if (!QUANT) {
+            for (int t = wave; t < ntiles; t += 4) {
+                f16x8 v0, v1;
+                tile(t, v0, v1);
+                const int pt = t / g.KT, kp = (t - pt * g.KT) * 32 + c;
+                if (kp < K) {
+                    uint4* op = reinterpret_cast<uint4*>(yp + (int64_t)kp * P + pt * 32 + h * 16);
+                    op[0] = __builtin_bit_cast(uint4, v0);
+                    op[1] = __builtin_bit_cast(uint4, v1);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < MAXT; ++u) {  // unrolled: res[] is indexed statically (registers)
+                const int t = wave + 4 * u;
+                if (t < ntiles) {
+                    tile(t, res[u][0], res[u][1]);
+                    const int pt = t / g.KT, kp = (t - pt * g.KT) * 32 + c;
+                    if (kp < K) {
+                        minmax8(res[u][0], mx, mn);
+                        minmax8(res[u][1], mx, mn);
+                    }
+                }
+            }
+        }
+        if (QUANT) {
+            float* red = reinterpret_cast<float*>(kfrag + (g.KP / 16) * g.KT * 64);  // 8 floats behind the fragments
+            mx = fq_wave_max(mx);
+            mn = fq_wave_min(mn);
+            if (lane == 0) {
+                red[wave] = mx;
+                red[4 + wave] = mn;
+            }
+            __syncthreads();  // also: every wave is done reading V -> it becomes the packed-output stage
+            mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            mn = fminf(fminf(red[4], red[5]), fminf(red[6], red[7]));
+            const float sc = fq_token_scale<FQ_QUANT_F16>(mx, mn, hq.sig_max, hq.sig_min, 0);
+            unsigned char* obuf = smem;  // [K][P/2] bytes
+#pragma unroll
+            for (int u = 0; u < MAXT; ++u) {
+                const int t = wave + 4 * u;
+                const int pt = t / g.KT, kt = t - pt * g.KT;
+                const int kp = kt * 32 + c;
+                if (t < ntiles && kp < K)
+                    *reinterpret_cast<uint2*>(obuf + ((int64_t)kp * P + pt * 32 + h * 16) / 2) =
+                        make_uint2(quant8_h(res[u][0], (f16)sc), quant8_h(res[u][1], (f16)sc));
+            }
+            __syncthreads();
+            if (tid == 0) hq.scale[row] = (f16)sc;
+            uint4* qp = reinterpret_cast<uint4*>(hq.q + row * ((int64_t)K * P / 2));
+            for (int i = tid; i < K * P / 32; i += 256) qp[i] = reinterpret_cast<const uint4*>(obuf)[i];
         }
     }
 }
 
-template <int CH>
-int launch_pow2(const f16* x, f16* y, int64_t rows, float scale, int n_cu, hipStream_t stream) {
+template <int CH, bool QUANT>
+int launch_pow2(const f16* x, f16* y, int64_t rows, float scale, const HadQuant& hq, int n_cu, hipStream_t stream) {
     int64_t blocks = (rows + 3) / 4;
     const int64_t cap = (int64_t)n_cu * (CH <= 8 ? 4 : 2);  // 16 / 8 waves per CU
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((fq_had_pow2_kernel<CH>), dim3((unsigned)blocks), dim3(256), 0, stream, x, y, rows, scale);
+    hipLaunchKernelGGL((fq_had_pow2_kernel<CH, QUANT>), dim3((unsigned)blocks), dim3(256), 0, stream, x, y, rows, scale, hq);
     return (int)hipGetLastError();
 }
 
-template <int CH>
-int launch_kmix(const f16* x, f16* y, int64_t rows, int K, const f16* hadK, float scale, int n_cu, hipStream_t stream) {
+template <int CH, bool QUANT>
+int launch_kmix(const f16* x, f16* y, int64_t rows, int K, const f16* hadK, float scale, const HadQuant& hq, int n_cu,
+                hipStream_t stream) {
     KmixGeom g;
     g.K = K;
     g.KP = (K + 15) / 16 * 16;
     g.KT = (K + 31) / 32;
-    const size_t lds = (size_t)g.KP * (512 * CH + 8) * 2 + (size_t)(g.KP / 16) * g.KT * 1024;
+    if (QUANT && g.KT > 2) return -1000;  // the fused form keeps a wave's tiles in registers (sized for KT <= 2)
+    const size_t lds = (size_t)g.KP * (512 * CH + 8) * 2 + (size_t)(g.KP / 16) * g.KT * 1024 + 64;
     if (lds > 160 * 1024) return -1000;
-    auto kern = fq_had_kmix_kernel<CH>;
+    auto kern = fq_had_kmix_kernel<CH, QUANT>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -260,8 +346,29 @@ int launch_kmix(const f16* x, f16* y, int64_t rows, int K, const f16* hadK, floa
     int64_t blocks = (int64_t)n_cu * per_cu;
     if (blocks > rows) blocks = rows;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, x, y, rows, g, hadK, scale);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, x, y, rows, g, hadK, scale, hq);
     return (int)hipGetLastError();
+}
+
+template <bool QUANT>
+int dispatch_reg(const f16* x, f16* y, int64_t rows, int n, int K, const f16* hadK, float scale, const HadQuant& hq,
+                 int n_cu, hipStream_t stream) {
+    if (K < 1 || n % K) return -1000;
+    const int P = n / K;
+    if (K == 1) {
+        switch (P) {
+            case 512: return launch_pow2<1, QUANT>(x, y, rows, scale, hq, n_cu, stream);
+            case 1024: return launch_pow2<2, QUANT>(x, y, rows, scale, hq, n_cu, stream);
+            case 2048: return launch_pow2<4, QUANT>(x, y, rows, scale, hq, n_cu, stream);
+            case 4096: return launch_pow2<8, QUANT>(x, y, rows, scale, hq, n_cu, stream);
+            case 8192: return launch_pow2<16, QUANT>(x, y, rows, scale, hq, n_cu, stream);
+            default: return -1000;
+        }
+    }
+    if (K > 192) return -1000;
+    if (P == 512) return launch_kmix<1, QUANT>(x, y, rows, K, hadK, scale, hq, n_cu, stream);
+    if (P == 1024) return launch_kmix<2, QUANT>(x, y, rows, K, hadK, scale, hq, n_cu, stream);
+    return -1000;
 }
 
 }  // namespace
@@ -269,20 +376,11 @@ int launch_kmix(const f16* x, f16* y, int64_t rows, int K, const f16* hadK, floa
 // Returns -1000 for shapes this file does not cover (the caller falls back to fq_hadamard.hip).
 int fq_launch_hadamard_reg(const f16* x, f16* y, int64_t rows, int n, int K, const f16* hadK, float scale, int n_cu,
                            hipStream_t stream) {
-    if (K < 1 || n % K) return -1000;
-    const int P = n / K;
-    if (K == 1) {
-        switch (P) {
-            case 512: return launch_pow2<1>(x, y, rows, scale, n_cu, stream);
-            case 1024: return launch_pow2<2>(x, y, rows, scale, n_cu, stream);
-            case 2048: return launch_pow2<4>(x, y, rows, scale, n_cu, stream);
-            case 4096: return launch_pow2<8>(x, y, rows, scale, n_cu, stream);
-            case 8192: return launch_pow2<16>(x, y, rows, scale, n_cu, stream);
-            default: return -1000;
-        }
-    }
-    if (K > 192) return -1000;
-    if (P == 512) return launch_kmix<1>(x, y, rows, K, hadK, scale, n_cu, stream);
-    if (P == 1024) return launch_kmix<2>(x, y, rows, K, hadK, scale, n_cu, stream);
-    return -1000;
+    return dispatch_reg<false>(x, y, rows, n, K, hadK, scale, HadQuant{1.0f, 1.0f, nullptr, nullptr}, n_cu, stream);
+}
+
+// Hadamard + deploy.nn.Quantizer in one launch (no fp16 round trip through HBM). -1000: shape not covered.
+int fq_launch_hadamard_quant(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max,
+                             float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream) {
+    return dispatch_reg<true>(x, nullptr, rows, n, K, hadK, scale, HadQuant{sig_max, sig_min, q, scale_out}, n_cu, stream);
 }

@@ -9,7 +9,7 @@ from .. import PackedQuantizedTensor
 
 
 def _clip(v):
-    return float(v.item()) if isinstance(v, torch.Tensor) else float(v)
+    return ops.host_scalar(v)  # no per-call device sync for the buffers the deploy modules keep on the GPU
 
 
 def kronecker_matmul(x, invs, clip_factor_a_max=1.0, clip_factor_a_min=1.0):

@@ -40,8 +40,18 @@ class OnlineTrans(torch.nn.Module):
         self.register_buffer("clip_factor_a_max", torch.tensor(1.0))
         self.register_buffer("clip_factor_a_min", torch.tensor(1.0))
 
-    def forward(self, x):
+    def forward(self, x, quantizer=None):
+        """``quantizer`` (extension, optional): the deploy.nn.Quantizer that consumes this transform's output. For
+        trans="had" the two then run as ONE launch and a PackedQuantizedTensor comes back (the Quantizer passes packed
+        inputs through, quantization.py:14), bit-identical to calling them one after the other."""
         if self.trans == "had":
+            if quantizer is not None and getattr(quantizer, "lac", False) and not self.fp32_trans:
+                from ... import ops
+                from .. import PackedQuantizedTensor
+                sig = ops.sigmoid_pair(quantizer.clip_factor_a_max, quantizer.clip_factor_a_min)
+                q, s = ops.hadamard_quant(x.contiguous(), self.rem_dim, self.had_rem_dim, sig)
+                lead = x.shape[:-1]
+                return PackedQuantizedTensor(q, s.reshape(*lead, 1) if len(lead) > 1 else s.reshape(-1, 1))
             if self.fp32_trans:
                 # the reference up-casts and returns fp32 (online_trans.py:56-59); the HIP kernel already
                 # runs its butterflies in fp32, so only the result is widened.

@@ -23,7 +23,7 @@ class Quantizer(torch.nn.Module):
         if isinstance(x, PackedQuantizedTensor):
             return x
         if self.lac:
-            sig = ops.sigmoid_pair(float(self.clip_factor_a_max), float(self.clip_factor_a_min))
+            sig = ops.sigmoid_pair(self.clip_factor_a_max, self.clip_factor_a_min)
         elif self.input_clip_ratio == 1.0:
             sig = (1.0, 1.0)
         else:

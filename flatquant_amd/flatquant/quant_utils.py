@@ -44,8 +44,8 @@ class ActivationQuantizer(torch.nn.Module):
 
     def _sig(self):
         if self.lac:
-            return (float(torch.sigmoid(self.clip_factor_a_max.detach().float().cpu())[0]),
-                    float(torch.sigmoid(self.clip_factor_a_min.detach().float().cpu())[0]))
+            # fp32 sigmoid on the host; the parameters are read back once per version, not once per call
+            return ops.sigmoid_pair(self.clip_factor_a_max.detach(), self.clip_factor_a_min.detach())
         if self._clip_ratio is not None:
             return float(self._clip_ratio), float(self._clip_ratio)
         return 1.0, 1.0

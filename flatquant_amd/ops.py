@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import collections
 import ctypes
+import functools
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -19,11 +20,39 @@ from ._lib import (FQ_MAX_CLIPS, FQ_NO_CLAMP0, FQ_OUT_FAKEQUANT, FQ_OUT_PACKED, 
 Sig = Tuple[float, float]  # (sigmoid(clip_factor_a_max), sigmoid(clip_factor_a_min)); (1.0, 1.0) = no clip
 
 
+@functools.lru_cache(maxsize=4096)
+def _sigmoid_pair_cached(clip_max: float, clip_min: float) -> Sig:
+    t = torch.sigmoid(torch.tensor([clip_max, clip_min], dtype=torch.float32))
+    return float(t[0]), float(t[1])
+
+
 def sigmoid_pair(clip_max, clip_min) -> Sig:
     """fp32 sigmoid of the raw (pre-sigmoid) learnable clipping factors, evaluated by torch on the host —
     the value the reference multiplies the row extrema with (quant_utils.py:96-97, kron_matmul.py:93-94)."""
-    t = torch.sigmoid(torch.tensor([float(clip_max), float(clip_min)], dtype=torch.float32))
-    return float(t[0]), float(t[1])
+    return _sigmoid_pair_cached(host_scalar(clip_max), host_scalar(clip_min))
+
+
+_SCALARS: "collections.OrderedDict" = collections.OrderedDict()
+
+
+def host_scalar(v) -> float:
+    """float(v) for a Python number or a one-element tensor, WITHOUT a device synchronisation per call: a CUDA
+    scalar (the deploy modules keep clip_factor_a_max/min as buffers; the reference's loader turns them into Python
+    floats, modeling_llama.py:532-538) is read back once per (storage, version) and remembered. The entry holds the
+    tensor, so its address cannot be recycled under it."""
+    if not isinstance(v, torch.Tensor):
+        return float(v)
+    if not v.is_cuda:
+        return float(v)
+    key = (v.data_ptr(), v._version)
+    hit = _SCALARS.get(key)
+    if hit is not None:
+        return hit[0]
+    val = float(v.item())
+    _SCALARS[key] = (val, v)
+    if len(_SCALARS) > 4096:
+        _SCALARS.popitem(last=False)
+    return val
 
 
 def _chk(t: torch.Tensor, name: str, dtype=torch.float16) -> None:
@@ -200,6 +229,36 @@ def hadamard(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None,
     with torch.cuda.device(x.device):
         check(lib.fq_hadamard_f16(_ptr(x), _ptr(y), rows, n, K, _ptr(hadK), ctypes.c_float(scale), _stream(x)))
     return y
+
+
+def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None, sig: Sig = (1.0, 1.0),
+                   scale: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Hadamard rotation fused with the deploy Quantizer (fq_hadamard_quant_f16): -> (q uint8 [..., n/2], scales fp16
+    [rows]). Bit-identical to rowquant(hadamard(x), [sig], FQ_OUT_PACKED | FQ_QUANT_F16); shapes the fused kernels do
+    not cover take exactly that two-launch route."""
+    _chk(x, "x")
+    n = x.shape[-1]
+    if K > 1:
+        if hadK is None:
+            raise ValueError("hadK required when K > 1")
+        _chk(hadK, "hadK")
+        if hadK.shape != (K, K):
+            raise ValueError("hadK must be [K, K]")
+    if scale is None:
+        scale = float(1.0 / torch.tensor(n).sqrt())
+    rows = x.numel() // n
+    q = torch.empty(x.shape[:-1] + (n // 2,), dtype=torch.uint8, device=x.device)
+    s = torch.empty((rows,), dtype=torch.float16, device=x.device)
+    if rows == 0:
+        return q, s
+    with torch.cuda.device(x.device):
+        rc = lib.fq_hadamard_quant_f16(_ptr(x), rows, n, K, _ptr(hadK), ctypes.c_float(scale), ctypes.c_float(sig[0]),
+                                       ctypes.c_float(sig[1]), _ptr(q), _ptr(s), _stream(x))
+    if rc == _lib.FQ_EUNSUPPORTED:
+        o = rowquant(hadamard(x, K, hadK, scale), [sig], FQ_OUT_PACKED | FQ_QUANT_F16)
+        return o.q[0], o.scale[0].reshape(-1)
+    check(rc)
+    return q, s
 
 
 def sym_quant(x: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:

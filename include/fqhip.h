@@ -15,6 +15,7 @@
  *                          flatquant/quant_utils.py:71-119 (ActivationQuantizer)
  *   fq_block_quant_f16     deploy/kernels/block_matmul.py:231-311 (block_matmul)
  *   fq_hadamard_f16        flatquant/hadamard_utils.py:89-110,132-141 (matmul_hadU[_cuda]),
+ *   (fq_hadamard_quant_f16: the same followed by deploy/nn/quantization.py:13-36, fused)
  *                          deploy/functional/online_trans.py:144-151
  *   fq_rowquant_f16        deploy/nn/quantization.py:13-36 (Quantizer.forward),
  *                          flatquant/quant_utils.py:77-119
@@ -109,6 +110,19 @@ int fq_block_quant_f16(const void* x, const void* P, int64_t rows, int R, int C,
  */
 int fq_hadamard_f16(const void* x, void* y, int64_t rows, int n, int K, const void* hadK, float scale,
                     void* stream);
+
+/*
+ * The same Hadamard transform fused with deploy.nn.Quantizer (deploy/nn/quantization.py:13-36 with lac clip
+ * factors): the fp16 result never goes to HBM. Per row: extrema of the fp16 transform output (clamped through 0),
+ * scale = fp16(max(|xmin*sig_min|, xmax*sig_max) / 7), q = clamp(rint(y /h scale), -8, 7) with the fp16 division
+ * of quant.cu:40, packed two per byte (low nibble = even column).  Equals fq_hadamard_f16 followed by
+ * fq_rowquant_f16(FQ_OUT_PACKED | FQ_QUANT_F16) bit for bit.  Returns FQ_EUNSUPPORTED for shapes the fused
+ * kernels do not cover (n/K not in {512, 1024} for K > 1, n not in 512..8192 for K == 1): call the two
+ * separately then.
+ *   q_out [rows, n/2] uint8, scale_out [rows] fp16
+ */
+int fq_hadamard_quant_f16(const void* x, int64_t rows, int n, int K, const void* hadK, float scale,
+                          float sig_max, float sig_min, void* q_out, void* scale_out, void* stream);
 
 /*
  * Per-token scale + INT4 quantisation of an fp16 matrix (Quantizer.forward / ActivationQuantizer).

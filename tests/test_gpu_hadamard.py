@@ -88,3 +88,36 @@ def test_module_surface(ops):
     # QuaRot-style pipeline: Hadamard -> Quantizer -> packed
     p = deploy.nn.Quantizer()(y.reshape(-1, 14336))
     assert p.quantized_x.shape == (16, 7168)
+
+
+@pytest.mark.parametrize("n,K", [(512, 1), (4096, 1), (8192, 1), (14336, 28), (28672, 28), (6144, 12), (10240, 20),
+                                 (11008, 172), (5120, 40)])
+def test_fused_hadamard_quantizer_equals_two_launches(ops, n, K):
+    """fq_hadamard_quant_f16 == fq_hadamard_f16 followed by the deploy Quantizer (fp16-arithmetic rowquant), bit for
+    bit, on every shape: fused kernels where they exist (P = 512, 1024; pow2 n <= 8192), the two-launch route else."""
+    from flatquant_amd._lib import FQ_OUT_PACKED, FQ_QUANT_F16
+    g = torch.Generator().manual_seed(n + K)
+    rows = 37
+    x = torch.randn(rows, n, generator=g).half()
+    x[3] = 0
+    x[:, ::53] *= 12
+    x = x.cuda()
+    hk = None if K == 1 else torch.from_numpy(hadk_matrix(K)).cuda()
+    for sig in [(0.9820137619972229, 0.9820137619972229), (0.7, 0.9), (1.0, 1.0)]:
+        q, s = ops.hadamard_quant(x, K, hk, sig)
+        two = ops.rowquant(ops.hadamard(x, K, hk), [sig], FQ_OUT_PACKED | FQ_QUANT_F16)
+        assert torch.equal(q, two.q[0]), (n, K, sig)
+        assert torch.equal(s.reshape(-1), two.scale[0].reshape(-1)), (n, K, sig)
+
+
+def test_online_trans_with_quantizer_argument(ops):
+    import flatquant_amd.deploy as deploy
+    t = deploy.nn.OnlineTrans(14336, trans="had").cuda()
+    qz = deploy.nn.Quantizer(lac=True).cuda()
+    x = torch.randn(2, 9, 14336, generator=torch.Generator().manual_seed(1)).half().cuda()
+    fused = t(x, quantizer=qz)
+    ref = qz(t(x))
+    assert isinstance(fused, deploy.PackedQuantizedTensor)
+    assert torch.equal(fused.quantized_x, ref.quantized_x.reshape(fused.quantized_x.shape))
+    assert torch.equal(fused.scales_x.reshape(-1), ref.scales_x.reshape(-1))
+    assert qz(fused) is fused   # the Quantizer passes packed inputs through

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""BASELINE config C3/C4: the activation path of ONE decoder layer through the deploy modules (GPU box only).
+
+Per layer the reference's deploy model runs, in front of its 4-bit linears (deploy/transformers/modeling_llama.py):
+  ln_trans      OnlineTrans(hidden, matmul, decompose)   -> packed  (input of q/k/v_proj)
+  o_proj trans  OnlineTrans(num_heads, matmul, no decompose) on [bsz, seq, head_dim, heads] -> packed
+  up_gate_trans OnlineTrans(hidden, matmul, decompose)   -> packed  (input of up/gate_proj)
+  down_proj     OnlineTrans(ffn, had) -> fp16, then Quantizer(lac) -> packed
+This script times exactly those module calls (random matrices, synthetic activations, 8 x 2048 tokens) and prints
+microseconds per call, the algorithmic GB/s and the layer total. The GEMMs themselves are out of scope.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import flatquant_amd.deploy as deploy  # noqa: E402
+
+MODELS = {
+    "llama-3-8b": dict(hidden=4096, ffn=14336, heads=32, head_dim=128),
+    "llama-2-70b": dict(hidden=8192, ffn=28672, heads=64, head_dim=128),
+}
+
+
+def timeit(fn, steps, warm=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="llama-3-8b", choices=sorted(MODELS))
+    ap.add_argument("--bsz", type=int, default=8)
+    ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=50)
+    a = ap.parse_args()
+    m = MODELS[a.model]
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(0)
+    T = a.bsz * a.seq
+
+    def act(*shape):
+        return torch.randn(*shape, generator=g, device=dev, dtype=torch.float16)
+
+    def trans(dim, decompose=True):
+        t = deploy.nn.OnlineTrans(dim, trans="matmul", decompose=decompose, lac=True).to(dev)
+        for name in ("left_matrix", "right_matrix"):
+            if hasattr(t, name):
+                b = getattr(t, name)
+                b.copy_(torch.randn(b.shape, generator=g, device=dev) / b.shape[0] ** 0.5)
+        t.clip_factor_a_max.fill_(4.0)
+        t.clip_factor_a_min.fill_(4.0)
+        return t
+
+    ln_trans, ug_trans = trans(m["hidden"]), trans(m["hidden"])
+    o_trans = trans(m["heads"], decompose=False)
+    had = deploy.nn.OnlineTrans(m["ffn"], trans="had").to(dev)
+    quant = deploy.nn.Quantizer(lac=True).to(dev)
+    xs = [act(a.bsz, a.seq, m["hidden"]) for _ in range(3)]
+    xo = [act(a.bsz, a.seq, m["head_dim"], m["heads"]) for _ in range(3)]
+    xf = [act(a.bsz, a.seq, m["ffn"]) for _ in range(2)]
+    it = [0]
+
+    def nxt(lst):
+        it[0] += 1
+        return lst[it[0] % len(lst)]
+
+    rows = [
+        ("ln_trans (q/k/v input)", lambda: ln_trans(nxt(xs)), 2.5 * m["hidden"] + 2),
+        ("o_proj head transform", lambda: o_trans(nxt(xo)), 2.5 * m["hidden"] + 2),
+        ("up_gate_trans", lambda: ug_trans(nxt(xs)), 2.5 * m["hidden"] + 2),
+        ("down_proj Hadamard", lambda: had(nxt(xf)), 4.0 * m["ffn"]),
+        ("down_proj Quantizer", lambda: quant(nxt(xf)), 2.5 * m["ffn"] + 2),
+    ]
+    fused = ("down_proj Hadamard+Quantizer, one launch (OnlineTrans.forward(x, quantizer=...))",
+             lambda: had(nxt(xf), quantizer=quant), 2.5 * m["ffn"] + 2)
+    total = 0.0
+    print(f"{a.model}: {a.bsz} x {a.seq} tokens, one decoder layer, activation path through flatquant_amd.deploy.nn")
+    for name, fn, bpt in rows:
+        us = timeit(fn, a.steps)
+        total += us
+        print(f"  {name:26s} {us:9.1f} us   {T * bpt / us / 1e3:7.0f} GB/s algorithmic")
+    print(f"  {'layer total':26s} {total:9.1f} us   ({T / total:.1f} tokens/us through the activation path)")
+    us = timeit(fused[1], a.steps)
+    two = sum(timeit(fn, a.steps) for _, fn, _ in rows[3:])
+    print(f"  {fused[0]}: {us:.1f} us ({T * fused[2] / us / 1e3:.0f} GB/s) instead of {two:.1f} us"
+          f" -> layer total {total - two + us:.1f} us")
+
+
+if __name__ == "__main__":
+    main()
