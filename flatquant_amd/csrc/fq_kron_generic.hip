@@ -319,25 +319,52 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
         for (int s = 0; s < KS1; ++s)
             RF[t][s] = nt < NT ? __builtin_bit_cast(f16x8, ws[((size_t)nt * KS1 + s) * 64 + lane]) : f16x8{0};
     }
+    // Make the R fragments "arrived" in the compiler's bookkeeping HERE: otherwise it covers their first use inside
+    // the token loop with an s_waitcnt vmcnt(n), and that counter also sees the hand-issued prefetch loads in flight
+    // there (the wait for loads of the prologue then drains the prefetch in front of GEMM 1).
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) asm volatile("" : "+v"(RF[t][s]));
     // LDS slot of prefetch register k of this thread (chunk q = tid + 256 k of the token)
     u32x4 PF[NPF];
     int64_t tok = blockIdx.x;
-    if (tok < rows) {
-        const uint4* xp = reinterpret_cast<const uint4*>(x + tok * d);
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-            const int q = tid + THREADS * k;
-            PF[k] = q < n_chunks ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xp) + q) : u32x4{0, 0, 0, 0};
-        }
+    // Prefetch loads are inline asm with a hand-placed wait: left to hipcc, an s_waitcnt vmcnt(1) appeared in front of
+    // GEMM 1's first MFMA, i.e. the loads that were meant to land during the multiplication were waited for before it.
+    // Out-of-range chunks of a ragged last register re-load the token's last chunk (no divergent branch around the asm).
+#define FQ_PF_LOAD(tokidx)                                                                               \
+    {                                                                                                    \
+        const u32x4* xp_ = reinterpret_cast<const u32x4*>(x + (tokidx) * d);                             \
+        _Pragma("unroll") for (int k = 0; k < NPF; ++k) {                                                \
+            int q_ = pf_q0 + THREADS * k;                                                                \
+            q_ = q_ < n_chunks ? q_ : n_chunks - 1;                                                      \
+            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(PF[k]) : "v"(xp_ + q_) : "memory"); \
+        }                                                                                                \
     }
+    int pf_q0 = tid;
+    if (tok < rows) FQ_PF_LOAD(tok)
 
     for (; tok < rows; tok += gridDim.x) {
         // ---- stage the prefetched token (the previous token's readers passed the statistics barrier) ----
-        {
+        // The thread index is laundered once per token: otherwise every per-chunk address (global pointer, LDS slot,
+        // diag pointer) is loop-invariant, gets hoisted out of the token loop and SPILLED (37 VGPRs in the 112x128
+        // build), and each reload sat in front of its load behind an s_waitcnt vmcnt(0) that serialised the seven
+        // prefetch loads into seven HBM round trips per token (the kernel ran 2x slower than it should).
+        int q0 = tid;
+        asm volatile("" : "+v"(q0));
+        pf_q0 = q0;
+        {   // the prefetch has had a whole token's time to land
+            if (NPF == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(PF[0]));
+            else if (NPF <= 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(PF[0]), "+v"(PF[1 % NPF]), "+v"(PF[2 % NPF]), "+v"(PF[3 % NPF]));
+            else {
+#pragma unroll
+                for (int k = 0; k < NPF; k += 4)
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(PF[k]), "+v"(PF[(k + 1) % NPF]), "+v"(PF[(k + 2) % NPF]), "+v"(PF[(k + 3) % NPF]));
+            }
             const uint4* dp = reinterpret_cast<const uint4*>(diag);
 #pragma unroll
             for (int k = 0; k < NPF; ++k) {
-                const int q = tid + THREADS * k;
+                const int q = q0 + THREADS * k;
                 if (q < n_chunks) {
                     uint4 v = __builtin_bit_cast(uint4, PF[k]);
                     if (diag != nullptr)
@@ -348,17 +375,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
             }
         }
         __syncthreads();
-        {   // next token -> registers; lands while this one is multiplied and quantised
-            const int64_t nxt = tok + gridDim.x;
-            if (nxt < rows) {
-                const uint4* xp = reinterpret_cast<const uint4*>(x + nxt * d);
-#pragma unroll
-                for (int k = 0; k < NPF; ++k) {
-                    const int q = tid + THREADS * k;
-                    if (q < n_chunks && !(flags & 0x4000)) PF[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xp) + q);
-                }
-            }
-        }
+        if (tok + gridDim.x < rows && !(flags & 0x4000)) FQ_PF_LOAD(tok + gridDim.x)  // lands during this token's work
 
         int loff = lane;
         asm volatile("" : "+v"(loff));  // keep the L-fragment reads inside the token loop (see fq_kron64.hip)
@@ -509,11 +526,11 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                         if (clampq) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j)
-                                qp[j] = fq_qmagic2<true>(ok ? f32x2{yv[2 * j], yv[2 * j + 1]} : f32x2{0, 0}, inv2, dmax);
+                                qp[j] = fq_qmagic2<true>(f32x2{yv[2 * j], yv[2 * j + 1]}, inv2, dmax);
                         } else {
 #pragma unroll
                             for (int j = 0; j < 8; ++j)
-                                qp[j] = fq_qmagic2<false>(ok ? f32x2{yv[2 * j], yv[2 * j + 1]} : f32x2{0, 0}, inv2, dmax);
+                                qp[j] = fq_qmagic2<false>(f32x2{yv[2 * j], yv[2 * j + 1]}, inv2, dmax);
                         }
                         exact = fq_wave_needs_exact(dmax);
                     }
