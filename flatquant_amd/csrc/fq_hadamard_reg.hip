@@ -224,9 +224,24 @@ __global__ __launch_bounds__(256) void fq_had_kmix_kernel(const f16* __restrict_
     for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         const f16* xr = x + row * (int64_t)K * P;
         __syncthreads();  // the previous row's fragment reads are done
+        u32x4 raw[CH];  // the NEXT sub-vector's chunks are requested before the current one is transformed
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            raw[j] = wave < K ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xr + (int64_t)wave * P + j * 512 + lane * 8))
+                              : u32x4{0, 0, 0, 0};
         for (int k = wave; k < K; k += 4) {
             float v[CH][8];
-            load_vec<CH>(xr + (int64_t)k * P, lane, v);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const f16x8 hv = __builtin_bit_cast(f16x8, raw[j]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[j][e] = (float)hv[e];
+            }
+            if (k + 4 < K) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j)
+                    raw[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xr + (int64_t)(k + 4) * P + j * 512 + lane * 8));
+            }
             fwht_wave<CH>(v, km);
             f16x8 o[CH];
             to_f16<CH>(v, scale, o);
