@@ -35,31 +35,46 @@ __device__ __forceinline__ float flip(float v, unsigned m) {
     return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) ^ m);
 }
 
-// sign masks of the six cross-lane stages: 0x80000000 where bit s of the lane number is set
+// per-lane constants of the six cross-lane stages: sign-bit masks (0x80000000 where bit s of the lane number is set)
+// for the stages that flip-and-add, +-1.0f for the two that use an fma
 struct XMask {
-    unsigned m[6];
+    unsigned m[2];
+    float sgn[2];
     __device__ __forceinline__ explicit XMask(int lane) {
-#pragma unroll
-        for (int s = 0; s < 6; ++s) m[s] = ((lane >> s) & 1) ? 0x80000000u : 0u;
+        m[0] = (lane & 1) ? 0x80000000u : 0u;
+        m[1] = (lane & 2) ? 0x80000000u : 0u;
+        sgn[0] = (lane & 16) ? -1.0f : 1.0f;
+        sgn[1] = (lane & 32) ? -1.0f : 1.0f;
     }
 };
 
-// the six cross-lane butterfly stages on one register
+// the six cross-lane butterfly stages on one register (14 VALU). "s_nop 1": a VALU result needs two wait states
+// before a DPP / permlane read of it.
 __device__ __forceinline__ float xlane(float v, const XMask& k) {
-    v = flip(v, k.m[0]) + dppf<0xB1>(v);                 // lane ^ 1: quad_perm [1,0,3,2]
-    v = flip(v, k.m[1]) + dppf<0x4E>(v);                 // lane ^ 2: quad_perm [2,3,0,1]
-    v = flip(v, k.m[2]) + dppf<0x1B>(dppf<0x141>(v));    // lane ^ 4: row_half_mirror (^7) then quad_perm [3,2,1,0] (^3)
-    v = flip(v, k.m[3]) + dppf<0x128>(v);                // lane ^ 8: row_ror:8
-    {   // lane ^ 16: after the swap, a = value of the lower lane of the pair, b = of the upper one, in BOTH lanes' view:
-        // even rows keep a = own and receive b = partner; odd rows receive a = partner and keep b = own
+    v = flip(v, k.m[0]) + dppf<0xB1>(v);  // lane ^ 1: quad_perm [1,0,3,2]; lanes with the bit set need partner - own
+    v = flip(v, k.m[1]) + dppf<0x4E>(v);  // lane ^ 2: quad_perm [2,3,0,1]
+    {   // lane ^ 4 and lane ^ 8: the partner sits one / two banks (groups of 4 lanes) away -> row shifts, one masked add
+        // for the lower lanes of each pair (own + partner) and one masked sub for the upper ones (partner - own)
+        float r;
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                     "v_sub_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa"
+                     : "=&v"(r) : "v"(v));
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+                     "v_sub_f32_dpp %0, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xc"
+                     : "=&v"(v) : "v"(r));
+    }
+    {   // lane ^ 16: after the swap, a = value of the lower lane of the pair, b = of the upper one, in BOTH lanes' view
+        // (even rows keep a = own and receive b = partner; odd rows receive a = partner and keep b = own)
         float a = v, b = v;
         asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-        v = a + flip(b, k.m[4]);
+        v = __builtin_fmaf(b, k.sgn[0], a);  // a +- b, one rounding
     }
     {   // lane ^ 32: same with the wave's halves
         float a = v, b = v;
         asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-        v = a + flip(b, k.m[5]);
+        v = __builtin_fmaf(b, k.sgn[1], a);
     }
     return v;
 }
