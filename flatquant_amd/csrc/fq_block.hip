@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
             float scale;
             if (flags & FQ_QUANT_F16) scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
             else scale = fq_token_scale<0>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
-            const float inv = 1.0f / scale;
+            const float inv = fq_fast_inv(scale);
             if ((flags & FQ_OUT_PACKED) && lane == 0) out.scale[ci][tok] = (f16)scale;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {

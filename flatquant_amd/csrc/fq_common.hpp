@@ -175,6 +175,15 @@ __device__ __forceinline__ f16 fq_dequant1(int q, float scale) {
 // ---------------------------------------------------------------------------------------------------
 constexpr float FQ_NEAR = 4e-6f;
 
+// 1/scale for the fast quantisers: v_rcp_f32 (1 ulp) instead of the IEEE division (~12 VALU on every lane for a
+// wave-uniform value). The proofs below only need |inv - 1/s| <= 2^-23 / s: with |t| <= 16 the fast quotient then
+// differs from fl(y/s) by < 2.9e-6 + 1e-6 < FQ_NEAR. (The scale itself, an output, stays a correctly rounded m / 7.)
+#ifndef FQ_IEEE_INV
+#define FQ_IEEE_INV 0  // 1 (A/B builds): the correctly rounded reciprocal
+#endif
+__device__ __forceinline__ float fq_fast_inv(float scale) { return FQ_IEEE_INV ? 1.0f / scale : __builtin_amdgcn_rcpf(scale); }
+
+
 // Single-instruction 3-input max/min. fmaxf(fmaxf(a,b),c) compiles to v_max3_f32 only after hipcc has inserted
 // a canonicalising v_max_f32 x,x per MFMA-produced operand (one extra VALU per element); NaNs are not part of the
 // contract here, so use the instruction directly.

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                                 pw[mo][w] = d;
                             }
                     } else {
-                        const float inv = 1.0f / scale;
+                        const float inv = fq_fast_inv(scale);
                         // bit (4*mo + w) of near: some lane's dword has a quotient within FQ_NEAR of a tie
                         unsigned near;
 #if FQ_K64_ABLATE & 2
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                                 for (int e = 0; e < 8; ++e)
                                     fv[mo][w][e] = fq_dequant1<FLAGS>(fq_quant1<FLAGS>(FQ_YV(mo, w, e), scale), scale);
                     } else {
-                        const float inv = 1.0f / scale;
+                        const float inv = fq_fast_inv(scale);
                         const f32x2 inv2 = {inv, inv};
                         const bool magic = fq_magic_ok(vmax, vmin, inv);
                         const bool clampq = fq_needs_clamp(vmax, vmin, inv);

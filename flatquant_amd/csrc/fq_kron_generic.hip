@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void fq_kron_generic_kernel(const f16* __restr
             float scale;
             if (flags & FQ_QUANT_F16) scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
             else scale = fq_token_scale<0>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
-            const float inv = 1.0f / scale;
+            const float inv = fq_fast_inv(scale);
 
             // quantise this lane's slice once: 16 integer-valued floats per (t, mo)
 #pragma unroll
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
             float scale;
             if (flags & FQ_QUANT_F16) scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
             else scale = fq_token_scale<0>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
-            const float inv = 1.0f / scale;
+            const float inv = fq_fast_inv(scale);
             const f32x2 inv2 = {inv, inv};
             const bool magic = !(flags & FQ_QUANT_F16) && fq_magic_ok(vmax, vmin, inv);
             const bool clampq = fq_needs_clamp(vmax, vmin, inv);

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
 
         for (int ci = 0; ci < out.n_clips; ++ci) {
             const float scale = fq_token_scale<0>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
-            const float inv = 1.0f / scale;
+            const float inv = fq_fast_inv(scale);
             const f32x2 inv2 = {inv, inv};
             const bool magic = fq_magic_ok(vmax, vmin, inv);
             const bool clampq = fq_needs_clamp(vmax, vmin, inv);

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void fq_rowquant_wave_kernel(const f16* __rest
         vmin = fq_wave_min(vmin);
         for (int ci = 0; ci < out.n_clips; ++ci) {
             const float scale = fq_token_scale<FLAGS>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
-            const float inv = 1.0f / scale;
+            const float inv = fq_fast_inv(scale);
             if (FLAGS & FQ_OUT_PACKED) {
                 if (lane == 0) out.scale[ci][row] = (f16)scale;
                 uint32_t* qp = reinterpret_cast<uint32_t*>(out.q[ci] + row * (int64_t)(cols >> 1));
