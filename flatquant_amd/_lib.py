@@ -38,6 +38,8 @@ SYMBOLS = {
     "fq_kron_workspace_bytes": (_i64, [_i, _i]),
     "fq_kron_prepare_f16": (_i, [_vp, _vp, _i, _i, _vp, _i64, _vp]),
     "fq_block_quant_f16": (_i, [_vp, _vp, _i64, _i, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp]),
+    "fq_int4_gemm_i32": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
+    "fq_int4_linear_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
     "fq_hadamard_f16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _f, _vp]),
     "fq_hadamard_quant_f16": (_i, [_vp, _i64, _i, _i, _vp, _f, _f, _f, _vp, _vp, _vp]),
     "fq_rowquant_f16": (_i, [_vp, _i64, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp]),

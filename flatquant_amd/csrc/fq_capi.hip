@@ -16,6 +16,8 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
                            int64_t workspace_bytes, int n_cu, hipStream_t stream);
 int fq_launch_hadamard_quant(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max,
                              float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream);
+int fq_launch_gemm_i4(const uint8_t* X, const uint8_t* W, int64_t M, int N, int K, int32_t* c, f16* y, const f16* srow,
+                      const f16* scol, const f16* bias, hipStream_t stream);
 int64_t fq_kron_generic_workspace_bytes(int M, int N);
 int fq_launch_kron_prepare(const f16* left, const f16* right, int M, int N, void* workspace, hipStream_t stream);
 int fq_launch_block(int flags, const f16* x, const f16* P, int64_t rows, int R, int C, int transpose_out,
@@ -199,6 +201,29 @@ int fq_hadamard_f16(const void* x, void* y, int64_t rows, int n, int K, const vo
     int rc = fq_launch_hadamard((const f16*)x, (f16*)y, rows, n, K, (const f16*)hadK, scale, cu_count(),
                                 (hipStream_t)stream);
     return check_launch(rc, "fq_hadamard_f16");
+}
+
+int fq_int4_gemm_i32(const void* x, const void* w, int64_t M, int N, int K, void* c, void* stream) {
+    if (!x || !w || !c) return fail(FQ_EINVAL, "fq_int4_gemm_i32: NULL pointer");
+    if (M < 0 || N <= 0 || K <= 0) return fail(FQ_EINVAL, "fq_int4_gemm_i32: bad sizes");
+    if (K % 32) return fail(FQ_EINVAL, "fq_int4_gemm_i32: K=%d must be a multiple of 32", K);
+    if (M == 0) return FQ_OK;
+    const int rc = fq_launch_gemm_i4((const uint8_t*)x, (const uint8_t*)w, M, N, K, (int32_t*)c, nullptr, nullptr, nullptr,
+                                     nullptr, (hipStream_t)stream);
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "fq_int4_gemm_i32: shape M=%lld N=%d K=%d not supported", (long long)M, N, K);
+    return check_launch(rc, "fq_int4_gemm_i32");
+}
+
+int fq_int4_linear_f16(const void* x, const void* x_scale, const void* w, const void* w_scale, const void* bias,
+                       int64_t M, int N, int K, void* y, void* stream) {
+    if (!x || !w || !y || !x_scale || !w_scale) return fail(FQ_EINVAL, "fq_int4_linear_f16: NULL pointer");
+    if (M < 0 || N <= 0 || K <= 0) return fail(FQ_EINVAL, "fq_int4_linear_f16: bad sizes");
+    if (K % 32) return fail(FQ_EINVAL, "fq_int4_linear_f16: K=%d must be a multiple of 32", K);
+    if (M == 0) return FQ_OK;
+    const int rc = fq_launch_gemm_i4((const uint8_t*)x, (const uint8_t*)w, M, N, K, nullptr, (f16*)y, (const f16*)x_scale,
+                                     (const f16*)w_scale, (const f16*)bias, (hipStream_t)stream);
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "fq_int4_linear_f16: shape M=%lld N=%d K=%d not supported", (long long)M, N, K);
+    return check_launch(rc, "fq_int4_linear_f16");
 }
 
 int fq_hadamard_quant_f16(const void* x, int64_t rows, int n, int K, const void* hadK, float scale, float sig_max,

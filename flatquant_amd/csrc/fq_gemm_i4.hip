@@ -1,0 +1,238 @@
+// fq_gemm_i4.hip — INT4 x INT4 -> INT32 GEMM, the consumer of the packed activations (first "next" row):
+//     C[m][n] = sum_k x[m][k] * w[n][k],   x [M, K/2] and w [N, K/2] packed two's-complement nibbles (even k low)
+// Replaces deploy/kernels/gemm.cu:8-47 (CUTLASS int4 tensor-op GEMM, row-major A, column-major B, int32 out) behind
+// deploy.matmul (deploy/__init__.py:37-41), and — with the epilogue fused — Linear4bit.forward
+// (deploy/nn/linear.py:41-56: matmul, then sym_dequant quant.cu:66-85, then bias).
+//
+// gfx950 has no INT4 matrix instruction; v_mfma_i32_32x32x32_i8 takes signed bytes. A nibble left in the HIGH half of
+// its byte IS the signed byte 16*q, so unpacking is one AND for the odd elements and shift + AND for the even ones
+// (3 VALU per packed dword, single-width: they issue in the shadow of the MFMAs), every product is 256*x*w and the
+// accumulator is shifted right by 8 at the end (exact; |sum| < 2^31 for K <= 131072). No sign-extension
+// arithmetic, no zero-point correction terms.
+//
+// Tiling: 256 x 256 output tile per 8-wave workgroup, K in steps of 128 nibbles (64 bytes per row), three LDS stages of
+// 32 KB filled by LDS-DMA (16 rows x 64 bytes per instruction, 16-byte pieces XOR-swizzled by (row>>2)&3 on the source
+// side so that the ds_read_b64 fragment reads are conflict-free), counted vmcnt, one barrier per K-step.
+// The weight rows feed the MFMA A operand with a row permutation (prow) that leaves each lane with 16 CONSECUTIVE n of
+// one output row m: 64-byte (int32) or 32-byte (fp16) contiguous stores.
+#include "fq_common.hpp"
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_g;
+
+constexpr int BM = 256, BN = 256;     // output tile (tokens x output features)
+constexpr int BKB = 64;               // packed bytes of K per stage and row (128 nibbles = 4 MFMA K-steps)
+constexpr int STAGES = 3;
+constexpr int TILE_BYTES = (BM + BN) * BKB;  // 32 KB: [W rows 0..255][X rows 0..255], 64 bytes each
+constexpr int GT = 512;               // threads
+
+// A-operand row (0..31) of a 32-row tile -> the n it holds, so that D's lane (h, .) ends with n = 16 h + reg
+__device__ __forceinline__ int prow(int c) { return ((c >> 2) & 1) * 16 + (c & 3) + 4 * (c >> 3); }
+
+// 16 nibbles (8 bytes) -> 16 signed bytes = 16 * q, as {hi(x.x), lo(x.x), hi(x.y), lo(x.y)}: the same element order on
+// both operands, which is all the contraction needs
+__device__ __forceinline__ i32x4 unpack16(uint2 p) {
+    i32x4 r;
+    r[0] = (int)(p.x & 0xF0F0F0F0u);
+    r[1] = (int)((p.x << 4) & 0xF0F0F0F0u);
+    r[2] = (int)(p.y & 0xF0F0F0F0u);
+    r[3] = (int)((p.y << 4) & 0xF0F0F0F0u);
+    return r;
+}
+
+// quant.cu:5-10,66-85: x = s_row * s_col * half(int(q / 10.0f)) * half(10), fp16 products left to right
+__device__ __forceinline__ f16 dequant1(int q, f16 srow, f16 scol) {
+    int iv = (int)((float)q / 10.0f);  // C truncation toward zero
+    iv = max(-65176, min(65176, iv));
+    f16 r = srow * scol;
+    r = r * (f16)iv;
+    return r * (f16)10.0f;
+}
+
+struct GemmOut {
+    int32_t* c;          // [M, N] int32, or nullptr
+    f16* y;              // [M, N] fp16 (fused dequant), or nullptr
+    const f16* srow;     // [M]  activation scales
+    const f16* scol;     // [N]  weight scales
+    const f16* bias;     // [N] or nullptr
+};
+
+__global__ __launch_bounds__(GT) void fq_gemm_i4_kernel(const uint8_t* __restrict__ X, const uint8_t* __restrict__ W,
+                                                        int M, int N, int Kb, GemmOut out) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;  // wave tile: 128 tokens x 64 features
+    const int nb_n = (N + BN - 1) / BN;
+    const int mb = blockIdx.x / nb_n, nb = blockIdx.x - mb * nb_n;  // consecutive workgroups share the token tile
+    const int m0 = mb * BM, n0 = nb * BN;
+    const int nk = Kb / BKB;
+
+    // ---- DMA plan: a stage is 32 instructions of 1 KB (16 rows x 64 B); wave w issues instructions 4w .. 4w+3.
+    // instruction i < 16 -> weight rows 16 i .., else token rows 16 (i - 16) .. ; lane l: row + (l >> 2), physical
+    // 16-byte piece l & 3 holds logical piece (l & 3) ^ ((row >> 2) & 3)
+    const unsigned char* gsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = wave * 4 + j;
+        const int r = (i & 15) * 16 + (lane >> 2);  // row inside the 256-row half
+        const int piece = (lane & 3) ^ ((r >> 2) & 3);
+        int64_t grow;
+        const unsigned char* base;
+        if (i < 16) {
+            grow = n0 + r < N ? n0 + r : N - 1;
+            base = W;
+        } else {
+            grow = m0 + r < M ? m0 + r : M - 1;
+            base = X;
+        }
+        gsrc[j] = base + grow * Kb + piece * 16;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(lds_void_g*)smem;
+    auto issue_stage = [&](int kb) {
+        const unsigned dst = lds0 + (unsigned)((kb % STAGES) * TILE_BYTES) + (unsigned)(wave * 4) * 1024u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned char* src = gsrc[j] + (int64_t)kb * BKB;
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %2\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, off\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src), "s"(__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)j * 1024u)))
+                : "memory");
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside a stage): row r, 8-byte chunk q: r*64 + ((q>>1) ^ ((r>>2)&3))*16 + (q&1)*8
+    int woff[2], xoff[4];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) woff[tn] = (wn * 64 + tn * 32 + prow(c)) * BKB;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) xoff[tm] = BN * BKB + (wm * 128 + tm * 32 + c) * BKB;
+    const int wsw = (prow(c) >> 2) & 3;  // (row >> 2) & 3 of the weight rows: tile bases are multiples of 32
+    const int xsw = (c >> 2) & 3;
+
+    i32x16 acc[2][4];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = i32x16{0};
+
+    issue_stage(0);
+    if (nk > 1) issue_stage(1);
+    for (int kb = 0; kb < nk; ++kb) {
+        // stage kb landed: at most the next stage's 4 DMAs of this wave may still be in flight
+        if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everyone's part of stage kb is in LDS; everyone is done reading stage kb-1
+        if (kb + 2 < nk) issue_stage(kb + 2);  // overwrites the buffer of stage kb-1
+        const unsigned char* st = smem + (kb % STAGES) * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int q = ks * 2 + h;  // this lane's 8-byte chunk of the row (16 nibbles of the 32-deep K-step)
+            i32x4 wf[2], xf[4];
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+                wf[tn] = unpack16(*reinterpret_cast<const uint2*>(st + woff[tn] + (((q >> 1) ^ wsw) << 4) + ((q & 1) << 3)));
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+                xf[tm] = unpack16(*reinterpret_cast<const uint2*>(st + xoff[tm] + (((q >> 1) ^ xsw) << 4) + ((q & 1) << 3)));
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane (h, c) of tile (tn, tm) holds n = n0 + wn*64 + tn*32 + 16 h + r (r = 0..15) of token
+    //      m = m0 + wm*128 + tm*32 + c; products carry a factor 256 ----
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+        const int m = m0 + wm * 128 + tm * 32 + c;
+        if (m >= M) continue;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int nbase = n0 + wn * 64 + tn * 32 + 16 * h;
+            if (nbase >= N) continue;  // N % 16 == 0 (checked by the launcher)
+            int v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[tn][tm][r] >> 8;
+            if (out.c != nullptr) {
+                int4* cp = reinterpret_cast<int4*>(out.c + (int64_t)m * N + nbase);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) cp[g] = make_int4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+            }
+            if (out.y != nullptr) {
+                const f16 sr = out.srow[m];
+                f16x8 o0, o1;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    o0[r] = dequant1(v[r], sr, out.scol[nbase + r]);
+                    o1[r] = dequant1(v[8 + r], sr, out.scol[nbase + 8 + r]);
+                    if (out.bias != nullptr) {
+                        o0[r] = o0[r] + out.bias[nbase + r];
+                        o1[r] = o1[r] + out.bias[nbase + 8 + r];
+                    }
+                }
+                uint4* yp = reinterpret_cast<uint4*>(out.y + (int64_t)m * N + nbase);
+                yp[0] = __builtin_bit_cast(uint4, o0);
+                yp[1] = __builtin_bit_cast(uint4, o1);
+            }
+        }
+    }
+}
+
+// Any other shape the reference accepts (K % 32 == 0, deploy/__init__.py:38): one thread per output element,
+// 32-bit loads of 8 nibbles, sign extension by shifts. Correct, not fast; the model shapes never get here.
+__global__ __launch_bounds__(256) void fq_gemm_i4_simple_kernel(const uint8_t* __restrict__ X, const uint8_t* __restrict__ W,
+                                                               int M, int N, int Kb, GemmOut out) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
+        const uint32_t* xp = reinterpret_cast<const uint32_t*>(X + (int64_t)m * Kb);
+        const uint32_t* wp = reinterpret_cast<const uint32_t*>(W + (int64_t)n * Kb);
+        int acc = 0;
+        for (int k = 0; k < Kb / 4; ++k) {
+            const uint32_t a = xp[k], b = wp[k];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += (((int)(a << (28 - 4 * e))) >> 28) * (((int)(b << (28 - 4 * e))) >> 28);
+        }
+        if (out.c != nullptr) out.c[i] = acc;
+        if (out.y != nullptr) {
+            f16 v = dequant1(acc, out.srow[m], out.scol[n]);
+            if (out.bias != nullptr) v = v + out.bias[n];
+            out.y[i] = v;
+        }
+    }
+}
+
+}  // namespace
+
+// -1000: shape not accepted (K must be a multiple of 32, as deploy.matmul asserts).
+int fq_launch_gemm_i4(const uint8_t* X, const uint8_t* W, int64_t M, int N, int K, int32_t* c, f16* y, const f16* srow,
+                      const f16* scol, const f16* bias, hipStream_t stream) {
+    if ((K & 31) || K < 32 || M < 1 || N < 1 || M > (1 << 30)) return -1000;
+    GemmOut o;
+    o.c = c;
+    o.y = y;
+    o.srow = srow;
+    o.scol = scol;
+    o.bias = bias;
+    if ((K & 127) || (N & 15)) {
+        int64_t blocks = (M * (int64_t)N + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        hipLaunchKernelGGL(fq_gemm_i4_simple_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, X, W, (int)M, N, K / 2, o);
+        return (int)hipGetLastError();
+    }
+    const int64_t blocks = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    hipLaunchKernelGGL(fq_gemm_i4_kernel, dim3((unsigned)blocks), dim3(GT), 0, stream, X, W, (int)M, N, K / 2, o);
+    return (int)hipGetLastError();
+}

@@ -46,9 +46,11 @@ def sym_dequant(q, scale_row, scale_col, bits=32):
 
 
 def matmul(A, B):
-    """INT4 x INT4 -> INT32 GEMM (deploy/__init__.py:37-41 -> gemm.cu, CUTLASS): the CONSUMER of the path,
-    SURVEY 8f rank 1 — not built in this round."""
-    raise NotImplementedError("flatquant_amd.deploy.matmul (int4 GEMM) is the next scope row, not built yet")
+    """INT4 x INT4 -> INT32 GEMM on packed nibbles (deploy/__init__.py:37-41 -> gemm.cu, CUTLASS)."""
+    assert A.shape[-1] % 32 == 0, "A.shape[-1]: {} must be multiplication of 32".format(A.shape[-1])
+    A, A_shape_excl_last = flatten_last_dim_and_return_shape(A)
+    B, B_shape_excl_last = flatten_last_dim_and_return_shape(B)
+    return ops.int4_matmul(A.contiguous(), B.contiguous()).view(*A_shape_excl_last, *B_shape_excl_last)
 
 
 from . import functional, nn  # noqa: E402,F401

@@ -1,0 +1,52 @@
+"""Counterpart of deploy/nn/linear.py."""
+import torch
+
+from ... import ops
+from .. import PackedQuantizedTensor
+from ..functional.quantization import pack_i4
+
+
+class Linear4bit(torch.nn.Module):
+    """Symmetric 4-bit linear layer.  Reference: deploy/nn/linear.py:22-83 — same constructor, same buffers
+    (``weight`` uint8 [out, in/2] packed nibbles, ``weight_scales`` [out, 1], optional ``bias``), so reference state
+    dicts load unchanged.  ``forward`` takes the PackedQuantizedTensor the online transform / Quantizer produced and
+    returns fp16: the reference runs deploy.matmul (CUTLASS int4 GEMM -> int32 in HBM) and deploy.sym_dequant as two
+    launches (+ a torch add for the bias); here the dequantisation and the bias sit in the GEMM's epilogue
+    (fq_int4_linear_f16), bit-identical to the two-step form."""
+
+    def __init__(self, in_features, out_features, bias=False, dtype=torch.float16):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.register_buffer("weight_scales", torch.zeros((self.out_features, 1), requires_grad=False))
+        self.register_buffer("weight", torch.randint(1, 7, (self.out_features, self.in_features // 2),
+                                                     dtype=torch.uint8, requires_grad=False))
+        if bias:
+            self.register_buffer("bias", torch.zeros((self.out_features), dtype=dtype))
+        else:
+            self.bias = None
+
+    def forward(self, x):
+        assert type(x) == PackedQuantizedTensor  # quantized input is given (linear.py:45)
+        q, scales_x = x.quantized_x, x.scales_x
+        lead = q.shape[:-1]
+        y = ops.int4_linear(q.reshape(-1, q.shape[-1]).contiguous(), scales_x.reshape(-1).contiguous(),
+                            self.weight, self.weight_scales.reshape(-1).to(torch.float16).contiguous(),
+                            None if self.bias is None else self.bias.to(torch.float16))
+        return y.view(*lead, self.out_features)
+
+    @staticmethod
+    def from_float(module: torch.nn.Linear, weight_scales=None):
+        """linear.py:58-83: round(weight / weight_scales) packed two per byte."""
+        weight_matrix = module.weight.data
+        int_module = Linear4bit(module.in_features, module.out_features, bias=module.bias is not None,
+                                dtype=weight_matrix.dtype).to(weight_matrix.dtype)
+        if weight_scales is not None:
+            assert weight_scales.shape == (module.out_features, 1), "weight_scales should have shape (out_features, 1)"
+            weight_matrix = weight_matrix.cuda()
+            int_module.weight_scales.copy_(weight_scales.to(weight_matrix.dtype))
+            int_rounded_weight = (weight_matrix / weight_scales.cuda()).round()
+            int_module.weight.copy_(pack_i4(int_rounded_weight.to(torch.int8)).cpu())
+            if module.bias is not None:
+                int_module.bias.copy_(module.bias.data)
+        return int_module

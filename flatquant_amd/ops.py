@@ -261,6 +261,41 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
     return q, s
 
 
+def int4_matmul(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """_CUDA.matmul (bindings.cpp:9-25 -> gemm.cu): x uint8 [M, K/2], w uint8 [N, K/2], packed nibbles -> int32 [M, N]."""
+    _chk(x, "x", torch.uint8), _chk(w, "w", torch.uint8)
+    if x.dim() != 2 or w.dim() != 2 or x.shape[1] != w.shape[1]:
+        raise RuntimeError(f"int4_matmul: expected x [M, K/2] and w [N, K/2], got {tuple(x.shape)} and {tuple(w.shape)}")
+    M, N, K = x.shape[0], w.shape[0], x.shape[1] * 2
+    c = torch.empty((M, N), dtype=torch.int32, device=x.device)
+    if M == 0:
+        return c
+    with torch.cuda.device(x.device):
+        check(lib.fq_int4_gemm_i32(_ptr(x), _ptr(w), M, N, K, _ptr(c), _stream(x)))
+    return c
+
+
+def int4_linear(x: torch.Tensor, x_scale: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor,
+                bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Linear4bit.forward in one launch (fq_int4_linear_f16): packed x [M, K/2] with fp16 scales [M], packed w [N, K/2]
+    with fp16 scales [N], optional fp16 bias [N] -> fp16 [M, N]; == sym_dequant(int4_matmul(x, w), ...) (+ bias)."""
+    _chk(x, "x", torch.uint8), _chk(w, "w", torch.uint8), _chk(x_scale, "x_scale"), _chk(w_scale, "w_scale")
+    if bias is not None:
+        _chk(bias, "bias")
+    if x.dim() != 2 or w.dim() != 2 or x.shape[1] != w.shape[1]:
+        raise RuntimeError(f"int4_linear: expected x [M, K/2] and w [N, K/2], got {tuple(x.shape)} and {tuple(w.shape)}")
+    M, N, K = x.shape[0], w.shape[0], x.shape[1] * 2
+    if x_scale.numel() != M or w_scale.numel() != N or (bias is not None and bias.numel() != N):
+        raise RuntimeError("int4_linear: scale / bias sizes do not match M / N")
+    y = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    if M == 0:
+        return y
+    with torch.cuda.device(x.device):
+        check(lib.fq_int4_linear_f16(_ptr(x), _ptr(x_scale), _ptr(w), _ptr(w_scale), _ptr(bias), M, N, K, _ptr(y),
+                                     _stream(x)))
+    return y
+
+
 def sym_quant(x: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
     """_CUDA.sym_quant (bindings.cpp:27-44): x fp16 [rows, cols], scale fp16 [rows] -> uint8 [rows, ceil(cols/2)]."""
     _chk(x, "x"), _chk(scale, "scale")

@@ -14,6 +14,8 @@
  *                          flatquant/flat_utils.py:6-17 (kronecker_matmul) +
  *                          flatquant/quant_utils.py:71-119 (ActivationQuantizer)
  *   fq_block_quant_f16     deploy/kernels/block_matmul.py:231-311 (block_matmul)
+ *   fq_int4_gemm_i32       deploy/kernels/gemm.cu:8-47 (matmul_host) / deploy.matmul
+ *   fq_int4_linear_f16     deploy/nn/linear.py:41-56 (Linear4bit.forward = matmul + sym_dequant + bias)
  *   fq_hadamard_f16        flatquant/hadamard_utils.py:89-110,132-141 (matmul_hadU[_cuda]),
  *   (fq_hadamard_quant_f16: the same followed by deploy/nn/quantization.py:13-36, fused)
  *                          deploy/functional/online_trans.py:144-151
@@ -100,6 +102,24 @@ int fq_block_quant_f16(const void* x, const void* P, int64_t rows, int R, int C,
                        const float* sig_max, const float* sig_min, int n_clips, int flags,
                        void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
                        void* stream);
+
+/*
+ * INT4 x INT4 -> INT32 GEMM on packed nibbles (deploy/kernels/gemm.cu:8-47 behind deploy.matmul,
+ * deploy/__init__.py:37-41):  c[m][n] = sum_k x[m][k] * w[n][k].
+ *   x [M, K/2] uint8 (packed activations, e.g. PackedQuantizedTensor.quantized_x), w [N, K/2] uint8 (Linear4bit.weight),
+ *   low nibble = even k, two's complement;  c [M, N] int32.  K % 32 == 0 (the reference's assert).
+ */
+int fq_int4_gemm_i32(const void* x, const void* w, int64_t M, int N, int K, void* c, void* stream);
+
+/*
+ * Linear4bit.forward in one launch (deploy/nn/linear.py:41-56): the GEMM above with sym_dequant (quant.cu:66-85:
+ * y = x_scale[m] * w_scale[n] * half(int(c / 10.0f)) * half(10), fp16 products left to right) and the optional bias
+ * fused into its epilogue: the int32 matrix never goes to HBM.  Bit-identical to fq_int4_gemm_i32 followed by
+ * fq_sym_dequant_i32_f16 (+ bias).
+ *   x_scale [M] fp16, w_scale [N] fp16, bias [N] fp16 or NULL, y [M, N] fp16
+ */
+int fq_int4_linear_f16(const void* x, const void* x_scale, const void* w, const void* w_scale, const void* bias,
+                       int64_t M, int N, int K, void* y, void* stream);
 
 /*
  * Normalised Hadamard transform over the last axis, n = K * 2^p:

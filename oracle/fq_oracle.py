@@ -261,6 +261,25 @@ def sym_dequant(q32, scale_row16, scale_col16):
     return r
 
 
+def int4_matmul(x_packed, w_packed):
+    """deploy/kernels/gemm.cu:8-47 (CUTLASS int4b_t row-major x column-major -> int32): c[m][n] = sum_k x[m][k] w[n][k]
+    on the nibbles of pack_i4's layout (even k in the low nibble, two's complement). Exact integer arithmetic."""
+    x = unpack_i4(np.asarray(x_packed, dtype=np.uint8)).astype(np.int64)
+    w = unpack_i4(np.asarray(w_packed, dtype=np.uint8)).astype(np.int64)
+    c = x @ w.T
+    assert np.abs(c).max(initial=0) < 2 ** 31
+    return c.astype(np.int32)
+
+
+def linear4bit(x_packed, x_scale16, w_packed, w_scale16, bias16=None):
+    """deploy/nn/linear.py:41-56: sym_dequant(matmul(x, w), scales_x, weight_scales) (+ bias, an fp16 add)."""
+    y = sym_dequant(int4_matmul(x_packed, w_packed), x_scale16, w_scale16)
+    if bias16 is not None:
+        with np.errstate(over="ignore"):
+            y = (y.astype(F32) + np.asarray(bias16, dtype=F16).reshape(1, -1).astype(F32)).astype(F16)
+    return y
+
+
 # --------------------------------------------------------------------------------------------------
 # Hadamard
 # --------------------------------------------------------------------------------------------------

@@ -1,0 +1,93 @@
+"""GPU parity for the INT4 x INT4 -> INT32 GEMM and the fused Linear4bit (deploy.matmul / deploy.nn.Linear4bit):
+integer work, so the bar is bit-exact against the oracle (oracle/fq_oracle.py:int4_matmul, linear4bit)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from flatquant_amd import ops as _ops
+    return _ops
+
+
+def rand_packed(gen, rows, K, lo=-8, hi=8):
+    q = torch.randint(lo, hi, (rows, K), generator=gen, dtype=torch.int32).numpy()
+    return O.pack_i4(q), q
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 256, 4096), (300, 272, 256), (1, 16, 128), (257, 4096, 512),
+                                   (1000, 1024, 1024), (33, 48, 384), (64, 256, 14336),
+                                   (7, 40, 96), (65, 24, 160)])   # the last two: general-shape kernel (K % 128, N % 16)
+def test_int4_gemm_bit_exact(ops, M, N, K):
+    gen = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    xp, xq = rand_packed(gen, M, K)
+    wp, wq = rand_packed(gen, N, K)
+    c = ops.int4_matmul(torch.from_numpy(xp).cuda(), torch.from_numpy(wp).cuda()).cpu().numpy()
+    ref = xq.astype(np.int64) @ wq.astype(np.int64).T
+    assert np.array_equal(c, ref.astype(np.int32))
+    assert np.array_equal(O.int4_matmul(xp, wp), ref.astype(np.int32))
+
+
+def test_int4_gemm_extreme_values_no_overflow(ops):
+    """All nibbles -8: every product +64, K = 14336 -> 917504 per output; the kernel's 256x-scaled accumulator peaks
+    at 2.3e8 < 2^31."""
+    M, N, K = 40, 32, 14336
+    xp = O.pack_i4(np.full((M, K), -8, dtype=np.int32))
+    wp = O.pack_i4(np.full((N, K), -8, dtype=np.int32))
+    c = ops.int4_matmul(torch.from_numpy(xp).cuda(), torch.from_numpy(wp).cuda()).cpu().numpy()
+    assert np.all(c == 64 * K)
+    wp = O.pack_i4(np.full((N, K), 7, dtype=np.int32))
+    c = ops.int4_matmul(torch.from_numpy(xp).cuda(), torch.from_numpy(wp).cuda()).cpu().numpy()
+    assert np.all(c == -56 * K)
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(512, 256, 4096, False), (300, 272, 256, True), (129, 1024, 1024, True),
+                                        (9, 24, 160, True)])
+def test_fused_linear4bit_equals_matmul_then_dequant(ops, M, N, K, bias):
+    gen = torch.Generator().manual_seed(M + N + K)
+    xp, _ = rand_packed(gen, M, K)
+    wp, _ = rand_packed(gen, N, K)
+    sx = (torch.rand(M, generator=gen) * 0.05 + 0.001).half()
+    sw = (torch.rand(N, generator=gen) * 0.02 + 0.0005).half()
+    b = torch.randn(N, generator=gen).half() if bias else None
+    y = ops.int4_linear(torch.from_numpy(xp).cuda(), sx.cuda(), torch.from_numpy(wp).cuda(), sw.cuda(),
+                        None if b is None else b.cuda()).cpu().numpy()
+    ref = O.linear4bit(xp, sx.numpy(), wp, sw.numpy(), None if b is None else b.numpy())
+    assert np.array_equal(y.view(np.uint16), ref.view(np.uint16))
+    # and against the two-launch route of the reference
+    two = ops.sym_dequant(ops.int4_matmul(torch.from_numpy(xp).cuda(), torch.from_numpy(wp).cuda()), sx.cuda(), sw.cuda())
+    if b is not None:
+        two = two + b.cuda()
+    assert torch.equal(two.cpu(), torch.from_numpy(y))
+
+
+def test_deploy_linear4bit_module_end_to_end(ops):
+    """OnlineTrans (Kronecker transform + INT4 quantisation) -> Linear4bit, as deploy/transformers/modeling_llama.py
+    chains them; state-dict names as the reference's."""
+    import flatquant_amd.deploy as deploy
+    gen = torch.Generator().manual_seed(3)
+    lin = torch.nn.Linear(4096, 512, bias=True).half()
+    ws = (lin.weight.detach().abs().amax(dim=1, keepdim=True) / 7).half()
+    q = deploy.nn.Linear4bit.from_float(lin, ws).cuda()
+    assert set(q.state_dict()) == {"weight_scales", "weight", "bias"}
+    t = deploy.nn.OnlineTrans(4096, trans="matmul", decompose=True, lac=True).cuda()
+    t.left_matrix.copy_(torch.eye(64).half())
+    t.right_matrix.copy_(torch.eye(64).half())
+    x = torch.randn(2, 33, 4096, generator=gen).half().cuda()
+    packed = t(x)
+    y = q(packed)
+    assert y.shape == (2, 33, 512) and y.dtype == torch.float16
+    ref = O.linear4bit(packed.quantized_x.reshape(-1, 2048).cpu().numpy(), packed.scales_x.reshape(-1).cpu().numpy(),
+                       q.weight.cpu().numpy(), q.weight_scales.reshape(-1).half().cpu().numpy(), q.bias.detach().cpu().numpy())
+    assert np.array_equal(y.reshape(-1, 512).cpu().numpy().view(np.uint16), ref.view(np.uint16))
+    # identity transform, 4-bit both sides: the result tracks the fp16 linear layer
+    full = torch.nn.functional.linear(x.float(), lin.weight.float().cuda(), lin.bias.float().cuda())
+    rel = (y.float() - full).norm() / full.norm()
+    assert rel < 0.25
+    assert torch.equal(deploy.matmul(packed.quantized_x, q.weight).reshape(-1, 512),
+                       ops.int4_matmul(packed.quantized_x.reshape(-1, 2048), q.weight))

@@ -62,6 +62,18 @@ def main():
         del xs
     if os.environ.get("KRON_ONLY"):
         return
+    if not os.environ.get("NO_GEMM"):
+        # the consumer of the packed activations: INT4 x INT4 GEMM with the dequant epilogue (Linear4bit), 16384 tokens
+        for N_, K_ in ((4096, 4096), (14336, 4096), (4096, 14336), (8192, 8192)):
+            xq = torch.randint(0, 256, (ROWS, K_ // 2), generator=g, device="cuda", dtype=torch.uint8)
+            wq = torch.randint(0, 256, (N_, K_ // 2), generator=g, device="cuda", dtype=torch.uint8)
+            sx = torch.rand(ROWS, generator=g, device="cuda").half() * 0.01
+            sw = torch.rand(N_, generator=g, device="cuda").half() * 0.01
+            us = timeit(lambda i: ops.int4_linear(xq, sx, wq, sw), steps=20)
+            tops = 2.0 * ROWS * N_ * K_ / us / 1e6
+            print(f"{'int4 linear (gemm + dequant)':34s} {'M=%d N=%d K=%d' % (ROWS, N_, K_):22s} {us:9.1f} us  {tops:8.0f} TOP/s")
+            us = timeit(lambda i: ops.int4_matmul(xq, wq), steps=20)
+            print(f"{'int4 gemm -> int32':34s} {'M=%d N=%d K=%d' % (ROWS, N_, K_):22s} {us:9.1f} us  {2.0 * ROWS * N_ * K_ / us / 1e6:8.0f} TOP/s")
     for hd, H in ((128, 32), (128, 64)):
         xs = [torch.randn(ROWS, hd, H, generator=g, device="cuda", dtype=torch.float16) for _ in range(NB)]
         P = (torch.randn(H, H, generator=g, device="cuda") / H ** 0.5).half()
