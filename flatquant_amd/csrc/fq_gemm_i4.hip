@@ -27,7 +27,21 @@ constexpr int BM = 256, BN = 256;     // output tile (tokens x output features)
 constexpr int BKB = 64;               // packed bytes of K per stage and row (128 nibbles = 4 MFMA K-steps)
 constexpr int STAGES = 3;
 constexpr int TILE_BYTES = (BM + BN) * BKB;  // 32 KB: [W rows 0..255][X rows 0..255], 64 bytes each
-constexpr int GT = 512;               // threads
+#ifndef FQ_GEMM_WAVES
+#define FQ_GEMM_WAVES 16  // 16: 4 x 4 waves of 64 x 64 (4 accumulator tiles, <= 128 VGPRs, 4 waves per SIMD whose
+                          // unpack VALU fills the other waves' MFMA shadows); 8: 2 x 4 waves of 128 x 64
+#endif
+constexpr int GW = FQ_GEMM_WAVES;     // waves per workgroup
+constexpr int GT = GW * 64;           // threads
+constexpr int NWM = GW / 4;           // waves along the token dimension (4 along the feature dimension)
+constexpr int TMT = BM / 32 / NWM;    // 32-token tiles per wave
+constexpr int DPW = 32 / GW;          // DMA instructions per wave and stage
+
+// 16-byte piece swizzles (XOR on the piece index 0..3 of a 64-byte row): the 16 lanes a ds_read_b128 serves per LDS
+// cycle must hit 16 different (row & 3, piece) slots. Token rows are read in natural order (lane c -> row c), weight
+// rows through prow(): lanes 0..15 read rows {0-3, 16-19, 4-7, 20-23}.
+__device__ __forceinline__ int swz_x(int r) { return (r >> 2) & 3; }
+__device__ __forceinline__ int swz_w(int r) { return ((r >> 2) & 1) | (((r >> 4) & 1) << 1); }
 
 // A-operand row (0..31) of a 32-row tile -> the n it holds, so that D's lane (h, .) ends with n = 16 h + reg
 __device__ __forceinline__ int prow(int c) { return ((c >> 2) & 1) * 16 + (c & 3) + 4 * (c >> 3); }
@@ -65,7 +79,7 @@ __global__ __launch_bounds__(GT) void fq_gemm_i4_kernel(const uint8_t* __restric
     __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * TILE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;  // wave tile: 128 tokens x 64 features
+    const int wm = wave % NWM, wn = wave / NWM;  // wave tile: TMT*32 tokens x 64 features
     const int nb_n = (N + BN - 1) / BN;
     const int mb = blockIdx.x / nb_n, nb = blockIdx.x - mb * nb_n;  // consecutive workgroups share the token tile
     const int m0 = mb * BM, n0 = nb * BN;
@@ -73,13 +87,13 @@ __global__ __launch_bounds__(GT) void fq_gemm_i4_kernel(const uint8_t* __restric
 
     // ---- DMA plan: a stage is 32 instructions of 1 KB (16 rows x 64 B); wave w issues instructions 4w .. 4w+3.
     // instruction i < 16 -> weight rows 16 i .., else token rows 16 (i - 16) .. ; lane l: row + (l >> 2), physical
-    // 16-byte piece l & 3 holds logical piece (l & 3) ^ ((row >> 2) & 3)
-    const unsigned char* gsrc[4];
+    // 16-byte piece l & 3 holds logical piece (l & 3) ^ swz(row)
+    const unsigned char* gsrc[DPW];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = wave * 4 + j;
+    for (int j = 0; j < DPW; ++j) {
+        const int i = wave * DPW + j;
         const int r = (i & 15) * 16 + (lane >> 2);  // row inside the 256-row half
-        const int piece = (lane & 3) ^ ((r >> 2) & 3);
+        const int piece = (lane & 3) ^ (i < 16 ? swz_w(r) : swz_x(r));
         int64_t grow;
         const unsigned char* base;
         if (i < 16) {
@@ -93,9 +107,9 @@ __global__ __launch_bounds__(GT) void fq_gemm_i4_kernel(const uint8_t* __restric
     }
     const unsigned lds0 = (unsigned)(size_t)(lds_void_g*)smem;
     auto issue_stage = [&](int kb) {
-        const unsigned dst = lds0 + (unsigned)((kb % STAGES) * TILE_BYTES) + (unsigned)(wave * 4) * 1024u;
+        const unsigned dst = lds0 + (unsigned)((kb % STAGES) * TILE_BYTES) + (unsigned)(wave * DPW) * 1024u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < DPW; ++j) {
             const unsigned char* src = gsrc[j] + (int64_t)kb * BKB;
             unsigned keep;
             asm volatile(
@@ -110,53 +124,66 @@ __global__ __launch_bounds__(GT) void fq_gemm_i4_kernel(const uint8_t* __restric
         }
     };
 
-    // ---- fragment read offsets (bytes inside a stage): row r, 8-byte chunk q: r*64 + ((q>>1) ^ ((r>>2)&3))*16 + (q&1)*8
-    int woff[2], xoff[4];
+    // ---- fragment read offsets (bytes inside a stage). A lane reads whole 16-byte pieces (ds_read_b128: one LDS
+    // instruction per fragment and PAIR of K-steps, 64-bank addressing; two ds_read_b64 get merged by hipcc into
+    // ds_read2st64_b64, which banks modulo 32 and measured 16 conflict cycles per instruction): logical piece 2 p + h of
+    // row r sits at r*64 + ((2 p + h) ^ swz(r))*16; its first 8 bytes feed K-step 2p, the second 8 bytes K-step 2p+1
+    // (any split of k over the steps is fine as long as both operands use the same one).
+    int woff[2], xoff[TMT];
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) woff[tn] = (wn * 64 + tn * 32 + prow(c)) * BKB;
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) xoff[tm] = BN * BKB + (wm * 128 + tm * 32 + c) * BKB;
-    const int wsw = (prow(c) >> 2) & 3;  // (row >> 2) & 3 of the weight rows: tile bases are multiples of 32
-    const int xsw = (c >> 2) & 3;
+    for (int tm = 0; tm < TMT; ++tm) xoff[tm] = BN * BKB + (wm * (TMT * 32) + tm * 32 + c) * BKB;
+    const int wsw = swz_w(prow(c));  // tile bases are multiples of 32 rows: the swizzle only sees prow(c) / c
+    const int xsw = swz_x(c);
 
-    i32x16 acc[2][4];
+    i32x16 acc[2][TMT];
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = i32x16{0};
+        for (int tm = 0; tm < TMT; ++tm) acc[tn][tm] = i32x16{0};
 
     issue_stage(0);
     if (nk > 1) issue_stage(1);
     for (int kb = 0; kb < nk; ++kb) {
-        // stage kb landed: at most the next stage's 4 DMAs of this wave may still be in flight
-        if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // stage kb landed: at most the next stage's DPW DMAs of this wave may still be in flight
+        if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // everyone's part of stage kb is in LDS; everyone is done reading stage kb-1
         if (kb + 2 < nk) issue_stage(kb + 2);  // overwrites the buffer of stage kb-1
         const unsigned char* st = smem + (kb % STAGES) * TILE_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int q = ks * 2 + h;  // this lane's 8-byte chunk of the row (16 nibbles of the 32-deep K-step)
-            i32x4 wf[2], xf[4];
+        for (int p = 0; p < 2; ++p) {  // pairs of K-steps
+            uint4 wr[2], xr[TMT];
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
-                wf[tn] = unpack16(*reinterpret_cast<const uint2*>(st + woff[tn] + (((q >> 1) ^ wsw) << 4) + ((q & 1) << 3)));
+                wr[tn] = *reinterpret_cast<const uint4*>(st + woff[tn] + (((2 * p + h) ^ wsw) << 4));
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
-                xf[tm] = unpack16(*reinterpret_cast<const uint2*>(st + xoff[tm] + (((q >> 1) ^ xsw) << 4) + ((q & 1) << 3)));
+            for (int tm = 0; tm < TMT; ++tm)
+                xr[tm] = *reinterpret_cast<const uint4*>(st + xoff[tm] + (((2 * p + h) ^ xsw) << 4));
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
+            for (int half = 0; half < 2; ++half) {
+                i32x4 wf[2], xf[TMT];
 #pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
-                    acc[tn][tm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+                for (int tn = 0; tn < 2; ++tn)
+                    wf[tn] = unpack16(half ? make_uint2(wr[tn].z, wr[tn].w) : make_uint2(wr[tn].x, wr[tn].y));
+#pragma unroll
+                for (int tm = 0; tm < TMT; ++tm)
+                    xf[tm] = unpack16(half ? make_uint2(xr[tm].z, xr[tm].w) : make_uint2(xr[tm].x, xr[tm].y));
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < TMT; ++tm)
+                        acc[tn][tm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+            }
         }
     }
 
     // ---- epilogue: lane (h, c) of tile (tn, tm) holds n = n0 + wn*64 + tn*32 + 16 h + r (r = 0..15) of token
     //      m = m0 + wm*128 + tm*32 + c; products carry a factor 256 ----
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-        const int m = m0 + wm * 128 + tm * 32 + c;
+    for (int tm = 0; tm < TMT; ++tm) {
+        const int m = m0 + wm * (TMT * 32) + tm * 32 + c;
         if (m >= M) continue;
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
