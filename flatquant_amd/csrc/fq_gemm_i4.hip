@@ -25,7 +25,10 @@ typedef __attribute__((address_space(3))) void lds_void_g;
 
 constexpr int BM = 256, BN = 256;     // output tile (tokens x output features)
 constexpr int BKB = 64;               // packed bytes of K per stage and row (128 nibbles = 4 MFMA K-steps)
-constexpr int STAGES = 3;
+#ifndef FQ_GEMM_STAGES
+#define FQ_GEMM_STAGES 3   // LDS stages of 32 KB, all of them in flight or being read
+#endif
+constexpr int STAGES = FQ_GEMM_STAGES;
 constexpr int TILE_BYTES = (BM + BN) * BKB;  // 32 KB: [W rows 0..255][X rows 0..255], 64 bytes each
 #ifndef FQ_GEMM_WAVES
 #define FQ_GEMM_WAVES 16  // 16: 4 x 4 waves of 64 x 64 (4 accumulator tiles, <= 128 VGPRs, 4 waves per SIMD whose
@@ -50,6 +53,10 @@ __device__ __forceinline__ int prow(int c) { return ((c >> 2) & 1) * 16 + (c & 3
 // both operands, which is all the contraction needs
 __device__ __forceinline__ i32x4 unpack16(uint2 p) {
     i32x4 r;
+#ifdef FQ_GEMM_NOUNPACK  // measurement build (wrong results): what does the unpack cost?
+    r[0] = (int)p.x; r[1] = (int)p.y; r[2] = (int)p.x; r[3] = (int)p.y;
+    return r;
+#endif
     r[0] = (int)(p.x & 0xF0F0F0F0u);
     r[1] = (int)((p.x << 4) & 0xF0F0F0F0u);
     r[2] = (int)(p.y & 0xF0F0F0F0u);
@@ -143,41 +150,59 @@ __global__ __launch_bounds__(GT) void fq_gemm_i4_kernel(const uint8_t* __restric
 #pragma unroll
         for (int tm = 0; tm < TMT; ++tm) acc[tn][tm] = i32x16{0};
 
-    issue_stage(0);
-    if (nk > 1) issue_stage(1);
-    for (int kb = 0; kb < nk; ++kb) {
-        // stage kb landed: at most the next stage's DPW DMAs of this wave may still be in flight
-        if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // everyone's part of stage kb is in LDS; everyone is done reading stage kb-1
-        if (kb + 2 < nk) issue_stage(kb + 2);  // overwrites the buffer of stage kb-1
-        const unsigned char* st = smem + (kb % STAGES) * TILE_BYTES;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {  // pairs of K-steps
-            uint4 wr[2], xr[TMT];
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-                wr[tn] = *reinterpret_cast<const uint4*>(st + woff[tn] + (((2 * p + h) ^ wsw) << 4));
-#pragma unroll
-            for (int tm = 0; tm < TMT; ++tm)
-                xr[tm] = *reinterpret_cast<const uint4*>(st + xoff[tm] + (((2 * p + h) ^ xsw) << 4));
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                i32x4 wf[2], xf[TMT];
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-                    wf[tn] = unpack16(half ? make_uint2(wr[tn].z, wr[tn].w) : make_uint2(wr[tn].x, wr[tn].y));
-#pragma unroll
-                for (int tm = 0; tm < TMT; ++tm)
-                    xf[tm] = unpack16(half ? make_uint2(xr[tm].z, xr[tm].w) : make_uint2(xr[tm].x, xr[tm].y));
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                    for (int tm = 0; tm < TMT; ++tm)
-                        acc[tn][tm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
-            }
-        }
+    // Pipeline. Per stage two pairs of K-steps; the pieces of pair 1 are read BEFORE the stage hand-over (wait for
+    // stage kb+1, barrier, DMA of stage kb+STAGES into the buffer every wave has just finished reading) and the pieces
+    // of the next stage's pair 0 right after it, so the MFMAs of pair 1 start the moment the barrier releases and
+    // cover those reads: no LDS round trip between a barrier and the first MFMA behind it.
+    uint4 r0w[2], r0x[TMT], r1w[2], r1x[TMT];
+#define FQ_READ(ST, P, RW, RX)                                                                                      \
+    {                                                                                                                \
+        _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) RW[tn] =                                                    \
+            *reinterpret_cast<const uint4*>((ST) + woff[tn] + (((2 * (P) + h) ^ wsw) << 4));                         \
+        _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm) RX[tm] =                                                  \
+            *reinterpret_cast<const uint4*>((ST) + xoff[tm] + (((2 * (P) + h) ^ xsw) << 4));                         \
     }
+#define FQ_COMPUTE(RW, RX)                                                                                          \
+    _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                         \
+        i32x4 wf[2], xf[TMT];                                                                                        \
+        _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) wf[tn] =                                                    \
+            unpack16(half ? make_uint2(RW[tn].z, RW[tn].w) : make_uint2(RW[tn].x, RW[tn].y));                        \
+        _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm) xf[tm] =                                                  \
+            unpack16(half ? make_uint2(RX[tm].z, RX[tm].w) : make_uint2(RX[tm].x, RX[tm].y));                        \
+        _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm)          \
+            acc[tn][tm] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);               \
+    }
+#pragma unroll
+    for (int p = 0; p < STAGES; ++p)
+        if (p < nk) issue_stage(p);
+    {   // stage 0 landed: up to STAGES - 1 younger stages of this wave in flight
+        const int younger = nk - 1 < STAGES - 1 ? nk - 1 : STAGES - 1;
+        if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * DPW) : "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * DPW) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    FQ_READ(smem, 0, r0w, r0x)
+    for (int kb = 0; kb < nk; ++kb) {
+        const unsigned char* st = smem + (kb % STAGES) * TILE_BYTES;
+        FQ_READ(st, 1, r1w, r1x)
+        FQ_COMPUTE(r0w, r0x)
+        if (kb + 1 < nk) {
+            // stage kb+1 landed: the stages kb+2 .. kb+STAGES-1 of this wave may still be in flight
+            const int younger = nk - 2 - kb < STAGES - 2 ? nk - 2 - kb : STAGES - 2;
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(2 * DPW) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(DPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave holds all of stage kb in registers: its buffer is free
+            if (kb + STAGES < nk) issue_stage(kb + STAGES);
+            const unsigned char* sn = smem + ((kb + 1) % STAGES) * TILE_BYTES;
+            FQ_READ(sn, 0, r0w, r0x)
+        }
+        FQ_COMPUTE(r1w, r1x)
+    }
+#undef FQ_READ
+#undef FQ_COMPUTE
 
     // ---- epilogue: lane (h, c) of tile (tn, tm) holds n = n0 + wn*64 + tn*32 + 16 h + r (r = 0..15) of token
     //      m = m0 + wm*128 + tm*32 + c; products carry a factor 256 ----

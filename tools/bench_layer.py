@@ -19,8 +19,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import flatquant_amd.deploy as deploy  # noqa: E402
 
 MODELS = {
-    "llama-3-8b": dict(hidden=4096, ffn=14336, heads=32, head_dim=128),
-    "llama-2-70b": dict(hidden=8192, ffn=28672, heads=64, head_dim=128),
+    "llama-3-8b": dict(hidden=4096, ffn=14336, heads=32, head_dim=128, kv_heads=8),
+    "llama-2-70b": dict(hidden=8192, ffn=28672, heads=64, head_dim=128, kv_heads=8),
 }
 
 
@@ -95,6 +95,22 @@ def main():
     two = sum(timeit(fn, a.steps) for _, fn, _ in rows[3:])
     print(f"  {fused[0]}: {us:.1f} us ({T * fused[2] / us / 1e3:.0f} GB/s) instead of {two:.1f} us"
           f" -> layer total {total - two + us:.1f} us")
+
+    # the seven 4-bit linears that consume those packed activations (Linear4bit = INT4 GEMM + dequant epilogue)
+    kv = m["kv_heads"] * m["head_dim"]
+    lins = [("q_proj", m["hidden"], m["hidden"]), ("k_proj", m["hidden"], kv), ("v_proj", m["hidden"], kv),
+            ("o_proj", m["hidden"], m["hidden"]), ("up_proj", m["hidden"], m["ffn"]),
+            ("gate_proj", m["hidden"], m["ffn"]), ("down_proj", m["ffn"], m["hidden"])]
+    packed = {m["hidden"]: ln_trans(xs[0]), m["ffn"]: had(xf[0], quantizer=quant)}
+    gtot = 0.0
+    for name, k_in, n_out in lins:
+        lin = deploy.nn.Linear4bit(k_in, n_out).to(dev)
+        lin.weight_scales.fill_(0.01)
+        us = timeit(lambda: lin(packed[k_in]), max(a.steps // 5, 5), warm=3)
+        gtot += us
+        print(f"  {'Linear4bit ' + name:26s} {us:9.1f} us   {2.0 * T * k_in * n_out / us / 1e6:7.0f} TOP/s")
+        del lin
+    print(f"  {'seven linears':26s} {gtot:9.1f} us;  activation path + linears: {total - two + us + gtot:.1f} us per layer")
 
 
 if __name__ == "__main__":
