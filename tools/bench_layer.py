@@ -91,7 +91,7 @@ def main():
         total += us
         print(f"  {name:26s} {us:9.1f} us   {T * bpt / us / 1e3:7.0f} GB/s algorithmic")
     print(f"  {'layer total':26s} {total:9.1f} us   ({T / total:.1f} tokens/us through the activation path)")
-    us = timeit(fused[1], a.steps)
+    fused_us = us = timeit(fused[1], a.steps)
     two = sum(timeit(fn, a.steps) for _, fn, _ in rows[3:])
     print(f"  {fused[0]}: {us:.1f} us ({T * fused[2] / us / 1e3:.0f} GB/s) instead of {two:.1f} us"
           f" -> layer total {total - two + us:.1f} us")
@@ -110,7 +110,7 @@ def main():
         gtot += us
         print(f"  {'Linear4bit ' + name:26s} {us:9.1f} us   {2.0 * T * k_in * n_out / us / 1e6:7.0f} TOP/s")
         del lin
-    print(f"  {'seven linears':26s} {gtot:9.1f} us;  activation path + linears: {total - two + us + gtot:.1f} us per layer")
+    print(f"  {'seven linears':26s} {gtot:9.1f} us;  activation path + linears: {total - two + fused_us + gtot:.1f} us per layer")
 
 
 if __name__ == "__main__":
