@@ -217,3 +217,40 @@ def test_broadcast_and_row_sharding_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs), outs
+
+
+def test_oracle_int4_matmul_and_linear4bit():
+    """The integer restatement behind deploy.matmul / Linear4bit (gemm.cu:8-47, linear.py:41-56, quant.cu:66-85)."""
+    from oracle import fq_oracle as O
+    rng = np.random.RandomState(3)
+    xq, wq = rng.randint(-8, 8, (6, 96)), rng.randint(-8, 8, (5, 96))
+    xp, wp = O.pack_i4(xq), O.pack_i4(wq)
+    c = O.int4_matmul(xp, wp)
+    assert c.dtype == np.int32 and np.array_equal(c, xq @ wq.T)
+    sx = (rng.rand(6) * 0.1 + 0.01).astype(np.float16)
+    sw = (rng.rand(5) * 0.1 + 0.01).astype(np.float16)
+    b = rng.randn(5).astype(np.float16)
+    y = O.linear4bit(xp, sx, wp, sw, b)
+    assert y.dtype == np.float16 and y.shape == (6, 5)
+    # quant.cu:83-84 literally: half(int(q / 10)) * half(10), products in fp16 left to right, then the bias add
+    iv = np.trunc(c.astype(np.float32) / np.float32(10.0))
+    r = (sx.reshape(-1, 1).astype(np.float32) * sw.reshape(1, -1).astype(np.float32)).astype(np.float16)
+    r = (r.astype(np.float32) * iv.astype(np.float16).astype(np.float32)).astype(np.float16)
+    r = (r.astype(np.float32) * np.float32(10.0)).astype(np.float16)
+    r = (r.astype(np.float32) + b.reshape(1, -1).astype(np.float32)).astype(np.float16)
+    assert np.array_equal(y.view(np.uint16), r.view(np.uint16))
+
+
+def test_linear4bit_module_surface():
+    """Constructor, buffers and dtypes of deploy/nn/linear.py:22-39 (state dicts must load unchanged)."""
+    import flatquant_amd.deploy as deploy
+    lin = deploy.nn.Linear4bit(256, 64, bias=True)
+    sd = lin.state_dict()
+    assert set(sd) == {"weight_scales", "weight", "bias"}
+    assert sd["weight"].shape == (64, 128) and sd["weight"].dtype == torch.uint8
+    assert sd["weight_scales"].shape == (64, 1) and sd["bias"].shape == (64,) and sd["bias"].dtype == torch.float16
+    assert deploy.nn.Linear4bit(256, 64).bias is None
+    with pytest.raises(AssertionError):
+        lin(torch.zeros(2, 256))            # the reference asserts a PackedQuantizedTensor input (linear.py:45)
+    with pytest.raises(AssertionError):
+        deploy.matmul(torch.zeros(4, 24, dtype=torch.uint8), torch.zeros(4, 24, dtype=torch.uint8))   # K/2 % 32
