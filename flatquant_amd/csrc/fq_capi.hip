@@ -18,6 +18,7 @@ int fq_launch_hadamard_quant(const f16* x, int64_t rows, int n, int K, const f16
                              float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream);
 int fq_launch_gemm_i4(const uint8_t* X, const uint8_t* W, int64_t M, int N, int K, int32_t* c, f16* y, const f16* srow,
                       const f16* scol, const f16* bias, hipStream_t stream);
+int fq_launch_rmsnorm(const f16* x, f16* y, int64_t rows, int cols, float eps, int n_cu, hipStream_t stream);
 int64_t fq_kron_generic_workspace_bytes(int M, int N);
 int fq_launch_kron_prepare(const f16* left, const f16* right, int M, int N, void* workspace, hipStream_t stream);
 int fq_launch_block(int flags, const f16* x, const f16* P, int64_t rows, int R, int C, int transpose_out,
@@ -154,6 +155,35 @@ int fq_kron_quant_f16(const void* x, const void* left, const void* right, const 
         return fail(FQ_EINVAL, "fq_kron_quant_f16: workspace of %lld bytes required for M=%d N=%d (got %lld)",
                     (long long)fq_kron_generic_workspace_bytes(M, N), M, N, (long long)(workspace ? workspace_bytes : 0));
     return check_launch(rc, "fq_kron_quant_f16[generic]");
+}
+
+int fq_rmsnorm_kron_quant_f16(const void* x, float eps, const void* left, const void* right, int64_t rows, int M, int N,
+                              const float* sig_max, const float* sig_min, int n_clips, int flags,
+                              void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                              void* stream) {
+    if (rows < 0 || M <= 0 || N <= 0) return fail(FQ_EINVAL, "fq_rmsnorm_kron_quant_f16: bad sizes");
+    if (!(eps >= 0.0f)) return fail(FQ_EINVAL, "fq_rmsnorm_kron_quant_f16: eps must be >= 0");
+    if (M != 64 || N != 64) return fail(FQ_EUNSUPPORTED, "fq_rmsnorm_kron_quant_f16: only 64 x 64 factors are fused (got %d x %d)", M, N);
+    if (flags & (FQ_QUANT_F16 | FQ_OUT_FAKEQUANT)) return fail(FQ_EUNSUPPORTED, "fq_rmsnorm_kron_quant_f16: packed / transform outputs only");
+    FqQuantOut o;
+    int rc = fill_out("fq_rmsnorm_kron_quant_f16", o, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out, y_out);
+    if (rc != FQ_OK) return rc;
+    if (rows == 0) return FQ_OK;
+    if (!x || !left || !right) return fail(FQ_EINVAL, "fq_rmsnorm_kron_quant_f16: x/left/right is NULL");
+    o.rms_eps = eps;
+    rc = fq_launch_kron64(flags | FQ_IN_RMSNORM, (const f16*)x, (const f16*)left, (const f16*)right, nullptr, rows, o,
+                          cu_count(), (hipStream_t)stream);
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "fq_rmsnorm_kron_quant_f16: output set 0x%x has no fused kernel", flags);
+    return check_launch(rc, "fq_rmsnorm_kron_quant_f16");
+}
+
+int fq_rmsnorm_f16(const void* x, void* y, int64_t rows, int cols, float eps, void* stream) {
+    if (!x || !y) return fail(FQ_EINVAL, "fq_rmsnorm_f16: x/y is NULL");
+    if (rows < 0 || cols <= 0 || !(eps >= 0.0f)) return fail(FQ_EINVAL, "fq_rmsnorm_f16: bad arguments");
+    if (rows == 0) return FQ_OK;
+    const int rc = fq_launch_rmsnorm((const f16*)x, (f16*)y, rows, cols, eps, cu_count(), (hipStream_t)stream);
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "fq_rmsnorm_f16: cols=%d must be a multiple of 8 and <= 16384", cols);
+    return check_launch(rc, "fq_rmsnorm_f16");
 }
 
 int fq_kron_prepare_f16(const void* left, const void* right, int M, int N, void* workspace, int64_t workspace_bytes,

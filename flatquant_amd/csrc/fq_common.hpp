@@ -29,10 +29,11 @@ struct FqQuantOut {
     f16*     y;                    // transformed fp16, or nullptr
     int      n_clips;
     int      rt_flags;             // run-time flags: FQ_ROUND_Y_F16, FQ_NO_CLAMP0 (wave-uniform branches)
+    float    rms_eps;              // FQ_IN_RMSNORM: epsilon of the fused RMSNorm
 };
 
 // Flags that select a compile-time kernel specialisation; the rest travel in FqQuantOut::rt_flags.
-constexpr int FQ_CT_MASK = FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_QUANT_F16;
+constexpr int FQ_CT_MASK = FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_QUANT_F16 | FQ_IN_RMSNORM;
 
 // Wave64 all-reduce in registers: four DPP steps inside each 16-lane row, then v_permlane16_swap and
 // v_permlane32_swap (gfx950) across rows. ~6 VALU-latency steps instead of six ds_bpermute round trips
@@ -96,6 +97,18 @@ __device__ __forceinline__ float fq_wave_reduce(float v, Op op) {
     }
     return v;
 }
+struct FqAddOp {
+    __device__ __forceinline__ float operator()(float a, float b) const { return a + b; }
+    __device__ __forceinline__ float row(float v) const {
+        float r;
+        FQ_DPP_STEP("v_add_f32_dpp", "quad_perm:[1,0,3,2]")
+        FQ_DPP_STEP("v_add_f32_dpp", "quad_perm:[2,3,0,1]")
+        FQ_DPP_STEP("v_add_f32_dpp", "row_half_mirror")
+        FQ_DPP_STEP("v_add_f32_dpp", "row_mirror")
+        return v;
+    }
+};
+__device__ __forceinline__ float fq_wave_sum(float v) { return fq_wave_reduce(v, FqAddOp()); }  // every lane: the total
 __device__ __forceinline__ float fq_wave_max(float v) { return fq_wave_reduce(v, FqMaxOp()); }
 __device__ __forceinline__ float fq_wave_min(float v) { return fq_wave_reduce(v, FqMinOp()); }
 

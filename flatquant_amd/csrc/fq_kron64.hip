@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     static_assert(PULL_AT != 3 || (FLAGS & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)), "no statistics phase to pull behind");
     // output stores a single-clip packed token issues after its DMA (2 x 16 B + the scale): lets the top-of-loop
     // wait be a COUNTED vmcnt that does not also wait for the previous token's stores to reach memory.
-    constexpr bool COUNTED_WAIT = (FLAGS & FQ_CT_MASK) == FQ_OUT_PACKED;
+    constexpr bool COUNTED_WAIT = (FLAGS & FQ_CT_MASK & ~FQ_IN_RMSNORM) == FQ_OUT_PACKED;
     unsigned long long tr_wait = 0, tr_g1 = 0, tr_g2 = 0, tr_epi = 0;
     const unsigned long long tr_start = TRACE ? __builtin_amdgcn_s_memtime() : 0;
     const unsigned long long tr_start_rt = TRACE ? __builtin_amdgcn_s_memrealtime() : 0;  // 100 MHz, chip-wide
@@ -389,6 +389,31 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) X[mt][s] = tb[(mt * 32 + c) * 8 + ((h * 4 + s) ^ sw)];
+        }
+        if (FLAGS & FQ_IN_RMSNORM) {
+            // deploy.nn.RMSNorm in front of the transform (normalization.py:16-23): the wave's X fragments cover the
+            // token exactly once, so sum(x^2) is 64 fmas per lane (four chains) + a wave all-reduce; the normalised
+            // values are rounded to fp16 (the module returns fp16) before they enter GEMM 1.
+            float ss[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const f16x8 v = __builtin_bit_cast(f16x8, X[mt][s]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss[j & 3] = __builtin_fmaf((float)v[j], (float)v[j], ss[j & 3]);
+                }
+            const float tot = fq_wave_sum((ss[0] + ss[1]) + (ss[2] + ss[3]));
+            const float rinv = __builtin_amdgcn_rsqf(tot / (float)KD + out.rms_eps);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    f16x8 v = __builtin_bit_cast(f16x8, X[mt][s]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fq_mul_to_f16((float)v[j], rinv);
+                    X[mt][s] = __builtin_bit_cast(u32x4, v);
+                }
         }
         if (diag != nullptr) {  // x * diag_scale, rounded to fp16 (trans_utils.py:86-90)
             const uint4* dp = reinterpret_cast<const uint4*>(diag + lane_off);
@@ -706,6 +731,12 @@ int fq_launch_kron64(int flags, const f16* x, const f16* left, const f16* right,
         FQ_CASE(FQ_OUT_TRANSFORM | FQ_OUT_PACKED)
         FQ_CASE(FQ_OUT_TRANSFORM | FQ_OUT_FAKEQUANT)
         FQ_CASE(FQ_OUT_TRANSFORM | FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)
+        case FQ_OUT_PACKED | FQ_IN_RMSNORM:
+            return launch_kron64<FQ_OUT_PACKED | FQ_IN_RMSNORM>(x, left, right, diag, rows, out, n_cu, stream);
+        case FQ_OUT_TRANSFORM | FQ_IN_RMSNORM:
+            return launch_kron64<FQ_OUT_TRANSFORM | FQ_IN_RMSNORM>(x, left, right, diag, rows, out, n_cu, stream);
+        case FQ_OUT_TRANSFORM | FQ_OUT_PACKED | FQ_IN_RMSNORM:
+            return launch_kron64<FQ_OUT_TRANSFORM | FQ_OUT_PACKED | FQ_IN_RMSNORM>(x, left, right, diag, rows, out, n_cu, stream);
         case FQ_OUT_TRANSFORM:
         case FQ_OUT_TRANSFORM | FQ_QUANT_F16:
             return launch_kron64<FQ_OUT_TRANSFORM>(x, left, right, diag, rows, out, n_cu, stream);

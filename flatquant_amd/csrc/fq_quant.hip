@@ -238,6 +238,40 @@ __global__ __launch_bounds__(256) void fq_rowquant_wave_kernel(const f16* __rest
     }
 }
 
+// deploy.nn.RMSNorm alone (deploy/nn/normalization.py:16-23): a wave per row, the row in registers.
+template <int NCH>
+__global__ __launch_bounds__(256) void fq_rmsnorm_kernel(const f16* __restrict__ x, f16* __restrict__ y, int64_t rows,
+                                                         int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nchunks = cols >> 3;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nw) {
+        const u32x4* xp = reinterpret_cast<const u32x4*>(x + row * (int64_t)cols);
+        f16x8 v[NCH];
+        float ss[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + k * 64;
+            v[k] = (ch < nchunks) ? __builtin_bit_cast(f16x8, __builtin_nontemporal_load(xp + ch)) : f16x8{0};
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss[e & 3] = __builtin_fmaf((float)v[k][e], (float)v[k][e], ss[e & 3]);
+        const float tot = fq_wave_sum((ss[0] + ss[1]) + (ss[2] + ss[3]));
+        const float rinv = __builtin_amdgcn_rsqf(tot / (float)cols + eps);
+        uint4* yp = reinterpret_cast<uint4*>(y + row * (int64_t)cols);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + k * 64;
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fq_mul_to_f16((float)v[k][e], rinv);
+            if (ch < nchunks) yp[ch] = __builtin_bit_cast(uint4, o);
+        }
+    }
+}
+
 template <int FLAGS>
 int launch_rowquant(const f16* x, int64_t rows, int cols, const FqQuantOut& out, int n_cu,
                     hipStream_t stream) {
@@ -353,4 +387,20 @@ int fq_launch_probe_stream(const void* x, int64_t rows, void* q, void* s, int n_
     hipLaunchKernelGGL(fq_probe_stream_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const u32x4*)x,
                        rows, (u32x4*)q, (f16*)s);
     return (int)hipGetLastError();
+}
+
+int fq_launch_rmsnorm(const f16* x, f16* y, int64_t rows, int cols, float eps, int n_cu, hipStream_t stream) {
+    if ((cols & 7) || cols < 8 || cols > 16384) return -1000;
+    const int nchw = ((cols >> 3) + 63) / 64;
+    int64_t wb = (rows + 3) / 4;
+    if (wb > (int64_t)n_cu * 8) wb = (int64_t)n_cu * 8;
+    if (wb < 1) wb = 1;
+#define FQ_RN(N)                                                                                                     \
+    if (nchw <= (N)) {                                                                                               \
+        hipLaunchKernelGGL((fq_rmsnorm_kernel<(N)>), dim3((unsigned)wb), dim3(256), 0, stream, x, y, rows, cols, eps); \
+        return (int)hipGetLastError();                                                                               \
+    }
+    FQ_RN(4) FQ_RN(8) FQ_RN(16) FQ_RN(32)
+#undef FQ_RN
+    return -1000;
 }

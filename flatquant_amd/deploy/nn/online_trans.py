@@ -40,8 +40,10 @@ class OnlineTrans(torch.nn.Module):
         self.register_buffer("clip_factor_a_max", torch.tensor(1.0))
         self.register_buffer("clip_factor_a_min", torch.tensor(1.0))
 
-    def forward(self, x, quantizer=None):
-        """``quantizer`` (extension, optional): the deploy.nn.Quantizer that consumes this transform's output. For
+    def forward(self, x, quantizer=None, norm=None):
+        """``norm`` (extension, optional): the deploy.nn.RMSNorm whose output this transform consumes; pass its INPUT as
+        ``x`` and the normalisation runs inside the transform + quantisation launch (trans="matmul", decompose).
+        ``quantizer`` (extension, optional): the deploy.nn.Quantizer that consumes this transform's output. For
         trans="had" the two then run as ONE launch and a PackedQuantizedTensor comes back (the Quantizer passes packed
         inputs through, quantization.py:14), bit-identical to calling them one after the other."""
         if self.trans == "had":
@@ -57,6 +59,17 @@ class OnlineTrans(torch.nn.Module):
                 # runs its butterflies in fp32, so only the result is widened.
                 return functional.matmul_hadU_cuda(x.to(torch.float16), self.had_rem_dim, self.rem_dim).float()
             return functional.matmul_hadU_cuda(x, self.had_rem_dim, self.rem_dim)
+        if self.trans == "matmul" and norm is not None:
+            if not (self.decompose and hasattr(self, "left_matrix")):
+                raise RuntimeError("OnlineTrans: norm= is fused for the decomposed (Kronecker) transform only")
+            from ... import ops
+            from ..._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED
+            from .. import PackedQuantizedTensor
+            bsz, seq_len, _ = x.shape
+            sig = ops.sigmoid_pair(self.clip_factor_a_max, self.clip_factor_a_min)
+            o = ops.rmsnorm_kron_quant(x.contiguous(), float(norm.eps), self.left_matrix.contiguous(),
+                                       self.right_matrix.contiguous(), [sig], FQ_OUT_PACKED | FQ_NO_CLAMP0)
+            return PackedQuantizedTensor(o.q[0].reshape(bsz, seq_len, -1), o.scale[0].reshape(bsz, 1, seq_len))
         if self.trans == "matmul":
             invs = []
             if hasattr(self, "left_matrix"):

@@ -173,6 +173,42 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
     return o
 
 
+def rmsnorm(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """deploy.nn.RMSNorm (deploy/nn/normalization.py:16-23): fp16 in, fp16 out, no weight (fq_rmsnorm_f16)."""
+    _chk(x, "x")
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    y = torch.empty_like(x)
+    if rows == 0:
+        return y
+    with torch.cuda.device(x.device):
+        check(lib.fq_rmsnorm_f16(_ptr(x), _ptr(y), rows, cols, ctypes.c_float(eps), _stream(x)))
+    return y
+
+
+def rmsnorm_kron_quant(x: torch.Tensor, eps: float, left: torch.Tensor, right: torch.Tensor,
+                       sigs: Sequence[Sig] = ((1.0, 1.0),), flags: int = FQ_OUT_PACKED) -> FusedOutputs:
+    """RMSNorm + Kronecker transform + INT4 quantisation in one launch (fq_rmsnorm_kron_quant_f16) for the 64 x 64 factor
+    pair; any other pair runs rmsnorm() and kron_quant() one after the other (same arithmetic, one more round trip)."""
+    _chk(x, "x"), _chk(left, "left"), _chk(right, "right")
+    M, N = left.shape[0], right.shape[0]
+    if (M, N) != (64, 64) or (flags & (FQ_OUT_FAKEQUANT | FQ_QUANT_F16)):
+        return kron_quant(rmsnorm(x, eps), left, right, sigs, flags)
+    d = M * N
+    if x.shape[-1] != d:
+        raise ValueError(f"x.shape[-1]={x.shape[-1]} != {M}*{N}")
+    rows = x.numel() // d
+    smax, smin, n = _sig_arrays(sigs)
+    o = _alloc_outputs(x, rows, d, n, flags, x.shape[:-1] + (d // 2,), x.shape)
+    if rows == 0:
+        return o
+    with torch.cuda.device(x.device):
+        check(lib.fq_rmsnorm_kron_quant_f16(_ptr(x), ctypes.c_float(eps), _ptr(left), _ptr(right), rows, M, N, smax, smin,
+                                            n, flags, _ptr_array(o.q), _ptr_array(o.scale), _ptr_array(o.fq), _ptr(o.y),
+                                            _stream(x)))
+    return o
+
+
 def block_quant(x: torch.Tensor, P: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),),
                 flags: int = FQ_OUT_PACKED | FQ_NO_CLAMP0, transpose_out: bool = True) -> FusedOutputs:
     """x [..., R, C] @ P [C, C], quantised per [R, C] block (fq_block_quant_f16)."""

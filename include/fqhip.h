@@ -13,6 +13,7 @@
  *   fq_kron_quant_f16      deploy/kernels/kron_matmul.py:192-266 (kron_matmul) +
  *                          flatquant/flat_utils.py:6-17 (kronecker_matmul) +
  *                          flatquant/quant_utils.py:71-119 (ActivationQuantizer)
+ *   fq_rmsnorm_f16, fq_rmsnorm_kron_quant_f16   deploy/nn/normalization.py:4-23 (RMSNorm), alone / fused in front
  *   fq_block_quant_f16     deploy/kernels/block_matmul.py:231-311 (block_matmul)
  *   fq_int4_gemm_i32       deploy/kernels/gemm.cu:8-47 (matmul_host) / deploy.matmul
  *   fq_int4_linear_f16     deploy/nn/linear.py:41-56 (Linear4bit.forward = matmul + sym_dequant + bias)
@@ -54,6 +55,8 @@ extern "C" {
                                    fq_kron_prepare_f16: skip the re-pack launch (the matrices are constants of a
                                    deployed layer; the re-pack is ~5 us per call)                          */
 
+#define FQ_IN_RMSNORM     0x80  /* fq_rmsnorm_kron_quant_f16 only (set by it): x is RMS-normalised first */
+
 #define FQ_MAX_CLIPS 4
 
 /*
@@ -81,6 +84,22 @@ int fq_kron_quant_f16(const void* x, const void* left, const void* right, const 
                       const float* sig_max, const float* sig_min, int n_clips, int flags,
                       void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * deploy.nn.RMSNorm (deploy/nn/normalization.py:16-23; the weight is folded into the next layer) in front of the
+ * transform, in the same launch:  x <- fp16( fp32(x) * rsqrt( sum(x^2) / (M*N) + eps ) ),  then exactly
+ * fq_kron_quant_f16 on that. Saves writing and re-reading the normalised activation (4 bytes per element).
+ * The fp32 sum of squares is accumulated per lane and combined across the wave (an order of its own, like any other
+ * kernel's: results agree with the unfused sequence to the last fp32 bits of the variance, not bit for bit).
+ * Only the 64 x 64 factor pair (d = 4096) is fused; FQ_EUNSUPPORTED otherwise: run fq_rmsnorm_f16 first then.
+ */
+int fq_rmsnorm_kron_quant_f16(const void* x, float eps, const void* left, const void* right, int64_t rows, int M, int N,
+                              const float* sig_max, const float* sig_min, int n_clips, int flags,
+                              void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                              void* stream);
+
+/* deploy.nn.RMSNorm alone: y[r] = fp16( fp32(x[r]) * rsqrt( sum(x[r]^2) / cols + eps ) ), cols % 8 == 0, cols <= 16384. */
+int fq_rmsnorm_f16(const void* x, void* y, int64_t rows, int cols, float eps, void* stream);
 
 /* Bytes of device workspace fq_kron_quant_f16 needs for factor sizes (M, N); 0 when none is needed;
  * negative (FQ_EUNSUPPORTED) when no kernel handles the shape (needs N % 16 == 0, M <= 128, N <= 256). */

@@ -261,6 +261,15 @@ def sym_dequant(q32, scale_row16, scale_col16):
     return r
 
 
+def rmsnorm(x16, eps=1e-5):
+    """deploy/nn/normalization.py:16-23: fp32(x) * rsqrt(sum(x^2) / d + eps) -> fp16 (no weight). The fp32 sum uses
+    numpy's pairwise order; any kernel's order differs in the last bits of the variance (tests allow for that)."""
+    x = np.asarray(x16, dtype=F16).astype(F32)
+    var = (x * x).sum(axis=-1, keepdims=True, dtype=F32) / F32(x.shape[-1])
+    r = (F32(1.0) / np.sqrt(var + F32(eps))).astype(F32)
+    return (x * r).astype(F16)
+
+
 def int4_matmul(x_packed, w_packed):
     """deploy/kernels/gemm.cu:8-47 (CUTLASS int4b_t row-major x column-major -> int32): c[m][n] = sum_k x[m][k] w[n][k]
     on the nibbles of pack_i4's layout (even k in the low nibble, two's complement). Exact integer arithmetic."""

@@ -96,6 +96,12 @@ def main():
     print(f"  {fused[0]}: {us:.1f} us ({T * fused[2] / us / 1e3:.0f} GB/s) instead of {two:.1f} us"
           f" -> layer total {total - two + us:.1f} us")
 
+    # RMSNorm in front of ln_trans / up_gate_trans: separate launch vs fused into the transform launch
+    norm = deploy.nn.RMSNorm(m["hidden"])
+    sep = timeit(lambda: ln_trans(norm(nxt(xs))), a.steps)
+    fus = timeit(lambda: ln_trans(nxt(xs), norm=norm), a.steps)
+    print(f"  RMSNorm + ln_trans: {sep:.1f} us as two launches, {fus:.1f} us fused (OnlineTrans.forward(x, norm=...))")
+
     # the seven 4-bit linears that consume those packed activations (Linear4bit = INT4 GEMM + dequant epilogue)
     kv = m["kv_heads"] * m["head_dim"]
     lins = [("q_proj", m["hidden"], m["hidden"]), ("k_proj", m["hidden"], kv), ("v_proj", m["hidden"], kv),

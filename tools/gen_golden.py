@@ -283,8 +283,31 @@ def gen_pack():
     save("pack_roundtrip", q=grid.numpy(), packed=packed.numpy(), unpacked=unpack_i4(packed).numpy())
 
 
+def gen_rmsnorm():
+    """deploy.nn.RMSNorm alone (two widths, x scaled so rows differ in magnitude) and in front of path B (64 x 64)."""
+    from deploy.nn.normalization import RMSNorm as RefRMSNorm
+    arrays = {}
+    for d in (4096, 11008, 40):
+        x = (make_x(12, d, seed=40 + d % 7).float() * torch.logspace(-2, 1.5, 12)[:, None]).to(torch.float16)
+        for eps in (1e-5, 1e-6):
+            arrays[f"x_{d}"] = x.numpy()
+            arrays[f"y_{d}_eps{eps:g}"] = RefRMSNorm(d, eps)(x).numpy()
+    M = N = 64
+    bsz, seq = 2, 6
+    x = arrays["x_4096"]
+    L, R = make_mat(M, 41), make_mat(N, 42)
+    xn = RefRMSNorm(M * N, 1e-5)(torch.from_numpy(x))
+    qx, sx = path_b_kron(xn, L, R, 4.0, 3.0, bsz, seq)
+    arrays.update(L=L.numpy(), R=R.numpy(), sig=np.array([sig(4.0), sig(3.0)], dtype=np.float32), b_packed=qx, b_scale=sx)
+    save("rmsnorm", **arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "rmsnorm":
+        gen_rmsnorm()
+        sys.exit(0)
+    gen_rmsnorm()
     gen_decompose()
     gen_pack()
     gen_hadk_data()
