@@ -25,6 +25,7 @@ FQ_NO_CLAMP0 = 0x10
 FQ_QUANT_F16 = 0x20
 FQ_WS_PREPARED = 0x40
 FQ_IN_RMSNORM = 0x80
+FQ_IN_SILU_MUL = 0x100
 FQ_MAX_CLIPS = 4
 
 FQ_OK, FQ_EINVAL, FQ_EUNSUPPORTED, FQ_ELAUNCH = 0, -1, -2, -3
@@ -40,6 +41,10 @@ SYMBOLS = {
     "fq_kron_prepare_f16": (_i, [_vp, _vp, _i, _i, _vp, _i64, _vp]),
     "fq_rmsnorm_kron_quant_f16": (_i, [_vp, _f, _vp, _vp, _i64, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp]),
     "fq_rmsnorm_f16": (_i, [_vp, _vp, _i64, _i, _f, _vp]),
+    "fq_silu_mul_kron_quant_f16": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp,
+                                        _i64, _vp]),
+    "fq_silu_mul_f16": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "fq_silu_mul_hadamard_quant_f16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _f, _f, _f, _vp, _vp, _vp]),
     "fq_block_quant_f16": (_i, [_vp, _vp, _i64, _i, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp]),
     "fq_int4_gemm_i32": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "fq_int4_linear_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),

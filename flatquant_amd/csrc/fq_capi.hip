@@ -19,6 +19,9 @@ int fq_launch_hadamard_quant(const f16* x, int64_t rows, int n, int K, const f16
 int fq_launch_gemm_i4(const uint8_t* X, const uint8_t* W, int64_t M, int N, int K, int32_t* c, f16* y, const f16* srow,
                       const f16* scol, const f16* bias, hipStream_t stream);
 int fq_launch_rmsnorm(const f16* x, f16* y, int64_t rows, int cols, float eps, int n_cu, hipStream_t stream);
+int fq_launch_silu_mul(const f16* gate, const f16* up, f16* y, int64_t n, int n_cu, hipStream_t stream);
+int fq_launch_silu_hadamard_quant(const f16* gate, const f16* up, int64_t rows, int n, int K, const f16* hadK, float scale,
+                                  float sig_max, float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream);
 int64_t fq_kron_generic_workspace_bytes(int M, int N);
 int fq_launch_kron_prepare(const f16* left, const f16* right, int M, int N, void* workspace, hipStream_t stream);
 int fq_launch_block(int flags, const f16* x, const f16* P, int64_t rows, int R, int C, int transpose_out,
@@ -101,6 +104,8 @@ int fill_out(const char* what, FqQuantOut& o, const float* sig_max, const float*
         o.y = (f16*)y_out;
     }
     o.rt_flags = flags & (FQ_ROUND_Y_F16 | FQ_NO_CLAMP0);
+    o.rms_eps = 0.0f;
+    o.in2 = nullptr;
     return FQ_OK;
 }
 
@@ -175,6 +180,53 @@ int fq_rmsnorm_kron_quant_f16(const void* x, float eps, const void* left, const 
                           cu_count(), (hipStream_t)stream);
     if (rc == -1000) return fail(FQ_EUNSUPPORTED, "fq_rmsnorm_kron_quant_f16: output set 0x%x has no fused kernel", flags);
     return check_launch(rc, "fq_rmsnorm_kron_quant_f16");
+}
+
+int fq_silu_mul_kron_quant_f16(const void* gate, const void* up, const void* left, const void* right, int64_t rows,
+                               int M, int N, const float* sig_max, const float* sig_min, int n_clips, int flags,
+                               void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                               void* workspace, int64_t workspace_bytes, void* stream) {
+    if (rows < 0 || M <= 0 || N <= 0 || (N & 1)) return fail(FQ_EINVAL, "fq_silu_mul_kron_quant_f16: bad sizes rows=%lld M=%d N=%d", (long long)rows, M, N);
+    FqQuantOut o;
+    int rc = fill_out("fq_silu_mul_kron_quant_f16", o, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out, y_out);
+    if (rc != FQ_OK) return rc;
+    if (rows == 0) return FQ_OK;
+    if (!gate || !up || !left || !right) return fail(FQ_EINVAL, "fq_silu_mul_kron_quant_f16: gate/up/left/right is NULL");
+    o.in2 = (const f16*)up;
+    rc = fq_launch_kron_generic(flags | FQ_IN_SILU_MUL, (const f16*)gate, (const f16*)left, (const f16*)right, nullptr,
+                                rows, M, N, o, workspace, workspace_bytes, cu_count(), (hipStream_t)stream);
+    if (rc == -1001)
+        return fail(FQ_EINVAL, "fq_silu_mul_kron_quant_f16: workspace of %lld bytes required for M=%d N=%d (got %lld)",
+                    (long long)fq_kron_generic_workspace_bytes(M, N), M, N, (long long)(workspace ? workspace_bytes : 0));
+    if (rc == -1000)
+        return fail(FQ_EUNSUPPORTED, "fq_silu_mul_kron_quant_f16: no fused kernel for M=%d N=%d (use fq_silu_mul_f16 + fq_kron_quant_f16)", M, N);
+    return check_launch(rc, "fq_silu_mul_kron_quant_f16");
+}
+
+int fq_silu_mul_f16(const void* gate, const void* up, void* y, int64_t n, void* stream) {
+    if (n < 0) return fail(FQ_EINVAL, "fq_silu_mul_f16: n < 0");
+    if (n == 0) return FQ_OK;
+    if (!gate || !up || !y) return fail(FQ_EINVAL, "fq_silu_mul_f16: NULL pointer");
+    const int rc = fq_launch_silu_mul((const f16*)gate, (const f16*)up, (f16*)y, n, cu_count(), (hipStream_t)stream);
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "fq_silu_mul_f16: n=%lld must be a multiple of 8", (long long)n);
+    return check_launch(rc, "fq_silu_mul_f16");
+}
+
+int fq_silu_mul_hadamard_quant_f16(const void* gate, const void* up, int64_t rows, int n, int K, const void* hadK,
+                                   float scale, float sig_max, float sig_min, void* q_out, void* scale_out,
+                                   void* stream) {
+    if (!q_out || !scale_out) return fail(FQ_EINVAL, "fq_silu_mul_hadamard_quant_f16: NULL pointer");
+    if (rows < 0 || n <= 0 || K <= 0 || n % K) return fail(FQ_EINVAL, "fq_silu_mul_hadamard_quant_f16: bad sizes n=%d K=%d", n, K);
+    if (K > 1 && !hadK) return fail(FQ_EINVAL, "fq_silu_mul_hadamard_quant_f16: hadK is NULL with K=%d", K);
+    if (!(sig_max > 0.0f) || !(sig_min > 0.0f)) return fail(FQ_EINVAL, "fq_silu_mul_hadamard_quant_f16: sig_max/sig_min must be > 0");
+    if (rows == 0) return FQ_OK;
+    if (!gate || !up) return fail(FQ_EINVAL, "fq_silu_mul_hadamard_quant_f16: gate/up is NULL");
+    const int rc = fq_launch_silu_hadamard_quant((const f16*)gate, (const f16*)up, rows, n, K, (const f16*)hadK, scale,
+                                                 sig_max, sig_min, (uint8_t*)q_out, (f16*)scale_out, cu_count(),
+                                                 (hipStream_t)stream);
+    if (rc == -1000)
+        return fail(FQ_EUNSUPPORTED, "fq_silu_mul_hadamard_quant_f16: no fused kernel for n=%d K=%d", n, K);
+    return check_launch(rc, "fq_silu_mul_hadamard_quant_f16");
 }
 
 int fq_rmsnorm_f16(const void* x, void* y, int64_t rows, int cols, float eps, void* stream) {

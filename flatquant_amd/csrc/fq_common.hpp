@@ -30,6 +30,7 @@ struct FqQuantOut {
     int      n_clips;
     int      rt_flags;             // run-time flags: FQ_ROUND_Y_F16, FQ_NO_CLAMP0 (wave-uniform branches)
     float    rms_eps;              // FQ_IN_RMSNORM: epsilon of the fused RMSNorm
+    const f16* in2;                // FQ_IN_SILU_MUL: the `up` tensor (x is `gate`), same shape as x
 };
 
 // Flags that select a compile-time kernel specialisation; the rest travel in FqQuantOut::rt_flags.
@@ -165,6 +166,21 @@ __device__ __forceinline__ f16 fq_mul_to_f16(float a, float b) {
     float p = a * b;
     asm volatile("" : "+v"(p));
     return (f16)p;
+}
+
+// x_up * act_fn(x_gate) in front of a down_proj transform (deploy/transformers/modeling_llama.py:277-278, fp16 tensors):
+// ac = fp16( g / (1 + exp(-g)) ) evaluated in fp32 (torch's SiLU opmath), x = fp16(ac * up). v_exp_f32 / v_rcp_f32
+// are 1-ulp fp32 approximations: after the fp16 rounding a few results in 10^4 differ from a correctly rounded fp32
+// evaluation by one fp16 step (tests/test_gpu_silu.py states the bound).
+__device__ __forceinline__ f16x8 fq_silu_mul8(f16x8 g, f16x8 u) {
+    f16x8 a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float gf = (float)g[j];
+        const float e = __builtin_amdgcn_exp2f(gf * -1.44269504088896340736f);
+        a[j] = (f16)(gf * __builtin_amdgcn_rcpf(1.0f + e));
+    }
+    return a * u;
 }
 
 template <int FLAGS>

@@ -117,12 +117,18 @@ __device__ __forceinline__ void fwht_wave(float (&v)[CH][8], const XMask& k) {
             }
 }
 
-template <int CH>
-__device__ __forceinline__ void load_vec(const f16* __restrict__ p, int lane, float (&v)[CH][8]) {
+template <int CH, bool SILU = false>
+__device__ __forceinline__ void load_vec(const f16* __restrict__ p, const f16* __restrict__ p2, int lane, float (&v)[CH][8]) {
+    u32x4 r[CH], r2[SILU ? CH : 1];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-        const f16x8 hv = __builtin_bit_cast(
-            f16x8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + j * 512 + lane * 8)));
+        r[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + j * 512 + lane * 8));
+        if (SILU) r2[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p2 + j * 512 + lane * 8));
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        f16x8 hv = __builtin_bit_cast(f16x8, r[j]);
+        if (SILU) hv = fq_silu_mul8(hv, __builtin_bit_cast(f16x8, r2[SILU ? j : 0]));
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[j][e] = (float)hv[e];
     }
@@ -141,6 +147,7 @@ struct HadQuant {
     float sig_max, sig_min;
     uint8_t* q;   // [rows, n/2]
     f16* scale;   // [rows]
+    const f16* up;  // SILU kernels: x is `gate`, the transform's input is fp16(up * fp16(silu(gate))) (fq_silu_mul8)
 };
 __device__ __forceinline__ uint32_t quant8_h(f16x8 v, f16 s) {
     uint32_t d = 0;
@@ -157,7 +164,7 @@ __device__ __forceinline__ void minmax8(f16x8 v, float& mx, float& mn) {
 }
 
 // ---- K == 1: one wave per row ----
-template <int CH, bool QUANT>
+template <int CH, bool QUANT, bool SILU = false>
 __global__ __launch_bounds__(256) void fq_had_pow2_kernel(const f16* __restrict__ x, f16* __restrict__ y, int64_t rows,
                                                           float scale, HadQuant hq) {
     constexpr int n = 512 * CH;
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256) void fq_had_pow2_kernel(const f16* __restrict_
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
     for (int64_t row = wave_id; row < rows; row += n_waves) {
         float v[CH][8];
-        load_vec<CH>(x + row * n, lane, v);
+        load_vec<CH, SILU>(x + row * n, SILU ? hq.up + row * n : nullptr, lane, v);
         fwht_wave<CH>(v, k);
         f16x8 o[CH];
         to_f16<CH>(v, scale, o);
@@ -196,7 +203,7 @@ struct KmixGeom {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <int CH, bool QUANT>
+template <int CH, bool QUANT, bool SILU = false>
 __global__ __launch_bounds__(256) void fq_had_kmix_kernel(const f16* __restrict__ x, f16* __restrict__ y, int64_t rows,
                                                           KmixGeom g, const f16* __restrict__ hadK, float scale,
                                                           HadQuant hq) {
@@ -239,23 +246,33 @@ __global__ __launch_bounds__(256) void fq_had_kmix_kernel(const f16* __restrict_
     for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         const f16* xr = x + row * (int64_t)K * P;
         __syncthreads();  // the previous row's fragment reads are done
+        const f16* ur = SILU ? hq.up + row * (int64_t)K * P : nullptr;
         u32x4 raw[CH];  // the NEXT sub-vector's chunks are requested before the current one is transformed
+        u32x4 raw2[SILU ? CH : 1];
 #pragma unroll
-        for (int j = 0; j < CH; ++j)
+        for (int j = 0; j < CH; ++j) {
             raw[j] = wave < K ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xr + (int64_t)wave * P + j * 512 + lane * 8))
                               : u32x4{0, 0, 0, 0};
+            if (SILU)
+                raw2[j] = wave < K ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ur + (int64_t)wave * P + j * 512 + lane * 8))
+                                   : u32x4{0, 0, 0, 0};
+        }
         for (int k = wave; k < K; k += 4) {
             float v[CH][8];
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
-                const f16x8 hv = __builtin_bit_cast(f16x8, raw[j]);
+                f16x8 hv = __builtin_bit_cast(f16x8, raw[j]);
+                if (SILU) hv = fq_silu_mul8(hv, __builtin_bit_cast(f16x8, raw2[SILU ? j : 0]));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[j][e] = (float)hv[e];
             }
             if (k + 4 < K) {
 #pragma unroll
-                for (int j = 0; j < CH; ++j)
+                for (int j = 0; j < CH; ++j) {
                     raw[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xr + (int64_t)(k + 4) * P + j * 512 + lane * 8));
+                    if (SILU)
+                        raw2[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ur + (int64_t)(k + 4) * P + j * 512 + lane * 8));
+                }
             }
             fwht_wave<CH>(v, km);
             f16x8 o[CH];
@@ -344,17 +361,17 @@ __global__ __launch_bounds__(256) void fq_had_kmix_kernel(const f16* __restrict_
     }
 }
 
-template <int CH, bool QUANT>
+template <int CH, bool QUANT, bool SILU>
 int launch_pow2(const f16* x, f16* y, int64_t rows, float scale, const HadQuant& hq, int n_cu, hipStream_t stream) {
     int64_t blocks = (rows + 3) / 4;
     const int64_t cap = (int64_t)n_cu * (CH <= 8 ? 4 : 2);  // 16 / 8 waves per CU
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((fq_had_pow2_kernel<CH, QUANT>), dim3((unsigned)blocks), dim3(256), 0, stream, x, y, rows, scale, hq);
+    hipLaunchKernelGGL((fq_had_pow2_kernel<CH, QUANT, SILU>), dim3((unsigned)blocks), dim3(256), 0, stream, x, y, rows, scale, hq);
     return (int)hipGetLastError();
 }
 
-template <int CH, bool QUANT>
+template <int CH, bool QUANT, bool SILU>
 int launch_kmix(const f16* x, f16* y, int64_t rows, int K, const f16* hadK, float scale, const HadQuant& hq, int n_cu,
                 hipStream_t stream) {
     KmixGeom g;
@@ -364,7 +381,7 @@ int launch_kmix(const f16* x, f16* y, int64_t rows, int K, const f16* hadK, floa
     if (QUANT && g.KT > 2) return -1000;  // the fused form keeps a wave's tiles in registers (sized for KT <= 2)
     const size_t lds = (size_t)g.KP * (512 * CH + 8) * 2 + (size_t)(g.KP / 16) * g.KT * 1024 + 64;
     if (lds > 160 * 1024) return -1000;
-    auto kern = fq_had_kmix_kernel<CH, QUANT>;
+    auto kern = fq_had_kmix_kernel<CH, QUANT, SILU>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -380,24 +397,24 @@ int launch_kmix(const f16* x, f16* y, int64_t rows, int K, const f16* hadK, floa
     return (int)hipGetLastError();
 }
 
-template <bool QUANT>
+template <bool QUANT, bool SILU = false>
 int dispatch_reg(const f16* x, f16* y, int64_t rows, int n, int K, const f16* hadK, float scale, const HadQuant& hq,
                  int n_cu, hipStream_t stream) {
     if (K < 1 || n % K) return -1000;
     const int P = n / K;
     if (K == 1) {
         switch (P) {
-            case 512: return launch_pow2<1, QUANT>(x, y, rows, scale, hq, n_cu, stream);
-            case 1024: return launch_pow2<2, QUANT>(x, y, rows, scale, hq, n_cu, stream);
-            case 2048: return launch_pow2<4, QUANT>(x, y, rows, scale, hq, n_cu, stream);
-            case 4096: return launch_pow2<8, QUANT>(x, y, rows, scale, hq, n_cu, stream);
-            case 8192: return launch_pow2<16, QUANT>(x, y, rows, scale, hq, n_cu, stream);
+            case 512: return launch_pow2<1, QUANT, SILU>(x, y, rows, scale, hq, n_cu, stream);
+            case 1024: return launch_pow2<2, QUANT, SILU>(x, y, rows, scale, hq, n_cu, stream);
+            case 2048: return launch_pow2<4, QUANT, SILU>(x, y, rows, scale, hq, n_cu, stream);
+            case 4096: return launch_pow2<8, QUANT, SILU>(x, y, rows, scale, hq, n_cu, stream);
+            case 8192: return launch_pow2<16, QUANT, SILU>(x, y, rows, scale, hq, n_cu, stream);
             default: return -1000;
         }
     }
     if (K > 192) return -1000;
-    if (P == 512) return launch_kmix<1, QUANT>(x, y, rows, K, hadK, scale, hq, n_cu, stream);
-    if (P == 1024) return launch_kmix<2, QUANT>(x, y, rows, K, hadK, scale, hq, n_cu, stream);
+    if (P == 512) return launch_kmix<1, QUANT, SILU>(x, y, rows, K, hadK, scale, hq, n_cu, stream);
+    if (P == 1024) return launch_kmix<2, QUANT, SILU>(x, y, rows, K, hadK, scale, hq, n_cu, stream);
     return -1000;
 }
 
@@ -406,11 +423,18 @@ int dispatch_reg(const f16* x, f16* y, int64_t rows, int n, int K, const f16* ha
 // Returns -1000 for shapes this file does not cover (the caller falls back to fq_hadamard.hip).
 int fq_launch_hadamard_reg(const f16* x, f16* y, int64_t rows, int n, int K, const f16* hadK, float scale, int n_cu,
                            hipStream_t stream) {
-    return dispatch_reg<false>(x, y, rows, n, K, hadK, scale, HadQuant{1.0f, 1.0f, nullptr, nullptr}, n_cu, stream);
+    return dispatch_reg<false>(x, y, rows, n, K, hadK, scale, HadQuant{1.0f, 1.0f, nullptr, nullptr, nullptr}, n_cu, stream);
 }
 
 // Hadamard + deploy.nn.Quantizer in one launch (no fp16 round trip through HBM). -1000: shape not covered.
 int fq_launch_hadamard_quant(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max,
                              float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream) {
-    return dispatch_reg<true>(x, nullptr, rows, n, K, hadK, scale, HadQuant{sig_max, sig_min, q, scale_out}, n_cu, stream);
+    return dispatch_reg<true>(x, nullptr, rows, n, K, hadK, scale, HadQuant{sig_max, sig_min, q, scale_out, nullptr}, n_cu, stream);
+}
+
+// x_up * silu(x_gate) formed in registers in front of the same Hadamard + Quantizer launch.
+int fq_launch_silu_hadamard_quant(const f16* gate, const f16* up, int64_t rows, int n, int K, const f16* hadK, float scale,
+                                  float sig_max, float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream) {
+    return dispatch_reg<true, true>(gate, nullptr, rows, n, K, hadK, scale, HadQuant{sig_max, sig_min, q, scale_out, up},
+                                    n_cu, stream);
 }

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void fq_kron_generic_kernel(const f16* __restr
 // Barriers per token: stage written | statistics exchanged (= stage free) | output stage complete.
 // ---------------------------------------------------------------------------------------------------------------
 // OCC = workgroups per CU the register allocation must leave room for (waves per SIMD = OCC * WAVES / 4).
-template <int MT, int NT, int KS1, int WAVES, int OCC>
+template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false>
 __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fast_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
                                                            const f16* __restrict__ diag, int64_t rows, int M, int /*N*/,
                                                            FqQuantOut out, int flags) {
@@ -328,6 +328,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
         for (int s = 0; s < KS1; ++s) asm volatile("" : "+v"(RF[t][s]));
     // LDS slot of prefetch register k of this thread (chunk q = tid + 256 k of the token)
     u32x4 PF[NPF];
+    u32x4 PF2[SILU ? NPF : 1];  // FQ_IN_SILU_MUL: x is `gate`, out.in2 is `up`; x_up * silu(x_gate) is formed while staging
     int64_t tok = blockIdx.x;
     // Prefetch loads are inline asm with a hand-placed wait: left to hipcc, an s_waitcnt vmcnt(1) appeared in front of
     // GEMM 1's first MFMA, i.e. the loads that were meant to land during the multiplication were waited for before it.
@@ -339,6 +340,10 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
             int q_ = pf_q0 + THREADS * k;                                                                \
             q_ = q_ < n_chunks ? q_ : n_chunks - 1;                                                      \
             asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(PF[k]) : "v"(xp_ + q_) : "memory"); \
+            if (SILU) {                                                                                  \
+                const u32x4* up_ = reinterpret_cast<const u32x4*>(out.in2 + (tokidx) * d);               \
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(PF2[k]) : "v"(up_ + q_) : "memory"); \
+            }                                                                                            \
         }                                                                                                \
     }
     int pf_q0 = tid;
@@ -361,12 +366,19 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                 for (int k = 0; k < NPF; k += 4)
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(PF[k]), "+v"(PF[(k + 1) % NPF]), "+v"(PF[(k + 2) % NPF]), "+v"(PF[(k + 3) % NPF]));
             }
+            if (SILU) {
+#pragma unroll
+                for (int k = 0; k < NPF; ++k) asm volatile("" : "+v"(PF2[k]));  // arrived with the vmcnt(0) above
+            }
             const uint4* dp = reinterpret_cast<const uint4*>(diag);
 #pragma unroll
             for (int k = 0; k < NPF; ++k) {
                 const int q = q0 + THREADS * k;
                 if (q < n_chunks) {
                     uint4 v = __builtin_bit_cast(uint4, PF[k]);
+                    if (SILU)
+                        v = __builtin_bit_cast(uint4, fq_silu_mul8(__builtin_bit_cast(f16x8, PF[k]),
+                                                                   __builtin_bit_cast(f16x8, PF2[k])));
                     if (diag != nullptr)
                         v = __builtin_bit_cast(uint4, __builtin_bit_cast(f16x8, v) * __builtin_bit_cast(f16x8, dp[q]));
                     const int row = q / cpr, ch = q - row * cpr;
@@ -591,13 +603,13 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
     }
 }
 
-template <int MT, int NT, int KS1, int WAVES, int OCC>
+template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false>
 int launch_fast(int flags, const f16* x, const uint4* ws, const f16* diag, int64_t rows, int M, int N,
                 const FqQuantOut& out, int n_cu, hipStream_t stream) {
     constexpr int PITCH = (KS1 * 2) | 1;
     const size_t lds = (size_t)2 * MT * MT * 1024 + (size_t)MT * 32 * PITCH * 16 + (((size_t)M * N / 2 + 15) & ~(size_t)15) + 128;
     if (lds > 160 * 1024) return -1000;
-    auto kern = fq_kron_fast_kernel<MT, NT, KS1, WAVES, OCC>;
+    auto kern = fq_kron_fast_kernel<MT, NT, KS1, WAVES, OCC, SILU>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -661,6 +673,11 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream) {
     if ((N & 15) || M < 1 || M > 128 || N > 256 || ((M * N / 2) & 15)) return -1000;
+    if (flags & FQ_IN_SILU_MUL) {  // fused for the down_proj shapes only; said before any workspace complaint
+        const int mt = tiles32(M), nt = tiles32(N), ks = (N + 15) / 16;
+        if (!((mt == 4 && nt == 4 && ks == 8) || (mt == 3 && nt == 4 && ks == 8) || (mt == 4 && nt == 7 && ks == 14)))
+            return -1000;
+    }
     if (!workspace || workspace_bytes < fq_kron_generic_workspace_bytes(M, N)) return -1001;
     KronGeom g;
     g.M = M;
@@ -675,6 +692,16 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
         if (rc != 0) return rc;
     }
     flags &= ~FQ_WS_PREPARED;
+    if (flags & FQ_IN_SILU_MUL) {  // x_up * silu(x_gate) formed while the token is staged: the down_proj shapes (MT >= 3)
+        flags &= ~FQ_IN_SILU_MUL;
+        if (diag != nullptr || out.in2 == nullptr) return -1000;
+#define FQ_FS(MT_, NT_, KS1_, W_, OCC_)                                                                          \
+    if (MT == MT_ && NT == NT_ && g.KS1 == KS1_)                                                                \
+        return launch_fast<MT_, NT_, KS1_, W_, OCC_, true>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
+        FQ_FS(4, 4, 8, 4, 2) FQ_FS(3, 4, 8, 4, 2) FQ_FS(4, 7, 14, 8, 1)
+#undef FQ_FS
+        return -1000;
+    }
     if (!getenv("FQ_KRON_NO_WAVE")) {  // one wave per token where a token fits a wave (packed output only)
         rc = fq_launch_kron_wave(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;

@@ -389,6 +389,26 @@ int fq_launch_probe_stream(const void* x, int64_t rows, void* q, void* s, int n_
     return (int)hipGetLastError();
 }
 
+// x_up * act_fn(x_gate) alone (modeling_llama.py:277-278): 16 bytes per lane per tensor, grid-stride.
+__global__ __launch_bounds__(256) void fq_silu_mul_kernel(const f16* __restrict__ gate, const f16* __restrict__ up,
+                                                          f16* __restrict__ y, int64_t chunks) {
+    const int64_t step = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += step) {
+        const f16x8 g = __builtin_bit_cast(f16x8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(gate) + i));
+        const f16x8 u = __builtin_bit_cast(f16x8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(up) + i));
+        reinterpret_cast<uint4*>(y)[i] = __builtin_bit_cast(uint4, fq_silu_mul8(g, u));
+    }
+}
+
+int fq_launch_silu_mul(const f16* gate, const f16* up, f16* y, int64_t n, int n_cu, hipStream_t stream) {
+    if (n & 7) return -1000;
+    const int64_t chunks = n >> 3;
+    int64_t blocks = (chunks + 255) / 256;
+    if (blocks > (int64_t)n_cu * 16) blocks = (int64_t)n_cu * 16;
+    hipLaunchKernelGGL(fq_silu_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, gate, up, y, chunks);
+    return (int)hipGetLastError();
+}
+
 int fq_launch_rmsnorm(const f16* x, f16* y, int64_t rows, int cols, float eps, int n_cu, hipStream_t stream) {
     if ((cols & 7) || cols < 8 || cols > 16384) return -1000;
     const int nchw = ((cols >> 3) + 63) / 64;

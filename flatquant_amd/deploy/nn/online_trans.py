@@ -40,20 +40,29 @@ class OnlineTrans(torch.nn.Module):
         self.register_buffer("clip_factor_a_max", torch.tensor(1.0))
         self.register_buffer("clip_factor_a_min", torch.tensor(1.0))
 
-    def forward(self, x, quantizer=None, norm=None):
-        """``norm`` (extension, optional): the deploy.nn.RMSNorm whose output this transform consumes; pass its INPUT as
+    def forward(self, x, quantizer=None, norm=None, up=None):
+        """``up`` (extension, optional): ``x`` is then x_gate and the transform consumes x_up * silu(x_gate)
+        (FlatQuantLlamaMLP.forward, modeling_llama.py:277-279) formed inside the launch: trans="matmul" (decomposed)
+        returns the PackedQuantizedTensor as always, trans="had" needs ``quantizer`` as well.
+        ``norm`` (extension, optional): the deploy.nn.RMSNorm whose output this transform consumes; pass its INPUT as
         ``x`` and the normalisation runs inside the transform + quantisation launch (trans="matmul", decompose).
         ``quantizer`` (extension, optional): the deploy.nn.Quantizer that consumes this transform's output. For
         trans="had" the two then run as ONE launch and a PackedQuantizedTensor comes back (the Quantizer passes packed
         inputs through, quantization.py:14), bit-identical to calling them one after the other."""
+        if up is not None and norm is not None:
+            raise RuntimeError("OnlineTrans: up= and norm= are exclusive")
         if self.trans == "had":
             if quantizer is not None and getattr(quantizer, "lac", False) and not self.fp32_trans:
                 from ... import ops
                 from .. import PackedQuantizedTensor
                 sig = ops.sigmoid_pair(quantizer.clip_factor_a_max, quantizer.clip_factor_a_min)
-                q, s = ops.hadamard_quant(x.contiguous(), self.rem_dim, self.had_rem_dim, sig)
+                q, s = ops.hadamard_quant(x.contiguous(), self.rem_dim, self.had_rem_dim, sig,
+                                          up=None if up is None else up.contiguous())
                 lead = x.shape[:-1]
                 return PackedQuantizedTensor(q, s.reshape(*lead, 1) if len(lead) > 1 else s.reshape(-1, 1))
+            if up is not None:
+                from ... import ops
+                x = ops.silu_mul(x.contiguous(), up.contiguous())
             if self.fp32_trans:
                 # the reference up-casts and returns fp32 (online_trans.py:56-59); the HIP kernel already
                 # runs its butterflies in fp32, so only the result is widened.
@@ -70,6 +79,18 @@ class OnlineTrans(torch.nn.Module):
             o = ops.rmsnorm_kron_quant(x.contiguous(), float(norm.eps), self.left_matrix.contiguous(),
                                        self.right_matrix.contiguous(), [sig], FQ_OUT_PACKED | FQ_NO_CLAMP0)
             return PackedQuantizedTensor(o.q[0].reshape(bsz, seq_len, -1), o.scale[0].reshape(bsz, 1, seq_len))
+        if self.trans == "matmul" and up is not None:
+            from ... import ops
+            if not (self.decompose and hasattr(self, "left_matrix") and hasattr(self, "right_matrix")):
+                x, up = ops.silu_mul(x.contiguous(), up.contiguous()), None
+            else:
+                from ..._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED
+                from .. import PackedQuantizedTensor
+                bsz, seq_len, _ = x.shape
+                sig = ops.sigmoid_pair(self.clip_factor_a_max, self.clip_factor_a_min)
+                o = ops.silu_mul_kron_quant(x.contiguous(), up.contiguous(), self.left_matrix.contiguous(),
+                                            self.right_matrix.contiguous(), [sig], FQ_OUT_PACKED | FQ_NO_CLAMP0)
+                return PackedQuantizedTensor(o.q[0].reshape(bsz, seq_len, -1), o.scale[0].reshape(bsz, 1, seq_len))
         if self.trans == "matmul":
             invs = []
             if hasattr(self, "left_matrix"):

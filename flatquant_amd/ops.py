@@ -209,6 +209,51 @@ def rmsnorm_kron_quant(x: torch.Tensor, eps: float, left: torch.Tensor, right: t
     return o
 
 
+def silu_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """x_up * act_fn(x_gate) with act_fn = SiLU on fp16 tensors (modeling_llama.py:277-278), one launch."""
+    _chk(gate, "gate"), _chk(up, "up")
+    if gate.shape != up.shape:
+        raise ValueError("gate and up must have the same shape")
+    y = torch.empty_like(gate)
+    if gate.numel() == 0:
+        return y
+    with torch.cuda.device(gate.device):
+        check(lib.fq_silu_mul_f16(_ptr(gate), _ptr(up), _ptr(y), gate.numel(), _stream(gate)))
+    return y
+
+
+def silu_mul_kron_quant(gate: torch.Tensor, up: torch.Tensor, left: torch.Tensor, right: torch.Tensor,
+                        sigs: Sequence[Sig] = ((1.0, 1.0),), flags: int = FQ_OUT_PACKED) -> FusedOutputs:
+    """kron_quant(up * silu(gate), ...) with the product formed inside the transform launch
+    (fq_silu_mul_kron_quant_f16, factor pairs with M > 64); other pairs run silu_mul() + kron_quant()."""
+    _chk(gate, "gate"), _chk(up, "up"), _chk(left, "left"), _chk(right, "right")
+    if gate.shape != up.shape:
+        raise ValueError("gate and up must have the same shape")
+    M, N = left.shape[0], right.shape[0]
+    if left.shape != (M, M) or right.shape != (N, N):
+        raise ValueError("left/right must be square")
+    d = M * N
+    if gate.shape[-1] != d:
+        raise ValueError(f"gate.shape[-1]={gate.shape[-1]} != {M}*{N}")
+    rows = gate.numel() // d
+    smax, smin, n = _sig_arrays(sigs)
+    o = _alloc_outputs(gate, rows, d, n, flags, gate.shape[:-1] + (d // 2,), gate.shape)
+    if rows == 0:
+        return o
+    with torch.cuda.device(gate.device):
+        ws, ws_bytes, prepared, key = _kron_workspace(gate.device, M, N, left, right)
+        rc = lib.fq_silu_mul_kron_quant_f16(_ptr(gate), _ptr(up), _ptr(left), _ptr(right), rows, M, N, smax, smin, n,
+                                            flags | (FQ_WS_PREPARED if prepared else 0), _ptr_array(o.q),
+                                            _ptr_array(o.scale), _ptr_array(o.fq), _ptr(o.y), _ptr(ws), ws_bytes,
+                                            _stream(gate))
+        if rc == _lib.FQ_EUNSUPPORTED:
+            return kron_quant(silu_mul(gate, up), left, right, sigs, flags)
+        check(rc)
+        if key is not None and not prepared:
+            _kron_workspace_commit(key, ws, left, right)
+    return o
+
+
 def block_quant(x: torch.Tensor, P: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),),
                 flags: int = FQ_OUT_PACKED | FQ_NO_CLAMP0, transpose_out: bool = True) -> FusedOutputs:
     """x [..., R, C] @ P [C, C], quantised per [R, C] block (fq_block_quant_f16)."""
@@ -268,11 +313,16 @@ def hadamard(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None,
 
 
 def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None, sig: Sig = (1.0, 1.0),
-                   scale: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                   scale: Optional[float] = None, up: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Hadamard rotation fused with the deploy Quantizer (fq_hadamard_quant_f16): -> (q uint8 [..., n/2], scales fp16
     [rows]). Bit-identical to rowquant(hadamard(x), [sig], FQ_OUT_PACKED | FQ_QUANT_F16); shapes the fused kernels do
-    not cover take exactly that two-launch route."""
+    not cover take exactly that two-launch route. With ``up``: x is x_gate and the input of the rotation is
+    up * silu(x), formed in registers (fq_silu_mul_hadamard_quant_f16)."""
     _chk(x, "x")
+    if up is not None:
+        _chk(up, "up")
+        if up.shape != x.shape:
+            raise ValueError("up must have x's shape")
     n = x.shape[-1]
     if K > 1:
         if hadK is None:
@@ -288,9 +338,16 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
     if rows == 0:
         return q, s
     with torch.cuda.device(x.device):
-        rc = lib.fq_hadamard_quant_f16(_ptr(x), rows, n, K, _ptr(hadK), ctypes.c_float(scale), ctypes.c_float(sig[0]),
-                                       ctypes.c_float(sig[1]), _ptr(q), _ptr(s), _stream(x))
+        if up is not None:
+            rc = lib.fq_silu_mul_hadamard_quant_f16(_ptr(x), _ptr(up), rows, n, K, _ptr(hadK), ctypes.c_float(scale),
+                                                    ctypes.c_float(sig[0]), ctypes.c_float(sig[1]), _ptr(q), _ptr(s),
+                                                    _stream(x))
+        else:
+            rc = lib.fq_hadamard_quant_f16(_ptr(x), rows, n, K, _ptr(hadK), ctypes.c_float(scale), ctypes.c_float(sig[0]),
+                                           ctypes.c_float(sig[1]), _ptr(q), _ptr(s), _stream(x))
     if rc == _lib.FQ_EUNSUPPORTED:
+        if up is not None:
+            x = silu_mul(x, up)
         o = rowquant(hadamard(x, K, hadK, scale), [sig], FQ_OUT_PACKED | FQ_QUANT_F16)
         return o.q[0], o.scale[0].reshape(-1)
     check(rc)

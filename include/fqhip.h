@@ -14,6 +14,8 @@
  *                          flatquant/flat_utils.py:6-17 (kronecker_matmul) +
  *                          flatquant/quant_utils.py:71-119 (ActivationQuantizer)
  *   fq_rmsnorm_f16, fq_rmsnorm_kron_quant_f16   deploy/nn/normalization.py:4-23 (RMSNorm), alone / fused in front
+ *   fq_silu_mul_f16, fq_silu_mul_kron_quant_f16, fq_silu_mul_hadamard_quant_f16
+ *                          deploy/transformers/modeling_llama.py:277-279 (x_up * act_fn(x_gate) -> down_proj), alone / fused
  *   fq_block_quant_f16     deploy/kernels/block_matmul.py:231-311 (block_matmul)
  *   fq_int4_gemm_i32       deploy/kernels/gemm.cu:8-47 (matmul_host) / deploy.matmul
  *   fq_int4_linear_f16     deploy/nn/linear.py:41-56 (Linear4bit.forward = matmul + sym_dequant + bias)
@@ -56,6 +58,8 @@ extern "C" {
                                    deployed layer; the re-pack is ~5 us per call)                          */
 
 #define FQ_IN_RMSNORM     0x80  /* fq_rmsnorm_kron_quant_f16 only (set by it): x is RMS-normalised first */
+
+#define FQ_IN_SILU_MUL    0x100 /* fq_silu_mul_* entry points only (set by them): x = fp16(up * fp16(silu(gate))) */
 
 #define FQ_MAX_CLIPS 4
 
@@ -100,6 +104,23 @@ int fq_rmsnorm_kron_quant_f16(const void* x, float eps, const void* left, const 
 
 /* deploy.nn.RMSNorm alone: y[r] = fp16( fp32(x[r]) * rsqrt( sum(x[r]^2) / cols + eps ) ), cols % 8 == 0, cols <= 16384. */
 int fq_rmsnorm_f16(const void* x, void* y, int64_t rows, int cols, float eps, void* stream);
+
+/*
+ * x_up * act_fn(x_gate) (deploy/transformers/modeling_llama.py:277-278, act_fn = SiLU, fp16 tensors) in front of the
+ * down_proj transform, in the same launch: the product is formed while a token is staged and never goes to HBM
+ * (the eager sequence moves 10 bytes per element before the transform reads its 2).
+ *   ac = fp16( g / (1 + exp(-g)) ) with g = fp32(gate);  x = fp16(ac * up);  then exactly fq_kron_quant_f16(x, ...).
+ * Fused for the factor pairs with M > 64 (ffn widths: 112x128, 86..96x128, 128x224); FQ_EUNSUPPORTED otherwise:
+ * run fq_silu_mul_f16 first then. Other arguments as fq_kron_quant_f16 (no diag).
+ */
+int fq_silu_mul_kron_quant_f16(const void* gate, const void* up, const void* left, const void* right,
+                               int64_t rows, int M, int N,
+                               const float* sig_max, const float* sig_min, int n_clips, int flags,
+                               void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+
+/* y = fp16(up * fp16(silu(gate))) element-wise over n fp16 values (n % 8 == 0). */
+int fq_silu_mul_f16(const void* gate, const void* up, void* y, int64_t n, void* stream);
 
 /* Bytes of device workspace fq_kron_quant_f16 needs for factor sizes (M, N); 0 when none is needed;
  * negative (FQ_EUNSUPPORTED) when no kernel handles the shape (needs N % 16 == 0, M <= 128, N <= 256). */
@@ -162,6 +183,11 @@ int fq_hadamard_f16(const void* x, void* y, int64_t rows, int n, int K, const vo
  */
 int fq_hadamard_quant_f16(const void* x, int64_t rows, int n, int K, const void* hadK, float scale,
                           float sig_max, float sig_min, void* q_out, void* scale_out, void* stream);
+
+/* fq_hadamard_quant_f16 on x = fp16(up * fp16(silu(gate))) formed in registers (see fq_silu_mul_kron_quant_f16). */
+int fq_silu_mul_hadamard_quant_f16(const void* gate, const void* up, int64_t rows, int n, int K, const void* hadK,
+                                   float scale, float sig_max, float sig_min, void* q_out, void* scale_out,
+                                   void* stream);
 
 /*
  * Per-token scale + INT4 quantisation of an fp16 matrix (Quantizer.forward / ActivationQuantizer).

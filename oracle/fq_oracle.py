@@ -261,6 +261,15 @@ def sym_dequant(q32, scale_row16, scale_col16):
     return r
 
 
+def silu_mul(gate16, up16):
+    """deploy/transformers/modeling_llama.py:277-278 on fp16 tensors: ac = act_fn(x_gate) (SiLU: fp32 g / (1 + exp(-g)),
+    rounded to fp16), x = x_up * ac (fp16 product = exact product rounded once)."""
+    g = np.asarray(gate16, dtype=F16).astype(F32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        ac = (g / (F32(1.0) + np.exp(-g, dtype=F32))).astype(F16)
+    return (np.asarray(up16, dtype=F16).astype(F32) * ac.astype(F32)).astype(F16)
+
+
 def rmsnorm(x16, eps=1e-5):
     """deploy/nn/normalization.py:16-23: fp32(x) * rsqrt(sum(x^2) / d + eps) -> fp16 (no weight). The fp32 sum uses
     numpy's pairwise order; any kernel's order differs in the last bits of the variance (tests allow for that)."""

@@ -254,3 +254,22 @@ def test_linear4bit_module_surface():
         lin(torch.zeros(2, 256))            # the reference asserts a PackedQuantizedTensor input (linear.py:45)
     with pytest.raises(AssertionError):
         deploy.matmul(torch.zeros(4, 24, dtype=torch.uint8), torch.zeros(4, 24, dtype=torch.uint8))   # K/2 % 32
+
+
+def test_oracle_silu_mul_and_rmsnorm_vs_reference_goldens(golden):
+    """oracle restatements of deploy.nn.RMSNorm and x_up * SiLU(x_gate) against outputs of the reference modules."""
+    import numpy as np
+    from oracle import fq_oracle as O
+    g = golden("rmsnorm")
+    for d in (4096, 11008, 40):
+        for eps in (1e-5, 1e-6):
+            assert np.array_equal(O.rmsnorm(g[f"x_{d}"], eps), g[f"y_{d}_eps{eps:g}"])
+    g = golden("silu_mul")
+    y, ref = O.silu_mul(g["gate"], g["up"]), g["x"]
+    ok = np.isfinite(ref.astype(np.float32))
+    ka = y.view(np.uint16).astype(np.int32)
+    kb = ref.view(np.uint16).astype(np.int32)
+    ka, kb = np.where(ka & 0x8000, -(ka & 0x7FFF), ka), np.where(kb & 0x8000, -(kb & 0x7FFF), kb)
+    st = np.abs(ka - kb)[ok]
+    # numpy's expf vs torch's: one fp16 step in SiLU on ~2e-4 of the elements, which the product can stretch to two
+    assert st.max() <= 2 and np.mean(st != 0) <= 1e-3

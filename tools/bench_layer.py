@@ -102,6 +102,19 @@ def main():
     fus = timeit(lambda: ln_trans(nxt(xs), norm=norm), a.steps)
     print(f"  RMSNorm + ln_trans: {sep:.1f} us as two launches, {fus:.1f} us fused (OnlineTrans.forward(x, norm=...))")
 
+    # x_up * silu(x_gate) in front of the down_proj transform: eager torch, one HIP launch, fused into the transform
+    from flatquant_amd import ops
+    gates, ups = xf, [act(a.bsz, a.seq, m["ffn"]) for _ in range(2)]
+    eager = timeit(lambda: torch.nn.functional.silu(nxt(gates)) * ups[0], a.steps)
+    alone = timeit(lambda: ops.silu_mul(nxt(gates), ups[0]), a.steps)
+    hq = timeit(lambda: had(nxt(gates), quantizer=quant, up=ups[0]), a.steps)
+    down_mm = trans(m["ffn"])
+    mm = timeit(lambda: down_mm(nxt(xf)), a.steps)
+    mmf = timeit(lambda: down_mm(nxt(gates), up=ups[0]), a.steps)
+    print(f"  SiLU.mul: torch eager {eager:.1f} us, fq_silu_mul_f16 {alone:.1f} us")
+    print(f"  down_proj input, Hadamard + Quantizer: {fused_us:.1f} us -> with SiLU.mul inside {hq:.1f} us")
+    print(f"  down_proj input, FlatQuant matmul transform ({m['ffn']}): {mm:.1f} us -> with SiLU.mul inside {mmf:.1f} us")
+
     # the seven 4-bit linears that consume those packed activations (Linear4bit = INT4 GEMM + dequant epilogue)
     kv = m["kv_heads"] * m["head_dim"]
     lins = [("q_proj", m["hidden"], m["hidden"]), ("k_proj", m["hidden"], kv), ("v_proj", m["hidden"], kv),

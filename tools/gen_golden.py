@@ -302,8 +302,27 @@ def gen_rmsnorm():
     save("rmsnorm", **arrays)
 
 
+def gen_silu_mul():
+    """x_up * act_fn(x_gate) as FlatQuantLlamaMLP.forward runs it (transformers' ACT2FN["silu"], fp16 CPU tensors)."""
+    from transformers.activations import ACT2FN
+    act = ACT2FN["silu"]
+    g = torch.Generator().manual_seed(77)
+    gate = (torch.randn(6, 14336, generator=g) * 3.0).to(torch.float16)
+    up = (torch.randn(6, 14336, generator=g) * 2.0).to(torch.float16)
+    gate[0, :40] = torch.linspace(-30, 30, 40).to(torch.float16)        # saturating tails
+    gate[1, :8] = torch.tensor([0.0, -0.0, 65504.0, -65504.0, 6e-8, -6e-8, 11.0, -11.0]).to(torch.float16)
+    with torch.no_grad():
+        ac = act(gate)
+        x = up * ac
+    save("silu_mul", gate=gate.numpy(), up=up.numpy(), ac=ac.numpy(), x=x.numpy())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "silu":
+        gen_silu_mul()
+        sys.exit(0)
+    gen_silu_mul()
     if len(sys.argv) > 1 and sys.argv[1] == "rmsnorm":
         gen_rmsnorm()
         sys.exit(0)
