@@ -317,8 +317,62 @@ def gen_silu_mul():
     save("silu_mul", gate=gate.numpy(), up=up.numpy(), ac=ac.numpy(), x=x.numpy())
 
 
+def gen_checkpoint():
+    """The reference's export flow on a tiny random Llama (CPU): apply FlatQuant -> seeded 'calibrated' parameters ->
+    save_flat_matrices -> reparameterize_model -> RTN weight quantisation -> save_quantized_weights_with_safetensors.
+    Writes the two wire formats (flat_matrices.pth, model.safetensors + quantization_config.json) as fixtures under
+    tests/golden/ckpt/, and ckpt_io.npz: inputs/outputs of the reference's own (fake-quant, fp32) MLP block and q/k/v
+    projections on that exported model. The reference moves tensors with .cuda() in its constructors; this harness
+    makes that a no-op for the duration (no reference file is touched)."""
+    import shutil
+    from transformers import LlamaConfig, LlamaForCausalLM
+    import gptq_utils
+    from flatquant import flat_utils as ref_fu
+    from flatquant.model_tools.llama_utils import apply_flatquant_to_llama
+    saved = (torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.empty_cache)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.cuda.empty_cache = lambda: None
+    try:
+        cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                          num_key_value_heads=2, vocab_size=64, max_position_embeddings=64)
+        cfg._attn_implementation = "eager"
+        torch.manual_seed(0)
+        model = LlamaForCausalLM(cfg)
+        out_dir = os.path.join(OUT, "ckpt")
+        shutil.rmtree(out_dir, ignore_errors=True)
+        os.makedirs(out_dir)
+        args = types.SimpleNamespace(
+            w_bits=4, a_bits=4, q_bits=16, k_bits=4, v_bits=4, lac=True, lwc=True, direct_inv=False, add_diag=True,
+            diag_init="sq_style", separate_vtrans=False, q_asym=False, k_asym=True, v_asym=True, a_groupsize=-1,
+            w_groupsize=-1, a_asym=False, w_asym=False, k_groupsize=128, v_groupsize=128, exp_dir=out_dir,
+            model="tiny-random-llama", gptq_mse=False)
+        model = apply_flatquant_to_llama(args, model)
+        g = torch.Generator().manual_seed(1)
+        for n, p in model.named_parameters():
+            if "trans." in n or "clip_factor" in n:
+                p.data.add_(torch.randn(p.shape, generator=g) * 0.05)
+        ref_fu.save_flat_matrices(args, model)
+        ref_fu.reparameterize_model(model)
+        quantizers = gptq_utils.rtn_fwrd(model, "cpu", args)
+        ref_fu.save_quantized_weights_with_safetensors(args, model, quantizers)
+        layer = model.model.layers[0]
+        x = (torch.randn(2, 8, 256, generator=g) * 1.5).to(torch.float16)
+        with torch.no_grad():
+            mlp_out = layer.mlp(x.float())
+            q, k, v = layer.self_attn._trans_forward_after_ln(x.float())
+        save("ckpt_io", x=x.numpy(), mlp_out=mlp_out.numpy(), q=q.numpy(), k=k.numpy(), v=v.numpy())
+        print(sorted(os.listdir(out_dir)), sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir)))
+    finally:
+        torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.empty_cache = saved
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "ckpt":
+        gen_checkpoint()
+        sys.exit(0)
+    gen_checkpoint()
     if len(sys.argv) > 1 and sys.argv[1] == "silu":
         gen_silu_mul()
         sys.exit(0)
