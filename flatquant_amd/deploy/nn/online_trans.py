@@ -99,3 +99,32 @@ class OnlineTrans(torch.nn.Module):
                 invs.append(self.right_matrix)
             return functional.online_trans.kronecker_matmul(x, invs, self.clip_factor_a_max, self.clip_factor_a_min)
         return x
+
+
+def fused_forward(x, transforms, norm=None):
+    """Several decomposed ``OnlineTrans`` modules that share one Kronecker factor pair and differ only in their clip
+    factors — inp_trans_q / inp_trans_k / inp_trans_v, inp_trans_u / inp_trans_g after the reference's loader handed
+    them the attention's / MLP's matrices (modeling_llama.py:518-529) — applied to the same ``x`` in ONE launch:
+    the token is read and transformed once and quantised once per clip pair (the reference runs the whole transform
+    per projection, modeling_llama.py:66-77, 270-271). ``norm``: see ``OnlineTrans.forward``.
+    Returns one PackedQuantizedTensor per module, each bit-identical to ``t(x)``."""
+    from ... import ops
+    from ..._lib import FQ_MAX_CLIPS, FQ_NO_CLAMP0, FQ_OUT_PACKED
+    from .. import PackedQuantizedTensor
+    first = transforms[0]
+    if not 1 <= len(transforms) <= FQ_MAX_CLIPS:
+        raise ValueError(f"fused_forward: 1..{FQ_MAX_CLIPS} transforms")
+    for t in transforms:
+        if not (t.trans == "matmul" and t.decompose and hasattr(t, "left_matrix") and hasattr(t, "right_matrix")):
+            raise RuntimeError("fused_forward: decomposed matmul transforms only")
+        if t.left_matrix.data_ptr() != first.left_matrix.data_ptr() or t.right_matrix.data_ptr() != first.right_matrix.data_ptr():
+            raise RuntimeError("fused_forward: the transforms must share their left/right matrices")
+    bsz, seq_len, _ = x.shape
+    sigs = [ops.sigmoid_pair(t.clip_factor_a_max, t.clip_factor_a_min) for t in transforms]
+    left, right = first.left_matrix.contiguous(), first.right_matrix.contiguous()
+    if norm is not None:
+        o = ops.rmsnorm_kron_quant(x.contiguous(), float(norm.eps), left, right, sigs, FQ_OUT_PACKED | FQ_NO_CLAMP0)
+    else:
+        o = ops.kron_quant(x.contiguous(), left, right, sigs, FQ_OUT_PACKED | FQ_NO_CLAMP0)
+    return [PackedQuantizedTensor(o.q[i].reshape(bsz, seq_len, -1), o.scale[i].reshape(bsz, 1, seq_len))
+            for i in range(len(transforms))]

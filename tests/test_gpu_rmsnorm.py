@@ -136,3 +136,29 @@ def test_fallback_shapes_and_errors(ops, golden):
     g = golden("kron_A_64x64")
     with pytest.raises(Exception):
         ops.kron_quant(dev(g["x"]), dev(g["L"]), dev(g["R"]), [(1.0, 1.0)], P | FQ_IN_RMSNORM)
+
+
+def test_fused_forward_shared_factors(ops, golden):
+    """q/k/v (and up/gate) transforms share the factor pair: one launch, each output == the module's own forward."""
+    import flatquant_amd.deploy as deploy
+    g = golden("rmsnorm")
+    ts = [deploy.nn.OnlineTrans(4096, trans="matmul", decompose=True, lac=True).cuda() for _ in range(3)]
+    L, R = dev(g["L"]), dev(g["R"])
+    for i, t in enumerate(ts):
+        for name, m in (("left_matrix", L), ("right_matrix", R)):
+            del t._buffers[name]
+            t.register_buffer(name, m)
+        t.clip_factor_a_max.fill_(4.0 - i), t.clip_factor_a_min.fill_(2.0 + 0.5 * i)
+    x = dev(g["x_4096"]).reshape(2, 6, 4096)
+    outs = deploy.nn.fused_forward(x, ts)
+    for t, o in zip(ts, outs):
+        r = t(x)
+        assert torch.equal(o.quantized_x, r.quantized_x) and torch.equal(o.scales_x, r.scales_x)
+    norm = deploy.nn.RMSNorm(4096, 1e-5)
+    outs = deploy.nn.fused_forward(x, ts[:2], norm=norm)
+    for t, o in zip(ts, outs):
+        r = t(x, norm=norm)
+        assert torch.equal(o.quantized_x, r.quantized_x) and torch.equal(o.scales_x, r.scales_x)
+    other = deploy.nn.OnlineTrans(4096, trans="matmul", decompose=True, lac=True).cuda()
+    with pytest.raises(RuntimeError):
+        deploy.nn.fused_forward(x, [ts[0], other])

@@ -102,6 +102,19 @@ def main():
     fus = timeit(lambda: ln_trans(nxt(xs), norm=norm), a.steps)
     print(f"  RMSNorm + ln_trans: {sep:.1f} us as two launches, {fus:.1f} us fused (OnlineTrans.forward(x, norm=...))")
 
+    # q/k/v (three clip pairs) and up/gate (two) share one factor pair: one launch each instead of three / two
+    qkv = [trans(m["hidden"]) for _ in range(3)]
+    for t in qkv[1:]:
+        for name in ("left_matrix", "right_matrix"):
+            del t._buffers[name]
+            t.register_buffer(name, getattr(qkv[0], name))
+    three = timeit(lambda: [t(nxt(xs)) for t in qkv], a.steps)
+    one = timeit(lambda: deploy.nn.fused_forward(nxt(xs), qkv), a.steps)
+    one_n = timeit(lambda: deploy.nn.fused_forward(nxt(xs), qkv, norm=norm), a.steps)
+    two = timeit(lambda: deploy.nn.fused_forward(nxt(xs), qkv[:2], norm=norm), a.steps)
+    print(f"  inp_trans_q/k/v: {three:.1f} us as three launches (reference structure), {one:.1f} us as one, "
+          f"{one_n:.1f} us with RMSNorm inside; up/gate pair with RMSNorm: {two:.1f} us")
+
     # x_up * silu(x_gate) in front of the down_proj transform: eager torch, one HIP launch, fused into the transform
     from flatquant_amd import ops
     gates, ups = xf, [act(a.bsz, a.seq, m["ffn"]) for _ in range(2)]
@@ -114,6 +127,18 @@ def main():
     print(f"  SiLU.mul: torch eager {eager:.1f} us, fq_silu_mul_f16 {alone:.1f} us")
     print(f"  down_proj input, Hadamard + Quantizer: {fused_us:.1f} us -> with SiLU.mul inside {hq:.1f} us")
     print(f"  down_proj input, FlatQuant matmul transform ({m['ffn']}): {mm:.1f} us -> with SiLU.mul inside {mmf:.1f} us")
+
+    # FlatQuant's own deploy layer (trans="matmul" everywhere): the reference's launch structure on these kernels vs
+    # the fused launches
+    o_us = timeit(lambda: o_trans(nxt(xo)), a.steps)
+    norm_us = timeit(lambda: norm(nxt(xs)), a.steps)
+    pair = timeit(lambda: [t(nxt(xs)) for t in qkv[:2]], a.steps)
+    ref_struct = norm_us + three + o_us + norm_us + pair + alone + mm
+    fused_struct = one_n + o_us + two + mmf
+    print(f"  FlatQuant layer, activation path: reference launch structure {ref_struct:.1f} us "
+          f"(RMSNorm {norm_us:.1f} x2, q/k/v {three:.1f}, o {o_us:.1f}, up/gate {pair:.1f}, SiLU.mul {alone:.1f}, down {mm:.1f}; "
+          f"with torch-eager SiLU.mul {ref_struct - alone + eager:.1f}) -> fused launches {fused_struct:.1f} us "
+          f"(norm+q/k/v {one_n:.1f}, o {o_us:.1f}, norm+up/gate {two:.1f}, SiLU.mul+down {mmf:.1f})")
 
     # the seven 4-bit linears that consume those packed activations (Linear4bit = INT4 GEMM + dequant epilogue)
     kv = m["kv_heads"] * m["head_dim"]
