@@ -111,9 +111,9 @@ def main():
     three = timeit(lambda: [t(nxt(xs)) for t in qkv], a.steps)
     one = timeit(lambda: deploy.nn.fused_forward(nxt(xs), qkv), a.steps)
     one_n = timeit(lambda: deploy.nn.fused_forward(nxt(xs), qkv, norm=norm), a.steps)
-    two = timeit(lambda: deploy.nn.fused_forward(nxt(xs), qkv[:2], norm=norm), a.steps)
+    ug_n = timeit(lambda: deploy.nn.fused_forward(nxt(xs), qkv[:2], norm=norm), a.steps)
     print(f"  inp_trans_q/k/v: {three:.1f} us as three launches (reference structure), {one:.1f} us as one, "
-          f"{one_n:.1f} us with RMSNorm inside; up/gate pair with RMSNorm: {two:.1f} us")
+          f"{one_n:.1f} us with RMSNorm inside; up/gate pair with RMSNorm: {ug_n:.1f} us")
 
     # x_up * silu(x_gate) in front of the down_proj transform: eager torch, one HIP launch, fused into the transform
     from flatquant_amd import ops
@@ -134,11 +134,11 @@ def main():
     norm_us = timeit(lambda: norm(nxt(xs)), a.steps)
     pair = timeit(lambda: [t(nxt(xs)) for t in qkv[:2]], a.steps)
     ref_struct = norm_us + three + o_us + norm_us + pair + alone + mm
-    fused_struct = one_n + o_us + two + mmf
+    fused_struct = one_n + o_us + ug_n + mmf
     print(f"  FlatQuant layer, activation path: reference launch structure {ref_struct:.1f} us "
           f"(RMSNorm {norm_us:.1f} x2, q/k/v {three:.1f}, o {o_us:.1f}, up/gate {pair:.1f}, SiLU.mul {alone:.1f}, down {mm:.1f}; "
           f"with torch-eager SiLU.mul {ref_struct - alone + eager:.1f}) -> fused launches {fused_struct:.1f} us "
-          f"(norm+q/k/v {one_n:.1f}, o {o_us:.1f}, norm+up/gate {two:.1f}, SiLU.mul+down {mmf:.1f})")
+          f"(norm+q/k/v {one_n:.1f}, o {o_us:.1f}, norm+up/gate {ug_n:.1f}, SiLU.mul+down {mmf:.1f})")
 
     # the seven 4-bit linears that consume those packed activations (Linear4bit = INT4 GEMM + dequant epilogue)
     kv = m["kv_heads"] * m["head_dim"]
@@ -154,7 +154,7 @@ def main():
         gtot += us
         print(f"  {'Linear4bit ' + name:26s} {us:9.1f} us   {2.0 * T * k_in * n_out / us / 1e6:7.0f} TOP/s")
         del lin
-    print(f"  {'seven linears':26s} {gtot:9.1f} us;  activation path + linears: {total - two + fused_us + gtot:.1f} us per layer")
+    print(f"  {'seven linears':26s} {gtot:9.1f} us;  FlatQuant layer, fused activation path + linears: {fused_struct + gtot:.1f} us")
 
 
 if __name__ == "__main__":
