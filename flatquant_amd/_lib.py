@@ -26,6 +26,7 @@ FQ_QUANT_F16 = 0x20
 FQ_WS_PREPARED = 0x40
 FQ_IN_RMSNORM = 0x80
 FQ_IN_SILU_MUL = 0x100
+FQ_KV_LAC = 0x1
 FQ_MAX_CLIPS = 4
 
 FQ_OK, FQ_EINVAL, FQ_EUNSUPPORTED, FQ_ELAUNCH = 0, -1, -2, -3
@@ -44,6 +45,8 @@ SYMBOLS = {
     "fq_silu_mul_kron_quant_f16": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp,
                                         _i64, _vp]),
     "fq_silu_mul_f16": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "fq_kv_quant_f16": (_i, [_vp, _vp, _i64, _i, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "fq_kv_dequant_f16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "fq_silu_mul_hadamard_quant_f16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _f, _f, _f, _vp, _vp, _vp]),
     "fq_block_quant_f16": (_i, [_vp, _vp, _i64, _i, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp]),
     "fq_int4_gemm_i32": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),

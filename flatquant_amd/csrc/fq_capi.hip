@@ -19,6 +19,10 @@ int fq_launch_hadamard_quant(const f16* x, int64_t rows, int n, int K, const f16
 int fq_launch_gemm_i4(const uint8_t* X, const uint8_t* W, int64_t M, int N, int K, int32_t* c, f16* y, const f16* srow,
                       const f16* scol, const f16* bias, hipStream_t stream);
 int fq_launch_rmsnorm(const f16* x, f16* y, int64_t rows, int cols, float eps, int n_cu, hipStream_t stream);
+int fq_launch_kv_quant(const f16* x, const f16* T, int64_t rows, int hd, float cmax, float cmin, bool lac, uint8_t* q,
+                       f16* param, f16* y, int n_cu, hipStream_t stream);
+int fq_launch_kv_dequant(const uint8_t* q, const f16* param, int64_t rows, int hd, bool lac, f16* y, int n_cu,
+                         hipStream_t stream);
 int fq_launch_silu_mul(const f16* gate, const f16* up, f16* y, int64_t n, int n_cu, hipStream_t stream);
 int fq_launch_silu_hadamard_quant(const f16* gate, const f16* up, int64_t rows, int n, int K, const f16* hadK, float scale,
                                   float sig_max, float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream);
@@ -320,6 +324,30 @@ int fq_hadamard_quant_f16(const void* x, int64_t rows, int n, int K, const void*
     if (rc == -1000)
         return fail(FQ_EUNSUPPORTED, "fq_hadamard_quant_f16: no fused kernel for n=%d K=%d (use fq_hadamard_f16 + fq_rowquant_f16)", n, K);
     return check_launch(rc, "fq_hadamard_quant_f16");
+}
+
+int fq_kv_quant_f16(const void* x, const void* trans, int64_t rows, int head_dim, float clip_max, float clip_min,
+                    int flags, void* q_out, void* param_out, void* y_out, void* stream) {
+    if (rows < 0 || head_dim <= 0) return fail(FQ_EINVAL, "fq_kv_quant_f16: bad sizes rows=%lld head_dim=%d", (long long)rows, head_dim);
+    if (flags & ~FQ_KV_LAC) return fail(FQ_EINVAL, "fq_kv_quant_f16: unknown flags 0x%x", flags);
+    if (head_dim != 64 && head_dim != 128) return fail(FQ_EUNSUPPORTED, "fq_kv_quant_f16: head_dim=%d (64 or 128)", head_dim);
+    if (y_out && !trans) return fail(FQ_EINVAL, "fq_kv_quant_f16: y_out without trans");
+    if (rows == 0) return FQ_OK;
+    if (!x || !q_out || !param_out) return fail(FQ_EINVAL, "fq_kv_quant_f16: NULL pointer");
+    const int rc = fq_launch_kv_quant((const f16*)x, (const f16*)trans, rows, head_dim, clip_max, clip_min,
+                                      (flags & FQ_KV_LAC) != 0, (uint8_t*)q_out, (f16*)param_out, (f16*)y_out, cu_count(),
+                                      (hipStream_t)stream);
+    return check_launch(rc, "fq_kv_quant_f16");
+}
+
+int fq_kv_dequant_f16(const void* q, const void* param, int64_t rows, int head_dim, int flags, void* y, void* stream) {
+    if (rows < 0 || head_dim <= 0 || (head_dim & 7)) return fail(FQ_EINVAL, "fq_kv_dequant_f16: bad sizes");
+    if (flags & ~FQ_KV_LAC) return fail(FQ_EINVAL, "fq_kv_dequant_f16: unknown flags 0x%x", flags);
+    if (rows == 0) return FQ_OK;
+    if (!q || !param || !y) return fail(FQ_EINVAL, "fq_kv_dequant_f16: NULL pointer");
+    const int rc = fq_launch_kv_dequant((const uint8_t*)q, (const f16*)param, rows, head_dim, (flags & FQ_KV_LAC) != 0,
+                                        (f16*)y, cu_count(), (hipStream_t)stream);
+    return check_launch(rc, "fq_kv_dequant_f16");
 }
 
 int fq_rowquant_f16(const void* x, int64_t rows, int cols, const float* sig_max, const float* sig_min,

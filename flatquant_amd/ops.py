@@ -354,6 +354,42 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
     return q, s
 
 
+def kv_quant(x: torch.Tensor, trans: Optional[torch.Tensor] = None, clip: Sig = (1.0, 1.0), lac: bool = False,
+             return_transformed: bool = False):
+    """K/V cache quantisation (fq_kv_quant_f16): x [..., head_dim] fp16 -> (q uint8 [..., head_dim/2], param fp16
+    [..., 2] = (scale, zero)[, y fp16 [..., head_dim]]). ``trans`` [head_dim, head_dim]: y = x @ trans first (the K
+    transform). ``clip`` = the sigmoid-ed clip factors, used with ``lac`` only (kv_cache.py:11-51)."""
+    _chk(x, "x")
+    hd = x.shape[-1]
+    if trans is not None:
+        _chk(trans, "trans")
+        if trans.shape != (hd, hd):
+            raise ValueError("trans must be [head_dim, head_dim]")
+    elif return_transformed:
+        raise ValueError("return_transformed needs trans")
+    rows = x.numel() // hd
+    q = torch.empty(x.shape[:-1] + (hd // 2,), dtype=torch.uint8, device=x.device)
+    param = torch.empty(x.shape[:-1] + (2,), dtype=torch.float16, device=x.device)
+    y = torch.empty_like(x) if return_transformed else None
+    with torch.cuda.device(x.device):
+        check(lib.fq_kv_quant_f16(_ptr(x), _ptr(trans), rows, hd, ctypes.c_float(clip[0]), ctypes.c_float(clip[1]),
+                                  _lib.FQ_KV_LAC if lac else 0, _ptr(q), _ptr(param), _ptr(y), _stream(x)))
+    return (q, param, y) if return_transformed else (q, param)
+
+
+def kv_dequant(q: torch.Tensor, param: torch.Tensor, lac: bool = False) -> torch.Tensor:
+    """unpack_i4_and_asym_dequantize (kv_cache.py:54-61): q uint8 [..., hd/2], param fp16 [..., 2] -> fp16 [..., hd]."""
+    _chk(q, "q", torch.uint8), _chk(param, "param")
+    hd = q.shape[-1] * 2
+    rows = q.numel() // q.shape[-1]
+    if param.numel() != rows * 2:
+        raise ValueError("param must be [..., 2] with q's leading shape")
+    y = torch.empty(q.shape[:-1] + (hd,), dtype=torch.float16, device=q.device)
+    with torch.cuda.device(q.device):
+        check(lib.fq_kv_dequant_f16(_ptr(q), _ptr(param), rows, hd, _lib.FQ_KV_LAC if lac else 0, _ptr(y), _stream(q)))
+    return y
+
+
 def int4_matmul(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """_CUDA.matmul (bindings.cpp:9-25 -> gemm.cu): x uint8 [M, K/2], w uint8 [N, K/2], packed nibbles -> int32 [M, N]."""
     _chk(x, "x", torch.uint8), _chk(w, "w", torch.uint8)

@@ -22,6 +22,7 @@
  *   fq_hadamard_f16        flatquant/hadamard_utils.py:89-110,132-141 (matmul_hadU[_cuda]),
  *   (fq_hadamard_quant_f16: the same followed by deploy/nn/quantization.py:13-36, fused)
  *                          deploy/functional/online_trans.py:144-151
+ *   fq_kv_quant_f16, fq_kv_dequant_f16   deploy/transformers/kv_cache.py:11-61,268 (K transform + asym INT4 pack)
  *   fq_rowquant_f16        deploy/nn/quantization.py:13-36 (Quantizer.forward),
  *                          flatquant/quant_utils.py:77-119
  *   fq_sym_quant_f16       deploy/kernels/bindings.cpp:27-44 -> quant.cu:13-63 (sym_quant)
@@ -197,6 +198,27 @@ int fq_rowquant_f16(const void* x, int64_t rows, int cols,
                     const float* sig_max, const float* sig_min, int n_clips, int flags,
                     void* const* q_out, void* const* scale_out, void* const* fq_out,
                     void* stream);
+
+/*
+ * KV-cache quantisation (deploy/transformers/kv_cache.py:11-51 asym_quantize_and_pack_i4, :268 the K transform), one
+ * launch: per row of head_dim fp16 values (a row = one head of one token; x is [rows, head_dim] contiguous)
+ *   y = trans ? fp16(x . trans) : x                               trans [head_dim, head_dim] fp16 row-major or NULL
+ *   default (the cache's own calls, lac=False):  scale = fp16(max(fp16(ymax - ymin), 1e-5) / 15), zero = -ymin,
+ *                                                q = clamp(rint(fp16(fp16(y + zero) / scale)), 0, 15)
+ *   FQ_KV_LAC: extrema through 0, times clip_max / clip_min (already sigmoid-ed, fp16 values), (0,0) -> (-1,1),
+ *              scale = fp16(fp16(ymax - ymin) / 15), zero = rint(fp16(-ymin / scale)),
+ *              q = clamp(fp16(rint(fp16(y / scale)) + zero), 0, 15)
+ * every step in fp16 arithmetic as the torch expression evaluates it.
+ *   q_out [rows, head_dim/2] uint8 (low nibble = even column), param_out [rows, 2] fp16 (scale, zero) — the k_param /
+ *   v_param layout of kv_cache.py:296-297; y_out [rows, head_dim] fp16 or NULL (the transformed rows, trans only).
+ * head_dim in {64, 128}.
+ */
+#define FQ_KV_LAC 0x1
+int fq_kv_quant_f16(const void* x, const void* trans, int64_t rows, int head_dim, float clip_max, float clip_min,
+                    int flags, void* q_out, void* param_out, void* y_out, void* stream);
+
+/* kv_cache.py:54-61 unpack_i4_and_asym_dequantize: y = q * scale - zero, or scale * (q - zero) with FQ_KV_LAC (fp16). */
+int fq_kv_dequant_f16(const void* q, const void* param, int64_t rows, int head_dim, int flags, void* y, void* stream);
 
 /* q = clamp(rn(x /fp16 scale[row]), -8, 7), two per byte, even column -> low nibble (quant.cu:13-47). */
 int fq_sym_quant_f16(const void* x, const void* scale, int64_t rows, int cols, void* q, void* stream);

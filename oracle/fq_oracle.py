@@ -261,6 +261,56 @@ def sym_dequant(q32, scale_row16, scale_col16):
     return r
 
 
+def kv_asym_quant(x16, clip_max16=1.0, clip_min16=1.0, lac=False):
+    """deploy/transformers/kv_cache.py:11-51 (asym_quantize_and_pack_i4) on fp16 tensors, every torch op rounding to
+    fp16 as it does there. Per last-axis row: -> (packed uint8 [..., n/2] low nibble = even column, scale fp16 [..., 1],
+    zero fp16 [..., 1], q uint8 [..., n]). The cache's own call sites leave lac=False (kv_cache.py:283-284)."""
+    x = np.asarray(x16, dtype=F16)
+    xmax = x.max(axis=-1, keepdims=True)
+    xmin = x.min(axis=-1, keepdims=True)
+    with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+        if lac:
+            xmax = np.maximum(xmax, F16(0))
+            xmin = np.minimum(xmin, F16(0))
+            xmax = (xmax.astype(F32) * F32(F16(clip_max16))).astype(F16)
+            xmin = (xmin.astype(F32) * F32(F16(clip_min16))).astype(F16)
+            both = (xmin == 0) & (xmax == 0)
+            xmin = np.where(both, F16(-1), xmin)
+            xmax = np.where(both, F16(1), xmax)
+            d = (xmax.astype(F32) - xmin.astype(F32)).astype(F16)
+            scale = (d.astype(F32) / F32(15)).astype(F16)
+            nx = (F32(-1.0) * xmin.astype(F32)).astype(F16)
+            zero = np.rint((nx.astype(F32) / scale.astype(F32)).astype(F16)).astype(F16)
+            t = np.rint((x.astype(F32) / scale.astype(F32)).astype(F16)).astype(F16)
+            q = np.clip((t.astype(F32) + zero.astype(F32)).astype(F16), F16(0), F16(15))
+        else:
+            d = (xmax.astype(F32) - xmin.astype(F32)).astype(F16)
+            d = np.maximum(d, F16(1e-5))
+            scale = (d.astype(F32) / F32(15)).astype(F16)
+            zero = (-xmin).astype(F16)
+            t = (x.astype(F32) + zero.astype(F32)).astype(F16)
+            q = np.clip(np.rint((t.astype(F32) / scale.astype(F32)).astype(F16)), F16(0), F16(15))
+    q8 = np.nan_to_num(q.astype(F32), nan=0.0).astype(np.uint8)
+    packed = (q8[..., 0::2] | (q8[..., 1::2] << 4)).astype(np.uint8)
+    return packed, scale, zero, q8
+
+
+def kv_asym_dequant(packed, scale16, zero16, lac=False):
+    """kv_cache.py:54-61 (unpack_i4_and_asym_dequantize): lac: scale * (q - zero); else q * scale - zero (fp16 ops)."""
+    p = np.asarray(packed, dtype=np.uint8)
+    q = np.stack((p & 0x0F, (p >> 4) & 0x0F), axis=-1).reshape(*p.shape[:-1], p.shape[-1] * 2).astype(F16)
+    s, z = np.asarray(scale16, dtype=F16), np.asarray(zero16, dtype=F16)
+    with np.errstate(over="ignore", invalid="ignore"):
+        if lac:
+            return (s.astype(F32) * (q.astype(F32) - z.astype(F32)).astype(F16).astype(F32)).astype(F16)
+        return ((q.astype(F32) * s.astype(F32)).astype(F16).astype(F32) - z.astype(F32)).astype(F16)
+
+
+def kv_transform(x16, trans16):
+    """kv_cache.py:268 torch.matmul(key_states.to(fp16), trans_matrix_k): fp32 accumulation, fp16 result."""
+    return (np.asarray(x16, dtype=F16).astype(F32) @ np.asarray(trans16, dtype=F16).astype(F32)).astype(F16)
+
+
 def silu_mul(gate16, up16):
     """deploy/transformers/modeling_llama.py:277-278 on fp16 tensors: ac = act_fn(x_gate) (SiLU: fp32 g / (1 + exp(-g)),
     rounded to fp16), x = x_up * ac (fp16 product = exact product rounded once)."""

@@ -273,3 +273,18 @@ def test_oracle_silu_mul_and_rmsnorm_vs_reference_goldens(golden):
     st = np.abs(ka - kb)[ok]
     # numpy's expf vs torch's: one fp16 step in SiLU on ~2e-4 of the elements, which the product can stretch to two
     assert st.max() <= 2 and np.mean(st != 0) <= 1e-3
+
+
+def test_oracle_kv_quant_vs_reference_golden(golden):
+    """kv_cache.py asym_quantize_and_pack_i4 / unpack_i4_and_asym_dequantize / the K transform: bit for bit."""
+    import numpy as np
+    from oracle import fq_oracle as O
+    g = golden("kv_quant")
+    cm, cn = g["clip"]
+    for lac, tag in ((False, "plain"), (True, "lac")):
+        p, s, z, _ = O.kv_asym_quant(g["x"], cm, cn, lac)
+        assert np.array_equal(p, g[f"{tag}_q"])
+        assert np.array_equal(s.view(np.uint16), g[f"{tag}_scale"].view(np.uint16))
+        assert np.array_equal(z.view(np.uint16), g[f"{tag}_zero"].view(np.uint16))
+        assert np.array_equal(O.kv_asym_dequant(p, s, z, lac).view(np.uint16), g[f"{tag}_deq"].view(np.uint16))
+    assert np.array_equal(O.kv_transform(g["x"], g["T"]).view(np.uint16), g["xT"].view(np.uint16))

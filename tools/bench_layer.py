@@ -140,6 +140,24 @@ def main():
           f"with torch-eager SiLU.mul {ref_struct - alone + eager:.1f}) -> fused launches {fused_struct:.1f} us "
           f"(norm+q/k/v {one_n:.1f}, o {o_us:.1f}, norm+up/gate {ug_n:.1f}, SiLU.mul+down {mmf:.1f})")
 
+    # KV-cache side: K transform + asym INT4 pack of the new keys / values (kv_cache.py:262-297), fused vs torch eager
+    import flatquant_amd.deploy.transformers as dt
+    ks = [act(a.bsz, a.seq, m["kv_heads"], m["head_dim"]) for _ in range(2)]
+    tk = (torch.randn(m["head_dim"], m["head_dim"], generator=g, device=dev) / m["head_dim"] ** 0.5).half()
+
+    def eager(k, v):
+        out = []
+        for t in (torch.matmul(k, tk), v):
+            xmax, xmin = t.amax(-1, keepdim=True), t.amin(-1, keepdim=True)
+            scale = (xmax - xmin).clamp(min=1e-5) / 15
+            q = torch.clamp(torch.round((t - xmin) / scale), 0, 15).to(torch.uint8)
+            out.append((q[..., 0::2] | (q[..., 1::2] << 4), scale, -xmin))
+        return out
+    kv_e = timeit(lambda: eager(nxt(ks), ks[0]), a.steps)
+    kv_f = timeit(lambda: dt.transform_quantize_kv(nxt(ks), ks[0], tk), a.steps)
+    print(f"  K transform + K/V asym INT4 pack ({a.bsz}x{a.seq} tokens x {m['kv_heads']} heads x {m['head_dim']}): "
+          f"torch eager (the reference's op sequence) {kv_e:.1f} us, fq_kv_quant_f16 x2 {kv_f:.1f} us")
+
     # the seven 4-bit linears that consume those packed activations (Linear4bit = INT4 GEMM + dequant epilogue)
     kv = m["kv_heads"] * m["head_dim"]
     lins = [("q_proj", m["hidden"], m["hidden"]), ("k_proj", m["hidden"], kv), ("v_proj", m["hidden"], kv),

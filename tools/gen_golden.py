@@ -23,6 +23,7 @@ sys.dont_write_bytecode = True
 REF = "/root/reference"
 sys.path.insert(0, REF)
 sys.modules["fast_hadamard_transform"] = types.ModuleType("fast_hadamard_transform")
+sys.modules["fast_hadamard_transform"].hadamard_transform = None   # imported by name in deploy/transformers/kv_cache.py, never called here
 sys.modules["deploy._CUDA"] = types.ModuleType("deploy._CUDA")
 
 import numpy as np  # noqa: E402
@@ -367,8 +368,39 @@ def gen_checkpoint():
         torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.empty_cache = saved
 
 
+def gen_kv_quant():
+    """deploy/transformers/kv_cache.py: asym_quantize_and_pack_i4 (both lac settings), unpack_i4_and_asym_dequantize and
+    the K transform torch.matmul(key_states, trans_matrix_k) on fp16 CPU tensors [bsz, seq, kv_heads, head_dim]."""
+    from deploy.transformers import kv_cache as kc
+    g = torch.Generator().manual_seed(123)
+    x = (torch.randn(2, 9, 4, 128, generator=g) * 1.7).to(torch.float16)
+    x[0, 0, 0] = 0                                   # all-zero row (scale floor / the lac (-1, 1) substitution)
+    x[0, 0, 1] = x[0, 0, 1].abs()                    # single-signed rows
+    x[0, 0, 2] = -x[0, 0, 2].abs()
+    x[0, 1, 0] = 3.0                                 # constant row
+    x[0, 1, 1, 5] = 60000.0                          # outlier near the fp16 maximum
+    x[0, 1, 2] *= 1e-4                               # tiny values
+    x[0, 1, 3, ::2] = 0.5                            # many exact .5 ties after scaling
+    cmax, cmin = torch.sigmoid(torch.tensor(4.0, dtype=torch.float16)), torch.sigmoid(torch.tensor(2.5, dtype=torch.float16))
+    arrays = {"x": x.numpy(), "clip": np.array([float(cmax), float(cmin)], dtype=np.float16)}
+    for lac in (False, True):
+        q, s, z = kc.asym_quantize_and_pack_i4(x, cmax, cmin, lac=lac)
+        fq, _, _ = kc.asym_quantize_and_pack_i4(x, cmax, cmin, lac=lac, quantize=False)
+        tag = "lac" if lac else "plain"
+        arrays.update({f"{tag}_q": q.numpy(), f"{tag}_scale": s.numpy(), f"{tag}_zero": z.numpy(), f"{tag}_fq": fq.numpy(),
+                       f"{tag}_deq": kc.unpack_i4_and_asym_dequantize(q, s, z, lac=lac).numpy()})
+    T = make_mat(128, 77)
+    arrays["T"] = T.numpy()
+    arrays["xT"] = torch.matmul(x, T).numpy()
+    save("kv_quant", **arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "kv":
+        gen_kv_quant()
+        sys.exit(0)
+    gen_kv_quant()
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt":
         gen_checkpoint()
         sys.exit(0)
