@@ -23,6 +23,10 @@ int fq_launch_kv_quant(const f16* x, const f16* T, int64_t rows, int hd, float c
                        f16* param, f16* y, int n_cu, hipStream_t stream);
 int fq_launch_kv_dequant(const uint8_t* q, const f16* param, int64_t rows, int hd, bool lac, f16* y, int n_cu,
                          hipStream_t stream);
+int64_t fq_bf6_blob_bytes(int64_t rows, int K);  // fq_gemm_bf6.hip (exported as is)
+int fq_launch_i4_to_bf6(const uint8_t* q, int64_t rows, int K, int perm, uint8_t* blob, int n_cu, hipStream_t stream);
+int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, int N, int K, int32_t* c, f16* y,
+                       const f16* srow, const f16* scol, const f16* bias, hipStream_t stream);
 int fq_launch_silu_mul(const f16* gate, const f16* up, f16* y, int64_t n, int n_cu, hipStream_t stream);
 int fq_launch_silu_hadamard_quant(const f16* gate, const f16* up, int64_t rows, int n, int K, const f16* hadK, float scale,
                                   float sig_max, float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream);
@@ -310,6 +314,36 @@ int fq_int4_linear_f16(const void* x, const void* x_scale, const void* w, const 
                                      (const f16*)w_scale, (const f16*)bias, (hipStream_t)stream);
     if (rc == -1000) return fail(FQ_EUNSUPPORTED, "fq_int4_linear_f16: shape M=%lld N=%d K=%d not supported", (long long)M, N, K);
     return check_launch(rc, "fq_int4_linear_f16");
+}
+
+int fq_int4_to_bf6(const void* q, int64_t rows, int K, int role, void* blob, void* stream) {
+    if (rows < 0 || K <= 0 || (role != 0 && role != 1)) return fail(FQ_EINVAL, "fq_int4_to_bf6: bad arguments");
+    if (K % 64) return fail(FQ_EUNSUPPORTED, "fq_int4_to_bf6: K=%d must be a multiple of 64", K);
+    if (rows == 0) return FQ_OK;
+    if (!q || !blob) return fail(FQ_EINVAL, "fq_int4_to_bf6: NULL pointer");
+    const int rc = fq_launch_i4_to_bf6((const uint8_t*)q, rows, K, role, (uint8_t*)blob, cu_count(), (hipStream_t)stream);
+    return check_launch(rc, "fq_int4_to_bf6");
+}
+
+int fq_bf6_gemm_i32(const void* xblob, const void* wblob, int64_t M, int N, int K, void* c, void* stream) {
+    if (M < 0 || N <= 0 || K <= 0) return fail(FQ_EINVAL, "fq_bf6_gemm_i32: bad sizes");
+    if (M == 0) return FQ_OK;
+    if (!xblob || !wblob || !c) return fail(FQ_EINVAL, "fq_bf6_gemm_i32: NULL pointer");
+    const int rc = fq_launch_gemm_bf6((const uint8_t*)xblob, (const uint8_t*)wblob, M, N, K, (int32_t*)c, nullptr, nullptr,
+                                      nullptr, nullptr, (hipStream_t)stream);
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "fq_bf6_gemm_i32: shape M=%lld N=%d K=%d not covered (K %% 128, N %% 16)", (long long)M, N, K);
+    return check_launch(rc, "fq_bf6_gemm_i32");
+}
+
+int fq_bf6_linear_f16(const void* xblob, const void* x_scale, const void* wblob, const void* w_scale, const void* bias,
+                      int64_t M, int N, int K, void* y, void* stream) {
+    if (M < 0 || N <= 0 || K <= 0) return fail(FQ_EINVAL, "fq_bf6_linear_f16: bad sizes");
+    if (M == 0) return FQ_OK;
+    if (!xblob || !wblob || !y || !x_scale || !w_scale) return fail(FQ_EINVAL, "fq_bf6_linear_f16: NULL pointer");
+    const int rc = fq_launch_gemm_bf6((const uint8_t*)xblob, (const uint8_t*)wblob, M, N, K, nullptr, (f16*)y,
+                                      (const f16*)x_scale, (const f16*)w_scale, (const f16*)bias, (hipStream_t)stream);
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "fq_bf6_linear_f16: shape M=%lld N=%d K=%d not covered (K %% 128, N %% 16)", (long long)M, N, K);
+    return check_launch(rc, "fq_bf6_linear_f16");
 }
 
 int fq_hadamard_quant_f16(const void* x, int64_t rows, int n, int K, const void* hadK, float scale, float sig_max,

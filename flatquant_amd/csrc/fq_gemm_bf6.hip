@@ -1,0 +1,295 @@
+// fq_gemm_bf6.hip — the INT4 x INT4 GEMM of Linear4bit on the FP6 matrix path of gfx950 ("explore
+// FP4/FP6 block-scaled MFMA"), bit-identical to fq_gemm_i4.hip.
+//
+// gfx950 has no INT4 MFMA. fq_gemm_i4.hip widens nibbles to bytes for v_mfma_i32_32x32x32_i8. But every integer in
+// [-8, 7] is exactly representable in BF6 (E3M2: 0, +-1, 2, 3, 4, 5, 6, 7, 8), and
+// v_mfma_scale_f32_32x32x64_f8f6f4 with both operands BF6 and unit block scales (E8M0 = 127) multiplies them exactly
+// and accumulates in fp32: |product| <= 64 and K <= 2^18 keep every partial sum an integer below 2^24, i.e. the fp32
+// accumulator IS the int32 result. Measured on MI355X with register-resident operands (tools/scratch/bf6_probe.hip):
+// 5.1 Pop/s for BF6 32x32x64 against 3.6 Pop/s for i8 32x32x32 under the same sustained load, and no unpack VALU.
+//
+// Operands are pre-arranged as "blobs" (fq_i4_to_bf6_kernel): for a tile of 32 rows and a block of 64 k, the 64 lanes'
+// MFMA operand registers — lane (kh, r) holds the 32 six-bit codes of row r, k = 64 kb + 32 kh .. + 31 as a 24-byte
+// little-endian bit string — stored as three planes of 64 x 8 bytes (1536 bytes per blob, blobs of a row tile
+// consecutive in k). A stage of the K loop (128 k) is then whole contiguous 3 KB segments: LDS-DMA with no address
+// arithmetic, fragment reads are 3 conflict-free ds_read_b64 (consecutive lanes, consecutive 8 bytes), no swizzle.
+// Weights are converted once per layer (their rows in the permuted order that leaves a lane with 16 consecutive n,
+// as in fq_gemm_i4.hip); activations by one small launch per call (0.5 -> 0.75 bytes per element).
+//
+// Tiling: 256 x 256 per 8-wave workgroup, wave tile 128 tokens x 64 features (8 accumulator tiles: 6 fragments per 8
+// MFMAs), three LDS stages of 48 KB, counted vmcnt, one barrier per stage — the pipeline of fq_gemm_i4.hip.
+#include "fq_common.hpp"
+
+namespace {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void_b;
+
+constexpr int BM = 256, BN = 256;
+constexpr int BLOB = 1536;                     // bytes: 32 rows x 64 k of BF6
+constexpr int SEG = 2 * BLOB;                  // a row tile's two blobs of one stage (128 k)
+constexpr int OPB = 8 * SEG;                   // one operand's share of a stage: 8 row tiles
+constexpr int TILE_BYTES = 2 * OPB;            // 48 KB: [W tiles 0..7][X tiles 0..7]
+constexpr int STAGES = 3;
+constexpr int GW = 8, GT = GW * 64;
+constexpr int TMT = 4;                         // token tiles per wave (2 waves along tokens, 4 along features)
+constexpr int DPW = (TILE_BYTES / 1024) / GW;  // DMA instructions per wave and stage: 6
+
+__device__ __forceinline__ int prow(int c) { return ((c >> 2) & 1) * 16 + (c & 3) + 4 * (c >> 3); }
+
+// quant.cu:5-10,66-85 (same as fq_gemm_i4.hip)
+__device__ __forceinline__ f16 dequant1(int q, f16 srow, f16 scol) {
+    int iv = (int)((float)q / 10.0f);
+    iv = max(-65176, min(65176, iv));
+    f16 r = srow * scol;
+    r = r * (f16)iv;
+    return r * (f16)10.0f;
+}
+
+// XCD-aware tile order. Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own 4 MB L2. XCD x
+// takes a CONTIGUOUS share of the tile sequence, and the sequence walks 8-feature-tile-wide column blocks row by row,
+// so the ~32 workgroups resident on an XCD at a time form a 4 x 8 patch of tiles: 12 distinct operand tiles per K
+// stage instead of 64, i.e. most of the operand traffic stays in that XCD's L2 instead of crossing the fabric.
+__device__ __forceinline__ bool xcd_tile(int bid, int TM, int TN, int& tm, int& tn) {
+    const int T = TM * TN, per = (T + 7) >> 3;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int L = xcd * per + local;
+    if (local >= per || L >= T) return false;
+    const int blk = L / (8 * TM), rem = L - blk * 8 * TM;
+    const int width = TN - blk * 8 < 8 ? TN - blk * 8 : 8;
+    tm = rem / width;
+    tn = blk * 8 + (rem - tm * width);
+    return true;
+}
+
+struct GemmOut {
+    int32_t* c;
+    f16* y;
+    const f16* srow;
+    const f16* scol;
+    const f16* bias;
+};
+
+// ---- INT4 nibbles -> BF6 blobs ----------------------------------------------------------------------------------
+// E3M2 codes of 0..8; a negative value sets bit 5
+__device__ __forceinline__ unsigned bf6_code(int v) {  // v in [-8, 7]
+    const unsigned mag = (unsigned)(v < 0 ? -v : v);
+    const unsigned tab[9] = {0x00, 0x0C, 0x10, 0x12, 0x14, 0x15, 0x16, 0x17, 0x18};
+    return tab[mag] | (v < 0 ? 0x20u : 0u);
+}
+
+__global__ __launch_bounds__(256) void fq_i4_to_bf6_kernel(const uint8_t* __restrict__ src, int64_t rows, int Kb, int perm,
+                                                           uint8_t* __restrict__ dst) {
+    __shared__ unsigned short lut[256];  // packed byte (two nibbles, even k low) -> 12 bits of codes
+    {
+        const int b = threadIdx.x;
+        const int lo = ((b & 15) ^ 8) - 8, hi = (((b >> 4) & 15) ^ 8) - 8;
+        lut[b] = (unsigned short)(bf6_code(lo) | (bf6_code(hi) << 6));
+    }
+    __syncthreads();
+    const int KB = Kb / 32;  // blobs per row tile (64 k = 32 packed bytes)
+    const int64_t n_rt = (rows + 31) / 32;
+    const int64_t total = n_rt * KB * 64;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        const int64_t blob = i >> 6;
+        const int64_t rt = blob / KB;
+        const int kb = (int)(blob - rt * KB);
+        const int kh = lane >> 5, r = lane & 31;
+        const int64_t row = rt * 32 + (perm ? prow(r) : r);
+        uint4 in = make_uint4(0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u);  // never used: rows beyond the end are zeros
+        const bool ok = row < rows;
+        if (ok) in = *reinterpret_cast<const uint4*>(src + row * Kb + kb * 32 + kh * 16);
+        const unsigned w[4] = {in.x, in.y, in.z, in.w};
+        unsigned long long g[4];  // 48 bits each: the 8 codes of one input dword
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned long long t0 = lut[w[j] & 255], t1 = lut[(w[j] >> 8) & 255], t2 = lut[(w[j] >> 16) & 255],
+                                     t3 = lut[w[j] >> 24];
+            g[j] = ok ? (t0 | (t1 << 12) | (t2 << 24) | (t3 << 36)) : 0ull;
+        }
+        const unsigned long long o0 = g[0] | (g[1] << 48);
+        const unsigned long long o1 = (g[1] >> 16) | (g[2] << 32);
+        const unsigned long long o2 = (g[2] >> 32) | (g[3] << 16);
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(dst + blob * BLOB) + lane;
+        d[0] = o0;
+        d[64] = o1;
+        d[128] = o2;
+    }
+}
+
+// ---- the GEMM ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GT, 2) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB, const uint8_t* __restrict__ WB,
+                                                            int M, int N, int KB, GemmOut out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;  // wave tile: tokens 128 wm .., features 64 wn ..
+    int mb, nb;
+    if (!xcd_tile(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, mb, nb)) return;
+    const int m0 = mb * BM, n0 = nb * BN;
+    const int nk = KB / 2;  // stages of 128 k
+    const int mt_last = (M + 31) / 32 - 1, nt_last = (N + 31) / 32 - 1;
+
+    // DMA plan: instruction i = 6 wave + j: operand i / 24 (0 = W), row tile (i % 24) / 3, 1 KB part i % 3 of its 3 KB
+    const unsigned char* gsrc[DPW];
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int i = wave * DPW + j;
+        const int op = i / 24, t = (i % 24) / 3, part = i % 3;
+        int64_t rt = (op == 0 ? n0 : m0) / 32 + t;
+        const int last = op == 0 ? nt_last : mt_last;
+        rt = rt < last ? rt : last;  // tiles beyond the matrix re-read its last tile (their outputs are never stored)
+        gsrc[j] = (op == 0 ? WB : XB) + rt * (int64_t)KB * BLOB + part * 1024 + lane * 16;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(lds_void_b*)smem;
+    auto issue_stage = [&](int s) {
+        const unsigned dst = lds0 + (unsigned)((s % STAGES) * TILE_BYTES) + (unsigned)(wave * DPW) * 1024u;
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const unsigned char* src = gsrc[j] + (int64_t)s * SEG;
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %2\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, off\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src), "s"(__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)j * 1024u)))
+                : "memory");
+        }
+    };
+
+    const int woff = (wn * 2) * SEG + lane * 8;             // + tn * SEG + kbl * BLOB + plane * 512
+    const int xoff = OPB + (wm * TMT) * SEG + lane * 8;     // + tm * SEG + ...
+
+    f32x16 acc[2][TMT];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TMT; ++tm) acc[tn][tm] = f32x16{0};
+
+    uint2 r0w[2][3], r0x[TMT][3], r1w[2][3], r1x[TMT][3];
+#define FQ_READ(ST, KBL, RW, RX)                                                                                    \
+    {                                                                                                                \
+        _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) _Pragma("unroll") for (int p = 0; p < 3; ++p) RW[tn][p] =   \
+            *reinterpret_cast<const uint2*>((ST) + woff + tn * SEG + (KBL) * BLOB + p * 512);                        \
+        _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm) _Pragma("unroll") for (int p = 0; p < 3; ++p) RX[tm][p] = \
+            *reinterpret_cast<const uint2*>((ST) + xoff + tm * SEG + (KBL) * BLOB + p * 512);                        \
+    }
+#define FQ_FRAG(R) i32x8{(int)R[0].x, (int)R[0].y, (int)R[1].x, (int)R[1].y, (int)R[2].x, (int)R[2].y, 0, 0}
+#define FQ_COMPUTE(RW, RX)                                                                                          \
+    {                                                                                                                \
+        i32x8 wf[2], xf[TMT];                                                                                        \
+        _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) wf[tn] = FQ_FRAG(RW[tn]);                                   \
+        _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm) xf[tm] = FQ_FRAG(RX[tm]);                                 \
+        _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm)          \
+            acc[tn][tm] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[tn], xf[tm], acc[tn][tm], 3, 3, 0,       \
+                                                                          0x7f7f7f7f, 0, 0x7f7f7f7f);               \
+    }
+#pragma unroll
+    for (int p = 0; p < STAGES; ++p)
+        if (p < nk) issue_stage(p);
+    {
+        const int younger = nk - 1 < STAGES - 1 ? nk - 1 : STAGES - 1;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * DPW) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    FQ_READ(smem, 0, r0w, r0x)
+    for (int s = 0; s < nk; ++s) {
+        const unsigned char* st = smem + (s % STAGES) * TILE_BYTES;
+        FQ_READ(st, 1, r1w, r1x)
+        FQ_COMPUTE(r0w, r0x)
+        if (s + 1 < nk) {
+            const int younger = nk - 2 - s < STAGES - 2 ? nk - 2 - s : STAGES - 2;
+            if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(DPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave holds all of stage s in registers: its buffer is free
+            if (s + STAGES < nk) issue_stage(s + STAGES);
+            const unsigned char* sn = smem + ((s + 1) % STAGES) * TILE_BYTES;
+            FQ_READ(sn, 0, r0w, r0x)
+        }
+        FQ_COMPUTE(r1w, r1x)
+    }
+#undef FQ_READ
+#undef FQ_FRAG
+#undef FQ_COMPUTE
+
+    // ---- epilogue: lane (h, c) of tile (tn, tm): n = n0 + 64 wn + 32 tn + 16 h + r, token m = m0 + 128 wm + 32 tm + c
+#pragma unroll
+    for (int tm = 0; tm < TMT; ++tm) {
+        const int m = m0 + wm * (TMT * 32) + tm * 32 + c;
+        if (m >= M) continue;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int nbase = n0 + wn * 64 + tn * 32 + 16 * h;
+            if (nbase >= N) continue;  // N % 16 == 0
+            int v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = (int)acc[tn][tm][r];  // an integer below 2^24: exact
+            if (out.c != nullptr) {
+                int4* cp = reinterpret_cast<int4*>(out.c + (int64_t)m * N + nbase);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) cp[g] = make_int4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+            }
+            if (out.y != nullptr) {
+                const f16 sr = out.srow[m];
+                f16x8 o0, o1;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    o0[r] = dequant1(v[r], sr, out.scol[nbase + r]);
+                    o1[r] = dequant1(v[8 + r], sr, out.scol[nbase + 8 + r]);
+                    if (out.bias != nullptr) {
+                        o0[r] = o0[r] + out.bias[nbase + r];
+                        o1[r] = o1[r] + out.bias[nbase + 8 + r];
+                    }
+                }
+                uint4* yp = reinterpret_cast<uint4*>(out.y + (int64_t)m * N + nbase);
+                yp[0] = __builtin_bit_cast(uint4, o0);
+                yp[1] = __builtin_bit_cast(uint4, o1);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int64_t fq_bf6_blob_bytes(int64_t rows, int K) {
+    if (rows < 0 || K <= 0 || (K & 63)) return -1;
+    return ((rows + 31) / 32) * (int64_t)(K / 64) * BLOB;
+}
+
+// -1000: K % 64 != 0
+int fq_launch_i4_to_bf6(const uint8_t* q, int64_t rows, int K, int perm, uint8_t* blob, int n_cu, hipStream_t stream) {
+    if ((K & 63) || rows < 1) return -1000;
+    const int64_t total = ((rows + 31) / 32) * (int64_t)(K / 64) * 64;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > (int64_t)n_cu * 16) blocks = (int64_t)n_cu * 16;
+    hipLaunchKernelGGL(fq_i4_to_bf6_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q, rows, K / 2, perm, blob);
+    return (int)hipGetLastError();
+}
+
+// -1000: shape not covered (K % 128 != 0, N % 16 != 0, K > 2^18): use the i8 kernel
+int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, int N, int K, int32_t* c, f16* y,
+                       const f16* srow, const f16* scol, const f16* bias, hipStream_t stream) {
+    if ((K & 127) || (N & 15) || K > (1 << 18) || M < 1 || N < 1 || M > (1 << 30)) return -1000;
+    GemmOut o;
+    o.c = c;
+    o.y = y;
+    o.srow = srow;
+    o.scol = scol;
+    o.bias = bias;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fq_gemm_bf6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  STAGES * TILE_BYTES);
+        attr_set = true;
+    }
+    const int64_t blocks = 8 * ((((M + BM - 1) / BM) * ((N + BN - 1) / BN) + 7) / 8);  // see xcd_tile
+    hipLaunchKernelGGL(fq_gemm_bf6_kernel, dim3((unsigned)blocks), dim3(GT), STAGES * TILE_BYTES, stream, xblob, wblob, (int)M,
+                       N, K / 64, o);
+    return (int)hipGetLastError();
+}

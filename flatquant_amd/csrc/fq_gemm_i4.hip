@@ -73,6 +73,22 @@ __device__ __forceinline__ f16 dequant1(int q, f16 srow, f16 scol) {
     return r * (f16)10.0f;
 }
 
+// XCD-aware tile order. Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own 4 MB L2. XCD x
+// takes a CONTIGUOUS share of the tile sequence, and the sequence walks 8-feature-tile-wide column blocks row by row,
+// so the ~32 workgroups resident on an XCD at a time form a 4 x 8 patch of tiles: 12 distinct operand tiles per K
+// stage instead of 64, i.e. most of the operand traffic stays in that XCD's L2 instead of crossing the fabric.
+__device__ __forceinline__ bool xcd_tile(int bid, int TM, int TN, int& tm, int& tn) {
+    const int T = TM * TN, per = (T + 7) >> 3;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int L = xcd * per + local;
+    if (local >= per || L >= T) return false;
+    const int blk = L / (8 * TM), rem = L - blk * 8 * TM;
+    const int width = TN - blk * 8 < 8 ? TN - blk * 8 : 8;
+    tm = rem / width;
+    tn = blk * 8 + (rem - tm * width);
+    return true;
+}
+
 struct GemmOut {
     int32_t* c;          // [M, N] int32, or nullptr
     f16* y;              // [M, N] fp16 (fused dequant), or nullptr
@@ -87,8 +103,14 @@ __global__ __launch_bounds__(GT) void fq_gemm_i4_kernel(const uint8_t* __restric
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % NWM, wn = wave / NWM;  // wave tile: TMT*32 tokens x 64 features
+    int mb, nb;
+#ifdef FQ_GEMM_LINEAR_ORDER
     const int nb_n = (N + BN - 1) / BN;
-    const int mb = blockIdx.x / nb_n, nb = blockIdx.x - mb * nb_n;  // consecutive workgroups share the token tile
+    mb = blockIdx.x / nb_n, nb = blockIdx.x - mb * nb_n;
+    if (mb * BM >= M) return;
+#else
+    if (!xcd_tile(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, mb, nb)) return;
+#endif
     const int m0 = mb * BM, n0 = nb * BN;
     const int nk = Kb / BKB;
 
@@ -284,7 +306,7 @@ int fq_launch_gemm_i4(const uint8_t* X, const uint8_t* W, int64_t M, int N, int 
         hipLaunchKernelGGL(fq_gemm_i4_simple_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, X, W, (int)M, N, K / 2, o);
         return (int)hipGetLastError();
     }
-    const int64_t blocks = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int64_t blocks = 8 * ((((M + BM - 1) / BM) * ((N + BN - 1) / BN) + 7) / 8);  // see xcd_tile
     hipLaunchKernelGGL(fq_gemm_i4_kernel, dim3((unsigned)blocks), dim3(GT), 0, stream, X, W, (int)M, N, K / 2, o);
     return (int)hipGetLastError();
 }

@@ -1,4 +1,6 @@
 """Counterpart of deploy/nn/linear.py."""
+import os
+
 import torch
 
 from ... import ops
@@ -12,7 +14,9 @@ class Linear4bit(torch.nn.Module):
     dicts load unchanged.  ``forward`` takes the PackedQuantizedTensor the online transform / Quantizer produced and
     returns fp16: the reference runs deploy.matmul (CUTLASS int4 GEMM -> int32 in HBM) and deploy.sym_dequant as two
     launches (+ a torch add for the bias); here the dequantisation and the bias sit in the GEMM's epilogue
-    (fq_int4_linear_f16), bit-identical to the two-step form."""
+    (fq_int4_linear_f16), bit-identical to the two-step form. With FQ_FP6_GEMM=1 (and K % 128 == 0, N % 16 == 0) the
+    GEMM runs on the FP6 matrix path instead (BF6 holds every INT4 value exactly; same bits out): the weight
+    image is built once and cached, the packed activations are converted by one small launch per call."""
 
     def __init__(self, in_features, out_features, bias=False, dtype=torch.float16):
         super().__init__()
@@ -26,10 +30,30 @@ class Linear4bit(torch.nn.Module):
         else:
             self.bias = None
 
+    def _weight_image(self):
+        """BF6 operand image of ``weight`` for the FP6 matrix path (csrc/fq_gemm_bf6.hip), rebuilt when the buffer is
+        replaced or written in place. Opt-in (FQ_FP6_GEMM=1): measured on MI355X the two paths are within +-10 % of each
+        other, and this one pays a conversion launch per call. None when off or the shape is not covered."""
+        if os.environ.get("FQ_FP6_GEMM") != "1" or not ops.bf6_supported(self.out_features, self.in_features):
+            return None
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        if getattr(self, "_wimg_key", None) != key:
+            self._wimg = ops.int4_to_bf6(self.weight, weights=True)
+            self._wimg_key = key
+        return self._wimg
+
     def forward(self, x):
         assert type(x) == PackedQuantizedTensor  # quantized input is given (linear.py:45)
         q, scales_x = x.quantized_x, x.scales_x
         lead = q.shape[:-1]
+        wimg = self._weight_image() if q.is_cuda else None
+        if wimg is not None:
+            q2 = q.reshape(-1, q.shape[-1]).contiguous()
+            y = ops.bf6_linear(ops.int4_to_bf6(q2), scales_x.reshape(-1).contiguous(), wimg,
+                               self.weight_scales.reshape(-1).to(torch.float16).contiguous(),
+                               None if self.bias is None else self.bias.to(torch.float16),
+                               q2.shape[0], self.out_features, self.in_features)
+            return y.view(*lead, self.out_features)
         y = ops.int4_linear(q.reshape(-1, q.shape[-1]).contiguous(), scales_x.reshape(-1).contiguous(),
                             self.weight, self.weight_scales.reshape(-1).to(torch.float16).contiguous(),
                             None if self.bias is None else self.bias.to(torch.float16))

@@ -354,6 +354,52 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
     return q, s
 
 
+def int4_to_bf6(q: torch.Tensor, weights: bool = False) -> torch.Tensor:
+    """Packed INT4 [rows, K/2] -> the BF6 operand image of the FP6-path GEMM (fq_int4_to_bf6). ``weights``: the image of
+    a Linear4bit.weight (convert once per layer); else of packed activations. K % 64 == 0."""
+    _chk(q, "q", torch.uint8)
+    if q.dim() != 2:
+        raise RuntimeError("int4_to_bf6: expected [rows, K/2]")
+    rows, K = q.shape[0], q.shape[1] * 2
+    nbytes = lib.fq_bf6_blob_bytes(rows, K)
+    if nbytes < 0:
+        raise _lib.FqError(_lib.FQ_EUNSUPPORTED, f"int4_to_bf6: K={K} must be a multiple of 64")
+    blob = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+    if rows:
+        with torch.cuda.device(q.device):
+            check(lib.fq_int4_to_bf6(_ptr(q), rows, K, 1 if weights else 0, _ptr(blob), _stream(q)))
+    return blob
+
+
+def bf6_supported(N: int, K: int) -> bool:
+    return K % 128 == 0 and N % 16 == 0 and K <= (1 << 18)
+
+
+def bf6_matmul(xblob: torch.Tensor, wblob: torch.Tensor, M: int, N: int, K: int) -> torch.Tensor:
+    """int4_matmul on the FP6 matrix path: blobs from int4_to_bf6 -> int32 [M, N], bit-identical."""
+    c = torch.empty((M, N), dtype=torch.int32, device=xblob.device)
+    if M:
+        with torch.cuda.device(xblob.device):
+            check(lib.fq_bf6_gemm_i32(_ptr(xblob), _ptr(wblob), M, N, K, _ptr(c), _stream(xblob)))
+    return c
+
+
+def bf6_linear(xblob: torch.Tensor, x_scale: torch.Tensor, wblob: torch.Tensor, w_scale: torch.Tensor,
+               bias: Optional[torch.Tensor], M: int, N: int, K: int) -> torch.Tensor:
+    """int4_linear on the FP6 matrix path (fq_bf6_linear_f16), bit-identical."""
+    _chk(x_scale, "x_scale"), _chk(w_scale, "w_scale")
+    if x_scale.numel() != M or w_scale.numel() != N:
+        raise RuntimeError("bf6_linear: x_scale must have M elements, w_scale N")
+    if bias is not None:
+        _chk(bias, "bias")
+    y = torch.empty((M, N), dtype=torch.float16, device=xblob.device)
+    if M:
+        with torch.cuda.device(xblob.device):
+            check(lib.fq_bf6_linear_f16(_ptr(xblob), _ptr(x_scale), _ptr(wblob), _ptr(w_scale), _ptr(bias), M, N, K, _ptr(y),
+                                        _stream(xblob)))
+    return y
+
+
 def kv_quant(x: torch.Tensor, trans: Optional[torch.Tensor] = None, clip: Sig = (1.0, 1.0), lac: bool = False,
              return_transformed: bool = False):
     """K/V cache quantisation (fq_kv_quant_f16): x [..., head_dim] fp16 -> (q uint8 [..., head_dim/2], param fp16

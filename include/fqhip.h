@@ -19,6 +19,7 @@
  *   fq_block_quant_f16     deploy/kernels/block_matmul.py:231-311 (block_matmul)
  *   fq_int4_gemm_i32       deploy/kernels/gemm.cu:8-47 (matmul_host) / deploy.matmul
  *   fq_int4_linear_f16     deploy/nn/linear.py:41-56 (Linear4bit.forward = matmul + sym_dequant + bias)
+ *   fq_int4_to_bf6, fq_bf6_gemm_i32, fq_bf6_linear_f16   the same two on the FP6 matrix path (bit-identical results)
  *   fq_hadamard_f16        flatquant/hadamard_utils.py:89-110,132-141 (matmul_hadU[_cuda]),
  *   (fq_hadamard_quant_f16: the same followed by deploy/nn/quantization.py:13-36, fused)
  *                          deploy/functional/online_trans.py:144-151
@@ -161,6 +162,23 @@ int fq_int4_gemm_i32(const void* x, const void* w, int64_t M, int N, int K, void
  */
 int fq_int4_linear_f16(const void* x, const void* x_scale, const void* w, const void* w_scale, const void* bias,
                        int64_t M, int N, int K, void* y, void* stream);
+
+/*
+ * The same GEMM / Linear4bit on the FP6 matrix path (v_mfma_scale_f32_32x32x64_f8f6f4, both operands BF6 = E3M2, unit
+ * block scales): every integer in [-8, 7] is a BF6 value and the fp32 accumulator holds the exact integer sum
+ * (K <= 2^18), so the results are bit-identical to fq_int4_gemm_i32 / fq_int4_linear_f16 — at ~1.4x the sustained
+ * matrix rate of the int8 instruction and without unpack arithmetic. Operands are converted first:
+ *   fq_bf6_blob_bytes(rows, K)            bytes of the converted operand (K % 64 == 0; -1 otherwise)
+ *   fq_int4_to_bf6(q [rows, K/2], rows, K, role, blob)   role 0 = activations (x), 1 = weights (w; once per layer)
+ * The blob layout is private to this library (fragment order of the MFMA operand, csrc/fq_gemm_bf6.hip).
+ *   fq_bf6_gemm_i32 / fq_bf6_linear_f16: as the int4 entry points with blobs in place of x and w;
+ *   K % 128 == 0, N % 16 == 0, K <= 262144, FQ_EUNSUPPORTED otherwise (use the int4 entry points).
+ */
+int64_t fq_bf6_blob_bytes(int64_t rows, int K);
+int fq_int4_to_bf6(const void* q, int64_t rows, int K, int role, void* blob, void* stream);
+int fq_bf6_gemm_i32(const void* xblob, const void* wblob, int64_t M, int N, int K, void* c, void* stream);
+int fq_bf6_linear_f16(const void* xblob, const void* x_scale, const void* wblob, const void* w_scale, const void* bias,
+                      int64_t M, int N, int K, void* y, void* stream);
 
 /*
  * Normalised Hadamard transform over the last axis, n = K * 2^p:

@@ -1,0 +1,104 @@
+"""The INT4 GEMM / Linear4bit on the FP6 matrix path (fq_int4_to_bf6 + fq_bf6_gemm_i32 / fq_bf6_linear_f16): integer
+work carried by exactly representable BF6 values and an fp32 accumulator that stays an integer — the bar is bit-exact
+against the integer oracle and against the int8-path kernel."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from flatquant_amd import ops as _ops
+    return _ops
+
+
+def rand_packed(gen, rows, K, lo=-8, hi=8):
+    q = torch.randint(lo, hi, (rows, K), generator=gen, dtype=torch.int32).numpy()
+    return O.pack_i4(q), q
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 256, 4096), (300, 272, 256), (1, 16, 128), (257, 4096, 512),
+                                   (1000, 1024, 1024), (33, 48, 384), (64, 256, 14336), (31, 32, 128), (513, 528, 640)])
+def test_bf6_gemm_bit_exact(ops, M, N, K):
+    gen = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    xp, xq = rand_packed(gen, M, K)
+    wp, wq = rand_packed(gen, N, K)
+    xb = ops.int4_to_bf6(torch.from_numpy(xp).cuda())
+    wb = ops.int4_to_bf6(torch.from_numpy(wp).cuda(), weights=True)
+    c = ops.bf6_matmul(xb, wb, M, N, K).cpu().numpy()
+    ref = xq.astype(np.int64) @ wq.astype(np.int64).T
+    assert np.array_equal(c, ref.astype(np.int32))
+
+
+def test_every_value_pair_and_extremes(ops):
+    """all 256 (x, w) nibble pairs isolated one per output, then all -8 x -8 at K = 14336 (917504 per output < 2^24)."""
+    vals = np.arange(-8, 8)
+    M = N = 16
+    K = 128
+    xq = np.zeros((M, K), dtype=np.int32)
+    wq = np.zeros((N, K), dtype=np.int32)
+    xq[:, 5] = vals
+    wq[:, 5] = vals
+    xb = ops.int4_to_bf6(torch.from_numpy(O.pack_i4(xq)).cuda())
+    wb = ops.int4_to_bf6(torch.from_numpy(O.pack_i4(wq)).cuda(), weights=True)
+    c = ops.bf6_matmul(xb, wb, M, N, K).cpu().numpy()
+    assert np.array_equal(c, np.outer(vals, vals))
+    M, N, K = 40, 32, 14336
+    xb = ops.int4_to_bf6(torch.from_numpy(O.pack_i4(np.full((M, K), -8, dtype=np.int32))).cuda())
+    wb = ops.int4_to_bf6(torch.from_numpy(O.pack_i4(np.full((N, K), -8, dtype=np.int32))).cuda(), weights=True)
+    assert np.all(ops.bf6_matmul(xb, wb, M, N, K).cpu().numpy() == 64 * K)
+    wb = ops.int4_to_bf6(torch.from_numpy(O.pack_i4(np.full((N, K), 7, dtype=np.int32))).cuda(), weights=True)
+    assert np.all(ops.bf6_matmul(xb, wb, M, N, K).cpu().numpy() == -56 * K)
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(512, 256, 4096, False), (300, 272, 256, True), (129, 1024, 1024, True)])
+def test_bf6_linear_equals_int8_path_and_oracle(ops, M, N, K, bias):
+    gen = torch.Generator().manual_seed(M + N + K)
+    xp, _ = rand_packed(gen, M, K)
+    wp, _ = rand_packed(gen, N, K)
+    sx = (torch.rand(M, generator=gen) * 0.05 + 0.001).half()
+    sw = (torch.rand(N, generator=gen) * 0.02 + 0.0005).half()
+    b = torch.randn(N, generator=gen).half() if bias else None
+    x, w = torch.from_numpy(xp).cuda(), torch.from_numpy(wp).cuda()
+    bb = None if b is None else b.cuda()
+    y = ops.bf6_linear(ops.int4_to_bf6(x), sx.cuda(), ops.int4_to_bf6(w, weights=True), sw.cuda(), bb, M, N, K)
+    y8 = ops.int4_linear(x, sx.cuda(), w, sw.cuda(), bb)
+    assert torch.equal(y, y8)
+    ref = O.linear4bit(xp, sx.numpy(), wp, sw.numpy(), None if b is None else b.numpy())
+    assert np.array_equal(y.cpu().numpy().view(np.uint16), ref.view(np.uint16))
+
+
+def test_module_uses_the_fp6_path_transparently(ops, monkeypatch):
+    import flatquant_amd.deploy as deploy
+    monkeypatch.setenv("FQ_FP6_GEMM", "1")
+    gen = torch.Generator().manual_seed(3)
+    lin = deploy.nn.Linear4bit(512, 384, bias=True).cuda()
+    wp, _ = rand_packed(gen, 384, 512)
+    lin.weight.copy_(torch.from_numpy(wp))
+    lin.weight_scales.copy_((torch.rand(384, 1, generator=gen) * 0.02 + 0.001))
+    lin.bias.copy_(torch.randn(384, generator=gen).half())
+    xp, _ = rand_packed(gen, 2 * 9, 512)
+    p = deploy.PackedQuantizedTensor(torch.from_numpy(xp).cuda().reshape(2, 9, 256),
+                                     (torch.rand(2, 1, 9, generator=gen) * 0.05 + 0.001).half().cuda())
+    y = lin(p)
+    assert lin._weight_image() is not None      # the FP6 path really ran
+    ref = ops.int4_linear(p.quantized_x.reshape(-1, 256), p.scales_x.reshape(-1), lin.weight,
+                          lin.weight_scales.reshape(-1).half(), lin.bias.half()).view(2, 9, 384)
+    assert torch.equal(y, ref)
+    lin.weight.copy_(torch.from_numpy(rand_packed(gen, 384, 512)[0]))      # in-place update: the cached image must follow
+    ref2 = ops.int4_linear(p.quantized_x.reshape(-1, 256), p.scales_x.reshape(-1), lin.weight,
+                           lin.weight_scales.reshape(-1).half(), lin.bias.half()).view(2, 9, 384)
+    assert torch.equal(lin(p), ref2) and not torch.equal(ref, ref2)
+
+
+def test_errors(ops):
+    with pytest.raises(Exception):
+        ops.int4_to_bf6(torch.zeros(4, 16, dtype=torch.uint8, device="cuda"))          # K = 32
+    xb = ops.int4_to_bf6(torch.zeros(4, 32, dtype=torch.uint8, device="cuda"))
+    wb = ops.int4_to_bf6(torch.zeros(16, 32, dtype=torch.uint8, device="cuda"), weights=True)
+    with pytest.raises(Exception):
+        ops.bf6_matmul(xb, wb, 4, 16, 64)                                               # K % 128 != 0
