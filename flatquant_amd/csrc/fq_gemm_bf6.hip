@@ -19,6 +19,7 @@
 // Tiling: 256 x 256 per 8-wave workgroup, wave tile 128 tokens x 64 features (8 accumulator tiles: 6 fragments per 8
 // MFMAs), three LDS stages of 48 KB, counted vmcnt, one barrier per stage — the pipeline of fq_gemm_i4.hip.
 #include "fq_common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(256) void fq_i4_to_bf6_kernel(const uint8_t* __rest
 }
 
 // ---- the GEMM ---------------------------------------------------------------------------------------------------
+template <int ABL>  // measurement builds (wrong results): 1 = no MFMA, 2 = fragment reads of the first stage only, 4 = no DMA after the prologue
 __global__ __launch_bounds__(GT, 2) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB, const uint8_t* __restrict__ WB,
                                                             int M, int N, int KB, GemmOut out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -131,32 +133,36 @@ __global__ __launch_bounds__(GT, 2) void fq_gemm_bf6_kernel(const uint8_t* __res
     const int nk = KB / 2;  // stages of 128 k
     const int mt_last = (M + 31) / 32 - 1, nt_last = (N + 31) / 32 - 1;
 
-    // DMA plan: instruction i = 6 wave + j: operand i / 24 (0 = W), row tile (i % 24) / 3, 1 KB part i % 3 of its 3 KB
-    const unsigned char* gsrc[DPW];
+    // DMA plan: instruction i = 6 wave + j: operand i / 24 (0 = W), row tile (i % 24) / 3, 1 KB part i % 3 of its 3 KB.
+    // The source of an instruction is wave-uniform (SGPR base) + 16 * lane: twelve address VGPRs less than per-lane
+    // pointers — those had pushed the kernel into a spill whose reload sat between the DMA instructions of a stage
+    // behind an s_waitcnt vmcnt(0), i.e. every stage waited for its own loads (found in the ISA, cost ~2x).
+    const unsigned char* gbase[DPW];
 #pragma unroll
     for (int j = 0; j < DPW; ++j) {
         const int i = wave * DPW + j;
         const int op = i / 24, t = (i % 24) / 3, part = i % 3;
-        int64_t rt = (op == 0 ? n0 : m0) / 32 + t;
+        int rt = (op == 0 ? n0 : m0) / 32 + t;
         const int last = op == 0 ? nt_last : mt_last;
         rt = rt < last ? rt : last;  // tiles beyond the matrix re-read its last tile (their outputs are never stored)
-        gsrc[j] = (op == 0 ? WB : XB) + rt * (int64_t)KB * BLOB + part * 1024 + lane * 16;
+        gbase[j] = (op == 0 ? WB : XB) + (int64_t)rt * KB * BLOB + part * 1024;
     }
+    const unsigned voff = (unsigned)lane * 16u;
     const unsigned lds0 = (unsigned)(size_t)(lds_void_b*)smem;
     auto issue_stage = [&](int s) {
         const unsigned dst = lds0 + (unsigned)((s % STAGES) * TILE_BYTES) + (unsigned)(wave * DPW) * 1024u;
 #pragma unroll
         for (int j = 0; j < DPW; ++j) {
-            const unsigned char* src = gsrc[j] + (int64_t)s * SEG;
+            const unsigned char* src = gbase[j] + (int64_t)s * SEG;
             unsigned keep;
             asm volatile(
                 "s_mov_b32 %0, m0\n\t"
-                "s_mov_b32 m0, %2\n\t"
+                "s_mov_b32 m0, %3\n\t"
                 "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %1, off\n\t"
+                "global_load_lds_dwordx4 %1, %2\n\t"
                 "s_mov_b32 m0, %0"
                 : "=&s"(keep)
-                : "v"(src), "s"(__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)j * 1024u)))
+                : "v"(voff), "s"(src), "s"(__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)j * 1024u)))
                 : "memory");
         }
     };
@@ -184,9 +190,14 @@ __global__ __launch_bounds__(GT, 2) void fq_gemm_bf6_kernel(const uint8_t* __res
         i32x8 wf[2], xf[TMT];                                                                                        \
         _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) wf[tn] = FQ_FRAG(RW[tn]);                                   \
         _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm) xf[tm] = FQ_FRAG(RX[tm]);                                 \
+        if (ABL & 1) {                                                                                               \
+            _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm)      \
+                acc[tn][tm][0] += (float)(wf[tn][0] ^ xf[tm][5]);                                                    \
+        } else {                                                                                                     \
         _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm)          \
             acc[tn][tm] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[tn], xf[tm], acc[tn][tm], 3, 3, 0,       \
                                                                           0x7f7f7f7f, 0, 0x7f7f7f7f);               \
+        }                                                                                                            \
     }
 #pragma unroll
     for (int p = 0; p < STAGES; ++p)
@@ -201,18 +212,21 @@ __global__ __launch_bounds__(GT, 2) void fq_gemm_bf6_kernel(const uint8_t* __res
     FQ_READ(smem, 0, r0w, r0x)
     for (int s = 0; s < nk; ++s) {
         const unsigned char* st = smem + (s % STAGES) * TILE_BYTES;
-        FQ_READ(st, 1, r1w, r1x)
+        if (!(ABL & 2) || s == 0) FQ_READ(st, 1, r1w, r1x)
         FQ_COMPUTE(r0w, r0x)
+        __builtin_amdgcn_sched_barrier(0);  // these MFMAs cover the reads above; hipcc otherwise sinks them below the barrier
         if (s + 1 < nk) {
             const int younger = nk - 2 - s < STAGES - 2 ? nk - 2 - s : STAGES - 2;
             if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(DPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // every wave holds all of stage s in registers: its buffer is free
-            if (s + STAGES < nk) issue_stage(s + STAGES);
+            if (s + STAGES < nk && !(ABL & 4)) issue_stage(s + STAGES);
             const unsigned char* sn = smem + ((s + 1) % STAGES) * TILE_BYTES;
-            FQ_READ(sn, 0, r0w, r0x)
+            if (!(ABL & 2)) FQ_READ(sn, 0, r0w, r0x)
         }
+        __builtin_amdgcn_sched_barrier(0);
         FQ_COMPUTE(r1w, r1x)
+        __builtin_amdgcn_sched_barrier(0);
     }
 #undef FQ_READ
 #undef FQ_FRAG
@@ -282,14 +296,25 @@ int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, in
     o.srow = srow;
     o.scol = scol;
     o.bias = bias;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fq_gemm_bf6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  STAGES * TILE_BYTES);
-        attr_set = true;
-    }
     const int64_t blocks = 8 * ((((M + BM - 1) / BM) * ((N + BN - 1) / BN) + 7) / 8);  // see xcd_tile
-    hipLaunchKernelGGL(fq_gemm_bf6_kernel, dim3((unsigned)blocks), dim3(GT), STAGES * TILE_BYTES, stream, xblob, wblob, (int)M,
-                       N, K / 64, o);
+    const char* e = getenv("FQ_GEMM_ABLATE");
+    const int abl = e ? atoi(e) : 0;
+#define FQ_LAUNCH(A)                                                                                                 \
+    {                                                                                                                \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fq_gemm_bf6_kernel<A>),                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * TILE_BYTES);              \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL(fq_gemm_bf6_kernel<A>, dim3((unsigned)blocks), dim3(GT), STAGES * TILE_BYTES, stream, xblob, \
+                           wblob, (int)M, N, K / 64, o);                                                             \
+    }
+    if (abl == 1) FQ_LAUNCH(1)
+    else if (abl == 2) FQ_LAUNCH(2)
+    else if (abl == 4) FQ_LAUNCH(4)
+    else if (abl == 6) FQ_LAUNCH(6)
+    else FQ_LAUNCH(0)
+#undef FQ_LAUNCH
     return (int)hipGetLastError();
 }

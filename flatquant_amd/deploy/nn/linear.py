@@ -14,7 +14,7 @@ class Linear4bit(torch.nn.Module):
     dicts load unchanged.  ``forward`` takes the PackedQuantizedTensor the online transform / Quantizer produced and
     returns fp16: the reference runs deploy.matmul (CUTLASS int4 GEMM -> int32 in HBM) and deploy.sym_dequant as two
     launches (+ a torch add for the bias); here the dequantisation and the bias sit in the GEMM's epilogue
-    (fq_int4_linear_f16), bit-identical to the two-step form. With FQ_FP6_GEMM=1 (and K % 128 == 0, N % 16 == 0) the
+    (fq_int4_linear_f16), bit-identical to the two-step form. For K % 128 == 0, N % 16 == 0, N >= 2048 the
     GEMM runs on the FP6 matrix path instead (BF6 holds every INT4 value exactly; same bits out): the weight
     image is built once and cached, the packed activations are converted by one small launch per call."""
 
@@ -32,9 +32,13 @@ class Linear4bit(torch.nn.Module):
 
     def _weight_image(self):
         """BF6 operand image of ``weight`` for the FP6 matrix path (csrc/fq_gemm_bf6.hip), rebuilt when the buffer is
-        replaced or written in place. Opt-in (FQ_FP6_GEMM=1): measured on MI355X the two paths are within +-10 % of each
-        other, and this one pays a conversion launch per call. None when off or the shape is not covered."""
-        if os.environ.get("FQ_FP6_GEMM") != "1" or not ops.bf6_supported(self.out_features, self.in_features):
+        replaced or written in place. Used when the shape is covered and wide enough to amortise the per-call conversion
+        of the activations (out_features >= 2048: measured 25-30 % faster than the int8 path there, slower for the
+        1024-wide k/v projections); FQ_FP6_GEMM=0 turns it off, =1 forces it for every covered shape."""
+        mode = os.environ.get("FQ_FP6_GEMM", "")
+        if mode == "0" or not ops.bf6_supported(self.out_features, self.in_features):
+            return None
+        if mode != "1" and self.out_features < 2048:
             return None
         key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
         if getattr(self, "_wimg_key", None) != key:
