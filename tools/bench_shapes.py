@@ -74,6 +74,43 @@ def main():
             print(f"{'int4 linear (gemm + dequant)':34s} {'M=%d N=%d K=%d' % (ROWS, N_, K_):22s} {us:9.1f} us  {tops:8.0f} TOP/s")
             us = timeit(lambda i: ops.int4_matmul(xq, wq), steps=20)
             print(f"{'int4 gemm -> int32':34s} {'M=%d N=%d K=%d' % (ROWS, N_, K_):22s} {us:9.1f} us  {2.0 * ROWS * N_ * K_ / us / 1e6:8.0f} TOP/s")
+            wb, xb = ops.int4_to_bf6(wq, weights=True), ops.int4_to_bf6(xq)
+            us = timeit(lambda i: ops.bf6_linear(xb, sx, wb, sw, None, ROWS, N_, K_), steps=20)
+            uc = timeit(lambda i: ops.int4_to_bf6(xq), steps=20)
+            print(f"{'int4 linear, FP6 matrix path':34s} {'M=%d N=%d K=%d' % (ROWS, N_, K_):22s} {us:9.1f} us  "
+                  f"{2.0 * ROWS * N_ * K_ / us / 1e6:8.0f} TOP/s  (+ {uc:.1f} us to convert the activations)")
+            del wb, xb
+    # fusions either side of the path
+    xs = [torch.randn(ROWS, 4096, generator=g, device="cuda", dtype=torch.float16) for _ in range(NB)]
+    L = (torch.randn(64, 64, generator=g, device="cuda") / 8).half()
+    R = (torch.randn(64, 64, generator=g, device="cuda") / 8).half()
+    us = timeit(lambda i: ops.rmsnorm(xs[i % NB], 1e-5))
+    line("rmsnorm", "d=4096", us, 4.0 * 4096, 4096)
+    us = timeit(lambda i: ops.rmsnorm_kron_quant(xs[i % NB], 1e-5, L, R, sig, FQ_OUT_PACKED | FQ_NO_CLAMP0))
+    line("rmsnorm + kron + quant, one launch", "d=4096 (64x64)", us, 2.5 * 4096 + 2, 4096)
+    us = timeit(lambda i: ops.rmsnorm_kron_quant(xs[i % NB], 1e-5, L, R, sig * 3, FQ_OUT_PACKED | FQ_NO_CLAMP0))
+    line("rmsnorm + kron + 3 clip sets", "d=4096 (64x64)", us, 2.0 * 4096 + 3 * (2048 + 2), 4096)
+    del xs
+    gs = [torch.randn(ROWS, 14336, generator=g, device="cuda", dtype=torch.float16) for _ in range(2)]
+    up = torch.randn(ROWS, 14336, generator=g, device="cuda", dtype=torch.float16)
+    M_, N_ = get_decompose_dim(14336)
+    L = (torch.randn(M_, M_, generator=g, device="cuda") / M_ ** 0.5).half()
+    R = (torch.randn(N_, N_, generator=g, device="cuda") / N_ ** 0.5).half()
+    us = timeit(lambda i: ops.silu_mul(gs[i % 2], up))
+    line("silu.mul", "d=14336", us, 6.0 * 14336, 14336)
+    us = timeit(lambda i: ops.silu_mul_kron_quant(gs[i % 2], up, L, R, sig, FQ_OUT_PACKED | FQ_NO_CLAMP0))
+    line("silu.mul + kron + quant, one launch", f"d=14336 ({M_}x{N_})", us, 4.5 * 14336 + 2, 14336)
+    hk, K = get_hadK(14336)
+    us = timeit(lambda i: ops.hadamard_quant(gs[i % 2], K, hk.half().cuda(), sig[0], up=up))
+    line("silu.mul + hadamard + quantizer", "n=14336 (K=28)", us, 4.5 * 14336 + 2, 14336)
+    del gs, up
+    ks = [torch.randn(ROWS * 8, 128, generator=g, device="cuda", dtype=torch.float16) for _ in range(NB)]
+    T = (torch.randn(128, 128, generator=g, device="cuda") / 128 ** 0.5).half()
+    us = timeit(lambda i: ops.kv_quant(ks[i % NB], T))
+    line("K transform + asym INT4 pack", "16384 x 8 heads x 128", us, 2.5 * 128 + 4, 128, ROWS * 8)
+    us = timeit(lambda i: ops.kv_quant(ks[i % NB]))
+    line("V asym INT4 pack", "16384 x 8 heads x 128", us, 2.5 * 128 + 4, 128, ROWS * 8)
+    del ks
     for hd, H in ((128, 32), (128, 64)):
         xs = [torch.randn(ROWS, hd, H, generator=g, device="cuda", dtype=torch.float16) for _ in range(NB)]
         P = (torch.randn(H, H, generator=g, device="cuda") / H ** 0.5).half()
