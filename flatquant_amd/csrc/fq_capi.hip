@@ -27,6 +27,8 @@ int64_t fq_bf6_blob_bytes(int64_t rows, int K);  // fq_gemm_bf6.hip (exported as
 int fq_launch_i4_to_bf6(const uint8_t* q, int64_t rows, int K, int perm, uint8_t* blob, int n_cu, hipStream_t stream);
 int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, int N, int K, int32_t* c, f16* y,
                        const f16* srow, const f16* scol, const f16* bias, hipStream_t stream);
+int fq_launch_kron_any(int flags, const f16* x, const f16* left, const f16* right, const f16* diag, int64_t rows, int M,
+                       int N, const FqQuantOut& out, int n_cu, hipStream_t stream);
 int fq_launch_silu_mul(const f16* gate, const f16* up, f16* y, int64_t n, int n_cu, hipStream_t stream);
 int fq_launch_silu_hadamard_quant(const f16* gate, const f16* up, int64_t rows, int n, int K, const f16* hadK, float scale,
                                   float sig_max, float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream);
@@ -167,6 +169,13 @@ int fq_kron_quant_f16(const void* x, const void* left, const void* right, const 
     if (rc == -1001)
         return fail(FQ_EINVAL, "fq_kron_quant_f16: workspace of %lld bytes required for M=%d N=%d (got %lld)",
                     (long long)fq_kron_generic_workspace_bytes(M, N), M, N, (long long)(workspace ? workspace_bytes : 0));
+    if (rc == -1000) {  // no MFMA kernel for this pair: the any-shape kernel (csrc/fq_kron_any.hip), no workspace
+        rc = fq_launch_kron_any(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag, rows, M, N, o,
+                                n_cu, (hipStream_t)stream);
+        if (rc == -1000)
+            return fail(FQ_EUNSUPPORTED, "fq_kron_quant_f16: no kernel for factors (%d, %d): M, N <= 256 and M*N <= 32768", M, N);
+        return check_launch(rc, "fq_kron_quant_f16[any]");
+    }
     return check_launch(rc, "fq_kron_quant_f16[generic]");
 }
 
@@ -261,7 +270,11 @@ int fq_kron_prepare_f16(const void* left, const void* right, int M, int N, void*
 
 int64_t fq_kron_workspace_bytes(int M, int N) {
     if (M == 64 && N == 64) return 0;
-    if ((N & 15) || M < 1 || M > 128 || N < 16 || N > 256 || ((M * N / 2) & 15)) return FQ_EUNSUPPORTED;
+    if ((N & 15) || M < 1 || M > 128 || N < 16 || N > 256 || ((M * N / 2) & 15)) {
+        // pairs only the any-shape kernel takes (csrc/fq_kron_any.hip): no workspace
+        if (M >= 1 && N >= 1 && M <= 256 && N <= 256 && (int64_t)M * N <= 32768) return 0;
+        return FQ_EUNSUPPORTED;
+    }
     return fq_kron_generic_workspace_bytes(M, N);
 }
 

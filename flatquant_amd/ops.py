@@ -126,7 +126,7 @@ def _kron_workspace(device: torch.device, M: int, N: int, left: torch.Tensor, ri
     caller registers a fresh workspace (_kron_workspace_commit) once the launch that fills it has been accepted."""
     nbytes = int(lib.fq_kron_workspace_bytes(M, N))
     if nbytes < 0:
-        raise _lib.FqError(nbytes, f"no kernel for Kronecker factors ({M}, {N}): need N % 16 == 0, M <= 128, N <= 256")
+        raise _lib.FqError(nbytes, f"no kernel for Kronecker factors ({M}, {N}): need M, N <= 256 and M * N <= 32768")
     if nbytes == 0:
         return None, 0, False, None
     key = (device.index, torch.cuda.current_stream(device).cuda_stream, M, N,

@@ -125,7 +125,8 @@ int fq_silu_mul_kron_quant_f16(const void* gate, const void* up, const void* lef
 int fq_silu_mul_f16(const void* gate, const void* up, void* y, int64_t n, void* stream);
 
 /* Bytes of device workspace fq_kron_quant_f16 needs for factor sizes (M, N); 0 when none is needed;
- * negative (FQ_EUNSUPPORTED) when no kernel handles the shape (needs N % 16 == 0, M <= 128, N <= 256). */
+ * negative (FQ_EUNSUPPORTED) when no kernel handles the shape. MFMA kernels: N % 16 == 0, M <= 128, N <= 256,
+ * M*N/2 % 16 == 0; every other pair with M, N <= 256 and M*N <= 32768 runs a plain-FMA kernel (slow, no workspace). */
 int64_t fq_kron_workspace_bytes(int M, int N);
 
 /* Re-pack left [M,M] / right [N,N] into the MFMA fragment image fq_kron_quant_f16 consumes, once, for callers whose

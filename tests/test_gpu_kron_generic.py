@@ -151,8 +151,43 @@ def test_single_signed_token_no_clamp_masks_padding(ops):
 def test_unsupported_shape_raises(ops):
     from flatquant_amd._lib import FqError
     x = torch.randn(2, 60 * 63).half().cuda()
-    with pytest.raises(FqError):
+    with pytest.raises(FqError):                               # odd element count: nothing to pack two per byte
         ops.kron_quant(x, torch.eye(60).half().cuda(), torch.eye(63).half().cuda())
+    with pytest.raises(FqError):                               # beyond even the any-shape kernel (M * N > 32768)
+        ops.kron_quant(torch.zeros(1, 200 * 200).half().cuda(), torch.eye(200).half().cuda(), torch.eye(200).half().cuda())
+
+
+@pytest.mark.parametrize("M,N", [(128, 148), (144, 192), (168, 176), (60, 62), (3, 6), (130, 16), (20, 12)])
+def test_any_shape_kernel(ops, M, N):
+    """Factor pairs no MFMA kernel takes (Qwen2.5 ffn widths 18944 = 128 x 148, 27648 = 144 x 192, 29568 = 168 x 176,
+    odd ones) run the plain-FMA kernel (csrc/fq_kron_any.hip): same bars — transform within 1e-3 of the row maximum,
+    every quantiser output bit-exact on the kernel's own transform, packed result vs the oracle pipeline."""
+    gen = torch.Generator().manual_seed(M * 1000 + N)
+    rows = 5
+    x = torch.randn(rows, M * N, generator=gen).half()
+    x[1] = 0
+    x[2] = x[2].abs()
+    L = (torch.randn(M, M, generator=gen) / (M ** 0.5)).half()
+    Rm = (torch.randn(N, N, generator=gen) / (N ** 0.5)).half()
+    sigs = [(0.97, 0.9), (1.0, 1.0)]
+    o = ops.kron_quant(x.cuda(), L.cuda(), Rm.cuda(), sigs, T | P | F | R16)
+    y16 = o.y.cpu().numpy()
+    y32 = O.kron_transform(x.numpy(), L.numpy(), Rm.numpy()).reshape(rows, -1)
+    den = np.abs(y32).max(axis=1, keepdims=True) + 1e-30
+    assert np.max(np.abs(y16.astype(np.float32) - y32) / den) <= 1e-3
+    for ci, (smax, smin) in enumerate(sigs):
+        ref = O.quant_outputs(y16.astype(np.float32), smax, smin)
+        assert np.array_equal(o.q[ci].cpu().numpy(), ref["packed"])
+        assert np.array_equal(o.scale[ci].cpu().numpy(), ref["scale16"])
+        assert np.array_equal(o.fq[ci].cpu().numpy(), ref["fq"])
+    o2 = ops.kron_quant(x.cuda(), L.cuda(), Rm.cuda(), [sigs[0]], P | NC0)
+    ref = O.kron_quant(x.numpy(), L.numpy(), Rm.numpy(), sigs[0][0], sigs[0][1], clamp0=False)
+    q = O.unpack_i4(o2.q[0].cpu().numpy())
+    assert mismatch(q, ref["q"]) <= 2e-3 and np.max(np.abs(q - ref["q"].astype(np.int32))) <= 1
+    d = torch.rand(M * N, generator=gen).half() + 0.5
+    od = ops.kron_quant(x.cuda(), L.cuda(), Rm.cuda(), flags=T, diag=d.cuda()).y.cpu().numpy()
+    yd = O.kron_transform((x * d).numpy(), L.numpy(), Rm.numpy()).reshape(rows, -1)
+    assert np.max(np.abs(od.astype(np.float32) - yd) / (np.abs(yd).max(axis=1, keepdims=True) + 1e-30)) <= 1e-3
 
 
 def test_prepared_workspace_reuse_and_invalidation(ops):
