@@ -50,9 +50,18 @@ struct XMask {
 
 // the six cross-lane butterfly stages on one register (14 VALU). "s_nop 1": a VALU result needs two wait states
 // before a DPP / permlane read of it.
+template <int XS = 6>  // XS: how many of the stages (lane ^ 1, 2, 4, 8, 16, 32) to run: vectors of 8 * 2^XS elements
 __device__ __forceinline__ float xlane(float v, const XMask& k) {
     v = flip(v, k.m[0]) + dppf<0xB1>(v);  // lane ^ 1: quad_perm [1,0,3,2]; lanes with the bit set need partner - own
     v = flip(v, k.m[1]) + dppf<0x4E>(v);  // lane ^ 2: quad_perm [2,3,0,1]
+    if (XS == 3) {  // lane ^ 4 only
+        float r;
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                     "v_sub_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa"
+                     : "=&v"(r) : "v"(v));
+        return r;
+    }
     {   // lane ^ 4 and lane ^ 8: the partner sits one / two banks (groups of 4 lanes) away -> row shifts, one masked add
         // for the lower lanes of each pair (own + partner) and one masked sub for the upper ones (partner - own)
         float r;
@@ -65,12 +74,14 @@ __device__ __forceinline__ float xlane(float v, const XMask& k) {
                      "v_sub_f32_dpp %0, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xc"
                      : "=&v"(v) : "v"(r));
     }
+    if (XS == 4) return v;
     {   // lane ^ 16: after the swap, a = value of the lower lane of the pair, b = of the upper one, in BOTH lanes' view
         // (even rows keep a = own and receive b = partner; odd rows receive a = partner and keep b = own)
         float a = v, b = v;
         asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
         v = __builtin_fmaf(b, k.sgn[0], a);  // a +- b, one rounding
     }
+    if (XS == 5) return v;
     {   // lane ^ 32: same with the wave's halves
         float a = v, b = v;
         asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
@@ -95,14 +106,14 @@ __device__ __forceinline__ void bfly8(float (&v)[8]) {
 }
 
 // FWHT of a length 512*CH vector held as v[chunk][8] (see the header for the element mapping)
-template <int CH>
+template <int CH, int XS = 6>
 __device__ __forceinline__ void fwht_wave(float (&v)[CH][8], const XMask& k) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) bfly8<3>(v[j]);
 #pragma unroll
     for (int j = 0; j < CH; ++j)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[j][e] = xlane(v[j][e], k);
+        for (int e = 0; e < 8; ++e) v[j][e] = xlane<XS>(v[j][e], k);
 #pragma unroll
     for (int s = 1; s < CH; s <<= 1)
 #pragma unroll
@@ -163,14 +174,32 @@ __device__ __forceinline__ void minmax8(f16x8 v, float& mx, float& mn) {
     }
 }
 
-// ---- K == 1: one wave per row ----
-template <int CH, bool QUANT, bool SILU = false>
+// ---- K == 1: one wave per row (n >= 512), or SUB = 512 / n rows per wave (n = 64, 128, 256: XS cross-lane stages) ----
+template <int CH, bool QUANT, bool SILU = false, int SUB = 1>
 __global__ __launch_bounds__(256) void fq_had_pow2_kernel(const f16* __restrict__ x, f16* __restrict__ y, int64_t rows,
                                                           float scale, HadQuant hq) {
-    constexpr int n = 512 * CH;
+    static_assert(SUB == 1 || (CH == 1 && !QUANT), "short vectors: one chunk per lane, no fused quantiser");
+    constexpr int n = 512 * CH / SUB;
+    constexpr int XS = SUB == 1 ? 6 : SUB == 2 ? 5 : SUB == 4 ? 4 : 3;
     const int lane = threadIdx.x & 63;
     const XMask k(lane);
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    if (SUB > 1) {  // consecutive rows are contiguous: a wave's 512 elements are rows SUB * g .. SUB * g + SUB - 1
+        const int64_t groups = (rows + SUB - 1) / SUB;
+        for (int64_t g = wave_id; g < groups; g += n_waves) {
+            const bool ok = g * SUB + lane / (64 / SUB) < rows;
+            float v[1][8];
+            f16x8 hv = {0};
+            if (ok) hv = __builtin_bit_cast(f16x8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + g * 512 + lane * 8)));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[0][e] = (float)hv[e];
+            fwht_wave<1, XS>(v, k);
+            f16x8 o[1];
+            to_f16<1>(v, scale, o);
+            if (ok) *reinterpret_cast<uint4*>(y + g * 512 + lane * 8) = __builtin_bit_cast(uint4, o[0]);
+        }
+        return;
+    }
     for (int64_t row = wave_id; row < rows; row += n_waves) {
         float v[CH][8];
         load_vec<CH, SILU>(x + row * n, SILU ? hq.up + row * n : nullptr, lane, v);
@@ -203,11 +232,13 @@ struct KmixGeom {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <int CH, bool QUANT, bool SILU = false>
+template <int CH, bool QUANT, bool SILU = false, int SUB = 1>
 __global__ __launch_bounds__(256) void fq_had_kmix_kernel(const f16* __restrict__ x, f16* __restrict__ y, int64_t rows,
                                                           KmixGeom g, const f16* __restrict__ hadK, float scale,
                                                           HadQuant hq) {
-    constexpr int P = 512 * CH;
+    static_assert(SUB == 1 || (CH == 1 && !QUANT && !SILU), "short sub-vectors: one chunk per lane, plain output");
+    constexpr int P = 512 * CH / SUB;  // SUB > 1: P = 256, 128, 64 and a wave transforms SUB consecutive sub-vectors at once
+    constexpr int XS = SUB == 1 ? 6 : SUB == 2 ? 5 : SUB == 4 ? 4 : 3;
     constexpr int PITCH = P + 8;  // fp16 elements per image row: +16 bytes skews consecutive k rows across the banks
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f16* V = reinterpret_cast<f16*>(smem);                                   // [KP][PITCH]
@@ -251,12 +282,29 @@ __global__ __launch_bounds__(256) void fq_had_kmix_kernel(const f16* __restrict_
         u32x4 raw2[SILU ? CH : 1];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            raw[j] = wave < K ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xr + (int64_t)wave * P + j * 512 + lane * 8))
+            raw[j] = (SUB == 1 && wave < K) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xr + (int64_t)wave * P + j * 512 + lane * 8))
                               : u32x4{0, 0, 0, 0};
             if (SILU)
                 raw2[j] = wave < K ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ur + (int64_t)wave * P + j * 512 + lane * 8))
                                    : u32x4{0, 0, 0, 0};
         }
+        if (SUB > 1) {
+            // sub-vectors are contiguous, so group kg (sub-vectors SUB kg ..) is one coalesced 1 KB load like a P = 512
+            // vector; lanes of sub-vectors beyond K (last group) stay out of the load and the image
+            const int sub = lane / (64 / SUB), sl = lane % (64 / SUB);
+            for (int kg = wave; kg * SUB < K; kg += 4) {
+                const int k = kg * SUB + sub;
+                float v[1][8];
+                f16x8 hv = {0};
+                if (k < K) hv = __builtin_bit_cast(f16x8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xr + (int64_t)kg * 512 + lane * 8)));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[0][e] = (float)hv[e];
+                fwht_wave<1, XS>(v, km);
+                f16x8 o[1];
+                to_f16<1>(v, scale, o);
+                if (k < K) *reinterpret_cast<uint4*>(V + k * PITCH + sl * 8) = __builtin_bit_cast(uint4, o[0]);
+            }
+        } else
         for (int k = wave; k < K; k += 4) {
             float v[CH][8];
 #pragma unroll
@@ -361,17 +409,17 @@ __global__ __launch_bounds__(256) void fq_had_kmix_kernel(const f16* __restrict_
     }
 }
 
-template <int CH, bool QUANT, bool SILU>
+template <int CH, bool QUANT, bool SILU, int SUB = 1>
 int launch_pow2(const f16* x, f16* y, int64_t rows, float scale, const HadQuant& hq, int n_cu, hipStream_t stream) {
-    int64_t blocks = (rows + 3) / 4;
+    int64_t blocks = ((rows + SUB - 1) / SUB + 3) / 4;
     const int64_t cap = (int64_t)n_cu * (CH <= 8 ? 4 : 2);  // 16 / 8 waves per CU
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((fq_had_pow2_kernel<CH, QUANT, SILU>), dim3((unsigned)blocks), dim3(256), 0, stream, x, y, rows, scale, hq);
+    hipLaunchKernelGGL((fq_had_pow2_kernel<CH, QUANT, SILU, SUB>), dim3((unsigned)blocks), dim3(256), 0, stream, x, y, rows, scale, hq);
     return (int)hipGetLastError();
 }
 
-template <int CH, bool QUANT, bool SILU>
+template <int CH, bool QUANT, bool SILU, int SUB = 1>
 int launch_kmix(const f16* x, f16* y, int64_t rows, int K, const f16* hadK, float scale, const HadQuant& hq, int n_cu,
                 hipStream_t stream) {
     KmixGeom g;
@@ -379,9 +427,9 @@ int launch_kmix(const f16* x, f16* y, int64_t rows, int K, const f16* hadK, floa
     g.KP = (K + 15) / 16 * 16;
     g.KT = (K + 31) / 32;
     if (QUANT && g.KT > 2) return -1000;  // the fused form keeps a wave's tiles in registers (sized for KT <= 2)
-    const size_t lds = (size_t)g.KP * (512 * CH + 8) * 2 + (size_t)(g.KP / 16) * g.KT * 1024 + 64;
+    const size_t lds = (size_t)g.KP * (512 * CH / SUB + 8) * 2 + (size_t)(g.KP / 16) * g.KT * 1024 + 64;
     if (lds > 160 * 1024) return -1000;
-    auto kern = fq_had_kmix_kernel<CH, QUANT, SILU>;
+    auto kern = fq_had_kmix_kernel<CH, QUANT, SILU, SUB>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -409,12 +457,23 @@ int dispatch_reg(const f16* x, f16* y, int64_t rows, int n, int K, const f16* ha
             case 2048: return launch_pow2<4, QUANT, SILU>(x, y, rows, scale, hq, n_cu, stream);
             case 4096: return launch_pow2<8, QUANT, SILU>(x, y, rows, scale, hq, n_cu, stream);
             case 8192: return launch_pow2<16, QUANT, SILU>(x, y, rows, scale, hq, n_cu, stream);
-            default: return -1000;
+            default: break;
         }
+        if (!QUANT && !SILU) {  // short vectors (e.g. head_dim 128): several rows per wave
+            if (P == 256) return launch_pow2<1, false, false, 2>(x, y, rows, scale, hq, n_cu, stream);
+            if (P == 128) return launch_pow2<1, false, false, 4>(x, y, rows, scale, hq, n_cu, stream);
+            if (P == 64) return launch_pow2<1, false, false, 8>(x, y, rows, scale, hq, n_cu, stream);
+        }
+        return -1000;
     }
     if (K > 192) return -1000;
     if (P == 512) return launch_kmix<1, QUANT, SILU>(x, y, rows, K, hadK, scale, hq, n_cu, stream);
     if (P == 1024) return launch_kmix<2, QUANT, SILU>(x, y, rows, K, hadK, scale, hq, n_cu, stream);
+    if (!QUANT && !SILU) {  // 11008 = 172 x 64, 5120 = 40 x 128, 7168 = 28 x 256, 18944 = 148 x 128 ...
+        if (P == 256) return launch_kmix<1, false, false, 2>(x, y, rows, K, hadK, scale, hq, n_cu, stream);
+        if (P == 128) return launch_kmix<1, false, false, 4>(x, y, rows, K, hadK, scale, hq, n_cu, stream);
+        if (P == 64) return launch_kmix<1, false, false, 8>(x, y, rows, K, hadK, scale, hq, n_cu, stream);
+    }
     return -1000;
 }
 
