@@ -32,8 +32,12 @@ constexpr int SEG = 2 * BLOB;                  // a row tile's two blobs of one 
 constexpr int OPB = 8 * SEG;                   // one operand's share of a stage: 8 row tiles
 constexpr int TILE_BYTES = 2 * OPB;            // 48 KB: [W tiles 0..7][X tiles 0..7]
 constexpr int STAGES = 3;
-constexpr int GW = 8, GT = GW * 64;
-constexpr int TMT = 4;                         // token tiles per wave (2 waves along tokens, 4 along features)
+#ifndef FQ_BF6_WAVES
+#define FQ_BF6_WAVES 8   // 8: 2 x 4 waves of 128 x 64 (2 per SIMD); 16: 4 x 4 waves of 64 x 64 (4 per SIMD, <= 128 VGPRs)
+#endif
+constexpr int GW = FQ_BF6_WAVES, GT = GW * 64;
+constexpr int NWM = GW / 4;                    // waves along the token dimension (4 along the feature dimension)
+constexpr int TMT = BM / 32 / NWM;             // token tiles per wave
 constexpr int DPW = (TILE_BYTES / 1024) / GW;  // DMA instructions per wave and stage: 6
 
 __device__ __forceinline__ int prow(int c) { return ((c >> 2) & 1) * 16 + (c & 3) + 4 * (c >> 3); }
@@ -121,12 +125,12 @@ __global__ __launch_bounds__(256) void fq_i4_to_bf6_kernel(const uint8_t* __rest
 
 // ---- the GEMM ---------------------------------------------------------------------------------------------------
 template <int ABL>  // measurement builds (wrong results): 1 = no MFMA, 2 = fragment reads of the first stage only, 4 = no DMA after the prologue
-__global__ __launch_bounds__(GT, 2) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB, const uint8_t* __restrict__ WB,
+__global__ __launch_bounds__(GT, GW / 4) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB, const uint8_t* __restrict__ WB,
                                                             int M, int N, int KB, GemmOut out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;  // wave tile: tokens 128 wm .., features 64 wn ..
+    const int wm = wave % NWM, wn = wave / NWM;  // wave tile: tokens (32 TMT) wm .., features 64 wn ..
     int mb, nb;
     if (!xcd_tile(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, mb, nb)) return;
     const int m0 = mb * BM, n0 = nb * BN;
