@@ -38,7 +38,12 @@ constexpr int STAGES = 3;
 constexpr int GW = FQ_BF6_WAVES, GT = GW * 64;
 constexpr int NWM = GW / 4;                    // waves along the token dimension (4 along the feature dimension)
 constexpr int TMT = BM / 32 / NWM;             // token tiles per wave
-constexpr int DPW = (TILE_BYTES / 1024) / GW;  // DMA instructions per wave and stage: 6
+#ifndef FQ_BF6_DMA_WAVES
+#define FQ_BF6_DMA_WAVES 8   // waves that issue the DMA. (4 = one per SIMD, so that the two waves of a SIMD leave each barrier
+                             // differently loaded and stop marching in step: measured no difference, 226 vs 224 us)
+#endif
+constexpr int DW = FQ_BF6_DMA_WAVES;
+constexpr int DPW = (TILE_BYTES / 1024) / DW;  // DMA instructions per issuing wave and stage
 
 __device__ __forceinline__ int prow(int c) { return ((c >> 2) & 1) * 16 + (c & 3) + 4 * (c >> 3); }
 
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(GT, GW / 4) void fq_gemm_bf6_kernel(const uint8_t* 
     const unsigned char* gbase[DPW];
 #pragma unroll
     for (int j = 0; j < DPW; ++j) {
-        const int i = wave * DPW + j;
+        const int i = (wave < DW ? wave : 0) * DPW + j;
         const int op = i / 24, t = (i % 24) / 3, part = i % 3;
         int rt = (op == 0 ? n0 : m0) / 32 + t;
         const int last = op == 0 ? nt_last : mt_last;
@@ -154,6 +159,7 @@ __global__ __launch_bounds__(GT, GW / 4) void fq_gemm_bf6_kernel(const uint8_t* 
     const unsigned voff = (unsigned)lane * 16u;
     const unsigned lds0 = (unsigned)(size_t)(lds_void_b*)smem;
     auto issue_stage = [&](int s) {
+        if (wave >= DW) return;  // (their vmcnt waits below find nothing outstanding and fall through)
         const unsigned dst = lds0 + (unsigned)((s % STAGES) * TILE_BYTES) + (unsigned)(wave * DPW) * 1024u;
 #pragma unroll
         for (int j = 0; j < DPW; ++j) {
