@@ -284,10 +284,14 @@ __global__ __launch_bounds__(256) void fq_kron_generic_kernel(const f16* __restr
 // Barriers per token: stage written | statistics exchanged (= stage free) | output stage complete.
 // ---------------------------------------------------------------------------------------------------------------
 // OCC = workgroups per CU the register allocation must leave room for (waves per SIMD = OCC * WAVES / 4).
-template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false>
+// CTF >= 0: the OUTPUT-SET bits of `flags` are this compile-time constant (packed-only builds of the deploy shapes: the
+// transform / fake-quant / fp16-quantiser branches, their register copies and exec-mask juggling drop out); the
+// run-time bits (FQ_ROUND_Y_F16, FQ_NO_CLAMP0, measurement bits) still come from the argument.
+template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1>
 __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fast_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
                                                            const f16* __restrict__ diag, int64_t rows, int M, int /*N*/,
-                                                           FqQuantOut out, int flags) {
+                                                           FqQuantOut out, int flags_rt) {
+    const int flags = CTF >= 0 ? (CTF | (flags_rt & (FQ_ROUND_Y_F16 | FQ_NO_CLAMP0 | 0xF000))) : flags_rt;
     constexpr int N = KS1 * 16;                    // N % 16 == 0 is a precondition, so KS1 fixes N
     constexpr int THREADS = WAVES * 64;
     constexpr int TPW = (NT + WAVES - 1) / WAVES;  // n'-tiles per wave
@@ -603,13 +607,13 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
     }
 }
 
-template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false>
+template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1>
 int launch_fast(int flags, const f16* x, const uint4* ws, const f16* diag, int64_t rows, int M, int N,
                 const FqQuantOut& out, int n_cu, hipStream_t stream) {
     constexpr int PITCH = (KS1 * 2) | 1;
     const size_t lds = (size_t)2 * MT * MT * 1024 + (size_t)MT * 32 * PITCH * 16 + (((size_t)M * N / 2 + 15) & ~(size_t)15) + 128;
     if (lds > 160 * 1024) return -1000;
-    auto kern = fq_kron_fast_kernel<MT, NT, KS1, WAVES, OCC, SILU>;
+    auto kern = fq_kron_fast_kernel<MT, NT, KS1, WAVES, OCC, SILU, CTF>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -696,8 +700,11 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
         flags &= ~FQ_IN_SILU_MUL;
         if (diag != nullptr || out.in2 == nullptr) return -1000;
 #define FQ_FS(MT_, NT_, KS1_, W_, OCC_)                                                                          \
-    if (MT == MT_ && NT == NT_ && g.KS1 == KS1_)                                                                \
-        return launch_fast<MT_, NT_, KS1_, W_, OCC_, true>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
+    if (MT == MT_ && NT == NT_ && g.KS1 == KS1_) {                                                              \
+        if ((flags & FQ_CT_MASK) == FQ_OUT_PACKED && !getenv("FQ_KRON_NO_CTF"))                                 \
+            return launch_fast<MT_, NT_, KS1_, W_, OCC_, true, FQ_OUT_PACKED>(flags, x, ws, diag, rows, M, N, out, n_cu, stream); \
+        return launch_fast<MT_, NT_, KS1_, W_, OCC_, true>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);  \
+    }
         FQ_FS(4, 4, 8, 4, 2) FQ_FS(3, 4, 8, 4, 2) FQ_FS(4, 7, 14, 8, 1)
 #undef FQ_FS
         return -1000;
@@ -710,7 +717,10 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
     if (!getenv("FQ_KRON_GENERIC_V1")) {  // (the original kernel stays reachable for A/B runs)
 #define FQ_F(MT_, NT_, KS1_, W_, OCC_)                                                                   \
     if (MT == MT_ && NT == NT_ && g.KS1 == KS1_) {                                                       \
-        rc = launch_fast<MT_, NT_, KS1_, W_, OCC_>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);   \
+        if (MT_ >= 3 && (flags & FQ_CT_MASK) == FQ_OUT_PACKED && !getenv("FQ_KRON_NO_CTF"))              \
+            rc = launch_fast<MT_, NT_, KS1_, W_, OCC_, false, (MT_ >= 3 ? FQ_OUT_PACKED : -1)>(flags, x, ws, diag, rows, M, N, out, n_cu, stream); \
+        else                                                                                             \
+            rc = launch_fast<MT_, NT_, KS1_, W_, OCC_>(flags, x, ws, diag, rows, M, N, out, n_cu, stream); \
         if (rc != -1000) return rc;                                                                      \
     }
 #ifndef FQ_GEN_OCC2
