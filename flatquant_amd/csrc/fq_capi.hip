@@ -29,6 +29,12 @@ int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, in
                        const f16* srow, const f16* scol, const f16* bias, hipStream_t stream);
 int fq_launch_kron_any(int flags, const f16* x, const f16* left, const f16* right, const f16* diag, int64_t rows, int M,
                        int N, const FqQuantOut& out, int n_cu, hipStream_t stream);
+int fq_launch_kv_append(void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last, const uint8_t* k,
+                        const uint8_t* v, const f16* kparam, const f16* vparam, const int* seqlen_indptr, int64_t total_tokens,
+                        int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, int n_cu,
+                        hipStream_t stream);
+int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
+                        int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, hipStream_t stream);
 int fq_launch_silu_mul(const f16* gate, const f16* up, f16* y, int64_t n, int n_cu, hipStream_t stream);
 int fq_launch_silu_hadamard_quant(const f16* gate, const f16* up, int64_t rows, int n, int K, const f16* hadK, float scale,
                                   float sig_max, float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream);
@@ -395,6 +401,44 @@ int fq_kv_dequant_f16(const void* q, const void* param, int64_t rows, int head_d
     const int rc = fq_launch_kv_dequant((const uint8_t*)q, (const f16*)param, rows, head_dim, (flags & FQ_KV_LAC) != 0,
                                         (f16*)y, cu_count(), (hipStream_t)stream);
     return check_launch(rc, "fq_kv_dequant_f16");
+}
+
+static int kv_geometry_ok(const char* what, int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch) {
+    if (num_layers <= 0 || layer_idx < 0 || layer_idx >= num_layers || num_heads <= 0 || page_size <= 0 || batch <= 0)
+        return fail(FQ_EINVAL, "%s: bad cache geometry", what);
+    if (head_dim != 64 && head_dim != 128) return fail(FQ_EUNSUPPORTED, "%s: head_dim=%d (64 or 128)", what, head_dim);
+    return FQ_OK;
+}
+
+int fq_kv_append_i4(void* kv_data, void* kv_param, const void* kv_indptr, const void* kv_indices,
+                    const void* last_page_offset, const void* k, const void* v, const void* k_param, const void* v_param,
+                    const void* seqlen_indptr, int64_t tokens, int num_layers, int layer_idx, int num_heads, int page_size,
+                    int head_dim, int batch_size, void* stream) {
+    int rc = kv_geometry_ok("fq_kv_append_i4", num_layers, layer_idx, num_heads, page_size, head_dim, batch_size);
+    if (rc != FQ_OK) return rc;
+    if (tokens < 0) return fail(FQ_EINVAL, "fq_kv_append_i4: tokens < 0");
+    if (!seqlen_indptr && tokens != batch_size) return fail(FQ_EINVAL, "fq_kv_append_i4: without seqlen_indptr every request appends one token (tokens == batch_size)");
+    if (tokens == 0) return FQ_OK;
+    if (!kv_data || !kv_param || !kv_indptr || !kv_indices || !last_page_offset || !k || !v || !k_param || !v_param)
+        return fail(FQ_EINVAL, "fq_kv_append_i4: NULL pointer");
+    rc = fq_launch_kv_append(kv_data, kv_param, (const int*)kv_indptr, (const int*)kv_indices, (const int*)last_page_offset,
+                             (const uint8_t*)k, (const uint8_t*)v, (const f16*)k_param, (const f16*)v_param,
+                             (const int*)seqlen_indptr, tokens, num_layers, layer_idx, num_heads, page_size, head_dim, batch_size,
+                             cu_count(), (hipStream_t)stream);
+    return check_launch(rc, "fq_kv_append_i4");
+}
+
+int fq_kv_batch_decode_i4(void* o, const void* q, const void* kv_data, const void* kv_param, const void* kv_indptr,
+                          const void* kv_indices, const void* last_page_offset, int num_layers, int layer_idx,
+                          int num_heads, int page_size, int head_dim, int batch_size, void* stream) {
+    int rc = kv_geometry_ok("fq_kv_batch_decode_i4", num_layers, layer_idx, num_heads, page_size, head_dim, batch_size);
+    if (rc != FQ_OK) return rc;
+    if (!o || !q || !kv_data || !kv_param || !kv_indptr || !kv_indices || !last_page_offset)
+        return fail(FQ_EINVAL, "fq_kv_batch_decode_i4: NULL pointer");
+    rc = fq_launch_kv_decode((f16*)o, (const f16*)q, (void*)kv_data, (void*)kv_param, (const int*)kv_indptr,
+                             (const int*)kv_indices, (const int*)last_page_offset, num_layers, layer_idx, num_heads, page_size,
+                             head_dim, batch_size, (hipStream_t)stream);
+    return check_launch(rc, "fq_kv_batch_decode_i4");
 }
 
 int fq_rowquant_f16(const void* x, int64_t rows, int cols, const float* sig_max, const float* sig_min,

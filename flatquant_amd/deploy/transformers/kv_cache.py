@@ -44,3 +44,119 @@ def transform_quantize_kv(key_states: torch.Tensor, value_states: torch.Tensor, 
     kq, kp = ops.kv_quant(key_states.contiguous(), t, (_clip(kclip[0]), _clip(kclip[1])), lac)
     vq, vp = ops.kv_quant(value_states.contiguous(), None, (_clip(vclip[0]), _clip(vclip[1])), lac)
     return kq, kp.reshape(b * n, heads, 2), vq, vp.reshape(b * n, heads, 2)
+
+
+def init_kv_i4(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, k, v, k_param, v_param, seqlen_indptr, layer_idx):
+    """kv_cache.py:69-80 (-> _CUDA.init_kv_i4): append each request's tokens seqlen_indptr[b] .. seqlen_indptr[b+1] - 1."""
+    ops.kv_append(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, k.contiguous(), v.contiguous(),
+                  k_param.contiguous(), v_param.contiguous(), layer_idx, seqlen_indptr)
+
+
+def append_kv_i4(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, k, v, k_param, v_param, layer_idx):
+    """kv_cache.py:83-95 (-> _CUDA.append_kv_i4): one new token per request."""
+    ops.kv_append(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, k.contiguous(), v.contiguous(),
+                  k_param.contiguous(), v_param.contiguous(), layer_idx, None)
+
+
+def batch_decode_i4(o, q, kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, layer_idx):
+    """kv_cache.py:98-105 (-> _CUDA.batch_decode_i4): writes the attention output into ``o``."""
+    o.copy_(ops.kv_batch_decode(q.contiguous(), kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, layer_idx))
+    return o
+
+
+class MultiLayerPagedKVCache4Bit:
+    """The INT4 configuration of kv_cache.py:166-359 (``disable_quant=False``, ``trans`` "matmul" or "none") with the
+    same constructor arguments, page / scale tensors and ``update`` contract: the first call per layer stores the
+    (transformed, quantised) prompt keys / values and returns the fp16 key / value states for the prefill attention; every
+    later call appends one token per request and returns a callable that runs the INT4 decode attention for the
+    layer's query ([bsz, 1, heads, head_dim] -> the same shape). Requests have equal lengths (no attention mask), as
+    the reference's own restriction to one page count per batch implies (:371-372). trans="had" (QuaRot's fast Hadamard
+    on the keys) is not offered; pass the Hadamard matrix as ``trans_matrix_k`` with trans="matmul" instead."""
+
+    def __init__(self, batch_size, page_size, max_seq_len, device, n_layers, num_heads, head_dim, disable_quant=False,
+                 trans_dtype=torch.float16, trans="had", group_size=1):
+        if disable_quant:
+            raise NotImplementedError("flatquant_amd: the fp16 configuration of the paged cache is not built")
+        if trans == "had":
+            raise NotImplementedError("flatquant_amd: trans='had' on the keys is not built (use trans='matmul' with the matrix)")
+        self.page_size, self.batch_size, self.max_seq_len = page_size, batch_size, max_seq_len
+        self.device, self.n_layers, self.trans, self.group_size = device, n_layers, trans, group_size
+        self.org_head_dim = head_dim
+        n_pages = self.page_cnt_from_length(max_seq_len) * batch_size
+        self.pages = torch.empty((n_pages, n_layers, 2, num_heads, page_size, head_dim // 2), dtype=torch.uint8, device=device)
+        self.scales = torch.empty((n_pages, n_layers, 2, num_heads, page_size, 2), dtype=torch.float16, device=device)
+        self._needs_init = [True] * n_layers
+        self.length = 0
+
+    def page_cnt_from_length(self, length):
+        return (length + self.page_size - 1) // self.page_size
+
+    def _ensure_page_cnt_per_batch(self, expected):
+        need = expected * self.batch_size
+        have = self.pages.shape[0]
+        if need <= have:
+            return
+        grow = max(need, have * 2) - have
+        self.pages = torch.cat([self.pages, torch.empty((grow, *self.pages.shape[1:]), dtype=self.pages.dtype, device=self.device)])
+        self.scales = torch.cat([self.scales, torch.empty((grow, *self.scales.shape[1:]), dtype=self.scales.dtype, device=self.device)])
+
+    @property
+    def seen_tokens(self):
+        return self.length
+
+    def get_seq_length(self, layer_idx=0):
+        return self.length
+
+    def get_cache_specs_for_flash_infer(self):
+        """kv_cache.py:362-385 without an attention mask: page p of request b is page index p * batch_size + b."""
+        page_cnt = self.page_cnt_from_length(self.length)
+        ptr = self.length % self.page_size
+        if self.length != 0 and ptr == 0:
+            ptr = self.page_size
+        dev = self.device
+        return {
+            "kv_data": self.pages,
+            "kv_param": self.scales,
+            "kv_indptr": torch.arange(0, self.batch_size + 1, device=dev, dtype=torch.int32) * page_cnt,
+            "kv_indices": ((torch.arange(page_cnt, device=dev, dtype=torch.int32) * self.batch_size).unsqueeze(0)
+                           + torch.arange(self.batch_size, device=dev, dtype=torch.int32).unsqueeze(1)).reshape(-1).contiguous(),
+            "last_page_offset": torch.full((self.batch_size,), ptr, device=dev, dtype=torch.int32),
+        }
+
+    def update(self, key_states, value_states, layer_idx, cache_kwargs=None):
+        cache_kwargs = cache_kwargs or {}
+        if cache_kwargs.get("attention_mask") is not None:
+            raise NotImplementedError("flatquant_amd: ragged batches (attention_mask) are not built")
+        b, added, heads, hd = key_states.shape
+        assert b == self.batch_size
+        tk = cache_kwargs.get("trans_matrix_k") if self.trans.startswith("matmul") else None
+        tk_inv_t = cache_kwargs.get("trans_matrix_k_inv_t") if self.trans.startswith("matmul") else None
+        # kv_cache.py:283-284: the cache's own calls leave lac off, so the clip factors play no part
+        kq, kp, vq, vp = transform_quantize_kv(key_states, value_states, tk)
+        if self.group_size > 1:  # :286-296 grouped-query attention: every query head gets its copy
+            kq, vq = kq.repeat_interleave(self.group_size, dim=2), vq.repeat_interleave(self.group_size, dim=2)
+            kp, vp = kp.repeat_interleave(self.group_size, dim=1), vp.repeat_interleave(self.group_size, dim=1)
+            heads *= self.group_size
+        if layer_idx == 0:
+            self._ensure_page_cnt_per_batch(self.page_cnt_from_length(self.length + added))
+            self.length += added
+        specs = self.get_cache_specs_for_flash_infer()
+        args = (specs["kv_data"], specs["kv_param"], specs["kv_indptr"], specs["kv_indices"], specs["last_page_offset"])
+        kq, vq = kq.reshape(b * added, heads, hd // 2), vq.reshape(b * added, heads, hd // 2)
+        if self._needs_init[layer_idx]:
+            self._needs_init[layer_idx] = False
+            seqlens = torch.arange(b + 1, device=self.device, dtype=torch.int32) * added
+            init_kv_i4(*args, kq, vq, kp, vp, seqlens, layer_idx)
+            keys = key_states if tk is None else torch.matmul(key_states.to(torch.float16), tk.to(key_states.device, torch.float16))
+            return keys, value_states                                   # :341-344: the un-quantised states for prefill
+        assert added == 1
+        append_kv_i4(*args, kq, vq, kp, vp, layer_idx)
+
+        def attend(q):
+            bq, q_len, n_q, d = q.shape
+            assert q_len == 1
+            q2 = q.reshape(bq, n_q, d)
+            if tk_inv_t is not None:                                        # :134-140: the query side of the K transform
+                q2 = torch.matmul(q2.to(torch.float16), tk_inv_t.to(q.device, torch.float16))
+            return ops.kv_batch_decode(q2.contiguous(), *args, layer_idx).unsqueeze(1)
+        return attend

@@ -436,6 +436,52 @@ def kv_dequant(q: torch.Tensor, param: torch.Tensor, lac: bool = False) -> torch
     return y
 
 
+def _kv_geometry(kv_data: torch.Tensor):
+    pages, n_layers, two, heads, page_size, half_hd = kv_data.shape
+    if two != 2:
+        raise ValueError("kv_data must be [pages, layers, 2, heads, page_size, head_dim/2]")
+    return n_layers, heads, page_size, half_hd * 2
+
+
+def kv_append(kv_data: torch.Tensor, kv_param: torch.Tensor, kv_indptr: torch.Tensor, kv_indices: torch.Tensor,
+              last_page_offset: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_param: torch.Tensor, v_param: torch.Tensor,
+              layer_idx: int, seqlen_indptr: Optional[torch.Tensor] = None) -> None:
+    """init_kv_i4 (with ``seqlen_indptr``) / append_kv_i4 (without) of deploy/transformers/kv_cache.py:69-95: scatter
+    packed keys / values [tokens, heads, head_dim/2] uint8 and their (scale, zero) [tokens, heads, 2] fp16 into the paged
+    cache (fq_kv_append_i4). The index tensors are int32 on the cache's device."""
+    _chk(kv_data, "kv_data", torch.uint8), _chk(kv_param, "kv_param"), _chk(k, "k", torch.uint8), _chk(v, "v", torch.uint8)
+    _chk(k_param, "k_param"), _chk(v_param, "v_param")
+    for t, n in ((kv_indptr, "kv_indptr"), (kv_indices, "kv_indices"), (last_page_offset, "last_page_offset")):
+        _chk(t, n, torch.int32)
+    if seqlen_indptr is not None:
+        _chk(seqlen_indptr, "seqlen_indptr", torch.int32)
+    n_layers, heads, page_size, hd = _kv_geometry(kv_data)
+    batch = last_page_offset.numel()
+    tokens = k.numel() // (heads * hd // 2)
+    if k.shape != v.shape or k_param.numel() != tokens * heads * 2 or v_param.numel() != tokens * heads * 2:
+        raise ValueError("k / v / k_param / v_param shapes do not agree")
+    with torch.cuda.device(kv_data.device):
+        check(lib.fq_kv_append_i4(_ptr(kv_data), _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
+                                  _ptr(k), _ptr(v), _ptr(k_param), _ptr(v_param), _ptr(seqlen_indptr), tokens, n_layers,
+                                  layer_idx, heads, page_size, hd, batch, _stream(kv_data)))
+
+
+def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tensor, kv_indptr: torch.Tensor,
+                    kv_indices: torch.Tensor, last_page_offset: torch.Tensor, layer_idx: int) -> torch.Tensor:
+    """batch_decode_i4 (kv_cache.py:98-105): q [batch, heads, head_dim] fp16 -> o of the same shape, attention over each
+    request's cached rows (fq_kv_batch_decode_i4)."""
+    _chk(q, "q"), _chk(kv_data, "kv_data", torch.uint8), _chk(kv_param, "kv_param")
+    n_layers, heads, page_size, hd = _kv_geometry(kv_data)
+    batch = last_page_offset.numel()
+    if q.shape != (batch, heads, hd):
+        raise ValueError(f"q must be [{batch}, {heads}, {hd}]")
+    o = torch.empty_like(q)
+    with torch.cuda.device(q.device):
+        check(lib.fq_kv_batch_decode_i4(_ptr(o), _ptr(q), _ptr(kv_data), _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices),
+                                        _ptr(last_page_offset), n_layers, layer_idx, heads, page_size, hd, batch, _stream(q)))
+    return o
+
+
 def int4_matmul(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """_CUDA.matmul (bindings.cpp:9-25 -> gemm.cu): x uint8 [M, K/2], w uint8 [N, K/2], packed nibbles -> int32 [M, N]."""
     _chk(x, "x", torch.uint8), _chk(w, "w", torch.uint8)

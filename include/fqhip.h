@@ -24,6 +24,7 @@
  *   (fq_hadamard_quant_f16: the same followed by deploy/nn/quantization.py:13-36, fused)
  *                          deploy/functional/online_trans.py:144-151
  *   fq_kv_quant_f16, fq_kv_dequant_f16   deploy/transformers/kv_cache.py:11-61,268 (K transform + asym INT4 pack)
+ *   fq_kv_append_i4, fq_kv_batch_decode_i4   deploy/kernels/flashinfer.cu:9-96 (paged INT4 cache append + decode attention)
  *   fq_rowquant_f16        deploy/nn/quantization.py:13-36 (Quantizer.forward),
  *                          flatquant/quant_utils.py:77-119
  *   fq_sym_quant_f16       deploy/kernels/bindings.cpp:27-44 -> quant.cu:13-63 (sym_quant)
@@ -238,6 +239,30 @@ int fq_kv_quant_f16(const void* x, const void* trans, int64_t rows, int head_dim
 
 /* kv_cache.py:54-61 unpack_i4_and_asym_dequantize: y = q * scale - zero, or scale * (q - zero) with FQ_KV_LAC (fp16). */
 int fq_kv_dequant_f16(const void* q, const void* param, int64_t rows, int head_dim, int flags, void* y, void* stream);
+
+/*
+ * The paged INT4 KV cache of MultiLayerPagedKVCache4Bit (deploy/transformers/kv_cache.py:166-359; the reference binds a
+ * vendored FlashInfer: kernels/flashinfer.cu:9-96, include/flashinfer/{page,decode,quantization}.cuh).
+ *   kv_data  [pages, num_layers, 2 (k, v), num_heads, page_size, head_dim/2] uint8, low nibble = even feature
+ *   kv_param [pages, num_layers, 2, num_heads, page_size, 2] fp16 = (scale, zero) per cached row
+ *   kv_indptr [batch+1], kv_indices [n_pages], last_page_offset [batch] int32: request b owns the pages
+ *   kv_indices[kv_indptr[b] .. kv_indptr[b+1]); its length is (n_pages_b - 1) * page_size + last_page_offset[b]
+ *   (the length AFTER the append, as in page.cuh:135-137,176-183).
+ * fq_kv_append_i4: k, v [tokens, num_heads, head_dim/2] uint8 and k_param, v_param [tokens, num_heads, 2] fp16 (the
+ *   outputs of fq_kv_quant_f16). seqlen_indptr [batch+1] int32: request b appends tokens seqlen_indptr[b] ..
+ *   seqlen_indptr[b+1] - 1 at the END of its current length (init_kv_i4, page.cuh:163-214); NULL: one token per
+ *   request, tokens == batch (append_kv_i4, page.cuh:118-161).
+ * fq_kv_batch_decode_i4: one query token per request, q and o [batch, num_heads, head_dim] fp16 (decode.cuh:492-683,
+ *   no rotary embedding, softmax scale 1/sqrt(head_dim)): o = softmax(q . K^T / sqrt(hd)) . V over the request's cached
+ *   rows, K and V de-quantised as n * scale - zero (quantization.cuh:58-80), fp32 arithmetic. head_dim in {64, 128}.
+ */
+int fq_kv_append_i4(void* kv_data, void* kv_param, const void* kv_indptr, const void* kv_indices,
+                    const void* last_page_offset, const void* k, const void* v, const void* k_param, const void* v_param,
+                    const void* seqlen_indptr, int64_t tokens, int num_layers, int layer_idx, int num_heads, int page_size,
+                    int head_dim, int batch_size, void* stream);
+int fq_kv_batch_decode_i4(void* o, const void* q, const void* kv_data, const void* kv_param, const void* kv_indptr,
+                          const void* kv_indices, const void* last_page_offset, int num_layers, int layer_idx,
+                          int num_heads, int page_size, int head_dim, int batch_size, void* stream);
 
 /* q = clamp(rn(x /fp16 scale[row]), -8, 7), two per byte, even column -> low nibble (quant.cu:13-47). */
 int fq_sym_quant_f16(const void* x, const void* scale, int64_t rows, int cols, void* q, void* stream);

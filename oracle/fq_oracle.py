@@ -311,6 +311,55 @@ def kv_transform(x16, trans16):
     return (np.asarray(x16, dtype=F16).astype(F32) @ np.asarray(trans16, dtype=F16).astype(F32)).astype(F16)
 
 
+# The paged-cache functions below restate CUDA kernels of the reference (vendored FlashInfer) that cannot be run in this
+# container and have no test vectors in the reference: PARITY UNPINNED for these two (formulas cited by file:line).
+def kv_cache_append(kv_data, kv_param, indptr, indices, last_page_offset, layer_idx, k, v, k_param, v_param,
+                    seqlen_indptr=None):
+    """page.cuh:118-214 in numpy (in place): kv_data [pages, layers, 2, heads, page, hd/2] uint8, kv_param [..., page, 2]
+    fp16; k, v [tokens, heads, hd/2], params [tokens, heads, 2]. Lengths are the ones AFTER the append."""
+    batch = len(last_page_offset)
+    page_size = kv_data.shape[4]
+    for b in range(batch):
+        seq_len = (indptr[b + 1] - indptr[b] - 1) * page_size + last_page_offset[b]
+        if seqlen_indptr is None:
+            toks = [b]
+        else:
+            toks = list(range(seqlen_indptr[b], seqlen_indptr[b + 1]))
+        start = seq_len - len(toks)
+        for j, t in enumerate(toks):
+            pos = start + j
+            page, entry = indices[indptr[b] + pos // page_size], pos % page_size
+            kv_data[page, layer_idx, 0, :, entry, :] = k[t]
+            kv_data[page, layer_idx, 1, :, entry, :] = v[t]
+            kv_param[page, layer_idx, 0, :, entry, :] = k_param[t]
+            kv_param[page, layer_idx, 1, :, entry, :] = v_param[t]
+
+
+def kv_cache_decode(q16, kv_data, kv_param, indptr, indices, last_page_offset, layer_idx):
+    """decode.cuh:492-683 (rotary none) as a plain fp64 softmax attention over the de-quantised rows
+    (quantization.cuh:58-80: n * scale - zero with fp32(fp16) parameters): q [batch, heads, hd] -> o fp16."""
+    q = np.asarray(q16, dtype=F16).astype(np.float64)
+    batch, heads, hd = q.shape
+    page_size = kv_data.shape[4]
+    out = np.zeros((batch, heads, hd), dtype=np.float64)
+    for b in range(batch):
+        seq_len = (indptr[b + 1] - indptr[b] - 1) * page_size + last_page_offset[b]
+        rows = [(indices[indptr[b] + pos // page_size], pos % page_size) for pos in range(seq_len)]
+        for h in range(heads):
+            kd, vd = [], []
+            for page, entry in rows:
+                for which, dst in ((0, kd), (1, vd)):
+                    p8 = kv_data[page, layer_idx, which, h, entry]
+                    n = np.stack((p8 & 15, p8 >> 4), axis=-1).reshape(-1).astype(np.float64)
+                    s, z = kv_param[page, layer_idx, which, h, entry].astype(np.float64)
+                    dst.append(n * s - z)
+            K, V = np.array(kd), np.array(vd)
+            x = K @ q[b, h] / np.sqrt(hd)
+            w = np.exp(x - x.max())
+            out[b, h] = (w / w.sum()) @ V
+    return out.astype(F16)
+
+
 def silu_mul(gate16, up16):
     """deploy/transformers/modeling_llama.py:277-278 on fp16 tensors: ac = act_fn(x_gate) (SiLU: fp32 g / (1 + exp(-g)),
     rounded to fp16), x = x_up * ac (fp16 product = exact product rounded once)."""

@@ -1,0 +1,138 @@
+"""Paged INT4 KV cache: append (bit-exact placement against the numpy restatement of page.cuh) and decode attention
+(fp32 online softmax over de-quantised rows; tolerance 2e-3 of the output's maximum against an fp64 softmax attention on
+the same cache contents). The reference's kernels are CUDA (vendored FlashInfer) and cannot run here: the oracle restates
+their formulas (file:line in oracle/fq_oracle.py) — parity for this row is pinned on those, not on reference outputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from flatquant_amd import ops as _ops
+    return _ops
+
+
+def make_cache(pages, layers, heads, page_size, hd, seed):
+    rng = np.random.default_rng(seed)
+    data = rng.integers(0, 256, (pages, layers, 2, heads, page_size, hd // 2), dtype=np.uint8)
+    param = np.stack([rng.uniform(0.02, 0.3, (pages, layers, 2, heads, page_size)),
+                      rng.uniform(0.1, 2.0, (pages, layers, 2, heads, page_size))], axis=-1).astype(np.float16)
+    return data, param
+
+
+def i32(a):
+    return torch.tensor(np.asarray(a), dtype=torch.int32, device="cuda")
+
+
+@pytest.mark.parametrize("hd,heads,page_size,lens", [(128, 4, 16, [37, 37]), (128, 2, 8, [8, 1, 23]), (64, 3, 32, [65]),
+                                                      (128, 8, 2048, [300, 300])])
+def test_append_prefill_then_decode_steps(ops, hd, heads, page_size, lens):
+    layers, layer = 3, 1
+    batch = len(lens)
+    pages_per = [(n + 1 + page_size - 1) // page_size for n in lens]          # room for one more token each
+    indptr = np.concatenate([[0], np.cumsum(pages_per)]).astype(np.int32)
+    rng = np.random.default_rng(hd + heads)
+    indices = rng.permutation(int(indptr[-1])).astype(np.int32)                  # pages scattered on purpose
+    data, param = make_cache(int(indptr[-1]), layers, heads, page_size, hd, 1)
+    ref_data, ref_param = data.copy(), param.copy()
+    d_data, d_param = torch.from_numpy(data).cuda(), torch.from_numpy(param).cuda()
+    # ---- prefill: request b appends lens[b] tokens ----
+    tot = sum(lens)
+    k = rng.integers(0, 256, (tot, heads, hd // 2), dtype=np.uint8)
+    v = rng.integers(0, 256, (tot, heads, hd // 2), dtype=np.uint8)
+    kp = rng.uniform(0.01, 1.0, (tot, heads, 2)).astype(np.float16)
+    vp = rng.uniform(0.01, 1.0, (tot, heads, 2)).astype(np.float16)
+    seq_indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    last = np.array([(n - 1) % page_size + 1 for n in lens], dtype=np.int32)
+    used_indptr = np.concatenate([[0], np.cumsum([(n + page_size - 1) // page_size for n in lens])]).astype(np.int32)
+    used_indices = np.concatenate([indices[indptr[b]:indptr[b] + used_indptr[b + 1] - used_indptr[b]] for b in range(batch)])
+    ops.kv_append(d_data, d_param, i32(used_indptr), i32(used_indices), i32(last), torch.from_numpy(k).cuda(),
+                  torch.from_numpy(v).cuda(), torch.from_numpy(kp).cuda(), torch.from_numpy(vp).cuda(), layer, i32(seq_indptr))
+    O.kv_cache_append(ref_data, ref_param, used_indptr, used_indices, last, layer, k, v, kp, vp, seq_indptr)
+    assert np.array_equal(d_data.cpu().numpy(), ref_data)
+    assert np.array_equal(d_param.cpu().numpy().view(np.uint16), ref_param.view(np.uint16))
+    # ---- one decode step: every request appends one token, then attends ----
+    lens2 = [n + 1 for n in lens]
+    last2 = np.array([(n - 1) % page_size + 1 for n in lens2], dtype=np.int32)
+    ind2 = np.concatenate([[0], np.cumsum([(n + page_size - 1) // page_size for n in lens2])]).astype(np.int32)
+    idx2 = np.concatenate([indices[indptr[b]:indptr[b] + ind2[b + 1] - ind2[b]] for b in range(batch)])
+    k1 = rng.integers(0, 256, (batch, heads, hd // 2), dtype=np.uint8)
+    v1 = rng.integers(0, 256, (batch, heads, hd // 2), dtype=np.uint8)
+    kp1 = rng.uniform(0.01, 1.0, (batch, heads, 2)).astype(np.float16)
+    vp1 = rng.uniform(0.01, 1.0, (batch, heads, 2)).astype(np.float16)
+    ops.kv_append(d_data, d_param, i32(ind2), i32(idx2), i32(last2), torch.from_numpy(k1).cuda(), torch.from_numpy(v1).cuda(),
+                  torch.from_numpy(kp1).cuda(), torch.from_numpy(vp1).cuda(), layer)
+    O.kv_cache_append(ref_data, ref_param, ind2, idx2, last2, layer, k1, v1, kp1, vp1)
+    assert np.array_equal(d_data.cpu().numpy(), ref_data)
+    assert np.array_equal(d_param.cpu().numpy().view(np.uint16), ref_param.view(np.uint16))
+    q = (rng.standard_normal((batch, heads, hd)) * 0.5).astype(np.float16)
+    o = ops.kv_batch_decode(torch.from_numpy(q).cuda(), d_data, d_param, i32(ind2), i32(idx2), i32(last2), layer).cpu().numpy()
+    ref = O.kv_cache_decode(q, ref_data, ref_param, ind2, idx2, last2, layer)
+    err = np.abs(o.astype(np.float64) - ref.astype(np.float64)).max(axis=-1) / np.abs(ref.astype(np.float64)).max(axis=-1)
+    assert err.max() <= 2e-3, err.max()
+
+
+def test_cache_class_prefill_and_decode_match_dense_attention(ops):
+    """MultiLayerPagedKVCache4Bit end to end against dense fp32 attention on the de-quantised keys / values."""
+    import flatquant_amd.deploy.transformers as T
+    g = torch.Generator(device="cuda").manual_seed(0)
+    bsz, prompt, kv_heads, group, hd, layers = 2, 21, 2, 2, 128, 2
+    cache = T.MultiLayerPagedKVCache4Bit(bsz, 16, 64, "cuda", layers, kv_heads * group, hd, trans="matmul", group_size=group)
+    tk = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half()
+    tk_inv_t = torch.linalg.inv(tk.float()).T.contiguous().half()
+    kw = {"trans_matrix_k": tk, "trans_matrix_k_inv_t": tk_inv_t}
+    dense_k = [[] for _ in range(layers)]
+    dense_v = [[] for _ in range(layers)]
+
+    def deq32(q8, par):          # n * scale - zero in fp32, as the decode kernel (and quantization.cuh:58-80) evaluates it
+        n = torch.stack((q8 & 15, q8 >> 4), dim=-1).reshape(*q8.shape[:-1], -1).float()
+        par = par.reshape(*q8.shape[:-1], 2).float()
+        return n * par[..., 0:1] - par[..., 1:2]
+
+    def record(layer, k, v):
+        kq, kp, vq, vp = T.transform_quantize_kv(k, v, tk)
+        dense_k[layer].append(deq32(kq, kp))
+        dense_v[layer].append(deq32(vq, vp))
+
+    for layer in range(layers):
+        k = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+        v = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+        out = cache.update(k, v, layer, dict(kw))
+        assert isinstance(out, tuple) and out[0].shape == k.shape
+        record(layer, k, v)
+    assert cache.get_seq_length() == prompt
+    for step in range(3):
+        for layer in range(layers):
+            k = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+            v = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+            attend = cache.update(k, v, layer, dict(kw))
+            record(layer, k, v)
+            q = torch.randn(bsz, 1, kv_heads * group, hd, generator=g, device="cuda").half()
+            o = attend(q)
+            assert o.shape == q.shape
+            K = torch.cat(dense_k[layer], dim=1).float().repeat_interleave(group, dim=2)      # [b, s, heads, hd]
+            V = torch.cat(dense_v[layer], dim=1).float().repeat_interleave(group, dim=2)
+            qt = torch.matmul(q.reshape(bsz, -1, hd).half(), tk_inv_t).float()                  # [b, heads, hd]
+            x = torch.einsum("bhd,bshd->bhs", qt, K) / hd ** 0.5
+            ref = torch.einsum("bhs,bshd->bhd", torch.softmax(x, dim=-1), V)
+            err = (o.reshape(bsz, -1, hd).float() - ref).abs().amax(-1) / ref.abs().amax(-1)
+            assert err.max().item() <= 3e-3
+    assert cache.get_seq_length() == prompt + 3
+
+
+def test_errors(ops):
+    import flatquant_amd.deploy.transformers as T
+    with pytest.raises(NotImplementedError):
+        T.MultiLayerPagedKVCache4Bit(1, 16, 32, "cuda", 1, 2, 128, disable_quant=True)
+    with pytest.raises(NotImplementedError):
+        T.MultiLayerPagedKVCache4Bit(1, 16, 32, "cuda", 1, 2, 128, trans="had")
+    data = torch.zeros(2, 1, 2, 2, 16, 48, dtype=torch.uint8, device="cuda")                     # head_dim 96
+    par = torch.zeros(2, 1, 2, 2, 16, 2, dtype=torch.float16, device="cuda")
+    z = torch.zeros(2, dtype=torch.int32, device="cuda")
+    with pytest.raises(Exception):
+        ops.kv_batch_decode(torch.zeros(1, 2, 96, dtype=torch.float16, device="cuda"), data, par, z, z, z[:1], 0)

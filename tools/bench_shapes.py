@@ -111,6 +111,20 @@ def main():
     us = timeit(lambda i: ops.kv_quant(ks[i % NB]))
     line("V asym INT4 pack", "16384 x 8 heads x 128", us, 2.5 * 128 + 4, 128, ROWS * 8)
     del ks
+    # paged INT4 cache: decode attention, one query token per request (kv_cache.py batch_decode_i4)
+    for bsz, seq in ((16, 2048), (64, 2048), (8, 8192)):
+        heads, hd, page = 32, 128, 2048
+        n_pg = (seq + page - 1) // page
+        data = torch.randint(0, 256, (bsz * n_pg, 1, 2, heads, page, hd // 2), generator=g, device="cuda", dtype=torch.uint8)
+        par = (torch.rand(bsz * n_pg, 1, 2, heads, page, 2, generator=g, device="cuda") * 0.2 + 0.05).half()
+        indptr = (torch.arange(bsz + 1, device="cuda", dtype=torch.int32) * n_pg)
+        indices = torch.arange(bsz * n_pg, device="cuda", dtype=torch.int32)
+        last = torch.full((bsz,), (seq - 1) % page + 1, device="cuda", dtype=torch.int32)
+        q = torch.randn(bsz, heads, hd, generator=g, device="cuda").half()
+        us = timeit(lambda i: ops.kv_batch_decode(q, data, par, indptr, indices, last, 0))
+        byt = bsz * heads * seq * 2 * (hd // 2 + 4)
+        print(f"{'INT4 paged decode attention':34s} {'bsz=%d seq=%d heads=32' % (bsz, seq):22s} {us:9.1f} us  {byt / us / 1e3:8.0f} GB/s")
+        del data, par
     for hd, H in ((128, 32), (128, 64)):
         xs = [torch.randn(ROWS, hd, H, generator=g, device="cuda", dtype=torch.float16) for _ in range(NB)]
         P = (torch.randn(H, H, generator=g, device="cuda") / H ** 0.5).half()
