@@ -3,8 +3,8 @@
 // 29568 = 168 x 176). The reference's Triton kernels mask their way through any (M, N) (kron_matmul.py:29-110); this is
 // the counterpart of that generality: same mathematics and rounding points as the other kernels (U = fp16(X . R) with
 // fp32 accumulation, Y = L^T . U in fp32), plain FMA loops instead of matrix instructions. Correct, not fast
-// (measured 30.6 ms for 16384 tokens of 128 x 148, ~100x an MFMA kernel of that size: latency-bound dependent FMA chains
-// on operands read from L2); every shape of the BASELINE configs has a fast kernel.
+// (measured 24 ms for 16384 tokens of 128 x 148, ~100x an MFMA kernel of that size: one LDS and one L2 load per FMA
+// issue-bound on memory instructions); every shape of the BASELINE configs has a fast kernel.
 //
 // One 1024-thread workgroup per token. X and U live in LDS as fp16 [M][N]; thread t owns the outputs t, t + 1024, ...
 // (<= 32 per thread: M * N <= 32768) in registers through statistics and quantisation; nibbles meet their neighbours
@@ -34,9 +34,18 @@ __global__ __launch_bounds__(ANY_T) void fq_kron_any_kernel(const f16* __restric
         for (int i = tid; i < d; i += ANY_T) {  // U[m][n'] = fp16(sum_n X[m][n] R[n][n'])
             const int m = i / N, np = i - m * N;
             const f16* xr = X + m * N;
-            float acc = 0.0f;
-            for (int n = 0; n < N; ++n) acc = __builtin_fmaf((float)xr[n], (float)R[n * N + np], acc);
-            U[i] = (f16)acc;
+            const f16* rc = R + np;
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;  // four chains: the loads of 8 steps are in flight together
+            int n = 0;
+#pragma unroll 2
+            for (; n + 4 <= N; n += 4) {
+                a0 = __builtin_fmaf((float)xr[n], (float)rc[n * N], a0);
+                a1 = __builtin_fmaf((float)xr[n + 1], (float)rc[(n + 1) * N], a1);
+                a2 = __builtin_fmaf((float)xr[n + 2], (float)rc[(n + 2) * N], a2);
+                a3 = __builtin_fmaf((float)xr[n + 3], (float)rc[(n + 3) * N], a3);
+            }
+            for (; n < N; ++n) a0 = __builtin_fmaf((float)xr[n], (float)rc[n * N], a0);
+            U[i] = (f16)((a0 + a1) + (a2 + a3));
         }
         __syncthreads();
         float y[ANY_MAXJ];
@@ -47,8 +56,19 @@ __global__ __launch_bounds__(ANY_T) void fq_kron_any_kernel(const f16* __restric
             const int i = tid + j * ANY_T;
             if (j < nj && i < d) {
                 const int mp = i / N, n = i - mp * N;
-                float acc = 0.0f;
-                for (int m = 0; m < M; ++m) acc = __builtin_fmaf((float)L[m * M + mp], (float)U[m * N + n], acc);
+                const f16* lc = L + mp;
+                const f16* uc = U + n;
+                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+                int m = 0;
+#pragma unroll 2
+                for (; m + 4 <= M; m += 4) {
+                    a0 = __builtin_fmaf((float)lc[m * M], (float)uc[m * N], a0);
+                    a1 = __builtin_fmaf((float)lc[(m + 1) * M], (float)uc[(m + 1) * N], a1);
+                    a2 = __builtin_fmaf((float)lc[(m + 2) * M], (float)uc[(m + 2) * N], a2);
+                    a3 = __builtin_fmaf((float)lc[(m + 3) * M], (float)uc[(m + 3) * N], a3);
+                }
+                for (; m < M; ++m) a0 = __builtin_fmaf((float)lc[m * M], (float)uc[m * N], a0);
+                float acc = (a0 + a1) + (a2 + a3);
                 if (flags & FQ_ROUND_Y_F16) acc = (float)(f16)acc;
                 y[j] = acc;
                 vmax = fmaxf(vmax, acc);
