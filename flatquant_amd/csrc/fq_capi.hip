@@ -23,6 +23,10 @@ int fq_launch_kv_quant(const f16* x, const f16* T, int64_t rows, int hd, float c
                        f16* param, f16* y, int n_cu, hipStream_t stream);
 int fq_launch_kv_dequant(const uint8_t* q, const f16* param, int64_t rows, int hd, bool lac, f16* y, int n_cu,
                          hipStream_t stream);
+int64_t fq_i4_frag_bytes(int N, int K);
+int fq_launch_i4_to_frag(const uint8_t* W, int N, int K, void* img, int n_cu, hipStream_t stream);
+int fq_launch_gemm_i4_skinny(const uint8_t* X, const void* wimg, int64_t M, int N, int K, int32_t* c, f16* y, const f16* srow,
+                             const f16* scol, const f16* bias, hipStream_t stream);
 int64_t fq_bf6_blob_bytes(int64_t rows, int K);  // fq_gemm_bf6.hip (exported as is)
 int fq_launch_i4_to_bf6(const uint8_t* q, int64_t rows, int K, int perm, uint8_t* blob, int n_cu, hipStream_t stream);
 int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, int N, int K, int32_t* c, f16* y,
@@ -333,6 +337,36 @@ int fq_int4_linear_f16(const void* x, const void* x_scale, const void* w, const 
                                      (const f16*)w_scale, (const f16*)bias, (hipStream_t)stream);
     if (rc == -1000) return fail(FQ_EUNSUPPORTED, "fq_int4_linear_f16: shape M=%lld N=%d K=%d not supported", (long long)M, N, K);
     return check_launch(rc, "fq_int4_linear_f16");
+}
+
+int64_t fq_int4_frag_bytes(int N, int K) { return fq_i4_frag_bytes(N, K); }
+
+int fq_int4_to_frag(const void* w, int N, int K, void* image, void* stream) {
+    if (N <= 0 || K <= 0) return fail(FQ_EINVAL, "fq_int4_to_frag: bad sizes");
+    if (K % 64) return fail(FQ_EUNSUPPORTED, "fq_int4_to_frag: K=%d must be a multiple of 64", K);
+    if (!w || !image) return fail(FQ_EINVAL, "fq_int4_to_frag: NULL pointer");
+    return check_launch(fq_launch_i4_to_frag((const uint8_t*)w, N, K, image, cu_count(), (hipStream_t)stream), "fq_int4_to_frag");
+}
+
+int fq_int4_skinny_gemm_i32(const void* x, const void* w_image, int64_t M, int N, int K, void* c, void* stream) {
+    if (M < 0 || N <= 0 || K <= 0) return fail(FQ_EINVAL, "fq_int4_skinny_gemm_i32: bad sizes");
+    if (M == 0) return FQ_OK;
+    if (!x || !w_image || !c) return fail(FQ_EINVAL, "fq_int4_skinny_gemm_i32: NULL pointer");
+    const int rc = fq_launch_gemm_i4_skinny((const uint8_t*)x, w_image, M, N, K, (int32_t*)c, nullptr, nullptr, nullptr, nullptr,
+                                            (hipStream_t)stream);
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "fq_int4_skinny_gemm_i32: M=%lld K=%d (M <= 128, K %% 64 == 0)", (long long)M, K);
+    return check_launch(rc, "fq_int4_skinny_gemm_i32");
+}
+
+int fq_int4_skinny_linear_f16(const void* x, const void* x_scale, const void* w_image, const void* w_scale,
+                              const void* bias, int64_t M, int N, int K, void* y, void* stream) {
+    if (M < 0 || N <= 0 || K <= 0) return fail(FQ_EINVAL, "fq_int4_skinny_linear_f16: bad sizes");
+    if (M == 0) return FQ_OK;
+    if (!x || !w_image || !y || !x_scale || !w_scale) return fail(FQ_EINVAL, "fq_int4_skinny_linear_f16: NULL pointer");
+    const int rc = fq_launch_gemm_i4_skinny((const uint8_t*)x, w_image, M, N, K, nullptr, (f16*)y, (const f16*)x_scale,
+                                            (const f16*)w_scale, (const f16*)bias, (hipStream_t)stream);
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "fq_int4_skinny_linear_f16: M=%lld K=%d (M <= 128, K %% 64 == 0)", (long long)M, K);
+    return check_launch(rc, "fq_int4_skinny_linear_f16");
 }
 
 int fq_int4_to_bf6(const void* q, int64_t rows, int K, int role, void* blob, void* stream) {

@@ -288,6 +288,84 @@ __global__ __launch_bounds__(256) void fq_gemm_i4_simple_kernel(const uint8_t* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Skinny GEMM for decode-sized batches (M <= 128): the work is streaming the weights once (N K / 2 bytes), so
+//  * the weights come from an IMAGE in MFMA fragment order (fq_i4_to_frag_kernel, built once per layer): blob
+//    (32-feature tile rt, 64-k block kb) = 64 lanes x 16 bytes, lane (h, c) = row prow(c), packed bytes
+//    32 kb + 16 h .. + 15 -> every load of a wave is 1 KB contiguous and a wave walks memory sequentially;
+//  * a 16-wave workgroup owns one feature tile and splits K between its waves (enough loads in flight with only
+//    N / 32 workgroups), each wave reusing its weight fragment for all token tiles; the 16 partial 32 x 32 tiles meet
+//    in LDS through ds_add_u32;
+//  * the activations (M x K / 2 bytes, L2-resident) are read directly as B fragments.
+// The big-tile kernel above spends ~46 us on any M <= 128 (it streams a 256-token tile that is mostly padding).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fq_i4_to_frag_kernel(const uint8_t* __restrict__ W, int N, int Kb, uint4* __restrict__ img) {
+    const int KB = Kb / 32;
+    const int64_t total = (int64_t)((N + 31) / 32) * KB * 64;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        const int64_t blob = i >> 6;
+        const int64_t rt = blob / KB;
+        const int kb = (int)(blob - rt * KB);
+        const int64_t row = rt * 32 + prow(lane & 31);
+        img[i] = row < N ? *reinterpret_cast<const uint4*>(W + row * Kb + kb * 32 + (lane >> 5) * 16) : make_uint4(0, 0, 0, 0);
+    }
+}
+
+constexpr int SK_WAVES = 16;
+
+template <int MT>
+__global__ __launch_bounds__(SK_WAVES * 64) void fq_gemm_i4_skinny_kernel(const uint8_t* __restrict__ X,
+                                                                         const uint4* __restrict__ Wimg, int M, int N,
+                                                                         int Kb, GemmOut out) {
+    __shared__ int tile[MT][32][33];  // [token tile][token][feature], +1 padding
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = blockIdx.x, KB = Kb / 32;
+    for (int i = tid; i < MT * 32 * 33; i += SK_WAVES * 64) (&tile[0][0][0])[i] = 0;
+    __syncthreads();
+
+    i32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = i32x16{0};
+    const uint4* wp = Wimg + (size_t)rt * KB * 64 + lane;
+    const uint8_t* xrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 32 + c;
+        xrow[mt] = X + (size_t)(m < M ? m : M - 1) * Kb + 16 * h;
+    }
+    for (int kb = wave; kb < KB; kb += SK_WAVES) {
+        const u32x4 a_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)kb * 64));
+        const uint4 a = make_uint4(a_[0], a_[1], a_[2], a_[3]);
+        const i32x4 a0 = unpack16(make_uint2(a.x, a.y)), a1 = unpack16(make_uint2(a.z, a.w));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const uint4 b = *reinterpret_cast<const uint4*>(xrow[mt] + (size_t)kb * 32);
+            acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, unpack16(make_uint2(b.x, b.y)), acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, unpack16(make_uint2(b.z, b.w)), acc[mt], 0, 0, 0);
+        }
+    }
+    // lane (h, c) of tile mt: token 32 mt + c, features 16 h + r
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(&tile[mt][c][16 * h + r], acc[mt][r]);
+    __syncthreads();
+    for (int i = tid; i < MT * 32 * 32; i += SK_WAVES * 64) {
+        const int mt = i >> 10, tok = (i >> 5) & 31, nl = i & 31;
+        const int m = mt * 32 + tok, n = rt * 32 + nl;
+        if (m >= M || n >= N) continue;
+        const int v = tile[mt][tok][nl] >> 8;  // products carry 256 (see unpack16)
+        if (out.c != nullptr) out.c[(int64_t)m * N + n] = v;
+        if (out.y != nullptr) {
+            f16 y = dequant1(v, out.srow[m], out.scol[n]);
+            if (out.bias != nullptr) y = y + out.bias[n];
+            out.y[(int64_t)m * N + n] = y;
+        }
+    }
+}
+
 }  // namespace
 
 // -1000: shape not accepted (K must be a multiple of 32, as deploy.matmul asserts).
@@ -308,5 +386,37 @@ int fq_launch_gemm_i4(const uint8_t* X, const uint8_t* W, int64_t M, int N, int 
     }
     const int64_t blocks = 8 * ((((M + BM - 1) / BM) * ((N + BN - 1) / BN) + 7) / 8);  // see xcd_tile
     hipLaunchKernelGGL(fq_gemm_i4_kernel, dim3((unsigned)blocks), dim3(GT), 0, stream, X, W, (int)M, N, K / 2, o);
+    return (int)hipGetLastError();
+}
+
+int64_t fq_i4_frag_bytes(int N, int K) {
+    if (N < 1 || K < 64 || (K & 63)) return -1;
+    return (int64_t)((N + 31) / 32) * (K / 64) * 1024;
+}
+
+int fq_launch_i4_to_frag(const uint8_t* W, int N, int K, void* img, int n_cu, hipStream_t stream) {
+    if (fq_i4_frag_bytes(N, K) < 0) return -1000;
+    const int64_t total = (int64_t)((N + 31) / 32) * (K / 64) * 64;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > (int64_t)n_cu * 16) blocks = (int64_t)n_cu * 16;
+    hipLaunchKernelGGL(fq_i4_to_frag_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, W, N, K / 2, reinterpret_cast<uint4*>(img));
+    return (int)hipGetLastError();
+}
+
+// -1000: M > 128 or K % 64 != 0 (use the tile kernel)
+int fq_launch_gemm_i4_skinny(const uint8_t* X, const void* wimg, int64_t M, int N, int K, int32_t* c, f16* y, const f16* srow,
+                             const f16* scol, const f16* bias, hipStream_t stream) {
+    if (M < 1 || M > 128 || N < 1 || (K & 63) || K < 64 || K > 131072) return -1000;
+    GemmOut o;
+    o.c = c;
+    o.y = y;
+    o.srow = srow;
+    o.scol = scol;
+    o.bias = bias;
+    const dim3 grid((unsigned)((N + 31) / 32));
+    const uint4* img = reinterpret_cast<const uint4*>(wimg);
+    if (M <= 32) hipLaunchKernelGGL(fq_gemm_i4_skinny_kernel<1>, grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o);
+    else if (M <= 64) hipLaunchKernelGGL(fq_gemm_i4_skinny_kernel<2>, grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o);
+    else hipLaunchKernelGGL(fq_gemm_i4_skinny_kernel<4>, grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o);
     return (int)hipGetLastError();
 }

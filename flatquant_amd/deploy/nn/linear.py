@@ -46,10 +46,29 @@ class Linear4bit(torch.nn.Module):
             self._wimg_key = key
         return self._wimg
 
+    def _decode_image(self):
+        """``weight`` in MFMA fragment order for the decode-sized (M <= 128) weight-streaming kernel; cached like the
+        FP6 image. FQ_SKINNY_GEMM=0 turns the path off."""
+        if os.environ.get("FQ_SKINNY_GEMM") == "0" or self.in_features % 64:
+            return None
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        if getattr(self, "_dimg_key", None) != key:
+            self._dimg = ops.int4_to_frag(self.weight)
+            self._dimg_key = key
+        return self._dimg
+
     def forward(self, x):
         assert type(x) == PackedQuantizedTensor  # quantized input is given (linear.py:45)
         q, scales_x = x.quantized_x, x.scales_x
         lead = q.shape[:-1]
+        rows = q.numel() // q.shape[-1]
+        if q.is_cuda and ops.skinny_supported(rows, self.in_features):
+            dimg = self._decode_image()
+            if dimg is not None:
+                y = ops.int4_skinny_linear(q.reshape(rows, -1).contiguous(), scales_x.reshape(-1).contiguous(), dimg,
+                                           self.weight_scales.reshape(-1).to(torch.float16).contiguous(),
+                                           None if self.bias is None else self.bias.to(torch.float16), self.out_features)
+                return y.view(*lead, self.out_features)
         wimg = self._weight_image() if q.is_cuda else None
         if wimg is not None:
             q2 = q.reshape(-1, q.shape[-1]).contiguous()

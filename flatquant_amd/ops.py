@@ -354,6 +354,51 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
     return q, s
 
 
+def int4_to_frag(w: torch.Tensor) -> torch.Tensor:
+    """Linear4bit.weight [N, K/2] -> its image in MFMA fragment order for the decode-sized GEMM (fq_int4_to_frag)."""
+    _chk(w, "w", torch.uint8)
+    N, K = w.shape[0], w.shape[1] * 2
+    nbytes = lib.fq_int4_frag_bytes(N, K)
+    if nbytes < 0:
+        raise _lib.FqError(_lib.FQ_EUNSUPPORTED, f"int4_to_frag: K={K} must be a multiple of 64")
+    img = torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        check(lib.fq_int4_to_frag(_ptr(w), N, K, _ptr(img), _stream(w)))
+    return img
+
+
+def skinny_supported(M: int, K: int) -> bool:
+    return 1 <= M <= 128 and K % 64 == 0
+
+
+def int4_skinny_matmul(x: torch.Tensor, w_image: torch.Tensor, N: int) -> torch.Tensor:
+    """int4_matmul for M <= 128 rows against a weight image from int4_to_frag (fq_int4_skinny_gemm_i32)."""
+    _chk(x, "x", torch.uint8)
+    M, K = x.shape[0], x.shape[1] * 2
+    c = torch.empty((M, N), dtype=torch.int32, device=x.device)
+    if M:
+        with torch.cuda.device(x.device):
+            check(lib.fq_int4_skinny_gemm_i32(_ptr(x), _ptr(w_image), M, N, K, _ptr(c), _stream(x)))
+    return c
+
+
+def int4_skinny_linear(x: torch.Tensor, x_scale: torch.Tensor, w_image: torch.Tensor, w_scale: torch.Tensor,
+                       bias: Optional[torch.Tensor], N: int) -> torch.Tensor:
+    """int4_linear for M <= 128 rows against a weight image (fq_int4_skinny_linear_f16), bit-identical."""
+    _chk(x, "x", torch.uint8), _chk(x_scale, "x_scale"), _chk(w_scale, "w_scale")
+    M, K = x.shape[0], x.shape[1] * 2
+    if x_scale.numel() != M or w_scale.numel() != N:
+        raise RuntimeError("int4_skinny_linear: x_scale must have M elements, w_scale N")
+    if bias is not None:
+        _chk(bias, "bias")
+    y = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    if M:
+        with torch.cuda.device(x.device):
+            check(lib.fq_int4_skinny_linear_f16(_ptr(x), _ptr(x_scale), _ptr(w_image), _ptr(w_scale), _ptr(bias), M, N, K,
+                                                _ptr(y), _stream(x)))
+    return y
+
+
 def int4_to_bf6(q: torch.Tensor, weights: bool = False) -> torch.Tensor:
     """Packed INT4 [rows, K/2] -> the BF6 operand image of the FP6-path GEMM (fq_int4_to_bf6). ``weights``: the image of
     a Linear4bit.weight (convert once per layer); else of packed activations. K % 64 == 0."""

@@ -166,6 +166,20 @@ int fq_int4_linear_f16(const void* x, const void* x_scale, const void* w, const 
                        int64_t M, int N, int K, void* y, void* stream);
 
 /*
+ * Decode-sized batches (M <= 128): the same GEMM / Linear4bit as a weight-streaming kernel. The weights are read from an
+ * image in MFMA fragment order, built once per layer:
+ *   fq_int4_frag_bytes(N, K)                 bytes of the image (K % 64 == 0; -1 otherwise)
+ *   fq_int4_to_frag(w [N, K/2], N, K, image)
+ *   fq_int4_skinny_gemm_i32 / fq_int4_skinny_linear_f16: as fq_int4_gemm_i32 / fq_int4_linear_f16 with the image in
+ *   place of w; M <= 128, K % 64 == 0, FQ_EUNSUPPORTED otherwise. Bit-identical results.
+ */
+int64_t fq_int4_frag_bytes(int N, int K);
+int fq_int4_to_frag(const void* w, int N, int K, void* image, void* stream);
+int fq_int4_skinny_gemm_i32(const void* x, const void* w_image, int64_t M, int N, int K, void* c, void* stream);
+int fq_int4_skinny_linear_f16(const void* x, const void* x_scale, const void* w_image, const void* w_scale,
+                              const void* bias, int64_t M, int N, int K, void* y, void* stream);
+
+/*
  * The same GEMM / Linear4bit on the FP6 matrix path (v_mfma_scale_f32_32x32x64_f8f6f4, both operands BF6 = E3M2, unit
  * block scales): every integer in [-8, 7] is a BF6 value and the fp32 accumulator holds the exact integer sum
  * (K <= 2^18), so the results are bit-identical to fq_int4_gemm_i32 / fq_int4_linear_f16 — at ~1.4x the sustained

@@ -91,3 +91,46 @@ def test_deploy_linear4bit_module_end_to_end(ops):
     assert rel < 0.25
     assert torch.equal(deploy.matmul(packed.quantized_x, q.weight).reshape(-1, 512),
                        ops.int4_matmul(packed.quantized_x.reshape(-1, 2048), q.weight))
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 1024, 4096), (32, 256, 128), (33, 272, 256), (64, 4096, 1024),
+                                   (100, 48, 384), (128, 14336, 4096), (5, 4096, 14336), (17, 40, 64)])
+def test_skinny_gemm_bit_exact(ops, M, N, K):
+    """decode-sized batches: the weight-streaming kernel on the fragment-order weight image == the integer product"""
+    gen = torch.Generator().manual_seed(M * 7 + N * 3 + K + 1)
+    xp, xq = rand_packed(gen, M, K)
+    wp, wq = rand_packed(gen, N, K)
+    img = ops.int4_to_frag(torch.from_numpy(wp).cuda())
+    c = ops.int4_skinny_matmul(torch.from_numpy(xp).cuda(), img, N).cpu().numpy()
+    ref = xq.astype(np.int64) @ wq.astype(np.int64).T
+    assert np.array_equal(c, ref.astype(np.int32))
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(16, 256, 4096, False), (65, 272, 256, True), (128, 1024, 1024, True)])
+def test_skinny_linear_equals_tile_kernel(ops, M, N, K, bias):
+    gen = torch.Generator().manual_seed(M + N + K + 2)
+    xp, _ = rand_packed(gen, M, K)
+    wp, _ = rand_packed(gen, N, K)
+    sx = (torch.rand(M, generator=gen) * 0.05 + 0.001).half().cuda()
+    sw = (torch.rand(N, generator=gen) * 0.02 + 0.0005).half().cuda()
+    b = torch.randn(N, generator=gen).half().cuda() if bias else None
+    x, w = torch.from_numpy(xp).cuda(), torch.from_numpy(wp).cuda()
+    y = ops.int4_skinny_linear(x, sx, ops.int4_to_frag(w), sw, b, N)
+    assert torch.equal(y, ops.int4_linear(x, sx, w, sw, b))
+
+
+def test_module_takes_the_skinny_path_for_decode_batches(ops):
+    import flatquant_amd.deploy as deploy
+    gen = torch.Generator().manual_seed(9)
+    lin = deploy.nn.Linear4bit(512, 384, bias=True).cuda()
+    lin.weight.copy_(torch.from_numpy(rand_packed(gen, 384, 512)[0]))
+    lin.weight_scales.copy_((torch.rand(384, 1, generator=gen) * 0.02 + 0.001))
+    lin.bias.copy_(torch.randn(384, generator=gen).half())
+    xp, _ = rand_packed(gen, 4, 512)
+    p = deploy.PackedQuantizedTensor(torch.from_numpy(xp).cuda().reshape(4, 1, 256),
+                                     (torch.rand(4, 1, 1, generator=gen) * 0.05 + 0.001).half().cuda())
+    y = lin(p)
+    assert getattr(lin, "_dimg", None) is not None
+    ref = ops.int4_linear(p.quantized_x.reshape(-1, 256), p.scales_x.reshape(-1), lin.weight,
+                          lin.weight_scales.reshape(-1).half(), lin.bias.half()).view(4, 1, 384)
+    assert torch.equal(y, ref)
