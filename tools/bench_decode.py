@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""One decoder layer's quantised decode step (one new token per request) through flatquant_amd's deploy modules, replayed
+from a captured HIP graph (from Python every launch costs ~10 us of allocation + ctypes, more than most of these kernels):
+norm + q/k/v transform (one launch) -> three Linear4bit (weight-streaming kernel) -> K transform + K/V INT4 pack ->
+paged-cache append -> INT4 decode attention -> o_proj head transform -> Linear4bit -> norm + up/gate transform ->
+two Linear4bit -> SiLU.mul + down_proj transform -> Linear4bit.  RoPE and the residual adds are left out (torch ops of
+the host model). Llama-3-8B shapes, random weights."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import flatquant_amd.deploy as deploy  # noqa: E402
+import flatquant_amd.deploy.transformers as dt  # noqa: E402
+from flatquant_amd import ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bsz", type=int, default=16)
+    ap.add_argument("--cache", type=int, default=2048, help="cached tokens per request")
+    ap.add_argument("--iters", type=int, default=200)
+    a = ap.parse_args()
+    hidden, ffn, heads, kv_heads, hd = 4096, 14336, 32, 8, 128
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(0)
+
+    def trans(dim, decompose=True):
+        t = deploy.nn.OnlineTrans(dim, trans="matmul", decompose=decompose, lac=True).to(dev)
+        for name in ("left_matrix", "right_matrix"):
+            if hasattr(t, name):
+                b = getattr(t, name)
+                b.copy_(torch.randn(b.shape, generator=g, device=dev) / b.shape[0] ** 0.5)
+        t.clip_factor_a_max.fill_(4.0), t.clip_factor_a_min.fill_(4.0)
+        return t
+
+    def share(ts):
+        for t in ts[1:]:
+            for name in ("left_matrix", "right_matrix"):
+                del t._buffers[name]
+                t.register_buffer(name, getattr(ts[0], name))
+        return ts
+
+    def lin(k_in, n_out):
+        m = deploy.nn.Linear4bit(k_in, n_out).to(dev)
+        m.weight_scales.fill_(0.01)
+        return m
+
+    qkv_t, ug_t = share([trans(hidden) for _ in range(3)]), share([trans(hidden) for _ in range(2)])
+    o_t, down_t = trans(heads, decompose=False), trans(ffn)
+    norm = deploy.nn.RMSNorm(hidden)
+    q_l, k_l, v_l, o_l = lin(hidden, hidden), lin(hidden, kv_heads * hd), lin(hidden, kv_heads * hd), lin(hidden, hidden)
+    up_l, gate_l, down_l = lin(hidden, ffn), lin(hidden, ffn), lin(ffn, hidden)
+    tk = (torch.randn(hd, hd, generator=g, device=dev) / hd ** 0.5).half()
+    cache = dt.MultiLayerPagedKVCache4Bit(a.bsz, 2048, a.cache + 8, dev, 1, heads, hd, trans="matmul", group_size=heads // kv_heads)
+    kw = {"trans_matrix_k": tk, "trans_matrix_k_inv_t": tk}
+    cache.update(torch.randn(a.bsz, a.cache, kv_heads, hd, generator=g, device=dev).half(),
+                 torch.randn(a.bsz, a.cache, kv_heads, hd, generator=g, device=dev).half(), 0, dict(kw))
+    x = torch.randn(a.bsz, 1, hidden, generator=g, device=dev).half()
+
+    def step(h):
+        pq, pk, pv = deploy.nn.fused_forward(h, qkv_t, norm=norm)
+        q, k, v = q_l(pq), k_l(pk), v_l(pv)
+        attend = cache.update(k.view(a.bsz, 1, kv_heads, hd), v.view(a.bsz, 1, kv_heads, hd), 0, dict(kw))
+        att = attend(q.view(a.bsz, 1, heads, hd))                                   # [bsz, 1, heads, hd]
+        po = o_t(att.transpose(-1, -2).contiguous())
+        po.quantized_x = po.quantized_x.contiguous().reshape(a.bsz, 1, -1)
+        h2 = o_l(po)
+        pu, pg = deploy.nn.fused_forward(h2, ug_t, norm=norm)
+        return down_l(down_t(gate_l(pg), up=up_l(pu)))
+
+    # eager warm-up (fills the weight-image / workspace / scalar caches), rewinding the cache length each time
+    for _ in range(3):
+        y = step(x)
+        cache.length -= 1
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        step(x)
+        cache.length -= 1
+    e1.record()
+    torch.cuda.synchronize()
+    eager = e0.elapsed_time(e1) / 20 * 1e3
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step(x)
+        cache.length -= 1
+        with torch.cuda.graph(graph, stream=s):
+            y = step(x)
+        cache.length -= 1
+    torch.cuda.synchronize()
+    for _ in range(10):
+        graph.replay()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(a.iters):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / a.iters * 1e3
+    print(f"Llama-3-8B decoder layer, decode step, {a.bsz} requests x {a.cache} cached tokens: {us:.1f} us per layer from a "
+          f"captured graph ({eager:.1f} us launched eagerly from Python); output finite: {bool(torch.isfinite(y.float()).all())}")
+
+
+if __name__ == "__main__":
+    main()
