@@ -35,7 +35,7 @@ int fq_launch_kron_any(int flags, const f16* x, const f16* left, const f16* righ
                        int N, const FqQuantOut& out, int n_cu, hipStream_t stream);
 int fq_launch_kv_append(void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last, const uint8_t* k,
                         const uint8_t* v, const f16* kparam, const f16* vparam, const int* seqlen_indptr, int64_t total_tokens,
-                        int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, int n_cu,
+                        int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, int group, int n_cu,
                         hipStream_t stream);
 int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, hipStream_t stream);
@@ -447,9 +447,10 @@ static int kv_geometry_ok(const char* what, int num_layers, int layer_idx, int n
 int fq_kv_append_i4(void* kv_data, void* kv_param, const void* kv_indptr, const void* kv_indices,
                     const void* last_page_offset, const void* k, const void* v, const void* k_param, const void* v_param,
                     const void* seqlen_indptr, int64_t tokens, int num_layers, int layer_idx, int num_heads, int page_size,
-                    int head_dim, int batch_size, void* stream) {
+                    int head_dim, int batch_size, int group_size, void* stream) {
     int rc = kv_geometry_ok("fq_kv_append_i4", num_layers, layer_idx, num_heads, page_size, head_dim, batch_size);
     if (rc != FQ_OK) return rc;
+    if (group_size < 1 || num_heads % group_size) return fail(FQ_EINVAL, "fq_kv_append_i4: group_size=%d must divide num_heads=%d", group_size, num_heads);
     if (tokens < 0) return fail(FQ_EINVAL, "fq_kv_append_i4: tokens < 0");
     if (!seqlen_indptr && tokens != batch_size) return fail(FQ_EINVAL, "fq_kv_append_i4: without seqlen_indptr every request appends one token (tokens == batch_size)");
     if (tokens == 0) return FQ_OK;
@@ -458,7 +459,7 @@ int fq_kv_append_i4(void* kv_data, void* kv_param, const void* kv_indptr, const 
     rc = fq_launch_kv_append(kv_data, kv_param, (const int*)kv_indptr, (const int*)kv_indices, (const int*)last_page_offset,
                              (const uint8_t*)k, (const uint8_t*)v, (const f16*)k_param, (const f16*)v_param,
                              (const int*)seqlen_indptr, tokens, num_layers, layer_idx, num_heads, page_size, head_dim, batch_size,
-                             cu_count(), (hipStream_t)stream);
+                             group_size, cu_count(), (hipStream_t)stream);
     return check_launch(rc, "fq_kv_append_i4");
 }
 

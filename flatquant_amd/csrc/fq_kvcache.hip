@@ -39,7 +39,7 @@ __device__ __forceinline__ size_t v_entry(const PagedKv& p, size_t page, size_t 
 __global__ __launch_bounds__(256) void fq_kv_append_kernel(PagedKv p, const uint8_t* __restrict__ key,
                                                            const uint8_t* __restrict__ value, const f16* __restrict__ kparam,
                                                            const f16* __restrict__ vparam, const int* __restrict__ seqlen_indptr,
-                                                           int64_t total_tokens) {
+                                                           int64_t total_tokens, int group) {
     const int cpr = p.head_dim / 32;  // 16-byte chunks per packed row
     const int64_t items = total_tokens * p.num_heads * cpr;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
@@ -64,12 +64,14 @@ __global__ __launch_bounds__(256) void fq_kv_append_kernel(PagedKv p, const uint
         const size_t page = (size_t)p.indices[p.indptr[b] + pos / p.page_size];
         const size_t entry = (size_t)(pos % p.page_size);
         const size_t ke = k_entry(p, page, head, entry), ve = v_entry(p, page, head, entry);
-        const size_t src = ((size_t)tok * p.num_heads + head) * (p.head_dim / 2) + (size_t)ch * 16;
+        // grouped-query attention (kv_cache.py:286-296): the inputs hold num_heads / group heads, cache head h copies head h / group
+        const size_t shead = (size_t)tok * (p.num_heads / group) + head / group;
+        const size_t src = shead * (p.head_dim / 2) + (size_t)ch * 16;
         *reinterpret_cast<uint4*>(p.data + ke * (p.head_dim / 2) + ch * 16) = *reinterpret_cast<const uint4*>(key + src);
         *reinterpret_cast<uint4*>(p.data + ve * (p.head_dim / 2) + ch * 16) = *reinterpret_cast<const uint4*>(value + src);
         if (ch == 0) {
-            reinterpret_cast<uint32_t*>(p.param)[ke] = reinterpret_cast<const uint32_t*>(kparam)[(size_t)tok * p.num_heads + head];
-            reinterpret_cast<uint32_t*>(p.param)[ve] = reinterpret_cast<const uint32_t*>(vparam)[(size_t)tok * p.num_heads + head];
+            reinterpret_cast<uint32_t*>(p.param)[ke] = reinterpret_cast<const uint32_t*>(kparam)[shead];
+            reinterpret_cast<uint32_t*>(p.param)[ve] = reinterpret_cast<const uint32_t*>(vparam)[shead];
         }
     }
 }
@@ -176,16 +178,16 @@ static PagedKv make_kv(void* kv_data, void* kv_param, const int* indptr, const i
 
 int fq_launch_kv_append(void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last, const uint8_t* k,
                         const uint8_t* v, const f16* kparam, const f16* vparam, const int* seqlen_indptr, int64_t total_tokens,
-                        int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, int n_cu,
+                        int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, int group, int n_cu,
                         hipStream_t stream) {
-    if (head_dim % 32) return -1000;
+    if (head_dim % 32 || group < 1 || num_heads % group) return -1000;
     const PagedKv p = make_kv(kv_data, kv_param, indptr, indices, last, num_layers, layer_idx, num_heads, page_size, head_dim, batch);
     const int64_t items = total_tokens * num_heads * (head_dim / 32);
     int64_t blocks = (items + 255) / 256;
     if (blocks > (int64_t)n_cu * 16) blocks = (int64_t)n_cu * 16;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(fq_kv_append_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, k, v, kparam, vparam, seqlen_indptr,
-                       total_tokens);
+                       total_tokens, group);
     return (int)hipGetLastError();
 }
 

@@ -46,16 +46,18 @@ def transform_quantize_kv(key_states: torch.Tensor, value_states: torch.Tensor, 
     return kq, kp.reshape(b * n, heads, 2), vq, vp.reshape(b * n, heads, 2)
 
 
-def init_kv_i4(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, k, v, k_param, v_param, seqlen_indptr, layer_idx):
-    """kv_cache.py:69-80 (-> _CUDA.init_kv_i4): append each request's tokens seqlen_indptr[b] .. seqlen_indptr[b+1] - 1."""
+def init_kv_i4(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, k, v, k_param, v_param, seqlen_indptr, layer_idx,
+               group_size=1):
+    """kv_cache.py:69-80 (-> _CUDA.init_kv_i4): append each request's tokens seqlen_indptr[b] .. seqlen_indptr[b+1] - 1.
+    ``group_size`` (extension): see ops.kv_append."""
     ops.kv_append(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, k.contiguous(), v.contiguous(),
-                  k_param.contiguous(), v_param.contiguous(), layer_idx, seqlen_indptr)
+                  k_param.contiguous(), v_param.contiguous(), layer_idx, seqlen_indptr, group_size)
 
 
-def append_kv_i4(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, k, v, k_param, v_param, layer_idx):
+def append_kv_i4(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, k, v, k_param, v_param, layer_idx, group_size=1):
     """kv_cache.py:83-95 (-> _CUDA.append_kv_i4): one new token per request."""
     ops.kv_append(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, k.contiguous(), v.contiguous(),
-                  k_param.contiguous(), v_param.contiguous(), layer_idx, None)
+                  k_param.contiguous(), v_param.contiguous(), layer_idx, None, group_size)
 
 
 def batch_decode_i4(o, q, kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, layer_idx):
@@ -133,24 +135,23 @@ class MultiLayerPagedKVCache4Bit:
         tk_inv_t = cache_kwargs.get("trans_matrix_k_inv_t") if self.trans.startswith("matmul") else None
         # kv_cache.py:283-284: the cache's own calls leave lac off, so the clip factors play no part
         kq, kp, vq, vp = transform_quantize_kv(key_states, value_states, tk)
-        if self.group_size > 1:  # :286-296 grouped-query attention: every query head gets its copy
-            kq, vq = kq.repeat_interleave(self.group_size, dim=2), vq.repeat_interleave(self.group_size, dim=2)
-            kp, vp = kp.repeat_interleave(self.group_size, dim=1), vp.repeat_interleave(self.group_size, dim=1)
-            heads *= self.group_size
+        # :286-296 grouped-query attention: every query head gets its copy — made by the scatter (group_size below)
         if layer_idx == 0:
             self._ensure_page_cnt_per_batch(self.page_cnt_from_length(self.length + added))
             self.length += added
-        specs = self.get_cache_specs_for_flash_infer()
+        if getattr(self, "_specs_len", None) != (self.length, self.pages.data_ptr()):   # index tensors: once per step, not per layer
+            self._specs, self._specs_len = self.get_cache_specs_for_flash_infer(), (self.length, self.pages.data_ptr())
+        specs = self._specs
         args = (specs["kv_data"], specs["kv_param"], specs["kv_indptr"], specs["kv_indices"], specs["last_page_offset"])
         kq, vq = kq.reshape(b * added, heads, hd // 2), vq.reshape(b * added, heads, hd // 2)
         if self._needs_init[layer_idx]:
             self._needs_init[layer_idx] = False
             seqlens = torch.arange(b + 1, device=self.device, dtype=torch.int32) * added
-            init_kv_i4(*args, kq, vq, kp, vp, seqlens, layer_idx)
+            init_kv_i4(*args, kq, vq, kp, vp, seqlens, layer_idx, self.group_size)
             keys = key_states if tk is None else torch.matmul(key_states.to(torch.float16), tk.to(key_states.device, torch.float16))
             return keys, value_states                                   # :341-344: the un-quantised states for prefill
         assert added == 1
-        append_kv_i4(*args, kq, vq, kp, vp, layer_idx)
+        append_kv_i4(*args, kq, vq, kp, vp, layer_idx, self.group_size)
 
         def attend(q):
             bq, q_len, n_q, d = q.shape

@@ -490,10 +490,11 @@ def _kv_geometry(kv_data: torch.Tensor):
 
 def kv_append(kv_data: torch.Tensor, kv_param: torch.Tensor, kv_indptr: torch.Tensor, kv_indices: torch.Tensor,
               last_page_offset: torch.Tensor, k: torch.Tensor, v: torch.Tensor, k_param: torch.Tensor, v_param: torch.Tensor,
-              layer_idx: int, seqlen_indptr: Optional[torch.Tensor] = None) -> None:
+              layer_idx: int, seqlen_indptr: Optional[torch.Tensor] = None, group_size: int = 1) -> None:
     """init_kv_i4 (with ``seqlen_indptr``) / append_kv_i4 (without) of deploy/transformers/kv_cache.py:69-95: scatter
     packed keys / values [tokens, heads, head_dim/2] uint8 and their (scale, zero) [tokens, heads, 2] fp16 into the paged
-    cache (fq_kv_append_i4). The index tensors are int32 on the cache's device."""
+    cache (fq_kv_append_i4). The index tensors are int32 on the cache's device. ``group_size`` g: k / v hold heads / g
+    heads and every cache head h receives head h // g (the GQA repeat of kv_cache.py:286-296, done by the scatter)."""
     _chk(kv_data, "kv_data", torch.uint8), _chk(kv_param, "kv_param"), _chk(k, "k", torch.uint8), _chk(v, "v", torch.uint8)
     _chk(k_param, "k_param"), _chk(v_param, "v_param")
     for t, n in ((kv_indptr, "kv_indptr"), (kv_indices, "kv_indices"), (last_page_offset, "last_page_offset")):
@@ -502,13 +503,14 @@ def kv_append(kv_data: torch.Tensor, kv_param: torch.Tensor, kv_indptr: torch.Te
         _chk(seqlen_indptr, "seqlen_indptr", torch.int32)
     n_layers, heads, page_size, hd = _kv_geometry(kv_data)
     batch = last_page_offset.numel()
-    tokens = k.numel() // (heads * hd // 2)
-    if k.shape != v.shape or k_param.numel() != tokens * heads * 2 or v_param.numel() != tokens * heads * 2:
+    src_heads = heads // group_size
+    tokens = k.numel() // (src_heads * hd // 2)
+    if k.shape != v.shape or k_param.numel() != tokens * src_heads * 2 or v_param.numel() != tokens * src_heads * 2:
         raise ValueError("k / v / k_param / v_param shapes do not agree")
     with torch.cuda.device(kv_data.device):
         check(lib.fq_kv_append_i4(_ptr(kv_data), _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
                                   _ptr(k), _ptr(v), _ptr(k_param), _ptr(v_param), _ptr(seqlen_indptr), tokens, n_layers,
-                                  layer_idx, heads, page_size, hd, batch, _stream(kv_data)))
+                                  layer_idx, heads, page_size, hd, batch, group_size, _stream(kv_data)))
 
 
 def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tensor, kv_indptr: torch.Tensor,

@@ -265,7 +265,9 @@ int fq_kv_dequant_f16(const void* q, const void* param, int64_t rows, int head_d
  * fq_kv_append_i4: k, v [tokens, num_heads, head_dim/2] uint8 and k_param, v_param [tokens, num_heads, 2] fp16 (the
  *   outputs of fq_kv_quant_f16). seqlen_indptr [batch+1] int32: request b appends tokens seqlen_indptr[b] ..
  *   seqlen_indptr[b+1] - 1 at the END of its current length (init_kv_i4, page.cuh:163-214); NULL: one token per
- *   request, tokens == batch (append_kv_i4, page.cuh:118-161).
+ *   request, tokens == batch (append_kv_i4, page.cuh:118-161). group_size g > 1 (grouped-query attention,
+ *   kv_cache.py:286-296, which repeats the tensors first): k, v and their params hold num_heads / g heads and cache head h
+ *   receives head h / g — the repeat_interleave happens in the scatter.
  * fq_kv_batch_decode_i4: one query token per request, q and o [batch, num_heads, head_dim] fp16 (decode.cuh:492-683,
  *   no rotary embedding, softmax scale 1/sqrt(head_dim)): o = softmax(q . K^T / sqrt(hd)) . V over the request's cached
  *   rows, K and V de-quantised as n * scale - zero (quantization.cuh:58-80), fp32 arithmetic. head_dim in {64, 128}.
@@ -273,7 +275,7 @@ int fq_kv_dequant_f16(const void* q, const void* param, int64_t rows, int head_d
 int fq_kv_append_i4(void* kv_data, void* kv_param, const void* kv_indptr, const void* kv_indices,
                     const void* last_page_offset, const void* k, const void* v, const void* k_param, const void* v_param,
                     const void* seqlen_indptr, int64_t tokens, int num_layers, int layer_idx, int num_heads, int page_size,
-                    int head_dim, int batch_size, void* stream);
+                    int head_dim, int batch_size, int group_size, void* stream);
 int fq_kv_batch_decode_i4(void* o, const void* q, const void* kv_data, const void* kv_param, const void* kv_indptr,
                           const void* kv_indices, const void* last_page_offset, int num_layers, int layer_idx,
                           int num_heads, int page_size, int head_dim, int batch_size, void* stream);
