@@ -46,6 +46,18 @@ class Linear4bit(torch.nn.Module):
             self._wimg_key = key
         return self._wimg
 
+    def _scales16(self):
+        """(weight_scales as a flat fp16 vector, bias as fp16 or None), converted once per buffer version: the buffers are
+        fp32 unless the model was built under a fp16 default dtype, and a conversion launch per call costs more than the
+        decode-sized GEMM itself."""
+        b = self.bias
+        key = (self.weight_scales.data_ptr(), self.weight_scales._version, None if b is None else (b.data_ptr(), b._version))
+        if getattr(self, "_s16_key", None) != key:
+            self._s16 = (self.weight_scales.reshape(-1).to(torch.float16).contiguous(),
+                         None if b is None else b.to(torch.float16).contiguous())
+            self._s16_key = key
+        return self._s16
+
     def _decode_image(self):
         """``weight`` in MFMA fragment order for the decode-sized (M <= 128) weight-streaming kernel; cached like the
         FP6 image. FQ_SKINNY_GEMM=0 turns the path off."""
@@ -65,21 +77,20 @@ class Linear4bit(torch.nn.Module):
         if q.is_cuda and ops.skinny_supported(rows, self.in_features):
             dimg = self._decode_image()
             if dimg is not None:
+                ws16, b16 = self._scales16()
                 y = ops.int4_skinny_linear(q.reshape(rows, -1).contiguous(), scales_x.reshape(-1).contiguous(), dimg,
-                                           self.weight_scales.reshape(-1).to(torch.float16).contiguous(),
-                                           None if self.bias is None else self.bias.to(torch.float16), self.out_features)
+                                           ws16, b16, self.out_features)
                 return y.view(*lead, self.out_features)
         wimg = self._weight_image() if q.is_cuda else None
         if wimg is not None:
             q2 = q.reshape(-1, q.shape[-1]).contiguous()
-            y = ops.bf6_linear(ops.int4_to_bf6(q2), scales_x.reshape(-1).contiguous(), wimg,
-                               self.weight_scales.reshape(-1).to(torch.float16).contiguous(),
-                               None if self.bias is None else self.bias.to(torch.float16),
+            ws16, b16 = self._scales16()
+            y = ops.bf6_linear(ops.int4_to_bf6(q2), scales_x.reshape(-1).contiguous(), wimg, ws16, b16,
                                q2.shape[0], self.out_features, self.in_features)
             return y.view(*lead, self.out_features)
+        ws16, b16 = self._scales16()
         y = ops.int4_linear(q.reshape(-1, q.shape[-1]).contiguous(), scales_x.reshape(-1).contiguous(),
-                            self.weight, self.weight_scales.reshape(-1).to(torch.float16).contiguous(),
-                            None if self.bias is None else self.bias.to(torch.float16))
+                            self.weight, ws16, b16)
         return y.view(*lead, self.out_features)
 
     @staticmethod
