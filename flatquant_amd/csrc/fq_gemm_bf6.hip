@@ -18,10 +18,12 @@
 //
 // Tiling: 256 x 256 per 8-wave workgroup, wave tile 128 tokens x 64 features (8 accumulator tiles: 6 fragments per 8
 // MFMAs), three LDS stages of 48 KB, counted vmcnt, one barrier per stage — the pipeline of fq_gemm_i4.hip.
-#include "fq_common.hpp"
+#include "fq_gemm_common.hpp"
 #include <stdlib.h>
 
 namespace {
+
+using namespace fqgemm;
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_b;
@@ -44,41 +46,6 @@ constexpr int TMT = BM / 32 / NWM;             // token tiles per wave
 #endif
 constexpr int DW = FQ_BF6_DMA_WAVES;
 constexpr int DPW = (TILE_BYTES / 1024) / DW;  // DMA instructions per issuing wave and stage
-
-__device__ __forceinline__ int prow(int c) { return ((c >> 2) & 1) * 16 + (c & 3) + 4 * (c >> 3); }
-
-// quant.cu:5-10,66-85 (same as fq_gemm_i4.hip)
-__device__ __forceinline__ f16 dequant1(int q, f16 srow, f16 scol) {
-    int iv = (int)((float)q / 10.0f);
-    iv = max(-65176, min(65176, iv));
-    f16 r = srow * scol;
-    r = r * (f16)iv;
-    return r * (f16)10.0f;
-}
-
-// XCD-aware tile order. Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own 4 MB L2. XCD x
-// takes a CONTIGUOUS share of the tile sequence, and the sequence walks 8-feature-tile-wide column blocks row by row,
-// so the ~32 workgroups resident on an XCD at a time form a 4 x 8 patch of tiles: 12 distinct operand tiles per K
-// stage instead of 64, i.e. most of the operand traffic stays in that XCD's L2 instead of crossing the fabric.
-__device__ __forceinline__ bool xcd_tile(int bid, int TM, int TN, int& tm, int& tn) {
-    const int T = TM * TN, per = (T + 7) >> 3;
-    const int xcd = bid & 7, local = bid >> 3;
-    const int L = xcd * per + local;
-    if (local >= per || L >= T) return false;
-    const int blk = L / (8 * TM), rem = L - blk * 8 * TM;
-    const int width = TN - blk * 8 < 8 ? TN - blk * 8 : 8;
-    tm = rem / width;
-    tn = blk * 8 + (rem - tm * width);
-    return true;
-}
-
-struct GemmOut {
-    int32_t* c;
-    f16* y;
-    const f16* srow;
-    const f16* scol;
-    const f16* bias;
-};
 
 // ---- INT4 nibbles -> BF6 blobs ----------------------------------------------------------------------------------
 // E3M2 codes of 0..8; a negative value sets bit 5

@@ -15,9 +15,11 @@
 // side so that the ds_read_b64 fragment reads are conflict-free), counted vmcnt, one barrier per K-step.
 // The weight rows feed the MFMA A operand with a row permutation (prow) that leaves each lane with 16 CONSECUTIVE n of
 // one output row m: 64-byte (int32) or 32-byte (fp16) contiguous stores.
-#include "fq_common.hpp"
+#include "fq_gemm_common.hpp"
 
 namespace {
+
+using namespace fqgemm;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
@@ -46,8 +48,6 @@ constexpr int DPW = 32 / GW;          // DMA instructions per wave and stage
 __device__ __forceinline__ int swz_x(int r) { return (r >> 2) & 3; }
 __device__ __forceinline__ int swz_w(int r) { return ((r >> 2) & 1) | (((r >> 4) & 1) << 1); }
 
-// A-operand row (0..31) of a 32-row tile -> the n it holds, so that D's lane (h, .) ends with n = 16 h + reg
-__device__ __forceinline__ int prow(int c) { return ((c >> 2) & 1) * 16 + (c & 3) + 4 * (c >> 3); }
 
 // 16 nibbles (8 bytes) -> 16 signed bytes = 16 * q, as {hi(x.x), lo(x.x), hi(x.y), lo(x.y)}: the same element order on
 // both operands, which is all the contraction needs
@@ -63,39 +63,6 @@ __device__ __forceinline__ i32x4 unpack16(uint2 p) {
     r[3] = (int)((p.y << 4) & 0xF0F0F0F0u);
     return r;
 }
-
-// quant.cu:5-10,66-85: x = s_row * s_col * half(int(q / 10.0f)) * half(10), fp16 products left to right
-__device__ __forceinline__ f16 dequant1(int q, f16 srow, f16 scol) {
-    int iv = (int)((float)q / 10.0f);  // C truncation toward zero
-    iv = max(-65176, min(65176, iv));
-    f16 r = srow * scol;
-    r = r * (f16)iv;
-    return r * (f16)10.0f;
-}
-
-// XCD-aware tile order. Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own 4 MB L2. XCD x
-// takes a CONTIGUOUS share of the tile sequence, and the sequence walks 8-feature-tile-wide column blocks row by row,
-// so the ~32 workgroups resident on an XCD at a time form a 4 x 8 patch of tiles: 12 distinct operand tiles per K
-// stage instead of 64, i.e. most of the operand traffic stays in that XCD's L2 instead of crossing the fabric.
-__device__ __forceinline__ bool xcd_tile(int bid, int TM, int TN, int& tm, int& tn) {
-    const int T = TM * TN, per = (T + 7) >> 3;
-    const int xcd = bid & 7, local = bid >> 3;
-    const int L = xcd * per + local;
-    if (local >= per || L >= T) return false;
-    const int blk = L / (8 * TM), rem = L - blk * 8 * TM;
-    const int width = TN - blk * 8 < 8 ? TN - blk * 8 : 8;
-    tm = rem / width;
-    tn = blk * 8 + (rem - tm * width);
-    return true;
-}
-
-struct GemmOut {
-    int32_t* c;          // [M, N] int32, or nullptr
-    f16* y;              // [M, N] fp16 (fused dequant), or nullptr
-    const f16* srow;     // [M]  activation scales
-    const f16* scol;     // [N]  weight scales
-    const f16* bias;     // [N] or nullptr
-};
 
 __global__ __launch_bounds__(GT) void fq_gemm_i4_kernel(const uint8_t* __restrict__ X, const uint8_t* __restrict__ W,
                                                         int M, int N, int Kb, GemmOut out) {
