@@ -706,7 +706,9 @@ static int launch_kron64(const f16* x, const f16* left, const f16* right, const 
     if (blocks < 1) blocks = 1;
     const int64_t tpb = WAVES * FQ_K64_TPW;
 #else
-    int64_t blocks = (rows + WAVES - 1) / WAVES;
+    // few rows (decode): four tokens per workgroup, so that only the first SIMD-slot group of waves has work and no wave
+    // sits out the start-up stagger (up to 3 x 2560 cycles for the last group: most of an 11 us launch at 16 rows)
+    int64_t blocks = (rows + 3) / 4;
     if (blocks > n_cu) blocks = n_cu;  // one persistent workgroup per CU (LDS: 16 KB + 8 KB per wave)
     if (blocks < 1) blocks = 1;
     const int64_t tpb = (rows + blocks - 1) / blocks;
