@@ -105,10 +105,23 @@ __global__ __launch_bounds__(NW * 64) void fq_kv_decode_kernel(f16* __restrict__
 #pragma unroll
     for (int j = 0; j < 32; ++j) acc[j] = 0.0f;
 
+    const size_t page_stride = (size_t)p.num_layers * 2 * p.num_heads * p.page_size;
+    const size_t k_off = ((size_t)p.layer_idx * 2 * p.num_heads + head) * p.page_size, kv_off = (size_t)p.num_heads * p.page_size;
+    // (page, entry) of this quad's row advance incrementally: a 64-bit division per row would cost more than the row
+    int pit = 0, ent = wave * RPW + slot;
+    while (ent >= p.page_size) {
+        ent -= p.page_size;
+        ++pit;
+    }
     for (int64_t pos = (int64_t)wave * RPW + slot; pos < seq_len; pos += NS) {
-        const size_t page = (size_t)p.indices[pg0 + pos / p.page_size];
-        const size_t entry = (size_t)(pos % p.page_size);
-        const size_t ke = k_entry(p, page, head, entry), ve = v_entry(p, page, head, entry);
+        const size_t page = (size_t)p.indices[pg0 + pit];
+        const size_t entry = (size_t)ent;
+        ent += NS;
+        while (ent >= p.page_size) {
+            ent -= p.page_size;
+            ++pit;
+        }
+        const size_t ke = page * page_stride + k_off + entry, ve = ke + kv_off;   // = k_entry / v_entry, constants hoisted
         const uint4 kq = *reinterpret_cast<const uint4*>(p.data + ke * (HD / 2) + part * 16);
         const uint4 vq = *reinterpret_cast<const uint4*>(p.data + ve * (HD / 2) + part * 16);
         const uint32_t kpar = reinterpret_cast<const uint32_t*>(p.param)[ke];
