@@ -23,6 +23,10 @@ int fq_launch_kv_quant(const f16* x, const f16* T, int64_t rows, int hd, float c
                        f16* param, f16* y, int n_cu, hipStream_t stream);
 int fq_launch_kv_dequant(const uint8_t* q, const f16* param, int64_t rows, int hd, bool lac, f16* y, int n_cu,
                          hipStream_t stream);
+int fq_launch_kv_quant_append(const f16* k, const f16* v, const f16* T, int64_t tokens, int src_heads, int hd, const float* clip4,
+                              bool lac, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
+                              int num_layers, int layer_idx, int num_heads, int page_size, int added, int group, int n_cu,
+                              hipStream_t stream);
 int64_t fq_i4_frag_bytes(int N, int K);
 int fq_launch_i4_to_frag(const uint8_t* W, int N, int K, void* img, int n_cu, hipStream_t stream);
 int fq_launch_gemm_i4_skinny(const uint8_t* X, const void* wimg, int64_t M, int N, int K, int32_t* c, f16* y, const f16* srow,
@@ -461,6 +465,27 @@ int fq_kv_append_i4(void* kv_data, void* kv_param, const void* kv_indptr, const 
                              (const int*)seqlen_indptr, tokens, num_layers, layer_idx, num_heads, page_size, head_dim, batch_size,
                              group_size, cu_count(), (hipStream_t)stream);
     return check_launch(rc, "fq_kv_append_i4");
+}
+
+int fq_kv_quant_append_i4(const void* k, const void* v, const void* trans, int64_t tokens, int src_heads, int head_dim,
+                          const float* clip, int flags, void* kv_data, void* kv_param, const void* kv_indptr,
+                          const void* kv_indices, const void* last_page_offset, int num_layers, int layer_idx,
+                          int num_heads, int page_size, int batch_size, int group_size, void* stream) {
+    int rc = kv_geometry_ok("fq_kv_quant_append_i4", num_layers, layer_idx, num_heads, page_size, head_dim, batch_size);
+    if (rc != FQ_OK) return rc;
+    if (flags & ~FQ_KV_LAC) return fail(FQ_EINVAL, "fq_kv_quant_append_i4: unknown flags 0x%x", flags);
+    if (tokens < 0 || src_heads <= 0 || tokens % batch_size) return fail(FQ_EINVAL, "fq_kv_quant_append_i4: tokens=%lld must be a multiple of batch_size=%d", (long long)tokens, batch_size);
+    if (group_size < 1 || group_size > 4 || src_heads * group_size != num_heads)
+        return fail(FQ_EINVAL, "fq_kv_quant_append_i4: num_heads=%d must be src_heads=%d x group_size=%d (<= 4)", num_heads, src_heads, group_size);
+    if (tokens == 0) return FQ_OK;
+    if (!k || !v || !kv_data || !kv_param || !kv_indptr || !kv_indices || !last_page_offset)
+        return fail(FQ_EINVAL, "fq_kv_quant_append_i4: NULL pointer");
+    const float unit[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    rc = fq_launch_kv_quant_append((const f16*)k, (const f16*)v, (const f16*)trans, tokens, src_heads, head_dim,
+                                   clip ? clip : unit, (flags & FQ_KV_LAC) != 0, kv_data, kv_param, (const int*)kv_indptr,
+                                   (const int*)kv_indices, (const int*)last_page_offset, num_layers, layer_idx, num_heads,
+                                   page_size, (int)(tokens / batch_size), group_size, cu_count(), (hipStream_t)stream);
+    return check_launch(rc, "fq_kv_quant_append_i4");
 }
 
 int fq_kv_batch_decode_i4(void* o, const void* q, const void* kv_data, const void* kv_param, const void* kv_indptr,

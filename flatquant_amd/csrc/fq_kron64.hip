@@ -700,8 +700,8 @@ template <int FLAGS>
 static int launch_kron64(const f16* x, const f16* left, const f16* right, const f16* diag, int64_t rows,
                          const FqQuantOut& out, int n_cu, hipStream_t stream) {
     constexpr int THREADS = kron64_threads<FLAGS>();
-    constexpr int WAVES = THREADS / 64;
 #ifdef FQ_K64_TPW  // measurement builds: small workgroups of WAVES * FQ_K64_TPW tokens, balanced by the dispatcher
+    constexpr int WAVES = THREADS / 64;
     int64_t blocks = (rows + WAVES * FQ_K64_TPW - 1) / (WAVES * FQ_K64_TPW);
     if (blocks < 1) blocks = 1;
     const int64_t tpb = WAVES * FQ_K64_TPW;

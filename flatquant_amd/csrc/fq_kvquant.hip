@@ -68,10 +68,33 @@ __device__ __forceinline__ unsigned kv_q1(f16 x, KvParams p) {
     return (unsigned)(int)r;
 }
 
+// Inputs / outputs of one launch. which = blockIdx.y: 0 = keys (transformed when TRANS), 1 = values (never transformed;
+// present when x[1] != nullptr: K and V of a layer step in one launch). Dense destinations q / param / y, or — data != nullptr —
+// straight into the paged cache (the scatter of fq_kv_append_kernel, fq_kvcache.hip: every request appends `added` tokens
+// at the end of its current length, each source head feeds `group` cache heads).
+struct KvIO {
+    const f16* x[2];
+    uint8_t* q[2];
+    f16* param[2];
+    f16* y;
+    float cmax[2], cmin[2];
+    uint8_t* data;
+    f16* pparam;
+    const int* indptr;
+    const int* indices;
+    const int* last;
+    int num_layers, layer_idx, num_heads, page_size, added, group, src_heads;
+};
+
 template <int HD, bool TRANS, bool LAC>
-__global__ __launch_bounds__(256) void fq_kv_quant_kernel(const f16* __restrict__ x, const f16* __restrict__ T, int64_t rows,
-                                                          float clip_max, float clip_min, uint8_t* __restrict__ q_out,
-                                                          f16* __restrict__ param, f16* __restrict__ y_out) {
+__global__ __launch_bounds__(256) void fq_kv_quant_kernel(KvIO io, const f16* __restrict__ T, int64_t rows) {
+    const int which = blockIdx.y;
+    const bool do_trans = TRANS && which == 0;
+    const f16* __restrict__ x = io.x[which];
+    uint8_t* __restrict__ q_out = io.q[which];
+    f16* __restrict__ param = io.param[which];
+    f16* __restrict__ y_out = which == 0 ? io.y : nullptr;
+    const float clip_max = io.cmax[which], clip_min = io.cmin[which];
     constexpr int KS = HD / 16, NTL = HD / 32;
     __shared__ __attribute__((aligned(16))) uint4 tfrag[TRANS ? KS * NTL * 64 : 1];  // [(s * NTL + nt)][lane]
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
@@ -99,7 +122,7 @@ __global__ __launch_bounds__(256) void fq_kv_quant_kernel(const f16* __restrict_
         for (int s = 0; s < KS; ++s) xf[s] = __builtin_bit_cast(f16x8, xp[2 * s + h]);
 
         f16 v[NTL][16];  // TRANS: columns nt*32 + 16h + r;  else: v[s/2][(s&1)*8 + j] = column (2s + h)*8 + j
-        if (TRANS) {
+        if (TRANS && do_trans) {
             int foff = lane;
             asm volatile("" : "+v"(foff));
             const uint4* tf = tfrag + foff;
@@ -145,7 +168,30 @@ __global__ __launch_bounds__(256) void fq_kv_quant_kernel(const f16* __restrict_
         mn = omn < mn ? omn : mn;
         const KvParams p = kv_params<LAC>(mx, mn, cmax, cmin);
 
-        uint8_t* qrow = q_out + row * (HD / 2);
+        // destination(s) of this lane's row: the dense row, or `group` rows of the paged cache
+        uint8_t* qdst[4];
+        unsigned* pdst[4];
+        int ndst = 1;
+        if (io.data == nullptr) {
+            qdst[0] = q_out + row * (HD / 2);
+            pdst[0] = reinterpret_cast<unsigned*>(param + row * 2);
+        } else {
+            const int64_t t = lrow / io.src_heads;
+            const int hs = (int)(lrow - t * io.src_heads);
+            const int b = (int)(t / io.added), j = (int)(t - (int64_t)b * io.added);
+            const int64_t seq_len = (int64_t)(io.indptr[b + 1] - io.indptr[b] - 1) * io.page_size + io.last[b];
+            const int64_t pos = seq_len - io.added + j;
+            const size_t page = (size_t)io.indices[io.indptr[b] + pos / io.page_size];
+            const size_t entry = (size_t)(pos % io.page_size);
+            ndst = io.group;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const size_t e = (((page * io.num_layers + io.layer_idx) * 2 + which) * io.num_heads + (size_t)hs * io.group + (g < ndst ? g : 0)) *
+                                     io.page_size + entry;
+                qdst[g] = io.data + e * (HD / 2);
+                pdst[g] = reinterpret_cast<unsigned*>(io.pparam) + e;
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
             unsigned w0 = 0, w1 = 0;
@@ -155,17 +201,23 @@ __global__ __launch_bounds__(256) void fq_kv_quant_kernel(const f16* __restrict_
                 w1 |= kv_q1<LAC>(v[nt][8 + e], p) << (4 * e);
             }
             if (ok) {
-                if (TRANS) {
-                    *reinterpret_cast<uint2*>(qrow + nt * 16 + 8 * h) = make_uint2(w0, w1);
-                } else {  // chunk s = 2nt (w0), 2nt + 1 (w1): bytes (2s + h) * 4
-                    *reinterpret_cast<unsigned*>(qrow + (4 * nt + h) * 4) = w0;
-                    *reinterpret_cast<unsigned*>(qrow + (4 * nt + 2 + h) * 4) = w1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (g >= ndst) break;
+                    if (TRANS && do_trans) {
+                        *reinterpret_cast<uint2*>(qdst[g] + nt * 16 + 8 * h) = make_uint2(w0, w1);
+                    } else {  // chunk s = 2nt (w0), 2nt + 1 (w1): bytes (2s + h) * 4
+                        *reinterpret_cast<unsigned*>(qdst[g] + (4 * nt + h) * 4) = w0;
+                        *reinterpret_cast<unsigned*>(qdst[g] + (4 * nt + 2 + h) * 4) = w1;
+                    }
                 }
             }
         }
         if (ok && h == 0) {
             const unsigned short s16 = __builtin_bit_cast(unsigned short, p.scale), z16 = __builtin_bit_cast(unsigned short, p.zero);
-            *reinterpret_cast<unsigned*>(param + row * 2) = (unsigned)s16 | ((unsigned)z16 << 16);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (g < ndst) *pdst[g] = (unsigned)s16 | ((unsigned)z16 << 16);
         }
     }
 }
@@ -197,14 +249,12 @@ __global__ __launch_bounds__(256) void fq_kv_dequant_kernel(const uint8_t* __res
 }
 
 template <int HD>
-int launch_kv(const f16* x, const f16* T, int64_t rows, float cmax, float cmin, bool lac, uint8_t* q, f16* param, f16* y,
-              int n_cu, hipStream_t stream) {
+int launch_kv(const KvIO& io, const f16* T, int64_t rows, bool lac, int n_cu, hipStream_t stream) {
     int64_t blocks = (rows + 127) / 128;
     if (blocks > (int64_t)n_cu * 2) blocks = (int64_t)n_cu * 2;
     if (blocks < 1) blocks = 1;
-#define FQ_KV(TR, LC)                                                                                                     \
-    hipLaunchKernelGGL((fq_kv_quant_kernel<HD, TR, LC>), dim3((unsigned)blocks), dim3(256), 0, stream, x, T, rows, cmax, cmin, \
-                       q, param, y)
+    const dim3 grid((unsigned)blocks, io.x[1] != nullptr ? 2u : 1u);
+#define FQ_KV(TR, LC) hipLaunchKernelGGL((fq_kv_quant_kernel<HD, TR, LC>), grid, dim3(256), 0, stream, io, T, rows)
     if (T != nullptr) {
         if (lac) FQ_KV(true, true);
         else FQ_KV(true, false);
@@ -218,10 +268,53 @@ int launch_kv(const f16* x, const f16* T, int64_t rows, float cmax, float cmin, 
 
 }  // namespace
 
+static KvIO kv_io_dense(const f16* x, float cmax, float cmin, uint8_t* q, f16* param, f16* y) {
+    KvIO io = {};
+    io.x[0] = x;
+    io.q[0] = q;
+    io.param[0] = param;
+    io.y = y;
+    io.cmax[0] = cmax;
+    io.cmin[0] = cmin;
+    return io;
+}
+
 int fq_launch_kv_quant(const f16* x, const f16* T, int64_t rows, int hd, float cmax, float cmin, bool lac, uint8_t* q,
                        f16* param, f16* y, int n_cu, hipStream_t stream) {
-    if (hd == 128) return launch_kv<128>(x, T, rows, cmax, cmin, lac, q, param, y, n_cu, stream);
-    if (hd == 64) return launch_kv<64>(x, T, rows, cmax, cmin, lac, q, param, y, n_cu, stream);
+    const KvIO io = kv_io_dense(x, cmax, cmin, q, param, y);
+    if (hd == 128) return launch_kv<128>(io, T, rows, lac, n_cu, stream);
+    if (hd == 64) return launch_kv<64>(io, T, rows, lac, n_cu, stream);
+    return -1000;
+}
+
+// K (transformed when T != nullptr) and V of one layer step, quantised and written straight into the paged cache.
+int fq_launch_kv_quant_append(const f16* k, const f16* v, const f16* T, int64_t tokens, int src_heads, int hd, const float* clip4,
+                              bool lac, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
+                              int num_layers, int layer_idx, int num_heads, int page_size, int added, int group, int n_cu,
+                              hipStream_t stream) {
+    if (group < 1 || group > 4 || src_heads * group != num_heads || added < 1) return -1000;
+    KvIO io = {};
+    io.x[0] = k;
+    io.x[1] = v;
+    io.cmax[0] = clip4[0];
+    io.cmin[0] = clip4[1];
+    io.cmax[1] = clip4[2];
+    io.cmin[1] = clip4[3];
+    io.data = (uint8_t*)kv_data;
+    io.pparam = (f16*)kv_param;
+    io.indptr = indptr;
+    io.indices = indices;
+    io.last = last;
+    io.num_layers = num_layers;
+    io.layer_idx = layer_idx;
+    io.num_heads = num_heads;
+    io.page_size = page_size;
+    io.added = added;
+    io.group = group;
+    io.src_heads = src_heads;
+    const int64_t rows = tokens * src_heads;
+    if (hd == 128) return launch_kv<128>(io, T, rows, lac, n_cu, stream);
+    if (hd == 64) return launch_kv<64>(io, T, rows, lac, n_cu, stream);
     return -1000;
 }
 

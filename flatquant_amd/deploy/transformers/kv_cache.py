@@ -133,9 +133,8 @@ class MultiLayerPagedKVCache4Bit:
         assert b == self.batch_size
         tk = cache_kwargs.get("trans_matrix_k") if self.trans.startswith("matmul") else None
         tk_inv_t = cache_kwargs.get("trans_matrix_k_inv_t") if self.trans.startswith("matmul") else None
-        # kv_cache.py:283-284: the cache's own calls leave lac off, so the clip factors play no part
-        kq, kp, vq, vp = transform_quantize_kv(key_states, value_states, tk)
-        # :286-296 grouped-query attention: every query head gets its copy — made by the scatter (group_size below)
+        # :286-296 grouped-query attention: every query head gets its copy — made by the scatter (group_size below).
+        # kv_cache.py:283-284: the cache's own calls leave lac off, so the clip factors play no part.
         if layer_idx == 0:
             self._ensure_page_cnt_per_batch(self.page_cnt_from_length(self.length + added))
             self.length += added
@@ -143,15 +142,14 @@ class MultiLayerPagedKVCache4Bit:
             self._specs, self._specs_len = self.get_cache_specs_for_flash_infer(), (self.length, self.pages.data_ptr())
         specs = self._specs
         args = (specs["kv_data"], specs["kv_param"], specs["kv_indptr"], specs["kv_indices"], specs["last_page_offset"])
-        kq, vq = kq.reshape(b * added, heads, hd // 2), vq.reshape(b * added, heads, hd // 2)
+        tk16 = None if tk is None else tk.to(device=key_states.device, dtype=torch.float16).contiguous()
+        # K transform + K / V quantisation + append: one launch (fq_kv_quant_append_i4)
+        ops.kv_quant_append(key_states.contiguous(), value_states.contiguous(), tk16, *args, layer_idx, self.group_size)
         if self._needs_init[layer_idx]:
             self._needs_init[layer_idx] = False
-            seqlens = torch.arange(b + 1, device=self.device, dtype=torch.int32) * added
-            init_kv_i4(*args, kq, vq, kp, vp, seqlens, layer_idx, self.group_size)
-            keys = key_states if tk is None else torch.matmul(key_states.to(torch.float16), tk.to(key_states.device, torch.float16))
+            keys = key_states if tk16 is None else torch.matmul(key_states.to(torch.float16), tk16)
             return keys, value_states                                   # :341-344: the un-quantised states for prefill
         assert added == 1
-        append_kv_i4(*args, kq, vq, kp, vp, layer_idx, self.group_size)
 
         def attend(q):
             bq, q_len, n_q, d = q.shape

@@ -513,6 +513,28 @@ def kv_append(kv_data: torch.Tensor, kv_param: torch.Tensor, kv_indptr: torch.Te
                                   layer_idx, heads, page_size, hd, batch, group_size, _stream(kv_data)))
 
 
+def kv_quant_append(k: torch.Tensor, v: torch.Tensor, trans: Optional[torch.Tensor], kv_data: torch.Tensor,
+                    kv_param: torch.Tensor, kv_indptr: torch.Tensor, kv_indices: torch.Tensor, last_page_offset: torch.Tensor,
+                    layer_idx: int, group_size: int = 1, clip=None, lac: bool = False) -> None:
+    """kv_quant(k, trans) + kv_quant(v) + kv_append in ONE launch (fq_kv_quant_append_i4): k, v [bsz, added, kv_heads,
+    head_dim] fp16, every request appends ``added`` tokens at the end of its current length."""
+    _chk(k, "k"), _chk(v, "v"), _chk(kv_data, "kv_data", torch.uint8), _chk(kv_param, "kv_param")
+    if trans is not None:
+        _chk(trans, "trans")
+    n_layers, heads, page_size, hd = _kv_geometry(kv_data)
+    batch = last_page_offset.numel()
+    if k.shape != v.shape or k.shape[-1] != hd or k.shape[0] != batch:
+        raise ValueError("k / v must be [batch, added, kv_heads, head_dim]")
+    src_heads = k.shape[-2]
+    tokens = k.numel() // (src_heads * hd)
+    c4 = None if clip is None else (ctypes.c_float * 4)(*[float(t) for t in clip])
+    with torch.cuda.device(k.device):
+        check(lib.fq_kv_quant_append_i4(_ptr(k), _ptr(v), _ptr(trans), tokens, src_heads, hd, c4, _lib.FQ_KV_LAC if lac else 0,
+                                        _ptr(kv_data), _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices),
+                                        _ptr(last_page_offset), n_layers, layer_idx, heads, page_size, batch, group_size,
+                                        _stream(k)))
+
+
 def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tensor, kv_indptr: torch.Tensor,
                     kv_indices: torch.Tensor, last_page_offset: torch.Tensor, layer_idx: int) -> torch.Tensor:
     """batch_decode_i4 (kv_cache.py:98-105): q [batch, heads, head_dim] fp16 -> o of the same shape, attention over each

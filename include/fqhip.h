@@ -276,6 +276,18 @@ int fq_kv_append_i4(void* kv_data, void* kv_param, const void* kv_indptr, const 
                     const void* last_page_offset, const void* k, const void* v, const void* k_param, const void* v_param,
                     const void* seqlen_indptr, int64_t tokens, int num_layers, int layer_idx, int num_heads, int page_size,
                     int head_dim, int batch_size, int group_size, void* stream);
+/*
+ * fq_kv_quant_f16 on the new keys (with trans) AND values of a layer step, written straight into the paged cache — one
+ * launch instead of two quantiser launches and the append: k, v [tokens, src_heads, head_dim] fp16 with
+ * tokens = batch_size * added (every request appends the same number of tokens, request-major, at the END of its
+ * current length, as fq_kv_append_i4 with seqlen_indptr = added * arange); num_heads = src_heads * group_size cache heads,
+ * group_size <= 4. clip = {k_max, k_min, v_max, v_min} (sigmoid-ed; used with FQ_KV_LAC) or NULL. Same bits in the cache
+ * as fq_kv_quant_f16 x 2 + fq_kv_append_i4.
+ */
+int fq_kv_quant_append_i4(const void* k, const void* v, const void* trans, int64_t tokens, int src_heads, int head_dim,
+                          const float* clip, int flags, void* kv_data, void* kv_param, const void* kv_indptr,
+                          const void* kv_indices, const void* last_page_offset, int num_layers, int layer_idx,
+                          int num_heads, int page_size, int batch_size, int group_size, void* stream);
 int fq_kv_batch_decode_i4(void* o, const void* q, const void* kv_data, const void* kv_param, const void* kv_indptr,
                           const void* kv_indices, const void* last_page_offset, int num_layers, int layer_idx,
                           int num_heads, int page_size, int head_dim, int batch_size, void* stream);

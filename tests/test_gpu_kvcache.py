@@ -136,3 +136,37 @@ def test_errors(ops):
     z = torch.zeros(2, dtype=torch.int32, device="cuda")
     with pytest.raises(Exception):
         ops.kv_batch_decode(torch.zeros(1, 2, 96, dtype=torch.float16, device="cuda"), data, par, z, z, z[:1], 0)
+
+
+@pytest.mark.parametrize("hd,kv_heads,group,added,lac", [(128, 2, 2, 21, False), (128, 8, 4, 1, False), (64, 3, 1, 5, True),
+                                                        (128, 1, 3, 1, True)])
+def test_fused_quantise_and_append_equals_the_three_launches(ops, hd, kv_heads, group, added, lac):
+    """fq_kv_quant_append_i4 == fq_kv_quant_f16 (keys, with the transform) + fq_kv_quant_f16 (values) + fq_kv_append_i4
+    with the GQA repeat: identical cache bytes and parameters."""
+    g = torch.Generator(device="cuda").manual_seed(hd + kv_heads + added)
+    bsz, page, layers, layer = 3, 16, 2, 1
+    heads = kv_heads * group
+    prior = 7                                                        # tokens already in the cache
+    total = prior + added
+    n_pg = (total + page - 1) // page
+    shape = (bsz * n_pg, layers, 2, heads, page, hd // 2)
+    base_d = torch.randint(0, 256, shape, generator=g, device="cuda", dtype=torch.uint8)
+    base_p = torch.rand(*shape[:-1], 2, generator=g, device="cuda").half()
+    indptr = (torch.arange(bsz + 1, device="cuda", dtype=torch.int32) * n_pg)
+    indices = torch.randperm(bsz * n_pg, generator=g, device="cuda").to(torch.int32)
+    last = torch.full((bsz,), (total - 1) % page + 1, device="cuda", dtype=torch.int32)
+    k = (torch.randn(bsz, added, kv_heads, hd, generator=g, device="cuda") * 2).half()
+    v = (torch.randn(bsz, added, kv_heads, hd, generator=g, device="cuda") * 2).half()
+    T = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half()
+    clip = (0.98, 0.9, 0.95, 0.97)
+    d1, p1 = base_d.clone(), base_p.clone()
+    ops.kv_quant_append(k, v, T, d1, p1, indptr, indices, last, layer, group, clip, lac)
+    d2, p2 = base_d.clone(), base_p.clone()
+    kq, kp = ops.kv_quant(k, T, clip[:2], lac)
+    vq, vp = ops.kv_quant(v, None, clip[2:], lac)
+    seq = (torch.arange(bsz + 1, device="cuda", dtype=torch.int32) * added)
+    ops.kv_append(d2, p2, indptr, indices, last, kq.reshape(-1, kv_heads, hd // 2), vq.reshape(-1, kv_heads, hd // 2),
+                  kp.reshape(-1, kv_heads, 2), vp.reshape(-1, kv_heads, 2), layer, seq, group)
+    assert torch.equal(d1, d2)
+    assert torch.equal(p1.view(torch.int16), p2.view(torch.int16))
+    assert not torch.equal(d1, base_d)
