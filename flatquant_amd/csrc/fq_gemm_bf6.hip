@@ -40,6 +40,9 @@ constexpr int STAGES = 3;
 constexpr int GW = FQ_BF6_WAVES, GT = GW * 64;
 constexpr int NWM = GW / 4;                    // waves along the token dimension (4 along the feature dimension)
 constexpr int TMT = BM / 32 / NWM;             // token tiles per wave
+#ifndef FQ_BF6_LATE_DMA
+#define FQ_BF6_LATE_DMA 0   // 1: refill after the second half's MFMAs instead of right behind the barrier (measured neutral: 227 vs 224 us)
+#endif
 #ifndef FQ_BF6_DMA_WAVES
 #define FQ_BF6_DMA_WAVES 8   // waves that issue the DMA. (4 = one per SIMD, so that the two waves of a SIMD leave each barrier
                              // differently loaded and stop marching in step: measured no difference, 226 vs 224 us)
@@ -197,13 +200,19 @@ __global__ __launch_bounds__(GT, GW / 4) void fq_gemm_bf6_kernel(const uint8_t* 
             if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(DPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // every wave holds all of stage s in registers: its buffer is free
+#if !FQ_BF6_LATE_DMA
             if (s + STAGES < nk && !(ABL & 4)) issue_stage(s + STAGES);
+#endif
             const unsigned char* sn = smem + ((s + 1) % STAGES) * TILE_BYTES;
             if (!(ABL & 2)) FQ_READ(sn, 0, r0w, r0x)
         }
         __builtin_amdgcn_sched_barrier(0);
         FQ_COMPUTE(r1w, r1x)
         __builtin_amdgcn_sched_barrier(0);
+#if FQ_BF6_LATE_DMA   // refill the freed buffer AFTER the second half's MFMAs are queued: shortens barrier -> first MFMA
+        if (s + 1 < nk && s + STAGES < nk && !(ABL & 4)) issue_stage(s + STAGES);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 #undef FQ_READ
 #undef FQ_FRAG
