@@ -72,15 +72,14 @@ class MultiLayerPagedKVCache4Bit:
     (transformed, quantised) prompt keys / values and returns the fp16 key / value states for the prefill attention; every
     later call appends one token per request and returns a callable that runs the INT4 decode attention for the
     layer's query ([bsz, 1, heads, head_dim] -> the same shape). Requests have equal lengths (no attention mask), as
-    the reference's own restriction to one page count per batch implies (:371-372). trans="had" (QuaRot's fast Hadamard
-    on the keys) is not offered; pass the Hadamard matrix as ``trans_matrix_k`` with trans="matmul" instead."""
+    the reference's own restriction to one page count per batch implies (:371-372). trans="had" (QuaRot: a normalised
+    Hadamard rotation of keys and queries over head_dim, kv_cache.py:64-67) runs the register FWHT (fq_hadamard_f16)
+    in front of the quantiser / of the decode attention."""
 
     def __init__(self, batch_size, page_size, max_seq_len, device, n_layers, num_heads, head_dim, disable_quant=False,
                  trans_dtype=torch.float16, trans="had", group_size=1):
         if disable_quant:
             raise NotImplementedError("flatquant_amd: the fp16 configuration of the paged cache is not built")
-        if trans == "had":
-            raise NotImplementedError("flatquant_amd: trans='had' on the keys is not built (use trans='matmul' with the matrix)")
         self.page_size, self.batch_size, self.max_seq_len = page_size, batch_size, max_seq_len
         self.device, self.n_layers, self.trans, self.group_size = device, n_layers, trans, group_size
         self.org_head_dim = head_dim
@@ -143,6 +142,9 @@ class MultiLayerPagedKVCache4Bit:
         specs = self._specs
         args = (specs["kv_data"], specs["kv_param"], specs["kv_indptr"], specs["kv_indices"], specs["last_page_offset"])
         tk16 = None if tk is None else tk.to(device=key_states.device, dtype=torch.float16).contiguous()
+        had = self.trans == "had"
+        if had:                                                         # :265-266 matmul_had_cuda on the keys
+            key_states = ops.hadamard(key_states.to(torch.float16).contiguous())
         # K transform + K / V quantisation + append: one launch (fq_kv_quant_append_i4)
         ops.kv_quant_append(key_states.contiguous(), value_states.contiguous(), tk16, *args, layer_idx, self.group_size)
         if self._needs_init[layer_idx]:
@@ -155,7 +157,9 @@ class MultiLayerPagedKVCache4Bit:
             bq, q_len, n_q, d = q.shape
             assert q_len == 1
             q2 = q.reshape(bq, n_q, d)
-            if tk_inv_t is not None:                                        # :134-140: the query side of the K transform
+            if had:                                                         # :134-138: the query side of the rotation
+                q2 = ops.hadamard(q2.to(torch.float16).contiguous())
+            elif tk_inv_t is not None:                                      # :139-140: ... of the learned K transform
                 q2 = torch.matmul(q2.to(torch.float16), tk_inv_t.to(q.device, torch.float16))
             return ops.kv_batch_decode(q2.contiguous(), *args, layer_idx).unsqueeze(1)
         return attend

@@ -129,8 +129,6 @@ def test_errors(ops):
     import flatquant_amd.deploy.transformers as T
     with pytest.raises(NotImplementedError):
         T.MultiLayerPagedKVCache4Bit(1, 16, 32, "cuda", 1, 2, 128, disable_quant=True)
-    with pytest.raises(NotImplementedError):
-        T.MultiLayerPagedKVCache4Bit(1, 16, 32, "cuda", 1, 2, 128, trans="had")
     data = torch.zeros(2, 1, 2, 2, 16, 48, dtype=torch.uint8, device="cuda")                     # head_dim 96
     par = torch.zeros(2, 1, 2, 2, 16, 2, dtype=torch.float16, device="cuda")
     z = torch.zeros(2, dtype=torch.int32, device="cuda")
@@ -170,3 +168,33 @@ def test_fused_quantise_and_append_equals_the_three_launches(ops, hd, kv_heads, 
     assert torch.equal(d1, d2)
     assert torch.equal(p1.view(torch.int16), p2.view(torch.int16))
     assert not torch.equal(d1, base_d)
+
+
+def test_cache_class_hadamard_keys(ops):
+    """trans="had" (QuaRot): keys and queries rotated by the normalised Hadamard transform; q.k is invariant under it, so
+    the attention output equals dense attention on (rotated, de-quantised) keys with the rotated query."""
+    import flatquant_amd.deploy.transformers as T
+    g = torch.Generator(device="cuda").manual_seed(11)
+    bsz, prompt, heads, hd = 2, 19, 4, 128
+    cache = T.MultiLayerPagedKVCache4Bit(bsz, 16, 64, "cuda", 1, heads, hd, trans="had")
+    k0 = torch.randn(bsz, prompt, heads, hd, generator=g, device="cuda").half()
+    v0 = torch.randn(bsz, prompt, heads, hd, generator=g, device="cuda").half()
+    keys, vals = cache.update(k0, v0, 0, {})
+    assert torch.equal(keys, ops.hadamard(k0)) and torch.equal(vals, v0)
+    k1 = torch.randn(bsz, 1, heads, hd, generator=g, device="cuda").half()
+    v1 = torch.randn(bsz, 1, heads, hd, generator=g, device="cuda").half()
+    attend = cache.update(k1, v1, 0, {})
+    q = torch.randn(bsz, 1, heads, hd, generator=g, device="cuda").half()
+    o = attend(q)
+
+    def deq32(x):
+        q8, par = ops.kv_quant(x)
+        n = torch.stack((q8 & 15, q8 >> 4), dim=-1).reshape(*q8.shape[:-1], -1).float()
+        return n * par[..., 0:1].float() - par[..., 1:2].float()
+    K = deq32(ops.hadamard(torch.cat([k0, k1], dim=1).contiguous()))
+    V = deq32(torch.cat([v0, v1], dim=1).contiguous())
+    qr = ops.hadamard(q.reshape(bsz, heads, hd).contiguous()).float()
+    x = torch.einsum("bhd,bshd->bhs", qr, K) / hd ** 0.5
+    ref = torch.einsum("bhs,bshd->bhd", torch.softmax(x, dim=-1), V)
+    err = (o.reshape(bsz, heads, hd).float() - ref).abs().amax(-1) / ref.abs().amax(-1)
+    assert err.max().item() <= 3e-3
