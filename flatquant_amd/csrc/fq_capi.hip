@@ -42,7 +42,8 @@ int fq_launch_kv_append(void* kv_data, void* kv_param, const int* indptr, const 
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, int group, int n_cu,
                         hipStream_t stream);
 int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
-                        int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, hipStream_t stream);
+                        int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, const f16* qt,
+                        int transpose_out, hipStream_t stream);
 int fq_launch_silu_mul(const f16* gate, const f16* up, f16* y, int64_t n, int n_cu, hipStream_t stream);
 int fq_launch_silu_hadamard_quant(const f16* gate, const f16* up, int64_t rows, int n, int K, const f16* hadK, float scale,
                                   float sig_max, float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream);
@@ -488,16 +489,29 @@ int fq_kv_quant_append_i4(const void* k, const void* v, const void* trans, int64
     return check_launch(rc, "fq_kv_quant_append_i4");
 }
 
+int fq_kv_batch_decode_i4_ex(void* o, const void* q, const void* q_trans, int transpose_out, const void* kv_data,
+                             const void* kv_param, const void* kv_indptr, const void* kv_indices,
+                             const void* last_page_offset, int num_layers, int layer_idx, int num_heads, int page_size,
+                             int head_dim, int batch_size, void* stream);
+
 int fq_kv_batch_decode_i4(void* o, const void* q, const void* kv_data, const void* kv_param, const void* kv_indptr,
                           const void* kv_indices, const void* last_page_offset, int num_layers, int layer_idx,
                           int num_heads, int page_size, int head_dim, int batch_size, void* stream) {
+    return fq_kv_batch_decode_i4_ex(o, q, nullptr, 0, kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, num_layers,
+                                    layer_idx, num_heads, page_size, head_dim, batch_size, stream);
+}
+
+int fq_kv_batch_decode_i4_ex(void* o, const void* q, const void* q_trans, int transpose_out, const void* kv_data,
+                             const void* kv_param, const void* kv_indptr, const void* kv_indices,
+                             const void* last_page_offset, int num_layers, int layer_idx, int num_heads, int page_size,
+                             int head_dim, int batch_size, void* stream) {
     int rc = kv_geometry_ok("fq_kv_batch_decode_i4", num_layers, layer_idx, num_heads, page_size, head_dim, batch_size);
     if (rc != FQ_OK) return rc;
     if (!o || !q || !kv_data || !kv_param || !kv_indptr || !kv_indices || !last_page_offset)
         return fail(FQ_EINVAL, "fq_kv_batch_decode_i4: NULL pointer");
     rc = fq_launch_kv_decode((f16*)o, (const f16*)q, (void*)kv_data, (void*)kv_param, (const int*)kv_indptr,
                              (const int*)kv_indices, (const int*)last_page_offset, num_layers, layer_idx, num_heads, page_size,
-                             head_dim, batch_size, (hipStream_t)stream);
+                             head_dim, batch_size, (const f16*)q_trans, transpose_out != 0, (hipStream_t)stream);
     return check_launch(rc, "fq_kv_batch_decode_i4");
 }
 

@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void fq_kv_append_kernel(PagedKv p, const uint
 }
 
 template <int HD, int NW>  // NW waves per workgroup: 4, or 8 when there are too few (request, head) pairs to fill the chip
-__global__ __launch_bounds__(NW * 64) void fq_kv_decode_kernel(f16* __restrict__ o, const f16* __restrict__ q, PagedKv p) {
+__global__ __launch_bounds__(NW * 64) void fq_kv_decode_kernel(f16* __restrict__ o, const f16* __restrict__ q, PagedKv p,
+                                                               const f16* __restrict__ qt, int transpose_out) {
     constexpr int QL = HD / 32;        // lanes per cached row (16 bytes = 32 features each): 4 for head_dim 128
     constexpr int RPW = 64 / QL;       // rows per wave and step
     constexpr int NS = NW * RPW;       // partial softmax states per workgroup
@@ -93,7 +94,23 @@ __global__ __launch_bounds__(NW * 64) void fq_kv_decode_kernel(f16* __restrict__
     const int64_t seq_len = (int64_t)(pg1 - pg0 - 1) * p.page_size + p.last_page_offset[b];
 
     float qv[32], qsum = 0.0f;
-    {
+    if (qt != nullptr) {
+        // the query side of the K transform (kv_cache.py:139-140: torch.matmul(q.half(), trans_matrix_k_inv_t)) in here:
+        // q' = fp16(q . qt), fp32 accumulation, one output feature per thread, handed round through LDS
+        float* s_q = s_d + NS;
+        const f16* qrow = q + ((size_t)b * p.num_heads + head) * HD;
+        for (int j = tid; j < HD; j += NW * 64) {
+            float a = 0.0f;
+            for (int i = 0; i < HD; ++i) a = __builtin_fmaf((float)qrow[i], (float)qt[i * HD + j], a);
+            s_q[j] = (float)(f16)a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            qv[j] = s_q[part * 32 + j];
+            qsum += qv[j];
+        }
+    } else {
         const f16* qp = q + ((size_t)b * p.num_heads + head) * HD + part * 32;
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
@@ -166,7 +183,10 @@ __global__ __launch_bounds__(NW * 64) void fq_kv_decode_kernel(f16* __restrict__
             dd += s_d[s] * w;
             oo += s_o[s][tid] * w;
         }
-        o[((size_t)b * p.num_heads + head) * HD + tid] = (f16)(oo / dd);
+        // transpose_out: [batch, head_dim, heads] — the layout the o_proj head transform takes (modeling_llama.py:147-149
+        // transposes and copies the attention output before block_matmul)
+        const size_t oi = transpose_out ? ((size_t)b * HD + tid) * p.num_heads + head : ((size_t)b * p.num_heads + head) * HD + tid;
+        o[oi] = (f16)(oo / dd);
     }
 }
 
@@ -205,20 +225,21 @@ int fq_launch_kv_append(void* kv_data, void* kv_param, const int* indptr, const 
 }
 
 int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
-                        int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, hipStream_t stream) {
+                        int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, const f16* qt,
+                        int transpose_out, hipStream_t stream) {
     const PagedKv p = make_kv(kv_data, kv_param, indptr, indices, last, num_layers, layer_idx, num_heads, page_size, head_dim, batch);
     const dim3 grid((unsigned)batch, (unsigned)num_heads);
     const bool wide = (int64_t)batch * num_heads < 512;  // fewer than two workgroups per CU: 8 waves each instead of 4 (measured: 158 -> 113 us at 8 x 8192; no gain from 512 up)
 #define FQ_DEC(HD_, NW_)                                                                                              \
     {                                                                                                                 \
-        constexpr size_t lds = sizeof(float) * (size_t)(NW_ * (64 / (HD_ / 32))) * (HD_ + 1 + 2);                     \
+        constexpr size_t lds = sizeof(float) * ((size_t)(NW_ * (64 / (HD_ / 32))) * (HD_ + 1 + 2) + HD_);                     \
         static bool attr_set = false;                                                                                 \
         if (!attr_set) {                                                                                              \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fq_kv_decode_kernel<HD_, NW_>),                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
             attr_set = true;                                                                                          \
         }                                                                                                             \
-        hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_>), grid, dim3(NW_ * 64), lds, stream, o, q, p);               \
+        hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
     }
     if (head_dim == 128) {
         if (wide) FQ_DEC(128, 8) else FQ_DEC(128, 4)

@@ -153,13 +153,16 @@ class MultiLayerPagedKVCache4Bit:
             return keys, value_states                                   # :341-344: the un-quantised states for prefill
         assert added == 1
 
-        def attend(q):
+        def attend(q, transposed=False):
+            """q [bsz, 1, heads, head_dim] -> attention output of the same shape; ``transposed`` (extension): as
+            [bsz, 1, head_dim, heads], what o_proj_trans takes (saves the transpose + copy of modeling_llama.py:147-149)."""
             bq, q_len, n_q, d = q.shape
             assert q_len == 1
-            q2 = q.reshape(bq, n_q, d)
+            q2 = q.reshape(bq, n_q, d).to(torch.float16)
+            qt = None
             if had:                                                         # :134-138: the query side of the rotation
-                q2 = ops.hadamard(q2.to(torch.float16).contiguous())
-            elif tk_inv_t is not None:                                      # :139-140: ... of the learned K transform
-                q2 = torch.matmul(q2.to(torch.float16), tk_inv_t.to(q.device, torch.float16))
-            return ops.kv_batch_decode(q2.contiguous(), *args, layer_idx).unsqueeze(1)
+                q2 = ops.hadamard(q2.contiguous())
+            elif tk_inv_t is not None:                                      # :139-140: ... of the learned K transform, in the launch
+                qt = tk_inv_t.to(q.device, torch.float16).contiguous()
+            return ops.kv_batch_decode(q2.contiguous(), *args, layer_idx, qt, transposed).unsqueeze(1)
         return attend

@@ -536,18 +536,25 @@ def kv_quant_append(k: torch.Tensor, v: torch.Tensor, trans: Optional[torch.Tens
 
 
 def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tensor, kv_indptr: torch.Tensor,
-                    kv_indices: torch.Tensor, last_page_offset: torch.Tensor, layer_idx: int) -> torch.Tensor:
+                    kv_indices: torch.Tensor, last_page_offset: torch.Tensor, layer_idx: int,
+                    q_trans: Optional[torch.Tensor] = None, transpose_out: bool = False) -> torch.Tensor:
     """batch_decode_i4 (kv_cache.py:98-105): q [batch, heads, head_dim] fp16 -> o of the same shape, attention over each
-    request's cached rows (fq_kv_batch_decode_i4)."""
+    request's cached rows (fq_kv_batch_decode_i4[_ex]). ``q_trans`` [head_dim, head_dim]: the query is multiplied by it
+    inside the launch; ``transpose_out``: o comes back as [batch, head_dim, heads]."""
     _chk(q, "q"), _chk(kv_data, "kv_data", torch.uint8), _chk(kv_param, "kv_param")
     n_layers, heads, page_size, hd = _kv_geometry(kv_data)
     batch = last_page_offset.numel()
     if q.shape != (batch, heads, hd):
         raise ValueError(f"q must be [{batch}, {heads}, {hd}]")
-    o = torch.empty_like(q)
+    if q_trans is not None:
+        _chk(q_trans, "q_trans")
+        if q_trans.shape != (hd, hd):
+            raise ValueError("q_trans must be [head_dim, head_dim]")
+    o = torch.empty((batch, hd, heads) if transpose_out else (batch, heads, hd), dtype=torch.float16, device=q.device)
     with torch.cuda.device(q.device):
-        check(lib.fq_kv_batch_decode_i4(_ptr(o), _ptr(q), _ptr(kv_data), _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices),
-                                        _ptr(last_page_offset), n_layers, layer_idx, heads, page_size, hd, batch, _stream(q)))
+        check(lib.fq_kv_batch_decode_i4_ex(_ptr(o), _ptr(q), _ptr(q_trans), 1 if transpose_out else 0, _ptr(kv_data),
+                                           _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
+                                           n_layers, layer_idx, heads, page_size, hd, batch, _stream(q)))
     return o
 
 

@@ -291,6 +291,13 @@ int fq_kv_quant_append_i4(const void* k, const void* v, const void* trans, int64
 int fq_kv_batch_decode_i4(void* o, const void* q, const void* kv_data, const void* kv_param, const void* kv_indptr,
                           const void* kv_indices, const void* last_page_offset, int num_layers, int layer_idx,
                           int num_heads, int page_size, int head_dim, int batch_size, void* stream);
+/* The same with the two torch ops either side of it folded in: q_trans [head_dim, head_dim] fp16 or NULL — the query is
+ * first multiplied by it (q' = fp16(q . q_trans), kv_cache.py:139-140, trans_matrix_k_inv_t); transpose_out != 0 — o is
+ * written as [batch, head_dim, num_heads], the layout the o_proj head transform takes (modeling_llama.py:147-149). */
+int fq_kv_batch_decode_i4_ex(void* o, const void* q, const void* q_trans, int transpose_out, const void* kv_data,
+                             const void* kv_param, const void* kv_indptr, const void* kv_indices,
+                             const void* last_page_offset, int num_layers, int layer_idx, int num_heads, int page_size,
+                             int head_dim, int batch_size, void* stream);
 
 /* q = clamp(rn(x /fp16 scale[row]), -8, 7), two per byte, even column -> low nibble (quant.cu:13-47). */
 int fq_sym_quant_f16(const void* x, const void* scale, int64_t rows, int cols, void* q, void* stream);

@@ -198,3 +198,25 @@ def test_cache_class_hadamard_keys(ops):
     ref = torch.einsum("bhs,bshd->bhd", torch.softmax(x, dim=-1), V)
     err = (o.reshape(bsz, heads, hd).float() - ref).abs().amax(-1) / ref.abs().amax(-1)
     assert err.max().item() <= 3e-3
+
+
+def test_decode_with_query_transform_and_transposed_output(ops):
+    """fq_kv_batch_decode_i4_ex: the query transform inside the launch (vs torch.matmul in front, tolerance: another
+    accumulation order before the fp16 rounding of q') and the [batch, head_dim, heads] output layout (exact)."""
+    g = torch.Generator(device="cuda").manual_seed(21)
+    bsz, heads, hd, page, seq = 3, 4, 128, 16, 45
+    n_pg = (seq + page - 1) // page
+    data = torch.randint(0, 256, (bsz * n_pg, 1, 2, heads, page, hd // 2), generator=g, device="cuda", dtype=torch.uint8)
+    par = (torch.rand(bsz * n_pg, 1, 2, heads, page, 2, generator=g, device="cuda") * 0.2 + 0.05).half()
+    indptr = torch.arange(bsz + 1, device="cuda", dtype=torch.int32) * n_pg
+    indices = torch.randperm(bsz * n_pg, generator=g, device="cuda").to(torch.int32)
+    last = torch.full((bsz,), (seq - 1) % page + 1, device="cuda", dtype=torch.int32)
+    q = torch.randn(bsz, heads, hd, generator=g, device="cuda").half()
+    Tq = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half()
+    plain = ops.kv_batch_decode(q, data, par, indptr, indices, last, 0)
+    tr = ops.kv_batch_decode(q, data, par, indptr, indices, last, 0, transpose_out=True)
+    assert tr.shape == (bsz, hd, heads) and torch.equal(tr.transpose(1, 2), plain)
+    fused = ops.kv_batch_decode(q, data, par, indptr, indices, last, 0, q_trans=Tq)
+    ref = ops.kv_batch_decode(torch.matmul(q, Tq).contiguous(), data, par, indptr, indices, last, 0)
+    err = (fused.float() - ref.float()).abs().amax(-1) / ref.float().abs().amax(-1)
+    assert err.max().item() <= 3e-3

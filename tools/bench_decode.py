@@ -64,8 +64,8 @@ def main():
         pq, pk, pv = deploy.nn.fused_forward(h, qkv_t, norm=norm)
         q, k, v = q_l(pq), k_l(pk), v_l(pv)
         attend = cache.update(k.view(a.bsz, 1, kv_heads, hd), v.view(a.bsz, 1, kv_heads, hd), 0, dict(kw))
-        att = attend(q.view(a.bsz, 1, heads, hd))                                   # [bsz, 1, heads, hd]
-        po = o_t(att.transpose(-1, -2).contiguous())
+        att_t = attend(q.view(a.bsz, 1, heads, hd), transposed=True)                # [bsz, 1, hd, heads]
+        po = o_t(att_t)
         po.quantized_x = po.quantized_x.contiguous().reshape(a.bsz, 1, -1)
         h2 = o_l(po)
         pu, pg = deploy.nn.fused_forward(h2, ug_t, norm=norm)
