@@ -164,7 +164,11 @@ __global__ __launch_bounds__(GT, GW / 4) void fq_gemm_bf6_kernel(const uint8_t* 
         _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm) _Pragma("unroll") for (int p = 0; p < 3; ++p) RX[tm][p] = \
             *reinterpret_cast<const uint2*>((ST) + xoff + tm * SEG + (KBL) * BLOB + p * 512);                        \
     }
-#define FQ_FRAG(R) i32x8{(int)R[0].x, (int)R[0].y, (int)R[1].x, (int)R[1].y, (int)R[2].x, (int)R[2].y, 0, 0}
+// the BF6 operand is 6 registers; the builtin's type is 8 wide — the upper two lanes are left UNDEFINED (shufflevector
+// index -1) so that no zeroing moves are emitted for them (24 v_mov per 128 k otherwise)
+typedef int i32x6 __attribute__((ext_vector_type(6)));
+#define FQ_FRAG(R) __builtin_shufflevector(i32x6{(int)R[0].x, (int)R[0].y, (int)R[1].x, (int)R[1].y, (int)R[2].x, (int)R[2].y}, \
+                                           i32x6{0, 0, 0, 0, 0, 0}, 0, 1, 2, 3, 4, 5, -1, -1)
 #define FQ_COMPUTE(RW, RX)                                                                                          \
     {                                                                                                                \
         i32x8 wf[2], xf[TMT];                                                                                        \
