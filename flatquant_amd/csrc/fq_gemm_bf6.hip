@@ -156,7 +156,11 @@ __global__ __launch_bounds__(GT, GW / 4) void fq_gemm_bf6_kernel(const uint8_t* 
 #pragma unroll
         for (int tm = 0; tm < TMT; ++tm) acc[tn][tm] = f32x16{0};
 
+#if FQ_BF6_WAVES == 16
+    uint2 r0w[2][3], r0x[TMT][3];
+#else
     uint2 r0w[2][3], r0x[TMT][3], r1w[2][3], r1x[TMT][3];
+#endif
 #define FQ_READ(ST, KBL, RW, RX)                                                                                    \
     {                                                                                                                \
         _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) _Pragma("unroll") for (int p = 0; p < 3; ++p) RW[tn][p] =   \
@@ -193,6 +197,26 @@ typedef int i32x6 __attribute__((ext_vector_type(6)));
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+#if FQ_BF6_WAVES == 16
+    // 16-wave build: four waves per SIMD hide the fragment reads of each other, so a wave reads and multiplies one 64-k
+    // block at a time with a single fragment buffer (<= 128 VGPRs)
+    for (int s = 0; s < nk; ++s) {
+        const unsigned char* st = smem + (s % STAGES) * TILE_BYTES;
+        FQ_READ(st, 0, r0w, r0x)
+        FQ_COMPUTE(r0w, r0x)
+        __builtin_amdgcn_sched_barrier(0);
+        FQ_READ(st, 1, r0w, r0x)
+        FQ_COMPUTE(r0w, r0x)
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nk) {
+            const int younger = nk - 2 - s < STAGES - 2 ? nk - 2 - s : STAGES - 2;
+            if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(DPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (s + STAGES < nk) issue_stage(s + STAGES);
+        }
+    }
+#else
     FQ_READ(smem, 0, r0w, r0x)
     for (int s = 0; s < nk; ++s) {
         const unsigned char* st = smem + (s % STAGES) * TILE_BYTES;
@@ -218,6 +242,7 @@ typedef int i32x6 __attribute__((ext_vector_type(6)));
         __builtin_amdgcn_sched_barrier(0);
 #endif
     }
+#endif
 #undef FQ_READ
 #undef FQ_FRAG
 #undef FQ_COMPUTE
