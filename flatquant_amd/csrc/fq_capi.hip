@@ -9,8 +9,6 @@
 // launchers defined in the kernel translation units
 int fq_launch_kron64(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
                      int64_t rows, const FqQuantOut& out, int n_cu, hipStream_t stream);
-int fq_launch_kron64p(const f16* x, const f16* left, const f16* right, int64_t rows, const FqQuantOut& out, int n_cu,
-                      hipStream_t stream);
 int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream);
@@ -168,13 +166,6 @@ int fq_kron_quant_f16(const void* x, const void* left, const void* right, const 
     if (!x || !left || !right) return fail(FQ_EINVAL, "fq_kron_quant_f16: x/left/right is NULL");
     const int n_cu = cu_count();
     if (M == 64 && N == 64) {
-        // FQ_KRON64_PIPE=1 in the environment selects the software-pipelined variant (fq_kron64p.hip) for the headline
-        // contract — kept for A/B measurements: on MI355X it measured 44.0 us vs 42.5 us for the plain kernel.
-        static const bool use_pipe = [] { const char* e = getenv("FQ_KRON64_PIPE"); return e && e[0] == '1'; }();
-        if (use_pipe && (flags & FQ_CT_MASK) == FQ_OUT_PACKED && n_clips == 1 && diag == nullptr) {
-            rc = fq_launch_kron64p((const f16*)x, (const f16*)left, (const f16*)right, rows, o, n_cu, (hipStream_t)stream);
-            return check_launch(rc, "fq_kron_quant_f16[64x64 pipelined]");
-        }
         rc = fq_launch_kron64(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag,
                               rows, o, n_cu, (hipStream_t)stream);
         if (rc != -1000) return check_launch(rc, "fq_kron_quant_f16[64x64]");

@@ -33,6 +33,21 @@ struct FqQuantOut {
     const f16* in2;                // FQ_IN_SILU_MUL: the `up` tensor (x is `gate`), same shape as x
 };
 
+// Raise a kernel's dynamic-LDS cap once PER DEVICE (hipFuncSetAttribute acts on the current device; one process may
+// drive several GPUs). Used inside the int-returning launchers: a failure is returned as the hipError_t.
+#define FQ_RAISE_LDS_CAP(kern, bytes)                                                                               \
+    do {                                                                                                            \
+        static unsigned long long fq_done_ = 0; /* bit per device; a racy double-set stores the same attribute */   \
+        int fq_dev_ = 0;                                                                                            \
+        (void)hipGetDevice(&fq_dev_);                                                                               \
+        if (!((fq_done_ >> (fq_dev_ & 63)) & 1ull)) {                                                               \
+            const hipError_t fq_e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            if (fq_e_ != hipSuccess) return (int)fq_e_;                                                             \
+            fq_done_ |= 1ull << (fq_dev_ & 63);                                                                     \
+        }                                                                                                           \
+    } while (0)
+
 // Flags that select a compile-time kernel specialisation; the rest travel in FqQuantOut::rt_flags.
 constexpr int FQ_CT_MASK = FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_QUANT_F16 | FQ_IN_RMSNORM;
 

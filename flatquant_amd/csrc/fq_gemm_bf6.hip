@@ -312,16 +312,15 @@ int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, in
     o.scol = scol;
     o.bias = bias;
     const int64_t blocks = 8 * ((((M + BM - 1) / BM) * ((N + BN - 1) / BN) + 7) / 8);  // see xcd_tile
+#ifdef FQ_MEASURE  // measurement builds only (tools/scratch/gemm_ablate.sh): ablation selected from the environment
     const char* e = getenv("FQ_GEMM_ABLATE");
     const int abl = e ? atoi(e) : 0;
+#else
+    constexpr int abl = 0;
+#endif
 #define FQ_LAUNCH(A)                                                                                                 \
     {                                                                                                                \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fq_gemm_bf6_kernel<A>),                          \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * TILE_BYTES);              \
-            attr_set = true;                                                                                         \
-        }                                                                                                            \
+        FQ_RAISE_LDS_CAP(fq_gemm_bf6_kernel<A>, STAGES * TILE_BYTES);                                                \
         hipLaunchKernelGGL(fq_gemm_bf6_kernel<A>, dim3((unsigned)blocks), dim3(GT), STAGES * TILE_BYTES, stream, xblob, \
                            wblob, (int)M, N, K / 64, o);                                                             \
     }

@@ -219,7 +219,7 @@ int fq_launch_hadamard_reg(const f16* x, f16* y, int64_t rows, int n, int K, con
 
 int fq_launch_hadamard(const f16* x, f16* y, int64_t rows, int n, int K, const f16* hadK, float scale, int n_cu,
                        hipStream_t stream) {
-    if (!getenv("FQ_HADAMARD_LDS")) {  // register FWHT where it applies (P = 512 * 2^q); this file is the general case
+    {  // register FWHT where it applies (P = 64 ... 512 * 2^q); this file is the general case
         const int rc = fq_launch_hadamard_reg(x, y, rows, n, K, hadK, scale, n_cu, stream);
         if (rc != -1000) return rc;
     }
@@ -245,12 +245,7 @@ int fq_launch_hadamard(const f16* x, f16* y, int64_t rows, int n, int K, const f
     g.frag_off = (int)main_bytes;
     const size_t lds = main_bytes + (K > 1 ? (size_t)(g.KP / 16) * g.KT * 1024 : 0);
     if (lds > 160 * 1024) return -1000;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fq_hadamard_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    FQ_RAISE_LDS_CAP(fq_hadamard_kernel, 160 * 1024);
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;

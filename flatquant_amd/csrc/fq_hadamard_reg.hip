@@ -430,11 +430,7 @@ int launch_kmix(const f16* x, f16* y, int64_t rows, int K, const f16* hadK, floa
     const size_t lds = (size_t)g.KP * (512 * CH / SUB + 8) * 2 + (size_t)(g.KP / 16) * g.KT * 1024 + 64;
     if (lds > 160 * 1024) return -1000;
     auto kern = fq_had_kmix_kernel<CH, QUANT, SILU, SUB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    FQ_RAISE_LDS_CAP(kern, 160 * 1024);
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;

@@ -36,9 +36,23 @@ constexpr int KM = 64, KN = 64, KD = KM * KN;
 constexpr int FRAG_BYTES = 16 * 64 * 16;  // 16 fragments x 64 lanes x 16 B
 constexpr int TOK_BYTES = KD * 2;         // 8192
 
-#ifndef FQ_K64_NT_STORE
-#define FQ_K64_NT_STORE 0  // 1: non-temporal packed-output stores. A/B (tools/time_variants.py): plain stores 1.7 us faster
+// Cache policy of the packed-output stores (16 B per lane, 2 per token): 0 plain (write-back: the lines stay dirty in the
+// XCD's L2 and are written back at the end-of-kernel release), 1 nt, 2 sc1, 3 sc0 sc1 (write-through: nothing left to
+// flush at the kernel boundary). A/B (tools/time_variants.py) in DESIGN 4.1.
+#ifndef FQ_K64_STORE_MODE
+#define FQ_K64_STORE_MODE 0
 #endif
+__device__ __forceinline__ void store_q16(uint8_t* p, u32x4 v) {
+#if FQ_K64_STORE_MODE == 1
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+#elif FQ_K64_STORE_MODE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+#elif FQ_K64_STORE_MODE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+#else
+    *reinterpret_cast<u32x4*>(p) = v;
+#endif
+}
 #ifndef FQ_K64_ABLATE
 #define FQ_K64_ABLATE 0  // measurement builds only: bit 0 = no MFMA, bit 1 = no quantiser arithmetic, bit 2 = no DMA
 #endif
@@ -92,17 +106,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // the prefetch right after issuing it. The asm form is invisible to its counters; completion is waited for by
 // the COUNTED s_waitcnt at the top of the token loop. M0 (LDS base of the DMA) is saved/restored because the
 // compiler owns it.
-#ifndef FQ_K64_NT_LOAD
-#define FQ_K64_NT_LOAD 1  // token DMAs carry the nt (streaming) hint: x is read exactly once
-#endif
-#if FQ_K64_NT_LOAD
 #define FQ_DMA_NT "nt"
-#else
-#define FQ_DMA_NT ""
-#endif
-#ifndef FQ_DMA_INST_OFFSET
-#define FQ_DMA_INST_OFFSET 1  // 1: the instruction's offset field advances BOTH the global and the LDS address
-#endif
 __device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok, unsigned lds_base, int lane) {
 #if FQ_K64_ABLATE & 4
     return;  // measurement build: no HBM reads (compute on whatever is in LDS)
@@ -119,7 +123,6 @@ __device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok
     const unsigned long long sb0 = (unsigned long long)lo32 | ((unsigned long long)hi32 << 32);
     const unsigned long long sb1 = sb0 + 4096;
     unsigned keep;
-#if FQ_DMA_INST_OFFSET
     asm volatile(
         "s_nop 4\n\t"  // SGPR base / offsets may come straight from v_readfirstlane: 5 wait states before VMEM reads them
         "s_mov_b32 %0, m0\n\t"
@@ -139,82 +142,95 @@ __device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok
         : "=&s"(keep)
         : "v"(voff_e), "v"(voff_o), "s"(sb0), "s"(sb1), "s"(lds_base), "s"(lds_base + 4096)
         : "memory");
-#else
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const unsigned voff = ((i & 1) ? voff_o : voff_e) + (i & 3) * 1024;
-        asm volatile(
-            "s_nop 4\n\t"
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %3\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2 nt\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(voff), "s"(i < 4 ? sb0 : sb1), "s"(lds_base + i * 1024)
-            : "memory");
-    }
-#endif
 }
 
-// Fast quantiser over one token's fragment (see fq_qmagic2): fills the 2 x 4 packed dwords this lane stores and
-// returns the mask of dwords (bit 4*mo + w) that some lane of the wave wants redone with the true division.
+// The quantiser of the packed output: one asm block per dword (8 elements), single-width VALU only.
+// v_pk_fma_f32 / v_pk_add_f32 (what hipcc's SLP vectoriser makes of fq_qmagic2 / fq_pack8p in fq_common.hpp) slow a
+// SIMD down next to another wave's MFMAs (tools/scratch/phase_overlap.hip: MFMA phase + pk phase take MORE than their
+// sum, single-width VALU hides a third of the MFMA time) and each one drags a hazard s_nop along; the C++ form of
+// single-width arithmetic (-fno-slp-vectorize) is scheduled into 72 spilled VGPRs at this kernel's 128-register cap.
+// Here the six temporaries are all there is.
+//
+// The exactness proof, two-sided. The pinned result is q = rint(fl(y / s)) with a correctly rounded division.
+// With ilo = inv (1 - 2^-21) and ihi = inv (1 + 2^-21)
+// (inv = v_rcp_f32(s), 1 ulp), both the true quotient y/s and its fp32 rounding fl(y/s) lie between the exact products
+// y*ilo and y*ihi (relative slack 2^-21 against 2^-23 + 2^-24 + 2^-24 of rcp, the rounding of ilo/ihi and of the
+// quotient). u = fma(y, ilo, MAGIC) and v = fma(y, ihi, MAGIC) are those products rounded to integers, once, half to
+// even, and rint is monotone: u == v  =>  rint(fl(y/s)) == u. The integer r sits in the low mantissa bits of u
+// (bits(u) = 0x4B400000 + r, two's complement), so the eight digits are combined by integer Horner steps
+// v_lshl_add_u32 on the raw bits of u and of v; the MAGIC exponent bits fall out of the dword except for the
+// constant K = 0x3F400000, (acc - K + 0x88888888) ^ 0x88888888 is the two's-complement nibble string (offset
+// binary r + 8 per digit, then the XOR), and ONE v_cmp_ne of the two dwords says whether any of the eight digits
+// was ambiguous (then the caller redoes that dword with the true division). CLAMP: med3 on u, v as floats.
+template <bool CLAMP>
+__device__ __forceinline__ uint32_t quant8_two(float y0, float y1, float y2, float y3, float y4, float y5, float y6,
+                                               float y7, float ilo, float ihi, unsigned long long& differ) {
+    uint32_t a, b;
+    float t0, s0, t1, s1;
+    const float magic = FQ_MAGIC;
+    const float lo8 = FQ_MAGIC - 8.0f;
+    float hi7 = FQ_MAGIC + 7.0f;
+    if (CLAMP) asm volatile("" : "+v"(hi7));
+#define FQ_UV(t, s, y) "v_fma_f32 %[" #t "], %[" #y "], %[ilo], %[mg]\n\tv_fma_f32 %[" #s "], %[" #y "], %[ihi], %[mg]\n\t"
+#define FQ_CL(t, s) "v_med3_f32 %[" #t "], %[" #t "], %[lo8], %[hi7]\n\tv_med3_f32 %[" #s "], %[" #s "], %[lo8], %[hi7]\n\t"
+#define FQ_HN(t, s) "v_lshl_add_u32 %[a], %[a], 4, %[" #t "]\n\tv_lshl_add_u32 %[b], %[b], 4, %[" #s "]\n\t"
+#define FQ_TAIL "v_cmp_ne_u32_e64 %[m], %[a], %[b]\n\tv_add_u32_e32 %[a], 0x49488888, %[a]\n\tv_xor_b32_e32 %[a], 0x88888888, %[a]"
+#define FQ_OUTS [a] "=&v"(a), [b] "=&v"(b), [t0] "=&v"(t0), [s0] "=&v"(s0), [t1] "=&v"(t1), [s1] "=&v"(s1), [m] "=&s"(differ)
+#define FQ_INS [y0] "v"(y0), [y1] "v"(y1), [y2] "v"(y2), [y3] "v"(y3), [y4] "v"(y4), [y5] "v"(y5), [y6] "v"(y6), \
+               [y7] "v"(y7), [ilo] "v"(ilo), [ihi] "v"(ihi), [mg] "s"(magic)
+    if (CLAMP)
+        asm(FQ_UV(a, b, y7) FQ_UV(t0, s0, y6) FQ_CL(a, b) FQ_UV(t1, s1, y5) FQ_CL(t0, s0) FQ_HN(t0, s0)
+            FQ_UV(t0, s0, y4) FQ_CL(t1, s1) FQ_HN(t1, s1) FQ_UV(t1, s1, y3) FQ_CL(t0, s0) FQ_HN(t0, s0)
+            FQ_UV(t0, s0, y2) FQ_CL(t1, s1) FQ_HN(t1, s1) FQ_UV(t1, s1, y1) FQ_CL(t0, s0) FQ_HN(t0, s0)
+            FQ_UV(t0, s0, y0) FQ_CL(t1, s1) FQ_HN(t1, s1) FQ_CL(t0, s0) FQ_HN(t0, s0) FQ_TAIL
+            : FQ_OUTS
+            : FQ_INS, [lo8] "s"(lo8), [hi7] "v"(hi7));
+    else
+        asm(FQ_UV(a, b, y7) FQ_UV(t0, s0, y6) FQ_UV(t1, s1, y5) FQ_HN(t0, s0) FQ_UV(t0, s0, y4) FQ_HN(t1, s1)
+            FQ_UV(t1, s1, y3) FQ_HN(t0, s0) FQ_UV(t0, s0, y2) FQ_HN(t1, s1) FQ_UV(t1, s1, y1) FQ_HN(t0, s0)
+            FQ_UV(t0, s0, y0) FQ_HN(t1, s1) FQ_HN(t0, s0) FQ_TAIL
+            : FQ_OUTS
+            : FQ_INS);
+#undef FQ_UV
+#undef FQ_CL
+#undef FQ_HN
+#undef FQ_TAIL
+#undef FQ_OUTS
+#undef FQ_INS
+    return a;
+}
+
+// Quantise + pack one token's fragment: fills the 2 x 4 dwords this lane stores and returns the mask of dwords
+// (bit 4*mo + w) in which some lane of the wave saw an ambiguous digit (to be redone with the true division).
 template <bool CLAMP>
 __device__ __forceinline__ unsigned quant_pack_token(const f32x16 (&Y)[2][2], float inv, uint32_t (&pw)[2][4]) {
-    const f32x2 inv2 = {inv, inv};
-    float dm[2][4];
+    const float ilo = inv * 0.999999523162841796875f, ihi = inv * 1.000000476837158203125f;  // 1 -+ 2^-21
+    unsigned near = 0;
 #pragma unroll
     for (int mo = 0; mo < 2; ++mo)
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const f32x16& t = Y[w >> 1][mo];
             const int b = (w & 1) * 8;
-            float dmax = 0.0f;
-            const f32x2 q01 = fq_qmagic2<CLAMP>(f32x2{t[b + 0], t[b + 1]}, inv2, dmax);
-            const f32x2 q23 = fq_qmagic2<CLAMP>(f32x2{t[b + 2], t[b + 3]}, inv2, dmax);
-            const f32x2 q45 = fq_qmagic2<CLAMP>(f32x2{t[b + 4], t[b + 5]}, inv2, dmax);
-            const f32x2 q67 = fq_qmagic2<CLAMP>(f32x2{t[b + 6], t[b + 7]}, inv2, dmax);
-            pw[mo][w] = fq_pack8p(q01, q23, q45, q67);
-            dm[mo][w] = dmax;
+            unsigned long long differ;
+            pw[mo][w] = quant8_two<CLAMP>(t[b + 0], t[b + 1], t[b + 2], t[b + 3], t[b + 4], t[b + 5], t[b + 6],
+                                          t[b + 7], ilo, ihi, differ);
+            near |= differ ? (1u << (4 * mo + w)) : 0u;  // SALU only
         }
-#ifndef FQ_K64_DEFER_NEAR
-#define FQ_K64_DEFER_NEAR 0  // 1: one wave-wide tie test per token, per-dword tests only if it fires. Keeping the eight
-                             // residual maxima alive costs 52 spilled VGPRs at this kernel's 128-register cap: 39 -> 62 us.
-#endif
-    unsigned near = 0;
-#if FQ_K64_DEFER_NEAR
-    const float dall = fq_max3(fq_max3(dm[0][0], dm[0][1], dm[0][2]), fq_max3(dm[0][3], dm[1][0], dm[1][1]),
-                               FqMaxOp()(dm[1][2], dm[1][3]));
-    if (!fq_wave_needs_exact(dall)) return 0;
-#endif
-#pragma unroll
-    for (int mo = 0; mo < 2; ++mo)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) near |= fq_wave_needs_exact(dm[mo][w]) ? (1u << (4 * mo + w)) : 0u;  // SALU only
     return near;
 }
 
-// Take the next token of the workgroup's range and start its DMA into this wave's (already drained) buffer.
-// FQ_K64_PULL_AT (measurement knob) picks the point of the iteration: 0 = behind GEMM 1's first K-step (all eight
-// X fragments were requested before the first MFMA, so the buffer is free), 1 = after GEMM 1, 2 = after GEMM 2,
-// 3 = after the statistics. Measured round-robin in one process (tools/time_variants.py, C2): 0: 35.7 us (+-0.4),
-// 3: 39.4 us with 4 us of run-to-run spread -- the DMA wants the whole iteration to land.
-#ifndef FQ_K64_PULL_AT
-#define FQ_K64_PULL_AT 0
-#endif
-template <int FLAGS>
-constexpr int kron64_pull_at() {
-    return FQ_K64_PULL_AT;
-}
+// Take the next token of the workgroup's range (LDS counter) and start its DMA into this wave's (already drained)
+// buffer. Placed behind GEMM 1's first K-step: all eight X fragments were requested before the first MFMA, so the
+// buffer is free, and the DMA has the whole iteration to land (pulling after the statistics instead measured
+// 39.4 us against 35.7, tools/time_variants.py, round 1).
 #define FQ_PULL_NEXT()                                                       \
     {                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                   \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
-        int nxt = slot + WAVES;                                              \
-        if (!FQ_K64_STATIC) {                                                \
-            if (lane == 0) nxt = (int)atomicAdd(next_slot, 1u);              \
-            nxt = __builtin_amdgcn_readfirstlane(nxt);                       \
-        }                                                                    \
+        int nxt = 0;                                                         \
+        if (lane == 0) nxt = (int)atomicAdd(next_slot, 1u);                  \
+        nxt = __builtin_amdgcn_readfirstlane(nxt);                           \
         if (nxt < blk_cnt) dma_token(x, blk_base + nxt, tok_lds, lane);      \
         next_pulled = nxt;                                                   \
         __builtin_amdgcn_sched_barrier(0);                                   \
@@ -229,18 +245,13 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                                                            unsigned long long* __restrict__ trace) {
     constexpr int THREADS = kron64_threads<FLAGS>();
     constexpr int WAVES = THREADS / 64;
-    constexpr int PULL_AT = kron64_pull_at<FLAGS>();
-    static_assert(PULL_AT != 3 || (FLAGS & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)), "no statistics phase to pull behind");
     // output stores a single-clip packed token issues after its DMA (2 x 16 B + the scale): lets the top-of-loop
     // wait be a COUNTED vmcnt that does not also wait for the previous token's stores to reach memory.
     constexpr bool COUNTED_WAIT = (FLAGS & FQ_CT_MASK & ~FQ_IN_RMSNORM) == FQ_OUT_PACKED;
     unsigned long long tr_wait = 0, tr_g1 = 0, tr_g2 = 0, tr_epi = 0;
     const unsigned long long tr_start = TRACE ? __builtin_amdgcn_s_memtime() : 0;
     const unsigned long long tr_start_rt = TRACE ? __builtin_amdgcn_s_memrealtime() : 0;  // 100 MHz, chip-wide
-#ifndef FQ_K64_STATIC
-#define FQ_K64_STATIC 0  // 1: waves take tokens wave, wave + WAVES, ... of the workgroup's range (no LDS counter)
-#endif
-    __shared__ __attribute__((aligned(16))) unsigned char smem[FRAG_BYTES + WAVES * TOK_BYTES + (FQ_K64_STATIC ? 0 : 16)];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[FRAG_BYTES + WAVES * TOK_BYTES + 16];
     unsigned* next_slot = reinterpret_cast<unsigned*>(smem + FRAG_BYTES + WAVES * TOK_BYTES);  // work counter
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     // measured 2.8x spread in per-wave loop time.) The first WAVES tokens are handed out statically.
     const int64_t blk_base = (int64_t)blockIdx.x * tpb;
     const int blk_cnt = (int)(rows - blk_base < tpb ? (rows - blk_base < 0 ? 0 : rows - blk_base) : tpb);
-    if (!FQ_K64_STATIC && tid == 0) *next_slot = WAVES;
+    if (tid == 0) *next_slot = WAVES;
     int slot = wave;
 
     // ---- prologue: B-operand fragments of R and L (gathered straight from the 2 x 8 KB row-major matrices) and the
@@ -275,18 +286,12 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     // The gather loads are inline asm because the compiler cannot see the DMAs in its vmcnt accounting: their
     // completion is waited for by hand (8 younger VMEM ops = the DMA, for group 0).
 #ifndef FQ_K64_STAGGER
-#define FQ_K64_STAGGER 40
+#define FQ_K64_STAGGER 20
 #endif
     uint4* frag = reinterpret_cast<uint4*>(smem);
     constexpr int ITEMS = 16 * 64 / THREADS;  // fragment slots (f, lane') this thread fills: 1 or 2
     static_assert(ITEMS * THREADS == 16 * 64, "fragment image is 1024 x 16 B");
     unsigned gv[ITEMS][8];
-#ifdef FQ_K64_SKIP_GATHER  // measurement build: what would a free fragment build be worth?
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) gv[it][j] = 0;
-#else
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int item = tid + it * THREADS;                              // (f, lane') with lane' fastest
@@ -304,7 +309,6 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
         }
 #undef FQ_LD
     }
-#endif
     const bool have_first = slot < blk_cnt;
     const int grp = wave >> 2;
     unsigned long long tr_args = 0, tr_issue = 0;
@@ -353,17 +357,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     const int sw = (c >> 1) & 7;
     const int lane_off = c * KN + h * 32;  // same element offset in HBM (used by diag and by the outputs)
     bool first = true;
-    int prio_rot = 0;
-    (void)prio_rot;
     int next_pulled = 0;
-#ifndef FQ_K64_REGFRAG
-#define FQ_K64_REGFRAG 0  // 1: keep the 16 B-operand fragments in 64 VGPRs (needs the 512-thread build)
-#endif
-#if FQ_K64_REGFRAG
-    f16x8 FR[16];
-#pragma unroll
-    for (int f = 0; f < 16; ++f) FR[f] = __builtin_bit_cast(f16x8, frag[f * 64 + lane]);
-#endif
 
     while (slot < blk_cnt) {
         const int64_t tok = blk_base + slot;
@@ -429,36 +423,18 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
         // ---- GEMM 1: U[mt][nt] = X(mt,:) . R(:, nt); four independent accumulator chains ----
         // Matrix phases run at raised priority: an MFMA needs one issue slot per 32 cycles, so letting it win the
         // arbitration keeps the matrix pipe fed while the other waves' VALU work (quantiser) fills the gaps.
-#ifndef FQ_K64_PRIO
-#define FQ_K64_PRIO 2
-#endif
-#ifndef FQ_K64_PRIO_MODE
-#define FQ_K64_PRIO_MODE 0  // 0: raised in the GEMM phases; 1: flat; 2: younger wave groups higher; 3: rotating per token
-#endif
-#if FQ_K64_PRIO_MODE == 0
-        __builtin_amdgcn_s_setprio(FQ_K64_PRIO);
-#elif FQ_K64_PRIO_MODE == 2
-        if (first) { switch (wave >> 2) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break;
-                                          case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); } }
-#elif FQ_K64_PRIO_MODE == 3
-        switch (((wave >> 2) + prio_rot++) & 3) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break;
-                                                  case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); }
-#endif
+        __builtin_amdgcn_s_setprio(2);
         f32x16 U[2][2];
         U[0][0] = f32x16{0}; U[0][1] = f32x16{0}; U[1][0] = f32x16{0}; U[1][1] = f32x16{0};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-#if FQ_K64_REGFRAG
-            const f16x8 b0 = FR[0 * 4 + s], b1 = FR[1 * 4 + s];
-#else
             const f16x8 b0 = __builtin_bit_cast(f16x8, myfrag[(0 * 4 + s) * 64]);
             const f16x8 b1 = __builtin_bit_cast(f16x8, myfrag[(1 * 4 + s) * 64]);
-#endif
             U[0][0] = mfma32(__builtin_bit_cast(f16x8, X[0][s]), b0, U[0][0]);
             U[1][0] = mfma32(__builtin_bit_cast(f16x8, X[1][s]), b0, U[1][0]);
             U[0][1] = mfma32(__builtin_bit_cast(f16x8, X[0][s]), b1, U[0][1]);
             U[1][1] = mfma32(__builtin_bit_cast(f16x8, X[1][s]), b1, U[1][1]);
-            if (PULL_AT == 0 && s == 0) FQ_PULL_NEXT()  // (all eight X fragments were requested before the first MFMA)
+            if (s == 0) FQ_PULL_NEXT()  // (all eight X fragments were requested before the first MFMA)
         }
 
         // ---- fp16 rounding of U (flat_utils.py:15); C fragment -> A fragment of GEMM 2, no data movement ----
@@ -470,28 +446,20 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
 #pragma unroll
                 for (int j = 0; j < 8; ++j) Uh[nt][ks][j] = (f16)U[ks >> 1][nt][(ks & 1) * 8 + j];
 
-        if (PULL_AT == 1) FQ_PULL_NEXT()
         FQ_TICK(c2)
         // ---- GEMM 2: Y^T(nt, mo) = U(:, nt)^T . L(:, mo) ----
         f32x16 Y[2][2];  // [nt][mo]: Y^T[n' = 32h + 16nt + r][m' = 32mo + c]
         Y[0][0] = f32x16{0}; Y[0][1] = f32x16{0}; Y[1][0] = f32x16{0}; Y[1][1] = f32x16{0};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-#if FQ_K64_REGFRAG
-            const f16x8 b0 = FR[8 + ks * 2 + 0], b1 = FR[8 + ks * 2 + 1];
-#else
             const f16x8 b0 = __builtin_bit_cast(f16x8, myfrag[(8 + ks * 2 + 0) * 64]);
             const f16x8 b1 = __builtin_bit_cast(f16x8, myfrag[(8 + ks * 2 + 1) * 64]);
-#endif
             Y[0][0] = mfma32(Uh[0][ks], b0, Y[0][0]);
             Y[1][0] = mfma32(Uh[1][ks], b0, Y[1][0]);
             Y[0][1] = mfma32(Uh[0][ks], b1, Y[0][1]);
             Y[1][1] = mfma32(Uh[1][ks], b1, Y[1][1]);
         }
-#if FQ_K64_PRIO_MODE == 0
         __builtin_amdgcn_s_setprio(0);
-#endif
-        if (PULL_AT == 2) FQ_PULL_NEXT()
 
         if (out.rt_flags & FQ_ROUND_Y_F16) {
 #pragma unroll
@@ -537,7 +505,6 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
             float vmin = fq_min3(pmin[0], pmin[1], FqMinOp()(pmin[2], pmin[3]));
             vmax = fq_wave_max(vmax);
             vmin = fq_wave_min(vmin);
-            if (PULL_AT == 3) FQ_PULL_NEXT()
             FQ_TICK(c3)
 
             for (int ci = 0; ci < out.n_clips; ++ci) {
@@ -597,14 +564,8 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                     }
 #pragma unroll
                     for (int mo = 0; mo < 2; ++mo)
-#if FQ_K64_NT_STORE
-                        __builtin_nontemporal_store(u32x4{pw[mo][0], pw[mo][1], pw[mo][2], pw[mo][3]},
-                                                    reinterpret_cast<u32x4*>(out.q[ci] + tok * (KD / 2) +
-                                                                             (mo * 32 + c) * (KN / 2) + h * 16));
-#else
-                        *reinterpret_cast<uint4*>(out.q[ci] + tok * (KD / 2) + (mo * 32 + c) * (KN / 2) +
-                                                  h * 16) = make_uint4(pw[mo][0], pw[mo][1], pw[mo][2], pw[mo][3]);
-#endif
+                        store_q16(out.q[ci] + tok * (KD / 2) + (mo * 32 + c) * (KN / 2) + h * 16,
+                                  u32x4{pw[mo][0], pw[mo][1], pw[mo][2], pw[mo][3]});
                 }
                 if (FLAGS & FQ_OUT_FAKEQUANT) {
                     f16x8 fv[2][4];
@@ -700,19 +661,12 @@ template <int FLAGS>
 static int launch_kron64(const f16* x, const f16* left, const f16* right, const f16* diag, int64_t rows,
                          const FqQuantOut& out, int n_cu, hipStream_t stream) {
     constexpr int THREADS = kron64_threads<FLAGS>();
-#ifdef FQ_K64_TPW  // measurement builds: small workgroups of WAVES * FQ_K64_TPW tokens, balanced by the dispatcher
-    constexpr int WAVES = THREADS / 64;
-    int64_t blocks = (rows + WAVES * FQ_K64_TPW - 1) / (WAVES * FQ_K64_TPW);
-    if (blocks < 1) blocks = 1;
-    const int64_t tpb = WAVES * FQ_K64_TPW;
-#else
     // few rows (decode): four tokens per workgroup, so that only the first SIMD-slot group of waves has work and no wave
     // sits out the start-up stagger (up to 3 x 2560 cycles for the last group: most of an 11 us launch at 16 rows)
     int64_t blocks = (rows + 3) / 4;
     if (blocks > n_cu) blocks = n_cu;  // one persistent workgroup per CU (LDS: 16 KB + 8 KB per wave)
     if (blocks < 1) blocks = 1;
     const int64_t tpb = (rows + blocks - 1) / blocks;
-#endif
     hipLaunchKernelGGL((fq_kron64_kernel<FLAGS, false>), dim3((unsigned)blocks), dim3(THREADS), 0, stream, x, left,
                        right, diag, rows, tpb, out, (unsigned long long*)nullptr);
     return (int)hipGetLastError();

@@ -130,12 +130,7 @@ int fq_launch_kron_any(int flags, const f16* x, const f16* left, const f16* righ
     if ((flags & FQ_OUT_PACKED) && ((M * N) & 1)) return -1000;
     const int d8 = (M * N + 7) & ~7;
     const size_t lds = (size_t)d8 * 4 + 32 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fq_kron_any_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        attr_set = true;
-    }
+    FQ_RAISE_LDS_CAP(fq_kron_any_kernel, 160 * 1024);
     int64_t blocks = n_cu;
     if (blocks > rows) blocks = rows;
     if (blocks < 1) blocks = 1;

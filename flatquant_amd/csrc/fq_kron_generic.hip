@@ -18,6 +18,14 @@
 #include "fq_common.hpp"
 #include <stdlib.h>
 
+// Environment switches exist in measurement builds only (-DFQ_MEASURE, tools/scratch/*.sh): the product library reads
+// no environment variables and keeps no mutable global state.
+#ifdef FQ_MEASURE
+static inline bool fq_measure_env(const char* name) { return getenv(name) != nullptr; }
+#else
+static constexpr bool fq_measure_env(const char*) { return false; }
+#endif
+
 namespace {
 
 __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
@@ -614,12 +622,7 @@ int launch_fast(int flags, const f16* x, const uint4* ws, const f16* diag, int64
     const size_t lds = (size_t)2 * MT * MT * 1024 + (size_t)MT * 32 * PITCH * 16 + (((size_t)M * N / 2 + 15) & ~(size_t)15) + 128;
     if (lds > 160 * 1024) return -1000;
     auto kern = fq_kron_fast_kernel<MT, NT, KS1, WAVES, OCC, SILU, CTF>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        attr_set = true;
-    }
+    FQ_RAISE_LDS_CAP(kern, 160 * 1024);
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > OCC) per_cu = OCC;
     if (per_cu < 1) per_cu = 1;
@@ -638,12 +641,7 @@ int launch_generic(int flags, const f16* x, const uint4* ws, const f16* diag, in
     const size_t lds = xs_bytes + ob + 64;
     if (lds > 160 * 1024) return -1000;
     auto kern = fq_kron_generic_kernel<MT, NT>;
-    static bool attr_set = false;  // idempotent: raises the dynamic-LDS cap of this instantiation once
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        attr_set = true;
-    }
+    FQ_RAISE_LDS_CAP(kern, 160 * 1024);
     int per_cu = (int)((160 * 1024) / lds);  // workgroups that fit a CU's 160 KB of LDS: they overlap each other's
     if (per_cu > 4) per_cu = 4;              // synchronous token load with compute
     if (per_cu < 1) per_cu = 1;
@@ -701,7 +699,7 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
         if (diag != nullptr || out.in2 == nullptr) return -1000;
 #define FQ_FS(MT_, NT_, KS1_, W_, OCC_)                                                                          \
     if (MT == MT_ && NT == NT_ && g.KS1 == KS1_) {                                                              \
-        if ((flags & FQ_CT_MASK) == FQ_OUT_PACKED && !getenv("FQ_KRON_NO_CTF"))                                 \
+        if ((flags & FQ_CT_MASK) == FQ_OUT_PACKED && !fq_measure_env("FQ_KRON_NO_CTF"))                                 \
             return launch_fast<MT_, NT_, KS1_, W_, OCC_, true, FQ_OUT_PACKED>(flags, x, ws, diag, rows, M, N, out, n_cu, stream); \
         return launch_fast<MT_, NT_, KS1_, W_, OCC_, true>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);  \
     }
@@ -709,15 +707,17 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
 #undef FQ_FS
         return -1000;
     }
-    if (!getenv("FQ_KRON_NO_WAVE")) {  // one wave per token where a token fits a wave (packed output only)
+    if (!fq_measure_env("FQ_KRON_NO_WAVE")) {  // one wave per token where a token fits a wave (packed output only)
         rc = fq_launch_kron_wave(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }
+#ifdef FQ_MEASURE
     if (const char* dbg = getenv("FQ_KRON_DBG")) flags |= atoi(dbg) & 0x7000;  // measurement: ablation bits of the fast kernel
-    if (!getenv("FQ_KRON_GENERIC_V1")) {  // (the original kernel stays reachable for A/B runs)
+#endif
+    if (!fq_measure_env("FQ_KRON_GENERIC_V1")) {  // (the original kernel stays reachable for A/B runs)
 #define FQ_F(MT_, NT_, KS1_, W_, OCC_)                                                                   \
     if (MT == MT_ && NT == NT_ && g.KS1 == KS1_) {                                                       \
-        if (MT_ >= 3 && (flags & FQ_CT_MASK) == FQ_OUT_PACKED && !getenv("FQ_KRON_NO_CTF"))              \
+        if (MT_ >= 3 && (flags & FQ_CT_MASK) == FQ_OUT_PACKED && !fq_measure_env("FQ_KRON_NO_CTF"))              \
             rc = launch_fast<MT_, NT_, KS1_, W_, OCC_, false, (MT_ >= 3 ? FQ_OUT_PACKED : -1)>(flags, x, ws, diag, rows, M, N, out, n_cu, stream); \
         else                                                                                             \
             rc = launch_fast<MT_, NT_, KS1_, W_, OCC_>(flags, x, ws, diag, rows, M, N, out, n_cu, stream); \

@@ -233,12 +233,7 @@ int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, con
 #define FQ_DEC(HD_, NW_)                                                                                              \
     {                                                                                                                 \
         constexpr size_t lds = sizeof(float) * ((size_t)(NW_ * (64 / (HD_ / 32))) * (HD_ + 1 + 2) + HD_);                     \
-        static bool attr_set = false;                                                                                 \
-        if (!attr_set) {                                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fq_kv_decode_kernel<HD_, NW_>),                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
-            attr_set = true;                                                                                          \
-        }                                                                                                             \
+        FQ_RAISE_LDS_CAP((fq_kv_decode_kernel<HD_, NW_>), lds);                                                       \
         hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
     }
     if (head_dim == 128) {
