@@ -26,6 +26,8 @@ FQ_QUANT_F16 = 0x20
 FQ_WS_PREPARED = 0x40
 FQ_IN_RMSNORM = 0x80
 FQ_IN_SILU_MUL = 0x100
+FQ_GROUP128 = 0x200
+FQ_SIG_F16 = 0x400
 FQ_KV_LAC = 0x1
 FQ_MAX_CLIPS = 4
 
@@ -38,6 +40,7 @@ _vpp = ctypes.POINTER(ctypes.c_void_p)
 SYMBOLS = {
     "fq_kron_quant_f16": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp, _i64,
                                _vp]),
+    "fq_kron_quant_grouped_f16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "fq_kron_workspace_bytes": (_i64, [_i, _i]),
     "fq_kron_prepare_f16": (_i, [_vp, _vp, _i, _i, _vp, _i64, _vp]),
     "fq_rmsnorm_kron_quant_f16": (_i, [_vp, _f, _vp, _vp, _i64, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp]),

@@ -100,7 +100,7 @@ int fill_out(const char* what, FqQuantOut& o, const float* sig_max, const float*
     const int outs = flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM);
     if (outs == 0) return fail(FQ_EINVAL, "%s: flags select no output", what);
     if (flags & ~(FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_ROUND_Y_F16 | FQ_NO_CLAMP0 | FQ_WS_PREPARED |
-                  FQ_QUANT_F16))
+                  FQ_QUANT_F16 | FQ_GROUP128 | FQ_SIG_F16))
         return fail(FQ_EINVAL, "%s: unknown flag bits 0x%x", what, flags);
     if (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) {
         if (n_clips < 1 || n_clips > FQ_MAX_CLIPS)
@@ -126,7 +126,7 @@ int fill_out(const char* what, FqQuantOut& o, const float* sig_max, const float*
         if (!y_out) return fail(FQ_EINVAL, "%s: FQ_OUT_TRANSFORM needs y_out", what);
         o.y = (f16*)y_out;
     }
-    o.rt_flags = flags & (FQ_ROUND_Y_F16 | FQ_NO_CLAMP0);
+    o.rt_flags = flags & (FQ_ROUND_Y_F16 | FQ_NO_CLAMP0 | FQ_GROUP128 | FQ_SIG_F16);
     o.rms_eps = 0.0f;
     o.in2 = nullptr;
     return FQ_OK;
@@ -148,10 +148,44 @@ __global__ void fq_probe_mfma_kernel(const f16* __restrict__ A, const f16* __res
 
 }  // namespace
 
+// Kernel selection shared by fq_kron_quant_f16 and fq_kron_quant_grouped_f16 (o carries the outputs, the run-time flags
+// and, for a grouped launch, the group arrays).
+static int kron_dispatch(const char* what, const FqQuantOut& o, int flags, const void* x, const void* left, const void* right,
+                         const void* diag, int64_t rows, int M, int N, void* workspace, int64_t workspace_bytes,
+                         void* stream) {
+    int rc;
+    const int n_cu = cu_count();
+    const bool special = o.group_offsets != nullptr || (o.rt_flags & FQ_GROUP128);  // only the fused MFMA kernels take these
+    if ((o.rt_flags & FQ_GROUP128) && ((M * N) % 128 != 0 || (flags & (FQ_QUANT_F16 | FQ_OUT_FAKEQUANT)) || o.n_clips != 1))
+        return fail(FQ_EUNSUPPORTED, "%s: FQ_GROUP128 is fused for packed output, one clip set, fp32 arithmetic, M*N %% 128 == 0", what);
+    if (M == 64 && N == 64) {
+        rc = fq_launch_kron64(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag,
+                              rows, o, n_cu, (hipStream_t)stream);
+        if (rc != -1000) return check_launch(rc, what);
+        if (o.rt_flags & FQ_GROUP128) return fail(FQ_EUNSUPPORTED, "%s: FQ_GROUP128 needs the packed-only output set at 64 x 64", what);
+    }
+    rc = fq_launch_kron_generic(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag,
+                                rows, M, N, o, workspace, workspace_bytes, n_cu, (hipStream_t)stream);
+    if (rc == -1001)
+        return fail(FQ_EINVAL, "%s: workspace of %lld bytes required for M=%d N=%d (got %lld)", what,
+                    (long long)fq_kron_generic_workspace_bytes(M, N), M, N, (long long)(workspace ? workspace_bytes : 0));
+    if (rc == -1000 && special)
+        return fail(FQ_EUNSUPPORTED, "%s: grouped / FQ_GROUP128 launches need a fused MFMA kernel; factors (%d, %d) with "
+                    "flags 0x%x have none", what, M, N, flags);
+    if (rc == -1000) {  // no MFMA kernel for this pair: the any-shape kernel (csrc/fq_kron_any.hip), no workspace
+        rc = fq_launch_kron_any(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag, rows, M, N, o,
+                                n_cu, (hipStream_t)stream);
+        if (rc == -1000)
+            return fail(FQ_EUNSUPPORTED, "%s: no kernel for factors (%d, %d): M, N <= 256 and M*N <= 32768", what, M, N);
+        return check_launch(rc, what);
+    }
+    return check_launch(rc, what);
+}
+
 extern "C" {
 
 const char* fq_last_error(void) { return g_err; }
-int fq_version(void) { return 100; }
+int fq_version(void) { return 110; }
 
 int fq_kron_quant_f16(const void* x, const void* left, const void* right, const void* diag, int64_t rows,
                       int M, int N, const float* sig_max, const float* sig_min, int n_clips, int flags,
@@ -164,25 +198,35 @@ int fq_kron_quant_f16(const void* x, const void* left, const void* right, const 
     if (rc != FQ_OK) return rc;
     if (rows == 0) return FQ_OK;  // empty batch: nothing to launch (zero-size tensors have NULL data)
     if (!x || !left || !right) return fail(FQ_EINVAL, "fq_kron_quant_f16: x/left/right is NULL");
-    const int n_cu = cu_count();
-    if (M == 64 && N == 64) {
-        rc = fq_launch_kron64(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag,
-                              rows, o, n_cu, (hipStream_t)stream);
-        if (rc != -1000) return check_launch(rc, "fq_kron_quant_f16[64x64]");
+    return kron_dispatch("fq_kron_quant_f16", o, flags, x, left, right, diag, rows, M, N, workspace, workspace_bytes, stream);
+}
+
+int fq_kron_quant_grouped_f16(const void* x, const void* left, const void* right, int64_t rows, int M, int N,
+                              const int64_t* group_offsets, int n_groups, const float* sig_max_g, const float* sig_min_g,
+                              int flags, void* q_out, void* scale_out, void* fq_out, void* y_out,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+    const char* what = "fq_kron_quant_grouped_f16";
+    if (rows < 0 || M <= 0 || N <= 0) return fail(FQ_EINVAL, "%s: bad sizes rows=%lld M=%d N=%d", what, (long long)rows, M, N);
+    if (N & 1) return fail(FQ_EINVAL, "%s: N=%d must be even (two INT4 per byte)", what, N);
+    if (n_groups < 1) return fail(FQ_EINVAL, "%s: n_groups=%d", what, n_groups);
+    if (flags & FQ_QUANT_F16) return fail(FQ_EUNSUPPORTED, "%s: fp32 quantiser arithmetic only", what);
+    const bool quant = (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) != 0;
+    const float one = 1.0f;  // fill_out wants a host clip pair; the kernels read the per-group device arrays instead
+    void* q1[FQ_MAX_CLIPS] = {q_out}, *s1[FQ_MAX_CLIPS] = {scale_out}, *f1[FQ_MAX_CLIPS] = {fq_out};
+    FqQuantOut o;
+    int rc = fill_out(what, o, &one, &one, 1, flags, q1, s1, f1, y_out);
+    if (rc != FQ_OK) return rc;
+    if (rows == 0) return FQ_OK;
+    if (!x || !left || !right) return fail(FQ_EINVAL, "%s: x/left/right is NULL", what);
+    if (!group_offsets || (quant && (!sig_max_g || !sig_min_g)))
+        return fail(FQ_EINVAL, "%s: group_offsets / sig_max_g / sig_min_g is NULL", what);
+    if (quant) {  // a transform-only launch needs no clip pairs: leave it ungrouped
+        o.group_offsets = group_offsets;
+        o.sig_max_g = sig_max_g;
+        o.sig_min_g = sig_min_g;
+        o.n_groups = n_groups;
     }
-    rc = fq_launch_kron_generic(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag,
-                                rows, M, N, o, workspace, workspace_bytes, n_cu, (hipStream_t)stream);
-    if (rc == -1001)
-        return fail(FQ_EINVAL, "fq_kron_quant_f16: workspace of %lld bytes required for M=%d N=%d (got %lld)",
-                    (long long)fq_kron_generic_workspace_bytes(M, N), M, N, (long long)(workspace ? workspace_bytes : 0));
-    if (rc == -1000) {  // no MFMA kernel for this pair: the any-shape kernel (csrc/fq_kron_any.hip), no workspace
-        rc = fq_launch_kron_any(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag, rows, M, N, o,
-                                n_cu, (hipStream_t)stream);
-        if (rc == -1000)
-            return fail(FQ_EUNSUPPORTED, "fq_kron_quant_f16: no kernel for factors (%d, %d): M, N <= 256 and M*N <= 32768", M, N);
-        return check_launch(rc, "fq_kron_quant_f16[any]");
-    }
-    return check_launch(rc, "fq_kron_quant_f16[generic]");
+    return kron_dispatch(what, o, flags, x, left, right, nullptr, rows, M, N, workspace, workspace_bytes, stream);
 }
 
 int fq_rmsnorm_kron_quant_f16(const void* x, float eps, const void* left, const void* right, int64_t rows, int M, int N,

@@ -31,7 +31,46 @@ struct FqQuantOut {
     int      rt_flags;             // run-time flags: FQ_ROUND_Y_F16, FQ_NO_CLAMP0 (wave-uniform branches)
     float    rms_eps;              // FQ_IN_RMSNORM: epsilon of the fused RMSNorm
     const f16* in2;                // FQ_IN_SILU_MUL: the `up` tensor (x is `gate`), same shape as x
+    // grouped launch (fq_kron_quant_grouped_f16): rows are sorted by group (expert), group g owns rows
+    // [group_offsets[g], group_offsets[g+1]) and quantises with its own clip pair; nullptr = not grouped
+    const int64_t* group_offsets;  // device, [n_groups + 1]
+    const float*   sig_max_g;      // device, [n_groups]
+    const float*   sig_min_g;      // device, [n_groups]
+    int            n_groups;
 };
+
+// Clip pair of token `tok` (wave-uniform): the launch-wide pair `ci`, or the pair of the token's group. A wave walks its
+// tokens in increasing order, so it keeps a cursor (g, [begin, end)) and only searches when the token leaves the range:
+// a binary search over group_offsets with scalar loads (<= 10 dependent s_loads for 1024 groups), taking the LAST group
+// whose offset is <= tok, i.e. skipping empty groups.
+struct FqGroupCursor {
+    int g = -1;
+    int64_t begin = 0, end = 0;
+    float smax = 1.0f, smin = 1.0f;
+};
+__device__ __forceinline__ void fq_token_sigs(const FqQuantOut& out, int ci, int64_t tok, FqGroupCursor& cur, float& smax,
+                                              float& smin) {
+    if (out.group_offsets == nullptr) {
+        smax = out.sig_max[ci];
+        smin = out.sig_min[ci];
+        return;
+    }
+    if (cur.g < 0 || tok >= cur.end || tok < cur.begin) {
+        int lo = 0, hi = out.n_groups;  // invariant: offsets[lo] <= tok < offsets[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (out.group_offsets[mid] <= tok) lo = mid;
+            else hi = mid;
+        }
+        cur.g = lo;
+        cur.begin = out.group_offsets[lo];
+        cur.end = out.group_offsets[lo + 1];
+        cur.smax = out.sig_max_g[lo];
+        cur.smin = out.sig_min_g[lo];
+    }
+    smax = cur.smax;
+    smin = cur.smin;
+}
 
 // Raise a kernel's dynamic-LDS cap once PER DEVICE (hipFuncSetAttribute acts on the current device; one process may
 // drive several GPUs). Used inside the int-returning launchers: a failure is returned as the hipError_t.
@@ -128,6 +167,33 @@ __device__ __forceinline__ float fq_wave_sum(float v) { return fq_wave_reduce(v,
 __device__ __forceinline__ float fq_wave_max(float v) { return fq_wave_reduce(v, FqMaxOp()); }
 __device__ __forceinline__ float fq_wave_min(float v) { return fq_wave_reduce(v, FqMinOp()); }
 
+// fp16(fp32(a * b)): the fp32 product is ROUNDED TO fp32 FIRST, then to fp16 — what torch does for
+// (scale * q).to(float16) (quant_utils.py:25-26,81). hipcc otherwise selects v_fma_mixlo_f16 for
+// fptrunc(fmul), which rounds the exact product once and differs when the fp32 product lands on an fp16 tie
+// (seen on the GPU: 7 * 3.184152 -> 22.297 instead of 22.281). The empty asm makes the product opaque.
+__device__ __forceinline__ f16 fq_mul_to_f16(float a, float b) {
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return (f16)p;
+}
+
+// FQ_GROUP128 with N = 64: a 128-element group is two consecutive 64-element rows of the transformed token, held by the
+// lanes (h, c) with c in {2j, 2j+1}, h in {0, 1} of one output-row tile: combine a per-lane partial extremum over
+// lane ^ 1 (DPP quad_perm) and lane ^ 32 (v_permlane32_swap). Every one of the four lanes ends with the group's value.
+template <class Op>
+__device__ __forceinline__ float fq_group4_reduce(float v, Op op) {
+    {
+        const float r = fq_dpp<0xB1>(v);  // quad_perm:[1,0,3,2]: lane ^ 1
+        v = op(v, r);
+    }
+    {
+        float a = v, b = v;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        v = op(a, b);
+    }
+    return v;
+}
+
 // scale from (xmax, xmin) of one token and one clip set; see header comment for the pinned arithmetic.
 template <int FLAGS>
 __device__ __forceinline__ float fq_token_scale(float xmax, float xmin, float sig_max, float sig_min,
@@ -136,8 +202,17 @@ __device__ __forceinline__ float fq_token_scale(float xmax, float xmin, float si
         xmax = fmaxf(xmax, 0.0f);
         xmin = fminf(xmin, 0.0f);
     }
-    xmax = xmax * sig_max;
-    xmin = xmin * sig_min;
+    if ((FLAGS & FQ_QUANT_F16) && (rt_flags & FQ_SIG_F16)) {
+        // deploy.nn.Quantizer(lac=True), deploy/nn/quantization.py:21-22: an fp16 [rows, 1] tensor times a 0-dim fp32
+        // sigmoid tensor is an fp16 RESULT under torch's type promotion: the product is formed in fp32 (fp16 extremum x the
+        // fp32 sigmoid, rounded to fp32) and then rounded to fp16 — two roundings (run on the reference: golden
+        // quantizer_lac.npz). The (1,)-shaped parameters of quant_utils.py:96-97 promote the result to fp32 instead.
+        xmax = (float)fq_mul_to_f16(xmax, sig_max);
+        xmin = (float)fq_mul_to_f16(xmin, sig_min);
+    } else {
+        xmax = xmax * sig_max;
+        xmin = xmin * sig_min;
+    }
     float m = fmaxf(fabsf(xmin), xmax);
     float scale;
     if (FLAGS & FQ_QUANT_F16) {
@@ -171,16 +246,6 @@ __device__ __forceinline__ int fq_quant1_h(f16 y, f16 s) {
     float r = __builtin_rintf((float)t);
     r = __builtin_amdgcn_fmed3f(r, -8.0f, 7.0f);
     return (int)r;
-}
-
-// fp16(fp32(a * b)): the fp32 product is ROUNDED TO fp32 FIRST, then to fp16 — what torch does for
-// (scale * q).to(float16) (quant_utils.py:25-26,81). hipcc otherwise selects v_fma_mixlo_f16 for
-// fptrunc(fmul), which rounds the exact product once and differs when the fp32 product lands on an fp16 tie
-// (seen on the GPU: 7 * 3.184152 -> 22.297 instead of 22.281). The empty asm makes the product opaque.
-__device__ __forceinline__ f16 fq_mul_to_f16(float a, float b) {
-    float p = a * b;
-    asm volatile("" : "+v"(p));
-    return (f16)p;
 }
 
 // x_up * act_fn(x_gate) in front of a down_proj transform (deploy/transformers/modeling_llama.py:277-278, fp16 tensors):

@@ -33,6 +33,8 @@
 namespace {
 
 constexpr int KM = 64, KN = 64, KD = KM * KN;
+constexpr int FQ_K64_G128 = 0x10000;     // internal template bits (not ABI flags): the FQ_GROUP128 instantiation,
+constexpr int FQ_K64_GROUPED = 0x20000;  // the grouped-launch instantiations (fq_kron_quant_grouped_f16)
 constexpr int FRAG_BYTES = 16 * 64 * 16;  // 16 fragments x 64 lanes x 16 B
 constexpr int TOK_BYTES = KD * 2;         // 8192
 
@@ -83,7 +85,7 @@ constexpr int kron64_threads() {
 #ifndef FQ_K64_THREADS
 #define FQ_K64_THREADS 1024
 #endif
-    return (outs == 1 && !(FLAGS & FQ_QUANT_F16)) ? FQ_K64_THREADS : 512;
+    return (outs == 1 && !(FLAGS & (FQ_QUANT_F16 | FQ_K64_G128 | FQ_K64_GROUPED))) ? FQ_K64_THREADS : 512;
 }
 
 // TRACE (debug build of the same kernel, fq_debug_kron64_trace): lane 0 of every wave accumulates s_memtime
@@ -203,11 +205,12 @@ __device__ __forceinline__ uint32_t quant8_two(float y0, float y1, float y2, flo
 // Quantise + pack one token's fragment: fills the 2 x 4 dwords this lane stores and returns the mask of dwords
 // (bit 4*mo + w) in which some lane of the wave saw an ambiguous digit (to be redone with the true division).
 template <bool CLAMP>
-__device__ __forceinline__ unsigned quant_pack_token(const f32x16 (&Y)[2][2], float inv, uint32_t (&pw)[2][4]) {
-    const float ilo = inv * 0.999999523162841796875f, ihi = inv * 1.000000476837158203125f;  // 1 -+ 2^-21
+__device__ __forceinline__ unsigned quant_pack_token(const f32x16 (&Y)[2][2], const float (&inv)[2], uint32_t (&pw)[2][4]) {
     unsigned near = 0;
 #pragma unroll
-    for (int mo = 0; mo < 2; ++mo)
+    for (int mo = 0; mo < 2; ++mo) {
+        // (inv[0] and inv[1] are the same register unless the launch is FQ_GROUP128: one scale per pair of output rows)
+        const float ilo = inv[mo] * 0.999999523162841796875f, ihi = inv[mo] * 1.000000476837158203125f;  // 1 -+ 2^-21
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const f32x16& t = Y[w >> 1][mo];
@@ -217,6 +220,7 @@ __device__ __forceinline__ unsigned quant_pack_token(const f32x16 (&Y)[2][2], fl
                                           t[b + 7], ilo, ihi, differ);
             near |= differ ? (1u << (4 * mo + w)) : 0u;  // SALU only
         }
+    }
     return near;
 }
 
@@ -245,6 +249,9 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                                                            unsigned long long* __restrict__ trace) {
     constexpr int THREADS = kron64_threads<FLAGS>();
     constexpr int WAVES = THREADS / 64;
+    constexpr bool G128 = (FLAGS & FQ_K64_G128) != 0;
+    constexpr bool GROUPED = (FLAGS & FQ_K64_GROUPED) != 0;  // per-group clip pairs (own instantiations: the cursor costs
+                                                             // the single-output kernels their 128-register fit)
     // output stores a single-clip packed token issues after its DMA (2 x 16 B + the scale): lets the top-of-loop
     // wait be a COUNTED vmcnt that does not also wait for the previous token's stores to reach memory.
     constexpr bool COUNTED_WAIT = (FLAGS & FQ_CT_MASK & ~FQ_IN_RMSNORM) == FQ_OUT_PACKED;
@@ -358,6 +365,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     const int lane_off = c * KN + h * 32;  // same element offset in HBM (used by diag and by the outputs)
     bool first = true;
     int next_pulled = 0;
+    FqGroupCursor gcur;  // grouped launches: the clip pair follows the token's group
 
     while (slot < blk_cnt) {
         const int64_t tok = blk_base + slot;
@@ -508,11 +516,35 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
             FQ_TICK(c3)
 
             for (int ci = 0; ci < out.n_clips; ++ci) {
-                const float scale = fq_token_scale<FLAGS>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
+                float sig_max = out.sig_max[ci], sig_min = out.sig_min[ci];
+                if (GROUPED) fq_token_sigs(out, ci, tok, gcur, sig_max, sig_min);
+                const float scale = fq_token_scale<FLAGS>(vmax, vmin, sig_max, sig_min, out.rt_flags);
                 // value of element e (0..7) of dword w (0..3) of output row mo: Y^T[n' = 32h + 8w + e]
 #define FQ_YV(mo, w, e) Y[(w) >> 1][mo][((w) & 1) * 8 + (e)]
                 if (FLAGS & FQ_OUT_PACKED) {
-                    if (lane == 0) out.scale[ci][tok] = (f16)scale;
+                    // FQ_GROUP128 (own instantiation): one scale per 128 consecutive elements = output rows (2j, 2j+1),
+                    // i.e. lanes c in {2j, 2j+1}, both column halves h, per output-row tile mo; [rows, 32] scales
+                    float scl[2] = {scale, scale};
+                    bool g_magic = true, g_clamp = false;
+                    if (G128) {
+#pragma unroll
+                        for (int mo = 0; mo < 2; ++mo) {
+                            float a = FqMaxOp()(Y[0][mo][0], Y[0][mo][1]), b = FqMinOp()(Y[0][mo][0], Y[0][mo][1]);
+#pragma unroll
+                            for (int r = 2; r < 32; r += 2) {
+                                a = fq_max3(a, Y[r >> 4][mo][r & 15], Y[r >> 4][mo][(r & 15) + 1]);
+                                b = fq_min3(b, Y[r >> 4][mo][r & 15], Y[r >> 4][mo][(r & 15) + 1]);
+                            }
+                            const float gmax = fq_group4_reduce(a, FqMaxOp()), gmin = fq_group4_reduce(b, FqMinOp());
+                            scl[mo] = fq_token_scale<FLAGS>(gmax, gmin, sig_max, sig_min, out.rt_flags);
+                            const float gi = fq_fast_inv(scl[mo]);
+                            g_magic = g_magic && !__any(!fq_magic_ok(gmax, gmin, gi));
+                            g_clamp = g_clamp || __any(fq_needs_clamp(gmax, gmin, gi));
+                            if (h == 0 && !(c & 1)) out.scale[ci][tok * (KD / 128) + ((mo * 32 + c) >> 1)] = (f16)scl[mo];
+                        }
+                    } else if (lane == 0) {
+                        out.scale[ci][tok] = (f16)scale;
+                    }
                     uint32_t pw[2][4];
                     if (FLAGS & FQ_QUANT_F16) {
 #pragma unroll
@@ -522,12 +554,12 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                                 uint32_t d = 0;
 #pragma unroll
                                 for (int e = 0; e < 8; ++e)
-                                    d |= (uint32_t)(fq_quant1<FLAGS>(FQ_YV(mo, w, e), scale) & 15) << (4 * e);
+                                    d |= (uint32_t)(fq_quant1<FLAGS>(FQ_YV(mo, w, e), scl[mo]) & 15) << (4 * e);
                                 pw[mo][w] = d;
                             }
                     } else {
-                        const float inv = fq_fast_inv(scale);
-                        // bit (4*mo + w) of near: some lane's dword has a quotient within FQ_NEAR of a tie
+                        const float inv[2] = {fq_fast_inv(scl[0]), G128 ? fq_fast_inv(scl[1]) : fq_fast_inv(scl[0])};
+                        // bit (4*mo + w) of near: some lane's dword has an ambiguous digit
                         unsigned near;
 #if FQ_K64_ABLATE & 2
                         near = 0;
@@ -539,11 +571,11 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                                             __builtin_bit_cast(unsigned, FQ_YV(mo, w, 2)) ^ __builtin_bit_cast(unsigned, FQ_YV(mo, w, 3)) ^
                                             __builtin_bit_cast(unsigned, FQ_YV(mo, w, 4)) ^ __builtin_bit_cast(unsigned, FQ_YV(mo, w, 5)) ^
                                             __builtin_bit_cast(unsigned, FQ_YV(mo, w, 6)) ^ __builtin_bit_cast(unsigned, FQ_YV(mo, w, 7)) ^
-                                            __builtin_bit_cast(unsigned, inv);
+                                            __builtin_bit_cast(unsigned, inv[mo]);
 #else
-                        if (!fq_magic_ok(vmax, vmin, inv)) {
+                        if (G128 ? !g_magic : !fq_magic_ok(vmax, vmin, inv[0])) {
                             near = 0xffu;  // quotients too large for the magic-number rounding: true division throughout
-                        } else if (fq_needs_clamp(vmax, vmin, inv)) {
+                        } else if (G128 ? g_clamp : fq_needs_clamp(vmax, vmin, inv[0])) {
                             near = quant_pack_token<true>(Y, inv, pw);
                         } else {
                             near = quant_pack_token<false>(Y, inv, pw);
@@ -556,10 +588,10 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                                 for (int w = 0; w < 4; ++w)
                                     if (near & (1u << (4 * mo + w)))
                                         pw[mo][w] = fq_pack8(
-                                            fq_qexact(FQ_YV(mo, w, 0), scale), fq_qexact(FQ_YV(mo, w, 1), scale),
-                                            fq_qexact(FQ_YV(mo, w, 2), scale), fq_qexact(FQ_YV(mo, w, 3), scale),
-                                            fq_qexact(FQ_YV(mo, w, 4), scale), fq_qexact(FQ_YV(mo, w, 5), scale),
-                                            fq_qexact(FQ_YV(mo, w, 6), scale), fq_qexact(FQ_YV(mo, w, 7), scale));
+                                            fq_qexact(FQ_YV(mo, w, 0), scl[mo]), fq_qexact(FQ_YV(mo, w, 1), scl[mo]),
+                                            fq_qexact(FQ_YV(mo, w, 2), scl[mo]), fq_qexact(FQ_YV(mo, w, 3), scl[mo]),
+                                            fq_qexact(FQ_YV(mo, w, 4), scl[mo]), fq_qexact(FQ_YV(mo, w, 5), scl[mo]),
+                                            fq_qexact(FQ_YV(mo, w, 6), scl[mo]), fq_qexact(FQ_YV(mo, w, 7), scl[mo]));
                         }
                     }
 #pragma unroll
@@ -680,6 +712,26 @@ int fq_launch_kron64(int flags, const f16* x, const f16* left, const f16* right,
         return launch_kron64<(F)>(x, left, right, diag, rows, out, n_cu, stream);      \
     case (F) | FQ_QUANT_F16:                                                           \
         return launch_kron64<(F) | FQ_QUANT_F16>(x, left, right, diag, rows, out, n_cu, stream);
+    if (out.rt_flags & FQ_GROUP128) {  // per-128-element scales: packed output, fp32 quantiser arithmetic only
+        if ((flags & FQ_CT_MASK) != FQ_OUT_PACKED) return -1000;
+        if (out.group_offsets != nullptr)
+            return launch_kron64<FQ_OUT_PACKED | FQ_K64_G128 | FQ_K64_GROUPED>(x, left, right, diag, rows, out, n_cu, stream);
+        return launch_kron64<FQ_OUT_PACKED | FQ_K64_G128>(x, left, right, diag, rows, out, n_cu, stream);
+    }
+    if (out.group_offsets != nullptr) {  // grouped launch: packed or fake-quant output (+ the transform)
+        switch (flags & FQ_CT_MASK) {
+            case FQ_OUT_PACKED:
+                return launch_kron64<FQ_OUT_PACKED | FQ_K64_GROUPED>(x, left, right, diag, rows, out, n_cu, stream);
+            case FQ_OUT_FAKEQUANT:
+                return launch_kron64<FQ_OUT_FAKEQUANT | FQ_K64_GROUPED>(x, left, right, diag, rows, out, n_cu, stream);
+            case FQ_OUT_PACKED | FQ_OUT_TRANSFORM:
+                return launch_kron64<FQ_OUT_PACKED | FQ_OUT_TRANSFORM | FQ_K64_GROUPED>(x, left, right, diag, rows, out, n_cu, stream);
+            case FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM:
+                return launch_kron64<FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_K64_GROUPED>(x, left, right, diag, rows, out, n_cu, stream);
+            default:
+                return -1000;
+        }
+    }
     switch (flags & FQ_CT_MASK) {
         FQ_CASE(FQ_OUT_PACKED)
         FQ_CASE(FQ_OUT_FAKEQUANT)

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(ANY_T) void fq_kron_any_kernel(const f16* __restric
 // -1000: outside even this kernel's range (M * N > 32768, M or N > 256, odd N with packed output)
 int fq_launch_kron_any(int flags, const f16* x, const f16* left, const f16* right, const f16* diag, int64_t rows, int M,
                        int N, const FqQuantOut& out, int n_cu, hipStream_t stream) {
+    if (out.group_offsets != nullptr || (out.rt_flags & FQ_GROUP128)) return -1000;  // not in this kernel
     if (M < 1 || N < 1 || M > 256 || N > 256 || (int64_t)M * N > ANY_T * ANY_MAXJ) return -1000;
     if ((flags & FQ_OUT_PACKED) && ((M * N) & 1)) return -1000;
     const int d8 = (M * N + 7) & ~7;

@@ -360,6 +360,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
     }
     int pf_q0 = tid;
     if (tok < rows) FQ_PF_LOAD(tok)
+    FqGroupCursor gcur;  // grouped launches: the clip pair follows the token's group
 
     for (; tok < rows; tok += gridDim.x) {
         // ---- stage the prefetched token (the previous token's readers passed the statistics barrier) ----
@@ -524,9 +525,10 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
 
         for (int ci = 0; ci < out.n_clips; ++ci) {
             if (!(flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT))) break;
-            float scale;
-            if (flags & FQ_QUANT_F16) scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
-            else scale = fq_token_scale<0>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
+            float scale, sig_max = out.sig_max[ci], sig_min = out.sig_min[ci];
+            if (!SILU) fq_token_sigs(out, ci, tok, gcur, sig_max, sig_min);  // (the SiLU.mul launches are never grouped)
+            if (flags & FQ_QUANT_F16) scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, sig_max, sig_min, flags);
+            else scale = fq_token_scale<0>(vmax, vmin, sig_max, sig_min, flags);
             const float inv = fq_fast_inv(scale);
             const f32x2 inv2 = {inv, inv};
             const bool magic = !(flags & FQ_QUANT_F16) && fq_magic_ok(vmax, vmin, inv);
@@ -711,6 +713,7 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
         rc = fq_launch_kron_wave(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }
+    if (out.rt_flags & FQ_GROUP128) return -1000;  // per-128-element scales exist in the wave kernel (N = 64) only
 #ifdef FQ_MEASURE
     if (const char* dbg = getenv("FQ_KRON_DBG")) flags |= atoi(dbg) & 0x7000;  // measurement: ablation bits of the fast kernel
 #endif
@@ -733,6 +736,7 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
         FQ_F(1, 2, 4, 4, 4) FQ_F(2, 2, 4, 4, FQ_GEN_OCC2) FQ_F(2, 3, 5, 4, FQ_GEN_OCC2)
 #undef FQ_F
     }
+    if (out.group_offsets != nullptr) return -1000;  // (the first-generation kernel below takes no group arrays)
 #define FQ_G(MT_, NT_)                                                                                   \
     if (MT == MT_ && NT == NT_)                                                                          \
         return launch_generic<MT_, NT_>(flags, x, ws, diag, rows, g, out, n_cu, stream);

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
     const int sw = swz<CPR>(c);  // rows 32 mt + c share their low bits with c
     bool first = true;
     int next_pulled = 0;
+    FqGroupCursor gcur;  // grouped launches: the clip pair follows the token's group
 
     while (slot < blk_cnt) {
         const int64_t tok = blk_base + slot;
@@ -219,14 +220,42 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
         vmin = fq_wave_min(vmin);
 
         for (int ci = 0; ci < out.n_clips; ++ci) {
-            const float scale = fq_token_scale<0>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
-            const float inv = fq_fast_inv(scale);
-            const f32x2 inv2 = {inv, inv};
-            const bool magic = fq_magic_ok(vmax, vmin, inv);
-            const bool clampq = fq_needs_clamp(vmax, vmin, inv);
-            if (lane == 0) out.scale[ci][tok] = (f16)scale;
+            float sig_max, sig_min;
+            fq_token_sigs(out, ci, tok, gcur, sig_max, sig_min);
+            const bool g128 = (NT == 2 && N == 64) && (out.rt_flags & FQ_GROUP128);  // (the launcher admits it for N = 64 only)
+            float scale = 0.0f, inv = 0.0f;
+            bool magic = true, clampq = false;
+            if (!g128) {
+                scale = fq_token_scale<0>(vmax, vmin, sig_max, sig_min, out.rt_flags);
+                inv = fq_fast_inv(scale);
+                magic = fq_magic_ok(vmax, vmin, inv);
+                clampq = fq_needs_clamp(vmax, vmin, inv);
+                if (lane == 0) out.scale[ci][tok] = (f16)scale;
+            }
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo) {
+                if (g128) {
+                    // one scale per 128 consecutive elements = output rows (2j, 2j+1): this lane's row 32 mo + c and its
+                    // neighbour's, both column halves (ActivationQuantizer(groupsize=128) reshapes to (-1, 128))
+                    float a = -INFINITY, b = INFINITY;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const f32x16& t = Y[nt][mo];
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            a = fq_max3(a, t[r], t[r + 1]);
+                            b = fq_min3(b, t[r], t[r + 1]);
+                        }
+                    }
+                    const float gmax = fq_group4_reduce(a, FqMaxOp()), gmin = fq_group4_reduce(b, FqMinOp());
+                    scale = fq_token_scale<0>(gmax, gmin, sig_max, sig_min, out.rt_flags);
+                    inv = fq_fast_inv(scale);
+                    magic = !__any(!fq_magic_ok(gmax, gmin, inv));    // wave-uniform route: the slowest any lane needs
+                    clampq = __any(fq_needs_clamp(gmax, gmin, inv)) != 0;
+                    if (h == 0 && !(c & 1) && (mo * 32 + c) < M)
+                        out.scale[ci][tok * (int64_t)(M * N / 128) + ((mo * 32 + c) >> 1)] = (f16)scale;
+                }
+                const f32x2 inv2 = {inv, inv};
                 uint32_t pw[NT * 2];  // dword nt*2 + w: elements n' = h*NT*16 + nt*16 + 8w .. +8 of row 32 mo + c
                 float dm[NT * 2];     // per dword: max |residual| of the magic-number rounding
 #pragma unroll
@@ -293,6 +322,7 @@ int fq_launch_kron_wave(int flags, const f16* x, const void* ws, const f16* diag
                         const FqQuantOut& out, int n_cu, hipStream_t stream) {
     if ((flags & FQ_CT_MASK) != FQ_OUT_PACKED || diag != nullptr) return -1000;
     if (M < 1 || M > 64 || (N & 15) || ((M * (N / 8)) & 63)) return -1000;
+    if ((out.rt_flags & FQ_GROUP128) && (N != 64 || (M & 1))) return -1000;  // groups = pairs of 64-element rows
     const int MT = (M + 31) / 32, KS1 = N / 16;
     const uint4* w = reinterpret_cast<const uint4*>(ws);
 #define FQ_W(MT_, NT_, KS1_, W_) \

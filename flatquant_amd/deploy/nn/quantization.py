@@ -2,15 +2,16 @@
 import torch
 
 from ... import ops
-from ..._lib import FQ_OUT_PACKED, FQ_QUANT_F16
+from ..._lib import FQ_OUT_PACKED, FQ_QUANT_F16, FQ_SIG_F16
 from .. import PackedQuantizedTensor
 
 
 class Quantizer(torch.nn.Module):
     """Per-token INT4 activation quantiser; passes an already packed input through.
     Reference: deploy/nn/quantization.py:5-36 (5-8 torch launches + the CUDA pack kernel) — here one HIP
-    launch reads each row once.  Arithmetic as the reference: fp32 statistics, scale rounded to fp16,
-    x / scale in fp16 (quant.cu:40), round-half-even, clamp, low nibble = even column."""
+    launch reads each row once.  Arithmetic as the reference: extrema of the fp16 data, extremum x sigmoid rounded to
+    fp16 (torch's promotion of fp16 tensor x 0-dim fp32 tensor), fp16 division by 7, x / scale in fp16 (quant.cu:40),
+    round-half-even, clamp, low nibble = even column."""
 
     def __init__(self, input_clip_ratio=1.0, lac=False):
         super().__init__()
@@ -31,6 +32,8 @@ class Quantizer(torch.nn.Module):
             from .. import sym_quant
             scales = (torch.max(torch.abs(x), dim=-1)[0].unsqueeze(1) / 7).to(torch.float16) * self.input_clip_ratio
             return PackedQuantizedTensor(sym_quant(x, scales), scales)
-        o = ops.rowquant(x.contiguous(), [sig], FQ_OUT_PACKED | FQ_QUANT_F16)
+        # lac: the reference multiplies the fp16 row extrema by a 0-dim fp32 sigmoid, which torch evaluates in fp16
+        # (deploy/nn/quantization.py:21-22) -> FQ_SIG_F16; pinned by tests/golden/quantizer_lac.npz
+        o = ops.rowquant(x.contiguous(), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | (FQ_SIG_F16 if self.lac else 0))
         lead = x.shape[:-1]
         return PackedQuantizedTensor(o.q[0], o.scale[0].reshape(*lead, 1) if len(lead) > 1 else o.scale[0].reshape(-1, 1))

@@ -13,8 +13,8 @@ class FlatQuantizedLinear(nn.Module):
     Same constructor (``args`` needs ``w_bits w_asym a_bits a_asym lac a_groupsize lwc``), same attribute /
     parameter names (``linear``, ``act_quantizer.clip_factor_a_{max,min}``, ``clip_factor_w_{max,min}``).
     Calibration (``_train_forward``: weight quantiser in the loop, flat_linear.py:45-67) is out of scope and
-    raises.  ``reparameterize`` (offline, weights only, fp64 — flat_linear.py:82-97) is kept in torch: it is
-    not on the hot path.
+    raises.  ``reparameterize`` (offline, weights only, fp64 — flat_linear.py:82-97) folds the transforms and the
+    learnable weight clipping into ``linear`` with plain torch ops: it is not on the hot path.
     """
 
     def __init__(self, args, linear: nn.Linear):
@@ -30,19 +30,7 @@ class FlatQuantizedLinear(nn.Module):
             init_value = 4.0
             self.clip_factor_w_max = nn.Parameter(torch.ones((lwc_dim, 1)) * init_value, requires_grad=True)
             self.clip_factor_w_min = nn.Parameter(torch.ones((lwc_dim, 1)) * init_value, requires_grad=True)
-            self.sigmoid = nn.Sigmoid()
         self._eval_mode = False
-
-    def apply_wclip(self, weight):
-        wmin, wmax = weight.min(1, keepdim=True)[0], weight.max(1, keepdim=True)[0]
-        wmax = wmax * self.sigmoid(self.clip_factor_w_max)
-        wmin = wmin * self.sigmoid(self.clip_factor_w_min)
-        return torch.clamp(weight, min=wmin, max=wmax)
-
-    def apply_trans(self, weight, qa_trans):
-        if isinstance(qa_trans, list):
-            return kronecker_matmul(weight, qa_trans[0].to(weight), qa_trans[1].to(weight))
-        return qa_trans(weight, inv_t=True)
 
     def _ori_forward(self, hidden_states):
         return self.linear(hidden_states)
@@ -63,16 +51,35 @@ class FlatQuantizedLinear(nn.Module):
 
     @torch.no_grad()
     def reparameterize(self, qa_trans=None, out_trans=None):
-        weight = self.linear.weight.data
-        ori_dtype = weight.dtype
-        weight = weight.to(torch.float64)
-        if qa_trans is not None:
-            weight = self.apply_trans(weight, qa_trans)
+        """Fold the offline pieces into ``linear`` and switch to the inference forward (flat_linear.py:82-97: the
+        input-side transform acts on the weight's input axis with the inverse-transpose, learnable weight clipping
+        narrows every output row, ``out_trans`` rotates the output axis and the bias). Done once, in float64, off
+        the hot path."""
+        lin = self.linear
+        w = _fold_input_transform(lin.weight.data.double(), qa_trans)
         if self.lwc:
-            weight = self.apply_wclip(weight)
+            w = _clip_rows(w, torch.sigmoid(self.clip_factor_w_max), torch.sigmoid(self.clip_factor_w_min))
         if out_trans is not None:
-            weight = out_trans(weight.T).T
-        if out_trans is not None and self.linear.bias is not None:
-            self.linear.bias.data = out_trans(self.linear.bias.data)
-        self.linear.weight.data = weight.to(ori_dtype)
+            w = out_trans(w.t()).t()
+            if lin.bias is not None:
+                lin.bias.data = out_trans(lin.bias.data)
+        lin.weight.data = w.to(lin.weight.dtype)
         self._eval_mode = True
+
+
+def _fold_input_transform(w64: torch.Tensor, qa_trans) -> torch.Tensor:
+    """W <- W . T^{-T} along the input axis. A ``[left, right]`` pair is already the inverse-transposed Kronecker
+    factors (the q/k/v and up/gate layers share them, llama_utils.py:85-110); a transform module is asked for them."""
+    if qa_trans is None:
+        return w64
+    if isinstance(qa_trans, (list, tuple)):
+        left, right = qa_trans
+        return kronecker_matmul(w64, left.to(w64), right.to(w64))
+    return qa_trans(w64, inv_t=True)
+
+
+def _clip_rows(w: torch.Tensor, keep_max: torch.Tensor, keep_min: torch.Tensor) -> torch.Tensor:
+    """Learnable weight clipping: every output row is clamped to [min * keep_min, max * keep_max] ([out, 1] factors)."""
+    hi = w.amax(dim=1, keepdim=True) * keep_max.to(w)
+    lo = w.amin(dim=1, keepdim=True) * keep_min.to(w)
+    return torch.maximum(torch.minimum(w, hi), lo)

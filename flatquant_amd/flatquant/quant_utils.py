@@ -31,8 +31,11 @@ class ActivationQuantizer(torch.nn.Module):
         self.q_max, self.q_min = get_qmin_qmax(bits, sym)
         self.sym = sym
         self.groupsize = groupsize
-        if self.groupsize > 0:
-            raise NotImplementedError("Not support per-group quantization for activation yet.")
+        # groupsize > 0: flatquant/quant_utils.py:59-60 raises; the vLLM copy of the class
+        # (vllm_custom/model_executor/layers/quantization/utils/fake_quant_utils.py:72-78) and the DeepSeek flow
+        # (--a_groupsize, main_dpskv3.py:512) reshape to (-1, groupsize) first — that behaviour is provided here.
+        if self.groupsize not in (-1, 0) and self.groupsize < 8:
+            raise NotImplementedError("activation groups of fewer than 8 elements are not supported")
         self.lac = lac
         self._clip_ratio = clip_ratio
         if self.lac:
@@ -59,4 +62,8 @@ class ActivationQuantizer(torch.nn.Module):
         if self.bits != 4 or not self.sym:
             raise NotImplementedError("flatquant_amd: only 4-bit symmetric activation quantisation is on the hot path")
         flags = FQ_OUT_FAKEQUANT | (0 if self.lac else FQ_QUANT_F16)
+        if self.groupsize > 0:
+            if x.shape[-1] % self.groupsize:
+                raise ValueError(f"last dimension {x.shape[-1]} is not a multiple of groupsize {self.groupsize}")
+            return ops.rowquant(x.contiguous().reshape(-1, self.groupsize), [self._sig()], flags).fq[0].reshape(x.shape)
         return ops.rowquant(x.contiguous(), [self._sig()], flags).fq[0]

@@ -15,6 +15,25 @@ from .flat_utils import kronecker_matmul
 from .function_utils import get_init_weight, get_inverse
 
 
+class _Fp16Cache:
+    """fp16 device copies of a module's (usually fp32) matrices, made once per (parameter storage, version, device):
+    the kernels' fragment workspaces are keyed by the address and version of the matrices they were packed from, so
+    handing them a fresh .to(fp16) copy on every call would re-pack on every call (and pin every copy in that cache)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, p: torch.Tensor, device) -> torch.Tensor:
+        key = (p.data_ptr(), p._version, str(device))
+        hit = self._c.get(key)
+        if hit is None:
+            if len(self._c) > 16:
+                self._c.clear()
+            hit = p.detach().to(device=device, dtype=torch.float16).contiguous()
+            self._c[key] = hit
+        return hit
+
+
 class _DecomposeTransBase(nn.Module):
     """Shared eval-mode behaviour of {SVD,Inv}DecomposeTransMatrix (trans_utils.py:85-116, :190-213)."""
 
@@ -33,6 +52,7 @@ class _DecomposeTransBase(nn.Module):
                 diag_init_para = torch.ones(left_size * right_size, dtype=diag_dtype or torch.get_default_dtype())
             self.diag_scale = nn.Parameter(diag_init_para, requires_grad=False)
         self._eval_mode = True
+        self._f16 = _Fp16Cache()
 
     def to_eval_mode(self):
         self._eval_mode = True
@@ -49,8 +69,7 @@ class _DecomposeTransBase(nn.Module):
                     inp = inp / d
                 else:
                     diag = d.contiguous()
-            l16 = left.to(device=inp.device, dtype=torch.float16).contiguous()
-            r16 = right.to(device=inp.device, dtype=torch.float16).contiguous()
+            l16, r16 = self._f16.get(left, inp.device), self._f16.get(right, inp.device)
             return ops.kron_quant(inp.contiguous(), l16, r16, flags=FQ_OUT_TRANSFORM, diag=diag).y
         if use_diag:
             inp = inp / self.diag_scale.to(inp) if inv_t else inp * self.diag_scale.to(inp)
@@ -81,6 +100,7 @@ class _SingleTransBase(nn.Module):
         self.matrix = nn.Parameter(m, requires_grad=False)
         self.matrix_inv_t = nn.Parameter(get_inverse(m).T.contiguous(), requires_grad=False)
         self._eval_mode = True
+        self._f16 = _Fp16Cache()
 
     def to_eval_mode(self):
         self._eval_mode = True
@@ -90,10 +110,19 @@ class _SingleTransBase(nn.Module):
 
     def forward(self, inp, inv_t=False):
         init_shape = inp.shape
+        n = self.matrix.shape[0]
+        rows = inp.numel() // n
+        if inp.dtype == torch.float16 and inp.is_cuda and n in (32, 64):
+            # the activation path (llama_utils.py:275-277: attn_output [.., head_dim, num_heads] over the heads axis):
+            # the block-transform kernel with the natural (non-transposed) fp16 output = inp.reshape(-1, n) @ matrix,
+            # R rows of n per launch unit (any R the kernel has that divides the row count)
+            for R in (128, 96, 64, 32):
+                if rows % R == 0:
+                    m16 = self._f16.get(self.get_matrix(inv_t=inv_t), inp.device)
+                    return ops.block_quant(inp.reshape(-1, R, n).contiguous(), m16, flags=FQ_OUT_TRANSFORM,
+                                           transpose_out=False).y.reshape(init_shape)
+        # everything else (the offline fp64 weight-side use in reparameterize, odd sizes): the reference's own op
         matrix = self.get_matrix(inv_t=inv_t).to(inp)
-        n = matrix.shape[0]
-        # a plain [rows, n] x [n, n] library GEMM (rocBLAS through torch), exactly trans_utils.py:21-25; the
-        # fused, quantising form of this transform on the o_proj input is ops.block_quant.
         return inp.reshape(-1, n).matmul(matrix).reshape(init_shape)
 
     def __repr__(self):

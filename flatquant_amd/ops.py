@@ -14,8 +14,8 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (FQ_MAX_CLIPS, FQ_NO_CLAMP0, FQ_OUT_FAKEQUANT, FQ_OUT_PACKED, FQ_OUT_TRANSFORM,
-                   FQ_QUANT_F16, FQ_ROUND_Y_F16, FQ_WS_PREPARED, check, lib)
+from ._lib import (FQ_EUNSUPPORTED, FQ_GROUP128, FQ_MAX_CLIPS, FQ_NO_CLAMP0, FQ_OUT_FAKEQUANT, FQ_OUT_PACKED,
+                   FQ_OUT_TRANSFORM, FQ_QUANT_F16, FQ_ROUND_Y_F16, FQ_WS_PREPARED, check, lib)
 
 Sig = Tuple[float, float]  # (sigmoid(clip_factor_a_max), sigmoid(clip_factor_a_min)); (1.0, 1.0) = no clip
 
@@ -144,9 +144,29 @@ def _kron_workspace_commit(key, ws: torch.Tensor, left: torch.Tensor, right: tor
         _WS_LRU.popitem(last=False)
 
 
+def _group_scales_shape(o: FusedOutputs, lead, groups_per_row: int) -> None:
+    o.scale = [sc.reshape(lead + (groups_per_row,)) for sc in o.scale]
+
+
+def _quant_groups_of(y: torch.Tensor, sigs: Sequence[Sig], flags: int, groupsize: int, o: FusedOutputs) -> FusedOutputs:
+    """groupsize-element groups of an already transformed fp16 activation: the reference's own formulation,
+    ``x.reshape(-1, groupsize)`` then the per-row quantiser (vllm_custom/.../fake_quant_utils.py:72-78)."""
+    d = y.shape[-1]
+    r = rowquant(y.reshape(-1, groupsize), sigs, flags & ~FQ_OUT_TRANSFORM)
+    o.q = [q.reshape(y.shape[:-1] + (d // 2,)) for q in r.q]
+    o.scale = [sc.reshape(y.shape[:-1] + (d // groupsize,)) for sc in r.scale]
+    o.fq = [f.reshape(y.shape) for f in r.fq]
+    return o
+
+
 def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),),
-               flags: int = FQ_OUT_PACKED, diag: Optional[torch.Tensor] = None) -> FusedOutputs:
-    """y = x @ kron(left, right) fused with per-token INT4 quantisation (fq_kron_quant_f16)."""
+               flags: int = FQ_OUT_PACKED, diag: Optional[torch.Tensor] = None, groupsize: int = -1) -> FusedOutputs:
+    """y = x @ kron(left, right) fused with per-token INT4 quantisation (fq_kron_quant_f16).
+
+    groupsize = 128: one scale per 128 consecutive elements of the transformed token instead of one per token
+    (ActivationQuantizer(groupsize=128)); scales come back as [..., d/128]. One launch (FQ_GROUP128) where the library
+    fuses it (packed output, N = 64), otherwise the transform launch followed by the row quantiser over the
+    (-1, 128) view of its fp16 result — the reference's own order of operations."""
     _chk(x, "x"), _chk(left, "left"), _chk(right, "right")
     M, N = left.shape[0], right.shape[0]
     if left.shape != (M, M) or right.shape != (N, N):
@@ -158,9 +178,19 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
         _chk(diag, "diag")
         if diag.numel() != d:
             raise ValueError("diag must have M*N elements")
+    if groupsize not in (-1, 128) or (groupsize == 128 and d % 128):
+        raise ValueError("groupsize must be -1 (per token) or 128 with M*N % 128 == 0")
     rows = x.numel() // d
     smax, smin, n = _sig_arrays(sigs)
-    o = _alloc_outputs(x, rows, d, n, flags, x.shape[:-1] + (d // 2,), x.shape)
+    fused_g = groupsize == 128 and (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_QUANT_F16)) == FQ_OUT_PACKED \
+        and n == 1 and N == 64 and M % 2 == 0 and diag is None
+    if groupsize == 128 and not fused_g:
+        o = kron_quant(x, left, right, flags=FQ_OUT_TRANSFORM | (flags & FQ_WS_PREPARED), diag=diag)
+        return _quant_groups_of(o.y, sigs, flags, 128, o) if flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT) else o
+    o = _alloc_outputs(x, rows * (d // 128 if fused_g else 1), d, n, flags, x.shape[:-1] + (d // 2,), x.shape)
+    if fused_g:
+        _group_scales_shape(o, x.shape[:-1], d // 128)
+        flags |= FQ_GROUP128
     if rows == 0:
         return o
     with torch.cuda.device(x.device):
@@ -168,6 +198,80 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
         check(lib.fq_kron_quant_f16(_ptr(x), _ptr(left), _ptr(right), _ptr(diag), rows, M, N, smax, smin, n,
                                     flags | (FQ_WS_PREPARED if prepared else 0), _ptr_array(o.q), _ptr_array(o.scale),
                                     _ptr_array(o.fq), _ptr(o.y), _ptr(ws), ws_bytes, _stream(x)))
+        if key is not None and not prepared:
+            _kron_workspace_commit(key, ws, left, right)
+    return o
+
+
+def moe_group_rows(indices: torch.Tensor, n_groups: int):
+    """(token, slot) pairs of a top-k routing table sorted by expert — the device-side form of the reference's
+    ``counts = torch.bincount(indices.flatten(), minlength=E)`` + ``idx, top = torch.where(indices == i)`` loop
+    (flatquant/model_tools/deepseekv3_utils.py:434-439), without the host round trip of ``.tolist()``.
+    indices [T, k] integer -> (token_idx [T*k] int64: source row of every grouped row, in expert order and, inside an
+    expert, in token order like torch.where; group_offsets [n_groups + 1] int64). Plumbing only (torch sort/bincount)."""
+    flat = indices.reshape(-1).to(torch.int64)
+    order = torch.sort(flat, stable=True).indices                   # stable: token order inside an expert
+    counts = torch.bincount(flat, minlength=n_groups)
+    offsets = torch.zeros(n_groups + 1, dtype=torch.int64, device=indices.device)
+    offsets[1:] = torch.cumsum(counts, 0)
+    return order // indices.shape[-1], offsets
+
+
+def kron_quant_grouped(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, group_offsets: torch.Tensor,
+                       sig_max_g: torch.Tensor, sig_min_g: torch.Tensor, flags: int = FQ_OUT_PACKED,
+                       groupsize: int = -1) -> FusedOutputs:
+    """Grouped (per-expert) transform + quantisation (fq_kron_quant_grouped_f16): x [rows, d] sorted by group, group g
+    owns rows [group_offsets[g], group_offsets[g+1]) and quantises with sigmoid factors (sig_max_g[g], sig_min_g[g])
+    (fp32 device tensors; the reference shares ONE quantiser across the routed experts: expand it). One launch, nothing
+    read back, when left / right are 2-D (shared transform: deepseekv3_utils.py:470). 3-D left / right [G, M, M] /
+    [G, N, N] are the reference's ``routed_w2_trans[i]`` branch (:446): one launch per non-empty group, with the
+    group sizes read back to the host exactly like the reference's ``counts ... .tolist()``."""
+    _chk(x, "x"), _chk(left, "left"), _chk(right, "right")
+    _chk(group_offsets, "group_offsets", torch.int64)
+    _chk(sig_max_g, "sig_max_g", torch.float32), _chk(sig_min_g, "sig_min_g", torch.float32)
+    G = group_offsets.numel() - 1
+    if G < 1 or sig_max_g.numel() != G or sig_min_g.numel() != G:
+        raise ValueError("group_offsets must have n_groups + 1 entries and sig_*_g n_groups")
+    M, N = left.shape[-1], right.shape[-1]
+    d = M * N
+    if x.dim() != 2 or x.shape[1] != d:
+        raise ValueError(f"x must be [rows, {M}*{N}]")
+    if groupsize not in (-1, 128) or (groupsize == 128 and d % 128):
+        raise ValueError("groupsize must be -1 (per token) or 128 with M*N % 128 == 0")
+    rows = x.shape[0]
+    if left.dim() == 3 or right.dim() == 3:                        # one transform per expert
+        if left.shape[0] != G or right.shape[0] != G or left.dim() != 3 or right.dim() != 3:
+            raise ValueError("per-group matrices must be [n_groups, M, M] and [n_groups, N, N]")
+        offs = group_offsets.tolist()
+        smax, smin = sig_max_g.tolist(), sig_min_g.tolist()
+        o = _alloc_outputs(x, rows * (d // groupsize if groupsize > 0 else 1), d, 1, flags, (rows, d // 2), x.shape)
+        if groupsize > 0:
+            _group_scales_shape(o, (rows,), d // groupsize)
+        for g in range(G):
+            a, b = offs[g], offs[g + 1]
+            if b > a:
+                part = kron_quant(x[a:b], left[g], right[g], [(smax[g], smin[g])], flags, groupsize=groupsize)
+                for dst, src in ((o.q, part.q), (o.scale, part.scale), (o.fq, part.fq)):
+                    if dst:
+                        dst[0][a:b] = src[0]
+                if o.y is not None:
+                    o.y[a:b] = part.y
+        return o
+    fused_g = groupsize == 128 and (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) == FQ_OUT_PACKED and N == 64 and M % 2 == 0
+    if groupsize == 128 and not fused_g:
+        raise _lib.FqError(FQ_EUNSUPPORTED, "grouped launch with 128-element scales is fused for packed output and N = 64 only")
+    o = _alloc_outputs(x, rows * (d // 128 if fused_g else 1), d, 1, flags, (rows, d // 2), x.shape)
+    if fused_g:
+        _group_scales_shape(o, (rows,), d // 128)
+        flags |= FQ_GROUP128
+    if rows == 0:
+        return o
+    with torch.cuda.device(x.device):
+        ws, ws_bytes, prepared, key = _kron_workspace(x.device, M, N, left, right)
+        check(lib.fq_kron_quant_grouped_f16(
+            _ptr(x), _ptr(left), _ptr(right), rows, M, N, _ptr(group_offsets), G, _ptr(sig_max_g), _ptr(sig_min_g),
+            flags | (FQ_WS_PREPARED if prepared else 0), _ptr(o.q[0] if o.q else None), _ptr(o.scale[0] if o.scale else None),
+            _ptr(o.fq[0] if o.fq else None), _ptr(o.y), _ptr(ws), ws_bytes, _stream(x)))
         if key is not None and not prepared:
             _kron_workspace_commit(key, ws, left, right)
     return o

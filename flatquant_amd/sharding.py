@@ -25,17 +25,27 @@ def broadcast_matrices(mats: Dict[str, torch.Tensor], src: int = 0, group=None) 
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return mats
     keys = sorted(mats)
-    flat = torch.cat([mats[k].reshape(-1).view(torch.uint8) for k in keys]) if keys else None
-    if flat is not None:
-        dist.broadcast(flat, src=src, group=group)
-        off = 0
-        out = {}
-        for k in keys:
-            nbytes = mats[k].numel() * mats[k].element_size()
-            out[k] = flat[off:off + nbytes].view(mats[k].dtype).reshape(mats[k].shape).clone()
-            off += nbytes
-        return out
-    return mats
+    if not keys:
+        return mats
+    # every tensor starts on a 16-byte boundary of the flat buffer: an odd-length fp16 tensor followed by an fp32 one
+    # would otherwise leave the second at a 2-byte offset, which .view(dtype) rejects
+    ALIGN = 16
+    dev = mats[keys[0]].device
+    offs, total = {}, 0
+    for k in keys:
+        offs[k] = total
+        nbytes = mats[k].numel() * mats[k].element_size()
+        total += (nbytes + ALIGN - 1) // ALIGN * ALIGN
+    flat = torch.zeros(total, dtype=torch.uint8, device=dev)
+    for k in keys:
+        src_bytes = mats[k].contiguous().reshape(-1).view(torch.uint8)
+        flat[offs[k]:offs[k] + src_bytes.numel()] = src_bytes
+    dist.broadcast(flat, src=src, group=group)
+    out = {}
+    for k in keys:
+        nbytes = mats[k].numel() * mats[k].element_size()
+        out[k] = flat[offs[k]:offs[k] + nbytes].view(mats[k].dtype).reshape(mats[k].shape).clone()
+    return out
 
 
 def gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:

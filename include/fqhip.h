@@ -13,6 +13,8 @@
  *   fq_kron_quant_f16      deploy/kernels/kron_matmul.py:192-266 (kron_matmul) +
  *                          flatquant/flat_utils.py:6-17 (kronecker_matmul) +
  *                          flatquant/quant_utils.py:71-119 (ActivationQuantizer)
+ *   fq_kron_quant_grouped_f16   flatquant/model_tools/deepseekv3_utils.py:427-452 (FlatQuantMoE.forward: rows grouped per
+ *                          expert, one transform, per-expert activation quantisers) + :365-390 (_trans_forward)
  *   fq_rmsnorm_f16, fq_rmsnorm_kron_quant_f16   deploy/nn/normalization.py:4-23 (RMSNorm), alone / fused in front
  *   fq_silu_mul_f16, fq_silu_mul_kron_quant_f16, fq_silu_mul_hadamard_quant_f16
  *                          deploy/transformers/modeling_llama.py:277-279 (x_up * act_fn(x_gate) -> down_proj), alone / fused
@@ -64,6 +66,19 @@ extern "C" {
 
 #define FQ_IN_SILU_MUL    0x100 /* fq_silu_mul_* entry points only (set by them): x = fp16(up * fp16(silu(gate))) */
 
+#define FQ_GROUP128       0x200 /* one scale per 128 CONSECUTIVE elements of the transformed token instead of one per
+                                   token: ActivationQuantizer(groupsize=128) reshapes to (-1, groupsize) before it takes
+                                   the extrema (vllm_custom/model_executor/layers/quantization/utils/fake_quant_utils.py:
+                                   72-78); deepseek_v3/kernel.py:10-30 uses the same 128-element blocks. scale_out is then
+                                   [rows, M*N/128]. Fused for packed output with N = 64 (rows pairs are the groups);
+                                   FQ_EUNSUPPORTED otherwise: write FQ_OUT_TRANSFORM and run fq_rowquant_f16 with
+                                   cols = 128 over the reshaped buffer (what flatquant_amd.ops does) */
+
+#define FQ_SIG_F16        0x400 /* with FQ_QUANT_F16: extremum x sigmoid is rounded to fp16 before the division by 7 — what
+                                   deploy/nn/quantization.py:21-22 evaluates (an fp16 [rows,1] tensor times a 0-dim fp32
+                                   tensor gives an fp16 tensor under torch's type promotion; the (1,)-shaped parameters of
+                                   flatquant/quant_utils.py:96-97 promote the product, scale and quotient to fp32 instead) */
+
 #define FQ_MAX_CLIPS 4
 
 /*
@@ -91,6 +106,26 @@ int fq_kron_quant_f16(const void* x, const void* left, const void* right, const 
                       const float* sig_max, const float* sig_min, int n_clips, int flags,
                       void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * Grouped (per-expert) form of fq_kron_quant_f16: the routed experts of a MoE layer
+ * (flatquant/model_tools/deepseekv3_utils.py:427-452: `idx, top = torch.where(indices == i)`, `expert(x[idx], ...)`; the
+ * rows of one expert are contiguous once the (token, expert) pairs are sorted by expert). All groups share the
+ * transform (`routed_w2_trans`, deepseekv3_utils.py:470; the reference hard-codes independent_w2_trans = False) and each
+ * group quantises with its own clip pair (one ActivationQuantizer per expert is what the expert module owns,
+ * deepseekv3_utils.py:369-371; the reference shares one across the routed experts: pass n_groups equal pairs).
+ *   x              [rows, M*N] fp16, rows sorted by group
+ *   group_offsets  DEVICE int64 [n_groups + 1], non-decreasing, [0] = 0, [n_groups] = rows; empty groups allowed
+ *   sig_max_g / sig_min_g   DEVICE float [n_groups] = sigmoid(clip_factor_a_max/min) of each group
+ *   q_out [rows, M*N/2] u8, scale_out [rows] fp16 ([rows, M*N/128] with FQ_GROUP128), fq_out / y_out [rows, M*N] fp16,
+ *   selected by flags as in fq_kron_quant_f16 (one clip set). Nothing is read back to the host: no synchronisation.
+ * Shapes: the pairs the fused MFMA kernels cover (fq_kron_workspace_bytes(M, N) >= 0 and not the plain-FMA fallback);
+ * FQ_EUNSUPPORTED otherwise. workspace / FQ_WS_PREPARED as in fq_kron_quant_f16.
+ */
+int fq_kron_quant_grouped_f16(const void* x, const void* left, const void* right, int64_t rows, int M, int N,
+                              const int64_t* group_offsets, int n_groups, const float* sig_max_g, const float* sig_min_g,
+                              int flags, void* q_out, void* scale_out, void* fq_out, void* y_out,
+                              void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * deploy.nn.RMSNorm (deploy/nn/normalization.py:16-23; the weight is folded into the next layer) in front of the

@@ -142,7 +142,7 @@ def single_transform(x16, P16, groups=None):
 # --------------------------------------------------------------------------------------------------
 # per-token symmetric INT4 quantisation
 # --------------------------------------------------------------------------------------------------
-def token_scale(y32, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False):
+def token_scale(y32, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False, sig_f16=False):
     """y32 [T, d] fp32 -> scale fp32 [T].
 
     quant_utils.py:88-107 (clamp to 0, lac sigmoid factors, m = max(|xmin|, xmax), scale = m/q_max,
@@ -156,8 +156,15 @@ def token_scale(y32, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False):
     if clamp0:
         xmax = np.maximum(xmax, F32(0))
         xmin = np.minimum(xmin, F32(0))
-    xmax = (xmax * F32(sig_max)).astype(F32)
-    xmin = (xmin * F32(sig_min)).astype(F32)
+    if sig_f16:
+        # deploy/nn/quantization.py:21-22: fp16 [rows, 1] extrema times a 0-dim fp32 sigmoid tensor -> torch's result is
+        # fp16: the product is formed in fp32 (the sigmoid keeps its fp32 value) and rounded to fp16 (checked against the
+        # reference module: tests/golden/quantizer_lac.npz)
+        xmax = (xmax * F32(sig_max)).astype(F32).astype(F16).astype(F32)
+        xmin = (xmin * F32(sig_min)).astype(F32).astype(F16).astype(F32)
+    else:
+        xmax = (xmax * F32(sig_max)).astype(F32)
+        xmin = (xmin * F32(sig_min)).astype(F32)
     m = np.maximum(np.abs(xmin), xmax).astype(F32)
     with np.errstate(divide="ignore", invalid="ignore"):
         scale = (m / F32(7.0)).astype(F32)
@@ -189,35 +196,80 @@ def dequantize(q, scale, quant_f16=False):
     return (s * q.astype(F32)).astype(F16)
 
 
-def quant_outputs(y32, sig_max=1.0, sig_min=1.0, round_y_f16=False, clamp0=True, quant_f16=False):
-    """Everything the fused kernels can emit for one clip set, from the fp32 transformed activation."""
+def quant_outputs(y32, sig_max=1.0, sig_min=1.0, round_y_f16=False, clamp0=True, quant_f16=False, groupsize=-1,
+                  sig_f16=False):
+    """Everything the fused kernels can emit for one clip set, from the fp32 transformed activation.
+
+    groupsize > 0: ``ActivationQuantizer(groupsize=g)`` of vllm_custom/model_executor/layers/quantization/utils/
+    fake_quant_utils.py:72-78 — ``x.reshape(-1, groupsize)`` before the extrema, i.e. one scale per `groupsize`
+    consecutive elements of a token; "scale" is then [T, d / groupsize] (deepseek_v3/kernel.py:10-30 uses the same
+    128-element blocks)."""
     y32 = np.asarray(y32, dtype=F32)
     T = y32.shape[0]
     y = y32.reshape(T, -1)
+    d = y.shape[1]
     y16 = y.astype(F16)
     if round_y_f16:
         y = y16.astype(F32)
-    scale = token_scale(y, sig_max, sig_min, clamp0, quant_f16)
-    q = quantize(y, scale, quant_f16)
+    if groupsize > 0:
+        assert d % groupsize == 0
+        yg = y.reshape(T * (d // groupsize), groupsize)
+        scale = token_scale(yg, sig_max, sig_min, clamp0, quant_f16, sig_f16)
+        q = quantize(yg, scale, quant_f16).reshape(T, d)
+        fq = dequantize(q.reshape(yg.shape), scale, quant_f16).reshape(T, d)
+        scale = scale.reshape(T, d // groupsize)
+    else:
+        scale = token_scale(y, sig_max, sig_min, clamp0, quant_f16, sig_f16)
+        q = quantize(y, scale, quant_f16)
+        fq = dequantize(q, scale, quant_f16)
     return {
         "y16": y16,
         "scale": scale,
         "scale16": scale.astype(F16),
         "q": q,
         "packed": pack_i4(q),
-        "fq": dequantize(q, scale, quant_f16),
+        "fq": fq,
     }
 
 
 def kron_quant(x16, left16, right16, sig_max=1.0, sig_min=1.0, diag16=None, round_y_f16=False,
-               clamp0=True, quant_f16=False, groups1=None, groups2=None, left_first=False):
+               clamp0=True, quant_f16=False, groups1=None, groups2=None, left_first=False, groupsize=-1):
     y = kron_transform(x16, left16, right16, diag16, groups1, groups2, left_first)
-    return quant_outputs(y, sig_max, sig_min, round_y_f16, clamp0, quant_f16)
+    return quant_outputs(y, sig_max, sig_min, round_y_f16, clamp0, quant_f16, groupsize)
 
 
-def rowquant(x16, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False):
+def kron_quant_grouped(x16, left16, right16, group_offsets, sig_max_g, sig_min_g, round_y_f16=False, clamp0=True,
+                       groupsize=-1):
+    """The routed experts of flatquant/model_tools/deepseekv3_utils.py:427-452: rows sorted by expert, expert i owns
+    rows [group_offsets[i], group_offsets[i+1]) (``idx, top = torch.where(indices == i)``; ``expert(x[idx], ...)``),
+    every expert transforms with its matrices and quantises with its own clip pair. left16 / right16: one shared pair
+    ([M, M], [N, N]: ``routed_w2_trans`` at :470, independent_w2_trans = False) or one pair per expert ([G, M, M],
+    [G, N, N]: the ``routed_w2_trans[i]`` branch, :446). Returns the same dict as kron_quant over all rows."""
     x16 = np.asarray(x16, dtype=F16)
-    return quant_outputs(x16.astype(F32).reshape(x16.shape[0], -1), sig_max, sig_min, False, clamp0, quant_f16)
+    left16, right16 = np.asarray(left16, dtype=F16), np.asarray(right16, dtype=F16)
+    offs = [int(v) for v in group_offsets]
+    parts = []
+    for g in range(len(offs) - 1):
+        a, b = offs[g], offs[g + 1]
+        if b == a:
+            continue
+        L = left16[g] if left16.ndim == 3 else left16
+        R = right16[g] if right16.ndim == 3 else right16
+        parts.append(kron_quant(x16[a:b], L, R, float(sig_max_g[g]), float(sig_min_g[g]), None, round_y_f16, clamp0,
+                                False, groupsize=groupsize))
+    if not parts:                                              # no rows at all: the empty result, shapes intact
+        d = left16.shape[-1] * right16.shape[-1]
+        ns = d // groupsize if groupsize > 0 else None
+        return {"y16": np.zeros((0, d), F16), "scale": np.zeros((0, ns) if ns else (0,), F32),
+                "scale16": np.zeros((0, ns) if ns else (0,), F16), "q": np.zeros((0, d), np.int8),
+                "packed": np.zeros((0, d // 2), np.uint8), "fq": np.zeros((0, d), F16)}
+    return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
+
+
+def rowquant(x16, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False, sig_f16=False):
+    x16 = np.asarray(x16, dtype=F16)
+    return quant_outputs(x16.astype(F32).reshape(x16.shape[0], -1), sig_max, sig_min, False, clamp0, quant_f16,
+                         sig_f16=sig_f16)
 
 
 def block_quant(x16, P16, sig_max=1.0, sig_min=1.0, transpose_out=True, round_y_f16=False, clamp0=False,

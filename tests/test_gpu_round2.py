@@ -1,0 +1,266 @@
+"""GPU parity, round 2: grouped (per-expert) launches and 128-element scales (BASELINE config 5), the module-level
+contracts of SURVEY 8c (FlatQuantizedLinear._eval_forward, {Inv,SVD}DecomposeTransMatrix.forward incl. inv_t / diag,
+SVDSingleTransMatrix.forward on the HIP path), deploy.nn.Quantizer(lac=True), row shards through the kernel."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fq_oracle as O
+
+pytestmark = pytest.mark.gpu
+P, F, T, R16, NC0, Q16 = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from flatquant_amd import ops as _ops
+    return _ops
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+# ------------------------------------------------------------------------------------------------- grouped launches
+def _groups(rng, rows, n_groups, empties=True):
+    cuts = np.sort(rng.integers(0, rows + 1, size=n_groups - 1))
+    offs = np.concatenate([[0], cuts, [rows]]).astype(np.int64)
+    if empties and n_groups >= 4:
+        offs[1] = offs[0]                      # group 0 empty
+        offs[-2] = offs[-1]                    # last group empty
+    return offs
+
+
+@pytest.mark.parametrize("shape,rows,n_groups", [((32, 64), 333, 9), ((64, 112), 61, 5), ((64, 64), 200, 7),
+                                                  ((56, 64), 40, 4), ((64, 128), 30, 3), ((32, 64), 4100, 256)])
+def test_grouped_quant_stage_bit_exact_and_transform_shared(ops, shape, rows, n_groups):
+    """Per-group clip pairs: packed and fake-quant outputs of the grouped launch equal the oracle's quantiser applied,
+    group by group, to the transform the SAME launch returns; the transform equals the ungrouped launch's bit for bit."""
+    M, N = shape
+    rng = np.random.default_rng(rows)
+    x = (rng.standard_normal((rows, M * N)) * (1 + 5 * (rng.random((rows, 1)) < 0.1))).astype(np.float16)
+    L = (rng.standard_normal((M, M)) / np.sqrt(M)).astype(np.float16)
+    R = (rng.standard_normal((N, N)) / np.sqrt(N)).astype(np.float16)
+    offs = _groups(rng, rows, n_groups)
+    smax = rng.uniform(0.3, 1.0, n_groups).astype(np.float32)
+    smin = rng.uniform(0.3, 1.0, n_groups).astype(np.float32)
+    smax[n_groups // 2] = 0.05                                           # one group clips hard: the clamp route
+    xd, Ld, Rd = dev(x), dev(L), dev(R)
+    y_plain = host(ops.kron_quant(xd, Ld, Rd, flags=T).y)
+    for fl in (P | T | R16, F | T | R16):
+        o = ops.kron_quant_grouped(xd, Ld, Rd, dev(offs), dev(smax), dev(smin), fl)
+        y16 = host(o.y)
+        assert np.array_equal(y16, y_plain)
+        for gi in range(n_groups):
+            a, b = int(offs[gi]), int(offs[gi + 1])
+            if a == b:
+                continue
+            ref = O.quant_outputs(y16[a:b].astype(np.float32), float(smax[gi]), float(smin[gi]))
+            if fl & P:
+                assert np.array_equal(host(o.q[0])[a:b], ref["packed"]), (gi, a, b)
+                assert np.array_equal(host(o.scale[0])[a:b], ref["scale16"])
+            else:
+                assert np.array_equal(host(o.fq[0])[a:b], ref["fq"]), (gi, a, b)
+    # packed-only launch (its own kernels: one wave per token): same bytes as the packed + transform launch
+    o1 = ops.kron_quant_grouped(xd, Ld, Rd, dev(offs), dev(smax), dev(smin), P | R16)
+    o2 = ops.kron_quant_grouped(xd, Ld, Rd, dev(offs), dev(smax), dev(smin), P | T | R16)
+    assert torch.equal(o1.q[0], o2.q[0]) and torch.equal(o1.scale[0], o2.scale[0])
+
+
+def test_grouped_edge_cases(ops):
+    rng = np.random.default_rng(7)
+    x = dev(rng.standard_normal((6, 2048)).astype(np.float16))
+    L, R = dev((rng.standard_normal((32, 32)) / 6).astype(np.float16)), dev((rng.standard_normal((64, 64)) / 8).astype(np.float16))
+    one = ops.kron_quant(x, L, R, [(0.9, 0.8)], P)
+    # empty groups everywhere, one single-row group, all groups with the same pair == the ungrouped launch
+    offs = dev(np.array([0, 0, 1, 1, 6, 6, 6], dtype=np.int64))
+    sm, sn = dev(np.full(6, 0.9, np.float32)), dev(np.full(6, 0.8, np.float32))
+    o = ops.kron_quant_grouped(x, L, R, offs, sm, sn, P)
+    assert torch.equal(o.q[0], one.q[0]) and torch.equal(o.scale[0], one.scale[0])
+    # no rows at all
+    e = ops.kron_quant_grouped(x[:0], L, R, dev(np.array([0, 0], dtype=np.int64)), sm[:1], sn[:1], P)
+    assert e.q[0].shape == (0, 1024)
+    # a shape without a fused kernel is refused, not silently mis-quantised
+    from flatquant_amd._lib import FqError
+    La, Ra = dev(np.eye(60, dtype=np.float16)), dev(np.eye(62, dtype=np.float16))
+    with pytest.raises(FqError):
+        ops.kron_quant_grouped(dev(np.zeros((4, 60 * 62), np.float16)), La, Ra, dev(np.array([0, 4], dtype=np.int64)),
+                               sm[:1], sn[:1], P)
+
+
+def test_moe_routed_experts_match_reference_flow(ops, golden):
+    """flatquant/model_tools/deepseekv3_utils.py:427-452 with the reference's own primitives (tools/gen_golden.py):
+    w1_trans once + shared routed quantiser (64 x 112), then the experts' hidden rows through routed_w2_trans (32 x 64,
+    shared and per expert) and the w2 quantiser."""
+    g = golden("moe_grouped")
+    offs = g["offsets"]
+    E = len(offs) - 1
+    # routing plumbing: same row order as the reference's torch.where loop
+    tok_idx, offsets = ops.moe_group_rows(dev(g["indices"]), E)
+    assert np.array_equal(host(offsets), offs) and np.array_equal(host(tok_idx), g["rows_tok"])
+    # stage 1: transform + fake-quant of all tokens, gathered per expert
+    s1 = (float(g["sig1"][0]), float(g["sig1"][1]))
+    o = ops.kron_quant(dev(g["x"]), dev(g["L1"]), dev(g["R1"]), [s1], F | T | R16)
+    assert rel_err(host(o.y), g["xt"]) <= 1e-3
+    fq1 = host(o.fq[0][tok_idx])
+    assert np.mean(fq1 != g["fq1"]) <= 2e-3 and rel_err(fq1, g["fq1"]) <= 0.08      # (one INT4 step of a 4-bit grid)
+    assert np.array_equal(host(o.fq[0]), O.quant_outputs(host(o.y).astype(np.float32), *s1)["fq"])
+    # stage 2: grouped launch, shared transform + the shared quantiser expanded per expert
+    s2 = np.tile(g["sig2"][None, :], (E, 1)).astype(np.float32)
+    h = dev(g["h"])
+    o2 = ops.kron_quant_grouped(h, dev(g["L2"]), dev(g["R2"]), offsets, dev(s2[:, 0]), dev(s2[:, 1]), F | T | R16)
+    assert rel_err(host(o2.y), g["y2_shared"]) <= 1e-3
+    assert np.mean(host(o2.fq[0]) != g["fq2_shared"]) <= 2e-3
+    # per-expert transforms and quantisers (the routed_w2_trans[i] branch)
+    o3 = ops.kron_quant_grouped(h, dev(g["L2e"]), dev(g["R2e"]), offsets, dev(g["sig2e"][:, 0].copy()),
+                                dev(g["sig2e"][:, 1].copy()), F | R16)
+    assert np.mean(host(o3.fq[0]) != g["fq2_indep"]) <= 2e-3
+    ref = O.kron_quant_grouped(g["h"], g["L2e"], g["R2e"], offs, g["sig2e"][:, 0], g["sig2e"][:, 1], round_y_f16=True)
+    assert np.mean(host(o3.fq[0]) != ref["fq"]) <= 2e-3
+
+
+# ------------------------------------------------------------------------------------------- 128-element scales
+@pytest.mark.parametrize("tag", ["32x64", "64x64", "56x64", "64x112"])
+def test_group128_scales(ops, golden, tag):
+    g = golden("group128")
+    x, L, R = dev(g[f"{tag}_x"]), dev(g[f"{tag}_L"]), dev(g[f"{tag}_R"])
+    rows, d = g[f"{tag}_x"].shape
+    y = ops.kron_quant(x, L, R, flags=T).y
+    assert rel_err(host(y), g[f"{tag}_y"]) <= 1e-3
+    for ci in range(2):
+        sig = (float(g[f"{tag}_sig{ci}"][0]), float(g[f"{tag}_sig{ci}"][1]))
+        ref = O.quant_outputs(host(y).astype(np.float32), *sig, groupsize=128)
+        o = ops.kron_quant(x, L, R, [sig], P | R16, groupsize=128)        # fused where N = 64, two launches otherwise
+        assert o.scale[0].shape == (rows, d // 128)
+        assert np.array_equal(host(o.q[0]), ref["packed"])
+        assert np.array_equal(host(o.scale[0]), ref["scale16"])
+        o = ops.kron_quant(x, L, R, [sig], F | R16, groupsize=128)
+        assert np.array_equal(host(o.fq[0]), ref["fq"])
+        assert np.mean(host(o.fq[0]) != g[f"{tag}_fq{ci}"]) <= 2e-3       # vs the reference's vLLM ActivationQuantizer
+    if tag in ("32x64", "64x64"):                                         # grouped + 128-element scales in one launch
+        offs = dev(np.array([0, 1, 1, rows], dtype=np.int64))
+        sm, sn = dev(np.array([0.9, 0.5, 0.7], np.float32)), dev(np.array([0.8, 0.5, 0.6], np.float32))
+        o = ops.kron_quant_grouped(x, L, R, offs, sm, sn, P | R16, groupsize=128)
+        r0 = O.quant_outputs(host(y)[:1].astype(np.float32), 0.9, 0.8, groupsize=128)
+        r2 = O.quant_outputs(host(y)[1:].astype(np.float32), float(np.float32(0.7)), float(np.float32(0.6)), groupsize=128)
+        assert np.array_equal(host(o.q[0]), np.concatenate([r0["packed"], r2["packed"]]))
+        assert np.array_equal(host(o.scale[0]), np.concatenate([r0["scale16"], r2["scale16"]]))
+
+
+def test_activation_quantizer_groupsize_module(golden):
+    from flatquant_amd.flatquant import ActivationQuantizer
+    g = golden("group128")
+    q = ActivationQuantizer(bits=4, sym=True, lac=True, groupsize=128).cuda()
+    q.clip_factor_a_max.data.fill_(1.7), q.clip_factor_a_min.data.fill_(-0.4)
+    fq = q(dev(g["64x112_y"]))
+    assert np.array_equal(host(fq), g["64x112_fq1"])                      # same fp16 input -> bit-exact vs the reference
+
+
+# ------------------------------------------------------------------------------------ module-level contracts (8c)
+def test_decompose_trans_matrix_forward_diag_and_inv_t(golden):
+    from flatquant_amd.flatquant import InvDecomposeTransMatrix, SVDDecomposeTransMatrix
+    g = golden("modules")
+    x = dev(g["dec_x"])
+    for cls in (InvDecomposeTransMatrix, SVDDecomposeTransMatrix):
+        tr = cls(64, 64, add_diag=True)
+        sd = {k: torch.from_numpy(g["dec_" + k]) for k in ("matrix_left", "matrix_right", "matrix_left_inv",
+                                                          "matrix_right_inv", "diag_scale")}
+        tr.load_state_dict(sd)
+        tr = tr.cuda()
+        y = tr(x)
+        assert y.dtype == torch.float16 and rel_err(host(y), g["dec_y"]) <= 1e-3
+        yi = tr(x, inv_t=True)                                            # x / diag, inverse-transposed factors
+        assert rel_err(host(yi), g["dec_y_inv_t"]) <= 1e-3
+        tr.use_diag = False
+        assert rel_err(host(tr(x)), g["dec_y_nodiag"]) <= 1e-3
+        # against the oracle with the exact op order (diag multiply rounded to fp16 first)
+        ref = O.kron_transform(g["dec_x"], g["dec_matrix_left"].astype(np.float16), g["dec_matrix_right"].astype(np.float16))
+        assert np.mean(host(tr(x)) != ref.reshape(6, -1).astype(np.float16)) <= 5e-3
+        # the fp16 copies of the matrices are made once (stable workspace keys), not per call
+        assert len(tr._f16._c) <= 4
+
+
+def test_single_trans_matrix_forward_on_the_hip_path(golden):
+    from flatquant_amd.flatquant import InvSingleTransMatrix, SVDSingleTransMatrix
+    g = golden("modules")
+    x = dev(g["single_x"])                                                # [T, head_dim, H]: heads last (llama_utils.py:276)
+    for cls in (SVDSingleTransMatrix, InvSingleTransMatrix):
+        st = cls(32)
+        st.load_state_dict({"matrix": torch.from_numpy(g["single_matrix"]), "matrix_inv_t": torch.from_numpy(g["single_matrix_inv_t"])})
+        st = st.cuda()
+        y = st(x)
+        assert y.shape == x.shape and y.dtype == torch.float16
+        assert rel_err(host(y), g["single_y"]) <= 1e-3
+        assert rel_err(host(st(x, inv_t=True)), g["single_y_inv_t"]) <= 1e-3
+        ref = O.single_transform(g["single_x"], g["single_matrix"].astype(np.float16)).astype(np.float16)
+        assert np.mean(host(y) != ref) <= 5e-3                            # same fp16 operands, fp32 accumulation
+    # 64 heads (Llama-2-70B), row counts of 128 / 96 / 64 / 32 per launch unit, and the torch route for anything else
+    rng = np.random.default_rng(3)
+    st = SVDSingleTransMatrix(64).cuda()
+    for rows in (128 * 3, 96, 64 * 5, 32):
+        a = rng.standard_normal((rows, 64)).astype(np.float16)
+        ref = O.single_transform(a[None], host(st.matrix).astype(np.float16))[0]
+        assert rel_err(host(st(dev(a))), ref) <= 1e-3
+    a = rng.standard_normal((40, 64)).astype(np.float16)                  # 40 rows: no kernel geometry -> reference op
+    assert rel_err(host(st(dev(a))), O.single_transform(a[None], host(st.matrix).astype(np.float16))[0]) <= 2e-3
+
+
+def test_flat_quantized_linear_eval_forward(golden):
+    """flat_linear.py:75-80: fake-quant of the input (HIP), then the wrapped linear."""
+    from types import SimpleNamespace
+    from flatquant_amd.flatquant import FlatQuantizedLinear
+    g = golden("modules")
+    args = SimpleNamespace(w_bits=4, w_asym=False, a_bits=4, a_asym=False, lac=True, a_groupsize=-1, lwc=False)
+    lin = torch.nn.Linear(4096, 96, bias=True)
+    lin.weight.data, lin.bias.data = torch.from_numpy(g["fql_w"]).float(), torch.from_numpy(g["fql_b"]).float()
+    m = FlatQuantizedLinear(args, lin)
+    m.act_quantizer.clip_factor_a_max.data.fill_(3.3), m.act_quantizer.clip_factor_a_min.data.fill_(2.1)
+    m.reparameterize()
+    m = m.half().cuda()
+    x = dev(g["fql_x"])
+    fq = m.act_quantizer(x)
+    assert np.array_equal(host(fq), g["fql_fq"])                          # the quantiser: bit-exact vs the reference module
+    out = m(x)
+    ref = torch.nn.functional.linear(torch.from_numpy(g["fql_fq"]).float(), torch.from_numpy(g["fql_w"]).float(),
+                                     torch.from_numpy(g["fql_b"]).float()).numpy()
+    assert out.dtype == torch.float16 and rel_err(host(out), ref) <= 2e-3
+    assert rel_err(host(out), g["fql_out"]) <= 4e-3                       # the reference's own fp16 CPU GEMM
+
+
+def test_deploy_quantizer_lac_bit_exact_vs_reference_module(ops, golden):
+    from flatquant_amd import deploy
+    g = golden("quantizer_lac")
+    for ci in range(3):
+        qz = deploy.nn.Quantizer(lac=True).cuda()
+        qz.clip_factor_a_max.fill_(float(g[f"clip{ci}"][0])), qz.clip_factor_a_min.fill_(float(g[f"clip{ci}"][1]))
+        p = qz(dev(g[f"x{ci}"]))
+        assert np.array_equal(host(p.scales_x).reshape(-1), g[f"scales{ci}"])
+        assert np.array_equal(host(p.quantized_x), g[f"packed{ci}"])
+
+
+# -------------------------------------------------------------------------------------------- row shards (8e)
+def test_row_shards_through_the_kernel_equal_the_unsharded_launch(ops):
+    """sharding.shard_rows: every rank's shard through the real kernel, concatenated, equals one launch over all rows
+    bit for bit (rows are independent: no data-path collective is needed or used)."""
+    from flatquant_amd import sharding
+    rng = np.random.default_rng(11)
+    rows = 1000
+    x = dev(rng.standard_normal((rows, 4096)).astype(np.float16))
+    L, R = dev((rng.standard_normal((64, 64)) / 8).astype(np.float16)), dev((rng.standard_normal((64, 64)) / 8).astype(np.float16))
+    full = ops.kron_quant(x, L, R, [(0.98, 0.97)], P | NC0)
+    for world in (2, 3, 8):
+        qs, ss = [], []
+        for rank in range(world):
+            a, b = sharding.shard_rows(rows, world, rank)
+            o = ops.kron_quant(x[a:b].contiguous(), L, R, [(0.98, 0.97)], P | NC0)
+            qs.append(o.q[0]), ss.append(o.scale[0])
+        assert torch.equal(torch.cat(qs), full.q[0]) and torch.equal(torch.cat(ss), full.scale[0])

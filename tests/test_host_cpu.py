@@ -125,8 +125,8 @@ def test_module_surfaces_match_reference_names():
     assert float(aq.clip_factor_a_max.detach()) == 4.0 and int(aq.q_max) == 7 and int(aq.q_min) == -8
     x = torch.randn(3, 8)
     assert ActivationQuantizer(bits=16)(x) is x
-    with pytest.raises(NotImplementedError):
-        ActivationQuantizer(bits=4, sym=True, groupsize=128)
+    # groupsize: flatquant/quant_utils.py raises, the vLLM copy of the class reshapes to (-1, groupsize): that is provided
+    assert ActivationQuantizer(bits=4, sym=True, groupsize=128).groupsize == 128
 
     for cls in (InvDecomposeTransMatrix, SVDDecomposeTransMatrix):
         tr = cls(64, 64, add_diag=True)
@@ -188,14 +188,19 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["MASTER_PORT"], rank=rank, world_size=world)
 g = torch.Generator().manual_seed(7)
 ref = {"left": torch.randn(64, 64, generator=g).half(), "right": torch.randn(64, 64, generator=g).half(),
-       "hadK": torch.randn(28, 28, generator=g).half(), "clip": torch.tensor([4.0, 3.5])}
+       "hadK": torch.randn(28, 28, generator=g).half(), "clip": torch.tensor([4.0, 3.5]),
+       # an odd number of fp16 values in front of fp32 / int64 tensors (key order: a_odd < b_f32 < c_i64): every tensor
+       # must start aligned inside the flat broadcast buffer
+       "a_odd": torch.randn(7, generator=g).half(), "b_f32": torch.randn(5, generator=g),
+       "c_i64": torch.arange(3, dtype=torch.int64)}
 mats = ref if rank == 0 else {k: torch.zeros_like(v) for k, v in ref.items()}
 out = sharding.broadcast_matrices(mats, src=0)
 assert all(torch.equal(out[k], ref[k]) and out[k].dtype == ref[k].dtype for k in ref), rank
 total = 1001
 x = torch.arange(total * 4, dtype=torch.float32).reshape(total, 4)
 a, b = sharding.shard_rows(total, world, rank)
-local = x[a:b] * 2                     # stand-in for the per-rank kernel: rows are independent
+local = x[a:b] * 2                     # stand-in for the per-rank kernel: rows are independent (the kernel itself runs its
+                                       # shards in tests/test_gpu_round2.py::test_row_shards_through_the_kernel_...)
 if total % world == 0:
     full = sharding.gather_rows(local)
     assert torch.equal(full, x * 2)

@@ -395,8 +395,191 @@ def gen_kv_quant():
     save("kv_quant", **arrays)
 
 
+# ------------------------------------------------------------------------------------------------
+# round 2 fixtures
+def _load_vllm_fake_quant_utils():
+    """vllm_custom/model_executor/layers/quantization/utils/fake_quant_utils.py is plain torch (no vllm import):
+    load it by path. Its ActivationQuantizer is the reference's only activation quantiser with groupsize > 0."""
+    import importlib.util
+    path = os.path.join(REF, "vllm_custom/model_executor/layers/quantization/utils/fake_quant_utils.py")
+    spec = importlib.util.spec_from_file_location("ref_vllm_fake_quant_utils", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_group128():
+    """ActivationQuantizer(bits=4, sym=True, lac=True, groupsize=128) on the fp16 transformed activation (path A)."""
+    fq_utils = _load_vllm_fake_quant_utils()
+    arrays = {}
+    for tag, M, N, rows in (("32x64", 32, 64, 8), ("64x64", 64, 64, 4), ("64x112", 64, 112, 3), ("56x64", 56, 64, 3)):
+        x = make_x(rows, M * N, seed=40)
+        L, R = make_mat(M, 41), make_mat(N, 42)
+        with torch.no_grad():
+            y = ref_kronecker_matmul(x.to(torch.float16), L, R)
+            for ci, (cmax, cmin) in enumerate([(4.0, 4.0), (1.7, -0.4)]):
+                q = fq_utils.ActivationQuantizer(bits=4, sym=True, lac=True, groupsize=128)
+                q.clip_factor_a_max.data.fill_(cmax)
+                q.clip_factor_a_min.data.fill_(cmin)
+                fq = q(y)
+                scale, _ = q.get_scale_zero(y.reshape(-1, 128))
+                assert scale.dtype == torch.float32 and fq.dtype == torch.float16
+                arrays[f"{tag}_fq{ci}"] = fq.numpy()
+                arrays[f"{tag}_scale{ci}"] = scale[:, 0].numpy().reshape(rows, -1)
+                arrays[f"{tag}_sig{ci}"] = np.array([sig(cmax), sig(cmin)], dtype=np.float32)
+        arrays[f"{tag}_x"], arrays[f"{tag}_L"], arrays[f"{tag}_R"], arrays[f"{tag}_y"] = x.numpy(), L.numpy(), R.numpy(), y.numpy()
+    save("group128", **arrays)
+
+
+def gen_moe_grouped():
+    """The routed-expert flow of flatquant/model_tools/deepseekv3_utils.py:427-452 with the reference's own primitives
+    (the module itself needs the DeepSeek model classes and fp8 kernels): w1_trans once over all tokens, then per
+    expert ``idx, top = torch.where(indices == i)`` and the shared routed quantiser on x[idx]; the expert's hidden rows
+    through routed_w2_trans (shared, :450, and the per-expert branch, :448) and the w2 quantiser."""
+    T, E, K = 24, 8, 2
+    d1, (M1, N1) = 7168, ref_get_decompose_dim(7168)
+    d2, (M2, N2) = 2048, ref_get_decompose_dim(2048)
+    assert (M1, N1, M2, N2) == (64, 112, 32, 64)
+    g = torch.Generator().manual_seed(50)
+    x = make_x(T, d1, seed=51)
+    pop = torch.tensor([8.0, 4.0, 2.0, 1.0, 0.5, 0.0, 0.25, 0.0])      # Zipf-like popularity, two experts never chosen
+    indices = torch.stack([torch.multinomial(pop, K, replacement=False, generator=g) for _ in range(T)])
+    L1, R1, L2, R2 = make_mat(M1, 52), make_mat(N1, 53), make_mat(M2, 54), make_mat(N2, 55)
+    L2e = torch.stack([make_mat(M2, 60 + i) for i in range(E)])
+    R2e = torch.stack([make_mat(N2, 80 + i) for i in range(E)])
+    clip1, clip2 = (3.1, 2.2), (4.0, 1.3)
+    clip2e = [(4.0 - 0.4 * i, 1.0 + 0.3 * i) for i in range(E)]
+
+    def quantizer(cmax, cmin):
+        q = RefActQ(bits=4, sym=True, lac=True)
+        q.clip_factor_a_max.data.fill_(cmax)
+        q.clip_factor_a_min.data.fill_(cmin)
+        return q
+
+    q1, q2 = quantizer(*clip1), quantizer(*clip2)
+    with torch.no_grad():
+        xt = ref_kronecker_matmul(x.to(torch.float16), L1, R1)                  # self.w1_trans(x), once (:432-433)
+        counts = torch.bincount(indices.flatten(), minlength=E).tolist()       # (:434)
+        rows_tok, fq1, hs, fq2_shared, fq2_indep, y2_shared, offs = [], [], [], [], [], [], [0]
+        for i in range(E):
+            offs.append(offs[-1] + counts[i])
+            if counts[i] == 0:
+                continue
+            idx, top = torch.where(indices == i)                                # (:438)
+            rows_tok.append(idx)
+            fq1.append(q1(xt[idx]))                                             # expert.w1/w3(x[idx]): shared routed quantiser
+            h = make_x(counts[i], d2, seed=100 + i).to(torch.float16)          # stands for silu(gate) * up of this expert
+            hs.append(h)
+            y2 = ref_kronecker_matmul(h, L2, R2)                                # routed_w2_trans(x_act_fn), shared (:450)
+            y2_shared.append(y2)
+            fq2_shared.append(q2(y2))
+            fq2_indep.append(quantizer(*clip2e[i])(ref_kronecker_matmul(h, L2e[i], R2e[i])))   # routed_w2_trans[i] (:448)
+    save("moe_grouped", x=x.numpy(), indices=indices.numpy(), L1=L1.numpy(), R1=R1.numpy(), L2=L2.numpy(), R2=R2.numpy(),
+         L2e=L2e.numpy(), R2e=R2e.numpy(), sig1=np.array([sig(clip1[0]), sig(clip1[1])], dtype=np.float32),
+         sig2=np.array([sig(clip2[0]), sig(clip2[1])], dtype=np.float32),
+         sig2e=np.array([[sig(a), sig(b)] for a, b in clip2e], dtype=np.float32),
+         offsets=np.array(offs, dtype=np.int64), rows_tok=torch.cat(rows_tok).numpy(), xt=xt.numpy(),
+         fq1=torch.cat(fq1).numpy(), h=torch.cat(hs).numpy(), y2_shared=torch.cat(y2_shared).numpy(),
+         fq2_shared=torch.cat(fq2_shared).numpy(), fq2_indep=torch.cat(fq2_indep).numpy())
+
+
+def gen_modules():
+    """Module-level fixtures: InvDecomposeTransMatrix(add_diag=True).forward incl. inv_t,
+    SVDSingleTransMatrix.forward on [T, H, hd], FlatQuantizedLinear._eval_forward."""
+    from flatquant.flat_linear import FlatQuantizedLinear as RefFQL
+    from flatquant.trans_utils import SVDSingleTransMatrix as RefSVDSingle
+    arrays = {}
+    M = N = 64
+    x = make_x(6, M * N, seed=70)
+    diag = (torch.rand(M * N, generator=torch.Generator().manual_seed(71)) + 0.5)
+    tr = RefInvDec(M, N, add_diag=True, diag_init_para=diag.clone())
+    tr.linear_left.weight.data = make_mat(M, 72).float()
+    tr.linear_right.weight.data = make_mat(N, 73).float()
+    tr.to_eval_mode()
+    with torch.no_grad():
+        arrays["dec_y"] = tr(x.to(torch.float16)).numpy()
+        arrays["dec_y_inv_t"] = tr(x.to(torch.float16), inv_t=True).numpy()
+        tr.use_diag = False
+        arrays["dec_y_nodiag"] = tr(x.to(torch.float16)).numpy()
+    for k in ("matrix_left", "matrix_right", "matrix_left_inv", "matrix_right_inv", "diag_scale"):
+        arrays["dec_" + k] = getattr(tr, k).detach().numpy()
+    arrays["dec_x"] = x.numpy()
+    # o_proj head transform (llama_utils.py:275-277): attn_output.reshape(-1, H, hd) -> o_trans(...) over the heads axis
+    H, hd, T = 32, 128, 5
+    st = RefSVDSingle(H)
+    st.to_eval_mode()
+    a = make_x(T, H * hd, seed=74).to(torch.float16)
+    with torch.no_grad():
+        # reference call site: attn_output.reshape(bsz, q_len, H, hd).transpose(-1, -2) ... matmul over the last axis
+        a4 = a.reshape(T, H, hd).transpose(-1, -2).contiguous()            # [T, hd, H]: heads last, as llama_utils.py:276
+        arrays["single_y"] = st(a4).numpy()
+        arrays["single_y_inv_t"] = st(a4, inv_t=True).numpy()
+    arrays["single_x"] = a4.numpy()
+    arrays["single_matrix"] = st.matrix.detach().numpy()
+    arrays["single_matrix_inv_t"] = st.matrix_inv_t.detach().numpy()
+    # FlatQuantizedLinear eval forward (flat_linear.py:75-80): fake-quant of the (already transformed) input, then linear
+    args = types.SimpleNamespace(w_bits=4, w_asym=False, a_bits=4, a_asym=False, lac=True, a_groupsize=-1, lwc=False)
+    lin = torch.nn.Linear(4096, 96, bias=True)
+    g = torch.Generator().manual_seed(75)
+    lin.weight.data = (torch.randn(96, 4096, generator=g) / 64)
+    lin.bias.data = torch.randn(96, generator=g)
+    fql = RefFQL(args, lin)
+    fql.act_quantizer.clip_factor_a_max.data.fill_(3.3)
+    fql.act_quantizer.clip_factor_a_min.data.fill_(2.1)
+    fql.reparameterize()
+    fql = fql.half()
+    xin = make_x(7, 4096, seed=76).to(torch.float16)
+    with torch.no_grad():
+        arrays["fql_out"] = fql(xin).numpy()
+        arrays["fql_fq"] = fql.act_quantizer(xin).to(torch.float16).numpy()
+    arrays["fql_x"], arrays["fql_w"], arrays["fql_b"] = xin.numpy(), fql.linear.weight.detach().numpy(), fql.linear.bias.detach().numpy()
+    arrays["fql_sig"] = np.array([sig(3.3), sig(2.1)], dtype=np.float32)
+    save("modules", **arrays)
+
+
+def gen_quantizer_lac():
+    """deploy.nn.Quantizer(lac=True): the scales come from the reference module (fp16 tensor x 0-dim fp32 sigmoid: the
+    sigmoid and the product are rounded to fp16, deploy/nn/quantization.py:21-28); the pack kernel behind
+    deploy.sym_quant (quant.cu:13-47, cannot be built here) is stood in for by its restatement."""
+    from deploy.nn.quantization import Quantizer as RefQuantizer
+    import deploy as ref_deploy
+
+    def sym_quant_restated(x, scale):      # quant.cu:40: __half2int_rn(__hdiv(x, s)), clamp, low nibble = even column
+        q = torch.clamp(torch.round((x / scale[:, None]).to(torch.float16).float()), -8, 7).to(torch.int8)
+        u = (q.to(torch.int16) & 0xF).to(torch.uint8)
+        return u[:, 0::2] | (u[:, 1::2] << 4)
+    sys.modules["deploy._CUDA"].sym_quant = sym_quant_restated
+    ref_deploy._CUDA = sys.modules["deploy._CUDA"]
+    arrays = {}
+    for ci, (cmax, cmin) in enumerate([(4.0, 4.0), (2.3, -0.7), (0.31, 1.9)]):
+        x = make_x(64, 4096, seed=90 + ci).to(torch.float16)
+        qz = RefQuantizer(lac=True)
+        qz.clip_factor_a_max.fill_(cmax)
+        qz.clip_factor_a_min.fill_(cmin)
+        with torch.no_grad():
+            p = qz(x)
+        assert p.scales_x.dtype == torch.float16
+        arrays[f"x{ci}"], arrays[f"scales{ci}"], arrays[f"packed{ci}"] = x.numpy(), p.scales_x.numpy().reshape(-1), p.quantized_x.numpy()
+        arrays[f"clip{ci}"] = np.array([cmax, cmin], dtype=np.float32)
+        arrays[f"sig{ci}"] = np.array([sig(cmax), sig(cmin)], dtype=np.float32)
+    save("quantizer_lac", **arrays)
+
+
+def gen_round2():
+    gen_group128()
+    gen_moe_grouped()
+    gen_modules()
+    gen_quantizer_lac()
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "r2":
+        gen_round2()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "qlac":
+        gen_quantizer_lac()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "kv":
         gen_kv_quant()
         sys.exit(0)
@@ -422,3 +605,4 @@ if __name__ == "__main__":
     gen_edge()
     gen_block_b()
     gen_kron_b()
+    gen_round2()
