@@ -33,10 +33,18 @@ __device__ __forceinline__ int rmap(int RT, int rt, int i) {
     return ((i >> 2) & 1) * (RT * 16) + rt * 16 + (i & 3) + 4 * (i >> 3);
 }
 
-template <int RT, int CT, bool DMA>
+// NAT = false: outputs in the reference kernel's transposed order [C][R] (block_matmul.py:86-101): X rows are the MFMA A
+// operand (row order permuted by rmap), P the B operand, lane (h, c) ends with column c' = 32 ct + c and a run of rows.
+// NAT = true: natural order [R][C] = inp.reshape(-1, C) @ P, the contract of {SVD,Inv}SingleTransMatrix.forward
+// (trans_utils.py:21-25): the operands swap roles — P^T rows (permuted the same way) are the A operand, X^T the B
+// operand, whose fragment is the very same 16-byte piece of row (32 rt + c) — and lane (h, c) ends with row 32 rt + c and
+// a run of CT*16 consecutive columns. Either way a lane stores contiguous runs; the epilogue below is written once in
+// terms of (outer tile o = its major index / 32, inner tiles i along its run).
+template <int RT, int CT, bool DMA, bool NAT>
 __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x, const f16* __restrict__ P,
                                                        int64_t rows, FqQuantOut out, int flags) {
     constexpr int R = RT * 32, C = CT * 32, KS = C / 16, D = R * C, CPR = C / 8;
+    constexpr int OC = NAT ? RT : CT, IC = NAT ? CT : RT, LEN = IC * 32;  // outer / inner tile counts, length of a major row
     static_assert(!DMA || CPR == 8, "the DMA variant is the C = 64 one");
     __shared__ __attribute__((aligned(16))) uint4 pfrag[KS * CT * 64];  // [(s*CT + ct)][lane]
     __shared__ __attribute__((aligned(16))) unsigned char tokmem[DMA ? 4 * D * 2 : 16];  // wave-private token buffers
@@ -46,7 +54,7 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
         const int s = f / CT, ct = f - s * CT;
         f16x8 v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = P[(s * 16 + fh * 8 + j) * C + ct * 32 + fc];
+        for (int j = 0; j < 8; ++j) v[j] = P[(s * 16 + fh * 8 + j) * C + (NAT ? rmap(CT, ct, fc) : ct * 32 + fc)];
         pfrag[item] = __builtin_bit_cast(uint4, v);
     }
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + (tid >> 6);
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
     __syncthreads();  // (the compiler knows of no VMEM in flight here: lgkmcnt(0) + s_barrier)
     // packed-only single-clip launches: the stores a token issues after its successor's DMA are a fixed number, so the
     // wait for that DMA can leave them in flight
-    constexpr int PACKED_STORES = CT * ((RT + 1) / 2) + 1;
+    constexpr int PACKED_STORES = OC * ((IC + 1) / 2) + 1;
     const bool counted = DMA && (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM)) == FQ_OUT_PACKED &&
                          out.n_clips == 1;
     bool first = true;
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
         f32x16 Y[RT][CT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            const int row = rmap(RT, rt, c);
+            const int row = NAT ? rt * 32 + c : rmap(RT, rt, c);
             const uint4* xp = reinterpret_cast<const uint4*>(x + tok * D + (int64_t)row * C + h * 8);
             const uint4* lp = reinterpret_cast<const uint4*>(tokbuf) + row * CPR;  // chunk (2 s + h) ^ swz(row)
             const int sw = DMA ? swz<8>(row) : 0;
@@ -91,15 +99,19 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
                 if (DMA) a = __builtin_bit_cast(f16x8, lp[(s * 2 + h) ^ sw]);
                 else a = __builtin_bit_cast(f16x8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xp) + s * 2));
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    Y[rt][ct] = mfma32(a, __builtin_bit_cast(f16x8, myp[(s * CT + ct) * 64]), Y[rt][ct]);
+                for (int ct = 0; ct < CT; ++ct) {
+                    const f16x8 pf = __builtin_bit_cast(f16x8, myp[(s * CT + ct) * 64]);
+                    Y[rt][ct] = NAT ? mfma32(pf, a, Y[rt][ct]) : mfma32(a, pf, Y[rt][ct]);
+                }
             }
         }
         if (DMA) {  // the buffer has been read: fetch this wave's next token while the current one is quantised
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (tok + n_waves < rows) dma_token<8>(x, tok + n_waves, (int64_t)D * 2, D * 2 / 1024, tok_lds, voff);
         }
-        // lane (h, c) now holds, for column c' = 32 ct + c, rows r = RT*16*h + 16 rt + reg
+        // lane (h, c) now holds, for column c' = 32 ct + c, rows r = RT*16*h + 16 rt + reg   (NAT: for row 32 rt + c,
+        // columns c' = CT*16*h + 16 ct + reg): major index 32 o + c, run of IC*16 elements starting at IC*16*h
+#define FQ_TILE(o, i) (NAT ? Y[o][i] : Y[i][o])
 
         if (flags & FQ_ROUND_Y_F16) {
 #pragma unroll
@@ -111,16 +123,16 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
         }
         if (flags & FQ_OUT_TRANSFORM) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                uint4* yp = reinterpret_cast<uint4*>(out.y + tok * D + (int64_t)(ct * 32 + c) * R + h * (RT * 16));
+            for (int o = 0; o < OC; ++o) {
+                uint4* yp = reinterpret_cast<uint4*>(out.y + tok * D + (int64_t)(o * 32 + c) * LEN + h * (IC * 16));
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
+                for (int i = 0; i < IC; ++i)
 #pragma unroll
                     for (int w = 0; w < 2; ++w) {
                         f16x8 v;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (f16)Y[rt][ct][w * 8 + e];
-                        yp[rt * 2 + w] = __builtin_bit_cast(uint4, v);
+                        for (int e = 0; e < 8; ++e) v[e] = (f16)FQ_TILE(o, i)[w * 8 + e];
+                        yp[i * 2 + w] = __builtin_bit_cast(uint4, v);
                     }
             }
         }
@@ -146,36 +158,36 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
             const float inv = fq_fast_inv(scale);
             if ((flags & FQ_OUT_PACKED) && lane == 0) out.scale[ci][tok] = (f16)scale;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
+            for (int o = 0; o < OC; ++o) {
                 uint8_t* qrow = (flags & FQ_OUT_PACKED)
-                                    ? out.q[ci] + tok * (D / 2) + (int64_t)(ct * 32 + c) * (R / 2) + h * (RT * 8)
+                                    ? out.q[ci] + tok * (D / 2) + (int64_t)(o * 32 + c) * (LEN / 2) + h * (IC * 8)
                                     : nullptr;
                 f16* frow = (flags & FQ_OUT_FAKEQUANT)
-                                ? out.fq[ci] + tok * D + (int64_t)(ct * 32 + c) * R + h * (RT * 16)
+                                ? out.fq[ci] + tok * D + (int64_t)(o * 32 + c) * LEN + h * (IC * 16)
                                 : nullptr;
-                uint2 pk[RT];
+                uint2 pk[IC];
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
+                for (int i = 0; i < IC; ++i) {
                     float qv[16];
                     if (flags & FQ_QUANT_F16) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) qv[r] = (float)fq_quant1<FQ_QUANT_F16>(Y[rt][ct][r], scale);
+                        for (int r = 0; r < 16; ++r) qv[r] = (float)fq_quant1<FQ_QUANT_F16>(FQ_TILE(o, i)[r], scale);
                     } else {
                         float dmax = 0.0f;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) qv[r] = fq_qfast(Y[rt][ct][r], inv, dmax);
+                        for (int r = 0; r < 16; ++r) qv[r] = fq_qfast(FQ_TILE(o, i)[r], inv, dmax);
                         if (fq_wave_needs_exact(dmax)) {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) qv[r] = fq_qexact(Y[rt][ct][r], scale);
+                            for (int r = 0; r < 16; ++r) qv[r] = fq_qexact(FQ_TILE(o, i)[r], scale);
                         }
                     }
                     if (flags & FQ_OUT_PACKED) {  // 8 bytes per row tile; two tiles share one 16-byte store
-                        pk[rt].x = fq_pack8(qv[0], qv[1], qv[2], qv[3], qv[4], qv[5], qv[6], qv[7]);
-                        pk[rt].y = fq_pack8(qv[8], qv[9], qv[10], qv[11], qv[12], qv[13], qv[14], qv[15]);
-                        if (rt & 1)
-                            *reinterpret_cast<uint4*>(qrow + (rt - 1) * 8) = make_uint4(pk[rt - 1].x, pk[rt - 1].y, pk[rt].x, pk[rt].y);
-                        else if (rt == RT - 1)
-                            *reinterpret_cast<uint2*>(qrow + rt * 8) = pk[rt];
+                        pk[i].x = fq_pack8(qv[0], qv[1], qv[2], qv[3], qv[4], qv[5], qv[6], qv[7]);
+                        pk[i].y = fq_pack8(qv[8], qv[9], qv[10], qv[11], qv[12], qv[13], qv[14], qv[15]);
+                        if (i & 1)
+                            *reinterpret_cast<uint4*>(qrow + (i - 1) * 8) = make_uint4(pk[i - 1].x, pk[i - 1].y, pk[i].x, pk[i].y);
+                        else if (i == IC - 1)
+                            *reinterpret_cast<uint2*>(qrow + i * 8) = pk[i];
                     }
                     if (flags & FQ_OUT_FAKEQUANT) {
                         f16x8 v0, v1;
@@ -189,7 +201,7 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
                                 v1[e] = fq_mul_to_f16(scale, qv[8 + e]);
                             }
                         }
-                        uint4* fp = reinterpret_cast<uint4*>(frow + rt * 16);
+                        uint4* fp = reinterpret_cast<uint4*>(frow + i * 16);
                         fp[0] = __builtin_bit_cast(uint4, v0);
                         fp[1] = __builtin_bit_cast(uint4, v1);
                     }
@@ -199,7 +211,9 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
     }
 }
 
-template <int RT, int CT>
+#undef FQ_TILE
+
+template <int RT, int CT, bool NAT>
 int launch_block(int flags, const f16* x, const f16* P, int64_t rows, const FqQuantOut& out, int n_cu,
                  hipStream_t stream) {
     constexpr bool DMA = CT == 2;  // C = 64: whole-line DMA staging (see the header)
@@ -207,7 +221,7 @@ int launch_block(int flags, const f16* x, const f16* P, int64_t rows, const FqQu
     const int64_t cap = (int64_t)n_cu * 2;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((fq_block_kernel<RT, CT, DMA>), dim3((unsigned)blocks), dim3(256), 0, stream, x, P, rows, out, flags);
+    hipLaunchKernelGGL((fq_block_kernel<RT, CT, DMA, NAT>), dim3((unsigned)blocks), dim3(256), 0, stream, x, P, rows, out, flags);
     return (int)hipGetLastError();
 }
 
@@ -215,11 +229,12 @@ int launch_block(int flags, const f16* x, const f16* P, int64_t rows, const FqQu
 
 int fq_launch_block(int flags, const f16* x, const f16* P, int64_t rows, int R, int C, int transpose_out,
                     const FqQuantOut& out, int n_cu, hipStream_t stream) {
-    if (!transpose_out) return -1000;  // natural [R][C] packing is not what the reference emits; not built
     if ((R & 31) || R < 32 || R > 128 || (C != 32 && C != 64)) return -1000;
     const int RT = R / 32, CT = C / 32;
-#define FQ_B(RT_, CT_) \
-    if (RT == RT_ && CT == CT_) return launch_block<RT_, CT_>(flags, x, P, rows, out, n_cu, stream);
+#define FQ_B(RT_, CT_)                                                                                       \
+    if (RT == RT_ && CT == CT_)                                                                              \
+        return transpose_out ? launch_block<RT_, CT_, false>(flags, x, P, rows, out, n_cu, stream)           \
+                             : launch_block<RT_, CT_, true>(flags, x, P, rows, out, n_cu, stream);
     FQ_B(1, 1) FQ_B(2, 1) FQ_B(3, 1) FQ_B(4, 1) FQ_B(1, 2) FQ_B(2, 2) FQ_B(3, 2) FQ_B(4, 2)
 #undef FQ_B
     return -1000;

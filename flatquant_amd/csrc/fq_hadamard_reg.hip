@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void fq_had_pow2_kernel(const f16* __restrict_
             for (int j = 0; j < CH; ++j) minmax8(o[j], mx, mn);
             mx = fq_wave_max(mx);
             mn = fq_wave_min(mn);
-            const float sc = fq_token_scale<FQ_QUANT_F16>(mx, mn, hq.sig_max, hq.sig_min, 0);
+            const float sc = fq_token_scale<FQ_QUANT_F16>(mx, mn, hq.sig_max, hq.sig_min, FQ_SIG_F16);  // deploy.nn.Quantizer arithmetic
             if (lane == 0) hq.scale[row] = (f16)sc;
             uint32_t* qp = reinterpret_cast<uint32_t*>(hq.q + row * (n / 2));
 #pragma unroll
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void fq_had_kmix_kernel(const f16* __restrict_
             __syncthreads();  // also: every wave is done reading V -> it becomes the packed-output stage
             mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
             mn = fminf(fminf(red[4], red[5]), fminf(red[6], red[7]));
-            const float sc = fq_token_scale<FQ_QUANT_F16>(mx, mn, hq.sig_max, hq.sig_min, 0);
+            const float sc = fq_token_scale<FQ_QUANT_F16>(mx, mn, hq.sig_max, hq.sig_min, FQ_SIG_F16);  // deploy.nn.Quantizer arithmetic
             unsigned char* obuf = smem;  // [K][P/2] bytes
 #pragma unroll
             for (int u = 0; u < MAXT; ++u) {

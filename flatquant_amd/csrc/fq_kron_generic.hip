@@ -361,6 +361,11 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
     int pf_q0 = tid;
     if (tok < rows) FQ_PF_LOAD(tok)
     FqGroupCursor gcur;  // grouped launches: the clip pair follows the token's group
+    // The zero fill of xs above and the first token's staging below touch the same LDS words from DIFFERENT threads
+    // (fill: chunk tid + k THREADS; staging: row * PITCH + chunk): without this barrier a wave that is late in the
+    // prologue (cold instruction cache on a kernel's first launches) zeroes rows another wave has already staged —
+    // seen as one wrong output token per affected workgroup, about once in a few dozen fresh processes (round 2).
+    __syncthreads();
 
     for (; tok < rows; tok += gridDim.x) {
         // ---- stage the prefetched token (the previous token's readers passed the statistics barrier) ----

@@ -2,7 +2,7 @@
 import torch
 
 from .. import ops
-from .._lib import FQ_OUT_FAKEQUANT, FQ_QUANT_F16
+from .._lib import FQ_OUT_FAKEQUANT, FQ_QUANT_F16, FQ_SIG_F16
 
 
 def get_qmin_qmax(bits, sym):
@@ -45,8 +45,16 @@ class ActivationQuantizer(torch.nn.Module):
             self.clip_factor_a_min = torch.nn.Parameter(torch.ones((1,)) * init_value, requires_grad=True)
         self.enable = True
 
+    def _lac_f16(self):
+        """lac with fp16 clip parameters (the whole module was .half()'ed): fp16 extrema x fp16 sigmoid stays fp16 in the
+        reference, and so do scale, x / scale and scale * q — the all-fp16 route, not the promoted fp32 one."""
+        return self.lac and self.clip_factor_a_max.dtype == torch.float16
+
     def _sig(self):
         if self.lac:
+            if self._lac_f16():   # torch.sigmoid of an fp16 tensor: evaluated in fp32, rounded to fp16
+                return tuple(float(torch.sigmoid(torch.tensor(ops.host_scalar(p.detach()), dtype=torch.float16)))
+                             for p in (self.clip_factor_a_max, self.clip_factor_a_min))
             # fp32 sigmoid on the host; the parameters are read back once per version, not once per call
             return ops.sigmoid_pair(self.clip_factor_a_max.detach(), self.clip_factor_a_min.detach())
         if self._clip_ratio is not None:
@@ -62,6 +70,8 @@ class ActivationQuantizer(torch.nn.Module):
         if self.bits != 4 or not self.sym:
             raise NotImplementedError("flatquant_amd: only 4-bit symmetric activation quantisation is on the hot path")
         flags = FQ_OUT_FAKEQUANT | (0 if self.lac else FQ_QUANT_F16)
+        if self._lac_f16():
+            flags |= FQ_QUANT_F16 | FQ_SIG_F16
         if self.groupsize > 0:
             if x.shape[-1] % self.groupsize:
                 raise ValueError(f"last dimension {x.shape[-1]} is not a multiple of groupsize {self.groupsize}")

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import (FQ_EUNSUPPORTED, FQ_GROUP128, FQ_MAX_CLIPS, FQ_NO_CLAMP0, FQ_OUT_FAKEQUANT, FQ_OUT_PACKED,
-                   FQ_OUT_TRANSFORM, FQ_QUANT_F16, FQ_ROUND_Y_F16, FQ_WS_PREPARED, check, lib)
+                   FQ_OUT_TRANSFORM, FQ_QUANT_F16, FQ_ROUND_Y_F16, FQ_SIG_F16, FQ_WS_PREPARED, check, lib)
 
 Sig = Tuple[float, float]  # (sigmoid(clip_factor_a_max), sigmoid(clip_factor_a_min)); (1.0, 1.0) = no clip
 
@@ -419,7 +419,8 @@ def hadamard(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None,
 def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None, sig: Sig = (1.0, 1.0),
                    scale: Optional[float] = None, up: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Hadamard rotation fused with the deploy Quantizer (fq_hadamard_quant_f16): -> (q uint8 [..., n/2], scales fp16
-    [rows]). Bit-identical to rowquant(hadamard(x), [sig], FQ_OUT_PACKED | FQ_QUANT_F16); shapes the fused kernels do
+    [rows]). Bit-identical to rowquant(hadamard(x), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16) = the deploy
+    Quantizer's arithmetic (deploy/nn/quantization.py:15-29); shapes the fused kernels do
     not cover take exactly that two-launch route. With ``up``: x is x_gate and the input of the rotation is
     up * silu(x), formed in registers (fq_silu_mul_hadamard_quant_f16)."""
     _chk(x, "x")
@@ -452,7 +453,7 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
     if rc == _lib.FQ_EUNSUPPORTED:
         if up is not None:
             x = silu_mul(x, up)
-        o = rowquant(hadamard(x, K, hadK, scale), [sig], FQ_OUT_PACKED | FQ_QUANT_F16)
+        o = rowquant(hadamard(x, K, hadK, scale), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)
         return o.q[0], o.scale[0].reshape(-1)
     check(rc)
     return q, s

@@ -95,7 +95,7 @@ def test_module_surface(ops):
 def test_fused_hadamard_quantizer_equals_two_launches(ops, n, K):
     """fq_hadamard_quant_f16 == fq_hadamard_f16 followed by the deploy Quantizer (fp16-arithmetic rowquant), bit for
     bit, on every shape: fused kernels where they exist (P = 512, 1024; pow2 n <= 8192), the two-launch route else."""
-    from flatquant_amd._lib import FQ_OUT_PACKED, FQ_QUANT_F16
+    from flatquant_amd._lib import FQ_OUT_PACKED, FQ_QUANT_F16, FQ_SIG_F16
     g = torch.Generator().manual_seed(n + K)
     rows = 37
     x = torch.randn(rows, n, generator=g).half()
@@ -105,7 +105,7 @@ def test_fused_hadamard_quantizer_equals_two_launches(ops, n, K):
     hk = None if K == 1 else torch.from_numpy(hadk_matrix(K)).cuda()
     for sig in [(0.9820137619972229, 0.9820137619972229), (0.7, 0.9), (1.0, 1.0)]:
         q, s = ops.hadamard_quant(x, K, hk, sig)
-        two = ops.rowquant(ops.hadamard(x, K, hk), [sig], FQ_OUT_PACKED | FQ_QUANT_F16)
+        two = ops.rowquant(ops.hadamard(x, K, hk), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)  # = deploy Quantizer
         assert torch.equal(q, two.q[0]), (n, K, sig)
         assert torch.equal(s.reshape(-1), two.scale[0].reshape(-1)), (n, K, sig)
 
