@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py — Melem/s of the fused Kronecker-transform + INT4-quant hot path on MI355X.
+"""bench.py — Melem/s of the fused transform + INT4-quant hot path on MI355X.
 
-Workload (BASELINE.json configs[1], "C2"): Llama-3-8B single linear input, d = 4096 (64 x 64 Kronecker
+Default workload (BASELINE.json configs[1], "C2"): Llama-3-8B single linear input, d = 4096 (64 x 64 Kronecker
 factors), bs x seq = 8 x 2048 = 16384 tokens PER GPU (weak scaling: tokens shard, no data-path collective;
 the two 64x64 factor matrices are broadcast once from rank 0 over RCCL).  One step = one launch of
 fq_kron_quant_f16 (packed INT4 + fp16 scales out) over one 128 MiB activation buffer already resident in
 HBM; buffers rotate over > 256 MiB so the Infinity Cache cannot serve the stream.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C4|C5]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
 
+--config (the other BASELINE.json configs; one "element" = one input activation scalar of one (token, linear) unit):
+  C3  Llama-3-8B decoder layer, the activation path of its 7 linears: RMSNorm + 64x64 transform with 3 clip sets (q/k/v),
+      o_proj head transform (head_dim 128 x 32 heads), RMSNorm + 64x64 with 2 clip sets (up/gate), online Hadamard
+      28 x 512 + Quantizer on the down_proj input. 4 launches per step, 8 x 2048 tokens per GPU (weak scaling).
+  C4  Llama-2-70B shapes (d = 8192 = 64x128, ffn 28672 = 128x224, 64 heads), all 80 layers per step (320 launches,
+      replayed from ONE captured HIP graph), 8 x 2048 tokens in total, rows sharded over the GPUs (strong scaling).
+  C5  DeepSeek-V3 MoE: w1_trans 64x112 over 16384 tokens of d = 7168, then the routed experts' hidden rows
+      [8 x 16384, 2048] in 256 groups (Zipf routing) through the grouped 32x64 launch with per-expert clip pairs;
+      experts (groups) and tokens sharded over the GPUs (strong scaling).
+
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (HBM, algorithmic bytes / HIP-
-event time per launch) and `cpu_baseline` (torch restatement of the reference's CPU fake-quant path, timed on
-the host cores, bounded sample).
+event time per launch of the dominant kernel) and `cpu_baseline` (torch restatement of the reference's CPU fake-quant
+path, timed on the host cores, bounded sample).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -31,53 +42,59 @@ ROWS = BSZ * SEQ
 BYTES_PER_TOKEN = 2 * D + D // 2 + 2          # fp16 in + packed INT4 out + fp16 scale = 10242
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8 TB/s spec
 N_BUF = 4                                     # 4 x 128 MiB inputs + 4 x 32 MiB outputs rotate (> 256 MiB L3)
+SIG4 = 0.9820137619972229                     # fp32 sigmoid(4.0): the clip factors' initial value
 
 
-def make_inputs(device, seed):
+def packed_bytes(d):
+    """fp16 in + packed INT4 out + one fp16 scale per token."""
+    return 2 * d + d // 2 + 2
+
+
+def make_inputs(device, seed, rows=ROWS, d=D, n_buf=N_BUF):
     g = torch.Generator(device=device).manual_seed(seed)
     xs = []
-    for _ in range(N_BUF):
-        x = torch.randn(ROWS, D, generator=g, device=device, dtype=torch.float16)
+    for _ in range(n_buf):
+        x = torch.randn(rows, d, generator=g, device=device, dtype=torch.float16)
         x[:, :: 97] *= 20.0                    # LLM-like outlier channels
         xs.append(x)
     return xs
 
 
+def make_matrix(n, seed, device):
+    """random orthogonal . diag(U[0.5, 2]) in fp64 -> fp16."""
+    g = torch.Generator().manual_seed(seed)
+    q, r = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
+    q = q * torch.sign(torch.diagonal(r))[None, :]
+    m = q * (torch.rand(n, generator=g, dtype=torch.float64) * 1.5 + 0.5)[None, :]
+    return m.to(torch.float16).contiguous().to(device)
+
+
 def make_matrices(device):
-    """random orthogonal . diag(U[0.5, 2]) in fp64 -> fp16, seeds 1 and 2."""
-    mats = {}
-    for name, n, seed in (("left", M, 1), ("right", N, 2)):
-        g = torch.Generator().manual_seed(seed)
-        q, r = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
-        q = q * torch.sign(torch.diagonal(r))[None, :]
-        m = q * (torch.rand(n, generator=g, dtype=torch.float64) * 1.5 + 0.5)[None, :]
-        mats[name] = m.to(torch.float16).to(device)
-    return mats
+    return {"left": make_matrix(M, 1, device), "right": make_matrix(N, 2, device)}
 
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC run (tools/prof.sh: separate
     --pmc passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled per the gfx950 correction). None if absent."""
-    path = os.path.join(ROOT, "profiles", "r02_kron64_pmc.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01_kron64_pmc.json")
-    try:
-        with open(path) as fh:
-            return json.load(fh)["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ("r02_kron64_pmc.json", "r01_kron64_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                return json.load(fh)["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
-def cpu_baseline(max_seconds=20.0):
+def cpu_baseline(max_seconds=20.0, m=M, n=N):
     """The reference's CPU fake-quant path (flat_utils.py:6-17 + quant_utils.py:71-119), restated in torch by
-    oracle/path_a_torch.py, on a bounded sample: C1-sized batches (2048 x 4096 fp16) for <= ~20 s."""
+    oracle/path_a_torch.py, on a bounded sample: C1-sized batches (2048 tokens, fp16) for <= ~20 s."""
     from oracle import path_a_torch
     # torch's CPU GEMM on 64x64 factors scales poorly past a few dozen threads; time a short ladder and report the
     # best (cores = the thread count actually used for `value`).
-    rows = 2048
+    rows, d = 2048, m * n
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(rows, D, generator=g).to(torch.float16)
-    mats = make_matrices("cpu")
+    x = torch.randn(rows, d, generator=g).to(torch.float16)
+    left, right = make_matrix(m, 1, "cpu"), make_matrix(n, 2, "cpu")
     sig = (float(torch.sigmoid(torch.tensor(4.0))),) * 2
     ncpu = os.cpu_count() or 1
     ladder = sorted({t for t in (1, 8, 16, 32, 64, ncpu) if t <= ncpu})
@@ -86,36 +103,244 @@ def cpu_baseline(max_seconds=20.0):
     t_start = time.perf_counter()
     for threads in ladder:
         torch.set_num_threads(threads)
-        path_a_torch.kron_fakequant(x, mats["left"], mats["right"], sig)   # warm-up
+        path_a_torch.kron_fakequant(x, left, right, sig)   # warm-up
         times = []
         t_cfg = time.perf_counter()
         while len(times) < 5 and time.perf_counter() - t_cfg < max_seconds / len(ladder):
             t0 = time.perf_counter()
-            path_a_torch.kron_fakequant(x, mats["left"], mats["right"], sig)
+            path_a_torch.kron_fakequant(x, left, right, sig)
             times.append(time.perf_counter() - t0)
         times.sort()
         med = times[len(times) // 2]
-        results[threads] = rows * D / med / 1e6
+        results[threads] = rows * d / med / 1e6
         if best is None or results[threads] > results[best]:
             best = threads
         if time.perf_counter() - t_start > max_seconds:
             break
     return {"value": results[best], "unit": "Melem/s", "cores": best, "kind": "port",
-            "sample": f"median of <=5 x ({rows} x {D} fp16 tokens) per thread count, torch {torch.__version__} CPU; "
-                      f"host has {ncpu} logical CPUs",
+            "sample": f"median of <=5 x ({rows} x {d} fp16 tokens, {m}x{n} factors) per thread count, torch "
+                      f"{torch.__version__} CPU; host has {ncpu} logical CPUs",
             "by_threads": {str(k): round(v, 2) for k, v in results.items()}}
+
+
+# ---------------------------------------------------------------------------------------------------- workloads
+class Workload:
+    """step(i): one pass of the hot path over one batch (launches on torch's current stream).
+    kernels: [(name, fn(i), algorithmic bytes per call)] — the individual launches of a step, timed one by one after the
+    timed region to name the dominant kernel. elems: input activation scalars per step on THIS rank."""
+    scaling = "weak"
+    graph = False
+
+
+class C2(Workload):
+    name = "C2"
+    metric = "Melems/s for fused kron-transform+INT4-quant, Llama-3-8B d=4096, bs×seq=8×2048"
+
+    def __init__(self, device, rank, world, sharding, bcast):
+        from flatquant_amd import ops
+        from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED, check, lib
+        mats = make_matrices(device) if rank == 0 else {
+            "left": torch.empty(M, M, dtype=torch.float16, device=device),
+            "right": torch.empty(N, N, dtype=torch.float16, device=device)}
+        mats = bcast(mats)                                     # the only collective on the path (set-up time)
+        left, right = mats["left"].contiguous(), mats["right"].contiguous()
+        sig = [ops.sigmoid_pair(4.0, 4.0)]
+        self.xs = xs = make_inputs(device, seed=rank)
+        flags = FQ_OUT_PACKED | FQ_NO_CLAMP0                   # deploy OnlineTrans(matmul) contract
+        # pre-allocated rotating outputs; the timed region calls the C ABI directly (no allocator in the loop)
+        self.qs = qs = [torch.empty(ROWS, D // 2, dtype=torch.uint8, device=device) for _ in range(N_BUF)]
+        self.ss = ss = [torch.empty(ROWS, dtype=torch.float16, device=device) for _ in range(N_BUF)]
+        smax = (ctypes.c_float * 4)(sig[0][0])
+        smin = (ctypes.c_float * 4)(sig[0][1])
+        sp = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+        def arr(t):
+            a = (ctypes.c_void_p * 4)()
+            a[0] = t.data_ptr()
+            return a
+        calls = [(ctypes.c_void_p(xs[i].data_ptr()), arr(qs[i]), arr(ss[i])) for i in range(N_BUF)]
+        lp, rp = ctypes.c_void_p(left.data_ptr()), ctypes.c_void_p(right.data_ptr())
+        none4 = (ctypes.c_void_p * 4)()
+        self._keep = (left, right, smax, smin, calls, none4)
+
+        def step(i):
+            xp, qa, sa = calls[i % N_BUF]
+            check(lib.fq_kron_quant_f16(xp, lp, rp, None, ROWS, M, N, smax, smin, 1, flags, qa, sa, none4, None, None, 0, sp))
+        self.step = step
+        self.elems = ROWS * D
+        self.kernels = [("fq_kron64_kernel", step, ROWS * BYTES_PER_TOKEN)]
+        self.config = {"workload": "C2: Llama-3-8B single linear (q_proj input), d=4096 = 64x64 Kronecker, "
+                                   "8x2048 tokens per GPU, packed INT4 + fp16 scale out",
+                       "rows_per_gpu": ROWS, "d": D, "factors": [M, N], "parallelism": f"rows x{world}"}
+
+    def floor_us(self, stream):
+        """practical HBM floor: the same bytes (8 KB in, 2 KB + 2 B out per token) moved by a no-arithmetic kernel"""
+        from flatquant_amd import ops
+        for i in range(5):
+            ops.probe_stream_4096(self.xs[i % N_BUF], self.qs[i % N_BUF], self.ss[i % N_BUF])
+        torch.cuda.synchronize()
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record(stream)
+        for i in range(50):
+            ops.probe_stream_4096(self.xs[i % N_BUF], self.qs[i % N_BUF], self.ss[i % N_BUF])
+        f1.record(stream)
+        torch.cuda.synchronize()
+        return f0.elapsed_time(f1) / 50 * 1e3
+
+
+def _hadk(K, device):
+    from flatquant_amd.flatquant.hadamard_utils import get_hadK
+    h, k = get_hadK(K * 512)
+    assert k == K
+    return h.to(torch.float16).to(device).contiguous()
+
+
+class C3(Workload):
+    name = "C3"
+    metric = "Melems/s, Llama-3-8B decoder layer activation path (7 linears, W4A4, online Hadamard on down_proj), 8x2048 tokens"
+
+    def __init__(self, device, rank, world, sharding, bcast):
+        from flatquant_amd import ops
+        from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED
+        hid, ffn, H, hd, rows = 4096, 14336, 32, 128, ROWS
+        mats = {"ln_l": make_matrix(64, 1, device), "ln_r": make_matrix(64, 2, device), "ug_l": make_matrix(64, 3, device),
+                "ug_r": make_matrix(64, 4, device), "o": make_matrix(H, 5, device), "hadk": _hadk(28, device)}
+        mats = bcast(mats)
+        nb = 2
+        xs = make_inputs(device, rank, rows, hid, nb)
+        xa = [x.reshape(rows, hd, H) for x in make_inputs(device, rank + 100, rows, hid, nb)]
+        x2 = make_inputs(device, rank + 200, rows, hid, nb)
+        xf = make_inputs(device, rank + 300, rows, ffn, nb)
+        s3, s2, s1 = [(SIG4, SIG4)] * 3, [(SIG4, SIG4)] * 2, (SIG4, SIG4)
+        P = FQ_OUT_PACKED | FQ_NO_CLAMP0
+        k_qkv = lambda i: ops.rmsnorm_kron_quant(xs[i % nb], 1e-5, mats["ln_l"], mats["ln_r"], s3, P)
+        k_o = lambda i: ops.block_quant(xa[i % nb], mats["o"], [s1], P)
+        k_ug = lambda i: ops.rmsnorm_kron_quant(x2[i % nb], 1e-5, mats["ug_l"], mats["ug_r"], s2, P)
+        k_dn = lambda i: ops.hadamard_quant(xf[i % nb], 28, mats["hadk"], s1)
+        self.kernels = [("rmsnorm+kron64 x3 clips (q/k/v)", k_qkv, rows * (2 * hid + 3 * (hid // 2 + 2))),
+                        ("block transform (o_proj)", k_o, rows * packed_bytes(hid)),
+                        ("rmsnorm+kron64 x2 clips (up/gate)", k_ug, rows * (2 * hid + 2 * (hid // 2 + 2))),
+                        ("hadamard 28x512 + Quantizer (down_proj)", k_dn, rows * packed_bytes(ffn))]
+
+        def step(i):
+            k_qkv(i), k_o(i), k_ug(i), k_dn(i)
+        self.step = step
+        self.elems = rows * (3 * hid + hid + 2 * hid + ffn)
+        self.config = {"workload": "C3: Llama-3-8B decoder layer, activation path of the 7 linears (RMSNorm+64x64 x3 clips, "
+                                   "o_proj head transform 128x32, RMSNorm+64x64 x2 clips, Hadamard 28x512 + Quantizer), "
+                                   "8x2048 tokens per GPU", "rows_per_gpu": rows, "launches_per_step": 4,
+                       "parallelism": f"rows x{world}"}
+
+
+class C4(Workload):
+    name = "C4"
+    metric = "Melems/s, Llama-2-70B shapes (d=8192, ffn=28672, 64 heads), activation path of all 80 layers, 8x2048 tokens total"
+    scaling = "strong"
+    graph = True
+
+    def __init__(self, device, rank, world, sharding, bcast):
+        from flatquant_amd import ops
+        from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED
+        hid, ffn, H, hd, layers = 8192, 28672, 64, 128, 80
+        a, b = sharding.shard_rows(ROWS, world, rank)
+        rows = b - a
+        nm = 4                                                   # matrix sets rotate over the layers (per-layer seeds)
+        mats = {}
+        for j in range(nm):
+            mats.update({f"ln_l{j}": make_matrix(64, 10 * j + 1, device), f"ln_r{j}": make_matrix(128, 10 * j + 2, device),
+                         f"ug_l{j}": make_matrix(64, 10 * j + 3, device), f"ug_r{j}": make_matrix(128, 10 * j + 4, device),
+                         f"o{j}": make_matrix(H, 10 * j + 5, device), f"dn_l{j}": make_matrix(128, 10 * j + 6, device),
+                         f"dn_r{j}": make_matrix(224, 10 * j + 7, device)})
+        mats = bcast(mats)
+        nb = max(2, min(8, (320 << 20) // max(1, rows * ffn * 2)))   # inputs rotate over > 256 MiB
+        xs = make_inputs(device, rank, rows, hid, nb)
+        xa = [x.reshape(rows, hd, H) for x in make_inputs(device, rank + 100, rows, hid, nb)]
+        xf = make_inputs(device, rank + 300, rows, ffn, nb)
+        s3, s2, s1 = [(SIG4, SIG4)] * 3, [(SIG4, SIG4)] * 2, [(SIG4, SIG4)]
+        P = FQ_OUT_PACKED | FQ_NO_CLAMP0
+        k_qkv = lambda i: ops.kron_quant(xs[i % nb], mats[f"ln_l{i % nm}"], mats[f"ln_r{i % nm}"], s3, P)
+        k_o = lambda i: ops.block_quant(xa[i % nb], mats[f"o{i % nm}"], s1, P)
+        k_ug = lambda i: ops.kron_quant(xs[(i + 1) % nb], mats[f"ug_l{i % nm}"], mats[f"ug_r{i % nm}"], s2, P)
+        k_dn = lambda i: ops.kron_quant(xf[i % nb], mats[f"dn_l{i % nm}"], mats[f"dn_r{i % nm}"], s1, P)
+        self.kernels = [("kron 64x128 x3 clips (q/k/v)", k_qkv, rows * (2 * hid + 3 * (hid // 2 + 2))),
+                        ("block transform 128x64 (o_proj)", k_o, rows * packed_bytes(hid)),
+                        ("kron 64x128 x2 clips (up/gate)", k_ug, rows * (2 * hid + 2 * (hid // 2 + 2))),
+                        ("kron 128x224 (down_proj)", k_dn, rows * packed_bytes(ffn))]
+
+        def step(i):
+            for layer in range(layers):
+                k_qkv(layer), k_o(layer), k_ug(layer), k_dn(layer)
+        self.step = step
+        self.elems = rows * layers * (3 * hid + hid + 2 * hid + ffn)
+        self.config = {"workload": "C4: Llama-2-70B shapes, 80 layers x (64x128 x3 clips, head transform 128x64, 64x128 x2 "
+                                   "clips, 128x224), 8x2048 tokens in total, rows sharded; one step = 320 launches replayed "
+                                   "from one captured HIP graph", "rows_per_gpu": rows, "layers": layers,
+                       "launches_per_step": 4 * layers, "parallelism": f"rows /{world}"}
+
+
+class C5(Workload):
+    name = "C5"
+    metric = "Melems/s, DeepSeek-V3 MoE expert inputs: w1_trans 64x112 (d=7168) + grouped 32x64 (2048) over 256 experts, top-8, 16384 tokens"
+    scaling = "strong"
+
+    def __init__(self, device, rank, world, sharding, bcast):
+        from flatquant_amd import ops
+        from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED
+        T, d1, d2, E, K = ROWS, 7168, 2048, 256, 8
+        # routing: seeded multinomial with Zipf-skewed expert popularity (SURVEY 8d), identical on every rank
+        g = torch.Generator().manual_seed(5)
+        pop = 1.0 / torch.arange(1, E + 1, dtype=torch.float64) ** 0.8
+        indices = torch.multinomial(pop[torch.randperm(E, generator=g)].expand(T, E), K, replacement=False, generator=g)
+        counts = torch.bincount(indices.flatten(), minlength=E)
+        e0, e1 = sharding.shard_rows(E, world, rank)             # EP-style: this rank owns experts [e0, e1)
+        t0, t1 = sharding.shard_rows(T, world, rank)             # and a row block of the shared w1_trans stage
+        offs = torch.zeros(e1 - e0 + 1, dtype=torch.int64)
+        offs[1:] = torch.cumsum(counts[e0:e1], 0)
+        rows2 = int(offs[-1])
+        mats = bcast({"l1": make_matrix(64, 1, device), "r1": make_matrix(112, 2, device),
+                      "l2": make_matrix(32, 3, device), "r2": make_matrix(64, 4, device)})
+        nb = 2
+        x1 = make_inputs(device, rank, t1 - t0, d1, nb)
+        x2 = make_inputs(device, rank + 50, rows2, d2, nb)
+        offs_d = offs.to(device)
+        gsig = torch.Generator().manual_seed(6)
+        smax = torch.sigmoid(torch.rand(e1 - e0, generator=gsig) * 4 + 1).float().to(device)   # per-expert clip pairs
+        smin = torch.sigmoid(torch.rand(e1 - e0, generator=gsig) * 4 + 1).float().to(device)
+        P = FQ_OUT_PACKED | FQ_NO_CLAMP0
+        k1 = lambda i: ops.kron_quant(x1[i % nb], mats["l1"], mats["r1"], [(SIG4, SIG4)], P)
+        k2 = lambda i: ops.kron_quant_grouped(x2[i % nb], mats["l2"], mats["r2"], offs_d, smax, smin, P)
+        self.kernels = [("kron 64x112 (w1_trans, all tokens)", k1, (t1 - t0) * packed_bytes(d1)),
+                        ("grouped kron 32x64 (routed_w2_trans, per-expert clips)", k2, rows2 * packed_bytes(d2))]
+
+        def step(i):
+            k1(i), k2(i)
+        self.step = step
+        self.elems = (t1 - t0) * d1 + rows2 * d2
+        self.config = {"workload": "C5: DeepSeek-V3 MoE, 16384 tokens d=7168 through w1_trans (64x112) + 8 x 16384 routed "
+                                   "hidden rows of 2048 in 256 expert groups (Zipf routing) through the grouped 32x64 launch",
+                       "tokens_this_rank": t1 - t0, "grouped_rows_this_rank": rows2, "experts_this_rank": e1 - e0,
+                       "largest_group": int(counts.max()), "empty_groups": int((counts == 0).sum()),
+                       "launches_per_step": 2, "parallelism": f"experts+tokens /{world}"}
+
+
+WORKLOADS = {"C2": C2, "C3": C3, "C4": C4, "C5": C5}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed clock-settle phase before the counted warm-up: launches of the same step for this "
                          "many milliseconds (reported as settle_launches); 0 disables it")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"C2": 1000, "C3": 100, "C4": 5, "C5": 50}[args.config]
+    if args.warmup is None:
+        args.warmup = {"C2": 200, "C3": 10, "C4": 2, "C5": 5}[args.config]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -127,49 +352,32 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)   # RCCL
 
-    from flatquant_amd import ops, sharding
-    from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED
-
-    mats = make_matrices(device) if rank == 0 else {
-        "left": torch.empty(M, M, dtype=torch.float16, device=device),
-        "right": torch.empty(N, N, dtype=torch.float16, device=device)}
-    mats = sharding.broadcast_matrices(mats, src=0)         # the only collective on the path (set-up time)
-    left, right = mats["left"].contiguous(), mats["right"].contiguous()
-    sig = [ops.sigmoid_pair(4.0, 4.0)]
-    xs = make_inputs(device, seed=rank)
-    flags = FQ_OUT_PACKED | FQ_NO_CLAMP0                    # deploy OnlineTrans(matmul) contract
-
-    # pre-allocated rotating outputs; the timed region calls the C ABI directly (no allocator in the loop)
-    import ctypes
-    from flatquant_amd._lib import check, lib
-    qs = [torch.empty(ROWS, D // 2, dtype=torch.uint8, device=device) for _ in range(N_BUF)]
-    ss = [torch.empty(ROWS, dtype=torch.float16, device=device) for _ in range(N_BUF)]
-    smax = (ctypes.c_float * 4)(sig[0][0]); smin = (ctypes.c_float * 4)(sig[0][1])
+    from flatquant_amd import sharding
+    wl = WORKLOADS[args.config](device, rank, world, sharding, lambda m: sharding.broadcast_matrices(m, src=0))
     stream = torch.cuda.current_stream(device)
-    sp = ctypes.c_void_p(stream.cuda_stream)
-
-    def arr(t):
-        a = (ctypes.c_void_p * 4)()
-        a[0] = t.data_ptr()
-        return a
-    calls = [(ctypes.c_void_p(xs[i].data_ptr()), arr(qs[i]), arr(ss[i])) for i in range(N_BUF)]
-    lp, rp = ctypes.c_void_p(left.data_ptr()), ctypes.c_void_p(right.data_ptr())
-    none4 = (ctypes.c_void_p * 4)()
-
-    def step(i):
-        xp, qa, sa = calls[i % N_BUF]
-        check(lib.fq_kron_quant_f16(xp, lp, rp, None, ROWS, M, N, smax, smin, 1, flags, qa, sa, none4, None, None, 0, sp))
+    step = wl.step
+    if wl.graph:
+        # launch-bound step (hundreds of short launches): capture it once, replay it (HIP graph); the captured launches
+        # read rotating inputs selected by the Python-side index at capture time, so one graph = one fixed step
+        step(0)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            wl.step(0)
+        step = lambda i: graph.replay()
+        stream = torch.cuda.current_stream(device)
 
     # Declared, UNTIMED clock-settle phase: the part needs tens of milliseconds of load before its clocks and power
     # state reach steady state (the first ~100 launches of a cold process run 10-20 % slow); a 20-step run otherwise
     # measures the ramp, not the kernel. Not part of --warmup, not part of the timed region; reported below.
     settle_launches = 0
     if args.settle_ms > 0:
+        chunk = 64 if args.config == "C2" else 1
         t_settle = time.perf_counter()
         while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
-            for i in range(64):
+            for i in range(chunk):
                 step(i)
-            settle_launches += 64
+            settle_launches += chunk
             torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
@@ -188,9 +396,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps             # average launch duration from HIP events
+    kern_ms = ev0.elapsed_time(ev1) / args.steps             # average step duration from HIP events
 
-    # Per-launch distribution (the reference's own quantiles, deploy/kernels/kron_matmul.py:269-281): a SEPARATE
+    # Per-step distribution (the reference's own quantiles, deploy/kernels/kron_matmul.py:269-281): a SEPARATE
     # untimed pass of the same K steps with one event pair per step, so that the timed region above carries no
     # event markers between its launches. median / p20 / p80 in microseconds.
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -203,45 +411,57 @@ def main():
     quant = lambda f: per[min(len(per) - 1, int(f * len(per)))]
     per_launch = {"median_us": quant(0.5), "p20_us": quant(0.2), "p80_us": quant(0.8), "min_us": per[0], "max_us": per[-1]}
 
-    # practical HBM floor: the same bytes (8 KB in, 2 KB + 2 B out per token) moved by a no-arithmetic kernel
-    floor_us = None
-    if rank == 0:
-        for i in range(5):
-            ops.probe_stream_4096(xs[i % N_BUF], qs[i % N_BUF], ss[i % N_BUF])
+    # the individual launches of a step, each timed back to back on its own (HIP events): names the dominant kernel
+    kern_us = []
+    for name, fn, nbytes in wl.kernels:
+        reps = max(10, min(200, args.steps))
+        for i in range(3):
+            fn(i)
         torch.cuda.synchronize()
-        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        f0.record(stream)
-        for i in range(50):
-            ops.probe_stream_4096(xs[i % N_BUF], qs[i % N_BUF], ss[i % N_BUF])
-        f1.record(stream)
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record(torch.cuda.current_stream(device))
+        for i in range(reps):
+            fn(i)
+        k1.record(torch.cuda.current_stream(device))
         torch.cuda.synchronize()
-        floor_us = f0.elapsed_time(f1) / 50 * 1e3
+        kern_us.append((name, k0.elapsed_time(k1) / reps * 1e3, nbytes))
+    floor_us = wl.floor_us(stream) if (rank == 0 and hasattr(wl, "floor_us")) else None
 
     t = torch.tensor([wall, kern_ms], dtype=torch.float64, device=device)
+    elems = torch.tensor([float(wl.elems)], dtype=torch.float64, device=device)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)             # MAX over ranks
+        dist.all_reduce(elems, op=dist.ReduceOp.SUM)         # units all ranks processed
     wall, kern_ms = float(t[0]), float(t[1])
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
-        value = world * ROWS * D / (wall / args.steps) / 1e6
-        achieved = ROWS * BYTES_PER_TOKEN / (kern_ms * 1e-3) / 1e9
+        value = float(elems[0]) / (wall / args.steps) / 1e6
+        if args.config == "C2":                              # one launch per step: the timed region IS the kernel
+            dom_name, dom_us, dom_bytes = wl.kernels[0][0], kern_ms * 1e3, wl.kernels[0][2]
+        else:
+            dom_name, dom_us, dom_bytes = max(kern_us, key=lambda k: k[1])
+        achieved = dom_bytes / (dom_us * 1e-6) / 1e9
         out = {
-            "metric": "Melems/s for fused kron-transform+INT4-quant, Llama-3-8B d=4096, bs×seq=8×2048",
-            "value": value, "unit": "Melem/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic", "settle_launches": settle_launches, "settle_ms": args.settle_ms,
-            "config": {"workload": "C2: Llama-3-8B single linear (q_proj input), d=4096 = 64x64 Kronecker, "
-                                   "8x2048 tokens per GPU, packed INT4 + fp16 scale out",
-                       "rows_per_gpu": ROWS, "d": D, "factors": [M, N], "parallelism": f"rows x{world}"},
+            "metric": wl.metric, "value": value, "unit": "Melem/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": wl.scaling,
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic", "settle_launches": settle_launches,
+            "settle_ms": args.settle_ms, "config": wl.config,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
-                         "kernel": "fq_kron64_kernel", "algorithmic_bytes_per_launch": ROWS * BYTES_PER_TOKEN,
-                         "launch_us": kern_ms * 1e3, "per_launch": per_launch, "hbm_stream_floor_us": floor_us,
-                         "frac_of_stream_floor": (floor_us / (kern_ms * 1e3)) if floor_us else None},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if args.config == "C2" else None,
+                         "kernel": dom_name, "algorithmic_bytes_per_launch": dom_bytes,
+                         "launch_us": dom_us, "per_launch": per_launch, "hbm_stream_floor_us": floor_us,
+                         "frac_of_stream_floor": (floor_us / dom_us) if floor_us else None},
         }
+        if args.config != "C2":
+            step_bytes = sum(k[2] for k in wl.kernels) * (wl.config.get("layers", 1))
+            out["roofline"]["step"] = {"algorithmic_bytes": step_bytes, "step_us": kern_ms * 1e3,
+                                       "frac": step_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            out["roofline"]["kernels"] = [{"kernel": n, "launch_us": u, "algorithmic_bytes": b,
+                                           "frac": b / (u * 1e-6) / 1e9 / HBM_PEAK_GBS} for n, u, b in kern_us]
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(*{"C2": (20.0, 64, 64), "C3": (20.0, 64, 64), "C4": (20.0, 64, 128),
+                                                 "C5": (20.0, 32, 64)}[args.config])
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
