@@ -146,61 +146,7 @@ __device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok
         : "memory");
 }
 
-// The quantiser of the packed output: one asm block per dword (8 elements), single-width VALU only.
-// v_pk_fma_f32 / v_pk_add_f32 (what hipcc's SLP vectoriser makes of fq_qmagic2 / fq_pack8p in fq_common.hpp) slow a
-// SIMD down next to another wave's MFMAs (tools/scratch/phase_overlap.hip: MFMA phase + pk phase take MORE than their
-// sum, single-width VALU hides a third of the MFMA time) and each one drags a hazard s_nop along; the C++ form of
-// single-width arithmetic (-fno-slp-vectorize) is scheduled into 72 spilled VGPRs at this kernel's 128-register cap.
-// Here the six temporaries are all there is.
-//
-// The exactness proof, two-sided. The pinned result is q = rint(fl(y / s)) with a correctly rounded division.
-// With ilo = inv (1 - 2^-21) and ihi = inv (1 + 2^-21)
-// (inv = v_rcp_f32(s), 1 ulp), both the true quotient y/s and its fp32 rounding fl(y/s) lie between the exact products
-// y*ilo and y*ihi (relative slack 2^-21 against 2^-23 + 2^-24 + 2^-24 of rcp, the rounding of ilo/ihi and of the
-// quotient). u = fma(y, ilo, MAGIC) and v = fma(y, ihi, MAGIC) are those products rounded to integers, once, half to
-// even, and rint is monotone: u == v  =>  rint(fl(y/s)) == u. The integer r sits in the low mantissa bits of u
-// (bits(u) = 0x4B400000 + r, two's complement), so the eight digits are combined by integer Horner steps
-// v_lshl_add_u32 on the raw bits of u and of v; the MAGIC exponent bits fall out of the dword except for the
-// constant K = 0x3F400000, (acc - K + 0x88888888) ^ 0x88888888 is the two's-complement nibble string (offset
-// binary r + 8 per digit, then the XOR), and ONE v_cmp_ne of the two dwords says whether any of the eight digits
-// was ambiguous (then the caller redoes that dword with the true division). CLAMP: med3 on u, v as floats.
-template <bool CLAMP>
-__device__ __forceinline__ uint32_t quant8_two(float y0, float y1, float y2, float y3, float y4, float y5, float y6,
-                                               float y7, float ilo, float ihi, unsigned long long& differ) {
-    uint32_t a, b;
-    float t0, s0, t1, s1;
-    const float magic = FQ_MAGIC;
-    const float lo8 = FQ_MAGIC - 8.0f;
-    float hi7 = FQ_MAGIC + 7.0f;
-    if (CLAMP) asm volatile("" : "+v"(hi7));
-#define FQ_UV(t, s, y) "v_fma_f32 %[" #t "], %[" #y "], %[ilo], %[mg]\n\tv_fma_f32 %[" #s "], %[" #y "], %[ihi], %[mg]\n\t"
-#define FQ_CL(t, s) "v_med3_f32 %[" #t "], %[" #t "], %[lo8], %[hi7]\n\tv_med3_f32 %[" #s "], %[" #s "], %[lo8], %[hi7]\n\t"
-#define FQ_HN(t, s) "v_lshl_add_u32 %[a], %[a], 4, %[" #t "]\n\tv_lshl_add_u32 %[b], %[b], 4, %[" #s "]\n\t"
-#define FQ_TAIL "v_cmp_ne_u32_e64 %[m], %[a], %[b]\n\tv_add_u32_e32 %[a], 0x49488888, %[a]\n\tv_xor_b32_e32 %[a], 0x88888888, %[a]"
-#define FQ_OUTS [a] "=&v"(a), [b] "=&v"(b), [t0] "=&v"(t0), [s0] "=&v"(s0), [t1] "=&v"(t1), [s1] "=&v"(s1), [m] "=&s"(differ)
-#define FQ_INS [y0] "v"(y0), [y1] "v"(y1), [y2] "v"(y2), [y3] "v"(y3), [y4] "v"(y4), [y5] "v"(y5), [y6] "v"(y6), \
-               [y7] "v"(y7), [ilo] "v"(ilo), [ihi] "v"(ihi), [mg] "s"(magic)
-    if (CLAMP)
-        asm(FQ_UV(a, b, y7) FQ_UV(t0, s0, y6) FQ_CL(a, b) FQ_UV(t1, s1, y5) FQ_CL(t0, s0) FQ_HN(t0, s0)
-            FQ_UV(t0, s0, y4) FQ_CL(t1, s1) FQ_HN(t1, s1) FQ_UV(t1, s1, y3) FQ_CL(t0, s0) FQ_HN(t0, s0)
-            FQ_UV(t0, s0, y2) FQ_CL(t1, s1) FQ_HN(t1, s1) FQ_UV(t1, s1, y1) FQ_CL(t0, s0) FQ_HN(t0, s0)
-            FQ_UV(t0, s0, y0) FQ_CL(t1, s1) FQ_HN(t1, s1) FQ_CL(t0, s0) FQ_HN(t0, s0) FQ_TAIL
-            : FQ_OUTS
-            : FQ_INS, [lo8] "s"(lo8), [hi7] "v"(hi7));
-    else
-        asm(FQ_UV(a, b, y7) FQ_UV(t0, s0, y6) FQ_UV(t1, s1, y5) FQ_HN(t0, s0) FQ_UV(t0, s0, y4) FQ_HN(t1, s1)
-            FQ_UV(t1, s1, y3) FQ_HN(t0, s0) FQ_UV(t0, s0, y2) FQ_HN(t1, s1) FQ_UV(t1, s1, y1) FQ_HN(t0, s0)
-            FQ_UV(t0, s0, y0) FQ_HN(t1, s1) FQ_HN(t0, s0) FQ_TAIL
-            : FQ_OUTS
-            : FQ_INS);
-#undef FQ_UV
-#undef FQ_CL
-#undef FQ_HN
-#undef FQ_TAIL
-#undef FQ_OUTS
-#undef FQ_INS
-    return a;
-}
+// (the asm quantiser fq_quant8_two lives in fq_common.hpp: shared with the other Kronecker kernels)
 
 // Quantise + pack one token's fragment: fills the 2 x 4 dwords this lane stores and returns the mask of dwords
 // (bit 4*mo + w) in which some lane of the wave saw an ambiguous digit (to be redone with the true division).
@@ -216,7 +162,7 @@ __device__ __forceinline__ unsigned quant_pack_token(const f32x16 (&Y)[2][2], co
             const f32x16& t = Y[w >> 1][mo];
             const int b = (w & 1) * 8;
             unsigned long long differ;
-            pw[mo][w] = quant8_two<CLAMP>(t[b + 0], t[b + 1], t[b + 2], t[b + 3], t[b + 4], t[b + 5], t[b + 6],
+            pw[mo][w] = fq_quant8_two<CLAMP>(t[b + 0], t[b + 1], t[b + 2], t[b + 3], t[b + 4], t[b + 5], t[b + 6],
                                           t[b + 7], ilo, ihi, differ);
             near |= differ ? (1u << (4 * mo + w)) : 0u;  // SALU only
         }

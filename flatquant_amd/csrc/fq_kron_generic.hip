@@ -546,6 +546,30 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                 for (int mo = 0; mo < MT; ++mo) {
                     const bool ok = nt < NT && n0 < N && (mo * 32 + c) < M;
                     const f32x16& yv = Y[t][mo];
+                    if (CTF == FQ_OUT_PACKED && !(flags & 0x2000)) {
+                        // packed-only instantiations: the single-width asm quantiser (fq_quant8_two, fq_common.hpp) — no
+                        // v_pk_*_f32 next to the other wave's MFMAs, no per-element residual bookkeeping
+                        uint2 pk = {0u, 0u};
+                        unsigned long long d0 = ~0ull, d1 = ~0ull;
+                        if (magic) {
+                            const float ilo = fq_inv_lo(inv), ihi = fq_inv_hi(inv);
+                            if (clampq) {
+                                pk.x = fq_quant8_two<true>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], ilo, ihi, d0);
+                                pk.y = fq_quant8_two<true>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], ilo, ihi, d1);
+                            } else {
+                                pk.x = fq_quant8_two<false>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], ilo, ihi, d0);
+                                pk.y = fq_quant8_two<false>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], ilo, ihi, d1);
+                            }
+                        }
+                        if (d0)  // rare: an ambiguous digit somewhere in the wave -> the true division for this dword
+                            pk.x = fq_pack8(fq_qexact(yv[0], scale), fq_qexact(yv[1], scale), fq_qexact(yv[2], scale), fq_qexact(yv[3], scale),
+                                            fq_qexact(yv[4], scale), fq_qexact(yv[5], scale), fq_qexact(yv[6], scale), fq_qexact(yv[7], scale));
+                        if (d1)
+                            pk.y = fq_pack8(fq_qexact(yv[8], scale), fq_qexact(yv[9], scale), fq_qexact(yv[10], scale), fq_qexact(yv[11], scale),
+                                            fq_qexact(yv[12], scale), fq_qexact(yv[13], scale), fq_qexact(yv[14], scale), fq_qexact(yv[15], scale));
+                        if (ok) *reinterpret_cast<uint2*>(obuf + (mo * 32 + c) * (N >> 1) + (n0 >> 1)) = pk;
+                        continue;
+                    }
                     f32x2 qp[8];  // integer-valued pairs (r_2j, r_2j+1)
                     bool exact = !magic;
                     if (flags & 0x2000) {

@@ -40,22 +40,22 @@ struct WaveGeom {
     static constexpr int STORES = MT * (NPAIR + ((V1 % 32) == 16 ? 1 : 0)) + 1;  // VMEM stores per token and clip
 };
 
-// Magic-number quantiser over one output row group (mo) of a lane: NT * 2 packed dwords + their residual maxima.
+// The single-width asm quantiser (fq_quant8_two, fq_common.hpp) over one output row group (mo) of a lane: NT * 2 packed
+// dwords; returns the mask of dwords in which some lane of the wave saw an ambiguous digit (redone with the true division).
 template <bool CLAMP, int NT, int MT>
-__device__ __forceinline__ void quant_row(const f32x16 (&Y)[NT][MT], int mo, f32x2 inv2, uint32_t (&pw)[NT * 2],
-                                          float (&dm)[NT * 2]) {
+__device__ __forceinline__ unsigned quant_row(const f32x16 (&Y)[NT][MT], int mo, float inv, uint32_t (&pw)[NT * 2]) {
+    const float ilo = fq_inv_lo(inv), ihi = fq_inv_hi(inv);
+    unsigned near = 0;
 #pragma unroll
     for (int k = 0; k < NT * 2; ++k) {
         const f32x16& t = Y[k >> 1][mo];
         const int b = (k & 1) * 8;
-        float dmax = 0.0f;
-        const f32x2 q0 = fq_qmagic2<CLAMP>(f32x2{t[b + 0], t[b + 1]}, inv2, dmax);
-        const f32x2 q1 = fq_qmagic2<CLAMP>(f32x2{t[b + 2], t[b + 3]}, inv2, dmax);
-        const f32x2 q2 = fq_qmagic2<CLAMP>(f32x2{t[b + 4], t[b + 5]}, inv2, dmax);
-        const f32x2 q3 = fq_qmagic2<CLAMP>(f32x2{t[b + 6], t[b + 7]}, inv2, dmax);
-        pw[k] = fq_pack8p(q0, q1, q2, q3);
-        dm[k] = dmax;
+        unsigned long long differ;
+        pw[k] = fq_quant8_two<CLAMP>(t[b + 0], t[b + 1], t[b + 2], t[b + 3], t[b + 4], t[b + 5], t[b + 6], t[b + 7], ilo, ihi,
+                                     differ);
+        near |= differ ? (1u << k) : 0u;
     }
+    return near;
 }
 
 template <int MT, int NT, int KS1, int W>
@@ -255,24 +255,16 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
                     if (h == 0 && !(c & 1) && (mo * 32 + c) < M)
                         out.scale[ci][tok * (int64_t)(M * N / 128) + ((mo * 32 + c) >> 1)] = (f16)scale;
                 }
-                const f32x2 inv2 = {inv, inv};
                 uint32_t pw[NT * 2];  // dword nt*2 + w: elements n' = h*NT*16 + nt*16 + 8w .. +8 of row 32 mo + c
-                float dm[NT * 2];     // per dword: max |residual| of the magic-number rounding
-#pragma unroll
-                for (int k = 0; k < NT * 2; ++k) dm[k] = 0.0f;
+                unsigned near = (1u << (NT * 2)) - 1;  // !magic: quotients too large for the magic-number rounding
                 if (magic) {
-                    if (clampq) quant_row<true, NT, MT>(Y, mo, inv2, pw, dm);
-                    else quant_row<false, NT, MT>(Y, mo, inv2, pw, dm);
+                    if (clampq) near = quant_row<true, NT, MT>(Y, mo, inv, pw);
+                    else near = quant_row<false, NT, MT>(Y, mo, inv, pw);
                 }
-                // ONE wave-wide test per output row group instead of one per dword (each costs a VALU -> SALU round
-                // trip); the per-dword tests only run on the rare row that has a quotient within FQ_NEAR of a tie
-                float dall = dm[0];
-#pragma unroll
-                for (int k = 1; k < NT * 2; k += 2) dall = fq_max3(dall, dm[k], k + 1 < NT * 2 ? dm[k + 1] : dm[k]);
-                if (!magic || fq_wave_needs_exact(dall)) {
+                if (near) {  // rare: redo the flagged dwords with the true division
 #pragma unroll
                     for (int k = 0; k < NT * 2; ++k) {
-                        if (!magic || fq_wave_needs_exact(dm[k])) {
+                        if (near & (1u << k)) {
                             const f32x16& t = Y[k >> 1][mo];
                             const int b = (k & 1) * 8;
                             pw[k] = fq_pack8p(f32x2{fq_qexact(t[b + 0], scale), fq_qexact(t[b + 1], scale)},
