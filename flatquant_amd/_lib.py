@@ -41,6 +41,7 @@ SYMBOLS = {
     "fq_kron_quant_f16": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp, _i64,
                                _vp]),
     "fq_kron_quant_grouped_f16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "fq_kron_quant_ex_f16": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp, _i64, _vp]),
     "fq_kron_workspace_bytes": (_i64, [_i, _i]),
     "fq_kron_prepare_f16": (_i, [_vp, _vp, _i, _i, _vp, _i64, _vp]),
     "fq_rmsnorm_kron_quant_f16": (_i, [_vp, _f, _vp, _vp, _i64, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp]),

@@ -270,6 +270,31 @@ int fq_silu_mul_kron_quant_f16(const void* gate, const void* up, const void* lef
     return check_launch(rc, "fq_silu_mul_kron_quant_f16");
 }
 
+int fq_kron_quant_ex_f16(const void* x, const void* up, const void* left, const void* right, int64_t rows, int M, int N,
+                         float post_scale, const float* sig_max, const float* sig_min, int n_clips, int flags,
+                         void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                         void* workspace, int64_t workspace_bytes, void* stream) {
+    const char* what = "fq_kron_quant_ex_f16";
+    if (rows < 0 || M <= 0 || N <= 0 || (N & 1)) return fail(FQ_EINVAL, "%s: bad sizes rows=%lld M=%d N=%d", what, (long long)rows, M, N);
+    if (!(post_scale > 0.0f) || !(post_scale < 3.0e38f)) return fail(FQ_EINVAL, "%s: post_scale must be a positive finite number", what);
+    FqQuantOut o;
+    int rc = fill_out(what, o, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out, y_out);
+    if (rc != FQ_OK) return rc;
+    if (rows == 0) return FQ_OK;
+    if (!x || !left || !right) return fail(FQ_EINVAL, "%s: x/left/right is NULL", what);
+    o.post_scale = post_scale == 1.0f ? 0.0f : post_scale;
+    o.in2 = (const f16*)up;
+    // the scaled / SiLU.mul forms live in the workgroup-per-token kernel family only (the shapes this entry exists for:
+    // M > 64, e.g. a Hadamard rotation of n = K * P as the Kronecker product (hadK x H_{P/N}) (x) H_N)
+    rc = fq_launch_kron_generic(flags | (up ? FQ_IN_SILU_MUL : 0) | FQ_NO_WAVE_KERNEL, (const f16*)x, (const f16*)left, (const f16*)right,
+                                nullptr, rows, M, N, o, workspace, workspace_bytes, cu_count(), (hipStream_t)stream);
+    if (rc == -1001)
+        return fail(FQ_EINVAL, "%s: workspace of %lld bytes required for M=%d N=%d (got %lld)", what,
+                    (long long)fq_kron_generic_workspace_bytes(M, N), M, N, (long long)(workspace ? workspace_bytes : 0));
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "%s: no kernel for M=%d N=%d with flags 0x%x", what, M, N, flags);
+    return check_launch(rc, what);
+}
+
 int fq_silu_mul_f16(const void* gate, const void* up, void* y, int64_t n, void* stream) {
     if (n < 0) return fail(FQ_EINVAL, "fq_silu_mul_f16: n < 0");
     if (n == 0) return FQ_OK;

@@ -37,6 +37,8 @@ struct FqQuantOut {
     const float*   sig_max_g;      // device, [n_groups]
     const float*   sig_min_g;      // device, [n_groups]
     int            n_groups;
+    float          post_scale;     // != 0: the transformed activation is multiplied by it (fp32) before rounding / statistics
+                                   // (fq_kron_quant_ex_f16: a normalisation that fp16 factor matrices cannot carry exactly)
 };
 
 // Clip pair of token `tok` (wave-uniform): the launch-wide pair `ci`, or the pair of the token's group. A wave walks its
@@ -86,6 +88,8 @@ __device__ __forceinline__ void fq_token_sigs(const FqQuantOut& out, int ci, int
             fq_done_ |= 1ull << (fq_dev_ & 63);                                                                     \
         }                                                                                                           \
     } while (0)
+
+constexpr int FQ_NO_WAVE_KERNEL = 0x40000000;  // internal (launcher to launcher): skip the wave-per-token kernels
 
 // Flags that select a compile-time kernel specialisation; the rest travel in FqQuantOut::rt_flags.
 constexpr int FQ_CT_MASK = FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_QUANT_F16 | FQ_IN_RMSNORM;

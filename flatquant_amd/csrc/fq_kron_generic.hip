@@ -299,7 +299,7 @@ template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CT
 __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fast_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
                                                            const f16* __restrict__ diag, int64_t rows, int M, int /*N*/,
                                                            FqQuantOut out, int flags_rt) {
-    const int flags = CTF >= 0 ? (CTF | (flags_rt & (FQ_ROUND_Y_F16 | FQ_NO_CLAMP0 | 0xF000))) : flags_rt;
+    const int flags = CTF >= 0 ? (CTF | (flags_rt & (FQ_ROUND_Y_F16 | FQ_NO_CLAMP0 | FQ_SIG_F16 | 0xF000))) : flags_rt;
     constexpr int N = KS1 * 16;                    // N % 16 == 0 is a precondition, so KS1 fixes N
     constexpr int THREADS = WAVES * 64;
     constexpr int TPW = (NT + WAVES - 1) / WAVES;  // n'-tiles per wave
@@ -461,6 +461,15 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                 }
             }
         }
+        if (out.post_scale != 0.0f) {  // (fq_kron_quant_ex_f16: e.g. the 1/sqrt(n) of a Hadamard rotation run as a Kronecker product)
+            const float ps = out.post_scale;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Y[t][mo][r] *= ps;
+        }
         if (flags & FQ_ROUND_Y_F16) {
 #pragma unroll
             for (int t = 0; t < TPW; ++t)
@@ -567,6 +576,23 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                         if (d1)
                             pk.y = fq_pack8(fq_qexact(yv[8], scale), fq_qexact(yv[9], scale), fq_qexact(yv[10], scale), fq_qexact(yv[11], scale),
                                             fq_qexact(yv[12], scale), fq_qexact(yv[13], scale), fq_qexact(yv[14], scale), fq_qexact(yv[15], scale));
+                        if (ok) *reinterpret_cast<uint2*>(obuf + (mo * 32 + c) * (N >> 1) + (n0 >> 1)) = pk;
+                        continue;
+                    }
+                    if (CTF == (FQ_OUT_PACKED | FQ_QUANT_F16) && !(flags & 0x2000)) {
+                        // packed-only instantiations with the fp16 (deploy Quantizer) arithmetic: Y is an fp16 value here
+                        // (FQ_ROUND_Y_F16 is part of that contract), so x / scale is the native _Float16 division
+                        // (correctly rounded, tools/scratch/h16div.hip), not the fp32 division + rounding of fq_quant1
+                        const f16 s16 = (f16)scale;
+                        float r[16];
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const f16 tq = (f16)yv[e] / s16;
+                            r[e] = __builtin_amdgcn_fmed3f(__builtin_rintf((float)tq), -8.0f, 7.0f);
+                        }
+                        uint2 pk;
+                        pk.x = fq_pack8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+                        pk.y = fq_pack8(r[8], r[9], r[10], r[11], r[12], r[13], r[14], r[15]);
                         if (ok) *reinterpret_cast<uint2*>(obuf + (mo * 32 + c) * (N >> 1) + (n0 >> 1)) = pk;
                         continue;
                     }
@@ -706,9 +732,12 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream) {
     if ((N & 15) || M < 1 || M > 128 || N > 256 || ((M * N / 2) & 15)) return -1000;
+    const bool no_wave = (flags & FQ_NO_WAVE_KERNEL) != 0 || out.post_scale != 0.0f;  // (the wave kernels take no post_scale)
+    flags &= ~FQ_NO_WAVE_KERNEL;
     if (flags & FQ_IN_SILU_MUL) {  // fused for the down_proj shapes only; said before any workspace complaint
         const int mt = tiles32(M), nt = tiles32(N), ks = (N + 15) / 16;
-        if (!((mt == 4 && nt == 4 && ks == 8) || (mt == 3 && nt == 4 && ks == 8) || (mt == 4 && nt == 7 && ks == 14)))
+        if (!((mt == 4 && nt == 4 && ks == 8) || (mt == 3 && nt == 4 && ks == 8) || (mt == 4 && nt == 7 && ks == 14) ||
+              (mt == 4 && nt == 8 && ks == 16)))
             return -1000;
     }
     if (!workspace || workspace_bytes < fq_kron_generic_workspace_bytes(M, N)) return -1001;
@@ -732,13 +761,15 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
     if (MT == MT_ && NT == NT_ && g.KS1 == KS1_) {                                                              \
         if ((flags & FQ_CT_MASK) == FQ_OUT_PACKED && !fq_measure_env("FQ_KRON_NO_CTF"))                                 \
             return launch_fast<MT_, NT_, KS1_, W_, OCC_, true, FQ_OUT_PACKED>(flags, x, ws, diag, rows, M, N, out, n_cu, stream); \
+        if ((flags & FQ_CT_MASK) == (FQ_OUT_PACKED | FQ_QUANT_F16) && (flags & FQ_ROUND_Y_F16))                         \
+            return launch_fast<MT_, NT_, KS1_, W_, OCC_, true, FQ_OUT_PACKED | FQ_QUANT_F16>(flags, x, ws, diag, rows, M, N, out, n_cu, stream); \
         return launch_fast<MT_, NT_, KS1_, W_, OCC_, true>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);  \
     }
-        FQ_FS(4, 4, 8, 4, 2) FQ_FS(3, 4, 8, 4, 2) FQ_FS(4, 7, 14, 8, 1)
+        FQ_FS(4, 4, 8, 4, 2) FQ_FS(3, 4, 8, 4, 2) FQ_FS(4, 7, 14, 8, 1) FQ_FS(4, 8, 16, 8, 1)
 #undef FQ_FS
         return -1000;
     }
-    if (!fq_measure_env("FQ_KRON_NO_WAVE")) {  // one wave per token where a token fits a wave (packed output only)
+    if (!no_wave && !fq_measure_env("FQ_KRON_NO_WAVE")) {  // one wave per token where a token fits a wave (packed output only)
         rc = fq_launch_kron_wave(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }
@@ -751,6 +782,8 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
     if (MT == MT_ && NT == NT_ && g.KS1 == KS1_) {                                                       \
         if (MT_ >= 3 && (flags & FQ_CT_MASK) == FQ_OUT_PACKED && !fq_measure_env("FQ_KRON_NO_CTF"))              \
             rc = launch_fast<MT_, NT_, KS1_, W_, OCC_, false, (MT_ >= 3 ? FQ_OUT_PACKED : -1)>(flags, x, ws, diag, rows, M, N, out, n_cu, stream); \
+        else if (MT_ >= 3 && (flags & FQ_CT_MASK) == (FQ_OUT_PACKED | FQ_QUANT_F16) && (flags & FQ_ROUND_Y_F16)) \
+            rc = launch_fast<MT_, NT_, KS1_, W_, OCC_, false, (MT_ >= 3 ? (FQ_OUT_PACKED | FQ_QUANT_F16) : -1)>(flags, x, ws, diag, rows, M, N, out, n_cu, stream); \
         else                                                                                             \
             rc = launch_fast<MT_, NT_, KS1_, W_, OCC_>(flags, x, ws, diag, rows, M, N, out, n_cu, stream); \
         if (rc != -1000) return rc;                                                                      \
@@ -762,10 +795,11 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
 #define FQ_GEN_W2 4
 #endif
         FQ_F(2, 4, 8, FQ_GEN_W2, FQ_GEN_OCC2) FQ_F(4, 4, 8, 4, 2) FQ_F(3, 4, 8, 4, 2) FQ_F(4, 7, 14, 8, 1) FQ_F(2, 4, 7, FQ_GEN_W2, FQ_GEN_OCC2)
+        FQ_F(4, 8, 16, 8, 1)  // 112 x 256: the Hadamard rotation of 28672 = (28 x 4) x 256 as a Kronecker product
         FQ_F(1, 2, 4, 4, 4) FQ_F(2, 2, 4, 4, FQ_GEN_OCC2) FQ_F(2, 3, 5, 4, FQ_GEN_OCC2)
 #undef FQ_F
     }
-    if (out.group_offsets != nullptr) return -1000;  // (the first-generation kernel below takes no group arrays)
+    if (out.group_offsets != nullptr || out.post_scale != 0.0f) return -1000;  // (the first-generation kernel below takes neither)
 #define FQ_G(MT_, NT_)                                                                                   \
     if (MT == MT_ && NT == NT_)                                                                          \
         return launch_generic<MT_, NT_>(flags, x, ws, diag, rows, g, out, n_cu, stream);

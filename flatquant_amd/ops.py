@@ -203,6 +203,70 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
     return o
 
 
+def kron_quant_ex(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, post_scale: float = 1.0,
+                  sigs: Sequence[Sig] = ((1.0, 1.0),), flags: int = FQ_OUT_PACKED, up: Optional[torch.Tensor] = None) -> FusedOutputs:
+    """fq_kron_quant_ex_f16: fq_kron_quant_f16 whose transformed activation is multiplied by ``post_scale`` (fp32) before
+    rounding / quantisation, optionally with x = gate and the transform's input fp16(up * fp16(silu(gate)))."""
+    _chk(x, "x"), _chk(left, "left"), _chk(right, "right")
+    if up is not None:
+        _chk(up, "up")
+        if up.shape != x.shape:
+            raise ValueError("up must have x's shape")
+    M, N = left.shape[0], right.shape[0]
+    d = M * N
+    if x.shape[-1] != d or left.shape != (M, M) or right.shape != (N, N):
+        raise ValueError("shape mismatch between x, left and right")
+    rows = x.numel() // d
+    smax, smin, n = _sig_arrays(sigs)
+    o = _alloc_outputs(x, rows, d, n, flags, x.shape[:-1] + (d // 2,), x.shape)
+    if rows == 0:
+        return o
+    with torch.cuda.device(x.device):
+        ws, ws_bytes, prepared, key = _kron_workspace(x.device, M, N, left, right)
+        check(lib.fq_kron_quant_ex_f16(_ptr(x), _ptr(up), _ptr(left), _ptr(right), rows, M, N, ctypes.c_float(post_scale), smax,
+                                       smin, n, flags | (FQ_WS_PREPARED if prepared else 0), _ptr_array(o.q),
+                                       _ptr_array(o.scale), _ptr_array(o.fq), _ptr(o.y), _ptr(ws), ws_bytes, _stream(x)))
+        if key is not None and not prepared:
+            _kron_workspace_commit(key, ws, left, right)
+    return o
+
+
+# The online Hadamard rotation of n = K * P (hadK (x) H_P, 1/sqrt(n)) in front of the deploy Quantizer as ONE Kronecker
+# launch: x.view(K * P / N, N) -> left = kron(hadK, H_{P/N}) (+-1), right = H_N / 16, post_scale = 16 / sqrt(n). The
+# factor pair is built once per (hadK, P) and kept (the fragment workspace cache is keyed by these tensors).
+_HAD_KRON: "collections.OrderedDict" = collections.OrderedDict()
+
+
+def _sylvester(n: int) -> torch.Tensor:
+    h = torch.ones(1, 1, dtype=torch.float32)
+    while h.shape[0] < n:
+        h = torch.cat([torch.cat([h, h], 1), torch.cat([h, -h], 1)], 0)
+    return h
+
+
+def _hadamard_as_kron(K: int, P: int, hadK: Optional[torch.Tensor], device):
+    """-> (left [M, M], right [N, N], post_scale) or None when the pair is not one the fused kernels take."""
+    if K == 1 or hadK is None:
+        return None
+    for N in (128, 256):
+        M = K * (P // N) if P % N == 0 else 0
+        # factor pairs with a packed-only instantiation of the workgroup-per-token kernel: M in (64, 128] with N = 128,
+        # M in (96, 128] with N = 256
+        if (N == 128 and 64 < M <= 128) or (N == 256 and 96 < M <= 128):
+            key = (hadK.data_ptr(), hadK._version, K, P, N, str(device))
+            hit = _HAD_KRON.get(key)
+            if hit is None:
+                # out = hadK @ x.view(K, P): Y = L^T U contracts L's FIRST index, so L = kron(hadK, H)^T = kron(hadK^T, H)
+                left = torch.kron(hadK.detach().float().cpu().T.contiguous(), _sylvester(P // N)).to(torch.float16).contiguous().to(device)
+                right = (_sylvester(N) / 16.0).to(torch.float16).contiguous().to(device)
+                hit = (left, right, hadK)
+                _HAD_KRON[key] = hit
+                if len(_HAD_KRON) > 32:
+                    _HAD_KRON.popitem(last=False)
+            return hit[0], hit[1], N
+    return None
+
+
 def moe_group_rows(indices: torch.Tensor, n_groups: int):
     """(token, slot) pairs of a top-k routing table sorted by expert — the device-side form of the reference's
     ``counts = torch.bincount(indices.flatten(), minlength=E)`` + ``idx, top = torch.where(indices == i)`` loop
@@ -438,6 +502,16 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
     if scale is None:
         scale = float(1.0 / torch.tensor(n).sqrt())
     rows = x.numel() // n
+    kr = _hadamard_as_kron(K, n // K, hadK, x.device) if n % K == 0 else None
+    if kr is not None and rows > 0:
+        # K > 1 shapes whose rotation is a Kronecker pair the fused MFMA kernels take (14336 = 112 x 128, 28672 = 112 x 256):
+        # one launch of the transform + Quantizer kernel instead of the register FWHT + K-factor kernel (1.5x faster; the
+        # two differ in where the intermediate is rounded to fp16, both within the 1e-3 tolerance of the reference)
+        left, right, N = kr
+        o = kron_quant_ex(x.reshape(rows, n), left, right, 16.0 * scale, [sig],
+                          FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16 | FQ_ROUND_Y_F16,
+                          up=None if up is None else up.reshape(rows, n))
+        return o.q[0].reshape(x.shape[:-1] + (n // 2,)), o.scale[0]
     q = torch.empty(x.shape[:-1] + (n // 2,), dtype=torch.uint8, device=x.device)
     s = torch.empty((rows,), dtype=torch.float16, device=x.device)
     if rows == 0:

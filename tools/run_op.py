@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Launch ONE op of the library N times (for rocprofv3 --pmc / --kernel-trace runs): tools/run_op.py <op> [n]
+  ops: kron112 (112x128 packed), kron128x224, kron64x128, kron64x112, kron32x64g (grouped, 131072 rows), hadq14336
+       (Hadamard 28x512 + Quantizer), rowq4096 / rowq14336 (deploy Quantizer), block32, block64"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from flatquant_amd import ops  # noqa: E402
+from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED, FQ_QUANT_F16, FQ_SIG_F16  # noqa: E402
+
+op, n = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 30
+dev = torch.device("cuda")
+g = torch.Generator(device=dev).manual_seed(0)
+SIG = [(0.9820137619972229, 0.9820137619972229)]
+
+
+def act(rows, d):
+    x = torch.randn(rows, d, generator=g, device=dev, dtype=torch.float16)
+    x[:, ::97] *= 20
+    return x
+
+
+def mat(k):
+    return (torch.randn(k, k, generator=g, device=dev) / k ** 0.5).half()
+
+
+P = FQ_OUT_PACKED | FQ_NO_CLAMP0
+if op.startswith("kron") and not op.endswith("g"):
+    M, N = {"kron112": (112, 128), "kron128x224": (128, 224), "kron64x128": (64, 128), "kron64x112": (64, 112),
+            "kron86": (86, 128), "kron32x64": (32, 64)}[op]
+    rows = 8192 if M * N > 20000 else 16384
+    xs = [act(rows, M * N) for _ in range(2)]
+    L, R = mat(M), mat(N)
+    fn = lambda i: ops.kron_quant(xs[i % 2], L, R, SIG, P)
+elif op == "kron32x64g":
+    rows, G = 131072, 256
+    xs = [act(rows, 2048) for _ in range(2)]
+    L, R = mat(32), mat(64)
+    offs = torch.linspace(0, rows, G + 1, device=dev).long()
+    sm = torch.full((G,), 0.98, device=dev)
+    fn = lambda i: ops.kron_quant_grouped(xs[i % 2], L, R, offs, sm, sm, P)
+elif op == "hadq14336":
+    from flatquant_amd.flatquant.hadamard_utils import get_hadK
+    hk = get_hadK(14336)[0].half().to(dev).contiguous()
+    xs = [act(16384, 14336) for _ in range(2)]
+    fn = lambda i: ops.hadamard_quant(xs[i % 2], 28, hk, SIG[0])
+elif op.startswith("rowq"):
+    d = int(op[4:])
+    xs = [act(16384, d) for _ in range(2)]
+    fn = lambda i: ops.rowquant(xs[i % 2], SIG, FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)
+elif op.startswith("block"):
+    H = int(op[5:])
+    xs = [act(16384, 128 * H).reshape(16384, 128, H) for _ in range(2)]
+    Pm = mat(H)
+    fn = lambda i: ops.block_quant(xs[i % 2], Pm, SIG, P)
+else:
+    raise SystemExit(__doc__)
+for i in range(n):
+    fn(i)
+torch.cuda.synchronize()
