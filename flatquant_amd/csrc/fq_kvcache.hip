@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NW * 64) void fq_kv_decode_kernel(f16* __restrict__
         // transpose_out: [batch, head_dim, heads] — the layout the o_proj head transform takes (modeling_llama.py:147-149
         // transposes and copies the attention output before block_matmul)
         const size_t oi = transpose_out ? ((size_t)b * HD + tid) * p.num_heads + head : ((size_t)b * p.num_heads + head) * HD + tid;
-        o[oi] = (f16)(oo / dd);
+        o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;  // an empty sequence attends to nothing: zeros, not 0/0
     }
 }
 

@@ -14,9 +14,19 @@ class Linear4bit(torch.nn.Module):
     dicts load unchanged.  ``forward`` takes the PackedQuantizedTensor the online transform / Quantizer produced and
     returns fp16: the reference runs deploy.matmul (CUTLASS int4 GEMM -> int32 in HBM) and deploy.sym_dequant as two
     launches (+ a torch add for the bias); here the dequantisation and the bias sit in the GEMM's epilogue
-    (fq_int4_linear_f16), bit-identical to the two-step form. For K % 128 == 0, N % 16 == 0, N >= 2048 the
-    GEMM runs on the FP6 matrix path instead (BF6 holds every INT4 value exactly; same bits out): the weight
-    image is built once and cached, the packed activations are converted by one small launch per call."""
+    (fq_int4_linear_f16), bit-identical to the two-step form.
+
+    Memory. ``weight`` is 0.5 byte per parameter. Two optional operand images trade memory for speed, each built once
+    per buffer version and kept until ``release_images()``:
+      * the decode image (M <= 128 weight-streaming kernel, 4-9 us per linear instead of 46-144): +0.5 B/param, built on
+        the first decode-sized call — ON by default (``Linear4bit.decode_image``; FQ_SKINNY_GEMM=0/1 overrides);
+      * the FP6 image (BF6 operands on the FP6 matrix path for K % 128 == 0, N % 16 == 0, N >= 2048: the prefill GEMM runs
+        25-30 % faster, same bits out): +0.75 B/param — OFF by default (``Linear4bit.fp6_image = True`` or
+        FQ_FP6_GEMM=1 turn it on): with both images a layer would sit at 1.75 B/param, 3.5x the INT4 footprint.
+    The default is therefore 1.0 B/param once a layer has decoded, 0.5 before."""
+
+    decode_image = True   # class-wide policy switches (set on the class or on an instance)
+    fp6_image = False
 
     def __init__(self, in_features, out_features, bias=False, dtype=torch.float16):
         super().__init__()
@@ -36,7 +46,7 @@ class Linear4bit(torch.nn.Module):
         of the activations (out_features >= 2048: measured 25-30 % faster than the int8 path there, slower for the
         1024-wide k/v projections); FQ_FP6_GEMM=0 turns it off, =1 forces it for every covered shape."""
         mode = os.environ.get("FQ_FP6_GEMM", "")
-        if mode == "0" or not ops.bf6_supported(self.out_features, self.in_features):
+        if mode == "0" or (mode != "1" and not self.fp6_image) or not ops.bf6_supported(self.out_features, self.in_features):
             return None
         if mode != "1" and self.out_features < 2048:
             return None
@@ -61,13 +71,25 @@ class Linear4bit(torch.nn.Module):
     def _decode_image(self):
         """``weight`` in MFMA fragment order for the decode-sized (M <= 128) weight-streaming kernel; cached like the
         FP6 image. FQ_SKINNY_GEMM=0 turns the path off."""
-        if os.environ.get("FQ_SKINNY_GEMM") == "0" or self.in_features % 64:
+        mode = os.environ.get("FQ_SKINNY_GEMM", "")
+        if mode == "0" or (mode != "1" and not self.decode_image) or self.in_features % 64:
             return None
         key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
         if getattr(self, "_dimg_key", None) != key:
             self._dimg = ops.int4_to_frag(self.weight)
             self._dimg_key = key
         return self._dimg
+
+    def release_images(self):
+        """Drop the cached operand images and fp16 scale / bias copies (they are rebuilt on demand)."""
+        for name in ("_wimg", "_wimg_key", "_dimg", "_dimg_key", "_s16", "_s16_key"):
+            if hasattr(self, name):
+                delattr(self, name)
+
+    def image_bytes(self):
+        """Bytes currently held by the cached operand images (on top of ``weight``)."""
+        return sum(t.numel() * t.element_size() for t in (getattr(self, "_wimg", None), getattr(self, "_dimg", None))
+                   if t is not None)
 
     def forward(self, x):
         assert type(x) == PackedQuantizedTensor  # quantized input is given (linear.py:45)

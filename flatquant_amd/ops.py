@@ -35,11 +35,24 @@ def sigmoid_pair(clip_max, clip_min) -> Sig:
 _SCALARS: "collections.OrderedDict" = collections.OrderedDict()
 
 
+def invalidate_caches() -> None:
+    """Forget every value this module derived from tensors it does not own: host copies of clip scalars (host_scalar),
+    fragment workspaces of factor matrices, Hadamard factor pairs. The caches are keyed by (data_ptr, tensor._version):
+    an in-place write through the tensor itself (``t.fill_()``, ``t.copy_()``) bumps the version and is seen, a write
+    through ``t.data`` (``mod.clip_factor_a_max.data.fill_(..)``, ``weight.data.copy_(..)``) does NOT — call this after
+    such an update (checkpoint loaders that assign ``.data`` should), or update in place on the tensor."""
+    _SCALARS.clear()
+    _sigmoid_pair_cached.cache_clear()
+    _WS_LRU.clear()
+    _HAD_KRON.clear()
+
+
 def host_scalar(v) -> float:
     """float(v) for a Python number or a one-element tensor, WITHOUT a device synchronisation per call: a CUDA
     scalar (the deploy modules keep clip_factor_a_max/min as buffers; the reference's loader turns them into Python
     floats, modeling_llama.py:532-538) is read back once per (storage, version) and remembered. The entry holds the
-    tensor, so its address cannot be recycled under it."""
+    tensor, so its address cannot be recycled under it. Writes through ``.data`` do not bump the version: see
+    invalidate_caches()."""
     if not isinstance(v, torch.Tensor):
         return float(v)
     if not v.is_cuda:
@@ -641,6 +654,8 @@ def kv_quant(x: torch.Tensor, trans: Optional[torch.Tensor] = None, clip: Sig = 
     q = torch.empty(x.shape[:-1] + (hd // 2,), dtype=torch.uint8, device=x.device)
     param = torch.empty(x.shape[:-1] + (2,), dtype=torch.float16, device=x.device)
     y = torch.empty_like(x) if return_transformed else None
+    if rows == 0:
+        return (q, param, y) if return_transformed else (q, param)
     with torch.cuda.device(x.device):
         check(lib.fq_kv_quant_f16(_ptr(x), _ptr(trans), rows, hd, ctypes.c_float(clip[0]), ctypes.c_float(clip[1]),
                                   _lib.FQ_KV_LAC if lac else 0, _ptr(q), _ptr(param), _ptr(y), _stream(x)))
@@ -660,6 +675,17 @@ def kv_dequant(q: torch.Tensor, param: torch.Tensor, lac: bool = False) -> torch
     return y
 
 
+def _chk_kv_index(kv_indptr: torch.Tensor, kv_indices: torch.Tensor, last_page_offset: torch.Tensor) -> int:
+    """The paged-cache index tensors as the kernels read them: int32, contiguous, on the device; kv_indptr has batch + 1
+    entries (torch's default int64, or the reference's stride-0 expanded last_page_offset, would be read as garbage)."""
+    for t, n in ((kv_indptr, "kv_indptr"), (kv_indices, "kv_indices"), (last_page_offset, "last_page_offset")):
+        _chk(t, n, torch.int32)
+    batch = last_page_offset.numel()
+    if kv_indptr.numel() != batch + 1:
+        raise ValueError(f"kv_indptr must have batch + 1 = {batch + 1} entries, got {kv_indptr.numel()}")
+    return batch
+
+
 def _kv_geometry(kv_data: torch.Tensor):
     pages, n_layers, two, heads, page_size, half_hd = kv_data.shape
     if two != 2:
@@ -676,12 +702,10 @@ def kv_append(kv_data: torch.Tensor, kv_param: torch.Tensor, kv_indptr: torch.Te
     heads and every cache head h receives head h // g (the GQA repeat of kv_cache.py:286-296, done by the scatter)."""
     _chk(kv_data, "kv_data", torch.uint8), _chk(kv_param, "kv_param"), _chk(k, "k", torch.uint8), _chk(v, "v", torch.uint8)
     _chk(k_param, "k_param"), _chk(v_param, "v_param")
-    for t, n in ((kv_indptr, "kv_indptr"), (kv_indices, "kv_indices"), (last_page_offset, "last_page_offset")):
-        _chk(t, n, torch.int32)
+    batch = _chk_kv_index(kv_indptr, kv_indices, last_page_offset)
     if seqlen_indptr is not None:
         _chk(seqlen_indptr, "seqlen_indptr", torch.int32)
     n_layers, heads, page_size, hd = _kv_geometry(kv_data)
-    batch = last_page_offset.numel()
     src_heads = heads // group_size
     tokens = k.numel() // (src_heads * hd // 2)
     if k.shape != v.shape or k_param.numel() != tokens * src_heads * 2 or v_param.numel() != tokens * src_heads * 2:
@@ -701,11 +725,13 @@ def kv_quant_append(k: torch.Tensor, v: torch.Tensor, trans: Optional[torch.Tens
     if trans is not None:
         _chk(trans, "trans")
     n_layers, heads, page_size, hd = _kv_geometry(kv_data)
-    batch = last_page_offset.numel()
+    batch = _chk_kv_index(kv_indptr, kv_indices, last_page_offset)
     if k.shape != v.shape or k.shape[-1] != hd or k.shape[0] != batch:
         raise ValueError("k / v must be [batch, added, kv_heads, head_dim]")
     src_heads = k.shape[-2]
     tokens = k.numel() // (src_heads * hd)
+    if tokens == 0:
+        return
     c4 = None if clip is None else (ctypes.c_float * 4)(*[float(t) for t in clip])
     with torch.cuda.device(k.device):
         check(lib.fq_kv_quant_append_i4(_ptr(k), _ptr(v), _ptr(trans), tokens, src_heads, hd, c4, _lib.FQ_KV_LAC if lac else 0,
@@ -722,7 +748,7 @@ def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tens
     inside the launch; ``transpose_out``: o comes back as [batch, head_dim, heads]."""
     _chk(q, "q"), _chk(kv_data, "kv_data", torch.uint8), _chk(kv_param, "kv_param")
     n_layers, heads, page_size, hd = _kv_geometry(kv_data)
-    batch = last_page_offset.numel()
+    batch = _chk_kv_index(kv_indptr, kv_indices, last_page_offset)
     if q.shape != (batch, heads, hd):
         raise ValueError(f"q must be [{batch}, {heads}, {hd}]")
     if q_trans is not None:
@@ -730,6 +756,8 @@ def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tens
         if q_trans.shape != (hd, hd):
             raise ValueError("q_trans must be [head_dim, head_dim]")
     o = torch.empty((batch, hd, heads) if transpose_out else (batch, heads, hd), dtype=torch.float16, device=q.device)
+    if batch == 0:
+        return o
     with torch.cuda.device(q.device):
         check(lib.fq_kv_batch_decode_i4_ex(_ptr(o), _ptr(q), _ptr(q_trans), 1 if transpose_out else 0, _ptr(kv_data),
                                            _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
