@@ -160,18 +160,22 @@ struct HadQuant {
     f16* scale;   // [rows]
     const f16* up;  // SILU kernels: x is `gate`, the transform's input is fp16(up * fp16(silu(gate))) (fq_silu_mul8)
 };
-__device__ __forceinline__ uint32_t quant8_h(f16x8 v, f16 s) {
-    uint32_t d = 0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) d |= (uint32_t)(fq_quant1_h(v[e], s) & 15) << (4 * e);
-    return d;
+// 8 fp16 results -> one dword of nibbles: packed pairs, exact fp16 quotient without a division (fq_quant8_h16, fq_common.hpp)
+__device__ __forceinline__ uint32_t quant8_h(f16x8 v, float s, float r, bool clamp) {
+    const u32x4 xv = __builtin_bit_cast(u32x4, v);
+    return clamp ? fq_quant8_h16<true>(xv[0], xv[1], xv[2], xv[3], r, s) : fq_quant8_h16<false>(xv[0], xv[1], xv[2], xv[3], r, s);
 }
 __device__ __forceinline__ void minmax8(f16x8 v, float& mx, float& mn) {
+    // extrema on packed fp16 pairs (the values are fp16: exact), then the two halves
+    f16x2 a = {v[0], v[1]}, b = a;
 #pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-        mx = fq_max3(mx, (float)v[e], (float)v[e + 1]);
-        mn = fq_min3(mn, (float)v[e], (float)v[e + 1]);
+    for (int e = 2; e < 8; e += 2) {
+        const f16x2 pr = {v[e], v[e + 1]};
+        a = __builtin_elementwise_max(a, pr);
+        b = __builtin_elementwise_min(b, pr);
     }
+    mx = fq_max3(mx, (float)a[0], (float)a[1]);
+    mn = fq_min3(mn, (float)b[0], (float)b[1]);
 }
 
 // ---- K == 1: one wave per row (n >= 512), or SUB = 512 / n rows per wave (n = 64, 128, 256: XS cross-lane stages) ----
@@ -218,9 +222,11 @@ __global__ __launch_bounds__(256) void fq_had_pow2_kernel(const f16* __restrict_
             mn = fq_wave_min(mn);
             const float sc = fq_token_scale<FQ_QUANT_F16>(mx, mn, hq.sig_max, hq.sig_min, FQ_SIG_F16);  // deploy.nn.Quantizer arithmetic
             if (lane == 0) hq.scale[row] = (f16)sc;
+            const float rinv = fq_fast_inv(sc);
+            const bool clampq = fq_h16_needs_clamp(mx, mn, rinv);
             uint32_t* qp = reinterpret_cast<uint32_t*>(hq.q + row * (n / 2));
 #pragma unroll
-            for (int j = 0; j < CH; ++j) qp[j * 64 + lane] = quant8_h(o[j], (f16)sc);  // 8 nibbles = elements j*512 + 8 lane ..
+            for (int j = 0; j < CH; ++j) qp[j * 64 + lane] = quant8_h(o[j], sc, rinv, clampq);  // 8 nibbles = elements j*512 + 8 lane ..
         }
     }
 }
@@ -391,6 +397,8 @@ __global__ __launch_bounds__(256) void fq_had_kmix_kernel(const f16* __restrict_
             mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
             mn = fminf(fminf(red[4], red[5]), fminf(red[6], red[7]));
             const float sc = fq_token_scale<FQ_QUANT_F16>(mx, mn, hq.sig_max, hq.sig_min, FQ_SIG_F16);  // deploy.nn.Quantizer arithmetic
+            const float rinv = fq_fast_inv(sc);
+            const bool clampq = fq_h16_needs_clamp(mx, mn, rinv);
             unsigned char* obuf = smem;  // [K][P/2] bytes
 #pragma unroll
             for (int u = 0; u < MAXT; ++u) {
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(256) void fq_had_kmix_kernel(const f16* __restrict_
                 const int kp = kt * 32 + c;
                 if (t < ntiles && kp < K)
                     *reinterpret_cast<uint2*>(obuf + ((int64_t)kp * P + pt * 32 + h * 16) / 2) =
-                        make_uint2(quant8_h(res[u][0], (f16)sc), quant8_h(res[u][1], (f16)sc));
+                        make_uint2(quant8_h(res[u][0], sc, rinv, clampq), quant8_h(res[u][1], sc, rinv, clampq));
             }
             __syncthreads();
             if (tid == 0) hq.scale[row] = (f16)sc;

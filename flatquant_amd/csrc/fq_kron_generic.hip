@@ -461,16 +461,49 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                 }
             }
         }
-        if (out.post_scale != 0.0f) {  // (fq_kron_quant_ex_f16: e.g. the 1/sqrt(n) of a Hadamard rotation run as a Kronecker product)
+        // Packed-only instantiations with the fp16 (deploy Quantizer) arithmetic: the whole epilogue runs on PACKED fp16
+        // pairs H — post-scale + rounding to fp16 (the product is rounded to fp32 first, as in the generic path below),
+        // extrema with v_pk_max/min_f16 — and the quantiser takes the pairs (fq_quant8_h16). Same bits as the generic path.
+        constexpr bool H16 = CTF == (FQ_OUT_PACKED | FQ_QUANT_F16);
+        uint32_t H[H16 ? TPW : 1][H16 ? MT : 1][8];
+        float vmax = -INFINITY, vmin = INFINITY;
+        if (H16) {
+            const float ps = out.post_scale != 0.0f ? out.post_scale : 1.0f;
+            f16x2 pmax = {(f16)-INFINITY, (f16)-INFINITY}, pmin = {(f16)INFINITY, (f16)INFINITY};
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int nt = wave + WAVES * t;
+                const bool col_ok = nt < NT && (h * NT * 16 + nt * 16) < N;
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const f16x2 pr = {fq_mul_to_f16(Y[t][mo][2 * j], ps), fq_mul_to_f16(Y[t][mo][2 * j + 1], ps)};
+                        H[H16 ? t : 0][H16 ? mo : 0][j] = __builtin_bit_cast(uint32_t, pr);
+                        if (col_ok && (mo * 32 + c) < M) {
+                            pmax = __builtin_elementwise_max(pmax, pr);
+                            pmin = __builtin_elementwise_min(pmin, pr);
+                        }
+                    }
+                }
+            }
+            vmax = fmaxf((float)pmax[0], (float)pmax[1]);
+            vmin = fminf((float)pmin[0], (float)pmin[1]);
+        }
+        if (!H16 && out.post_scale != 0.0f) {  // (fq_kron_quant_ex_f16: e.g. the 1/sqrt(n) of a Hadamard rotation run as a Kronecker product)
             const float ps = out.post_scale;
 #pragma unroll
             for (int t = 0; t < TPW; ++t)
 #pragma unroll
                 for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Y[t][mo][r] *= ps;
+                    for (int r = 0; r < 16; ++r) {
+                        float p = Y[t][mo][r] * ps;
+                        asm volatile("" : "+v"(p));  // the product is an fp32 VALUE (no fusion with a later rounding to fp16)
+                        Y[t][mo][r] = p;
+                    }
         }
-        if (flags & FQ_ROUND_Y_F16) {
+        if (!H16 && (flags & FQ_ROUND_Y_F16)) {
 #pragma unroll
             for (int t = 0; t < TPW; ++t)
 #pragma unroll
@@ -480,9 +513,8 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
         }
 
         // ---- per-token extrema over the VALID entries (padding rows/columns are excluded) ----
-        float vmax = -INFINITY, vmin = INFINITY;
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) {
+        for (int t = 0; t < (H16 ? 0 : TPW); ++t) {
             const int nt = wave + WAVES * t;
             const bool col_ok = nt < NT && (h * NT * 16 + nt * 16) < N;  // the lane's 16 columns of this tile
 #pragma unroll
@@ -579,20 +611,17 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                         if (ok) *reinterpret_cast<uint2*>(obuf + (mo * 32 + c) * (N >> 1) + (n0 >> 1)) = pk;
                         continue;
                     }
-                    if (CTF == (FQ_OUT_PACKED | FQ_QUANT_F16) && !(flags & 0x2000)) {
-                        // packed-only instantiations with the fp16 (deploy Quantizer) arithmetic: Y is an fp16 value here
-                        // (FQ_ROUND_Y_F16 is part of that contract), so x / scale is the native _Float16 division
-                        // (correctly rounded, tools/scratch/h16div.hip), not the fp32 division + rounding of fq_quant1
-                        const f16 s16 = (f16)scale;
-                        float r[16];
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const f16 tq = (f16)yv[e] / s16;
-                            r[e] = __builtin_amdgcn_fmed3f(__builtin_rintf((float)tq), -8.0f, 7.0f);
-                        }
+                    if (H16 && !(flags & 0x2000)) {
+                        // the fp16 pairs of this tile: exact fp16 quotient without a division, packed rounding and pack
+                        const uint32_t(&hv)[8] = H[H16 ? t : 0][H16 ? mo : 0];
                         uint2 pk;
-                        pk.x = fq_pack8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
-                        pk.y = fq_pack8(r[8], r[9], r[10], r[11], r[12], r[13], r[14], r[15]);
+                        if (clampq) {
+                            pk.x = fq_quant8_h16<true>(hv[0], hv[1], hv[2], hv[3], inv, scale);
+                            pk.y = fq_quant8_h16<true>(hv[4], hv[5], hv[6], hv[7], inv, scale);
+                        } else {
+                            pk.x = fq_quant8_h16<false>(hv[0], hv[1], hv[2], hv[3], inv, scale);
+                            pk.y = fq_quant8_h16<false>(hv[4], hv[5], hv[6], hv[7], inv, scale);
+                        }
                         if (ok) *reinterpret_cast<uint2*>(obuf + (mo * 32 + c) * (N >> 1) + (n0 >> 1)) = pk;
                         continue;
                     }

@@ -23,20 +23,22 @@ __global__ __launch_bounds__(RQ_THREADS) void fq_rowquant_kernel(const f16* __re
         const uint4* xp = reinterpret_cast<const uint4*>(x + row * (int64_t)cols);
         f16x8 v[NCH];
         float vmax = -INFINITY, vmin = INFINITY;
+        f16x2 pmax = {(f16)-INFINITY, (f16)-INFINITY}, pmin = {(f16)INFINITY, (f16)INFINITY};
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int ch = tid + k * RQ_THREADS;
             if (ch < nchunks) {
                 v[k] = __builtin_bit_cast(f16x8, xp[ch]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    vmax = fmaxf(vmax, (float)v[k][e]);
-                    vmin = fminf(vmin, (float)v[k][e]);
+                for (int e = 0; e < 8; e += 2) {  // extrema on packed fp16 pairs (exact: the data is fp16)
+                    const f16x2 pr = {v[k][e], v[k][e + 1]};
+                    pmax = __builtin_elementwise_max(pmax, pr);
+                    pmin = __builtin_elementwise_min(pmin, pr);
                 }
             }
         }
-        vmax = fq_wave_max(vmax);
-        vmin = fq_wave_min(vmin);
+        vmax = fq_wave_max(fmaxf((float)pmax[0], (float)pmax[1]));
+        vmin = fq_wave_min(fminf((float)pmin[0], (float)pmin[1]));
         __syncthreads();  // protect `red` against the previous iteration's readers
         if ((tid & 63) == 0) {
             red[0][tid >> 6] = vmax;
@@ -48,6 +50,8 @@ __global__ __launch_bounds__(RQ_THREADS) void fq_rowquant_kernel(const f16* __re
 
         for (int ci = 0; ci < out.n_clips; ++ci) {
             const float scale = fq_token_scale<FLAGS>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
+            const float h16_inv = fq_fast_inv(scale);
+            const bool h16_clamp = fq_h16_needs_clamp(vmax, vmin, h16_inv);
             if (FLAGS & FQ_OUT_PACKED) {
                 if (tid == 0) out.scale[ci][row] = (f16)scale;
                 uint32_t* qp = reinterpret_cast<uint32_t*>(out.q[ci] + row * (int64_t)(cols >> 1));
@@ -56,10 +60,15 @@ __global__ __launch_bounds__(RQ_THREADS) void fq_rowquant_kernel(const f16* __re
                     const int ch = tid + k * RQ_THREADS;
                     if (ch < nchunks) {
                         uint32_t d = 0;
+                        if (FLAGS & FQ_QUANT_F16) {   // packed pairs, exact fp16 quotient without a division (fq_quant8_h16)
+                            const u32x4 xv = __builtin_bit_cast(u32x4, v[k]);
+                            d = h16_clamp ? fq_quant8_h16<true>(xv[0], xv[1], xv[2], xv[3], h16_inv, scale)
+                                          : fq_quant8_h16<false>(xv[0], xv[1], xv[2], xv[3], h16_inv, scale);
+                        } else {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            d |= (uint32_t)(((FLAGS & FQ_QUANT_F16) ? fq_quant1_h(v[k][e], (f16)scale)
-                                                                    : fq_quant1<FLAGS>((float)v[k][e], scale)) & 15) << (4 * e);
+                            for (int e = 0; e < 8; ++e)
+                                d |= (uint32_t)(fq_quant1<FLAGS>((float)v[k][e], scale) & 15) << (4 * e);
+                        }
                         qp[ch] = d;
                     }
                 }
@@ -166,21 +175,28 @@ __global__ __launch_bounds__(256) void fq_rowquant_wave_kernel(const f16* __rest
             v[k] = (ch < nchunks) ? __builtin_bit_cast(f16x8, __builtin_nontemporal_load(xp + ch)) : f16x8{0};
         }
         float vmax = -INFINITY, vmin = INFINITY;
+        {   // extrema on packed fp16 pairs (the data IS fp16: exact), two values per instruction
+            f16x2 pmax = {(f16)-INFINITY, (f16)-INFINITY}, pmin = {(f16)INFINITY, (f16)INFINITY};
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            if (lane + k * 64 < nchunks) {
+            for (int k = 0; k < NCH; ++k) {
+                if (lane + k * 64 < nchunks) {
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    vmax = fq_max3(vmax, (float)v[k][e], (float)v[k][e + 1]);
-                    vmin = fq_min3(vmin, (float)v[k][e], (float)v[k][e + 1]);
+                    for (int e = 0; e < 8; e += 2) {
+                        const f16x2 pr = {v[k][e], v[k][e + 1]};
+                        pmax = __builtin_elementwise_max(pmax, pr);
+                        pmin = __builtin_elementwise_min(pmin, pr);
+                    }
                 }
             }
+            vmax = fmaxf((float)pmax[0], (float)pmax[1]);
+            vmin = fminf((float)pmin[0], (float)pmin[1]);
         }
         vmax = fq_wave_max(vmax);
         vmin = fq_wave_min(vmin);
         for (int ci = 0; ci < out.n_clips; ++ci) {
             const float scale = fq_token_scale<FLAGS>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
             const float inv = fq_fast_inv(scale);
+            const bool h16_clamp = fq_h16_needs_clamp(vmax, vmin, inv);
             if (FLAGS & FQ_OUT_PACKED) {
                 if (lane == 0) out.scale[ci][row] = (f16)scale;
                 uint32_t* qp = reinterpret_cast<uint32_t*>(out.q[ci] + row * (int64_t)(cols >> 1));
@@ -189,9 +205,9 @@ __global__ __launch_bounds__(256) void fq_rowquant_wave_kernel(const f16* __rest
                     const int ch = lane + k * 64;
                     uint32_t d;
                     if (FLAGS & FQ_QUANT_F16) {
-                        d = 0;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) d |= (uint32_t)(fq_quant1_h(v[k][e], (f16)scale) & 15) << (4 * e);
+                        const u32x4 xv = __builtin_bit_cast(u32x4, v[k]);   // packed pairs, exact fp16 quotient (fq_quant8_h16)
+                        d = h16_clamp ? fq_quant8_h16<true>(xv[0], xv[1], xv[2], xv[3], inv, scale)
+                                      : fq_quant8_h16<false>(xv[0], xv[1], xv[2], xv[3], inv, scale);
                     } else {
                         float dmax = 0.0f;
                         const f32x2 inv2 = {inv, inv};

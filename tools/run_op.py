@@ -61,3 +61,12 @@ else:
 for i in range(n):
     fn(i)
 torch.cuda.synchronize()
+if os.environ.get("TIME_OP"):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(100):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{op}: {e0.elapsed_time(e1) * 10:.1f} us per call")
