@@ -69,3 +69,52 @@ __device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok
     }
 }
 
+// A wave's share of a token that several waves stage together (fq_kron_trio.hip): instructions [i0, i0 + n) of the token,
+// i.e. the KBs [i0, i0 + n) of its LDS image. `src` / `lds_base` already point at KB i0; rv[j] is the per-lane offset
+// of instruction i0 + j (dma_span_offsets), which repeats every four instructions.
+template <int CPR>
+__device__ __forceinline__ void dma_span_offsets(int lane, int i0, unsigned (&rv)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j, q = i * 64 + lane;
+        const int r = q / CPR, pch = q - r * CPR;
+        rv[j] = (unsigned)((r * CPR + (pch ^ swz<CPR>(r))) * 16 - i * 1024);
+    }
+}
+__device__ __forceinline__ void dma_span(const unsigned char* src, int n, unsigned lds_base, const unsigned (&rv)[4]) {
+    const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)src);
+    const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((size_t)src >> 32));
+    const unsigned long long sb = (unsigned long long)lo32 | ((unsigned long long)hi32 << 32);
+    int g = 0;
+    for (; g + 4 <= n; g += 4) {
+        unsigned keep;
+        asm volatile(
+            "s_nop 4\n\t"
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %6\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %5 nt\n\t"
+            "global_load_lds_dwordx4 %2, %5 offset:1024 nt\n\t"
+            "global_load_lds_dwordx4 %3, %5 offset:2048 nt\n\t"
+            "global_load_lds_dwordx4 %4, %5 offset:3072 nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(rv[0]), "v"(rv[1]), "v"(rv[2]), "v"(rv[3]), "s"(sb + (unsigned long long)g * 1024),
+              "s"(lds_base + (unsigned)g * 1024)
+            : "memory");
+    }
+    for (int j = 0; g + j < n; ++j) {  // tail (n % 4 instructions)
+        unsigned keep;
+        asm volatile(
+            "s_nop 4\n\t"
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2 nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(j == 0 ? rv[0] : j == 1 ? rv[1] : rv[2]), "s"(sb + (unsigned long long)(g + j) * 1024),
+              "s"(lds_base + (unsigned)(g + j) * 1024)
+            : "memory");
+    }
+}

@@ -741,6 +741,8 @@ int launch_generic(int flags, const f16* x, const uint4* ws, const f16* diag, in
 
 int fq_launch_kron_wave(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
                         const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_wave.hip
+int fq_launch_kron_trio(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
+                        const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_trio.hip
 
 static inline int tiles32(int n) { return (n + 31) / 32; }
 
@@ -803,6 +805,10 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
         if (rc != -1000) return rc;
     }
     if (out.rt_flags & FQ_GROUP128) return -1000;  // per-128-element scales exist in the wave kernel (N = 64) only
+    if (!fq_measure_env("FQ_KRON_NO_TRIO")) {  // 64 < M <= 128, N = 128, packed output: three token groups one phase apart
+        rc = fq_launch_kron_trio(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
+        if (rc != -1000) return rc;
+    }
 #ifdef FQ_MEASURE
     if (const char* dbg = getenv("FQ_KRON_DBG")) flags |= atoi(dbg) & 0x7000;  // measurement: ablation bits of the fast kernel
 #endif
