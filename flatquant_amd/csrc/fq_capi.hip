@@ -33,8 +33,6 @@ int64_t fq_bf6_blob_bytes(int64_t rows, int K);  // fq_gemm_bf6.hip (exported as
 int fq_launch_i4_to_bf6(const uint8_t* q, int64_t rows, int K, int perm, uint8_t* blob, int n_cu, hipStream_t stream);
 int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, int N, int K, int32_t* c, f16* y,
                        const f16* srow, const f16* scol, const f16* bias, hipStream_t stream);
-int fq_launch_kron_any(int flags, const f16* x, const f16* left, const f16* right, const f16* diag, int64_t rows, int M,
-                       int N, const FqQuantOut& out, int n_cu, hipStream_t stream);
 int fq_launch_kv_append(void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last, const uint8_t* k,
                         const uint8_t* v, const f16* kparam, const f16* vparam, const int* seqlen_indptr, int64_t total_tokens,
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, int group, int n_cu,
@@ -172,13 +170,8 @@ static int kron_dispatch(const char* what, const FqQuantOut& o, int flags, const
     if (rc == -1000 && special)
         return fail(FQ_EUNSUPPORTED, "%s: grouped / FQ_GROUP128 launches need a fused MFMA kernel; factors (%d, %d) with "
                     "flags 0x%x have none", what, M, N, flags);
-    if (rc == -1000) {  // no MFMA kernel for this pair: the any-shape kernel (csrc/fq_kron_any.hip), no workspace
-        rc = fq_launch_kron_any(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag, rows, M, N, o,
-                                n_cu, (hipStream_t)stream);
-        if (rc == -1000)
-            return fail(FQ_EUNSUPPORTED, "%s: no kernel for factors (%d, %d): M, N <= 256 and M*N <= 32768", what, M, N);
-        return check_launch(rc, what);
-    }
+    if (rc == -1000)
+        return fail(FQ_EUNSUPPORTED, "%s: no kernel for factors (%d, %d) with flags 0x%x: M, N <= 256, N even, M*N <= 32768", what, M, N, flags);
     return check_launch(rc, what);
 }
 
@@ -345,11 +338,7 @@ int fq_kron_prepare_f16(const void* left, const void* right, int M, int N, void*
 
 int64_t fq_kron_workspace_bytes(int M, int N) {
     if (M == 64 && N == 64) return 0;
-    if ((N & 15) || M < 1 || M > 128 || N < 16 || N > 256 || ((M * N / 2) & 15)) {
-        // pairs only the any-shape kernel takes (csrc/fq_kron_any.hip): no workspace
-        if (M >= 1 && N >= 1 && M <= 256 && N <= 256 && (int64_t)M * N <= 32768) return 0;
-        return FQ_EUNSUPPORTED;
-    }
+    if (M < 1 || N < 2 || (N & 1) || M > 256 || N > 256 || (int64_t)M * N > 32768) return FQ_EUNSUPPORTED;
     return fq_kron_generic_workspace_bytes(M, N);
 }
 

@@ -1,16 +1,18 @@
-// fq_kron_generic.hip — fused Kronecker transform + per-token INT4 quantisation for any (M, N) with
-// N % 16 == 0, M <= 128, N <= 256: d = 8192 (64x128), 14336 (112x128), 28672 (128x224), 11008 (86x128),
-// 7168 (64x112), 2048 (32x64), 3584 (56x64), 5120 (64x80) ... (function_utils.py:11-21 factor pairs).
+// fq_kron_generic.hip — fused Kronecker transform + per-token INT4 quantisation, ONE WORKGROUP PER TOKEN, for the factor
+// pairs deployed models use whose token does not fit a wave or whose output set is not packed-only: d = 14336 (112x128),
+// 28672 (128x224), 11008 (86x128), 8192 (64x128), 7168 (64x112), 2048 (32x64), 3584 (56x64), 5120 (64x80)
+// (function_utils.py:11-21 factor pairs); plus the fragment-image builder (fq_kron_prepare_kernel) and the launcher that
+// picks a kernel for ANY pair (fq_launch_kron_generic): wave-per-token (fq_kron_wave.hip), three token groups per CU
+// (fq_kron_trio.hip), this file's kernel, and fq_kron_general.hip for every other pair (run-time N, N % 16 != 0, M > 128).
 //
 // Same mathematics and fragment chaining as fq_kron64.hip (U = X.R rounded to fp16, Y^T = U^T.L, the C
 // fragment of GEMM 1 is the A fragment of GEMM 2), but a token no longer fits one wave's registers, so:
-//   * one 4-wave workgroup owns one token; the token is staged in LDS once (coalesced 16-byte loads, row
+//   * one 4- or 8-wave workgroup owns one token; the token is staged in LDS once (coalesced 16-byte loads, row
 //     pitch padded to an odd number of 16-byte chunks -> conflict-free ds_read_b128 A fragments);
-//   * wave w computes the 32-column n'-tiles w, w+4, ...: GEMM 1 for its tile over all rows, fp16
+//   * wave w computes the 32-column n'-tiles w, w+WAVES, ...: GEMM 1 for its tile over all rows, fp16
 //     conversion in registers, GEMM 2 against all of L; its slice of Y stays in registers;
 //   * the B-operand fragments of R and L come from a caller-provided WORKSPACE in fragment order
-//     (fq_kron_prepare_kernel, launched by the same C-ABI call; <= 130 KB, L2-resident): every fragment
-//     read is one coalesced 1 KB global load;
+//     (fq_kron_prepare_kernel, launched by the same C-ABI call; <= 170 KB, L2-resident);
 //   * per-token max/min: wave all-reduce + 8 floats of LDS; quantised nibbles / fp16 outputs are staged in
 //     LDS and written out with full 16-byte coalesced stores.
 // This single pass replaces the reference's split path for M > 64 (kron_matmul.py:213-247), which writes the
@@ -73,217 +75,8 @@ __global__ void fq_kron_prepare_kernel(const f16* __restrict__ left, const f16* 
     }
 }
 
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void fq_kron_generic_kernel(const f16* __restrict__ x,
-                                                              const uint4* __restrict__ ws,
-                                                              const f16* __restrict__ diag, int64_t rows,
-                                                              KronGeom g, FqQuantOut out, int flags) {
-    constexpr int TPW = (NT + 3) / 4;  // n'-tiles per wave
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int M = g.M, N = g.N, KS1 = g.KS1, pitch = g.pitch;
-    uint4* xs = reinterpret_cast<uint4*>(smem);                          // [MT*32][pitch] 16-byte chunks
-    const int xs_chunks = MT * 32 * pitch;
-    unsigned char* obuf = smem + (size_t)xs_chunks * 16;                 // packed output stage: M*N/2 bytes
-    float* red = reinterpret_cast<float*>(obuf + ((M * N / 2 + 15) & ~15));  // [2][4]
-    const uint4* rfrag = ws;
-    const uint4* lfrag = ws + (size_t)NT * KS1 * 64;
-
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cpr = N >> 3;          // 16-byte chunks per token row
-    const int n_chunks = M * cpr;    // chunks per token
-    const int64_t d = (int64_t)M * N;
-
-    for (int i = tid; i < xs_chunks; i += 256) xs[i] = make_uint4(0, 0, 0, 0);  // padding stays zero forever
-
-    for (int64_t tok = blockIdx.x; tok < rows; tok += gridDim.x) {
-        __syncthreads();  // everyone is done with xs / obuf of the previous token
-        {
-            const uint4* xp = reinterpret_cast<const uint4*>(x + tok * d);
-            const uint4* dp = reinterpret_cast<const uint4*>(diag);
-            for (int q = tid; q < n_chunks; q += 256) {
-                uint4 v = xp[q];
-                if (diag != nullptr)
-                    v = __builtin_bit_cast(uint4, __builtin_bit_cast(f16x8, v) * __builtin_bit_cast(f16x8, dp[q]));
-                const int row = q / cpr, ch = q - row * cpr;
-                xs[row * pitch + ch] = v;
-            }
-        }
-        __syncthreads();
-
-        f32x16 Y[TPW][MT];  // Y^T of tile (nt = wave + 4t, mo): rows n' = h*NT*16 + nt*16 + r, col m' = 32mo + c
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-            const int nt = wave + 4 * t;
-#pragma unroll
-            for (int mo = 0; mo < MT; ++mo) Y[t][mo] = f32x16{0};
-            if (nt < NT) {
-                f32x16 U[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) U[mt] = f32x16{0};
-                const uint4* rf = rfrag + (size_t)nt * KS1 * 64 + lane;
-                for (int s = 0; s < KS1; ++s) {
-                    const f16x8 b = __builtin_bit_cast(f16x8, rf[s * 64]);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const f16x8 a = __builtin_bit_cast(f16x8, xs[(mt * 32 + c) * pitch + s * 2 + h]);
-                        U[mt] = mfma32(a, b, U[mt]);
-                    }
-                }
-                f16x8 Uh[MT][2];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int p = 0; p < 2; ++p)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) Uh[mt][p][j] = (f16)U[mt][p * 8 + j];
-#pragma unroll
-                for (int ks = 0; ks < 2 * MT; ++ks)
-#pragma unroll
-                    for (int mo = 0; mo < MT; ++mo) {
-                        const f16x8 b = __builtin_bit_cast(f16x8, lfrag[((size_t)ks * MT + mo) * 64 + lane]);
-                        Y[t][mo] = mfma32(Uh[ks >> 1][ks & 1], b, Y[t][mo]);
-                    }
-            }
-        }
-
-        if (flags & FQ_ROUND_Y_F16) {
-#pragma unroll
-            for (int t = 0; t < TPW; ++t)
-#pragma unroll
-                for (int mo = 0; mo < MT; ++mo)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) Y[t][mo][r] = (float)(f16)Y[t][mo][r];
-        }
-
-        // ---- per-token extrema over the VALID entries (padding rows/columns are excluded) ----
-        float vmax = -INFINITY, vmin = INFINITY;
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-            const int nt = wave + 4 * t;
-            const bool col_ok = nt < NT && (h * NT * 16 + nt * 16) < N;  // the lane's 16 columns of this tile
-#pragma unroll
-            for (int mo = 0; mo < MT; ++mo) {
-                if (col_ok && (mo * 32 + c) < M) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        vmax = fmaxf(vmax, Y[t][mo][r]);
-                        vmin = fminf(vmin, Y[t][mo][r]);
-                    }
-                }
-            }
-        }
-        vmax = fq_wave_max(vmax);
-        vmin = fq_wave_min(vmin);
-        if (lane == 0) {
-            red[wave] = vmax;
-            red[4 + wave] = vmin;
-        }
-        __syncthreads();  // also: every wave has finished reading xs -> it may be reused as an output stage
-        vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        vmin = fminf(fminf(red[4], red[5]), fminf(red[6], red[7]));
-
-        // ---- fp16 outputs (transform / fake-quant) are staged dense [M][N] in xs, then streamed out ----
-        f16* stage = reinterpret_cast<f16*>(smem);
-        if (flags & FQ_OUT_TRANSFORM) {
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int nt = wave + 4 * t, n0 = h * NT * 16 + nt * 16;
-#pragma unroll
-                for (int mo = 0; mo < MT; ++mo)
-                    if (nt < NT && n0 < N && (mo * 32 + c) < M) {
-                        f16x8 v0, v1;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            v0[e] = (f16)Y[t][mo][e];
-                            v1[e] = (f16)Y[t][mo][8 + e];
-                        }
-                        uint4* sp = reinterpret_cast<uint4*>(stage + (mo * 32 + c) * N + n0);
-                        sp[0] = __builtin_bit_cast(uint4, v0);
-                        sp[1] = __builtin_bit_cast(uint4, v1);
-                    }
-            }
-            __syncthreads();
-            uint4* yp = reinterpret_cast<uint4*>(out.y + tok * d);
-            for (int q = tid; q < n_chunks; q += 256) yp[q] = reinterpret_cast<const uint4*>(stage)[q];
-            __syncthreads();
-        }
-
-        for (int ci = 0; ci < out.n_clips; ++ci) {
-            if (!(flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT))) break;
-            float scale;
-            if (flags & FQ_QUANT_F16) scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
-            else scale = fq_token_scale<0>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
-            const float inv = fq_fast_inv(scale);
-
-            // quantise this lane's slice once: 16 integer-valued floats per (t, mo)
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int nt = wave + 4 * t, n0 = h * NT * 16 + nt * 16;
-#pragma unroll
-                for (int mo = 0; mo < MT; ++mo) {
-                    const bool ok = nt < NT && n0 < N && (mo * 32 + c) < M;
-                    float qv[16];
-                    if (flags & FQ_QUANT_F16) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) qv[r] = (float)fq_quant1<FQ_QUANT_F16>(Y[t][mo][r], scale);
-                    } else {
-                        float dmax = 0.0f;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) qv[r] = fq_qfast(ok ? Y[t][mo][r] : 0.0f, inv, dmax);
-                        if (fq_wave_needs_exact(dmax)) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) qv[r] = fq_qexact(Y[t][mo][r], scale);
-                        }
-                    }
-                    if (ok && (flags & FQ_OUT_PACKED)) {
-                        uint2 pk;
-                        pk.x = fq_pack8(qv[0], qv[1], qv[2], qv[3], qv[4], qv[5], qv[6], qv[7]);
-                        pk.y = fq_pack8(qv[8], qv[9], qv[10], qv[11], qv[12], qv[13], qv[14], qv[15]);
-                        *reinterpret_cast<uint2*>(obuf + (mo * 32 + c) * (N >> 1) + (n0 >> 1)) = pk;
-                    }
-                    if (ok && (flags & FQ_OUT_FAKEQUANT)) {
-                        f16x8 v0, v1;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            if (flags & FQ_QUANT_F16) {
-                                v0[e] = fq_dequant1<FQ_QUANT_F16>((int)qv[e], scale);
-                                v1[e] = fq_dequant1<FQ_QUANT_F16>((int)qv[8 + e], scale);
-                            } else {
-                                v0[e] = fq_mul_to_f16(scale, qv[e]);
-                                v1[e] = fq_mul_to_f16(scale, qv[8 + e]);
-                            }
-                        }
-                        uint4* sp = reinterpret_cast<uint4*>(stage + (mo * 32 + c) * N + n0);
-                        sp[0] = __builtin_bit_cast(uint4, v0);
-                        sp[1] = __builtin_bit_cast(uint4, v1);
-                    }
-                }
-            }
-            __syncthreads();
-            if (flags & FQ_OUT_PACKED) {
-                if (tid == 0) out.scale[ci][tok] = (f16)scale;
-                uint4* qp = reinterpret_cast<uint4*>(out.q[ci] + tok * (d >> 1));
-                for (int q = tid; q < (n_chunks >> 2); q += 256) qp[q] = reinterpret_cast<const uint4*>(obuf)[q];
-                // M*N/2 bytes is a multiple of 16 whenever N % 32 == 0 or M % 2 == 0 (checked by the launcher)
-            }
-            if (flags & FQ_OUT_FAKEQUANT) {
-                uint4* fp = reinterpret_cast<uint4*>(out.fq[ci] + tok * d);
-                for (int q = tid; q < n_chunks; q += 256) fp[q] = reinterpret_cast<const uint4*>(stage)[q];
-            }
-            __syncthreads();
-        }
-
-        // the output stage lives in xs: restore the zero padding the next token relies on
-        if (flags & (FQ_OUT_TRANSFORM | FQ_OUT_FAKEQUANT)) {
-            for (int i = tid; i < xs_chunks; i += 256) xs[i] = make_uint4(0, 0, 0, 0);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// Fast variant for the factor pairs real models use (compile-time KS1). Same partition (wave w owns the n'-tiles
-// w, w+4, ...), but the per-token traffic that made the kernel above L2-bound is gone:
+// Compile-time K-steps (the factor pairs real models use). Per-token traffic kept off L2:
 //   * a wave's R fragments never change -> loaded once into registers (TPW x KS1 x 4 VGPRs);
 //   * the L fragments every wave needs in full live in LDS (2 MT^2 KB, copied once per workgroup);
 //   * the next token is fetched into registers (coalesced 16-byte loads) while the current one is being
@@ -719,30 +512,14 @@ int launch_fast(int flags, const f16* x, const uint4* ws, const f16* diag, int64
     return (int)hipGetLastError();
 }
 
-template <int MT, int NT>
-int launch_generic(int flags, const f16* x, const uint4* ws, const f16* diag, int64_t rows, const KronGeom& g,
-                   const FqQuantOut& out, int n_cu, hipStream_t stream) {
-    const size_t xs_bytes = (size_t)MT * 32 * g.pitch * 16;
-    const size_t ob = ((size_t)g.M * g.N / 2 + 15) & ~(size_t)15;
-    const size_t lds = xs_bytes + ob + 64;
-    if (lds > 160 * 1024) return -1000;
-    auto kern = fq_kron_generic_kernel<MT, NT>;
-    FQ_RAISE_LDS_CAP(kern, 160 * 1024);
-    int per_cu = (int)((160 * 1024) / lds);  // workgroups that fit a CU's 160 KB of LDS: they overlap each other's
-    if (per_cu > 4) per_cu = 4;              // synchronous token load with compute
-    if (per_cu < 1) per_cu = 1;
-    int64_t blocks = (int64_t)n_cu * per_cu;
-    if (blocks > rows) blocks = rows;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, x, ws, diag, rows, g, out, flags);
-    return (int)hipGetLastError();
-}
-
 }  // namespace
 
 int fq_launch_kron_wave(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
                         const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_wave.hip
 int fq_launch_kron_trio(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
                         const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_trio.hip
+int fq_launch_kron_general(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
+                           const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_general.hip
 
 static inline int tiles32(int n) { return (n + 31) / 32; }
 
@@ -762,10 +539,13 @@ int fq_launch_kron_prepare(const f16* left, const f16* right, int M, int N, void
 int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream) {
-    if ((N & 15) || M < 1 || M > 128 || N > 256 || ((M * N / 2) & 15)) return -1000;
+    if (M < 1 || N < 2 || (N & 1) || M > 256 || N > 256 || (int64_t)M * N > 32768) return -1000;
+    // the specialised kernels below: N in whole K-steps, M <= 128, 16-byte packed tokens; every other pair: fq_kron_general.hip
+    const bool spec = !(N & 15) && M <= 128 && !((M * N / 2) & 15);
     const bool no_wave = (flags & FQ_NO_WAVE_KERNEL) != 0 || out.post_scale != 0.0f;  // (the wave kernels take no post_scale)
     flags &= ~FQ_NO_WAVE_KERNEL;
     if (flags & FQ_IN_SILU_MUL) {  // fused for the down_proj shapes only; said before any workspace complaint
+        if (!spec) return -1000;
         const int mt = tiles32(M), nt = tiles32(N), ks = (N + 15) / 16;
         if (!((mt == 4 && nt == 4 && ks == 8) || (mt == 3 && nt == 4 && ks == 8) || (mt == 4 && nt == 7 && ks == 14) ||
               (mt == 4 && nt == 8 && ks == 16)))
@@ -800,19 +580,19 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
 #undef FQ_FS
         return -1000;
     }
-    if (!no_wave && !fq_measure_env("FQ_KRON_NO_WAVE")) {  // one wave per token where a token fits a wave (packed output only)
+    if (spec && !no_wave && !fq_measure_env("FQ_KRON_NO_WAVE")) {  // one wave per token where a token fits a wave (packed output only)
         rc = fq_launch_kron_wave(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }
     if (out.rt_flags & FQ_GROUP128) return -1000;  // per-128-element scales exist in the wave kernel (N = 64) only
-    if (!fq_measure_env("FQ_KRON_NO_TRIO")) {  // 64 < M <= 128, N = 128, packed output: three token groups one phase apart
+    if (spec && !fq_measure_env("FQ_KRON_NO_TRIO")) {  // 64 < M <= 128, N = 128, packed output: three token groups one phase apart
         rc = fq_launch_kron_trio(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }
 #ifdef FQ_MEASURE
     if (const char* dbg = getenv("FQ_KRON_DBG")) flags |= atoi(dbg) & 0x7000;  // measurement: ablation bits of the fast kernel
 #endif
-    if (!fq_measure_env("FQ_KRON_GENERIC_V1")) {  // (the original kernel stays reachable for A/B runs)
+    if (spec) {
 #define FQ_F(MT_, NT_, KS1_, W_, OCC_)                                                                   \
     if (MT == MT_ && NT == NT_ && g.KS1 == KS1_) {                                                       \
         if (MT_ >= 3 && (flags & FQ_CT_MASK) == FQ_OUT_PACKED && !fq_measure_env("FQ_KRON_NO_CTF"))              \
@@ -834,12 +614,5 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
         FQ_F(1, 2, 4, 4, 4) FQ_F(2, 2, 4, 4, FQ_GEN_OCC2) FQ_F(2, 3, 5, 4, FQ_GEN_OCC2)
 #undef FQ_F
     }
-    if (out.group_offsets != nullptr || out.post_scale != 0.0f) return -1000;  // (the first-generation kernel below takes neither)
-#define FQ_G(MT_, NT_)                                                                                   \
-    if (MT == MT_ && NT == NT_)                                                                          \
-        return launch_generic<MT_, NT_>(flags, x, ws, diag, rows, g, out, n_cu, stream);
-    FQ_G(1, 1) FQ_G(1, 2) FQ_G(2, 2) FQ_G(2, 3) FQ_G(2, 4) FQ_G(3, 3) FQ_G(3, 4) FQ_G(4, 4) FQ_G(4, 5) FQ_G(4, 6)
-    FQ_G(4, 7) FQ_G(4, 8) FQ_G(2, 8)
-#undef FQ_G
-    return -1000;
+    return fq_launch_kron_general(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
 }

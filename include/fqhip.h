@@ -119,8 +119,7 @@ int fq_kron_quant_f16(const void* x, const void* left, const void* right, const 
  *   sig_max_g / sig_min_g   DEVICE float [n_groups] = sigmoid(clip_factor_a_max/min) of each group
  *   q_out [rows, M*N/2] u8, scale_out [rows] fp16 ([rows, M*N/128] with FQ_GROUP128), fq_out / y_out [rows, M*N] fp16,
  *   selected by flags as in fq_kron_quant_f16 (one clip set). Nothing is read back to the host: no synchronisation.
- * Shapes: the pairs the fused MFMA kernels cover (fq_kron_workspace_bytes(M, N) >= 0 and not the plain-FMA fallback);
- * FQ_EUNSUPPORTED otherwise. workspace / FQ_WS_PREPARED as in fq_kron_quant_f16.
+ * Shapes: every pair fq_kron_quant_f16 takes (fq_kron_workspace_bytes(M, N) >= 0); FQ_EUNSUPPORTED otherwise. workspace / FQ_WS_PREPARED as in fq_kron_quant_f16.
  */
 int fq_kron_quant_grouped_f16(const void* x, const void* left, const void* right, int64_t rows, int M, int N,
                               const int64_t* group_offsets, int n_groups, const float* sig_max_g, const float* sig_min_g,
@@ -178,8 +177,9 @@ int fq_kron_quant_ex_f16(const void* x, const void* up, const void* left, const 
 int fq_silu_mul_f16(const void* gate, const void* up, void* y, int64_t n, void* stream);
 
 /* Bytes of device workspace fq_kron_quant_f16 needs for factor sizes (M, N); 0 when none is needed;
- * negative (FQ_EUNSUPPORTED) when no kernel handles the shape. MFMA kernels: N % 16 == 0, M <= 128, N <= 256,
- * M*N/2 % 16 == 0; every other pair with M, N <= 256 and M*N <= 32768 runs a plain-FMA kernel (slow, no workspace). */
+ * negative (FQ_EUNSUPPORTED) when no kernel handles the shape. Every pair with M <= 256, even N <= 256 and M*N <= 32768
+ * has an MFMA kernel (tuned ones for the deploy shapes, csrc/fq_kron_general.hip for the rest, e.g. 128 x 148); all of them
+ * but 64 x 64 read L and R from the fragment image in this workspace. */
 int64_t fq_kron_workspace_bytes(int M, int N);
 
 /* Re-pack left [M,M] / right [N,N] into the MFMA fragment image fq_kron_quant_f16 consumes, once, for callers whose

@@ -153,15 +153,17 @@ def test_unsupported_shape_raises(ops):
     x = torch.randn(2, 60 * 63).half().cuda()
     with pytest.raises(FqError):                               # odd element count: nothing to pack two per byte
         ops.kron_quant(x, torch.eye(60).half().cuda(), torch.eye(63).half().cuda())
-    with pytest.raises(FqError):                               # beyond even the any-shape kernel (M * N > 32768)
+    with pytest.raises(FqError):                               # beyond the general kernel (M * N > 32768)
         ops.kron_quant(torch.zeros(1, 200 * 200).half().cuda(), torch.eye(200).half().cuda(), torch.eye(200).half().cuda())
 
 
-@pytest.mark.parametrize("M,N", [(128, 148), (144, 192), (168, 176), (60, 62), (3, 6), (130, 16), (20, 12)])
-def test_any_shape_kernel(ops, M, N):
-    """Factor pairs no MFMA kernel takes (Qwen2.5 ffn widths 18944 = 128 x 148, 27648 = 144 x 192, 29568 = 168 x 176,
-    odd ones) run the plain-FMA kernel (csrc/fq_kron_any.hip): same bars — transform within 1e-3 of the row maximum,
-    every quantiser output bit-exact on the kernel's own transform, packed result vs the oracle pipeline."""
+@pytest.mark.parametrize("M,N", [(128, 148), (144, 192), (168, 176), (60, 62), (3, 6), (130, 16), (20, 12), (64, 80), (96, 96),
+                                 (256, 128), (192, 170), (2, 2), (129, 254), (40, 100)])
+def test_general_kernel_any_pair(ops, M, N):
+    """Factor pairs the specialised kernels do not take (Qwen2.5 ffn widths 18944 = 128 x 148, 27648 = 144 x 192,
+    29568 = 168 x 176; N % 16 != 0, N % 4 != 0, M > 128, tokens of 36 bytes) run the general MFMA kernel
+    (csrc/fq_kron_general.hip): same bars — transform within 1e-3 of the row maximum, every quantiser output bit-exact on
+    the kernel's own transform, packed result vs the oracle pipeline."""
     gen = torch.Generator().manual_seed(M * 1000 + N)
     rows = 5
     x = torch.randn(rows, M * N, generator=gen).half()
@@ -223,3 +225,28 @@ def test_prepared_workspace_reuse_and_invalidation(ops):
                                 P | FQ_WS_PREPARED, qa, sa, none4, None, ws.data_ptr(), nbytes, st))
     assert torch.equal(q, c.q[0]) and torch.equal(s, c.scale[0])
     assert lib.fq_kron_prepare_f16(L.data_ptr(), R.data_ptr(), M, N, ws.data_ptr(), 16, st) < 0   # too small
+
+
+def test_general_kernel_grouped_and_post_scale(ops):
+    """Grouped (per-expert clip pairs) launches and the post-scale of fq_kron_quant_ex_f16 on a pair only the general kernel
+    takes (128 x 148)."""
+    M, N, rows = 128, 148, 50
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(rows, M * N, generator=gen).half().cuda()
+    L = (torch.randn(M, M, generator=gen) / M ** 0.5).half().cuda()
+    Rm = (torch.randn(N, N, generator=gen) / N ** 0.5).half().cuda()
+    offs = torch.tensor([0, 10, 10, 50], dtype=torch.int64, device="cuda")
+    smax = torch.tensor([0.9, 0.5, 0.7], device="cuda")
+    smin = torch.tensor([0.8, 0.5, 1.0], device="cuda")
+    o = ops.kron_quant_grouped(x, L, Rm, offs, smax, smin, P | NC0)
+    for g in (0, 2):
+        a, b = int(offs[g]), int(offs[g + 1])
+        one = ops.kron_quant(x[a:b].contiguous(), L, Rm, [(float(smax[g]), float(smin[g]))], P | NC0)
+        assert torch.equal(o.q[0][a:b], one.q[0]) and torch.equal(o.scale[0][a:b], one.scale[0])
+    ps = 0.37
+    y0 = ops.kron_quant(x, L, Rm, flags=T).y.float().cpu().numpy()
+    ex = ops.kron_quant_ex(x, L, Rm, ps, [(0.97, 0.9)], T | P | R16)
+    y = ex.y.cpu().numpy().astype(np.float32)
+    assert np.max(np.abs(y - y0 * ps) / (np.abs(y0 * ps).max(axis=1, keepdims=True))) <= 2e-3
+    ref = O.quant_outputs(y, 0.97, 0.9)
+    assert np.array_equal(ex.q[0].cpu().numpy(), ref["packed"]) and np.array_equal(ex.scale[0].cpu().numpy(), ref["scale16"])

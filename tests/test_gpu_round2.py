@@ -89,12 +89,18 @@ def test_grouped_edge_cases(ops):
     # no rows at all
     e = ops.kron_quant_grouped(x[:0], L, R, dev(np.array([0, 0], dtype=np.int64)), sm[:1], sn[:1], P)
     assert e.q[0].shape == (0, 1024)
-    # a shape without a fused kernel is refused, not silently mis-quantised
+    # a pair only the general MFMA kernel takes (60 x 62) is grouped too; a pair without any kernel is refused
     from flatquant_amd._lib import FqError
-    La, Ra = dev(np.eye(60, dtype=np.float16)), dev(np.eye(62, dtype=np.float16))
+    xa = dev(rng.standard_normal((4, 60 * 62)).astype(np.float16))
+    La, Ra = dev((rng.standard_normal((60, 60)) / 8).astype(np.float16)), dev((rng.standard_normal((62, 62)) / 8).astype(np.float16))
+    ga = ops.kron_quant_grouped(xa, La, Ra, dev(np.array([0, 1, 4], dtype=np.int64)), sm[:2] * 0 + dev(np.array([0.9, 0.6], np.float32)),
+                                sn[:2], P)
+    for (a, b, s_) in ((0, 1, 0.9), (1, 4, 0.6)):
+        ref = ops.kron_quant(xa[a:b].contiguous(), La, Ra, [(s_, 0.8)], P)
+        assert torch.equal(ga.q[0][a:b], ref.q[0]) and torch.equal(ga.scale[0][a:b], ref.scale[0])
     with pytest.raises(FqError):
-        ops.kron_quant_grouped(dev(np.zeros((4, 60 * 62), np.float16)), La, Ra, dev(np.array([0, 4], dtype=np.int64)),
-                               sm[:1], sn[:1], P)
+        ops.kron_quant_grouped(dev(np.zeros((4, 200 * 200), np.float16)), dev(np.eye(200, dtype=np.float16)),
+                               dev(np.eye(200, dtype=np.float16)), dev(np.array([0, 4], dtype=np.int64)), sm[:1], sn[:1], P)
 
 
 def test_moe_routed_experts_match_reference_flow(ops, golden):

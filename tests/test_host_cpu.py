@@ -44,8 +44,9 @@ def test_abi_argument_validation_without_gpu():
     assert lib.fq_hadamard_f16(vp, vp, 4, 96, 1, None, ctypes.c_float(1.0), None) == FQ_EINVAL    # 96 not 2^p
     assert lib.fq_kron_workspace_bytes(64, 64) == 0
     assert lib.fq_kron_workspace_bytes(128, 224) == (7 * 14 + 2 * 4 * 4) * 1024
-    assert lib.fq_kron_workspace_bytes(60, 63) == 0            # no MFMA kernel: the any-shape kernel, no workspace
-    assert lib.fq_kron_workspace_bytes(128, 148) == 0
+    assert lib.fq_kron_workspace_bytes(60, 63) == FQ_EUNSUPPORTED          # odd N: nothing to pack two per byte
+    assert lib.fq_kron_workspace_bytes(128, 148) == (5 * 10 + 2 * 4 * 4) * 1024   # N % 16 != 0: the general MFMA kernel
+    assert lib.fq_kron_workspace_bytes(168, 176) == (6 * 11 + 2 * 6 * 6) * 1024
     assert lib.fq_kron_workspace_bytes(300, 16) == FQ_EUNSUPPORTED and lib.fq_kron_workspace_bytes(200, 200) == FQ_EUNSUPPORTED
     assert lib.fq_kron_quant_f16(vp, vp, vp, None, 0, 64, 64, f4, f4, 1, 1, a4, a4, a4, None, None, 0, None) == 0  # empty
 

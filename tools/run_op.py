@@ -30,7 +30,8 @@ def mat(k):
 P = FQ_OUT_PACKED | FQ_NO_CLAMP0
 if op.startswith("kron") and not op.endswith("g"):
     M, N = {"kron112": (112, 128), "kron128x224": (128, 224), "kron64x128": (64, 128), "kron64x112": (64, 112),
-            "kron86": (86, 128), "kron32x64": (32, 64)}[op]
+            "kron86": (86, 128), "kron32x64": (32, 64), "kron128x148": (128, 148), "kron144x192": (144, 192),
+            "kron168x176": (168, 176), "kron96": (96, 96)}[op]
     rows = 8192 if M * N > 20000 else 16384
     xs = [act(rows, M * N) for _ in range(2)]
     L, R = mat(M), mat(N)
