@@ -77,7 +77,7 @@ __device__ __forceinline__ void gen_copy_out(unsigned char* dst, const unsigned 
     }
 }
 
-template <int MT, int WAVES>
+template <int MT, int WAVES, bool LLDS>
 __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
                                                                    const f16* __restrict__ diag, int64_t rows, GenGeom g,
                                                                    FqQuantOut out, int flags) {
@@ -88,8 +88,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
     const int xs_chunks = MT * 32 * pitch;
     unsigned char* obuf = smem + (size_t)xs_chunks * 16;                 // packed output stage: M*N/2 bytes
     float* red = reinterpret_cast<float*>(obuf + ((M * N / 2 + 15) & ~15));  // [2][WAVES]
+    uint4* lds_l = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(red) + 2 * WAVES * sizeof(float) + 32 - ((2 * WAVES * sizeof(float)) & 15));
     const uint4* rfrag = ws;
-    const uint4* lfrag = ws + (size_t)NT * KS1 * 64;
+    const uint4* lfrag_g = ws + (size_t)NT * KS1 * 64;
 
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,6 +101,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
     FqGroupCursor gcur;
 
     for (int i = tid; i < xs_chunks; i += THREADS) xs[i] = make_uint4(0, 0, 0, 0);  // the padding stays zero
+    if (LLDS) {  // the L fragment image (2 MT^2 KB) fits next to the token: every wave reads all of it once per sweep
+        for (int i = tid; i < 2 * MT * MT * 64; i += THREADS) lds_l[i] = lfrag_g[i];
+    }
 
     for (int64_t tok = blockIdx.x; tok < rows; tok += gridDim.x) {
         __syncthreads();  // everyone is done with xs / obuf of the previous token
@@ -146,8 +150,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) U[mt] = f32x16{0};
             const uint4* rf = rfrag + (size_t)nt * KS1 * 64 + lane;
+            f16x8 bn = __builtin_bit_cast(f16x8, rf[0]);
             for (int s = 0; s < KS1; ++s) {
-                const f16x8 b = __builtin_bit_cast(f16x8, rf[s * 64]);
+                const f16x8 b = bn;
+                if (s + 1 < KS1) bn = __builtin_bit_cast(f16x8, rf[(s + 1) * 64]);  // (from L2: one K-step ahead)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const f16x8 a = __builtin_bit_cast(f16x8, xs[(mt * 32 + c) * pitch + s * 2 + h]);
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
         const float ps = out.post_scale;
         auto row_tile = [&](int mo) -> f32x16 {
             f32x16 Y = f32x16{0};
-            const uint4* lf = lfrag + (size_t)mo * 64 + lane;
+            const uint4* lf = (LLDS ? static_cast<const uint4*>(lds_l) : lfrag_g) + (size_t)mo * 64 + lane;
 #pragma unroll
             for (int ks = 0; ks < 2 * MT; ++ks)
                 if (ks < ks_n) Y = mfma32(Uh[ks >> 1][ks & 1], __builtin_bit_cast(f16x8, lf[(size_t)ks * MT * 64]), Y);
@@ -311,14 +317,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
     }
 }
 
-template <int MT, int WAVES>
-int launch_general(int flags, const f16* x, const uint4* ws, const f16* diag, int64_t rows, const GenGeom& g,
+template <int MT, int WAVES, bool LLDS>
+int launch_general_l(int flags, const f16* x, const uint4* ws, const f16* diag, int64_t rows, const GenGeom& g,
                    const FqQuantOut& out, int n_cu, hipStream_t stream) {
     const size_t xs_bytes = (size_t)MT * 32 * g.pitch * 16;
     const size_t ob = ((size_t)g.M * g.N / 2 + 15) & ~(size_t)15;
-    const size_t lds = xs_bytes + ob + 2 * WAVES * sizeof(float) + 32;
+    const size_t lds = xs_bytes + ob + 2 * WAVES * sizeof(float) + 48 + (LLDS ? (size_t)2 * MT * MT * 1024 : 0);
     if (lds > 160 * 1024) return -1000;
-    auto kern = fq_kron_general_kernel<MT, WAVES>;
+    auto kern = fq_kron_general_kernel<MT, WAVES, LLDS>;
     FQ_RAISE_LDS_CAP(kern, 160 * 1024);
     int per_cu = (int)((160 * 1024) / lds);  // workgroups that fit a CU's LDS: they overlap each other's synchronous token load
     const int cap = WAVES == 4 ? 4 : 2;
@@ -329,6 +335,13 @@ int launch_general(int flags, const f16* x, const uint4* ws, const f16* diag, in
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), lds, stream, x, ws, diag, rows, g, out, flags);
     return (int)hipGetLastError();
+}
+
+template <int MT, int WAVES>
+int launch_general(int flags, const f16* x, const uint4* ws, const f16* diag, int64_t rows, const GenGeom& g,
+                   const FqQuantOut& out, int n_cu, hipStream_t stream) {
+    const int rc = launch_general_l<MT, WAVES, true>(flags, x, ws, diag, rows, g, out, n_cu, stream);  // L image in LDS if it fits
+    return rc != -1000 ? rc : launch_general_l<MT, WAVES, false>(flags, x, ws, diag, rows, g, out, n_cu, stream);
 }
 
 }  // namespace

@@ -22,8 +22,8 @@
 //     complete a row's 64 bytes within the same phase (L2 merges them). (Measured: two contiguous 16-byte stores per wave,
 //     or two row-wise ones, time the same within 2 %.)
 // Same mathematics, rounding points and fragment chaining as the other Kronecker kernels; same workspace image
-// (fq_kron_prepare_kernel). Everything this kernel does not take (fp16 outputs, SiLU.mul input, diag, per-128 scales,
-// M % 4 != 0) stays with fq_kron_generic.hip. What limits it is in DESIGN.md 4.2 (the shader clock under this load).
+// (fq_kron_prepare_kernel). Everything this kernel does not take (fp16 outputs, SiLU.mul input, diag, per-128 scales)
+// stays with fq_kron_generic.hip. What limits it is in DESIGN.md 4.2 (the shader clock under this load).
 #include "fq_common.hpp"
 #include "fq_dma.hpp"
 
@@ -91,7 +91,7 @@ __device__ __forceinline__ void trio_meet(unsigned cnt_lds, unsigned target, int
 }
 #define TRIO_MEET() { meet_n += 4; trio_meet(meet, meet_n, lane); }
 
-template <int MT, bool H16>
+template <int MT, bool H16, bool TAIL>
 __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
                                                                   int64_t rows, int64_t tpb, int M, FqQuantOut out) {
     typedef TrioGeom<MT> G;
@@ -107,10 +107,12 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
     const unsigned ctl_lds = (unsigned)(size_t)(lds_void*)ctl, meet = ctl_lds + grp * 4;
     const unsigned tok_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)tokbuf);
     const int64_t tok_bytes = (int64_t)M * (N * 2);
-    const int n_dma = M >> 2;              // 1 KB instructions per token (M % 4 == 0)
+    const int n_dma = (M + 3) >> 2;        // 1 KB instructions per token; the last one covers M % 4 rows only when M % 4 != 0
     const int per = (n_dma + 3) >> 2;      // this wave stages instructions [d0, d0 + dn)
     const int d0 = wq * per;
     const int dn = n_dma - d0 < per ? (n_dma - d0 < 0 ? 0 : n_dma - d0) : per;
+    const int tail_lanes = (M & 3) * 16;   // lanes of that last instruction that carry data (M = 86: 32)
+    const bool own_tail = TAIL && dn > 0 && d0 + dn == n_dma;   // TAIL: M % 4 != 0 (its own instantiation: registers)
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(x);
 
     const int64_t blk_base = (int64_t)blockIdx.x * tpb;
@@ -132,8 +134,18 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
     __syncthreads();  // (the R fragments have arrived: vmcnt(0); the zero fill is visible before any DMA lands next to it)
 #pragma unroll
     for (int s = 0; s < KS1; ++s) asm volatile("" : "+v"(RF[s]));
-    if (grp < blk_cnt && dn > 0)
-        dma_span(xb + (blk_base + grp) * tok_bytes + (int64_t)d0 * 1024, dn, tok_lds + (unsigned)d0 * 1024, rv);
+    // this wave's share of token k's DMA; a partial last instruction runs with the lanes beyond the token masked off
+    // (they would fetch the next token's bytes into the zero rows below this one)
+    auto stage_token = [&](int k, const unsigned (&rvv)[4]) {
+        const unsigned char* src = xb + (blk_base + k) * tok_bytes + (int64_t)d0 * 1024;
+        const int nfull = own_tail ? dn - 1 : dn;
+        if (nfull > 0) dma_span(src, nfull, tok_lds + (unsigned)d0 * 1024, rvv);
+        if (own_tail && lane < tail_lanes) {
+            const unsigned r1[4] = {rvv[nfull & 3], 0u, 0u, 0u};
+            dma_span(src + (int64_t)nfull * 1024, 1, tok_lds + (unsigned)(d0 + nfull) * 1024, r1);
+        }
+    };
+    if (grp < blk_cnt && dn > 0) stage_token(grp, rv);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     const int sw = swz<CPR>(c);
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
 #pragma unroll
             for (int j = 0; j < 4; ++j) rv[j] = (unsigned)((lb + (pe ^ ((4 * (d0 + j)) & 15))) << 4);
         }
-        if (more) dma_span(xb + (blk_base + knext) * tok_bytes + (int64_t)d0 * 1024, dn, tok_lds + (unsigned)d0 * 1024, rv);
+        if (more) stage_token(knext, rv);
         TRIO_STAMP(4)
         f32x16 Y[MT];  // Y^T of tile (wq, mo): rows n' = h*64 + wq*16 + r, col m' = 32 mo + c
         {
@@ -359,17 +371,23 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
     }
 }
 
-template <int MT, bool H16>
-int launch_trio(const f16* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
+template <int MT, bool H16, bool TAIL>
+int launch_trio_t(const f16* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
     typedef TrioGeom<MT> G;
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
     int64_t blocks = (rows + TRIO_GROUPS - 1) / TRIO_GROUPS;
     if (blocks > n_cu) blocks = n_cu;  // one persistent workgroup per CU
     if (blocks < 1) blocks = 1;
     const int64_t tpb = (rows + blocks - 1) / blocks;
-    hipLaunchKernelGGL((fq_kron_trio_kernel<MT, H16>), dim3((unsigned)blocks), dim3(TRIO_THREADS), 0, stream, x, ws, rows, tpb,
+    hipLaunchKernelGGL((fq_kron_trio_kernel<MT, H16, TAIL>), dim3((unsigned)blocks), dim3(TRIO_THREADS), 0, stream, x, ws, rows, tpb,
                        M, out);
     return (int)hipGetLastError();
+}
+
+template <int MT, bool H16>
+int launch_trio(const f16* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
+    return (M & 3) ? launch_trio_t<MT, H16, true>(x, ws, rows, M, out, n_cu, stream)
+                   : launch_trio_t<MT, H16, false>(x, ws, rows, M, out, n_cu, stream);
 }
 
 }  // namespace
@@ -384,7 +402,7 @@ extern "C" int fq_trio_trace_read(void* dst) {
 // ws: fragment workspace already filled by fq_kron_prepare_kernel (rfrag [4][8][64], lfrag [2MT][MT][64]).
 int fq_launch_kron_trio(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
                         const FqQuantOut& out, int n_cu, hipStream_t stream) {
-    if (N != 128 || M <= 64 || M > 128 || (M & 3) || diag != nullptr) return -1000;
+    if (N != 128 || M <= 64 || M > 128 || diag != nullptr) return -1000;
     if (out.rt_flags & FQ_GROUP128) return -1000;
     const int ct = flags & FQ_CT_MASK;
     const bool h16 = ct == (FQ_OUT_PACKED | FQ_QUANT_F16) && (flags & FQ_ROUND_Y_F16);

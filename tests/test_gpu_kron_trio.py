@@ -1,10 +1,10 @@
-"""GPU parity for fq_kron_trio_kernel (csrc/fq_kron_trio.hip): packed-only launches with 64 < M <= 128, M % 4 == 0, N = 128.
+"""GPU parity for fq_kron_trio_kernel (csrc/fq_kron_trio.hip): packed-only launches with 64 < M <= 128, N = 128.
 
 The kernel shares nothing with the workgroup-per-token kernel but the fragment workspace and the quantiser helpers: its
 token staging (LDS-DMA by four waves), its synchronisation (LDS counters), its token claims and its stores are its own. So
 besides the oracle checks that tests/test_gpu_kron_generic.py runs on 112x128, every case here is also compared BIT FOR BIT
 with the workgroup-per-token kernel (a launch that also asks for the transform takes that one), over ragged row counts
-(fewer tokens than groups, tokens % 3 != 0, more workgroups than CUs), all M the kernel admits, grouped launches, and
+(fewer tokens than groups, tokens % 3 != 0, more workgroups than CUs), all kinds of M the kernel admits (M % 4 != 0: a masked last DMA instruction), grouped launches, and
 repeated launches (a missing meeting shows up as a token that changes between launches).
 """
 import numpy as np
@@ -34,7 +34,7 @@ def make(M, rows, seed, spike=True):
     return x.cuda(), L.cuda(), R.cuda()
 
 
-@pytest.mark.parametrize("M", [68, 96, 100, 112, 128])
+@pytest.mark.parametrize("M", [68, 86, 96, 100, 102, 112, 127, 128])
 @pytest.mark.parametrize("rows", [1, 2, 7, 100, 1000])
 def test_bit_equal_to_workgroup_kernel_and_oracle(ops, M, rows):
     x, L, R = make(M, rows, M * 7 + rows)

@@ -36,7 +36,7 @@ def line(name, shape, us, bytes_per_row, d, rows=ROWS):
 def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     sig = [(0.982, 0.982)]
-    for d in (4096, 8192, 14336, 28672, 11008, 7168, 2048):
+    for d in (4096, 8192, 14336, 28672, 11008, 7168, 2048, 18944, 27648, 29568):  # (the last three: Qwen2.5 ffn widths)
         M, N = get_decompose_dim(d)
         rows = ROWS if d <= 14336 else ROWS // 2
         xs = [torch.randn(rows, d, generator=g, device="cuda", dtype=torch.float16) for _ in range(NB)]
@@ -101,8 +101,11 @@ def main():
     us = timeit(lambda i: ops.silu_mul_kron_quant(gs[i % 2], up, L, R, sig, FQ_OUT_PACKED | FQ_NO_CLAMP0))
     line("silu.mul + kron + quant, one launch", f"d=14336 ({M_}x{N_})", us, 4.5 * 14336 + 2, 14336)
     hk, K = get_hadK(14336)
-    us = timeit(lambda i: ops.hadamard_quant(gs[i % 2], K, hk.half().cuda(), sig[0], up=up))
+    hk = hk.half().cuda()   # (once: the Kronecker factors of this rotation are cached per hadK tensor)
+    us = timeit(lambda i: ops.hadamard_quant(gs[i % 2], K, hk, sig[0], up=up))
     line("silu.mul + hadamard + quantizer", "n=14336 (K=28)", us, 4.5 * 14336 + 2, 14336)
+    us = timeit(lambda i: ops.hadamard_quant(gs[i % 2], K, hk, sig[0]))
+    line("hadamard + quantizer, one launch", "n=14336 (K=28)", us, 2.5 * 14336 + 2, 14336)
     del gs, up
     ks = [torch.randn(ROWS * 8, 128, generator=g, device="cuda", dtype=torch.float16) for _ in range(NB)]
     T = (torch.randn(128, 128, generator=g, device="cuda") / 128 ** 0.5).half()
