@@ -318,8 +318,12 @@ def gen_silu_mul():
     save("silu_mul", gate=gate.numpy(), up=up.numpy(), ac=ac.numpy(), x=x.numpy())
 
 
-def gen_checkpoint():
-    """The reference's export flow on a tiny random Llama (CPU): apply FlatQuant -> seeded 'calibrated' parameters ->
+def gen_checkpoint(hidden=256, ffn=512, heads=4, kv_heads=2, layers=2, name="ckpt", clip_noise=0.05):
+    """(hidden = ffn = 2048, one layer: the K >= 2048 fixture `ckpt2k`, where sym_dequant's multiple-of-10 truncation of the
+    accumulators is ~2-3 % of the output norm instead of ~6 %; its activation clip factors are spread over sigmoid(3..5) so that
+    an exchanged pair shows in the scales, and the reference's fake-quantised activations in front of every linear are kept:
+    `aq_*`.)
+    The reference's export flow on a tiny random Llama (CPU): apply FlatQuant -> seeded 'calibrated' parameters ->
     save_flat_matrices -> reparameterize_model -> RTN weight quantisation -> save_quantized_weights_with_safetensors.
     Writes the two wire formats (flat_matrices.pth, model.safetensors + quantization_config.json) as fixtures under
     tests/golden/ckpt/, and ckpt_io.npz: inputs/outputs of the reference's own (fake-quant, fp32) MLP block and q/k/v
@@ -335,12 +339,12 @@ def gen_checkpoint():
     torch.nn.Module.cuda = lambda self, *a, **k: self
     torch.cuda.empty_cache = lambda: None
     try:
-        cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
-                          num_key_value_heads=2, vocab_size=64, max_position_embeddings=64)
+        cfg = LlamaConfig(hidden_size=hidden, intermediate_size=ffn, num_hidden_layers=layers, num_attention_heads=heads,
+                          num_key_value_heads=kv_heads, vocab_size=64, max_position_embeddings=64)
         cfg._attn_implementation = "eager"
         torch.manual_seed(0)
         model = LlamaForCausalLM(cfg)
-        out_dir = os.path.join(OUT, "ckpt")
+        out_dir = os.path.join(OUT, name)
         shutil.rmtree(out_dir, ignore_errors=True)
         os.makedirs(out_dir)
         args = types.SimpleNamespace(
@@ -352,17 +356,26 @@ def gen_checkpoint():
         g = torch.Generator().manual_seed(1)
         for n, p in model.named_parameters():
             if "trans." in n or "clip_factor" in n:
-                p.data.add_(torch.randn(p.shape, generator=g) * 0.05)
+                p.data.add_(torch.randn(p.shape, generator=g) * (clip_noise if "clip_factor_a" in n else 0.05))
         ref_fu.save_flat_matrices(args, model)
         ref_fu.reparameterize_model(model)
         quantizers = gptq_utils.rtn_fwrd(model, "cpu", args)
         ref_fu.save_quantized_weights_with_safetensors(args, model, quantizers)
         layer = model.model.layers[0]
-        x = (torch.randn(2, 8, 256, generator=g) * 1.5).to(torch.float16)
+        x = (torch.randn(2, 8, hidden, generator=g) * 1.5).to(torch.float16)
+        aq, hooks = {}, []
+        for tag, mod in (("q", layer.self_attn.q_proj), ("k", layer.self_attn.k_proj), ("v", layer.self_attn.v_proj),
+                         ("up", layer.mlp.up_proj), ("gate", layer.mlp.gate_proj), ("down", layer.mlp.down_proj)):
+            hooks.append(mod.act_quantizer.register_forward_hook(
+                lambda m, i, o, tag=tag: aq.__setitem__("aq_" + tag, o.detach().float().numpy().copy())))
+        hooks.append(layer.mlp.down_trans.register_forward_hook(       # x_up * silu(x_gate): the input of the down_proj stage
+            lambda m, i, o: aq.__setitem__("act", i[0].detach().float().numpy().copy())))
         with torch.no_grad():
             mlp_out = layer.mlp(x.float())
             q, k, v = layer.self_attn._trans_forward_after_ln(x.float())
-        save("ckpt_io", x=x.numpy(), mlp_out=mlp_out.numpy(), q=q.numpy(), k=k.numpy(), v=v.numpy())
+        for h in hooks:
+            h.remove()
+        save(name + "_io", x=x.numpy(), mlp_out=mlp_out.numpy(), q=q.numpy(), k=k.numpy(), v=v.numpy(), **aq)
         print(sorted(os.listdir(out_dir)), sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir)))
     finally:
         torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.empty_cache = saved
@@ -574,6 +587,9 @@ def gen_round2():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "ckpt2k":   # the K = 2048 export (12 MB): only on request
+        gen_checkpoint(hidden=2048, ffn=2048, heads=16, kv_heads=2, layers=1, name="ckpt2k", clip_noise=0.6)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "r2":
         gen_round2()
         sys.exit(0)
