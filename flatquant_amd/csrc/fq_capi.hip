@@ -36,10 +36,10 @@ int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, in
 int fq_launch_kv_append(void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last, const uint8_t* k,
                         const uint8_t* v, const f16* kparam, const f16* vparam, const int* seqlen_indptr, int64_t total_tokens,
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, int group, int n_cu,
-                        hipStream_t stream);
+                        hipStream_t stream, bool f16_cache = false);
 int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, const f16* qt,
-                        int transpose_out, hipStream_t stream);
+                        int transpose_out, hipStream_t stream, bool f16_cache = false);
 int fq_launch_silu_mul(const f16* gate, const f16* up, f16* y, int64_t n, int n_cu, hipStream_t stream);
 int fq_launch_silu_hadamard_quant(const f16* gate, const f16* up, int64_t rows, int n, int K, const f16* hadK, float scale,
                                   float sig_max, float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream);
@@ -515,6 +515,46 @@ int fq_kv_append_i4(void* kv_data, void* kv_param, const void* kv_indptr, const 
                              (const int*)seqlen_indptr, tokens, num_layers, layer_idx, num_heads, page_size, head_dim, batch_size,
                              group_size, cu_count(), (hipStream_t)stream);
     return check_launch(rc, "fq_kv_append_i4");
+}
+
+int fq_kv_append_f16(void* kv_data, void* kv_param, const void* kv_indptr, const void* kv_indices,
+                     const void* last_page_offset, const void* k, const void* v, const void* k_param, const void* v_param,
+                     const void* seqlen_indptr, int64_t tokens, int num_layers, int layer_idx, int num_heads, int page_size,
+                     int head_dim, int batch_size, int group_size, void* stream) {
+    int rc = kv_geometry_ok("fq_kv_append_f16", num_layers, layer_idx, num_heads, page_size, head_dim, batch_size);
+    if (rc != FQ_OK) return rc;
+    if (group_size < 1 || num_heads % group_size) return fail(FQ_EINVAL, "fq_kv_append_f16: group_size=%d must divide num_heads=%d", group_size, num_heads);
+    if (tokens < 0) return fail(FQ_EINVAL, "fq_kv_append_f16: tokens < 0");
+    if (!seqlen_indptr && tokens != batch_size) return fail(FQ_EINVAL, "fq_kv_append_f16: without seqlen_indptr every request appends one token (tokens == batch_size)");
+    if (tokens == 0) return FQ_OK;
+    if (!kv_data || !kv_param || !kv_indptr || !kv_indices || !last_page_offset || !k || !v || !k_param || !v_param)
+        return fail(FQ_EINVAL, "fq_kv_append_f16: NULL pointer");
+    rc = fq_launch_kv_append(kv_data, kv_param, (const int*)kv_indptr, (const int*)kv_indices, (const int*)last_page_offset,
+                             (const uint8_t*)k, (const uint8_t*)v, (const f16*)k_param, (const f16*)v_param,
+                             (const int*)seqlen_indptr, tokens, num_layers, layer_idx, num_heads, page_size, head_dim, batch_size,
+                             group_size, cu_count(), (hipStream_t)stream, true);
+    return check_launch(rc, "fq_kv_append_f16");
+}
+
+int fq_kv_batch_decode_f16_ex(void* o, const void* q, const void* q_trans, int transpose_out, const void* kv_data,
+                              const void* kv_param, const void* kv_indptr, const void* kv_indices,
+                              const void* last_page_offset, int num_layers, int layer_idx, int num_heads, int page_size,
+                              int head_dim, int batch_size, void* stream) {
+    int rc = kv_geometry_ok("fq_kv_batch_decode_f16", num_layers, layer_idx, num_heads, page_size, head_dim, batch_size);
+    if (rc != FQ_OK) return rc;
+    if (!o || !q || !kv_data || !kv_indptr || !kv_indices || !last_page_offset)
+        return fail(FQ_EINVAL, "fq_kv_batch_decode_f16: NULL pointer");
+    rc = fq_launch_kv_decode((f16*)o, (const f16*)q, (void*)kv_data, (void*)kv_param, (const int*)kv_indptr,
+                             (const int*)kv_indices, (const int*)last_page_offset, num_layers, layer_idx, num_heads, page_size,
+                             head_dim, batch_size, (const f16*)q_trans, transpose_out != 0, (hipStream_t)stream, true);
+    return check_launch(rc, "fq_kv_batch_decode_f16");
+}
+
+int fq_kv_batch_decode_f16(void* o, const void* q, const void* kv_data, const void* kv_param, const void* kv_indptr,
+                           const void* kv_indices, const void* last_page_offset, int num_layers, int layer_idx,
+                           int num_heads, int page_size, int head_dim, int batch_size, void* stream) {
+    return fq_kv_batch_decode_f16_ex(o, q, nullptr, 0, kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, num_layers,
+                                     layer_idx, num_heads, page_size, head_dim, batch_size, stream);
 }
 
 int fq_kv_quant_append_i4(const void* k, const void* v, const void* trans, int64_t tokens, int src_heads, int head_dim,

@@ -35,12 +35,15 @@ __device__ __forceinline__ size_t v_entry(const PagedKv& p, size_t page, size_t 
 
 // page.cuh:118-214. seqlen_indptr == nullptr: one token per request (append_kv_i4), else request b appends
 // seqlen_indptr[b+1] - seqlen_indptr[b] tokens that END at its current length (init_kv_i4).
-// One thread per 16 bytes of one (token, head) row of k and of v.
+// One thread per 16 bytes of one (token, head) row of k and of v. F16: the fp16 configuration of the cache
+// (disable_quant=True, init_kv_f16 / append_kv_f16): rows of head_dim fp16 values instead of head_dim / 2 bytes.
+template <bool F16>
 __global__ __launch_bounds__(256) void fq_kv_append_kernel(PagedKv p, const uint8_t* __restrict__ key,
                                                            const uint8_t* __restrict__ value, const f16* __restrict__ kparam,
                                                            const f16* __restrict__ vparam, const int* __restrict__ seqlen_indptr,
                                                            int64_t total_tokens, int group) {
-    const int cpr = p.head_dim / 32;  // 16-byte chunks per packed row
+    const int row_bytes = F16 ? p.head_dim * 2 : p.head_dim / 2;
+    const int cpr = row_bytes / 16;  // 16-byte chunks per cached row
     const int64_t items = total_tokens * p.num_heads * cpr;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
         const int ch = (int)(i % cpr);
@@ -66,9 +69,9 @@ __global__ __launch_bounds__(256) void fq_kv_append_kernel(PagedKv p, const uint
         const size_t ke = k_entry(p, page, head, entry), ve = v_entry(p, page, head, entry);
         // grouped-query attention (kv_cache.py:286-296): the inputs hold num_heads / group heads, cache head h copies head h / group
         const size_t shead = (size_t)tok * (p.num_heads / group) + head / group;
-        const size_t src = shead * (p.head_dim / 2) + (size_t)ch * 16;
-        *reinterpret_cast<uint4*>(p.data + ke * (p.head_dim / 2) + ch * 16) = *reinterpret_cast<const uint4*>(key + src);
-        *reinterpret_cast<uint4*>(p.data + ve * (p.head_dim / 2) + ch * 16) = *reinterpret_cast<const uint4*>(value + src);
+        const size_t src = shead * row_bytes + (size_t)ch * 16;
+        *reinterpret_cast<uint4*>(p.data + ke * row_bytes + ch * 16) = *reinterpret_cast<const uint4*>(key + src);
+        *reinterpret_cast<uint4*>(p.data + ve * row_bytes + ch * 16) = *reinterpret_cast<const uint4*>(value + src);
         if (ch == 0) {
             reinterpret_cast<uint32_t*>(p.param)[ke] = reinterpret_cast<const uint32_t*>(kparam)[shead];
             reinterpret_cast<uint32_t*>(p.param)[ve] = reinterpret_cast<const uint32_t*>(vparam)[shead];
@@ -76,7 +79,9 @@ __global__ __launch_bounds__(256) void fq_kv_append_kernel(PagedKv p, const uint
     }
 }
 
-template <int HD, int NW>  // NW waves per workgroup: 4, or 8 when there are too few (request, head) pairs to fill the chip
+// F16: the fp16 configuration of the cache (batch_decode_f16): a cached row is head_dim fp16 values, no (scale, zero); a lane
+// still owns 32 features of a row (64 bytes: four 16-byte loads).
+template <int HD, int NW, bool F16 = false>  // NW waves per workgroup: 4, or 8 when there are too few (request, head) pairs to fill the chip
 __global__ __launch_bounds__(NW * 64) void fq_kv_decode_kernel(f16* __restrict__ o, const f16* __restrict__ q, PagedKv p,
                                                                const f16* __restrict__ qt, int transpose_out) {
     constexpr int QL = HD / 32;        // lanes per cached row (16 bytes = 32 features each): 4 for head_dim 128
@@ -139,19 +144,39 @@ __global__ __launch_bounds__(NW * 64) void fq_kv_decode_kernel(f16* __restrict__
             ++pit;
         }
         const size_t ke = page * page_stride + k_off + entry, ve = ke + kv_off;   // = k_entry / v_entry, constants hoisted
-        const uint4 kq = *reinterpret_cast<const uint4*>(p.data + ke * (HD / 2) + part * 16);
-        const uint4 vq = *reinterpret_cast<const uint4*>(p.data + ve * (HD / 2) + part * 16);
-        const uint32_t kpar = reinterpret_cast<const uint32_t*>(p.param)[ke];
-        const uint32_t vpar = reinterpret_cast<const uint32_t*>(p.param)[ve];
-        const float ks = (float)__builtin_bit_cast(f16, (unsigned short)(kpar & 0xFFFF)), kz = (float)__builtin_bit_cast(f16, (unsigned short)(kpar >> 16));
-        const float vs = (float)__builtin_bit_cast(f16, (unsigned short)(vpar & 0xFFFF)), vz = (float)__builtin_bit_cast(f16, (unsigned short)(vpar >> 16));
-        const uint32_t kw[4] = {kq.x, kq.y, kq.z, kq.w}, vw[4] = {vq.x, vq.y, vq.z, vq.w};
-        float dotn = 0.0f;
+        float part_dot, vf[32], vs = 1.0f, vz = 0.0f;   // v_j = vf[j] * vs - vz
+        if (F16) {
+            const uint4* kp = reinterpret_cast<const uint4*>(p.data + ke * (HD * 2) + part * 64);
+            const uint4* vp = reinterpret_cast<const uint4*>(p.data + ve * (HD * 2) + part * 64);
+            part_dot = 0.0f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
+            for (int w = 0; w < 4; ++w) {
+                const f16x8 kh = __builtin_bit_cast(f16x8, kp[w]), vh = __builtin_bit_cast(f16x8, vp[w]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dotn = __builtin_fmaf(qv[w * 8 + e], (float)((kw[w] >> (4 * e)) & 15u), dotn);
-        float part_dot = ks * dotn - kz * qsum;       // this lane's 32 features of q . k
+                for (int e = 0; e < 8; ++e) {
+                    part_dot = __builtin_fmaf(qv[w * 8 + e], (float)kh[e], part_dot);
+                    vf[w * 8 + e] = (float)vh[e];
+                }
+            }
+        } else {
+            const uint4 kq = *reinterpret_cast<const uint4*>(p.data + ke * (HD / 2) + part * 16);
+            const uint4 vq = *reinterpret_cast<const uint4*>(p.data + ve * (HD / 2) + part * 16);
+            const uint32_t kpar = reinterpret_cast<const uint32_t*>(p.param)[ke];
+            const uint32_t vpar = reinterpret_cast<const uint32_t*>(p.param)[ve];
+            const float ks = (float)__builtin_bit_cast(f16, (unsigned short)(kpar & 0xFFFF)), kz = (float)__builtin_bit_cast(f16, (unsigned short)(kpar >> 16));
+            vs = (float)__builtin_bit_cast(f16, (unsigned short)(vpar & 0xFFFF));
+            vz = (float)__builtin_bit_cast(f16, (unsigned short)(vpar >> 16));
+            const uint32_t kw[4] = {kq.x, kq.y, kq.z, kq.w}, vw[4] = {vq.x, vq.y, vq.z, vq.w};
+            float dotn = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    dotn = __builtin_fmaf(qv[w * 8 + e], (float)((kw[w] >> (4 * e)) & 15u), dotn);
+                    vf[w * 8 + e] = (float)((vw[w] >> (4 * e)) & 15u);
+                }
+            part_dot = ks * dotn - kz * qsum;       // this lane's 32 features of q . k
+        }
 #pragma unroll
         for (int off = 1; off < QL; off <<= 1) part_dot += __shfl_xor(part_dot, off, 64);
         const float x = part_dot * sm_scale;
@@ -160,10 +185,7 @@ __global__ __launch_bounds__(NW * 64) void fq_kv_decode_kernel(f16* __restrict__
         d = d * alpha + pr;
         const float pvs = pr * vs, pvz = pr * vz;
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                acc[w * 8 + e] = __builtin_fmaf((float)((vw[w] >> (4 * e)) & 15u), pvs, acc[w * 8 + e] * alpha - pvz);
+        for (int j = 0; j < 32; ++j) acc[j] = __builtin_fmaf(vf[j], pvs, acc[j] * alpha - pvz);
         m = m_new;
     }
     const int st = wave * RPW + slot;
@@ -212,29 +234,38 @@ static PagedKv make_kv(void* kv_data, void* kv_param, const int* indptr, const i
 int fq_launch_kv_append(void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last, const uint8_t* k,
                         const uint8_t* v, const f16* kparam, const f16* vparam, const int* seqlen_indptr, int64_t total_tokens,
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, int group, int n_cu,
-                        hipStream_t stream) {
+                        hipStream_t stream, bool f16_cache) {
     if (head_dim % 32 || group < 1 || num_heads % group) return -1000;
     const PagedKv p = make_kv(kv_data, kv_param, indptr, indices, last, num_layers, layer_idx, num_heads, page_size, head_dim, batch);
-    const int64_t items = total_tokens * num_heads * (head_dim / 32);
+    const int64_t items = total_tokens * num_heads * (f16_cache ? head_dim / 8 : head_dim / 32);
     int64_t blocks = (items + 255) / 256;
     if (blocks > (int64_t)n_cu * 16) blocks = (int64_t)n_cu * 16;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(fq_kv_append_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, k, v, kparam, vparam, seqlen_indptr,
-                       total_tokens, group);
+    if (f16_cache)
+        hipLaunchKernelGGL(fq_kv_append_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, p, k, v, kparam, vparam,
+                           seqlen_indptr, total_tokens, group);
+    else
+        hipLaunchKernelGGL(fq_kv_append_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, p, k, v, kparam, vparam,
+                           seqlen_indptr, total_tokens, group);
     return (int)hipGetLastError();
 }
 
 int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, const f16* qt,
-                        int transpose_out, hipStream_t stream) {
+                        int transpose_out, hipStream_t stream, bool f16_cache) {
     const PagedKv p = make_kv(kv_data, kv_param, indptr, indices, last, num_layers, layer_idx, num_heads, page_size, head_dim, batch);
     const dim3 grid((unsigned)batch, (unsigned)num_heads);
     const bool wide = (int64_t)batch * num_heads < 512;  // fewer than two workgroups per CU: 8 waves each instead of 4 (measured: 158 -> 113 us at 8 x 8192; no gain from 512 up)
 #define FQ_DEC(HD_, NW_)                                                                                              \
     {                                                                                                                 \
         constexpr size_t lds = sizeof(float) * ((size_t)(NW_ * (64 / (HD_ / 32))) * (HD_ + 1 + 2) + HD_);                     \
-        FQ_RAISE_LDS_CAP((fq_kv_decode_kernel<HD_, NW_>), lds);                                                       \
-        hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
+        if (f16_cache) {                                                                                              \
+            FQ_RAISE_LDS_CAP((fq_kv_decode_kernel<HD_, NW_, true>), lds);                                             \
+            hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_, true>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
+        } else {                                                                                                      \
+            FQ_RAISE_LDS_CAP((fq_kv_decode_kernel<HD_, NW_>), lds);                                                   \
+            hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
+        }                                                                                                             \
     }
     if (head_dim == 128) {
         if (wide) FQ_DEC(128, 8) else FQ_DEC(128, 4)

@@ -67,24 +67,31 @@ def batch_decode_i4(o, q, kv_data, kv_param, kv_indptr, kv_indices, last_page_of
 
 
 class MultiLayerPagedKVCache4Bit:
-    """The INT4 configuration of kv_cache.py:166-359 (``disable_quant=False``, ``trans`` "matmul" or "none") with the
-    same constructor arguments, page / scale tensors and ``update`` contract: the first call per layer stores the
-    (transformed, quantised) prompt keys / values and returns the fp16 key / value states for the prefill attention; every
-    later call appends one token per request and returns a callable that runs the INT4 decode attention for the
-    layer's query ([bsz, 1, heads, head_dim] -> the same shape). Requests have equal lengths (no attention mask), as
-    the reference's own restriction to one page count per batch implies (:371-372). trans="had" (QuaRot: a normalised
-    Hadamard rotation of keys and queries over head_dim, kv_cache.py:64-67) runs the register FWHT (fq_hadamard_f16)
-    in front of the quantiser / of the decode attention."""
+    """kv_cache.py:166-392 with the same constructor arguments, page / scale tensors and ``update`` contract: the first call
+    per layer stores the (transformed, quantised) prompt keys / values and returns the fp16 key / value states for the prefill
+    attention; every later call appends one token per request and returns a callable that runs the decode attention for the
+    layer's query ([bsz, 1, heads, head_dim] -> the same shape).
+
+    * ``disable_quant=False``: the INT4 cache (uint8 pages of head_dim / 2 bytes per row + (scale, zero) per row);
+      ``disable_quant=True``: the fp16 configuration (:177-190, init_kv_f16 / append_kv_f16 / batch_decode_f16): fp16 pages,
+      the scale tensor is kept and filled with (1, 0) like the reference's, the prefill gets the UN-transformed states back
+      (:262-263 are assigned before the transform and only the INT4 branch re-assigns them, :280-281).
+    * ``trans`` "matmul*" (the learned K transform, with its inverse-transpose on the query side), "had" (QuaRot: a normalised
+      Hadamard rotation of keys and queries over head_dim, :64-67, here the register FWHT) or anything else (none).
+    * ``cache_kwargs["attention_mask"]`` [bsz, seq] of 0 / 1 (ragged prompts, :315-326,362-372): the prompt tokens whose mask
+      is 1 are compacted request by request into the cache; request lengths are the mask's row sums from then on (the mask
+      grows by one column per decode step). As in the reference, all requests must need the same number of pages
+      (NotImplementedError otherwise, :371-372)."""
 
     def __init__(self, batch_size, page_size, max_seq_len, device, n_layers, num_heads, head_dim, disable_quant=False,
                  trans_dtype=torch.float16, trans="had", group_size=1):
-        if disable_quant:
-            raise NotImplementedError("flatquant_amd: the fp16 configuration of the paged cache is not built")
         self.page_size, self.batch_size, self.max_seq_len = page_size, batch_size, max_seq_len
         self.device, self.n_layers, self.trans, self.group_size = device, n_layers, trans, group_size
+        self.disable_quant = disable_quant
         self.org_head_dim = head_dim
         n_pages = self.page_cnt_from_length(max_seq_len) * batch_size
-        self.pages = torch.empty((n_pages, n_layers, 2, num_heads, page_size, head_dim // 2), dtype=torch.uint8, device=device)
+        self.pages = torch.empty((n_pages, n_layers, 2, num_heads, page_size, head_dim if disable_quant else head_dim // 2),
+                                 dtype=torch.float16 if disable_quant else torch.uint8, device=device)
         self.scales = torch.empty((n_pages, n_layers, 2, num_heads, page_size, 2), dtype=torch.float16, device=device)
         self._needs_init = [True] * n_layers
         self.length = 0
@@ -108,26 +115,36 @@ class MultiLayerPagedKVCache4Bit:
     def get_seq_length(self, layer_idx=0):
         return self.length
 
-    def get_cache_specs_for_flash_infer(self):
-        """kv_cache.py:362-385 without an attention mask: page p of request b is page index p * batch_size + b."""
-        page_cnt = self.page_cnt_from_length(self.length)
-        ptr = self.length % self.page_size
-        if self.length != 0 and ptr == 0:
-            ptr = self.page_size
+    def get_cache_specs_for_flash_infer(self, attention_mask=None):
+        """kv_cache.py:362-385: page p of request b is page index p * batch_size + b; without a mask every request has
+        ``self.length`` tokens, with one its row sum."""
         dev = self.device
+        if attention_mask is None:
+            page_cnt = self.page_cnt_from_length(self.length)
+            ptr = self.length % self.page_size
+            if self.length != 0 and ptr == 0:
+                ptr = self.page_size
+            last = torch.full((self.batch_size,), ptr, device=dev, dtype=torch.int32)
+        else:
+            seqlens = attention_mask.to(dev).sum(dim=-1, dtype=torch.int32)
+            cnt = self.page_cnt_from_length(seqlens)
+            if bool((cnt[0] != cnt).any()):                                            # (:371-372, a host read as there)
+                raise NotImplementedError("Current implementation does not support the case where batches have different number of pages")
+            page_cnt = int(cnt[0])
+            last = seqlens % self.page_size
+            last = torch.where((seqlens != 0) & (last == 0), torch.full_like(last, self.page_size), last).to(torch.int32).contiguous()
         return {
             "kv_data": self.pages,
             "kv_param": self.scales,
             "kv_indptr": torch.arange(0, self.batch_size + 1, device=dev, dtype=torch.int32) * page_cnt,
             "kv_indices": ((torch.arange(page_cnt, device=dev, dtype=torch.int32) * self.batch_size).unsqueeze(0)
                            + torch.arange(self.batch_size, device=dev, dtype=torch.int32).unsqueeze(1)).reshape(-1).contiguous(),
-            "last_page_offset": torch.full((self.batch_size,), ptr, device=dev, dtype=torch.int32),
+            "last_page_offset": last,
         }
 
     def update(self, key_states, value_states, layer_idx, cache_kwargs=None):
         cache_kwargs = cache_kwargs or {}
-        if cache_kwargs.get("attention_mask") is not None:
-            raise NotImplementedError("flatquant_amd: ragged batches (attention_mask) are not built")
+        mask = cache_kwargs.get("attention_mask")
         b, added, heads, hd = key_states.shape
         assert b == self.batch_size
         tk = cache_kwargs.get("trans_matrix_k") if self.trans.startswith("matmul") else None
@@ -137,20 +154,55 @@ class MultiLayerPagedKVCache4Bit:
         if layer_idx == 0:
             self._ensure_page_cnt_per_batch(self.page_cnt_from_length(self.length + added))
             self.length += added
-        if getattr(self, "_specs_len", None) != (self.length, self.pages.data_ptr()):   # index tensors: once per step, not per layer
-            self._specs, self._specs_len = self.get_cache_specs_for_flash_infer(), (self.length, self.pages.data_ptr())
+        key = (self.length, self.pages.data_ptr(), None if mask is None else (mask.data_ptr(), mask._version, tuple(mask.shape)))
+        if getattr(self, "_specs_key", None) != key:   # index tensors: once per step, not per layer
+            self._specs, self._specs_key = self.get_cache_specs_for_flash_infer(mask), key
         specs = self._specs
         args = (specs["kv_data"], specs["kv_param"], specs["kv_indptr"], specs["kv_indices"], specs["last_page_offset"])
         tk16 = None if tk is None else tk.to(device=key_states.device, dtype=torch.float16).contiguous()
         had = self.trans == "had"
+        orig_k, orig_v = key_states, value_states
+        init = self._needs_init[layer_idx]
         if had:                                                         # :265-266 matmul_had_cuda on the keys
             key_states = ops.hadamard(key_states.to(torch.float16).contiguous())
-        # K transform + K / V quantisation + append: one launch (fq_kv_quant_append_i4)
-        ops.kv_quant_append(key_states.contiguous(), value_states.contiguous(), tk16, *args, layer_idx, self.group_size)
-        if self._needs_init[layer_idx]:
+        ragged_init = init and mask is not None
+        if not self.disable_quant and not ragged_init:
+            # K transform + K / V quantisation + append: one launch (fq_kv_quant_append_i4); every request appends `added`
+            # tokens at the end of ITS length (last_page_offset is per request)
+            ops.kv_quant_append(key_states.contiguous(), value_states.contiguous(), tk16, *args, layer_idx, self.group_size)
+            keys_t = None
+        else:
+            keys_t = key_states.to(torch.float16) if tk16 is None else torch.matmul(key_states.to(torch.float16), tk16)
+            if self.disable_quant:                                      # :270-274: fp16 rows, (scale, zero) = (1, 0)
+                kq, vq = keys_t.contiguous(), value_states.to(torch.float16).contiguous()
+                one = torch.tensor([1.0, 0.0], dtype=torch.float16, device=kq.device)
+                kp = one.expand(b, added, heads, 2).contiguous()
+                vp = kp
+            else:
+                kq, kp = ops.kv_quant(keys_t.contiguous())
+                vq, vp = ops.kv_quant(value_states.to(torch.float16).contiguous())
+            kq, vq = kq.reshape(b * added, heads, -1), vq.reshape(b * added, heads, -1)
+            kp, vp = kp.reshape(b * added, heads, 2), vp.reshape(b * added, heads, 2)
+            if init:
+                if mask is not None:                                    # :315-326: keep the tokens whose mask is 1
+                    m = mask.to(kq.device)
+                    keep = torch.nonzero(m.flatten(), as_tuple=False).flatten()
+                    kq, vq, kp, vp = (t.index_select(0, keep).contiguous() for t in (kq, vq, kp, vp))
+                    indptr = torch.nn.functional.pad(torch.cumsum(m.sum(dim=-1, dtype=torch.int32), 0, dtype=torch.int32), (1, 0))
+                else:
+                    indptr = torch.arange(b + 1, device=kq.device, dtype=torch.int32) * added
+                ops.kv_append(*args, kq.contiguous(), vq.contiguous(), kp.contiguous(), vp.contiguous(), layer_idx,
+                              indptr.contiguous(), self.group_size)
+            else:
+                ops.kv_append(*args, kq.contiguous(), vq.contiguous(), kp.contiguous(), vp.contiguous(), layer_idx, None,
+                              self.group_size)
+        if init:
             self._needs_init[layer_idx] = False
-            keys = key_states if tk16 is None else torch.matmul(key_states.to(torch.float16), tk16)
-            return keys, value_states                                   # :341-344: the un-quantised states for prefill
+            if self.disable_quant:
+                return orig_k, orig_v                                   # :262-263 (never re-assigned on this branch)
+            if keys_t is None:
+                keys_t = key_states if tk16 is None else torch.matmul(key_states.to(torch.float16), tk16)
+            return keys_t, value_states                                 # :280-281,341-344: the un-quantised states for prefill
         assert added == 1
 
         def attend(q, transposed=False):

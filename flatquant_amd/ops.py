@@ -687,10 +687,12 @@ def _chk_kv_index(kv_indptr: torch.Tensor, kv_indices: torch.Tensor, last_page_o
 
 
 def _kv_geometry(kv_data: torch.Tensor):
-    pages, n_layers, two, heads, page_size, half_hd = kv_data.shape
-    if two != 2:
-        raise ValueError("kv_data must be [pages, layers, 2, heads, page_size, head_dim/2]")
-    return n_layers, heads, page_size, half_hd * 2
+    """-> (layers, heads, page_size, head_dim) of a paged cache: uint8 pages hold head_dim / 2 bytes per row (INT4), float16
+    pages head_dim values (the ``disable_quant`` configuration, kv_cache.py:177-190)."""
+    pages, n_layers, two, heads, page_size, last = kv_data.shape
+    if two != 2 or kv_data.dtype not in (torch.uint8, torch.float16):
+        raise ValueError("kv_data must be [pages, layers, 2, heads, page_size, head_dim/2] uint8 or [..., head_dim] float16")
+    return n_layers, heads, page_size, last * 2 if kv_data.dtype == torch.uint8 else last
 
 
 def kv_append(kv_data: torch.Tensor, kv_param: torch.Tensor, kv_indptr: torch.Tensor, kv_indices: torch.Tensor,
@@ -700,20 +702,21 @@ def kv_append(kv_data: torch.Tensor, kv_param: torch.Tensor, kv_indptr: torch.Te
     packed keys / values [tokens, heads, head_dim/2] uint8 and their (scale, zero) [tokens, heads, 2] fp16 into the paged
     cache (fq_kv_append_i4). The index tensors are int32 on the cache's device. ``group_size`` g: k / v hold heads / g
     heads and every cache head h receives head h // g (the GQA repeat of kv_cache.py:286-296, done by the scatter)."""
-    _chk(kv_data, "kv_data", torch.uint8), _chk(kv_param, "kv_param"), _chk(k, "k", torch.uint8), _chk(v, "v", torch.uint8)
+    f16c = kv_data.dtype == torch.float16            # init_kv_f16 / append_kv_f16 (kv_cache.py:107-129): fp16 rows
+    _chk(kv_data, "kv_data", kv_data.dtype), _chk(kv_param, "kv_param"), _chk(k, "k", kv_data.dtype), _chk(v, "v", kv_data.dtype)
     _chk(k_param, "k_param"), _chk(v_param, "v_param")
     batch = _chk_kv_index(kv_indptr, kv_indices, last_page_offset)
     if seqlen_indptr is not None:
         _chk(seqlen_indptr, "seqlen_indptr", torch.int32)
     n_layers, heads, page_size, hd = _kv_geometry(kv_data)
     src_heads = heads // group_size
-    tokens = k.numel() // (src_heads * hd // 2)
+    tokens = k.numel() // (src_heads * (hd if f16c else hd // 2))
     if k.shape != v.shape or k_param.numel() != tokens * src_heads * 2 or v_param.numel() != tokens * src_heads * 2:
         raise ValueError("k / v / k_param / v_param shapes do not agree")
     with torch.cuda.device(kv_data.device):
-        check(lib.fq_kv_append_i4(_ptr(kv_data), _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
-                                  _ptr(k), _ptr(v), _ptr(k_param), _ptr(v_param), _ptr(seqlen_indptr), tokens, n_layers,
-                                  layer_idx, heads, page_size, hd, batch, group_size, _stream(kv_data)))
+        check((lib.fq_kv_append_f16 if f16c else lib.fq_kv_append_i4)(_ptr(kv_data), _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
+            _ptr(k), _ptr(v), _ptr(k_param), _ptr(v_param), _ptr(seqlen_indptr), tokens, n_layers,
+            layer_idx, heads, page_size, hd, batch, group_size, _stream(kv_data)))
 
 
 def kv_quant_append(k: torch.Tensor, v: torch.Tensor, trans: Optional[torch.Tensor], kv_data: torch.Tensor,
@@ -746,9 +749,10 @@ def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tens
     """batch_decode_i4 (kv_cache.py:98-105): q [batch, heads, head_dim] fp16 -> o of the same shape, attention over each
     request's cached rows (fq_kv_batch_decode_i4[_ex]). ``q_trans`` [head_dim, head_dim]: the query is multiplied by it
     inside the launch; ``transpose_out``: o comes back as [batch, head_dim, heads]."""
-    _chk(q, "q"), _chk(kv_data, "kv_data", torch.uint8), _chk(kv_param, "kv_param")
+    _chk(q, "q"), _chk(kv_data, "kv_data", kv_data.dtype), _chk(kv_param, "kv_param")
     n_layers, heads, page_size, hd = _kv_geometry(kv_data)
     batch = _chk_kv_index(kv_indptr, kv_indices, last_page_offset)
+    decode = lib.fq_kv_batch_decode_f16_ex if kv_data.dtype == torch.float16 else lib.fq_kv_batch_decode_i4_ex
     if q.shape != (batch, heads, hd):
         raise ValueError(f"q must be [{batch}, {heads}, {hd}]")
     if q_trans is not None:
@@ -759,9 +763,9 @@ def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tens
     if batch == 0:
         return o
     with torch.cuda.device(q.device):
-        check(lib.fq_kv_batch_decode_i4_ex(_ptr(o), _ptr(q), _ptr(q_trans), 1 if transpose_out else 0, _ptr(kv_data),
-                                           _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
-                                           n_layers, layer_idx, heads, page_size, hd, batch, _stream(q)))
+        check(decode(_ptr(o), _ptr(q), _ptr(q_trans), 1 if transpose_out else 0, _ptr(kv_data),
+                     _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
+                     n_layers, layer_idx, heads, page_size, hd, batch, _stream(q)))
     return o
 
 

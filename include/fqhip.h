@@ -27,6 +27,7 @@
  *                          deploy/functional/online_trans.py:144-151
  *   fq_kv_quant_f16, fq_kv_dequant_f16   deploy/transformers/kv_cache.py:11-61,268 (K transform + asym INT4 pack)
  *   fq_kv_append_i4, fq_kv_batch_decode_i4   deploy/kernels/flashinfer.cu:9-96 (paged INT4 cache append + decode attention)
+ *   fq_kv_append_f16, fq_kv_batch_decode_f16 deploy/kernels/flashinfer.cu:98-224 (the fp16 configuration of the same cache)
  *   fq_rowquant_f16        deploy/nn/quantization.py:13-36 (Quantizer.forward),
  *                          flatquant/quant_utils.py:77-119
  *   fq_sym_quant_f16       deploy/kernels/bindings.cpp:27-44 -> quant.cu:13-63 (sym_quant)
@@ -350,6 +351,25 @@ int fq_kv_batch_decode_i4_ex(void* o, const void* q, const void* q_trans, int tr
                              const void* kv_param, const void* kv_indptr, const void* kv_indices,
                              const void* last_page_offset, int num_layers, int layer_idx, int num_heads, int page_size,
                              int head_dim, int batch_size, void* stream);
+
+/*
+ * The fp16 configuration of the same cache (MultiLayerPagedKVCache4Bit(disable_quant=True), kv_cache.py:177-190;
+ * init_kv_f16 / append_kv_f16 / batch_decode_f16, kv_cache.py:107-137): kv_data [pages, num_layers, 2, num_heads, page_size,
+ * head_dim] fp16; k, v [tokens, num_heads / group_size, head_dim] fp16; k_param / v_param are scattered as in the INT4
+ * configuration (the reference passes ones / zeros) and never read by the decode. Everything else as fq_kv_append_i4 /
+ * fq_kv_batch_decode_i4[_ex].
+ */
+int fq_kv_append_f16(void* kv_data, void* kv_param, const void* kv_indptr, const void* kv_indices,
+                     const void* last_page_offset, const void* k, const void* v, const void* k_param, const void* v_param,
+                     const void* seqlen_indptr, int64_t tokens, int num_layers, int layer_idx, int num_heads, int page_size,
+                     int head_dim, int batch_size, int group_size, void* stream);
+int fq_kv_batch_decode_f16(void* o, const void* q, const void* kv_data, const void* kv_param, const void* kv_indptr,
+                           const void* kv_indices, const void* last_page_offset, int num_layers, int layer_idx,
+                           int num_heads, int page_size, int head_dim, int batch_size, void* stream);
+int fq_kv_batch_decode_f16_ex(void* o, const void* q, const void* q_trans, int transpose_out, const void* kv_data,
+                              const void* kv_param, const void* kv_indptr, const void* kv_indices,
+                              const void* last_page_offset, int num_layers, int layer_idx, int num_heads, int page_size,
+                              int head_dim, int batch_size, void* stream);
 
 /* q = clamp(rn(x /fp16 scale[row]), -8, 7), two per byte, even column -> low nibble (quant.cu:13-47). */
 int fq_sym_quant_f16(const void* x, const void* scale, int64_t rows, int cols, void* q, void* stream);

@@ -127,8 +127,8 @@ def test_cache_class_prefill_and_decode_match_dense_attention(ops):
 
 def test_errors(ops):
     import flatquant_amd.deploy.transformers as T
-    with pytest.raises(NotImplementedError):
-        T.MultiLayerPagedKVCache4Bit(1, 16, 32, "cuda", 1, 2, 128, disable_quant=True)
+    c16 = T.MultiLayerPagedKVCache4Bit(1, 16, 32, "cuda", 1, 2, 128, disable_quant=True)   # (built in round 2)
+    assert c16.pages.dtype == torch.float16 and c16.pages.shape[-1] == 128
     data = torch.zeros(2, 1, 2, 2, 16, 48, dtype=torch.uint8, device="cuda")                     # head_dim 96
     par = torch.zeros(2, 1, 2, 2, 16, 2, dtype=torch.float16, device="cuda")
     z = torch.zeros(2, dtype=torch.int32, device="cuda")
@@ -220,3 +220,147 @@ def test_decode_with_query_transform_and_transposed_output(ops):
     ref = ops.kv_batch_decode(torch.matmul(q, Tq).contiguous(), data, par, indptr, indices, last, 0)
     err = (fused.float() - ref.float()).abs().amax(-1) / ref.float().abs().amax(-1)
     assert err.max().item() <= 3e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 2: the fp16 configuration of the cache (disable_quant=True: init_kv_f16 / append_kv_f16 / batch_decode_f16,
+# kv_cache.py:107-137,177-190) and ragged batches (attention_mask, kv_cache.py:315-326,362-372).
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("hd,heads,group,page_size,lens", [(128, 4, 1, 16, [37, 35]), (128, 4, 2, 8, [8, 1, 7]), (64, 6, 3, 32, [65])])
+def test_fp16_cache_append_and_decode(ops, hd, heads, group, page_size, lens):
+    """fp16 pages: placement bit-exact (rows scattered like the INT4 rows, GQA repeat in the scatter), decode against an fp64
+    softmax attention over the same cache contents."""
+    layers, layer, batch = 2, 1, len(lens)
+    rng = np.random.default_rng(hd + heads + group)
+    used_indptr = np.concatenate([[0], np.cumsum([(n + page_size - 1) // page_size for n in lens])]).astype(np.int32)
+    n_pages = int(used_indptr[-1]) + 2
+    indices = rng.permutation(n_pages).astype(np.int32)[:used_indptr[-1]]
+    data = (rng.standard_normal((n_pages, layers, 2, heads, page_size, hd)) * 3).astype(np.float16)
+    param = rng.uniform(0.1, 1.0, (n_pages, layers, 2, heads, page_size, 2)).astype(np.float16)
+    ref = data.copy()
+    d_data, d_param = torch.from_numpy(data).cuda(), torch.from_numpy(param).cuda()
+    tot, src = sum(lens), heads // group
+    k = rng.standard_normal((tot, src, hd)).astype(np.float16)
+    v = rng.standard_normal((tot, src, hd)).astype(np.float16)
+    one = np.tile(np.array([1.0, 0.0], np.float16), (tot, src, 1))
+    seq_indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    last = np.array([(n - 1) % page_size + 1 for n in lens], dtype=np.int32)
+    ops.kv_append(d_data, d_param, i32(used_indptr), i32(indices), i32(last), torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda(),
+                  torch.from_numpy(one).cuda(), torch.from_numpy(one).cuda(), layer, i32(seq_indptr), group)
+    for b in range(batch):
+        for j in range(lens[b]):
+            page, entry = indices[used_indptr[b] + j // page_size], j % page_size
+            ref[page, layer, 0, :, entry] = np.repeat(k[seq_indptr[b] + j], group, axis=0)
+            ref[page, layer, 1, :, entry] = np.repeat(v[seq_indptr[b] + j], group, axis=0)
+    got = d_data.cpu().numpy()
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16))
+    p = d_param.cpu().numpy()
+    for b in range(batch):                                      # the (1, 0) parameters are scattered like the reference's
+        page = indices[used_indptr[b]]
+        assert np.all(p[page, layer, :, :, 0, 0] == 1.0) and np.all(p[page, layer, :, :, 0, 1] == 0.0)
+    q = (rng.standard_normal((batch, heads, hd)) * 0.5).astype(np.float16)
+    o = ops.kv_batch_decode(torch.from_numpy(q).cuda(), d_data, d_param, i32(used_indptr), i32(indices), i32(last), layer)
+    o = o.cpu().numpy().astype(np.float64)
+    for b in range(batch):
+        rows = [(indices[used_indptr[b] + j // page_size], j % page_size) for j in range(lens[b])]
+        for h in range(heads):
+            K = np.array([ref[pg, layer, 0, h, e] for pg, e in rows], dtype=np.float64)
+            V = np.array([ref[pg, layer, 1, h, e] for pg, e in rows], dtype=np.float64)
+            x = K @ q[b, h].astype(np.float64) / np.sqrt(hd)
+            w = np.exp(x - x.max())
+            want = (w / w.sum()) @ V
+            assert np.abs(o[b, h] - want).max() / np.abs(want).max() <= 2e-3
+    # transposed output + query transform, as the INT4 decode takes them
+    qt = (rng.standard_normal((hd, hd)) / hd ** 0.5).astype(np.float16)
+    o2 = ops.kv_batch_decode(torch.from_numpy(q).cuda(), d_data, d_param, i32(used_indptr), i32(indices), i32(last), layer,
+                             torch.from_numpy(qt).cuda(), True)
+    q2 = torch.matmul(torch.from_numpy(q).cuda(), torch.from_numpy(qt).cuda())
+    o3 = ops.kv_batch_decode(q2.contiguous(), d_data, d_param, i32(used_indptr), i32(indices), i32(last), layer)
+    assert (o2.transpose(1, 2).float() - o3.float()).abs().max().item() <= 2e-3 * o3.float().abs().max().item()
+
+
+def _dense_attention(q, K, V, lens, group, qfun):
+    """q [b, 1, heads, hd]; K, V [b, s, kv_heads, hd] fp32 with request b's valid rows first (lens[b] of them)."""
+    b, _, heads, hd = q.shape
+    out = torch.zeros(b, heads, hd, device=q.device)
+    for i in range(b):
+        Ki = K[i, :lens[i]].repeat_interleave(group, dim=1)
+        Vi = V[i, :lens[i]].repeat_interleave(group, dim=1)
+        qi = qfun(q[i, 0])
+        x = torch.einsum("hd,shd->hs", qi.float(), Ki) / hd ** 0.5
+        out[i] = torch.einsum("hs,shd->hd", torch.softmax(x, dim=-1), Vi)
+    return out
+
+
+@pytest.mark.parametrize("disable_quant,trans", [(False, "matmul"), (True, "matmul"), (True, "none"), (False, "had")])
+def test_cache_class_ragged_prompts_and_fp16_configuration(ops, disable_quant, trans):
+    """MultiLayerPagedKVCache4Bit with an attention mask (left-padded prompts of different lengths, the mask growing by one column
+    per decode step) in both cache configurations, against dense attention over each request's own tokens."""
+    import flatquant_amd.deploy.transformers as T
+    g = torch.Generator(device="cuda").manual_seed(3)
+    bsz, prompt, kv_heads, group, hd, layers, page = 3, 20, 2, 2, 128, 2, 16
+    valid = [20, 17, 18]                                        # same page count (2 pages of 16) for every request
+    mask = torch.zeros(bsz, prompt, dtype=torch.int64, device="cuda")
+    for i, n in enumerate(valid):
+        mask[i, prompt - n:] = 1                               # left padding, as HF generates it
+    cache = T.MultiLayerPagedKVCache4Bit(bsz, page, 64, "cuda", layers, kv_heads * group, hd, disable_quant=disable_quant,
+                                         trans=trans, group_size=group)
+    tk = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half()
+    tk_inv_t = torch.linalg.inv(tk.float()).T.contiguous().half()
+    kfun = {"matmul": lambda t: torch.matmul(t.half(), tk), "had": lambda t: ops.hadamard(t.half().contiguous()),
+            "none": lambda t: t.half()}[trans]                  # what happens to the keys on the way into the cache
+    qfun = {"matmul": lambda t: torch.matmul(t.half(), tk_inv_t), "had": lambda t: ops.hadamard(t.half().contiguous()),
+            "none": lambda t: t.half()}[trans]                  # ... and to the query
+    kw = {"trans_matrix_k": tk, "trans_matrix_k_inv_t": tk_inv_t}
+
+    def stored(k, v):           # the fp32 values the cache holds for these keys / values
+        kt = kfun(k)
+        if disable_quant:
+            return kt.float(), v.float()
+        kq, kp = ops.kv_quant(kt.contiguous())
+        vq, vp = ops.kv_quant(v.half().contiguous())
+        deq = lambda q8, par: (torch.stack((q8 & 15, q8 >> 4), dim=-1).reshape(*q8.shape[:-1], -1).float()
+                               * par[..., 0:1].float() - par[..., 1:2].float())
+        return deq(kq, kp), deq(vq, vp)
+
+    Ks, Vs = [], []
+    for layer in range(layers):
+        k = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+        v = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+        out = cache.update(k, v, layer, dict(kw, attention_mask=mask))
+        assert isinstance(out, tuple) and out[0].shape == k.shape
+        if disable_quant:
+            assert torch.equal(out[0], k) and torch.equal(out[1], v)       # the un-transformed states (kv_cache.py:262-263)
+        K, V = stored(k, v)
+        Kc, Vc = torch.zeros_like(K), torch.zeros_like(V)
+        for i, n in enumerate(valid):                                      # compact: valid tokens first
+            Kc[i, :n], Vc[i, :n] = K[i, prompt - n:], V[i, prompt - n:]
+        Ks.append([Kc]), Vs.append([Vc])
+    lens = list(valid)
+    for step in range(3):
+        mask = torch.cat([mask, torch.ones(bsz, 1, dtype=mask.dtype, device="cuda")], dim=1)
+        lens = [n + 1 for n in lens]
+        for layer in range(layers):
+            k = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+            v = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+            attend = cache.update(k, v, layer, dict(kw, attention_mask=mask))
+            K1, V1 = stored(k, v)
+            Ks[layer].append(K1), Vs[layer].append(V1)
+            # request i's rows: its valid prompt tokens, then the decode tokens
+            S = prompt + step + 1
+            K = torch.zeros(bsz, S, kv_heads, hd, device="cuda")
+            V = torch.zeros_like(K)
+            for i, n in enumerate(valid):
+                K[i, :n], V[i, :n] = Ks[layer][0][i, :n], Vs[layer][0][i, :n]
+                for t in range(step + 1):
+                    K[i, n + t], V[i, n + t] = Ks[layer][1 + t][i, 0], Vs[layer][1 + t][i, 0]
+            q = torch.randn(bsz, 1, kv_heads * group, hd, generator=g, device="cuda").half()
+            o = attend(q).reshape(bsz, -1, hd).float()
+            ref = _dense_attention(q, K, V, lens, group, qfun)
+            err = (o - ref).abs().amax(-1) / ref.abs().amax(-1)
+            assert err.max().item() <= 4e-3, (disable_quant, trans, step, layer, err.max().item())
+    # requests that need different page counts are refused like the reference refuses them (kv_cache.py:371-372)
+    bad = torch.ones(bsz, 40, dtype=torch.int64, device="cuda")
+    bad[0, :30] = 0
+    with pytest.raises(NotImplementedError):
+        cache.get_cache_specs_for_flash_infer(bad)

@@ -127,7 +127,13 @@ def main():
         us = timeit(lambda i: ops.kv_batch_decode(q, data, par, indptr, indices, last, 0))
         byt = bsz * heads * seq * 2 * (hd // 2 + 4)
         print(f"{'INT4 paged decode attention':34s} {'bsz=%d seq=%d heads=32' % (bsz, seq):22s} {us:9.1f} us  {byt / us / 1e3:8.0f} GB/s")
-        del data, par
+        del data
+        if (bsz, seq) == (16, 2048):   # the fp16 configuration of the same cache (disable_quant=True)
+            data16 = torch.randn(bsz * n_pg, 1, 2, heads, page, hd, generator=g, device="cuda").half()
+            us = timeit(lambda i: ops.kv_batch_decode(q, data16, par, indptr, indices, last, 0))
+            print(f"{'fp16 paged decode attention':34s} {'bsz=%d seq=%d heads=32' % (bsz, seq):22s} {us:9.1f} us  {bsz * heads * seq * 2 * hd * 2 / us / 1e3:8.0f} GB/s")
+            del data16
+        del par
     for hd, H in ((128, 32), (128, 64)):
         xs = [torch.randn(ROWS, hd, H, generator=g, device="cuda", dtype=torch.float16) for _ in range(NB)]
         P = (torch.randn(H, H, generator=g, device="cuda") / H ** 0.5).half()
