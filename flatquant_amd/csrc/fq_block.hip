@@ -40,9 +40,14 @@ __device__ __forceinline__ int rmap(int RT, int rt, int i) {
 // operand, whose fragment is the very same 16-byte piece of row (32 rt + c) — and lane (h, c) ends with row 32 rt + c and
 // a run of CT*16 consecutive columns. Either way a lane stores contiguous runs; the epilogue below is written once in
 // terms of (outer tile o = its major index / 32, inner tiles i along its run).
-template <int RT, int CT, bool DMA, bool NAT>
-__global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x, const f16* __restrict__ P,
-                                                       int64_t rows, FqQuantOut out, int flags) {
+// PK: packed-only launches (the deploy contract), compiled separately: the output-set branches and their register copies drop
+// out, the quantiser is the single-width asm one of fq_common.hpp (fq_quant8_two), the extrema run as independent max3 / min3
+// chains, and — for C = 32, where the token comes straight from HBM — the next token's fragments are prefetched into
+// registers behind the GEMM so that they land during the epilogue (the loop used to load and multiply in the same breath).
+template <int RT, int CT, bool DMA, bool NAT, bool PK>
+__global__ __launch_bounds__(256, (PK && CT == 1) ? (RT == 4 ? 3 : 4) : (PK ? 2 : 1)) void fq_block_kernel(const f16* __restrict__ x, const f16* __restrict__ P,
+                                                       int64_t rows, FqQuantOut out, int flags_rt) {
+    const int flags = PK ? (FQ_OUT_PACKED | (flags_rt & ~(FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_QUANT_F16))) : flags_rt;
     constexpr int R = RT * 32, C = CT * 32, KS = C / 16, D = R * C, CPR = C / 8;
     constexpr int OC = NAT ? RT : CT, IC = NAT ? CT : RT, LEN = IC * 32;  // outer / inner tile counts, length of a major row
     static_assert(!DMA || CPR == 8, "the DMA variant is the C = 64 one");
@@ -73,8 +78,31 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
     const bool counted = DMA && (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM)) == FQ_OUT_PACKED &&
                          out.n_clips == 1;
     bool first = true;
+    constexpr bool PFR = PK && !DMA;      // register prefetch of the next token's A fragments
+    u32x4 PF[PFR ? RT : 1][PFR ? KS : 1];
+    // (inline asm + a hand-placed counted wait: the fragments of the NEXT token are in flight across the epilogue, whose stores
+    //  are issued after them and may stay in flight at the wait)
+#define FQ_BLOCK_PF(t)                                                                                              \
+    {                                                                                                               \
+        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                                         \
+            const int row_ = NAT ? rt * 32 + c : rmap(RT, rt, c);                                                   \
+            const u32x4* xp_ = reinterpret_cast<const u32x4*>(x + (t) * D + (int64_t)row_ * C + h * 8);             \
+            _Pragma("unroll") for (int s = 0; s < KS; ++s)                                                          \
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(PF[PFR ? rt : 0][PFR ? s : 0]) : "v"(xp_), "n"(s * 32) : "memory"); \
+        }                                                                                                           \
+    }
+    if (PFR && wave_id < rows) FQ_BLOCK_PF(wave_id)
 
     for (int64_t tok = wave_id; tok < rows; tok += n_waves) {
+        if (PFR) {
+            if (!first && out.n_clips == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PACKED_STORES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            first = false;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(PF[PFR ? rt : 0][PFR ? s : 0]));  // arrived with the wait above
+        }
         if (DMA) {
             if (counted && !first) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PACKED_STORES) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -97,6 +125,7 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
             for (int s = 0; s < KS; ++s) {
                 f16x8 a;  // k = 16 s + 8 h .. +8
                 if (DMA) a = __builtin_bit_cast(f16x8, lp[(s * 2 + h) ^ sw]);
+                else if (PFR) a = __builtin_bit_cast(f16x8, PF[PFR ? rt : 0][PFR ? s : 0]);
                 else a = __builtin_bit_cast(f16x8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xp) + s * 2));
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
@@ -104,6 +133,10 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
                     Y[rt][ct] = NAT ? mfma32(pf, a, Y[rt][ct]) : mfma32(a, pf, Y[rt][ct]);
                 }
             }
+        }
+        if (PFR && tok + n_waves < rows) {  // the fragments have been consumed: the next token's land during the epilogue
+            __builtin_amdgcn_sched_barrier(0);
+            FQ_BLOCK_PF(tok + n_waves)
         }
         if (DMA) {  // the buffer has been read: fetch this wave's next token while the current one is quantised
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -135,6 +168,69 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
                         yp[i * 2 + w] = __builtin_bit_cast(uint4, v);
                     }
             }
+        }
+        if (PK) {
+            float pmx[RT * CT], pmn[RT * CT];  // one independent max3 / min3 chain per tile
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const f32x16& t = Y[rt][ct];
+                    float a = FqMaxOp()(t[0], t[1]), b = FqMinOp()(t[0], t[1]);
+#pragma unroll
+                    for (int r = 2; r < 16; r += 2) {
+                        a = fq_max3(a, t[r], t[r + 1]);
+                        b = fq_min3(b, t[r], t[r + 1]);
+                    }
+                    pmx[rt * CT + ct] = a;
+                    pmn[rt * CT + ct] = b;
+                }
+            float vmax = pmx[0], vmin = pmn[0];
+#pragma unroll
+            for (int k = 1; k < RT * CT; ++k) {
+                vmax = fmaxf(vmax, pmx[k]);
+                vmin = fminf(vmin, pmn[k]);
+            }
+            vmax = fq_wave_max(vmax);
+            vmin = fq_wave_min(vmin);
+            for (int ci = 0; ci < out.n_clips; ++ci) {
+                const float scale = fq_token_scale<0>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
+                const float inv = fq_fast_inv(scale);
+                const bool magic = fq_magic_ok(vmax, vmin, inv), clampq = fq_needs_clamp(vmax, vmin, inv);
+                const float ilo = fq_inv_lo(inv), ihi = fq_inv_hi(inv);
+                if (lane == 0) out.scale[ci][tok] = (f16)scale;
+#pragma unroll
+                for (int o = 0; o < OC; ++o) {
+                    uint8_t* qrow = out.q[ci] + tok * (D / 2) + (int64_t)(o * 32 + c) * (LEN / 2) + h * (IC * 8);
+                    uint2 pk[IC];
+#pragma unroll
+                    for (int i = 0; i < IC; ++i) {
+                        const f32x16& t = FQ_TILE(o, i);
+                        unsigned long long d0 = ~0ull, d1 = ~0ull;
+                        pk[i] = uint2{0u, 0u};
+                        if (magic) {
+                            if (clampq) {
+                                pk[i].x = fq_quant8_two<true>(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], ilo, ihi, d0);
+                                pk[i].y = fq_quant8_two<true>(t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15], ilo, ihi, d1);
+                            } else {
+                                pk[i].x = fq_quant8_two<false>(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], ilo, ihi, d0);
+                                pk[i].y = fq_quant8_two<false>(t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15], ilo, ihi, d1);
+                            }
+                        }
+                        if (d0)  // rare: an ambiguous digit somewhere in the wave -> the true division for this dword
+                            pk[i].x = fq_pack8(fq_qexact(t[0], scale), fq_qexact(t[1], scale), fq_qexact(t[2], scale), fq_qexact(t[3], scale),
+                                               fq_qexact(t[4], scale), fq_qexact(t[5], scale), fq_qexact(t[6], scale), fq_qexact(t[7], scale));
+                        if (d1)
+                            pk[i].y = fq_pack8(fq_qexact(t[8], scale), fq_qexact(t[9], scale), fq_qexact(t[10], scale), fq_qexact(t[11], scale),
+                                               fq_qexact(t[12], scale), fq_qexact(t[13], scale), fq_qexact(t[14], scale), fq_qexact(t[15], scale));
+                        if (i & 1)
+                            *reinterpret_cast<uint4*>(qrow + (i - 1) * 8) = make_uint4(pk[i - 1].x, pk[i - 1].y, pk[i].x, pk[i].y);
+                        else if (i == IC - 1)
+                            *reinterpret_cast<uint2*>(qrow + i * 8) = pk[i];
+                    }
+                }
+            }
+            continue;
         }
         if (!(flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT))) continue;
 
@@ -212,16 +308,21 @@ __global__ __launch_bounds__(256) void fq_block_kernel(const f16* __restrict__ x
 }
 
 #undef FQ_TILE
+#undef FQ_BLOCK_PF
 
 template <int RT, int CT, bool NAT>
 int launch_block(int flags, const f16* x, const f16* P, int64_t rows, const FqQuantOut& out, int n_cu,
                  hipStream_t stream) {
     constexpr bool DMA = CT == 2;  // C = 64: whole-line DMA staging (see the header)
     int64_t blocks = (rows + 3) / 4;
-    const int64_t cap = (int64_t)n_cu * 2;
+    const bool pk = (flags & FQ_CT_MASK) == FQ_OUT_PACKED;
+    const int64_t cap = (int64_t)n_cu * ((pk && CT == 1) ? (RT == 4 ? 3 : 4) : 2);   // workgroups per CU the registers allow
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((fq_block_kernel<RT, CT, DMA, NAT>), dim3((unsigned)blocks), dim3(256), 0, stream, x, P, rows, out, flags);
+    if (pk)
+        hipLaunchKernelGGL((fq_block_kernel<RT, CT, DMA, NAT, true>), dim3((unsigned)blocks), dim3(256), 0, stream, x, P, rows, out, flags);
+    else
+        hipLaunchKernelGGL((fq_block_kernel<RT, CT, DMA, NAT, false>), dim3((unsigned)blocks), dim3(256), 0, stream, x, P, rows, out, flags);
     return (int)hipGetLastError();
 }
 

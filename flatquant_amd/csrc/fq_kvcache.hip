@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void fq_kv_append_kernel(PagedKv p, const uint
 // F16: the fp16 configuration of the cache (batch_decode_f16): a cached row is head_dim fp16 values, no (scale, zero); a lane
 // still owns 32 features of a row (64 bytes: four 16-byte loads).
 template <int HD, int NW, bool F16 = false>  // NW waves per workgroup: 4, or 8 when there are too few (request, head) pairs to fill the chip
-__global__ __launch_bounds__(NW * 64) void fq_kv_decode_kernel(f16* __restrict__ o, const f16* __restrict__ q, PagedKv p,
+__global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restrict__ o, const f16* __restrict__ q, PagedKv p,
                                                                const f16* __restrict__ qt, int transpose_out) {
     constexpr int QL = HD / 32;        // lanes per cached row (16 bytes = 32 features each): 4 for head_dim 128
     constexpr int RPW = 64 / QL;       // rows per wave and step
@@ -144,39 +144,50 @@ __global__ __launch_bounds__(NW * 64) void fq_kv_decode_kernel(f16* __restrict__
             ++pit;
         }
         const size_t ke = page * page_stride + k_off + entry, ve = ke + kv_off;   // = k_entry / v_entry, constants hoisted
-        float part_dot, vf[32], vs = 1.0f, vz = 0.0f;   // v_j = vf[j] * vs - vz
         if (F16) {
             const uint4* kp = reinterpret_cast<const uint4*>(p.data + ke * (HD * 2) + part * 64);
             const uint4* vp = reinterpret_cast<const uint4*>(p.data + ve * (HD * 2) + part * 64);
-            part_dot = 0.0f;
+            uint4 kq[4], vq[4];
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const f16x8 kh = __builtin_bit_cast(f16x8, kp[w]), vh = __builtin_bit_cast(f16x8, vp[w]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    part_dot = __builtin_fmaf(qv[w * 8 + e], (float)kh[e], part_dot);
-                    vf[w * 8 + e] = (float)vh[e];
-                }
+                kq[w] = kp[w];
+                vq[w] = vp[w];
             }
-        } else {
-            const uint4 kq = *reinterpret_cast<const uint4*>(p.data + ke * (HD / 2) + part * 16);
-            const uint4 vq = *reinterpret_cast<const uint4*>(p.data + ve * (HD / 2) + part * 16);
-            const uint32_t kpar = reinterpret_cast<const uint32_t*>(p.param)[ke];
-            const uint32_t vpar = reinterpret_cast<const uint32_t*>(p.param)[ve];
-            const float ks = (float)__builtin_bit_cast(f16, (unsigned short)(kpar & 0xFFFF)), kz = (float)__builtin_bit_cast(f16, (unsigned short)(kpar >> 16));
-            vs = (float)__builtin_bit_cast(f16, (unsigned short)(vpar & 0xFFFF));
-            vz = (float)__builtin_bit_cast(f16, (unsigned short)(vpar >> 16));
-            const uint32_t kw[4] = {kq.x, kq.y, kq.z, kq.w}, vw[4] = {vq.x, vq.y, vq.z, vq.w};
-            float dotn = 0.0f;
+            float part_dot = 0.0f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w)
+            for (int w = 0; w < 4; ++w) {
+                const f16x8 kh = __builtin_bit_cast(f16x8, kq[w]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    dotn = __builtin_fmaf(qv[w * 8 + e], (float)((kw[w] >> (4 * e)) & 15u), dotn);
-                    vf[w * 8 + e] = (float)((vw[w] >> (4 * e)) & 15u);
-                }
-            part_dot = ks * dotn - kz * qsum;       // this lane's 32 features of q . k
+                for (int e = 0; e < 8; ++e) part_dot = __builtin_fmaf(qv[w * 8 + e], (float)kh[e], part_dot);
+            }
+#pragma unroll
+            for (int off = 1; off < QL; off <<= 1) part_dot += __shfl_xor(part_dot, off, 64);
+            const float x = part_dot * sm_scale;
+            const float m_new = fmaxf(m, x);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new), pr = __builtin_amdgcn_exp2f(x - m_new);
+            d = d * alpha + pr;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const f16x8 vh = __builtin_bit_cast(f16x8, vq[w]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[w * 8 + e] = __builtin_fmaf((float)vh[e], pr, acc[w * 8 + e] * alpha);
+            }
+            m = m_new;
+            continue;
         }
+        const uint4 kq = *reinterpret_cast<const uint4*>(p.data + ke * (HD / 2) + part * 16);
+        const uint4 vq = *reinterpret_cast<const uint4*>(p.data + ve * (HD / 2) + part * 16);
+        const uint32_t kpar = reinterpret_cast<const uint32_t*>(p.param)[ke];
+        const uint32_t vpar = reinterpret_cast<const uint32_t*>(p.param)[ve];
+        const float ks = (float)__builtin_bit_cast(f16, (unsigned short)(kpar & 0xFFFF)), kz = (float)__builtin_bit_cast(f16, (unsigned short)(kpar >> 16));
+        const float vs = (float)__builtin_bit_cast(f16, (unsigned short)(vpar & 0xFFFF)), vz = (float)__builtin_bit_cast(f16, (unsigned short)(vpar >> 16));
+        const uint32_t kw[4] = {kq.x, kq.y, kq.z, kq.w}, vw[4] = {vq.x, vq.y, vq.z, vq.w};
+        float dotn = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dotn = __builtin_fmaf(qv[w * 8 + e], (float)((kw[w] >> (4 * e)) & 15u), dotn);
+        float part_dot = ks * dotn - kz * qsum;       // this lane's 32 features of q . k
 #pragma unroll
         for (int off = 1; off < QL; off <<= 1) part_dot += __shfl_xor(part_dot, off, 64);
         const float x = part_dot * sm_scale;
@@ -185,7 +196,10 @@ __global__ __launch_bounds__(NW * 64) void fq_kv_decode_kernel(f16* __restrict__
         d = d * alpha + pr;
         const float pvs = pr * vs, pvz = pr * vz;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) acc[j] = __builtin_fmaf(vf[j], pvs, acc[j] * alpha - pvz);
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                acc[w * 8 + e] = __builtin_fmaf((float)((vw[w] >> (4 * e)) & 15u), pvs, acc[w * 8 + e] * alpha - pvz);
         m = m_new;
     }
     const int st = wave * RPW + slot;
@@ -197,9 +211,13 @@ __global__ __launch_bounds__(NW * 64) void fq_kv_decode_kernel(f16* __restrict__
     for (int j = 0; j < 32; ++j) s_o[st][part * 32 + j] = acc[j];
     __syncthreads();
     if (tid < HD) {   // state.cuh merge: rescale every partial state to the common maximum
+        // (bounded unrolling: fully unrolled for NS = 64, these loops hoisted 128 LDS reads and pushed the 4-wave build from
+        //  198 to 260 VGPRs — one wave per SIMD, 48 -> 71 us at 16 x 2048 — when the output select below was added)
         float mm = -INFINITY;
+#pragma unroll 8
         for (int s = 0; s < NS; ++s) mm = fmaxf(mm, s_m[s]);
         float dd = 0.0f, oo = 0.0f;
+#pragma unroll 8
         for (int s = 0; s < NS; ++s) {
             const float w = s_m[s] == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(s_m[s] - mm);
             dd += s_d[s] * w;
