@@ -296,3 +296,48 @@ def test_oracle_kv_quant_vs_reference_golden(golden):
         assert np.array_equal(z.view(np.uint16), g[f"{tag}_zero"].view(np.uint16))
         assert np.array_equal(O.kv_asym_dequant(p, s, z, lac).view(np.uint16), g[f"{tag}_deq"].view(np.uint16))
     assert np.array_equal(O.kv_transform(g["x"], g["T"]).view(np.uint16), g["xT"].view(np.uint16))
+
+
+def test_hot_kernels_keep_their_occupancy_budget():
+    """The compiler's per-kernel resource reports (flatquant_amd/csrc/build/*.res, written by the Makefile's
+    -Rpass-analysis=kernel-resource-usage) against the occupancy each hot kernel was tuned at. A source change that makes the
+    register allocator cross 128 / 168 / 256 VGPRs halves a kernel's waves per SIMD without failing anything else (this is how
+    the decode-attention kernel went from 48 to 71 us for three commits in round 2)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from kernel_resources import parse
+    res = parse()
+    if not res:
+        pytest.skip("no build/*.res next to the sources (library built elsewhere)")
+    budget = {  # kernel: (min waves per SIMD, max spilled VGPRs)
+        "fq_kron64_kernel<1,0>": (4, 0),                  # C2 headline, packed-only, 16 waves per CU
+        "fq_kron64_kernel<129,0>": (4, 0),                # ... with the RMSNorm fused in front (C3's q/k/v and up/gate launches)
+        "fq_kron_wave_kernel<2,4,8,7>": (2, 0),           # 64 x 128
+        "fq_kron_wave_kernel<2,4,7,8>": (2, 0),           # 64 x 112
+        "fq_kron_wave_kernel<1,2,4,16>": (4, 0),          # 32 x 64 (grouped MoE launch)
+        "fq_kron_trio_kernel<4,0,0>": (3, 0),             # 112 x 128 packed
+        "fq_kron_trio_kernel<4,1,0>": (3, 0),             # ... fp16 quantiser (Hadamard 14336 + Quantizer)
+        "fq_kron_trio_kernel<3,0,1>": (3, 0),             # 86 x 128
+        "fq_kron_fast_kernel<4,7,14,8,1,0,1>": (2, 0),    # 128 x 224 packed
+        "fq_kron_general_kernel<4,8,1>": (2, 0),          # 128 x 148
+        "fq_kron_general_kernel<6,8,1>": (2, 0),          # 168 x 176
+        "fq_block_kernel<4,1,0,0,1>": (3, 0),             # o_proj transform, 32 heads
+        "fq_block_kernel<4,2,1,0,1>": (2, 0),             # ... 64 heads
+        "fq_kv_decode_kernel<128,4,0>": (3, 0),
+        "fq_kv_decode_kernel<128,8,0>": (3, 0),
+        "fq_kv_decode_kernel<128,4,1>": (3, 0),
+        "fq_rowquant_wave_kernel<33,8>": (4, 0),          # deploy Quantizer at 4096
+        "fq_had_pow2_kernel<8,1,1,1>": (3, 0),            # Hadamard 4096 + Quantizer
+    }
+    present = [k for k in budget if k in res]
+    assert len(present) >= len(budget) - 2, sorted(set(budget) - set(res))      # (names follow the template arguments)
+    for k in present:
+        occ, spill = budget[k]
+        assert res[k]["occupancy"] >= occ, (k, res[k])
+        assert res[k]["vgpr_spill"] <= spill, (k, res[k])
+    # nothing new may spill: the kernels that do are known (generic SiLU.mul builds, two rare instantiations)
+    allowed = {"fq_kron_fast_kernel<4,7,14,8,1,1,-1>", "fq_kron_fast_kernel<4,8,16,8,1,0,-1>", "fq_kron_fast_kernel<4,8,16,8,1,1,-1>",
+               "fq_kron_trio_kernel<4,1,1>", "fq_kron_wave_kernel<2,2,4,16>"}
+    spilling = {k for k, r in res.items() if r.get("vgpr_spill", 0) > 0}
+    assert spilling <= allowed, sorted(spilling - allowed)
