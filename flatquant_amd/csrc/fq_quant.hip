@@ -161,7 +161,10 @@ __global__ __launch_bounds__(256) void fq_sym_dequant_kernel(const int32_t* __re
 // (The one-workgroup-per-row kernel above keeps only 2 loads per lane in flight and pays two barriers per row:
 // 55 us for 16384 x 4096, where moving the same bytes takes 28 us.) Rows are handed out grid-stride per wave.
 template <int FLAGS, int NCH>
-__global__ __launch_bounds__(256) void fq_rowquant_wave_kernel(const f16* __restrict__ x, int64_t rows, int cols,
+// (occupancy bound for the packed fp16-quantiser builds only — the deploy Quantizer: their epilogue is 5 VALU per element on
+//  packed pairs and fits; the fp32-quantiser builds keep the compiler's own choice)
+__global__ __launch_bounds__(256, ((FLAGS & (FQ_QUANT_F16 | FQ_OUT_FAKEQUANT)) == FQ_QUANT_F16) ? (NCH > 24 ? 2 : NCH > 16 ? 3 : 4) : 1)
+void fq_rowquant_wave_kernel(const f16* __restrict__ x, int64_t rows, int cols,
                                                                FqQuantOut out) {
     const int lane = threadIdx.x & 63;
     const int nchunks = cols >> 3;
@@ -303,6 +306,7 @@ int launch_rowquant(const f16* x, int64_t rows, int cols, const FqQuantOut& out,
         return (int)hipGetLastError();                                                                            \
     }
         FQ_RW(4) FQ_RW(8) FQ_RW(16) FQ_RW(24)  // beyond 24 chunks per lane the one-workgroup-per-row kernel measured faster
+                                               // (round 2, fp16 quantiser, 28 chunks at two waves per SIMD: 111.7 vs 110-114 us — no gain)
 #undef FQ_RW
     }
     const int nch = ((cols >> 3) + RQ_THREADS - 1) / RQ_THREADS;
