@@ -66,6 +66,22 @@ def batch_decode_i4(o, q, kv_data, kv_param, kv_indptr, kv_indices, last_page_of
     return o
 
 
+# The fp16 configuration's entry points (kv_cache.py:107-137 -> _CUDA.init_kv_f16 / append_kv_f16 / batch_decode_f16): the same
+# calls on fp16 pages [pages, layers, 2, heads, page_size, head_dim]; ops.kv_append / ops.kv_batch_decode pick the kernel by the
+# page dtype.
+def init_kv_f16(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, k, v, k_param, v_param, seqlen_indptr, layer_idx,
+                group_size=1):
+    init_kv_i4(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, k, v, k_param, v_param, seqlen_indptr, layer_idx, group_size)
+
+
+def append_kv_f16(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, k, v, k_param, v_param, layer_idx, group_size=1):
+    append_kv_i4(kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, k, v, k_param, v_param, layer_idx, group_size)
+
+
+def batch_decode_f16(o, q, kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, layer_idx):
+    return batch_decode_i4(o, q, kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, layer_idx)
+
+
 class MultiLayerPagedKVCache4Bit:
     """kv_cache.py:166-392 with the same constructor arguments, page / scale tensors and ``update`` contract: the first call
     per layer stores the (transformed, quantised) prompt keys / values and returns the fp16 key / value states for the prefill
