@@ -364,3 +364,65 @@ def test_cache_class_ragged_prompts_and_fp16_configuration(ops, disable_quant, t
     bad[0, :30] = 0
     with pytest.raises(NotImplementedError):
         cache.get_cache_specs_for_flash_infer(bad)
+
+
+@pytest.mark.parametrize("cfg", ["i4", "f16"])
+def test_cache_class_against_the_reference_class_calls(ops, golden, cfg):
+    """tests/golden/kv_class.npz: what the REFERENCE's MultiLayerPagedKVCache4Bit hands to its CUDA entry points (recorded on the
+    CPU by tools/gen_golden.py: page tables, offsets, seqlen_indptr, repeated packed keys / values and parameters) for ragged
+    prompts, GQA group 2 and two decode steps, in both configurations. The same inputs through this class must leave the same
+    bytes in the cache: the recorded calls are replayed into a zeroed cache with the oracle's restatement of page.cuh and
+    compared with this class's pages and scales after every step."""
+    import flatquant_amd.deploy.transformers as T
+    g = golden("kv_class")
+    bsz, prompt, kv_heads, group, hd, page = (int(t) for t in g["geom"])
+    valid = g["valid"].tolist()
+    cache = T.MultiLayerPagedKVCache4Bit(bsz, page, 64, "cuda", 1, kv_heads * group, hd, disable_quant=(cfg == "f16"),
+                                         trans="none", group_size=group)
+    cache.pages.zero_(), cache.scales.zero_()
+    ref_data = np.zeros(tuple(cache.pages.shape), dtype=np.uint8 if cfg == "i4" else np.float16)
+    ref_param = np.zeros(tuple(cache.scales.shape), dtype=np.float16)
+    mask = torch.zeros(bsz, prompt, dtype=torch.int64, device="cuda")
+    for i, n in enumerate(valid):
+        mask[i, prompt - n:] = 1
+
+    def call(ci, key):
+        return g[f"{cfg}_call{ci}_{key}"]
+
+    def replay(ci):
+        seq = call(ci, "seqlen_indptr") if f"{cfg}_call{ci}_seqlen_indptr" in g.files else None
+        O.kv_cache_append(ref_data, ref_param, call(ci, "kv_indptr"), call(ci, "kv_indices"), call(ci, "last_page_offset"), 0,
+                          call(ci, "k"), call(ci, "v"), call(ci, "k_param"), call(ci, "v_param"), seq)
+
+    def same_tables(ci):
+        s = cache.get_cache_specs_for_flash_infer(mask)
+        for key in ("kv_indptr", "kv_indices", "last_page_offset"):
+            assert np.array_equal(s[key].cpu().numpy(), call(ci, key)), (ci, key)
+
+    def same_cache(ci):
+        got = cache.pages.cpu().numpy()
+        assert np.array_equal(got.view(np.uint8 if cfg == "i4" else np.uint16), ref_data.view(np.uint8 if cfg == "i4" else np.uint16)), ci
+        assert np.array_equal(cache.scales.cpu().numpy().view(np.uint16), ref_param.view(np.uint16)), ci
+
+    out = cache.update(torch.from_numpy(g[f"{cfg}_k0"]).cuda(), torch.from_numpy(g[f"{cfg}_v0"]).cuda(), 0, {"attention_mask": mask})
+    assert str(g[f"{cfg}_call0_name"]) == ("init_kv_i4" if cfg == "i4" else "init_kv_f16")
+    same_tables(0), replay(0), same_cache(0)
+    assert np.array_equal(out[0].cpu().numpy(), g[f"{cfg}_ret_k"]) and np.array_equal(out[1].cpu().numpy(), g[f"{cfg}_ret_v"])
+    ci = 1
+    for step in (1, 2):
+        mask = torch.cat([mask, torch.ones(bsz, 1, dtype=mask.dtype, device="cuda")], dim=1)
+        attend = cache.update(torch.from_numpy(g[f"{cfg}_k{step}"]).cuda(), torch.from_numpy(g[f"{cfg}_v{step}"]).cuda(), 0,
+                              {"attention_mask": mask})
+        same_tables(ci), replay(ci), same_cache(ci)
+        ci += 1
+        # the decode call: same page tables; the output against the oracle's attention over the replayed cache
+        q = torch.from_numpy(g[f"{cfg}_q{step}"]).cuda()
+        assert np.array_equal(call(ci, "q"), g[f"{cfg}_q{step}"].reshape(bsz, kv_heads * group, hd))
+        same_tables(ci)
+        o = attend(q).reshape(bsz, -1, hd).cpu().numpy().astype(np.float64)
+        if cfg == "i4":
+            want = O.kv_cache_decode(call(ci, "q"), ref_data, ref_param, call(ci, "kv_indptr"), call(ci, "kv_indices"),
+                                     call(ci, "last_page_offset"), 0).astype(np.float64)
+            assert (np.abs(o - want).max(axis=-1) / np.abs(want).max(axis=-1)).max() <= 3e-3
+        ci += 1
+    assert ci == int(g[f"{cfg}_n_calls"])

@@ -341,3 +341,24 @@ def test_hot_kernels_keep_their_occupancy_budget():
                "fq_kron_trio_kernel<4,1,1>", "fq_kron_wave_kernel<2,2,4,16>"}
     spilling = {k for k, r in res.items() if r.get("vgpr_spill", 0) > 0}
     assert spilling <= allowed, sorted(spilling - allowed)
+
+
+def test_kv_cache_page_tables_match_the_reference_class(golden):
+    """The host side of MultiLayerPagedKVCache4Bit with an attention mask, on the CPU: the page tables and per-request offsets it
+    computes equal what the reference's class passed to its kernels (tests/golden/kv_class.npz, recorded by tools/gen_golden.py)."""
+    from flatquant_amd.deploy.transformers import MultiLayerPagedKVCache4Bit
+    g = golden("kv_class")
+    bsz, prompt, kv_heads, group, hd, page = (int(t) for t in g["geom"])
+    cache = MultiLayerPagedKVCache4Bit(bsz, page, 64, "cpu", 1, kv_heads * group, hd, trans="none", group_size=group)
+    mask = torch.zeros(bsz, prompt, dtype=torch.int64)
+    for i, n in enumerate(g["valid"].tolist()):
+        mask[i, prompt - n:] = 1
+    for ci in (0, 1, 3):                 # init, first and second decode step
+        s = cache.get_cache_specs_for_flash_infer(mask)
+        for key in ("kv_indptr", "kv_indices", "last_page_offset"):
+            assert np.array_equal(s[key].numpy(), g[f"i4_call{ci}_{key}"]), (ci, key)
+        mask = torch.cat([mask, torch.ones(bsz, 1, dtype=mask.dtype)], dim=1)
+    bad = torch.ones(bsz, 40, dtype=torch.int64)
+    bad[0, :30] = 0
+    with pytest.raises(NotImplementedError):
+        cache.get_cache_specs_for_flash_infer(bad)

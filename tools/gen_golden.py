@@ -408,6 +408,68 @@ def gen_kv_quant():
     save("kv_quant", **arrays)
 
 
+def gen_kv_class():
+    """deploy/transformers/kv_cache.py MultiLayerPagedKVCache4Bit on the CPU with its three _CUDA entry points replaced by
+    RECORDERS: what the reference's class hands to init_kv / append_kv / batch_decode — page tables, per-request offsets,
+    seqlen_indptr, (repeated) packed keys / values and their parameters — for ragged prompts (attention_mask, left padding), GQA
+    group_size 2, two decode steps, in the INT4 and in the fp16 (disable_quant) configuration. trans = "none": every byte
+    is reproducible bit for bit. (trans="had" needs the fast_hadamard_transform package, which is not here.)"""
+    from deploy.transformers import kv_cache as kc
+    stub = sys.modules["deploy._CUDA"]
+    calls = []
+
+    def rec(name):
+        def f(*a):
+            calls.append((name, [t.clone() if isinstance(t, torch.Tensor) else t for t in a]))
+        return f
+    for nm in ("init_kv_i4", "append_kv_i4", "batch_decode_i4", "init_kv_f16", "append_kv_f16", "batch_decode_f16"):
+        setattr(stub, nm, rec(nm))
+    kc._CUDA = stub
+    bsz, prompt, kv_heads, group, hd, page = 3, 20, 2, 2, 128, 16
+    valid = [20, 17, 18]
+    arrays = {"valid": np.array(valid, np.int32), "geom": np.array([bsz, prompt, kv_heads, group, hd, page], np.int32)}
+    for cfg, disable in (("i4", False), ("f16", True)):
+        calls.clear()
+        g = torch.Generator().manual_seed(77)
+        # (this image's transformers makes Cache.batch_size a read-only property; the reference targets 4.45, where the class
+        #  sets it. The class body is re-based on `object` for the run — same functions, no reference file touched.)
+        RefCache = type("RefCache", (object,), {k_: v_ for k_, v_ in vars(kc.MultiLayerPagedKVCache4Bit).items()
+                                                if k_ not in ("__dict__", "__weakref__")})
+        cache = RefCache(bsz, page, 64, "cpu", 1, kv_heads * group, hd, disable_quant=disable,
+                         trans_dtype=torch.float16, trans="none", group_size=group)
+        mask = torch.zeros(bsz, prompt, dtype=torch.int64)
+        for i, n in enumerate(valid):
+            mask[i, prompt - n:] = 1
+        kw = lambda m: {"attention_mask": m, "kclip_factor_a_max": torch.tensor(4.0), "kclip_factor_a_min": torch.tensor(4.0),
+                        "vclip_factor_a_max": torch.tensor(4.0), "vclip_factor_a_min": torch.tensor(4.0)}
+        k = (torch.randn(bsz, prompt, kv_heads, hd, generator=g) * 1.3).half()
+        v = (torch.randn(bsz, prompt, kv_heads, hd, generator=g) * 1.3).half()
+        arrays[f"{cfg}_k0"], arrays[f"{cfg}_v0"] = k.numpy(), v.numpy()
+        out = cache.update(k, v, 0, kw(mask))
+        arrays[f"{cfg}_ret_k"], arrays[f"{cfg}_ret_v"] = out[0].numpy(), out[1].numpy()
+        for step in (1, 2):
+            mask = torch.cat([mask, torch.ones(bsz, 1, dtype=mask.dtype)], dim=1)
+            k = (torch.randn(bsz, 1, kv_heads, hd, generator=g) * 1.3).half()
+            v = (torch.randn(bsz, 1, kv_heads, hd, generator=g) * 1.3).half()
+            arrays[f"{cfg}_k{step}"], arrays[f"{cfg}_v{step}"] = k.numpy(), v.numpy()
+            attend = cache.update(k, v, 0, kw(mask))
+            q = torch.randn(bsz, 1, kv_heads * group, hd, generator=g).half()
+            arrays[f"{cfg}_q{step}"] = q.numpy()
+            attend(q)                                   # records the batch_decode call (its output is the recorder's: unused)
+        names = ["kv_data", "kv_param", "kv_indptr", "kv_indices", "last_page_offset", "k", "v", "k_param", "v_param", "seqlen_indptr"]
+        for ci, (nm, a) in enumerate(calls):
+            arrays[f"{cfg}_call{ci}_name"] = np.array(nm)
+            if nm.startswith("batch_decode"):     # (o, q, kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, layer_idx)
+                arrays[f"{cfg}_call{ci}_q"] = a[1].numpy()
+                for j, key in ((4, "kv_indptr"), (5, "kv_indices"), (6, "last_page_offset")):
+                    arrays[f"{cfg}_call{ci}_{key}"] = a[j].numpy()
+            else:                                 # (kv_data, kv_param, indptr, indices, last, k, v, k_param, v_param[, seqlen_indptr], layer)
+                for j in range(2, len(a) - 1):
+                    arrays[f"{cfg}_call{ci}_{names[j]}"] = a[j].contiguous().numpy()
+        arrays[f"{cfg}_n_calls"] = np.array(len(calls), np.int32)
+    save("kv_class", **arrays)
+
+
 # ------------------------------------------------------------------------------------------------
 # round 2 fixtures
 def _load_vllm_fake_quant_utils():
@@ -579,6 +641,7 @@ def gen_quantizer_lac():
 
 
 def gen_round2():
+    gen_kv_class()
     gen_group128()
     gen_moe_grouped()
     gen_modules()
@@ -589,6 +652,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt2k":   # the K = 2048 export (12 MB): only on request
         gen_checkpoint(hidden=2048, ffn=2048, heads=16, kv_heads=2, layers=1, name="ckpt2k", clip_noise=0.6)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "kvclass":
+        gen_kv_class()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "r2":
         gen_round2()
