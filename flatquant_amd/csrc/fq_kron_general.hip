@@ -105,9 +105,80 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
         for (int i = tid; i < 2 * MT * MT * 64; i += THREADS) lds_l[i] = lfrag_g[i];
     }
 
+    // Register prefetch of the next token (MT <= 4: the registers allow it; 16- and 8-byte staging): up to 8 x 16 bytes per
+    // thread are requested right after the current token has been staged and written to LDS at the top of the next
+    // iteration — the token's HBM latency then overlaps the two GEMMs and the output sweeps instead of preceding them.
+    constexpr int NPF = MT <= 4 ? 8 : 1;
+    u32x4 PF[NPF];
+    const int pieces = !(N & 7) ? M * (N >> 3) : M * (N >> 2);            // 16-byte or 8-byte pieces per token
+    const int per_thr = (pieces + THREADS - 1) / THREADS;
+    const bool pf16 = MT <= 4 && !(N & 7) && per_thr <= NPF;
+    const bool pf8 = MT <= 4 && (N & 7) && !(N & 3) && per_thr <= 2 * NPF;
+#define FQ_GEN_PF(t)                                                                                                  \
+    {                                                                                                                 \
+    int tl_ = tid;                                                                                                    \
+    asm volatile("" : "+v"(tl_)); /* per-piece addresses are loop-invariant: hoisted out of the token loop they are spilled */ \
+    if (pf16) {                                                                                                       \
+        const u32x4* xp_ = reinterpret_cast<const u32x4*>(x + (t) * d);                                               \
+        _Pragma("unroll") for (int k = 0; k < NPF; ++k) {                                                             \
+            int q_ = tl_ + k * THREADS;                                                                               \
+            q_ = q_ < pieces ? q_ : pieces - 1;                                                                       \
+            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(PF[k]) : "v"(xp_ + q_) : "memory");               \
+        }                                                                                                             \
+    } else if (pf8) {                                                                                                 \
+        typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));                                                  \
+        const u32x2_* xp_ = reinterpret_cast<const u32x2_*>(x + (t) * d);                                             \
+        _Pragma("unroll") for (int k = 0; k < NPF; ++k) {                                                             \
+            int q0_ = tl_ + (2 * k) * THREADS, q1_ = tl_ + (2 * k + 1) * THREADS;                                     \
+            q0_ = q0_ < pieces ? q0_ : pieces - 1;                                                                    \
+            q1_ = q1_ < pieces ? q1_ : pieces - 1;                                                                    \
+            u32x2_ lo_, hi_;                                                                                          \
+            asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(lo_) : "v"(xp_ + q0_) : "memory");               \
+            asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(hi_) : "v"(xp_ + q1_) : "memory");               \
+            PF[k] = u32x4{lo_[0], lo_[1], hi_[0], hi_[1]};                                                            \
+        }                                                                                                             \
+    }                                                                                                                 \
+    }
+    if (blockIdx.x < rows) FQ_GEN_PF((int64_t)blockIdx.x)
+
     for (int64_t tok = blockIdx.x; tok < rows; tok += gridDim.x) {
         __syncthreads();  // everyone is done with xs / obuf of the previous token
-        if (!(N & 7)) {   // rows are whole 16-byte chunks
+        if (pf16 || pf8) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) asm volatile("" : "+v"(PF[k]));  // arrived with the wait above
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+            if (pf16) {
+                const int cpr = N >> 3;
+                const uint4* dp = reinterpret_cast<const uint4*>(diag);
+#pragma unroll
+                for (int k = 0; k < NPF; ++k) {
+                    const int q = tl + k * THREADS;
+                    if (q < pieces) {
+                        uint4 v = __builtin_bit_cast(uint4, PF[k]);
+                        if (diag != nullptr) v = __builtin_bit_cast(uint4, __builtin_bit_cast(f16x8, v) * __builtin_bit_cast(f16x8, dp[q]));
+                        const int row = q / cpr, ch = q - row * cpr;
+                        xs[row * pitch + ch] = v;
+                    }
+                }
+            } else {
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                const int cpr = N >> 2;
+                const uint2* dp = reinterpret_cast<const uint2*>(diag);
+                uint2* xs2 = reinterpret_cast<uint2*>(xs);
+#pragma unroll
+                for (int k = 0; k < 2 * NPF; ++k) {
+                    const int q = tl + k * THREADS;
+                    if (q < pieces) {
+                        uint2 v = (k & 1) ? make_uint2(PF[k >> 1][2], PF[k >> 1][3]) : make_uint2(PF[k >> 1][0], PF[k >> 1][1]);
+                        if (diag != nullptr) v = __builtin_bit_cast(uint2, __builtin_bit_cast(f16x4, v) * __builtin_bit_cast(f16x4, dp[q]));
+                        const int row = q / cpr, ch = q - row * cpr;
+                        xs2[row * pitch * 2 + ch] = v;
+                    }
+                }
+            }
+        } else if (!(N & 7)) {   // rows are whole 16-byte chunks
             const int cpr = N >> 3;
             const uint4* xp = reinterpret_cast<const uint4*>(x + tok * d);
             const uint4* dp = reinterpret_cast<const uint4*>(diag);
@@ -142,6 +213,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
             }
         }
         __syncthreads();
+        if (tok + gridDim.x < rows) FQ_GEN_PF(tok + gridDim.x)
 
         // ---- GEMM 1 for this wave's n'-tile over all row tiles, rounded to fp16: the A fragments of GEMM 2 ----
         f16x8 Uh[MT][2];
@@ -150,15 +222,30 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) U[mt] = f32x16{0};
             const uint4* rf = rfrag + (size_t)nt * KS1 * 64 + lane;
-            f16x8 bn = __builtin_bit_cast(f16x8, rf[0]);
-            for (int s = 0; s < KS1; ++s) {
-                const f16x8 b = bn;
-                if (s + 1 < KS1) bn = __builtin_bit_cast(f16x8, rf[(s + 1) * 64]);  // (from L2: one K-step ahead)
+            // R fragments come from L2 (the image is up to 128 KB): four K-steps are fetched while the previous four are
+            // multiplied, so the L2 latency is paid once per token and not once per K-step (CH K-steps per batch)
+            constexpr int CH = MT >= 7 ? 1 : 4;   // (M > 192: the accumulators leave no room for more)
+            f16x8 bc[CH], bn[CH];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const f16x8 a = __builtin_bit_cast(f16x8, xs[(mt * 32 + c) * pitch + s * 2 + h]);
-                    U[mt] = mfma32(a, b, U[mt]);
+            for (int j = 0; j < CH; ++j) bc[j] = __builtin_bit_cast(f16x8, rf[(j < KS1 ? j : KS1 - 1) * 64]);
+            for (int s0 = 0; s0 < KS1; s0 += CH) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int sn = s0 + CH + j;
+                    bn[j] = __builtin_bit_cast(f16x8, rf[(sn < KS1 ? sn : KS1 - 1) * 64]);
                 }
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    if (s0 + j < KS1) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const f16x8 a = __builtin_bit_cast(f16x8, xs[(mt * 32 + c) * pitch + (s0 + j) * 2 + h]);
+                            U[mt] = mfma32(a, bc[j], U[mt]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < CH; ++j) bc[j] = bn[j];
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -174,11 +261,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
         const int ks_n = (M + 15) >> 4;  // rows of L beyond M are zero
         const float ps = out.post_scale;
         auto row_tile = [&](int mo) -> f32x16 {
-            f32x16 Y = f32x16{0};
             const uint4* lf = (LLDS ? static_cast<const uint4*>(lds_l) : lfrag_g) + (size_t)mo * 64 + lane;
+            // the tile's L fragments are fetched in batches of MT before their MFMAs: a fragment read issued right in front of
+            // its MFMA put a full LDS / L2 latency in front of each of the 2 MT dependent MFMAs (same summation order as before)
+            f32x16 Y = f32x16{0};
 #pragma unroll
-            for (int ks = 0; ks < 2 * MT; ++ks)
-                if (ks < ks_n) Y = mfma32(Uh[ks >> 1][ks & 1], __builtin_bit_cast(f16x8, lf[(size_t)ks * MT * 64]), Y);
+            for (int k0 = 0; k0 < 2 * MT; k0 += MT) {
+                f16x8 Bf[MT];
+#pragma unroll
+                for (int j = 0; j < MT; ++j) Bf[j] = __builtin_bit_cast(f16x8, lf[(size_t)(k0 + j) * MT * 64]);
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    if (k0 + j < ks_n) Y = mfma32(Uh[(k0 + j) >> 1][(k0 + j) & 1], Bf[j], Y);
+            }
             if (ps != 0.0f) {  // (fq_kron_quant_ex_f16)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -316,6 +411,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
         }
     }
 }
+
+#undef FQ_GEN_PF
 
 template <int MT, int WAVES, bool LLDS>
 int launch_general_l(int flags, const f16* x, const uint4* ws, const f16* diag, int64_t rows, const GenGeom& g,
