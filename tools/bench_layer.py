@@ -24,9 +24,17 @@ MODELS = {
 }
 
 
-def timeit(fn, steps, warm=10):
+def timeit(fn, steps, warm=10, settle_ms=60.0):
+    """events around `steps` calls, after `warm` calls AND at least `settle_ms` of the same launches (the part needs tens of
+    milliseconds of load before its clocks settle: ten 200 us launches measure the ramp, 20 % slow)"""
+    import time
     for _ in range(warm):
         fn()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < settle_ms:
+        for _ in range(8):
+            fn()
+        torch.cuda.synchronize()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
