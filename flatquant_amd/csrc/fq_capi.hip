@@ -1,5 +1,6 @@
 // fq_capi.hip — the C ABI of libfqhip.so (include/fqhip.h). Argument validation + dispatch only.
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -72,6 +73,17 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// Every tensor the kernels touch with 16-byte accesses (activations, factor matrices, packed / fp16 outputs, workspaces, cache
+// pages) must start on a 16-byte boundary: torch allocations do (256 B), views that start mid-row may not. NULL passes (optional).
+bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+#define FQ_NEED_ALIGN16(what, ...)                                                                                   \
+    do {                                                                                                             \
+        const void* fq_ptrs_[] = {__VA_ARGS__};                                                                      \
+        for (size_t fq_i_ = 0; fq_i_ < sizeof(fq_ptrs_) / sizeof(fq_ptrs_[0]); ++fq_i_)                              \
+            if (misaligned16(fq_ptrs_[fq_i_]))                                                                       \
+                return fail(FQ_EINVAL, "%s: pointer argument %d of {" #__VA_ARGS__ "} is not 16-byte aligned", what, (int)fq_i_); \
+    } while (0)
+
 int cu_count() {
     (void)hipGetLastError();  // drop any stale error of this thread so the post-launch check is ours
     int dev = 0;
@@ -124,6 +136,8 @@ int fill_out(const char* what, FqQuantOut& o, const float* sig_max, const float*
         if (!y_out) return fail(FQ_EINVAL, "%s: FQ_OUT_TRANSFORM needs y_out", what);
         o.y = (f16*)y_out;
     }
+    for (int i = 0; i < FQ_MAX_CLIPS; ++i) FQ_NEED_ALIGN16(what, o.q[i], o.fq[i]);
+    FQ_NEED_ALIGN16(what, o.y);
     o.rt_flags = flags & (FQ_ROUND_Y_F16 | FQ_NO_CLAMP0 | FQ_GROUP128 | FQ_SIG_F16);
     o.rms_eps = 0.0f;
     o.in2 = nullptr;
@@ -152,6 +166,7 @@ static int kron_dispatch(const char* what, const FqQuantOut& o, int flags, const
                          const void* diag, int64_t rows, int M, int N, void* workspace, int64_t workspace_bytes,
                          void* stream) {
     int rc;
+    FQ_NEED_ALIGN16(what, x, left, right, diag, workspace);
     const int n_cu = cu_count();
     const bool special = o.group_offsets != nullptr || (o.rt_flags & FQ_GROUP128);  // only the fused MFMA kernels take these
     if ((o.rt_flags & FQ_GROUP128) && ((M * N) % 128 != 0 || (flags & (FQ_QUANT_F16 | FQ_OUT_FAKEQUANT)) || o.n_clips != 1))
@@ -235,6 +250,7 @@ int fq_rmsnorm_kron_quant_f16(const void* x, float eps, const void* left, const 
     if (rc != FQ_OK) return rc;
     if (rows == 0) return FQ_OK;
     if (!x || !left || !right) return fail(FQ_EINVAL, "fq_rmsnorm_kron_quant_f16: x/left/right is NULL");
+    FQ_NEED_ALIGN16("fq_rmsnorm_kron_quant_f16", x, left, right);
     o.rms_eps = eps;
     rc = fq_launch_kron64(flags | FQ_IN_RMSNORM, (const f16*)x, (const f16*)left, (const f16*)right, nullptr, rows, o,
                           cu_count(), (hipStream_t)stream);
@@ -252,6 +268,7 @@ int fq_silu_mul_kron_quant_f16(const void* gate, const void* up, const void* lef
     if (rc != FQ_OK) return rc;
     if (rows == 0) return FQ_OK;
     if (!gate || !up || !left || !right) return fail(FQ_EINVAL, "fq_silu_mul_kron_quant_f16: gate/up/left/right is NULL");
+    FQ_NEED_ALIGN16("fq_silu_mul_kron_quant_f16", gate, up, left, right, workspace);
     o.in2 = (const f16*)up;
     rc = fq_launch_kron_generic(flags | FQ_IN_SILU_MUL, (const f16*)gate, (const f16*)left, (const f16*)right, nullptr,
                                 rows, M, N, o, workspace, workspace_bytes, cu_count(), (hipStream_t)stream);
@@ -275,6 +292,7 @@ int fq_kron_quant_ex_f16(const void* x, const void* up, const void* left, const 
     if (rc != FQ_OK) return rc;
     if (rows == 0) return FQ_OK;
     if (!x || !left || !right) return fail(FQ_EINVAL, "%s: x/left/right is NULL", what);
+    FQ_NEED_ALIGN16(what, x, up, left, right, workspace);
     o.post_scale = post_scale == 1.0f ? 0.0f : post_scale;
     o.in2 = (const f16*)up;
     // the scaled / SiLU.mul forms live in the workgroup-per-token kernel family only (the shapes this entry exists for:
@@ -289,6 +307,7 @@ int fq_kron_quant_ex_f16(const void* x, const void* up, const void* left, const 
 }
 
 int fq_silu_mul_f16(const void* gate, const void* up, void* y, int64_t n, void* stream) {
+    FQ_NEED_ALIGN16("fq_silu_mul_f16", gate, up, y);
     if (n < 0) return fail(FQ_EINVAL, "fq_silu_mul_f16: n < 0");
     if (n == 0) return FQ_OK;
     if (!gate || !up || !y) return fail(FQ_EINVAL, "fq_silu_mul_f16: NULL pointer");
@@ -306,6 +325,7 @@ int fq_silu_mul_hadamard_quant_f16(const void* gate, const void* up, int64_t row
     if (!(sig_max > 0.0f) || !(sig_min > 0.0f)) return fail(FQ_EINVAL, "fq_silu_mul_hadamard_quant_f16: sig_max/sig_min must be > 0");
     if (rows == 0) return FQ_OK;
     if (!gate || !up) return fail(FQ_EINVAL, "fq_silu_mul_hadamard_quant_f16: gate/up is NULL");
+    FQ_NEED_ALIGN16("fq_silu_mul_hadamard_quant_f16", gate, up, hadK, q_out);
     const int rc = fq_launch_silu_hadamard_quant((const f16*)gate, (const f16*)up, rows, n, K, (const f16*)hadK, scale,
                                                  sig_max, sig_min, (uint8_t*)q_out, (f16*)scale_out, cu_count(),
                                                  (hipStream_t)stream);
@@ -315,6 +335,7 @@ int fq_silu_mul_hadamard_quant_f16(const void* gate, const void* up, int64_t row
 }
 
 int fq_rmsnorm_f16(const void* x, void* y, int64_t rows, int cols, float eps, void* stream) {
+    FQ_NEED_ALIGN16("fq_rmsnorm_f16", x, y);
     if (!x || !y) return fail(FQ_EINVAL, "fq_rmsnorm_f16: x/y is NULL");
     if (rows < 0 || cols <= 0 || !(eps >= 0.0f)) return fail(FQ_EINVAL, "fq_rmsnorm_f16: bad arguments");
     if (rows == 0) return FQ_OK;
@@ -347,6 +368,7 @@ int fq_block_quant_f16(const void* x, const void* P, int64_t rows, int R, int C,
                        void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
                        void* stream) {
     if (!x || !P) return fail(FQ_EINVAL, "fq_block_quant_f16: x/P is NULL");
+    FQ_NEED_ALIGN16("fq_block_quant_f16", x, P);
     if (rows < 0 || R <= 0 || C <= 0) return fail(FQ_EINVAL, "fq_block_quant_f16: bad sizes");
     FqQuantOut o;
     int rc = fill_out("fq_block_quant_f16", o, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out, y_out);
@@ -360,6 +382,7 @@ int fq_block_quant_f16(const void* x, const void* P, int64_t rows, int R, int C,
 int fq_hadamard_f16(const void* x, void* y, int64_t rows, int n, int K, const void* hadK, float scale,
                     void* stream) {
     if (!x || !y) return fail(FQ_EINVAL, "fq_hadamard_f16: x/y is NULL");
+    FQ_NEED_ALIGN16("fq_hadamard_f16", x, y, hadK);
     if (rows < 0 || n <= 0 || K <= 0 || n % K) return fail(FQ_EINVAL, "fq_hadamard_f16: bad sizes n=%d K=%d", n, K);
     const int p2 = n / K;
     if (p2 & (p2 - 1)) return fail(FQ_EINVAL, "fq_hadamard_f16: n/K=%d is not a power of two", p2);
@@ -372,6 +395,7 @@ int fq_hadamard_f16(const void* x, void* y, int64_t rows, int n, int K, const vo
 
 int fq_int4_gemm_i32(const void* x, const void* w, int64_t M, int N, int K, void* c, void* stream) {
     if (!x || !w || !c) return fail(FQ_EINVAL, "fq_int4_gemm_i32: NULL pointer");
+    FQ_NEED_ALIGN16("fq_int4_gemm_i32", x, w, c);
     if (M < 0 || N <= 0 || K <= 0) return fail(FQ_EINVAL, "fq_int4_gemm_i32: bad sizes");
     if (K % 32) return fail(FQ_EINVAL, "fq_int4_gemm_i32: K=%d must be a multiple of 32", K);
     if (M == 0) return FQ_OK;
@@ -384,6 +408,7 @@ int fq_int4_gemm_i32(const void* x, const void* w, int64_t M, int N, int K, void
 int fq_int4_linear_f16(const void* x, const void* x_scale, const void* w, const void* w_scale, const void* bias,
                        int64_t M, int N, int K, void* y, void* stream) {
     if (!x || !w || !y || !x_scale || !w_scale) return fail(FQ_EINVAL, "fq_int4_linear_f16: NULL pointer");
+    FQ_NEED_ALIGN16("fq_int4_linear_f16", x, w, y);
     if (M < 0 || N <= 0 || K <= 0) return fail(FQ_EINVAL, "fq_int4_linear_f16: bad sizes");
     if (K % 32) return fail(FQ_EINVAL, "fq_int4_linear_f16: K=%d must be a multiple of 32", K);
     if (M == 0) return FQ_OK;
@@ -456,6 +481,7 @@ int fq_bf6_linear_f16(const void* xblob, const void* x_scale, const void* wblob,
 int fq_hadamard_quant_f16(const void* x, int64_t rows, int n, int K, const void* hadK, float scale, float sig_max,
                           float sig_min, void* q_out, void* scale_out, void* stream) {
     if (!x || !q_out || !scale_out) return fail(FQ_EINVAL, "fq_hadamard_quant_f16: NULL pointer");
+    FQ_NEED_ALIGN16("fq_hadamard_quant_f16", x, hadK, q_out);
     if (rows < 0 || n <= 0 || K <= 0 || n % K) return fail(FQ_EINVAL, "fq_hadamard_quant_f16: bad sizes n=%d K=%d", n, K);
     if (K > 1 && !hadK) return fail(FQ_EINVAL, "fq_hadamard_quant_f16: hadK is NULL with K=%d", K);
     if (!(sig_max > 0.0f) || !(sig_min > 0.0f)) return fail(FQ_EINVAL, "fq_hadamard_quant_f16: sig_max/sig_min must be > 0");
@@ -475,6 +501,7 @@ int fq_kv_quant_f16(const void* x, const void* trans, int64_t rows, int head_dim
     if (y_out && !trans) return fail(FQ_EINVAL, "fq_kv_quant_f16: y_out without trans");
     if (rows == 0) return FQ_OK;
     if (!x || !q_out || !param_out) return fail(FQ_EINVAL, "fq_kv_quant_f16: NULL pointer");
+    FQ_NEED_ALIGN16("fq_kv_quant_f16", x, trans, q_out, y_out);
     const int rc = fq_launch_kv_quant((const f16*)x, (const f16*)trans, rows, head_dim, clip_max, clip_min,
                                       (flags & FQ_KV_LAC) != 0, (uint8_t*)q_out, (f16*)param_out, (f16*)y_out, cu_count(),
                                       (hipStream_t)stream);
@@ -486,6 +513,7 @@ int fq_kv_dequant_f16(const void* q, const void* param, int64_t rows, int head_d
     if (flags & ~FQ_KV_LAC) return fail(FQ_EINVAL, "fq_kv_dequant_f16: unknown flags 0x%x", flags);
     if (rows == 0) return FQ_OK;
     if (!q || !param || !y) return fail(FQ_EINVAL, "fq_kv_dequant_f16: NULL pointer");
+    FQ_NEED_ALIGN16("fq_kv_dequant_f16", q, y);
     const int rc = fq_launch_kv_dequant((const uint8_t*)q, (const f16*)param, rows, head_dim, (flags & FQ_KV_LAC) != 0,
                                         (f16*)y, cu_count(), (hipStream_t)stream);
     return check_launch(rc, "fq_kv_dequant_f16");
@@ -510,6 +538,7 @@ int fq_kv_append_i4(void* kv_data, void* kv_param, const void* kv_indptr, const 
     if (tokens == 0) return FQ_OK;
     if (!kv_data || !kv_param || !kv_indptr || !kv_indices || !last_page_offset || !k || !v || !k_param || !v_param)
         return fail(FQ_EINVAL, "fq_kv_append_i4: NULL pointer");
+    FQ_NEED_ALIGN16("fq_kv_append_i4", kv_data, k, v);
     rc = fq_launch_kv_append(kv_data, kv_param, (const int*)kv_indptr, (const int*)kv_indices, (const int*)last_page_offset,
                              (const uint8_t*)k, (const uint8_t*)v, (const f16*)k_param, (const f16*)v_param,
                              (const int*)seqlen_indptr, tokens, num_layers, layer_idx, num_heads, page_size, head_dim, batch_size,
@@ -529,6 +558,7 @@ int fq_kv_append_f16(void* kv_data, void* kv_param, const void* kv_indptr, const
     if (tokens == 0) return FQ_OK;
     if (!kv_data || !kv_param || !kv_indptr || !kv_indices || !last_page_offset || !k || !v || !k_param || !v_param)
         return fail(FQ_EINVAL, "fq_kv_append_f16: NULL pointer");
+    FQ_NEED_ALIGN16("fq_kv_append_f16", kv_data, k, v);
     rc = fq_launch_kv_append(kv_data, kv_param, (const int*)kv_indptr, (const int*)kv_indices, (const int*)last_page_offset,
                              (const uint8_t*)k, (const uint8_t*)v, (const f16*)k_param, (const f16*)v_param,
                              (const int*)seqlen_indptr, tokens, num_layers, layer_idx, num_heads, page_size, head_dim, batch_size,
@@ -544,6 +574,7 @@ int fq_kv_batch_decode_f16_ex(void* o, const void* q, const void* q_trans, int t
     if (rc != FQ_OK) return rc;
     if (!o || !q || !kv_data || !kv_indptr || !kv_indices || !last_page_offset)
         return fail(FQ_EINVAL, "fq_kv_batch_decode_f16: NULL pointer");
+    FQ_NEED_ALIGN16("fq_kv_batch_decode_f16", kv_data, q_trans);
     rc = fq_launch_kv_decode((f16*)o, (const f16*)q, (void*)kv_data, (void*)kv_param, (const int*)kv_indptr,
                              (const int*)kv_indices, (const int*)last_page_offset, num_layers, layer_idx, num_heads, page_size,
                              head_dim, batch_size, (const f16*)q_trans, transpose_out != 0, (hipStream_t)stream, true);
@@ -570,6 +601,7 @@ int fq_kv_quant_append_i4(const void* k, const void* v, const void* trans, int64
     if (tokens == 0) return FQ_OK;
     if (!k || !v || !kv_data || !kv_param || !kv_indptr || !kv_indices || !last_page_offset)
         return fail(FQ_EINVAL, "fq_kv_quant_append_i4: NULL pointer");
+    FQ_NEED_ALIGN16("fq_kv_quant_append_i4", k, v, trans, kv_data);
     const float unit[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     rc = fq_launch_kv_quant_append((const f16*)k, (const f16*)v, (const f16*)trans, tokens, src_heads, head_dim,
                                    clip ? clip : unit, (flags & FQ_KV_LAC) != 0, kv_data, kv_param, (const int*)kv_indptr,
@@ -598,6 +630,7 @@ int fq_kv_batch_decode_i4_ex(void* o, const void* q, const void* q_trans, int tr
     if (rc != FQ_OK) return rc;
     if (!o || !q || !kv_data || !kv_param || !kv_indptr || !kv_indices || !last_page_offset)
         return fail(FQ_EINVAL, "fq_kv_batch_decode_i4: NULL pointer");
+    FQ_NEED_ALIGN16("fq_kv_batch_decode_i4", kv_data, q_trans);
     rc = fq_launch_kv_decode((f16*)o, (const f16*)q, (void*)kv_data, (void*)kv_param, (const int*)kv_indptr,
                              (const int*)kv_indices, (const int*)last_page_offset, num_layers, layer_idx, num_heads, page_size,
                              head_dim, batch_size, (const f16*)q_trans, transpose_out != 0, (hipStream_t)stream);
@@ -608,6 +641,7 @@ int fq_rowquant_f16(const void* x, int64_t rows, int cols, const float* sig_max,
                     int n_clips, int flags, void* const* q_out, void* const* scale_out,
                     void* const* fq_out, void* stream) {
     if (!x) return fail(FQ_EINVAL, "fq_rowquant_f16: x is NULL");
+    FQ_NEED_ALIGN16("fq_rowquant_f16", x);
     if (rows < 0 || cols <= 0) return fail(FQ_EINVAL, "fq_rowquant_f16: bad sizes");
     if (cols & 7) return fail(FQ_EUNSUPPORTED, "fq_rowquant_f16: cols=%d must be a multiple of 8", cols);
     if (cols > 32768) return fail(FQ_EUNSUPPORTED, "fq_rowquant_f16: cols=%d > 32768", cols);
@@ -622,6 +656,7 @@ int fq_rowquant_f16(const void* x, int64_t rows, int cols, const float* sig_max,
 
 int fq_sym_quant_f16(const void* x, const void* scale, int64_t rows, int cols, void* q, void* stream) {
     if (!x || !scale || !q) return fail(FQ_EINVAL, "fq_sym_quant_f16: NULL pointer");
+    FQ_NEED_ALIGN16("fq_sym_quant_f16", x, q);
     if (rows < 0 || cols <= 0) return fail(FQ_EINVAL, "fq_sym_quant_f16: bad sizes");
     if (rows == 0) return FQ_OK;
     return check_launch(fq_launch_sym_quant((const f16*)x, (const f16*)scale, rows, cols, (uint8_t*)q,

@@ -3,7 +3,9 @@
  * transform + INT4 activation-quantisation hot path.
  *
  * Every entry point:
- *   - takes raw DEVICE pointers owned by the caller (no allocation inside),
+ *   - takes raw DEVICE pointers owned by the caller (no allocation inside); every tensor (activations, factor matrices,
+ *     packed / fp16 outputs, workspaces, cache pages) must start on a 16-byte boundary — the kernels use 16-byte
+ *     accesses — and is refused with FQ_EINVAL otherwise (scales and index arrays: their natural alignment),
  *   - takes the HIP stream to launch on (void* == hipStream_t; NULL = default stream),
  *   - returns 0 on success or a negative FQ_E* code and never throws;
  *     fq_last_error() returns a thread-local message for the last failure,

@@ -362,3 +362,20 @@ def test_kv_cache_page_tables_match_the_reference_class(golden):
     bad[0, :30] = 0
     with pytest.raises(NotImplementedError):
         cache.get_cache_specs_for_flash_infer(bad)
+
+
+def test_misaligned_tensor_pointers_are_refused():
+    """include/fqhip.h: tensors must start on a 16-byte boundary (the kernels use 16-byte accesses). Checked before any launch,
+    so it can be exercised without a GPU: the pointers are never dereferenced."""
+    from flatquant_amd._lib import FQ_EINVAL, lib
+    vp = ctypes.c_void_p(0x1000)
+    odd = ctypes.c_void_p(0x1008)
+    f4 = (ctypes.c_float * 4)(1.0, 1.0, 1.0, 1.0)
+    a4 = (ctypes.c_void_p * 4)(0x2000, 0, 0, 0)
+    bad_q = (ctypes.c_void_p * 4)(0x2004, 0, 0, 0)
+    assert lib.fq_kron_quant_f16(odd, vp, vp, None, 4, 64, 64, f4, f4, 1, 1, a4, a4, a4, None, None, 0, None) == FQ_EINVAL
+    assert b"16-byte aligned" in lib.fq_last_error()
+    assert lib.fq_kron_quant_f16(vp, vp, vp, None, 4, 64, 64, f4, f4, 1, 1, bad_q, a4, a4, None, None, 0, None) == FQ_EINVAL
+    assert lib.fq_rowquant_f16(odd, 4, 4096, f4, f4, 1, 1, a4, a4, a4, None) == FQ_EINVAL
+    assert lib.fq_hadamard_f16(odd, vp, 4, 4096, 1, None, ctypes.c_float(1.0), None) == FQ_EINVAL
+    assert lib.fq_block_quant_f16(vp, odd, 4, 128, 32, 1, f4, f4, 1, 1, a4, a4, a4, None, None) == FQ_EINVAL
