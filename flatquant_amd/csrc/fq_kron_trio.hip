@@ -148,7 +148,6 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
     if (grp < blk_cnt && dn > 0) stage_token(grp, rv);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    const int sw = swz<CPR>(c);
     FqGroupCursor gcur;
     const float ps = out.post_scale != 0.0f ? out.post_scale : 1.0f;
 
@@ -167,8 +166,9 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
         TRIO_STAMP(1)
         f16x8 Uh[MT][2];
         {
-            int foff = c * CPR, swl = sw;
-            asm volatile("" : "+v"(foff), "+v"(swl));  // keep the address arithmetic inside the loop (hoisted, it is spilled)
+            int cl = c;
+            asm volatile("" : "+v"(cl));  // keep the address arithmetic inside the loop (hoisted, it is spilled)
+            const int foff = cl * CPR, swl = swz<CPR>(cl);
             const uint4* tb = reinterpret_cast<const uint4*>(tokbuf) + foff;
             f32x16 U[MT];
             // fragment reads run TRIO_DA - 1 MFMAs (32 cycles each) ahead of their use, flattened over (s, mt)
@@ -241,14 +241,23 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
             f16x2 pmax = {(f16)-INFINITY, (f16)-INFINITY}, pmin = {(f16)INFINITY, (f16)INFINITY};
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo) {
+                // rows of every tile but the last are all valid (M > 32 (MT - 1)): only the last tile's extrema need the mask
+                f16x2 tmax = {(f16)-INFINITY, (f16)-INFINITY}, tmin = {(f16)INFINITY, (f16)INFINITY};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const f16x2 pr = {fq_mul_to_f16(Y[mo][2 * j], ps), fq_mul_to_f16(Y[mo][2 * j + 1], ps)};
                     H[H16 ? mo : 0][j] = __builtin_bit_cast(uint32_t, pr);
-                    if ((mo * 32 + c) < M) {
+                    if (mo == MT - 1) {
+                        tmax = __builtin_elementwise_max(tmax, pr);
+                        tmin = __builtin_elementwise_min(tmin, pr);
+                    } else {
                         pmax = __builtin_elementwise_max(pmax, pr);
                         pmin = __builtin_elementwise_min(pmin, pr);
                     }
+                }
+                if (mo == MT - 1 && (mo * 32 + c) < M) {
+                    pmax = __builtin_elementwise_max(pmax, tmax);
+                    pmin = __builtin_elementwise_min(pmin, tmin);
                 }
             }
             vmax = fmaxf((float)pmax[0], (float)pmax[1]);
@@ -280,7 +289,7 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
                     a = fq_max3(a, t[r], t[r + 1]);
                     b = fq_min3(b, t[r], t[r + 1]);
                 }
-                const bool ok = (mo * 32 + c) < M;
+                const bool ok = mo < MT - 1 || (mo * 32 + c) < M;   // (only the last row tile can hold padding rows)
                 pmx[mo] = ok ? a : -INFINITY;
                 pmn[mo] = ok ? b : INFINITY;
             }
