@@ -50,6 +50,16 @@ struct FqGroupCursor {
     int64_t begin = 0, end = 0;
     float smax = 1.0f, smin = 1.0f;
 };
+// (the cursor is wave-uniform, but what a global load returns lives in VGPRs: without the readfirstlane below the compiler
+//  keeps the whole cursor — two 64-bit bounds and the clip pair — in vector registers and shuffles them around every token)
+__device__ __forceinline__ int64_t fq_uniform_i64(int64_t v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float fq_uniform_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
 __device__ __forceinline__ void fq_token_sigs(const FqQuantOut& out, int ci, int64_t tok, FqGroupCursor& cur, float& smax,
                                               float& smin) {
     if (out.group_offsets == nullptr) {
@@ -61,14 +71,14 @@ __device__ __forceinline__ void fq_token_sigs(const FqQuantOut& out, int ci, int
         int lo = 0, hi = out.n_groups;  // invariant: offsets[lo] <= tok < offsets[hi]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (out.group_offsets[mid] <= tok) lo = mid;
+            if (fq_uniform_i64(out.group_offsets[mid]) <= tok) lo = mid;
             else hi = mid;
         }
         cur.g = lo;
-        cur.begin = out.group_offsets[lo];
-        cur.end = out.group_offsets[lo + 1];
-        cur.smax = out.sig_max_g[lo];
-        cur.smin = out.sig_min_g[lo];
+        cur.begin = fq_uniform_i64(out.group_offsets[lo]);
+        cur.end = fq_uniform_i64(out.group_offsets[lo + 1]);
+        cur.smax = fq_uniform_f32(out.sig_max_g[lo]);
+        cur.smin = fq_uniform_f32(out.sig_min_g[lo]);
     }
     smax = cur.smax;
     smin = cur.smin;
