@@ -423,30 +423,36 @@ __device__ __forceinline__ uint32_t fq_pack8p(f32x2 p0, f32x2 p1, f32x2 p2, f32x
 // v_lshl_add_u32 on the raw bits of u and of v; the MAGIC exponent bits fall out of the dword except for the
 // constant K = 0x3F400000, (acc - K + 0x88888888) ^ 0x88888888 is the two's-complement nibble string (offset
 // binary r + 8 per digit, then the XOR), and ONE v_cmp_ne of the two dwords says whether any of the eight digits
-// was ambiguous (then the caller redoes that dword with the true division). CLAMP: med3 on u, v as floats.
+// was ambiguous (then the caller redoes that dword with the true division). CLAMP: see below.
 template <bool CLAMP>
 __device__ __forceinline__ uint32_t fq_quant8_two(float y0, float y1, float y2, float y3, float y4, float y5, float y6,
                                                float y7, float ilo, float ihi, unsigned long long& differ) {
     uint32_t a, b;
     float t0, s0, t1, s1;
     const float magic = FQ_MAGIC;
-    const float lo8 = FQ_MAGIC - 8.0f;
-    float hi7 = FQ_MAGIC + 7.0f;
-    if (CLAMP) asm volatile("" : "+v"(hi7));
+    // CLAMP: the bounds go onto y, ONE v_med3_f32 per element in front of the two products (on u and v it took two).
+    // yhi = 7 / ilo and ylo = -8 / ilo (v_rcp_f32, 1 ulp) lie within 2^-20 (relative) of 7 s and -8 s: both products of
+    // a bound round to 7 / -8 with no ambiguity, the quotient is monotone in y, so every y beyond a bound gets the digit
+    // of the bound, which is what the clamp of the pinned result gives it; every y inside is untouched.
+    float ylo = 0.0f, yhi = 0.0f;
+    if (CLAMP) {
+        const float s = __builtin_amdgcn_rcpf(ilo);
+        ylo = -8.0f * s;
+        yhi = 7.0f * s;
+    }
 #define FQ_UV(t, s, y) "v_fma_f32 %[" #t "], %[" #y "], %[ilo], %[mg]\n\tv_fma_f32 %[" #s "], %[" #y "], %[ihi], %[mg]\n\t"
-#define FQ_CL(t, s) "v_med3_f32 %[" #t "], %[" #t "], %[lo8], %[hi7]\n\tv_med3_f32 %[" #s "], %[" #s "], %[lo8], %[hi7]\n\t"
+#define FQ_CV(t, s, y) "v_med3_f32 %[" #t "], %[" #y "], %[ylo], %[yhi]\n\tv_fma_f32 %[" #s "], %[" #t "], %[ihi], %[mg]\n\tv_fma_f32 %[" #t "], %[" #t "], %[ilo], %[mg]\n\t"
 #define FQ_HN(t, s) "v_lshl_add_u32 %[a], %[a], 4, %[" #t "]\n\tv_lshl_add_u32 %[b], %[b], 4, %[" #s "]\n\t"
 #define FQ_TAIL "v_cmp_ne_u32_e64 %[m], %[a], %[b]\n\tv_add_u32_e32 %[a], 0x49488888, %[a]\n\tv_xor_b32_e32 %[a], 0x88888888, %[a]"
 #define FQ_OUTS [a] "=&v"(a), [b] "=&v"(b), [t0] "=&v"(t0), [s0] "=&v"(s0), [t1] "=&v"(t1), [s1] "=&v"(s1), [m] "=&s"(differ)
 #define FQ_INS [y0] "v"(y0), [y1] "v"(y1), [y2] "v"(y2), [y3] "v"(y3), [y4] "v"(y4), [y5] "v"(y5), [y6] "v"(y6), \
                [y7] "v"(y7), [ilo] "v"(ilo), [ihi] "v"(ihi), [mg] "s"(magic)
     if (CLAMP)
-        asm(FQ_UV(a, b, y7) FQ_UV(t0, s0, y6) FQ_CL(a, b) FQ_UV(t1, s1, y5) FQ_CL(t0, s0) FQ_HN(t0, s0)
-            FQ_UV(t0, s0, y4) FQ_CL(t1, s1) FQ_HN(t1, s1) FQ_UV(t1, s1, y3) FQ_CL(t0, s0) FQ_HN(t0, s0)
-            FQ_UV(t0, s0, y2) FQ_CL(t1, s1) FQ_HN(t1, s1) FQ_UV(t1, s1, y1) FQ_CL(t0, s0) FQ_HN(t0, s0)
-            FQ_UV(t0, s0, y0) FQ_CL(t1, s1) FQ_HN(t1, s1) FQ_CL(t0, s0) FQ_HN(t0, s0) FQ_TAIL
+        asm(FQ_CV(a, b, y7) FQ_CV(t0, s0, y6) FQ_CV(t1, s1, y5) FQ_HN(t0, s0) FQ_CV(t0, s0, y4) FQ_HN(t1, s1)
+            FQ_CV(t1, s1, y3) FQ_HN(t0, s0) FQ_CV(t0, s0, y2) FQ_HN(t1, s1) FQ_CV(t1, s1, y1) FQ_HN(t0, s0)
+            FQ_CV(t0, s0, y0) FQ_HN(t1, s1) FQ_HN(t0, s0) FQ_TAIL
             : FQ_OUTS
-            : FQ_INS, [lo8] "s"(lo8), [hi7] "v"(hi7));
+            : FQ_INS, [ylo] "v"(ylo), [yhi] "v"(yhi));
     else
         asm(FQ_UV(a, b, y7) FQ_UV(t0, s0, y6) FQ_UV(t1, s1, y5) FQ_HN(t0, s0) FQ_UV(t0, s0, y4) FQ_HN(t1, s1)
             FQ_UV(t1, s1, y3) FQ_HN(t0, s0) FQ_UV(t0, s0, y2) FQ_HN(t1, s1) FQ_UV(t1, s1, y1) FQ_HN(t0, s0)
@@ -454,7 +460,7 @@ __device__ __forceinline__ uint32_t fq_quant8_two(float y0, float y1, float y2, 
             : FQ_OUTS
             : FQ_INS);
 #undef FQ_UV
-#undef FQ_CL
+#undef FQ_CV
 #undef FQ_HN
 #undef FQ_TAIL
 #undef FQ_OUTS

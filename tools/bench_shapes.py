@@ -35,7 +35,9 @@ def line(name, shape, us, bytes_per_row, d, rows=ROWS):
 
 def main():
     g = torch.Generator(device="cuda").manual_seed(0)
-    sig = [(0.982, 0.982)]
+    sig = [(0.982, 0.982)]   # sigmoid(4.0): the reference's initial clip factors (no digit outside [-8, 7])
+    if os.environ.get("SIG"):  # e.g. SIG=0.9: trained clip factors, the quantiser's clamp route
+        sig = [(float(os.environ["SIG"]),) * 2]
     for d in (4096, 8192, 14336, 28672, 11008, 7168, 2048, 18944, 27648, 29568):  # (the last three: Qwen2.5 ffn widths)
         M, N = get_decompose_dim(d)
         rows = ROWS if d <= 14336 else ROWS // 2
