@@ -646,8 +646,11 @@ int fq_rowquant_f16(const void* x, int64_t rows, int cols, const float* sig_max,
     if (cols & 7) return fail(FQ_EUNSUPPORTED, "fq_rowquant_f16: cols=%d must be a multiple of 8", cols);
     if (cols > 32768) return fail(FQ_EUNSUPPORTED, "fq_rowquant_f16: cols=%d > 32768", cols);
     if (flags & FQ_OUT_TRANSFORM) return fail(FQ_EINVAL, "fq_rowquant_f16: FQ_OUT_TRANSFORM is meaningless here");
+    if ((flags & FQ_ASYM) && (flags & ~(FQ_ASYM | FQ_OUT_FAKEQUANT | FQ_QUANT_F16)) )
+        return fail(FQ_EINVAL, "fq_rowquant_f16: FQ_ASYM goes with FQ_OUT_FAKEQUANT (and FQ_QUANT_F16) only, flags 0x%x", flags);
+    if ((flags & FQ_ASYM) && !(flags & FQ_OUT_FAKEQUANT)) return fail(FQ_EINVAL, "fq_rowquant_f16: FQ_ASYM needs FQ_OUT_FAKEQUANT");
     FqQuantOut o;
-    int rc = fill_out("fq_rowquant_f16", o, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out, nullptr);
+    int rc = fill_out("fq_rowquant_f16", o, sig_max, sig_min, n_clips, flags & ~FQ_ASYM, q_out, scale_out, fq_out, nullptr);
     if (rc != FQ_OK) return rc;
     if (rows == 0) return FQ_OK;
     rc = fq_launch_rowquant(flags, (const f16*)x, rows, cols, o, cu_count(), (hipStream_t)stream);

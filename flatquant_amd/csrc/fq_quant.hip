@@ -3,6 +3,8 @@
 //   fq_rowquant_kernel      deploy/nn/quantization.py:13-36 (Quantizer.forward: 5-8 torch launches + the
 //                           CUDA pack kernel) and flatquant/quant_utils.py:77-119 in ONE pass: a row is
 //                           read once into registers, reduced, quantised, packed, written.
+//   fq_rowquant_asym_kernel flatquant/quant_utils.py:33-46,109-117 (ActivationQuantizer(sym=False): the K / V / Q cache
+//                           quantisers of llama_utils.py:124-132 under --k_asym --v_asym), fake-quant output, one pass
 //   fq_sym_quant_kernel     deploy/kernels/quant.cu:13-47  (fp16 division, rn, clamp, low nibble first)
 //   fq_sym_dequant_kernel   deploy/kernels/quant.cu:66-85
 #include "fq_common.hpp"
@@ -325,6 +327,128 @@ int launch_rowquant(const f16* x, int64_t rows, int cols, const FqQuantOut& out,
     return -1000;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Asymmetric per-row fake quantisation (FQ_ASYM): rows of `cols` fp16 values, LPR = 2^k lanes per row (cols = 128, a
+// head: 16 lanes, four rows per wave), each lane keeps its <= NV 16-byte vectors in registers (NV == 0: rows longer than
+// the register budget are read a second time — from L2). Pinned arithmetic, as torch evaluates the reference
+// (quant_utils.py:86-117, 33-46) on an fp16 activation:
+//   xmax = max(amax, 0), xmin = min(amin, 0); times the clip factors; both zero -> (-1, +1);
+//   scale = (xmax - xmin) / 15; zero = rint(-xmin / scale); q = clamp(rint(x / scale) + zero, 0, 15);
+//   out = fp16(scale * (q - zero))
+// F16A == false (lac with fp32 clip parameters: the (1,)-shaped fp32 sigmoid promotes extrema, scale, zero, the quotient
+// and the product to fp32): every operation rounds to fp32. F16A == true (no lac, clip_ratio, or a half()'ed module):
+// every operation rounds to fp16 — the extremum x factor product (fp32 opmath, then fp16: two roundings), the
+// difference, both quotients (fp16(a / b) from the correctly rounded fp32 quotient IS the correctly rounded fp16
+// quotient: 24 >= 2 * 11 + 2 bits), the product. (round_ste's (r - t) + t is r exactly in both widths.)
+template <bool F16A, int NV>
+__global__ __launch_bounds__(256) void fq_rowquant_asym_kernel(const f16* __restrict__ x, int64_t rows, int cols, int lpr_log2,
+                                                               FqQuantOut out) {
+    const int lane = threadIdx.x & 63;
+    const int lpr = 1 << lpr_log2, sub = lane & (lpr - 1), rpw = 64 >> lpr_log2;
+    const int nvec = cols >> 3;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r0 = wave * rpw; r0 < rows; r0 += nwaves * rpw) {
+        const int64_t row = r0 + (lane >> lpr_log2);
+        const bool live = row < rows;
+        const uint4* xp = reinterpret_cast<const uint4*>(x + (live ? row : 0) * (int64_t)cols);
+        f16x8 v[NV > 0 ? NV : 1];
+        f16x2 pmax = {(f16)-INFINITY, (f16)-INFINITY}, pmin = {(f16)INFINITY, (f16)INFINITY};
+        auto take = [&](const f16x8& w) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f16x2 pr = {w[e], w[e + 1]};
+                pmax = __builtin_elementwise_max(pmax, pr);
+                pmin = __builtin_elementwise_min(pmin, pr);
+            }
+        };
+        if (NV > 0) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int i = sub + k * lpr;
+                if (live && i < nvec) {
+                    v[k] = __builtin_bit_cast(f16x8, xp[i]);
+                    take(v[k]);
+                }
+            }
+        } else {
+            for (int i = sub; live && i < nvec; i += lpr) take(__builtin_bit_cast(f16x8, xp[i]));
+        }
+        float vmax = fmaxf((float)pmax[0], (float)pmax[1]), vmin = fminf((float)pmin[0], (float)pmin[1]);
+        for (int m = 1; m < lpr; m <<= 1) {  // the lanes of a row are an aligned group of 2^k: xor butterflies stay inside it
+            vmax = fmaxf(vmax, __shfl_xor(vmax, m));
+            vmin = fminf(vmin, __shfl_xor(vmin, m));
+        }
+        vmax = fmaxf(vmax, 0.0f);
+        vmin = fminf(vmin, 0.0f);
+        for (int ci = 0; ci < out.n_clips; ++ci) {
+            float xmax, xmin;
+            if (F16A) {
+                xmax = (float)fq_mul_to_f16(vmax, out.sig_max[ci]);
+                xmin = (float)fq_mul_to_f16(vmin, out.sig_min[ci]);
+            } else {
+                xmax = vmax * out.sig_max[ci];
+                xmin = vmin * out.sig_min[ci];
+            }
+            if (xmax == 0.0f && xmin == 0.0f) {
+                xmin = -1.0f;
+                xmax = 1.0f;
+            }
+            float scale, zero;
+            if (F16A) {
+                const float d = (float)(f16)(xmax - xmin);
+                scale = (float)(f16)(d / 15.0f);
+                zero = __builtin_rintf((float)(f16)(-xmin / scale));
+            } else {
+                const float d = xmax - xmin;
+                scale = d / 15.0f;
+                zero = __builtin_rintf(-xmin / scale);
+            }
+            uint4* op = reinterpret_cast<uint4*>(out.fq[ci] + (live ? row : 0) * (int64_t)cols);
+            auto emit = [&](const f16x8& w, int i) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = (float)w[e] / scale;            // correctly rounded fp32 division
+                    if (F16A) t = (float)(f16)t;
+                    float q = __builtin_rintf(t) + zero;      // (integers of small magnitude: exact in either width)
+                    q = __builtin_amdgcn_fmed3f(q, 0.0f, 15.0f);
+                    o[e] = fq_mul_to_f16(scale, q - zero);    // fp32 product rounded to fp32, then to fp16; F16A: the product
+                }                                             // of an 11-bit by a 5-bit significand is exact in fp32
+                op[i] = __builtin_bit_cast(uint4, o);
+            };
+            if (NV > 0) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int i = sub + k * lpr;
+                    if (live && i < nvec) emit(v[k], i);
+                }
+            } else {
+                for (int i = sub; live && i < nvec; i += lpr) emit(__builtin_bit_cast(f16x8, xp[i]), i);
+            }
+        }
+    }
+}
+
+template <bool F16A>
+int launch_rowquant_asym(const f16* x, int64_t rows, int cols, const FqQuantOut& out, int n_cu, hipStream_t stream) {
+    const int nvec = cols >> 3;
+    int lg = 0;
+    while (lg < 6 && (1 << lg) < nvec) ++lg;  // lanes per row: the power of two >= cols / 8, at most a wave
+    const int per_lane = (nvec + (1 << lg) - 1) >> lg;
+    const int64_t waves = (rows + (64 >> lg) - 1) / (64 >> lg);
+    int64_t blocks = (waves + 3) / 4;
+    if (blocks > (int64_t)n_cu * 8) blocks = (int64_t)n_cu * 8;
+    if (blocks < 1) blocks = 1;
+#define FQ_ASYM_LAUNCH(NV_)                                                                                             \
+    hipLaunchKernelGGL((fq_rowquant_asym_kernel<F16A, NV_>), dim3((unsigned)blocks), dim3(256), 0, stream, x, rows, cols, lg, out)
+    if (per_lane <= 1) FQ_ASYM_LAUNCH(1);
+    else if (per_lane <= 4) FQ_ASYM_LAUNCH(4);
+    else if (per_lane <= 8) FQ_ASYM_LAUNCH(8);
+    else FQ_ASYM_LAUNCH(0);
+#undef FQ_ASYM_LAUNCH
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 int fq_launch_rowquant(int flags, const f16* x, int64_t rows, int cols, const FqQuantOut& out, int n_cu,
@@ -334,6 +458,11 @@ int fq_launch_rowquant(int flags, const f16* x, int64_t rows, int cols, const Fq
         return launch_rowquant<(F)>(x, rows, cols, out, n_cu, stream);          \
     case (F) | FQ_QUANT_F16:                                                    \
         return launch_rowquant<(F) | FQ_QUANT_F16>(x, rows, cols, out, n_cu, stream);
+    if (flags & FQ_ASYM) {  // (fq_capi admits it with FQ_OUT_FAKEQUANT alone)
+        if ((flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM)) != FQ_OUT_FAKEQUANT) return -1000;
+        return (flags & FQ_QUANT_F16) ? launch_rowquant_asym<true>(x, rows, cols, out, n_cu, stream)
+                                      : launch_rowquant_asym<false>(x, rows, cols, out, n_cu, stream);
+    }
     switch (flags & FQ_CT_MASK) {
         FQ_CASE(FQ_OUT_PACKED)
         FQ_CASE(FQ_OUT_FAKEQUANT)

@@ -2,7 +2,7 @@
 import torch
 
 from .. import ops
-from .._lib import FQ_OUT_FAKEQUANT, FQ_QUANT_F16, FQ_SIG_F16
+from .._lib import FQ_ASYM, FQ_OUT_FAKEQUANT, FQ_QUANT_F16, FQ_SIG_F16
 
 
 def get_qmin_qmax(bits, sym):
@@ -22,7 +22,7 @@ class ActivationQuantizer(torch.nn.Module):
     shape (1,), init 4.0 when ``lac``) and attributes (``bits sym lac enable q_max q_min groupsize``).
     Arithmetic: with ``lac`` the reference's type promotion evaluates scale, x/scale and scale*q in fp32
     (fp16 extrema x fp32 sigmoid); without it everything stays fp16 — both are reproduced (FQ_QUANT_F16).
-    Only the 4-bit symmetric case is on the hot path; asymmetric raises NotImplementedError.
+    4-bit only: symmetric (the activation quantisers) and asymmetric (``sym=False``: the K / V / Q cache quantisers).
     """
 
     def __init__(self, bits, sym=False, lac=False, groupsize=-1, clip_ratio=None):
@@ -67,11 +67,16 @@ class ActivationQuantizer(torch.nn.Module):
         return self.fake_quant(x)
 
     def fake_quant(self, x):
-        if self.bits != 4 or not self.sym:
-            raise NotImplementedError("flatquant_amd: only 4-bit symmetric activation quantisation is on the hot path")
+        if self.bits != 4:
+            raise NotImplementedError("flatquant_amd: only 4-bit activation quantisation is on the hot path")
         flags = FQ_OUT_FAKEQUANT | (0 if self.lac else FQ_QUANT_F16)
         if self._lac_f16():
             flags |= FQ_QUANT_F16 | FQ_SIG_F16
+        if not self.lac and self._clip_ratio is not None:
+            flags |= FQ_SIG_F16     # fp16 extremum x python float: an fp16 product (quant_utils.py:99-100)
+        if not self.sym:
+            # quant_utils.py:33-46,109-117: the K / V / Q cache quantisers under --k_asym --v_asym (llama_utils.py:124-132)
+            flags = (flags & ~FQ_SIG_F16) | FQ_ASYM   # (the asymmetric kernel always rounds the fp16 route's products)
         if self.groupsize > 0:
             if x.shape[-1] % self.groupsize:
                 raise ValueError(f"last dimension {x.shape[-1]} is not a multiple of groupsize {self.groupsize}")

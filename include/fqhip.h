@@ -82,6 +82,12 @@ extern "C" {
                                    tensor gives an fp16 tensor under torch's type promotion; the (1,)-shaped parameters of
                                    flatquant/quant_utils.py:96-97 promote the product, scale and quotient to fp32 instead) */
 
+#define FQ_ASYM           0x800 /* fq_rowquant_f16 with FQ_OUT_FAKEQUANT alone: the ASYMMETRIC quantiser of
+                                   flatquant/quant_utils.py:33-46,109-117 (ActivationQuantizer(sym=False): the K / V / Q cache
+                                   quantisers under --k_asym --v_asym, llama_utils.py:124-132): scale = (xmax - xmin) / 15,
+                                   zero = rint(-xmin / scale), out = scale * (clamp(rint(x / scale) + zero, 0, 15) - zero);
+                                   fp32 arithmetic, or fp16 throughout with FQ_QUANT_F16 (no lac / clip_ratio / half module) */
+
 #define FQ_MAX_CLIPS 4
 
 /*

@@ -272,6 +272,33 @@ def rowquant(x16, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False, sig_f1
                          sig_f16=sig_f16)
 
 
+def rowquant_asym(x16, sig_max=1.0, sig_min=1.0, quant_f16=False):
+    """ActivationQuantizer(sym=False).fake_quant on an fp16 activation -> fp16 [rows, cols].
+
+    quant_utils.py:86-92 (row extrema through 0), :95-100 (clip factors), :109-113 (both zero -> (-1, +1);
+    scale = (xmax - xmin) / q_max, q_max = 15; zero = round(-xmin / scale)), :33-46 (q = clamp(round_ste(x / scale) + zero,
+    0, q_max); scale * (q - zero)), :81 (.to(x_dtype)). round_ste's (r - t) + t equals r exactly in both widths.
+    quant_f16=False: lac with fp32 (1,)-shaped clip parameters — torch promotes the extrema, scale, zero, quotient and
+    product to fp32. quant_f16=True: no lac / clip_ratio / half()'ed module — every operation rounds to fp16 (the
+    extremum x factor product is formed in fp32 opmath and then rounded to fp16).
+    """
+    x16 = np.asarray(x16, dtype=F16)
+    x = x16.astype(F32).reshape(x16.shape[0], -1)
+    rnd = (lambda a: a.astype(F32).astype(F16).astype(F32)) if quant_f16 else (lambda a: a.astype(F32))
+    xmax = np.maximum(x.max(axis=-1), F32(0))
+    xmin = np.minimum(x.min(axis=-1), F32(0))
+    xmax = rnd((xmax * F32(sig_max)).astype(F32))
+    xmin = rnd((xmin * F32(sig_min)).astype(F32))
+    both = (xmax == 0) & (xmin == 0)
+    xmin = np.where(both, F32(-1), xmin).astype(F32)
+    xmax = np.where(both, F32(1), xmax).astype(F32)
+    scale = rnd(rnd(xmax - xmin) / F32(15))
+    zero = np.rint(rnd((-xmin) / scale)).astype(F32)
+    t = rnd(x / scale[:, None])
+    q = np.clip(np.rint(t) + zero[:, None], 0, 15).astype(F32)
+    return (scale[:, None] * (q - zero[:, None])).astype(F32).astype(F16)
+
+
 def block_quant(x16, P16, sig_max=1.0, sig_min=1.0, transpose_out=True, round_y_f16=False, clamp0=False,
                 quant_f16=False, groups=None):
     """block_matmul.py:29-104: Y = x[t] ([R, C]) @ P; statistics over the whole block; the quantised block

@@ -90,3 +90,73 @@ def test_deploy_api_round_trip(ops):
     assert np.array_equal(p.scales_x.cpu().numpy().reshape(-1), ref["scale16"])
     again = deploy.sym_quant(x, p.scales_x.reshape(-1))
     assert torch.equal(again, p.quantized_x)             # Quantizer == scales + sym_quant, as in the reference
+
+
+# ---- asymmetric fake quantisation (ActivationQuantizer(sym=False): the K / V / Q cache quantisers) ----
+ASYM = 0x800
+ASYM_CASES = [("lac32", False), ("lac32b", False), ("plain", True), ("ratio", True), ("lac16", True)]
+
+
+def _asym_sig(g, name):
+    if f"{name}_sig" in g:
+        return float(g[f"{name}_sig"][0]), float(g[f"{name}_sig"][1])
+    return (0.83, 0.83) if name == "ratio" else (1.0, 1.0)
+
+
+@pytest.mark.parametrize("name,f16", ASYM_CASES)
+@pytest.mark.parametrize("cols", [128, 64, 1000, 4096, 10240])
+def test_rowquant_asym_matches_reference(ops, golden, name, f16, cols):
+    """fq_rowquant_f16(FQ_ASYM) against what the reference's ActivationQuantizer(sym=False) returned: every bit."""
+    g = golden("act_asym")
+    x, y = g[f"{name}_{cols}_x"], g[f"{name}_{cols}_y"]
+    o = ops.rowquant(torch.from_numpy(x).cuda(), [_asym_sig(g, name)], F | ASYM | (Q16 if f16 else 0))
+    assert np.array_equal(o.fq[0].cpu().numpy().view(np.uint16), y.view(np.uint16))
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 8), (3, 16), (5, 24), (130, 128), (1027, 128), (9, 136), (7, 520), (4, 2048),
+                                       (3, 2056), (2, 4104), (2, 32768), (4096, 64)])
+@pytest.mark.parametrize("f16", [False, True])
+def test_rowquant_asym_bit_exact_vs_oracle(ops, rows, cols, f16):
+    """every lanes-per-row / vectors-per-lane build (one row per 1..64 lanes, 1 / 4 / 8 cached vectors, re-read rows),
+    ragged row counts, three clip sets in one launch"""
+    x = rand_x(rows, cols, rows * 17 + cols)
+    if rows > 2:
+        x[1] = 0
+        x[2] = x[2].abs()
+    sigs = [(0.982, 0.982), (0.55, 0.9), (1.0, 0.31)]
+    o = ops.rowquant(x.cuda(), sigs, F | ASYM | (Q16 if f16 else 0))
+    for ci, s in enumerate(sigs):
+        ref = O.rowquant_asym(x.numpy(), s[0], s[1], quant_f16=f16)
+        assert np.array_equal(o.fq[ci].cpu().numpy().view(np.uint16), ref.view(np.uint16)), (rows, cols, f16, ci)
+
+
+def test_activation_quantizer_module_asym_and_clip_ratio(ops, golden):
+    """The module (flatquant_amd.flatquant.quant_utils.ActivationQuantizer) in the reference's five asymmetric
+    configurations and the symmetric clip_ratio one, on the reference's inputs, 3-D like the cache quantisers' callers."""
+    from flatquant_amd.flatquant.quant_utils import ActivationQuantizer
+    g = golden("act_asym")
+    for name, kw in (("lac32", dict(lac=True)), ("lac32b", dict(lac=True)), ("plain", {}), ("ratio", dict(clip_ratio=0.83)),
+                     ("lac16", dict(lac=True))):
+        q = ActivationQuantizer(bits=4, sym=False, **kw)
+        if f"{name}_clip" in g:
+            q.clip_factor_a_max.data.fill_(float(g[f"{name}_clip"][0]))
+            q.clip_factor_a_min.data.fill_(float(g[f"{name}_clip"][1]))
+        q = q.cuda()
+        if name == "lac16":
+            q = q.half()
+        for cols in (128, 4096):
+            x, y = g[f"{name}_{cols}_x"], g[f"{name}_{cols}_y"]
+            out = q(torch.from_numpy(x).cuda().reshape(2, -1, cols))
+            assert out.shape == (2, x.shape[0] // 2, cols) and out.dtype == torch.float16
+            assert np.array_equal(out.reshape(-1, cols).cpu().numpy().view(np.uint16), y.view(np.uint16)), (name, cols)
+    q = ActivationQuantizer(bits=4, sym=True, clip_ratio=0.83).cuda()
+    for cols in (128, 4096):
+        out = q(torch.from_numpy(g[f"symratio_{cols}_x"]).cuda())
+        assert np.array_equal(out.cpu().numpy().view(np.uint16), g[f"symratio_{cols}_y"].view(np.uint16))
+
+
+def test_rowquant_asym_flag_errors(ops):
+    x = rand_x(4, 128, 1).cuda()
+    for flags in (P | ASYM, P | F | ASYM, F | ASYM | NC0):
+        with pytest.raises(Exception):
+            ops.rowquant(x, [(1.0, 1.0)], flags)

@@ -213,3 +213,27 @@ def test_path_a_torch_port_matches_reference_goldens(golden):
         assert np.array_equal(fq.numpy(), g[f"a16_lac{ci}_fq"])
     y = path_a_torch.kronecker_matmul(x, L, R)
     assert np.array_equal(y.numpy(), g["a16_lac0_y"])
+
+
+ASYM_CASES = [("lac32", False), ("lac32b", False), ("plain", True), ("ratio", True), ("lac16", True)]
+
+
+@pytest.mark.parametrize("name,f16", ASYM_CASES)
+@pytest.mark.parametrize("cols", [128, 64, 1000, 4096, 10240])
+def test_asymmetric_quantizer_bit_exact_vs_reference(golden, name, f16, cols):
+    """ActivationQuantizer(sym=False) of the reference (quant_utils.py:33-46,109-117), run by tools/gen_golden.py on
+    fp16 activations in five configurations (fp32-promoted lac, plain, clip_ratio, half()'ed lac): every output bit."""
+    g = golden("act_asym")
+    x, y = g[f"{name}_{cols}_x"], g[f"{name}_{cols}_y"]
+    smax, smin = (g[f"{name}_sig"] if f"{name}_sig" in g else ((0.83, 0.83) if name == "ratio" else (1.0, 1.0)))
+    o = O.rowquant_asym(x, smax, smin, quant_f16=f16)
+    assert np.array_equal(o.view(np.uint16), y.view(np.uint16))
+
+
+@pytest.mark.parametrize("cols", [128, 4096])
+def test_symmetric_quantizer_with_clip_ratio_vs_reference(golden, cols):
+    """clip_ratio without lac: the fp16 extremum times the python float is an fp16 tensor (sig_f16), then / 7 in fp16."""
+    g = golden("act_asym")
+    x, y = g[f"symratio_{cols}_x"], g[f"symratio_{cols}_y"]
+    o = O.rowquant(x, 0.83, 0.83, clamp0=True, quant_f16=True, sig_f16=True)["fq"]
+    assert np.array_equal(o.view(np.uint16), y.view(np.uint16))

@@ -640,7 +640,49 @@ def gen_quantizer_lac():
     save("quantizer_lac", **arrays)
 
 
+def gen_act_asym():
+    """ActivationQuantizer(bits=4, sym=False) (quant_utils.py:33-46,109-117) — the K / V / Q cache quantisers under
+    --k_asym --v_asym (llama_utils.py:124-132, rows = (token, head), 128 columns) — run on fp16 activations: lac with the
+    fp32 clip parameters (arithmetic promoted to fp32), no lac, clip_ratio, and a half()'ed lac module (all fp16); plus
+    the symmetric quantiser with clip_ratio (the fp16 product rounding the lac-less route shares)."""
+    arrays = {}
+    cases = [("lac32", dict(lac=True), (4.0, 4.0)), ("lac32b", dict(lac=True), (1.7, 0.4)), ("plain", dict(lac=False), None),
+             ("ratio", dict(lac=False, clip_ratio=0.83), None), ("lac16", dict(lac=True), (2.1, 0.9))]
+    for ci, (name, kw, clips) in enumerate(cases):
+        for cols in (128, 64, 1000, 4096, 10240):
+            x = make_x(10 if cols <= 1000 else 6, cols, seed=300 + ci * 10 + cols % 7)
+            x[1] = 0                      # both extrema zero: (-1, +1)
+            x[2] = x[2].abs()             # xmin clamps to 0
+            x[3] = -x[3].abs()            # xmax clamps to 0
+            x[4, ::3] *= 30               # outliers: quotients far outside [0, 15]
+            q = RefActQ(bits=4, sym=False, **kw)
+            if clips is not None:
+                q.clip_factor_a_max.data.fill_(clips[0])
+                q.clip_factor_a_min.data.fill_(clips[1])
+            if name == "lac16":
+                q = q.half()
+            with torch.no_grad():
+                y = q(x)
+            assert y.dtype == torch.float16
+            arrays[f"{name}_{cols}_x"], arrays[f"{name}_{cols}_y"] = x.numpy(), y.numpy()
+        if clips is not None:
+            arrays[f"{name}_clip"] = np.array(clips, dtype=np.float32)
+            if name == "lac16":   # torch.sigmoid of the fp16 parameter (fp32 opmath, rounded to fp16)
+                arrays[f"{name}_sig"] = np.array([float(torch.sigmoid(torch.tensor(c, dtype=torch.float16))) for c in clips], dtype=np.float32)
+            else:
+                arrays[f"{name}_sig"] = np.array([sig(c) for c in clips], dtype=np.float32)
+    # symmetric + clip_ratio (fp16 route: the product extremum x ratio is rounded to fp16 before the division by 7)
+    for cols in (128, 4096):
+        x = make_x(8, cols, seed=377 + cols % 5)
+        x[1] = 0
+        q = RefActQ(bits=4, sym=True, lac=False, clip_ratio=0.83)
+        with torch.no_grad():
+            arrays[f"symratio_{cols}_x"], arrays[f"symratio_{cols}_y"] = x.numpy(), q(x).numpy()
+    save("act_asym", **arrays)
+
+
 def gen_round2():
+    gen_act_asym()
     gen_kv_class()
     gen_group128()
     gen_moe_grouped()
@@ -652,6 +694,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt2k":   # the K = 2048 export (12 MB): only on request
         gen_checkpoint(hidden=2048, ffn=2048, heads=16, kv_heads=2, layers=1, name="ckpt2k", clip_noise=0.6)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "asym":
+        gen_act_asym()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "kvclass":
         gen_kv_class()
