@@ -2,7 +2,7 @@
 import torch
 
 from ... import ops
-from ..._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED, FQ_QUANT_F16
+from ..._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED, FQ_QUANT_F16, FQ_SIG_F16
 from ...flatquant.function_utils import get_decompose_dim  # noqa: F401
 from ...flatquant.hadamard_utils import get_hadK, is_pow2, matmul_hadU_cuda  # noqa: F401
 from .. import PackedQuantizedTensor
@@ -43,10 +43,14 @@ def quant(x, clip_factor_a_max=1.0, clip_factor_a_min=1.0, input_clip_ratio=1.0)
     cmax, cmin = _clip(clip_factor_a_max), _clip(clip_factor_a_min)
     x2 = x.reshape(-1, x.shape[-1])
     if cmax != 1.0:
-        sig = ops.sigmoid_pair(cmax, cmin)
+        # :91-104: fp16 extrema x a 0-dim fp32 sigmoid tensor is an fp16 product under torch's promotion -> FQ_SIG_F16
+        o = ops.rowquant(x2.contiguous(), [ops.sigmoid_pair(cmax, cmin)], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)
+    elif input_clip_ratio != 1.0:
+        # :106: (max|x| / 7).to(fp16) * ratio keeps the reference's op order in torch (x itself, not the flattened view:
+        # the scales keep x's leading shape); the pack is the kernel behind deploy.sym_quant
+        from .. import sym_quant
+        scales = (torch.max(torch.abs(x), dim=-1)[0].unsqueeze(1) / 7).to(torch.float16) * input_clip_ratio
+        return PackedQuantizedTensor(sym_quant(x, scales), scales)
     else:
-        if input_clip_ratio != 1.0:
-            raise NotImplementedError("input_clip_ratio != 1 is not fused; scale with torch and call deploy.sym_quant")
-        sig = (1.0, 1.0)
-    o = ops.rowquant(x2.contiguous(), [sig], FQ_OUT_PACKED | FQ_QUANT_F16)
+        o = ops.rowquant(x2.contiguous(), [(1.0, 1.0)], FQ_OUT_PACKED | FQ_QUANT_F16)
     return PackedQuantizedTensor(o.q[0], o.scale[0].reshape(-1, 1))

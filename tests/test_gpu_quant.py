@@ -160,3 +160,29 @@ def test_rowquant_asym_flag_errors(ops):
     for flags in (P | ASYM, P | F | ASYM, F | ASYM | NC0):
         with pytest.raises(Exception):
             ops.rowquant(x, [(1.0, 1.0)], flags)
+
+
+def test_functional_quant_lac_and_input_clip_ratio(ops, golden):
+    """deploy.functional.online_trans.quant (deploy/functional/online_trans.py:90-110): with clip factors it is the
+    arithmetic of deploy.nn.Quantizer(lac=True) — the reference module's own scales and bytes (quantizer_lac.npz);
+    with input_clip_ratio the scales are (max|x| / 7).to(fp16) * ratio and the pack is sym_quant."""
+    from flatquant_amd.deploy.functional.online_trans import quant
+    g = golden("quantizer_lac")
+    for ci in range(3):
+        x = torch.from_numpy(g[f"x{ci}"]).cuda()
+        p = quant(x, float(g[f"clip{ci}"][0]), float(g[f"clip{ci}"][1]))
+        assert np.array_equal(p.scales_x.cpu().numpy().reshape(-1), g[f"scales{ci}"])
+        assert np.array_equal(p.quantized_x.cpu().numpy(), g[f"packed{ci}"])
+    x = rand_x(33, 4096, 5)
+    p = quant(x.cuda(), input_clip_ratio=0.9)
+    # the scales are torch ops in the reference's order; fp16 x python float is ONE rounding in torch-ROCm's kernel
+    # (v_fma_mixlo_f16) and two (fp32, then fp16) on the CPU: equal except on fp32 products that land on an fp16 tie
+    scales = ((x.float().abs().amax(dim=-1, keepdim=True) / 7).half().float() * 0.9).half()
+    got = p.scales_x.cpu()
+    assert got.shape == scales.shape and got.dtype == torch.float16
+    ulp = (got.view(torch.int16).int() - scales.view(torch.int16).int()).abs()
+    assert int(ulp.max()) <= 1 and int((ulp != 0).sum()) <= 8
+    assert np.array_equal(p.quantized_x.cpu().numpy(), O.sym_quant(x.numpy(), got.numpy().reshape(-1)))
+    p1 = quant(x.cuda())
+    ref = O.rowquant(x.numpy(), quant_f16=True)
+    assert np.array_equal(p1.quantized_x.cpu().numpy(), ref["packed"]) and np.array_equal(p1.scales_x.cpu().numpy().reshape(-1), ref["scale16"])
