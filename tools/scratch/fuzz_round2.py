@@ -3,6 +3,7 @@
   * general MFMA kernel: every output set bit-exact against the oracle's quantiser on its own transform, random (M, N)
   * packed-only block kernel == the all-output-sets build (C = 32 / 64, both output orders)
   * grouped launches == one launch per group
+  * every quantiser route (magic / clamp / true division) of the specialised kernels vs the oracle; the asymmetric quantiser
 Run it several times in FRESH processes (different seeds): races show on cold launches."""
 import os
 import random
@@ -96,4 +97,35 @@ for it in range(15 if ONLY in ("", "grouped") else 0):    # grouped launches (wa
         if not (torch.equal(o.q[0][a0:a1], one.q[0]) and torch.equal(o.scale[0][a0:a1], one.scale[0])):
             bad += 1
             print("grouped mismatch", M, N, gi, a0, a1)
+for it in range(40 if ONLY in ("", "clamp") else 0):    # quantiser routes of the wave / 64x64 / workgroup kernels vs the oracle on the kernel's own transform
+    M, N = random.choice([(64, 64), (64, 128), (64, 112), (32, 64), (56, 64), (112, 128), (128, 224), (86, 128)])
+    rows = random.choice([1, 3, 64, 257, 1500])
+    x = (torch.randn(rows, M * N, generator=g, device="cuda") * random.choice([0.01, 1.0, 30.0])).half()
+    if it % 2 == 0:
+        x[:, ::37] *= 40
+    L, R = mats(M, N)
+    sigs = [(random.choice([1.0, 0.98, 0.9, 0.5, 0.1, 1e-3, 1e-7]), random.choice([1.0, 0.98, 0.9, 0.5, 0.1, 1e-3, 1e-7])) for _ in range(3)]
+    both = ops.kron_quant(x, L, R, sigs, P | T | R16)
+    y = both.y.cpu().numpy().astype(np.float32)
+    only = ops.kron_quant(x, L, R, sigs, P | R16)
+    for ci, sg in enumerate(sigs):
+        ref = O.quant_outputs(y, sg[0], sg[1])
+        for o in (both, only):
+            if not (np.array_equal(o.q[ci].cpu().numpy(), ref["packed"]) and np.array_equal(o.scale[ci].cpu().numpy(), ref["scale16"])):
+                bad += 1
+                print("quantiser route mismatch", M, N, rows, sg, "packed-only" if o is only else "all outputs")
+for it in range(40 if ONLY in ("", "asym") else 0):    # asymmetric fake quantiser vs the oracle
+    cols = 8 * random.choice([1, 2, 3, 8, 16, 17, 64, 65, 128, 256, 257, 512, 513, 1000, 4096])
+    rows = random.choice([1, 2, 63, 64, 65, 1000, 4097])
+    x = (torch.randn(rows, cols, generator=g, device="cuda") * random.choice([0.01, 1.0, 100.0])).half()
+    if it % 3 == 0:
+        x[::2] = x[::2].abs()
+    sigs = [(random.uniform(0.05, 1.0), random.uniform(0.05, 1.0)) for _ in range(random.randint(1, 4))]
+    f16 = random.random() < 0.5
+    o = ops.rowquant(x, sigs, F | 0x800 | (Q16 if f16 else 0))
+    for ci, sg in enumerate(sigs):
+        ref = O.rowquant_asym(x.cpu().numpy(), sg[0], sg[1], quant_f16=f16)
+        if not np.array_equal(o.fq[ci].cpu().numpy().view(np.uint16), ref.view(np.uint16)):
+            bad += 1
+            print("asym mismatch", rows, cols, sg, f16)
 print(f"fuzz_round2 seed {seed}: mismatches {bad}")
