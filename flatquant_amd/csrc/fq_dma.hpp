@@ -7,7 +7,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 // chunk swizzle of row r inside the token buffer (16-byte chunks, CPR per row): 8 consecutive rows must spread over
 // the 16 chunk-aligned bank groups. CPR = 16: rows alias -> XOR the row's low bits; CPR = 8: pairs of rows alias;
-// CPR = 14 (N = 112): the row pitch already rotates by 14 mod 16.
+// CPR = 14 (N = 112) and CPR = 10 (N = 80): the row pitch already rotates (14 r, 10 r mod 16 are eight distinct even slots).
 template <int CPR>
 __device__ __forceinline__ int swz(int r) {
     return CPR == 16 ? (r & 15) : CPR == 8 ? ((r >> 1) & 7) : 0;
@@ -30,7 +30,7 @@ __device__ __forceinline__ void dma_offsets(int lane, unsigned (&voff)[4]) {
 template <int CPR>
 __device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok, int64_t tok_bytes, int n_dma,
                                           unsigned lds_base, const unsigned (&voff)[4]) {
-    static_assert(CPR == 16 || CPR == 8 || CPR == 14, "offset pattern must repeat every 4 instructions");
+    static_assert(CPR == 16 || CPR == 8 || CPR == 14 || CPR == 10, "offset pattern must repeat every 4 instructions");
     const unsigned char* base = reinterpret_cast<const unsigned char*>(x) + tok * tok_bytes;  // wave-uniform
     const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)base);
     const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((size_t)base >> 32));

@@ -1,6 +1,7 @@
 // fq_kron_wave.hip — fused Kronecker transform + per-token INT4 quantisation, ONE WAVE PER TOKEN, for factor pairs
-// whose token fits a wave's registers: M <= 64, N in {64, 112, 128} (N/32 rounded up even, <= 4 column tiles):
-// d = 8192 (64x128, Llama-2-70B hidden), 7168 (64x112, DeepSeek-V3 hidden), 3584 (56x64), 2048 (32x64).
+// whose token fits a wave's registers: M <= 64, N in {64, 80, 112, 128} (<= 4 column tiles):
+// d = 8192 (64x128, Llama-2-70B hidden), 7168 (64x112, DeepSeek-V3 hidden), 5120 (64x80, Qwen2.5-14B/32B hidden),
+// 3584 (56x64), 2048 (32x64).
 // Packed INT4 + fp16 scale output (the deploy.nn.OnlineTrans contract: deploy/kernels/kron_matmul.py:192-266,
 // functional/online_trans.py:113-122); everything else goes to fq_kron_generic.hip.
 //
@@ -36,8 +37,19 @@ struct WaveGeom {
     static constexpr int LFR = 2 * MT * MT * 64;            // uint4
     static constexpr int LDS = (RFR + LFR) * 16 + W * TOKBUF + 16;
     static constexpr int V1 = N - NT * 16;                  // valid n' in the h = 1 half of a lane's run
-    static constexpr int NPAIR = NT / 2;                    // 16-byte pieces of a lane's packed run
-    static constexpr int STORES = MT * (NPAIR + ((V1 % 32) == 16 ? 1 : 0)) + 1;  // VMEM stores per token and clip
+    static constexpr int NPIECE = (NT * 2 + 3) / 4;         // 16-byte pieces of a lane's packed run (the last may be 8 bytes)
+    // VMEM store instructions per output row group: piece p is a 16-byte store for the halves with >= 32 p + 32 valid n',
+    // an 8-byte store for those with exactly 32 p + 16 (h = 0 runs hold NT * 16 valid n', h = 1 runs V1)
+    static constexpr int row_stores() {
+        int n = 0;
+        for (int p = 0; p < NPIECE; ++p) {
+            const int a = NT * 16 - 32 * p, b = V1 - 32 * p;
+            n += (a >= 32 || b >= 32) ? 1 : 0;
+            n += ((a >= 16 && a < 32) || (b >= 16 && b < 32)) ? 1 : 0;
+        }
+        return n;
+    }
+    static constexpr int STORES = MT * row_stores() + 1;    // VMEM stores per token and clip (+ the scale)
 };
 
 // The single-width asm quantiser (fq_quant8_two, fq_common.hpp) over one output row group (mo) of a lane: NT * 2 packed
@@ -63,7 +75,7 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
                                                             int64_t rows, int64_t tpb, int M, FqQuantOut out) {
     typedef WaveGeom<MT, NT, KS1, W> G;
     constexpr int N = G::N, CPR = G::CPR;
-    static_assert(NT % 2 == 0 && NT <= 4 && MT <= 2, "a token must fit one wave's accumulators");
+    static_assert(NT <= 4 && MT <= 2, "a token must fit one wave's accumulators");
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
     uint4* rfr = reinterpret_cast<uint4*>(smem);
     uint4* lfr = rfr + G::RFR;
@@ -279,11 +291,13 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
                     uint8_t* qrow = out.q[ci] + tok * ((int64_t)M * N / 2) + (int64_t)(mo * 32 + c) * (N / 2) + h * (NT * 8);
                     const int nvalid = h ? G::V1 : NT * 16;  // valid elements of the run
 #pragma unroll
-                    for (int p = 0; p < G::NPAIR; ++p) {
+                    for (int p = 0; p < G::NPIECE; ++p) {
+                        constexpr int LAST = NT * 2 - 1;  // (indices beyond the run only appear in branches that are never taken)
                         if (nvalid >= p * 32 + 32)
                             *reinterpret_cast<uint4*>(qrow + p * 16) =
-                                make_uint4(pw[4 * p], pw[4 * p + 1], pw[4 * p + 2], pw[4 * p + 3]);
-                        else if ((G::V1 % 32) == 16 && nvalid == p * 32 + 16)
+                                make_uint4(pw[4 * p], pw[4 * p + 1 < LAST ? 4 * p + 1 : LAST], pw[4 * p + 2 < LAST ? 4 * p + 2 : LAST],
+                                           pw[4 * p + 3 < LAST ? 4 * p + 3 : LAST]);
+                        else if (nvalid >= p * 32 + 16)
                             *reinterpret_cast<uint2*>(qrow + p * 16) = make_uint2(pw[4 * p], pw[4 * p + 1]);
                     }
                 }
@@ -321,6 +335,7 @@ int fq_launch_kron_wave(int flags, const f16* x, const void* ws, const f16* diag
     if (MT == MT_ && KS1 == KS1_) return launch_wave<MT_, NT_, KS1_, W_>(x, w, rows, M, out, n_cu, stream);
     FQ_W(2, 4, 8, 7)    // 64x128
     FQ_W(2, 4, 7, 8)    // 64x112
+    FQ_W(2, 3, 5, 12)   // 64x80 (5120 = Qwen2.5-14B/32B hidden, in the reference's benchmark list: kernel_benchmark.py:234-246)
     FQ_W(2, 2, 4, 16)   // 56x64, (64x64 stays with fq_kron64.hip)
     FQ_W(1, 2, 4, 16)   // 32x64
 #undef FQ_W

@@ -250,3 +250,32 @@ def test_general_kernel_grouped_and_post_scale(ops):
     assert np.max(np.abs(y - y0 * ps) / (np.abs(y0 * ps).max(axis=1, keepdims=True))) <= 2e-3
     ref = O.quant_outputs(y, 0.97, 0.9)
     assert np.array_equal(ex.q[0].cpu().numpy(), ref["packed"]) and np.array_equal(ex.scale[0].cpu().numpy(), ref["scale16"])
+
+
+@pytest.mark.parametrize("rows", [1, 2, 11, 12, 13, 500, 3073])
+def test_wave_kernel_64x80_packed_only(ops, rows):
+    """64 x 80 (5120 = Qwen2.5-14B/32B hidden; kernel_benchmark.py:234-246 lists it): the packed-only launch runs the
+    wave-per-token kernel with THREE column tiles (80 = 2.5 x 32: a lane's run is 24 bytes, the h = 1 half holds 32 valid
+    n' of 48) — bit-equal to the launch that also returns the transform, and to the oracle's quantiser on it, on the
+    three quantiser routes, with and without the clamp of the extrema through zero."""
+    gen = torch.Generator().manual_seed(80 + rows)
+    x = torch.randn(rows, 64 * 80, generator=gen).half()
+    x[:, ::41] *= 25
+    if rows > 1:
+        x[1] = x[1].abs() + 1                                   # single-signed token: NO_CLAMP0 must not see the padding columns
+    L = (torch.randn(64, 64, generator=gen) / 8).half().cuda()
+    Rm = (torch.randn(80, 80, generator=gen) / 80 ** 0.5).half().cuda()
+    if rows > 1:
+        L, Rm = L.abs(), Rm.abs()                               # keeps that token's transform positive
+    sigs = [(0.982, 0.982), (0.9, 0.33), (1e-7, 1e-7)]
+    for fl, clamp0 in ((R16, True), (R16 | NC0, False)):
+        both = ops.kron_quant(x.cuda(), L, Rm, sigs, T | P | fl)
+        only = ops.kron_quant(x.cuda(), L, Rm, sigs, P | fl)
+        y = both.y.cpu().numpy().astype(np.float32)
+        for ci, s in enumerate(sigs):
+            ref = O.quant_outputs(y, s[0], s[1], clamp0=clamp0)
+            assert np.array_equal(only.q[ci].cpu().numpy(), ref["packed"]), (rows, fl, s)
+            assert np.array_equal(only.scale[ci].cpu().numpy(), ref["scale16"]), (rows, fl, s)
+            assert torch.equal(only.q[ci], both.q[ci]) and torch.equal(only.scale[ci], both.scale[ci])
+    again = ops.kron_quant(x.cuda(), L, Rm, sigs, P | R16 | NC0)  # a second launch: same bytes (prefetch / counted waits)
+    assert all(torch.equal(a, b) for a, b in zip(again.q, only.q))
