@@ -304,7 +304,16 @@ constexpr float FQ_NEAR = 4e-6f;
 #ifndef FQ_IEEE_INV
 #define FQ_IEEE_INV 0  // 1 (A/B builds): the correctly rounded reciprocal
 #endif
-__device__ __forceinline__ float fq_fast_inv(float scale) { return FQ_IEEE_INV ? 1.0f / scale : __builtin_amdgcn_rcpf(scale); }
+// Issued as asm with one wait state behind it: the consumers are often the first instruction of an inline-asm quantiser
+// block, where the compiler's hazard recogniser does not see the read — gfx950 needs one wait state between a
+// transcendental op and a VALU read of its result (without it the first element of a block occasionally used a stale
+// reciprocal: fq_kv_quant_kernel, 10 of 131072 rows).
+__device__ __forceinline__ float fq_fast_inv(float scale) {
+    if (FQ_IEEE_INV) return 1.0f / scale;
+    float r;
+    asm("v_rcp_f32_e32 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(scale));
+    return r;
+}
 
 
 // Single-instruction 3-input max/min. fmaxf(fmaxf(a,b),c) compiles to v_max3_f32 only after hipcc has inserted
@@ -327,6 +336,25 @@ __device__ __forceinline__ float fq_max3_abs(float a, float b, float c) {  // ma
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Packed fp16 max / min as the bare instruction. __builtin_elementwise_max on data that came straight from memory makes
+// hipcc canonicalise every operand first (a v_pk_max_f16 x, x per loaded dword: +50 % on the extrema of the row
+// quantisers); NaNs are not part of the contract here.
+#ifdef FQ_PK_BUILTIN  // measurement builds: the builtin (with its canonicalising copies)
+__device__ __forceinline__ f16x2 fq_pk_max(f16x2 a, f16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ f16x2 fq_pk_min(f16x2 a, f16x2 b) { return __builtin_elementwise_min(a, b); }
+#else
+__device__ __forceinline__ f16x2 fq_pk_max(f16x2 a, f16x2 b) {
+    f16x2 d;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f16x2 fq_pk_min(f16x2 a, f16x2 b) {
+    f16x2 d;
+    asm("v_pk_min_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+#endif
 
 // Two elements at once: v_pk_mul_f32 / v_pk_add_f32 process a register pair per instruction on gfx950.
 // Returns the clamped integer-valued pair; dmax accumulates max |t - rint(t)| (see fq_qfast).

@@ -68,6 +68,69 @@ __device__ __forceinline__ unsigned kv_q1(f16 x, KvParams p) {
     return (unsigned)(int)r;
 }
 
+// Eight elements (four packed fp16 pairs) -> one dword of unsigned nibbles, the arithmetic of kv_q1 without a division and
+// on packed pairs (the pieces of fq_quant8_h16, fq_common.hpp): the fp16 quotient RN16(a / s) is exact from three fp32 fmas on
+// r = v_rcp_f32(s) (a and s are fp16 values); rint is the packed add of 1536 (ulp 1 in [1024, 2048): half to even), the
+// zero point (an integer <= 15 with lac) is added to that sum exactly, the clamp to [0, 15] is a packed max / min against
+// 1536 / 1551, and the digit is the low nibble of each half. Quotients beyond +-512 leave the exact range of the magic add
+// on the side they are clamped to. Without lac the zero point (-xmin, not an integer) is added BEFORE the division
+// (kv_cache.py:36-43), a packed fp16 add.
+template <bool LAC>
+__device__ __forceinline__ unsigned kv_q8(uint32_t xa, uint32_t xb, uint32_t xc, uint32_t xd, float r, float s, uint32_t zero2) {
+    uint32_t ha, hb, hc, hd;
+    float t0, t1, e0, e1;
+    if (!LAC)
+        asm("v_pk_add_f16 %0, %0, %4\n\tv_pk_add_f16 %1, %1, %4\n\tv_pk_add_f16 %2, %2, %4\n\tv_pk_add_f16 %3, %3, %4"
+            : "+v"(xa), "+v"(xb), "+v"(xc), "+v"(xd)
+            : "v"(zero2));
+#define FQ_KV_PAIR(h, x)                                                                    \
+    "v_fma_mix_f32 %[t0], %[" #x "], %[r], 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"          \
+    "v_fma_mix_f32 %[t1], %[" #x "], %[r], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"          \
+    "v_fma_mix_f32 %[e0], -%[t0], %[s], %[" #x "] op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"     \
+    "v_fma_mix_f32 %[e1], -%[t1], %[s], %[" #x "] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"     \
+    "v_fma_f32 %[t0], %[e0], %[r], %[t0]\n\t"                                               \
+    "v_fma_f32 %[t1], %[e1], %[r], %[t1]\n\t"                                               \
+    "v_cvt_pk_f16_f32 %[" #h "], %[t0], %[t1]\n\t"
+    asm(FQ_KV_PAIR(ha, xa) FQ_KV_PAIR(hb, xb) FQ_KV_PAIR(hc, xc) FQ_KV_PAIR(hd, xd)
+        : [ha] "=&v"(ha), [hb] "=&v"(hb), [hc] "=&v"(hc), [hd] "=&v"(hd), [t0] "=&v"(t0), [t1] "=&v"(t1), [e0] "=&v"(e0),
+          [e1] "=&v"(e1)
+        : [xa] "v"(xa), [xb] "v"(xb), [xc] "v"(xc), [xd] "v"(xd), [r] "v"(r), [s] "v"(s));
+#undef FQ_KV_PAIR
+    const uint32_t magic2 = 0x66006600u;   // (1536.0h, 1536.0h)
+    uint32_t hi2 = 0x660F660Fu;            // (1551.0h, 1551.0h)
+    asm volatile("" : "+v"(hi2));
+    asm("v_pk_add_f16 %[ha], %[ha], %[mg]\n\tv_pk_add_f16 %[hb], %[hb], %[mg]\n\t"
+        "v_pk_add_f16 %[hc], %[hc], %[mg]\n\tv_pk_add_f16 %[hd], %[hd], %[mg]"
+        : [ha] "+v"(ha), [hb] "+v"(hb), [hc] "+v"(hc), [hd] "+v"(hd)
+        : [mg] "s"(magic2));
+    if (LAC)
+        asm("v_pk_add_f16 %0, %0, %4\n\tv_pk_add_f16 %1, %1, %4\n\tv_pk_add_f16 %2, %2, %4\n\tv_pk_add_f16 %3, %3, %4"
+            : "+v"(ha), "+v"(hb), "+v"(hc), "+v"(hd)
+            : "v"(zero2));
+    uint32_t d, p1, p2, u1, u2;
+    const uint32_t sel = 0x06040200u;      // bytes 0 and 2 of the second source, then of the first
+    // lac only: without it (x + zero) / scale lies in [0, 15] by construction (x + zero <= fp16(xmax - xmin) = 15 scale
+    // up to 2^-11, and >= fp16(xmin - xmin) = 0; the 1e-5 floor only makes the quotients smaller)
+    if (LAC)
+        asm("v_pk_max_f16 %[ha], %[ha], %[mg]\n\tv_pk_max_f16 %[hb], %[hb], %[mg]\n\t"
+            "v_pk_max_f16 %[hc], %[hc], %[mg]\n\tv_pk_max_f16 %[hd], %[hd], %[mg]\n\t"
+            "v_pk_min_f16 %[ha], %[ha], %[hi]\n\tv_pk_min_f16 %[hb], %[hb], %[hi]\n\t"
+            "v_pk_min_f16 %[hc], %[hc], %[hi]\n\tv_pk_min_f16 %[hd], %[hd], %[hi]"
+            : [ha] "+v"(ha), [hb] "+v"(hb), [hc] "+v"(hc), [hd] "+v"(hd)
+            : [mg] "s"(magic2), [hi] "v"(hi2));
+    asm("v_perm_b32 %[p1], %[hb], %[ha], %[sel]\n\t"        // low bytes of e0, e1, e2, e3
+        "v_perm_b32 %[p2], %[hd], %[hc], %[sel]\n\t"        // low bytes of e4 .. e7
+        "v_lshrrev_b32_e32 %[u1], 4, %[p1]\n\t"
+        "v_lshrrev_b32_e32 %[u2], 4, %[p2]\n\t"
+        "v_bfi_b32 %[p1], %[m4], %[u1], %[p1]\n\t"          // byte 0 = n0 | n1 << 4, byte 2 = n2 | n3 << 4
+        "v_bfi_b32 %[p2], %[m4], %[u2], %[p2]\n\t"
+        "v_perm_b32 %[d], %[p2], %[p1], %[sel]"
+        : [d] "=v"(d), [p1] "=&v"(p1), [p2] "=&v"(p2), [u1] "=&v"(u1), [u2] "=&v"(u2), [ha] "+v"(ha), [hb] "+v"(hb),
+          [hc] "+v"(hc), [hd] "+v"(hd)
+        : [sel] "s"(sel), [m4] "v"(0x00F000F0u));
+    return d;
+}
+
 // Inputs / outputs of one launch. which = blockIdx.y: 0 = keys (transformed when TRANS), 1 = values (never transformed;
 // present when x[1] != nullptr: K and V of a layer step in one launch). Dense destinations q / param / y, or — data != nullptr —
 // straight into the paged cache (the scatter of fq_kv_append_kernel, fq_kvcache.hip: every request appends `added` tokens
@@ -112,14 +175,29 @@ __global__ __launch_bounds__(256) void fq_kv_quant_kernel(KvIO io, const f16* __
     }
     const f16 cmax = (f16)clip_max, cmin = (f16)clip_min;
     const int64_t n_tiles = (rows + 31) / 32;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + (tid >> 6); tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    // the next tile's row is requested before this one is worked on: a wave's loads overlap its own arithmetic (all waves
+    // of a launch start together, so without this the launch is a load phase followed by an arithmetic phase)
+    const int64_t tstep = (int64_t)gridDim.x * 4;
+    auto fetch = [&](int64_t t, f16x8 (&dst)[KS]) {
+        int64_t r = t * 32 + c;
+        r = r < rows ? r : rows - 1;
+        const uint4* xp = reinterpret_cast<const uint4*>(x + r * HD);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) dst[s] = __builtin_bit_cast(f16x8, xp[2 * s + h]);
+    };
+    f16x8 xn[KS];
+    {
+        const int64_t t0 = (int64_t)blockIdx.x * 4 + (tid >> 6);
+        if (t0 < n_tiles) fetch(t0, xn);
+    }
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + (tid >> 6); tile < n_tiles; tile += tstep) {
         const int64_t row = tile * 32 + c;
         const bool ok = row < rows;
         const int64_t lrow = ok ? row : rows - 1;
-        const uint4* xp = reinterpret_cast<const uint4*>(x + lrow * HD);
         f16x8 xf[KS];  // chunk 2s + h of the row (8 consecutive columns each)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) xf[s] = __builtin_bit_cast(f16x8, xp[2 * s + h]);
+        for (int s = 0; s < KS; ++s) xf[s] = xn[s];
+        if (tile + tstep < n_tiles) fetch(tile + tstep, xn);
 
         f16 v[NTL][16];  // TRANS: columns nt*32 + 16h + r;  else: v[s/2][(s&1)*8 + j] = column (2s + h)*8 + j
         if (TRANS && do_trans) {
@@ -155,14 +233,16 @@ __global__ __launch_bounds__(256) void fq_kv_quant_kernel(KvIO io, const f16* __
                 for (int j = 0; j < 8; ++j) v[s >> 1][(s & 1) * 8 + j] = xf[s][j];
         }
 
-        f16 mx = v[0][0], mn = v[0][0];
+        f16x2 pmx = {v[0][0], v[0][1]}, pmn = pmx;
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                mx = v[nt][r] > mx ? v[nt][r] : mx;
-                mn = v[nt][r] < mn ? v[nt][r] : mn;
+            for (int r = 0; r < 16; r += 2) {
+                const f16x2 pr = {v[nt][r], v[nt][r + 1]};
+                pmx = fq_pk_max(pmx, pr);
+                pmn = fq_pk_min(pmn, pr);
             }
+        f16 mx = pmx[0] > pmx[1] ? pmx[0] : pmx[1], mn = pmn[0] < pmn[1] ? pmn[0] : pmn[1];
         const f16 omx = xchg32(mx, lane), omn = xchg32(mn, lane);
         mx = omx > mx ? omx : mx;
         mn = omn < mn ? omn : mn;
@@ -192,14 +272,15 @@ __global__ __launch_bounds__(256) void fq_kv_quant_kernel(KvIO io, const f16* __
                 pdst[g] = reinterpret_cast<unsigned*>(io.pparam) + e;
             }
         }
+        const float sc = (float)p.scale, rc = fq_fast_inv(sc);
+        const uint32_t zero2 = __builtin_bit_cast(uint32_t, f16x2{p.zero, p.zero});
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
-            unsigned w0 = 0, w1 = 0;
+            uint32_t pr[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                w0 |= kv_q1<LAC>(v[nt][e], p) << (4 * e);
-                w1 |= kv_q1<LAC>(v[nt][8 + e], p) << (4 * e);
-            }
+            for (int j = 0; j < 8; ++j) pr[j] = __builtin_bit_cast(uint32_t, f16x2{v[nt][2 * j], v[nt][2 * j + 1]});
+            const unsigned w0 = kv_q8<LAC>(pr[0], pr[1], pr[2], pr[3], rc, sc, zero2);
+            const unsigned w1 = kv_q8<LAC>(pr[4], pr[5], pr[6], pr[7], rc, sc, zero2);
             if (ok) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -251,7 +332,10 @@ __global__ __launch_bounds__(256) void fq_kv_dequant_kernel(const uint8_t* __res
 template <int HD>
 int launch_kv(const KvIO& io, const f16* T, int64_t rows, bool lac, int n_cu, hipStream_t stream) {
     int64_t blocks = (rows + 127) / 128;
-    if (blocks > (int64_t)n_cu * 2) blocks = (int64_t)n_cu * 2;
+#ifndef FQ_KV_OCC
+#define FQ_KV_OCC 2
+#endif
+    if (blocks > (int64_t)n_cu * FQ_KV_OCC) blocks = (int64_t)n_cu * FQ_KV_OCC;
     if (blocks < 1) blocks = 1;
     const dim3 grid((unsigned)blocks, io.x[1] != nullptr ? 2u : 1u);
 #define FQ_KV(TR, LC) hipLaunchKernelGGL((fq_kv_quant_kernel<HD, TR, LC>), grid, dim3(256), 0, stream, io, T, rows)

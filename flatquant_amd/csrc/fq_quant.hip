@@ -34,8 +34,8 @@ __global__ __launch_bounds__(RQ_THREADS) void fq_rowquant_kernel(const f16* __re
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {  // extrema on packed fp16 pairs (exact: the data is fp16)
                     const f16x2 pr = {v[k][e], v[k][e + 1]};
-                    pmax = __builtin_elementwise_max(pmax, pr);
-                    pmin = __builtin_elementwise_min(pmin, pr);
+                    pmax = fq_pk_max(pmax, pr);
+                    pmin = fq_pk_min(pmin, pr);
                 }
             }
         }
@@ -188,8 +188,8 @@ void fq_rowquant_wave_kernel(const f16* __restrict__ x, int64_t rows, int cols,
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
                         const f16x2 pr = {v[k][e], v[k][e + 1]};
-                        pmax = __builtin_elementwise_max(pmax, pr);
-                        pmin = __builtin_elementwise_min(pmin, pr);
+                        pmax = fq_pk_max(pmax, pr);
+                        pmin = fq_pk_min(pmin, pr);
                     }
                 }
             }
@@ -357,8 +357,8 @@ __global__ __launch_bounds__(256) void fq_rowquant_asym_kernel(const f16* __rest
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
                 const f16x2 pr = {w[e], w[e + 1]};
-                pmax = __builtin_elementwise_max(pmax, pr);
-                pmin = __builtin_elementwise_min(pmin, pr);
+                pmax = fq_pk_max(pmax, pr);
+                pmin = fq_pk_min(pmin, pr);
             }
         };
         if (NV > 0) {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch ONE op of the library N times (for rocprofv3 --pmc / --kernel-trace runs): tools/run_op.py <op> [n]
-  ops: kron112 (112x128 packed), kron128x224, kron64x128, kron64x112, kron32x64g (grouped, 131072 rows), hadq14336
+  ops: kron112 (112x128 packed), kron128x224, kron64x128, kron64x112, kron32x64g (grouped, 131072 rows), hadq14336, kvk / kvv (KV-cache quantisers)
        (Hadamard 28x512 + Quantizer), rowq4096 / rowq14336 (deploy Quantizer), block32, block64"""
 import os
 import sys
@@ -52,6 +52,10 @@ elif op.startswith("rowq"):
     d = int(op[4:])
     xs = [act(16384, d) for _ in range(2)]
     fn = lambda i: ops.rowquant(xs[i % 2], SIG, FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)
+elif op in ("kvk", "kvv"):   # K transform + asymmetric INT4 pack / V pack, 16384 tokens x 8 heads x 128
+    xs = [act(16384 * 8, 128) for _ in range(2)]
+    Tm = mat(128)
+    fn = (lambda i: ops.kv_quant(xs[i % 2], Tm)) if op == "kvk" else (lambda i: ops.kv_quant(xs[i % 2]))
 elif op.startswith("block"):
     H = int(op[5:])
     xs = [act(16384, 128 * H).reshape(16384, 128, H) for _ in range(2)]
