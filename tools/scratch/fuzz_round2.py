@@ -3,7 +3,8 @@
   * general MFMA kernel: every output set bit-exact against the oracle's quantiser on its own transform, random (M, N)
   * packed-only block kernel == the all-output-sets build (C = 32 / 64, both output orders)
   * grouped launches == one launch per group
-  * every quantiser route (magic / clamp / true division) of the specialised kernels vs the oracle; the asymmetric quantiser
+  * every quantiser route (magic / clamp / true division) of the specialised kernels vs the oracle; the asymmetric quantiser;
+    the row quantisers (fp32 / fp16 contracts, fake-quant) and the KV-cache quantisers
 Run it several times in FRESH processes (different seeds): races show on cold launches."""
 import os
 import random
@@ -128,4 +129,44 @@ for it in range(40 if ONLY in ("", "asym") else 0):    # asymmetric fake quantis
         if not np.array_equal(o.fq[ci].cpu().numpy().view(np.uint16), ref.view(np.uint16)):
             bad += 1
             print("asym mismatch", rows, cols, sg, f16)
+for it in range(30 if ONLY in ("", "rowq") else 0):    # row quantisers (fp32 contract, deploy fp16 contract, fake-quant) vs the oracle
+    cols = 8 * random.choice([1, 7, 8, 64, 100, 512, 513, 1376, 1792, 3584])
+    rows = random.choice([1, 5, 64, 1000, 4097])
+    x = (torch.randn(rows, cols, generator=g, device="cuda") * random.choice([0.01, 1.0, 100.0])).half()
+    if it % 2 == 0:
+        x[:, ::29] *= 30
+    sigs = [(random.choice([1.0, 0.98, 0.9, 0.4]), random.choice([1.0, 0.98, 0.9, 0.4])) for _ in range(random.randint(1, 3))]
+    fl, kw = random.choice([(P, {}), (P | NC0, dict(clamp0=False)), (P | Q16, dict(quant_f16=True)), (P | Q16 | 0x400, dict(quant_f16=True, sig_f16=True)),
+                            (F, {}), (F | Q16, dict(quant_f16=True)), (P | F, {})])
+    o = ops.rowquant(x, sigs, fl)
+    for ci, sg in enumerate(sigs):
+        ref = O.rowquant(x.cpu().numpy(), sg[0], sg[1], **kw)
+        ok = True
+        if fl & P:
+            ok = ok and np.array_equal(o.q[ci].cpu().numpy(), ref["packed"]) and np.array_equal(o.scale[ci].cpu().numpy(), ref["scale16"])
+        if fl & F:
+            ok = ok and np.array_equal(o.fq[ci].cpu().numpy(), ref["fq"])   # values: the sign of a zero is not pinned (rule 10)
+        if not ok:
+            bad += 1
+            print("rowquant mismatch", rows, cols, hex(fl), sg)
+for it in range(30 if ONLY in ("", "kv") else 0):    # KV-cache quantisers vs the oracle on the kernel's own transform
+    hd = random.choice([64, 128])
+    rows = random.choice([1, 31, 32, 33, 1000, 40000])
+    x = (torch.randn(rows, hd, generator=g, device="cuda") * random.choice([0.01, 1.0, 50.0])).half()
+    if it % 3 == 0:
+        x[::3] = x[::3].abs()
+    lac = random.random() < 0.5
+    clip = (random.uniform(0.3, 1.0), random.uniform(0.3, 1.0))
+    if random.random() < 0.5:
+        Tm = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half()
+        q, p, y = ops.kv_quant(x, Tm, clip=clip, lac=lac, return_transformed=True)
+    else:
+        q, p = ops.kv_quant(x, clip=clip, lac=lac)
+        y = x
+    pk, sc, z, _ = O.kv_asym_quant(y.cpu().numpy(), clip[0], clip[1], lac=lac)
+    pn = p.cpu().numpy().reshape(-1, 2)
+    if not (np.array_equal(q.cpu().numpy().reshape(-1, hd // 2), pk) and np.array_equal(pn[:, 0].view(np.uint16), sc[:, 0].view(np.uint16))
+            and np.array_equal(pn[:, 1].view(np.uint16), z[:, 0].view(np.uint16))):
+        bad += 1
+        print("kv mismatch", rows, hd, lac, clip)
 print(f"fuzz_round2 seed {seed}: mismatches {bad}")
