@@ -182,6 +182,38 @@ def main():
         del lin
     print(f"  {'seven linears':26s} {gtot:9.1f} us;  FlatQuant layer, fused activation path + linears: {fused_struct + gtot:.1f} us")
 
+    # the same seven linears with the FP6 operand image of the weights (Linear4bit.fp6_image: +0.75 B/param, same bits out)
+    deploy.nn.Linear4bit.fp6_image = True
+    g6 = 0.0
+    for name, k_in, n_out in lins:
+        lin = deploy.nn.Linear4bit(k_in, n_out).to(dev)
+        lin.weight_scales.fill_(0.01)
+        us = timeit(lambda: lin(packed[k_in]), max(a.steps // 5, 5), warm=3)
+        g6 += us
+        del lin
+    deploy.nn.Linear4bit.fp6_image = False
+    print(f"  {'seven linears, FP6 path':26s} {g6:9.1f} us;  FlatQuant layer, fused activation path + linears: {fused_struct + g6:.1f} us")
+
+    # FP16 baseline of the same layer pieces (what benchmarks/layer_benchmark.py:200-274 compares against): the seven
+    # nn.Linear GEMMs in fp16 (rocBLAS / hipBLASLt through torch), two RMSNorms and SiLU.mul in torch eager; the
+    # attention core is in neither number.
+    f16tot = 0.0
+    for name, k_in, n_out in lins:
+        lin = torch.nn.Linear(k_in, n_out, bias=False, device=dev, dtype=torch.float16)
+        xin = xs[0] if k_in == m["hidden"] else xf[0]
+        us = timeit(lambda: lin(xin), max(a.steps // 5, 5), warm=3)
+        f16tot += us
+        print(f"  {'fp16 nn.Linear ' + name:26s} {us:9.1f} us   {2.0 * T * k_in * n_out / us / 1e6:7.0f} TFLOP/s")
+        del lin
+    wn = torch.ones(m["hidden"], device=dev, dtype=torch.float16)
+    n16 = timeit(lambda: torch.nn.functional.rms_norm(nxt(xs), (m["hidden"],), wn, 1e-5), a.steps)
+    sm16 = timeit(lambda: torch.nn.functional.silu(xf[0]) * xf[1], a.steps)
+    f16layer = f16tot + 2 * n16 + sm16
+    print(f"  fp16 layer (seven linears {f16tot:.1f} us + 2 x torch rms_norm {n16:.1f} + SiLU.mul eager {sm16:.1f}): {f16layer:.1f} us; "
+          f"FlatQuant W4A4 layer {fused_struct + gtot:.1f} us -> {f16layer / (fused_struct + gtot):.2f}x "
+          f"(linears alone {f16tot / gtot:.2f}x); with the FP6 operand image {fused_struct + g6:.1f} us -> "
+          f"{f16layer / (fused_struct + g6):.2f}x (linears alone {f16tot / g6:.2f}x)")
+
 
 if __name__ == "__main__":
     main()
