@@ -293,8 +293,8 @@ __global__ __launch_bounds__(256, (PK && CT == 1) ? (RT == 4 ? 3 : 4) : (PK ? 2 
                                 v0[e] = fq_dequant1<FQ_QUANT_F16>((int)qv[e], scale);
                                 v1[e] = fq_dequant1<FQ_QUANT_F16>((int)qv[8 + e], scale);
                             } else {
-                                v0[e] = fq_mul_to_f16(scale, qv[e]);
-                                v1[e] = fq_mul_to_f16(scale, qv[8 + e]);
+                                v0[e] = fq_fake_f16(scale, qv[e]);
+                                v1[e] = fq_fake_f16(scale, qv[8 + e]);
                             }
                         }
                         uint4* fp = reinterpret_cast<uint4*>(frow + i * 16);

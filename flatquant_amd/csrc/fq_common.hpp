@@ -277,6 +277,16 @@ __device__ __forceinline__ f16x8 fq_silu_mul8(f16x8 g, f16x8 u) {
     return a * u;
 }
 
+// The fake-quant value fp16(fp32(scale * q)) of an integer-valued float q. A zero product is made +0.0: the reference
+// rounds with round_ste (quant_utils.py:3-7: (x.round() - x) + x), which never returns -0.0, while v_rndne_f32 of a small
+// negative quotient does (the reference-written fixtures hold no negative zero).
+__device__ __forceinline__ f16 fq_fake_f16(float scale, float q) {
+    float p = scale * q;
+    asm volatile("" : "+v"(p));
+    p = p + 0.0f;
+    return (f16)p;
+}
+
 template <int FLAGS>
 __device__ __forceinline__ f16 fq_dequant1(int q, float scale) {
     // FQ_QUANT_F16: scale is an fp16 value and |q| <= 8, so the fp32 product is exact and one rounding remains

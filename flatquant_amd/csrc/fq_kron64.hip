@@ -585,6 +585,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                                 for (int j = 0; j < 4; ++j) {  // fp16(fp32(scale * q)): two roundings, as torch (fq_mul_to_f16)
                                     f32x2 pr = q[j] * f32x2{scale, scale};
                                     asm volatile("" : "+v"(pr));
+                                    pr = pr + f32x2{0.0f, 0.0f};  // a zero product is +0.0 (fq_fake_f16, fq_common.hpp)
                                     o[2 * j] = (f16)pr.x;
                                     o[2 * j + 1] = (f16)pr.y;
                                 }

@@ -387,8 +387,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
                                 v0[e] = fq_dequant1<FQ_QUANT_F16>((int)qv[e], scale);
                                 v1[e] = fq_dequant1<FQ_QUANT_F16>((int)qv[8 + e], scale);
                             } else {
-                                v0[e] = fq_mul_to_f16(scale, qv[e]);
-                                v1[e] = fq_mul_to_f16(scale, qv[8 + e]);
+                                v0[e] = fq_fake_f16(scale, qv[e]);
+                                v1[e] = fq_fake_f16(scale, qv[8 + e]);
                             }
                         }
                         gen_put_run16(stage + (mo * 32 + c) * N + n0, v0, v1, nvalid);

@@ -463,8 +463,8 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                                 v0[e] = fq_dequant1<FQ_QUANT_F16>((int)q0, scale);
                                 v1[e] = fq_dequant1<FQ_QUANT_F16>((int)q1, scale);
                             } else {
-                                v0[e] = fq_mul_to_f16(scale, q0);
-                                v1[e] = fq_mul_to_f16(scale, q1);
+                                v0[e] = fq_fake_f16(scale, q0);
+                                v1[e] = fq_fake_f16(scale, q1);
                             }
                         }
                         uint4* sp = reinterpret_cast<uint4*>(stage + (mo * 32 + c) * N + n0);

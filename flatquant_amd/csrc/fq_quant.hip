@@ -250,7 +250,7 @@ void fq_rowquant_wave_kernel(const f16* __restrict__ x, int64_t rows, int cols,
                             for (int e = 0; e < 8; ++e) r[e] = fq_qexact((float)v[k][e], scale);
                         }
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = fq_mul_to_f16(scale, r[e]);
+                        for (int e = 0; e < 8; ++e) o[e] = fq_fake_f16(scale, r[e]);
                     }
                     if (ch < nchunks) fp[ch] = __builtin_bit_cast(uint4, o);
                 }

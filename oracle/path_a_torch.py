@@ -3,7 +3,7 @@
 
   kronecker_matmul      flatquant/flat_utils.py:6-17     (reshape, x @ hadR, hadL.T @ x)
   get_scale_zero        flatquant/quant_utils.py:85-107  (amax/amin, clamp to 0, lac sigmoid, m/q_max, repeat)
-  sym_quant_dequant     flatquant/quant_utils.py:19-30   (x/scale, round, clamp, scale*q)
+  sym_quant_dequant     flatquant/quant_utils.py:3-7,19-30   (x/scale, round_ste, clamp, scale*q)
 
 It keeps the reference's operator sequence (including the full-size ``scale.repeat``) so that its timing is
 representative of the reference's PyTorch CPU path; equivalence to the reference is pinned by
@@ -35,7 +35,8 @@ def fake_quant(x, sig, lac=True, bits=4):
     scale = xmax / q_max
     scale[tmp] = 1
     scale = scale.repeat(1, reshaped_x.shape[-1]).reshape(init_shape)
-    q = torch.clamp(torch.round(x / scale), -(q_max + 1), q_max)
+    t = x / scale
+    q = torch.clamp((t.round() - t) + t, -(q_max + 1), q_max)   # round_ste, quant_utils.py:3-7 (never returns -0.0)
     return (scale * q).to(x.dtype)
 
 

@@ -50,3 +50,10 @@ def hadk_matrix(K):
     z = np.load(os.path.join(ROOT, "flatquant_amd", "data", "hadk.npz"))
     bits = np.unpackbits(z[f"had{K}"])[: K * K].reshape(K, K)
     return (bits.astype(np.float32) * 2 - 1).astype(np.float16)
+
+
+def same_bits(a, b):
+    """fp16 arrays equal BIT FOR BIT (np.array_equal would let -0.0 pass for +0.0): fake-quant outputs are compared this
+    way — the reference's round_ste never returns -0.0 and neither may the kernels (rule 10)."""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype == np.float16 and np.array_equal(a.view(np.uint16), b.view(np.uint16))

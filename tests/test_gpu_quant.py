@@ -1,6 +1,7 @@
 """GPU parity for the standalone quantisation kernels (bit-exact: byte/integer results of IEEE arithmetic)."""
 import numpy as np
 import pytest
+from tests.conftest import same_bits
 import torch
 
 from oracle import fq_oracle as O
@@ -38,7 +39,7 @@ def test_rowquant_bit_exact(ops, rows, cols, flags, kw):
             assert np.array_equal(o.q[ci].cpu().numpy(), ref["packed"])
             assert np.array_equal(o.scale[ci].cpu().numpy(), ref["scale16"])
         if flags & F:
-            assert np.array_equal(o.fq[ci].cpu().numpy(), ref["fq"])
+            assert same_bits(o.fq[ci].cpu().numpy(), ref["fq"])
 
 
 def test_rowquant_matches_reference_path_a_quantizer(ops, golden):
@@ -49,9 +50,9 @@ def test_rowquant_matches_reference_path_a_quantizer(ops, golden):
     for ci in range(2):
         s = (float(g["sig"][ci][0]), float(g["sig"][ci][1]))
         o = ops.rowquant(y, [s], F)
-        assert np.array_equal(o.fq[0].cpu().numpy(), g[f"a16_lac{ci}_fq"].reshape(rows, -1))
+        assert same_bits(o.fq[0].cpu().numpy(), g[f"a16_lac{ci}_fq"].reshape(rows, -1))
     o = ops.rowquant(y, [(1.0, 1.0)], F | Q16)
-    assert np.array_equal(o.fq[0].cpu().numpy(), g["a16_nolac_fq"].reshape(rows, -1))
+    assert same_bits(o.fq[0].cpu().numpy(), g["a16_nolac_fq"].reshape(rows, -1))
 
 
 @pytest.mark.parametrize("rows,cols", [(1, 2), (5, 63), (4, 64), (17, 4096), (3, 4097), (64, 14336)])

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import fq_oracle as O
-from tests.conftest import hadk_matrix
+from tests.conftest import hadk_matrix, same_bits
 
 KRON_A_SHAPES = ["64x64", "64x128", "112x128", "128x224", "86x128", "64x112", "32x64", "56x64"]
 
@@ -44,12 +44,12 @@ def test_quant_stage_bit_exact_vs_path_a(golden, shape):
         o = O.quant_outputs(y, g["sig"][ci][0], g["sig"][ci][1])       # lac: fp32 arithmetic
         assert np.array_equal(o["scale"], g[f"a16_lac{ci}_scale"])
         assert np.array_equal(o["q"], g[f"a16_lac{ci}_q"].reshape(rows, -1))
-        assert np.array_equal(o["fq"], g[f"a16_lac{ci}_fq"].reshape(rows, -1))
+        assert same_bits(o["fq"], g[f"a16_lac{ci}_fq"].reshape(rows, -1))
     y = g["a16_lac0_y"].reshape(rows, -1).astype(np.float32)
     o = O.quant_outputs(y, 1.0, 1.0, quant_f16=True)                   # no lac: fp16 arithmetic
     assert np.array_equal(o["scale"], g["a16_nolac_scale"].astype(np.float32))
     assert np.array_equal(o["q"], g["a16_nolac_q"].reshape(rows, -1))
-    assert np.array_equal(o["fq"], g["a16_nolac_fq"].reshape(rows, -1))
+    assert same_bits(o["fq"], g["a16_nolac_fq"].reshape(rows, -1))
 
 
 @pytest.mark.parametrize("shape", KRON_A_SHAPES)
@@ -93,7 +93,7 @@ def test_exact_fixtures_bit_exact_both_paths(golden, shape):
             assert np.array_equal(a["y16"], g[f"a_y{ci}"].reshape(rows, -1))
             assert np.array_equal(a["q"], g[f"a_q{ci}"].reshape(rows, -1))
             assert np.array_equal(a["scale"], g[f"a_scale{ci}"])
-            assert np.array_equal(a["fq"], g[f"a_fq{ci}"].reshape(rows, -1))
+            assert same_bits(a["fq"], g[f"a_fq{ci}"].reshape(rows, -1))
             b = O.kron_quant(g["x"], g["L"], g["R"], s[0], s[1], clamp0=False, left_first=left_first)
             assert np.array_equal(b["packed"], g[f"b_packed{ci}"])
             assert np.array_equal(b["scale16"], g[f"b_scale{ci}"])
@@ -210,7 +210,7 @@ def test_path_a_torch_port_matches_reference_goldens(golden):
     x, L, R = (torch.from_numpy(g[k]) for k in ("x", "L", "R"))
     for ci in range(2):
         fq = path_a_torch.kron_fakequant(x, L, R, (float(g["sig"][ci][0]), float(g["sig"][ci][1])))
-        assert np.array_equal(fq.numpy(), g[f"a16_lac{ci}_fq"])
+        assert same_bits(fq.numpy(), g[f"a16_lac{ci}_fq"])
     y = path_a_torch.kronecker_matmul(x, L, R)
     assert np.array_equal(y.numpy(), g["a16_lac0_y"])
 

@@ -145,7 +145,7 @@ for it in range(30 if ONLY in ("", "rowq") else 0):    # row quantisers (fp32 co
         if fl & P:
             ok = ok and np.array_equal(o.q[ci].cpu().numpy(), ref["packed"]) and np.array_equal(o.scale[ci].cpu().numpy(), ref["scale16"])
         if fl & F:
-            ok = ok and np.array_equal(o.fq[ci].cpu().numpy(), ref["fq"])   # values: the sign of a zero is not pinned (rule 10)
+            ok = ok and np.array_equal(o.fq[ci].cpu().numpy().view(np.uint16), ref["fq"].view(np.uint16))   # bits: no -0.0 (rule 10)
         if not ok:
             bad += 1
             print("rowquant mismatch", rows, cols, hex(fl), sg)
