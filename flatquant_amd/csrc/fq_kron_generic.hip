@@ -540,8 +540,8 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream) {
     if (M < 1 || N < 2 || (N & 1) || M > 256 || N > 256 || (int64_t)M * N > 32768) return -1000;
-    // the specialised kernels below: N in whole K-steps, M <= 128, 16-byte packed tokens; every other pair: fq_kron_general.hip
-    const bool spec = !(N & 15) && M <= 128 && !((M * N / 2) & 15);
+    // the specialised kernels below: N in whole K-steps, M <= 192, 16-byte packed tokens; every other pair: fq_kron_general.hip
+    const bool spec = !(N & 15) && M <= 192 && !((M * N / 2) & 15);
     const bool no_wave = (flags & FQ_NO_WAVE_KERNEL) != 0 || out.post_scale != 0.0f;  // (the wave kernels take no post_scale)
     flags &= ~FQ_NO_WAVE_KERNEL;
     if (flags & FQ_IN_SILU_MUL) {  // fused for the down_proj shapes only; said before any workspace complaint
@@ -612,6 +612,11 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
         FQ_F(2, 4, 8, FQ_GEN_W2, FQ_GEN_OCC2) FQ_F(4, 4, 8, 4, 2) FQ_F(3, 4, 8, 4, 2) FQ_F(4, 7, 14, 8, 1) FQ_F(2, 4, 7, FQ_GEN_W2, FQ_GEN_OCC2)
         FQ_F(4, 8, 16, 8, 1)  // 112 x 256: the Hadamard rotation of 28672 = (28 x 4) x 256 as a Kronecker product
         FQ_F(1, 2, 4, 4, 4) FQ_F(2, 2, 4, 4, FQ_GEN_OCC2) FQ_F(2, 3, 5, 4, FQ_GEN_OCC2)
+        FQ_F(4, 5, 9, 8, 1)   // 128 x 144 = 18432 (DeepSeek-V3 dense ffn), and every 96 < M <= 128 with N = 144
+        FQ_F(3, 4, 7, 4, 2)   // 80 x 112 = 8960 (Qwen2.5-1.5B ffn)
+        FQ_F(1, 2, 3, 4, 4)   // 32 x 48 = 1536 (Qwen2.5-1.5B hidden)
+        FQ_F(5, 6, 12, 8, 1)  // 144 x 192 = 27648 (Qwen2.5-32B ffn)
+        FQ_F(6, 6, 11, 8, 1)  // 168 x 176 = 29568 (Qwen2.5-72B ffn)
 #undef FQ_F
     }
     return fq_launch_kron_general(flags, x, ws, diag, rows, M, N, out, n_cu, stream);

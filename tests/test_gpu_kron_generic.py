@@ -121,7 +121,8 @@ def test_vs_reference_path_b_packed(ops, golden, shape):
 
 
 @pytest.mark.parametrize("M,N,rows", [(64, 128, 0), (64, 128, 1), (112, 128, 3), (128, 224, 5), (32, 64, 1025),
-                                      (64, 80, 7), (128, 128, 9), (96, 96, 4), (128, 256, 3)])
+                                      (64, 80, 7), (128, 128, 9), (96, 96, 4), (128, 256, 3), (128, 144, 5), (80, 112, 3),
+                                      (32, 48, 9), (100, 144, 2)])
 def test_ragged_rows_and_other_factor_pairs(ops, M, N, rows):
     gen = torch.Generator().manual_seed(M * 1000 + N + rows)
     x = torch.randn(rows, M * N, generator=gen).half()

@@ -38,9 +38,9 @@ def main():
     sig = [(0.982, 0.982)]   # sigmoid(4.0): the reference's initial clip factors (no digit outside [-8, 7])
     if os.environ.get("SIG"):  # e.g. SIG=0.9: trained clip factors, the quantiser's clamp route
         sig = [(float(os.environ["SIG"]),) * 2]
-    for d in (4096, 8192, 14336, 28672, 11008, 7168, 2048, 5120, 13824, 18944, 27648, 29568):  # (the last five: Qwen2.5 hidden 5120 = 64x80 and ffn widths)
+    for d in (4096, 8192, 14336, 28672, 11008, 7168, 2048, 18432, 5120, 13824, 8960, 18944, 27648, 29568):  # (18432 = DeepSeek-V3 dense ffn; the last six: Qwen2.5 widths)
         M, N = get_decompose_dim(d)
-        rows = ROWS if d <= 14336 else ROWS // 2
+        rows = ROWS if d <= 14336 else ROWS // 2   # (8192 tokens for the wide ones)
         xs = [torch.randn(rows, d, generator=g, device="cuda", dtype=torch.float16) for _ in range(NB)]
         L = (torch.randn(M, M, generator=g, device="cuda") / M ** 0.5).half()
         R = (torch.randn(N, N, generator=g, device="cuda") / N ** 0.5).half()
