@@ -17,6 +17,7 @@ typedef f16   f16x4  __attribute__((ext_vector_type(4)));
 typedef f16   f16x8  __attribute__((ext_vector_type(8)));
 typedef float f32x4  __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Per-launch output description, passed by value as a kernel argument.

@@ -88,17 +88,24 @@ __global__ void fq_kron_prepare_kernel(const f16* __restrict__ left, const f16* 
 // CTF >= 0: the OUTPUT-SET bits of `flags` are this compile-time constant (packed-only builds of the deploy shapes: the
 // transform / fake-quant / fp16-quantiser branches, their register copies and exec-mask juggling drop out); the
 // run-time bits (FQ_ROUND_Y_F16, FQ_NO_CLAMP0, measurement bits) still come from the argument.
-template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1>
+// NV != 0: the TRUE row length N = NV with N % 16 != 0 (N % 4 == 0; 148 = Qwen2.5-7B's ffn pair 128 x 148), packed-only
+// instantiations: KS1 / NT describe N padded to whole K-steps, the token is staged in 8-byte units (a 16-byte chunk would
+// straddle two rows), the last 16-column run of a row is cut by N (extrema and stores take its valid part) and rows of the
+// packed stage (N / 2 = 74 bytes) are written in 2-byte pieces.
+template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1, int NV = 0>
 __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fast_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
                                                            const f16* __restrict__ diag, int64_t rows, int M, int /*N*/,
                                                            FqQuantOut out, int flags_rt) {
     const int flags = CTF >= 0 ? (CTF | (flags_rt & (FQ_ROUND_Y_F16 | FQ_NO_CLAMP0 | FQ_SIG_F16 | 0xF000))) : flags_rt;
-    constexpr int N = KS1 * 16;                    // N % 16 == 0 is a precondition, so KS1 fixes N
+    constexpr int N = NV ? NV : KS1 * 16;          // N % 16 == 0 unless NV says otherwise, so KS1 fixes N
+    constexpr bool ODD = NV != 0;
+    static_assert(!ODD || (CTF == FQ_OUT_PACKED && !SILU && NV % 4 == 0 && NV > KS1 * 16 - 16 && NV < KS1 * 16), "NV: packed-only");
     constexpr int THREADS = WAVES * 64;
     constexpr int TPW = (NT + WAVES - 1) / WAVES;  // n'-tiles per wave
     constexpr int PITCH = (KS1 * 2) | 1;           // LDS row pitch of the staged token, in 16-byte chunks (odd)
     constexpr int XS_CHUNKS = MT * 32 * PITCH;
-    constexpr int NPF = (MT * 32 * KS1 * 2 + THREADS - 1) / THREADS;  // prefetch registers (uint4) per thread, upper bound
+    constexpr int NPF = ODD ? (MT * 32 * (N / 4) + 2 * THREADS - 1) / (2 * THREADS)    // (ODD: two 8-byte units per register)
+                            : (MT * 32 * KS1 * 2 + THREADS - 1) / THREADS;  // prefetch registers (uint4) per thread, upper bound
     constexpr int LFR = 2 * MT * MT * 64;          // L fragments, uint4 each
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* lfr = reinterpret_cast<uint4*>(smem);
@@ -108,8 +115,10 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
 
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int cpr = N >> 3;      // 16-byte chunks per token row
+    constexpr int cpr = N >> 3;      // 16-byte chunks per token row (ODD: unused, rows are N / 4 8-byte units)
     const int n_chunks = M * cpr;    // chunks per token
+    constexpr int upr = N >> 2;      // ODD: 8-byte units per token row
+    const int n_units = M * upr;
     const int64_t d = (int64_t)M * N;
 
     // ---- once per workgroup ----
@@ -133,13 +142,21 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
         for (int s = 0; s < KS1; ++s) asm volatile("" : "+v"(RF[t][s]));
     // LDS slot of prefetch register k of this thread (chunk q = tid + 256 k of the token)
     u32x4 PF[NPF];
+    u32x2 PF8[ODD ? 2 * NPF : 1];  // ODD: the prefetch registers are 8-byte units (the asm load writes them directly)
     u32x4 PF2[SILU ? NPF : 1];  // FQ_IN_SILU_MUL: x is `gate`, out.in2 is `up`; x_up * silu(x_gate) is formed while staging
     int64_t tok = blockIdx.x;
     // Prefetch loads are inline asm with a hand-placed wait: left to hipcc, an s_waitcnt vmcnt(1) appeared in front of
     // GEMM 1's first MFMA, i.e. the loads that were meant to land during the multiplication were waited for before it.
     // Out-of-range chunks of a ragged last register re-load the token's last chunk (no divergent branch around the asm).
 #define FQ_PF_LOAD(tokidx)                                                                               \
-    {                                                                                                    \
+    if (ODD) {                                                                                           \
+        const uint2* xp_ = reinterpret_cast<const uint2*>(x + (tokidx) * d);                             \
+        _Pragma("unroll") for (int k = 0; k < 2 * NPF; ++k) {                                            \
+            int q_ = pf_q0 + THREADS * k;                                                                \
+            q_ = q_ < n_units ? q_ : n_units - 1;                                                        \
+            asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(PF8[k]) : "v"(xp_ + q_) : "memory"); \
+        }                                                                                                \
+    } else {                                                                                             \
         const u32x4* xp_ = reinterpret_cast<const u32x4*>(x + (tokidx) * d);                             \
         _Pragma("unroll") for (int k = 0; k < NPF; ++k) {                                                \
             int q_ = pf_q0 + THREADS * k;                                                                \
@@ -170,7 +187,10 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
         asm volatile("" : "+v"(q0));
         pf_q0 = q0;
         {   // the prefetch has had a whole token's time to land
-            if (NPF == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(PF[0]));
+            if (ODD) {
+#pragma unroll
+                for (int k = 0; k < 2 * NPF; ++k) asm volatile("s_waitcnt vmcnt(0)" : "+v"(PF8[k]));
+            } else if (NPF == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(PF[0]));
             else if (NPF <= 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(PF[0]), "+v"(PF[1 % NPF]), "+v"(PF[2 % NPF]), "+v"(PF[3 % NPF]));
             else {
 #pragma unroll
@@ -182,8 +202,19 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                 for (int k = 0; k < NPF; ++k) asm volatile("" : "+v"(PF2[k]));  // arrived with the vmcnt(0) above
             }
             const uint4* dp = reinterpret_cast<const uint4*>(diag);
+            if (ODD) {
+                unsigned char* xsb = reinterpret_cast<unsigned char*>(xs);
 #pragma unroll
-            for (int k = 0; k < NPF; ++k) {
+                for (int k = 0; k < 2 * NPF; ++k) {
+                    const int q = q0 + THREADS * k;
+                    if (q < n_units) {
+                        const int row = q / upr, u = q - row * upr;
+                        *reinterpret_cast<uint2*>(xsb + (row * PITCH) * 16 + u * 8) = __builtin_bit_cast(uint2, PF8[k]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < (ODD ? 0 : NPF); ++k) {
                 const int q = q0 + THREADS * k;
                 if (q < n_chunks) {
                     uint4 v = __builtin_bit_cast(uint4, PF[k]);
@@ -309,14 +340,24 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
 #pragma unroll
         for (int t = 0; t < (H16 ? 0 : TPW); ++t) {
             const int nt = wave + WAVES * t;
-            const bool col_ok = nt < NT && (h * NT * 16 + nt * 16) < N;  // the lane's 16 columns of this tile
+            const int nval = N - (h * NT * 16 + nt * 16);                // valid columns of the lane's run of this tile
+            const bool col_ok = nt < NT && nval > 0;                     // the lane's 16 columns of this tile
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo) {
                 if (col_ok && (mo * 32 + c) < M) {
+                    if (!ODD || nval >= 16) {
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        vmax = fq_max3(vmax, Y[t][mo][r], Y[t][mo][r + 1]);
-                        vmin = fq_min3(vmin, Y[t][mo][r], Y[t][mo][r + 1]);
+                        for (int r = 0; r < 16; r += 2) {
+                            vmax = fq_max3(vmax, Y[t][mo][r], Y[t][mo][r + 1]);
+                            vmin = fq_min3(vmin, Y[t][mo][r], Y[t][mo][r + 1]);
+                        }
+                    } else {  // the run N cuts (N % 4 == 0: whole pairs)
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2)
+                            if (r < nval) {
+                                vmax = fq_max3(vmax, Y[t][mo][r], Y[t][mo][r + 1]);
+                                vmin = fq_min3(vmin, Y[t][mo][r], Y[t][mo][r + 1]);
+                            }
                     }
                 }
             }
@@ -401,6 +442,17 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                         if (d1)
                             pk.y = fq_pack8(fq_qexact(yv[8], scale), fq_qexact(yv[9], scale), fq_qexact(yv[10], scale), fq_qexact(yv[11], scale),
                                             fq_qexact(yv[12], scale), fq_qexact(yv[13], scale), fq_qexact(yv[14], scale), fq_qexact(yv[15], scale));
+                        if (ODD) {  // rows of N / 2 bytes are only 2-byte aligned: four 2-byte pieces (4 digits each), cut by N
+                            if (ok) {
+                                unsigned short* op = reinterpret_cast<unsigned short*>(obuf + (mo * 32 + c) * (N >> 1) + (n0 >> 1));
+                                const int nval = N - n0;
+                                op[0] = (unsigned short)pk.x;
+                                if (nval > 4) op[1] = (unsigned short)(pk.x >> 16);
+                                if (nval > 8) op[2] = (unsigned short)pk.y;
+                                if (nval > 12) op[3] = (unsigned short)(pk.y >> 16);
+                            }
+                            continue;
+                        }
                         if (ok) *reinterpret_cast<uint2*>(obuf + (mo * 32 + c) * (N >> 1) + (n0 >> 1)) = pk;
                         continue;
                     }
@@ -477,7 +529,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
             if (flags & FQ_OUT_PACKED) {
                 if (tid == 0) out.scale[ci][tok] = (f16)scale;
                 uint4* qp4 = reinterpret_cast<uint4*>(out.q[ci] + tok * (d >> 1));
-                for (int q = tid; q < (n_chunks >> 2); q += THREADS) qp4[q] = reinterpret_cast<const uint4*>(obuf)[q];
+                for (int q = tid; q < (M * N) / 32; q += THREADS) qp4[q] = reinterpret_cast<const uint4*>(obuf)[q];
             }
             if (flags & FQ_OUT_FAKEQUANT) {
                 uint4* fp = reinterpret_cast<uint4*>(out.fq[ci] + tok * d);
@@ -494,13 +546,13 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
     }
 }
 
-template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1>
+template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1, int NV = 0>
 int launch_fast(int flags, const f16* x, const uint4* ws, const f16* diag, int64_t rows, int M, int N,
                 const FqQuantOut& out, int n_cu, hipStream_t stream) {
     constexpr int PITCH = (KS1 * 2) | 1;
     const size_t lds = (size_t)2 * MT * MT * 1024 + (size_t)MT * 32 * PITCH * 16 + (((size_t)M * N / 2 + 15) & ~(size_t)15) + 128;
     if (lds > 160 * 1024) return -1000;
-    auto kern = fq_kron_fast_kernel<MT, NT, KS1, WAVES, OCC, SILU, CTF>;
+    auto kern = fq_kron_fast_kernel<MT, NT, KS1, WAVES, OCC, SILU, CTF, NV>;
     FQ_RAISE_LDS_CAP(kern, 160 * 1024);
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > OCC) per_cu = OCC;
@@ -592,6 +644,11 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
 #ifdef FQ_MEASURE
     if (const char* dbg = getenv("FQ_KRON_DBG")) flags |= atoi(dbg) & 0x7000;  // measurement: ablation bits of the fast kernel
 #endif
+    // N % 16 != 0 in the workgroup-per-token kernel: the packed-only launch of 96 < M <= 128, N = 148 (18944 = 128 x 148,
+    // Qwen2.5-7B ffn); its other output sets, diag and every other such pair: fq_kron_general.hip
+    if (N == 148 && MT == 4 && (flags & FQ_CT_MASK) == FQ_OUT_PACKED && diag == nullptr && !((M * N / 2) & 15) &&
+        !fq_measure_env("FQ_KRON_NO_CTF"))
+        return launch_fast<4, 5, 10, 8, 1, false, FQ_OUT_PACKED, 148>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
     if (spec) {
 #define FQ_F(MT_, NT_, KS1_, W_, OCC_)                                                                   \
     if (MT == MT_ && NT == NT_ && g.KS1 == KS1_) {                                                       \

@@ -281,3 +281,31 @@ def test_wave_kernel_64x80_packed_only(ops, rows):
             assert torch.equal(only.q[ci], both.q[ci]) and torch.equal(only.scale[ci], both.scale[ci])
     again = ops.kron_quant(x.cuda(), L, Rm, sigs, P | R16 | NC0)  # a second launch: same bytes (prefetch / counted waits)
     assert all(torch.equal(a, b) for a, b in zip(again.q, only.q))
+
+
+@pytest.mark.parametrize("M", [104, 120, 128])
+@pytest.mark.parametrize("rows", [1, 3, 300, 1025])
+def test_workgroup_kernel_n148_packed_only(ops, M, rows):
+    """N = 148 (18944 = 128 x 148, Qwen2.5-7B ffn; N % 16 != 0): the packed-only launch runs the workgroup-per-token
+    kernel (8-byte staging units, a last 16-column run cut to 4 columns, 74-byte packed rows) — bit-equal to the launch
+    that also returns the transform (general kernel) and to the oracle's quantiser on that transform, on the three
+    quantiser routes, with and without the clamp of the extrema through zero (the cut run must not leak its padding)."""
+    gen = torch.Generator().manual_seed(148 + M + rows)
+    x = torch.randn(rows, M * 148, generator=gen).half()
+    x[:, ::43] *= 25
+    L = (torch.randn(M, M, generator=gen) / M ** 0.5).half().cuda()
+    Rm = (torch.randn(148, 148, generator=gen) / 148 ** 0.5).half().cuda()
+    if rows > 1:
+        x[1] = x[1].abs() + 1                                   # single-signed token
+        L, Rm = L.abs(), Rm.abs()
+    sigs = [(0.982, 0.982), (0.9, 0.33), (1e-7, 1e-7)]
+    for fl, clamp0 in ((R16, True), (R16 | NC0, False)):
+        both = ops.kron_quant(x.cuda(), L, Rm, sigs, T | P | fl)
+        only = ops.kron_quant(x.cuda(), L, Rm, sigs, P | fl)
+        y = both.y.cpu().numpy().astype(np.float32)
+        for ci, s in enumerate(sigs):
+            ref = O.quant_outputs(y, s[0], s[1], clamp0=clamp0)
+            assert np.array_equal(only.q[ci].cpu().numpy(), ref["packed"]), (M, rows, fl, s)
+            assert np.array_equal(only.scale[ci].cpu().numpy(), ref["scale16"]), (M, rows, fl, s)
+    again = ops.kron_quant(x.cuda(), L, Rm, sigs, P | R16 | NC0)
+    assert all(torch.equal(a, b) for a, b in zip(again.q, only.q))

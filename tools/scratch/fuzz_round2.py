@@ -99,7 +99,8 @@ for it in range(15 if ONLY in ("", "grouped") else 0):    # grouped launches (wa
             bad += 1
             print("grouped mismatch", M, N, gi, a0, a1)
 for it in range(40 if ONLY in ("", "clamp") else 0):    # quantiser routes of the wave / 64x64 / workgroup kernels vs the oracle on the kernel's own transform
-    M, N = random.choice([(64, 64), (64, 128), (64, 112), (64, 80), (32, 64), (56, 64), (112, 128), (128, 224), (86, 128)])
+    M, N = random.choice([(64, 64), (64, 128), (64, 112), (64, 80), (32, 64), (56, 64), (112, 128), (128, 224), (86, 128),
+                          (128, 148), (120, 148), (144, 192), (168, 176), (128, 144), (80, 112), (32, 48)])
     rows = random.choice([1, 3, 64, 257, 1500])
     x = (torch.randn(rows, M * N, generator=g, device="cuda") * random.choice([0.01, 1.0, 30.0])).half()
     if it % 2 == 0:
