@@ -1,9 +1,10 @@
 // fq_kron_generic.hip — fused Kronecker transform + per-token INT4 quantisation, ONE WORKGROUP PER TOKEN, for the factor
 // pairs deployed models use whose token does not fit a wave or whose output set is not packed-only: d = 14336 (112x128),
-// 28672 (128x224), 11008 (86x128), 8192 (64x128), 7168 (64x112), 2048 (32x64), 3584 (56x64), 5120 (64x80)
+// 28672 (128x224), 11008 (86x128), 8192 (64x128), 7168 (64x112), 2048 (32x64), 3584 (56x64), 5120 (64x80), 18432 (128x144),
+// 27648 (144x192), 29568 (168x176), 8960 (80x112), and — packed-only, true row length as a template parameter — 18944 (128x148)
 // (function_utils.py:11-21 factor pairs); plus the fragment-image builder (fq_kron_prepare_kernel) and the launcher that
 // picks a kernel for ANY pair (fq_launch_kron_generic): wave-per-token (fq_kron_wave.hip), three token groups per CU
-// (fq_kron_trio.hip), this file's kernel, and fq_kron_general.hip for every other pair (run-time N, N % 16 != 0, M > 128).
+// (fq_kron_trio.hip), this file's kernel, and fq_kron_general.hip for every other pair (run-time N, N % 16 != 0, M > 192).
 //
 // Same mathematics and fragment chaining as fq_kron64.hip (U = X.R rounded to fp16, Y^T = U^T.L, the C
 // fragment of GEMM 1 is the A fragment of GEMM 2), but a token no longer fits one wave's registers, so:
