@@ -162,21 +162,30 @@ __global__ __launch_bounds__(256) void fq_sym_dequant_kernel(const int32_t* __re
 // lane, all loads issued back to back), max/min by a register wave all-reduce, no LDS and no workgroup barrier.
 // (The one-workgroup-per-row kernel above keeps only 2 loads per lane in flight and pays two barriers per row:
 // 55 us for 16384 x 4096, where moving the same bytes takes 28 us.) Rows are handed out grid-stride per wave.
-template <int FLAGS, int NCH>
+// MULTI (short rows, cols <= 256: heads, 128-element groups): a row occupies 2^lg lanes, 64 >> lg rows per wave — one row per
+// wave would leave 3 of 4 lanes idle at cols = 128 (measured 0.6-1.1 TB/s against 3.5-3.8 with the lanes filled); the
+// extrema are reduced by xor butterflies inside the lane group and every row carries its own scale through the same epilogue.
+template <int FLAGS, int NCH, bool MULTI = false>
 // (occupancy bound for the packed fp16-quantiser builds only — the deploy Quantizer: their epilogue is 5 VALU per element on
 //  packed pairs and fits; the fp32-quantiser builds keep the compiler's own choice)
 __global__ __launch_bounds__(256, ((FLAGS & (FQ_QUANT_F16 | FQ_OUT_FAKEQUANT)) == FQ_QUANT_F16) ? (NCH > 24 ? 2 : NCH > 16 ? 3 : 4) : 1)
 void fq_rowquant_wave_kernel(const f16* __restrict__ x, int64_t rows, int cols,
-                                                               FqQuantOut out) {
-    const int lane = threadIdx.x & 63;
+                                                               FqQuantOut out, int lg) {
+    static_assert(!MULTI || NCH == 1, "short rows: one chunk per lane");
+    const int wl = threadIdx.x & 63;
+    const int lpr = MULTI ? (1 << lg) : 64, rpw = MULTI ? (64 >> lg) : 1;
+    const int lane = MULTI ? (wl & (lpr - 1)) : wl;            // the lane's position inside its row
     const int nchunks = cols >> 3;
-    const int64_t nw = (int64_t)gridDim.x * 4;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nw) {
+    const int64_t nw = (int64_t)gridDim.x * 4 * rpw;
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw; row0 < rows; row0 += nw) {
+        const int64_t rown = row0 + (MULTI ? (wl >> lg) : 0);
+        const bool live = !MULTI || rown < rows;
+        const int64_t row = live ? rown : rows - 1;              // (idle lane groups of the last wave re-read the last row, store nothing)
         const u32x4* xp = reinterpret_cast<const u32x4*>(x + row * (int64_t)cols);
         f16x8 v[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            const int ch = lane + k * 64;
+            const int ch = lane + k * lpr;
             v[k] = (ch < nchunks) ? __builtin_bit_cast(f16x8, __builtin_nontemporal_load(xp + ch)) : f16x8{0};
         }
         float vmax = -INFINITY, vmin = INFINITY;
@@ -184,7 +193,7 @@ void fq_rowquant_wave_kernel(const f16* __restrict__ x, int64_t rows, int cols,
             f16x2 pmax = {(f16)-INFINITY, (f16)-INFINITY}, pmin = {(f16)INFINITY, (f16)INFINITY};
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
-                if (lane + k * 64 < nchunks) {
+                if (lane + k * lpr < nchunks) {
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
                         const f16x2 pr = {v[k][e], v[k][e + 1]};
@@ -196,18 +205,25 @@ void fq_rowquant_wave_kernel(const f16* __restrict__ x, int64_t rows, int cols,
             vmax = fmaxf((float)pmax[0], (float)pmax[1]);
             vmin = fminf((float)pmin[0], (float)pmin[1]);
         }
-        vmax = fq_wave_max(vmax);
-        vmin = fq_wave_min(vmin);
+        if (MULTI) {
+            for (int m = 1; m < lpr; m <<= 1) {
+                vmax = fmaxf(vmax, __shfl_xor(vmax, m));
+                vmin = fminf(vmin, __shfl_xor(vmin, m));
+            }
+        } else {
+            vmax = fq_wave_max(vmax);
+            vmin = fq_wave_min(vmin);
+        }
         for (int ci = 0; ci < out.n_clips; ++ci) {
             const float scale = fq_token_scale<FLAGS>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
             const float inv = fq_fast_inv(scale);
             const bool h16_clamp = fq_h16_needs_clamp(vmax, vmin, inv);
             if (FLAGS & FQ_OUT_PACKED) {
-                if (lane == 0) out.scale[ci][row] = (f16)scale;
+                if (lane == 0 && live) out.scale[ci][row] = (f16)scale;
                 uint32_t* qp = reinterpret_cast<uint32_t*>(out.q[ci] + row * (int64_t)(cols >> 1));
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
-                    const int ch = lane + k * 64;
+                    const int ch = lane + k * lpr;
                     uint32_t d;
                     if (FLAGS & FQ_QUANT_F16) {
                         const u32x4 xv = __builtin_bit_cast(u32x4, v[k]);   // packed pairs, exact fp16 quotient (fq_quant8_h16)
@@ -227,14 +243,14 @@ void fq_rowquant_wave_kernel(const f16* __restrict__ x, int64_t rows, int cols,
                                          fq_qexact((float)v[k][4], scale), fq_qexact((float)v[k][5], scale),
                                          fq_qexact((float)v[k][6], scale), fq_qexact((float)v[k][7], scale));
                     }
-                    if (ch < nchunks) qp[ch] = d;
+                    if (ch < nchunks && live) qp[ch] = d;
                 }
             }
             if (FLAGS & FQ_OUT_FAKEQUANT) {
                 uint4* fp = reinterpret_cast<uint4*>(out.fq[ci] + row * (int64_t)cols);
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
-                    const int ch = lane + k * 64;
+                    const int ch = lane + k * lpr;
                     f16x8 o;
                     if (FLAGS & FQ_QUANT_F16) {
 #pragma unroll
@@ -252,7 +268,7 @@ void fq_rowquant_wave_kernel(const f16* __restrict__ x, int64_t rows, int cols,
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = fq_fake_f16(scale, r[e]);
                     }
-                    if (ch < nchunks) fp[ch] = __builtin_bit_cast(uint4, o);
+                    if (ch < nchunks && live) fp[ch] = __builtin_bit_cast(uint4, o);
                 }
             }
         }
@@ -296,6 +312,16 @@ __global__ __launch_bounds__(256) void fq_rmsnorm_kernel(const f16* __restrict__
 template <int FLAGS>
 int launch_rowquant(const f16* x, int64_t rows, int cols, const FqQuantOut& out, int n_cu,
                     hipStream_t stream) {
+    if ((cols >> 3) <= 32) {   // short rows: several rows per wave (2^lg lanes each)
+        int lg = 0;
+        while ((1 << lg) < (cols >> 3)) ++lg;
+        const int rpw = 64 >> lg;
+        int64_t wb = ((rows + rpw - 1) / rpw + 3) / 4;
+        if (wb > (int64_t)n_cu * 8) wb = (int64_t)n_cu * 8;
+        if (wb < 1) wb = 1;
+        hipLaunchKernelGGL((fq_rowquant_wave_kernel<FLAGS, 1, true>), dim3((unsigned)wb), dim3(256), 0, stream, x, rows, cols, out, lg);
+        return (int)hipGetLastError();
+    }
     {   // wave-per-row fast path: the row fits one wave's registers (up to 32 chunks of 16 bytes per lane)
         const int nchw = ((cols >> 3) + 63) / 64;
         int64_t wb = (rows + 3) / 4;
@@ -304,7 +330,7 @@ int launch_rowquant(const f16* x, int64_t rows, int cols, const FqQuantOut& out,
 #define FQ_RW(N)                                                                                                  \
     if (nchw <= (N)) {                                                                                            \
         hipLaunchKernelGGL((fq_rowquant_wave_kernel<FLAGS, (N)>), dim3((unsigned)wb), dim3(256), 0, stream, x, rows, \
-                           cols, out);                                                                            \
+                           cols, out, 6);                                                                            \
         return (int)hipGetLastError();                                                                            \
     }
         FQ_RW(4) FQ_RW(8) FQ_RW(16) FQ_RW(24)  // beyond 24 chunks per lane the one-workgroup-per-row kernel measured faster
