@@ -430,8 +430,33 @@ __global__ __launch_bounds__(256) void fq_rowquant_asym_kernel(const f16* __rest
                 zero = __builtin_rintf(-xmin / scale);
             }
             uint4* op = reinterpret_cast<uint4*>(out.fq[ci] + (live ? row : 0) * (int64_t)cols);
+            // fp32 route without a division (the two-sided magic-number test of fq_quant8_two, fq_common.hpp): with
+            // ilo / ihi = v_rcp_f32(scale) (1 -+ 2^-21), u = fma(x, ilo, 1.5 * 2^23) and v = fma(x, ihi, ...) bracket
+            // rint(fl(x / scale)); u == v on all eight elements (of every lane at work) proves u, else the vector is redone
+            // with the division. u - (1.5 * 2^23 - zero) = rint(x / scale) + zero exactly (integers below 2^24).
+            const float inv = fq_fast_inv(scale), ilo = fq_inv_lo(inv), ihi = fq_inv_hi(inv), cz = FQ_MAGIC - zero;
+            const bool fast_ok = !F16A && fmaxf(vmax, -vmin) * inv < 2097152.0f;
             auto emit = [&](const f16x8& w, int i) {
                 f16x8 o;
+                if (fast_ok) {
+                    float u[8];
+                    bool differ = false;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xf = (float)w[e];
+                        u[e] = __builtin_fmaf(xf, ilo, FQ_MAGIC);
+                        differ |= u[e] != __builtin_fmaf(xf, ihi, FQ_MAGIC);
+                    }
+                    if (!__any(differ)) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float q = __builtin_amdgcn_fmed3f(u[e] - cz, 0.0f, 15.0f);
+                            o[e] = fq_mul_to_f16(scale, q - zero);
+                        }
+                        op[i] = __builtin_bit_cast(uint4, o);
+                        return;
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float t = (float)w[e] / scale;            // correctly rounded fp32 division
