@@ -310,6 +310,225 @@ __global__ __launch_bounds__(256, (PK && CT == 1) ? (RT == 4 ? 3 : 4) : (PK ? 2 
 #undef FQ_TILE
 #undef FQ_BLOCK_PF
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Any head count, either element type (round 3). The reference kernel masks arbitrary sizes
+// (block_matmul.py:56-66: `% M`, `% N`, masked loads / stores) and its callers meet num_attention_heads = 28 (Qwen2.5-7B),
+// 40 (Llama-2-13B, Qwen2.5-14B / 32B), 12 / 14 / 16 (the small Qwen2.5), and the path-A op is dtype-generic
+// ({SVD,Inv}SingleTransMatrix.forward, trans_utils.py:21-25; bf16 on Llama-3 / Qwen: model_utils.py:20). This kernel takes
+// every even C <= 64 with R in {32, 64, 96, 128} for T in {f16, bf16}: the K dimension and the output columns are padded to
+// whole 32-column tiles with ZEROS in the P fragments, the A fragments are loaded with the widest access the row length
+// allows and zero beyond the row (a row of 28 heads is 56 bytes: dword pieces), padding columns are excluded from the
+// extrema and the stores, and a lane's run of outputs is written with the widest store its address allows (packed rows of
+// 14 bytes exist). One wave per token like the tuned kernel above, which keeps C in {32, 64} on fp16.
+// ---------------------------------------------------------------------------------------------------------------------
+// first `nbytes` (<= 16) bytes of v to dst, any alignment
+__device__ __forceinline__ void blk_store_bytes(unsigned char* dst, u32x4 v, int nbytes) {
+    if (nbytes <= 0) return;
+    const unsigned a = (unsigned)(size_t)dst;
+    if (nbytes == 16 && !(a & 15)) {
+        *reinterpret_cast<u32x4*>(dst) = v;
+    } else if (!((a | nbytes) & 3)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (4 * k < nbytes) reinterpret_cast<uint32_t*>(dst)[k] = v[k];
+    } else if (!((a | nbytes) & 1)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (2 * k < nbytes) reinterpret_cast<unsigned short*>(dst)[k] = (unsigned short)(v[k >> 1] >> (16 * (k & 1)));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (k < nbytes) dst[k] = (unsigned char)(v[k >> 2] >> (8 * (k & 3)));
+    }
+}
+
+template <int RT, int CT, bool NAT, typename T>
+__global__ __launch_bounds__(256) void fq_block_any_kernel(const T* __restrict__ x, const T* __restrict__ P, int64_t rows, int Cv,
+                                                           FqQuantOut out, int flags) {
+    typedef typename FqVec<T>::x8 X8;
+    constexpr int R = RT * 32, KS = CT * 2;
+    constexpr int OC = NAT ? RT : CT, IC = NAT ? CT : RT;   // outer / inner tile counts of a lane's output runs
+    const int D = R * Cv, LEN = NAT ? Cv : R;               // elements per token, length of a major row of the output
+    __shared__ __attribute__((aligned(16))) uint4 pfrag[KS * CT * 64];  // [(s*CT + ct)][lane], zero outside [Cv, Cv]
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    for (int item = tid; item < KS * CT * 64; item += 256) {
+        const int f = item >> 6, ln = item & 63, fh = ln >> 5, fc = ln & 31;
+        const int s = f / CT, ct = f - s * CT;
+        const int col = NAT ? rmap(CT, ct, fc) : ct * 32 + fc;
+        X8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = s * 16 + fh * 8 + j;
+            v[j] = (k < Cv && col < Cv) ? P[k * Cv + col] : (T)0.0f;
+        }
+        pfrag[item] = __builtin_bit_cast(uint4, v);
+    }
+    __syncthreads();
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (tid >> 6), n_waves = (int64_t)gridDim.x * 4;
+    const bool wide = !(Cv & 7);   // rows are whole 16-byte chunks
+    // valid leading elements of tile (o, i) of this lane's run: transposed order masks whole columns c' = 32 o + c, natural
+    // order cuts the run of columns IC*16*h + 16 i + reg at Cv
+#define FQ_NVAL(o, i) (NAT ? min(16, max(0, Cv - (IC * 16 * h + 16 * (i)))) : (((o) * 32 + c) < Cv ? 16 : 0))
+#define FQ_TILE(o, i) (NAT ? Y[o][i] : Y[i][o])
+    for (int64_t tok = wave_id; tok < rows; tok += n_waves) {
+        int foff = lane;
+        asm volatile("" : "+v"(foff));  // keep the fragment reads inside the loop (see fq_kron64.hip)
+        const uint4* myp = pfrag + foff;
+        f32x16 Y[RT][CT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int row = NAT ? rt * 32 + c : rmap(RT, rt, c);
+            const T* xr = x + tok * D + (int64_t)row * Cv;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) Y[rt][ct] = f32x16{0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (16 * s >= Cv) continue;              // (wave-uniform) a K-step of nothing but padding
+                const int k0 = 16 * s + 8 * h, nv = Cv - k0;   // this lane's 8 k-slots, valid ones (even; may be <= 0)
+                u32x4 w = {0u, 0u, 0u, 0u};
+                if (wide) {
+                    if (nv >= 8) w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xr + k0));
+                } else {
+                    const uint32_t* xp = reinterpret_cast<const uint32_t*>(xr + k0);   // Cv even: rows are dword-aligned
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (2 * k < nv) w[k] = xp[k];
+                }
+                const X8 a = __builtin_bit_cast(X8, w);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const X8 pf = __builtin_bit_cast(X8, myp[(s * CT + ct) * 64]);
+                    Y[rt][ct] = NAT ? fq_mfma32<T>(pf, a, Y[rt][ct]) : fq_mfma32<T>(a, pf, Y[rt][ct]);
+                }
+            }
+        }
+        if (flags & FQ_ROUND_Y_F16) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Y[rt][ct][r] = (float)(T)Y[rt][ct][r];
+        }
+        if (flags & FQ_OUT_TRANSFORM) {
+#pragma unroll
+            for (int o = 0; o < OC; ++o) {
+                unsigned char* yp = reinterpret_cast<unsigned char*>(reinterpret_cast<T*>(out.y) + tok * D + (int64_t)(o * 32 + c) * LEN + h * (IC * 16));
+#pragma unroll
+                for (int i = 0; i < IC; ++i) {
+                    const int nval = FQ_NVAL(o, i);
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        X8 v;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (T)FQ_TILE(o, i)[w * 8 + e];
+                        blk_store_bytes(yp + (i * 16 + w * 8) * 2, __builtin_bit_cast(u32x4, v), 2 * min(8, nval - 8 * w));
+                    }
+                }
+            }
+        }
+        if (!(flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT))) continue;
+
+        float vmax = -INFINITY, vmin = INFINITY;
+#pragma unroll
+        for (int o = 0; o < OC; ++o)
+#pragma unroll
+            for (int i = 0; i < IC; ++i) {
+                const int nval = FQ_NVAL(o, i);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (r < nval) {
+                        vmax = fmaxf(vmax, FQ_TILE(o, i)[r]);
+                        vmin = fminf(vmin, FQ_TILE(o, i)[r]);
+                    }
+            }
+        vmax = fq_wave_max(vmax);
+        vmin = fq_wave_min(vmin);
+
+        for (int ci = 0; ci < out.n_clips; ++ci) {
+            float scale;
+            if (flags & FQ_QUANT_F16) scale = fq_token_scale<FQ_QUANT_F16, T>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
+            else scale = fq_token_scale<0, T>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], flags);
+            const float inv = fq_fast_inv(scale);
+            const bool magic = !(flags & FQ_QUANT_F16) && fq_magic_ok(vmax, vmin, inv);
+            if ((flags & FQ_OUT_PACKED) && lane == 0) reinterpret_cast<T*>(out.scale[ci])[tok] = (T)scale;
+#pragma unroll
+            for (int o = 0; o < OC; ++o) {
+                unsigned char* qrow = (flags & FQ_OUT_PACKED)
+                                          ? out.q[ci] + tok * (D / 2) + (int64_t)(o * 32 + c) * (LEN / 2) + h * (IC * 8)
+                                          : nullptr;
+                unsigned char* frow = (flags & FQ_OUT_FAKEQUANT)
+                                          ? reinterpret_cast<unsigned char*>(reinterpret_cast<T*>(out.fq[ci]) + tok * D + (int64_t)(o * 32 + c) * LEN + h * (IC * 16))
+                                          : nullptr;
+#pragma unroll
+                for (int i = 0; i < IC; ++i) {
+                    const int nval = FQ_NVAL(o, i);
+                    float qv[16];
+                    if (flags & FQ_QUANT_F16) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) qv[r] = (float)fq_quant1<FQ_QUANT_F16, T>(FQ_TILE(o, i)[r], scale);
+                    } else {
+                        float dmax = 1.0f;  // !magic: quotients too large for the fast rounding -> the true division
+                        if (magic) {
+                            dmax = 0.0f;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) qv[r] = fq_qfast(r < nval ? FQ_TILE(o, i)[r] : 0.0f, inv, dmax);
+                        }
+                        if (fq_wave_needs_exact(dmax)) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) qv[r] = fq_qexact(FQ_TILE(o, i)[r], scale);
+                        }
+                    }
+                    if (flags & FQ_OUT_PACKED) {
+                        const u32x4 pk = {fq_pack8(qv[0], qv[1], qv[2], qv[3], qv[4], qv[5], qv[6], qv[7]),
+                                          fq_pack8(qv[8], qv[9], qv[10], qv[11], qv[12], qv[13], qv[14], qv[15]), 0u, 0u};
+                        blk_store_bytes(qrow + i * 8, pk, nval >> 1);
+                    }
+                    if (flags & FQ_OUT_FAKEQUANT) {
+                        X8 v0, v1;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (flags & FQ_QUANT_F16) {
+                                v0[e] = fq_dequant1<FQ_QUANT_F16, T>((int)qv[e], scale);
+                                v1[e] = fq_dequant1<FQ_QUANT_F16, T>((int)qv[8 + e], scale);
+                            } else {
+                                v0[e] = fq_fake<T>(scale, qv[e]);
+                                v1[e] = fq_fake<T>(scale, qv[8 + e]);
+                            }
+                        }
+                        blk_store_bytes(frow + i * 32, __builtin_bit_cast(u32x4, v0), 2 * min(8, nval));
+                        blk_store_bytes(frow + i * 32 + 16, __builtin_bit_cast(u32x4, v1), 2 * min(8, nval - 8));
+                    }
+                }
+            }
+        }
+    }
+#undef FQ_NVAL
+#undef FQ_TILE
+}
+
+template <int RT, int CT, bool NAT, typename T>
+int launch_block_any(int flags, const T* x, const T* P, int64_t rows, int C, const FqQuantOut& out, int n_cu, hipStream_t stream) {
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > (int64_t)n_cu * 2) blocks = (int64_t)n_cu * 2;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((fq_block_any_kernel<RT, CT, NAT, T>), dim3((unsigned)blocks), dim3(256), 0, stream, x, P, rows, C, out, flags);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int launch_block_any_t(int flags, const T* x, const T* P, int64_t rows, int R, int C, int transpose_out, const FqQuantOut& out,
+                       int n_cu, hipStream_t stream) {
+    const int RT = R / 32, CT = (C + 31) / 32;
+#define FQ_BA(RT_, CT_)                                                                                          \
+    if (RT == RT_ && CT == CT_)                                                                                  \
+        return transpose_out ? launch_block_any<RT_, CT_, false, T>(flags, x, P, rows, C, out, n_cu, stream)     \
+                             : launch_block_any<RT_, CT_, true, T>(flags, x, P, rows, C, out, n_cu, stream);
+    FQ_BA(1, 1) FQ_BA(2, 1) FQ_BA(3, 1) FQ_BA(4, 1) FQ_BA(1, 2) FQ_BA(2, 2) FQ_BA(3, 2) FQ_BA(4, 2)
+#undef FQ_BA
+    return -1000;
+}
+
 template <int RT, int CT, bool NAT>
 int launch_block(int flags, const f16* x, const f16* P, int64_t rows, const FqQuantOut& out, int n_cu,
                  hipStream_t stream) {
@@ -330,7 +549,10 @@ int launch_block(int flags, const f16* x, const f16* P, int64_t rows, const FqQu
 
 int fq_launch_block(int flags, const f16* x, const f16* P, int64_t rows, int R, int C, int transpose_out,
                     const FqQuantOut& out, int n_cu, hipStream_t stream) {
-    if ((R & 31) || R < 32 || R > 128 || (C != 32 && C != 64)) return -1000;
+    if ((R & 31) || R < 32 || R > 128 || (C & 1) || C < 2 || C > 64) return -1000;
+    if (flags & FQ_DT_BF16)
+        return launch_block_any_t<bf16>(flags & ~FQ_DT_BF16, (const bf16*)x, (const bf16*)P, rows, R, C, transpose_out, out, n_cu, stream);
+    if (C != 32 && C != 64) return launch_block_any_t<f16>(flags, x, P, rows, R, C, transpose_out, out, n_cu, stream);
     const int RT = R / 32, CT = C / 32;
 #define FQ_B(RT_, CT_)                                                                                       \
     if (RT == RT_ && CT == CT_)                                                                              \

@@ -164,8 +164,9 @@ __global__ void fq_probe_mfma_kernel(const f16* __restrict__ A, const f16* __res
 // and, for a grouped launch, the group arrays).
 static int kron_dispatch(const char* what, const FqQuantOut& o, int flags, const void* x, const void* left, const void* right,
                          const void* diag, int64_t rows, int M, int N, void* workspace, int64_t workspace_bytes,
-                         void* stream) {
+                         void* stream, int dt = 0) {
     int rc;
+    flags |= dt;  // FQ_DT_BF16 (internal): the launchers pick the bf16 instantiations
     FQ_NEED_ALIGN16(what, x, left, right, diag, workspace);
     const int n_cu = cu_count();
     const bool special = o.group_offsets != nullptr || (o.rt_flags & FQ_GROUP128);  // only the fused MFMA kernels take these
@@ -175,6 +176,7 @@ static int kron_dispatch(const char* what, const FqQuantOut& o, int flags, const
         rc = fq_launch_kron64(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag,
                               rows, o, n_cu, (hipStream_t)stream);
         if (rc != -1000) return check_launch(rc, what);
+        if (dt) return fail(FQ_EUNSUPPORTED, "%s: output set 0x%x has no bf16 kernel at 64 x 64", what, flags & ~dt);
         if (o.rt_flags & FQ_GROUP128) return fail(FQ_EUNSUPPORTED, "%s: FQ_GROUP128 needs the packed-only output set at 64 x 64", what);
     }
     rc = fq_launch_kron_generic(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag,
@@ -193,27 +195,42 @@ static int kron_dispatch(const char* what, const FqQuantOut& o, int flags, const
 extern "C" {
 
 const char* fq_last_error(void) { return g_err; }
-int fq_version(void) { return 110; }
+int fq_version(void) { return 120; }
+
+static int kron_quant_impl(const char* what, int dt, const void* x, const void* left, const void* right, const void* diag, int64_t rows,
+                           int M, int N, const float* sig_max, const float* sig_min, int n_clips, int flags,
+                           void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
+    if (rows < 0 || M <= 0 || N <= 0) return fail(FQ_EINVAL, "%s: bad sizes rows=%lld M=%d N=%d", what, (long long)rows, M, N);
+    if (N & 1) return fail(FQ_EINVAL, "%s: N=%d must be even (two INT4 per byte)", what, N);
+    FqQuantOut o;
+    int rc = fill_out(what, o, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out, y_out);
+    if (rc != FQ_OK) return rc;
+    if (rows == 0) return FQ_OK;  // empty batch: nothing to launch (zero-size tensors have NULL data)
+    if (!x || !left || !right) return fail(FQ_EINVAL, "%s: x/left/right is NULL", what);
+    return kron_dispatch(what, o, flags, x, left, right, diag, rows, M, N, workspace, workspace_bytes, stream, dt);
+}
 
 int fq_kron_quant_f16(const void* x, const void* left, const void* right, const void* diag, int64_t rows,
                       int M, int N, const float* sig_max, const float* sig_min, int n_clips, int flags,
                       void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
                       void* workspace, int64_t workspace_bytes, void* stream) {
-    if (rows < 0 || M <= 0 || N <= 0) return fail(FQ_EINVAL, "fq_kron_quant_f16: bad sizes rows=%lld M=%d N=%d", (long long)rows, M, N);
-    if (N & 1) return fail(FQ_EINVAL, "fq_kron_quant_f16: N=%d must be even (two INT4 per byte)", N);
-    FqQuantOut o;
-    int rc = fill_out("fq_kron_quant_f16", o, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out, y_out);
-    if (rc != FQ_OK) return rc;
-    if (rows == 0) return FQ_OK;  // empty batch: nothing to launch (zero-size tensors have NULL data)
-    if (!x || !left || !right) return fail(FQ_EINVAL, "fq_kron_quant_f16: x/left/right is NULL");
-    return kron_dispatch("fq_kron_quant_f16", o, flags, x, left, right, diag, rows, M, N, workspace, workspace_bytes, stream);
+    return kron_quant_impl("fq_kron_quant_f16", 0, x, left, right, diag, rows, M, N, sig_max, sig_min, n_clips, flags, q_out,
+                           scale_out, fq_out, y_out, workspace, workspace_bytes, stream);
 }
 
-int fq_kron_quant_grouped_f16(const void* x, const void* left, const void* right, int64_t rows, int M, int N,
+int fq_kron_quant_bf16(const void* x, const void* left, const void* right, const void* diag, int64_t rows,
+                       int M, int N, const float* sig_max, const float* sig_min, int n_clips, int flags,
+                       void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                       void* workspace, int64_t workspace_bytes, void* stream) {
+    return kron_quant_impl("fq_kron_quant_bf16", FQ_DT_BF16, x, left, right, diag, rows, M, N, sig_max, sig_min, n_clips, flags,
+                           q_out, scale_out, fq_out, y_out, workspace, workspace_bytes, stream);
+}
+
+static int kron_quant_grouped_impl(const char* what, int dt, const void* x, const void* left, const void* right, int64_t rows, int M, int N,
                               const int64_t* group_offsets, int n_groups, const float* sig_max_g, const float* sig_min_g,
                               int flags, void* q_out, void* scale_out, void* fq_out, void* y_out,
                               void* workspace, int64_t workspace_bytes, void* stream) {
-    const char* what = "fq_kron_quant_grouped_f16";
     if (rows < 0 || M <= 0 || N <= 0) return fail(FQ_EINVAL, "%s: bad sizes rows=%lld M=%d N=%d", what, (long long)rows, M, N);
     if (N & 1) return fail(FQ_EINVAL, "%s: N=%d must be even (two INT4 per byte)", what, N);
     if (n_groups < 1) return fail(FQ_EINVAL, "%s: n_groups=%d", what, n_groups);
@@ -234,7 +251,23 @@ int fq_kron_quant_grouped_f16(const void* x, const void* left, const void* right
         o.sig_min_g = sig_min_g;
         o.n_groups = n_groups;
     }
-    return kron_dispatch(what, o, flags, x, left, right, nullptr, rows, M, N, workspace, workspace_bytes, stream);
+    return kron_dispatch(what, o, flags, x, left, right, nullptr, rows, M, N, workspace, workspace_bytes, stream, dt);
+}
+
+int fq_kron_quant_grouped_f16(const void* x, const void* left, const void* right, int64_t rows, int M, int N,
+                              const int64_t* group_offsets, int n_groups, const float* sig_max_g, const float* sig_min_g,
+                              int flags, void* q_out, void* scale_out, void* fq_out, void* y_out,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+    return kron_quant_grouped_impl("fq_kron_quant_grouped_f16", 0, x, left, right, rows, M, N, group_offsets, n_groups, sig_max_g,
+                                   sig_min_g, flags, q_out, scale_out, fq_out, y_out, workspace, workspace_bytes, stream);
+}
+
+int fq_kron_quant_grouped_bf16(const void* x, const void* left, const void* right, int64_t rows, int M, int N,
+                               const int64_t* group_offsets, int n_groups, const float* sig_max_g, const float* sig_min_g,
+                               int flags, void* q_out, void* scale_out, void* fq_out, void* y_out,
+                               void* workspace, int64_t workspace_bytes, void* stream) {
+    return kron_quant_grouped_impl("fq_kron_quant_grouped_bf16", FQ_DT_BF16, x, left, right, rows, M, N, group_offsets, n_groups,
+                                   sig_max_g, sig_min_g, flags, q_out, scale_out, fq_out, y_out, workspace, workspace_bytes, stream);
 }
 
 int fq_rmsnorm_kron_quant_f16(const void* x, float eps, const void* left, const void* right, int64_t rows, int M, int N,
@@ -357,26 +390,50 @@ int fq_kron_prepare_f16(const void* left, const void* right, int M, int N, void*
                         "fq_kron_prepare_f16");
 }
 
+int fq_kron_prepare_bf16(const void* left, const void* right, int M, int N, void* workspace, int64_t workspace_bytes,
+                         void* stream) {
+    // the fragment image re-arranges 16-bit words and pads with zero bits: one kernel for both element types
+    return fq_kron_prepare_f16(left, right, M, N, workspace, workspace_bytes, stream);
+}
+
 int64_t fq_kron_workspace_bytes(int M, int N) {
     if (M == 64 && N == 64) return 0;
     if (M < 1 || N < 2 || (N & 1) || M > 256 || N > 256 || (int64_t)M * N > 32768) return FQ_EUNSUPPORTED;
     return fq_kron_generic_workspace_bytes(M, N);
 }
 
+static int block_quant_impl(const char* what, int dt, const void* x, const void* P, int64_t rows, int R, int C, int transpose_out,
+                            const float* sig_max, const float* sig_min, int n_clips, int flags,
+                            void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                            void* stream) {
+    if (!x || !P) return fail(FQ_EINVAL, "%s: x/P is NULL", what);
+    FQ_NEED_ALIGN16(what, x, P);
+    if (rows < 0 || R <= 0 || C <= 0) return fail(FQ_EINVAL, "%s: bad sizes", what);
+    if ((R & 31) || R > 128 || (C & 1) || C > 64)
+        return fail(FQ_EUNSUPPORTED, "%s: R=%d must be 32, 64, 96 or 128 and C=%d even and <= 64", what, R, C);
+    FqQuantOut o;
+    int rc = fill_out(what, o, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out, y_out);
+    if (rc != FQ_OK) return rc;
+    if (rows == 0) return FQ_OK;
+    rc = fq_launch_block(flags | dt, (const f16*)x, (const f16*)P, rows, R, C, transpose_out, o, cu_count(),
+                         (hipStream_t)stream);
+    return check_launch(rc, what);
+}
+
 int fq_block_quant_f16(const void* x, const void* P, int64_t rows, int R, int C, int transpose_out,
                        const float* sig_max, const float* sig_min, int n_clips, int flags,
                        void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
                        void* stream) {
-    if (!x || !P) return fail(FQ_EINVAL, "fq_block_quant_f16: x/P is NULL");
-    FQ_NEED_ALIGN16("fq_block_quant_f16", x, P);
-    if (rows < 0 || R <= 0 || C <= 0) return fail(FQ_EINVAL, "fq_block_quant_f16: bad sizes");
-    FqQuantOut o;
-    int rc = fill_out("fq_block_quant_f16", o, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out, y_out);
-    if (rc != FQ_OK) return rc;
-    if (rows == 0) return FQ_OK;
-    rc = fq_launch_block(flags, (const f16*)x, (const f16*)P, rows, R, C, transpose_out, o, cu_count(),
-                         (hipStream_t)stream);
-    return check_launch(rc, "fq_block_quant_f16");
+    return block_quant_impl("fq_block_quant_f16", 0, x, P, rows, R, C, transpose_out, sig_max, sig_min, n_clips, flags, q_out,
+                            scale_out, fq_out, y_out, stream);
+}
+
+int fq_block_quant_bf16(const void* x, const void* P, int64_t rows, int R, int C, int transpose_out,
+                        const float* sig_max, const float* sig_min, int n_clips, int flags,
+                        void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                        void* stream) {
+    return block_quant_impl("fq_block_quant_bf16", FQ_DT_BF16, x, P, rows, R, C, transpose_out, sig_max, sig_min, n_clips, flags,
+                            q_out, scale_out, fq_out, y_out, stream);
 }
 
 int fq_hadamard_f16(const void* x, void* y, int64_t rows, int n, int K, const void* hadK, float scale,
@@ -637,24 +694,37 @@ int fq_kv_batch_decode_i4_ex(void* o, const void* q, const void* q_trans, int tr
     return check_launch(rc, "fq_kv_batch_decode_i4");
 }
 
+static int rowquant_impl(const char* what, int dt, const void* x, int64_t rows, int cols, const float* sig_max, const float* sig_min,
+                         int n_clips, int flags, void* const* q_out, void* const* scale_out,
+                         void* const* fq_out, void* stream) {
+    if (!x) return fail(FQ_EINVAL, "%s: x is NULL", what);
+    FQ_NEED_ALIGN16(what, x);
+    if (rows < 0 || cols <= 0) return fail(FQ_EINVAL, "%s: bad sizes", what);
+    if (cols & 7) return fail(FQ_EUNSUPPORTED, "%s: cols=%d must be a multiple of 8", what, cols);
+    if (cols > 32768) return fail(FQ_EUNSUPPORTED, "%s: cols=%d > 32768", what, cols);
+    if (flags & FQ_OUT_TRANSFORM) return fail(FQ_EINVAL, "%s: FQ_OUT_TRANSFORM is meaningless here", what);
+    if ((flags & FQ_ASYM) && (flags & ~(FQ_ASYM | FQ_OUT_FAKEQUANT | FQ_QUANT_F16)) )
+        return fail(FQ_EINVAL, "%s: FQ_ASYM goes with FQ_OUT_FAKEQUANT (and FQ_QUANT_F16) only, flags 0x%x", what, flags);
+    if ((flags & FQ_ASYM) && !(flags & FQ_OUT_FAKEQUANT)) return fail(FQ_EINVAL, "%s: FQ_ASYM needs FQ_OUT_FAKEQUANT", what);
+    FqQuantOut o;
+    int rc = fill_out(what, o, sig_max, sig_min, n_clips, flags & ~FQ_ASYM, q_out, scale_out, fq_out, nullptr);
+    if (rc != FQ_OK) return rc;
+    if (rows == 0) return FQ_OK;
+    rc = fq_launch_rowquant(flags | dt, (const f16*)x, rows, cols, o, cu_count(), (hipStream_t)stream);
+    return check_launch(rc, what);
+}
+
 int fq_rowquant_f16(const void* x, int64_t rows, int cols, const float* sig_max, const float* sig_min,
                     int n_clips, int flags, void* const* q_out, void* const* scale_out,
                     void* const* fq_out, void* stream) {
-    if (!x) return fail(FQ_EINVAL, "fq_rowquant_f16: x is NULL");
-    FQ_NEED_ALIGN16("fq_rowquant_f16", x);
-    if (rows < 0 || cols <= 0) return fail(FQ_EINVAL, "fq_rowquant_f16: bad sizes");
-    if (cols & 7) return fail(FQ_EUNSUPPORTED, "fq_rowquant_f16: cols=%d must be a multiple of 8", cols);
-    if (cols > 32768) return fail(FQ_EUNSUPPORTED, "fq_rowquant_f16: cols=%d > 32768", cols);
-    if (flags & FQ_OUT_TRANSFORM) return fail(FQ_EINVAL, "fq_rowquant_f16: FQ_OUT_TRANSFORM is meaningless here");
-    if ((flags & FQ_ASYM) && (flags & ~(FQ_ASYM | FQ_OUT_FAKEQUANT | FQ_QUANT_F16)) )
-        return fail(FQ_EINVAL, "fq_rowquant_f16: FQ_ASYM goes with FQ_OUT_FAKEQUANT (and FQ_QUANT_F16) only, flags 0x%x", flags);
-    if ((flags & FQ_ASYM) && !(flags & FQ_OUT_FAKEQUANT)) return fail(FQ_EINVAL, "fq_rowquant_f16: FQ_ASYM needs FQ_OUT_FAKEQUANT");
-    FqQuantOut o;
-    int rc = fill_out("fq_rowquant_f16", o, sig_max, sig_min, n_clips, flags & ~FQ_ASYM, q_out, scale_out, fq_out, nullptr);
-    if (rc != FQ_OK) return rc;
-    if (rows == 0) return FQ_OK;
-    rc = fq_launch_rowquant(flags, (const f16*)x, rows, cols, o, cu_count(), (hipStream_t)stream);
-    return check_launch(rc, "fq_rowquant_f16");
+    return rowquant_impl("fq_rowquant_f16", 0, x, rows, cols, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out, stream);
+}
+
+int fq_rowquant_bf16(const void* x, int64_t rows, int cols, const float* sig_max, const float* sig_min,
+                     int n_clips, int flags, void* const* q_out, void* const* scale_out,
+                     void* const* fq_out, void* stream) {
+    return rowquant_impl("fq_rowquant_bf16", FQ_DT_BF16, x, rows, cols, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out,
+                         stream);
 }
 
 int fq_sym_quant_f16(const void* x, const void* scale, int64_t rows, int cols, void* q, void* stream) {

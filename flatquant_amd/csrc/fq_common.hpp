@@ -20,6 +20,37 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// bfloat16 activations (round 3): the reference's path A is dtype-generic (flat_utils.py:6-17; quant_utils.py:86 casts q_max
+// to x's dtype) and its pipeline feeds it bf16 on Llama-3 / Qwen / DeepSeek (model_utils.py:20 torch_dtype='auto',
+// main_dpskv3.py:395 set_default_dtype(bfloat16)). Kernels that serve that surface take the element type as a template
+// parameter T in {f16, bf16}: v_mfma_f32_32x32x16_bf16, v_cvt_pk_bf16_f32 (round to nearest even) for every rounding the
+// torch expression performs, fp32 for everything the type promotion makes fp32. The f16 instantiations are unchanged code.
+typedef __bf16 bf16;
+typedef bf16  bf16x2 __attribute__((ext_vector_type(2)));
+typedef bf16  bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16  bf16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct FqVec;
+template <> struct FqVec<f16>  { typedef f16x8  x8; typedef f16x4  x4; typedef f16x2  x2; static constexpr bool is_f16 = true;  };
+template <> struct FqVec<bf16> { typedef bf16x8 x8; typedef bf16x4 x4; typedef bf16x2 x2; static constexpr bool is_f16 = false; };
+
+// internal launcher flag (never part of the ABI's `flags`): the tensors are bf16
+constexpr int FQ_DT_BF16 = 0x20000000;
+
+template <typename T>
+__device__ __forceinline__ f32x16 fq_mfma32(typename FqVec<T>::x8 a, typename FqVec<T>::x8 b, f32x16 c);
+template <>
+__device__ __forceinline__ f32x16 fq_mfma32<f16>(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16 fq_mfma32<bf16>(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// fp32 -> T -> fp32: the rounding a torch op with a T result performs on its fp32 opmath value
+template <typename T>
+__device__ __forceinline__ float fq_round_to(float v) { return (float)(T)v; }
+
 // Per-launch output description, passed by value as a kernel argument.
 struct FqQuantOut {
     float    sig_max[FQ_MAX_CLIPS];
@@ -186,11 +217,13 @@ __device__ __forceinline__ float fq_wave_min(float v) { return fq_wave_reduce(v,
 // (scale * q).to(float16) (quant_utils.py:25-26,81). hipcc otherwise selects v_fma_mixlo_f16 for
 // fptrunc(fmul), which rounds the exact product once and differs when the fp32 product lands on an fp16 tie
 // (seen on the GPU: 7 * 3.184152 -> 22.297 instead of 22.281). The empty asm makes the product opaque.
-__device__ __forceinline__ f16 fq_mul_to_f16(float a, float b) {
+template <typename T>
+__device__ __forceinline__ T fq_mul_to(float a, float b) {
     float p = a * b;
     asm volatile("" : "+v"(p));
-    return (f16)p;
+    return (T)p;
 }
+__device__ __forceinline__ f16 fq_mul_to_f16(float a, float b) { return fq_mul_to<f16>(a, b); }
 
 // FQ_GROUP128 with N = 64: a 128-element group is two consecutive 64-element rows of the transformed token, held by the
 // lanes (h, c) with c in {2j, 2j+1}, h in {0, 1} of one output-row tile: combine a per-lane partial extremum over
@@ -210,7 +243,7 @@ __device__ __forceinline__ float fq_group4_reduce(float v, Op op) {
 }
 
 // scale from (xmax, xmin) of one token and one clip set; see header comment for the pinned arithmetic.
-template <int FLAGS>
+template <int FLAGS, typename T = f16>
 __device__ __forceinline__ float fq_token_scale(float xmax, float xmin, float sig_max, float sig_min,
                                                 int rt_flags) {
     if (!(rt_flags & FQ_NO_CLAMP0)) {
@@ -222,8 +255,10 @@ __device__ __forceinline__ float fq_token_scale(float xmax, float xmin, float si
         // sigmoid tensor is an fp16 RESULT under torch's type promotion: the product is formed in fp32 (fp16 extremum x the
         // fp32 sigmoid, rounded to fp32) and then rounded to fp16 — two roundings (run on the reference: golden
         // quantizer_lac.npz). The (1,)-shaped parameters of quant_utils.py:96-97 promote the result to fp32 instead.
-        xmax = (float)fq_mul_to_f16(xmax, sig_max);
-        xmin = (float)fq_mul_to_f16(xmin, sig_min);
+        // (T = bf16: a bf16 extremum times a bf16 sigmoid — main_dpskv3.py:395 makes the clip parameters bf16 — is exact in
+        //  fp32 and rounds to bf16 once; the caller passes the bf16-rounded sigmoid)
+        xmax = (float)fq_mul_to<T>(xmax, sig_max);
+        xmin = (float)fq_mul_to<T>(xmin, sig_min);
     } else {
         xmax = xmax * sig_max;
         xmin = xmin * sig_min;
@@ -233,7 +268,8 @@ __device__ __forceinline__ float fq_token_scale(float xmax, float xmin, float si
     if (FLAGS & FQ_QUANT_F16) {
         // fp16 scale: (m/7).to(fp16) as deploy/nn/quantization.py:25-30 and quant_utils.py:103 (fp16
         // tensors; with sig == 1 m is itself an fp16 value, so fp16(m/7) is the fp16 division).
-        scale = (float)(f16)(m / 7.0f);
+        // (T = bf16: the fp32 quotient of two 8-bit significands rounded to bf16 is the correctly rounded bf16 quotient)
+        scale = (float)(T)(m / 7.0f);
         if (m == 0.0f) scale = 1.0f;
     } else {
         scale = m / 7.0f;
@@ -243,10 +279,10 @@ __device__ __forceinline__ float fq_token_scale(float xmax, float xmin, float si
 }
 
 // clamp(rint(y/scale), -8, 7) as an integer in [-8, 7].
-template <int FLAGS>
+template <int FLAGS, typename T = f16>
 __device__ __forceinline__ int fq_quant1(float y, float scale) {
     float t = y / scale;                       // correctly rounded fp32 division
-    if (FLAGS & FQ_QUANT_F16) t = (float)(f16)t;  // fp16 quotient (== __hdiv, no double-rounding issue)
+    if (FLAGS & FQ_QUANT_F16) t = (float)(T)t;  // fp16 / bf16 quotient (== __hdiv, no double-rounding issue)
     t = __builtin_rintf(t);
     t = fminf(fmaxf(t, -8.0f), 7.0f);
     return (int)t;
@@ -259,6 +295,14 @@ __device__ __forceinline__ int fq_quant1(float y, float scale) {
 __device__ __forceinline__ int fq_quant1_h(f16 y, f16 s) {
     const f16 t = y / s;
     float r = __builtin_rintf((float)t);
+    r = __builtin_amdgcn_fmed3f(r, -8.0f, 7.0f);
+    return (int)r;
+}
+// bf16: torch evaluates x / scale in fp32 opmath and rounds the quotient to bf16 (a quotient of two 8-bit significands is
+// never within 2^-24 of a bf16 rounding boundary unless it lies on it: the double rounding is harmless)
+__device__ __forceinline__ int fq_quant1_h(bf16 y, bf16 s) {
+    const float t = (float)(bf16)((float)y / (float)s);
+    float r = __builtin_rintf(t);
     r = __builtin_amdgcn_fmed3f(r, -8.0f, 7.0f);
     return (int)r;
 }
@@ -281,18 +325,28 @@ __device__ __forceinline__ f16x8 fq_silu_mul8(f16x8 g, f16x8 u) {
 // The fake-quant value fp16(fp32(scale * q)) of an integer-valued float q. A zero product is made +0.0: the reference
 // rounds with round_ste (quant_utils.py:3-7: (x.round() - x) + x), which never returns -0.0, while v_rndne_f32 of a small
 // negative quotient does (the reference-written fixtures hold no negative zero).
-__device__ __forceinline__ f16 fq_fake_f16(float scale, float q) {
+template <typename T>
+__device__ __forceinline__ T fq_fake(float scale, float q) {
     float p = scale * q;
     asm volatile("" : "+v"(p));
     p = p + 0.0f;
-    return (f16)p;
+    return (T)p;
+}
+__device__ __forceinline__ f16 fq_fake_f16(float scale, float q) { return fq_fake<f16>(scale, q); }
+
+template <int FLAGS, typename T = f16>
+__device__ __forceinline__ T fq_dequant1(int q, float scale) {
+    // FQ_QUANT_F16: scale is an fp16 (bf16) value and |q| <= 8, so the fp32 product is exact and one rounding remains
+    if (FLAGS & FQ_QUANT_F16) return (T)((float)(T)scale * (float)q);
+    return fq_mul_to<T>(scale, (float)q);
 }
 
-template <int FLAGS>
-__device__ __forceinline__ f16 fq_dequant1(int q, float scale) {
-    // FQ_QUANT_F16: scale is an fp16 value and |q| <= 8, so the fp32 product is exact and one rounding remains
-    if (FLAGS & FQ_QUANT_F16) return (f16)((float)(f16)scale * (float)q);
-    return fq_mul_to_f16(scale, (float)q);
+// Extrema of eight 16-bit floats held as four dwords (a 16-byte chunk of an activation row). fp16: packed v_pk_max/min_f16
+// on running pairs (see fq_pk_max below); bf16 has no packed max on gfx950 — a bf16 IS the upper half of an fp32, so the two
+// halves of a dword become fp32 values with one shift / one and, and the extrema run on v_max3 / v_min3_f32.
+__device__ __forceinline__ void fq_bf16_pair(uint32_t w, float& lo, float& hi) {
+    lo = __builtin_bit_cast(float, w << 16);
+    hi = __builtin_bit_cast(float, w & 0xFFFF0000u);
 }
 
 // ---------------------------------------------------------------------------------------------------

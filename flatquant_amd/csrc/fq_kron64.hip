@@ -58,12 +58,13 @@ __device__ __forceinline__ void store_q16(uint8_t* p, u32x4 v) {
 #ifndef FQ_K64_ABLATE
 #define FQ_K64_ABLATE 0  // measurement builds only: bit 0 = no MFMA, bit 1 = no quantiser arithmetic, bit 2 = no DMA
 #endif
-__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+template <typename T>
+__device__ __forceinline__ f32x16 mfma32(typename FqVec<T>::x8 a, typename FqVec<T>::x8 b, f32x16 c) {
 #if FQ_K64_ABLATE & 1
     c[0] += (float)a[0] + (float)b[0];
     return c;
 #else
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    return fq_mfma32<T>(a, b, c);
 #endif
 }
 
@@ -109,7 +110,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 // the COUNTED s_waitcnt at the top of the token loop. M0 (LDS base of the DMA) is saved/restored because the
 // compiler owns it.
 #define FQ_DMA_NT "nt"
-__device__ __forceinline__ void dma_token(const f16* __restrict__ x, int64_t tok, unsigned lds_base, int lane) {
+__device__ __forceinline__ void dma_token(const void* __restrict__ x, int64_t tok, unsigned lds_base, int lane) {
 #if FQ_K64_ABLATE & 4
     return;  // measurement build: no HBM reads (compute on whatever is in LDS)
 #endif
@@ -186,13 +187,14 @@ __device__ __forceinline__ unsigned quant_pack_token(const f32x16 (&Y)[2][2], co
         __builtin_amdgcn_sched_barrier(0);                                   \
     }
 
-template <int FLAGS, bool TRACE = false>
-__global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(const f16* __restrict__ x,
-                                                           const f16* __restrict__ left,
-                                                           const f16* __restrict__ right,
-                                                           const f16* __restrict__ diag,
+template <int FLAGS, bool TRACE = false, typename T = f16>
+__global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(const T* __restrict__ x,
+                                                           const T* __restrict__ left,
+                                                           const T* __restrict__ right,
+                                                           const T* __restrict__ diag,
                                                            int64_t rows, int64_t tpb, FqQuantOut out,
                                                            unsigned long long* __restrict__ trace) {
+    typedef typename FqVec<T>::x8 X8;  // eight activation / matrix elements = one 16-byte MFMA operand
     constexpr int THREADS = kron64_threads<FLAGS>();
     constexpr int WAVES = THREADS / 64;
     constexpr bool G128 = (FLAGS & FQ_K64_G128) != 0;
@@ -253,11 +255,11 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
 #define FQ_LD(j, off) asm volatile("global_load_ushort %0, %1, off offset:" #off : "=v"(gv[it][j]) : "v"(src) : "memory");
         if (f < 8) {  // element j: row + j of R
             const int nt = f >> 2, sk = f & 3;
-            const f16* src = right + (fh * 32 + sk * 8) * KN + nperm(nt, fc);
+            const T* src = right + (fh * 32 + sk * 8) * KN + nperm(nt, fc);
             FQ_LD(0, 0) FQ_LD(1, 128) FQ_LD(2, 256) FQ_LD(3, 384) FQ_LD(4, 512) FQ_LD(5, 640) FQ_LD(6, 768) FQ_LD(7, 896)
         } else {      // element j: row + 8 (j>>2) + (j&3) of L
             const int ks = (f - 8) >> 1, mo = (f - 8) & 1;
-            const f16* src = left + ((ks >> 1) * 32 + 16 * (ks & 1) + 4 * fh) * KM + mo * 32 + fc;
+            const T* src = left + ((ks >> 1) * 32 + 16 * (ks & 1) + 4 * fh) * KM + mo * 32 + fc;
             FQ_LD(0, 0) FQ_LD(1, 128) FQ_LD(2, 256) FQ_LD(3, 384) FQ_LD(4, 1024) FQ_LD(5, 1152) FQ_LD(6, 1280) FQ_LD(7, 1408)
         }
 #undef FQ_LD
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const f16x8 v = __builtin_bit_cast(f16x8, X[mt][s]);
+                    const X8 v = __builtin_bit_cast(X8, X[mt][s]);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) ss[j & 3] = __builtin_fmaf((float)v[j], (float)v[j], ss[j & 3]);
                 }
@@ -357,9 +359,9 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    f16x8 v = __builtin_bit_cast(f16x8, X[mt][s]);
+                    X8 v = __builtin_bit_cast(X8, X[mt][s]);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = fq_mul_to_f16((float)v[j], rinv);
+                    for (int j = 0; j < 8; ++j) v[j] = fq_mul_to<T>((float)v[j], rinv);
                     X[mt][s] = __builtin_bit_cast(u32x4, v);
                 }
         }
@@ -369,8 +371,8 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    f16x8 dv = __builtin_bit_cast(f16x8, dp[mt * (32 * KN / 8) + s]);
-                    X[mt][s] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8, X[mt][s]) * dv);
+                    X8 dv = __builtin_bit_cast(X8, dp[mt * (32 * KN / 8) + s]);
+                    X[mt][s] = __builtin_bit_cast(u32x4, __builtin_bit_cast(X8, X[mt][s]) * dv);
                 }
         }
 
@@ -382,23 +384,23 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
         U[0][0] = f32x16{0}; U[0][1] = f32x16{0}; U[1][0] = f32x16{0}; U[1][1] = f32x16{0};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const f16x8 b0 = __builtin_bit_cast(f16x8, myfrag[(0 * 4 + s) * 64]);
-            const f16x8 b1 = __builtin_bit_cast(f16x8, myfrag[(1 * 4 + s) * 64]);
-            U[0][0] = mfma32(__builtin_bit_cast(f16x8, X[0][s]), b0, U[0][0]);
-            U[1][0] = mfma32(__builtin_bit_cast(f16x8, X[1][s]), b0, U[1][0]);
-            U[0][1] = mfma32(__builtin_bit_cast(f16x8, X[0][s]), b1, U[0][1]);
-            U[1][1] = mfma32(__builtin_bit_cast(f16x8, X[1][s]), b1, U[1][1]);
+            const X8 b0 = __builtin_bit_cast(X8, myfrag[(0 * 4 + s) * 64]);
+            const X8 b1 = __builtin_bit_cast(X8, myfrag[(1 * 4 + s) * 64]);
+            U[0][0] = mfma32<T>(__builtin_bit_cast(X8, X[0][s]), b0, U[0][0]);
+            U[1][0] = mfma32<T>(__builtin_bit_cast(X8, X[1][s]), b0, U[1][0]);
+            U[0][1] = mfma32<T>(__builtin_bit_cast(X8, X[0][s]), b1, U[0][1]);
+            U[1][1] = mfma32<T>(__builtin_bit_cast(X8, X[1][s]), b1, U[1][1]);
             if (s == 0) FQ_PULL_NEXT()  // (all eight X fragments were requested before the first MFMA)
         }
 
         // ---- fp16 rounding of U (flat_utils.py:15); C fragment -> A fragment of GEMM 2, no data movement ----
-        f16x8 Uh[2][4];  // [nt][ks]
+        X8 Uh[2][4];  // [nt][ks]
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) Uh[nt][ks][j] = (f16)U[ks >> 1][nt][(ks & 1) * 8 + j];
+                for (int j = 0; j < 8; ++j) Uh[nt][ks][j] = (T)U[ks >> 1][nt][(ks & 1) * 8 + j];
 
         FQ_TICK(c2)
         // ---- GEMM 2: Y^T(nt, mo) = U(:, nt)^T . L(:, mo) ----
@@ -406,12 +408,12 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
         Y[0][0] = f32x16{0}; Y[0][1] = f32x16{0}; Y[1][0] = f32x16{0}; Y[1][1] = f32x16{0};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const f16x8 b0 = __builtin_bit_cast(f16x8, myfrag[(8 + ks * 2 + 0) * 64]);
-            const f16x8 b1 = __builtin_bit_cast(f16x8, myfrag[(8 + ks * 2 + 1) * 64]);
-            Y[0][0] = mfma32(Uh[0][ks], b0, Y[0][0]);
-            Y[1][0] = mfma32(Uh[1][ks], b0, Y[1][0]);
-            Y[0][1] = mfma32(Uh[0][ks], b1, Y[0][1]);
-            Y[1][1] = mfma32(Uh[1][ks], b1, Y[1][1]);
+            const X8 b0 = __builtin_bit_cast(X8, myfrag[(8 + ks * 2 + 0) * 64]);
+            const X8 b1 = __builtin_bit_cast(X8, myfrag[(8 + ks * 2 + 1) * 64]);
+            Y[0][0] = mfma32<T>(Uh[0][ks], b0, Y[0][0]);
+            Y[1][0] = mfma32<T>(Uh[1][ks], b0, Y[1][0]);
+            Y[0][1] = mfma32<T>(Uh[0][ks], b1, Y[0][1]);
+            Y[1][1] = mfma32<T>(Uh[1][ks], b1, Y[1][1]);
         }
         __builtin_amdgcn_s_setprio(0);
 
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
 #pragma unroll
                 for (int mo = 0; mo < 2; ++mo)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Y[nt][mo][r] = (float)(f16)Y[nt][mo][r];
+                    for (int r = 0; r < 16; ++r) Y[nt][mo][r] = (float)(T)Y[nt][mo][r];
         }
 
         if (FLAGS & FQ_OUT_TRANSFORM) {
@@ -432,9 +434,9 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int w = 0; w < 2; ++w) {
-                        f16x8 v;
+                        X8 v;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (f16)Y[nt][mo][w * 8 + e];
+                        for (int e = 0; e < 8; ++e) v[e] = (T)Y[nt][mo][w * 8 + e];
                         yp[nt * 2 + w] = __builtin_bit_cast(uint4, v);
                     }
             }
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
             for (int ci = 0; ci < out.n_clips; ++ci) {
                 float sig_max = out.sig_max[ci], sig_min = out.sig_min[ci];
                 if (GROUPED) fq_token_sigs(out, ci, tok, gcur, sig_max, sig_min);
-                const float scale = fq_token_scale<FLAGS>(vmax, vmin, sig_max, sig_min, out.rt_flags);
+                const float scale = fq_token_scale<FLAGS, T>(vmax, vmin, sig_max, sig_min, out.rt_flags);
                 // value of element e (0..7) of dword w (0..3) of output row mo: Y^T[n' = 32h + 8w + e]
 #define FQ_YV(mo, w, e) Y[(w) >> 1][mo][((w) & 1) * 8 + (e)]
                 if (FLAGS & FQ_OUT_PACKED) {
@@ -482,14 +484,14 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                                 b = fq_min3(b, Y[r >> 4][mo][r & 15], Y[r >> 4][mo][(r & 15) + 1]);
                             }
                             const float gmax = fq_group4_reduce(a, FqMaxOp()), gmin = fq_group4_reduce(b, FqMinOp());
-                            scl[mo] = fq_token_scale<FLAGS>(gmax, gmin, sig_max, sig_min, out.rt_flags);
+                            scl[mo] = fq_token_scale<FLAGS, T>(gmax, gmin, sig_max, sig_min, out.rt_flags);
                             const float gi = fq_fast_inv(scl[mo]);
                             g_magic = g_magic && !__any(!fq_magic_ok(gmax, gmin, gi));
                             g_clamp = g_clamp || __any(fq_needs_clamp(gmax, gmin, gi));
-                            if (h == 0 && !(c & 1)) out.scale[ci][tok * (KD / 128) + ((mo * 32 + c) >> 1)] = (f16)scl[mo];
+                            if (h == 0 && !(c & 1)) reinterpret_cast<T*>(out.scale[ci])[tok * (KD / 128) + ((mo * 32 + c) >> 1)] = (T)scl[mo];
                         }
                     } else if (lane == 0) {
-                        out.scale[ci][tok] = (f16)scale;
+                        reinterpret_cast<T*>(out.scale[ci])[tok] = (T)scale;
                     }
                     uint32_t pw[2][4];
                     if (FLAGS & FQ_QUANT_F16) {
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                                 uint32_t d = 0;
 #pragma unroll
                                 for (int e = 0; e < 8; ++e)
-                                    d |= (uint32_t)(fq_quant1<FLAGS>(FQ_YV(mo, w, e), scl[mo]) & 15) << (4 * e);
+                                    d |= (uint32_t)(fq_quant1<FLAGS, T>(FQ_YV(mo, w, e), scl[mo]) & 15) << (4 * e);
                                 pw[mo][w] = d;
                             }
                     } else {
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                                   u32x4{pw[mo][0], pw[mo][1], pw[mo][2], pw[mo][3]});
                 }
                 if (FLAGS & FQ_OUT_FAKEQUANT) {
-                    f16x8 fv[2][4];
+                    X8 fv[2][4];
                     if (FLAGS & FQ_QUANT_F16) {
 #pragma unroll
                         for (int mo = 0; mo < 2; ++mo)
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                             for (int w = 0; w < 4; ++w)
 #pragma unroll
                                 for (int e = 0; e < 8; ++e)
-                                    fv[mo][w][e] = fq_dequant1<FLAGS>(fq_quant1<FLAGS>(FQ_YV(mo, w, e), scale), scale);
+                                    fv[mo][w][e] = fq_dequant1<FLAGS, T>(fq_quant1<FLAGS, T>(FQ_YV(mo, w, e), scale), scale);
                     } else {
                         const float inv = fq_fast_inv(scale);
                         const f32x2 inv2 = {inv, inv};
@@ -580,14 +582,14 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                                     for (int j = 0; j < 4; ++j)
                                         q[j] = f32x2{fq_qexact(FQ_YV(mo, w, 2 * j), scale), fq_qexact(FQ_YV(mo, w, 2 * j + 1), scale)};
                                 }
-                                f16x8 o;
+                                X8 o;
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {  // fp16(fp32(scale * q)): two roundings, as torch (fq_mul_to_f16)
                                     f32x2 pr = q[j] * f32x2{scale, scale};
                                     asm volatile("" : "+v"(pr));
                                     pr = pr + f32x2{0.0f, 0.0f};  // a zero product is +0.0 (fq_fake_f16, fq_common.hpp)
-                                    o[2 * j] = (f16)pr.x;
-                                    o[2 * j + 1] = (f16)pr.y;
+                                    o[2 * j] = (T)pr.x;
+                                    o[2 * j + 1] = (T)pr.y;
                                 }
                                 // stored at once: keeping all eight chunks of a token costs 32 VGPRs this kernel lacks
                                 reinterpret_cast<uint4*>(out.fq[ci] + tok * KD + (mo * 32 + c) * KN + h * 32)[w] =
@@ -636,8 +638,8 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
 }  // namespace
 
 // Host-side launcher used by the C ABI (fq_capi.hip). Returns hipError_t as int.
-template <int FLAGS>
-static int launch_kron64(const f16* x, const f16* left, const f16* right, const f16* diag, int64_t rows,
+template <int FLAGS, typename T>
+static int launch_kron64(const T* x, const T* left, const T* right, const T* diag, int64_t rows,
                          const FqQuantOut& out, int n_cu, hipStream_t stream) {
     constexpr int THREADS = kron64_threads<FLAGS>();
     // few rows (decode): four tokens per workgroup, so that only the first SIMD-slot group of waves has work and no wave
@@ -646,35 +648,36 @@ static int launch_kron64(const f16* x, const f16* left, const f16* right, const 
     if (blocks > n_cu) blocks = n_cu;  // one persistent workgroup per CU (LDS: 16 KB + 8 KB per wave)
     if (blocks < 1) blocks = 1;
     const int64_t tpb = (rows + blocks - 1) / blocks;
-    hipLaunchKernelGGL((fq_kron64_kernel<FLAGS, false>), dim3((unsigned)blocks), dim3(THREADS), 0, stream, x, left,
+    hipLaunchKernelGGL((fq_kron64_kernel<FLAGS, false, T>), dim3((unsigned)blocks), dim3(THREADS), 0, stream, x, left,
                        right, diag, rows, tpb, out, (unsigned long long*)nullptr);
     return (int)hipGetLastError();
 }
 
-int fq_launch_kron64(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
-                     int64_t rows, const FqQuantOut& out, int n_cu, hipStream_t stream) {
+template <typename T>
+static int launch_kron64_any(int flags, const T* x, const T* left, const T* right, const T* diag,
+                             int64_t rows, const FqQuantOut& out, int n_cu, hipStream_t stream) {
     // Compile-time specialisations: output set x fp16-quant arithmetic. Everything else is run-time.
 #define FQ_CASE(F)                                                                     \
     case (F):                                                                          \
-        return launch_kron64<(F)>(x, left, right, diag, rows, out, n_cu, stream);      \
+        return launch_kron64<(F), T>(x, left, right, diag, rows, out, n_cu, stream);      \
     case (F) | FQ_QUANT_F16:                                                           \
-        return launch_kron64<(F) | FQ_QUANT_F16>(x, left, right, diag, rows, out, n_cu, stream);
+        return launch_kron64<(F) | FQ_QUANT_F16, T>(x, left, right, diag, rows, out, n_cu, stream);
     if (out.rt_flags & FQ_GROUP128) {  // per-128-element scales: packed output, fp32 quantiser arithmetic only
         if ((flags & FQ_CT_MASK) != FQ_OUT_PACKED) return -1000;
         if (out.group_offsets != nullptr)
-            return launch_kron64<FQ_OUT_PACKED | FQ_K64_G128 | FQ_K64_GROUPED>(x, left, right, diag, rows, out, n_cu, stream);
-        return launch_kron64<FQ_OUT_PACKED | FQ_K64_G128>(x, left, right, diag, rows, out, n_cu, stream);
+            return launch_kron64<FQ_OUT_PACKED | FQ_K64_G128 | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream);
+        return launch_kron64<FQ_OUT_PACKED | FQ_K64_G128, T>(x, left, right, diag, rows, out, n_cu, stream);
     }
     if (out.group_offsets != nullptr) {  // grouped launch: packed or fake-quant output (+ the transform)
         switch (flags & FQ_CT_MASK) {
             case FQ_OUT_PACKED:
-                return launch_kron64<FQ_OUT_PACKED | FQ_K64_GROUPED>(x, left, right, diag, rows, out, n_cu, stream);
+                return launch_kron64<FQ_OUT_PACKED | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream);
             case FQ_OUT_FAKEQUANT:
-                return launch_kron64<FQ_OUT_FAKEQUANT | FQ_K64_GROUPED>(x, left, right, diag, rows, out, n_cu, stream);
+                return launch_kron64<FQ_OUT_FAKEQUANT | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream);
             case FQ_OUT_PACKED | FQ_OUT_TRANSFORM:
-                return launch_kron64<FQ_OUT_PACKED | FQ_OUT_TRANSFORM | FQ_K64_GROUPED>(x, left, right, diag, rows, out, n_cu, stream);
+                return launch_kron64<FQ_OUT_PACKED | FQ_OUT_TRANSFORM | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream);
             case FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM:
-                return launch_kron64<FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_K64_GROUPED>(x, left, right, diag, rows, out, n_cu, stream);
+                return launch_kron64<FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream);
             default:
                 return -1000;
         }
@@ -686,19 +689,31 @@ int fq_launch_kron64(int flags, const f16* x, const f16* left, const f16* right,
         FQ_CASE(FQ_OUT_TRANSFORM | FQ_OUT_PACKED)
         FQ_CASE(FQ_OUT_TRANSFORM | FQ_OUT_FAKEQUANT)
         FQ_CASE(FQ_OUT_TRANSFORM | FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)
+        // (the RMSNorm-fused launches serve deploy.nn.RMSNorm, an fp16-only module in the reference)
         case FQ_OUT_PACKED | FQ_IN_RMSNORM:
-            return launch_kron64<FQ_OUT_PACKED | FQ_IN_RMSNORM>(x, left, right, diag, rows, out, n_cu, stream);
+            if constexpr (FqVec<T>::is_f16) return launch_kron64<FQ_OUT_PACKED | FQ_IN_RMSNORM, T>(x, left, right, diag, rows, out, n_cu, stream);
+            return -1000;
         case FQ_OUT_TRANSFORM | FQ_IN_RMSNORM:
-            return launch_kron64<FQ_OUT_TRANSFORM | FQ_IN_RMSNORM>(x, left, right, diag, rows, out, n_cu, stream);
+            if constexpr (FqVec<T>::is_f16) return launch_kron64<FQ_OUT_TRANSFORM | FQ_IN_RMSNORM, T>(x, left, right, diag, rows, out, n_cu, stream);
+            return -1000;
         case FQ_OUT_TRANSFORM | FQ_OUT_PACKED | FQ_IN_RMSNORM:
-            return launch_kron64<FQ_OUT_TRANSFORM | FQ_OUT_PACKED | FQ_IN_RMSNORM>(x, left, right, diag, rows, out, n_cu, stream);
+            if constexpr (FqVec<T>::is_f16) return launch_kron64<FQ_OUT_TRANSFORM | FQ_OUT_PACKED | FQ_IN_RMSNORM, T>(x, left, right, diag, rows, out, n_cu, stream);
+            return -1000;
         case FQ_OUT_TRANSFORM:
         case FQ_OUT_TRANSFORM | FQ_QUANT_F16:
-            return launch_kron64<FQ_OUT_TRANSFORM>(x, left, right, diag, rows, out, n_cu, stream);
+            return launch_kron64<FQ_OUT_TRANSFORM, T>(x, left, right, diag, rows, out, n_cu, stream);
         default:
             return -1000;
     }
 #undef FQ_CASE
+}
+
+int fq_launch_kron64(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
+                     int64_t rows, const FqQuantOut& out, int n_cu, hipStream_t stream) {
+    if (flags & FQ_DT_BF16)
+        return launch_kron64_any<bf16>(flags & ~FQ_DT_BF16, (const bf16*)x, (const bf16*)left, (const bf16*)right, (const bf16*)diag,
+                                       rows, out, n_cu, stream);
+    return launch_kron64_any<f16>(flags, x, left, right, diag, rows, out, n_cu, stream);
 }
 
 // Debug: the packed kernel with per-phase s_memtime accounting (see FQ_TICK). trace: [n_waves, 4] u64,
@@ -708,7 +723,7 @@ int fq_launch_kron64_trace(const f16* x, const f16* left, const f16* right, int6
     int64_t blocks = (rows + 15) / 16;
     if (blocks > n_cu) blocks = n_cu;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((fq_kron64_kernel<FQ_OUT_PACKED, true>), dim3((unsigned)blocks), dim3(1024), 0, stream, x, left,
+    hipLaunchKernelGGL((fq_kron64_kernel<FQ_OUT_PACKED, true, f16>), dim3((unsigned)blocks), dim3(1024), 0, stream, x, left,
                        right, (const f16*)nullptr, rows, (rows + blocks - 1) / blocks, out, trace);
     return (int)hipGetLastError();
 }

@@ -21,9 +21,6 @@
 
 namespace {
 
-__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
 
 struct GenGeom {
     int M, N;
@@ -33,7 +30,8 @@ struct GenGeom {
 };
 
 // 16 fp16 values of a lane's run -> dense fp16 stage in LDS, `nvalid` of them, at any 2-byte-aligned address
-__device__ __forceinline__ void gen_put_run16(f16* p, const f16x8& v0, const f16x8& v1, int nvalid) {
+template <typename T>
+__device__ __forceinline__ void gen_put_run16(T* p, const typename FqVec<T>::x8& v0, const typename FqVec<T>::x8& v1, int nvalid) {
     const unsigned a = (unsigned)(size_t)p;
     if (nvalid == 16 && !(a & 15)) {
         reinterpret_cast<uint4*>(p)[0] = __builtin_bit_cast(uint4, v0);
@@ -77,10 +75,13 @@ __device__ __forceinline__ void gen_copy_out(unsigned char* dst, const unsigned 
     }
 }
 
-template <int MT, int WAVES, bool LLDS>
-__global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
-                                                                   const f16* __restrict__ diag, int64_t rows, GenGeom g,
+template <int MT, int WAVES, bool LLDS, typename T = f16>
+__global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const T* __restrict__ x, const uint4* __restrict__ ws,
+                                                                   const T* __restrict__ diag, int64_t rows, GenGeom g,
                                                                    FqQuantOut out, int flags) {
+    typedef typename FqVec<T>::x8 X8;
+    typedef typename FqVec<T>::x4 X4;
+    typedef typename FqVec<T>::x2 X2;
     constexpr int THREADS = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = g.M, N = g.N, KS1 = g.KS1, NT = g.NT, pitch = g.pitch;
@@ -157,13 +158,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
                     const int q = tl + k * THREADS;
                     if (q < pieces) {
                         uint4 v = __builtin_bit_cast(uint4, PF[k]);
-                        if (diag != nullptr) v = __builtin_bit_cast(uint4, __builtin_bit_cast(f16x8, v) * __builtin_bit_cast(f16x8, dp[q]));
+                        if (diag != nullptr) v = __builtin_bit_cast(uint4, __builtin_bit_cast(X8, v) * __builtin_bit_cast(X8, dp[q]));
                         const int row = q / cpr, ch = q - row * cpr;
                         xs[row * pitch + ch] = v;
                     }
                 }
             } else {
-                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
                 const int cpr = N >> 2;
                 const uint2* dp = reinterpret_cast<const uint2*>(diag);
                 uint2* xs2 = reinterpret_cast<uint2*>(xs);
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
                     const int q = tl + k * THREADS;
                     if (q < pieces) {
                         uint2 v = (k & 1) ? make_uint2(PF[k >> 1][2], PF[k >> 1][3]) : make_uint2(PF[k >> 1][0], PF[k >> 1][1]);
-                        if (diag != nullptr) v = __builtin_bit_cast(uint2, __builtin_bit_cast(f16x4, v) * __builtin_bit_cast(f16x4, dp[q]));
+                        if (diag != nullptr) v = __builtin_bit_cast(uint2, __builtin_bit_cast(X4, v) * __builtin_bit_cast(X4, dp[q]));
                         const int row = q / cpr, ch = q - row * cpr;
                         xs2[row * pitch * 2 + ch] = v;
                     }
@@ -184,19 +184,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
             const uint4* dp = reinterpret_cast<const uint4*>(diag);
             for (int q = tid; q < M * cpr; q += THREADS) {
                 uint4 v = xp[q];
-                if (diag != nullptr) v = __builtin_bit_cast(uint4, __builtin_bit_cast(f16x8, v) * __builtin_bit_cast(f16x8, dp[q]));
+                if (diag != nullptr) v = __builtin_bit_cast(uint4, __builtin_bit_cast(X8, v) * __builtin_bit_cast(X8, dp[q]));
                 const int row = q / cpr, ch = q - row * cpr;
                 xs[row * pitch + ch] = v;
             }
         } else if (!(N & 3)) {  // 8-byte pieces (N = 148: 37 per row)
-            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
             const int cpr = N >> 2;
             const uint2* xp = reinterpret_cast<const uint2*>(x + tok * d);
             const uint2* dp = reinterpret_cast<const uint2*>(diag);
             uint2* xs2 = reinterpret_cast<uint2*>(xs);
             for (int q = tid; q < M * cpr; q += THREADS) {
                 uint2 v = xp[q];
-                if (diag != nullptr) v = __builtin_bit_cast(uint2, __builtin_bit_cast(f16x4, v) * __builtin_bit_cast(f16x4, dp[q]));
+                if (diag != nullptr) v = __builtin_bit_cast(uint2, __builtin_bit_cast(X4, v) * __builtin_bit_cast(X4, dp[q]));
                 const int row = q / cpr, ch = q - row * cpr;
                 xs2[row * pitch * 2 + ch] = v;
             }
@@ -207,7 +206,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
             uint32_t* xs1 = reinterpret_cast<uint32_t*>(xs);
             for (int q = tid; q < M * cpr; q += THREADS) {
                 uint32_t v = xp[q];
-                if (diag != nullptr) v = __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, v) * __builtin_bit_cast(f16x2, dp[q]));
+                if (diag != nullptr) v = __builtin_bit_cast(uint32_t, __builtin_bit_cast(X2, v) * __builtin_bit_cast(X2, dp[q]));
                 const int row = q / cpr, ch = q - row * cpr;
                 xs1[row * pitch * 4 + ch] = v;
             }
@@ -216,7 +215,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
         if (tok + gridDim.x < rows) FQ_GEN_PF(tok + gridDim.x)
 
         // ---- GEMM 1 for this wave's n'-tile over all row tiles, rounded to fp16: the A fragments of GEMM 2 ----
-        f16x8 Uh[MT][2];
+        X8 Uh[MT][2];
         if (nt < NT) {  // (wave-uniform: an MFMA takes operands from all 64 lanes, also those whose run lies beyond N)
             f32x16 U[MT];
 #pragma unroll
@@ -225,22 +224,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
             // R fragments come from L2 (the image is up to 128 KB): four K-steps are fetched while the previous four are
             // multiplied, so the L2 latency is paid once per token and not once per K-step (CH K-steps per batch)
             constexpr int CH = MT >= 7 ? 1 : 4;   // (M > 192: the accumulators leave no room for more)
-            f16x8 bc[CH], bn[CH];
+            X8 bc[CH], bn[CH];
 #pragma unroll
-            for (int j = 0; j < CH; ++j) bc[j] = __builtin_bit_cast(f16x8, rf[(j < KS1 ? j : KS1 - 1) * 64]);
+            for (int j = 0; j < CH; ++j) bc[j] = __builtin_bit_cast(X8, rf[(j < KS1 ? j : KS1 - 1) * 64]);
             for (int s0 = 0; s0 < KS1; s0 += CH) {
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
                     const int sn = s0 + CH + j;
-                    bn[j] = __builtin_bit_cast(f16x8, rf[(sn < KS1 ? sn : KS1 - 1) * 64]);
+                    bn[j] = __builtin_bit_cast(X8, rf[(sn < KS1 ? sn : KS1 - 1) * 64]);
                 }
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
                     if (s0 + j < KS1) {
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
-                            const f16x8 a = __builtin_bit_cast(f16x8, xs[(mt * 32 + c) * pitch + (s0 + j) * 2 + h]);
-                            U[mt] = mfma32(a, bc[j], U[mt]);
+                            const X8 a = __builtin_bit_cast(X8, xs[(mt * 32 + c) * pitch + (s0 + j) * 2 + h]);
+                            U[mt] = fq_mfma32<T>(a, bc[j], U[mt]);
                         }
                     }
                 }
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) Uh[mt][p][j] = (f16)U[mt][p * 8 + j];
+                    for (int j = 0; j < 8; ++j) Uh[mt][p][j] = (T)U[mt][p * 8 + j];
         }
         // GEMM 2 for ONE output row tile: Y^T of tile (nt, mo), rows n' = n0 + r, col m' = 32 mo + c, with the post-scale and
         // the fp16 rounding applied. The kernel never holds more than one of them: the extrema take one sweep over the row
@@ -267,12 +266,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
             f32x16 Y = f32x16{0};
 #pragma unroll
             for (int k0 = 0; k0 < 2 * MT; k0 += MT) {
-                f16x8 Bf[MT];
+                X8 Bf[MT];
 #pragma unroll
-                for (int j = 0; j < MT; ++j) Bf[j] = __builtin_bit_cast(f16x8, lf[(size_t)(k0 + j) * MT * 64]);
+                for (int j = 0; j < MT; ++j) Bf[j] = __builtin_bit_cast(X8, lf[(size_t)(k0 + j) * MT * 64]);
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
-                    if (k0 + j < ks_n) Y = mfma32(Uh[(k0 + j) >> 1][(k0 + j) & 1], Bf[j], Y);
+                    if (k0 + j < ks_n) Y = fq_mfma32<T>(Uh[(k0 + j) >> 1][(k0 + j) & 1], Bf[j], Y);
             }
             if (ps != 0.0f) {  // (fq_kron_quant_ex_f16)
 #pragma unroll
@@ -284,7 +283,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
             }
             if (flags & FQ_ROUND_Y_F16) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) Y[r] = (float)(f16)Y[r];
+                for (int r = 0; r < 16; ++r) Y[r] = (float)(T)Y[r];
             }
             return Y;
         };
@@ -322,20 +321,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
         }
 
         // ---- fp16 outputs (transform / fake-quant) are staged dense [M][N] in xs, then streamed out ----
-        f16* stage = reinterpret_cast<f16*>(smem);
+        T* stage = reinterpret_cast<T*>(smem);
         if (flags & FQ_OUT_TRANSFORM) {
             if (nt < NT) {
 #pragma unroll 1
                 for (int mo = 0; mo < MT; ++mo) {
                     const f32x16 Y = row_tile(mo);
                     if (nvalid > 0 && (mo * 32 + c) < M) {
-                        f16x8 v0, v1;
+                        X8 v0, v1;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            v0[e] = (f16)Y[e];
-                            v1[e] = (f16)Y[8 + e];
+                            v0[e] = (T)Y[e];
+                            v1[e] = (T)Y[8 + e];
                         }
-                        gen_put_run16(stage + (mo * 32 + c) * N + n0, v0, v1, nvalid);
+                        gen_put_run16<T>(stage + (mo * 32 + c) * N + n0, v0, v1, nvalid);
                     }
                 }
             }
@@ -348,8 +347,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
             if (!(flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT))) break;
             float scale, sig_max, sig_min;
             fq_token_sigs(out, ci, tok, gcur, sig_max, sig_min);
-            if (flags & FQ_QUANT_F16) scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, sig_max, sig_min, flags);
-            else scale = fq_token_scale<0>(vmax, vmin, sig_max, sig_min, flags);
+            if (flags & FQ_QUANT_F16) scale = fq_token_scale<FQ_QUANT_F16, T>(vmax, vmin, sig_max, sig_min, flags);
+            else scale = fq_token_scale<0, T>(vmax, vmin, sig_max, sig_min, flags);
             const float inv = fq_fast_inv(scale);
             const bool magic = !(flags & FQ_QUANT_F16) && fq_magic_ok(vmax, vmin, inv);
             if (nt < NT) {
@@ -360,7 +359,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
                     float qv[16];
                     if (flags & FQ_QUANT_F16) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) qv[r] = (float)fq_quant1<FQ_QUANT_F16>(Y[r], scale);
+                        for (int r = 0; r < 16; ++r) qv[r] = (float)fq_quant1<FQ_QUANT_F16, T>(Y[r], scale);
                     } else {
                         float dmax = 1.0f;  // !magic: quotients too large for the fast rounding -> the true division
                         if (magic) {
@@ -380,24 +379,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
                         gen_put_run8(obuf + (mo * 32 + c) * (N >> 1) + (n0 >> 1), pk, nvalid >> 1);
                     }
                     if (ok && (flags & FQ_OUT_FAKEQUANT)) {
-                        f16x8 v0, v1;
+                        X8 v0, v1;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             if (flags & FQ_QUANT_F16) {
-                                v0[e] = fq_dequant1<FQ_QUANT_F16>((int)qv[e], scale);
-                                v1[e] = fq_dequant1<FQ_QUANT_F16>((int)qv[8 + e], scale);
+                                v0[e] = fq_dequant1<FQ_QUANT_F16, T>((int)qv[e], scale);
+                                v1[e] = fq_dequant1<FQ_QUANT_F16, T>((int)qv[8 + e], scale);
                             } else {
-                                v0[e] = fq_fake_f16(scale, qv[e]);
-                                v1[e] = fq_fake_f16(scale, qv[8 + e]);
+                                v0[e] = fq_fake<T>(scale, qv[e]);
+                                v1[e] = fq_fake<T>(scale, qv[8 + e]);
                             }
                         }
-                        gen_put_run16(stage + (mo * 32 + c) * N + n0, v0, v1, nvalid);
+                        gen_put_run16<T>(stage + (mo * 32 + c) * N + n0, v0, v1, nvalid);
                     }
                 }
             }
             __syncthreads();
             if (flags & FQ_OUT_PACKED) {
-                if (tid == 0) out.scale[ci][tok] = (f16)scale;
+                if (tid == 0) reinterpret_cast<T*>(out.scale[ci])[tok] = (T)scale;
                 gen_copy_out(out.q[ci] + tok * (d >> 1), obuf, (int)(d >> 1), tid, THREADS);
             }
             if (flags & FQ_OUT_FAKEQUANT)
@@ -414,14 +413,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fq_kron_general_kernel(const f1
 
 #undef FQ_GEN_PF
 
-template <int MT, int WAVES, bool LLDS>
-int launch_general_l(int flags, const f16* x, const uint4* ws, const f16* diag, int64_t rows, const GenGeom& g,
+template <int MT, int WAVES, bool LLDS, typename T>
+int launch_general_l(int flags, const T* x, const uint4* ws, const T* diag, int64_t rows, const GenGeom& g,
                    const FqQuantOut& out, int n_cu, hipStream_t stream) {
     const size_t xs_bytes = (size_t)MT * 32 * g.pitch * 16;
     const size_t ob = ((size_t)g.M * g.N / 2 + 15) & ~(size_t)15;
     const size_t lds = xs_bytes + ob + 2 * WAVES * sizeof(float) + 48 + (LLDS ? (size_t)2 * MT * MT * 1024 : 0);
     if (lds > 160 * 1024) return -1000;
-    auto kern = fq_kron_general_kernel<MT, WAVES, LLDS>;
+    auto kern = fq_kron_general_kernel<MT, WAVES, LLDS, T>;
     FQ_RAISE_LDS_CAP(kern, 160 * 1024);
     int per_cu = (int)((160 * 1024) / lds);  // workgroups that fit a CU's LDS: they overlap each other's synchronous token load
     const int cap = WAVES == 4 ? 4 : 2;
@@ -434,11 +433,11 @@ int launch_general_l(int flags, const f16* x, const uint4* ws, const f16* diag, 
     return (int)hipGetLastError();
 }
 
-template <int MT, int WAVES>
-int launch_general(int flags, const f16* x, const uint4* ws, const f16* diag, int64_t rows, const GenGeom& g,
+template <int MT, int WAVES, typename T>
+int launch_general(int flags, const T* x, const uint4* ws, const T* diag, int64_t rows, const GenGeom& g,
                    const FqQuantOut& out, int n_cu, hipStream_t stream) {
-    const int rc = launch_general_l<MT, WAVES, true>(flags, x, ws, diag, rows, g, out, n_cu, stream);  // L image in LDS if it fits
-    return rc != -1000 ? rc : launch_general_l<MT, WAVES, false>(flags, x, ws, diag, rows, g, out, n_cu, stream);
+    const int rc = launch_general_l<MT, WAVES, true, T>(flags, x, ws, diag, rows, g, out, n_cu, stream);  // L image in LDS if it fits
+    return rc != -1000 ? rc : launch_general_l<MT, WAVES, false, T>(flags, x, ws, diag, rows, g, out, n_cu, stream);
 }
 
 }  // namespace
@@ -457,10 +456,22 @@ int fq_launch_kron_general(int flags, const f16* x, const void* ws, const f16* d
     g.pitch = (g.KS1 * 2) | 1;
     const int MT = (M + 31) / 32;
     const uint4* w = reinterpret_cast<const uint4*>(ws);
+    if (flags & FQ_DT_BF16) {
+        flags &= ~FQ_DT_BF16;
+        const bf16* xb = (const bf16*)x;
+        const bf16* db = (const bf16*)diag;
+#define FQ_GNB(MT_)                                                                                              \
+    if (MT == MT_)                                                                                               \
+        return g.NT <= 4 ? launch_general<MT_, 4, bf16>(flags, xb, w, db, rows, g, out, n_cu, stream)            \
+                         : launch_general<MT_, 8, bf16>(flags, xb, w, db, rows, g, out, n_cu, stream);
+        FQ_GNB(1) FQ_GNB(2) FQ_GNB(3) FQ_GNB(4) FQ_GNB(5) FQ_GNB(6) FQ_GNB(7) FQ_GNB(8)
+#undef FQ_GNB
+        return -1000;
+    }
 #define FQ_GN(MT_)                                                                                        \
     if (MT == MT_)                                                                                        \
-        return g.NT <= 4 ? launch_general<MT_, 4>(flags, x, w, diag, rows, g, out, n_cu, stream)          \
-                         : launch_general<MT_, 8>(flags, x, w, diag, rows, g, out, n_cu, stream);
+        return g.NT <= 4 ? launch_general<MT_, 4, f16>(flags, x, w, diag, rows, g, out, n_cu, stream)     \
+                         : launch_general<MT_, 8, f16>(flags, x, w, diag, rows, g, out, n_cu, stream);
     FQ_GN(1) FQ_GN(2) FQ_GN(3) FQ_GN(4) FQ_GN(5) FQ_GN(6) FQ_GN(7) FQ_GN(8)
 #undef FQ_GN
     return -1000;

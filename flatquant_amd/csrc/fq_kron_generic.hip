@@ -31,9 +31,6 @@ static constexpr bool fq_measure_env(const char*) { return false; }
 
 namespace {
 
-__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
 
 struct KronGeom {
     int M, N;        // factor sizes
@@ -93,10 +90,12 @@ __global__ void fq_kron_prepare_kernel(const f16* __restrict__ left, const f16* 
 // instantiations: KS1 / NT describe N padded to whole K-steps, the token is staged in 8-byte units (a 16-byte chunk would
 // straddle two rows), the last 16-column run of a row is cut by N (extrema and stores take its valid part) and rows of the
 // packed stage (N / 2 = 74 bytes) are written in 2-byte pieces.
-template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1, int NV = 0>
-__global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fast_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
-                                                           const f16* __restrict__ diag, int64_t rows, int M, int /*N*/,
+template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1, int NV = 0, typename T = f16>
+__global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fast_kernel(const T* __restrict__ x, const uint4* __restrict__ ws,
+                                                           const T* __restrict__ diag, int64_t rows, int M, int /*N*/,
                                                            FqQuantOut out, int flags_rt) {
+    typedef typename FqVec<T>::x8 X8;
+    static_assert(FqVec<T>::is_f16 || (!SILU && CTF < 0 && NV == 0), "bf16: the all-output-sets instantiation only");
     const int flags = CTF >= 0 ? (CTF | (flags_rt & (FQ_ROUND_Y_F16 | FQ_NO_CLAMP0 | FQ_SIG_F16 | 0xF000))) : flags_rt;
     constexpr int N = NV ? NV : KS1 * 16;          // N % 16 == 0 unless NV says otherwise, so KS1 fixes N
     constexpr bool ODD = NV != 0;
@@ -126,13 +125,13 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
     const uint4* lsrc = ws + (size_t)NT * KS1 * 64;
     for (int i = tid; i < LFR; i += THREADS) lfr[i] = lsrc[i];
     for (int i = tid; i < XS_CHUNKS; i += THREADS) xs[i] = make_uint4(0, 0, 0, 0);  // padding stays zero
-    f16x8 RF[TPW][KS1];
+    X8 RF[TPW][KS1];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int nt = wave + WAVES * t;
 #pragma unroll
         for (int s = 0; s < KS1; ++s)
-            RF[t][s] = nt < NT ? __builtin_bit_cast(f16x8, ws[((size_t)nt * KS1 + s) * 64 + lane]) : f16x8{0};
+            RF[t][s] = nt < NT ? __builtin_bit_cast(X8, ws[((size_t)nt * KS1 + s) * 64 + lane]) : __builtin_bit_cast(X8, u32x4{0, 0, 0, 0});
     }
     // Make the R fragments "arrived" in the compiler's bookkeeping HERE: otherwise it covers their first use inside
     // the token loop with an s_waitcnt vmcnt(n), and that counter also sees the hand-issued prefetch loads in flight
@@ -219,11 +218,11 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                 const int q = q0 + THREADS * k;
                 if (q < n_chunks) {
                     uint4 v = __builtin_bit_cast(uint4, PF[k]);
-                    if (SILU)
+                    if constexpr (SILU)
                         v = __builtin_bit_cast(uint4, fq_silu_mul8(__builtin_bit_cast(f16x8, PF[k]),
                                                                    __builtin_bit_cast(f16x8, PF2[k])));
                     if (diag != nullptr)
-                        v = __builtin_bit_cast(uint4, __builtin_bit_cast(f16x8, v) * __builtin_bit_cast(f16x8, dp[q]));
+                        v = __builtin_bit_cast(uint4, __builtin_bit_cast(X8, v) * __builtin_bit_cast(X8, dp[q]));
                     const int row = q / cpr, ch = q - row * cpr;
                     xs[row * PITCH + ch] = v;
                 }
@@ -246,42 +245,42 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                 // with a scheduling barrier per step: left alone, hipcc hoists ALL fragment reads of a GEMM (128
                 // VGPRs each) in front of its first MFMA and spills.
                 f32x16 U[MT];
-                f16x8 A[2][MT];
+                X8 A[2][MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     U[mt] = f32x16{0};
-                    A[0][mt] = __builtin_bit_cast(f16x8, xs[(mt * 32 + c) * PITCH + h]);
+                    A[0][mt] = __builtin_bit_cast(X8, xs[(mt * 32 + c) * PITCH + h]);
                 }
 #pragma unroll
                 for (int s = 0; s < KS1; ++s) {
                     if (s + 1 < KS1) {
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            A[(s + 1) & 1][mt] = __builtin_bit_cast(f16x8, xs[(mt * 32 + c) * PITCH + (s + 1) * 2 + h]);
+                            A[(s + 1) & 1][mt] = __builtin_bit_cast(X8, xs[(mt * 32 + c) * PITCH + (s + 1) * 2 + h]);
                     }
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) U[mt] = mfma32(A[s & 1][mt], RF[t][s], U[mt]);
+                    for (int mt = 0; mt < MT; ++mt) U[mt] = fq_mfma32<T>(A[s & 1][mt], RF[t][s], U[mt]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                f16x8 Uh[MT][2];
+                X8 Uh[MT][2];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int p = 0; p < 2; ++p)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) Uh[mt][p][j] = (f16)U[mt][p * 8 + j];
-                f16x8 B[2][MT];
+                        for (int j = 0; j < 8; ++j) Uh[mt][p][j] = (T)U[mt][p * 8 + j];
+                X8 B[2][MT];
 #pragma unroll
-                for (int mo = 0; mo < MT; ++mo) B[0][mo] = __builtin_bit_cast(f16x8, mylfr[mo * 64]);
+                for (int mo = 0; mo < MT; ++mo) B[0][mo] = __builtin_bit_cast(X8, mylfr[mo * 64]);
 #pragma unroll
                 for (int ks = 0; ks < 2 * MT; ++ks) {
                     if (ks + 1 < 2 * MT) {
 #pragma unroll
                         for (int mo = 0; mo < MT; ++mo)
-                            B[(ks + 1) & 1][mo] = __builtin_bit_cast(f16x8, mylfr[((ks + 1) * MT + mo) * 64]);
+                            B[(ks + 1) & 1][mo] = __builtin_bit_cast(X8, mylfr[((ks + 1) * MT + mo) * 64]);
                     }
 #pragma unroll
-                    for (int mo = 0; mo < MT; ++mo) Y[t][mo] = mfma32(Uh[ks >> 1][ks & 1], B[ks & 1][mo], Y[t][mo]);
+                    for (int mo = 0; mo < MT; ++mo) Y[t][mo] = fq_mfma32<T>(Uh[ks >> 1][ks & 1], B[ks & 1][mo], Y[t][mo]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
         // Packed-only instantiations with the fp16 (deploy Quantizer) arithmetic: the whole epilogue runs on PACKED fp16
         // pairs H — post-scale + rounding to fp16 (the product is rounded to fp32 first, as in the generic path below),
         // extrema with v_pk_max/min_f16 — and the quantiser takes the pairs (fq_quant8_h16). Same bits as the generic path.
-        constexpr bool H16 = CTF == (FQ_OUT_PACKED | FQ_QUANT_F16);
+        constexpr bool H16 = CTF == (FQ_OUT_PACKED | FQ_QUANT_F16) && FqVec<T>::is_f16;
         uint32_t H[H16 ? TPW : 1][H16 ? MT : 1][8];
         float vmax = -INFINITY, vmin = INFINITY;
         if (H16) {
@@ -334,7 +333,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
 #pragma unroll
                 for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Y[t][mo][r] = (float)(f16)Y[t][mo][r];
+                    for (int r = 0; r < 16; ++r) Y[t][mo][r] = (float)(T)Y[t][mo][r];
         }
 
         // ---- per-token extrema over the VALID entries (padding rows/columns are excluded) ----
@@ -379,7 +378,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
         }
 
         // ---- fp16 outputs (transform / fake-quant) are staged dense [M][N] in xs, then streamed out ----
-        f16* stage = reinterpret_cast<f16*>(xs);
+        T* stage = reinterpret_cast<T*>(xs);
         if (flags & FQ_OUT_TRANSFORM) {
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
@@ -387,11 +386,11 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
 #pragma unroll
                 for (int mo = 0; mo < MT; ++mo)
                     if (nt < NT && n0 < N && (mo * 32 + c) < M) {
-                        f16x8 v0, v1;
+                        X8 v0, v1;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            v0[e] = (f16)Y[t][mo][e];
-                            v1[e] = (f16)Y[t][mo][8 + e];
+                            v0[e] = (T)Y[t][mo][e];
+                            v1[e] = (T)Y[t][mo][8 + e];
                         }
                         uint4* sp = reinterpret_cast<uint4*>(stage + (mo * 32 + c) * N + n0);
                         sp[0] = __builtin_bit_cast(uint4, v0);
@@ -408,8 +407,8 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
             if (!(flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT))) break;
             float scale, sig_max = out.sig_max[ci], sig_min = out.sig_min[ci];
             if (!SILU) fq_token_sigs(out, ci, tok, gcur, sig_max, sig_min);  // (the SiLU.mul launches are never grouped)
-            if (flags & FQ_QUANT_F16) scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, sig_max, sig_min, flags);
-            else scale = fq_token_scale<0>(vmax, vmin, sig_max, sig_min, flags);
+            if (flags & FQ_QUANT_F16) scale = fq_token_scale<FQ_QUANT_F16, T>(vmax, vmin, sig_max, sig_min, flags);
+            else scale = fq_token_scale<0, T>(vmax, vmin, sig_max, sig_min, flags);
             const float inv = fq_fast_inv(scale);
             const f32x2 inv2 = {inv, inv};
             const bool magic = !(flags & FQ_QUANT_F16) && fq_magic_ok(vmax, vmin, inv);
@@ -494,8 +493,8 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             if (flags & FQ_QUANT_F16)
-                                qp[j] = f32x2{(float)fq_quant1<FQ_QUANT_F16>(yv[2 * j], scale),
-                                              (float)fq_quant1<FQ_QUANT_F16>(yv[2 * j + 1], scale)};
+                                qp[j] = f32x2{(float)fq_quant1<FQ_QUANT_F16, T>(yv[2 * j], scale),
+                                              (float)fq_quant1<FQ_QUANT_F16, T>(yv[2 * j + 1], scale)};
                             else
                                 qp[j] = f32x2{fq_qexact(yv[2 * j], scale), fq_qexact(yv[2 * j + 1], scale)};
                         }
@@ -507,17 +506,17 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                         *reinterpret_cast<uint2*>(obuf + (mo * 32 + c) * (N >> 1) + (n0 >> 1)) = pk;
                     }
                     if (ok && (flags & FQ_OUT_FAKEQUANT)) {
-                        f16x8 v0, v1;
+                        X8 v0, v1;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const float q0 = (e & 1) ? qp[e >> 1].y : qp[e >> 1].x;
                             const float q1 = (e & 1) ? qp[4 + (e >> 1)].y : qp[4 + (e >> 1)].x;
                             if (flags & FQ_QUANT_F16) {
-                                v0[e] = fq_dequant1<FQ_QUANT_F16>((int)q0, scale);
-                                v1[e] = fq_dequant1<FQ_QUANT_F16>((int)q1, scale);
+                                v0[e] = fq_dequant1<FQ_QUANT_F16, T>((int)q0, scale);
+                                v1[e] = fq_dequant1<FQ_QUANT_F16, T>((int)q1, scale);
                             } else {
-                                v0[e] = fq_fake_f16(scale, q0);
-                                v1[e] = fq_fake_f16(scale, q1);
+                                v0[e] = fq_fake<T>(scale, q0);
+                                v1[e] = fq_fake<T>(scale, q1);
                             }
                         }
                         uint4* sp = reinterpret_cast<uint4*>(stage + (mo * 32 + c) * N + n0);
@@ -528,7 +527,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
             }
             __syncthreads();
             if (flags & FQ_OUT_PACKED) {
-                if (tid == 0) out.scale[ci][tok] = (f16)scale;
+                if (tid == 0) reinterpret_cast<T*>(out.scale[ci])[tok] = (T)scale;
                 uint4* qp4 = reinterpret_cast<uint4*>(out.q[ci] + tok * (d >> 1));
                 for (int q = tid; q < (M * N) / 32; q += THREADS) qp4[q] = reinterpret_cast<const uint4*>(obuf)[q];
             }
@@ -547,13 +546,13 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
     }
 }
 
-template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1, int NV = 0>
-int launch_fast(int flags, const f16* x, const uint4* ws, const f16* diag, int64_t rows, int M, int N,
+template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1, int NV = 0, typename T = f16>
+int launch_fast(int flags, const T* x, const uint4* ws, const T* diag, int64_t rows, int M, int N,
                 const FqQuantOut& out, int n_cu, hipStream_t stream) {
     constexpr int PITCH = (KS1 * 2) | 1;
     const size_t lds = (size_t)2 * MT * MT * 1024 + (size_t)MT * 32 * PITCH * 16 + (((size_t)M * N / 2 + 15) & ~(size_t)15) + 128;
     if (lds > 160 * 1024) return -1000;
-    auto kern = fq_kron_fast_kernel<MT, NT, KS1, WAVES, OCC, SILU, CTF, NV>;
+    auto kern = fq_kron_fast_kernel<MT, NT, KS1, WAVES, OCC, SILU, CTF, NV, T>;
     FQ_RAISE_LDS_CAP(kern, 160 * 1024);
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > OCC) per_cu = OCC;
@@ -572,7 +571,7 @@ int fq_launch_kron_wave(int flags, const f16* x, const void* ws, const f16* diag
 int fq_launch_kron_trio(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
                         const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_trio.hip
 int fq_launch_kron_general(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
-                           const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_general.hip
+                           const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_general.hip (FQ_DT_BF16 in flags: bf16)
 
 static inline int tiles32(int n) { return (n + 31) / 32; }
 
@@ -589,10 +588,47 @@ int fq_launch_kron_prepare(const f16* left, const f16* right, int M, int N, void
     return (int)hipGetLastError();
 }
 
+// bf16 activations (the path-A surface: kronecker_matmul, {Inv,SVD}DecomposeTransMatrix, the fake-quant contract): the
+// all-output-sets instantiation of the workgroup-per-token kernel for the factor pairs of the supported model families,
+// fq_kron_general.hip for every other pair. The packed-only kernel families (wave / trio / compile-time output sets) and the
+// SiLU.mul / post-scale forms are the deploy contract, which is fp16-only in the reference (deploy/kernels/*.py assert it).
+static int launch_kron_generic_bf16(int flags, const bf16* x, const bf16* left, const bf16* right, const bf16* diag,
+                                    int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
+                                    int64_t workspace_bytes, int n_cu, hipStream_t stream) {
+    if (flags & (FQ_IN_SILU_MUL | FQ_IN_RMSNORM)) return -1000;
+    if (out.post_scale != 0.0f || (out.rt_flags & FQ_GROUP128)) return -1000;
+    flags &= ~FQ_NO_WAVE_KERNEL;
+    if (!workspace || workspace_bytes < fq_kron_generic_workspace_bytes(M, N)) return -1001;
+    const int MT = tiles32(M), NT = tiles32(N), KS1 = (N + 15) / 16;
+    uint4* ws = reinterpret_cast<uint4*>(workspace);
+    if (!(flags & FQ_WS_PREPARED)) {  // the fragment image is a re-arrangement of 16-bit words: the same kernel for both types
+        const int rc = fq_launch_kron_prepare((const f16*)left, (const f16*)right, M, N, workspace, stream);
+        if (rc != 0) return rc;
+    }
+    flags &= ~FQ_WS_PREPARED;
+    const bool spec = !(N & 15) && M <= 192 && !((M * N / 2) & 15);
+    if (spec) {
+        int rc;
+#define FQ_FB(MT_, NT_, KS1_, W_, OCC_)                                                                                       \
+    if (MT == MT_ && NT == NT_ && KS1 == KS1_) {                                                                              \
+        rc = launch_fast<MT_, NT_, KS1_, W_, OCC_, false, -1, 0, bf16>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);     \
+        if (rc != -1000) return rc;                                                                                           \
+    }
+        FQ_FB(2, 4, 8, 4, 2) FQ_FB(4, 4, 8, 4, 2) FQ_FB(3, 4, 8, 4, 2) FQ_FB(4, 7, 14, 8, 1) FQ_FB(2, 4, 7, 4, 2)
+        FQ_FB(1, 2, 4, 4, 4) FQ_FB(2, 2, 4, 4, 2) FQ_FB(2, 3, 5, 4, 2) FQ_FB(4, 5, 9, 8, 1) FQ_FB(3, 4, 7, 4, 2) FQ_FB(1, 2, 3, 4, 4)
+        FQ_FB(5, 6, 12, 8, 1) FQ_FB(6, 6, 11, 8, 1)
+#undef FQ_FB
+    }
+    return fq_launch_kron_general(flags | FQ_DT_BF16, (const f16*)x, ws, (const f16*)diag, rows, M, N, out, n_cu, stream);
+}
+
 int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream) {
     if (M < 1 || N < 2 || (N & 1) || M > 256 || N > 256 || (int64_t)M * N > 32768) return -1000;
+    if (flags & FQ_DT_BF16)
+        return launch_kron_generic_bf16(flags & ~FQ_DT_BF16, (const bf16*)x, (const bf16*)left, (const bf16*)right, (const bf16*)diag,
+                                        rows, M, N, out, workspace, workspace_bytes, n_cu, stream);
     // the specialised kernels below: N in whole K-steps, M <= 192, 16-byte packed tokens; every other pair: fq_kron_general.hip
     const bool spec = !(N & 15) && M <= 192 && !((M * N / 2) & 15);
     const bool no_wave = (flags & FQ_NO_WAVE_KERNEL) != 0 || out.post_scale != 0.0f;  // (the wave kernels take no post_scale)

@@ -11,36 +11,65 @@
 
 namespace {
 
+// Running extrema of the 16-byte chunks a lane holds. fp16: packed pairs (v_pk_max/min_f16, exact: the data is fp16);
+// bf16: each dword's halves widened to fp32 (one shift, one and) and v_max3 / v_min3_f32.
+template <typename T> struct RowExtrema;
+template <> struct RowExtrema<f16> {
+    f16x2 pmax = {(f16)-INFINITY, (f16)-INFINITY}, pmin = {(f16)INFINITY, (f16)INFINITY};
+    __device__ __forceinline__ void take(const f16x8& v) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const f16x2 pr = {v[e], v[e + 1]};
+            pmax = fq_pk_max(pmax, pr);
+            pmin = fq_pk_min(pmin, pr);
+        }
+    }
+    __device__ __forceinline__ float vmax() const { return fmaxf((float)pmax[0], (float)pmax[1]); }
+    __device__ __forceinline__ float vmin() const { return fminf((float)pmin[0], (float)pmin[1]); }
+};
+template <> struct RowExtrema<bf16> {
+    float mx = -INFINITY, mn = INFINITY;
+    __device__ __forceinline__ void take(const bf16x8& v) {
+        const u32x4 w = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float lo, hi;
+            fq_bf16_pair(w[k], lo, hi);
+            mx = fq_max3(mx, lo, hi);
+            mn = fq_min3(mn, lo, hi);
+        }
+    }
+    __device__ __forceinline__ float vmax() const { return mx; }
+    __device__ __forceinline__ float vmin() const { return mn; }
+};
+
 constexpr int RQ_THREADS = 256;
 constexpr int RQ_MAXCH = 16;  // 16-byte chunks per thread: cols <= 256 * 16 * 8 = 32768
 
 // One workgroup per row; each thread keeps its 16-byte chunks (8 fp16) in registers.
-template <int FLAGS, int NCH>
-__global__ __launch_bounds__(RQ_THREADS) void fq_rowquant_kernel(const f16* __restrict__ x, int64_t rows,
+template <int FLAGS, int NCH, typename T = f16>
+__global__ __launch_bounds__(RQ_THREADS) void fq_rowquant_kernel(const T* __restrict__ x, int64_t rows,
                                                                  int cols, FqQuantOut out) {
+    typedef typename FqVec<T>::x8 X8;
+    constexpr bool IS16 = FqVec<T>::is_f16;
     __shared__ float red[2][RQ_THREADS / 64];
     const int tid = threadIdx.x;
     const int nchunks = cols >> 3;  // cols % 8 == 0 enforced by the host
     for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         const uint4* xp = reinterpret_cast<const uint4*>(x + row * (int64_t)cols);
-        f16x8 v[NCH];
+        X8 v[NCH];
         float vmax = -INFINITY, vmin = INFINITY;
-        f16x2 pmax = {(f16)-INFINITY, (f16)-INFINITY}, pmin = {(f16)INFINITY, (f16)INFINITY};
+        RowExtrema<T> ext;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int ch = tid + k * RQ_THREADS;
             if (ch < nchunks) {
-                v[k] = __builtin_bit_cast(f16x8, xp[ch]);
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {  // extrema on packed fp16 pairs (exact: the data is fp16)
-                    const f16x2 pr = {v[k][e], v[k][e + 1]};
-                    pmax = fq_pk_max(pmax, pr);
-                    pmin = fq_pk_min(pmin, pr);
-                }
+                v[k] = __builtin_bit_cast(X8, xp[ch]);
+                ext.take(v[k]);
             }
         }
-        vmax = fq_wave_max(fmaxf((float)pmax[0], (float)pmax[1]));
-        vmin = fq_wave_min(fminf((float)pmin[0], (float)pmin[1]));
+        vmax = fq_wave_max(ext.vmax());
+        vmin = fq_wave_min(ext.vmin());
         __syncthreads();  // protect `red` against the previous iteration's readers
         if ((tid & 63) == 0) {
             red[0][tid >> 6] = vmax;
@@ -51,25 +80,25 @@ __global__ __launch_bounds__(RQ_THREADS) void fq_rowquant_kernel(const f16* __re
         vmin = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
 
         for (int ci = 0; ci < out.n_clips; ++ci) {
-            const float scale = fq_token_scale<FLAGS>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
+            const float scale = fq_token_scale<FLAGS, T>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
             const float h16_inv = fq_fast_inv(scale);
             const bool h16_clamp = fq_h16_needs_clamp(vmax, vmin, h16_inv);
             if (FLAGS & FQ_OUT_PACKED) {
-                if (tid == 0) out.scale[ci][row] = (f16)scale;
+                if (tid == 0) reinterpret_cast<T*>(out.scale[ci])[row] = (T)scale;
                 uint32_t* qp = reinterpret_cast<uint32_t*>(out.q[ci] + row * (int64_t)(cols >> 1));
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
                     const int ch = tid + k * RQ_THREADS;
                     if (ch < nchunks) {
                         uint32_t d = 0;
-                        if (FLAGS & FQ_QUANT_F16) {   // packed pairs, exact fp16 quotient without a division (fq_quant8_h16)
+                        if ((FLAGS & FQ_QUANT_F16) && IS16) {   // packed pairs, exact fp16 quotient without a division (fq_quant8_h16)
                             const u32x4 xv = __builtin_bit_cast(u32x4, v[k]);
                             d = h16_clamp ? fq_quant8_h16<true>(xv[0], xv[1], xv[2], xv[3], h16_inv, scale)
                                           : fq_quant8_h16<false>(xv[0], xv[1], xv[2], xv[3], h16_inv, scale);
                         } else {
 #pragma unroll
                             for (int e = 0; e < 8; ++e)
-                                d |= (uint32_t)(fq_quant1<FLAGS>((float)v[k][e], scale) & 15) << (4 * e);
+                                d |= (uint32_t)(fq_quant1<FLAGS, T>((float)v[k][e], scale) & 15) << (4 * e);
                         }
                         qp[ch] = d;
                     }
@@ -81,11 +110,11 @@ __global__ __launch_bounds__(RQ_THREADS) void fq_rowquant_kernel(const f16* __re
                 for (int k = 0; k < NCH; ++k) {
                     const int ch = tid + k * RQ_THREADS;
                     if (ch < nchunks) {
-                        f16x8 o;
+                        X8 o;
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
-                            o[e] = fq_dequant1<FLAGS>((FLAGS & FQ_QUANT_F16) ? fq_quant1_h(v[k][e], (f16)scale)
-                                                                             : fq_quant1<FLAGS>((float)v[k][e], scale), scale);
+                            o[e] = fq_dequant1<FLAGS, T>((FLAGS & FQ_QUANT_F16) ? fq_quant1_h(v[k][e], (T)scale)
+                                                                                : fq_quant1<FLAGS, T>((float)v[k][e], scale), scale);
                         fp[ch] = __builtin_bit_cast(uint4, o);
                     }
                 }
@@ -165,13 +194,15 @@ __global__ __launch_bounds__(256) void fq_sym_dequant_kernel(const int32_t* __re
 // MULTI (short rows, cols <= 256: heads, 128-element groups): a row occupies 2^lg lanes, 64 >> lg rows per wave — one row per
 // wave would leave 3 of 4 lanes idle at cols = 128 (measured 0.6-1.1 TB/s against 3.5-3.8 with the lanes filled); the
 // extrema are reduced by xor butterflies inside the lane group and every row carries its own scale through the same epilogue.
-template <int FLAGS, int NCH, bool MULTI = false>
+template <int FLAGS, int NCH, bool MULTI = false, typename T = f16>
 // (occupancy bound for the packed fp16-quantiser builds only — the deploy Quantizer: their epilogue is 5 VALU per element on
 //  packed pairs and fits; the fp32-quantiser builds keep the compiler's own choice)
 __global__ __launch_bounds__(256, ((FLAGS & (FQ_QUANT_F16 | FQ_OUT_FAKEQUANT)) == FQ_QUANT_F16) ? (NCH > 24 ? 2 : NCH > 16 ? 3 : 4) : 1)
-void fq_rowquant_wave_kernel(const f16* __restrict__ x, int64_t rows, int cols,
+void fq_rowquant_wave_kernel(const T* __restrict__ x, int64_t rows, int cols,
                                                                FqQuantOut out, int lg) {
     static_assert(!MULTI || NCH == 1, "short rows: one chunk per lane");
+    typedef typename FqVec<T>::x8 X8;
+    constexpr bool IS16 = FqVec<T>::is_f16;
     const int wl = threadIdx.x & 63;
     const int lpr = MULTI ? (1 << lg) : 64, rpw = MULTI ? (64 >> lg) : 1;
     const int lane = MULTI ? (wl & (lpr - 1)) : wl;            // the lane's position inside its row
@@ -182,28 +213,21 @@ void fq_rowquant_wave_kernel(const f16* __restrict__ x, int64_t rows, int cols,
         const bool live = !MULTI || rown < rows;
         const int64_t row = live ? rown : rows - 1;              // (idle lane groups of the last wave re-read the last row, store nothing)
         const u32x4* xp = reinterpret_cast<const u32x4*>(x + row * (int64_t)cols);
-        f16x8 v[NCH];
+        X8 v[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int ch = lane + k * lpr;
-            v[k] = (ch < nchunks) ? __builtin_bit_cast(f16x8, __builtin_nontemporal_load(xp + ch)) : f16x8{0};
+            v[k] = __builtin_bit_cast(X8, (ch < nchunks) ? __builtin_nontemporal_load(xp + ch) : u32x4{0, 0, 0, 0});
         }
         float vmax = -INFINITY, vmin = INFINITY;
-        {   // extrema on packed fp16 pairs (the data IS fp16: exact), two values per instruction
-            f16x2 pmax = {(f16)-INFINITY, (f16)-INFINITY}, pmin = {(f16)INFINITY, (f16)INFINITY};
+        {   // extrema on packed fp16 pairs (the data IS fp16: exact), two values per instruction; bf16: RowExtrema
+            RowExtrema<T> ext;
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
-                if (lane + k * lpr < nchunks) {
-#pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        const f16x2 pr = {v[k][e], v[k][e + 1]};
-                        pmax = fq_pk_max(pmax, pr);
-                        pmin = fq_pk_min(pmin, pr);
-                    }
-                }
+                if (lane + k * lpr < nchunks) ext.take(v[k]);
             }
-            vmax = fmaxf((float)pmax[0], (float)pmax[1]);
-            vmin = fminf((float)pmin[0], (float)pmin[1]);
+            vmax = ext.vmax();
+            vmin = ext.vmin();
         }
         if (MULTI) {
             for (int m = 1; m < lpr; m <<= 1) {
@@ -215,20 +239,24 @@ void fq_rowquant_wave_kernel(const f16* __restrict__ x, int64_t rows, int cols,
             vmin = fq_wave_min(vmin);
         }
         for (int ci = 0; ci < out.n_clips; ++ci) {
-            const float scale = fq_token_scale<FLAGS>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
+            const float scale = fq_token_scale<FLAGS, T>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
             const float inv = fq_fast_inv(scale);
             const bool h16_clamp = fq_h16_needs_clamp(vmax, vmin, inv);
             if (FLAGS & FQ_OUT_PACKED) {
-                if (lane == 0 && live) out.scale[ci][row] = (f16)scale;
+                if (lane == 0 && live) reinterpret_cast<T*>(out.scale[ci])[row] = (T)scale;
                 uint32_t* qp = reinterpret_cast<uint32_t*>(out.q[ci] + row * (int64_t)(cols >> 1));
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
                     const int ch = lane + k * lpr;
                     uint32_t d;
-                    if (FLAGS & FQ_QUANT_F16) {
+                    if ((FLAGS & FQ_QUANT_F16) && IS16) {
                         const u32x4 xv = __builtin_bit_cast(u32x4, v[k]);   // packed pairs, exact fp16 quotient (fq_quant8_h16)
                         d = h16_clamp ? fq_quant8_h16<true>(xv[0], xv[1], xv[2], xv[3], inv, scale)
                                       : fq_quant8_h16<false>(xv[0], xv[1], xv[2], xv[3], inv, scale);
+                    } else if (FLAGS & FQ_QUANT_F16) {   // bf16 arithmetic: the quotient rounded to bf16, element by element
+                        d = 0;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) d |= (uint32_t)(fq_quant1_h(v[k][e], (T)scale) & 15) << (4 * e);
                     } else {
                         float dmax = 0.0f;
                         const f32x2 inv2 = {inv, inv};
@@ -251,11 +279,11 @@ void fq_rowquant_wave_kernel(const f16* __restrict__ x, int64_t rows, int cols,
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
                     const int ch = lane + k * lpr;
-                    f16x8 o;
+                    X8 o;
                     if (FLAGS & FQ_QUANT_F16) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
-                            o[e] = fq_dequant1<FLAGS>(fq_quant1_h(v[k][e], (f16)scale), scale);
+                            o[e] = fq_dequant1<FLAGS, T>(fq_quant1_h(v[k][e], (T)scale), scale);
                     } else {
                         float dmax = 0.0f;
                         float r[8];
@@ -266,7 +294,7 @@ void fq_rowquant_wave_kernel(const f16* __restrict__ x, int64_t rows, int cols,
                             for (int e = 0; e < 8; ++e) r[e] = fq_qexact((float)v[k][e], scale);
                         }
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = fq_fake_f16(scale, r[e]);
+                        for (int e = 0; e < 8; ++e) o[e] = fq_fake<T>(scale, r[e]);
                     }
                     if (ch < nchunks && live) fp[ch] = __builtin_bit_cast(uint4, o);
                 }
@@ -309,8 +337,8 @@ __global__ __launch_bounds__(256) void fq_rmsnorm_kernel(const f16* __restrict__
     }
 }
 
-template <int FLAGS>
-int launch_rowquant(const f16* x, int64_t rows, int cols, const FqQuantOut& out, int n_cu,
+template <int FLAGS, typename T>
+int launch_rowquant(const T* x, int64_t rows, int cols, const FqQuantOut& out, int n_cu,
                     hipStream_t stream) {
     if ((cols >> 3) <= 32) {   // short rows: several rows per wave (2^lg lanes each)
         int lg = 0;
@@ -319,7 +347,7 @@ int launch_rowquant(const f16* x, int64_t rows, int cols, const FqQuantOut& out,
         int64_t wb = ((rows + rpw - 1) / rpw + 3) / 4;
         if (wb > (int64_t)n_cu * 8) wb = (int64_t)n_cu * 8;
         if (wb < 1) wb = 1;
-        hipLaunchKernelGGL((fq_rowquant_wave_kernel<FLAGS, 1, true>), dim3((unsigned)wb), dim3(256), 0, stream, x, rows, cols, out, lg);
+        hipLaunchKernelGGL((fq_rowquant_wave_kernel<FLAGS, 1, true, T>), dim3((unsigned)wb), dim3(256), 0, stream, x, rows, cols, out, lg);
         return (int)hipGetLastError();
     }
     {   // wave-per-row fast path: the row fits one wave's registers (up to 32 chunks of 16 bytes per lane)
@@ -329,7 +357,7 @@ int launch_rowquant(const f16* x, int64_t rows, int cols, const FqQuantOut& out,
         if (wb < 1) wb = 1;
 #define FQ_RW(N)                                                                                                  \
     if (nchw <= (N)) {                                                                                            \
-        hipLaunchKernelGGL((fq_rowquant_wave_kernel<FLAGS, (N)>), dim3((unsigned)wb), dim3(256), 0, stream, x, rows, \
+        hipLaunchKernelGGL((fq_rowquant_wave_kernel<FLAGS, (N), false, T>), dim3((unsigned)wb), dim3(256), 0, stream, x, rows, \
                            cols, out, 6);                                                                            \
         return (int)hipGetLastError();                                                                            \
     }
@@ -345,7 +373,7 @@ int launch_rowquant(const f16* x, int64_t rows, int cols, const FqQuantOut& out,
     dim3 g((unsigned)blocks), b(RQ_THREADS);
 #define FQ_RQ(N)                                                                                 \
     if (nch <= (N)) {                                                                            \
-        hipLaunchKernelGGL((fq_rowquant_kernel<FLAGS, (N)>), g, b, 0, stream, x, rows, cols, out); \
+        hipLaunchKernelGGL((fq_rowquant_kernel<FLAGS, (N), T>), g, b, 0, stream, x, rows, cols, out); \
         return (int)hipGetLastError();                                                           \
     }
     FQ_RQ(2) FQ_RQ(4) FQ_RQ(8) FQ_RQ(RQ_MAXCH)
@@ -366,9 +394,10 @@ int launch_rowquant(const f16* x, int64_t rows, int cols, const FqQuantOut& out,
 // every operation rounds to fp16 — the extremum x factor product (fp32 opmath, then fp16: two roundings), the
 // difference, both quotients (fp16(a / b) from the correctly rounded fp32 quotient IS the correctly rounded fp16
 // quotient: 24 >= 2 * 11 + 2 bits), the product. (round_ste's (r - t) + t is r exactly in both widths.)
-template <bool F16A, int NV>
-__global__ __launch_bounds__(256) void fq_rowquant_asym_kernel(const f16* __restrict__ x, int64_t rows, int cols, int lpr_log2,
+template <bool F16A, int NV, typename T = f16>
+__global__ __launch_bounds__(256) void fq_rowquant_asym_kernel(const T* __restrict__ x, int64_t rows, int cols, int lpr_log2,
                                                                FqQuantOut out) {
+    typedef typename FqVec<T>::x8 X8;
     const int lane = threadIdx.x & 63;
     const int lpr = 1 << lpr_log2, sub = lane & (lpr - 1), rpw = 64 >> lpr_log2;
     const int nvec = cols >> 3;
@@ -377,29 +406,22 @@ __global__ __launch_bounds__(256) void fq_rowquant_asym_kernel(const f16* __rest
         const int64_t row = r0 + (lane >> lpr_log2);
         const bool live = row < rows;
         const uint4* xp = reinterpret_cast<const uint4*>(x + (live ? row : 0) * (int64_t)cols);
-        f16x8 v[NV > 0 ? NV : 1];
-        f16x2 pmax = {(f16)-INFINITY, (f16)-INFINITY}, pmin = {(f16)INFINITY, (f16)INFINITY};
-        auto take = [&](const f16x8& w) {
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const f16x2 pr = {w[e], w[e + 1]};
-                pmax = fq_pk_max(pmax, pr);
-                pmin = fq_pk_min(pmin, pr);
-            }
-        };
+        X8 v[NV > 0 ? NV : 1];
+        RowExtrema<T> ext;
+        auto take = [&](const X8& w) { ext.take(w); };
         if (NV > 0) {
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const int i = sub + k * lpr;
                 if (live && i < nvec) {
-                    v[k] = __builtin_bit_cast(f16x8, xp[i]);
+                    v[k] = __builtin_bit_cast(X8, xp[i]);
                     take(v[k]);
                 }
             }
         } else {
-            for (int i = sub; live && i < nvec; i += lpr) take(__builtin_bit_cast(f16x8, xp[i]));
+            for (int i = sub; live && i < nvec; i += lpr) take(__builtin_bit_cast(X8, xp[i]));
         }
-        float vmax = fmaxf((float)pmax[0], (float)pmax[1]), vmin = fminf((float)pmin[0], (float)pmin[1]);
+        float vmax = ext.vmax(), vmin = ext.vmin();
         for (int m = 1; m < lpr; m <<= 1) {  // the lanes of a row are an aligned group of 2^k: xor butterflies stay inside it
             vmax = fmaxf(vmax, __shfl_xor(vmax, m));
             vmin = fminf(vmin, __shfl_xor(vmin, m));
@@ -409,8 +431,8 @@ __global__ __launch_bounds__(256) void fq_rowquant_asym_kernel(const f16* __rest
         for (int ci = 0; ci < out.n_clips; ++ci) {
             float xmax, xmin;
             if (F16A) {
-                xmax = (float)fq_mul_to_f16(vmax, out.sig_max[ci]);
-                xmin = (float)fq_mul_to_f16(vmin, out.sig_min[ci]);
+                xmax = (float)fq_mul_to<T>(vmax, out.sig_max[ci]);
+                xmin = (float)fq_mul_to<T>(vmin, out.sig_min[ci]);
             } else {
                 xmax = vmax * out.sig_max[ci];
                 xmin = vmin * out.sig_min[ci];
@@ -421,9 +443,9 @@ __global__ __launch_bounds__(256) void fq_rowquant_asym_kernel(const f16* __rest
             }
             float scale, zero;
             if (F16A) {
-                const float d = (float)(f16)(xmax - xmin);
-                scale = (float)(f16)(d / 15.0f);
-                zero = __builtin_rintf((float)(f16)(-xmin / scale));
+                const float d = (float)(T)(xmax - xmin);
+                scale = (float)(T)(d / 15.0f);
+                zero = __builtin_rintf((float)(T)(-xmin / scale));
             } else {
                 const float d = xmax - xmin;
                 scale = d / 15.0f;
@@ -436,8 +458,8 @@ __global__ __launch_bounds__(256) void fq_rowquant_asym_kernel(const f16* __rest
             // with the division. u - (1.5 * 2^23 - zero) = rint(x / scale) + zero exactly (integers below 2^24).
             const float inv = fq_fast_inv(scale), ilo = fq_inv_lo(inv), ihi = fq_inv_hi(inv), cz = FQ_MAGIC - zero;
             const bool fast_ok = !F16A && fmaxf(vmax, -vmin) * inv < 2097152.0f;
-            auto emit = [&](const f16x8& w, int i) {
-                f16x8 o;
+            auto emit = [&](const X8& w, int i) {
+                X8 o;
                 if (fast_ok) {
                     float u[8];
                     bool differ = false;
@@ -451,7 +473,7 @@ __global__ __launch_bounds__(256) void fq_rowquant_asym_kernel(const f16* __rest
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const float q = __builtin_amdgcn_fmed3f(u[e] - cz, 0.0f, 15.0f);
-                            o[e] = fq_mul_to_f16(scale, q - zero);
+                            o[e] = fq_mul_to<T>(scale, q - zero);
                         }
                         op[i] = __builtin_bit_cast(uint4, o);
                         return;
@@ -460,10 +482,10 @@ __global__ __launch_bounds__(256) void fq_rowquant_asym_kernel(const f16* __rest
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float t = (float)w[e] / scale;            // correctly rounded fp32 division
-                    if (F16A) t = (float)(f16)t;
+                    if (F16A) t = (float)(T)t;
                     float q = __builtin_rintf(t) + zero;      // (integers of small magnitude: exact in either width)
                     q = __builtin_amdgcn_fmed3f(q, 0.0f, 15.0f);
-                    o[e] = fq_mul_to_f16(scale, q - zero);    // fp32 product rounded to fp32, then to fp16; F16A: the product
+                    o[e] = fq_mul_to<T>(scale, q - zero);     // fp32 product rounded to fp32, then to fp16; F16A: the product
                 }                                             // of an 11-bit by a 5-bit significand is exact in fp32
                 op[i] = __builtin_bit_cast(uint4, o);
             };
@@ -474,14 +496,14 @@ __global__ __launch_bounds__(256) void fq_rowquant_asym_kernel(const f16* __rest
                     if (live && i < nvec) emit(v[k], i);
                 }
             } else {
-                for (int i = sub; live && i < nvec; i += lpr) emit(__builtin_bit_cast(f16x8, xp[i]), i);
+                for (int i = sub; live && i < nvec; i += lpr) emit(__builtin_bit_cast(X8, xp[i]), i);
             }
         }
     }
 }
 
-template <bool F16A>
-int launch_rowquant_asym(const f16* x, int64_t rows, int cols, const FqQuantOut& out, int n_cu, hipStream_t stream) {
+template <bool F16A, typename T>
+int launch_rowquant_asym(const T* x, int64_t rows, int cols, const FqQuantOut& out, int n_cu, hipStream_t stream) {
     const int nvec = cols >> 3;
     int lg = 0;
     while (lg < 6 && (1 << lg) < nvec) ++lg;  // lanes per row: the power of two >= cols / 8, at most a wave
@@ -491,7 +513,7 @@ int launch_rowquant_asym(const f16* x, int64_t rows, int cols, const FqQuantOut&
     if (blocks > (int64_t)n_cu * 8) blocks = (int64_t)n_cu * 8;
     if (blocks < 1) blocks = 1;
 #define FQ_ASYM_LAUNCH(NV_)                                                                                             \
-    hipLaunchKernelGGL((fq_rowquant_asym_kernel<F16A, NV_>), dim3((unsigned)blocks), dim3(256), 0, stream, x, rows, cols, lg, out)
+    hipLaunchKernelGGL((fq_rowquant_asym_kernel<F16A, NV_, T>), dim3((unsigned)blocks), dim3(256), 0, stream, x, rows, cols, lg, out)
     if (per_lane <= 1) FQ_ASYM_LAUNCH(1);
     else if (per_lane <= 4) FQ_ASYM_LAUNCH(4);
     else if (per_lane <= 8) FQ_ASYM_LAUNCH(8);
@@ -502,17 +524,18 @@ int launch_rowquant_asym(const f16* x, int64_t rows, int cols, const FqQuantOut&
 
 }  // namespace
 
-int fq_launch_rowquant(int flags, const f16* x, int64_t rows, int cols, const FqQuantOut& out, int n_cu,
-                       hipStream_t stream) {
+template <typename T>
+static int launch_rowquant_any(int flags, const T* x, int64_t rows, int cols, const FqQuantOut& out, int n_cu,
+                               hipStream_t stream) {
 #define FQ_CASE(F)                                                              \
     case (F):                                                                   \
-        return launch_rowquant<(F)>(x, rows, cols, out, n_cu, stream);          \
+        return launch_rowquant<(F), T>(x, rows, cols, out, n_cu, stream);       \
     case (F) | FQ_QUANT_F16:                                                    \
-        return launch_rowquant<(F) | FQ_QUANT_F16>(x, rows, cols, out, n_cu, stream);
+        return launch_rowquant<(F) | FQ_QUANT_F16, T>(x, rows, cols, out, n_cu, stream);
     if (flags & FQ_ASYM) {  // (fq_capi admits it with FQ_OUT_FAKEQUANT alone)
         if ((flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM)) != FQ_OUT_FAKEQUANT) return -1000;
-        return (flags & FQ_QUANT_F16) ? launch_rowquant_asym<true>(x, rows, cols, out, n_cu, stream)
-                                      : launch_rowquant_asym<false>(x, rows, cols, out, n_cu, stream);
+        return (flags & FQ_QUANT_F16) ? launch_rowquant_asym<true, T>(x, rows, cols, out, n_cu, stream)
+                                      : launch_rowquant_asym<false, T>(x, rows, cols, out, n_cu, stream);
     }
     switch (flags & FQ_CT_MASK) {
         FQ_CASE(FQ_OUT_PACKED)
@@ -522,6 +545,12 @@ int fq_launch_rowquant(int flags, const f16* x, int64_t rows, int cols, const Fq
             return -1000;
     }
 #undef FQ_CASE
+}
+
+int fq_launch_rowquant(int flags, const f16* x, int64_t rows, int cols, const FqQuantOut& out, int n_cu,
+                       hipStream_t stream) {
+    if (flags & FQ_DT_BF16) return launch_rowquant_any<bf16>(flags & ~FQ_DT_BF16, (const bf16*)x, rows, cols, out, n_cu, stream);
+    return launch_rowquant_any<f16>(flags, x, rows, cols, out, n_cu, stream);
 }
 
 int fq_launch_sym_quant(const f16* x, const f16* scale, int64_t rows, int cols, uint8_t* q, int n_cu,

@@ -82,4 +82,6 @@ def _clip_rows(w: torch.Tensor, keep_max: torch.Tensor, keep_min: torch.Tensor) 
     """Learnable weight clipping: every output row is clamped to [min * keep_min, max * keep_max] ([out, 1] factors)."""
     hi = w.amax(dim=1, keepdim=True) * keep_max.to(w)
     lo = w.amin(dim=1, keepdim=True) * keep_min.to(w)
-    return torch.maximum(torch.minimum(w, hi), lo)
+    # torch.clamp(w, min=lo, max=hi) = min(max(w, lo), hi): when lo > hi (a single-signed row whose factors cross) the
+    # upper bound wins, as in the reference (flat_linear.py:91)
+    return torch.clamp(w, min=lo, max=hi)

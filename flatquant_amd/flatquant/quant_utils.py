@@ -21,7 +21,8 @@ class ActivationQuantizer(torch.nn.Module):
     Reference: flatquant/quant_utils.py:48-119.  Same constructor, parameters (``clip_factor_a_max/min``,
     shape (1,), init 4.0 when ``lac``) and attributes (``bits sym lac enable q_max q_min groupsize``).
     Arithmetic: with ``lac`` the reference's type promotion evaluates scale, x/scale and scale*q in fp32
-    (fp16 extrema x fp32 sigmoid); without it everything stays fp16 — both are reproduced (FQ_QUANT_F16).
+    (fp16 / bf16 extrema x fp32 sigmoid); without it everything stays in the activation's dtype — both are reproduced
+    (FQ_QUANT_F16), for fp16 and for bf16 activations (model_utils.py:20 torch_dtype='auto').
     4-bit only: symmetric (the activation quantisers) and asymmetric (``sym=False``: the K / V / Q cache quantisers).
     """
 
@@ -45,15 +46,19 @@ class ActivationQuantizer(torch.nn.Module):
             self.clip_factor_a_min = torch.nn.Parameter(torch.ones((1,)) * init_value, requires_grad=True)
         self.enable = True
 
-    def _lac_f16(self):
-        """lac with fp16 clip parameters (the whole module was .half()'ed): fp16 extrema x fp16 sigmoid stays fp16 in the
-        reference, and so do scale, x / scale and scale * q — the all-fp16 route, not the promoted fp32 one."""
-        return self.lac and self.clip_factor_a_max.dtype == torch.float16
+    def _lowp_params(self, x_dtype):
+        """lac whose clip parameters have the ACTIVATION's dtype (a module that was .half()'ed / .bfloat16()'ed as a whole,
+        or built under torch.set_default_dtype(bfloat16) as main_dpskv3.py:395 does): extremum x sigmoid stays in that
+        dtype in the reference, and so do scale, x / scale and scale * q — the all-low-precision route. Any other pairing
+        (fp32 parameters next to an fp16 / bf16 activation — the usual case, flat_linear.py:16 under the fp32 default dtype —
+        or fp16 parameters next to a bf16 activation) promotes to fp32."""
+        return self.lac and self.clip_factor_a_max.dtype == x_dtype
 
-    def _sig(self):
+    def _sig(self, x_dtype=torch.float16):
         if self.lac:
-            if self._lac_f16():   # torch.sigmoid of an fp16 tensor: evaluated in fp32, rounded to fp16
-                return tuple(float(torch.sigmoid(torch.tensor(ops.host_scalar(p.detach()), dtype=torch.float16)))
+            pd = self.clip_factor_a_max.dtype
+            if pd in (torch.float16, torch.bfloat16):   # torch.sigmoid of a 16-bit tensor: evaluated in fp32, rounded to it
+                return tuple(float(torch.sigmoid(torch.tensor(ops.host_scalar(p.detach()), dtype=pd)))
                              for p in (self.clip_factor_a_max, self.clip_factor_a_min))
             # fp32 sigmoid on the host; the parameters are read back once per version, not once per call
             return ops.sigmoid_pair(self.clip_factor_a_max.detach(), self.clip_factor_a_min.detach())
@@ -69,8 +74,10 @@ class ActivationQuantizer(torch.nn.Module):
     def fake_quant(self, x):
         if self.bits != 4:
             raise NotImplementedError("flatquant_amd: only 4-bit activation quantisation is on the hot path")
+        # fp16 or bf16 activations (ops.rowquant picks fq_rowquant_f16 / _bf16); FQ_QUANT_F16 / FQ_SIG_F16 mean "in the
+        # activation's dtype"
         flags = FQ_OUT_FAKEQUANT | (0 if self.lac else FQ_QUANT_F16)
-        if self._lac_f16():
+        if self._lowp_params(x.dtype):
             flags |= FQ_QUANT_F16 | FQ_SIG_F16
         if not self.lac and self._clip_ratio is not None:
             flags |= FQ_SIG_F16     # fp16 extremum x python float: an fp16 product (quant_utils.py:99-100)
@@ -80,5 +87,5 @@ class ActivationQuantizer(torch.nn.Module):
         if self.groupsize > 0:
             if x.shape[-1] % self.groupsize:
                 raise ValueError(f"last dimension {x.shape[-1]} is not a multiple of groupsize {self.groupsize}")
-            return ops.rowquant(x.contiguous().reshape(-1, self.groupsize), [self._sig()], flags).fq[0].reshape(x.shape)
-        return ops.rowquant(x.contiguous(), [self._sig()], flags).fq[0]
+            return ops.rowquant(x.contiguous().reshape(-1, self.groupsize), [self._sig(x.dtype)], flags).fq[0].reshape(x.shape)
+        return ops.rowquant(x.contiguous(), [self._sig(x.dtype)], flags).fq[0]

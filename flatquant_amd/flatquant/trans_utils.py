@@ -16,22 +16,37 @@ from .function_utils import get_init_weight, get_inverse
 
 
 class _Fp16Cache:
-    """fp16 device copies of a module's (usually fp32) matrices, made once per (parameter storage, version, device):
-    the kernels' fragment workspaces are keyed by the address and version of the matrices they were packed from, so
-    handing them a fresh .to(fp16) copy on every call would re-pack on every call (and pin every copy in that cache)."""
+    """Device copies, in the activation's dtype (fp16 / bf16), of a module's (usually fp32) matrices, made once per
+    (parameter storage, version, device, dtype): the kernels' fragment workspaces are keyed by the address and version of
+    the matrices they were packed from, so handing them a fresh .to(fp16) copy on every call would re-pack on every call
+    (and pin every copy in that cache). An entry keeps its SOURCE storage alive: a matrix replaced through ``.data =`` /
+    ``load_state_dict(assign=True)`` / ``module.to()`` can then not be given the old address (with version 0) and hit the
+    stale copy. ``ops.invalidate_caches()`` clears every instance."""
+
+    _instances = None  # weakref.WeakSet of every cache (created lazily)
 
     def __init__(self):
+        import weakref
+        if _Fp16Cache._instances is None:
+            _Fp16Cache._instances = weakref.WeakSet()
+        _Fp16Cache._instances.add(self)
         self._c = {}
 
-    def get(self, p: torch.Tensor, device) -> torch.Tensor:
-        key = (p.data_ptr(), p._version, str(device))
+    def get(self, p: torch.Tensor, device, dtype=torch.float16) -> torch.Tensor:
+        key = (p.data_ptr(), p._version, str(device), dtype)
         hit = self._c.get(key)
-        if hit is None:
-            if len(self._c) > 16:
-                self._c.clear()
-            hit = p.detach().to(device=device, dtype=torch.float16).contiguous()
-            self._c[key] = hit
-        return hit
+        if hit is not None:
+            return hit[0]
+        if len(self._c) > 16:
+            self._c.clear()
+        copy = p.detach().to(device=device, dtype=dtype).contiguous()
+        self._c[key] = (copy, p.untyped_storage())   # the storage object pins the address: it cannot be recycled under the key
+        return copy
+
+    @classmethod
+    def clear_all(cls):
+        for c in list(cls._instances or ()):
+            c._c.clear()
 
 
 class _DecomposeTransBase(nn.Module):
@@ -60,7 +75,7 @@ class _DecomposeTransBase(nn.Module):
     def forward(self, inp, inv_t=False):
         left, right = (self.matrix_left_inv, self.matrix_right_inv) if inv_t else (self.matrix_left, self.matrix_right)
         use_diag = self.add_diag and self.use_diag
-        if inp.dtype == torch.float16 and inp.is_cuda:
+        if inp.dtype in ops.ACT_DTYPES and inp.is_cuda:
             diag = None
             if use_diag:
                 d = self.diag_scale.to(inp)
@@ -69,7 +84,7 @@ class _DecomposeTransBase(nn.Module):
                     inp = inp / d
                 else:
                     diag = d.contiguous()
-            l16, r16 = self._f16.get(left, inp.device), self._f16.get(right, inp.device)
+            l16, r16 = self._f16.get(left, inp.device, inp.dtype), self._f16.get(right, inp.device, inp.dtype)
             return ops.kron_quant(inp.contiguous(), l16, r16, flags=FQ_OUT_TRANSFORM, diag=diag).y
         if use_diag:
             inp = inp / self.diag_scale.to(inp) if inv_t else inp * self.diag_scale.to(inp)
@@ -112,13 +127,14 @@ class _SingleTransBase(nn.Module):
         init_shape = inp.shape
         n = self.matrix.shape[0]
         rows = inp.numel() // n
-        if inp.dtype == torch.float16 and inp.is_cuda and n in (32, 64):
+        if inp.dtype in ops.ACT_DTYPES and inp.is_cuda and n % 2 == 0 and n <= 64:
             # the activation path (llama_utils.py:275-277: attn_output [.., head_dim, num_heads] over the heads axis):
-            # the block-transform kernel with the natural (non-transposed) fp16 output = inp.reshape(-1, n) @ matrix,
-            # R rows of n per launch unit (any R the kernel has that divides the row count)
+            # the block-transform kernel with the natural (non-transposed) output = inp.reshape(-1, n) @ matrix in the
+            # activation's dtype, R rows of n per launch unit (any R the kernel has that divides the row count); n = any even
+            # head count up to 64 (28 / 40: Qwen2.5, Llama-2-13B), fp16 or bf16
             for R in (128, 96, 64, 32):
                 if rows % R == 0:
-                    m16 = self._f16.get(self.get_matrix(inv_t=inv_t), inp.device)
+                    m16 = self._f16.get(self.get_matrix(inv_t=inv_t), inp.device, inp.dtype)
                     return ops.block_quant(inp.reshape(-1, R, n).contiguous(), m16, flags=FQ_OUT_TRANSFORM,
                                            transpose_out=False).y.reshape(init_shape)
         # everything else (the offline fp64 weight-side use in reparameterize, odd sizes): the reference's own op

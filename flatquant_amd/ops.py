@@ -45,6 +45,8 @@ def invalidate_caches() -> None:
     _sigmoid_pair_cached.cache_clear()
     _WS_LRU.clear()
     _HAD_KRON.clear()
+    from .flatquant.trans_utils import _Fp16Cache   # the modules' fp16 / bf16 copies of their (fp32) matrices
+    _Fp16Cache.clear_all()
 
 
 def host_scalar(v) -> float:
@@ -77,6 +79,26 @@ def _chk(t: torch.Tensor, name: str, dtype=torch.float16) -> None:
         raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise RuntimeError(f"{name} must be contiguous")
+
+
+ACT_DTYPES = (torch.float16, torch.bfloat16)
+
+
+def _chk_act(x: torch.Tensor, name: str = "x"):
+    """The activation of a path-A entry point: fp16 or bf16 (the reference's eval pipeline feeds whatever the checkpoint
+    declares, flatquant/model_utils.py:20 torch_dtype='auto'; main_dpskv3.py:395). Returns its dtype: every other fp tensor
+    of the call must have it too, and the library's *_f16 / *_bf16 entry point is picked by it (_fn)."""
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if x.dtype not in ACT_DTYPES:
+        raise TypeError(f"{name} must be torch.float16 or torch.bfloat16, got {x.dtype}")
+    _chk(x, name, x.dtype)
+    return x.dtype
+
+
+def _fn(stem: str, dtype):
+    """libfqhip entry point of a dtype: fq_<stem>_f16 / fq_<stem>_bf16."""
+    return getattr(lib, f"fq_{stem}_bf16" if dtype == torch.bfloat16 else f"fq_{stem}_f16")
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -118,11 +140,11 @@ def _alloc_outputs(x: torch.Tensor, rows: int, d: int, n_clips: int, flags: int,
     for _ in range(n_clips if flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT) else 0):
         if flags & FQ_OUT_PACKED:
             o.q.append(torch.empty(q_shape, dtype=torch.uint8, device=x.device))
-            o.scale.append(torch.empty((rows,), dtype=torch.float16, device=x.device))
+            o.scale.append(torch.empty((rows,), dtype=x.dtype, device=x.device))
         if flags & FQ_OUT_FAKEQUANT:
-            o.fq.append(torch.empty(y_shape, dtype=torch.float16, device=x.device))
+            o.fq.append(torch.empty(y_shape, dtype=x.dtype, device=x.device))
     if flags & FQ_OUT_TRANSFORM:
-        o.y = torch.empty(y_shape, dtype=torch.float16, device=x.device)
+        o.y = torch.empty(y_shape, dtype=x.dtype, device=x.device)
     return o
 
 
@@ -179,8 +201,11 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
     groupsize = 128: one scale per 128 consecutive elements of the transformed token instead of one per token
     (ActivationQuantizer(groupsize=128)); scales come back as [..., d/128]. One launch (FQ_GROUP128) where the library
     fuses it (packed output, N = 64), otherwise the transform launch followed by the row quantiser over the
-    (-1, 128) view of its fp16 result — the reference's own order of operations."""
-    _chk(x, "x"), _chk(left, "left"), _chk(right, "right")
+    (-1, 128) view of its fp16 result — the reference's own order of operations.
+
+    x fp16 or bf16 (left / right / diag of the same dtype): fq_kron_quant_f16 / fq_kron_quant_bf16; outputs in x's dtype."""
+    dt = _chk_act(x)
+    _chk(left, "left", dt), _chk(right, "right", dt)
     M, N = left.shape[0], right.shape[0]
     if left.shape != (M, M) or right.shape != (N, N):
         raise ValueError("left/right must be square")
@@ -188,7 +213,7 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
     if x.shape[-1] != d:
         raise ValueError(f"x.shape[-1]={x.shape[-1]} != {M}*{N}")
     if diag is not None:
-        _chk(diag, "diag")
+        _chk(diag, "diag", dt)
         if diag.numel() != d:
             raise ValueError("diag must have M*N elements")
     if groupsize not in (-1, 128) or (groupsize == 128 and d % 128):
@@ -196,7 +221,7 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
     rows = x.numel() // d
     smax, smin, n = _sig_arrays(sigs)
     fused_g = groupsize == 128 and (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_QUANT_F16)) == FQ_OUT_PACKED \
-        and n == 1 and N == 64 and M % 2 == 0 and diag is None
+        and n == 1 and N == 64 and M % 2 == 0 and diag is None and dt == torch.float16
     if groupsize == 128 and not fused_g:
         o = kron_quant(x, left, right, flags=FQ_OUT_TRANSFORM | (flags & FQ_WS_PREPARED), diag=diag)
         return _quant_groups_of(o.y, sigs, flags, 128, o) if flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT) else o
@@ -208,7 +233,7 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
         return o
     with torch.cuda.device(x.device):
         ws, ws_bytes, prepared, key = _kron_workspace(x.device, M, N, left, right)
-        check(lib.fq_kron_quant_f16(_ptr(x), _ptr(left), _ptr(right), _ptr(diag), rows, M, N, smax, smin, n,
+        check(_fn("kron_quant", dt)(_ptr(x), _ptr(left), _ptr(right), _ptr(diag), rows, M, N, smax, smin, n,
                                     flags | (FQ_WS_PREPARED if prepared else 0), _ptr_array(o.q), _ptr_array(o.scale),
                                     _ptr_array(o.fq), _ptr(o.y), _ptr(ws), ws_bytes, _stream(x)))
         if key is not None and not prepared:
@@ -303,7 +328,8 @@ def kron_quant_grouped(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor,
     read back, when left / right are 2-D (shared transform: deepseekv3_utils.py:470). 3-D left / right [G, M, M] /
     [G, N, N] are the reference's ``routed_w2_trans[i]`` branch (:446): one launch per non-empty group, with the
     group sizes read back to the host exactly like the reference's ``counts ... .tolist()``."""
-    _chk(x, "x"), _chk(left, "left"), _chk(right, "right")
+    dt = _chk_act(x)
+    _chk(left, "left", dt), _chk(right, "right", dt)
     _chk(group_offsets, "group_offsets", torch.int64)
     _chk(sig_max_g, "sig_max_g", torch.float32), _chk(sig_min_g, "sig_min_g", torch.float32)
     G = group_offsets.numel() - 1
@@ -334,7 +360,8 @@ def kron_quant_grouped(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor,
                 if o.y is not None:
                     o.y[a:b] = part.y
         return o
-    fused_g = groupsize == 128 and (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) == FQ_OUT_PACKED and N == 64 and M % 2 == 0
+    fused_g = groupsize == 128 and (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) == FQ_OUT_PACKED and N == 64 and M % 2 == 0 \
+        and dt == torch.float16
     if groupsize == 128 and not fused_g:
         raise _lib.FqError(FQ_EUNSUPPORTED, "grouped launch with 128-element scales is fused for packed output and N = 64 only")
     o = _alloc_outputs(x, rows * (d // 128 if fused_g else 1), d, 1, flags, (rows, d // 2), x.shape)
@@ -345,7 +372,7 @@ def kron_quant_grouped(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor,
         return o
     with torch.cuda.device(x.device):
         ws, ws_bytes, prepared, key = _kron_workspace(x.device, M, N, left, right)
-        check(lib.fq_kron_quant_grouped_f16(
+        check(_fn("kron_quant_grouped", dt)(
             _ptr(x), _ptr(left), _ptr(right), rows, M, N, _ptr(group_offsets), G, _ptr(sig_max_g), _ptr(sig_min_g),
             flags | (FQ_WS_PREPARED if prepared else 0), _ptr(o.q[0] if o.q else None), _ptr(o.scale[0] if o.scale else None),
             _ptr(o.fq[0] if o.fq else None), _ptr(o.y), _ptr(ws), ws_bytes, _stream(x)))
@@ -437,8 +464,9 @@ def silu_mul_kron_quant(gate: torch.Tensor, up: torch.Tensor, left: torch.Tensor
 
 def block_quant(x: torch.Tensor, P: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),),
                 flags: int = FQ_OUT_PACKED | FQ_NO_CLAMP0, transpose_out: bool = True) -> FusedOutputs:
-    """x [..., R, C] @ P [C, C], quantised per [R, C] block (fq_block_quant_f16)."""
-    _chk(x, "x"), _chk(P, "P")
+    """x [..., R, C] @ P [C, C], quantised per [R, C] block (fq_block_quant_f16 / _bf16 by x's dtype)."""
+    dt = _chk_act(x)
+    _chk(P, "P", dt)
     R, C = x.shape[-2], x.shape[-1]
     if P.shape != (C, C):
         raise ValueError("P must be [C, C] with C = x.shape[-1]")
@@ -450,15 +478,15 @@ def block_quant(x: torch.Tensor, P: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1
     if rows == 0:
         return o
     with torch.cuda.device(x.device):
-        check(lib.fq_block_quant_f16(_ptr(x), _ptr(P), rows, R, C, int(transpose_out), smax, smin, n, flags,
+        check(_fn("block_quant", dt)(_ptr(x), _ptr(P), rows, R, C, int(transpose_out), smax, smin, n, flags,
                                      _ptr_array(o.q), _ptr_array(o.scale), _ptr_array(o.fq), _ptr(o.y),
                                      _stream(x)))
     return o
 
 
 def rowquant(x: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),), flags: int = FQ_OUT_PACKED) -> FusedOutputs:
-    """Per-token scale + INT4 quantisation of x [..., cols] (fq_rowquant_f16)."""
-    _chk(x, "x")
+    """Per-token scale + INT4 quantisation of x [..., cols] (fq_rowquant_f16 / _bf16 by x's dtype)."""
+    dt = _chk_act(x)
     cols = x.shape[-1]
     rows = x.numel() // cols
     smax, smin, n = _sig_arrays(sigs)
@@ -466,7 +494,7 @@ def rowquant(x: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),), flags: int = 
     if rows == 0:
         return o
     with torch.cuda.device(x.device):
-        check(lib.fq_rowquant_f16(_ptr(x), rows, cols, smax, smin, n, flags, _ptr_array(o.q),
+        check(_fn("rowquant", dt)(_ptr(x), rows, cols, smax, smin, n, flags, _ptr_array(o.q),
                                   _ptr_array(o.scale), _ptr_array(o.fq), _stream(x)))
     return o
 

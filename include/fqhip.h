@@ -91,6 +91,23 @@ extern "C" {
 #define FQ_MAX_CLIPS 4
 
 /*
+ * bfloat16 activations: the *_bf16 entry points.
+ * The reference's fake-quant path is dtype-generic (flatquant/flat_utils.py:6-17 multiplies in x's dtype;
+ * flatquant/quant_utils.py:86 casts q_max to x's dtype) and its eval pipeline feeds it whatever the checkpoint declares:
+ * flatquant/model_utils.py:20,34,54,68 (torch_dtype='auto': bfloat16 for Llama-3 and Qwen2.5), train_utils.py:28,
+ * main_dpskv3.py:241,395 and deepseek_v3/model.py:807 (set_default_dtype(bfloat16)). fq_kron_quant_bf16,
+ * fq_kron_quant_grouped_bf16, fq_block_quant_bf16, fq_rowquant_bf16 and fq_kron_prepare_bf16 take the SAME arguments as
+ * their _f16 namesakes with every fp16 tensor (x, left, right, diag, P, fq_out, y_out, scale_out) a bf16 tensor, and compute
+ * what torch computes for bf16 tensors: bf16 operands on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, the intermediate
+ * U = x . right rounded to bf16 (torch.matmul's result type), FQ_ROUND_Y_F16 = the transformed activation rounded to bf16,
+ * FQ_QUANT_F16 / FQ_SIG_F16 = scale, quotient and product (extremum x sigmoid) rounded to bf16 — the route torch's type
+ * promotion takes when the clip parameters are bf16 as well (main_dpskv3.py:395) or absent — and fp32 statistics / division
+ * otherwise (fp32 clip parameters next to a bf16 model: flat_linear.py:16 under the fp32 default dtype). Packed output is an
+ * extension here (the reference's deploy kernels assert fp16): the scales come back in bf16. Not offered in bf16: FQ_GROUP128
+ * fused, FQ_IN_RMSNORM / FQ_IN_SILU_MUL and post_scale forms (deploy-module contracts, fp16-only in the reference).
+ */
+
+/*
  * Fused Kronecker transform + per-token symmetric INT4 quantisation.
  *   y[t] = x[t] (as [M,N] row-major) ; U = fp16(x[t] . right) ; Y = left^T . U   (fp32 accumulate)
  *   == x_flat[t] @ kron(left, right)                         (flat_utils.py:6-17)
@@ -115,6 +132,11 @@ int fq_kron_quant_f16(const void* x, const void* left, const void* right, const 
                       const float* sig_max, const float* sig_min, int n_clips, int flags,
                       void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
                       void* workspace, int64_t workspace_bytes, void* stream);
+int fq_kron_quant_bf16(const void* x, const void* left, const void* right, const void* diag,
+                       int64_t rows, int M, int N,
+                       const float* sig_max, const float* sig_min, int n_clips, int flags,
+                       void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                       void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * Grouped (per-expert) form of fq_kron_quant_f16: the routed experts of a MoE layer
@@ -134,6 +156,10 @@ int fq_kron_quant_grouped_f16(const void* x, const void* left, const void* right
                               const int64_t* group_offsets, int n_groups, const float* sig_max_g, const float* sig_min_g,
                               int flags, void* q_out, void* scale_out, void* fq_out, void* y_out,
                               void* workspace, int64_t workspace_bytes, void* stream);
+int fq_kron_quant_grouped_bf16(const void* x, const void* left, const void* right, int64_t rows, int M, int N,
+                               const int64_t* group_offsets, int n_groups, const float* sig_max_g, const float* sig_min_g,
+                               int flags, void* q_out, void* scale_out, void* fq_out, void* y_out,
+                               void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * deploy.nn.RMSNorm (deploy/nn/normalization.py:16-23; the weight is folded into the next layer) in front of the
@@ -196,17 +222,26 @@ int64_t fq_kron_workspace_bytes(int M, int N);
  * workspace with FQ_WS_PREPARED afterwards. A no-op (FQ_OK) for M = N = 64, which needs no workspace. */
 int fq_kron_prepare_f16(const void* left, const void* right, int M, int N, void* workspace, int64_t workspace_bytes,
                         void* stream);
+int fq_kron_prepare_bf16(const void* left, const void* right, int M, int N, void* workspace, int64_t workspace_bytes,
+                         void* stream);
 
 /*
  * Single-matrix transform over the LAST axis of [rows, R, C] blocks (o_proj head transform):
  *   Y[t] = x[t] ([R,C] row-major) . P ([C,C]);  quantised per token over all R*C values.
  * Packed output follows block_matmul.py:86-101: the quantised block is TRANSPOSED before packing when
  * transpose_out != 0 (logical [C, R] per token), natural [R, C] otherwise.
+ * R (head_dim) in {32, 64, 96, 128}; C (num_attention_heads) any even number <= 64: 32 / 64 (Llama) on the tuned kernel,
+ * 28 / 40 / 48 / 12 / 14 / 16 (Qwen2.5, Llama-2-13B) on the masked one — the reference kernel masks arbitrary sizes
+ * (block_matmul.py:56-66,101-103). FQ_EUNSUPPORTED otherwise.
  */
 int fq_block_quant_f16(const void* x, const void* P, int64_t rows, int R, int C, int transpose_out,
                        const float* sig_max, const float* sig_min, int n_clips, int flags,
                        void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
                        void* stream);
+int fq_block_quant_bf16(const void* x, const void* P, int64_t rows, int R, int C, int transpose_out,
+                        const float* sig_max, const float* sig_min, int n_clips, int flags,
+                        void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                        void* stream);
 
 /*
  * INT4 x INT4 -> INT32 GEMM on packed nibbles (deploy/kernels/gemm.cu:8-47 behind deploy.matmul,
@@ -293,6 +328,10 @@ int fq_rowquant_f16(const void* x, int64_t rows, int cols,
                     const float* sig_max, const float* sig_min, int n_clips, int flags,
                     void* const* q_out, void* const* scale_out, void* const* fq_out,
                     void* stream);
+int fq_rowquant_bf16(const void* x, int64_t rows, int cols,
+                     const float* sig_max, const float* sig_min, int n_clips, int flags,
+                     void* const* q_out, void* const* scale_out, void* const* fq_out,
+                     void* stream);
 
 /*
  * KV-cache quantisation (deploy/transformers/kv_cache.py:11-51 asym_quantize_and_pack_i4, :268 the K transform), one

@@ -42,6 +42,48 @@ import numpy as np
 F16 = np.float16
 F32 = np.float32
 
+# --------------------------------------------------------------------------------------------------
+# bfloat16 (round 3). The reference's path A is dtype-generic and its pipeline feeds bf16 on Llama-3 / Qwen / DeepSeek
+# (flatquant/model_utils.py:20 torch_dtype='auto'; main_dpskv3.py:395). numpy has no bf16: a bf16 tensor is held here as a
+# float32 array whose values are bf16-representable (tests/golden stores the 16-bit patterns: bf16_from_bits / bf16_bits).
+# Every function below that rounds to "the activation's dtype" takes lowp = "f16" | "bf16" and rounds through _rnd.
+# --------------------------------------------------------------------------------------------------
+def bf16_round(a) -> np.ndarray:
+    """fp32 -> bf16 (round to nearest even, what torch's .to(bfloat16) and v_cvt_pk_bf16_f32 do) -> fp32."""
+    a = np.ascontiguousarray(np.asarray(a, dtype=F32))
+    u = a.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    out = u.astype(np.uint32).view(F32).reshape(a.shape)
+    return np.where(np.isnan(a), a, out).astype(F32)
+
+
+def bf16_from_bits(bits) -> np.ndarray:
+    return (np.asarray(bits).astype(np.uint32) << 16).view(F32)
+
+
+def bf16_bits(a) -> np.ndarray:
+    a = np.ascontiguousarray(np.asarray(a, dtype=F32))
+    assert np.array_equal(bf16_round(a), a, equal_nan=True), "not bf16-representable"
+    return (a.view(np.uint32) >> 16).astype(np.uint16)
+
+
+def _rnd(a, lowp="f16") -> np.ndarray:
+    """Round an fp32 array to the 16-bit activation dtype and return it as fp32."""
+    if lowp == "bf16":
+        return bf16_round(a)
+    with np.errstate(over="ignore"):
+        return np.asarray(a, dtype=F32).astype(F16).astype(F32)
+
+
+def _as_lowp(a, lowp="f16") -> np.ndarray:
+    """An input tensor of the activation dtype as fp32 values (fp16 arrays convert exactly; bf16 inputs already are
+    bf16-representable fp32 arrays — asserted)."""
+    if lowp == "bf16":
+        a = np.asarray(a, dtype=F32)
+        assert np.array_equal(bf16_round(a), a, equal_nan=True), "bf16 input holds values that are not bf16-representable"
+        return a
+    return np.asarray(a, dtype=F16).astype(F32)
+
 
 # --------------------------------------------------------------------------------------------------
 # integer helpers
@@ -104,7 +146,7 @@ def _grouped_matmul(a16: np.ndarray, b16: np.ndarray, groups: Optional[Sequence[
     return acc
 
 
-def kron_transform(x16, left16, right16, diag16=None, groups1=None, groups2=None, left_first=False):
+def kron_transform(x16, left16, right16, diag16=None, groups1=None, groups2=None, left_first=False, lowp="f16"):
     """Y = left^T . fp16(X . right) for every token; returns fp32 [T, M, N].
 
     left_first=True evaluates the deploy Triton kernel's association instead (kron_matmul.py:63-71):
@@ -116,33 +158,34 @@ def kron_transform(x16, left16, right16, diag16=None, groups1=None, groups2=None
     caller's choice here (FQ_ROUND_Y_F16 / round_y_f16) because the deploy kernels quantise the fp32
     accumulator (kron_matmul.py:71-107).
     """
-    x16 = np.asarray(x16, dtype=F16)
-    left16 = np.asarray(left16, dtype=F16)
-    right16 = np.asarray(right16, dtype=F16)
+    x16 = _as_lowp(x16, lowp)          # (fp32 arrays of fp16- / bf16-representable values from here on)
+    left16 = _as_lowp(left16, lowp)
+    right16 = _as_lowp(right16, lowp)
     M, N = left16.shape[0], right16.shape[0]
     X = x16.reshape(-1, M, N)
     if diag16 is not None:
-        d = np.asarray(diag16, dtype=F16).reshape(M, N)
-        X = (X.astype(F32) * d.astype(F32)).astype(F16)      # one fp16 multiply
+        d = _as_lowp(diag16, lowp).reshape(M, N)
+        X = _rnd((X * d).astype(F32), lowp)      # one fp16 / bf16 multiply (the product of two such values is exact in fp32
+                                                 # for bf16 and rounded once to fp32 for fp16: a multiply in fp32 opmath)
     if left_first:
         # T[t, m', n] = sum_m L[m, m'] X[t, m, n]   ->  (X^T)[t, n, m] @ L
-        Tt = _grouped_matmul(np.swapaxes(X, -1, -2), left16, groups1).astype(F16)   # [T, N, M']
+        Tt = _rnd(_grouped_matmul(np.swapaxes(X, -1, -2), left16, groups1), lowp)   # [T, N, M']
         return _grouped_matmul(np.swapaxes(Tt, -1, -2), right16, groups2)           # [T, M', N']
-    U = _grouped_matmul(X, right16, groups1).astype(F16)       # [T, M, N'] fp16
+    U = _rnd(_grouped_matmul(X, right16, groups1), lowp)       # [T, M, N'] rounded to the activation dtype
     # Y[t, m', n'] = sum_m L[m, m'] U[t, m, n']  ->  (U^T)[t, n', m] @ L[m, m']
     Yt = _grouped_matmul(np.swapaxes(U, -1, -2), left16, groups2)   # [T, N', M']
     return np.ascontiguousarray(np.swapaxes(Yt, -1, -2))               # [T, M', N']
 
 
-def single_transform(x16, P16, groups=None):
+def single_transform(x16, P16, groups=None, lowp="f16"):
     """x [T, R, C] fp16 @ P [C, C] -> fp32 [T, R, C]  (block_matmul.py:59-70; trans_utils.py:21-25)."""
-    return _grouped_matmul(np.asarray(x16, dtype=F16), np.asarray(P16, dtype=F16), groups)
+    return _grouped_matmul(_as_lowp(x16, lowp), _as_lowp(P16, lowp), groups)
 
 
 # --------------------------------------------------------------------------------------------------
 # per-token symmetric INT4 quantisation
 # --------------------------------------------------------------------------------------------------
-def token_scale(y32, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False, sig_f16=False):
+def token_scale(y32, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False, sig_f16=False, lowp="f16"):
     """y32 [T, d] fp32 -> scale fp32 [T].
 
     quant_utils.py:88-107 (clamp to 0, lac sigmoid factors, m = max(|xmin|, xmax), scale = m/q_max,
@@ -160,8 +203,8 @@ def token_scale(y32, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False, sig
         # deploy/nn/quantization.py:21-22: fp16 [rows, 1] extrema times a 0-dim fp32 sigmoid tensor -> torch's result is
         # fp16: the product is formed in fp32 (the sigmoid keeps its fp32 value) and rounded to fp16 (checked against the
         # reference module: tests/golden/quantizer_lac.npz)
-        xmax = (xmax * F32(sig_max)).astype(F32).astype(F16).astype(F32)
-        xmin = (xmin * F32(sig_min)).astype(F32).astype(F16).astype(F32)
+        xmax = _rnd((xmax * F32(sig_max)).astype(F32), lowp)
+        xmin = _rnd((xmin * F32(sig_min)).astype(F32), lowp)
     else:
         xmax = (xmax * F32(sig_max)).astype(F32)
         xmin = (xmin * F32(sig_min)).astype(F32)
@@ -169,35 +212,36 @@ def token_scale(y32, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False, sig
     with np.errstate(divide="ignore", invalid="ignore"):
         scale = (m / F32(7.0)).astype(F32)
     if quant_f16:
-        scale = scale.astype(F16).astype(F32)
+        scale = _rnd(scale, lowp)
     scale = np.where(m == 0, F32(1.0), scale).astype(F32)
     return scale
 
 
-def quantize(y32, scale, quant_f16=False):
+def quantize(y32, scale, quant_f16=False, lowp="f16"):
     """clamp(rint(y/scale), -8, 7) -> int8; division fp32 (fp16-rounded quotient when quant_f16)."""
     y32 = np.asarray(y32, dtype=F32)
     s = np.asarray(scale, dtype=F32)[..., None]
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         t = (y32 / s).astype(F32)
         if quant_f16:
-            t = t.astype(F16).astype(F32)
+            t = _rnd(t, lowp)
     t = np.rint(t)
     t = np.clip(t, -8, 7)
     t = np.where(np.isnan(t), 0, t)
     return t.astype(np.int8)
 
 
-def dequantize(q, scale, quant_f16=False):
-    """(scale * q).to(fp16)  (quant_utils.py:25-26,81)."""
+def dequantize(q, scale, quant_f16=False, lowp="f16"):
+    """(scale * q).to(fp16)  (quant_utils.py:25-26,81). lowp="bf16": the bf16 result as an fp32 array."""
     s = np.asarray(scale, dtype=F32)[..., None]
     if quant_f16:
-        s = s.astype(F16).astype(F32)
-    return (s * q.astype(F32)).astype(F16)
+        s = _rnd(s, lowp)
+    p = (s * q.astype(F32)).astype(F32)
+    return bf16_round(p) if lowp == "bf16" else p.astype(F16)
 
 
 def quant_outputs(y32, sig_max=1.0, sig_min=1.0, round_y_f16=False, clamp0=True, quant_f16=False, groupsize=-1,
-                  sig_f16=False):
+                  sig_f16=False, lowp="f16"):
     """Everything the fused kernels can emit for one clip set, from the fp32 transformed activation.
 
     groupsize > 0: ``ActivationQuantizer(groupsize=g)`` of vllm_custom/model_executor/layers/quantization/utils/
@@ -208,24 +252,25 @@ def quant_outputs(y32, sig_max=1.0, sig_min=1.0, round_y_f16=False, clamp0=True,
     T = y32.shape[0]
     y = y32.reshape(T, -1)
     d = y.shape[1]
-    y16 = y.astype(F16)
+    # "y16" / "fq" / "scale16": fp16 arrays, or (lowp="bf16") fp32 arrays of bf16-representable values
+    y16 = bf16_round(y) if lowp == "bf16" else y.astype(F16)
     if round_y_f16:
         y = y16.astype(F32)
     if groupsize > 0:
         assert d % groupsize == 0
         yg = y.reshape(T * (d // groupsize), groupsize)
-        scale = token_scale(yg, sig_max, sig_min, clamp0, quant_f16, sig_f16)
-        q = quantize(yg, scale, quant_f16).reshape(T, d)
-        fq = dequantize(q.reshape(yg.shape), scale, quant_f16).reshape(T, d)
+        scale = token_scale(yg, sig_max, sig_min, clamp0, quant_f16, sig_f16, lowp)
+        q = quantize(yg, scale, quant_f16, lowp).reshape(T, d)
+        fq = dequantize(q.reshape(yg.shape), scale, quant_f16, lowp).reshape(T, d)
         scale = scale.reshape(T, d // groupsize)
     else:
-        scale = token_scale(y, sig_max, sig_min, clamp0, quant_f16, sig_f16)
-        q = quantize(y, scale, quant_f16)
-        fq = dequantize(q, scale, quant_f16)
+        scale = token_scale(y, sig_max, sig_min, clamp0, quant_f16, sig_f16, lowp)
+        q = quantize(y, scale, quant_f16, lowp)
+        fq = dequantize(q, scale, quant_f16, lowp)
     return {
         "y16": y16,
         "scale": scale,
-        "scale16": scale.astype(F16),
+        "scale16": bf16_round(scale) if lowp == "bf16" else scale.astype(F16),
         "q": q,
         "packed": pack_i4(q),
         "fq": fq,
@@ -233,20 +278,22 @@ def quant_outputs(y32, sig_max=1.0, sig_min=1.0, round_y_f16=False, clamp0=True,
 
 
 def kron_quant(x16, left16, right16, sig_max=1.0, sig_min=1.0, diag16=None, round_y_f16=False,
-               clamp0=True, quant_f16=False, groups1=None, groups2=None, left_first=False, groupsize=-1):
-    y = kron_transform(x16, left16, right16, diag16, groups1, groups2, left_first)
-    return quant_outputs(y, sig_max, sig_min, round_y_f16, clamp0, quant_f16, groupsize)
+               clamp0=True, quant_f16=False, groups1=None, groups2=None, left_first=False, groupsize=-1, sig_f16=False,
+               lowp="f16"):
+    y = kron_transform(x16, left16, right16, diag16, groups1, groups2, left_first, lowp)
+    return quant_outputs(y, sig_max, sig_min, round_y_f16, clamp0, quant_f16, groupsize, sig_f16, lowp)
 
 
 def kron_quant_grouped(x16, left16, right16, group_offsets, sig_max_g, sig_min_g, round_y_f16=False, clamp0=True,
-                       groupsize=-1):
+                       groupsize=-1, quant_f16=False, sig_f16=False, lowp="f16"):
     """The routed experts of flatquant/model_tools/deepseekv3_utils.py:427-452: rows sorted by expert, expert i owns
     rows [group_offsets[i], group_offsets[i+1]) (``idx, top = torch.where(indices == i)``; ``expert(x[idx], ...)``),
     every expert transforms with its matrices and quantises with its own clip pair. left16 / right16: one shared pair
     ([M, M], [N, N]: ``routed_w2_trans`` at :470, independent_w2_trans = False) or one pair per expert ([G, M, M],
     [G, N, N]: the ``routed_w2_trans[i]`` branch, :446). Returns the same dict as kron_quant over all rows."""
-    x16 = np.asarray(x16, dtype=F16)
-    left16, right16 = np.asarray(left16, dtype=F16), np.asarray(right16, dtype=F16)
+    lp = F32 if lowp == "bf16" else F16
+    x16 = np.asarray(x16, dtype=lp)
+    left16, right16 = np.asarray(left16, dtype=lp), np.asarray(right16, dtype=lp)
     offs = [int(v) for v in group_offsets]
     parts = []
     for g in range(len(offs) - 1):
@@ -256,23 +303,23 @@ def kron_quant_grouped(x16, left16, right16, group_offsets, sig_max_g, sig_min_g
         L = left16[g] if left16.ndim == 3 else left16
         R = right16[g] if right16.ndim == 3 else right16
         parts.append(kron_quant(x16[a:b], L, R, float(sig_max_g[g]), float(sig_min_g[g]), None, round_y_f16, clamp0,
-                                False, groupsize=groupsize))
+                                quant_f16, groupsize=groupsize, sig_f16=sig_f16, lowp=lowp))
     if not parts:                                              # no rows at all: the empty result, shapes intact
         d = left16.shape[-1] * right16.shape[-1]
         ns = d // groupsize if groupsize > 0 else None
-        return {"y16": np.zeros((0, d), F16), "scale": np.zeros((0, ns) if ns else (0,), F32),
-                "scale16": np.zeros((0, ns) if ns else (0,), F16), "q": np.zeros((0, d), np.int8),
-                "packed": np.zeros((0, d // 2), np.uint8), "fq": np.zeros((0, d), F16)}
+        return {"y16": np.zeros((0, d), lp), "scale": np.zeros((0, ns) if ns else (0,), F32),
+                "scale16": np.zeros((0, ns) if ns else (0,), lp), "q": np.zeros((0, d), np.int8),
+                "packed": np.zeros((0, d // 2), np.uint8), "fq": np.zeros((0, d), lp)}
     return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
 
 
-def rowquant(x16, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False, sig_f16=False):
-    x16 = np.asarray(x16, dtype=F16)
-    return quant_outputs(x16.astype(F32).reshape(x16.shape[0], -1), sig_max, sig_min, False, clamp0, quant_f16,
-                         sig_f16=sig_f16)
+def rowquant(x16, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False, sig_f16=False, lowp="f16"):
+    x = _as_lowp(x16, lowp)
+    return quant_outputs(x.reshape(x.shape[0], -1), sig_max, sig_min, False, clamp0, quant_f16,
+                         sig_f16=sig_f16, lowp=lowp)
 
 
-def rowquant_asym(x16, sig_max=1.0, sig_min=1.0, quant_f16=False):
+def rowquant_asym(x16, sig_max=1.0, sig_min=1.0, quant_f16=False, lowp="f16"):
     """ActivationQuantizer(sym=False).fake_quant on an fp16 activation -> fp16 [rows, cols].
 
     quant_utils.py:86-92 (row extrema through 0), :95-100 (clip factors), :109-113 (both zero -> (-1, +1);
@@ -282,9 +329,9 @@ def rowquant_asym(x16, sig_max=1.0, sig_min=1.0, quant_f16=False):
     product to fp32. quant_f16=True: no lac / clip_ratio / half()'ed module — every operation rounds to fp16 (the
     extremum x factor product is formed in fp32 opmath and then rounded to fp16).
     """
-    x16 = np.asarray(x16, dtype=F16)
-    x = x16.astype(F32).reshape(x16.shape[0], -1)
-    rnd = (lambda a: a.astype(F32).astype(F16).astype(F32)) if quant_f16 else (lambda a: a.astype(F32))
+    x = _as_lowp(x16, lowp)
+    x = x.reshape(x.shape[0], -1)
+    rnd = (lambda a: _rnd(a.astype(F32), lowp)) if quant_f16 else (lambda a: a.astype(F32))
     xmax = np.maximum(x.max(axis=-1), F32(0))
     xmin = np.minimum(x.min(axis=-1), F32(0))
     xmax = rnd((xmax * F32(sig_max)).astype(F32))
@@ -296,17 +343,18 @@ def rowquant_asym(x16, sig_max=1.0, sig_min=1.0, quant_f16=False):
     zero = np.rint(rnd((-xmin) / scale)).astype(F32)
     t = rnd(x / scale[:, None])
     q = np.clip(np.rint(t) + zero[:, None], 0, 15).astype(F32)
-    return (scale[:, None] * (q - zero[:, None])).astype(F32).astype(F16)
+    out = (scale[:, None] * (q - zero[:, None])).astype(F32)
+    return bf16_round(out) if lowp == "bf16" else out.astype(F16)
 
 
 def block_quant(x16, P16, sig_max=1.0, sig_min=1.0, transpose_out=True, round_y_f16=False, clamp0=False,
-                quant_f16=False, groups=None):
+                quant_f16=False, groups=None, lowp="f16"):
     """block_matmul.py:29-104: Y = x[t] ([R, C]) @ P; statistics over the whole block; the quantised block
     is transposed before packing (:86-90) when transpose_out."""
-    y = single_transform(x16, P16, groups)               # [T, R, C]
+    y = single_transform(x16, P16, groups, lowp)         # [T, R, C]
     if transpose_out:
         y = np.ascontiguousarray(np.swapaxes(y, -1, -2))  # [T, C, R]
-    return quant_outputs(y, sig_max, sig_min, round_y_f16, clamp0, quant_f16)
+    return quant_outputs(y, sig_max, sig_min, round_y_f16, clamp0, quant_f16, lowp=lowp)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -1,0 +1,220 @@
+"""GPU parity, round 3: the path-A surface on bfloat16 activations — kronecker_matmul, {Inv,SVD}DecomposeTransMatrix,
+{SVD,Inv}SingleTransMatrix, ActivationQuantizer (every promotion route, symmetric and asymmetric), FlatQuantizedLinear, the
+DeepSeek routed-expert flow under set_default_dtype(bfloat16) — against fixtures the REFERENCE wrote on bf16 tensors
+(tools/gen_golden.py r3; flatquant/model_utils.py:20 torch_dtype='auto', main_dpskv3.py:395).
+
+Bars (the fp16 ones, restated for 8-bit significands): the quantiser stage is BIT-EXACT — against the reference's own outputs
+where it receives the same bf16 rows (ActivationQuantizer), against the oracle applied to the transform the same launch
+returns otherwise; the transform (bf16 MFMA, its own summation order) differs from the reference's CPU GEMM on few elements,
+each by one bf16 step or <= 4e-3 of the row's largest value (bf16 itself resolves 3.9e-3)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fq_oracle as O
+
+pytestmark = pytest.mark.gpu
+P, F, T, RY, NC0, QL, SL = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x400   # FQ_QUANT_F16 / FQ_SIG_F16 = "in the activation dtype"
+BF = torch.bfloat16
+PAIRS = ["64x64", "64x112", "32x64", "112x128", "56x64", "128x148"]
+MODES = {"lac32": (0, dict(quant_f16=False, sig_f16=False)), "lac16": (QL | SL, dict(quant_f16=True, sig_f16=True)),
+         "nolac": (QL, dict(quant_f16=True, sig_f16=False))}
+
+
+def tbf(bits_arr):
+    """uint16 bit patterns -> bf16 CUDA tensor."""
+    return torch.from_numpy(np.ascontiguousarray(bits_arr).view(np.int16)).view(BF).cuda()
+
+
+def bits(t):
+    return t.detach().contiguous().cpu().view(torch.int16).numpy().view(np.uint16)
+
+
+def f32(t):
+    return t.detach().float().cpu().numpy()
+
+
+def ulps(a_bits, b_bits):
+    ia, ib = a_bits.astype(np.int64), b_bits.astype(np.int64)
+    ia = np.where(ia & 0x8000, 0x8000 - ia, ia)
+    ib = np.where(ib & 0x8000, 0x8000 - ib, ib)
+    return np.abs(ia - ib)
+
+
+def close_bf16(y_bits, want_bits, frac=2e-2, tol=4e-3):
+    y, w = O.bf16_from_bits(y_bits), O.bf16_from_bits(want_bits)
+    rowmax = np.abs(w).reshape(w.shape[0], -1).max(axis=1).reshape((-1,) + (1,) * (w.ndim - 1))
+    ok = (ulps(y_bits, want_bits) <= 1) | (np.abs(y - w) <= tol * rowmax)
+    return float(np.mean(y_bits != want_bits)) < frac and bool(np.all(ok))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from flatquant_amd import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize("tag", PAIRS)
+def test_transform_and_quantiser_vs_reference(ops, golden, tag):
+    g = golden("bf16_path_a")
+    k = "k" + tag
+    x, L, R = tbf(g[k + "_x_bits"]), tbf(g[k + "_L_bits"]), tbf(g[k + "_R_bits"])
+    rows = x.shape[0]
+    for mode, (fl, kw) in MODES.items():
+        sig = tuple(float(v) for v in g[f"{k}_{mode}_sig"]) if mode != "nolac" else (1.0, 1.0)
+        o = ops.kron_quant(x, L, R, [sig], T | F | P | RY | fl)
+        assert o.y.dtype == BF and o.fq[0].dtype == BF and o.scale[0].dtype == BF
+        yb = bits(o.y)
+        assert close_bf16(yb, g[f"{k}_{mode}_y_bits"]), (tag, mode)
+        # quantiser stage: bit-exact on the transform the same launch returned
+        ref = O.quant_outputs(O.bf16_from_bits(yb), *sig, round_y_f16=True, lowp="bf16", **kw)
+        assert np.array_equal(bits(o.fq[0]), O.bf16_bits(ref["fq"])), (tag, mode)
+        assert np.array_equal(o.q[0].cpu().numpy(), ref["packed"]), (tag, mode)
+        assert np.array_equal(bits(o.scale[0]), O.bf16_bits(ref["scale16"])), (tag, mode)
+        # against the reference's own digits: a bf16 step of the transform moves a digit now and then
+        q = O.unpack_i4(o.q[0].cpu().numpy())
+        assert np.mean(q != g[f"{k}_{mode}_q"]) < 2e-2 and np.max(np.abs(q - g[f"{k}_{mode}_q"])) <= 1, (tag, mode)
+    # transform-only launch == the transform of the fused launch; kronecker_matmul mirror
+    from flatquant_amd.flatquant import kronecker_matmul
+    y = kronecker_matmul(x.reshape(1, rows, -1), L, R)
+    assert y.dtype == BF and y.shape == (1, rows, x.shape[1])
+    assert np.array_equal(bits(y).reshape(rows, -1), bits(ops.kron_quant(x, L, R, flags=T).y))
+
+
+def test_decompose_trans_matrix_bf16_diag_and_inv_t(golden):
+    from flatquant_amd.flatquant import InvDecomposeTransMatrix
+    g = golden("bf16_path_a")
+    x = tbf(g["dec_x_bits"])
+    tr = InvDecomposeTransMatrix(64, 64, add_diag=True)
+    tr.load_state_dict({kk: torch.from_numpy(g["dec_" + kk]) for kk in ("matrix_left", "matrix_right", "matrix_left_inv",
+                                                                         "matrix_right_inv", "diag_scale")})
+    tr = tr.cuda()
+    y = tr(x)
+    assert y.dtype == BF and close_bf16(bits(y), g["dec_y_bits"])
+    assert close_bf16(bits(tr(x, inv_t=True)), g["dec_y_inv_t_bits"])
+    # the same module still serves fp16 activations (one cache entry per dtype)
+    assert tr(x.half()).dtype == torch.float16
+
+
+def _module(sym, name, clips):
+    from flatquant_amd.flatquant import ActivationQuantizer
+    kw = dict(lac=name.startswith("lac"))
+    if name == "ratio":
+        kw["clip_ratio"] = 0.83
+    q = ActivationQuantizer(bits=4, sym=sym, **kw)
+    if clips is not None:
+        q.clip_factor_a_max.data.fill_(clips[0]), q.clip_factor_a_min.data.fill_(clips[1])
+    if name == "lac16":
+        q = q.bfloat16()
+    return q.cuda()
+
+
+@pytest.mark.parametrize("sym", [True, False])
+def test_activation_quantizer_bf16_bit_exact_vs_reference(golden, sym):
+    """Same bf16 rows in, the reference module's own bf16 rows out: bit for bit, all five configurations x three widths."""
+    g = golden("bf16_path_a")
+    cases = [("lac32", (4.0, 4.0)), ("lac32b", (1.7, 0.4)), ("plain", None), ("ratio", None), ("lac16", (2.1, 0.9))]
+    for name, clips in cases:
+        q = _module(sym, name, clips)
+        for cols in (128, 4096, 7168):
+            t = f"aq_{'sym' if sym else 'asym'}_{name}_{cols}"
+            y = q(tbf(g[t + "_x_bits"]))
+            assert y.dtype == BF
+            assert np.array_equal(bits(y), g[t + "_y_bits"]), (name, cols)
+
+
+def test_flat_quantized_linear_bf16(golden):
+    from types import SimpleNamespace
+    from flatquant_amd.flatquant import FlatQuantizedLinear
+    g = golden("bf16_path_a")
+    args = SimpleNamespace(w_bits=4, w_asym=False, a_bits=4, a_asym=False, lac=True, a_groupsize=-1, lwc=False)
+    lin = torch.nn.Linear(4096, 96, bias=True)
+    m = FlatQuantizedLinear(args, lin)
+    m.act_quantizer.clip_factor_a_max.data.fill_(3.3), m.act_quantizer.clip_factor_a_min.data.fill_(2.1)
+    m.reparameterize()
+    m.linear = m.linear.bfloat16()                         # a bf16 model whose FlatQuant parameters stayed fp32 (the HF flow)
+    m.linear.weight.data, m.linear.bias.data = tbf(g["fql_w_bits"]).cpu(), tbf(g["fql_b_bits"]).cpu()
+    m = m.cuda()
+    x = tbf(g["fql_x_bits"])
+    assert np.array_equal(bits(m.act_quantizer(x)), g["fql_fq_bits"])   # the quantiser: bit-exact vs the reference module
+    out = m(x)
+    assert out.dtype == BF
+    want = O.bf16_from_bits(g["fql_out_bits"])
+    assert np.max(np.abs(f32(out) - want)) <= 1e-2 * np.max(np.abs(want))   # a bf16 GEMM behind it (rocBLAS vs the CPU's)
+
+
+def test_moe_flow_bf16(ops, golden):
+    """deepseekv3_utils.py:427-452 in the dtype main_dpskv3.py:395 runs it in: one grouped launch per stage, bf16 clip
+    parameters (all-bf16 quantiser), vs the reference flow's fake-quantised rows."""
+    g = golden("moe_bf16")
+    offs = torch.from_numpy(g["offsets"]).cuda()
+    E = len(g["offsets"]) - 1
+    s1, s2 = tuple(float(v) for v in g["sig1"]), tuple(float(v) for v in g["sig2"])
+    x, L1, R1 = tbf(g["x_bits"]), tbf(g["L1_bits"]), tbf(g["R1_bits"])
+    o1 = ops.kron_quant(x, L1, R1, [s1], T | F | RY | QL | SL)
+    assert close_bf16(bits(o1.y), g["xt_bits"])
+    ref1 = O.quant_outputs(O.bf16_from_bits(bits(o1.y)), *s1, round_y_f16=True, quant_f16=True, sig_f16=True, lowp="bf16")
+    assert np.array_equal(bits(o1.fq[0]), O.bf16_bits(ref1["fq"]))
+    assert np.mean(bits(o1.fq[0])[g["rows_tok"]] != g["fq1_bits"]) < 3e-2
+    h, L2, R2 = tbf(g["h_bits"]), tbf(g["L2_bits"]), tbf(g["R2_bits"])
+    smax = torch.full((E,), s2[0], dtype=torch.float32, device="cuda")
+    smin = torch.full((E,), s2[1], dtype=torch.float32, device="cuda")
+    o2 = ops.kron_quant_grouped(h, L2, R2, offs, smax, smin, T | F | RY | QL | SL)
+    assert close_bf16(bits(o2.y), g["y2_bits"])
+    ref2 = O.quant_outputs(O.bf16_from_bits(bits(o2.y)), *s2, round_y_f16=True, quant_f16=True, sig_f16=True, lowp="bf16")
+    assert np.array_equal(bits(o2.fq[0]), O.bf16_bits(ref2["fq"]))
+    assert np.mean(bits(o2.fq[0]) != g["fq2_bits"]) < 3e-2
+
+
+def test_bf16_dyadic_inputs_bit_exact(ops):
+    """Every partial sum representable in bf16 and fp32 -> independent of the MFMA's summation order: bit-exact end to end."""
+    rng = np.random.RandomState(7)
+    for M, N in ((64, 64), (32, 64), (64, 128)):
+        x = (rng.randint(-8, 9, size=(12, M * N)) / 8.0).astype(np.float32)
+
+        def hadlike(n, seed):
+            r = np.random.RandomState(seed)
+            h = np.array([[1.0]])
+            while h.shape[0] < n:
+                h = np.block([[h, h], [h, -h]])
+            return (h[r.permutation(n)] * r.choice([-1.0, 1.0], size=(1, n)) / 8.0).astype(np.float32)
+        L, R = hadlike(M, 1), hadlike(N, 2)
+        xd, Ld, Rd = (torch.from_numpy(a).to(BF).cuda() for a in (x, L, R))
+        o = ops.kron_quant(xd, Ld, Rd, [(0.982, 0.9)], T | F | P | RY)
+        ref = O.kron_quant(x, L, R, 0.982, 0.9, round_y_f16=True, lowp="bf16")
+        assert np.array_equal(bits(o.y), O.bf16_bits(ref["y16"]))
+        assert np.array_equal(bits(o.fq[0]), O.bf16_bits(ref["fq"]))
+        assert np.array_equal(o.q[0].cpu().numpy(), ref["packed"])
+
+
+def test_bf16_full_size_properties(ops):
+    """BASELINE config 2 in bf16: 16384 x 4096 through the fake-quant contract; every row's outputs are multiples of its
+    scale within [-8 s, 7 s], the extreme element reaches +-7 s, and 64 sampled rows equal the oracle on the launch's own
+    transform."""
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    rows = 16384
+    x = torch.randn(rows, 4096, device="cuda", generator=gen).to(BF)
+    L = (torch.randn(64, 64, device="cuda", generator=gen) / 8).to(BF)
+    R = (torch.randn(64, 64, device="cuda", generator=gen) / 8).to(BF)
+    sig = (0.982, 0.982)
+    o = ops.kron_quant(x, L, R, [sig], T | F | RY)
+    y, fq = o.y.float(), o.fq[0].float()
+    m = torch.maximum(y.amax(1).clamp_min(0) * sig[0], (y.amin(1).clamp_max(0) * sig[1]).abs())
+    s = m / 7
+    assert bool((fq.abs().amax(1) <= 8 * s * 1.004 + 1e-6).all())
+    idx = torch.arange(0, rows, rows // 64, device="cuda")
+    ref = O.quant_outputs(O.bf16_from_bits(bits(o.y[idx])), *sig, round_y_f16=True, lowp="bf16")
+    assert np.array_equal(bits(o.fq[0][idx]), O.bf16_bits(ref["fq"]))
+
+
+def test_bf16_refused_where_the_reference_has_no_bf16_contract(ops):
+    from flatquant_amd import _lib
+    x = torch.zeros(4, 4096, dtype=BF, device="cuda")
+    L = torch.eye(64, dtype=BF, device="cuda")
+    with pytest.raises(TypeError):
+        ops.kron_quant(x, L.half(), L)                       # mixed dtypes
+    with pytest.raises(TypeError):
+        ops.rmsnorm(x)                                       # deploy.nn.RMSNorm is an fp16 module
+    o = ops.kron_quant(x, L, L, flags=P, groupsize=128)      # composed route (transform + row quantiser), not refused
+    assert o.scale[0].shape == (4, 32) and o.scale[0].dtype == BF
+    assert _lib.lib.fq_version() >= 120

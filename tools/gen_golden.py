@@ -681,6 +681,219 @@ def gen_act_asym():
     save("act_asym", **arrays)
 
 
+# ------------------------------------------------------------------------------------------------
+# round 3: bfloat16 activations (the dtype the reference's own eval pipeline feeds this path on Llama-3 / Qwen / DeepSeek:
+# flatquant/model_utils.py:20 torch_dtype='auto', train_utils.py:28, main_dpskv3.py:241,395) and head counts other than 32 / 64.
+# numpy has no bfloat16: bf16 tensors are stored as their 16-bit patterns (uint16, suffix _bits).
+# ------------------------------------------------------------------------------------------------
+def bits(t):
+    assert t.dtype == torch.bfloat16
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def path_a_bf16(x, L, R, clip_max, clip_min, mode, diag=None):
+    """Reference path A on bf16 activations. mode: "lac32" — clip parameters fp32 (flat_linear.py:16 under the fp32 default
+    dtype next to a bf16 model: statistics, scale, quotient promoted to fp32), "lac16" — the quantiser .bfloat16()'ed (what
+    torch.set_default_dtype(bfloat16) of main_dpskv3.py:395 gives: everything stays bf16), "nolac" — no clip parameters."""
+    M, N = L.shape[0], R.shape[0]
+    tr = RefInvDec(M, N, add_diag=diag is not None, diag_init_para=None if diag is None else diag.clone())
+    tr.to_eval_mode()
+    tr.matrix_left.data = L.clone()
+    tr.matrix_right.data = R.clone()
+    q = RefActQ(bits=4, sym=True, lac=mode != "nolac")
+    if mode != "nolac":
+        q.clip_factor_a_max.data.fill_(clip_max)
+        q.clip_factor_a_min.data.fill_(clip_min)
+    if mode == "lac16":
+        q = q.bfloat16()
+    with torch.no_grad():
+        xin = x.to(torch.bfloat16)
+        y = tr(xin)
+        assert y.dtype == torch.bfloat16
+        scale, _ = q.get_scale_zero(y)
+        fq = q(y)
+        assert fq.dtype == torch.bfloat16
+        from flatquant.quant_utils import sym_quant
+        qi, _ = sym_quant(y, scale, q.q_max.to(y))
+    out = {"y_bits": bits(y), "scale": scale[:, 0].float().numpy(), "scale_dtype": str(scale.dtype),
+           "q": qi.float().numpy().astype(np.int8), "fq_bits": bits(fq)}
+    if mode == "lac16":   # torch.sigmoid of the bf16 parameter (fp32 opmath, rounded to bf16)
+        out["sig"] = np.array([float(torch.sigmoid(p.detach())) for p in (q.clip_factor_a_max, q.clip_factor_a_min)], dtype=np.float32)
+    return out
+
+
+def gen_bf16():
+    arrays = {}
+    # 1. transform + symmetric quantiser, the factor pairs of Llama-3-8B (64x64), DeepSeek-V3 (64x112, 32x64), the ffn 112x128
+    for M, N, rows in [(64, 64, 8), (64, 112, 4), (32, 64, 8), (112, 128, 3), (56, 64, 4), (128, 148, 2)]:
+        d = M * N
+        x = make_x(rows, d, seed=400 + M).to(torch.bfloat16)
+        L, R = make_mat(M, 401).to(torch.bfloat16), make_mat(N, 402).to(torch.bfloat16)
+        tag = f"k{M}x{N}"
+        arrays[f"{tag}_x_bits"], arrays[f"{tag}_L_bits"], arrays[f"{tag}_R_bits"] = bits(x), bits(L), bits(R)
+        for mode, clips in (("lac32", (2.3, 0.7)), ("lac16", (2.3, 0.7)), ("nolac", (0, 0))):
+            a = path_a_bf16(x.float(), L.float(), R.float(), clips[0], clips[1], mode)
+            assert a["scale_dtype"] == ("torch.float32" if mode == "lac32" else "torch.bfloat16"), (mode, a["scale_dtype"])
+            for k in ("y_bits", "scale", "q", "fq_bits"):
+                arrays[f"{tag}_{mode}_{k}"] = a[k]
+            if mode == "lac16":
+                arrays[f"{tag}_lac16_sig"] = a["sig"]
+        arrays[f"{tag}_lac32_sig"] = np.array([sig(2.3), sig(0.7)], dtype=np.float32)
+    # diag_scale (trans_utils.py:192-196) in bf16, and inv_t (division by the diagonal)
+    M = N = 64
+    x = make_x(4, M * N, seed=410).to(torch.bfloat16)
+    diag = (torch.rand(M * N, generator=torch.Generator().manual_seed(411)) + 0.5)
+    tr = RefInvDec(M, N, add_diag=True, diag_init_para=diag.clone())
+    tr.linear_left.weight.data = make_mat(M, 412).float()
+    tr.linear_right.weight.data = make_mat(N, 413).float()
+    tr.to_eval_mode()
+    with torch.no_grad():
+        arrays["dec_y_bits"] = bits(tr(x))
+        arrays["dec_y_inv_t_bits"] = bits(tr(x, inv_t=True))
+    for k in ("matrix_left", "matrix_right", "matrix_left_inv", "matrix_right_inv", "diag_scale"):
+        arrays["dec_" + k] = getattr(tr, k).detach().float().numpy()
+    arrays["dec_x_bits"] = bits(x)
+    # 2. ActivationQuantizer alone on bf16 rows: symmetric and asymmetric, every promotion route
+    cases = [("lac32", dict(lac=True), (4.0, 4.0)), ("lac32b", dict(lac=True), (1.7, 0.4)), ("plain", dict(lac=False), None),
+             ("ratio", dict(lac=False, clip_ratio=0.83), None), ("lac16", dict(lac=True), (2.1, 0.9))]
+    for sym in (True, False):
+        for ci, (name, kw, clips) in enumerate(cases):
+            for cols in (128, 4096, 7168):
+                x = make_x(8, cols, seed=420 + ci * 10 + cols % 7 + (0 if sym else 50)).to(torch.bfloat16)
+                x[1] = 0
+                x[2] = x[2].abs()
+                x[3] = -x[3].abs()
+                x[4, ::3] *= 30
+                q = RefActQ(bits=4, sym=sym, **kw)
+                if clips is not None:
+                    q.clip_factor_a_max.data.fill_(clips[0])
+                    q.clip_factor_a_min.data.fill_(clips[1])
+                if name == "lac16":
+                    q = q.bfloat16()
+                with torch.no_grad():
+                    y = q(x)
+                assert y.dtype == torch.bfloat16
+                t = f"aq_{'sym' if sym else 'asym'}_{name}_{cols}"
+                arrays[t + "_x_bits"], arrays[t + "_y_bits"] = bits(x), bits(y)
+            if clips is not None and sym:
+                if name == "lac16":
+                    arrays[f"aq_{name}_sig"] = np.array([float(torch.sigmoid(torch.tensor(c, dtype=torch.bfloat16))) for c in clips], dtype=np.float32)
+                else:
+                    arrays[f"aq_{name}_sig"] = np.array([sig(c) for c in clips], dtype=np.float32)
+    # 3. FlatQuantizedLinear._eval_forward on a bf16 model (fp32 clip parameters: the HF flow) and fully .bfloat16()'ed
+    from flatquant.flat_linear import FlatQuantizedLinear as RefFQL
+    args = types.SimpleNamespace(w_bits=4, w_asym=False, a_bits=4, a_asym=False, lac=True, a_groupsize=-1, lwc=False)
+    lin = torch.nn.Linear(4096, 96, bias=True)
+    g = torch.Generator().manual_seed(430)
+    lin.weight.data = (torch.randn(96, 4096, generator=g) / 64)
+    lin.bias.data = torch.randn(96, generator=g)
+    fql = RefFQL(args, lin)
+    fql.act_quantizer.clip_factor_a_max.data.fill_(3.3)
+    fql.act_quantizer.clip_factor_a_min.data.fill_(2.1)
+    fql.reparameterize()
+    fql.linear = fql.linear.bfloat16()          # the model is bf16, the FlatQuant parameters stay fp32
+    xin = make_x(7, 4096, seed=431).to(torch.bfloat16)
+    with torch.no_grad():
+        arrays["fql_out_bits"] = bits(fql(xin))
+        arrays["fql_fq_bits"] = bits(fql.act_quantizer(xin).to(torch.bfloat16))
+    arrays["fql_x_bits"], arrays["fql_w_bits"], arrays["fql_b_bits"] = bits(xin), bits(fql.linear.weight.detach()), bits(fql.linear.bias.detach())
+    arrays["fql_sig"] = np.array([sig(3.3), sig(2.1)], dtype=np.float32)
+    save("bf16_path_a", **arrays)
+
+
+def gen_moe_bf16():
+    """gen_moe_grouped in the dtype the reference runs it in: torch.set_default_dtype(bfloat16) (main_dpskv3.py:395,
+    deepseek_v3/model.py:807) — activations, transform matrices AND the clip parameters are bf16, so the quantiser takes the
+    all-bf16 route (bf16 sigmoid, bf16 product, bf16 scale / quotient)."""
+    T, E, K = 24, 8, 2
+    d1, (M1, N1) = 7168, ref_get_decompose_dim(7168)
+    d2, (M2, N2) = 2048, ref_get_decompose_dim(2048)
+    g = torch.Generator().manual_seed(450)
+    x = make_x(T, d1, seed=451).to(torch.bfloat16)
+    pop = torch.tensor([8.0, 4.0, 2.0, 1.0, 0.5, 0.0, 0.25, 0.0])
+    indices = torch.stack([torch.multinomial(pop, K, replacement=False, generator=g) for _ in range(T)])
+    bf = torch.bfloat16
+    L1, R1, L2, R2 = make_mat(M1, 452).to(bf), make_mat(N1, 453).to(bf), make_mat(M2, 454).to(bf), make_mat(N2, 455).to(bf)
+    clip1, clip2 = (3.1, 2.2), (4.0, 1.3)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        def quantizer(cmax, cmin):
+            q = RefActQ(bits=4, sym=True, lac=True)
+            assert q.clip_factor_a_max.dtype == torch.bfloat16
+            q.clip_factor_a_max.data.fill_(cmax)
+            q.clip_factor_a_min.data.fill_(cmin)
+            return q
+        q1, q2 = quantizer(*clip1), quantizer(*clip2)
+        sig1 = [float(torch.sigmoid(p.detach())) for p in (q1.clip_factor_a_max, q1.clip_factor_a_min)]
+        sig2 = [float(torch.sigmoid(p.detach())) for p in (q2.clip_factor_a_max, q2.clip_factor_a_min)]
+        with torch.no_grad():
+            xt = ref_kronecker_matmul(x, L1, R1)
+            counts = torch.bincount(indices.flatten(), minlength=E).tolist()
+            rows_tok, fq1, hs, fq2, y2s, offs = [], [], [], [], [], [0]
+            for i in range(E):
+                offs.append(offs[-1] + counts[i])
+                if counts[i] == 0:
+                    continue
+                idx, top = torch.where(indices == i)
+                rows_tok.append(idx)
+                fq1.append(q1(xt[idx]))
+                h = make_x(counts[i], d2, seed=500 + i).to(bf)
+                hs.append(h)
+                y2 = ref_kronecker_matmul(h, L2, R2)
+                y2s.append(y2)
+                fq2.append(q2(y2))
+    finally:
+        torch.set_default_dtype(old)
+    save("moe_bf16", x_bits=bits(x), indices=indices.numpy(), L1_bits=bits(L1), R1_bits=bits(R1), L2_bits=bits(L2), R2_bits=bits(R2),
+         sig1=np.array(sig1, dtype=np.float32), sig2=np.array(sig2, dtype=np.float32), offsets=np.array(offs, dtype=np.int64),
+         rows_tok=torch.cat(rows_tok).numpy(), xt_bits=bits(xt), fq1_bits=bits(torch.cat(fq1)), h_bits=bits(torch.cat(hs)),
+         y2_bits=bits(torch.cat(y2s)), fq2_bits=bits(torch.cat(fq2)))
+
+
+def gen_heads():
+    """o_proj head transform for head counts other than 32 / 64 (num_attention_heads = 28: Qwen2.5-7B; 40: Llama-2-13B,
+    Qwen2.5-14B / 32B; 12, 16: the small Qwen2.5). Path A: {SVD}SingleTransMatrix.forward (trans_utils.py:21-25, call site
+    llama_utils.py:275-277) in fp16 and bf16. Path B: the reference's Triton block_matmul (block_matmul.py:29-104) where
+    the interpreter takes the size (tl.arange wants powers of two: recorded per head count in `pathb_ok`)."""
+    from flatquant.trans_utils import SVDSingleTransMatrix as RefSVDSingle
+    arrays, ok = {}, []
+    for H, hd in [(28, 128), (40, 128), (48, 64), (12, 128), (16, 128), (14, 64)]:
+        T = 5
+        st = RefSVDSingle(H)
+        st.linear_u.weight.data = torch.from_numpy(np.linalg.qr(np.random.RandomState(600 + H).randn(H, H))[0]).float()
+        st.to_eval_mode()
+        a = make_x(T, H * hd, seed=601 + H)
+        a4 = a.reshape(T, H, hd).transpose(-1, -2).contiguous()            # [T, hd, H]: heads last, as llama_utils.py:276
+        tag = f"h{H}x{hd}"
+        with torch.no_grad():
+            arrays[f"{tag}_y16"] = st(a4.to(torch.float16)).numpy()
+            arrays[f"{tag}_y16_inv_t"] = st(a4.to(torch.float16), inv_t=True).numpy()
+            arrays[f"{tag}_ybf_bits"] = bits(st(a4.to(torch.bfloat16)))
+        arrays[f"{tag}_x"] = a4.to(torch.float16).numpy()
+        arrays[f"{tag}_matrix"] = st.matrix.detach().numpy()
+        arrays[f"{tag}_matrix_inv_t"] = st.matrix_inv_t.detach().numpy()
+        # path B (deploy): [bsz, seq, hd, H] @ P, quantised per token, transposed pack
+        P = make_mat(H, 602 + H)
+        x4 = a4.to(torch.float16).reshape(1, T, hd, H)
+        try:
+            qx, sx = path_b_block(x4, P, 4.0, 4.0)
+            arrays[f"{tag}_b_packed"], arrays[f"{tag}_b_scale"], arrays[f"{tag}_P"] = qx, sx, P.numpy()
+            arrays[f"{tag}_b_sig"] = np.array([sig(4.0), sig(4.0)], dtype=np.float32)
+            ok.append(1)
+        except Exception as e:  # noqa: BLE001
+            print(f"path B block_matmul refuses H={H}, hd={hd}: {type(e).__name__}: {str(e)[:120]}")
+            ok.append(0)
+    arrays["pathb_ok"] = np.array(ok)
+    save("heads_any", **arrays)
+
+
+def gen_round3():
+    gen_bf16()
+    gen_moe_bf16()
+    gen_heads()
+
+
 def gen_round2():
     gen_act_asym()
     gen_kv_class()
@@ -694,6 +907,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt2k":   # the K = 2048 export (12 MB): only on request
         gen_checkpoint(hidden=2048, ffn=2048, heads=16, kv_heads=2, layers=1, name="ckpt2k", clip_noise=0.6)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "r3":
+        gen_round3()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "asym":
         gen_act_asym()
@@ -733,3 +949,4 @@ if __name__ == "__main__":
     gen_block_b()
     gen_kron_b()
     gen_round2()
+    gen_round3()
