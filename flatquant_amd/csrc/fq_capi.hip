@@ -234,7 +234,8 @@ static int kron_quant_grouped_impl(const char* what, int dt, const void* x, cons
     if (rows < 0 || M <= 0 || N <= 0) return fail(FQ_EINVAL, "%s: bad sizes rows=%lld M=%d N=%d", what, (long long)rows, M, N);
     if (N & 1) return fail(FQ_EINVAL, "%s: N=%d must be even (two INT4 per byte)", what, N);
     if (n_groups < 1) return fail(FQ_EINVAL, "%s: n_groups=%d", what, n_groups);
-    if (flags & FQ_QUANT_F16) return fail(FQ_EUNSUPPORTED, "%s: fp32 quantiser arithmetic only", what);
+    if ((flags & FQ_QUANT_F16) && (flags & (FQ_OUT_PACKED | FQ_GROUP128)))
+        return fail(FQ_EUNSUPPORTED, "%s: the low-precision quantiser arithmetic is offered for the fake-quant output only", what);
     const bool quant = (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) != 0;
     const float one = 1.0f;  // fill_out wants a host clip pair; the kernels read the per-group device arrays instead
     void* q1[FQ_MAX_CLIPS] = {q_out}, *s1[FQ_MAX_CLIPS] = {scale_out}, *f1[FQ_MAX_CLIPS] = {fq_out};

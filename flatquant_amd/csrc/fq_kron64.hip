@@ -678,6 +678,12 @@ static int launch_kron64_any(int flags, const T* x, const T* left, const T* righ
                 return launch_kron64<FQ_OUT_PACKED | FQ_OUT_TRANSFORM | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream);
             case FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM:
                 return launch_kron64<FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream);
+            // the all-low-precision quantiser (clip parameters of the activation's dtype: the DeepSeek flow under
+            // torch.set_default_dtype(bfloat16), main_dpskv3.py:395)
+            case FQ_OUT_FAKEQUANT | FQ_QUANT_F16:
+                return launch_kron64<FQ_OUT_FAKEQUANT | FQ_QUANT_F16 | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream);
+            case FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_QUANT_F16:
+                return launch_kron64<FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_QUANT_F16 | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream);
             default:
                 return -1000;
         }

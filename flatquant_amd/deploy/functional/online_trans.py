@@ -44,7 +44,7 @@ def quant(x, clip_factor_a_max=1.0, clip_factor_a_min=1.0, input_clip_ratio=1.0)
     x2 = x.reshape(-1, x.shape[-1])
     if cmax != 1.0:
         # :91-104: fp16 extrema x a 0-dim fp32 sigmoid tensor is an fp16 product under torch's promotion -> FQ_SIG_F16
-        o = ops.rowquant(x2.contiguous(), [ops.sigmoid_pair(cmax, cmin)], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)
+        o = ops.rowquant(x2.contiguous(), [ops.sigmoid_pair_f16(cmax, cmin)], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)
     elif input_clip_ratio != 1.0:
         # :106: (max|x| / 7).to(fp16) * ratio keeps the reference's op order in torch (x itself, not the flattened view:
         # the scales keep x's leading shape); the pack is the kernel behind deploy.sym_quant

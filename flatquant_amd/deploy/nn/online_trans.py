@@ -55,7 +55,7 @@ class OnlineTrans(torch.nn.Module):
             if quantizer is not None and getattr(quantizer, "lac", False) and not self.fp32_trans:
                 from ... import ops
                 from .. import PackedQuantizedTensor
-                sig = ops.sigmoid_pair(quantizer.clip_factor_a_max, quantizer.clip_factor_a_min)
+                sig = ops.sigmoid_pair_f16(quantizer.clip_factor_a_max, quantizer.clip_factor_a_min)   # (device semantics)
                 q, s = ops.hadamard_quant(x.contiguous(), self.rem_dim, self.had_rem_dim, sig,
                                           up=None if up is None else up.contiguous())
                 lead = x.shape[:-1]

@@ -9,9 +9,10 @@ from .. import PackedQuantizedTensor
 class Quantizer(torch.nn.Module):
     """Per-token INT4 activation quantiser; passes an already packed input through.
     Reference: deploy/nn/quantization.py:5-36 (5-8 torch launches + the CUDA pack kernel) — here one HIP
-    launch reads each row once.  Arithmetic as the reference: extrema of the fp16 data, extremum x sigmoid rounded to
-    fp16 (torch's promotion of fp16 tensor x 0-dim fp32 tensor), fp16 division by 7, x / scale in fp16 (quant.cu:40),
-    round-half-even, clamp, low nibble = even column."""
+    launch reads each row once.  Arithmetic as the reference ON A DEVICE: extrema of the fp16 data, the 0-dim fp32 sigmoid
+    cast to fp16 and the product rounded to fp16 (torch's device kernels load a 0-dim operand in the result dtype:
+    ops.sigmoid_pair_f16), fp16 division by 7, x / scale in fp16 (quant.cu:40), round-half-even, clamp, low nibble = even
+    column."""
 
     def __init__(self, input_clip_ratio=1.0, lac=False):
         super().__init__()
@@ -24,7 +25,7 @@ class Quantizer(torch.nn.Module):
         if isinstance(x, PackedQuantizedTensor):
             return x
         if self.lac:
-            sig = ops.sigmoid_pair(self.clip_factor_a_max, self.clip_factor_a_min)
+            sig = ops.sigmoid_pair_f16(self.clip_factor_a_max, self.clip_factor_a_min)
         elif self.input_clip_ratio == 1.0:
             sig = (1.0, 1.0)
         else:

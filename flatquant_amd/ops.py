@@ -32,6 +32,17 @@ def sigmoid_pair(clip_max, clip_min) -> Sig:
     return _sigmoid_pair_cached(host_scalar(clip_max), host_scalar(clip_min))
 
 
+def sigmoid_pair_f16(clip_max, clip_min) -> Sig:
+    """sigmoid_pair rounded to fp16: what a DEVICE multiplies an fp16 tensor with when the other operand is a 0-dim fp32
+    tensor (deploy/nn/quantization.py:21-22, deploy/functional/online_trans.py:97-98 move the 0-dim sigmoid to x's device;
+    torch's device kernels cast a 0-dim operand to the result dtype on load — measured on MI355X,
+    tools/scratch/sig_f16_probe.py: every finite fp16 extremum agrees with fp16(x * fp16(sigmoid)); the CPU keeps the fp32
+    value). The product of two fp16 values is exact in fp32, so FQ_SIG_F16 then rounds once."""
+    a, b = sigmoid_pair(clip_max, clip_min)
+    t = torch.tensor([a, b], dtype=torch.float32).to(torch.float16)
+    return float(t[0]), float(t[1])
+
+
 _SCALARS: "collections.OrderedDict" = collections.OrderedDict()
 
 

@@ -187,3 +187,24 @@ def test_functional_quant_lac_and_input_clip_ratio(ops, golden):
     p1 = quant(x.cuda())
     ref = O.rowquant(x.numpy(), quant_f16=True)
     assert np.array_equal(p1.quantized_x.cpu().numpy(), ref["packed"]) and np.array_equal(p1.scales_x.cpu().numpy().reshape(-1), ref["scale16"])
+
+
+def test_deploy_quantizer_lac_scales_equal_torch_device_ops(ops):
+    """deploy/nn/quantization.py:15-28 evaluated by torch ON THE DEVICE, op for op (the reference never runs this module
+    anywhere else: its pack kernel is CUDA): the 0-dim fp32 sigmoid is loaded in the result dtype by torch's device kernels,
+    so the extremum is multiplied with the fp16-ROUNDED sigmoid (tools/scratch/sig_f16_probe.py; round-2 ADVICE). The HIP
+    launch must give the same fp16 scales bit for bit — this is the live form of tests/golden/quantizer_lac.npz."""
+    from flatquant_amd import deploy
+    for ci, (cmax, cmin) in enumerate([(4.0, 4.0), (2.3, -0.7), (0.31, 1.9), (1.0, 3.0)]):
+        x = rand_x(512, 4096, 40 + ci).cuda()
+        qz = deploy.nn.Quantizer(lac=True).cuda()
+        qz.clip_factor_a_max.fill_(cmax), qz.clip_factor_a_min.fill_(cmin)
+        p = qz(x)
+        xmax, xmin = x.amax(1, keepdim=True), x.amin(1, keepdim=True)
+        tmp = torch.zeros_like(xmax)
+        xmax, xmin = torch.maximum(xmax, tmp), torch.minimum(xmin, tmp)
+        xmax = xmax * torch.sigmoid(torch.tensor(cmax).to(x.device))
+        xmin = xmin * torch.sigmoid(torch.tensor(cmin).to(x.device))
+        xmax = torch.maximum(torch.abs(xmin), xmax)
+        scales = (xmax / 7).to(torch.float16)
+        assert torch.equal(p.scales_x.reshape(-1), scales.reshape(-1)), ci

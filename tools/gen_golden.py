@@ -618,6 +618,22 @@ def gen_quantizer_lac():
     deploy.sym_quant (quant.cu:13-47, cannot be built here) is stood in for by its restatement."""
     from deploy.nn.quantization import Quantizer as RefQuantizer
     import deploy as ref_deploy
+    import deploy.nn.quantization as ref_qmod
+
+    # Accommodation 4 (round 3, harness side; no reference file touched): DEVICE semantics of `fp16 tensor * 0-dim fp32
+    # tensor`. The reference moves the 0-dim sigmoid to x's device (quantization.py:21-22 `.to(x.device)`); torch's device
+    # kernels cast a 0-dim operand to the result dtype on load, so the product is fp16(x * fp16(sigmoid)) — measured on the
+    # MI355X with tools/scratch/sig_f16_probe.py: 63487 of 63487 finite fp16 extrema agree with that form for four clip values,
+    # 44667-56899 with the CPU's fp16(x * fp32 sigmoid). The deploy modules only ever run on a device (their pack kernel is
+    # CUDA), so the device form is the contract: the module runs here with torch.sigmoid's result rounded to fp16.
+    class _DeviceSigmoid:
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def sigmoid(t):
+            return torch.sigmoid(t).to(torch.float16)
+    ref_qmod.torch = _DeviceSigmoid()
 
     def sym_quant_restated(x, scale):      # quant.cu:40: __half2int_rn(__hdiv(x, s)), clamp, low nibble = even column
         q = torch.clamp(torch.round((x / scale[:, None]).to(torch.float16).float()), -8, 7).to(torch.int8)
@@ -636,7 +652,9 @@ def gen_quantizer_lac():
         assert p.scales_x.dtype == torch.float16
         arrays[f"x{ci}"], arrays[f"scales{ci}"], arrays[f"packed{ci}"] = x.numpy(), p.scales_x.numpy().reshape(-1), p.quantized_x.numpy()
         arrays[f"clip{ci}"] = np.array([cmax, cmin], dtype=np.float32)
-        arrays[f"sig{ci}"] = np.array([sig(cmax), sig(cmin)], dtype=np.float32)
+        arrays[f"sig32_{ci}"] = np.array([sig(cmax), sig(cmin)], dtype=np.float32)
+        arrays[f"sig{ci}"] = arrays[f"sig32_{ci}"].astype(np.float16).astype(np.float32)    # what the device multiplies with
+    ref_qmod.torch = torch
     save("quantizer_lac", **arrays)
 
 
