@@ -561,6 +561,61 @@ __device__ __forceinline__ uint32_t fq_quant8_two(float y0, float y1, float y2, 
     return a;
 }
 
+// The quantiser of the FAKE-QUANT output (FlatQuantizedLinear._eval_forward, flat_linear.py:75-80 -> quant_utils.py:77-83):
+// eight transformed values -> eight fp16 (bf16) values scale * q, one asm block, single-width VALU only (round 3; the C++ form
+// fq_qmagic2 is turned into v_pk_fma_f32 / v_pk_add_f32 by the SLP vectoriser: slow next to other waves' MFMAs, see above).
+// One-sided exactness test, as fq_qmagic2: u = fma(y, inv, MAGIC) rounds the exact product to an integer, r = u - MAGIC
+// (never -0.0: x - x = +0), e = fma(y, inv, -r) is the residual rounded once; |e| <= 0.5 - FQ_NEAR proves
+// rint(fl(y / s)) == r (|y inv - y/s| and |fl(y/s) - y/s| <= |t| 2^-23.4 < FQ_NEAR for |t| <= 16; beyond, both sides clamp
+// alike). dmax accumulates max |e| over the caller's whole token: ONE wave vote per token instead of one per 16-byte piece.
+// p = r * scale is rounded to fp32 by v_mul_f32 and to T by the conversion: the two roundings of (scale * q).to(x_dtype).
+// 41 VALU per 8 elements (49 with the clamp).
+template <bool CLAMP, typename T>
+__device__ __forceinline__ u32x4 fq_fake8(float y0, float y1, float y2, float y3, float y4, float y5, float y6, float y7,
+                                          float inv, float scale, float& dmax) {
+    uint32_t d0, d1, d2, d3;
+    float u0, u1, e0, e1;
+    const float magic = FQ_MAGIC;
+    float lo = -8.0f, hi = 7.0f;
+    if (CLAMP) asm volatile("" : "+v"(lo), "+v"(hi));  // (VGPR operands: neither is an inline constant, one SGPR per VALU op)
+#define FQ_FK1(u, e, y)                                                 \
+    "v_fma_f32 %[" #u "], %[" #y "], %[inv], %[mg]\n\t"                 \
+    "v_subrev_f32_e32 %[" #u "], %[mg], %[" #u "]\n\t"                  \
+    "v_fma_f32 %[" #e "], %[" #y "], %[inv], -%[" #u "]\n\t"
+#define FQ_FKC(u) "v_med3_f32 %[" #u "], %[" #u "], %[lo], %[hi]\n\t"
+#define FQ_FK_MAX "v_max3_f32 %[dm], %[dm], |%[e0]|, |%[e1]|\n\t"
+#define FQ_FK_MUL(u) "v_mul_f32_e32 %[" #u "], %[sc], %[" #u "]\n\t"
+#define FQ_FK_CVT_F16(d) "v_cvt_pk_f16_f32 %[" #d "], %[u0], %[u1]\n\t"
+#define FQ_FK_CVT_BF16(d) "v_cvt_pk_bf16_f32 %[" #d "], %[u0], %[u1]\n\t"
+#define FQ_FK_PAIR(d, ya, yb, CL, CVT) FQ_FK1(u0, e0, ya) FQ_FK1(u1, e1, yb) FQ_FK_MAX CL(u0) CL(u1) FQ_FK_MUL(u0) FQ_FK_MUL(u1) CVT(d)
+#define FQ_FK_NOCL(u)
+#define FQ_FK_OUTS [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [u0] "=&v"(u0), [u1] "=&v"(u1), \
+                   [e0] "=&v"(e0), [e1] "=&v"(e1), [dm] "+v"(dmax)
+#define FQ_FK_INS [y0] "v"(y0), [y1] "v"(y1), [y2] "v"(y2), [y3] "v"(y3), [y4] "v"(y4), [y5] "v"(y5), [y6] "v"(y6), \
+                  [y7] "v"(y7), [inv] "v"(inv), [sc] "v"(scale), [mg] "s"(magic)
+#define FQ_FK_BODY(CL, CVT) FQ_FK_PAIR(d0, y0, y1, CL, CVT) FQ_FK_PAIR(d1, y2, y3, CL, CVT) FQ_FK_PAIR(d2, y4, y5, CL, CVT) \
+                            FQ_FK_PAIR(d3, y6, y7, CL, CVT)
+    if (FqVec<T>::is_f16) {
+        if (CLAMP) asm(FQ_FK_BODY(FQ_FKC, FQ_FK_CVT_F16) : FQ_FK_OUTS : FQ_FK_INS, [lo] "v"(lo), [hi] "v"(hi));
+        else asm(FQ_FK_BODY(FQ_FK_NOCL, FQ_FK_CVT_F16) : FQ_FK_OUTS : FQ_FK_INS);
+    } else {
+        if (CLAMP) asm(FQ_FK_BODY(FQ_FKC, FQ_FK_CVT_BF16) : FQ_FK_OUTS : FQ_FK_INS, [lo] "v"(lo), [hi] "v"(hi));
+        else asm(FQ_FK_BODY(FQ_FK_NOCL, FQ_FK_CVT_BF16) : FQ_FK_OUTS : FQ_FK_INS);
+    }
+#undef FQ_FK1
+#undef FQ_FKC
+#undef FQ_FK_MAX
+#undef FQ_FK_MUL
+#undef FQ_FK_CVT_F16
+#undef FQ_FK_CVT_BF16
+#undef FQ_FK_PAIR
+#undef FQ_FK_NOCL
+#undef FQ_FK_OUTS
+#undef FQ_FK_INS
+#undef FQ_FK_BODY
+    return u32x4{d0, d1, d2, d3};
+}
+
 // The reciprocals fq_quant8_two takes, from inv = fq_fast_inv(scale): 1 -+ 2^-21.
 __device__ __forceinline__ float fq_inv_lo(float inv) { return inv * 0.999999523162841796875f; }
 __device__ __forceinline__ float fq_inv_hi(float inv) { return inv * 1.000000476837158203125f; }

@@ -86,6 +86,8 @@ constexpr int kron64_threads() {
 #ifndef FQ_K64_THREADS
 #define FQ_K64_THREADS 1024
 #endif
+    // (round 3) the 16-bit-output sets (no packed output) run 8 waves: see STAGE in the kernel
+    if (!(FLAGS & FQ_OUT_PACKED)) return 512;
     return (outs == 1 && !(FLAGS & (FQ_QUANT_F16 | FQ_K64_G128 | FQ_K64_GROUPED))) ? FQ_K64_THREADS : 512;
 }
 
@@ -175,14 +177,14 @@ __device__ __forceinline__ unsigned quant_pack_token(const f32x16 (&Y)[2][2], co
 // buffer. Placed behind GEMM 1's first K-step: all eight X fragments were requested before the first MFMA, so the
 // buffer is free, and the DMA has the whole iteration to land (pulling after the statistics instead measured
 // 39.4 us against 35.7, tools/time_variants.py, round 1).
-#define FQ_PULL_NEXT()                                                       \
+#define FQ_PULL_NEXT(LDS_DST)                                                \
     {                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                   \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
         int nxt = 0;                                                         \
         if (lane == 0) nxt = (int)atomicAdd(next_slot, 1u);                  \
         nxt = __builtin_amdgcn_readfirstlane(nxt);                           \
-        if (nxt < blk_cnt) dma_token(x, blk_base + nxt, tok_lds, lane);      \
+        if (nxt < blk_cnt) dma_token(x, blk_base + nxt, (LDS_DST), lane);    \
         next_pulled = nxt;                                                   \
         __builtin_amdgcn_sched_barrier(0);                                   \
     }
@@ -203,6 +205,20 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     // output stores a single-clip packed token issues after its DMA (2 x 16 B + the scale): lets the top-of-loop
     // wait be a COUNTED vmcnt that does not also wait for the previous token's stores to reach memory.
     constexpr bool COUNTED_WAIT = (FLAGS & FQ_CT_MASK & ~FQ_IN_RMSNORM) == FQ_OUT_PACKED;
+    constexpr int OUT_SET = FLAGS & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM);
+    // (round 3) FULL-LINE stores for the 16-bit outputs (fake-quant / transform: 8 KB per token). Straight from the C/D fragment a
+    // lane holds 64 bytes of one output row and a store instruction puts 16 bytes into each of 32 different 128-byte lines:
+    // measured (tools/time_variants.py MODE=fq / y, same kernel with and without its stores) 35.6 us without them, 61-65 us with.
+    // With STAGE the eight pieces go through the wave's own 8 KB token buffer (XOR-swizzled, conflict-free both ways) and leave
+    // as eight 1 KB-contiguous non-temporal stores; the buffer is only free once the X fragments are in registers AND the next
+    // token has not been requested, so these instantiations request it after the stores instead of behind GEMM 1's first K-step
+    // (the other waves of the CU cover the wait), and they run EIGHT waves per CU, not sixteen: 16384 tokens, fake-quant output
+    // 64.0 -> 50.3 us (0.52 -> 0.67 of 8 TB/s), transform only 61 -> 46.3 (0.72), transform + fake-quant 99 -> 71.7 (0.70).
+    // Tried and dropped (A/B in one process): 16 waves with staging 63.3 (no gain over 63.5 unstaged: more waves,
+    // more requests in flight, lower throughput), a second token buffer per wave with the early request 52.3 (vs 50.3), a
+    // counted wait that leaves the stores in flight (no change), plain / sc1 / write-through stores (51.8 / 62.7 / 62.7).
+    constexpr bool STAGE = !(FLAGS & FQ_OUT_PACKED) && OUT_SET != 0;
+
     unsigned long long tr_wait = 0, tr_g1 = 0, tr_g2 = 0, tr_epi = 0;
     const unsigned long long tr_start = TRACE ? __builtin_amdgcn_s_memtime() : 0;
     const unsigned long long tr_start_rt = TRACE ? __builtin_amdgcn_s_memrealtime() : 0;  // 100 MHz, chip-wide
@@ -331,6 +347,25 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
         }
         first = false;
         FQ_TICK(c1)
+        // STAGE: piece w (16 bytes = columns 32 h + 8 w .. + 8) of output row 32 mo + c -> the token buffer, chunk index XOR
+        // (row & 7); then the whole 8 KB image leaves in row-linear order, 1 KB per store instruction
+        auto stage_put = [&](int mo, int w, u32x4 v) {
+            const int r = mo * 32 + c;
+            reinterpret_cast<u32x4*>(tokbuf)[r * 8 + ((h * 4 + w) ^ (r & 7))] = v;
+        };
+        auto stage_flush = [&](void* dst_token) {
+            const u32x4* tb = reinterpret_cast<const u32x4*>(tokbuf);
+            u32x4* dp = reinterpret_cast<u32x4*>(dst_token) + lane;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const u32x4 v = tb[(8 * i + (lane >> 3)) * 8 + ((lane & 7) ^ (lane >> 3))];
+#if !(FQ_K64_ABLATE & 8)
+                __builtin_nontemporal_store(v, dp + i * 64);
+#else
+                asm volatile("" : : "v"(v));
+#endif
+            }
+        };
 
         u32x4 X[2][4];
         {
@@ -390,7 +425,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
             U[1][0] = mfma32<T>(__builtin_bit_cast(X8, X[1][s]), b0, U[1][0]);
             U[0][1] = mfma32<T>(__builtin_bit_cast(X8, X[0][s]), b1, U[0][1]);
             U[1][1] = mfma32<T>(__builtin_bit_cast(X8, X[1][s]), b1, U[1][1]);
-            if (s == 0) FQ_PULL_NEXT()  // (all eight X fragments were requested before the first MFMA)
+            if (s == 0 && !STAGE) FQ_PULL_NEXT(tok_lds)  // (all eight X fragments were requested before the first MFMA)
         }
 
         // ---- fp16 rounding of U (flat_utils.py:15); C fragment -> A fragment of GEMM 2, no data movement ----
@@ -437,9 +472,11 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                         X8 v;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = (T)Y[nt][mo][w * 8 + e];
-                        yp[nt * 2 + w] = __builtin_bit_cast(uint4, v);
+                        if (STAGE) stage_put(mo, nt * 2 + w, __builtin_bit_cast(u32x4, v));
+                        else yp[nt * 2 + w] = __builtin_bit_cast(uint4, v);
                     }
             }
+            if (STAGE) stage_flush(reinterpret_cast<T*>(out.y) + tok * KD);
         }
 
         if (FLAGS & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) {
@@ -559,42 +596,44 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                                     fv[mo][w][e] = fq_dequant1<FLAGS, T>(fq_quant1<FLAGS, T>(FQ_YV(mo, w, e), scale), scale);
                     } else {
                         const float inv = fq_fast_inv(scale);
-                        const f32x2 inv2 = {inv, inv};
                         const bool magic = fq_magic_ok(vmax, vmin, inv);
                         const bool clampq = fq_needs_clamp(vmax, vmin, inv);
+                        // single-width asm quantiser (fq_fake8, fq_common.hpp), each 16-byte piece stored at once (keeping a
+                        // token's eight pieces costs 32 VGPRs this kernel lacks), ONE exactness vote per token
+                        float dmax = 0.0f;
+#if FQ_K64_ABLATE & 8
+#define FQ_FQ_STORE(mo, w, v) asm volatile("" : : "v"(v));
+#else
+#define FQ_FQ_STORE(mo, w, v)                                                                                              \
+    if (STAGE) stage_put(mo, w, v);                                                                                        \
+    else reinterpret_cast<u32x4*>(reinterpret_cast<T*>(out.fq[ci]) + tok * KD + ((mo) * 32 + c) * KN + h * 32)[w] = (v);
+#endif
+                        if (magic) {
 #pragma unroll
-                        for (int mo = 0; mo < 2; ++mo)
+                            for (int mo = 0; mo < 2; ++mo)
 #pragma unroll
-                            for (int w = 0; w < 4; ++w) {
-                                float dmax = 0.0f;
-                                f32x2 q[4];
-                                if (magic && clampq) {
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j)
-                                        q[j] = fq_qmagic2<true>(f32x2{FQ_YV(mo, w, 2 * j), FQ_YV(mo, w, 2 * j + 1)}, inv2, dmax);
-                                } else if (magic) {
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j)
-                                        q[j] = fq_qmagic2<false>(f32x2{FQ_YV(mo, w, 2 * j), FQ_YV(mo, w, 2 * j + 1)}, inv2, dmax);
+                                for (int w = 0; w < 4; ++w) {
+                                    const u32x4 o = clampq
+                                        ? fq_fake8<true, T>(FQ_YV(mo, w, 0), FQ_YV(mo, w, 1), FQ_YV(mo, w, 2), FQ_YV(mo, w, 3), FQ_YV(mo, w, 4),
+                                                            FQ_YV(mo, w, 5), FQ_YV(mo, w, 6), FQ_YV(mo, w, 7), inv, scale, dmax)
+                                        : fq_fake8<false, T>(FQ_YV(mo, w, 0), FQ_YV(mo, w, 1), FQ_YV(mo, w, 2), FQ_YV(mo, w, 3), FQ_YV(mo, w, 4),
+                                                             FQ_YV(mo, w, 5), FQ_YV(mo, w, 6), FQ_YV(mo, w, 7), inv, scale, dmax);
+                                    FQ_FQ_STORE(mo, w, o)
                                 }
-                                if (!magic || fq_wave_needs_exact(dmax)) {
+                        }
+                        if (!magic || fq_wave_needs_exact(dmax)) {  // rare (~3 % of tokens): the whole token with the true division
 #pragma unroll
-                                    for (int j = 0; j < 4; ++j)
-                                        q[j] = f32x2{fq_qexact(FQ_YV(mo, w, 2 * j), scale), fq_qexact(FQ_YV(mo, w, 2 * j + 1), scale)};
-                                }
-                                X8 o;
+                            for (int mo = 0; mo < 2; ++mo)
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) {  // fp16(fp32(scale * q)): two roundings, as torch (fq_mul_to_f16)
-                                    f32x2 pr = q[j] * f32x2{scale, scale};
-                                    asm volatile("" : "+v"(pr));
-                                    pr = pr + f32x2{0.0f, 0.0f};  // a zero product is +0.0 (fq_fake_f16, fq_common.hpp)
-                                    o[2 * j] = (T)pr.x;
-                                    o[2 * j + 1] = (T)pr.y;
+                                for (int w = 0; w < 4; ++w) {
+                                    X8 o;
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) o[e] = fq_fake<T>(scale, fq_qexact(FQ_YV(mo, w, e), scale));
+                                    FQ_FQ_STORE(mo, w, __builtin_bit_cast(u32x4, o))
                                 }
-                                // stored at once: keeping all eight chunks of a token costs 32 VGPRs this kernel lacks
-                                reinterpret_cast<uint4*>(out.fq[ci] + tok * KD + (mo * 32 + c) * KN + h * 32)[w] =
-                                    __builtin_bit_cast(uint4, o);
-                            }
+                        }
+#undef FQ_FQ_STORE
+                        if (STAGE) stage_flush(reinterpret_cast<T*>(out.fq[ci]) + tok * KD);
                     }
                     if (FLAGS & FQ_QUANT_F16) {
 #pragma unroll
@@ -602,8 +641,12 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                             uint4* fp =
                                 reinterpret_cast<uint4*>(out.fq[ci] + tok * KD + (mo * 32 + c) * KN + h * 32);
 #pragma unroll
-                            for (int w = 0; w < 4; ++w) fp[w] = __builtin_bit_cast(uint4, fv[mo][w]);
+                            for (int w = 0; w < 4; ++w) {
+                                if (STAGE) stage_put(mo, w, __builtin_bit_cast(u32x4, fv[mo][w]));
+                                else fp[w] = __builtin_bit_cast(uint4, fv[mo][w]);
+                            }
                         }
+                        if (STAGE) stage_flush(reinterpret_cast<T*>(out.fq[ci]) + tok * KD);
                     }
                 }
 #undef FQ_YV
@@ -616,6 +659,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                 tr_epi += c4 - c3;
             }
         }
+        if (STAGE) FQ_PULL_NEXT(tok_lds)  // (the buffer served as the output stage: the next token is requested only now)
         slot = next_pulled;
     }
     if (TRACE && lane == 0) {

@@ -86,7 +86,7 @@ def test_deploy_api_round_trip(ops):
     assert qz(p) is p                                    # already packed: pass-through (quantization.py:14,35)
     q = unpack_i4(p.quantized_x)
     assert torch.equal(pack_i4(q.to(torch.int8)), p.quantized_x)
-    ref = O.rowquant(x.cpu().numpy(), *ops.sigmoid_pair(4.0, 4.0), quant_f16=True, sig_f16=True)
+    ref = O.rowquant(x.cpu().numpy(), *ops.sigmoid_pair_f16(4.0, 4.0), quant_f16=True, sig_f16=True)   # (device semantics)
     assert np.array_equal(p.quantized_x.cpu().numpy(), ref["packed"])
     assert np.array_equal(p.scales_x.cpu().numpy().reshape(-1), ref["scale16"])
     again = deploy.sym_quant(x, p.scales_x.reshape(-1))

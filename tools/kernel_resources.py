@@ -27,10 +27,15 @@ def demangle(names):
             rest = rest[1:]
             while True:
                 a = re.match(r"L[ibjlmxy](n?)(\d+)E", rest)
-                if not a:
+                if a:
+                    args.append(("-" if a.group(1) else "") + a.group(2))
+                    rest = rest[a.end():]
+                    continue
+                t = re.match(r"DF16(_|b)", rest)       # element type of the round-3 templates: _Float16 / __bf16
+                if not t:
                     break
-                args.append(("-" if a.group(1) else "") + a.group(2))
-                rest = rest[a.end():]
+                args.append("f16" if t.group(1) == "_" else "bf16")
+                rest = rest[t.end():]
         out.append(name + ("<" + ",".join(args) + ">" if args else ""))
     return out
 

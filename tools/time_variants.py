@@ -42,11 +42,27 @@ for name, path in libs.items():
     fns[name] = fn
 
 
+# MODE=packed (the C2 launch, default) | fq (fake-quant output, FlatQuantizedLinear's contract: 16 KB per token) |
+#      fqy (transform + fake-quant outputs) | y (transform only)
+MODE = os.environ.get("MODE", "packed")
+fqs = [torch.empty(ROWS, 4096, dtype=torch.float16, device="cuda") for _ in range(4)] if MODE != "packed" else None
+ys = [torch.empty(ROWS, 4096, dtype=torch.float16, device="cuda") for _ in range(4)] if MODE in ("fqy", "y") else None
+if os.environ.get("SIGV"):
+    sig = float(os.environ["SIGV"])
+    smax, smin = (ctypes.c_float * 4)(sig), (ctypes.c_float * 4)(sig)
+
+
 def launch(fn, i):
-    qa, sa = (ctypes.c_void_p * 4)(), (ctypes.c_void_p * 4)()
-    qa[0], sa[0] = qs[i % 4].data_ptr(), s.data_ptr()
-    rc = fn(xs[i % 4].data_ptr(), L.data_ptr(), R.data_ptr(), None, ROWS, 64, 64, smax, smin, 1,
-            FQ_OUT_PACKED | FQ_NO_CLAMP0, qa, sa, none4, None, None, 0, sp)
+    qa, sa, fa = (ctypes.c_void_p * 4)(), (ctypes.c_void_p * 4)(), (ctypes.c_void_p * 4)()
+    if MODE == "packed":
+        qa[0], sa[0] = qs[i % 4].data_ptr(), s.data_ptr()
+        rc = fn(xs[i % 4].data_ptr(), L.data_ptr(), R.data_ptr(), None, ROWS, 64, 64, smax, smin, 1,
+                FQ_OUT_PACKED | FQ_NO_CLAMP0, qa, sa, none4, None, None, 0, sp)
+    else:
+        fa[0] = fqs[i % 4].data_ptr()
+        flags = {"fq": 0x02 | 0x08, "fqy": 0x02 | 0x04 | 0x08, "y": 0x04}[MODE]
+        rc = fn(xs[i % 4].data_ptr(), L.data_ptr(), R.data_ptr(), None, ROWS, 64, 64, smax, smin, 1,
+                flags, none4, none4, fa, ys[i % 4].data_ptr() if ys else None, None, 0, sp)
     assert rc == 0, rc
 
 
