@@ -377,8 +377,9 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
             vmin = fminf(vmin, red[WAVES + w]);
         }
 
-        // ---- fp16 outputs (transform / fake-quant) are staged dense [M][N] in xs, then streamed out ----
-        T* stage = reinterpret_cast<T*>(xs);
+        // ---- 16-bit outputs (transform / fake-quant) are staged in xs IN THE TOKEN'S OWN LAYOUT (row pitch PITCH chunks: the
+        // padding chunks and rows are never written and stay zero for the next token — round 3; the dense stage of round 2
+        // had to be re-zeroed, 35 KB of LDS writes and a barrier per token), then streamed out in whole 16-byte chunks ----
         if (flags & FQ_OUT_TRANSFORM) {
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
@@ -392,14 +393,17 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                             v0[e] = (T)Y[t][mo][e];
                             v1[e] = (T)Y[t][mo][8 + e];
                         }
-                        uint4* sp = reinterpret_cast<uint4*>(stage + (mo * 32 + c) * N + n0);
+                        uint4* sp = xs + (mo * 32 + c) * PITCH + (n0 >> 3);
                         sp[0] = __builtin_bit_cast(uint4, v0);
                         sp[1] = __builtin_bit_cast(uint4, v1);
                     }
             }
             __syncthreads();
-            uint4* yp = reinterpret_cast<uint4*>(out.y + tok * d);
-            for (int q = tid; q < n_chunks; q += THREADS) yp[q] = reinterpret_cast<const uint4*>(stage)[q];
+            u32x4* yp = reinterpret_cast<u32x4*>(reinterpret_cast<T*>(out.y) + tok * d);
+            for (int q = tid; q < n_chunks; q += THREADS) {
+                const int row = q / cpr, ch = q - row * cpr;
+                __builtin_nontemporal_store(__builtin_bit_cast(u32x4, xs[row * PITCH + ch]), yp + q);
+            }
             __syncthreads();
         }
 
@@ -414,8 +418,39 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
             const bool magic = !(flags & FQ_QUANT_F16) && fq_magic_ok(vmax, vmin, inv);
             const bool clampq = fq_needs_clamp(vmax, vmin, inv);
 
+            // The fake-quant contract alone (FlatQuantizedLinear._eval_forward; fp32 quantiser arithmetic): the single-width asm
+            // block fq_fake8 (fq_common.hpp) per half tile, ONE exactness vote per wave and token; an ambiguous digit anywhere in
+            // the wave (~3 % of tokens) sends the wave through the generic code below, which then rewrites the same stage slots.
+            bool fake_done = false;
+            if (CTF < 0 && (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_QUANT_F16 | 0x2000)) == FQ_OUT_FAKEQUANT && magic) {
+                float dmax = 0.0f;
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    const int nt = wave + WAVES * t, n0 = h * NT * 16 + nt * 16;
+#pragma unroll
+                    for (int mo = 0; mo < MT; ++mo) {
+                        const f32x16& yv = Y[t][mo];
+                        u32x4 o0, o1;
+                        if (clampq) {
+                            o0 = fq_fake8<true, T>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], inv, scale, dmax);
+                            o1 = fq_fake8<true, T>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], inv, scale, dmax);
+                        } else {
+                            o0 = fq_fake8<false, T>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], inv, scale, dmax);
+                            o1 = fq_fake8<false, T>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], inv, scale, dmax);
+                        }
+                        if (nt < NT && n0 < N && (mo * 32 + c) < M) {
+                            uint4* sp = xs + (mo * 32 + c) * PITCH + (n0 >> 3);
+                            sp[0] = __builtin_bit_cast(uint4, o0);
+                            sp[1] = __builtin_bit_cast(uint4, o1);
+                        }
+                    }
+                }
+                fake_done = !fq_wave_needs_exact(dmax);
+            }
+
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
+                if (fake_done) break;   // (wave-uniform; a run-time trip count would push Y into scratch)
                 const int nt = wave + WAVES * t, n0 = h * NT * 16 + nt * 16;
 #pragma unroll
                 for (int mo = 0; mo < MT; ++mo) {
@@ -519,7 +554,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                                 v1[e] = fq_fake<T>(scale, q1);
                             }
                         }
-                        uint4* sp = reinterpret_cast<uint4*>(stage + (mo * 32 + c) * N + n0);
+                        uint4* sp = xs + (mo * 32 + c) * PITCH + (n0 >> 3);
                         sp[0] = __builtin_bit_cast(uint4, v0);
                         sp[1] = __builtin_bit_cast(uint4, v1);
                     }
@@ -532,17 +567,15 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                 for (int q = tid; q < (M * N) / 32; q += THREADS) qp4[q] = reinterpret_cast<const uint4*>(obuf)[q];
             }
             if (flags & FQ_OUT_FAKEQUANT) {
-                uint4* fp = reinterpret_cast<uint4*>(out.fq[ci] + tok * d);
-                for (int q = tid; q < n_chunks; q += THREADS) fp[q] = reinterpret_cast<const uint4*>(stage)[q];
+                u32x4* fp = reinterpret_cast<u32x4*>(reinterpret_cast<T*>(out.fq[ci]) + tok * d);
+                for (int q = tid; q < n_chunks; q += THREADS) {
+                    const int row = q / cpr, ch = q - row * cpr;
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, xs[row * PITCH + ch]), fp + q);
+                }
             }
             if ((flags & FQ_OUT_FAKEQUANT) || ci + 1 < out.n_clips) __syncthreads();  // stage / obuf are rewritten next
         }
 
-        // the dense output stage lives in xs: restore the zero padding the next token relies on
-        if (flags & (FQ_OUT_TRANSFORM | FQ_OUT_FAKEQUANT)) {
-            for (int i = tid; i < XS_CHUNKS; i += THREADS) xs[i] = make_uint4(0, 0, 0, 0);
-            __syncthreads();
-        }
     }
 }
 

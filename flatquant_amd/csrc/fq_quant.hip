@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void fq_sym_dequant_kernel(const int32_t* __re
 template <int FLAGS, int NCH, bool MULTI = false, typename T = f16>
 // (occupancy bound for the packed fp16-quantiser builds only — the deploy Quantizer: their epilogue is 5 VALU per element on
 //  packed pairs and fits; the fp32-quantiser builds keep the compiler's own choice)
-__global__ __launch_bounds__(256, ((FLAGS & (FQ_QUANT_F16 | FQ_OUT_FAKEQUANT)) == FQ_QUANT_F16) ? (NCH > 24 ? 2 : NCH > 16 ? 3 : 4) : 1)
+__global__ __launch_bounds__(256, ((FLAGS & (FQ_QUANT_F16 | FQ_OUT_FAKEQUANT)) == FQ_QUANT_F16 && FqVec<T>::is_f16) ? (NCH > 24 ? 2 : NCH > 16 ? 3 : 4) : 1)
 void fq_rowquant_wave_kernel(const T* __restrict__ x, int64_t rows, int cols,
                                                                FqQuantOut out, int lg) {
     static_assert(!MULTI || NCH == 1, "short rows: one chunk per lane");

@@ -310,9 +310,13 @@ def test_hot_kernels_keep_their_occupancy_budget():
     res = parse()
     if not res:
         pytest.skip("no build/*.res next to the sources (library built elsewhere)")
-    budget = {  # kernel: (min waves per SIMD, max spilled VGPRs)
-        "fq_kron64_kernel<1,0>": (4, 0),                  # C2 headline, packed-only, 16 waves per CU
-        "fq_kron64_kernel<129,0>": (4, 0),                # ... with the RMSNorm fused in front (C3's q/k/v and up/gate launches)
+    budget = {  # kernel: (min waves per SIMD, max spilled VGPRs); template arguments end with the element type since round 3
+        "fq_kron64_kernel<1,0,f16>": (4, 0),              # C2 headline, packed-only, 16 waves per CU
+        "fq_kron64_kernel<1,0,bf16>": (4, 0),             # ... on bf16 activations
+        "fq_kron64_kernel<129,0,f16>": (4, 0),            # ... with the RMSNorm fused in front (C3's q/k/v and up/gate launches)
+        "fq_kron64_kernel<2,0,f16>": (2, 0),              # fake-quant output (FlatQuantizedLinear's contract): 8 waves per CU, staged stores
+        "fq_kron64_kernel<2,0,bf16>": (2, 0),
+        "fq_kron64_kernel<4,0,bf16>": (2, 0),             # kronecker_matmul on bf16
         "fq_kron_wave_kernel<2,4,8,7>": (2, 0),           # 64 x 128
         "fq_kron_wave_kernel<2,4,7,8>": (2, 0),           # 64 x 112
         "fq_kron_wave_kernel<1,2,4,16>": (4, 0),          # 32 x 64 (grouped MoE launch)
@@ -320,17 +324,23 @@ def test_hot_kernels_keep_their_occupancy_budget():
         "fq_kron_trio_kernel<4,1,0>": (3, 0),             # ... fp16 quantiser (Hadamard 14336 + Quantizer)
         "fq_kron_trio_kernel<3,0,1>": (3, 0),             # 86 x 128
         "fq_kron_wave_kernel<2,3,5,12>": (3, 0),          # 64 x 80, 12 waves per CU
-        "fq_kron_fast_kernel<4,7,14,8,1,0,1,0>": (2, 0),  # 128 x 224 packed
-        "fq_kron_fast_kernel<4,5,10,8,1,0,1,148>": (2, 0),  # 128 x 148 packed (true row length 148)
-        "fq_kron_fast_kernel<5,6,12,8,1,0,1,0>": (2, 0),  # 144 x 192 packed
-        "fq_kron_general_kernel<4,8,1>": (2, 0),          # 128 x 148
-        "fq_kron_general_kernel<6,8,1>": (2, 0),          # 168 x 176
+        "fq_kron_fast_kernel<4,7,14,8,1,0,1,0,f16>": (2, 0),  # 128 x 224 packed
+        "fq_kron_fast_kernel<4,5,10,8,1,0,1,148,f16>": (2, 0),  # 128 x 148 packed (true row length 148)
+        "fq_kron_fast_kernel<5,6,12,8,1,0,1,0,f16>": (2, 0),  # 144 x 192 packed
+        "fq_kron_fast_kernel<4,4,8,4,2,0,-1,0,f16>": (2, 0),  # 112 x 128, every output set (the fake-quant contract)
+        "fq_kron_fast_kernel<4,4,8,4,2,0,-1,0,bf16>": (2, 0),
+        "fq_kron_fast_kernel<2,4,7,4,2,0,-1,0,bf16>": (3, 0),  # 64 x 112 on bf16 (DeepSeek-V3 hidden)
+        "fq_kron_fast_kernel<1,2,4,4,4,0,-1,0,bf16>": (5, 0),  # 32 x 64 on bf16 (DeepSeek-V3 moe_inter)
+        "fq_kron_general_kernel<4,8,1,f16>": (2, 0),      # 128 x 148
+        "fq_kron_general_kernel<6,8,1,f16>": (2, 0),      # 168 x 176
         "fq_block_kernel<4,1,0,0,1>": (3, 0),             # o_proj transform, 32 heads
         "fq_block_kernel<4,2,1,0,1>": (2, 0),             # ... 64 heads
+        "fq_block_any_kernel<4,2,0,f16>": (1, 0),         # ... 40 heads (masked kernel)
         "fq_kv_decode_kernel<128,4,0>": (3, 0),
         "fq_kv_decode_kernel<128,8,0>": (3, 0),
         "fq_kv_decode_kernel<128,4,1>": (3, 0),
-        "fq_rowquant_wave_kernel<33,8>": (4, 0),          # deploy Quantizer at 4096
+        "fq_rowquant_wave_kernel<33,8,0,f16>": (4, 0),    # deploy Quantizer at 4096
+        "fq_rowquant_wave_kernel<2,8,0,bf16>": (2, 0),    # ActivationQuantizer on bf16 rows of 4096
         "fq_had_pow2_kernel<8,1,1,1>": (3, 0),            # Hadamard 4096 + Quantizer
     }
     present = [k for k in budget if k in res]
@@ -341,9 +351,10 @@ def test_hot_kernels_keep_their_occupancy_budget():
         assert res[k]["vgpr_spill"] <= spill, (k, res[k])
     # nothing new may spill: the kernels that do are known (generic SiLU.mul builds, two rare instantiations)
     # (and the M > 128 builds: 144 x 192 with all output sets, 168 x 176 = six row tiles in every output set)
-    allowed = {"fq_kron_fast_kernel<4,7,14,8,1,1,-1,0>", "fq_kron_fast_kernel<4,8,16,8,1,0,-1,0>", "fq_kron_fast_kernel<4,8,16,8,1,1,-1,0>",
-               "fq_kron_fast_kernel<5,6,12,8,1,0,-1,0>", "fq_kron_fast_kernel<6,6,11,8,1,0,-1,0>", "fq_kron_fast_kernel<6,6,11,8,1,0,1,0>",
-               "fq_kron_fast_kernel<6,6,11,8,1,0,33,0>", "fq_kron_trio_kernel<4,1,1>", "fq_kron_wave_kernel<2,2,4,16>"}
+    allowed = {"fq_kron_fast_kernel<4,7,14,8,1,1,-1,0,f16>", "fq_kron_fast_kernel<4,8,16,8,1,0,-1,0,f16>", "fq_kron_fast_kernel<4,8,16,8,1,1,-1,0,f16>",
+               "fq_kron_fast_kernel<5,6,12,8,1,0,-1,0,f16>", "fq_kron_fast_kernel<5,6,12,8,1,0,-1,0,bf16>", "fq_kron_fast_kernel<6,6,11,8,1,0,-1,0,f16>",
+               "fq_kron_fast_kernel<6,6,11,8,1,0,-1,0,bf16>", "fq_kron_fast_kernel<6,6,11,8,1,0,1,0,f16>",
+               "fq_kron_fast_kernel<6,6,11,8,1,0,33,0,f16>", "fq_kron_trio_kernel<4,1,1>", "fq_kron_wave_kernel<2,2,4,16>"}
     spilling = {k for k, r in res.items() if r.get("vgpr_spill", 0) > 0}
     assert spilling <= allowed, sorted(spilling - allowed)
 
