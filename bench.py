@@ -7,10 +7,14 @@ the two 64x64 factor matrices are broadcast once from rank 0 over RCCL).  One st
 fq_kron_quant_f16 (packed INT4 + fp16 scales out) over one 128 MiB activation buffer already resident in
 HBM; buffers rotate over > 256 MiB so the Infinity Cache cannot serve the stream.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C4|C5]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C1|C3|C4|C5] [--dtype f16|bf16]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
 
 --config (the other BASELINE.json configs; one "element" = one input activation scalar of one (token, linear) unit):
+  C1  the FlatQuantizedLinear contract of BASELINE configs[0] (flat_linear.py:75-80: per-token W4A4 FAKE-quant of the
+      transformed activation, fp16 / bf16 out, 16 KB per token) at C2's size: 64x64 factors, 8 x 2048 tokens per GPU, one
+      launch of fq_kron_quant_{f16,bf16}(FQ_OUT_FAKEQUANT | FQ_ROUND_Y_F16) per step. --dtype bf16: the dtype the reference's
+      eval pipeline feeds this path on Llama-3 / Qwen / DeepSeek (model_utils.py:20); also valid for C2 (packed out).
   C3  Llama-3-8B decoder layer, the activation path of its 7 linears: RMSNorm + 64x64 transform with 3 clip sets (q/k/v),
       o_proj head transform (head_dim 128 x 32 heads), RMSNorm + 64x64 with 2 clip sets (up/gate), online Hadamard
       28 x 512 + Quantizer on the down_proj input. 4 launches per step, 8 x 2048 tokens per GPU (weak scaling).
@@ -74,15 +78,27 @@ def make_matrices(device):
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC run (tools/prof.sh: separate
-    --pmc passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled per the gfx950 correction). None if absent."""
-    for name in ("r02_kron64_pmc.json", "r01_kron64_pmc.json"):
+    """(HBM bytes per launch of the dominant kernel, source file) from the COMMITTED rocprofv3 PMC run of this same command
+    (tools/prof.sh: separate --pmc passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled per the gfx950 correction) — a
+    counter pass cannot run inside a timed bench process, so the line names the file the number is read from."""
+    for name in ("r03_kron64_pmc.json", "r02_kron64_pmc.json", "r01_kron64_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
-                return json.load(fh)["hbm_bytes_per_launch"]
+                return json.load(fh)["hbm_bytes_per_launch"], "profiles/" + name
         except (OSError, KeyError, ValueError):
             continue
-    return None
+    return None, None
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(max_seconds=20.0, m=M, n=N):
@@ -99,28 +115,37 @@ def cpu_baseline(max_seconds=20.0, m=M, n=N):
     ncpu = os.cpu_count() or 1
     ladder = sorted({t for t in (1, 8, 16, 32, 64, ncpu) if t <= ncpu})
     best = None
-    results = {}
+    results, results32 = {}, {}
     t_start = time.perf_counter()
-    for threads in ladder:
-        torch.set_num_threads(threads)
-        path_a_torch.kron_fakequant(x, left, right, sig)   # warm-up
+
+    def median_rate(xx, ll, rr, budget):
+        path_a_torch.kron_fakequant(xx, ll, rr, sig)   # warm-up
         times = []
         t_cfg = time.perf_counter()
-        while len(times) < 5 and time.perf_counter() - t_cfg < max_seconds / len(ladder):
+        while len(times) < 5 and time.perf_counter() - t_cfg < budget:
             t0 = time.perf_counter()
-            path_a_torch.kron_fakequant(x, left, right, sig)
+            path_a_torch.kron_fakequant(xx, ll, rr, sig)
             times.append(time.perf_counter() - t0)
         times.sort()
-        med = times[len(times) // 2]
-        results[threads] = rows * d / med / 1e6
+        return rows * d / times[len(times) // 2] / 1e6
+    for threads in ladder:
+        torch.set_num_threads(threads)
+        results[threads] = median_rate(x, left, right, max_seconds * 0.7 / len(ladder))
         if best is None or results[threads] > results[best]:
             best = threads
-        if time.perf_counter() - t_start > max_seconds:
+        if time.perf_counter() - t_start > max_seconds * 0.7:
             break
-    return {"value": results[best], "unit": "Melem/s", "cores": best, "kind": "port",
+    # the fp32 leg SURVEY 8d asks for beside the fp16 one (the reference's calibration dtype): 1 thread and the best count
+    x32, l32, r32 = x.float(), left.float(), right.float()
+    for threads in sorted({1, best}):
+        torch.set_num_threads(threads)
+        results32[threads] = median_rate(x32, l32, r32, max_seconds * 0.15)
+    return {"value": results[best], "unit": "Melem/s", "cores": best, "kind": "port", "cpu_model": cpu_model(),
+            "logical_cpus": ncpu,
             "sample": f"median of <=5 x ({rows} x {d} fp16 tokens, {m}x{n} factors) per thread count, torch "
-                      f"{torch.__version__} CPU; host has {ncpu} logical CPUs",
-            "by_threads": {str(k): round(v, 2) for k, v in results.items()}}
+                      f"{torch.__version__} CPU ({cpu_model()}, {ncpu} logical CPUs)",
+            "by_threads": {str(k): round(v, 2) for k, v in results.items()},
+            "fp32_by_threads": {str(k): round(v, 2) for k, v in results32.items()}}
 
 
 # ---------------------------------------------------------------------------------------------------- workloads
@@ -136,47 +161,74 @@ class Workload:
 class C2(Workload):
     name = "C2"
     metric = "Melems/s for fused kron-transform+INT4-quant, Llama-3-8B d=4096, bs×seq=8×2048"
+    fakequant = False      # C1: the fake-quant output (FlatQuantizedLinear's contract) instead of the packed one
 
-    def __init__(self, device, rank, world, sharding, bcast):
+    def __init__(self, device, rank, world, sharding, bcast, dtype="f16"):
         from flatquant_amd import ops
-        from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED, check, lib
+        from flatquant_amd._lib import (FQ_NO_CLAMP0, FQ_OUT_FAKEQUANT, FQ_OUT_PACKED, FQ_ROUND_Y_F16, FQ_WS_PREPARED, check, lib)
+        td = torch.bfloat16 if dtype == "bf16" else torch.float16
         mats = make_matrices(device) if rank == 0 else {
             "left": torch.empty(M, M, dtype=torch.float16, device=device),
             "right": torch.empty(N, N, dtype=torch.float16, device=device)}
         mats = bcast(mats)                                     # the only collective on the path (set-up time)
-        left, right = mats["left"].contiguous(), mats["right"].contiguous()
+        left, right = mats["left"].to(td).contiguous(), mats["right"].to(td).contiguous()
         sig = [ops.sigmoid_pair(4.0, 4.0)]
-        self.xs = xs = make_inputs(device, seed=rank)
-        flags = FQ_OUT_PACKED | FQ_NO_CLAMP0                   # deploy OnlineTrans(matmul) contract
-        # pre-allocated rotating outputs; the timed region calls the C ABI directly (no allocator in the loop)
-        self.qs = qs = [torch.empty(ROWS, D // 2, dtype=torch.uint8, device=device) for _ in range(N_BUF)]
-        self.ss = ss = [torch.empty(ROWS, dtype=torch.float16, device=device) for _ in range(N_BUF)]
+        self.xs = xs = [x.to(td) for x in make_inputs(device, seed=rank)]
+        fn = lib.fq_kron_quant_bf16 if dtype == "bf16" else lib.fq_kron_quant_f16
+        sp = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        # the matrices are constants of a deployed layer: their fragment image is prepared ONCE (fq_kron_prepare_f16, set-up
+        # time, like the broadcast) and every launch passes FQ_WS_PREPARED
+        wsb = int(lib.fq_kron_workspace_bytes(M, N))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=device)
+        check((lib.fq_kron_prepare_bf16 if dtype == "bf16" else lib.fq_kron_prepare_f16)(
+            left.data_ptr(), right.data_ptr(), M, N, ws.data_ptr(), wsb, sp))
         smax = (ctypes.c_float * 4)(sig[0][0])
         smin = (ctypes.c_float * 4)(sig[0][1])
-        sp = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
         def arr(t):
             a = (ctypes.c_void_p * 4)()
             a[0] = t.data_ptr()
             return a
-        calls = [(ctypes.c_void_p(xs[i].data_ptr()), arr(qs[i]), arr(ss[i])) for i in range(N_BUF)]
-        lp, rp = ctypes.c_void_p(left.data_ptr()), ctypes.c_void_p(right.data_ptr())
+        lp, rp, wp = ctypes.c_void_p(left.data_ptr()), ctypes.c_void_p(right.data_ptr()), ctypes.c_void_p(ws.data_ptr())
         none4 = (ctypes.c_void_p * 4)()
-        self._keep = (left, right, smax, smin, calls, none4)
+        # pre-allocated rotating outputs; the timed region calls the C ABI directly (no allocator in the loop)
+        if self.fakequant:
+            flags = FQ_OUT_FAKEQUANT | FQ_ROUND_Y_F16 | FQ_WS_PREPARED      # path A: Y rounded to the activation dtype, fp32 quantiser
+            self.fqs = fqs = [torch.empty(ROWS, D, dtype=td, device=device) for _ in range(N_BUF)]
+            calls = [(ctypes.c_void_p(xs[i].data_ptr()), arr(fqs[i])) for i in range(N_BUF)]
 
-        def step(i):
-            xp, qa, sa = calls[i % N_BUF]
-            check(lib.fq_kron_quant_f16(xp, lp, rp, None, ROWS, M, N, smax, smin, 1, flags, qa, sa, none4, None, None, 0, sp))
+            def step(i):
+                xp, fa = calls[i % N_BUF]
+                check(fn(xp, lp, rp, None, ROWS, M, N, smax, smin, 1, flags, none4, none4, fa, None, wp, wsb, sp))
+            bytes_per_token = 4 * D
+            what = f"fake-quant {dtype} out (FlatQuantizedLinear._eval_forward contract, 16 KB per token)"
+        else:
+            flags = FQ_OUT_PACKED | FQ_NO_CLAMP0 | FQ_WS_PREPARED           # deploy OnlineTrans(matmul) contract
+            self.qs = qs = [torch.empty(ROWS, D // 2, dtype=torch.uint8, device=device) for _ in range(N_BUF)]
+            self.ss = ss = [torch.empty(ROWS, dtype=td, device=device) for _ in range(N_BUF)]
+            calls = [(ctypes.c_void_p(xs[i].data_ptr()), arr(qs[i]), arr(ss[i])) for i in range(N_BUF)]
+
+            def step(i):
+                xp, qa, sa = calls[i % N_BUF]
+                check(fn(xp, lp, rp, None, ROWS, M, N, smax, smin, 1, flags, qa, sa, none4, None, wp, wsb, sp))
+            bytes_per_token = BYTES_PER_TOKEN
+            what = f"packed INT4 + {dtype} scale out"
+        self._keep = (left, right, ws, smax, smin, calls, none4)
         self.step = step
         self.elems = ROWS * D
-        self.kernels = [("fq_kron64_kernel", step, ROWS * BYTES_PER_TOKEN)]
-        self.config = {"workload": "C2: Llama-3-8B single linear (q_proj input), d=4096 = 64x64 Kronecker, "
-                                   "8x2048 tokens per GPU, packed INT4 + fp16 scale out",
-                       "rows_per_gpu": ROWS, "d": D, "factors": [M, N], "parallelism": f"rows x{world}"}
+        self.kernels = [("fq_kron64_kernel", step, ROWS * bytes_per_token)]
+        self.config = {"workload": f"{self.name}: Llama-3-8B single linear (q_proj input), d=4096 = 64x64 Kronecker, "
+                                   f"8x2048 tokens per GPU, {what}",
+                       "rows_per_gpu": ROWS, "d": D, "factors": [M, N], "parallelism": f"rows x{world}",
+                       "activation_dtype": dtype, "fragment_image": "prepared once (FQ_WS_PREPARED)"}
+        if self.fakequant:
+            self.floor_us = None   # (the streaming probe moves the packed contract's byte mix)
 
     def floor_us(self, stream):
         """practical HBM floor: the same bytes (8 KB in, 2 KB + 2 B out per token) moved by a no-arithmetic kernel"""
         from flatquant_amd import ops
+        if self.xs[0].dtype != torch.float16:
+            return None
         for i in range(5):
             ops.probe_stream_4096(self.xs[i % N_BUF], self.qs[i % N_BUF], self.ss[i % N_BUF])
         torch.cuda.synchronize()
@@ -187,6 +239,12 @@ class C2(Workload):
         f1.record(stream)
         torch.cuda.synchronize()
         return f0.elapsed_time(f1) / 50 * 1e3
+
+
+class C1(C2):
+    name = "C1"
+    metric = "Melems/s for fused kron-transform+INT4 FAKE-quant (FlatQuantizedLinear contract), Llama-3-8B d=4096, bs×seq=8×2048"
+    fakequant = True
 
 
 def _hadk(K, device):
@@ -327,7 +385,7 @@ class C5(Workload):
                        "parallelism": f"experts+tokens /{world}"}
 
 
-WORKLOADS = {"C2": C2, "C3": C3, "C4": C4, "C5": C5}
+WORKLOADS = {"C1": C1, "C2": C2, "C3": C3, "C4": C4, "C5": C5}
 
 
 def main():
@@ -336,15 +394,18 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="activation dtype (C1 / C2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed clock-settle phase before the counted warm-up: launches of the same step for this "
                          "many milliseconds (reported as settle_launches); 0 disables it")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {"C2": 1000, "C3": 100, "C4": 5, "C5": 50}[args.config]
+        args.steps = {"C1": 500, "C2": 1000, "C3": 100, "C4": 5, "C5": 50}[args.config]
     if args.warmup is None:
-        args.warmup = {"C2": 200, "C3": 10, "C4": 2, "C5": 5}[args.config]
+        args.warmup = {"C1": 100, "C2": 200, "C3": 10, "C4": 2, "C5": 5}[args.config]
+    if args.dtype != "f16" and args.config not in ("C1", "C2"):
+        ap.error("--dtype bf16 goes with --config C1 / C2 (the deploy configs are fp16 contracts)")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -357,7 +418,8 @@ def main():
         dist.init_process_group("nccl", device_id=device)   # RCCL
 
     from flatquant_amd import sharding
-    wl = WORKLOADS[args.config](device, rank, world, sharding, lambda m: sharding.broadcast_matrices(m, src=0))
+    kw = {"dtype": args.dtype} if args.config in ("C1", "C2") else {}
+    wl = WORKLOADS[args.config](device, rank, world, sharding, lambda m: sharding.broadcast_matrices(m, src=0), **kw)
     stream = torch.cuda.current_stream(device)
     step = wl.step
     if wl.graph:
@@ -381,7 +443,7 @@ def main():
     # measures the ramp, not the kernel. Not part of --warmup, not part of the timed region; reported below.
     settle_launches = 0
     if args.settle_ms > 0:
-        chunk = 64 if args.config == "C2" else 1
+        chunk = 64 if args.config in ("C1", "C2") else 1
         t_settle = time.perf_counter()
         while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
             for i in range(chunk):
@@ -434,7 +496,7 @@ def main():
         k1.record(torch.cuda.current_stream(device))
         torch.cuda.synchronize()
         kern_us.append((name, k0.elapsed_time(k1) / reps * 1e3, nbytes))
-    floor_us = wl.floor_us(stream) if (rank == 0 and hasattr(wl, "floor_us")) else None
+    floor_us = wl.floor_us(stream) if (rank == 0 and getattr(wl, "floor_us", None) is not None) else None
 
     t = torch.tensor([wall, kern_ms], dtype=torch.float64, device=device)
     elems = torch.tensor([float(wl.elems)], dtype=torch.float64, device=device)
@@ -446,7 +508,7 @@ def main():
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         value = float(elems[0]) / (wall / args.steps) / 1e6
-        if args.config == "C2":                              # one launch per step: the timed region IS the kernel
+        if args.config in ("C1", "C2"):                      # one launch per step: the timed region IS the kernel
             dom_name, dom_us, dom_bytes = wl.kernels[0][0], kern_ms * 1e3, wl.kernels[0][2]
         else:
             dom_name, dom_us, dom_bytes = max(kern_us, key=lambda k: k[1])
@@ -454,23 +516,25 @@ def main():
         out = {
             "metric": wl.metric, "value": value, "unit": "Melem/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": wl.scaling,
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic", "settle_launches": settle_launches,
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "settle_launches": settle_launches,
             "settle_ms": args.settle_ms, "config": wl.config,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if args.config == "C2" else None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic()[0] if (args.config == "C2" and args.dtype == "f16") else None,
+                         "traffic_source": pmc_traffic()[1] if (args.config == "C2" and args.dtype == "f16") else None,
                          "kernel": dom_name, "algorithmic_bytes_per_launch": dom_bytes,
                          "launch_us": dom_us, "per_launch": per_launch, "hbm_stream_floor_us": floor_us,
                          "frac_of_stream_floor": (floor_us / dom_us) if floor_us else None},
         }
-        if args.config != "C2":
+        if args.config not in ("C1", "C2"):
             step_bytes = sum(k[2] for k in wl.kernels) * (wl.config.get("layers", 1))
             out["roofline"]["step"] = {"algorithmic_bytes": step_bytes, "step_us": kern_ms * 1e3,
                                        "frac": step_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             out["roofline"]["kernels"] = [{"kernel": n, "launch_us": u, "algorithmic_bytes": b,
                                            "frac": b / (u * 1e-6) / 1e9 / HBM_PEAK_GBS} for n, u, b in kern_us]
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(*{"C2": (20.0, 64, 64), "C3": (20.0, 64, 64), "C4": (20.0, 64, 128),
-                                                 "C5": (20.0, 32, 64)}[args.config])
+            out["cpu_baseline"] = cpu_baseline(*{"C1": (20.0, 64, 64), "C2": (20.0, 64, 64), "C3": (20.0, 64, 64),
+                                                 "C4": (20.0, 64, 128), "C5": (20.0, 32, 64)}[args.config])
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -9,7 +9,11 @@
 
 // launchers defined in the kernel translation units
 int fq_launch_kron64(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
-                     int64_t rows, const FqQuantOut& out, int n_cu, hipStream_t stream);
+                     int64_t rows, const FqQuantOut& out, int n_cu, hipStream_t stream, const void* prep = nullptr);
+int fq_launch_kron64_prepare(const void* left, const void* right, void* image, hipStream_t stream);
+// The optional workspace of the 64 x 64 pair: the 16 KB fragment image fq_kron64_kernel reads, followed by the 16 KB image of the
+// workgroup-per-token kernel (the few output sets fq_kron64 has no instantiation for fall through to it).
+constexpr int64_t FQ_K64_IMAGE_BYTES = 16384, FQ_K64_WS_BYTES = 32768;
 int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream);
@@ -173,11 +177,27 @@ static int kron_dispatch(const char* what, const FqQuantOut& o, int flags, const
     if ((o.rt_flags & FQ_GROUP128) && ((M * N) % 128 != 0 || (flags & (FQ_QUANT_F16 | FQ_OUT_FAKEQUANT)) || o.n_clips != 1))
         return fail(FQ_EUNSUPPORTED, "%s: FQ_GROUP128 is fused for packed output, one clip set, fp32 arithmetic, M*N %% 128 == 0", what);
     if (M == 64 && N == 64) {
-        rc = fq_launch_kron64(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag,
-                              rows, o, n_cu, (hipStream_t)stream);
+        // the workspace is OPTIONAL at 64 x 64: with one (>= 16 KB) the kernel reads the fragment image from it (written here
+        // unless FQ_WS_PREPARED says it is there already), without one it gathers the fragments from the matrices itself
+        const void* prep = (workspace && workspace_bytes >= FQ_K64_WS_BYTES) ? workspace : nullptr;
+        if (prep && !(flags & FQ_WS_PREPARED)) {
+            rc = fq_launch_kron64_prepare(left, right, workspace, (hipStream_t)stream);
+            if (rc == 0) rc = fq_launch_kron_prepare((const f16*)left, (const f16*)right, 64, 64,
+                                                     static_cast<unsigned char*>(workspace) + FQ_K64_IMAGE_BYTES, (hipStream_t)stream);
+            if (rc != 0) return check_launch(rc, what);
+            flags |= FQ_WS_PREPARED;   // (both images are there now, also for the fall-through below)
+        }
+        rc = fq_launch_kron64(flags & ~FQ_WS_PREPARED, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag,
+                              rows, o, n_cu, (hipStream_t)stream, prep);
         if (rc != -1000) return check_launch(rc, what);
         if (dt) return fail(FQ_EUNSUPPORTED, "%s: output set 0x%x has no bf16 kernel at 64 x 64", what, flags & ~dt);
         if (o.rt_flags & FQ_GROUP128) return fail(FQ_EUNSUPPORTED, "%s: FQ_GROUP128 needs the packed-only output set at 64 x 64", what);
+        if (prep) {   // the second half of the 64 x 64 workspace is the other kernel family's image
+            workspace = static_cast<unsigned char*>(workspace) + FQ_K64_IMAGE_BYTES;
+            workspace_bytes -= FQ_K64_IMAGE_BYTES;
+        } else {
+            flags &= ~FQ_WS_PREPARED;
+        }
     }
     rc = fq_launch_kron_generic(flags, (const f16*)x, (const f16*)left, (const f16*)right, (const f16*)diag,
                                 rows, M, N, o, workspace, workspace_bytes, n_cu, (hipStream_t)stream);
@@ -380,7 +400,15 @@ int fq_rmsnorm_f16(const void* x, void* y, int64_t rows, int cols, float eps, vo
 
 int fq_kron_prepare_f16(const void* left, const void* right, int M, int N, void* workspace, int64_t workspace_bytes,
                         void* stream) {
-    if (M == 64 && N == 64) return FQ_OK;
+    if (M == 64 && N == 64) {   // optional image: written when a workspace is given, a no-op otherwise (as before round 3)
+        if (!workspace || workspace_bytes < FQ_K64_WS_BYTES) return FQ_OK;
+        if (!left || !right) return fail(FQ_EINVAL, "fq_kron_prepare_f16: left/right is NULL");
+        FQ_NEED_ALIGN16("fq_kron_prepare_f16", left, right, workspace);
+        int rc = fq_launch_kron64_prepare(left, right, workspace, (hipStream_t)stream);
+        if (rc == 0) rc = fq_launch_kron_prepare((const f16*)left, (const f16*)right, 64, 64,
+                                                 static_cast<unsigned char*>(workspace) + FQ_K64_IMAGE_BYTES, (hipStream_t)stream);
+        return check_launch(rc, "fq_kron_prepare_f16");
+    }
     const int64_t need = fq_kron_workspace_bytes(M, N);
     if (need < 0) return fail(FQ_EUNSUPPORTED, "fq_kron_prepare_f16: no kernel for factors (%d, %d)", M, N);
     if (!left || !right) return fail(FQ_EINVAL, "fq_kron_prepare_f16: left/right is NULL");
@@ -398,7 +426,7 @@ int fq_kron_prepare_bf16(const void* left, const void* right, int M, int N, void
 }
 
 int64_t fq_kron_workspace_bytes(int M, int N) {
-    if (M == 64 && N == 64) return 0;
+    if (M == 64 && N == 64) return FQ_K64_WS_BYTES;   // optional (NULL still works): the prepared fragment images
     if (M < 1 || N < 2 || (N & 1) || M > 256 || N > 256 || (int64_t)M * N > 32768) return FQ_EUNSUPPORTED;
     return fq_kron_generic_workspace_bytes(M, N);
 }

@@ -194,8 +194,8 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
                                                            const T* __restrict__ left,
                                                            const T* __restrict__ right,
                                                            const T* __restrict__ diag,
-                                                           int64_t rows, int64_t tpb, FqQuantOut out,
-                                                           unsigned long long* __restrict__ trace) {
+                                                           int64_t rows, int64_t tpb, const uint4* __restrict__ prep,
+                                                           FqQuantOut out, unsigned long long* __restrict__ trace) {
     typedef typename FqVec<T>::x8 X8;  // eight activation / matrix elements = one 16-byte MFMA operand
     constexpr int THREADS = kron64_threads<FLAGS>();
     constexpr int WAVES = THREADS / 64;
@@ -263,8 +263,19 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     constexpr int ITEMS = 16 * 64 / THREADS;  // fragment slots (f, lane') this thread fills: 1 or 2
     static_assert(ITEMS * THREADS == 16 * 64, "fragment image is 1024 x 16 B");
     unsigned gv[ITEMS][8];
+    // (round 3) `prep` != nullptr: the caller passed the fragment image fq_kron_prepare_f16 wrote (FQ_WS_PREPARED, 16 KB, the
+    // exact LDS image below): ONE coalesced 16-byte load per slot instead of eight 2-byte gathers and their address arithmetic
+    // — the matrices are constants of a deployed layer. Same wait accounting (these loads are older than the DMA).
+    u32x4 pv[ITEMS];
+    const bool prepared = prep != nullptr;   // (kernel-uniform)
+    if (prepared) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pv[it]) : "v"(prep + tid + it * THREADS) : "memory");
+    }
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
+        if (prepared) break;
         const int item = tid + it * THREADS;                              // (f, lane') with lane' fastest
         const int f = __builtin_amdgcn_readfirstlane(item >> 6);          // one fragment per wave and item
         const int ln = item & 63, fh = ln >> 5, fc = ln & 31;
@@ -298,19 +309,26 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     const int dma_ops = ((FQ_K64_ABLATE & 4) || !have_first || grp != 0) ? 0 : 8;
 #define FQ_WAIT_GATHER                                                                                      \
     "s_cmp_eq_u32 %[n], 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(8)\n\ts_branch 2f\n1:\n\ts_waitcnt vmcnt(0)\n2:"
-    if (ITEMS == 1) asm volatile(FQ_WAIT_GATHER : FQ_GV(0) : [n] "s"(dma_ops) : "scc");
-    else asm volatile(FQ_WAIT_GATHER : FQ_GV(0), FQ_GV(ITEMS - 1) : [n] "s"(dma_ops) : "scc");
+    if (prepared) {
+        if (ITEMS == 1) asm volatile(FQ_WAIT_GATHER : "+v"(pv[0]) : [n] "s"(dma_ops) : "scc");
+        else asm volatile(FQ_WAIT_GATHER : "+v"(pv[0]), "+v"(pv[ITEMS - 1]) : [n] "s"(dma_ops) : "scc");
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) frag[tid + it * THREADS] = __builtin_bit_cast(uint4, pv[it]);
+    } else {
+        if (ITEMS == 1) asm volatile(FQ_WAIT_GATHER : FQ_GV(0) : [n] "s"(dma_ops) : "scc");
+        else asm volatile(FQ_WAIT_GATHER : FQ_GV(0), FQ_GV(ITEMS - 1) : [n] "s"(dma_ops) : "scc");
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            uint4 v;
+            v.x = gv[it][0] | (gv[it][1] << 16);  // global_load_ushort zero-extends
+            v.y = gv[it][2] | (gv[it][3] << 16);
+            v.z = gv[it][4] | (gv[it][5] << 16);
+            v.w = gv[it][6] | (gv[it][7] << 16);
+            frag[tid + it * THREADS] = v;
+        }
+    }
 #undef FQ_WAIT_GATHER
 #undef FQ_GV
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        uint4 v;
-        v.x = gv[it][0] | (gv[it][1] << 16);  // global_load_ushort zero-extends
-        v.y = gv[it][2] | (gv[it][3] << 16);
-        v.z = gv[it][4] | (gv[it][5] << 16);
-        v.w = gv[it][6] | (gv[it][7] << 16);
-        frag[tid + it * THREADS] = v;
-    }
     const unsigned long long tr_gather = TRACE ? __builtin_amdgcn_s_memtime() : 0;
     if (have_first && grp == 1) dma_token(x, blk_base + slot, tok_lds, lane);
     unsigned long long tr_prebar = 0;
@@ -682,9 +700,30 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
 }  // namespace
 
 // Host-side launcher used by the C ABI (fq_capi.hip). Returns hipError_t as int.
+// The 16 KB fragment image of (left, right) for `prep`: slot (f, lane') as the kernel's prologue gathers it.
+__global__ void fq_kron64_prepare_kernel(const unsigned short* __restrict__ left, const unsigned short* __restrict__ right,
+                                         uint4* __restrict__ image) {
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= 16 * 64) return;
+    const int f = item >> 6, ln = item & 63, fh = ln >> 5, fc = ln & 31;
+    unsigned e[8];
+    if (f < 8) {
+        const int nt = f >> 2, sk = f & 3;
+        const unsigned short* src = right + (fh * 32 + sk * 8) * KN + nperm(nt, fc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = src[j * KN];
+    } else {
+        const int ks = (f - 8) >> 1, mo = (f - 8) & 1;
+        const unsigned short* src = left + ((ks >> 1) * 32 + 16 * (ks & 1) + 4 * fh) * KM + mo * 32 + fc;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = src[(8 * (j >> 2) + (j & 3)) * KM];
+    }
+    image[item] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+}
+
 template <int FLAGS, typename T>
 static int launch_kron64(const T* x, const T* left, const T* right, const T* diag, int64_t rows,
-                         const FqQuantOut& out, int n_cu, hipStream_t stream) {
+                         const FqQuantOut& out, int n_cu, hipStream_t stream, const void* prep = nullptr) {
     constexpr int THREADS = kron64_threads<FLAGS>();
     // few rows (decode): four tokens per workgroup, so that only the first SIMD-slot group of waves has work and no wave
     // sits out the start-up stagger (up to 3 x 2560 cycles for the last group: most of an 11 us launch at 16 rows)
@@ -693,41 +732,41 @@ static int launch_kron64(const T* x, const T* left, const T* right, const T* dia
     if (blocks < 1) blocks = 1;
     const int64_t tpb = (rows + blocks - 1) / blocks;
     hipLaunchKernelGGL((fq_kron64_kernel<FLAGS, false, T>), dim3((unsigned)blocks), dim3(THREADS), 0, stream, x, left,
-                       right, diag, rows, tpb, out, (unsigned long long*)nullptr);
+                       right, diag, rows, tpb, reinterpret_cast<const uint4*>(prep), out, (unsigned long long*)nullptr);
     return (int)hipGetLastError();
 }
 
 template <typename T>
 static int launch_kron64_any(int flags, const T* x, const T* left, const T* right, const T* diag,
-                             int64_t rows, const FqQuantOut& out, int n_cu, hipStream_t stream) {
+                             int64_t rows, const FqQuantOut& out, int n_cu, hipStream_t stream, const void* prep) {
     // Compile-time specialisations: output set x fp16-quant arithmetic. Everything else is run-time.
 #define FQ_CASE(F)                                                                     \
     case (F):                                                                          \
-        return launch_kron64<(F), T>(x, left, right, diag, rows, out, n_cu, stream);      \
+        return launch_kron64<(F), T>(x, left, right, diag, rows, out, n_cu, stream, prep);      \
     case (F) | FQ_QUANT_F16:                                                           \
-        return launch_kron64<(F) | FQ_QUANT_F16, T>(x, left, right, diag, rows, out, n_cu, stream);
+        return launch_kron64<(F) | FQ_QUANT_F16, T>(x, left, right, diag, rows, out, n_cu, stream, prep);
     if (out.rt_flags & FQ_GROUP128) {  // per-128-element scales: packed output, fp32 quantiser arithmetic only
         if ((flags & FQ_CT_MASK) != FQ_OUT_PACKED) return -1000;
         if (out.group_offsets != nullptr)
-            return launch_kron64<FQ_OUT_PACKED | FQ_K64_G128 | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream);
-        return launch_kron64<FQ_OUT_PACKED | FQ_K64_G128, T>(x, left, right, diag, rows, out, n_cu, stream);
+            return launch_kron64<FQ_OUT_PACKED | FQ_K64_G128 | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream, prep);
+        return launch_kron64<FQ_OUT_PACKED | FQ_K64_G128, T>(x, left, right, diag, rows, out, n_cu, stream, prep);
     }
     if (out.group_offsets != nullptr) {  // grouped launch: packed or fake-quant output (+ the transform)
         switch (flags & FQ_CT_MASK) {
             case FQ_OUT_PACKED:
-                return launch_kron64<FQ_OUT_PACKED | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream);
+                return launch_kron64<FQ_OUT_PACKED | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream, prep);
             case FQ_OUT_FAKEQUANT:
-                return launch_kron64<FQ_OUT_FAKEQUANT | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream);
+                return launch_kron64<FQ_OUT_FAKEQUANT | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream, prep);
             case FQ_OUT_PACKED | FQ_OUT_TRANSFORM:
-                return launch_kron64<FQ_OUT_PACKED | FQ_OUT_TRANSFORM | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream);
+                return launch_kron64<FQ_OUT_PACKED | FQ_OUT_TRANSFORM | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream, prep);
             case FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM:
-                return launch_kron64<FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream);
+                return launch_kron64<FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream, prep);
             // the all-low-precision quantiser (clip parameters of the activation's dtype: the DeepSeek flow under
             // torch.set_default_dtype(bfloat16), main_dpskv3.py:395)
             case FQ_OUT_FAKEQUANT | FQ_QUANT_F16:
-                return launch_kron64<FQ_OUT_FAKEQUANT | FQ_QUANT_F16 | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream);
+                return launch_kron64<FQ_OUT_FAKEQUANT | FQ_QUANT_F16 | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream, prep);
             case FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_QUANT_F16:
-                return launch_kron64<FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_QUANT_F16 | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream);
+                return launch_kron64<FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_QUANT_F16 | FQ_K64_GROUPED, T>(x, left, right, diag, rows, out, n_cu, stream, prep);
             default:
                 return -1000;
         }
@@ -741,17 +780,17 @@ static int launch_kron64_any(int flags, const T* x, const T* left, const T* righ
         FQ_CASE(FQ_OUT_TRANSFORM | FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)
         // (the RMSNorm-fused launches serve deploy.nn.RMSNorm, an fp16-only module in the reference)
         case FQ_OUT_PACKED | FQ_IN_RMSNORM:
-            if constexpr (FqVec<T>::is_f16) return launch_kron64<FQ_OUT_PACKED | FQ_IN_RMSNORM, T>(x, left, right, diag, rows, out, n_cu, stream);
+            if constexpr (FqVec<T>::is_f16) return launch_kron64<FQ_OUT_PACKED | FQ_IN_RMSNORM, T>(x, left, right, diag, rows, out, n_cu, stream, prep);
             return -1000;
         case FQ_OUT_TRANSFORM | FQ_IN_RMSNORM:
-            if constexpr (FqVec<T>::is_f16) return launch_kron64<FQ_OUT_TRANSFORM | FQ_IN_RMSNORM, T>(x, left, right, diag, rows, out, n_cu, stream);
+            if constexpr (FqVec<T>::is_f16) return launch_kron64<FQ_OUT_TRANSFORM | FQ_IN_RMSNORM, T>(x, left, right, diag, rows, out, n_cu, stream, prep);
             return -1000;
         case FQ_OUT_TRANSFORM | FQ_OUT_PACKED | FQ_IN_RMSNORM:
-            if constexpr (FqVec<T>::is_f16) return launch_kron64<FQ_OUT_TRANSFORM | FQ_OUT_PACKED | FQ_IN_RMSNORM, T>(x, left, right, diag, rows, out, n_cu, stream);
+            if constexpr (FqVec<T>::is_f16) return launch_kron64<FQ_OUT_TRANSFORM | FQ_OUT_PACKED | FQ_IN_RMSNORM, T>(x, left, right, diag, rows, out, n_cu, stream, prep);
             return -1000;
         case FQ_OUT_TRANSFORM:
         case FQ_OUT_TRANSFORM | FQ_QUANT_F16:
-            return launch_kron64<FQ_OUT_TRANSFORM, T>(x, left, right, diag, rows, out, n_cu, stream);
+            return launch_kron64<FQ_OUT_TRANSFORM, T>(x, left, right, diag, rows, out, n_cu, stream, prep);
         default:
             return -1000;
     }
@@ -759,11 +798,17 @@ static int launch_kron64_any(int flags, const T* x, const T* left, const T* righ
 }
 
 int fq_launch_kron64(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
-                     int64_t rows, const FqQuantOut& out, int n_cu, hipStream_t stream) {
+                     int64_t rows, const FqQuantOut& out, int n_cu, hipStream_t stream, const void* prep) {
     if (flags & FQ_DT_BF16)
         return launch_kron64_any<bf16>(flags & ~FQ_DT_BF16, (const bf16*)x, (const bf16*)left, (const bf16*)right, (const bf16*)diag,
-                                       rows, out, n_cu, stream);
-    return launch_kron64_any<f16>(flags, x, left, right, diag, rows, out, n_cu, stream);
+                                       rows, out, n_cu, stream, prep);
+    return launch_kron64_any<f16>(flags, x, left, right, diag, rows, out, n_cu, stream, prep);
+}
+
+int fq_launch_kron64_prepare(const void* left, const void* right, void* image, hipStream_t stream) {
+    hipLaunchKernelGGL(fq_kron64_prepare_kernel, dim3(4), dim3(256), 0, stream, (const unsigned short*)left,
+                       (const unsigned short*)right, reinterpret_cast<uint4*>(image));
+    return (int)hipGetLastError();
 }
 
 // Debug: the packed kernel with per-phase s_memtime accounting (see FQ_TICK). trace: [n_waves, 4] u64,
@@ -774,6 +819,6 @@ int fq_launch_kron64_trace(const f16* x, const f16* left, const f16* right, int6
     if (blocks > n_cu) blocks = n_cu;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((fq_kron64_kernel<FQ_OUT_PACKED, true, f16>), dim3((unsigned)blocks), dim3(1024), 0, stream, x, left,
-                       right, (const f16*)nullptr, rows, (rows + blocks - 1) / blocks, out, trace);
+                       right, (const f16*)nullptr, rows, (rows + blocks - 1) / blocks, (const uint4*)nullptr, out, trace);
     return (int)hipGetLastError();
 }

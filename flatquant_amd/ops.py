@@ -173,7 +173,7 @@ def _kron_workspace(device: torch.device, M: int, N: int, left: torch.Tensor, ri
     nbytes = int(lib.fq_kron_workspace_bytes(M, N))
     if nbytes < 0:
         raise _lib.FqError(nbytes, f"no kernel for Kronecker factors ({M}, {N}): need M, N <= 256 and M * N <= 32768")
-    if nbytes == 0:
+    if nbytes == 0:   # (no pair has a zero-size workspace since round 3: 64 x 64 takes its optional 32 KB image)
         return None, 0, False, None
     key = (device.index, torch.cuda.current_stream(device).cuda_stream, M, N,
            left.data_ptr(), left._version, right.data_ptr(), right._version)

@@ -124,8 +124,10 @@ extern "C" {
  * scale_out[c] [rows] fp16           (FQ_OUT_PACKED)
  * fq_out[c]    [rows, M*N] fp16      (FQ_OUT_FAKEQUANT)
  * y_out        [rows, M*N] fp16      (FQ_OUT_TRANSFORM)
- * workspace   device scratch of at least fq_kron_workspace_bytes(M, N) bytes (0 for M = N = 64, where it may be
- *             NULL): the call re-packs left/right into MFMA fragment order there before the main kernel.
+ * workspace   device scratch of at least fq_kron_workspace_bytes(M, N) bytes: the call re-packs left/right into MFMA fragment
+ *             order there before the main kernel (skipped with FQ_WS_PREPARED). OPTIONAL for M = N = 64 (NULL / 0 bytes:
+ *             the kernel gathers its fragments from the matrices itself; with the 32 KB workspace every workgroup starts
+ *             with one coalesced load per thread instead of eight 2-byte gathers).
  */
 int fq_kron_quant_f16(const void* x, const void* left, const void* right, const void* diag,
                       int64_t rows, int M, int N,
@@ -211,7 +213,7 @@ int fq_kron_quant_ex_f16(const void* x, const void* up, const void* left, const 
 /* y = fp16(up * fp16(silu(gate))) element-wise over n fp16 values (n % 8 == 0). */
 int fq_silu_mul_f16(const void* gate, const void* up, void* y, int64_t n, void* stream);
 
-/* Bytes of device workspace fq_kron_quant_f16 needs for factor sizes (M, N); 0 when none is needed;
+/* Bytes of device workspace fq_kron_quant_f16 takes for factor sizes (M, N) (32768 for 64 x 64, where it is optional);
  * negative (FQ_EUNSUPPORTED) when no kernel handles the shape. Every pair with M <= 256, even N <= 256 and M*N <= 32768
  * has an MFMA kernel (tuned ones for the deploy shapes, csrc/fq_kron_general.hip for the rest, e.g. 128 x 148); all of them
  * but 64 x 64 read L and R from the fragment image in this workspace. */
@@ -219,7 +221,8 @@ int64_t fq_kron_workspace_bytes(int M, int N);
 
 /* Re-pack left [M,M] / right [N,N] into the MFMA fragment image fq_kron_quant_f16 consumes, once, for callers whose
  * matrices do not change between calls (deploy/nn/online_trans.py:18-67 keeps them as buffers). Pass the same
- * workspace with FQ_WS_PREPARED afterwards. A no-op (FQ_OK) for M = N = 64, which needs no workspace. */
+ * workspace with FQ_WS_PREPARED afterwards. M = N = 64: writes the optional 32 KB of images when a workspace is given, a no-op
+ * (FQ_OK) with workspace == NULL. */
 int fq_kron_prepare_f16(const void* left, const void* right, int M, int N, void* workspace, int64_t workspace_bytes,
                         void* stream);
 int fq_kron_prepare_bf16(const void* left, const void* right, int M, int N, void* workspace, int64_t workspace_bytes,

@@ -223,3 +223,56 @@ def test_argument_errors(ops):
     from flatquant_amd._lib import FqError
     with pytest.raises(FqError):
         ops.kron_quant(x.cuda(), L.cuda(), L.cuda(), flags=0)       # no output selected
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_prepared_fragment_image_equals_the_in_kernel_gather(dtype):
+    """Round 3: the optional 32 KB workspace of the 64 x 64 pair (fq_kron_prepare_f16 + FQ_WS_PREPARED: one coalesced load per
+    thread in the prologue instead of eight 2-byte gathers). Every output set, both element types: bit-identical to the
+    launch without a workspace; an unprepared workspace is filled by the call itself; ops.kron_quant sees in-place updates."""
+    import ctypes
+    from flatquant_amd import ops
+    from flatquant_amd._lib import FQ_WS_PREPARED, check, lib
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    fn = lib.fq_kron_quant_bf16 if dtype == "bf16" else lib.fq_kron_quant_f16
+    gen = torch.Generator().manual_seed(11)
+    rows = 777
+    x = torch.randn(rows, 4096, generator=gen).to(td).cuda()
+    L = (torch.randn(64, 64, generator=gen) / 8).to(td).cuda()
+    R = (torch.randn(64, 64, generator=gen) / 8).to(td).cuda()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nbytes = int(lib.fq_kron_workspace_bytes(64, 64))
+    assert nbytes == 32768
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    check(lib.fq_kron_prepare_f16(L.data_ptr(), R.data_ptr(), 64, 64, ws.data_ptr(), nbytes, st))
+    smax, smin = (ctypes.c_float * 4)(0.93, 0.8), (ctypes.c_float * 4)(0.9, 0.7)
+
+    def run(flags, workspace, wbytes, nclip=1):
+        q = [torch.zeros(rows, 2048, dtype=torch.uint8, device="cuda") for _ in range(nclip)]
+        s = [torch.zeros(rows, dtype=td, device="cuda") for _ in range(nclip)]
+        f = [torch.zeros(rows, 4096, dtype=td, device="cuda") for _ in range(nclip)]
+        y = torch.zeros(rows, 4096, dtype=td, device="cuda")
+        qa, sa, fa = (ctypes.c_void_p * 4)(), (ctypes.c_void_p * 4)(), (ctypes.c_void_p * 4)()
+        for c in range(nclip):
+            qa[c], sa[c], fa[c] = q[c].data_ptr(), s[c].data_ptr(), f[c].data_ptr()
+        check(fn(x.data_ptr(), L.data_ptr(), R.data_ptr(), None, rows, 64, 64, smax, smin, nclip, flags, qa, sa, fa,
+                 y.data_ptr(), workspace, wbytes, st))
+        torch.cuda.synchronize()
+        return [t.view(torch.int16) if t.dtype == td else t for t in q + s + f + [y]]
+
+    for flags, nclip in ((P, 1), (P, 2), (F | R16, 1), (T, 1), (P | T | F, 2), (F | T | R16 | Q16, 1)):
+        a = run(flags, None, 0, nclip)
+        b = run(flags | FQ_WS_PREPARED, ws.data_ptr(), nbytes, nclip)
+        ws2 = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        c = run(flags, ws2.data_ptr(), nbytes, nclip)               # not prepared: the call writes the image itself
+        for ta, tb, tc in zip(a, b, c):
+            assert torch.equal(ta, tb) and torch.equal(ta, tc), (dtype, flags)
+        assert torch.equal(ws2, ws)
+    # the tensor-level entry: workspace cached per (matrices, version)
+    o1 = ops.kron_quant(x, L, R, [(0.93, 0.9)], P)
+    o2 = ops.kron_quant(x, L, R, [(0.93, 0.9)], P)
+    assert torch.equal(o1.q[0], o2.q[0])
+    L.mul_(-1.0)
+    o3 = ops.kron_quant(x, L, R, [(0.93, 0.9)], P)
+    o4 = ops.kron_quant(x, L.clone(), R.clone(), [(0.93, 0.9)], P)
+    assert torch.equal(o3.q[0], o4.q[0]) and not torch.equal(o3.q[0], o1.q[0])

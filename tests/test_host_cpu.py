@@ -42,7 +42,7 @@ def test_abi_argument_validation_without_gpu():
     assert lib.fq_rowquant_f16(vp, 4, 4100, f4, f4, 1, 1, a4, a4, a4, None) == FQ_EUNSUPPORTED
     assert lib.fq_hadamard_f16(vp, vp, 4, 96, 5, vp, ctypes.c_float(1.0), None) == FQ_EINVAL      # 96 % 5 != 0
     assert lib.fq_hadamard_f16(vp, vp, 4, 96, 1, None, ctypes.c_float(1.0), None) == FQ_EINVAL    # 96 not 2^p
-    assert lib.fq_kron_workspace_bytes(64, 64) == 0
+    assert lib.fq_kron_workspace_bytes(64, 64) == 32768                   # optional at 64 x 64 (NULL still works)
     assert lib.fq_kron_workspace_bytes(128, 224) == (7 * 14 + 2 * 4 * 4) * 1024
     assert lib.fq_kron_workspace_bytes(60, 63) == FQ_EUNSUPPORTED          # odd N: nothing to pack two per byte
     assert lib.fq_kron_workspace_bytes(128, 148) == (5 * 10 + 2 * 4 * 4) * 1024   # N % 16 != 0: the general MFMA kernel
