@@ -29,6 +29,7 @@ FQ_IN_SILU_MUL = 0x100
 FQ_GROUP128 = 0x200
 FQ_SIG_F16 = 0x400
 FQ_ASYM = 0x800
+FQ_RATIO_POST = 0x10000
 FQ_KV_LAC = 0x1
 FQ_MAX_CLIPS = 4
 

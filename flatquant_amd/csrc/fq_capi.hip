@@ -114,7 +114,7 @@ int fill_out(const char* what, FqQuantOut& o, const float* sig_max, const float*
     const int outs = flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM);
     if (outs == 0) return fail(FQ_EINVAL, "%s: flags select no output", what);
     if (flags & ~(FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_ROUND_Y_F16 | FQ_NO_CLAMP0 | FQ_WS_PREPARED |
-                  FQ_QUANT_F16 | FQ_GROUP128 | FQ_SIG_F16))
+                  FQ_QUANT_F16 | FQ_GROUP128 | FQ_SIG_F16 | FQ_RATIO_POST))
         return fail(FQ_EINVAL, "%s: unknown flag bits 0x%x", what, flags);
     if (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) {
         if (n_clips < 1 || n_clips > FQ_MAX_CLIPS)
@@ -142,7 +142,7 @@ int fill_out(const char* what, FqQuantOut& o, const float* sig_max, const float*
     }
     for (int i = 0; i < FQ_MAX_CLIPS; ++i) FQ_NEED_ALIGN16(what, o.q[i], o.fq[i]);
     FQ_NEED_ALIGN16(what, o.y);
-    o.rt_flags = flags & (FQ_ROUND_Y_F16 | FQ_NO_CLAMP0 | FQ_GROUP128 | FQ_SIG_F16);
+    o.rt_flags = flags & (FQ_ROUND_Y_F16 | FQ_NO_CLAMP0 | FQ_GROUP128 | FQ_SIG_F16 | FQ_RATIO_POST);
     o.rms_eps = 0.0f;
     o.in2 = nullptr;
     return FQ_OK;
@@ -223,6 +223,7 @@ static int kron_quant_impl(const char* what, int dt, const void* x, const void* 
                            void* workspace, int64_t workspace_bytes, void* stream) {
     if (rows < 0 || M <= 0 || N <= 0) return fail(FQ_EINVAL, "%s: bad sizes rows=%lld M=%d N=%d", what, (long long)rows, M, N);
     if (N & 1) return fail(FQ_EINVAL, "%s: N=%d must be even (two INT4 per byte)", what, N);
+    if (flags & FQ_RATIO_POST) return fail(FQ_EINVAL, "%s: FQ_RATIO_POST is a row-quantiser flag", what);
     FqQuantOut o;
     int rc = fill_out(what, o, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out, y_out);
     if (rc != FQ_OK) return rc;
@@ -735,6 +736,8 @@ static int rowquant_impl(const char* what, int dt, const void* x, int64_t rows, 
     if ((flags & FQ_ASYM) && (flags & ~(FQ_ASYM | FQ_OUT_FAKEQUANT | FQ_QUANT_F16)) )
         return fail(FQ_EINVAL, "%s: FQ_ASYM goes with FQ_OUT_FAKEQUANT (and FQ_QUANT_F16) only, flags 0x%x", what, flags);
     if ((flags & FQ_ASYM) && !(flags & FQ_OUT_FAKEQUANT)) return fail(FQ_EINVAL, "%s: FQ_ASYM needs FQ_OUT_FAKEQUANT", what);
+    if ((flags & FQ_RATIO_POST) && (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_QUANT_F16 | FQ_ASYM | FQ_SIG_F16)) != (FQ_OUT_PACKED | FQ_QUANT_F16))
+        return fail(FQ_EINVAL, "%s: FQ_RATIO_POST goes with FQ_OUT_PACKED | FQ_QUANT_F16 only, flags 0x%x", what, flags);
     FqQuantOut o;
     int rc = fill_out(what, o, sig_max, sig_min, n_clips, flags & ~FQ_ASYM, q_out, scale_out, fq_out, nullptr);
     if (rc != FQ_OK) return rc;

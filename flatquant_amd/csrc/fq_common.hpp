@@ -250,6 +250,12 @@ __device__ __forceinline__ float fq_token_scale(float xmax, float xmin, float si
         xmax = fmaxf(xmax, 0.0f);
         xmin = fminf(xmin, 0.0f);
     }
+    if ((FLAGS & FQ_QUANT_F16) && (rt_flags & FQ_RATIO_POST)) {
+        // deploy Quantizer(input_clip_ratio) (deploy/nn/quantization.py:30): (max|x| / 7).to(fp16) * ratio, both steps in T
+        const float m0 = fmaxf(fabsf(xmin), xmax);
+        if (m0 == 0.0f) return 1.0f;   // (quantise with 1: every digit is 0; the caller stores the reference's scale, 0)
+        return (float)fq_mul_to<T>((float)(T)(m0 / 7.0f), sig_max);
+    }
     if ((FLAGS & FQ_QUANT_F16) && (rt_flags & FQ_SIG_F16)) {
         // deploy.nn.Quantizer(lac=True), deploy/nn/quantization.py:21-22: an fp16 [rows, 1] tensor times a 0-dim fp32
         // sigmoid tensor is an fp16 RESULT under torch's type promotion: the product is formed in fp32 (fp16 extremum x the

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(RQ_THREADS) void fq_rowquant_kernel(const T* __rest
             const float h16_inv = fq_fast_inv(scale);
             const bool h16_clamp = fq_h16_needs_clamp(vmax, vmin, h16_inv);
             if (FLAGS & FQ_OUT_PACKED) {
-                if (tid == 0) reinterpret_cast<T*>(out.scale[ci])[row] = (T)scale;
+                if (tid == 0) reinterpret_cast<T*>(out.scale[ci])[row] = ((out.rt_flags & FQ_RATIO_POST) && vmax == 0.0f && vmin == 0.0f) ? (T)0.0f : (T)scale;
                 uint32_t* qp = reinterpret_cast<uint32_t*>(out.q[ci] + row * (int64_t)(cols >> 1));
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
@@ -243,7 +243,7 @@ void fq_rowquant_wave_kernel(const T* __restrict__ x, int64_t rows, int cols,
             const float inv = fq_fast_inv(scale);
             const bool h16_clamp = fq_h16_needs_clamp(vmax, vmin, inv);
             if (FLAGS & FQ_OUT_PACKED) {
-                if (lane == 0 && live) reinterpret_cast<T*>(out.scale[ci])[row] = (T)scale;
+                if (lane == 0 && live) reinterpret_cast<T*>(out.scale[ci])[row] = ((out.rt_flags & FQ_RATIO_POST) && vmax == 0.0f && vmin == 0.0f) ? (T)0.0f : (T)scale;
                 uint32_t* qp = reinterpret_cast<uint32_t*>(out.q[ci] + row * (int64_t)(cols >> 1));
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {

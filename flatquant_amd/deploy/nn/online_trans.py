@@ -58,8 +58,7 @@ class OnlineTrans(torch.nn.Module):
                 sig = ops.sigmoid_pair_f16(quantizer.clip_factor_a_max, quantizer.clip_factor_a_min)   # (device semantics)
                 q, s = ops.hadamard_quant(x.contiguous(), self.rem_dim, self.had_rem_dim, sig,
                                           up=None if up is None else up.contiguous())
-                lead = x.shape[:-1]
-                return PackedQuantizedTensor(q, s.reshape(*lead, 1) if len(lead) > 1 else s.reshape(-1, 1))
+                return PackedQuantizedTensor(q, s.reshape(-1, 1))   # (the lac Quantizer's [rows, 1] scales, quantization.py:16-28)
             if up is not None:
                 from ... import ops
                 x = ops.silu_mul(x.contiguous(), up.contiguous())
@@ -77,7 +76,8 @@ class OnlineTrans(torch.nn.Module):
             bsz, seq_len, _ = x.shape
             sig = ops.sigmoid_pair(self.clip_factor_a_max, self.clip_factor_a_min)
             o = ops.rmsnorm_kron_quant(x.contiguous(), float(norm.eps), self.left_matrix.contiguous(),
-                                       self.right_matrix.contiguous(), [sig], FQ_OUT_PACKED | FQ_NO_CLAMP0)
+                                       self.right_matrix.contiguous(), [sig],
+                                       functional.online_trans.deploy_kron_flags(self.left_matrix.shape[0], self.right_matrix.shape[0]))
             return PackedQuantizedTensor(o.q[0].reshape(bsz, seq_len, -1), o.scale[0].reshape(bsz, 1, seq_len))
         if self.trans == "matmul" and up is not None:
             from ... import ops
@@ -89,7 +89,8 @@ class OnlineTrans(torch.nn.Module):
                 bsz, seq_len, _ = x.shape
                 sig = ops.sigmoid_pair(self.clip_factor_a_max, self.clip_factor_a_min)
                 o = ops.silu_mul_kron_quant(x.contiguous(), up.contiguous(), self.left_matrix.contiguous(),
-                                            self.right_matrix.contiguous(), [sig], FQ_OUT_PACKED | FQ_NO_CLAMP0)
+                                            self.right_matrix.contiguous(), [sig],
+                                            functional.online_trans.deploy_kron_flags(self.left_matrix.shape[0], self.right_matrix.shape[0]))
                 return PackedQuantizedTensor(o.q[0].reshape(bsz, seq_len, -1), o.scale[0].reshape(bsz, 1, seq_len))
         if self.trans == "matmul":
             invs = []
@@ -122,9 +123,10 @@ def fused_forward(x, transforms, norm=None):
     bsz, seq_len, _ = x.shape
     sigs = [ops.sigmoid_pair(t.clip_factor_a_max, t.clip_factor_a_min) for t in transforms]
     left, right = first.left_matrix.contiguous(), first.right_matrix.contiguous()
+    flags = functional.online_trans.deploy_kron_flags(left.shape[0], right.shape[0])   # (as each module's own forward)
     if norm is not None:
-        o = ops.rmsnorm_kron_quant(x.contiguous(), float(norm.eps), left, right, sigs, FQ_OUT_PACKED | FQ_NO_CLAMP0)
+        o = ops.rmsnorm_kron_quant(x.contiguous(), float(norm.eps), left, right, sigs, flags)
     else:
-        o = ops.kron_quant(x.contiguous(), left, right, sigs, FQ_OUT_PACKED | FQ_NO_CLAMP0)
+        o = ops.kron_quant(x.contiguous(), left, right, sigs, flags)
     return [PackedQuantizedTensor(o.q[i].reshape(bsz, seq_len, -1), o.scale[i].reshape(bsz, 1, seq_len))
             for i in range(len(transforms))]

@@ -2,7 +2,7 @@
 import torch
 
 from ... import ops
-from ..._lib import FQ_OUT_PACKED, FQ_QUANT_F16, FQ_SIG_F16
+from ..._lib import FQ_OUT_PACKED, FQ_QUANT_F16, FQ_RATIO_POST, FQ_SIG_F16
 from .. import PackedQuantizedTensor
 
 
@@ -25,16 +25,14 @@ class Quantizer(torch.nn.Module):
         if isinstance(x, PackedQuantizedTensor):
             return x
         if self.lac:
+            # the reference multiplies the fp16 row extrema by a 0-dim fp32 sigmoid, which torch's device kernels load in fp16
+            # (deploy/nn/quantization.py:21-22) -> FQ_SIG_F16 with the fp16-rounded sigmoid; scales are [rows, 1] (:16-28)
             sig = ops.sigmoid_pair_f16(self.clip_factor_a_max, self.clip_factor_a_min)
-        elif self.input_clip_ratio == 1.0:
-            sig = (1.0, 1.0)
-        else:
-            # (max|x|/7).to(fp16) * ratio: keep the reference's exact op order with torch, pack with the kernel
-            from .. import sym_quant
-            scales = (torch.max(torch.abs(x), dim=-1)[0].unsqueeze(1) / 7).to(torch.float16) * self.input_clip_ratio
-            return PackedQuantizedTensor(sym_quant(x, scales), scales)
-        # lac: the reference multiplies the fp16 row extrema by a 0-dim fp32 sigmoid, which torch evaluates in fp16
-        # (deploy/nn/quantization.py:21-22) -> FQ_SIG_F16; pinned by tests/golden/quantizer_lac.npz
-        o = ops.rowquant(x.contiguous(), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | (FQ_SIG_F16 if self.lac else 0))
-        lead = x.shape[:-1]
-        return PackedQuantizedTensor(o.q[0], o.scale[0].reshape(*lead, 1) if len(lead) > 1 else o.scale[0].reshape(-1, 1))
+            o = ops.rowquant(x.contiguous(), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)
+            return PackedQuantizedTensor(o.q[0], o.scale[0].reshape(-1, 1))
+        # (max|x| / 7).to(fp16) * ratio (quantization.py:30), one launch: FQ_RATIO_POST applies the factor to the scale
+        # (ratio == 1: the product is the identity); the scales keep the shape of `torch.max(..., dim=-1)[0].unsqueeze(1)`
+        ratio = float(self.input_clip_ratio)
+        flags = FQ_OUT_PACKED | FQ_QUANT_F16 | (FQ_RATIO_POST if ratio != 1.0 else 0)
+        o = ops.rowquant(x.contiguous(), [(ratio, 1.0) if ratio != 1.0 else (1.0, 1.0)], flags)
+        return PackedQuantizedTensor(o.q[0], o.scale[0].reshape(x.shape[:-1]).unsqueeze(1))

@@ -88,6 +88,13 @@ extern "C" {
                                    zero = rint(-xmin / scale), out = scale * (clamp(rint(x / scale) + zero, 0, 15) - zero);
                                    fp32 arithmetic, or fp16 throughout with FQ_QUANT_F16 (no lac / clip_ratio / half module) */
 
+#define FQ_RATIO_POST     0x10000 /* fq_rowquant_f16 with FQ_QUANT_F16 | FQ_OUT_PACKED: the factor multiplies the SCALE, not the
+                                   extrema — deploy.nn.Quantizer(input_clip_ratio) / functional.quant(input_clip_ratio),
+                                   deploy/nn/quantization.py:30, deploy/functional/online_trans.py:106:
+                                   scale = fp16( fp16(max|x| / 7) * ratio ), the product rounded to fp32 and then to fp16 (the
+                                   mul functor's float opmath on the reference's platform); sig_max carries the ratio; an
+                                   all-zero row gets scale 0 like the reference's (its digits are 0 either way) */
+
 #define FQ_MAX_CLIPS 4
 
 /*
