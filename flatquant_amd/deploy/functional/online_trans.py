@@ -61,11 +61,9 @@ def quant(x, clip_factor_a_max=1.0, clip_factor_a_min=1.0, input_clip_ratio=1.0)
     if cmax != 1.0:
         # :91-104: fp16 extrema x a 0-dim fp32 sigmoid tensor is an fp16 product under torch's promotion -> FQ_SIG_F16
         o = ops.rowquant(x2.contiguous(), [ops.sigmoid_pair_f16(cmax, cmin)], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)
-    elif input_clip_ratio != 1.0:
+    else:
         # :106: (max|x| / 7).to(fp16) * ratio in the same launch (FQ_RATIO_POST); the scales keep x's leading shape as the
         # reference's `torch.max(..., dim=-1)[0].unsqueeze(1)` gives it
         o = ops.rowquant(x2.contiguous(), [(ops.scalar_f16(input_clip_ratio), 1.0)], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_RATIO_POST)
         return PackedQuantizedTensor(o.q[0].reshape(x.shape[:-1] + (x.shape[-1] // 2,)), o.scale[0].reshape(x.shape[:-1]).unsqueeze(1))
-    else:
-        o = ops.rowquant(x2.contiguous(), [(1.0, 1.0)], FQ_OUT_PACKED | FQ_QUANT_F16)
-    return PackedQuantizedTensor(o.q[0], o.scale[0].reshape(-1, 1))
+    return PackedQuantizedTensor(o.q[0].reshape(x.shape[:-1] + (x.shape[-1] // 2,)), o.scale[0].reshape(-1, 1))

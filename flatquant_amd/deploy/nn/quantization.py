@@ -31,8 +31,8 @@ class Quantizer(torch.nn.Module):
             o = ops.rowquant(x.contiguous(), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)
             return PackedQuantizedTensor(o.q[0], o.scale[0].reshape(-1, 1))
         # (max|x| / 7).to(fp16) * ratio (quantization.py:30), one launch: FQ_RATIO_POST applies the factor to the scale
-        # (ratio == 1: the product is the identity); the scales keep the shape of `torch.max(..., dim=-1)[0].unsqueeze(1)`
+        # (ratio == 1: the product is the identity, and — like the reference, which has no zero guard on this branch — an all-zero
+        # row keeps scale 0); the scales keep the shape of `torch.max(..., dim=-1)[0].unsqueeze(1)`
         ratio = ops.scalar_f16(self.input_clip_ratio)   # (device semantics: the python scalar is read as fp16)
-        flags = FQ_OUT_PACKED | FQ_QUANT_F16 | (FQ_RATIO_POST if ratio != 1.0 else 0)
-        o = ops.rowquant(x.contiguous(), [(ratio, 1.0) if ratio != 1.0 else (1.0, 1.0)], flags)
+        o = ops.rowquant(x.contiguous(), [(ratio, 1.0)], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_RATIO_POST)
         return PackedQuantizedTensor(o.q[0], o.scale[0].reshape(x.shape[:-1]).unsqueeze(1))
