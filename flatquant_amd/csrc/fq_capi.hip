@@ -49,7 +49,10 @@ int fq_launch_silu_mul(const f16* gate, const f16* up, f16* y, int64_t n, int n_
 int fq_launch_silu_hadamard_quant(const f16* gate, const f16* up, int64_t rows, int n, int K, const f16* hadK, float scale,
                                   float sig_max, float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream);
 int64_t fq_kron_generic_workspace_bytes(int M, int N);
-int fq_launch_kron_prepare(const f16* left, const f16* right, int M, int N, void* workspace, hipStream_t stream);
+int fq_launch_kron_prepare(const f16* left, const f16* right, int M, int N, void* workspace, hipStream_t stream, int groups = 1);
+int fq_launch_kron_grouped_mats(int flags, const void* x, const void* left, const void* right, int64_t rows, int M, int N,
+                                const FqQuantOut& out, int n_groups, void* workspace, int64_t workspace_bytes, int n_cu,
+                                hipStream_t stream);
 int fq_launch_block(int flags, const f16* x, const f16* P, int64_t rows, int R, int C, int transpose_out,
                     const FqQuantOut& out, int n_cu, hipStream_t stream);
 int fq_launch_hadamard(const f16* x, f16* y, int64_t rows, int n, int K, const f16* hadK, float scale,
@@ -290,6 +293,56 @@ int fq_kron_quant_grouped_bf16(const void* x, const void* left, const void* righ
                                void* workspace, int64_t workspace_bytes, void* stream) {
     return kron_quant_grouped_impl("fq_kron_quant_grouped_bf16", FQ_DT_BF16, x, left, right, rows, M, N, group_offsets, n_groups,
                                    sig_max_g, sig_min_g, flags, q_out, scale_out, fq_out, y_out, workspace, workspace_bytes, stream);
+}
+
+static int kron_quant_grouped_mats_impl(const char* what, int dt, const void* x, const void* left_g, const void* right_g, int64_t rows,
+                                        int M, int N, const int64_t* group_offsets, int n_groups, const float* sig_max_g,
+                                        const float* sig_min_g, int flags, void* q_out, void* scale_out, void* fq_out, void* y_out,
+                                        void* workspace, int64_t workspace_bytes, void* stream) {
+    if (rows < 0 || M <= 0 || N <= 0) return fail(FQ_EINVAL, "%s: bad sizes rows=%lld M=%d N=%d", what, (long long)rows, M, N);
+    if (N & 1) return fail(FQ_EINVAL, "%s: N=%d must be even (two INT4 per byte)", what, N);
+    if (n_groups < 1) return fail(FQ_EINVAL, "%s: n_groups=%d", what, n_groups);
+    if (flags & (FQ_GROUP128 | FQ_RATIO_POST)) return fail(FQ_EUNSUPPORTED, "%s: per-token scales only", what);
+    const bool quant = (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) != 0;
+    const float one = 1.0f;
+    void* q1[FQ_MAX_CLIPS] = {q_out}, *s1[FQ_MAX_CLIPS] = {scale_out}, *f1[FQ_MAX_CLIPS] = {fq_out};
+    FqQuantOut o;
+    int rc = fill_out(what, o, &one, &one, 1, flags, q1, s1, f1, y_out);
+    if (rc != FQ_OK) return rc;
+    if (rows == 0) return FQ_OK;
+    if (!x || !left_g || !right_g || !group_offsets) return fail(FQ_EINVAL, "%s: x / left_g / right_g / group_offsets is NULL", what);
+    if (quant && (!sig_max_g || !sig_min_g)) return fail(FQ_EINVAL, "%s: sig_max_g / sig_min_g is NULL", what);
+    FQ_NEED_ALIGN16(what, x, left_g, right_g, workspace);
+    if ((((int64_t)M * M * 2) & 15) || (((int64_t)N * N * 2) & 15))
+        return fail(FQ_EUNSUPPORTED, "%s: the per-group matrices must each start on a 16-byte boundary (M*M and N*N multiples of 8)", what);
+    o.group_offsets = group_offsets;     // (the matrices follow the groups even in a transform-only launch)
+    o.sig_max_g = quant ? sig_max_g : nullptr;
+    o.sig_min_g = quant ? sig_min_g : nullptr;
+    o.n_groups = n_groups;
+    rc = fq_launch_kron_grouped_mats(flags | dt, x, left_g, right_g, rows, M, N, o, n_groups, workspace, workspace_bytes, cu_count(),
+                                     (hipStream_t)stream);
+    if (rc == -1001)
+        return fail(FQ_EINVAL, "%s: workspace of %lld bytes required for %d groups of M=%d N=%d (got %lld)", what,
+                    (long long)(fq_kron_generic_workspace_bytes(M, N) * n_groups), n_groups, M, N, (long long)(workspace ? workspace_bytes : 0));
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "%s: no workgroup-per-token kernel for factors (%d, %d)", what, M, N);
+    return check_launch(rc, what);
+}
+
+int fq_kron_quant_grouped_mats_f16(const void* x, const void* left_g, const void* right_g, int64_t rows, int M, int N,
+                                   const int64_t* group_offsets, int n_groups, const float* sig_max_g, const float* sig_min_g,
+                                   int flags, void* q_out, void* scale_out, void* fq_out, void* y_out,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
+    return kron_quant_grouped_mats_impl("fq_kron_quant_grouped_mats_f16", 0, x, left_g, right_g, rows, M, N, group_offsets, n_groups,
+                                        sig_max_g, sig_min_g, flags, q_out, scale_out, fq_out, y_out, workspace, workspace_bytes, stream);
+}
+
+int fq_kron_quant_grouped_mats_bf16(const void* x, const void* left_g, const void* right_g, int64_t rows, int M, int N,
+                                    const int64_t* group_offsets, int n_groups, const float* sig_max_g, const float* sig_min_g,
+                                    int flags, void* q_out, void* scale_out, void* fq_out, void* y_out,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+    return kron_quant_grouped_mats_impl("fq_kron_quant_grouped_mats_bf16", FQ_DT_BF16, x, left_g, right_g, rows, M, N, group_offsets,
+                                        n_groups, sig_max_g, sig_min_g, flags, q_out, scale_out, fq_out, y_out, workspace, workspace_bytes,
+                                        stream);
 }
 
 int fq_rmsnorm_kron_quant_f16(const void* x, float eps, const void* left, const void* right, int64_t rows, int M, int N,

@@ -71,6 +71,9 @@ struct FqQuantOut {
     int            n_groups;
     float          post_scale;     // != 0: the transformed activation is multiplied by it (fp32) before rounding / statistics
                                    // (fq_kron_quant_ex_f16: a normalisation that fp16 factor matrices cannot carry exactly)
+    int64_t        ws_group_stride;  // != 0 (fq_kron_quant_grouped_mats_*): every group has its OWN factor pair; the workspace
+                                     // holds n_groups fragment images this many 16-byte chunks apart (routed_w2_trans[i],
+                                     // deepseekv3_utils.py:446)
 };
 
 // Clip pair of token `tok` (wave-uniform): the launch-wide pair `ci`, or the pair of the token's group. A wave walks its
@@ -92,6 +95,9 @@ __device__ __forceinline__ int64_t fq_uniform_i64(int64_t v) {
 __device__ __forceinline__ float fq_uniform_f32(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
+// Move the cursor to the group of token `tok` (wave-uniform; a no-op while the token stays inside the cursor's range).
+__device__ __forceinline__ void fq_group_locate(const FqQuantOut& out, int64_t tok, FqGroupCursor& cur);
+
 __device__ __forceinline__ void fq_token_sigs(const FqQuantOut& out, int ci, int64_t tok, FqGroupCursor& cur, float& smax,
                                               float& smin) {
     if (out.group_offsets == nullptr) {
@@ -99,6 +105,12 @@ __device__ __forceinline__ void fq_token_sigs(const FqQuantOut& out, int ci, int
         smin = out.sig_min[ci];
         return;
     }
+    fq_group_locate(out, tok, cur);
+    smax = cur.smax;
+    smin = cur.smin;
+}
+
+__device__ __forceinline__ void fq_group_locate(const FqQuantOut& out, int64_t tok, FqGroupCursor& cur) {
     if (cur.g < 0 || tok >= cur.end || tok < cur.begin) {
         int lo = 0, hi = out.n_groups;  // invariant: offsets[lo] <= tok < offsets[hi]
         while (hi - lo > 1) {
@@ -109,11 +121,9 @@ __device__ __forceinline__ void fq_token_sigs(const FqQuantOut& out, int ci, int
         cur.g = lo;
         cur.begin = fq_uniform_i64(out.group_offsets[lo]);
         cur.end = fq_uniform_i64(out.group_offsets[lo + 1]);
-        cur.smax = fq_uniform_f32(out.sig_max_g[lo]);
-        cur.smin = fq_uniform_f32(out.sig_min_g[lo]);
+        cur.smax = out.sig_max_g ? fq_uniform_f32(out.sig_max_g[lo]) : 1.0f;   // (a transform-only launch carries no clip pairs)
+        cur.smin = out.sig_min_g ? fq_uniform_f32(out.sig_min_g[lo]) : 1.0f;
     }
-    smax = cur.smax;
-    smin = cur.smin;
 }
 
 // Raise a kernel's dynamic-LDS cap once PER DEVICE (hipFuncSetAttribute acts on the current device; one process may

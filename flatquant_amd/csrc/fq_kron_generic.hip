@@ -44,9 +44,13 @@ __device__ __forceinline__ int ncol(int NT, int nt, int c) {
 }
 
 // Workspace layout: rfrag [NT][KS1][64 lanes] uint4, then lfrag [2*MT][MT][64 lanes] uint4.
+// blockIdx.y = group (fq_kron_quant_grouped_mats_*: left [G, M, M], right [G, N, N], one image per group; 0 otherwise).
 __global__ void fq_kron_prepare_kernel(const f16* __restrict__ left, const f16* __restrict__ right, int M, int N,
                                        int MT, int NT, int KS1, uint4* __restrict__ ws) {
     const int n_r = NT * KS1 * 64, n_l = 2 * MT * MT * 64;
+    left += (size_t)blockIdx.y * M * M;
+    right += (size_t)blockIdx.y * N * N;
+    ws += (size_t)blockIdx.y * (n_r + n_l);
     for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < n_r + n_l; item += gridDim.x * blockDim.x) {
         f16x8 v;
         if (item < n_r) {
@@ -90,7 +94,9 @@ __global__ void fq_kron_prepare_kernel(const f16* __restrict__ left, const f16* 
 // instantiations: KS1 / NT describe N padded to whole K-steps, the token is staged in 8-byte units (a 16-byte chunk would
 // straddle two rows), the last 16-column run of a row is cut by N (extrema and stores take its valid part) and rows of the
 // packed stage (N / 2 = 74 bytes) are written in 2-byte pieces.
-template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1, int NV = 0, typename T = f16>
+// GM: the grouped launch with one factor pair per group (fq_kron_quant_grouped_mats_*): its own instantiations, so that the
+// cursor and the image reload do not cost the ordinary launches registers (128 x 224 would spill).
+template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1, int NV = 0, typename T = f16, bool GM = false>
 __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fast_kernel(const T* __restrict__ x, const uint4* __restrict__ ws,
                                                            const T* __restrict__ diag, int64_t rows, int M, int /*N*/,
                                                            FqQuantOut out, int flags_rt) {
@@ -171,6 +177,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
     int pf_q0 = tid;
     if (tok < rows) FQ_PF_LOAD(tok)
     FqGroupCursor gcur;  // grouped launches: the clip pair follows the token's group
+    int mats_g = 0;      // ws_group_stride != 0: the group whose fragment image is loaded (group 0's after the prologue)
     // The zero fill of xs above and the first token's staging below touch the same LDS words from DIFFERENT threads
     // (fill: chunk tid + k THREADS; staging: row * PITCH + chunk): without this barrier a wave that is late in the
     // prologue (cold instruction cache on a kernel's first launches) zeroes rows another wave has already staged —
@@ -225,6 +232,25 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                         v = __builtin_bit_cast(uint4, __builtin_bit_cast(X8, v) * __builtin_bit_cast(X8, dp[q]));
                     const int row = q / cpr, ch = q - row * cpr;
                     xs[row * PITCH + ch] = v;
+                }
+            }
+        }
+        if (GM) {
+            // every group has its own factor pair (routed_w2_trans[i], deepseekv3_utils.py:446): when the token's group
+            // changes — rows are sorted by group, so once per group and workgroup — the R fragments (registers) and the L
+            // image (LDS) are re-read from that group's image in the workspace (L2-resident, a few KB)
+            fq_group_locate(out, tok, gcur);
+            if (gcur.g != mats_g) {
+                mats_g = gcur.g;
+                const uint4* wg = ws + (size_t)mats_g * out.ws_group_stride;
+                const uint4* lg = wg + (size_t)NT * KS1 * 64;
+                for (int i = tid; i < LFR; i += THREADS) lfr[i] = lg[i];   // (every wave passed the previous token's barriers)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    const int nt = wave + WAVES * t;
+#pragma unroll
+                    for (int s = 0; s < KS1; ++s)
+                        if (nt < NT) RF[t][s] = __builtin_bit_cast(X8, wg[((size_t)nt * KS1 + s) * 64 + lane]);
                 }
             }
         }
@@ -579,13 +605,13 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
     }
 }
 
-template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1, int NV = 0, typename T = f16>
+template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1, int NV = 0, typename T = f16, bool GM = false>
 int launch_fast(int flags, const T* x, const uint4* ws, const T* diag, int64_t rows, int M, int N,
                 const FqQuantOut& out, int n_cu, hipStream_t stream) {
     constexpr int PITCH = (KS1 * 2) | 1;
     const size_t lds = (size_t)2 * MT * MT * 1024 + (size_t)MT * 32 * PITCH * 16 + (((size_t)M * N / 2 + 15) & ~(size_t)15) + 128;
     if (lds > 160 * 1024) return -1000;
-    auto kern = fq_kron_fast_kernel<MT, NT, KS1, WAVES, OCC, SILU, CTF, NV, T>;
+    auto kern = fq_kron_fast_kernel<MT, NT, KS1, WAVES, OCC, SILU, CTF, NV, T, GM>;
     FQ_RAISE_LDS_CAP(kern, 160 * 1024);
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > OCC) per_cu = OCC;
@@ -613,12 +639,52 @@ int64_t fq_kron_generic_workspace_bytes(int M, int N) {
     return ((int64_t)NT * KS1 + 2 * (int64_t)MT * MT) * 1024;
 }
 
-int fq_launch_kron_prepare(const f16* left, const f16* right, int M, int N, void* workspace, hipStream_t stream) {
+int fq_launch_kron_prepare(const f16* left, const f16* right, int M, int N, void* workspace, hipStream_t stream, int groups = 1);
+int fq_launch_kron_prepare(const f16* left, const f16* right, int M, int N, void* workspace, hipStream_t stream, int groups) {
     const int MT = tiles32(M), NT = tiles32(N), KS1 = (N + 15) / 16;
     const int items = (NT * KS1 + 2 * MT * MT) * 64;
-    hipLaunchKernelGGL(fq_kron_prepare_kernel, dim3((items + 255) / 256), dim3(256), 0, stream, left, right, M, N, MT,
+    hipLaunchKernelGGL(fq_kron_prepare_kernel, dim3((items + 255) / 256, groups), dim3(256), 0, stream, left, right, M, N, MT,
                        NT, KS1, reinterpret_cast<uint4*>(workspace));
     return (int)hipGetLastError();
+}
+
+// Grouped launch in which every group has its own factor pair (fq_kron_quant_grouped_mats_{f16,bf16}): left [G, M, M],
+// right [G, N, N]; the workspace holds G fragment images. The workgroup-per-token kernel (all output sets) for the factor pairs
+// it is instantiated for; -1000 otherwise.
+template <typename T>
+static int launch_kron_grouped_mats_t(int flags, const T* x, const T* left, const T* right, int64_t rows, int M, int N,
+                                      FqQuantOut out, int n_groups, void* workspace, int64_t workspace_bytes, int n_cu,
+                                      hipStream_t stream) {
+    if (M < 1 || N < 2 || (N & 15) || M > 192 || ((M * N / 2) & 15)) return -1000;
+    const int64_t img = fq_kron_generic_workspace_bytes(M, N);
+    if (!workspace || workspace_bytes < img * n_groups) return -1001;
+    if (!(flags & FQ_WS_PREPARED)) {
+        const int rc = fq_launch_kron_prepare((const f16*)left, (const f16*)right, M, N, workspace, stream, n_groups);
+        if (rc != 0) return rc;
+    }
+    flags &= ~FQ_WS_PREPARED;
+    out.ws_group_stride = img / 16;
+    const int MT = tiles32(M), NT = tiles32(N), KS1 = N / 16;
+    const uint4* ws = reinterpret_cast<const uint4*>(workspace);
+#define FQ_FG(MT_, NT_, KS1_, W_, OCC_)                                                                                  \
+    if (MT == MT_ && NT == NT_ && KS1 == KS1_)                                                                           \
+        return launch_fast<MT_, NT_, KS1_, W_, OCC_, false, -1, 0, T, true>(flags, x, ws, (const T*)nullptr, rows, M, N, out, n_cu, stream);
+    // (the pairs an expert's hidden / model dimension decomposes into: 32x64 = 2048 DeepSeek-V3 moe_inter, 64x112 = 7168,
+    //  64x64, 56x64, 64x128, 64x80, 112x128, 86..96x128)
+    FQ_FG(1, 2, 4, 4, 4) FQ_FG(2, 2, 4, 4, 2) FQ_FG(2, 4, 7, 4, 2) FQ_FG(2, 4, 8, 4, 2) FQ_FG(2, 3, 5, 4, 2) FQ_FG(4, 4, 8, 4, 2)
+    FQ_FG(3, 4, 8, 4, 2)
+#undef FQ_FG
+    return -1000;
+}
+
+int fq_launch_kron_grouped_mats(int flags, const void* x, const void* left, const void* right, int64_t rows, int M, int N,
+                                const FqQuantOut& out, int n_groups, void* workspace, int64_t workspace_bytes, int n_cu,
+                                hipStream_t stream) {
+    if (flags & FQ_DT_BF16)
+        return launch_kron_grouped_mats_t<bf16>(flags & ~FQ_DT_BF16, (const bf16*)x, (const bf16*)left, (const bf16*)right, rows, M,
+                                                N, out, n_groups, workspace, workspace_bytes, n_cu, stream);
+    return launch_kron_grouped_mats_t<f16>(flags, (const f16*)x, (const f16*)left, (const f16*)right, rows, M, N, out, n_groups,
+                                           workspace, workspace_bytes, n_cu, stream);
 }
 
 // bf16 activations (the path-A surface: kronecker_matmul, {Inv,SVD}DecomposeTransMatrix, the fake-quant contract): the

@@ -343,9 +343,9 @@ def kron_quant_grouped(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor,
     """Grouped (per-expert) transform + quantisation (fq_kron_quant_grouped_f16): x [rows, d] sorted by group, group g
     owns rows [group_offsets[g], group_offsets[g+1]) and quantises with sigmoid factors (sig_max_g[g], sig_min_g[g])
     (fp32 device tensors; the reference shares ONE quantiser across the routed experts: expand it). One launch, nothing
-    read back, when left / right are 2-D (shared transform: deepseekv3_utils.py:470). 3-D left / right [G, M, M] /
-    [G, N, N] are the reference's ``routed_w2_trans[i]`` branch (:446): one launch per non-empty group, with the
-    group sizes read back to the host exactly like the reference's ``counts ... .tolist()``."""
+    read back: 2-D left / right = the shared transform (deepseekv3_utils.py:470), fq_kron_quant_grouped_*; 3-D left / right
+    [G, M, M] / [G, N, N] = the reference's ``routed_w2_trans[i]`` branch (:443-446), fq_kron_quant_grouped_mats_* (one
+    fragment image per group in the cached workspace; the reference loops over the experts on the host with ``.tolist()``)."""
     dt = _chk_act(x)
     _chk(left, "left", dt), _chk(right, "right", dt)
     _chk(group_offsets, "group_offsets", torch.int64)
@@ -363,20 +363,35 @@ def kron_quant_grouped(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor,
     if left.dim() == 3 or right.dim() == 3:                        # one transform per expert
         if left.shape[0] != G or right.shape[0] != G or left.dim() != 3 or right.dim() != 3:
             raise ValueError("per-group matrices must be [n_groups, M, M] and [n_groups, N, N]")
-        offs = group_offsets.tolist()
-        smax, smin = sig_max_g.tolist(), sig_min_g.tolist()
-        o = _alloc_outputs(x, rows * (d // groupsize if groupsize > 0 else 1), d, 1, flags, (rows, d // 2), x.shape)
         if groupsize > 0:
-            _group_scales_shape(o, (rows,), d // groupsize)
-        for g in range(G):
-            a, b = offs[g], offs[g + 1]
-            if b > a:
-                part = kron_quant(x[a:b], left[g], right[g], [(smax[g], smin[g])], flags, groupsize=groupsize)
-                for dst, src in ((o.q, part.q), (o.scale, part.scale), (o.fq, part.fq)):
-                    if dst:
-                        dst[0][a:b] = src[0]
-                if o.y is not None:
-                    o.y[a:b] = part.y
+            # 128-element scales next to per-expert matrices: the grouped transform launch, then the row quantiser over the
+            # (-1, 128) view — the row quantiser takes one clip pair per launch, so the groups' pairs must agree (the reference
+            # shares one quantiser across the routed experts: deepseekv3_utils.py:418-419)
+            if not (bool((sig_max_g == sig_max_g[0]).all()) and bool((sig_min_g == sig_min_g[0]).all())):
+                raise _lib.FqError(FQ_EUNSUPPORTED, "per-expert matrices with 128-element scales need one shared clip pair")
+            o = kron_quant_grouped(x, left, right, group_offsets, sig_max_g, sig_min_g, FQ_OUT_TRANSFORM)
+            sig = (float(sig_max_g[0]), float(sig_min_g[0]))
+            return _quant_groups_of(o.y, [sig], flags, groupsize, o) if flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT) else o
+        o = _alloc_outputs(x, rows, d, 1, flags, (rows, d // 2), x.shape)
+        if rows == 0:
+            return o
+        with torch.cuda.device(x.device):
+            per = int(lib.fq_kron_workspace_bytes(M, N))
+            if per < 0:
+                raise _lib.FqError(per, f"no kernel for Kronecker factors ({M}, {N})")
+            key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream, M, N, G,
+                   left.data_ptr(), left._version, right.data_ptr(), right._version)
+            ent = _WS_LRU.get(key)
+            prepared = ent is not None
+            ws = ent[0] if prepared else torch.empty(per * G, dtype=torch.uint8, device=x.device)
+            check(_fn("kron_quant_grouped_mats", dt)(
+                _ptr(x), _ptr(left), _ptr(right), rows, M, N, _ptr(group_offsets), G, _ptr(sig_max_g), _ptr(sig_min_g),
+                flags | (FQ_WS_PREPARED if prepared else 0), _ptr(o.q[0] if o.q else None), _ptr(o.scale[0] if o.scale else None),
+                _ptr(o.fq[0] if o.fq else None), _ptr(o.y), _ptr(ws), per * G, _stream(x)))
+            if not prepared:
+                _kron_workspace_commit(key, ws, left, right)
+            else:
+                _WS_LRU.move_to_end(key)
         return o
     fused_g = groupsize == 128 and (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) == FQ_OUT_PACKED and N == 64 and M % 2 == 0 \
         and dt == torch.float16

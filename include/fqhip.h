@@ -172,6 +172,25 @@ int fq_kron_quant_grouped_bf16(const void* x, const void* left, const void* righ
                                void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * The same with ONE FACTOR PAIR PER GROUP — the `routed_w2_trans[i]` branch of flatquant/model_tools/deepseekv3_utils.py:443-446
+ * (independent_w2_trans: every routed expert owns its transform) — in one launch, nothing read back:
+ *   left_g  [n_groups, M, M], right_g [n_groups, N, N]   contiguous device tensors of x's element type
+ *   workspace  n_groups * fq_kron_workspace_bytes(M, N) bytes always suffice: one fragment image per group, written by the
+ *              call unless FQ_WS_PREPARED (the matrices are constants of a deployed layer). A workgroup re-reads the image of a
+ *              token's group when the group changes: once per group.
+ * sig_max_g / sig_min_g may be NULL for a transform-only launch. Factor pairs: 32x64 (DeepSeek-V3 moe_inter 2048), 56x64, 64x64,
+ * 64x80, 64x112 (7168), 64x128, 86..128 x 128; FQ_EUNSUPPORTED otherwise.
+ */
+int fq_kron_quant_grouped_mats_f16(const void* x, const void* left_g, const void* right_g, int64_t rows, int M, int N,
+                                   const int64_t* group_offsets, int n_groups, const float* sig_max_g, const float* sig_min_g,
+                                   int flags, void* q_out, void* scale_out, void* fq_out, void* y_out,
+                                   void* workspace, int64_t workspace_bytes, void* stream);
+int fq_kron_quant_grouped_mats_bf16(const void* x, const void* left_g, const void* right_g, int64_t rows, int M, int N,
+                                    const int64_t* group_offsets, int n_groups, const float* sig_max_g, const float* sig_min_g,
+                                    int flags, void* q_out, void* scale_out, void* fq_out, void* y_out,
+                                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
  * deploy.nn.RMSNorm (deploy/nn/normalization.py:16-23; the weight is folded into the next layer) in front of the
  * transform, in the same launch:  x <- fp16( fp32(x) * rsqrt( sum(x^2) / (M*N) + eps ) ),  then exactly
  * fq_kron_quant_f16 on that. Saves writing and re-reading the normalised activation (4 bytes per element).

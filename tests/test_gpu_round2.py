@@ -271,3 +271,48 @@ def test_row_shards_through_the_kernel_equal_the_unsharded_launch(ops):
             o = ops.kron_quant(x[a:b].contiguous(), L, R, [(0.98, 0.97)], P | NC0)
             qs.append(o.q[0]), ss.append(o.scale[0])
         assert torch.equal(torch.cat(qs), full.q[0]) and torch.equal(torch.cat(ss), full.scale[0])
+
+
+# ------------------------------------------------------------- per-expert matrices in ONE launch (round 3, config 5)
+@pytest.mark.parametrize("shape,dtype", [((32, 64), "f16"), ((64, 112), "f16"), ((32, 64), "bf16"), ((64, 64), "f16")])
+def test_grouped_launch_with_one_factor_pair_per_group(ops, shape, dtype):
+    """fq_kron_quant_grouped_mats_*: routed_w2_trans[i] (deepseekv3_utils.py:443-446) without the host loop. Every group's rows
+    equal what the plain launch gives with THAT group's matrices and clip pair, bit for bit (same kernel family, transform and
+    fake-quant outputs); empty groups, a 1-row group, 40 groups; the workspace is prepared once and reused."""
+    M, N = shape
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    rng = np.random.default_rng(M * N)
+    rows, G = 700, 40
+    x = torch.from_numpy((rng.standard_normal((rows, M * N)) * (1 + 4 * (rng.random((rows, 1)) < 0.1))).astype(np.float32)).to(td).cuda()
+    Lg = torch.from_numpy((rng.standard_normal((G, M, M)) / np.sqrt(M)).astype(np.float32)).to(td).cuda()
+    Rg = torch.from_numpy((rng.standard_normal((G, N, N)) / np.sqrt(N)).astype(np.float32)).to(td).cuda()
+    offs = _groups(rng, rows, G)
+    offs[5] = offs[4] + 1 if offs[4] + 1 <= offs[6] else offs[5]          # a 1-row group where the cuts allow it
+    smax = rng.uniform(0.3, 1.0, G).astype(np.float32)
+    smin = rng.uniform(0.3, 1.0, G).astype(np.float32)
+    for fl in (F | T | R16, P | T):
+        o = ops.kron_quant_grouped(x, Lg, Rg, dev(offs), dev(smax), dev(smin), fl)
+        o_again = ops.kron_quant_grouped(x, Lg, Rg, dev(offs), dev(smax), dev(smin), fl)     # cached images (FQ_WS_PREPARED)
+        for g in range(G):
+            a, b = int(offs[g]), int(offs[g + 1])
+            if b == a:
+                continue
+            one = ops.kron_quant(x[a:b], Lg[g].contiguous(), Rg[g].contiguous(), [(float(smax[g]), float(smin[g]))], F | T | R16 if fl & F else T)
+            assert torch.equal(o.y[a:b].view(torch.int16), one.y.view(torch.int16)), (g, "transform")
+            if fl & F:
+                assert torch.equal(o.fq[0][a:b].view(torch.int16), one.fq[0].view(torch.int16)), (g, "fake-quant")
+            else:   # packed: the quantiser stage on the launch's own transform (fp32 accumulators are quantised: compare digits
+                    # through the oracle on the fp16 transform with a tolerance for the unrounded accumulator)
+                lowp = "bf16" if dtype == "bf16" else "f16"
+                yv = O.bf16_from_bits(o.y[a:b].cpu().view(torch.int16).numpy().view(np.uint16)) if dtype == "bf16" else host(o.y[a:b]).astype(np.float32)
+                ref = O.quant_outputs(yv, float(smax[g]), float(smin[g]), lowp=lowp)
+                q = O.unpack_i4(host(o.q[0][a:b]))
+                assert np.mean(q != ref["q"]) <= 4e-3 and np.max(np.abs(q - ref["q"])) <= 1
+        assert torch.equal(o.y.view(torch.int16), o_again.y.view(torch.int16))
+    # transform only: no clip pairs needed at the C ABI (ops passes them anyway); and the reference fixture's per-expert branch
+    if shape == (32, 64) and dtype == "f16":
+        import os
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", "moe_grouped.npz"))
+        o3 = ops.kron_quant_grouped(dev(g["h"]), dev(g["L2e"]), dev(g["R2e"]), dev(g["offsets"]), dev(g["sig2e"][:, 0].copy()),
+                                    dev(g["sig2e"][:, 1].copy()), F | R16)
+        assert np.mean(host(o3.fq[0]) != g["fq2_indep"]) <= 2e-3
