@@ -64,6 +64,6 @@ def quant(x, clip_factor_a_max=1.0, clip_factor_a_min=1.0, input_clip_ratio=1.0)
     else:
         # :106: (max|x| / 7).to(fp16) * ratio in the same launch (FQ_RATIO_POST); the scales keep x's leading shape as the
         # reference's `torch.max(..., dim=-1)[0].unsqueeze(1)` gives it
-        o = ops.rowquant(x2.contiguous(), [(ops.scalar_f16(input_clip_ratio), 1.0)], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_RATIO_POST)
+        o = ops.rowquant(x2.contiguous(), [(float(input_clip_ratio), 1.0)], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_RATIO_POST)
         return PackedQuantizedTensor(o.q[0].reshape(x.shape[:-1] + (x.shape[-1] // 2,)), o.scale[0].reshape(x.shape[:-1]).unsqueeze(1))
     return PackedQuantizedTensor(o.q[0].reshape(x.shape[:-1] + (x.shape[-1] // 2,)), o.scale[0].reshape(-1, 1))

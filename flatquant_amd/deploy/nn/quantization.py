@@ -33,6 +33,9 @@ class Quantizer(torch.nn.Module):
         # (max|x| / 7).to(fp16) * ratio (quantization.py:30), one launch: FQ_RATIO_POST applies the factor to the scale
         # (ratio == 1: the product is the identity, and — like the reference, which has no zero guard on this branch — an all-zero
         # row keeps scale 0); the scales keep the shape of `torch.max(..., dim=-1)[0].unsqueeze(1)`
-        ratio = ops.scalar_f16(self.input_clip_ratio)   # (device semantics: the python scalar is read as fp16)
+        # (a PYTHON scalar keeps its fp32 value in torch's mul — unlike the 0-dim tensor of the lac branch; tools/scratch/
+        #  dbg_ratio.py: torch-ROCm's own kernel agrees with fp16(fp32(s) * fp32(r)) on 95-99 % of the rows and is one fp16 step
+        #  off on the rest, in a pattern no plain rounding reproduces; the CPU and the oracle give exactly this product)
+        ratio = float(self.input_clip_ratio)
         o = ops.rowquant(x.contiguous(), [(ratio, 1.0)], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_RATIO_POST)
         return PackedQuantizedTensor(o.q[0], o.scale[0].reshape(x.shape[:-1]).unsqueeze(1))

@@ -43,13 +43,6 @@ def sigmoid_pair_f16(clip_max, clip_min) -> Sig:
     return float(t[0]), float(t[1])
 
 
-def scalar_f16(v) -> float:
-    """A python scalar as a DEVICE kernel multiplies an fp16 tensor with it: torch casts the wrapped number to the result
-    dtype (fp16) before the kernel reads it (measured on MI355X, tools/scratch/dbg_ratio.py: `(max|x| / 7).half() * 0.9` equals
-    fp16(s * fp16(0.9)) on every row and fp16(s * 0.9f) on 572 of 600); the CPU keeps the full value."""
-    return float(torch.tensor(float(v), dtype=torch.float32).to(torch.float16))
-
-
 _SCALARS: "collections.OrderedDict" = collections.OrderedDict()
 
 

@@ -91,10 +91,9 @@ extern "C" {
 #define FQ_RATIO_POST     0x10000 /* fq_rowquant_f16 with FQ_QUANT_F16 | FQ_OUT_PACKED: the factor multiplies the SCALE, not the
                                    extrema — deploy.nn.Quantizer(input_clip_ratio) / functional.quant(input_clip_ratio),
                                    deploy/nn/quantization.py:30, deploy/functional/online_trans.py:106:
-                                   scale = fp16( fp16(max|x| / 7) * ratio ); sig_max carries the ratio — pass it ROUNDED TO
-                                   fp16, as torch's device kernels read a python scalar next to an fp16 tensor (the product
-                                   of two fp16 values is exact in fp32: one rounding); an all-zero row gets scale 0 like the
-                                   reference's (its digits are 0 either way) */
+                                   scale = fp16( fp32( fp16(max|x| / 7) * ratio ) ): the product in torch's float opmath, then
+                                   rounded to fp16 (what the CPU computes for an fp16 tensor times a python scalar); sig_max
+                                   carries the ratio; an all-zero row gets scale 0 like the reference's (digits 0 either way) */
 
 #define FQ_MAX_CLIPS 4
 

@@ -290,7 +290,7 @@ def test_grouped_launch_with_one_factor_pair_per_group(ops, shape, dtype):
     offs[5] = offs[4] + 1 if offs[4] + 1 <= offs[6] else offs[5]          # a 1-row group where the cuts allow it
     smax = rng.uniform(0.3, 1.0, G).astype(np.float32)
     smin = rng.uniform(0.3, 1.0, G).astype(np.float32)
-    for fl in (F | T | R16, P | T):
+    for fl in (F | T | R16, P | T | R16):
         o = ops.kron_quant_grouped(x, Lg, Rg, dev(offs), dev(smax), dev(smin), fl)
         o_again = ops.kron_quant_grouped(x, Lg, Rg, dev(offs), dev(smax), dev(smin), fl)     # cached images (FQ_WS_PREPARED)
         for g in range(G):
@@ -298,16 +298,22 @@ def test_grouped_launch_with_one_factor_pair_per_group(ops, shape, dtype):
             if b == a:
                 continue
             one = ops.kron_quant(x[a:b], Lg[g].contiguous(), Rg[g].contiguous(), [(float(smax[g]), float(smin[g]))], F | T | R16 if fl & F else T)
-            assert torch.equal(o.y[a:b].view(torch.int16), one.y.view(torch.int16)), (g, "transform")
+            if shape != (64, 64):   # (64 x 64: the plain launch runs fq_kron64, whose K-steps take the contraction index in
+                                    #  another order — equal up to the last bits of the accumulators, compared below)
+                assert torch.equal(o.y[a:b].view(torch.int16), one.y.view(torch.int16)), (g, "transform")
+            else:
+                assert float((o.y[a:b] != one.y).float().mean()) <= 5e-3
+            lowp = "bf16" if dtype == "bf16" else "f16"
+            yv = O.bf16_from_bits(o.y[a:b].cpu().view(torch.int16).numpy().view(np.uint16)) if dtype == "bf16" else host(o.y[a:b]).astype(np.float32)
+            ref = O.quant_outputs(yv, float(smax[g]), float(smin[g]), round_y_f16=True, lowp=lowp)   # the group's OWN clip pair
             if fl & F:
-                assert torch.equal(o.fq[0][a:b].view(torch.int16), one.fq[0].view(torch.int16)), (g, "fake-quant")
-            else:   # packed: the quantiser stage on the launch's own transform (fp32 accumulators are quantised: compare digits
-                    # through the oracle on the fp16 transform with a tolerance for the unrounded accumulator)
-                lowp = "bf16" if dtype == "bf16" else "f16"
-                yv = O.bf16_from_bits(o.y[a:b].cpu().view(torch.int16).numpy().view(np.uint16)) if dtype == "bf16" else host(o.y[a:b]).astype(np.float32)
-                ref = O.quant_outputs(yv, float(smax[g]), float(smin[g]), lowp=lowp)
-                q = O.unpack_i4(host(o.q[0][a:b]))
-                assert np.mean(q != ref["q"]) <= 4e-3 and np.max(np.abs(q - ref["q"])) <= 1
+                if shape != (64, 64):
+                    assert torch.equal(o.fq[0][a:b].view(torch.int16), one.fq[0].view(torch.int16)), (g, "fake-quant")
+                got = o.fq[0][a:b].cpu().view(torch.int16).numpy().view(np.uint16)
+                want = O.bf16_bits(ref["fq"]) if dtype == "bf16" else ref["fq"].view(np.uint16)
+                assert np.array_equal(got, want), (g, "fake-quant vs oracle")
+            else:   # packed: the quantiser stage on the launch's own (rounded) transform, bit for bit
+                assert np.array_equal(host(o.q[0][a:b]), ref["packed"]), (g, "packed")
         assert torch.equal(o.y.view(torch.int16), o_again.y.view(torch.int16))
     # transform only: no clip pairs needed at the C ABI (ops passes them anyway); and the reference fixture's per-expert branch
     if shape == (32, 64) and dtype == "f16":
