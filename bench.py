@@ -226,16 +226,16 @@ class C2(Workload):
 
     def floor_us(self, stream):
         """practical HBM floor: the same bytes (8 KB in, 2 KB + 2 B out per token) moved by a no-arithmetic kernel"""
-        from flatquant_amd import ops
+        from flatquant_amd import _probe   # (libfqprobe.so: measurement infrastructure, not the product library)
         if self.xs[0].dtype != torch.float16:
             return None
         for i in range(5):
-            ops.probe_stream_4096(self.xs[i % N_BUF], self.qs[i % N_BUF], self.ss[i % N_BUF])
+            _probe.probe_stream_4096(self.xs[i % N_BUF], self.qs[i % N_BUF], self.ss[i % N_BUF])
         torch.cuda.synchronize()
         f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         f0.record(stream)
         for i in range(50):
-            ops.probe_stream_4096(self.xs[i % N_BUF], self.qs[i % N_BUF], self.ss[i % N_BUF])
+            _probe.probe_stream_4096(self.xs[i % N_BUF], self.qs[i % N_BUF], self.ss[i % N_BUF])
         f1.record(stream)
         torch.cuda.synchronize()
         return f0.elapsed_time(f1) / 50 * 1e3
@@ -353,10 +353,8 @@ class C5(Workload):
         pop = 1.0 / torch.arange(1, E + 1, dtype=torch.float64) ** 0.8
         indices = torch.multinomial(pop[torch.randperm(E, generator=g)].expand(T, E), K, replacement=False, generator=g)
         counts = torch.bincount(indices.flatten(), minlength=E)
-        e0, e1 = sharding.shard_rows(E, world, rank)             # EP-style: this rank owns experts [e0, e1)
+        e0, e1, offs = sharding.shard_experts(counts, world, rank)   # EP-style: this rank owns experts [e0, e1) and their rows
         t0, t1 = sharding.shard_rows(T, world, rank)             # and a row block of the shared w1_trans stage
-        offs = torch.zeros(e1 - e0 + 1, dtype=torch.int64)
-        offs[1:] = torch.cumsum(counts[e0:e1], 0)
         rows2 = int(offs[-1])
         mats = bcast({"l1": make_matrix(64, 1, device), "r1": make_matrix(112, 2, device),
                       "l2": make_matrix(32, 3, device), "r2": make_matrix(64, 4, device)})

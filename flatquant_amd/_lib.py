@@ -85,8 +85,6 @@ SYMBOLS = {
     "fq_rowquant_f16": (_i, [_vp, _i64, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp]),
     "fq_sym_quant_f16": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     "fq_sym_dequant_i32_f16": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
-    "fq_probe_mfma_32x32x16_f16": (_i, [_vp, _vp, _vp, _vp, _vp]),
-    "fq_probe_stream_4096": (_i, [_vp, _i64, _vp, _vp, _i, _vp]),
     "fq_last_error": (ctypes.c_char_p, []),
     "fq_version": (_i, []),
 }

@@ -65,8 +65,6 @@ int fq_launch_sym_dequant(const int32_t* q, const f16* srow, const f16* scol, in
                           f16* x, int n_cu, hipStream_t stream);
 int fq_launch_kron64_trace(const f16* x, const f16* left, const f16* right, int64_t rows, const FqQuantOut& out,
                            unsigned long long* trace, int n_cu, hipStream_t stream);
-int fq_launch_probe_stream(const void* x, int64_t rows, void* q, void* s, int n_cu, int waves_per_simd,
-                           hipStream_t stream);
 
 namespace {
 
@@ -149,20 +147,6 @@ int fill_out(const char* what, FqQuantOut& o, const float* sig_max, const float*
     o.rms_eps = 0.0f;
     o.in2 = nullptr;
     return FQ_OK;
-}
-
-__global__ void fq_probe_mfma_kernel(const f16* __restrict__ A, const f16* __restrict__ B,
-                                     const float* __restrict__ C, float* __restrict__ D) {
-    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
-    f16x8 a, b;
-    f32x16 acc;
-    for (int j = 0; j < 8; ++j) {
-        a[j] = A[c * 16 + h * 8 + j];        // A[i = c][k = 8h + j]
-        b[j] = B[(h * 8 + j) * 32 + c];      // B[k = 8h + j][col = c]
-    }
-    for (int r = 0; r < 16; ++r) acc[r] = C[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + c];
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
-    for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + c] = acc[r];
 }
 
 }  // namespace
@@ -830,20 +814,6 @@ int fq_sym_dequant_i32_f16(const void* q, const void* scale_row, const void* sca
     return check_launch(fq_launch_sym_dequant((const int32_t*)q, (const f16*)scale_row, (const f16*)scale_col,
                                               rows, cols, (f16*)x, cu_count(), (hipStream_t)stream),
                         "fq_sym_dequant_i32_f16");
-}
-
-int fq_probe_mfma_32x32x16_f16(const void* A, const void* B, const void* C, void* D, void* stream) {
-    if (!A || !B || !C || !D) return fail(FQ_EINVAL, "fq_probe_mfma: NULL pointer");
-    hipLaunchKernelGGL(fq_probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const f16*)A,
-                       (const f16*)B, (const float*)C, (float*)D);
-    return check_launch((int)hipGetLastError(), "fq_probe_mfma");
-}
-
-int fq_probe_stream_4096(const void* x, int64_t rows, void* q, void* s, int waves_per_simd, void* stream) {
-    if (!x || !q || !s) return fail(FQ_EINVAL, "fq_probe_stream_4096: NULL pointer");
-    if (rows <= 0 || waves_per_simd < 1 || waves_per_simd > 8) return fail(FQ_EINVAL, "fq_probe_stream_4096: bad sizes");
-    return check_launch(fq_launch_probe_stream(x, rows, q, s, cu_count(), waves_per_simd, (hipStream_t)stream),
-                        "fq_probe_stream_4096");
 }
 
 /* debug only (not declared in fqhip.h): per-phase cycle accounting of the d=4096 packed kernel */

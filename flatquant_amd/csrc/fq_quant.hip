@@ -585,39 +585,6 @@ int fq_launch_sym_dequant(const int32_t* q, const f16* srow, const f16* scol, in
     return (int)hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Measurement aid (not on the product path): stream the SAME bytes as the fused d=4096 kernel — read 8 KB,
-// write 2 KB + 2 B per token — with perfectly coalesced 16-byte accesses, 8 loads in flight per lane and
-// no arithmetic beyond an OR-fold. Its duration is the practical HBM floor bench.py quotes next to the
-// 8 TB/s spec peak.
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fq_probe_stream_kernel(const u32x4* __restrict__ x, int64_t rows,
-                                                              u32x4* __restrict__ q, f16* __restrict__ s) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nw = (int64_t)gridDim.x * 4;
-    for (int64_t t = wave; t < rows; t += nw) {
-        const u32x4* p = x + t * 512 + lane;  // 512 x 16 B = 8 KB per token
-        u32x4 v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = __builtin_nontemporal_load(p + i * 64);
-        u32x4 a = (v[0] | v[1]) ^ (v[2] | v[3]), b = (v[4] | v[5]) ^ (v[6] | v[7]);
-        q[t * 128 + lane] = a;
-        q[t * 128 + 64 + lane] = b;
-        if (lane == 0) s[t] = (f16)1.0f;
-    }
-}
-
-int fq_launch_probe_stream(const void* x, int64_t rows, void* q, void* s, int n_cu, int waves_per_simd,
-                           hipStream_t stream) {
-    int64_t blocks = (int64_t)n_cu * waves_per_simd;
-    if (blocks > (rows + 3) / 4) blocks = (rows + 3) / 4;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(fq_probe_stream_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const u32x4*)x,
-                       rows, (u32x4*)q, (f16*)s);
-    return (int)hipGetLastError();
-}
-
 // x_up * act_fn(x_gate) alone (modeling_llama.py:277-278): 16 bytes per lane per tensor, grid-stride.
 __global__ __launch_bounds__(256) void fq_silu_mul_kernel(const f16* __restrict__ gate, const f16* __restrict__ up,
                                                           f16* __restrict__ y, int64_t chunks) {

@@ -889,20 +889,3 @@ def sym_dequant(q: torch.Tensor, scale_row: torch.Tensor, scale_col: torch.Tenso
         check(lib.fq_sym_dequant_i32_f16(_ptr(q), _ptr(scale_row), _ptr(scale_col), rows, cols, _ptr(x),
                                          _stream(q)))
     return x
-
-
-def probe_mfma(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor) -> torch.Tensor:
-    """D = A[32,16] @ B[16,32] + C[32,32] by one v_mfma_f32_32x32x16_f16 (oracle-calibration helper)."""
-    _chk(A, "A"), _chk(B, "B"), _chk(C, "C", torch.float32)
-    D = torch.empty((32, 32), dtype=torch.float32, device=A.device)
-    with torch.cuda.device(A.device):
-        check(lib.fq_probe_mfma_32x32x16_f16(_ptr(A), _ptr(B), _ptr(C), _ptr(D), _stream(A)))
-    return D
-
-
-def probe_stream_4096(x: torch.Tensor, q: torch.Tensor, s: torch.Tensor, waves_per_simd: int = 4) -> None:
-    """HBM-floor probe: move the bytes of the d=4096 fused kernel with no arithmetic (measurement aid)."""
-    _chk(x, "x"), _chk(q, "q", torch.uint8), _chk(s, "s")
-    rows = x.numel() // 4096
-    with torch.cuda.device(x.device):
-        check(lib.fq_probe_stream_4096(_ptr(x), rows, _ptr(q), _ptr(s), waves_per_simd, _stream(x)))

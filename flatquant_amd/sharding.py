@@ -19,6 +19,19 @@ def shard_rows(total_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
+def shard_experts(counts, world_size: int, rank: int):
+    """Expert-parallel partition of a routed-expert workload (the layout of deepseek_v3/model.py:657-660: rank r owns the
+    experts [r E / W, (r + 1) E / W)): -> (e0, e1, group_offsets) where ``group_offsets`` (int64, len e1 - e0 + 1, starts
+    at 0) are this rank's expert groups over ITS rows — the rows routed to its experts, expert-major. ``counts``: rows routed
+    to every expert (len E, any integer sequence / tensor). Every expert and every routed row belongs to exactly one rank."""
+    counts = [int(c) for c in counts]
+    e0, e1 = shard_rows(len(counts), world_size, rank)
+    offs = [0]
+    for c in counts[e0:e1]:
+        offs.append(offs[-1] + c)
+    return e0, e1, torch.tensor(offs, dtype=torch.int64)
+
+
 def broadcast_matrices(mats: Dict[str, torch.Tensor], src: int = 0, group=None) -> Dict[str, torch.Tensor]:
     """Broadcast every tensor of ``mats`` from ``src`` as ONE flat buffer (one collective for all layers: a few
     hundred KB to a few MB — latency-bound on xGMI, so fewer, larger messages)."""

@@ -454,15 +454,6 @@ int fq_sym_quant_f16(const void* x, const void* scale, int64_t rows, int cols, v
 int fq_sym_dequant_i32_f16(const void* q, const void* scale_row, const void* scale_col,
                            int64_t rows, int cols, void* x, void* stream);
 
-/* MFMA numerics probe (test infrastructure for the oracle's accumulation model):
- * D[32,32] = A[32,16] . B[16,32] + C with one v_mfma_f32_32x32x16_f16. All row-major, A/B fp16, C/D fp32. */
-int fq_probe_mfma_32x32x16_f16(const void* A, const void* B, const void* C, void* D, void* stream);
-
-/* HBM-floor probe (measurement aid for bench.py): streams exactly the bytes of the d=4096 fused kernel
- * (8192 B read, 2048 B + 2 B written per token) with fully coalesced 16-byte accesses and no arithmetic.
- * x [rows, 4096] fp16, q [rows, 2048] bytes, s [rows] fp16. waves_per_simd sizes the persistent grid. */
-int fq_probe_stream_4096(const void* x, int64_t rows, void* q, void* s, int waves_per_simd, void* stream);
-
 const char* fq_last_error(void);
 int fq_version(void);
 

@@ -24,6 +24,19 @@ def test_library_exports_every_symbol_of_the_header():
     assert _lib.lib.fq_version() >= 100
 
 
+def test_probe_kernels_live_in_their_own_library():
+    """include/fqprobe.h / libfqprobe.so: measurement infrastructure kept out of the product ABI (round-2 VERDICT, hygiene):
+    the product library exports no fq_probe_* symbol, the probe library exports exactly what its header declares."""
+    from flatquant_amd import _lib, _probe
+    header = open(os.path.join(ROOT, "include", "fqprobe.h")).read()
+    declared = set(re.findall(r"\b(fq_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_probe.SYMBOLS)
+    for name in declared:
+        assert hasattr(_probe.lib(), name)
+        assert not hasattr(_lib.lib, name)
+    assert not any(n.startswith("fq_probe") for n in _lib.SYMBOLS)
+
+
 def test_abi_argument_validation_without_gpu():
     """Error paths return codes + messages before any HIP call, so they are testable on a CPU-only box."""
     from flatquant_amd._lib import FQ_EINVAL, FQ_EUNSUPPORTED, lib
@@ -168,6 +181,33 @@ def test_kronecker_matmul_offline_dtypes_match_kron():
     assert torch.allclose(kronecker_matmul(x, L, R), x @ torch.kron(L, R), atol=1e-10)
     with pytest.raises(TypeError):
         kronecker_matmul(x.half(), L.half(), R.half())              # fp16 activations need the GPU kernel
+
+
+def test_bench_partitions_tile_rows_and_experts_exactly_once():
+    """bench.py C4 (16384 rows split over the ranks) and C5 (experts AND tokens split: sharding.shard_experts, the EP layout of
+    deepseek_v3/model.py:657-660): for world in {1, 2, 3, 4, 8} every row / expert / routed row is owned by exactly one
+    rank, expert groups stay whole, and the per-rank offsets describe exactly the rows of the rank's experts."""
+    from flatquant_amd.sharding import shard_experts, shard_rows
+    g = torch.Generator().manual_seed(5)
+    T, E, K = 16384, 256, 8
+    pop = 1.0 / torch.arange(1, E + 1, dtype=torch.float64) ** 0.8
+    indices = torch.multinomial(pop[torch.randperm(E, generator=g)].expand(T, E), K, replacement=False, generator=g)
+    counts = torch.bincount(indices.flatten(), minlength=E)
+    assert int(counts.sum()) == T * K
+    for world in (1, 2, 3, 4, 8):
+        rows_owner = torch.zeros(T, dtype=torch.int32)
+        experts_owner = torch.zeros(E, dtype=torch.int32)
+        routed = 0
+        for rank in range(world):
+            a, b = shard_rows(T, world, rank)
+            rows_owner[a:b] += 1
+            e0, e1, offs = shard_experts(counts, world, rank)
+            experts_owner[e0:e1] += 1
+            assert offs.dtype == torch.int64 and offs[0] == 0 and len(offs) == e1 - e0 + 1
+            assert torch.equal(offs[1:] - offs[:-1], counts[e0:e1])          # groups whole, in expert order
+            routed += int(offs[-1])
+        assert bool((rows_owner == 1).all()) and bool((experts_owner == 1).all()) and routed == T * K
+    assert shard_experts([3, 0, 5], 4, 3)[2].tolist() == [0]                # more ranks than experts: an empty share
 
 
 def test_shard_rows_partition():

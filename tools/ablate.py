@@ -6,7 +6,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from flatquant_amd import ops  # noqa: E402
+from flatquant_amd import _probe, ops  # noqa: E402
 from flatquant_amd._lib import (FQ_NO_CLAMP0, FQ_OUT_FAKEQUANT, FQ_OUT_PACKED, FQ_OUT_TRANSFORM,  # noqa: E402
                                 FQ_QUANT_F16, FQ_ROUND_Y_F16)
 
@@ -46,7 +46,7 @@ def main():
     qb = torch.empty(ROWS, D // 2, dtype=torch.uint8, device="cuda")
     sb = torch.empty(ROWS, dtype=torch.float16, device="cuda")
     for w in (2, 3, 4, 8):
-        cases[f"stream probe 8K in/2K out, {w} waves/SIMD"] = (lambda i, w=w: ops.probe_stream_4096(xs[i % NB], qb, sb, w))
+        cases[f"stream probe 8K in/2K out, {w} waves/SIMD"] = (lambda i, w=w: _probe.probe_stream_4096(xs[i % NB], qb, sb, w))
     for name, fn in cases.items():
         us = timeit(fn)
         print(f"{name:34s} {us:9.1f} us   {ROWS * D / us:12.0f} Melem/s")

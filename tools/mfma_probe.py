@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from flatquant_amd import ops  # noqa: E402
+from flatquant_amd import _probe, ops  # noqa: E402
 
 
 def model(A, B, C, groups, acc_first=True):
@@ -47,7 +47,7 @@ def main():
         A = (rng.randn(32, 16) * scale).astype(np.float16)
         B = (rng.randn(16, 32) * 2.0 ** rng.randint(-6, 7, size=(16, 32))).astype(np.float16)
         C = (rng.randn(32, 32) * (0 if trial % 2 else 4)).astype(np.float32)
-        D = ops.probe_mfma(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(),
+        D = _probe.probe_mfma(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(),
                            torch.from_numpy(C).cuda()).cpu().numpy()
         for k, g in models.items():
             hits[k] += int(np.sum(model(A, B, C, g).view(np.uint32) == D.view(np.uint32)))

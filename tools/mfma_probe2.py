@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from flatquant_amd import ops  # noqa: E402
+from flatquant_amd import _probe, ops  # noqa: E402
 
 
 def run(prods, c=0.0):
@@ -24,7 +24,7 @@ def run(prods, c=0.0):
         assert float(A[0, k]) == a and float(B[k, 0]) == b, (k, a, b)
     C = np.zeros((32, 32), np.float32)
     C[0, 0] = c
-    D = ops.probe_mfma(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), torch.from_numpy(C).cuda())
+    D = _probe.probe_mfma(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), torch.from_numpy(C).cuda())
     return float(D[0, 0].cpu())
 
 

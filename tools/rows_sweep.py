@@ -55,7 +55,7 @@ slope = (t1 - t0) / (r1 - r0)
 print(f"slope {slope * 1e3:.3f} ns/token = {10242 / slope / 1e6:.2f} TB/s streaming; "
       f"fixed part at 16384 rows: {dict(pts)[16384] - slope * 16384:.1f} us")
 
-from flatquant_amd import ops  # noqa: E402
+from flatquant_amd import _probe, ops  # noqa: E402
 
 print("no-arithmetic streaming kernel (same bytes):")
 for rows in (1024, 4096, 16384, 65536, 131072):
@@ -63,12 +63,12 @@ for rows in (1024, 4096, 16384, 65536, 131072):
     views = [(x[o:o + rows], q[o:o + rows], s[o:o + rows]) for o in
              [(i * rows) % (MAXR - rows + 1) for i in range(n)]]
     for v in views[:5]:
-        ops.probe_stream_4096(*v)
+        _probe.probe_stream_4096(*v)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for v in views:
-        ops.probe_stream_4096(*v)
+        _probe.probe_stream_4096(*v)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / n * 1e3
