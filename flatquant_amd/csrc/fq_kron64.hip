@@ -38,23 +38,9 @@ constexpr int FQ_K64_GROUPED = 0x20000;  // the grouped-launch instantiations (f
 constexpr int FRAG_BYTES = 16 * 64 * 16;  // 16 fragments x 64 lanes x 16 B
 constexpr int TOK_BYTES = KD * 2;         // 8192
 
-// Cache policy of the packed-output stores (16 B per lane, 2 per token): 0 plain (write-back: the lines stay dirty in the
-// XCD's L2 and are written back at the end-of-kernel release), 1 nt, 2 sc1, 3 sc0 sc1 (write-through: nothing left to
-// flush at the kernel boundary). A/B (tools/time_variants.py) in DESIGN 4.1.
-#ifndef FQ_K64_STORE_MODE
-#define FQ_K64_STORE_MODE 0
-#endif
-__device__ __forceinline__ void store_q16(uint8_t* p, u32x4 v) {
-#if FQ_K64_STORE_MODE == 1
-    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
-#elif FQ_K64_STORE_MODE == 2
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-#elif FQ_K64_STORE_MODE == 3
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-#else
-    *reinterpret_cast<u32x4*>(p) = v;
-#endif
-}
+// Packed-output stores (16 B per lane, 2 per token): plain write-back stores. Non-temporal, sc1 and write-through forms
+// measured 34.3-35.4 us against 34.3 plain (round 2, DESIGN log): nothing to gain, the knob is gone.
+__device__ __forceinline__ void store_q16(uint8_t* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 #ifndef FQ_K64_ABLATE
 #define FQ_K64_ABLATE 0  // measurement builds only: bit 0 = no MFMA, bit 1 = no quantiser arithmetic, bit 2 = no DMA
 #endif
