@@ -55,6 +55,8 @@ SYMBOLS = {
     "fq_kron_workspace_bytes": (_i64, [_i, _i]),
     "fq_kron_prepare_f16": (_i, [_vp, _vp, _i, _i, _vp, _i64, _vp]),
     "fq_rmsnorm_kron_quant_f16": (_i, [_vp, _f, _vp, _vp, _i64, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp]),
+    "fq_rmsnorm_kron_quant_ws_f16": (_i, [_vp, _f, _vp, _vp, _i64, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp, _i64,
+                                          _vp]),
     "fq_rmsnorm_f16": (_i, [_vp, _vp, _i64, _i, _f, _vp]),
     "fq_silu_mul_kron_quant_f16": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp,
                                         _i64, _vp]),

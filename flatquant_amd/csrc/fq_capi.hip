@@ -329,6 +329,36 @@ int fq_kron_quant_grouped_mats_bf16(const void* x, const void* left_g, const voi
                                         stream);
 }
 
+int fq_rmsnorm_kron_quant_ws_f16(const void* x, float eps, const void* left, const void* right, int64_t rows, int M, int N,
+                                 const float* sig_max, const float* sig_min, int n_clips, int flags,
+                                 void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+    const char* what = "fq_rmsnorm_kron_quant_ws_f16";
+    if (M == 64 && N == 64)   // (the 64 x 64 kernel gathers its fragments itself when the launch carries no image)
+        return fq_rmsnorm_kron_quant_f16(x, eps, left, right, rows, M, N, sig_max, sig_min, n_clips, flags & ~FQ_WS_PREPARED, q_out,
+                                         scale_out, fq_out, y_out, stream);
+    if (rows < 0 || M <= 0 || N <= 0 || (N & 1)) return fail(FQ_EINVAL, "%s: bad sizes", what);
+    if (!(eps >= 0.0f)) return fail(FQ_EINVAL, "%s: eps must be >= 0", what);
+    if ((flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_QUANT_F16)) != FQ_OUT_PACKED || (flags & (FQ_GROUP128 | FQ_RATIO_POST)))
+        return fail(FQ_EUNSUPPORTED, "%s: packed output only for pairs other than 64 x 64", what);
+    FqQuantOut o;
+    int rc = fill_out(what, o, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out, y_out);
+    if (rc != FQ_OK) return rc;
+    if (rows == 0) return FQ_OK;
+    if (!x || !left || !right) return fail(FQ_EINVAL, "%s: x/left/right is NULL", what);
+    FQ_NEED_ALIGN16(what, x, left, right, workspace);
+    o.rms_eps = eps;
+    rc = fq_launch_kron_generic(flags | FQ_IN_RMSNORM, (const f16*)x, (const f16*)left, (const f16*)right, nullptr, rows, M, N, o,
+                                workspace, workspace_bytes, cu_count(), (hipStream_t)stream);
+    if (rc == -1001)
+        return fail(FQ_EINVAL, "%s: workspace of %lld bytes required for M=%d N=%d (got %lld)", what,
+                    (long long)fq_kron_generic_workspace_bytes(M, N), M, N, (long long)(workspace ? workspace_bytes : 0));
+    if (rc == -1000)
+        return fail(FQ_EUNSUPPORTED, "%s: the RMSNorm is fused for 64 x 64 and the wave-per-token pairs (M <= 64, N in {64, 80, 112, 128}); "
+                    "run fq_rmsnorm_f16 first for (%d, %d)", what, M, N);
+    return check_launch(rc, what);
+}
+
 int fq_rmsnorm_kron_quant_f16(const void* x, float eps, const void* left, const void* right, int64_t rows, int M, int N,
                               const float* sig_max, const float* sig_min, int n_clips, int flags,
                               void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,

@@ -768,6 +768,10 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
 #undef FQ_FS
         return -1000;
     }
+    if (flags & FQ_IN_RMSNORM) {   // fused RMSNorm: the wave-per-token kernel (packed output) is the one that has it
+        if (!spec || no_wave || diag != nullptr) return -1000;
+        return fq_launch_kron_wave(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
+    }
     if (spec && !no_wave && !fq_measure_env("FQ_KRON_NO_WAVE")) {  // one wave per token where a token fits a wave (packed output only)
         rc = fq_launch_kron_wave(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;

@@ -70,7 +70,13 @@ __device__ __forceinline__ unsigned quant_row(const f32x16 (&Y)[NT][MT], int mo,
     return near;
 }
 
-template <int MT, int NT, int KS1, int W>
+// RMS (round 3): deploy.nn.RMSNorm in front of the transform in the same launch (deploy/nn/normalization.py:16-23,
+// modeling_llama.py:351-357 apply it in front of EVERY pair; round 2 fused it for 64 x 64 only). The wave owns the whole token
+// in its LDS buffer: one linear pass over it for the sum of squares (M * N / 512 conflict-free ds_read_b128 per lane, fp32 fmas
+// in four chains, wave all-reduce, v_rsq_f32), then every A fragment is scaled — fp32 product rounded to fp32 and to fp16, the
+// module's `(x.float() * rsqrt(...)).to(fp16)` — on its way into GEMM 1. No extra HBM traffic; the separate normalisation launch
+// moves 4 bytes per element.
+template <int MT, int NT, int KS1, int W, bool RMS = false>
 __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
                                                             int64_t rows, int64_t tpb, int M, FqQuantOut out) {
     typedef WaveGeom<MT, NT, KS1, W> G;
@@ -122,6 +128,28 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
         }
         first = false;
 
+        float rinv = 1.0f;
+        if (RMS) {
+            const uint4* tb = reinterpret_cast<const uint4*>(tokbuf);
+            float ss[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            constexpr int NCH = MT * 32 * CPR / 64;    // 16-byte chunks per lane (rows beyond M are zero: they add nothing)
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const f16x8 v = __builtin_bit_cast(f16x8, tb[i * 64 + lane]);   // (the swizzle permutes chunks inside a row: the sum does not care)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss[j & 3] = __builtin_fmaf((float)v[j], (float)v[j], ss[j & 3]);
+            }
+            const float tot = fq_wave_sum((ss[0] + ss[1]) + (ss[2] + ss[3]));
+            rinv = __builtin_amdgcn_rsqf(tot / (float)(M * N) + out.rms_eps);
+        }
+        auto norm8 = [&](f16x8 v) -> f16x8 {
+            if (RMS) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fq_mul_to<f16>((float)v[j], rinv);
+            }
+            return v;
+        };
+
         // ---- GEMM 1, K-step outermost: U[nt][mt] += X(mt, s) . R(s, nt) ----
         f32x16 U[NT][MT];
 #pragma unroll
@@ -132,7 +160,7 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
             const uint4* tb = reinterpret_cast<const uint4*>(tokbuf);
             f16x8 A[2][MT], B[2][NT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) A[0][mt] = __builtin_bit_cast(f16x8, tb[(mt * 32 + c) * CPR + (h ^ sw)]);
+            for (int mt = 0; mt < MT; ++mt) A[0][mt] = norm8(__builtin_bit_cast(f16x8, tb[(mt * 32 + c) * CPR + (h ^ sw)]));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) B[0][nt] = __builtin_bit_cast(f16x8, myr[(nt * KS1) * 64]);
 #pragma unroll
@@ -141,7 +169,7 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         A[(s + 1) & 1][mt] =
-                            __builtin_bit_cast(f16x8, tb[(mt * 32 + c) * CPR + (((s + 1) * 2 + h) ^ sw)]);
+                            norm8(__builtin_bit_cast(f16x8, tb[(mt * 32 + c) * CPR + (((s + 1) * 2 + h) ^ sw)]));
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         B[(s + 1) & 1][nt] = __builtin_bit_cast(f16x8, myr[(nt * KS1 + s + 1) * 64]);
@@ -307,7 +335,7 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
     }
 }
 
-template <int MT, int NT, int KS1, int W>
+template <int MT, int NT, int KS1, int W, bool RMS = false>
 int launch_wave(const f16* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
     typedef WaveGeom<MT, NT, KS1, W> G;
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
@@ -315,7 +343,7 @@ int launch_wave(const f16* x, const uint4* ws, int64_t rows, int M, const FqQuan
     if (blocks > n_cu) blocks = n_cu;  // one persistent workgroup per CU
     if (blocks < 1) blocks = 1;
     const int64_t tpb = (rows + blocks - 1) / blocks;
-    hipLaunchKernelGGL((fq_kron_wave_kernel<MT, NT, KS1, W>), dim3((unsigned)blocks), dim3(W * 64), 0, stream, x, ws, rows,
+    hipLaunchKernelGGL((fq_kron_wave_kernel<MT, NT, KS1, W, RMS>), dim3((unsigned)blocks), dim3(W * 64), 0, stream, x, ws, rows,
                        tpb, M, out);
     return (int)hipGetLastError();
 }
@@ -326,13 +354,16 @@ int launch_wave(const f16* x, const uint4* ws, int64_t rows, int M, const FqQuan
 // ws: fragment workspace already filled by fq_kron_prepare_kernel (rfrag [NT][KS1][64], lfrag [2MT][MT][64]).
 int fq_launch_kron_wave(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
                         const FqQuantOut& out, int n_cu, hipStream_t stream) {
-    if ((flags & FQ_CT_MASK) != FQ_OUT_PACKED || diag != nullptr) return -1000;
+    const bool rms = (flags & FQ_IN_RMSNORM) != 0;
+    if ((flags & FQ_CT_MASK & ~FQ_IN_RMSNORM) != FQ_OUT_PACKED || diag != nullptr) return -1000;
     if (M < 1 || M > 64 || (N & 15) || ((M * (N / 8)) & 63)) return -1000;
     if ((out.rt_flags & FQ_GROUP128) && (N != 64 || (M & 1))) return -1000;  // groups = pairs of 64-element rows
     const int MT = (M + 31) / 32, KS1 = N / 16;
     const uint4* w = reinterpret_cast<const uint4*>(ws);
-#define FQ_W(MT_, NT_, KS1_, W_) \
-    if (MT == MT_ && KS1 == KS1_) return launch_wave<MT_, NT_, KS1_, W_>(x, w, rows, M, out, n_cu, stream);
+#define FQ_W(MT_, NT_, KS1_, W_)                                                                          \
+    if (MT == MT_ && KS1 == KS1_)                                                                        \
+        return rms ? launch_wave<MT_, NT_, KS1_, W_, true>(x, w, rows, M, out, n_cu, stream)             \
+                   : launch_wave<MT_, NT_, KS1_, W_>(x, w, rows, M, out, n_cu, stream);
     FQ_W(2, 4, 8, 7)    // 64x128
     FQ_W(2, 4, 7, 8)    // 64x112
     FQ_W(2, 3, 5, 12)   // 64x80 (5120 = Qwen2.5-14B/32B hidden, in the reference's benchmark list: kernel_benchmark.py:234-246)

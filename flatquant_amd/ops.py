@@ -422,10 +422,30 @@ def rmsnorm(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
 
 def rmsnorm_kron_quant(x: torch.Tensor, eps: float, left: torch.Tensor, right: torch.Tensor,
                        sigs: Sequence[Sig] = ((1.0, 1.0),), flags: int = FQ_OUT_PACKED) -> FusedOutputs:
-    """RMSNorm + Kronecker transform + INT4 quantisation in one launch (fq_rmsnorm_kron_quant_f16) for the 64 x 64 factor
-    pair; any other pair runs rmsnorm() and kron_quant() one after the other (same arithmetic, one more round trip)."""
+    """RMSNorm + Kronecker transform + INT4 quantisation in one launch: fq_rmsnorm_kron_quant_f16 for the 64 x 64 factor
+    pair, fq_rmsnorm_kron_quant_ws_f16 (packed output) for the wave-per-token pairs (64 x 128, 64 x 112, 56 x 64, 64 x 80,
+    32 x 64); any other pair / output set runs rmsnorm() and kron_quant() one after the other (same arithmetic, one more
+    round trip)."""
     _chk(x, "x"), _chk(left, "left"), _chk(right, "right")
     M, N = left.shape[0], right.shape[0]
+    wave_pair = M <= 64 and N in (64, 80, 112, 128) and (M, N) != (64, 64) and (M * (N // 8)) % 64 == 0
+    if wave_pair and (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_QUANT_F16)) == FQ_OUT_PACKED:
+        d = M * N
+        if x.shape[-1] != d:
+            raise ValueError(f"x.shape[-1]={x.shape[-1]} != {M}*{N}")
+        rows = x.numel() // d
+        smax, smin, n = _sig_arrays(sigs)
+        o = _alloc_outputs(x, rows, d, n, flags, x.shape[:-1] + (d // 2,), x.shape)
+        if rows == 0:
+            return o
+        with torch.cuda.device(x.device):
+            ws, ws_bytes, prepared, key = _kron_workspace(x.device, M, N, left, right)
+            check(lib.fq_rmsnorm_kron_quant_ws_f16(_ptr(x), ctypes.c_float(eps), _ptr(left), _ptr(right), rows, M, N, smax, smin,
+                                                   n, flags | (FQ_WS_PREPARED if prepared else 0), _ptr_array(o.q),
+                                                   _ptr_array(o.scale), _ptr_array(o.fq), _ptr(o.y), _ptr(ws), ws_bytes, _stream(x)))
+            if key is not None and not prepared:
+                _kron_workspace_commit(key, ws, left, right)
+        return o
     if (M, N) != (64, 64) or (flags & (FQ_OUT_FAKEQUANT | FQ_QUANT_F16)):
         return kron_quant(rmsnorm(x, eps), left, right, sigs, flags)
     d = M * N

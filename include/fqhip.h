@@ -202,6 +202,14 @@ int fq_rmsnorm_kron_quant_f16(const void* x, float eps, const void* left, const 
                               void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
                               void* stream);
 
+/* The same for the other pairs of the supported models' hidden sizes (round 3): M <= 64 with N in {64, 80, 112, 128} — 64 x 128
+ * (Llama-2-70B, 8192), 64 x 112 (DeepSeek-V3, 7168), 56 x 64 (3584), 64 x 80 (5120), 32 x 64 — packed output, in the
+ * wave-per-token kernel; 64 x 64 as above. workspace / FQ_WS_PREPARED as in fq_kron_quant_f16. FQ_EUNSUPPORTED otherwise. */
+int fq_rmsnorm_kron_quant_ws_f16(const void* x, float eps, const void* left, const void* right, int64_t rows, int M, int N,
+                                 const float* sig_max, const float* sig_min, int n_clips, int flags,
+                                 void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,
+                                 void* workspace, int64_t workspace_bytes, void* stream);
+
 /* deploy.nn.RMSNorm alone: y[r] = fp16( fp32(x[r]) * rsqrt( sum(x[r]^2) / cols + eps ) ), cols % 8 == 0, cols <= 16384. */
 int fq_rmsnorm_f16(const void* x, void* y, int64_t rows, int cols, float eps, void* stream);
 

@@ -162,3 +162,38 @@ def test_fused_forward_shared_factors(ops, golden):
     other = deploy.nn.OnlineTrans(4096, trans="matmul", decompose=True, lac=True).cuda()
     with pytest.raises(RuntimeError):
         deploy.nn.fused_forward(x, [ts[0], other])
+
+
+@pytest.mark.parametrize("M,N", [(64, 128), (64, 112), (56, 64), (32, 64), (64, 80)])
+def test_fused_rmsnorm_on_the_wave_per_token_pairs(ops, M, N):
+    """Round 3: deploy.nn.RMSNorm fused in front of the transform for the pairs of the wave-per-token kernel (the hidden sizes
+    8192, 7168, 3584, 2048, 5120), packed output, one to three clip sets. Against the un-fused pair of launches (rmsnorm, then
+    kron_quant: the two kernels sum the squares in different orders, so the fp16 normalisation may differ in the last place on a
+    few elements) and against the oracle (RMSNorm restated from normalization.py:16-23, then the transform + quantiser): INT4
+    digits differ on <= 2e-3 of the elements by one step, scales within 1e-3."""
+    rng = np.random.default_rng(M * 1000 + N)
+    rows, d = 300, M * N
+    x = (rng.standard_normal((rows, d)) * rng.uniform(0.05, 20, (rows, 1))).astype(np.float16)
+    x[:, ::97] *= 8
+    x[3] = 0
+    L = (rng.standard_normal((M, M)) / np.sqrt(M)).astype(np.float16)
+    R = (rng.standard_normal((N, N)) / np.sqrt(N)).astype(np.float16)
+    sigs = [(0.982, 0.953), (0.7, 0.9), (1.0, 1.0)]
+    xd, Ld, Rd = dev(x), dev(L), dev(R)
+    fused = ops.rmsnorm_kron_quant(xd, 1e-5, Ld, Rd, sigs, P | NC0)
+    again = ops.rmsnorm_kron_quant(xd, 1e-5, Ld, Rd, sigs, P | NC0)                 # prepared workspace
+    two = ops.kron_quant(ops.rmsnorm(xd, 1e-5), Ld, Rd, sigs, P | NC0)
+    xn = O.rmsnorm(x, 1e-5)
+    for ci, (a, b) in enumerate(sigs):
+        assert torch.equal(fused.q[ci], again.q[ci]) and torch.equal(fused.scale[ci], again.scale[ci])
+        qf, q2 = O.unpack_i4(fused.q[ci].cpu().numpy()), O.unpack_i4(two.q[ci].cpu().numpy())
+        assert np.mean(qf != q2) <= 2e-3 and np.max(np.abs(qf - q2)) <= 1, (M, N, ci)
+        sf, s2 = fused.scale[ci].float().cpu().numpy(), two.scale[ci].float().cpu().numpy()
+        assert np.max(np.abs(sf - s2) / np.maximum(s2, 1e-30)) <= 1e-3
+        ref = O.kron_quant(xn, L, R, a, b, clamp0=False)
+        assert np.mean(qf != ref["q"]) <= 2e-3 and np.max(np.abs(qf - ref["q"].astype(np.int32))) <= 1
+    # a single-clip launch larger than one round of resident waves (the persistent loop, counted waits)
+    big = dev(np.tile(x, (40, 1)))
+    fb = ops.rmsnorm_kron_quant(big, 1e-5, Ld, Rd, [sigs[0]], P | NC0)
+    assert torch.equal(fb.q[0][:rows], fused.q[0]) and torch.equal(fb.q[0][-rows:], fused.q[0])
+    assert torch.equal(fb.scale[0][:rows], fused.scale[0])
