@@ -628,7 +628,9 @@ int launch_fast(int flags, const T* x, const uint4* ws, const T* diag, int64_t r
 int fq_launch_kron_wave(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
                         const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_wave.hip
 int fq_launch_kron_trio(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
-                        const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_trio.hip
+                        const FqQuantOut& out, int n_cu, hipStream_t stream);
+int fq_launch_kron_duo(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
+                       const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_trio.hip
 int fq_launch_kron_general(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
                            const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_general.hip (FQ_DT_BF16 in flags: bf16)
 
@@ -779,6 +781,10 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
     if (out.rt_flags & FQ_GROUP128) return -1000;  // per-128-element scales exist in the wave kernel (N = 64) only
     if (spec && !fq_measure_env("FQ_KRON_NO_TRIO")) {  // 64 < M <= 128, N = 128, packed output: three token groups one phase apart
         rc = fq_launch_kron_trio(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
+        if (rc != -1000) return rc;
+    }
+    if (spec && !fq_measure_env("FQ_KRON_NO_DUO")) {   // 96 < M <= 128, N = 224, packed output: two token groups per CU
+        rc = fq_launch_kron_duo(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }
 #ifdef FQ_MEASURE
