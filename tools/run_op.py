@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch ONE op of the library N times (for rocprofv3 --pmc / --kernel-trace runs): tools/run_op.py <op> [n]
-  ops: kron112 (112x128 packed), kron128x224, kron64x128, kron64x112, kron32x64g (grouped, 131072 rows), hadq14336, kvk / kvv (KV-cache quantisers)
+  ops: kron112 (112x128 packed), kron128x224, kron64x128, kron64x112, kron32x64g (grouped, 131072 rows), kron64fq (fake-quant output), hadq14336, kvk / kvv (KV-cache quantisers)
        (Hadamard 28x512 + Quantizer), rowq4096 / rowq14336 (deploy Quantizer), block32, block64"""
 import os
 import sys
@@ -28,7 +28,12 @@ def mat(k):
 
 
 P = FQ_OUT_PACKED | FQ_NO_CLAMP0
-if op.startswith("kron") and not op.endswith("g"):
+if op == "kron64fq":   # C1: the fake-quant contract at 64 x 64 (FlatQuantizedLinear._eval_forward)
+    from flatquant_amd._lib import FQ_OUT_FAKEQUANT, FQ_ROUND_Y_F16
+    xs = [act(16384, 4096) for _ in range(2)]
+    L, R = mat(64), mat(64)
+    fn = lambda i: ops.kron_quant(xs[i % 2], L, R, SIG, FQ_OUT_FAKEQUANT | FQ_ROUND_Y_F16)
+elif op.startswith("kron") and not op.endswith("g"):
     M, N = {"kron112": (112, 128), "kron128x224": (128, 224), "kron64x128": (64, 128), "kron64x112": (64, 112),
             "kron86": (86, 128), "kron32x64": (32, 64), "kron128x148": (128, 148), "kron144x192": (144, 192),
             "kron168x176": (168, 176), "kron96": (96, 96)}[op]
