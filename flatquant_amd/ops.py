@@ -568,12 +568,18 @@ def hadamard(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None,
 
 
 def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None, sig: Sig = (1.0, 1.0),
-                   scale: Optional[float] = None, up: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                   scale: Optional[float] = None, up: Optional[torch.Tensor] = None,
+                   fwht_route: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """Hadamard rotation fused with the deploy Quantizer (fq_hadamard_quant_f16): -> (q uint8 [..., n/2], scales fp16
-    [rows]). Bit-identical to rowquant(hadamard(x), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16) = the deploy
-    Quantizer's arithmetic (deploy/nn/quantization.py:15-29); shapes the fused kernels do
-    not cover take exactly that two-launch route. With ``up``: x is x_gate and the input of the rotation is
-    up * silu(x), formed in registers (fq_silu_mul_hadamard_quant_f16)."""
+    [rows]); the Quantizer's arithmetic is deploy/nn/quantization.py:15-29. Two routes:
+      * the register FWHT + K-factor kernel — bit-identical to rowquant(hadamard(x), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 |
+        FQ_SIG_F16); shapes the fused kernels do not cover take exactly that two-launch sequence;
+      * n = 14336 (K = 28) and n = 28672 (K = 28): the rotation runs as ONE Kronecker launch (112 x 128 / 112 x 256,
+        kron_quant_ex), 1.5x faster. It rounds the intermediate to fp16 at a different point: the rotated values agree with
+        the FWHT route within 2e-3 of the row maximum (the reference's own tolerance class, tests/test_gpu_hadamard.py), so
+        scales can differ by an fp16 step and digits by +-1 on ~1e-3 of elements — NOT bit for bit.
+    ``fwht_route=True`` forces the first route for callers that need hadamard() + Quantizer == hadamard_quant() exactly.
+    With ``up``: x is x_gate and the input of the rotation is up * silu(x), formed in registers."""
     _chk(x, "x")
     if up is not None:
         _chk(up, "up")
@@ -589,7 +595,7 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
     if scale is None:
         scale = float(1.0 / torch.tensor(n).sqrt())
     rows = x.numel() // n
-    kr = _hadamard_as_kron(K, n // K, hadK, x.device) if n % K == 0 else None
+    kr = _hadamard_as_kron(K, n // K, hadK, x.device) if (n % K == 0 and not fwht_route) else None
     if kr is not None and rows > 0:
         # K > 1 shapes whose rotation is a Kronecker pair the fused MFMA kernels take (14336 = 112 x 128, 28672 = 112 x 256):
         # one launch of the transform + Quantizer kernel instead of the register FWHT + K-factor kernel (1.5x faster; the

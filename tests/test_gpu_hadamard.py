@@ -148,6 +148,20 @@ def test_hadamard_as_kronecker_launch(ops, n, K):
     assert torch.equal(q2, q3) and torch.equal(s2, s3)
 
 
+@pytest.mark.parametrize("n,K", [(14336, 28), (28672, 28)])
+def test_fwht_route_switch_is_bit_identical_to_the_two_launch_sequence(ops, n, K):
+    """hadamard_quant(..., fwht_route=True): the register FWHT route on the shapes that default to the Kronecker launch —
+    exactly hadamard() followed by the deploy Quantizer's row quantiser (for callers that need that equality)."""
+    from flatquant_amd._lib import FQ_OUT_PACKED, FQ_QUANT_F16, FQ_SIG_F16
+    g = torch.Generator().manual_seed(n + 1)
+    x = torch.randn(37, n, generator=g).half().cuda()
+    hk = torch.from_numpy(hadk_matrix(K)).cuda()
+    sig = (0.91, 0.77)
+    q, s = ops.hadamard_quant(x, K, hk, sig, fwht_route=True)
+    two = ops.rowquant(ops.hadamard(x, K, hk), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)
+    assert torch.equal(q, two.q[0]) and torch.equal(s.reshape(-1), two.scale[0].reshape(-1))
+
+
 def test_online_trans_with_quantizer_argument(ops):
     import flatquant_amd.deploy as deploy
     t = deploy.nn.OnlineTrans(14336, trans="had").cuda()
