@@ -630,7 +630,9 @@ int fq_launch_kron_wave(int flags, const f16* x, const void* ws, const f16* diag
 int fq_launch_kron_trio(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
                         const FqQuantOut& out, int n_cu, hipStream_t stream);
 int fq_launch_kron_duo(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
-                       const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_trio.hip
+                       const FqQuantOut& out, int n_cu, hipStream_t stream);
+int fq_launch_kron_tall(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
+                        const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_trio.hip
 int fq_launch_kron_general(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
                            const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_general.hip (FQ_DT_BF16 in flags: bf16)
 
@@ -785,6 +787,10 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
     }
     if (spec && !fq_measure_env("FQ_KRON_NO_DUO")) {   // 96 < M <= 128, N = 224, packed output: two token groups per CU
         rc = fq_launch_kron_duo(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
+        if (rc != -1000) return rc;
+    }
+    if (spec && !fq_measure_env("FQ_KRON_NO_TALL")) {  // 64 < M <= 192, N = 64, packed output: a wave per ROW tile (172 x 64: Hadamard 11008)
+        rc = fq_launch_kron_tall(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }
 #ifdef FQ_MEASURE

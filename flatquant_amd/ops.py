@@ -293,21 +293,27 @@ def _sylvester(n: int) -> torch.Tensor:
     return h
 
 
+def _had_right_div(N: int) -> float:
+    """The +-1 Sylvester factor is stored as +-1/div (sqrt(N) up to a power of two: the fp16 intermediate keeps the
+    activation's range); the launch's post-scale carries the div back."""
+    return 16.0 if N >= 128 else 8.0
+
+
 def _hadamard_as_kron(K: int, P: int, hadK: Optional[torch.Tensor], device):
     """-> (left [M, M], right [N, N], post_scale) or None when the pair is not one the fused kernels take."""
     if K == 1 or hadK is None:
         return None
-    for N in (128, 256):
+    for N in (128, 256, 64):
         M = K * (P // N) if P % N == 0 else 0
-        # factor pairs with a packed-only instantiation of the workgroup-per-token kernel: M in (64, 128] with N = 128,
-        # M in (96, 128] with N = 256
-        if (N == 128 and 64 < M <= 128) or (N == 256 and 96 < M <= 128):
+        # factor pairs with a packed-only kernel of their own: M in (64, 128] with N = 128 (three token groups per CU),
+        # M in (96, 128] with N = 256 (workgroup per token), M in (64, 192] with N = 64 (a wave per row tile: 11008 = 172 x 64)
+        if (N == 128 and 64 < M <= 128) or (N == 256 and 96 < M <= 128) or (N == 64 and 64 < M <= 192):
             key = (hadK.data_ptr(), hadK._version, K, P, N, str(device))
             hit = _HAD_KRON.get(key)
             if hit is None:
                 # out = hadK @ x.view(K, P): Y = L^T U contracts L's FIRST index, so L = kron(hadK, H)^T = kron(hadK^T, H)
                 left = torch.kron(hadK.detach().float().cpu().T.contiguous(), _sylvester(P // N)).to(torch.float16).contiguous().to(device)
-                right = (_sylvester(N) / 16.0).to(torch.float16).contiguous().to(device)
+                right = (_sylvester(N) / _had_right_div(N)).to(torch.float16).contiguous().to(device)
                 hit = (left, right, hadK)
                 _HAD_KRON[key] = hit
                 if len(_HAD_KRON) > 32:
@@ -574,8 +580,9 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
     [rows]); the Quantizer's arithmetic is deploy/nn/quantization.py:15-29. Two routes:
       * the register FWHT + K-factor kernel — bit-identical to rowquant(hadamard(x), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 |
         FQ_SIG_F16); shapes the fused kernels do not cover take exactly that two-launch sequence;
-      * n = 14336 (K = 28) and n = 28672 (K = 28): the rotation runs as ONE Kronecker launch (112 x 128 / 112 x 256,
-        kron_quant_ex), 1.5x faster. It rounds the intermediate to fp16 at a different point: the rotated values agree with
+      * n = 14336 (K = 28), 28672 (K = 28), 11008 (K = 172) and every other n = K 2^p whose rotation is a factor pair with a
+        packed-only kernel of its own (_hadamard_as_kron): the rotation runs as ONE Kronecker launch (112 x 128 / 112 x 256 /
+        172 x 64, kron_quant_ex), 1.5-2x faster. It rounds the intermediate to fp16 at a different point: the rotated values agree with
         the FWHT route within 2e-3 of the row maximum (the reference's own tolerance class, tests/test_gpu_hadamard.py), so
         scales can differ by an fp16 step and digits by +-1 on ~1e-3 of elements — NOT bit for bit.
     ``fwht_route=True`` forces the first route for callers that need hadamard() + Quantizer == hadamard_quant() exactly.
@@ -601,7 +608,9 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
         # one launch of the transform + Quantizer kernel instead of the register FWHT + K-factor kernel (1.5x faster; the
         # two differ in where the intermediate is rounded to fp16, both within the 1e-3 tolerance of the reference)
         left, right, N = kr
-        o = kron_quant_ex(x.reshape(rows, n), left, right, 16.0 * scale, [sig],
+        if up is not None and N == 64:     # the SiLU.mul input is fused for the down_proj pairs of N >= 128 only
+            x, up = silu_mul(x, up), None
+        o = kron_quant_ex(x.reshape(rows, n), left, right, _had_right_div(N) * scale, [sig],
                           FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16 | FQ_ROUND_Y_F16,
                           up=None if up is None else up.reshape(rows, n))
         return o.q[0].reshape(x.shape[:-1] + (n // 2,)), o.scale[0]

@@ -233,10 +233,10 @@ int fq_silu_mul_kron_quant_f16(const void* gate, const void* up, const void* lef
  *               normalisation fp16 factor matrices cannot carry exactly. The online Hadamard rotation of n = K * P
  *               (flatquant/hadamard_utils.py:132-141, deploy/functional/online_trans.py:144-151) is such a product:
  *               x.view(K*P/N, N) -> left = kron(hadK, H_{P/N}) (+-1 entries), right = H_N * 2^-e, post_scale = 2^e / sqrt(n);
- *               that is how flatquant_amd runs n = 14336 (112 x 128) and 28672 (112 x 256) in front of the Quantizer.
+ *               that is how flatquant_amd runs n = 14336 (112 x 128), 28672 (112 x 256) and 11008 (172 x 64) in front of the Quantizer.
  *   up          NULL, or the `up` tensor of the down_proj input: x is then `gate` and the transform's input is
  *               fp16(up * fp16(silu(gate))) as in fq_silu_mul_kron_quant_f16.
- * Workgroup-per-token kernels only (M > 64 or N >= 128 shapes); FQ_EUNSUPPORTED otherwise. Other arguments as
+ * Workgroup-per-token kernels only (M > 64 or N >= 128 shapes; `up` for N >= 128 only); FQ_EUNSUPPORTED otherwise. Other arguments as
  * fq_kron_quant_f16 (no diag).
  */
 int fq_kron_quant_ex_f16(const void* x, const void* up, const void* left, const void* right, int64_t rows, int M, int N,

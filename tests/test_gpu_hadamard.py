@@ -118,7 +118,7 @@ def test_fused_hadamard_quantizer_equals_two_launches(ops, n, K):
         assert torch.equal(s.reshape(-1), two.scale[0].reshape(-1)), (n, K, sig)
 
 
-@pytest.mark.parametrize("n,K", [(14336, 28), (28672, 28)])
+@pytest.mark.parametrize("n,K", [(14336, 28), (28672, 28), (11008, 172), (8960, 140), (5120, 40), (6144, 12)])
 def test_hadamard_as_kronecker_launch(ops, n, K):
     """The K > 1 rotations that are Kronecker pairs of the fused kernels: (hadK (x) H_{P/N}) (x) H_N with the 1/sqrt(n) as an
     fp32 post-scale (fq_kron_quant_ex_f16). Transform within 1e-3 of the oracle's matmul_hadU restatement; Quantizer stage
@@ -130,8 +130,9 @@ def test_hadamard_as_kronecker_launch(ops, n, K):
     x[:, ::61] *= 9
     hk = torch.from_numpy(hadk_matrix(K))
     left, right, N = ops._hadamard_as_kron(K, n // K, hk.cuda(), torch.device("cuda", 0))
-    assert left.shape == (112, 112) and right.shape == (N, N)
-    scale = 16.0 / float(torch.tensor(float(n)).sqrt())
+    assert left.shape == (n // N, n // N) and right.shape == (N, N)
+    assert (n // N, N) == {14336: (112, 128), 28672: (112, 256), 11008: (172, 64), 8960: (140, 64), 5120: (80, 64), 6144: (96, 64)}[n]
+    scale = ops._had_right_div(N) / float(torch.tensor(float(n)).sqrt())
     sig = (0.83, 0.64)
     fl = FQ_QUANT_F16 | FQ_SIG_F16 | FQ_ROUND_Y_F16
     o = ops.kron_quant_ex(x.cuda(), left, right, scale, [sig], FQ_OUT_PACKED | FQ_OUT_TRANSFORM | fl)
@@ -148,7 +149,7 @@ def test_hadamard_as_kronecker_launch(ops, n, K):
     assert torch.equal(q2, q3) and torch.equal(s2, s3)
 
 
-@pytest.mark.parametrize("n,K", [(14336, 28), (28672, 28)])
+@pytest.mark.parametrize("n,K", [(14336, 28), (28672, 28), (11008, 172)])
 def test_fwht_route_switch_is_bit_identical_to_the_two_launch_sequence(ops, n, K):
     """hadamard_quant(..., fwht_route=True): the register FWHT route on the shapes that default to the Kronecker launch —
     exactly hadamard() followed by the deploy Quantizer's row quantiser (for callers that need that equality)."""

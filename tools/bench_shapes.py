@@ -109,6 +109,15 @@ def main():
     us = timeit(lambda i: ops.hadamard_quant(gs[i % 2], K, hk, sig[0]))
     line("hadamard + quantizer, one launch", "n=14336 (K=28)", us, 2.5 * 14336 + 2, 14336)
     del gs, up
+    for n in (11008, 8960):   # Llama-2-7B / Qwen2.5-1.5B ffn: K = 172 / 140, the rotation as a 172 x 64 / 140 x 64 Kronecker launch
+        gs = [torch.randn(ROWS, n, generator=g, device="cuda", dtype=torch.float16) for _ in range(2)]
+        hk, K = get_hadK(n)
+        hk = hk.half().cuda()
+        us = timeit(lambda i: ops.hadamard_quant(gs[i % 2], K, hk, sig[0]))
+        line("hadamard + quantizer, one launch", f"n={n} (K={K})", us, 2.5 * n + 2, n)
+        us = timeit(lambda i: ops.hadamard_quant(gs[i % 2], K, hk, sig[0], fwht_route=True))
+        line("hadamard + quantizer, FWHT route", f"n={n} (K={K})", us, 2.5 * n + 2, n)
+        del gs
     ks = [torch.randn(ROWS * 8, 128, generator=g, device="cuda", dtype=torch.float16) for _ in range(NB)]
     T = (torch.randn(128, 128, generator=g, device="cuda") / 128 ** 0.5).half()
     us = timeit(lambda i: ops.kv_quant(ks[i % NB], T))

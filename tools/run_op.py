@@ -48,11 +48,13 @@ elif op == "kron32x64g":
     offs = torch.linspace(0, rows, G + 1, device=dev).long()
     sm = torch.full((G,), 0.98, device=dev)
     fn = lambda i: ops.kron_quant_grouped(xs[i % 2], L, R, offs, sm, sm, P)
-elif op == "hadq14336":
+elif op in ("hadq14336", "hadq11008", "hadq11008fwht"):
     from flatquant_amd.flatquant.hadamard_utils import get_hadK
-    hk = get_hadK(14336)[0].half().to(dev).contiguous()
-    xs = [act(16384, 14336) for _ in range(2)]
-    fn = lambda i: ops.hadamard_quant(xs[i % 2], 28, hk, SIG[0])
+    n = int(op[4:9])
+    hk, K = get_hadK(n)
+    hk = hk.half().to(dev).contiguous()
+    xs = [act(16384, n) for _ in range(2)]
+    fn = lambda i: ops.hadamard_quant(xs[i % 2], K, hk, SIG[0], fwht_route=op.endswith("fwht"))
 elif op.startswith("rowq"):
     d = int(op[4:])
     xs = [act(16384, d) for _ in range(2)]
