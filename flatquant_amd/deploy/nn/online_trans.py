@@ -1,6 +1,7 @@
 """Counterpart of deploy/nn/online_trans.py."""
 import torch
 
+from ... import ops
 from .. import functional
 from ...flatquant.function_utils import get_decompose_dim  # noqa: F401
 
@@ -37,6 +38,7 @@ class OnlineTrans(torch.nn.Module):
             else:
                 self.register_buffer("right_matrix", torch.randn([trans_dim, trans_dim], dtype=torch.float16))
         self.lac = lac
+        ops.invalidate_on_load(self)   # matrices / clip factors loaded later: no stale fragment images or host scalars
         self.register_buffer("clip_factor_a_max", torch.tensor(1.0))
         self.register_buffer("clip_factor_a_min", torch.tensor(1.0))
 

@@ -18,6 +18,7 @@ class Quantizer(torch.nn.Module):
         super().__init__()
         self.input_clip_ratio = input_clip_ratio
         self.lac = lac
+        ops.invalidate_on_load(self)
         self.register_buffer("clip_factor_a_max", torch.tensor(4.0))
         self.register_buffer("clip_factor_a_min", torch.tensor(4.0))
 

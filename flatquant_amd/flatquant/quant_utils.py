@@ -28,6 +28,7 @@ class ActivationQuantizer(torch.nn.Module):
 
     def __init__(self, bits, sym=False, lac=False, groupsize=-1, clip_ratio=None):
         super().__init__()
+        ops.invalidate_on_load(self)   # clip factors loaded later: no stale host copies of their sigmoids
         self.bits = bits
         self.q_max, self.q_min = get_qmin_qmax(bits, sym)
         self.sym = sym

@@ -68,6 +68,7 @@ class _DecomposeTransBase(nn.Module):
             self.diag_scale = nn.Parameter(diag_init_para, requires_grad=False)
         self._eval_mode = True
         self._f16 = _Fp16Cache()
+        ops.invalidate_on_load(self)
 
     def to_eval_mode(self):
         self._eval_mode = True
@@ -116,6 +117,7 @@ class _SingleTransBase(nn.Module):
         self.matrix_inv_t = nn.Parameter(get_inverse(m).T.contiguous(), requires_grad=False)
         self._eval_mode = True
         self._f16 = _Fp16Cache()
+        ops.invalidate_on_load(self)
 
     def to_eval_mode(self):
         self._eval_mode = True

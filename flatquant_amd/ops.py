@@ -60,6 +60,13 @@ def invalidate_caches() -> None:
     _Fp16Cache.clear_all()
 
 
+def invalidate_on_load(module: torch.nn.Module) -> None:
+    """Mirror modules call this in their constructor: after ``load_state_dict`` (whose ``copy_`` goes through ``param.data``
+    semantics for assign=True / ``.data`` loaders and may recycle addresses) every derived cache is dropped, so a module never
+    runs on fragments or scalars of the matrices it held before the load."""
+    module.register_load_state_dict_post_hook(lambda mod, incompatible: invalidate_caches())
+
+
 def host_scalar(v) -> float:
     """float(v) for a Python number or a one-element tensor, WITHOUT a device synchronisation per call: a CUDA
     scalar (the deploy modules keep clip_factor_a_max/min as buffers; the reference's loader turns them into Python

@@ -439,3 +439,17 @@ def test_misaligned_tensor_pointers_are_refused():
     assert lib.fq_rowquant_f16(odd, 4, 4096, f4, f4, 1, 1, a4, a4, a4, None) == FQ_EINVAL
     assert lib.fq_hadamard_f16(odd, vp, 4, 4096, 1, None, ctypes.c_float(1.0), None) == FQ_EINVAL
     assert lib.fq_block_quant_f16(vp, odd, 4, 128, 32, 1, f4, f4, 1, 1, a4, a4, a4, None, None) == FQ_EINVAL
+
+
+def test_load_state_dict_invalidates_the_derived_caches():
+    """the mirrors key their caches on (data_ptr, _version); a checkpoint load must drop them — every
+    mirror module registers ops.invalidate_on_load in its constructor."""
+    import torch
+    from flatquant_amd import ops
+    from flatquant_amd.flatquant import ActivationQuantizer, InvDecomposeTransMatrix
+    import flatquant_amd.deploy as deploy
+    for mod in (InvDecomposeTransMatrix(8, 8), ActivationQuantizer(4, sym=True, lac=True), deploy.nn.Quantizer(lac=True),
+                deploy.nn.OnlineTrans(64, trans="matmul")):
+        ops._SCALARS[("sentinel",)] = (None, 1.0)
+        mod.load_state_dict(mod.state_dict())
+        assert ("sentinel",) not in ops._SCALARS, type(mod).__name__
