@@ -161,8 +161,13 @@ static int kron_dispatch(const char* what, const FqQuantOut& o, int flags, const
     FQ_NEED_ALIGN16(what, x, left, right, diag, workspace);
     const int n_cu = cu_count();
     const bool special = o.group_offsets != nullptr || (o.rt_flags & FQ_GROUP128);  // only the fused MFMA kernels take these
-    if ((o.rt_flags & FQ_GROUP128) && ((M * N) % 128 != 0 || (flags & (FQ_QUANT_F16 | FQ_OUT_FAKEQUANT)) || o.n_clips != 1))
-        return fail(FQ_EUNSUPPORTED, "%s: FQ_GROUP128 is fused for packed output, one clip set, fp32 arithmetic, M*N %% 128 == 0", what);
+    // FQ_GROUP128: packed-only fp32-arithmetic launches at N = 64 quantise the fp32 accumulator (wave-per-token kernels); every
+    // other output set / arithmetic / pair runs the group epilogue of the workgroup-per-token kernel, which quantises the
+    // transformed activation ROUNDED to the activation dtype — what ActivationQuantizer(groupsize=128) is handed (path A)
+    if ((o.rt_flags & FQ_GROUP128) && ((M * N) % 128 != 0 || o.n_clips != 1 ||
+                                       ((flags & (FQ_QUANT_F16 | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM)) && !(flags & FQ_ROUND_Y_F16))))
+        return fail(FQ_EUNSUPPORTED, "%s: FQ_GROUP128 needs one clip set, M*N %% 128 == 0, and FQ_ROUND_Y_F16 for any output set other "
+                    "than packed with fp32 arithmetic", what);
     if (M == 64 && N == 64) {
         // the workspace is OPTIONAL at 64 x 64: with one (>= 16 KB) the kernel reads the fragment image from it (written here
         // unless FQ_WS_PREPARED says it is there already), without one it gathers the fragments from the matrices itself
@@ -178,7 +183,8 @@ static int kron_dispatch(const char* what, const FqQuantOut& o, int flags, const
                               rows, o, n_cu, (hipStream_t)stream, prep);
         if (rc != -1000) return check_launch(rc, what);
         if (dt) return fail(FQ_EUNSUPPORTED, "%s: output set 0x%x has no bf16 kernel at 64 x 64", what, flags & ~dt);
-        if (o.rt_flags & FQ_GROUP128) return fail(FQ_EUNSUPPORTED, "%s: FQ_GROUP128 needs the packed-only output set at 64 x 64", what);
+        if ((o.rt_flags & FQ_GROUP128) && !(flags & FQ_ROUND_Y_F16))
+            return fail(FQ_EUNSUPPORTED, "%s: FQ_GROUP128 at 64 x 64 needs the packed-only output set or FQ_ROUND_Y_F16", what);
         if (prep) {   // the second half of the 64 x 64 workspace is the other kernel family's image
             workspace = static_cast<unsigned char*>(workspace) + FQ_K64_IMAGE_BYTES;
             workspace_bytes -= FQ_K64_IMAGE_BYTES;
@@ -242,7 +248,7 @@ static int kron_quant_grouped_impl(const char* what, int dt, const void* x, cons
     if (rows < 0 || M <= 0 || N <= 0) return fail(FQ_EINVAL, "%s: bad sizes rows=%lld M=%d N=%d", what, (long long)rows, M, N);
     if (N & 1) return fail(FQ_EINVAL, "%s: N=%d must be even (two INT4 per byte)", what, N);
     if (n_groups < 1) return fail(FQ_EINVAL, "%s: n_groups=%d", what, n_groups);
-    if ((flags & FQ_QUANT_F16) && (flags & (FQ_OUT_PACKED | FQ_GROUP128)))
+    if ((flags & FQ_QUANT_F16) && (flags & FQ_OUT_PACKED))
         return fail(FQ_EUNSUPPORTED, "%s: the low-precision quantiser arithmetic is offered for the fake-quant output only", what);
     const bool quant = (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) != 0;
     const float one = 1.0f;  // fill_out wants a host clip pair; the kernels read the per-group device arrays instead

@@ -437,6 +437,38 @@ __device__ __forceinline__ f16x2 fq_pk_min(f16x2 a, f16x2 b) {
 }
 #endif
 
+// Running extrema of 16-byte chunks of an activation row (row quantisers; the group-128 epilogue of the Kronecker kernels).
+template <typename T> struct RowExtrema;
+template <> struct RowExtrema<f16> {
+    f16x2 pmax = {(f16)-INFINITY, (f16)-INFINITY}, pmin = {(f16)INFINITY, (f16)INFINITY};
+    __device__ __forceinline__ void take(const f16x8& v) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const f16x2 pr = {v[e], v[e + 1]};
+            pmax = fq_pk_max(pmax, pr);
+            pmin = fq_pk_min(pmin, pr);
+        }
+    }
+    __device__ __forceinline__ float vmax() const { return fmaxf((float)pmax[0], (float)pmax[1]); }
+    __device__ __forceinline__ float vmin() const { return fminf((float)pmin[0], (float)pmin[1]); }
+};
+template <> struct RowExtrema<bf16> {
+    float mx = -INFINITY, mn = INFINITY;
+    __device__ __forceinline__ void take(const bf16x8& v) {
+        const u32x4 w = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float lo, hi;
+            fq_bf16_pair(w[k], lo, hi);
+            mx = fq_max3(mx, lo, hi);
+            mn = fq_min3(mn, lo, hi);
+        }
+    }
+    __device__ __forceinline__ float vmax() const { return mx; }
+    __device__ __forceinline__ float vmin() const { return mn; }
+};
+
+
 // Two elements at once: v_pk_mul_f32 / v_pk_add_f32 process a register pair per instruction on gfx950.
 // Returns the clamped integer-valued pair; dmax accumulates max |t - rint(t)| (see fq_qfast).
 __device__ __forceinline__ f32x2 fq_qfast2(f32x2 y, f32x2 inv2, float& dmax) {

@@ -362,6 +362,105 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                     for (int r = 0; r < 16; ++r) Y[t][mo][r] = (float)(T)Y[t][mo][r];
         }
 
+        // ---- FQ_GROUP128 (ActivationQuantizer(groupsize=128), vllm_custom/.../fake_quant_utils.py:72-78; round 3): one scale per
+        // 128 CONSECUTIVE elements of the transformed token. The reference hands the quantiser the transformed tensor, i.e. Y
+        // rounded to the activation dtype (path A, FQ_ROUND_Y_F16 required): the token is staged in xs in its own layout — as
+        // for the transform output — and a second pass walks it in linear order: a thread owns a 16-byte chunk, a group is 16
+        // consecutive chunks = 16 consecutive lanes, extrema by xor butterflies inside them, every lane its group's scale,
+        // outputs written straight to HBM, fully coalesced. (Before: transform launch + row-quantiser launch, 8 d bytes of HBM
+        // traffic per token instead of 4 d.)
+        if (CTF < 0 && !SILU && !ODD && (out.rt_flags & FQ_GROUP128)) {
+            __syncthreads();   // every wave has finished reading xs (GEMM 1)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int nt = wave + WAVES * t, n0 = h * NT * 16 + nt * 16;
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo)
+                    if (nt < NT && n0 < N && (mo * 32 + c) < M) {
+                        X8 v0, v1;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            v0[e] = (T)Y[t][mo][e];
+                            v1[e] = (T)Y[t][mo][8 + e];
+                        }
+                        uint4* sp = xs + (mo * 32 + c) * PITCH + (n0 >> 3);
+                        sp[0] = __builtin_bit_cast(uint4, v0);
+                        sp[1] = __builtin_bit_cast(uint4, v1);
+                    }
+            }
+            __syncthreads();
+            float sig_max = out.sig_max[0], sig_min = out.sig_min[0];
+            fq_token_sigs(out, 0, tok, gcur, sig_max, sig_min);
+            for (int q = tid; q < n_chunks; q += THREADS) {   // (n_chunks % 16 == 0: a group never straddles the loop stride)
+                const int row = q / cpr, ch = q - row * cpr;
+                const X8 v = __builtin_bit_cast(X8, xs[row * PITCH + ch]);
+                RowExtrema<T> ext;
+                ext.take(v);
+                float gmax = ext.vmax(), gmin = ext.vmin();
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+                    gmax = fmaxf(gmax, __shfl_xor(gmax, m));
+                    gmin = fminf(gmin, __shfl_xor(gmin, m));
+                }
+                float scale;
+                if (flags & FQ_QUANT_F16) scale = fq_token_scale<FQ_QUANT_F16, T>(gmax, gmin, sig_max, sig_min, flags);
+                else scale = fq_token_scale<0, T>(gmax, gmin, sig_max, sig_min, flags);
+                const float inv = fq_fast_inv(scale);
+                // the fake-quant contract alone, fp32 arithmetic (FlatQuantizedLinear / the vLLM quantiser): the single-width asm
+                // block fq_fake8 — wave-uniform route (the clamped form is right for every lane; one exactness vote per chunk row)
+                bool done = false;
+                if ((flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_QUANT_F16)) == FQ_OUT_FAKEQUANT && !__any(!fq_magic_ok(gmax, gmin, inv))) {
+                    float dmax = 0.0f;
+                    u32x4 o;
+                    if (__any(fq_needs_clamp(gmax, gmin, inv)))
+                        o = fq_fake8<true, T>((float)v[0], (float)v[1], (float)v[2], (float)v[3], (float)v[4], (float)v[5], (float)v[6], (float)v[7], inv, scale, dmax);
+                    else
+                        o = fq_fake8<false, T>((float)v[0], (float)v[1], (float)v[2], (float)v[3], (float)v[4], (float)v[5], (float)v[6], (float)v[7], inv, scale, dmax);
+                    if (!fq_wave_needs_exact(dmax)) {
+                        __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(reinterpret_cast<T*>(out.fq[0]) + tok * d) + q);
+                        done = true;
+                    }
+                }
+                int dq[8];   // the digits
+                if (done) {
+                } else if (flags & FQ_QUANT_F16) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dq[e] = fq_quant1_h(v[e], (T)scale);
+                } else {
+                    float dmax = 0.0f, r[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) r[e] = fq_qfast((float)v[e], inv, dmax);
+                    if (fq_wave_needs_exact(dmax)) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) r[e] = fq_qexact((float)v[e], scale);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dq[e] = (int)r[e];
+                }
+                if (flags & FQ_OUT_TRANSFORM)
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(reinterpret_cast<T*>(out.y) + tok * d) + q);
+                if ((flags & FQ_OUT_FAKEQUANT) && !done) {
+                    X8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (flags & FQ_QUANT_F16) o[e] = fq_dequant1<FQ_QUANT_F16, T>(dq[e], scale);
+                        else o[e] = fq_fake<T>(scale, (float)dq[e]);
+                    }
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(reinterpret_cast<T*>(out.fq[0]) + tok * d) + q);
+                }
+                if (flags & FQ_OUT_PACKED) {
+                    uint32_t pk = 0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pk |= (uint32_t)(dq[e] & 15) << (4 * e);
+                    reinterpret_cast<uint32_t*>(out.q[0] + tok * (d >> 1))[q] = pk;
+                }
+                if ((flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) && !(q & 15) && out.scale[0] != nullptr)
+                    reinterpret_cast<T*>(out.scale[0])[tok * (d >> 7) + (q >> 4)] = (T)scale;
+            }
+            __syncthreads();   // the stage is read: the next token may overwrite it
+            continue;
+        }
+
         // ---- per-token extrema over the VALID entries (padding rows/columns are excluded) ----
 #pragma unroll
         for (int t = 0; t < (H16 ? 0 : TPW); ++t) {
@@ -699,7 +798,8 @@ static int launch_kron_generic_bf16(int flags, const bf16* x, const bf16* left, 
                                     int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                                     int64_t workspace_bytes, int n_cu, hipStream_t stream) {
     if (flags & (FQ_IN_SILU_MUL | FQ_IN_RMSNORM)) return -1000;
-    if (out.post_scale != 0.0f || (out.rt_flags & FQ_GROUP128)) return -1000;
+    if (out.post_scale != 0.0f) return -1000;
+    if ((out.rt_flags & FQ_GROUP128) && !(flags & FQ_ROUND_Y_F16)) return -1000;  // (the group epilogue quantises the rounded transform)
     flags &= ~FQ_NO_WAVE_KERNEL;
     if (!workspace || workspace_bytes < fq_kron_generic_workspace_bytes(M, N)) return -1001;
     const int MT = tiles32(M), NT = tiles32(N), KS1 = (N + 15) / 16;
@@ -722,6 +822,7 @@ static int launch_kron_generic_bf16(int flags, const bf16* x, const bf16* left, 
         FQ_FB(5, 6, 12, 8, 1) FQ_FB(6, 6, 11, 8, 1)
 #undef FQ_FB
     }
+    if (out.rt_flags & FQ_GROUP128) return -1000;   // (the general kernel has no group epilogue)
     return fq_launch_kron_general(flags | FQ_DT_BF16, (const f16*)x, ws, (const f16*)diag, rows, M, N, out, n_cu, stream);
 }
 
@@ -780,16 +881,19 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
         rc = fq_launch_kron_wave(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }
-    if (out.rt_flags & FQ_GROUP128) return -1000;  // per-128-element scales exist in the wave kernel (N = 64) only
-    if (spec && !fq_measure_env("FQ_KRON_NO_TRIO")) {  // 64 < M <= 128, N = 128, packed output: three token groups one phase apart
+    // per-128-element scales: the wave kernel above (N = 64, packed, fp32 accumulator) or the group epilogue of the
+    // workgroup-per-token kernel's all-output-sets instantiations (the transform rounded to the activation dtype)
+    const bool g128 = (out.rt_flags & FQ_GROUP128) != 0;
+    if (g128 && (!(flags & FQ_ROUND_Y_F16) || !spec)) return -1000;
+    if (!g128 && spec && !fq_measure_env("FQ_KRON_NO_TRIO")) {  // 64 < M <= 128, N = 128, packed output: three token groups one phase apart
         rc = fq_launch_kron_trio(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }
-    if (spec && !fq_measure_env("FQ_KRON_NO_DUO")) {   // 96 < M <= 128, N = 224, packed output: two token groups per CU
+    if (!g128 && spec && !fq_measure_env("FQ_KRON_NO_DUO")) {   // 96 < M <= 128, N = 224, packed output: two token groups per CU
         rc = fq_launch_kron_duo(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }
-    if (spec && !fq_measure_env("FQ_KRON_NO_TALL")) {  // 64 < M <= 192, N = 64, packed output: a wave per ROW tile (172 x 64: Hadamard 11008)
+    if (!g128 && spec && !fq_measure_env("FQ_KRON_NO_TALL")) {  // 64 < M <= 192, N = 64, packed output: a wave per ROW tile (172 x 64: Hadamard 11008)
         rc = fq_launch_kron_tall(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }
@@ -798,15 +902,15 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
 #endif
     // N % 16 != 0 in the workgroup-per-token kernel: the packed-only launch of 96 < M <= 128, N = 148 (18944 = 128 x 148,
     // Qwen2.5-7B ffn); its other output sets, diag and every other such pair: fq_kron_general.hip
-    if (N == 148 && MT == 4 && (flags & FQ_CT_MASK) == FQ_OUT_PACKED && diag == nullptr && !((M * N / 2) & 15) &&
+    if (!g128 && N == 148 && MT == 4 && (flags & FQ_CT_MASK) == FQ_OUT_PACKED && diag == nullptr && !((M * N / 2) & 15) &&
         !fq_measure_env("FQ_KRON_NO_CTF"))
         return launch_fast<4, 5, 10, 8, 1, false, FQ_OUT_PACKED, 148>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
     if (spec) {
 #define FQ_F(MT_, NT_, KS1_, W_, OCC_)                                                                   \
     if (MT == MT_ && NT == NT_ && g.KS1 == KS1_) {                                                       \
-        if (MT_ >= 3 && (flags & FQ_CT_MASK) == FQ_OUT_PACKED && !fq_measure_env("FQ_KRON_NO_CTF"))              \
+        if (!g128 && MT_ >= 3 && (flags & FQ_CT_MASK) == FQ_OUT_PACKED && !fq_measure_env("FQ_KRON_NO_CTF"))    \
             rc = launch_fast<MT_, NT_, KS1_, W_, OCC_, false, (MT_ >= 3 ? FQ_OUT_PACKED : -1)>(flags, x, ws, diag, rows, M, N, out, n_cu, stream); \
-        else if (MT_ >= 3 && (flags & FQ_CT_MASK) == (FQ_OUT_PACKED | FQ_QUANT_F16) && (flags & FQ_ROUND_Y_F16)) \
+        else if (!g128 && MT_ >= 3 && (flags & FQ_CT_MASK) == (FQ_OUT_PACKED | FQ_QUANT_F16) && (flags & FQ_ROUND_Y_F16)) \
             rc = launch_fast<MT_, NT_, KS1_, W_, OCC_, false, (MT_ >= 3 ? (FQ_OUT_PACKED | FQ_QUANT_F16) : -1)>(flags, x, ws, diag, rows, M, N, out, n_cu, stream); \
         else                                                                                             \
             rc = launch_fast<MT_, NT_, KS1_, W_, OCC_>(flags, x, ws, diag, rows, M, N, out, n_cu, stream); \
@@ -828,5 +932,6 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
         FQ_F(6, 6, 11, 8, 1)  // 168 x 176 = 29568 (Qwen2.5-72B ffn)
 #undef FQ_F
     }
+    if (g128) return -1000;   // (the general kernel has no group epilogue)
     return fq_launch_kron_general(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
 }

@@ -13,36 +13,6 @@ namespace {
 
 // Running extrema of the 16-byte chunks a lane holds. fp16: packed pairs (v_pk_max/min_f16, exact: the data is fp16);
 // bf16: each dword's halves widened to fp32 (one shift, one and) and v_max3 / v_min3_f32.
-template <typename T> struct RowExtrema;
-template <> struct RowExtrema<f16> {
-    f16x2 pmax = {(f16)-INFINITY, (f16)-INFINITY}, pmin = {(f16)INFINITY, (f16)INFINITY};
-    __device__ __forceinline__ void take(const f16x8& v) {
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-            const f16x2 pr = {v[e], v[e + 1]};
-            pmax = fq_pk_max(pmax, pr);
-            pmin = fq_pk_min(pmin, pr);
-        }
-    }
-    __device__ __forceinline__ float vmax() const { return fmaxf((float)pmax[0], (float)pmax[1]); }
-    __device__ __forceinline__ float vmin() const { return fminf((float)pmin[0], (float)pmin[1]); }
-};
-template <> struct RowExtrema<bf16> {
-    float mx = -INFINITY, mn = INFINITY;
-    __device__ __forceinline__ void take(const bf16x8& v) {
-        const u32x4 w = __builtin_bit_cast(u32x4, v);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float lo, hi;
-            fq_bf16_pair(w[k], lo, hi);
-            mx = fq_max3(mx, lo, hi);
-            mn = fq_min3(mn, lo, hi);
-        }
-    }
-    __device__ __forceinline__ float vmax() const { return mx; }
-    __device__ __forceinline__ float vmin() const { return mn; }
-};
-
 constexpr int RQ_THREADS = 256;
 constexpr int RQ_MAXCH = 16;  // 16-byte chunks per thread: cols <= 256 * 16 * 8 = 32768
 

@@ -218,8 +218,9 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
 
     groupsize = 128: one scale per 128 consecutive elements of the transformed token instead of one per token
     (ActivationQuantizer(groupsize=128)); scales come back as [..., d/128]. One launch (FQ_GROUP128) where the library
-    fuses it (packed output, N = 64), otherwise the transform launch followed by the row quantiser over the
-    (-1, 128) view of its fp16 result — the reference's own order of operations.
+    fuses it — packed output at N = 64, and with FQ_ROUND_Y_F16 every output set of the listed pairs (64x112 = 7168,
+    32x64 = 2048, 64x128, 112x128, ...), fp16 and bf16 — otherwise the transform launch followed by the row quantiser over
+    the (-1, 128) view of its result: the reference's own order of operations.
 
     x fp16 or bf16 (left / right / diag of the same dtype): fq_kron_quant_f16 / fq_kron_quant_bf16; outputs in x's dtype."""
     dt = _chk_act(x)
@@ -238,11 +239,20 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
         raise ValueError("groupsize must be -1 (per token) or 128 with M*N % 128 == 0")
     rows = x.numel() // d
     smax, smin, n = _sig_arrays(sigs)
-    fused_g = groupsize == 128 and (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_QUANT_F16)) == FQ_OUT_PACKED \
+    # one launch (FQ_GROUP128): the packed fp32-arithmetic launch at N = 64 (wave-per-token kernels), or — with
+    # FQ_ROUND_Y_F16, the transformed activation rounded to x's dtype as ActivationQuantizer(groupsize=128) sees it — any
+    # output set of the pairs the workgroup-per-token kernel lists (group epilogue, round 3); otherwise two launches
+    fused_acc = groupsize == 128 and (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_QUANT_F16)) == FQ_OUT_PACKED \
         and n == 1 and N == 64 and M % 2 == 0 and diag is None and dt == torch.float16
+    fused_rnd = groupsize == 128 and n == 1 and bool(flags & FQ_ROUND_Y_F16) and bool(flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT))
+    fused_g = fused_acc or fused_rnd
+
+    def two_launches():
+        o2 = kron_quant(x, left, right, flags=FQ_OUT_TRANSFORM | (flags & FQ_WS_PREPARED), diag=diag)
+        return _quant_groups_of(o2.y, sigs, flags, 128, o2) if flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT) else o2
+
     if groupsize == 128 and not fused_g:
-        o = kron_quant(x, left, right, flags=FQ_OUT_TRANSFORM | (flags & FQ_WS_PREPARED), diag=diag)
-        return _quant_groups_of(o.y, sigs, flags, 128, o) if flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT) else o
+        return two_launches()
     o = _alloc_outputs(x, rows * (d // 128 if fused_g else 1), d, n, flags, x.shape[:-1] + (d // 2,), x.shape)
     if fused_g:
         _group_scales_shape(o, x.shape[:-1], d // 128)
@@ -251,9 +261,12 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
         return o
     with torch.cuda.device(x.device):
         ws, ws_bytes, prepared, key = _kron_workspace(x.device, M, N, left, right)
-        check(_fn("kron_quant", dt)(_ptr(x), _ptr(left), _ptr(right), _ptr(diag), rows, M, N, smax, smin, n,
-                                    flags | (FQ_WS_PREPARED if prepared else 0), _ptr_array(o.q), _ptr_array(o.scale),
-                                    _ptr_array(o.fq), _ptr(o.y), _ptr(ws), ws_bytes, _stream(x)))
+        rc = _fn("kron_quant", dt)(_ptr(x), _ptr(left), _ptr(right), _ptr(diag), rows, M, N, smax, smin, n,
+                                   flags | (FQ_WS_PREPARED if prepared else 0), _ptr_array(o.q), _ptr_array(o.scale),
+                                   _ptr_array(o.fq), _ptr(o.y), _ptr(ws), ws_bytes, _stream(x))
+        if rc == _lib.FQ_EUNSUPPORTED and fused_rnd:     # a pair without a group epilogue: the reference's own two steps
+            return two_launches()
+        check(rc)
         if key is not None and not prepared:
             _kron_workspace_commit(key, ws, left, right)
     return o
@@ -399,10 +412,12 @@ def kron_quant_grouped(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor,
             else:
                 _WS_LRU.move_to_end(key)
         return o
-    fused_g = groupsize == 128 and (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) == FQ_OUT_PACKED and N == 64 and M % 2 == 0 \
-        and dt == torch.float16
+    fused_g = groupsize == 128 and ((flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)) == FQ_OUT_PACKED and N == 64
+                                    and M % 2 == 0 and dt == torch.float16
+                                    or bool(flags & FQ_ROUND_Y_F16) and bool(flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT)))
     if groupsize == 128 and not fused_g:
-        raise _lib.FqError(FQ_EUNSUPPORTED, "grouped launch with 128-element scales is fused for packed output and N = 64 only")
+        raise _lib.FqError(FQ_EUNSUPPORTED, "grouped launch with 128-element scales: packed output at N = 64, or FQ_ROUND_Y_F16 "
+                           "(the group epilogue quantises the transform rounded to x's dtype)")
     o = _alloc_outputs(x, rows * (d // 128 if fused_g else 1), d, 1, flags, (rows, d // 2), x.shape)
     if fused_g:
         _group_scales_shape(o, (rows,), d // 128)
