@@ -96,12 +96,14 @@ __global__ void fq_kron_prepare_kernel(const f16* __restrict__ left, const f16* 
 // packed stage (N / 2 = 74 bytes) are written in 2-byte pieces.
 // GM: the grouped launch with one factor pair per group (fq_kron_quant_grouped_mats_*): its own instantiations, so that the
 // cursor and the image reload do not cost the ordinary launches registers (128 x 224 would spill).
-template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1, int NV = 0, typename T = f16, bool GM = false>
+template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1, int NV = 0, typename T = f16, bool GM = false,
+          bool G128 = false>
 __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fast_kernel(const T* __restrict__ x, const uint4* __restrict__ ws,
                                                            const T* __restrict__ diag, int64_t rows, int M, int /*N*/,
                                                            FqQuantOut out, int flags_rt) {
     typedef typename FqVec<T>::x8 X8;
     static_assert(FqVec<T>::is_f16 || (!SILU && CTF < 0 && NV == 0), "bf16: the all-output-sets instantiation only");
+    static_assert(!G128 || (!SILU && CTF < 0 && NV == 0), "FQ_GROUP128: the all-output-sets instantiation only");
     const int flags = CTF >= 0 ? (CTF | (flags_rt & (FQ_ROUND_Y_F16 | FQ_NO_CLAMP0 | FQ_SIG_F16 | 0xF000))) : flags_rt;
     constexpr int N = NV ? NV : KS1 * 16;          // N % 16 == 0 unless NV says otherwise, so KS1 fixes N
     constexpr bool ODD = NV != 0;
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
         // consecutive chunks = 16 consecutive lanes, extrema by xor butterflies inside them, every lane its group's scale,
         // outputs written straight to HBM, fully coalesced. (Before: transform launch + row-quantiser launch, 8 d bytes of HBM
         // traffic per token instead of 4 d.)
-        if (CTF < 0 && !SILU && !ODD && (out.rt_flags & FQ_GROUP128)) {
+        if (G128) {   // (its own instantiations: in the common ones the epilogue cost 15-30 VGPRs and a wave per SIMD)
             __syncthreads();   // every wave has finished reading xs (GEMM 1)
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
@@ -704,13 +706,15 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
     }
 }
 
-template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1, int NV = 0, typename T = f16, bool GM = false>
+template <int MT, int NT, int KS1, int WAVES, int OCC, bool SILU = false, int CTF = -1, int NV = 0, typename T = f16, bool GM = false,
+          bool G128 = false>
 int launch_fast(int flags, const T* x, const uint4* ws, const T* diag, int64_t rows, int M, int N,
                 const FqQuantOut& out, int n_cu, hipStream_t stream) {
     constexpr int PITCH = (KS1 * 2) | 1;
     const size_t lds = (size_t)2 * MT * MT * 1024 + (size_t)MT * 32 * PITCH * 16 + (((size_t)M * N / 2 + 15) & ~(size_t)15) + 128;
     if (lds > 160 * 1024) return -1000;
-    auto kern = fq_kron_fast_kernel<MT, NT, KS1, WAVES, OCC, SILU, CTF, NV, T, GM>;
+    if (G128 != ((out.rt_flags & FQ_GROUP128) != 0)) return -1000;   // (the group epilogue is its own instantiation: registers)
+    auto kern = fq_kron_fast_kernel<MT, NT, KS1, WAVES, OCC, SILU, CTF, NV, T, GM, G128>;
     FQ_RAISE_LDS_CAP(kern, 160 * 1024);
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > OCC) per_cu = OCC;
@@ -810,6 +814,16 @@ static int launch_kron_generic_bf16(int flags, const bf16* x, const bf16* left, 
     }
     flags &= ~FQ_WS_PREPARED;
     const bool spec = !(N & 15) && M <= 192 && !((M * N / 2) & 15);
+    if (out.rt_flags & FQ_GROUP128) {
+        if (!spec) return -1000;
+#define FQ_FBG(MT_, NT_, KS1_, W_, OCC_) \
+    if (MT == MT_ && NT == NT_ && KS1 == KS1_) \
+        return launch_fast<MT_, NT_, KS1_, W_, OCC_, false, -1, 0, bf16, false, true>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
+        FQ_FBG(1, 2, 4, 4, 4) FQ_FBG(2, 2, 4, 4, 2) FQ_FBG(2, 4, 7, 4, 2) FQ_FBG(2, 4, 8, 4, 2) FQ_FBG(2, 3, 5, 4, 2) FQ_FBG(3, 4, 8, 4, 2)
+        FQ_FBG(4, 4, 8, 4, 2)
+#undef FQ_FBG
+        return -1000;
+    }
     if (spec) {
         int rc;
 #define FQ_FB(MT_, NT_, KS1_, W_, OCC_)                                                                                       \
@@ -905,6 +919,15 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
     if (!g128 && N == 148 && MT == 4 && (flags & FQ_CT_MASK) == FQ_OUT_PACKED && diag == nullptr && !((M * N / 2) & 15) &&
         !fq_measure_env("FQ_KRON_NO_CTF"))
         return launch_fast<4, 5, 10, 8, 1, false, FQ_OUT_PACKED, 148>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
+    if (g128) {   // the pairs with a group-epilogue instantiation (DeepSeek-V3: 64 x 112 hidden, 32 x 64 moe_inter; the N = 64, 80, 128 pairs)
+#define FQ_FG1(MT_, NT_, KS1_, W_, OCC_) \
+    if (MT == MT_ && NT == NT_ && g.KS1 == KS1_) \
+        return launch_fast<MT_, NT_, KS1_, W_, OCC_, false, -1, 0, f16, false, true>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
+        FQ_FG1(1, 2, 4, 4, 4) FQ_FG1(2, 2, 4, 4, 2) FQ_FG1(2, 4, 7, 4, 2) FQ_FG1(2, 4, 8, 4, 2)
+        FQ_FG1(2, 3, 5, 4, 2) FQ_FG1(3, 4, 8, 4, 2) FQ_FG1(4, 4, 8, 4, 2)
+#undef FQ_FG1
+        return -1000;
+    }
     if (spec) {
 #define FQ_F(MT_, NT_, KS1_, W_, OCC_)                                                                   \
     if (MT == MT_ && NT == NT_ && g.KS1 == KS1_) {                                                       \
