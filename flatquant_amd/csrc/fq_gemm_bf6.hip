@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void fq_i4_to_bf6_kernel(const uint8_t* __rest
 }
 
 // ---- the GEMM ---------------------------------------------------------------------------------------------------
-template <int ABL>  // measurement builds (wrong results): 1 = no MFMA, 2 = fragment reads of the first stage only, 4 = no DMA after the prologue
+template <int ABL>  // measurement builds (wrong results): 1 = no MFMA, 2 = fragment reads of the first stage only, 4 = no DMA after the prologue,
+                    // 8 = no epilogue stores, 16 = one output row in eight dequantised and stored
 __global__ __launch_bounds__(GT, GW / 4) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB, const uint8_t* __restrict__ WB,
                                                             int M, int N, int KB, GemmOut out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -252,6 +253,7 @@ typedef int i32x6 __attribute__((ext_vector_type(6)));
     for (int tm = 0; tm < TMT; ++tm) {
         const int m = m0 + wm * (TMT * 32) + tm * 32 + c;
         if (m >= M) continue;
+        if ((ABL & 16) && (c & 7)) continue;
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
             const int nbase = n0 + wn * 64 + tn * 32 + 16 * h;
@@ -265,20 +267,13 @@ typedef int i32x6 __attribute__((ext_vector_type(6)));
                 for (int g = 0; g < 4; ++g) cp[g] = make_int4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
             }
             if (out.y != nullptr) {
-                const f16 sr = out.srow[m];
                 f16x8 o0, o1;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    o0[r] = dequant1(v[r], sr, out.scol[nbase + r]);
-                    o1[r] = dequant1(v[8 + r], sr, out.scol[nbase + 8 + r]);
-                    if (out.bias != nullptr) {
-                        o0[r] = o0[r] + out.bias[nbase + r];
-                        o1[r] = o1[r] + out.bias[nbase + 8 + r];
-                    }
-                }
+                dequant16(v, out.srow[m], out.scol + nbase, out.bias != nullptr ? out.bias + nbase : nullptr, o0, o1);
                 uint4* yp = reinterpret_cast<uint4*>(out.y + (int64_t)m * N + nbase);
-                yp[0] = __builtin_bit_cast(uint4, o0);
-                yp[1] = __builtin_bit_cast(uint4, o1);
+                if (!(ABL & 8) || o0[0] == (f16)12345.0f) {
+                    yp[0] = __builtin_bit_cast(uint4, o0);
+                    yp[1] = __builtin_bit_cast(uint4, o1);
+                }
             }
         }
     }
@@ -328,6 +323,8 @@ int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, in
     else if (abl == 2) FQ_LAUNCH(2)
     else if (abl == 4) FQ_LAUNCH(4)
     else if (abl == 6) FQ_LAUNCH(6)
+    else if (abl == 8) FQ_LAUNCH(8)
+    else if (abl == 16) FQ_LAUNCH(16)
     else FQ_LAUNCH(0)
 #undef FQ_LAUNCH
     return (int)hipGetLastError();

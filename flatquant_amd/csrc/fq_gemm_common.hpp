@@ -18,6 +18,46 @@ __device__ __forceinline__ f16 dequant1(int q, f16 srow, f16 scol) {
     return r * (f16)10.0f;
 }
 
+// The same for a lane's 16 consecutive features of one token (the tile kernels' epilogue), 8 VALU per element instead of ~40
+// (round 3: the epilogue had grown to the cost of the whole K loop — 42.7 M VALU against 4.2 M MFMA per 16384 x 4096 x 4096
+// launch, profiles/r03_gemm_bf6_pmc.txt). Bit-identical to dequant1:
+//   * int(q / 10.0f) == q / 10 (C integer division, toward zero) for every |q| < 2^24: q / 10 = k + f/10 lies at least 0.1 from
+//     an integer unless it is one, and the fp32 quotient is within half an ulp <= 0.0625 (|q / 10| < 2^21) of it;
+//   * half(iv) of |iv| <= 65176 through fp32 is one rounding (the int is exact in fp32);
+//   * the three fp16 products are formed two elements per instruction (v_pk_mul_f16 rounds each half like v_mul_f16);
+//   * the 16 column scales (and biases) are two 16-byte loads, not 16 two-byte loads.
+__device__ __forceinline__ void dequant16(const int (&q)[16], f16 srow, const f16* __restrict__ scol16, const f16* __restrict__ bias16,
+                                          f16x8& o0, f16x8& o1) {
+    const uint4 c0 = *reinterpret_cast<const uint4*>(scol16), c1 = *reinterpret_cast<const uint4*>(scol16 + 8);
+    const f16x8 s0 = __builtin_bit_cast(f16x8, c0), s1 = __builtin_bit_cast(f16x8, c1);
+    const f16x2 sr2 = {srow, srow}, ten2 = {(f16)10.0f, (f16)10.0f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {   // element pairs (2j, 2j + 1) of the 16
+        const int e = 2 * j;
+        int i0 = q[e] / 10, i1 = q[e + 1] / 10;
+        i0 = max(-65176, min(65176, i0));
+        i1 = max(-65176, min(65176, i1));
+        const f16x2 iv = {(f16)(float)i0, (f16)(float)i1};
+        const f16x2 sc = e < 8 ? f16x2{s0[e], s0[e + 1]} : f16x2{s1[e - 8], s1[e - 7]};
+        f16x2 r = sr2 * sc;
+        r = r * iv;
+        r = r * ten2;
+        if (e < 8) {
+            o0[e] = r[0];
+            o0[e + 1] = r[1];
+        } else {
+            o1[e - 8] = r[0];
+            o1[e - 7] = r[1];
+        }
+    }
+    if (bias16 != nullptr) {
+        const f16x8 b0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(bias16));
+        const f16x8 b1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(bias16 + 8));
+        o0 = o0 + b0;
+        o1 = o1 + b1;
+    }
+}
+
 // XCD-aware tile order. Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own 4 MB L2. XCD x
 // takes a CONTIGUOUS share of the tile sequence, and the sequence walks 8-feature-tile-wide column blocks row by row,
 // so the ~32 workgroups resident on an XCD at a time form a 4 x 8 patch of tiles: 12 distinct operand tiles per K

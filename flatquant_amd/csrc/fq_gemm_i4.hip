@@ -212,17 +212,8 @@ __global__ __launch_bounds__(GT) void fq_gemm_i4_kernel(const uint8_t* __restric
                 for (int g = 0; g < 4; ++g) cp[g] = make_int4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
             }
             if (out.y != nullptr) {
-                const f16 sr = out.srow[m];
                 f16x8 o0, o1;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    o0[r] = dequant1(v[r], sr, out.scol[nbase + r]);
-                    o1[r] = dequant1(v[8 + r], sr, out.scol[nbase + 8 + r]);
-                    if (out.bias != nullptr) {
-                        o0[r] = o0[r] + out.bias[nbase + r];
-                        o1[r] = o1[r] + out.bias[nbase + 8 + r];
-                    }
-                }
+                dequant16(v, out.srow[m], out.scol + nbase, out.bias != nullptr ? out.bias + nbase : nullptr, o0, o1);
                 uint4* yp = reinterpret_cast<uint4*>(out.y + (int64_t)m * N + nbase);
                 yp[0] = __builtin_bit_cast(uint4, o0);
                 yp[1] = __builtin_bit_cast(uint4, o1);

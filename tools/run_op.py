@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Launch ONE op of the library N times (for rocprofv3 --pmc / --kernel-trace runs): tools/run_op.py <op> [n]
   ops: kron112 (112x128 packed), kron128x224, kron64x128, kron64x112, kron32x64g (grouped, 131072 rows), kron64fq (fake-quant output), hadq14336, kvk / kvv (KV-cache quantisers)
-       (Hadamard 28x512 + Quantizer), rowq4096 / rowq14336 (deploy Quantizer), block32, block64"""
+       gemmbf6 / gemmi8 (Linear4bit 16384 x 4096 x 4096), (Hadamard 28x512 + Quantizer), rowq4096 / rowq14336 (deploy Quantizer), block32, block64"""
 import os
 import sys
 
@@ -34,7 +34,7 @@ if op == "kron64fq":   # C1: the fake-quant contract at 64 x 64 (FlatQuantizedLi
     L, R = mat(64), mat(64)
     fn = lambda i: ops.kron_quant(xs[i % 2], L, R, SIG, FQ_OUT_FAKEQUANT | FQ_ROUND_Y_F16)
 elif op.startswith("kron") and not op.endswith("g"):
-    M, N = {"kron112": (112, 128), "kron128x224": (128, 224), "kron64x128": (64, 128), "kron64x112": (64, 112),
+    M, N = {"kron64": (64, 64), "kron172x64": (172, 64), "kron112": (112, 128), "kron128x224": (128, 224), "kron64x128": (64, 128), "kron64x112": (64, 112),
             "kron86": (86, 128), "kron32x64": (32, 64), "kron128x148": (128, 148), "kron144x192": (144, 192),
             "kron168x176": (168, 176), "kron96": (96, 96)}[op]
     rows = 8192 if M * N > 20000 else 16384
@@ -63,6 +63,17 @@ elif op in ("kvk", "kvv"):   # K transform + asymmetric INT4 pack / V pack, 1638
     xs = [act(16384 * 8, 128) for _ in range(2)]
     Tm = mat(128)
     fn = (lambda i: ops.kv_quant(xs[i % 2], Tm)) if op == "kvk" else (lambda i: ops.kv_quant(xs[i % 2]))
+elif op in ("gemmbf6", "gemmi8"):   # Linear4bit 16384 x 4096 x 4096: the FP6 matrix path / the int8 matrix path
+    Mg, Ng, Kg = 16384, 4096, 4096
+    xq = torch.randint(0, 256, (Mg, Kg // 2), generator=g, device=dev, dtype=torch.uint8)
+    wq = torch.randint(0, 256, (Ng, Kg // 2), generator=g, device=dev, dtype=torch.uint8)
+    sx = torch.rand(Mg, generator=g, device=dev).half() * 0.01
+    sw = torch.rand(Ng, generator=g, device=dev).half() * 0.01
+    if op == "gemmbf6":
+        wb, xb = ops.int4_to_bf6(wq, weights=True), ops.int4_to_bf6(xq)
+        fn = lambda i: ops.bf6_linear(xb, sx, wb, sw, None, Mg, Ng, Kg)
+    else:
+        fn = lambda i: ops.int4_linear(xq, sx, wq, sw, None)
 elif op.startswith("block"):
     H = int(op[5:])
     xs = [act(16384, 128 * H).reshape(16384, 128, H) for _ in range(2)]
