@@ -34,6 +34,9 @@
 
 namespace {
 
+#ifndef DUO_MEET_SLEEP
+#define DUO_MEET_SLEEP 1   // s_sleep argument (x 64 cycles) between two polls of a meeting counter (measured: 4 -> +2 us, 12 -> +4 us)
+#endif
 #ifndef DUO_ABL
 #define DUO_ABL 0   // measurement builds (tools/variants.sh): 1 no GEMM 1 MFMAs, 2 no GEMM 2 MFMAs, 4 no quantiser, 8 no DMA after the first
 #endif              // token, 16 no extrema, 32 no A-fragment reads, 64 no L-fragment reads, 128 no R stream
@@ -82,7 +85,7 @@ __device__ __forceinline__ void duo_meet(unsigned cnt_lds, unsigned target, int 
         unsigned v;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cnt_lds) : "memory");
         if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(DUO_MEET_SLEEP);
     }
 }
 #define DUO_MEET() { meet_n += DUO_WPG; duo_meet(meet, meet_n, lane); }
