@@ -7,7 +7,7 @@ the two 64x64 factor matrices are broadcast once from rank 0 over RCCL).  One st
 fq_kron_quant_f16 (packed INT4 + fp16 scales out) over one 128 MiB activation buffer already resident in
 HBM; buffers rotate over > 256 MiB so the Infinity Cache cannot serve the stream.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C1|C3|C4|C5] [--dtype f16|bf16]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C2S|C1|C3|C4|C5] [--dtype f16|bf16]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
 
 --config (the other BASELINE.json configs; one "element" = one input activation scalar of one (token, linear) unit):
@@ -15,6 +15,8 @@ HBM; buffers rotate over > 256 MiB so the Infinity Cache cannot serve the stream
       transformed activation, fp16 / bf16 out, 16 KB per token) at C2's size: 64x64 factors, 8 x 2048 tokens per GPU, one
       launch of fq_kron_quant_{f16,bf16}(FQ_OUT_FAKEQUANT | FQ_ROUND_Y_F16) per step. --dtype bf16: the dtype the reference's
       eval pipeline feeds this path on Llama-3 / Qwen / DeepSeek (model_utils.py:20); also valid for C2 (packed out).
+  C2S the default workload in its STRONG-scaling form: the 8 x 2048 tokens BASELINE quotes the metric on are split over the
+      ranks (2048 tokens per launch at N = 8). At N = 1 identical to C2.
   C3  Llama-3-8B decoder layer, the activation path of its 7 linears: RMSNorm + 64x64 transform with 3 clip sets (q/k/v),
       o_proj head transform (head_dim 128 x 32 heads), RMSNorm + 64x64 with 2 clip sets (up/gate), online Hadamard
       28 x 512 + Quantizer on the down_proj input. 4 launches per step, 8 x 2048 tokens per GPU (weak scaling).
@@ -162,6 +164,7 @@ class C2(Workload):
     name = "C2"
     metric = "Melems/s for fused kron-transform+INT4-quant, Llama-3-8B d=4096, bs×seq=8×2048"
     fakequant = False      # C1: the fake-quant output (FlatQuantizedLinear's contract) instead of the packed one
+    strong = False         # C2S: the same 16384 tokens split over the ranks (strong scaling)
 
     def __init__(self, device, rank, world, sharding, bcast, dtype="f16"):
         from flatquant_amd import ops
@@ -173,7 +176,14 @@ class C2(Workload):
         mats = bcast(mats)                                     # the only collective on the path (set-up time)
         left, right = mats["left"].to(td).contiguous(), mats["right"].to(td).contiguous()
         sig = [ops.sigmoid_pair(4.0, 4.0)]
-        self.xs = xs = [x.to(td) for x in make_inputs(device, seed=rank)]
+        # weak scaling (C1, C2): every rank its own 8 x 2048 tokens; strong scaling (C2S): the 8 x 2048 tokens BASELINE quotes the
+        # metric on, split over the ranks (flatquant_amd.sharding.shard_rows) — at N = 8 a rank's launch is 2048 tokens, 5 us
+        if self.strong:
+            a, b = sharding.shard_rows(ROWS, world, rank)
+            ROWS_ = b - a
+        else:
+            ROWS_ = ROWS
+        self.xs = xs = [x.to(td) for x in make_inputs(device, seed=rank, rows=max(ROWS_, 1))]
         fn = lib.fq_kron_quant_bf16 if dtype == "bf16" else lib.fq_kron_quant_f16
         sp = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
         # the matrices are constants of a deployed layer: their fragment image is prepared ONCE (fq_kron_prepare_f16, set-up
@@ -194,32 +204,32 @@ class C2(Workload):
         # pre-allocated rotating outputs; the timed region calls the C ABI directly (no allocator in the loop)
         if self.fakequant:
             flags = FQ_OUT_FAKEQUANT | FQ_ROUND_Y_F16 | FQ_WS_PREPARED      # path A: Y rounded to the activation dtype, fp32 quantiser
-            self.fqs = fqs = [torch.empty(ROWS, D, dtype=td, device=device) for _ in range(N_BUF)]
+            self.fqs = fqs = [torch.empty(max(ROWS_, 1), D, dtype=td, device=device) for _ in range(N_BUF)]
             calls = [(ctypes.c_void_p(xs[i].data_ptr()), arr(fqs[i])) for i in range(N_BUF)]
 
             def step(i):
                 xp, fa = calls[i % N_BUF]
-                check(fn(xp, lp, rp, None, ROWS, M, N, smax, smin, 1, flags, none4, none4, fa, None, wp, wsb, sp))
+                check(fn(xp, lp, rp, None, ROWS_, M, N, smax, smin, 1, flags, none4, none4, fa, None, wp, wsb, sp))
             bytes_per_token = 4 * D
             what = f"fake-quant {dtype} out (FlatQuantizedLinear._eval_forward contract, 16 KB per token)"
         else:
             flags = FQ_OUT_PACKED | FQ_NO_CLAMP0 | FQ_WS_PREPARED           # deploy OnlineTrans(matmul) contract
-            self.qs = qs = [torch.empty(ROWS, D // 2, dtype=torch.uint8, device=device) for _ in range(N_BUF)]
-            self.ss = ss = [torch.empty(ROWS, dtype=td, device=device) for _ in range(N_BUF)]
+            self.qs = qs = [torch.empty(max(ROWS_, 1), D // 2, dtype=torch.uint8, device=device) for _ in range(N_BUF)]
+            self.ss = ss = [torch.empty(max(ROWS_, 1), dtype=td, device=device) for _ in range(N_BUF)]
             calls = [(ctypes.c_void_p(xs[i].data_ptr()), arr(qs[i]), arr(ss[i])) for i in range(N_BUF)]
 
             def step(i):
                 xp, qa, sa = calls[i % N_BUF]
-                check(fn(xp, lp, rp, None, ROWS, M, N, smax, smin, 1, flags, qa, sa, none4, None, wp, wsb, sp))
+                check(fn(xp, lp, rp, None, ROWS_, M, N, smax, smin, 1, flags, qa, sa, none4, None, wp, wsb, sp))
             bytes_per_token = BYTES_PER_TOKEN
             what = f"packed INT4 + {dtype} scale out"
         self._keep = (left, right, ws, smax, smin, calls, none4)
         self.step = step
-        self.elems = ROWS * D
-        self.kernels = [("fq_kron64_kernel", step, ROWS * bytes_per_token)]
+        self.elems = ROWS_ * D
+        self.kernels = [("fq_kron64_kernel", step, ROWS_ * bytes_per_token)]
         self.config = {"workload": f"{self.name}: Llama-3-8B single linear (q_proj input), d=4096 = 64x64 Kronecker, "
-                                   f"8x2048 tokens per GPU, {what}",
-                       "rows_per_gpu": ROWS, "d": D, "factors": [M, N], "parallelism": f"rows x{world}",
+                                   f"8x2048 tokens {'in total, rows sharded' if self.strong else 'per GPU'}, {what}",
+                       "rows_per_gpu": ROWS_, "d": D, "factors": [M, N], "parallelism": f"rows /{world}" if self.strong else f"rows x{world}",
                        "activation_dtype": dtype, "fragment_image": "prepared once (FQ_WS_PREPARED)"}
         if self.fakequant:
             self.floor_us = None   # (the streaming probe moves the packed contract's byte mix)
@@ -239,6 +249,15 @@ class C2(Workload):
         f1.record(stream)
         torch.cuda.synchronize()
         return f0.elapsed_time(f1) / 50 * 1e3
+
+
+class C2S(C2):
+    """The headline workload in its STRONG-scaling form (missing #6): BASELINE quotes the metric on bs x seq = 8 x 2048
+    tokens; here those 16384 tokens are split over the ranks, so the per-rank launch shrinks with N (2048 tokens = 5 us at N = 8:
+    the launch, not the kernel, bounds the curve — the honest counterpart of the weak-scaling default)."""
+    name = "C2S"
+    strong = True
+    scaling = "strong"
 
 
 class C1(C2):
@@ -385,7 +404,7 @@ class C5(Workload):
                        "parallelism": f"experts+tokens /{world}"}
 
 
-WORKLOADS = {"C1": C1, "C2": C2, "C3": C3, "C4": C4, "C5": C5}
+WORKLOADS = {"C1": C1, "C2": C2, "C2S": C2S, "C3": C3, "C4": C4, "C5": C5}
 
 
 def main():
@@ -401,9 +420,9 @@ def main():
                          "many milliseconds (reported as settle_launches); 0 disables it")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {"C1": 500, "C2": 1000, "C3": 100, "C4": 5, "C5": 50}[args.config]
+        args.steps = {"C1": 500, "C2": 1000, "C2S": 1000, "C3": 100, "C4": 5, "C5": 50}[args.config]
     if args.warmup is None:
-        args.warmup = {"C1": 100, "C2": 200, "C3": 10, "C4": 2, "C5": 5}[args.config]
+        args.warmup = {"C1": 100, "C2": 200, "C2S": 200, "C3": 10, "C4": 2, "C5": 5}[args.config]
     if args.dtype != "f16" and args.config not in ("C1", "C2"):
         ap.error("--dtype bf16 goes with --config C1 / C2 (the deploy configs are fp16 contracts)")
 
@@ -418,7 +437,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)   # RCCL
 
     from flatquant_amd import sharding
-    kw = {"dtype": args.dtype} if args.config in ("C1", "C2") else {}
+    kw = {"dtype": args.dtype} if args.config in ("C1", "C2", "C2S") else {}
     wl = WORKLOADS[args.config](device, rank, world, sharding, lambda m: sharding.broadcast_matrices(m, src=0), **kw)
     stream = torch.cuda.current_stream(device)
     step = wl.step
@@ -443,7 +462,7 @@ def main():
     # measures the ramp, not the kernel. Not part of --warmup, not part of the timed region; reported below.
     settle_launches = 0
     if args.settle_ms > 0:
-        chunk = 64 if args.config in ("C1", "C2") else 1
+        chunk = 64 if args.config in ("C1", "C2", "C2S") else 1
         t_settle = time.perf_counter()
         while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
             for i in range(chunk):
@@ -508,7 +527,7 @@ def main():
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         value = float(elems[0]) / (wall / args.steps) / 1e6
-        if args.config in ("C1", "C2"):                      # one launch per step: the timed region IS the kernel
+        if args.config in ("C1", "C2", "C2S"):               # one launch per step: the timed region IS the kernel
             dom_name, dom_us, dom_bytes = wl.kernels[0][0], kern_ms * 1e3, wl.kernels[0][2]
         else:
             dom_name, dom_us, dom_bytes = max(kern_us, key=lambda k: k[1])
@@ -533,7 +552,7 @@ def main():
             out["roofline"]["kernels"] = [{"kernel": n, "launch_us": u, "algorithmic_bytes": b,
                                            "frac": b / (u * 1e-6) / 1e9 / HBM_PEAK_GBS} for n, u, b in kern_us]
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(*{"C1": (20.0, 64, 64), "C2": (20.0, 64, 64), "C3": (20.0, 64, 64),
+            out["cpu_baseline"] = cpu_baseline(*{"C1": (20.0, 64, 64), "C2": (20.0, 64, 64), "C2S": (20.0, 64, 64), "C3": (20.0, 64, 64),
                                                  "C4": (20.0, 64, 128), "C5": (20.0, 32, 64)}[args.config])
         print(json.dumps(out))
     if dist is not None:
