@@ -17,9 +17,23 @@
 // as in fq_gemm_i4.hip); activations by one small launch per call (0.5 -> 0.75 bytes per element).
 //
 // Tiling: 256 x 256 per 8-wave workgroup, wave tile 128 tokens x 64 features (8 accumulator tiles: 6 fragments per 8
-// MFMAs), three LDS stages of 48 KB, counted vmcnt, one barrier per stage — the pipeline of fq_gemm_i4.hip.
+// MFMAs), three LDS stages of 48 KB filled by LDS-DMA, counted vmcnt, one barrier per stage (128 k).
+// Second session of round 3 (195.9 -> see profiles/r03_gemm_bf6_pipeline.txt, 16384 x 4096 x 4096):
+//   * EXPLICIT SOFTWARE PIPELINE. A wave issues in order: a run of 18 fragment reads (or 6 LDS-DMA instructions) in front of
+//     a block's MFMAs keeps the matrix pipe idle while the LDS queue — shared by the eight waves, all at the same point behind
+//     the barrier — takes them. Now step i of a block issues MFMA i, then one DMA instruction of the stage three ahead, then the
+//     three reads of fragment i of the NEXT block. The loop is split by hand (stages that refill | the last STAGES - 1 | the
+//     last) so that a stage is straight-line code between two s_barrier's.
+//   * -mllvm -disable-machine-sink for this file (Makefile): LLVM's MachineSink moved the first half-stage's eight MFMAs across
+//     the barrier into the join block behind the `if (s + 1 < nk)` (legal: nothing in between reads the accumulators), next to
+//     the second half's — all sixteen then sat BEHIND the barrier, the DMA issue and the next reads, and the fragment reads in
+//     front of the barrier had nothing to hide behind (found in the ISA; it also cost 18 v_mov_b64 per stage).
+//   * PERSISTENT WORKGROUPS, one per CU, walking their XCD's tile sequence: the next tile's first three stages are requested
+//     BEFORE the epilogue of the current one, and the epilogue's 512 KB of stores drain under the next tile's K loop instead of
+//     holding the CU until the workgroup has ended (the tiles of a launch end together: the stores came as four chip-wide bursts).
+//   * the sym_dequant epilogue in the float pipeline (dequant16f): 6 VALU per output element instead of 11.
 #include "fq_gemm_common.hpp"
-#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -34,21 +48,11 @@ constexpr int SEG = 2 * BLOB;                  // a row tile's two blobs of one 
 constexpr int OPB = 8 * SEG;                   // one operand's share of a stage: 8 row tiles
 constexpr int TILE_BYTES = 2 * OPB;            // 48 KB: [W tiles 0..7][X tiles 0..7]
 constexpr int STAGES = 3;
-#ifndef FQ_BF6_WAVES
-#define FQ_BF6_WAVES 8   // 8: 2 x 4 waves of 128 x 64 (2 per SIMD); 16: 4 x 4 waves of 64 x 64 (4 per SIMD, <= 128 VGPRs)
-#endif
-constexpr int GW = FQ_BF6_WAVES, GT = GW * 64;
+constexpr int GW = 8, GT = GW * 64;            // 2 x 4 waves of 128 x 64, two per SIMD (tried and dropped, round 3: 4 waves of 256 x 64,
+                                               // 16 waves of 64 x 64, DMA from one wave per SIMD, DMA behind the second half's MFMAs)
 constexpr int NWM = GW / 4;                    // waves along the token dimension (4 along the feature dimension)
 constexpr int TMT = BM / 32 / NWM;             // token tiles per wave
-#ifndef FQ_BF6_LATE_DMA
-#define FQ_BF6_LATE_DMA 0   // 1: refill after the second half's MFMAs instead of right behind the barrier (measured neutral: 227 vs 224 us)
-#endif
-#ifndef FQ_BF6_DMA_WAVES
-#define FQ_BF6_DMA_WAVES 8   // waves that issue the DMA. (4 = one per SIMD, so that the two waves of a SIMD leave each barrier
-                             // differently loaded and stop marching in step: measured no difference, 226 vs 224 us)
-#endif
-constexpr int DW = FQ_BF6_DMA_WAVES;
-constexpr int DPW = (TILE_BYTES / 1024) / DW;  // DMA instructions per issuing wave and stage
+constexpr int DPW = (TILE_BYTES / 1024) / GW;  // DMA instructions per wave and stage
 
 // ---- INT4 nibbles -> BF6 blobs ----------------------------------------------------------------------------------
 // E3M2 codes of 0..8; a negative value sets bit 5
@@ -99,17 +103,15 @@ __global__ __launch_bounds__(256) void fq_i4_to_bf6_kernel(const uint8_t* __rest
 }
 
 // ---- the GEMM ---------------------------------------------------------------------------------------------------
-template <int ABL>  // measurement builds (wrong results): 1 = no MFMA, 2 = fragment reads of the first stage only, 4 = no DMA after the prologue,
-                    // 8 = no epilogue stores, 16 = one output row in eight dequantised and stored
+typedef int i32x6 __attribute__((ext_vector_type(6)));
+
 __global__ __launch_bounds__(GT, GW / 4) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB, const uint8_t* __restrict__ WB,
-                                                            int M, int N, int KB, GemmOut out) {
+                                                            int M, int N, int KB, int n_vblocks, GemmOut out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % NWM, wn = wave / NWM;  // wave tile: tokens (32 TMT) wm .., features 64 wn ..
-    int mb, nb;
-    if (!xcd_tile(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, mb, nb)) return;
-    const int m0 = mb * BM, n0 = nb * BN;
+    const int TMg = (M + BM - 1) / BM, TNg = (N + BN - 1) / BN;
     const int nk = KB / 2;  // stages of 128 k
     const int mt_last = (M + 31) / 32 - 1, nt_last = (N + 31) / 32 - 1;
 
@@ -118,165 +120,203 @@ __global__ __launch_bounds__(GT, GW / 4) void fq_gemm_bf6_kernel(const uint8_t* 
     // pointers — those had pushed the kernel into a spill whose reload sat between the DMA instructions of a stage
     // behind an s_waitcnt vmcnt(0), i.e. every stage waited for its own loads (found in the ISA, cost ~2x).
     const unsigned char* gbase[DPW];
-#pragma unroll
-    for (int j = 0; j < DPW; ++j) {
-        const int i = (wave < DW ? wave : 0) * DPW + j;
-        const int op = i / 24, t = (i % 24) / 3, part = i % 3;
-        int rt = (op == 0 ? n0 : m0) / 32 + t;
-        const int last = op == 0 ? nt_last : mt_last;
-        rt = rt < last ? rt : last;  // tiles beyond the matrix re-read its last tile (their outputs are never stored)
-        gbase[j] = (op == 0 ? WB : XB) + (int64_t)rt * KB * BLOB + part * 1024;
-    }
-    const unsigned voff = (unsigned)lane * 16u;
-    const unsigned lds0 = (unsigned)(size_t)(lds_void_b*)smem;
-    auto issue_stage = [&](int s) {
-        if (wave >= DW) return;  // (their vmcnt waits below find nothing outstanding and fall through)
-        const unsigned dst = lds0 + (unsigned)((s % STAGES) * TILE_BYTES) + (unsigned)(wave * DPW) * 1024u;
+    auto plan = [&](int mb, int nb) {
 #pragma unroll
         for (int j = 0; j < DPW; ++j) {
-            const unsigned char* src = gbase[j] + (int64_t)s * SEG;
-            unsigned keep;
-            asm volatile(
-                "s_mov_b32 %0, m0\n\t"
-                "s_mov_b32 m0, %3\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %1, %2\n\t"
-                "s_mov_b32 m0, %0"
-                : "=&s"(keep)
-                : "v"(voff), "s"(src), "s"(__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)j * 1024u)))
-                : "memory");
+            const int i = wave * DPW + j;
+            const int op = i / 24, t = (i % 24) / 3, part = i % 3;
+            int rt = (op == 0 ? nb * BN : mb * BM) / 32 + t;
+            const int last = op == 0 ? nt_last : mt_last;
+            rt = rt < last ? rt : last;  // tiles beyond the matrix re-read its last tile (their outputs are never stored)
+            gbase[j] = (op == 0 ? WB : XB) + (int64_t)rt * KB * BLOB + part * 1024;
         }
+    };
+    const unsigned voff = (unsigned)lane * 16u;
+    const unsigned lds0 = (unsigned)(size_t)(lds_void_b*)smem;
+    auto issue_one = [&](int s, int j) {   // instruction j of this wave's share of stage s
+        const unsigned dst = lds0 + (unsigned)((s % STAGES) * TILE_BYTES) + (unsigned)(wave * DPW + j) * 1024u;
+        const unsigned char* src = gbase[j] + (int64_t)s * SEG;
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(src), "s"(__builtin_amdgcn_readfirstlane((int)dst))
+            : "memory");
+    };
+    auto request_first_stages = [&]() {
+#pragma unroll
+        for (int p = 0; p < STAGES; ++p)
+            if (p < nk) {
+#pragma unroll
+                for (int j = 0; j < DPW; ++j) issue_one(p, j);
+            }
+    };
+    // the tile sequence of this workgroup: virtual blocks blockIdx.x, + gridDim.x, ... (gridDim.x % 8 == 0: the XCD stays)
+    auto next_tile = [&](int& vb, int& mb, int& nb) -> bool {
+        for (; vb < n_vblocks; vb += (int)gridDim.x)
+            if (xcd_tile(vb, TMg, TNg, mb, nb)) return true;
+        return false;
     };
 
     const int woff = (wn * 2) * SEG + lane * 8;             // + tn * SEG + kbl * BLOB + plane * 512
     const int xoff = OPB + (wm * TMT) * SEG + lane * 8;     // + tm * SEG + ...
-
     f32x16 acc[2][TMT];
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < TMT; ++tm) acc[tn][tm] = f32x16{0};
+    uint2 r0w[2][3], r0x[TMT][3], r1w[2][3], r1x[TMT][3];   // the fragments of the current and of the next 64-k block
 
-#if FQ_BF6_WAVES == 16
-    uint2 r0w[2][3], r0x[TMT][3];
-#else
-    uint2 r0w[2][3], r0x[TMT][3], r1w[2][3], r1x[TMT][3];
-#endif
-#define FQ_READ(ST, KBL, RW, RX)                                                                                    \
-    {                                                                                                                \
-        _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) _Pragma("unroll") for (int p = 0; p < 3; ++p) RW[tn][p] =   \
-            *reinterpret_cast<const uint2*>((ST) + woff + tn * SEG + (KBL) * BLOB + p * 512);                        \
-        _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm) _Pragma("unroll") for (int p = 0; p < 3; ++p) RX[tm][p] = \
-            *reinterpret_cast<const uint2*>((ST) + xoff + tm * SEG + (KBL) * BLOB + p * 512);                        \
-    }
 // the BF6 operand is 6 registers; the builtin's type is 8 wide — the upper two lanes are left UNDEFINED (shufflevector
 // index -1) so that no zeroing moves are emitted for them (24 v_mov per 128 k otherwise)
-typedef int i32x6 __attribute__((ext_vector_type(6)));
 #define FQ_FRAG(R) __builtin_shufflevector(i32x6{(int)R[0].x, (int)R[0].y, (int)R[1].x, (int)R[1].y, (int)R[2].x, (int)R[2].y}, \
                                            i32x6{0, 0, 0, 0, 0, 0}, 0, 1, 2, 3, 4, 5, -1, -1)
-#define FQ_COMPUTE(RW, RX)                                                                                          \
-    {                                                                                                                \
-        i32x8 wf[2], xf[TMT];                                                                                        \
-        _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) wf[tn] = FQ_FRAG(RW[tn]);                                   \
-        _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm) xf[tm] = FQ_FRAG(RX[tm]);                                 \
-        if (ABL & 1) {                                                                                               \
-            _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm)      \
-                acc[tn][tm][0] += (float)(wf[tn][0] ^ xf[tm][5]);                                                    \
-        } else {                                                                                                     \
-        _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm)          \
-            acc[tn][tm] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[tn], xf[tm], acc[tn][tm], 3, 3, 0,       \
-                                                                          0x7f7f7f7f, 0, 0x7f7f7f7f);               \
-        }                                                                                                            \
+#define FQ_MFMA1(RW, RX, I)                                                                                          \
+    acc[(I) / TMT][(I) % TMT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(FQ_FRAG(RW[(I) / TMT]), FQ_FRAG(RX[(I) % TMT]), \
+                                                                                acc[(I) / TMT][(I) % TMT], 3, 3, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+// fragment I of a block: I < 2 the weight row tiles, then the TMT token row tiles; three conflict-free 8-byte reads
+#define FQ_READ1(ST, KBL, RW, RX, I)                                                                                 \
+    if ((I) < 2) {                                                                                                   \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) RW[(I) < 2 ? (I) : 0][p] =                                     \
+            *reinterpret_cast<const uint2*>((ST) + woff + ((I) < 2 ? (I) : 0) * SEG + (KBL) * BLOB + p * 512);       \
+    } else if ((I) < 2 + TMT) {                                                                                      \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) RX[(I) >= 2 && (I) < 2 + TMT ? (I) - 2 : 0][p] =               \
+            *reinterpret_cast<const uint2*>((ST) + xoff + ((I) >= 2 && (I) < 2 + TMT ? (I) - 2 : 0) * SEG + (KBL) * BLOB + p * 512); \
     }
+    static_assert(2 + TMT <= 2 * TMT && DPW <= 2 * TMT, "a block has enough MFMAs to carry its successor's fragments and the DMA share");
+    auto half_a = [&](const unsigned char* st) {   // block 0 of a stage from r0, block 1's fragments into r1
 #pragma unroll
-    for (int p = 0; p < STAGES; ++p)
-        if (p < nk) issue_stage(p);
-    {
+        for (int i = 0; i < 2 * TMT; ++i) {
+            FQ_MFMA1(r0w, r0x, i)
+            FQ_READ1(st, 1, r1w, r1x, i)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto half_b = [&](const unsigned char* sn, int s_dma, auto dma_c, auto next_c) {   // block 1 from r1, the next stage's block 0 into r0
+#pragma unroll
+        for (int i = 0; i < 2 * TMT; ++i) {
+            FQ_MFMA1(r1w, r1x, i)
+            if (decltype(dma_c)::value && i < DPW) issue_one(s_dma, i);
+            if (decltype(next_c)::value) { FQ_READ1(sn, 0, r0w, r0x, i) }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    int vb = blockIdx.x, mb = 0, nb = 0;
+    if (!next_tile(vb, mb, nb)) return;
+    plan(mb, nb);
+    request_first_stages();
+    {   // the first tile starts as soon as its first stage is there
         const int younger = nk - 1 < STAGES - 1 ? nk - 1 : STAGES - 1;
         if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * DPW) : "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-#if FQ_BF6_WAVES == 16
-    // 16-wave build: four waves per SIMD hide the fragment reads of each other, so a wave reads and multiplies one 64-k
-    // block at a time with a single fragment buffer (<= 128 VGPRs)
-    for (int s = 0; s < nk; ++s) {
-        const unsigned char* st = smem + (s % STAGES) * TILE_BYTES;
-        FQ_READ(st, 0, r0w, r0x)
-        FQ_COMPUTE(r0w, r0x)
-        __builtin_amdgcn_sched_barrier(0);
-        FQ_READ(st, 1, r0w, r0x)
-        FQ_COMPUTE(r0w, r0x)
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < nk) {
-            const int younger = nk - 2 - s < STAGES - 2 ? nk - 2 - s : STAGES - 2;
-            if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(DPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (s + STAGES < nk) issue_stage(s + STAGES);
-        }
-    }
-#else
-    FQ_READ(smem, 0, r0w, r0x)
-    for (int s = 0; s < nk; ++s) {
-        const unsigned char* st = smem + (s % STAGES) * TILE_BYTES;
-        if (!(ABL & 2) || s == 0) FQ_READ(st, 1, r1w, r1x)
-        FQ_COMPUTE(r0w, r0x)
-        __builtin_amdgcn_sched_barrier(0);  // these MFMAs cover the reads above; hipcc otherwise sinks them below the barrier
-        if (s + 1 < nk) {
-            const int younger = nk - 2 - s < STAGES - 2 ? nk - 2 - s : STAGES - 2;
-            if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(DPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // every wave holds all of stage s in registers: its buffer is free
-#if !FQ_BF6_LATE_DMA
-            if (s + STAGES < nk && !(ABL & 4)) issue_stage(s + STAGES);
-#endif
-            const unsigned char* sn = smem + ((s + 1) % STAGES) * TILE_BYTES;
-            if (!(ABL & 2)) FQ_READ(sn, 0, r0w, r0x)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        FQ_COMPUTE(r1w, r1x)
-        __builtin_amdgcn_sched_barrier(0);
-#if FQ_BF6_LATE_DMA   // refill the freed buffer AFTER the second half's MFMAs are queued: shortens barrier -> first MFMA
-        if (s + 1 < nk && s + STAGES < nk && !(ABL & 4)) issue_stage(s + STAGES);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
-#endif
-#undef FQ_READ
-#undef FQ_FRAG
-#undef FQ_COMPUTE
-
-    // ---- epilogue: lane (h, c) of tile (tn, tm): n = n0 + 64 wn + 32 tn + 16 h + r, token m = m0 + 128 wm + 32 tm + c
+    for (;;) {
+        const int m0 = mb * BM, n0 = nb * BN;
+        static_assert(TMT == 4, "the asm statement behind the K loop names sr[0..3]");
+        f16 sr[TMT] = {};
+        u32x4 sc[2][2] = {}, bs[2][2] = {};
 #pragma unroll
-    for (int tm = 0; tm < TMT; ++tm) {
-        const int m = m0 + wm * (TMT * 32) + tm * 32 + c;
-        if (m >= M) continue;
-        if ((ABL & 16) && (c & 7)) continue;
+        for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int nbase = n0 + wn * 64 + tn * 32 + 16 * h;
-            if (nbase >= N) continue;  // N % 16 == 0
-            int v[16];
+            for (int tm = 0; tm < TMT; ++tm) acc[tn][tm] = f32x16{0};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = (int)acc[tn][tm][r];  // an integer below 2^24: exact
-            if (out.c != nullptr) {
-                int4* cp = reinterpret_cast<int4*>(out.c + (int64_t)m * N + nbase);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) cp[g] = make_int4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        for (int i = 0; i < 2 + TMT; ++i) { FQ_READ1(smem, 0, r0w, r0x, i) }
+        {
+            int s = 0;
+            for (; s + STAGES < nk; ++s) {   // stages whose buffer is refilled
+                half_a(smem + (s % STAGES) * TILE_BYTES);
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(DPW) : "memory");   // stage s + 1 has landed (s + 2 may be in flight)
+                __builtin_amdgcn_s_barrier();   // ... for every wave, and every wave holds all of stage s in registers: its buffer is free
+                half_b(smem + ((s + 1) % STAGES) * TILE_BYTES, s + STAGES, std::true_type{}, std::true_type{});
             }
+            for (; s + 1 < nk; ++s) {        // the last STAGES - 1 stages with a successor: nothing left to request
+                half_a(smem + (s % STAGES) * TILE_BYTES);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                half_b(smem + ((s + 1) % STAGES) * TILE_BYTES, 0, std::false_type{}, std::true_type{});
+            }
+            half_a(smem + (s % STAGES) * TILE_BYTES);   // the last stage
+            // the epilogue's scales, requested under the last eight MFMAs (the fragment registers of the next block are free)
             if (out.y != nullptr) {
-                f16x8 o0, o1;
-                dequant16(v, out.srow[m], out.scol + nbase, out.bias != nullptr ? out.bias + nbase : nullptr, o0, o1);
-                uint4* yp = reinterpret_cast<uint4*>(out.y + (int64_t)m * N + nbase);
-                if (!(ABL & 8) || o0[0] == (f16)12345.0f) {
+#pragma unroll
+                for (int tm = 0; tm < TMT; ++tm) {
+                    const int m = m0 + wm * (TMT * 32) + tm * 32 + c;
+                    sr[tm] = out.srow[m < M ? m : M - 1];
+                }
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    int nbase = n0 + wn * 64 + tn * 32 + 16 * h;
+                    nbase = nbase < N ? nbase : N - 16;   // N % 16 == 0; runs beyond N are never stored
+                    sc[tn][0] = *reinterpret_cast<const u32x4*>(out.scol + nbase);
+                    sc[tn][1] = *reinterpret_cast<const u32x4*>(out.scol + nbase + 8);
+                    if (out.bias != nullptr) {
+                        bs[tn][0] = *reinterpret_cast<const u32x4*>(out.bias + nbase);
+                        bs[tn][1] = *reinterpret_cast<const u32x4*>(out.bias + nbase + 8);
+                    }
+                }
+            }
+            half_b(smem, 0, std::false_type{}, std::false_type{});
+        }
+
+        // The scales are waited for HERE (hipcc puts its s_waitcnt in front of this statement), before the next tile's requests go
+        // out: the LDS-DMA instructions are inline asm, invisible to the compiler's vmcnt bookkeeping — a later "all but my last
+        // seven loads" of its own would wait for eleven of the eighteen requests instead.
+        asm volatile("" : "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]), "+v"(sc[0][0]), "+v"(sc[0][1]), "+v"(sc[1][0]),
+                     "+v"(sc[1][1]), "+v"(bs[0][0]), "+v"(bs[0][1]), "+v"(bs[1][0]), "+v"(bs[1][1]));
+        // the next tile of this workgroup: its first stages are requested NOW, in front of the epilogue
+        int nvb = vb + (int)gridDim.x, nmb = 0, nnb = 0;
+        const bool more = next_tile(nvb, nmb, nnb);
+        if (more) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // every wave has read the last stage: all three buffers are free
+            plan(nmb, nnb);
+            request_first_stages();
+        }
+
+        // ---- epilogue: lane (h, c) of tile (tn, tm): n = n0 + 64 wn + 32 tn + 16 h + r, token m = m0 + 128 wm + 32 tm + c
+#pragma unroll
+        for (int tm = 0; tm < TMT; ++tm) {
+            const int m = m0 + wm * (TMT * 32) + tm * 32 + c;
+            if (m >= M) continue;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const int nbase = n0 + wn * 64 + tn * 32 + 16 * h;
+                if (nbase >= N) continue;  // N % 16 == 0
+                if (out.c != nullptr) {
+                    int v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = (int)acc[tn][tm][r];  // an integer below 2^24: exact
+                    int4* cp = reinterpret_cast<int4*>(out.c + (int64_t)m * N + nbase);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) cp[g] = make_int4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+                }
+                if (out.y != nullptr) {
+                    f16x8 o0, o1;
+                    dequant16f(acc[tn][tm], sr[tm], __builtin_bit_cast(f16x8, sc[tn][0]), __builtin_bit_cast(f16x8, sc[tn][1]),
+                               out.bias != nullptr, __builtin_bit_cast(f16x8, bs[tn][0]), __builtin_bit_cast(f16x8, bs[tn][1]), o0, o1);
+                    uint4* yp = reinterpret_cast<uint4*>(out.y + (int64_t)m * N + nbase);
                     yp[0] = __builtin_bit_cast(uint4, o0);
                     yp[1] = __builtin_bit_cast(uint4, o1);
                 }
             }
         }
+        if (!more) break;
+        vb = nvb;
+        mb = nmb;
+        nb = nnb;
+        // The requested stages have had the whole epilogue to land. An interior tile with the fused epilogue alone issued exactly
+        // 4 TMT stores behind them (vmcnt counts loads and stores in issue order on gfx9): the wait leaves those in flight — they
+        // drain under the next tile's first stages. Every other case waits for everything.
+        if (out.c == nullptr && m0 + BM <= M && n0 + BN <= N) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * TMT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
+#undef FQ_FRAG
+#undef FQ_MFMA1
+#undef FQ_READ1
 }
 
 }  // namespace
@@ -306,26 +346,21 @@ int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, in
     o.srow = srow;
     o.scol = scol;
     o.bias = bias;
-    const int64_t blocks = 8 * ((((M + BM - 1) / BM) * ((N + BN - 1) / BN) + 7) / 8);  // see xcd_tile
-#ifdef FQ_MEASURE  // measurement builds only (tools/scratch/gemm_ablate.sh): ablation selected from the environment
-    const char* e = getenv("FQ_GEMM_ABLATE");
-    const int abl = e ? atoi(e) : 0;
-#else
-    constexpr int abl = 0;
-#endif
-#define FQ_LAUNCH(A)                                                                                                 \
-    {                                                                                                                \
-        FQ_RAISE_LDS_CAP(fq_gemm_bf6_kernel<A>, STAGES * TILE_BYTES);                                                \
-        hipLaunchKernelGGL(fq_gemm_bf6_kernel<A>, dim3((unsigned)blocks), dim3(GT), STAGES * TILE_BYTES, stream, xblob, \
-                           wblob, (int)M, N, K / 64, o);                                                             \
+    const int64_t n_vblocks = 8 * ((((M + BM - 1) / BM) * ((N + BN - 1) / BN) + 7) / 8);  // see xcd_tile
+    // persistent workgroups: one per CU (144 KB of LDS each), a multiple of 8 so that a workgroup stays on its XCD's share
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
     }
-    if (abl == 1) FQ_LAUNCH(1)
-    else if (abl == 2) FQ_LAUNCH(2)
-    else if (abl == 4) FQ_LAUNCH(4)
-    else if (abl == 6) FQ_LAUNCH(6)
-    else if (abl == 8) FQ_LAUNCH(8)
-    else if (abl == 16) FQ_LAUNCH(16)
-    else FQ_LAUNCH(0)
-#undef FQ_LAUNCH
+    int64_t blocks = (cus[dev] / 8) * 8;
+    if (blocks < 8) blocks = 8;
+    if (blocks > n_vblocks) blocks = n_vblocks;
+    FQ_RAISE_LDS_CAP(fq_gemm_bf6_kernel, STAGES * TILE_BYTES);
+    hipLaunchKernelGGL(fq_gemm_bf6_kernel, dim3((unsigned)blocks), dim3(GT), STAGES * TILE_BYTES, stream, xblob, wblob, (int)M, N,
+                       K / 64, (int)n_vblocks, o);
     return (int)hipGetLastError();
 }

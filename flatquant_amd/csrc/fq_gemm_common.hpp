@@ -58,6 +58,43 @@ __device__ __forceinline__ void dequant16(const int (&q)[16], f16 srow, const f1
     }
 }
 
+// The same from the accumulator AS A FLOAT (the FP6 path's fp32 accumulator holds the exact integer; the int8 path converts once):
+// int(q / 10.0f) == trunc(fl(q * 0.1f)) for EVERY |q| <= 2^24 — checked exhaustively on the CPU (numpy, IEEE fp32): 0.1f lies
+// 1.5e-8 (relative) above 1/10 and the product's rounding adds at most 0.0625, together < 0.1, the distance of q / 10 from the next
+// integer below its magnitude — so the division becomes v_mul_f32 + v_trunc_f32, the clamp one v_med3_f32, and the value never
+// leaves the float pipeline: 6 VALU per element instead of 11 (second session of round 3: the epilogue was 5.9 us of every
+// 256 x 256 tile, four tiles per CU at 16384 x 4096 x 4096). Bit-identical to dequant1 / dequant16 (tests/test_gpu_gemm.py).
+// (the 16 column scales and biases arrive in registers: the FP6-path kernel loads them under its last MFMAs)
+__device__ __forceinline__ void dequant16f(const f32x16& q, f16 srow, f16x8 s0, f16x8 s1, bool has_bias, f16x8 b0, f16x8 b1,
+                                           f16x8& o0, f16x8& o1) {
+    const f16x2 sr2 = {srow, srow}, ten2 = {(f16)10.0f, (f16)10.0f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {   // element pairs (2j, 2j + 1) of the 16
+        const int e = 2 * j;
+        float t0 = q[e] * 0.1f, t1 = q[e + 1] * 0.1f;
+        asm volatile("" : "+v"(t0), "+v"(t1));   // fp32 VALUES (the product rounded to fp32 before the truncation)
+        // (+ 0.0f: trunc(-0.3) is -0.0 where the int of the reference converts to +0.0; -0.0 + 0.0 = +0.0)
+        t0 = __builtin_amdgcn_fmed3f(__builtin_truncf(t0) + 0.0f, -65176.0f, 65176.0f);
+        t1 = __builtin_amdgcn_fmed3f(__builtin_truncf(t1) + 0.0f, -65176.0f, 65176.0f);
+        const f16x2 iv = {(f16)t0, (f16)t1};
+        const f16x2 sc = e < 8 ? f16x2{s0[e], s0[e + 1]} : f16x2{s1[e - 8], s1[e - 7]};
+        f16x2 r = sr2 * sc;
+        r = r * iv;
+        r = r * ten2;
+        if (e < 8) {
+            o0[e] = r[0];
+            o0[e + 1] = r[1];
+        } else {
+            o1[e - 8] = r[0];
+            o1[e - 7] = r[1];
+        }
+    }
+    if (has_bias) {
+        o0 = o0 + b0;
+        o1 = o1 + b1;
+    }
+}
+
 // XCD-aware tile order. Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own 4 MB L2. XCD x
 // takes a CONTIGUOUS share of the tile sequence, and the sequence walks 8-feature-tile-wide column blocks row by row,
 // so the ~32 workgroups resident on an XCD at a time form a 4 x 8 patch of tiles: 12 distinct operand tiles per K

@@ -1,0 +1,99 @@
+// Same-wave interleaving against phase alternation (gfx950): per iteration a wave issues 32 x v_mfma_f32_32x32x16_f16 and NV
+// single-width VALU instructions of the quantiser's mix (v_fma_f32, v_lshl_add_u32, v_max3_f32, v_cvt_pk_f16_f32) — the work of
+// one 64 x 64 token of fq_kron64_kernel (32 MFMAs, ~480 VALU) —
+//   PHASE:  32 MFMAs, then NV VALU                      (what the kernels do today: the hardware arbiter overlaps waves)
+//   MIXED:  (1 MFMA, NV / 32 VALU) x 32, independent    (a software-pipelined token loop: token i + 1's MFMAs between token i's
+//                                                         quantiser instructions)
+// at W waves per SIMD. Reported: shader cycles per iteration per SIMD (all W waves), and per wave-iteration.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/scratch/interleave tools/scratch/interleave.hip && gpurun -- tools/scratch/interleave
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define V8(a, b, ia)                                                                        \
+    asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[0]) : "v"(b[0]));                      \
+    asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[1]) : "v"(b[1]));                      \
+    asm volatile("v_lshl_add_u32 %0, %0, 4, %1" : "+v"(ia[0]) : "v"(ia[1]));                \
+    asm volatile("v_lshl_add_u32 %0, %0, 4, %1" : "+v"(ia[2]) : "v"(ia[3]));                \
+    asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[2]) : "v"(b[2]));                      \
+    asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[3]) : "v"(b[3]), "v"(b[4]));          \
+    asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(a[4]) : "v"(b[5]));                   \
+    asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(a[5]) : "v"(b[6]), "v"(b[7]));
+
+template <int NV, int MODE>   // MODE 0: MFMA only, 1: VALU only, 2: PHASE, 3: MIXED
+__global__ __launch_bounds__(1024) void k(unsigned long long* out, float seed, int iters) {
+    float a[8], b[8];
+    unsigned ia[8];
+    for (int i = 0; i < 8; ++i) {
+        a[i] = seed + i + threadIdx.x;
+        b[i] = seed * i;
+        ia[i] = threadIdx.x * 7 + i;
+    }
+    f16x8 fa, fb;
+    for (int j = 0; j < 8; ++j) {
+        fa[j] = (_Float16)(seed + j);
+        fb[j] = (_Float16)(seed - j);
+    }
+    f32x16 acc[4] = {};
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0 || MODE == 2) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) acc[r & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[r & 3], 0, 0, 0);
+        }
+        if (MODE == 4 || MODE == 5) {   // accumulators in AGPRs (the matrix pipe's own register file ports)
+#pragma unroll
+            for (int r = 0; r < 32; ++r) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[r & 3]) : "v"(fa), "v"(fb));
+        }
+        if (MODE == 1 || MODE == 2 || MODE == 5) {
+#pragma unroll
+            for (int u = 0; u < NV / 8; ++u) { V8(a, b, ia) }
+        }
+        if (MODE == 3) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[r & 3]) : "v"(fa), "v"(fb));
+#pragma unroll
+                for (int u = 0; u < NV / 256; ++u) { V8(a, b, ia) }   // NV / 32 VALU behind every MFMA
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += a[i] + (float)ia[i];
+    for (int c = 0; c < 4; ++c) s += acc[c][0];
+    if (s == 12345.678f) out[1] = 1;
+    if ((threadIdx.x & 63) == 0) atomicMax(&out[0], t1 - t0);
+}
+
+template <int NV, int MODE>
+static double run(unsigned long long* d, int threads) {
+    const int iters = 64;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipMemset(d, 0, 16);
+        k<NV, MODE><<<256, threads>>>(d, 1.0f, iters);
+    }
+    unsigned long long h = 0;
+    hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+    return (double)h / iters;
+}
+
+int main() {
+    unsigned long long* d;
+    hipMalloc(&d, 16);
+    for (int threads : {256, 512, 1024}) {
+        const int w = threads / 256;
+        const double mf = run<512, 0>(d, threads), va = run<512, 1>(d, threads), ph = run<512, 2>(d, threads), mx = run<512, 3>(d, threads);
+        printf("%d wave(s)/SIMD, 32 MFMA + 512 VALU per wave-iteration: mfma-only %7.0f  valu-only %7.0f  PHASE %7.0f  MIXED %7.0f cycles per "
+               "iteration of all waves  (per wave-iteration: phase %6.0f, mixed %6.0f; sum %6.0f)\n",
+               w, mf, va, ph, mx, ph / w, mx / w, (mf + va) / w);
+        const double mfa = run<512, 4>(d, threads), pha = run<512, 5>(d, threads);
+        printf("%d wave(s)/SIMD, accumulators in AGPRs: mfma-only %7.0f  PHASE %7.0f\n", w, mfa, pha);
+        const double va2 = run<256, 1>(d, threads), ph2 = run<256, 2>(d, threads), mx2 = run<256, 3>(d, threads);
+        printf("%d wave(s)/SIMD, 32 MFMA + 256 VALU per wave-iteration: mfma-only %7.0f  valu-only %7.0f  PHASE %7.0f  MIXED %7.0f\n", w, mf, va2,
+               ph2, mx2);
+    }
+    return 0;
+}

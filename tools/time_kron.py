@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel time of fq_kron_quant_{f16,bf16} through the C ABI with pre-allocated, rotating buffers (no torch allocation,
 no Python module path inside the timed loop), one line per case:
-    tools/time_kron.py [M N rows mode dtype] ...      mode = packed | fq | y | fqy | packed3 | h16   dtype = f16 | bf16
+    tools/time_kron.py [M N rows mode dtype] ...      mode = packed | packedr | fq | y | fqy | packed3 | h16   dtype = f16 | bf16
     (h16: fq_kron_quant_ex_f16 with the deploy Quantizer's fp16 arithmetic and a post-scale — a Hadamard rotation as one launch)
 Without arguments: the table of the fake-quant contract (FlatQuantizedLinear._eval_forward) next to the packed one.
 Prints us per launch (HIP events over 100 launches, median of 5 rounds), algorithmic GB/s and the fraction of 8 TB/s."""
@@ -20,9 +20,10 @@ lib = _lib.lib
 P4 = ctypes.c_void_p * 4
 F4 = ctypes.c_float * 4
 FLAGS = {"packed": 0x01 | 0x10, "fq": 0x02 | 0x08, "y": 0x04, "fqy": 0x02 | 0x04 | 0x08, "packed3": 0x01 | 0x10,
+         "packedr": 0x01 | 0x08,   # the deploy flags of a pair with M > 64 (deploy_kron_flags): Y through fp16, extrema clamped
          "h16": 0x01 | 0x08 | 0x20 | 0x400}
 BYTES = {"packed": lambda d: 2.5 * d + 2, "fq": lambda d: 4.0 * d, "y": lambda d: 4.0 * d, "fqy": lambda d: 6.0 * d,
-         "packed3": lambda d: 2.0 * d + 3 * (0.5 * d + 2), "h16": lambda d: 2.5 * d + 2}
+         "packed3": lambda d: 2.0 * d + 3 * (0.5 * d + 2), "packedr": lambda d: 2.5 * d + 2, "h16": lambda d: 2.5 * d + 2}
 
 
 def time_case(M, N, rows, mode, dtype="f16", rounds=5, steps=100, sig=0.9820137619972229):
@@ -35,7 +36,7 @@ def time_case(M, N, rows, mode, dtype="f16", rounds=5, steps=100, sig=0.98201376
     L = (torch.randn(M, M, generator=g, device="cuda") / M ** 0.5).to(td)
     R = (torch.randn(N, N, generator=g, device="cuda") / N ** 0.5).to(td)
     nclip = 3 if mode == "packed3" else 1
-    qs = [[torch.empty(rows, d // 2, dtype=torch.uint8, device="cuda") for _ in range(nclip)] for _ in range(nb)] if mode in ("packed", "packed3", "h16") else None
+    qs = [[torch.empty(rows, d // 2, dtype=torch.uint8, device="cuda") for _ in range(nclip)] for _ in range(nb)] if mode in ("packed", "packedr", "packed3", "h16") else None
     ss = [torch.empty(rows, dtype=td, device="cuda") for _ in range(nclip)]
     fqs = [torch.empty(rows, d, dtype=td, device="cuda") for _ in range(nb)] if "fq" in mode else None
     ys = [torch.empty(rows, d, dtype=td, device="cuda") for _ in range(nb)] if "y" in mode else None
