@@ -113,6 +113,7 @@ __global__ __launch_bounds__(GT, GW / 4) void fq_gemm_bf6_kernel(const uint8_t* 
     const int wm = wave % NWM, wn = wave / NWM;  // wave tile: tokens (32 TMT) wm .., features 64 wn ..
     const int TMg = (M + BM - 1) / BM, TNg = (N + BN - 1) / BN;
     const int nk = KB / 2;  // stages of 128 k
+    const bool may_clamp = KB > 10176 / 64;   // |q| <= 64 K: beyond K = 10176 the epilogue's clamp to +-65176 (x 10) can bind
     const int mt_last = (M + 31) / 32 - 1, nt_last = (N + 31) / 32 - 1;
 
     // DMA plan: instruction i = 6 wave + j: operand i / 24 (0 = W), row tile (i % 24) / 3, 1 KB part i % 3 of its 3 KB.
@@ -295,8 +296,12 @@ __global__ __launch_bounds__(GT, GW / 4) void fq_gemm_bf6_kernel(const uint8_t* 
                 }
                 if (out.y != nullptr) {
                     f16x8 o0, o1;
-                    dequant16f(acc[tn][tm], sr[tm], __builtin_bit_cast(f16x8, sc[tn][0]), __builtin_bit_cast(f16x8, sc[tn][1]),
-                               out.bias != nullptr, __builtin_bit_cast(f16x8, bs[tn][0]), __builtin_bit_cast(f16x8, bs[tn][1]), o0, o1);
+                    if (may_clamp)
+                        dequant16f<true>(acc[tn][tm], sr[tm], __builtin_bit_cast(f16x8, sc[tn][0]), __builtin_bit_cast(f16x8, sc[tn][1]),
+                                         out.bias != nullptr, __builtin_bit_cast(f16x8, bs[tn][0]), __builtin_bit_cast(f16x8, bs[tn][1]), o0, o1);
+                    else
+                        dequant16f<false>(acc[tn][tm], sr[tm], __builtin_bit_cast(f16x8, sc[tn][0]), __builtin_bit_cast(f16x8, sc[tn][1]),
+                                          out.bias != nullptr, __builtin_bit_cast(f16x8, bs[tn][0]), __builtin_bit_cast(f16x8, bs[tn][1]), o0, o1);
                     uint4* yp = reinterpret_cast<uint4*>(out.y + (int64_t)m * N + nbase);
                     yp[0] = __builtin_bit_cast(uint4, o0);
                     yp[1] = __builtin_bit_cast(uint4, o1);

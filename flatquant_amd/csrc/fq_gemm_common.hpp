@@ -18,65 +18,36 @@ __device__ __forceinline__ f16 dequant1(int q, f16 srow, f16 scol) {
     return r * (f16)10.0f;
 }
 
-// The same for a lane's 16 consecutive features of one token (the tile kernels' epilogue), 8 VALU per element instead of ~40
-// (round 3: the epilogue had grown to the cost of the whole K loop — 42.7 M VALU against 4.2 M MFMA per 16384 x 4096 x 4096
-// launch, profiles/r03_gemm_bf6_pmc.txt). Bit-identical to dequant1:
-//   * int(q / 10.0f) == q / 10 (C integer division, toward zero) for every |q| < 2^24: q / 10 = k + f/10 lies at least 0.1 from
-//     an integer unless it is one, and the fp32 quotient is within half an ulp <= 0.0625 (|q / 10| < 2^21) of it;
-//   * half(iv) of |iv| <= 65176 through fp32 is one rounding (the int is exact in fp32);
-//   * the three fp16 products are formed two elements per instruction (v_pk_mul_f16 rounds each half like v_mul_f16);
-//   * the 16 column scales (and biases) are two 16-byte loads, not 16 two-byte loads.
-__device__ __forceinline__ void dequant16(const int (&q)[16], f16 srow, const f16* __restrict__ scol16, const f16* __restrict__ bias16,
-                                          f16x8& o0, f16x8& o1) {
-    const uint4 c0 = *reinterpret_cast<const uint4*>(scol16), c1 = *reinterpret_cast<const uint4*>(scol16 + 8);
-    const f16x8 s0 = __builtin_bit_cast(f16x8, c0), s1 = __builtin_bit_cast(f16x8, c1);
-    const f16x2 sr2 = {srow, srow}, ten2 = {(f16)10.0f, (f16)10.0f};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {   // element pairs (2j, 2j + 1) of the 16
-        const int e = 2 * j;
-        int i0 = q[e] / 10, i1 = q[e + 1] / 10;
-        i0 = max(-65176, min(65176, i0));
-        i1 = max(-65176, min(65176, i1));
-        const f16x2 iv = {(f16)(float)i0, (f16)(float)i1};
-        const f16x2 sc = e < 8 ? f16x2{s0[e], s0[e + 1]} : f16x2{s1[e - 8], s1[e - 7]};
-        f16x2 r = sr2 * sc;
-        r = r * iv;
-        r = r * ten2;
-        if (e < 8) {
-            o0[e] = r[0];
-            o0[e + 1] = r[1];
-        } else {
-            o1[e - 8] = r[0];
-            o1[e - 7] = r[1];
-        }
-    }
-    if (bias16 != nullptr) {
-        const f16x8 b0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(bias16));
-        const f16x8 b1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(bias16 + 8));
-        o0 = o0 + b0;
-        o1 = o1 + b1;
-    }
-}
-
-// The same from the accumulator AS A FLOAT (the FP6 path's fp32 accumulator holds the exact integer; the int8 path converts once):
+// The same for a lane's 16 consecutive features of one token (the tile kernels' epilogue). Round 3, first form (dequant16, 11 VALU
+// per element instead of the ~40 of sixteen dequant1 calls — the epilogue had grown to the cost of the whole K loop: 42.7 M VALU
+// against 4.2 M MFMA per 16384 x 4096 x 4096 launch, profiles/r03_gemm_bf6_pmc.txt): integer division by 10 (== int(q / 10.0f) for
+// |q| < 2^24), the three fp16 products two elements per instruction (v_pk_mul_f16 rounds each half like v_mul_f16), the 16 column
+// scales (and biases) as two 16-byte loads. Replaced by the float-pipeline form below.
+// From the accumulator AS A FLOAT (the FP6 path's fp32 accumulator holds the exact integer; the int8 path converts once):
 // int(q / 10.0f) == trunc(fl(q * 0.1f)) for EVERY |q| <= 2^24 — checked exhaustively on the CPU (numpy, IEEE fp32): 0.1f lies
 // 1.5e-8 (relative) above 1/10 and the product's rounding adds at most 0.0625, together < 0.1, the distance of q / 10 from the next
 // integer below its magnitude — so the division becomes v_mul_f32 + v_trunc_f32, the clamp one v_med3_f32, and the value never
-// leaves the float pipeline: 6 VALU per element instead of 11 (second session of round 3: the epilogue was 5.9 us of every
-// 256 x 256 tile, four tiles per CU at 16384 x 4096 x 4096). Bit-identical to dequant1 / dequant16 (tests/test_gpu_gemm.py).
+// leaves the float pipeline: 4 - 5 VALU per element instead of 11 (second session of round 3: the epilogue was 5.9 us of every
+// 256 x 256 tile, four tiles per CU at 16384 x 4096 x 4096). Bit-identical to dequant1 (tests/test_gpu_gemm_*.py against the integer oracle).
 // (the 16 column scales and biases arrive in registers: the FP6-path kernel loads them under its last MFMAs)
+// Two elements per instruction where gfx950 has one: v_pk_mul_f32 for the 0.1, v_pk_add_f32 for the + 0.0 (trunc(-0.3) is -0.0 where
+// the int of the reference converts to +0.0; -0.0 + 0.0 = +0.0), v_cvt_pk_f16_f32, v_pk_mul_f16 x 3. CLAMP = false when the caller
+// knows |q| <= 651760 (K <= 10176: every product is at most 64): the clamp of quant.cu:78 to +-65176 cannot bind.
+template <bool CLAMP>
 __device__ __forceinline__ void dequant16f(const f32x16& q, f16 srow, f16x8 s0, f16x8 s1, bool has_bias, f16x8 b0, f16x8 b1,
                                            f16x8& o0, f16x8& o1) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     const f16x2 sr2 = {srow, srow}, ten2 = {(f16)10.0f, (f16)10.0f};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {   // element pairs (2j, 2j + 1) of the 16
         const int e = 2 * j;
-        float t0 = q[e] * 0.1f, t1 = q[e + 1] * 0.1f;
-        asm volatile("" : "+v"(t0), "+v"(t1));   // fp32 VALUES (the product rounded to fp32 before the truncation)
-        // (+ 0.0f: trunc(-0.3) is -0.0 where the int of the reference converts to +0.0; -0.0 + 0.0 = +0.0)
-        t0 = __builtin_amdgcn_fmed3f(__builtin_truncf(t0) + 0.0f, -65176.0f, 65176.0f);
-        t1 = __builtin_amdgcn_fmed3f(__builtin_truncf(t1) + 0.0f, -65176.0f, 65176.0f);
-        const f16x2 iv = {(f16)t0, (f16)t1};
+        f32x2 t = f32x2{q[e], q[e + 1]} * f32x2{0.1f, 0.1f};   // (rounded to fp32: -ffp-contract=off, and nothing fuses into a truncation)
+        t = f32x2{__builtin_truncf(t.x), __builtin_truncf(t.y)} + f32x2{0.0f, 0.0f};
+        if (CLAMP) {
+            t.x = __builtin_amdgcn_fmed3f(t.x, -65176.0f, 65176.0f);
+            t.y = __builtin_amdgcn_fmed3f(t.y, -65176.0f, 65176.0f);
+        }
+        const f16x2 iv = {(f16)t.x, (f16)t.y};
         const f16x2 sc = e < 8 ? f16x2{s0[e], s0[e + 1]} : f16x2{s1[e - 8], s1[e - 7]};
         f16x2 r = sr2 * sc;
         r = r * iv;
