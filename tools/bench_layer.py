@@ -19,6 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import flatquant_amd.deploy as deploy  # noqa: E402
 
 MODELS = {
+    "llama-2-7b": dict(hidden=4096, ffn=11008, heads=32, head_dim=128, kv_heads=32),   # the model of the reference's own layer benchmark (README.md:288-310)
     "llama-3-8b": dict(hidden=4096, ffn=14336, heads=32, head_dim=128, kv_heads=8),
     "llama-2-70b": dict(hidden=8192, ffn=28672, heads=64, head_dim=128, kv_heads=8),
 }
