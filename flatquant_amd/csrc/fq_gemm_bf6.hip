@@ -42,17 +42,25 @@ using namespace fqgemm;
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_b;
 
-constexpr int BM = 256, BN = 256;
+constexpr int BN = 256;
 constexpr int BLOB = 1536;                     // bytes: 32 rows x 64 k of BF6
 constexpr int SEG = 2 * BLOB;                  // a row tile's two blobs of one stage (128 k)
-constexpr int OPB = 8 * SEG;                   // one operand's share of a stage: 8 row tiles
-constexpr int TILE_BYTES = 2 * OPB;            // 48 KB: [W tiles 0..7][X tiles 0..7]
+constexpr int OPB = 8 * SEG;                   // the weight operand's share of a stage: 8 row tiles
 constexpr int STAGES = 3;
-constexpr int GW = 8, GT = GW * 64;            // 2 x 4 waves of 128 x 64, two per SIMD (tried and dropped, round 3: 4 waves of 256 x 64,
-                                               // 16 waves of 64 x 64, DMA from one wave per SIMD, DMA behind the second half's MFMAs)
-constexpr int NWM = GW / 4;                    // waves along the token dimension (4 along the feature dimension)
-constexpr int TMT = BM / 32 / NWM;             // token tiles per wave
-constexpr int DPW = (TILE_BYTES / 1024) / GW;  // DMA instructions per wave and stage
+constexpr int TMT = 4;                         // token tiles per wave: the wave tile is 128 tokens x 64 features
+// Geometry of a workgroup tile of BM tokens x 256 features: BM / 128 x 4 waves of 128 x 64 (tried and dropped, round 3: waves of
+// 256 x 64 and of 64 x 64, DMA from one wave per SIMD, DMA behind the second half's MFMAs).
+//   BM = 256: 8 waves, two per SIMD, 48 KB per stage — the prefill shape;
+//   BM = 128: 4 waves, 36 KB per stage — twice the tiles for launches that would leave CUs without one (2048 tokens x 4096
+//             features are 128 tiles of 256 x 256 on 256 CUs).
+template <int BM>
+struct Geo {
+    static constexpr int NWM = BM / 128;                      // waves along the token dimension (4 along the feature dimension)
+    static constexpr int GW = 4 * NWM, GT = GW * 64;
+    static constexpr int TILE_BYTES = OPB + (BM / 32) * SEG;  // [W tiles 0..7][X tiles 0..BM/32-1]
+    static constexpr int DPW = (TILE_BYTES / 1024) / GW;      // DMA instructions per wave and stage (6 | 9)
+    static_assert(DPW * GW * 1024 == TILE_BYTES, "whole DMA instructions per wave");
+};
 
 // ---- INT4 nibbles -> BF6 blobs ----------------------------------------------------------------------------------
 // E3M2 codes of 0..8; a negative value sets bit 5
@@ -105,8 +113,10 @@ __global__ __launch_bounds__(256) void fq_i4_to_bf6_kernel(const uint8_t* __rest
 // ---- the GEMM ---------------------------------------------------------------------------------------------------
 typedef int i32x6 __attribute__((ext_vector_type(6)));
 
-__global__ __launch_bounds__(GT, GW / 4) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB, const uint8_t* __restrict__ WB,
-                                                            int M, int N, int KB, int n_vblocks, GemmOut out) {
+template <int BM>
+__global__ __launch_bounds__(Geo<BM>::GT, Geo<BM>::GW / 4) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB, const uint8_t* __restrict__ WB,
+                                                                              int M, int N, int KB, int n_vblocks, GemmOut out) {
+    constexpr int NWM = Geo<BM>::NWM, TILE_BYTES = Geo<BM>::TILE_BYTES, DPW = Geo<BM>::DPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,7 +126,8 @@ __global__ __launch_bounds__(GT, GW / 4) void fq_gemm_bf6_kernel(const uint8_t* 
     const bool may_clamp = KB > 10176 / 64;   // |q| <= 64 K: beyond K = 10176 the epilogue's clamp to +-65176 (x 10) can bind
     const int mt_last = (M + 31) / 32 - 1, nt_last = (N + 31) / 32 - 1;
 
-    // DMA plan: instruction i = 6 wave + j: operand i / 24 (0 = W), row tile (i % 24) / 3, 1 KB part i % 3 of its 3 KB.
+    // DMA plan: instruction i = DPW wave + j: the first 24 the weight row tiles, then the token row tiles; row tile (i % 24) / 3
+    // (resp. (i - 24) / 3), 1 KB part i % 3 of its 3 KB.
     // The source of an instruction is wave-uniform (SGPR base) + 16 * lane: twelve address VGPRs less than per-lane
     // pointers — those had pushed the kernel into a spill whose reload sat between the DMA instructions of a stage
     // behind an s_waitcnt vmcnt(0), i.e. every stage waited for its own loads (found in the ISA, cost ~2x).
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(GT, GW / 4) void fq_gemm_bf6_kernel(const uint8_t* 
 #pragma unroll
         for (int j = 0; j < DPW; ++j) {
             const int i = wave * DPW + j;
-            const int op = i / 24, t = (i % 24) / 3, part = i % 3;
+            const int op = i < 24 ? 0 : 1, t = (i < 24 ? i : i - 24) / 3, part = i % 3;
             int rt = (op == 0 ? nb * BN : mb * BM) / 32 + t;
             const int last = op == 0 ? nt_last : mt_last;
             rt = rt < last ? rt : last;  // tiles beyond the matrix re-read its last tile (their outputs are never stored)
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(GT, GW / 4) void fq_gemm_bf6_kernel(const uint8_t* 
         _Pragma("unroll") for (int p = 0; p < 3; ++p) RX[(I) >= 2 && (I) < 2 + TMT ? (I) - 2 : 0][p] =               \
             *reinterpret_cast<const uint2*>((ST) + xoff + ((I) >= 2 && (I) < 2 + TMT ? (I) - 2 : 0) * SEG + (KBL) * BLOB + p * 512); \
     }
-    static_assert(2 + TMT <= 2 * TMT && DPW <= 2 * TMT, "a block has enough MFMAs to carry its successor's fragments and the DMA share");
+    static_assert(2 + TMT <= 2 * TMT && DPW <= 4 * TMT, "a block has enough MFMAs to carry its successor's fragments and the DMA share");
     auto half_a = [&](const unsigned char* st) {   // block 0 of a stage from r0, block 1's fragments into r1
 #pragma unroll
         for (int i = 0; i < 2 * TMT; ++i) {
@@ -197,7 +208,10 @@ __global__ __launch_bounds__(GT, GW / 4) void fq_gemm_bf6_kernel(const uint8_t* 
 #pragma unroll
         for (int i = 0; i < 2 * TMT; ++i) {
             FQ_MFMA1(r1w, r1x, i)
-            if (decltype(dma_c)::value && i < DPW) issue_one(s_dma, i);
+            if (decltype(dma_c)::value) {   // this step's share of the DPW requests (one, sometimes two)
+#pragma unroll
+                for (int j = i * DPW / (2 * TMT); j < (i + 1) * DPW / (2 * TMT); ++j) issue_one(s_dma, j);
+            }
             if (decltype(next_c)::value) { FQ_READ1(sn, 0, r0w, r0x, i) }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -351,8 +365,7 @@ int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, in
     o.srow = srow;
     o.scol = scol;
     o.bias = bias;
-    const int64_t n_vblocks = 8 * ((((M + BM - 1) / BM) * ((N + BN - 1) / BN) + 7) / 8);  // see xcd_tile
-    // persistent workgroups: one per CU (144 KB of LDS each), a multiple of 8 so that a workgroup stays on its XCD's share
+    // persistent workgroups: one per CU, a multiple of 8 so that a workgroup stays on its XCD's share of the tile sequence
     static int cus[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -361,11 +374,21 @@ int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, in
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         cus[dev] = n;
     }
+    const int64_t tiles256 = ((M + 255) / 256) * ((N + BN - 1) / BN);
+    const bool half = tiles256 * 4 < (int64_t)cus[dev] * 3;   // 256-token tiles would leave a quarter of the CUs (or more) without one
+    const int bm = half ? 128 : 256;
+    const int64_t n_vblocks = 8 * ((((M + bm - 1) / bm) * ((N + BN - 1) / BN) + 7) / 8);  // see xcd_tile
     int64_t blocks = (cus[dev] / 8) * 8;
     if (blocks < 8) blocks = 8;
     if (blocks > n_vblocks) blocks = n_vblocks;
-    FQ_RAISE_LDS_CAP(fq_gemm_bf6_kernel, STAGES * TILE_BYTES);
-    hipLaunchKernelGGL(fq_gemm_bf6_kernel, dim3((unsigned)blocks), dim3(GT), STAGES * TILE_BYTES, stream, xblob, wblob, (int)M, N,
-                       K / 64, (int)n_vblocks, o);
+    if (half) {
+        FQ_RAISE_LDS_CAP(fq_gemm_bf6_kernel<128>, STAGES * Geo<128>::TILE_BYTES);
+        hipLaunchKernelGGL(fq_gemm_bf6_kernel<128>, dim3((unsigned)blocks), dim3(Geo<128>::GT), STAGES * Geo<128>::TILE_BYTES, stream, xblob,
+                           wblob, (int)M, N, K / 64, (int)n_vblocks, o);
+    } else {
+        FQ_RAISE_LDS_CAP(fq_gemm_bf6_kernel<256>, STAGES * Geo<256>::TILE_BYTES);
+        hipLaunchKernelGGL(fq_gemm_bf6_kernel<256>, dim3((unsigned)blocks), dim3(Geo<256>::GT), STAGES * Geo<256>::TILE_BYTES, stream, xblob,
+                           wblob, (int)M, N, K / 64, (int)n_vblocks, o);
+    }
     return (int)hipGetLastError();
 }
