@@ -20,13 +20,18 @@ class Linear4bit(torch.nn.Module):
     per buffer version and kept until ``release_images()``:
       * the decode image (M <= 128 weight-streaming kernel, 4-9 us per linear instead of 46-144): +0.5 B/param, built on
         the first decode-sized call — ON by default (``Linear4bit.decode_image``; FQ_SKINNY_GEMM=0/1 overrides);
-      * the FP6 image (BF6 operands on the FP6 matrix path for K % 128 == 0, N % 16 == 0, N >= 2048: the prefill GEMM runs
-        25-30 % faster, same bits out): +0.75 B/param — OFF by default (``Linear4bit.fp6_image = True`` or
-        FQ_FP6_GEMM=1 turn it on): with both images a layer would sit at 1.75 B/param, 3.5x the INT4 footprint.
-    The default is therefore 1.0 B/param once a layer has decoded, 0.5 before."""
+      * the FP6 image (BF6 operands on the FP6 matrix path for K % 128 == 0, N % 16 == 0: same bits out, the GEMM 1.6x
+        faster than on the int8 path — 16384 x 4096 x 4096: 159 us against 285, profiles/r03_gemm_bf6_pipeline.txt):
+        +0.75 B/param — OFF by default (``Linear4bit.fp6_image = True`` or FQ_FP6_GEMM=1 keep it): with both images a
+        layer would sit at 1.75 B/param, 3.5x the INT4 footprint.
+    Without the kept image a prefill-sized call (>= ``fp6_transient_rows`` tokens) still takes the FP6 path: the weights
+    are converted INTO A TRANSIENT image for the call (12.6 MB for 4096 x 4096: ~8 us, freed with the call — the caching
+    allocator hands the same block to the next layer), which costs 463 / rows of the GEMM's own time and leaves the
+    resident footprint at 0.5 - 1.0 B/param. FQ_FP6_GEMM=0 turns every FP6 route off (int8 matrix path only)."""
 
     decode_image = True   # class-wide policy switches (set on the class or on an instance)
     fp6_image = False
+    fp6_transient_rows = 2048   # calls with at least this many tokens convert the weights for the call when no image is kept (0: never)
 
     def __init__(self, in_features, out_features, bias=False, dtype=torch.float16):
         super().__init__()
@@ -104,6 +109,9 @@ class Linear4bit(torch.nn.Module):
                                            ws16, b16, self.out_features)
                 return y.view(*lead, self.out_features)
         wimg = self._weight_image() if q.is_cuda else None
+        if (wimg is None and q.is_cuda and self.fp6_transient_rows and rows >= self.fp6_transient_rows
+                and os.environ.get("FQ_FP6_GEMM", "") != "0" and ops.bf6_supported(self.out_features, self.in_features)):
+            wimg = ops.int4_to_bf6(self.weight, weights=True)   # transient: lives for this call only
         if wimg is not None:
             q2 = q.reshape(-1, q.shape[-1]).contiguous()
             ws16, b16 = self._scales16()

@@ -95,6 +95,32 @@ def test_module_uses_the_fp6_path_transparently(ops, monkeypatch):
     assert torch.equal(lin(p), ref2) and not torch.equal(ref, ref2)
 
 
+def test_prefill_sized_calls_take_the_fp6_path_with_a_transient_image(ops, monkeypatch):
+    """Default policy (no image kept): >= fp6_transient_rows tokens convert the weights for the call; same bits as the int8 path,
+    nothing cached on the module."""
+    import flatquant_amd.deploy as deploy
+    monkeypatch.delenv("FQ_FP6_GEMM", raising=False)
+    gen = torch.Generator().manual_seed(5)
+    lin = deploy.nn.Linear4bit(256, 272).cuda()
+    lin.weight.copy_(torch.from_numpy(rand_packed(gen, 272, 256)[0]))
+    lin.weight_scales.copy_((torch.rand(272, 1, generator=gen) * 0.02 + 0.001))
+    rows = 2048 + 3
+    xp, _ = rand_packed(gen, rows, 256)
+    p = deploy.PackedQuantizedTensor(torch.from_numpy(xp).cuda().reshape(1, rows, 128),
+                                     (torch.rand(1, 1, rows, generator=gen) * 0.05 + 0.001).half().cuda())
+    calls = []
+    real = ops.int4_to_bf6
+    monkeypatch.setattr(ops, "int4_to_bf6", lambda q, weights=False: (calls.append(weights), real(q, weights))[1])
+    y = lin(p)
+    assert calls.count(True) == 1 and lin.image_bytes() == 0          # the weights were converted for the call and not kept
+    ref = ops.int4_linear(p.quantized_x.reshape(-1, 128), p.scales_x.reshape(-1), lin.weight, lin.weight_scales.reshape(-1).half(),
+                          None).view(1, rows, 272)
+    assert torch.equal(y, ref)
+    calls.clear()
+    lin.fp6_transient_rows = 0                                          # policy off: the int8 matrix path
+    assert torch.equal(lin(p), ref) and not calls
+
+
 def test_errors(ops):
     with pytest.raises(Exception):
         ops.int4_to_bf6(torch.zeros(4, 16, dtype=torch.uint8, device="cuda"))          # K = 32
