@@ -104,7 +104,7 @@ def test_prefill_sized_calls_take_the_fp6_path_with_a_transient_image(ops, monke
     lin = deploy.nn.Linear4bit(256, 272).cuda()
     lin.weight.copy_(torch.from_numpy(rand_packed(gen, 272, 256)[0]))
     lin.weight_scales.copy_((torch.rand(272, 1, generator=gen) * 0.02 + 0.001))
-    rows = 2048 + 3
+    rows = lin.fp6_transient_rows + 3
     xp, _ = rand_packed(gen, rows, 256)
     p = deploy.PackedQuantizedTensor(torch.from_numpy(xp).cuda().reshape(1, rows, 128),
                                      (torch.rand(1, 1, rows, generator=gen) * 0.05 + 0.001).half().cuda())
