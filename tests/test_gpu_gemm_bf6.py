@@ -72,6 +72,46 @@ def test_bf6_linear_equals_int8_path_and_oracle(ops, M, N, K, bias):
     assert np.array_equal(y.cpu().numpy().view(np.uint16), ref.view(np.uint16))
 
 
+@pytest.mark.parametrize("M,N,K", [(4096 + 37, 4096 + 16, 256), (8192, 2048, 128), (2048 + 1, 8192 + 32, 384)])
+def test_persistent_workgroups_many_tiles_bit_exact(ops, M, N, K):
+    """>= 192 tiles of 256 x 256: the 8-wave kernel with persistent workgroups (more tiles than CUs: a workgroup walks two or three,
+    the next tile's stages requested in front of the epilogue), edge tiles in both dimensions, K loops of 1 - 3 stages."""
+    assert ((M + 255) // 256) * ((N + 255) // 256) >= 192
+    gen = torch.Generator().manual_seed(M + 3 * N + K)
+    xp, xq = rand_packed(gen, M, K)
+    wp, wq = rand_packed(gen, N, K)
+    c = ops.bf6_matmul(ops.int4_to_bf6(torch.from_numpy(xp).cuda()), ops.int4_to_bf6(torch.from_numpy(wp).cuda(), weights=True), M, N, K)
+    ref = (xq.astype(np.float64) @ wq.astype(np.float64).T).astype(np.int32)      # |sum| <= 64 K: exact in fp64
+    assert np.array_equal(c.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(4096, 3072, 11776, True), (8192 + 5, 4096, 384, True), (16384, 4096, 256, False),
+                                        (1536 + 9, 4096, 11776, False)])
+def test_linear_many_tiles_and_the_clamp_variant(ops, M, N, K, bias):
+    """The fused sym_dequant epilogue behind the persistent K loop (interior tiles leave their stores in flight: counted vmcnt) and
+    behind the 128-token tiles; K > 10176 takes the epilogue with the +-65176 clamp, and full-scale rows make it bind on both sides
+    (-8 x -8 x 11776 = 753664, -8 x 7 x 11776 = -659456; |q| / 10 > 65176). Same bits as the int8-path kernel everywhere, and as
+    the oracle on a sample of token rows."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    xq = torch.randint(-8, 8, (M, K), generator=gen, dtype=torch.int32).numpy()
+    wq = torch.randint(-8, 8, (N, K), generator=gen, dtype=torch.int32).numpy()
+    if K > 10176:
+        xq[::3] = -8
+        wq[::4] = -8
+        wq[1::4] = 7
+    xp, wp = O.pack_i4(xq), O.pack_i4(wq)
+    sx = (torch.rand(M, generator=gen) * 0.05 + 0.001).half()
+    sw = (torch.rand(N, generator=gen) * 0.02 + 0.0005).half()
+    b = torch.randn(N, generator=gen).half() if bias else None
+    x, w = torch.from_numpy(xp).cuda(), torch.from_numpy(wp).cuda()
+    bb = None if b is None else b.cuda()
+    y = ops.bf6_linear(ops.int4_to_bf6(x), sx.cuda(), ops.int4_to_bf6(w, weights=True), sw.cuda(), bb, M, N, K)
+    assert torch.equal(y.view(torch.int16), ops.int4_linear(x, sx.cuda(), w, sw.cuda(), bb).view(torch.int16))
+    rows = np.unique(np.concatenate([np.arange(0, M, max(1, M // 24)), [M - 1]]))
+    ref = O.linear4bit(xp[rows], sx.numpy()[rows], wp, sw.numpy(), None if b is None else b.numpy())
+    assert np.array_equal(y.cpu().numpy()[rows].view(np.uint16), ref.view(np.uint16))
+
+
 def test_module_uses_the_fp6_path_transparently(ops, monkeypatch):
     import flatquant_amd.deploy as deploy
     monkeypatch.setenv("FQ_FP6_GEMM", "1")
