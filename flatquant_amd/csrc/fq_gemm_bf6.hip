@@ -46,7 +46,6 @@ constexpr int BN = 256;
 constexpr int BLOB = 1536;                     // bytes: 32 rows x 64 k of BF6
 constexpr int SEG = 2 * BLOB;                  // a row tile's two blobs of one stage (128 k)
 constexpr int OPB = 8 * SEG;                   // the weight operand's share of a stage: 8 row tiles
-constexpr int STAGES = 3;
 constexpr int TMT = 4;                         // token tiles per wave: the wave tile is 128 tokens x 64 features
 // Geometry of a workgroup tile of BM tokens x 256 features: BM / 128 x 4 waves of 128 x 64 (tried and dropped, round 3: waves of
 // 256 x 64 and of 64 x 64, DMA from one wave per SIMD, DMA behind the second half's MFMAs).
@@ -59,6 +58,8 @@ struct Geo {
     static constexpr int GW = 4 * NWM, GT = GW * 64;
     static constexpr int TILE_BYTES = OPB + (BM / 32) * SEG;  // [W tiles 0..7][X tiles 0..BM/32-1]
     static constexpr int DPW = (TILE_BYTES / 1024) / GW;      // DMA instructions per wave and stage (6 | 9)
+    static constexpr int STAGES = 3;                          // LDS stages (measured: 128-token tiles with two stages and two workgroups
+                                                              // per CU, forced onto 16384 x 4096 x 4096: 210 us against 157)
     static_assert(DPW * GW * 1024 == TILE_BYTES, "whole DMA instructions per wave");
 };
 
@@ -116,7 +117,7 @@ typedef int i32x6 __attribute__((ext_vector_type(6)));
 template <int BM>
 __global__ __launch_bounds__(Geo<BM>::GT, Geo<BM>::GW / 4) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB, const uint8_t* __restrict__ WB,
                                                                               int M, int N, int KB, int n_vblocks, GemmOut out) {
-    constexpr int NWM = Geo<BM>::NWM, TILE_BYTES = Geo<BM>::TILE_BYTES, DPW = Geo<BM>::DPW;
+    constexpr int NWM = Geo<BM>::NWM, TILE_BYTES = Geo<BM>::TILE_BYTES, DPW = Geo<BM>::DPW, STAGES = Geo<BM>::STAGES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(Geo<BM>::GT, Geo<BM>::GW / 4) void fq_gemm_bf6_kern
             int s = 0;
             for (; s + STAGES < nk; ++s) {   // stages whose buffer is refilled
                 half_a(smem + (s % STAGES) * TILE_BYTES);
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(DPW) : "memory");   // stage s + 1 has landed (s + 2 may be in flight)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"((STAGES - 2) * DPW) : "memory");   // stage s + 1 has landed (s + 2 may be in flight)
                 __builtin_amdgcn_s_barrier();   // ... for every wave, and every wave holds all of stage s in registers: its buffer is free
                 half_b(smem + ((s + 1) % STAGES) * TILE_BYTES, s + STAGES, std::true_type{}, std::true_type{});
             }
@@ -382,12 +383,12 @@ int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, in
     if (blocks < 8) blocks = 8;
     if (blocks > n_vblocks) blocks = n_vblocks;
     if (half) {
-        FQ_RAISE_LDS_CAP(fq_gemm_bf6_kernel<128>, STAGES * Geo<128>::TILE_BYTES);
-        hipLaunchKernelGGL(fq_gemm_bf6_kernel<128>, dim3((unsigned)blocks), dim3(Geo<128>::GT), STAGES * Geo<128>::TILE_BYTES, stream, xblob,
+        FQ_RAISE_LDS_CAP(fq_gemm_bf6_kernel<128>, Geo<128>::STAGES * Geo<128>::TILE_BYTES);
+        hipLaunchKernelGGL(fq_gemm_bf6_kernel<128>, dim3((unsigned)blocks), dim3(Geo<128>::GT), Geo<128>::STAGES * Geo<128>::TILE_BYTES, stream, xblob,
                            wblob, (int)M, N, K / 64, (int)n_vblocks, o);
     } else {
-        FQ_RAISE_LDS_CAP(fq_gemm_bf6_kernel<256>, STAGES * Geo<256>::TILE_BYTES);
-        hipLaunchKernelGGL(fq_gemm_bf6_kernel<256>, dim3((unsigned)blocks), dim3(Geo<256>::GT), STAGES * Geo<256>::TILE_BYTES, stream, xblob,
+        FQ_RAISE_LDS_CAP(fq_gemm_bf6_kernel<256>, Geo<256>::STAGES * Geo<256>::TILE_BYTES);
+        hipLaunchKernelGGL(fq_gemm_bf6_kernel<256>, dim3((unsigned)blocks), dim3(Geo<256>::GT), Geo<256>::STAGES * Geo<256>::TILE_BYTES, stream, xblob,
                            wblob, (int)M, N, K / 64, (int)n_vblocks, o);
     }
     return (int)hipGetLastError();
