@@ -318,7 +318,7 @@ __global__ __launch_bounds__(Geo<BM>::GT, Geo<BM>::GW / 4) void fq_gemm_bf6_kern
                         dequant16f<false>(acc[tn][tm], sr[tm], __builtin_bit_cast(f16x8, sc[tn][0]), __builtin_bit_cast(f16x8, sc[tn][1]),
                                           out.bias != nullptr, __builtin_bit_cast(f16x8, bs[tn][0]), __builtin_bit_cast(f16x8, bs[tn][1]), o0, o1);
                     uint4* yp = reinterpret_cast<uint4*>(out.y + (int64_t)m * N + nbase);
-                    yp[0] = __builtin_bit_cast(uint4, o0);
+                    yp[0] = __builtin_bit_cast(uint4, o0);   // (plain stores: non-temporal ones measured 163 -> 173 us)
                     yp[1] = __builtin_bit_cast(uint4, o1);
                 }
             }
