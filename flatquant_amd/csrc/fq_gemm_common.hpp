@@ -24,7 +24,7 @@ __device__ __forceinline__ f16 dequant1(int q, f16 srow, f16 scol) {
 // |q| < 2^24), the three fp16 products two elements per instruction (v_pk_mul_f16 rounds each half like v_mul_f16), the 16 column
 // scales (and biases) as two 16-byte loads. Replaced by the float-pipeline form below.
 // From the accumulator AS A FLOAT (the FP6 path's fp32 accumulator holds the exact integer; the int8 path converts once):
-// int(q / 10.0f) == trunc(fl(q * 0.1f)) for EVERY |q| <= 2^24 — checked exhaustively on the CPU (numpy, IEEE fp32): 0.1f lies
+// int(q / 10.0f) == trunc(fl(q * 0.1f)) for EVERY |q| <= 2^24 — checked exhaustively on the CPU (tests/test_dequant_identity.py: numpy, IEEE fp32): 0.1f lies
 // 1.5e-8 (relative) above 1/10 and the product's rounding adds at most 0.0625, together < 0.1, the distance of q / 10 from the next
 // integer below its magnitude — so the division becomes v_mul_f32 + v_trunc_f32, the clamp one v_med3_f32, and the value never
 // leaves the float pipeline: 4 - 5 VALU per element instead of 11 (second session of round 3: the epilogue was 5.9 us of every
