@@ -81,33 +81,41 @@ __global__ __launch_bounds__(256) void fq_i4_to_bf6_kernel(const uint8_t* __rest
     }
     __syncthreads();
     const int KB = Kb / 32;  // blobs per row tile (64 k = 32 packed bytes)
+    const int KBP = (KB + 1) / 2;   // pairs of neighbouring blobs: a thread converts one row of one blob (both K-halves: 32 packed bytes),
+                                    // lanes 0-31 the rows of blob 2 j, lanes 32-63 the same rows of blob 2 j + 1 — a wave reads 64
+                                    // contiguous bytes of each of 32 rows (one blob per wave read 32 bytes per row: 16384 x 14336 78.5 -> 68.6 us)
     const int64_t n_rt = (rows + 31) / 32;
-    const int64_t total = n_rt * KB * 64;
+    const int64_t total = n_rt * KBP * 64;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int lane = (int)(i & 63);
-        const int64_t blob = i >> 6;
-        const int64_t rt = blob / KB;
-        const int kb = (int)(blob - rt * KB);
-        const int kh = lane >> 5, r = lane & 31;
+        const int64_t pair = i >> 6;
+        const int64_t rt = pair / KBP;
+        const int kb = 2 * (int)(pair - rt * KBP) + (lane >> 5);
+        if (kb >= KB) continue;
+        const int r = lane & 31;
         const int64_t row = rt * 32 + (perm ? prow(r) : r);
-        uint4 in = make_uint4(0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u);  // never used: rows beyond the end are zeros
         const bool ok = row < rows;
-        if (ok) in = *reinterpret_cast<const uint4*>(src + row * Kb + kb * 32 + kh * 16);
-        const unsigned w[4] = {in.x, in.y, in.z, in.w};
-        unsigned long long g[4];  // 48 bits each: the 8 codes of one input dword
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned long long t0 = lut[w[j] & 255], t1 = lut[(w[j] >> 8) & 255], t2 = lut[(w[j] >> 16) & 255],
-                                     t3 = lut[w[j] >> 24];
-            g[j] = ok ? (t0 | (t1 << 12) | (t2 << 24) | (t3 << 36)) : 0ull;
+        uint4 in2[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};   // (rows beyond the end are zeros: never read when !ok)
+        if (ok) {
+            const uint4* sp = reinterpret_cast<const uint4*>(src + row * Kb + kb * 32);
+            in2[0] = sp[0];
+            in2[1] = sp[1];
         }
-        const unsigned long long o0 = g[0] | (g[1] << 48);
-        const unsigned long long o1 = (g[1] >> 16) | (g[2] << 32);
-        const unsigned long long o2 = (g[2] >> 32) | (g[3] << 16);
-        unsigned long long* d = reinterpret_cast<unsigned long long*>(dst + blob * BLOB) + lane;
-        d[0] = o0;
-        d[64] = o1;
-        d[128] = o2;
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(dst + (rt * KB + kb) * BLOB) + r;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const unsigned w[4] = {in2[kh].x, in2[kh].y, in2[kh].z, in2[kh].w};
+            unsigned long long g[4];  // 48 bits each: the 8 codes of one input dword
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned long long t0 = lut[w[j] & 255], t1 = lut[(w[j] >> 8) & 255], t2 = lut[(w[j] >> 16) & 255],
+                                         t3 = lut[w[j] >> 24];
+                g[j] = ok ? (t0 | (t1 << 12) | (t2 << 24) | (t3 << 36)) : 0ull;
+            }
+            d[kh * 32] = g[0] | (g[1] << 48);
+            d[kh * 32 + 64] = (g[1] >> 16) | (g[2] << 32);
+            d[kh * 32 + 128] = (g[2] >> 32) | (g[3] << 16);
+        }
     }
 }
 
@@ -349,7 +357,7 @@ int64_t fq_bf6_blob_bytes(int64_t rows, int K) {
 // -1000: K % 64 != 0
 int fq_launch_i4_to_bf6(const uint8_t* q, int64_t rows, int K, int perm, uint8_t* blob, int n_cu, hipStream_t stream) {
     if ((K & 63) || rows < 1) return -1000;
-    const int64_t total = ((rows + 31) / 32) * (int64_t)(K / 64) * 64;
+    const int64_t total = ((rows + 31) / 32) * (int64_t)((K / 64 + 1) / 2) * 64;
     int64_t blocks = (total + 255) / 256;
     if (blocks > (int64_t)n_cu * 16) blocks = (int64_t)n_cu * 16;
     hipLaunchKernelGGL(fq_i4_to_bf6_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q, rows, K / 2, perm, blob);
