@@ -338,7 +338,7 @@ __global__ __launch_bounds__(Geo<BM>::GT, Geo<BM>::GW / 4) void fq_gemm_bf6_kern
         // The requested stages have had the whole epilogue to land. An interior tile with the fused epilogue alone issued exactly
         // 4 TMT stores behind them (vmcnt counts loads and stores in issue order on gfx9): the wait leaves those in flight — they
         // drain under the next tile's first stages. Every other case waits for everything.
-        if (out.c == nullptr && m0 + BM <= M && n0 + BN <= N) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * TMT) : "memory");
+        if (out.c == nullptr && out.y != nullptr && m0 + BM <= M && n0 + BN <= N) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * TMT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
