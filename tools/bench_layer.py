@@ -25,12 +25,22 @@ MODELS = {
 }
 
 
+GRAPH = False   # --graph: every timed callable is captured once into a HIP graph (torch.cuda.graph) and replayed — at 2048 tokens the
+                # Python module path (output allocation, ctypes marshalling: ~25 us per call) is longer than most of the kernels
+
+
 def timeit(fn, steps, warm=10, settle_ms=60.0):
     """events around `steps` calls, after `warm` calls AND at least `settle_ms` of the same launches (the part needs tens of
     milliseconds of load before its clocks settle: ten 200 us launches measure the ramp, 20 % slow)"""
     import time
     for _ in range(warm):
         fn()
+    if GRAPH:
+        torch.cuda.synchronize()
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph):
+            keep = fn()   # noqa: F841  (outputs stay alive for the replays)
+        fn = gph.replay
     t0 = time.perf_counter()
     while (time.perf_counter() - t0) * 1e3 < settle_ms:
         for _ in range(8):
@@ -52,7 +62,10 @@ def main():
     ap.add_argument("--bsz", type=int, default=8)
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--graph", action="store_true", help="time HIP-graph replays of every piece (kernel time, no Python launch path)")
     a = ap.parse_args()
+    global GRAPH
+    GRAPH = a.graph
     m = MODELS[a.model]
     dev = torch.device("cuda")
     g = torch.Generator(device=dev).manual_seed(0)
@@ -94,7 +107,8 @@ def main():
     fused = ("down_proj Hadamard+Quantizer, one launch (OnlineTrans.forward(x, quantizer=...))",
              lambda: had(nxt(xf), quantizer=quant), 2.5 * m["ffn"] + 2)
     total = 0.0
-    print(f"{a.model}: {a.bsz} x {a.seq} tokens, one decoder layer, activation path through flatquant_amd.deploy.nn")
+    print(f"{a.model}: {a.bsz} x {a.seq} tokens, one decoder layer, activation path through flatquant_amd.deploy.nn"
+          + (" — every piece replayed from a HIP graph" if GRAPH else ""))
     for name, fn, bpt in rows:
         us = timeit(fn, a.steps)
         total += us
