@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void fq_i4_to_bf6_kernel(const uint8_t* __rest
 typedef int i32x6 __attribute__((ext_vector_type(6)));
 
 template <int BM>
-__global__ __launch_bounds__(Geo<BM>::GT, Geo<BM>::GW / 4) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB, const uint8_t* __restrict__ WB,
+__global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB, const uint8_t* __restrict__ WB,
                                                                               int M, int N, int KB, int n_vblocks, GemmOut out) {
     constexpr int NWM = Geo<BM>::NWM, TILE_BYTES = Geo<BM>::TILE_BYTES, DPW = Geo<BM>::DPW, STAGES = Geo<BM>::STAGES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
