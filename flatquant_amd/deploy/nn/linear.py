@@ -24,15 +24,17 @@ class Linear4bit(torch.nn.Module):
         faster than on the int8 path — 16384 x 4096 x 4096: 159 us against 285, profiles/r03_gemm_bf6_pipeline.txt):
         +0.75 B/param — OFF by default (``Linear4bit.fp6_image = True`` or FQ_FP6_GEMM=1 keep it): with both images a
         layer would sit at 1.75 B/param, 3.5x the INT4 footprint.
-    Without the kept image a call of >= ``fp6_transient_rows`` (512) tokens still takes the FP6 path: the weights
+    Without the kept image a call of >= ``fp6_transient_rows`` (129: above the decode kernel's range) tokens still takes the FP6 path: the weights
     are converted INTO A TRANSIENT image for the call (12.6 MB for 4096 x 4096: ~8 us, freed with the call — the caching
     allocator hands the same block to the next layer), which costs 463 / rows of the GEMM's own time and leaves the
     resident footprint at 0.5 - 1.0 B/param. FQ_FP6_GEMM=0 turns every FP6 route off (int8 matrix path only)."""
 
     decode_image = True   # class-wide policy switches (set on the class or on an instance)
     fp6_image = False
-    fp6_transient_rows = 512    # calls with at least this many tokens convert the weights for the call when no image is kept (0: never;
-                                # measured, 4096 x 4096: 512 tokens 20.7 + ~10 us of conversions against 47.7 us on the int8 path)
+    fp6_transient_rows = 129    # calls with at least this many tokens convert the weights for the call when no image is kept (0: never).
+                                # 129 = everything above the decode kernel's range: measured with both conversions inside the call
+                                # (tools/scratch/gemm_small_m.py), 129 tokens x 4096 x 4096: 34.6 us against 45.6 on the int8 path,
+                                # K = 11008: 55 against 111
 
     def __init__(self, in_features, out_features, bias=False, dtype=torch.float16):
         super().__init__()
