@@ -69,6 +69,7 @@ SYMBOLS = {
     "fq_int4_to_bf6": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "fq_bf6_gemm_i32": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "fq_bf6_linear_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
+    "fq_int4_linear_fp6_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _i64, _vp]),
     "fq_kv_quant_f16": (_i, [_vp, _vp, _i64, _i, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "fq_kv_dequant_f16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "fq_kv_append_i4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -638,6 +638,32 @@ int fq_bf6_linear_f16(const void* xblob, const void* x_scale, const void* wblob,
     return check_launch(rc, "fq_bf6_linear_f16");
 }
 
+int fq_int4_linear_fp6_f16(const void* x, const void* x_scale, const void* w, const void* wblob, const void* w_scale,
+                           const void* bias, int64_t M, int N, int K, void* y, void* scratch, int64_t scratch_bytes, void* stream) {
+    const char* what = "fq_int4_linear_fp6_f16";
+    if (M < 0 || N <= 0 || K <= 0) return fail(FQ_EINVAL, "%s: bad sizes", what);
+    if (M == 0) return FQ_OK;
+    if (!x || !y || !x_scale || !w_scale || !scratch || (!w && !wblob)) return fail(FQ_EINVAL, "%s: NULL pointer", what);
+    if ((K & 127) || (N & 15) || K > (1 << 18))
+        return fail(FQ_EUNSUPPORTED, "%s: shape M=%lld N=%d K=%d not covered (K %% 128, N %% 16)", what, (long long)M, N, K);
+    FQ_NEED_ALIGN16(what, x, w, wblob, y, scratch);
+    const int64_t xb = fq_bf6_blob_bytes(M, K), wb = wblob ? 0 : fq_bf6_blob_bytes(N, K);
+    if (scratch_bytes < xb + wb)
+        return fail(FQ_EINVAL, "%s: scratch of %lld bytes required (got %lld)", what, (long long)(xb + wb), (long long)scratch_bytes);
+    uint8_t* xs = static_cast<uint8_t*>(scratch);
+    int rc = fq_launch_i4_to_bf6((const uint8_t*)x, M, K, 0, xs, cu_count(), (hipStream_t)stream);
+    if (rc != 0) return check_launch(rc, what);
+    const uint8_t* wsrc = (const uint8_t*)wblob;
+    if (!wblob) {
+        rc = fq_launch_i4_to_bf6((const uint8_t*)w, N, K, 1, xs + xb, cu_count(), (hipStream_t)stream);
+        if (rc != 0) return check_launch(rc, what);
+        wsrc = xs + xb;
+    }
+    rc = fq_launch_gemm_bf6(xs, wsrc, M, N, K, nullptr, (f16*)y, (const f16*)x_scale, (const f16*)w_scale, (const f16*)bias,
+                            (hipStream_t)stream);
+    return check_launch(rc, what);
+}
+
 int fq_hadamard_quant_f16(const void* x, int64_t rows, int n, int K, const void* hadK, float scale, float sig_max,
                           float sig_min, void* q_out, void* scale_out, void* stream) {
     if (!x || !q_out || !scale_out) return fail(FQ_EINVAL, "fq_hadamard_quant_f16: NULL pointer");

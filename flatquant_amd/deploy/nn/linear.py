@@ -111,16 +111,13 @@ class Linear4bit(torch.nn.Module):
                 y = ops.int4_skinny_linear(q.reshape(rows, -1).contiguous(), scales_x.reshape(-1).contiguous(), dimg,
                                            ws16, b16, self.out_features)
                 return y.view(*lead, self.out_features)
-        wimg = self._weight_image() if q.is_cuda else None
-        if (wimg is None and q.is_cuda and self.fp6_transient_rows and rows >= self.fp6_transient_rows
-                and os.environ.get("FQ_FP6_GEMM", "") != "0" and ops.bf6_supported(self.out_features, self.in_features)):
-            wimg = ops.int4_to_bf6(self.weight, weights=True)   # transient: lives for this call only
-        if wimg is not None:
-            q2 = q.reshape(-1, q.shape[-1]).contiguous()
-            ws16, b16 = self._scales16()
-            y = ops.bf6_linear(ops.int4_to_bf6(q2), scales_x.reshape(-1).contiguous(), wimg, ws16, b16,
-                               q2.shape[0], self.out_features, self.in_features)
-            return y.view(*lead, self.out_features)
+        if q.is_cuda and os.environ.get("FQ_FP6_GEMM", "") != "0" and ops.bf6_supported(self.out_features, self.in_features):
+            wimg = self._weight_image()                     # the kept image, or None: converted for this call (transient)
+            if wimg is not None or (self.fp6_transient_rows and rows >= self.fp6_transient_rows):
+                ws16, b16 = self._scales16()
+                y = ops.int4_linear_fp6(q.reshape(-1, q.shape[-1]).contiguous(), scales_x.reshape(-1).contiguous(), self.weight, wimg,
+                                        ws16, b16)
+                return y.view(*lead, self.out_features)
         ws16, b16 = self._scales16()
         y = ops.int4_linear(q.reshape(-1, q.shape[-1]).contiguous(), scales_x.reshape(-1).contiguous(),
                             self.weight, ws16, b16)

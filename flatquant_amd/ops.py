@@ -748,6 +748,32 @@ def bf6_linear(xblob: torch.Tensor, x_scale: torch.Tensor, wblob: torch.Tensor, 
     return y
 
 
+def int4_linear_fp6(x: torch.Tensor, x_scale: torch.Tensor, w: torch.Tensor, w_image: Optional[torch.Tensor], w_scale: torch.Tensor,
+                    bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Linear4bit.forward on the FP6 path as one library call (fq_int4_linear_fp6_f16): packed x [M, K/2], packed w [N, K/2] and,
+    if the layer keeps one, its FP6 image (else the weights are converted for the call into the same scratch block as the
+    activations) -> fp16 [M, N], the bits of int4_linear. One scratch allocation, one ctypes call, three launches."""
+    _chk(x, "x", torch.uint8), _chk(w, "w", torch.uint8), _chk(x_scale, "x_scale"), _chk(w_scale, "w_scale")
+    if bias is not None:
+        _chk(bias, "bias")
+    if x.dim() != 2 or w.dim() != 2 or x.shape[1] != w.shape[1]:
+        raise RuntimeError(f"int4_linear_fp6: expected x [M, K/2] and w [N, K/2], got {tuple(x.shape)} and {tuple(w.shape)}")
+    M, N, K = x.shape[0], w.shape[0], x.shape[1] * 2
+    if x_scale.numel() != M or w_scale.numel() != N or (bias is not None and bias.numel() != N):
+        raise RuntimeError("int4_linear_fp6: scale / bias sizes do not match M / N")
+    if not bf6_supported(N, K):
+        raise _lib.FqError(_lib.FQ_EUNSUPPORTED, f"int4_linear_fp6: N={N} K={K} not covered (K % 128, N % 16)")
+    y = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    if M == 0:
+        return y
+    nbytes = int(lib.fq_bf6_blob_bytes(M, K)) + (0 if w_image is not None else int(lib.fq_bf6_blob_bytes(N, K)))
+    scratch = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.fq_int4_linear_fp6_f16(_ptr(x), _ptr(x_scale), _ptr(w), _ptr(w_image), _ptr(w_scale), _ptr(bias), M, N, K, _ptr(y),
+                                         _ptr(scratch), nbytes, _stream(x)))
+    return y
+
+
 def kv_quant(x: torch.Tensor, trans: Optional[torch.Tensor] = None, clip: Sig = (1.0, 1.0), lac: bool = False,
              return_transformed: bool = False):
     """K/V cache quantisation (fq_kv_quant_f16): x [..., head_dim] fp16 -> (q uint8 [..., head_dim/2], param fp16

@@ -23,7 +23,7 @@
  *   fq_block_quant_f16     deploy/kernels/block_matmul.py:231-311 (block_matmul)
  *   fq_int4_gemm_i32       deploy/kernels/gemm.cu:8-47 (matmul_host) / deploy.matmul
  *   fq_int4_linear_f16     deploy/nn/linear.py:41-56 (Linear4bit.forward = matmul + sym_dequant + bias)
- *   fq_int4_to_bf6, fq_bf6_gemm_i32, fq_bf6_linear_f16   the same two on the FP6 matrix path (bit-identical results)
+ *   fq_int4_to_bf6, fq_bf6_gemm_i32, fq_bf6_linear_f16, fq_int4_linear_fp6_f16   the same two on the FP6 matrix path (bit-identical results)
  *   fq_hadamard_f16        flatquant/hadamard_utils.py:89-110,132-141 (matmul_hadU[_cuda]),
  *   (fq_hadamard_quant_f16: the same followed by deploy/nn/quantization.py:13-36, fused)
  *                          deploy/functional/online_trans.py:144-151
@@ -328,6 +328,16 @@ int fq_int4_to_bf6(const void* q, int64_t rows, int K, int role, void* blob, voi
 int fq_bf6_gemm_i32(const void* xblob, const void* wblob, int64_t M, int N, int K, void* c, void* stream);
 int fq_bf6_linear_f16(const void* xblob, const void* x_scale, const void* wblob, const void* w_scale, const void* bias,
                       int64_t M, int N, int K, void* y, void* stream);
+/*
+ * Linear4bit.forward (deploy/nn/linear.py:41-56) on the FP6 path as ONE call — what the host side needs per layer call: the packed
+ * activations x [M, K/2] are converted into `scratch`, the weights are taken from the kept image `wblob` or, when it is NULL,
+ * converted from the packed `w` [N, K/2] into `scratch` as well (a transient image: nothing stays resident), then
+ * fq_bf6_linear_f16 runs on the two blobs — three launches on `stream`, one library call.
+ *   scratch_bytes >= fq_bf6_blob_bytes(M, K) + (wblob ? 0 : fq_bf6_blob_bytes(N, K)), 16-byte aligned; contents undefined afterwards.
+ * Same shape limits and the same bits as fq_bf6_linear_f16 / fq_int4_linear_f16.
+ */
+int fq_int4_linear_fp6_f16(const void* x, const void* x_scale, const void* w, const void* wblob, const void* w_scale,
+                           const void* bias, int64_t M, int N, int K, void* y, void* scratch, int64_t scratch_bytes, void* stream);
 
 /*
  * Normalised Hadamard transform over the last axis, n = K * 2^p:

@@ -136,8 +136,8 @@ def test_module_uses_the_fp6_path_transparently(ops, monkeypatch):
 
 
 def test_prefill_sized_calls_take_the_fp6_path_with_a_transient_image(ops, monkeypatch):
-    """Default policy (no image kept): >= fp6_transient_rows tokens convert the weights for the call; same bits as the int8 path,
-    nothing cached on the module."""
+    """Default policy (no image kept): >= fp6_transient_rows tokens convert the weights for the call (inside the one library call
+    fq_int4_linear_fp6_f16); same bits as the int8 path, nothing cached on the module."""
     import flatquant_amd.deploy as deploy
     monkeypatch.delenv("FQ_FP6_GEMM", raising=False)
     gen = torch.Generator().manual_seed(5)
@@ -149,16 +149,33 @@ def test_prefill_sized_calls_take_the_fp6_path_with_a_transient_image(ops, monke
     p = deploy.PackedQuantizedTensor(torch.from_numpy(xp).cuda().reshape(1, rows, 128),
                                      (torch.rand(1, 1, rows, generator=gen) * 0.05 + 0.001).half().cuda())
     calls = []
-    real = ops.int4_to_bf6
-    monkeypatch.setattr(ops, "int4_to_bf6", lambda q, weights=False: (calls.append(weights), real(q, weights))[1])
+    real = ops.int4_linear_fp6
+    monkeypatch.setattr(ops, "int4_linear_fp6", lambda *a: (calls.append(a[3] is None), real(*a))[1])
     y = lin(p)
-    assert calls.count(True) == 1 and lin.image_bytes() == 0          # the weights were converted for the call and not kept
+    assert calls == [True] and lin.image_bytes() == 0                  # the weights were converted for the call and not kept
     ref = ops.int4_linear(p.quantized_x.reshape(-1, 128), p.scales_x.reshape(-1), lin.weight, lin.weight_scales.reshape(-1).half(),
                           None).view(1, rows, 272)
     assert torch.equal(y, ref)
     calls.clear()
     lin.fp6_transient_rows = 0                                          # policy off: the int8 matrix path
     assert torch.equal(lin(p), ref) and not calls
+    lin.fp6_image = True                                                # a kept image: the same entry point, no weight conversion
+    lin._weight_image = lambda: ops.int4_to_bf6(lin.weight, weights=True)
+    assert torch.equal(lin(p), ref) and calls == [False]
+
+
+@pytest.mark.parametrize("M,N,K,bias,keep", [(300, 272, 256, True, False), (300, 272, 256, False, True), (2500, 4096, 512, True, True)])
+def test_one_call_entry_point(ops, M, N, K, bias, keep):
+    """fq_int4_linear_fp6_f16 (conversions + GEMM in one library call, with a kept or a transient weight image) == fq_int4_linear_f16."""
+    gen = torch.Generator().manual_seed(M + N + K + keep)
+    x, w = torch.from_numpy(rand_packed(gen, M, K)[0]).cuda(), torch.from_numpy(rand_packed(gen, N, K)[0]).cuda()
+    sx = (torch.rand(M, generator=gen) * 0.05 + 0.001).half().cuda()
+    sw = (torch.rand(N, generator=gen) * 0.02 + 0.0005).half().cuda()
+    b = torch.randn(N, generator=gen).half().cuda() if bias else None
+    img = ops.int4_to_bf6(w, weights=True) if keep else None
+    assert torch.equal(ops.int4_linear_fp6(x, sx, w, img, sw, b).view(torch.int16), ops.int4_linear(x, sx, w, sw, b).view(torch.int16))
+    with pytest.raises(Exception):
+        ops.int4_linear_fp6(x[:, :32].contiguous(), sx, w[:, :32].contiguous(), None, sw, b)      # K = 64
 
 
 def test_errors(ops):
