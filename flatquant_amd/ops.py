@@ -123,7 +123,12 @@ def _ptr(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+_NULL4 = (ctypes.c_void_p * FQ_MAX_CLIPS)()   # the output sets a launch does not write (read-only on the C side)
+
+
 def _ptr_array(ts: Sequence[Optional[torch.Tensor]]):
+    if not ts:
+        return _NULL4
     arr = (ctypes.c_void_p * FQ_MAX_CLIPS)()
     for i, t in enumerate(ts):
         arr[i] = 0 if t is None else t.data_ptr()
@@ -137,6 +142,31 @@ def _sig_arrays(sigs: Sequence[Sig]):
     smax = (ctypes.c_float * FQ_MAX_CLIPS)(*[float(s[0]) for s in sigs])
     smin = (ctypes.c_float * FQ_MAX_CLIPS)(*[float(s[1]) for s in sigs])
     return smax, smin, n
+
+
+class _on:
+    """``with _on(t.device):`` — the launch's device made current for the library call (kernels go to the CURRENT device's stream
+    handle; a multi-GPU process may hold tensors of several). ``torch.cuda.device`` does the same but exchanges the device on
+    entry and exit unconditionally (~6 us of the ~30 us a module call spends on the host); the tensor's device almost always IS the
+    current one, and then this is one cached look-up."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device: torch.device):
+        self.idx = device.index
+        self.prev = -1
+
+    def __enter__(self):
+        if self.idx is not None:
+            cur = torch.cuda.current_device()
+            if cur != self.idx:
+                torch.cuda.set_device(self.idx)
+                self.prev = cur
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def _stream(t: torch.Tensor):
@@ -174,10 +204,15 @@ _WS_LRU: "collections.OrderedDict" = collections.OrderedDict()
 _WS_LRU_MAX = 512
 
 
+_WS_BYTES: dict = {}   # fq_kron_workspace_bytes(M, N): a pure function of the pair
+
+
 def _kron_workspace(device: torch.device, M: int, N: int, left: torch.Tensor, right: torch.Tensor):
     """-> (workspace | None, bytes, prepared, key). Keyed by stream too: two streams must not share a buffer. The
     caller registers a fresh workspace (_kron_workspace_commit) once the launch that fills it has been accepted."""
-    nbytes = int(lib.fq_kron_workspace_bytes(M, N))
+    nbytes = _WS_BYTES.get((M, N))
+    if nbytes is None:
+        nbytes = _WS_BYTES[(M, N)] = int(lib.fq_kron_workspace_bytes(M, N))
     if nbytes < 0:
         raise _lib.FqError(nbytes, f"no kernel for Kronecker factors ({M}, {N}): need M, N <= 256 and M * N <= 32768")
     if nbytes == 0:   # (no pair has a zero-size workspace since round 3: 64 x 64 takes its optional 32 KB image)
@@ -259,7 +294,7 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
         flags |= FQ_GROUP128
     if rows == 0:
         return o
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         ws, ws_bytes, prepared, key = _kron_workspace(x.device, M, N, left, right)
         rc = _fn("kron_quant", dt)(_ptr(x), _ptr(left), _ptr(right), _ptr(diag), rows, M, N, smax, smin, n,
                                    flags | (FQ_WS_PREPARED if prepared else 0), _ptr_array(o.q), _ptr_array(o.scale),
@@ -290,7 +325,7 @@ def kron_quant_ex(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, post
     o = _alloc_outputs(x, rows, d, n, flags, x.shape[:-1] + (d // 2,), x.shape)
     if rows == 0:
         return o
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         ws, ws_bytes, prepared, key = _kron_workspace(x.device, M, N, left, right)
         check(lib.fq_kron_quant_ex_f16(_ptr(x), _ptr(up), _ptr(left), _ptr(right), rows, M, N, ctypes.c_float(post_scale), smax,
                                        smin, n, flags | (FQ_WS_PREPARED if prepared else 0), _ptr_array(o.q),
@@ -394,7 +429,7 @@ def kron_quant_grouped(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor,
         o = _alloc_outputs(x, rows, d, 1, flags, (rows, d // 2), x.shape)
         if rows == 0:
             return o
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             per = int(lib.fq_kron_workspace_bytes(M, N))
             if per < 0:
                 raise _lib.FqError(per, f"no kernel for Kronecker factors ({M}, {N})")
@@ -424,7 +459,7 @@ def kron_quant_grouped(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor,
         flags |= FQ_GROUP128
     if rows == 0:
         return o
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         ws, ws_bytes, prepared, key = _kron_workspace(x.device, M, N, left, right)
         check(_fn("kron_quant_grouped", dt)(
             _ptr(x), _ptr(left), _ptr(right), rows, M, N, _ptr(group_offsets), G, _ptr(sig_max_g), _ptr(sig_min_g),
@@ -443,7 +478,7 @@ def rmsnorm(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     y = torch.empty_like(x)
     if rows == 0:
         return y
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(lib.fq_rmsnorm_f16(_ptr(x), _ptr(y), rows, cols, ctypes.c_float(eps), _stream(x)))
     return y
 
@@ -466,7 +501,7 @@ def rmsnorm_kron_quant(x: torch.Tensor, eps: float, left: torch.Tensor, right: t
         o = _alloc_outputs(x, rows, d, n, flags, x.shape[:-1] + (d // 2,), x.shape)
         if rows == 0:
             return o
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             ws, ws_bytes, prepared, key = _kron_workspace(x.device, M, N, left, right)
             check(lib.fq_rmsnorm_kron_quant_ws_f16(_ptr(x), ctypes.c_float(eps), _ptr(left), _ptr(right), rows, M, N, smax, smin,
                                                    n, flags | (FQ_WS_PREPARED if prepared else 0), _ptr_array(o.q),
@@ -484,7 +519,7 @@ def rmsnorm_kron_quant(x: torch.Tensor, eps: float, left: torch.Tensor, right: t
     o = _alloc_outputs(x, rows, d, n, flags, x.shape[:-1] + (d // 2,), x.shape)
     if rows == 0:
         return o
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(lib.fq_rmsnorm_kron_quant_f16(_ptr(x), ctypes.c_float(eps), _ptr(left), _ptr(right), rows, M, N, smax, smin,
                                             n, flags, _ptr_array(o.q), _ptr_array(o.scale), _ptr_array(o.fq), _ptr(o.y),
                                             _stream(x)))
@@ -499,7 +534,7 @@ def silu_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     y = torch.empty_like(gate)
     if gate.numel() == 0:
         return y
-    with torch.cuda.device(gate.device):
+    with _on(gate.device):
         check(lib.fq_silu_mul_f16(_ptr(gate), _ptr(up), _ptr(y), gate.numel(), _stream(gate)))
     return y
 
@@ -522,7 +557,7 @@ def silu_mul_kron_quant(gate: torch.Tensor, up: torch.Tensor, left: torch.Tensor
     o = _alloc_outputs(gate, rows, d, n, flags, gate.shape[:-1] + (d // 2,), gate.shape)
     if rows == 0:
         return o
-    with torch.cuda.device(gate.device):
+    with _on(gate.device):
         ws, ws_bytes, prepared, key = _kron_workspace(gate.device, M, N, left, right)
         rc = lib.fq_silu_mul_kron_quant_f16(_ptr(gate), _ptr(up), _ptr(left), _ptr(right), rows, M, N, smax, smin, n,
                                             flags | (FQ_WS_PREPARED if prepared else 0), _ptr_array(o.q),
@@ -551,7 +586,7 @@ def block_quant(x: torch.Tensor, P: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1
     o = _alloc_outputs(x, rows, d, n, flags, x.shape[:-2] + (d // 2,), yshape)
     if rows == 0:
         return o
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(_fn("block_quant", dt)(_ptr(x), _ptr(P), rows, R, C, int(transpose_out), smax, smin, n, flags,
                                      _ptr_array(o.q), _ptr_array(o.scale), _ptr_array(o.fq), _ptr(o.y),
                                      _stream(x)))
@@ -567,7 +602,7 @@ def rowquant(x: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),), flags: int = 
     o = _alloc_outputs(x, rows, cols, n, flags, x.shape[:-1] + (cols // 2,), x.shape)
     if rows == 0:
         return o
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(_fn("rowquant", dt)(_ptr(x), rows, cols, smax, smin, n, flags, _ptr_array(o.q),
                                   _ptr_array(o.scale), _ptr_array(o.fq), _stream(x)))
     return o
@@ -590,7 +625,7 @@ def hadamard(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None,
     y = torch.empty_like(x)
     if rows == 0:
         return y
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(lib.fq_hadamard_f16(_ptr(x), _ptr(y), rows, n, K, _ptr(hadK), ctypes.c_float(scale), _stream(x)))
     return y
 
@@ -640,7 +675,7 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
     s = torch.empty((rows,), dtype=torch.float16, device=x.device)
     if rows == 0:
         return q, s
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         if up is not None:
             rc = lib.fq_silu_mul_hadamard_quant_f16(_ptr(x), _ptr(up), rows, n, K, _ptr(hadK), ctypes.c_float(scale),
                                                     ctypes.c_float(sig[0]), ctypes.c_float(sig[1]), _ptr(q), _ptr(s),
@@ -665,7 +700,7 @@ def int4_to_frag(w: torch.Tensor) -> torch.Tensor:
     if nbytes < 0:
         raise _lib.FqError(_lib.FQ_EUNSUPPORTED, f"int4_to_frag: K={K} must be a multiple of 64")
     img = torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
-    with torch.cuda.device(w.device):
+    with _on(w.device):
         check(lib.fq_int4_to_frag(_ptr(w), N, K, _ptr(img), _stream(w)))
     return img
 
@@ -680,7 +715,7 @@ def int4_skinny_matmul(x: torch.Tensor, w_image: torch.Tensor, N: int) -> torch.
     M, K = x.shape[0], x.shape[1] * 2
     c = torch.empty((M, N), dtype=torch.int32, device=x.device)
     if M:
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             check(lib.fq_int4_skinny_gemm_i32(_ptr(x), _ptr(w_image), M, N, K, _ptr(c), _stream(x)))
     return c
 
@@ -696,7 +731,7 @@ def int4_skinny_linear(x: torch.Tensor, x_scale: torch.Tensor, w_image: torch.Te
         _chk(bias, "bias")
     y = torch.empty((M, N), dtype=torch.float16, device=x.device)
     if M:
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             check(lib.fq_int4_skinny_linear_f16(_ptr(x), _ptr(x_scale), _ptr(w_image), _ptr(w_scale), _ptr(bias), M, N, K,
                                                 _ptr(y), _stream(x)))
     return y
@@ -714,7 +749,7 @@ def int4_to_bf6(q: torch.Tensor, weights: bool = False) -> torch.Tensor:
         raise _lib.FqError(_lib.FQ_EUNSUPPORTED, f"int4_to_bf6: K={K} must be a multiple of 64")
     blob = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
     if rows:
-        with torch.cuda.device(q.device):
+        with _on(q.device):
             check(lib.fq_int4_to_bf6(_ptr(q), rows, K, 1 if weights else 0, _ptr(blob), _stream(q)))
     return blob
 
@@ -727,7 +762,7 @@ def bf6_matmul(xblob: torch.Tensor, wblob: torch.Tensor, M: int, N: int, K: int)
     """int4_matmul on the FP6 matrix path: blobs from int4_to_bf6 -> int32 [M, N], bit-identical."""
     c = torch.empty((M, N), dtype=torch.int32, device=xblob.device)
     if M:
-        with torch.cuda.device(xblob.device):
+        with _on(xblob.device):
             check(lib.fq_bf6_gemm_i32(_ptr(xblob), _ptr(wblob), M, N, K, _ptr(c), _stream(xblob)))
     return c
 
@@ -742,7 +777,7 @@ def bf6_linear(xblob: torch.Tensor, x_scale: torch.Tensor, wblob: torch.Tensor, 
         _chk(bias, "bias")
     y = torch.empty((M, N), dtype=torch.float16, device=xblob.device)
     if M:
-        with torch.cuda.device(xblob.device):
+        with _on(xblob.device):
             check(lib.fq_bf6_linear_f16(_ptr(xblob), _ptr(x_scale), _ptr(wblob), _ptr(w_scale), _ptr(bias), M, N, K, _ptr(y),
                                         _stream(xblob)))
     return y
@@ -768,7 +803,7 @@ def int4_linear_fp6(x: torch.Tensor, x_scale: torch.Tensor, w: torch.Tensor, w_i
         return y
     nbytes = int(lib.fq_bf6_blob_bytes(M, K)) + (0 if w_image is not None else int(lib.fq_bf6_blob_bytes(N, K)))
     scratch = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(lib.fq_int4_linear_fp6_f16(_ptr(x), _ptr(x_scale), _ptr(w), _ptr(w_image), _ptr(w_scale), _ptr(bias), M, N, K, _ptr(y),
                                          _ptr(scratch), nbytes, _stream(x)))
     return y
@@ -793,7 +828,7 @@ def kv_quant(x: torch.Tensor, trans: Optional[torch.Tensor] = None, clip: Sig = 
     y = torch.empty_like(x) if return_transformed else None
     if rows == 0:
         return (q, param, y) if return_transformed else (q, param)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(lib.fq_kv_quant_f16(_ptr(x), _ptr(trans), rows, hd, ctypes.c_float(clip[0]), ctypes.c_float(clip[1]),
                                   _lib.FQ_KV_LAC if lac else 0, _ptr(q), _ptr(param), _ptr(y), _stream(x)))
     return (q, param, y) if return_transformed else (q, param)
@@ -807,7 +842,7 @@ def kv_dequant(q: torch.Tensor, param: torch.Tensor, lac: bool = False) -> torch
     if param.numel() != rows * 2:
         raise ValueError("param must be [..., 2] with q's leading shape")
     y = torch.empty(q.shape[:-1] + (hd,), dtype=torch.float16, device=q.device)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         check(lib.fq_kv_dequant_f16(_ptr(q), _ptr(param), rows, hd, _lib.FQ_KV_LAC if lac else 0, _ptr(y), _stream(q)))
     return y
 
@@ -850,7 +885,7 @@ def kv_append(kv_data: torch.Tensor, kv_param: torch.Tensor, kv_indptr: torch.Te
     tokens = k.numel() // (src_heads * (hd if f16c else hd // 2))
     if k.shape != v.shape or k_param.numel() != tokens * src_heads * 2 or v_param.numel() != tokens * src_heads * 2:
         raise ValueError("k / v / k_param / v_param shapes do not agree")
-    with torch.cuda.device(kv_data.device):
+    with _on(kv_data.device):
         check((lib.fq_kv_append_f16 if f16c else lib.fq_kv_append_i4)(_ptr(kv_data), _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
             _ptr(k), _ptr(v), _ptr(k_param), _ptr(v_param), _ptr(seqlen_indptr), tokens, n_layers,
             layer_idx, heads, page_size, hd, batch, group_size, _stream(kv_data)))
@@ -873,7 +908,7 @@ def kv_quant_append(k: torch.Tensor, v: torch.Tensor, trans: Optional[torch.Tens
     if tokens == 0:
         return
     c4 = None if clip is None else (ctypes.c_float * 4)(*[float(t) for t in clip])
-    with torch.cuda.device(k.device):
+    with _on(k.device):
         check(lib.fq_kv_quant_append_i4(_ptr(k), _ptr(v), _ptr(trans), tokens, src_heads, hd, c4, _lib.FQ_KV_LAC if lac else 0,
                                         _ptr(kv_data), _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices),
                                         _ptr(last_page_offset), n_layers, layer_idx, heads, page_size, batch, group_size,
@@ -899,7 +934,7 @@ def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tens
     o = torch.empty((batch, hd, heads) if transpose_out else (batch, heads, hd), dtype=torch.float16, device=q.device)
     if batch == 0:
         return o
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         check(decode(_ptr(o), _ptr(q), _ptr(q_trans), 1 if transpose_out else 0, _ptr(kv_data),
                      _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
                      n_layers, layer_idx, heads, page_size, hd, batch, _stream(q)))
@@ -915,7 +950,7 @@ def int4_matmul(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     c = torch.empty((M, N), dtype=torch.int32, device=x.device)
     if M == 0:
         return c
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(lib.fq_int4_gemm_i32(_ptr(x), _ptr(w), M, N, K, _ptr(c), _stream(x)))
     return c
 
@@ -935,7 +970,7 @@ def int4_linear(x: torch.Tensor, x_scale: torch.Tensor, w: torch.Tensor, w_scale
     y = torch.empty((M, N), dtype=torch.float16, device=x.device)
     if M == 0:
         return y
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(lib.fq_int4_linear_f16(_ptr(x), _ptr(x_scale), _ptr(w), _ptr(w_scale), _ptr(bias), M, N, K, _ptr(y),
                                      _stream(x)))
     return y
@@ -952,7 +987,7 @@ def sym_quant(x: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
     q = torch.empty((rows, (cols + 1) // 2), dtype=torch.uint8, device=x.device)
     if rows == 0:
         return q
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(lib.fq_sym_quant_f16(_ptr(x), _ptr(scale), rows, cols, _ptr(q), _stream(x)))
     return q
 
@@ -968,7 +1003,7 @@ def sym_dequant(q: torch.Tensor, scale_row: torch.Tensor, scale_col: torch.Tenso
     x = torch.empty((rows, cols), dtype=torch.float16, device=q.device)
     if rows == 0:
         return x
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         check(lib.fq_sym_dequant_i32_f16(_ptr(q), _ptr(scale_row), _ptr(scale_col), rows, cols, _ptr(x),
                                          _stream(q)))
     return x
