@@ -16,22 +16,24 @@
 // Weights are converted once per layer (their rows in the permuted order that leaves a lane with 16 consecutive n,
 // as in fq_gemm_i4.hip); activations by one small launch per call (0.5 -> 0.75 bytes per element).
 //
-// Tiling: 256 x 256 per 8-wave workgroup, wave tile 128 tokens x 64 features (8 accumulator tiles: 6 fragments per 8
-// MFMAs), three LDS stages of 48 KB filled by LDS-DMA, counted vmcnt, one barrier per stage (128 k).
-// Second session of round 3 (195.9 -> see profiles/r03_gemm_bf6_pipeline.txt, 16384 x 4096 x 4096):
+// Tiling: 256 x 256 per 8-wave workgroup (128 x 256 / 4 waves for launches with few tiles), wave tile 128 tokens x 64 features
+// (8 accumulator tiles: 6 fragments per 8 MFMAs), three LDS stages of 48 KB filled by LDS-DMA, counted vmcnt, one barrier per
+// 128-k stage. 16384 x 4096 x 4096: 159 us = 3.45 Pop/s, K = 14336: 4.3 Pop/s (profiles/r03_gemm_bf6_pipeline.txt).
 //   * EXPLICIT SOFTWARE PIPELINE. A wave issues in order: a run of 18 fragment reads (or 6 LDS-DMA instructions) in front of
 //     a block's MFMAs keeps the matrix pipe idle while the LDS queue — shared by the eight waves, all at the same point behind
-//     the barrier — takes them. Now step i of a block issues MFMA i, then one DMA instruction of the stage three ahead, then the
+//     the barrier — takes them. Step i of a block issues MFMA i, then one DMA instruction of the stage three ahead, then the
 //     three reads of fragment i of the NEXT block. The loop is split by hand (stages that refill | the last STAGES - 1 | the
 //     last) so that a stage is straight-line code between two s_barrier's.
-//   * -mllvm -disable-machine-sink for this file (Makefile): LLVM's MachineSink moved the first half-stage's eight MFMAs across
-//     the barrier into the join block behind the `if (s + 1 < nk)` (legal: nothing in between reads the accumulators), next to
-//     the second half's — all sixteen then sat BEHIND the barrier, the DMA issue and the next reads, and the fragment reads in
-//     front of the barrier had nothing to hide behind (found in the ISA; it also cost 18 v_mov_b64 per stage).
+//   * -mllvm -disable-machine-sink for this file (Makefile): LLVM's MachineSink had moved the first half-stage's eight MFMAs
+//     across the barrier into the join block behind an `if (s + 1 < nk)` (legal: nothing in between reads the accumulators) —
+//     all sixteen then sat BEHIND the barrier, the DMA issue and the next reads, and the fragment reads in front of the barrier
+//     had nothing to hide behind (found in the ISA; it also cost 18 v_mov_b64 per stage).
 //   * PERSISTENT WORKGROUPS, one per CU, walking their XCD's tile sequence: the next tile's first three stages are requested
-//     BEFORE the epilogue of the current one, and the epilogue's 512 KB of stores drain under the next tile's K loop instead of
-//     holding the CU until the workgroup has ended (the tiles of a launch end together: the stores came as four chip-wide bursts).
-//   * the sym_dequant epilogue in the float pipeline (dequant16f): 6 VALU per output element instead of 11.
+//     BEFORE the epilogue of the current one; the tile boundary waits with a counted vmcnt that leaves the epilogue's stores
+//     in flight.
+//   * the sym_dequant epilogue in the float pipeline (fq_gemm_common.hpp, dequant16f): 5 - 6 VALU per output element, not 11.
+// Built, measured and dropped (docs/DESIGN_LOG.md 10): E2M3 operands, v_mfma_scale_f32_16x16x128_f8f6f4 with its own operand image,
+// 128-token tiles with two stages and two workgroups per CU, non-temporal output stores, waves of 256 x 64 / 64 x 64.
 #include "fq_gemm_common.hpp"
 #include <type_traits>
 
@@ -47,8 +49,7 @@ constexpr int BLOB = 1536;                     // bytes: 32 rows x 64 k of BF6
 constexpr int SEG = 2 * BLOB;                  // a row tile's two blobs of one stage (128 k)
 constexpr int OPB = 8 * SEG;                   // the weight operand's share of a stage: 8 row tiles
 constexpr int TMT = 4;                         // token tiles per wave: the wave tile is 128 tokens x 64 features
-// Geometry of a workgroup tile of BM tokens x 256 features: BM / 128 x 4 waves of 128 x 64 (tried and dropped, round 3: waves of
-// 256 x 64 and of 64 x 64, DMA from one wave per SIMD, DMA behind the second half's MFMAs).
+// Geometry of a workgroup tile of BM tokens x 256 features: BM / 128 x 4 waves of 128 x 64.
 //   BM = 256: 8 waves, two per SIMD, 48 KB per stage — the prefill shape;
 //   BM = 128: 4 waves, 36 KB per stage — twice the tiles for launches that would leave CUs without one (2048 tokens x 4096
 //             features are 128 tiles of 256 x 256 on 256 CUs).
