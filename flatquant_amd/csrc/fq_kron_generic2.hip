@@ -48,12 +48,16 @@ int fq_launch_kron_grouped_mats(int flags, const void* x, const void* left, cons
 // all-output-sets instantiation of the workgroup-per-token kernel for the factor pairs of the supported model families,
 // fq_kron_general.hip for every other pair. The packed-only kernel families (wave / trio / compile-time output sets) and the
 // SiLU.mul / post-scale forms are the deploy contract, which is fp16-only in the reference (deploy/kernels/*.py assert it).
+int fq_launch_kron_wave_bf16(int flags, const void* x, const void* ws, const void* diag, int64_t rows, int M, int N,
+                             const FqQuantOut& out, int n_cu, hipStream_t stream);   // fq_kron_wave.hip
+
 int fq_launch_kron_generic_bf16(int flags, const f16* x_, const f16* left_, const f16* right_, const f16* diag_, int64_t rows, int M, int N,
                                 const FqQuantOut& out, void* workspace, int64_t workspace_bytes, int n_cu, hipStream_t stream) {
     const bf16 *x = (const bf16*)x_, *left = (const bf16*)left_, *right = (const bf16*)right_, *diag = (const bf16*)diag_;
-    if (flags & (FQ_IN_SILU_MUL | FQ_IN_RMSNORM)) return -1000;
+    if (flags & (FQ_IN_SILU_MUL | FQ_IN_RMSNORM)) return -1000;   // (deploy.nn.RMSNorm and the SiLU.mul fusion are fp16 contracts)
     if (out.post_scale != 0.0f) return -1000;
     if ((out.rt_flags & FQ_GROUP128) && !(flags & FQ_ROUND_Y_F16)) return -1000;  // (the group epilogue quantises the rounded transform)
+    const int flags_in = flags;
     flags &= ~FQ_NO_WAVE_KERNEL;
     if (!workspace || workspace_bytes < fq_kron_generic_workspace_bytes(M, N)) return -1001;
     const int MT = tiles32(M), NT = tiles32(N), KS1 = (N + 15) / 16;
@@ -64,6 +68,11 @@ int fq_launch_kron_generic_bf16(int flags, const f16* x_, const f16* left_, cons
     }
     flags &= ~FQ_WS_PREPARED;
     const bool spec = !(N & 15) && M <= 192 && !((M * N / 2) & 15);
+    const bool no_wave = (flags_in & FQ_NO_WAVE_KERNEL) != 0;
+    if (spec && !no_wave && !(out.rt_flags & FQ_GROUP128)) {   // one wave per token where a token fits a wave (packed output only)
+        const int rc = fq_launch_kron_wave_bf16(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
+        if (rc != -1000) return rc;
+    }
     if (out.rt_flags & FQ_GROUP128) {
         if (!spec) return -1000;
 #define FQ_FBG(MT_, NT_, KS1_, W_, OCC_) \

@@ -19,14 +19,13 @@
 //   * statistics, scale, magic-number quantiser and nibble packing on the accumulators in registers; a lane ends
 //     up with NT*16 consecutive n' of an output row = NT*8 contiguous bytes -> 16-byte stores.
 // LDS reads per 64x128 token: 16 (A) + 32 (R) + 8 (L) ds_read_b128 against 96 MFMAs.
+// bf16 activations (round 3, second session): the kernel is a template on the element type like the other path-A kernels (bf16 MFMA,
+// U / the optional Y rounding / the norm / the scale in bf16); fq_launch_kron_wave_bf16 serves the packed-only bf16 launches
+// that used to run the workgroup-per-token kernel (64 x 128: 117 us against 77).
 #include "fq_common.hpp"
 #include "fq_dma.hpp"
 
 namespace {
-
-__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
 
 template <int MT, int NT, int KS1, int W>
 struct WaveGeom {
@@ -76,10 +75,11 @@ __device__ __forceinline__ unsigned quant_row(const f32x16 (&Y)[NT][MT], int mo,
 // in four chains, wave all-reduce, v_rsq_f32), then every A fragment is scaled — fp32 product rounded to fp32 and to fp16, the
 // module's `(x.float() * rsqrt(...)).to(fp16)` — on its way into GEMM 1. No extra HBM traffic; the separate normalisation launch
 // moves 4 bytes per element.
-template <int MT, int NT, int KS1, int W, bool RMS = false>
-__global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
+template <int MT, int NT, int KS1, int W, bool RMS = false, typename T = f16>
+__global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const T* __restrict__ x, const uint4* __restrict__ ws,
                                                             int64_t rows, int64_t tpb, int M, FqQuantOut out) {
     typedef WaveGeom<MT, NT, KS1, W> G;
+    typedef typename FqVec<T>::x8 X8;
     constexpr int N = G::N, CPR = G::CPR;
     static_assert(NT <= 4 && MT <= 2, "a token must fit one wave's accumulators");
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
     for (int i = M * CPR + lane; i < MT * 32 * CPR; i += 64) reinterpret_cast<uint4*>(tokbuf)[i] = make_uint4(0, 0, 0, 0);
     unsigned voff[4];
     dma_offsets<CPR>(lane, voff);
-    if (slot < blk_cnt) dma_token<CPR>(x, blk_base + slot, tok_bytes, n_dma, tok_lds, voff);
+    if (slot < blk_cnt) dma_token<CPR>(reinterpret_cast<const f16*>(x), blk_base + slot, tok_bytes, n_dma, tok_lds, voff);   // (16-bit elements either way)
     __syncthreads();  // (no VMEM the compiler knows of is in flight: lgkmcnt(0) + s_barrier)
 
     // A-fragment byte offsets of this lane: row (32 mt + c), chunk (2 s + h) ^ swz(row)
@@ -135,17 +135,17 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
             constexpr int NCH = MT * 32 * CPR / 64;    // 16-byte chunks per lane (rows beyond M are zero: they add nothing)
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
-                const f16x8 v = __builtin_bit_cast(f16x8, tb[i * 64 + lane]);   // (the swizzle permutes chunks inside a row: the sum does not care)
+                const X8 v = __builtin_bit_cast(X8, tb[i * 64 + lane]);   // (the swizzle permutes chunks inside a row: the sum does not care)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) ss[j & 3] = __builtin_fmaf((float)v[j], (float)v[j], ss[j & 3]);
             }
             const float tot = fq_wave_sum((ss[0] + ss[1]) + (ss[2] + ss[3]));
             rinv = __builtin_amdgcn_rsqf(tot / (float)(M * N) + out.rms_eps);
         }
-        auto norm8 = [&](f16x8 v) -> f16x8 {
+        auto norm8 = [&](X8 v) -> X8 {
             if (RMS) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fq_mul_to<f16>((float)v[j], rinv);
+                for (int j = 0; j < 8; ++j) v[j] = fq_mul_to<T>((float)v[j], rinv);
             }
             return v;
         };
@@ -158,26 +158,26 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
             for (int mt = 0; mt < MT; ++mt) U[nt][mt] = f32x16{0};
         {
             const uint4* tb = reinterpret_cast<const uint4*>(tokbuf);
-            f16x8 A[2][MT], B[2][NT];
+            X8 A[2][MT], B[2][NT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) A[0][mt] = norm8(__builtin_bit_cast(f16x8, tb[(mt * 32 + c) * CPR + (h ^ sw)]));
+            for (int mt = 0; mt < MT; ++mt) A[0][mt] = norm8(__builtin_bit_cast(X8, tb[(mt * 32 + c) * CPR + (h ^ sw)]));
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) B[0][nt] = __builtin_bit_cast(f16x8, myr[(nt * KS1) * 64]);
+            for (int nt = 0; nt < NT; ++nt) B[0][nt] = __builtin_bit_cast(X8, myr[(nt * KS1) * 64]);
 #pragma unroll
             for (int s = 0; s < KS1; ++s) {
                 if (s + 1 < KS1) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         A[(s + 1) & 1][mt] =
-                            norm8(__builtin_bit_cast(f16x8, tb[(mt * 32 + c) * CPR + (((s + 1) * 2 + h) ^ sw)]));
+                            norm8(__builtin_bit_cast(X8, tb[(mt * 32 + c) * CPR + (((s + 1) * 2 + h) ^ sw)]));
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        B[(s + 1) & 1][nt] = __builtin_bit_cast(f16x8, myr[(nt * KS1 + s + 1) * 64]);
+                        B[(s + 1) & 1][nt] = __builtin_bit_cast(X8, myr[(nt * KS1 + s + 1) * 64]);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) U[nt][mt] = mfma32(A[s & 1][mt], B[s & 1][nt], U[nt][mt]);
+                    for (int mt = 0; mt < MT; ++mt) U[nt][mt] = fq_mfma32<T>(A[s & 1][mt], B[s & 1][nt], U[nt][mt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -187,18 +187,18 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
             int nxt = 0;
             if (lane == 0) nxt = (int)atomicAdd(next_slot, 1u);
             nxt = __builtin_amdgcn_readfirstlane(nxt);
-            if (nxt < blk_cnt) dma_token<CPR>(x, blk_base + nxt, tok_bytes, n_dma, tok_lds, voff);
+            if (nxt < blk_cnt) dma_token<CPR>(reinterpret_cast<const f16*>(x), blk_base + nxt, tok_bytes, n_dma, tok_lds, voff);
             next_pulled = nxt;
         }
 
         // ---- fp16 rounding of U (flat_utils.py:15): C fragments -> A fragments of GEMM 2, no data movement ----
-        f16x8 Uh[NT][2 * MT];  // [nt][ks]
+        X8 Uh[NT][2 * MT];  // [nt][ks]
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int ks = 0; ks < 2 * MT; ++ks)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) Uh[nt][ks][j] = (f16)U[nt][ks >> 1][(ks & 1) * 8 + j];
+                for (int j = 0; j < 8; ++j) Uh[nt][ks][j] = (T)U[nt][ks >> 1][(ks & 1) * 8 + j];
 
         // ---- GEMM 2, (ks, mo) outermost: Y[nt][mo] += U(:, nt)^T(ks) . L(ks, mo) ----
         f32x16 Y[NT][MT];  // Y^T of tile (nt, mo): rows n' = h*NT*16 + nt*16 + r, col m' = 32 mo + c
@@ -207,14 +207,14 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo) Y[nt][mo] = f32x16{0};
         {
-            f16x8 B[2];
-            B[0] = __builtin_bit_cast(f16x8, myl[0]);
+            X8 B[2];
+            B[0] = __builtin_bit_cast(X8, myl[0]);
 #pragma unroll
             for (int i = 0; i < 2 * MT * MT; ++i) {  // i = ks * MT + mo
-                if (i + 1 < 2 * MT * MT) B[(i + 1) & 1] = __builtin_bit_cast(f16x8, myl[(i + 1) * 64]);
+                if (i + 1 < 2 * MT * MT) B[(i + 1) & 1] = __builtin_bit_cast(X8, myl[(i + 1) * 64]);
                 const int ks = i / MT, mo = i % MT;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) Y[nt][mo] = mfma32(Uh[nt][ks], B[i & 1], Y[nt][mo]);
+                for (int nt = 0; nt < NT; ++nt) Y[nt][mo] = fq_mfma32<T>(Uh[nt][ks], B[i & 1], Y[nt][mo]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
 #pragma unroll
                 for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Y[nt][mo][r] = (float)(f16)Y[nt][mo][r];
+                    for (int r = 0; r < 16; ++r) Y[nt][mo][r] = (float)(T)Y[nt][mo][r];
         }
 
         // ---- per-token extrema over the valid entries ----
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
                 inv = fq_fast_inv(scale);
                 magic = fq_magic_ok(vmax, vmin, inv);
                 clampq = fq_needs_clamp(vmax, vmin, inv);
-                if (lane == 0) out.scale[ci][tok] = (f16)scale;
+                if (lane == 0) reinterpret_cast<T*>(out.scale[ci])[tok] = (T)scale;
             }
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo) {
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
                     magic = !__any(!fq_magic_ok(gmax, gmin, inv));    // wave-uniform route: the slowest any lane needs
                     clampq = __any(fq_needs_clamp(gmax, gmin, inv)) != 0;
                     if (h == 0 && !(c & 1) && (mo * 32 + c) < M)
-                        out.scale[ci][tok * (int64_t)(M * N / 128) + ((mo * 32 + c) >> 1)] = (f16)scale;
+                        reinterpret_cast<T*>(out.scale[ci])[tok * (int64_t)(M * N / 128) + ((mo * 32 + c) >> 1)] = (T)scale;
                 }
                 uint32_t pw[NT * 2];  // dword nt*2 + w: elements n' = h*NT*16 + nt*16 + 8w .. +8 of row 32 mo + c
                 unsigned near = (1u << (NT * 2)) - 1;  // !magic: quotients too large for the magic-number rounding
@@ -335,15 +335,15 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const f16* __restr
     }
 }
 
-template <int MT, int NT, int KS1, int W, bool RMS = false>
-int launch_wave(const f16* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
+template <int MT, int NT, int KS1, int W, bool RMS = false, typename T = f16>
+int launch_wave(const T* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
     typedef WaveGeom<MT, NT, KS1, W> G;
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
     int64_t blocks = (rows + W - 1) / W;
     if (blocks > n_cu) blocks = n_cu;  // one persistent workgroup per CU
     if (blocks < 1) blocks = 1;
     const int64_t tpb = (rows + blocks - 1) / blocks;
-    hipLaunchKernelGGL((fq_kron_wave_kernel<MT, NT, KS1, W, RMS>), dim3((unsigned)blocks), dim3(W * 64), 0, stream, x, ws, rows,
+    hipLaunchKernelGGL((fq_kron_wave_kernel<MT, NT, KS1, W, RMS, T>), dim3((unsigned)blocks), dim3(W * 64), 0, stream, x, ws, rows,
                        tpb, M, out);
     return (int)hipGetLastError();
 }
@@ -352,18 +352,23 @@ int launch_wave(const f16* x, const uint4* ws, int64_t rows, int M, const FqQuan
 
 // Returns -1000 when the shape / output set is not one this kernel covers (the caller falls back to the generic one).
 // ws: fragment workspace already filled by fq_kron_prepare_kernel (rfrag [NT][KS1][64], lfrag [2MT][MT][64]).
-int fq_launch_kron_wave(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
-                        const FqQuantOut& out, int n_cu, hipStream_t stream) {
+template <typename T>
+static int launch_kron_wave_t(int flags, const T* x, const void* ws, const void* diag, int64_t rows, int M, int N,
+                              const FqQuantOut& out, int n_cu, hipStream_t stream) {
     const bool rms = (flags & FQ_IN_RMSNORM) != 0;
     if ((flags & FQ_CT_MASK & ~FQ_IN_RMSNORM) != FQ_OUT_PACKED || diag != nullptr) return -1000;
     if (M < 1 || M > 64 || (N & 15) || ((M * (N / 8)) & 63)) return -1000;
     if ((out.rt_flags & FQ_GROUP128) && (N != 64 || (M & 1))) return -1000;  // groups = pairs of 64-element rows
     const int MT = (M + 31) / 32, KS1 = N / 16;
     const uint4* w = reinterpret_cast<const uint4*>(ws);
+    if (rms && !FqVec<T>::is_f16) return -1000;   // (deploy.nn.RMSNorm is an fp16 module: no bf16 instantiation with the norm)
 #define FQ_W(MT_, NT_, KS1_, W_)                                                                          \
-    if (MT == MT_ && KS1 == KS1_)                                                                        \
-        return rms ? launch_wave<MT_, NT_, KS1_, W_, true>(x, w, rows, M, out, n_cu, stream)             \
-                   : launch_wave<MT_, NT_, KS1_, W_>(x, w, rows, M, out, n_cu, stream);
+    if (MT == MT_ && KS1 == KS1_) {                                                                      \
+        if constexpr (FqVec<T>::is_f16) {                                                                \
+            if (rms) return launch_wave<MT_, NT_, KS1_, W_, true, T>(x, w, rows, M, out, n_cu, stream);  \
+        }                                                                                                \
+        return launch_wave<MT_, NT_, KS1_, W_, false, T>(x, w, rows, M, out, n_cu, stream);              \
+    }
     FQ_W(2, 4, 8, 7)    // 64x128
     FQ_W(2, 4, 7, 8)    // 64x112
     FQ_W(2, 3, 5, 12)   // 64x80 (5120 = Qwen2.5-14B/32B hidden, in the reference's benchmark list: kernel_benchmark.py:234-246)
@@ -371,4 +376,17 @@ int fq_launch_kron_wave(int flags, const f16* x, const void* ws, const f16* diag
     FQ_W(1, 2, 4, 16)   // 32x64
 #undef FQ_W
     return -1000;
+}
+
+int fq_launch_kron_wave(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
+                        const FqQuantOut& out, int n_cu, hipStream_t stream) {
+    return launch_kron_wave_t<f16>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
+}
+
+// the bf16 instantiations (called from fq_launch_kron_generic_bf16, fq_kron_generic2.hip; 64 x 64 stays with fq_kron64.hip)
+int fq_launch_kron_wave_bf16(int flags, const void* x, const void* ws, const void* diag, int64_t rows, int M, int N,
+                             const FqQuantOut& out, int n_cu, hipStream_t stream) {
+    if (M == 64 && N == 64) return -1000;
+    if (out.rt_flags & FQ_GROUP128) return -1000;   // (bf16 group-128 launches: the workgroup kernel's group epilogue)
+    return launch_kron_wave_t<bf16>(flags, (const bf16*)x, ws, diag, rows, M, N, out, n_cu, stream);
 }

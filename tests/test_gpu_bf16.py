@@ -207,6 +207,32 @@ def test_bf16_full_size_properties(ops):
     assert np.array_equal(bits(o.fq[0][idx]), O.bf16_bits(ref["fq"]))
 
 
+@pytest.mark.parametrize("M,N", [(64, 128), (64, 112), (64, 80), (56, 64), (32, 64), (37, 64)])
+@pytest.mark.parametrize("rows", [1, 7, 300])
+def test_bf16_packed_only_launches_on_the_wave_per_token_kernel(ops, M, N, rows):
+    """Packed-only bf16 launches whose token fits a wave run fq_kron_wave_kernel<..., bf16> (second session of round 3; they ran the
+    workgroup-per-token kernel). Same mathematics and fragment chaining: bit-equal, clip set by clip set and flag route by flag
+    route, to the launch that also returns the transform (the workgroup kernel), and to the oracle's quantiser on that transform."""
+    gen = torch.Generator().manual_seed(M * 131 + N + rows)
+    x = torch.randn(rows, M * N, generator=gen)
+    x[:, ::97] *= 20
+    x = x.to(BF).cuda()
+    L = (torch.randn(M, M, generator=gen) / M ** 0.5).to(BF).cuda()
+    R = (torch.randn(N, N, generator=gen) / N ** 0.5).to(BF).cuda()
+    sigs = [(0.9820137619972229, 0.9820137619972229), (0.9, 0.33), (1e-7, 1e-7)]   # magic-number, clamp, true-division routes
+    for flags in (P | NC0, P, P | RY | NC0):
+        both = ops.kron_quant(x, L, R, sigs, flags | T)
+        multi = ops.kron_quant(x, L, R, sigs, flags)
+        for ci, sig in enumerate(sigs):
+            one = ops.kron_quant(x, L, R, [sig], flags)
+            for o, k in ((one, 0), (multi, ci)):
+                assert torch.equal(o.q[k], both.q[ci]), (M, N, rows, flags, sig)
+                assert torch.equal(o.scale[k].view(torch.int16), both.scale[ci].view(torch.int16)), (M, N, rows, flags, sig)
+        if flags & RY:   # the quantiser saw exactly the bf16 transform the other launch returned
+            ref = O.quant_outputs(O.bf16_from_bits(bits(both.y)), *sigs[0], round_y_f16=True, clamp0=not (flags & NC0), lowp="bf16")
+            assert np.array_equal(multi.q[0].cpu().numpy(), ref["packed"])
+
+
 def test_bf16_refused_where_the_reference_has_no_bf16_contract(ops):
     from flatquant_amd import _lib
     x = torch.zeros(4, 4096, dtype=BF, device="cuda")
