@@ -388,6 +388,9 @@ def test_hot_kernels_keep_their_occupancy_budget():
         "fq_rowquant_wave_kernel<33,8,0,f16>": (4, 0),    # deploy Quantizer at 4096
         "fq_rowquant_wave_kernel<2,8,0,bf16>": (2, 0),    # ActivationQuantizer on bf16 rows of 4096
         "fq_had_pow2_kernel<8,1,1,1>": (3, 0),            # Hadamard 4096 + Quantizer
+        "fq_gemm_bf6_kernel<256>": (2, 0),                # Linear4bit, FP6 matrix path: 8 waves = two per SIMD, no spill (a spill's reload
+        "fq_gemm_bf6_kernel<128>": (2, 0),                # once sat between the DMA instructions of a stage behind s_waitcnt vmcnt(0))
+        "fq_gemm_i4_kernel": (4, 0),                      # int8 matrix path: 16 waves per workgroup
     }
     present = [k for k in budget if k in res]
     assert len(present) >= len(budget) - 2, sorted(set(budget) - set(res))      # (names follow the template arguments)
