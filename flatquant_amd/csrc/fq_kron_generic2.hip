@@ -46,8 +46,9 @@ int fq_launch_kron_grouped_mats(int flags, const void* x, const void* left, cons
 
 // bf16 activations (the path-A surface: kronecker_matmul, {Inv,SVD}DecomposeTransMatrix, the fake-quant contract): the
 // all-output-sets instantiation of the workgroup-per-token kernel for the factor pairs of the supported model families,
-// fq_kron_general.hip for every other pair. The packed-only kernel families (wave / trio / compile-time output sets) and the
-// SiLU.mul / post-scale forms are the deploy contract, which is fp16-only in the reference (deploy/kernels/*.py assert it).
+// fq_kron_general.hip for every other pair; packed-only launches whose token fits a wave take the bf16 instantiations of the
+// wave-per-token kernel (fq_kron_wave.hip). The other packed-only families (trio / duo / tall / compile-time output sets) and the
+// SiLU.mul / RMSNorm / post-scale forms are the deploy contract, which is fp16-only in the reference (deploy/kernels/*.py assert it).
 int fq_launch_kron_wave_bf16(int flags, const void* x, const void* ws, const void* diag, int64_t rows, int M, int N,
                              const FqQuantOut& out, int n_cu, hipStream_t stream);   // fq_kron_wave.hip
 
