@@ -210,11 +210,11 @@ __global__ __launch_bounds__(256, (PK && CT == 1) ? (RT == 4 ? 3 : 4) : (PK ? 2 
                         pk[i] = uint2{0u, 0u};
                         if (magic) {
                             if (clampq) {
-                                pk[i].x = fq_quant8_two<true>(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], ilo, ihi, d0);
-                                pk[i].y = fq_quant8_two<true>(t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15], ilo, ihi, d1);
+                                pk[i].x = fq_quant8<true>(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], inv, ilo, ihi, d0);
+                                pk[i].y = fq_quant8<true>(t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15], inv, ilo, ihi, d1);
                             } else {
-                                pk[i].x = fq_quant8_two<false>(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], ilo, ihi, d0);
-                                pk[i].y = fq_quant8_two<false>(t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15], ilo, ihi, d1);
+                                pk[i].x = fq_quant8<false>(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], inv, ilo, ihi, d0);
+                                pk[i].y = fq_quant8<false>(t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15], inv, ilo, ihi, d1);
                             }
                         }
                         if (d0)  // rare: an ambiguous digit somewhere in the wave -> the true division for this dword

@@ -17,6 +17,8 @@ constexpr int64_t FQ_K64_IMAGE_BYTES = 16384, FQ_K64_WS_BYTES = 32768;
 int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream);
+int fq_launch_had_mfma(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max, float sig_min,
+                       uint8_t* q_out, f16* scale_out, f16* y_out, int n_cu, hipStream_t stream);
 int fq_launch_hadamard_quant(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max,
                              float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream);
 int fq_launch_gemm_i4(const uint8_t* X, const uint8_t* W, int64_t M, int N, int K, int32_t* c, f16* y, const f16* srow,
@@ -677,6 +679,21 @@ int fq_hadamard_quant_f16(const void* x, int64_t rows, int n, int K, const void*
     if (rc == -1000)
         return fail(FQ_EUNSUPPORTED, "fq_hadamard_quant_f16: no fused kernel for n=%d K=%d (use fq_hadamard_f16 + fq_rowquant_f16)", n, K);
     return check_launch(rc, "fq_hadamard_quant_f16");
+}
+
+int fq_hadamard_quant_mfma_f16(const void* x, int64_t rows, int n, int K, const void* hadK, float scale, float sig_max,
+                               float sig_min, void* q_out, void* scale_out, void* y_out, void* stream) {
+    const char* what = "fq_hadamard_quant_mfma_f16";
+    if (!x || !q_out != !scale_out || (!q_out && !y_out)) return fail(FQ_EINVAL, "%s: NULL pointer (x, q_out with scale_out, or y_out)", what);
+    FQ_NEED_ALIGN16(what, x, hadK, q_out, y_out);
+    if (rows < 0 || n <= 0 || K <= 0 || n % K) return fail(FQ_EINVAL, "%s: bad sizes n=%d K=%d", what, n, K);
+    if (K > 1 && !hadK) return fail(FQ_EINVAL, "%s: hadK is NULL with K=%d", what, K);
+    if (q_out && (!(sig_max > 0.0f) || !(sig_min > 0.0f))) return fail(FQ_EINVAL, "%s: sig_max/sig_min must be > 0", what);
+    if (rows == 0) return FQ_OK;
+    const int rc = fq_launch_had_mfma((const f16*)x, rows, n, K, (const f16*)hadK, scale, sig_max, sig_min, (uint8_t*)q_out,
+                                      (f16*)scale_out, (f16*)y_out, cu_count(), (hipStream_t)stream);
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "%s: n=%d K=%d (n = K * 512 with K <= 32, K %% 4 == 0)", what, n, K);
+    return check_launch(rc, what);
 }
 
 int fq_kv_quant_f16(const void* x, const void* trans, int64_t rows, int head_dim, float clip_max, float clip_min,

@@ -234,6 +234,14 @@ __device__ __forceinline__ T fq_mul_to(float a, float b) {
     return (T)p;
 }
 __device__ __forceinline__ f16 fq_mul_to_f16(float a, float b) { return fq_mul_to<f16>(a, b); }
+// The same for two values at once: v_pk_mul_f32 (both fp32 products, each rounded to fp32) + v_cvt_pk_f16_f32 — one VALU per element
+// where two fq_mul_to_f16 cost two (the fp16 epilogues of the Hadamard-as-Kronecker launches: round 4). Needs f32x2 (defined below).
+typedef float fq_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f16x2 fq_mul_to_f16x2(float a0, float a1, fq_f32x2_t b2) {
+    fq_f32x2_t p = fq_f32x2_t{a0, a1} * b2;
+    asm volatile("" : "+v"(p));
+    return f16x2{(f16)p.x, (f16)p.y};
+}
 
 // FQ_GROUP128 with N = 64: a 128-element group is two consecutive 64-element rows of the transformed token, held by the
 // lanes (h, c) with c in {2j, 2j+1}, h in {0, 1} of one output-row tile: combine a per-lane partial extremum over
@@ -609,6 +617,122 @@ __device__ __forceinline__ uint32_t fq_quant8_two(float y0, float y1, float y2, 
     return a;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Round 4: the packed quantiser with the FRACTION IN THE LOW HALF — 23 VALU per 8 elements (19 with v_pk_fma_f32) against the 33
+// of fq_quant8_two; with the clamp 31 (27) against 41. tools/scratch/quant3.hip holds the experiment (exhaustive-style check
+// against the true division, issue rate alone and next to MFMA phases).
+//
+//   u = fma(y, inv, C),  C = 200.5 + 2^-16 (0x43488001: 24 significant bits, exact).  For p = y inv in [-8.5, 7.5) the sum lies
+//   in [192, 208) where ulp = 2^-16, so the ONE rounding of the fma leaves
+//       bits(u) = 0x43400000 + floor-to-nearest((p + 8.5 + 2^-16) 2^16)
+//   high half = 0x4340 + I,  I = floor(F) in [0, 15],  low half = frac(F) in units of 2^-16,  F = p + 8.5 + 2^-16 + e, |e| <= 2^-17.
+//   Claim: low half >= 2  =>  rint(fl(y / s)) = I - 8.   With f = low half 2^-16 in [2^-15, 1 - 2^-16]:
+//       p = (I - 8) - 0.5 + (f - 2^-16 - e),  f - 2^-16 - e in [2^-17, 1 - 1.5 2^-16]
+//   so p is at least 2^-17 = 7.6e-6 away from both half-integers next to I - 8, while fl(y / s) differs from p by at most
+//   |y/s| (2^-23 + 2^-24) (1 ulp of v_rcp_f32 in inv, the rounding of the quotient) < 3.1e-6 for |y/s| <= 17: fl(y / s) lies
+//   strictly inside (I - 8.5, I - 7.5) and rounds to I - 8 — no tie can occur. A low half of 0 or 1 (probability 3e-5 per
+//   element) flags the dword; the caller redoes it with the true division, as with fq_quant8_two.
+//   Digits: I is the offset-binary nibble. v_mad_u32_u16 (op_sel: high half of src0) accumulates sum (0x4340 + I_k) 16^k over
+//   four elements into 32 bits; the constant part 0x4340 * 0x1111 = 0x047BB740 of both halves leaves with the start value
+//   -(0x047BB740 * 65537) = 0x444448C0, (b << 16) + a is the offset-binary string and ^ 0x88888888 the two's complement.
+//   Test: v_min3_u16 over the low halves, one v_cmp per dword.
+//   CLAMP: v_med3_i32 on the BITS of u (positive floats order like integers, a negative u is a negative integer) between
+//   0x43408000 and 0x434F8000: p < -8.5 gives digit -8 and p >= 7.5 digit 7, which is what clamp(rint(.), -8, 7) gives them
+//   (at p = -8.5 exactly rint may be -8 or -9: both clamp to -8), and the clamped low half 0x8000 is never flagged.
+//   Callers guarantee what fq_quant8_two's callers do: without CLAMP every quotient of the token rounds into [-8, 7]
+//   (fq_needs_clamp), and |y inv| < 2^21 (fq_magic_ok) so that u is finite and monotone in y.
+// ---------------------------------------------------------------------------------------------------
+#define FQ_LO_MAD(acc, u, k, src2) "v_mad_u32_u16 %[" #acc "], %[" #u "], " k ", " src2 " op_sel:[1,0,0,0]\n\t"
+#define FQ_LO_CL(u) "v_med3_i32 %[" #u "], %[" #u "], %[blo], %[bhi]\n\t"
+#define FQ_LO_NOCL(u)
+// elements 0..3 of a dword: u0..u3 hold fma(y, inv, C); -> a (digits 0..3 + start value), tm (running minimum of the low halves)
+#define FQ_LO_HALF_A(CL)                                                                                     \
+    CL(u0) CL(u1) CL(u2) CL(u3)                                                                              \
+    FQ_LO_MAD(a, u0, "1", "%[ini]") FQ_LO_MAD(a, u1, "16", "%[a]") "v_min3_u16 %[tm], %[u0], %[u1], %[u2]\n\t" \
+    FQ_LO_MAD(a, u2, "%[k256]", "%[a]") FQ_LO_MAD(a, u3, "%[k4096]", "%[a]") "v_min_u16_e32 %[tm], %[tm], %[u3]\n\t"
+// elements 4..7: -> the finished dword in a, the ambiguity mask in m
+#define FQ_LO_HALF_B(CL)                                                                                     \
+    CL(u0) CL(u1) CL(u2) CL(u3)                                                                              \
+    FQ_LO_MAD(b, u0, "1", "0") FQ_LO_MAD(b, u1, "16", "%[b]") "v_min3_u16 %[tm], %[tm], %[u0], %[u1]\n\t"     \
+    FQ_LO_MAD(b, u2, "%[k256]", "%[b]") FQ_LO_MAD(b, u3, "%[k4096]", "%[b]") "v_min3_u16 %[tm], %[tm], %[u2], %[u3]\n\t" \
+    "v_cmp_gt_u16_e64 %[m], 2, %[tm]\n\t"                                                                    \
+    "v_lshl_add_u32 %[a], %[b], 16, %[a]\n\t"                                                                \
+    "v_xor_b32_e32 %[a], 0x88888888, %[a]"
+#define FQ_LO_FMA4(ya, yb, yc, yd)                                                                           \
+    "v_fma_f32 %[u0], %[" #ya "], %[inv], %[cc]\n\tv_fma_f32 %[u1], %[" #yb "], %[inv], %[cc]\n\t"             \
+    "v_fma_f32 %[u2], %[" #yc "], %[inv], %[cc]\n\tv_fma_f32 %[u3], %[" #yd "], %[inv], %[cc]\n\t"
+template <bool CLAMP, bool PK>
+__device__ __forceinline__ uint32_t fq_quant8_lo(f32x2 y01, f32x2 y23, f32x2 y45, f32x2 y67, float inv, unsigned long long& amb) {
+    uint32_t a, b, tm;
+    const uint32_t ini = 0x444448C0u, k256 = 256u, k4096 = 4096u, blo = 0x43408000u;
+    uint32_t bhi = 0x434F8000u;
+    if (CLAMP) asm volatile("" : "+v"(bhi));   // (v_med3_i32 is VOP3: one scalar operand per instruction on gfx9, the other bound sits in a VGPR)
+    if (PK) {
+        // (y0 inv + C, y1 inv + C) in one v_pk_fma_f32: src1 / src2 broadcast their low dword (op_sel_hi 0)
+        f32x2 u01, u23;
+        const f32x2 inv2 = {inv, inv};
+        const unsigned long long cc2 = 0x4348800143488001ull;
+        asm("v_pk_fma_f32 %[u01], %[y01], %[inv2], %[cc2]\n\tv_pk_fma_f32 %[u23], %[y23], %[inv2], %[cc2]"
+            : [u01] "=&v"(u01), [u23] "=&v"(u23) : [y01] "v"(y01), [y23] "v"(y23), [inv2] "v"(inv2), [cc2] "s"(cc2));
+        {
+            uint32_t u0 = __builtin_bit_cast(uint32_t, u01.x), u1 = __builtin_bit_cast(uint32_t, u01.y), u2 = __builtin_bit_cast(uint32_t, u23.x),
+                     u3 = __builtin_bit_cast(uint32_t, u23.y);
+            if (CLAMP)
+                asm(FQ_LO_HALF_A(FQ_LO_CL) : [a] "=&v"(a), [tm] "=&v"(tm), [u0] "+v"(u0), [u1] "+v"(u1), [u2] "+v"(u2), [u3] "+v"(u3)
+                    : [ini] "s"(ini), [k256] "s"(k256), [k4096] "s"(k4096), [blo] "s"(blo), [bhi] "v"(bhi));
+            else
+                asm(FQ_LO_HALF_A(FQ_LO_NOCL) : [a] "=&v"(a), [tm] "=&v"(tm) : [u0] "v"(u0), [u1] "v"(u1), [u2] "v"(u2), [u3] "v"(u3),
+                    [ini] "s"(ini), [k256] "s"(k256), [k4096] "s"(k4096));
+        }
+        asm("v_pk_fma_f32 %[u01], %[y01], %[inv2], %[cc2]\n\tv_pk_fma_f32 %[u23], %[y23], %[inv2], %[cc2]"
+            : [u01] "=&v"(u01), [u23] "=&v"(u23) : [y01] "v"(y45), [y23] "v"(y67), [inv2] "v"(inv2), [cc2] "s"(cc2));
+        {
+            uint32_t u0 = __builtin_bit_cast(uint32_t, u01.x), u1 = __builtin_bit_cast(uint32_t, u01.y), u2 = __builtin_bit_cast(uint32_t, u23.x),
+                     u3 = __builtin_bit_cast(uint32_t, u23.y);
+            if (CLAMP)
+                asm(FQ_LO_HALF_B(FQ_LO_CL) : [a] "+v"(a), [b] "=&v"(b), [tm] "+v"(tm), [m] "=&s"(amb), [u0] "+v"(u0), [u1] "+v"(u1), [u2] "+v"(u2),
+                    [u3] "+v"(u3) : [k256] "s"(k256), [k4096] "s"(k4096), [blo] "s"(blo), [bhi] "v"(bhi));
+            else
+                asm(FQ_LO_HALF_B(FQ_LO_NOCL) : [a] "+v"(a), [b] "=&v"(b), [tm] "+v"(tm), [m] "=&s"(amb) : [u0] "v"(u0), [u1] "v"(u1), [u2] "v"(u2),
+                    [u3] "v"(u3), [k256] "s"(k256), [k4096] "s"(k4096));
+        }
+    } else {
+        uint32_t u0, u1, u2, u3;
+        const float y0 = y01.x, y1 = y01.y, y2 = y23.x, y3 = y23.y, y4 = y45.x, y5 = y45.y, y6 = y67.x, y7 = y67.y;
+        const uint32_t cc = 0x43488001u;
+#define FQ_LO_OUTS [a] "=&v"(a), [b] "=&v"(b), [tm] "=&v"(tm), [m] "=&s"(amb), [u0] "=&v"(u0), [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3)
+#define FQ_LO_INS [y0] "v"(y0), [y1] "v"(y1), [y2] "v"(y2), [y3] "v"(y3), [y4] "v"(y4), [y5] "v"(y5), [y6] "v"(y6), [y7] "v"(y7), \
+                  [inv] "v"(inv), [cc] "s"(cc), [ini] "s"(ini), [k256] "s"(k256), [k4096] "s"(k4096)
+        if (CLAMP)
+            asm(FQ_LO_FMA4(y0, y1, y2, y3) FQ_LO_HALF_A(FQ_LO_CL) FQ_LO_FMA4(y4, y5, y6, y7) FQ_LO_HALF_B(FQ_LO_CL)
+                : FQ_LO_OUTS : FQ_LO_INS, [blo] "s"(blo), [bhi] "v"(bhi));
+        else
+            asm(FQ_LO_FMA4(y0, y1, y2, y3) FQ_LO_HALF_A(FQ_LO_NOCL) FQ_LO_FMA4(y4, y5, y6, y7) FQ_LO_HALF_B(FQ_LO_NOCL)
+                : FQ_LO_OUTS : FQ_LO_INS);
+#undef FQ_LO_OUTS
+#undef FQ_LO_INS
+    }
+    return a;
+}
+#undef FQ_LO_MAD
+#undef FQ_LO_CL
+#undef FQ_LO_NOCL
+#undef FQ_LO_HALF_A
+#undef FQ_LO_HALF_B
+#undef FQ_LO_FMA4
+
+// What the packed kernels call. FQ_QUANT_LO selects the formulation at build time: 0 fq_quant8_two (two-sided, round 3),
+// 1 fq_quant8_lo with single-width fmas, 2 with v_pk_fma_f32. Bit-identical results by construction (both are exact or flagged).
+#ifndef FQ_QUANT_LO
+#define FQ_QUANT_LO 1
+#endif
+template <bool CLAMP>
+__device__ __forceinline__ uint32_t fq_quant8(float y0, float y1, float y2, float y3, float y4, float y5, float y6, float y7, float inv,
+                                              float ilo, float ihi, unsigned long long& differ) {
+    if (FQ_QUANT_LO == 0) return fq_quant8_two<CLAMP>(y0, y1, y2, y3, y4, y5, y6, y7, ilo, ihi, differ);
+    return fq_quant8_lo<CLAMP, FQ_QUANT_LO == 2>(f32x2{y0, y1}, f32x2{y2, y3}, f32x2{y4, y5}, f32x2{y6, y7}, inv, differ);
+}
+
 // The quantiser of the FAKE-QUANT output (FlatQuantizedLinear._eval_forward, flat_linear.py:75-80 -> quant_utils.py:77-83):
 // eight transformed values -> eight fp16 (bf16) values scale * q, one asm block, single-width VALU only (round 3; the C++ form
 // fq_qmagic2 is turned into v_pk_fma_f32 / v_pk_add_f32 by the SLP vectoriser: slow next to other waves' MFMAs, see above).
@@ -671,34 +795,46 @@ __device__ __forceinline__ float fq_inv_hi(float inv) { return inv * 1.000000476
 // ---------------------------------------------------------------------------------------------------
 // The fp16 (deploy Quantizer) contract on PACKED fp16 pairs, single-width VALU, no division: 8 elements -> one dword.
 //   q = clamp(rint(RN16(x / s)), -8, 7)                     (quant.cu:40 __hdiv, __half2int_rn; x, s fp16)
-// Exact fp16 quotient in three fp32 operations that read the fp16 halves directly (v_fma_mix_f32):
-//   t = x * r (r = v_rcp_f32(s)),  e = fma(-t, s, x)  (EXACT: the residual has <= 13 significant bits),
-//   t' = fma(e, r, t) = RN32(x / s) up to 2^-44   =>   RN16(t') == RN16(x / s)
-// because a quotient of two 11-bit significands is never within 2^-24 (relative) of an fp16 rounding boundary, or
-// within 2^-36 of an fp32 one, unless it sits exactly on it (then t' is exact and rounds the same way). Checked for
-// every positive fp16 x against 3072 scales and reciprocals off by +-1 ulp (round-2 notes; the sign is
-// symmetric). Then v_cvt_pk_f16_f32, an optional packed clamp (rint and the clamp to [-8, 7] commute: the bounds are
+// Exact fp16 quotient in TWO fp32 operations per element that read the fp16 halves directly (v_fma_mix_f32) — round 4; round 3
+// used three (t = x r, e = fma(-t, s, x), t' = fma(e, r, t) with r = v_rcp_f32(s)):
+//   once per row:  rhi = RN32(1 / s) (the IEEE division),  e = fma(-s, rhi, 1) (EXACT: s has 11 significant bits, the residual of
+//                  a correctly rounded reciprocal at most 11),  rlo = RN32(e rhi)   =>   rhi + rlo = (1 / s)(1 + d), |d| < 2^-46
+//   per element:   p = RN32(x rlo),  t = fma(x, rhi, p) = RN32(Q (1 + d')), Q = x / s, |d'| < 2^-45   (x rhi is exact inside the fma)
+//   RN16(t) == RN16(Q): a quotient of two 11-bit significands is never within 2^-23 (relative) of an fp16 rounding boundary m (a
+//   12-bit significand) unless it IS m — x - m s is a multiple of one unit in the last place of the 23-bit product m s — and t is
+//   within 2^-24 + 2^-45 of Q: the same side of every boundary; and Q == m gives t == m exactly (m is an fp32 value), the same tie.
+//   (Checked on the device against the native _Float16 division for every positive fp16 x and 3072 scales: tools/scratch/h16div2.hip.)
+// Then v_cvt_pk_f16_f32, an optional packed clamp (rint and the clamp to [-8, 7] commute: the bounds are
 // integers), v_pk_add_f16 with 1536.0 = 1.5 * 2^10 (the sum rounds to an integer, half to even, and 1536 is even: the
 // low byte of each half is the two's-complement digit), and the eight low nibbles are gathered with v_perm_b32 / v_bfi_b32.
-// 39 VALU per 8 elements (47 with the clamp) against ~100 for the per-element C++ form.
+// 31 VALU per 8 elements (39 with the clamp) against 39 (47) of the round-3 form and ~100 of the per-element C++ form.
+struct FqH16Recip {
+    float hi, lo;
+};
+// (pure function of a row-uniform scale: call it once per row, outside the element loop)
+__device__ __forceinline__ FqH16Recip fq_h16_recip(float s) {
+    FqH16Recip r;
+    r.hi = 1.0f / s;                                  // correctly rounded (the build keeps IEEE division)
+    r.lo = __builtin_fmaf(-s, r.hi, 1.0f) * r.hi;
+    return r;
+}
 template <bool CLAMP>
-__device__ __forceinline__ uint32_t fq_quant8_h16(uint32_t xa, uint32_t xb, uint32_t xc, uint32_t xd, float r, float s) {
+__device__ __forceinline__ uint32_t fq_quant8_h16(uint32_t xa, uint32_t xb, uint32_t xc, uint32_t xd, FqH16Recip rc) {
     uint32_t ha, hb, hc, hd;
-    float t0, t1, e0, e1;
+    float t0, t1, l0, l1;
+    const float rhi = rc.hi, rlo = rc.lo;
     const uint32_t magic2 = 0x66006600u;   // (1536.0h, 1536.0h)
     const uint32_t sel = 0x06040200u;      // bytes 0 and 2 of the second source, then of the first
-#define FQ_H16_PAIR(h, x)                                                                   \
-    "v_fma_mix_f32 %[t0], %[" #x "], %[r], 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"          \
-    "v_fma_mix_f32 %[t1], %[" #x "], %[r], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"          \
-    "v_fma_mix_f32 %[e0], -%[t0], %[s], %[" #x "] op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"     \
-    "v_fma_mix_f32 %[e1], -%[t1], %[s], %[" #x "] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"     \
-    "v_fma_f32 %[t0], %[e0], %[r], %[t0]\n\t"                                               \
-    "v_fma_f32 %[t1], %[e1], %[r], %[t1]\n\t"                                               \
+#define FQ_H16_PAIR(h, x)                                                                       \
+    "v_fma_mix_f32 %[l0], %[" #x "], %[rlo], 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"            \
+    "v_fma_mix_f32 %[l1], %[" #x "], %[rlo], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"            \
+    "v_fma_mix_f32 %[t0], %[" #x "], %[rhi], %[l0] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"        \
+    "v_fma_mix_f32 %[t1], %[" #x "], %[rhi], %[l1] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"        \
     "v_cvt_pk_f16_f32 %[" #h "], %[t0], %[t1]\n\t"
     asm(FQ_H16_PAIR(ha, xa) FQ_H16_PAIR(hb, xb) FQ_H16_PAIR(hc, xc) FQ_H16_PAIR(hd, xd)
-        : [ha] "=&v"(ha), [hb] "=&v"(hb), [hc] "=&v"(hc), [hd] "=&v"(hd), [t0] "=&v"(t0), [t1] "=&v"(t1), [e0] "=&v"(e0),
-          [e1] "=&v"(e1)
-        : [xa] "v"(xa), [xb] "v"(xb), [xc] "v"(xc), [xd] "v"(xd), [r] "v"(r), [s] "v"(s));
+        : [ha] "=&v"(ha), [hb] "=&v"(hb), [hc] "=&v"(hc), [hd] "=&v"(hd), [t0] "=&v"(t0), [t1] "=&v"(t1), [l0] "=&v"(l0),
+          [l1] "=&v"(l1)
+        : [xa] "v"(xa), [xb] "v"(xb), [xc] "v"(xc), [xd] "v"(xd), [rhi] "v"(rhi), [rlo] "v"(rlo));
 #undef FQ_H16_PAIR
     if (CLAMP) {
         const uint32_t lo = 0xC800C800u;   // (-8.0h, -8.0h)

@@ -1,0 +1,350 @@
+// fq_had_mfma.hip — the online Hadamard rotation of n = K * 512 (K <= 32, K % 4 == 0: 14336 = 28 * 512, Llama-3-8B's ffn width)
+// fused with the deploy Quantizer, with the STRUCTURE of the rotation used instead of two dense Kronecker factors (round 4).
+//   y = hadK [K,K] @ FWHT_512( x.view(rows, K, 512) ) / sqrt(n)            hadamard_utils.py:132-141, deploy/functional/online_trans.py:144-151
+//   -> deploy.nn.Quantizer (deploy/nn/quantization.py:13-36), packed INT4 + fp16 scale per token
+//
+// Why. As ONE Kronecker launch (fq_kron_trio.hip: 112 x 128 = (hadK (x) H_4) (x) H_128) a token costs 240 dense 32x32x16 MFMAs, and on
+// this part the matrix pipe's ENERGY is what the launch pays for: every fused kernel of this library runs AT the 1400 W package cap
+// (profiles/r03_power_clock.txt), 0.8 PFLOP/s of fp16 MFMA next to 3.6 TB/s of HBM traffic, and a 13 % cut of the VALU stream moved the
+// three-group kernel by 1 % (profiles/r04_quant_lo_ab.txt). H_512 = H_4 (x) H_4 (x) H_32 needs no dense 128-wide contraction:
+//   token x[k, a, b, c]   (k < K rows of hadK; a, b in 0..3; c in 0..31;   memory row 4 k + a of 128 columns 32 b + c)
+//   1. b-butterfly (H_4 over the four 32-column blocks) on the A fragments, packed fp16 adds, scaled by nothing (the sums stay in range:
+//      the activation is the fp16 input, a sum of four doubles its RMS);
+//   2. GEMM 1: contraction over c with H_32 / 16 — K = 32: TWO MFMAs per row tile instead of eight;
+//   3. a-butterfly (H_4 over the four ROW TILES: rows are read in the order (a, k), so a is the tile index and the butterfly is
+//      element-wise across the wave's four accumulator tiles, fp32);
+//   4. rounding to fp16, chained into GEMM 2's A operand in registers as in every kernel here;
+//   5. GEMM 2: contraction over k with hadK (zero-padded to 32 x 32) — TWO MFMAs per output tile instead of seven;
+//   6. x 16 / sqrt(n) in fp32, rounding to fp16, the Quantizer's fp16 arithmetic (fq_quant8_h16), 8-byte stores.
+// 16 MFMAs per wave and token instead of 60; both B operands are 2 x 4 VGPRs generated once per wave (H_32 from the parity of c & c',
+// hadK from the caller's [K, K] table): no fragment image, no L image in LDS, no workspace.
+// Structure otherwise as fq_kron_trio.hip: one persistent 12-wave workgroup per CU, three token groups of four waves (wave w owns the
+// output columns of block b' = w), LDS-DMA staging, meetings on LDS counters, token claims one ahead.
+// Rounding points differ from the FWHT route (fq_hadamard_reg.hip) and from the dense Kronecker route: parity is the reference's own
+// tolerance class for this op (tests/test_gpu_hadamard.py: 2e-3 of the row maximum against matmul_hadU's fixtures), not bit identity;
+// ops.hadamard_quant(fwht_route=True) keeps the bit-identical route.
+#include "fq_common.hpp"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void hm_lds_void;
+
+#ifndef HM_ABL
+#define HM_ABL 0   // measurement builds: 1 no quantiser, 2 no GEMM 1, 4 no GEMM 2, 8 no stores, 16 no DMA after the first, 32 no b-butterfly, 64 no a-butterfly
+#endif
+#ifndef HM_NGROUPS
+#define HM_NGROUPS 3   // token groups per CU (4: sixteen waves, needs <= 128 VGPRs)
+#endif
+constexpr int HM_GROUPS = HM_NGROUPS, HM_WPG = 4, HM_THREADS = HM_GROUPS * HM_WPG * 64;
+constexpr int HM_TOKBUF = 128 * 256;   // bytes: 128 rows (4 tiles of 32; rows >= 4 K stay zero) of 128 fp16
+constexpr int HM_LDS = HM_GROUPS * HM_TOKBUF + HM_GROUPS * 32 + 64;   // + [max x4][min x4] per group + control words
+
+__device__ __forceinline__ unsigned hm_lds_read(unsigned addr) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned hm_lds_add_rtn(unsigned addr, unsigned val) {
+    unsigned v;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr), "v"(val) : "memory");
+    return v;
+}
+__device__ __forceinline__ void hm_lds_write(unsigned addr, unsigned val) {
+    asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(val) : "memory");
+}
+// group meeting on a counter in LDS (see fq_kron_trio.hip)
+__device__ __forceinline__ void hm_meet(unsigned cnt_lds, unsigned target, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) asm volatile("ds_add_u32 %0, %1" : : "v"(cnt_lds), "v"(1u) : "memory");
+    for (;;) {
+        unsigned v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cnt_lds) : "memory");
+        if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+#define HM_MEET() { meet_n += 4; hm_meet(meet, meet_n, lane); }
+
+// a * sgn + c on packed fp16 pairs with sgn = (+-1, +-1): the product is exact, ONE rounding (of the sum) — a packed add or subtract
+// whose sign is a wave-uniform operand instead of a branch
+__device__ __forceinline__ uint32_t hm_pk_addsub(uint32_t c, uint32_t a, uint32_t sgn) {
+    uint32_t d;
+    asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(sgn), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 hm_pk_add32(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 hm_pk_sub32(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// QUANT: packed INT4 + scale (the Quantizer); YOUT: the rotated activation itself, fp16 (matmul_hadU_cuda's result)
+template <bool QUANT, bool YOUT>
+__global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __restrict__ x, const f16* __restrict__ hadK, int K, int64_t rows,
+                                                             int64_t tpb, float post_scale, float sig_max, float sig_min,
+                                                             uint8_t* __restrict__ q_out, f16* __restrict__ scale_out,
+                                                             f16* __restrict__ y_out) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[HM_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;   // token group; this wave's column block b' (output columns 32 wq .. 32 wq + 31)
+    unsigned char* tokbuf = smem + grp * HM_TOKBUF;
+    float* red = reinterpret_cast<float*>(smem + HM_GROUPS * HM_TOKBUF) + grp * 8;   // [max x4][min x4]
+    unsigned* ctl = reinterpret_cast<unsigned*>(smem + HM_GROUPS * HM_TOKBUF + HM_GROUPS * 32);   // [meet x G][next][claim x G]
+    const unsigned ctl_lds = (unsigned)(size_t)(hm_lds_void*)ctl, meet = ctl_lds + grp * 4;
+    const unsigned tok_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(hm_lds_void*)tokbuf);
+    const int M = 4 * K;                       // token rows of 256 bytes
+    const int64_t tok_bytes = (int64_t)M * 256;
+    const int n_dma = K;                       // 1 KB instructions per token: instruction i = rows 4 i .. 4 i + 3 = (k = i, a = 0..3)
+    const int per = (n_dma + 3) >> 2, d0 = wq * per;
+    const int dn = n_dma - d0 < per ? (n_dma - d0 < 0 ? 0 : n_dma - d0) : per;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(x);
+
+    const int64_t blk_base = (int64_t)blockIdx.x * tpb;
+    const int blk_cnt = (int)(rows - blk_base < tpb ? (rows - blk_base < 0 ? 0 : rows - blk_base) : tpb);
+
+    // ---- once per workgroup: control words, the zero rows below the token ----
+    if (tid < 16) ctl[tid] = tid == HM_GROUPS ? HM_GROUPS : 0;   // meeting counters, the next unclaimed token, (published claims)
+    constexpr unsigned NEXT = HM_GROUPS * 4, CLAIM = HM_GROUPS * 4 + 4;   // byte offsets inside ctl
+    for (int i = M * 16 + (tid & 255); i < 128 * 16; i += 256) reinterpret_cast<uint4*>(tokbuf)[i] = make_uint4(0, 0, 0, 0);
+
+    // ---- once per wave: the two B operands, in registers for the whole launch ----
+    // GEMM 1: B1[s] lane (h, c) element j = H_32[cc = 16 s + 8 h + j][pi(c)] / 16. pi puts the 16 registers of an output lane on 16
+    // consecutive output columns: accumulator row i = 8 q + 4 h' + t (q = r >> 2, t = r & 3) of GEMM 2's output is the column that
+    // GEMM 1's lane c = i produced, and lane (h', .) register r shall hold column 16 h' + r: pi(8 q + 4 h' + t) = 16 h' + 4 q + t.
+    // GEMM 2: B2[s] lane (h, c) element j = hadK[k' = c][kk] for the K-order of the chained A operand, kk = 16 s + 8 (j >> 2) + 4 h + (j & 3)
+    // (register r = 8 s + j of the rounded accumulator holds row 8 (r >> 2) + 4 h + (r & 3)); zero beyond K.
+    f16x8 B1[2], B2[2];
+    {
+        const int pic = 16 * ((c >> 2) & 1) + 4 * (c >> 3) + (c & 3);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int cc = 16 * s + 8 * h + j;
+                B1[s][j] = (__builtin_popcount(cc & pic) & 1) ? (f16)-0.0625f : (f16)0.0625f;
+                const int kk = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+                B2[s][j] = (kk < K && c < K) ? hadK[c * K + kk] : (f16)0.0f;
+            }
+    }
+    __syncthreads();   // (the zero fill is visible before any DMA lands next to it; hadK has arrived: vmcnt(0))
+#pragma unroll
+    for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(B1[s]), "+v"(B2[s]));
+
+    // This wave's share of token k's DMA: instructions [d0, d0 + dn). Instruction i fills the LDS rows 4 i .. 4 i + 3 linearly; lane l
+    // (row 4 i + l / 16, position l % 16) fetches the chunk that the swizzle maps there: position ^ (row >> 2 & 15) = l % 16 ^ (i & 15)
+    // — keyed on row >> 2 because an A fragment reads the rows 4 c + a of 32 lanes c: their positions must differ with c.
+    auto stage_token = [&](int k) {
+        const unsigned char* src = xb + (blk_base + k) * tok_bytes;
+        const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)src);
+        const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((size_t)src >> 32));
+        const unsigned long long sb = (unsigned long long)lo32 | ((unsigned long long)hi32 << 32);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int lb = ln & 48, lp = ln & 15;
+        for (int j = 0; j < dn; ++j) {
+            const int i = d0 + j;   // wave-uniform
+            const unsigned rv = (unsigned)((lb + (lp ^ (i & 15))) << 4);
+            unsigned keep;
+            asm volatile(
+                "s_nop 4\n\t"
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %3\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, %2 nt\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(rv), "s"(sb + (unsigned long long)i * 1024),
+                  "s"((unsigned)__builtin_amdgcn_readfirstlane((int)(tok_lds + (unsigned)i * 1024)))
+                : "memory");
+        }
+    };
+    if (grp < blk_cnt && dn > 0) stage_token(grp);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    unsigned meet_n = 0;
+    for (int k = grp; k < blk_cnt;) {   // k: the group's current token (of this workgroup's range), claimed one token ahead
+        const int64_t tok = blk_base + k;
+        HM_MEET()   // C|A: every wave of the group waited for its share of the DMA before its stores
+
+        // ===== phase A: b-butterfly on the A fragments, GEMM 1 (contraction over c, K = 32), a-butterfly, fp16 rounding =====
+        f16x8 Uh[4][2];
+        {
+            int cl = c, hl = h;
+            asm volatile("" : "+v"(cl), "+v"(hl));   // (address arithmetic stays inside the loop)
+            const uint4* tb = reinterpret_cast<const uint4*>(tokbuf) + cl * 64;   // row 4 c (+ a): 16 chunks per row
+            const int sw = cl & 15;
+            const uint32_t sg1 = (wq & 1) ? 0xBC00BC00u : 0x3C003C00u, sg2 = (wq & 2) ? 0xBC00BC00u : 0x3C003C00u;   // packed (+-1.0h, +-1.0h)
+            f32x16 U[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) U[a] = f32x16{0};
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    // the four column blocks of (row tile a, K-step s): chunk 4 b + 2 s + h of row 4 c + a
+                    u32x4 X[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) X[b] = __builtin_bit_cast(u32x4, tb[a * 16 + ((4 * b + 2 * s + hl) ^ sw)]);
+                    u32x4 A;
+                    if (HM_ABL & 32) A = X[wq];
+                    else {
+                        // H_4 column wq: (+ + + +), (+ - + -), (+ + - -), (+ - - +): x0 + s1 x1 + s2 (x2 + s1 x3)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t p = hm_pk_addsub(X[0][e], X[1][e], sg1), q = hm_pk_addsub(X[2][e], X[3][e], sg1);
+                            A[e] = hm_pk_addsub(p, q, sg2);
+                        }
+                    }
+                    if (!(HM_ABL & 2)) U[a] = fq_mfma32<f16>(__builtin_bit_cast(f16x8, A), B1[s], U[a]);
+                }
+            }
+            if (!(HM_ABL & 64)) {
+                // a-butterfly: U''[a'] = sum_a H_4[a][a'] U[a], element-wise across the four accumulator tiles (64 v_pk_add_f32)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f32x2 u0 = {U[0][2 * j], U[0][2 * j + 1]}, u1 = {U[1][2 * j], U[1][2 * j + 1]};
+                    const f32x2 u2 = {U[2][2 * j], U[2][2 * j + 1]}, u3 = {U[3][2 * j], U[3][2 * j + 1]};
+                    const f32x2 s0 = hm_pk_add32(u0, u1), s1 = hm_pk_sub32(u0, u1), s2 = hm_pk_add32(u2, u3), s3 = hm_pk_sub32(u2, u3);
+                    const f32x2 o0 = hm_pk_add32(s0, s2), o1 = hm_pk_add32(s1, s3), o2 = hm_pk_sub32(s0, s2), o3 = hm_pk_sub32(s1, s3);
+                    U[0][2 * j] = o0.x, U[0][2 * j + 1] = o0.y, U[1][2 * j] = o1.x, U[1][2 * j + 1] = o1.y;
+                    U[2][2 * j] = o2.x, U[2][2 * j + 1] = o2.y, U[3][2 * j] = o3.x, U[3][2 * j + 1] = o3.y;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) Uh[a][p][j] = (f16)U[a][p * 8 + j];
+        }
+
+        // ===== phase B: next token's DMA, GEMM 2 (contraction over k with hadK, K = 32 per output tile), extrema =====
+        if (wq == 0 && lane == 0) hm_lds_write(ctl_lds + CLAIM + grp * 4, hm_lds_add_rtn(ctl_lds + NEXT, 1u));   // claim the next token
+        HM_MEET()   // A|B: the group has read its token buffer
+        const int knext = __builtin_amdgcn_readfirstlane((int)hm_lds_read(ctl_lds + CLAIM + grp * 4));
+        const bool more = !(HM_ABL & 16) && knext < blk_cnt && dn > 0;
+        if (more) stage_token(knext);
+        f32x16 Y[4];   // Y^T of (column block wq, row tile a'): register r of lane (h, c) = column 32 wq + 16 h + r of row (a', k' = c)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            Y[a] = f32x16{0};
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                if (!(HM_ABL & 4)) Y[a] = fq_mfma32<f16>(Uh[a][s], B2[s], Y[a]);
+        }
+        uint32_t H[4][8];   // the fp16 pairs the deploy Quantizer sees (and the transform output)
+        float vmax = 0.0f, vmin = 0.0f;
+        {
+            f16x2 pmax = {(f16)-INFINITY, (f16)-INFINITY}, pmin = {(f16)INFINITY, (f16)INFINITY};
+            const f32x2 ps2 = {post_scale, post_scale};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f16x2 pr = fq_mul_to_f16x2(Y[a][2 * j], Y[a][2 * j + 1], ps2);   // fp32 product, then fp16: two roundings, as the other routes
+                    H[a][j] = __builtin_bit_cast(uint32_t, pr);
+                    if (QUANT) {
+                        pmax = fq_pk_max(pmax, pr);
+                        pmin = fq_pk_min(pmin, pr);
+                    }
+                }
+            if (QUANT) {
+                // lanes c >= K hold the zero columns of the padded hadK: 0 never moves extrema that are clamped through 0 (Quantizer)
+                vmax = fq_wave_max(fmaxf((float)pmax[0], (float)pmax[1]));
+                vmin = fq_wave_min(fminf((float)pmin[0], (float)pmin[1]));
+                if (lane == 0) {
+                    red[wq] = vmax;
+                    red[4 + wq] = vmin;
+                }
+            }
+        }
+
+        // ===== phase C: the token's extrema, scale, quantiser, pack, stores =====
+        uint2 pk[4];
+        float scale = 1.0f;
+        if (QUANT) {
+            HM_MEET()   // B|C: the four partial extrema are in LDS
+            {
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(red), r1 = *reinterpret_cast<const f32x4*>(red + 4);
+                vmax = fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3]));
+                vmin = fminf(fminf(r1[0], r1[1]), fminf(r1[2], r1[3]));
+            }
+            scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, sig_max, sig_min, FQ_SIG_F16);
+            const float inv = fq_fast_inv(scale);
+            const bool clampq = fq_h16_needs_clamp(vmax, vmin, inv);
+            const FqH16Recip rc = fq_h16_recip(scale);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (HM_ABL & 1) pk[a] = uint2{H[a][0], H[a][4]};
+                else if (clampq) {
+                    pk[a].x = fq_quant8_h16<true>(H[a][0], H[a][1], H[a][2], H[a][3], rc);
+                    pk[a].y = fq_quant8_h16<true>(H[a][4], H[a][5], H[a][6], H[a][7], rc);
+                } else {
+                    pk[a].x = fq_quant8_h16<false>(H[a][0], H[a][1], H[a][2], H[a][3], rc);
+                    pk[a].y = fq_quant8_h16<false>(H[a][4], H[a][5], H[a][6], H[a][7], rc);
+                }
+            }
+        }
+        // the DMA of the group's next token is waited for HERE, in front of the stores (which are never waited for)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(HM_ABL & 8)) {
+            int lq = lane;
+            asm volatile("" : "+v"(lq));
+            // row (a', k' = c) is memory row 4 c + a'; this lane: columns 32 wq + 16 h .. + 15 of it
+            if (QUANT) {
+                uint8_t* qtok = q_out + tok * ((int64_t)M * 64) + wq * 16;   // 64 packed bytes per row
+                const unsigned lane_off = (unsigned)((lq & 31) * 256 + (lq >> 5) * 8);
+                if ((lq & 31) < K) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) *reinterpret_cast<uint2*>(qtok + (lane_off + a * 64)) = pk[a];
+                }
+                if (wq == 0 && lane == 0) scale_out[tok] = (f16)scale;
+            }
+            if (YOUT) {
+                unsigned char* ytok = reinterpret_cast<unsigned char*>(y_out) + tok * tok_bytes + wq * 64;   // 256 bytes per row
+                const unsigned lane_off = (unsigned)((lq & 31) * 1024 + (lq >> 5) * 32);
+                if ((lq & 31) < K) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        *reinterpret_cast<u32x4*>(ytok + (lane_off + a * 256)) = u32x4{H[a][0], H[a][1], H[a][2], H[a][3]};
+                        *reinterpret_cast<u32x4*>(ytok + (lane_off + a * 256 + 16)) = u32x4{H[a][4], H[a][5], H[a][6], H[a][7]};
+                    }
+                }
+            }
+        }
+        k = knext;
+    }
+}
+
+}  // namespace
+
+// Returns -1000 when the shape is not one this kernel covers (n = K * 512 with K <= 32, K % 4 == 0, hadK given).
+// q_out / scale_out may be NULL (rotation only), y_out may be NULL (Quantizer output only). In place (y_out == x) is allowed: a token
+// has landed in LDS completely (vmcnt(0) + the group's first meeting) before any of its rows is stored, and tokens do not overlap.
+int fq_launch_had_mfma(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max, float sig_min,
+                       uint8_t* q_out, f16* scale_out, f16* y_out, int n_cu, hipStream_t stream) {
+    if (K <= 1 || K > 32 || (K & 3) || hadK == nullptr || n != K * 512) return -1000;
+    if (!q_out && !y_out) return -1000;
+    int64_t blocks = (rows + HM_GROUPS - 1) / HM_GROUPS;
+    if (blocks > n_cu) blocks = n_cu;   // one persistent workgroup per CU
+    if (blocks < 1) blocks = 1;
+    const int64_t tpb = (rows + blocks - 1) / blocks;
+    // the +-1 / 16 right factor is undone here: y = (1 / sqrt(n)) H x = scale * 16 * (H / 16) x
+    const float ps = scale * 16.0f;
+    if (q_out && y_out)
+        hipLaunchKernelGGL((fq_had512_kernel<true, true>), dim3((unsigned)blocks), dim3(HM_THREADS), 0, stream, x, hadK, K, rows, tpb, ps,
+                           sig_max, sig_min, q_out, scale_out, y_out);
+    else if (q_out)
+        hipLaunchKernelGGL((fq_had512_kernel<true, false>), dim3((unsigned)blocks), dim3(HM_THREADS), 0, stream, x, hadK, K, rows, tpb, ps,
+                           sig_max, sig_min, q_out, scale_out, y_out);
+    else
+        hipLaunchKernelGGL((fq_had512_kernel<false, true>), dim3((unsigned)blocks), dim3(HM_THREADS), 0, stream, x, hadK, K, rows, tpb, ps,
+                           sig_max, sig_min, q_out, scale_out, y_out);
+    return (int)hipGetLastError();
+}

@@ -161,9 +161,9 @@ struct HadQuant {
     const f16* up;  // SILU kernels: x is `gate`, the transform's input is fp16(up * fp16(silu(gate))) (fq_silu_mul8)
 };
 // 8 fp16 results -> one dword of nibbles: packed pairs, exact fp16 quotient without a division (fq_quant8_h16, fq_common.hpp)
-__device__ __forceinline__ uint32_t quant8_h(f16x8 v, float s, float r, bool clamp) {
+__device__ __forceinline__ uint32_t quant8_h(f16x8 v, FqH16Recip rc, bool clamp) {
     const u32x4 xv = __builtin_bit_cast(u32x4, v);
-    return clamp ? fq_quant8_h16<true>(xv[0], xv[1], xv[2], xv[3], r, s) : fq_quant8_h16<false>(xv[0], xv[1], xv[2], xv[3], r, s);
+    return clamp ? fq_quant8_h16<true>(xv[0], xv[1], xv[2], xv[3], rc) : fq_quant8_h16<false>(xv[0], xv[1], xv[2], xv[3], rc);
 }
 __device__ __forceinline__ void minmax8(f16x8 v, float& mx, float& mn) {
     // extrema on packed fp16 pairs (the values are fp16: exact), then the two halves
@@ -224,9 +224,10 @@ __global__ __launch_bounds__(256) void fq_had_pow2_kernel(const f16* __restrict_
             if (lane == 0) hq.scale[row] = (f16)sc;
             const float rinv = fq_fast_inv(sc);
             const bool clampq = fq_h16_needs_clamp(mx, mn, rinv);
+            const FqH16Recip rc = fq_h16_recip(sc);
             uint32_t* qp = reinterpret_cast<uint32_t*>(hq.q + row * (n / 2));
 #pragma unroll
-            for (int j = 0; j < CH; ++j) qp[j * 64 + lane] = quant8_h(o[j], sc, rinv, clampq);  // 8 nibbles = elements j*512 + 8 lane ..
+            for (int j = 0; j < CH; ++j) qp[j * 64 + lane] = quant8_h(o[j], rc, clampq);  // 8 nibbles = elements j*512 + 8 lane ..
         }
     }
 }
@@ -399,6 +400,7 @@ __global__ __launch_bounds__(256) void fq_had_kmix_kernel(const f16* __restrict_
             const float sc = fq_token_scale<FQ_QUANT_F16>(mx, mn, hq.sig_max, hq.sig_min, FQ_SIG_F16);  // deploy.nn.Quantizer arithmetic
             const float rinv = fq_fast_inv(sc);
             const bool clampq = fq_h16_needs_clamp(mx, mn, rinv);
+            const FqH16Recip rc = fq_h16_recip(sc);
             unsigned char* obuf = smem;  // [K][P/2] bytes
 #pragma unroll
             for (int u = 0; u < MAXT; ++u) {
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(256) void fq_had_kmix_kernel(const f16* __restrict_
                 const int kp = kt * 32 + c;
                 if (t < ntiles && kp < K)
                     *reinterpret_cast<uint2*>(obuf + ((int64_t)kp * P + pt * 32 + h * 16) / 2) =
-                        make_uint2(quant8_h(res[u][0], sc, rinv, clampq), quant8_h(res[u][1], sc, rinv, clampq));
+                        make_uint2(quant8_h(res[u][0], rc, clampq), quant8_h(res[u][1], rc, clampq));
             }
             __syncthreads();
             if (tid == 0) hq.scale[row] = (f16)sc;

@@ -151,8 +151,8 @@ __device__ __forceinline__ unsigned quant_pack_token(const f32x16 (&Y)[2][2], co
             const f32x16& t = Y[w >> 1][mo];
             const int b = (w & 1) * 8;
             unsigned long long differ;
-            pw[mo][w] = fq_quant8_two<CLAMP>(t[b + 0], t[b + 1], t[b + 2], t[b + 3], t[b + 4], t[b + 5], t[b + 6],
-                                          t[b + 7], ilo, ihi, differ);
+            pw[mo][w] = fq_quant8<CLAMP>(t[b + 0], t[b + 1], t[b + 2], t[b + 3], t[b + 4], t[b + 5], t[b + 6],
+                                          t[b + 7], inv[mo], ilo, ihi, differ);
             near |= differ ? (1u << (4 * mo + w)) : 0u;  // SALU only
         }
     }

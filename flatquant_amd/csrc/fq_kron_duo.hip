@@ -47,7 +47,9 @@ template <int MT>
 struct DuoGeom {
     static constexpr int LFR = 2 * MT * MT * 64;              // uint4: the L fragment image
     static constexpr int XS = MT * 32 * DUO_PITCH;            // uint4: one group's token buffer
-    static constexpr int LDS = LFR * 16 + DUO_GROUPS * XS * 16 + DUO_GROUPS * 32 + 32;   // + [max x4, min x4] per group + control words
+    static constexpr int CTL = LFR * 16 + DUO_GROUPS * XS * 16;          // byte offset of [max x4, min x4] per group + control words
+    static constexpr int DMT = CTL + DUO_GROUPS * 32 + 32;                // byte offset of the DMA offset table: [7 starts][64 lanes] uint4 (7 KB)
+    static constexpr int LDS = DMT + 7 * 64 * 16;
 };
 
 typedef __attribute__((address_space(3))) void duo_lds_void;
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
     uint4* xs = lfr + G::LFR + grp * G::XS;        // [MT*32][PITCH]
     float* red = reinterpret_cast<float*>(smem + (G::LFR + DUO_GROUPS * G::XS) * 16) + grp * 8;   // [max x4][min x4]
     unsigned* ctl = reinterpret_cast<unsigned*>(smem + (G::LFR + DUO_GROUPS * G::XS) * 16 + DUO_GROUPS * 32);  // [meet x2][next][claim x2]
+    unsigned* dmt = reinterpret_cast<unsigned*>(smem + G::DMT);
     const unsigned ctl_lds = (unsigned)(size_t)(duo_lds_void*)ctl, meet = ctl_lds + grp * 4;
     const int64_t d = (int64_t)M * N;
 
@@ -116,6 +119,15 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
         uint4* xall = lfr + G::LFR;
         for (int i = tid; i < DUO_GROUPS * G::XS; i += DUO_THREADS) xall[i] = make_uint4(0, 0, 0, 0);
         if (tid < 8) ctl[tid] = tid == 2 ? DUO_GROUPS : 0;   // meeting counters, the next unclaimed token, (published claims)
+        // the per-lane source offsets of a DMA block (see below), for each of the seven residues of its first instruction mod 7
+        for (int e = tid; e < 7 * 64 * 4; e += DUO_THREADS) {
+            const int kk = e & 3, ln = (e >> 2) & 63, st = e >> 8;
+            const int m = (st + kk) % 7;
+            const int q = 64 * m + ln, r = (q * 2341) >> 16;   // q / 28 for q < 512
+            int pos = q - 28 * r - ((r >> 2) & 3);
+            pos += pos < 0 ? CPR : 0;
+            dmt[e] = (unsigned)((r * CPR + pos - 64 * m) * 16 + 64);   // relative to the instruction's KB; + 64: never negative
+        }
     }
     __syncthreads();
 
@@ -143,17 +155,11 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
     auto dma_block = [&](unsigned long long sb, int b) {
         const int i0 = 4 * b;
         if (i0 > n_full || (i0 == n_full && tail_lanes == 0)) return;
-        unsigned rv[4];
+        // (round 4: the four offsets come from the table in LDS — one ds_read_b128 instead of ~50 VALU per block, 200 per token and wave)
         int ln = lane;
-        asm volatile("" : "+v"(ln));
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int m = (i0 + kk) % 7;                        // (wave-uniform)
-            const int q = 64 * m + ln, r = (q * 2341) >> 16;   // q / 28 for q < 512
-            int pos = q - 28 * r - ((r >> 2) & 3);
-            pos += pos < 0 ? CPR : 0;
-            rv[kk] = (unsigned)((r * CPR + pos - 64 * m) * 16 + 64);   // relative to the instruction's KB; + 64: never negative
-        }
+        asm volatile("" : "+v"(ln));   // (the address arithmetic stays here: hoisted, it is spilled, and a reload waits for the DMA in flight)
+        const u32x4 rvv = reinterpret_cast<const u32x4*>(dmt)[(i0 % 7) * 64 + ln];
+        const unsigned rv[4] = {rvv[0], rvv[1], rvv[2], rvv[3]};
         const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(xs_lds + (unsigned)i0 * 1024));
         // (the compiler's uniformity analysis loses sb and i0 through the lambdas: an "s" operand it believes divergent is
         //  handed over in VGPRs, so both halves go through v_readfirstlane explicitly)
@@ -398,7 +404,10 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
             const bool magic = fq_magic_ok(vmax, vmin, inv), clampq = fq_needs_clamp(vmax, vmin, inv);
             const float ilo = fq_inv_lo(inv), ihi = fq_inv_hi(inv);
             // the wave's tiles are neighbours: a lane's two 8-byte runs (16 n' each) of a row are 16 contiguous bytes
-            uint8_t* qtok = out.q[ci] + tok * (d >> 1) + h * (NT * 8) + wq * 16;
+            uint8_t* qtok = out.q[ci] + tok * (d >> 1) + wq * 16;   // wave-uniform; the lane's part is a 32-bit offset recomputed here
+            int lq = lane;                                            // (kept live across the GEMMs it is spilled: a reload waits for the DMA)
+            asm volatile("" : "+v"(lq));
+            const unsigned lane_off = (unsigned)((lq >> 5) * (NT * 8) + (lq & 31) * (N / 2));
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo) {
                 uint2 pk[2] = {{0u, 0u}, {0u, 0u}};
@@ -409,11 +418,11 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
                     unsigned long long d0m = ~0ull, d1m = ~0ull;
                     if (magic) {
                         if (clampq) {
-                            pk[t].x = fq_quant8_two<true>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], ilo, ihi, d0m);
-                            pk[t].y = fq_quant8_two<true>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], ilo, ihi, d1m);
+                            pk[t].x = fq_quant8<true>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], inv, ilo, ihi, d0m);
+                            pk[t].y = fq_quant8<true>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], inv, ilo, ihi, d1m);
                         } else {
-                            pk[t].x = fq_quant8_two<false>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], ilo, ihi, d0m);
-                            pk[t].y = fq_quant8_two<false>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], ilo, ihi, d1m);
+                            pk[t].x = fq_quant8<false>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], inv, ilo, ihi, d0m);
+                            pk[t].y = fq_quant8<false>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], inv, ilo, ihi, d1m);
                         }
                     }
                     if (d0m)   // rare: an ambiguous digit somewhere in the wave -> the true division for this dword
@@ -423,8 +432,8 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
                         pk[t].y = fq_pack8(fq_qexact(yv[8], scale), fq_qexact(yv[9], scale), fq_qexact(yv[10], scale), fq_qexact(yv[11], scale),
                                            fq_qexact(yv[12], scale), fq_qexact(yv[13], scale), fq_qexact(yv[14], scale), fq_qexact(yv[15], scale));
                 }
-                if ((mo * 32 + c) < M) {
-                    uint8_t* dst = qtok + (mo * 32 + c) * (N / 2);
+                if ((mo * 32 + (lq & 31)) < M) {
+                    uint8_t* dst = qtok + (mo * 32 * (N / 2) + lane_off);
                     if (two) *reinterpret_cast<u32x4_a8*>(dst) = u32x4{pk[0].x, pk[0].y, pk[1].x, pk[1].y};   // (8-byte aligned: h * 56)
                     else *reinterpret_cast<uint2*>(dst) = pk[0];
                 }

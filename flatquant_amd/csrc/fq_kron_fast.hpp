@@ -282,11 +282,11 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                 for (int mo = 0; mo < MT; ++mo) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const f16x2 pr = {fq_mul_to_f16(Y[t][mo][2 * j], ps), fq_mul_to_f16(Y[t][mo][2 * j + 1], ps)};
+                        const f16x2 pr = fq_mul_to_f16x2(Y[t][mo][2 * j], Y[t][mo][2 * j + 1], f32x2{ps, ps});
                         H[H16 ? t : 0][H16 ? mo : 0][j] = __builtin_bit_cast(uint32_t, pr);
                         if (col_ok && (mo * 32 + c) < M) {
-                            pmax = __builtin_elementwise_max(pmax, pr);
-                            pmin = __builtin_elementwise_min(pmin, pr);
+                            pmax = fq_pk_max(pmax, pr);
+                            pmin = fq_pk_min(pmin, pr);
                         }
                     }
                 }
@@ -493,6 +493,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
             if (flags & FQ_QUANT_F16) scale = fq_token_scale<FQ_QUANT_F16, T>(vmax, vmin, sig_max, sig_min, flags);
             else scale = fq_token_scale<0, T>(vmax, vmin, sig_max, sig_min, flags);
             const float inv = fq_fast_inv(scale);
+            const FqH16Recip rc = H16 ? fq_h16_recip(scale) : FqH16Recip{0.0f, 0.0f};
             const f32x2 inv2 = {inv, inv};
             const bool magic = !(flags & FQ_QUANT_F16) && fq_magic_ok(vmax, vmin, inv);
             const bool clampq = fq_needs_clamp(vmax, vmin, inv);
@@ -543,11 +544,11 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                         if (magic) {
                             const float ilo = fq_inv_lo(inv), ihi = fq_inv_hi(inv);
                             if (clampq) {
-                                pk.x = fq_quant8_two<true>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], ilo, ihi, d0);
-                                pk.y = fq_quant8_two<true>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], ilo, ihi, d1);
+                                pk.x = fq_quant8<true>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], inv, ilo, ihi, d0);
+                                pk.y = fq_quant8<true>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], inv, ilo, ihi, d1);
                             } else {
-                                pk.x = fq_quant8_two<false>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], ilo, ihi, d0);
-                                pk.y = fq_quant8_two<false>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], ilo, ihi, d1);
+                                pk.x = fq_quant8<false>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], inv, ilo, ihi, d0);
+                                pk.y = fq_quant8<false>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], inv, ilo, ihi, d1);
                             }
                         }
                         if (d0)  // rare: an ambiguous digit somewhere in the wave -> the true division for this dword
@@ -575,11 +576,11 @@ __global__ __launch_bounds__(WAVES * 64, (OCC * WAVES + 3) / 4) void fq_kron_fas
                         const uint32_t(&hv)[8] = H[H16 ? t : 0][H16 ? mo : 0];
                         uint2 pk;
                         if (clampq) {
-                            pk.x = fq_quant8_h16<true>(hv[0], hv[1], hv[2], hv[3], inv, scale);
-                            pk.y = fq_quant8_h16<true>(hv[4], hv[5], hv[6], hv[7], inv, scale);
+                            pk.x = fq_quant8_h16<true>(hv[0], hv[1], hv[2], hv[3], rc);
+                            pk.y = fq_quant8_h16<true>(hv[4], hv[5], hv[6], hv[7], rc);
                         } else {
-                            pk.x = fq_quant8_h16<false>(hv[0], hv[1], hv[2], hv[3], inv, scale);
-                            pk.y = fq_quant8_h16<false>(hv[4], hv[5], hv[6], hv[7], inv, scale);
+                            pk.x = fq_quant8_h16<false>(hv[0], hv[1], hv[2], hv[3], rc);
+                            pk.y = fq_quant8_h16<false>(hv[4], hv[5], hv[6], hv[7], rc);
                         }
                         if (ok) *reinterpret_cast<uint2*>(obuf + (mo * 32 + c) * (N >> 1) + (n0 >> 1)) = pk;
                         continue;

@@ -16,6 +16,9 @@
 //     row are neighbours: one 16-byte store, and the 64 lanes of a store cover 1 KB of contiguous output.
 // Two or three such workgroups per CU overlap each other's barriers. Same mathematics, rounding points, fragment chaining and
 // workspace image (fq_kron_prepare_kernel) as the other Kronecker kernels.
+// (round 4) this kernel keeps the two-sided quantiser of round 3: it runs at 2.26-2.29 GHz, VALU-issue-bound rather than power-bound,
+// and the low-half form's v_min3_u16 issues at half rate (tools/scratch/vrate.hip) — 164 -> 178 us with it (profiles/r04_quant_lo_ab.txt)
+#define FQ_QUANT_LO 0
 #include "fq_common.hpp"
 
 namespace {
@@ -129,10 +132,10 @@ __global__ __launch_bounds__(MT * 64) void fq_kron_tall_kernel(const f16* __rest
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const f16x2 pr = {fq_mul_to_f16(Y[nt][2 * j], ps), fq_mul_to_f16(Y[nt][2 * j + 1], ps)};
+                    const f16x2 pr = fq_mul_to_f16x2(Y[nt][2 * j], Y[nt][2 * j + 1], f32x2{ps, ps});
                     H[H16 ? nt : 0][j] = __builtin_bit_cast(uint32_t, pr);
-                    pmax = __builtin_elementwise_max(pmax, pr);
-                    pmin = __builtin_elementwise_min(pmin, pr);
+                    pmax = fq_pk_max(pmax, pr);
+                    pmin = fq_pk_min(pmin, pr);
                 }
             if (row_ok) {
                 vmax = fmaxf((float)pmax[0], (float)pmax[1]);
@@ -205,6 +208,7 @@ __global__ __launch_bounds__(MT * 64) void fq_kron_tall_kernel(const f16* __rest
             if (H16) scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, sig_max, sig_min, out.rt_flags);
             else scale = fq_token_scale<0>(vmax, vmin, sig_max, sig_min, out.rt_flags);
             const float inv = fq_fast_inv(scale);
+            const FqH16Recip rc = H16 ? fq_h16_recip(scale) : FqH16Recip{0.0f, 0.0f};
             const bool magic = H16 || fq_magic_ok(vmax, vmin, inv);
             const bool clampq = fq_needs_clamp(vmax, vmin, inv);
             uint2 pk[NT];
@@ -213,11 +217,11 @@ __global__ __launch_bounds__(MT * 64) void fq_kron_tall_kernel(const f16* __rest
                 if (H16) {
                     const uint32_t(&hv)[8] = H[H16 ? nt : 0];
                     if (clampq) {
-                        pk[nt].x = fq_quant8_h16<true>(hv[0], hv[1], hv[2], hv[3], inv, scale);
-                        pk[nt].y = fq_quant8_h16<true>(hv[4], hv[5], hv[6], hv[7], inv, scale);
+                        pk[nt].x = fq_quant8_h16<true>(hv[0], hv[1], hv[2], hv[3], rc);
+                        pk[nt].y = fq_quant8_h16<true>(hv[4], hv[5], hv[6], hv[7], rc);
                     } else {
-                        pk[nt].x = fq_quant8_h16<false>(hv[0], hv[1], hv[2], hv[3], inv, scale);
-                        pk[nt].y = fq_quant8_h16<false>(hv[4], hv[5], hv[6], hv[7], inv, scale);
+                        pk[nt].x = fq_quant8_h16<false>(hv[0], hv[1], hv[2], hv[3], rc);
+                        pk[nt].y = fq_quant8_h16<false>(hv[4], hv[5], hv[6], hv[7], rc);
                     }
                 } else {
                     const f32x16& yv = Y[nt];
@@ -226,11 +230,11 @@ __global__ __launch_bounds__(MT * 64) void fq_kron_tall_kernel(const f16* __rest
                     if (magic) {
                         const float ilo = fq_inv_lo(inv), ihi = fq_inv_hi(inv);
                         if (clampq) {
-                            pk[nt].x = fq_quant8_two<true>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], ilo, ihi, d0m);
-                            pk[nt].y = fq_quant8_two<true>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], ilo, ihi, d1m);
+                            pk[nt].x = fq_quant8<true>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], inv, ilo, ihi, d0m);
+                            pk[nt].y = fq_quant8<true>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], inv, ilo, ihi, d1m);
                         } else {
-                            pk[nt].x = fq_quant8_two<false>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], ilo, ihi, d0m);
-                            pk[nt].y = fq_quant8_two<false>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], ilo, ihi, d1m);
+                            pk[nt].x = fq_quant8<false>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], inv, ilo, ihi, d0m);
+                            pk[nt].y = fq_quant8<false>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], inv, ilo, ihi, d1m);
                         }
                     }
                     if (d0m)   // rare: an ambiguous digit somewhere in the wave -> the true division for this dword

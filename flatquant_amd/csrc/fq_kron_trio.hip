@@ -245,19 +245,19 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
                 f16x2 tmax = {(f16)-INFINITY, (f16)-INFINITY}, tmin = {(f16)INFINITY, (f16)INFINITY};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const f16x2 pr = {fq_mul_to_f16(Y[mo][2 * j], ps), fq_mul_to_f16(Y[mo][2 * j + 1], ps)};
+                    const f16x2 pr = fq_mul_to_f16x2(Y[mo][2 * j], Y[mo][2 * j + 1], f32x2{ps, ps});
                     H[H16 ? mo : 0][j] = __builtin_bit_cast(uint32_t, pr);
                     if (mo == MT - 1) {
-                        tmax = __builtin_elementwise_max(tmax, pr);
-                        tmin = __builtin_elementwise_min(tmin, pr);
+                        tmax = fq_pk_max(tmax, pr);
+                        tmin = fq_pk_min(tmin, pr);
                     } else {
-                        pmax = __builtin_elementwise_max(pmax, pr);
-                        pmin = __builtin_elementwise_min(pmin, pr);
+                        pmax = fq_pk_max(pmax, pr);
+                        pmin = fq_pk_min(pmin, pr);
                     }
                 }
                 if (mo == MT - 1 && (mo * 32 + c) < M) {
-                    pmax = __builtin_elementwise_max(pmax, tmax);
-                    pmin = __builtin_elementwise_min(pmin, tmin);
+                    pmax = fq_pk_max(pmax, tmax);
+                    pmin = fq_pk_min(pmin, tmin);
                 }
             }
             vmax = fmaxf((float)pmax[0], (float)pmax[1]);
@@ -323,6 +323,7 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
             if (H16) scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, sig_max, sig_min, out.rt_flags);
             else scale = fq_token_scale<0>(vmax, vmin, sig_max, sig_min, out.rt_flags);
             const float inv = fq_fast_inv(scale);
+            const FqH16Recip rc = H16 ? fq_h16_recip(scale) : FqH16Recip{0.0f, 0.0f};
             const bool magic = H16 || fq_magic_ok(vmax, vmin, inv);
             const bool clampq = fq_needs_clamp(vmax, vmin, inv);
             uint2 pk[MT];
@@ -333,11 +334,11 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
                 } else if (H16) {
                     const uint32_t(&hv)[8] = H[H16 ? mo : 0];
                     if (clampq) {
-                        pk[mo].x = fq_quant8_h16<true>(hv[0], hv[1], hv[2], hv[3], inv, scale);
-                        pk[mo].y = fq_quant8_h16<true>(hv[4], hv[5], hv[6], hv[7], inv, scale);
+                        pk[mo].x = fq_quant8_h16<true>(hv[0], hv[1], hv[2], hv[3], rc);
+                        pk[mo].y = fq_quant8_h16<true>(hv[4], hv[5], hv[6], hv[7], rc);
                     } else {
-                        pk[mo].x = fq_quant8_h16<false>(hv[0], hv[1], hv[2], hv[3], inv, scale);
-                        pk[mo].y = fq_quant8_h16<false>(hv[4], hv[5], hv[6], hv[7], inv, scale);
+                        pk[mo].x = fq_quant8_h16<false>(hv[0], hv[1], hv[2], hv[3], rc);
+                        pk[mo].y = fq_quant8_h16<false>(hv[4], hv[5], hv[6], hv[7], rc);
                     }
                 } else {
                     const f32x16& yv = Y[mo];
@@ -346,11 +347,11 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
                     if (magic) {
                         const float ilo = fq_inv_lo(inv), ihi = fq_inv_hi(inv);
                         if (clampq) {
-                            pk[mo].x = fq_quant8_two<true>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], ilo, ihi, d0m);
-                            pk[mo].y = fq_quant8_two<true>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], ilo, ihi, d1m);
+                            pk[mo].x = fq_quant8<true>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], inv, ilo, ihi, d0m);
+                            pk[mo].y = fq_quant8<true>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], inv, ilo, ihi, d1m);
                         } else {
-                            pk[mo].x = fq_quant8_two<false>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], ilo, ihi, d0m);
-                            pk[mo].y = fq_quant8_two<false>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], ilo, ihi, d1m);
+                            pk[mo].x = fq_quant8<false>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], inv, ilo, ihi, d0m);
+                            pk[mo].y = fq_quant8<false>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], inv, ilo, ihi, d1m);
                         }
                     }
                     if (d0m)  // rare: an ambiguous digit somewhere in the wave -> the true division for this dword

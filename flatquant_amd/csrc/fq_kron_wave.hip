@@ -62,7 +62,7 @@ __device__ __forceinline__ unsigned quant_row(const f32x16 (&Y)[NT][MT], int mo,
         const f32x16& t = Y[k >> 1][mo];
         const int b = (k & 1) * 8;
         unsigned long long differ;
-        pw[k] = fq_quant8_two<CLAMP>(t[b + 0], t[b + 1], t[b + 2], t[b + 3], t[b + 4], t[b + 5], t[b + 6], t[b + 7], ilo, ihi,
+        pw[k] = fq_quant8<CLAMP>(t[b + 0], t[b + 1], t[b + 2], t[b + 3], t[b + 4], t[b + 5], t[b + 6], t[b + 7], inv, ilo, ihi,
                                      differ);
         near |= differ ? (1u << k) : 0u;
     }

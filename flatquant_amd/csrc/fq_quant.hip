@@ -52,6 +52,7 @@ __global__ __launch_bounds__(RQ_THREADS) void fq_rowquant_kernel(const T* __rest
         for (int ci = 0; ci < out.n_clips; ++ci) {
             const float scale = fq_token_scale<FLAGS, T>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
             const float h16_inv = fq_fast_inv(scale);
+            const FqH16Recip h16rc = ((FLAGS & FQ_QUANT_F16) && IS16) ? fq_h16_recip(scale) : FqH16Recip{0.0f, 0.0f};
             const bool h16_clamp = fq_h16_needs_clamp(vmax, vmin, h16_inv);
             if (FLAGS & FQ_OUT_PACKED) {
                 if (tid == 0) reinterpret_cast<T*>(out.scale[ci])[row] = ((out.rt_flags & FQ_RATIO_POST) && vmax == 0.0f && vmin == 0.0f) ? (T)0.0f : (T)scale;
@@ -63,8 +64,8 @@ __global__ __launch_bounds__(RQ_THREADS) void fq_rowquant_kernel(const T* __rest
                         uint32_t d = 0;
                         if ((FLAGS & FQ_QUANT_F16) && IS16) {   // packed pairs, exact fp16 quotient without a division (fq_quant8_h16)
                             const u32x4 xv = __builtin_bit_cast(u32x4, v[k]);
-                            d = h16_clamp ? fq_quant8_h16<true>(xv[0], xv[1], xv[2], xv[3], h16_inv, scale)
-                                          : fq_quant8_h16<false>(xv[0], xv[1], xv[2], xv[3], h16_inv, scale);
+                            d = h16_clamp ? fq_quant8_h16<true>(xv[0], xv[1], xv[2], xv[3], h16rc)
+                                          : fq_quant8_h16<false>(xv[0], xv[1], xv[2], xv[3], h16rc);
                         } else {
 #pragma unroll
                             for (int e = 0; e < 8; ++e)
@@ -211,6 +212,7 @@ void fq_rowquant_wave_kernel(const T* __restrict__ x, int64_t rows, int cols,
         for (int ci = 0; ci < out.n_clips; ++ci) {
             const float scale = fq_token_scale<FLAGS, T>(vmax, vmin, out.sig_max[ci], out.sig_min[ci], out.rt_flags);
             const float inv = fq_fast_inv(scale);
+            const FqH16Recip h16rc = ((FLAGS & FQ_QUANT_F16) && IS16) ? fq_h16_recip(scale) : FqH16Recip{0.0f, 0.0f};
             const bool h16_clamp = fq_h16_needs_clamp(vmax, vmin, inv);
             if (FLAGS & FQ_OUT_PACKED) {
                 if (lane == 0 && live) reinterpret_cast<T*>(out.scale[ci])[row] = ((out.rt_flags & FQ_RATIO_POST) && vmax == 0.0f && vmin == 0.0f) ? (T)0.0f : (T)scale;
@@ -221,8 +223,8 @@ void fq_rowquant_wave_kernel(const T* __restrict__ x, int64_t rows, int cols,
                     uint32_t d;
                     if ((FLAGS & FQ_QUANT_F16) && IS16) {
                         const u32x4 xv = __builtin_bit_cast(u32x4, v[k]);   // packed pairs, exact fp16 quotient (fq_quant8_h16)
-                        d = h16_clamp ? fq_quant8_h16<true>(xv[0], xv[1], xv[2], xv[3], inv, scale)
-                                      : fq_quant8_h16<false>(xv[0], xv[1], xv[2], xv[3], inv, scale);
+                        d = h16_clamp ? fq_quant8_h16<true>(xv[0], xv[1], xv[2], xv[3], h16rc)
+                                      : fq_quant8_h16<false>(xv[0], xv[1], xv[2], xv[3], h16rc);
                     } else if (FLAGS & FQ_QUANT_F16) {   // bf16 arithmetic: the quotient rounded to bf16, element by element
                         d = 0;
 #pragma unroll

@@ -608,9 +608,43 @@ def rowquant(x: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),), flags: int = 
     return o
 
 
+def had_mfma_supported(n: int, K: int) -> bool:
+    """Shapes of the structured matrix-pipe rotation (fq_had_mfma.hip): n = K * 512, K <= 32, K % 4 == 0 (14336 = 28 * 512)."""
+    return 4 <= K <= 32 and K % 4 == 0 and n == K * 512
+
+
+def hadamard_mfma(x: torch.Tensor, K: int, hadK: torch.Tensor, sig: Optional[Sig] = None, scale: Optional[float] = None,
+                  want_y: bool = True):
+    """fq_hadamard_quant_mfma_f16: the rotation of n = K * 512 with its structure on the matrix pipe. -> (y or None, q or None,
+    scales or None); ``sig`` given: the deploy Quantizer's packed output as hadamard_quant; ``want_y``: the rotated activation."""
+    _chk(x, "x"), _chk(hadK, "hadK")
+    n = x.shape[-1]
+    if hadK.shape != (K, K) or not had_mfma_supported(n, K):
+        raise ValueError("hadamard_mfma: n = K * 512 with K <= 32, K % 4 == 0 and hadK [K, K]")
+    if sig is None and not want_y:
+        raise ValueError("hadamard_mfma: no output requested")
+    if scale is None:
+        scale = float(1.0 / torch.tensor(n).sqrt())
+    rows = x.numel() // n
+    y = torch.empty_like(x) if want_y else None
+    q = torch.empty(x.shape[:-1] + (n // 2,), dtype=torch.uint8, device=x.device) if sig is not None else None
+    s = torch.empty((rows,), dtype=torch.float16, device=x.device) if sig is not None else None
+    if rows > 0:
+        with _on(x.device):
+            check(lib.fq_hadamard_quant_mfma_f16(_ptr(x), rows, n, K, _ptr(hadK), ctypes.c_float(scale),
+                                                 ctypes.c_float(sig[0] if sig is not None else 1.0),
+                                                 ctypes.c_float(sig[1] if sig is not None else 1.0), _ptr(q), _ptr(s), _ptr(y), _stream(x)))
+    return y, q, s
+
+
 def hadamard(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None,
-             scale: Optional[float] = None) -> torch.Tensor:
-    """hadK @ FWHT(x.view(rows, K, n/K)) * scale  (fq_hadamard_f16)."""
+             scale: Optional[float] = None, fwht_route: bool = False) -> torch.Tensor:
+    """hadK @ FWHT(x.view(rows, K, n/K)) * scale. Two routes: the register FWHT + K-factor kernel (fq_hadamard_f16; bit-exact for
+    K = 1), and for n = K * 512 (K <= 32: 14336) the structured matrix-pipe kernel (fq_hadamard_quant_mfma_f16: same rotation,
+    the intermediate rounded to fp16 at other points — within 1e-3 of the row maximum of the exact rotation, not bit-identical to
+    the first route). ``fwht_route=True`` forces the first."""
+    if K > 1 and hadK is not None and not fwht_route and had_mfma_supported(x.shape[-1], K) and hadK.shape == (K, K) and x.numel() > 0:
+        return hadamard_mfma(x, K, hadK, None, scale, True)[0]
     _chk(x, "x")
     n = x.shape[-1]
     if K > 1:
@@ -632,18 +666,24 @@ def hadamard(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None,
 
 def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None, sig: Sig = (1.0, 1.0),
                    scale: Optional[float] = None, up: Optional[torch.Tensor] = None,
-                   fwht_route: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+                   fwht_route: bool = False, route: Optional[str] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Hadamard rotation fused with the deploy Quantizer (fq_hadamard_quant_f16): -> (q uint8 [..., n/2], scales fp16
     [rows]); the Quantizer's arithmetic is deploy/nn/quantization.py:15-29. Two routes:
       * the register FWHT + K-factor kernel — bit-identical to rowquant(hadamard(x), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 |
         FQ_SIG_F16); shapes the fused kernels do not cover take exactly that two-launch sequence;
-      * n = 14336 (K = 28), 28672 (K = 28), 11008 (K = 172) and every other n = K 2^p whose rotation is a factor pair with a
+      * n = K * 512 with K <= 32 (14336 = 28 * 512; round 4): the structured matrix-pipe kernel (hadamard_mfma) — H_512 as two
+        register butterflies and two K = 32 contractions, 16 MFMAs per wave and token instead of the 60 of the dense pair below;
+      * n = 28672 (K = 28), 11008 (K = 172), 14336 with ``up``, and every other n = K 2^p whose rotation is a factor pair with a
         packed-only kernel of its own (_hadamard_as_kron): the rotation runs as ONE Kronecker launch (112 x 128 / 112 x 256 /
         172 x 64, kron_quant_ex), 1.5-2x faster. It rounds the intermediate to fp16 at a different point: the rotated values agree with
         the FWHT route within 2e-3 of the row maximum (the reference's own tolerance class, tests/test_gpu_hadamard.py), so
         scales can differ by an fp16 step and digits by +-1 on ~1e-3 of elements — NOT bit for bit.
-    ``fwht_route=True`` forces the first route for callers that need hadamard() + Quantizer == hadamard_quant() exactly.
-    With ``up``: x is x_gate and the input of the rotation is up * silu(x), formed in registers."""
+    ``fwht_route=True`` (= ``route="fwht"``) forces the first route for callers that need hadamard(fwht_route=True) + Quantizer ==
+    hadamard_quant() exactly; ``route="kron"`` forces the dense Kronecker launch where it exists, ``route="mfma"`` the structured one.
+    With ``up``: x is x_gate and the input of the rotation is up * silu(x), formed in registers (dense Kronecker / FWHT routes)."""
+    if route not in (None, "fwht", "kron", "mfma"):
+        raise ValueError("route: None, 'fwht', 'kron' or 'mfma'")
+    fwht_route = fwht_route or route == "fwht"
     _chk(x, "x")
     if up is not None:
         _chk(up, "up")
@@ -659,6 +699,12 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
     if scale is None:
         scale = float(1.0 / torch.tensor(n).sqrt())
     rows = x.numel() // n
+    if route == "mfma" and (up is not None or not had_mfma_supported(n, K)):
+        raise _lib.FqError(FQ_EUNSUPPORTED, "hadamard_quant(route='mfma'): n = K * 512 with K <= 32, K % 4 == 0, no up=")
+    if not fwht_route and route != "kron" and up is None and rows > 0 and had_mfma_supported(n, K):
+        # the structured route (fq_had_mfma.hip): H_512 = H_4 (x) H_4 (x) H_32 as two register butterflies + two K = 32 contractions
+        _, q, s = hadamard_mfma(x, K, hadK, sig, scale, want_y=False)
+        return q, s
     kr = _hadamard_as_kron(K, n // K, hadK, x.device) if (n % K == 0 and not fwht_route) else None
     if kr is not None and rows > 0:
         # K > 1 shapes whose rotation is a Kronecker pair the fused MFMA kernels take (14336 = 112 x 128, 28672 = 112 x 256):

@@ -362,6 +362,21 @@ int fq_hadamard_f16(const void* x, void* y, int64_t rows, int n, int K, const vo
 int fq_hadamard_quant_f16(const void* x, int64_t rows, int n, int K, const void* hadK, float scale,
                           float sig_max, float sig_min, void* q_out, void* scale_out, void* stream);
 
+/*
+ * The same rotation (+ Quantizer) with the STRUCTURE of the rotation on the matrix pipe (round 4, fq_had_mfma.hip):
+ * H_512 = H_4 (x) H_4 (x) H_32 — two in-register butterflies and two K = 32 contractions (H_32, hadK) per tile, 16 MFMAs per wave and
+ * token where the dense Kronecker launch of the same rotation (fq_kron_quant_ex_f16 on (hadK (x) H_4) (x) H_128) needs 60.
+ * Same contracts as fq_hadamard_f16 (y_out) and fq_hadamard_quant_f16 (q_out + scale_out) EXCEPT bit identity: the intermediate is
+ * rounded to fp16 at different points, the rotated values agree with fq_hadamard_f16 within the op's tolerance class (1e-3 of the
+ * row maximum against the exact rotation; hadamard_utils.py:89-110 is the oracle), so a scale can differ by an fp16 step and a digit
+ * by +-1 on ~1e-3 of the elements.
+ * Covers n = K * 512 with 4 <= K <= 32, K % 4 == 0 (14336 = 28 * 512: Llama-3-8B ffn); FQ_EUNSUPPORTED otherwise.
+ *   hadK [K, K] fp16 (+-1); q_out [rows, n/2] uint8 with scale_out [rows] fp16, or both NULL; y_out [rows, n] fp16 or NULL (y_out == x
+ *   is allowed); at least one output. No workspace.
+ */
+int fq_hadamard_quant_mfma_f16(const void* x, int64_t rows, int n, int K, const void* hadK, float scale,
+                               float sig_max, float sig_min, void* q_out, void* scale_out, void* y_out, void* stream);
+
 /* fq_hadamard_quant_f16 on x = fp16(up * fp16(silu(gate))) formed in registers (see fq_silu_mul_kron_quant_f16). */
 int fq_silu_mul_hadamard_quant_f16(const void* gate, const void* up, int64_t rows, int n, int K, const void* hadK,
                                    float scale, float sig_max, float sig_min, void* q_out, void* scale_out,

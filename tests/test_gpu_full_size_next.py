@@ -60,7 +60,7 @@ def test_silu_fused_full_size(ops):
     from conftest import hadk_matrix
     hk = torch.from_numpy(hadk_matrix(28)).cuda()
     q, s = ops.hadamard_quant(gate, 28, hk, sig[0], up=up)
-    q2, s2 = ops.hadamard_quant(ops.silu_mul(gate, up), 28, hk, sig[0])
+    q2, s2 = ops.hadamard_quant(ops.silu_mul(gate, up), 28, hk, sig[0], route="kron")   # (the route that takes up=)
     assert torch.equal(q, q2) and torch.equal(s, s2)
 
 

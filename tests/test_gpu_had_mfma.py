@@ -1,0 +1,147 @@
+"""GPU parity for the structured matrix-pipe Hadamard rotation (fq_had_mfma.hip, round 4): n = K * 512, K <= 32.
+Oracle: matmul_hadU / matmul_hadU_cuda (hadamard_utils.py:89-110,132-141) restated in oracle/fq_oracle.py and pinned by the
+reference-written fixtures tests/golden/had_A.npz; the deploy Quantizer (deploy/nn/quantization.py:13-36) as O.rowquant."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fq_oracle as O
+from tests.conftest import hadk_matrix
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(14336, 28), (6144, 12), (10240, 20)]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from flatquant_amd import ops as _ops
+    return _ops
+
+
+def exact_rotation(x16, K):
+    """The rotation in float64: hadK @ H_512 over x.view(rows, K, 512), / sqrt(n) — no rounding anywhere."""
+    rows, n = x16.shape
+    P = n // K
+    h = np.ones((1, 1))
+    while h.shape[0] < P:
+        h = np.block([[h, h], [h, -h]])
+    v = x16.astype(np.float64).reshape(rows, K, P) @ h
+    v = np.einsum("jk,rkp->rjp", hadk_matrix(K).astype(np.float64), v)
+    return v.reshape(rows, n) / np.sqrt(n)
+
+
+def make_x(rows, n, seed, outliers=True):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, n, generator=g).half()
+    if outliers:
+        x[:, ::61] *= 9
+    return x
+
+
+@pytest.mark.parametrize("n,K", SHAPES)
+@pytest.mark.parametrize("rows", [1, 2, 3, 37, 1000])
+def test_rotation_within_tolerance_of_the_exact_rotation(ops, n, K, rows):
+    """north_star tolerance: 1e-3 of the row maximum against the exact rotation (what had_A.npz's y64 holds)."""
+    x = make_x(rows, n, n + rows)
+    if rows > 2:
+        x[2] = 0
+    hk = torch.from_numpy(hadk_matrix(K)).cuda()
+    y, _, _ = ops.hadamard_mfma(x.cuda(), K, hk)
+    ref = exact_rotation(x.numpy(), K)
+    den = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-30)
+    err = np.abs(y.cpu().numpy().astype(np.float64) - ref) / den
+    assert np.max(err) <= 1e-3, (n, K, rows, float(np.max(err)))
+    if rows > 2:
+        assert not y[2].any()   # a zero token stays zero
+
+
+@pytest.mark.parametrize("n,K", SHAPES)
+def test_quantizer_stage_bit_exact_on_the_launch_own_rotation(ops, n, K):
+    """Packed digits and scales == the deploy Quantizer's fp16 arithmetic applied to the fp16 rotation the SAME launch returns;
+    the packed-only and the rotation-only instantiations return the same bytes; clamp and no-clamp routes."""
+    rows = 53
+    x = make_x(rows, n, n + 7)
+    x[5] = 0
+    x[6, :] = x[6, :].abs()          # single-signed row
+    hk = torch.from_numpy(hadk_matrix(K)).cuda()
+    for sig in [(0.9820137619972229, 0.9820137619972229), (0.7, 0.9), (1.0, 1.0), (0.55, 0.5)]:
+        y, q, s = ops.hadamard_mfma(x.cuda(), K, hk, sig)
+        rq = O.rowquant(y.cpu().numpy(), *sig, clamp0=True, quant_f16=True, sig_f16=True)
+        assert np.array_equal(q.cpu().numpy(), rq["packed"]), (n, K, sig)
+        assert np.array_equal(s.cpu().numpy(), rq["scale16"]), (n, K, sig)
+        _, q2, s2 = ops.hadamard_mfma(x.cuda(), K, hk, sig, want_y=False)
+        assert torch.equal(q2, q) and torch.equal(s2, s)
+        y2, _, _ = ops.hadamard_mfma(x.cuda(), K, hk)
+        assert torch.equal(y2, y)
+        qh, sh = ops.hadamard_quant(x.cuda(), K, hk, sig)          # the default route of these shapes
+        assert torch.equal(qh, q) and torch.equal(sh.reshape(-1), s)
+
+
+@pytest.mark.parametrize("n,K", SHAPES)
+def test_agrees_with_the_fwht_route_to_rounding_noise(ops, n, K):
+    """Against the bit-identical route (register FWHT + K-factor, then the Quantizer): digits within +-1 on <= 2e-3 of the
+    elements, scales within an fp16 step — the bars the dense Kronecker launch of the same rotation has had since round 2."""
+    rows = 64
+    x = make_x(rows, n, n + 11)
+    hk = torch.from_numpy(hadk_matrix(K)).cuda()
+    for sig in [(0.9820137619972229, 0.9820137619972229), (0.7, 0.9)]:
+        q, s = ops.hadamard_quant(x.cuda(), K, hk, sig)
+        qf, sf = ops.hadamard_quant(x.cuda(), K, hk, sig, fwht_route=True)
+        qa, qb = O.unpack_i4(q.cpu().numpy().reshape(rows, -1)), O.unpack_i4(qf.cpu().numpy().reshape(rows, -1))
+        assert np.mean(qa != qb) <= 2e-3 and np.max(np.abs(qa - qb)) <= 1, (n, K, sig, float(np.mean(qa != qb)))
+        sa, sb = s.float().cpu().numpy().reshape(-1), sf.float().cpu().numpy().reshape(-1)
+        assert np.all(np.abs(sa - sb) <= 2e-3 * np.maximum(np.abs(sb), 1e-6))
+    y = ops.hadamard(x.cuda(), K, hk)
+    yf = ops.hadamard(x.cuda(), K, hk, fwht_route=True)
+    den = yf.float().abs().amax(dim=1, keepdim=True)
+    assert float(((y.float() - yf.float()).abs() / den).max()) <= 1e-3
+
+
+def test_reference_fixture_14336(ops, golden):
+    """matmul_hadU's own output on the reference's fixture (tests/golden/had_A.npz, written by tools/gen_golden.py)."""
+    g = golden("had_A")
+    x = torch.from_numpy(g["x_14336"]).cuda()
+    hk = torch.from_numpy(hadk_matrix(28)).cuda()
+    y = ops.hadamard(x, 28, hk).cpu().numpy()
+    y64 = g["y64_14336"]
+    den = np.abs(y64).max(axis=1, keepdims=True)
+    assert np.max(np.abs(y.astype(np.float64) - y64) / den) <= 1e-3
+
+
+def test_in_place_partition_and_repeatability(ops):
+    """y_out == x is allowed; any split of the rows over launches returns the same bytes (rows are independent); 20 repeated
+    full-size launches are bit-identical (the token claims and meetings are timing-dependent, the results must not be)."""
+    n, K = 14336, 28
+    rows = 4099
+    x = make_x(rows, n, 5, outliers=False).cuda()
+    hk = torch.from_numpy(hadk_matrix(K)).cuda()
+    sig = (0.83, 0.64)
+    y, q, s = ops.hadamard_mfma(x, K, hk, sig)
+    for _ in range(20):
+        y2, q2, s2 = ops.hadamard_mfma(x, K, hk, sig)
+        assert torch.equal(y2, y) and torch.equal(q2, q) and torch.equal(s2, s)
+    parts = [ops.hadamard_mfma(x[a:b].contiguous(), K, hk, sig) for a, b in [(0, 1), (1, 770), (770, 4099)]]
+    assert torch.equal(torch.cat([p[0] for p in parts]), y) and torch.equal(torch.cat([p[1] for p in parts]), q)
+    z = x.clone()
+    from flatquant_amd._lib import check, lib
+    import ctypes
+    check(lib.fq_hadamard_quant_mfma_f16(z.data_ptr(), rows, n, K, hk.data_ptr(), ctypes.c_float(float(1.0 / torch.tensor(n).sqrt())),
+                                         ctypes.c_float(1.0), ctypes.c_float(1.0), None, None, z.data_ptr(),
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert torch.equal(z, y)
+
+
+def test_unsupported_shapes_are_refused(ops):
+    from flatquant_amd import _lib
+    hk = torch.from_numpy(hadk_matrix(28)).cuda()
+    x = torch.zeros(4, 28672, dtype=torch.float16, device="cuda")
+    q = torch.empty(4, 14336, dtype=torch.uint8, device="cuda")
+    s = torch.empty(4, dtype=torch.float16, device="cuda")
+    import ctypes
+    rc = _lib.lib.fq_hadamard_quant_mfma_f16(x.data_ptr(), 4, 28672, 28, hk.data_ptr(), ctypes.c_float(1.0), ctypes.c_float(1.0),
+                                            ctypes.c_float(1.0), q.data_ptr(), s.data_ptr(), None, None)
+    assert rc == _lib.FQ_EUNSUPPORTED
+    rc = _lib.lib.fq_hadamard_quant_mfma_f16(x.data_ptr(), 4, 14336, 28, hk.data_ptr(), ctypes.c_float(1.0), ctypes.c_float(1.0),
+                                            ctypes.c_float(1.0), None, None, None, None)
+    assert rc == _lib.FQ_EINVAL

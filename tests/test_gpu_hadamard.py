@@ -37,9 +37,12 @@ def test_vs_reference_matmul_hadU_golden(ops, golden, n):
     K = int(g[f"K_{n}"])
     x = torch.from_numpy(g[f"x_{n}"]).cuda()
     hk = None if K == 1 else torch.from_numpy(hadk_matrix(K)).cuda()
-    y = ops.hadamard(x, K, hk).cpu().numpy()
     y64 = g[f"y64_{n}"]
     den = np.abs(y64).max(axis=1, keepdims=True)
+    if ops.had_mfma_supported(n, K):   # (round 4) the default route of n = K * 512 is the structured matrix-pipe kernel: tolerance only
+        yd = ops.hadamard(x, K, hk).cpu().numpy()
+        assert np.max(np.abs(yd.astype(np.float64) - y64) / den) <= 1e-3
+    y = ops.hadamard(x, K, hk, fwht_route=True).cpu().numpy()
     assert np.max(np.abs(y.astype(np.float64) - y64) / den) <= 1e-3          # north-star tolerance
     ref = O.hadamard(g[f"x_{n}"], K, None if K == 1 else hadk_matrix(K))
     if K == 1:
@@ -55,7 +58,9 @@ def test_non_power_of_two_orthogonality_and_rows(ops, n, K):
     rows = 70
     x = torch.randn(rows, n, generator=g).half()
     hk = torch.from_numpy(hadk_matrix(K)).cuda()
-    y = ops.hadamard(x.cuda(), K, hk)
+    yd = ops.hadamard(x.cuda(), K, hk)                       # default route (the structured kernel for 14336)
+    assert torch.allclose(x.double().norm(dim=1), yd.cpu().double().norm(dim=1), rtol=2e-3)
+    y = ops.hadamard(x.cuda(), K, hk, fwht_route=True)
     nx, ny = x.double().norm(dim=1), y.cpu().double().norm(dim=1)
     assert torch.allclose(nx, ny, rtol=2e-3)
     ref = O.hadamard(x[:3].numpy(), K, hadk_matrix(K))
@@ -105,8 +110,8 @@ def test_fused_hadamard_quantizer_equals_two_launches(ops, n, K):
     hk = None if K == 1 else torch.from_numpy(hadk_matrix(K)).cuda()
     for sig in [(0.9820137619972229, 0.9820137619972229), (0.7, 0.9), (1.0, 1.0)]:
         q, s = ops.hadamard_quant(x, K, hk, sig)
-        two = ops.rowquant(ops.hadamard(x, K, hk), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)  # = deploy Quantizer
-        if K > 1 and ops._hadamard_as_kron(K, n // K, hk, x.device) is not None:
+        two = ops.rowquant(ops.hadamard(x, K, hk, fwht_route=True), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)  # = deploy Quantizer
+        if K > 1 and (ops.had_mfma_supported(n, K) or ops._hadamard_as_kron(K, n // K, hk, x.device) is not None):
             # these shapes run as ONE Kronecker launch (112 x 128 / 112 x 256): the fp16 rounding of the intermediate sits
             # elsewhere than in the FWHT kernel, so the two routes agree to rounding noise, not bit for bit
             qa, qb = O.unpack_i4(q.cpu().numpy().reshape(rows, -1)), O.unpack_i4(two.q[0].cpu().numpy())
@@ -141,12 +146,16 @@ def test_hadamard_as_kronecker_launch(ops, n, K):
     assert np.max(np.abs(y.astype(np.float32) - ref.astype(np.float32))) <= 1e-3 * np.max(np.abs(ref.astype(np.float32)))
     rq = O.rowquant(y, *sig, clamp0=True, quant_f16=True, sig_f16=True)
     assert np.array_equal(o.q[0].cpu().numpy(), rq["packed"]) and np.array_equal(o.scale[0].cpu().numpy(), rq["scale16"])
-    q, s = ops.hadamard_quant(x.cuda(), K, hk.cuda(), sig)                # the packed-only instantiation: same bytes
-    assert np.array_equal(q.cpu().numpy(), rq["packed"]) and np.array_equal(s.cpu().numpy(), rq["scale16"])
+    op = ops.kron_quant_ex(x.cuda(), left, right, scale, [sig], FQ_OUT_PACKED | fl)   # the packed-only instantiation: same bytes
+    assert np.array_equal(op.q[0].cpu().numpy(), rq["packed"]) and np.array_equal(op.scale[0].cpu().numpy(), rq["scale16"])
+    if not ops.had_mfma_supported(n, K):   # (n = K * 512 defaults to the structured kernel: tests/test_gpu_had_mfma.py)
+        q, s = ops.hadamard_quant(x.cuda(), K, hk.cuda(), sig)
+        assert np.array_equal(q.cpu().numpy(), rq["packed"]) and np.array_equal(s.cpu().numpy(), rq["scale16"])
     up = torch.randn(rows, n, generator=g).half()
-    q2, s2 = ops.hadamard_quant(x.cuda(), K, hk.cuda(), sig, up=up.cuda())
-    q3, s3 = ops.hadamard_quant(ops.silu_mul(x.cuda(), up.cuda()), K, hk.cuda(), sig)
-    assert torch.equal(q2, q3) and torch.equal(s2, s3)
+    q2, s2 = ops.hadamard_quant(x.cuda(), K, hk.cuda(), sig, up=up.cuda())     # the SiLU.mul input stays with the dense pair
+    xs = ops.silu_mul(x.cuda(), up.cuda())
+    o3 = ops.kron_quant_ex(xs, left, right, scale, [sig], FQ_OUT_PACKED | fl)
+    assert torch.equal(q2, o3.q[0]) and torch.equal(s2, o3.scale[0])
 
 
 @pytest.mark.parametrize("n,K", [(14336, 28), (28672, 28), (11008, 172)])
@@ -159,7 +168,7 @@ def test_fwht_route_switch_is_bit_identical_to_the_two_launch_sequence(ops, n, K
     hk = torch.from_numpy(hadk_matrix(K)).cuda()
     sig = (0.91, 0.77)
     q, s = ops.hadamard_quant(x, K, hk, sig, fwht_route=True)
-    two = ops.rowquant(ops.hadamard(x, K, hk), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)
+    two = ops.rowquant(ops.hadamard(x, K, hk, fwht_route=True), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)
     assert torch.equal(q, two.q[0]) and torch.equal(s.reshape(-1), two.scale[0].reshape(-1))
 
 

@@ -132,7 +132,8 @@ def test_fused_hadamard_equals_two_launches(ops, n, K):
     hk = None if K == 1 else torch.from_numpy(hadk_matrix(K)).cuda()
     for sig in [(0.9820137619972229, 0.9820137619972229), (0.7, 0.9)]:
         q, s = ops.hadamard_quant(gate, K, hk, sig, up=up)
-        q2, s2 = ops.hadamard_quant(ops.silu_mul(gate, up), K, hk, sig)
+        # (n = K * 512 without up= defaults to the structured kernel since round 4: compare on the route that takes up=)
+        q2, s2 = ops.hadamard_quant(ops.silu_mul(gate, up), K, hk, sig, route="kron" if ops.had_mfma_supported(n, K) else None)
         assert torch.equal(q, q2) and torch.equal(s, s2)
 
 
@@ -153,7 +154,14 @@ def test_module_arguments(ops):
     h = deploy.nn.OnlineTrans(14336, trans="had").cuda()
     qz = deploy.nn.Quantizer(lac=True).cuda()
     a, b = h(gate, quantizer=qz, up=up), h(x, quantizer=qz)
-    assert torch.equal(a.quantized_x, b.quantized_x) and torch.equal(a.scales_x, b.scales_x)
+    # (round 4: without up= the rotation of 14336 runs the structured matrix-pipe kernel, with up= the dense Kronecker launch that
+    #  forms up * silu(gate) in registers: the two round the intermediate at different points — rounding-noise agreement)
+    import numpy as np
+    from oracle import fq_oracle as O
+    qa, qb = O.unpack_i4(a.quantized_x.cpu().numpy().reshape(18, -1)), O.unpack_i4(b.quantized_x.cpu().numpy().reshape(18, -1))
+    assert np.mean(qa != qb) <= 2e-3 and np.max(np.abs(qa - qb)) <= 1
+    sa, sb = a.scales_x.float().cpu().numpy().reshape(-1), b.scales_x.float().cpu().numpy().reshape(-1)
+    assert np.all(np.abs(sa - sb) <= 2e-3 * np.abs(sb))
     assert torch.equal(h(gate, up=up), h(x))            # no quantizer: silu_mul launch + Hadamard launch
     with pytest.raises(RuntimeError):
         t(gate, up=up, norm=deploy.nn.RMSNorm(14336))

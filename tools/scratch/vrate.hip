@@ -41,7 +41,18 @@
     F(31, "v_mov_b32", "v_mov_b32 %0, %1")                                                                  \
     F(34, "v_dot2_f32_f16", "v_dot2_f32_f16 %0, %1, %2, %0")                                                \
     F(35, "v_mad_u32_u24", "v_mad_u32_u24 %0, %0, %1, %2")                                                  \
-    F(36, "v_cmp_ne_u32 (sgpr dst)", "v_cmp_ne_u32_e64 s[20:21], %0, %1")
+    F(36, "v_cmp_ne_u32 (sgpr dst)", "v_cmp_ne_u32_e64 s[20:21], %0, %1")                                   \
+    F(37, "v_mad_u32_u16 op_sel hi", "v_mad_u32_u16 %0, %1, 16, %0 op_sel:[1,0,0,0]")                       \
+    F(38, "v_mad_u32_u16 sgpr", "v_mad_u32_u16 %0, %1, %3, %0 op_sel:[1,0,0,0]")                            \
+    F(39, "v_min3_u16", "v_min3_u16 %0, %0, %1, %2")                                                        \
+    F(40, "v_med3_i32", "v_med3_i32 %0, %0, %1, %2")                                                        \
+    F(41, "v_min_u16", "v_min_u16_e32 %0, %0, %1")                                                          \
+    F(42, "v_cmp_gt_u16 (sgpr dst)", "v_cmp_gt_u16_e64 s[20:21], 2, %0")                                    \
+    F(43, "v_alignbit_b32", "v_alignbit_b32 %0, %1, %0, 4")                                                 \
+    F(44, "v_bfe_u32", "v_bfe_u32 %0, %0, 16, 4")                                                           \
+    F(45, "v_lshl_or_b32", "v_lshl_or_b32 %0, %0, 4, %1")                                                   \
+    F(46, "v_bitop3_b32", "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x36")                                        \
+    F(47, "v_mad_u32_u24 k", "v_mad_u32_u24 %0, %1, 16, %0")
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int OP>

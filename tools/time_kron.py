@@ -26,7 +26,7 @@ BYTES = {"packed": lambda d: 2.5 * d + 2, "fq": lambda d: 4.0 * d, "y": lambda d
          "packed3": lambda d: 2.0 * d + 3 * (0.5 * d + 2), "packedr": lambda d: 2.5 * d + 2, "h16": lambda d: 2.5 * d + 2}
 
 
-def time_case(M, N, rows, mode, dtype="f16", rounds=5, steps=100, sig=0.9820137619972229):
+def time_case(M, N, rows, mode, dtype="f16", rounds=5, steps=100, sig=float(os.environ.get("SIG", "0.9820137619972229"))):   # SIG=0.7: the clamp path
     td = torch.bfloat16 if dtype == "bf16" else torch.float16
     fn = lib.fq_kron_quant_bf16 if dtype == "bf16" else lib.fq_kron_quant_f16
     d = M * N
