@@ -272,11 +272,11 @@ __global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __rest
             HM_MEET()   // B|C: the four partial extrema are in LDS
             {
                 const f32x4 r0 = *reinterpret_cast<const f32x4*>(red), r1 = *reinterpret_cast<const f32x4*>(red + 4);
-                vmax = fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3]));
-                vmin = fminf(fminf(r1[0], r1[1]), fminf(r1[2], r1[3]));
+                vmax = fq_uniform_f32(fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3])));   // (uniform by construction; told to the compiler)
+                vmin = fq_uniform_f32(fminf(fminf(r1[0], r1[1]), fminf(r1[2], r1[3])));
             }
             scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, sig_max, sig_min, FQ_SIG_F16);
-            const float inv = fq_fast_inv(scale);
+            const float inv = fq_uniform_f32(fq_fast_inv(scale));
             const bool clampq = fq_h16_needs_clamp(vmax, vmin, inv);
             const FqH16Recip rc = fq_h16_recip(scale);
 #pragma unroll

@@ -92,9 +92,12 @@ __device__ __forceinline__ void duo_meet(unsigned cnt_lds, unsigned target, int 
 }
 #define DUO_MEET() { meet_n += DUO_WPG; duo_meet(meet, meet_n, lane); }
 
-template <int MT>
+// FULL: M == 32 MT (128 x 224, the shape of BASELINE config 4): every DMA block is four whole instructions and no row is padding —
+// the lane-masked tail code, its scalar state (the launch spilled ~100 SGPRs to VGPR lanes) and the row tests are compiled out.
+template <int MT, bool FULL>
 __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
-                                                                int64_t rows, int64_t tpb, int M, FqQuantOut out) {
+                                                                int64_t rows, int64_t tpb, int M_rt, FqQuantOut out) {
+    const int M = FULL ? MT * 32 : M_rt;
     typedef DuoGeom<MT> G;
     constexpr int KS1 = DUO_KS1, NT = DUO_NT, CPR = DUO_CPR, PITCH = DUO_PITCH, N = DUO_N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
         const unsigned long long sbi = sb + (unsigned long long)i0 * 1024;
         const unsigned long long sbu = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sbi) |
                                        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sbi >> 32)) << 32);
-        if (i0 + 4 <= n_full) {
+        if (FULL || i0 + 4 <= n_full) {
             unsigned keep;
             asm volatile(
                 "s_nop 4\n\t"
@@ -389,8 +392,10 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
         if (more) dma_block(sbn, wq + 3 * DUO_WPG);
         {
             const f32x4 r0 = *reinterpret_cast<const f32x4*>(red), r1 = *reinterpret_cast<const f32x4*>(red + 4);
-            vmax = fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3]));
-            vmin = fminf(fminf(r1[0], r1[1]), fminf(r1[2], r1[3]));
+            // (wave-uniform BY CONSTRUCTION, but values out of LDS are divergent to the compiler: every branch on the scale below became
+            //  an exec-mask region, the quantiser's SGPR masks were copied into VGPRs to be tested, and ~100 SGPRs were spilled to lanes)
+            vmax = fq_uniform_f32(fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3])));
+            vmin = fq_uniform_f32(fminf(fminf(r1[0], r1[1]), fminf(r1[2], r1[3])));
         }
         if (wq == 0 && lane == 0) duo_lds_write(ctl_lds + 12 + grp * 4, duo_lds_add_rtn(ctl_lds + 8, 1u));  // the claim after next (everyone has read this one)
         // The ring is primed BEFORE this token's stores: vmcnt counts loads and stores in issue order, so a load behind the
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
             float sig_max, sig_min;
             fq_token_sigs(out, ci, tok, gcur, sig_max, sig_min);
             const float scale = fq_token_scale<0>(vmax, vmin, sig_max, sig_min, out.rt_flags);
-            const float inv = fq_fast_inv(scale);
+            const float inv = fq_uniform_f32(fq_fast_inv(scale));   // (an inline-asm VGPR result is divergent to the compiler: see above)
             const bool magic = fq_magic_ok(vmax, vmin, inv), clampq = fq_needs_clamp(vmax, vmin, inv);
             const float ilo = fq_inv_lo(inv), ihi = fq_inv_hi(inv);
             // the wave's tiles are neighbours: a lane's two 8-byte runs (16 n' each) of a row are 16 contiguous bytes
@@ -450,11 +455,11 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
     }
 }
 
-template <int MT>
+template <int MT, bool FULL>
 int launch_duo(const f16* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
     typedef DuoGeom<MT> G;
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
-    auto kern = fq_kron_duo_kernel<MT>;
+    auto kern = fq_kron_duo_kernel<MT, FULL>;
     FQ_RAISE_LDS_CAP(kern, 160 * 1024);
     int64_t blocks = (rows + DUO_GROUPS - 1) / DUO_GROUPS;
     if (blocks > n_cu) blocks = n_cu;   // one persistent workgroup per CU
@@ -479,5 +484,6 @@ int fq_launch_kron_duo(int flags, const f16* x, const void* ws, const f16* diag,
     if (N != DUO_N || M <= 96 || M > 128 || diag != nullptr) return -1000;
     if ((out.rt_flags & FQ_GROUP128) || out.post_scale != 0.0f) return -1000;
     if ((flags & FQ_CT_MASK) != FQ_OUT_PACKED) return -1000;
-    return launch_duo<4>(x, reinterpret_cast<const uint4*>(ws), rows, M, out, n_cu, stream);
+    if (M == 128) return launch_duo<4, true>(x, reinterpret_cast<const uint4*>(ws), rows, M, out, n_cu, stream);
+    return launch_duo<4, false>(x, reinterpret_cast<const uint4*>(ws), rows, M, out, n_cu, stream);
 }

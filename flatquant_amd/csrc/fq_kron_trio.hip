@@ -312,8 +312,9 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
         TRIO_STAMP(7)
         {
             const f32x4 r0 = *reinterpret_cast<const f32x4*>(red), r1 = *reinterpret_cast<const f32x4*>(red + 4);
-            vmax = fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3]));
-            vmin = fminf(fminf(r1[0], r1[1]), fminf(r1[2], r1[3]));
+            // (wave-uniform by construction; told to the compiler, or every branch on the scale is an exec-mask region: fq_kron_duo.hip)
+            vmax = fq_uniform_f32(fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3])));
+            vmin = fq_uniform_f32(fminf(fminf(r1[0], r1[1]), fminf(r1[2], r1[3])));
         }
         bool waited = false;
         for (int ci = 0; ci < out.n_clips; ++ci) {
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
             float scale;
             if (H16) scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, sig_max, sig_min, out.rt_flags);
             else scale = fq_token_scale<0>(vmax, vmin, sig_max, sig_min, out.rt_flags);
-            const float inv = fq_fast_inv(scale);
+            const float inv = fq_uniform_f32(fq_fast_inv(scale));
             const FqH16Recip rc = H16 ? fq_h16_recip(scale) : FqH16Recip{0.0f, 0.0f};
             const bool magic = H16 || fq_magic_ok(vmax, vmin, inv);
             const bool clampq = fq_needs_clamp(vmax, vmin, inv);
