@@ -103,51 +103,75 @@ def cpu_model():
     return "unknown"
 
 
+def physical_cores():
+    """Physical cores of the host (distinct (physical id, core id) pairs of /proc/cpuinfo); logical CPUs when that fails."""
+    try:
+        seen, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(max_seconds=20.0, m=M, n=N):
     """The reference's CPU fake-quant path (flat_utils.py:6-17 + quant_utils.py:71-119), restated in torch by
-    oracle/path_a_torch.py, on a bounded sample: C1-sized batches (2048 tokens, fp16) for <= ~20 s."""
+    oracle/path_a_torch.py, on a bounded sample: C1-sized batches (2048 tokens) for <= ~20 s. As SURVEY 8d asks: fp16 (the
+    dtype BASELINE configs[0] names) AND fp32 (the reference's calibration dtype), each at ONE thread and at ALL PHYSICAL cores
+    (torch.set_num_threads), plus a short ladder in between because torch's fp16 CPU GEMM on 64 x 64 factors anti-scales.
+    `value` / `cores`: the best fp16 figure; `fp32_value` / `fp32_cores`: the best fp32 one."""
     from oracle import path_a_torch
-    # torch's CPU GEMM on 64x64 factors scales poorly past a few dozen threads; time a short ladder and report the
-    # best (cores = the thread count actually used for `value`).
     rows, d = 2048, m * n
     g = torch.Generator().manual_seed(0)
     x = torch.randn(rows, d, generator=g).to(torch.float16)
     left, right = make_matrix(m, 1, "cpu"), make_matrix(n, 2, "cpu")
     sig = (float(torch.sigmoid(torch.tensor(4.0))),) * 2
-    ncpu = os.cpu_count() or 1
-    ladder = sorted({t for t in (1, 8, 16, 32, 64, ncpu) if t <= ncpu})
-    best = None
-    results, results32 = {}, {}
+    ncpu, nphys = os.cpu_count() or 1, physical_cores()
+    ladder = sorted({t for t in (1, 8, 32, nphys) if 1 <= t <= max(nphys, 1)})
     t_start = time.perf_counter()
 
     def median_rate(xx, ll, rr, budget):
         path_a_torch.kron_fakequant(xx, ll, rr, sig)   # warm-up
         times = []
         t_cfg = time.perf_counter()
-        while len(times) < 5 and time.perf_counter() - t_cfg < budget:
+        while len(times) < 5 and (not times or time.perf_counter() - t_cfg < budget):
             t0 = time.perf_counter()
             path_a_torch.kron_fakequant(xx, ll, rr, sig)
             times.append(time.perf_counter() - t0)
         times.sort()
         return rows * d / times[len(times) // 2] / 1e6
-    for threads in ladder:
+    results = {"fp16": {}, "fp32": {}}
+    operands = {"fp16": (x, left, right), "fp32": (x.float(), left.float(), right.float())}
+    # 1 thread and all physical cores first (what SURVEY 8d names), the ladder in between while the budget lasts
+    order = [1, nphys] + [t for t in ladder if t not in (1, nphys)]
+    per = max_seconds / (2 * max(len(order), 1))
+    for threads in order:
+        if threads < 1 or (threads not in (1, nphys) and time.perf_counter() - t_start > max_seconds * 0.8):
+            continue
         torch.set_num_threads(threads)
-        results[threads] = median_rate(x, left, right, max_seconds * 0.7 / len(ladder))
-        if best is None or results[threads] > results[best]:
-            best = threads
-        if time.perf_counter() - t_start > max_seconds * 0.7:
-            break
-    # the fp32 leg SURVEY 8d asks for beside the fp16 one (the reference's calibration dtype): 1 thread and the best count
-    x32, l32, r32 = x.float(), left.float(), right.float()
-    for threads in sorted({1, best}):
-        torch.set_num_threads(threads)
-        results32[threads] = median_rate(x32, l32, r32, max_seconds * 0.15)
-    return {"value": results[best], "unit": "Melem/s", "cores": best, "kind": "port", "cpu_model": cpu_model(),
-            "logical_cpus": ncpu,
-            "sample": f"median of <=5 x ({rows} x {d} fp16 tokens, {m}x{n} factors) per thread count, torch "
-                      f"{torch.__version__} CPU ({cpu_model()}, {ncpu} logical CPUs)",
-            "by_threads": {str(k): round(v, 2) for k, v in results.items()},
-            "fp32_by_threads": {str(k): round(v, 2) for k, v in results32.items()}}
+        for dt in ("fp16", "fp32"):
+            if threads not in results[dt]:
+                results[dt][threads] = median_rate(*operands[dt], per)
+    best16 = max(results["fp16"], key=results["fp16"].get)
+    best32 = max(results["fp32"], key=results["fp32"].get)
+    return {"value": results["fp16"][best16], "unit": "Melem/s", "cores": best16, "kind": "port", "cpu_model": cpu_model(),
+            "logical_cpus": ncpu, "physical_cores": nphys,
+            "fp32_value": results["fp32"][best32], "fp32_cores": best32,
+            "sample": f"median of <=5 x ({rows} x {d} tokens, {m}x{n} factors) per dtype and thread count, torch "
+                      f"{torch.__version__} CPU ({cpu_model()}, {nphys} physical cores / {ncpu} logical CPUs); value = best fp16 "
+                      f"figure, fp32_value = best fp32 figure",
+            "by_threads": {str(k): round(v, 2) for k, v in sorted(results["fp16"].items())},
+            "fp32_by_threads": {str(k): round(v, 2) for k, v in sorted(results["fp32"].items())}}
 
 
 # ---------------------------------------------------------------------------------------------------- workloads
@@ -365,10 +389,11 @@ class C5(Workload):
     metric = "Melems/s, DeepSeek-V3 MoE expert inputs: w1_trans 64x112 (d=7168) + grouped 32x64 (2048) over 256 experts, top-8, 16384 tokens"
     scaling = "strong"
 
-    def __init__(self, device, rank, world, sharding, bcast):
-        from flatquant_amd import ops
-        from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED
-        T, d1, d2, E, K = ROWS, 7168, 2048, 256, 8
+    @staticmethod
+    def plan(world, rank, sharding):
+        """The partition of the workload (host side, no device): routing counts (identical on every rank), this rank's experts
+        [e0, e1) with their group offsets over ITS routed rows, and its row block [t0, t1) of the shared w1_trans stage."""
+        T, E, K = ROWS, 256, 8
         # routing: seeded multinomial with Zipf-skewed expert popularity (SURVEY 8d), identical on every rank
         g = torch.Generator().manual_seed(5)
         pop = 1.0 / torch.arange(1, E + 1, dtype=torch.float64) ** 0.8
@@ -376,6 +401,14 @@ class C5(Workload):
         counts = torch.bincount(indices.flatten(), minlength=E)
         e0, e1, offs = sharding.shard_experts(counts, world, rank)   # EP-style: this rank owns experts [e0, e1) and their rows
         t0, t1 = sharding.shard_rows(T, world, rank)             # and a row block of the shared w1_trans stage
+        return {"T": T, "E": E, "K": K, "counts": counts, "e0": e0, "e1": e1, "offs": offs, "t0": t0, "t1": t1}
+
+    def __init__(self, device, rank, world, sharding, bcast):
+        from flatquant_amd import ops
+        from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED
+        d1, d2 = 7168, 2048
+        pl = self.plan(world, rank, sharding)
+        T, E, K, counts, e0, e1, offs, t0, t1 = (pl[k] for k in ("T", "E", "K", "counts", "e0", "e1", "offs", "t0", "t1"))
         rows2 = int(offs[-1])
         mats = bcast({"l1": make_matrix(64, 1, device), "r1": make_matrix(112, 2, device),
                       "l2": make_matrix(32, 3, device), "r2": make_matrix(64, 4, device)})
@@ -404,7 +437,132 @@ class C5(Workload):
                        "parallelism": f"experts+tokens /{world}"}
 
 
-WORKLOADS = {"C1": C1, "C2": C2, "C2S": C2S, "C3": C3, "C4": C4, "C5": C5}
+class C2SL(Workload):
+    """C2S over the LAYERS of the model in one launch (round 4; the `strong` sub-record of the default line): the 8 x 2048 tokens
+    BASELINE quotes the metric on are split over the ranks (strong scaling), and a step is the q_proj-input transform of ALL 32
+    decoder layers of Llama-3-8B on the rank's shard — 32 independent jobs (own activations, own factor pair) issued as ONE
+    multi-job launch (fq_kron_quant_multi_f16), so that at N = 8 a step is one 65536-token launch, not thirty-two 5 us ones."""
+    name = "C2S x 32 layers"
+    scaling = "strong"
+    layers = 32
+
+    def __init__(self, device, rank, world, sharding, bcast):
+        from flatquant_amd import ops
+        from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED
+        a, b = sharding.shard_rows(ROWS, world, rank)
+        rows = b - a
+        mats = {}
+        for j in range(self.layers):
+            mats[f"l{j:02d}"], mats[f"r{j:02d}"] = make_matrix(M, 100 + 2 * j, device), make_matrix(N, 101 + 2 * j, device)
+        mats = bcast(mats)                                     # one flat broadcast of all layers' matrices (512 KB)
+        g = torch.Generator(device=device).manual_seed(1000 + rank)
+        self.xs = [torch.randn(max(rows, 1), D, generator=g, device=device, dtype=torch.float16)[:rows] for _ in range(self.layers)]
+        self.plan = ops.KronMultiPlan(self.xs, [mats[f"l{j:02d}"] for j in range(self.layers)],
+                                      [mats[f"r{j:02d}"] for j in range(self.layers)], (SIG4, SIG4), FQ_OUT_PACKED | FQ_NO_CLAMP0)
+        self.step = lambda i: self.plan.run()
+        self.elems = self.layers * rows * D
+        self.kernels = [("fq_kron64_kernel (multi-job)", self.step, self.layers * rows * BYTES_PER_TOKEN)]
+        self.config = {"workload": f"C2S x {self.layers} layers: the 8x2048 tokens split over the ranks, the 64x64 transform + INT4 "
+                                   f"quantisation of all {self.layers} layers' q_proj inputs on the rank's shard as ONE multi-job launch",
+                       "rows_per_gpu": rows, "layers": self.layers, "launches_per_step": 1, "parallelism": f"rows /{world}"}
+
+
+WORKLOADS = {"C1": C1, "C2": C2, "C2S": C2S, "C3": C3, "C4": C4, "C5": C5, "C2SL": C2SL}
+
+
+class TimedBroadcast:
+    """sharding.broadcast_matrices with its wall time kept (the one collective of the path, set-up time): .ms after the call."""
+
+    def __init__(self, sharding, device):
+        self.sharding, self.device, self.ms, self.bytes = sharding, device, 0.0, 0
+
+    def __call__(self, mats):
+        cuda = torch.device(self.device).type == "cuda"
+        if cuda:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = self.sharding.broadcast_matrices(mats, src=0)
+        if cuda:
+            torch.cuda.synchronize()
+        self.ms += (time.perf_counter() - t0) * 1e3
+        self.bytes += sum(t.numel() * t.element_size() for t in mats.values())
+        return out
+
+
+def reduce_over_ranks(dist, device, wall_s, kern_ms, elems):
+    """MAX over ranks of the two clocks, SUM of the units, and every rank's own wall clock (all_gather) — the contract's
+    'max over ranks' plus what shows a straggler. Works on CPU tensors with gloo (tests) and on the GPU with RCCL."""
+    t = torch.tensor([wall_s, kern_ms], dtype=torch.float64, device=device)
+    e = torch.tensor([float(elems)], dtype=torch.float64, device=device)
+    per_rank = [wall_s]
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        mine = torch.tensor([wall_s], dtype=torch.float64, device=device)
+        parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, mine)
+        per_rank = [float(p[0]) for p in parts]
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+    return float(t[0]), float(t[1]), float(e[0]), per_rank
+
+
+def timed_region(step, steps, warmup, dist, stream):
+    """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides -> (wall seconds, average step
+    in ms from HIP events on the launch stream)."""
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)                                       # same stream the kernels are launched on
+    for i in range(steps):
+        step(i)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
+
+
+def capture_graphs(wl, device):
+    """launch-bound step (hundreds of short launches): capture it once, replay it (HIP graph); graph_inputs > 1: one graph per
+    rotating input set, replayed in turn, so that a step never re-reads what the previous one left in the Infinity Cache"""
+    graphs = []
+    for j in range(wl.graph_inputs):
+        wl.step(j)
+        torch.cuda.synchronize()
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph):
+            wl.step(j)
+        graphs.append(gph)
+    return lambda i: graphs[i % len(graphs)].replay()
+
+
+def sub_record(cls, steps, warmup, device, rank, world, sharding, dist):
+    """One more workload measured inside the same process with the same protocol, reported as a sub-record of the line (round 4:
+    the STRONG-scaling forms next to the weak-scaling default, so that a SCALE file cannot be read as 'N x because every GPU got
+    its own copy of the work')."""
+    bc = TimedBroadcast(sharding, device)
+    wl = cls(device, rank, world, sharding, bc)
+    step = capture_graphs(wl, device) if wl.graph else wl.step
+    stream = torch.cuda.current_stream(device)
+    wall, kern_ms = timed_region(step, steps, warmup, dist, stream)
+    wall, kern_ms, elems, per_rank = reduce_over_ranks(dist, device, wall, kern_ms, wl.elems)
+    rec = None
+    if rank == 0:
+        step_bytes = sum(k[2] for k in wl.kernels) * (wl.config.get("layers", 1) if cls is C4 else 1)
+        rec = {"workload": wl.config["workload"], "scaling": wl.scaling, "value": elems / (wall / steps) / 1e6, "unit": "Melem/s",
+               "steps": steps, "warmup": warmup, "ms_per_step": wall * 1e3 / steps,
+               "per_rank_ms_per_step": [w * 1e3 / steps for w in per_rank], "event_ms_per_step": kern_ms,
+               "rows_per_gpu": wl.config.get("rows_per_gpu"), "launches_per_step": wl.config.get("launches_per_step"),
+               "broadcast_ms": bc.ms, "broadcast_bytes": bc.bytes,
+               "step_hbm_frac_rank0": step_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    del wl
+    torch.cuda.empty_cache()
+    return rec
 
 
 def main():
@@ -415,14 +573,16 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="activation dtype (C1 / C2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub-records", action="store_true",
+                    help="default config only: skip the `strong` (C2S x 32 layers, one multi-job launch) and `c4` sub-records")
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed clock-settle phase before the counted warm-up: launches of the same step for this "
                          "many milliseconds (reported as settle_launches); 0 disables it")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {"C1": 500, "C2": 1000, "C2S": 1000, "C3": 100, "C4": 5, "C5": 50}[args.config]
+        args.steps = {"C1": 500, "C2": 1000, "C2S": 1000, "C3": 100, "C4": 5, "C5": 50, "C2SL": 50}[args.config]
     if args.warmup is None:
-        args.warmup = {"C1": 100, "C2": 200, "C2S": 200, "C3": 10, "C4": 2, "C5": 5}[args.config]
+        args.warmup = {"C1": 100, "C2": 200, "C2S": 200, "C3": 10, "C4": 2, "C5": 5, "C2SL": 10}[args.config]
     if args.dtype != "f16" and args.config not in ("C1", "C2"):
         ap.error("--dtype bf16 goes with --config C1 / C2 (the deploy configs are fp16 contracts)")
 
@@ -438,23 +598,12 @@ def main():
 
     from flatquant_amd import sharding
     kw = {"dtype": args.dtype} if args.config in ("C1", "C2", "C2S") else {}
-    wl = WORKLOADS[args.config](device, rank, world, sharding, lambda m: sharding.broadcast_matrices(m, src=0), **kw)
+    bcast = TimedBroadcast(sharding, device)
+    wl = WORKLOADS[args.config](device, rank, world, sharding, bcast, **kw)
     stream = torch.cuda.current_stream(device)
     step = wl.step
     if wl.graph:
-        # launch-bound step (hundreds of short launches): capture it once, replay it (HIP graph); the captured launches
-        # read rotating inputs selected by the Python-side index at capture time, so one graph = one fixed step
-        # (graph_inputs > 1: one graph per rotating input set, replayed in turn, so that a step never re-reads what the
-        #  previous step left in the 256 MB Infinity Cache)
-        graphs = []
-        for j in range(wl.graph_inputs):
-            wl.step(j)
-            torch.cuda.synchronize()
-            gph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gph):
-                wl.step(j)
-            graphs.append(gph)
-        step = lambda i: graphs[i % len(graphs)].replay()
+        step = capture_graphs(wl, device)
         stream = torch.cuda.current_stream(device)
 
     # Declared, UNTIMED clock-settle phase: the part needs tens of milliseconds of load before its clocks and power
@@ -469,24 +618,7 @@ def main():
                 step(i)
             settle_launches += chunk
             torch.cuda.synchronize()
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)                                       # same stream the kernels are launched on
-    for i in range(args.steps):
-        step(i)
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps             # average step duration from HIP events
+    wall, kern_ms = timed_region(step, args.steps, args.warmup, dist, stream)
 
     # Per-step distribution (the reference's own quantiles, deploy/kernels/kron_matmul.py:269-281): a SEPARATE
     # untimed pass of the same K steps with one event pair per step, so that the timed region above carries no
@@ -517,16 +649,20 @@ def main():
         kern_us.append((name, k0.elapsed_time(k1) / reps * 1e3, nbytes))
     floor_us = wl.floor_us(stream) if (rank == 0 and getattr(wl, "floor_us", None) is not None) else None
 
-    t = torch.tensor([wall, kern_ms], dtype=torch.float64, device=device)
-    elems = torch.tensor([float(wl.elems)], dtype=torch.float64, device=device)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)             # MAX over ranks
-        dist.all_reduce(elems, op=dist.ReduceOp.SUM)         # units all ranks processed
-    wall, kern_ms = float(t[0]), float(t[1])
+    wall, kern_ms, elems_total, per_rank_wall = reduce_over_ranks(dist, device, wall, kern_ms, wl.elems)
+
+    # (round 4) the STRONG-scaling sub-records of the default line: the driver only ever runs `bench.py --gpus N`, whose headline
+    # value is weak scaling (every GPU its own 8 x 2048 tokens)
+    subs = {}
+    if args.config == "C2" and args.dtype == "f16" and not args.no_sub_records:
+        del wl.xs
+        torch.cuda.empty_cache()
+        subs["strong"] = sub_record(C2SL, 20, 5, device, rank, world, sharding, dist)
+        subs["c4"] = sub_record(C4, 3, 1, device, rank, world, sharding, dist)
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
-        value = float(elems[0]) / (wall / args.steps) / 1e6
+        value = elems_total / (wall / args.steps) / 1e6
         if args.config in ("C1", "C2", "C2S"):               # one launch per step: the timed region IS the kernel
             dom_name, dom_us, dom_bytes = wl.kernels[0][0], kern_ms * 1e3, wl.kernels[0][2]
         else:
@@ -537,6 +673,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": wl.scaling,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "settle_launches": settle_launches,
             "settle_ms": args.settle_ms, "config": wl.config,
+            "per_rank_ms_per_step": [w * 1e3 / args.steps for w in per_rank_wall],
+            "broadcast_ms": bcast.ms, "broadcast_bytes": bcast.bytes,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic()[0] if (args.config == "C2" and args.dtype == "f16") else None,
@@ -551,9 +689,11 @@ def main():
                                        "frac": step_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             out["roofline"]["kernels"] = [{"kernel": n, "launch_us": u, "algorithmic_bytes": b,
                                            "frac": b / (u * 1e-6) / 1e9 / HBM_PEAK_GBS} for n, u, b in kern_us]
+        for k, v in subs.items():
+            out[k] = v
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(*{"C1": (20.0, 64, 64), "C2": (20.0, 64, 64), "C2S": (20.0, 64, 64), "C3": (20.0, 64, 64),
-                                                 "C4": (20.0, 64, 128), "C5": (20.0, 32, 64)}[args.config])
+                                                 "C4": (20.0, 64, 128), "C5": (20.0, 32, 64), "C2SL": (20.0, 64, 64)}[args.config])
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

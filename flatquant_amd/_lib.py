@@ -35,6 +35,12 @@ FQ_MAX_CLIPS = 4
 
 FQ_OK, FQ_EINVAL, FQ_EUNSUPPORTED, FQ_ELAUNCH = 0, -1, -2, -3
 
+
+class FqKronJob(ctypes.Structure):
+    """include/fqhip.h: one job of fq_kron_quant_multi_{f16,bf16}"""
+    _fields_ = [("x", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("q", ctypes.c_void_p), ("scale", ctypes.c_void_p),
+                ("rows", ctypes.c_int64)]
+
 # every symbol include/fqhip.h declares: (name, restype, argtypes)
 _vp, _i64, _i, _f = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 _fp = ctypes.POINTER(ctypes.c_float)
@@ -53,6 +59,10 @@ SYMBOLS = {
     "fq_kron_quant_grouped_f16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "fq_kron_quant_ex_f16": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp, _i64, _vp]),
     "fq_kron_workspace_bytes": (_i64, [_i, _i]),
+    "fq_kron_multi_table_bytes": (_i64, [_i]),
+    "fq_kron_multi_prepare": (_i, [_vp, _i, _vp, _i64, _vp]),
+    "fq_kron_quant_multi_f16": (_i, [_vp, _i, _i, _f, _f, _i, _vp]),
+    "fq_kron_quant_multi_bf16": (_i, [_vp, _i, _i, _f, _f, _i, _vp]),
     "fq_kron_prepare_f16": (_i, [_vp, _vp, _i, _i, _vp, _i64, _vp]),
     "fq_rmsnorm_kron_quant_f16": (_i, [_vp, _f, _vp, _vp, _i64, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp]),
     "fq_rmsnorm_kron_quant_ws_f16": (_i, [_vp, _f, _vp, _vp, _i64, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp, _i64,

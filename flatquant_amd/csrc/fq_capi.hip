@@ -17,6 +17,7 @@ constexpr int64_t FQ_K64_IMAGE_BYTES = 16384, FQ_K64_WS_BYTES = 32768;
 int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream);
+int fq_launch_kron64_multi(int bf16_dtype, const void* jobs, int n_jobs, int bpj, const FqQuantOut& out, hipStream_t stream);
 int fq_launch_had_mfma(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max, float sig_min,
                        uint8_t* q_out, f16* scale_out, f16* y_out, int n_cu, hipStream_t stream);
 int fq_launch_hadamard_quant(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max,
@@ -505,6 +506,73 @@ int64_t fq_kron_workspace_bytes(int M, int N) {
     if (M == 64 && N == 64) return FQ_K64_WS_BYTES;   // optional (NULL still works): the prepared fragment images
     if (M < 1 || N < 2 || (N & 1) || M > 256 || N > 256 || (int64_t)M * N > 32768) return FQ_EUNSUPPORTED;
     return fq_kron_generic_workspace_bytes(M, N);
+}
+
+// ---- multi-job launch (fq_kron64.hip, FQ_K64_MULTI) ----
+struct Kron64JobDev {   // = FqKron64Job of fq_kron64.hip
+    const void* x;
+    const void* prep;
+    void* q;
+    void* scale;
+    int64_t rows, tpb;
+};
+static int multi_wg_per_job(int n_jobs) {
+    const int n_cu = cu_count();
+    return n_jobs >= n_cu ? 1 : (n_cu + n_jobs - 1) / n_jobs;   // ~ one persistent workgroup per CU over all jobs
+}
+
+int64_t fq_kron_multi_table_bytes(int n_jobs) { return n_jobs > 0 ? (int64_t)n_jobs * (int64_t)sizeof(Kron64JobDev) : 0; }
+
+int fq_kron_multi_prepare(const FqKronJob* jobs, int n_jobs, void* table, int64_t table_bytes, void* stream) {
+    const char* what = "fq_kron_multi_prepare";
+    if (!jobs || n_jobs < 1 || n_jobs > 65536) return fail(FQ_EINVAL, "%s: jobs is NULL or n_jobs=%d out of [1, 65536]", what, n_jobs);
+    if (!table || table_bytes < fq_kron_multi_table_bytes(n_jobs))
+        return fail(FQ_EINVAL, "%s: table of %lld bytes required", what, (long long)fq_kron_multi_table_bytes(n_jobs));
+    FQ_NEED_ALIGN16(what, table);
+    const int bpj = multi_wg_per_job(n_jobs);
+    Kron64JobDev* host = static_cast<Kron64JobDev*>(malloc((size_t)n_jobs * sizeof(Kron64JobDev)));
+    if (!host) return fail(FQ_EINVAL, "%s: out of host memory", what);
+    for (int j = 0; j < n_jobs; ++j) {
+        const FqKronJob& jb = jobs[j];
+        if (jb.rows < 0 || (jb.rows > 0 && (!jb.x || !jb.workspace || !jb.q || !jb.scale))) {
+            free(host);
+            return fail(FQ_EINVAL, "%s: job %d has a NULL pointer or rows < 0", what, j);
+        }
+        if (((uintptr_t)jb.x | (uintptr_t)jb.workspace | (uintptr_t)jb.q) & 15) {
+            free(host);
+            return fail(FQ_EINVAL, "%s: job %d: x / workspace / q must be 16-byte aligned", what, j);
+        }
+        host[j] = Kron64JobDev{jb.x, jb.workspace, jb.q, jb.scale, jb.rows, (jb.rows + bpj - 1) / bpj};
+    }
+    // a set-up call (once per model): the copy is waited for here, so `host` and the caller's array can go at once
+    hipError_t e = hipMemcpyAsync(table, host, (size_t)n_jobs * sizeof(Kron64JobDev), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    free(host);
+    if (e != hipSuccess) return check_launch((int)e, what);
+    return bpj;
+}
+
+static int kron_multi_impl(const char* what, int bf16_dtype, const void* table, int n_jobs, int wg_per_job, float sig_max, float sig_min,
+                           int flags, void* stream) {
+    if (!table || n_jobs < 1 || n_jobs > 65536 || wg_per_job < 1) return fail(FQ_EINVAL, "%s: table is NULL, n_jobs=%d or wg_per_job=%d", what, n_jobs, wg_per_job);
+    if ((flags & ~(FQ_OUT_PACKED | FQ_NO_CLAMP0 | FQ_WS_PREPARED)) || !(flags & FQ_OUT_PACKED))
+        return fail(FQ_EUNSUPPORTED, "%s: flags 0x%x (FQ_OUT_PACKED, optionally FQ_NO_CLAMP0)", what, flags);
+    if (!(sig_max > 0.0f) || !(sig_min > 0.0f)) return fail(FQ_EINVAL, "%s: sig_max/sig_min must be > 0", what);
+    if ((int64_t)n_jobs * wg_per_job > 0x7fffffff) return fail(FQ_EINVAL, "%s: grid too large", what);
+    (void)cu_count();   // (drops a stale error of this thread)
+    FqQuantOut o;
+    memset(&o, 0, sizeof(o));
+    o.n_clips = 1;
+    o.sig_max[0] = sig_max;
+    o.sig_min[0] = sig_min;
+    o.rt_flags = flags & FQ_NO_CLAMP0;
+    return check_launch(fq_launch_kron64_multi(bf16_dtype, table, n_jobs, wg_per_job, o, (hipStream_t)stream), what);
+}
+int fq_kron_quant_multi_f16(const void* table, int n_jobs, int wg_per_job, float sig_max, float sig_min, int flags, void* stream) {
+    return kron_multi_impl("fq_kron_quant_multi_f16", 0, table, n_jobs, wg_per_job, sig_max, sig_min, flags, stream);
+}
+int fq_kron_quant_multi_bf16(const void* table, int n_jobs, int wg_per_job, float sig_max, float sig_min, int flags, void* stream) {
+    return kron_multi_impl("fq_kron_quant_multi_bf16", 1, table, n_jobs, wg_per_job, sig_max, sig_min, flags, stream);
 }
 
 static int block_quant_impl(const char* what, int dt, const void* x, const void* P, int64_t rows, int R, int C, int transpose_out,

@@ -35,6 +35,18 @@ namespace {
 constexpr int KM = 64, KN = 64, KD = KM * KN;
 constexpr int FQ_K64_G128 = 0x10000;     // internal template bits (not ABI flags): the FQ_GROUP128 instantiation,
 constexpr int FQ_K64_GROUPED = 0x20000;  // the grouped-launch instantiations (fq_kron_quant_grouped_f16)
+constexpr int FQ_K64_MULTI = 0x40000;    // (round 4) the multi-job instantiation (fq_kron_quant_multi_f16): ONE launch over several
+                                         // independent (activations, factor pair, outputs) jobs — a layer each, a rank's shard each
+// One job of a multi-job launch, device memory, filled by the launcher (fq_capi.hip). Every job runs on `bpj` consecutive
+// workgroups; tpb = tokens per workgroup of THIS job (ceil(rows / bpj)).
+struct FqKron64Job {
+    const void* x;       // [rows, 4096]
+    const void* prep;    // the job's 16 KB fragment image (fq_kron_prepare_f16)
+    void* q;             // [rows, 2048]
+    void* scale;         // [rows]
+    int64_t rows;
+    int64_t tpb;
+};
 constexpr int FRAG_BYTES = 16 * 64 * 16;  // 16 fragments x 64 lanes x 16 B
 constexpr int TOK_BYTES = KD * 2;         // 8192
 
@@ -176,13 +188,33 @@ __device__ __forceinline__ unsigned quant_pack_token(const f32x16 (&Y)[2][2], co
     }
 
 template <int FLAGS, bool TRACE = false, typename T = f16>
-__global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(const T* __restrict__ x,
+__global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(const T* __restrict__ x_,
                                                            const T* __restrict__ left,
                                                            const T* __restrict__ right,
                                                            const T* __restrict__ diag,
-                                                           int64_t rows, int64_t tpb, const uint4* __restrict__ prep,
-                                                           FqQuantOut out, unsigned long long* __restrict__ trace) {
+                                                           int64_t rows_, int64_t tpb_, const uint4* __restrict__ prep_,
+                                                           FqQuantOut out_, unsigned long long* __restrict__ trace,
+                                                           const FqKron64Job* __restrict__ jobs, int bpj) {
     typedef typename FqVec<T>::x8 X8;  // eight activation / matrix elements = one 16-byte MFMA operand
+    // (round 4) FQ_K64_MULTI: the workgroup finds its job — scalar loads of six qwords — and runs it exactly as a launch of its own
+    // would, on the job's `bpj` workgroups; everything below sees the job's pointers, row count and a job-relative workgroup index.
+    constexpr bool MULTI = (FLAGS & FQ_K64_MULTI) != 0;
+    const T* x = x_;
+    const uint4* prep = prep_;
+    int64_t rows = rows_, tpb = tpb_;
+    FqQuantOut out = out_;
+    unsigned wg = blockIdx.x;
+    if constexpr (MULTI) {
+        const unsigned job = blockIdx.x / (unsigned)bpj;
+        wg = blockIdx.x - job * (unsigned)bpj;
+        const FqKron64Job jb = jobs[job];
+        x = static_cast<const T*>(jb.x);
+        prep = static_cast<const uint4*>(jb.prep);
+        out.q[0] = static_cast<uint8_t*>(jb.q);
+        out.scale[0] = static_cast<f16*>(jb.scale);
+        rows = jb.rows;
+        tpb = jb.tpb;
+    }
     constexpr int THREADS = kron64_threads<FLAGS>();
     constexpr int WAVES = THREADS / 64;
     constexpr bool G128 = (FLAGS & FQ_K64_G128) != 0;
@@ -215,7 +247,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     const int h = lane >> 5;
     const int c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t wave_id = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t wave_id = (int64_t)blockIdx.x * WAVES + wave;   // (trace builds only)
     const int64_t n_waves = (int64_t)gridDim.x * WAVES;
     unsigned char* tokbuf = smem + FRAG_BYTES + wave * TOK_BYTES;  // wave-private, wave-uniform address
     const unsigned tok_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)tokbuf);
@@ -225,7 +257,7 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     // below starts without a kernarg round trip); its waves PULL tokens from a counter in LDS. (A static
     // tok += n_waves split ties the kernel's duration to the slowest wave: the SIMD arbiter favours older waves,
     // measured 2.8x spread in per-wave loop time.) The first WAVES tokens are handed out statically.
-    const int64_t blk_base = (int64_t)blockIdx.x * tpb;
+    const int64_t blk_base = (int64_t)wg * tpb;
     const int blk_cnt = (int)(rows - blk_base < tpb ? (rows - blk_base < 0 ? 0 : rows - blk_base) : tpb);
     if (tid == 0) *next_slot = WAVES;
     int slot = wave;
@@ -718,8 +750,25 @@ static int launch_kron64(const T* x, const T* left, const T* right, const T* dia
     if (blocks < 1) blocks = 1;
     const int64_t tpb = (rows + blocks - 1) / blocks;
     hipLaunchKernelGGL((fq_kron64_kernel<FLAGS, false, T>), dim3((unsigned)blocks), dim3(THREADS), 0, stream, x, left,
-                       right, diag, rows, tpb, reinterpret_cast<const uint4*>(prep), out, (unsigned long long*)nullptr);
+                       right, diag, rows, tpb, reinterpret_cast<const uint4*>(prep), out, (unsigned long long*)nullptr,
+                       (const FqKron64Job*)nullptr, 0);
     return (int)hipGetLastError();
+}
+
+// The multi-job launch (fq_kron_quant_multi_{f16,bf16}): packed output, one clip pair for all jobs, prepared images. `jobs` is
+// DEVICE memory, [n_jobs], already filled (x, prep, q, scale, rows, tpb = ceil(rows / bpj)).
+template <typename T>
+static int launch_kron64_multi(const FqKron64Job* jobs, int n_jobs, int bpj, const FqQuantOut& out, hipStream_t stream) {
+    constexpr int FL = FQ_OUT_PACKED | FQ_K64_MULTI;
+    constexpr int THREADS = kron64_threads<FL>();
+    hipLaunchKernelGGL((fq_kron64_kernel<FL, false, T>), dim3((unsigned)(n_jobs * bpj)), dim3(THREADS), 0, stream, (const T*)nullptr,
+                       (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, (int64_t)0, (int64_t)0, (const uint4*)jobs /* != nullptr: prepared */,
+                       out, (unsigned long long*)nullptr, jobs, bpj);
+    return (int)hipGetLastError();
+}
+int fq_launch_kron64_multi(int bf16_dtype, const void* jobs, int n_jobs, int bpj, const FqQuantOut& out, hipStream_t stream) {
+    return bf16_dtype ? launch_kron64_multi<bf16>((const FqKron64Job*)jobs, n_jobs, bpj, out, stream)
+                      : launch_kron64_multi<f16>((const FqKron64Job*)jobs, n_jobs, bpj, out, stream);
 }
 
 template <typename T>
@@ -805,6 +854,6 @@ int fq_launch_kron64_trace(const f16* x, const f16* left, const f16* right, int6
     if (blocks > n_cu) blocks = n_cu;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((fq_kron64_kernel<FQ_OUT_PACKED, true, f16>), dim3((unsigned)blocks), dim3(1024), 0, stream, x, left,
-                       right, (const f16*)nullptr, rows, (rows + blocks - 1) / blocks, (const uint4*)nullptr, out, trace);
+                       right, (const f16*)nullptr, rows, (rows + blocks - 1) / blocks, (const uint4*)nullptr, out, trace, (const FqKron64Job*)nullptr, 0);
     return (int)hipGetLastError();
 }

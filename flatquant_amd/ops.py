@@ -307,6 +307,55 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
     return o
 
 
+class KronMultiPlan:
+    """A prepared multi-job launch (fq_kron_quant_multi_{f16,bf16}): several independent 64 x 64 transform + quantisation jobs — a
+    layer each — as ONE kernel launch. Build once (the device job table, the fragment images and the outputs are kept), call
+    ``run()`` per step. ``xs[j]`` [rows_j, 4096] (fixed buffers: the table holds their addresses), ``lefts[j]`` / ``rights[j]``
+    [64, 64]; one clip pair and one flag set (FQ_OUT_PACKED, optionally FQ_NO_CLAMP0) for all jobs. Bit for bit the results of
+    ``kron_quant(xs[j], lefts[j], rights[j], [sig], flags)`` for every j."""
+
+    def __init__(self, xs: Sequence[torch.Tensor], lefts: Sequence[torch.Tensor], rights: Sequence[torch.Tensor], sig: Sig = (1.0, 1.0),
+                 flags: int = FQ_OUT_PACKED | FQ_NO_CLAMP0):
+        if not (len(xs) == len(lefts) == len(rights)) or len(xs) == 0:
+            raise ValueError("KronMultiPlan: xs, lefts, rights must be non-empty and of one length")
+        self.dtype = _chk_act(xs[0])
+        dev = xs[0].device
+        for x, l, r in zip(xs, lefts, rights):
+            _chk(x, "x", self.dtype), _chk(l, "left", self.dtype), _chk(r, "right", self.dtype)
+            if x.shape[-1] != 4096 or l.shape != (64, 64) or r.shape != (64, 64) or x.device != dev:
+                raise ValueError("KronMultiPlan: 64 x 64 factor pairs on d = 4096 activations of one device")
+        self.sig, self.flags, self.n = sig, flags, len(xs)
+        self.xs = list(xs)
+        wsb = int(lib.fq_kron_workspace_bytes(64, 64))
+        prep = _fn("kron_prepare", self.dtype)
+        self.ws, self.q, self.scale = [], [], []
+        jobs = (_lib.FqKronJob * self.n)()
+        with _on(dev):
+            st = _stream(xs[0])
+            for j, (x, l, r) in enumerate(zip(xs, lefts, rights)):
+                rows = x.numel() // 4096
+                w = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                check(prep(_ptr(l), _ptr(r), 64, 64, _ptr(w), wsb, st))
+                q = torch.empty(x.shape[:-1] + (2048,), dtype=torch.uint8, device=dev)
+                s = torch.empty((rows,), dtype=self.dtype, device=dev)
+                self.ws.append(w), self.q.append(q), self.scale.append(s)
+                jobs[j] = _lib.FqKronJob(x.data_ptr(), w.data_ptr(), q.data_ptr(), s.data_ptr(), rows)
+            tb = int(lib.fq_kron_multi_table_bytes(self.n))
+            self.table = torch.empty(tb, dtype=torch.uint8, device=dev)
+            rc = lib.fq_kron_multi_prepare(ctypes.cast(jobs, ctypes.c_void_p), self.n, _ptr(self.table), tb, st)
+            if rc <= 0:
+                check(rc if rc < 0 else _lib.FQ_EINVAL)
+            self.wg_per_job = rc
+        self._fn = _fn("kron_quant_multi", self.dtype)
+
+    def run(self):
+        """-> (q list, scale list): the kept output tensors, rewritten by this launch"""
+        with _on(self.table.device):
+            check(self._fn(_ptr(self.table), self.n, self.wg_per_job, ctypes.c_float(self.sig[0]), ctypes.c_float(self.sig[1]),
+                           self.flags, _stream(self.table)))
+        return self.q, self.scale
+
+
 def kron_quant_ex(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, post_scale: float = 1.0,
                   sigs: Sequence[Sig] = ((1.0, 1.0),), flags: int = FQ_OUT_PACKED, up: Optional[torch.Tensor] = None) -> FusedOutputs:
     """fq_kron_quant_ex_f16: fq_kron_quant_f16 whose transformed activation is multiplied by ``post_scale`` (fp32) before

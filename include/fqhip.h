@@ -263,6 +263,33 @@ int fq_kron_prepare_bf16(const void* left, const void* right, int M, int N, void
                          void* stream);
 
 /*
+ * Multi-job launch (round 4): SEVERAL independent 64 x 64 transform + quantisation jobs — one per layer of a model, or one per
+ * shard — as ONE kernel launch. What a caller that shards the rows over GPUs is left with per layer is a short launch (2048
+ * tokens = 5 us of kernel behind a launch that costs as much); the jobs of a step are independent (flat_linear.py:75-80 and
+ * deploy/nn/online_trans.py:61-99 hold no state between layers' inputs), so their launches fold into one. Every job has its own
+ * activations, factor pair (as the prepared image fq_kron_prepare_f16 writes: `workspace`, >= fq_kron_workspace_bytes(64, 64)),
+ * outputs and row count; all jobs share the clip pair and the flags (FQ_OUT_PACKED, optionally FQ_NO_CLAMP0). Results are bit
+ * for bit those of n_jobs calls of fq_kron_quant_f16(..., FQ_OUT_PACKED | FQ_WS_PREPARED | flags).
+ *   fq_kron_multi_table_bytes(n_jobs)   bytes of the DEVICE job table (16-byte aligned)
+ *   fq_kron_multi_prepare(jobs, n_jobs, table, table_bytes, stream)   writes the table from the HOST array `jobs` (a copy on
+ *       `stream`, waited for: a set-up call; `jobs` may be released on return); returns the number of workgroups per job (> 0)
+ *       or a negative error code
+ *   fq_kron_quant_multi_{f16,bf16}(table, n_jobs, wg_per_job, sig_max, sig_min, flags, stream)   the launch
+ * The table is valid for as long as the jobs' pointers and row counts are (a deployed model's layers: prepare once).
+ */
+typedef struct FqKronJob {
+    const void* x;          /* [rows, 4096] activations */
+    const void* workspace;  /* prepared image of this job's (left, right): fq_kron_prepare_f16 */
+    void* q;                /* [rows, 2048] packed INT4 */
+    void* scale;            /* [rows] */
+    int64_t rows;
+} FqKronJob;
+int64_t fq_kron_multi_table_bytes(int n_jobs);
+int fq_kron_multi_prepare(const FqKronJob* jobs, int n_jobs, void* table, int64_t table_bytes, void* stream);
+int fq_kron_quant_multi_f16(const void* table, int n_jobs, int wg_per_job, float sig_max, float sig_min, int flags, void* stream);
+int fq_kron_quant_multi_bf16(const void* table, int n_jobs, int wg_per_job, float sig_max, float sig_min, int flags, void* stream);
+
+/*
  * Single-matrix transform over the LAST axis of [rows, R, C] blocks (o_proj head transform):
  *   Y[t] = x[t] ([R,C] row-major) . P ([C,C]);  quantised per token over all R*C values.
  * Packed output follows block_matmul.py:86-101: the quantised block is TRANSPOSED before packing when

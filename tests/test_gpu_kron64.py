@@ -276,3 +276,45 @@ def test_prepared_fragment_image_equals_the_in_kernel_gather(dtype):
     o3 = ops.kron_quant(x, L, R, [(0.93, 0.9)], P)
     o4 = ops.kron_quant(x, L.clone(), R.clone(), [(0.93, 0.9)], P)
     assert torch.equal(o3.q[0], o4.q[0]) and not torch.equal(o3.q[0], o1.q[0])
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_multi_job_launch_equals_the_launches_it_replaces(dtype):
+    """Round 4: fq_kron_quant_multi_{f16,bf16} — several independent jobs (own activations, own factor pair, own outputs, own row
+    count: a layer each) in ONE launch — returns, job for job, the bytes of fq_kron_quant (flat_linear.py:75-80 /
+    deploy/nn/online_trans.py:61-99 once per layer). Row counts from empty to several tokens per workgroup; more jobs than CUs."""
+    from flatquant_amd import ops
+    from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    gen = torch.Generator().manual_seed(21)
+    for rows_list, flags, sig in [([2048, 1, 0, 5, 300, 2048, 77, 1031], FQ_OUT_PACKED | FQ_NO_CLAMP0, (0.9820137619972229, 0.9820137619972229)),
+                                  ([17] * 300, FQ_OUT_PACKED, (0.7, 0.55))]:
+        xs, ls, rs = [], [], []
+        for j, r in enumerate(rows_list):
+            x = torch.randn(r, 4096, generator=gen).to(td)
+            if r > 3:
+                x[3] = 0
+                x[:, ::97] *= 15
+            xs.append(x.cuda())
+            ls.append((torch.randn(64, 64, generator=gen) / 8).to(td).cuda())
+            rs.append((torch.randn(64, 64, generator=gen) / 8).to(td).cuda())
+        plan = ops.KronMultiPlan(xs, ls, rs, sig, flags)
+        for rep in range(2):    # (the plan is reusable: same table, same outputs)
+            q, s = plan.run()
+            for j, r in enumerate(rows_list):
+                one = ops.kron_quant(xs[j], ls[j], rs[j], [sig], flags)
+                assert torch.equal(q[j], one.q[0]), (dtype, j, r)
+                assert torch.equal(s[j].view(torch.int16), one.scale[0].view(torch.int16)), (dtype, j, r)
+
+
+def test_multi_job_argument_errors():
+    import ctypes
+    from flatquant_amd import _lib
+    lib = _lib.lib
+    t = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.fq_kron_quant_multi_f16(t.data_ptr(), 2, 4, ctypes.c_float(1.0), ctypes.c_float(1.0), _lib.FQ_OUT_FAKEQUANT, st) == _lib.FQ_EUNSUPPORTED
+    assert lib.fq_kron_quant_multi_f16(t.data_ptr(), 0, 4, ctypes.c_float(1.0), ctypes.c_float(1.0), _lib.FQ_OUT_PACKED, st) == _lib.FQ_EINVAL
+    jobs = (_lib.FqKronJob * 1)(_lib.FqKronJob(0, 0, 0, 0, 8))
+    assert lib.fq_kron_multi_prepare(ctypes.cast(jobs, ctypes.c_void_p), 1, t.data_ptr(), 4096, st) == _lib.FQ_EINVAL   # NULL pointers, rows > 0
+    assert lib.fq_kron_multi_prepare(ctypes.cast(jobs, ctypes.c_void_p), 1, t.data_ptr(), 8, st) == _lib.FQ_EINVAL      # table too small

@@ -55,6 +55,11 @@ def test_abi_argument_validation_without_gpu():
     assert lib.fq_rowquant_f16(vp, 4, 4100, f4, f4, 1, 1, a4, a4, a4, None) == FQ_EUNSUPPORTED
     assert lib.fq_hadamard_f16(vp, vp, 4, 96, 5, vp, ctypes.c_float(1.0), None) == FQ_EINVAL      # 96 % 5 != 0
     assert lib.fq_hadamard_f16(vp, vp, 4, 96, 1, None, ctypes.c_float(1.0), None) == FQ_EINVAL    # 96 not 2^p
+    assert lib.fq_kron_multi_table_bytes(3) == 3 * 48 and lib.fq_kron_multi_table_bytes(0) == 0
+    assert lib.fq_kron_quant_multi_f16(None, 2, 4, ctypes.c_float(1.0), ctypes.c_float(1.0), 1, None) == FQ_EINVAL      # no table
+    assert lib.fq_kron_multi_prepare(None, 2, vp, 4096, None) == FQ_EINVAL                                              # no jobs
+    assert lib.fq_hadamard_quant_mfma_f16(vp, 4, 14336, 28, vp, ctypes.c_float(1.0), ctypes.c_float(1.0), ctypes.c_float(1.0), None, None,
+                                          None, None) == FQ_EINVAL                                                       # no output
     assert lib.fq_kron_workspace_bytes(64, 64) == 32768                   # optional at 64 x 64 (NULL still works)
     assert lib.fq_kron_workspace_bytes(128, 224) == (7 * 14 + 2 * 4 * 4) * 1024
     assert lib.fq_kron_workspace_bytes(60, 63) == FQ_EUNSUPPORTED          # odd N: nothing to pack two per byte
@@ -263,6 +268,62 @@ def test_broadcast_and_row_sharding_world_size_2_gloo(tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs), outs
+
+
+_BENCH_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import bench
+from flatquant_amd import sharding
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["MASTER_PORT"], rank=rank, world_size=world)
+# (1) the broadcast of a sub-record's matrices, timed, on CPU tensors: every rank ends with rank 0's values
+g = torch.Generator().manual_seed(3 + rank)
+mats = {f"l{j:02d}": torch.randn(64, 64, generator=g).half() for j in range(4)}
+bc = bench.TimedBroadcast(sharding, "cpu")
+out = bc(mats)
+g0 = torch.Generator().manual_seed(3)
+ref = {f"l{j:02d}": torch.randn(64, 64, generator=g0).half() for j in range(4)}
+assert all(torch.equal(out[k], ref[k]) for k in ref), rank
+assert bc.ms > 0.0 and bc.bytes == 4 * 64 * 64 * 2
+# (2) the strong-scaling partitions of the sub-records (C2S x layers / C4: rows; C5: experts + rows): every unit exactly once
+a, b = sharding.shard_rows(bench.ROWS, world, rank)
+spans = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+dist.all_gather(spans, torch.tensor([a, b]))
+assert int(spans[0][0]) == 0 and int(spans[-1][1]) == bench.ROWS and all(int(spans[i][1]) == int(spans[i + 1][0]) for i in range(world - 1))
+pl = bench.C5.plan(world, rank, sharding)
+mine = torch.tensor([pl["e0"], pl["e1"], int(pl["offs"][-1]), pl["t0"], pl["t1"]])
+parts = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(parts, mine)
+assert int(parts[0][0]) == 0 and int(parts[-1][1]) == pl["E"] and all(int(parts[i][1]) == int(parts[i + 1][0]) for i in range(world - 1))
+assert sum(int(p[2]) for p in parts) == pl["T"] * pl["K"] == int(pl["counts"].sum())      # every routed row on exactly one rank
+assert int(pl["offs"][-1]) == int(pl["counts"][pl["e0"]:pl["e1"]].sum()) and len(pl["offs"]) == pl["e1"] - pl["e0"] + 1
+assert int(parts[0][3]) == 0 and int(parts[-1][4]) == pl["T"]
+# (3) the reduction of the timed region: MAX of the clocks, SUM of the units, every rank's own clock
+wall, kern, elems, per_rank = bench.reduce_over_ranks(dist, "cpu", 1.0 + rank, 10.0 * (rank + 1), 1000 * (rank + 1))
+assert wall == float(world) and kern == 10.0 * world and elems == 1000 * world * (world + 1) / 2
+assert per_rank == [1.0 + r for r in range(world)]
+w1 = bench.reduce_over_ranks(None, "cpu", 2.0, 3.0, 7)
+assert w1 == (2.0, 3.0, 7.0, [2.0])
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_bench_scaling_records_partition_broadcast_reduce_world_size_2_gloo(tmp_path):
+    """bench.py's own multi-rank logic — the timed broadcast, the strong-scaling partitions of the `strong` / `c4` / C5 records
+    and the MAX / SUM / per-rank reduction of the timed region — on CPU tensors over gloo (the kernels need a GPU, this does not)."""
+    script = tmp_path / "bench_worker.py"
+    script.write_text(_BENCH_WORKER)
+    port = str(31500 + os.getpid() % 2000)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs), outs
 
