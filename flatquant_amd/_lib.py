@@ -59,6 +59,8 @@ SYMBOLS = {
     "fq_kron_quant_grouped_f16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "fq_kron_quant_ex_f16": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _f, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp, _i64, _vp]),
     "fq_kron_workspace_bytes": (_i64, [_i, _i]),
+    "fq_single_trans_f16": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    "fq_single_trans_bf16": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     "fq_kron_multi_table_bytes": (_i64, [_i]),
     "fq_kron_multi_prepare": (_i, [_vp, _i, _vp, _i64, _vp]),
     "fq_kron_quant_multi_f16": (_i, [_vp, _i, _i, _f, _f, _i, _vp]),
@@ -94,6 +96,7 @@ SYMBOLS = {
     "fq_int4_gemm_i32": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "fq_int4_linear_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
     "fq_hadamard_f16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _f, _vp]),
+    "fq_fwht_f32_f16": (_i, [_vp, _vp, _i64, _i, _f, _vp]),
     "fq_hadamard_quant_f16": (_i, [_vp, _i64, _i, _i, _vp, _f, _f, _f, _vp, _vp, _vp]),
     "fq_hadamard_quant_mfma_f16": (_i, [_vp, _i64, _i, _i, _vp, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "fq_rowquant_f16": (_i, [_vp, _i64, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp]),

@@ -18,6 +18,8 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream);
 int fq_launch_kron64_multi(int bf16_dtype, const void* jobs, int n_jobs, int bpj, const FqQuantOut& out, hipStream_t stream);
+int fq_launch_rowmm(int bf16_dtype, const void* x, const void* Tm, void* y, int64_t rows, int n, int n_cu, hipStream_t stream);
+int fq_launch_fwht_f32(const f16* x, float* y32, int64_t vecs, int P, float scale, int n_cu, hipStream_t stream);
 int fq_launch_had_mfma(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max, float sig_min,
                        uint8_t* q_out, f16* scale_out, f16* y_out, int n_cu, hipStream_t stream);
 int fq_launch_hadamard_quant(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max,
@@ -638,7 +640,7 @@ int fq_int4_gemm_i32(const void* x, const void* w, int64_t M, int N, int K, void
 int fq_int4_linear_f16(const void* x, const void* x_scale, const void* w, const void* w_scale, const void* bias,
                        int64_t M, int N, int K, void* y, void* stream) {
     if (!x || !w || !y || !x_scale || !w_scale) return fail(FQ_EINVAL, "fq_int4_linear_f16: NULL pointer");
-    FQ_NEED_ALIGN16("fq_int4_linear_f16", x, w, y);
+    FQ_NEED_ALIGN16("fq_int4_linear_f16", x, w, y, w_scale, bias);   // (the epilogue reads w_scale / bias with 16-byte loads)
     if (M < 0 || N <= 0 || K <= 0) return fail(FQ_EINVAL, "fq_int4_linear_f16: bad sizes");
     if (K % 32) return fail(FQ_EINVAL, "fq_int4_linear_f16: K=%d must be a multiple of 32", K);
     if (M == 0) return FQ_OK;
@@ -716,7 +718,7 @@ int fq_int4_linear_fp6_f16(const void* x, const void* x_scale, const void* w, co
     if (!x || !y || !x_scale || !w_scale || !scratch || (!w && !wblob)) return fail(FQ_EINVAL, "%s: NULL pointer", what);
     if ((K & 127) || (N & 15) || K > (1 << 18))
         return fail(FQ_EUNSUPPORTED, "%s: shape M=%lld N=%d K=%d not covered (K %% 128, N %% 16)", what, (long long)M, N, K);
-    FQ_NEED_ALIGN16(what, x, w, wblob, y, scratch);
+    FQ_NEED_ALIGN16(what, x, w, wblob, y, scratch, w_scale, bias);
     const int64_t xb = fq_bf6_blob_bytes(M, K), wb = wblob ? 0 : fq_bf6_blob_bytes(N, K);
     if (scratch_bytes < xb + wb)
         return fail(FQ_EINVAL, "%s: scratch of %lld bytes required (got %lld)", what, (long long)(xb + wb), (long long)scratch_bytes);
@@ -732,6 +734,15 @@ int fq_int4_linear_fp6_f16(const void* x, const void* x_scale, const void* w, co
     rc = fq_launch_gemm_bf6(xs, wsrc, M, N, K, nullptr, (f16*)y, (const f16*)x_scale, (const f16*)w_scale, (const f16*)bias,
                             (hipStream_t)stream);
     return check_launch(rc, what);
+}
+
+int fq_fwht_f32_f16(const void* x, void* y, int64_t vecs, int P, float scale, void* stream) {
+    const char* what = "fq_fwht_f32_f16";
+    if (vecs < 0 || P < 64 || P > 8192 || (P & (P - 1))) return fail(FQ_EUNSUPPORTED, "%s: P=%d (a power of two in [64, 8192])", what, P);
+    if (vecs == 0) return FQ_OK;
+    if (!x || !y) return fail(FQ_EINVAL, "%s: x/y is NULL", what);
+    FQ_NEED_ALIGN16(what, x, y);
+    return check_launch(fq_launch_fwht_f32((const f16*)x, (float*)y, vecs, P, scale, cu_count(), (hipStream_t)stream), what);
 }
 
 int fq_hadamard_quant_f16(const void* x, int64_t rows, int n, int K, const void* hadK, float scale, float sig_max,
@@ -777,6 +788,21 @@ int fq_kv_quant_f16(const void* x, const void* trans, int64_t rows, int head_dim
                                       (flags & FQ_KV_LAC) != 0, (uint8_t*)q_out, (f16*)param_out, (f16*)y_out, cu_count(),
                                       (hipStream_t)stream);
     return check_launch(rc, "fq_kv_quant_f16");
+}
+
+static int single_trans_impl(const char* what, int bf16_dtype, const void* x, const void* matrix, int64_t rows, int n, void* y, void* stream) {
+    if (rows < 0 || n <= 0) return fail(FQ_EINVAL, "%s: bad sizes rows=%lld n=%d", what, (long long)rows, n);
+    if (n != 64 && n != 128) return fail(FQ_EUNSUPPORTED, "%s: n=%d (64 or 128; smaller even n: fq_block_quant with FQ_OUT_TRANSFORM)", what, n);
+    if (rows == 0) return FQ_OK;
+    if (!x || !matrix || !y) return fail(FQ_EINVAL, "%s: NULL pointer", what);
+    FQ_NEED_ALIGN16(what, x, matrix, y);
+    return check_launch(fq_launch_rowmm(bf16_dtype, x, matrix, y, rows, n, cu_count(), (hipStream_t)stream), what);
+}
+int fq_single_trans_f16(const void* x, const void* matrix, int64_t rows, int n, void* y, void* stream) {
+    return single_trans_impl("fq_single_trans_f16", 0, x, matrix, rows, n, y, stream);
+}
+int fq_single_trans_bf16(const void* x, const void* matrix, int64_t rows, int n, void* y, void* stream) {
+    return single_trans_impl("fq_single_trans_bf16", 1, x, matrix, rows, n, y, stream);
 }
 
 int fq_kv_dequant_f16(const void* q, const void* param, int64_t rows, int head_dim, int flags, void* y, void* stream) {

@@ -159,6 +159,8 @@ struct HadQuant {
     uint8_t* q;   // [rows, n/2]
     f16* scale;   // [rows]
     const f16* up;  // SILU kernels: x is `gate`, the transform's input is fp16(up * fp16(silu(gate))) (fq_silu_mul8)
+    float* y32;     // (round 4) != nullptr: the scaled fp32 butterflies are stored as they are — no rounding to fp16 — instead of y
+                    // (fast_hadamard_transform on an up-cast input: deploy/nn/online_trans.py:55-59, force_fp32=True)
 };
 // 8 fp16 results -> one dword of nibbles: packed pairs, exact fp16 quotient without a division (fq_quant8_h16, fq_common.hpp)
 __device__ __forceinline__ uint32_t quant8_h(f16x8 v, FqH16Recip rc, bool clamp) {
@@ -198,6 +200,14 @@ __global__ __launch_bounds__(256) void fq_had_pow2_kernel(const f16* __restrict_
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[0][e] = (float)hv[e];
             fwht_wave<1, XS>(v, k);
+            if (!QUANT && hq.y32 != nullptr) {
+                if (ok) {
+                    f32x4* dst = reinterpret_cast<f32x4*>(hq.y32 + g * 512 + lane * 8);
+                    dst[0] = f32x4{v[0][0] * scale, v[0][1] * scale, v[0][2] * scale, v[0][3] * scale};
+                    dst[1] = f32x4{v[0][4] * scale, v[0][5] * scale, v[0][6] * scale, v[0][7] * scale};
+                }
+                continue;
+            }
             f16x8 o[1];
             to_f16<1>(v, scale, o);
             if (ok) *reinterpret_cast<uint4*>(y + g * 512 + lane * 8) = __builtin_bit_cast(uint4, o[0]);
@@ -208,6 +218,15 @@ __global__ __launch_bounds__(256) void fq_had_pow2_kernel(const f16* __restrict_
         float v[CH][8];
         load_vec<CH, SILU>(x + row * n, SILU ? hq.up + row * n : nullptr, lane, v);
         fwht_wave<CH>(v, k);
+        if (!QUANT && !SILU && hq.y32 != nullptr) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                f32x4* dst = reinterpret_cast<f32x4*>(hq.y32 + row * n + j * 512 + lane * 8);
+                dst[0] = f32x4{v[j][0] * scale, v[j][1] * scale, v[j][2] * scale, v[j][3] * scale};
+                dst[1] = f32x4{v[j][4] * scale, v[j][5] * scale, v[j][6] * scale, v[j][7] * scale};
+            }
+            continue;
+        }
         f16x8 o[CH];
         to_f16<CH>(v, scale, o);
         if (!QUANT) {
@@ -488,18 +507,24 @@ int dispatch_reg(const f16* x, f16* y, int64_t rows, int n, int K, const f16* ha
 // Returns -1000 for shapes this file does not cover (the caller falls back to fq_hadamard.hip).
 int fq_launch_hadamard_reg(const f16* x, f16* y, int64_t rows, int n, int K, const f16* hadK, float scale, int n_cu,
                            hipStream_t stream) {
-    return dispatch_reg<false>(x, y, rows, n, K, hadK, scale, HadQuant{1.0f, 1.0f, nullptr, nullptr, nullptr}, n_cu, stream);
+    return dispatch_reg<false>(x, y, rows, n, K, hadK, scale, HadQuant{1.0f, 1.0f, nullptr, nullptr, nullptr, nullptr}, n_cu, stream);
+}
+
+// The power-of-two transform alone with an fp32 result: y32 [vecs, P] = FWHT_P(x [vecs, P]) * scale, P in {64 .. 8192}.
+int fq_launch_fwht_f32(const f16* x, float* y32, int64_t vecs, int P, float scale, int n_cu, hipStream_t stream) {
+    if (y32 == nullptr) return -1000;
+    return dispatch_reg<false>(x, nullptr, vecs, P, 1, nullptr, scale, HadQuant{1.0f, 1.0f, nullptr, nullptr, nullptr, y32}, n_cu, stream);
 }
 
 // Hadamard + deploy.nn.Quantizer in one launch (no fp16 round trip through HBM). -1000: shape not covered.
 int fq_launch_hadamard_quant(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max,
                              float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream) {
-    return dispatch_reg<true>(x, nullptr, rows, n, K, hadK, scale, HadQuant{sig_max, sig_min, q, scale_out, nullptr}, n_cu, stream);
+    return dispatch_reg<true>(x, nullptr, rows, n, K, hadK, scale, HadQuant{sig_max, sig_min, q, scale_out, nullptr, nullptr}, n_cu, stream);
 }
 
 // x_up * silu(x_gate) formed in registers in front of the same Hadamard + Quantizer launch.
 int fq_launch_silu_hadamard_quant(const f16* gate, const f16* up, int64_t rows, int n, int K, const f16* hadK, float scale,
                                   float sig_max, float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream) {
-    return dispatch_reg<true, true>(gate, nullptr, rows, n, K, hadK, scale, HadQuant{sig_max, sig_min, q, scale_out, up},
+    return dispatch_reg<true, true>(gate, nullptr, rows, n, K, hadK, scale, HadQuant{sig_max, sig_min, q, scale_out, up, nullptr},
                                     n_cu, stream);
 }

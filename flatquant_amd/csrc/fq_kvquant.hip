@@ -402,6 +402,86 @@ int fq_launch_kv_quant_append(const f16* k, const f16* v, const f16* T, int64_t 
     return -1000;
 }
 
+// ---- the single-matrix transform alone: y = x.reshape(-1, n) @ matrix in the activation's dtype (round 4) ----
+// {SVD,Inv}SingleTransMatrix.forward (flatquant/trans_utils.py:21-25, 136-151) at n = head_dim: the fake-quant eval path applies
+// kcache_trans(q, inv_t=True), kcache_trans(k) and vcache_trans(v) to [.., heads, head_dim] activations on every forward
+// (flatquant/model_tools/llama_utils.py:181-199) — rows = (token, head), n = 64 / 128, a torch.matmul on fp16 / bf16 in the reference.
+// Same scheme as fq_kv_quant_kernel's transform (the product formed transposed on the matrix pipe, A = fragments of matrix^T in LDS,
+// B = 32 rows straight from HBM, fp32 accumulation, one rounding to the dtype), without the quantiser; fp16 and bf16.
+template <int HD, typename T>
+__global__ __launch_bounds__(256) void fq_rowmm_kernel(const T* __restrict__ x, const T* __restrict__ Tm, T* __restrict__ y, int64_t rows) {
+    typedef typename FqVec<T>::x8 X8;
+    constexpr int KS = HD / 16, NTL = HD / 32;
+    __shared__ __attribute__((aligned(16))) uint4 tfrag[KS * NTL * 64];  // [(s * NTL + nt)][lane]
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    for (int item = tid; item < KS * NTL * 64; item += 256) {
+        const int f = item >> 6, ln = item & 63, fh = ln >> 5, fc = ln & 31;
+        const int s = f / NTL, nt = f - s * NTL;
+        const int n = nt * 32 + 16 * ((fc >> 2) & 1) + 4 * (fc >> 3) + (fc & 3);  // output column of A row fc
+        X8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = Tm[(s * 16 + fh * 8 + j) * HD + n];
+        tfrag[item] = __builtin_bit_cast(uint4, v);
+    }
+    __syncthreads();
+    const int64_t n_tiles = (rows + 31) / 32;
+    const int64_t tstep = (int64_t)gridDim.x * 4;
+    auto fetch = [&](int64_t t, X8 (&dst)[KS]) {
+        int64_t r = t * 32 + c;
+        r = r < rows ? r : rows - 1;
+        const uint4* xp = reinterpret_cast<const uint4*>(x + r * HD);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) dst[s] = __builtin_bit_cast(X8, xp[2 * s + h]);
+    };
+    X8 xn[KS];
+    {
+        const int64_t t0 = (int64_t)blockIdx.x * 4 + (tid >> 6);
+        if (t0 < n_tiles) fetch(t0, xn);
+    }
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + (tid >> 6); tile < n_tiles; tile += tstep) {
+        const int64_t row = tile * 32 + c;
+        X8 xf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xf[s] = xn[s];
+        if (tile + tstep < n_tiles) fetch(tile + tstep, xn);
+        int foff = lane;
+        asm volatile("" : "+v"(foff));
+        const uint4* tf = tfrag + foff;
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) {
+            f32x16 acc = {0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = fq_mfma32<T>(__builtin_bit_cast(X8, tf[(s * NTL + nt) * 64]), xf[s], acc);
+            X8 a, b;   // columns nt*32 + 16h + r of row c
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a[e] = (T)acc[e];
+                b[e] = (T)acc[8 + e];
+            }
+            if (row < rows) {
+                uint4* yp = reinterpret_cast<uint4*>(y + row * HD + nt * 32 + 16 * h);
+                yp[0] = __builtin_bit_cast(uint4, a);
+                yp[1] = __builtin_bit_cast(uint4, b);
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_rowmm(const T* x, const T* Tm, T* y, int64_t rows, int n, int n_cu, hipStream_t stream) {
+    int64_t blocks = (rows + 127) / 128;
+    if (blocks > (int64_t)n_cu * 8) blocks = (int64_t)n_cu * 8;
+    if (blocks < 1) blocks = 1;
+    if (n == 128) hipLaunchKernelGGL((fq_rowmm_kernel<128, T>), dim3((unsigned)blocks), dim3(256), 0, stream, x, Tm, y, rows);
+    else if (n == 64) hipLaunchKernelGGL((fq_rowmm_kernel<64, T>), dim3((unsigned)blocks), dim3(256), 0, stream, x, Tm, y, rows);
+    else return -1000;
+    return (int)hipGetLastError();
+}
+int fq_launch_rowmm(int bf16_dtype, const void* x, const void* Tm, void* y, int64_t rows, int n, int n_cu, hipStream_t stream) {
+    return bf16_dtype ? launch_rowmm<bf16>((const bf16*)x, (const bf16*)Tm, (bf16*)y, rows, n, n_cu, stream)
+                      : launch_rowmm<f16>((const f16*)x, (const f16*)Tm, (f16*)y, rows, n, n_cu, stream);
+}
+
 int fq_launch_kv_dequant(const uint8_t* q, const f16* param, int64_t rows, int hd, bool lac, f16* y, int n_cu,
                          hipStream_t stream) {
     if (hd & 7) return -1000;

@@ -1,6 +1,4 @@
 """Counterpart of deploy/nn/linear.py."""
-import os
-
 import torch
 
 from ... import ops
@@ -19,18 +17,23 @@ class Linear4bit(torch.nn.Module):
     Memory. ``weight`` is 0.5 byte per parameter. Two optional operand images trade memory for speed, each built once
     per buffer version and kept until ``release_images()``:
       * the decode image (M <= 128 weight-streaming kernel, 4-9 us per linear instead of 46-144): +0.5 B/param, built on
-        the first decode-sized call — ON by default (``Linear4bit.decode_image``; FQ_SKINNY_GEMM=0/1 overrides);
+        the first decode-sized call — ON by default (``Linear4bit.decode_image``, a class / instance attribute);
       * the FP6 image (BF6 operands on the FP6 matrix path for K % 128 == 0, N % 16 == 0: same bits out, the GEMM 1.6x
         faster than on the int8 path — 16384 x 4096 x 4096: 159 us against 285, profiles/r03_gemm_bf6_pipeline.txt):
-        +0.75 B/param — OFF by default (``Linear4bit.fp6_image = True`` or FQ_FP6_GEMM=1 keep it): with both images a
-        layer would sit at 1.75 B/param, 3.5x the INT4 footprint.
+        +0.75 B/param — OFF by default (``Linear4bit.fp6_image = True`` keeps it): with both images a layer would sit at
+        1.75 B/param, 3.5x the INT4 footprint.
     Without the kept image a call of >= ``fp6_transient_rows`` (129: above the decode kernel's range) tokens still takes the FP6 path: the weights
     are converted INTO A TRANSIENT image for the call (12.6 MB for 4096 x 4096: ~8 us, freed with the call — the caching
     allocator hands the same block to the next layer), which costs 463 / rows of the GEMM's own time and leaves the
-    resident footprint at 0.5 - 1.0 B/param. FQ_FP6_GEMM=0 turns every FP6 route off (int8 matrix path only)."""
+    resident footprint at 0.5 - 1.0 B/param. Both FP6 routes apply to layers of at least ``fp6_min_out_features`` outputs (2048:
+    25-30 % faster than the int8 path there, slower for the 1024-wide k/v projections, where a call would also re-convert the
+    whole weight); ``fp6_gemm = False`` turns every FP6 route off (int8 matrix path only). The routes are policy ATTRIBUTES of
+    the class (or of an instance) — no environment variable is read (round 4)."""
 
     decode_image = True   # class-wide policy switches (set on the class or on an instance)
+    fp6_gemm = True       # False: no FP6 route at all
     fp6_image = False
+    fp6_min_out_features = 2048   # narrower layers stay on the int8 matrix path (kept image AND transient route)
     fp6_transient_rows = 129    # calls with at least this many tokens convert the weights for the call when no image is kept (0: never).
                                 # 129 = everything above the decode kernel's range: measured with both conversions inside the call
                                 # (tools/scratch/gemm_small_m.py), 129 tokens x 4096 x 4096: 34.6 us against 45.6 on the int8 path,
@@ -51,12 +54,10 @@ class Linear4bit(torch.nn.Module):
     def _weight_image(self):
         """BF6 operand image of ``weight`` for the FP6 matrix path (csrc/fq_gemm_bf6.hip), rebuilt when the buffer is
         replaced or written in place. Used when the shape is covered and wide enough to amortise the per-call conversion
-        of the activations (out_features >= 2048: measured 25-30 % faster than the int8 path there, slower for the
-        1024-wide k/v projections); FQ_FP6_GEMM=0 turns it off, =1 forces it for every covered shape."""
-        mode = os.environ.get("FQ_FP6_GEMM", "")
-        if mode == "0" or (mode != "1" and not self.fp6_image) or not ops.bf6_supported(self.out_features, self.in_features):
+        of the activations (``fp6_min_out_features``)."""
+        if not (self.fp6_gemm and self.fp6_image) or not ops.bf6_supported(self.out_features, self.in_features):
             return None
-        if mode != "1" and self.out_features < 2048:
+        if self.out_features < self.fp6_min_out_features:
             return None
         key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
         if getattr(self, "_wimg_key", None) != key:
@@ -78,9 +79,8 @@ class Linear4bit(torch.nn.Module):
 
     def _decode_image(self):
         """``weight`` in MFMA fragment order for the decode-sized (M <= 128) weight-streaming kernel; cached like the
-        FP6 image. FQ_SKINNY_GEMM=0 turns the path off."""
-        mode = os.environ.get("FQ_SKINNY_GEMM", "")
-        if mode == "0" or (mode != "1" and not self.decode_image) or self.in_features % 64:
+        FP6 image. ``decode_image = False`` turns the path off."""
+        if not self.decode_image or self.in_features % 64:
             return None
         key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
         if getattr(self, "_dimg_key", None) != key:
@@ -111,9 +111,10 @@ class Linear4bit(torch.nn.Module):
                 y = ops.int4_skinny_linear(q.reshape(rows, -1).contiguous(), scales_x.reshape(-1).contiguous(), dimg,
                                            ws16, b16, self.out_features)
                 return y.view(*lead, self.out_features)
-        if q.is_cuda and os.environ.get("FQ_FP6_GEMM", "") != "0" and ops.bf6_supported(self.out_features, self.in_features):
+        if q.is_cuda and self.fp6_gemm and ops.bf6_supported(self.out_features, self.in_features):
             wimg = self._weight_image()                     # the kept image, or None: converted for this call (transient)
-            if wimg is not None or (self.fp6_transient_rows and rows >= self.fp6_transient_rows):
+            if wimg is not None or (self.fp6_transient_rows and rows >= self.fp6_transient_rows
+                                    and self.out_features >= self.fp6_min_out_features):
                 ws16, b16 = self._scales16()
                 y = ops.int4_linear_fp6(q.reshape(-1, q.shape[-1]).contiguous(), scales_x.reshape(-1).contiguous(), self.weight, wimg,
                                         ws16, b16)

@@ -65,9 +65,12 @@ class OnlineTrans(torch.nn.Module):
                 from ... import ops
                 x = ops.silu_mul(x.contiguous(), up.contiguous())
             if self.fp32_trans:
-                # the reference up-casts and returns fp32 (online_trans.py:56-59); the HIP kernel already
-                # runs its butterflies in fp32, so only the result is widened.
-                return functional.matmul_hadU_cuda(x.to(torch.float16), self.had_rem_dim, self.rem_dim).float()
+                # the reference up-casts and returns the fp32 transform (online_trans.py:55-59): the butterflies and the scaling in
+                # fp32 with NO rounding to fp16 (fq_fwht_f32_f16), the fp32 K x K factor as the reference's own GEMM (round 4)
+                from ... import ops
+                if x.dtype != torch.float16:
+                    raise TypeError("OnlineTrans(force_fp32=True): the HIP route takes fp16 activations (their up-cast is exact)")
+                return ops.hadamard_fp32(x.contiguous(), self.rem_dim, self.had_rem_dim)
             return functional.matmul_hadU_cuda(x, self.had_rem_dim, self.rem_dim)
         if self.trans == "matmul" and norm is not None:
             if not (self.decompose and hasattr(self, "left_matrix")):

@@ -139,6 +139,11 @@ class _SingleTransBase(nn.Module):
                     m16 = self._f16.get(self.get_matrix(inv_t=inv_t), inp.device, inp.dtype)
                     return ops.block_quant(inp.reshape(-1, R, n).contiguous(), m16, flags=FQ_OUT_TRANSFORM,
                                            transpose_out=False).y.reshape(init_shape)
+        if inp.dtype in ops.ACT_DTYPES and inp.is_cuda and n in (64, 128) and rows > 0:
+            # n = head_dim (round 4): kcache_trans(q, inv_t=True) / kcache_trans(k) / vcache_trans(v) over [.., heads, head_dim]
+            # (llama_utils.py:181-199) — rows of n straight through the matrix pipe, fp16 or bf16
+            m16 = self._f16.get(self.get_matrix(inv_t=inv_t), inp.device, inp.dtype)
+            return ops.single_trans(inp.contiguous(), m16).reshape(init_shape)
         # everything else (the offline fp64 weight-side use in reparameterize, odd sizes): the reference's own op
         matrix = self.get_matrix(inv_t=inv_t).to(inp)
         return inp.reshape(-1, n).matmul(matrix).reshape(init_shape)

@@ -202,6 +202,8 @@ def _alloc_outputs(x: torch.Tensor, rows: int, d: int, n_clips: int, flags: int,
 # recycled under it) and is keyed by torch's version counters (in-place updates miss). LRU-bounded.
 _WS_LRU: "collections.OrderedDict" = collections.OrderedDict()
 _WS_LRU_MAX = 512
+_WS_LRU_MAX_BYTES = 256 << 20   # and by bytes: a caller that re-stacks per-expert matrices on every call (keys never repeat) would
+                                # otherwise pin hundreds of multi-megabyte images before the count bound evicts one
 
 
 _WS_BYTES: dict = {}   # fq_kron_workspace_bytes(M, N): a pure function of the pair
@@ -228,8 +230,10 @@ def _kron_workspace(device: torch.device, M: int, N: int, left: torch.Tensor, ri
 
 def _kron_workspace_commit(key, ws: torch.Tensor, left: torch.Tensor, right: torch.Tensor) -> None:
     _WS_LRU[key] = (ws, left, right)
-    if len(_WS_LRU) > _WS_LRU_MAX:
-        _WS_LRU.popitem(last=False)
+    total = sum(e[0].numel() for e in _WS_LRU.values()) if ws.numel() > (1 << 20) else 0   # (only big images can hit the byte bound)
+    while len(_WS_LRU) > _WS_LRU_MAX or (total > _WS_LRU_MAX_BYTES and len(_WS_LRU) > 1):
+        _, ent = _WS_LRU.popitem(last=False)
+        total -= ent[0].numel()
 
 
 def _group_scales_shape(o: FusedOutputs, lead, groups_per_row: int) -> None:
@@ -479,7 +483,9 @@ def kron_quant_grouped(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor,
         if rows == 0:
             return o
         with _on(x.device):
-            per = int(lib.fq_kron_workspace_bytes(M, N))
+            per = _WS_BYTES.get((M, N))
+            if per is None:
+                per = _WS_BYTES[(M, N)] = int(lib.fq_kron_workspace_bytes(M, N))
             if per < 0:
                 raise _lib.FqError(per, f"no kernel for Kronecker factors ({M}, {N})")
             key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream, M, N, G,
@@ -540,7 +546,8 @@ def rmsnorm_kron_quant(x: torch.Tensor, eps: float, left: torch.Tensor, right: t
     round trip)."""
     _chk(x, "x"), _chk(left, "left"), _chk(right, "right")
     M, N = left.shape[0], right.shape[0]
-    wave_pair = M <= 64 and N in (64, 80, 112, 128) and (M, N) != (64, 64) and (M * (N // 8)) % 64 == 0
+    # (the wave kernel's one-row-tile instantiation exists for N = 64 only: 32 x 128, 32 x 112 ... take the two-launch route)
+    wave_pair = M <= 64 and N in (64, 80, 112, 128) and (M, N) != (64, 64) and (M * (N // 8)) % 64 == 0 and (M > 32 or N == 64)
     if wave_pair and (flags & (FQ_OUT_PACKED | FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM | FQ_QUANT_F16)) == FQ_OUT_PACKED:
         d = M * N
         if x.shape[-1] != d:
@@ -642,6 +649,21 @@ def block_quant(x: torch.Tensor, P: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1
     return o
 
 
+def single_trans(x: torch.Tensor, matrix: torch.Tensor) -> torch.Tensor:
+    """x.reshape(-1, n) @ matrix in x's dtype (fq_single_trans_{f16,bf16}): {SVD,Inv}SingleTransMatrix.forward at n = 64 / 128."""
+    dt = _chk_act(x)
+    _chk(matrix, "matrix", dt)
+    n = matrix.shape[0]
+    if matrix.shape != (n, n) or x.shape[-1] != n:
+        raise ValueError("single_trans: matrix [n, n] and x [..., n]")
+    rows = x.numel() // n
+    y = torch.empty_like(x)
+    if rows:
+        with _on(x.device):
+            check(_fn("single_trans", dt)(_ptr(x), _ptr(matrix), rows, n, _ptr(y), _stream(x)))
+    return y
+
+
 def rowquant(x: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),), flags: int = FQ_OUT_PACKED) -> FusedOutputs:
     """Per-token scale + INT4 quantisation of x [..., cols] (fq_rowquant_f16 / _bf16 by x's dtype)."""
     dt = _chk_act(x)
@@ -711,6 +733,29 @@ def hadamard(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None,
     with _on(x.device):
         check(lib.fq_hadamard_f16(_ptr(x), _ptr(y), rows, n, K, _ptr(hadK), ctypes.c_float(scale), _stream(x)))
     return y
+
+
+def hadamard_fp32(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
+    """matmul_hadU_cuda on x.float() (OnlineTrans(force_fp32=True), deploy/nn/online_trans.py:55-59) -> fp32: the power-of-two
+    transform with an fp32 result (fq_fwht_f32_f16: no fp16 rounding anywhere), then — K > 1 — the fp32 K x K factor as the
+    reference's own plain GEMM (`hadK.to(input.dtype) @ input`, online_trans.py:148-150). x fp16 (its up-cast is exact)."""
+    _chk(x, "x")
+    n = x.shape[-1]
+    if n % K:
+        raise ValueError("hadamard_fp32: n % K != 0")
+    P = n // K
+    if scale is None:
+        scale = float(1.0 / torch.tensor(n).sqrt())
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    vecs = x.numel() // P
+    if vecs:
+        with _on(x.device):
+            check(lib.fq_fwht_f32_f16(_ptr(x), _ptr(y), vecs, P, ctypes.c_float(scale), _stream(x)))
+    if K == 1:
+        return y
+    if hadK is None or hadK.shape != (K, K):
+        raise ValueError("hadK [K, K] required when K > 1")
+    return (hadK.to(device=x.device, dtype=torch.float32) @ y.view(*x.shape[:-1], K, P)).reshape(x.shape)
 
 
 def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None, sig: Sig = (1.0, 1.0),

@@ -73,9 +73,14 @@ extern "C" {
                                    token: ActivationQuantizer(groupsize=128) reshapes to (-1, groupsize) before it takes
                                    the extrema (vllm_custom/model_executor/layers/quantization/utils/fake_quant_utils.py:
                                    72-78); deepseek_v3/kernel.py:10-30 uses the same 128-element blocks. scale_out is then
-                                   [rows, M*N/128]. Fused for packed output with N = 64 (rows pairs are the groups);
-                                   FQ_EUNSUPPORTED otherwise: write FQ_OUT_TRANSFORM and run fq_rowquant_f16 with
-                                   cols = 128 over the reshaped buffer (what flatquant_amd.ops does) */
+                                   [rows, M*N/128]. Fused (one clip set, M*N % 128 == 0): packed output with fp32 arithmetic at
+                                   N = 64 quantises the fp32 accumulator in the wave-per-token kernels; every other output set
+                                   (fake-quant, transform, FQ_QUANT_F16), dtype (fp16 / bf16), plain or grouped launch, at 32x64,
+                                   56x64, 64x64, 64x80, 64x112, 64x128 and 86..128x128 runs the GROUP EPILOGUE of the
+                                   workgroup-per-token kernel (round 3) and needs FQ_ROUND_Y_F16 — it quantises the transform
+                                   rounded to the activation dtype, what ActivationQuantizer(groupsize=128) is handed.
+                                   FQ_EUNSUPPORTED otherwise: write FQ_OUT_TRANSFORM and run fq_rowquant_f16 with cols = 128 over
+                                   the reshaped buffer (what flatquant_amd.ops does) */
 
 #define FQ_SIG_F16        0x400 /* with FQ_QUANT_F16: extremum x sigmoid is rounded to fp16 before the division by 7 — what
                                    deploy/nn/quantization.py:21-22 evaluates (an fp16 [rows,1] tensor times a 0-dim fp32
@@ -377,6 +382,15 @@ int fq_hadamard_f16(const void* x, void* y, int64_t rows, int n, int K, const vo
                     void* stream);
 
 /*
+ * OnlineTrans(force_fp32=True) (deploy/nn/online_trans.py:55-59): the reference up-casts the activation and runs
+ * fast_hadamard_transform in fp32 — y [vecs, P] fp32 = FWHT_P( x [vecs, P] fp16 ) * scale, every butterfly and the scaling in fp32, NO
+ * rounding to fp16 (the stage order of hadamard_utils.py:94-101; bit for bit the oracle's fwht_f32 * scale). P a power of two in
+ * [64, 8192]. For n = K * P the caller views x as [rows * K, P] and applies the fp32 K x K factor itself, as the reference does
+ * (`hadK.to(input.dtype) @ input`, a plain fp32 GEMM: deploy/functional/online_trans.py:148-150).
+ */
+int fq_fwht_f32_f16(const void* x, void* y, int64_t vecs, int P, float scale, void* stream);
+
+/*
  * The same Hadamard transform fused with deploy.nn.Quantizer (deploy/nn/quantization.py:13-36 with lac clip
  * factors): the fp16 result never goes to HBM. Per row: extrema of the fp16 transform output (clamped through 0),
  * scale = fp16(max(|xmin*sig_min|, xmax*sig_max) / 7), q = clamp(rint(y /h scale), -8, 7) with the fp16 division
@@ -439,6 +453,15 @@ int fq_rowquant_bf16(const void* x, int64_t rows, int cols,
 #define FQ_KV_LAC 0x1
 int fq_kv_quant_f16(const void* x, const void* trans, int64_t rows, int head_dim, float clip_max, float clip_min,
                     int flags, void* q_out, void* param_out, void* y_out, void* stream);
+
+/*
+ * {SVD,Inv}SingleTransMatrix.forward at n = head_dim (flatquant/trans_utils.py:21-25, 136-151; the fake-quant eval path applies
+ * kcache_trans / vcache_trans to [.., heads, head_dim] activations on every forward, llama_utils.py:181-199):
+ *   y [rows, n] = x [rows, n] . matrix [n, n]   fp32 accumulation on the matrix pipe, one rounding to the activation dtype
+ * n in {64, 128} (smaller even n, the head-count axis of o_proj: fq_block_quant_* with FQ_OUT_TRANSFORM). y == x is NOT allowed.
+ */
+int fq_single_trans_f16(const void* x, const void* matrix, int64_t rows, int n, void* y, void* stream);
+int fq_single_trans_bf16(const void* x, const void* matrix, int64_t rows, int n, void* y, void* stream);
 
 /* kv_cache.py:54-61 unpack_i4_and_asym_dequantize: y = q * scale - zero, or scale * (q - zero) with FQ_KV_LAC (fp16). */
 int fq_kv_dequant_f16(const void* q, const void* param, int64_t rows, int head_dim, int flags, void* y, void* stream);

@@ -73,7 +73,9 @@ def test_transform_and_quantiser_vs_reference(ops, golden, tag):
         assert np.array_equal(bits(o.scale[0]), O.bf16_bits(ref["scale16"])), (tag, mode)
         # against the reference's own digits: a bf16 step of the transform moves a digit now and then
         q = O.unpack_i4(o.q[0].cpu().numpy())
-        assert np.mean(q != g[f"{k}_{mode}_q"]) < 2e-2 and np.max(np.abs(q - g[f"{k}_{mode}_q"])) <= 1, (tag, mode)
+        # (measured: 0 flipped digits on every pair and route, profiles/r03_flip_rates.txt; the bar is 2e-4 — a handful of digits of a
+        #  fixture — where round 3 allowed 2e-2)
+        assert np.mean(q != g[f"{k}_{mode}_q"]) <= 2e-4 and np.max(np.abs(q - g[f"{k}_{mode}_q"])) <= 1, (tag, mode)
     # transform-only launch == the transform of the fused launch; kronecker_matmul mirror
     from flatquant_amd.flatquant import kronecker_matmul
     y = kronecker_matmul(x.reshape(1, rows, -1), L, R)

@@ -114,9 +114,9 @@ def test_linear_many_tiles_and_the_clamp_variant(ops, M, N, K, bias):
 
 def test_module_uses_the_fp6_path_transparently(ops, monkeypatch):
     import flatquant_amd.deploy as deploy
-    monkeypatch.setenv("FQ_FP6_GEMM", "1")
     gen = torch.Generator().manual_seed(3)
     lin = deploy.nn.Linear4bit(512, 384, bias=True).cuda()
+    lin.fp6_image, lin.fp6_min_out_features = True, 0      # policy attributes of the instance (no environment variable: round 4)
     wp, _ = rand_packed(gen, 384, 512)
     lin.weight.copy_(torch.from_numpy(wp))
     lin.weight_scales.copy_((torch.rand(384, 1, generator=gen) * 0.02 + 0.001))
@@ -139,9 +139,9 @@ def test_prefill_sized_calls_take_the_fp6_path_with_a_transient_image(ops, monke
     """Default policy (no image kept): >= fp6_transient_rows tokens convert the weights for the call (inside the one library call
     fq_int4_linear_fp6_f16); same bits as the int8 path, nothing cached on the module."""
     import flatquant_amd.deploy as deploy
-    monkeypatch.delenv("FQ_FP6_GEMM", raising=False)
     gen = torch.Generator().manual_seed(5)
     lin = deploy.nn.Linear4bit(256, 272).cuda()
+    lin.fp6_min_out_features = 0                            # (a 272-wide layer: below the default width gate)
     lin.weight.copy_(torch.from_numpy(rand_packed(gen, 272, 256)[0]))
     lin.weight_scales.copy_((torch.rand(272, 1, generator=gen) * 0.02 + 0.001))
     rows = lin.fp6_transient_rows + 3

@@ -187,3 +187,29 @@ def test_online_trans_with_quantizer_argument(ops):
     sa, sb = fused.scales_x.float().cpu().numpy().reshape(-1), ref.scales_x.float().cpu().numpy().reshape(-1)
     assert np.all(np.abs(sa - sb) <= 2e-3 * np.abs(sb))
     assert qz(fused) is fused   # the Quantizer passes packed inputs through
+
+
+@pytest.mark.parametrize("n", [64, 128, 512, 4096, 8192, 14336, 11008, 28672])
+def test_force_fp32_returns_the_fp32_transform(ops, n):
+    """OnlineTrans(force_fp32=True) (deploy/nn/online_trans.py:55-59): x.float() through fast_hadamard_transform in fp32 and the
+    fp32 K x K factor — an fp32 tensor with NO fp16 rounding inside (round 3 widened the fp16 result). K = 1: bit for bit the
+    oracle's fp32 butterflies x scale; K > 1: the fp32 GEMM of the factor within fp32 rounding noise of the exact product."""
+    import flatquant_amd.deploy as deploy
+    t = deploy.nn.OnlineTrans(n, force_fp32=True, trans="had").cuda()
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(3, 5, n, generator=g).half()
+    x[..., ::29] *= 11
+    y = t(x.cuda())
+    assert y.dtype == torch.float32 and y.shape == x.shape
+    K = t.rem_dim
+    scale = np.float32(1.0) / np.sqrt(np.float32(n))
+    v = O.fwht_f32(x.numpy().astype(np.float32).reshape(15, K, n // K)) * scale          # fp32, the reference's stage order
+    if K == 1:
+        assert np.array_equal(y.cpu().numpy().reshape(15, 1, n).view(np.uint32), v.view(np.uint32))
+    else:
+        ref = np.einsum("jk,rkp->rjp", hadk_matrix(K).astype(np.float64), v.astype(np.float64)).reshape(15, n)
+        got = y.cpu().numpy().reshape(15, n).astype(np.float64)
+        assert np.max(np.abs(got - ref)) <= 2e-6 * np.max(np.abs(ref))
+        # and it is NOT the widened fp16 result: finer than fp16 resolution
+        y16 = t.__class__(n, trans="had").cuda()(x.cuda()).float().cpu().numpy().reshape(15, n)
+        assert np.max(np.abs(y16 - ref)) > 20 * np.max(np.abs(got - ref))

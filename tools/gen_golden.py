@@ -906,6 +906,45 @@ def gen_heads():
     save("heads_any", **arrays)
 
 
+def gen_single128():
+    """{SVD,Inv}SingleTransMatrix(128).forward on [tokens, heads, head_dim = 128] activations — kcache_trans(q, inv_t=True),
+    kcache_trans(k), vcache_trans(v) of the fake-quant eval path (llama_utils.py:181-199; trans_utils.py:21-25, 136-151) — in
+    fp16 and bf16, followed by the per-head ActivationQuantizer(bits=4, sym=False) the K cache gets (llama_utils.py:124-132)."""
+    from flatquant.trans_utils import InvSingleTransMatrix as RefInvSingle
+    from flatquant.trans_utils import SVDSingleTransMatrix as RefSVDSingle
+    arrays = {}
+    T, H, hd = 7, 8, 128
+    for tag, cls in (("svd", RefSVDSingle), ("inv", RefInvSingle)):
+        st = cls(hd)
+        if tag == "svd":
+            st.linear_u.weight.data = torch.from_numpy(np.linalg.qr(np.random.RandomState(910).randn(hd, hd))[0]).float()
+            st.linear_v.weight.data = torch.from_numpy(np.linalg.qr(np.random.RandomState(911).randn(hd, hd))[0]).float()
+            st.linear_diag.data = torch.from_numpy(np.random.RandomState(912).rand(hd) * 1.5 + 0.5).float()
+        else:
+            st.linear.weight.data = torch.from_numpy(np.linalg.qr(np.random.RandomState(913).randn(hd, hd))[0]
+                                                     * (np.random.RandomState(914).rand(hd) * 1.5 + 0.5)[None, :]).float()
+        st.to_eval_mode()
+        x = make_x(T, H * hd, seed=915).reshape(T, H, hd)
+        with torch.no_grad():
+            y16 = st(x.to(torch.float16))
+            arrays[f"{tag}_y16"], arrays[f"{tag}_y16_inv_t"] = y16.numpy(), st(x.to(torch.float16), inv_t=True).numpy()
+            arrays[f"{tag}_ybf_bits"] = bits(st(x.to(torch.bfloat16)))
+            arrays[f"{tag}_ybf_inv_t_bits"] = bits(st(x.to(torch.bfloat16), inv_t=True))
+            q = RefActQ(bits=4, sym=False, lac=True)
+            q.clip_factor_a_max.data.fill_(3.1)
+            q.clip_factor_a_min.data.fill_(2.2)
+            arrays[f"{tag}_kq16"] = q(y16).to(torch.float16).numpy()          # k_cache_quantizer(k).to(q) on the transformed keys
+        arrays[f"{tag}_x"] = x.to(torch.float16).numpy()
+        arrays[f"{tag}_matrix"], arrays[f"{tag}_matrix_inv_t"] = st.matrix.detach().numpy(), st.matrix_inv_t.detach().numpy()
+    arrays["kq_clip"] = np.array([3.1, 2.2], dtype=np.float32)
+    arrays["kq_sig"] = np.array([sig(3.1), sig(2.2)], dtype=np.float32)
+    save("single128", **arrays)
+
+
+def gen_round4():
+    gen_single128()
+
+
 def gen_round3():
     gen_bf16()
     gen_moe_bf16()
@@ -925,6 +964,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt2k":   # the K = 2048 export (12 MB): only on request
         gen_checkpoint(hidden=2048, ffn=2048, heads=16, kv_heads=2, layers=1, name="ckpt2k", clip_noise=0.6)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "r4":
+        gen_round4()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "r3":
         gen_round3()
