@@ -274,7 +274,10 @@ int fq_launch_kron_tall(int flags, const f16* x, const void* ws, const f16* diag
     if ((out.rt_flags & FQ_GROUP128) || out.ws_group_stride != 0) return -1000;
     const int ct = flags & FQ_CT_MASK, cq = ct & ~FQ_OUT_TRANSFORM;
     const bool yout = (ct & FQ_OUT_TRANSFORM) != 0;
-    const bool h16 = cq == (FQ_OUT_PACKED | FQ_QUANT_F16) && (flags & FQ_ROUND_Y_F16);
+    // (round 4) the transform ALONE (kronecker_matmul; the rotation of matmul_hadU_cuda run as a Kronecker pair): the fp16-epilogue
+    // instantiation with no clip set — the quantiser loop does not run, the rounded pairs go out as they are
+    const bool yonly = yout && (cq & ~FQ_QUANT_F16) == 0 && out.n_clips == 0;
+    const bool h16 = yonly || (cq == (FQ_OUT_PACKED | FQ_QUANT_F16) && (flags & FQ_ROUND_Y_F16));
     if (cq != FQ_OUT_PACKED && !h16) return -1000;
     if (yout && out.y == nullptr) return -1000;
     const uint4* wp = reinterpret_cast<const uint4*>(ws);

@@ -710,12 +710,26 @@ def hadamard_mfma(x: torch.Tensor, K: int, hadK: torch.Tensor, sig: Optional[Sig
 
 def hadamard(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None,
              scale: Optional[float] = None, fwht_route: bool = False) -> torch.Tensor:
-    """hadK @ FWHT(x.view(rows, K, n/K)) * scale. Two routes: the register FWHT + K-factor kernel (fq_hadamard_f16; bit-exact for
-    K = 1), and for n = K * 512 (K <= 32: 14336) the structured matrix-pipe kernel (fq_hadamard_quant_mfma_f16: same rotation,
-    the intermediate rounded to fp16 at other points — within 1e-3 of the row maximum of the exact rotation, not bit-identical to
-    the first route). ``fwht_route=True`` forces the first."""
-    if K > 1 and hadK is not None and not fwht_route and had_mfma_supported(x.shape[-1], K) and hadK.shape == (K, K) and x.numel() > 0:
-        return hadamard_mfma(x, K, hadK, None, scale, True)[0]
+    """hadK @ FWHT(x.view(rows, K, n/K)) * scale. Routes: the register FWHT + K-factor kernel (fq_hadamard_f16; bit-exact for K = 1,
+    the route of every K = 1 call); for K > 1 a matrix-pipe launch where one exists — the rotation as a dense Kronecker pair with the
+    transform as its only output (11008 = 172 x 64, 8960, 5120, 14336 = 112 x 128), else the structured kernel (n = K * 512). The
+    matrix-pipe routes round the intermediate to fp16 at other points: within 1e-3 of the row maximum of the exact rotation, not
+    bit-identical to the first route. ``fwht_route=True`` forces the first."""
+    if K > 1 and hadK is not None and not fwht_route and x.numel() > 0 and x.shape[-1] % K == 0 and hadK.shape == (K, K):
+        # (round 4) tall rotations — 11008 = 172 x 64 (Llama-2-7B), 8960 = 140 x 64, 5120 = 80 x 64 ... — as ONE dense Kronecker launch
+        # with the transform as its only output (fq_kron_tall.hip: 464 -> ~200 us per 16384 tokens of 11008); tolerance parity
+        # as the fused launch of the same pair (hadamard_quant), fwht_route=True keeps the bit-identical register FWHT
+        # 14336 = 112 x 128 too: with the transform as the ONLY output the dense pair's LDS-staged 1 KB stores (188 us) beat the
+        # structured kernel's 32-byte pieces (208 us; profiles/r04_hadamard_routes.txt) — the structured kernel is the fused one
+        kr = _hadamard_as_kron(K, x.shape[-1] // K, hadK, x.device)
+        if kr is not None and kr[2] in (64, 128):
+            _chk(x, "x"), _chk(hadK, "hadK")
+            n = x.shape[-1]
+            sc = float(1.0 / torch.tensor(n).sqrt()) if scale is None else scale
+            o = kron_quant_ex(x.reshape(-1, n), kr[0], kr[1], _had_right_div(kr[2]) * sc, [(1.0, 1.0)], FQ_OUT_TRANSFORM | FQ_ROUND_Y_F16)
+            return o.y.reshape(x.shape)
+        if had_mfma_supported(x.shape[-1], K):
+            return hadamard_mfma(x, K, hadK, None, scale, True)[0]
     _chk(x, "x")
     n = x.shape[-1]
     if K > 1:
@@ -826,7 +840,7 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
     if rc == _lib.FQ_EUNSUPPORTED:
         if up is not None:
             x = silu_mul(x, up)
-        o = rowquant(hadamard(x, K, hadK, scale), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)
+        o = rowquant(hadamard(x, K, hadK, scale, fwht_route=True), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)
         return o.q[0], o.scale[0].reshape(-1)
     check(rc)
     return q, s

@@ -92,7 +92,7 @@ def test_agrees_with_the_fwht_route_to_rounding_noise(ops, n, K):
         assert np.mean(qa != qb) <= 2e-3 and np.max(np.abs(qa - qb)) <= 1, (n, K, sig, float(np.mean(qa != qb)))
         sa, sb = s.float().cpu().numpy().reshape(-1), sf.float().cpu().numpy().reshape(-1)
         assert np.all(np.abs(sa - sb) <= 2e-3 * np.maximum(np.abs(sb), 1e-6))
-    y = ops.hadamard(x.cuda(), K, hk)
+    y = ops.hadamard_mfma(x.cuda(), K, hk)[0]
     yf = ops.hadamard(x.cuda(), K, hk, fwht_route=True)
     den = yf.float().abs().amax(dim=1, keepdim=True)
     assert float(((y.float() - yf.float()).abs() / den).max()) <= 1e-3
@@ -103,7 +103,7 @@ def test_reference_fixture_14336(ops, golden):
     g = golden("had_A")
     x = torch.from_numpy(g["x_14336"]).cuda()
     hk = torch.from_numpy(hadk_matrix(28)).cuda()
-    y = ops.hadamard(x, 28, hk).cpu().numpy()
+    y = ops.hadamard_mfma(x, 28, hk)[0].cpu().numpy()
     y64 = g["y64_14336"]
     den = np.abs(y64).max(axis=1, keepdims=True)
     assert np.max(np.abs(y.astype(np.float64) - y64) / den) <= 1e-3
