@@ -239,6 +239,9 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
     const int ks_n = (M + 15) >> 4;   // rows of L beyond M are zero
 
     int it = 0;
+#ifdef DUO_TRACE
+    unsigned long long store_ticks = 0;
+#endif
     for (int k = grp; k < blk_cnt; ++it) {   // k: the group's current token (of this workgroup's range)
         const int64_t tok = blk_base + k;
         DUO_STAMP(0)
@@ -437,15 +440,28 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
                         pk[t].y = fq_pack8(fq_qexact(yv[8], scale), fq_qexact(yv[9], scale), fq_qexact(yv[10], scale), fq_qexact(yv[11], scale),
                                            fq_qexact(yv[12], scale), fq_qexact(yv[13], scale), fq_qexact(yv[14], scale), fq_qexact(yv[15], scale));
                 }
+#ifdef DUO_TRACE   // (round 4) ticks spent ISSUING the four 16-byte stores of a token (slot 10): part of the quantiser phase's time
+                unsigned long long ts0 = 0;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts0) : : "memory");
+#endif
                 if ((mo * 32 + (lq & 31)) < M) {
                     uint8_t* dst = qtok + (mo * 32 * (N / 2) + lane_off);
                     if (two) *reinterpret_cast<u32x4_a8*>(dst) = u32x4{pk[0].x, pk[0].y, pk[1].x, pk[1].y};   // (8-byte aligned: h * 56)
                     else *reinterpret_cast<uint2*>(dst) = pk[0];
                 }
+#ifdef DUO_TRACE
+                unsigned long long ts1 = 0;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts1) : : "memory");
+                store_ticks += ts1 - ts0;
+#endif
             }
             if (wq == 0 && lane == 0) out.scale[ci][tok] = (f16)scale;
         }
         DUO_STAMP(8)
+#ifdef DUO_TRACE
+        if (blockIdx.x == DUO_TRACE && it < 32 && lane == 0) duo_trace[(wave * 32 + it) * 12 + 10] = store_ticks;
+        store_ticks = 0;
+#endif
         // this wave's share of the next token (and the ring) has landed: everything but the (at least) 4 stores behind them
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #pragma unroll

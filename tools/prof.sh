@@ -6,8 +6,8 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # kernel trace: the default bench command (1000 steps after 200 warm-up launches), minus the CPU baseline leg
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1
-CMD="python $R/bench.py --steps 200 --warmup 100 --no-cpu-baseline"   # counter passes: fewer launches
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/bench.py --no-cpu-baseline --no-sub-records > $OUT/trace.log 2>&1
+CMD="python $R/bench.py --steps 200 --warmup 100 --no-cpu-baseline --no-sub-records"   # counter passes: fewer launches
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
@@ -18,4 +18,7 @@ for PMC in "FETCH_SIZE" "WRITE_SIZE" \
   rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc$i -o p -- $CMD > $OUT/pmc$i.log 2>&1
 done
 python $R/tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
+# prune the raw rocprofv3 output (gpurun copies back at most 64 MiB): keep the summary and the kernel-stats csv
+find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \; 2>/dev/null
+rm -rf $OUT/trace $OUT/pmc[0-9]* 2>/dev/null; find $OUT -name "*.log" -size +64k -delete 2>/dev/null
 cat $OUT/summary.txt

@@ -28,13 +28,13 @@ t = buf.reshape(8, 32, 12).astype(np.int64)
 names = ["meetA", "gemm1", "meetX", "dma", "gemm2", "extrema", "meetB", "quant", "wait"]
 t0 = t[:, :, 0].min()
 print("stamp units: s_memtime ticks (100 MHz); columns = time between consecutive stamps")
-print("wave it  start " + " ".join(f"{n:>8s}" for n in names) + "    total")
+print("wave it  start " + " ".join(f"{n:>8s}" for n in names) + "    total   (stores: ticks inside `quant` spent issuing the token's four 16-byte stores)")
 for w in (0, 1, 3, 4, 7):
     for it in range(4, 12):
         r = t[w, it]
         d = np.diff(r[:10])
         nxt = t[w, it + 1, 0] - r[0]
-        print(f"{w:4d} {it:2d} {r[0] - t0:6d} " + " ".join(f"{v:8d}" for v in d) + f" {nxt:8d}")
+        print(f"{w:4d} {it:2d} {r[0] - t0:6d} " + " ".join(f"{v:8d}" for v in d) + f" {nxt:8d}   stores {r[10]:6d}")
 rt = (t[0, 14, 11] - t[0, 4, 11]) / 100.0  # s_memrealtime: 100 MHz
 print(f"s_memtime ticks per microsecond over wave 0's iterations 4..14: {(t[0, 14, 0] - t[0, 4, 0]) / rt:.0f} "
       f"({rt:.1f} us for 10 iterations = {rt / 10:.2f} us per token of a group)")
