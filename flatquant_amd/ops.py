@@ -38,8 +38,12 @@ def sigmoid_pair_f16(clip_max, clip_min) -> Sig:
     torch's device kernels cast a 0-dim operand to the result dtype on load — measured on MI355X,
     tools/scratch/sig_f16_probe.py: every finite fp16 extremum agrees with fp16(x * fp16(sigmoid)); the CPU keeps the fp32
     value). The product of two fp16 values is exact in fp32, so FQ_SIG_F16 then rounds once."""
-    a, b = sigmoid_pair(clip_max, clip_min)
-    t = torch.tensor([a, b], dtype=torch.float32).to(torch.float16)
+    return _sig_f16_cached(*sigmoid_pair(clip_max, clip_min))
+
+
+@functools.lru_cache(maxsize=4096)
+def _sig_f16_cached(a: float, b: float) -> Sig:
+    t = torch.tensor([a, b], dtype=torch.float32).to(torch.float16)   # (three tensor ops: ~6 us a call before the cache, round 4)
     return float(t[0]), float(t[1])
 
 
@@ -54,6 +58,7 @@ def invalidate_caches() -> None:
     such an update (checkpoint loaders that assign ``.data`` should), or update in place on the tensor."""
     _SCALARS.clear()
     _sigmoid_pair_cached.cache_clear()
+    _sig_f16_cached.cache_clear()
     _WS_LRU.clear()
     _HAD_KRON.clear()
     from .flatquant.trans_utils import _Fp16Cache   # the modules' fp16 / bf16 copies of their (fp32) matrices
@@ -120,7 +125,8 @@ def _fn(stem: str, dtype):
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+    """a tensor's address as ctypes takes it for a c_void_p argument: a plain int (None = NULL) — no c_void_p object per argument"""
+    return None if t is None else t.data_ptr()
 
 
 _NULL4 = (ctypes.c_void_p * FQ_MAX_CLIPS)()   # the output sets a launch does not write (read-only on the C side)
@@ -135,13 +141,19 @@ def _ptr_array(ts: Sequence[Optional[torch.Tensor]]):
     return arr
 
 
+@functools.lru_cache(maxsize=1024)
+def _sig_arrays_cached(key):
+    smax = (ctypes.c_float * FQ_MAX_CLIPS)(*[s[0] for s in key])
+    smin = (ctypes.c_float * FQ_MAX_CLIPS)(*[s[1] for s in key])
+    return smax, smin, len(key)
+
+
 def _sig_arrays(sigs: Sequence[Sig]):
+    """-> (float[4] sig_max, float[4] sig_min, n): read-only on the C side, so the arrays of a clip-set tuple are built once"""
     n = len(sigs)
     if not 1 <= n <= FQ_MAX_CLIPS:
         raise ValueError(f"between 1 and {FQ_MAX_CLIPS} clip sets are supported, got {n}")
-    smax = (ctypes.c_float * FQ_MAX_CLIPS)(*[float(s[0]) for s in sigs])
-    smin = (ctypes.c_float * FQ_MAX_CLIPS)(*[float(s[1]) for s in sigs])
-    return smax, smin, n
+    return _sig_arrays_cached(tuple((float(s[0]), float(s[1])) for s in sigs))
 
 
 class _on:
@@ -169,8 +181,20 @@ class _on:
         return False
 
 
+# The current stream's raw handle. torch.cuda.current_stream() builds a Stream object through two device-index helpers: ~4 us a call,
+# twice per launch (the workspace key and the launch argument) — 8 of the ~19 us a library call spent on the host (round 4,
+# tools/host_overhead.py). torch._C._cuda_getCurrentRawStream is the same look-up without the object.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream_handle(device: torch.device) -> int:
+    if _raw_stream is not None:
+        return _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def _stream(t: torch.Tensor):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return ctypes.c_void_p(_stream_handle(t.device))
 
 
 class FusedOutputs:
@@ -219,7 +243,7 @@ def _kron_workspace(device: torch.device, M: int, N: int, left: torch.Tensor, ri
         raise _lib.FqError(nbytes, f"no kernel for Kronecker factors ({M}, {N}): need M, N <= 256 and M * N <= 32768")
     if nbytes == 0:   # (no pair has a zero-size workspace since round 3: 64 x 64 takes its optional 32 KB image)
         return None, 0, False, None
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, M, N,
+    key = (device.index, _stream_handle(device), M, N,
            left.data_ptr(), left._version, right.data_ptr(), right._version)
     ent = _WS_LRU.get(key)
     if ent is not None:
@@ -488,7 +512,7 @@ def kron_quant_grouped(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor,
                 per = _WS_BYTES[(M, N)] = int(lib.fq_kron_workspace_bytes(M, N))
             if per < 0:
                 raise _lib.FqError(per, f"no kernel for Kronecker factors ({M}, {N})")
-            key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream, M, N, G,
+            key = (x.device.index, _stream_handle(x.device), M, N, G,
                    left.data_ptr(), left._version, right.data_ptr(), right._version)
             ent = _WS_LRU.get(key)
             prepared = ent is not None

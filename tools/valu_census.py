@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """VALU census of a kernel's per-token loop from a `hipcc -S --cuda-device-only` listing.
-    tools/valu_census.py file.s <kernel name substring> [--elems N] [--exclude LBB0_145,LBB0_262,...]
+    tools/valu_census.py file.s <kernel name substring> [--elems N] [--exclude LBB0_145,LBB0_262,...] [--loop LBB32_23]
 Walks the basic blocks of the kernel, keeps the blocks inside its outermost loop (the token loop: everything between the
 first backward-branch target and the last backward branch), drops the blocks of the rare exact-division fallback (they contain
 v_div_scale_f32 next to v_rndne: taken for ~3e-5 of the dwords), and sorts every VALU instruction into a category.
@@ -54,15 +54,20 @@ for i in range(start + 1, end + 1):
     cur["ins"].append((t, in_asm))
 names = {b["name"]: k for k, b in enumerate(blocks)}
 # outermost loop = [min target of a backward branch, max index of a backward branch]
-lo, hi = len(blocks), -1
+lo, hi, best_span = len(blocks), -1, 0
 for k, b in enumerate(blocks):
     for t, _ in b["ins"]:
         if t.startswith(("s_cbranch", "s_branch")):
             tgt = names.get(t.split()[1])
             if tgt is not None and tgt <= k:
                 span = k - tgt
-                if span > 20:      # the token loop, not a meeting spin or a search loop
-                    lo, hi = min(lo, tgt), max(hi, k)
+                if span > best_span:      # the token loop = the widest backward branch (meeting spins and search loops are short)
+                    best_span, lo, hi = span, tgt, k
+if "--loop" in sys.argv:   # --loop LBB32_23: the loop whose header is that block (up to the last branch back to it)
+    hdr = sys.argv[sys.argv.index("--loop") + 1]
+    lo = names["." + hdr.lstrip(".")]
+    hi = max(k for k, b in enumerate(blocks) for t, _ in b["ins"]
+             if t.startswith(("s_cbranch", "s_branch")) and t.split()[1] == "." + hdr.lstrip(".") and k >= lo)
 loop = blocks[lo:hi + 1]
 
 
