@@ -299,6 +299,8 @@ def _hadk(K, device):
 
 class C3(Workload):
     name = "C3"
+    graph = True        # (round 4) four launches of 33-130 us per step: replayed from a captured HIP graph like C4 / C5, so that the step
+    graph_inputs = 2    # is the kernels and not the ~15 us of host work per library call between them; two input sets alternate
     metric = "Melems/s, Llama-3-8B decoder layer activation path (7 linears, W4A4, online Hadamard on down_proj), 8x2048 tokens"
 
     def __init__(self, device, rank, world, sharding, bcast):
@@ -331,6 +333,7 @@ class C3(Workload):
         self.config = {"workload": "C3: Llama-3-8B decoder layer, activation path of the 7 linears (RMSNorm+64x64 x3 clips, "
                                    "o_proj head transform 128x32, RMSNorm+64x64 x2 clips, Hadamard 28x512 + Quantizer), "
                                    "8x2048 tokens per GPU", "rows_per_gpu": rows, "launches_per_step": 4,
+                       "launch": "HIP graph replay, two input sets alternating",
                        "parallelism": f"rows x{world}"}
 
 
