@@ -64,6 +64,8 @@ int fq_launch_kron_trio(int flags, const f16* x, const void* ws, const f16* diag
                         const FqQuantOut& out, int n_cu, hipStream_t stream);
 int fq_launch_kron_duo(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
                        const FqQuantOut& out, int n_cu, hipStream_t stream);
+int fq_launch_kron_tiles(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
+                         const FqQuantOut& out, int n_cu, hipStream_t stream);   // fq_kron_tiles.hip
 int fq_launch_kron_tall(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
                         const FqQuantOut& out, int n_cu, hipStream_t stream);  // fq_kron_trio.hip
 
@@ -152,6 +154,10 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
     }
     if (!g128 && spec && !fq_measure_env("FQ_KRON_NO_DUO")) {   // 96 < M <= 128, N = 224, packed output: two token groups per CU
         rc = fq_launch_kron_duo(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
+        if (rc != -1000) return rc;
+    }
+    if (!g128 && spec && !fq_measure_env("FQ_KRON_NO_TILES")) { // 80 x 112, 128 x 144, 144 x 192 (round 4): token groups of NT waves
+        rc = fq_launch_kron_tiles(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }
     if (!g128 && spec && !fq_measure_env("FQ_KRON_NO_TALL")) {  // 64 < M <= 192, N = 64, packed output: a wave per ROW tile (172 x 64: Hadamard 11008)

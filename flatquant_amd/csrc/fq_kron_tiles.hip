@@ -1,0 +1,379 @@
+// fq_kron_tiles.hip — fused Kronecker transform + per-token INT4 quantisation (packed output) for the factor pairs whose token
+// needs MORE or FEWER than four 32-column n'-tiles, or more than four row tiles: 80 x 112 (8960, Qwen2.5-1.5B ffn), 128 x 144
+// (18432, DeepSeek-V3 dense ffn: deepseekv3_utils.py:343-348), 144 x 192 (27648, Qwen2.5-32B ffn) — function_utils.py:11-21 pairs
+// that until round 4 ran the workgroup-per-token kernel with ONE token resident per CU (0.21-0.32 of the HBM roofline).
+//
+// The structure is fq_kron_trio.hip's, with the geometry as template parameters: one persistent workgroup per CU holds GROUPS token
+// groups of NT waves (a wave per n'-tile), the waves of a group meet on LDS counters and the groups drift apart, tokens are claimed
+// from a workgroup counter one ahead, staged by LDS-DMA, and never leave registers between GEMM 1 and the packed stores. What is new:
+//   * N = 16 KS1 for any KS1 (7, 9, 12 here): CPR = N / 8 chunks per row, unpadded rows; the bank rotation of a row is a property
+//     of CPR (tl_swz: none for CPR = 14, 18, 22 — the pitch already rotates —, an XOR of the row's bits 1..3 for CPR = 24), and the
+//     per-lane DMA source offsets follow from it, computed per block of four instructions (no closed form shared by all CPR);
+//   * a last n'-tile that is half padding (N % 32 = 16): its upper half-wave neither contributes extrema nor stores;
+//   * NO zero rows under the token: the row index of an A fragment is clamped to M - 1 instead (a padding row of U then holds finite
+//     copies, and meets zero rows of L in GEMM 2), so a buffer is exactly 16 LKS rows and 144 x 192 fits two tokens + its L image
+//     (trimmed to the K-steps that hold rows of L: LKS x MT KB) in 160 KB;
+//   * RS: the wave's R fragments (KS1 x 4 registers: 48 at N = 192) stream from the L2-resident image through a ring instead of
+//     living in registers, as in fq_kron_duo.hip.
+// Same mathematics, rounding points, fragment image (fq_kron_prepare_kernel) and quantiser helpers as every other Kronecker kernel;
+// bit-identical to the workgroup-per-token kernel (tests/test_gpu_kron_tiles.py).
+#include "fq_common.hpp"
+#include "fq_dma.hpp"
+
+namespace {
+
+#ifndef TILES_ABL
+#define TILES_ABL 0   // measurement builds: 1 no quantiser, 2 no GEMM 1, 4 no GEMM 2, 8 no stores, 16 no DMA after the first
+#endif
+
+// bank rotation of row r (8 consecutive rows of one K-half must hit 8 different 16-byte bank groups of the 16):
+// (CPR r + p) mod 16 with p the chunk. CPR = 2 (mod 4): 2 r .. 14 r (mod 16) are eight distinct even slots already.
+template <int CPR>
+__device__ __forceinline__ int tl_swz(int r) {
+    return CPR % 16 == 0 ? (r & 15) : CPR % 16 == 8 ? ((r >> 1) & 7) : CPR % 8 == 4 ? ((r >> 2) & 3) : 0;
+}
+template <int CPR>
+constexpr bool tl_has_swz() { return CPR % 4 == 0; }
+
+template <int MT, int NT, int N, int GROUPS, int LKS>
+struct TilesGeom {
+    static constexpr int KS1 = N / 16, CPR = N / 8, THREADS = GROUPS * NT * 64;
+    static constexpr int LFR = LKS * MT * 64;                 // uint4: the K-steps of the L image that hold rows of L
+    static constexpr int TOKBUF = LKS * 16 * CPR * 16;        // bytes: 16 LKS >= M rows
+    static constexpr int RED = LFR * 16 + GROUPS * TOKBUF;    // [max x8][min x8] floats per group
+    static constexpr int CTL = RED + GROUPS * 64;             // [meet x3][next][claim x3]
+    static constexpr int LDS = CTL + 32;
+    static_assert(N % 16 == 0 && NT == (N + 31) / 32 && LKS <= 2 * MT && LKS > 2 * MT - 2 && GROUPS <= 3 && NT <= 8, "geometry");
+};
+
+__device__ __forceinline__ unsigned tl_lds_read(unsigned addr) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned tl_lds_add_rtn(unsigned addr, unsigned val) {
+    unsigned v;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr), "v"(val) : "memory");
+    return v;
+}
+__device__ __forceinline__ void tl_lds_write(unsigned addr, unsigned val) {
+    asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(val) : "memory");
+}
+// group meeting on a counter in LDS (fq_kron_trio.hip: trio_meet)
+__device__ __forceinline__ void tl_meet(unsigned cnt_lds, unsigned target, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) asm volatile("ds_add_u32 %0, %1" : : "v"(cnt_lds), "v"(1u) : "memory");
+    for (;;) {
+        unsigned v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cnt_lds) : "memory");
+        if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+#define TILES_MEET() { meet_n += NT; tl_meet(meet, meet_n, lane); }
+
+// per-lane source offset of DMA instruction i (which fills the LDS slots [64 i, 64 i + 64) linearly), relative to the
+// instruction's own KB and biased by +128 bytes (an XOR moves a lane at most 7 chunks back: never negative)
+template <int CPR>
+__device__ __forceinline__ unsigned tl_dma_off(int i, int lane) {
+    if (!tl_has_swz<CPR>()) return (unsigned)(lane * 16 + 128);
+    const int q = i * 64 + lane, r = q / CPR, pch = q - r * CPR;
+    return (unsigned)((lane + ((pch ^ tl_swz<CPR>(r)) - pch)) * 16 + 128);
+}
+
+template <int MT, int NT, int N, int GROUPS, int LKS, bool RS>
+__global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
+                                                                       int64_t rows, int64_t tpb, int M, FqQuantOut out) {
+    typedef TilesGeom<MT, NT, N, GROUPS, LKS> G;
+    constexpr int KS1 = G::KS1, CPR = G::CPR, THREADS = G::THREADS;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave / NT, wq = wave - grp * NT;   // token group, n'-tile of this wave
+    uint4* lfr = reinterpret_cast<uint4*>(smem);
+    unsigned char* tokbuf = smem + G::LFR * 16 + grp * G::TOKBUF;
+    float* red = reinterpret_cast<float*>(smem + G::RED) + grp * 16;   // [max x8][min x8]
+    unsigned* ctl = reinterpret_cast<unsigned*>(smem + G::CTL);
+    const unsigned ctl_lds = (unsigned)(size_t)(lds_void*)ctl, meet = ctl_lds + grp * 4;
+    const unsigned tok_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)tokbuf);
+    const int64_t tok_bytes = (int64_t)M * (N * 2);
+    const int n_slots = M * CPR, n_dma = (n_slots + 63) >> 6;   // 1 KB instructions per token; the last one may end inside its KB
+    const int per = (n_dma + NT - 1) / NT;                      // this wave stages instructions [d0, d0 + dn)
+    const int d0 = wq * per;
+    const int dn = n_dma - d0 < per ? (n_dma - d0 < 0 ? 0 : n_dma - d0) : per;
+    const int tail_lanes = n_slots & 63;
+    const bool own_tail = tail_lanes != 0 && dn > 0 && d0 + dn == n_dma;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(x) - 128;   // (tl_dma_off's bias)
+    // N % 32 = 16: the upper half-wave of the last tile holds n' >= N (zero columns of R: its Y is 0 and belongs to nobody)
+    const bool nvalid = N % 32 == 0 || (h * NT * 16 + wq * 16) < N;
+
+    const int64_t blk_base = (int64_t)blockIdx.x * tpb;
+    const int blk_cnt = (int)(rows - blk_base < tpb ? (rows - blk_base < 0 ? 0 : rows - blk_base) : tpb);
+
+    // ---- once per workgroup: L image, control words, this wave's R fragments, first DMA ----
+    {
+        const uint4* lsrc = ws + NT * KS1 * 64;
+        for (int i = tid; i < G::LFR; i += THREADS) lfr[i] = lsrc[i];
+        if (tid < 8) ctl[tid] = tid == 3 ? GROUPS : 0;   // meeting counters, the next unclaimed token, (published claims)
+    }
+    const uint4* rsrc = ws + (size_t)wq * KS1 * 64;       // this wave's R fragments in the image (wave-uniform base)
+    constexpr int NRF = RS ? 1 : KS1, DR = 4;
+    f16x8 RF[NRF];
+    f16x8 RB[DR];
+    if (!RS) {
+#pragma unroll
+        for (int s = 0; s < NRF; ++s) RF[s] = __builtin_bit_cast(f16x8, rsrc[s * 64 + lane]);
+    }
+    __syncthreads();   // (the R fragments have arrived: vmcnt(0))
+    if (!RS) {
+#pragma unroll
+        for (int s = 0; s < NRF; ++s) asm volatile("" : "+v"(RF[s]));
+    }
+    // this wave's share of token k's DMA, four instructions per M0 / base pair; a partial last instruction runs with the lanes
+    // beyond the token masked off
+    auto stage_token = [&](int k) {
+        const unsigned char* src = xb + (blk_base + k) * tok_bytes + (int64_t)d0 * 1024;
+        const int nfull = own_tail ? dn - 1 : dn;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));   // (the offsets are recomputed here: hoisted, they are registers held across the GEMMs)
+        for (int g = 0; g < nfull; g += 4) {
+            unsigned rv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rv[j] = tl_dma_off<CPR>(d0 + g + j, ln);
+            dma_span(src + (int64_t)g * 1024, nfull - g < 4 ? nfull - g : 4, tok_lds + (unsigned)(d0 + g) * 1024, rv);
+        }
+        if (own_tail && lane < tail_lanes) {
+            const unsigned r1[4] = {tl_dma_off<CPR>(d0 + nfull, ln), 0u, 0u, 0u};
+            dma_span(src + (int64_t)nfull * 1024, 1, tok_lds + (unsigned)(d0 + nfull) * 1024, r1);
+        }
+    };
+    if (grp < blk_cnt && dn > 0) stage_token(grp);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto prime_r = [&]() {
+        if (RS) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+#pragma unroll
+            for (int i = 0; i < DR - 1; ++i) RB[i] = __builtin_bit_cast(f16x8, rsrc[i * 64 + ln]);
+        }
+    };
+    prime_r();
+
+    FqGroupCursor gcur;
+    const float ps = out.post_scale != 0.0f ? out.post_scale : 1.0f;
+    const int ks_n = (M + 15) >> 4;   // K-steps of GEMM 2 that hold rows of L
+    unsigned meet_n = 0;
+
+    for (int k = grp; k < blk_cnt;) {   // k: the group's current token (of this workgroup's range), claimed one token ahead
+        const int64_t tok = blk_base + k;
+
+        // ================= phase A: GEMM 1 (U = X . R for this wave's n'-tile), fp16 rounding =================
+        TILES_MEET()   // C|A: every wave of the group waited for its share of the DMA before its stores of phase C
+        f16x8 Uh[MT][2];
+        {
+            int cl = c;
+            asm volatile("" : "+v"(cl));   // keep the address arithmetic inside the loop
+            // rows of the last tile beyond the token read row M - 1 (finite; they meet zero rows of L)
+            const int rl = (MT - 1) * 32 + cl < M ? (MT - 1) * 32 + cl : M - 1;
+            const int swa = tl_swz<CPR>(cl), swl = tl_swz<CPR>(rl);   // (rows 32 mt + c rotate like row c)
+            const uint4* tb = reinterpret_cast<const uint4*>(tokbuf) + cl * CPR;
+            const uint4* tl = reinterpret_cast<const uint4*>(tokbuf) + rl * CPR;
+            auto afrag = [&](int i) -> f16x8 {   // i = s * MT + mt
+                const int s = i / MT, mt = i % MT;
+                return mt == MT - 1 ? __builtin_bit_cast(f16x8, tl[(s * 2 + h) ^ swl])
+                                    : __builtin_bit_cast(f16x8, tb[mt * 32 * CPR + ((s * 2 + h) ^ swa)]);
+            };
+            f32x16 U[MT];
+            constexpr int DA = RS ? 4 : (KS1 > 8 ? 4 : 8), NA = KS1 * MT;   // fragment reads in flight (x 4 VGPRs)
+            f16x8 A[DA];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) U[mt] = f32x16{0};
+#pragma unroll
+            for (int i = 0; i < DA - 1; ++i) A[i] = afrag(i);
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int s = i / MT;
+                if (RS && i % MT == 0 && s + DR - 1 < KS1) RB[(s + DR - 1) % DR] = __builtin_bit_cast(f16x8, rsrc[(s + DR - 1) * 64 + ln]);
+                if (i + DA - 1 < NA) A[(i + DA - 1) % DA] = afrag(i + DA - 1);
+                if (!(TILES_ABL & 2)) U[i % MT] = fq_mfma32<f16>(A[i % DA], RS ? RB[s % DR] : RF[RS ? 0 : s], U[i % MT]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) Uh[mt][p][j] = (f16)U[mt][p * 8 + j];
+        }
+
+        // ================= phase B: next token's DMA, GEMM 2 (Y^T = U^T . L), extrema =================
+        if (wq == 0 && lane == 0) tl_lds_write(ctl_lds + 16 + grp * 4, tl_lds_add_rtn(ctl_lds + 12, 1u));   // claim the group's next token
+        TILES_MEET()   // A|B: the group has read its token buffer
+        const int knext = __builtin_amdgcn_readfirstlane((int)tl_lds_read(ctl_lds + 16 + grp * 4));
+        const bool more = !(TILES_ABL & 16) && knext < blk_cnt && dn > 0;
+        if (more) stage_token(knext);
+        if (knext < blk_cnt) prime_r();   // (behind the DMA in the queue; first used after phase C's vmcnt(0))
+        f32x16 Y[MT];   // Y^T of tile (wq, mo): rows n' = h*NT*16 + wq*16 + r, col m' = 32 mo + c
+        {
+            int loff = lane;
+            asm volatile("" : "+v"(loff));
+            const uint4* mylfr = lfr + loff;
+            constexpr int DB = 2, NB = LKS * MT;
+            f16x8 B[DB];
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo) Y[mo] = f32x16{0};
+#pragma unroll
+            for (int i = 0; i < DB - 1; ++i) B[i] = __builtin_bit_cast(f16x8, mylfr[i * 64]);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {   // i = ks * MT + mo
+                const int ks = i / MT, mo = i % MT;
+                if (i + DB - 1 < NB) B[(i + DB - 1) % DB] = __builtin_bit_cast(f16x8, mylfr[(i + DB - 1) * 64]);
+                if (!(TILES_ABL & 4) && (ks < 2 * MT - 2 || ks < ks_n)) Y[mo] = fq_mfma32<f16>(Uh[ks >> 1][ks & 1], B[i % DB], Y[mo]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        float vmax = -INFINITY, vmin = INFINITY;
+        {
+            if (out.post_scale != 0.0f) {
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float p = Y[mo][r] * ps;
+                        asm volatile("" : "+v"(p));   // an fp32 VALUE (no fusion with a later rounding)
+                        Y[mo][r] = p;
+                    }
+            }
+            if (out.rt_flags & FQ_ROUND_Y_F16) {
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Y[mo][r] = (float)(f16)Y[mo][r];
+            }
+            float pmx[MT], pmn[MT];   // one independent max3 / min3 chain per tile
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo) {
+                const f32x16& t = Y[mo];
+                float a = FqMaxOp()(t[0], t[1]), b = FqMinOp()(t[0], t[1]);
+#pragma unroll
+                for (int r = 2; r < 16; r += 2) {
+                    a = fq_max3(a, t[r], t[r + 1]);
+                    b = fq_min3(b, t[r], t[r + 1]);
+                }
+                const bool ok = nvalid && (mo < MT - 1 || (mo * 32 + c) < M);   // (only the last row tile can hold padding rows)
+                pmx[mo] = ok ? a : -INFINITY;
+                pmn[mo] = ok ? b : INFINITY;
+            }
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo) {
+                vmax = fmaxf(vmax, pmx[mo]);
+                vmin = fminf(vmin, pmn[mo]);
+            }
+        }
+        vmax = fq_wave_max(vmax);
+        vmin = fq_wave_min(vmin);
+        if (lane == 0) {
+            red[wq] = vmax;
+            red[8 + wq] = vmin;
+        }
+
+        // ================= phase C: the token's extrema, scale, quantiser, pack, stores =================
+        TILES_MEET()   // B|C: the partial extrema are in LDS
+        {
+            float a = red[0], b = red[8];
+#pragma unroll
+            for (int w = 1; w < NT; ++w) {
+                a = fmaxf(a, red[w]);
+                b = fminf(b, red[8 + w]);
+            }
+            vmax = fq_uniform_f32(a);   // (wave-uniform by construction; told to the compiler: fq_kron_duo.hip)
+            vmin = fq_uniform_f32(b);
+        }
+        bool waited = false;
+        for (int ci = 0; ci < out.n_clips; ++ci) {
+            float sig_max, sig_min;
+            fq_token_sigs(out, ci, tok, gcur, sig_max, sig_min);
+            const float scale = fq_token_scale<0>(vmax, vmin, sig_max, sig_min, out.rt_flags);
+            const float inv = fq_uniform_f32(fq_fast_inv(scale));
+            const bool magic = fq_magic_ok(vmax, vmin, inv);
+            const bool clampq = fq_needs_clamp(vmax, vmin, inv);
+            uint2 pk[MT];
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo) {
+                if (TILES_ABL & 1) {
+                    pk[mo] = uint2{__builtin_bit_cast(uint32_t, Y[mo][0]), __builtin_bit_cast(uint32_t, Y[mo][8])};
+                } else {
+                    const f32x16& yv = Y[mo];
+                    unsigned long long d0m = ~0ull, d1m = ~0ull;
+                    pk[mo] = uint2{0u, 0u};
+                    if (magic) {
+                        const float ilo = fq_inv_lo(inv), ihi = fq_inv_hi(inv);
+                        if (clampq) {
+                            pk[mo].x = fq_quant8<true>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], inv, ilo, ihi, d0m);
+                            pk[mo].y = fq_quant8<true>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], inv, ilo, ihi, d1m);
+                        } else {
+                            pk[mo].x = fq_quant8<false>(yv[0], yv[1], yv[2], yv[3], yv[4], yv[5], yv[6], yv[7], inv, ilo, ihi, d0m);
+                            pk[mo].y = fq_quant8<false>(yv[8], yv[9], yv[10], yv[11], yv[12], yv[13], yv[14], yv[15], inv, ilo, ihi, d1m);
+                        }
+                    }
+                    if (d0m)   // rare: an ambiguous digit somewhere in the wave -> the true division for this dword
+                        pk[mo].x = fq_pack8(fq_qexact(yv[0], scale), fq_qexact(yv[1], scale), fq_qexact(yv[2], scale), fq_qexact(yv[3], scale),
+                                            fq_qexact(yv[4], scale), fq_qexact(yv[5], scale), fq_qexact(yv[6], scale), fq_qexact(yv[7], scale));
+                    if (d1m)
+                        pk[mo].y = fq_pack8(fq_qexact(yv[8], scale), fq_qexact(yv[9], scale), fq_qexact(yv[10], scale), fq_qexact(yv[11], scale),
+                                            fq_qexact(yv[12], scale), fq_qexact(yv[13], scale), fq_qexact(yv[14], scale), fq_qexact(yv[15], scale));
+                }
+            }
+            // the DMA of the group's next token (requested at the start of phase B) is waited for HERE, in front of the stores:
+            // the counter then only holds that request, and the stores are never waited for
+            if (!waited) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            waited = true;
+            if (!(TILES_ABL & 8)) {
+                uint8_t* qtok = out.q[ci] + tok * ((int64_t)M * (N / 2)) + (h * NT * 16 + wq * 16) / 2;
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo)
+                    if (nvalid && (mo * 32 + c) < M) *reinterpret_cast<uint2*>(qtok + (mo * 32 + c) * (N / 2)) = pk[mo];
+                if (wq == 0 && lane == 0) out.scale[ci][tok] = (f16)scale;
+            }
+        }
+        k = knext;
+    }
+}
+
+template <int MT, int NT, int N, int GROUPS, int LKS, bool RS>
+int launch_tiles(const f16* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
+    typedef TilesGeom<MT, NT, N, GROUPS, LKS> G;
+    static_assert(G::LDS <= 160 * 1024, "LDS budget");
+    int64_t blocks = (rows + GROUPS - 1) / GROUPS;
+    if (blocks > n_cu) blocks = n_cu;   // one persistent workgroup per CU
+    if (blocks < 1) blocks = 1;
+    const int64_t tpb = (rows + blocks - 1) / blocks;
+    hipLaunchKernelGGL((fq_kron_tiles_kernel<MT, NT, N, GROUPS, LKS, RS>), dim3((unsigned)blocks), dim3(G::THREADS), 0, stream, x, ws,
+                       rows, tpb, M, out);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// Returns -1000 when the shape / output set is not one this kernel covers (the caller goes on to the workgroup-per-token kernel).
+// ws: fragment workspace already filled by fq_kron_prepare_kernel (rfrag [NT][KS1][64], lfrag [2MT][MT][64]).
+int fq_launch_kron_tiles(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
+                         const FqQuantOut& out, int n_cu, hipStream_t stream) {
+    if (diag != nullptr || (out.rt_flags & FQ_GROUP128) || (flags & FQ_CT_MASK) != FQ_OUT_PACKED) return -1000;
+    const uint4* w = reinterpret_cast<const uint4*>(ws);
+    const int lks = (M + 15) >> 4;
+    if (N == 112 && M > 64 && M <= 96) {   // 80 x 112: three groups of four waves
+        return lks == 5 ? launch_tiles<3, 4, 112, 3, 5, false>(x, w, rows, M, out, n_cu, stream)
+                        : launch_tiles<3, 4, 112, 3, 6, false>(x, w, rows, M, out, n_cu, stream);
+    }
+    if (N == 144 && M > 96 && M <= 128) {  // 128 x 144: two groups of five waves
+        return lks == 7 ? launch_tiles<4, 5, 144, 2, 7, false>(x, w, rows, M, out, n_cu, stream)
+                        : launch_tiles<4, 5, 144, 2, 8, false>(x, w, rows, M, out, n_cu, stream);
+    }
+    if (N == 192 && M > 128 && M <= 144) { // 144 x 192: two groups of six waves, R streamed; 160 KB hold nine K-steps of L
+        return launch_tiles<5, 6, 192, 2, 9, true>(x, w, rows, M, out, n_cu, stream);
+    }
+    return -1000;
+}

@@ -1,0 +1,126 @@
+"""GPU parity for fq_kron_tiles_kernel (csrc/fq_kron_tiles.hip, round 4): packed-only launches of the factor pairs whose token is not
+four 32-column tiles wide — 80 x 112 (8960, Qwen2.5-1.5B ffn), 128 x 144 (18432, DeepSeek-V3 dense ffn), 144 x 192 (27648,
+Qwen2.5-32B ffn) and every M of the same tile counts (function_utils.py:11-21 pairs).
+
+It shares the fragment workspace and the quantiser helpers with the workgroup-per-token kernel; token staging (unpadded rows, a
+bank rotation per row pitch, row indices clamped instead of zero rows), the half-empty last n'-tile, the streamed R fragments, the
+meetings and the claims are its own. Every case is compared BIT FOR BIT with the workgroup-per-token kernel (a launch that also
+asks for the transform takes that one) and with the oracle's quantiser on that transform.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fq_oracle as O
+
+pytestmark = pytest.mark.gpu
+P, F, T, R16, NC0, Q16 = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
+SIG = (0.9820137619972229, 0.9820137619972229)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from flatquant_amd import ops as _ops
+    return _ops
+
+
+def make(M, N, rows, seed, spike=True):
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, M * N, generator=gen).half()
+    if spike and rows:
+        x[:, ::97] *= 20
+    L = (torch.randn(M, M, generator=gen) / M ** 0.5).half()
+    R = (torch.randn(N, N, generator=gen) / N ** 0.5).half()
+    return x.cuda(), L.cuda(), R.cuda()
+
+
+# (M, N): both K-step counts of every row-tile class, DMA tails (M * N / 8 % 64 != 0) and whole-instruction tokens
+PAIRS = [(80, 112), (66, 112), (96, 112), (88, 112), (128, 144), (98, 144), (112, 144), (100, 144), (126, 144),
+         (144, 192), (129, 192), (130, 192), (137, 192)]
+
+
+@pytest.mark.parametrize("M,N", PAIRS)
+@pytest.mark.parametrize("rows", [1, 2, 3, 7, 100, 777])
+def test_bit_equal_to_workgroup_kernel_and_oracle(ops, M, N, rows):
+    x, L, R = make(M, N, rows, M * 7 + N + rows)
+    sigs = [SIG, (0.9, 0.33), (1e-7, 1e-7)]     # magic-number route, clamp route, true-division route
+    both = ops.kron_quant(x, L, R, sigs, T | P | R16)           # workgroup-per-token kernel (asks for the transform too)
+    y16 = both.y.cpu().numpy().astype(np.float32)
+    multi = ops.kron_quant(x, L, R, sigs, P | R16)              # this kernel, three clip sets in one launch
+    for ci, sig in enumerate(sigs):
+        one = ops.kron_quant(x, L, R, [sig], P | R16)           # this kernel, one clip set
+        ref = O.quant_outputs(y16, sig[0], sig[1])
+        for o, k in ((one, 0), (multi, ci)):
+            assert torch.equal(o.q[k], both.q[ci]), (M, N, rows, sig)
+            assert torch.equal(o.scale[k], both.scale[ci]), (M, N, rows, sig)
+            assert np.array_equal(o.q[k].cpu().numpy(), ref["packed"]), (M, N, rows, sig)
+            assert np.array_equal(o.scale[k].cpu().numpy(), ref["scale16"]), (M, N, rows, sig)
+
+
+@pytest.mark.parametrize("M,N", [(80, 112), (128, 144), (144, 192)])
+@pytest.mark.parametrize("flags", [P | NC0, P, P | R16 | NC0])
+def test_flag_routes_bit_equal_to_workgroup_kernel(ops, M, N, flags):
+    """Path A / path B rounding and the no-clamp statistics: same bits as the kernel that also returns the transform. The
+    all-positive and all-negative tokens are where a padding lane's zero would show (the half-empty last tile at N = 112 / 144)."""
+    x, L, R = make(M, N, 333, 5)
+    x[3] = x[3].abs()
+    a = ops.kron_quant(x, L, R, [SIG], flags)
+    b = ops.kron_quant(x, L, R, [SIG], flags | T)
+    assert torch.equal(a.q[0], b.q[0]) and torch.equal(a.scale[0], b.scale[0])
+    # a transform whose values all have one sign: identity factors on a one-signed token
+    Li, Ri = torch.eye(M, device="cuda").half(), torch.eye(N, device="cuda").half()
+    for sgn in (1.0, -1.0):
+        xp = (x.abs() + 0.5) * sgn
+        a = ops.kron_quant(xp, Li, Ri, [SIG], flags)
+        b = ops.kron_quant(xp, Li, Ri, [SIG], flags | T)
+        assert torch.equal(a.q[0], b.q[0]) and torch.equal(a.scale[0], b.scale[0]), sgn
+
+
+@pytest.mark.parametrize("M,N,rows", [(80, 112, 16384), (128, 144, 8192), (144, 192, 8192)])
+def test_full_size_bit_equal_and_repeatable(ops, M, N, rows):
+    """Full-size launches: every token equals the workgroup-per-token kernel's, and ten launches in a row give the same bytes
+    (tokens are claimed dynamically: the schedule differs from launch to launch)."""
+    x, L, R = make(M, N, rows, 11)
+    ref = ops.kron_quant(x, L, R, [SIG], P | T | NC0)
+    q0, s0 = ref.q[0].clone(), ref.scale[0].clone()
+    del ref
+    for _ in range(10):
+        o = ops.kron_quant(x, L, R, [SIG], P | NC0)
+        assert torch.equal(o.q[0], q0) and torch.equal(o.scale[0], s0)
+
+
+@pytest.mark.parametrize("M,N", [(80, 112), (128, 144), (144, 192)])
+def test_grouped_launch(ops, M, N):
+    """Per-expert clip pairs (fq_kron_quant_grouped_f16) through this kernel: equal to one launch per group."""
+    x, L, R = make(M, N, 700, 17)
+    offs = torch.tensor([0, 0, 5, 5, 260, 699, 700], dtype=torch.int64, device="cuda")   # empty groups, a 1-token group
+    G = offs.numel() - 1
+    gen = torch.Generator().manual_seed(1)
+    smax = (0.5 + 0.5 * torch.rand(G, generator=gen)).cuda()
+    smin = (0.3 + 0.7 * torch.rand(G, generator=gen)).cuda()
+    o = ops.kron_quant_grouped(x, L, R, offs, smax, smin, P | NC0)
+    for g in range(G):
+        a, b = int(offs[g]), int(offs[g + 1])
+        if a == b:
+            continue
+        one = ops.kron_quant(x[a:b].contiguous(), L, R, [(float(smax[g]), float(smin[g]))], P | NC0)
+        assert torch.equal(o.q[0][a:b], one.q[0]) and torch.equal(o.scale[0][a:b], one.scale[0]), g
+
+
+def test_oracle_end_to_end_dyadic(ops):
+    """Dyadic factors and tokens (every product and sum exact in fp16 / fp32): the whole launch equals the oracle's path-A
+    transform + quantiser bit for bit, for each pair."""
+    for M, N in ((80, 112), (128, 144), (144, 192)):
+        gen = torch.Generator().manual_seed(M + N)
+        x = (torch.randint(-8, 9, (64, M * N), generator=gen).float() / 8).half()
+        L = torch.zeros(M, M)
+        R = torch.zeros(N, N)
+        L[torch.arange(M), torch.randperm(M, generator=gen)] = 1.0
+        L[torch.arange(M), torch.randperm(M, generator=gen)] += 0.5
+        R[torch.arange(N), torch.randperm(N, generator=gen)] = 1.0
+        R[torch.arange(N), torch.randperm(N, generator=gen)] -= 0.25
+        L, R = L.half(), R.half()
+        o = ops.kron_quant(x.cuda(), L.cuda(), R.cuda(), [SIG], P | R16)
+        ref = O.kron_quant(x.numpy(), L.numpy(), R.numpy(), SIG[0], SIG[1], round_y_f16=True)
+        assert np.array_equal(o.q[0].cpu().numpy(), ref["packed"]), (M, N)
+        assert np.array_equal(o.scale[0].cpu().numpy(), ref["scale16"]), (M, N)
