@@ -23,6 +23,9 @@
 
 namespace {
 
+#ifndef TALL_ASM_LOADS
+#define TALL_ASM_LOADS 1
+#endif
 #ifndef TALL_ABL
 #define TALL_ABL 0   // measurement builds: 1 = the first token's rows are reused (no loads after the first)
 #endif
@@ -57,6 +60,28 @@ __global__ __launch_bounds__(MT * 64) void fq_kron_tall_kernel(const f16* __rest
     }
     // this lane's row of the token: row 32 w + c, its K-half h of every K-step: 16 bytes at chunk 2 s + h of a 128-byte row
     const bool row_ok = (w * 32 + c) < M;
+#if TALL_ASM_LOADS
+    // (round 4) The next token's rows are requested by loads the compiler does not track, and waited for by an explicit vmcnt(0) IN
+    // FRONT OF the token's stores. With compiler-tracked loads the wait sat at the top of the loop, behind the stores of the previous
+    // token (vmcnt counts loads and stores in one queue, and the stores are conditional, so the compiler has to wait for 0): every
+    // token then waited for its predecessor's stores to be acknowledged — 1-2 us of a 6.6 us token period at 2.4 GHz and 1095 W.
+    // Rows below the token read row M - 1 instead of zeros (no select behind the load, which would copy a register the load has not
+    // written yet): a padding row of U holds finite copies and meets zero rows of L in GEMM 2.
+    const int row_ld = row_ok ? w * 32 + c : M - 1;
+    const int64_t lane_off = (int64_t)row_ld * N + h * 8;   // in elements
+    auto fetch = [&](int64_t tok, f16x8 (&A)[KS1]) {
+        const f16* p = x + tok * d + lane_off;
+        asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                     "global_load_dwordx4 %1, %4, off offset:32\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:64\n\t"
+                     "global_load_dwordx4 %3, %4, off offset:96"
+                     : "=&v"(A[0]), "=&v"(A[1]), "=&v"(A[2]), "=&v"(A[3]) : "v"(p) : "memory");
+    };
+    static_assert(KS1 == 4, "fetch issues four loads");
+// (the builtin, not inline asm: the compiler's own wait insertion sees it — it then knows that the fragment loads of the prologue
+//  are complete as well, and places no vmcnt wait of its own inside the loop; 0x0F70 = vmcnt(0), expcnt and lgkmcnt unconstrained)
+#define FQ_TALL_WAIT_ROWS() { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); }
+#else
     const int64_t lane_off = (int64_t)(w * 32 + c) * N + h * 8;   // in elements
     auto fetch = [&](int64_t tok, f16x8 (&A)[KS1]) {
         const f16* p = x + tok * d + lane_off;
@@ -66,12 +91,20 @@ __global__ __launch_bounds__(MT * 64) void fq_kron_tall_kernel(const f16* __rest
             else A[s] = f16x8{0};
         }
     };
+#define FQ_TALL_WAIT_ROWS()
+#endif
     const float ps = out.post_scale != 0.0f ? out.post_scale : 1.0f;
     FqGroupCursor gcur;
 
     f16x8 A[KS1];
     int64_t tok = blockIdx.x;
+#if TALL_ASM_LOADS
+    fetch(tok, A);   // (blockIdx.x < rows: the launcher starts at most one workgroup per token. Unconditional on purpose — a branch
+                     //  round the untracked loads makes A a phi, and a phi is a register COPY that may run before the data has arrived)
+#else
     if (tok < rows) fetch(tok, A);
+#endif
+    FQ_TALL_WAIT_ROWS();
     for (int it = 0; tok < rows; tok += gridDim.x, ++it) {
         const int buf = it & 1;
         // ================= GEMM 1: this wave's 32 rows against R, both n'-tiles =================
@@ -86,7 +119,11 @@ __global__ __launch_bounds__(MT * 64) void fq_kron_tall_kernel(const f16* __rest
             // the next token's rows: in flight under everything below. (Two tokens ahead measured no faster — 140 x 64: 206 vs
             // 202 us — and a build that re-uses the first token's rows only runs faster because identical data draws less power.)
             const int64_t nxt = tok + gridDim.x;
+#if TALL_ASM_LOADS
+            fetch(nxt < rows && !(TALL_ABL & 1) ? nxt : tok, A);   // (the last token re-reads itself: no branch round the loads, see above)
+#else
             if (nxt < rows && !(TALL_ABL & 1)) fetch(nxt, A);
+#endif
         }
         // U rounded to fp16: the C fragment of GEMM 1 is the A fragment of GEMM 2 (K-steps 2 w and 2 w + 1) — published
 #pragma unroll
@@ -171,6 +208,7 @@ __global__ __launch_bounds__(MT * 64) void fq_kron_tall_kernel(const f16* __rest
                 vmin = b;
             }
         }
+        FQ_TALL_WAIT_ROWS();   // the next token's rows have had GEMM 2 and the extrema to arrive; nothing waits for the stores below
         if (YOUT && row_ok) {   // the transformed activation as well (the launch the parity tests read; kronecker_matmul + quant)
             f16* yrow = out.y + tok * d + (int64_t)(w * 32 + c) * N + h * 32;   // n' = h*32 + nt*16 + r: 16 consecutive values per tile
 #pragma unroll

@@ -22,6 +22,16 @@
 
 namespace {
 
+// measurement knobs (tools/variants.sh): groups of the 80 x 112 launch, A fragments in flight, streamed R at N = 144
+#ifndef TILES_G112
+#define TILES_G112 4   // (measured: 3 groups 113 us, 4 groups 107.5 us per 16384 tokens of 80 x 112; 121-127 VGPRs with four A fragments in flight)
+#endif
+#ifndef TILES_DA
+#define TILES_DA 0   // 0: the per-geometry default below
+#endif
+#ifndef TILES_RS144
+#define TILES_RS144 false
+#endif
 #ifndef TILES_ABL
 #define TILES_ABL 0   // measurement builds: 1 no quantiser, 2 no GEMM 1, 4 no GEMM 2, 8 no stores, 16 no DMA after the first
 #endif
@@ -41,9 +51,9 @@ struct TilesGeom {
     static constexpr int LFR = LKS * MT * 64;                 // uint4: the K-steps of the L image that hold rows of L
     static constexpr int TOKBUF = LKS * 16 * CPR * 16;        // bytes: 16 LKS >= M rows
     static constexpr int RED = LFR * 16 + GROUPS * TOKBUF;    // [max x8][min x8] floats per group
-    static constexpr int CTL = RED + GROUPS * 64;             // [meet x3][next][claim x3]
-    static constexpr int LDS = CTL + 32;
-    static_assert(N % 16 == 0 && NT == (N + 31) / 32 && LKS <= 2 * MT && LKS > 2 * MT - 2 && GROUPS <= 3 && NT <= 8, "geometry");
+    static constexpr int CTL = RED + GROUPS * 64;             // [meet x4][next][claim x4]
+    static constexpr int LDS = CTL + 48;
+    static_assert(N % 16 == 0 && NT == (N + 31) / 32 && LKS <= 2 * MT && LKS > 2 * MT - 2 && GROUPS <= 4 && NT <= 8, "geometry");
 };
 
 __device__ __forceinline__ unsigned tl_lds_read(unsigned addr) {
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const f
     {
         const uint4* lsrc = ws + NT * KS1 * 64;
         for (int i = tid; i < G::LFR; i += THREADS) lfr[i] = lsrc[i];
-        if (tid < 8) ctl[tid] = tid == 3 ? GROUPS : 0;   // meeting counters, the next unclaimed token, (published claims)
+        if (tid < 12) ctl[tid] = tid == 4 ? GROUPS : 0;   // meeting counters, the next unclaimed token, (published claims)
     }
     const uint4* rsrc = ws + (size_t)wq * KS1 * 64;       // this wave's R fragments in the image (wave-uniform base)
     constexpr int NRF = RS ? 1 : KS1, DR = 4;
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const f
                                     : __builtin_bit_cast(f16x8, tb[mt * 32 * CPR + ((s * 2 + h) ^ swa)]);
             };
             f32x16 U[MT];
-            constexpr int DA = RS ? 4 : (KS1 > 8 ? 4 : 8), NA = KS1 * MT;   // fragment reads in flight (x 4 VGPRs)
+            constexpr int DA = TILES_DA ? TILES_DA : RS ? 4 : (KS1 > 8 || GROUPS == 4 ? 4 : 8), NA = KS1 * MT;   // fragment reads in flight (x 4 VGPRs)
             f16x8 A[DA];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) U[mt] = f32x16{0};
@@ -209,9 +219,9 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const f
         }
 
         // ================= phase B: next token's DMA, GEMM 2 (Y^T = U^T . L), extrema =================
-        if (wq == 0 && lane == 0) tl_lds_write(ctl_lds + 16 + grp * 4, tl_lds_add_rtn(ctl_lds + 12, 1u));   // claim the group's next token
+        if (wq == 0 && lane == 0) tl_lds_write(ctl_lds + 20 + grp * 4, tl_lds_add_rtn(ctl_lds + 16, 1u));   // claim the group's next token
         TILES_MEET()   // A|B: the group has read its token buffer
-        const int knext = __builtin_amdgcn_readfirstlane((int)tl_lds_read(ctl_lds + 16 + grp * 4));
+        const int knext = __builtin_amdgcn_readfirstlane((int)tl_lds_read(ctl_lds + 20 + grp * 4));
         const bool more = !(TILES_ABL & 16) && knext < blk_cnt && dn > 0;
         if (more) stage_token(knext);
         if (knext < blk_cnt) prime_r();   // (behind the DMA in the queue; first used after phase C's vmcnt(0))
@@ -364,13 +374,13 @@ int fq_launch_kron_tiles(int flags, const f16* x, const void* ws, const f16* dia
     if (diag != nullptr || (out.rt_flags & FQ_GROUP128) || (flags & FQ_CT_MASK) != FQ_OUT_PACKED) return -1000;
     const uint4* w = reinterpret_cast<const uint4*>(ws);
     const int lks = (M + 15) >> 4;
-    if (N == 112 && M > 64 && M <= 96) {   // 80 x 112: three groups of four waves
-        return lks == 5 ? launch_tiles<3, 4, 112, 3, 5, false>(x, w, rows, M, out, n_cu, stream)
-                        : launch_tiles<3, 4, 112, 3, 6, false>(x, w, rows, M, out, n_cu, stream);
+    if (N == 112 && M > 64 && M <= 96) {   // 80 x 112: four groups of four waves
+        return lks == 5 ? launch_tiles<3, 4, 112, TILES_G112, 5, false>(x, w, rows, M, out, n_cu, stream)
+                        : launch_tiles<3, 4, 112, TILES_G112, 6, false>(x, w, rows, M, out, n_cu, stream);
     }
     if (N == 144 && M > 96 && M <= 128) {  // 128 x 144: two groups of five waves
-        return lks == 7 ? launch_tiles<4, 5, 144, 2, 7, false>(x, w, rows, M, out, n_cu, stream)
-                        : launch_tiles<4, 5, 144, 2, 8, false>(x, w, rows, M, out, n_cu, stream);
+        return lks == 7 ? launch_tiles<4, 5, 144, 2, 7, TILES_RS144>(x, w, rows, M, out, n_cu, stream)
+                        : launch_tiles<4, 5, 144, 2, 8, TILES_RS144>(x, w, rows, M, out, n_cu, stream);
     }
     if (N == 192 && M > 128 && M <= 144) { // 144 x 192: two groups of six waves, R streamed; 160 KB hold nine K-steps of L
         return launch_tiles<5, 6, 192, 2, 9, true>(x, w, rows, M, out, n_cu, stream);

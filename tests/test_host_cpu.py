@@ -399,6 +399,28 @@ def test_oracle_kv_quant_vs_reference_golden(golden):
     assert np.array_equal(O.kv_transform(g["x"], g["T"]).view(np.uint16), g["xT"].view(np.uint16))
 
 
+def test_untracked_row_loads_are_not_read_before_their_wait(tmp_path):
+    """fq_kron_tall.hip requests the next token's rows with loads the compiler does not track (so that no wait lands behind the
+    previous token's stores) and waits for them explicitly. The ISA of every instantiation is checked: between such a load and the
+    next s_waitcnt vmcnt(0) nothing reads or copies the destination registers (tools/check_untracked_loads.py). A phi, a spill or
+    an AGPR move there would silently use stale data — round 4's first build had exactly that (a v_mov behind the prologue loads)."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asm = str(tmp_path / "tall.s")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm",
+                    "-amdgpu-kernarg-preload-count=16", "-S", "--cuda-device-only", "-o", asm,
+                    os.path.join(root, "flatquant_amd", "csrc", "fq_kron_tall.hip")], check=True, capture_output=True, timeout=600)
+    assert "global_load_dwordx4" in open(asm).read()
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_untracked_loads.py"), asm, "tall_kernel"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+
+
 def test_hot_kernels_keep_their_occupancy_budget():
     """The compiler's per-kernel resource reports (flatquant_amd/csrc/build/*.res, written by the Makefile's
     -Rpass-analysis=kernel-resource-usage) against the occupancy each hot kernel was tuned at. A source change that makes the
