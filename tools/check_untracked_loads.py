@@ -27,7 +27,7 @@ for i, l in enumerate(src):
         continue
     if not t or t.startswith((";", ".")):
         continue
-    m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\]", t)
+    m = re.match(r"global_load_dwordx[24] v\[(\d+):(\d+)\]", t)
     if in_asm and m:
         for r in range(int(m.group(1)), int(m.group(2)) + 1):
             pending[r] = i
