@@ -148,16 +148,16 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
     // workgroup-per-token kernel's all-output-sets instantiations (the transform rounded to the activation dtype)
     const bool g128 = (out.rt_flags & FQ_GROUP128) != 0;
     if (g128 && (!(flags & FQ_ROUND_Y_F16) || !spec)) return -1000;
+    if (!g128 && spec && !fq_measure_env("FQ_KRON_NO_TILES")) { // 80 x 112, 86 x 128, 128 x 144, 144 x 192 (round 4): token groups of NT waves
+        rc = fq_launch_kron_tiles(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
+        if (rc != -1000) return rc;
+    }
     if (!g128 && spec && !fq_measure_env("FQ_KRON_NO_TRIO")) {  // 64 < M <= 128, N = 128, packed output: three token groups one phase apart
         rc = fq_launch_kron_trio(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }
     if (!g128 && spec && !fq_measure_env("FQ_KRON_NO_DUO")) {   // 96 < M <= 128, N = 224, packed output: two token groups per CU
         rc = fq_launch_kron_duo(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
-        if (rc != -1000) return rc;
-    }
-    if (!g128 && spec && !fq_measure_env("FQ_KRON_NO_TILES")) { // 80 x 112, 128 x 144, 144 x 192 (round 4): token groups of NT waves
-        rc = fq_launch_kron_tiles(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }
     if (!g128 && spec && !fq_measure_env("FQ_KRON_NO_TALL")) {  // 64 < M <= 192, N = 64, packed output: a wave per ROW tile (172 x 64: Hadamard 11008)

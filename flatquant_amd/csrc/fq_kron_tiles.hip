@@ -91,10 +91,11 @@ __device__ __forceinline__ unsigned tl_dma_off(int i, int lane) {
     return (unsigned)((lane + ((pch ^ tl_swz<CPR>(r)) - pch)) * 16 + 128);
 }
 
-template <int MT, int NT, int N, int GROUPS, int LKS, bool RS>
-__global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
+template <int MT, int NT, int N, int GROUPS, int LKS, bool RS, typename T>
+__global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T* __restrict__ x, const uint4* __restrict__ ws,
                                                                        int64_t rows, int64_t tpb, int M, FqQuantOut out) {
     typedef TilesGeom<MT, NT, N, GROUPS, LKS> G;
+    typedef typename FqVec<T>::x8 X8;
     constexpr int KS1 = G::KS1, CPR = G::CPR, THREADS = G::THREADS;
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
@@ -128,11 +129,11 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const f
     }
     const uint4* rsrc = ws + (size_t)wq * KS1 * 64;       // this wave's R fragments in the image (wave-uniform base)
     constexpr int NRF = RS ? 1 : KS1, DR = 4;
-    f16x8 RF[NRF];
-    f16x8 RB[DR];
+    X8 RF[NRF];
+    X8 RB[DR];
     if (!RS) {
 #pragma unroll
-        for (int s = 0; s < NRF; ++s) RF[s] = __builtin_bit_cast(f16x8, rsrc[s * 64 + lane]);
+        for (int s = 0; s < NRF; ++s) RF[s] = __builtin_bit_cast(X8, rsrc[s * 64 + lane]);
     }
     __syncthreads();   // (the R fragments have arrived: vmcnt(0))
     if (!RS) {
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const f
             int ln = lane;
             asm volatile("" : "+v"(ln));
 #pragma unroll
-            for (int i = 0; i < DR - 1; ++i) RB[i] = __builtin_bit_cast(f16x8, rsrc[i * 64 + ln]);
+            for (int i = 0; i < DR - 1; ++i) RB[i] = __builtin_bit_cast(X8, rsrc[i * 64 + ln]);
         }
     };
     prime_r();
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const f
 
         // ================= phase A: GEMM 1 (U = X . R for this wave's n'-tile), fp16 rounding =================
         TILES_MEET()   // C|A: every wave of the group waited for its share of the DMA before its stores of phase C
-        f16x8 Uh[MT][2];
+        X8 Uh[MT][2];
         {
             int cl = c;
             asm volatile("" : "+v"(cl));   // keep the address arithmetic inside the loop
@@ -188,14 +189,14 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const f
             const int swa = tl_swz<CPR>(cl), swl = tl_swz<CPR>(rl);   // (rows 32 mt + c rotate like row c)
             const uint4* tb = reinterpret_cast<const uint4*>(tokbuf) + cl * CPR;
             const uint4* tl = reinterpret_cast<const uint4*>(tokbuf) + rl * CPR;
-            auto afrag = [&](int i) -> f16x8 {   // i = s * MT + mt
+            auto afrag = [&](int i) -> X8 {   // i = s * MT + mt
                 const int s = i / MT, mt = i % MT;
-                return mt == MT - 1 ? __builtin_bit_cast(f16x8, tl[(s * 2 + h) ^ swl])
-                                    : __builtin_bit_cast(f16x8, tb[mt * 32 * CPR + ((s * 2 + h) ^ swa)]);
+                return mt == MT - 1 ? __builtin_bit_cast(X8, tl[(s * 2 + h) ^ swl])
+                                    : __builtin_bit_cast(X8, tb[mt * 32 * CPR + ((s * 2 + h) ^ swa)]);
             };
             f32x16 U[MT];
             constexpr int DA = TILES_DA ? TILES_DA : RS ? 4 : (KS1 > 8 || GROUPS == 4 ? 4 : 8), NA = KS1 * MT;   // fragment reads in flight (x 4 VGPRs)
-            f16x8 A[DA];
+            X8 A[DA];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) U[mt] = f32x16{0};
 #pragma unroll
@@ -205,9 +206,9 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const f
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int s = i / MT;
-                if (RS && i % MT == 0 && s + DR - 1 < KS1) RB[(s + DR - 1) % DR] = __builtin_bit_cast(f16x8, rsrc[(s + DR - 1) * 64 + ln]);
+                if (RS && i % MT == 0 && s + DR - 1 < KS1) RB[(s + DR - 1) % DR] = __builtin_bit_cast(X8, rsrc[(s + DR - 1) * 64 + ln]);
                 if (i + DA - 1 < NA) A[(i + DA - 1) % DA] = afrag(i + DA - 1);
-                if (!(TILES_ABL & 2)) U[i % MT] = fq_mfma32<f16>(A[i % DA], RS ? RB[s % DR] : RF[RS ? 0 : s], U[i % MT]);
+                if (!(TILES_ABL & 2)) U[i % MT] = fq_mfma32<T>(A[i % DA], RS ? RB[s % DR] : RF[RS ? 0 : s], U[i % MT]);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const f
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) Uh[mt][p][j] = (f16)U[mt][p * 8 + j];
+                    for (int j = 0; j < 8; ++j) Uh[mt][p][j] = (T)U[mt][p * 8 + j];
         }
 
         // ================= phase B: next token's DMA, GEMM 2 (Y^T = U^T . L), extrema =================
@@ -231,16 +232,16 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const f
             asm volatile("" : "+v"(loff));
             const uint4* mylfr = lfr + loff;
             constexpr int DB = 2, NB = LKS * MT;
-            f16x8 B[DB];
+            X8 B[DB];
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo) Y[mo] = f32x16{0};
 #pragma unroll
-            for (int i = 0; i < DB - 1; ++i) B[i] = __builtin_bit_cast(f16x8, mylfr[i * 64]);
+            for (int i = 0; i < DB - 1; ++i) B[i] = __builtin_bit_cast(X8, mylfr[i * 64]);
 #pragma unroll
             for (int i = 0; i < NB; ++i) {   // i = ks * MT + mo
                 const int ks = i / MT, mo = i % MT;
-                if (i + DB - 1 < NB) B[(i + DB - 1) % DB] = __builtin_bit_cast(f16x8, mylfr[(i + DB - 1) * 64]);
-                if (!(TILES_ABL & 4) && (ks < 2 * MT - 2 || ks < ks_n)) Y[mo] = fq_mfma32<f16>(Uh[ks >> 1][ks & 1], B[i % DB], Y[mo]);
+                if (i + DB - 1 < NB) B[(i + DB - 1) % DB] = __builtin_bit_cast(X8, mylfr[(i + DB - 1) * 64]);
+                if (!(TILES_ABL & 4) && (ks < 2 * MT - 2 || ks < ks_n)) Y[mo] = fq_mfma32<T>(Uh[ks >> 1][ks & 1], B[i % DB], Y[mo]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const f
 #pragma unroll
                 for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Y[mo][r] = (float)(f16)Y[mo][r];
+                    for (int r = 0; r < 16; ++r) Y[mo][r] = (float)(T)Y[mo][r];
             }
             float pmx[MT], pmn[MT];   // one independent max3 / min3 chain per tile
 #pragma unroll
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const f
         for (int ci = 0; ci < out.n_clips; ++ci) {
             float sig_max, sig_min;
             fq_token_sigs(out, ci, tok, gcur, sig_max, sig_min);
-            const float scale = fq_token_scale<0>(vmax, vmin, sig_max, sig_min, out.rt_flags);
+            const float scale = fq_token_scale<0, T>(vmax, vmin, sig_max, sig_min, out.rt_flags);
             const float inv = fq_uniform_f32(fq_fast_inv(scale));
             const bool magic = fq_magic_ok(vmax, vmin, inv);
             const bool clampq = fq_needs_clamp(vmax, vmin, inv);
@@ -345,45 +346,62 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const f
 #pragma unroll
                 for (int mo = 0; mo < MT; ++mo)
                     if (nvalid && (mo * 32 + c) < M) *reinterpret_cast<uint2*>(qtok + (mo * 32 + c) * (N / 2)) = pk[mo];
-                if (wq == 0 && lane == 0) out.scale[ci][tok] = (f16)scale;
+                if (wq == 0 && lane == 0) reinterpret_cast<T*>(out.scale[ci])[tok] = (T)scale;
             }
         }
         k = knext;
     }
 }
 
-template <int MT, int NT, int N, int GROUPS, int LKS, bool RS>
-int launch_tiles(const f16* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
+template <int MT, int NT, int N, int GROUPS, int LKS, bool RS, typename T>
+int launch_tiles_t(const T* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
     typedef TilesGeom<MT, NT, N, GROUPS, LKS> G;
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
     int64_t blocks = (rows + GROUPS - 1) / GROUPS;
     if (blocks > n_cu) blocks = n_cu;   // one persistent workgroup per CU
     if (blocks < 1) blocks = 1;
     const int64_t tpb = (rows + blocks - 1) / blocks;
-    hipLaunchKernelGGL((fq_kron_tiles_kernel<MT, NT, N, GROUPS, LKS, RS>), dim3((unsigned)blocks), dim3(G::THREADS), 0, stream, x, ws,
+    hipLaunchKernelGGL((fq_kron_tiles_kernel<MT, NT, N, GROUPS, LKS, RS, T>), dim3((unsigned)blocks), dim3(G::THREADS), 0, stream, x, ws,
                        rows, tpb, M, out);
     return (int)hipGetLastError();
+}
+template <int MT, int NT, int N, int GROUPS, int LKS, bool RS>
+int launch_tiles(bool is_bf16, const f16* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
+    return is_bf16 ? launch_tiles_t<MT, NT, N, GROUPS, LKS, RS, bf16>((const bf16*)x, ws, rows, M, out, n_cu, stream)
+                   : launch_tiles_t<MT, NT, N, GROUPS, LKS, RS, f16>(x, ws, rows, M, out, n_cu, stream);
 }
 
 }  // namespace
 
 // Returns -1000 when the shape / output set is not one this kernel covers (the caller goes on to the workgroup-per-token kernel).
 // ws: fragment workspace already filled by fq_kron_prepare_kernel (rfrag [NT][KS1][64], lfrag [2MT][MT][64]).
+// flags & FQ_DT_BF16: bf16 activations and factors (the same geometry; bf16 MFMA and rounding points). On bf16 this kernel also takes
+// N = 128 (112 x 128, 86 x 128: fq_kron_trio.hip is fp16-only) — three groups of four waves, as there.
 int fq_launch_kron_tiles(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
                          const FqQuantOut& out, int n_cu, hipStream_t stream) {
+    const bool b = (flags & FQ_DT_BF16) != 0;
+    flags &= ~FQ_DT_BF16;
     if (diag != nullptr || (out.rt_flags & FQ_GROUP128) || (flags & FQ_CT_MASK) != FQ_OUT_PACKED) return -1000;
     const uint4* w = reinterpret_cast<const uint4*>(ws);
     const int lks = (M + 15) >> 4;
     if (N == 112 && M > 64 && M <= 96) {   // 80 x 112: four groups of four waves
-        return lks == 5 ? launch_tiles<3, 4, 112, TILES_G112, 5, false>(x, w, rows, M, out, n_cu, stream)
-                        : launch_tiles<3, 4, 112, TILES_G112, 6, false>(x, w, rows, M, out, n_cu, stream);
+        return lks == 5 ? launch_tiles<3, 4, 112, TILES_G112, 5, false>(b, x, w, rows, M, out, n_cu, stream)
+                        : launch_tiles<3, 4, 112, TILES_G112, 6, false>(b, x, w, rows, M, out, n_cu, stream);
     }
     if (N == 144 && M > 96 && M <= 128) {  // 128 x 144: two groups of five waves
-        return lks == 7 ? launch_tiles<4, 5, 144, 2, 7, TILES_RS144>(x, w, rows, M, out, n_cu, stream)
-                        : launch_tiles<4, 5, 144, 2, 8, TILES_RS144>(x, w, rows, M, out, n_cu, stream);
+        return lks == 7 ? launch_tiles<4, 5, 144, 2, 7, TILES_RS144>(b, x, w, rows, M, out, n_cu, stream)
+                        : launch_tiles<4, 5, 144, 2, 8, TILES_RS144>(b, x, w, rows, M, out, n_cu, stream);
     }
     if (N == 192 && M > 128 && M <= 144) { // 144 x 192: two groups of six waves, R streamed; 160 KB hold nine K-steps of L
-        return launch_tiles<5, 6, 192, 2, 9, true>(x, w, rows, M, out, n_cu, stream);
+        return launch_tiles<5, 6, 192, 2, 9, true>(b, x, w, rows, M, out, n_cu, stream);
+    }
+    if (N == 128 && M > 64 && M <= 96) {    // 86 x 128 (11008, Llama-2-7B ffn), fp16 and bf16: 123 us where fq_kron_trio.hip's MT = 3 build takes 145
+        return lks == 5 ? launch_tiles<3, 4, 128, 3, 5, false>(b, x, w, rows, M, out, n_cu, stream)
+                        : launch_tiles<3, 4, 128, 3, 6, false>(b, x, w, rows, M, out, n_cu, stream);
+    }
+    if (b && N == 128 && M > 96 && M <= 128) {   // bf16 112 x 128: three groups of four waves (fp16: fq_kron_trio.hip, the same speed)
+        return lks == 7 ? launch_tiles_t<4, 4, 128, 3, 7, false, bf16>((const bf16*)x, w, rows, M, out, n_cu, stream)
+                        : launch_tiles_t<4, 4, 128, 3, 8, false, bf16>((const bf16*)x, w, rows, M, out, n_cu, stream);
     }
     return -1000;
 }

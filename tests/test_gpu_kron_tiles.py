@@ -36,7 +36,7 @@ def make(M, N, rows, seed, spike=True):
 
 # (M, N): both K-step counts of every row-tile class, DMA tails (M * N / 8 % 64 != 0) and whole-instruction tokens
 PAIRS = [(80, 112), (66, 112), (96, 112), (88, 112), (128, 144), (98, 144), (112, 144), (100, 144), (126, 144),
-         (144, 192), (129, 192), (130, 192), (137, 192)]
+         (144, 192), (129, 192), (130, 192), (137, 192), (86, 128), (66, 128), (96, 128)]
 
 
 @pytest.mark.parametrize("M,N", PAIRS)
@@ -124,3 +124,50 @@ def test_oracle_end_to_end_dyadic(ops):
         ref = O.kron_quant(x.numpy(), L.numpy(), R.numpy(), SIG[0], SIG[1], round_y_f16=True)
         assert np.array_equal(o.q[0].cpu().numpy(), ref["packed"]), (M, N)
         assert np.array_equal(o.scale[0].cpu().numpy(), ref["scale16"]), (M, N)
+
+
+def _bits(t):
+    return t.view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("M,N", [(80, 112), (128, 144), (112, 144), (144, 192), (130, 192), (112, 128), (86, 128), (128, 128), (100, 128)])
+@pytest.mark.parametrize("rows", [1, 7, 300])
+def test_bf16_packed_only_launches(ops, M, N, rows):
+    """bf16 activations and factors (the DeepSeek-V3 flow runs under torch.set_default_dtype(bfloat16), main_dpskv3.py:395; 18432 =
+    128 x 144 is its dense ffn): the same kernel with bf16 MFMA and bf16 rounding points — and, on bf16, the N = 128 pairs as well
+    (fq_kron_trio.hip is fp16-only). Bit-equal, clip set by clip set and flag route by flag route, to the launch that also returns
+    the transform (the workgroup-per-token kernel), and to the oracle's bf16 quantiser on that transform."""
+    BF = torch.bfloat16
+    gen = torch.Generator().manual_seed(M * 131 + N + rows)
+    x = torch.randn(rows, M * N, generator=gen)
+    x[:, ::97] *= 20
+    x = x.to(BF).cuda()
+    L = (torch.randn(M, M, generator=gen) / M ** 0.5).to(BF).cuda()
+    R = (torch.randn(N, N, generator=gen) / N ** 0.5).to(BF).cuda()
+    sigs = [SIG, (0.9, 0.33), (1e-7, 1e-7)]   # magic-number, clamp, true-division routes
+    for flags in (P | NC0, P, P | R16 | NC0):
+        both = ops.kron_quant(x, L, R, sigs, flags | T)
+        multi = ops.kron_quant(x, L, R, sigs, flags)
+        for ci, sig in enumerate(sigs):
+            one = ops.kron_quant(x, L, R, [sig], flags)
+            for o, k in ((one, 0), (multi, ci)):
+                assert torch.equal(o.q[k], both.q[ci]), (M, N, rows, flags, sig)
+                assert np.array_equal(_bits(o.scale[k]), _bits(both.scale[ci])), (M, N, rows, flags, sig)
+        if flags & R16:   # the quantiser saw exactly the bf16 transform the other launch returned
+            ref = O.quant_outputs(O.bf16_from_bits(_bits(both.y)), *sigs[0], round_y_f16=True, clamp0=not (flags & NC0), lowp="bf16")
+            assert np.array_equal(multi.q[0].cpu().numpy(), ref["packed"])
+
+
+def test_bf16_full_size_repeatable(ops):
+    """DeepSeek-V3's dense ffn pair at full size on bf16: equal to the workgroup-per-token kernel on every token, and repeatable."""
+    BF = torch.bfloat16
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(8192, 128 * 144, generator=gen).to(BF).cuda()
+    L = (torch.randn(128, 128, generator=gen) / 128 ** 0.5).to(BF).cuda()
+    R = (torch.randn(144, 144, generator=gen) / 12.0).to(BF).cuda()
+    ref = ops.kron_quant(x, L, R, [SIG], P | T | NC0)
+    q0, s0 = ref.q[0].clone(), ref.scale[0].clone()
+    del ref
+    for _ in range(5):
+        o = ops.kron_quant(x, L, R, [SIG], P | NC0)
+        assert torch.equal(o.q[0], q0) and np.array_equal(_bits(o.scale[0]), _bits(s0))

@@ -445,7 +445,14 @@ def test_hot_kernels_keep_their_occupancy_budget():
         "fq_kron_wave_kernel<1,2,4,16,0,f16>": (4, 0),          # 32 x 64 (grouped MoE launch)
         "fq_kron_trio_kernel<4,0,0>": (3, 0),             # 112 x 128 packed
         "fq_kron_trio_kernel<4,1,0>": (3, 0),             # ... fp16 quantiser (Hadamard 14336 + Quantizer)
-        "fq_kron_trio_kernel<3,0,1>": (3, 0),             # 86 x 128
+        "fq_kron_trio_kernel<3,0,1>": (3, 0),             # 86 x 128 (round 4: packed launches of M <= 96 run fq_kron_tiles_kernel)
+        "fq_kron_tiles_kernel<3,4,128,3,6,0,f16>": (3, 0),     # 86 x 128 (Llama-2-7B ffn), round 4
+        "fq_kron_tiles_kernel<3,4,112,4,5,0,f16>": (4, 0),     # 80 x 112: four token groups of four waves
+        "fq_kron_tiles_kernel<4,5,144,2,8,0,f16>": (3, 0),     # 128 x 144 (DeepSeek-V3 dense ffn)
+        "fq_kron_tiles_kernel<4,5,144,2,8,0,bf16>": (3, 0),
+        "fq_kron_tiles_kernel<5,6,192,2,9,1,f16>": (3, 0),     # 144 x 192, R streamed
+        "fq_kron_tiles_kernel<4,4,128,3,7,0,bf16>": (3, 0),    # bf16 112 x 128
+        "fq_kron_tall_kernel<6,1,0>": (3, 0),                   # Hadamard 11008 + Quantizer
         "fq_kron_wave_kernel<2,3,5,12,0,f16>": (3, 0),          # 64 x 80, 12 waves per CU
         "fq_kron_wave_kernel<2,4,8,7,1,f16>": (2, 0),         # 64 x 128 with the RMSNorm fused in front (C4's q/k/v and up/gate)
         "fq_kron_wave_kernel<2,4,7,8,1,f16>": (2, 0),         # 64 x 112 ... (DeepSeek-V3 hidden)
