@@ -36,7 +36,7 @@ if op == "kron64fq":   # C1: the fake-quant contract at 64 x 64 (FlatQuantizedLi
 elif op.startswith("kron") and not op.endswith("g"):
     M, N = {"kron64": (64, 64), "kron172x64": (172, 64), "kron112": (112, 128), "kron128x224": (128, 224), "kron64x128": (64, 128), "kron64x112": (64, 112),
             "kron86": (86, 128), "kron32x64": (32, 64), "kron128x148": (128, 148), "kron144x192": (144, 192),
-            "kron168x176": (168, 176), "kron96": (96, 96)}[op]
+            "kron168x176": (168, 176), "kron96": (96, 96), "kron128x144": (128, 144), "kron80x112": (80, 112)}[op]
     rows = 8192 if M * N > 20000 else 16384
     xs = [act(rows, M * N) for _ in range(2)]
     L, R = mat(M), mat(N)
