@@ -54,6 +54,8 @@ SYMBOLS = {
     "fq_kron_prepare_bf16": (_i, [_vp, _vp, _i, _i, _vp, _i64, _vp]),
     "fq_block_quant_bf16": (_i, [_vp, _vp, _i64, _i, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp]),
     "fq_rowquant_bf16": (_i, [_vp, _i64, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp]),
+    "fq_fakequant_bits_f16": (_i, [_vp, _i64, _i, _f, _f, _i, _i, _vp, _vp]),
+    "fq_fakequant_bits_bf16": (_i, [_vp, _i64, _i, _f, _f, _i, _i, _vp, _vp]),
     "fq_kron_quant_grouped_mats_f16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "fq_kron_quant_grouped_mats_bf16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "fq_kron_quant_grouped_f16": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

@@ -17,6 +17,8 @@ constexpr int64_t FQ_K64_IMAGE_BYTES = 16384, FQ_K64_WS_BYTES = 32768;
 int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream);
+int fq_launch_fakequant_bits(int bf16_dtype, const void* x, void* y, int64_t rows, int cols, float sig_max, float sig_min, int bits, int flags,
+                             int n_cu, hipStream_t stream);   // fq_quant.hip
 int fq_launch_kron64_multi(int bf16_dtype, const void* jobs, int n_jobs, int bpj, const FqQuantOut& out, hipStream_t stream);
 int fq_launch_rowmm(int bf16_dtype, const void* x, const void* Tm, void* y, int64_t rows, int n, int n_cu, hipStream_t stream);
 int fq_launch_fwht_f32(const f16* x, float* y32, int64_t vecs, int P, float scale, int n_cu, hipStream_t stream);
@@ -967,6 +969,30 @@ int fq_rowquant_bf16(const void* x, int64_t rows, int cols, const float* sig_max
                      void* const* fq_out, void* stream) {
     return rowquant_impl("fq_rowquant_bf16", FQ_DT_BF16, x, rows, cols, sig_max, sig_min, n_clips, flags, q_out, scale_out, fq_out,
                          stream);
+}
+
+static int fakequant_bits_impl(const char* what, int bf, const void* x, int64_t rows, int cols, float sig_max, float sig_min, int bits,
+                               int flags, void* fq_out, void* stream) {
+    if (!x || !fq_out) return fail(FQ_EINVAL, "%s: x / fq_out is NULL", what);
+    FQ_NEED_ALIGN16(what, x, fq_out);
+    if (rows < 0 || cols <= 0) return fail(FQ_EINVAL, "%s: bad sizes", what);
+    if (cols & 7) return fail(FQ_EUNSUPPORTED, "%s: cols=%d must be a multiple of 8", what, cols);
+    if (bits < 2 || bits > 8) return fail(FQ_EUNSUPPORTED, "%s: bits=%d outside [2, 8]", what, bits);
+    if (flags & ~(FQ_ASYM | FQ_QUANT_F16 | FQ_SIG_F16)) return fail(FQ_EINVAL, "%s: flags 0x%x: FQ_ASYM, FQ_QUANT_F16, FQ_SIG_F16 only", what, flags);
+    if ((flags & FQ_SIG_F16) && !(flags & FQ_QUANT_F16)) return fail(FQ_EINVAL, "%s: FQ_SIG_F16 needs FQ_QUANT_F16", what);
+    if (!(sig_max > 0.0f) || !(sig_min > 0.0f)) return fail(FQ_EINVAL, "%s: clip factors must be positive", what);
+    if (rows == 0) return FQ_OK;
+    return check_launch(fq_launch_fakequant_bits(bf, x, fq_out, rows, cols, sig_max, sig_min, bits, flags, cu_count(), (hipStream_t)stream), what);
+}
+
+int fq_fakequant_bits_f16(const void* x, int64_t rows, int cols, float sig_max, float sig_min, int bits, int flags, void* fq_out,
+                          void* stream) {
+    return fakequant_bits_impl("fq_fakequant_bits_f16", 0, x, rows, cols, sig_max, sig_min, bits, flags, fq_out, stream);
+}
+
+int fq_fakequant_bits_bf16(const void* x, int64_t rows, int cols, float sig_max, float sig_min, int bits, int flags, void* fq_out,
+                           void* stream) {
+    return fakequant_bits_impl("fq_fakequant_bits_bf16", 1, x, rows, cols, sig_max, sig_min, bits, flags, fq_out, stream);
 }
 
 int fq_sym_quant_f16(const void* x, const void* scale, int64_t rows, int cols, void* q, void* stream) {

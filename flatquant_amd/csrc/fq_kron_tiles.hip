@@ -7,7 +7,7 @@
 // groups of NT waves (a wave per n'-tile), the waves of a group meet on LDS counters and the groups drift apart, tokens are claimed
 // from a workgroup counter one ahead, staged by LDS-DMA, and never leave registers between GEMM 1 and the packed stores. What is new:
 //   * N = 16 KS1 for any KS1 (7, 9, 12 here): CPR = N / 8 chunks per row, unpadded rows; the bank rotation of a row is a property
-//     of CPR (tl_swz: none for CPR = 14, 18, 22 — the pitch already rotates —, an XOR of the row's bits 1..3 for CPR = 24), and the
+//     of CPR (tl_swz: chunk bit 0 flipped in rows 8..15 for CPR = 14, 18, 22, an XOR of the row's bits 1..3 for CPR = 24), and the
 //     per-lane DMA source offsets follow from it, computed per block of four instructions (no closed form shared by all CPR);
 //   * a last n'-tile that is half padding (N % 32 = 16): its upper half-wave neither contributes extrema nor stores;
 //   * NO zero rows under the token: the row index of an A fragment is clamped to M - 1 instead (a padding row of U then holds finite
@@ -36,14 +36,18 @@ namespace {
 #define TILES_ABL 0   // measurement builds: 1 no quantiser, 2 no GEMM 1, 4 no GEMM 2, 8 no stores, 16 no DMA after the first
 #endif
 
-// bank rotation of row r (8 consecutive rows of one K-half must hit 8 different 16-byte bank groups of the 16):
-// (CPR r + p) mod 16 with p the chunk. CPR = 2 (mod 4): 2 r .. 14 r (mod 16) are eight distinct even slots already.
+// bank rotation of row r: the 16 lanes of a ds_read_b128 group — 16 CONSECUTIVE rows of one K-half — must hit the 16 different
+// 16-byte bank groups; lane c reads group (CPR c + p) mod 16, p the chunk. CPR = 16: all rows alias -> XOR the row's four low bits;
+// CPR = 8 (mod 16): rows alias in two classes -> XOR bits 1..3; CPR = 4 (mod 8): four classes -> XOR bits 2..3; CPR = 2 (mod 4)
+// (14, 18, 22): CPR c mod 16 runs through the eight EVEN groups twice -> rows 8..15 flip chunk bit 0. (The first build had no
+// rotation for that class — "eight rows, eight groups" — and PMC showed SQ_LDS_BANK_CONFLICT = 11.8 M cycles per launch at 128 x 144,
+// more than the LDS was otherwise active: profiles/r04_kron_128x144_pmc.txt.)
 template <int CPR>
 __device__ __forceinline__ int tl_swz(int r) {
-    return CPR % 16 == 0 ? (r & 15) : CPR % 16 == 8 ? ((r >> 1) & 7) : CPR % 8 == 4 ? ((r >> 2) & 3) : 0;
+    return CPR % 16 == 0 ? (r & 15) : CPR % 16 == 8 ? ((r >> 1) & 7) : CPR % 8 == 4 ? ((r >> 2) & 3) : ((r >> 3) & 1);
 }
 template <int CPR>
-constexpr bool tl_has_swz() { return CPR % 4 == 0; }
+constexpr bool tl_has_swz() { return true; }
 
 template <int MT, int NT, int N, int GROUPS, int LKS>
 struct TilesGeom {
@@ -52,7 +56,12 @@ struct TilesGeom {
     static constexpr int TOKBUF = LKS * 16 * CPR * 16;        // bytes: 16 LKS >= M rows
     static constexpr int RED = LFR * 16 + GROUPS * TOKBUF;    // [max x8][min x8] floats per group
     static constexpr int CTL = RED + GROUPS * 64;             // [meet x4][next][claim x4]
-    static constexpr int LDS = CTL + 48;
+    // the per-lane DMA source offsets repeat every DMP instructions (16 rows = 16 CPR slots, an instruction fills 64): a table of
+    // DMP x 64 dwords, filled once per workgroup — computed per instruction they cost ~15 VALU each (+24 % VALU at 128 x 144, measured)
+    static constexpr int DMP = CPR / (CPR % 4 == 0 ? 4 : CPR % 2 == 0 ? 2 : 1);
+    static constexpr int DMT = CTL + 48;
+    static constexpr int LDS = DMT + DMP * 256;
+    static_assert((DMP * 64) % (16 * CPR) == 0, "table period: a whole number of 16-row blocks");
     static_assert(N % 16 == 0 && NT == (N + 31) / 32 && LKS <= 2 * MT && LKS > 2 * MT - 2 && GROUPS <= 4 && NT <= 8, "geometry");
 };
 
@@ -126,7 +135,10 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
         const uint4* lsrc = ws + NT * KS1 * 64;
         for (int i = tid; i < G::LFR; i += THREADS) lfr[i] = lsrc[i];
         if (tid < 12) ctl[tid] = tid == 4 ? GROUPS : 0;   // meeting counters, the next unclaimed token, (published claims)
+        unsigned* dmt_w = reinterpret_cast<unsigned*>(smem + G::DMT);
+        for (int e = tid; e < G::DMP * 64; e += THREADS) dmt_w[e] = tl_dma_off<CPR>(e >> 6, e & 63);
     }
+    const unsigned* dmt = reinterpret_cast<const unsigned*>(smem + G::DMT);
     const uint4* rsrc = ws + (size_t)wq * KS1 * 64;       // this wave's R fragments in the image (wave-uniform base)
     constexpr int NRF = RS ? 1 : KS1, DR = 4;
     X8 RF[NRF];
@@ -150,11 +162,11 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
         for (int g = 0; g < nfull; g += 4) {
             unsigned rv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rv[j] = tl_dma_off<CPR>(d0 + g + j, ln);
+            for (int j = 0; j < 4; ++j) rv[j] = dmt[((d0 + g + j) % G::DMP) * 64 + ln];
             dma_span(src + (int64_t)g * 1024, nfull - g < 4 ? nfull - g : 4, tok_lds + (unsigned)(d0 + g) * 1024, rv);
         }
         if (own_tail && lane < tail_lanes) {
-            const unsigned r1[4] = {tl_dma_off<CPR>(d0 + nfull, ln), 0u, 0u, 0u};
+            const unsigned r1[4] = {dmt[((d0 + nfull) % G::DMP) * 64 + ln], 0u, 0u, 0u};
             dma_span(src + (int64_t)nfull * 1024, 1, tok_lds + (unsigned)(d0 + nfull) * 1024, r1);
         }
     };
@@ -187,10 +199,14 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
             // rows of the last tile beyond the token read row M - 1 (finite; they meet zero rows of L)
             const int rl = (MT - 1) * 32 + cl < M ? (MT - 1) * 32 + cl : M - 1;
             const int swa = tl_swz<CPR>(cl), swl = tl_swz<CPR>(rl);   // (rows 32 mt + c rotate like row c)
-            const uint4* tb = reinterpret_cast<const uint4*>(tokbuf) + cl * CPR;
-            const uint4* tl = reinterpret_cast<const uint4*>(tokbuf) + rl * CPR;
+            // CPR = 2 (mod 4): the rotation only flips chunk bit 0, i.e. the K-half — (2 s + h) ^ sw = 2 s + (h ^ sw): folded into the
+            // base pointer, and 2 s stays in the instruction's offset field (an XOR per read would be three VALU per fragment)
+            constexpr bool FOLD = CPR % 4 == 2;
+            const uint4* tb = reinterpret_cast<const uint4*>(tokbuf) + cl * CPR + (FOLD ? (h ^ swa) : 0);
+            const uint4* tl = reinterpret_cast<const uint4*>(tokbuf) + rl * CPR + (FOLD ? (h ^ swl) : 0);
             auto afrag = [&](int i) -> X8 {   // i = s * MT + mt
                 const int s = i / MT, mt = i % MT;
+                if (FOLD) return mt == MT - 1 ? __builtin_bit_cast(X8, tl[s * 2]) : __builtin_bit_cast(X8, tb[mt * 32 * CPR + s * 2]);
                 return mt == MT - 1 ? __builtin_bit_cast(X8, tl[(s * 2 + h) ^ swl])
                                     : __builtin_bit_cast(X8, tb[mt * 32 * CPR + ((s * 2 + h) ^ swa)]);
             };
@@ -394,6 +410,11 @@ int fq_launch_kron_tiles(int flags, const f16* x, const void* ws, const f16* dia
     }
     if (N == 192 && M > 128 && M <= 144) { // 144 x 192: two groups of six waves, R streamed; 160 KB hold nine K-steps of L
         return launch_tiles<5, 6, 192, 2, 9, true>(b, x, w, rows, M, out, n_cu, stream);
+    }
+    if (N == 176 && M > 160 && M <= 192) { // 168 x 176 (29568, Qwen2.5-72B ffn): ONE group of six waves (two tokens + the L image would need 184 KB);
+                                           // the next token's DMA still runs under GEMM 2 and the quantiser
+        return lks == 11 ? launch_tiles<6, 6, 176, 1, 11, false>(b, x, w, rows, M, out, n_cu, stream)
+                         : launch_tiles<6, 6, 176, 1, 12, false>(b, x, w, rows, M, out, n_cu, stream);
     }
     if (N == 128 && M > 64 && M <= 96) {    // 86 x 128 (11008, Llama-2-7B ffn), fp16 and bf16: 123 us where fq_kron_trio.hip's MT = 3 build takes 145
         return lks == 5 ? launch_tiles<3, 4, 128, 3, 5, false>(b, x, w, rows, M, out, n_cu, stream)

@@ -592,3 +592,101 @@ int fq_launch_rmsnorm(const f16* x, f16* y, int64_t rows, int cols, float eps, i
 #undef FQ_RN
     return -1000;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// ActivationQuantizer with bits != 4 (round 4): get_qmin_qmax (quant_utils.py:10-16) makes the grid a parameter — --a_bits / --q_bits /
+// --k_bits / --v_bits of args_utils.py:38,101,108,116 — and fake_quant (quant_utils.py:76-119, 18-46) is otherwise the same arithmetic.
+// Fake-quant output only (the packed format is the INT4 one). No reference script runs anything but 4 bits, so this is the plain form:
+// a wave per row, the row read twice (extrema, then values: the second read comes from L2), IEEE divisions. Pinned arithmetic = the
+// 4-bit kernels' with 7 / 15 replaced by qmax (oracle: rowquant(bits=) / rowquant_asym(bits=), pinned by tests/golden/act_bits.npz):
+//   sym:  xmax = max(amax, 0), xmin = min(amin, 0), times the clip factors, m = max(|xmin|, xmax), scale = m / qmax (1 if m == 0),
+//         q = clamp(rint(x / scale), -qmax - 1, qmax), out = T(scale q);      qmax = 2^(bits-1) - 1
+//   asym: both zero -> (-1, +1); scale = (xmax - xmin) / qmax, zero = rint(-xmin / scale), q = clamp(rint(x / scale) + zero, 0, qmax),
+//         out = T(scale (q - zero));                                            qmax = 2^bits - 1
+// F16A == false: lac with fp32 (1,)-shaped clip parameters — every operation in fp32. F16A == true: no lac / clip_ratio / a module in the
+// activation dtype — every operation rounds to T (sig_lowp: the extremum x factor product too; with factor 1 it is exact either way).
+template <typename T, bool ASYM, bool F16A>
+__global__ __launch_bounds__(256) void fq_fakequant_bits_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows, int cols,
+                                                                float sig_max, float sig_min, float qmax, int sig_lowp) {
+    typedef typename FqVec<T>::x8 X8;
+    const int lane = threadIdx.x & 63, nvec = cols >> 3;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    auto rnd = [](float v) -> float { return F16A ? (float)(T)v : v; };
+    for (int64_t row = wave; row < rows; row += nwaves) {
+        const uint4* xp = reinterpret_cast<const uint4*>(x + row * (int64_t)cols);
+        uint4* yp = reinterpret_cast<uint4*>(y + row * (int64_t)cols);
+        float vmax = -INFINITY, vmin = INFINITY;
+        for (int i = lane; i < nvec; i += 64) {
+            const X8 w = __builtin_bit_cast(X8, xp[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                vmax = fmaxf(vmax, (float)w[e]);
+                vmin = fminf(vmin, (float)w[e]);
+            }
+        }
+        vmax = fmaxf(fq_wave_max(vmax), 0.0f);
+        vmin = fminf(fq_wave_min(vmin), 0.0f);
+        float xmax, xmin;
+        if (F16A && sig_lowp) {
+            xmax = (float)fq_mul_to<T>(vmax, sig_max);
+            xmin = (float)fq_mul_to<T>(vmin, sig_min);
+        } else {
+            xmax = vmax * sig_max;
+            xmin = vmin * sig_min;
+        }
+        float scale, zero = 0.0f;
+        if (ASYM) {
+            if (xmax == 0.0f && xmin == 0.0f) {
+                xmin = -1.0f;
+                xmax = 1.0f;
+            }
+            scale = rnd(rnd(xmax - xmin) / qmax);
+            zero = __builtin_rintf(rnd(-xmin / scale));
+        } else {
+            const float m = fmaxf(fabsf(xmin), xmax);
+            scale = rnd(m / qmax);
+            if (m == 0.0f) scale = 1.0f;
+        }
+        for (int i = lane; i < nvec; i += 64) {
+            const X8 w = __builtin_bit_cast(X8, xp[i]);
+            X8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = rnd((float)w[e] / scale);   // correctly rounded fp32 division (then to T: the 16-bit quotient)
+                float q = __builtin_rintf(t);
+                if (ASYM) {
+                    q = __builtin_amdgcn_fmed3f(rnd(q + zero), 0.0f, qmax);
+                    o[e] = fq_mul_to<T>(scale, q - zero);
+                } else {
+                    q = __builtin_amdgcn_fmed3f(q, -qmax - 1.0f, qmax);
+                    o[e] = fq_fake<T>(scale, q);            // (+0.0 for a zero digit, like the 4-bit kernels)
+                }
+            }
+            yp[i] = __builtin_bit_cast(uint4, o);
+        }
+    }
+}
+
+template <typename T>
+static int launch_fakequant_bits_t(const T* x, T* y, int64_t rows, int cols, float sig_max, float sig_min, int bits, int flags, int n_cu,
+                                   hipStream_t stream) {
+    int64_t wb = (rows + 3) / 4;
+    if (wb > (int64_t)n_cu * 8) wb = (int64_t)n_cu * 8;
+    if (wb < 1) wb = 1;
+    const bool asym = (flags & FQ_ASYM) != 0, f16a = (flags & FQ_QUANT_F16) != 0;
+    const float qmax = asym ? (float)((1 << bits) - 1) : (float)((1 << (bits - 1)) - 1);
+    const int sl = (flags & FQ_SIG_F16) || asym ? 1 : 0;   // (the asymmetric route always rounds the 16-bit route's products: rowquant_asym)
+#define FQ_FB(A_, F_)                                                                                                         \
+    hipLaunchKernelGGL((fq_fakequant_bits_kernel<T, A_, F_>), dim3((unsigned)wb), dim3(256), 0, stream, x, y, rows, cols, sig_max, \
+                       sig_min, qmax, sl)
+    if (asym) { if (f16a) FQ_FB(true, true); else FQ_FB(true, false); }
+    else { if (f16a) FQ_FB(false, true); else FQ_FB(false, false); }
+#undef FQ_FB
+    return (int)hipGetLastError();
+}
+
+int fq_launch_fakequant_bits(int bf16_dtype, const void* x, void* y, int64_t rows, int cols, float sig_max, float sig_min, int bits, int flags,
+                             int n_cu, hipStream_t stream) {
+    return bf16_dtype ? launch_fakequant_bits_t<bf16>((const bf16*)x, (bf16*)y, rows, cols, sig_max, sig_min, bits, flags, n_cu, stream)
+                      : launch_fakequant_bits_t<f16>((const f16*)x, (f16*)y, rows, cols, sig_max, sig_min, bits, flags, n_cu, stream);
+}

@@ -73,8 +73,6 @@ class ActivationQuantizer(torch.nn.Module):
         return self.fake_quant(x)
 
     def fake_quant(self, x):
-        if self.bits != 4:
-            raise NotImplementedError("flatquant_amd: only 4-bit activation quantisation is on the hot path")
         # fp16 or bf16 activations (ops.rowquant picks fq_rowquant_f16 / _bf16); FQ_QUANT_F16 / FQ_SIG_F16 mean "in the
         # activation's dtype"
         flags = FQ_OUT_FAKEQUANT | (0 if self.lac else FQ_QUANT_F16)
@@ -85,8 +83,14 @@ class ActivationQuantizer(torch.nn.Module):
         if not self.sym:
             # quant_utils.py:33-46,109-117: the K / V / Q cache quantisers under --k_asym --v_asym (llama_utils.py:124-132)
             flags = (flags & ~FQ_SIG_F16) | FQ_ASYM   # (the asymmetric kernel always rounds the fp16 route's products)
-        if self.groupsize > 0:
-            if x.shape[-1] % self.groupsize:
-                raise ValueError(f"last dimension {x.shape[-1]} is not a multiple of groupsize {self.groupsize}")
-            return ops.rowquant(x.contiguous().reshape(-1, self.groupsize), [self._sig(x.dtype)], flags).fq[0].reshape(x.shape)
-        return ops.rowquant(x.contiguous(), [self._sig(x.dtype)], flags).fq[0]
+        if self.groupsize > 0 and x.shape[-1] % self.groupsize:
+            raise ValueError(f"last dimension {x.shape[-1]} is not a multiple of groupsize {self.groupsize}")
+        xin = x.contiguous().reshape(-1, self.groupsize) if self.groupsize > 0 else x.contiguous()
+        if self.bits != 4:
+            # any other grid of get_qmin_qmax (quant_utils.py:10-16; --a_bits / --q_bits / --k_bits / --v_bits): the plain kernel,
+            # same pinned arithmetic with q_max as an argument (fq_fakequant_bits_*; round 4)
+            if not 2 <= int(self.bits) <= 8:
+                raise NotImplementedError(f"flatquant_amd: ActivationQuantizer(bits={self.bits}): 2..8 and 16 are on the HIP path")
+            fl = flags & (FQ_QUANT_F16 | FQ_SIG_F16 | FQ_ASYM)
+            return ops.fakequant_bits(xin, self._sig(x.dtype), int(self.bits), fl).reshape(x.shape)
+        return ops.rowquant(xin, [self._sig(x.dtype)], flags).fq[0].reshape(x.shape)

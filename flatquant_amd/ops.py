@@ -703,6 +703,23 @@ def rowquant(x: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),), flags: int = 
     return o
 
 
+def fakequant_bits(x: torch.Tensor, sig: Sig, bits: int, flags: int = 0) -> torch.Tensor:
+    """ActivationQuantizer.fake_quant with bits != 4 (fq_fakequant_bits_f16 / _bf16): x [..., cols] -> the fake-quantised tensor.
+    flags: FQ_ASYM, FQ_QUANT_F16 (arithmetic in the activation dtype), FQ_SIG_F16. bits == 4 is served by rowquant() (same values)."""
+    dt = _chk_act(x)
+    if not 2 <= int(bits) <= 8:
+        raise ValueError(f"fakequant_bits: bits={bits} outside [2, 8]")
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    y = torch.empty_like(x)
+    if rows == 0:
+        return y
+    with _on(x.device):
+        check(_fn("fakequant_bits", dt)(_ptr(x), rows, cols, ctypes.c_float(sig[0]), ctypes.c_float(sig[1]), int(bits), flags, _ptr(y),
+                                        _stream(x)))
+    return y
+
+
 def had_mfma_supported(n: int, K: int) -> bool:
     """Shapes of the structured matrix-pipe rotation (fq_had_mfma.hip): n = K * 512, K <= 32, K % 4 == 0 (14336 = 28 * 512)."""
     return 4 <= K <= 32 and K % 4 == 0 and n == K * 512

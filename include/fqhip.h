@@ -437,6 +437,23 @@ int fq_rowquant_bf16(const void* x, int64_t rows, int cols,
                      void* stream);
 
 /*
+ * ActivationQuantizer.fake_quant with bits != 4 (round 4): flatquant/quant_utils.py:10-16 (get_qmin_qmax makes the grid a parameter —
+ * --a_bits / --q_bits / --k_bits / --v_bits, args_utils.py:38,101,108,116), :76-119 (statistics), :18-46 (quantise / dequantise).
+ * Fake-quant output only (the packed format of this library is the INT4 one); one clip pair; 2 <= bits <= 8.
+ *   symmetric (default): qmax = 2^(bits-1) - 1, scale = max(|xmin sig_min|, xmax sig_max) / qmax (1 if 0), q = clamp(rint(x / scale), -qmax-1, qmax)
+ *   FQ_ASYM:             qmax = 2^bits - 1, (0, 0) -> (-1, +1), scale = (xmax - xmin) / qmax, zero = rint(-xmin / scale),
+ *                        q = clamp(rint(x / scale) + zero, 0, qmax), out = scale (q - zero)
+ *   extrema through 0 in both (quant_utils.py:90-91). Default arithmetic: fp32 (lac with fp32 clip parameters). FQ_QUANT_F16: every
+ *   operation rounds to the activation dtype (no lac / clip_ratio / a module cast to it); FQ_SIG_F16 with it: the extremum x factor
+ *   product too (always with FQ_ASYM). bits == 4 gives the same values as fq_rowquant_* with FQ_OUT_FAKEQUANT (which is the fast path).
+ *   x, fq_out [rows, cols] fp16 (bf16), cols % 8 == 0, 16-byte aligned; fq_out == x is allowed.
+ */
+int fq_fakequant_bits_f16(const void* x, int64_t rows, int cols, float sig_max, float sig_min, int bits, int flags,
+                          void* fq_out, void* stream);
+int fq_fakequant_bits_bf16(const void* x, int64_t rows, int cols, float sig_max, float sig_min, int bits, int flags,
+                           void* fq_out, void* stream);
+
+/*
  * KV-cache quantisation (deploy/transformers/kv_cache.py:11-51 asym_quantize_and_pack_i4, :268 the K transform), one
  * launch: per row of head_dim fp16 values (a row = one head of one token; x is [rows, head_dim] contiguous)
  *   y = trans ? fp16(x . trans) : x                               trans [head_dim, head_dim] fp16 row-major or NULL

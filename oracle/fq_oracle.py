@@ -185,13 +185,14 @@ def single_transform(x16, P16, groups=None, lowp="f16"):
 # --------------------------------------------------------------------------------------------------
 # per-token symmetric INT4 quantisation
 # --------------------------------------------------------------------------------------------------
-def token_scale(y32, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False, sig_f16=False, lowp="f16"):
+def token_scale(y32, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False, sig_f16=False, lowp="f16", bits=4):
     """y32 [T, d] fp32 -> scale fp32 [T].
 
     quant_utils.py:88-107 (clamp to 0, lac sigmoid factors, m = max(|xmin|, xmax), scale = m/q_max,
     scale[m == 0] = 1) evaluated in fp32 — what torch's type promotion yields when ``lac`` multiplies the
     fp16 row extrema by the fp32 sigmoid — and kron_matmul.py:91-104 (no clamp: clamp0=False).
     quant_f16: the scale is rounded to fp16 ((m/7).to(float16), deploy/nn/quantization.py:25-30).
+    bits: q_max = 2^(bits-1) - 1 (get_qmin_qmax, quant_utils.py:10-16; every reference script uses 4).
     """
     y32 = np.asarray(y32, dtype=F32)
     xmax = y32.max(axis=-1)
@@ -210,15 +211,16 @@ def token_scale(y32, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False, sig
         xmin = (xmin * F32(sig_min)).astype(F32)
     m = np.maximum(np.abs(xmin), xmax).astype(F32)
     with np.errstate(divide="ignore", invalid="ignore"):
-        scale = (m / F32(7.0)).astype(F32)
+        scale = (m / F32(2 ** (bits - 1) - 1)).astype(F32)
     if quant_f16:
         scale = _rnd(scale, lowp)
     scale = np.where(m == 0, F32(1.0), scale).astype(F32)
     return scale
 
 
-def quantize(y32, scale, quant_f16=False, lowp="f16"):
-    """clamp(rint(y/scale), -8, 7) -> int8; division fp32 (fp16-rounded quotient when quant_f16)."""
+def quantize(y32, scale, quant_f16=False, lowp="f16", bits=4):
+    """clamp(rint(y/scale), -8, 7) -> int8 (bits != 4: [-2^(bits-1), 2^(bits-1) - 1] -> int16); division fp32 (fp16-rounded
+    quotient when quant_f16)."""
     y32 = np.asarray(y32, dtype=F32)
     s = np.asarray(scale, dtype=F32)[..., None]
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
@@ -226,9 +228,9 @@ def quantize(y32, scale, quant_f16=False, lowp="f16"):
         if quant_f16:
             t = _rnd(t, lowp)
     t = np.rint(t)
-    t = np.clip(t, -8, 7)
+    t = np.clip(t, -(2 ** (bits - 1)), 2 ** (bits - 1) - 1)
     t = np.where(np.isnan(t), 0, t)
-    return t.astype(np.int8)
+    return t.astype(np.int8 if bits <= 8 else np.int16)
 
 
 def dequantize(q, scale, quant_f16=False, lowp="f16"):
@@ -241,7 +243,7 @@ def dequantize(q, scale, quant_f16=False, lowp="f16"):
 
 
 def quant_outputs(y32, sig_max=1.0, sig_min=1.0, round_y_f16=False, clamp0=True, quant_f16=False, groupsize=-1,
-                  sig_f16=False, lowp="f16"):
+                  sig_f16=False, lowp="f16", bits=4):
     """Everything the fused kernels can emit for one clip set, from the fp32 transformed activation.
 
     groupsize > 0: ``ActivationQuantizer(groupsize=g)`` of vllm_custom/model_executor/layers/quantization/utils/
@@ -259,20 +261,20 @@ def quant_outputs(y32, sig_max=1.0, sig_min=1.0, round_y_f16=False, clamp0=True,
     if groupsize > 0:
         assert d % groupsize == 0
         yg = y.reshape(T * (d // groupsize), groupsize)
-        scale = token_scale(yg, sig_max, sig_min, clamp0, quant_f16, sig_f16, lowp)
-        q = quantize(yg, scale, quant_f16, lowp).reshape(T, d)
+        scale = token_scale(yg, sig_max, sig_min, clamp0, quant_f16, sig_f16, lowp, bits)
+        q = quantize(yg, scale, quant_f16, lowp, bits).reshape(T, d)
         fq = dequantize(q.reshape(yg.shape), scale, quant_f16, lowp).reshape(T, d)
         scale = scale.reshape(T, d // groupsize)
     else:
-        scale = token_scale(y, sig_max, sig_min, clamp0, quant_f16, sig_f16, lowp)
-        q = quantize(y, scale, quant_f16, lowp)
+        scale = token_scale(y, sig_max, sig_min, clamp0, quant_f16, sig_f16, lowp, bits)
+        q = quantize(y, scale, quant_f16, lowp, bits)
         fq = dequantize(q, scale, quant_f16, lowp)
     return {
         "y16": y16,
         "scale": scale,
         "scale16": bf16_round(scale) if lowp == "bf16" else scale.astype(F16),
         "q": q,
-        "packed": pack_i4(q),
+        "packed": pack_i4(q) if bits == 4 else None,   # (the packed format is the INT4 one)
         "fq": fq,
     }
 
@@ -313,13 +315,13 @@ def kron_quant_grouped(x16, left16, right16, group_offsets, sig_max_g, sig_min_g
     return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
 
 
-def rowquant(x16, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False, sig_f16=False, lowp="f16"):
+def rowquant(x16, sig_max=1.0, sig_min=1.0, clamp0=True, quant_f16=False, sig_f16=False, lowp="f16", bits=4):
     x = _as_lowp(x16, lowp)
     return quant_outputs(x.reshape(x.shape[0], -1), sig_max, sig_min, False, clamp0, quant_f16,
-                         sig_f16=sig_f16, lowp=lowp)
+                         sig_f16=sig_f16, lowp=lowp, bits=bits)
 
 
-def rowquant_asym(x16, sig_max=1.0, sig_min=1.0, quant_f16=False, lowp="f16"):
+def rowquant_asym(x16, sig_max=1.0, sig_min=1.0, quant_f16=False, lowp="f16", bits=4):
     """ActivationQuantizer(sym=False).fake_quant on an fp16 activation -> fp16 [rows, cols].
 
     quant_utils.py:86-92 (row extrema through 0), :95-100 (clip factors), :109-113 (both zero -> (-1, +1);
@@ -339,10 +341,11 @@ def rowquant_asym(x16, sig_max=1.0, sig_min=1.0, quant_f16=False, lowp="f16"):
     both = (xmax == 0) & (xmin == 0)
     xmin = np.where(both, F32(-1), xmin).astype(F32)
     xmax = np.where(both, F32(1), xmax).astype(F32)
-    scale = rnd(rnd(xmax - xmin) / F32(15))
+    qmax = 2 ** bits - 1   # (get_qmin_qmax, quant_utils.py:14; sums of two integers <= 2 qmax are exact in fp16, and inside [0, qmax] in bf16)
+    scale = rnd(rnd(xmax - xmin) / F32(qmax))
     zero = np.rint(rnd((-xmin) / scale)).astype(F32)
     t = rnd(x / scale[:, None])
-    q = np.clip(np.rint(t) + zero[:, None], 0, 15).astype(F32)
+    q = np.clip(rnd(np.rint(t) + zero[:, None]), 0, qmax).astype(F32)
     out = (scale[:, None] * (q - zero[:, None])).astype(F32)
     return bf16_round(out) if lowp == "bf16" else out.astype(F16)
 

@@ -36,7 +36,7 @@ def make(M, N, rows, seed, spike=True):
 
 # (M, N): both K-step counts of every row-tile class, DMA tails (M * N / 8 % 64 != 0) and whole-instruction tokens
 PAIRS = [(80, 112), (66, 112), (96, 112), (88, 112), (128, 144), (98, 144), (112, 144), (100, 144), (126, 144),
-         (144, 192), (129, 192), (130, 192), (137, 192), (86, 128), (66, 128), (96, 128)]
+         (144, 192), (129, 192), (130, 192), (137, 192), (86, 128), (66, 128), (96, 128), (168, 176), (162, 176), (178, 176)]
 
 
 @pytest.mark.parametrize("M,N", PAIRS)

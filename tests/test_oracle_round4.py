@@ -31,3 +31,47 @@ def test_single_trans_128_vs_reference(golden):
         y16 = g[tag + "_y16"]
         kq = O.rowquant_asym(y16.reshape(-1, 128), float(g["kq_sig"][0]), float(g["kq_sig"][1]))
         assert np.array_equal(kq.reshape(y16.shape).view(np.uint16), g[tag + "_kq16"].view(np.uint16)), tag
+
+
+def _bits_cases(g):
+    """(key, bits, sym, route, dtag, cols) of every case of tests/golden/act_bits.npz."""
+    for nb in (8, 6, 3):
+        for sym in (True, False):
+            for name in ("lac32", "lac32b", "plain", "ratio", "lac16"):
+                for dtag in ("f16", "bf16"):
+                    for cols in (128, 520):
+                        yield f"b{nb}_{'sym' if sym else 'asym'}_{name}_{dtag}_{cols}", nb, sym, name, dtag, cols
+
+
+def bits_case_args(g, name, dtag):
+    """-> (sig_max, sig_min, quant_f16, sig_f16): how the reference module of that case evaluates (see rowquant / rowquant_asym)."""
+    if name in ("lac32", "lac32b"):
+        s = g[name + "_sig"]
+        return float(s[0]), float(s[1]), False, False           # fp32 (1,)-shaped parameters promote everything to fp32
+    if name == "lac16":
+        s = g[f"lac16_{dtag}_sig"]
+        return float(s[0]), float(s[1]), True, True             # a module in the activation dtype: every operation rounds to it
+    if name == "ratio":
+        return 0.83, 0.83, True, True                           # 16-bit extremum x python float: a 16-bit product
+    return 1.0, 1.0, True, False
+
+
+def test_activation_quantizer_other_bit_widths_vs_reference(golden):
+    """ActivationQuantizer(bits = 8 / 6 / 3) — get_qmin_qmax (quant_utils.py:10-16), sym and asym, every clip route, fp16 and bf16 —
+    restated by O.rowquant(bits=) / O.rowquant_asym(bits=): bit for bit against the reference's outputs."""
+    g = golden("act_bits")
+    n = 0
+    for key, nb, sym, name, dtag, cols in _bits_cases(g):
+        lowp = "f16" if dtag == "f16" else "bf16"
+        x = g[key + "_x"] if dtag == "f16" else bf(g[key + "_x"])
+        smax, smin, qf16, sf16 = bits_case_args(g, name, dtag)
+        if sym:
+            got = O.rowquant(x, smax, smin, clamp0=True, quant_f16=qf16, sig_f16=sf16, lowp=lowp, bits=nb)["fq"]
+        else:
+            got = O.rowquant_asym(x, smax, smin, quant_f16=qf16, lowp=lowp, bits=nb)
+        if dtag == "f16":
+            assert np.array_equal(np.asarray(got, dtype=np.float16).view(np.uint16), g[key + "_y"].view(np.uint16)), key
+        else:
+            assert np.array_equal(O.bf16_bits(got), g[key + "_y"]), key
+        n += 1
+    assert n == 120

@@ -941,8 +941,48 @@ def gen_single128():
     save("single128", **arrays)
 
 
+def gen_act_bits():
+    """ActivationQuantizer with bits != 4 (get_qmin_qmax, quant_utils.py:10-16: --a_bits / --q_bits / --k_bits / --v_bits are free
+    parameters of the reference, args_utils.py:38,101,108,116) on fp16 and bf16 activations: symmetric and asymmetric, lac with fp32
+    clip parameters (arithmetic promoted to fp32), no lac, clip_ratio, a half()'ed / bfloat16()'ed lac module (everything in the
+    activation dtype). bf16 arrays are stored as bit patterns."""
+    arrays = {}
+    cases = [("lac32", dict(lac=True), (4.0, 4.0)), ("lac32b", dict(lac=True), (1.7, 0.4)), ("plain", dict(lac=False), None),
+             ("ratio", dict(lac=False, clip_ratio=0.83), None), ("lac16", dict(lac=True), (2.1, 0.9))]
+    for nb in (8, 6, 3):
+        for sym in (True, False):
+            for ci, (name, kw, clips) in enumerate(cases):
+                for dt, dtag in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+                    for cols in (128, 520):
+                        x = make_x(5, cols, seed=1200 + nb * 31 + ci * 10 + cols % 7 + (1 if sym else 0)).to(dt)
+                        x[1] = 0                      # both extrema zero
+                        x[2] = x[2].abs()             # xmin clamps to 0
+                        x[3] = -x[3].abs()            # xmax clamps to 0
+                        x[4, ::3] *= 30               # outliers: quotients far outside the grid
+                        q = RefActQ(bits=nb, sym=sym, **kw)
+                        if clips is not None:
+                            q.clip_factor_a_max.data.fill_(clips[0])
+                            q.clip_factor_a_min.data.fill_(clips[1])
+                        if name == "lac16":
+                            q = q.to(dt)
+                        with torch.no_grad():
+                            y = q(x)
+                        assert y.dtype == dt
+                        key = f"b{nb}_{'sym' if sym else 'asym'}_{name}_{dtag}_{cols}"
+                        if dt == torch.float16:
+                            arrays[key + "_x"], arrays[key + "_y"] = x.numpy(), y.numpy()
+                        else:
+                            arrays[key + "_x"], arrays[key + "_y"] = bits(x), bits(y)
+                    if name == "lac16":   # torch.sigmoid of the 16-bit parameter (fp32 opmath, rounded to it)
+                        arrays[f"lac16_{dtag}_sig"] = np.array([float(torch.sigmoid(torch.tensor(c, dtype=dt))) for c in clips], dtype=np.float32)
+                if clips is not None and name != "lac16":
+                    arrays[f"{name}_sig"] = np.array([sig(c) for c in clips], dtype=np.float32)
+    save("act_bits", **arrays)
+
+
 def gen_round4():
     gen_single128()
+    gen_act_bits()
 
 
 def gen_round3():
@@ -964,6 +1004,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt2k":   # the K = 2048 export (12 MB): only on request
         gen_checkpoint(hidden=2048, ffn=2048, heads=16, kv_heads=2, layers=1, name="ckpt2k", clip_noise=0.6)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bits":
+        gen_act_bits()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "r4":
         gen_round4()
