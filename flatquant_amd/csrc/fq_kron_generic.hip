@@ -167,6 +167,10 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
 #ifdef FQ_MEASURE
     if (const char* dbg = getenv("FQ_KRON_DBG")) flags |= atoi(dbg) & 0x7000;  // measurement: ablation bits of the fast kernel
 #endif
+    if (!g128 && N == 148 && !fq_measure_env("FQ_KRON_NO_TILES")) {   // (round 4) 128 x 148 on token groups of five waves
+        rc = fq_launch_kron_tiles(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
+        if (rc != -1000) return rc;
+    }
     // N % 16 != 0 in the workgroup-per-token kernel: the packed-only launch of 96 < M <= 128, N = 148 (18944 = 128 x 148,
     // Qwen2.5-7B ffn); its other output sets, diag and every other such pair: fq_kron_general.hip
     if (!g128 && N == 148 && MT == 4 && (flags & FQ_CT_MASK) == FQ_OUT_PACKED && diag == nullptr && !((M * N / 2) & 15) &&

@@ -76,7 +76,7 @@ int fq_launch_kron_generic_bf16(int flags, const f16* x_, const f16* left_, cons
         const int rc = fq_launch_kron_wave_bf16(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }
-    if (spec && !(out.rt_flags & FQ_GROUP128)) {   // (round 4) token groups of NT waves: 112 x 128, 86 x 128, 80 x 112, 128 x 144, 144 x 192 on bf16
+    if ((spec || N == 148) && !(out.rt_flags & FQ_GROUP128)) {   // (round 4) token groups of NT waves: 112 x 128, 86 x 128, 80 x 112, 128 x 144, 144 x 192 on bf16
         const int rc = fq_launch_kron_tiles(flags | FQ_DT_BF16, (const f16*)x, ws, (const f16*)diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }

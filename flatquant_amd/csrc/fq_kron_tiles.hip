@@ -48,21 +48,27 @@ __device__ __forceinline__ int tl_swz(int r) {
 }
 template <int CPR>
 constexpr bool tl_has_swz() { return true; }
+typedef uint2 tl_uint2_a2 __attribute__((aligned(2)));
 
 template <int MT, int NT, int N, int GROUPS, int LKS>
 struct TilesGeom {
-    static constexpr int KS1 = N / 16, CPR = N / 8, THREADS = GROUPS * NT * 64;
+    // ODDN (N % 16 != 0, N % 4 == 0: 148): a row is not a whole number of 16-byte chunks. The token is staged LINEARLY (row pitch 2 N
+    // bytes: 296 = 74 dwords, sixteen consecutive rows start in sixteen different bank pairs), a fragment is two 8-byte reads, the
+    // last K-step reads past the row's end into the next row (finite values against the zero rows of R) and the last row into 32
+    // zero bytes behind the buffer; the last n'-tile holds N - 16 (2 NT - 1) valid columns in its upper half-wave.
+    static constexpr bool ODDN = N % 16 != 0;
+    static constexpr int KS1 = (N + 15) / 16, CPR = ODDN ? 16 : N / 8, THREADS = GROUPS * NT * 64;   // (ODDN: CPR only names the "no rotation" class)
     static constexpr int LFR = LKS * MT * 64;                 // uint4: the K-steps of the L image that hold rows of L
-    static constexpr int TOKBUF = LKS * 16 * CPR * 16;        // bytes: 16 LKS >= M rows
+    static constexpr int TOKBUF = LKS * 16 * N * 2 + (ODDN ? 32 : 0);   // bytes: 16 LKS >= M rows (+ the zero tail)
     static constexpr int RED = LFR * 16 + GROUPS * TOKBUF;    // [max x8][min x8] floats per group
     static constexpr int CTL = RED + GROUPS * 64;             // [meet x4][next][claim x4]
     // the per-lane DMA source offsets repeat every DMP instructions (16 rows = 16 CPR slots, an instruction fills 64): a table of
     // DMP x 64 dwords, filled once per workgroup — computed per instruction they cost ~15 VALU each (+24 % VALU at 128 x 144, measured)
-    static constexpr int DMP = CPR / (CPR % 4 == 0 ? 4 : CPR % 2 == 0 ? 2 : 1);
+    static constexpr int DMP = ODDN ? 1 : CPR / (CPR % 4 == 0 ? 4 : CPR % 2 == 0 ? 2 : 1);
     static constexpr int DMT = CTL + 48;
     static constexpr int LDS = DMT + DMP * 256;
-    static_assert((DMP * 64) % (16 * CPR) == 0, "table period: a whole number of 16-row blocks");
-    static_assert(N % 16 == 0 && NT == (N + 31) / 32 && LKS <= 2 * MT && LKS > 2 * MT - 2 && GROUPS <= 4 && NT <= 8, "geometry");
+    static_assert(ODDN || (DMP * 64) % (16 * CPR) == 0, "table period: a whole number of 16-row blocks");
+    static_assert(N % 4 == 0 && (LKS * 16 * N * 2) % 16 == 0 && NT == (N + 31) / 32 && LKS <= 2 * MT && LKS > 2 * MT - 2 && GROUPS <= 4 && NT <= 8, "geometry");
 };
 
 __device__ __forceinline__ unsigned tl_lds_read(unsigned addr) {
@@ -106,6 +112,7 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
     typedef TilesGeom<MT, NT, N, GROUPS, LKS> G;
     typedef typename FqVec<T>::x8 X8;
     constexpr int KS1 = G::KS1, CPR = G::CPR, THREADS = G::THREADS;
+    constexpr bool ODDN = G::ODDN;
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
     const unsigned ctl_lds = (unsigned)(size_t)(lds_void*)ctl, meet = ctl_lds + grp * 4;
     const unsigned tok_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)tokbuf);
     const int64_t tok_bytes = (int64_t)M * (N * 2);
-    const int n_slots = M * CPR, n_dma = (n_slots + 63) >> 6;   // 1 KB instructions per token; the last one may end inside its KB
+    const int n_slots = (M * N) >> 3, n_dma = (n_slots + 63) >> 6;   // 16-byte slots; 1 KB instructions per token, the last one may end inside its KB
     const int per = (n_dma + NT - 1) / NT;                      // this wave stages instructions [d0, d0 + dn)
     const int d0 = wq * per;
     const int dn = n_dma - d0 < per ? (n_dma - d0 < 0 ? 0 : n_dma - d0) : per;
@@ -126,6 +133,8 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(x) - 128;   // (tl_dma_off's bias)
     // N % 32 = 16: the upper half-wave of the last tile holds n' >= N (zero columns of R: its Y is 0 and belongs to nobody)
     const bool nvalid = N % 32 == 0 || (h * NT * 16 + wq * 16) < N;
+    // ODDN: how many of the lane's 16 columns exist (16 everywhere but in the upper half-wave of the last tile: N - 16 (2 NT - 1) = 4 at N = 148)
+    const int nval = !ODDN ? 16 : (N - (h * NT * 16 + wq * 16) >= 16 ? 16 : N - (h * NT * 16 + wq * 16) > 0 ? N - (h * NT * 16 + wq * 16) : 0);
 
     const int64_t blk_base = (int64_t)blockIdx.x * tpb;
     const int blk_cnt = (int)(rows - blk_base < tpb ? (rows - blk_base < 0 ? 0 : rows - blk_base) : tpb);
@@ -136,7 +145,9 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
         for (int i = tid; i < G::LFR; i += THREADS) lfr[i] = lsrc[i];
         if (tid < 12) ctl[tid] = tid == 4 ? GROUPS : 0;   // meeting counters, the next unclaimed token, (published claims)
         unsigned* dmt_w = reinterpret_cast<unsigned*>(smem + G::DMT);
-        for (int e = tid; e < G::DMP * 64; e += THREADS) dmt_w[e] = tl_dma_off<CPR>(e >> 6, e & 63);
+        for (int e = tid; e < G::DMP * 64; e += THREADS) dmt_w[e] = ODDN ? (unsigned)((e & 63) * 16 + 128) : tl_dma_off<CPR>(e >> 6, e & 63);
+        if (ODDN && tid < GROUPS * 8)   // 32 zero bytes behind every token (the DMA never writes them: its last instruction is lane-masked)
+            *reinterpret_cast<unsigned*>(smem + G::LFR * 16 + (tid >> 3) * G::TOKBUF + M * (N * 2) + (tid & 7) * 4) = 0u;
     }
     const unsigned* dmt = reinterpret_cast<const unsigned*>(smem + G::DMT);
     const uint4* rsrc = ws + (size_t)wq * KS1 * 64;       // this wave's R fragments in the image (wave-uniform base)
@@ -204,8 +215,15 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
             constexpr bool FOLD = CPR % 4 == 2;
             const uint4* tb = reinterpret_cast<const uint4*>(tokbuf) + cl * CPR + (FOLD ? (h ^ swa) : 0);
             const uint4* tl = reinterpret_cast<const uint4*>(tokbuf) + rl * CPR + (FOLD ? (h ^ swl) : 0);
+            const unsigned char* ob = tokbuf + cl * (N * 2) + h * 16;   // ODDN: byte addresses, 8-byte aligned
+            const unsigned char* ol = tokbuf + rl * (N * 2) + h * 16;
             auto afrag = [&](int i) -> X8 {   // i = s * MT + mt
                 const int s = i / MT, mt = i % MT;
+                if (ODDN) {
+                    const unsigned char* pp = (mt == MT - 1 ? ol : ob + mt * 32 * (N * 2)) + s * 32;
+                    const uint2 a = *reinterpret_cast<const uint2*>(pp), b = *reinterpret_cast<const uint2*>(pp + 8);
+                    return __builtin_bit_cast(X8, uint4{a.x, a.y, b.x, b.y});
+                }
                 if (FOLD) return mt == MT - 1 ? __builtin_bit_cast(X8, tl[s * 2]) : __builtin_bit_cast(X8, tb[mt * 32 * CPR + s * 2]);
                 return mt == MT - 1 ? __builtin_bit_cast(X8, tl[(s * 2 + h) ^ swl])
                                     : __builtin_bit_cast(X8, tb[mt * 32 * CPR + ((s * 2 + h) ^ swa)]);
@@ -289,6 +307,16 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
                     a = fq_max3(a, t[r], t[r + 1]);
                     b = fq_min3(b, t[r], t[r + 1]);
                 }
+                if (ODDN && nval < 16) {   // the half-wave N cuts: its first nval columns only (N % 4 == 0: whole pairs)
+                    a = -INFINITY;
+                    b = INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2)
+                        if (r < nval) {
+                            a = fq_max3(a, t[r], t[r + 1]);
+                            b = fq_min3(b, t[r], t[r + 1]);
+                        }
+                }
                 const bool ok = nvalid && (mo < MT - 1 || (mo * 32 + c) < M);   // (only the last row tile can hold padding rows)
                 pmx[mo] = ok ? a : -INFINITY;
                 pmn[mo] = ok ? b : INFINITY;
@@ -361,7 +389,16 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
                 uint8_t* qtok = out.q[ci] + tok * ((int64_t)M * (N / 2)) + (h * NT * 16 + wq * 16) / 2;
 #pragma unroll
                 for (int mo = 0; mo < MT; ++mo)
-                    if (nvalid && (mo * 32 + c) < M) *reinterpret_cast<uint2*>(qtok + (mo * 32 + c) * (N / 2)) = pk[mo];
+                    if (nvalid && (mo * 32 + c) < M) {
+                        uint8_t* dst = qtok + (mo * 32 + c) * (N / 2);
+                        if (!ODDN) *reinterpret_cast<uint2*>(dst) = pk[mo];
+                        else if (nval == 16) *reinterpret_cast<tl_uint2_a2*>(dst) = pk[mo];   // (row pitch N / 2 = 74 bytes: 2-byte aligned)
+                        else {   // nval = 4, 8 or 12 columns: 2, 4 or 6 bytes
+                            if (nval >= 4) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)pk[mo].x;
+                            if (nval >= 8) *reinterpret_cast<uint16_t*>(dst + 2) = (uint16_t)(pk[mo].x >> 16);
+                            if (nval >= 12) *reinterpret_cast<uint16_t*>(dst + 4) = (uint16_t)pk[mo].y;
+                        }
+                    }
                 if (wq == 0 && lane == 0) reinterpret_cast<T*>(out.scale[ci])[tok] = (T)scale;
             }
         }
@@ -410,6 +447,10 @@ int fq_launch_kron_tiles(int flags, const f16* x, const void* ws, const f16* dia
     }
     if (N == 192 && M > 128 && M <= 144) { // 144 x 192: two groups of six waves, R streamed; 160 KB hold nine K-steps of L
         return launch_tiles<5, 6, 192, 2, 9, true>(b, x, w, rows, M, out, n_cu, stream);
+    }
+    if (N == 148 && M > 96 && M <= 128 && !(M & 1)) {   // 128 x 148 (18944, Qwen2.5-7B ffn): two groups of five waves, rows of 296 bytes
+        return lks == 7 ? launch_tiles<4, 5, 148, 2, 7, false>(b, x, w, rows, M, out, n_cu, stream)
+                        : launch_tiles<4, 5, 148, 2, 8, false>(b, x, w, rows, M, out, n_cu, stream);
     }
     if (N == 176 && M > 160 && M <= 192) { // 168 x 176 (29568, Qwen2.5-72B ffn): ONE group of six waves (two tokens + the L image would need 184 KB);
                                            // the next token's DMA still runs under GEMM 2 and the quantiser

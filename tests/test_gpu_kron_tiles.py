@@ -36,7 +36,8 @@ def make(M, N, rows, seed, spike=True):
 
 # (M, N): both K-step counts of every row-tile class, DMA tails (M * N / 8 % 64 != 0) and whole-instruction tokens
 PAIRS = [(80, 112), (66, 112), (96, 112), (88, 112), (128, 144), (98, 144), (112, 144), (100, 144), (126, 144),
-         (144, 192), (129, 192), (130, 192), (137, 192), (86, 128), (66, 128), (96, 128), (168, 176), (162, 176), (178, 176)]
+         (144, 192), (129, 192), (130, 192), (137, 192), (86, 128), (66, 128), (96, 128), (168, 176), (162, 176), (178, 176),
+         (128, 148), (98, 148), (112, 148), (126, 148)]   # N % 16 != 0: rows of 296 bytes, a quarter-valid last half-tile
 
 
 @pytest.mark.parametrize("M,N", PAIRS)
@@ -57,7 +58,7 @@ def test_bit_equal_to_workgroup_kernel_and_oracle(ops, M, N, rows):
             assert np.array_equal(o.scale[k].cpu().numpy(), ref["scale16"]), (M, N, rows, sig)
 
 
-@pytest.mark.parametrize("M,N", [(80, 112), (128, 144), (144, 192)])
+@pytest.mark.parametrize("M,N", [(80, 112), (128, 144), (144, 192), (128, 148), (168, 176)])
 @pytest.mark.parametrize("flags", [P | NC0, P, P | R16 | NC0])
 def test_flag_routes_bit_equal_to_workgroup_kernel(ops, M, N, flags):
     """Path A / path B rounding and the no-clamp statistics: same bits as the kernel that also returns the transform. The
@@ -76,7 +77,7 @@ def test_flag_routes_bit_equal_to_workgroup_kernel(ops, M, N, flags):
         assert torch.equal(a.q[0], b.q[0]) and torch.equal(a.scale[0], b.scale[0]), sgn
 
 
-@pytest.mark.parametrize("M,N,rows", [(80, 112, 16384), (128, 144, 8192), (144, 192, 8192)])
+@pytest.mark.parametrize("M,N,rows", [(80, 112, 16384), (128, 144, 8192), (144, 192, 8192), (128, 148, 8192), (168, 176, 4096)])
 def test_full_size_bit_equal_and_repeatable(ops, M, N, rows):
     """Full-size launches: every token equals the workgroup-per-token kernel's, and ten launches in a row give the same bytes
     (tokens are claimed dynamically: the schedule differs from launch to launch)."""
@@ -110,7 +111,7 @@ def test_grouped_launch(ops, M, N):
 def test_oracle_end_to_end_dyadic(ops):
     """Dyadic factors and tokens (every product and sum exact in fp16 / fp32): the whole launch equals the oracle's path-A
     transform + quantiser bit for bit, for each pair."""
-    for M, N in ((80, 112), (128, 144), (144, 192)):
+    for M, N in ((80, 112), (128, 144), (144, 192), (128, 148), (168, 176), (86, 128)):
         gen = torch.Generator().manual_seed(M + N)
         x = (torch.randint(-8, 9, (64, M * N), generator=gen).float() / 8).half()
         L = torch.zeros(M, M)
@@ -130,7 +131,8 @@ def _bits(t):
     return t.view(torch.int16).cpu().numpy().view(np.uint16)
 
 
-@pytest.mark.parametrize("M,N", [(80, 112), (128, 144), (112, 144), (144, 192), (130, 192), (112, 128), (86, 128), (128, 128), (100, 128)])
+@pytest.mark.parametrize("M,N", [(80, 112), (128, 144), (112, 144), (144, 192), (130, 192), (112, 128), (86, 128), (128, 128), (100, 128), (128, 148),
+                                 (110, 148), (168, 176)])
 @pytest.mark.parametrize("rows", [1, 7, 300])
 def test_bf16_packed_only_launches(ops, M, N, rows):
     """bf16 activations and factors (the DeepSeek-V3 flow runs under torch.set_default_dtype(bfloat16), main_dpskv3.py:395; 18432 =
