@@ -29,6 +29,9 @@ namespace {
 #ifndef TILES_DA
 #define TILES_DA 0   // 0: the per-geometry default below
 #endif
+#ifndef TILES_G144
+#define TILES_G144 2
+#endif
 #ifndef TILES_RS144
 #define TILES_RS144 false
 #endif
@@ -442,8 +445,8 @@ int fq_launch_kron_tiles(int flags, const f16* x, const void* ws, const f16* dia
                         : launch_tiles<3, 4, 112, TILES_G112, 6, false>(b, x, w, rows, M, out, n_cu, stream);
     }
     if (N == 144 && M > 96 && M <= 128) {  // 128 x 144: two groups of five waves
-        return lks == 7 ? launch_tiles<4, 5, 144, 2, 7, TILES_RS144>(b, x, w, rows, M, out, n_cu, stream)
-                        : launch_tiles<4, 5, 144, 2, 8, TILES_RS144>(b, x, w, rows, M, out, n_cu, stream);
+        return lks == 7 ? launch_tiles<4, 5, 144, TILES_G144, 7, TILES_RS144>(b, x, w, rows, M, out, n_cu, stream)
+                        : launch_tiles<4, 5, 144, TILES_G144, 8, TILES_RS144>(b, x, w, rows, M, out, n_cu, stream);
     }
     if (N == 192 && M > 128 && M <= 144) { // 144 x 192: two groups of six waves, R streamed; 160 KB hold nine K-steps of L
         return launch_tiles<5, 6, 192, 2, 9, true>(b, x, w, rows, M, out, n_cu, stream);
