@@ -45,6 +45,7 @@ class FqKronJob(ctypes.Structure):
 _vp, _i64, _i, _f = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 _fp = ctypes.POINTER(ctypes.c_float)
 _vpp = ctypes.POINTER(ctypes.c_void_p)
+_ip = ctypes.POINTER(ctypes.c_int)
 SYMBOLS = {
     "fq_kron_quant_f16": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp, _vp, _i64,
                                _vp]),
@@ -84,6 +85,7 @@ SYMBOLS = {
     "fq_bf6_gemm_i32": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "fq_bf6_linear_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
     "fq_int4_linear_fp6_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _i64, _vp]),
+    "fq_int4_linear_fp6_multi_f16": (_i, [_i, _vpp, _vpp, _vpp, _vpp, _vpp, _vpp, _i64, _ip, _i, _vpp, _vp, _i64, _vp]),
     "fq_kv_quant_f16": (_i, [_vp, _vp, _i64, _i, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "fq_kv_dequant_f16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "fq_kv_append_i4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),

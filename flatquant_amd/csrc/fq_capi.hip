@@ -17,6 +17,8 @@ constexpr int64_t FQ_K64_IMAGE_BYTES = 16384, FQ_K64_WS_BYTES = 32768;
 int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream);
+int fq_launch_gemm_bf6_multi(int n, const uint8_t* const* xblob, const uint8_t* const* wblob, int64_t M, const int* Ns, int K, f16* const* y,
+                             const f16* const* srow, const f16* const* scol, const f16* const* bias, hipStream_t stream);   // fq_gemm_bf6.hip
 int fq_launch_fakequant_bits(int bf16_dtype, const void* x, void* y, int64_t rows, int cols, float sig_max, float sig_min, int bits, int flags,
                              int n_cu, hipStream_t stream);   // fq_quant.hip
 int fq_launch_kron64_multi(int bf16_dtype, const void* jobs, int n_jobs, int bpj, const FqQuantOut& out, hipStream_t stream);
@@ -735,6 +737,54 @@ int fq_int4_linear_fp6_f16(const void* x, const void* x_scale, const void* w, co
     }
     rc = fq_launch_gemm_bf6(xs, wsrc, M, N, K, nullptr, (f16*)y, (const f16*)x_scale, (const f16*)w_scale, (const f16*)bias,
                             (hipStream_t)stream);
+    return check_launch(rc, what);
+}
+
+int fq_int4_linear_fp6_multi_f16(int n, const void* const* x, const void* const* x_scale, const void* const* w, const void* const* wblob,
+                                 const void* const* w_scale, const void* const* bias, int64_t M, const int* N, int K, void* const* y,
+                                 void* scratch, int64_t scratch_bytes, void* stream) {
+    const char* what = "fq_int4_linear_fp6_multi_f16";
+    if (n < 1 || n > 4) return fail(FQ_EINVAL, "%s: 1..4 problems (got %d)", what, n);
+    if (!x || !x_scale || !w || !wblob || !w_scale || !bias || !N || !y) return fail(FQ_EINVAL, "%s: NULL table", what);
+    if (M < 0 || K <= 0) return fail(FQ_EINVAL, "%s: bad sizes", what);
+    if (M == 0) return FQ_OK;
+    if (!scratch) return fail(FQ_EINVAL, "%s: scratch is NULL", what);
+    if ((K & 127) || K > (1 << 18)) return fail(FQ_EUNSUPPORTED, "%s: K=%d not covered (K %% 128)", what, K);
+    int64_t need = 0;
+    for (int p = 0; p < n; ++p) {
+        if (N[p] <= 0 || (N[p] & 15)) return fail(FQ_EUNSUPPORTED, "%s: N[%d]=%d not covered (N %% 16)", what, p, N[p]);
+        if (!x[p] || !y[p] || !x_scale[p] || !w_scale[p] || (!w[p] && !wblob[p])) return fail(FQ_EINVAL, "%s: NULL pointer in problem %d", what, p);
+        FQ_NEED_ALIGN16(what, x[p], w[p], wblob[p], y[p], w_scale[p], bias[p]);
+        bool seen = false;   // problems that share their activations (the same packed x) share one converted operand
+        for (int q = 0; q < p; ++q) seen |= x[q] == x[p];
+        if (!seen) need += fq_bf6_blob_bytes(M, K);
+        if (!wblob[p]) need += fq_bf6_blob_bytes(N[p], K);
+    }
+    FQ_NEED_ALIGN16(what, scratch);
+    if (scratch_bytes < need) return fail(FQ_EINVAL, "%s: scratch of %lld bytes required (got %lld)", what, (long long)need, (long long)scratch_bytes);
+    uint8_t* cur = static_cast<uint8_t*>(scratch);
+    const uint8_t* xb[4];
+    const uint8_t* wb[4];
+    for (int p = 0; p < n; ++p) {
+        xb[p] = nullptr;
+        for (int q = 0; q < p; ++q)
+            if (x[q] == x[p]) xb[p] = xb[q];
+        if (!xb[p]) {
+            int rc = fq_launch_i4_to_bf6((const uint8_t*)x[p], M, K, 0, cur, cu_count(), (hipStream_t)stream);
+            if (rc != 0) return check_launch(rc, what);
+            xb[p] = cur;
+            cur += fq_bf6_blob_bytes(M, K);
+        }
+        wb[p] = (const uint8_t*)wblob[p];
+        if (!wb[p]) {
+            int rc = fq_launch_i4_to_bf6((const uint8_t*)w[p], N[p], K, 1, cur, cu_count(), (hipStream_t)stream);
+            if (rc != 0) return check_launch(rc, what);
+            wb[p] = cur;
+            cur += fq_bf6_blob_bytes(N[p], K);
+        }
+    }
+    const int rc = fq_launch_gemm_bf6_multi(n, xb, wb, M, N, K, (f16* const*)y, (const f16* const*)x_scale, (const f16* const*)w_scale,
+                                            (const f16* const*)bias, (hipStream_t)stream);
     return check_launch(rc, what);
 }
 

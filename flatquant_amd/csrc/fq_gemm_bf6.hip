@@ -123,18 +123,48 @@ __global__ __launch_bounds__(256) void fq_i4_to_bf6_kernel(const uint8_t* __rest
 // ---- the GEMM ---------------------------------------------------------------------------------------------------
 typedef int i32x6 __attribute__((ext_vector_type(6)));
 
-template <int BM>
-__global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB, const uint8_t* __restrict__ WB,
-                                                                              int M, int N, int KB, int n_vblocks, GemmOut out) {
+// MULTI (round 4): up to four problems that share M and K — q / k / v, or up / gate of one layer: their own quantised activations, weights,
+// scales and outputs (deploy/nn/linear.py:40-54 once per projection) — as ONE launch: the feature tiles of the problems are laid side by
+// side in the tile sequence (problem p owns the column tiles [tn0[p], tn0[p + 1])), and a tile picks its problem's pointers. 2048
+// tokens x 4096 features are 128 tiles of 256 x 256 on 256 CUs: three such launches leave half the chip idle three times.
+template <bool MULTI> struct GemmMultiArg {};
+template <> struct GemmMultiArg<true> {
+    int n, tn0[5], N[4];
+    const uint8_t* xb[4];
+    const uint8_t* wb[4];
+    GemmOut out[4];
+};
+
+template <int BM, bool MULTI = false>
+__global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB_, const uint8_t* __restrict__ WB_,
+                                                                              int M, int N_, int KB, int n_vblocks, GemmOut out_,
+                                                                              GemmMultiArg<MULTI> mp) {
+    const uint8_t* XB = XB_;
+    const uint8_t* WB = WB_;
+    int N = N_;
+    GemmOut out = out_;
+    // (wave-uniform selects: a dynamic index into a by-value kernel argument could send it through scratch)
+#define FQ_PICK(arr, p) ((p) == 0 ? mp.arr[0] : (p) == 1 ? mp.arr[1] : (p) == 2 ? mp.arr[2] : mp.arr[3])
+    auto problem_of = [&](int& nb) -> int {   // global column tile -> (problem, its own column tile)
+        int p = 0;
+        if constexpr (MULTI) {
+            p = nb >= mp.tn0[3] ? 3 : nb >= mp.tn0[2] ? 2 : nb >= mp.tn0[1] ? 1 : 0;
+            p = p < mp.n ? p : mp.n - 1;
+            nb -= FQ_PICK(tn0, p);
+        }
+        return p;
+    };
     constexpr int NWM = Geo<BM>::NWM, TILE_BYTES = Geo<BM>::TILE_BYTES, DPW = Geo<BM>::DPW, STAGES = Geo<BM>::STAGES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % NWM, wn = wave / NWM;  // wave tile: tokens (32 TMT) wm .., features 64 wn ..
-    const int TMg = (M + BM - 1) / BM, TNg = (N + BN - 1) / BN;
+    int TNg_ = (N + BN - 1) / BN;
+    if constexpr (MULTI) TNg_ = mp.tn0[4];   // (slots behind the last problem hold the total)
+    const int TMg = (M + BM - 1) / BM, TNg = TNg_;
     const int nk = KB / 2;  // stages of 128 k
     const bool may_clamp = KB > 10176 / 64;   // |q| <= 64 K: beyond K = 10176 the epilogue's clamp to +-65176 (x 10) can bind
-    const int mt_last = (M + 31) / 32 - 1, nt_last = (N + 31) / 32 - 1;
+    const int mt_last = (M + 31) / 32 - 1;
 
     // DMA plan: instruction i = DPW wave + j: the first 24 the weight row tiles, then the token row tiles; row tile (i % 24) / 3
     // (resp. (i - 24) / 3), 1 KB part i % 3 of its 3 KB.
@@ -142,7 +172,16 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
     // pointers — those had pushed the kernel into a spill whose reload sat between the DMA instructions of a stage
     // behind an s_waitcnt vmcnt(0), i.e. every stage waited for its own loads (found in the ISA, cost ~2x).
     const unsigned char* gbase[DPW];
-    auto plan = [&](int mb, int nb) {
+    auto plan = [&](int mb, int nb, int p) {
+        const uint8_t* WBp = WB;
+        const uint8_t* XBp = XB;
+        int Np = N;
+        if constexpr (MULTI) {
+            WBp = FQ_PICK(wb, p);
+            XBp = FQ_PICK(xb, p);
+            Np = FQ_PICK(N, p);
+        }
+        const int nt_last = (Np + 31) / 32 - 1;
 #pragma unroll
         for (int j = 0; j < DPW; ++j) {
             const int i = wave * DPW + j;
@@ -150,7 +189,7 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
             int rt = (op == 0 ? nb * BN : mb * BM) / 32 + t;
             const int last = op == 0 ? nt_last : mt_last;
             rt = rt < last ? rt : last;  // tiles beyond the matrix re-read its last tile (their outputs are never stored)
-            gbase[j] = (op == 0 ? WB : XB) + (int64_t)rt * KB * BLOB + part * 1024;
+            gbase[j] = (op == 0 ? WBp : XBp) + (int64_t)rt * KB * BLOB + part * 1024;
         }
     };
     const unsigned voff = (unsigned)lane * 16u;
@@ -229,7 +268,8 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
 
     int vb = blockIdx.x, mb = 0, nb = 0;
     if (!next_tile(vb, mb, nb)) return;
-    plan(mb, nb);
+    int prob = problem_of(nb);
+    plan(mb, nb, prob);
     request_first_stages();
     {   // the first tile starts as soon as its first stage is there
         const int younger = nk - 1 < STAGES - 1 ? nk - 1 : STAGES - 1;
@@ -239,6 +279,10 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
     }
     __builtin_amdgcn_s_barrier();
     for (;;) {
+        if constexpr (MULTI) {
+            N = FQ_PICK(N, prob);
+            out = FQ_PICK(out, prob);
+        }
         const int m0 = mb * BM, n0 = nb * BN;
         static_assert(TMT == 4, "the asm statement behind the K loop names sr[0..3]");
         f16 sr[TMT] = {};
@@ -294,10 +338,12 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
         // the next tile of this workgroup: its first stages are requested NOW, in front of the epilogue
         int nvb = vb + (int)gridDim.x, nmb = 0, nnb = 0;
         const bool more = next_tile(nvb, nmb, nnb);
+        int nprob = 0;
         if (more) {
+            nprob = problem_of(nnb);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();   // every wave has read the last stage: all three buffers are free
-            plan(nmb, nnb);
+            plan(nmb, nnb, nprob);
             request_first_stages();
         }
 
@@ -336,6 +382,7 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
         vb = nvb;
         mb = nmb;
         nb = nnb;
+        prob = nprob;
         // The requested stages have had the whole epilogue to land. An interior tile with the fused epilogue alone issued exactly
         // 4 TMT stores behind them (vmcnt counts loads and stores in issue order on gfx9): the wait leaves those in flight — they
         // drain under the next tile's first stages. Every other case waits for everything.
@@ -346,6 +393,7 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
 #undef FQ_FRAG
 #undef FQ_MFMA1
 #undef FQ_READ1
+#undef FQ_PICK
 }
 
 }  // namespace
@@ -394,11 +442,63 @@ int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, in
     if (half) {
         FQ_RAISE_LDS_CAP(fq_gemm_bf6_kernel<128>, Geo<128>::STAGES * Geo<128>::TILE_BYTES);
         hipLaunchKernelGGL(fq_gemm_bf6_kernel<128>, dim3((unsigned)blocks), dim3(Geo<128>::GT), Geo<128>::STAGES * Geo<128>::TILE_BYTES, stream, xblob,
-                           wblob, (int)M, N, K / 64, (int)n_vblocks, o);
+                           wblob, (int)M, N, K / 64, (int)n_vblocks, o, GemmMultiArg<false>{});
     } else {
         FQ_RAISE_LDS_CAP(fq_gemm_bf6_kernel<256>, Geo<256>::STAGES * Geo<256>::TILE_BYTES);
         hipLaunchKernelGGL(fq_gemm_bf6_kernel<256>, dim3((unsigned)blocks), dim3(Geo<256>::GT), Geo<256>::STAGES * Geo<256>::TILE_BYTES, stream, xblob,
-                           wblob, (int)M, N, K / 64, (int)n_vblocks, o);
+                           wblob, (int)M, N, K / 64, (int)n_vblocks, o, GemmMultiArg<false>{});
+    }
+    return (int)hipGetLastError();
+}
+
+// Up to four problems with common M and K in one launch (fq_gemm_bf6_kernel<BM, true>). -1000: shape not covered.
+int fq_launch_gemm_bf6_multi(int n, const uint8_t* const* xblob, const uint8_t* const* wblob, int64_t M, const int* Ns, int K, f16* const* y,
+                             const f16* const* srow, const f16* const* scol, const f16* const* bias, hipStream_t stream) {
+    if (n < 1 || n > 4 || (K & 127) || K > (1 << 18) || M < 1 || M > (1 << 30)) return -1000;
+    GemmMultiArg<true> mp = {};
+    mp.n = n;
+    int tn = 0;
+    for (int p = 0; p < 4; ++p) {
+        const int q = p < n ? p : n - 1;   // (unused slots repeat the last problem: the selects never read garbage)
+        if (Ns[q] < 1 || (Ns[q] & 15)) return -1000;
+        mp.tn0[p] = tn;
+        if (p < n) tn += (Ns[q] + BN - 1) / BN;
+        mp.N[p] = Ns[q];
+        mp.xb[p] = xblob[q];
+        mp.wb[p] = wblob[q];
+        mp.out[p].c = nullptr;
+        mp.out[p].y = y[q];
+        mp.out[p].srow = srow[q];
+        mp.out[p].scol = scol[q];
+        mp.out[p].bias = bias[q];
+    }
+    for (int p = n; p < 5; ++p) mp.tn0[p] = tn;
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus[dev] == 0) {
+        int c = 0;
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        cus[dev] = c;
+    }
+    const int64_t tiles256 = ((M + 255) / 256) * tn;
+    const bool half = tiles256 * 4 < (int64_t)cus[dev] * 3;
+    const int bm = half ? 128 : 256;
+    const int64_t n_vblocks = 8 * ((((M + bm - 1) / bm) * tn + 7) / 8);
+    int64_t blocks = (cus[dev] / 8) * 8;
+    if (blocks < 8) blocks = 8;
+    if (blocks > n_vblocks) blocks = n_vblocks;
+    GemmOut o0 = mp.out[0];
+    if (half) {
+        auto kern = fq_gemm_bf6_kernel<128, true>;
+        FQ_RAISE_LDS_CAP(kern, Geo<128>::STAGES * Geo<128>::TILE_BYTES);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Geo<128>::GT), Geo<128>::STAGES * Geo<128>::TILE_BYTES, stream, mp.xb[0], mp.wb[0],
+                           (int)M, mp.N[0], K / 64, (int)n_vblocks, o0, mp);
+    } else {
+        auto kern = fq_gemm_bf6_kernel<256, true>;
+        FQ_RAISE_LDS_CAP(kern, Geo<256>::STAGES * Geo<256>::TILE_BYTES);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Geo<256>::GT), Geo<256>::STAGES * Geo<256>::TILE_BYTES, stream, mp.xb[0], mp.wb[0],
+                           (int)M, mp.N[0], K / 64, (int)n_vblocks, o0, mp);
     }
     return (int)hipGetLastError();
 }

@@ -139,3 +139,32 @@ class Linear4bit(torch.nn.Module):
             if module.bias is not None:
                 int_module.bias.copy_(module.bias.data)
         return int_module
+
+
+def linear4bit_multi(modules, inputs):
+    """Several ``Linear4bit`` modules of one decoder layer that see the same token count and input width — q_proj / k_proj / v_proj, or
+    up_proj / gate_proj (deploy/transformers/modeling_llama.py:66-78, 268-276: one GEMM + dequant per projection in the reference) — each
+    on its own PackedQuantizedTensor, as ONE GEMM launch on the FP6 matrix path (round 4, fq_int4_linear_fp6_multi_f16): at prefill sizes
+    of a few thousand tokens a single projection does not fill the chip. Returns one fp16 tensor per module, bit-identical to
+    ``m(x)``. Falls back to the modules' own forward when the FP6 route does not apply to every one of them (decode-sized inputs, shapes
+    the FP6 path does not cover, fp6_gemm off, layers narrower than fp6_min_out_features without a kept image)."""
+    assert len(modules) == len(inputs) and len(modules) >= 1
+    q0 = inputs[0].quantized_x
+    rows = q0.numel() // q0.shape[-1]
+    ok = 1 <= len(modules) <= 4 and q0.is_cuda and not ops.skinny_supported(rows, modules[0].in_features)
+    for m, x in zip(modules, inputs):
+        assert type(x) == PackedQuantizedTensor
+        ok = ok and m.fp6_gemm and ops.bf6_supported(m.out_features, m.in_features) and x.quantized_x.shape == q0.shape
+        ok = ok and m.in_features == modules[0].in_features
+        ok = ok and (m._weight_image() is not None or (m.fp6_transient_rows and rows >= m.fp6_transient_rows
+                                                        and m.out_features >= m.fp6_min_out_features))
+    if not ok:
+        return [m(x) for m, x in zip(modules, inputs)]
+    problems = []
+    for m, x in zip(modules, inputs):
+        ws16, b16 = m._scales16()
+        q = x.quantized_x
+        problems.append((q.reshape(-1, q.shape[-1]).contiguous(), x.scales_x.reshape(-1).contiguous(), m.weight, m._weight_image(), ws16, b16))
+    ys = ops.int4_linear_fp6_multi(problems)
+    lead = q0.shape[:-1]
+    return [y.view(*lead, m.out_features) for y, m in zip(ys, modules)]

@@ -753,15 +753,17 @@ def hadamard(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None,
              scale: Optional[float] = None, fwht_route: bool = False) -> torch.Tensor:
     """hadK @ FWHT(x.view(rows, K, n/K)) * scale. Routes: the register FWHT + K-factor kernel (fq_hadamard_f16; bit-exact for K = 1,
     the route of every K = 1 call); for K > 1 a matrix-pipe launch where one exists — the rotation as a dense Kronecker pair with the
-    transform as its only output (11008 = 172 x 64, 8960, 5120, 14336 = 112 x 128), else the structured kernel (n = K * 512). The
+    transform as its only output (11008 = 172 x 64, 8960, 5120), or the structured kernel (n = K * 512: 14336). The
     matrix-pipe routes round the intermediate to fp16 at other points: within 1e-3 of the row maximum of the exact rotation, not
     bit-identical to the first route. ``fwht_route=True`` forces the first."""
     if K > 1 and hadK is not None and not fwht_route and x.numel() > 0 and x.shape[-1] % K == 0 and hadK.shape == (K, K):
         # (round 4) tall rotations — 11008 = 172 x 64 (Llama-2-7B), 8960 = 140 x 64, 5120 = 80 x 64 ... — as ONE dense Kronecker launch
         # with the transform as its only output (fq_kron_tall.hip: 464 -> ~200 us per 16384 tokens of 11008); tolerance parity
         # as the fused launch of the same pair (hadamard_quant), fwht_route=True keeps the bit-identical register FWHT
-        # 14336 = 112 x 128 too: with the transform as the ONLY output the dense pair's LDS-staged 1 KB stores (188 us) beat the
-        # structured kernel's 32-byte pieces (208 us; profiles/r04_hadamard_routes.txt) — the structured kernel is the fused one
+        # 14336 = 28 * 512: the structured matrix-pipe kernel (end to end through this function, 16384 tokens: 181 us against 244 for the
+        # dense 112 x 128 pair with its post-scale and 238 for the FWHT route: profiles/r04_hadamard_standalone.txt, last block)
+        if had_mfma_supported(x.shape[-1], K):
+            return hadamard_mfma(x, K, hadK, None, scale, True)[0]
         kr = _hadamard_as_kron(K, x.shape[-1] // K, hadK, x.device)
         if kr is not None and kr[2] in (64, 128):
             _chk(x, "x"), _chk(hadK, "hadK")
@@ -769,8 +771,6 @@ def hadamard(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None,
             sc = float(1.0 / torch.tensor(n).sqrt()) if scale is None else scale
             o = kron_quant_ex(x.reshape(-1, n), kr[0], kr[1], _had_right_div(kr[2]) * sc, [(1.0, 1.0)], FQ_OUT_TRANSFORM | FQ_ROUND_Y_F16)
             return o.y.reshape(x.shape)
-        if had_mfma_supported(x.shape[-1], K):
-            return hadamard_mfma(x, K, hadK, None, scale, True)[0]
     _chk(x, "x")
     n = x.shape[-1]
     if K > 1:
@@ -1002,6 +1002,45 @@ def int4_linear_fp6(x: torch.Tensor, x_scale: torch.Tensor, w: torch.Tensor, w_i
         check(lib.fq_int4_linear_fp6_f16(_ptr(x), _ptr(x_scale), _ptr(w), _ptr(w_image), _ptr(w_scale), _ptr(bias), M, N, K, _ptr(y),
                                          _ptr(scratch), nbytes, _stream(x)))
     return y
+
+
+def int4_linear_fp6_multi(problems) -> list:
+    """Up to four Linear4bit problems that share M and K (q / k / v, or up / gate of one layer) as ONE GEMM launch
+    (fq_int4_linear_fp6_multi_f16). ``problems``: a sequence of (x packed [M, K/2], x_scale [M], w packed [N, K/2], w_image or None,
+    w_scale [N], bias [N] or None) -> a list of fp16 [M, N] tensors, each bit-identical to int4_linear_fp6() of its problem."""
+    n = len(problems)
+    if not 1 <= n <= 4:
+        raise ValueError("int4_linear_fp6_multi: 1..4 problems")
+    x0 = problems[0][0]
+    M, K = x0.shape[0], x0.shape[1] * 2
+    Ns, nbytes, seen = [], 0, []
+    for x, xs, w, wimg, ws, b in problems:
+        _chk(x, "x", torch.uint8), _chk(w, "w", torch.uint8), _chk(xs, "x_scale"), _chk(ws, "w_scale")
+        if b is not None:
+            _chk(b, "bias")
+        if x.dim() != 2 or w.dim() != 2 or x.shape != x0.shape or w.shape[1] != x.shape[1]:
+            raise RuntimeError("int4_linear_fp6_multi: the problems must share M and K (x [M, K/2], w [N, K/2])")
+        N = w.shape[0]
+        if xs.numel() != M or ws.numel() != N or (b is not None and b.numel() != N):
+            raise RuntimeError("int4_linear_fp6_multi: scale / bias sizes do not match M / N")
+        if not bf6_supported(N, K):
+            raise _lib.FqError(_lib.FQ_EUNSUPPORTED, f"int4_linear_fp6_multi: N={N} K={K} not covered (K % 128, N % 16)")
+        Ns.append(N)
+        if x.data_ptr() not in seen:
+            seen.append(x.data_ptr())
+            nbytes += int(lib.fq_bf6_blob_bytes(M, K))
+        if wimg is None:
+            nbytes += int(lib.fq_bf6_blob_bytes(N, K))
+    ys = [torch.empty((M, N), dtype=torch.float16, device=x0.device) for N in Ns]
+    if M == 0:
+        return ys
+    scratch = torch.empty((nbytes,), dtype=torch.uint8, device=x0.device)
+    VP = ctypes.c_void_p * n
+    tab = lambda k: VP(*[None if pr[k] is None else pr[k].data_ptr() for pr in problems])
+    with _on(x0.device):
+        check(lib.fq_int4_linear_fp6_multi_f16(n, tab(0), tab(1), tab(2), tab(3), tab(4), tab(5), M, (ctypes.c_int * n)(*Ns), K,
+                                               VP(*[y.data_ptr() for y in ys]), _ptr(scratch), nbytes, _stream(x0)))
+    return ys
 
 
 def kv_quant(x: torch.Tensor, trans: Optional[torch.Tensor] = None, clip: Sig = (1.0, 1.0), lac: bool = False,

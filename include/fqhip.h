@@ -372,6 +372,22 @@ int fq_int4_linear_fp6_f16(const void* x, const void* x_scale, const void* w, co
                            const void* bias, int64_t M, int N, int K, void* y, void* scratch, int64_t scratch_bytes, void* stream);
 
 /*
+ * (round 4) Up to FOUR Linear4bit problems that share their token count M and their K — q / k / v, or up / gate, of one decoder layer:
+ * each with its own quantised activations, weights, scales, bias and output (deploy/nn/linear.py:40-54 runs once per projection) — as
+ * ONE GEMM launch: the feature tiles of the problems are laid side by side in the persistent workgroups' tile sequence. At 2048 tokens a
+ * 4096-wide projection is 128 tiles of 256 x 256 on 256 CUs; three launches leave half the chip idle three times. Bit-identical to n
+ * calls of fq_int4_linear_fp6_f16.
+ *   n in 1..4; tables of n pointers: x[p] packed [M, K/2], x_scale[p] [M] fp16, w[p] packed [N[p], K/2] or NULL with wblob[p] its FP6
+ *   image (one of the two), w_scale[p] [N[p]] fp16, bias[p] [N[p]] fp16 or NULL, y[p] [M, N[p]] fp16. Problems whose x[p] pointers are
+ *   equal share one converted operand.
+ *   scratch_bytes >= sum over DISTINCT x of fq_bf6_blob_bytes(M, K) + sum over problems without a wblob of fq_bf6_blob_bytes(N[p], K).
+ *   K % 128 == 0, N[p] % 16 == 0 (FQ_EUNSUPPORTED otherwise).
+ */
+int fq_int4_linear_fp6_multi_f16(int n, const void* const* x, const void* const* x_scale, const void* const* w, const void* const* wblob,
+                                 const void* const* w_scale, const void* const* bias, int64_t M, const int* N, int K, void* const* y,
+                                 void* scratch, int64_t scratch_bytes, void* stream);
+
+/*
  * Normalised Hadamard transform over the last axis, n = K * 2^p:
  *   y = hadK [K,K] @ FWHT_{n/K}( x.view(rows, K, n/K) ) * scale         (hadamard_utils.py:132-141)
  * fp32 butterflies, result of the FWHT rounded to fp16 before the K-factor (as the un-vendored

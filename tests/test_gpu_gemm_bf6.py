@@ -185,3 +185,58 @@ def test_errors(ops):
     wb = ops.int4_to_bf6(torch.zeros(16, 32, dtype=torch.uint8, device="cuda"), weights=True)
     with pytest.raises(Exception):
         ops.bf6_matmul(xb, wb, 4, 16, 64)                                               # K % 128 != 0
+
+
+@pytest.mark.parametrize("M,Ns,K", [(300, (272, 256, 16), 256), (2048, (4096, 1024, 1024), 512), (129, (256,), 128), (2500, (1024, 1040), 384),
+                                    (4096 + 3, (4096, 4096, 4096, 512), 256), (16384, (2048, 2048), 128)])
+def test_multi_problem_launch_bit_identical_to_single_launches(ops, M, Ns, K):
+    """fq_int4_linear_fp6_multi_f16 (round 4): up to four problems with common M and K — each with its own activations, weights, scales,
+    bias, with a kept or a transient weight image — as one GEMM launch == one fq_int4_linear_fp6_f16 call per problem, bit for bit
+    (tile boundaries between problems that are not multiples of the 256-wide tile, 128- and 256-token tiles, shared activations)."""
+    gen = torch.Generator().manual_seed(M + sum(Ns) + K)
+    problems, want = [], []
+    x_shared = torch.from_numpy(rand_packed(gen, M, K)[0]).cuda()
+    for p, N in enumerate(Ns):
+        x = x_shared if p == 2 else torch.from_numpy(rand_packed(gen, M, K)[0]).cuda()     # (problems 0.. own x; problem 2 shares one)
+        if p == 0:
+            x_shared = x
+        if p == 2:
+            x = problems[0][0]
+        w = torch.from_numpy(rand_packed(gen, N, K)[0]).cuda()
+        sx = (torch.rand(M, generator=gen) * 0.05 + 0.001).half().cuda()
+        sw = (torch.rand(N, generator=gen) * 0.02 + 0.0005).half().cuda()
+        b = torch.randn(N, generator=gen).half().cuda() if p % 2 == 0 else None
+        img = ops.int4_to_bf6(w, weights=True) if p % 2 == 1 else None
+        problems.append((x, sx, w, img, sw, b))
+        want.append(ops.int4_linear_fp6(x, sx, w, img, sw, b))
+    got = ops.int4_linear_fp6_multi(problems)
+    assert len(got) == len(Ns)
+    for p in range(len(Ns)):
+        assert got[p].shape == (M, Ns[p]) and torch.equal(got[p].view(torch.int16), want[p].view(torch.int16)), p
+    with pytest.raises(Exception):
+        ops.int4_linear_fp6_multi(problems * 5)      # more than four
+
+
+def test_linear4bit_multi_module_entry(ops):
+    """deploy.nn.linear.linear4bit_multi: q / k / v modules on their own PackedQuantizedTensors in one launch == m(x) each; decode-sized
+    inputs and modules the FP6 route does not take fall back to the modules' own forward."""
+    from flatquant_amd.deploy import PackedQuantizedTensor
+    from flatquant_amd.deploy.nn.linear import Linear4bit, linear4bit_multi
+    gen = torch.Generator().manual_seed(9)
+    K = 512
+    mods = []
+    for N in (2048, 2048, 4096):
+        m = Linear4bit(K, N, bias=N == 4096).cuda()
+        m.weight.copy_(torch.from_numpy(rand_packed(gen, N, K)[0]))
+        m.weight_scales.copy_((torch.rand(N, 1, generator=gen) * 0.02 + 0.0005))
+        if m.bias is not None:
+            m.bias.copy_(torch.randn(N, generator=gen).half())
+        mods.append(m)
+    mods[1].fp6_image = True
+    for rows in (2048, 64):
+        xs = [PackedQuantizedTensor(torch.from_numpy(rand_packed(gen, rows, K)[0]).cuda().reshape(2, rows // 2, K // 2),
+                                    (torch.rand(2, rows // 2, 1, generator=gen) * 0.05 + 0.001).half().cuda()) for _ in mods]
+        ys = linear4bit_multi(mods, xs)
+        for m, x, y in zip(mods, xs, ys):
+            ref = m(x)
+            assert y.shape == ref.shape and torch.equal(y.view(torch.int16), ref.view(torch.int16)), (rows, m.out_features)

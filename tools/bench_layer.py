@@ -206,8 +206,27 @@ def main():
         us = timeit(lambda: lin(packed[k_in]), max(a.steps // 5, 5), warm=3)
         g6 += us
         del lin
-    deploy.nn.Linear4bit.fp6_image = False
     print(f"  {'seven linears, FP6 path':26s} {g6:9.1f} us;  FlatQuant layer, fused activation path + linears: {fused_struct + g6:.1f} us")
+    # (round 4) q / k / v as ONE GEMM launch and up / gate as one (deploy.nn.linear.linear4bit_multi, fq_int4_linear_fp6_multi_f16): each
+    # projection keeps its own packed input and weights; at a few thousand tokens a single projection does not fill the chip
+    from flatquant_amd.deploy.nn.linear import linear4bit_multi
+    deploy.nn.Linear4bit.fp6_min_out_features = 0      # (the 1024-wide k / v projections ride along in the q launch)
+    gm = 0.0
+    for names in (("q_proj", "k_proj", "v_proj"), ("o_proj",), ("up_proj", "gate_proj"), ("down_proj",)):
+        mods, ins = [], []
+        for name, k_in, n_out in lins:
+            if name in names:
+                lin = deploy.nn.Linear4bit(k_in, n_out).to(dev)
+                lin.weight_scales.fill_(0.01)
+                mods.append(lin)
+                ins.append(packed[k_in])
+        us = timeit(lambda: linear4bit_multi(mods, ins), max(a.steps // 5, 5), warm=3)
+        gm += us
+        print(f"  {'Linear4bit ' + ' + '.join(names) + ', one launch':58s} {us:9.1f} us")
+        del mods
+    deploy.nn.Linear4bit.fp6_min_out_features = 2048
+    deploy.nn.Linear4bit.fp6_image = False
+    print(f"  {'seven linears, FP6 path, q/k/v and up/gate as one launch each':62s} {gm:9.1f} us;  FlatQuant layer: {fused_struct + gm:.1f} us")
 
     # FP16 baseline of the same layer pieces (what benchmarks/layer_benchmark.py:200-274 compares against): the seven
     # nn.Linear GEMMs in fp16 (rocBLAS / hipBLASLt through torch), two RMSNorms and SiLU.mul in torch eager; the
@@ -227,7 +246,8 @@ def main():
     print(f"  fp16 layer (seven linears {f16tot:.1f} us + 2 x torch rms_norm {n16:.1f} + SiLU.mul eager {sm16:.1f}): {f16layer:.1f} us; "
           f"FlatQuant W4A4 layer {fused_struct + gtot:.1f} us -> {f16layer / (fused_struct + gtot):.2f}x "
           f"(linears alone {f16tot / gtot:.2f}x); with the FP6 operand image {fused_struct + g6:.1f} us -> "
-          f"{f16layer / (fused_struct + g6):.2f}x (linears alone {f16tot / g6:.2f}x)")
+          f"{f16layer / (fused_struct + g6):.2f}x (linears alone {f16tot / g6:.2f}x); with q/k/v and up/gate as one launch each "
+          f"{fused_struct + gm:.1f} us -> {f16layer / (fused_struct + gm):.2f}x (linears alone {f16tot / gm:.2f}x)")
 
 
 if __name__ == "__main__":
