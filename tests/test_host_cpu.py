@@ -460,7 +460,7 @@ def test_hot_kernels_keep_their_occupancy_budget():
         "fq_kron_wave_kernel<2,4,7,8,0,bf16>": (2, 0),
         "fq_kron_wave_kernel<1,2,4,16,0,bf16>": (4, 0),
         "fq_kron_fast_kernel<4,7,14,8,1,0,1,0,f16,0,0>": (2, 0),  # 128 x 224 packed (M <= 96 rows of it; 96 < M: the duo kernel)
-        "fq_kron_duo_kernel<4>": (2, 4),                  # 128 x 224 packed, two token groups per CU: 128 accumulators per wave, 4 spilled registers
+        "fq_kron_duo_kernel<4,1>": (2, 4),                  # 128 x 224 packed, two token groups per CU: 128 accumulators per wave, 4 spilled registers
         "fq_kron_fast_kernel<4,5,10,8,1,0,1,148,f16,0,0>": (2, 0),  # 128 x 148 packed (true row length 148)
         "fq_kron_fast_kernel<5,6,12,8,1,0,1,0,f16,0,0>": (2, 0),  # 144 x 192 packed
         "fq_kron_fast_kernel<4,4,8,4,2,0,-1,0,f16,0,0>": (2, 0),  # 112 x 128, every output set (the fake-quant contract)
@@ -478,8 +478,8 @@ def test_hot_kernels_keep_their_occupancy_budget():
         "fq_rowquant_wave_kernel<33,8,0,f16>": (4, 0),    # deploy Quantizer at 4096
         "fq_rowquant_wave_kernel<2,8,0,bf16>": (2, 0),    # ActivationQuantizer on bf16 rows of 4096
         "fq_had_pow2_kernel<8,1,1,1>": (3, 0),            # Hadamard 4096 + Quantizer
-        "fq_gemm_bf6_kernel<256>": (2, 0),                # Linear4bit, FP6 matrix path: 8 waves = two per SIMD, no spill (a spill's reload
-        "fq_gemm_bf6_kernel<128>": (2, 0),                # once sat between the DMA instructions of a stage behind s_waitcnt vmcnt(0))
+        "fq_gemm_bf6_kernel<256,0>": (2, 0),              # Linear4bit, FP6 matrix path: 8 waves = two per SIMD, no spill (a spill's reload
+        "fq_gemm_bf6_kernel<128,0>": (2, 0),              # once sat between the DMA instructions of a stage behind s_waitcnt vmcnt(0))
         "fq_gemm_i4_kernel": (4, 0),                      # int8 matrix path: 16 waves per workgroup
     }
     present = [k for k in budget if k in res]
