@@ -464,6 +464,10 @@ int fq_launch_kron_tiles(int flags, const f16* x, const void* ws, const f16* dia
         return lks == 5 ? launch_tiles<3, 4, 128, 3, 5, false>(b, x, w, rows, M, out, n_cu, stream)
                         : launch_tiles<3, 4, 128, 3, 6, false>(b, x, w, rows, M, out, n_cu, stream);
     }
+#ifdef TILES_G128X4   // measurement: 112 x 128 on FOUR groups of four waves (R streamed; 28 KB per token without zero rows + 28 KB of L = 140 KB)
+    if (N == 128 && M > 96 && M <= 112)
+        return launch_tiles<4, 4, 128, 4, 7, true>(b, x, w, rows, M, out, n_cu, stream);
+#endif
     if (b && N == 128 && M > 96 && M <= 128) {   // bf16 112 x 128: three groups of four waves (fp16: fq_kron_trio.hip, the same speed)
         return lks == 7 ? launch_tiles_t<4, 4, 128, 3, 7, false, bf16>((const bf16*)x, w, rows, M, out, n_cu, stream)
                         : launch_tiles_t<4, 4, 128, 3, 8, false, bf16>((const bf16*)x, w, rows, M, out, n_cu, stream);

@@ -77,6 +77,19 @@ def test_ops_reject_cpu_tensors_loudly():
                  lambda: ops.sym_quant(x, torch.ones(4).half()), lambda: ops.block_quant(x.view(4, 128, 32), m[:32, :32])):
         with pytest.raises(RuntimeError, match="no CPU path"):
             call()
+    # round 4 entry points: the bits != 4 quantiser, the single-matrix transform, the multi-problem linear
+    q = torch.zeros(256, 64, dtype=torch.uint8)
+    for call in (lambda: ops.fakequant_bits(x, (1.0, 1.0), 8),
+                 lambda: ops.single_trans(torch.zeros(4, 128, dtype=torch.float16), torch.eye(128, dtype=torch.float16)),
+                 lambda: ops.int4_linear_fp6_multi([(q, torch.ones(256).half(), q, None, torch.ones(256).half(), None)])):
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            call()
+    with pytest.raises(ValueError):
+        ops.int4_linear_fp6_multi([])
+    from flatquant_amd.flatquant.quant_utils import ActivationQuantizer
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ActivationQuantizer(bits=8, sym=True)(x)          # (routes to the HIP kernel: refuses a CPU tensor, does not fall back)
+    assert ActivationQuantizer(bits=16)(x) is x           # bits = 16 passes through, as in the reference (quant_utils.py:71-72)
 
 
 def test_get_decompose_dim_matches_reference_table(golden):
