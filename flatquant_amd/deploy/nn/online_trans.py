@@ -42,6 +42,29 @@ class OnlineTrans(torch.nn.Module):
         self.register_buffer("clip_factor_a_max", torch.tensor(1.0))
         self.register_buffer("clip_factor_a_min", torch.tensor(1.0))
 
+    static_outputs = False   # (round 4, opt-in, class or instance attribute) decomposed matmul transform: a prepared launch with STATIC
+                             # output buffers (ops.LaunchPlan) — the returned PackedQuantizedTensor is rewritten by the next call, as under
+                             # a captured graph. ~6 us of Python per call instead of ~20 (tools/host_overhead.py); same bits out.
+
+    def _planned(self, x):
+        # (buffers straight from the module's dict: nn.Module.__getattr__ costs ~0.5 us per name, four names per call)
+        bf = self._buffers
+        L, R, cmax, cmin = bf["left_matrix"], bf["right_matrix"], bf["clip_factor_a_max"], bf["clip_factor_a_min"]
+        st = self.__dict__.get("_plan_state")
+        if (st is None or st[0] is not L or st[1] != L._version or st[2] is not R or st[3] != R._version or st[4] != cmax._version
+                or st[5] != cmin._version or st[6] != ops.cache_epoch() or st[7].shape != x.shape or st[7].dtype != x.dtype
+                or st[7].device != x.device):
+            from .. import PackedQuantizedTensor
+            bsz, seq_len, _ = x.shape
+            sig = ops.sigmoid_pair(cmax, cmin)
+            plan = ops.kron_plan(x.contiguous(), L.contiguous(), R.contiguous(), [sig],
+                                 functional.online_trans.deploy_kron_flags(L.shape[0], R.shape[0]))
+            o = plan.outputs
+            plan.result = PackedQuantizedTensor(o.q[0].reshape(bsz, seq_len, -1), o.scale[0].reshape(bsz, 1, seq_len))
+            st = (L, L._version, R, R._version, cmax._version, cmin._version, ops.cache_epoch(), plan)
+            self.__dict__["_plan_state"] = st
+        return st[7].run(x)
+
     def forward(self, x, quantizer=None, norm=None, up=None):
         """``up`` (extension, optional): ``x`` is then x_gate and the transform consumes x_up * silu(x_gate)
         (FlatQuantLlamaMLP.forward, modeling_llama.py:277-279) formed inside the launch: trans="matmul" (decomposed)
@@ -97,6 +120,9 @@ class OnlineTrans(torch.nn.Module):
                                             self.right_matrix.contiguous(), [sig],
                                             functional.online_trans.deploy_kron_flags(self.left_matrix.shape[0], self.right_matrix.shape[0]))
                 return PackedQuantizedTensor(o.q[0].reshape(bsz, seq_len, -1), o.scale[0].reshape(bsz, 1, seq_len))
+        if self.static_outputs and self.trans == "matmul" and self.decompose and "left_matrix" in self._buffers and "right_matrix" in self._buffers \
+                and quantizer is None:
+            return self._planned(x)
         if self.trans == "matmul":
             invs = []
             if hasattr(self, "left_matrix"):

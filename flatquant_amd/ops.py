@@ -50,12 +50,21 @@ def _sig_f16_cached(a: float, b: float) -> Sig:
 _SCALARS: "collections.OrderedDict" = collections.OrderedDict()
 
 
+_CACHE_EPOCH = [0]
+
+
+def cache_epoch() -> int:
+    """Incremented by invalidate_caches(): part of the key of every cache a MODULE holds for itself."""
+    return _CACHE_EPOCH[0]
+
+
 def invalidate_caches() -> None:
     """Forget every value this module derived from tensors it does not own: host copies of clip scalars (host_scalar),
     fragment workspaces of factor matrices, Hadamard factor pairs. The caches are keyed by (data_ptr, tensor._version):
     an in-place write through the tensor itself (``t.fill_()``, ``t.copy_()``) bumps the version and is seen, a write
     through ``t.data`` (``mod.clip_factor_a_max.data.fill_(..)``, ``weight.data.copy_(..)``) does NOT — call this after
     such an update (checkpoint loaders that assign ``.data`` should), or update in place on the tensor."""
+    _CACHE_EPOCH[0] += 1    # (module-held launch plans carry the epoch in their key: deploy.nn.OnlineTrans / Quantizer with static_outputs)
     _SCALARS.clear()
     _sigmoid_pair_cached.cache_clear()
     _sig_f16_cached.cache_clear()
@@ -333,6 +342,112 @@ def kron_quant(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: S
         if key is not None and not prepared:
             _kron_workspace_commit(key, ws, left, right)
     return o
+
+
+class LaunchPlan:
+    """A prepared library call with STATIC outputs (round 4, the host path of VERDICT r03 item 4c): shapes, dtype, device, the factor pair /
+    clip sets, the output tensors, the fragment image and the ctypes argument list are fixed at construction; ``run(x)`` swaps in x's
+    address and the current stream and makes ONE foreign call — no allocation, no cache look-up, no argument conversion beyond ctypes'
+    own (tools/host_overhead.py: ~5 us per call where the general entry point spends 14-17). The outputs are REUSED by every call, as
+    under a captured graph: a caller that needs the previous result after the next call must copy it. Built by kron_plan() /
+    rowquant_plan(); ``result`` is whatever the builder put there (a FusedOutputs, or a module's PackedQuantizedTensor)."""
+    __slots__ = ("fn", "args", "shape", "dtype", "device", "dev_index", "keep", "result", "outputs")
+
+    def run(self, x: torch.Tensor):
+        if x.shape != self.shape or x.dtype != self.dtype or x.device != self.device or not x.is_contiguous():
+            raise ValueError(f"LaunchPlan: built for a contiguous {self.dtype} tensor of shape {tuple(self.shape)} on {self.device}, "
+                             f"got {x.dtype} {tuple(x.shape)} on {x.device}")
+        a = self.args
+        a[0] = x.data_ptr()
+        a[-1] = _stream_handle(self.device)
+        if torch.cuda.current_device() != self.dev_index:
+            with _on(self.device):
+                rc = self.fn(*a)
+        else:
+            rc = self.fn(*a)
+        if rc:
+            check(rc)
+        return self.result
+
+    def run2(self, x: torch.Tensor, x2: torch.Tensor):
+        """run() for entry points with two per-call inputs (argument 1 = x2: the packed activations AND their scales of a linear)"""
+        self.args[1] = x2.data_ptr()
+        return self.run(x)
+
+
+def skinny_linear_plan(x_like: torch.Tensor, w_image: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor], N: int) -> LaunchPlan:
+    """int4_skinny_linear (M <= 128 rows against a decode weight image) as a LaunchPlan: ``plan.run2(x_packed, x_scale)`` -> the static
+    fp16 [M, N] output. x_scale must be a contiguous fp16 tensor of M elements (not re-checked per call)."""
+    _chk(x_like, "x", torch.uint8), _chk(w_scale, "w_scale")
+    if bias is not None:
+        _chk(bias, "bias")
+    M, K = x_like.shape[0], x_like.shape[1] * 2
+    if M == 0 or w_scale.numel() != N:
+        raise ValueError("skinny_linear_plan: empty input or w_scale size")
+    y = torch.empty((M, N), dtype=torch.float16, device=x_like.device)
+    plan = LaunchPlan()
+    plan.fn = lib.fq_int4_skinny_linear_f16
+    plan.args = [0, 0, w_image.data_ptr(), w_scale.data_ptr(), None if bias is None else bias.data_ptr(), M, N, K, y.data_ptr(), 0]
+    plan.shape, plan.dtype, plan.device = x_like.shape, torch.uint8, x_like.device
+    plan.dev_index = x_like.device.index if x_like.device.index is not None else torch.cuda.current_device()
+    plan.keep = (w_image, w_scale, bias, y)
+    plan.outputs = plan.result = y
+    return plan
+
+
+def kron_plan(x_like: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),),
+              flags: int = FQ_OUT_PACKED) -> LaunchPlan:
+    """kron_quant(x, left, right, sigs, flags) as a LaunchPlan for inputs shaped like ``x_like`` (per-token scales, no diag). The fragment
+    image is prepared here; the plan keeps left / right alive and is only valid while they are not modified (the caller re-plans on a new
+    ``_version``, as deploy.nn.OnlineTrans does)."""
+    dt = _chk_act(x_like)
+    _chk(left, "left", dt), _chk(right, "right", dt)
+    M, N = left.shape[0], right.shape[0]
+    d = M * N
+    if left.shape != (M, M) or right.shape != (N, N) or x_like.shape[-1] != d:
+        raise ValueError("kron_plan: x [..., M*N], left [M, M], right [N, N]")
+    rows = x_like.numel() // d
+    if rows == 0:
+        raise ValueError("kron_plan: empty input")
+    smax, smin, n = _sig_arrays(sigs)
+    o = _alloc_outputs(x_like, rows, d, n, flags, x_like.shape[:-1] + (d // 2,), x_like.shape)
+    plan = LaunchPlan()
+    with _on(x_like.device):
+        nbytes = int(lib.fq_kron_workspace_bytes(M, N))
+        if nbytes < 0:
+            raise _lib.FqError(nbytes, f"no kernel for Kronecker factors ({M}, {N})")
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x_like.device)
+        if nbytes:
+            check(_fn("kron_prepare", dt)(_ptr(left), _ptr(right), M, N, _ptr(ws), nbytes, _stream(x_like)))
+    qa, sa, fa = _ptr_array(o.q), _ptr_array(o.scale), _ptr_array(o.fq)
+    plan.fn = _fn("kron_quant", dt)
+    plan.args = [0, left.data_ptr(), right.data_ptr(), None, rows, M, N, smax, smin, n, flags | (FQ_WS_PREPARED if nbytes else 0), qa, sa, fa,
+                 _ptr(o.y), ws.data_ptr() if nbytes else None, nbytes, 0]
+    plan.shape, plan.dtype, plan.device = x_like.shape, dt, x_like.device
+    plan.dev_index = x_like.device.index if x_like.device.index is not None else torch.cuda.current_device()
+    plan.keep = (left, right, ws, qa, sa, fa, smax, smin)
+    plan.outputs = plan.result = o
+    return plan
+
+
+def rowquant_plan(x_like: torch.Tensor, sigs: Sequence[Sig] = ((1.0, 1.0),), flags: int = FQ_OUT_PACKED) -> LaunchPlan:
+    """rowquant(x, sigs, flags) as a LaunchPlan for inputs shaped like ``x_like``."""
+    dt = _chk_act(x_like)
+    cols = x_like.shape[-1]
+    rows = x_like.numel() // cols
+    if rows == 0:
+        raise ValueError("rowquant_plan: empty input")
+    smax, smin, n = _sig_arrays(sigs)
+    o = _alloc_outputs(x_like, rows, cols, n, flags, x_like.shape[:-1] + (cols // 2,), x_like.shape)
+    qa, sa, fa = _ptr_array(o.q), _ptr_array(o.scale), _ptr_array(o.fq)
+    plan = LaunchPlan()
+    plan.fn = _fn("rowquant", dt)
+    plan.args = [0, rows, cols, smax, smin, n, flags, qa, sa, fa, 0]
+    plan.shape, plan.dtype, plan.device = x_like.shape, dt, x_like.device
+    plan.dev_index = x_like.device.index if x_like.device.index is not None else torch.cuda.current_device()
+    plan.keep = (qa, sa, fa, smax, smin)
+    plan.outputs = plan.result = o
+    return plan
 
 
 class KronMultiPlan:

@@ -322,3 +322,87 @@ def test_grouped_launch_with_one_factor_pair_per_group(ops, shape, dtype):
         o3 = ops.kron_quant_grouped(dev(g["h"]), dev(g["L2e"]), dev(g["R2e"]), dev(g["offsets"]), dev(g["sig2e"][:, 0].copy()),
                                     dev(g["sig2e"][:, 1].copy()), F | R16)
         assert np.mean(host(o3.fq[0]) != g["fq2_indep"]) <= 2e-3
+
+
+def test_launch_plans_and_static_output_modules():
+    """ops.kron_plan / ops.rowquant_plan (round 4): a prepared launch with static outputs gives the bits of the general entry point,
+    call after call, on changing inputs; a wrong shape / dtype / device is refused; deploy.nn.OnlineTrans / Quantizer with
+    static_outputs = True return the same values as without (their PackedQuantizedTensor is rewritten by the next call), re-plan
+    when a matrix or a clip factor changes in place, and after ops.invalidate_caches()."""
+    import torch
+    from flatquant_amd import deploy, ops
+    from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED, FQ_QUANT_F16, FQ_SIG_F16
+    gen = torch.Generator().manual_seed(77)
+    for (M, N, rows) in ((64, 64, 6), (112, 128, 40), (64, 128, 9)):
+        L = (torch.randn(M, M, generator=gen) / M ** 0.5).half().cuda()
+        R = (torch.randn(N, N, generator=gen) / N ** 0.5).half().cuda()
+        xs = [torch.randn(rows, M * N, generator=gen).half().cuda() for _ in range(3)]
+        sigs = [(0.98, 0.97), (0.8, 0.6)]
+        plan = ops.kron_plan(xs[0], L, R, sigs, FQ_OUT_PACKED | FQ_NO_CLAMP0)
+        for x in xs:
+            o = plan.run(x)
+            ref = ops.kron_quant(x, L, R, sigs, FQ_OUT_PACKED | FQ_NO_CLAMP0)
+            for ci in range(2):
+                assert torch.equal(o.q[ci], ref.q[ci]) and torch.equal(o.scale[ci], ref.scale[ci]), (M, N, ci)
+        import pytest
+        with pytest.raises(ValueError):
+            plan.run(xs[0][:-1])
+        with pytest.raises(ValueError):
+            plan.run(xs[0].to(torch.bfloat16))
+    x = torch.randn(5, 4096, generator=gen).half().cuda()
+    rp = ops.rowquant_plan(x, [(0.9, 0.9)], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)
+    for _ in range(2):
+        x = torch.randn(5, 4096, generator=gen).half().cuda()
+        o, ref = rp.run(x), ops.rowquant(x, [(0.9, 0.9)], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16)
+        assert torch.equal(o.q[0], ref.q[0]) and torch.equal(o.scale[0], ref.scale[0])
+    # modules
+    ot = deploy.nn.OnlineTrans(4096, trans="matmul", decompose=True, lac=True).cuda()
+    ot.left_matrix.copy_((torch.randn(64, 64, generator=gen) / 8).half())
+    ot.right_matrix.copy_((torch.randn(64, 64, generator=gen) / 8).half())
+    ot.clip_factor_a_max.fill_(3.0), ot.clip_factor_a_min.fill_(2.0)
+    qz = deploy.nn.Quantizer(lac=True).cuda()
+    qz2 = deploy.nn.Quantizer(input_clip_ratio=0.9).cuda()
+
+    def both(mod, x):
+        mod.static_outputs = False
+        a = mod(x)
+        mod.static_outputs = True
+        b = mod(x)
+        assert torch.equal(a.quantized_x, b.quantized_x) and torch.equal(a.scales_x, b.scales_x)
+        assert a.quantized_x.shape == b.quantized_x.shape and a.scales_x.shape == b.scales_x.shape
+        return b
+
+    for _ in range(3):
+        x3 = torch.randn(2, 3, 4096, generator=gen).half().cuda()
+        both(ot, x3), both(qz, x3.reshape(6, 4096)), both(qz2, x3.reshape(6, 4096))
+    first = both(ot, x3)
+    ptr = first.quantized_x.data_ptr()
+    assert both(ot, x3).quantized_x.data_ptr() == ptr                  # static buffers
+    ot.left_matrix.copy_((torch.randn(64, 64, generator=gen) / 8).half())   # in-place update: a new plan, right values
+    both(ot, x3)
+    ot.clip_factor_a_max.fill_(1.0)
+    both(ot, x3)
+    ot.right_matrix.data.copy_((torch.randn(64, 64, generator=gen) / 8).half())   # through .data: invisible until invalidate_caches()
+    ops.invalidate_caches()
+    both(ot, x3)
+    both(ot, torch.randn(1, 7, 4096, generator=gen).half().cuda())     # another shape: another plan
+    # Linear4bit at decode sizes
+    from oracle import fq_oracle as O
+    import numpy as np
+    lin = deploy.nn.Linear4bit(512, 1024, bias=True).cuda()
+    lin.weight.copy_(torch.from_numpy(O.pack_i4(torch.randint(-8, 8, (1024, 512), generator=gen, dtype=torch.int32).numpy())))
+    lin.weight_scales.copy_(torch.rand(1024, 1, generator=gen) * 0.02 + 0.001)
+    lin.bias.copy_(torch.randn(1024, generator=gen).half())
+    for rows in (4, 4, 16):
+        pk = deploy.PackedQuantizedTensor(torch.from_numpy(O.pack_i4(torch.randint(-8, 8, (rows, 512), generator=gen, dtype=torch.int32).numpy())).cuda()
+                                          .reshape(1, rows, 256), (torch.rand(1, rows, 1, generator=gen) * 0.05 + 0.001).half().cuda())
+        lin.static_outputs = False
+        a = lin(pk)
+        lin.static_outputs = True
+        b = lin(pk)
+        assert a.shape == b.shape and torch.equal(a.view(torch.int16), b.view(torch.int16)), rows
+    lin.weight_scales.mul_(2.0)            # in-place update: a new plan
+    lin.static_outputs = False
+    a = lin(pk)
+    lin.static_outputs = True
+    assert torch.equal(a.view(torch.int16), lin(pk).view(torch.int16))

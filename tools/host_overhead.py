@@ -50,6 +50,20 @@ timeit("ops.rowquant (deploy Quantizer arithmetic)", lambda: ops.rowquant(x, SIG
 timeit("deploy.nn.OnlineTrans(matmul).forward", lambda: ot(x3))
 timeit("deploy.nn.Quantizer(lac).forward", lambda: qz(x))
 timeit("deploy.nn.Linear4bit.forward (decode kernel)", lambda: lin(p))
+# (round 4) prepared launches with static outputs (ops.LaunchPlan; the modules' opt-in static_outputs attribute)
+kp = ops.kron_plan(x, L, R, SIG, P)
+timeit("ops.kron_plan(...).run 64x64 packed", lambda: kp.run(x))
+rp = ops.rowquant_plan(x, SIG, FQ_OUT_PACKED | 0x20 | 0x400)
+timeit("ops.rowquant_plan(...).run", lambda: rp.run(x))
+ot.static_outputs = True
+qz.static_outputs = True
+timeit("OnlineTrans(matmul).forward, static_outputs", lambda: ot(x3))
+timeit("Quantizer(lac).forward, static_outputs", lambda: qz(x))
+lin.static_outputs = True
+timeit("Linear4bit.forward (decode kernel), static_outputs", lambda: lin(p))
+lin.static_outputs = False
+ot.static_outputs = False
+qz.static_outputs = False
 timeit("torch.empty x2 (the output allocation alone)", lambda: (torch.empty((4, 2048), dtype=torch.uint8, device=dev), torch.empty((4,), dtype=torch.float16, device=dev)))
 if "--profile" in sys.argv:
     pr = cProfile.Profile()
