@@ -94,11 +94,12 @@ __device__ __forceinline__ void duo_meet(unsigned cnt_lds, unsigned target, int 
 
 // FULL: M == 32 MT (128 x 224, the shape of BASELINE config 4): every DMA block is four whole instructions and no row is padding —
 // the lane-masked tail code, its scalar state (the launch spilled ~100 SGPRs to VGPR lanes) and the row tests are compiled out.
-template <int MT, bool FULL>
-__global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __restrict__ x, const uint4* __restrict__ ws,
+template <int MT, bool FULL, typename T = f16>
+__global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const T* __restrict__ x, const uint4* __restrict__ ws,
                                                                 int64_t rows, int64_t tpb, int M_rt, FqQuantOut out) {
     const int M = FULL ? MT * 32 : M_rt;
     typedef DuoGeom<MT> G;
+    typedef typename FqVec<T>::x8 X8;   // (round 4: bf16 activations too — bf16 MFMA, bf16 rounding points)
     constexpr int KS1 = DUO_KS1, NT = DUO_NT, CPR = DUO_CPR, PITCH = DUO_PITCH, N = DUO_N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
@@ -218,14 +219,14 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
     const bool two = 2 * wq + 1 < NT;
     const uint4* rf0 = ws + (size_t)(2 * wq) * KS1 * 64;                      // wave-uniform bases, lane offset
     const uint4* rf1 = ws + (size_t)(two ? 2 * wq + 1 : 2 * wq) * KS1 * 64;
-    f16x8 RB[2][DR];
+    X8 RB[2][DR];
 #define DUO_PRIME_R()                                                         \
     {                                                                         \
         int ln_ = lane;                                                       \
         asm volatile("" : "+v"(ln_));                                         \
         _Pragma("unroll") for (int i = 0; i < DR - 1; ++i) {                  \
-            RB[0][i] = __builtin_bit_cast(f16x8, rf0[i * 64 + ln_]);          \
-            RB[1][i] = __builtin_bit_cast(f16x8, rf1[i * 64 + ln_]);          \
+            RB[0][i] = __builtin_bit_cast(X8, rf0[i * 64 + ln_]);          \
+            RB[1][i] = __builtin_bit_cast(X8, rf1[i * 64 + ln_]);          \
         }                                                                     \
     }
     DUO_PRIME_R()
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
         unsigned long long sbn = 0;
         auto gemms = [&](auto two_c) {
             constexpr int TN = decltype(two_c)::value ? 2 : 1;
-            f16x8 Uh[TN][MT][2];
+            X8 Uh[TN][MT][2];
             {
                 int cl = c, ln = lane;
                 asm volatile("" : "+v"(cl), "+v"(ln));   // keep the address arithmetic inside the loop
@@ -270,28 +271,28 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
                 const uint4* tb = xs + cl * PITCH + p0;
                 const int w12 = p0 >= 4 ? -CPR : 0, w13 = p0 >= 2 ? -CPR : 0;   // K-steps 12 and 13 wrap round the row for some lanes
                 f32x16 U[TN][MT];
-                f16x8 A[2][MT];
+                X8 A[2][MT];
 #pragma unroll
                 for (int t = 0; t < TN; ++t)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) U[t][mt] = f32x16{0};
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) A[0][mt] = __builtin_bit_cast(f16x8, tb[mt * 32 * PITCH]);
+                for (int mt = 0; mt < MT; ++mt) A[0][mt] = __builtin_bit_cast(X8, tb[mt * 32 * PITCH]);
 #pragma unroll
                 for (int s = 0; s < KS1; ++s) {
                     if (s + DR - 1 < KS1 && !(DUO_ABL & 128)) {
-                        RB[0][(s + DR - 1) % DR] = __builtin_bit_cast(f16x8, rf0[(s + DR - 1) * 64 + ln]);
-                        if (TN == 2) RB[1][(s + DR - 1) % DR] = __builtin_bit_cast(f16x8, rf1[(s + DR - 1) * 64 + ln]);
+                        RB[0][(s + DR - 1) % DR] = __builtin_bit_cast(X8, rf0[(s + DR - 1) * 64 + ln]);
+                        if (TN == 2) RB[1][(s + DR - 1) % DR] = __builtin_bit_cast(X8, rf1[(s + DR - 1) * 64 + ln]);
                     }
                     if (s + 1 < KS1 && !(DUO_ABL & 32)) {
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) A[(s + 1) & 1][mt] = __builtin_bit_cast(f16x8, tb[mt * 32 * PITCH + (s + 1) * 2 + (s + 1 == 12 ? w12 : s + 1 == 13 ? w13 : 0)]);
+                        for (int mt = 0; mt < MT; ++mt) A[(s + 1) & 1][mt] = __builtin_bit_cast(X8, tb[mt * 32 * PITCH + (s + 1) * 2 + (s + 1 == 12 ? w12 : s + 1 == 13 ? w13 : 0)]);
                     }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int t = 0; t < TN; ++t)
-                            if (!(DUO_ABL & 1)) U[t][mt] = fq_mfma32<f16>(A[s & 1][mt], RB[t][s % DR], U[t][mt]);
+                            if (!(DUO_ABL & 1)) U[t][mt] = fq_mfma32<T>(A[s & 1][mt], RB[t][s % DR], U[t][mt]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
 #pragma unroll
                         for (int p = 0; p < 2; ++p)
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) Uh[t][mt][p][j] = (f16)U[t][mt][p * 8 + j];
+                            for (int j = 0; j < 8; ++j) Uh[t][mt][p][j] = (T)U[t][mt][p * 8 + j];
             }
             DUO_STAMP(2)
             DUO_MEET()   // every wave of the group has read the token: its buffer is free, the published claim is visible
@@ -319,24 +320,24 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
                 asm volatile("" : "+v"(loff));
                 const uint4* mylfr = lfr + loff;
                 constexpr int NBUF = 2;
-                f16x8 B[NBUF][MT];
+                X8 B[NBUF][MT];
                 if (NBUF == 2) {
 #pragma unroll
-                    for (int mo = 0; mo < MT; ++mo) B[0][mo] = __builtin_bit_cast(f16x8, mylfr[mo * 64]);
+                    for (int mo = 0; mo < MT; ++mo) B[0][mo] = __builtin_bit_cast(X8, mylfr[mo * 64]);
                 }
 #pragma unroll
                 for (int ks = 0; ks < 2 * MT; ++ks) {
                     if (!(DUO_ABL & 64) && (NBUF == 1 || ks + 1 < 2 * MT)) {
                         const int kl = NBUF == 1 ? ks : ks + 1;
 #pragma unroll
-                        for (int mo = 0; mo < MT; ++mo) B[kl % NBUF][mo] = __builtin_bit_cast(f16x8, mylfr[(kl * MT + mo) * 64]);
+                        for (int mo = 0; mo < MT; ++mo) B[kl % NBUF][mo] = __builtin_bit_cast(X8, mylfr[(kl * MT + mo) * 64]);
                     }
                     if (ks < 2 * MT - 2 || ks < ks_n) {
 #pragma unroll
                         for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
                             for (int t = 0; t < TN; ++t)
-                                if (!(DUO_ABL & 2)) Y[t][mo] = fq_mfma32<f16>(Uh[t][ks >> 1][ks & 1], B[ks % NBUF][mo], Y[t][mo]);
+                                if (!(DUO_ABL & 2)) Y[t][mo] = fq_mfma32<T>(Uh[t][ks >> 1][ks & 1], B[ks % NBUF][mo], Y[t][mo]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
 #pragma unroll
                 for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Y[t][mo][r] = (float)(f16)Y[t][mo][r];
+                    for (int r = 0; r < 16; ++r) Y[t][mo][r] = (float)(T)Y[t][mo][r];
         }
         // ---- extrema over the valid entries (one independent max3 / min3 chain per tile) ----
         float vmax = -INFINITY, vmin = INFINITY;
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
         for (int ci = 0; ci < (DUO_ABL & 4 ? 0 : out.n_clips); ++ci) {
             float sig_max, sig_min;
             fq_token_sigs(out, ci, tok, gcur, sig_max, sig_min);
-            const float scale = fq_token_scale<0>(vmax, vmin, sig_max, sig_min, out.rt_flags);
+            const float scale = fq_token_scale<0, T>(vmax, vmin, sig_max, sig_min, out.rt_flags);
             const float inv = fq_uniform_f32(fq_fast_inv(scale));   // (an inline-asm VGPR result is divergent to the compiler: see above)
             const bool magic = fq_magic_ok(vmax, vmin, inv), clampq = fq_needs_clamp(vmax, vmin, inv);
             const float ilo = fq_inv_lo(inv), ihi = fq_inv_hi(inv);
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
                 store_ticks += ts1 - ts0;
 #endif
             }
-            if (wq == 0 && lane == 0) out.scale[ci][tok] = (f16)scale;
+            if (wq == 0 && lane == 0) reinterpret_cast<T*>(out.scale[ci])[tok] = (T)scale;
         }
         DUO_STAMP(8)
 #ifdef DUO_TRACE
@@ -471,11 +472,11 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const f16* __r
     }
 }
 
-template <int MT, bool FULL>
-int launch_duo(const f16* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
+template <int MT, bool FULL, typename T = f16>
+int launch_duo(const T* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
     typedef DuoGeom<MT> G;
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
-    auto kern = fq_kron_duo_kernel<MT, FULL>;
+    auto kern = fq_kron_duo_kernel<MT, FULL, T>;
     FQ_RAISE_LDS_CAP(kern, 160 * 1024);
     int64_t blocks = (rows + DUO_GROUPS - 1) / DUO_GROUPS;
     if (blocks > n_cu) blocks = n_cu;   // one persistent workgroup per CU
@@ -499,7 +500,12 @@ int fq_launch_kron_duo(int flags, const f16* x, const void* ws, const f16* diag,
                        const FqQuantOut& out, int n_cu, hipStream_t stream) {
     if (N != DUO_N || M <= 96 || M > 128 || diag != nullptr) return -1000;
     if ((out.rt_flags & FQ_GROUP128) || out.post_scale != 0.0f) return -1000;
+    const bool b = (flags & FQ_DT_BF16) != 0;   // (round 4) bf16 activations and factors: the same kernel on bf16 MFMA
+    flags &= ~FQ_DT_BF16;
     if ((flags & FQ_CT_MASK) != FQ_OUT_PACKED) return -1000;
-    if (M == 128) return launch_duo<4, true>(x, reinterpret_cast<const uint4*>(ws), rows, M, out, n_cu, stream);
-    return launch_duo<4, false>(x, reinterpret_cast<const uint4*>(ws), rows, M, out, n_cu, stream);
+    const uint4* w = reinterpret_cast<const uint4*>(ws);
+    if (b) return M == 128 ? launch_duo<4, true, bf16>((const bf16*)x, w, rows, M, out, n_cu, stream)
+                           : launch_duo<4, false, bf16>((const bf16*)x, w, rows, M, out, n_cu, stream);
+    if (M == 128) return launch_duo<4, true>(x, w, rows, M, out, n_cu, stream);
+    return launch_duo<4, false>(x, w, rows, M, out, n_cu, stream);
 }

@@ -54,6 +54,8 @@ int fq_launch_kron_wave_bf16(int flags, const void* x, const void* ws, const voi
 
 int fq_launch_kron_tiles(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
                          const FqQuantOut& out, int n_cu, hipStream_t stream);   // fq_kron_tiles.hip
+int fq_launch_kron_duo(int flags, const f16* x, const void* ws, const f16* diag, int64_t rows, int M, int N,
+                       const FqQuantOut& out, int n_cu, hipStream_t stream);   // fq_kron_duo.hip
 int fq_launch_kron_generic_bf16(int flags, const f16* x_, const f16* left_, const f16* right_, const f16* diag_, int64_t rows, int M, int N,
                                 const FqQuantOut& out, void* workspace, int64_t workspace_bytes, int n_cu, hipStream_t stream) {
     const bf16 *x = (const bf16*)x_, *left = (const bf16*)left_, *right = (const bf16*)right_, *diag = (const bf16*)diag_;
@@ -78,6 +80,10 @@ int fq_launch_kron_generic_bf16(int flags, const f16* x_, const f16* left_, cons
     }
     if ((spec || N == 148) && !(out.rt_flags & FQ_GROUP128)) {   // (round 4) token groups of NT waves: 112 x 128, 86 x 128, 80 x 112, 128 x 144, 144 x 192 on bf16
         const int rc = fq_launch_kron_tiles(flags | FQ_DT_BF16, (const f16*)x, ws, (const f16*)diag, rows, M, N, out, n_cu, stream);
+        if (rc != -1000) return rc;
+    }
+    if (spec && !(out.rt_flags & FQ_GROUP128)) {   // (round 4) 128 x 224 on bf16: two token groups per CU (fq_kron_duo.hip)
+        const int rc = fq_launch_kron_duo(flags | FQ_DT_BF16, (const f16*)x, ws, (const f16*)diag, rows, M, N, out, n_cu, stream);
         if (rc != -1000) return rc;
     }
     if (out.rt_flags & FQ_GROUP128) {

@@ -89,3 +89,34 @@ def test_grouped_launch(ops):
             continue
         one = ops.kron_quant(x[a:b].contiguous(), L, R, [(float(smax[g]), float(smin[g]))], P | NC0)
         assert torch.equal(o.q[0][a:b], one.q[0]) and torch.equal(o.scale[0][a:b], one.scale[0]), g
+
+
+def _bits(t):
+    return t.view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("M", [128, 120, 100])
+@pytest.mark.parametrize("rows", [1, 7, 300])
+def test_bf16_packed_only_launches(ops, M, rows):
+    """bf16 activations and factors on this kernel (round 4; they ran the workgroup-per-token kernel: 254 us per 8192 tokens): bit-equal,
+    clip set by clip set and flag route by flag route, to the launch that also returns the transform, and to the oracle's bf16
+    quantiser on that transform."""
+    BF = torch.bfloat16
+    gen = torch.Generator().manual_seed(M * 31 + rows)
+    x = torch.randn(rows, M * 224, generator=gen)
+    x[:, ::97] *= 20
+    x = x.to(BF).cuda()
+    L = (torch.randn(M, M, generator=gen) / M ** 0.5).to(BF).cuda()
+    R = (torch.randn(224, 224, generator=gen) / 224 ** 0.5).to(BF).cuda()
+    sigs = [SIG, (0.9, 0.33), (1e-7, 1e-7)]
+    for flags in (P | NC0, P, P | R16 | NC0):
+        both = ops.kron_quant(x, L, R, sigs, flags | T)
+        multi = ops.kron_quant(x, L, R, sigs, flags)
+        for ci, sig in enumerate(sigs):
+            one = ops.kron_quant(x, L, R, [sig], flags)
+            for o, k in ((one, 0), (multi, ci)):
+                assert torch.equal(o.q[k], both.q[ci]), (M, rows, flags, sig)
+                assert np.array_equal(_bits(o.scale[k]), _bits(both.scale[ci])), (M, rows, flags, sig)
+        if flags & R16:
+            ref = O.quant_outputs(O.bf16_from_bits(_bits(both.y)), *sigs[0], round_y_f16=True, clamp0=not (flags & NC0), lowp="bf16")
+            assert np.array_equal(multi.q[0].cpu().numpy(), ref["packed"])

@@ -473,7 +473,7 @@ def test_hot_kernels_keep_their_occupancy_budget():
         "fq_kron_wave_kernel<2,4,7,8,0,bf16>": (2, 0),
         "fq_kron_wave_kernel<1,2,4,16,0,bf16>": (4, 0),
         "fq_kron_fast_kernel<4,7,14,8,1,0,1,0,f16,0,0>": (2, 0),  # 128 x 224 packed (M <= 96 rows of it; 96 < M: the duo kernel)
-        "fq_kron_duo_kernel<4,1>": (2, 4),                  # 128 x 224 packed, two token groups per CU: 128 accumulators per wave, 4 spilled registers
+        "fq_kron_duo_kernel<4,1,f16>": (2, 4),                  # 128 x 224 packed, two token groups per CU: 128 accumulators per wave, 4 spilled registers
         "fq_kron_fast_kernel<4,5,10,8,1,0,1,148,f16,0,0>": (2, 0),  # 128 x 148 packed (true row length 148)
         "fq_kron_fast_kernel<5,6,12,8,1,0,1,0,f16,0,0>": (2, 0),  # 144 x 192 packed
         "fq_kron_fast_kernel<4,4,8,4,2,0,-1,0,f16,0,0>": (2, 0),  # 112 x 128, every output set (the fake-quant contract)
