@@ -406,9 +406,10 @@ class C5(Workload):
         t0, t1 = sharding.shard_rows(T, world, rank)             # and a row block of the shared w1_trans stage
         return {"T": T, "E": E, "K": K, "counts": counts, "e0": e0, "e1": e1, "offs": offs, "t0": t0, "t1": t1}
 
-    def __init__(self, device, rank, world, sharding, bcast):
+    def __init__(self, device, rank, world, sharding, bcast, dtype="f16"):
         from flatquant_amd import ops
         from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED
+        td = torch.bfloat16 if dtype == "bf16" else torch.float16   # (DeepSeek-V3 runs under torch.set_default_dtype(bfloat16): main_dpskv3.py:395)
         d1, d2 = 7168, 2048
         pl = self.plan(world, rank, sharding)
         T, E, K, counts, e0, e1, offs, t0, t1 = (pl[k] for k in ("T", "E", "K", "counts", "e0", "e1", "offs", "t0", "t1"))
@@ -416,8 +417,9 @@ class C5(Workload):
         mats = bcast({"l1": make_matrix(64, 1, device), "r1": make_matrix(112, 2, device),
                       "l2": make_matrix(32, 3, device), "r2": make_matrix(64, 4, device)})
         nb = 2
-        x1 = make_inputs(device, rank, t1 - t0, d1, nb)
-        x2 = make_inputs(device, rank + 50, rows2, d2, nb)
+        x1 = [x.to(td) for x in make_inputs(device, rank, t1 - t0, d1, nb)]
+        x2 = [x.to(td) for x in make_inputs(device, rank + 50, rows2, d2, nb)]
+        mats = {k: v.to(td) for k, v in mats.items()}
         offs_d = offs.to(device)
         gsig = torch.Generator().manual_seed(6)
         smax = torch.sigmoid(torch.rand(e1 - e0, generator=gsig) * 4 + 1).float().to(device)   # per-expert clip pairs
@@ -436,7 +438,7 @@ class C5(Workload):
                                    "hidden rows of 2048 in 256 expert groups (Zipf routing) through the grouped 32x64 launch",
                        "tokens_this_rank": t1 - t0, "grouped_rows_this_rank": rows2, "experts_this_rank": e1 - e0,
                        "largest_group": int(counts.max()), "empty_groups": int((counts == 0).sum()),
-                       "launches_per_step": 2, "launch": "HIP graph replay, two input sets alternating",
+                       "launches_per_step": 2, "launch": "HIP graph replay, two input sets alternating", "activation_dtype": dtype,
                        "parallelism": f"experts+tokens /{world}"}
 
 
@@ -574,7 +576,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="C2", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="activation dtype (C1 / C2)")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="activation dtype (C1 / C2 / C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-records", action="store_true",
                     help="default config only: skip the `strong` (C2S x 32 layers, one multi-job launch) and `c4` sub-records")
@@ -586,8 +588,8 @@ def main():
         args.steps = {"C1": 500, "C2": 1000, "C2S": 1000, "C3": 100, "C4": 5, "C5": 50, "C2SL": 50}[args.config]
     if args.warmup is None:
         args.warmup = {"C1": 100, "C2": 200, "C2S": 200, "C3": 10, "C4": 2, "C5": 5, "C2SL": 10}[args.config]
-    if args.dtype != "f16" and args.config not in ("C1", "C2"):
-        ap.error("--dtype bf16 goes with --config C1 / C2 (the deploy configs are fp16 contracts)")
+    if args.dtype != "f16" and args.config not in ("C1", "C2", "C5"):
+        ap.error("--dtype bf16 goes with --config C1 / C2 / C5 (C3 / C4 are the deploy configs: fp16 contracts of the reference)")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -600,7 +602,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)   # RCCL
 
     from flatquant_amd import sharding
-    kw = {"dtype": args.dtype} if args.config in ("C1", "C2", "C2S") else {}
+    kw = {"dtype": args.dtype} if args.config in ("C1", "C2", "C2S", "C5") else {}
     bcast = TimedBroadcast(sharding, device)
     wl = WORKLOADS[args.config](device, rank, world, sharding, bcast, **kw)
     stream = torch.cuda.current_stream(device)
