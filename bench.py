@@ -478,15 +478,15 @@ WORKLOADS = {"C1": C1, "C2": C2, "C2S": C2S, "C3": C3, "C4": C4, "C5": C5, "C2SL
 class TimedBroadcast:
     """sharding.broadcast_matrices with its wall time kept (the one collective of the path, set-up time): .ms after the call."""
 
-    def __init__(self, sharding, device):
-        self.sharding, self.device, self.ms, self.bytes = sharding, device, 0.0, 0
+    def __init__(self, sharding, device, force=False):
+        self.sharding, self.device, self.ms, self.bytes, self.force = sharding, device, 0.0, 0, force
 
     def __call__(self, mats):
         cuda = torch.device(self.device).type == "cuda"
         if cuda:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = self.sharding.broadcast_matrices(mats, src=0)
+        out = self.sharding.broadcast_matrices(mats, src=0, force=self.force)
         if cuda:
             torch.cuda.synchronize()
         self.ms += (time.perf_counter() - t0) * 1e3
@@ -494,13 +494,13 @@ class TimedBroadcast:
         return out
 
 
-def reduce_over_ranks(dist, device, wall_s, kern_ms, elems):
+def reduce_over_ranks(dist, device, wall_s, kern_ms, elems, force=False):
     """MAX over ranks of the two clocks, SUM of the units, and every rank's own wall clock (all_gather) — the contract's
     'max over ranks' plus what shows a straggler. Works on CPU tensors with gloo (tests) and on the GPU with RCCL."""
     t = torch.tensor([wall_s, kern_ms], dtype=torch.float64, device=device)
     e = torch.tensor([float(elems)], dtype=torch.float64, device=device)
     per_rank = [wall_s]
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force):
         mine = torch.tensor([wall_s], dtype=torch.float64, device=device)
         parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(parts, mine)
@@ -526,10 +526,11 @@ def timed_region(step, steps, warmup, dist, stream):
         step(i)
     ev1.record(stream)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    wall = time.perf_counter() - t0     # this rank's K steps, start to drained queue; the MAX over ranks is taken by the caller
+    if dist is not None:                # the closing barrier + synchronize of the bracket: behind the clock — an RCCL barrier is an
+        dist.barrier()                  # all-reduce of its own (~0.2 ms measured in a one-rank group: a third of 20 steps of 35 us)
     torch.cuda.synchronize()
-    return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
+    return wall, ev0.elapsed_time(ev1) / steps
 
 
 def capture_graphs(wl, device):
@@ -546,16 +547,16 @@ def capture_graphs(wl, device):
     return lambda i: graphs[i % len(graphs)].replay()
 
 
-def sub_record(cls, steps, warmup, device, rank, world, sharding, dist):
+def sub_record(cls, steps, warmup, device, rank, world, sharding, dist, force=False):
     """One more workload measured inside the same process with the same protocol, reported as a sub-record of the line (round 4:
     the STRONG-scaling forms next to the weak-scaling default, so that a SCALE file cannot be read as 'N x because every GPU got
     its own copy of the work')."""
-    bc = TimedBroadcast(sharding, device)
+    bc = TimedBroadcast(sharding, device, force=force)
     wl = cls(device, rank, world, sharding, bc)
     step = capture_graphs(wl, device) if wl.graph else wl.step
     stream = torch.cuda.current_stream(device)
     wall, kern_ms = timed_region(step, steps, warmup, dist, stream)
-    wall, kern_ms, elems, per_rank = reduce_over_ranks(dist, device, wall, kern_ms, wl.elems)
+    wall, kern_ms, elems, per_rank = reduce_over_ranks(dist, device, wall, kern_ms, wl.elems, force)
     rec = None
     if rank == 0:
         step_bytes = sum(k[2] for k in wl.kernels) * (wl.config.get("layers", 1) if cls is C4 else 1)
@@ -580,6 +581,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-records", action="store_true",
                     help="default config only: skip the `strong` (C2S x 32 layers, one multi-job launch) and `c4` sub-records")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="single process: run inside a ONE-rank RCCL group anyway (init, the set-up broadcast, barriers, the reductions): "
+                         "the N > 1 code path on a single-GPU box; the line then carries a `dist` record")
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed clock-settle phase before the counted warm-up: launches of the same step for this "
                          "many milliseconds (reported as settle_launches); 0 disables it")
@@ -597,13 +601,29 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    json_fd = None
+    if world > 1 or args.force_dist:
+        # ONE JSON line on stdout, and nothing else: RCCL prints a version banner to the C-level stdout at communicator creation (buffered,
+        # flushed at exit — i.e. BEHIND the JSON line; seen on the GPU box with RCCL 2.26). Everything written to file descriptor 1 from
+        # here on goes to stderr; rank 0 writes its line straight to the saved descriptor at the end.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)   # RCCL
+    elif args.force_dist:
+        # a ONE-rank RCCL group: init, the set-up broadcast, the barriers and the reductions of the timed region all run on the hardware
+        # (no 8-GPU node has been available to any round; this is the part of the N > 1 path a single-GPU box can execute)
+        import torch.distributed as dist
+        if "MASTER_ADDR" in os.environ and "RANK" in os.environ:
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1, device_id=device)
 
     from flatquant_amd import sharding
     kw = {"dtype": args.dtype} if args.config in ("C1", "C2", "C2S", "C5") else {}
-    bcast = TimedBroadcast(sharding, device)
+    bcast = TimedBroadcast(sharding, device, force=args.force_dist)
     wl = WORKLOADS[args.config](device, rank, world, sharding, bcast, **kw)
     stream = torch.cuda.current_stream(device)
     step = wl.step
@@ -654,7 +674,7 @@ def main():
         kern_us.append((name, k0.elapsed_time(k1) / reps * 1e3, nbytes))
     floor_us = wl.floor_us(stream) if (rank == 0 and getattr(wl, "floor_us", None) is not None) else None
 
-    wall, kern_ms, elems_total, per_rank_wall = reduce_over_ranks(dist, device, wall, kern_ms, wl.elems)
+    wall, kern_ms, elems_total, per_rank_wall = reduce_over_ranks(dist, device, wall, kern_ms, wl.elems, args.force_dist)
 
     # (round 4) the STRONG-scaling sub-records of the default line: the driver only ever runs `bench.py --gpus N`, whose headline
     # value is weak scaling (every GPU its own 8 x 2048 tokens)
@@ -662,8 +682,8 @@ def main():
     if args.config == "C2" and args.dtype == "f16" and not args.no_sub_records:
         del wl.xs
         torch.cuda.empty_cache()
-        subs["strong"] = sub_record(C2SL, 20, 5, device, rank, world, sharding, dist)
-        subs["c4"] = sub_record(C4, 3, 1, device, rank, world, sharding, dist)
+        subs["strong"] = sub_record(C2SL, 20, 5, device, rank, world, sharding, dist, args.force_dist)
+        subs["c4"] = sub_record(C4, 3, 1, device, rank, world, sharding, dist, args.force_dist)
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
@@ -680,6 +700,7 @@ def main():
             "settle_ms": args.settle_ms, "config": wl.config,
             "per_rank_ms_per_step": [w * 1e3 / args.steps for w in per_rank_wall],
             "broadcast_ms": bcast.ms, "broadcast_bytes": bcast.bytes,
+            "dist": None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "forced_single_rank": bool(args.force_dist and world == 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic()[0] if (args.config == "C2" and args.dtype == "f16") else None,
@@ -699,7 +720,11 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(*{"C1": (20.0, 64, 64), "C2": (20.0, 64, 64), "C2S": (20.0, 64, 64), "C3": (20.0, 64, 64),
                                                  "C4": (20.0, 64, 128), "C5": (20.0, 32, 64), "C2SL": (20.0, 64, 64)}[args.config])
-        print(json.dumps(out))
+        if json_fd is None:
+            print(json.dumps(out))
+        else:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

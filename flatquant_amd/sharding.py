@@ -32,10 +32,11 @@ def shard_experts(counts, world_size: int, rank: int):
     return e0, e1, torch.tensor(offs, dtype=torch.int64)
 
 
-def broadcast_matrices(mats: Dict[str, torch.Tensor], src: int = 0, group=None) -> Dict[str, torch.Tensor]:
+def broadcast_matrices(mats: Dict[str, torch.Tensor], src: int = 0, group=None, force: bool = False) -> Dict[str, torch.Tensor]:
     """Broadcast every tensor of ``mats`` from ``src`` as ONE flat buffer (one collective for all layers: a few
-    hundred KB to a few MB — latency-bound on xGMI, so fewer, larger messages)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    hundred KB to a few MB — latency-bound on xGMI, so fewer, larger messages). ``force``: run the collective in a one-rank group too
+    (bench.py --force-dist: the RCCL path exercised on a single-GPU box)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return mats
     keys = sorted(mats)
     if not keys:
