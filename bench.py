@@ -37,7 +37,11 @@ import os
 import sys
 import time
 
-import torch
+# multi-process GPU work on this platform needs dmabuf IPC (the host driver supports nothing else: without it RCCL fails with
+# hipIpcGetMemHandle: invalid argument); the driver's environment exports it already — kept here for a bare shell
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
