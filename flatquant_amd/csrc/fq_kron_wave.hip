@@ -75,11 +75,18 @@ __device__ __forceinline__ unsigned quant_row(const f32x16 (&Y)[NT][MT], int mo,
 // in four chains, wave all-reduce, v_rsq_f32), then every A fragment is scaled — fp32 product rounded to fp32 and to fp16, the
 // module's `(x.float() * rsqrt(...)).to(fp16)` — on its way into GEMM 1. No extra HBM traffic; the separate normalisation launch
 // moves 4 bytes per element.
-template <int MT, int NT, int KS1, int W, bool RMS = false, typename T = f16>
+// OS (round 4): the output set — FQ_OUT_PACKED (the deploy contract, everything above), or FQ_OUT_FAKEQUANT (FlatQuantizedLinear.
+// _eval_forward: scale * q in the activation dtype, flat_linear.py:75-80 — the reference's fake-quant eval flow, the only one it has for
+// DeepSeek-V3) or FQ_OUT_TRANSFORM (kronecker_matmul alone). A lane holds NT * 16 consecutive n' of an output row = NT * 32 contiguous
+// bytes (a whole 128-byte line at N = 128): stored as 16-byte pieces straight from the fragments; fq_fake8 with one exactness vote per
+// token, as fq_kron64.hip. fp32 quantiser arithmetic, per-token scales; everything else stays with the workgroup-per-token kernel
+// (which ran these outputs until now: 64 x 128 fake-quant 121 us, 32 x 64 45 us = 0.37 of the roofline).
+template <int MT, int NT, int KS1, int W, bool RMS = false, typename T = f16, int OS = FQ_OUT_PACKED>
 __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const T* __restrict__ x, const uint4* __restrict__ ws,
                                                             int64_t rows, int64_t tpb, int M, FqQuantOut out) {
     typedef WaveGeom<MT, NT, KS1, W> G;
     typedef typename FqVec<T>::x8 X8;
+    static_assert(OS == FQ_OUT_PACKED || OS == FQ_OUT_FAKEQUANT || OS == FQ_OUT_TRANSFORM, "one output set per instantiation");
     constexpr int N = G::N, CPR = G::CPR;
     static_assert(NT <= 4 && MT <= 2, "a token must fit one wave's accumulators");
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const T* __restric
         const uint4* myr = rfr + foff;
         const uint4* myl = lfr + foff;
         // this token's DMA: issued in the prologue or an iteration ago; younger VMEM ops = that iteration's stores
-        if (!first && out.n_clips == 1) {
+        if (OS == FQ_OUT_PACKED && !first && out.n_clips == 1) {
             asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G::STORES) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -182,7 +189,16 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const T* __restric
             }
         }
         // the token buffer has been read: pull the next token and start its DMA
-        {
+        // (16-bit outputs: the buffer serves as their output stage first — the request goes out behind the stores, below)
+        auto pull_next = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            int nxt = 0;
+            if (lane == 0) nxt = (int)atomicAdd(next_slot, 1u);
+            nxt = __builtin_amdgcn_readfirstlane(nxt);
+            if (nxt < blk_cnt) dma_token<CPR>(reinterpret_cast<const f16*>(x), blk_base + nxt, tok_bytes, n_dma, tok_lds, voff);
+            next_pulled = nxt;
+        };
+        if constexpr (OS == FQ_OUT_PACKED) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             int nxt = 0;
             if (lane == 0) nxt = (int)atomicAdd(next_slot, 1u);
@@ -258,6 +274,83 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const T* __restric
         }
         vmax = fq_wave_max(vmax);
         vmin = fq_wave_min(vmin);
+
+        if constexpr (OS != FQ_OUT_PACKED) {
+            // 16-bit outputs: piece (nt, b) of row m' = 32 mo + c holds n' = h*NT*16 + nt*16 + 8 b .. + 7. Straight from the fragments a
+            // store instruction puts 16 bytes into each of 64 different lines (measured: 64 x 128 fake-quant 161 us that way, 121 on the
+            // workgroup-per-token kernel). The pieces go through the wave's own token buffer instead — in the layout the DMA left the
+            // token in (same chunk rotation: conflict-free writes) — and leave as 1 KB-contiguous stores with the DMA's own per-lane
+            // offsets (stage_flush): the inverse of the staging copy.
+            auto piece_ok = [&](int nt, int mo) { return ((N == NT * 32) || (h * NT * 16 + nt * 16) < N) && (mo * 32 + c) < M; };
+            uint4* stg = reinterpret_cast<uint4*>(tokbuf);
+            auto stage_put = [&](int nt, int mo, int b, uint4 v) {
+                const int row = mo * 32 + c;
+                stg[row * CPR + ((h * NT * 2 + nt * 2 + b) ^ sw)] = v;
+            };
+            auto stage_flush = [&](T* dst) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                unsigned char* g = reinterpret_cast<unsigned char*>(dst);
+                for (int i = 0; i < n_dma; ++i) {
+                    const uint4 v = stg[i * 64 + lane];
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(g + (int64_t)i * 1024 + voff[i & 3]));
+                }
+            };
+            if constexpr (OS == FQ_OUT_TRANSFORM) {
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            X8 o;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = (T)Y[nt][mo][b * 8 + e];
+                            if (piece_ok(nt, mo)) stage_put(nt, mo, b, __builtin_bit_cast(uint4, o));
+                        }
+                stage_flush(reinterpret_cast<T*>(out.y) + tok * ((int64_t)M * N));
+            } else {
+                for (int ci = 0; ci < out.n_clips; ++ci) {
+                    float sig_max, sig_min;
+                    fq_token_sigs(out, ci, tok, gcur, sig_max, sig_min);
+                    const float scale = fq_token_scale<0, T>(vmax, vmin, sig_max, sig_min, out.rt_flags);
+                    const float inv = fq_fast_inv(scale);
+                    const bool magic = fq_magic_ok(vmax, vmin, inv), clampq = fq_needs_clamp(vmax, vmin, inv);
+                    float dmax = 0.0f;
+                    if (magic) {
+#pragma unroll
+                        for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                                for (int b = 0; b < 2; ++b) {
+                                    const f32x16& t = Y[nt][mo];
+                                    const int k = b * 8;
+                                    const u32x4 o = clampq ? fq_fake8<true, T>(t[k], t[k + 1], t[k + 2], t[k + 3], t[k + 4], t[k + 5], t[k + 6], t[k + 7], inv, scale, dmax)
+                                                           : fq_fake8<false, T>(t[k], t[k + 1], t[k + 2], t[k + 3], t[k + 4], t[k + 5], t[k + 6], t[k + 7], inv, scale, dmax);
+                                    if (piece_ok(nt, mo)) stage_put(nt, mo, b, __builtin_bit_cast(uint4, o));
+                                }
+                    }
+                    if (!magic || fq_wave_needs_exact(dmax)) {   // rare: the whole token again with the true division
+#pragma unroll
+                        for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                                for (int b = 0; b < 2; ++b) {
+                                    X8 o;
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) o[e] = fq_fake<T>(scale, fq_qexact(Y[nt][mo][b * 8 + e], scale));
+                                    if (piece_ok(nt, mo)) stage_put(nt, mo, b, __builtin_bit_cast(uint4, o));
+                                }
+                    }
+                    stage_flush(reinterpret_cast<T*>(out.fq[ci]) + tok * ((int64_t)M * N));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the next clip set rewrites the stage)
+                }
+            }
+            pull_next();   // the buffer is free again: the next token's DMA (the other waves of the CU cover its latency)
+            slot = next_pulled;
+            continue;
+        }
 
         for (int ci = 0; ci < out.n_clips; ++ci) {
             float sig_max, sig_min;
@@ -335,7 +428,7 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const T* __restric
     }
 }
 
-template <int MT, int NT, int KS1, int W, bool RMS = false, typename T = f16>
+template <int MT, int NT, int KS1, int W, bool RMS = false, typename T = f16, int OS = FQ_OUT_PACKED>
 int launch_wave(const T* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
     typedef WaveGeom<MT, NT, KS1, W> G;
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
@@ -343,7 +436,7 @@ int launch_wave(const T* x, const uint4* ws, int64_t rows, int M, const FqQuantO
     if (blocks > n_cu) blocks = n_cu;  // one persistent workgroup per CU
     if (blocks < 1) blocks = 1;
     const int64_t tpb = (rows + blocks - 1) / blocks;
-    hipLaunchKernelGGL((fq_kron_wave_kernel<MT, NT, KS1, W, RMS, T>), dim3((unsigned)blocks), dim3(W * 64), 0, stream, x, ws, rows,
+    hipLaunchKernelGGL((fq_kron_wave_kernel<MT, NT, KS1, W, RMS, T, OS>), dim3((unsigned)blocks), dim3(W * 64), 0, stream, x, ws, rows,
                        tpb, M, out);
     return (int)hipGetLastError();
 }
@@ -356,7 +449,15 @@ template <typename T>
 static int launch_kron_wave_t(int flags, const T* x, const void* ws, const void* diag, int64_t rows, int M, int N,
                               const FqQuantOut& out, int n_cu, hipStream_t stream) {
     const bool rms = (flags & FQ_IN_RMSNORM) != 0;
-    if ((flags & FQ_CT_MASK & ~FQ_IN_RMSNORM) != FQ_OUT_PACKED || diag != nullptr) return -1000;
+    const int ct = flags & FQ_CT_MASK & ~FQ_IN_RMSNORM;
+#ifndef WAVE_OS_MAXKS
+#define WAVE_OS_MAXKS 5   // 16-bit outputs on this kernel up to N = 16 x this = 80 (measured, profiles/r04_wave_fakequant.txt: the wider pairs — 128 elements per lane, two waves per SIMD — are faster on the workgroup-per-token kernel: 64 x 128 fake-quant 145 vs 121 us)
+#endif
+    const bool os_ok = N / 16 <= WAVE_OS_MAXKS;
+    const bool fq_only = os_ok && ct == FQ_OUT_FAKEQUANT && !rms && !(out.rt_flags & FQ_GROUP128);      // (round 4) 16-bit outputs, fp32 quantiser
+    const bool y_only = os_ok && (ct == FQ_OUT_TRANSFORM || ct == (FQ_OUT_TRANSFORM | FQ_QUANT_F16)) && !rms && !(out.rt_flags & FQ_GROUP128) && out.n_clips == 0;
+    if ((ct != FQ_OUT_PACKED && !fq_only && !y_only) || diag != nullptr) return -1000;
+    if ((fq_only && !out.fq[0]) || (y_only && !out.y)) return -1000;
     if (M < 1 || M > 64 || (N & 15) || ((M * (N / 8)) & 63)) return -1000;
     if ((out.rt_flags & FQ_GROUP128) && (N != 64 || (M & 1))) return -1000;  // groups = pairs of 64-element rows
     const int MT = (M + 31) / 32, KS1 = N / 16;
@@ -367,6 +468,8 @@ static int launch_kron_wave_t(int flags, const T* x, const void* ws, const void*
         if constexpr (FqVec<T>::is_f16) {                                                                \
             if (rms) return launch_wave<MT_, NT_, KS1_, W_, true, T>(x, w, rows, M, out, n_cu, stream);  \
         }                                                                                                \
+        if (fq_only) return launch_wave<MT_, NT_, KS1_, W_, false, T, FQ_OUT_FAKEQUANT>(x, w, rows, M, out, n_cu, stream); \
+        if (y_only) return launch_wave<MT_, NT_, KS1_, W_, false, T, FQ_OUT_TRANSFORM>(x, w, rows, M, out, n_cu, stream);   \
         return launch_wave<MT_, NT_, KS1_, W_, false, T>(x, w, rows, M, out, n_cu, stream);              \
     }
     FQ_W(2, 4, 8, 7)    // 64x128

@@ -309,3 +309,32 @@ def test_workgroup_kernel_n148_packed_only(ops, M, rows):
             assert np.array_equal(only.scale[ci].cpu().numpy(), ref["scale16"]), (M, rows, fl, s)
     again = ops.kron_quant(x.cuda(), L, Rm, sigs, P | R16 | NC0)
     assert all(torch.equal(a, b) for a, b in zip(again.q, only.q))
+
+
+@pytest.mark.parametrize("M,N", [(64, 128), (64, 112), (64, 80), (56, 64), (32, 64), (37, 64)])
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_wave_kernel_fake_quant_and_transform_outputs(ops, M, N, dt):
+    """Round 4: fake-quant-only and transform-only launches of the wave-per-token pairs run fq_kron_wave_kernel<..., OS> (they ran the
+    workgroup-per-token kernel). Bit-equal to the launch that asks for BOTH outputs (which still takes that kernel), clip route by clip
+    route, with and without the rounding of Y, fp16 and bf16; and the fake-quant values are the oracle's on the returned transform."""
+    td = torch.float16 if dt == "f16" else torch.bfloat16
+    gen = torch.Generator().manual_seed(M * 17 + N)
+    for rows in (1, 7, 300):
+        x = torch.randn(rows, M * N, generator=gen)
+        x[:, ::97] *= 20
+        x = x.to(td).cuda()
+        L = (torch.randn(M, M, generator=gen) / M ** 0.5).to(td).cuda()
+        R = (torch.randn(N, N, generator=gen) / N ** 0.5).to(td).cuda()
+        for sig in ((0.9820137619972229, 0.9820137619972229), (0.9, 0.33), (1e-7, 1e-7)):
+            for fl in (F | R16, F | R16 | NC0, F):
+                both = ops.kron_quant(x, L, R, [sig], fl | T)
+                fq = ops.kron_quant(x, L, R, [sig], fl)
+                assert torch.equal(fq.fq[0].view(torch.int16), both.fq[0].view(torch.int16)), (M, N, rows, sig, fl)
+                if fl & R16:
+                    y = ops.kron_quant(x, L, R, flags=T | R16)
+                    assert torch.equal(y.y.view(torch.int16), both.y.view(torch.int16)), (M, N, rows)
+        if dt == "f16":
+            sg = (0.9820137619972229, 0.9820137619972229)
+            b2 = ops.kron_quant(x, L, R, [sg], F | R16 | T)
+            ref = O.quant_outputs(b2.y.cpu().numpy().astype(np.float32), sg[0], sg[1], round_y_f16=False, clamp0=True)
+            assert same_bits(ops.kron_quant(x, L, R, [sg], F | R16).fq[0].cpu().numpy(), ref["fq"])
