@@ -177,8 +177,10 @@ def linear4bit_multi(modules, inputs):
         assert type(x) == PackedQuantizedTensor
         ok = ok and m.fp6_gemm and ops.bf6_supported(m.out_features, m.in_features) and x.quantized_x.shape == q0.shape
         ok = ok and m.in_features == modules[0].in_features
-        ok = ok and (m._weight_image() is not None or (m.fp6_transient_rows and rows >= m.fp6_transient_rows
-                                                        and m.out_features >= m.fp6_min_out_features))
+        # (a narrow projection — the 1024-wide k / v of a GQA model — rides along in the launch of a wide one: fp6_min_out_features is
+        #  asked of the widest module of the group, not of each)
+        ok = ok and (m._weight_image() is not None or bool(m.fp6_transient_rows and rows >= m.fp6_transient_rows))
+    ok = ok and max(m.out_features for m in modules) >= min(m.fp6_min_out_features for m in modules)
     if not ok:
         return [m(x) for m, x in zip(modules, inputs)]
     problems = []

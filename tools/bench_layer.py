@@ -210,7 +210,6 @@ def main():
     # (round 4) q / k / v as ONE GEMM launch and up / gate as one (deploy.nn.linear.linear4bit_multi, fq_int4_linear_fp6_multi_f16): each
     # projection keeps its own packed input and weights; at a few thousand tokens a single projection does not fill the chip
     from flatquant_amd.deploy.nn.linear import linear4bit_multi
-    deploy.nn.Linear4bit.fp6_min_out_features = 0      # (the 1024-wide k / v projections ride along in the q launch)
     gm = 0.0
     for names in (("q_proj", "k_proj", "v_proj"), ("o_proj",), ("up_proj", "gate_proj"), ("down_proj",)):
         mods, ins = [], []
@@ -224,7 +223,6 @@ def main():
         gm += us
         print(f"  {'Linear4bit ' + ' + '.join(names) + ', one launch':58s} {us:9.1f} us")
         del mods
-    deploy.nn.Linear4bit.fp6_min_out_features = 2048
     deploy.nn.Linear4bit.fp6_image = False
     print(f"  {'seven linears, FP6 path, q/k/v and up/gate as one launch each':62s} {gm:9.1f} us;  FlatQuant layer: {fused_struct + gm:.1f} us")
 
