@@ -69,6 +69,7 @@ def invalidate_caches() -> None:
     _sigmoid_pair_cached.cache_clear()
     _sig_f16_cached.cache_clear()
     _WS_LRU.clear()
+    _WS_ANY.clear()
     _HAD_KRON.clear()
     from .flatquant.trans_utils import _Fp16Cache   # the modules' fp16 / bf16 copies of their (fp32) matrices
     _Fp16Cache.clear_all()
@@ -240,6 +241,7 @@ _WS_LRU_MAX_BYTES = 256 << 20   # and by bytes: a caller that re-stacks per-expe
 
 
 _WS_BYTES: dict = {}   # fq_kron_workspace_bytes(M, N): a pure function of the pair
+_WS_ANY: dict = {}     # the same images by (device, M, N, left, right) WITHOUT the stream: (ws, left, right, [complete], event of the preparing launch)
 
 
 def _kron_workspace(device: torch.device, M: int, N: int, left: torch.Tensor, right: torch.Tensor):
@@ -258,11 +260,32 @@ def _kron_workspace(device: torch.device, M: int, N: int, left: torch.Tensor, ri
     if ent is not None:
         _WS_LRU.move_to_end(key)
         return ent[0], nbytes, True, key
+    # Another stream: an image of the same pair prepared on a DIFFERENT stream is read-only once its preparing launch has completed, and
+    # may then be shared. Under stream capture (torch.cuda.graph synchronises the device on entry: everything issued before is complete)
+    # it is taken as it is — otherwise every captured launch carried its own fq_kron_prepare_kernel into the graph and replayed it every
+    # step (round 4: 240 of them in bench.py's C4 graph, 4 % of C5's step). Outside capture the preparing launch's event is asked.
+    other = _WS_ANY.get(key[:1] + key[2:])
+    if other is not None:
+        done = other[3]
+        if not done[0]:
+            if torch.cuda.is_current_stream_capturing():
+                done[0] = True
+            elif other[4].query():
+                done[0] = True
+        if done[0]:
+            _WS_LRU[key] = other[:3]
+            return other[0], nbytes, True, key
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes, False, key
 
 
 def _kron_workspace_commit(key, ws: torch.Tensor, left: torch.Tensor, right: torch.Tensor) -> None:
     _WS_LRU[key] = (ws, left, right)
+    if not torch.cuda.is_current_stream_capturing():      # (an event recorded inside a capture belongs to the graph)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(ws.device))
+        _WS_ANY[key[:1] + key[2:]] = (ws, left, right, [False], ev)
+        if len(_WS_ANY) > 2 * _WS_LRU_MAX:
+            _WS_ANY.pop(next(iter(_WS_ANY)))
     total = sum(e[0].numel() for e in _WS_LRU.values()) if ws.numel() > (1 << 20) else 0   # (only big images can hit the byte bound)
     while len(_WS_LRU) > _WS_LRU_MAX or (total > _WS_LRU_MAX_BYTES and len(_WS_LRU) > 1):
         _, ent = _WS_LRU.popitem(last=False)

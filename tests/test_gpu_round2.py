@@ -406,3 +406,42 @@ def test_launch_plans_and_static_output_modules():
     a = lin(pk)
     lin.static_outputs = True
     assert torch.equal(a.view(torch.int16), lin(pk).view(torch.int16))
+
+
+def test_prepared_fragment_images_are_shared_across_streams_and_graph_capture():
+    """The fragment image of a factor pair prepared on one stream serves every other stream once its preparing launch has completed
+    (round 4): a launch captured into a HIP graph after a warm-up on the default stream must not carry its own prepare kernel. Checked
+    through the cache itself (same image tensor, `prepared`) and through the results (another stream, a captured graph)."""
+    import torch
+    from flatquant_amd import ops
+    from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED
+    gen = torch.Generator().manual_seed(123)
+    M, N = 64, 112
+    L = (torch.randn(M, M, generator=gen) / 8).half().cuda()
+    R = (torch.randn(N, N, generator=gen) / 10).half().cuda()
+    x = torch.randn(33, M * N, generator=gen).half().cuda()
+    ops.invalidate_caches()
+    ref = ops.kron_quant(x, L, R, [(0.98, 0.97)], FQ_OUT_PACKED | FQ_NO_CLAMP0)
+    torch.cuda.synchronize()
+    ws0 = ops._kron_workspace(x.device, M, N, L, R)
+    assert ws0[2] is True
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ws1 = ops._kron_workspace(x.device, M, N, L, R)
+        assert ws1[2] is True and ws1[0].data_ptr() == ws0[0].data_ptr()
+        o = ops.kron_quant(x, L, R, [(0.98, 0.97)], FQ_OUT_PACKED | FQ_NO_CLAMP0)
+    side.synchronize()
+    assert torch.equal(o.q[0], ref.q[0]) and torch.equal(o.scale[0], ref.scale[0])
+    # a pair first seen on the default stream, then captured
+    L2 = (torch.randn(M, M, generator=gen) / 8).half().cuda()
+    out = ops.kron_quant(x, L2, R, [(0.98, 0.97)], FQ_OUT_PACKED | FQ_NO_CLAMP0)
+    want_q, want_s = out.q[0].clone(), out.scale[0].clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        assert ops._kron_workspace(x.device, M, N, L2, R)[2] is True      # no prepare kernel inside the capture
+        cap = ops.kron_quant(x, L2, R, [(0.98, 0.97)], FQ_OUT_PACKED | FQ_NO_CLAMP0)
+    cap.q[0].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cap.q[0], want_q) and torch.equal(cap.scale[0], want_s)
