@@ -264,18 +264,26 @@ def _kron_workspace(device: torch.device, M: int, N: int, left: torch.Tensor, ri
     # may then be shared. Under stream capture (torch.cuda.graph synchronises the device on entry: everything issued before is complete)
     # it is taken as it is — otherwise every captured launch carried its own fq_kron_prepare_kernel into the graph and replayed it every
     # step (round 4: 240 of them in bench.py's C4 graph, 4 % of C5's step). Outside capture the preparing launch's event is asked.
-    other = _WS_ANY.get(key[:1] + key[2:])
+    other = _ws_shared(key)
     if other is not None:
-        done = other[3]
-        if not done[0]:
-            if torch.cuda.is_current_stream_capturing():
-                done[0] = True
-            elif other[4].query():
-                done[0] = True
-        if done[0]:
-            _WS_LRU[key] = other[:3]
-            return other[0], nbytes, True, key
+        return other[0], nbytes, True, key
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes, False, key
+
+
+def _ws_shared(key):
+    """The image of this key's pair prepared on ANOTHER stream, if its preparing launch has completed (it is then registered under
+    this stream as well); None otherwise."""
+    other = _WS_ANY.get(key[:1] + key[2:])
+    if other is None:
+        return None
+    done = other[3]
+    if not done[0]:
+        if torch.cuda.is_current_stream_capturing() or other[4].query():
+            done[0] = True
+    if not done[0]:
+        return None
+    _WS_LRU[key] = other[:3]
+    return other[:3]
 
 
 def _kron_workspace_commit(key, ws: torch.Tensor, left: torch.Tensor, right: torch.Tensor) -> None:
@@ -653,6 +661,8 @@ def kron_quant_grouped(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor,
             key = (x.device.index, _stream_handle(x.device), M, N, G,
                    left.data_ptr(), left._version, right.data_ptr(), right._version)
             ent = _WS_LRU.get(key)
+            if ent is None:
+                ent = _ws_shared(key)      # (prepared on another stream: see _kron_workspace)
             prepared = ent is not None
             ws = ent[0] if prepared else torch.empty(per * G, dtype=torch.uint8, device=x.device)
             check(_fn("kron_quant_grouped_mats", dt)(
