@@ -1,22 +1,29 @@
 // fq_kron_tiles.hip — fused Kronecker transform + per-token INT4 quantisation (packed output) for the factor pairs whose token
-// needs MORE or FEWER than four 32-column n'-tiles, or more than four row tiles: 80 x 112 (8960, Qwen2.5-1.5B ffn), 128 x 144
-// (18432, DeepSeek-V3 dense ffn: deepseekv3_utils.py:343-348), 144 x 192 (27648, Qwen2.5-32B ffn) — function_utils.py:11-21 pairs
-// that until round 4 ran the workgroup-per-token kernel with ONE token resident per CU (0.21-0.32 of the HBM roofline).
+// is not four 32-column n'-tiles wide, or more than four row tiles tall: 80 x 112 (8960, Qwen2.5-1.5B ffn), 86 x 128 (11008, Llama-2-7B ffn),
+// 128 x 144 (18432, DeepSeek-V3 dense ffn: deepseekv3_utils.py:343-348), 128 x 148 (18944, Qwen2.5-7B ffn), 144 x 192 (27648, Qwen2.5-32B
+// ffn), 168 x 176 (29568, Qwen2.5-72B ffn) — function_utils.py:11-21 pairs that until round 4 ran the workgroup-per-token kernel with ONE
+// token resident per CU (0.21-0.32 of the HBM roofline; 86 x 128 the trio kernel) — on fp16 AND bf16 activations (bf16 also 112 x 128).
 //
-// The structure is fq_kron_trio.hip's, with the geometry as template parameters: one persistent workgroup per CU holds GROUPS token
-// groups of NT waves (a wave per n'-tile), the waves of a group meet on LDS counters and the groups drift apart, tokens are claimed
-// from a workgroup counter one ahead, staged by LDS-DMA, and never leave registers between GEMM 1 and the packed stores. What is new:
-//   * N = 16 KS1 for any KS1 (7, 9, 12 here): CPR = N / 8 chunks per row, unpadded rows; the bank rotation of a row is a property
-//     of CPR (tl_swz: chunk bit 0 flipped in rows 8..15 for CPR = 14, 18, 22, an XOR of the row's bits 1..3 for CPR = 24), and the
-//     per-lane DMA source offsets follow from it, computed per block of four instructions (no closed form shared by all CPR);
+// The structure is fq_kron_trio.hip's, with the geometry as template parameters <MT, NT, N, GROUPS, LKS, RS, T>: one persistent workgroup
+// per CU holds GROUPS token groups of NT waves (a wave per n'-tile), the waves of a group meet on LDS counters and the groups drift apart,
+// tokens are claimed from a workgroup counter one ahead, staged by LDS-DMA, and never leave registers between GEMM 1 and the packed stores.
+// What is new:
+//   * N = 16 KS1 for any KS1 (7, 8, 9, 11, 12 here): CPR = N / 8 chunks per row, unpadded rows; the bank rotation of a row is a property
+//     of CPR (tl_swz: chunk bit 0 flipped in rows 8..15 for CPR = 14, 18, 22, an XOR of the row's bits 1..3 for CPR = 24, of bits 0..3 for
+//     16), and the per-lane DMA source offsets follow from it — a table in LDS, DMP x 64 dwords, filled once per workgroup;
+//   * N % 16 != 0 (148): the token staged linearly (row pitch 296 bytes), fragments as two 8-byte reads, 32 zero bytes behind the token
+//     for the last K-step of the last row, a last half-tile with 4 valid columns (TilesGeom::ODDN);
 //   * a last n'-tile that is half padding (N % 32 = 16): its upper half-wave neither contributes extrema nor stores;
 //   * NO zero rows under the token: the row index of an A fragment is clamped to M - 1 instead (a padding row of U then holds finite
 //     copies, and meets zero rows of L in GEMM 2), so a buffer is exactly 16 LKS rows and 144 x 192 fits two tokens + its L image
 //     (trimmed to the K-steps that hold rows of L: LKS x MT KB) in 160 KB;
 //   * RS: the wave's R fragments (KS1 x 4 registers: 48 at N = 192) stream from the L2-resident image through a ring instead of
-//     living in registers, as in fq_kron_duo.hip.
+//     living in registers, as in fq_kron_duo.hip;
+//   * group counts follow the register file and the LDS: 4 x 4 waves (80 x 112, 127 VGPRs), 3 x 4 (86 x 128), 2 x 5 (128 x 144 / 148), 2 x 6
+//     (144 x 192), 1 x 6 (168 x 176: two tokens + the L image would be 184 KB).
 // Same mathematics, rounding points, fragment image (fq_kron_prepare_kernel) and quantiser helpers as every other Kronecker kernel;
-// bit-identical to the workgroup-per-token kernel (tests/test_gpu_kron_tiles.py).
+// bit-identical to the workgroup-per-token kernel (tests/test_gpu_kron_tiles.py). Measurements: profiles/r04_tiles_timing.txt,
+// r04_kron_128x144_pmc.txt.
 #include "fq_common.hpp"
 #include "fq_dma.hpp"
 
