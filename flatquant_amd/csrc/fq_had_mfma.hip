@@ -24,6 +24,9 @@
 // tolerance class for this op (tests/test_gpu_hadamard.py: 2e-3 of the row maximum against matmul_hadU's fixtures), not bit identity;
 // ops.hadamard_quant(fwht_route=True) keeps the bit-identical route.
 #include "fq_common.hpp"
+#ifndef HM_PRIO_MFMA
+#define HM_PRIO_MFMA 0   // s_setprio level of a wave inside phases A / B (see fq_kron_duo.hip); measured, see profiles/r04_duo_trio_timing.txt
+#endif
 
 namespace {
 
@@ -171,6 +174,7 @@ __global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __rest
     for (int k = grp; k < blk_cnt;) {   // k: the group's current token (of this workgroup's range), claimed one token ahead
         const int64_t tok = blk_base + k;
         HM_MEET()   // C|A: every wave of the group waited for its share of the DMA before its stores
+        if (HM_PRIO_MFMA) __builtin_amdgcn_s_setprio(HM_PRIO_MFMA);
 
         // ===== phase A: b-butterfly on the A fragments, GEMM 1 (contraction over c, K = 32), a-butterfly, fp16 rounding =====
         f16x8 Uh[4][2];
@@ -238,6 +242,7 @@ __global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __rest
             for (int s = 0; s < 2; ++s)
                 if (!(HM_ABL & 4)) Y[a] = fq_mfma32<f16>(Uh[a][s], B2[s], Y[a]);
         }
+        if (HM_PRIO_MFMA) __builtin_amdgcn_s_setprio(0);
         uint32_t H[4][8];   // the fp16 pairs the deploy Quantizer sees (and the transform output)
         float vmax = 0.0f, vmin = 0.0f;
         {

@@ -25,6 +25,9 @@
 // bit-identical to the workgroup-per-token kernel (tests/test_gpu_kron_tiles.py). Measurements: profiles/r04_tiles_timing.txt,
 // r04_kron_128x144_pmc.txt.
 #include "fq_common.hpp"
+#ifndef FQ_PRIO_MFMA
+#define FQ_PRIO_MFMA 2   // s_setprio level of a wave inside its GEMM phases (0: off); see fq_kron_duo.hip
+#endif
 #include "fq_dma.hpp"
 
 namespace {
@@ -213,6 +216,7 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
 
         // ================= phase A: GEMM 1 (U = X . R for this wave's n'-tile), fp16 rounding =================
         TILES_MEET()   // C|A: every wave of the group waited for its share of the DMA before its stores of phase C
+        if (FQ_PRIO_MFMA) __builtin_amdgcn_s_setprio(FQ_PRIO_MFMA);
         X8 Uh[MT][2];
         {
             int cl = c;
@@ -289,6 +293,7 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (FQ_PRIO_MFMA) __builtin_amdgcn_s_setprio(0);
         float vmax = -INFINITY, vmin = INFINITY;
         {
             if (out.post_scale != 0.0f) {

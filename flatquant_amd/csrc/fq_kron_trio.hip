@@ -25,6 +25,9 @@
 // (fq_kron_prepare_kernel). Everything this kernel does not take (fp16 outputs, SiLU.mul input, diag, per-128 scales)
 // stays with fq_kron_generic.hip. What limits it is in DESIGN.md 4.2 (the shader clock under this load).
 #include "fq_common.hpp"
+#ifndef FQ_PRIO_MFMA
+#define FQ_PRIO_MFMA 2   // s_setprio level of a wave inside its GEMM phases (0: off)
+#endif
 #include "fq_dma.hpp"
 
 namespace {
@@ -164,6 +167,9 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
 #endif
         TRIO_MEET()  // C|A: every wave of the group waited for its share of the DMA before its stores of phase C
         TRIO_STAMP(1)
+        // (round 4) a wave inside its GEMM phases goes ahead of the quantising ones at the SIMD's arbiter: the matrix pipe is the scarcer
+        // resource and an MFMA that waits behind another wave's VALU burst idles it (measured: 128 x 224 194.5 -> 190.8 us, 112 x 128 159.3 -> 158.0)
+        if (FQ_PRIO_MFMA) __builtin_amdgcn_s_setprio(FQ_PRIO_MFMA);
         f16x8 Uh[MT][2];
         {
             int cl = c;
@@ -235,6 +241,7 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
             }
         }
         TRIO_STAMP(5)
+        if (FQ_PRIO_MFMA) __builtin_amdgcn_s_setprio(0);
         uint32_t H[H16 ? MT : 1][8];  // H16: the fp16 pairs the deploy Quantizer sees
         float vmax = -INFINITY, vmin = INFINITY;
         if (H16) {
