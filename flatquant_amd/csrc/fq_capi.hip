@@ -18,7 +18,7 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream);
 int fq_launch_gemm_bf6_multi(int n, const uint8_t* const* xblob, const uint8_t* const* wblob, int64_t M, const int* Ns, int K, f16* const* y,
-                             const f16* const* srow, const f16* const* scol, const f16* const* bias, hipStream_t stream);   // fq_gemm_bf6.hip
+                             const f16* const* srow, const f16* const* scol, const f16* const* bias, int gate_up, hipStream_t stream);   // fq_gemm_bf6.hip
 int fq_launch_fakequant_bits(int bf16_dtype, const void* x, void* y, int64_t rows, int cols, float sig_max, float sig_min, int bits, int flags,
                              int n_cu, hipStream_t stream);   // fq_quant.hip
 int fq_launch_kron64_multi(int bf16_dtype, const void* jobs, int n_jobs, int bpj, const FqQuantOut& out, hipStream_t stream);
@@ -45,6 +45,7 @@ int fq_launch_gemm_i4_skinny(const uint8_t* X, const void* wimg, int64_t M, int 
                              const f16* scol, const f16* bias, hipStream_t stream);
 int64_t fq_bf6_blob_bytes(int64_t rows, int K);  // fq_gemm_bf6.hip (exported as is)
 int fq_launch_i4_to_bf6(const uint8_t* q, int64_t rows, int K, int perm, uint8_t* blob, int n_cu, hipStream_t stream);
+int fq_launch_i4_to_bf6_multi(int nsrc, const uint8_t* const* q, int64_t rows, int K, int perm, uint8_t* blob, int n_cu, hipStream_t stream);
 int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, int N, int K, int32_t* c, f16* y,
                        const f16* srow, const f16* scol, const f16* bias, hipStream_t stream);
 int fq_launch_kv_append(void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last, const uint8_t* k,
@@ -740,10 +741,9 @@ int fq_int4_linear_fp6_f16(const void* x, const void* x_scale, const void* w, co
     return check_launch(rc, what);
 }
 
-int fq_int4_linear_fp6_multi_f16(int n, const void* const* x, const void* const* x_scale, const void* const* w, const void* const* wblob,
-                                 const void* const* w_scale, const void* const* bias, int64_t M, const int* N, int K, void* const* y,
-                                 void* scratch, int64_t scratch_bytes, void* stream) {
-    const char* what = "fq_int4_linear_fp6_multi_f16";
+static int linear_fp6_multi(const char* what, int gate_up, int n, const void* const* x, const void* const* x_scale, const void* const* w,
+                            const void* const* wblob, const void* const* w_scale, const void* const* bias, int64_t M, const int* N, int K,
+                            void* const* y, void* scratch, int64_t scratch_bytes, void* stream) {
     if (n < 1 || n > 4) return fail(FQ_EINVAL, "%s: 1..4 problems (got %d)", what, n);
     if (!x || !x_scale || !w || !wblob || !w_scale || !bias || !N || !y) return fail(FQ_EINVAL, "%s: NULL table", what);
     if (M < 0 || K <= 0) return fail(FQ_EINVAL, "%s: bad sizes", what);
@@ -765,16 +765,23 @@ int fq_int4_linear_fp6_multi_f16(int n, const void* const* x, const void* const*
     uint8_t* cur = static_cast<uint8_t*>(scratch);
     const uint8_t* xb[4];
     const uint8_t* wb[4];
+    const uint8_t* xsrc[4];   // the distinct packed activations: ONE conversion launch, their images one behind the other
+    int nx = 0;
     for (int p = 0; p < n; ++p) {
         xb[p] = nullptr;
         for (int q = 0; q < p; ++q)
             if (x[q] == x[p]) xb[p] = xb[q];
         if (!xb[p]) {
-            int rc = fq_launch_i4_to_bf6((const uint8_t*)x[p], M, K, 0, cur, cu_count(), (hipStream_t)stream);
-            if (rc != 0) return check_launch(rc, what);
+            xsrc[nx++] = (const uint8_t*)x[p];
             xb[p] = cur;
             cur += fq_bf6_blob_bytes(M, K);
         }
+    }
+    {
+        int rc = fq_launch_i4_to_bf6_multi(nx, xsrc, M, K, 0, static_cast<uint8_t*>(scratch), cu_count(), (hipStream_t)stream);
+        if (rc != 0) return check_launch(rc, what);
+    }
+    for (int p = 0; p < n; ++p) {
         wb[p] = (const uint8_t*)wblob[p];
         if (!wb[p]) {
             int rc = fq_launch_i4_to_bf6((const uint8_t*)w[p], N[p], K, 1, cur, cu_count(), (hipStream_t)stream);
@@ -784,8 +791,22 @@ int fq_int4_linear_fp6_multi_f16(int n, const void* const* x, const void* const*
         }
     }
     const int rc = fq_launch_gemm_bf6_multi(n, xb, wb, M, N, K, (f16* const*)y, (const f16* const*)x_scale, (const f16* const*)w_scale,
-                                            (const f16* const*)bias, (hipStream_t)stream);
+                                            (const f16* const*)bias, gate_up, (hipStream_t)stream);
     return check_launch(rc, what);
+}
+
+int fq_int4_linear_fp6_multi_f16(int n, const void* const* x, const void* const* x_scale, const void* const* w, const void* const* wblob,
+                                 const void* const* w_scale, const void* const* bias, int64_t M, const int* N, int K, void* const* y,
+                                 void* scratch, int64_t scratch_bytes, void* stream) {
+    return linear_fp6_multi("fq_int4_linear_fp6_multi_f16", 0, n, x, x_scale, w, wblob, w_scale, bias, M, N, K, y, scratch, scratch_bytes, stream);
+}
+
+int fq_int4_linear_fp6_gate_up_f16(const void* const* x, const void* const* x_scale, const void* const* w, const void* const* wblob,
+                                   const void* const* w_scale, const void* const* bias, int64_t M, int N, int K, void* y, void* scratch,
+                                   int64_t scratch_bytes, void* stream) {
+    const int Ns[2] = {N, N};
+    void* const ys[2] = {y, y};
+    return linear_fp6_multi("fq_int4_linear_fp6_gate_up_f16", 1, 2, x, x_scale, w, wblob, w_scale, bias, M, Ns, K, ys, scratch, scratch_bytes, stream);
 }
 
 int fq_fwht_f32_f16(const void* x, void* y, int64_t vecs, int P, float scale, void* stream) {

@@ -335,7 +335,7 @@ __device__ __forceinline__ int fq_quant1_h(bf16 y, bf16 s) {
 // ac = fp16( g / (1 + exp(-g)) ) evaluated in fp32 (torch's SiLU opmath), x = fp16(ac * up). v_exp_f32 / v_rcp_f32
 // are 1-ulp fp32 approximations: after the fp16 rounding a few results in 10^4 differ from a correctly rounded fp32
 // evaluation by one fp16 step (tests/test_gpu_silu.py states the bound).
-__device__ __forceinline__ f16x8 fq_silu_mul8(f16x8 g, f16x8 u) {
+__device__ __forceinline__ f16x8 fq_silu8(f16x8 g) {
     f16x8 a;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -343,8 +343,9 @@ __device__ __forceinline__ f16x8 fq_silu_mul8(f16x8 g, f16x8 u) {
         const float e = __builtin_amdgcn_exp2f(gf * -1.44269504088896340736f);
         a[j] = (f16)(gf * __builtin_amdgcn_rcpf(1.0f + e));
     }
-    return a * u;
+    return a;
 }
+__device__ __forceinline__ f16x8 fq_silu_mul8(f16x8 g, f16x8 u) { return fq_silu8(g) * u; }
 
 // The fake-quant value fp16(fp32(scale * q)) of an integer-valued float q. A zero product is made +0.0: the reference
 // rounds with round_ste (quant_utils.py:3-7: (x.round() - x) + x), which never returns -0.0, while v_rndne_f32 of a small

@@ -44,6 +44,9 @@ using namespace fqgemm;
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_b;
 
+#ifndef FQ_GU_ABL
+#define FQ_GU_ABL 0   // measurement builds of the gate / up epilogue: 1 = no SiLU arithmetic, 2 = no read-back of the gate tile's values (wrong results)
+#endif
 constexpr int BN = 256;
 constexpr int BLOB = 1536;                     // bytes: 32 rows x 64 k of BF6
 constexpr int SEG = 2 * BLOB;                  // a row tile's two blobs of one stage (128 k)
@@ -72,7 +75,10 @@ __device__ __forceinline__ unsigned bf6_code(int v) {  // v in [-8, 7]
     return tab[mag] | (v < 0 ? 0x20u : 0u);
 }
 
-__global__ __launch_bounds__(256) void fq_i4_to_bf6_kernel(const uint8_t* __restrict__ src, int64_t rows, int Kb, int perm,
+// Up to four sources of the same [rows, Kb] shape in one launch (round 4: the activations of q / k / v, or of gate / up, each quantised with
+// its own clip factors — at 2048 tokens a conversion launch is ~7 us of which the data are 2): their images are laid one behind the other in dst.
+struct ConvSrc { const uint8_t* s[4]; };
+__global__ __launch_bounds__(256) void fq_i4_to_bf6_kernel(ConvSrc srcs, int nsrc, int64_t rows, int Kb, int perm,
                                                            uint8_t* __restrict__ dst) {
     __shared__ unsigned short lut[256];  // packed byte (two nibbles, even k low) -> 12 bits of codes
     {
@@ -86,12 +92,15 @@ __global__ __launch_bounds__(256) void fq_i4_to_bf6_kernel(const uint8_t* __rest
                                     // lanes 0-31 the rows of blob 2 j, lanes 32-63 the same rows of blob 2 j + 1 — a wave reads 64
                                     // contiguous bytes of each of 32 rows (one blob per wave read 32 bytes per row: 16384 x 14336 78.5 -> 68.6 us)
     const int64_t n_rt = (rows + 31) / 32;
-    const int64_t total = n_rt * KBP * 64;
+    const int64_t total = nsrc * n_rt * KBP * 64;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int lane = (int)(i & 63);
         const int64_t pair = i >> 6;
-        const int64_t rt = pair / KBP;
-        const int kb = 2 * (int)(pair - rt * KBP) + (lane >> 5);
+        const int64_t rtg = pair / KBP;             // row tile in dst (all sources)
+        const int sp = (int)(rtg / n_rt);           // (wave-uniform: a wave is one pair)
+        const int64_t rt = rtg - sp * n_rt;         // row tile of its source
+        const uint8_t* __restrict__ src = sp == 0 ? srcs.s[0] : sp == 1 ? srcs.s[1] : sp == 2 ? srcs.s[2] : srcs.s[3];
+        const int kb = 2 * (int)(pair - rtg * KBP) + (lane >> 5);
         if (kb >= KB) continue;
         const int r = lane & 31;
         const int64_t row = rt * 32 + (perm ? prow(r) : r);
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(256) void fq_i4_to_bf6_kernel(const uint8_t* __rest
             in2[0] = sp[0];
             in2[1] = sp[1];
         }
-        unsigned long long* d = reinterpret_cast<unsigned long long*>(dst + (rt * KB + kb) * BLOB) + r;
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(dst + (rtg * KB + kb) * BLOB) + r;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             const unsigned w[4] = {in2[kh].x, in2[kh].y, in2[kh].z, in2[kh].w};
@@ -124,8 +133,8 @@ __global__ __launch_bounds__(256) void fq_i4_to_bf6_kernel(const uint8_t* __rest
 typedef int i32x6 __attribute__((ext_vector_type(6)));
 
 // MULTI (round 4): up to four problems that share M and K — q / k / v, or up / gate of one layer: their own quantised activations, weights,
-// scales and outputs (deploy/nn/linear.py:40-54 once per projection) — as ONE launch: the feature tiles of the problems are laid side by
-// side in the tile sequence (problem p owns the column tiles [tn0[p], tn0[p + 1])), and a tile picks its problem's pointers. 2048
+// scales and outputs (deploy/nn/linear.py:40-54 once per projection) — as ONE launch: problem p has tn0[p + 1] - tn0[p] column tiles, every XCD walks its share of problem 0's tiles, then of
+// problem 1's, ... (next_tile), and a tile picks its problem's pointers. 2048
 // tokens x 4096 features are 128 tiles of 256 x 256 on 256 CUs: three such launches leave half the chip idle three times.
 template <bool MULTI> struct GemmMultiArg {};
 template <> struct GemmMultiArg<true> {
@@ -135,25 +144,24 @@ template <> struct GemmMultiArg<true> {
     GemmOut out[4];
 };
 
-template <int BM, bool MULTI = false>
+//
+// MODE 2, GATE_UP (round 4): x_up * act_fn(x_gate) (deploy/transformers/modeling_llama.py:270-278) in the epilogue of the
+// gate / up pair. Problem 0 is gate_proj, problem 1 up_proj, with their own activations and the same N; a workgroup computes the gate tile
+// (mb, nb), writes a = fp16(silu(y_gate)) where the result will stand, then computes the up tile of the same (mb, nb), whose epilogue
+// has read a back — every lane its own 32 bytes per accumulator tile, written one K loop earlier — and stores a * y_up. The main loop,
+// the 256 x 256 tile and the accumulator count are those of the single-problem kernel (two accumulator sets would halve the tile); the
+// intermediate [M, N] tensors x_gate and x_up (2 x 470 MB written, read again by SiLU.mul at 16384 x 14336) never exist.
+template <int BM, int MODE = 0>
 __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB_, const uint8_t* __restrict__ WB_,
                                                                               int M, int N_, int KB, int n_vblocks, GemmOut out_,
-                                                                              GemmMultiArg<MULTI> mp) {
+                                                                              GemmMultiArg<(MODE != 0)> mp) {
+    constexpr bool MULTI = MODE != 0, GATE_UP = MODE == 2;
     const uint8_t* XB = XB_;
     const uint8_t* WB = WB_;
     int N = N_;
     GemmOut out = out_;
     // (wave-uniform selects: a dynamic index into a by-value kernel argument could send it through scratch)
 #define FQ_PICK(arr, p) ((p) == 0 ? mp.arr[0] : (p) == 1 ? mp.arr[1] : (p) == 2 ? mp.arr[2] : mp.arr[3])
-    auto problem_of = [&](int& nb) -> int {   // global column tile -> (problem, its own column tile)
-        int p = 0;
-        if constexpr (MULTI) {
-            p = nb >= mp.tn0[3] ? 3 : nb >= mp.tn0[2] ? 2 : nb >= mp.tn0[1] ? 1 : 0;
-            p = p < mp.n ? p : mp.n - 1;
-            nb -= FQ_PICK(tn0, p);
-        }
-        return p;
-    };
     constexpr int NWM = Geo<BM>::NWM, TILE_BYTES = Geo<BM>::TILE_BYTES, DPW = Geo<BM>::DPW, STAGES = Geo<BM>::STAGES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
@@ -217,10 +225,39 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
             }
     };
     // the tile sequence of this workgroup: virtual blocks blockIdx.x, + gridDim.x, ... (gridDim.x % 8 == 0: the XCD stays)
-    auto next_tile = [&](int& vb, int& mb, int& nb) -> bool {
-        for (; vb < n_vblocks; vb += (int)gridDim.x)
-            if (xcd_tile(vb, TMg, TNg, mb, nb)) return true;
-        return false;
+    // MULTI (MODE 1): an XCD's share of the sequence is its share of problem 0's tiles, then of problem 1's, ...: all eight XCDs work on
+    // the same problem at the same time, like a launch of its own would. Side by side in ONE sequence (first build) XCDs 0-3 streamed the
+    // activations of gate_proj while 4-7 streamed those of up_proj: 16384 x 14336 x 4096 with each projection on its own packed input
+    // 1237 us against 2 x 527 for two launches (tools/time_gate_up.py).
+    auto next_tile = [&](int& vb, int& mb, int& nb, int& p) -> bool {
+        if constexpr (MODE == 1) {
+            for (; vb < n_vblocks; vb += (int)gridDim.x) {
+                const int xcd = vb & 7;
+                int local = vb >> 3;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int tnq = mp.tn0[q + 1] - mp.tn0[q], Tq = TMg * tnq, per = (Tq + 7) >> 3;   // (problems beyond mp.n: zero tiles)
+                    if (local < per) {
+                        const int L = xcd * per + local;
+                        if (L < Tq) {
+                            const int blk = L / (8 * TMg), rem = L - blk * 8 * TMg;
+                            const int width = tnq - blk * 8 < 8 ? tnq - blk * 8 : 8;
+                            mb = rem / width;
+                            nb = blk * 8 + (rem - mb * width);
+                            p = q;
+                            return true;
+                        }
+                        break;   // a slot behind the end of this XCD's share of problem q
+                    }
+                    local -= per;
+                }
+            }
+            return false;
+        } else {
+            for (; vb < n_vblocks; vb += (int)gridDim.x)
+                if (xcd_tile(vb, TMg, TNg, mb, nb)) return true;
+            return false;
+        }
     };
 
     const int woff = (wn * 2) * SEG + lane * 8;             // + tn * SEG + kbl * BLOB + plane * 512
@@ -267,8 +304,8 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
     };
 
     int vb = blockIdx.x, mb = 0, nb = 0;
-    if (!next_tile(vb, mb, nb)) return;
-    int prob = problem_of(nb);
+    int prob = 0;
+    if (!next_tile(vb, mb, nb, prob)) return;
     plan(mb, nb, prob);
     request_first_stages();
     {   // the first tile starts as soon as its first stage is there
@@ -336,11 +373,15 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
         asm volatile("" : "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3]), "+v"(sc[0][0]), "+v"(sc[0][1]), "+v"(sc[1][0]),
                      "+v"(sc[1][1]), "+v"(bs[0][0]), "+v"(bs[0][1]), "+v"(bs[1][0]), "+v"(bs[1][1]));
         // the next tile of this workgroup: its first stages are requested NOW, in front of the epilogue
-        int nvb = vb + (int)gridDim.x, nmb = 0, nnb = 0;
-        const bool more = next_tile(nvb, nmb, nnb);
-        int nprob = 0;
+        int nvb = vb + (int)gridDim.x, nmb = 0, nnb = 0, nprob = 0;
+        bool more;
+        if (GATE_UP && prob == 0) {   // the up tile of the same (mb, nb)
+            nvb = vb, nmb = mb, nnb = nb, nprob = 1;
+            more = true;
+        } else {
+            more = next_tile(nvb, nmb, nnb, nprob);
+        }
         if (more) {
-            nprob = problem_of(nnb);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();   // every wave has read the last stage: all three buffers are free
             plan(nmb, nnb, nprob);
@@ -373,6 +414,21 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
                         dequant16f<false>(acc[tn][tm], sr[tm], __builtin_bit_cast(f16x8, sc[tn][0]), __builtin_bit_cast(f16x8, sc[tn][1]),
                                           out.bias != nullptr, __builtin_bit_cast(f16x8, bs[tn][0]), __builtin_bit_cast(f16x8, bs[tn][1]), o0, o1);
                     uint4* yp = reinterpret_cast<uint4*>(out.y + (int64_t)m * N + nbase);
+                    if constexpr (GATE_UP) {
+                        if (prob == 0) {
+                            if (!(FQ_GU_ABL & 1)) {
+                                o0 = fq_silu8(o0);
+                                o1 = fq_silu8(o1);
+                            }
+                        } else if (!(FQ_GU_ABL & 2)) {
+                            // These loads stand behind the next tile's LDS-DMA requests in the vmcnt queue: the epilogue of an up tile starts when those have
+                            // landed (7 us per tile pair, tools/r04_call48.sh). Requested in FRONT of them and waited for there (64 registers: spills in
+                            // the tail only) the launch was slower still, 1255 -> 1450 us (r04_call49): every workgroup reads its 128 KB back at the same
+                            // moment, a 32 MB burst, and nothing overlaps it.
+                            o0 = __builtin_bit_cast(f16x8, yp[0]) * o0;
+                            o1 = __builtin_bit_cast(f16x8, yp[1]) * o1;
+                        }
+                    }
                     yp[0] = __builtin_bit_cast(uint4, o0);   // (plain stores: non-temporal ones measured 163 -> 173 us)
                     yp[1] = __builtin_bit_cast(uint4, o1);
                 }
@@ -404,13 +460,19 @@ int64_t fq_bf6_blob_bytes(int64_t rows, int K) {
 }
 
 // -1000: K % 64 != 0
-int fq_launch_i4_to_bf6(const uint8_t* q, int64_t rows, int K, int perm, uint8_t* blob, int n_cu, hipStream_t stream) {
-    if ((K & 63) || rows < 1) return -1000;
-    const int64_t total = ((rows + 31) / 32) * (int64_t)((K / 64 + 1) / 2) * 64;
+int fq_launch_i4_to_bf6_multi(int nsrc, const uint8_t* const* q, int64_t rows, int K, int perm, uint8_t* blob, int n_cu, hipStream_t stream) {
+    if ((K & 63) || rows < 1 || nsrc < 1 || nsrc > 4) return -1000;
+    ConvSrc srcs;
+    for (int p = 0; p < 4; ++p) srcs.s[p] = q[p < nsrc ? p : nsrc - 1];
+    const int64_t total = nsrc * ((rows + 31) / 32) * (int64_t)((K / 64 + 1) / 2) * 64;
     int64_t blocks = (total + 255) / 256;
     if (blocks > (int64_t)n_cu * 16) blocks = (int64_t)n_cu * 16;
-    hipLaunchKernelGGL(fq_i4_to_bf6_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q, rows, K / 2, perm, blob);
+    hipLaunchKernelGGL(fq_i4_to_bf6_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, srcs, nsrc, rows, K / 2, perm, blob);
     return (int)hipGetLastError();
+}
+
+int fq_launch_i4_to_bf6(const uint8_t* q, int64_t rows, int K, int perm, uint8_t* blob, int n_cu, hipStream_t stream) {
+    return fq_launch_i4_to_bf6_multi(1, &q, rows, K, perm, blob, n_cu, stream);
 }
 
 // -1000: shape not covered (K % 128 != 0, N % 16 != 0, K > 2^18): use the i8 kernel
@@ -452,9 +514,11 @@ int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, in
 }
 
 // Up to four problems with common M and K in one launch (fq_gemm_bf6_kernel<BM, true>). -1000: shape not covered.
+// gate_up != 0: n == 2, problem 0 = gate_proj, problem 1 = up_proj, Ns[0] == Ns[1], y[0] == y[1] = the [M, N] result x_up * silu(x_gate).
 int fq_launch_gemm_bf6_multi(int n, const uint8_t* const* xblob, const uint8_t* const* wblob, int64_t M, const int* Ns, int K, f16* const* y,
-                             const f16* const* srow, const f16* const* scol, const f16* const* bias, hipStream_t stream) {
+                             const f16* const* srow, const f16* const* scol, const f16* const* bias, int gate_up, hipStream_t stream) {
     if (n < 1 || n > 4 || (K & 127) || K > (1 << 18) || M < 1 || M > (1 << 30)) return -1000;
+    if (gate_up && (n != 2 || Ns[0] != Ns[1] || y[0] != y[1])) return -1000;
     GemmMultiArg<true> mp = {};
     mp.n = n;
     int tn = 0;
@@ -473,6 +537,10 @@ int fq_launch_gemm_bf6_multi(int n, const uint8_t* const* xblob, const uint8_t* 
         mp.out[p].bias = bias[q];
     }
     for (int p = n; p < 5; ++p) mp.tn0[p] = tn;
+    if (gate_up) {   // the tile sequence is the one of ONE problem; a workgroup runs both problems on each of its tiles
+        tn = (Ns[0] + BN - 1) / BN;
+        for (int p = 1; p < 5; ++p) mp.tn0[p] = tn;
+    }
     static int cus[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -484,18 +552,34 @@ int fq_launch_gemm_bf6_multi(int n, const uint8_t* const* xblob, const uint8_t* 
     const int64_t tiles256 = ((M + 255) / 256) * tn;
     const bool half = tiles256 * 4 < (int64_t)cus[dev] * 3;
     const int bm = half ? 128 : 256;
-    const int64_t n_vblocks = 8 * ((((M + bm - 1) / bm) * tn + 7) / 8);
+    int64_t n_vblocks = 8 * ((((M + bm - 1) / bm) * tn + 7) / 8);
+    if (!gate_up) {   // eight XCD shares of the per-problem shares (next_tile, MODE 1)
+        n_vblocks = 0;
+        for (int p = 0; p < n; ++p) n_vblocks += 8 * ((((M + bm - 1) / bm) * (int64_t)(mp.tn0[p + 1] - mp.tn0[p]) + 7) / 8);
+    }
     int64_t blocks = (cus[dev] / 8) * 8;
     if (blocks < 8) blocks = 8;
     if (blocks > n_vblocks) blocks = n_vblocks;
     GemmOut o0 = mp.out[0];
-    if (half) {
-        auto kern = fq_gemm_bf6_kernel<128, true>;
+    if (gate_up) {
+        if (half) {
+            auto kern = fq_gemm_bf6_kernel<128, 2>;
+            FQ_RAISE_LDS_CAP(kern, Geo<128>::STAGES * Geo<128>::TILE_BYTES);
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Geo<128>::GT), Geo<128>::STAGES * Geo<128>::TILE_BYTES, stream, mp.xb[0], mp.wb[0],
+                               (int)M, mp.N[0], K / 64, (int)n_vblocks, o0, mp);
+        } else {
+            auto kern = fq_gemm_bf6_kernel<256, 2>;
+            FQ_RAISE_LDS_CAP(kern, Geo<256>::STAGES * Geo<256>::TILE_BYTES);
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Geo<256>::GT), Geo<256>::STAGES * Geo<256>::TILE_BYTES, stream, mp.xb[0], mp.wb[0],
+                               (int)M, mp.N[0], K / 64, (int)n_vblocks, o0, mp);
+        }
+    } else if (half) {
+        auto kern = fq_gemm_bf6_kernel<128, 1>;
         FQ_RAISE_LDS_CAP(kern, Geo<128>::STAGES * Geo<128>::TILE_BYTES);
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Geo<128>::GT), Geo<128>::STAGES * Geo<128>::TILE_BYTES, stream, mp.xb[0], mp.wb[0],
                            (int)M, mp.N[0], K / 64, (int)n_vblocks, o0, mp);
     } else {
-        auto kern = fq_gemm_bf6_kernel<256, true>;
+        auto kern = fq_gemm_bf6_kernel<256, 1>;
         FQ_RAISE_LDS_CAP(kern, Geo<256>::STAGES * Geo<256>::TILE_BYTES);
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Geo<256>::GT), Geo<256>::STAGES * Geo<256>::TILE_BYTES, stream, mp.xb[0], mp.wb[0],
                            (int)M, mp.N[0], K / 64, (int)n_vblocks, o0, mp);

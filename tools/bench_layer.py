@@ -210,7 +210,7 @@ def main():
     # (round 4) q / k / v as ONE GEMM launch and up / gate as one (deploy.nn.linear.linear4bit_multi, fq_int4_linear_fp6_multi_f16): each
     # projection keeps its own packed input and weights; at a few thousand tokens a single projection does not fill the chip
     from flatquant_amd.deploy.nn.linear import linear4bit_multi
-    gm = 0.0
+    gm, gm_by = 0.0, {}
     for names in (("q_proj", "k_proj", "v_proj"), ("o_proj",), ("up_proj", "gate_proj"), ("down_proj",)):
         mods, ins = [], []
         for name, k_in, n_out in lins:
@@ -218,13 +218,24 @@ def main():
                 lin = deploy.nn.Linear4bit(k_in, n_out).to(dev)
                 lin.weight_scales.fill_(0.01)
                 mods.append(lin)
-                ins.append(packed[k_in])
+                # (each projection its own packed input, as under FlatQuant's per-projection clip factors: a shared one flatters the launch)
+                ins.append(packed[k_in] if not ins else deploy.PackedQuantizedTensor(packed[k_in].quantized_x.clone(), packed[k_in].scales_x.clone()))
         us = timeit(lambda: linear4bit_multi(mods, ins), max(a.steps // 5, 5), warm=3)
         gm += us
+        gm_by[names[0]] = us
         print(f"  {'Linear4bit ' + ' + '.join(names) + ', one launch':58s} {us:9.1f} us")
+        if names[0] == "up_proj":
+            # (round 4) ... and with x_up * silu(x_gate) in that launch's epilogue (linear4bit_gate_up, fq_int4_linear_fp6_gate_up_f16): the two
+            # [tokens, ffn] projections are never written, the down_proj transform reads the product like any other activation
+            from flatquant_amd.deploy.nn.linear import linear4bit_gate_up
+            gu = timeit(lambda: linear4bit_gate_up(mods[1], mods[0], ins[1], ins[0]), max(a.steps // 5, 5), warm=3)
+            print(f"  {'Linear4bit gate_proj + up_proj + SiLU.mul, one launch':58s} {gu:9.1f} us")
         del mods
     deploy.nn.Linear4bit.fp6_image = False
     print(f"  {'seven linears, FP6 path, q/k/v and up/gate as one launch each':62s} {gm:9.1f} us;  FlatQuant layer: {fused_struct + gm:.1f} us")
+    gu_layer = (fused_struct - mmf + mm) + (gm - gm_by["up_proj"] + gu)
+    print(f"  ... with SiLU.mul in the gate/up GEMM epilogue (down transform {mm:.1f} us instead of {mmf:.1f}, gate/up launch {gu:.1f} instead of "
+          f"{gm_by['up_proj']:.1f}): FlatQuant layer {gu_layer:.1f} us")
 
     # FP16 baseline of the same layer pieces (what benchmarks/layer_benchmark.py:200-274 compares against): the seven
     # nn.Linear GEMMs in fp16 (rocBLAS / hipBLASLt through torch), two RMSNorms and SiLU.mul in torch eager; the
@@ -245,7 +256,8 @@ def main():
           f"FlatQuant W4A4 layer {fused_struct + gtot:.1f} us -> {f16layer / (fused_struct + gtot):.2f}x "
           f"(linears alone {f16tot / gtot:.2f}x); with the FP6 operand image {fused_struct + g6:.1f} us -> "
           f"{f16layer / (fused_struct + g6):.2f}x (linears alone {f16tot / g6:.2f}x); with q/k/v and up/gate as one launch each "
-          f"{fused_struct + gm:.1f} us -> {f16layer / (fused_struct + gm):.2f}x (linears alone {f16tot / gm:.2f}x)")
+          f"{fused_struct + gm:.1f} us -> {f16layer / (fused_struct + gm):.2f}x (linears alone {f16tot / gm:.2f}x); with SiLU.mul in the gate/up GEMM "
+          f"epilogue {gu_layer:.1f} us -> {f16layer / gu_layer:.2f}x")
 
 
 if __name__ == "__main__":
