@@ -7,7 +7,7 @@ the two 64x64 factor matrices are broadcast once from rank 0 over RCCL).  One st
 fq_kron_quant_f16 (packed INT4 + fp16 scales out) over one 128 MiB activation buffer already resident in
 HBM; buffers rotate over > 256 MiB so the Infinity Cache cannot serve the stream.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C2S|C1|C3|C4|C5] [--dtype f16|bf16]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C2S|C1|C3|C4|C4H|C5] [--dtype f16|bf16]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
 
 --config (the other BASELINE.json configs; one "element" = one input activation scalar of one (token, linear) unit):
@@ -22,6 +22,8 @@ HBM; buffers rotate over > 256 MiB so the Infinity Cache cannot serve the stream
       28 x 512 + Quantizer on the down_proj input. 4 launches per step, 8 x 2048 tokens per GPU (weak scaling).
   C4  Llama-2-70B shapes (d = 8192 = 64x128, ffn 28672 = 128x224, 64 heads), all 80 layers per step (320 launches,
       replayed from ONE captured HIP graph), 8 x 2048 tokens in total, rows sharded over the GPUs (strong scaling).
+  C4H C4 with the down_proj input as the reference's deploy model builds it (OnlineTrans(had) + Quantizer,
+      deploy/transformers/modeling_llama.py:248-253): Hadamard 28 x 1024 + Quantizer in one launch instead of the learned 128x224 pair.
   C5  DeepSeek-V3 MoE: w1_trans 64x112 over 16384 tokens of d = 7168, then the routed experts' hidden rows
       [8 x 16384, 2048] in 256 groups (Zipf routing) through the grouped 32x64 launch with per-expert clip pairs;
       experts (groups) and tokens sharded over the GPUs (strong scaling).
@@ -343,6 +345,7 @@ class C3(Workload):
 
 class C4(Workload):
     name = "C4"
+    down = "kron"       # down_proj input: the learned 128 x 224 pair (C4) | the online Hadamard 28 x 1024 + Quantizer (C4H, below)
     metric = "Melems/s, Llama-2-70B shapes (d=8192, ffn=28672, 64 heads), activation path of all 80 layers, 8x2048 tokens total"
     scaling = "strong"
     graph = True
@@ -373,10 +376,15 @@ class C4(Workload):
         k_o = lambda i: ops.block_quant(xa[i % nb], mats[f"o{i % nm}"], s1, P)
         k_ug = lambda i: ops.rmsnorm_kron_quant(xs[(i + 1) % nb], 1e-5, mats[f"ug_l{i % nm}"], mats[f"ug_r{i % nm}"], s2, P)
         k_dn = lambda i: ops.kron_quant(xf[i % nb], mats[f"dn_l{i % nm}"], mats[f"dn_r{i % nm}"], s1, P)
+        dn_name = "kron 128x224 (down_proj)"
+        if self.down == "hadamard":
+            hadk = bcast({"hadk": _hadk(28, device)})["hadk"]
+            k_dn = lambda i: ops.hadamard_quant(xf[i % nb], 28, hadk, s1[0])
+            dn_name = "hadamard 28x1024 + Quantizer (down_proj)"
         self.kernels = [("rmsnorm+kron 64x128 x3 clips (q/k/v)", k_qkv, rows * (2 * hid + 3 * (hid // 2 + 2))),
                         ("block transform 128x64 (o_proj)", k_o, rows * packed_bytes(hid)),
                         ("rmsnorm+kron 64x128 x2 clips (up/gate)", k_ug, rows * (2 * hid + 2 * (hid // 2 + 2))),
-                        ("kron 128x224 (down_proj)", k_dn, rows * packed_bytes(ffn))]
+                        (dn_name, k_dn, rows * packed_bytes(ffn))]
 
         def step(i):
             for layer in range(layers):
@@ -384,9 +392,18 @@ class C4(Workload):
         self.step = step
         self.elems = rows * layers * (3 * hid + hid + 2 * hid + ffn)
         self.config = {"workload": "C4: Llama-2-70B shapes, 80 layers x (RMSNorm+64x128 x3 clips, head transform 128x64, "
-                                   "RMSNorm+64x128 x2 clips, 128x224), 8x2048 tokens in total, rows sharded; one step = 320 launches replayed "
+                                   "RMSNorm+64x128 x2 clips, " + ("128x224" if self.down == "kron" else "Hadamard 28x1024 + Quantizer") +
+                                   "), 8x2048 tokens in total, rows sharded; one step = 320 launches replayed "
                                    "from one captured HIP graph", "rows_per_gpu": rows, "layers": layers,
                        "launches_per_step": 4 * layers, "parallelism": f"rows /{world}"}
+
+
+class C4H(C4):
+    """C4 with the down_proj input as the reference's DEPLOY model builds it — OnlineTrans(had) + Quantizer in front of Linear4bit
+    (deploy/transformers/modeling_llama.py:248-253): the online Hadamard rotation of 28672 = 28 x 1024 fused with the Quantizer (the
+    structured kernel, fq_had_mfma.hip) instead of the learned 128 x 224 pair of the fake-quant model (C4)."""
+    name = "C4H"
+    down = "hadamard"
 
 
 class C5(Workload):
@@ -476,7 +493,7 @@ class C2SL(Workload):
                        "rows_per_gpu": rows, "layers": self.layers, "launches_per_step": 1, "parallelism": f"rows /{world}"}
 
 
-WORKLOADS = {"C1": C1, "C2": C2, "C2S": C2S, "C3": C3, "C4": C4, "C5": C5, "C2SL": C2SL}
+WORKLOADS = {"C1": C1, "C2": C2, "C2S": C2S, "C3": C3, "C4": C4, "C4H": C4H, "C5": C5, "C2SL": C2SL}
 
 
 class TimedBroadcast:
@@ -563,7 +580,7 @@ def sub_record(cls, steps, warmup, device, rank, world, sharding, dist, force=Fa
     wall, kern_ms, elems, per_rank = reduce_over_ranks(dist, device, wall, kern_ms, wl.elems, force)
     rec = None
     if rank == 0:
-        step_bytes = sum(k[2] for k in wl.kernels) * (wl.config.get("layers", 1) if cls is C4 else 1)
+        step_bytes = sum(k[2] for k in wl.kernels) * (wl.config.get("layers", 1) if issubclass(cls, C4) else 1)
         rec = {"workload": wl.config["workload"], "scaling": wl.scaling, "value": elems / (wall / steps) / 1e6, "unit": "Melem/s",
                "steps": steps, "warmup": warmup, "ms_per_step": wall * 1e3 / steps,
                "per_rank_ms_per_step": [w * 1e3 / steps for w in per_rank], "event_ms_per_step": kern_ms,
@@ -593,9 +610,9 @@ def main():
                          "many milliseconds (reported as settle_launches); 0 disables it")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {"C1": 500, "C2": 1000, "C2S": 1000, "C3": 100, "C4": 5, "C5": 50, "C2SL": 50}[args.config]
+        args.steps = {"C1": 500, "C2": 1000, "C2S": 1000, "C3": 100, "C4": 5, "C4H": 5, "C5": 50, "C2SL": 50}[args.config]
     if args.warmup is None:
-        args.warmup = {"C1": 100, "C2": 200, "C2S": 200, "C3": 10, "C4": 2, "C5": 5, "C2SL": 10}[args.config]
+        args.warmup = {"C1": 100, "C2": 200, "C2S": 200, "C3": 10, "C4": 2, "C4H": 2, "C5": 5, "C2SL": 10}[args.config]
     if args.dtype != "f16" and args.config not in ("C1", "C2", "C5"):
         ap.error("--dtype bf16 goes with --config C1 / C2 / C5 (C3 / C4 are the deploy configs: fp16 contracts of the reference)")
 
@@ -723,7 +740,8 @@ def main():
             out[k] = v
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(*{"C1": (20.0, 64, 64), "C2": (20.0, 64, 64), "C2S": (20.0, 64, 64), "C3": (20.0, 64, 64),
-                                                 "C4": (20.0, 64, 128), "C5": (20.0, 32, 64), "C2SL": (20.0, 64, 64)}[args.config])
+                                                 "C4": (20.0, 64, 128), "C4H": (20.0, 64, 128), "C5": (20.0, 32, 64),
+                                                 "C2SL": (20.0, 64, 64)}[args.config])
         if json_fd is None:
             print(json.dumps(out))
         else:

@@ -844,7 +844,7 @@ int fq_hadamard_quant_mfma_f16(const void* x, int64_t rows, int n, int K, const 
     if (rows == 0) return FQ_OK;
     const int rc = fq_launch_had_mfma((const f16*)x, rows, n, K, (const f16*)hadK, scale, sig_max, sig_min, (uint8_t*)q_out,
                                       (f16*)scale_out, (f16*)y_out, cu_count(), (hipStream_t)stream);
-    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "%s: n=%d K=%d (n = K * 512 with K <= 32, K %% 4 == 0)", what, n, K);
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "%s: n=%d K=%d (n = K * 512 or K * 1024 with K <= 32, K %% 4 == 0)", what, n, K);
     return check_launch(rc, what);
 }
 

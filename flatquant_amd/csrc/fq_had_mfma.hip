@@ -1,4 +1,4 @@
-// fq_had_mfma.hip — the online Hadamard rotation of n = K * 512 (K <= 32, K % 4 == 0: 14336 = 28 * 512, Llama-3-8B's ffn width)
+// fq_had_mfma.hip — the online Hadamard rotation of n = K * 512 / K * 1024 (K <= 32, K % 4 == 0: 14336 = 28 * 512, Llama-3-8B's ffn width)
 // fused with the deploy Quantizer, with the STRUCTURE of the rotation used instead of two dense Kronecker factors (round 4).
 //   y = hadK [K,K] @ FWHT_512( x.view(rows, K, 512) ) / sqrt(n)            hadamard_utils.py:132-141, deploy/functional/online_trans.py:144-151
 //   -> deploy.nn.Quantizer (deploy/nn/quantization.py:13-36), packed INT4 + fp16 scale per token
@@ -20,6 +20,10 @@
 // hadK from the caller's [K, K] table): no fragment image, no L image in LDS, no workspace.
 // Structure otherwise as fq_kron_trio.hip: one persistent 12-wave workgroup per CU, three token groups of four waves (wave w owns the
 // output columns of block b' = w), LDS-DMA staging, meetings on LDS counters, token claims one ahead.
+// n = K * 1024 (28672 = 28 * 1024, Llama-2-70B's ffn width; late round 4): the same kernel with EIGHT row tiles per token (template NA = 8):
+// token x[k, a, b, c] with a in 0..7 (memory row 8 k + a), H_1024 = H_8 (x) H_4 (x) H_32 — the a-butterfly is three stages over eight
+// accumulator tiles, GEMM 1's factor is H_32 / 32, 32 MFMAs per wave and token where the dense 112 x 256 pair needs 128; a token is
+// 56 KB, so a CU holds TWO token groups (eight waves, 192 VGPRs).
 // Rounding points differ from the FWHT route (fq_hadamard_reg.hip) and from the dense Kronecker route: parity is the reference's own
 // tolerance class for this op (tests/test_gpu_hadamard.py: 2e-3 of the row maximum against matmul_hadU's fixtures), not bit identity;
 // ops.hadamard_quant(fwht_route=True) keeps the bit-identical route.
@@ -38,9 +42,18 @@ typedef __attribute__((address_space(3))) void hm_lds_void;
 #ifndef HM_NGROUPS
 #define HM_NGROUPS 3   // token groups per CU (4: sixteen waves, needs <= 128 VGPRs)
 #endif
-constexpr int HM_GROUPS = HM_NGROUPS, HM_WPG = 4, HM_THREADS = HM_GROUPS * HM_WPG * 64;
-constexpr int HM_TOKBUF = 128 * 256;   // bytes: 128 rows (4 tiles of 32; rows >= 4 K stay zero) of 128 fp16
-constexpr int HM_LDS = HM_GROUPS * HM_TOKBUF + HM_GROUPS * 32 + 64;   // + [max x4][min x4] per group + control words
+// Geometry. NA = row tiles of a token = size of the a-butterfly: 4 for n = K * 512 (H_512 = H_4 (x) H_4 (x) H_32), 8 for n = K * 1024
+// (H_1024 = H_8 (x) H_4 (x) H_32: 28672 = 28 * 1024, the ffn width of Llama-2-70B — a 56 KB token, TWO token groups per CU).
+template <int NA, int GROUPS>
+struct HmGeo {
+    static constexpr int WPG = 4, THREADS = GROUPS * WPG * 64;
+    static constexpr int ROWS = NA * 32;                          // LDS rows of a token buffer (rows >= NA * K stay zero)
+    static constexpr int TOKBUF = ROWS * 256;                     // bytes: rows of 128 fp16
+    static constexpr int LDS = GROUPS * TOKBUF + GROUPS * 32 + 64;   // + [max x4][min x4] per group + control words
+    static constexpr int KEY_SHIFT = NA == 8 ? 1 : 0;             // DMA instruction i fills rows 4 i .. 4 i + 3: swizzle key row / NA = i >> KEY_SHIFT
+    static_assert(NA == 4 || NA == 8, "row tiles");
+    static_assert(LDS <= 160 * 1024, "LDS");
+};
 
 __device__ __forceinline__ unsigned hm_lds_read(unsigned addr) {
     unsigned v;
@@ -87,12 +100,14 @@ __device__ __forceinline__ f32x2 hm_pk_sub32(f32x2 a, f32x2 b) {
 }
 
 // QUANT: packed INT4 + scale (the Quantizer); YOUT: the rotated activation itself, fp16 (matmul_hadU_cuda's result)
-template <bool QUANT, bool YOUT>
-__global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __restrict__ x, const f16* __restrict__ hadK, int K, int64_t rows,
+template <int NA, int GROUPS, bool QUANT, bool YOUT>
+__global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __restrict__ x, const f16* __restrict__ hadK, int K, int64_t rows,
                                                              int64_t tpb, float post_scale, float sig_max, float sig_min,
                                                              uint8_t* __restrict__ q_out, f16* __restrict__ scale_out,
                                                              f16* __restrict__ y_out) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[HM_LDS];
+    typedef HmGeo<NA, GROUPS> G;
+    constexpr int HM_GROUPS = GROUPS, HM_TOKBUF = G::TOKBUF;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wq = wave & 3;   // token group; this wave's column block b' (output columns 32 wq .. 32 wq + 31)
@@ -101,9 +116,9 @@ __global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __rest
     unsigned* ctl = reinterpret_cast<unsigned*>(smem + HM_GROUPS * HM_TOKBUF + HM_GROUPS * 32);   // [meet x G][next][claim x G]
     const unsigned ctl_lds = (unsigned)(size_t)(hm_lds_void*)ctl, meet = ctl_lds + grp * 4;
     const unsigned tok_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(hm_lds_void*)tokbuf);
-    const int M = 4 * K;                       // token rows of 256 bytes
+    const int M = NA * K;                      // token rows of 256 bytes
     const int64_t tok_bytes = (int64_t)M * 256;
-    const int n_dma = K;                       // 1 KB instructions per token: instruction i = rows 4 i .. 4 i + 3 = (k = i, a = 0..3)
+    const int n_dma = M >> 2;                  // 1 KB instructions per token: instruction i = rows 4 i .. 4 i + 3 (NA = 4: k = i, a = 0..3)
     const int per = (n_dma + 3) >> 2, d0 = wq * per;
     const int dn = n_dma - d0 < per ? (n_dma - d0 < 0 ? 0 : n_dma - d0) : per;
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(x);
@@ -114,7 +129,7 @@ __global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __rest
     // ---- once per workgroup: control words, the zero rows below the token ----
     if (tid < 16) ctl[tid] = tid == HM_GROUPS ? HM_GROUPS : 0;   // meeting counters, the next unclaimed token, (published claims)
     constexpr unsigned NEXT = HM_GROUPS * 4, CLAIM = HM_GROUPS * 4 + 4;   // byte offsets inside ctl
-    for (int i = M * 16 + (tid & 255); i < 128 * 16; i += 256) reinterpret_cast<uint4*>(tokbuf)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = M * 16 + (tid & 255); i < G::ROWS * 16; i += 256) reinterpret_cast<uint4*>(tokbuf)[i] = make_uint4(0, 0, 0, 0);
 
     // ---- once per wave: the two B operands, in registers for the whole launch ----
     // GEMM 1: B1[s] lane (h, c) element j = H_32[cc = 16 s + 8 h + j][pi(c)] / 16. pi puts the 16 registers of an output lane on 16
@@ -130,7 +145,9 @@ __global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __rest
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int cc = 16 * s + 8 * h + j;
-                B1[s][j] = (__builtin_popcount(cc & pic) & 1) ? (f16)-0.0625f : (f16)0.0625f;
+                // (+-1 / 16 for H_512, +-1 / 32 for H_1024: the fp16 intermediate keeps the same headroom, 32 |x|max at most)
+                const f16 b1 = NA == 8 ? (f16)0.03125f : (f16)0.0625f;
+                B1[s][j] = (__builtin_popcount(cc & pic) & 1) ? -b1 : b1;
                 const int kk = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
                 B2[s][j] = (kk < K && c < K) ? hadK[c * K + kk] : (f16)0.0f;
             }
@@ -140,8 +157,8 @@ __global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __rest
     for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(B1[s]), "+v"(B2[s]));
 
     // This wave's share of token k's DMA: instructions [d0, d0 + dn). Instruction i fills the LDS rows 4 i .. 4 i + 3 linearly; lane l
-    // (row 4 i + l / 16, position l % 16) fetches the chunk that the swizzle maps there: position ^ (row >> 2 & 15) = l % 16 ^ (i & 15)
-    // — keyed on row >> 2 because an A fragment reads the rows 4 c + a of 32 lanes c: their positions must differ with c.
+    // (row 4 i + l / 16, position l % 16) fetches the chunk that the swizzle maps there: position ^ (row / NA & 15) = l % 16 ^ (i >> KEY_SHIFT & 15)
+    // — keyed on row / NA because an A fragment reads the rows NA c + a of 32 lanes c: their positions must differ with c.
     auto stage_token = [&](int k) {
         const unsigned char* src = xb + (blk_base + k) * tok_bytes;
         const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)src);
@@ -152,7 +169,7 @@ __global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __rest
         const int lb = ln & 48, lp = ln & 15;
         for (int j = 0; j < dn; ++j) {
             const int i = d0 + j;   // wave-uniform
-            const unsigned rv = (unsigned)((lb + (lp ^ (i & 15))) << 4);
+            const unsigned rv = (unsigned)((lb + (lp ^ ((i >> G::KEY_SHIFT) & 15))) << 4);
             unsigned keep;
             asm volatile(
                 "s_nop 4\n\t"
@@ -177,18 +194,18 @@ __global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __rest
         if (HM_PRIO_MFMA) __builtin_amdgcn_s_setprio(HM_PRIO_MFMA);
 
         // ===== phase A: b-butterfly on the A fragments, GEMM 1 (contraction over c, K = 32), a-butterfly, fp16 rounding =====
-        f16x8 Uh[4][2];
+        f16x8 Uh[NA][2];
         {
             int cl = c, hl = h;
             asm volatile("" : "+v"(cl), "+v"(hl));   // (address arithmetic stays inside the loop)
-            const uint4* tb = reinterpret_cast<const uint4*>(tokbuf) + cl * 64;   // row 4 c (+ a): 16 chunks per row
+            const uint4* tb = reinterpret_cast<const uint4*>(tokbuf) + cl * (NA * 16);   // row NA c (+ a): 16 chunks per row
             const int sw = cl & 15;
             const uint32_t sg1 = (wq & 1) ? 0xBC00BC00u : 0x3C003C00u, sg2 = (wq & 2) ? 0xBC00BC00u : 0x3C003C00u;   // packed (+-1.0h, +-1.0h)
-            f32x16 U[4];
+            f32x16 U[NA];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) U[a] = f32x16{0};
+            for (int a = 0; a < NA; ++a) U[a] = f32x16{0};
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
+            for (int a = 0; a < NA; ++a) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     // the four column blocks of (row tile a, K-step s): chunk 4 b + 2 s + h of row 4 c + a
@@ -209,19 +226,27 @@ __global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __rest
                 }
             }
             if (!(HM_ABL & 64)) {
-                // a-butterfly: U''[a'] = sum_a H_4[a][a'] U[a], element-wise across the four accumulator tiles (64 v_pk_add_f32)
+                // a-butterfly: U''[a'] = sum_a H_NA[a][a'] U[a], element-wise across the accumulator tiles, in place: log2(NA) stages of
+                // NA / 2 packed add / subtract pairs per register pair (NA = 4: 64 v_pk_add_f32, NA = 8: 192)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const f32x2 u0 = {U[0][2 * j], U[0][2 * j + 1]}, u1 = {U[1][2 * j], U[1][2 * j + 1]};
-                    const f32x2 u2 = {U[2][2 * j], U[2][2 * j + 1]}, u3 = {U[3][2 * j], U[3][2 * j + 1]};
-                    const f32x2 s0 = hm_pk_add32(u0, u1), s1 = hm_pk_sub32(u0, u1), s2 = hm_pk_add32(u2, u3), s3 = hm_pk_sub32(u2, u3);
-                    const f32x2 o0 = hm_pk_add32(s0, s2), o1 = hm_pk_add32(s1, s3), o2 = hm_pk_sub32(s0, s2), o3 = hm_pk_sub32(s1, s3);
-                    U[0][2 * j] = o0.x, U[0][2 * j + 1] = o0.y, U[1][2 * j] = o1.x, U[1][2 * j + 1] = o1.y;
-                    U[2][2 * j] = o2.x, U[2][2 * j + 1] = o2.y, U[3][2 * j] = o3.x, U[3][2 * j + 1] = o3.y;
+                    f32x2 u[NA];
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) u[a] = f32x2{U[a][2 * j], U[a][2 * j + 1]};
+#pragma unroll
+                    for (int len = 1; len < NA; len <<= 1)
+#pragma unroll
+                        for (int a = 0; a < NA; ++a)
+                            if (!(a & len)) {
+                                const f32x2 p = hm_pk_add32(u[a], u[a + len]), q = hm_pk_sub32(u[a], u[a + len]);
+                                u[a] = p, u[a + len] = q;
+                            }
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) U[a][2 * j] = u[a].x, U[a][2 * j + 1] = u[a].y;
                 }
             }
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -234,22 +259,22 @@ __global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __rest
         const int knext = __builtin_amdgcn_readfirstlane((int)hm_lds_read(ctl_lds + CLAIM + grp * 4));
         const bool more = !(HM_ABL & 16) && knext < blk_cnt && dn > 0;
         if (more) stage_token(knext);
-        f32x16 Y[4];   // Y^T of (column block wq, row tile a'): register r of lane (h, c) = column 32 wq + 16 h + r of row (a', k' = c)
+        f32x16 Y[NA];   // Y^T of (column block wq, row tile a'): register r of lane (h, c) = column 32 wq + 16 h + r of row (a', k' = c)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
+        for (int a = 0; a < NA; ++a) {
             Y[a] = f32x16{0};
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 if (!(HM_ABL & 4)) Y[a] = fq_mfma32<f16>(Uh[a][s], B2[s], Y[a]);
         }
         if (HM_PRIO_MFMA) __builtin_amdgcn_s_setprio(0);
-        uint32_t H[4][8];   // the fp16 pairs the deploy Quantizer sees (and the transform output)
+        uint32_t H[NA][8];   // the fp16 pairs the deploy Quantizer sees (and the transform output)
         float vmax = 0.0f, vmin = 0.0f;
         {
             f16x2 pmax = {(f16)-INFINITY, (f16)-INFINITY}, pmin = {(f16)INFINITY, (f16)INFINITY};
             const f32x2 ps2 = {post_scale, post_scale};
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const f16x2 pr = fq_mul_to_f16x2(Y[a][2 * j], Y[a][2 * j + 1], ps2);   // fp32 product, then fp16: two roundings, as the other routes
@@ -271,7 +296,7 @@ __global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __rest
         }
 
         // ===== phase C: the token's extrema, scale, quantiser, pack, stores =====
-        uint2 pk[4];
+        uint2 pk[NA];
         float scale = 1.0f;
         if (QUANT) {
             HM_MEET()   // B|C: the four partial extrema are in LDS
@@ -285,7 +310,7 @@ __global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __rest
             const bool clampq = fq_h16_needs_clamp(vmax, vmin, inv);
             const FqH16Recip rc = fq_h16_recip(scale);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
+            for (int a = 0; a < NA; ++a) {
                 if (HM_ABL & 1) pk[a] = uint2{H[a][0], H[a][4]};
                 else if (clampq) {
                     pk[a].x = fq_quant8_h16<true>(H[a][0], H[a][1], H[a][2], H[a][3], rc);
@@ -301,22 +326,22 @@ __global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __rest
         if (!(HM_ABL & 8)) {
             int lq = lane;
             asm volatile("" : "+v"(lq));
-            // row (a', k' = c) is memory row 4 c + a'; this lane: columns 32 wq + 16 h .. + 15 of it
+            // row (a', k' = c) is memory row NA c + a'; this lane: columns 32 wq + 16 h .. + 15 of it
             if (QUANT) {
                 uint8_t* qtok = q_out + tok * ((int64_t)M * 64) + wq * 16;   // 64 packed bytes per row
-                const unsigned lane_off = (unsigned)((lq & 31) * 256 + (lq >> 5) * 8);
+                const unsigned lane_off = (unsigned)((lq & 31) * (NA * 64) + (lq >> 5) * 8);
                 if ((lq & 31) < K) {
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) *reinterpret_cast<uint2*>(qtok + (lane_off + a * 64)) = pk[a];
+                    for (int a = 0; a < NA; ++a) *reinterpret_cast<uint2*>(qtok + (lane_off + a * 64)) = pk[a];
                 }
                 if (wq == 0 && lane == 0) scale_out[tok] = (f16)scale;
             }
             if (YOUT) {
                 unsigned char* ytok = reinterpret_cast<unsigned char*>(y_out) + tok * tok_bytes + wq * 64;   // 256 bytes per row
-                const unsigned lane_off = (unsigned)((lq & 31) * 1024 + (lq >> 5) * 32);
+                const unsigned lane_off = (unsigned)((lq & 31) * (NA * 256) + (lq >> 5) * 32);
                 if ((lq & 31) < K) {
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
+                    for (int a = 0; a < NA; ++a) {
                         *reinterpret_cast<u32x4*>(ytok + (lane_off + a * 256)) = u32x4{H[a][0], H[a][1], H[a][2], H[a][3]};
                         *reinterpret_cast<u32x4*>(ytok + (lane_off + a * 256 + 16)) = u32x4{H[a][4], H[a][5], H[a][6], H[a][7]};
                     }
@@ -327,29 +352,36 @@ __global__ __launch_bounds__(HM_THREADS) void fq_had512_kernel(const f16* __rest
     }
 }
 
-}  // namespace
-
-// Returns -1000 when the shape is not one this kernel covers (n = K * 512 with K <= 32, K % 4 == 0, hadK given).
+// Returns -1000 when the shape is not one this kernel covers (n = K * 512 or n = K * 1024 with K <= 32, K % 4 == 0, hadK given).
 // q_out / scale_out may be NULL (rotation only), y_out may be NULL (Quantizer output only). In place (y_out == x) is allowed: a token
 // has landed in LDS completely (vmcnt(0) + the group's first meeting) before any of its rows is stored, and tokens do not overlap.
-int fq_launch_had_mfma(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max, float sig_min,
-                       uint8_t* q_out, f16* scale_out, f16* y_out, int n_cu, hipStream_t stream) {
-    if (K <= 1 || K > 32 || (K & 3) || hadK == nullptr || n != K * 512) return -1000;
-    if (!q_out && !y_out) return -1000;
-    int64_t blocks = (rows + HM_GROUPS - 1) / HM_GROUPS;
+template <int NA, int GROUPS>
+static int hm_launch(const f16* x, int64_t rows, int K, const f16* hadK, float ps, float sig_max, float sig_min, uint8_t* q_out,
+                     f16* scale_out, f16* y_out, int n_cu, hipStream_t stream) {
+    int64_t blocks = (rows + GROUPS - 1) / GROUPS;
     if (blocks > n_cu) blocks = n_cu;   // one persistent workgroup per CU
     if (blocks < 1) blocks = 1;
     const int64_t tpb = (rows + blocks - 1) / blocks;
-    // the +-1 / 16 right factor is undone here: y = (1 / sqrt(n)) H x = scale * 16 * (H / 16) x
-    const float ps = scale * 16.0f;
+    constexpr int T = HmGeo<NA, GROUPS>::THREADS;
     if (q_out && y_out)
-        hipLaunchKernelGGL((fq_had512_kernel<true, true>), dim3((unsigned)blocks), dim3(HM_THREADS), 0, stream, x, hadK, K, rows, tpb, ps,
+        hipLaunchKernelGGL((fq_had512_kernel<NA, GROUPS, true, true>), dim3((unsigned)blocks), dim3(T), 0, stream, x, hadK, K, rows, tpb, ps,
                            sig_max, sig_min, q_out, scale_out, y_out);
     else if (q_out)
-        hipLaunchKernelGGL((fq_had512_kernel<true, false>), dim3((unsigned)blocks), dim3(HM_THREADS), 0, stream, x, hadK, K, rows, tpb, ps,
+        hipLaunchKernelGGL((fq_had512_kernel<NA, GROUPS, true, false>), dim3((unsigned)blocks), dim3(T), 0, stream, x, hadK, K, rows, tpb, ps,
                            sig_max, sig_min, q_out, scale_out, y_out);
     else
-        hipLaunchKernelGGL((fq_had512_kernel<false, true>), dim3((unsigned)blocks), dim3(HM_THREADS), 0, stream, x, hadK, K, rows, tpb, ps,
+        hipLaunchKernelGGL((fq_had512_kernel<NA, GROUPS, false, true>), dim3((unsigned)blocks), dim3(T), 0, stream, x, hadK, K, rows, tpb, ps,
                            sig_max, sig_min, q_out, scale_out, y_out);
     return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int fq_launch_had_mfma(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max, float sig_min,
+                       uint8_t* q_out, f16* scale_out, f16* y_out, int n_cu, hipStream_t stream) {
+    if (K <= 1 || K > 32 || (K & 3) || hadK == nullptr || (n != K * 512 && n != K * 1024)) return -1000;
+    if (!q_out && !y_out) return -1000;
+    // the +-1 / 16 (+-1 / 32) right factor is undone here: y = (1 / sqrt(n)) H x = scale * 16 * (H / 16) x
+    if (n == K * 512) return hm_launch<4, HM_NGROUPS>(x, rows, K, hadK, scale * 16.0f, sig_max, sig_min, q_out, scale_out, y_out, n_cu, stream);
+    return hm_launch<8, 2>(x, rows, K, hadK, scale * 32.0f, sig_max, sig_min, q_out, scale_out, y_out, n_cu, stream);
 }

@@ -869,18 +869,19 @@ def fakequant_bits(x: torch.Tensor, sig: Sig, bits: int, flags: int = 0) -> torc
 
 
 def had_mfma_supported(n: int, K: int) -> bool:
-    """Shapes of the structured matrix-pipe rotation (fq_had_mfma.hip): n = K * 512, K <= 32, K % 4 == 0 (14336 = 28 * 512)."""
-    return 4 <= K <= 32 and K % 4 == 0 and n == K * 512
+    """Shapes of the structured matrix-pipe rotation (fq_had_mfma.hip): n = K * 512 or K * 1024, K <= 32, K % 4 == 0
+    (14336 = 28 * 512: Llama-3-8B ffn; 28672 = 28 * 1024: Llama-2-70B ffn)."""
+    return 4 <= K <= 32 and K % 4 == 0 and n in (K * 512, K * 1024)
 
 
 def hadamard_mfma(x: torch.Tensor, K: int, hadK: torch.Tensor, sig: Optional[Sig] = None, scale: Optional[float] = None,
                   want_y: bool = True):
-    """fq_hadamard_quant_mfma_f16: the rotation of n = K * 512 with its structure on the matrix pipe. -> (y or None, q or None,
+    """fq_hadamard_quant_mfma_f16: the rotation of n = K * 512 / K * 1024 with its structure on the matrix pipe. -> (y or None, q or None,
     scales or None); ``sig`` given: the deploy Quantizer's packed output as hadamard_quant; ``want_y``: the rotated activation."""
     _chk(x, "x"), _chk(hadK, "hadK")
     n = x.shape[-1]
     if hadK.shape != (K, K) or not had_mfma_supported(n, K):
-        raise ValueError("hadamard_mfma: n = K * 512 with K <= 32, K % 4 == 0 and hadK [K, K]")
+        raise ValueError("hadamard_mfma: n = K * 512 or K * 1024 with K <= 32, K % 4 == 0 and hadK [K, K]")
     if sig is None and not want_y:
         raise ValueError("hadamard_mfma: no output requested")
     if scale is None:
@@ -901,7 +902,7 @@ def hadamard(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None,
              scale: Optional[float] = None, fwht_route: bool = False) -> torch.Tensor:
     """hadK @ FWHT(x.view(rows, K, n/K)) * scale. Routes: the register FWHT + K-factor kernel (fq_hadamard_f16; bit-exact for K = 1,
     the route of every K = 1 call); for K > 1 a matrix-pipe launch where one exists — the rotation as a dense Kronecker pair with the
-    transform as its only output (11008 = 172 x 64, 8960, 5120), or the structured kernel (n = K * 512: 14336). The
+    transform as its only output (11008 = 172 x 64, 8960, 5120), or the structured kernel (n = K * 512 / K * 1024: 14336, 28672). The
     matrix-pipe routes round the intermediate to fp16 at other points: within 1e-3 of the row maximum of the exact rotation, not
     bit-identical to the first route. ``fwht_route=True`` forces the first."""
     if K > 1 and hadK is not None and not fwht_route and x.numel() > 0 and x.shape[-1] % K == 0 and hadK.shape == (K, K):
@@ -968,9 +969,10 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
     [rows]); the Quantizer's arithmetic is deploy/nn/quantization.py:15-29. Two routes:
       * the register FWHT + K-factor kernel — bit-identical to rowquant(hadamard(x), [sig], FQ_OUT_PACKED | FQ_QUANT_F16 |
         FQ_SIG_F16); shapes the fused kernels do not cover take exactly that two-launch sequence;
-      * n = K * 512 with K <= 32 (14336 = 28 * 512; round 4): the structured matrix-pipe kernel (hadamard_mfma) — H_512 as two
-        register butterflies and two K = 32 contractions, 16 MFMAs per wave and token instead of the 60 of the dense pair below;
-      * n = 28672 (K = 28), 11008 (K = 172), 14336 with ``up``, and every other n = K 2^p whose rotation is a factor pair with a
+      * n = K * 512 or K * 1024 with K <= 32 (14336 = 28 * 512, 28672 = 28 * 1024; round 4): the structured matrix-pipe kernel
+        (hadamard_mfma) — H_512 / H_1024 as two register butterflies and two K = 32 contractions, 16 / 32 MFMAs per wave and token
+        instead of the 60 / 128 of the dense pair below;
+      * n = 11008 (K = 172), 14336 / 28672 with ``up``, and every other n = K 2^p whose rotation is a factor pair with a
         packed-only kernel of its own (_hadamard_as_kron): the rotation runs as ONE Kronecker launch (112 x 128 / 112 x 256 /
         172 x 64, kron_quant_ex), 1.5-2x faster. It rounds the intermediate to fp16 at a different point: the rotated values agree with
         the FWHT route within 2e-3 of the row maximum (the reference's own tolerance class, tests/test_gpu_hadamard.py), so
@@ -997,9 +999,10 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
         scale = float(1.0 / torch.tensor(n).sqrt())
     rows = x.numel() // n
     if route == "mfma" and (up is not None or not had_mfma_supported(n, K)):
-        raise _lib.FqError(FQ_EUNSUPPORTED, "hadamard_quant(route='mfma'): n = K * 512 with K <= 32, K % 4 == 0, no up=")
+        raise _lib.FqError(FQ_EUNSUPPORTED, "hadamard_quant(route='mfma'): n = K * 512 or K * 1024 with K <= 32, K % 4 == 0, no up=")
     if not fwht_route and route != "kron" and up is None and rows > 0 and had_mfma_supported(n, K):
-        # the structured route (fq_had_mfma.hip): H_512 = H_4 (x) H_4 (x) H_32 as two register butterflies + two K = 32 contractions
+        # the structured route (fq_had_mfma.hip): H_512 = H_4 (x) H_4 (x) H_32 (H_1024 = H_8 (x) H_4 (x) H_32) as two register butterflies +
+        # two K = 32 contractions
         _, q, s = hadamard_mfma(x, K, hadK, sig, scale, want_y=False)
         return q, s
     kr = _hadamard_as_kron(K, n // K, hadK, x.device) if (n % K == 0 and not fwht_route) else None

@@ -1,4 +1,4 @@
-"""GPU parity for the structured matrix-pipe Hadamard rotation (fq_had_mfma.hip, round 4): n = K * 512, K <= 32.
+"""GPU parity for the structured matrix-pipe Hadamard rotation (fq_had_mfma.hip, round 4): n = K * 512 or K * 1024, K <= 32.
 Oracle: matmul_hadU / matmul_hadU_cuda (hadamard_utils.py:89-110,132-141) restated in oracle/fq_oracle.py and pinned by the
 reference-written fixtures tests/golden/had_A.npz; the deploy Quantizer (deploy/nn/quantization.py:13-36) as O.rowquant."""
 import numpy as np
@@ -10,7 +10,7 @@ from tests.conftest import hadk_matrix
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(14336, 28), (6144, 12), (10240, 20)]
+SHAPES = [(14336, 28), (6144, 12), (10240, 20), (28672, 28), (12288, 12), (20480, 20)]   # K * 512 and K * 1024
 
 
 @pytest.fixture(scope="module")
@@ -20,7 +20,7 @@ def ops():
 
 
 def exact_rotation(x16, K):
-    """The rotation in float64: hadK @ H_512 over x.view(rows, K, 512), / sqrt(n) — no rounding anywhere."""
+    """The rotation in float64: hadK @ H_P over x.view(rows, K, P), P = n / K, / sqrt(n) — no rounding anywhere."""
     rows, n = x16.shape
     P = n // K
     h = np.ones((1, 1))
@@ -98,22 +98,23 @@ def test_agrees_with_the_fwht_route_to_rounding_noise(ops, n, K):
     assert float(((y.float() - yf.float()).abs() / den).max()) <= 1e-3
 
 
-def test_reference_fixture_14336(ops, golden):
+@pytest.mark.parametrize("n", [14336, 28672])
+def test_reference_fixture(ops, golden, n):
     """matmul_hadU's own output on the reference's fixture (tests/golden/had_A.npz, written by tools/gen_golden.py)."""
     g = golden("had_A")
-    x = torch.from_numpy(g["x_14336"]).cuda()
+    x = torch.from_numpy(g[f"x_{n}"]).cuda()
     hk = torch.from_numpy(hadk_matrix(28)).cuda()
     y = ops.hadamard_mfma(x, 28, hk)[0].cpu().numpy()
-    y64 = g["y64_14336"]
+    y64 = g[f"y64_{n}"]
     den = np.abs(y64).max(axis=1, keepdims=True)
     assert np.max(np.abs(y.astype(np.float64) - y64) / den) <= 1e-3
 
 
-def test_in_place_partition_and_repeatability(ops):
+@pytest.mark.parametrize("n,rows", [(14336, 4099), (28672, 2051)])
+def test_in_place_partition_and_repeatability(ops, n, rows):
     """y_out == x is allowed; any split of the rows over launches returns the same bytes (rows are independent); 20 repeated
     full-size launches are bit-identical (the token claims and meetings are timing-dependent, the results must not be)."""
-    n, K = 14336, 28
-    rows = 4099
+    K = 28
     x = make_x(rows, n, 5, outliers=False).cuda()
     hk = torch.from_numpy(hadk_matrix(K)).cuda()
     sig = (0.83, 0.64)
@@ -121,7 +122,7 @@ def test_in_place_partition_and_repeatability(ops):
     for _ in range(20):
         y2, q2, s2 = ops.hadamard_mfma(x, K, hk, sig)
         assert torch.equal(y2, y) and torch.equal(q2, q) and torch.equal(s2, s)
-    parts = [ops.hadamard_mfma(x[a:b].contiguous(), K, hk, sig) for a, b in [(0, 1), (1, 770), (770, 4099)]]
+    parts = [ops.hadamard_mfma(x[a:b].contiguous(), K, hk, sig) for a, b in [(0, 1), (1, 770), (770, rows)]]
     assert torch.equal(torch.cat([p[0] for p in parts]), y) and torch.equal(torch.cat([p[1] for p in parts]), q)
     z = x.clone()
     from flatquant_amd._lib import check, lib
@@ -135,11 +136,11 @@ def test_in_place_partition_and_repeatability(ops):
 def test_unsupported_shapes_are_refused(ops):
     from flatquant_amd import _lib
     hk = torch.from_numpy(hadk_matrix(28)).cuda()
-    x = torch.zeros(4, 28672, dtype=torch.float16, device="cuda")
-    q = torch.empty(4, 14336, dtype=torch.uint8, device="cuda")
+    x = torch.zeros(4, 57344, dtype=torch.float16, device="cuda")      # 28 * 2048: neither K * 512 nor K * 1024
+    q = torch.empty(4, 28672, dtype=torch.uint8, device="cuda")
     s = torch.empty(4, dtype=torch.float16, device="cuda")
     import ctypes
-    rc = _lib.lib.fq_hadamard_quant_mfma_f16(x.data_ptr(), 4, 28672, 28, hk.data_ptr(), ctypes.c_float(1.0), ctypes.c_float(1.0),
+    rc = _lib.lib.fq_hadamard_quant_mfma_f16(x.data_ptr(), 4, 57344, 28, hk.data_ptr(), ctypes.c_float(1.0), ctypes.c_float(1.0),
                                             ctypes.c_float(1.0), q.data_ptr(), s.data_ptr(), None, None)
     assert rc == _lib.FQ_EUNSUPPORTED
     rc = _lib.lib.fq_hadamard_quant_mfma_f16(x.data_ptr(), 4, 14336, 28, hk.data_ptr(), ctypes.c_float(1.0), ctypes.c_float(1.0),
