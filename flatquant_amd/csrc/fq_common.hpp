@@ -445,6 +445,17 @@ __device__ __forceinline__ f16x2 fq_pk_min(f16x2 a, f16x2 b) {
     return d;
 }
 #endif
+// three-operand forms (gfx950: v_pk_maximum3_f16 / v_pk_minimum3_f16 — IEEE maximum / minimum: as the two-operand max / min on data without NaNs)
+__device__ __forceinline__ f16x2 fq_pk_max3(f16x2 a, f16x2 b, f16x2 c) {
+    f16x2 d;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f16x2 fq_pk_min3(f16x2 a, f16x2 b, f16x2 c) {
+    f16x2 d;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 
 // Running extrema of 16-byte chunks of an activation row (row quantisers; the group-128 epilogue of the Kronecker kernels).
 template <typename T> struct RowExtrema;
@@ -826,12 +837,23 @@ __device__ __forceinline__ uint32_t fq_quant8_h16(uint32_t xa, uint32_t xb, uint
     const float rhi = rc.hi, rlo = rc.lo;
     const uint32_t magic2 = 0x66006600u;   // (1536.0h, 1536.0h)
     const uint32_t sel = 0x06040200u;      // bytes 0 and 2 of the second source, then of the first
+#ifndef FQ_H16_MIXLO
+#define FQ_H16_MIXLO 0   // measurement: the second fma and the conversion as ONE v_fma_mixlo_f16 / v_fma_mixhi_f16 (4 VALU per pair instead of 5)
+#endif
+#if FQ_H16_MIXLO
+#define FQ_H16_PAIR(h, x)                                                                       \
+    "v_fma_mix_f32 %[l0], %[" #x "], %[rlo], 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"            \
+    "v_fma_mix_f32 %[l1], %[" #x "], %[rlo], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"            \
+    "v_fma_mixlo_f16 %[" #h "], %[" #x "], %[rhi], %[l0] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"  \
+    "v_fma_mixhi_f16 %[" #h "], %[" #x "], %[rhi], %[l1] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+#else
 #define FQ_H16_PAIR(h, x)                                                                       \
     "v_fma_mix_f32 %[l0], %[" #x "], %[rlo], 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"            \
     "v_fma_mix_f32 %[l1], %[" #x "], %[rlo], 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"            \
     "v_fma_mix_f32 %[t0], %[" #x "], %[rhi], %[l0] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"        \
     "v_fma_mix_f32 %[t1], %[" #x "], %[rhi], %[l1] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"        \
     "v_cvt_pk_f16_f32 %[" #h "], %[t0], %[t1]\n\t"
+#endif
     asm(FQ_H16_PAIR(ha, xa) FQ_H16_PAIR(hb, xb) FQ_H16_PAIR(hc, xc) FQ_H16_PAIR(hd, xd)
         : [ha] "=&v"(ha), [hb] "=&v"(hb), [hc] "=&v"(hc), [hd] "=&v"(hd), [t0] "=&v"(t0), [t1] "=&v"(t1), [l0] "=&v"(l0),
           [l1] "=&v"(l1)

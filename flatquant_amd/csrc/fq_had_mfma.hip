@@ -29,7 +29,8 @@
 // ops.hadamard_quant(fwht_route=True) keeps the bit-identical route.
 #include "fq_common.hpp"
 #ifndef HM_PRIO_MFMA
-#define HM_PRIO_MFMA 0   // s_setprio level of a wave inside phases A / B (see fq_kron_duo.hip); measured, see profiles/r04_duo_trio_timing.txt
+#define HM_PRIO_MFMA 2   // s_setprio level of a wave inside phases A / B (see fq_kron_duo.hip). 0 until the K * 1024 build: the rotation-only launches
+                         // gain (28672: 220 -> 207 us, 14336: 212 -> 209), the fused Quantizer launches are even (profiles/r04_hadamard_1024.txt)
 #endif
 
 namespace {
@@ -38,6 +39,12 @@ typedef __attribute__((address_space(3))) void hm_lds_void;
 
 #ifndef HM_ABL
 #define HM_ABL 0   // measurement builds: 1 no quantiser, 2 no GEMM 1, 4 no GEMM 2, 8 no stores, 16 no DMA after the first, 32 no b-butterfly, 64 no a-butterfly
+#endif
+#ifndef HM_MAX3
+#define HM_MAX3 1   // extrema of the rotated token with v_pk_maximum3_f16 / v_pk_minimum3_f16 (two pairs per instruction)
+#endif
+#ifndef HM_QSTAGE
+#define HM_QSTAGE 1   // packed output staged through LDS and written as 1 KB-contiguous 16-byte stores (0: 8-byte stores straight from the registers)
 #endif
 #ifndef HM_NGROUPS
 #define HM_NGROUPS 3   // token groups per CU (4: sixteen waves, needs <= 128 VGPRs)
@@ -50,9 +57,12 @@ struct HmGeo {
     static constexpr int ROWS = NA * 32;                          // LDS rows of a token buffer (rows >= NA * K stay zero)
     static constexpr int TOKBUF = ROWS * 256;                     // bytes: rows of 128 fp16
     static constexpr int LDS = GROUPS * TOKBUF + GROUPS * 32 + 64;   // + [max x4][min x4] per group + control words
+    static constexpr int QROWS = NA == 8 ? 224 : 128;             // rows of the packed-output staging buffer (NA = 8: K <= 28, or two token groups
+                                                                  // + staging would not fit 160 KB)
+    static constexpr int QST = QROWS * 64;                        // bytes: 64 packed bytes per row
     static constexpr int KEY_SHIFT = NA == 8 ? 1 : 0;             // DMA instruction i fills rows 4 i .. 4 i + 3: swizzle key row / NA = i >> KEY_SHIFT
     static_assert(NA == 4 || NA == 8, "row tiles");
-    static_assert(LDS <= 160 * 1024, "LDS");
+    static_assert(LDS + GROUPS * QST <= 160 * 1024, "LDS");
 };
 
 __device__ __forceinline__ unsigned hm_lds_read(unsigned addr) {
@@ -107,7 +117,9 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
                                                              f16* __restrict__ y_out) {
     typedef HmGeo<NA, GROUPS> G;
     constexpr int HM_GROUPS = GROUPS, HM_TOKBUF = G::TOKBUF;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
+    constexpr bool QSTAGE = QUANT && HM_QSTAGE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS + (QSTAGE ? GROUPS * G::QST : 0)];
+    unsigned char* qst = smem + G::LDS + (threadIdx.x >> 8) * G::QST;   // the group's staging buffer (QSTAGE only)
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wq = wave & 3;   // token group; this wave's column block b' (output columns 32 wq .. 32 wq + 31)
@@ -187,10 +199,29 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
     if (grp < blk_cnt && dn > 0) stage_token(grp);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+    // QSTAGE: the packed token leaves through LDS. A lane holds 8 bytes of 16-byte pieces that lie 64 bytes apart in memory (a row's other
+    // pieces belong to the other three waves): straight from the registers a token is 4 x NA store instructions per wave of 32 separate
+    // 16-byte segments each — measured (HM_ABL builds, profiles/r04_hadamard_1024.txt) the stores cost 41 of the 130 us of a 14336 launch
+    // for 20 % of its bytes. Staged: ds_write_b64 into the group's [row][4 x 16 B] image (chunk index XOR (c & 15) inside a lane row's
+    // NA x 64-byte block: conflict-free), and AFTER the group's next meeting (the C|A meeting of the following iteration — no extra
+    // meeting) the 256 lanes of the group copy it out linearly: every store instruction writes 1 KB of contiguous bytes.
+    int64_t q_pending = -1;   // token whose packed image is waiting in the staging buffer
+    auto q_copy_out = [&](int64_t ptok) {
+        int tg = (int)(threadIdx.x & 255);
+        asm volatile("" : "+v"(tg));
+        uint8_t* qtok = q_out + ptok * ((int64_t)M * 64);
+        const int n_chunks = M * 4;
+        for (int g = tg; g < n_chunks; g += 256) {
+            const int row = g >> 2, cc = NA == 8 ? row >> 3 : row >> 2, aa = row & (NA - 1);
+            const u32x4 v = reinterpret_cast<const u32x4*>(qst)[cc * (NA * 4) + ((aa * 4 + (g & 3)) ^ (cc & 15))];
+            *reinterpret_cast<u32x4*>(qtok + (int64_t)g * 16) = v;
+        }
+    };
     unsigned meet_n = 0;
     for (int k = grp; k < blk_cnt;) {   // k: the group's current token (of this workgroup's range), claimed one token ahead
         const int64_t tok = blk_base + k;
         HM_MEET()   // C|A: every wave of the group waited for its share of the DMA before its stores
+        if (QSTAGE && q_pending >= 0 && !(HM_ABL & 8)) q_copy_out(q_pending);   // (and has written its share of the previous token's packed image)
         if (HM_PRIO_MFMA) __builtin_amdgcn_s_setprio(HM_PRIO_MFMA);
 
         // ===== phase A: b-butterfly on the A fragments, GEMM 1 (contraction over c, K = 32), a-butterfly, fp16 rounding =====
@@ -276,12 +307,19 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
 #pragma unroll
             for (int a = 0; a < NA; ++a)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < 8; j += 2) {
                     const f16x2 pr = fq_mul_to_f16x2(Y[a][2 * j], Y[a][2 * j + 1], ps2);   // fp32 product, then fp16: two roundings, as the other routes
+                    const f16x2 pr1 = fq_mul_to_f16x2(Y[a][2 * j + 2], Y[a][2 * j + 3], ps2);
                     H[a][j] = __builtin_bit_cast(uint32_t, pr);
+                    H[a][j + 1] = __builtin_bit_cast(uint32_t, pr1);
                     if (QUANT) {
-                        pmax = fq_pk_max(pmax, pr);
-                        pmin = fq_pk_min(pmin, pr);
+                        if (HM_MAX3) {   // one three-operand instruction per two pairs
+                            pmax = fq_pk_max3(pmax, pr, pr1);
+                            pmin = fq_pk_min3(pmin, pr, pr1);
+                        } else {
+                            pmax = fq_pk_max(fq_pk_max(pmax, pr), pr1);
+                            pmin = fq_pk_min(fq_pk_min(pmin, pr), pr1);
+                        }
                     }
                 }
             if (QUANT) {
@@ -327,7 +365,16 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
             int lq = lane;
             asm volatile("" : "+v"(lq));
             // row (a', k' = c) is memory row NA c + a'; this lane: columns 32 wq + 16 h .. + 15 of it
-            if (QUANT) {
+            if (QSTAGE) {
+                const int cq = lq & 31;
+                unsigned char* qs = qst + cq * (NA * 64) + (lq >> 5) * 8;
+                if (cq < K) {
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) *reinterpret_cast<uint2*>(qs + (((a * 4 + wq) ^ (cq & 15)) << 4)) = pk[a];
+                }
+                q_pending = tok;
+                if (wq == 0 && lane == 0) scale_out[tok] = (f16)scale;
+            } else if (QUANT) {
                 uint8_t* qtok = q_out + tok * ((int64_t)M * 64) + wq * 16;   // 64 packed bytes per row
                 const unsigned lane_off = (unsigned)((lq & 31) * (NA * 64) + (lq >> 5) * 8);
                 if ((lq & 31) < K) {
@@ -349,6 +396,10 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
             }
         }
         k = knext;
+    }
+    if (QSTAGE && q_pending >= 0) {   // the group's last token
+        HM_MEET()
+        if (!(HM_ABL & 8)) q_copy_out(q_pending);
     }
 }
 
@@ -383,5 +434,6 @@ int fq_launch_had_mfma(const f16* x, int64_t rows, int n, int K, const f16* hadK
     if (!q_out && !y_out) return -1000;
     // the +-1 / 16 (+-1 / 32) right factor is undone here: y = (1 / sqrt(n)) H x = scale * 16 * (H / 16) x
     if (n == K * 512) return hm_launch<4, HM_NGROUPS>(x, rows, K, hadK, scale * 16.0f, sig_max, sig_min, q_out, scale_out, y_out, n_cu, stream);
+    if (K > 28) return -1000;   // (the staging buffer of the two-group geometry holds 224 rows)
     return hm_launch<8, 2>(x, rows, K, hadK, scale * 32.0f, sig_max, sig_min, q_out, scale_out, y_out, n_cu, stream);
 }

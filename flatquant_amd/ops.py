@@ -869,9 +869,9 @@ def fakequant_bits(x: torch.Tensor, sig: Sig, bits: int, flags: int = 0) -> torc
 
 
 def had_mfma_supported(n: int, K: int) -> bool:
-    """Shapes of the structured matrix-pipe rotation (fq_had_mfma.hip): n = K * 512 or K * 1024, K <= 32, K % 4 == 0
+    """Shapes of the structured matrix-pipe rotation (fq_had_mfma.hip): n = K * 512 (K <= 32) or K * 1024 (K <= 28), K % 4 == 0
     (14336 = 28 * 512: Llama-3-8B ffn; 28672 = 28 * 1024: Llama-2-70B ffn)."""
-    return 4 <= K <= 32 and K % 4 == 0 and n in (K * 512, K * 1024)
+    return K % 4 == 0 and ((4 <= K <= 32 and n == K * 512) or (4 <= K <= 28 and n == K * 1024))
 
 
 def hadamard_mfma(x: torch.Tensor, K: int, hadK: torch.Tensor, sig: Optional[Sig] = None, scale: Optional[float] = None,

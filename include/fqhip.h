@@ -441,7 +441,7 @@ int fq_hadamard_quant_f16(const void* x, int64_t rows, int n, int K, const void*
  * rounded to fp16 at different points, the rotated values agree with fq_hadamard_f16 within the op's tolerance class (1e-3 of the
  * row maximum against the exact rotation; hadamard_utils.py:89-110 is the oracle), so a scale can differ by an fp16 step and a digit
  * by +-1 on ~1e-3 of the elements.
- * Covers n = K * 512 and n = K * 1024 with 4 <= K <= 32, K % 4 == 0 (14336 = 28 * 512: Llama-3-8B ffn; 28672 = 28 * 1024: Llama-2-70B
+ * Covers n = K * 512 with 4 <= K <= 32 and n = K * 1024 with 4 <= K <= 28, K % 4 == 0 (14336 = 28 * 512: Llama-3-8B ffn; 28672 = 28 * 1024: Llama-2-70B
  * ffn, H_1024 = H_8 (x) H_4 (x) H_32, 32 MFMAs per wave and token where the dense 112 x 256 pair needs 128); FQ_EUNSUPPORTED otherwise.
  *   hadK [K, K] fp16 (+-1); q_out [rows, n/2] uint8 with scale_out [rows] fp16, or both NULL; y_out [rows, n] fp16 or NULL (y_out == x
  *   is allowed); at least one output. No workspace.

@@ -46,6 +46,8 @@ def main():
                  ("hadamard fwht (fp16 out)", lambda i: ops.hadamard(xs[i % 2], K, hk, fwht_route=True), r * 4.0 * n),
                  ("deploy Quantizer (rowquant fp16)",
                   lambda i: ops.rowquant(xs[i % 2], [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16), pb)]
+        if os.environ.get("TIME_HAD_FAST"):      # A/B runs: the two structured-kernel launches only
+            cases = [cases[0], cases[3]]
         for name, f, b in cases:
             us, mn = timeit(f)
             print(f"n={n:5d} rows={r:5d} {name:34s} {us:8.1f} us (min {mn:.1f})  {b / us / 1e3:7.0f} GB/s  {b / us / 8e6:5.3f} of 8 TB/s",
