@@ -25,7 +25,7 @@ int fq_launch_kron64_multi(int bf16_dtype, const void* jobs, int n_jobs, int bpj
 int fq_launch_rowmm(int bf16_dtype, const void* x, const void* Tm, void* y, int64_t rows, int n, int n_cu, hipStream_t stream);
 int fq_launch_fwht_f32(const f16* x, float* y32, int64_t vecs, int P, float scale, int n_cu, hipStream_t stream);
 int fq_launch_had_mfma(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max, float sig_min,
-                       uint8_t* q_out, f16* scale_out, f16* y_out, int n_cu, hipStream_t stream);
+                       uint8_t* q_out, f16* scale_out, f16* y_out, int n_cu, hipStream_t stream, const f16* up = nullptr);
 int fq_launch_hadamard_quant(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max,
                              float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream);
 int fq_launch_gemm_i4(const uint8_t* X, const uint8_t* W, int64_t M, int N, int K, int32_t* c, f16* y, const f16* srow,
@@ -845,6 +845,22 @@ int fq_hadamard_quant_mfma_f16(const void* x, int64_t rows, int n, int K, const 
     const int rc = fq_launch_had_mfma((const f16*)x, rows, n, K, (const f16*)hadK, scale, sig_max, sig_min, (uint8_t*)q_out,
                                       (f16*)scale_out, (f16*)y_out, cu_count(), (hipStream_t)stream);
     if (rc == -1000) return fail(FQ_EUNSUPPORTED, "%s: n=%d K=%d (n = K * 512 or K * 1024 with K <= 32, K %% 4 == 0)", what, n, K);
+    return check_launch(rc, what);
+}
+
+int fq_silu_mul_hadamard_quant_mfma_f16(const void* gate, const void* up, int64_t rows, int n, int K, const void* hadK, float scale,
+                                        float sig_max, float sig_min, void* q_out, void* scale_out, void* stream) {
+    const char* what = "fq_silu_mul_hadamard_quant_mfma_f16";
+    if (!q_out || !scale_out) return fail(FQ_EINVAL, "%s: NULL pointer", what);
+    if (rows < 0 || n <= 0 || K <= 0 || n % K) return fail(FQ_EINVAL, "%s: bad sizes n=%d K=%d", what, n, K);
+    if (K > 1 && !hadK) return fail(FQ_EINVAL, "%s: hadK is NULL with K=%d", what, K);
+    if (!(sig_max > 0.0f) || !(sig_min > 0.0f)) return fail(FQ_EINVAL, "%s: sig_max/sig_min must be > 0", what);
+    if (rows == 0) return FQ_OK;
+    if (!gate || !up) return fail(FQ_EINVAL, "%s: gate/up is NULL", what);
+    FQ_NEED_ALIGN16(what, gate, up, hadK, q_out);
+    const int rc = fq_launch_had_mfma((const f16*)gate, rows, n, K, (const f16*)hadK, scale, sig_max, sig_min, (uint8_t*)q_out,
+                                      (f16*)scale_out, nullptr, cu_count(), (hipStream_t)stream, (const f16*)up);
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "%s: n=%d K=%d (n = K * 512, K <= 32, or K * 1024, K <= 28; K %% 4 == 0)", what, n, K);
     return check_launch(rc, what);
 }
 

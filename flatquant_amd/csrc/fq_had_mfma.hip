@@ -110,11 +110,14 @@ __device__ __forceinline__ f32x2 hm_pk_sub32(f32x2 a, f32x2 b) {
 }
 
 // QUANT: packed INT4 + scale (the Quantizer); YOUT: the rotated activation itself, fp16 (matmul_hadU_cuda's result)
-template <int NA, int GROUPS, bool QUANT, bool YOUT>
+// SILU: x is x_gate and the rotation's input is fp16(up * fp16(silu(x_gate))) (deploy/transformers/modeling_llama.py:277-278; fq_silu_mul8):
+// a wave loads the chunks of `up` that match its own LDS-DMA instructions into registers next to them and, once both have landed,
+// rewrites ITS slots of the token buffer in place — no other wave touches them before the group's next meeting.
+template <int NA, int GROUPS, bool QUANT, bool YOUT, bool SILU = false>
 __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __restrict__ x, const f16* __restrict__ hadK, int K, int64_t rows,
                                                              int64_t tpb, float post_scale, float sig_max, float sig_min,
                                                              uint8_t* __restrict__ q_out, f16* __restrict__ scale_out,
-                                                             f16* __restrict__ y_out) {
+                                                             f16* __restrict__ y_out, const f16* __restrict__ up) {
     typedef HmGeo<NA, GROUPS> G;
     constexpr int HM_GROUPS = GROUPS, HM_TOKBUF = G::TOKBUF;
     constexpr bool QSTAGE = QUANT && HM_QSTAGE;
@@ -171,6 +174,8 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
     // This wave's share of token k's DMA: instructions [d0, d0 + dn). Instruction i fills the LDS rows 4 i .. 4 i + 3 linearly; lane l
     // (row 4 i + l / 16, position l % 16) fetches the chunk that the swizzle maps there: position ^ (row / NA & 15) = l % 16 ^ (i >> KEY_SHIFT & 15)
     // — keyed on row / NA because an A fragment reads the rows NA c + a of 32 lanes c: their positions must differ with c.
+    constexpr int MAXDN = SILU ? (NA == 8 ? 14 : 8) : 1;   // DMA instructions of a wave per token (K <= 32 | K <= 28)
+    u32x4 UP[MAXDN];                                       // SILU: the matching 16-byte chunks of `up`, one per DMA instruction
     auto stage_token = [&](int k) {
         const unsigned char* src = xb + (blk_base + k) * tok_bytes;
         const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)src);
@@ -195,9 +200,33 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
                   "s"((unsigned)__builtin_amdgcn_readfirstlane((int)(tok_lds + (unsigned)i * 1024)))
                 : "memory");
         }
+        if (SILU) {
+            const unsigned char* usrc = reinterpret_cast<const unsigned char*>(up) + (blk_base + k) * tok_bytes;
+#pragma unroll
+            for (int j = 0; j < MAXDN; ++j)
+                if (j < dn) {
+                    const int i = d0 + j;
+                    const unsigned rv = (unsigned)((lb + (lp ^ ((i >> G::KEY_SHIFT) & 15))) << 4);
+                    UP[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(usrc + (size_t)i * 1024 + rv));
+                }
+        }
+    };
+    // SILU: this wave's slots of the token buffer (slot 64 i + lane of DMA instruction i), gate -> fp16(up * fp16(silu(gate)))
+    auto silu_prepass = [&]() {
+        if (!SILU) return;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        u32x4* slots = reinterpret_cast<u32x4*>(tokbuf) + ln;
+#pragma unroll
+        for (int j = 0; j < MAXDN; ++j)
+            if (j < dn) {
+                const f16x8 g = __builtin_bit_cast(f16x8, slots[(d0 + j) * 64]);
+                slots[(d0 + j) * 64] = __builtin_bit_cast(u32x4, fq_silu_mul8(g, __builtin_bit_cast(f16x8, UP[j])));
+            }
     };
     if (grp < blk_cnt && dn > 0) stage_token(grp);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (grp < blk_cnt && dn > 0) silu_prepass();
 
     // QSTAGE: the packed token leaves through LDS. A lane holds 8 bytes of 16-byte pieces that lie 64 bytes apart in memory (a row's other
     // pieces belong to the other three waves): straight from the registers a token is 4 x NA store instructions per wave of 32 separate
@@ -361,6 +390,7 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
         }
         // the DMA of the group's next token is waited for HERE, in front of the stores (which are never waited for)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (more) silu_prepass();
         if (!(HM_ABL & 8)) {
             int lq = lane;
             asm volatile("" : "+v"(lq));
@@ -408,32 +438,37 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
 // has landed in LDS completely (vmcnt(0) + the group's first meeting) before any of its rows is stored, and tokens do not overlap.
 template <int NA, int GROUPS>
 static int hm_launch(const f16* x, int64_t rows, int K, const f16* hadK, float ps, float sig_max, float sig_min, uint8_t* q_out,
-                     f16* scale_out, f16* y_out, int n_cu, hipStream_t stream) {
+                     f16* scale_out, f16* y_out, const f16* up, int n_cu, hipStream_t stream) {
     int64_t blocks = (rows + GROUPS - 1) / GROUPS;
     if (blocks > n_cu) blocks = n_cu;   // one persistent workgroup per CU
     if (blocks < 1) blocks = 1;
     const int64_t tpb = (rows + blocks - 1) / blocks;
     constexpr int T = HmGeo<NA, GROUPS>::THREADS;
-    if (q_out && y_out)
+    if (up)
+        hipLaunchKernelGGL((fq_had512_kernel<NA, GROUPS, true, false, true>), dim3((unsigned)blocks), dim3(T), 0, stream, x, hadK, K, rows, tpb,
+                           ps, sig_max, sig_min, q_out, scale_out, y_out, up);
+    else if (q_out && y_out)
         hipLaunchKernelGGL((fq_had512_kernel<NA, GROUPS, true, true>), dim3((unsigned)blocks), dim3(T), 0, stream, x, hadK, K, rows, tpb, ps,
-                           sig_max, sig_min, q_out, scale_out, y_out);
+                           sig_max, sig_min, q_out, scale_out, y_out, up);
     else if (q_out)
         hipLaunchKernelGGL((fq_had512_kernel<NA, GROUPS, true, false>), dim3((unsigned)blocks), dim3(T), 0, stream, x, hadK, K, rows, tpb, ps,
-                           sig_max, sig_min, q_out, scale_out, y_out);
+                           sig_max, sig_min, q_out, scale_out, y_out, up);
     else
         hipLaunchKernelGGL((fq_had512_kernel<NA, GROUPS, false, true>), dim3((unsigned)blocks), dim3(T), 0, stream, x, hadK, K, rows, tpb, ps,
-                           sig_max, sig_min, q_out, scale_out, y_out);
+                           sig_max, sig_min, q_out, scale_out, y_out, up);
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
+// up != NULL: x is x_gate, the rotation's input fp16(up * fp16(silu(x))) (packed output only)
 int fq_launch_had_mfma(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max, float sig_min,
-                       uint8_t* q_out, f16* scale_out, f16* y_out, int n_cu, hipStream_t stream) {
+                       uint8_t* q_out, f16* scale_out, f16* y_out, int n_cu, hipStream_t stream, const f16* up) {
+    if (up && (!q_out || y_out)) return -1000;
     if (K <= 1 || K > 32 || (K & 3) || hadK == nullptr || (n != K * 512 && n != K * 1024)) return -1000;
     if (!q_out && !y_out) return -1000;
     // the +-1 / 16 (+-1 / 32) right factor is undone here: y = (1 / sqrt(n)) H x = scale * 16 * (H / 16) x
-    if (n == K * 512) return hm_launch<4, HM_NGROUPS>(x, rows, K, hadK, scale * 16.0f, sig_max, sig_min, q_out, scale_out, y_out, n_cu, stream);
+    if (n == K * 512) return hm_launch<4, HM_NGROUPS>(x, rows, K, hadK, scale * 16.0f, sig_max, sig_min, q_out, scale_out, y_out, up, n_cu, stream);
     if (K > 28) return -1000;   // (the staging buffer of the two-group geometry holds 224 rows)
-    return hm_launch<8, 2>(x, rows, K, hadK, scale * 32.0f, sig_max, sig_min, q_out, scale_out, y_out, n_cu, stream);
+    return hm_launch<8, 2>(x, rows, K, hadK, scale * 32.0f, sig_max, sig_min, q_out, scale_out, y_out, up, n_cu, stream);
 }

@@ -875,22 +875,32 @@ def had_mfma_supported(n: int, K: int) -> bool:
 
 
 def hadamard_mfma(x: torch.Tensor, K: int, hadK: torch.Tensor, sig: Optional[Sig] = None, scale: Optional[float] = None,
-                  want_y: bool = True):
+                  want_y: bool = True, up: Optional[torch.Tensor] = None):
     """fq_hadamard_quant_mfma_f16: the rotation of n = K * 512 / K * 1024 with its structure on the matrix pipe. -> (y or None, q or None,
-    scales or None); ``sig`` given: the deploy Quantizer's packed output as hadamard_quant; ``want_y``: the rotated activation."""
+    scales or None); ``sig`` given: the deploy Quantizer's packed output as hadamard_quant; ``want_y``: the rotated activation.
+    ``up`` (with ``sig``, ``want_y=False``): x is x_gate, the rotation's input is fp16(up * fp16(silu(x))) formed inside the launch
+    (fq_silu_mul_hadamard_quant_mfma_f16) — the same bytes as this function on silu_mul(x, up)."""
     _chk(x, "x"), _chk(hadK, "hadK")
     n = x.shape[-1]
     if hadK.shape != (K, K) or not had_mfma_supported(n, K):
         raise ValueError("hadamard_mfma: n = K * 512 or K * 1024 with K <= 32, K % 4 == 0 and hadK [K, K]")
     if sig is None and not want_y:
         raise ValueError("hadamard_mfma: no output requested")
+    if up is not None:
+        _chk(up, "up")
+        if up.shape != x.shape or sig is None or want_y:
+            raise ValueError("hadamard_mfma(up=...): up of x's shape, sig given, want_y=False")
     if scale is None:
         scale = float(1.0 / torch.tensor(n).sqrt())
     rows = x.numel() // n
     y = torch.empty_like(x) if want_y else None
     q = torch.empty(x.shape[:-1] + (n // 2,), dtype=torch.uint8, device=x.device) if sig is not None else None
     s = torch.empty((rows,), dtype=torch.float16, device=x.device) if sig is not None else None
-    if rows > 0:
+    if rows > 0 and up is not None:
+        with _on(x.device):
+            check(lib.fq_silu_mul_hadamard_quant_mfma_f16(_ptr(x), _ptr(up), rows, n, K, _ptr(hadK), ctypes.c_float(scale),
+                                                          ctypes.c_float(sig[0]), ctypes.c_float(sig[1]), _ptr(q), _ptr(s), _stream(x)))
+    elif rows > 0:
         with _on(x.device):
             check(lib.fq_hadamard_quant_mfma_f16(_ptr(x), rows, n, K, _ptr(hadK), ctypes.c_float(scale),
                                                  ctypes.c_float(sig[0] if sig is not None else 1.0),
@@ -972,14 +982,14 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
       * n = K * 512 or K * 1024 with K <= 32 (14336 = 28 * 512, 28672 = 28 * 1024; round 4): the structured matrix-pipe kernel
         (hadamard_mfma) — H_512 / H_1024 as two register butterflies and two K = 32 contractions, 16 / 32 MFMAs per wave and token
         instead of the 60 / 128 of the dense pair below;
-      * n = 11008 (K = 172), 14336 / 28672 with ``up``, and every other n = K 2^p whose rotation is a factor pair with a
+      * n = 11008 (K = 172) and every other n = K 2^p whose rotation is a factor pair with a
         packed-only kernel of its own (_hadamard_as_kron): the rotation runs as ONE Kronecker launch (112 x 128 / 112 x 256 /
         172 x 64, kron_quant_ex), 1.5-2x faster. It rounds the intermediate to fp16 at a different point: the rotated values agree with
         the FWHT route within 2e-3 of the row maximum (the reference's own tolerance class, tests/test_gpu_hadamard.py), so
         scales can differ by an fp16 step and digits by +-1 on ~1e-3 of elements — NOT bit for bit.
     ``fwht_route=True`` (= ``route="fwht"``) forces the first route for callers that need hadamard(fwht_route=True) + Quantizer ==
     hadamard_quant() exactly; ``route="kron"`` forces the dense Kronecker launch where it exists, ``route="mfma"`` the structured one.
-    With ``up``: x is x_gate and the input of the rotation is up * silu(x), formed in registers (dense Kronecker / FWHT routes)."""
+    With ``up``: x is x_gate and the input of the rotation is up * silu(x), formed inside the launch (every route)."""
     if route not in (None, "fwht", "kron", "mfma"):
         raise ValueError("route: None, 'fwht', 'kron' or 'mfma'")
     fwht_route = fwht_route or route == "fwht"
@@ -998,12 +1008,12 @@ def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = N
     if scale is None:
         scale = float(1.0 / torch.tensor(n).sqrt())
     rows = x.numel() // n
-    if route == "mfma" and (up is not None or not had_mfma_supported(n, K)):
-        raise _lib.FqError(FQ_EUNSUPPORTED, "hadamard_quant(route='mfma'): n = K * 512 or K * 1024 with K <= 32, K % 4 == 0, no up=")
-    if not fwht_route and route != "kron" and up is None and rows > 0 and had_mfma_supported(n, K):
+    if route == "mfma" and not had_mfma_supported(n, K):
+        raise _lib.FqError(FQ_EUNSUPPORTED, "hadamard_quant(route='mfma'): n = K * 512 (K <= 32) or K * 1024 (K <= 28), K % 4 == 0")
+    if not fwht_route and route != "kron" and rows > 0 and had_mfma_supported(n, K):
         # the structured route (fq_had_mfma.hip): H_512 = H_4 (x) H_4 (x) H_32 (H_1024 = H_8 (x) H_4 (x) H_32) as two register butterflies +
         # two K = 32 contractions
-        _, q, s = hadamard_mfma(x, K, hadK, sig, scale, want_y=False)
+        _, q, s = hadamard_mfma(x, K, hadK, sig, scale, want_y=False, up=up)
         return q, s
     kr = _hadamard_as_kron(K, n // K, hadK, x.device) if (n % K == 0 and not fwht_route) else None
     if kr is not None and rows > 0:

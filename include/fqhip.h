@@ -18,7 +18,7 @@
  *   fq_kron_quant_grouped_f16   flatquant/model_tools/deepseekv3_utils.py:427-452 (FlatQuantMoE.forward: rows grouped per
  *                          expert, one transform, per-expert activation quantisers) + :365-390 (_trans_forward)
  *   fq_rmsnorm_f16, fq_rmsnorm_kron_quant_f16   deploy/nn/normalization.py:4-23 (RMSNorm), alone / fused in front
- *   fq_silu_mul_f16, fq_silu_mul_kron_quant_f16, fq_silu_mul_hadamard_quant_f16
+ *   fq_silu_mul_f16, fq_silu_mul_kron_quant_f16, fq_silu_mul_hadamard_quant_f16, fq_silu_mul_hadamard_quant_mfma_f16
  *                          deploy/transformers/modeling_llama.py:277-279 (x_up * act_fn(x_gate) -> down_proj), alone / fused
  *   fq_block_quant_f16     deploy/kernels/block_matmul.py:231-311 (block_matmul)
  *   fq_int4_gemm_i32       deploy/kernels/gemm.cu:8-47 (matmul_host) / deploy.matmul
@@ -448,6 +448,16 @@ int fq_hadamard_quant_f16(const void* x, int64_t rows, int n, int K, const void*
  */
 int fq_hadamard_quant_mfma_f16(const void* x, int64_t rows, int n, int K, const void* hadK, float scale,
                                float sig_max, float sig_min, void* q_out, void* scale_out, void* y_out, void* stream);
+
+/*
+ * fq_hadamard_quant_mfma_f16 (packed output) on x = fp16(up * fp16(silu(gate))): deploy/transformers/modeling_llama.py:277-279 in front
+ * of down_proj = Sequential(OnlineTrans(had), Quantizer, Linear4bit) (:248-253) as ONE launch on the structured kernel. Every wave
+ * loads the chunks of `up` that match its own LDS-DMA instructions of `gate` and rewrites its slots of the staged token in place
+ * (the arithmetic of fq_silu_mul_f16, bit for bit: the result equals fq_hadamard_quant_mfma_f16 on fq_silu_mul_f16's output).
+ * Same shapes, same FQ_EUNSUPPORTED otherwise. gate, up [rows, n] fp16.
+ */
+int fq_silu_mul_hadamard_quant_mfma_f16(const void* gate, const void* up, int64_t rows, int n, int K, const void* hadK, float scale,
+                                        float sig_max, float sig_min, void* q_out, void* scale_out, void* stream);
 
 /* fq_hadamard_quant_f16 on x = fp16(up * fp16(silu(gate))) formed in registers (see fq_silu_mul_kron_quant_f16). */
 int fq_silu_mul_hadamard_quant_f16(const void* gate, const void* up, int64_t rows, int n, int K, const void* hadK,

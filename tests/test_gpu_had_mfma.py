@@ -79,6 +79,30 @@ def test_quantizer_stage_bit_exact_on_the_launch_own_rotation(ops, n, K):
 
 
 @pytest.mark.parametrize("n,K", SHAPES)
+@pytest.mark.parametrize("rows", [1, 5, 130, 777])
+def test_silu_mul_input_equals_the_two_launch_sequence(ops, n, K, rows):
+    """fq_silu_mul_hadamard_quant_mfma_f16: x_gate and up in, the rotation's input fp16(up * fp16(silu(gate))) formed inside the launch
+    (modeling_llama.py:277-279 in front of down_proj) — the same bytes as the structured launch on fq_silu_mul_f16's output."""
+    g = torch.Generator().manual_seed(n + rows)
+    gate = (torch.randn(rows, n, generator=g) * 2).half().cuda()
+    up = torch.randn(rows, n, generator=g).half().cuda()
+    gate[:, ::97] *= 6
+    if rows > 2:
+        gate[2] = 0
+    hk = torch.from_numpy(hadk_matrix(K)).cuda()
+    x = ops.silu_mul(gate, up)
+    for sig in [(0.9820137619972229, 0.9820137619972229), (0.7, 0.9)]:
+        _, q, s = ops.hadamard_mfma(gate, K, hk, sig, want_y=False, up=up)
+        _, q2, s2 = ops.hadamard_mfma(x, K, hk, sig, want_y=False)
+        assert torch.equal(q, q2) and torch.equal(s, s2), (n, K, rows, sig)
+        qd, sd = ops.hadamard_quant(gate, K, hk, sig, up=up)        # the default route of these shapes
+        assert torch.equal(qd, q) and torch.equal(sd.reshape(-1), s)
+    for _ in range(5):                                                # (claims and meetings are timing-dependent, results are not)
+        _, q3, s3 = ops.hadamard_mfma(gate, K, hk, (0.7, 0.9), want_y=False, up=up)
+        assert torch.equal(q3, q) and torch.equal(s3, s)
+
+
+@pytest.mark.parametrize("n,K", SHAPES)
 def test_agrees_with_the_fwht_route_to_rounding_noise(ops, n, K):
     """Against the bit-identical route (register FWHT + K-factor, then the Quantizer): digits within +-1 on <= 2e-3 of the
     elements, scales within an fp16 step — the bars the dense Kronecker launch of the same rotation has had since round 2."""

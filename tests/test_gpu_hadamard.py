@@ -153,7 +153,7 @@ def test_hadamard_as_kronecker_launch(ops, n, K):
         q, s = ops.hadamard_quant(x.cuda(), K, hk.cuda(), sig)
         assert np.array_equal(q.cpu().numpy(), rq["packed"]) and np.array_equal(s.cpu().numpy(), rq["scale16"])
     up = torch.randn(rows, n, generator=g).half()
-    q2, s2 = ops.hadamard_quant(x.cuda(), K, hk.cuda(), sig, up=up.cuda())     # the SiLU.mul input stays with the dense pair
+    q2, s2 = ops.hadamard_quant(x.cuda(), K, hk.cuda(), sig, up=up.cuda(), route="kron")     # the SiLU.mul input on the dense pair
     xs = ops.silu_mul(x.cuda(), up.cuda())
     o3 = ops.kron_quant_ex(xs, left, right, scale, [sig], FQ_OUT_PACKED | fl)
     assert torch.equal(q2, o3.q[0]) and torch.equal(s2, o3.scale[0])

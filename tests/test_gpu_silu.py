@@ -132,9 +132,13 @@ def test_fused_hadamard_equals_two_launches(ops, n, K):
     hk = None if K == 1 else torch.from_numpy(hadk_matrix(K)).cuda()
     for sig in [(0.9820137619972229, 0.9820137619972229), (0.7, 0.9)]:
         q, s = ops.hadamard_quant(gate, K, hk, sig, up=up)
-        # (n = K * 512 without up= defaults to the structured kernel since round 4: compare on the route that takes up=)
-        q2, s2 = ops.hadamard_quant(ops.silu_mul(gate, up), K, hk, sig, route="kron" if ops.had_mfma_supported(n, K) else None)
+        # (every route takes up=: the structured kernel for n = K * 512 / K * 1024, the dense Kronecker launch, the FWHT kernel)
+        q2, s2 = ops.hadamard_quant(ops.silu_mul(gate, up), K, hk, sig)
         assert torch.equal(q, q2) and torch.equal(s, s2)
+        if ops.had_mfma_supported(n, K):
+            q3, s3 = ops.hadamard_quant(gate, K, hk, sig, up=up, route="kron")
+            q4, s4 = ops.hadamard_quant(ops.silu_mul(gate, up), K, hk, sig, route="kron")
+            assert torch.equal(q3, q4) and torch.equal(s3, s4)
 
 
 def test_module_arguments(ops):

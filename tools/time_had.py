@@ -46,7 +46,14 @@ def main():
                  ("hadamard fwht (fp16 out)", lambda i: ops.hadamard(xs[i % 2], K, hk, fwht_route=True), r * 4.0 * n),
                  ("deploy Quantizer (rowquant fp16)",
                   lambda i: ops.rowquant(xs[i % 2], [sig], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_SIG_F16), pb)]
-        if os.environ.get("TIME_HAD_FAST"):      # A/B runs: the two structured-kernel launches only
+        if os.environ.get("TIME_HAD_SILU"):      # the SiLU.mul input (x_gate, up): fused per route, and the separate launch
+            ups = [torch.randn(r, n, generator=g, device="cuda", dtype=torch.float32).half() for _ in range(2)]
+            sb = r * (4.5 * n + 2)
+            cases = [("silu.mul + hadamard_quant default", lambda i: ops.hadamard_quant(xs[i % 2], K, hk, sig, up=ups[i % 2]), sb),
+                     ("silu.mul + hadamard_quant kron", lambda i: ops.hadamard_quant(xs[i % 2], K, hk, sig, up=ups[i % 2], route="kron"), sb),
+                     ("silu_mul alone (fq_silu_mul_f16)", lambda i: ops.silu_mul(xs[i % 2], ups[i % 2]), r * 6.0 * n),
+                     cases[0]]
+        elif os.environ.get("TIME_HAD_FAST"):      # A/B runs: the two structured-kernel launches only
             cases = [cases[0], cases[3]]
         for name, f, b in cases:
             us, mn = timeit(f)
