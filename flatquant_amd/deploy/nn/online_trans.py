@@ -161,3 +161,27 @@ def fused_forward(x, transforms, norm=None):
         o = ops.kron_quant(x.contiguous(), left, right, sigs, flags)
     return [PackedQuantizedTensor(o.q[i].reshape(bsz, seq_len, -1), o.scale[i].reshape(bsz, 1, seq_len))
             for i in range(len(transforms))]
+
+
+class FusedSequential(torch.nn.Sequential):
+    """``Sequential(OnlineTrans, Quantizer, ...)`` — the reference's down_proj (deploy/transformers/modeling_llama.py:248-253: OnlineTrans(had),
+    Quantizer, Linear4bit) — with the first two modules run as ONE launch: ``self[0](x, quantizer=self[1])`` returns the
+    PackedQuantizedTensor, the Quantizer passes packed inputs through (quantization.py:14), the remaining modules follow. Same children,
+    same state-dict keys as the ``nn.Sequential`` it replaces: ``model.mlp.down_proj = FusedSequential(*model.mlp.down_proj)`` is the
+    whole change for a model built by the reference's code. ``forward(x, up=None)``: with ``up``, x is x_gate and the transform
+    consumes x_up * silu(x_gate) inside the launch (modeling_llama.py:277-279)."""
+
+    def forward(self, x, up=None):
+        mods = list(self)
+        if len(mods) >= 2 and isinstance(mods[0], OnlineTrans):
+            x = mods[0](x, quantizer=mods[1], up=up)
+            rest = mods[1:]
+        else:
+            if up is not None:
+                from ... import ops
+                x = ops.silu_mul(x.contiguous(), up.contiguous())
+            rest = mods
+        for m in rest:
+            x = m(x)
+        return x
+

@@ -190,6 +190,29 @@ def test_online_trans_with_quantizer_argument(ops):
     assert qz(fused) is fused   # the Quantizer passes packed inputs through
 
 
+@pytest.mark.parametrize("n", [14336, 28672, 11008, 4096])
+def test_fused_sequential_is_the_sequential_with_one_launch(ops, n):
+    """deploy.nn.FusedSequential(*seq): the reference's down_proj = Sequential(OnlineTrans(had), Quantizer, ...)
+    (modeling_llama.py:248-253) with the first two modules as one launch — same children and state-dict keys, the same bytes as
+    OnlineTrans.forward(x, quantizer=...) and, with up=, as the same call on silu_mul's output."""
+    import flatquant_amd.deploy as deploy
+    seq = torch.nn.Sequential(deploy.nn.OnlineTrans(n, trans="had"), deploy.nn.Quantizer(lac=True)).cuda()
+    fused = deploy.nn.FusedSequential(*seq)
+    assert list(fused.state_dict().keys()) == list(seq.state_dict().keys())
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(2, 7, n, generator=g).half().cuda()
+    up = torch.randn(2, 7, n, generator=g).half().cuda()
+    a, b = fused(x), seq[0](x, quantizer=seq[1])
+    assert isinstance(a, deploy.PackedQuantizedTensor)
+    assert torch.equal(a.quantized_x, b.quantized_x) and torch.equal(a.scales_x, b.scales_x)
+    c, d = fused(x, up=up), seq[0](ops.silu_mul(x, up), quantizer=seq[1])
+    assert torch.equal(c.quantized_x, d.quantized_x) and torch.equal(c.scales_x, d.scales_x)
+    ref = seq(x)                                     # two launches: rounding-noise agreement where the fused route is a matrix-pipe one
+    qa = O.unpack_i4(a.quantized_x.cpu().numpy().reshape(14, -1))
+    qb = O.unpack_i4(ref.quantized_x.cpu().numpy().reshape(14, -1))
+    assert np.mean(qa != qb) <= 2e-3 and np.max(np.abs(qa - qb)) <= 1
+
+
 @pytest.mark.parametrize("n", [64, 128, 512, 4096, 8192, 14336, 11008, 28672])
 def test_force_fp32_returns_the_fp32_transform(ops, n):
     """OnlineTrans(force_fp32=True) (deploy/nn/online_trans.py:55-59): x.float() through fast_hadamard_transform in fp32 and the
