@@ -22,8 +22,9 @@ HBM; buffers rotate over > 256 MiB so the Infinity Cache cannot serve the stream
       28 x 512 + Quantizer on the down_proj input. 4 launches per step, 8 x 2048 tokens per GPU (weak scaling).
   C4  Llama-2-70B shapes (d = 8192 = 64x128, ffn 28672 = 128x224, 64 heads), all 80 layers per step (320 launches,
       replayed from ONE captured HIP graph), 8 x 2048 tokens in total, rows sharded over the GPUs (strong scaling).
-  C4H C4 with the down_proj input as the reference's deploy model builds it (OnlineTrans(had) + Quantizer,
-      deploy/transformers/modeling_llama.py:248-253): Hadamard 28 x 1024 + Quantizer in one launch instead of the learned 128x224 pair.
+  C4H C4 with the down_proj input of the reference's deploy model under options.trans == "had" (OnlineTrans(had) + Quantizer,
+      deploy/transformers/modeling_llama.py:248-253 — BASELINE config 3's "online Hadamard on down_proj" at Llama-2-70B shapes):
+      Hadamard 28 x 1024 + Quantizer in one launch instead of the learned 128x224 pair of options.trans == "matmul" (C4).
   C5  DeepSeek-V3 MoE: w1_trans 64x112 over 16384 tokens of d = 7168, then the routed experts' hidden rows
       [8 x 16384, 2048] in 256 groups (Zipf routing) through the grouped 32x64 launch with per-expert clip pairs;
       experts (groups) and tokens sharded over the GPUs (strong scaling).
@@ -399,9 +400,10 @@ class C4(Workload):
 
 
 class C4H(C4):
-    """C4 with the down_proj input as the reference's DEPLOY model builds it — OnlineTrans(had) + Quantizer in front of Linear4bit
-    (deploy/transformers/modeling_llama.py:248-253): the online Hadamard rotation of 28672 = 28 x 1024 fused with the Quantizer (the
-    structured kernel, fq_had_mfma.hip) instead of the learned 128 x 224 pair of the fake-quant model (C4)."""
+    """C4 with the down_proj input as the reference's deploy model builds it under options.trans == "had" — OnlineTrans(had) +
+    Quantizer in front of Linear4bit (deploy/transformers/modeling_llama.py:248-253; BASELINE config 3's "online Hadamard on down_proj"
+    at Llama-2-70B shapes): the rotation of 28672 = 28 x 1024 fused with the Quantizer (the structured kernel, fq_had_mfma.hip) instead
+    of the learned 128 x 224 pair of options.trans == "matmul" (C4)."""
     name = "C4H"
     down = "hadamard"
 

@@ -59,9 +59,10 @@ def test_silu_fused_full_size(ops):
     assert torch.equal(a.q[0], b.q[0]) and torch.equal(a.scale[0], b.scale[0])
     from conftest import hadk_matrix
     hk = torch.from_numpy(hadk_matrix(28)).cuda()
-    q, s = ops.hadamard_quant(gate, 28, hk, sig[0], up=up)
-    q2, s2 = ops.hadamard_quant(ops.silu_mul(gate, up), 28, hk, sig[0], route="kron")   # (the route that takes up=)
-    assert torch.equal(q, q2) and torch.equal(s, s2)
+    for route in (None, "kron"):   # the structured kernel (default since the late-round-4 build) and the dense pair: both take up=
+        q, s = ops.hadamard_quant(gate, 28, hk, sig[0], up=up, route=route)
+        q2, s2 = ops.hadamard_quant(ops.silu_mul(gate, up), 28, hk, sig[0], route=route)
+        assert torch.equal(q, q2) and torch.equal(s, s2), route
 
 
 def test_fp6_gemm_full_size_equals_int8_path(ops):
