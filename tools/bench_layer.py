@@ -47,13 +47,18 @@ def timeit(fn, steps, warm=10, settle_ms=60.0):
             fn()
         torch.cuda.synchronize()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(steps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / steps * 1e3
+    # median of three event-timed windows: one window is hostage to a single slow event inside it (an allocator round trip to the
+    # driver after the previous piece's tensors were freed measured 4x on one run of the q/k/v launch: profiles/r04_final_layer_l3_bs8.txt)
+    ts = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / steps * 1e3)
+    return sorted(ts)[1]
 
 
 def main():
