@@ -105,6 +105,7 @@ SYMBOLS = {
     "fq_hadamard_quant_f16": (_i, [_vp, _i64, _i, _i, _vp, _f, _f, _f, _vp, _vp, _vp]),
     "fq_hadamard_quant_mfma_f16": (_i, [_vp, _i64, _i, _i, _vp, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "fq_silu_mul_hadamard_quant_mfma_f16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _f, _f, _f, _vp, _vp, _vp]),
+    "fq_hadamard_quantizer_mfma_f16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     "fq_rowquant_f16": (_i, [_vp, _i64, _i, _fp, _fp, _i, _i, _vpp, _vpp, _vpp, _vp]),
     "fq_sym_quant_f16": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     "fq_sym_dequant_i32_f16": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),

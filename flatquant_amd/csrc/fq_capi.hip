@@ -25,7 +25,8 @@ int fq_launch_kron64_multi(int bf16_dtype, const void* jobs, int n_jobs, int bpj
 int fq_launch_rowmm(int bf16_dtype, const void* x, const void* Tm, void* y, int64_t rows, int n, int n_cu, hipStream_t stream);
 int fq_launch_fwht_f32(const f16* x, float* y32, int64_t vecs, int P, float scale, int n_cu, hipStream_t stream);
 int fq_launch_had_mfma(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max, float sig_min,
-                       uint8_t* q_out, f16* scale_out, f16* y_out, int n_cu, hipStream_t stream, const f16* up = nullptr);
+                       uint8_t* q_out, f16* scale_out, f16* y_out, int n_cu, hipStream_t stream, const f16* up = nullptr,
+                       int plain_quantizer = 0);
 int fq_launch_hadamard_quant(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max,
                              float sig_min, uint8_t* q, f16* scale_out, int n_cu, hipStream_t stream);
 int fq_launch_gemm_i4(const uint8_t* X, const uint8_t* W, int64_t M, int N, int K, int32_t* c, f16* y, const f16* srow,
@@ -860,6 +861,22 @@ int fq_silu_mul_hadamard_quant_mfma_f16(const void* gate, const void* up, int64_
     FQ_NEED_ALIGN16(what, gate, up, hadK, q_out);
     const int rc = fq_launch_had_mfma((const f16*)gate, rows, n, K, (const f16*)hadK, scale, sig_max, sig_min, (uint8_t*)q_out,
                                       (f16*)scale_out, nullptr, cu_count(), (hipStream_t)stream, (const f16*)up);
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "%s: n=%d K=%d (n = K * 512, K <= 32, or K * 1024, K <= 28; K %% 4 == 0)", what, n, K);
+    return check_launch(rc, what);
+}
+
+int fq_hadamard_quantizer_mfma_f16(const void* x, const void* up, int64_t rows, int n, int K, const void* hadK, float scale,
+                                   float input_clip_ratio, void* q_out, void* scale_out, void* y_out, void* stream) {
+    const char* what = "fq_hadamard_quantizer_mfma_f16";
+    if (!x || !q_out || !scale_out) return fail(FQ_EINVAL, "%s: NULL pointer (x, q_out, scale_out)", what);
+    if (up && y_out) return fail(FQ_EINVAL, "%s: y_out is not available with up", what);
+    if (rows < 0 || n <= 0 || K <= 0 || n % K) return fail(FQ_EINVAL, "%s: bad sizes n=%d K=%d", what, n, K);
+    if (K > 1 && !hadK) return fail(FQ_EINVAL, "%s: hadK is NULL with K=%d", what, K);
+    if (!(input_clip_ratio > 0.0f)) return fail(FQ_EINVAL, "%s: input_clip_ratio must be > 0", what);
+    FQ_NEED_ALIGN16(what, x, up, hadK, q_out, y_out);
+    if (rows == 0) return FQ_OK;
+    const int rc = fq_launch_had_mfma((const f16*)x, rows, n, K, (const f16*)hadK, scale, input_clip_ratio, 1.0f, (uint8_t*)q_out,
+                                      (f16*)scale_out, (f16*)y_out, cu_count(), (hipStream_t)stream, (const f16*)up, 1);
     if (rc == -1000) return fail(FQ_EUNSUPPORTED, "%s: n=%d K=%d (n = K * 512, K <= 32, or K * 1024, K <= 28; K %% 4 == 0)", what, n, K);
     return check_launch(rc, what);
 }

@@ -117,7 +117,7 @@ template <int NA, int GROUPS, bool QUANT, bool YOUT, bool SILU = false>
 __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __restrict__ x, const f16* __restrict__ hadK, int K, int64_t rows,
                                                              int64_t tpb, float post_scale, float sig_max, float sig_min,
                                                              uint8_t* __restrict__ q_out, f16* __restrict__ scale_out,
-                                                             f16* __restrict__ y_out, const f16* __restrict__ up) {
+                                                             f16* __restrict__ y_out, const f16* __restrict__ up, int rt_flags) {
     typedef HmGeo<NA, GROUPS> G;
     constexpr int HM_GROUPS = GROUPS, HM_TOKBUF = G::TOKBUF;
     constexpr bool QSTAGE = QUANT && HM_QSTAGE;
@@ -372,7 +372,9 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
                 vmax = fq_uniform_f32(fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3])));   // (uniform by construction; told to the compiler)
                 vmin = fq_uniform_f32(fminf(fminf(r1[0], r1[1]), fminf(r1[2], r1[3])));
             }
-            scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, sig_max, sig_min, FQ_SIG_F16);
+            // rt_flags: FQ_SIG_F16 — deploy.nn.Quantizer(lac=True) with the fp16-rounded sigmoids; FQ_RATIO_POST — Quantizer(lac=False):
+            // scale = fp16(max|x| / 7) * input_clip_ratio (sig_max), no zero guard (an all-zero token stores scale 0: quantization.py:30)
+            scale = fq_token_scale<FQ_QUANT_F16>(vmax, vmin, sig_max, sig_min, rt_flags);
             const float inv = fq_uniform_f32(fq_fast_inv(scale));
             const bool clampq = fq_h16_needs_clamp(vmax, vmin, inv);
             const FqH16Recip rc = fq_h16_recip(scale);
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
                     for (int a = 0; a < NA; ++a) *reinterpret_cast<uint2*>(qs + (((a * 4 + wq) ^ (cq & 15)) << 4)) = pk[a];
                 }
                 q_pending = tok;
-                if (wq == 0 && lane == 0) scale_out[tok] = (f16)scale;
+                if (wq == 0 && lane == 0) scale_out[tok] = ((rt_flags & FQ_RATIO_POST) && vmax == 0.0f && vmin == 0.0f) ? (f16)0.0f : (f16)scale;
             } else if (QUANT) {
                 uint8_t* qtok = q_out + tok * ((int64_t)M * 64) + wq * 16;   // 64 packed bytes per row
                 const unsigned lane_off = (unsigned)((lq & 31) * (NA * 64) + (lq >> 5) * 8);
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
 #pragma unroll
                     for (int a = 0; a < NA; ++a) *reinterpret_cast<uint2*>(qtok + (lane_off + a * 64)) = pk[a];
                 }
-                if (wq == 0 && lane == 0) scale_out[tok] = (f16)scale;
+                if (wq == 0 && lane == 0) scale_out[tok] = ((rt_flags & FQ_RATIO_POST) && vmax == 0.0f && vmin == 0.0f) ? (f16)0.0f : (f16)scale;
             }
             if (YOUT) {
                 unsigned char* ytok = reinterpret_cast<unsigned char*>(y_out) + tok * tok_bytes + wq * 64;   // 256 bytes per row
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
 // has landed in LDS completely (vmcnt(0) + the group's first meeting) before any of its rows is stored, and tokens do not overlap.
 template <int NA, int GROUPS>
 static int hm_launch(const f16* x, int64_t rows, int K, const f16* hadK, float ps, float sig_max, float sig_min, uint8_t* q_out,
-                     f16* scale_out, f16* y_out, const f16* up, int n_cu, hipStream_t stream) {
+                     f16* scale_out, f16* y_out, const f16* up, int rt_flags, int n_cu, hipStream_t stream) {
     int64_t blocks = (rows + GROUPS - 1) / GROUPS;
     if (blocks > n_cu) blocks = n_cu;   // one persistent workgroup per CU
     if (blocks < 1) blocks = 1;
@@ -446,16 +448,16 @@ static int hm_launch(const f16* x, int64_t rows, int K, const f16* hadK, float p
     constexpr int T = HmGeo<NA, GROUPS>::THREADS;
     if (up)
         hipLaunchKernelGGL((fq_had512_kernel<NA, GROUPS, true, false, true>), dim3((unsigned)blocks), dim3(T), 0, stream, x, hadK, K, rows, tpb,
-                           ps, sig_max, sig_min, q_out, scale_out, y_out, up);
+                           ps, sig_max, sig_min, q_out, scale_out, y_out, up, rt_flags);
     else if (q_out && y_out)
         hipLaunchKernelGGL((fq_had512_kernel<NA, GROUPS, true, true>), dim3((unsigned)blocks), dim3(T), 0, stream, x, hadK, K, rows, tpb, ps,
-                           sig_max, sig_min, q_out, scale_out, y_out, up);
+                           sig_max, sig_min, q_out, scale_out, y_out, up, rt_flags);
     else if (q_out)
         hipLaunchKernelGGL((fq_had512_kernel<NA, GROUPS, true, false>), dim3((unsigned)blocks), dim3(T), 0, stream, x, hadK, K, rows, tpb, ps,
-                           sig_max, sig_min, q_out, scale_out, y_out, up);
+                           sig_max, sig_min, q_out, scale_out, y_out, up, rt_flags);
     else
         hipLaunchKernelGGL((fq_had512_kernel<NA, GROUPS, false, true>), dim3((unsigned)blocks), dim3(T), 0, stream, x, hadK, K, rows, tpb, ps,
-                           sig_max, sig_min, q_out, scale_out, y_out, up);
+                           sig_max, sig_min, q_out, scale_out, y_out, up, rt_flags);
     return (int)hipGetLastError();
 }
 
@@ -463,12 +465,14 @@ static int hm_launch(const f16* x, int64_t rows, int K, const f16* hadK, float p
 
 // up != NULL: x is x_gate, the rotation's input fp16(up * fp16(silu(x))) (packed output only)
 int fq_launch_had_mfma(const f16* x, int64_t rows, int n, int K, const f16* hadK, float scale, float sig_max, float sig_min,
-                       uint8_t* q_out, f16* scale_out, f16* y_out, int n_cu, hipStream_t stream, const f16* up) {
+                       uint8_t* q_out, f16* scale_out, f16* y_out, int n_cu, hipStream_t stream, const f16* up, int plain_quantizer) {
+    // plain_quantizer: deploy.nn.Quantizer(lac=False) — sig_max is its input_clip_ratio (FQ_RATIO_POST), sig_min unused
+    const int rt_flags = plain_quantizer ? FQ_RATIO_POST : FQ_SIG_F16;
     if (up && (!q_out || y_out)) return -1000;
     if (K <= 1 || K > 32 || (K & 3) || hadK == nullptr || (n != K * 512 && n != K * 1024)) return -1000;
     if (!q_out && !y_out) return -1000;
     // the +-1 / 16 (+-1 / 32) right factor is undone here: y = (1 / sqrt(n)) H x = scale * 16 * (H / 16) x
-    if (n == K * 512) return hm_launch<4, HM_NGROUPS>(x, rows, K, hadK, scale * 16.0f, sig_max, sig_min, q_out, scale_out, y_out, up, n_cu, stream);
+    if (n == K * 512) return hm_launch<4, HM_NGROUPS>(x, rows, K, hadK, scale * 16.0f, sig_max, sig_min, q_out, scale_out, y_out, up, rt_flags, n_cu, stream);
     if (K > 28) return -1000;   // (the staging buffer of the two-group geometry holds 224 rows)
-    return hm_launch<8, 2>(x, rows, K, hadK, scale * 32.0f, sig_max, sig_min, q_out, scale_out, y_out, up, n_cu, stream);
+    return hm_launch<8, 2>(x, rows, K, hadK, scale * 32.0f, sig_max, sig_min, q_out, scale_out, y_out, up, rt_flags, n_cu, stream);
 }

@@ -908,6 +908,33 @@ def hadamard_mfma(x: torch.Tensor, K: int, hadK: torch.Tensor, sig: Optional[Sig
     return y, q, s
 
 
+def hadamard_quantizer_mfma(x: torch.Tensor, K: int, hadK: torch.Tensor, input_clip_ratio: float = 1.0, scale: Optional[float] = None,
+                            up: Optional[torch.Tensor] = None, want_y: bool = False):
+    """fq_hadamard_quantizer_mfma_f16: the structured rotation (had_mfma_supported shapes) in front of deploy.nn.Quantizer(
+    input_clip_ratio, lac=False) as ONE launch — scale = fp16(max|y| / 7) * ratio with no zero guard (deploy/nn/quantization.py:30), the
+    down_proj input of the reference's ``options.trans == "had"`` model. -> (q [..., n/2] uint8, scales [rows] fp16, y or None).
+    ``up``: x is x_gate, the rotation's input fp16(up * fp16(silu(x)))."""
+    _chk(x, "x"), _chk(hadK, "hadK")
+    n = x.shape[-1]
+    if hadK.shape != (K, K) or not had_mfma_supported(n, K):
+        raise ValueError("hadamard_quantizer_mfma: n = K * 512 (K <= 32) or K * 1024 (K <= 28), K % 4 == 0, hadK [K, K]")
+    if up is not None:
+        _chk(up, "up")
+        if up.shape != x.shape or want_y:
+            raise ValueError("hadamard_quantizer_mfma(up=...): up of x's shape, want_y=False")
+    if scale is None:
+        scale = float(1.0 / torch.tensor(n).sqrt())
+    rows = x.numel() // n
+    q = torch.empty(x.shape[:-1] + (n // 2,), dtype=torch.uint8, device=x.device)
+    s = torch.empty((rows,), dtype=torch.float16, device=x.device)
+    y = torch.empty_like(x) if want_y else None
+    if rows > 0:
+        with _on(x.device):
+            check(lib.fq_hadamard_quantizer_mfma_f16(_ptr(x), _ptr(up), rows, n, K, _ptr(hadK), ctypes.c_float(scale),
+                                                     ctypes.c_float(float(input_clip_ratio)), _ptr(q), _ptr(s), _ptr(y), _stream(x)))
+    return q, s, y
+
+
 def hadamard(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None,
              scale: Optional[float] = None, fwht_route: bool = False) -> torch.Tensor:
     """hadK @ FWHT(x.view(rows, K, n/K)) * scale. Routes: the register FWHT + K-factor kernel (fq_hadamard_f16; bit-exact for K = 1,

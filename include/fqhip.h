@@ -459,6 +459,17 @@ int fq_hadamard_quant_mfma_f16(const void* x, int64_t rows, int n, int K, const 
 int fq_silu_mul_hadamard_quant_mfma_f16(const void* gate, const void* up, int64_t rows, int n, int K, const void* hadK, float scale,
                                         float sig_max, float sig_min, void* q_out, void* scale_out, void* stream);
 
+/*
+ * The structured rotation in front of deploy.nn.Quantizer(input_clip_ratio, lac=False) — what the reference's deploy model builds under
+ * options.trans == "had": down_proj = Sequential(OnlineTrans(had), Quantizer(lac=False), Linear4bit), deploy/transformers/modeling_llama.py:241-253
+ * — as ONE launch: scale = fp16(max|y| / 7) * input_clip_ratio (deploy/nn/quantization.py:30; FQ_RATIO_POST arithmetic, as fq_rowquant_f16), NO
+ * zero guard (an all-zero token stores scale 0 and digits 0), digits by quant.cu:40 as every Quantizer route.
+ * up != NULL: x is x_gate, the rotation's input fp16(up * fp16(silu(x))) (as fq_silu_mul_hadamard_quant_mfma_f16; y_out must be NULL).
+ * y_out (optional, up == NULL): the rotated activation the digits were taken from. Shapes as fq_hadamard_quant_mfma_f16.
+ */
+int fq_hadamard_quantizer_mfma_f16(const void* x, const void* up, int64_t rows, int n, int K, const void* hadK, float scale,
+                                   float input_clip_ratio, void* q_out, void* scale_out, void* y_out, void* stream);
+
 /* fq_hadamard_quant_f16 on x = fp16(up * fp16(silu(gate))) formed in registers (see fq_silu_mul_kron_quant_f16). */
 int fq_silu_mul_hadamard_quant_f16(const void* gate, const void* up, int64_t rows, int n, int K, const void* hadK,
                                    float scale, float sig_max, float sig_min, void* q_out, void* scale_out,

@@ -103,6 +103,49 @@ def test_silu_mul_input_equals_the_two_launch_sequence(ops, n, K, rows):
 
 
 @pytest.mark.parametrize("n,K", SHAPES)
+def test_plain_quantizer_in_the_same_launch(ops, n, K):
+    """fq_hadamard_quantizer_mfma_f16: the rotation in front of deploy.nn.Quantizer(input_clip_ratio, lac=False) — the pair the
+    reference's options.trans == "had" model builds (modeling_llama.py:244-252, quantization.py:30) — as one launch: digits and scales
+    == the Quantizer module (fq_rowquant_f16 with FQ_RATIO_POST, pinned against torch in tests/test_gpu_quant.py) applied to the
+    rotation the SAME launch returns; an all-zero token keeps scale 0; the SiLU.mul input; the module route and its shapes."""
+    import flatquant_amd.deploy as deploy
+    rows = 53
+    x = make_x(rows, n, n + 3).cuda()
+    x[5] = 0
+    hk = torch.from_numpy(hadk_matrix(K)).cuda()
+    y0 = ops.hadamard_mfma(x, K, hk)[0]
+    g = torch.Generator().manual_seed(n)
+    gate, up = (torch.randn(rows, n, generator=g) * 2).half().cuda(), torch.randn(rows, n, generator=g).half().cuda()
+    for ratio in (1.0, 0.9, 0.83):
+        q, s, y = ops.hadamard_quantizer_mfma(x, K, hk, ratio, want_y=True)
+        assert torch.equal(y, y0)
+        p = deploy.nn.Quantizer(input_clip_ratio=ratio).cuda()(y)
+        assert torch.equal(p.quantized_x, q) and torch.equal(p.scales_x.reshape(-1), s), (n, K, ratio)
+        assert float(s[5]) == 0.0 and not q[5].any()
+        q2, s2, _ = ops.hadamard_quantizer_mfma(x, K, hk, ratio)          # the packed-only instantiation
+        assert torch.equal(q2, q) and torch.equal(s2, s)
+        q3, s3, _ = ops.hadamard_quantizer_mfma(gate, K, hk, ratio, up=up)
+        q4, s4, _ = ops.hadamard_quantizer_mfma(ops.silu_mul(gate, up), K, hk, ratio)
+        assert torch.equal(q3, q4) and torch.equal(s3, s4)
+    t = deploy.nn.OnlineTrans(n, trans="had").cuda()
+    qz = deploy.nn.Quantizer(lac=False).cuda()
+    x3 = x[:52].reshape(2, 26, n)
+    fused = t(x3, quantizer=qz)
+    if t.rem_dim != K:     # get_hadK prefers another factor for this width (10240 = 40 x 256): not a shape of the structured kernel,
+        assert torch.is_tensor(fused)                       # the module returns the rotation and the caller's Quantizer follows
+        two = deploy.nn.FusedSequential(t, qz)(x3)
+        assert isinstance(two, deploy.PackedQuantizedTensor) and two.scales_x.shape == (2, 1, 26)
+        return
+    assert isinstance(fused, deploy.PackedQuantizedTensor)
+    assert fused.scales_x.shape == (2, 1, 26) and fused.quantized_x.shape == (2, 26, n // 2)
+    q, s, _ = ops.hadamard_quantizer_mfma(x[:52].contiguous(), K, hk, 1.0)
+    assert torch.equal(fused.quantized_x.reshape(52, -1), q) and torch.equal(fused.scales_x.reshape(-1), s)
+    seq = deploy.nn.FusedSequential(t, qz)
+    again = seq(x3)
+    assert torch.equal(again.quantized_x, fused.quantized_x) and torch.equal(again.scales_x, fused.scales_x)
+
+
+@pytest.mark.parametrize("n,K", SHAPES)
 def test_agrees_with_the_fwht_route_to_rounding_noise(ops, n, K):
     """Against the bit-identical route (register FWHT + K-factor, then the Quantizer): digits within +-1 on <= 2e-3 of the
     elements, scales within an fp16 step — the bars the dense Kronecker launch of the same rotation has had since round 2."""
