@@ -432,6 +432,12 @@ int fq_kron_quant_ex_f16(const void* x, const void* up, const void* left, const 
     if (rows == 0) return FQ_OK;
     if (!x || !left || !right) return fail(FQ_EINVAL, "%s: x/left/right is NULL", what);
     FQ_NEED_ALIGN16(what, x, up, left, right, workspace);
+    // FQ_RATIO_POST (deploy.nn.Quantizer(lac=False) behind the rotation: scale = fp16(max|y| / 7) * sig_max, no zero guard): the tall kernel
+    // (64 < M <= 192, N = 64: 11008 = 172 x 64, ...) is the one Kronecker kernel that stores the reference's scale for an all-zero token
+    if ((flags & FQ_RATIO_POST) && !(N == 64 && M > 64 && M <= 192 && !up &&
+                                     (flags & ((FQ_CT_MASK & ~FQ_OUT_TRANSFORM) | FQ_ROUND_Y_F16 | FQ_SIG_F16)) ==
+                                         (FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_ROUND_Y_F16)))
+        return fail(FQ_EUNSUPPORTED, "%s: FQ_RATIO_POST goes with FQ_OUT_PACKED [| FQ_OUT_TRANSFORM] | FQ_QUANT_F16 | FQ_ROUND_Y_F16 on 64 < M <= 192, N = 64 (no up)", what);
     o.post_scale = post_scale == 1.0f ? 0.0f : post_scale;
     o.in2 = (const f16*)up;
     // the scaled / SiLU.mul forms live in the workgroup-per-token kernel family only (the shapes this entry exists for:

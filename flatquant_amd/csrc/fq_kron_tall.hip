@@ -288,7 +288,10 @@ __global__ __launch_bounds__(MT * 64) void fq_kron_tall_kernel(const f16* __rest
             if (row_ok)
                 *reinterpret_cast<u32x4*>(out.q[ci] + tok * (d >> 1) + (w * 32 + c) * (N / 2) + h * 16) =
                     u32x4{pk[0].x, pk[0].y, pk[1].x, pk[1].y};
-            if (w == 0 && lane == 0) out.scale[ci][tok] = (f16)scale;
+            // (FQ_RATIO_POST — deploy.nn.Quantizer(lac=False) behind a Hadamard rotation, fq_kron_quant_ex_f16: no zero guard, an all-zero
+            //  token stores scale 0 as fq_rowquant_f16 does, deploy/nn/quantization.py:30)
+            if (w == 0 && lane == 0)
+                out.scale[ci][tok] = ((out.rt_flags & FQ_RATIO_POST) && vmax == 0.0f && vmin == 0.0f) ? (f16)0.0f : (f16)scale;
         }
     }
 }

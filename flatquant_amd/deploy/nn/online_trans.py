@@ -75,7 +75,7 @@ class OnlineTrans(torch.nn.Module):
         trans="had" the two then run as ONE launch and a PackedQuantizedTensor comes back (the Quantizer passes packed
         inputs through, quantization.py:14), bit-identical to calling them one after the other on the FWHT route, to rounding noise
         on the matrix-pipe routes. Quantizer(lac=True): every width; Quantizer(lac=False) (the reference's options.trans == "had"
-        model): the widths of the structured kernel (ops.had_mfma_supported), two launches elsewhere."""
+        model): the widths of the structured kernel and of the tall Kronecker kernel (ops.hadamard_quantizer), two launches elsewhere."""
         if up is not None and norm is not None:
             raise RuntimeError("OnlineTrans: up= and norm= are exclusive")
         if self.trans == "had":
@@ -89,14 +89,15 @@ class OnlineTrans(torch.nn.Module):
             if (quantizer is not None and not getattr(quantizer, "lac", False) and not self.fp32_trans and x.dtype == torch.float16
                     and x.is_cuda and self.had_rem_dim is not None and float(quantizer.input_clip_ratio) > 0.0):
                 # Quantizer(lac=False): the pair the reference's options.trans == "had" model builds (modeling_llama.py:244-252). One launch
-                # on the structured kernel where it covers the width (14336, 28672, ...): fp16(max|y| / 7) * ratio, no zero guard, scales of
-                # the reference's shape [..., 1, seq] (quantization.py:30); the other widths run the two launches below
+                # where a fused route covers the width (the structured kernel: 14336, 28672, ...; the tall Kronecker kernel: 11008, 8960, ...):
+                # fp16(max|y| / 7) * ratio, no zero guard, scales of the reference's shape [..., 1, seq] (quantization.py:30); the other
+                # widths run the two launches below
                 from ... import ops
                 from .. import PackedQuantizedTensor
-                if ops.had_mfma_supported(x.shape[-1], self.rem_dim):
-                    q, s, _ = ops.hadamard_quantizer_mfma(x.contiguous(), self.rem_dim, self.had_rem_dim, float(quantizer.input_clip_ratio),
-                                                          up=None if up is None else up.contiguous())
-                    return PackedQuantizedTensor(q, s.reshape(x.shape[:-1]).unsqueeze(1))
+                qs = ops.hadamard_quantizer(x.contiguous(), self.rem_dim, self.had_rem_dim, float(quantizer.input_clip_ratio),
+                                            up=None if up is None else up.contiguous())
+                if qs is not None:
+                    return PackedQuantizedTensor(qs[0], qs[1].reshape(x.shape[:-1]).unsqueeze(1))
             if up is not None:
                 from ... import ops
                 x = ops.silu_mul(x.contiguous(), up.contiguous())

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import (FQ_EUNSUPPORTED, FQ_GROUP128, FQ_MAX_CLIPS, FQ_NO_CLAMP0, FQ_OUT_FAKEQUANT, FQ_OUT_PACKED,
-                   FQ_OUT_TRANSFORM, FQ_QUANT_F16, FQ_ROUND_Y_F16, FQ_SIG_F16, FQ_WS_PREPARED, check, lib)
+                   FQ_OUT_TRANSFORM, FQ_QUANT_F16, FQ_RATIO_POST, FQ_ROUND_Y_F16, FQ_SIG_F16, FQ_WS_PREPARED, check, lib)
 
 Sig = Tuple[float, float]  # (sigmoid(clip_factor_a_max), sigmoid(clip_factor_a_min)); (1.0, 1.0) = no clip
 
@@ -933,6 +933,30 @@ def hadamard_quantizer_mfma(x: torch.Tensor, K: int, hadK: torch.Tensor, input_c
             check(lib.fq_hadamard_quantizer_mfma_f16(_ptr(x), _ptr(up), rows, n, K, _ptr(hadK), ctypes.c_float(scale),
                                                      ctypes.c_float(float(input_clip_ratio)), _ptr(q), _ptr(s), _ptr(y), _stream(x)))
     return q, s, y
+
+
+def hadamard_quantizer(x: torch.Tensor, K: int, hadK: Optional[torch.Tensor], input_clip_ratio: float = 1.0,
+                       up: Optional[torch.Tensor] = None):
+    """The online Hadamard rotation in front of deploy.nn.Quantizer(input_clip_ratio, lac=False) as ONE launch where a fused route
+    exists — the structured kernel (hadamard_quantizer_mfma: 14336, 28672, ...) or the tall Kronecker kernel with FQ_RATIO_POST
+    (n = K' * 64 pairs: 11008 = 172 x 64, 8960, 5120 ...; ``up`` is multiplied in by its own launch there). -> (q, scales [rows])
+    or None when the width has neither (the caller runs the rotation and the Quantizer one after the other)."""
+    n = x.shape[-1]
+    if K <= 1 or hadK is None or x.dtype != torch.float16 or not x.is_cuda or x.numel() == 0 or n % K:
+        return None
+    if had_mfma_supported(n, K):
+        q, s, _ = hadamard_quantizer_mfma(x, K, hadK, input_clip_ratio, up=up)
+        return q, s
+    kr = _hadamard_as_kron(K, n // K, hadK, x.device)
+    if kr is None or kr[2] != 64 or not 64 < kr[0].shape[0] <= 192:
+        return None
+    left, right, N = kr
+    if up is not None:
+        x = silu_mul(x, up)
+    rows = x.numel() // n
+    o = kron_quant_ex(x.reshape(rows, n), left, right, _had_right_div(N) * float(1.0 / torch.tensor(n).sqrt()),
+                      [(float(input_clip_ratio), 1.0)], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_ROUND_Y_F16 | FQ_RATIO_POST)
+    return o.q[0].reshape(x.shape[:-1] + (n // 2,)), o.scale[0].reshape(-1)
 
 
 def hadamard(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None,

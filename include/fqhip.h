@@ -98,7 +98,11 @@ extern "C" {
                                    deploy/nn/quantization.py:30, deploy/functional/online_trans.py:106:
                                    scale = fp16( fp32( fp16(max|x| / 7) * ratio ) ): the product in torch's float opmath, then
                                    rounded to fp16 (what the CPU computes for an fp16 tensor times a python scalar); sig_max
-                                   carries the ratio; an all-zero row gets scale 0 like the reference's (digits 0 either way) */
+                                   carries the ratio; an all-zero row gets scale 0 like the reference's (digits 0 either way).
+                                   Also taken by fq_kron_quant_ex_f16 with FQ_OUT_PACKED [| FQ_OUT_TRANSFORM] | FQ_QUANT_F16 |
+                                   FQ_ROUND_Y_F16 on 64 < M <= 192, N = 64 (the tall kernel: a Hadamard rotation of n = K' x 64 — 11008 —
+                                   in front of Quantizer(lac=False), deploy/transformers/modeling_llama.py:244-252, as one launch);
+                                   FQ_EUNSUPPORTED on every other pair; the n = K * 512 / K * 1024 widths: fq_hadamard_quantizer_mfma_f16 */
 
 #define FQ_MAX_CLIPS 4
 

@@ -190,6 +190,43 @@ def test_online_trans_with_quantizer_argument(ops):
     assert qz(fused) is fused   # the Quantizer passes packed inputs through
 
 
+@pytest.mark.parametrize("n,K", [(11008, 172), (8960, 140), (5120, 40)])
+def test_plain_quantizer_behind_the_tall_kronecker_launch(ops, n, K):
+    """deploy.nn.Quantizer(input_clip_ratio, lac=False) behind the rotation of an n = K' x 64 width (the reference's options.trans == "had"
+    model on Llama-2-7B: modeling_llama.py:244-252) as ONE launch: fq_kron_quant_ex_f16 with FQ_RATIO_POST on the tall kernel — digits and
+    scales == the Quantizer module applied to the transform the same launch returns; an all-zero token keeps scale 0; other pairs refuse."""
+    import flatquant_amd.deploy as deploy
+    from flatquant_amd import _lib
+    from flatquant_amd._lib import FQ_OUT_PACKED, FQ_OUT_TRANSFORM, FQ_QUANT_F16, FQ_RATIO_POST, FQ_ROUND_Y_F16
+    g = torch.Generator().manual_seed(n + 5)
+    rows = 37
+    x = torch.randn(rows, n, generator=g).half()
+    x[:, ::61] *= 9
+    x[4] = 0
+    x = x.cuda()
+    hk = torch.from_numpy(hadk_matrix(K)).cuda()
+    left, right, N = ops._hadamard_as_kron(K, n // K, hk, x.device)
+    assert N == 64
+    scale = ops._had_right_div(N) / float(torch.tensor(float(n)).sqrt())
+    fl = FQ_QUANT_F16 | FQ_ROUND_Y_F16 | FQ_RATIO_POST
+    for ratio in (1.0, 0.9):
+        o = ops.kron_quant_ex(x, left, right, scale, [(ratio, 1.0)], FQ_OUT_PACKED | FQ_OUT_TRANSFORM | fl)
+        p = deploy.nn.Quantizer(input_clip_ratio=ratio).cuda()(o.y)
+        assert torch.equal(p.quantized_x, o.q[0]) and torch.equal(p.scales_x.reshape(-1), o.scale[0].reshape(-1)), (n, ratio)
+        assert float(o.scale[0].reshape(-1)[4]) == 0.0 and not o.q[0][4].any()
+        q, s = ops.hadamard_quantizer(x, K, hk, ratio)
+        assert torch.equal(q, o.q[0]) and torch.equal(s, o.scale[0].reshape(-1))
+    t = deploy.nn.OnlineTrans(n, trans="had").cuda()
+    if t.rem_dim == K:
+        fused = deploy.nn.FusedSequential(t, deploy.nn.Quantizer(lac=False).cuda())(x[:36].reshape(2, 18, n))
+        q, s = ops.hadamard_quantizer(x[:36].contiguous(), K, hk, 1.0)
+        assert fused.scales_x.shape == (2, 1, 18) and torch.equal(fused.quantized_x.reshape(36, -1), q)
+        assert torch.equal(fused.scales_x.reshape(-1), s)
+    with pytest.raises(_lib.FqError):                              # a pair of another kernel: refused, not silently guarded
+        l2, r2, _ = ops._hadamard_as_kron(28, 512, torch.from_numpy(hadk_matrix(28)).cuda(), x.device)
+        ops.kron_quant_ex(torch.zeros(2, 14336, dtype=torch.float16, device="cuda"), l2, r2, 1.0, [(1.0, 1.0)], FQ_OUT_PACKED | fl)
+
+
 @pytest.mark.parametrize("n", [14336, 28672, 11008, 4096])
 def test_fused_sequential_is_the_sequential_with_one_launch(ops, n):
     """deploy.nn.FusedSequential(*seq): the reference's down_proj = Sequential(OnlineTrans(had), Quantizer, ...)
