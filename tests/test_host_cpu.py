@@ -60,6 +60,15 @@ def test_abi_argument_validation_without_gpu():
     assert lib.fq_kron_multi_prepare(None, 2, vp, 4096, None) == FQ_EINVAL                                              # no jobs
     assert lib.fq_hadamard_quant_mfma_f16(vp, 4, 14336, 28, vp, ctypes.c_float(1.0), ctypes.c_float(1.0), ctypes.c_float(1.0), None, None,
                                           None, None) == FQ_EINVAL                                                       # no output
+    one = ctypes.c_float(1.0)
+    assert lib.fq_silu_mul_hadamard_quant_mfma_f16(vp, vp, 4, 14336, 28, vp, one, one, one, None, None, None) == FQ_EINVAL   # no output
+    assert lib.fq_silu_mul_hadamard_quant_mfma_f16(vp, None, 4, 14336, 28, vp, one, one, one, vp, vp, None) == FQ_EINVAL     # no up
+    assert lib.fq_hadamard_quantizer_mfma_f16(vp, None, 4, 14336, 28, vp, one, ctypes.c_float(0.0), vp, vp, None, None) == FQ_EINVAL   # ratio
+    assert lib.fq_hadamard_quantizer_mfma_f16(vp, vp, 4, 14336, 28, vp, one, one, vp, vp, vp, None) == FQ_EINVAL             # up with y_out
+    assert lib.fq_hadamard_quantizer_mfma_f16(vp, None, 0, 14336, 28, vp, one, one, vp, vp, None, None) == 0                 # empty
+    # FQ_RATIO_POST behind a Kronecker launch: the tall kernel's pairs only (0x10000 | packed | fp16 quantiser | rounded Y)
+    assert lib.fq_kron_quant_ex_f16(vp, None, vp, vp, 4, 112, 128, one, f4, f4, 1, 0x10000 | 0x01 | 0x20 | 0x08, a4, a4, a4, None, vp, 1 << 20,
+                                    None) == FQ_EUNSUPPORTED
     assert lib.fq_kron_workspace_bytes(64, 64) == 32768                   # optional at 64 x 64 (NULL still works)
     assert lib.fq_kron_workspace_bytes(128, 224) == (7 * 14 + 2 * 4 * 4) * 1024
     assert lib.fq_kron_workspace_bytes(60, 63) == FQ_EUNSUPPORTED          # odd N: nothing to pack two per byte
@@ -84,6 +93,17 @@ def test_ops_reject_cpu_tensors_loudly():
                  lambda: ops.int4_linear_fp6_multi([(q, torch.ones(256).half(), q, None, torch.ones(256).half(), None)])):
         with pytest.raises(RuntimeError, match="no CPU path"):
             call()
+    # late round 4: the structured Hadamard kernel's K * 1024 shapes, its SiLU.mul input, the plain Quantizer behind the rotation
+    from tests.conftest import hadk_matrix
+    hk = torch.from_numpy(hadk_matrix(28))
+    xh = torch.zeros(2, 28672, dtype=torch.float16)
+    assert ops.had_mfma_supported(14336, 28) and ops.had_mfma_supported(28672, 28) and ops.had_mfma_supported(12288, 12)
+    assert not ops.had_mfma_supported(32768, 32) and not ops.had_mfma_supported(11008, 172) and not ops.had_mfma_supported(57344, 28)
+    for call in (lambda: ops.hadamard_mfma(xh, 28, hk), lambda: ops.hadamard_mfma(xh, 28, hk, (1.0, 1.0), want_y=False, up=xh),
+                 lambda: ops.hadamard_quantizer_mfma(xh, 28, hk, 0.9), lambda: ops.hadamard_quant(xh, 28, hk, (1.0, 1.0), up=xh)):
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            call()
+    assert ops.hadamard_quantizer(xh, 28, hk, 1.0) is None     # (a CPU tensor has no fused route: the caller's two modules follow, and refuse)
     with pytest.raises(ValueError):
         ops.int4_linear_fp6_multi([])
     from flatquant_amd.flatquant.quant_utils import ActivationQuantizer
@@ -148,6 +168,13 @@ def test_module_surfaces_match_reference_names():
     assert [k for k, _ in t.named_buffers()] == ["right_matrix", "clip_factor_a_max", "clip_factor_a_min"]
     q = deploy.nn.Quantizer(lac=True)
     assert float(q.clip_factor_a_max) == 4.0 and float(q.clip_factor_a_min) == 4.0
+    # FusedSequential: the reference's down_proj = Sequential(OnlineTrans, Quantizer, Linear4bit) (modeling_llama.py:248-253) with the same
+    # children and state-dict keys
+    import torch as _t
+    seq = _t.nn.Sequential(deploy.nn.OnlineTrans(11008, trans="had"), deploy.nn.Quantizer(lac=False), deploy.nn.Linear4bit(11008, 4096))
+    fused = deploy.nn.FusedSequential(*seq)
+    assert list(fused.state_dict().keys()) == list(seq.state_dict().keys()) and fused[0] is seq[0] and fused[2] is seq[2]
+    assert seq[0].rem_dim == 172 and tuple(seq[0].had_rem_dim.shape) == (172, 172)
     p = deploy.PackedQuantizedTensor(torch.zeros(2, 3, dtype=torch.uint8), torch.ones(2, 1).half())
     assert p.size() == (2, 3) and p.dtype == torch.uint8 and p.device.type == "cpu"
     assert q(p) is p
