@@ -376,6 +376,18 @@ def sym_quant(x16, scale16):
     return pack_i4(t)
 
 
+def quantizer_plain(x16, input_clip_ratio=1.0):
+    """deploy.nn.Quantizer(input_clip_ratio, lac=False).forward on an fp16 [rows, cols] activation (deploy/nn/quantization.py:30-33):
+    scales = (max|x| / 7).to(fp16) * ratio — the division and the product each rounded to fp16 (an fp16 tensor times a python
+    scalar: the product formed in fp32 opmath, what the CPU evaluates) — with NO zero guard (an all-zero row keeps scale 0), then
+    deploy.sym_quant (quant.cu:13-47: 0 / 0 -> NaN -> digit 0). -> (packed uint8 [rows, cols/2], scales fp16 [rows])."""
+    x = np.asarray(x16, dtype=F16)
+    m = np.abs(x.astype(F32)).max(axis=-1)
+    s = (m / F32(7)).astype(F16)
+    s = (s.astype(F32) * F32(input_clip_ratio)).astype(F16)
+    return sym_quant(x, s), s
+
+
 def sym_dequant(q32, scale_row16, scale_col16):
     """quant.cu:5-10,66-85: x = s_row * s_col * half(int(q/10.0f)) * half(10), fp16 products left to right."""
     q32 = np.asarray(q32, dtype=np.int32)

@@ -122,6 +122,8 @@ def test_plain_quantizer_in_the_same_launch(ops, n, K):
         p = deploy.nn.Quantizer(input_clip_ratio=ratio).cuda()(y)
         assert torch.equal(p.quantized_x, q) and torch.equal(p.scales_x.reshape(-1), s), (n, K, ratio)
         assert float(s[5]) == 0.0 and not q[5].any()
+        pk, so = O.quantizer_plain(y.cpu().numpy(), ratio)               # the oracle's restatement of quantization.py:30 + quant.cu
+        assert np.array_equal(q.cpu().numpy(), pk) and np.array_equal(s.cpu().numpy(), so), (n, K, ratio)
         q2, s2, _ = ops.hadamard_quantizer_mfma(x, K, hk, ratio)          # the packed-only instantiation
         assert torch.equal(q2, q) and torch.equal(s2, s)
         q3, s3, _ = ops.hadamard_quantizer_mfma(gate, K, hk, ratio, up=up)

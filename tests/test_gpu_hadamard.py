@@ -214,6 +214,8 @@ def test_plain_quantizer_behind_the_tall_kronecker_launch(ops, n, K):
         p = deploy.nn.Quantizer(input_clip_ratio=ratio).cuda()(o.y)
         assert torch.equal(p.quantized_x, o.q[0]) and torch.equal(p.scales_x.reshape(-1), o.scale[0].reshape(-1)), (n, ratio)
         assert float(o.scale[0].reshape(-1)[4]) == 0.0 and not o.q[0][4].any()
+        pk, so = O.quantizer_plain(o.y.cpu().numpy(), ratio)             # the oracle's restatement of quantization.py:30 + quant.cu
+        assert np.array_equal(o.q[0].cpu().numpy(), pk) and np.array_equal(o.scale[0].cpu().numpy().reshape(-1), so), (n, ratio)
         q, s = ops.hadamard_quantizer(x, K, hk, ratio)
         assert torch.equal(q, o.q[0]) and torch.equal(s, o.scale[0].reshape(-1))
     t = deploy.nn.OnlineTrans(n, trans="had").cuda()

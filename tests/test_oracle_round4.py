@@ -75,3 +75,22 @@ def test_activation_quantizer_other_bit_widths_vs_reference(golden):
             assert np.array_equal(O.bf16_bits(got), g[key + "_y"]), key
         n += 1
     assert n == 120
+
+
+def test_plain_quantizer_restatement_matches_torch_cpu():
+    """oracle.quantizer_plain (deploy/nn/quantization.py:30: Quantizer(input_clip_ratio, lac=False)) against the same expression evaluated by
+    torch on the CPU, and its digits against the quant.cu restatement the reference-pinned sym_quant tests use; an all-zero row keeps
+    scale 0 and packs zeros (the reference has no guard on this branch)."""
+    import torch
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(64, 512, generator=g) * 3).half()
+    x[7] = 0
+    x[9, 3] = 60000.0
+    for ratio in (1.0, 0.9, 0.83):
+        packed, s = O.quantizer_plain(x.numpy(), ratio)
+        want = (torch.max(torch.abs(x), dim=-1)[0].unsqueeze(1) / 7).to(torch.float16) * ratio
+        assert np.array_equal(s, want.reshape(-1).numpy())
+        assert s[7] == 0 and not packed[7].any()
+        live = np.arange(64) != 7
+        assert np.array_equal(packed[live], O.sym_quant(x.numpy()[live], s[live]))
+
