@@ -493,6 +493,11 @@ def test_hot_kernels_keep_their_occupancy_budget():
         "fq_kron_tiles_kernel<5,6,192,2,9,1,f16>": (3, 0),     # 144 x 192, R streamed
         "fq_kron_tiles_kernel<4,4,128,3,7,0,bf16>": (3, 0),    # bf16 112 x 128
         "fq_kron_tall_kernel<6,1,0>": (3, 0),                   # Hadamard 11008 + Quantizer
+        "fq_had512_kernel<4,3,1,0,0>": (3, 0),                  # structured Hadamard 14336 + Quantizer (C3's dominant launch): three token groups per CU
+        "fq_had512_kernel<4,3,1,0,1>": (3, 0),                  # ... with the SiLU.mul input (28 more VGPRs: still three waves per SIMD)
+        "fq_had512_kernel<4,3,0,1,0>": (3, 0),                  # ... rotation only (matmul_hadU_cuda)
+        "fq_had512_kernel<8,2,1,0,0>": (2, 0),                  # 28672 = 28 x 1024: two token groups per CU
+        "fq_had512_kernel<8,2,1,0,1>": (2, 0),
         "fq_kron_wave_kernel<2,3,5,12,0,f16,1>": (3, 0),          # 64 x 80, 12 waves per CU
         "fq_kron_wave_kernel<2,4,8,7,1,f16,1>": (2, 0),         # 64 x 128 with the RMSNorm fused in front (C4's q/k/v and up/gate)
         "fq_kron_wave_kernel<2,4,7,8,1,f16,1>": (2, 0),         # 64 x 112 ... (DeepSeek-V3 hidden)
