@@ -48,13 +48,14 @@ elif op == "kron32x64g":
     offs = torch.linspace(0, rows, G + 1, device=dev).long()
     sm = torch.full((G,), 0.98, device=dev)
     fn = lambda i: ops.kron_quant_grouped(xs[i % 2], L, R, offs, sm, sm, P)
-elif op in ("hadq14336", "hadq11008", "hadq11008fwht"):
+elif op in ("hadq14336", "hadq11008", "hadq11008fwht", "hadq28672", "hadq14336silu"):
     from flatquant_amd.flatquant.hadamard_utils import get_hadK
     n = int(op[4:9])
     hk, K = get_hadK(n)
     hk = hk.half().to(dev).contiguous()
-    xs = [act(16384, n) for _ in range(2)]
-    fn = lambda i: ops.hadamard_quant(xs[i % 2], K, hk, SIG[0], fwht_route=op.endswith("fwht"))
+    xs = [act(16384 if n < 20000 else 8192, n) for _ in range(2)]
+    ups = [act(16384, n) for _ in range(2)] if op.endswith("silu") else None   # (the SiLU.mul input: x_gate and up)
+    fn = lambda i: ops.hadamard_quant(xs[i % 2], K, hk, SIG[0], fwht_route=op.endswith("fwht"), up=None if ups is None else ups[i % 2])
 elif op.startswith("rowq"):
     d = int(op[4:])
     xs = [act(16384, d) for _ in range(2)]
