@@ -55,6 +55,11 @@ typedef __attribute__((address_space(3))) void hm_lds_void;
 #define HM_COPY_LATE 0   // 1: the copy-out behind phase A (after the A|B meeting) instead of in front of it: its stores then queue behind the next
                          //    token's DMA requests instead of in front of them
 #endif
+#ifndef HM_YSTAGE
+#define HM_YSTAGE 0      // 1 (rotation-only launches; PREPARED, NOT YET RUN on a GPU: end of round 4): the rotated token staged through the group's own token
+                         //    buffer and written as 1 KB-contiguous stores (the ablation builds put the 32-byte pieces of the direct stores at 130 of 206 us).
+                         //    The next token's DMA is deferred: every wave copies out exactly the 1 KB slots its own DMA instructions refill, requests them, then stores.
+#endif
 #ifndef HM_NGROUPS
 #define HM_NGROUPS 3   // token groups per CU (4: sixteen waves, needs <= 128 VGPRs)
 #endif
@@ -183,7 +188,8 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
     // This wave's share of token k's DMA: instructions [d0, d0 + dn). Instruction i fills the LDS rows 4 i .. 4 i + 3 linearly; lane l
     // (row 4 i + l / 16, position l % 16) fetches the chunk that the swizzle maps there: position ^ (row / NA & 15) = l % 16 ^ (i >> KEY_SHIFT & 15)
     // — keyed on row / NA because an A fragment reads the rows NA c + a of 32 lanes c: their positions must differ with c.
-    constexpr int MAXDN = SILU ? (NA == 8 ? 14 : 8) : 1;   // DMA instructions of a wave per token (K <= 32 | K <= 28)
+    constexpr bool YSTAGE = HM_YSTAGE && YOUT && !QUANT && !SILU;
+    constexpr int MAXDN = (SILU || YSTAGE) ? (NA == 8 ? 14 : 8) : 1;   // DMA instructions of a wave per token (K <= 32 | K <= 28)
     u32x4 UP[MAXDN];                                       // SILU: the matching 16-byte chunks of `up`, one per DMA instruction
     auto stage_token = [&](int k) {
         const unsigned char* src = xb + (blk_base + k) * tok_bytes;
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
         HM_MEET()   // A|B: the group has read its token buffer
         const int knext = __builtin_amdgcn_readfirstlane((int)hm_lds_read(ctl_lds + CLAIM + grp * 4));
         const bool more = !(HM_ABL & 16) && knext < blk_cnt && dn > 0;
-        if (more) stage_token(knext);
+        if (more && !YSTAGE) stage_token(knext);
         // (HM_COPY_LATE: the previous token's image is still intact — this token's staging writes come after the B|C meeting)
         if (QSTAGE && HM_COPY_LATE && q_pending >= 0 && q_pending != tok && !(HM_ABL & 8)) q_copy_out(q_pending);
         f32x16 Y[NA];   // Y^T of (column block wq, row tile a'): register r of lane (h, c) = column 32 wq + 16 h + r of row (a', k' = c)
@@ -401,6 +407,51 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
                     pk[a].y = fq_quant8_h16<false>(H[a][4], H[a][5], H[a][6], H[a][7], rc);
                 }
             }
+        }
+        if (YSTAGE) {
+            // the token buffer has been free since the A|B meeting (the DMA was not requested): the rotation goes into it in the token's own
+            // memory layout, chunk index XOR (c & 15) as the input's (a lane's two chunks of row NA c + a': positions 4 wq + 2 h, + 1)
+            int lq = lane;
+            asm volatile("" : "+v"(lq));
+            const int cq = lq & 31, hq = lq >> 5;
+            u32x4* tb = reinterpret_cast<u32x4*>(tokbuf) + cq * (NA * 16);
+            if (cq < K) {
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    tb[a * 16 + ((4 * wq + 2 * hq) ^ (cq & 15))] = u32x4{H[a][0], H[a][1], H[a][2], H[a][3]};
+                    tb[a * 16 + ((4 * wq + 2 * hq + 1) ^ (cq & 15))] = u32x4{H[a][4], H[a][5], H[a][6], H[a][7]};
+                }
+            }
+            HM_MEET()   // S: the rotated token is complete in LDS
+            // slot 64 i + lane of this wave's DMA instruction i holds chunk (row 4 i + lane / 16, position lane % 16 ^ key) of the token — the
+            // source offset `rv` of that instruction: read the slots, request the next token INTO them, then store (1 KB of contiguous bytes per
+            // instruction); the counted wait leaves exactly those stores in flight
+            const int lb = lq & 48, lp = lq & 15;
+            const u32x4* slots = reinterpret_cast<const u32x4*>(tokbuf) + lq;
+#pragma unroll
+            for (int j = 0; j < MAXDN; ++j)
+                if (j < dn) UP[j] = slots[(d0 + j) * 64];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (more) stage_token(knext);
+            unsigned char* ytok = reinterpret_cast<unsigned char*>(y_out) + tok * tok_bytes;
+#pragma unroll
+            for (int j = 0; j < MAXDN; ++j)
+                if (j < dn && !(HM_ABL & 8)) {
+                    const int i = d0 + j;
+                    const unsigned rv = (unsigned)((lb + (lp ^ ((i >> G::KEY_SHIFT) & 15))) << 4);
+                    *reinterpret_cast<u32x4*>(ytok + (size_t)i * 1024 + rv) = UP[j];
+                }
+            // (the stores are younger than the DMA: vmcnt counts in issue order. A counted wait on a run-time count needs an immediate: one
+            //  instruction per possible count)
+            switch (dn) {
+                case 0: break;
+#define HM_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+                HM_W(1) HM_W(2) HM_W(3) HM_W(4) HM_W(5) HM_W(6) HM_W(7) HM_W(8) HM_W(9) HM_W(10) HM_W(11) HM_W(12) HM_W(13) HM_W(14)
+#undef HM_W
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+            k = knext;
+            continue;
         }
         // the DMA of the group's next token is waited for HERE, in front of the stores (which are never waited for)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

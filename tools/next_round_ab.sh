@@ -1,12 +1,14 @@
 #!/bin/bash
 # A/B builds prepared at the end of round 4 (no GPU budget was left to time them). On the container:
-#   SRC=fq_had_mfma.hip tools/variants.sh hmnt:"-DHM_COPY_NT=1" hmlate:"-DHM_COPY_LATE=1" hmntlate:"-DHM_COPY_NT=1 -DHM_COPY_LATE=1"
+#   SRC=fq_had_mfma.hip tools/variants.sh hmnt:"-DHM_COPY_NT=1" hmlate:"-DHM_COPY_LATE=1" hmntlate:"-DHM_COPY_NT=1 -DHM_COPY_LATE=1" hmystage:"-DHM_YSTAGE=1"
+# (hmystage: the rotation-only launches with the rotated token staged through the group's own buffer — written but never run on a GPU: run its parity first,
+#  FQHIP_LIB=variants/libfqhip_hmystage.so python -m pytest tests/test_gpu_had_mfma.py tests/test_gpu_hadamard.py -q -m gpu)
 # then, through gpurun (about 40 s of box time):
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/next_ab; mkdir -p $O
 export TIME_HAD_FAST=1
 for rep in 1 2; do
-for lib in default hmnt hmlate hmntlate; do
+for lib in default hmnt hmlate hmntlate hmystage; do
   if [ "$lib" = default ]; then unset FQHIP_LIB; else export FQHIP_LIB=variants/libfqhip_$lib.so; fi
   [ "$lib" = default ] || [ -f "$FQHIP_LIB" ] || continue
   echo "== $lib"
