@@ -10,6 +10,10 @@ HBM; buffers rotate over > 256 MiB so the Infinity Cache cannot serve the stream
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C2S|C1|C3|C4|C4H|C5] [--dtype f16|bf16]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
 
+`--gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset) LAUNCHES the N ranks itself (`launch_ranks`: one process per
+GPU under torch.distributed.run on 127.0.0.1 with a free port, RCCL) and fails loudly when the box has fewer than N GPUs; under
+an external launcher `--gpus` must equal WORLD_SIZE. Either way stdout is exactly one JSON line with `n_gpus == N`.
+
 --config (the other BASELINE.json configs; one "element" = one input activation scalar of one (token, linear) unit):
   C1  the FlatQuantizedLinear contract of BASELINE configs[0] (flat_linear.py:75-80: per-token W4A4 FAKE-quant of the
       transformed activation, fp16 / bf16 out, 16 KB per token) at C2's size: 64x64 factors, 8 x 2048 tokens per GPU, one
@@ -594,9 +598,93 @@ def sub_record(cls, steps, warmup, device, rank, world, sharding, dist, force=Fa
     return rec
 
 
-def main():
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, script=None, timeout=None):
+    """`bench.py --gpus N` without a launcher around it: start the N ranks ourselves, one process per GPU, the way the reference starts
+    its multi-GPU path with an explicit launcher (scripts/deepseek/deepseek-v3/w4a4kv4.sh:7 `torchrun --nproc-per-node ...`,
+    main_dpskv3.py:390 reading WORLD_SIZE / RANK / LOCAL_RANK). Re-executes this script under torch.distributed.run on 127.0.0.1 with a
+    free port; the children inherit stdout, rank 0 writes the ONE JSON line there. Returns the launcher's exit code (non-zero when any
+    rank failed: torch.distributed.run tears the others down)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "8")                    # torch.distributed.run otherwise sets 1 (with a warning): the cpu legs want threads
+    return subprocess.run(cmd, env=env, timeout=timeout).returncode
+
+
+def resolve_world(gpus, environ, device_count):
+    """What `--gpus` means given the environment -> ("single" | "ranks" | "launch", world). Raises SystemExit with a clear message when
+    the request cannot be honoured: N ranks asked for under a launcher that started a different number, or more GPUs than the box has."""
+    ws = environ.get("WORLD_SIZE")
+    if ws is not None:                                        # under torch.distributed.run (the driver's N > 1 form) or any launcher
+        world = int(ws)
+        if gpus is not None and gpus != world:
+            raise SystemExit(f"bench.py: --gpus {gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
+        return ("ranks" if world > 1 else "single"), world
+    n = 1 if gpus is None else gpus
+    if n < 1:
+        raise SystemExit(f"bench.py: --gpus {n}: need at least one GPU")
+    if n == 1:
+        return "single", 1
+    have = device_count()
+    if have < n:
+        raise SystemExit(f"bench.py: --gpus {n} asked for but this box has {have} GPU(s) visible; refusing to report n_gpus={n} "
+                         f"from fewer devices")
+    return "launch", n
+
+
+def dry_run(args, world, rank):
+    """--dry-run: the N > 1 plumbing WITHOUT a GPU (tests/test_host_cpu.py drives it with world 2): the launcher, the rank environment,
+    the stdout discipline, a gloo group in the place of RCCL, the timed set-up broadcast of the real matrices, the barrier-bracketed
+    timed loop (a no-op step), the MAX / SUM reduction and the one JSON line. No kernel runs: `value` is null and the line says so."""
+    from flatquant_amd import sharding
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    bc = TimedBroadcast(sharding, "cpu")
+    g = torch.Generator().manual_seed(100 + rank)             # only rank 0's values may survive the broadcast
+    mats = bc({"left": torch.randn(M, M, generator=g).half(), "right": torch.randn(N, N, generator=g).half()})
+    g0 = torch.Generator().manual_seed(100)
+    ref = {"left": torch.randn(M, M, generator=g0).half(), "right": torch.randn(N, N, generator=g0).half()}
+    same = all(torch.equal(mats[k], ref[k]) for k in ref)
+    a, b = sharding.shard_rows(ROWS, world, rank)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    wall = time.perf_counter() - t0 + 1e-9
+    if dist is not None:
+        dist.barrier()
+    wall, _, elems, per_rank = reduce_over_ranks(dist, "cpu", wall, 0.0, (b - a) * D)
+    if rank == 0:
+        out = {"metric": "dry run: no kernel was launched", "value": None, "unit": "Melem/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "dry_run": True, "broadcast_ok": bool(same), "elems_all_ranks": elems,
+               "per_rank_ms_per_step": [w * 1e3 / max(1, args.steps) for w in per_rank],
+               "dist": None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size()}}
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one per GPU). N > 1 without WORLD_SIZE in the environment: this process launches the N ranks itself; "
+                         "under a launcher it must equal WORLD_SIZE")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: launcher + gloo group + broadcast + reduction + the JSON line (CPU test)")
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="C2", choices=sorted(WORKLOADS))
@@ -610,7 +698,11 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed clock-settle phase before the counted warm-up: launches of the same step for this "
                          "many milliseconds (reported as settle_launches); 0 disables it")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    mode, world = resolve_world(args.gpus, os.environ, (lambda: 1 << 30) if args.dry_run else torch.cuda.device_count)
+    if mode == "launch":
+        sys.stdout.flush()
+        sys.exit(launch_ranks(world, argv))
     if args.steps is None:
         args.steps = {"C1": 500, "C2": 1000, "C2S": 1000, "C3": 100, "C4": 5, "C4H": 5, "C5": 50, "C2SL": 50}[args.config]
     if args.warmup is None:
@@ -618,9 +710,12 @@ def main():
     if args.dtype != "f16" and args.config not in ("C1", "C2", "C5"):
         ap.error("--dtype bf16 goes with --config C1 / C2 / C5 (C3 / C4 are the deploy configs: fp16 contracts of the reference)")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None

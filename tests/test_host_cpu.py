@@ -1,6 +1,7 @@
 """CPU-only checks: the C-ABI library loads and exports every declared symbol, argument validation, host-side
 helpers, module surfaces (names / buffers / state-dict keys of the reference), row sharding over gloo."""
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -366,6 +367,47 @@ def test_bench_scaling_records_partition_broadcast_reduce_world_size_2_gloo(tmp_
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs), outs
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself_world_size_2_gloo():
+    """`python bench.py --gpus 2` with no launcher around it starts the 2 ranks itself (bench.launch_ranks -> torch.distributed.run on
+    127.0.0.1 with a free port) and stdout is exactly ONE JSON line with n_gpus == 2 == dist.world_size. --dry-run puts a gloo group
+    and a no-op step in the place of RCCL and the kernels; everything else (launcher, rank environment, stdout discipline, set-up
+    broadcast of the matrices, barrier-bracketed loop, MAX / SUM reduction) is the code the GPU run executes."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "4", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dist"] == {"backend": "gloo", "world_size": 2}
+    assert rec["dry_run"] is True and rec["value"] is None and rec["broadcast_ok"] is True
+    assert rec["elems_all_ranks"] == 16384 * 4096 and len(rec["per_rank_ms_per_step"]) == 2      # the two row shards tile the batch
+    assert rec["steps"] == 4 and rec["warmup"] == 1
+
+
+def test_bench_gpus_flag_refuses_what_it_cannot_honour():
+    """--gpus N on a box with fewer than N GPUs exits non-zero with a message (this container has none); under a launcher --gpus must
+    equal WORLD_SIZE; the decision table itself (bench.resolve_world)."""
+    import bench
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode != 0 and r.stdout.strip() == "" and "--gpus 2" in r.stderr and "GPU(s) visible" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "must agree" in r.stderr
+    assert bench.resolve_world(None, {}, lambda: 0) == ("single", 1)
+    assert bench.resolve_world(1, {}, lambda: 0) == ("single", 1)
+    assert bench.resolve_world(8, {}, lambda: 8) == ("launch", 8)
+    assert bench.resolve_world(8, {"WORLD_SIZE": "8"}, lambda: 1) == ("ranks", 8)
+    assert bench.resolve_world(None, {"WORLD_SIZE": "4"}, lambda: 1) == ("ranks", 4)
+    assert bench.resolve_world(1, {"WORLD_SIZE": "1"}, lambda: 1) == ("single", 1)
+    for bad in ((8, {}, lambda: 4), (2, {"WORLD_SIZE": "8"}, lambda: 8), (0, {}, lambda: 8)):
+        with pytest.raises(SystemExit):
+            bench.resolve_world(*bad)
 
 
 def test_oracle_int4_matmul_and_linear4bit():
