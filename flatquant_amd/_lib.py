@@ -15,6 +15,10 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FQHIP_LIB", os.path.join(_HERE, "lib", "libfqhip.so"))  # FQHIP_LIB: A/B builds
+# FQHIP_OVERLAY (measurement only, tools/variants.sh): ':'-separated small shared objects, each ONE kernel file rebuilt with other -D
+# switches. Loaded RTLD_GLOBAL in front of the library, their fq_launch_* definitions take the place of the library's own (its calls
+# between translation units go through the PLT) — a 100 KB object per A/B variant instead of a 13 MB copy of the whole library.
+OVERLAYS = [p for p in os.environ.get("FQHIP_OVERLAY", "").split(":") if p]
 
 # flags (include/fqhip.h)
 FQ_OUT_PACKED = 0x01
@@ -128,6 +132,8 @@ def _load() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `make -C flatquant_amd/csrc` "
             "(needs hipcc, --offload-arch=gfx950). flatquant_amd has no CPU or PyTorch fallback.")
+    for ov in OVERLAYS:
+        ctypes.CDLL(os.path.abspath(ov), mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Shader clock and package power while ONE op of tools/run_op.py runs in a loop (rocm-smi sampled every 0.4 s):
-#   tools/scratch/clock_under_load.sh <op> [seconds]        e.g. gemmbf6, gemmi8, kron64fq, kron128x224, hadq14336
+#   tools/clock_under_load.sh <op> [seconds]        e.g. gemmbf6, gemmi8, kron64fq, kron128x224, hadq14336
+#   FQHIP_OVERLAY=variants/ov_duo3.so tools/clock_under_load.sh kron128x224      an ablation build: W x us per launch = joules per launch
 OP=$1; SEC=${2:-6}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
