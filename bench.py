@@ -567,6 +567,8 @@ def capture_graphs(wl, device):
     for j in range(wl.graph_inputs):
         wl.step(j)
         torch.cuda.synchronize()
+        from flatquant_amd import ops
+        ops.images_ready()          # the warm-up's fragment images are complete: the captured launches share them (no prepare kernel in the graph)
         gph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gph):
             wl.step(j)

@@ -69,7 +69,7 @@ def invalidate_caches() -> None:
     _sigmoid_pair_cached.cache_clear()
     _sig_f16_cached.cache_clear()
     _WS_LRU.clear()
-    _WS_ANY.clear()
+    _WS_ANY.clear()     # (_WS_PINNED stays: a captured graph replays the pointers it was given, see _pin_for_capture)
     _HAD_KRON.clear()
     from .flatquant.trans_utils import _Fp16Cache   # the modules' fp16 / bf16 copies of their (fp32) matrices
     _Fp16Cache.clear_all()
@@ -242,6 +242,31 @@ _WS_LRU_MAX_BYTES = 256 << 20   # and by bytes: a caller that re-stacks per-expe
 
 _WS_BYTES: dict = {}   # fq_kron_workspace_bytes(M, N): a pure function of the pair
 _WS_ANY: dict = {}     # the same images by (device, M, N, left, right) WITHOUT the stream: (ws, left, right, [complete], event of the preparing launch)
+_WS_ANY_MAX_BYTES = _WS_LRU_MAX_BYTES
+# Images handed to a launch issued UNDER STREAM CAPTURE: the graph holds the raw pointer (FQ_WS_PREPARED, no prepare kernel of its own)
+# for as long as it is replayed, so the cache may never free them — not on an LRU / byte-bound eviction, not on invalidate_caches()
+# (a load_state_dict hook of ANY module calls that). id(workspace) -> (workspace, left, right). Bounded by what graphs were captured.
+_WS_PINNED: dict = {}
+
+
+def _pin_for_capture(ent) -> None:
+    if torch.cuda.is_current_stream_capturing():
+        _WS_PINNED.setdefault(id(ent[0]), (ent[0], ent[1], ent[2]))
+
+
+def images_ready() -> int:
+    """Ask the preparing launch of every cached fragment image whether it has completed (an event query each; no wait) -> how many are
+    still pending. Call it after a device / stream synchronisation and BEFORE capturing a graph on another stream: inside a capture no
+    event may be queried, so a captured launch only shares an image already known complete — otherwise it prepares its own image inside
+    the graph (correct, and replayed with every step: the 240 prepare launches of round 4's C4 graph)."""
+    pending = 0
+    for ent in _WS_ANY.values():
+        if not ent[3][0]:
+            if ent[4].query():
+                ent[3][0] = True
+            else:
+                pending += 1
+    return pending
 
 
 def _kron_workspace(device: torch.device, M: int, N: int, left: torch.Tensor, right: torch.Tensor):
@@ -259,11 +284,13 @@ def _kron_workspace(device: torch.device, M: int, N: int, left: torch.Tensor, ri
     ent = _WS_LRU.get(key)
     if ent is not None:
         _WS_LRU.move_to_end(key)
+        _pin_for_capture(ent)
         return ent[0], nbytes, True, key
     # Another stream: an image of the same pair prepared on a DIFFERENT stream is read-only once its preparing launch has completed, and
-    # may then be shared. Under stream capture (torch.cuda.graph synchronises the device on entry: everything issued before is complete)
-    # it is taken as it is — otherwise every captured launch carried its own fq_kron_prepare_kernel into the graph and replayed it every
-    # step (round 4: 240 of them in bench.py's C4 graph, 4 % of C5's step). Outside capture the preparing launch's event is asked.
+    # may then be shared — otherwise every captured launch carried its own fq_kron_prepare_kernel into the graph and replayed it every
+    # step (round 4: 240 of them in bench.py's C4 graph, 4 % of C5's step). Outside capture the preparing launch's event is asked; under
+    # capture (no event may be queried there, and a raw CUDAGraph.capture_begin() does not synchronise the device as torch.cuda.graph
+    # does) only an image ALREADY known complete is shared: ops.images_ready() after the warm-up's synchronise establishes that.
     other = _ws_shared(key)
     if other is not None:
         return other[0], nbytes, True, key
@@ -278,26 +305,36 @@ def _ws_shared(key):
         return None
     done = other[3]
     if not done[0]:
-        if torch.cuda.is_current_stream_capturing() or other[4].query():
+        if torch.cuda.is_current_stream_capturing():
+            return None          # (cannot ask inside a capture; the launch prepares its own image in the capture's pool)
+        if other[4].query():
             done[0] = True
     if not done[0]:
         return None
     _WS_LRU[key] = other[:3]
+    _pin_for_capture(other)
     return other[:3]
 
 
 def _kron_workspace_commit(key, ws: torch.Tensor, left: torch.Tensor, right: torch.Tensor) -> None:
     _WS_LRU[key] = (ws, left, right)
+    _pin_for_capture((ws, left, right))     # (prepared INSIDE a capture: the graph's later launches and its replays read it)
     if not torch.cuda.is_current_stream_capturing():      # (an event recorded inside a capture belongs to the graph)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(ws.device))
         _WS_ANY[key[:1] + key[2:]] = (ws, left, right, [False], ev)
-        if len(_WS_ANY) > 2 * _WS_LRU_MAX:
-            _WS_ANY.pop(next(iter(_WS_ANY)))
+        # the stream-less index keeps its tensors alive too: bounded by count AND by bytes like the LRU (an entry the LRU drops leaves
+        # with it, below), so that re-stacked per-expert matrices — multi-megabyte images whose keys never repeat — cannot pin gigabytes
+        any_total = sum(e[0].numel() for e in _WS_ANY.values()) if ws.numel() > (1 << 20) else 0
+        while len(_WS_ANY) > 2 * _WS_LRU_MAX or (any_total > _WS_ANY_MAX_BYTES and len(_WS_ANY) > 1):
+            any_total -= _WS_ANY.pop(next(iter(_WS_ANY)))[0].numel()
     total = sum(e[0].numel() for e in _WS_LRU.values()) if ws.numel() > (1 << 20) else 0   # (only big images can hit the byte bound)
     while len(_WS_LRU) > _WS_LRU_MAX or (total > _WS_LRU_MAX_BYTES and len(_WS_LRU) > 1):
-        _, ent = _WS_LRU.popitem(last=False)
+        k_old, ent = _WS_LRU.popitem(last=False)
         total -= ent[0].numel()
+        other = _WS_ANY.get(k_old[:1] + k_old[2:])
+        if other is not None and other[0] is ent[0]:
+            del _WS_ANY[k_old[:1] + k_old[2:]]
 
 
 def _group_scales_shape(o: FusedOutputs, lead, groups_per_row: int) -> None:
@@ -663,6 +700,8 @@ def kron_quant_grouped(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor,
             ent = _WS_LRU.get(key)
             if ent is None:
                 ent = _ws_shared(key)      # (prepared on another stream: see _kron_workspace)
+            else:
+                _pin_for_capture(ent)
             prepared = ent is not None
             ws = ent[0] if prepared else torch.empty(per * G, dtype=torch.uint8, device=x.device)
             check(_fn("kron_quant_grouped_mats", dt)(

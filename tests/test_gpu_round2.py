@@ -437,6 +437,7 @@ def test_prepared_fragment_images_are_shared_across_streams_and_graph_capture():
     out = ops.kron_quant(x, L2, R, [(0.98, 0.97)], FQ_OUT_PACKED | FQ_NO_CLAMP0)
     want_q, want_s = out.q[0].clone(), out.scale[0].clone()
     torch.cuda.synchronize()
+    assert ops.images_ready() == 0     # (round 5: inside a capture no event may be asked; completion is established here)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         assert ops._kron_workspace(x.device, M, N, L2, R)[2] is True      # no prepare kernel inside the capture
@@ -445,3 +446,46 @@ def test_prepared_fragment_images_are_shared_across_streams_and_graph_capture():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(cap.q[0], want_q) and torch.equal(cap.scale[0], want_s)
+
+
+def test_captured_launch_keeps_its_fragment_image_alive_through_invalidate_and_eviction():
+    """ A launch issued under stream capture is handed a fragment image the cache owns; the graph replays that raw pointer.
+    invalidate_caches() — also fired by the load_state_dict hook of ANY module — and LRU eviction must not free it: the image is
+    pinned (ops._WS_PINNED). Here: warm-up, images_ready(), capture (the captured launch shares the warm-up's image: no prepare
+    kernel in the graph), then the caches are dropped, the allocator is flooded with same-sized blocks, and the replay must still
+    reproduce the eager result bit for bit. Also: under capture an image whose completion is unknown is NOT shared."""
+    from flatquant_amd import ops
+    rng = np.random.RandomState(81)
+    M, N = 64, 128
+    left = torch.from_numpy((rng.randn(M, M) / 8).astype(np.float16)).cuda()
+    right = torch.from_numpy((rng.randn(N, N) / 11).astype(np.float16)).cuda()
+    x = torch.from_numpy(rng.randn(256, M * N).astype(np.float16)).cuda()
+    ops.invalidate_caches()
+    want = ops.kron_quant(x, left, right)
+    torch.cuda.synchronize()
+    assert ops.images_ready() == 0
+    n_lru = len(ops._WS_LRU)
+    q = torch.empty_like(want.q[0])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        o = ops.kron_quant(x, left, right)
+        q.copy_(o.q[0])
+    assert len(ops._WS_PINNED) >= 1                       # the image the graph was handed
+    assert len(ops._WS_LRU) == n_lru + 1                  # shared under the capture stream's key, not prepared again
+    ops.invalidate_caches()
+    junk = [torch.full_like(w[0], 0xFF) for w in ops._WS_PINNED.values() for _ in range(8)]   # would recycle a freed image's block
+    for _ in range(3):
+        q.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(q, want.q[0])
+    del junk
+    # completion unknown -> no sharing inside a capture (the launch prepares its own image in the graph)
+    ops.invalidate_caches()
+    left2 = left.clone()
+    ops.kron_quant(x, left2, right)                       # eager: registers an image whose event has not been asked yet
+    ent = next(iter(ops._WS_ANY.values()))
+    ent[3][0] = False
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        assert ops._ws_shared((x.device.index, 12345, M, N, left2.data_ptr(), left2._version, right.data_ptr(), right._version)) is None

@@ -37,6 +37,8 @@ def timeit(fn, steps, warm=10, settle_ms=60.0):
         fn()
     if GRAPH:
         torch.cuda.synchronize()
+        from flatquant_amd import ops
+        ops.images_ready()      # the warm-up's fragment images are complete: captured launches share them instead of preparing their own
         gph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gph):
             keep = fn()   # noqa: F841  (outputs stay alive for the replays)
