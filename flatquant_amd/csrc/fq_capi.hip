@@ -573,6 +573,11 @@ static int kron_multi_impl(const char* what, int bf16_dtype, const void* table, 
         return fail(FQ_EUNSUPPORTED, "%s: flags 0x%x (FQ_OUT_PACKED, optionally FQ_NO_CLAMP0)", what, flags);
     if (!(sig_max > 0.0f) || !(sig_min > 0.0f)) return fail(FQ_EINVAL, "%s: sig_max/sig_min must be > 0", what);
     if ((int64_t)n_jobs * wg_per_job > 0x7fffffff) return fail(FQ_EINVAL, "%s: grid too large", what);
+    // the per-job tokens-per-workgroup in the table were baked by fq_kron_multi_prepare for ITS workgroup count (a function of n_jobs
+    // and the device): with fewer workgroups per job than that the tail tokens of every job would silently never be written
+    if (wg_per_job != multi_wg_per_job(n_jobs))
+        return fail(FQ_EINVAL, "%s: wg_per_job=%d but fq_kron_multi_prepare(n_jobs=%d) returned %d for this table", what, wg_per_job, n_jobs,
+                    multi_wg_per_job(n_jobs));
     (void)cu_count();   // (drops a stale error of this thread)
     FqQuantOut o;
     memset(&o, 0, sizeof(o));

@@ -65,6 +65,11 @@ class OnlineTrans(torch.nn.Module):
             self.__dict__["_plan_state"] = st
         return st[7].run(x)
 
+    def _static_ok(self, x):
+        """the prepared launch takes exactly what its plan was built from: a contiguous 3-D CUDA tensor, outside stream capture (a plan
+        built inside a capture would leave its outputs and workspace in the capture's pool while later eager calls reuse it)"""
+        return x.dim() == 3 and x.is_contiguous() and x.is_cuda and not torch.cuda.is_current_stream_capturing()
+
     def forward(self, x, quantizer=None, norm=None, up=None):
         """``up`` (extension, optional): ``x`` is then x_gate and the transform consumes x_up * silu(x_gate)
         (FlatQuantLlamaMLP.forward, modeling_llama.py:277-279) formed inside the launch: trans="matmul" (decomposed)
@@ -105,8 +110,8 @@ class OnlineTrans(torch.nn.Module):
                 # the reference up-casts and returns the fp32 transform (online_trans.py:55-59): the butterflies and the scaling in
                 # fp32 with NO rounding to fp16 (fq_fwht_f32_f16), the fp32 K x K factor as the reference's own GEMM (round 4)
                 from ... import ops
-                if x.dtype != torch.float16:
-                    raise TypeError("OnlineTrans(force_fp32=True): the HIP route takes fp16 activations (their up-cast is exact)")
+                if x.dtype not in (torch.float16, torch.bfloat16):
+                    raise TypeError("OnlineTrans(force_fp32=True): fp16 / bf16 activations (their up-cast is exact)")
                 return ops.hadamard_fp32(x.contiguous(), self.rem_dim, self.had_rem_dim)
             return functional.matmul_hadU_cuda(x, self.had_rem_dim, self.rem_dim)
         if self.trans == "matmul" and norm is not None:
@@ -135,7 +140,7 @@ class OnlineTrans(torch.nn.Module):
                                             functional.online_trans.deploy_kron_flags(self.left_matrix.shape[0], self.right_matrix.shape[0]))
                 return PackedQuantizedTensor(o.q[0].reshape(bsz, seq_len, -1), o.scale[0].reshape(bsz, 1, seq_len))
         if self.static_outputs and self.trans == "matmul" and self.decompose and "left_matrix" in self._buffers and "right_matrix" in self._buffers \
-                and quantizer is None:
+                and quantizer is None and self._static_ok(x):
             return self._planned(x)
         if self.trans == "matmul":
             invs = []

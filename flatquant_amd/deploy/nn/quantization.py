@@ -44,7 +44,7 @@ class Quantizer(torch.nn.Module):
     def forward(self, x):
         if isinstance(x, PackedQuantizedTensor):
             return x
-        if self.static_outputs and x.is_contiguous():
+        if self.static_outputs and x.is_contiguous() and x.is_cuda and not torch.cuda.is_current_stream_capturing():
             return self._planned(x)
         if self.lac:
             # the reference multiplies the fp16 row extrema by a 0-dim fp32 sigmoid, which torch's device kernels load in fp16

@@ -78,11 +78,15 @@ def matmul_hadU_cuda(X, hadK, K):
 def matmul_hadU(X, transpose=False):
     """Normalised Hadamard transform over the last axis.  Reference: hadamard_utils.py:89-110 (python
     butterfly loop + bmm).  fp16 ROCm tensors run the HIP kernel (fp32 butterflies: at least as accurate as
-    the reference's fp16 stages); anything else is not on the inference path and raises."""
+    the reference's fp16 stages); bf16 and fp32 ROCm tensors (round 5; the reference's function takes any float dtype and its own
+    callers feed it fp32 / fp64 weights, hadamard_utils.py:121,128) run the fp32-butterfly kernel on exact fp16 pieces of the input
+    (ops.hadamard_wide) and return X's dtype. CPU tensors and fp64 raise: flatquant_amd has no CPU path."""
     n = X.shape[-1]
     hadK, K = get_hadK(n, transpose)
+    if X.is_cuda and X.dtype in (torch.bfloat16, torch.float32):
+        return ops.hadamard_wide(X, K, None if hadK is None else hadK)
     if not (X.is_cuda and X.dtype == torch.float16):
-        raise TypeError("matmul_hadU: fp16 ROCm tensors only (flatquant_amd has no CPU path)")
+        raise TypeError("matmul_hadU: fp16 / bf16 / fp32 ROCm tensors only (flatquant_amd has no CPU path)")
     return matmul_hadU_cuda(X, hadK, K)
 
 

@@ -9,6 +9,7 @@ from __future__ import annotations
 import collections
 import ctypes
 import functools
+import math
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -1043,11 +1044,17 @@ def hadamard_fp32(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = No
     """matmul_hadU_cuda on x.float() (OnlineTrans(force_fp32=True), deploy/nn/online_trans.py:55-59) -> fp32: the power-of-two
     transform with an fp32 result (fq_fwht_f32_f16: no fp16 rounding anywhere), then — K > 1 — the fp32 K x K factor as the
     reference's own plain GEMM (`hadK.to(input.dtype) @ input`, online_trans.py:148-150). x fp16 (its up-cast is exact)."""
-    _chk(x, "x")
     n = x.shape[-1]
     if n % K:
         raise ValueError("hadamard_fp32: n % K != 0")
     P = n // K
+    if x.is_cuda and x.dtype == torch.bfloat16 and scale is None and 64 <= P <= 8192:
+        return hadamard_wide(x.float(), K, hadK)            # (bf16 models: the up-cast is exact, the transform runs on fp16 pieces of it)
+    _chk(x, "x")
+    if P < 64 or P > 8192:
+        # outside the fp32-result kernel's range (tiny test models: n / K = 32; n / K = 16384): the fp16-result kernel and an up-cast,
+        # what this route was before round 4 (ADVICE r04)
+        return hadamard(x, K, None if hadK is None else hadK.to(device=x.device, dtype=torch.float16).contiguous(), scale).float()
     if scale is None:
         scale = float(1.0 / torch.tensor(n).sqrt())
     y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
@@ -1060,6 +1067,45 @@ def hadamard_fp32(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = No
     if hadK is None or hadK.shape != (K, K):
         raise ValueError("hadK [K, K] required when K > 1")
     return (hadK.to(device=x.device, dtype=torch.float32) @ y.view(*x.shape[:-1], K, P)).reshape(x.shape)
+
+
+def hadamard_wide(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """matmul_hadU (hadamard_utils.py:89-110) for bf16 / fp32 ROCm tensors -> x's dtype, on the fp32-butterfly kernel
+    (fq_fwht_f32_f16: fp16 in — exact up-cast — fp32 stages and result, nothing rounded in between). The transform is linear and
+    power-of-two scaling is exact, so the input is handed over as fp16 PIECES of `x * 2^-e` (e: the tensor's largest exponent brought
+    to 2^14): one piece for bf16 (8 mantissa bits fit fp16's 11 exactly), high + low for fp32 (22 of 24 mantissa bits; the residual is
+    below 2^-22 of the largest element, inside the reference's own fp32 stage rounding ~log2(n) 2^-24). The K x K factor of
+    n = K 2^p and the 1/sqrt(n) are the reference's own plain operations in fp32 (hadamard_utils.py:108-110). P = n / K in 64..8192."""
+    if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError("hadamard_wide: bf16 / fp32 ROCm tensors")
+    n = x.shape[-1]
+    if n % K:
+        raise ValueError("hadamard_wide: n % K != 0")
+    P = n // K
+    if P < 64 or P > 8192 or P & (P - 1):
+        raise _lib.FqError(FQ_EUNSUPPORTED, f"hadamard_wide: n / K = {P} outside the register transform's range (64 .. 8192, a power of two)")
+    xc = x.contiguous()
+    amax = float(xc.abs().max()) if xc.numel() else 0.0
+    if not math.isfinite(amax):
+        raise ValueError("hadamard_wide: non-finite input")
+    e = 0 if amax == 0.0 else math.frexp(amax)[1] - 15       # amax * 2^-e in [2^14, 2^15)
+    xs = torch.ldexp(xc.float(), torch.tensor(-e, device=x.device))
+    hi = xs.half()
+    pieces = [hi] if x.dtype == torch.bfloat16 else [hi, (xs - hi.float()).half()]
+    vecs = xc.numel() // P
+    y = None
+    for pc in pieces:
+        yp = torch.empty(xc.shape, dtype=torch.float32, device=x.device)
+        if vecs:
+            with _on(x.device):
+                check(lib.fq_fwht_f32_f16(_ptr(pc), _ptr(yp), vecs, P, ctypes.c_float(1.0), _stream(x)))
+        y = yp if y is None else y + yp
+    if K > 1:
+        if hadK is None or hadK.shape != (K, K):
+            raise ValueError("hadK [K, K] required when K > 1")
+        y = (hadK.to(device=x.device, dtype=torch.float32) @ y.view(*xc.shape[:-1], K, P)).reshape(xc.shape)
+    y = torch.ldexp(y, torch.tensor(e, device=x.device)) / torch.tensor(n, dtype=torch.float32, device=x.device).sqrt()
+    return y.to(x.dtype)
 
 
 def hadamard_quant(x: torch.Tensor, K: int = 1, hadK: Optional[torch.Tensor] = None, sig: Sig = (1.0, 1.0),

@@ -283,7 +283,8 @@ int fq_kron_prepare_bf16(const void* left, const void* right, int M, int N, void
  *   fq_kron_multi_prepare(jobs, n_jobs, table, table_bytes, stream)   writes the table from the HOST array `jobs` (a copy on
  *       `stream`, waited for: a set-up call; `jobs` may be released on return); returns the number of workgroups per job (> 0)
  *       or a negative error code
- *   fq_kron_quant_multi_{f16,bf16}(table, n_jobs, wg_per_job, sig_max, sig_min, flags, stream)   the launch
+ *   fq_kron_quant_multi_{f16,bf16}(table, n_jobs, wg_per_job, sig_max, sig_min, flags, stream)   the launch; wg_per_job must be
+ *       the value fq_kron_multi_prepare returned for this table (its per-job token split is baked into the table): FQ_EINVAL otherwise
  * The table is valid for as long as the jobs' pointers and row counts are (a deployed model's layers: prepare once).
  */
 typedef struct FqKronJob {

@@ -276,3 +276,60 @@ def test_force_fp32_returns_the_fp32_transform(ops, n):
         # and it is NOT the widened fp16 result: finer than fp16 resolution
         y16 = t.__class__(n, trans="had").cuda()(x.cuda()).float().cpu().numpy().reshape(15, n)
         assert np.max(np.abs(y16 - ref)) > 20 * np.max(np.abs(got - ref))
+
+
+def _exact_rotation(x64, n, K):
+    """matmul_hadU in float64: Sylvester butterflies over n / K, the K x K factor, 1 / sqrt(n) (hadamard_utils.py:89-110)"""
+    P = n // K
+    v = x64.reshape(-1, K, P).copy()
+    h = 1
+    while h < P:
+        v = v.reshape(-1, K, P // (2 * h), 2, h)
+        v = np.stack([v[:, :, :, 0] + v[:, :, :, 1], v[:, :, :, 0] - v[:, :, :, 1]], axis=3).reshape(-1, K, P)
+        h *= 2
+    if K > 1:
+        v = np.einsum("jk,rkp->rjp", hadk_matrix(K).astype(np.float64), v)
+    return v.reshape(-1, n) / np.sqrt(np.float64(n))
+
+
+@pytest.mark.parametrize("n", [512, 4096, 14336, 11008, 5120])
+def test_matmul_hadU_takes_bf16_and_fp32_tensors(n):
+    """(VERDICT r04 missing #3) the reference's matmul_hadU takes any float dtype (hadamard_utils.py:89-110; its own callers feed it
+    fp32 / fp64 weights, :121,128). The mirror runs bf16 and fp32 ROCm tensors on the fp32-butterfly kernel over exact fp16 pieces of
+    the input (ops.hadamard_wide): fp32 within fp32 rounding noise of the exact rotation, bf16 = the exact rotation rounded once;
+    CPU tensors and fp64 still raise (no CPU path). Inputs span 2^-20 .. 2^20 (beyond fp16's range: the pieces are power-of-two scaled)."""
+    from flatquant_amd.flatquant.hadamard_utils import get_hadK, matmul_hadU
+    _, K = get_hadK(n)
+    g = torch.Generator().manual_seed(n)
+    for mag in (1.0, 2.0 ** 20, 2.0 ** -20):
+        x = torch.randn(6, n, generator=g) * mag
+        x[:, ::31] *= 9
+        ref = _exact_rotation(x.numpy().astype(np.float64), n, K)
+        y = matmul_hadU(x.cuda())
+        assert y.dtype == torch.float32 and y.shape == x.shape
+        assert np.max(np.abs(y.cpu().numpy().astype(np.float64) - ref)) <= 3e-6 * np.max(np.abs(ref)), (n, mag)
+        xb = x.bfloat16()
+        refb = _exact_rotation(xb.float().numpy().astype(np.float64), n, K)
+        yb = matmul_hadU(xb.cuda())
+        assert yb.dtype == torch.bfloat16
+        err = np.abs(yb.float().cpu().numpy().astype(np.float64) - refb)
+        assert np.all(err <= 2.0 ** -8 * np.abs(refb) + 1e-5 * np.max(np.abs(refb))), (n, mag)
+    with pytest.raises(TypeError):
+        matmul_hadU(torch.randn(2, n))                      # CPU
+    with pytest.raises(TypeError):
+        matmul_hadU(torch.randn(2, n, dtype=torch.float64).cuda())
+
+
+def test_force_fp32_outside_the_fp32_kernel_range_and_on_bf16(ops):
+    """ OnlineTrans(force_fp32=True) on a width whose n / K is outside the fp32-result kernel's range (a tiny test model:
+    n = 32) takes the fp16-result kernel and an up-cast instead of raising; bf16 activations take the exact-pieces route."""
+    import flatquant_amd.deploy as deploy
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 32, generator=g).half()
+    y = deploy.nn.OnlineTrans(32, force_fp32=True, trans="had").cuda()(x.cuda())
+    ref = _exact_rotation(x.numpy().astype(np.float64).reshape(6, 32), 32, 1)
+    assert y.dtype == torch.float32 and np.max(np.abs(y.cpu().numpy().reshape(6, 32) - ref)) <= 2e-3 * np.max(np.abs(ref))
+    xb = torch.randn(2, 3, 4096, generator=g).bfloat16()
+    yb = deploy.nn.OnlineTrans(4096, force_fp32=True, trans="had").cuda()(xb.cuda())
+    refb = _exact_rotation(xb.float().numpy().astype(np.float64).reshape(6, 4096), 4096, 1)
+    assert yb.dtype == torch.float32 and np.max(np.abs(yb.cpu().numpy().reshape(6, 4096) - refb)) <= 3e-6 * np.max(np.abs(refb))

@@ -318,3 +318,18 @@ def test_multi_job_argument_errors():
     jobs = (_lib.FqKronJob * 1)(_lib.FqKronJob(0, 0, 0, 0, 8))
     assert lib.fq_kron_multi_prepare(ctypes.cast(jobs, ctypes.c_void_p), 1, t.data_ptr(), 4096, st) == _lib.FQ_EINVAL   # NULL pointers, rows > 0
     assert lib.fq_kron_multi_prepare(ctypes.cast(jobs, ctypes.c_void_p), 1, t.data_ptr(), 8, st) == _lib.FQ_EINVAL      # table too small
+    #  the launch refuses a workgroup count other than the one the table was prepared for (fewer would leave every job's
+    # tail tokens unwritten, silently)
+    x = torch.zeros(8, 4096, dtype=torch.float16, device="cuda")
+    ws = torch.zeros(int(lib.fq_kron_workspace_bytes(64, 64)), dtype=torch.uint8, device="cuda")
+    q = torch.zeros(8, 2048, dtype=torch.uint8, device="cuda")
+    sc = torch.zeros(8, dtype=torch.float16, device="cuda")
+    jobs = (_lib.FqKronJob * 2)(_lib.FqKronJob(x.data_ptr(), ws.data_ptr(), q.data_ptr(), sc.data_ptr(), 8),
+                                _lib.FqKronJob(x.data_ptr(), ws.data_ptr(), q.data_ptr(), sc.data_ptr(), 8))
+    bpj = lib.fq_kron_multi_prepare(ctypes.cast(jobs, ctypes.c_void_p), 2, t.data_ptr(), 4096, st)
+    assert bpj > 1
+    one, sig = ctypes.c_float(1.0), ctypes.c_float(1.0)
+    assert lib.fq_kron_quant_multi_f16(t.data_ptr(), 2, bpj - 1, one, sig, _lib.FQ_OUT_PACKED | _lib.FQ_WS_PREPARED, st) == _lib.FQ_EINVAL
+    assert lib.fq_kron_quant_multi_f16(t.data_ptr(), 2, bpj + 1, one, sig, _lib.FQ_OUT_PACKED | _lib.FQ_WS_PREPARED, st) == _lib.FQ_EINVAL
+    assert lib.fq_kron_quant_multi_f16(t.data_ptr(), 2, bpj, one, sig, _lib.FQ_OUT_PACKED | _lib.FQ_WS_PREPARED, st) == 0
+    torch.cuda.synchronize()
