@@ -106,6 +106,11 @@ SYMBOLS = {
     "fq_int4_linear_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
     "fq_hadamard_f16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _f, _vp]),
     "fq_fwht_f32_f16": (_i, [_vp, _vp, _i64, _i, _f, _vp]),
+    "fq_plan_kron": (_vp, [_i, _vp, _vp, _i64, _i, _i, _f, _f, _i, _vp, _i64]),
+    "fq_plan_rowquant": (_vp, [_i, _i64, _i, _f, _f, _i]),
+    "fq_plan_skinny_linear": (_vp, [_vp, _vp, _vp, _i64, _i, _i]),
+    "fq_plan_run": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "fq_plan_free": (None, [_vp]),
     "fq_hadamard_quant_f16": (_i, [_vp, _i64, _i, _i, _vp, _f, _f, _f, _vp, _vp, _vp]),
     "fq_hadamard_quant_mfma_f16": (_i, [_vp, _i64, _i, _i, _vp, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "fq_silu_mul_hadamard_quant_mfma_f16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _f, _f, _f, _vp, _vp, _vp]),

@@ -594,6 +594,74 @@ int fq_kron_quant_multi_bf16(const void* table, int n_jobs, int wg_per_job, floa
     return kron_multi_impl("fq_kron_quant_multi_bf16", 1, table, n_jobs, wg_per_job, sig_max, sig_min, flags, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Prepared calls (round 5): an ARGUMENT CACHE for the three calls a deploy module makes per forward — OnlineTrans (fq_kron_quant_*,
+// one clip set, packed output), Quantizer (fq_rowquant_*) and the decode-sized Linear4bit (fq_int4_skinny_linear_f16). The plan
+// holds every argument that does not change between calls; fq_plan_run passes the per-call pointers (input, second input, two
+// outputs, stream) — five arguments for the host binding to convert instead of eighteen, with FRESH output buffers every call.
+// A plan is immutable after creation: any number of threads may run it concurrently. The plan owns nothing on the device.
+struct FqPlan {
+    int kind;            // 1 kron, 2 rowquant, 3 skinny linear
+    int bf16;
+    const void *a, *b, *c;   // kron: left, right, workspace | skinny: w_image, w_scale, bias
+    int64_t rows, ws_bytes;
+    int M, N, K, flags;
+    float sig_max, sig_min;
+};
+
+void* fq_plan_kron(int bf16, const void* left, const void* right, int64_t rows, int M, int N, float sig_max, float sig_min, int flags,
+                   void* workspace, int64_t workspace_bytes) {
+    if (!left || !right || rows < 0 || (flags & (FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM)) || !(flags & FQ_OUT_PACKED)) {
+        fail(FQ_EINVAL, "fq_plan_kron: left / right NULL, rows < 0, or an output set other than FQ_OUT_PACKED (flags 0x%x)", flags);
+        return nullptr;
+    }
+    FqPlan* p = static_cast<FqPlan*>(calloc(1, sizeof(FqPlan)));
+    if (!p) { fail(FQ_EINVAL, "fq_plan_kron: out of host memory"); return nullptr; }
+    *p = FqPlan{1, bf16 != 0, left, right, workspace, rows, workspace_bytes, M, N, 0, flags, sig_max, sig_min};
+    return p;
+}
+void* fq_plan_rowquant(int bf16, int64_t rows, int cols, float sig_max, float sig_min, int flags) {
+    if (rows < 0 || cols < 2 || (flags & (FQ_OUT_FAKEQUANT | FQ_OUT_TRANSFORM)) || !(flags & FQ_OUT_PACKED)) {
+        fail(FQ_EINVAL, "fq_plan_rowquant: rows < 0, cols < 2, or an output set other than FQ_OUT_PACKED (flags 0x%x)", flags);
+        return nullptr;
+    }
+    FqPlan* p = static_cast<FqPlan*>(calloc(1, sizeof(FqPlan)));
+    if (!p) { fail(FQ_EINVAL, "fq_plan_rowquant: out of host memory"); return nullptr; }
+    *p = FqPlan{2, bf16 != 0, nullptr, nullptr, nullptr, rows, 0, 0, cols, 0, flags, sig_max, sig_min};
+    return p;
+}
+void* fq_plan_skinny_linear(const void* w_image, const void* w_scale, const void* bias, int64_t M, int N, int K) {
+    if (!w_image || !w_scale || M < 1) {
+        fail(FQ_EINVAL, "fq_plan_skinny_linear: w_image / w_scale NULL or M < 1");
+        return nullptr;
+    }
+    FqPlan* p = static_cast<FqPlan*>(calloc(1, sizeof(FqPlan)));
+    if (!p) { fail(FQ_EINVAL, "fq_plan_skinny_linear: out of host memory"); return nullptr; }
+    *p = FqPlan{3, 0, w_image, w_scale, bias, M, 0, 0, N, K, 0, 0.0f, 0.0f};
+    return p;
+}
+int fq_plan_run(const void* plan, const void* in0, const void* in1, void* out0, void* out1, void* stream) {
+    const FqPlan* p = static_cast<const FqPlan*>(plan);
+    if (!p) return fail(FQ_EINVAL, "fq_plan_run: plan is NULL");
+    void* q[1] = {out0};
+    void* sc[1] = {out1};
+    switch (p->kind) {
+        case 1:
+            return p->bf16 ? fq_kron_quant_bf16(in0, p->a, p->b, nullptr, p->rows, p->M, p->N, &p->sig_max, &p->sig_min, 1, p->flags, q, sc, nullptr,
+                                                nullptr, const_cast<void*>(p->c), p->ws_bytes, stream)
+                           : fq_kron_quant_f16(in0, p->a, p->b, nullptr, p->rows, p->M, p->N, &p->sig_max, &p->sig_min, 1, p->flags, q, sc, nullptr,
+                                               nullptr, const_cast<void*>(p->c), p->ws_bytes, stream);
+        case 2:
+            return p->bf16 ? fq_rowquant_bf16(in0, p->rows, p->N, &p->sig_max, &p->sig_min, 1, p->flags, q, sc, nullptr, stream)
+                           : fq_rowquant_f16(in0, p->rows, p->N, &p->sig_max, &p->sig_min, 1, p->flags, q, sc, nullptr, stream);
+        case 3:
+            return fq_int4_skinny_linear_f16(in0, in1, p->a, p->b, p->c, p->rows, p->N, p->K, out0, stream);
+        default:
+            return fail(FQ_EINVAL, "fq_plan_run: not a plan (kind %d)", p->kind);
+    }
+}
+void fq_plan_free(void* plan) { free(plan); }
+
 static int block_quant_impl(const char* what, int dt, const void* x, const void* P, int64_t rows, int R, int C, int transpose_out,
                             const float* sig_max, const float* sig_min, int n_clips, int flags,
                             void* const* q_out, void* const* scale_out, void* const* fq_out, void* y_out,

@@ -46,18 +46,12 @@ typedef __attribute__((address_space(3))) void hm_lds_void;
 #ifndef HM_QSTAGE
 #define HM_QSTAGE 1   // packed output staged through LDS and written as 1 KB-contiguous 16-byte stores (0: 8-byte stores straight from the registers)
 #endif
-// Two measurement knobs for the copy-out of the staged packed token, prepared at the end of round 4 (no GPU budget left to time them; both default
-// to the measured build, whose ISA they do not change — tools/next_round_ab.sh builds and times the variants):
-#ifndef HM_COPY_NT
-#define HM_COPY_NT 0     // 1: non-temporal copy-out stores
-#endif
-#ifndef HM_COPY_LATE
-#define HM_COPY_LATE 0   // 1: the copy-out behind phase A (after the A|B meeting) instead of in front of it: its stores then queue behind the next
-                         //    token's DMA requests instead of in front of them
-#endif
+// (round 5, profiles/r05_had512_variants.txt) Two variants of the copy-out of the staged packed token prepared at the end of round 4 —
+// non-temporal stores, the copy-out behind phase A — were timed (130.6 / 131.9 / 132.6 us at 14336: no gain) and removed.
 #ifndef HM_YSTAGE
-#define HM_YSTAGE 0      // 1 (rotation-only launches; PREPARED, NOT YET RUN on a GPU: end of round 4): the rotated token staged through the group's own token
-                         //    buffer and written as 1 KB-contiguous stores (the ablation builds put the 32-byte pieces of the direct stores at 130 of 206 us).
+#define HM_YSTAGE 1      // rotation-only launches: the rotated token staged through the group's own token buffer and written as 1 KB-contiguous
+                         //    stores instead of 32-byte pieces straight from the registers (0). Measured round 5: 14336 205.5 -> 195.3 us,
+                         //    28672 203.2 -> 197.4 us per 8192 tokens; bit-identical (tests/test_gpu_had_mfma.py, test_gpu_hadamard.py on both builds).
                          //    The next token's DMA is deferred: every wave copies out exactly the 1 KB slots its own DMA instructions refill, requests them, then stores.
 #endif
 #ifndef HM_NGROUPS
@@ -258,15 +252,14 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
         for (int g = tg; g < n_chunks; g += 256) {
             const int row = g >> 2, cc = NA == 8 ? row >> 3 : row >> 2, aa = row & (NA - 1);
             const u32x4 v = reinterpret_cast<const u32x4*>(qst)[cc * (NA * 4) + ((aa * 4 + (g & 3)) ^ (cc & 15))];
-            if (HM_COPY_NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(qtok + (int64_t)g * 16));
-            else *reinterpret_cast<u32x4*>(qtok + (int64_t)g * 16) = v;
+            *reinterpret_cast<u32x4*>(qtok + (int64_t)g * 16) = v;
         }
     };
     unsigned meet_n = 0;
     for (int k = grp; k < blk_cnt;) {   // k: the group's current token (of this workgroup's range), claimed one token ahead
         const int64_t tok = blk_base + k;
         HM_MEET()   // C|A: every wave of the group waited for its share of the DMA before its stores
-        if (QSTAGE && !HM_COPY_LATE && q_pending >= 0 && !(HM_ABL & 8)) q_copy_out(q_pending);   // (and has written its share of the previous token's packed image)
+        if (QSTAGE && q_pending >= 0 && !(HM_ABL & 8)) q_copy_out(q_pending);   // (and has written its share of the previous token's packed image)
         if (HM_PRIO_MFMA) __builtin_amdgcn_s_setprio(HM_PRIO_MFMA);
 
         // ===== phase A: b-butterfly on the A fragments, GEMM 1 (contraction over c, K = 32), a-butterfly, fp16 rounding =====
@@ -335,8 +328,6 @@ __global__ __launch_bounds__(GROUPS * 256) void fq_had512_kernel(const f16* __re
         const int knext = __builtin_amdgcn_readfirstlane((int)hm_lds_read(ctl_lds + CLAIM + grp * 4));
         const bool more = !(HM_ABL & 16) && knext < blk_cnt && dn > 0;
         if (more && !YSTAGE) stage_token(knext);
-        // (HM_COPY_LATE: the previous token's image is still intact — this token's staging writes come after the B|C meeting)
-        if (QSTAGE && HM_COPY_LATE && q_pending >= 0 && q_pending != tok && !(HM_ABL & 8)) q_copy_out(q_pending);
         f32x16 Y[NA];   // Y^T of (column block wq, row tile a'): register r of lane (h, c) = column 32 wq + 16 h + r of row (a', k' = c)
 #pragma unroll
         for (int a = 0; a < NA; ++a) {

@@ -29,21 +29,7 @@ namespace {
 #ifndef TALL_ABL
 #define TALL_ABL 0   // measurement builds: 1 = the first token's rows are reused (no loads after the first)
 #endif
-#ifndef TALL_DEEP
-// How far ahead the next token's rows are requested, and where they are waited for (TALL_ASM_LOADS builds):
-//   0  round 4: requested behind GEMM 1, vmcnt(0) in front of the token's own stores (window: GEMM 2 + extrema);
-//   1  requested behind GEMM 1, COUNTED wait behind the token's stores — vmcnt(k), k = the store instructions this wave is certain to
-//      have issued behind the loads (the y pieces + one q store per clip set; the scale stores of wave 0 are left out: too small a k
-//      only waits for a few old stores, too large a k would return before the rows have landed) — window: the whole token period;
-//   2  TWO register sets: token t + 2 is requested behind GEMM 1 of token t into the set GEMM 1 has just read, vmcnt(4) in front of
-//      the stores leaves exactly those four loads in flight (window: two token periods); R is read from LDS to pay for the 16 VGPRs.
-#define TALL_DEEP 0
-#endif
-#if TALL_DEEP && !TALL_ASM_LOADS
-#error "TALL_DEEP needs the untracked loads"
-#endif
 constexpr int TALL_N = 64, TALL_NT = 2, TALL_KS1 = 4;
-constexpr bool TALL_RLDS = TALL_DEEP == 2;   // R's eight B fragments in LDS (shared by the workgroup) instead of 32 VGPRs per wave
 
 // Workgroup barrier for LDS traffic only. __syncthreads() also drains vmcnt: the next token's rows — requested one token ahead
 // on purpose — would be waited for at every barrier (measured: 5 us per token and workgroup, the HBM latency, whatever M).
@@ -56,22 +42,17 @@ __global__ __launch_bounds__(MT * 64) void fq_kron_tall_kernel(const f16* __rest
     // Uh image of one token: [MT waves][NT][2 halves][64 lanes] uint4, double-buffered; then the extrema [2][2][8] floats
     __shared__ __attribute__((aligned(16))) uint4 uimg[2][MT * NT * 2 * 64];
     __shared__ float red[2][2][8];
-    __shared__ __attribute__((aligned(16))) uint4 rimg[TALL_RLDS ? NT * KS1 * 64 : 1];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's row tile (GEMM 1) and output column tile (GEMM 2)
     const int64_t d = (int64_t)M * N;
     const int ks_n = (M + 15) >> 4;   // K-steps of GEMM 2 that hold rows of the token (rows of L beyond M are zero)
 
     // ---- constants of the launch: R (all of it) and this wave's column of L, as MFMA B fragments in registers ----
-    f16x8 RF[TALL_RLDS ? 1 : NT][TALL_RLDS ? 1 : KS1], LF[2 * MT];
-    if constexpr (TALL_RLDS) {
-        for (int i = tid; i < NT * KS1 * 64; i += MT * 64) rimg[i] = ws[i];
-    } else {
+    f16x8 RF[NT][KS1], LF[2 * MT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int s = 0; s < KS1; ++s) RF[TALL_RLDS ? 0 : nt][TALL_RLDS ? 0 : s] = __builtin_bit_cast(f16x8, ws[(nt * KS1 + s) * 64 + lane]);
-    }
+        for (int s = 0; s < KS1; ++s) RF[nt][s] = __builtin_bit_cast(f16x8, ws[(nt * KS1 + s) * 64 + lane]);
     {
         const uint4* lsrc = ws + NT * KS1 * 64;
 #pragma unroll
@@ -81,14 +62,15 @@ __global__ __launch_bounds__(MT * 64) void fq_kron_tall_kernel(const f16* __rest
     // the statement. Without it the scheduler sank the fragment loads below the prologue's vmcnt(0) and waited for them lazily, at
     // their first uses INSIDE the token loop — s_waitcnt vmcnt(19) ... vmcnt(0) in front of GEMM 2's MFMAs, executed every iteration:
     // no-ops for the fragments after the first token, but the counter is shared with the untracked row loads issued just above them,
-    // so every token waited for the NEXT token's rows (the full HBM latency) in the middle of GEMM 2. That, not the barriers, is why
-    // rounds 3 and 4 measured ~5 us per token and workgroup whatever M (and 2.39 GHz at 1100 W: a kernel that waits).
-    if constexpr (!TALL_RLDS) {
+    // so every token waited for the NEXT token's rows in the middle of GEMM 2:
+    // the builds of rounds 3 and 4 did that. Measured (round 5, profiles/r05_tall_prefetch.txt): 172 x 64 167 -> 162.5 us, 140 x 64 166 -> 155,
+    // 96 x 64 83 -> 77 — and NOT more: a build that never loads after the first token runs in the same 163 us, and two deeper-prefetch
+    // builds (a counted wait behind the stores; two register sets with vmcnt(4)) measured 165 / 170 us and were removed. What bounds this
+    // kernel is its two workgroup barriers per token over 6 waves on 4 SIMDs, not the loads.
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int s = 0; s < KS1; ++s) asm volatile("" : "+v"(RF[TALL_RLDS ? 0 : nt][TALL_RLDS ? 0 : s]));
-    }
+        for (int s = 0; s < KS1; ++s) asm volatile("" : "+v"(RF[nt][s]));
 #pragma unroll
     for (int ks = 0; ks < 2 * MT; ++ks) asm volatile("" : "+v"(LF[ks]));
     // this lane's row of the token: row 32 w + c, its K-half h of every K-step: 16 bytes at chunk 2 s + h of a 128-byte row
@@ -129,27 +111,6 @@ __global__ __launch_bounds__(MT * 64) void fq_kron_tall_kernel(const f16* __rest
     const float ps = out.post_scale != 0.0f ? out.post_scale : 1.0f;
     FqGroupCursor gcur;
 
-    // vmcnt(k) for a wave-uniform k (the instruction takes an immediate): k = 0 for anything beyond the cases
-#define FQ_TALL_WAIT_K(k)                                                                                                  \
-    {                                                                                                                      \
-        asm volatile("" ::: "memory");                                                                                     \
-        switch (k) {                                                                                                       \
-            case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;                                                             \
-            case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;                                                             \
-            case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;                                                             \
-            case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;                                                             \
-            case 5: __builtin_amdgcn_s_waitcnt(0x0F75); break;                                                             \
-            case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;                                                             \
-            case 7: __builtin_amdgcn_s_waitcnt(0x0F77); break;                                                             \
-            case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;                                                             \
-            default: __builtin_amdgcn_s_waitcnt(0x0F70); break;                                                            \
-        }                                                                                                                  \
-        asm volatile("" ::: "memory");                                                                                     \
-    }
-    // (TALL_DEEP 1) the VMEM stores this wave is certain to issue per token behind the request for the next rows: every wave owns at
-    // least one valid row (32 (MT - 1) < M), so the y pieces and the q store of every clip set are issued by every wave
-    [[maybe_unused]] const int kst = __builtin_amdgcn_readfirstlane((YOUT ? 2 * NT : 0) + out.n_clips);
-
     // ---- one token: `A` holds its rows (landed); `nxt` is the token whose rows are requested into `A` once GEMM 1 has read it ----
     auto token = [&](const int64_t tok, const int it, f16x8(&A)[KS1], const int64_t nxt) __attribute__((always_inline)) {
         const int buf = it & 1;
@@ -160,15 +121,7 @@ __global__ __launch_bounds__(MT * 64) void fq_kron_tall_kernel(const f16* __rest
 #pragma unroll
         for (int s = 0; s < KS1; ++s)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if constexpr (TALL_RLDS) {
-                    int ln = lane;
-                    asm volatile("" : "+v"(ln));   // (keeps the fragment reads inside the token loop: hoisted, they are 32 VGPRs again)
-                    U[nt] = fq_mfma32<f16>(A[s], __builtin_bit_cast(f16x8, rimg[(nt * KS1 + s) * 64 + ln]), U[nt]);
-                } else {
-                    U[nt] = fq_mfma32<f16>(A[s], RF[TALL_RLDS ? 0 : nt][TALL_RLDS ? 0 : s], U[nt]);
-                }
-            }
+            for (int nt = 0; nt < NT; ++nt) U[nt] = fq_mfma32<f16>(A[s], RF[nt][s], U[nt]);
         {
             // the next rows (nxt == tok: the last token re-reads itself — no branch round the untracked loads): in flight under
             // everything below. (round 3, with compiler-tracked loads: two tokens ahead measured no faster, 140 x 64 206 vs 202 us —
@@ -262,11 +215,7 @@ __global__ __launch_bounds__(MT * 64) void fq_kron_tall_kernel(const f16* __rest
                 vmin = b;
             }
         }
-#if TALL_DEEP == 0
         FQ_TALL_WAIT_ROWS();   // the next token's rows have had GEMM 2 and the extrema to arrive; nothing waits for the stores below
-#elif TALL_DEEP == 2
-        FQ_TALL_WAIT_K(4);     // everything but the four loads just issued: the OTHER register set (requested a token ago) has landed
-#endif
         if (YOUT && row_ok) {   // the transformed activation as well (the launch the parity tests read; kronecker_matmul + quant)
             f16* yrow = out.y + tok * d + (int64_t)(w * 32 + c) * N + h * 32;   // n' = h*32 + nt*16 + r: 16 consecutive values per tile
 #pragma unroll
@@ -351,27 +300,10 @@ __global__ __launch_bounds__(MT * 64) void fq_kron_tall_kernel(const f16* __rest
             if (w == 0 && lane == 0)
                 out.scale[ci][tok] = ((out.rt_flags & FQ_RATIO_POST) && vmax == 0.0f && vmin == 0.0f) ? (f16)0.0f : (f16)scale;
         }
-#if TALL_DEEP == 1
-        FQ_TALL_WAIT_K(kst);   // the rows requested behind GEMM 1 have landed; the kst stores issued since may still be in flight
-#endif
     };
 
     int64_t tok = blockIdx.x;
     const int64_t step = gridDim.x;
-#if TALL_DEEP == 2
-    f16x8 A0[KS1], A1[KS1];
-    fetch(tok, A0);   // (blockIdx.x < rows: the launcher starts at most one workgroup per token)
-    fetch(tok + step < rows ? tok + step : tok, A1);
-    FQ_TALL_WAIT_ROWS();
-    if constexpr (TALL_RLDS) FQ_TALL_LDS_BARRIER();   // the R image is complete
-    for (int it = 0; tok < rows;) {   // two tokens per trip: the register sets keep their roles (a swap would be a register COPY of in-flight data)
-        token(tok, it, A0, (tok + 2 * step < rows && !(TALL_ABL & 1)) ? tok + 2 * step : tok);
-        tok += step, ++it;
-        if (tok >= rows) break;
-        token(tok, it, A1, (tok + 2 * step < rows && !(TALL_ABL & 1)) ? tok + 2 * step : tok);
-        tok += step, ++it;
-    }
-#else
     f16x8 A[KS1];
 #if TALL_ASM_LOADS
     fetch(tok, A);   // (blockIdx.x < rows: the launcher starts at most one workgroup per token. Unconditional on purpose — a branch
@@ -384,7 +316,6 @@ __global__ __launch_bounds__(MT * 64) void fq_kron_tall_kernel(const f16* __rest
         const int64_t n1 = tok + step;
         token(tok, it, A, (n1 < rows && !(TALL_ABL & 1)) ? n1 : tok);
     }
-#endif
 }
 
 template <int MT, bool H16, bool YOUT>

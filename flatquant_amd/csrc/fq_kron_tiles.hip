@@ -119,11 +119,20 @@ __device__ __forceinline__ unsigned tl_dma_off(int i, int lane) {
     return (unsigned)((lane + ((pch ^ tl_swz<CPR>(r)) - pch)) * 16 + 128);
 }
 
-template <int MT, int NT, int N, int GROUPS, int LKS, bool RS, typename T>
+// H16 (round 5, N = 64 — the Hadamard rotations of 11008 = 172 x 64 (Llama-2-7B ffn), 8960 = 140 x 64, 5120 = 80 x 64 run as ONE Kronecker
+// launch in front of deploy.nn.Quantizer: hadamard_utils.py:132-141 + deploy/nn/quantization.py:13-36): the output arithmetic of
+// fq_kron_tall.hip's H16 instantiations — the transform times the post-scale rounded to fp16 PAIRS, extrema on the pairs, the Quantizer's
+// fp16 scale and the two-operation exact fp16 quotient (fq_quant8_h16), FQ_RATIO_POST's zero-token rule — and, when out.y is given, the
+// rounded transform itself (kronecker_matmul / the rotation alone: no clip set). A token of N = 64 is two n'-tiles: TWO waves per
+// token group and four groups per CU, each wave running both GEMMs of its 32 columns without meeting anybody (the contraction of GEMM 2
+// is over rows, inside the wave) — where fq_kron_tall.hip splits the token by ROW tile and pays two workgroup barriers per token over
+// 6 waves on 4 SIMDs (163 us per 16384 tokens of 172 x 64 with or without its loads: profiles/r05_tall_prefetch.txt).
+template <int MT, int NT, int N, int GROUPS, int LKS, bool RS, typename T, bool H16 = false>
 __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T* __restrict__ x, const uint4* __restrict__ ws,
                                                                        int64_t rows, int64_t tpb, int M, FqQuantOut out) {
     typedef TilesGeom<MT, NT, N, GROUPS, LKS> G;
     typedef typename FqVec<T>::x8 X8;
+    static_assert(!H16 || (FqVec<T>::is_f16 && N % 32 == 0), "the fp16 Quantizer epilogue: fp16 activations, whole n'-tiles");
     constexpr int KS1 = G::KS1, CPR = G::CPR, THREADS = G::THREADS;
     constexpr bool ODDN = G::ODDN;
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
@@ -295,7 +304,33 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
         }
         if (FQ_PRIO_MFMA) __builtin_amdgcn_s_setprio(0);
         float vmax = -INFINITY, vmin = INFINITY;
-        {
+        uint32_t H[H16 ? MT : 1][8];   // H16: the fp16 pairs the deploy Quantizer sees (Y is dead from here on)
+        if constexpr (H16) {
+            f16x2 pmax = {(f16)-INFINITY, (f16)-INFINITY}, pmin = {(f16)INFINITY, (f16)INFINITY};
+            f16x2 lmax = pmax, lmin = pmin;   // the last row tile on its own: only it can hold padding rows
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f16x2 pr = fq_mul_to_f16x2(Y[mo][2 * j], Y[mo][2 * j + 1], f32x2{ps, ps});
+                    H[H16 ? mo : 0][j] = __builtin_bit_cast(uint32_t, pr);
+                    if (mo < MT - 1) {
+                        pmax = fq_pk_max(pmax, pr);
+                        pmin = fq_pk_min(pmin, pr);
+                    } else {
+                        lmax = fq_pk_max(lmax, pr);
+                        lmin = fq_pk_min(lmin, pr);
+                    }
+                }
+            if (((MT - 1) * 32 + c) < M) {
+                pmax = fq_pk_max(pmax, lmax);
+                pmin = fq_pk_min(pmin, lmin);
+            }
+            if (MT > 1 || ((MT - 1) * 32 + c) < M) {
+                vmax = fmaxf((float)pmax[0], (float)pmax[1]);
+                vmin = fminf((float)pmin[0], (float)pmin[1]);
+            }
+        } else {
             if (out.post_scale != 0.0f) {
 #pragma unroll
                 for (int mo = 0; mo < MT; ++mo)
@@ -362,17 +397,45 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
             vmin = fq_uniform_f32(b);
         }
         bool waited = false;
+        if constexpr (H16) {
+            if (out.y != nullptr) {   // the rounded transform itself (wave-uniform): row m' = 32 mo + c, 16 consecutive n' = 32 bytes per lane
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the next token's DMA: see below — with no clip set this is the only wait)
+                waited = true;
+                if (!(TILES_ABL & 8)) {
+                    T* ytok = reinterpret_cast<T*>(out.y) + tok * ((int64_t)M * N) + (h * NT * 16 + wq * 16);
+#pragma unroll
+                    for (int mo = 0; mo < MT; ++mo)
+                        if ((mo * 32 + c) < M) {
+                            u32x4* dst = reinterpret_cast<u32x4*>(ytok + (mo * 32 + c) * N);
+                            const uint32_t(&hv)[8] = H[H16 ? mo : 0];
+                            dst[0] = u32x4{hv[0], hv[1], hv[2], hv[3]};
+                            dst[1] = u32x4{hv[4], hv[5], hv[6], hv[7]};
+                        }
+                }
+            }
+        }
         for (int ci = 0; ci < out.n_clips; ++ci) {
             float sig_max, sig_min;
             fq_token_sigs(out, ci, tok, gcur, sig_max, sig_min);
-            const float scale = fq_token_scale<0, T>(vmax, vmin, sig_max, sig_min, out.rt_flags);
+            const float scale = H16 ? fq_token_scale<FQ_QUANT_F16>(vmax, vmin, sig_max, sig_min, out.rt_flags)
+                                    : fq_token_scale<0, T>(vmax, vmin, sig_max, sig_min, out.rt_flags);
             const float inv = fq_uniform_f32(fq_fast_inv(scale));
-            const bool magic = fq_magic_ok(vmax, vmin, inv);
+            const bool magic = H16 || fq_magic_ok(vmax, vmin, inv);
             const bool clampq = fq_needs_clamp(vmax, vmin, inv);
+            const FqH16Recip rc = H16 ? fq_h16_recip(scale) : FqH16Recip{0.0f, 0.0f};
             uint2 pk[MT];
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo) {
-                if (TILES_ABL & 1) {
+                if constexpr (H16) {
+                    const uint32_t(&hv)[8] = H[H16 ? mo : 0];
+                    if (clampq) {
+                        pk[mo].x = fq_quant8_h16<true>(hv[0], hv[1], hv[2], hv[3], rc);
+                        pk[mo].y = fq_quant8_h16<true>(hv[4], hv[5], hv[6], hv[7], rc);
+                    } else {
+                        pk[mo].x = fq_quant8_h16<false>(hv[0], hv[1], hv[2], hv[3], rc);
+                        pk[mo].y = fq_quant8_h16<false>(hv[4], hv[5], hv[6], hv[7], rc);
+                    }
+                } else if (TILES_ABL & 1) {
                     pk[mo] = uint2{__builtin_bit_cast(uint32_t, Y[mo][0]), __builtin_bit_cast(uint32_t, Y[mo][8])};
                 } else {
                     const f32x16& yv = Y[mo];
@@ -414,14 +477,17 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
                             if (nval >= 12) *reinterpret_cast<uint16_t*>(dst + 4) = (uint16_t)pk[mo].y;
                         }
                     }
-                if (wq == 0 && lane == 0) reinterpret_cast<T*>(out.scale[ci])[tok] = (T)scale;
+                // (FQ_RATIO_POST — deploy.nn.Quantizer(lac=False) behind a Hadamard rotation: no zero guard, an all-zero token stores scale 0
+                //  as fq_rowquant_f16 does, deploy/nn/quantization.py:30)
+                if (wq == 0 && lane == 0)
+                    reinterpret_cast<T*>(out.scale[ci])[tok] = (H16 && (out.rt_flags & FQ_RATIO_POST) && vmax == 0.0f && vmin == 0.0f) ? (T)0.0f : (T)scale;
             }
         }
         k = knext;
     }
 }
 
-template <int MT, int NT, int N, int GROUPS, int LKS, bool RS, typename T>
+template <int MT, int NT, int N, int GROUPS, int LKS, bool RS, typename T, bool H16 = false>
 int launch_tiles_t(const T* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
     typedef TilesGeom<MT, NT, N, GROUPS, LKS> G;
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
@@ -429,7 +495,7 @@ int launch_tiles_t(const T* x, const uint4* ws, int64_t rows, int M, const FqQua
     if (blocks > n_cu) blocks = n_cu;   // one persistent workgroup per CU
     if (blocks < 1) blocks = 1;
     const int64_t tpb = (rows + blocks - 1) / blocks;
-    hipLaunchKernelGGL((fq_kron_tiles_kernel<MT, NT, N, GROUPS, LKS, RS, T>), dim3((unsigned)blocks), dim3(G::THREADS), 0, stream, x, ws,
+    hipLaunchKernelGGL((fq_kron_tiles_kernel<MT, NT, N, GROUPS, LKS, RS, T, H16>), dim3((unsigned)blocks), dim3(G::THREADS), 0, stream, x, ws,
                        rows, tpb, M, out);
     return (int)hipGetLastError();
 }
@@ -449,9 +515,35 @@ int fq_launch_kron_tiles(int flags, const f16* x, const void* ws, const f16* dia
                          const FqQuantOut& out, int n_cu, hipStream_t stream) {
     const bool b = (flags & FQ_DT_BF16) != 0;
     flags &= ~FQ_DT_BF16;
-    if (diag != nullptr || (out.rt_flags & FQ_GROUP128) || (flags & FQ_CT_MASK) != FQ_OUT_PACKED) return -1000;
+    if (diag != nullptr || (out.rt_flags & FQ_GROUP128)) return -1000;
     const uint4* w = reinterpret_cast<const uint4*>(ws);
     const int lks = (M + 15) >> 4;
+#ifndef TILES_N64
+#define TILES_N64 1   // 0: the tall pairs stay with fq_kron_tall.hip (A/B builds)
+#endif
+    if (TILES_N64 && N == 64 && M > 64 && M <= 192 && !b && out.ws_group_stride == 0) {
+        // (round 5) the TALL pairs — Hadamard rotations as a Kronecker launch — on two-wave token groups. Output sets: packed with the fp32
+        // quantiser, or the fp16 Quantizer arithmetic (H16: packed and / or the rounded transform, the launches of ops.hadamard_quant /
+        // hadamard_quantizer / hadamard at 11008, 8960, 5120 ...); the fp32 quantiser WITH the transform (a test-only set) stays with fq_kron_tall.hip
+        const int ct = flags & FQ_CT_MASK, cq = ct & ~FQ_OUT_TRANSFORM;
+        const bool yout = (ct & FQ_OUT_TRANSFORM) != 0;
+        const bool yonly = yout && (cq & ~FQ_QUANT_F16) == 0 && out.n_clips == 0;
+        const bool h16 = yonly || (cq == (FQ_OUT_PACKED | FQ_QUANT_F16) && (flags & FQ_ROUND_Y_F16));
+        if (yout && (out.y == nullptr || !h16)) return -1000;
+        if (!h16 && cq != FQ_OUT_PACKED) return -1000;
+        FqQuantOut o2 = out;
+        if (!yout) o2.y = nullptr;   // (the kernel writes the transform whenever out.y is given)
+        const int MT = (M + 31) / 32;
+#define FQ_T64(MT_, LKS_, G_)                                                                                               \
+    if (MT == MT_ && lks == LKS_)                                                                                          \
+        return h16 ? launch_tiles_t<MT_, 2, 64, G_, LKS_, false, f16, true>(x, w, rows, M, o2, n_cu, stream)               \
+                   : launch_tiles_t<MT_, 2, 64, G_, LKS_, false, f16, false>(x, w, rows, M, o2, n_cu, stream);
+        // four groups of two waves where 4 tokens + the L image fit 160 KB (a token: 2 LKS KB, the image: LKS x MT KB); 172 x 64 = 88 + 66 KB
+        FQ_T64(3, 5, 4) FQ_T64(3, 6, 4) FQ_T64(4, 7, 4) FQ_T64(4, 8, 4) FQ_T64(5, 9, 4) FQ_T64(5, 10, 4) FQ_T64(6, 11, 4) FQ_T64(6, 12, 3)
+#undef FQ_T64
+        return -1000;
+    }
+    if ((flags & FQ_CT_MASK) != FQ_OUT_PACKED) return -1000;
     if (N == 112 && M > 64 && M <= 96) {   // 80 x 112: four groups of four waves
         return lks == 5 ? launch_tiles<3, 4, 112, TILES_G112, 5, false>(b, x, w, rows, M, out, n_cu, stream)
                         : launch_tiles<3, 4, 112, TILES_G112, 6, false>(b, x, w, rows, M, out, n_cu, stream);

@@ -31,18 +31,17 @@ namespace {
 #define WAVE_ABL 0   // measurement builds (tools/variants.sh): 1 no quantiser arithmetic, 2 no GEMM 1 MFMAs, 4 no GEMM 2 MFMAs, 16 no DMA after the first token
 #endif
 
-// LR (round 5): the L fragments in REGISTERS (2 MT^2 x 4 VGPRs) and the tokens dealt to the waves statically (slot, slot + W, ...:
-// no counter in LDS) — at 64 x 128 that frees the 8 KB + 16 bytes which stood between 7 and 8 resident tokens (32 KB R image +
-// 8 x 16 KB = the whole 160 KB): two waves on every SIMD instead of 2 / 2 / 2 / 1.
-template <int MT, int NT, int KS1, int W, bool LR = false>
+// (round 5, measured and removed: 64 x 128 with EIGHT resident tokens — the L fragments in registers and static token slots free the
+//  8 KB + 16 bytes between 7 and 8 tokens, two waves on every SIMD instead of 2 / 2 / 2 / 1 — 76.3 against 75.5 us, packed3 112.9 against
+//  110.9: the launch runs at the 1400 W package cap, 1.75 GHz, and is bound by joules per token, not by waves — profiles/r05_energy_census.txt)
+template <int MT, int NT, int KS1, int W>
 struct WaveGeom {
     static constexpr int N = KS1 * 16;
     static constexpr int CPR = KS1 * 2;                     // 16-byte chunks per token row
     static constexpr int TOKBUF = MT * 32 * CPR * 16;       // bytes, rows padded to the tile
     static constexpr int RFR = NT * KS1 * 64;               // uint4
-    static constexpr int LFR = 2 * MT * MT * 64;            // uint4 (in the workspace image)
-    static constexpr int LFR_LDS = LR ? 0 : LFR;            // uint4 (in LDS)
-    static constexpr int LDS = (RFR + LFR_LDS) * 16 + W * TOKBUF + (LR ? 0 : 16);
+    static constexpr int LFR = 2 * MT * MT * 64;            // uint4
+    static constexpr int LDS = (RFR + LFR) * 16 + W * TOKBUF + 16;
     static constexpr int V1 = N - NT * 16;                  // valid n' in the h = 1 half of a lane's run
     static constexpr int NPIECE = (NT * 2 + 3) / 4;         // 16-byte pieces of a lane's packed run (the last may be 8 bytes)
     // VMEM store instructions per output row group: piece p is a 16-byte store for the halves with >= 32 p + 32 valid n',
@@ -89,11 +88,10 @@ __device__ __forceinline__ unsigned quant_row(const f32x16 (&Y)[NT][MT], int mo,
 // bytes (a whole 128-byte line at N = 128): stored as 16-byte pieces straight from the fragments; fq_fake8 with one exactness vote per
 // token, as fq_kron64.hip. fp32 quantiser arithmetic, per-token scales; everything else stays with the workgroup-per-token kernel
 // (which ran these outputs until now: 64 x 128 fake-quant 121 us, 32 x 64 45 us = 0.37 of the roofline).
-template <int MT, int NT, int KS1, int W, bool RMS = false, typename T = f16, int OS = FQ_OUT_PACKED, bool LR = false>
+template <int MT, int NT, int KS1, int W, bool RMS = false, typename T = f16, int OS = FQ_OUT_PACKED>
 __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const T* __restrict__ x, const uint4* __restrict__ ws,
                                                             int64_t rows, int64_t tpb, int M, FqQuantOut out) {
-    typedef WaveGeom<MT, NT, KS1, W, LR> G;
-    static_assert(!LR || OS == FQ_OUT_PACKED, "register-resident L: packed launches only");
+    typedef WaveGeom<MT, NT, KS1, W> G;
     typedef typename FqVec<T>::x8 X8;
     static_assert(OS == FQ_OUT_PACKED || OS == FQ_OUT_FAKEQUANT || OS == FQ_OUT_TRANSFORM, "one output set per instantiation");
     constexpr int N = G::N, CPR = G::CPR;
@@ -101,8 +99,8 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const T* __restric
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
     uint4* rfr = reinterpret_cast<uint4*>(smem);
     uint4* lfr = rfr + G::RFR;
-    unsigned char* tok0 = smem + (G::RFR + G::LFR_LDS) * 16;
-    unsigned* next_slot = reinterpret_cast<unsigned*>(tok0 + (LR ? 0 : W * G::TOKBUF));   // (LR: never dereferenced)
+    unsigned char* tok0 = smem + (G::RFR + G::LFR) * 16;
+    unsigned* next_slot = reinterpret_cast<unsigned*>(tok0 + W * G::TOKBUF);
 
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,18 +111,11 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const T* __restric
 
     const int64_t blk_base = (int64_t)blockIdx.x * tpb;
     const int blk_cnt = (int)(rows - blk_base < tpb ? (rows - blk_base < 0 ? 0 : rows - blk_base) : tpb);
-    if (!LR && tid == 0) *next_slot = W;
+    if (tid == 0) *next_slot = W;
     int slot = wave;
 
     // ---- once per workgroup: fragment image (coalesced copy), zero rows below the token, first DMA ----
-    for (int i = tid; i < G::RFR + G::LFR_LDS; i += W * 64) rfr[i] = ws[i];
-    X8 LFq[LR ? 2 * MT * MT : 1];
-    if constexpr (LR) {
-#pragma unroll
-        for (int i = 0; i < 2 * MT * MT; ++i) LFq[i] = __builtin_bit_cast(X8, ws[G::RFR + i * 64 + lane]);
-#pragma unroll
-        for (int i = 0; i < 2 * MT * MT; ++i) asm volatile("" : "+v"(LFq[i]));   // landed HERE, not at their first use inside the token loop
-    }
+    for (int i = tid; i < G::RFR + G::LFR; i += W * 64) rfr[i] = ws[i];
     for (int i = M * CPR + lane; i < MT * 32 * CPR; i += 64) reinterpret_cast<uint4*>(tokbuf)[i] = make_uint4(0, 0, 0, 0);
     unsigned voff[4];
     dma_offsets<CPR>(lane, voff);
@@ -217,12 +208,9 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const T* __restric
         };
         if constexpr (OS == FQ_OUT_PACKED) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            int nxt = slot + W;
-            if constexpr (!LR) {
-                nxt = 0;
-                if (lane == 0) nxt = (int)atomicAdd(next_slot, 1u);
-                nxt = __builtin_amdgcn_readfirstlane(nxt);
-            }
+            int nxt = 0;
+            if (lane == 0) nxt = (int)atomicAdd(next_slot, 1u);
+            nxt = __builtin_amdgcn_readfirstlane(nxt);
             if (nxt < blk_cnt && !(WAVE_ABL & 16)) dma_token<CPR>(reinterpret_cast<const f16*>(x), blk_base + nxt, tok_bytes, n_dma, tok_lds, voff);
             next_pulled = nxt;
         }
@@ -244,14 +232,14 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const T* __restric
             for (int mo = 0; mo < MT; ++mo) Y[nt][mo] = f32x16{0};
         {
             X8 B[2];
-            if constexpr (!LR) B[0] = __builtin_bit_cast(X8, myl[0]);
+            B[0] = __builtin_bit_cast(X8, myl[0]);
 #pragma unroll
             for (int i = 0; i < 2 * MT * MT; ++i) {  // i = ks * MT + mo
-                if (!LR && i + 1 < 2 * MT * MT) B[(i + 1) & 1] = __builtin_bit_cast(X8, myl[(i + 1) * 64]);
+                if (i + 1 < 2 * MT * MT) B[(i + 1) & 1] = __builtin_bit_cast(X8, myl[(i + 1) * 64]);
                 const int ks = i / MT, mo = i % MT;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    if (!(WAVE_ABL & 4)) Y[nt][mo] = fq_mfma32<T>(Uh[nt][ks], LR ? LFq[LR ? i : 0] : B[i & 1], Y[nt][mo]);
+                    if (!(WAVE_ABL & 4)) Y[nt][mo] = fq_mfma32<T>(Uh[nt][ks], B[i & 1], Y[nt][mo]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -453,15 +441,15 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const T* __restric
     }
 }
 
-template <int MT, int NT, int KS1, int W, bool RMS = false, typename T = f16, int OS = FQ_OUT_PACKED, bool LR = false>
+template <int MT, int NT, int KS1, int W, bool RMS = false, typename T = f16, int OS = FQ_OUT_PACKED>
 int launch_wave(const T* x, const uint4* ws, int64_t rows, int M, const FqQuantOut& out, int n_cu, hipStream_t stream) {
-    typedef WaveGeom<MT, NT, KS1, W, LR> G;
+    typedef WaveGeom<MT, NT, KS1, W> G;
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
     int64_t blocks = (rows + W - 1) / W;
     if (blocks > n_cu) blocks = n_cu;  // one persistent workgroup per CU
     if (blocks < 1) blocks = 1;
     const int64_t tpb = (rows + blocks - 1) / blocks;
-    hipLaunchKernelGGL((fq_kron_wave_kernel<MT, NT, KS1, W, RMS, T, OS, LR>), dim3((unsigned)blocks), dim3(W * 64), 0, stream, x, ws, rows,
+    hipLaunchKernelGGL((fq_kron_wave_kernel<MT, NT, KS1, W, RMS, T, OS>), dim3((unsigned)blocks), dim3(W * 64), 0, stream, x, ws, rows,
                        tpb, M, out);
     return (int)hipGetLastError();
 }
@@ -496,15 +484,6 @@ static int launch_kron_wave_t(int flags, const T* x, const void* ws, const void*
         if (fq_only) return launch_wave<MT_, NT_, KS1_, W_, false, T, FQ_OUT_FAKEQUANT>(x, w, rows, M, out, n_cu, stream); \
         if (y_only) return launch_wave<MT_, NT_, KS1_, W_, false, T, FQ_OUT_TRANSFORM>(x, w, rows, M, out, n_cu, stream);   \
         return launch_wave<MT_, NT_, KS1_, W_, false, T>(x, w, rows, M, out, n_cu, stream);              \
-    }
-#ifndef WAVE_W8
-#define WAVE_W8 0   // 1: 64 x 128 packed launches with EIGHT resident tokens (L fragments in registers, static token slots)
-#endif
-    if (WAVE_W8 && MT == 2 && KS1 == 8 && !fq_only && !y_only && !(out.rt_flags & FQ_GROUP128)) {
-        if constexpr (FqVec<T>::is_f16) {
-            if (rms) return launch_wave<2, 4, 8, 8, true, T, FQ_OUT_PACKED, true>(x, w, rows, M, out, n_cu, stream);
-        }
-        return launch_wave<2, 4, 8, 8, false, T, FQ_OUT_PACKED, true>(x, w, rows, M, out, n_cu, stream);
     }
     FQ_W(2, 4, 8, 7)    // 64x128
     FQ_W(2, 4, 7, 8)    // 64x112

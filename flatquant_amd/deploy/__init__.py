@@ -54,5 +54,6 @@ def matmul(A, B):
 
 
 from . import functional, nn  # noqa: E402,F401
+from .fuse import fuse, unfuse  # noqa: E402,F401
 
-__all__ = ["matmul", "sym_quant", "sym_dequant", "PackedQuantizedTensor", "nn", "functional"]
+__all__ = ["matmul", "sym_quant", "sym_dequant", "PackedQuantizedTensor", "nn", "functional", "fuse", "unfuse"]

@@ -20,8 +20,10 @@ class Linear4bit(torch.nn.Module):
         the first decode-sized call — ON by default (``Linear4bit.decode_image``, a class / instance attribute);
       * the FP6 image (BF6 operands on the FP6 matrix path for K % 128 == 0, N % 16 == 0: same bits out, the GEMM 1.6x
         faster than on the int8 path — 16384 x 4096 x 4096: 159 us against 285, profiles/r03_gemm_bf6_pipeline.txt):
-        +0.75 B/param — OFF by default (``Linear4bit.fp6_image = True`` keeps it): with both images a layer would sit at
-        1.75 B/param, 3.5x the INT4 footprint.
+        +0.75 B/param — kept by DEFAULT since round 5 (``Linear4bit.fp6_image``), built on the first prefill-sized call of a
+        layer of >= ``fp6_min_out_features`` outputs, and only while ``fp6_image_min_free`` (10 %) of the device memory would stay
+        free afterwards: a layer used for prefill AND decode then sits at 1.75 B/param, 3.5x the INT4 footprint — 122 GB for a
+        70 B-parameter model on a 288 GB part; ``fp6_image = False`` (class or instance) returns to 0.5 - 1.0 B/param.
     Without the kept image a call of >= ``fp6_transient_rows`` (129: above the decode kernel's range) tokens still takes the FP6 path: the weights
     are converted INTO A TRANSIENT image for the call (12.6 MB for 4096 x 4096: ~8 us, freed with the call — the caching
     allocator hands the same block to the next layer), which costs 463 / rows of the GEMM's own time and leaves the
@@ -31,9 +33,12 @@ class Linear4bit(torch.nn.Module):
     the class (or of an instance) — no environment variable is read (round 4)."""
 
     static_outputs = False   # (round 4, opt-in) decode-sized calls: a prepared launch with a static output buffer, ~6 us of Python instead of ~13
+    fast_path = True         # (round 5, default) decode-sized calls as a C-side prepared call with a FRESH output: ~8 us of Python, nothing aliases
     decode_image = True   # class-wide policy switches (set on the class or on an instance)
     fp6_gemm = True       # False: no FP6 route at all
-    fp6_image = False
+    fp6_image = True      # (round 5) kept by default for layers of >= fp6_min_out_features outputs while the device has room for it
+    fp6_image_min_free = 0.10   # ... i.e. while at least this fraction of the device memory would stay free after building the image;
+                                # otherwise (and with fp6_image = False) a prefill call converts the weights for the call (transient route)
     fp6_min_out_features = 2048   # narrower layers stay on the int8 matrix path (kept image AND transient route)
     fp6_transient_rows = 129    # calls with at least this many tokens convert the weights for the call when no image is kept (0: never).
                                 # 129 = everything above the decode kernel's range: measured with both conversions inside the call
@@ -62,7 +67,11 @@ class Linear4bit(torch.nn.Module):
             return None
         key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
         if getattr(self, "_wimg_key", None) != key:
-            self._wimg = ops.int4_to_bf6(self.weight, weights=True)
+            self._wimg = None
+            free, total = torch.cuda.mem_get_info(self.weight.device)
+            need = self.weight.numel() * 3 // 2            # 0.75 B/param on top of the 0.5 B/param of `weight`
+            if free - need >= self.fp6_image_min_free * total:
+                self._wimg = ops.int4_to_bf6(self.weight, weights=True)
             self._wimg_key = key
         return self._wimg
 
@@ -102,6 +111,11 @@ class Linear4bit(torch.nn.Module):
 
     def forward(self, x):
         assert type(x) == PackedQuantizedTensor  # quantized input is given (linear.py:45)
+        grp = self.__dict__.get("_group")      # (deploy.fuse: the projections of one attention / MLP run as one GEMM launch)
+        if grp is not None:
+            y = grp.get(self, x)
+            if y is not None:
+                return y
         q, scales_x = x.quantized_x, x.scales_x
         if self.static_outputs:
             st = self.__dict__.get("_plan_state")
@@ -127,6 +141,19 @@ class Linear4bit(torch.nn.Module):
                 self.__dict__["_plan_state"] = (bf["weight"], bf["weight"]._version, bf["weight_scales"]._version,
                                                 -1 if self.bias is None else self.bias._version, ops.cache_epoch(), plan)
                 return plan.run2(q, scales_x)
+            if (dimg is not None and self.fast_path and q.is_contiguous() and scales_x.is_contiguous() and scales_x.dtype == torch.float16
+                    and scales_x.numel() == rows and not torch.cuda.is_current_stream_capturing()):
+                # (round 5, default) the decode-sized call as a C-side prepared call with a FRESH output (ops.FreshPlan)
+                bf = self._buffers
+                w = bf["weight"]
+                st = self.__dict__.get("_fresh_state")
+                if (st is None or st[0] is not w or st[1] != w._version or st[2] != bf["weight_scales"]._version
+                        or st[3] != (-1 if self.bias is None else self.bias._version) or st[4] != ops.cache_epoch() or not st[5].matches(q)):
+                    ws16, b16 = self._scales16()
+                    plan = ops.skinny_linear_fresh_plan(q, dimg, ws16, b16, self.out_features, lead + (self.out_features,))
+                    st = (w, w._version, bf["weight_scales"]._version, -1 if self.bias is None else self.bias._version, ops.cache_epoch(), plan)
+                    self.__dict__["_fresh_state"] = st
+                return st[5].run_linear(q, scales_x)
             if dimg is not None:
                 ws16, b16 = self._scales16()
                 y = ops.int4_skinny_linear(q.reshape(rows, -1).contiguous(), scales_x.reshape(-1).contiguous(), dimg,

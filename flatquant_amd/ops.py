@@ -444,6 +444,103 @@ class LaunchPlan:
         return self.run(x)
 
 
+class FreshPlan:
+    """A prepared library call whose arguments live on the C side (fq_plan_*, round 5 — the host path of VERDICT r04 item 6a): every
+    ``run`` allocates FRESH outputs (no aliasing between calls, unlike LaunchPlan's static buffers) and makes one foreign call with five
+    pointers — ~8 us of Python per module call where the general entry points spend 14-20 (tools/host_overhead.py), same bits out.
+    Built for one input shape / dtype / device and one set of matrices / clip factors; the owner (a deploy.nn module) re-plans when any
+    of them changes. Not used under stream capture (a captured graph must not hold pointers into a plan the owner may rebuild)."""
+    __slots__ = ("handle", "shape", "dtype", "dev_index", "device", "keep", "q_shape", "s_shape", "s_dtype", "__weakref__")
+
+    def __init__(self, handle, x_like: torch.Tensor, q_shape, s_shape, s_dtype, keep):
+        if not handle:
+            raise _lib.FqError(_lib.FQ_EINVAL, lib.fq_last_error().decode("utf-8", "replace"))
+        self.handle = ctypes.c_void_p(handle)
+        self.shape, self.dtype, self.device = x_like.shape, x_like.dtype, x_like.device
+        self.dev_index = x_like.device.index if x_like.device.index is not None else torch.cuda.current_device()
+        self.q_shape, self.s_shape, self.s_dtype, self.keep = q_shape, s_shape, s_dtype, keep
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            lib.fq_plan_free(h)
+
+    def matches(self, x: torch.Tensor) -> bool:
+        return x.shape == self.shape and x.dtype == self.dtype and x.device == self.device
+
+    def run(self, x: torch.Tensor):
+        """-> (q uint8 ``q_shape``, scales ``s_shape``): fresh tensors. x: contiguous, ``matches(x)`` (the caller has checked)."""
+        q = torch.empty(self.q_shape, dtype=torch.uint8, device=self.device)
+        sc = torch.empty(self.s_shape, dtype=self.s_dtype, device=self.device)
+        if torch.cuda.current_device() != self.dev_index:
+            with _on(self.device):
+                rc = lib.fq_plan_run(self.handle, x.data_ptr(), None, q.data_ptr(), sc.data_ptr(), _stream_handle(self.device))
+        else:
+            rc = lib.fq_plan_run(self.handle, x.data_ptr(), None, q.data_ptr(), sc.data_ptr(), _stream_handle(self.device))
+        if rc:
+            check(rc)
+        return q, sc
+
+    def run_linear(self, xq: torch.Tensor, xs: torch.Tensor):
+        """skinny linear plans: (packed x, its fp16 scales) -> fresh y of ``q_shape`` (fp16)"""
+        y = torch.empty(self.q_shape, dtype=torch.float16, device=self.device)
+        if torch.cuda.current_device() != self.dev_index:
+            with _on(self.device):
+                rc = lib.fq_plan_run(self.handle, xq.data_ptr(), xs.data_ptr(), y.data_ptr(), None, _stream_handle(self.device))
+        else:
+            rc = lib.fq_plan_run(self.handle, xq.data_ptr(), xs.data_ptr(), y.data_ptr(), None, _stream_handle(self.device))
+        if rc:
+            check(rc)
+        return y
+
+
+def kron_fresh_plan(x_like: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sig: Sig, flags: int, q_shape, s_shape) -> FreshPlan:
+    """deploy.nn.OnlineTrans(matmul, decompose).forward as a FreshPlan: one clip pair, packed output; the fragment image is prepared
+    here and kept by the plan (as are left / right: their addresses cannot be recycled under it)."""
+    dt = _chk_act(x_like)
+    _chk(left, "left", dt), _chk(right, "right", dt)
+    M, N = left.shape[0], right.shape[0]
+    d = M * N
+    if left.shape != (M, M) or right.shape != (N, N) or x_like.shape[-1] != d or x_like.numel() == 0:
+        raise ValueError("kron_fresh_plan: x [..., M*N] (not empty), left [M, M], right [N, N]")
+    rows = x_like.numel() // d
+    with _on(x_like.device):
+        nbytes = int(lib.fq_kron_workspace_bytes(M, N))
+        if nbytes < 0:
+            raise _lib.FqError(nbytes, f"no kernel for Kronecker factors ({M}, {N})")
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x_like.device)
+        if nbytes:
+            check(_fn("kron_prepare", dt)(_ptr(left), _ptr(right), M, N, _ptr(ws), nbytes, _stream(x_like)))
+    h = lib.fq_plan_kron(int(dt == torch.bfloat16), left.data_ptr(), right.data_ptr(), rows, M, N, float(sig[0]), float(sig[1]),
+                         (flags & ~FQ_WS_PREPARED) | (FQ_WS_PREPARED if nbytes else 0), ws.data_ptr() if nbytes else None, nbytes)
+    return FreshPlan(h, x_like, q_shape, s_shape, dt, (left, right, ws))
+
+
+def rowquant_fresh_plan(x_like: torch.Tensor, sig: Sig, flags: int, q_shape, s_shape) -> FreshPlan:
+    """deploy.nn.Quantizer.forward as a FreshPlan (one clip pair, packed output)."""
+    dt = _chk_act(x_like)
+    cols = x_like.shape[-1]
+    if x_like.numel() == 0:
+        raise ValueError("rowquant_fresh_plan: empty input")
+    h = lib.fq_plan_rowquant(int(dt == torch.bfloat16), x_like.numel() // cols, cols, float(sig[0]), float(sig[1]), flags)
+    return FreshPlan(h, x_like, q_shape, s_shape, dt, ())
+
+
+def skinny_linear_fresh_plan(x_like: torch.Tensor, w_image: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor], N: int,
+                             y_shape) -> FreshPlan:
+    """the decode-sized Linear4bit.forward (fq_int4_skinny_linear_f16) as a FreshPlan: ``plan.run_linear(x_packed, x_scales)`` -> a fresh
+    fp16 ``y_shape`` tensor. x_scales: contiguous fp16 of M elements (the caller checks)."""
+    _chk(x_like, "x", torch.uint8), _chk(w_scale, "w_scale")
+    if bias is not None:
+        _chk(bias, "bias")
+    K = x_like.shape[-1] * 2
+    M = x_like.numel() // x_like.shape[-1] if x_like.numel() else 0
+    if M == 0 or w_scale.numel() != N:
+        raise ValueError("skinny_linear_fresh_plan: empty input or w_scale size")
+    h = lib.fq_plan_skinny_linear(w_image.data_ptr(), w_scale.data_ptr(), None if bias is None else bias.data_ptr(), M, N, K)
+    return FreshPlan(h, x_like, y_shape, None, None, (w_image, w_scale, bias))
+
+
 def skinny_linear_plan(x_like: torch.Tensor, w_image: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor], N: int) -> LaunchPlan:
     """int4_skinny_linear (M <= 128 rows against a decode weight image) as a LaunchPlan: ``plan.run2(x_packed, x_scale)`` -> the static
     fp16 [M, N] output. x_scale must be a contiguous fp16 tensor of M elements (not re-checked per call)."""

@@ -272,6 +272,26 @@ int fq_kron_prepare_bf16(const void* left, const void* right, int M, int N, void
                          void* stream);
 
 /*
+ * Prepared calls (round 5): an argument cache for the calls a deploy module makes on every forward — what the reference's modules
+ * do per call in Python around their kernels (deploy/nn/online_trans.py:61-99 -> functional/online_trans.py:113-122 ->
+ * kernels/kron_matmul.py:192-266; deploy/nn/quantization.py:13-36; deploy/nn/linear.py:41-56). A plan fixes everything that does not
+ * change between calls; fq_plan_run(plan, in0, in1, out0, out1, stream) supplies the per-call pointers:
+ *   fq_plan_kron            in0 = x [rows, M*N]            out0 = q [rows, M*N/2] uint8, out1 = scale [rows]   (FQ_OUT_PACKED, one clip set;
+ *                           left / right / workspace as for fq_kron_quant_{f16,bf16}; with FQ_WS_PREPARED the image fq_kron_prepare_* wrote)
+ *   fq_plan_rowquant        in0 = x [rows, cols]           out0 = q, out1 = scale                              (FQ_OUT_PACKED, one clip set)
+ *   fq_plan_skinny_linear   in0 = packed x [M, K/2], in1 = x scales [M] fp16      out0 = y [M, N] fp16         (fq_int4_skinny_linear_f16)
+ * sig_max / sig_min are the sigmoid-ed factors (as the float arrays of the plain entry points). Outputs are the CALLER'S buffers, fresh
+ * or reused; results are bit for bit those of the plain entry point. A plan is immutable and holds no device memory: run it from any
+ * thread; it stays valid while the pointers it was built from do. fq_plan_* return NULL on bad arguments (fq_last_error()).
+ */
+void* fq_plan_kron(int bf16, const void* left, const void* right, int64_t rows, int M, int N, float sig_max, float sig_min, int flags,
+                   void* workspace, int64_t workspace_bytes);
+void* fq_plan_rowquant(int bf16, int64_t rows, int cols, float sig_max, float sig_min, int flags);
+void* fq_plan_skinny_linear(const void* w_image, const void* w_scale, const void* bias, int64_t M, int N, int K);
+int fq_plan_run(const void* plan, const void* in0, const void* in1, void* out0, void* out1, void* stream);
+void fq_plan_free(void* plan);
+
+/*
  * Multi-job launch (round 4): SEVERAL independent 64 x 64 transform + quantisation jobs — one per layer of a model, or one per
  * shard — as ONE kernel launch. What a caller that shards the rows over GPUs is left with per layer is a short launch (2048
  * tokens = 5 us of kernel behind a launch that costs as much); the jobs of a step are independent (flat_linear.py:75-80 and

@@ -5,8 +5,9 @@ fq_kron_tall.hip).
 (1) HAZARDS: between such a load and the wait that covers it no instruction may READ or COPY the destination registers (the data
     has not arrived; a register copy there — a phi, a spill, an AGPR move — silently takes the old contents). Waits:
       s_waitcnt vmcnt(0)              covers everything;
-      s_waitcnt vmcnt(4)  (--deep 2)  covers all but the four loads issued last (the two-register-set build, TALL_DEEP=2);
-      s_waitcnt vmcnt(k)  (--deep 1)  the counted wait behind the token's stores (TALL_DEEP=1: k = stores issued since): covers all.
+      s_waitcnt vmcnt(4)  (--deep 2)  covers all but the four loads issued last (a two-register-set build);
+      s_waitcnt vmcnt(k)  (--deep 1)  a counted wait behind the token's stores (k = stores issued since): covers all.
+    (the two --deep forms belong to prefetch variants measured and removed in round 5; kept for the next experiment of that kind)
 (2) LOOP WAITS (round 5): inside the token loop the ONLY vmcnt waits may be the kernel's own explicit ones and the vmcnt(0) directly
     behind a compiler-tracked load of a grouped launch's clip / offset arrays. Rounds 3-4 shipped a build whose compiler-inserted
     waits for the factor fragments (loaded once, in the prologue, and sunk below the prologue's wait by the scheduler) sat in front
