@@ -90,7 +90,6 @@ SYMBOLS = {
     "fq_bf6_linear_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
     "fq_int4_linear_fp6_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _i64, _vp]),
     "fq_int4_linear_fp6_multi_f16": (_i, [_i, _vpp, _vpp, _vpp, _vpp, _vpp, _vpp, _i64, _ip, _i, _vpp, _vp, _i64, _vp]),
-    "fq_int4_linear_fp6_gate_up_f16": (_i, [_vpp, _vpp, _vpp, _vpp, _vpp, _vpp, _i64, _i, _i, _vp, _vp, _i64, _vp]),
     "fq_kv_quant_f16": (_i, [_vp, _vp, _i64, _i, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "fq_kv_dequant_f16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "fq_kv_append_i4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -18,7 +18,7 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
                            int64_t rows, int M, int N, const FqQuantOut& out, void* workspace,
                            int64_t workspace_bytes, int n_cu, hipStream_t stream);
 int fq_launch_gemm_bf6_multi(int n, const uint8_t* const* xblob, const uint8_t* const* wblob, int64_t M, const int* Ns, int K, f16* const* y,
-                             const f16* const* srow, const f16* const* scol, const f16* const* bias, int gate_up, hipStream_t stream);   // fq_gemm_bf6.hip
+                             const f16* const* srow, const f16* const* scol, const f16* const* bias, hipStream_t stream);   // fq_gemm_bf6.hip
 int fq_launch_fakequant_bits(int bf16_dtype, const void* x, void* y, int64_t rows, int cols, float sig_max, float sig_min, int bits, int flags,
                              int n_cu, hipStream_t stream);   // fq_quant.hip
 int fq_launch_kron64_multi(int bf16_dtype, const void* jobs, int n_jobs, int bpj, const FqQuantOut& out, hipStream_t stream);
@@ -821,7 +821,7 @@ int fq_int4_linear_fp6_f16(const void* x, const void* x_scale, const void* w, co
     return check_launch(rc, what);
 }
 
-static int linear_fp6_multi(const char* what, int gate_up, int n, const void* const* x, const void* const* x_scale, const void* const* w,
+static int linear_fp6_multi(const char* what, int n, const void* const* x, const void* const* x_scale, const void* const* w,
                             const void* const* wblob, const void* const* w_scale, const void* const* bias, int64_t M, const int* N, int K,
                             void* const* y, void* scratch, int64_t scratch_bytes, void* stream) {
     if (n < 1 || n > 4) return fail(FQ_EINVAL, "%s: 1..4 problems (got %d)", what, n);
@@ -871,22 +871,14 @@ static int linear_fp6_multi(const char* what, int gate_up, int n, const void* co
         }
     }
     const int rc = fq_launch_gemm_bf6_multi(n, xb, wb, M, N, K, (f16* const*)y, (const f16* const*)x_scale, (const f16* const*)w_scale,
-                                            (const f16* const*)bias, gate_up, (hipStream_t)stream);
+                                            (const f16* const*)bias, (hipStream_t)stream);
     return check_launch(rc, what);
 }
 
 int fq_int4_linear_fp6_multi_f16(int n, const void* const* x, const void* const* x_scale, const void* const* w, const void* const* wblob,
                                  const void* const* w_scale, const void* const* bias, int64_t M, const int* N, int K, void* const* y,
                                  void* scratch, int64_t scratch_bytes, void* stream) {
-    return linear_fp6_multi("fq_int4_linear_fp6_multi_f16", 0, n, x, x_scale, w, wblob, w_scale, bias, M, N, K, y, scratch, scratch_bytes, stream);
-}
-
-int fq_int4_linear_fp6_gate_up_f16(const void* const* x, const void* const* x_scale, const void* const* w, const void* const* wblob,
-                                   const void* const* w_scale, const void* const* bias, int64_t M, int N, int K, void* y, void* scratch,
-                                   int64_t scratch_bytes, void* stream) {
-    const int Ns[2] = {N, N};
-    void* const ys[2] = {y, y};
-    return linear_fp6_multi("fq_int4_linear_fp6_gate_up_f16", 1, 2, x, x_scale, w, wblob, w_scale, bias, M, Ns, K, ys, scratch, scratch_bytes, stream);
+    return linear_fp6_multi("fq_int4_linear_fp6_multi_f16", n, x, x_scale, w, wblob, w_scale, bias, M, N, K, y, scratch, scratch_bytes, stream);
 }
 
 int fq_fwht_f32_f16(const void* x, void* y, int64_t vecs, int P, float scale, void* stream) {

@@ -44,9 +44,6 @@ using namespace fqgemm;
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_b;
 
-#ifndef FQ_GU_ABL
-#define FQ_GU_ABL 0   // measurement builds of the gate / up epilogue: 1 = no SiLU arithmetic, 2 = no read-back of the gate tile's values (wrong results)
-#endif
 constexpr int BN = 256;
 constexpr int BLOB = 1536;                     // bytes: 32 rows x 64 k of BF6
 constexpr int SEG = 2 * BLOB;                  // a row tile's two blobs of one stage (128 k)
@@ -144,18 +141,14 @@ template <> struct GemmMultiArg<true> {
     GemmOut out[4];
 };
 
-//
-// MODE 2, GATE_UP (round 4): x_up * act_fn(x_gate) (deploy/transformers/modeling_llama.py:270-278) in the epilogue of the
-// gate / up pair. Problem 0 is gate_proj, problem 1 up_proj, with their own activations and the same N; a workgroup computes the gate tile
-// (mb, nb), writes a = fp16(silu(y_gate)) where the result will stand, then computes the up tile of the same (mb, nb), whose epilogue
-// has read a back — every lane its own 32 bytes per accumulator tile, written one K loop earlier — and stores a * y_up. The main loop,
-// the 256 x 256 tile and the accumulator count are those of the single-problem kernel (two accumulator sets would halve the tile); the
-// intermediate [M, N] tensors x_gate and x_up (2 x 470 MB written, read again by SiLU.mul at 16384 x 14336) never exist.
+// (round 4 built, measured and round 5 removed a MODE 2: x_up * silu(x_gate) in the epilogue of the gate / up pair — bit-identical to the
+//  GEMMs + fq_silu_mul_f16, and no faster: the up tile's epilogue reads the gate tile's values back (~100 us per 16384 x 14336 launch) and the
+//  SiLU arithmetic sits where no MFMA overlaps it; 1401 us fused against 1397 separate, a loss at 2048 tokens — profiles/r04_gate_up_epilogue.txt)
 template <int BM, int MODE = 0>
 __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB_, const uint8_t* __restrict__ WB_,
                                                                               int M, int N_, int KB, int n_vblocks, GemmOut out_,
                                                                               GemmMultiArg<(MODE != 0)> mp) {
-    constexpr bool MULTI = MODE != 0, GATE_UP = MODE == 2;
+    constexpr bool MULTI = MODE != 0;
     const uint8_t* XB = XB_;
     const uint8_t* WB = WB_;
     int N = N_;
@@ -374,13 +367,7 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
                      "+v"(sc[1][1]), "+v"(bs[0][0]), "+v"(bs[0][1]), "+v"(bs[1][0]), "+v"(bs[1][1]));
         // the next tile of this workgroup: its first stages are requested NOW, in front of the epilogue
         int nvb = vb + (int)gridDim.x, nmb = 0, nnb = 0, nprob = 0;
-        bool more;
-        if (GATE_UP && prob == 0) {   // the up tile of the same (mb, nb)
-            nvb = vb, nmb = mb, nnb = nb, nprob = 1;
-            more = true;
-        } else {
-            more = next_tile(nvb, nmb, nnb, nprob);
-        }
+        const bool more = next_tile(nvb, nmb, nnb, nprob);
         if (more) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();   // every wave has read the last stage: all three buffers are free
@@ -414,21 +401,6 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
                         dequant16f<false>(acc[tn][tm], sr[tm], __builtin_bit_cast(f16x8, sc[tn][0]), __builtin_bit_cast(f16x8, sc[tn][1]),
                                           out.bias != nullptr, __builtin_bit_cast(f16x8, bs[tn][0]), __builtin_bit_cast(f16x8, bs[tn][1]), o0, o1);
                     uint4* yp = reinterpret_cast<uint4*>(out.y + (int64_t)m * N + nbase);
-                    if constexpr (GATE_UP) {
-                        if (prob == 0) {
-                            if (!(FQ_GU_ABL & 1)) {
-                                o0 = fq_silu8(o0);
-                                o1 = fq_silu8(o1);
-                            }
-                        } else if (!(FQ_GU_ABL & 2)) {
-                            // These loads stand behind the next tile's LDS-DMA requests in the vmcnt queue: the epilogue of an up tile starts when those have
-                            // landed (7 us per tile pair, tools/r04_call48.sh). Requested in FRONT of them and waited for there (64 registers: spills in
-                            // the tail only) the launch was slower still, 1255 -> 1450 us (r04_call49): every workgroup reads its 128 KB back at the same
-                            // moment, a 32 MB burst, and nothing overlaps it.
-                            o0 = __builtin_bit_cast(f16x8, yp[0]) * o0;
-                            o1 = __builtin_bit_cast(f16x8, yp[1]) * o1;
-                        }
-                    }
                     yp[0] = __builtin_bit_cast(uint4, o0);   // (plain stores: non-temporal ones measured 163 -> 173 us)
                     yp[1] = __builtin_bit_cast(uint4, o1);
                 }
@@ -514,11 +486,9 @@ int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, in
 }
 
 // Up to four problems with common M and K in one launch (fq_gemm_bf6_kernel<BM, true>). -1000: shape not covered.
-// gate_up != 0: n == 2, problem 0 = gate_proj, problem 1 = up_proj, Ns[0] == Ns[1], y[0] == y[1] = the [M, N] result x_up * silu(x_gate).
 int fq_launch_gemm_bf6_multi(int n, const uint8_t* const* xblob, const uint8_t* const* wblob, int64_t M, const int* Ns, int K, f16* const* y,
-                             const f16* const* srow, const f16* const* scol, const f16* const* bias, int gate_up, hipStream_t stream) {
+                             const f16* const* srow, const f16* const* scol, const f16* const* bias, hipStream_t stream) {
     if (n < 1 || n > 4 || (K & 127) || K > (1 << 18) || M < 1 || M > (1 << 30)) return -1000;
-    if (gate_up && (n != 2 || Ns[0] != Ns[1] || y[0] != y[1])) return -1000;
     GemmMultiArg<true> mp = {};
     mp.n = n;
     int tn = 0;
@@ -537,10 +507,6 @@ int fq_launch_gemm_bf6_multi(int n, const uint8_t* const* xblob, const uint8_t* 
         mp.out[p].bias = bias[q];
     }
     for (int p = n; p < 5; ++p) mp.tn0[p] = tn;
-    if (gate_up) {   // the tile sequence is the one of ONE problem; a workgroup runs both problems on each of its tiles
-        tn = (Ns[0] + BN - 1) / BN;
-        for (int p = 1; p < 5; ++p) mp.tn0[p] = tn;
-    }
     static int cus[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -552,28 +518,13 @@ int fq_launch_gemm_bf6_multi(int n, const uint8_t* const* xblob, const uint8_t* 
     const int64_t tiles256 = ((M + 255) / 256) * tn;
     const bool half = tiles256 * 4 < (int64_t)cus[dev] * 3;
     const int bm = half ? 128 : 256;
-    int64_t n_vblocks = 8 * ((((M + bm - 1) / bm) * tn + 7) / 8);
-    if (!gate_up) {   // eight XCD shares of the per-problem shares (next_tile, MODE 1)
-        n_vblocks = 0;
-        for (int p = 0; p < n; ++p) n_vblocks += 8 * ((((M + bm - 1) / bm) * (int64_t)(mp.tn0[p + 1] - mp.tn0[p]) + 7) / 8);
-    }
+    int64_t n_vblocks = 0;   // eight XCD shares of the per-problem shares (next_tile, MODE 1)
+    for (int p = 0; p < n; ++p) n_vblocks += 8 * ((((M + bm - 1) / bm) * (int64_t)(mp.tn0[p + 1] - mp.tn0[p]) + 7) / 8);
     int64_t blocks = (cus[dev] / 8) * 8;
     if (blocks < 8) blocks = 8;
     if (blocks > n_vblocks) blocks = n_vblocks;
     GemmOut o0 = mp.out[0];
-    if (gate_up) {
-        if (half) {
-            auto kern = fq_gemm_bf6_kernel<128, 2>;
-            FQ_RAISE_LDS_CAP(kern, Geo<128>::STAGES * Geo<128>::TILE_BYTES);
-            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Geo<128>::GT), Geo<128>::STAGES * Geo<128>::TILE_BYTES, stream, mp.xb[0], mp.wb[0],
-                               (int)M, mp.N[0], K / 64, (int)n_vblocks, o0, mp);
-        } else {
-            auto kern = fq_gemm_bf6_kernel<256, 2>;
-            FQ_RAISE_LDS_CAP(kern, Geo<256>::STAGES * Geo<256>::TILE_BYTES);
-            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Geo<256>::GT), Geo<256>::STAGES * Geo<256>::TILE_BYTES, stream, mp.xb[0], mp.wb[0],
-                               (int)M, mp.N[0], K / 64, (int)n_vblocks, o0, mp);
-        }
-    } else if (half) {
+    if (half) {
         auto kern = fq_gemm_bf6_kernel<128, 1>;
         FQ_RAISE_LDS_CAP(kern, Geo<128>::STAGES * Geo<128>::TILE_BYTES);
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Geo<128>::GT), Geo<128>::STAGES * Geo<128>::TILE_BYTES, stream, mp.xb[0], mp.wb[0],

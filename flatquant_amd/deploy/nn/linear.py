@@ -218,32 +218,3 @@ def linear4bit_multi(modules, inputs):
     ys = ops.int4_linear_fp6_multi(problems)
     lead = q0.shape[:-1]
     return [y.view(*lead, m.out_features) for y, m in zip(ys, modules)]
-
-
-def linear4bit_gate_up(gate_proj, up_proj, x_gate, x_up=None):
-    """``up_proj(x_up) * silu(gate_proj(x_gate))`` of a gated MLP (deploy/transformers/modeling_llama.py:268-278: two Linear4bit calls, the
-    activation and a multiplication, three [tokens, intermediate] fp16 tensors written and two read back) as ONE GEMM launch whose epilogue
-    applies SiLU and the product (round 4, fq_int4_linear_fp6_gate_up_f16). ``x_gate`` / ``x_up``: the PackedQuantizedTensor of each
-    projection (``x_up=None``: both see ``x_gate`` — the reference's fuseLN branch, one Quantizer). Bit-identical to
-    ``ops.silu_mul(gate_proj(x_gate), up_proj(x_up))``; falls back to exactly that when the FP6 route does not apply to both modules."""
-    x_up = x_gate if x_up is None else x_up
-    assert type(x_gate) == PackedQuantizedTensor and type(x_up) == PackedQuantizedTensor
-    qg, qu = x_gate.quantized_x, x_up.quantized_x
-    rows = qg.numel() // qg.shape[-1]
-    ok = qg.is_cuda and qg.shape == qu.shape and not ops.skinny_supported(rows, gate_proj.in_features)
-    ok = ok and gate_proj.in_features == up_proj.in_features and gate_proj.out_features == up_proj.out_features
-    for m in (gate_proj, up_proj):
-        ok = ok and m.fp6_gemm and ops.bf6_supported(m.out_features, m.in_features) and m.out_features >= m.fp6_min_out_features
-        ok = ok and (m._weight_image() is not None or bool(m.fp6_transient_rows and rows >= m.fp6_transient_rows))
-    if not ok:
-        return ops.silu_mul(gate_proj(x_gate), up_proj(x_up))
-    problems = []
-    for m, x in ((gate_proj, x_gate), (up_proj, x_up)):
-        ws16, b16 = m._scales16()
-        q = x.quantized_x
-        problems.append((q.reshape(-1, q.shape[-1]).contiguous(), x.scales_x.reshape(-1).contiguous(), m.weight, m._weight_image(), ws16, b16))
-    if x_up is x_gate:   # one converted operand for both
-        problems[1] = (problems[0][0], problems[0][1]) + problems[1][2:]
-    y = ops.int4_linear_fp6_gate_up(problems[0], problems[1])
-    return y.view(*qg.shape[:-1], gate_proj.out_features)
-

@@ -1437,40 +1437,6 @@ def int4_linear_fp6_multi(problems) -> list:
     return ys
 
 
-def int4_linear_fp6_gate_up(gate, up) -> torch.Tensor:
-    """gate_proj, up_proj and ``x_up * silu(x_gate)`` of a gated MLP as ONE GEMM launch with the activation in its epilogue
-    (fq_int4_linear_fp6_gate_up_f16; deploy/transformers/modeling_llama.py:268-278 is two Linear4bit calls, SiLU and a multiplication).
-    ``gate`` / ``up``: (x packed [M, K/2], x_scale [M], w packed [N, K/2], w_image or None, w_scale [N], bias [N] or None) with common M,
-    K, N -> fp16 [M, N], bit-identical to silu_mul(int4_linear_fp6(gate), int4_linear_fp6(up)). The two [M, N] projections never exist."""
-    problems = (gate, up)
-    x0 = gate[0]
-    M, K, N = x0.shape[0], x0.shape[1] * 2, gate[2].shape[0]
-    nbytes = 0
-    for x, xs, w, wimg, ws, b in problems:
-        _chk(x, "x", torch.uint8), _chk(w, "w", torch.uint8), _chk(xs, "x_scale"), _chk(ws, "w_scale")
-        if b is not None:
-            _chk(b, "bias")
-        if x.dim() != 2 or w.dim() != 2 or x.shape != x0.shape or w.shape != (N, x.shape[1]):
-            raise RuntimeError("int4_linear_fp6_gate_up: gate and up must share M, K and N (x [M, K/2], w [N, K/2])")
-        if xs.numel() != M or ws.numel() != N or (b is not None and b.numel() != N):
-            raise RuntimeError("int4_linear_fp6_gate_up: scale / bias sizes do not match M / N")
-        if wimg is None:
-            nbytes += int(lib.fq_bf6_blob_bytes(N, K))
-    if not bf6_supported(N, K):
-        raise _lib.FqError(_lib.FQ_EUNSUPPORTED, f"int4_linear_fp6_gate_up: N={N} K={K} not covered (K % 128, N % 16)")
-    nbytes += int(lib.fq_bf6_blob_bytes(M, K)) * (1 if up[0].data_ptr() == x0.data_ptr() else 2)
-    y = torch.empty((M, N), dtype=torch.float16, device=x0.device)
-    if M == 0:
-        return y
-    scratch = torch.empty((nbytes,), dtype=torch.uint8, device=x0.device)
-    VP = ctypes.c_void_p * 2
-    tab = lambda k: VP(*[None if pr[k] is None else pr[k].data_ptr() for pr in problems])
-    with _on(x0.device):
-        check(lib.fq_int4_linear_fp6_gate_up_f16(tab(0), tab(1), tab(2), tab(3), tab(4), tab(5), M, N, K, _ptr(y), _ptr(scratch), nbytes,
-                                                 _stream(x0)))
-    return y
-
-
 def kv_quant(x: torch.Tensor, trans: Optional[torch.Tensor] = None, clip: Sig = (1.0, 1.0), lac: bool = False,
              return_transformed: bool = False):
     """K/V cache quantisation (fq_kv_quant_f16): x [..., head_dim] fp16 -> (q uint8 [..., head_dim/2], param fp16

@@ -413,20 +413,6 @@ int fq_int4_linear_fp6_multi_f16(int n, const void* const* x, const void* const*
                                  void* scratch, int64_t scratch_bytes, void* stream);
 
 /*
- * (round 4) gate_proj, up_proj and x_up * act_fn(x_gate) of a gated MLP (deploy/transformers/modeling_llama.py:268-278: two Linear4bit
- * calls, SiLU, a multiplication — four launches and three [M, N] fp16 intermediates in the reference) as ONE GEMM launch with the
- * activation in its epilogue: y = fp16(fp16(silu(x_gate)) * x_up), x_gate / x_up being exactly what fq_int4_linear_fp6_f16 returns for
- * problem 0 (gate) / problem 1 (up). Tables of TWO pointers as in fq_int4_linear_fp6_multi_f16 (index 0 = gate_proj, 1 = up_proj; equal
- * x[0] == x[1] share one converted operand: the reference's fuseLN branch, one Quantizer for both); both projections are N wide; y [M, N]
- * fp16. A workgroup computes the gate tile, leaves a = fp16(silu(.)) in y, computes the up tile of the same coordinates and multiplies:
- * x_gate and x_up never exist in memory. Bit-identical to fq_silu_mul_f16 over the two single-problem results.
- *   scratch_bytes as for fq_int4_linear_fp6_multi_f16 with n = 2; K % 128 == 0, N % 16 == 0 (FQ_EUNSUPPORTED otherwise).
- */
-int fq_int4_linear_fp6_gate_up_f16(const void* const* x, const void* const* x_scale, const void* const* w, const void* const* wblob,
-                                   const void* const* w_scale, const void* const* bias, int64_t M, int N, int K, void* y, void* scratch,
-                                   int64_t scratch_bytes, void* stream);
-
-/*
  * Normalised Hadamard transform over the last axis, n = K * 2^p:
  *   y = hadK [K,K] @ FWHT_{n/K}( x.view(rows, K, n/K) ) * scale         (hadamard_utils.py:132-141)
  * fp32 butterflies, result of the FWHT rounded to fp16 before the K-factor (as the un-vendored

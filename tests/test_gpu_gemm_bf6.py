@@ -240,53 +240,3 @@ def test_linear4bit_multi_module_entry(ops):
         for m, x, y in zip(mods, xs, ys):
             ref = m(x)
             assert y.shape == ref.shape and torch.equal(y.view(torch.int16), ref.view(torch.int16)), (rows, m.out_features)
-
-
-@pytest.mark.parametrize("M,N,K,shared", [(300, 272, 256, False), (2048, 4096, 512, False), (129, 256, 128, True), (2500, 1040, 384, False),
-                                          (4096 + 3, 2048, 256, True), (16384, 1024, 128, False), (8192, 3584, 10240, False)])
-def test_gate_up_epilogue_bit_identical_to_two_linears_and_silu_mul(ops, M, N, K, shared):
-    """fq_int4_linear_fp6_gate_up_f16 (round 4): gate_proj, up_proj and x_up * silu(x_gate) as one GEMM launch ==
-    fq_silu_mul_f16 over the two single-problem results, bit for bit: partial tiles in both directions, 128- and 256-token tiles, own and
-    shared activations, kept and transient weight images, bias, K beyond 10176 (the epilogue's clamp), ten repeated launches."""
-    gen = torch.Generator().manual_seed(M + N + K)
-    problems, ys = [], []
-    for p in range(2):
-        x = problems[0][0] if (p == 1 and shared) else torch.from_numpy(rand_packed(gen, M, K)[0]).cuda()
-        w = torch.from_numpy(rand_packed(gen, N, K)[0]).cuda()
-        sx = problems[0][1] if (p == 1 and shared) else (torch.rand(M, generator=gen) * 0.05 + 0.001).half().cuda()
-        sw = (torch.rand(N, generator=gen) * 0.02 + 0.0005).half().cuda()
-        b = torch.randn(N, generator=gen).half().cuda() if (p == 0 and K < 1024) else None
-        img = ops.int4_to_bf6(w, weights=True) if p == 1 else None
-        problems.append((x, sx, w, img, sw, b))
-        ys.append(ops.int4_linear_fp6(x, sx, w, img, sw, b))
-    want = ops.silu_mul(ys[0], ys[1])
-    for rep in range(10 if M >= 8192 else 2):
-        got = ops.int4_linear_fp6_gate_up(problems[0], problems[1])
-        assert got.shape == (M, N) and torch.equal(got.view(torch.int16), want.view(torch.int16)), rep
-    assert torch.isfinite(want.float()).all() and float(want.float().abs().max()) > 0
-    with pytest.raises(Exception):
-        ops.int4_linear_fp6_gate_up(problems[0], (problems[1][0], problems[1][1], problems[1][2][:16], None, problems[1][4][:16], None))   # N differs
-
-
-def test_linear4bit_gate_up_module_entry(ops):
-    """deploy.nn.linear.linear4bit_gate_up: the gated MLP's two projections + activation + product in one launch == the reference's four
-    steps on the same modules; decode-sized inputs fall back to those steps; x_up=None shares the packed input (fuseLN branch)."""
-    from flatquant_amd.deploy import PackedQuantizedTensor
-    from flatquant_amd.deploy.nn.linear import Linear4bit, linear4bit_gate_up
-    gen = torch.Generator().manual_seed(11)
-    K, N = 512, 2816
-    mods = []
-    for i in range(2):
-        m = Linear4bit(K, N, bias=False).cuda()
-        m.weight.copy_(torch.from_numpy(rand_packed(gen, N, K)[0]))
-        m.weight_scales.copy_((torch.rand(N, 1, generator=gen) * 0.02 + 0.0005))
-        mods.append(m)
-    mods[1].fp6_image = True
-    for rows in (2048, 64):
-        xs = [PackedQuantizedTensor(torch.from_numpy(rand_packed(gen, rows, K)[0]).cuda().reshape(2, rows // 2, K // 2),
-                                    (torch.rand(2, rows // 2, 1, generator=gen) * 0.05 + 0.001).half().cuda()) for _ in mods]
-        for xu in (xs[1], None):
-            y = linear4bit_gate_up(mods[0], mods[1], xs[0], xu)
-            ref = ops.silu_mul(mods[0](xs[0]), mods[1](xs[0] if xu is None else xu))
-            assert y.shape == ref.shape == (2, rows // 2, N) and torch.equal(y.view(torch.int16), ref.view(torch.int16)), (rows, xu is None)
-

@@ -194,6 +194,7 @@ def main():
             ("o_proj", m["hidden"], m["hidden"]), ("up_proj", m["hidden"], m["ffn"]),
             ("gate_proj", m["hidden"], m["ffn"]), ("down_proj", m["ffn"], m["hidden"])]
     packed = {m["hidden"]: ln_trans(xs[0]), m["ffn"]: had(xf[0], quantizer=quant)}
+    deploy.nn.Linear4bit.fp6_image = False   # (round 4's default: the weights converted per call)
     gtot = 0.0
     for name, k_in, n_out in lins:
         lin = deploy.nn.Linear4bit(k_in, n_out).to(dev)
@@ -205,7 +206,7 @@ def main():
     print(f"  {'seven linears':26s} {gtot:9.1f} us;  FlatQuant layer, fused activation path + linears: {fused_struct + gtot:.1f} us")
 
     # the same seven linears with the FP6 operand image of the weights (Linear4bit.fp6_image: +0.75 B/param, same bits out)
-    deploy.nn.Linear4bit.fp6_image = True
+    deploy.nn.Linear4bit.fp6_image = True   # (the default since round 5)
     g6 = 0.0
     for name, k_in, n_out in lins:
         lin = deploy.nn.Linear4bit(k_in, n_out).to(dev)
@@ -231,19 +232,8 @@ def main():
         gm += us
         gm_by[names[0]] = us
         print(f"  {'Linear4bit ' + ' + '.join(names) + ', one launch':58s} {us:9.1f} us")
-        if names[0] == "up_proj":
-            # (round 4) ... and with x_up * silu(x_gate) in that launch's epilogue (linear4bit_gate_up, fq_int4_linear_fp6_gate_up_f16): the two
-            # [tokens, ffn] projections are never written, the down_proj transform reads the product like any other activation
-            from flatquant_amd.deploy.nn.linear import linear4bit_gate_up
-            gu = timeit(lambda: linear4bit_gate_up(mods[1], mods[0], ins[1], ins[0]), max(a.steps // 5, 5), warm=3)
-            print(f"  {'Linear4bit gate_proj + up_proj + SiLU.mul, one launch':58s} {gu:9.1f} us")
         del mods
-    deploy.nn.Linear4bit.fp6_image = False
     print(f"  {'seven linears, FP6 path, q/k/v and up/gate as one launch each':62s} {gm:9.1f} us;  FlatQuant layer: {fused_struct + gm:.1f} us")
-    gu_layer = (fused_struct - mmf + mm) + (gm - gm_by["up_proj"] + gu)
-    print(f"  ... with SiLU.mul in the gate/up GEMM epilogue (down transform {mm:.1f} us instead of {mmf:.1f}, gate/up launch {gu:.1f} instead of "
-          f"{gm_by['up_proj']:.1f}): FlatQuant layer {gu_layer:.1f} us")
-
     # FP16 baseline of the same layer pieces (what benchmarks/layer_benchmark.py:200-274 compares against): the seven
     # nn.Linear GEMMs in fp16 (rocBLAS / hipBLASLt through torch), two RMSNorms and SiLU.mul in torch eager; the
     # attention core is in neither number.
@@ -263,8 +253,7 @@ def main():
           f"FlatQuant W4A4 layer {fused_struct + gtot:.1f} us -> {f16layer / (fused_struct + gtot):.2f}x "
           f"(linears alone {f16tot / gtot:.2f}x); with the FP6 operand image {fused_struct + g6:.1f} us -> "
           f"{f16layer / (fused_struct + g6):.2f}x (linears alone {f16tot / g6:.2f}x); with q/k/v and up/gate as one launch each "
-          f"{fused_struct + gm:.1f} us -> {f16layer / (fused_struct + gm):.2f}x (linears alone {f16tot / gm:.2f}x); with SiLU.mul in the gate/up GEMM "
-          f"epilogue {gu_layer:.1f} us -> {f16layer / gu_layer:.2f}x")
+          f"{fused_struct + gm:.1f} us -> {f16layer / (fused_struct + gm):.2f}x (linears alone {f16tot / gm:.2f}x)")
 
 
 if __name__ == "__main__":

@@ -16,17 +16,22 @@ ROWS = 16384
 NB = 3
 
 
-def timeit(fn, steps=50, warm=5):
+def timeit(fn, steps=50, warm=10):
+    """median of per-launch event pairs (round 5: the mean of 50 launches after 5 warm-ups, with the outputs allocated inside every
+    call, put two 4x outliers into round 4's tables — 144x192 at 792 us, 168x176 at 1117 — that the kernel does not have:
+    profiles/r05_tiles_outliers.txt, 2050 launches each under rocprofv3: max / avg = 1.47 / 1.30). Also prints nothing else: callers
+    that want the spread use tools/time_dist.py."""
     for i in range(warm):
         fn(i)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record()
     for i in range(steps):
         fn(i)
-    e1.record()
+        ev[i + 1].record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / steps * 1e3
+    us = sorted(ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(steps))
+    return us[len(us) // 2]
 
 
 def line(name, shape, us, bytes_per_row, d, rows=ROWS):

@@ -47,9 +47,15 @@ p = ot(x3)
 timeit("ops.kron_quant 64x64 packed", lambda: ops.kron_quant(x, L, R, SIG, P))
 timeit("ops.kron_quant 112x128 packed", lambda: ops.kron_quant(xf, L2, R2, SIG, P))
 timeit("ops.rowquant (deploy Quantizer arithmetic)", lambda: ops.rowquant(x, SIG, FQ_OUT_PACKED | 0x20 | 0x400))
-timeit("deploy.nn.OnlineTrans(matmul).forward", lambda: ot(x3))
-timeit("deploy.nn.Quantizer(lac).forward", lambda: qz(x))
-timeit("deploy.nn.Linear4bit.forward (decode kernel)", lambda: lin(p))
+# (round 5) the modules' DEFAULT forward: a C-side prepared call with fresh outputs (ops.FreshPlan, fq_plan_*)
+timeit("deploy.nn.OnlineTrans(matmul).forward (default)", lambda: ot(x3))
+timeit("deploy.nn.Quantizer(lac).forward (default)", lambda: qz(x))
+timeit("deploy.nn.Linear4bit.forward, decode (default)", lambda: lin(p))
+ot.fast_path = qz.fast_path = lin.fast_path = False   # the general entry points (round 4's default)
+timeit("OnlineTrans(matmul).forward, fast_path = False", lambda: ot(x3))
+timeit("Quantizer(lac).forward, fast_path = False", lambda: qz(x))
+timeit("Linear4bit.forward, decode, fast_path = False", lambda: lin(p))
+ot.fast_path = qz.fast_path = lin.fast_path = True
 # (round 4) prepared launches with static outputs (ops.LaunchPlan; the modules' opt-in static_outputs attribute)
 kp = ops.kron_plan(x, L, R, SIG, P)
 timeit("ops.kron_plan(...).run 64x64 packed", lambda: kp.run(x))

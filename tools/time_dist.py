@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-launch time DISTRIBUTION of fq_kron_quant_f16 through the C ABI with pre-allocated, rotating buffers (nothing is allocated
 inside the timed loop): one HIP-event pair per launch, N launches per case.
-    tools/time_dist.py [M N rows [launches]] ...          default: the two pairs of VERDICT r04 weak #3 (144x192, 168x176; 8192 tokens; 2000)
+    tools/time_dist.py [MxN:rows[:launches]] ...         default: the two pairs of VERDICT r04 weak #3 (144x192:8192:2000 168x176:8192:2000)
 Prints min / p1 / median / p99 / max, the number of launches beyond 2x the median and where in the sequence they sit — a kernel with
 a slow mode shows them spread over the run, a cold start shows them at the front. Run it under
 `rocprofv3 --kernel-trace --stats` for the kernel's own durations (the event pairs include the gap in front of a launch)."""
@@ -69,16 +69,11 @@ def distribution(launch, n, warm=50):
 
 
 def main():
-    a = sys.argv[1:]
     cases = []
-    while a:
-        M, N, rows = int(a[0]), int(a[1]), int(a[2])
-        n = 2000
-        a = a[3:]
-        if a and len(a) % 3 != 0:
-            n = int(a[0])
-            a = a[1:]
-        cases.append((M, N, rows, n))
+    for spec in sys.argv[1:]:
+        f = spec.split(":")
+        M, N = (int(v) for v in f[0].split("x"))
+        cases.append((M, N, int(f[1]), int(f[2]) if len(f) > 2 else 2000))
     if not cases:
         cases = [(144, 192, 8192, 2000), (168, 176, 8192, 2000)]
     for M, N, rows, n in cases:
