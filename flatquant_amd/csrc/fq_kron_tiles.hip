@@ -39,6 +39,9 @@ namespace {
 #ifndef TILES_DA
 #define TILES_DA 0   // 0: the per-geometry default below
 #endif
+#ifndef TILES_DB
+#define TILES_DB 0   // 0: the default below (2)
+#endif
 #ifndef TILES_G144
 #define TILES_G144 2
 #endif
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
             int loff = lane;
             asm volatile("" : "+v"(loff));
             const uint4* mylfr = lfr + loff;
-            constexpr int DB = 2, NB = LKS * MT;
+            constexpr int DB = TILES_DB ? TILES_DB : 2, NB = LKS * MT;   // L fragments in flight (x 4 VGPRs)
             X8 B[DB];
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo) Y[mo] = f32x16{0};
@@ -531,6 +534,9 @@ int fq_launch_kron_tiles(int flags, const f16* x, const void* ws, const f16* dia
         const bool h16 = yonly || (cq == (FQ_OUT_PACKED | FQ_QUANT_F16) && (flags & FQ_ROUND_Y_F16));
         if (yout && (out.y == nullptr || !h16)) return -1000;
         if (!h16 && cq != FQ_OUT_PACKED) return -1000;
+        // (measured, profiles/r05_tall_on_tiles.txt) the rotation ALONE (no clip set: 4 d bytes per token, 32-byte pieces of 128-byte rows from every
+        // lane) is slower here than on the row-split kernel at six row tiles — 172 x 64: 180 against 171 us — and level or faster below
+        if (yonly && M > 160) return -1000;
         FqQuantOut o2 = out;
         if (!yout) o2.y = nullptr;   // (the kernel writes the transform whenever out.y is given)
         const int MT = (M + 31) / 32;
@@ -539,7 +545,10 @@ int fq_launch_kron_tiles(int flags, const f16* x, const void* ws, const f16* dia
         return h16 ? launch_tiles_t<MT_, 2, 64, G_, LKS_, false, f16, true>(x, w, rows, M, o2, n_cu, stream)               \
                    : launch_tiles_t<MT_, 2, 64, G_, LKS_, false, f16, false>(x, w, rows, M, o2, n_cu, stream);
         // four groups of two waves where 4 tokens + the L image fit 160 KB (a token: 2 LKS KB, the image: LKS x MT KB); 172 x 64 = 88 + 66 KB
-        FQ_T64(3, 5, 4) FQ_T64(3, 6, 4) FQ_T64(4, 7, 4) FQ_T64(4, 8, 4) FQ_T64(5, 9, 4) FQ_T64(5, 10, 4) FQ_T64(6, 11, 4) FQ_T64(6, 12, 3)
+#ifndef TILES_G64
+#define TILES_G64 4   // (measurement knob) token groups of the 172 x 64 launch
+#endif
+        FQ_T64(3, 5, 4) FQ_T64(3, 6, 4) FQ_T64(4, 7, 4) FQ_T64(4, 8, 4) FQ_T64(5, 9, 4) FQ_T64(5, 10, 4) FQ_T64(6, 11, TILES_G64) FQ_T64(6, 12, 3)
 #undef FQ_T64
         return -1000;
     }

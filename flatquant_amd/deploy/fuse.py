@@ -33,6 +33,9 @@ from .nn.online_trans import FusedSequential, OnlineTrans, fused_forward
 from .nn.quantization import Quantizer
 
 
+DECODE_ROWS = 128   # at or below this many tokens a module call is launch- / Python-bound (tools/ref_layer.py --seq 1): the groups step aside
+
+
 class TransformGroup:
     """The OnlineTrans modules of one attention (q, k, v) or MLP (up, gate): one launch per distinct input tensor."""
 
@@ -62,6 +65,8 @@ class TransformGroup:
         self._ref, self._outs, self._taken = None, None, 0
 
     def get(self, member, x):
+        if x.dim() != 3 or x.shape[0] * x.shape[1] <= DECODE_ROWS:
+            return None                                      # decode-sized: the members' own prepared calls are the faster route
         i = self.index[id(member)]
         bit = 1 << i
         if self._outs is not None and self._ref is not None and self._ref() is x and self._version == x._version and not (self._taken & bit):
@@ -100,8 +105,8 @@ class LinearGroup:
         self.served = 0
 
     def get(self, member, x):
-        if self._busy:
-            return None
+        if self._busy or (self._ys is None and self.tg.outputs() is None):
+            return None                                      # (no fused transform launch behind this call, e.g. decode-sized: on its own)
         i = self.index[id(member)]
         bit = 1 << i
         if self._ys is not None and self._ins[i] is x and not (self._taken & bit):

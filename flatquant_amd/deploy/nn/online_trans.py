@@ -169,8 +169,9 @@ class OnlineTrans(torch.nn.Module):
                                             self.right_matrix.contiguous(), [sig],
                                             functional.online_trans.deploy_kron_flags(self.left_matrix.shape[0], self.right_matrix.shape[0]))
                 return PackedQuantizedTensor(o.q[0].reshape(bsz, seq_len, -1), o.scale[0].reshape(bsz, 1, seq_len))
+        # (quantizer=...: a matmul transform returns the packed tensor whatever Quantizer follows — it passes packed inputs through)
         if self.trans == "matmul" and self.decompose and "left_matrix" in self._buffers and "right_matrix" in self._buffers \
-                and quantizer is None and self._static_ok(x):
+                and self._static_ok(x):
             if self.static_outputs:
                 return self._planned(x)
             if self.fast_path:

@@ -462,7 +462,7 @@ class FreshPlan:
 
     def __del__(self):
         h = getattr(self, "handle", None)
-        if h:
+        if h and lib is not None:      # (at interpreter shutdown the module globals may already be gone)
             lib.fq_plan_free(h)
 
     def matches(self, x: torch.Tensor) -> bool:

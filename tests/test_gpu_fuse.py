@@ -38,9 +38,10 @@ def test_fused_layer_is_bit_identical_to_the_reference_structure(down, bsz, seq)
             got = layer(x)
             for a, b in zip(got, want[i]):
                 assert torch.equal(a, b)
-            assert tga.launches == i + 1 and tga.served == 2 * (i + 1)          # one transform launch for q / k / v
-            assert tgm.launches == i + 1 and tgm.served == i + 1                # ... and one for up / gate
-            assert lga.launches == i + 1 and lga.served == 2 * (i + 1) and lgm.launches == i + 1 and lgm.served == i + 1
+            n = i + 1 if bsz * seq > 128 else 0      # (decode-sized calls: the groups step aside, every module runs its own prepared call)
+            assert tga.launches == n and tga.served == 2 * n                     # one transform launch for q / k / v
+            assert tgm.launches == n and tgm.served == n                         # ... and one for up / gate
+            assert lga.launches == n and lga.served == 2 * n and lgm.launches == n and lgm.served == n
             assert tga._outs is None and tgm._outs is None and lga._ys is None and lgm._ys is None   # nothing activation-sized is kept
         # a member called on its own with some other tensor simply runs (and does not disturb the group)
         alone = layer.self_attn.inp_trans_k(xs[0])

@@ -142,6 +142,7 @@ def test_prefill_sized_calls_take_the_fp6_path_with_a_transient_image(ops, monke
     gen = torch.Generator().manual_seed(5)
     lin = deploy.nn.Linear4bit(256, 272).cuda()
     lin.fp6_min_out_features = 0                            # (a 272-wide layer: below the default width gate)
+    lin.fp6_image = False                                   # (round 5: the kept image is the default; this is the transient route)
     lin.weight.copy_(torch.from_numpy(rand_packed(gen, 272, 256)[0]))
     lin.weight_scales.copy_((torch.rand(272, 1, generator=gen) * 0.02 + 0.001))
     rows = lin.fp6_transient_rows + 3
