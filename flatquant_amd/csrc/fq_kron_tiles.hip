@@ -291,7 +291,9 @@ __global__ __launch_bounds__(GROUPS * NT * 64) void fq_kron_tiles_kernel(const T
             int loff = lane;
             asm volatile("" : "+v"(loff));
             const uint4* mylfr = lfr + loff;
-            constexpr int DB = TILES_DB ? TILES_DB : 2, NB = LKS * MT;   // L fragments in flight (x 4 VGPRs)
+            // L fragments in flight (x 4 VGPRs). N = 64 (two waves per SIMD, 66 fragment reads per token and wave at 172 x 64): four —
+            // measured 141.8 -> 135.8 us (172 x 64, fp16 Quantizer epilogue), 111.4 -> 106.3 (140 x 64); profiles/r05_tall_on_tiles.txt
+            constexpr int DB = TILES_DB ? TILES_DB : (N == 64 ? 4 : 2), NB = LKS * MT;
             X8 B[DB];
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo) Y[mo] = f32x16{0};

@@ -149,18 +149,22 @@ def test_plain_quantizer_in_the_same_launch(ops, n, K):
 
 @pytest.mark.parametrize("n,K", SHAPES)
 def test_agrees_with_the_fwht_route_to_rounding_noise(ops, n, K):
-    """Against the bit-identical route (register FWHT + K-factor, then the Quantizer): digits within +-1 on <= 2e-3 of the
-    elements, scales within an fp16 step — the bars the dense Kronecker launch of the same rotation has had since round 2."""
-    rows = 64
-    x = make_x(rows, n, n + 11)
+    """Against the bit-identical route (register FWHT + K-factor, then the Quantizer): digits within +-1 on <= 1e-3 of the elements
+    (SURVEY section 7's bar — round 4 allowed 2e-3; MEASURED on exactly this data, profiles/r05_flip_rates.txt: 4.8e-4 .. 8.4e-4 per
+    width, 0 where the structured route is not taken), scales within one fp16 step, the rotation within 1e-3 of the row maximum
+    (measured 7.2e-4 .. 9.5e-4). 2048 rows: the data of tools/flip_rates_had.py, so the bound is the measurement, not a sample of it."""
+    rows = 2048
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(rows, n, generator=g).half()
+    x[:, ::61] *= 9
     hk = torch.from_numpy(hadk_matrix(K)).cuda()
     for sig in [(0.9820137619972229, 0.9820137619972229), (0.7, 0.9)]:
         q, s = ops.hadamard_quant(x.cuda(), K, hk, sig)
         qf, sf = ops.hadamard_quant(x.cuda(), K, hk, sig, fwht_route=True)
         qa, qb = O.unpack_i4(q.cpu().numpy().reshape(rows, -1)), O.unpack_i4(qf.cpu().numpy().reshape(rows, -1))
-        assert np.mean(qa != qb) <= 2e-3 and np.max(np.abs(qa - qb)) <= 1, (n, K, sig, float(np.mean(qa != qb)))
+        assert np.mean(qa != qb) <= 1e-3 and np.max(np.abs(qa - qb)) <= 1, (n, K, sig, float(np.mean(qa != qb)))
         sa, sb = s.float().cpu().numpy().reshape(-1), sf.float().cpu().numpy().reshape(-1)
-        assert np.all(np.abs(sa - sb) <= 2e-3 * np.maximum(np.abs(sb), 1e-6))
+        assert np.all(np.abs(sa - sb) <= 2e-3 * np.maximum(np.abs(sb), 1e-6))          # (one fp16 step of the scale)
     y = ops.hadamard_mfma(x.cuda(), K, hk)[0]
     yf = ops.hadamard(x.cuda(), K, hk, fwht_route=True)
     den = yf.float().abs().amax(dim=1, keepdim=True)

@@ -333,3 +333,26 @@ def test_force_fp32_outside_the_fp32_kernel_range_and_on_bf16(ops):
     yb = deploy.nn.OnlineTrans(4096, force_fp32=True, trans="had").cuda()(xb.cuda())
     refb = _exact_rotation(xb.float().numpy().astype(np.float64).reshape(6, 4096), 4096, 1)
     assert yb.dtype == torch.float32 and np.max(np.abs(yb.cpu().numpy().reshape(6, 4096) - refb)) <= 3e-6 * np.max(np.abs(refb))
+
+
+@pytest.mark.parametrize("n,K", [(11008, 172), (8960, 140), (5120, 40)])
+def test_kronecker_launch_flip_rate_is_within_the_surveys_bar(ops, n, K):
+    """The rotations that run as ONE dense Kronecker launch in front of the Quantizer (11008 = 172 x 64 on two-wave token groups since
+    round 5) against the bit-identical route, on the 2048 rows tools/flip_rates_had.py measures: digits differ by at most 1 on <= 1e-3
+    of the elements (measured 4.8e-4 .. 5.9e-4, profiles/r05_flip_rates.txt; the small-sample tests above keep round 4's 2e-3 — 14 to
+    37 rows are a sample, this is the population), scales within one fp16 step, the rotation within 1e-3 of the row maximum (8.4e-4)."""
+    rows = 2048
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(rows, n, generator=g).half()
+    x[:, ::61] *= 9
+    xc = x.cuda()
+    hk = torch.from_numpy(hadk_matrix(K)).cuda()
+    for sig in [(0.9820137619972229, 0.9820137619972229), (0.7, 0.9)]:
+        q, s = ops.hadamard_quant(xc, K, hk, sig)
+        qf, sf = ops.hadamard_quant(xc, K, hk, sig, fwht_route=True)
+        qa, qb = O.unpack_i4(q.cpu().numpy().reshape(rows, -1)), O.unpack_i4(qf.cpu().numpy().reshape(rows, -1))
+        assert np.mean(qa != qb) <= 1e-3 and np.max(np.abs(qa - qb)) <= 1, (n, K, sig, float(np.mean(qa != qb)))
+        sa, sb = s.float().cpu().numpy().reshape(-1), sf.float().cpu().numpy().reshape(-1)
+        assert np.all(np.abs(sa - sb) <= 2e-3 * np.maximum(np.abs(sb), 1e-6))
+    y, yf = ops.hadamard(xc, K, hk).float(), ops.hadamard(xc, K, hk, fwht_route=True).float()
+    assert float(((y - yf).abs() / yf.abs().amax(dim=1, keepdim=True)).max()) <= 1e-3
