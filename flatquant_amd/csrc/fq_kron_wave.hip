@@ -135,6 +135,8 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const T* __restric
         const uint4* myr = rfr + foff;
         const uint4* myl = lfr + foff;
         // this token's DMA: issued in the prologue or an iteration ago; younger VMEM ops = that iteration's stores
+        // (round 5, measured and removed: counted waits for the multi-clip launches too — vmcnt(n_clips x STORES) — 64 x 128 with three
+        //  clip sets 112.5 against 113.3 us, C4 step 54.57 against 54.75 ms: the store acknowledgements are already hidden; profiles/r05_nclip_wait.txt)
         if (OS == FQ_OUT_PACKED && !first && out.n_clips == 1) {
             asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G::STORES) : "memory");
         } else {

@@ -10,7 +10,7 @@ root = sys.argv[1]
 
 
 def short(name):
-    for key in ("fq_had512", "fq_rowmm", "fq_gemm_bf6", "fq_kron_tall", "fq_kv_decode", "fq_gemm_i4_skinny", "fq_kron64", "fq_kron_duo", "fq_kron_trio", "fq_kron_fast", "fq_kron_wave", "fq_gemm_i4", "fq_rowquant", "fq_probe_stream", "fq_kron_generic", "fq_hadamard", "fq_block", "copyBuffer"):
+    for key in ("fq_had512", "fq_rowmm", "fq_kron_tiles", "fq_kron_general", "fq_fakequant", "fq_silu", "fq_rmsnorm", "fq_gemm_bf6", "fq_kron_tall", "fq_kv_decode", "fq_gemm_i4_skinny", "fq_kron64", "fq_kron_duo", "fq_kron_trio", "fq_kron_fast", "fq_kron_wave", "fq_gemm_i4", "fq_rowquant", "fq_probe_stream", "fq_kron_generic", "fq_hadamard", "fq_block", "copyBuffer"):
         if key in name:
             i = name.find(key)
             return name[i:i + 46]

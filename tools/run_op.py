@@ -50,11 +50,11 @@ elif op == "kron32x64g":
     fn = lambda i: ops.kron_quant_grouped(xs[i % 2], L, R, offs, sm, sm, P)
 elif op in ("hadq14336", "hadq11008", "hadq11008fwht", "hadq28672", "hadq14336silu"):
     from flatquant_amd.flatquant.hadamard_utils import get_hadK
-    n = int(op[4:9])
-    hk, K = get_hadK(n)
+    width = int(op[4:9])      # (not `n`: that is the launch count of the loop below — round 5 found 11008 launches per counter pass)
+    hk, K = get_hadK(width)
     hk = hk.half().to(dev).contiguous()
-    xs = [act(16384 if n < 20000 else 8192, n) for _ in range(2)]
-    ups = [act(16384, n) for _ in range(2)] if op.endswith("silu") else None   # (the SiLU.mul input: x_gate and up)
+    xs = [act(16384 if width < 20000 else 8192, width) for _ in range(2)]
+    ups = [act(16384, width) for _ in range(2)] if op.endswith("silu") else None   # (the SiLU.mul input: x_gate and up)
     fn = lambda i: ops.hadamard_quant(xs[i % 2], K, hk, SIG[0], fwht_route=op.endswith("fwht"), up=None if ups is None else ups[i % 2])
 elif op.startswith("rowq"):
     d = int(op[4:])
