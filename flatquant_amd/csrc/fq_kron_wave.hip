@@ -456,6 +456,17 @@ int launch_wave(const T* x, const uint4* ws, int64_t rows, int M, const FqQuantO
     return (int)hipGetLastError();
 }
 
+
+// (round 5, built, measured and removed: this kernel on v_mfma_f32_16x16x32_{f16,bf16} — under the power limit the 16x16x32 shape sustains
+//  2.07 PFLOP/s where the 32x32x16 shape sustains 1.78 (half the accumulator traffic per FLOP: tools/mfma_energy.hip, profiles/r05_mfma_energy.txt),
+//  and every dense kernel here is bound by joules. A full port — 16-row / 16-column tiles, K-steps of 32, the R image's columns permuted so that a lane
+//  group ends up with N/4 consecutive n' of its output row, L's image re-paired so that two C tiles of GEMM 1 ARE the A operand of GEMM 2, both built in
+//  the prologue from the same workspace, 1 KB-contiguous packed stores — passed 140 parity cases on its first run (fp16 bit-equal to the
+//  workgroup-per-token kernel; bf16 differs from it in accumulation order, as a different instruction may) and measured 64 x 128 packed 78.4 us against
+//  79-81, bf16 74.3 against 74.9, with three clip sets 124.4 against 117.0, C4's RMSNorm launches 139 / 115 against 129 / 108 (244 VGPRs): twice as many
+//  MFMA instructions for the same FLOPs cost issue slots (~14 cycles each, docs/DESIGN_LOG.md section 9) that eat the energy the shape saves.
+//  profiles/r05_wave16.txt; the source is commit history.)
+
 }  // namespace
 
 // Returns -1000 when the shape / output set is not one this kernel covers (the caller falls back to the generic one).
