@@ -465,7 +465,7 @@ int launch_wave(const T* x, const uint4* ws, int64_t rows, int M, const FqQuantO
 //  workgroup-per-token kernel; bf16 differs from it in accumulation order, as a different instruction may) and measured 64 x 128 packed 78.4 us against
 //  79-81, bf16 74.3 against 74.9, with three clip sets 124.4 against 117.0, C4's RMSNorm launches 139 / 115 against 129 / 108 (244 VGPRs): twice as many
 //  MFMA instructions for the same FLOPs cost issue slots (~14 cycles each, docs/DESIGN_LOG.md section 9) that eat the energy the shape saves.
-//  profiles/r05_wave16.txt; the source is commit history.)
+//  profiles/r05_wave16.txt; the lane maps and image re-indexings: docs/experiments/fq_kron_wave16_kernel.hip.txt)
 
 }  // namespace
 
