@@ -147,13 +147,14 @@ class Linear4bit(torch.nn.Module):
                 bf = self._buffers
                 w = bf["weight"]
                 st = self.__dict__.get("_fresh_state")
-                if (st is None or st[0] is not w or st[1] != w._version or st[2] != bf["weight_scales"]._version
-                        or st[3] != (-1 if self.bias is None else self.bias._version) or st[4] != ops.cache_epoch() or not st[5].matches(q)):
+                if st is None:
+                    st = self.__dict__["_fresh_state"] = ops.FreshPlanSet()
+                plan = st.lookup((id(w), w._version, bf["weight_scales"]._version, -1 if self.bias is None else self.bias._version,
+                                  ops.cache_epoch()), q)
+                if plan is None:
                     ws16, b16 = self._scales16()
-                    plan = ops.skinny_linear_fresh_plan(q, dimg, ws16, b16, self.out_features, lead + (self.out_features,))
-                    st = (w, w._version, bf["weight_scales"]._version, -1 if self.bias is None else self.bias._version, ops.cache_epoch(), plan)
-                    self.__dict__["_fresh_state"] = st
-                return st[5].run_linear(q, scales_x)
+                    plan = st.add(q, ops.skinny_linear_fresh_plan(q, dimg, ws16, b16, self.out_features, lead + (self.out_features,)), (w,))
+                return plan.run_linear(q, scales_x)
             if dimg is not None:
                 ws16, b16 = self._scales16()
                 y = ops.int4_skinny_linear(q.reshape(rows, -1).contiguous(), scales_x.reshape(-1).contiguous(), dimg,

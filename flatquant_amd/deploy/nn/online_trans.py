@@ -75,19 +75,19 @@ class OnlineTrans(torch.nn.Module):
         cmax, cmin = bf.get("clip_factor_a_max"), bf.get("clip_factor_a_min")
         if cmax is None or cmin is None:
             cmax, cmin = self.clip_factor_a_max, self.clip_factor_a_min
-        kmax = cmax._version if isinstance(cmax, torch.Tensor) else cmax
-        kmin = cmin._version if isinstance(cmin, torch.Tensor) else cmin
+        kmax = (id(cmax), cmax._version) if isinstance(cmax, torch.Tensor) else cmax
+        kmin = (id(cmin), cmin._version) if isinstance(cmin, torch.Tensor) else cmin
         st = self.__dict__.get("_fresh_state")
-        if (st is None or st[0] is not L or st[1] != L._version or st[2] is not R or st[3] != R._version or st[4] != kmax
-                or st[5] != kmin or st[6] != ops.cache_epoch() or not st[7].matches(x)):
+        if st is None:
+            st = self.__dict__["_fresh_state"] = ops.FreshPlanSet()
+        plan = st.lookup((id(L), L._version, id(R), R._version, kmax, kmin, ops.cache_epoch()), x)
+        if plan is None:
             bsz, seq_len, d = x.shape
-            plan = ops.kron_fresh_plan(x, L.contiguous(), R.contiguous(), ops.sigmoid_pair(cmax, cmin),
-                                       functional.online_trans.deploy_kron_flags(L.shape[0], R.shape[0]),
-                                       (bsz, seq_len, d // 2), (bsz, 1, seq_len))
-            st = (L, L._version, R, R._version, kmax, kmin, ops.cache_epoch(), plan)
-            self.__dict__["_fresh_state"] = st
+            plan = st.add(x, ops.kron_fresh_plan(x, L.contiguous(), R.contiguous(), ops.sigmoid_pair(cmax, cmin),
+                                                 functional.online_trans.deploy_kron_flags(L.shape[0], R.shape[0]),
+                                                 (bsz, seq_len, d // 2), (bsz, 1, seq_len)), (L, R, cmax, cmin))
         from .. import PackedQuantizedTensor
-        q, sc = st[7].run(x)
+        q, sc = plan.run(x)
         return PackedQuantizedTensor(q, sc)
 
     def _static_ok(self, x):

@@ -48,11 +48,13 @@ class Quantizer(torch.nn.Module):
         cmax, cmin = bf.get("clip_factor_a_max"), bf.get("clip_factor_a_min")
         if cmax is None or cmin is None:   # (Python floats after the reference's loader, modeling_llama.py:532-538)
             cmax, cmin = self.clip_factor_a_max, self.clip_factor_a_min
-        kmax = cmax._version if isinstance(cmax, torch.Tensor) else cmax
-        kmin = cmin._version if isinstance(cmin, torch.Tensor) else cmin
+        kmax = (id(cmax), cmax._version) if isinstance(cmax, torch.Tensor) else cmax
+        kmin = (id(cmin), cmin._version) if isinstance(cmin, torch.Tensor) else cmin
         st = self.__dict__.get("_fresh_state")
-        if (st is None or st[0] != kmax or st[1] != kmin or st[2] != ops.cache_epoch() or st[3] != self.lac
-                or st[4] != self.input_clip_ratio or not st[5].matches(x)):
+        if st is None:
+            st = self.__dict__["_fresh_state"] = ops.FreshPlanSet()
+        plan = st.lookup((kmax, kmin, ops.cache_epoch(), self.lac, self.input_clip_ratio), x)
+        if plan is None:
             rows = x.numel() // x.shape[-1]
             qs = x.shape[:-1] + (x.shape[-1] // 2,)
             if self.lac:   # scales [rows, 1] (quantization.py:16-28)
@@ -61,9 +63,8 @@ class Quantizer(torch.nn.Module):
                 ss = x.shape[:-1]
                 plan = ops.rowquant_fresh_plan(x, (float(self.input_clip_ratio), 1.0), FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_RATIO_POST, qs,
                                                ss[:1] + (1,) + ss[1:])
-            st = (kmax, kmin, ops.cache_epoch(), self.lac, self.input_clip_ratio, plan)
-            self.__dict__["_fresh_state"] = st
-        q, sc = st[5].run(x)
+            st.add(x, plan, (cmax, cmin))
+        q, sc = plan.run(x)
         return PackedQuantizedTensor(q, sc)
 
     def forward(self, x):

@@ -494,6 +494,37 @@ class FreshPlan:
         return y
 
 
+class FreshPlanSet:
+    """The FreshPlans of ONE deploy.nn module: one per input (shape, dtype, device) — a server alternating prefill- and decode-sized
+    calls keeps both instead of re-planning on every switch — at most ``KEEP``, all dropped when ``key`` (the owner's matrices / clip
+    factors / cache epoch, as ids and versions) changes. ``refs`` keeps the objects whose ids are in the key alive."""
+    __slots__ = ("key", "refs", "plans", "last")
+    KEEP = 4
+
+    def __init__(self):
+        self.key, self.refs, self.plans, self.last = None, None, {}, None
+
+    def lookup(self, key, x: torch.Tensor):
+        if key != self.key:
+            self.key, self.refs, self.last = key, None, None
+            self.plans.clear()
+            return None
+        p = self.last
+        if p is not None and p.matches(x):
+            return p
+        p = self.plans.get((x.shape, x.dtype, x.device))
+        if p is not None:
+            self.last = p
+        return p
+
+    def add(self, x: torch.Tensor, plan: "FreshPlan", refs=None):
+        if len(self.plans) >= self.KEEP:
+            self.plans.pop(next(iter(self.plans)))           # (insertion order: the oldest)
+        self.plans[(x.shape, x.dtype, x.device)] = plan
+        self.last, self.refs = plan, refs
+        return plan
+
+
 def kron_fresh_plan(x_like: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sig: Sig, flags: int, q_shape, s_shape) -> FreshPlan:
     """deploy.nn.OnlineTrans(matmul, decompose).forward as a FreshPlan: one clip pair, packed output; the fragment image is prepared
     here and kept by the plan (as are left / right: their addresses cannot be recycled under it)."""

@@ -7,6 +7,8 @@ import sys
 import pytest
 import torch
 
+from flatquant_amd import ops
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
@@ -95,6 +97,15 @@ def test_default_module_path_returns_fresh_outputs_and_follows_updates():
     assert torch.equal(c.quantized_x, ref2.quantized_x) and not torch.equal(c.scales_x, a.scales_x)
     x2 = torch.randn(1, 3, 4096, generator=g, device="cuda", dtype=torch.float16)   # another shape
     assert t(x2).quantized_x.shape == (1, 3, 2048)
+    st = t.__dict__["_fresh_state"]                           # alternating shapes (prefill / decode) keep BOTH plans
+    plans = dict(st.plans)
+    assert len(plans) == 2
+    for _ in range(3):
+        assert torch.equal(t(x).quantized_x, c.quantized_x) and t(x2).quantized_x.shape == (1, 3, 2048)
+    assert all(st.plans[k] is v for k, v in plans.items()) and len(st.plans) == 2
+    for k in range(4, 4 + 2 * ops.FreshPlanSet.KEEP):        # bounded
+        t(torch.zeros(1, k, 4096, device="cuda", dtype=torch.float16))
+    assert len(st.plans) == ops.FreshPlanSet.KEEP
     for name in ("clip_factor_a_max", "clip_factor_a_min"):  # the loader's floats
         v = getattr(t, name).item()
         delattr(t, name)

@@ -638,3 +638,32 @@ def test_load_state_dict_invalidates_the_derived_caches():
         ops._SCALARS[("sentinel",)] = (None, 1.0)
         mod.load_state_dict(mod.state_dict())
         assert ("sentinel",) not in ops._SCALARS, type(mod).__name__
+
+
+def test_fresh_plan_set_keeps_one_plan_per_shape_and_drops_all_on_a_key_change():
+    """ops.FreshPlanSet (the per-module plan table of the default deploy.nn forward): plans are found by (shape, dtype, device), the
+    table is bounded, and a changed owner key (matrix version, clip factor, cache epoch) empties it."""
+    import torch
+    from flatquant_amd import ops
+
+    class Plan:
+        def __init__(self, x):
+            self.shape, self.dtype, self.device = x.shape, x.dtype, x.device
+
+        def matches(self, x):
+            return x.shape == self.shape and x.dtype == self.dtype and x.device == self.device
+
+    st = ops.FreshPlanSet()
+    a, b = torch.zeros(2, 8), torch.zeros(1, 8)
+    assert st.lookup(("k", 0), a) is None
+    pa = st.add(a, Plan(a), refs=(a,))
+    assert st.lookup(("k", 0), a) is pa and st.lookup(("k", 0), b) is None
+    pb = st.add(b, Plan(b))
+    for _ in range(3):
+        assert st.lookup(("k", 0), a) is pa and st.lookup(("k", 0), b) is pb
+    assert st.lookup(("k", 0), a.double()) is None            # another dtype: not the same plan
+    for n in range(3, 3 + 2 * st.KEEP):
+        x = torch.zeros(n, 8)
+        st.add(x, Plan(x))
+    assert len(st.plans) == st.KEEP
+    assert st.lookup(("k", 1), b) is None and not st.plans and st.last is None
