@@ -8,11 +8,20 @@
 // Decode attention, one query token per request (decode.cuh:492-683 with rotary_mode none): for every (request, head)
 //   k_i = float(n) * scale_i - zero_i  (quantization.cuh:58-80),  x_i = (q . k_i) / sqrt(head_dim),
 //   o = sum_i softmax(x)_i * v_i, fp32 throughout, fp16 out.
-// Here: one 4-wave workgroup per (request, head). A cached row is 64 bytes; a QUAD of lanes owns one row per step (16
-// bytes = 32 features per lane, a wave reads 16 consecutive rows = 1 KB per instruction) and runs its OWN online softmax
-// over the rows it sees — no cross-lane traffic in the loop beyond the 4-lane dot-product reduction. The 64 partial
-// states (m, d, o[head_dim]) are merged once at the end through LDS (the standard max-rescaled merge, state.cuh).
-// The dequantisation is folded into the dot product: q . k = scale * sum(q_j n_j) - zero * sum(q_j).
+// Here: one 4-wave workgroup per (request, head); a cached row is 64 bytes, a lane owns 16 bytes = 32 features of one row per step and a
+// wave reads 16 consecutive rows = 1 KB per instruction. Every row's four lanes run their OWN online softmax over the rows they see; the
+// 64 partial states (m, d, o[head_dim]) are merged once at the end through LDS (the standard max-rescaled merge, state.cuh).
+//   * fp16 cache (fq_kv_decode_kernel): a quad of neighbouring lanes owns a row, the dot product is 32 fp32 FMAs + a 4-lane reduction.
+//   * INT4 cache (fq_kv_decode_i4_kernel, round 5): the scalar form of rounds 1-4 spent ~9 VALU operations per cached byte (shift, mask,
+//     convert, FMA per nibble, twice) and was VALU-bound at 0.33-0.39 of the HBM roofline. Now (a) eight nibbles of a dword become eight
+//     EXACT fp16 values with 9 operations (the nibble is OR-ed into the mantissa of 1024.0 — or of 1024 + 16 n, scaled back by a packed
+//     FMA); (b) q . k runs on the matrix pipe: v_mfma_f32_16x16x32_f16 with the query replicated over the 16 rows of A and the wave's 16
+//     cached rows as the columns of B — lane l = 16 g + i supplies features 32 g .. 32 g + 31 of row i, exactly the 16 bytes it loaded,
+//     and receives row i's full 128-feature sum (exact fp16 x fp16 products, fp32 accumulation: no 4-lane reduction); (c) the
+//     dequantisation stays folded: q . k = scale * sum(q_j n_j) - zero * sum(q_j), o = sum_i (p_i scale_i) n_i - sum_i p_i zero_i with
+//     the second sum a scalar per lane; (d) the running maximum is rescaled lazily (a wave-uniform branch, taken when some lane's maximum
+//     moved); (e) the next step's rows are requested before the current step's arithmetic. head_dim 64: two lanes per row, 32 rows per
+//     step, v_mfma_f32_32x32x16_f16.
 #include "fq_common.hpp"
 
 namespace {
@@ -79,9 +88,9 @@ __global__ __launch_bounds__(256) void fq_kv_append_kernel(PagedKv p, const uint
     }
 }
 
-// F16: the fp16 configuration of the cache (batch_decode_f16): a cached row is head_dim fp16 values, no (scale, zero); a lane
-// still owns 32 features of a row (64 bytes: four 16-byte loads).
-template <int HD, int NW, bool F16 = false>  // NW waves per workgroup: 4, or 8 when there are too few (request, head) pairs to fill the chip
+// The fp16 configuration of the cache (batch_decode_f16): a cached row is head_dim fp16 values, no (scale, zero); a lane owns 32
+// features of a row (64 bytes: four 16-byte loads), a quad of neighbouring lanes the row.
+template <int HD, int NW>  // NW waves per workgroup: 4, or 8 when there are too few (request, head) pairs to fill the chip
 __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restrict__ o, const f16* __restrict__ q, PagedKv p,
                                                                const f16* __restrict__ qt, int transpose_out) {
     constexpr int QL = HD / 32;        // lanes per cached row (16 bytes = 32 features each): 4 for head_dim 128
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
             ++pit;
         }
         const size_t ke = page * page_stride + k_off + entry, ve = ke + kv_off;   // = k_entry / v_entry, constants hoisted
-        if (F16) {
+        {
             const uint4* kp = reinterpret_cast<const uint4*>(p.data + ke * (HD * 2) + part * 64);
             const uint4* vp = reinterpret_cast<const uint4*>(p.data + ve * (HD * 2) + part * 64);
             uint4 kq[4], vq[4];
@@ -173,34 +182,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
                 for (int e = 0; e < 8; ++e) acc[w * 8 + e] = __builtin_fmaf((float)vh[e], pr, acc[w * 8 + e] * alpha);
             }
             m = m_new;
-            continue;
         }
-        const uint4 kq = *reinterpret_cast<const uint4*>(p.data + ke * (HD / 2) + part * 16);
-        const uint4 vq = *reinterpret_cast<const uint4*>(p.data + ve * (HD / 2) + part * 16);
-        const uint32_t kpar = reinterpret_cast<const uint32_t*>(p.param)[ke];
-        const uint32_t vpar = reinterpret_cast<const uint32_t*>(p.param)[ve];
-        const float ks = (float)__builtin_bit_cast(f16, (unsigned short)(kpar & 0xFFFF)), kz = (float)__builtin_bit_cast(f16, (unsigned short)(kpar >> 16));
-        const float vs = (float)__builtin_bit_cast(f16, (unsigned short)(vpar & 0xFFFF)), vz = (float)__builtin_bit_cast(f16, (unsigned short)(vpar >> 16));
-        const uint32_t kw[4] = {kq.x, kq.y, kq.z, kq.w}, vw[4] = {vq.x, vq.y, vq.z, vq.w};
-        float dotn = 0.0f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dotn = __builtin_fmaf(qv[w * 8 + e], (float)((kw[w] >> (4 * e)) & 15u), dotn);
-        float part_dot = ks * dotn - kz * qsum;       // this lane's 32 features of q . k
-#pragma unroll
-        for (int off = 1; off < QL; off <<= 1) part_dot += __shfl_xor(part_dot, off, 64);
-        const float x = part_dot * sm_scale;
-        const float m_new = fmaxf(m, x);
-        const float alpha = __builtin_amdgcn_exp2f(m - m_new), pr = __builtin_amdgcn_exp2f(x - m_new);
-        d = d * alpha + pr;
-        const float pvs = pr * vs, pvz = pr * vz;
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                acc[w * 8 + e] = __builtin_fmaf((float)((vw[w] >> (4 * e)) & 15u), pvs, acc[w * 8 + e] * alpha - pvz);
-        m = m_new;
     }
     const int st = wave * RPW + slot;
     if (part == 0) {
@@ -225,6 +207,203 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
         }
         // transpose_out: [batch, head_dim, heads] — the layout the o_proj head transform takes (modeling_llama.py:147-149
         // transposes and copies the attention output before block_matmul)
+        const size_t oi = transpose_out ? ((size_t)b * HD + tid) * p.num_heads + head : ((size_t)b * p.num_heads + head) * HD + tid;
+        o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;  // an empty sequence attends to nothing: zeros, not 0/0
+    }
+}
+
+// eight INT4 of one dword -> the eight EXACT fp16 values 16 + n as four packed pairs, in the order (n0, n4) (n1, n5) (n2, n6) (n3, n7):
+// 0x4C00 is 16.0 and the top four bits of its mantissa (bits 6..9) count units of one, so a nibble moved to bits 6..9 (and its partner
+// four nibbles up to bits 22..25) and OR-ed into 0x4C004C00 is the pair (16 + n_k, 16 + n_k+4). One shift and one v_and_or_b32 per
+// pair — eight operations per eight nibbles where shift / mask / convert are 24 — and the offset 16 leaves the sums: q . (16 + n) =
+// 16 sum(q) + q . n, sum_i p_i s_i (16 + n_i) = 16 sum_i p_i s_i + ..., both removed with one scalar operation per row.
+constexpr int KV_PERM[8] = {0, 4, 1, 5, 2, 6, 3, 7};   // feature (within the dword's eight) of packed slot e
+constexpr float KV_OFF = 16.0f;
+__device__ __forceinline__ uint32_t kv_and_or(uint32_t x, uint32_t mask, uint32_t bits) {
+    uint32_t r;   // (gfx9: one constant-bus operand per VOP3 — the mask in an SGPR, the exponent bits in a VGPR)
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask), "v"(bits));
+    return r;
+}
+__device__ __forceinline__ void kv_unpack8(uint32_t w, uint32_t ebits, uint32_t (&r)[4]) {
+    constexpr uint32_t M = 0x03C003C0u;
+    r[0] = kv_and_or(w << 6, M, ebits);
+    r[1] = kv_and_or(w << 2, M, ebits);
+    r[2] = kv_and_or(w >> 2, M, ebits);
+    r[3] = kv_and_or(w >> 6, M, ebits);
+}
+// acc += float(half h of the packed pair) * s: v_fma_mix_f32 reads the fp16 half directly (a convert + an FMA otherwise)
+template <int HI>
+__device__ __forceinline__ void kv_fma_half(float& acc, uint32_t pair, float s) {
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(pair), "v"(s));
+    else asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(pair), "v"(s));
+}
+
+// sum_j q_j n_ij for the wave's RPW cached rows on the matrix pipe: A = the query in every row, B = the rows as columns. Lane
+// l = RPW g + i holds features 32 g .. 32 g + 31 of row i (one dword per K-step) and gets row i's sum over ALL features back.
+template <int QL>
+__device__ __forceinline__ float kv_qk(const f16x8 (&qa)[4], const uint4 kq, uint32_t ebits) {   // -> sum_j q_j (16 + n_ij)
+    const uint32_t kw[4] = {kq.x, kq.y, kq.z, kq.w};
+    f16x8 kb[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint32_t r[4];
+        kv_unpack8(kw[w], ebits, r);
+        kb[w] = __builtin_bit_cast(f16x8, u32x4{r[0], r[1], r[2], r[3]});
+    }
+    if constexpr (QL == 4) {
+        f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[w], kb[w], c, 0, 0, 0);
+        return c[0];
+    } else {
+        f32x16 c = {0};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[w], kb[w], c, 0, 0, 0);
+        return c[0];
+    }
+}
+
+// The INT4 cache (batch_decode_i4): see the head of this file. Lane l = RPW part + slot: row `slot` of the wave's RPW rows, 16-byte
+// chunk `part` of that row (a wave's load is still RPW consecutive rows = 1 KB).
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_i4_kernel(f16* __restrict__ o, const f16* __restrict__ q, PagedKv p,
+                                                                  const f16* __restrict__ qt, int transpose_out) {
+    constexpr int QL = HD / 32;        // lanes per cached row: 4 for head_dim 128, 2 for 64
+    constexpr int RPW = 64 / QL;       // rows per wave and step: the N of the MFMA (16 / 32)
+    constexpr int NS = NW * RPW;       // partial softmax states per workgroup
+    static_assert(QL == 4 || QL == 2, "head_dim 128 (16x16x32) or 64 (32x32x16)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char kv_smem[];
+    float (*s_o)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(kv_smem);
+    float* s_m = reinterpret_cast<float*>(kv_smem + sizeof(float) * NS * (HD + 1));
+    float* s_d = s_m + NS;
+    float* s_q = s_d + NS;
+    const int b = blockIdx.x, head = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int part = lane / RPW, slot = lane % RPW;
+    const float sm_scale = 1.44269504088896340736f / __builtin_sqrtf((float)HD);  // log2(e) / sqrt(head_dim): exp2 below
+    const int pg0 = p.indptr[b], pg1 = p.indptr[b + 1];
+    const int64_t seq_len = (int64_t)(pg1 - pg0 - 1) * p.page_size + p.last_page_offset[b];
+
+    // the query as fp16 values in LDS: q itself, or q' = fp16(q . qt) (kv_cache.py:139-140: torch.matmul(q.half(),
+    // trans_matrix_k_inv_t)), fp32 accumulation, one output feature per thread
+    {
+        const f16* qrow = q + ((size_t)b * p.num_heads + head) * HD;
+        for (int j = tid; j < HD; j += NW * 64) {
+            if (qt != nullptr) {
+                float a = 0.0f;
+                for (int i = 0; i < HD; ++i) a = __builtin_fmaf((float)qrow[i], (float)qt[i * HD + j], a);
+                s_q[j] = (float)(f16)a;
+            } else {
+                s_q[j] = (float)qrow[j];
+            }
+        }
+        __syncthreads();
+    }
+    f16x8 qa[4];      // the A operand of K-step w: features 32 part + 8 w + KV_PERM[e] (the order kv_unpack8 leaves the nibbles in)
+    float qsum = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = s_q[part * 32 + w * 8 + KV_PERM[e]];
+            qa[w][e] = (f16)v;
+            qsum += v;
+        }
+#pragma unroll
+    for (int off = RPW; off < 64; off <<= 1) qsum += __shfl_xor(qsum, off, 64);   // over the row's QL lanes: sum of ALL features
+    const float qoff = KV_OFF * qsum;
+    uint32_t ebits = 0x4C004C00u;   // (16.0, 16.0): kept in a VGPR
+    asm volatile("" : "+v"(ebits));
+
+    float m = -INFINITY, d = 0.0f, zacc = 0.0f, acc[32];   // acc[8 w + e]: feature 32 part + 8 w + KV_PERM[e] of sum_i p_i s_i (16 + n_i); zacc: sum_i p_i (z_i + 16 s_i)
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc[j] = 0.0f;
+
+    const size_t page_stride = (size_t)p.num_layers * 2 * p.num_heads * p.page_size;
+    const size_t k_off = ((size_t)p.layer_idx * 2 * p.num_heads + head) * p.page_size, kv_off = (size_t)p.num_heads * p.page_size;
+    // (page, entry) of this lane's row advance incrementally: a 64-bit division per row would cost more than the row
+    int pit = 0, ent = wave * RPW + slot;
+    while (ent >= p.page_size) {
+        ent -= p.page_size;
+        ++pit;
+    }
+    // the loop is WAVE-uniform (the MFMA wants every lane): a lane whose row lies beyond the sequence reads entry 0 of the request's
+    // last page instead and contributes p = 0
+    uint4 kq, vq;
+    uint32_t kpar, vpar;
+    auto request = [&](int64_t base, uint4& kq_, uint4& vq_, uint32_t& kpar_, uint32_t& vpar_) {
+        const bool valid = base + slot < seq_len;
+        const size_t page = (size_t)p.indices[valid ? pg0 + pit : pg1 - 1];
+        const size_t entry = valid ? (size_t)ent : 0;
+        ent += NS;
+        while (ent >= p.page_size) {
+            ent -= p.page_size;
+            ++pit;
+        }
+        const size_t ke = page * page_stride + k_off + entry, ve = ke + kv_off;   // = k_entry / v_entry, constants hoisted
+        kq_ = *reinterpret_cast<const uint4*>(p.data + ke * (HD / 2) + part * 16);
+        vq_ = *reinterpret_cast<const uint4*>(p.data + ve * (HD / 2) + part * 16);
+        kpar_ = reinterpret_cast<const uint32_t*>(p.param)[ke];
+        vpar_ = reinterpret_cast<const uint32_t*>(p.param)[ve];
+    };
+    const int64_t base0 = (int64_t)wave * RPW;
+    if (base0 < seq_len) request(base0, kq, vq, kpar, vpar);
+    for (int64_t base = base0; base < seq_len; base += NS) {
+        uint4 nkq = kq, nvq = vq;
+        uint32_t nkpar = kpar, nvpar = vpar;
+        if (base + NS < seq_len) request(base + NS, nkq, nvq, nkpar, nvpar);   // the next step's rows: in flight under this step's arithmetic
+        const bool valid = base + slot < seq_len;
+        const float ks = (float)__builtin_bit_cast(f16, (unsigned short)(kpar & 0xFFFF)), kz = (float)__builtin_bit_cast(f16, (unsigned short)(kpar >> 16));
+        const float vs = (float)__builtin_bit_cast(f16, (unsigned short)(vpar & 0xFFFF)), vz = (float)__builtin_bit_cast(f16, (unsigned short)(vpar >> 16));
+        const float dotn = kv_qk<QL>(qa, kq, ebits) - qoff;
+        const float x = valid ? (ks * dotn - kz * qsum) * sm_scale : -INFINITY;
+        const float m_new = fmaxf(m, x);
+        if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {   // some lane's maximum moved: everybody rescales (by 1 where it did not)
+            const float alpha = m_new > m ? __builtin_amdgcn_exp2f(m - m_new) : 1.0f;
+            d *= alpha;
+            zacc *= alpha;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc[j] *= alpha;
+            m = m_new;
+        }
+        const float pr = valid ? __builtin_amdgcn_exp2f(x - m) : 0.0f;
+        d += pr;
+        const float pvs = pr * vs;
+        zacc = __builtin_fmaf(pvs, KV_OFF, __builtin_fmaf(pr, vz, zacc));
+        const uint32_t vw[4] = {vq.x, vq.y, vq.z, vq.w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t r[4];
+            kv_unpack8(vw[w], ebits, r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                kv_fma_half<0>(acc[w * 8 + 2 * e], r[e], pvs);
+                kv_fma_half<1>(acc[w * 8 + 2 * e + 1], r[e], pvs);
+            }
+        }
+        kq = nkq, vq = nvq, kpar = nkpar, vpar = nvpar;
+    }
+    const int st = wave * RPW + slot;
+    if (part == 0) {
+        s_m[st] = m;
+        s_d[st] = d;
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_o[st][part * 32 + w * 8 + KV_PERM[e]] = acc[w * 8 + e] - zacc;
+    __syncthreads();
+    if (tid < HD) {   // state.cuh merge: rescale every partial state to the common maximum (see fq_kv_decode_kernel)
+        float mm = -INFINITY;
+#pragma unroll 8
+        for (int s = 0; s < NS; ++s) mm = fmaxf(mm, s_m[s]);
+        float dd = 0.0f, oo = 0.0f;
+#pragma unroll 8
+        for (int s = 0; s < NS; ++s) {
+            const float w = s_m[s] == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(s_m[s] - mm);
+            dd += s_d[s] * w;
+            oo += s_o[s][tid] * w;
+        }
         const size_t oi = transpose_out ? ((size_t)b * HD + tid) * p.num_heads + head : ((size_t)b * p.num_heads + head) * HD + tid;
         o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;  // an empty sequence attends to nothing: zeros, not 0/0
     }
@@ -278,11 +457,11 @@ int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, con
     {                                                                                                                 \
         constexpr size_t lds = sizeof(float) * ((size_t)(NW_ * (64 / (HD_ / 32))) * (HD_ + 1 + 2) + HD_);                     \
         if (f16_cache) {                                                                                              \
-            FQ_RAISE_LDS_CAP((fq_kv_decode_kernel<HD_, NW_, true>), lds);                                             \
-            hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_, true>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
-        } else {                                                                                                      \
             FQ_RAISE_LDS_CAP((fq_kv_decode_kernel<HD_, NW_>), lds);                                                   \
             hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
+        } else {                                                                                                      \
+            FQ_RAISE_LDS_CAP((fq_kv_decode_i4_kernel<HD_, NW_>), lds);                                                \
+            hipLaunchKernelGGL((fq_kv_decode_i4_kernel<HD_, NW_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
         }                                                                                                             \
     }
     if (head_dim == 128) {
