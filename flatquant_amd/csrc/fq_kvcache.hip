@@ -12,16 +12,20 @@
 // wave reads 16 consecutive rows = 1 KB per instruction. Every row's four lanes run their OWN online softmax over the rows they see; the
 // 64 partial states (m, d, o[head_dim]) are merged once at the end through LDS (the standard max-rescaled merge, state.cuh).
 //   * fp16 cache (fq_kv_decode_kernel): a quad of neighbouring lanes owns a row, the dot product is 32 fp32 FMAs + a 4-lane reduction.
-//   * INT4 cache (fq_kv_decode_i4_kernel, round 5): the scalar form of rounds 1-4 spent ~9 VALU operations per cached byte (shift, mask,
-//     convert, FMA per nibble, twice) and was VALU-bound at 0.33-0.39 of the HBM roofline. Now (a) eight nibbles of a dword become eight
-//     EXACT fp16 values with 9 operations (the nibble is OR-ed into the mantissa of 1024.0 — or of 1024 + 16 n, scaled back by a packed
-//     FMA); (b) q . k runs on the matrix pipe: v_mfma_f32_16x16x32_f16 with the query replicated over the 16 rows of A and the wave's 16
-//     cached rows as the columns of B — lane l = 16 g + i supplies features 32 g .. 32 g + 31 of row i, exactly the 16 bytes it loaded,
-//     and receives row i's full 128-feature sum (exact fp16 x fp16 products, fp32 accumulation: no 4-lane reduction); (c) the
-//     dequantisation stays folded: q . k = scale * sum(q_j n_j) - zero * sum(q_j), o = sum_i (p_i scale_i) n_i - sum_i p_i zero_i with
-//     the second sum a scalar per lane; (d) the running maximum is rescaled lazily (a wave-uniform branch, taken when some lane's maximum
-//     moved); (e) the next step's rows are requested before the current step's arithmetic. head_dim 64: two lanes per row, 32 rows per
-//     step, v_mfma_f32_32x32x16_f16.
+//   * INT4 cache (fq_kv_decode_i4_kernel, round 5): the scalar form of rounds 1-4 spent ~9 VALU operations per cached byte (extract,
+//     convert, FMA per nibble, twice) and was VALU-bound at 0.33-0.39 of the HBM roofline. Now (a) the eight nibbles of a dword become the
+//     eight EXACT fp16 values 16 + n with eight operations (a shift and a v_and_or_b32 per pair: the nibble lands in the top mantissa
+//     bits of 16.0; the offset leaves both sums as one scalar correction per row); (b) q . k runs on the matrix pipe:
+//     v_mfma_f32_16x16x32_f16 with the query in all 16 rows of A and the wave's 16 cached rows as the columns of B — lane l = 16 g + i
+//     supplies features 32 g .. 32 g + 31 of row i, exactly the 16 bytes it loaded, and receives row i's full 128-feature sum (exact
+//     fp16 x fp16 products, fp32 accumulation: no 4-lane reduction); (c) p . v reads the fp16 halves directly (v_fma_mix_f32: one
+//     operation per feature) and the dequantisation stays folded: q . k = scale * sum(q_j n_j) - zero * sum(q_j), o = sum_i (p_i scale_i)
+//     n_i - sum_i p_i zero_i with the second sum a scalar per lane; (d) the running maximum is rescaled lazily (a wave-uniform branch,
+//     taken when some lane's maximum moved); (e) the page index is a scalar load where a wave's 16 rows cannot straddle a page, and
+//     the next step's rows are requested before the current step's arithmetic inside a condition-free steady-state loop (counted
+//     vmcnt waits). head_dim 64: two lanes per row, 32 rows per step, v_mfma_f32_32x32x16_f16.
+//     64 requests x 2048 tokens x 32 heads: 180.7 -> 113 us (0.39 -> 0.63 of 8 TB/s), 8 x 8192: 108 -> 54 us, 128 x 4096: 0.715
+//     (profiles/r05_kvdecode_timing.txt).
 #include "fq_common.hpp"
 
 namespace {
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
 // four nibbles up to bits 22..25) and OR-ed into 0x4C004C00 is the pair (16 + n_k, 16 + n_k+4). One shift and one v_and_or_b32 per
 // pair — eight operations per eight nibbles where shift / mask / convert are 24 — and the offset 16 leaves the sums: q . (16 + n) =
 // 16 sum(q) + q . n, sum_i p_i s_i (16 + n_i) = 16 sum_i p_i s_i + ..., both removed with one scalar operation per row.
+typedef const int __attribute__((address_space(4))) kv_const_int;
 constexpr int KV_PERM[8] = {0, 4, 1, 5, 2, 6, 3, 7};   // feature (within the dword's eight) of packed slot e
 constexpr float KV_OFF = 16.0f;
 __device__ __forceinline__ uint32_t kv_and_or(uint32_t x, uint32_t mask, uint32_t bits) {
@@ -265,7 +270,10 @@ __device__ __forceinline__ float kv_qk(const f16x8 (&qa)[4], const uint4 kq, uin
 
 // The INT4 cache (batch_decode_i4): see the head of this file. Lane l = RPW part + slot: row `slot` of the wave's RPW rows, 16-byte
 // chunk `part` of that row (a wave's load is still RPW consecutive rows = 1 KB).
-template <int HD, int NW>
+#ifndef KV_DEPTH
+#define KV_DEPTH 1   // steps of rows in flight under a step's arithmetic (measured: 1, 2, 3 within 2 % — profiles/r05_kvdecode_timing.txt)
+#endif
+template <int HD, int NW, bool UNI>
 __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_i4_kernel(f16* __restrict__ o, const f16* __restrict__ q, PagedKv p,
                                                                   const f16* __restrict__ qt, int transpose_out) {
     constexpr int QL = HD / 32;        // lanes per cached row: 4 for head_dim 128, 2 for 64
@@ -321,41 +329,54 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_i4_kernel(f16* __rest
 
     const size_t page_stride = (size_t)p.num_layers * 2 * p.num_heads * p.page_size;
     const size_t k_off = ((size_t)p.layer_idx * 2 * p.num_heads + head) * p.page_size, kv_off = (size_t)p.num_heads * p.page_size;
-    // (page, entry) of this lane's row advance incrementally: a 64-bit division per row would cost more than the row
-    int pit = 0, ent = wave * RPW + slot;
-    while (ent >= p.page_size) {
-        ent -= p.page_size;
-        ++pit;
+    // Where the wave's next RPW rows live, advanced incrementally in request order (a 64-bit division per row would cost more than
+    // the row). UNI (page_size % RPW == 0: the wave's RPW consecutive rows never straddle a page): ONE page index per wave and step, a
+    // scalar load on its own counter, and the lanes differ by `slot` entries; rows of the last step beyond the sequence lie in the same
+    // (allocated) page and are masked. Otherwise every lane walks its own (page, entry) and a row beyond the sequence reads entry 0
+    // of the request's last page instead. The loop itself is WAVE-uniform either way (the MFMA wants every lane).
+    int pit, ent;
+    if (UNI) {
+        pit = (wave * RPW) / p.page_size;
+        ent = wave * RPW - pit * p.page_size;
+    } else {
+        pit = 0, ent = wave * RPW + slot;
+        while (ent >= p.page_size) {
+            ent -= p.page_size;
+            ++pit;
+        }
     }
-    // the loop is WAVE-uniform (the MFMA wants every lane): a lane whose row lies beyond the sequence reads entry 0 of the request's
-    // last page instead and contributes p = 0
-    uint4 kq, vq;
-    uint32_t kpar, vpar;
-    auto request = [&](int64_t base, uint4& kq_, uint4& vq_, uint32_t& kpar_, uint32_t& vpar_) {
-        const bool valid = base + slot < seq_len;
-        const size_t page = (size_t)p.indices[valid ? pg0 + pit : pg1 - 1];
-        const size_t entry = valid ? (size_t)ent : 0;
+    struct Rows {
+        uint4 kq, vq;
+        uint32_t kpar, vpar;
+    };
+    auto request = [&](int64_t base, Rows& r) {
+        size_t page, entry;
+        if (UNI) {
+            // (through the constant address space: a scalar load on lgkmcnt — as a vector load it would sit in front of the rows on
+            //  vmcnt, and waiting for it would wait for every row in flight)
+            page = (size_t)reinterpret_cast<kv_const_int*>(reinterpret_cast<uintptr_t>(p.indices))[pg0 + pit];
+            entry = (size_t)(ent + slot);
+        } else {
+            const bool valid = base + slot < seq_len;
+            page = (size_t)p.indices[valid ? pg0 + pit : pg1 - 1];
+            entry = valid ? (size_t)ent : 0;
+        }
         ent += NS;
         while (ent >= p.page_size) {
             ent -= p.page_size;
             ++pit;
         }
         const size_t ke = page * page_stride + k_off + entry, ve = ke + kv_off;   // = k_entry / v_entry, constants hoisted
-        kq_ = *reinterpret_cast<const uint4*>(p.data + ke * (HD / 2) + part * 16);
-        vq_ = *reinterpret_cast<const uint4*>(p.data + ve * (HD / 2) + part * 16);
-        kpar_ = reinterpret_cast<const uint32_t*>(p.param)[ke];
-        vpar_ = reinterpret_cast<const uint32_t*>(p.param)[ve];
+        r.kq = *reinterpret_cast<const uint4*>(p.data + ke * (HD / 2) + part * 16);
+        r.vq = *reinterpret_cast<const uint4*>(p.data + ve * (HD / 2) + part * 16);
+        r.kpar = reinterpret_cast<const uint32_t*>(p.param)[ke];
+        r.vpar = reinterpret_cast<const uint32_t*>(p.param)[ve];
     };
-    const int64_t base0 = (int64_t)wave * RPW;
-    if (base0 < seq_len) request(base0, kq, vq, kpar, vpar);
-    for (int64_t base = base0; base < seq_len; base += NS) {
-        uint4 nkq = kq, nvq = vq;
-        uint32_t nkpar = kpar, nvpar = vpar;
-        if (base + NS < seq_len) request(base + NS, nkq, nvq, nkpar, nvpar);   // the next step's rows: in flight under this step's arithmetic
+    auto step = [&](int64_t base, const Rows& r) {
         const bool valid = base + slot < seq_len;
-        const float ks = (float)__builtin_bit_cast(f16, (unsigned short)(kpar & 0xFFFF)), kz = (float)__builtin_bit_cast(f16, (unsigned short)(kpar >> 16));
-        const float vs = (float)__builtin_bit_cast(f16, (unsigned short)(vpar & 0xFFFF)), vz = (float)__builtin_bit_cast(f16, (unsigned short)(vpar >> 16));
-        const float dotn = kv_qk<QL>(qa, kq, ebits) - qoff;
+        const float ks = (float)__builtin_bit_cast(f16, (unsigned short)(r.kpar & 0xFFFF)), kz = (float)__builtin_bit_cast(f16, (unsigned short)(r.kpar >> 16));
+        const float vs = (float)__builtin_bit_cast(f16, (unsigned short)(r.vpar & 0xFFFF)), vz = (float)__builtin_bit_cast(f16, (unsigned short)(r.vpar >> 16));
+        const float dotn = kv_qk<QL>(qa, r.kq, ebits) - qoff;
         const float x = valid ? (ks * dotn - kz * qsum) * sm_scale : -INFINITY;
         const float m_new = fmaxf(m, x);
         if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {   // some lane's maximum moved: everybody rescales (by 1 where it did not)
@@ -368,20 +389,48 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_i4_kernel(f16* __rest
         }
         const float pr = valid ? __builtin_amdgcn_exp2f(x - m) : 0.0f;
         d += pr;
-        const float pvs = pr * vs;
-        zacc = __builtin_fmaf(pvs, KV_OFF, __builtin_fmaf(pr, vz, zacc));
-        const uint32_t vw[4] = {vq.x, vq.y, vq.z, vq.w};
+        const float pvs = valid ? pr * vs : 0.0f, pvz = valid ? pr * vz : 0.0f;   // (UNI: a masked row's parameters are whatever the page holds)
+        zacc += __builtin_fmaf(pvs, KV_OFF, pvz);
+        const uint32_t vw[4] = {r.vq.x, r.vq.y, r.vq.z, r.vq.w};
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            uint32_t r[4];
-            kv_unpack8(vw[w], ebits, r);
+            uint32_t u[4];
+            kv_unpack8(vw[w], ebits, u);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                kv_fma_half<0>(acc[w * 8 + 2 * e], r[e], pvs);
-                kv_fma_half<1>(acc[w * 8 + 2 * e + 1], r[e], pvs);
+                kv_fma_half<0>(acc[w * 8 + 2 * e], u[e], pvs);
+                kv_fma_half<1>(acc[w * 8 + 2 * e + 1], u[e], pvs);
             }
         }
-        kq = nkq, vq = nvq, kpar = nkpar, vpar = nvpar;
+    };
+    // NB - 1 steps of rows are in flight under a step's arithmetic (a step is 2.1 KB per wave; 16 waves per CU). The steady-state loop
+    // is free of conditions on purpose: the compiler counts s_waitcnt vmcnt over EVERY path to a use, and one conditional request
+    // makes it wait for all but the shortest path's loads — i.e. for the prefetched rows (seen in the first build: vmcnt(3) in front
+    // of the MFMA with twelve loads in flight). Head and tail (at most 2 (NB - 1) steps) run the conditional form.
+    constexpr int NB = KV_DEPTH + 1;
+    Rows buf[NB];
+    int64_t base = (int64_t)wave * RPW;
+    if (base + (int64_t)2 * (NB - 1) * NS < seq_len) {
+#pragma unroll
+        for (int i = 0; i < NB - 1; ++i) request(base + (int64_t)i * NS, buf[i]);
+        for (; base + (int64_t)2 * (NB - 1) * NS < seq_len; base += (int64_t)NB * NS) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                request(base + (int64_t)(i + NB - 1) * NS, buf[(i + NB - 1) % NB]);
+                step(base + (int64_t)i * NS, buf[i]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NB - 1; ++i)
+            if (base + (int64_t)i * NS < seq_len) request(base + (int64_t)i * NS, buf[i]);
+    }
+    // the last (at most 2 (NB - 1)) steps: step j lives in buf[j % NB], the first NB - 1 are in flight
+#pragma unroll
+    for (int j = 0; j < 2 * (NB - 1); ++j) {
+        if (j + NB - 1 < 2 * (NB - 1) && base + (int64_t)(j + NB - 1) * NS < seq_len)
+            request(base + (int64_t)(j + NB - 1) * NS, buf[(j + NB - 1) % NB]);
+        if (base + (int64_t)j * NS < seq_len) step(base + (int64_t)j * NS, buf[j % NB]);
     }
     const int st = wave * RPW + slot;
     if (part == 0) {
@@ -460,8 +509,13 @@ int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, con
             FQ_RAISE_LDS_CAP((fq_kv_decode_kernel<HD_, NW_>), lds);                                                   \
             hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
         } else {                                                                                                      \
-            FQ_RAISE_LDS_CAP((fq_kv_decode_i4_kernel<HD_, NW_>), lds);                                                \
-            hipLaunchKernelGGL((fq_kv_decode_i4_kernel<HD_, NW_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
+            if (page_size % (64 / (HD_ / 32)) == 0) {                                                                 \
+                FQ_RAISE_LDS_CAP((fq_kv_decode_i4_kernel<HD_, NW_, true>), lds);                                      \
+                hipLaunchKernelGGL((fq_kv_decode_i4_kernel<HD_, NW_, true>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
+            } else {                                                                                                  \
+                FQ_RAISE_LDS_CAP((fq_kv_decode_i4_kernel<HD_, NW_, false>), lds);                                     \
+                hipLaunchKernelGGL((fq_kv_decode_i4_kernel<HD_, NW_, false>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
+            }                                                                                                         \
         }                                                                                                             \
     }
     if (head_dim == 128) {
