@@ -92,135 +92,6 @@ __global__ __launch_bounds__(256) void fq_kv_append_kernel(PagedKv p, const uint
     }
 }
 
-// The fp16 configuration of the cache (batch_decode_f16): a cached row is head_dim fp16 values, no (scale, zero); a lane owns 32
-// features of a row (64 bytes: four 16-byte loads), a quad of neighbouring lanes the row.
-template <int HD, int NW>  // NW waves per workgroup: 4, or 8 when there are too few (request, head) pairs to fill the chip
-__global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restrict__ o, const f16* __restrict__ q, PagedKv p,
-                                                               const f16* __restrict__ qt, int transpose_out) {
-    constexpr int QL = HD / 32;        // lanes per cached row (16 bytes = 32 features each): 4 for head_dim 128
-    constexpr int RPW = 64 / QL;       // rows per wave and step
-    constexpr int NS = NW * RPW;       // partial softmax states per workgroup
-    extern __shared__ __attribute__((aligned(16))) unsigned char kv_smem[];
-    float (*s_o)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(kv_smem);
-    float* s_m = reinterpret_cast<float*>(kv_smem + sizeof(float) * NS * (HD + 1));
-    float* s_d = s_m + NS;
-    const int b = blockIdx.x, head = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int part = lane % QL, slot = lane / QL;
-    const float sm_scale = 1.44269504088896340736f / __builtin_sqrtf((float)HD);  // log2(e) / sqrt(head_dim): exp2 below
-    const int pg0 = p.indptr[b], pg1 = p.indptr[b + 1];
-    const int64_t seq_len = (int64_t)(pg1 - pg0 - 1) * p.page_size + p.last_page_offset[b];
-
-    float qv[32], qsum = 0.0f;
-    if (qt != nullptr) {
-        // the query side of the K transform (kv_cache.py:139-140: torch.matmul(q.half(), trans_matrix_k_inv_t)) in here:
-        // q' = fp16(q . qt), fp32 accumulation, one output feature per thread, handed round through LDS
-        float* s_q = s_d + NS;
-        const f16* qrow = q + ((size_t)b * p.num_heads + head) * HD;
-        for (int j = tid; j < HD; j += NW * 64) {
-            float a = 0.0f;
-            for (int i = 0; i < HD; ++i) a = __builtin_fmaf((float)qrow[i], (float)qt[i * HD + j], a);
-            s_q[j] = (float)(f16)a;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            qv[j] = s_q[part * 32 + j];
-            qsum += qv[j];
-        }
-    } else {
-        const f16* qp = q + ((size_t)b * p.num_heads + head) * HD + part * 32;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            qv[j] = (float)qp[j];
-            qsum += qv[j];
-        }
-    }
-    float m = -INFINITY, d = 0.0f, acc[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) acc[j] = 0.0f;
-
-    const size_t page_stride = (size_t)p.num_layers * 2 * p.num_heads * p.page_size;
-    const size_t k_off = ((size_t)p.layer_idx * 2 * p.num_heads + head) * p.page_size, kv_off = (size_t)p.num_heads * p.page_size;
-    // (page, entry) of this quad's row advance incrementally: a 64-bit division per row would cost more than the row
-    int pit = 0, ent = wave * RPW + slot;
-    while (ent >= p.page_size) {
-        ent -= p.page_size;
-        ++pit;
-    }
-    for (int64_t pos = (int64_t)wave * RPW + slot; pos < seq_len; pos += NS) {
-        const size_t page = (size_t)p.indices[pg0 + pit];
-        const size_t entry = (size_t)ent;
-        ent += NS;
-        while (ent >= p.page_size) {
-            ent -= p.page_size;
-            ++pit;
-        }
-        const size_t ke = page * page_stride + k_off + entry, ve = ke + kv_off;   // = k_entry / v_entry, constants hoisted
-        {
-            const uint4* kp = reinterpret_cast<const uint4*>(p.data + ke * (HD * 2) + part * 64);
-            const uint4* vp = reinterpret_cast<const uint4*>(p.data + ve * (HD * 2) + part * 64);
-            uint4 kq[4], vq[4];
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                kq[w] = kp[w];
-                vq[w] = vp[w];
-            }
-            float part_dot = 0.0f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const f16x8 kh = __builtin_bit_cast(f16x8, kq[w]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) part_dot = __builtin_fmaf(qv[w * 8 + e], (float)kh[e], part_dot);
-            }
-#pragma unroll
-            for (int off = 1; off < QL; off <<= 1) part_dot += __shfl_xor(part_dot, off, 64);
-            const float x = part_dot * sm_scale;
-            const float m_new = fmaxf(m, x);
-            const float alpha = __builtin_amdgcn_exp2f(m - m_new), pr = __builtin_amdgcn_exp2f(x - m_new);
-            d = d * alpha + pr;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const f16x8 vh = __builtin_bit_cast(f16x8, vq[w]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[w * 8 + e] = __builtin_fmaf((float)vh[e], pr, acc[w * 8 + e] * alpha);
-            }
-            m = m_new;
-        }
-    }
-    const int st = wave * RPW + slot;
-    if (part == 0) {
-        s_m[st] = m;
-        s_d[st] = d;
-    }
-#pragma unroll
-    for (int j = 0; j < 32; ++j) s_o[st][part * 32 + j] = acc[j];
-    __syncthreads();
-    if (tid < HD) {   // state.cuh merge: rescale every partial state to the common maximum
-        // (bounded unrolling: fully unrolled for NS = 64, these loops hoisted 128 LDS reads and pushed the 4-wave build from
-        //  198 to 260 VGPRs — one wave per SIMD, 48 -> 71 us at 16 x 2048 — when the output select below was added)
-        float mm = -INFINITY;
-#pragma unroll 8
-        for (int s = 0; s < NS; ++s) mm = fmaxf(mm, s_m[s]);
-        float dd = 0.0f, oo = 0.0f;
-#pragma unroll 8
-        for (int s = 0; s < NS; ++s) {
-            const float w = s_m[s] == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(s_m[s] - mm);
-            dd += s_d[s] * w;
-            oo += s_o[s][tid] * w;
-        }
-        // transpose_out: [batch, head_dim, heads] — the layout the o_proj head transform takes (modeling_llama.py:147-149
-        // transposes and copies the attention output before block_matmul)
-        const size_t oi = transpose_out ? ((size_t)b * HD + tid) * p.num_heads + head : ((size_t)b * p.num_heads + head) * HD + tid;
-        o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;  // an empty sequence attends to nothing: zeros, not 0/0
-    }
-}
-
-// eight INT4 of one dword -> the eight EXACT fp16 values 16 + n as four packed pairs, in the order (n0, n4) (n1, n5) (n2, n6) (n3, n7):
-// 0x4C00 is 16.0 and the top four bits of its mantissa (bits 6..9) count units of one, so a nibble moved to bits 6..9 (and its partner
-// four nibbles up to bits 22..25) and OR-ed into 0x4C004C00 is the pair (16 + n_k, 16 + n_k+4). One shift and one v_and_or_b32 per
-// pair — eight operations per eight nibbles where shift / mask / convert are 24 — and the offset 16 leaves the sums: q . (16 + n) =
-// 16 sum(q) + q . n, sum_i p_i s_i (16 + n_i) = 16 sum_i p_i s_i + ..., both removed with one scalar operation per row.
 typedef const int __attribute__((address_space(4))) kv_const_int;
 constexpr int KV_PERM[8] = {0, 4, 1, 5, 2, 6, 3, 7};   // feature (within the dword's eight) of packed slot e
 constexpr float KV_OFF = 16.0f;
@@ -246,15 +117,7 @@ __device__ __forceinline__ void kv_fma_half(float& acc, uint32_t pair, float s) 
 // sum_j q_j n_ij for the wave's RPW cached rows on the matrix pipe: A = the query in every row, B = the rows as columns. Lane
 // l = RPW g + i holds features 32 g .. 32 g + 31 of row i (one dword per K-step) and gets row i's sum over ALL features back.
 template <int QL>
-__device__ __forceinline__ float kv_qk(const f16x8 (&qa)[4], const uint4 kq, uint32_t ebits) {   // -> sum_j q_j (16 + n_ij)
-    const uint32_t kw[4] = {kq.x, kq.y, kq.z, kq.w};
-    f16x8 kb[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        uint32_t r[4];
-        kv_unpack8(kw[w], ebits, r);
-        kb[w] = __builtin_bit_cast(f16x8, u32x4{r[0], r[1], r[2], r[3]});
-    }
+__device__ __forceinline__ float kv_qk_mfma(const f16x8 (&qa)[4], const f16x8 (&kb)[4]) {
     if constexpr (QL == 4) {
         f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -267,14 +130,27 @@ __device__ __forceinline__ float kv_qk(const f16x8 (&qa)[4], const uint4 kq, uin
         return c[0];
     }
 }
+template <int QL>
+__device__ __forceinline__ float kv_qk(const f16x8 (&qa)[4], const uint4 kq, uint32_t ebits) {   // INT4 row -> sum_j q_j (16 + n_ij)
+    const uint32_t kw[4] = {kq.x, kq.y, kq.z, kq.w};
+    f16x8 kb[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint32_t r[4];
+        kv_unpack8(kw[w], ebits, r);
+        kb[w] = __builtin_bit_cast(f16x8, u32x4{r[0], r[1], r[2], r[3]});
+    }
+    return kv_qk_mfma<QL>(qa, kb);
+}
 
-// The INT4 cache (batch_decode_i4): see the head of this file. Lane l = RPW part + slot: row `slot` of the wave's RPW rows, 16-byte
-// chunk `part` of that row (a wave's load is still RPW consecutive rows = 1 KB).
+// Decode attention (batch_decode_i4 / batch_decode_f16): see the head of this file. Lane l = RPW part + slot: row `slot` of the wave's
+// RPW rows, chunk `part` (32 features) of that row: 16 bytes of the INT4 cache (a wave's load is RPW consecutive rows = 1 KB), or 64
+// bytes = four 16-byte loads of the fp16 configuration (F16: no (scale, zero), no unpacking — the loaded dwords ARE the B fragments).
 #ifndef KV_DEPTH
 #define KV_DEPTH 1   // steps of rows in flight under a step's arithmetic (measured: 1, 2, 3 within 2 % — profiles/r05_kvdecode_timing.txt)
 #endif
-template <int HD, int NW, bool UNI>
-__global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_i4_kernel(f16* __restrict__ o, const f16* __restrict__ q, PagedKv p,
+template <int HD, int NW, bool UNI, bool F16>
+__global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restrict__ o, const f16* __restrict__ q, PagedKv p,
                                                                   const f16* __restrict__ qt, int transpose_out) {
     constexpr int QL = HD / 32;        // lanes per cached row: 4 for head_dim 128, 2 for 64
     constexpr int RPW = 64 / QL;       // rows per wave and step: the N of the MFMA (16 / 32)
@@ -307,13 +183,15 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_i4_kernel(f16* __rest
         }
         __syncthreads();
     }
-    f16x8 qa[4];      // the A operand of K-step w: features 32 part + 8 w + KV_PERM[e] (the order kv_unpack8 leaves the nibbles in)
+    // the A operand of K-step w: features 32 part + 8 w + feat(e) — INT4: the order kv_unpack8 leaves the nibbles in
+    auto feat = [](int e) { return F16 ? e : KV_PERM[e]; };
+    f16x8 qa[4];
     float qsum = 0.0f;
 #pragma unroll
     for (int w = 0; w < 4; ++w)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = s_q[part * 32 + w * 8 + KV_PERM[e]];
+            const float v = s_q[part * 32 + w * 8 + feat(e)];
             qa[w][e] = (f16)v;
             qsum += v;
         }
@@ -346,7 +224,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_i4_kernel(f16* __rest
         }
     }
     struct Rows {
-        uint4 kq, vq;
+        uint4 kq[F16 ? 4 : 1], vq[F16 ? 4 : 1];
         uint32_t kpar, vpar;
     };
     auto request = [&](int64_t base, Rows& r) {
@@ -367,17 +245,34 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_i4_kernel(f16* __rest
             ++pit;
         }
         const size_t ke = page * page_stride + k_off + entry, ve = ke + kv_off;   // = k_entry / v_entry, constants hoisted
-        r.kq = *reinterpret_cast<const uint4*>(p.data + ke * (HD / 2) + part * 16);
-        r.vq = *reinterpret_cast<const uint4*>(p.data + ve * (HD / 2) + part * 16);
-        r.kpar = reinterpret_cast<const uint32_t*>(p.param)[ke];
-        r.vpar = reinterpret_cast<const uint32_t*>(p.param)[ve];
+        if constexpr (F16) {
+            const uint4* kp = reinterpret_cast<const uint4*>(p.data + ke * (HD * 2) + part * 64);
+            const uint4* vp = reinterpret_cast<const uint4*>(p.data + ve * (HD * 2) + part * 64);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) r.kq[w] = kp[w];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) r.vq[w] = vp[w];
+        } else {
+            r.kq[0] = *reinterpret_cast<const uint4*>(p.data + ke * (HD / 2) + part * 16);
+            r.vq[0] = *reinterpret_cast<const uint4*>(p.data + ve * (HD / 2) + part * 16);
+            r.kpar = reinterpret_cast<const uint32_t*>(p.param)[ke];
+            r.vpar = reinterpret_cast<const uint32_t*>(p.param)[ve];
+        }
     };
     auto step = [&](int64_t base, const Rows& r) {
         const bool valid = base + slot < seq_len;
-        const float ks = (float)__builtin_bit_cast(f16, (unsigned short)(r.kpar & 0xFFFF)), kz = (float)__builtin_bit_cast(f16, (unsigned short)(r.kpar >> 16));
-        const float vs = (float)__builtin_bit_cast(f16, (unsigned short)(r.vpar & 0xFFFF)), vz = (float)__builtin_bit_cast(f16, (unsigned short)(r.vpar >> 16));
-        const float dotn = kv_qk<QL>(qa, r.kq, ebits) - qoff;
-        const float x = valid ? (ks * dotn - kz * qsum) * sm_scale : -INFINITY;
+        float x, vs = 1.0f, vz = 0.0f;
+        if constexpr (F16) {
+            f16x8 kb[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) kb[w] = __builtin_bit_cast(f16x8, r.kq[w]);
+            x = valid ? kv_qk_mfma<QL>(qa, kb) * sm_scale : -INFINITY;
+        } else {
+            const float ks = (float)__builtin_bit_cast(f16, (unsigned short)(r.kpar & 0xFFFF)), kz = (float)__builtin_bit_cast(f16, (unsigned short)(r.kpar >> 16));
+            vs = (float)__builtin_bit_cast(f16, (unsigned short)(r.vpar & 0xFFFF)), vz = (float)__builtin_bit_cast(f16, (unsigned short)(r.vpar >> 16));
+            const float dotn = kv_qk<QL>(qa, r.kq[0], ebits) - qoff;
+            x = valid ? (ks * dotn - kz * qsum) * sm_scale : -INFINITY;
+        }
         const float m_new = fmaxf(m, x);
         if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {   // some lane's maximum moved: everybody rescales (by 1 where it did not)
             const float alpha = m_new > m ? __builtin_amdgcn_exp2f(m - m_new) : 1.0f;
@@ -389,17 +284,31 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_i4_kernel(f16* __rest
         }
         const float pr = valid ? __builtin_amdgcn_exp2f(x - m) : 0.0f;
         d += pr;
-        const float pvs = valid ? pr * vs : 0.0f, pvz = valid ? pr * vz : 0.0f;   // (UNI: a masked row's parameters are whatever the page holds)
-        zacc += __builtin_fmaf(pvs, KV_OFF, pvz);
-        const uint32_t vw[4] = {r.vq.x, r.vq.y, r.vq.z, r.vq.w};
+        if constexpr (F16) {
+            // (a masked row's VALUES are whatever the page holds, maybe NaN: they must not meet p = 0 in an FMA)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            uint32_t u[4];
-            kv_unpack8(vw[w], ebits, u);
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t vw[4] = {r.vq[w].x, r.vq[w].y, r.vq[w].z, r.vq[w].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                kv_fma_half<0>(acc[w * 8 + 2 * e], u[e], pvs);
-                kv_fma_half<1>(acc[w * 8 + 2 * e + 1], u[e], pvs);
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t pair = (!UNI || valid) ? vw[e] : 0u;
+                    kv_fma_half<0>(acc[w * 8 + 2 * e], pair, pr);
+                    kv_fma_half<1>(acc[w * 8 + 2 * e + 1], pair, pr);
+                }
+            }
+        } else {
+            const float pvs = valid ? pr * vs : 0.0f, pvz = valid ? pr * vz : 0.0f;   // (UNI: a masked row's parameters are whatever the page holds)
+            zacc += __builtin_fmaf(pvs, KV_OFF, pvz);
+            const uint32_t vw[4] = {r.vq[0].x, r.vq[0].y, r.vq[0].z, r.vq[0].w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                uint32_t u[4];
+                kv_unpack8(vw[w], ebits, u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    kv_fma_half<0>(acc[w * 8 + 2 * e], u[e], pvs);
+                    kv_fma_half<1>(acc[w * 8 + 2 * e + 1], u[e], pvs);
+                }
             }
         }
     };
@@ -440,9 +349,11 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_i4_kernel(f16* __rest
 #pragma unroll
     for (int w = 0; w < 4; ++w)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s_o[st][part * 32 + w * 8 + KV_PERM[e]] = acc[w * 8 + e] - zacc;
+        for (int e = 0; e < 8; ++e) s_o[st][part * 32 + w * 8 + feat(e)] = acc[w * 8 + e] - zacc;
     __syncthreads();
-    if (tid < HD) {   // state.cuh merge: rescale every partial state to the common maximum (see fq_kv_decode_kernel)
+    if (tid < HD) {   // state.cuh merge: rescale every partial state to the common maximum
+        // (bounded unrolling: fully unrolled for NS = 64, these loops hoisted 128 LDS reads and pushed a 4-wave build from 198 to 260
+        //  VGPRs — one wave per SIMD, 48 -> 71 us at 16 x 2048 — in round 2)
         float mm = -INFINITY;
 #pragma unroll 8
         for (int s = 0; s < NS; ++s) mm = fmaxf(mm, s_m[s]);
@@ -502,20 +413,19 @@ int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, con
     const PagedKv p = make_kv(kv_data, kv_param, indptr, indices, last, num_layers, layer_idx, num_heads, page_size, head_dim, batch);
     const dim3 grid((unsigned)batch, (unsigned)num_heads);
     const bool wide = (int64_t)batch * num_heads < 512;  // fewer than two workgroups per CU: 8 waves each instead of 4 (measured: 158 -> 113 us at 8 x 8192; no gain from 512 up)
+#define FQ_DEC2(HD_, NW_, UNI_, F16_)                                                                                  \
+    {                                                                                                                 \
+        FQ_RAISE_LDS_CAP((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_>), lds);                                           \
+        hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
+    }
 #define FQ_DEC(HD_, NW_)                                                                                              \
     {                                                                                                                 \
-        constexpr size_t lds = sizeof(float) * ((size_t)(NW_ * (64 / (HD_ / 32))) * (HD_ + 1 + 2) + HD_);                     \
+        constexpr size_t lds = sizeof(float) * ((size_t)(NW_ * (64 / (HD_ / 32))) * (HD_ + 1 + 2) + HD_);             \
+        const bool uni = page_size % (64 / (HD_ / 32)) == 0;   /* a wave's rows never straddle a page */              \
         if (f16_cache) {                                                                                              \
-            FQ_RAISE_LDS_CAP((fq_kv_decode_kernel<HD_, NW_>), lds);                                                   \
-            hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
+            if (uni) FQ_DEC2(HD_, NW_, true, true) else FQ_DEC2(HD_, NW_, false, true)                                \
         } else {                                                                                                      \
-            if (page_size % (64 / (HD_ / 32)) == 0) {                                                                 \
-                FQ_RAISE_LDS_CAP((fq_kv_decode_i4_kernel<HD_, NW_, true>), lds);                                      \
-                hipLaunchKernelGGL((fq_kv_decode_i4_kernel<HD_, NW_, true>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
-            } else {                                                                                                  \
-                FQ_RAISE_LDS_CAP((fq_kv_decode_i4_kernel<HD_, NW_, false>), lds);                                     \
-                hipLaunchKernelGGL((fq_kv_decode_i4_kernel<HD_, NW_, false>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
-            }                                                                                                         \
+            if (uni) FQ_DEC2(HD_, NW_, true, false) else FQ_DEC2(HD_, NW_, false, false)                              \
         }                                                                                                             \
     }
     if (head_dim == 128) {
@@ -526,5 +436,6 @@ int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, con
         return -1000;
     }
 #undef FQ_DEC
+#undef FQ_DEC2
     return (int)hipGetLastError();
 }
