@@ -149,6 +149,37 @@ struct KvIO {
     int num_layers, layer_idx, num_heads, page_size, added, group, src_heads;
 };
 
+// The A fragments of matrix^T for fq_kv_quant_kernel / fq_rowmm_kernel: A row fc <-> output column n, eight consecutive k per lane — a
+// COLUMN piece of the row-major matrix. Gathered from global memory that is eight 2-byte loads 2 HD bytes apart per fragment, 64
+// latency-bound loads per thread: ~8 us in front of every launch, 10.7 us for the 128 rows of a decode step (rocprofv3, tools/gpu_call.sh
+// r05c18). Now the matrix goes through LDS: coalesced 16-byte loads of HD / 2 rows at a time (row pitch HD + 2 halfwords: consecutive
+// rows start one bank apart), the column pieces are gathered from there.
+template <int HD, typename T>
+__device__ __forceinline__ void kv_stage_tfrag(const T* __restrict__ Tm, uint4* tfrag, unsigned short* raw, int tid) {
+    constexpr int KS = HD / 16, NTL = HD / 32, PITCH = HD + 2, HALF = HD / 2, CPR = HD / 8;
+    for (int half = 0; half < 2; ++half) {
+        for (int i = tid; i < HALF * CPR; i += 256) {
+            const int k = i / CPR, c8 = i - k * CPR;
+            const uint4 v = reinterpret_cast<const uint4*>(Tm + (size_t)(half * HALF) * HD)[i];
+            unsigned* dst = reinterpret_cast<unsigned*>(raw + k * PITCH + c8 * 8);   // (4-byte aligned: PITCH is even)
+            dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+        }
+        __syncthreads();
+        for (int item = tid + half * (KS / 2) * NTL * 64; item < (half + 1) * (KS / 2) * NTL * 64; item += 256) {
+            const int f = item >> 6, ln = item & 63, fh = ln >> 5, fc = ln & 31;
+            const int s = f / NTL, nt = f - s * NTL;
+            const int n = nt * 32 + 16 * ((fc >> 2) & 1) + 4 * (fc >> 3) + (fc & 3);  // output column of A row fc
+            const unsigned short* src = raw + ((s * 16 - half * HALF) + fh * 8) * PITCH + n;
+            unsigned short e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = src[j * PITCH];
+            tfrag[item] = uint4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                                (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+        }
+        __syncthreads();
+    }
+}
+
 template <int HD, bool TRANS, bool LAC>
 __global__ __launch_bounds__(256) void fq_kv_quant_kernel(KvIO io, const f16* __restrict__ T, int64_t rows) {
     const int which = blockIdx.y;
@@ -161,18 +192,7 @@ __global__ __launch_bounds__(256) void fq_kv_quant_kernel(KvIO io, const f16* __
     constexpr int KS = HD / 16, NTL = HD / 32;
     __shared__ __attribute__((aligned(16))) uint4 tfrag[TRANS ? KS * NTL * 64 : 1];  // [(s * NTL + nt)][lane]
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
-    if (TRANS) {
-        for (int item = tid; item < KS * NTL * 64; item += 256) {
-            const int f = item >> 6, ln = item & 63, fh = ln >> 5, fc = ln & 31;
-            const int s = f / NTL, nt = f - s * NTL;
-            const int n = nt * 32 + 16 * ((fc >> 2) & 1) + 4 * (fc >> 3) + (fc & 3);  // output column of A row fc
-            f16x8 v;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = T[(s * 16 + fh * 8 + j) * HD + n];
-            tfrag[item] = __builtin_bit_cast(uint4, v);
-        }
-        __syncthreads();
-    }
+    __shared__ __attribute__((aligned(16))) unsigned short traw[TRANS ? (HD / 2) * (HD + 2) : 2];
     const f16 cmax = (f16)clip_max, cmin = (f16)clip_min;
     const int64_t n_tiles = (rows + 31) / 32;
     // the next tile's row is requested before this one is worked on: a wave's loads overlap its own arithmetic (all waves
@@ -190,10 +210,54 @@ __global__ __launch_bounds__(256) void fq_kv_quant_kernel(KvIO io, const f16* __
         const int64_t t0 = (int64_t)blockIdx.x * 4 + (tid >> 6);
         if (t0 < n_tiles) fetch(t0, xn);
     }
+    // (behind the first rows' loads: a decode step is ONE tile per wave and two workgroups per launch — every dependent round trip
+    //  of this kernel is exposed there. The values' workgroups (which == 1) never use the matrix.)
+    if (TRANS && do_trans) kv_stage_tfrag<HD, f16>(T, tfrag, traw, tid);
+    const bool small = rows <= 0x7FFFFFFF;   // 32-bit index arithmetic (a 64-bit division is ~100 instructions, four of them per row)
     for (int64_t tile = (int64_t)blockIdx.x * 4 + (tid >> 6); tile < n_tiles; tile += tstep) {
         const int64_t row = tile * 32 + c;
         const bool ok = row < rows;
         const int64_t lrow = ok ? row : rows - 1;
+        // destination(s) of this lane's row: the dense row, or `group` rows of the paged cache — located FIRST: the page-table loads
+        // (two dependent round trips) run under the transform and the quantiser instead of behind them
+        uint8_t* qdst[4];
+        unsigned* pdst[4];
+        int ndst = 1;
+        if (io.data == nullptr) {
+            qdst[0] = q_out + row * (HD / 2);
+            pdst[0] = reinterpret_cast<unsigned*>(param + row * 2);
+        } else {
+            int64_t t;
+            int hs, b, j;
+            if (small) {
+                const unsigned lr = (unsigned)lrow, t32 = lr / (unsigned)io.src_heads, b32 = t32 / (unsigned)io.added;
+                t = t32, hs = (int)(lr - t32 * (unsigned)io.src_heads), b = (int)b32, j = (int)(t32 - b32 * (unsigned)io.added);
+            } else {
+                t = lrow / io.src_heads, hs = (int)(lrow - t * io.src_heads);
+                b = (int)(t / io.added), j = (int)(t - (int64_t)b * io.added);
+            }
+            const int pgb = io.indptr[b];
+            const int64_t seq_len = (int64_t)(io.indptr[b + 1] - pgb - 1) * io.page_size + io.last[b];
+            const int64_t pos = seq_len - io.added + j;
+            int64_t pq;
+            int entry_i;
+            if ((uint64_t)pos <= 0x7FFFFFFFu) {
+                const unsigned p32 = (unsigned)pos, q32 = p32 / (unsigned)io.page_size;
+                pq = q32, entry_i = (int)(p32 - q32 * (unsigned)io.page_size);
+            } else {
+                pq = pos / io.page_size, entry_i = (int)(pos - pq * io.page_size);
+            }
+            const size_t page = (size_t)io.indices[pgb + pq];
+            const size_t entry = (size_t)entry_i;
+            ndst = io.group;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const size_t e = (((page * io.num_layers + io.layer_idx) * 2 + which) * io.num_heads + (size_t)hs * io.group + (g < ndst ? g : 0)) *
+                                     io.page_size + entry;
+                qdst[g] = io.data + e * (HD / 2);
+                pdst[g] = reinterpret_cast<unsigned*>(io.pparam) + e;
+            }
+        }
         f16x8 xf[KS];  // chunk 2s + h of the row (8 consecutive columns each)
 #pragma unroll
         for (int s = 0; s < KS; ++s) xf[s] = xn[s];
@@ -248,30 +312,6 @@ __global__ __launch_bounds__(256) void fq_kv_quant_kernel(KvIO io, const f16* __
         mn = omn < mn ? omn : mn;
         const KvParams p = kv_params<LAC>(mx, mn, cmax, cmin);
 
-        // destination(s) of this lane's row: the dense row, or `group` rows of the paged cache
-        uint8_t* qdst[4];
-        unsigned* pdst[4];
-        int ndst = 1;
-        if (io.data == nullptr) {
-            qdst[0] = q_out + row * (HD / 2);
-            pdst[0] = reinterpret_cast<unsigned*>(param + row * 2);
-        } else {
-            const int64_t t = lrow / io.src_heads;
-            const int hs = (int)(lrow - t * io.src_heads);
-            const int b = (int)(t / io.added), j = (int)(t - (int64_t)b * io.added);
-            const int64_t seq_len = (int64_t)(io.indptr[b + 1] - io.indptr[b] - 1) * io.page_size + io.last[b];
-            const int64_t pos = seq_len - io.added + j;
-            const size_t page = (size_t)io.indices[io.indptr[b] + pos / io.page_size];
-            const size_t entry = (size_t)(pos % io.page_size);
-            ndst = io.group;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const size_t e = (((page * io.num_layers + io.layer_idx) * 2 + which) * io.num_heads + (size_t)hs * io.group + (g < ndst ? g : 0)) *
-                                     io.page_size + entry;
-                qdst[g] = io.data + e * (HD / 2);
-                pdst[g] = reinterpret_cast<unsigned*>(io.pparam) + e;
-            }
-        }
         const float sc = (float)p.scale, rc = fq_fast_inv(sc);
         const uint32_t zero2 = __builtin_bit_cast(uint32_t, f16x2{p.zero, p.zero});
 #pragma unroll
@@ -414,16 +454,8 @@ __global__ __launch_bounds__(256) void fq_rowmm_kernel(const T* __restrict__ x, 
     constexpr int KS = HD / 16, NTL = HD / 32;
     __shared__ __attribute__((aligned(16))) uint4 tfrag[KS * NTL * 64];  // [(s * NTL + nt)][lane]
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
-    for (int item = tid; item < KS * NTL * 64; item += 256) {
-        const int f = item >> 6, ln = item & 63, fh = ln >> 5, fc = ln & 31;
-        const int s = f / NTL, nt = f - s * NTL;
-        const int n = nt * 32 + 16 * ((fc >> 2) & 1) + 4 * (fc >> 3) + (fc & 3);  // output column of A row fc
-        X8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = Tm[(s * 16 + fh * 8 + j) * HD + n];
-        tfrag[item] = __builtin_bit_cast(uint4, v);
-    }
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) unsigned short traw[(HD / 2) * (HD + 2)];
+    kv_stage_tfrag<HD, T>(Tm, tfrag, traw, tid);
     const int64_t n_tiles = (rows + 31) / 32;
     const int64_t tstep = (int64_t)gridDim.x * 4;
     auto fetch = [&](int64_t t, X8 (&dst)[KS]) {
