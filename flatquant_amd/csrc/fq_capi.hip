@@ -42,6 +42,8 @@ int fq_launch_kv_quant_append(const f16* k, const f16* v, const f16* T, int64_t 
                               hipStream_t stream);
 int64_t fq_i4_frag_bytes(int N, int K);
 int fq_launch_i4_to_frag(const uint8_t* W, int N, int K, void* img, int n_cu, hipStream_t stream);
+int fq_launch_gemm_i4_skinny_multi(int n, const uint8_t* const* X, const void* const* wimg, int64_t M, const int* N, int K, f16* const* y,
+                                   const f16* const* srow, const f16* const* scol, const f16* const* bias, hipStream_t stream);
 int fq_launch_gemm_i4_skinny(const uint8_t* X, const void* wimg, int64_t M, int N, int K, int32_t* c, f16* y, const f16* srow,
                              const f16* scol, const f16* bias, hipStream_t stream);
 int64_t fq_bf6_blob_bytes(int64_t rows, int K);  // fq_gemm_bf6.hip (exported as is)
@@ -763,6 +765,24 @@ int fq_int4_skinny_linear_f16(const void* x, const void* x_scale, const void* w_
                                             (const f16*)w_scale, (const f16*)bias, (hipStream_t)stream);
     if (rc == -1000) return fail(FQ_EUNSUPPORTED, "fq_int4_skinny_linear_f16: M=%lld K=%d (M <= 128, K %% 64 == 0)", (long long)M, K);
     return check_launch(rc, "fq_int4_skinny_linear_f16");
+}
+
+int fq_int4_skinny_linear_multi_f16(int n, const void* const* x, const void* const* x_scale, const void* const* w_image,
+                                    const void* const* w_scale, const void* const* bias, int64_t M, const int* N, int K, void* const* y,
+                                    void* stream) {
+    const char* what = "fq_int4_skinny_linear_multi_f16";
+    if (n < 1 || n > 4) return fail(FQ_EINVAL, "%s: n=%d problems (1..4)", what, n);
+    if (M < 0 || K <= 0 || !N) return fail(FQ_EINVAL, "%s: bad sizes", what);
+    if (!x || !x_scale || !w_image || !w_scale || !y) return fail(FQ_EINVAL, "%s: NULL pointer table", what);
+    for (int p = 0; p < n; ++p) {
+        if (N[p] <= 0) return fail(FQ_EINVAL, "%s: N[%d]=%d", what, p, N[p]);
+        if (M && (!x[p] || !x_scale[p] || !w_image[p] || !w_scale[p] || !y[p])) return fail(FQ_EINVAL, "%s: NULL pointer in problem %d", what, p);
+    }
+    if (M == 0) return FQ_OK;
+    const int rc = fq_launch_gemm_i4_skinny_multi(n, (const uint8_t* const*)x, w_image, M, N, K, (f16* const*)y, (const f16* const*)x_scale,
+                                                  (const f16* const*)w_scale, (const f16* const*)bias, (hipStream_t)stream);
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "%s: M=%lld K=%d (M <= 128, K %% 64 == 0)", what, (long long)M, K);
+    return check_launch(rc, what);
 }
 
 int fq_int4_to_bf6(const void* q, int64_t rows, int K, int role, void* blob, void* stream) {

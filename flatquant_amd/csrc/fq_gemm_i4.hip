@@ -284,14 +284,42 @@ __global__ __launch_bounds__(256) void fq_i4_to_frag_kernel(const uint8_t* __res
 
 constexpr int SK_WAVES = 16;
 
-template <int MT>
-__global__ __launch_bounds__(SK_WAVES * 64) void fq_gemm_i4_skinny_kernel(const uint8_t* __restrict__ X,
-                                                                         const uint4* __restrict__ Wimg, int M, int N,
-                                                                         int Kb, GemmOut out) {
+// Up to four problems that share M and K (q / k / v or up / gate of a decoder layer, each with its own activations, image, scales, bias,
+// output) as ONE launch: the feature tiles of the problems side by side in the grid. A decode-sized launch sits on the ~4 us floor of a
+// small dispatch whatever it streams (4.4 us for the 8 MB of a 4096 x 4096 projection, 4.0 us for the 2 MB of a 1024-wide one:
+// profiles/r05_skinny_prefetch.txt), so three launches cost three floors.
+struct SkinnyProblems {
+    const uint8_t* X[4];
+    const uint4* Wimg[4];
+    GemmOut out[4];
+    int N[4];
+    int tile0[4];   // first feature tile (workgroup) of problem p
+    int n;
+};
+
+template <int MT, bool MULTI>
+__global__ __launch_bounds__(SK_WAVES * 64) void fq_gemm_i4_skinny_kernel(const uint8_t* __restrict__ X_,
+                                                                         const uint4* __restrict__ Wimg_, int M, int N_,
+                                                                         int Kb, GemmOut out_, SkinnyProblems pr) {
     __shared__ int tile[MT][32][33];  // [token tile][token][feature], +1 padding
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rt = blockIdx.x, KB = Kb / 32;
+    int rt = blockIdx.x;
+    const int KB = Kb / 32;
+    const uint8_t* __restrict__ X = X_;
+    const uint4* __restrict__ Wimg = Wimg_;
+    GemmOut out = out_;
+    int N = N_;
+    if (MULTI) {   // (workgroup-uniform selects)
+        int pi = 0;
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (q < pr.n && rt >= pr.tile0[q]) pi = q;
+        X = pr.X[0], Wimg = pr.Wimg[0], out = pr.out[0], N = pr.N[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (pi == q) X = pr.X[q], Wimg = pr.Wimg[q], out = pr.out[q], N = pr.N[q], rt -= pr.tile0[q];
+    }
     for (int i = tid; i < MT * 32 * 33; i += SK_WAVES * 64) (&tile[0][0][0])[i] = 0;
     __syncthreads();
 
@@ -385,8 +413,37 @@ int fq_launch_gemm_i4_skinny(const uint8_t* X, const void* wimg, int64_t M, int 
     o.bias = bias;
     const dim3 grid((unsigned)((N + 31) / 32));
     const uint4* img = reinterpret_cast<const uint4*>(wimg);
-    if (M <= 32) hipLaunchKernelGGL(fq_gemm_i4_skinny_kernel<1>, grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o);
-    else if (M <= 64) hipLaunchKernelGGL(fq_gemm_i4_skinny_kernel<2>, grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o);
-    else hipLaunchKernelGGL(fq_gemm_i4_skinny_kernel<4>, grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o);
+    const SkinnyProblems none = {};
+    if (M <= 32) hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<1, false>), grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o, none);
+    else if (M <= 64) hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<2, false>), grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o, none);
+    else hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<4, false>), grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o, none);
+    return (int)hipGetLastError();
+}
+
+// -1000: n not in 1..4, M > 128 or K % 64 != 0
+int fq_launch_gemm_i4_skinny_multi(int n, const uint8_t* const* X, const void* const* wimg, int64_t M, const int* N, int K, f16* const* y,
+                                   const f16* const* srow, const f16* const* scol, const f16* const* bias, hipStream_t stream) {
+    if (n < 1 || n > 4 || M < 1 || M > 128 || (K & 63) || K < 64 || K > 131072) return -1000;
+    SkinnyProblems pr = {};
+    pr.n = n;
+    int tiles = 0;
+    for (int p = 0; p < n; ++p) {
+        if (N[p] < 1) return -1000;
+        pr.X[p] = X[p];
+        pr.Wimg[p] = reinterpret_cast<const uint4*>(wimg[p]);
+        pr.out[p].c = nullptr;
+        pr.out[p].y = y[p];
+        pr.out[p].srow = srow[p];
+        pr.out[p].scol = scol[p];
+        pr.out[p].bias = bias ? bias[p] : nullptr;
+        pr.N[p] = N[p];
+        pr.tile0[p] = tiles;
+        tiles += (N[p] + 31) / 32;
+    }
+    const dim3 grid((unsigned)tiles);
+    GemmOut o = {};
+    if (M <= 32) hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<1, true>), grid, dim3(SK_WAVES * 64), 0, stream, nullptr, nullptr, (int)M, 0, K / 2, o, pr);
+    else if (M <= 64) hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<2, true>), grid, dim3(SK_WAVES * 64), 0, stream, nullptr, nullptr, (int)M, 0, K / 2, o, pr);
+    else hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<4, true>), grid, dim3(SK_WAVES * 64), 0, stream, nullptr, nullptr, (int)M, 0, K / 2, o, pr);
     return (int)hipGetLastError();
 }

@@ -195,11 +195,29 @@ def linear4bit_multi(modules, inputs):
     up_proj / gate_proj (deploy/transformers/modeling_llama.py:66-78, 268-276: one GEMM + dequant per projection in the reference) — each
     on its own PackedQuantizedTensor, as ONE GEMM launch on the FP6 matrix path (round 4, fq_int4_linear_fp6_multi_f16): at prefill sizes
     of a few thousand tokens a single projection does not fill the chip. Returns one fp16 tensor per module, bit-identical to
-    ``m(x)``. Falls back to the modules' own forward when the FP6 route does not apply to every one of them (decode-sized inputs, shapes
-    the FP6 path does not cover, fp6_gemm off, layers narrower than fp6_min_out_features without a kept image)."""
+    ``m(x)``. Decode-sized inputs (<= 128 rows) take ONE launch of the weight-streaming kernel instead (round 5). Falls back to the modules' own
+    forward when neither route applies to every one of them (shapes the FP6 path does not cover, fp6_gemm off, layers narrower than
+    fp6_min_out_features without a kept image; no decode image)."""
     assert len(modules) == len(inputs) and len(modules) >= 1
     q0 = inputs[0].quantized_x
     rows = q0.numel() // q0.shape[-1]
+    if 2 <= len(modules) <= 4 and q0.is_cuda and ops.skinny_supported(rows, modules[0].in_features):
+        # (round 5) decode-sized: ONE launch of the weight-streaming kernel over the members' weight images (a decode-sized launch
+        # costs ~4 us whatever it streams — fq_int4_skinny_linear_multi_f16)
+        problems = []
+        for m, x in zip(modules, inputs):
+            assert type(x) == PackedQuantizedTensor
+            dimg = m._decode_image() if m.in_features == modules[0].in_features and x.quantized_x.shape == q0.shape else None
+            if dimg is None or x.scales_x.dtype != torch.float16 or x.scales_x.numel() != rows:
+                problems = None
+                break
+            ws16, b16 = m._scales16()
+            q = x.quantized_x
+            problems.append((q.reshape(rows, -1).contiguous(), x.scales_x.reshape(-1).contiguous(), dimg, ws16, b16))
+        if problems is not None:
+            ys = ops.int4_skinny_linear_multi(problems)
+            lead = q0.shape[:-1]
+            return [y.view(*lead, m.out_features) for y, m in zip(ys, modules)]
     ok = 1 <= len(modules) <= 4 and q0.is_cuda and not ops.skinny_supported(rows, modules[0].in_features)
     for m, x in zip(modules, inputs):
         assert type(x) == PackedQuantizedTensor

@@ -1357,6 +1357,37 @@ def int4_skinny_linear(x: torch.Tensor, x_scale: torch.Tensor, w_image: torch.Te
     return y
 
 
+def int4_skinny_linear_multi(problems) -> list:
+    """Up to four decode-sized Linear4bit problems that share M (<= 128) and K — q / k / v, or up / gate of one layer — as ONE launch of the
+    weight-streaming kernel (fq_int4_skinny_linear_multi_f16). ``problems``: a sequence of (x packed [M, K/2], x_scale [M], w_image
+    (int4_to_frag), w_scale [N], bias [N] or None) -> a list of fp16 [M, N] tensors, each bit-identical to int4_skinny_linear()."""
+    n = len(problems)
+    if not 1 <= n <= 4:
+        raise ValueError("int4_skinny_linear_multi: 1..4 problems")
+    x0 = problems[0][0]
+    M, K = x0.shape[0], x0.shape[1] * 2
+    Ns = []
+    for x, xs, wimg, ws, b in problems:
+        _chk(x, "x", torch.uint8), _chk(xs, "x_scale"), _chk(ws, "w_scale")
+        if b is not None:
+            _chk(b, "bias")
+        if x.dim() != 2 or x.shape != x0.shape:
+            raise RuntimeError("int4_skinny_linear_multi: the problems must share M and K (x [M, K/2])")
+        N = ws.numel()
+        if xs.numel() != M or (b is not None and b.numel() != N) or wimg.numel() != int(lib.fq_int4_frag_bytes(N, K)):
+            raise RuntimeError("int4_skinny_linear_multi: scale / bias / image sizes do not match M / N / K")
+        Ns.append(N)
+    ys = [torch.empty((M, N), dtype=torch.float16, device=x0.device) for N in Ns]
+    if M == 0:
+        return ys
+    VP = ctypes.c_void_p * n
+    tab = lambda k: VP(*[None if pr[k] is None else pr[k].data_ptr() for pr in problems])
+    with _on(x0.device):
+        check(lib.fq_int4_skinny_linear_multi_f16(n, tab(0), tab(1), tab(2), tab(3), tab(4), M, (ctypes.c_int * n)(*Ns), K,
+                                                  VP(*[y.data_ptr() for y in ys]), _stream(x0)))
+    return ys
+
+
 def int4_to_bf6(q: torch.Tensor, weights: bool = False) -> torch.Tensor:
     """Packed INT4 [rows, K/2] -> the BF6 operand image of the FP6-path GEMM (fq_int4_to_bf6). ``weights``: the image of
     a Linear4bit.weight (convert once per layer); else of packed activations. K % 64 == 0."""

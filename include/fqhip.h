@@ -368,6 +368,16 @@ int fq_int4_to_frag(const void* w, int N, int K, void* image, void* stream);
 int fq_int4_skinny_gemm_i32(const void* x, const void* w_image, int64_t M, int N, int K, void* c, void* stream);
 int fq_int4_skinny_linear_f16(const void* x, const void* x_scale, const void* w_image, const void* w_scale,
                               const void* bias, int64_t M, int N, int K, void* y, void* stream);
+/*
+ * (round 5) Up to FOUR decode-sized Linear4bit problems that share M (<= 128) and K — q / k / v, or up / gate, of one decoder layer
+ * (deploy/nn/linear.py:40-54 runs once per projection; modeling_llama.py:66-78, 268-280), each with its own packed activations,
+ * weight image (fq_int4_to_frag), scales, bias and output — as ONE launch of the weight-streaming kernel: the feature tiles of the
+ * problems side by side in the grid. Bit-identical to n calls of fq_int4_skinny_linear_f16 (a decode-sized launch costs ~4 us whatever
+ * it streams: three launches are three of those). Tables of n pointers; bias may be NULL (no problem has one) or hold NULL entries.
+ */
+int fq_int4_skinny_linear_multi_f16(int n, const void* const* x, const void* const* x_scale, const void* const* w_image,
+                                    const void* const* w_scale, const void* const* bias, int64_t M, const int* N, int K, void* const* y,
+                                    void* stream);
 
 /*
  * The same GEMM / Linear4bit on the FP6 matrix path (v_mfma_scale_f32_32x32x64_f8f6f4, both operands BF6 = E3M2, unit

@@ -119,6 +119,73 @@ def test_skinny_linear_equals_tile_kernel(ops, M, N, K, bias):
     assert torch.equal(y, ops.int4_linear(x, sx, w, sw, b))
 
 
+@pytest.mark.parametrize("M,K,Ns,bias", [(1, 4096, (4096, 1024, 1024), (False, False, False)), (16, 4096, (14336, 14336), (True, False)),
+                                         (33, 256, (272, 48, 40, 512), (True, True, False, True)), (128, 1024, (1024, 96), (False, True)),
+                                         (7, 14336, (4096,), (True,))])
+def test_skinny_multi_problem_launch_equals_the_single_launches(ops, M, K, Ns, bias):
+    """fq_int4_skinny_linear_multi_f16 (round 5): up to four decode-sized problems sharing M and K as ONE launch, each with its own
+    activations, weight image, scales, bias and output — bit for bit the separate fq_int4_skinny_linear_f16 launches (and, through
+    test_skinny_linear_equals_tile_kernel, the tile kernel and the integer oracle)."""
+    gen = torch.Generator().manual_seed(M * 11 + K + sum(Ns))
+    problems, want = [], []
+    for N, hb in zip(Ns, bias):
+        x = torch.from_numpy(rand_packed(gen, M, K)[0]).cuda()
+        w = torch.from_numpy(rand_packed(gen, N, K)[0]).cuda()
+        sx = (torch.rand(M, generator=gen) * 0.05 + 0.001).half().cuda()
+        sw = (torch.rand(N, generator=gen) * 0.02 + 0.0005).half().cuda()
+        b = torch.randn(N, generator=gen).half().cuda() if hb else None
+        img = ops.int4_to_frag(w)
+        problems.append((x, sx, img, sw, b))
+        want.append(ops.int4_skinny_linear(x, sx, img, sw, b, N))
+    got = ops.int4_skinny_linear_multi(problems)
+    assert len(got) == len(Ns)
+    for y, ref, N in zip(got, want, Ns):
+        assert y.shape == (M, N) and torch.equal(y, ref)
+
+
+def test_skinny_multi_refuses_what_it_cannot_run(ops):
+    gen = torch.Generator().manual_seed(3)
+    x = torch.from_numpy(rand_packed(gen, 4, 256)[0]).cuda()
+    w = torch.from_numpy(rand_packed(gen, 64, 256)[0]).cuda()
+    s4, s64 = torch.ones(4, dtype=torch.float16, device="cuda"), torch.ones(64, dtype=torch.float16, device="cuda")
+    one = (x, s4, ops.int4_to_frag(w), s64, None)
+    with pytest.raises(ValueError):
+        ops.int4_skinny_linear_multi([one] * 5)
+    with pytest.raises(RuntimeError):                      # another M
+        ops.int4_skinny_linear_multi([one, (x[:2].contiguous(), s4[:2].contiguous(), one[2], s64, None)])
+    big = torch.zeros(129, 128, dtype=torch.uint8, device="cuda")
+    with pytest.raises(Exception):                         # M > 128: FQ_EUNSUPPORTED
+        ops.int4_skinny_linear_multi([(big, torch.ones(129, dtype=torch.float16, device="cuda"), one[2], s64, None)])
+
+
+def test_linear4bit_multi_takes_one_skinny_launch_for_decode_batches(ops):
+    """deploy.nn.linear.linear4bit_multi at decode sizes: q / k / v modules on their own packed inputs == m(x) each."""
+    import flatquant_amd.deploy as deploy
+    from flatquant_amd.deploy.nn.linear import linear4bit_multi
+    gen = torch.Generator().manual_seed(12)
+    mods, ins = [], []
+    for n_out, hb in ((512, True), (128, False), (128, True)):
+        lin = deploy.nn.Linear4bit(256, n_out, bias=hb).cuda()
+        lin.weight.copy_(torch.from_numpy(rand_packed(gen, n_out, 256)[0]))
+        lin.weight_scales.copy_((torch.rand(n_out, 1, generator=gen) * 0.02 + 0.001))
+        if hb:
+            lin.bias.copy_(torch.randn(n_out, generator=gen).half())
+        mods.append(lin)
+        ins.append(deploy.PackedQuantizedTensor(torch.from_numpy(rand_packed(gen, 6, 256)[0]).cuda().reshape(3, 2, 128),
+                                                (torch.rand(3, 1, 2, generator=gen) * 0.05 + 0.001).half().cuda()))
+    want = [m(x) for m, x in zip(mods, ins)]
+    calls = []
+    real = ops.int4_skinny_linear_multi
+    ops.int4_skinny_linear_multi = lambda pr: calls.append(len(pr)) or real(pr)
+    try:
+        got = linear4bit_multi(mods, ins)
+    finally:
+        ops.int4_skinny_linear_multi = real
+    assert calls == [3]
+    for y, ref in zip(got, want):
+        assert y.shape == ref.shape and torch.equal(y, ref)
+
+
 def test_module_takes_the_skinny_path_for_decode_batches(ops):
     import flatquant_amd.deploy as deploy
     gen = torch.Generator().manual_seed(9)

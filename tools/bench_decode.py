@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--bsz", type=int, default=16)
     ap.add_argument("--cache", type=int, default=2048, help="cached tokens per request")
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--single", action="store_true", help="one launch per projection (rounds 1-4) instead of the multi-problem launches")
     a = ap.parse_args()
     hidden, ffn, heads, kv_heads, hd = 4096, 14336, 32, 8, 128
     dev = torch.device("cuda")
@@ -62,14 +63,17 @@ def main():
 
     def step(h):
         pq, pk, pv = deploy.nn.fused_forward(h, qkv_t, norm=norm)
-        q, k, v = q_l(pq), k_l(pk), v_l(pv)
+        q, k, v = deploy.nn.linear.linear4bit_multi([q_l, k_l, v_l], [pq, pk, pv]) if not a.single else (q_l(pq), k_l(pk), v_l(pv))
         attend = cache.update(k.view(a.bsz, 1, kv_heads, hd), v.view(a.bsz, 1, kv_heads, hd), 0, dict(kw))
         att_t = attend(q.view(a.bsz, 1, heads, hd), transposed=True)                # [bsz, 1, hd, heads]
         po = o_t(att_t)
         po.quantized_x = po.quantized_x.contiguous().reshape(a.bsz, 1, -1)
         h2 = o_l(po)
         pu, pg = deploy.nn.fused_forward(h2, ug_t, norm=norm)
-        return down_l(down_t(gate_l(pg), up=up_l(pu)))
+        if a.single:
+            return down_l(down_t(gate_l(pg), up=up_l(pu)))
+        yu, yg = deploy.nn.linear.linear4bit_multi([up_l, gate_l], [pu, pg])
+        return down_l(down_t(yg, up=yu))
 
     # eager warm-up (fills the weight-image / workspace / scalar caches), rewinding the cache length each time
     for _ in range(3):
