@@ -146,12 +146,19 @@ __device__ __forceinline__ float kv_qk(const f16x8 (&qa)[4], const uint4 kq, uin
 // Decode attention (batch_decode_i4 / batch_decode_f16): see the head of this file. Lane l = RPW part + slot: row `slot` of the wave's
 // RPW rows, chunk `part` (32 features) of that row: 16 bytes of the INT4 cache (a wave's load is RPW consecutive rows = 1 KB), or 64
 // bytes = four 16-byte loads of the fp16 configuration (F16: no (scale, zero), no unpacking — the loaded dwords ARE the B fragments).
+// the split decode's workspace: a counter per (request, head) pair first (a fixed place, whatever the split count), the states behind them
+__device__ __forceinline__ float* kv_states(float* ws, size_t pairs) { return ws + ((pairs + 3) & ~(size_t)3); }
+
 #ifndef KV_DEPTH
 #define KV_DEPTH 1   // steps of rows in flight under a step's arithmetic (measured: 1, 2, 3 within 2 % — profiles/r05_kvdecode_timing.txt)
 #endif
-template <int HD, int NW, bool UNI, bool F16>
+// SPLIT (round 5): a request's rows over gridDim.z workgroups — with few (request, head) pairs the launch fills a fraction of the chip
+// (one request x 32 heads: 32 of 256 CUs, ~20 us for 9 MB). The workgroups of a pair take the wave-steps round robin (virtual wave
+// blockIdx.z * NW + wave of gridDim.z * NW), each leaves its un-normalised (m, d, o[HD]) in `ws`, and the LAST one to arrive (a counter
+// per pair behind the states, left at zero again) merges them like the states of one workgroup and writes the output.
+template <int HD, int NW, bool UNI, bool F16, bool SPLIT>
 __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restrict__ o, const f16* __restrict__ q, PagedKv p,
-                                                                  const f16* __restrict__ qt, int transpose_out) {
+                                                               const f16* __restrict__ qt, int transpose_out, float* ws) {
     constexpr int QL = HD / 32;        // lanes per cached row: 4 for head_dim 128, 2 for 64
     constexpr int RPW = 64 / QL;       // rows per wave and step: the N of the MFMA (16 / 32)
     constexpr int NS = NW * RPW;       // partial softmax states per workgroup
@@ -212,12 +219,14 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
     // scalar load on its own counter, and the lanes differ by `slot` entries; rows of the last step beyond the sequence lie in the same
     // (allocated) page and are masked. Otherwise every lane walks its own (page, entry) and a row beyond the sequence reads entry 0
     // of the request's last page instead. The loop itself is WAVE-uniform either way (the MFMA wants every lane).
+    const int vwave = SPLIT ? (int)blockIdx.z * NW + wave : wave;        // this wave's place among the pair's waves
+    const int STRIDE = SPLIT ? (int)gridDim.z * NS : NS;                 // rows between two steps of a wave
     int pit, ent;
     if (UNI) {
-        pit = (wave * RPW) / p.page_size;
-        ent = wave * RPW - pit * p.page_size;
+        pit = (vwave * RPW) / p.page_size;
+        ent = vwave * RPW - pit * p.page_size;
     } else {
-        pit = 0, ent = wave * RPW + slot;
+        pit = 0, ent = vwave * RPW + slot;
         while (ent >= p.page_size) {
             ent -= p.page_size;
             ++pit;
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
             page = (size_t)p.indices[valid ? pg0 + pit : pg1 - 1];
             entry = valid ? (size_t)ent : 0;
         }
-        ent += NS;
+        ent += STRIDE;
         while (ent >= p.page_size) {
             ent -= p.page_size;
             ++pit;
@@ -318,28 +327,28 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
     // of the MFMA with twelve loads in flight). Head and tail (at most 2 (NB - 1) steps) run the conditional form.
     constexpr int NB = KV_DEPTH + 1;
     Rows buf[NB];
-    int64_t base = (int64_t)wave * RPW;
-    if (base + (int64_t)2 * (NB - 1) * NS < seq_len) {
+    int64_t base = (int64_t)vwave * RPW;
+    if (base + (int64_t)2 * (NB - 1) * STRIDE < seq_len) {
 #pragma unroll
-        for (int i = 0; i < NB - 1; ++i) request(base + (int64_t)i * NS, buf[i]);
-        for (; base + (int64_t)2 * (NB - 1) * NS < seq_len; base += (int64_t)NB * NS) {
+        for (int i = 0; i < NB - 1; ++i) request(base + (int64_t)i * STRIDE, buf[i]);
+        for (; base + (int64_t)2 * (NB - 1) * STRIDE < seq_len; base += (int64_t)NB * STRIDE) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                request(base + (int64_t)(i + NB - 1) * NS, buf[(i + NB - 1) % NB]);
-                step(base + (int64_t)i * NS, buf[i]);
+                request(base + (int64_t)(i + NB - 1) * STRIDE, buf[(i + NB - 1) % NB]);
+                step(base + (int64_t)i * STRIDE, buf[i]);
             }
         }
     } else {
 #pragma unroll
         for (int i = 0; i < NB - 1; ++i)
-            if (base + (int64_t)i * NS < seq_len) request(base + (int64_t)i * NS, buf[i]);
+            if (base + (int64_t)i * STRIDE < seq_len) request(base + (int64_t)i * STRIDE, buf[i]);
     }
     // the last (at most 2 (NB - 1)) steps: step j lives in buf[j % NB], the first NB - 1 are in flight
 #pragma unroll
     for (int j = 0; j < 2 * (NB - 1); ++j) {
-        if (j + NB - 1 < 2 * (NB - 1) && base + (int64_t)(j + NB - 1) * NS < seq_len)
-            request(base + (int64_t)(j + NB - 1) * NS, buf[(j + NB - 1) % NB]);
-        if (base + (int64_t)j * NS < seq_len) step(base + (int64_t)j * NS, buf[j % NB]);
+        if (j + NB - 1 < 2 * (NB - 1) && base + (int64_t)(j + NB - 1) * STRIDE < seq_len)
+            request(base + (int64_t)(j + NB - 1) * STRIDE, buf[(j + NB - 1) % NB]);
+        if (base + (int64_t)j * STRIDE < seq_len) step(base + (int64_t)j * STRIDE, buf[j % NB]);
     }
     const int st = wave * RPW + slot;
     if (part == 0) {
@@ -365,7 +374,47 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
             oo += s_o[s][tid] * w;
         }
         const size_t oi = transpose_out ? ((size_t)b * HD + tid) * p.num_heads + head : ((size_t)b * p.num_heads + head) * HD + tid;
-        o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;  // an empty sequence attends to nothing: zeros, not 0/0
+        if (!SPLIT) {
+            o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;  // an empty sequence attends to nothing: zeros, not 0/0
+        } else {
+            // Agent-scope stores (sc1: written through to memory — the XCDs' L2s are not coherent with each other) instead of plain
+            // stores + __threadfence(): the fence is a write-back of the XCD's whole L2 per workgroup (buffer_wbl2), measured +20 us
+            // on a 26 us launch.
+            float* mine = kv_states(ws, (size_t)gridDim.x * gridDim.y) + (((size_t)b * p.num_heads + head) * gridDim.z + blockIdx.z) * (HD + 2);
+            if (tid == 0) {
+                __hip_atomic_store(mine, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine + 1, dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __hip_atomic_store(mine + 2 + tid, oo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (SPLIT) {
+        const int S = (int)gridDim.z;
+        unsigned* cnt = reinterpret_cast<unsigned*>(ws) + (size_t)b * p.num_heads + head;
+        __shared__ unsigned s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's state has reached memory ...
+        __syncthreads();
+        if (tid == 0) s_last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(S - 1);   // ... before it is counted
+        __syncthreads();
+        if (s_last) {
+            if (tid < HD) {
+                const float* all = kv_states(ws, (size_t)gridDim.x * gridDim.y) + ((size_t)b * p.num_heads + head) * S * (HD + 2);
+                auto ld = [](const float* ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };   // (sc1: not this XCD's L2)
+                float mm = -INFINITY;
+                for (int z = 0; z < S; ++z) mm = fmaxf(mm, ld(all + (size_t)z * (HD + 2)));
+                float dd = 0.0f, oo = 0.0f;
+                for (int z = 0; z < S; ++z) {
+                    const float* st_z = all + (size_t)z * (HD + 2);
+                    const float mz = ld(st_z);
+                    const float w = mz == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(mz - mm);
+                    dd += ld(st_z + 1) * w;
+                    oo += ld(st_z + 2 + tid) * w;
+                }
+                const size_t oi = transpose_out ? ((size_t)b * HD + tid) * p.num_heads + head : ((size_t)b * p.num_heads + head) * HD + tid;
+                o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;
+            }
+            if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch finds the counters as this one did
+        }
     }
 }
 
@@ -407,16 +456,41 @@ int fq_launch_kv_append(void* kv_data, void* kv_param, const int* indptr, const 
     return (int)hipGetLastError();
 }
 
+// Split form: how many workgroups share a (request, head) pair, and the workspace they meet in. One pair per workgroup above 128
+// pairs; below, as many as bring the launch to ~256 eight-wave workgroups (one per CU) — but no split shorter than 256 rows when the
+// caller knows the sequence length (seq_hint > 0): a workgroup's fixed work (the query, the merge of its 128 lane states) is worth ~4 steps.
+int fq_kv_decode_splits(int batch, int num_heads, int seq_hint) {
+    const int64_t pairs = (int64_t)batch * num_heads;
+    if (pairs <= 0 || pairs > 128) return 1;
+    int s = (int)(256 / pairs);   // one 8-wave workgroup per CU
+    if (s > 16) s = 16;
+    if (seq_hint > 0) {
+        const int by_len = seq_hint / 256;
+        if (s > by_len) s = by_len;
+    }
+    return s < 2 ? 1 : s;
+}
+int64_t fq_kv_decode_ws_bytes(int batch, int num_heads, int head_dim) {   // for ANY split count this library chooses (<= 16)
+    const int64_t pairs = (int64_t)batch * num_heads;
+    if (pairs <= 0 || pairs > 128) return 0;
+    return ((pairs + 3) & ~(int64_t)3) * (int64_t)sizeof(unsigned) + pairs * 16 * (head_dim + 2) * (int64_t)sizeof(float);
+}
+
 int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, const f16* qt,
-                        int transpose_out, hipStream_t stream, bool f16_cache) {
+                        int transpose_out, hipStream_t stream, bool f16_cache, float* ws, int splits) {
     const PagedKv p = make_kv(kv_data, kv_param, indptr, indices, last, num_layers, layer_idx, num_heads, page_size, head_dim, batch);
-    const dim3 grid((unsigned)batch, (unsigned)num_heads);
-    const bool wide = (int64_t)batch * num_heads < 512;  // fewer than two workgroups per CU: 8 waves each instead of 4 (measured: 158 -> 113 us at 8 x 8192; no gain from 512 up)
+    const bool split = ws != nullptr && splits > 1;
+    const dim3 grid((unsigned)batch, (unsigned)num_heads, split ? (unsigned)splits : 1u);
+    const bool wide = (int64_t)batch * num_heads * (split ? splits : 1) < 512;  // fewer than two workgroups per CU: 8 waves each instead of 4 (measured: 158 -> 113 us at 8 x 8192; no gain from 512 up)
+#define FQ_DEC3(HD_, NW_, UNI_, F16_, SP_)                                                                             \
+    {                                                                                                                 \
+        FQ_RAISE_LDS_CAP((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_, SP_>), lds);                                      \
+        hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_, SP_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out, ws); \
+    }
 #define FQ_DEC2(HD_, NW_, UNI_, F16_)                                                                                  \
     {                                                                                                                 \
-        FQ_RAISE_LDS_CAP((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_>), lds);                                           \
-        hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out); \
+        if (split) FQ_DEC3(HD_, NW_, UNI_, F16_, true) else FQ_DEC3(HD_, NW_, UNI_, F16_, false)                      \
     }
 #define FQ_DEC(HD_, NW_)                                                                                              \
     {                                                                                                                 \
@@ -437,5 +511,6 @@ int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, con
     }
 #undef FQ_DEC
 #undef FQ_DEC2
+#undef FQ_DEC3
     return (int)hipGetLastError();
 }

@@ -191,9 +191,11 @@ class MultiLayerPagedKVCache4Bit:
             keys_t = key_states.to(torch.float16) if tk16 is None else torch.matmul(key_states.to(torch.float16), tk16)
             if self.disable_quant:                                      # :270-274: fp16 rows, (scale, zero) = (1, 0)
                 kq, vq = keys_t.contiguous(), value_states.to(torch.float16).contiguous()
-                one = torch.tensor([1.0, 0.0], dtype=torch.float16, device=kq.device)
-                kp = one.expand(b, added, heads, 2).contiguous()
-                vp = kp
+                pk = (b, added, heads, kq.device)
+                if getattr(self, "_unit_param_key", None) != pk:   # (kept: a host-to-device copy per step otherwise, and no graph capture)
+                    one = torch.tensor([1.0, 0.0], dtype=torch.float16, device=kq.device)
+                    self._unit_param, self._unit_param_key = one.expand(b, added, heads, 2).contiguous(), pk
+                kp = vp = self._unit_param
             else:
                 kq, kp = ops.kv_quant(keys_t.contiguous())
                 vq, vp = ops.kv_quant(value_states.to(torch.float16).contiguous())
@@ -220,6 +222,7 @@ class MultiLayerPagedKVCache4Bit:
                 keys_t = key_states if tk16 is None else torch.matmul(key_states.to(torch.float16), tk16)
             return keys_t, value_states                                 # :280-281,341-344: the un-quantised states for prefill
         assert added == 1
+        length_now = self.length                                          # (an upper bound of every request's rows: the split decode's hint)
 
         def attend(q, transposed=False):
             """q [bsz, 1, heads, head_dim] -> attention output of the same shape; ``transposed`` (extension): as
@@ -232,5 +235,5 @@ class MultiLayerPagedKVCache4Bit:
                 q2 = ops.hadamard(q2.contiguous())
             elif tk_inv_t is not None:                                      # :139-140: ... of the learned K transform, in the launch
                 qt = tk_inv_t.to(q.device, torch.float16).contiguous()
-            return ops.kv_batch_decode(q2.contiguous(), *args, layer_idx, qt, transposed).unsqueeze(1)
+            return ops.kv_batch_decode(q2.contiguous(), *args, layer_idx, qt, transposed, seq_hint=length_now).unsqueeze(1)
         return attend

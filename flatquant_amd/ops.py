@@ -1605,16 +1605,21 @@ def kv_quant_append(k: torch.Tensor, v: torch.Tensor, trans: Optional[torch.Tens
                                         _stream(k)))
 
 
+_KV_SPLIT_WS: dict = {}   # (device index, stream handle, bytes) -> zeroed workspace of the split decode launches (one launch at a time per stream)
+
+
 def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tensor, kv_indptr: torch.Tensor,
                     kv_indices: torch.Tensor, last_page_offset: torch.Tensor, layer_idx: int,
-                    q_trans: Optional[torch.Tensor] = None, transpose_out: bool = False) -> torch.Tensor:
+                    q_trans: Optional[torch.Tensor] = None, transpose_out: bool = False, seq_hint: int = 0, split: bool = True) -> torch.Tensor:
     """batch_decode_i4 (kv_cache.py:98-105): q [batch, heads, head_dim] fp16 -> o of the same shape, attention over each
     request's cached rows (fq_kv_batch_decode_i4[_ex]). ``q_trans`` [head_dim, head_dim]: the query is multiplied by it
-    inside the launch; ``transpose_out``: o comes back as [batch, head_dim, heads]."""
+    inside the launch; ``transpose_out``: o comes back as [batch, head_dim, heads]. With at most 128 (request, head) pairs the rows
+    of a request are split over several workgroups (fq_kv_batch_decode_split, round 5; ``seq_hint``: the longest request, 0 = unknown;
+    ``split=False``: never) — same results up to the order of fp32 additions."""
     _chk(q, "q"), _chk(kv_data, "kv_data", kv_data.dtype), _chk(kv_param, "kv_param")
     n_layers, heads, page_size, hd = _kv_geometry(kv_data)
     batch = _chk_kv_index(kv_indptr, kv_indices, last_page_offset)
-    decode = lib.fq_kv_batch_decode_f16_ex if kv_data.dtype == torch.float16 else lib.fq_kv_batch_decode_i4_ex
+    f16_cache = kv_data.dtype == torch.float16
     if q.shape != (batch, heads, hd):
         raise ValueError(f"q must be [{batch}, {heads}, {hd}]")
     if q_trans is not None:
@@ -1625,6 +1630,20 @@ def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tens
     if batch == 0:
         return o
     with _on(q.device):
+        nbytes = int(lib.fq_kv_decode_workspace_bytes(batch, heads, hd)) if split else 0
+        if nbytes > 0:
+            stream = _stream(q)
+            key = (q.device.index, stream.value, nbytes)
+            ws = _KV_SPLIT_WS.get(key)
+            if ws is None:
+                if len(_KV_SPLIT_WS) >= 16:
+                    _KV_SPLIT_WS.pop(next(iter(_KV_SPLIT_WS)))
+                ws = _KV_SPLIT_WS[key] = torch.zeros((nbytes,), dtype=torch.uint8, device=q.device)
+            check(lib.fq_kv_batch_decode_split(1 if f16_cache else 0, _ptr(o), _ptr(q), _ptr(q_trans), 1 if transpose_out else 0, _ptr(kv_data),
+                                               _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
+                                               n_layers, layer_idx, heads, page_size, hd, batch, int(seq_hint), _ptr(ws), nbytes, stream))
+            return o
+        decode = lib.fq_kv_batch_decode_f16_ex if f16_cache else lib.fq_kv_batch_decode_i4_ex
         check(decode(_ptr(o), _ptr(q), _ptr(q_trans), 1 if transpose_out else 0, _ptr(kv_data),
                      _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
                      n_layers, layer_idx, heads, page_size, hd, batch, _stream(q)))

@@ -615,6 +615,23 @@ int fq_kv_append_f16(void* kv_data, void* kv_param, const void* kv_indptr, const
 int fq_kv_batch_decode_f16(void* o, const void* q, const void* kv_data, const void* kv_param, const void* kv_indptr,
                            const void* kv_indices, const void* last_page_offset, int num_layers, int layer_idx,
                            int num_heads, int page_size, int head_dim, int batch_size, void* stream);
+/*
+ * (round 5) The same decode attention with a request's rows SPLIT over several workgroups: with few (request, head) pairs — one request
+ * of a 32-head model is 32 workgroups on a 256-CU part — the launch above streams the cache through a fraction of the chip (the
+ * reference's own sweep, benchmarks/qattention_benchmark.py:150-153, starts at batch size 1; FlashInfer partitions the sequence the same way, decode.cuh's
+ * partition-kv path). The library picks the split count from batch_size x num_heads (1 above 128 pairs: then this IS the launch
+ * above) and from seq_hint, the caller's idea of the longest request (0: unknown; no split is made shorter than 256 rows); each
+ * workgroup leaves its partial softmax state in `workspace`, the last one to arrive merges them. Results equal the unsplit launch up to
+ * the order of fp32 additions.
+ *   workspace: fq_kv_decode_workspace_bytes(batch_size, num_heads, head_dim) bytes (0: this geometry is never split), 16-byte aligned,
+ *   ZEROED once before its first use (the launches leave it as they found it), used by one launch at a time. NULL: no split.
+ *   fp16_cache != 0: the fp16 configuration (kv_data as fq_kv_append_f16 lays it out; kv_param unused).
+ */
+int64_t fq_kv_decode_workspace_bytes(int batch_size, int num_heads, int head_dim);
+int fq_kv_batch_decode_split(int fp16_cache, void* o, const void* q, const void* q_trans, int transpose_out, const void* kv_data,
+                             const void* kv_param, const void* kv_indptr, const void* kv_indices, const void* last_page_offset,
+                             int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch_size, int seq_hint,
+                             void* workspace, int64_t workspace_bytes, void* stream);
 int fq_kv_batch_decode_f16_ex(void* o, const void* q, const void* q_trans, int transpose_out, const void* kv_data,
                               const void* kv_param, const void* kv_indptr, const void* kv_indices,
                               const void* last_page_offset, int num_layers, int layer_idx, int num_heads, int page_size,

@@ -426,3 +426,60 @@ def test_cache_class_against_the_reference_class_calls(ops, golden, cfg):
             assert (np.abs(o - want).max(axis=-1) / np.abs(want).max(axis=-1)).max() <= 3e-3
         ci += 1
     assert ci == int(g[f"{cfg}_n_calls"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 5: a request's rows split over several workgroups (fq_kv_batch_decode_split)
+@pytest.mark.parametrize("fp16", [False, True])
+@pytest.mark.parametrize("bsz,heads,hd,page,lens", [(1, 32, 128, 2048, [2048]), (2, 4, 128, 16, [700, 333]), (3, 8, 64, 32, [65, 1000, 1]),
+                                                   (1, 2, 128, 8, [523]), (4, 64, 128, 256, [256, 255, 257, 3]), (2, 3, 128, 2, [37, 90])])
+def test_split_decode_equals_the_unsplit_launch(ops, fp16, bsz, heads, hd, page, lens):
+    """With at most 128 (request, head) pairs ops.kv_batch_decode takes the split launch: the partial states of a pair's workgroups meet in a
+    workspace and the last one merges them — the unsplit launch's result up to the order of fp32 additions, for both cache configurations,
+    ragged lengths (requests shorter than a split's share), pages a wave's rows straddle, the query transform and the transposed output;
+    a second launch finds the counters at zero again."""
+    g = torch.Generator(device="cuda").manual_seed(bsz * 100 + heads + page)
+    n_pg = [(n + page - 1) // page for n in lens]
+    tot = sum(n_pg)
+    if fp16:
+        data = torch.randn(tot, 2, 2, heads, page, hd, generator=g, device="cuda").half()
+    else:
+        data = torch.randint(0, 256, (tot, 2, 2, heads, page, hd // 2), generator=g, device="cuda", dtype=torch.uint8)
+    par = (torch.rand(tot, 2, 2, heads, page, 2, generator=g, device="cuda") * 0.2 + 0.05).half()
+    indptr = torch.tensor(np.concatenate([[0], np.cumsum(n_pg)]), dtype=torch.int32, device="cuda")
+    indices = torch.randperm(tot, generator=g, device="cuda").to(torch.int32)
+    last = torch.tensor([(n - 1) % page + 1 for n in lens], dtype=torch.int32, device="cuda")
+    q = torch.randn(bsz, heads, hd, generator=g, device="cuda").half()
+    Tq = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half()
+    for hint in (0, max(lens)):
+        for kw in ({}, {"q_trans": Tq, "transpose_out": True}):
+            ref = ops.kv_batch_decode(q, data, par, indptr, indices, last, 1, split=False, **kw).float()
+            for _ in range(2):
+                got = ops.kv_batch_decode(q, data, par, indptr, indices, last, 1, seq_hint=hint, **kw).float()
+                assert got.shape == ref.shape and torch.isfinite(got).all()
+                err = (got - ref).abs().amax() / ref.abs().amax()
+                assert err.item() <= 1e-3, (hint, kw.keys(), err.item())
+
+
+def test_split_decode_workspace_contract(ops):
+    """fq_kv_decode_workspace_bytes: 0 beyond 128 pairs (never split), else room for 16 splits; the launch refuses a workspace that is too small."""
+    import ctypes
+    from flatquant_amd import _lib
+    lib = _lib.lib
+    assert lib.fq_kv_decode_workspace_bytes(16, 32, 128) == 0 and lib.fq_kv_decode_workspace_bytes(1, 1, 96) == -1
+    need = lib.fq_kv_decode_workspace_bytes(2, 32, 128)
+    assert need == 64 * 4 + 64 * 16 * 130 * 4
+    data = torch.zeros(2, 1, 2, 32, 16, 64, dtype=torch.uint8, device="cuda")
+    par = torch.ones(2, 1, 2, 32, 16, 2, dtype=torch.float16, device="cuda")
+    z = torch.tensor([0, 1, 2], dtype=torch.int32, device="cuda")
+    one = torch.tensor([16, 16], dtype=torch.int32, device="cuda")
+    q = torch.zeros(2, 32, 128, dtype=torch.float16, device="cuda")
+    o = torch.empty_like(q)
+    ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    args = lambda w, n: (0, o.data_ptr(), q.data_ptr(), None, 0, data.data_ptr(), par.data_ptr(), z.data_ptr(), z.data_ptr(), one.data_ptr(),
+                         1, 0, 32, 16, 128, 2, 0, w, n, None)
+    assert lib.fq_kv_batch_decode_split(*args(ws.data_ptr(), need - 16)) == _lib.FQ_EINVAL
+    assert lib.fq_kv_batch_decode_split(*args(ws.data_ptr(), need)) == 0
+    assert lib.fq_kv_batch_decode_split(*args(None, 0)) == 0              # no workspace: the unsplit launch
+    torch.cuda.synchronize()
+    assert int(ws.view(torch.int32)[:64].abs().sum()) == 0                # the counters are zero again
