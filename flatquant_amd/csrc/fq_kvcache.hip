@@ -149,6 +149,9 @@ __device__ __forceinline__ float kv_qk(const f16x8 (&qa)[4], const uint4 kq, uin
 // the split decode's workspace: a counter per (request, head) pair first (a fixed place, whatever the split count), the states behind them
 __device__ __forceinline__ float* kv_states(float* ws, size_t pairs) { return ws + ((pairs + 3) & ~(size_t)3); }
 
+#ifndef KV_ABL
+#define KV_ABL 0   // measurement builds: 1 no row loop, 2 no state sums in the merge
+#endif
 #ifndef KV_DEPTH
 #define KV_DEPTH 1   // steps of rows in flight under a step's arithmetic (measured: 1, 2, 3 within 2 % — profiles/r05_kvdecode_timing.txt)
 #endif
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
     // of the MFMA with twelve loads in flight). Head and tail (at most 2 (NB - 1) steps) run the conditional form.
     constexpr int NB = KV_DEPTH + 1;
     Rows buf[NB];
-    int64_t base = (int64_t)vwave * RPW;
+    int64_t base = (KV_ABL & 1) ? seq_len : (int64_t)vwave * RPW;
     if (base + (int64_t)2 * (NB - 1) * STRIDE < seq_len) {
 #pragma unroll
         for (int i = 0; i < NB - 1; ++i) request(base + (int64_t)i * STRIDE, buf[i]);
@@ -360,18 +363,49 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
 #pragma unroll
         for (int e = 0; e < 8; ++e) s_o[st][part * 32 + w * 8 + feat(e)] = acc[w * 8 + e] - zacc;
     __syncthreads();
-    if (tid < HD) {   // state.cuh merge: rescale every partial state to the common maximum
-        // (bounded unrolling: fully unrolled for NS = 64, these loops hoisted 128 LDS reads and pushed a 4-wave build from 198 to 260
-        //  VGPRs — one wave per SIMD, 48 -> 71 us at 16 x 2048 — in round 2)
-        float mm = -INFINITY;
+    // state.cuh merge: every partial state rescaled to the common maximum. Rounds 1-5 let 128 threads walk all NS states (two serial loops
+    // of NS LDS round trips): 7 of the 10.8 us of a launch over 64 cached tokens (ablation builds, tools/gpu_call.sh r05c29). Now (a) the
+    // maximum by a wave reduction, every state's weight computed once by thread s; (b) ALL threads sum: thread (feature f, chunk c) the
+    // states of chunk c; (c) the NCH partial sums per feature.
+    constexpr int THREADS = NW * 64, NCH = THREADS / HD, CH = NS / NCH;
+    static_assert(NCH >= 1 && NS % NCH == 0 && NS <= THREADS, "merge geometry");
+    float* s_w = s_q + HD;                  // [NS] weights
+    float* s_red = s_w + NS;                // [NW] wave maxima
+    float* s_pd = s_red + NW;               // [NCH] partial denominators
+    float (*s_po)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(s_pd + NCH);   // [NCH][HD + 1] partial numerators
+    const float mloc = tid < NS ? s_m[tid] : -INFINITY;
+    const float wmax = fq_wave_max(mloc);
+    if (lane == 0) s_red[wave] = wmax;
+    __syncthreads();
+    float mm = s_red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mm = fmaxf(mm, s_red[w]);
+    if (tid < NS) {
+        const float w = mloc == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(mloc - mm);
+        s_w[tid] = w;
+        s_d[tid] *= w;
+    }
+    __syncthreads();
+    {
+        const int f = tid % HD, c = tid / HD;
+        float oo = 0.0f, dd = 0.0f;
+        if (!(KV_ABL & 2)) {
 #pragma unroll 8
-        for (int s = 0; s < NS; ++s) mm = fmaxf(mm, s_m[s]);
+            for (int s = c * CH; s < (c + 1) * CH; ++s) {
+                oo = __builtin_fmaf(s_o[s][f], s_w[s], oo);
+                dd += s_d[s];
+            }
+        }
+        s_po[c][f] = oo;
+        if (f == 0) s_pd[c] = dd;
+    }
+    __syncthreads();
+    if (tid < HD) {
         float dd = 0.0f, oo = 0.0f;
-#pragma unroll 8
-        for (int s = 0; s < NS; ++s) {
-            const float w = s_m[s] == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(s_m[s] - mm);
-            dd += s_d[s] * w;
-            oo += s_o[s][tid] * w;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            dd += s_pd[c];
+            oo += s_po[c][tid];
         }
         const size_t oi = transpose_out ? ((size_t)b * HD + tid) * p.num_heads + head : ((size_t)b * p.num_heads + head) * HD + tid;
         if (!SPLIT) {
@@ -400,15 +434,21 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
             if (tid < HD) {
                 const float* all = kv_states(ws, (size_t)gridDim.x * gridDim.y) + ((size_t)b * p.num_heads + head) * S * (HD + 2);
                 auto ld = [](const float* ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };   // (sc1: not this XCD's L2)
+                float mz[16], dz[16], oz[16];      // every load first (S <= 16 round trips side by side, not one after the other)
+#pragma unroll
+                for (int z = 0; z < 16; ++z) {
+                    const float* st_z = all + (size_t)(z < S ? z : 0) * (HD + 2);
+                    mz[z] = ld(st_z), dz[z] = ld(st_z + 1), oz[z] = ld(st_z + 2 + tid);
+                }
                 float mm = -INFINITY;
-                for (int z = 0; z < S; ++z) mm = fmaxf(mm, ld(all + (size_t)z * (HD + 2)));
+#pragma unroll
+                for (int z = 0; z < 16; ++z) mm = z < S ? fmaxf(mm, mz[z]) : mm;
                 float dd = 0.0f, oo = 0.0f;
-                for (int z = 0; z < S; ++z) {
-                    const float* st_z = all + (size_t)z * (HD + 2);
-                    const float mz = ld(st_z);
-                    const float w = mz == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(mz - mm);
-                    dd += ld(st_z + 1) * w;
-                    oo += ld(st_z + 2 + tid) * w;
+#pragma unroll
+                for (int z = 0; z < 16; ++z) {
+                    const float w = (z >= S || mz[z] == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(mz[z] - mm);
+                    dd += dz[z] * w;
+                    oo += oz[z] * w;
                 }
                 const size_t oi = transpose_out ? ((size_t)b * HD + tid) * p.num_heads + head : ((size_t)b * p.num_heads + head) * HD + tid;
                 o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;
@@ -494,7 +534,8 @@ int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, con
     }
 #define FQ_DEC(HD_, NW_)                                                                                              \
     {                                                                                                                 \
-        constexpr size_t lds = sizeof(float) * ((size_t)(NW_ * (64 / (HD_ / 32))) * (HD_ + 1 + 2) + HD_);             \
+        constexpr size_t ns_ = (size_t)(NW_ * (64 / (HD_ / 32))), nch_ = (size_t)NW_ * 64 / HD_;                      \
+        constexpr size_t lds = sizeof(float) * (ns_ * (HD_ + 1 + 2) + HD_ + ns_ + NW_ + nch_ + nch_ * (HD_ + 1));     \
         const bool uni = page_size % (64 / (HD_ / 32)) == 0;   /* a wave's rows never straddle a page */              \
         if (f16_cache) {                                                                                              \
             if (uni) FQ_DEC2(HD_, NW_, true, true) else FQ_DEC2(HD_, NW_, false, true)                                \

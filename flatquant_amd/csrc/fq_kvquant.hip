@@ -205,63 +205,80 @@ __global__ __launch_bounds__(256) void fq_kv_quant_kernel(KvIO io, const f16* __
 #pragma unroll
         for (int s = 0; s < KS; ++s) dst[s] = __builtin_bit_cast(f16x8, xp[2 * s + h]);
     };
+    const bool small = rows <= 0x7FFFFFFF;   // 32-bit index arithmetic (a 64-bit division is ~100 instructions, four of them per row)
+    // destination(s) of a lane's row: the dense row, or `group` rows of the paged cache (two dependent page-table round trips)
+    struct Dest {       // group copy g lives g * page_size entries further (cache head hs * group + g of the same page and entry)
+        uint8_t* q;
+        unsigned* p;
+        int n;
+    };
+    auto locate = [&](int64_t tile, Dest& d) {
+        const int64_t row = tile * 32 + c;
+        const int64_t lrow = row < rows ? row : rows - 1;
+        d.n = 1;
+        if (io.data == nullptr) {
+            d.q = q_out + row * (HD / 2);
+            d.p = reinterpret_cast<unsigned*>(param + row * 2);
+            return;
+        }
+        int64_t t;
+        int hs, b, j;
+        if (small) {
+            const unsigned lr = (unsigned)lrow, t32 = lr / (unsigned)io.src_heads, b32 = t32 / (unsigned)io.added;
+            t = t32, hs = (int)(lr - t32 * (unsigned)io.src_heads), b = (int)b32, j = (int)(t32 - b32 * (unsigned)io.added);
+        } else {
+            t = lrow / io.src_heads, hs = (int)(lrow - t * io.src_heads);
+            b = (int)(t / io.added), j = (int)(t - (int64_t)b * io.added);
+        }
+        const int pgb = io.indptr[b];
+        const int64_t seq_len = (int64_t)(io.indptr[b + 1] - pgb - 1) * io.page_size + io.last[b];
+        const int64_t pos = seq_len - io.added + j;
+        int64_t pq;
+        int entry_i;
+        if ((uint64_t)pos <= 0x7FFFFFFFu) {
+            const unsigned p32 = (unsigned)pos, q32 = p32 / (unsigned)io.page_size;
+            pq = q32, entry_i = (int)(p32 - q32 * (unsigned)io.page_size);
+        } else {
+            pq = pos / io.page_size, entry_i = (int)(pos - pq * io.page_size);
+        }
+        const size_t page = (size_t)io.indices[pgb + pq];
+        const size_t entry = (size_t)entry_i;
+        d.n = io.group;
+        const size_t e = (((page * io.num_layers + io.layer_idx) * 2 + which) * io.num_heads + (size_t)hs * io.group) * io.page_size + entry;
+        d.q = io.data + e * (HD / 2);
+        d.p = reinterpret_cast<unsigned*>(io.pparam) + e;
+    };
+    // A decode step is ONE tile per wave and two workgroups per launch: every dependent round trip of this kernel is exposed there. So
+    // the first rows and their destinations are requested before the matrix is staged (the values' workgroups, which == 1, never use it),
+    // and the next tile's during the current one.
     f16x8 xn[KS];
+    Dest dn;
     {
         const int64_t t0 = (int64_t)blockIdx.x * 4 + (tid >> 6);
-        if (t0 < n_tiles) fetch(t0, xn);
+        if (t0 < n_tiles) {
+            fetch(t0, xn);
+            locate(t0, dn);
+        }
     }
-    // (behind the first rows' loads: a decode step is ONE tile per wave and two workgroups per launch — every dependent round trip
-    //  of this kernel is exposed there. The values' workgroups (which == 1) never use the matrix.)
     if (TRANS && do_trans) kv_stage_tfrag<HD, f16>(T, tfrag, traw, tid);
-    const bool small = rows <= 0x7FFFFFFF;   // 32-bit index arithmetic (a 64-bit division is ~100 instructions, four of them per row)
     for (int64_t tile = (int64_t)blockIdx.x * 4 + (tid >> 6); tile < n_tiles; tile += tstep) {
         const int64_t row = tile * 32 + c;
         const bool ok = row < rows;
-        const int64_t lrow = ok ? row : rows - 1;
-        // destination(s) of this lane's row: the dense row, or `group` rows of the paged cache — located FIRST: the page-table loads
-        // (two dependent round trips) run under the transform and the quantiser instead of behind them
         uint8_t* qdst[4];
         unsigned* pdst[4];
-        int ndst = 1;
-        if (io.data == nullptr) {
-            qdst[0] = q_out + row * (HD / 2);
-            pdst[0] = reinterpret_cast<unsigned*>(param + row * 2);
-        } else {
-            int64_t t;
-            int hs, b, j;
-            if (small) {
-                const unsigned lr = (unsigned)lrow, t32 = lr / (unsigned)io.src_heads, b32 = t32 / (unsigned)io.added;
-                t = t32, hs = (int)(lr - t32 * (unsigned)io.src_heads), b = (int)b32, j = (int)(t32 - b32 * (unsigned)io.added);
-            } else {
-                t = lrow / io.src_heads, hs = (int)(lrow - t * io.src_heads);
-                b = (int)(t / io.added), j = (int)(t - (int64_t)b * io.added);
-            }
-            const int pgb = io.indptr[b];
-            const int64_t seq_len = (int64_t)(io.indptr[b + 1] - pgb - 1) * io.page_size + io.last[b];
-            const int64_t pos = seq_len - io.added + j;
-            int64_t pq;
-            int entry_i;
-            if ((uint64_t)pos <= 0x7FFFFFFFu) {
-                const unsigned p32 = (unsigned)pos, q32 = p32 / (unsigned)io.page_size;
-                pq = q32, entry_i = (int)(p32 - q32 * (unsigned)io.page_size);
-            } else {
-                pq = pos / io.page_size, entry_i = (int)(pos - pq * io.page_size);
-            }
-            const size_t page = (size_t)io.indices[pgb + pq];
-            const size_t entry = (size_t)entry_i;
-            ndst = io.group;
+        const int ndst = dn.n;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const size_t e = (((page * io.num_layers + io.layer_idx) * 2 + which) * io.num_heads + (size_t)hs * io.group + (g < ndst ? g : 0)) *
-                                     io.page_size + entry;
-                qdst[g] = io.data + e * (HD / 2);
-                pdst[g] = reinterpret_cast<unsigned*>(io.pparam) + e;
-            }
+        for (int g = 0; g < 4; ++g) {
+            qdst[g] = dn.q + (size_t)g * io.page_size * (HD / 2);
+            pdst[g] = dn.p + (size_t)g * io.page_size;
         }
         f16x8 xf[KS];  // chunk 2s + h of the row (8 consecutive columns each)
 #pragma unroll
         for (int s = 0; s < KS; ++s) xf[s] = xn[s];
-        if (tile + tstep < n_tiles) fetch(tile + tstep, xn);
+        if (tile + tstep < n_tiles) {
+            fetch(tile + tstep, xn);
+            locate(tile + tstep, dn);
+        }
 
         f16 v[NTL][16];  // TRANS: columns nt*32 + 16h + r;  else: v[s/2][(s&1)*8 + j] = column (2s + h)*8 + j
         if (TRANS && do_trans) {

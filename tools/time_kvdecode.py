@@ -25,7 +25,8 @@ def case(bsz, seq, heads=32, hd=128, page=2048, fp16=False, rounds=5, steps=50):
     indices = torch.randperm(bsz * n_pg, generator=g, device="cuda").to(torch.int32)
     last = torch.full((bsz,), (seq - 1) % page + 1, device="cuda", dtype=torch.int32)
     q = torch.randn(bsz, heads, hd, generator=g, device="cuda").half()
-    fn = lambda: ops.kv_batch_decode(q, data, par, indptr, indices, last, 0)
+    split = os.environ.get("SPLIT", "1") != "0"   # SPLIT=0: one workgroup per (request, head) pair at every size
+    fn = lambda: ops.kv_batch_decode(q, data, par, indptr, indices, last, 0, seq_hint=seq, split=split)
     for _ in range(10):
         fn()
     torch.cuda.synchronize()
