@@ -1605,7 +1605,7 @@ def kv_quant_append(k: torch.Tensor, v: torch.Tensor, trans: Optional[torch.Tens
                                         _stream(k)))
 
 
-_KV_SPLIT_WS: dict = {}   # (device index, stream handle, bytes) -> zeroed workspace of the split decode launches (one launch at a time per stream)
+_KV_SPLIT_WS: dict = {}   # (device index, stream handle, pairs, head_dim) -> zeroed workspace of the split decode launches (one launch at a time per stream)
 
 
 def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tensor, kv_indptr: torch.Tensor,
@@ -1633,11 +1633,9 @@ def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tens
         nbytes = int(lib.fq_kv_decode_workspace_bytes(batch, heads, hd)) if split else 0
         if nbytes > 0:
             stream = _stream(q)
-            key = (q.device.index, stream.value, nbytes)
+            key = (q.device.index, stream.value, batch * heads, hd)   # (one per geometry: the counters sit in front of the states)
             ws = _KV_SPLIT_WS.get(key)
-            if ws is None:
-                if len(_KV_SPLIT_WS) >= 16:
-                    _KV_SPLIT_WS.pop(next(iter(_KV_SPLIT_WS)))
+            if ws is None:   # (never freed: a captured graph may hold its address; a few hundred KB per geometry and stream)
                 ws = _KV_SPLIT_WS[key] = torch.zeros((nbytes,), dtype=torch.uint8, device=q.device)
             check(lib.fq_kv_batch_decode_split(1 if f16_cache else 0, _ptr(o), _ptr(q), _ptr(q_trans), 1 if transpose_out else 0, _ptr(kv_data),
                                                _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),

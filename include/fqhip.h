@@ -624,7 +624,8 @@ int fq_kv_batch_decode_f16(void* o, const void* q, const void* kv_data, const vo
  * workgroup leaves its partial softmax state in `workspace`, the last one to arrive merges them. Results equal the unsplit launch up to
  * the order of fp32 additions.
  *   workspace: fq_kv_decode_workspace_bytes(batch_size, num_heads, head_dim) bytes (0: this geometry is never split), 16-byte aligned,
- *   ZEROED once before its first use (the launches leave it as they found it), used by one launch at a time. NULL: no split.
+ *   ZEROED once before its first use (the launches leave its counters as they found them), used by one launch at a time and for ONE geometry
+ *   (batch_size x num_heads, head_dim) — zero it again before using it for another. NULL: no split.
  *   fp16_cache != 0: the fp16 configuration (kv_data as fq_kv_append_f16 lays it out; kv_param unused).
  */
 int64_t fq_kv_decode_workspace_bytes(int batch_size, int num_heads, int head_dim);
