@@ -20,12 +20,16 @@
 //     supplies features 32 g .. 32 g + 31 of row i, exactly the 16 bytes it loaded, and receives row i's full 128-feature sum (exact
 //     fp16 x fp16 products, fp32 accumulation: no 4-lane reduction); (c) p . v reads the fp16 halves directly (v_fma_mix_f32: one
 //     operation per feature) and the dequantisation stays folded: q . k = scale * sum(q_j n_j) - zero * sum(q_j), o = sum_i (p_i scale_i)
-//     n_i - sum_i p_i zero_i with the second sum a scalar per lane; (d) the running maximum is rescaled lazily (a wave-uniform branch,
-//     taken when some lane's maximum moved); (e) the page index is a scalar load where a wave's 16 rows cannot straddle a page, and
-//     the next step's rows are requested before the current step's arithmetic inside a condition-free steady-state loop (counted
-//     vmcnt waits). head_dim 64: two lanes per row, 32 rows per step, v_mfma_f32_32x32x16_f16.
-//     64 requests x 2048 tokens x 32 heads: 180.7 -> 113 us (0.39 -> 0.63 of 8 TB/s), 8 x 8192: 108 -> 54 us, 128 x 4096: 0.715
-//     (profiles/r05_kvdecode_timing.txt).
+//     n_i - sum_i p_i zero_i with the second sum a scalar per lane; (d) a lane's running softmax refers to a bound 2^8 above the row that
+//     last raised it, not to its exact maximum (which moves in most steps of a 2048-token request and costs 34 register rescales in every
+//     lane each time), rescaled in a wave-uniform branch; (e) the page index is a scalar load where a wave's 16 rows cannot straddle a
+//     page, the row addresses a scalar base + a loop-invariant lane offset, and the next step's rows are requested before the current
+//     step's arithmetic inside a condition-free steady-state loop (counted vmcnt waits); (f) the lane states merge on ALL threads (a wave
+//     reduction for the maximum, every state's weight once, chunked sums), and with few (request, head) pairs a request's rows are split
+//     over several workgroups (SPLIT below). head_dim 64: two lanes per row, 32 rows per step, v_mfma_f32_32x32x16_f16.
+//     64 requests x 2048 tokens x 32 heads: 180.7 -> 102.7 us (0.39 -> 0.69 of 8 TB/s; FETCH_SIZE 571 MB for 570 MB of rows, 136 VALU
+//     instructions per 16-row step where the scalar kernel had ~300), 8 x 8192: 108 -> 46 us (0.77), 128 x 4096: 0.74, one request x 2048:
+//     20.8 -> 8.6 us (profiles/r05_kvdecode_timing.txt, r05_kvdecode_pmc.txt).
 #include "fq_common.hpp"
 
 namespace {
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(256) void fq_kv_append_kernel(PagedKv p, const uint
 typedef const int __attribute__((address_space(4))) kv_const_int;
 constexpr int KV_PERM[8] = {0, 4, 1, 5, 2, 6, 3, 7};   // feature (within the dword's eight) of packed slot e
 constexpr float KV_OFF = 16.0f;
+constexpr float KV_MARGIN = 8.0f;   // see the step of fq_kv_decode_kernel
 __device__ __forceinline__ uint32_t kv_and_or(uint32_t x, uint32_t mask, uint32_t bits) {
     uint32_t r;   // (gfx9: one constant-bus operand per VOP3 — the mask in an SGPR, the exponent bits in a VGPR)
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask), "v"(bits));
@@ -146,6 +151,10 @@ __device__ __forceinline__ float kv_qk(const f16x8 (&qa)[4], const uint4 kq, uin
 // Decode attention (batch_decode_i4 / batch_decode_f16): see the head of this file. Lane l = RPW part + slot: row `slot` of the wave's
 // RPW rows, chunk `part` (32 features) of that row: 16 bytes of the INT4 cache (a wave's load is RPW consecutive rows = 1 KB), or 64
 // bytes = four 16-byte loads of the fp16 configuration (F16: no (scale, zero), no unpacking — the loaded dwords ARE the B fragments).
+__device__ __forceinline__ size_t kv_uniform64(size_t v) {
+    return ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 // the split decode's workspace: a counter per (request, head) pair first (a fixed place, whatever the split count), the states behind them
 __device__ __forceinline__ float* kv_states(float* ws, size_t pairs) { return ws + ((pairs + 3) & ~(size_t)3); }
 
@@ -239,36 +248,47 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
         uint4 kq[F16 ? 4 : 1], vq[F16 ? 4 : 1];
         uint32_t kpar, vpar;
     };
+    constexpr int ROWB = F16 ? HD * 2 : HD / 2;                          // bytes of a cached row
+    const unsigned lane_row = (unsigned)slot * ROWB + (unsigned)part * (F16 ? 64 : 16);   // UNI: this lane's bytes behind the wave's first row
     auto request = [&](int64_t base, Rows& r) {
-        size_t page, entry;
+        const uint8_t *kp_, *vp_;
+        const uint32_t *kpar_, *vpar_;
         if (UNI) {
-            // (through the constant address space: a scalar load on lgkmcnt — as a vector load it would sit in front of the rows on
-            //  vmcnt, and waiting for it would wait for every row in flight)
-            page = (size_t)reinterpret_cast<kv_const_int*>(reinterpret_cast<uintptr_t>(p.indices))[pg0 + pit];
-            entry = (size_t)(ent + slot);
+            // (the page index through the constant address space: a scalar load on lgkmcnt — as a vector load it would sit in front of
+            //  the rows on vmcnt, and waiting for it would wait for every row in flight. Everything up to the wave's first row is
+            //  wave-uniform — scalar arithmetic, an SGPR base for the loads — and the lane adds a loop-invariant 32-bit offset:
+            //  the 64-bit address arithmetic per lane and request was ~25 of the ~160 VALU instructions of a step, rocprofv3 r05c31)
+            const size_t page = (size_t)reinterpret_cast<kv_const_int*>(reinterpret_cast<uintptr_t>(p.indices))[pg0 + pit];
+            const size_t e0 = kv_uniform64(page * page_stride + k_off + (size_t)ent);   // (told to the compiler: it is wave-uniform)
+            const uint8_t* kb = p.data + e0 * ROWB;
+            kp_ = kb + lane_row;
+            vp_ = kb + kv_off * ROWB + lane_row;
+            kpar_ = reinterpret_cast<const uint32_t*>(p.param) + e0 + slot;
+            vpar_ = kpar_ + kv_off;
         } else {
             const bool valid = base + slot < seq_len;
-            page = (size_t)p.indices[valid ? pg0 + pit : pg1 - 1];
-            entry = valid ? (size_t)ent : 0;
+            const size_t page = (size_t)p.indices[valid ? pg0 + pit : pg1 - 1];
+            const size_t ke = page * page_stride + k_off + (valid ? (size_t)ent : 0), ve = ke + kv_off;   // = k_entry / v_entry, constants hoisted
+            kp_ = p.data + ke * ROWB + part * (F16 ? 64 : 16);
+            vp_ = p.data + ve * ROWB + part * (F16 ? 64 : 16);
+            kpar_ = reinterpret_cast<const uint32_t*>(p.param) + ke;
+            vpar_ = reinterpret_cast<const uint32_t*>(p.param) + ve;
         }
         ent += STRIDE;
         while (ent >= p.page_size) {
             ent -= p.page_size;
             ++pit;
         }
-        const size_t ke = page * page_stride + k_off + entry, ve = ke + kv_off;   // = k_entry / v_entry, constants hoisted
         if constexpr (F16) {
-            const uint4* kp = reinterpret_cast<const uint4*>(p.data + ke * (HD * 2) + part * 64);
-            const uint4* vp = reinterpret_cast<const uint4*>(p.data + ve * (HD * 2) + part * 64);
 #pragma unroll
-            for (int w = 0; w < 4; ++w) r.kq[w] = kp[w];
+            for (int w = 0; w < 4; ++w) r.kq[w] = reinterpret_cast<const uint4*>(kp_)[w];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) r.vq[w] = vp[w];
+            for (int w = 0; w < 4; ++w) r.vq[w] = reinterpret_cast<const uint4*>(vp_)[w];
         } else {
-            r.kq[0] = *reinterpret_cast<const uint4*>(p.data + ke * (HD / 2) + part * 16);
-            r.vq[0] = *reinterpret_cast<const uint4*>(p.data + ve * (HD / 2) + part * 16);
-            r.kpar = reinterpret_cast<const uint32_t*>(p.param)[ke];
-            r.vpar = reinterpret_cast<const uint32_t*>(p.param)[ve];
+            r.kq[0] = *reinterpret_cast<const uint4*>(kp_);
+            r.vq[0] = *reinterpret_cast<const uint4*>(vp_);
+            r.kpar = *kpar_;
+            r.vpar = *vpar_;
         }
     };
     auto step = [&](int64_t base, const Rows& r) {
@@ -285,9 +305,13 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
             const float dotn = kv_qk<QL>(qa, r.kq[0], ebits) - qoff;
             x = valid ? (ks * dotn - kz * qsum) * sm_scale : -INFINITY;
         }
-        const float m_new = fmaxf(m, x);
-        if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {   // some lane's maximum moved: everybody rescales (by 1 where it did not)
-            const float alpha = m_new > m ? __builtin_amdgcn_exp2f(m - m_new) : 1.0f;
+        // The reference point of a lane's running softmax is not its exact maximum but a bound KV_MARGIN (log2 units) above the row
+        // that last raised it: exact maxima move in most steps of a 2048-token request (16 row lanes per wave, each a new maximum
+        // with probability 1 / t) and every move rescales 34 registers in all lanes; a bound 2^8 above moves once or twice per
+        // request. p = exp2(x - m) stays <= 1, the merge takes m as it is.
+        const float m_new = x > m ? x + KV_MARGIN : m;
+        if (__builtin_amdgcn_ballot_w64(x > m) != 0) {   // some lane's bound moved: everybody rescales (by 1 where it did not)
+            const float alpha = x > m ? __builtin_amdgcn_exp2f(m - m_new) : 1.0f;
             d *= alpha;
             zacc *= alpha;
 #pragma unroll
