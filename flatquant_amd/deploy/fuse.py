@@ -33,7 +33,8 @@ from .nn.online_trans import FusedSequential, OnlineTrans, fused_forward
 from .nn.quantization import Quantizer
 
 
-DECODE_ROWS = 128   # at or below this many tokens a module call is launch- / Python-bound (tools/ref_layer.py --seq 1): the groups step aside
+DECODE_ROWS = 128   # at or below this many tokens an EAGER module call is Python-bound (tools/ref_layer.py --seq 1): the groups step aside
+                    # — except while a HIP graph is being captured, where fewer launches are what counts
 
 
 class TransformGroup:
@@ -65,8 +66,12 @@ class TransformGroup:
         self._ref, self._outs, self._taken = None, None, 0
 
     def get(self, member, x):
-        if x.dim() != 3 or x.shape[0] * x.shape[1] <= DECODE_ROWS:
-            return None                                      # decode-sized: the members' own prepared calls are the faster route
+        if x.dim() != 3:
+            return None
+        if x.shape[0] * x.shape[1] <= DECODE_ROWS and not torch.cuda.is_current_stream_capturing():
+            return None                                      # decode-sized and eager: the members' own prepared calls are the faster route
+        # (decode-sized under stream CAPTURE: the host cost is paid once, the replayed graph keeps one transform launch and one
+        #  weight-streaming launch per group instead of three — a small launch costs ~4 us on the device whatever it does)
         i = self.index[id(member)]
         bit = 1 << i
         if self._outs is not None and self._ref is not None and self._ref() is x and self._version == x._version and not (self._taken & bit):

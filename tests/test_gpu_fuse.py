@@ -54,6 +54,52 @@ def test_fused_layer_is_bit_identical_to_the_reference_structure(down, bsz, seq)
             assert torch.equal(a, b)
 
 
+def test_groups_serve_decode_sized_calls_while_a_graph_is_captured():
+    """Eager decode-sized calls leave the groups aside (Python-bound: the members' prepared calls are cheaper); under stream capture the
+    groups serve them — the replayed graph holds one transform launch and one weight-streaming GEMM launch per group — and the replay is
+    bit for bit the eager unfused layer."""
+    import flatquant_amd.deploy as deploy
+    from ref_layer import RefLayer
+    with torch.no_grad():
+        layer = RefLayer("tiny", seed=5)
+        g = torch.Generator(device="cuda").manual_seed(13)
+        x = torch.randn(3, 1, 4096, generator=g, device="cuda", dtype=torch.float16)
+        want = layer(x)
+        deploy.fuse(layer)
+        tga, lga, tgm, lgm = _groups(layer)
+        for a, b in zip(layer(x), want):                     # eager: the groups step aside
+            assert torch.equal(a, b)
+        assert tga.launches == 0 and lga.launches == 0
+        xs = x.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            layer(xs)                                        # (warm-up on the side stream: images, workspaces)
+            n0 = (tga.launches, lga.launches, tgm.launches, lgm.launches)
+            with torch.cuda.graph(graph, stream=s):
+                got = layer(xs)
+        torch.cuda.synchronize()
+        assert (tga.launches, lga.launches, tgm.launches, lgm.launches) == tuple(v + 1 for v in n0)   # one fused launch per group, captured
+        assert tga.served >= 2 and lga.served >= 2
+        graph.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+        x2 = torch.randn(3, 1, 4096, generator=g, device="cuda", dtype=torch.float16)
+        want2 = [t.clone() for t in RefLayerEager(layer, x2)]
+        xs.copy_(x2)
+        graph.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(got, want2):
+            assert torch.equal(a, b)
+
+
+def RefLayerEager(layer, x):
+    """the fused layer called eagerly at a decode size (the groups step aside): the reference result for a replay with new inputs"""
+    return layer(x)
+
+
 def test_fuse_without_linear_groups_and_with_static_outputs():
     import flatquant_amd.deploy as deploy
     from ref_layer import RefLayer

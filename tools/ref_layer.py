@@ -165,6 +165,27 @@ def timeit(fn, steps=20, warm=5, settle_ms=80.0):
     return sorted(ts)[1]
 
 
+def graph_time(fn, x, steps=200):
+    """us per replay of fn(x) captured in a HIP graph (x is a fixed input buffer)"""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        fn(x)
+        with torch.cuda.graph(gr, stream=s):
+            fn(x)
+    torch.cuda.synchronize()
+    for _ in range(10):
+        gr.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        gr.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="llama-2-7b", choices=sorted(MODELS))
@@ -172,6 +193,7 @@ def main():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--down", default="matmul", choices=["matmul", "had"], help="the down_proj input transform (options.trans)")
+    ap.add_argument("--graph", action="store_true", help="also: the layer replayed from a captured HIP graph (decode sizes: the host cost is out of the picture)")
     a = ap.parse_args()
     xs = [torch.randn(a.bsz, a.seq, MODELS[a.model]["hidden"], device="cuda", dtype=torch.float16) for _ in range(3)]
     it = [0]
@@ -182,6 +204,7 @@ def main():
     with torch.no_grad():
         f16 = Fp16Layer(a.model)
         t16 = timeit(lambda: f16(nxt()), a.steps)
+        g16 = graph_time(f16, xs[0]) if a.graph else None
         del f16
         print(f"{a.model}, {a.bsz} x {a.seq} tokens, one decoder layer WITHOUT the attention core (both sides), end to end, Python included")
         print(f"  fp16 layer (7 nn.Linear, 2 rms_norm, SiLU.mul)                              {t16:9.1f} us")
@@ -195,6 +218,9 @@ def main():
         deploy.nn.Linear4bit.fp6_image = True
         t1 = timeit(lambda: layer(nxt()), a.steps)
         print(f"  W4A4 layer, reference structure, default modules (round 5)                  {t1:9.1f} us   {t16 / t1:5.2f}x")
+        if a.graph:
+            g1 = graph_time(layer, xs[0])
+            print(f"  captured HIP graph: fp16 layer {g16:9.1f} us, W4A4 layer (reference structure, one launch per module) {g1:9.1f} us   {g16 / g1:5.2f}x")
         rep = deploy.fuse(layer, linears=False)
         t2 = timeit(lambda: layer(nxt()), a.steps)
         print(f"  ... after deploy.fuse(model, linears=False) {rep}: {t2:9.1f} us   {t16 / t2:5.2f}x")
@@ -202,6 +228,9 @@ def main():
         rep = deploy.fuse(layer)
         t3 = timeit(lambda: layer(nxt()), a.steps)
         print(f"  ... after deploy.fuse(model) {rep}: {t3:9.1f} us   {t16 / t3:5.2f}x")
+        if a.graph:
+            g3 = graph_time(layer, xs[0])
+            print(f"  captured HIP graph after deploy.fuse(model) (the groups serve decode-sized calls under capture) {g3:9.1f} us   {g16 / g3:5.2f}x")
         deploy.fuse(layer, static_outputs=True)
         t4 = timeit(lambda: layer(nxt()), a.steps)
         print(f"  ... after deploy.fuse(model, static_outputs=True)                             {t4:9.1f} us   {t16 / t4:5.2f}x")
