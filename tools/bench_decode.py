@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--cache", type=int, default=2048, help="cached tokens per request")
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--single", action="store_true", help="one launch per projection (rounds 1-4) instead of the multi-problem launches")
+    ap.add_argument("--fp16", action="store_true", help="also time the same step in fp16 (nn.Linear, rms_norm, SiLU.mul, the fp16 configuration of the paged cache) "
+                                                        "— the baseline of the reference's decode table, README.md:300-310")
     a = ap.parse_args()
     hidden, ffn, heads, kv_heads, hd = 4096, 14336, 32, 8, 128
     dev = torch.device("cuda")
@@ -75,6 +77,63 @@ def main():
         yu, yg = deploy.nn.linear.linear4bit_multi([up_l, gate_l], [pu, pg])
         return down_l(down_t(yg, up=yu))
 
+    def measure(step, cache):
+        """-> (us per step from a captured graph, us per step launched eagerly)"""
+        for _ in range(3):                      # eager warm-up (weight images, workspaces, scalar caches), rewinding the cache length each time
+            step(x)
+            cache.length -= 1
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            step(x)
+            cache.length -= 1
+        e1.record()
+        torch.cuda.synchronize()
+        eager = e0.elapsed_time(e1) / 20 * 1e3
+        graph = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            step(x)
+            cache.length -= 1
+            with torch.cuda.graph(graph, stream=s):
+                step(x)
+            cache.length -= 1
+        torch.cuda.synchronize()
+        for _ in range(10):
+            graph.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(a.iters):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / a.iters * 1e3, eager
+
+    if a.fp16:
+        import torch.nn.functional as F
+        mk = lambda i, o: torch.nn.Linear(i, o, bias=False, device=dev, dtype=torch.float16)
+        with torch.no_grad():
+            fq, fk, fv, fo = mk(hidden, hidden), mk(hidden, kv_heads * hd), mk(hidden, kv_heads * hd), mk(hidden, hidden)
+            fu, fg, fd = mk(hidden, ffn), mk(hidden, ffn), mk(ffn, hidden)
+        w1 = torch.ones(hidden, device=dev, dtype=torch.float16)
+        cache16 = dt.MultiLayerPagedKVCache4Bit(a.bsz, 2048, a.cache + 8, dev, 1, heads, hd, disable_quant=True, trans="none", group_size=heads // kv_heads)
+        cache16.update(torch.randn(a.bsz, a.cache, kv_heads, hd, generator=g, device=dev).half(),
+                       torch.randn(a.bsz, a.cache, kv_heads, hd, generator=g, device=dev).half(), 0, {})
+
+        @torch.no_grad()
+        def step16(h):
+            xn = F.rms_norm(h, (hidden,), w1, 1e-6)
+            q, k, v = fq(xn), fk(xn), fv(xn)
+            att = cache16.update(k.view(a.bsz, 1, kv_heads, hd), v.view(a.bsz, 1, kv_heads, hd), 0, {})(q.view(a.bsz, 1, heads, hd))
+            h2 = fo(att.reshape(a.bsz, 1, hidden))
+            xn2 = F.rms_norm(h2, (hidden,), w1, 1e-6)
+            return fd(F.silu(fg(xn2)) * fu(xn2))
+        us16, eager16 = measure(step16, cache16)
+        del fq, fk, fv, fo, fu, fg, fd, cache16
+        torch.cuda.empty_cache()
+
     # eager warm-up (fills the weight-image / workspace / scalar caches), rewinding the cache length each time
     for _ in range(3):
         y = step(x)
@@ -108,7 +167,9 @@ def main():
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / a.iters * 1e3
     print(f"Llama-3-8B decoder layer, decode step, {a.bsz} requests x {a.cache} cached tokens: {us:.1f} us per layer from a "
-          f"captured graph ({eager:.1f} us launched eagerly from Python); output finite: {bool(torch.isfinite(y.float()).all())}")
+          f"captured graph ({eager:.1f} us launched eagerly from Python); output finite: {bool(torch.isfinite(y.float()).all())}"
+          + (f"   | the same step in fp16 (fp16 paged cache): {us16:.1f} us captured ({eager16:.1f} eager): speed-up {us16 / us:.2f}x captured, "
+             f"{eager16 / eager:.2f}x eager" if a.fp16 else ""))
 
 
 if __name__ == "__main__":
