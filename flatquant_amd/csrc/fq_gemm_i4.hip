@@ -297,7 +297,7 @@ struct SkinnyProblems {
     int n;
 };
 
-template <int MT, bool MULTI>
+template <int MT, bool MULTI, int U = 1>
 __global__ __launch_bounds__(SK_WAVES * 64) void fq_gemm_i4_skinny_kernel(const uint8_t* __restrict__ X_,
                                                                          const uint4* __restrict__ Wimg_, int M, int N_,
                                                                          int Kb, GemmOut out_, SkinnyProblems pr) {
@@ -333,8 +333,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void fq_gemm_i4_skinny_kernel(const 
         const int m = mt * 32 + c;
         xrow[mt] = X + (size_t)(m < M ? m : M - 1) * Kb + 16 * h;
     }
-    for (int kb = wave; kb < KB; kb += SK_WAVES) {
-        const u32x4 a_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)kb * 64));
+    auto block = [&](int kb, const u32x4 a_) {
         const uint4 a = make_uint4(a_[0], a_[1], a_[2], a_[3]);
         const i32x4 a0 = unpack16(make_uint2(a.x, a.y)), a1 = unpack16(make_uint2(a.z, a.w));
 #pragma unroll
@@ -343,7 +342,20 @@ __global__ __launch_bounds__(SK_WAVES * 64) void fq_gemm_i4_skinny_kernel(const 
             acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, unpack16(make_uint2(b.x, b.y)), acc[mt], 0, 0, 0);
             acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, unpack16(make_uint2(b.z, b.w)), acc[mt], 0, 0, 0);
         }
+    };
+    // U weight blobs of a wave requested at a time. U = 1 keeps two workgroups per CU (41 VGPRs) — right for the wide launches (N = 14336:
+    // 448 workgroups, the q/k/v and up/gate groups); a 4096-wide projection alone is 128 workgroups with ONE 1 KB load per wave in
+    // flight, 2 MB on the whole chip: latency-bound at 1.9-3.3 TB/s — there U = 2 (measured with the knob on every launch, per-dispatch
+    // durations: 7.56 -> 5.8 us on the N = 4096 launches, slower on N = 1024 and 14336: profiles/r05_skinny_prefetch.txt).
+    int kb = wave;
+    for (; kb + (U - 1) * SK_WAVES < KB; kb += U * SK_WAVES) {
+        u32x4 a_[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) a_[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)(kb + u * SK_WAVES) * 64));
+#pragma unroll
+        for (int u = 0; u < U; ++u) block(kb + u * SK_WAVES, a_[u]);
     }
+    for (; kb < KB; kb += SK_WAVES) block(kb, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)kb * 64)));
     // lane (h, c) of tile mt: token 32 mt + c, features 16 h + r
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -414,7 +426,10 @@ int fq_launch_gemm_i4_skinny(const uint8_t* X, const void* wimg, int64_t M, int 
     const dim3 grid((unsigned)((N + 31) / 32));
     const uint4* img = reinterpret_cast<const uint4*>(wimg);
     const SkinnyProblems none = {};
-    if (M <= 32) hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<1, false>), grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o, none);
+    const bool deep = M <= 32 && (N + 31) / 32 <= 256 && (N + 31) / 32 >= 64 && K / 64 >= 2 * SK_WAVES;   // a lone 2048- to 8192-wide projection of <= 32 rows
+                                                                                                        // (64 / 128 rows: no gain / 31.5 vs 28.5 us): see the kernel
+    if (deep) hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<1, false, 2>), grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o, none);
+    else if (M <= 32) hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<1, false>), grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o, none);
     else if (M <= 64) hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<2, false>), grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o, none);
     else hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<4, false>), grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o, none);
     return (int)hipGetLastError();
