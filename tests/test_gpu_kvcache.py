@@ -483,3 +483,30 @@ def test_split_decode_workspace_contract(ops):
     assert lib.fq_kv_batch_decode_split(*args(None, 0)) == 0              # no workspace: the unsplit launch
     torch.cuda.synchronize()
     assert int(ws.view(torch.int32)[:64].abs().sum()) == 0                # the counters are zero again
+
+
+def test_split_decode_is_bit_stable_over_many_launches(ops):
+    """The split launch's workgroups hand their partial states over through agent-scope stores, a counter and agent-scope loads (no fence:
+    fq_kvcache.hip). A state read before it has arrived would change the result: 600 launches on the same inputs — two geometries, alternating,
+    so that consecutive launches of a geometry reuse workspace lines the other one's neighbours just wrote — must give the same bits every time
+    (the merge order is fixed) and stay within tolerance of the unsplit launch."""
+    g = torch.Generator(device="cuda").manual_seed(77)
+    cases = []
+    for bsz, heads, seq, page in ((1, 32, 2048, 2048), (3, 16, 1500, 16)):
+        n_pg = (seq + page - 1) // page
+        data = torch.randint(0, 256, (bsz * n_pg, 1, 2, heads, page, 64), generator=g, device="cuda", dtype=torch.uint8)
+        par = (torch.rand(bsz * n_pg, 1, 2, heads, page, 2, generator=g, device="cuda") * 0.2 + 0.05).half()
+        indptr = torch.arange(bsz + 1, device="cuda", dtype=torch.int32) * n_pg
+        indices = torch.randperm(bsz * n_pg, generator=g, device="cuda").to(torch.int32)
+        last = torch.full((bsz,), (seq - 1) % page + 1, device="cuda", dtype=torch.int32)
+        q = torch.randn(bsz, heads, 128, generator=g, device="cuda").half()
+        args = (q, data, par, indptr, indices, last, 0)
+        ref = ops.kv_batch_decode(*args, split=False).float()
+        first = ops.kv_batch_decode(*args, seq_hint=seq)
+        assert ((first.float() - ref).abs().amax() / ref.abs().amax()).item() <= 1e-3
+        cases.append((args, seq, first))
+    bad = torch.zeros((), dtype=torch.int64, device="cuda")
+    for _ in range(300):
+        for args, seq, first in cases:
+            bad += (ops.kv_batch_decode(*args, seq_hint=seq) != first).sum()     # (compared on the device: nothing waits for the host)
+    assert int(bad) == 0
