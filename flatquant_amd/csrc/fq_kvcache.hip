@@ -148,9 +148,6 @@ __device__ __forceinline__ float kv_qk(const f16x8 (&qa)[4], const uint4 kq, uin
     return kv_qk_mfma<QL>(qa, kb);
 }
 
-// Decode attention (batch_decode_i4 / batch_decode_f16): see the head of this file. Lane l = RPW part + slot: row `slot` of the wave's
-// RPW rows, chunk `part` (32 features) of that row: 16 bytes of the INT4 cache (a wave's load is RPW consecutive rows = 1 KB), or 64
-// bytes = four 16-byte loads of the fp16 configuration (F16: no (scale, zero), no unpacking — the loaded dwords ARE the B fragments).
 __device__ __forceinline__ size_t kv_uniform64(size_t v) {
     return ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
@@ -164,6 +161,9 @@ __device__ __forceinline__ float* kv_states(float* ws, size_t pairs) { return ws
 #ifndef KV_DEPTH
 #define KV_DEPTH 1   // steps of rows in flight under a step's arithmetic (measured: 1, 2, 3 within 2 % — profiles/r05_kvdecode_timing.txt)
 #endif
+// Decode attention (batch_decode_i4 / batch_decode_f16): see the head of this file. Lane l = RPW part + slot: row `slot` of the wave's
+// RPW rows, chunk `part` (32 features) of that row: 16 bytes of the INT4 cache (a wave's load is RPW consecutive rows = 1 KB), or 64
+// bytes = four 16-byte loads of the fp16 configuration (F16: no (scale, zero), no unpacking — the loaded dwords ARE the B fragments).
 // SPLIT (round 5): a request's rows over gridDim.z workgroups — with few (request, head) pairs the launch fills a fraction of the chip
 // (one request x 32 heads: 32 of 256 CUs, ~20 us for 9 MB). The workgroups of a pair take the wave-steps round robin (virtual wave
 // blockIdx.z * NW + wave of gridDim.z * NW), each leaves its un-normalised (m, d, o[HD]) in `ws`, and the LAST one to arrive (a counter
@@ -188,17 +188,27 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
     const int64_t seq_len = (int64_t)(pg1 - pg0 - 1) * p.page_size + p.last_page_offset[b];
 
     // the query as fp16 values in LDS: q itself, or q' = fp16(q . qt) (kv_cache.py:139-140: torch.matmul(q.half(),
-    // trans_matrix_k_inv_t)), fp32 accumulation, one output feature per thread
+    // trans_matrix_k_inv_t)), fp32 accumulation — every thread sums HD / NCHQ terms of one output feature (one thread per feature
+    // walked all HD terms in a dependent chain: microseconds in front of every workgroup, and a split launch has many), the NCHQ
+    // partial sums meet in LDS (s_o is free until the states are written)
     {
         const f16* qrow = q + ((size_t)b * p.num_heads + head) * HD;
-        for (int j = tid; j < HD; j += NW * 64) {
-            if (qt != nullptr) {
-                float a = 0.0f;
-                for (int i = 0; i < HD; ++i) a = __builtin_fmaf((float)qrow[i], (float)qt[i * HD + j], a);
-                s_q[j] = (float)(f16)a;
-            } else {
-                s_q[j] = (float)qrow[j];
+        if (qt != nullptr) {
+            constexpr int NCHQ = NW * 64 / HD, CHQ = HD / NCHQ;
+            const int j = tid % HD, c = tid / HD;
+            float a = 0.0f;
+#pragma unroll 8
+            for (int i = c * CHQ; i < (c + 1) * CHQ; ++i) a = __builtin_fmaf((float)qrow[i], (float)qt[i * HD + j], a);
+            s_o[c][j] = a;
+            __syncthreads();
+            if (tid < HD) {
+                float t = 0.0f;
+#pragma unroll
+                for (int cc = 0; cc < NCHQ; ++cc) t += s_o[cc][tid];
+                s_q[tid] = (float)(f16)t;
             }
+        } else {
+            for (int j = tid; j < HD; j += NW * 64) s_q[j] = (float)qrow[j];
         }
         __syncthreads();
     }
