@@ -156,11 +156,20 @@ struct KvIO {
 // rows start one bank apart), the column pieces are gathered from there.
 template <int HD, typename T>
 __device__ __forceinline__ void kv_stage_tfrag(const T* __restrict__ Tm, uint4* tfrag, unsigned short* raw, int tid) {
-    constexpr int KS = HD / 16, NTL = HD / 32, PITCH = HD + 2, HALF = HD / 2, CPR = HD / 8;
+    constexpr int KS = HD / 16, NTL = HD / 32, PITCH = HD + 2, HALF = HD / 2, CPR = HD / 8, NLD = HALF * CPR / 256;
+    static_assert(HALF * CPR % 256 == 0, "whole 16-byte loads per thread");
+    uint4 pre[2][NLD];   // both halves requested at once: one global round trip in front of the launch's first MFMA, not two
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int k2 = 0; k2 < NLD; ++k2) pre[half][k2] = reinterpret_cast<const uint4*>(Tm + (size_t)(half * HALF) * HD)[tid + 256 * k2];
+#pragma unroll
     for (int half = 0; half < 2; ++half) {
-        for (int i = tid; i < HALF * CPR; i += 256) {
+#pragma unroll
+        for (int k2 = 0; k2 < NLD; ++k2) {
+            const int i = tid + 256 * k2;
             const int k = i / CPR, c8 = i - k * CPR;
-            const uint4 v = reinterpret_cast<const uint4*>(Tm + (size_t)(half * HALF) * HD)[i];
+            const uint4 v = pre[half][k2];
             unsigned* dst = reinterpret_cast<unsigned*>(raw + k * PITCH + c8 * 8);   // (4-byte aligned: PITCH is even)
             dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
         }
