@@ -32,6 +32,9 @@
 //     BEFORE the epilogue of the current one; the tile boundary waits with a counted vmcnt that leaves the epilogue's stores
 //     in flight.
 //   * the sym_dequant epilogue in the float pipeline (fq_gemm_common.hpp, dequant16f): 5 - 6 VALU per output element, not 11.
+// Round 6 (profiles/r06_gemm_epilogue_experiments.txt): the epilogue is 19 of 147 us (stores 12.5, arithmetic 6.7), the K loop 128; holding part
+// of a tile's output under the next K loop, a start-time stagger of the workgroups, wider or single fragment reads, four waves of 128 x 128 with
+// 256 AGPR accumulators (one wave per SIMD, 0.5 fragment reads per MFMA: 151.8 us), a rotated loop with C = 0 first blocks: all bit-exact, none faster.
 // Built, measured and dropped (docs/DESIGN_LOG.md 10): E2M3 operands, v_mfma_scale_f32_16x16x128_f8f6f4 with its own operand image,
 // 128-token tiles with two stages and two workgroups per CU, non-temporal output stores, waves of 256 x 64 / 64 x 64.
 #include "fq_gemm_common.hpp"
@@ -144,6 +147,13 @@ template <> struct GemmMultiArg<true> {
 // (round 4 built, measured and round 5 removed a MODE 2: x_up * silu(x_gate) in the epilogue of the gate / up pair — bit-identical to the
 //  GEMMs + fq_silu_mul_f16, and no faster: the up tile's epilogue reads the gate tile's values back (~100 us per 16384 x 14336 launch) and the
 //  SiLU arithmetic sits where no MFMA overlaps it; 1401 us fused against 1397 separate, a loss at 2048 tokens — profiles/r04_gate_up_epilogue.txt)
+// Measurement knob (tools/variants.sh builds overlay objects with it; the product build leaves it 0) — the ablations behind
+// profiles/r06_gemm_epilogue_experiments.txt: 1 the epilogue's arithmetic without its stores; 2 no epilogue; 3 no LDS reads of the weight
+// fragments; 4 = 3 + no LDS-DMA of the weight operand; 5 no fragment reads at all; 6 no MFMAs (the fragments are consumed by an empty asm).
+#ifndef GEMM_ABL
+#define GEMM_ABL 0
+#endif
+
 template <int BM, int MODE = 0>
 __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB_, const uint8_t* __restrict__ WB_,
                                                                               int M, int N_, int KB, int n_vblocks, GemmOut out_,
@@ -196,6 +206,7 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
     const unsigned voff = (unsigned)lane * 16u;
     const unsigned lds0 = (unsigned)(size_t)(lds_void_b*)smem;
     auto issue_one = [&](int s, int j) {   // instruction j of this wave's share of stage s
+        if (GEMM_ABL == 4 && wave * DPW + j < 24) return;
         const unsigned dst = lds0 + (unsigned)((s % STAGES) * TILE_BYTES) + (unsigned)(wave * DPW + j) * 1024u;
         const unsigned char* src = gbase[j] + (int64_t)s * SEG;
         unsigned keep;
@@ -262,12 +273,19 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
 // index -1) so that no zeroing moves are emitted for them (24 v_mov per 128 k otherwise)
 #define FQ_FRAG(R) __builtin_shufflevector(i32x6{(int)R[0].x, (int)R[0].y, (int)R[1].x, (int)R[1].y, (int)R[2].x, (int)R[2].y}, \
                                            i32x6{0, 0, 0, 0, 0, 0}, 0, 1, 2, 3, 4, 5, -1, -1)
+#if GEMM_ABL == 6
+#define FQ_MFMA1(RW, RX, I)                                                                                          \
+    asm volatile("" : "+v"(acc[(I) / TMT][(I) % TMT]) : "v"(FQ_FRAG(RW[(I) / TMT])), "v"(FQ_FRAG(RX[(I) % TMT])));
+#else
 #define FQ_MFMA1(RW, RX, I)                                                                                          \
     acc[(I) / TMT][(I) % TMT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(FQ_FRAG(RW[(I) / TMT]), FQ_FRAG(RX[(I) % TMT]), \
                                                                                 acc[(I) / TMT][(I) % TMT], 3, 3, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#endif
 // fragment I of a block: I < 2 the weight row tiles, then the TMT token row tiles; three conflict-free 8-byte reads
 #define FQ_READ1(ST, KBL, RW, RX, I)                                                                                 \
-    if ((I) < 2) {                                                                                                   \
+    if ((GEMM_ABL == 3 || GEMM_ABL == 4) && (I) < 2) {                                                               \
+    } else if (GEMM_ABL == 5) {                                                                                      \
+    } else if ((I) < 2) {                                                                                            \
         _Pragma("unroll") for (int p = 0; p < 3; ++p) RW[(I) < 2 ? (I) : 0][p] =                                     \
             *reinterpret_cast<const uint2*>((ST) + woff + ((I) < 2 ? (I) : 0) * SEG + (KBL) * BLOB + p * 512);       \
     } else if ((I) < 2 + TMT) {                                                                                      \
@@ -392,7 +410,9 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
 #pragma unroll
                     for (int g = 0; g < 4; ++g) cp[g] = make_int4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
                 }
-                if (out.y != nullptr) {
+                if (GEMM_ABL == 2) {
+                    asm volatile("" : : "v"(acc[tn][tm]));
+                } else if (out.y != nullptr) {
                     f16x8 o0, o1;
                     if (may_clamp)
                         dequant16f<true>(acc[tn][tm], sr[tm], __builtin_bit_cast(f16x8, sc[tn][0]), __builtin_bit_cast(f16x8, sc[tn][1]),
@@ -400,6 +420,10 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
                     else
                         dequant16f<false>(acc[tn][tm], sr[tm], __builtin_bit_cast(f16x8, sc[tn][0]), __builtin_bit_cast(f16x8, sc[tn][1]),
                                           out.bias != nullptr, __builtin_bit_cast(f16x8, bs[tn][0]), __builtin_bit_cast(f16x8, bs[tn][1]), o0, o1);
+                    if (GEMM_ABL == 1) {
+                        asm volatile("" : : "v"(o0), "v"(o1));
+                        continue;
+                    }
                     uint4* yp = reinterpret_cast<uint4*>(out.y + (int64_t)m * N + nbase);
                     yp[0] = __builtin_bit_cast(uint4, o0);   // (plain stores: non-temporal ones measured 163 -> 173 us)
                     yp[1] = __builtin_bit_cast(uint4, o1);
