@@ -94,7 +94,7 @@ def pmc_traffic():
     """(HBM bytes per launch of the dominant kernel, source file) from the COMMITTED rocprofv3 PMC run of this same command
     (tools/prof.sh: separate --pmc passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled per the gfx950 correction) — a
     counter pass cannot run inside a timed bench process, so the line names the file the number is read from."""
-    for name in ("r05_kron64_pmc.json", "r04_kron64_pmc.json", "r03_kron64_pmc.json", "r02_kron64_pmc.json", "r01_kron64_pmc.json"):
+    for name in ("r06_kron64_pmc.json", "r05_kron64_pmc.json", "r04_kron64_pmc.json", "r03_kron64_pmc.json", "r02_kron64_pmc.json", "r01_kron64_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 return json.load(fh)["hbm_bytes_per_launch"], "profiles/" + name
@@ -802,14 +802,23 @@ def main(argv=None):
     if args.config == "C2" and args.dtype == "f16" and not args.no_sub_records:
         del wl.xs
         torch.cuda.empty_cache()
+        if world > 1 or args.force_dist:
+            # (round 6) BASELINE quotes the metric on 8 x 2048 tokens IN TOTAL: at N > 1 that exact workload (the tokens split over the ranks,
+            # one launch per rank and step) is a first-class record with its own value and per-rank times next to the weak headline —
+            # the number that answers ">= 6x at 8 GPUs" (at N = 8 a rank's launch is 2048 tokens = ~5 us: launch-bound, and said so)
+            subs["baseline_workload_strong"] = sub_record(C2S, 200, 50, device, rank, world, sharding, dist, args.force_dist)
         subs["strong"] = sub_record(C2SL, 20, 5, device, rank, world, sharding, dist, args.force_dist)
         subs["c4"] = sub_record(C4, 3, 1, device, rank, world, sharding, dist, args.force_dist)
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         value = elems_total / (wall / args.steps) / 1e6
+        ev_us = None
         if args.config in ("C1", "C2", "C2S"):               # one launch per step: the timed region IS the kernel
-            dom_name, dom_us, dom_bytes = wl.kernels[0][0], kern_ms * 1e3, wl.kernels[0][2]
+            # (round 6) ONE clock: the roofline figure of the line follows from the same wall clock as `value` and
+            # `ms_per_step` (launch gaps included: the kinder event clock of the same region stays beside it as *_events)
+            dom_name, dom_us, dom_bytes = wl.kernels[0][0], ms_per_step * 1e3, wl.kernels[0][2]
+            ev_us = kern_ms * 1e3
         else:
             dom_name, dom_us, dom_bytes = max(kern_us, key=lambda k: k[1])
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9
@@ -826,7 +835,10 @@ def main(argv=None):
                          "traffic": pmc_traffic()[0] if (args.config == "C2" and args.dtype == "f16") else None,
                          "traffic_source": pmc_traffic()[1] if (args.config == "C2" and args.dtype == "f16") else None,
                          "kernel": dom_name, "algorithmic_bytes_per_launch": dom_bytes,
-                         "launch_us": dom_us, "per_launch": per_launch, "hbm_stream_floor_us": floor_us,
+                         "launch_us": dom_us, "clock": "wall (ms_per_step)" if ev_us is not None else "hip events, the kernel alone back to back",
+                         "launch_us_events": ev_us, "achieved_events": (dom_bytes / (ev_us * 1e-6) / 1e9) if ev_us else None,
+                         "frac_events": (dom_bytes / (ev_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if ev_us else None,
+                         "per_launch": per_launch, "hbm_stream_floor_us": floor_us,
                          "frac_of_stream_floor": (floor_us / dom_us) if floor_us else None},
         }
         if args.config not in ("C1", "C2"):

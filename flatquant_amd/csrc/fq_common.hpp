@@ -314,7 +314,7 @@ __device__ __forceinline__ int fq_quant1(float y, float scale) {
 
 // The fp16-arithmetic quantiser when y itself is an fp16 value (rowquant / sym_quant inputs; quant.cu:40 __hdiv):
 // the native _Float16 division (v_rcp_f32 + two v_fma_mix refinements + v_div_fixup_f16, ~7 VALU with the reciprocal
-// of the per-row scale hoisted) instead of the ~11 of an IEEE fp32 division. tools/scratch/h16div.hip checked on
+// of the per-row scale hoisted) instead of the ~11 of an IEEE fp32 division. tools/microbench/h16div.hip checked on
 // gfx950 that it equals the correctly rounded quotient for ALL 2^32 pairs of finite fp16 values.
 __device__ __forceinline__ int fq_quant1_h(f16 y, f16 s) {
     const f16 t = y / s;
@@ -569,7 +569,7 @@ __device__ __forceinline__ uint32_t fq_pack8p(f32x2 p0, f32x2 p1, f32x2 p2, f32x
 
 // The quantiser of the packed output: one asm block per dword (8 elements), single-width VALU only.
 // v_pk_fma_f32 / v_pk_add_f32 (what hipcc's SLP vectoriser makes of fq_qmagic2 / fq_pack8p in fq_common.hpp) slow a
-// SIMD down next to another wave's MFMAs (tools/scratch/phase_overlap.hip: MFMA phase + pk phase take MORE than their
+// SIMD down next to another wave's MFMAs (tools/microbench/phase_overlap.hip: MFMA phase + pk phase take MORE than their
 // sum, single-width VALU hides a third of the MFMA time) and each one drags a hazard s_nop along; the C++ form of
 // single-width arithmetic (-fno-slp-vectorize) is scheduled into 72 spilled VGPRs at fq_kron64_kernel's 128-register cap.
 // Here the six temporaries are all there is.
@@ -631,7 +631,7 @@ __device__ __forceinline__ uint32_t fq_quant8_two(float y0, float y1, float y2, 
 
 // ---------------------------------------------------------------------------------------------------
 // Round 4: the packed quantiser with the FRACTION IN THE LOW HALF — 23 VALU per 8 elements (19 with v_pk_fma_f32) against the 33
-// of fq_quant8_two; with the clamp 31 (27) against 41. tools/scratch/quant3.hip holds the experiment (exhaustive-style check
+// of fq_quant8_two; with the clamp 31 (27) against 41. tools/microbench/quant3.hip holds the experiment (exhaustive-style check
 // against the true division, issue rate alone and next to MFMA phases).
 //
 //   u = fma(y, inv, C),  C = 200.5 + 2^-16 (0x43488001: 24 significant bits, exact).  For p = y inv in [-8.5, 7.5) the sum lies
@@ -815,7 +815,7 @@ __device__ __forceinline__ float fq_inv_hi(float inv) { return inv * 1.000000476
 //   RN16(t) == RN16(Q): a quotient of two 11-bit significands is never within 2^-23 (relative) of an fp16 rounding boundary m (a
 //   12-bit significand) unless it IS m — x - m s is a multiple of one unit in the last place of the 23-bit product m s — and t is
 //   within 2^-24 + 2^-45 of Q: the same side of every boundary; and Q == m gives t == m exactly (m is an fp32 value), the same tie.
-//   (Checked on the device against the native _Float16 division for every positive fp16 x and 3072 scales: tools/scratch/h16div2.hip.)
+//   (Checked on the device against the native _Float16 division for every positive fp16 x and 3072 scales: tools/microbench/h16div2.hip.)
 // Then v_cvt_pk_f16_f32, an optional packed clamp (rint and the clamp to [-8, 7] commute: the bounds are
 // integers), v_pk_add_f16 with 1536.0 = 1.5 * 2^10 (the sum rounds to an integer, half to even, and 1536 is even: the
 // low byte of each half is the two's-complement digit), and the eight low nibbles are gathered with v_perm_b32 / v_bfi_b32.

@@ -5,7 +5,7 @@
 // [-8, 7] is exactly representable in BF6 (E3M2: 0, +-1, 2, 3, 4, 5, 6, 7, 8), and
 // v_mfma_scale_f32_32x32x64_f8f6f4 with both operands BF6 and unit block scales (E8M0 = 127) multiplies them exactly
 // and accumulates in fp32: |product| <= 64 and K <= 2^18 keep every partial sum an integer below 2^24, i.e. the fp32
-// accumulator IS the int32 result. Measured on MI355X with register-resident operands (tools/scratch/bf6_probe.hip):
+// accumulator IS the int32 result. Measured on MI355X with register-resident operands (tools/microbench/bf6_probe.hip):
 // 5.1 Pop/s for BF6 32x32x64 against 3.6 Pop/s for i8 32x32x32 under the same sustained load, and no unpack VALU.
 //
 // Operands are pre-arranged as "blobs" (fq_i4_to_bf6_kernel): for a tile of 32 rows and a block of 64 k, the 64 lanes'

@@ -20,7 +20,7 @@
 //   * token claims run one token ahead; behind the second meeting the group starts the LDS-DMA of its next token into the
 //     buffer GEMM 1 has just finished with — rows unpadded, chunks rotated per row for conflict-free A-fragment reads, seven
 //     per-lane source offsets, four instructions per M0 — one block of four instructions at a time between the phases that
-//     follow (an LDS-DMA instruction costs its wave ~200 cycles of issue: tools/scratch/duo_trace.py);
+//     follow (an LDS-DMA instruction costs its wave ~200 cycles of issue: tools/microbench/duo_trace.py);
 //   * no output stage: a lane's two 8-byte runs (16 n' of each tile) of a row are neighbours: one 16-byte store.
 // Measured (round 3, 8192 tokens of 128 x 224): 256-259 us -> 208 us (0.285 -> 0.353 of 8 TB/s). Tried and dropped on the way:
 // one tile after the other (LDS-bound: 221 us), token staged through registers (spills next to 128 accumulators), the whole
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const T* __res
     // instructions of a block: seven more permanent registers do not fit), four instructions per M0 / base pair through the
     // instruction offset field (which advances the global AND the LDS address).
     // An LDS-DMA instruction costs its wave ~200 cycles of issue inside a busy phase (MI355X_MICROARCH.md: 100-185; measured here,
-    // tools/scratch/duo_trace.py: a wave that issues its quarter of a token — 14 instructions — in one go stands there for ~3000
+    // tools/microbench/duo_trace.py: a wave that issues its quarter of a token — 14 instructions — in one go stands there for ~3000
     // cycles, one wave issuing the whole token 27000). A wave's share goes out one block of four instructions at a time, at four
     // points of the token's schedule (dma_block): the cost is the same in total, but no phase waits for all of it.
     const unsigned xs_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(duo_lds_void*)xs);

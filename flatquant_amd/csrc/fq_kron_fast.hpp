@@ -6,7 +6,7 @@
 #include "fq_common.hpp"
 #include <stdlib.h>
 
-// Environment switches exist in measurement builds only (-DFQ_MEASURE, tools/scratch/*.sh): the product library reads
+// Environment switches exist in measurement builds only (-DFQ_MEASURE, tools/microbench/*.sh): the product library reads
 // no environment variables and keeps no mutable global state.
 #ifdef FQ_MEASURE
 static inline bool fq_measure_env(const char* name) { return getenv(name) != nullptr; }

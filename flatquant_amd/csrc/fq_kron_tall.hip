@@ -17,7 +17,7 @@
 // Two or three such workgroups per CU overlap each other's barriers. Same mathematics, rounding points, fragment chaining and
 // workspace image (fq_kron_prepare_kernel) as the other Kronecker kernels.
 // (round 4) this kernel keeps the two-sided quantiser of round 3: it runs at 2.26-2.29 GHz, VALU-issue-bound rather than power-bound,
-// and the low-half form's v_min3_u16 issues at half rate (tools/scratch/vrate.hip) — 164 -> 178 us with it (profiles/r04_quant_lo_ab.txt)
+// and the low-half form's v_min3_u16 issues at half rate (tools/microbench/vrate.hip) — 164 -> 178 us with it (profiles/r04_quant_lo_ab.txt)
 #define FQ_QUANT_LO 0
 #include "fq_common.hpp"
 

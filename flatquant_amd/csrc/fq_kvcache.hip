@@ -457,6 +457,12 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
         }
     }
     if (SPLIT) {
+        // The hand-over below (relaxed agent-scope atomics, s_waitcnt vmcnt(0), barrier, relaxed fetch_add) has no release / acquire pair: it is
+        // correct because gfx9 counts stores in vmcnt and the sc1 (agent-scope) stores write through to memory the merging workgroup's sc1 loads
+        // read. A target where stores retire on another counter (gfx10+: vscnt) needs the fences back — this file is gfx942 / gfx950 only.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "fq_kv_decode_kernel<SPLIT>: the vmcnt-based hand-over is only valid on gfx942 / gfx950"
+#endif
         const int S = (int)gridDim.z;
         unsigned* cnt = reinterpret_cast<unsigned*>(ws) + (size_t)b * p.num_heads + head;
         __shared__ unsigned s_last;
@@ -553,6 +559,7 @@ int64_t fq_kv_decode_ws_bytes(int batch, int num_heads, int head_dim) {   // for
 int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, const f16* qt,
                         int transpose_out, hipStream_t stream, bool f16_cache, float* ws, int splits) {
+    if (splits > 16) return -1000;   // (the merge of the split launch reads at most 16 states: fq_kv_decode_splits never returns more)
     const PagedKv p = make_kv(kv_data, kv_param, indptr, indices, last, num_layers, layer_idx, num_heads, page_size, head_dim, batch);
     const bool split = ws != nullptr && splits > 1;
     const dim3 grid((unsigned)batch, (unsigned)num_heads, split ? (unsigned)splits : 1u);

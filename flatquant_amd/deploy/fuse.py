@@ -28,6 +28,7 @@ import weakref
 
 import torch
 
+from .. import ops
 from .nn.linear import Linear4bit, linear4bit_multi
 from .nn.online_trans import FusedSequential, OnlineTrans, fused_forward
 from .nn.quantization import Quantizer
@@ -45,7 +46,7 @@ class TransformGroup:
         self.index = {id(m): i for i, m in enumerate(self.members)}
         self.linear_group = None
         self._ref = None          # weakref of the tensor the cached results belong to
-        self._version = -1
+        self._xver = -1
         self._outs = None
         self._taken = 0           # bit mask of the members that have taken their result
         self.launches = 0         # (counters for tests / reports)
@@ -74,7 +75,7 @@ class TransformGroup:
         #  weight-streaming launch per group instead of three — a small launch costs ~4 us on the device whatever it does)
         i = self.index[id(member)]
         bit = 1 << i
-        if self._outs is not None and self._ref is not None and self._ref() is x and self._version == x._version and not (self._taken & bit):
+        if self._outs is not None and self._ref is not None and self._ref() is x and self._xver == ops.ver(x) and not (self._taken & bit):
             out = self._outs[i]
             self._taken |= bit
             self.served += 1
@@ -83,7 +84,7 @@ class TransformGroup:
                 return None                                  # (the caller runs on its own)
             outs = fused_forward(x, self.members)
             self.launches += 1
-            self._ref, self._version, self._outs, self._taken = weakref.ref(x), x._version, outs, bit
+            self._ref, self._xver, self._outs, self._taken = weakref.ref(x), ops.ver(x), outs, bit
             out = outs[i]
         if self._taken == (1 << len(self.members)) - 1 and self.linear_group is None:
             self.drop()                                      # everybody has theirs: keep nothing activation-sized
@@ -141,13 +142,24 @@ def _is_trans(m):
     return isinstance(m, OnlineTrans) and m.trans == "matmul" and m.decompose
 
 
-def fuse(model: torch.nn.Module, down_proj: bool = True, linears: bool = True, static_outputs: bool = False) -> dict:
+def fuse(model: torch.nn.Module, down_proj: bool = True, linears: bool = True, static_outputs: bool = False,
+         fp6_image=None, fp6_image_budget_bytes=None) -> dict:
     """Walk ``model`` (built by the reference's deploy/transformers/modeling_llama.py with ``import flatquant_amd.deploy as deploy``)
     and install the fused launches described in this module's docstring. Idempotent. ``static_outputs=True`` additionally sets the
     modules' opt-in static output plans (results rewritten by the next call of the same module — safe for the reference's forward,
     which consumes every result before the module is called again). Returns what was installed:
-    ``{"transform_groups": n, "linear_groups": n, "down_proj": n}``."""
+    ``{"transform_groups": n, "linear_groups": n, "down_proj": n}``.
+    ``fp6_image`` (True / False; None leaves the modules' policy alone) and ``fp6_image_budget_bytes`` set, on every Linear4bit of ``model``,
+    whether the layer keeps its FP6 operand image (+0.75 B/param, the prefill GEMM 1.6x faster) and the cap on what all images may hold
+    together — the memory side of the deployment in the one call that configures it (INTEGRATION.md "Memory")."""
     report = {"transform_groups": 0, "linear_groups": 0, "down_proj": 0}
+    if fp6_image is not None or fp6_image_budget_bytes is not None:
+        for mod in model.modules():
+            if isinstance(mod, Linear4bit):
+                if fp6_image is not None:
+                    mod.fp6_image = bool(fp6_image)
+                if fp6_image_budget_bytes is not None:
+                    mod.fp6_image_budget_bytes = int(fp6_image_budget_bytes)
     for mod in list(model.modules()):
         for tnames, lnames in ((("inp_trans_q", "inp_trans_k", "inp_trans_v"), ("q_proj", "k_proj", "v_proj")),
                                (("inp_trans_u", "inp_trans_g"), ("up_proj", "gate_proj"))):

@@ -37,12 +37,14 @@ class Linear4bit(torch.nn.Module):
     decode_image = True   # class-wide policy switches (set on the class or on an instance)
     fp6_gemm = True       # False: no FP6 route at all
     fp6_image = True      # (round 5) kept by default for layers of >= fp6_min_out_features outputs while the device has room for it
+    fp6_image_budget_bytes = None   # explicit cap on the bytes ALL layers' kept FP6 images may hold together (None: the free-memory rule below)
+    _fp6_image_bytes_held = 0       # (class-wide account of the kept images)
     fp6_image_min_free = 0.10   # ... i.e. while at least this fraction of the device memory would stay free after building the image;
                                 # otherwise (and with fp6_image = False) a prefill call converts the weights for the call (transient route)
     fp6_min_out_features = 2048   # narrower layers stay on the int8 matrix path (kept image AND transient route)
     fp6_transient_rows = 129    # calls with at least this many tokens convert the weights for the call when no image is kept (0: never).
                                 # 129 = everything above the decode kernel's range: measured with both conversions inside the call
-                                # (tools/scratch/gemm_small_m.py), 129 tokens x 4096 x 4096: 34.6 us against 45.6 on the int8 path,
+                                # (tools/microbench/gemm_small_m.py), 129 tokens x 4096 x 4096: 34.6 us against 45.6 on the int8 path,
                                 # K = 11008: 55 against 111
 
     def __init__(self, in_features, out_features, bias=False, dtype=torch.float16):
@@ -65,22 +67,43 @@ class Linear4bit(torch.nn.Module):
             return None
         if self.out_features < self.fp6_min_out_features:
             return None
-        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        key = (self.weight.data_ptr(), ops.ver(self.weight), self.weight.device)
         if getattr(self, "_wimg_key", None) != key:
-            self._wimg = None
-            free, total = torch.cuda.mem_get_info(self.weight.device)
+            self._drop_wimg()
             need = self.weight.numel() * 3 // 2            # 0.75 B/param on top of the 0.5 B/param of `weight`
-            if free - need >= self.fp6_image_min_free * total:
+            if self._image_room(need):
                 self._wimg = ops.int4_to_bf6(self.weight, weights=True)
-            self._wimg_key = key
+                Linear4bit._fp6_image_bytes_held += need
+                self._wimg_need = need
+                self._wimg_key = key
+            # (a refusal is NOT remembered: the next prefill call asks again — memory may have been released, a budget raised)
         return self._wimg
+
+    def _drop_wimg(self):
+        if getattr(self, "_wimg", None) is not None:
+            Linear4bit._fp6_image_bytes_held -= getattr(self, "_wimg_need", 0)
+        self._wimg = None
+        self._wimg_key = None
+
+    def _image_room(self, need: int) -> bool:
+        """May this layer keep ``need`` more bytes of FP6 image? With an explicit ``fp6_image_budget_bytes`` (class or instance attribute;
+        deploy.fuse(model, fp6_image_budget_bytes=...)): while the images of ALL layers stay within it — the deployment's own number, which
+        knows about KV-page growth and other processes. Without one: while ``fp6_image_min_free`` of the device would stay free, counting
+        what torch's caching allocator holds but has not handed out as free (mem_get_info alone does not see it)."""
+        budget = self.fp6_image_budget_bytes
+        if budget is not None:
+            return Linear4bit._fp6_image_bytes_held + need <= budget
+        dev = self.weight.device
+        free, total = torch.cuda.mem_get_info(dev)
+        free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        return free - need >= self.fp6_image_min_free * total
 
     def _scales16(self):
         """(weight_scales as a flat fp16 vector, bias as fp16 or None), converted once per buffer version: the buffers are
         fp32 unless the model was built under a fp16 default dtype, and a conversion launch per call costs more than the
         decode-sized GEMM itself."""
         b = self.bias
-        key = (self.weight_scales.data_ptr(), self.weight_scales._version, None if b is None else (b.data_ptr(), b._version))
+        key = (self.weight_scales.data_ptr(), ops.ver(self.weight_scales), None if b is None else (b.data_ptr(), ops.ver(b)))
         if getattr(self, "_s16_key", None) != key:
             self._s16 = (self.weight_scales.reshape(-1).to(torch.float16).contiguous(),
                          None if b is None else b.to(torch.float16).contiguous())
@@ -92,7 +115,7 @@ class Linear4bit(torch.nn.Module):
         FP6 image. ``decode_image = False`` turns the path off."""
         if not self.decode_image or self.in_features % 64:
             return None
-        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        key = (self.weight.data_ptr(), ops.ver(self.weight), self.weight.device)
         if getattr(self, "_dimg_key", None) != key:
             self._dimg = ops.int4_to_frag(self.weight)
             self._dimg_key = key
@@ -100,7 +123,8 @@ class Linear4bit(torch.nn.Module):
 
     def release_images(self):
         """Drop the cached operand images and fp16 scale / bias copies (they are rebuilt on demand)."""
-        for name in ("_wimg", "_wimg_key", "_dimg", "_dimg_key", "_s16", "_s16_key"):
+        self._drop_wimg()
+        for name in ("_wimg", "_wimg_key", "_wimg_need", "_dimg", "_dimg_key", "_s16", "_s16_key"):
             if hasattr(self, name):
                 delattr(self, name)
 
@@ -122,8 +146,8 @@ class Linear4bit(torch.nn.Module):
             if st is not None:
                 bf = self._buffers
                 w = bf["weight"]
-                if (st[0] is w and st[1] == w._version and st[2] == bf["weight_scales"]._version
-                        and st[3] == (-1 if self.bias is None else self.bias._version) and st[4] == ops.cache_epoch()
+                if (st[0] is w and st[1] == ops.ver(w) and st[2] == ops.ver(bf["weight_scales"])
+                        and st[3] == (-1 if self.bias is None else ops.ver(self.bias)) and st[4] == ops.cache_epoch()
                         and scales_x.dtype == torch.float16 and scales_x.is_contiguous() and scales_x.numel() == st[5].args[5]):
                     return st[5].run2(q, scales_x)      # (run() checks q's shape, dtype, device and contiguity)
                 del self.__dict__["_plan_state"]
@@ -138,8 +162,8 @@ class Linear4bit(torch.nn.Module):
                 plan.shape = q.shape                         # (run() compares the caller's own shape: no reshape per call)
                 plan.result = plan.outputs.view(*lead, self.out_features)
                 bf = self._buffers
-                self.__dict__["_plan_state"] = (bf["weight"], bf["weight"]._version, bf["weight_scales"]._version,
-                                                -1 if self.bias is None else self.bias._version, ops.cache_epoch(), plan)
+                self.__dict__["_plan_state"] = (bf["weight"], ops.ver(bf["weight"]), ops.ver(bf["weight_scales"]),
+                                                -1 if self.bias is None else ops.ver(self.bias), ops.cache_epoch(), plan)
                 return plan.run2(q, scales_x)
             if (dimg is not None and self.fast_path and q.is_contiguous() and scales_x.is_contiguous() and scales_x.dtype == torch.float16
                     and scales_x.numel() == rows and not torch.cuda.is_current_stream_capturing()):
@@ -149,7 +173,7 @@ class Linear4bit(torch.nn.Module):
                 st = self.__dict__.get("_fresh_state")
                 if st is None:
                     st = self.__dict__["_fresh_state"] = ops.FreshPlanSet()
-                plan = st.lookup((id(w), w._version, bf["weight_scales"]._version, -1 if self.bias is None else self.bias._version,
+                plan = st.lookup((id(w), ops.ver(w), ops.ver(bf["weight_scales"]), -1 if self.bias is None else ops.ver(self.bias),
                                   ops.cache_epoch()), q)
                 if plan is None:
                     ws16, b16 = self._scales16()

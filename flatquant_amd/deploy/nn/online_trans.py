@@ -51,8 +51,8 @@ class OnlineTrans(torch.nn.Module):
         bf = self._buffers
         L, R, cmax, cmin = bf["left_matrix"], bf["right_matrix"], bf["clip_factor_a_max"], bf["clip_factor_a_min"]
         st = self.__dict__.get("_plan_state")
-        if (st is None or st[0] is not L or st[1] != L._version or st[2] is not R or st[3] != R._version or st[4] != cmax._version
-                or st[5] != cmin._version or st[6] != ops.cache_epoch() or st[7].shape != x.shape or st[7].dtype != x.dtype
+        if (st is None or st[0] is not L or st[1] != ops.ver(L) or st[2] is not R or st[3] != ops.ver(R) or st[4] != ops.ver(cmax)
+                or st[5] != ops.ver(cmin) or st[6] != ops.cache_epoch() or st[7].shape != x.shape or st[7].dtype != x.dtype
                 or st[7].device != x.device):
             from .. import PackedQuantizedTensor
             bsz, seq_len, _ = x.shape
@@ -61,7 +61,7 @@ class OnlineTrans(torch.nn.Module):
                                  functional.online_trans.deploy_kron_flags(L.shape[0], R.shape[0]))
             o = plan.outputs
             plan.result = PackedQuantizedTensor(o.q[0].reshape(bsz, seq_len, -1), o.scale[0].reshape(bsz, 1, seq_len))
-            st = (L, L._version, R, R._version, cmax._version, cmin._version, ops.cache_epoch(), plan)
+            st = (L, ops.ver(L), R, ops.ver(R), ops.ver(cmax), ops.ver(cmin), ops.cache_epoch(), plan)
             self.__dict__["_plan_state"] = st
         return st[7].run(x)
 
@@ -75,12 +75,12 @@ class OnlineTrans(torch.nn.Module):
         cmax, cmin = bf.get("clip_factor_a_max"), bf.get("clip_factor_a_min")
         if cmax is None or cmin is None:
             cmax, cmin = self.clip_factor_a_max, self.clip_factor_a_min
-        kmax = (id(cmax), cmax._version) if isinstance(cmax, torch.Tensor) else cmax
-        kmin = (id(cmin), cmin._version) if isinstance(cmin, torch.Tensor) else cmin
+        kmax = (id(cmax), ops.ver(cmax)) if isinstance(cmax, torch.Tensor) else cmax
+        kmin = (id(cmin), ops.ver(cmin)) if isinstance(cmin, torch.Tensor) else cmin
         st = self.__dict__.get("_fresh_state")
         if st is None:
             st = self.__dict__["_fresh_state"] = ops.FreshPlanSet()
-        plan = st.lookup((id(L), L._version, id(R), R._version, kmax, kmin, ops.cache_epoch()), x)
+        plan = st.lookup((id(L), ops.ver(L), id(R), ops.ver(R), kmax, kmin, ops.cache_epoch()), x)
         if plan is None:
             bsz, seq_len, d = x.shape
             plan = st.add(x, ops.kron_fresh_plan(x, L.contiguous(), R.contiguous(), ops.sigmoid_pair(cmax, cmin),

@@ -28,7 +28,7 @@ class Quantizer(torch.nn.Module):
         bf = self._buffers
         cmax, cmin = bf["clip_factor_a_max"], bf["clip_factor_a_min"]
         st = self.__dict__.get("_plan_state")
-        if (st is None or st[0] != cmax._version or st[1] != cmin._version or st[2] != ops.cache_epoch() or st[3] != self.lac
+        if (st is None or st[0] != ops.ver(cmax) or st[1] != ops.ver(cmin) or st[2] != ops.cache_epoch() or st[3] != self.lac
                 or st[4] != self.input_clip_ratio or st[5].shape != x.shape or st[5].dtype != x.dtype or st[5].device != x.device):
             if self.lac:
                 sig = ops.sigmoid_pair_f16(cmax, cmin)
@@ -37,7 +37,7 @@ class Quantizer(torch.nn.Module):
             else:
                 plan = ops.rowquant_plan(x, [(float(self.input_clip_ratio), 1.0)], FQ_OUT_PACKED | FQ_QUANT_F16 | FQ_RATIO_POST)
                 plan.result = PackedQuantizedTensor(plan.outputs.q[0], plan.outputs.scale[0].reshape(x.shape[:-1]).unsqueeze(1))
-            st = (cmax._version, cmin._version, ops.cache_epoch(), self.lac, self.input_clip_ratio, plan)
+            st = (ops.ver(cmax), ops.ver(cmin), ops.cache_epoch(), self.lac, self.input_clip_ratio, plan)
             self.__dict__["_plan_state"] = st
         return st[5].run(x)
 
@@ -48,8 +48,8 @@ class Quantizer(torch.nn.Module):
         cmax, cmin = bf.get("clip_factor_a_max"), bf.get("clip_factor_a_min")
         if cmax is None or cmin is None:   # (Python floats after the reference's loader, modeling_llama.py:532-538)
             cmax, cmin = self.clip_factor_a_max, self.clip_factor_a_min
-        kmax = (id(cmax), cmax._version) if isinstance(cmax, torch.Tensor) else cmax
-        kmin = (id(cmin), cmin._version) if isinstance(cmin, torch.Tensor) else cmin
+        kmax = (id(cmax), ops.ver(cmax)) if isinstance(cmax, torch.Tensor) else cmax
+        kmin = (id(cmin), ops.ver(cmin)) if isinstance(cmin, torch.Tensor) else cmin
         st = self.__dict__.get("_fresh_state")
         if st is None:
             st = self.__dict__["_fresh_state"] = ops.FreshPlanSet()
@@ -82,7 +82,7 @@ class Quantizer(torch.nn.Module):
         # (max|x| / 7).to(fp16) * ratio (quantization.py:30), one launch: FQ_RATIO_POST applies the factor to the scale
         # (ratio == 1: the product is the identity, and — like the reference, which has no zero guard on this branch — an all-zero
         # row keeps scale 0); the scales keep the shape of `torch.max(..., dim=-1)[0].unsqueeze(1)`
-        # (a PYTHON scalar keeps its fp32 value in torch's mul — unlike the 0-dim tensor of the lac branch; tools/scratch/
+        # (a PYTHON scalar keeps its fp32 value in torch's mul — unlike the 0-dim tensor of the lac branch; tools/microbench/
         #  dbg_ratio.py: torch-ROCm's own kernel agrees with fp16(fp32(s) * fp32(r)) on 95-99 % of the rows and is one fp16 step
         #  off on the rest, in a pattern no plain rounding reproduces; the CPU and the oracle give exactly this product)
         ratio = float(self.input_clip_ratio)

@@ -170,7 +170,7 @@ class MultiLayerPagedKVCache4Bit:
         if layer_idx == 0:
             self._ensure_page_cnt_per_batch(self.page_cnt_from_length(self.length + added))
             self.length += added
-        key = (self.length, self.pages.data_ptr(), None if mask is None else (mask.data_ptr(), mask._version, tuple(mask.shape)))
+        key = (self.length, self.pages.data_ptr(), None if mask is None else (mask.data_ptr(), ops.ver(mask), tuple(mask.shape)))
         if getattr(self, "_specs_key", None) != key:   # index tensors: once per step, not per layer
             self._specs, self._specs_key = self.get_cache_specs_for_flash_infer(mask), key
         specs = self._specs

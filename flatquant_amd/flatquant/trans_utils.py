@@ -33,7 +33,7 @@ class _Fp16Cache:
         self._c = {}
 
     def get(self, p: torch.Tensor, device, dtype=torch.float16) -> torch.Tensor:
-        key = (p.data_ptr(), p._version, str(device), dtype)
+        key = (p.data_ptr(), ops.ver(p), str(device), dtype)
         hit = self._c.get(key)
         if hit is not None:
             return hit[0]

@@ -37,7 +37,7 @@ def sigmoid_pair_f16(clip_max, clip_min) -> Sig:
     """sigmoid_pair rounded to fp16: what a DEVICE multiplies an fp16 tensor with when the other operand is a 0-dim fp32
     tensor (deploy/nn/quantization.py:21-22, deploy/functional/online_trans.py:97-98 move the 0-dim sigmoid to x's device;
     torch's device kernels cast a 0-dim operand to the result dtype on load — measured on MI355X,
-    tools/scratch/sig_f16_probe.py: every finite fp16 extremum agrees with fp16(x * fp16(sigmoid)); the CPU keeps the fp32
+    tools/microbench/sig_f16_probe.py: every finite fp16 extremum agrees with fp16(x * fp16(sigmoid)); the CPU keeps the fp32
     value). The product of two fp16 values is exact in fp32, so FQ_SIG_F16 then rounds once."""
     return _sig_f16_cached(*sigmoid_pair(clip_max, clip_min))
 
@@ -52,6 +52,15 @@ _SCALARS: "collections.OrderedDict" = collections.OrderedDict()
 
 
 _CACHE_EPOCH = [0]
+
+
+def ver(t: torch.Tensor) -> int:
+    """``t._version`` for the cache keys of this package — 0 for an INFERENCE tensor, which has no version counter (reading it raises
+    "Inference tensors do not track version counter"): the reference decorates its generation and benchmark entry points with
+    ``@torch.inference_mode()`` (benchmarks/qlinear_benchmark.py builds its modules inside one), so buffers created and activations
+    produced there are inference tensors. They cannot be written in place outside inference mode at all; a caller that rewrites one in
+    place INSIDE inference mode (no counter to see it by) calls invalidate_caches(), as after a write through ``.data``."""
+    return 0 if t.is_inference() else t._version
 
 
 def cache_epoch() -> int:
@@ -93,7 +102,7 @@ def host_scalar(v) -> float:
         return float(v)
     if not v.is_cuda:
         return float(v)
-    key = (v.data_ptr(), v._version)
+    key = (v.data_ptr(), ver(v))
     hit = _SCALARS.get(key)
     if hit is not None:
         return hit[0]
@@ -281,7 +290,7 @@ def _kron_workspace(device: torch.device, M: int, N: int, left: torch.Tensor, ri
     if nbytes == 0:   # (no pair has a zero-size workspace since round 3: 64 x 64 takes its optional 32 KB image)
         return None, 0, False, None
     key = (device.index, _stream_handle(device), M, N,
-           left.data_ptr(), left._version, right.data_ptr(), right._version)
+           left.data_ptr(), ver(left), right.data_ptr(), ver(right))
     ent = _WS_LRU.get(key)
     if ent is not None:
         _WS_LRU.move_to_end(key)
@@ -752,7 +761,7 @@ def _hadamard_as_kron(K: int, P: int, hadK: Optional[torch.Tensor], device):
         # factor pairs with a packed-only kernel of their own: M in (64, 128] with N = 128 (three token groups per CU),
         # M in (96, 128] with N = 256 (workgroup per token), M in (64, 192] with N = 64 (a wave per row tile: 11008 = 172 x 64)
         if (N == 128 and 64 < M <= 128) or (N == 256 and 96 < M <= 128) or (N == 64 and 64 < M <= 192):
-            key = (hadK.data_ptr(), hadK._version, K, P, N, str(device))
+            key = (hadK.data_ptr(), ver(hadK), K, P, N, str(device))
             hit = _HAD_KRON.get(key)
             if hit is None:
                 # out = hadK @ x.view(K, P): Y = L^T U contracts L's FIRST index, so L = kron(hadK, H)^T = kron(hadK^T, H)
@@ -825,7 +834,7 @@ def kron_quant_grouped(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor,
             if per < 0:
                 raise _lib.FqError(per, f"no kernel for Kronecker factors ({M}, {N})")
             key = (x.device.index, _stream_handle(x.device), M, N, G,
-                   left.data_ptr(), left._version, right.data_ptr(), right._version)
+                   left.data_ptr(), ver(left), right.data_ptr(), ver(right))
             ent = _WS_LRU.get(key)
             if ent is None:
                 ent = _ws_shared(key)      # (prepared on another stream: see _kron_workspace)
@@ -1605,7 +1614,35 @@ def kv_quant_append(k: torch.Tensor, v: torch.Tensor, trans: Optional[torch.Tens
                                         _stream(k)))
 
 
-_KV_SPLIT_WS: dict = {}   # (device index, stream handle, pairs, head_dim) -> zeroed workspace of the split decode launches (one launch at a time per stream)
+# Workspaces of the split decode launches: (device index, stream handle, pairs, head_dim) -> a buffer ZEROED EAGERLY once (the launches leave its
+# counters as they found them), used by one launch at a time in stream order. ADVICE r05: never created inside a stream capture — a torch.zeros
+# there is a memset NODE of that graph in that graph's private pool: a second graph captured on the same stream would find the cached buffer, record
+# no memset, and replayed first would read garbage counters. A capture that finds no workspace runs the unsplit launch (same results up to
+# the order of fp32 additions); warm the shape up eagerly on the capture stream first (tools/bench_decode.py does; torch.cuda.graph's own
+# warm-up convention). An entry a capture HAS used is pinned (the graph replays its address); the others are bounded, least recently used first.
+_KV_SPLIT_WS: "collections.OrderedDict" = collections.OrderedDict()
+_KV_SPLIT_WS_PINNED: dict = {}
+_KV_SPLIT_WS_MAX = 16
+
+
+def _kv_split_workspace(key, nbytes: int, device) -> Optional[torch.Tensor]:
+    capturing = torch.cuda.is_current_stream_capturing()
+    ws = _KV_SPLIT_WS_PINNED.get(key)
+    if ws is not None:
+        return ws
+    ws = _KV_SPLIT_WS.get(key)
+    if ws is None:
+        if capturing:
+            return None
+        ws = torch.zeros((nbytes,), dtype=torch.uint8, device=device)
+        _KV_SPLIT_WS[key] = ws
+        while len(_KV_SPLIT_WS) > _KV_SPLIT_WS_MAX:
+            _KV_SPLIT_WS.popitem(last=False)
+    else:
+        _KV_SPLIT_WS.move_to_end(key)
+    if capturing:
+        _KV_SPLIT_WS_PINNED[key] = _KV_SPLIT_WS.pop(key)
+    return ws
 
 
 def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tensor, kv_indptr: torch.Tensor,
@@ -1631,12 +1668,9 @@ def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tens
         return o
     with _on(q.device):
         nbytes = int(lib.fq_kv_decode_workspace_bytes(batch, heads, hd)) if split else 0
-        if nbytes > 0:
-            stream = _stream(q)
-            key = (q.device.index, stream.value, batch * heads, hd)   # (one per geometry: the counters sit in front of the states)
-            ws = _KV_SPLIT_WS.get(key)
-            if ws is None:   # (never freed: a captured graph may hold its address; a few hundred KB per geometry and stream)
-                ws = _KV_SPLIT_WS[key] = torch.zeros((nbytes,), dtype=torch.uint8, device=q.device)
+        stream = _stream(q)
+        ws = _kv_split_workspace((q.device.index, stream.value, batch * heads, hd), nbytes, q.device) if nbytes > 0 else None
+        if ws is not None:
             check(lib.fq_kv_batch_decode_split(1 if f16_cache else 0, _ptr(o), _ptr(q), _ptr(q_trans), 1 if transpose_out else 0, _ptr(kv_data),
                                                _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
                                                n_layers, layer_idx, heads, page_size, hd, batch, int(seq_hint), _ptr(ws), nbytes, stream))

@@ -57,3 +57,41 @@ def same_bits(a, b):
     way — the reference's round_ste never returns -0.0 and neither may the kernels (rule 10)."""
     a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
     return a.shape == b.shape and a.dtype == b.dtype == np.float16 and np.array_equal(a.view(np.uint16), b.view(np.uint16))
+
+
+_FLIPS = []
+
+
+def flip_ok(qa, qb, site, bound=1e-3, max_step=1):
+    """INT4 digits (or fake-quant values) of two routes that share the arithmetic up to rounding noise: the fraction that differs is
+    RECORDED (profiles/r06_flip_rates.txt is the session's list, written to gpurun_out/flip_rates.txt on the GPU box) and bounded by
+    SURVEY 7's 1e-3 — `bound` is larger only where the site says why (a population of a few rows, where one row with a one-ulp scale
+    difference is already 1e-3 of the digits)."""
+    qa, qb = np.asarray(qa), np.asarray(qb)
+    rate = float(np.mean(qa != qb))
+    _FLIPS.append((site, int(qa.size), rate, bound))
+    ok = rate <= bound
+    if ok and max_step is not None and qa.dtype.kind in "iu":
+        ok = int(np.max(np.abs(qa.astype(np.int32) - qb.astype(np.int32)))) <= max_step
+    return ok
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _FLIPS:
+        return
+    try:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "flip_rates.txt"), "w") as fh:
+            fh.write("# site | digits compared | fraction that differs | bound asserted\n")
+            for site, n, rate, bound in _FLIPS:
+                fh.write(f"{site:70s} {n:10d} {rate:.3e} {bound:.1e}\n")
+    except OSError:
+        pass
+
+
+# Small-sample sites (a few dozen rows): ONE row whose fp16 scale lands one ulp away from the other route's re-quantises with a
+# different step and can differ on a few per cent of ITS digits — 1e-3 of a 37-row population. These sites therefore keep round 4's
+# 2e-3 as the assertion, record what they measure (profiles/r06_flip_rates.txt), and the >= 1e6-digit populations of
+# tests/test_gpu_flip_rates.py hold every route to SURVEY 7's 1e-3.
+BOUND37 = 2e-3

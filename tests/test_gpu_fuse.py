@@ -175,3 +175,30 @@ def test_default_module_path_returns_fresh_outputs_and_follows_updates():
     lin.fast_path = False
     y0 = lin(pk)
     assert y1.data_ptr() != y2.data_ptr() and torch.equal(y1, y0) and torch.equal(y2, y0) and y1.shape == (2, 4, 1024)
+
+
+@pytest.mark.parametrize("bsz,seq", [(2, 160), (1, 4)])
+def test_modules_built_and_called_under_inference_mode(bsz, seq):
+    """the reference decorates its generation / benchmark entry points with @torch.inference_mode() and
+    benchmarks/qlinear_benchmark.py builds its modules inside one — inference tensors have no version counter (``t._version`` raises).
+    Modules built INSIDE inference mode, called there, fused there: the bits of the same layer under no_grad."""
+    import flatquant_amd.deploy as deploy
+    from ref_layer import RefLayer
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x = torch.randn(bsz, seq, 4096, generator=g, device="cuda", dtype=torch.float16)
+    with torch.no_grad():
+        want = RefLayer("tiny", seed=7)(x)
+    with torch.inference_mode():
+        layer = RefLayer("tiny", seed=7)
+        assert layer.self_attn.q_proj.weight.is_inference()
+        xi = x.clone()
+        assert xi.is_inference()
+        for a, b in zip(layer(xi), want):                     # the default prepared-call paths (Quantizer._fresh, OnlineTrans._fresh, Linear4bit plans)
+            assert torch.equal(a, b)
+        deploy.fuse(layer)
+        for _ in range(2):
+            for a, b in zip(layer(xi), want):                 # TransformGroup.get on an inference activation
+                assert torch.equal(a, b)
+        q = deploy.nn.Quantizer(lac=True).to("cuda")
+        p = q(xi.reshape(-1, 4096))
+        assert p.quantized_x.shape == (bsz * seq, 2048)

@@ -241,3 +241,33 @@ def test_linear4bit_multi_module_entry(ops):
         for m, x, y in zip(mods, xs, ys):
             ref = m(x)
             assert y.shape == ref.shape and torch.equal(y.view(torch.int16), ref.view(torch.int16)), (rows, m.out_features)
+
+
+def test_fp6_image_budget_is_honoured_and_a_refusal_is_not_latched(ops):
+    """an explicit budget for the kept FP6 images of ALL layers (deploy.fuse(model, fp6_image_budget_bytes=...)); a layer the budget
+    refuses runs the transient route and asks again at its next prefill call; release_images() returns its bytes to the account."""
+    import flatquant_amd.deploy as deploy
+    L4 = deploy.nn.Linear4bit
+    gen = torch.Generator().manual_seed(9)
+    held0 = L4._fp6_image_bytes_held
+    model = torch.nn.Sequential(L4(256, 272), L4(256, 272)).cuda()
+    need = 272 * 128 * 3 // 2
+    deploy.fuse(model, fp6_image=True, fp6_image_budget_bytes=held0 + need)       # room for ONE image
+    rows = L4.fp6_transient_rows + 3
+    p = deploy.PackedQuantizedTensor(torch.from_numpy(rand_packed(gen, rows, 256)[0]).cuda().reshape(1, rows, 128),
+                                     (torch.rand(1, 1, rows, generator=gen) * 0.05 + 0.001).half().cuda())
+    refs = []
+    for lin in model:
+        lin.fp6_min_out_features = 0
+        lin.weight.copy_(torch.from_numpy(rand_packed(gen, 272, 256)[0]))
+        lin.weight_scales.copy_((torch.rand(272, 1, generator=gen) * 0.02 + 0.001))
+        refs.append(ops.int4_linear(p.quantized_x.reshape(-1, 128), p.scales_x.reshape(-1), lin.weight, lin.weight_scales.reshape(-1).half(),
+                                    None).view(1, rows, 272))
+    assert torch.equal(model[0](p), refs[0]) and torch.equal(model[1](p), refs[1])
+    assert model[0].image_bytes() == need and model[1].image_bytes() == 0         # the second layer was refused (transient route: same bits)
+    assert L4._fp6_image_bytes_held == held0 + need
+    model[0].release_images()
+    assert L4._fp6_image_bytes_held == held0
+    assert torch.equal(model[1](p), refs[1]) and model[1].image_bytes() == need   # asked again, now there is room
+    model[1].release_images()
+    assert L4._fp6_image_bytes_held == held0

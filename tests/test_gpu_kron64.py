@@ -9,6 +9,8 @@ Everything goes through the C ABI (flatquant_amd.ops -> libfqhip.so).  Bars:
 """
 import numpy as np
 import pytest
+
+from conftest import BOUND37, flip_ok
 from tests.conftest import same_bits
 import torch
 
@@ -127,7 +129,7 @@ def test_vs_reference_path_a_and_b_goldens(ops, golden):
         assert mismatch(q, qa) <= 1e-3 and np.max(np.abs(q - qa)) <= 1
         fq, fa = o.fq[0].cpu().numpy().astype(np.float32), g[f"a16_lac{ci}_fq"].reshape(q.shape).astype(np.float32)
         assert np.max(np.abs(fq - fa) / (np.abs(fa).max(axis=1, keepdims=True))) <= 0.15  # one INT4 step at most
-        assert np.mean(fq != fa) <= 2e-3
+        assert flip_ok(fq, fa, "kron64 fake-quant vs path A golden", BOUND37)
     g = golden("kron_B_64x64")
     x, L, Rm = dev(g["x"]), dev(g["L"]), dev(g["R"])
     for ci in range(3):

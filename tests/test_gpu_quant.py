@@ -192,7 +192,7 @@ def test_functional_quant_lac_and_input_clip_ratio(ops, golden):
 def test_deploy_quantizer_lac_scales_equal_torch_device_ops(ops):
     """deploy/nn/quantization.py:15-28 evaluated by torch ON THE DEVICE, op for op (the reference never runs this module
     anywhere else: its pack kernel is CUDA): the 0-dim fp32 sigmoid is loaded in the result dtype by torch's device kernels,
-    so the extremum is multiplied with the fp16-ROUNDED sigmoid (tools/scratch/sig_f16_probe.py; round-2 ADVICE). The HIP
+    so the extremum is multiplied with the fp16-ROUNDED sigmoid (tools/microbench/sig_f16_probe.py; round-2 ADVICE). The HIP
     launch must give the same fp16 scales bit for bit — this is the live form of tests/golden/quantizer_lac.npz."""
     from flatquant_amd import deploy
     for ci, (cmax, cmin) in enumerate([(4.0, 4.0), (2.3, -0.7), (0.31, 1.9), (1.0, 3.0)]):
@@ -214,7 +214,7 @@ def test_input_clip_ratio_is_one_launch_and_matches_torch_device_ops(ops):
     """deploy.nn.Quantizer(input_clip_ratio=r) / functional.quant(input_clip_ratio=r) (quantization.py:30, online_trans.py:106):
     scale = (max|x| / 7).to(fp16) * r — FQ_RATIO_POST, one launch: the fp32 product rounded to fp16 (CPU torch; bit for bit
     against that expression evaluated in fp32 here). torch-ROCm's own mul kernel is one fp16 step off on a few per cent of the
-    rows (tools/scratch/dbg_ratio.py: no plain rounding reproduces its pattern): bounded, not imitated. Digits = sym_quant with
+    rows (tools/microbench/dbg_ratio.py: no plain rounding reproduces its pattern): bounded, not imitated. Digits = sym_quant with
     OUR scales bit for bit; shapes as the reference's ([rows, 1] for 2-D, [bsz, 1, seq] for 3-D); an all-zero row keeps scale 0."""
     from flatquant_amd import deploy
     from flatquant_amd.deploy.functional.online_trans import quant

@@ -7,6 +7,8 @@ stage stays bit-exact given the kernel's own transform output.
 """
 import numpy as np
 import pytest
+
+from conftest import BOUND37, flip_ok
 import torch
 
 from oracle import fq_oracle as O
@@ -102,7 +104,7 @@ def test_fused_vs_reference_path_b_golden(ops, golden):
     s = (float(g["sig"][0]), float(g["sig"][1]))
     o = ops.rmsnorm_kron_quant(dev(g["x_4096"]), 1e-5, dev(g["L"]), dev(g["R"]), [s], P | NC0)
     q, qr = O.unpack_i4(o.q[0].cpu().numpy()), O.unpack_i4(g["b_packed"])
-    assert np.mean(q != qr) <= 2e-3 and np.max(np.abs(q.astype(np.int32) - qr)) <= 1
+    assert flip_ok(q.astype(np.int32), qr, "rmsnorm+kron64 vs oracle", BOUND37)
     sg = o.scale[0].cpu().numpy().astype(np.float32).reshape(-1)
     assert np.max(np.abs(sg - g["b_scale"].astype(np.float32)) / g["b_scale"].astype(np.float32)) <= 1e-3
 
@@ -118,7 +120,7 @@ def test_online_trans_norm_argument(ops, golden):
     a, b = t(x, norm=norm), t(norm(x))
     qa, qb = O.unpack_i4(a.quantized_x.cpu().numpy()), O.unpack_i4(b.quantized_x.cpu().numpy())
     assert a.quantized_x.shape == b.quantized_x.shape and a.scales_x.shape == b.scales_x.shape
-    assert np.mean(qa != qb) <= 2e-3 and np.max(np.abs(qa.astype(np.int32) - qb)) <= 1
+    assert flip_ok(qa.astype(np.int32), qb, "rmsnorm fused vs two launches", BOUND37)
     assert torch.allclose(a.scales_x.float(), b.scales_x.float(), rtol=1e-3, atol=0)
 
 
@@ -187,11 +189,11 @@ def test_fused_rmsnorm_on_the_wave_per_token_pairs(ops, M, N):
     for ci, (a, b) in enumerate(sigs):
         assert torch.equal(fused.q[ci], again.q[ci]) and torch.equal(fused.scale[ci], again.scale[ci])
         qf, q2 = O.unpack_i4(fused.q[ci].cpu().numpy()), O.unpack_i4(two.q[ci].cpu().numpy())
-        assert np.mean(qf != q2) <= 2e-3 and np.max(np.abs(qf - q2)) <= 1, (M, N, ci)
+        assert flip_ok(qf, q2, f"rmsnorm+wave {M}x{N} clip {ci} vs two launches", BOUND37), (M, N, ci)
         sf, s2 = fused.scale[ci].float().cpu().numpy(), two.scale[ci].float().cpu().numpy()
         assert np.max(np.abs(sf - s2) / np.maximum(s2, 1e-30)) <= 1e-3
         ref = O.kron_quant(xn, L, R, a, b, clamp0=False)
-        assert np.mean(qf != ref["q"]) <= 2e-3 and np.max(np.abs(qf - ref["q"].astype(np.int32))) <= 1
+        assert flip_ok(qf, ref["q"].astype(np.int32), f"rmsnorm+wave {M}x{N} vs oracle", BOUND37)
     # a single-clip launch larger than one round of resident waves (the persistent loop, counted waits)
     big = dev(np.tile(x, (40, 1)))
     fb = ops.rmsnorm_kron_quant(big, 1e-5, Ld, Rd, [sigs[0]], P | NC0)

@@ -3,6 +3,8 @@ contracts of SURVEY 8c (FlatQuantizedLinear._eval_forward, {Inv,SVD}DecomposeTra
 SVDSingleTransMatrix.forward on the HIP path), deploy.nn.Quantizer(lac=True), row shards through the kernel."""
 import numpy as np
 import pytest
+
+from conftest import BOUND37, flip_ok
 from tests.conftest import same_bits
 import torch
 
@@ -119,20 +121,20 @@ def test_moe_routed_experts_match_reference_flow(ops, golden):
     o = ops.kron_quant(dev(g["x"]), dev(g["L1"]), dev(g["R1"]), [s1], F | T | R16)
     assert rel_err(host(o.y), g["xt"]) <= 1e-3
     fq1 = host(o.fq[0][tok_idx])
-    assert np.mean(fq1 != g["fq1"]) <= 2e-3 and rel_err(fq1, g["fq1"]) <= 0.08      # (one INT4 step of a 4-bit grid)
+    assert flip_ok(fq1, g["fq1"], "moe flow fq1 vs reference golden", BOUND37) and rel_err(fq1, g["fq1"]) <= 0.08      # (one INT4 step of a 4-bit grid)
     assert same_bits(host(o.fq[0]), O.quant_outputs(host(o.y).astype(np.float32), *s1)["fq"])
     # stage 2: grouped launch, shared transform + the shared quantiser expanded per expert
     s2 = np.tile(g["sig2"][None, :], (E, 1)).astype(np.float32)
     h = dev(g["h"])
     o2 = ops.kron_quant_grouped(h, dev(g["L2"]), dev(g["R2"]), offsets, dev(s2[:, 0]), dev(s2[:, 1]), F | T | R16)
     assert rel_err(host(o2.y), g["y2_shared"]) <= 1e-3
-    assert np.mean(host(o2.fq[0]) != g["fq2_shared"]) <= 2e-3
+    assert flip_ok(host(o2.fq[0]), g["fq2_shared"], "moe flow fq2 shared vs reference golden", BOUND37)
     # per-expert transforms and quantisers (the routed_w2_trans[i] branch)
     o3 = ops.kron_quant_grouped(h, dev(g["L2e"]), dev(g["R2e"]), offsets, dev(g["sig2e"][:, 0].copy()),
                                 dev(g["sig2e"][:, 1].copy()), F | R16)
-    assert np.mean(host(o3.fq[0]) != g["fq2_indep"]) <= 2e-3
+    assert flip_ok(host(o3.fq[0]), g["fq2_indep"], "moe flow fq2 per-expert vs reference golden", BOUND37)
     ref = O.kron_quant_grouped(g["h"], g["L2e"], g["R2e"], offs, g["sig2e"][:, 0], g["sig2e"][:, 1], round_y_f16=True)
-    assert np.mean(host(o3.fq[0]) != ref["fq"]) <= 2e-3
+    assert flip_ok(host(o3.fq[0]), ref["fq"], "moe flow fq2 per-expert vs oracle", BOUND37)
 
 
 # ------------------------------------------------------------------------------------------- 128-element scales
@@ -152,7 +154,7 @@ def test_group128_scales(ops, golden, tag):
         assert np.array_equal(host(o.scale[0]), ref["scale16"])
         o = ops.kron_quant(x, L, R, [sig], F | R16, groupsize=128)
         assert same_bits(host(o.fq[0]), ref["fq"])
-        assert np.mean(host(o.fq[0]) != g[f"{tag}_fq{ci}"]) <= 2e-3       # vs the reference's vLLM ActivationQuantizer
+        assert flip_ok(host(o.fq[0]), g[f"{tag}_fq{ci}"], f"group128 {tag} clip {ci} vs reference golden", BOUND37)       # vs the reference's vLLM ActivationQuantizer
     if tag in ("32x64", "64x64"):                                         # grouped + 128-element scales in one launch
         offs = dev(np.array([0, 1, 1, rows], dtype=np.int64))
         sm, sn = dev(np.array([0.9, 0.5, 0.7], np.float32)), dev(np.array([0.8, 0.5, 0.6], np.float32))
@@ -321,7 +323,7 @@ def test_grouped_launch_with_one_factor_pair_per_group(ops, shape, dtype):
         g = np.load(os.path.join(os.path.dirname(__file__), "golden", "moe_grouped.npz"))
         o3 = ops.kron_quant_grouped(dev(g["h"]), dev(g["L2e"]), dev(g["R2e"]), dev(g["offsets"]), dev(g["sig2e"][:, 0].copy()),
                                     dev(g["sig2e"][:, 1].copy()), F | R16)
-        assert np.mean(host(o3.fq[0]) != g["fq2_indep"]) <= 2e-3
+        assert flip_ok(host(o3.fq[0]), g["fq2_indep"], "moe bf16/again fq2 per-expert vs golden", BOUND37)
 
 
 def test_launch_plans_and_static_output_modules():

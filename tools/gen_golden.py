@@ -623,7 +623,7 @@ def gen_quantizer_lac():
     # Accommodation 4 (round 3, harness side; no reference file touched): DEVICE semantics of `fp16 tensor * 0-dim fp32
     # tensor`. The reference moves the 0-dim sigmoid to x's device (quantization.py:21-22 `.to(x.device)`); torch's device
     # kernels cast a 0-dim operand to the result dtype on load, so the product is fp16(x * fp16(sigmoid)) — measured on the
-    # MI355X with tools/scratch/sig_f16_probe.py: 63487 of 63487 finite fp16 extrema agree with that form for four clip values,
+    # MI355X with tools/microbench/sig_f16_probe.py: 63487 of 63487 finite fp16 extrema agree with that form for four clip values,
     # 44667-56899 with the CPU's fp16(x * fp32 sigmoid). The deploy modules only ever run on a device (their pack kernel is
     # CUDA), so the device form is the contract: the module runs here with torch.sigmoid's result rounded to fp16.
     class _DeviceSigmoid:

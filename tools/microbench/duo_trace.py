@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase stamps of fq_kron_duo_kernel (measurement build -DDUO_TRACE=<workgroup>): FQHIP_LIB=variants/libfqhip_dtrace.so
-python tools/scratch/duo_trace.py.  Prints, per wave and iteration, the s_memtime deltas between the stamps."""
+python tools/microbench/duo_trace.py.  Prints, per wave and iteration, the s_memtime deltas between the stamps."""
 import ctypes
 import os
 import sys

@@ -1,8 +1,8 @@
 // Round 4: exhaustive check of the two-operation exact fp16 quotient of fq_quant8_h16 (fq_common.hpp):
 //   rhi = RN32(1 / s), rlo = RN32(fma(-s, rhi, 1) rhi);  t = fma(x, rhi, RN32(x rlo));  RN16(t) == x /h s  (native _Float16 division,
-//   itself checked against the correctly rounded quotient for all 2^32 pairs by tools/scratch/h16div.hip)
+//   itself checked against the correctly rounded quotient for all 2^32 pairs by tools/microbench/h16div.hip)
 // for EVERY finite fp16 x and EVERY positive finite fp16 s (65536 x 31743 pairs), through the same v_fma_mix_f32 instructions.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/scratch/h16div2 tools/scratch/h16div2.hip && gpurun -- tools/scratch/h16div2
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/microbench/h16div2 tools/microbench/h16div2.hip && gpurun -- tools/microbench/h16div2
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "../../flatquant_amd/csrc/fq_common.hpp"

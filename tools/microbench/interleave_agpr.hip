@@ -5,7 +5,7 @@
 //   MIXED:  (1 MFMA, NV / 32 VALU) x 32, independent    (a software-pipelined token loop: token i + 1's MFMAs between token i's
 //                                                         quantiser instructions)
 // at W waves per SIMD. Reported: shader cycles per iteration per SIMD (all W waves), and per wave-iteration.
-//   hipcc --offload-arch=gfx950 -O3 -o tools/scratch/interleave tools/scratch/interleave.hip && gpurun -- tools/scratch/interleave
+//   hipcc --offload-arch=gfx950 -O3 -o tools/microbench/interleave tools/microbench/interleave.hip && gpurun -- tools/microbench/interleave
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

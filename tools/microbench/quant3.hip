@@ -5,7 +5,7 @@
 //   of y inv + 8.5 (+ 2^-16) in units of 2^-16.  A low half >= 2 proves rint(fl(y / s)) == high - 0x4348 (see fq_common.hpp);
 //   digits gather by v_mad_u32_u16 (op_sel picks the high half), the test is a v_min3_u16 chain over the low halves.
 // 23 VALU per 8 elements (19 with v_pk_fma_f32) against 33 of fq_quant8_two.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/scratch/quant3 tools/scratch/quant3.hip && gpurun -- tools/scratch/quant3
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/microbench/quant3 tools/microbench/quant3.hip && gpurun -- tools/microbench/quant3
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -46,7 +46,7 @@ __global__ void check(const float* y, const float* scale, int n8, unsigned long 
     }
 }
 
-// ---- rate: MFMA phase + quantiser phase per iteration, like tools/scratch/phase_overlap.hip -----------------------
+// ---- rate: MFMA phase + quantiser phase per iteration, like tools/microbench/phase_overlap.hip -----------------------
 template <int KIND, bool MFMA, bool QUANT>   // KIND 0 fq_quant8_two<false>, 1 lo<false,false>, 2 lo<false,true>, 3 two<true>, 4 lo<true,false>, 5 lo<true,true>
 __global__ __launch_bounds__(1024) void rate(unsigned long long* out, float seed, int iters) {
     extern __shared__ unsigned char lds_[];

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase stamps of fq_kron_trio_kernel (measurement build -DTRIO_TRACE=<workgroup>): FQHIP_LIB=variants/libfqhip_trace.so
-python tools/scratch/trio_trace.py.  Prints, per wave and iteration, the s_memtime deltas between the stamps."""
+python tools/microbench/trio_trace.py.  Prints, per wave and iteration, the s_memtime deltas between the stamps."""
 import ctypes
 import os
 import sys

@@ -1,7 +1,7 @@
 // Issue cost of single VALU instructions on gfx950 (MI355X): s_memtime ticks per instruction per SIMD with 1, 2 and 4 waves
 // resident on the SIMD, 8 independent chains per wave (second session of round 3: which of the quantiser's candidate
 // instructions are full rate — v_fma_mix_f32 and the packed fp16 ops in particular).
-//   hipcc --offload-arch=gfx950 -O3 -o tools/scratch/vrate tools/scratch/vrate.hip && gpurun -- tools/scratch/vrate
+//   hipcc --offload-arch=gfx950 -O3 -o tools/microbench/vrate tools/microbench/vrate.hip && gpurun -- tools/microbench/vrate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 

@@ -14,7 +14,7 @@ python tools/show_bench.py $OUT/bench_C2_driver.json $OUT/bench_C3.json $OUT/ben
 bash tools/pmc_op.sh kron112 trio112 > /dev/null 2>&1; cp $R/gpurun_out/pmc_trio112/summary.txt $OUT/pmc_kron_trio_112x128.txt
 bash tools/pmc_op.sh hadq14336 hadq > /dev/null 2>&1; cp $R/gpurun_out/pmc_hadq/summary.txt $OUT/pmc_hadamard_quant_14336.txt
 for v in trace tracecomp tracemem; do
-  if [ -f variants/libfqhip_$v.so ]; then echo "== $v"; FQHIP_LIB=$R/variants/libfqhip_$v.so python tools/scratch/trio_trace.py 2>&1 | grep -v amdgpu.ids; fi
+  if [ -f variants/libfqhip_$v.so ]; then echo "== $v"; FQHIP_LIB=$R/variants/libfqhip_$v.so python tools/microbench/trio_trace.py 2>&1 | grep -v amdgpu.ids; fi
 done > $OUT/trio_phase_trace.txt
 rocm-smi --showmaxpower 2>&1 | grep -i "power" >> $OUT/trio_phase_trace.txt
 tail -3 $OUT/configs_bench.txt; grep "112x128\|14336\|18944\|27648\|29568" $OUT/shapes_table.txt | head -20

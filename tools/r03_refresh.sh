@@ -17,5 +17,5 @@ python tools/flip_rates.py 2>&1 | grep -v amdgpu.ids > $OUT/flip_rates.txt
 python tools/bench_shapes.py 2>&1 | grep -v amdgpu.ids > $OUT/shapes_table.txt
 bash tools/pmc_op.sh kron128x224 duo224 > /dev/null 2>&1; cp $R/gpurun_out/pmc_duo224/summary.txt $OUT/pmc_kron_duo_128x224.txt
 bash tools/pmc_op.sh kron64fq fq64 > /dev/null 2>&1; cp $R/gpurun_out/pmc_fq64/summary.txt $OUT/pmc_kron64_fakequant.txt
-if [ -f variants/libfqhip_dtrace.so ]; then FQHIP_LIB=$R/variants/libfqhip_dtrace.so python tools/scratch/duo_trace.py 2>&1 | grep -v amdgpu.ids > $OUT/duo_phase_trace.txt; fi
+if [ -f variants/libfqhip_dtrace.so ]; then FQHIP_LIB=$R/variants/libfqhip_dtrace.so python tools/microbench/duo_trace.py 2>&1 | grep -v amdgpu.ids > $OUT/duo_phase_trace.txt; fi
 tail -8 $OUT/configs_bench.txt; tail -12 $OUT/flip_rates.txt
