@@ -70,7 +70,7 @@ class Linear4bit(torch.nn.Module):
         key = (self.weight.data_ptr(), ops.ver(self.weight), self.weight.device)
         if getattr(self, "_wimg_key", None) != key:
             self._drop_wimg()
-            need = self.weight.numel() * 3 // 2            # 0.75 B/param on top of the 0.5 B/param of `weight`
+            need = int(ops.lib.fq_bf6_blob_bytes(self.out_features, self.in_features))   # 0.75 B/param (rows padded to 32) on top of the 0.5 B/param of `weight`
             if self._image_room(need):
                 self._wimg = ops.int4_to_bf6(self.weight, weights=True)
                 Linear4bit._fp6_image_bytes_held += need

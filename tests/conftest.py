@@ -90,8 +90,7 @@ def pytest_sessionfinish(session, exitstatus):
         pass
 
 
-# Small-sample sites (a few dozen rows): ONE row whose fp16 scale lands one ulp away from the other route's re-quantises with a
-# different step and can differ on a few per cent of ITS digits — 1e-3 of a 37-row population. These sites therefore keep round 4's
-# 2e-3 as the assertion, record what they measure (profiles/r06_flip_rates.txt), and the >= 1e6-digit populations of
-# tests/test_gpu_flip_rates.py hold every route to SURVEY 7's 1e-3.
-BOUND37 = 2e-3
+# The small-sample sites (14 - 300 rows) that asserted 2e-3 through round 5. Measured in round 6 (profiles/r06_flip_rates.txt): the largest is
+# 7.9e-4 (hadamard_quant n = 6144, 37 rows), every Kronecker / RMSNorm site is below 3.1e-4 — so they all assert SURVEY 7's 1e-3 now; the
+# >= 1e6-digit populations of tests/test_gpu_flip_rates.py hold the same routes to it on populations where one row cannot move the figure.
+BOUND37 = 1e-3

@@ -101,10 +101,10 @@ def test_c5_full_size_properties(ops, dtype):
     matrices. Properties: every group's bytes and scales equal the UNGROUPED launch on that group's rows with that group's pair / matrices
     (checked on every non-empty group for the shared transform, on 24 groups for the per-expert one); the launch is repeatable; the
     quantise + pack stage re-derived by the oracle from the kernel's own transform on sample rows."""
-    T, E, K, d = ROWS, 256, 8, 2048
+    TOK, E, K, d = ROWS, 256, 8, 2048
     g = torch.Generator().manual_seed(5)
     pop = 1.0 / torch.arange(1, E + 1, dtype=torch.float64) ** 0.8
-    idx = torch.multinomial(pop[torch.randperm(E, generator=g)].expand(T, E), K, replacement=False, generator=g)
+    idx = torch.multinomial(pop[torch.randperm(E, generator=g)].expand(TOK, E), K, replacement=False, generator=g)
     counts = torch.bincount(idx.flatten(), minlength=E)
     counts[7] += counts[3]                      # an EMPTY group and, below, a one-row group (whatever the routing drew)
     counts[3] = 0
@@ -113,7 +113,7 @@ def test_c5_full_size_properties(ops, dtype):
     offs = torch.zeros(E + 1, dtype=torch.int64)
     offs[1:] = torch.cumsum(counts, 0)
     rows = int(offs[-1])
-    assert rows == T * K and int((counts == 0).sum()) >= 1
+    assert rows == TOK * K and int((counts == 0).sum()) >= 1
     gd = torch.Generator(device="cuda").manual_seed(6)
     x = (torch.randn(rows, d, generator=gd, device="cuda") * (torch.rand(rows, 1, generator=gd, device="cuda") * 3 + 0.1)).to(dtype)
     L, R = mats(32, 64, 7)

@@ -251,7 +251,7 @@ def test_fp6_image_budget_is_honoured_and_a_refusal_is_not_latched(ops):
     gen = torch.Generator().manual_seed(9)
     held0 = L4._fp6_image_bytes_held
     model = torch.nn.Sequential(L4(256, 272), L4(256, 272)).cuda()
-    need = 272 * 128 * 3 // 2
+    need = int(ops.lib.fq_bf6_blob_bytes(272, 256))
     deploy.fuse(model, fp6_image=True, fp6_image_budget_bytes=held0 + need)       # room for ONE image
     rows = L4.fp6_transient_rows + 3
     p = deploy.PackedQuantizedTensor(torch.from_numpy(rand_packed(gen, rows, 256)[0]).cuda().reshape(1, rows, 128),
