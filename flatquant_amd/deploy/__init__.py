@@ -55,5 +55,6 @@ def matmul(A, B):
 
 from . import functional, nn  # noqa: E402,F401
 from .fuse import fuse, unfuse  # noqa: E402,F401
+from .graphed import GraphedDecode  # noqa: E402,F401
 
-__all__ = ["matmul", "sym_quant", "sym_dequant", "PackedQuantizedTensor", "nn", "functional", "fuse", "unfuse"]
+__all__ = ["matmul", "sym_quant", "sym_dequant", "PackedQuantizedTensor", "nn", "functional", "fuse", "unfuse", "GraphedDecode"]

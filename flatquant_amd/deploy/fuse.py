@@ -29,6 +29,7 @@ import weakref
 import torch
 
 from .. import ops
+from .graphed import GraphedDecode
 from .nn.linear import Linear4bit, linear4bit_multi
 from .nn.online_trans import FusedSequential, OnlineTrans, fused_forward
 from .nn.quantization import Quantizer
@@ -143,7 +144,7 @@ def _is_trans(m):
 
 
 def fuse(model: torch.nn.Module, down_proj: bool = True, linears: bool = True, static_outputs: bool = False,
-         fp6_image=None, fp6_image_budget_bytes=None) -> dict:
+         fp6_image=None, fp6_image_budget_bytes=None, capture: bool = False) -> dict:
     """Walk ``model`` (built by the reference's deploy/transformers/modeling_llama.py with ``import flatquant_amd.deploy as deploy``)
     and install the fused launches described in this module's docstring. Idempotent. ``static_outputs=True`` additionally sets the
     modules' opt-in static output plans (results rewritten by the next call of the same module — safe for the reference's forward,
@@ -151,8 +152,17 @@ def fuse(model: torch.nn.Module, down_proj: bool = True, linears: bool = True, s
     ``{"transform_groups": n, "linear_groups": n, "down_proj": n}``.
     ``fp6_image`` (True / False; None leaves the modules' policy alone) and ``fp6_image_budget_bytes`` set, on every Linear4bit of ``model``,
     whether the layer keeps its FP6 operand image (+0.75 B/param, the prefill GEMM 1.6x faster) and the cap on what all images may hold
-    together — the memory side of the deployment in the one call that configures it (INTEGRATION.md "Memory")."""
+    together — the memory side of the deployment in the one call that configures it (INTEGRATION.md "Memory").
+    ``capture=True`` (round 6): every decoder layer (a module with ``self_attn`` and ``mlp`` children, the reference's LlamaDecoderLayer
+    shape) serves its decode-sized calls from captured HIP graphs, transparently — deploy/graphed.py; reported as ``"graphed_layers"``."""
     report = {"transform_groups": 0, "linear_groups": 0, "down_proj": 0}
+    if capture:
+        report["graphed_layers"] = 0
+        for mod in model.modules():
+            if (isinstance(getattr(mod, "self_attn", None), torch.nn.Module) and isinstance(getattr(mod, "mlp", None), torch.nn.Module)
+                    and not isinstance(mod.__dict__.get("forward"), GraphedDecode)):
+                mod.forward = GraphedDecode(mod.forward)      # (an instance attribute: nn.Module.__call__ finds it before the class's)
+                report["graphed_layers"] += 1
     if fp6_image is not None or fp6_image_budget_bytes is not None:
         for mod in model.modules():
             if isinstance(mod, Linear4bit):
@@ -191,5 +201,7 @@ def fuse(model: torch.nn.Module, down_proj: bool = True, linears: bool = True, s
 def unfuse(model: torch.nn.Module) -> None:
     """Remove the groups ``fuse`` installed (``down_proj`` stays a FusedSequential: same children, same results)."""
     for mod in model.modules():
+        if isinstance(mod.__dict__.get("forward"), GraphedDecode):
+            mod.__dict__.pop("forward").release()
         if isinstance(mod, (OnlineTrans, Linear4bit)):
             mod.__dict__.pop("_group", None)

@@ -111,6 +111,9 @@ class MultiLayerPagedKVCache4Bit:
         self.scales = torch.empty((n_pages, n_layers, 2, num_heads, page_size, 2), dtype=torch.float16, device=device)
         self._needs_init = [True] * n_layers
         self.length = 0
+        self.generation = 0     # bumped when the page / index storage moves: graphs captured over the old pointers are stale (deploy.graphed)
+        self._log = None        # deploy.graphed: the (layer_idx, added) host steps of the calls made while it is a list
+        self._skip_host = False  # deploy.graphed: update() leaves the host step to replay_host() (capture pass)
 
     def page_cnt_from_length(self, length):
         return (length + self.page_size - 1) // self.page_size
@@ -123,6 +126,11 @@ class MultiLayerPagedKVCache4Bit:
         grow = max(need, have * 2) - have
         self.pages = torch.cat([self.pages, torch.empty((grow, *self.pages.shape[1:]), dtype=self.pages.dtype, device=self.device)])
         self.scales = torch.cat([self.scales, torch.empty((grow, *self.scales.shape[1:]), dtype=self.scales.dtype, device=self.device)])
+        self.generation += 1
+
+    def would_grow(self, added: int) -> bool:
+        """Would appending ``added`` tokens per request re-allocate the pages (and so move every pointer a captured graph holds)?"""
+        return self.page_cnt_from_length(self.length + added) * self.batch_size > self.pages.shape[0]
 
     @property
     def seen_tokens(self):
@@ -158,6 +166,51 @@ class MultiLayerPagedKVCache4Bit:
             "last_page_offset": last,
         }
 
+    def _static_specs(self):
+        """The index tensors of the no-mask case (every request ``self.length`` tokens long) as STATIC device buffers rewritten in place:
+        kv_indptr / kv_indices only when the page count changes, last_page_offset by one fill per step — same values as
+        get_cache_specs_for_flash_infer(None) (tests/test_gpu_kvcache.py), no arange / full / reshape launches per step, and addresses
+        a captured decode step can keep (deploy.graphed)."""
+        bsz, dev = self.batch_size, self.device
+        st = self.__dict__.get("_st")
+        if st is None or st["pages_ptr"] != self.pages.data_ptr():
+            st = {"pages_ptr": self.pages.data_ptr(), "page_cnt": -1, "ptr": -1,
+                  "indptr": torch.zeros(bsz + 1, dtype=torch.int32, device=dev),
+                  "indices": torch.zeros(max(1, self.pages.shape[0]), dtype=torch.int32, device=dev),
+                  "last": torch.zeros(bsz, dtype=torch.int32, device=dev)}
+            self._st = st
+            self.generation += 1
+        page_cnt = self.page_cnt_from_length(self.length)
+        ptr = self.length % self.page_size
+        if self.length != 0 and ptr == 0:
+            ptr = self.page_size
+        if st["page_cnt"] != page_cnt:
+            st["indptr"].copy_(torch.arange(0, bsz + 1, device=dev, dtype=torch.int32) * page_cnt)
+            st["indices"][:bsz * page_cnt].copy_(((torch.arange(page_cnt, device=dev, dtype=torch.int32) * bsz).unsqueeze(0)
+                                                  + torch.arange(bsz, device=dev, dtype=torch.int32).unsqueeze(1)).reshape(-1))
+            st["page_cnt"] = page_cnt
+        if st["ptr"] != ptr:
+            st["last"].fill_(ptr)
+            st["ptr"] = ptr
+        return {"kv_data": self.pages, "kv_param": self.scales, "kv_indptr": st["indptr"],
+                "kv_indices": st["indices"][:bsz * page_cnt], "last_page_offset": st["last"]}
+
+    def _host_step(self, layer_idx, added, mask=None):
+        """The host side of one ``update``: layer 0 makes room and advances the length; the index tensors follow the length."""
+        if layer_idx == 0:
+            self._ensure_page_cnt_per_batch(self.page_cnt_from_length(self.length + added))
+            self.length += added
+        key = (self.length, self.pages.data_ptr(), None if mask is None else (mask.data_ptr(), ops.ver(mask), tuple(mask.shape)))
+        if getattr(self, "_specs_key", None) != key:   # index tensors: once per step, not per layer
+            self._specs = self._static_specs() if mask is None else self.get_cache_specs_for_flash_infer(mask)
+            self._specs_key = key
+
+    def replay_host(self, log):
+        """deploy.graphed: apply the host steps ``log`` recorded ([(layer_idx, added), ...]) — what the update() calls inside a captured
+        decode step did on the host — before the graph that holds their launches is replayed."""
+        for layer_idx, added in log:
+            self._host_step(layer_idx, added)
+
     def update(self, key_states, value_states, layer_idx, cache_kwargs=None):
         cache_kwargs = cache_kwargs or {}
         mask = cache_kwargs.get("attention_mask")
@@ -167,12 +220,10 @@ class MultiLayerPagedKVCache4Bit:
         tk_inv_t = cache_kwargs.get("trans_matrix_k_inv_t") if self.trans.startswith("matmul") else None
         # :286-296 grouped-query attention: every query head gets its copy — made by the scatter (group_size below).
         # kv_cache.py:283-284: the cache's own calls leave lac off, so the clip factors play no part.
-        if layer_idx == 0:
-            self._ensure_page_cnt_per_batch(self.page_cnt_from_length(self.length + added))
-            self.length += added
-        key = (self.length, self.pages.data_ptr(), None if mask is None else (mask.data_ptr(), ops.ver(mask), tuple(mask.shape)))
-        if getattr(self, "_specs_key", None) != key:   # index tensors: once per step, not per layer
-            self._specs, self._specs_key = self.get_cache_specs_for_flash_infer(mask), key
+        if self._log is not None:
+            self._log.append((layer_idx, added) if (mask is None and not self._needs_init[layer_idx]) else None)   # None: not replayable
+        if not self._skip_host:
+            self._host_step(layer_idx, added, mask)
         specs = self._specs
         args = (specs["kv_data"], specs["kv_param"], specs["kv_indptr"], specs["kv_indices"], specs["last_page_offset"])
         tk16 = None if tk is None else tk.to(device=key_states.device, dtype=torch.float16).contiguous()

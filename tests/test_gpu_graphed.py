@@ -1,0 +1,147 @@
+"""deploy.fuse(model, capture=True) / deploy.GraphedDecode: a decoder layer's decode step served from captured HIP graphs with no graph code
+on the caller's side (the reference's eager decode loop: deploy/transformers/modeling_llama.py:45-153,
+benchmarks/layer_benchmark.py:131-143). The replayed step must be the eager step bit for bit, token after token, with the paged INT4 cache
+really growing: two identical caches, one driven eagerly, one through the wrapper."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def build(bsz, page, prompt, max_len, seed=0):
+    import flatquant_amd.deploy as deploy
+    import flatquant_amd.deploy.transformers as dt
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(seed)
+    hidden, heads, kv_heads, hd = 4096, 32, 8, 128
+
+    def trans(dim, decompose=True):
+        t = deploy.nn.OnlineTrans(dim, trans="matmul", decompose=decompose, lac=True).to(dev)
+        for name in ("left_matrix", "right_matrix"):
+            if name in t._buffers:
+                b = t._buffers[name]
+                b.copy_(torch.randn(b.shape, generator=g, device=dev) / b.shape[0] ** 0.5)
+        t.clip_factor_a_max.fill_(4.0), t.clip_factor_a_min.fill_(3.5)
+        return t
+
+    def lin(k_in, n_out):
+        m = deploy.nn.Linear4bit(k_in, n_out).to(dev)
+        m.weight.copy_(torch.randint(0, 256, m.weight.shape, generator=g, device=dev, dtype=torch.uint8))
+        m.weight_scales.copy_(torch.rand(m.weight_scales.shape, generator=g, device=dev) * 0.02 + 0.005)
+        return m
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.inp_trans_q = trans(hidden)
+            self.q_proj, self.k_proj, self.v_proj, self.o_proj = lin(hidden, hidden), lin(hidden, kv_heads * hd), lin(hidden, kv_heads * hd), lin(hidden, hidden)
+            self.o_proj_trans = trans(heads, decompose=False)
+            self.register_buffer("tk", (torch.randn(hd, hd, generator=g, device=dev) / hd ** 0.5).half())
+
+        def forward(self, h, cache):
+            b = h.shape[0]
+            p = self.inp_trans_q(h)
+            q, k, v = self.q_proj(p), self.k_proj(p), self.v_proj(p)
+            kw = {"trans_matrix_k": self.tk, "trans_matrix_k_inv_t": self.tk}
+            attend = cache.update(k.view(b, 1, kv_heads, hd), v.view(b, 1, kv_heads, hd), 0, kw)
+            po = self.o_proj_trans(attend(q.view(b, 1, heads, hd), transposed=True))
+            po.quantized_x = po.quantized_x.contiguous().reshape(b, 1, -1)
+            return self.o_proj(po)
+
+    class Mlp(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.inp_trans_u = trans(hidden)
+            self.up_proj = lin(hidden, 1024)
+
+        def forward(self, h):
+            return self.up_proj(self.inp_trans_u(h))
+
+    class Layer(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.self_attn, self.mlp = Attn(), Mlp()
+
+        def forward(self, h, cache, scale=1.0):
+            a = self.self_attn(h, cache)
+            return h + a * scale, self.mlp(a)
+
+    def new_cache():
+        c = dt.MultiLayerPagedKVCache4Bit(bsz, page, max_len, dev, 1, heads, hd, trans="matmul", group_size=heads // kv_heads)
+        gk = torch.Generator(device=dev).manual_seed(99)
+        c.update(torch.randn(bsz, prompt, kv_heads, hd, generator=gk, device=dev).half(),
+                 torch.randn(bsz, prompt, kv_heads, hd, generator=gk, device=dev).half(), 0,
+                 {"trans_matrix_k": layer.self_attn.tk, "trans_matrix_k_inv_t": layer.self_attn.tk})
+        return c
+
+    layer = Layer()
+    return layer, new_cache, g
+
+
+@pytest.mark.parametrize("bsz", [1, 3])
+def test_graphed_layer_replays_the_eager_step_token_after_token(bsz):
+    import flatquant_amd.deploy as deploy
+    with torch.no_grad():
+        layer, new_cache, g = build(bsz, page=16, prompt=21, max_len=64)
+        xs = [torch.randn(bsz, 1, 4096, generator=g, device="cuda", dtype=torch.float16) for _ in range(14)]
+        ref_cache = new_cache()
+        want = [tuple(t.clone() for t in layer(x, ref_cache)) for x in xs]           # eager, cache growing 21 -> 35 (crosses a page at 32)
+        rep = deploy.fuse(layer, capture=True)
+        assert rep["graphed_layers"] == 1
+        gd = layer.__dict__["forward"]
+        cache = new_cache()
+        for i, x in enumerate(xs):
+            got = layer(x, cache)
+            assert cache.length == 21 + i + 1
+            for a, b in zip(got, want[i]):
+                assert torch.equal(a, b), i
+        assert gd.eager_calls == 2 and gd.captures == 1 and gd.replays == 12        # two warm-up calls, then every step from the graph
+        assert torch.equal(cache.pages, ref_cache.pages) and torch.equal(cache.scales[:, :, :, :, :cache.page_size], ref_cache.scales[:, :, :, :, :cache.page_size])
+        # another signature (a different python scalar argument) gets its own warm-up + graph; prefill-sized calls stay eager
+        c2, c3 = new_cache(), new_cache()
+        for x in xs[:4]:
+            a = layer(x, c2, scale=0.5)
+        deploy.unfuse(layer)
+        for x in xs[:4]:
+            b = layer(x, c3, scale=0.5)
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
+        assert "forward" not in layer.__dict__
+
+
+def test_page_growth_makes_the_graph_stale_and_it_is_recaptured():
+    """max_seq_len 32 -> two pages per request allocated; the 33rd token re-allocates the pages (every pointer moves): the wrapper sees it
+    coming (would_grow), runs that step eagerly and captures again over the new storage."""
+    import flatquant_amd.deploy as deploy
+    with torch.no_grad():
+        layer, new_cache, g = build(2, page=16, prompt=26, max_len=32, seed=3)
+        xs = [torch.randn(2, 1, 4096, generator=g, device="cuda", dtype=torch.float16) for _ in range(12)]
+        ref_cache = new_cache()
+        want = [tuple(t.clone() for t in layer(x, ref_cache)) for x in xs]           # 26 -> 38: grows at 33
+        gd = deploy.GraphedDecode(layer.forward)
+        cache = new_cache()
+        gen0 = cache.generation
+        for i, x in enumerate(xs):
+            got = gd(x, cache)
+            for a, b in zip(got, want[i]):
+                assert torch.equal(a, b), i
+        assert cache.generation > gen0 and gd.captures == 2 and cache.length == 38
+        assert gd.eager_calls == 3                                                   # two warm-ups + the step that grew the pages
+
+
+def test_calls_that_are_not_decode_steps_stay_eager():
+    import flatquant_amd.deploy as deploy
+    layer, new_cache, g = build(1, page=16, prompt=5, max_len=64, seed=5)
+    gd = deploy.GraphedDecode(layer.mlp.forward)
+    with torch.no_grad():
+        big = torch.randn(1, 200, 4096, generator=g, device="cuda", dtype=torch.float16)
+        for _ in range(4):
+            gd(big)                                                                  # prefill-sized
+        assert gd.captures == 0 and gd.replays == 0
+        x = torch.randn(1, 1, 4096, generator=g, device="cuda", dtype=torch.float16)
+        outs = [gd(x).clone() for _ in range(5)]
+        assert gd.captures == 1 and gd.replays == 3 and all(torch.equal(o, outs[0]) for o in outs)
+    xg = torch.randn(1, 1, 4096, device="cuda", dtype=torch.float16)
+    n = gd.replays
+    with torch.enable_grad():
+        gd(xg)                                                                       # autograd on: eager
+    assert gd.replays == n

@@ -77,6 +77,40 @@ def main():
         yu, yg = deploy.nn.linear.linear4bit_multi([up_l, gate_l], [pu, pg])
         return down_l(down_t(yg, up=yu))
 
+    class Layer(torch.nn.Module):
+        """the same step as a decoder LAYER (a module with self_attn / mlp children, called as layer(h, cache)): what deploy.fuse(model,
+        capture=True) wraps — the caller writes no graph code and the cache really grows by one token per call"""
+
+        def __init__(self):
+            super().__init__()
+            self.self_attn = torch.nn.ModuleList([*qkv_t, q_l, k_l, v_l, o_t, o_l])
+            self.mlp = torch.nn.ModuleList([*ug_t, up_l, gate_l, down_t, down_l])
+
+        def forward(self, h, cache):
+            pq, pk, pv = deploy.nn.fused_forward(h, qkv_t, norm=norm)
+            q, k, v = deploy.nn.linear.linear4bit_multi([q_l, k_l, v_l], [pq, pk, pv])
+            attend = cache.update(k.view(a.bsz, 1, kv_heads, hd), v.view(a.bsz, 1, kv_heads, hd), 0, dict(kw))
+            po = o_t(attend(q.view(a.bsz, 1, heads, hd), transposed=True))
+            po.quantized_x = po.quantized_x.contiguous().reshape(a.bsz, 1, -1)
+            pu, pg = deploy.nn.fused_forward(o_l(po), ug_t, norm=norm)
+            yu, yg = deploy.nn.linear.linear4bit_multi([up_l, gate_l], [pu, pg])
+            return down_l(down_t(yg, up=yu))
+
+    def time_calls(fn, cache, n):
+        """us per call of fn() launched from Python, the cache growing by one token per call (rewound afterwards)"""
+        l0 = cache.length
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        cache.length = l0
+        return e0.elapsed_time(e1) / n * 1e3
+
     def measure(step, cache):
         """-> (us per step from a captured graph, us per step launched eagerly)"""
         for _ in range(3):                      # eager warm-up (weight images, workspaces, scalar caches), rewinding the cache length each time
@@ -131,7 +165,10 @@ def main():
             xn2 = F.rms_norm(h2, (hidden,), w1, 1e-6)
             return fd(F.silu(fg(xn2)) * fu(xn2))
         us16, eager16 = measure(step16, cache16)
-        del fq, fk, fv, fo, fu, fg, fd, cache16
+        g16 = deploy.GraphedDecode(lambda h, c: step16(h))        # the fp16 step through the SAME transparent helper (its cache passed so that
+        with torch.no_grad():                                      # the host steps are recorded): what the baseline gains from it
+            trans16 = time_calls(lambda: g16(x, cache16), cache16, min(a.iters, 100))
+        del g16, fq, fk, fv, fo, fu, fg, fd, cache16
         torch.cuda.empty_cache()
 
     # eager warm-up (fills the weight-image / workspace / scalar caches), rewinding the cache length each time
@@ -166,6 +203,17 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / a.iters * 1e3
+    # (round 6) no caller-side graph code: the layer as a module, deploy.fuse(layer, capture=True), then plain calls from Python
+    layer = Layer()
+    with torch.no_grad():
+        rep = deploy.fuse(layer, capture=True)
+        y2 = layer(x, cache)
+        transparent = time_calls(lambda: layer(x, cache), cache, min(a.iters, 100))
+        gd = layer.__dict__["forward"]
+    print(f"   deploy.fuse(layer, capture=True) {rep}: {transparent:.1f} us per call from Python, no graph code on the caller's side "
+          f"({gd.captures} capture(s), {gd.replays} replays, {gd.eager_calls} eager warm-up calls); output finite: {bool(torch.isfinite(y2.float()).all())}"
+          + (f"   | fp16 step through the same helper: {trans16:.1f} us -> {trans16 / transparent:.2f}x; against the EAGER fp16 step "
+             f"({eager16:.1f} us): {eager16 / transparent:.2f}x" if a.fp16 else ""))
     print(f"Llama-3-8B decoder layer, decode step, {a.bsz} requests x {a.cache} cached tokens: {us:.1f} us per layer from a "
           f"captured graph ({eager:.1f} us launched eagerly from Python); output finite: {bool(torch.isfinite(y.float()).all())}"
           + (f"   | the same step in fp16 (fp16 paged cache): {us16:.1f} us captured ({eager16:.1f} eager): speed-up {us16 / us:.2f}x captured, "
