@@ -234,6 +234,18 @@ def main():
         deploy.fuse(layer, static_outputs=True)
         t4 = timeit(lambda: layer(nxt()), a.steps)
         print(f"  ... after deploy.fuse(model, static_outputs=True)                             {t4:9.1f} us   {t16 / t4:5.2f}x")
+        if a.bsz * a.seq <= 128:     # (round 6) decode sizes: the layer's calls served from a captured graph, no graph code here
+            deploy.unfuse(layer)
+            for mod in layer.modules():
+                if isinstance(mod, (deploy.nn.OnlineTrans, deploy.nn.Quantizer, deploy.nn.Linear4bit)):
+                    mod.static_outputs = False
+            rep = deploy.fuse(layer, capture=True)
+            t5 = timeit(lambda: layer(nxt()), a.steps)
+            f16 = Fp16Layer(a.model)
+            g16t = deploy.GraphedDecode(f16.forward)
+            t16g = timeit(lambda: g16t(nxt()), a.steps)
+            print(f"  ... after deploy.fuse(model, capture=True) {rep}: {t5:9.1f} us   {t16 / t5:5.2f}x the eager fp16 layer, "
+                  f"{t16g / t5:5.2f}x the fp16 layer through the same helper ({t16g:.1f} us)")
 
 
 if __name__ == "__main__":
