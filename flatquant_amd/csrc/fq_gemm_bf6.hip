@@ -47,21 +47,25 @@ using namespace fqgemm;
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_b;
 
-constexpr int BN = 256;
+constexpr int BN256 = 256;                     // feature width of the prefill tiles (the template's default BN)
 constexpr int BLOB = 1536;                     // bytes: 32 rows x 64 k of BF6
 constexpr int SEG = 2 * BLOB;                  // a row tile's two blobs of one stage (128 k)
-constexpr int OPB = 8 * SEG;                   // the weight operand's share of a stage: 8 row tiles
 constexpr int TMT = 4;                         // token tiles per wave: the wave tile is 128 tokens x 64 features
 // Geometry of a workgroup tile of BM tokens x 256 features: BM / 128 x 4 waves of 128 x 64.
 //   BM = 256: 8 waves, two per SIMD, 48 KB per stage — the prefill shape;
 //   BM = 128: 4 waves, 36 KB per stage — twice the tiles for launches that would leave CUs without one (2048 tokens x 4096
 //             features are 128 tiles of 256 x 256 on 256 CUs).
-template <int BM>
+//   BM = 128, BN = 128 (round 6): 2 waves, 24 KB per stage, two workgroups per CU — DECODE-sized calls of 33 .. 128 rows, where the launch is
+//             the weight stream and what counts is workgroups: a 128 x 256 tile puts 16 workgroups on a 4096-wide projection, 112 on up + gate.
+template <int BM, int BN = BN256>
 struct Geo {
-    static constexpr int NWM = BM / 128;                      // waves along the token dimension (4 along the feature dimension)
-    static constexpr int GW = 4 * NWM, GT = GW * 64;
-    static constexpr int TILE_BYTES = OPB + (BM / 32) * SEG;  // [W tiles 0..7][X tiles 0..BM/32-1]
-    static constexpr int DPW = (TILE_BYTES / 1024) / GW;      // DMA instructions per wave and stage (6 | 9)
+    static constexpr int NWM = BM / 128;                      // waves along the token dimension
+    static constexpr int NWN = BN / 64;                       // ... along the feature dimension (64 features each)
+    static constexpr int GW = NWN * NWM, GT = GW * 64;
+    static constexpr int OPB = (BN / 32) * SEG;               // the weight operand's share of a stage
+    static constexpr int WDMA = (BN / 32) * 3;                // ... in 1 KB DMA instructions
+    static constexpr int TILE_BYTES = OPB + (BM / 32) * SEG;  // [W tiles 0..BN/32-1][X tiles 0..BM/32-1]
+    static constexpr int DPW = (TILE_BYTES / 1024) / GW;      // DMA instructions per wave and stage (6 | 9 | 12)
     static constexpr int STAGES = 3;                          // LDS stages (measured: 128-token tiles with two stages and two workgroups
                                                               // per CU, forced onto 16384 x 4096 x 4096: 210 us against 157)
     static_assert(DPW * GW * 1024 == TILE_BYTES, "whole DMA instructions per wave");
@@ -154,8 +158,8 @@ template <> struct GemmMultiArg<true> {
 #define GEMM_ABL 0
 #endif
 
-template <int BM, int MODE = 0>
-__global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB_, const uint8_t* __restrict__ WB_,
+template <int BM, int MODE = 0, int BN = BN256>
+__global__ __launch_bounds__((Geo<BM, BN>::GT), 2) void fq_gemm_bf6_kernel(const uint8_t* __restrict__ XB_, const uint8_t* __restrict__ WB_,
                                                                               int M, int N_, int KB, int n_vblocks, GemmOut out_,
                                                                               GemmMultiArg<(MODE != 0)> mp) {
     constexpr bool MULTI = MODE != 0;
@@ -165,7 +169,8 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
     GemmOut out = out_;
     // (wave-uniform selects: a dynamic index into a by-value kernel argument could send it through scratch)
 #define FQ_PICK(arr, p) ((p) == 0 ? mp.arr[0] : (p) == 1 ? mp.arr[1] : (p) == 2 ? mp.arr[2] : mp.arr[3])
-    constexpr int NWM = Geo<BM>::NWM, TILE_BYTES = Geo<BM>::TILE_BYTES, DPW = Geo<BM>::DPW, STAGES = Geo<BM>::STAGES;
+    using G = Geo<BM, BN>;
+    constexpr int NWM = G::NWM, TILE_BYTES = G::TILE_BYTES, DPW = G::DPW, STAGES = G::STAGES, OPB = G::OPB, WDMA = G::WDMA;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -177,12 +182,15 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
     const bool may_clamp = KB > 10176 / 64;   // |q| <= 64 K: beyond K = 10176 the epilogue's clamp to +-65176 (x 10) can bind
     const int mt_last = (M + 31) / 32 - 1;
 
-    // DMA plan: instruction i = DPW wave + j: the first 24 the weight row tiles, then the token row tiles; row tile (i % 24) / 3
-    // (resp. (i - 24) / 3), 1 KB part i % 3 of its 3 KB.
+    // DMA plan: instruction i = DPW wave + j: the first WDMA (24 for the 256-wide tile) the weight row tiles, then the token row tiles;
+    // row tile i / 3 (resp. (i - WDMA) / 3), 1 KB part i % 3 of its 3 KB.
     // The source of an instruction is wave-uniform (SGPR base) + 16 * lane: twelve address VGPRs less than per-lane
     // pointers — those had pushed the kernel into a spill whose reload sat between the DMA instructions of a stage
     // behind an s_waitcnt vmcnt(0), i.e. every stage waited for its own loads (found in the ISA, cost ~2x).
-    const unsigned char* gbase[DPW];
+    // (round 6) one base per ROW TILE, its three 1 KB parts through the instruction's immediate offset: DPW / 3 SGPR pairs instead of DPW
+    // (12 and 18 instructions per wave in the narrow decode tiles: the pointers no longer fit the scalar file otherwise)
+    static_assert(DPW % 3 == 0, "a wave's DMA share is whole row tiles");
+    const unsigned char* gbase[DPW / 3];
     auto plan = [&](int mb, int nb, int p) {
         const uint8_t* WBp = WB;
         const uint8_t* XBp = XB;
@@ -194,31 +202,30 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
         }
         const int nt_last = (Np + 31) / 32 - 1;
 #pragma unroll
-        for (int j = 0; j < DPW; ++j) {
-            const int i = wave * DPW + j;
-            const int op = i < 24 ? 0 : 1, t = (i < 24 ? i : i - 24) / 3, part = i % 3;
+        for (int j = 0; j < DPW / 3; ++j) {
+            const int i = wave * DPW + 3 * j;
+            const int op = i < WDMA ? 0 : 1, t = (i < WDMA ? i : i - WDMA) / 3;
             int rt = (op == 0 ? nb * BN : mb * BM) / 32 + t;
             const int last = op == 0 ? nt_last : mt_last;
             rt = rt < last ? rt : last;  // tiles beyond the matrix re-read its last tile (their outputs are never stored)
-            gbase[j] = (op == 0 ? WBp : XBp) + (int64_t)rt * KB * BLOB + part * 1024;
+            gbase[j] = (op == 0 ? WBp : XBp) + (int64_t)rt * KB * BLOB;
         }
     };
     const unsigned voff = (unsigned)lane * 16u;
     const unsigned lds0 = (unsigned)(size_t)(lds_void_b*)smem;
     auto issue_one = [&](int s, int j) {   // instruction j of this wave's share of stage s
-        if (GEMM_ABL == 4 && wave * DPW + j < 24) return;
-        const unsigned dst = lds0 + (unsigned)((s % STAGES) * TILE_BYTES) + (unsigned)(wave * DPW + j) * 1024u;
-        const unsigned char* src = gbase[j] + (int64_t)s * SEG;
+        if (GEMM_ABL == 4 && wave * DPW + j < WDMA) return;
+        // (the instruction's immediate offset moves BOTH addresses: the LDS base in M0 is the row tile's, part j % 3 comes from the offset)
+        const unsigned dst = lds0 + (unsigned)((s % STAGES) * TILE_BYTES) + (unsigned)(wave * DPW + j - j % 3) * 1024u;
+        const unsigned char* src = gbase[j / 3] + (int64_t)s * SEG;
         unsigned keep;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %3\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(voff), "s"(src), "s"(__builtin_amdgcn_readfirstlane((int)dst))
-            : "memory");
+#define FQ_GLDS(OFF)                                                                                                  \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" OFF "\n\ts_mov_b32 m0, %0"        \
+                     : "=&s"(keep) : "v"(voff), "s"(src), "s"(__builtin_amdgcn_readfirstlane((int)dst)) : "memory")
+        if (j % 3 == 0) FQ_GLDS("");
+        else if (j % 3 == 1) FQ_GLDS(" offset:1024");
+        else FQ_GLDS(" offset:2048");
+#undef FQ_GLDS
     };
     auto request_first_stages = [&]() {
 #pragma unroll
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(Geo<BM>::GT, 2) void fq_gemm_bf6_kernel(const uint8
         _Pragma("unroll") for (int p = 0; p < 3; ++p) RX[(I) >= 2 && (I) < 2 + TMT ? (I) - 2 : 0][p] =               \
             *reinterpret_cast<const uint2*>((ST) + xoff + ((I) >= 2 && (I) < 2 + TMT ? (I) - 2 : 0) * SEG + (KBL) * BLOB + p * 512); \
     }
-    static_assert(2 + TMT <= 2 * TMT && DPW <= 4 * TMT, "a block has enough MFMAs to carry its successor's fragments and the DMA share");
+    static_assert(2 + TMT <= 2 * TMT && DPW <= 6 * TMT, "a block has enough MFMAs to carry its successor's fragments and the DMA share");
     auto half_a = [&](const unsigned char* st) {   // block 0 of a stage from r0, block 1's fragments into r1
 #pragma unroll
         for (int i = 0; i < 2 * TMT; ++i) {
@@ -471,6 +478,60 @@ int fq_launch_i4_to_bf6(const uint8_t* q, int64_t rows, int K, int perm, uint8_t
     return fq_launch_i4_to_bf6_multi(1, &q, rows, K, perm, blob, n_cu, stream);
 }
 
+namespace {
+
+int bf6_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
+// Measurement knob: force the feature width of the <= 128-token tiles (0: the rule below)
+#ifndef GEMM_BN_SMALL
+#define GEMM_BN_SMALL 0
+#endif
+
+// The tile geometry of a launch of `cols` feature columns in total (one problem: N; several: their sum, each rounded up to the tile).
+//   bm: 256-token tiles unless they would leave a quarter of the CUs (or more) without one;
+//   bn: 256, except for DECODE-sized calls (M <= 128: one row of tiles), where a narrower tile is what puts workgroups on the chip —
+//       128 features when 256-wide tiles are fewer than 3/4 of the CUs (a 64-wide, one-wave tile does not build: its DMA sources leave the
+//       scalar file).
+void bf6_geometry(int64_t M, const int* Ns, int n, int cus, int& bm, int& bn) {
+    auto tiles = [&](int w) {
+        int64_t t = 0;
+        for (int p = 0; p < n; ++p) t += (Ns[p] + w - 1) / w;
+        return t;
+    };
+    bn = 256;
+    bm = ((M + 255) / 256) * tiles(256) * 4 < (int64_t)cus * 3 ? 128 : 256;
+    if (M <= 128) {
+        if (tiles(256) * 4 < (int64_t)cus * 3) bn = 128;
+        if (GEMM_BN_SMALL) bn = GEMM_BN_SMALL;
+    }
+}
+
+template <int BM, int MODE, int BN>
+int bf6_launch(int64_t n_vblocks, int wg_per_cu, const uint8_t* xb, const uint8_t* wb, int64_t M, int N, int K, const GemmOut& o,
+               const GemmMultiArg<(MODE != 0)>& mp, hipStream_t stream) {
+    using G = Geo<BM, BN>;
+    // persistent workgroups: wg_per_cu per CU, a multiple of 8 so that a workgroup stays on its XCD's share of the tile sequence
+    int64_t blocks = (int64_t)(bf6_cus() / 8) * 8 * wg_per_cu;
+    if (blocks < 8) blocks = 8;
+    if (blocks > n_vblocks) blocks = n_vblocks;
+    auto kern = fq_gemm_bf6_kernel<BM, MODE, BN>;
+    FQ_RAISE_LDS_CAP(kern, G::STAGES * G::TILE_BYTES);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(G::GT), G::STAGES * G::TILE_BYTES, stream, xb, wb, (int)M, N, K / 64, (int)n_vblocks, o, mp);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
 // -1000: shape not covered (K % 128 != 0, N % 16 != 0, K > 2^18): use the i8 kernel
 int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, int N, int K, int32_t* c, f16* y,
                        const f16* srow, const f16* scol, const f16* bias, hipStream_t stream) {
@@ -481,46 +542,30 @@ int fq_launch_gemm_bf6(const uint8_t* xblob, const uint8_t* wblob, int64_t M, in
     o.srow = srow;
     o.scol = scol;
     o.bias = bias;
-    // persistent workgroups: one per CU, a multiple of 8 so that a workgroup stays on its XCD's share of the tile sequence
-    static int cus[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (cus[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus[dev] = n;
-    }
-    const int64_t tiles256 = ((M + 255) / 256) * ((N + BN - 1) / BN);
-    const bool half = tiles256 * 4 < (int64_t)cus[dev] * 3;   // 256-token tiles would leave a quarter of the CUs (or more) without one
-    const int bm = half ? 128 : 256;
-    const int64_t n_vblocks = 8 * ((((M + bm - 1) / bm) * ((N + BN - 1) / BN) + 7) / 8);  // see xcd_tile
-    int64_t blocks = (cus[dev] / 8) * 8;
-    if (blocks < 8) blocks = 8;
-    if (blocks > n_vblocks) blocks = n_vblocks;
-    if (half) {
-        FQ_RAISE_LDS_CAP(fq_gemm_bf6_kernel<128>, Geo<128>::STAGES * Geo<128>::TILE_BYTES);
-        hipLaunchKernelGGL(fq_gemm_bf6_kernel<128>, dim3((unsigned)blocks), dim3(Geo<128>::GT), Geo<128>::STAGES * Geo<128>::TILE_BYTES, stream, xblob,
-                           wblob, (int)M, N, K / 64, (int)n_vblocks, o, GemmMultiArg<false>{});
-    } else {
-        FQ_RAISE_LDS_CAP(fq_gemm_bf6_kernel<256>, Geo<256>::STAGES * Geo<256>::TILE_BYTES);
-        hipLaunchKernelGGL(fq_gemm_bf6_kernel<256>, dim3((unsigned)blocks), dim3(Geo<256>::GT), Geo<256>::STAGES * Geo<256>::TILE_BYTES, stream, xblob,
-                           wblob, (int)M, N, K / 64, (int)n_vblocks, o, GemmMultiArg<false>{});
-    }
-    return (int)hipGetLastError();
+    int bm, bn;
+    bf6_geometry(M, &N, 1, bf6_cus(), bm, bn);
+    const int64_t n_vblocks = 8 * ((((M + bm - 1) / bm) * ((N + bn - 1) / bn) + 7) / 8);  // see xcd_tile
+    const GemmMultiArg<false> none{};
+    if (bn == 128) return bf6_launch<128, 0, 128>(n_vblocks, 2, xblob, wblob, M, N, K, o, none, stream);
+    if (bm == 128) return bf6_launch<128, 0, 256>(n_vblocks, 1, xblob, wblob, M, N, K, o, none, stream);
+    return bf6_launch<256, 0, 256>(n_vblocks, 1, xblob, wblob, M, N, K, o, none, stream);
 }
 
 // Up to four problems with common M and K in one launch (fq_gemm_bf6_kernel<BM, true>). -1000: shape not covered.
 int fq_launch_gemm_bf6_multi(int n, const uint8_t* const* xblob, const uint8_t* const* wblob, int64_t M, const int* Ns, int K, f16* const* y,
                              const f16* const* srow, const f16* const* scol, const f16* const* bias, hipStream_t stream) {
     if (n < 1 || n > 4 || (K & 127) || K > (1 << 18) || M < 1 || M > (1 << 30)) return -1000;
+    for (int p = 0; p < n; ++p)
+        if (Ns[p] < 1 || (Ns[p] & 15)) return -1000;
+    int bm, bn;
+    bf6_geometry(M, Ns, n, bf6_cus(), bm, bn);
     GemmMultiArg<true> mp = {};
     mp.n = n;
     int tn = 0;
     for (int p = 0; p < 4; ++p) {
         const int q = p < n ? p : n - 1;   // (unused slots repeat the last problem: the selects never read garbage)
-        if (Ns[q] < 1 || (Ns[q] & 15)) return -1000;
         mp.tn0[p] = tn;
-        if (p < n) tn += (Ns[q] + BN - 1) / BN;
+        if (p < n) tn += (Ns[q] + bn - 1) / bn;
         mp.N[p] = Ns[q];
         mp.xb[p] = xblob[q];
         mp.wb[p] = wblob[q];
@@ -531,33 +576,10 @@ int fq_launch_gemm_bf6_multi(int n, const uint8_t* const* xblob, const uint8_t* 
         mp.out[p].bias = bias[q];
     }
     for (int p = n; p < 5; ++p) mp.tn0[p] = tn;
-    static int cus[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (cus[dev] == 0) {
-        int c = 0;
-        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
-        cus[dev] = c;
-    }
-    const int64_t tiles256 = ((M + 255) / 256) * tn;
-    const bool half = tiles256 * 4 < (int64_t)cus[dev] * 3;
-    const int bm = half ? 128 : 256;
     int64_t n_vblocks = 0;   // eight XCD shares of the per-problem shares (next_tile, MODE 1)
     for (int p = 0; p < n; ++p) n_vblocks += 8 * ((((M + bm - 1) / bm) * (int64_t)(mp.tn0[p + 1] - mp.tn0[p]) + 7) / 8);
-    int64_t blocks = (cus[dev] / 8) * 8;
-    if (blocks < 8) blocks = 8;
-    if (blocks > n_vblocks) blocks = n_vblocks;
-    GemmOut o0 = mp.out[0];
-    if (half) {
-        auto kern = fq_gemm_bf6_kernel<128, 1>;
-        FQ_RAISE_LDS_CAP(kern, Geo<128>::STAGES * Geo<128>::TILE_BYTES);
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Geo<128>::GT), Geo<128>::STAGES * Geo<128>::TILE_BYTES, stream, mp.xb[0], mp.wb[0],
-                           (int)M, mp.N[0], K / 64, (int)n_vblocks, o0, mp);
-    } else {
-        auto kern = fq_gemm_bf6_kernel<256, 1>;
-        FQ_RAISE_LDS_CAP(kern, Geo<256>::STAGES * Geo<256>::TILE_BYTES);
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Geo<256>::GT), Geo<256>::STAGES * Geo<256>::TILE_BYTES, stream, mp.xb[0], mp.wb[0],
-                           (int)M, mp.N[0], K / 64, (int)n_vblocks, o0, mp);
-    }
-    return (int)hipGetLastError();
+    const GemmOut o0 = mp.out[0];
+    if (bn == 128) return bf6_launch<128, 1, 128>(n_vblocks, 2, mp.xb[0], mp.wb[0], M, mp.N[0], K, o0, mp, stream);
+    if (bm == 128) return bf6_launch<128, 1, 256>(n_vblocks, 1, mp.xb[0], mp.wb[0], M, mp.N[0], K, o0, mp, stream);
+    return bf6_launch<256, 1, 256>(n_vblocks, 1, mp.xb[0], mp.wb[0], M, mp.N[0], K, o0, mp, stream);
 }

@@ -214,6 +214,10 @@ class Linear4bit(torch.nn.Module):
         return int_module
 
 
+WIDE_DECODE_ROWS = 33          # linear4bit_multi: from this many rows a group of >= WIDE_DECODE_FEATURES output features takes the FP6 tile kernel
+WIDE_DECODE_FEATURES = 16384
+
+
 def linear4bit_multi(modules, inputs):
     """Several ``Linear4bit`` modules of one decoder layer that see the same token count and input width — q_proj / k_proj / v_proj, or
     up_proj / gate_proj (deploy/transformers/modeling_llama.py:66-78, 268-276: one GEMM + dequant per projection in the reference) — each
@@ -225,7 +229,15 @@ def linear4bit_multi(modules, inputs):
     assert len(modules) == len(inputs) and len(modules) >= 1
     q0 = inputs[0].quantized_x
     rows = q0.numel() // q0.shape[-1]
-    if 2 <= len(modules) <= 4 and q0.is_cuda and ops.skinny_supported(rows, modules[0].in_features):
+    # (round 6) 33 .. 128 rows on a WIDE group (up + gate of a decoder layer: >= 16384 features together): the weight-streaming kernel is
+    # compute-bound there (int8 MFMAs behind a nibble unpack: 31 / 44 / 54 us at 64 / 96 / 128 rows of Llama-3-8B's up + gate), the FP6 tile
+    # kernel on its 128 x 128 decode tile is not (26.8 / 27.9 / 29.9 us, activation conversion included; profiles/r06_decode_gemm_routes.txt).
+    # Only with KEPT FP6 images; every narrower group and every lone projection stays on the weight-streaming kernel (faster there).
+    wide = (2 <= len(modules) <= 4 and q0.is_cuda and WIDE_DECODE_ROWS <= rows <= 128 and sum(m.out_features for m in modules) >= WIDE_DECODE_FEATURES
+            and all(m.fp6_gemm and m.fp6_image and ops.bf6_supported(m.out_features, m.in_features) and m.in_features == modules[0].in_features
+                    for m in modules)
+            and all(m._weight_image() is not None for m in modules))
+    if not wide and 2 <= len(modules) <= 4 and q0.is_cuda and ops.skinny_supported(rows, modules[0].in_features):
         # (round 5) decode-sized: ONE launch of the weight-streaming kernel over the members' weight images (a decode-sized launch
         # costs ~4 us whatever it streams — fq_int4_skinny_linear_multi_f16)
         problems = []
@@ -242,7 +254,7 @@ def linear4bit_multi(modules, inputs):
             ys = ops.int4_skinny_linear_multi(problems)
             lead = q0.shape[:-1]
             return [y.view(*lead, m.out_features) for y, m in zip(ys, modules)]
-    ok = 1 <= len(modules) <= 4 and q0.is_cuda and not ops.skinny_supported(rows, modules[0].in_features)
+    ok = 1 <= len(modules) <= 4 and q0.is_cuda and (wide or not ops.skinny_supported(rows, modules[0].in_features))
     for m, x in zip(modules, inputs):
         assert type(x) == PackedQuantizedTensor
         ok = ok and m.fp6_gemm and ops.bf6_supported(m.out_features, m.in_features) and x.quantized_x.shape == q0.shape

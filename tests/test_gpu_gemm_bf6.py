@@ -271,3 +271,59 @@ def test_fp6_image_budget_is_honoured_and_a_refusal_is_not_latched(ops):
     assert torch.equal(model[1](p), refs[1]) and model[1].image_bytes() == need   # asked again, now there is room
     model[1].release_images()
     assert L4._fp6_image_bytes_held == held0
+
+
+@pytest.mark.parametrize("M", [33, 64, 97, 128])
+@pytest.mark.parametrize("Ns,K", [([272], 256), ([4096], 512), ([1040, 528], 384), ([2064, 4096, 16], 256)])
+def test_decode_tile_128x128_bit_identical(ops, M, Ns, K):
+    """(round 6) M <= 128 on the FP6 path runs 128 x 128 tiles (two waves, two workgroups per CU): the same bits as the int8-path kernel —
+    ragged feature counts (a last tile that is mostly padding, a 16-wide problem), one and several problems per launch."""
+    gen = torch.Generator().manual_seed(M + sum(Ns) + K)
+    probs, refs = [], []
+    for N in Ns:
+        x, w = torch.from_numpy(rand_packed(gen, M, K)[0]).cuda(), torch.from_numpy(rand_packed(gen, N, K)[0]).cuda()
+        sx = (torch.rand(M, generator=gen) * 0.05 + 0.001).half().cuda()
+        sw = (torch.rand(N, generator=gen) * 0.02 + 0.0005).half().cuda()
+        b = torch.randn(N, generator=gen).half().cuda() if N % 32 == 16 else None
+        probs.append((x, sx, w, ops.int4_to_bf6(w, weights=True), sw, b))
+        refs.append(ops.int4_linear(x, sx, w, sw, b))
+    ys = [ops.int4_linear_fp6(*probs[0])] if len(Ns) == 1 else ops.int4_linear_fp6_multi(probs)
+    for y, r in zip(ys, refs):
+        assert torch.equal(y.view(torch.int16), r.view(torch.int16))
+
+
+def test_wide_decode_group_takes_the_fp6_tile_kernel(ops, monkeypatch):
+    """linear4bit_multi: a group of >= 16384 output features at 33 .. 128 rows (up + gate at decode batch 64 - 128) runs the FP6 tile kernel
+    over the kept images; fewer rows, a narrower group, or a member without a kept image stay on the weight-streaming kernel. Same bits."""
+    from flatquant_amd.deploy import PackedQuantizedTensor
+    from flatquant_amd.deploy.nn.linear import Linear4bit, linear4bit_multi
+    gen = torch.Generator().manual_seed(4)
+    K = 256
+    mods = []
+    for N in (8192, 8192):
+        m = Linear4bit(K, N).cuda()
+        m.weight.copy_(torch.from_numpy(rand_packed(gen, N, K)[0]))
+        m.weight_scales.copy_((torch.rand(N, 1, generator=gen) * 0.02 + 0.0005))
+        mods.append(m)
+    calls = []
+    real_fp6, real_sk = ops.int4_linear_fp6_multi, ops.int4_skinny_linear_multi
+    monkeypatch.setattr(ops, "int4_linear_fp6_multi", lambda p: (calls.append("fp6"), real_fp6(p))[1])
+    monkeypatch.setattr(ops, "int4_skinny_linear_multi", lambda p: (calls.append("skinny"), real_sk(p))[1])
+    for rows, want in ((64, "fp6"), (128, "fp6"), (33, "fp6"), (32, "skinny"), (1, "skinny")):
+        xs = [PackedQuantizedTensor(torch.from_numpy(rand_packed(gen, rows, K)[0]).cuda().reshape(1, rows, K // 2),
+                                    (torch.rand(1, 1, rows, generator=gen) * 0.05 + 0.001).half().cuda()) for _ in mods]
+        calls.clear()
+        ys = linear4bit_multi(mods, xs)
+        assert calls == [want], (rows, calls)
+        for m, x, y in zip(mods, xs, ys):
+            ref = ops.int4_linear(x.quantized_x.reshape(rows, -1), x.scales_x.reshape(-1), m.weight, m.weight_scales.reshape(-1).half(), None)
+            assert torch.equal(y.reshape(rows, -1).view(torch.int16), ref.view(torch.int16)), rows
+    mods[1].fp6_image = False                      # no kept image on one member: the weight-streaming kernel
+    mods[1].release_images()
+    calls.clear()
+    linear4bit_multi(mods, xs[:2] if rows != 1 else xs)
+    xs = [PackedQuantizedTensor(torch.from_numpy(rand_packed(gen, 64, K)[0]).cuda().reshape(1, 64, K // 2),
+                                (torch.rand(1, 1, 64, generator=gen) * 0.05 + 0.001).half().cuda()) for _ in mods]
+    calls.clear()
+    linear4bit_multi(mods, xs)
+    assert calls == ["skinny"]
