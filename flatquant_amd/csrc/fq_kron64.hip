@@ -367,6 +367,17 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     int next_pulled = 0;
     FqGroupCursor gcur;  // grouped launches: the clip pair follows the token's group
 
+#ifndef FQ_K64_HOIST
+#define FQ_K64_HOIST 0   // measurement: 1 = the 16 factor fragments live in registers (64 VGPRs; needs FQ_K64_THREADS=512: two waves per SIMD)
+#endif
+#if FQ_K64_HOIST
+    X8 BF[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) BF[f] = __builtin_bit_cast(X8, frag[f * 64 + lane]);
+#define FQ_BFRAG(f) BF[f]
+#else
+#define FQ_BFRAG(f) __builtin_bit_cast(X8, myfrag[(f) * 64])
+#endif
     while (slot < blk_cnt) {
         const int64_t tok = blk_base + slot;
         // Launder the lane offset every iteration: otherwise LICM hoists all 16 loop-invariant fragment reads
@@ -455,8 +466,8 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
         U[0][0] = f32x16{0}; U[0][1] = f32x16{0}; U[1][0] = f32x16{0}; U[1][1] = f32x16{0};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const X8 b0 = __builtin_bit_cast(X8, myfrag[(0 * 4 + s) * 64]);
-            const X8 b1 = __builtin_bit_cast(X8, myfrag[(1 * 4 + s) * 64]);
+            const X8 b0 = FQ_BFRAG(0 * 4 + s);
+            const X8 b1 = FQ_BFRAG(1 * 4 + s);
             U[0][0] = mfma32<T>(__builtin_bit_cast(X8, X[0][s]), b0, U[0][0]);
             U[1][0] = mfma32<T>(__builtin_bit_cast(X8, X[1][s]), b0, U[1][0]);
             U[0][1] = mfma32<T>(__builtin_bit_cast(X8, X[0][s]), b1, U[0][1]);
@@ -479,8 +490,8 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
         Y[0][0] = f32x16{0}; Y[0][1] = f32x16{0}; Y[1][0] = f32x16{0}; Y[1][1] = f32x16{0};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const X8 b0 = __builtin_bit_cast(X8, myfrag[(8 + ks * 2 + 0) * 64]);
-            const X8 b1 = __builtin_bit_cast(X8, myfrag[(8 + ks * 2 + 1) * 64]);
+            const X8 b0 = FQ_BFRAG(8 + ks * 2 + 0);
+            const X8 b1 = FQ_BFRAG(8 + ks * 2 + 1);
             Y[0][0] = mfma32<T>(Uh[0][ks], b0, Y[0][0]);
             Y[1][0] = mfma32<T>(Uh[1][ks], b0, Y[1][0]);
             Y[0][1] = mfma32<T>(Uh[0][ks], b1, Y[0][1]);
