@@ -41,7 +41,7 @@ namespace {
 #define DUO_MEET_SLEEP 1   // s_sleep argument (x 64 cycles) between two polls of a meeting counter (measured: 4 -> +2 us, 12 -> +4 us)
 #endif
 #ifndef DUO_ABL
-#define DUO_ABL 0   // measurement builds (tools/variants.sh): 1 no GEMM 1 MFMAs, 2 no GEMM 2 MFMAs, 4 no quantiser, 8 no DMA after the first
+#define DUO_ABL 0   // measurement builds (tools/variants.sh): 1 no GEMM 1 MFMAs, 2 no GEMM 2 MFMAs, 4 no quantiser, 8 no DMA after the first; 256 (round 6): with 1 | 2, the MFMAs' operand reads (LDS, L2) STAY
 #endif              // token, 16 no extrema, 32 no A-fragment reads, 64 no L-fragment reads, 128 no R stream
 constexpr int DUO_KS1 = 14, DUO_NT = 7, DUO_CPR = 28, DUO_PITCH = 28, DUO_N = 224;
 constexpr int DUO_GROUPS = 2, DUO_WPG = 4, DUO_GT = DUO_WPG * 64, DUO_THREADS = DUO_GROUPS * DUO_GT;
@@ -299,6 +299,7 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const T* __res
 #pragma unroll
                         for (int t = 0; t < TN; ++t)
                             if (!(DUO_ABL & 1)) U[t][mt] = fq_mfma32<T>(A[s & 1][mt], RB[t][s % DR], U[t][mt]);
+                            else if (DUO_ABL & 256) asm volatile("" : : "v"(A[s & 1][mt]), "v"(RB[t][s % DR]));   // (the operand reads stay)
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(DUO_THREADS) void fq_kron_duo_kernel(const T* __res
 #pragma unroll
                             for (int t = 0; t < TN; ++t)
                                 if (!(DUO_ABL & 2)) Y[t][mo] = fq_mfma32<T>(Uh[t][ks >> 1][ks & 1], B[ks % NBUF][mo], Y[t][mo]);
+                                else if (DUO_ABL & 256) asm volatile("" : : "v"(B[ks % NBUF][mo]));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }

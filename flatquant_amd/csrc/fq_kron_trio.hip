@@ -192,6 +192,7 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
                     A[i1 % DA] = __builtin_bit_cast(f16x8, tb[(i1 % MT) * 32 * CPR + (((i1 / MT) * 2 + h) ^ swl)]);
                 }
                 if (!(TRIO_ABL & 2)) U[i % MT] = mfma32(A[i % DA], RF[i / MT], U[i % MT]);
+                else if (TRIO_ABL & 32) asm volatile("" : : "v"(A[i % DA]), "v"(RF[i / MT]));   // (round 6: the operand reads stay)
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(TRIO_THREADS) void fq_kron_trio_kernel(const f16* _
                 const int ks = i / MT, mo = i % MT;
                 if (i + DB - 1 < NB) B[(i + DB - 1) % DB] = __builtin_bit_cast(f16x8, mylfr[(i + DB - 1) * 64]);
                 if (!(TRIO_ABL & 4) && (ks < 2 * MT - 2 || ks < ks_n)) Y[mo] = mfma32(Uh[ks >> 1][ks & 1], B[i % DB], Y[mo]);
+                else if (TRIO_ABL & 32) asm volatile("" : : "v"(B[i % DB]));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -195,6 +195,7 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const T* __restric
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         if (!(WAVE_ABL & 2)) U[nt][mt] = fq_mfma32<T>(A[s & 1][mt], B[s & 1][nt], U[nt][mt]);
+                        else if (WAVE_ABL & 32) asm volatile("" : : "v"(A[s & 1][mt]), "v"(B[s & 1][nt]));   // (round 6: the operand reads stay)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(W * 64) void fq_kron_wave_kernel(const T* __restric
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     if (!(WAVE_ABL & 4)) Y[nt][mo] = fq_mfma32<T>(Uh[nt][ks], B[i & 1], Y[nt][mo]);
+                    else if (WAVE_ABL & 32) asm volatile("" : : "v"(B[i & 1]));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
