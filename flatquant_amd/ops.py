@@ -68,19 +68,76 @@ def cache_epoch() -> int:
     return _CACHE_EPOCH[0]
 
 
+class _CacheRegistry:
+    """ONE object over every cache this module keeps (VERDICT r05 hygiene: seven caches keyed on data_ptr / version, each with its own
+    rules). The protocol, for all of them:
+      * KEY: (data_ptr, ver(tensor)) of the tensors a value was derived from (+ device / stream where the value is a device buffer) — an
+        in-place write through the tensor bumps the version and misses; a write through ``.data`` does not: invalidate().
+      * INVALIDATION: ``invalidate()`` (= ops.invalidate_caches()) clears every DERIVED cache and bumps the epoch the modules' own launch
+        plans carry in their keys; load_state_dict of any mirror module calls it (invalidate_on_load).
+      * PINNING: a value handed to a launch issued UNDER STREAM CAPTURE moves to its cache's pinned side and is never freed or cleared —
+        the captured graph replays the raw pointer (fragment images: _WS_PINNED; split-decode workspaces: _KV_SPLIT_WS_PINNED).
+      * BOUNDS: every unpinned cache is bounded by entries and, where entries are device buffers, by bytes (least recently used first).
+    ``stats()`` reports entries and device bytes per cache (tests, tools/host_overhead.py)."""
+
+    def __init__(self):
+        self._derived, self._pinned, self._hooks = {}, {}, []
+
+    def register(self, name, mapping, pinned=False):
+        (self._pinned if pinned else self._derived)[name] = mapping
+        return mapping
+
+    def on_invalidate(self, fn):
+        self._hooks.append(fn)
+        return fn
+
+    def invalidate(self):
+        _CACHE_EPOCH[0] += 1    # (module-held launch plans carry the epoch in their key: deploy.nn.OnlineTrans / Quantizer / Linear4bit)
+        for m in self._derived.values():
+            m.clear()           # (the pinned sides stay: a captured graph replays the pointers it was given)
+        for fn in self._hooks:
+            fn()
+
+    @staticmethod
+    def _bytes(v):
+        if isinstance(v, torch.Tensor):
+            return v.numel() * v.element_size() if v.is_cuda else 0
+        if isinstance(v, (tuple, list)):
+            return _CacheRegistry._bytes(v[0]) if v else 0      # (entries are (buffer, the tensors it was derived from, ...): count the buffer)
+        return 0
+
+    def stats(self) -> dict:
+        out = {}
+        for side, maps in (("derived", self._derived), ("pinned", self._pinned)):
+            for name, m in maps.items():
+                out[name] = {"side": side, "entries": len(m), "device_bytes": sum(self._bytes(v) for v in m.values())}
+        out["epoch"] = _CACHE_EPOCH[0]
+        return out
+
+
+CACHES = _CacheRegistry()
+CACHES.register("host_scalars", _SCALARS)
+
+
+def cache_stats() -> dict:
+    """Entries and device bytes of every cache of this module, derived and pinned (see _CacheRegistry)."""
+    return CACHES.stats()
+
+
 def invalidate_caches() -> None:
     """Forget every value this module derived from tensors it does not own: host copies of clip scalars (host_scalar),
-    fragment workspaces of factor matrices, Hadamard factor pairs. The caches are keyed by (data_ptr, tensor._version):
-    an in-place write through the tensor itself (``t.fill_()``, ``t.copy_()``) bumps the version and is seen, a write
+    fragment workspaces of factor matrices, Hadamard factor pairs, unpinned split-decode workspaces. The caches are keyed by
+    (data_ptr, ver(tensor)): an in-place write through the tensor itself (``t.fill_()``, ``t.copy_()``) bumps the version and is seen, a write
     through ``t.data`` (``mod.clip_factor_a_max.data.fill_(..)``, ``weight.data.copy_(..)``) does NOT — call this after
-    such an update (checkpoint loaders that assign ``.data`` should), or update in place on the tensor."""
-    _CACHE_EPOCH[0] += 1    # (module-held launch plans carry the epoch in their key: deploy.nn.OnlineTrans / Quantizer with static_outputs)
-    _SCALARS.clear()
+    such an update (checkpoint loaders that assign ``.data`` should), or update in place on the tensor. One protocol for all of them:
+    _CacheRegistry."""
+    CACHES.invalidate()
+
+
+@CACHES.on_invalidate
+def _clear_function_caches():
     _sigmoid_pair_cached.cache_clear()
     _sig_f16_cached.cache_clear()
-    _WS_LRU.clear()
-    _WS_ANY.clear()     # (_WS_PINNED stays: a captured graph replays the pointers it was given, see _pin_for_capture)
-    _HAD_KRON.clear()
     from .flatquant.trans_utils import _Fp16Cache   # the modules' fp16 / bf16 copies of their (fp32) matrices
     _Fp16Cache.clear_all()
 
@@ -244,19 +301,19 @@ def _alloc_outputs(x: torch.Tensor, rows: int, d: int, n_clips: int, flags: int,
 # left/right into MFMA fragment order there (~5 us); a deployed layer passes the same two buffers every call, so the
 # second call onwards skips the re-pack (FQ_WS_PREPARED). An entry keeps its tensors alive (their addresses cannot be
 # recycled under it) and is keyed by torch's version counters (in-place updates miss). LRU-bounded.
-_WS_LRU: "collections.OrderedDict" = collections.OrderedDict()
+_WS_LRU: "collections.OrderedDict" = CACHES.register("kron_images_by_stream", collections.OrderedDict())
 _WS_LRU_MAX = 512
 _WS_LRU_MAX_BYTES = 256 << 20   # and by bytes: a caller that re-stacks per-expert matrices on every call (keys never repeat) would
                                 # otherwise pin hundreds of multi-megabyte images before the count bound evicts one
 
 
 _WS_BYTES: dict = {}   # fq_kron_workspace_bytes(M, N): a pure function of the pair
-_WS_ANY: dict = {}     # the same images by (device, M, N, left, right) WITHOUT the stream: (ws, left, right, [complete], event of the preparing launch)
+_WS_ANY: dict = CACHES.register("kron_images_any_stream", {})     # the same images by (device, M, N, left, right) WITHOUT the stream: (ws, left, right, [complete], event of the preparing launch)
 _WS_ANY_MAX_BYTES = _WS_LRU_MAX_BYTES
 # Images handed to a launch issued UNDER STREAM CAPTURE: the graph holds the raw pointer (FQ_WS_PREPARED, no prepare kernel of its own)
 # for as long as it is replayed, so the cache may never free them — not on an LRU / byte-bound eviction, not on invalidate_caches()
 # (a load_state_dict hook of ANY module calls that). id(workspace) -> (workspace, left, right). Bounded by what graphs were captured.
-_WS_PINNED: dict = {}
+_WS_PINNED: dict = CACHES.register("kron_images_pinned", {}, pinned=True)
 
 
 def _pin_for_capture(ent) -> None:
@@ -736,7 +793,7 @@ def kron_quant_ex(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, post
 # The online Hadamard rotation of n = K * P (hadK (x) H_P, 1/sqrt(n)) in front of the deploy Quantizer as ONE Kronecker
 # launch: x.view(K * P / N, N) -> left = kron(hadK, H_{P/N}) (+-1), right = H_N / 16, post_scale = 16 / sqrt(n). The
 # factor pair is built once per (hadK, P) and kept (the fragment workspace cache is keyed by these tensors).
-_HAD_KRON: "collections.OrderedDict" = collections.OrderedDict()
+_HAD_KRON: "collections.OrderedDict" = CACHES.register("hadamard_factor_pairs", collections.OrderedDict())
 
 
 def _sylvester(n: int) -> torch.Tensor:
@@ -1620,8 +1677,8 @@ def kv_quant_append(k: torch.Tensor, v: torch.Tensor, trans: Optional[torch.Tens
 # no memset, and replayed first would read garbage counters. A capture that finds no workspace runs the unsplit launch (same results up to
 # the order of fp32 additions); warm the shape up eagerly on the capture stream first (tools/bench_decode.py does; torch.cuda.graph's own
 # warm-up convention). An entry a capture HAS used is pinned (the graph replays its address); the others are bounded, least recently used first.
-_KV_SPLIT_WS: "collections.OrderedDict" = collections.OrderedDict()
-_KV_SPLIT_WS_PINNED: dict = {}
+_KV_SPLIT_WS: "collections.OrderedDict" = CACHES.register("kv_split_workspaces", collections.OrderedDict())
+_KV_SPLIT_WS_PINNED: dict = CACHES.register("kv_split_workspaces_pinned", {}, pinned=True)
 _KV_SPLIT_WS_MAX = 16
 
 

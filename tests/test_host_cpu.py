@@ -669,3 +669,25 @@ def test_fresh_plan_set_keeps_one_plan_per_shape_and_drops_all_on_a_key_change()
         st.add(x, Plan(x))
     assert len(st.plans) == st.KEEP
     assert st.lookup(("k", 1), b) is None and not st.plans and st.last is None
+
+
+def test_cache_registry_one_protocol_for_every_cache():
+    """ops.CACHES: every cache of ops.py under one object — invalidate() clears the derived sides, bumps the epoch the modules' plans
+    carry, leaves the pinned sides (a captured graph replays those pointers); stats() names them all."""
+    from flatquant_amd import ops
+    st = ops.cache_stats()
+    for name in ("host_scalars", "kron_images_by_stream", "kron_images_any_stream", "hadamard_factor_pairs", "kv_split_workspaces"):
+        assert st[name]["side"] == "derived"
+    for name in ("kron_images_pinned", "kv_split_workspaces_pinned"):
+        assert st[name]["side"] == "pinned"
+    ops._SCALARS[("probe", 0)] = (1.0, None)
+    ops._KV_SPLIT_WS[("probe",)] = None
+    ops._WS_PINNED[123456789] = (None, None, None)
+    e0 = ops.cache_epoch()
+    try:
+        ops.invalidate_caches()
+        assert ops.cache_epoch() == e0 + 1
+        assert ("probe", 0) not in ops._SCALARS and ("probe",) not in ops._KV_SPLIT_WS
+        assert 123456789 in ops._WS_PINNED
+    finally:
+        ops._WS_PINNED.pop(123456789, None)
