@@ -18,6 +18,7 @@ for PMC in "FETCH_SIZE" "WRITE_SIZE" \
   rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc$i -o p -- $CMD > $OUT/pmc$i.log 2>&1
 done
 python $R/tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
+python $R/tools/trace_outliers.py $OUT/trace fq_kron64_kernel > $OUT/outliers.txt 2>&1   # (round 6: where the slow launches of the trace sit)
 # prune the raw rocprofv3 output (gpurun copies back at most 64 MiB): keep the summary and the kernel-stats csv
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \; 2>/dev/null
 rm -rf $OUT/trace $OUT/pmc[0-9]* 2>/dev/null; find $OUT -name "*.log" -size +64k -delete 2>/dev/null
