@@ -153,7 +153,10 @@ template <> struct GemmMultiArg<true> {
 //  SiLU arithmetic sits where no MFMA overlaps it; 1401 us fused against 1397 separate, a loss at 2048 tokens — profiles/r04_gate_up_epilogue.txt)
 // Measurement knob (tools/variants.sh builds overlay objects with it; the product build leaves it 0) — the ablations behind
 // profiles/r06_gemm_epilogue_experiments.txt: 1 the epilogue's arithmetic without its stores; 2 no epilogue; 3 no LDS reads of the weight
-// fragments; 4 = 3 + no LDS-DMA of the weight operand; 5 no fragment reads at all; 6 no MFMAs (the fragments are consumed by an empty asm).
+// fragments; 4 = 3 + no LDS-DMA of the weight operand; 5 no fragment reads at all; 6 no MFMAs (the fragments are consumed by an empty asm);
+// 9 (timing only, wrong data): the token operand's LDS-DMA GATHERS 16-byte units from a token-major image (32 rows x 2 units per instruction) —
+// what a transform kernel could write without a 32-token transpose (FQ_OUT_BF6): 154 -> 190 us, the address path of the gather costs twice
+// what the conversion launch it would save does (profiles/r06_gemm_epilogue_experiments.txt, 5).
 #ifndef GEMM_ABL
 #define GEMM_ABL 0
 #endif
@@ -218,7 +221,22 @@ __global__ __launch_bounds__((Geo<BM, BN>::GT), 2) void fq_gemm_bf6_kernel(const
         // (the instruction's immediate offset moves BOTH addresses: the LDS base in M0 is the row tile's, part j % 3 comes from the offset)
         const unsigned dst = lds0 + (unsigned)((s % STAGES) * TILE_BYTES) + (unsigned)(wave * DPW + j - j % 3) * 1024u;
         const unsigned char* src = gbase[j / 3] + (int64_t)s * SEG;
+        if (GEMM_ABL == 9) {
+            const size_t s_ = (size_t)src;
+            src = reinterpret_cast<const unsigned char*>(
+                (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)s_) | ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(s_ >> 32)) << 32));
+        }
         unsigned keep;
+        if (GEMM_ABL == 9 && wave * DPW + j >= WDMA) {   // timing only: the token operand GATHERED from a token-major image (32 rows x 2 units per instruction)
+            const unsigned vx = (unsigned)(lane & 31) * (unsigned)(KB * 48) + (unsigned)(lane >> 5) * 16u;
+            const size_t sx_ = (size_t)(gbase[j / 3] + (int64_t)s * 96 + (j % 3) * 32);
+            const unsigned char* srcx = reinterpret_cast<const unsigned char*>(
+                (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sx_) | ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sx_ >> 32)) << 32));
+            const unsigned dstx = dst + (unsigned)(j % 3) * 1024u;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(vx), "s"(srcx), "s"(__builtin_amdgcn_readfirstlane((int)dstx)) : "memory");
+            return;
+        }
 #define FQ_GLDS(OFF)                                                                                                  \
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" OFF "\n\ts_mov_b32 m0, %0"        \
                      : "=&s"(keep) : "v"(voff), "s"(src), "s"(__builtin_amdgcn_readfirstlane((int)dst)) : "memory")
