@@ -23,6 +23,7 @@ What makes an entry stale and sends the call back to the eager path (then re-cap
 The returned tensors are the graph's OUTPUT BUFFERS: valid until the next call of the same wrapper with the same signature — a decoder
 layer's output is consumed by the next layer within the step, which is the reference's usage; ``clone_outputs=True`` copies them out."""
 import torch
+from torch.utils import _pytree
 
 from .. import ops
 
@@ -48,49 +49,55 @@ class _Entry:
 
 
 class GraphedDecode:
+    MAX_SIGNATURES = 64     # captured graphs + signatures still in warm-up kept per wrapper (least recently created first out)
+
     def __init__(self, fn, max_rows: int = DECODE_ROWS, warmup: int = 2, clone_outputs: bool = False):
         self.fn, self.max_rows, self.warmup, self.clone_outputs = fn, max_rows, max(1, warmup), clone_outputs
-        self._entries, self._seen = {}, {}
+        self._entries, self._seen, self._logs = {}, {}, {}
         self._stream = None
         self.replays = self.captures = self.eager_calls = 0     # (counters: tests, tools/bench_decode.py)
 
     # -- argument handling ------------------------------------------------------------------------------------------------
     def _split(self, args, kwargs):
-        """-> (tensor slots [(where, key)], tensors, caches, signature) or None when the call is not one to capture."""
-        slots, tensors, caches, sig = [], [], [], []
-        for where, items in (("a", enumerate(args)), ("k", sorted(kwargs.items()))):
-            for k, v in items:
-                if isinstance(v, torch.Tensor):
-                    if not v.is_cuda or v.requires_grad:
-                        return None
-                    slots.append((where, k)), tensors.append(v)
-                    sig.append((where, k, tuple(v.shape), v.dtype, v.device.index))
-                elif _is_cache(v):
-                    caches.append(v)
-                    sig.append((where, k, "cache", id(v)))
-                elif v is None or isinstance(v, (bool, int, float, str)):
-                    sig.append((where, k, v))
-                else:
-                    sig.append((where, k, "obj", id(v)))     # (a module, a tuple of tensors, ...: by identity — its CONTENT must be static)
+        """-> (leaves, spec, tensor positions, tensors, caches, signature) or None when the call is not one to capture. The arguments are
+        flattened as a pytree, so tensors inside tuples / lists / dicts (HF's ``position_embeddings=(cos, sin)``) are graph inputs too."""
+        leaves, spec = _pytree.tree_flatten((args, kwargs))
+        pos, tensors, caches, sig = [], [], [], [spec]
+        for i, v in enumerate(leaves):
+            if isinstance(v, torch.Tensor):
+                if not v.is_cuda or v.requires_grad:
+                    return None
+                pos.append(i), tensors.append(v)
+                sig.append((tuple(v.shape), v.dtype, v.device.index))
+            elif _is_cache(v):
+                caches.append(v)
+                sig.append(("cache", id(v)))
+            elif v is None or isinstance(v, (bool, int, float, str)):
+                sig.append(v)
+            else:
+                sig.append(("obj", id(v)))     # (a module, a config object, ...: by identity — its CONTENT must not change between steps)
         if not tensors:
             return None
-        lead = tensors[0]
         rows = 1
-        for d in lead.shape[:-1]:
+        for d in tensors[0].shape[:-1]:
             rows *= d
         if rows > self.max_rows or rows == 0:
             return None
-        return slots, tensors, caches, tuple(sig)
+        return leaves, spec, pos, tensors, caches, tuple(sig)
 
     @staticmethod
-    def _subst(args, kwargs, slots, tensors):
-        args, kwargs = list(args), dict(kwargs)
-        for (where, k), t in zip(slots, tensors):
-            if where == "a":
-                args[k] = t
-            else:
-                kwargs[k] = t
-        return args, kwargs
+    def _subst(leaves, spec, pos, tensors):
+        leaves = list(leaves)
+        for i, t in zip(pos, tensors):
+            leaves[i] = t
+        return _pytree.tree_unflatten(leaves, spec)
+
+    def _remember(self, sig, n):
+        """warm-up counts per signature, bounded: a caller whose signature changes on every call (a growing attention mask, a fresh
+        object per step) must not grow this table without limit — it simply stays eager."""
+        if sig not in self._seen and len(self._seen) >= self.MAX_SIGNATURES:
+            self._seen.pop(next(iter(self._seen)))
+        self._seen[sig] = n
 
     # -- the call -----------------------------------------------------------------------------------------------------------
     def __call__(self, *args, **kwargs):
@@ -99,7 +106,7 @@ class GraphedDecode:
         sp = self._split(args, kwargs)
         if sp is None:
             return self.fn(*args, **kwargs)
-        slots, tensors, caches, sig = sp
+        leaves, spec, pos, tensors, caches, sig = sp
         if any(any(c._needs_init) for c in caches):          # (a prompt has not been through this cache yet: the prefill branch of update())
             return self.fn(*args, **kwargs)
         ent = self._entries.get(sig)
@@ -108,22 +115,24 @@ class GraphedDecode:
                 or any(c.would_grow(sum(a for _, a in log)) for c, log in zip(caches, ent.logs))
             if stale:
                 del self._entries[sig]
-                self._seen[sig] = self.warmup - 1            # one eager call (it re-allocates / re-warms), then a new capture
+                self._remember(sig, self.warmup - 1)         # one eager call (it re-allocates / re-warms), then a new capture
                 ent = None
         if ent is None:
             n = self._seen.get(sig, 0)
             if n + 1 < self.warmup:
-                self._seen[sig] = n + 1
+                self._remember(sig, n + 1)
                 self.eager_calls += 1
                 return self.fn(*args, **kwargs)
             if n + 1 == self.warmup:                          # the last warm-up: on the capture stream, recording the caches' host steps
-                self._seen[sig] = n + 1
+                self._remember(sig, n + 1)
                 self.eager_calls += 1
                 return self._recorded_eager(args, kwargs, caches, sig)
-            ent = self._capture(args, kwargs, slots, tensors, caches, sig)
+            ent = self._capture(leaves, spec, pos, tensors, caches, sig)
             if ent is None:
                 self.eager_calls += 1
                 return self.fn(*args, **kwargs)
+            if len(self._entries) >= self.MAX_SIGNATURES:
+                self._entries.pop(next(iter(self._entries)))
             self._entries[sig] = ent
         else:
             for s, t in zip(ent.static_in, tensors):
@@ -149,11 +158,13 @@ class GraphedDecode:
             for c in caches:
                 c._log = None
         cur.wait_stream(self._stream)
-        self._seen[("logs", sig)] = logs
+        if sig not in self._logs and len(self._logs) >= self.MAX_SIGNATURES:
+            self._logs.pop(next(iter(self._logs)))
+        self._logs[sig] = logs
         return out
 
-    def _capture(self, args, kwargs, slots, tensors, caches, sig):
-        logs = self._seen.get(("logs", sig))
+    def _capture(self, leaves, spec, pos, tensors, caches, sig):
+        logs = self._logs.pop(sig, None)
         if logs is None or any(step is None for log in logs for step in log):
             return None                                       # (a masked / prefill update: not a replayable step)
         if any(c.would_grow(sum(a for _, a in log)) for c, log in zip(caches, logs)):
@@ -163,7 +174,7 @@ class GraphedDecode:
         self._stream.wait_stream(cur)
         with torch.cuda.stream(self._stream):
             ent.static_in = [t.clone() for t in tensors]
-        sargs, skwargs = self._subst(args, kwargs, slots, ent.static_in)
+        sargs, skwargs = self._subst(leaves, spec, pos, ent.static_in)
         for c, log in zip(caches, logs):
             c.replay_host(log)                                # the host side of THIS step, outside the capture (stream-ordered in front of it)
         self._stream.wait_stream(cur)
@@ -184,4 +195,4 @@ class GraphedDecode:
 
     def release(self):
         """Drop every captured graph (and its private memory pool)."""
-        self._entries.clear(), self._seen.clear()
+        self._entries.clear(), self._seen.clear(), self._logs.clear()

@@ -150,3 +150,27 @@ def test_calls_that_are_not_decode_steps_stay_eager():
     with torch.enable_grad():
         gd(xg)                                                                       # autograd on: eager
     assert gd.replays == n
+
+
+def test_tensors_inside_containers_are_graph_inputs_and_changing_signatures_stay_bounded():
+    """HF passes ``position_embeddings=(cos, sin)``: tensors inside tuples / dicts are copied into static inputs like top-level ones; a caller
+    whose signature changes on every call (a growing mask) never captures, stays correct and does not grow the wrapper's tables."""
+    import flatquant_amd.deploy as deploy
+
+    def fn(h, pe=None, extra=None):
+        cos, sin = pe
+        return h * cos + sin + (0 if extra is None else extra["b"])
+
+    gd = deploy.GraphedDecode(fn)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    with torch.no_grad():
+        for i in range(6):
+            h, c, s_, b = (torch.randn(2, 1, 64, generator=g, device="cuda", dtype=torch.float16) for _ in range(4))
+            got = gd(h, pe=(c, s_), extra={"b": b})
+            assert torch.equal(got, fn(h, pe=(c, s_), extra={"b": b})), i
+        assert gd.captures == 1 and gd.replays == 4
+        gd.MAX_SIGNATURES = 8
+        for i in range(40):                                   # a new shape every call: warm-up forever, tables bounded
+            m = torch.ones(2, 1, 3 + i, device="cuda", dtype=torch.float16)
+            assert gd(m, pe=(m, m)).shape == m.shape
+        assert gd.captures == 1 and len(gd._seen) <= 8 and len(gd._logs) <= 8 and len(gd._entries) <= 8
