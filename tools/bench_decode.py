@@ -97,19 +97,24 @@ def main():
             return down_l(down_t(yg, up=yu))
 
     def time_calls(fn, cache, n):
-        """us per call of fn() launched from Python, the cache growing by one token per call (rewound afterwards)"""
+        """us per call of fn() launched from Python, the cache growing by one token per call (rewound afterwards): the MEDIAN of ten windows of
+        n / 10 calls — one host stall (a 40 ms pause around the hundredth call of the fp16 step, seen at every batch size: a Python GC pass) inside
+        a single window of 100 calls once read 500 us per call for a 165 us step"""
         l0 = cache.length
-        for _ in range(4):
+        for _ in range(12):      # (two eager warm-up calls, the capture, the first replays)
             fn()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
+        per, wins = max(1, n // 10), []
+        for _ in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(per):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            wins.append(e0.elapsed_time(e1) / per * 1e3)
         cache.length = l0
-        return e0.elapsed_time(e1) / n * 1e3
+        return sorted(wins)[len(wins) // 2]
 
     def measure(step, cache):
         """-> (us per step from a captured graph, us per step launched eagerly)"""
@@ -168,6 +173,7 @@ def main():
         g16 = deploy.GraphedDecode(lambda h, c: step16(h))        # the fp16 step through the SAME transparent helper (its cache passed so that
         with torch.no_grad():                                      # the host steps are recorded): what the baseline gains from it
             trans16 = time_calls(lambda: g16(x, cache16), cache16, min(a.iters, 100))
+        g16_counts = (g16.captures, g16.replays, g16.eager_calls)
         del g16, fq, fk, fv, fo, fu, fg, fd, cache16
         torch.cuda.empty_cache()
 
@@ -212,7 +218,7 @@ def main():
         gd = layer.__dict__["forward"]
     print(f"   deploy.fuse(layer, capture=True) {rep}: {transparent:.1f} us per call from Python, no graph code on the caller's side "
           f"({gd.captures} capture(s), {gd.replays} replays, {gd.eager_calls} eager warm-up calls); output finite: {bool(torch.isfinite(y2.float()).all())}"
-          + (f"   | fp16 step through the same helper: {trans16:.1f} us -> {trans16 / transparent:.2f}x; against the EAGER fp16 step "
+          + (f"   | fp16 step through the same helper: {trans16:.1f} us (captures / replays / eager {g16_counts}) -> {trans16 / transparent:.2f}x; against the EAGER fp16 step "
              f"({eager16:.1f} us): {eager16 / transparent:.2f}x" if a.fp16 else ""))
     print(f"Llama-3-8B decoder layer, decode step, {a.bsz} requests x {a.cache} cached tokens: {us:.1f} us per layer from a "
           f"captured graph ({eager:.1f} us launched eagerly from Python); output finite: {bool(torch.isfinite(y.float()).all())}"
