@@ -57,7 +57,17 @@ def _run(world, tmp_path):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=600)[0] for p in procs]
+    import time
+    t0 = time.time()
+    while any(p.poll() is None for p in procs) and time.time() - t0 < 600:
+        if any(p.poll() not in (None, 0) for p in procs):   # one rank gave up (77) or failed: its peers would wait for it in a collective
+            time.sleep(2.0)
+            break
+        time.sleep(0.2)
+    for p in procs:
+        if p.poll() is None:
+            p.kill()
+    outs = [p.communicate()[0] for p in procs]
     if any(p.returncode == 77 for p in procs):
         pytest.skip("RCCL communicator did not come up on this box: " + " | ".join(o.strip()[-200:] for o in outs))
     assert all(p.returncode == 0 for p in procs), outs
