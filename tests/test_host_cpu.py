@@ -691,3 +691,31 @@ def test_cache_registry_one_protocol_for_every_cache():
         assert 123456789 in ops._WS_PINNED
     finally:
         ops._WS_PINNED.pop(123456789, None)
+
+
+def test_static_cache_specs_equal_the_reference_formulas_and_keep_their_storage():
+    """MultiLayerPagedKVCache4Bit._static_specs (round 6: index tensors as static buffers rewritten in place, what a captured decode step needs)
+    == get_cache_specs_for_flash_infer(None) (the reference's per-step formulas, kv_cache.py:362-385) at every length, across page
+    boundaries; the buffers' storage does not move while the pages do not."""
+    from flatquant_amd.deploy.transformers import MultiLayerPagedKVCache4Bit
+    c = MultiLayerPagedKVCache4Bit(3, 16, 64, "cpu", 1, 4, 128, trans="none")
+    ptrs = None
+    for length in (0, 1, 15, 16, 17, 31, 32, 33, 48, 64):
+        c.length = length
+        a, b = c._static_specs(), c.get_cache_specs_for_flash_infer(None)
+        for k in ("kv_indptr", "kv_indices", "last_page_offset"):
+            assert torch.equal(a[k], b[k]) and a[k].dtype == b[k].dtype == torch.int32, (length, k)
+        now = (a["kv_indptr"].data_ptr(), c._st["indices"].data_ptr(), a["last_page_offset"].data_ptr())   # (kv_indices is a view of it: empty at length 0)
+        assert ptrs is None or now == ptrs
+        ptrs = now
+    g0 = c.generation
+    assert not c.would_grow(0) and c.would_grow(1)          # 64 tokens = the 4 pages per request it was built with
+    c._ensure_page_cnt_per_batch(c.page_cnt_from_length(65))
+    c.length = 65
+    assert c.generation == g0 + 1 and c._static_specs()["kv_indices"].numel() == 3 * 5 and c.generation == g0 + 2     # storage moved: captured graphs are stale
+    # the host-step log of update(): what deploy.GraphedDecode replays
+    c2 = MultiLayerPagedKVCache4Bit(2, 16, 64, "cpu", 2, 4, 128, trans="none")
+    c2._needs_init = [False, False]
+    c2.length = 20
+    c2.replay_host([(0, 1), (1, 1)])
+    assert c2.length == 21 and int(c2._specs["last_page_offset"][0]) == 5
