@@ -53,7 +53,7 @@ class GraphedDecode:
 
     def __init__(self, fn, max_rows: int = DECODE_ROWS, warmup: int = 2, clone_outputs: bool = False):
         self.fn, self.max_rows, self.warmup, self.clone_outputs = fn, max_rows, max(1, warmup), clone_outputs
-        self._entries, self._seen, self._logs = {}, {}, {}
+        self._entries, self._seen, self._logs, self._blocked = {}, {}, {}, set()
         self._stream = None
         self.replays = self.captures = self.eager_calls = 0     # (counters: tests, tools/bench_decode.py)
 
@@ -107,8 +107,8 @@ class GraphedDecode:
         if sp is None:
             return self.fn(*args, **kwargs)
         leaves, spec, pos, tensors, caches, sig = sp
-        if any(any(c._needs_init) for c in caches):          # (a prompt has not been through this cache yet: the prefill branch of update())
-            return self.fn(*args, **kwargs)
+        if sig in self._blocked or any(any(c._needs_init) for c in caches):   # (capture failed once | a prompt has not been through this cache
+            return self.fn(*args, **kwargs)                                    #  yet: the prefill branch of update())
         ent = self._entries.get(sig)
         if ent is not None:
             stale = ent.epoch != ops.cache_epoch() or any(c.generation != g for c, g in zip(caches, ent.gens)) \
@@ -128,6 +128,9 @@ class GraphedDecode:
                 self.eager_calls += 1
                 return self._recorded_eager(args, kwargs, caches, sig)
             ent = self._capture(leaves, spec, pos, tensors, caches, sig)
+            if isinstance(ent, tuple):                        # (the capture failed; the step ran eagerly inside _capture)
+                self.eager_calls += 1
+                return ent[1]
             if ent is None:
                 self.eager_calls += 1
                 return self.fn(*args, **kwargs)
@@ -185,6 +188,12 @@ class GraphedDecode:
         try:
             with torch.cuda.graph(ent.graph, stream=self._stream):
                 ent.out = self.fn(*sargs, **skwargs)
+        except Exception:
+            # The callable cannot be captured (an op that synchronises, allocates on the host, ...). The caches' host steps of THIS call have
+            # been applied: run the step eagerly with the caches still told to leave their host side alone, never try this signature again.
+            self._blocked.add(sig)
+            torch.cuda.synchronize()
+            return ("eager", self.fn(*sargs, **skwargs))
         finally:
             for c in caches:
                 c._skip_host = False
@@ -195,4 +204,4 @@ class GraphedDecode:
 
     def release(self):
         """Drop every captured graph (and its private memory pool)."""
-        self._entries.clear(), self._seen.clear(), self._logs.clear()
+        self._entries.clear(), self._seen.clear(), self._logs.clear(), self._blocked.clear()

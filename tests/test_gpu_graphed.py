@@ -174,3 +174,25 @@ def test_tensors_inside_containers_are_graph_inputs_and_changing_signatures_stay
             m = torch.ones(2, 1, 3 + i, device="cuda", dtype=torch.float16)
             assert gd(m, pe=(m, m)).shape == m.shape
         assert gd.captures == 1 and len(gd._seen) <= 8 and len(gd._logs) <= 8 and len(gd._entries) <= 8
+
+
+def test_a_callable_that_cannot_be_captured_falls_back_to_eager_for_good():
+    """An op that synchronises inside the callable makes stream capture fail: the wrapper runs that call eagerly, remembers the signature and never
+    tries again — results stay right, nothing raises."""
+    import flatquant_amd.deploy as deploy
+
+    def fn(h):
+        return h * float(h.abs().max().item())          # .item(): a device synchronisation, illegal under capture
+
+    gd = deploy.GraphedDecode(fn)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    with torch.no_grad():
+        for i in range(6):
+            h = torch.randn(1, 1, 64, generator=g, device="cuda", dtype=torch.float16)
+            assert torch.equal(gd(h), fn(h)), i
+    assert gd.captures == 0 and gd.replays == 0 and len(gd._blocked) == 1
+    # the wrapper still captures other callables' signatures afterwards (the failed capture left no capture state behind)
+    gd2 = deploy.GraphedDecode(lambda h: h + 1)
+    with torch.no_grad():
+        outs = [gd2(torch.ones(1, 1, 8, device="cuda", dtype=torch.float16)).clone() for _ in range(4)]
+    assert gd2.captures == 1 and all(torch.equal(o, outs[0]) for o in outs)
