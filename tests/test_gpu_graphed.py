@@ -196,3 +196,45 @@ def test_a_callable_that_cannot_be_captured_falls_back_to_eager_for_good():
     with torch.no_grad():
         outs = [gd2(torch.ones(1, 1, 8, device="cuda", dtype=torch.float16)).clone() for _ in range(4)]
     assert gd2.captures == 1 and all(torch.equal(o, outs[0]) for o in outs)
+
+
+def test_hf_shaped_layer_call_with_keyword_arguments():
+    """The call shape of the reference's decoder layer (deploy/transformers/modeling_llama.py:45-153 behind HF's LlamaDecoderLayer.forward):
+    everything by keyword — position ids and cache position as tensors that change every step, (cos, sin) as a tuple, the cache as
+    ``past_key_value``, flags as Python bools, a tuple coming back — through deploy.fuse(model, capture=True), against the eager layer."""
+    import flatquant_amd.deploy as deploy
+    with torch.no_grad():
+        inner, new_cache, g = build(2, page=16, prompt=9, max_len=64, seed=8)
+
+        class HFLayer(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.self_attn, self.mlp = inner.self_attn, inner.mlp
+
+            def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False,
+                        use_cache=False, cache_position=None, position_embeddings=None):
+                cos, sin = position_embeddings
+                h = hidden_states * cos + sin + position_ids.to(hidden_states.dtype).unsqueeze(-1) * 0.001
+                a = self.self_attn(h, past_key_value)
+                out = (hidden_states + a + cache_position.to(a.dtype).reshape(1, 1, 1) * 0.01,)
+                return out + ((self.mlp(a),) if use_cache else ())
+
+        layer = HFLayer()
+        steps = []
+        for t in range(8):
+            steps.append(dict(hidden_states=torch.randn(2, 1, 4096, generator=g, device="cuda", dtype=torch.float16), attention_mask=None,
+                              position_ids=torch.full((2, 1), 9 + t, device="cuda"), output_attentions=False, use_cache=True,
+                              cache_position=torch.tensor([9 + t], device="cuda"),
+                              position_embeddings=(torch.rand(2, 1, 4096, generator=g, device="cuda", dtype=torch.float16),
+                                                   torch.rand(2, 1, 4096, generator=g, device="cuda", dtype=torch.float16))))
+        ref_cache = new_cache()
+        want = [tuple(o.clone() for o in layer(past_key_value=ref_cache, **kw)) for kw in steps]
+        assert deploy.fuse(layer, capture=True)["graphed_layers"] == 1
+        cache = new_cache()
+        for t, kw in enumerate(steps):
+            got = layer(past_key_value=cache, **kw)
+            assert isinstance(got, tuple) and len(got) == 2
+            for a, b in zip(got, want[t]):
+                assert torch.equal(a, b), t
+        gd = layer.__dict__["forward"]
+        assert gd.captures == 1 and gd.replays == 6 and cache.length == ref_cache.length == 17
