@@ -11,6 +11,9 @@
 int fq_launch_kron64(int flags, const f16* x, const f16* left, const f16* right, const f16* diag,
                      int64_t rows, const FqQuantOut& out, int n_cu, hipStream_t stream, const void* prep = nullptr);
 int fq_launch_kron64_prepare(const void* left, const void* right, void* image, hipStream_t stream);
+int fq_launch_kron64_linear(const f16* x, const void* prep, int64_t M, float rms_eps, bool rms, int rt_flags, int n, const void* const* wimg,
+                            const f16* const* scol, const f16* const* bias, const float* sig_max, const float* sig_min, const int* N,
+                            f16* const* y, int n_cu, hipStream_t stream);
 // The optional workspace of the 64 x 64 pair: the 16 KB fragment image fq_kron64_kernel reads, followed by the 16 KB image of the
 // workgroup-per-token kernel (the few output sets fq_kron64 has no instantiation for fall through to it).
 constexpr int64_t FQ_K64_IMAGE_BYTES = 16384, FQ_K64_WS_BYTES = 32768;
@@ -784,6 +787,42 @@ int fq_int4_skinny_linear_multi_f16(int n, const void* const* x, const void* con
     const int rc = fq_launch_gemm_i4_skinny_multi(n, (const uint8_t* const*)x, w_image, M, N, K, (f16* const*)y, (const f16* const*)x_scale,
                                                   (const f16* const*)w_scale, (const f16* const*)bias, (hipStream_t)stream);
     if (rc == -1000) return fail(FQ_EUNSUPPORTED, "%s: M=%lld K=%d (M <= 128, K %% 64 == 0)", what, (long long)M, K);
+    return check_launch(rc, what);
+}
+
+int fq_kron64_linear_multi_f16(const void* x, int rmsnorm, float rms_eps, const void* left, const void* right, int64_t M, int n,
+                               const float* sig_max, const float* sig_min, int flags, const void* const* w_image, const void* const* w_scale,
+                               const void* const* bias, const int* N, void* const* y, void* workspace, int64_t workspace_bytes, void* stream) {
+    const char* what = "fq_kron64_linear_multi_f16";
+    if (n < 1 || n > 4) return fail(FQ_EINVAL, "%s: n=%d problems (1..4)", what, n);
+    if (M < 0 || !N) return fail(FQ_EINVAL, "%s: bad sizes", what);
+    if (flags & ~(FQ_NO_CLAMP0 | FQ_ROUND_Y_F16 | FQ_WS_PREPARED)) return fail(FQ_EINVAL, "%s: unknown flag bits 0x%x", what, flags);
+    if (rmsnorm && !(rms_eps >= 0.0f)) return fail(FQ_EINVAL, "%s: eps must be >= 0", what);
+    if (!sig_max || !sig_min || !w_image || !w_scale || !y) return fail(FQ_EINVAL, "%s: NULL pointer table", what);
+    for (int p = 0; p < n; ++p) {
+        if (N[p] <= 0) return fail(FQ_EINVAL, "%s: N[%d]=%d", what, p, N[p]);
+        if (!(sig_max[p] > 0.0f) || !(sig_min[p] > 0.0f)) return fail(FQ_EINVAL, "%s: sig_max/sig_min must be > 0", what);
+        if (M && (!w_image[p] || !w_scale[p] || !y[p])) return fail(FQ_EINVAL, "%s: NULL pointer in problem %d", what, p);
+    }
+    if (M == 0) return FQ_OK;
+    if (!x || !left || !right) return fail(FQ_EINVAL, "%s: x/left/right is NULL", what);
+    if (!workspace || workspace_bytes < FQ_K64_WS_BYTES)
+        return fail(FQ_EINVAL, "%s: workspace of %lld bytes required (fq_kron_workspace_bytes(64, 64))", what, (long long)FQ_K64_WS_BYTES);
+    FQ_NEED_ALIGN16(what, x, left, right, workspace);
+    if (M > 16) return fail(FQ_EUNSUPPORTED, "%s: M=%lld tokens (the fused decode launch takes 1..16; run the transform and the linears as two launches)", what, (long long)M);
+    for (int p = 0; p < n; ++p)
+        if (N[p] & 31) return fail(FQ_EUNSUPPORTED, "%s: N[%d]=%d is not a multiple of 32", what, p, N[p]);
+    int rc;
+    if (!(flags & FQ_WS_PREPARED)) {
+        rc = fq_launch_kron64_prepare(left, right, workspace, (hipStream_t)stream);
+        if (rc == 0) rc = fq_launch_kron_prepare((const f16*)left, (const f16*)right, 64, 64,
+                                                 static_cast<unsigned char*>(workspace) + FQ_K64_IMAGE_BYTES, (hipStream_t)stream);
+        if (rc != 0) return check_launch(rc, what);
+    }
+    rc = fq_launch_kron64_linear((const f16*)x, workspace, M, rms_eps, rmsnorm != 0, flags & (FQ_NO_CLAMP0 | FQ_ROUND_Y_F16), n, w_image,
+                                 (const f16* const*)w_scale, (const f16* const*)bias, sig_max, sig_min, N, (f16* const*)y, cu_count(),
+                                 (hipStream_t)stream);
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "%s: shape not covered", what);
     return check_launch(rc, what);
 }
 

@@ -9,6 +9,22 @@ namespace fqgemm {
 // A-operand row (0..31) of a 32-row tile -> the n it holds, so that D's lane (h, .) ends with n = 16 h + reg
 __device__ __forceinline__ int prow(int c) { return ((c >> 2) & 1) * 16 + (c & 3) + 4 * (c >> 3); }
 
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+// 16 nibbles (8 bytes) -> 16 signed bytes = 16 * q, as {hi(x.x), lo(x.x), hi(x.y), lo(x.y)}: the same element order on
+// both operands, which is all the contraction needs (the int8 matrix path: products carry 256)
+__device__ __forceinline__ i32x4_t unpack16(uint2 p) {
+    i32x4_t r;
+#ifdef FQ_GEMM_NOUNPACK  // measurement build (wrong results): what does the unpack cost?
+    r[0] = (int)p.x; r[1] = (int)p.y; r[2] = (int)p.x; r[3] = (int)p.y;
+    return r;
+#endif
+    r[0] = (int)(p.x & 0xF0F0F0F0u);
+    r[1] = (int)((p.x << 4) & 0xF0F0F0F0u);
+    r[2] = (int)(p.y & 0xF0F0F0F0u);
+    r[3] = (int)((p.y << 4) & 0xF0F0F0F0u);
+    return r;
+}
+
 // quant.cu:5-10,66-85: x = s_row * s_col * half(int(q / 10.0f)) * half(10), fp16 products left to right
 __device__ __forceinline__ f16 dequant1(int q, f16 srow, f16 scol) {
     int iv = (int)((float)q / 10.0f);  // C truncation toward zero

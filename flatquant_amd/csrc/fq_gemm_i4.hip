@@ -49,20 +49,7 @@ __device__ __forceinline__ int swz_x(int r) { return (r >> 2) & 3; }
 __device__ __forceinline__ int swz_w(int r) { return ((r >> 2) & 1) | (((r >> 4) & 1) << 1); }
 
 
-// 16 nibbles (8 bytes) -> 16 signed bytes = 16 * q, as {hi(x.x), lo(x.x), hi(x.y), lo(x.y)}: the same element order on
-// both operands, which is all the contraction needs
-__device__ __forceinline__ i32x4 unpack16(uint2 p) {
-    i32x4 r;
-#ifdef FQ_GEMM_NOUNPACK  // measurement build (wrong results): what does the unpack cost?
-    r[0] = (int)p.x; r[1] = (int)p.y; r[2] = (int)p.x; r[3] = (int)p.y;
-    return r;
-#endif
-    r[0] = (int)(p.x & 0xF0F0F0F0u);
-    r[1] = (int)((p.x << 4) & 0xF0F0F0F0u);
-    r[2] = (int)(p.y & 0xF0F0F0F0u);
-    r[3] = (int)((p.y << 4) & 0xF0F0F0F0u);
-    return r;
-}
+// (unpack16 — 16 nibbles -> 16 signed bytes = 16 q — lives in fq_gemm_common.hpp: shared with the fused decode launch of fq_kron64.hip)
 
 __global__ __launch_bounds__(GT) void fq_gemm_i4_kernel(const uint8_t* __restrict__ X, const uint8_t* __restrict__ W,
                                                         int M, int N, int Kb, GemmOut out) {

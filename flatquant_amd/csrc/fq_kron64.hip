@@ -29,6 +29,7 @@
 //
 // Algorithmic traffic per token: 8192 B read + 2048 B packed + 2 B scale = 10242 B.
 #include "fq_common.hpp"
+#include "fq_gemm_common.hpp"
 
 namespace {
 
@@ -726,7 +727,373 @@ __global__ __launch_bounds__(kron64_threads<FLAGS>()) void fq_kron64_kernel(cons
     }
 }
 
+
+// =====================================================================================================================
+// (round 6) THE TRANSFORM AS THE GEMM'S PROLOGUE, decode regime: [RMSNorm +] 64 x 64 Kronecker transform + per-token INT4 quantisation +
+// up to four Linear4bit projections of the quantised tokens (q / k / v, or up / gate: their own clip pair, weights, scales, bias, output)
+// as ONE launch for M <= 16 tokens — deploy/nn/online_trans.py + quantization.py in front of deploy/nn/linear.py:40-54, the launch pair
+// fq_[rmsnorm_]kron_quant_f16 -> fq_int4_skinny_linear_multi_f16 of the captured decode step. At one to sixteen tokens both launches sit on
+// the latency floor of a small dispatch (5.0 + 5.6 us for q / k / v at one token, 5.0 + 11.8 for up / gate: profiles/r05_decode_layer.txt)
+// whose parts — kernel arguments, fragment image, token, weights — are dependent round trips to memory. Here every persistent workgroup
+//   1. requests the fragment image, the tokens and its first TWO feature tiles of weights at once,
+//   2. transforms and quantises the M tokens itself (a wave per token, two rounds for M > 8: the code of fq_kron64_kernel) with the clip
+//      pair of ITS problem while the weights are in flight — 192 .. 256 workgroups repeat the same 1 MFLOP per token, nobody waits for a
+//      producer launch — and leaves the packed digits and the scales in LDS,
+//   3. walks its feature tiles (32 features, K split over the 8 waves as in fq_gemm_i4_skinny_kernel: same weight image, same MFMAs,
+//      same reduction through ds_add, same sym_dequant arithmetic) with the tile after next requested under the current one.
+// The quantised activations are never written to memory. Bit-identical to the two launches by construction (tests/test_gpu_fused_decode.py).
+// Every VMEM operation of the kernel is inline asm: the compiler's own s_waitcnt bookkeeping would otherwise turn each wait for a scale
+// or a store into a wait for the prefetched weights (vmcnt is one in-order counter).
+// =====================================================================================================================
+constexpr int KL_WAVES = 8, KL_THREADS = KL_WAVES * 64, KL_MAXM = 16;
+constexpr int KL_KB = KD / 64;                    // 64-k blocks of a weight row tile (K = 4096)
+constexpr int KL_BPW = KL_KB / KL_WAVES;          // blobs per wave and tile: 8
+struct K64LinProblems {
+    const uint4* wimg[4];     // weight images (fq_int4_to_frag: blob (32-feature tile, 64-k block) = 64 lanes x 16 B)
+    f16* y[4];                // [M, N[p]]
+    const f16* scol[4];       // [N[p]] weight scales
+    const f16* bias[4];       // [N[p]] or nullptr
+    float sig_max[4], sig_min[4];
+    int N[4];                 // N[p] % 32 == 0
+    int wg0[5];               // first workgroup of problem p; [n] = the grid
+    int n;
+};
+typedef int kl_i32x16 __attribute__((ext_vector_type(16)));
+
+// Loads whose completion is waited for by hand. "+v": the destination is the register the variable ALREADY lives in — with "=v" the
+// register allocator is free to load into a fresh register and copy it into the loop-carried one at the back edge, i.e. to read a register
+// whose data has not landed (found in the ISA of the first build: v_mov_b64 of all eight weight fragments in front of the wait).
+__device__ __forceinline__ void kl_load16(u32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void kl_load2(unsigned& d, const void* p) { asm volatile("global_load_ushort %0, %1, off" : "+v"(d) : "v"(p) : "memory"); }
+// ONE asm statement per wait, the count selected at run time inside it (sel 0..3): separate statements in the arms of an if make the
+// register allocator copy the still-in-flight registers ahead of the wait (fq_kron64_kernel's prologue, FQ_WAIT_GATHER).
+#define KL_WAIT4(sel, C0, C1, C2, C3, ...)                                                                               \
+    asm volatile("s_cmp_eq_u32 %[n], 0\n\ts_cbranch_scc1 5f\n\ts_cmp_eq_u32 %[n], 1\n\ts_cbranch_scc1 6f\n\t"           \
+                 "s_cmp_eq_u32 %[n], 2\n\ts_cbranch_scc1 7f\n\ts_waitcnt vmcnt(" #C3 ")\n\ts_branch 9f\n"                \
+                 "5:\n\ts_waitcnt vmcnt(" #C0 ")\n\ts_branch 9f\n6:\n\ts_waitcnt vmcnt(" #C1 ")\n\ts_branch 9f\n"        \
+                 "7:\n\ts_waitcnt vmcnt(" #C2 ")\n9:"                                                                   \
+                 : __VA_ARGS__ : [n] "s"(__builtin_amdgcn_readfirstlane(sel)) : "scc", "memory")
+
+// the transform of the token in `tokbuf` (this wave's 8 KB, landed): Y^T fragments + the token's extrema — the body of fq_kron64_kernel's loop
+template <bool RMS>
+__device__ __forceinline__ void kl_transform(const unsigned char* tokbuf, const uint4* frag, int lane, float rms_eps, int rt_flags,
+                                             f32x16 (&Y)[2][2], float& vmax, float& vmin) {
+    typedef f16x8 X8;
+    const int h = lane >> 5, c = lane & 31, sw = (c >> 1) & 7;
+    u32x4 X[2][4];
+    {
+        const u32x4* tb = reinterpret_cast<const u32x4*>(tokbuf);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) X[mt][s] = tb[(mt * 32 + c) * 8 + ((h * 4 + s) ^ sw)];
+    }
+    if (RMS) {   // deploy.nn.RMSNorm (normalization.py:16-23), as in fq_kron64_kernel
+        float ss[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const X8 v = __builtin_bit_cast(X8, X[mt][s]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss[j & 3] = __builtin_fmaf((float)v[j], (float)v[j], ss[j & 3]);
+            }
+        const float tot = fq_wave_sum((ss[0] + ss[1]) + (ss[2] + ss[3]));
+        const float rinv = __builtin_amdgcn_rsqf(tot / (float)KD + rms_eps);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                X8 v = __builtin_bit_cast(X8, X[mt][s]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fq_mul_to<f16>((float)v[j], rinv);
+                X[mt][s] = __builtin_bit_cast(u32x4, v);
+            }
+    }
+    const uint4* myfrag = frag + lane;
+    f32x16 U[2][2];
+    U[0][0] = f32x16{0}; U[0][1] = f32x16{0}; U[1][0] = f32x16{0}; U[1][1] = f32x16{0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const X8 b0 = __builtin_bit_cast(X8, myfrag[(0 * 4 + s) * 64]);
+        const X8 b1 = __builtin_bit_cast(X8, myfrag[(1 * 4 + s) * 64]);
+        U[0][0] = fq_mfma32<f16>(__builtin_bit_cast(X8, X[0][s]), b0, U[0][0]);
+        U[1][0] = fq_mfma32<f16>(__builtin_bit_cast(X8, X[1][s]), b0, U[1][0]);
+        U[0][1] = fq_mfma32<f16>(__builtin_bit_cast(X8, X[0][s]), b1, U[0][1]);
+        U[1][1] = fq_mfma32<f16>(__builtin_bit_cast(X8, X[1][s]), b1, U[1][1]);
+    }
+    X8 Uh[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Uh[nt][ks][j] = (f16)U[ks >> 1][nt][(ks & 1) * 8 + j];
+    Y[0][0] = f32x16{0}; Y[0][1] = f32x16{0}; Y[1][0] = f32x16{0}; Y[1][1] = f32x16{0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const X8 b0 = __builtin_bit_cast(X8, myfrag[(8 + ks * 2 + 0) * 64]);
+        const X8 b1 = __builtin_bit_cast(X8, myfrag[(8 + ks * 2 + 1) * 64]);
+        Y[0][0] = fq_mfma32<f16>(Uh[0][ks], b0, Y[0][0]);
+        Y[1][0] = fq_mfma32<f16>(Uh[1][ks], b0, Y[1][0]);
+        Y[0][1] = fq_mfma32<f16>(Uh[0][ks], b1, Y[0][1]);
+        Y[1][1] = fq_mfma32<f16>(Uh[1][ks], b1, Y[1][1]);
+    }
+    if (rt_flags & FQ_ROUND_Y_F16) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[nt][mo][r] = (float)(f16)Y[nt][mo][r];
+    }
+    float pmax[4], pmin[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x16& t = Y[k >> 1][k & 1];
+        float a = FqMaxOp()(t[0], t[1]), b = FqMinOp()(t[0], t[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) {
+            a = fq_max3(a, t[r], t[r + 1]);
+            b = fq_min3(b, t[r], t[r + 1]);
+        }
+        pmax[k] = a;
+        pmin[k] = b;
+    }
+    vmax = fq_wave_max(fq_max3(pmax[0], pmax[1], FqMaxOp()(pmax[2], pmax[3])));
+    vmin = fq_wave_min(fq_min3(pmin[0], pmin[1], FqMinOp()(pmin[2], pmin[3])));
+}
+
+template <bool RMS>
+__global__ __launch_bounds__(KL_THREADS) void fq_kron64_linear_kernel(const f16* __restrict__ x, const uint4* __restrict__ prep, int M,
+                                                                      float rms_eps, int rt_flags, K64LinProblems pr) {
+    using namespace fqgemm;
+    extern __shared__ __attribute__((aligned(16))) unsigned char klsm[];
+    // [fragment image 16 KB][M token buffers of 8 KB: the token, then its packed digits in the first 2 KB][tile sums 2 x 32 x 33 int][scales 16 float]
+    uint4* frag = reinterpret_cast<uint4*>(klsm);
+    unsigned char* toks = klsm + FRAG_BYTES;
+    int (*tile)[32][33] = reinterpret_cast<int (*)[32][33]>(toks + (size_t)M * TOK_BYTES);
+    float* sc_lds = reinterpret_cast<float*>(toks + (size_t)M * TOK_BYTES + 2 * 32 * 33 * 4);
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- which problem, which feature tiles (workgroup-uniform) ----
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < pr.n && (int)blockIdx.x >= pr.wg0[q]) p = q;
+    const uint4* wimg = pr.wimg[0];
+    f16* yout = pr.y[0];
+    const f16* scol = pr.scol[0];
+    const f16* bias = pr.bias[0];
+    float sig_max = pr.sig_max[0], sig_min = pr.sig_min[0];
+    int N = pr.N[0], wg_lo = pr.wg0[0], wg_hi = pr.wg0[1];
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (p == q) wimg = pr.wimg[q], yout = pr.y[q], scol = pr.scol[q], bias = pr.bias[q], sig_max = pr.sig_max[q], sig_min = pr.sig_min[q],
+                    N = pr.N[q], wg_lo = pr.wg0[q], wg_hi = pr.wg0[q + 1];
+    const int n_tiles = N >> 5, step = wg_hi - wg_lo;
+    int t0 = (int)blockIdx.x - wg_lo;                      // tiles t0, t0 + step, ...
+    const f16* bsrc = bias != nullptr ? bias : scol;       // (a dummy source keeps the number of loads per tile fixed: the waits below count them)
+
+    // ---- 1. everything this workgroup needs from memory, requested at once ----
+    u32x4 pv[2] = {};
+    kl_load16(pv[0], prep + tid);
+    kl_load16(pv[1], prep + tid + KL_THREADS);
+    const unsigned tok_lds0 = (unsigned)(size_t)(lds_void*)toks;
+    for (int m = wave; m < M; m += KL_WAVES)               // (wave-uniform) two VMEM ops + ... : 8 DMA instructions per token
+        dma_token(x, m, __builtin_amdgcn_readfirstlane(tok_lds0 + (unsigned)m * TOK_BYTES), lane);
+    // weights of two tiles in flight per wave: ring slot = tile parity; + the tile's column scale and bias for this thread's output element
+    u32x4 W0[KL_BPW] = {}, W1[KL_BPW] = {};
+    unsigned s0 = 0, b0 = 0, s1 = 0, b1 = 0;
+    const int nl = tid & 31, mrow = tid >> 5;              // the output element of this thread in a tile: token mrow (clamped below), feature nl
+#define KL_REQ(Wr, sr, br, t)                                                                                     \
+    {                                                                                                             \
+        const uint4* wp_ = wimg + ((size_t)(t) * KL_KB + wave) * 64 + lane;                                       \
+        _Pragma("unroll") for (int j = 0; j < KL_BPW; ++j) kl_load16(Wr[j], wp_ + (size_t)j * KL_WAVES * 64);     \
+        kl_load2(sr, scol + (t) * 32 + nl);                                                                       \
+        kl_load2(br, bsrc + (t) * 32 + nl);                                                                       \
+    }
+    const bool have0 = t0 < n_tiles, have1 = t0 + step < n_tiles;
+    if (have0) KL_REQ(W0, s0, b0, t0)
+    if (have1) KL_REQ(W1, s1, b1, t0 + step)
+    // the image and the tokens are older than the weights: wait for them only (10 loads per requested tile stay in flight)
+    {
+        const int sel = have1 ? 2 : have0 ? 1 : 0;
+        KL_WAIT4(sel, 0, 10, 20, 20, "+v"(pv[0]), "+v"(pv[1]));
+    }
+    frag[tid] = __builtin_bit_cast(uint4, pv[0]);
+    frag[tid + KL_THREADS] = __builtin_bit_cast(uint4, pv[1]);
+    for (int i = tid; i < 2 * 32 * 33; i += KL_THREADS) (&tile[0][0][0])[i] = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // the image is in LDS (the tokens: every wave waited for its own DMAs)
+
+    // ---- 2. transform + quantise: wave w takes tokens w, w + 8 ----
+#ifndef FQ_KL_ABL
+#define FQ_KL_ABL 0   // measurement builds (wrong results): 1 = no transform (the digits are whatever the token's first 2 KB hold)
+#endif
+    for (int m = wave; m < M; m += KL_WAVES) {
+        unsigned char* tokbuf = toks + (size_t)m * TOK_BYTES;
+        if (FQ_KL_ABL & 1) {
+            if (lane == 0) sc_lds[m] = 1.0f;
+            continue;
+        }
+        f32x16 Y[2][2];
+        float vmax, vmin;
+        kl_transform<RMS>(tokbuf, frag, lane, rms_eps, rt_flags, Y, vmax, vmin);
+        const float scale = fq_token_scale<FQ_OUT_PACKED, f16>(vmax, vmin, sig_max, sig_min, rt_flags);
+        const float inv[2] = {fq_fast_inv(scale), fq_fast_inv(scale)};
+        uint32_t pw[2][4];
+        unsigned near;
+        if (!fq_magic_ok(vmax, vmin, inv[0])) near = 0xffu;
+        else if (fq_needs_clamp(vmax, vmin, inv[0])) near = quant_pack_token<true>(Y, inv, pw);
+        else near = quant_pack_token<false>(Y, inv, pw);
+#define FQ_YV(mo, w, e) Y[(w) >> 1][mo][((w) & 1) * 8 + (e)]
+        if (near) {
+#pragma unroll
+            for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    if (near & (1u << (4 * mo + w)))
+                        pw[mo][w] = fq_pack8(fq_qexact(FQ_YV(mo, w, 0), scale), fq_qexact(FQ_YV(mo, w, 1), scale), fq_qexact(FQ_YV(mo, w, 2), scale),
+                                             fq_qexact(FQ_YV(mo, w, 3), scale), fq_qexact(FQ_YV(mo, w, 4), scale), fq_qexact(FQ_YV(mo, w, 5), scale),
+                                             fq_qexact(FQ_YV(mo, w, 6), scale), fq_qexact(FQ_YV(mo, w, 7), scale));
+        }
+#undef FQ_YV
+        // the packed row of the token, natural order (what fq_kron64_kernel stores): output row 32 mo + c, bytes 16 h .. of its 32
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+            *reinterpret_cast<u32x4*>(tokbuf + (mo * 32 + c) * (KN / 2) + h * 16) = u32x4{pw[mo][0], pw[mo][1], pw[mo][2], pw[mo][3]};
+        if (lane == 0) sc_lds[m] = (float)(f16)scale;      // (the fp16 scale the packed launch stores and the GEMM reads)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- 3. the feature tiles ----
+    // B fragments of this wave's 8 k-blocks: token min(c, M - 1), packed bytes 32 kb + 16 h .. (loop-invariant: registers)
+    u32x4 BX[KL_BPW];
+    {
+        const unsigned char* xr = toks + (size_t)(c < M ? c : M - 1) * TOK_BYTES + 16 * h;
+#pragma unroll
+        for (int j = 0; j < KL_BPW; ++j) BX[j] = *reinterpret_cast<const u32x4*>(xr + (wave + j * KL_WAVES) * 32);
+    }
+    const int mo_ = mrow < M ? mrow : M - 1;               // rows >= M hold copies of token M - 1: the same value to the same address
+    const f16 srow = (f16)sc_lds[mo_];
+    int par = 0;
+    auto consume = [&](u32x4 (&Wr)[KL_BPW], unsigned sr, unsigned br, int t) {
+        kl_i32x16 acc = kl_i32x16{0};
+#pragma unroll
+        for (int j = 0; j < KL_BPW; ++j) {
+            const i32x4_t a0 = unpack16(make_uint2(Wr[j][0], Wr[j][1])), a1 = unpack16(make_uint2(Wr[j][2], Wr[j][3]));
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, unpack16(make_uint2(BX[j][0], BX[j][1])), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, unpack16(make_uint2(BX[j][2], BX[j][3])), acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    auto finish = [&](const kl_i32x16& acc, unsigned sr, unsigned br, int t) {
+        // lane (h, c): token c, features 16 h + r; the eight waves' partial sums meet in LDS
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(&tile[par][c][16 * h + r], acc[r]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int v = tile[par][mrow][nl] >> 8;            // products carry 256 (unpack16)
+        f16 yv = dequant1(v, srow, __builtin_bit_cast(f16, (unsigned short)sr));
+        if (bias != nullptr) yv = yv + __builtin_bit_cast(f16, (unsigned short)br);
+        const unsigned yb = (unsigned)__builtin_bit_cast(unsigned short, yv);
+        f16* dst = yout + (size_t)mo_ * N + t * 32 + nl;
+        asm volatile("global_store_short %0, %1, off" : : "v"(dst), "v"(yb) : "memory");
+        tile[par][mrow][nl] = 0;                           // (this buffer is next used two tiles on: a barrier lies in between)
+        par ^= 1;
+    };
+    for (int t = t0; t < n_tiles; t += 2 * step) {
+        // Issue order of an iteration: [wait slot 0] MFMAs, request slot 0 again (10 loads), store of tile t (1), [wait slot 1] MFMAs, request
+        // slot 1 again (10), store of tile t + step (1). Operations YOUNGER than the loads a wait is for:
+        //   slot 0, first iteration: slot 1's request (10 | 0);          later: store, slot 1's request, store (12 | 2)
+        //   slot 1, first iteration: slot 0's new request, store (11 | 1); later: store, request, store (12 | 2)
+        const bool nx = t + step < n_tiles, first = t == t0;
+#define KL_W0 "+v"(W0[0]), "+v"(W0[1]), "+v"(W0[2]), "+v"(W0[3]), "+v"(W0[4]), "+v"(W0[5]), "+v"(W0[6]), "+v"(W0[7]), "+v"(s0), "+v"(b0)
+        {
+            const int sel = (first ? 0 : 2) + (nx ? 1 : 0);    // first: 0 | 10, later: 2 | 12
+            KL_WAIT4(sel, 0, 10, 2, 12, KL_W0);
+        }
+#undef KL_W0
+        const kl_i32x16 a0 = consume(W0, s0, b0, t);
+        unsigned sk0, bk0;   // (real moves: a C++ copy lets the allocator keep the OLD value in place and load the new one elsewhere)
+        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(sk0), "=&v"(bk0) : "v"(s0), "v"(b0));
+        if (t + 2 * step < n_tiles) KL_REQ(W0, s0, b0, t + 2 * step)
+        finish(a0, sk0, bk0, t);
+        if (!nx) break;
+        // tile t + step (slot 1): younger = slot 0's 10 loads (when requested) + the store of tile t
+        const bool nx2 = t + 2 * step < n_tiles;
+#define KL_W1 "+v"(W1[0]), "+v"(W1[1]), "+v"(W1[2]), "+v"(W1[3]), "+v"(W1[4]), "+v"(W1[5]), "+v"(W1[6]), "+v"(W1[7]), "+v"(s1), "+v"(b1)
+        {
+            const int sel = (first ? 0 : 2) + (nx2 ? 1 : 0);   // first: 1 | 11, later: 2 | 12
+            KL_WAIT4(sel, 1, 11, 2, 12, KL_W1);
+        }
+#undef KL_W1
+        const kl_i32x16 a1 = consume(W1, s1, b1, t + step);
+        unsigned sk1, bk1;
+        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(sk1), "=&v"(bk1) : "v"(s1), "v"(b1));
+        if (t + 3 * step < n_tiles) KL_REQ(W1, s1, b1, t + 3 * step)
+        finish(a1, sk1, bk1, t + step);
+    }
+#undef KL_REQ
+}
+
 }  // namespace
+
+// The fused decode launch (fq_kron64_linear_multi_f16): -1000 when the shape is not covered. 
+int fq_launch_kron64_linear(const f16* x, const void* prep, int64_t M, float rms_eps, bool rms, int rt_flags, int n, const void* const* wimg,
+                            const f16* const* scol, const f16* const* bias, const float* sig_max, const float* sig_min, const int* N,
+                            f16* const* y, int n_cu, hipStream_t stream) {
+    if (n < 1 || n > 4 || M < 1 || M > KL_MAXM || prep == nullptr) return -1000;
+    K64LinProblems pr = {};
+    pr.n = n;
+    int tiles[4] = {0, 0, 0, 0}, total = 0;
+    for (int p = 0; p < n; ++p) {
+        if (N[p] < 32 || (N[p] & 31)) return -1000;
+        pr.wimg[p] = reinterpret_cast<const uint4*>(wimg[p]);
+        pr.y[p] = y[p];
+        pr.scol[p] = scol[p];
+        pr.bias[p] = bias ? bias[p] : nullptr;
+        pr.sig_max[p] = sig_max[p];
+        pr.sig_min[p] = sig_min[p];
+        pr.N[p] = N[p];
+        tiles[p] = N[p] >> 5;
+        total += tiles[p];
+    }
+    // workgroups: one per CU (or one per tile when there are fewer tiles), dealt to the problems in proportion to their tiles
+#ifndef FQ_KL_WG_PER_CU
+#define FQ_KL_WG_PER_CU 1   // (measurement knob) persistent workgroups per CU
+#endif
+    int grid = n_cu * FQ_KL_WG_PER_CU;
+    if (grid > total) grid = total;
+    // a problem's share of the grid in proportion to its tiles, then trimmed so that its workgroups walk the SAME number of tiles where the
+    // counts allow (448 tiles on a share of 128 workgroups are 3.5 each — half of them stream a fourth tile alone, with too few requests in
+    // flight for the memory system: 13.0 us; 112 workgroups x 4 tiles: measured below)
+    int wgs[4] = {0, 0, 0, 0};
+    for (int p = 0; p < n; ++p) {
+        int share = (int)((int64_t)grid * tiles[p] / total);
+        if (share < 1) share = 1;
+        if (share > tiles[p]) share = tiles[p];
+        const int per = (tiles[p] + share - 1) / share;
+        wgs[p] = (tiles[p] + per - 1) / per;
+    }
+    pr.wg0[0] = 0;
+    for (int p = 0; p < n; ++p) pr.wg0[p + 1] = pr.wg0[p] + wgs[p];
+    for (int p = n + 1; p < 5; ++p) pr.wg0[p] = pr.wg0[n];
+    const int lds = FRAG_BYTES + (int)M * TOK_BYTES + 2 * 32 * 33 * 4 + KL_MAXM * 4;
+    if (rms) {
+        FQ_RAISE_LDS_CAP((fq_kron64_linear_kernel<true>), 160 * 1024);
+        hipLaunchKernelGGL((fq_kron64_linear_kernel<true>), dim3((unsigned)pr.wg0[n]), dim3(KL_THREADS), lds, stream, x,
+                           reinterpret_cast<const uint4*>(prep), (int)M, rms_eps, rt_flags, pr);
+    } else {
+        FQ_RAISE_LDS_CAP((fq_kron64_linear_kernel<false>), 160 * 1024);
+        hipLaunchKernelGGL((fq_kron64_linear_kernel<false>), dim3((unsigned)pr.wg0[n]), dim3(KL_THREADS), lds, stream, x,
+                           reinterpret_cast<const uint4*>(prep), (int)M, rms_eps, rt_flags, pr);
+    }
+    return (int)hipGetLastError();
+}
 
 // Host-side launcher used by the C ABI (fq_capi.hip). Returns hipError_t as int.
 // The 16 KB fragment image of (left, right) for `prep`: slot (f, lane') as the kernel's prologue gathers it.

@@ -23,6 +23,36 @@ class PackedQuantizedTensor:
         return self.quantized_x.dtype
 
 
+class LazyPackedQuantizedTensor(PackedQuantizedTensor):
+    """(round 6) What a fused OnlineTrans group hands out when the projections behind it can run the transform as their launch's
+    PROLOGUE (deploy/fuse.py, decode-sized calls under capture): the packed bytes are only produced if somebody other than those
+    projections asks for them (``.quantized_x`` / ``.scales_x`` then run the group's transform launch, once for all members)."""
+
+    def __init__(self, group, index, shape):
+        self._group, self._index, self._shape = group, index, shape
+
+    def _real(self):
+        return self._group.materialise()[self._index]
+
+    @property
+    def quantized_x(self):
+        return self._real().quantized_x
+
+    @quantized_x.setter
+    def quantized_x(self, v):      # (a caller that replaces the bytes owns them from then on)
+        r = self._real()
+        self.__class__ = PackedQuantizedTensor
+        self.__dict__.clear()
+        self.quantized_x, self.scales_x = v, r.scales_x
+
+    @property
+    def scales_x(self):
+        return self._real().scales_x
+
+    def size(self):
+        return torch.Size(self._shape)
+
+
 def flatten_last_dim_and_return_shape(x: torch.Tensor):
     shape_excl_last = x.shape[:-1]
     return x.view(-1, x.shape[-1]), shape_excl_last

@@ -30,7 +30,7 @@ import torch
 
 from .. import ops
 from .graphed import GraphedDecode
-from .nn.linear import Linear4bit, linear4bit_multi
+from .nn.linear import Linear4bit, _fused_decode_problems, fused_transform_linear, linear4bit_multi
 from .nn.online_trans import FusedSequential, OnlineTrans, fused_forward
 from .nn.quantization import Quantizer
 
@@ -46,12 +46,15 @@ class TransformGroup:
         self.members = list(members)
         self.index = {id(m): i for i, m in enumerate(self.members)}
         self.linear_group = None
+        self._real = None
         self._ref = None          # weakref of the tensor the cached results belong to
         self._xver = -1
         self._outs = None
         self._taken = 0           # bit mask of the members that have taken their result
+        self._lazy_x = None       # the input of lazy results (the transform has not run: the projections' launch may carry it as its prologue)
         self.launches = 0         # (counters for tests / reports)
         self.served = 0
+        self.lazy = 0
 
     def shareable(self):
         f = self.members[0]
@@ -65,7 +68,17 @@ class TransformGroup:
         return True
 
     def drop(self):
-        self._ref, self._outs, self._taken = None, None, 0
+        self._ref, self._outs, self._taken, self._lazy_x = None, None, 0, None
+
+    def materialise(self):
+        """The real results behind lazy ones (somebody other than the group's projections asked for the packed bytes)."""
+        x = self._lazy_x
+        if x is None:
+            raise RuntimeError("a lazy PackedQuantizedTensor outlived its group's call")
+        if self._real is None:
+            self._real = fused_forward(x, self.members)
+            self.launches += 1
+        return self._real
 
     def get(self, member, x):
         if x.dim() != 3:
@@ -83,8 +96,18 @@ class TransformGroup:
         else:
             if not (x.dim() == 3 and x.is_cuda and self.shareable()):
                 return None                                  # (the caller runs on its own)
-            outs = fused_forward(x, self.members)
-            self.launches += 1
+            lg = self.linear_group
+            if lg is not None and _fused_decode_problems(x, self.members, lg.members) is not None:
+                # (round 6) decode-sized, and the projections behind this group can run the transform as their launch's prologue: hand
+                # out lazy results — the bytes exist only if somebody else asks for them
+                from . import LazyPackedQuantizedTensor
+                shape = tuple(x.shape[:-1]) + (x.shape[-1] // 2,)
+                outs = [LazyPackedQuantizedTensor(self, k, shape) for k in range(len(self.members))]
+                self._lazy_x, self._real = x, None
+                self.lazy += 1
+            else:
+                outs = fused_forward(x, self.members)
+                self.launches += 1
             self._ref, self._xver, self._outs, self._taken = weakref.ref(x), ops.ver(x), outs, bit
             out = outs[i]
         if self._taken == (1 << len(self.members)) - 1 and self.linear_group is None:
@@ -110,6 +133,7 @@ class LinearGroup:
         self._busy = False        # inside linear4bit_multi (whose fall-back calls the members' own forward)
         self.launches = 0
         self.served = 0
+        self.fused = 0            # launches that carried the group's transform as their prologue
 
     def get(self, member, x):
         if self._busy or (self._ys is None and self.tg.outputs() is None):
@@ -127,7 +151,12 @@ class LinearGroup:
             self._ins = list(outs)
             self._busy = True
             try:
-                self._ys = linear4bit_multi(self.members, self._ins)
+                lazy_x = self.tg._lazy_x
+                if lazy_x is not None and self.tg._real is None:
+                    self._ys = fused_transform_linear(lazy_x, self.tg.members, self.members)     # ONE launch: transform + projections
+                    self.fused += 1
+                else:
+                    self._ys = linear4bit_multi(self.members, self.tg.materialise() if lazy_x is not None else self._ins)
             finally:
                 self._busy = False
             self.launches += 1

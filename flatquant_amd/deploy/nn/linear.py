@@ -134,7 +134,7 @@ class Linear4bit(torch.nn.Module):
                    if t is not None)
 
     def forward(self, x):
-        assert type(x) == PackedQuantizedTensor  # quantized input is given (linear.py:45)
+        assert isinstance(x, PackedQuantizedTensor)  # quantized input is given (linear.py:45; a fused group's lazy form is one too)
         grp = self.__dict__.get("_group")      # (deploy.fuse: the projections of one attention / MLP run as one GEMM launch)
         if grp is not None:
             y = grp.get(self, x)
@@ -273,3 +273,56 @@ def linear4bit_multi(modules, inputs):
     ys = ops.int4_linear_fp6_multi(problems)
     lead = q0.shape[:-1]
     return [y.view(*lead, m.out_features) for y, m in zip(ys, modules)]
+
+
+FUSED_DECODE_ROWS = 8          # fused_transform_linear: up to this many tokens the transform runs as the GEMM launch's prologue (measured,
+                               # profiles/r06_fused_decode.txt: q / k / v 11.0 -> 7.0 us at 1 token, 12.8 -> 10.3 at 8; level at 16)
+
+
+def _fused_decode_problems(x, transforms, linears):
+    """The (w_image, w_scale, bias) triples of ops.kron64_linear_multi when the fused decode launch covers this call, else None."""
+    from ... import ops as _ops
+    if not (x.is_cuda and x.dtype == torch.float16 and x.shape[-1] == 4096 and 1 <= len(linears) <= 4 and len(linears) == len(transforms)):
+        return None
+    rows = x.numel() // 4096
+    if not 1 <= rows <= min(FUSED_DECODE_ROWS, _ops.FUSED_DECODE_MAX_ROWS):
+        return None
+    first = transforms[0]
+    if not (first.trans == "matmul" and first.decompose and tuple(first.left_matrix.shape) == (64, 64) and tuple(first.right_matrix.shape) == (64, 64)
+            and first.left_matrix.dtype == torch.float16):
+        return None
+    problems = []
+    for m in linears:
+        dimg = m._decode_image() if (m.in_features == 4096 and m.out_features % 32 == 0) else None
+        if dimg is None:
+            return None
+        ws16, b16 = m._scales16()
+        problems.append((dimg, ws16, b16))
+    return problems
+
+
+def fused_transform_linear(x, transforms, linears, norm=None):
+    """``[m(t(norm(x))) for t, m in zip(transforms, linears)]`` — the OnlineTrans modules of one attention / MLP (sharing their Kronecker
+    pair, their own clip factors: fused_forward's contract) and the Linear4bit projections behind them — with THE TRANSFORM AS THE GEMM'S
+    PROLOGUE where that pays (round 6): up to FUSED_DECODE_ROWS tokens of d = 4096 run as ONE launch (fq_kron64_linear_multi_f16: every
+    workgroup transforms and quantises the tokens itself while its weights are in flight; the packed activations never reach memory);
+    anything else as fused_forward + linear4bit_multi. Bit-identical either way (tests/test_gpu_fused_decode.py)."""
+    from ... import ops as _ops
+    from ..._lib import FQ_NO_CLAMP0, FQ_ROUND_Y_F16
+    from ..functional.online_trans import deploy_kron_flags
+    from .online_trans import fused_forward
+    problems = _fused_decode_problems(x, transforms, linears)
+    if problems is not None:
+        first = transforms[0]
+        for t in transforms:
+            if not (t.trans == "matmul" and t.decompose and t.left_matrix.data_ptr() == first.left_matrix.data_ptr()
+                    and t.right_matrix.data_ptr() == first.right_matrix.data_ptr()):
+                raise RuntimeError("fused_transform_linear: the transforms must share their left/right matrices")
+        sigs = [_ops.sigmoid_pair(t.clip_factor_a_max, t.clip_factor_a_min) for t in transforms]
+        flags = deploy_kron_flags(64, 64) & (FQ_NO_CLAMP0 | FQ_ROUND_Y_F16)
+        ys = _ops.kron64_linear_multi(x.contiguous(), first.left_matrix.contiguous(), first.right_matrix.contiguous(), sigs, problems,
+                                      eps=None if norm is None else float(norm.eps), flags=flags)
+        if ys is not None:
+            lead = x.shape[:-1]
+            return [y.view(*lead, m.out_features) for y, m in zip(ys, linears)]
+    return linear4bit_multi(linears, fused_forward(x, transforms, norm=norm))

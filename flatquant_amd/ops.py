@@ -1454,6 +1454,49 @@ def int4_skinny_linear_multi(problems) -> list:
     return ys
 
 
+FUSED_DECODE_MAX_ROWS = 16
+
+
+def kron64_linear_multi(x: torch.Tensor, left: torch.Tensor, right: torch.Tensor, sigs: Sequence[Sig], problems, eps: Optional[float] = None,
+                        flags: int = 0) -> Optional[list]:
+    """The transform as the GEMM's prologue, decode regime (fq_kron64_linear_multi_f16): [RMSNorm(eps) +] the 64 x 64 Kronecker transform +
+    per-token INT4 quantisation of x [..., 4096] (<= 16 tokens) + up to four Linear4bit problems — ``problems``: (w_image (int4_to_frag),
+    w_scale [N], bias [N] or None), problem p quantised with sigs[p] — as ONE launch. -> a list of fp16 [M, N] tensors, bit-identical to
+    [rmsnorm_]kron_quant(..., sigs, FQ_OUT_PACKED | flags) followed by int4_skinny_linear_multi; None when the shape is not covered
+    (more than 16 tokens, a pair other than 64 x 64, N % 32 != 0): the caller runs the two launches."""
+    n = len(problems)
+    if not 1 <= n <= 4 or len(sigs) != n:
+        raise ValueError("kron64_linear_multi: 1..4 problems, one clip pair each")
+    if left.shape != (64, 64) or right.shape != (64, 64) or x.shape[-1] != 4096 or x.dtype != torch.float16:
+        return None
+    M = x.numel() // 4096
+    Ns = [pr[1].numel() for pr in problems]
+    if M > FUSED_DECODE_MAX_ROWS or any(N % 32 for N in Ns):
+        return None
+    _chk(x, "x"), _chk(left, "left"), _chk(right, "right")
+    for (wimg, ws, b), N in zip(problems, Ns):
+        _chk(ws, "w_scale")
+        if b is not None:
+            _chk(b, "bias")
+        if (b is not None and b.numel() != N) or wimg.numel() != int(lib.fq_int4_frag_bytes(N, 4096)):
+            raise RuntimeError("kron64_linear_multi: bias / image sizes do not match N / K")
+    ys = [torch.empty((M, N), dtype=torch.float16, device=x.device) for N in Ns]
+    if M == 0:
+        return ys
+    smax, smin, _ = _sig_arrays(sigs)
+    VP = ctypes.c_void_p * n
+    tab = lambda k: VP(*[None if pr[k] is None else pr[k].data_ptr() for pr in problems])
+    with _on(x.device):
+        ws, ws_bytes, prepared, key = _kron_workspace(x.device, 64, 64, left, right)
+        check(lib.fq_kron64_linear_multi_f16(_ptr(x), 0 if eps is None else 1, ctypes.c_float(0.0 if eps is None else eps), _ptr(left),
+                                             _ptr(right), M, n, smax, smin, flags | (FQ_WS_PREPARED if prepared else 0), tab(0), tab(1),
+                                             tab(2), (ctypes.c_int * n)(*Ns), VP(*[y.data_ptr() for y in ys]), _ptr(ws), ws_bytes,
+                                             _stream(x)))
+        if key is not None and not prepared:
+            _kron_workspace_commit(key, ws, left, right)
+    return ys
+
+
 def int4_to_bf6(q: torch.Tensor, weights: bool = False) -> torch.Tensor:
     """Packed INT4 [rows, K/2] -> the BF6 operand image of the FP6-path GEMM (fq_int4_to_bf6). ``weights``: the image of
     a Linear4bit.weight (convert once per layer); else of packed activations. K % 64 == 0."""

@@ -380,6 +380,23 @@ int fq_int4_skinny_linear_multi_f16(int n, const void* const* x, const void* con
                                     void* stream);
 
 /*
+ * (round 6) THE TRANSFORM AS THE GEMM'S PROLOGUE, decode regime. ONE launch for what the reference runs as ln_trans -> quantizer -> q / k / v
+ * (or up / gate) projections on 1..16 tokens of d = 4096 (deploy/transformers/modeling_llama.py:66-78,268-280; deploy/nn/online_trans.py,
+ * quantization.py, linear.py:40-54): [RMSNorm, normalization.py:16-23, when rmsnorm != 0] + the 64 x 64 Kronecker transform + per-token INT4
+ * quantisation with problem p's clip pair (sig_max[p], sig_min[p]) + Linear4bit of problem p — n in 1..4 problems that share x and the
+ * factor pair and have their own clip pair, weight image (fq_int4_to_frag), weight scales, bias (table or entries may be NULL) and output
+ * y[p] [M, N[p]] fp16. The quantised activations are never written to memory: every workgroup repeats the transform of the M tokens while
+ * its weights are in flight, so the launch costs ONE small-dispatch latency floor instead of two (profiles/r06_fused_decode.txt).
+ * Bit-identical to fq_[rmsnorm_]kron_quant_f16(FQ_OUT_PACKED | flags, n clip sets) followed by fq_int4_skinny_linear_multi_f16.
+ *   flags: FQ_NO_CLAMP0, FQ_ROUND_Y_F16, FQ_WS_PREPARED (workspace holds the images of fq_kron_prepare_f16(left, right, 64, 64)); without
+ *   FQ_WS_PREPARED they are written first. workspace_bytes >= fq_kron_workspace_bytes(64, 64), required.
+ *   FQ_EUNSUPPORTED: M > 16 or N[p] % 32 != 0 — run the two launches.
+ */
+int fq_kron64_linear_multi_f16(const void* x, int rmsnorm, float rms_eps, const void* left, const void* right, int64_t M, int n,
+                               const float* sig_max, const float* sig_min, int flags, const void* const* w_image, const void* const* w_scale,
+                               const void* const* bias, const int* N, void* const* y, void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
  * The same GEMM / Linear4bit on the FP6 matrix path (v_mfma_scale_f32_32x32x64_f8f6f4, both operands BF6 = E3M2, unit
  * block scales): every integer in [-8, 7] is a BF6 value and the fp32 accumulator holds the exact integer sum
  * (K <= 2^18), so the results are bit-identical to fq_int4_gemm_i32 / fq_int4_linear_f16 — at ~1.4x the sustained

@@ -76,11 +76,14 @@ def test_groups_serve_decode_sized_calls_while_a_graph_is_captured():
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.stream(s):
             layer(xs)                                        # (warm-up on the side stream: images, workspaces)
-            n0 = (tga.launches, lga.launches, tgm.launches, lgm.launches)
+            n0 = (tga.launches + tga.lazy, lga.launches, tgm.launches + tgm.lazy, lgm.launches)
+            f0 = (tga.launches, lga.fused, tgm.launches, lgm.fused)
             with torch.cuda.graph(graph, stream=s):
                 got = layer(xs)
         torch.cuda.synchronize()
-        assert (tga.launches, lga.launches, tgm.launches, lgm.launches) == tuple(v + 1 for v in n0)   # one fused launch per group, captured
+        assert (tga.launches + tga.lazy, lga.launches, tgm.launches + tgm.lazy, lgm.launches) == tuple(v + 1 for v in n0)   # one fused launch per group, captured
+        # (round 6) three tokens of d = 4096: the transform ran as the projections' PROLOGUE — no transform launch at all in the graph
+        assert (tga.launches, lga.fused, tgm.launches, lgm.fused) == (f0[0], f0[1] + 1, f0[2], f0[3] + 1)
         assert tga.served >= 2 and lga.served >= 2
         graph.replay()
         torch.cuda.synchronize()
@@ -202,3 +205,37 @@ def test_modules_built_and_called_under_inference_mode(bsz, seq):
         q = deploy.nn.Quantizer(lac=True).to("cuda")
         p = q(xi.reshape(-1, 4096))
         assert p.quantized_x.shape == (bsz * seq, 2048)
+
+
+def test_lazy_group_results_materialise_when_somebody_else_asks():
+    """Under capture a decode-sized transform group hands out LAZY packed tensors (the projections' launch carries the transform); a caller
+    that reads the packed bytes itself gets them — the group's transform launch runs then, once — and the projections still agree."""
+    import flatquant_amd.deploy as deploy
+    from ref_layer import RefLayer
+    with torch.no_grad():
+        layer = RefLayer("tiny", seed=7)
+        g = torch.Generator(device="cuda").manual_seed(17)
+        x = torch.randn(2, 1, 4096, generator=g, device="cuda", dtype=torch.float16)
+        a = layer.self_attn
+        want_p = [t(x) for t in (a.inp_trans_q, a.inp_trans_k, a.inp_trans_v)]
+        want_y = [l(p) for l, p in zip((a.q_proj, a.k_proj, a.v_proj), want_p)]
+        deploy.fuse(layer)
+        tga, lga, _, _ = _groups(layer)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            [l(t(x)) for t, l in zip((a.inp_trans_q, a.inp_trans_k, a.inp_trans_v), (a.q_proj, a.k_proj, a.v_proj))]   # warm-up (eager: own calls)
+            with torch.cuda.graph(graph, stream=s):
+                pq, pk, pv = a.inp_trans_q(x), a.inp_trans_k(x), a.inp_trans_v(x)
+                assert type(pq).__name__ == "LazyPackedQuantizedTensor" and isinstance(pq, deploy.PackedQuantizedTensor)
+                assert tuple(pq.size()) == (2, 1, 2048) and tga.launches == 0
+                kq = pk.quantized_x                                   # somebody else asks: the transform launch runs now
+                assert tga.launches == 1
+                ys = [a.q_proj(pq), a.k_proj(pk), a.v_proj(pv)]       # ... and the projections take the materialised tensors
+                assert lga.fused == 0 and lga.launches == 1
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(kq, want_p[1].quantized_x)
+        for y, w in zip(ys, want_y):
+            assert torch.equal(y, w)

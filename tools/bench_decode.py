@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--bsz", type=int, default=16)
     ap.add_argument("--cache", type=int, default=2048, help="cached tokens per request")
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--two-launches", action="store_true", help="round 5's launch structure: transform launch + projection launch per group (no fused prologue)")
     ap.add_argument("--single", action="store_true", help="one launch per projection (rounds 1-4) instead of the multi-problem launches")
     ap.add_argument("--fp16", action="store_true", help="also time the same step in fp16 (nn.Linear, rms_norm, SiLU.mul, the fp16 configuration of the paged cache) "
                                                         "— the baseline of the reference's decode table, README.md:300-310")
@@ -64,17 +65,23 @@ def main():
     x = torch.randn(a.bsz, 1, hidden, generator=g, device=dev).half()
 
     def step(h):
-        pq, pk, pv = deploy.nn.fused_forward(h, qkv_t, norm=norm)
-        q, k, v = deploy.nn.linear.linear4bit_multi([q_l, k_l, v_l], [pq, pk, pv]) if not a.single else (q_l(pq), k_l(pk), v_l(pv))
+        if a.single or a.two_launches:
+            pq, pk, pv = deploy.nn.fused_forward(h, qkv_t, norm=norm)
+            q, k, v = deploy.nn.linear.linear4bit_multi([q_l, k_l, v_l], [pq, pk, pv]) if not a.single else (q_l(pq), k_l(pk), v_l(pv))
+        else:   # (round 6) the transform as the projections' prologue where that pays (<= 8 tokens), the two launches otherwise
+            q, k, v = deploy.nn.fused_transform_linear(h, qkv_t, [q_l, k_l, v_l], norm=norm)
         attend = cache.update(k.view(a.bsz, 1, kv_heads, hd), v.view(a.bsz, 1, kv_heads, hd), 0, dict(kw))
         att_t = attend(q.view(a.bsz, 1, heads, hd), transposed=True)                # [bsz, 1, hd, heads]
         po = o_t(att_t)
         po.quantized_x = po.quantized_x.contiguous().reshape(a.bsz, 1, -1)
         h2 = o_l(po)
-        pu, pg = deploy.nn.fused_forward(h2, ug_t, norm=norm)
-        if a.single:
-            return down_l(down_t(gate_l(pg), up=up_l(pu)))
-        yu, yg = deploy.nn.linear.linear4bit_multi([up_l, gate_l], [pu, pg])
+        if a.single or a.two_launches:
+            pu, pg = deploy.nn.fused_forward(h2, ug_t, norm=norm)
+            if a.single:
+                return down_l(down_t(gate_l(pg), up=up_l(pu)))
+            yu, yg = deploy.nn.linear.linear4bit_multi([up_l, gate_l], [pu, pg])
+        else:
+            yu, yg = deploy.nn.fused_transform_linear(h2, ug_t, [up_l, gate_l], norm=norm)
         return down_l(down_t(yg, up=yu))
 
     class Layer(torch.nn.Module):
@@ -87,13 +94,11 @@ def main():
             self.mlp = torch.nn.ModuleList([*ug_t, up_l, gate_l, down_t, down_l])
 
         def forward(self, h, cache):
-            pq, pk, pv = deploy.nn.fused_forward(h, qkv_t, norm=norm)
-            q, k, v = deploy.nn.linear.linear4bit_multi([q_l, k_l, v_l], [pq, pk, pv])
+            q, k, v = deploy.nn.fused_transform_linear(h, qkv_t, [q_l, k_l, v_l], norm=norm)
             attend = cache.update(k.view(a.bsz, 1, kv_heads, hd), v.view(a.bsz, 1, kv_heads, hd), 0, dict(kw))
             po = o_t(attend(q.view(a.bsz, 1, heads, hd), transposed=True))
             po.quantized_x = po.quantized_x.contiguous().reshape(a.bsz, 1, -1)
-            pu, pg = deploy.nn.fused_forward(o_l(po), ug_t, norm=norm)
-            yu, yg = deploy.nn.linear.linear4bit_multi([up_l, gate_l], [pu, pg])
+            yu, yg = deploy.nn.fused_transform_linear(o_l(po), ug_t, [up_l, gate_l], norm=norm)
             return down_l(down_t(yg, up=yu))
 
     def time_calls(fn, cache, n):

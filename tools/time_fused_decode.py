@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""The fused decode launch (fq_kron64_linear_multi_f16: [RMSNorm +] 64 x 64 transform + quantiser + q / k / v or up / gate projections) against
+the two launches it replaces, Llama-3-8B shapes, M = 1 .. 16 tokens: us per call from a captured HIP graph of REPS calls each (what a captured
+decode step sees), the weights rotated over NB layers' worth of images so that they stream from HBM as in a real model."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from flatquant_amd import ops  # noqa: E402
+from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED  # noqa: E402
+
+REPS = int(os.environ.get("REPS", "40"))
+NB = int(os.environ.get("NB", "6"))
+TAG = os.environ.get("FQHIP_OVERLAY", "default").split("/")[-1]
+
+
+def graph_time(fn):
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for i in range(NB):
+            fn(i)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for i in range(REPS):
+                fn(i)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(7):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / REPS)
+    return sorted(ts)[len(ts) // 2]
+
+
+def main():
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    L = (torch.randn(64, 64, generator=gen, device="cuda") / 8).half()
+    R = (torch.randn(64, 64, generator=gen, device="cuda") / 8).half()
+    for name, Ns in (("q/k/v", (4096, 1024, 1024)), ("up/gate", (14336, 14336))):
+        sigs = [(0.98, 0.98)] * len(Ns)
+        imgs = [[ops.int4_to_frag(torch.randint(0, 256, (N, 2048), generator=gen, device="cuda", dtype=torch.uint8)) for N in Ns] for _ in range(NB)]
+        wss = [torch.rand(N, generator=gen, device="cuda").half() * 0.01 for N in Ns]
+        for M in (1, 4, 8, 16):
+            x = torch.randn(M, 4096, generator=gen, device="cuda").half()
+
+            def two(i):
+                o = ops.rmsnorm_kron_quant(x, 1e-5, L, R, sigs, FQ_OUT_PACKED | FQ_NO_CLAMP0)
+                return ops.int4_skinny_linear_multi([(o.q[p], o.scale[p], imgs[i % NB][p], wss[p], None) for p in range(len(Ns))])
+
+            def one(i):
+                return ops.kron64_linear_multi(x, L, R, sigs, [(imgs[i % NB][p], wss[p], None) for p in range(len(Ns))], eps=1e-5, flags=FQ_NO_CLAMP0)
+
+            a, b = two(0), one(0)
+            ok = all(torch.equal(u, v) for u, v in zip(a, b))
+            t2, t1 = graph_time(two), graph_time(one)
+            mb = sum(Ns) * 2048 / 1e6
+            print(f"[{TAG}] {name:8s} M={M:2d}: two launches {t2:6.2f} us, fused {t1:6.2f} us ({mb / t1:5.2f} TB/s of weights)  exact={ok}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
