@@ -106,7 +106,9 @@ def test_skinny_gemm_bit_exact(ops, M, N, K):
     assert np.array_equal(c, ref.astype(np.int32))
 
 
-@pytest.mark.parametrize("M,N,K,bias", [(16, 256, 4096, False), (65, 272, 256, True), (128, 1024, 1024, True)])
+@pytest.mark.parametrize("M,N,K,bias", [(16, 256, 4096, False), (65, 272, 256, True), (128, 1024, 1024, True),
+                                        # lone 2048- to 4096-wide projections of <= 32 rows (two weight blobs of a wave in flight)
+                                        (32, 4096, 4096, True), (3, 2048, 2048, True), (1, 4096, 14336, False), (7, 2304, 2048, True)])
 def test_skinny_linear_equals_tile_kernel(ops, M, N, K, bias):
     gen = torch.Generator().manual_seed(M + N + K + 2)
     xp, _ = rand_packed(gen, M, K)

@@ -16,11 +16,12 @@ NB = int(os.environ.get("NB", "6"))
 TAG = os.environ.get("FQHIP_OVERLAY", "default").split("/")[-1]
 
 
-def graph_time(fn):
+def graph_time(fn, warm=None):
+    warm = NB if warm is None else warm
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
-        for i in range(NB):
+        for i in range(warm):
             fn(i)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -66,5 +67,22 @@ def main():
             print(f"[{TAG}] {name:8s} M={M:2d}: two launches {t2:6.2f} us, fused {t1:6.2f} us ({mb / t1:5.2f} TB/s of weights)  exact={ok}", flush=True)
 
 
+def main_lone():
+    """the lone projections of the step (o_proj 4096 x 4096, down_proj 4096 x 14336) on the weight-streaming kernel, graph-replayed"""
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    for name, N, K in (("o_proj", 4096, 4096), ("down", 4096, 14336)):
+        nb = max(NB, int(400e6 // (N * K // 2)))
+        imgs = [ops.int4_to_frag(torch.randint(0, 256, (N, K // 2), generator=gen, device="cuda", dtype=torch.uint8)) for _ in range(nb)]
+        ws = torch.rand(N, generator=gen, device="cuda").half() * 0.01
+        for M in (1, 8, 16):
+            x = torch.randint(0, 256, (M, K // 2), generator=gen, device="cuda", dtype=torch.uint8)
+            sx = torch.rand(M, generator=gen, device="cuda").half() * 0.01
+            t = graph_time(lambda i: ops.int4_skinny_linear(x, sx, imgs[i % nb], ws, None, N), warm=nb)
+            print(f"[{TAG}] {name:8s} M={M:2d}: {t:6.2f} us ({N * K / 2 / 1e6 / t:5.2f} TB/s of weights)", flush=True)
+
+
 if __name__ == "__main__":
+    if os.environ.get("LONE"):
+        main_lone()
+        sys.exit(0)
     main()
