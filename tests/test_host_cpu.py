@@ -503,6 +503,29 @@ def test_untracked_row_loads_are_not_read_before_their_wait(tmp_path):
     assert r.returncode == 0, r.stdout
 
 
+def test_fused_decode_launch_does_not_read_requested_registers_before_a_wait(tmp_path):
+    """fq_kron64_linear_kernel (round 6) keeps two feature tiles of weights in flight in registers across its token transform, requested
+    by inline-asm loads and waited for with counted vmcnt. Its first build read stale weights: the allocator had put the new requests
+    into fresh registers and COPIED them into the loop-carried ones at the back edge, in front of the wait. The same ISA check as for
+    fq_kron_tall.hip: between a request and the next wait nothing reads or copies the destination registers."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asm = str(tmp_path / "k64.s")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm",
+                    "-amdgpu-kernarg-preload-count=16", "-S", "--cuda-device-only", "-o", asm,
+                    os.path.join(root, "flatquant_amd", "csrc", "fq_kron64.hip")], check=True, capture_output=True, timeout=900)
+    text = open(asm).read()
+    assert "fq_kron64_linear_kernel" in text and "global_load_ushort" in text
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_untracked_loads.py"), asm, "linear_kernel", "--deep", "1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+
+
 def test_hot_kernels_keep_their_occupancy_budget():
     """The compiler's per-kernel resource reports (flatquant_amd/csrc/build/*.res, written by the Makefile's
     -Rpass-analysis=kernel-resource-usage) against the occupancy each hot kernel was tuned at. A source change that makes the
@@ -572,6 +595,8 @@ def test_hot_kernels_keep_their_occupancy_budget():
         "fq_gemm_bf6_kernel<256,0>": (2, 0),              # Linear4bit, FP6 matrix path: 8 waves = two per SIMD, no spill (a spill's reload
         "fq_gemm_bf6_kernel<128,0>": (2, 0),              # once sat between the DMA instructions of a stage behind s_waitcnt vmcnt(0))
         "fq_gemm_i4_kernel": (4, 0),                      # int8 matrix path: 16 waves per workgroup
+        "fq_kron64_linear_kernel<0>": (2, 0),             # the fused decode launch: 8 waves per CU, two weight tiles in registers, no spill
+        "fq_kron64_linear_kernel<1>": (2, 0),
     }
     present = [k for k in budget if k in res]
     assert len(present) >= len(budget) - 2, sorted(set(budget) - set(res))      # (names follow the template arguments)

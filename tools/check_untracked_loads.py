@@ -6,7 +6,10 @@ fq_kron_tall.hip).
     has not arrived; a register copy there — a phi, a spill, an AGPR move — silently takes the old contents). Waits:
       s_waitcnt vmcnt(0)              covers everything;
       s_waitcnt vmcnt(4)  (--deep 2)  covers all but the four loads issued last (a two-register-set build);
-      s_waitcnt vmcnt(k)  (--deep 1)  a counted wait behind the token's stores (k = stores issued since): covers all.
+      s_waitcnt vmcnt(k)  (--deep 1)  a counted wait behind the token's stores (k = stores issued since): covers all. Also the mode for
+                                      fq_kron64_linear_kernel (round 6: two weight tiles in flight, counts chosen at run time inside one asm
+                                      statement): every wait is taken to cover everything, i.e. what is checked is "no read or copy between a
+                                      request and the NEXT wait" — where the first build's copies sat (the loop's back edge).
     (the two --deep forms belong to prefetch variants measured and removed in round 5; kept for the next experiment of that kind)
 (2) LOOP WAITS (round 5): inside the token loop the ONLY vmcnt waits may be the kernel's own explicit ones and the vmcnt(0) directly
     behind a compiler-tracked load of a grouped launch's clip / offset arrays. Rounds 3-4 shipped a build whose compiler-inserted
@@ -68,6 +71,10 @@ for i, l in enumerate(src):
     m = re.match(r"global_load_dwordx[24] v\[(\d+):(\d+)\]", t)
     if in_asm and m:
         pending.append((set(range(int(m.group(1)), int(m.group(2)) + 1)), i))
+        continue
+    m1 = re.match(r"global_load_(?:ushort|dword) v(\d+),", t)      # (round 6: the fused decode launch's column scales / biases)
+    if in_asm and m1:
+        pending.append(({int(m1.group(1))}, i))
         continue
     mw = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", t)
     if mw:
