@@ -132,6 +132,13 @@ int fq_launch_kron_generic(int flags, const f16* x, const f16* left, const f16* 
             return launch_fast<MT_, NT_, KS1_, W_, OCC_, true, FQ_OUT_PACKED | FQ_QUANT_F16>(flags, x, ws, diag, rows, M, N, out, n_cu, stream); \
         return launch_fast<MT_, NT_, KS1_, W_, OCC_, true>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);  \
     }
+#ifndef FQ_FS_DECODE_W
+#define FQ_FS_DECODE_W 8   // (measurement knob) waves of the decode-sized 112 x 128 SiLU.mul launch; 4 = the prefill build at every size
+#endif
+        // decode-sized (a handful of tokens, one workgroup each, the chip idle around them): eight waves per token — the four without an
+        // n'-tile halve the rounds of the image copy and of the token's loads (a latency chain, not bandwidth)
+        if (FQ_FS_DECODE_W != 4 && rows <= 64 && MT == 4 && NT == 4 && g.KS1 == 8 && (flags & FQ_CT_MASK) == FQ_OUT_PACKED)
+            return launch_fast<4, 4, 8, FQ_FS_DECODE_W, 1, true, FQ_OUT_PACKED>(flags, x, ws, diag, rows, M, N, out, n_cu, stream);
         FQ_FS(4, 4, 8, 4, 2) FQ_FS(3, 4, 8, 4, 2) FQ_FS(4, 7, 14, 8, 1) FQ_FS(4, 8, 16, 8, 1)
 #undef FQ_FS
         return -1000;

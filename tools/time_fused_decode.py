@@ -81,7 +81,22 @@ def main_lone():
             print(f"[{TAG}] {name:8s} M={M:2d}: {t:6.2f} us ({N * K / 2 / 1e6 / t:5.2f} TB/s of weights)", flush=True)
 
 
+def main_silu():
+    """the down_proj input of a decode step: SiLU.mul + 112 x 128 transform + quantiser (fq_silu_mul_kron_quant_f16), graph-replayed"""
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    L = (torch.randn(112, 112, generator=gen, device="cuda") / 10).half()
+    R = (torch.randn(128, 128, generator=gen, device="cuda") / 11).half()
+    for M in (1, 4, 8, 16, 64):
+        gate = torch.randn(M, 14336, generator=gen, device="cuda").half()
+        up = torch.randn(M, 14336, generator=gen, device="cuda").half()
+        t = graph_time(lambda i: ops.silu_mul_kron_quant(gate, up, L, R, [(0.98, 0.98)], FQ_OUT_PACKED | 0x08), warm=3)
+        print(f"[{TAG}] silu.mul + 112x128  M={M:2d}: {t:6.2f} us", flush=True)
+
+
 if __name__ == "__main__":
+    if os.environ.get("SILU"):
+        main_silu()
+        sys.exit(0)
     if os.environ.get("LONE"):
         main_lone()
         sys.exit(0)
