@@ -901,7 +901,7 @@ __global__ __launch_bounds__(KL_THREADS) void fq_kron64_linear_kernel(const f16*
     kl_load16(pv[0], prep + tid);
     kl_load16(pv[1], prep + tid + KL_THREADS);
     const unsigned tok_lds0 = (unsigned)(size_t)(lds_void*)toks;
-    for (int m = wave; m < M; m += KL_WAVES)               // (wave-uniform) two VMEM ops + ... : 8 DMA instructions per token
+    for (int m = wave; m < M; m += KL_WAVES)               // (wave-uniform) 8 LDS-DMA instructions per token, older than every weight request
         dma_token(x, m, __builtin_amdgcn_readfirstlane(tok_lds0 + (unsigned)m * TOK_BYTES), lane);
     // weights of two tiles in flight per wave: ring slot = tile parity; + the tile's column scale and bias for this thread's output element
     u32x4 W0[KL_BPW] = {}, W1[KL_BPW] = {};
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(KL_THREADS) void fq_kron64_linear_kernel(const f16*
     const int mo_ = mrow < M ? mrow : M - 1;               // rows >= M hold copies of token M - 1: the same value to the same address
     const f16 srow = (f16)sc_lds[mo_];
     int par = 0;
-    auto consume = [&](u32x4 (&Wr)[KL_BPW], unsigned sr, unsigned br, int t) {
+    auto consume = [&](u32x4 (&Wr)[KL_BPW]) {
         kl_i32x16 acc = kl_i32x16{0};
 #pragma unroll
         for (int j = 0; j < KL_BPW; ++j) {
@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(KL_THREADS) void fq_kron64_linear_kernel(const f16*
             KL_WAIT4(sel, 0, 10, 2, 12, KL_W0);
         }
 #undef KL_W0
-        const kl_i32x16 a0 = consume(W0, s0, b0, t);
+        const kl_i32x16 a0 = consume(W0);
         unsigned sk0, bk0;   // (real moves: a C++ copy lets the allocator keep the OLD value in place and load the new one elsewhere)
         asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(sk0), "=&v"(bk0) : "v"(s0), "v"(b0));
         if (t + 2 * step < n_tiles) KL_REQ(W0, s0, b0, t + 2 * step)
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(KL_THREADS) void fq_kron64_linear_kernel(const f16*
             KL_WAIT4(sel, 1, 11, 2, 12, KL_W1);
         }
 #undef KL_W1
-        const kl_i32x16 a1 = consume(W1, s1, b1, t + step);
+        const kl_i32x16 a1 = consume(W1);
         unsigned sk1, bk1;
         asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(sk1), "=&v"(bk1) : "v"(s1), "v"(b1));
         if (t + 3 * step < n_tiles) KL_REQ(W1, s1, b1, t + 3 * step)
