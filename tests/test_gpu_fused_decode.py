@@ -92,3 +92,22 @@ def test_uncovered_shapes_return_none_or_say_so(ops):
                                              VP(pr[1].data_ptr()), VP(pr[2].data_ptr()), VP(None), (ctypes.c_int * 1)(64), VP(y.data_ptr()),
                                              ws.data_ptr(), 32768, None)
     assert rc == _lib.FQ_EUNSUPPORTED
+
+
+@pytest.mark.parametrize("Ns", [(40960,), (14336, 14336, 14336, 14336), (4096, 32, 22528)])
+def test_long_tile_sequences_per_workgroup(ops, Ns):
+    """five to seven feature tiles per workgroup: the steady-state iterations of the two-slot weight ring (every wait count of the loop, odd and
+    even tile counts, the last tile in either slot), against the two launches"""
+    from flatquant_amd._lib import FQ_NO_CLAMP0, FQ_OUT_PACKED
+    gen = torch.Generator().manual_seed(sum(Ns))
+    M = 3
+    x = torch.randn(M, 4096, generator=gen).half().cuda()
+    L, R = _mats(gen, 64), _mats(gen, 64)
+    sigs = [(1.0, 1.0), (0.71, 0.83), (0.5, 0.45), (0.93, 0.6)][:len(Ns)]
+    probs = [_problem(ops, gen, N, p == 0) for p, N in enumerate(Ns)]
+    ref_q = ops.rmsnorm_kron_quant(x, 1e-6, L, R, sigs, FQ_OUT_PACKED | FQ_NO_CLAMP0)
+    ref = ops.int4_skinny_linear_multi([(ref_q.q[p], ref_q.scale[p], probs[p][1], probs[p][2], probs[p][3]) for p in range(len(Ns))])
+    for _ in range(3):          # (repeatable: no state survives a launch)
+        got = ops.kron64_linear_multi(x, L, R, sigs, [(pr[1], pr[2], pr[3]) for pr in probs], eps=1e-6, flags=FQ_NO_CLAMP0)
+        for p in range(len(Ns)):
+            assert torch.equal(ref[p], got[p]), (Ns, p, int((ref[p] != got[p]).sum()))
