@@ -60,7 +60,7 @@ int fq_launch_kv_append(void* kv_data, void* kv_param, const int* indptr, const 
                         hipStream_t stream, bool f16_cache = false);
 int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, const f16* qt,
-                        int transpose_out, hipStream_t stream, bool f16_cache = false, float* ws = nullptr, int splits = 1);
+                        int transpose_out, hipStream_t stream, bool f16_cache = false, float* ws = nullptr, int splits = 1, int qgroup = 1);
 int fq_kv_decode_splits(int batch, int num_heads, int seq_hint);
 int64_t fq_kv_decode_ws_bytes(int batch, int num_heads, int head_dim);
 int fq_launch_silu_mul(const f16* gate, const f16* up, f16* y, int64_t n, int n_cu, hipStream_t stream);
@@ -1194,6 +1194,28 @@ int fq_kv_batch_decode_split(int fp16_cache, void* o, const void* q, const void*
     rc = fq_launch_kv_decode((f16*)o, (const f16*)q, (void*)kv_data, (void*)kv_param, (const int*)kv_indptr, (const int*)kv_indices,
                              (const int*)last_page_offset, num_layers, layer_idx, num_heads, page_size, head_dim, batch_size,
                              (const f16*)q_trans, transpose_out != 0, (hipStream_t)stream, fp16_cache != 0, (float*)workspace, splits);
+    return check_launch(rc, what);
+}
+
+int fq_kv_batch_decode_gqa(int fp16_cache, void* o, const void* q, const void* q_trans, int transpose_out, const void* kv_data,
+                           const void* kv_param, const void* kv_indptr, const void* kv_indices, const void* last_page_offset,
+                           int num_layers, int layer_idx, int num_kv_heads, int q_group, int page_size, int head_dim, int batch_size, int seq_hint,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
+    const char* what = "fq_kv_batch_decode_gqa";
+    int rc = kv_geometry_ok(what, num_layers, layer_idx, num_kv_heads, page_size, head_dim, batch_size);
+    if (rc != FQ_OK) return rc;
+    if (q_group < 1 || q_group > 64) return fail(FQ_EINVAL, "%s: q_group=%d out of [1, 64]", what, q_group);
+    if (!o || !q || !kv_data || (!fp16_cache && !kv_param) || !kv_indptr || !kv_indices || !last_page_offset)
+        return fail(FQ_EINVAL, "%s: NULL pointer", what);
+    FQ_NEED_ALIGN16(what, kv_data, q_trans, workspace);
+    const int q_heads = num_kv_heads * q_group;
+    const int64_t need = fq_kv_decode_ws_bytes(batch_size, q_heads, head_dim);
+    const int splits = (workspace && need > 0) ? fq_kv_decode_splits(batch_size, q_heads, seq_hint) : 1;
+    if (splits > 1 && workspace_bytes < need)
+        return fail(FQ_EINVAL, "%s: workspace of %lld bytes, fq_kv_decode_workspace_bytes(batch, q heads) says %lld", what, (long long)workspace_bytes, (long long)need);
+    rc = fq_launch_kv_decode((f16*)o, (const f16*)q, (void*)kv_data, (void*)kv_param, (const int*)kv_indptr, (const int*)kv_indices,
+                             (const int*)last_page_offset, num_layers, layer_idx, q_heads, page_size, head_dim, batch_size,
+                             (const f16*)q_trans, transpose_out != 0, (hipStream_t)stream, fp16_cache != 0, (float*)workspace, splits, q_group);
     return check_launch(rc, what);
 }
 

@@ -170,7 +170,7 @@ __device__ __forceinline__ float* kv_states(float* ws, size_t pairs) { return ws
 // per pair behind the states, left at zero again) merges them like the states of one workgroup and writes the output.
 template <int HD, int NW, bool UNI, bool F16, bool SPLIT>
 __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restrict__ o, const f16* __restrict__ q, PagedKv p,
-                                                               const f16* __restrict__ qt, int transpose_out, float* ws) {
+                                                               const f16* __restrict__ qt, int transpose_out, float* ws, int qgroup) {
     constexpr int QL = HD / 32;        // lanes per cached row: 4 for head_dim 128, 2 for 64
     constexpr int RPW = 64 / QL;       // rows per wave and step: the N of the MFMA (16 / 32)
     constexpr int NS = NW * RPW;       // partial softmax states per workgroup
@@ -180,7 +180,11 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
     float* s_m = reinterpret_cast<float*>(kv_smem + sizeof(float) * NS * (HD + 1));
     float* s_d = s_m + NS;
     float* s_q = s_d + NS;
-    const int b = blockIdx.x, head = blockIdx.y;
+    // (round 6) qgroup > 1: a cache that holds the KV heads ONCE (grouped-query attention without the reference's per-query-head copies,
+    // kv_cache.py:286-296): query head `head` of QH = gridDim.y reads cache head head / qgroup of p.num_heads = QH / qgroup. Same values
+    // read, same arithmetic: the output is bit-identical to the replicated cache's; the cache is qgroup times smaller and the qgroup
+    // workgroups of a KV head re-read rows the memory-side cache still holds.
+    const int b = blockIdx.x, head = blockIdx.y, QH = (int)gridDim.y, chead = head / qgroup;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int part = lane / RPW, slot = lane % RPW;
     const float sm_scale = 1.44269504088896340736f / __builtin_sqrtf((float)HD);  // log2(e) / sqrt(head_dim): exp2 below
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
     // walked all HD terms in a dependent chain: microseconds in front of every workgroup, and a split launch has many), the NCHQ
     // partial sums meet in LDS (s_o is free until the states are written)
     {
-        const f16* qrow = q + ((size_t)b * p.num_heads + head) * HD;
+        const f16* qrow = q + ((size_t)b * QH + head) * HD;
         if (qt != nullptr) {
             constexpr int NCHQ = NW * 64 / HD, CHQ = HD / NCHQ;
             const int j = tid % HD, c = tid / HD;
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
     for (int j = 0; j < 32; ++j) acc[j] = 0.0f;
 
     const size_t page_stride = (size_t)p.num_layers * 2 * p.num_heads * p.page_size;
-    const size_t k_off = ((size_t)p.layer_idx * 2 * p.num_heads + head) * p.page_size, kv_off = (size_t)p.num_heads * p.page_size;
+    const size_t k_off = ((size_t)p.layer_idx * 2 * p.num_heads + chead) * p.page_size, kv_off = (size_t)p.num_heads * p.page_size;
     // Where the wave's next RPW rows live, advanced incrementally in request order (a 64-bit division per row would cost more than
     // the row). UNI (page_size % RPW == 0: the wave's RPW consecutive rows never straddle a page): ONE page index per wave and step, a
     // scalar load on its own counter, and the lanes differ by `slot` entries; rows of the last step beyond the sequence lie in the same
@@ -441,14 +445,14 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
             dd += s_pd[c];
             oo += s_po[c][tid];
         }
-        const size_t oi = transpose_out ? ((size_t)b * HD + tid) * p.num_heads + head : ((size_t)b * p.num_heads + head) * HD + tid;
+        const size_t oi = transpose_out ? ((size_t)b * HD + tid) * QH + head : ((size_t)b * QH + head) * HD + tid;
         if (!SPLIT) {
             o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;  // an empty sequence attends to nothing: zeros, not 0/0
         } else {
             // Agent-scope stores (sc1: written through to memory — the XCDs' L2s are not coherent with each other) instead of plain
             // stores + __threadfence(): the fence is a write-back of the XCD's whole L2 per workgroup (buffer_wbl2), measured +20 us
             // on a 26 us launch.
-            float* mine = kv_states(ws, (size_t)gridDim.x * gridDim.y) + (((size_t)b * p.num_heads + head) * gridDim.z + blockIdx.z) * (HD + 2);
+            float* mine = kv_states(ws, (size_t)gridDim.x * gridDim.y) + (((size_t)b * QH + head) * gridDim.z + blockIdx.z) * (HD + 2);
             if (tid == 0) {
                 __hip_atomic_store(mine, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(mine + 1, dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
 #error "fq_kv_decode_kernel<SPLIT>: the vmcnt-based hand-over is only valid on gfx942 / gfx950"
 #endif
         const int S = (int)gridDim.z;
-        unsigned* cnt = reinterpret_cast<unsigned*>(ws) + (size_t)b * p.num_heads + head;
+        unsigned* cnt = reinterpret_cast<unsigned*>(ws) + (size_t)b * QH + head;
         __shared__ unsigned s_last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's state has reached memory ...
         __syncthreads();
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
         __syncthreads();
         if (s_last) {
             if (tid < HD) {
-                const float* all = kv_states(ws, (size_t)gridDim.x * gridDim.y) + ((size_t)b * p.num_heads + head) * S * (HD + 2);
+                const float* all = kv_states(ws, (size_t)gridDim.x * gridDim.y) + ((size_t)b * QH + head) * S * (HD + 2);
                 auto ld = [](const float* ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };   // (sc1: not this XCD's L2)
                 float mz[16], dz[16], oz[16];      // every load first (S <= 16 round trips side by side, not one after the other)
 #pragma unroll
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
                     dd += dz[z] * w;
                     oo += oz[z] * w;
                 }
-                const size_t oi = transpose_out ? ((size_t)b * HD + tid) * p.num_heads + head : ((size_t)b * p.num_heads + head) * HD + tid;
+                const size_t oi = transpose_out ? ((size_t)b * HD + tid) * QH + head : ((size_t)b * QH + head) * HD + tid;
                 o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;
             }
             if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch finds the counters as this one did
@@ -558,16 +562,17 @@ int64_t fq_kv_decode_ws_bytes(int batch, int num_heads, int head_dim) {   // for
 
 int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, const f16* qt,
-                        int transpose_out, hipStream_t stream, bool f16_cache, float* ws, int splits) {
-    if (splits > 16) return -1000;   // (the merge of the split launch reads at most 16 states: fq_kv_decode_splits never returns more)
-    const PagedKv p = make_kv(kv_data, kv_param, indptr, indices, last, num_layers, layer_idx, num_heads, page_size, head_dim, batch);
+                        int transpose_out, hipStream_t stream, bool f16_cache, float* ws, int splits, int qgroup) {
+    // num_heads: QUERY heads (q, o, the grid); the cache holds num_heads / qgroup heads (qgroup = 1: the reference's layout)
+    if (splits > 16 || qgroup < 1 || num_heads % qgroup) return -1000;   // (the merge of the split launch reads at most 16 states: fq_kv_decode_splits never returns more)
+    const PagedKv p = make_kv(kv_data, kv_param, indptr, indices, last, num_layers, layer_idx, num_heads / qgroup, page_size, head_dim, batch);
     const bool split = ws != nullptr && splits > 1;
     const dim3 grid((unsigned)batch, (unsigned)num_heads, split ? (unsigned)splits : 1u);
     const bool wide = (int64_t)batch * num_heads * (split ? splits : 1) < 512;  // fewer than two workgroups per CU: 8 waves each instead of 4 (measured: 158 -> 113 us at 8 x 8192; no gain from 512 up)
 #define FQ_DEC3(HD_, NW_, UNI_, F16_, SP_)                                                                             \
     {                                                                                                                 \
         FQ_RAISE_LDS_CAP((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_, SP_>), lds);                                      \
-        hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_, SP_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out, ws); \
+        hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_, SP_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out, ws, qgroup); \
     }
 #define FQ_DEC2(HD_, NW_, UNI_, F16_)                                                                                  \
     {                                                                                                                 \

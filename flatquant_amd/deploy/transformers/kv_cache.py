@@ -100,9 +100,19 @@ class MultiLayerPagedKVCache4Bit:
       (NotImplementedError otherwise, :371-372)."""
 
     def __init__(self, batch_size, page_size, max_seq_len, device, n_layers, num_heads, head_dim, disable_quant=False,
-                 trans_dtype=torch.float16, trans="had", group_size=1):
+                 trans_dtype=torch.float16, trans="had", group_size=1, share_kv_heads=False):
+        """``share_kv_heads`` (extension, round 6): with grouped-query attention (``group_size`` > 1) the reference's cache holds one copy of
+        every KV head per QUERY head (:286-296). With this flag the pages hold the ``num_heads // group_size`` KV heads once and the decode
+        launch maps query head h to cache head h // group_size (fq_kv_batch_decode_gqa): the same attention output bit for bit, 1 / group_size
+        of the cache memory and of the bytes a decode step reads (a Llama-3-8B layer's step at 64 requests x 2048 tokens:
+        profiles/r06_gqa_cache.txt). The page layout then differs from the reference's in its head count, nothing else."""
         self.page_size, self.batch_size, self.max_seq_len = page_size, batch_size, max_seq_len
         self.device, self.n_layers, self.trans, self.group_size = device, n_layers, trans, group_size
+        self.share_kv_heads = bool(share_kv_heads) and group_size > 1
+        if self.share_kv_heads:
+            assert num_heads % group_size == 0
+            num_heads = num_heads // group_size          # heads the pages hold
+            self.group_size = 1                          # ... and the append scatters every source head to exactly one cache head
         self.disable_quant = disable_quant
         self.org_head_dim = head_dim
         n_pages = self.page_cnt_from_length(max_seq_len) * batch_size

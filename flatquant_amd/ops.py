@@ -1754,11 +1754,14 @@ def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tens
     of a request are split over several workgroups (fq_kv_batch_decode_split, round 5; ``seq_hint``: the longest request, 0 = unknown;
     ``split=False``: never) — same results up to the order of fp32 additions."""
     _chk(q, "q"), _chk(kv_data, "kv_data", kv_data.dtype), _chk(kv_param, "kv_param")
-    n_layers, heads, page_size, hd = _kv_geometry(kv_data)
+    n_layers, kv_heads, page_size, hd = _kv_geometry(kv_data)
     batch = _chk_kv_index(kv_indptr, kv_indices, last_page_offset)
     f16_cache = kv_data.dtype == torch.float16
-    if q.shape != (batch, heads, hd):
-        raise ValueError(f"q must be [{batch}, {heads}, {hd}]")
+    # (round 6) a cache that holds the KV heads once: q carries q_group query heads per cache head (fq_kv_batch_decode_gqa)
+    if q.dim() != 3 or q.shape[0] != batch or q.shape[2] != hd or q.shape[1] % kv_heads:
+        raise ValueError(f"q must be [{batch}, a multiple of {kv_heads}, {hd}]")
+    heads = q.shape[1]
+    q_group = heads // kv_heads
     if q_trans is not None:
         _chk(q_trans, "q_trans")
         if q_trans.shape != (hd, hd):
@@ -1770,6 +1773,12 @@ def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tens
         nbytes = int(lib.fq_kv_decode_workspace_bytes(batch, heads, hd)) if split else 0
         stream = _stream(q)
         ws = _kv_split_workspace((q.device.index, stream.value, batch * heads, hd), nbytes, q.device) if nbytes > 0 else None
+        if q_group > 1:
+            check(lib.fq_kv_batch_decode_gqa(1 if f16_cache else 0, _ptr(o), _ptr(q), _ptr(q_trans), 1 if transpose_out else 0, _ptr(kv_data),
+                                             _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
+                                             n_layers, layer_idx, kv_heads, q_group, page_size, hd, batch, int(seq_hint), _ptr(ws),
+                                             nbytes if ws is not None else 0, stream))
+            return o
         if ws is not None:
             check(lib.fq_kv_batch_decode_split(1 if f16_cache else 0, _ptr(o), _ptr(q), _ptr(q_trans), 1 if transpose_out else 0, _ptr(kv_data),
                                                _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),

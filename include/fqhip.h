@@ -618,6 +618,19 @@ int fq_kv_batch_decode_i4_ex(void* o, const void* q, const void* q_trans, int tr
                              const void* last_page_offset, int num_layers, int layer_idx, int num_heads, int page_size,
                              int head_dim, int batch_size, void* stream);
 
+/* (round 6, extension) The decode attention over a cache that holds the KV heads ONCE: grouped-query attention without the per-query-head
+ * copies the reference's cache class makes (kv_cache.py:286-296 repeats every KV head num_heads / num_kv_heads times at append time). kv_data /
+ * kv_param are laid out with num_kv_heads heads (filled by fq_kv_quant_append_i4 / fq_kv_append_* with num_heads = num_kv_heads,
+ * group_size = 1); q and o hold num_kv_heads * q_group query heads, query head h reads cache head h / q_group. The same rows, the same
+ * arithmetic: o is bit-identical to fq_kv_batch_decode_split on the replicated cache — from 1 / q_group of the cache memory, and with the
+ * q_group workgroups of a KV head re-reading rows the memory-side cache still holds (profiles/r06_gqa_cache.txt). fp16_cache, q_trans,
+ * transpose_out, seq_hint, workspace (fq_kv_decode_workspace_bytes(batch, num_kv_heads * q_group, head_dim); may be NULL: no split): as
+ * fq_kv_batch_decode_split. */
+int fq_kv_batch_decode_gqa(int fp16_cache, void* o, const void* q, const void* q_trans, int transpose_out, const void* kv_data,
+                           const void* kv_param, const void* kv_indptr, const void* kv_indices, const void* last_page_offset,
+                           int num_layers, int layer_idx, int num_kv_heads, int q_group, int page_size, int head_dim, int batch_size, int seq_hint,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
 /*
  * The fp16 configuration of the same cache (MultiLayerPagedKVCache4Bit(disable_quant=True), kv_cache.py:177-190;
  * init_kv_f16 / append_kv_f16 / batch_decode_f16, kv_cache.py:107-137): kv_data [pages, num_layers, 2, num_heads, page_size,

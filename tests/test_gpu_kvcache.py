@@ -510,3 +510,41 @@ def test_split_decode_is_bit_stable_over_many_launches(ops):
         for args, seq, first in cases:
             bad += (ops.kv_batch_decode(*args, seq_hint=seq) != first).sum()     # (compared on the device: nothing waits for the host)
     assert int(bad) == 0
+
+
+@pytest.mark.parametrize("disable_quant", [False, True])
+@pytest.mark.parametrize("bsz,prompt,kv_heads,group,hd,page", [(3, 37, 2, 4, 128, 16), (1, 300, 8, 4, 128, 64), (5, 20, 4, 2, 64, 16), (40, 70, 2, 4, 128, 32)])
+def test_shared_kv_heads_cache_equals_the_replicated_cache(ops, disable_quant, bsz, prompt, kv_heads, group, hd, page):
+    """share_kv_heads=True (round 6, extension): the pages hold the KV heads once, query head h reads cache head h // group
+    (fq_kv_batch_decode_gqa). Same rows, same arithmetic: the attention output is BIT-identical to the reference-shaped cache's (one copy
+    per query head, kv_cache.py:286-296) — unsplit and split launches, the query transform, the transposed output, both cache dtypes."""
+    import flatquant_amd.deploy.transformers as T
+    g = torch.Generator(device="cuda").manual_seed(bsz * 100 + prompt)
+    heads = kv_heads * group
+    mk = lambda share: T.MultiLayerPagedKVCache4Bit(bsz, page, prompt + 8, "cuda", 2, heads, hd, trans="matmul", group_size=group,
+                                                    disable_quant=disable_quant, share_kv_heads=share)
+    rep, sh = mk(False), mk(True)
+    rep.pages.zero_(), sh.pages.zero_()      # (torch.empty pages: the entries no token reached are compared below too)
+    assert sh.pages.shape[3] == kv_heads and rep.pages.shape[3] == heads and sh.pages.numel() * group == rep.pages.numel()
+    tk = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half()
+    kw = {"trans_matrix_k": tk, "trans_matrix_k_inv_t": torch.linalg.inv(tk.float()).T.contiguous().half()}
+    for layer in range(2):
+        k = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+        v = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+        rep.update(k, v, layer, dict(kw)), sh.update(k, v, layer, dict(kw))
+    for step in range(4):
+        for layer in range(2):
+            k = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+            v = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+            a_rep, a_sh = rep.update(k, v, layer, dict(kw)), sh.update(k, v, layer, dict(kw))
+            q = torch.randn(bsz, 1, heads, hd, generator=g, device="cuda").half()
+            for transposed in (False, True):
+                assert torch.equal(a_rep(q, transposed=transposed), a_sh(q, transposed=transposed)), (step, layer, transposed)
+    # the rows themselves: cache head j of the shared pages == every one of its `group` copies in the replicated pages
+    assert torch.equal(rep.pages[:sh.pages.shape[0]].reshape(-1, 2, 2, kv_heads, group, *rep.pages.shape[4:])[:, :, :, :, 0], sh.pages.reshape(-1, 2, 2, kv_heads, *sh.pages.shape[4:]))
+    # no split workspace (split=False) and the plain entry without a query transform
+    specs_r, specs_s = rep._specs, sh._specs
+    q2 = torch.randn(bsz, heads, hd, generator=g, device="cuda").half()
+    ar = (specs_r["kv_data"], specs_r["kv_param"], specs_r["kv_indptr"], specs_r["kv_indices"], specs_r["last_page_offset"])
+    as_ = (specs_s["kv_data"], specs_s["kv_param"], specs_s["kv_indptr"], specs_s["kv_indices"], specs_s["last_page_offset"])
+    assert torch.equal(ops.kv_batch_decode(q2, *ar, 1, split=False), ops.kv_batch_decode(q2, *as_, 1, split=False))

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--cache", type=int, default=2048, help="cached tokens per request")
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--two-launches", action="store_true", help="round 5's launch structure: transform launch + projection launch per group (no fused prologue)")
+    ap.add_argument("--share-kv", action="store_true", help="the cache holds the KV heads once (share_kv_heads=True: 1 / group of the memory and of the rows a step reads)")
     ap.add_argument("--single", action="store_true", help="one launch per projection (rounds 1-4) instead of the multi-problem launches")
     ap.add_argument("--fp16", action="store_true", help="also time the same step in fp16 (nn.Linear, rms_norm, SiLU.mul, the fp16 configuration of the paged cache) "
                                                         "— the baseline of the reference's decode table, README.md:300-310")
@@ -58,7 +59,7 @@ def main():
     q_l, k_l, v_l, o_l = lin(hidden, hidden), lin(hidden, kv_heads * hd), lin(hidden, kv_heads * hd), lin(hidden, hidden)
     up_l, gate_l, down_l = lin(hidden, ffn), lin(hidden, ffn), lin(ffn, hidden)
     tk = (torch.randn(hd, hd, generator=g, device=dev) / hd ** 0.5).half()
-    cache = dt.MultiLayerPagedKVCache4Bit(a.bsz, 2048, a.cache + 8, dev, 1, heads, hd, trans="matmul", group_size=heads // kv_heads)
+    cache = dt.MultiLayerPagedKVCache4Bit(a.bsz, 2048, a.cache + 8, dev, 1, heads, hd, trans="matmul", group_size=heads // kv_heads, share_kv_heads=a.share_kv)
     kw = {"trans_matrix_k": tk, "trans_matrix_k_inv_t": tk}
     cache.update(torch.randn(a.bsz, a.cache, kv_heads, hd, generator=g, device=dev).half(),
                  torch.randn(a.bsz, a.cache, kv_heads, hd, generator=g, device=dev).half(), 0, dict(kw))
@@ -162,7 +163,7 @@ def main():
             fq, fk, fv, fo = mk(hidden, hidden), mk(hidden, kv_heads * hd), mk(hidden, kv_heads * hd), mk(hidden, hidden)
             fu, fg, fd = mk(hidden, ffn), mk(hidden, ffn), mk(ffn, hidden)
         w1 = torch.ones(hidden, device=dev, dtype=torch.float16)
-        cache16 = dt.MultiLayerPagedKVCache4Bit(a.bsz, 2048, a.cache + 8, dev, 1, heads, hd, disable_quant=True, trans="none", group_size=heads // kv_heads)
+        cache16 = dt.MultiLayerPagedKVCache4Bit(a.bsz, 2048, a.cache + 8, dev, 1, heads, hd, disable_quant=True, trans="none", group_size=heads // kv_heads, share_kv_heads=a.share_kv)
         cache16.update(torch.randn(a.bsz, a.cache, kv_heads, hd, generator=g, device=dev).half(),
                        torch.randn(a.bsz, a.cache, kv_heads, hd, generator=g, device=dev).half(), 0, {})
 
