@@ -62,6 +62,8 @@ int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, con
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, const f16* qt,
                         int transpose_out, hipStream_t stream, bool f16_cache = false, float* ws = nullptr, int splits = 1, int qgroup = 1);
 int fq_kv_decode_splits(int batch, int num_heads, int seq_hint);
+int fq_kv_decode_wg_heads(int batch, int num_q_heads, int q_group, int head_dim);
+int64_t fq_kv_decode_ws_bytes_gqa(int batch, int num_q_heads, int q_group, int head_dim);
 int64_t fq_kv_decode_ws_bytes(int batch, int num_heads, int head_dim);
 int fq_launch_silu_mul(const f16* gate, const f16* up, f16* y, int64_t n, int n_cu, hipStream_t stream);
 int fq_launch_silu_hadamard_quant(const f16* gate, const f16* up, int64_t rows, int n, int K, const f16* hadK, float scale,
@@ -1177,6 +1179,11 @@ int64_t fq_kv_decode_workspace_bytes(int batch_size, int num_heads, int head_dim
     return fq_kv_decode_ws_bytes(batch_size, num_heads, head_dim);
 }
 
+int64_t fq_kv_decode_workspace_bytes_gqa(int batch_size, int num_kv_heads, int q_group, int head_dim) {
+    if (batch_size < 0 || num_kv_heads <= 0 || q_group < 1 || (head_dim != 64 && head_dim != 128)) return -1;
+    return fq_kv_decode_ws_bytes_gqa(batch_size, num_kv_heads * q_group, q_group, head_dim);
+}
+
 int fq_kv_batch_decode_split(int fp16_cache, void* o, const void* q, const void* q_trans, int transpose_out, const void* kv_data,
                              const void* kv_param, const void* kv_indptr, const void* kv_indices, const void* last_page_offset,
                              int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch_size, int seq_hint,
@@ -1209,10 +1216,10 @@ int fq_kv_batch_decode_gqa(int fp16_cache, void* o, const void* q, const void* q
         return fail(FQ_EINVAL, "%s: NULL pointer", what);
     FQ_NEED_ALIGN16(what, kv_data, q_trans, workspace);
     const int q_heads = num_kv_heads * q_group;
-    const int64_t need = fq_kv_decode_ws_bytes(batch_size, q_heads, head_dim);
-    const int splits = (workspace && need > 0) ? fq_kv_decode_splits(batch_size, q_heads, seq_hint) : 1;
+    const int64_t need = fq_kv_decode_ws_bytes_gqa(batch_size, q_heads, q_group, head_dim);
+    const int splits = (workspace && need > 0) ? fq_kv_decode_splits(batch_size, fq_kv_decode_wg_heads(batch_size, q_heads, q_group, head_dim), seq_hint) : 1;
     if (splits > 1 && workspace_bytes < need)
-        return fail(FQ_EINVAL, "%s: workspace of %lld bytes, fq_kv_decode_workspace_bytes(batch, q heads) says %lld", what, (long long)workspace_bytes, (long long)need);
+        return fail(FQ_EINVAL, "%s: workspace of %lld bytes, fq_kv_decode_workspace_bytes_gqa says %lld", what, (long long)workspace_bytes, (long long)need);
     rc = fq_launch_kv_decode((f16*)o, (const f16*)q, (void*)kv_data, (void*)kv_param, (const int*)kv_indptr, (const int*)kv_indices,
                              (const int*)last_page_offset, num_layers, layer_idx, q_heads, page_size, head_dim, batch_size,
                              (const f16*)q_trans, transpose_out != 0, (hipStream_t)stream, fp16_cache != 0, (float*)workspace, splits, q_group);

@@ -135,6 +135,14 @@ __device__ __forceinline__ float kv_qk_mfma(const f16x8 (&qa)[4], const f16x8 (&
         return c[0];
     }
 }
+// The same for head_dim 128 with the first four D rows kept: with A row m = the query of head m % QG (fq_kv_decode_kernel<.., QG>), lane
+// (part, i) — which holds D rows 4 part .. 4 part + 3 of column i — gets the sums of heads 0 .. 3 for ITS row i in c[0..3], no lane exchange.
+__device__ __forceinline__ f32x4 kv_qk_mfma4(const f16x8 (&qa)[4], const f16x8 (&kb)[4]) {
+    f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[w], kb[w], c, 0, 0, 0);
+    return c;
+}
 template <int QL>
 __device__ __forceinline__ float kv_qk(const f16x8 (&qa)[4], const uint4 kq, uint32_t ebits) {   // INT4 row -> sum_j q_j (16 + n_ij)
     const uint32_t kw[4] = {kq.x, kq.y, kq.z, kq.w};
@@ -155,6 +163,9 @@ __device__ __forceinline__ size_t kv_uniform64(size_t v) {
 // the split decode's workspace: a counter per (request, head) pair first (a fixed place, whatever the split count), the states behind them
 __device__ __forceinline__ float* kv_states(float* ws, size_t pairs) { return ws + ((pairs + 3) & ~(size_t)3); }
 
+#ifndef KV_MERGE_HEADS
+#define KV_MERGE_HEADS 1   // (measurement knob) 0: a workgroup per query head on a shared cache too (fq_launch_kv_decode)
+#endif
 #ifndef KV_ABL
 #define KV_ABL 0   // measurement builds: 1 no row loop, 2 no state sums in the merge
 #endif
@@ -168,7 +179,12 @@ __device__ __forceinline__ float* kv_states(float* ws, size_t pairs) { return ws
 // (one request x 32 heads: 32 of 256 CUs, ~20 us for 9 MB). The workgroups of a pair take the wave-steps round robin (virtual wave
 // blockIdx.z * NW + wave of gridDim.z * NW), each leaves its un-normalised (m, d, o[HD]) in `ws`, and the LAST one to arrive (a counter
 // per pair behind the states, left at zero again) merges them like the states of one workgroup and writes the output.
-template <int HD, int NW, bool UNI, bool F16, bool SPLIT>
+// QG (round 6): QUERY HEADS PER WORKGROUP over a cache that holds the KV heads once (grouped-query attention, fq_kv_batch_decode_gqa):
+// blockIdx.y is the CACHE head, the workgroup serves its QG query heads from ONE pass over the rows — the rows are loaded and their
+// nibbles unpacked once, the q . k MFMA that had one useful A row of sixteen carries all QG queries (A row m = query m % QG), and only the
+// per-head softmax state and the p . v accumulation are QG-fold. head_dim 128 only (the 16 x 16 x 32 shape's D rows). QG = 1: every
+// workgroup one query head (qgroup: how many of them share a cache head; 1 = the reference's replicated cache).
+template <int HD, int NW, bool UNI, bool F16, bool SPLIT, int QG = 1>
 __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restrict__ o, const f16* __restrict__ q, PagedKv p,
                                                                const f16* __restrict__ qt, int transpose_out, float* ws, int qgroup) {
     constexpr int QL = HD / 32;        // lanes per cached row: 4 for head_dim 128, 2 for 64
@@ -184,7 +200,9 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
     // kv_cache.py:286-296): query head `head` of QH = gridDim.y reads cache head head / qgroup of p.num_heads = QH / qgroup. Same values
     // read, same arithmetic: the output is bit-identical to the replicated cache's; the cache is qgroup times smaller and the qgroup
     // workgroups of a KV head re-read rows the memory-side cache still holds.
-    const int b = blockIdx.x, head = blockIdx.y, QH = (int)gridDim.y, chead = head / qgroup;
+    static_assert(QG == 1 || (HD == 128 && (QG == 2 || QG == 4)), "several query heads per workgroup: head_dim 128, groups of 2 or 4");
+    const int b = blockIdx.x, head = QG > 1 ? (int)blockIdx.y * QG : (int)blockIdx.y;        // (QG > 1: the FIRST query head of this workgroup)
+    const int QH = QG > 1 ? (int)gridDim.y * QG : (int)gridDim.y, chead = QG > 1 ? (int)blockIdx.y : head / qgroup;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int part = lane / RPW, slot = lane % RPW;
     const float sm_scale = 1.44269504088896340736f / __builtin_sqrtf((float)HD);  // log2(e) / sqrt(head_dim): exp2 below
@@ -195,8 +213,9 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
     // trans_matrix_k_inv_t)), fp32 accumulation — every thread sums HD / NCHQ terms of one output feature (one thread per feature
     // walked all HD terms in a dependent chain: microseconds in front of every workgroup, and a split launch has many), the NCHQ
     // partial sums meet in LDS (s_o is free until the states are written)
-    {
-        const f16* qrow = q + ((size_t)b * QH + head) * HD;
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const f16* qrow = q + ((size_t)b * QH + head + g) * HD;
         if (qt != nullptr) {
             constexpr int NCHQ = NW * 64 / HD, CHQ = HD / NCHQ;
             const int j = tid % HD, c = tid / HD;
@@ -209,34 +228,46 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
                 float t = 0.0f;
 #pragma unroll
                 for (int cc = 0; cc < NCHQ; ++cc) t += s_o[cc][tid];
-                s_q[tid] = (float)(f16)t;
+                s_q[g * HD + tid] = (float)(f16)t;
             }
         } else {
-            for (int j = tid; j < HD; j += NW * 64) s_q[j] = (float)qrow[j];
+            for (int j = tid; j < HD; j += NW * 64) s_q[g * HD + j] = (float)qrow[j];
         }
         __syncthreads();
     }
     // the A operand of K-step w: features 32 part + 8 w + feat(e) — INT4: the order kv_unpack8 leaves the nibbles in
     auto feat = [](int e) { return F16 ? e : KV_PERM[e]; };
     f16x8 qa[4];
-    float qsum = 0.0f;
+    float qsum[QG], qoff[QG];
+    {
+        const int ga = slot % QG;   // the query this lane's A row carries (QG = 1: the one query in every row)
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
+        for (int w = 0; w < 4; ++w)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float v = s_q[part * 32 + w * 8 + feat(e)];
-            qa[w][e] = (f16)v;
-            qsum += v;
+            for (int e = 0; e < 8; ++e) qa[w][e] = (f16)s_q[ga * HD + part * 32 + w * 8 + feat(e)];
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            float t = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t += s_q[g * HD + part * 32 + w * 8 + feat(e)];
+#pragma unroll
+            for (int off = RPW; off < 64; off <<= 1) t += __shfl_xor(t, off, 64);   // over the row's QL lanes: sum of ALL features
+            qsum[g] = t;
+            qoff[g] = KV_OFF * t;
         }
-#pragma unroll
-    for (int off = RPW; off < 64; off <<= 1) qsum += __shfl_xor(qsum, off, 64);   // over the row's QL lanes: sum of ALL features
-    const float qoff = KV_OFF * qsum;
+    }
     uint32_t ebits = 0x4C004C00u;   // (16.0, 16.0): kept in a VGPR
     asm volatile("" : "+v"(ebits));
 
-    float m = -INFINITY, d = 0.0f, zacc = 0.0f, acc[32];   // acc[8 w + e]: feature 32 part + 8 w + KV_PERM[e] of sum_i p_i s_i (16 + n_i); zacc: sum_i p_i (z_i + 16 s_i)
+    float m[QG], d[QG], zacc[QG], acc[QG][32];   // acc[g][8 w + e]: feature 32 part + 8 w + KV_PERM[e] of sum_i p_i s_i (16 + n_i); zacc: sum_i p_i (z_i + 16 s_i)
 #pragma unroll
-    for (int j = 0; j < 32; ++j) acc[j] = 0.0f;
+    for (int g = 0; g < QG; ++g) {
+        m[g] = -INFINITY, d[g] = 0.0f, zacc[g] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc[g][j] = 0.0f;
+    }
 
     const size_t page_stride = (size_t)p.num_layers * 2 * p.num_heads * p.page_size;
     const size_t k_off = ((size_t)p.layer_idx * 2 * p.num_heads + chead) * p.page_size, kv_off = (size_t)p.num_heads * p.page_size;
@@ -307,33 +338,60 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
     };
     auto step = [&](int64_t base, const Rows& r) {
         const bool valid = base + slot < seq_len;
-        float x, vs = 1.0f, vz = 0.0f;
+        float x[QG], vs = 1.0f, vz = 0.0f;
         if constexpr (F16) {
             f16x8 kb[4];
 #pragma unroll
             for (int w = 0; w < 4; ++w) kb[w] = __builtin_bit_cast(f16x8, r.kq[w]);
-            x = valid ? kv_qk_mfma<QL>(qa, kb) * sm_scale : -INFINITY;
+            if constexpr (QG > 1) {
+                const f32x4 c4 = kv_qk_mfma4(qa, kb);
+#pragma unroll
+                for (int g = 0; g < QG; ++g) x[g] = valid ? c4[g] * sm_scale : -INFINITY;
+            } else {
+                x[0] = valid ? kv_qk_mfma<QL>(qa, kb) * sm_scale : -INFINITY;
+            }
         } else {
             const float ks = (float)__builtin_bit_cast(f16, (unsigned short)(r.kpar & 0xFFFF)), kz = (float)__builtin_bit_cast(f16, (unsigned short)(r.kpar >> 16));
             vs = (float)__builtin_bit_cast(f16, (unsigned short)(r.vpar & 0xFFFF)), vz = (float)__builtin_bit_cast(f16, (unsigned short)(r.vpar >> 16));
-            const float dotn = kv_qk<QL>(qa, r.kq[0], ebits) - qoff;
-            x = valid ? (ks * dotn - kz * qsum) * sm_scale : -INFINITY;
+            if constexpr (QG > 1) {
+                const uint32_t kw[4] = {r.kq[0].x, r.kq[0].y, r.kq[0].z, r.kq[0].w};
+                f16x8 kb[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    uint32_t u[4];
+                    kv_unpack8(kw[w], ebits, u);
+                    kb[w] = __builtin_bit_cast(f16x8, u32x4{u[0], u[1], u[2], u[3]});
+                }
+                const f32x4 c4 = kv_qk_mfma4(qa, kb);
+#pragma unroll
+                for (int g = 0; g < QG; ++g) {
+                    const float dotn = c4[g] - qoff[g];
+                    x[g] = valid ? (ks * dotn - kz * qsum[g]) * sm_scale : -INFINITY;
+                }
+            } else {
+                const float dotn = kv_qk<QL>(qa, r.kq[0], ebits) - qoff[0];
+                x[0] = valid ? (ks * dotn - kz * qsum[0]) * sm_scale : -INFINITY;
+            }
         }
         // The reference point of a lane's running softmax is not its exact maximum but a bound KV_MARGIN (log2 units) above the row
         // that last raised it: exact maxima move in most steps of a 2048-token request (16 row lanes per wave, each a new maximum
         // with probability 1 / t) and every move rescales 34 registers in all lanes; a bound 2^8 above moves once or twice per
         // request. p = exp2(x - m) stays <= 1, the merge takes m as it is.
-        const float m_new = x > m ? x + KV_MARGIN : m;
-        if (__builtin_amdgcn_ballot_w64(x > m) != 0) {   // some lane's bound moved: everybody rescales (by 1 where it did not)
-            const float alpha = x > m ? __builtin_amdgcn_exp2f(m - m_new) : 1.0f;
-            d *= alpha;
-            zacc *= alpha;
+        float pr[QG];
 #pragma unroll
-            for (int j = 0; j < 32; ++j) acc[j] *= alpha;
-            m = m_new;
+        for (int g = 0; g < QG; ++g) {
+            const float m_new = x[g] > m[g] ? x[g] + KV_MARGIN : m[g];
+            if (__builtin_amdgcn_ballot_w64(x[g] > m[g]) != 0) {   // some lane's bound moved: everybody rescales (by 1 where it did not)
+                const float alpha = x[g] > m[g] ? __builtin_amdgcn_exp2f(m[g] - m_new) : 1.0f;
+                d[g] *= alpha;
+                zacc[g] *= alpha;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) acc[g][j] *= alpha;
+                m[g] = m_new;
+            }
+            pr[g] = valid ? __builtin_amdgcn_exp2f(x[g] - m[g]) : 0.0f;
+            d[g] += pr[g];
         }
-        const float pr = valid ? __builtin_amdgcn_exp2f(x - m) : 0.0f;
-        d += pr;
         if constexpr (F16) {
             // (a masked row's VALUES are whatever the page holds, maybe NaN: they must not meet p = 0 in an FMA)
 #pragma unroll
@@ -342,23 +400,33 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t pair = (!UNI || valid) ? vw[e] : 0u;
-                    kv_fma_half<0>(acc[w * 8 + 2 * e], pair, pr);
-                    kv_fma_half<1>(acc[w * 8 + 2 * e + 1], pair, pr);
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) {
+                        kv_fma_half<0>(acc[g][w * 8 + 2 * e], pair, pr[g]);
+                        kv_fma_half<1>(acc[g][w * 8 + 2 * e + 1], pair, pr[g]);
+                    }
                 }
             }
         } else {
-            const float pvs = valid ? pr * vs : 0.0f, pvz = valid ? pr * vz : 0.0f;   // (UNI: a masked row's parameters are whatever the page holds)
-            zacc += __builtin_fmaf(pvs, KV_OFF, pvz);
+            float pvs[QG];
+#pragma unroll
+            for (int g = 0; g < QG; ++g) {
+                pvs[g] = valid ? pr[g] * vs : 0.0f;   // (UNI: a masked row's parameters are whatever the page holds)
+                const float pvz = valid ? pr[g] * vz : 0.0f;
+                zacc[g] += __builtin_fmaf(pvs[g], KV_OFF, pvz);
+            }
             const uint32_t vw[4] = {r.vq[0].x, r.vq[0].y, r.vq[0].z, r.vq[0].w};
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 uint32_t u[4];
                 kv_unpack8(vw[w], ebits, u);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    kv_fma_half<0>(acc[w * 8 + 2 * e], u[e], pvs);
-                    kv_fma_half<1>(acc[w * 8 + 2 * e + 1], u[e], pvs);
-                }
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) {
+                        kv_fma_half<0>(acc[g][w * 8 + 2 * e], u[e], pvs[g]);
+                        kv_fma_half<1>(acc[g][w * 8 + 2 * e + 1], u[e], pvs[g]);
+                    }
             }
         }
     };
@@ -391,114 +459,119 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
             request(base + (int64_t)(j + NB - 1) * STRIDE, buf[(j + NB - 1) % NB]);
         if (base + (int64_t)j * STRIDE < seq_len) step(base + (int64_t)j * STRIDE, buf[j % NB]);
     }
-    const int st = wave * RPW + slot;
-    if (part == 0) {
-        s_m[st] = m;
-        s_d[st] = d;
-    }
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s_o[st][part * 32 + w * 8 + feat(e)] = acc[w * 8 + e] - zacc;
-    __syncthreads();
-    // state.cuh merge: every partial state rescaled to the common maximum. Rounds 1-5 let 128 threads walk all NS states (two serial loops
-    // of NS LDS round trips): 7 of the 10.8 us of a launch over 64 cached tokens (ablation builds, tools/gpu_call.sh r05c29). Now (a) the
-    // maximum by a wave reduction, every state's weight computed once by thread s; (b) ALL threads sum: thread (feature f, chunk c) the
-    // states of chunk c; (c) the NCH partial sums per feature.
-    constexpr int THREADS = NW * 64, NCH = THREADS / HD, CH = NS / NCH;
-    static_assert(NCH >= 1 && NS % NCH == 0 && NS <= THREADS, "merge geometry");
-    float* s_w = s_q + HD;                  // [NS] weights
-    float* s_red = s_w + NS;                // [NW] wave maxima
-    float* s_pd = s_red + NW;               // [NCH] partial denominators
-    float (*s_po)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(s_pd + NCH);   // [NCH][HD + 1] partial numerators
-    const float mloc = tid < NS ? s_m[tid] : -INFINITY;
-    const float wmax = fq_wave_max(mloc);
-    if (lane == 0) s_red[wave] = wmax;
-    __syncthreads();
-    float mm = s_red[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) mm = fmaxf(mm, s_red[w]);
-    if (tid < NS) {
-        const float w = mloc == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(mloc - mm);
-        s_w[tid] = w;
-        s_d[tid] *= w;
-    }
-    __syncthreads();
-    {
-        const int f = tid % HD, c = tid / HD;
-        float oo = 0.0f, dd = 0.0f;
-        if (!(KV_ABL & 2)) {
-#pragma unroll 8
-            for (int s = c * CH; s < (c + 1) * CH; ++s) {
-                oo = __builtin_fmaf(s_o[s][f], s_w[s], oo);
-                dd += s_d[s];
-            }
+    for (int g = 0; g < QG; ++g) {   // (QG > 1: the heads' states go through the same LDS one after the other)
+        const int st = wave * RPW + slot;
+        if (part == 0) {
+            s_m[st] = m[g];
+            s_d[st] = d[g];
         }
-        s_po[c][f] = oo;
-        if (f == 0) s_pd[c] = dd;
-    }
-    __syncthreads();
-    if (tid < HD) {
-        float dd = 0.0f, oo = 0.0f;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            dd += s_pd[c];
-            oo += s_po[c][tid];
-        }
-        const size_t oi = transpose_out ? ((size_t)b * HD + tid) * QH + head : ((size_t)b * QH + head) * HD + tid;
-        if (!SPLIT) {
-            o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;  // an empty sequence attends to nothing: zeros, not 0/0
-        } else {
-            // Agent-scope stores (sc1: written through to memory — the XCDs' L2s are not coherent with each other) instead of plain
-            // stores + __threadfence(): the fence is a write-back of the XCD's whole L2 per workgroup (buffer_wbl2), measured +20 us
-            // on a 26 us launch.
-            float* mine = kv_states(ws, (size_t)gridDim.x * gridDim.y) + (((size_t)b * QH + head) * gridDim.z + blockIdx.z) * (HD + 2);
-            if (tid == 0) {
-                __hip_atomic_store(mine, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(mine + 1, dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __hip_atomic_store(mine + 2 + tid, oo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if (SPLIT) {
-        // The hand-over below (relaxed agent-scope atomics, s_waitcnt vmcnt(0), barrier, relaxed fetch_add) has no release / acquire pair: it is
-        // correct because gfx9 counts stores in vmcnt and the sc1 (agent-scope) stores write through to memory the merging workgroup's sc1 loads
-        // read. A target where stores retire on another counter (gfx10+: vscnt) needs the fences back — this file is gfx942 / gfx950 only.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
-#error "fq_kv_decode_kernel<SPLIT>: the vmcnt-based hand-over is only valid on gfx942 / gfx950"
-#endif
-        const int S = (int)gridDim.z;
-        unsigned* cnt = reinterpret_cast<unsigned*>(ws) + (size_t)b * QH + head;
-        __shared__ unsigned s_last;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's state has reached memory ...
+    #pragma unroll
+        for (int w = 0; w < 4; ++w)
+    #pragma unroll
+            for (int e = 0; e < 8; ++e) s_o[st][part * 32 + w * 8 + feat(e)] = acc[g][w * 8 + e] - zacc[g];
         __syncthreads();
-        if (tid == 0) s_last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(S - 1);   // ... before it is counted
+        // state.cuh merge: every partial state rescaled to the common maximum. Rounds 1-5 let 128 threads walk all NS states (two serial loops
+        // of NS LDS round trips): 7 of the 10.8 us of a launch over 64 cached tokens (ablation builds, tools/gpu_call.sh r05c29). Now (a) the
+        // maximum by a wave reduction, every state's weight computed once by thread s; (b) ALL threads sum: thread (feature f, chunk c) the
+        // states of chunk c; (c) the NCH partial sums per feature.
+        constexpr int THREADS = NW * 64, NCH = THREADS / HD, CH = NS / NCH;
+        static_assert(NCH >= 1 && NS % NCH == 0 && NS <= THREADS, "merge geometry");
+        float* s_w = s_q + QG * HD;             // [NS] weights
+        float* s_red = s_w + NS;                // [NW] wave maxima
+        float* s_pd = s_red + NW;               // [NCH] partial denominators
+        float (*s_po)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(s_pd + NCH);   // [NCH][HD + 1] partial numerators
+        const float mloc = tid < NS ? s_m[tid] : -INFINITY;
+        const float wmax = fq_wave_max(mloc);
+        if (lane == 0) s_red[wave] = wmax;
         __syncthreads();
-        if (s_last) {
-            if (tid < HD) {
-                const float* all = kv_states(ws, (size_t)gridDim.x * gridDim.y) + ((size_t)b * QH + head) * S * (HD + 2);
-                auto ld = [](const float* ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };   // (sc1: not this XCD's L2)
-                float mz[16], dz[16], oz[16];      // every load first (S <= 16 round trips side by side, not one after the other)
-#pragma unroll
-                for (int z = 0; z < 16; ++z) {
-                    const float* st_z = all + (size_t)(z < S ? z : 0) * (HD + 2);
-                    mz[z] = ld(st_z), dz[z] = ld(st_z + 1), oz[z] = ld(st_z + 2 + tid);
-                }
-                float mm = -INFINITY;
-#pragma unroll
-                for (int z = 0; z < 16; ++z) mm = z < S ? fmaxf(mm, mz[z]) : mm;
-                float dd = 0.0f, oo = 0.0f;
-#pragma unroll
-                for (int z = 0; z < 16; ++z) {
-                    const float w = (z >= S || mz[z] == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(mz[z] - mm);
-                    dd += dz[z] * w;
-                    oo += oz[z] * w;
-                }
-                const size_t oi = transpose_out ? ((size_t)b * HD + tid) * QH + head : ((size_t)b * QH + head) * HD + tid;
-                o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;
-            }
-            if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch finds the counters as this one did
+        float mm = s_red[0];
+    #pragma unroll
+        for (int w = 1; w < NW; ++w) mm = fmaxf(mm, s_red[w]);
+        if (tid < NS) {
+            const float w = mloc == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(mloc - mm);
+            s_w[tid] = w;
+            s_d[tid] *= w;
         }
+        __syncthreads();
+        {
+            const int f = tid % HD, c = tid / HD;
+            float oo = 0.0f, dd = 0.0f;
+            if (!(KV_ABL & 2)) {
+    #pragma unroll 8
+                for (int s = c * CH; s < (c + 1) * CH; ++s) {
+                    oo = __builtin_fmaf(s_o[s][f], s_w[s], oo);
+                    dd += s_d[s];
+                }
+            }
+            s_po[c][f] = oo;
+            if (f == 0) s_pd[c] = dd;
+        }
+        __syncthreads();
+        if (tid < HD) {
+            float dd = 0.0f, oo = 0.0f;
+    #pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                dd += s_pd[c];
+                oo += s_po[c][tid];
+            }
+            const size_t oi = transpose_out ? ((size_t)b * HD + tid) * QH + head + g : ((size_t)b * QH + head + g) * HD + tid;
+            if (!SPLIT) {
+                o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;  // an empty sequence attends to nothing: zeros, not 0/0
+            } else {
+                // Agent-scope stores (sc1: written through to memory — the XCDs' L2s are not coherent with each other) instead of plain
+                // stores + __threadfence(): the fence is a write-back of the XCD's whole L2 per workgroup (buffer_wbl2), measured +20 us
+                // on a 26 us launch.
+                float* mine = kv_states(ws, (size_t)gridDim.x * QH) + (((size_t)b * QH + head + g) * gridDim.z + blockIdx.z) * (HD + 2);
+                if (tid == 0) {
+                    __hip_atomic_store(mine, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(mine + 1, dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __hip_atomic_store(mine + 2 + tid, oo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (SPLIT) {
+            // The hand-over below (relaxed agent-scope atomics, s_waitcnt vmcnt(0), barrier, relaxed fetch_add) has no release / acquire pair: it is
+            // correct because gfx9 counts stores in vmcnt and the sc1 (agent-scope) stores write through to memory the merging workgroup's sc1 loads
+            // read. A target where stores retire on another counter (gfx10+: vscnt) needs the fences back — this file is gfx942 / gfx950 only.
+    #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+    #error "fq_kv_decode_kernel<SPLIT>: the vmcnt-based hand-over is only valid on gfx942 / gfx950"
+    #endif
+            const int S = (int)gridDim.z;
+            unsigned* cnt = reinterpret_cast<unsigned*>(ws) + (size_t)b * QH + head + g;
+            __shared__ unsigned s_last;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's state has reached memory ...
+            __syncthreads();
+            if (tid == 0) s_last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(S - 1);   // ... before it is counted
+            __syncthreads();
+            if (s_last) {
+                if (tid < HD) {
+                    const float* all = kv_states(ws, (size_t)gridDim.x * QH) + ((size_t)b * QH + head + g) * S * (HD + 2);
+                    auto ld = [](const float* ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };   // (sc1: not this XCD's L2)
+                    float mz[16], dz[16], oz[16];      // every load first (S <= 16 round trips side by side, not one after the other)
+    #pragma unroll
+                    for (int z = 0; z < 16; ++z) {
+                        const float* st_z = all + (size_t)(z < S ? z : 0) * (HD + 2);
+                        mz[z] = ld(st_z), dz[z] = ld(st_z + 1), oz[z] = ld(st_z + 2 + tid);
+                    }
+                    float mm = -INFINITY;
+    #pragma unroll
+                    for (int z = 0; z < 16; ++z) mm = z < S ? fmaxf(mm, mz[z]) : mm;
+                    float dd = 0.0f, oo = 0.0f;
+    #pragma unroll
+                    for (int z = 0; z < 16; ++z) {
+                        const float w = (z >= S || mz[z] == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(mz[z] - mm);
+                        dd += dz[z] * w;
+                        oo += oz[z] * w;
+                    }
+                    const size_t oi = transpose_out ? ((size_t)b * HD + tid) * QH + head + g : ((size_t)b * QH + head + g) * HD + tid;
+                    o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;
+                }
+                if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch finds the counters as this one did
+            }
+        }
+
+        if (QG > 1) __syncthreads();   // the next head's states overwrite s_m / s_d / s_o / s_w
     }
 }
 
@@ -554,6 +627,22 @@ int fq_kv_decode_splits(int batch, int num_heads, int seq_hint) {
     }
     return s < 2 ? 1 : s;
 }
+// The shared-cache launch (fq_kv_batch_decode_gqa): workgroups are (request, KV head) pairs where the query heads of a KV head share one
+// (head_dim 128, groups of 2 / 4) — that count decides the split; the workspace holds a counter and up to 16 states per QUERY head either way.
+// Merged where it pays (measured, profiles/r06_gqa_cache.txt: a Llama-3-8B step 178 -> 161 us at 64 requests, 293 -> 261 at 128, but 65 -> 79 at
+// one request and 102 -> 111 at sixteen: a quarter of the workgroups, each with four times the p . v arithmetic): from one merged workgroup per CU on.
+#ifndef KV_MERGE_MIN_PAIRS
+#define KV_MERGE_MIN_PAIRS 256
+#endif
+int fq_kv_decode_wg_heads(int batch, int num_q_heads, int q_group, int head_dim) {
+    const bool merge = KV_MERGE_HEADS && head_dim == 128 && (q_group == 2 || q_group == 4) && (int64_t)batch * (num_q_heads / q_group) >= KV_MERGE_MIN_PAIRS;
+    return merge ? num_q_heads / q_group : num_q_heads;
+}
+int64_t fq_kv_decode_ws_bytes_gqa(int batch, int num_q_heads, int q_group, int head_dim) {
+    const int64_t wg_pairs = (int64_t)batch * fq_kv_decode_wg_heads(batch, num_q_heads, q_group, head_dim), pairs = (int64_t)batch * num_q_heads;
+    if (wg_pairs <= 0 || wg_pairs > 128) return 0;
+    return ((pairs + 3) & ~(int64_t)3) * (int64_t)sizeof(unsigned) + pairs * 16 * (head_dim + 2) * (int64_t)sizeof(float);
+}
 int64_t fq_kv_decode_ws_bytes(int batch, int num_heads, int head_dim) {   // for ANY split count this library chooses (<= 16)
     const int64_t pairs = (int64_t)batch * num_heads;
     if (pairs <= 0 || pairs > 128) return 0;
@@ -563,16 +652,29 @@ int64_t fq_kv_decode_ws_bytes(int batch, int num_heads, int head_dim) {   // for
 int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, const f16* qt,
                         int transpose_out, hipStream_t stream, bool f16_cache, float* ws, int splits, int qgroup) {
-    // num_heads: QUERY heads (q, o, the grid); the cache holds num_heads / qgroup heads (qgroup = 1: the reference's layout)
+    // num_heads: QUERY heads (q, o); the cache holds num_heads / qgroup heads (qgroup = 1: the reference's layout)
     if (splits > 16 || qgroup < 1 || num_heads % qgroup) return -1000;   // (the merge of the split launch reads at most 16 states: fq_kv_decode_splits never returns more)
     const PagedKv p = make_kv(kv_data, kv_param, indptr, indices, last, num_layers, layer_idx, num_heads / qgroup, page_size, head_dim, batch);
     const bool split = ws != nullptr && splits > 1;
-    const dim3 grid((unsigned)batch, (unsigned)num_heads, split ? (unsigned)splits : 1u);
-    const bool wide = (int64_t)batch * num_heads * (split ? splits : 1) < 512;  // fewer than two workgroups per CU: 8 waves each instead of 4 (measured: 158 -> 113 us at 8 x 8192; no gain from 512 up)
+    // (round 6) a shared cache with 2 or 4 query heads per KV head at head_dim 128: ONE workgroup per (request, KV head) serves its query heads
+    // from one pass over the rows (fq_kv_decode_kernel<.., QG>); every other geometry: a workgroup per query head
+    const int wg_heads = fq_kv_decode_wg_heads(batch, num_heads, qgroup, head_dim);
+    const int qg = num_heads / wg_heads;
+    const dim3 grid((unsigned)batch, (unsigned)wg_heads, split ? (unsigned)splits : 1u);
+    const bool wide = (int64_t)batch * wg_heads * (split ? splits : 1) < 512;  // fewer than two workgroups per CU: 8 waves each instead of 4 (measured: 158 -> 113 us at 8 x 8192; no gain from 512 up)
+#define FQ_DEC4(HD_, NW_, UNI_, F16_, SP_, QG_)                                                                        \
+    {                                                                                                                 \
+        constexpr size_t ns_ = (size_t)(NW_ * (64 / (HD_ / 32))), nch_ = (size_t)NW_ * 64 / HD_;                      \
+        constexpr size_t lds = sizeof(float) * (ns_ * (HD_ + 1 + 2) + QG_ * HD_ + ns_ + NW_ + nch_ + nch_ * (HD_ + 1)); \
+        FQ_RAISE_LDS_CAP((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_, SP_, QG_>), lds);                                 \
+        hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_, SP_, QG_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out, ws, qgroup); \
+    }
 #define FQ_DEC3(HD_, NW_, UNI_, F16_, SP_)                                                                             \
     {                                                                                                                 \
-        FQ_RAISE_LDS_CAP((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_, SP_>), lds);                                      \
-        hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_, SP_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out, ws, qgroup); \
+        if constexpr (HD_ == 128) {                                                                                   \
+            if (qg == 4) FQ_DEC4(HD_, NW_, UNI_, F16_, SP_, 4) else if (qg == 2) FQ_DEC4(HD_, NW_, UNI_, F16_, SP_, 2) \
+            else FQ_DEC4(HD_, NW_, UNI_, F16_, SP_, 1)                                                                \
+        } else FQ_DEC4(HD_, NW_, UNI_, F16_, SP_, 1)                                                                  \
     }
 #define FQ_DEC2(HD_, NW_, UNI_, F16_)                                                                                  \
     {                                                                                                                 \
@@ -580,8 +682,6 @@ int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, con
     }
 #define FQ_DEC(HD_, NW_)                                                                                              \
     {                                                                                                                 \
-        constexpr size_t ns_ = (size_t)(NW_ * (64 / (HD_ / 32))), nch_ = (size_t)NW_ * 64 / HD_;                      \
-        constexpr size_t lds = sizeof(float) * (ns_ * (HD_ + 1 + 2) + HD_ + ns_ + NW_ + nch_ + nch_ * (HD_ + 1));     \
         const bool uni = page_size % (64 / (HD_ / 32)) == 0;   /* a wave's rows never straddle a page */              \
         if (f16_cache) {                                                                                              \
             if (uni) FQ_DEC2(HD_, NW_, true, true) else FQ_DEC2(HD_, NW_, false, true)                                \
@@ -599,5 +699,6 @@ int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, con
 #undef FQ_DEC
 #undef FQ_DEC2
 #undef FQ_DEC3
+#undef FQ_DEC4
     return (int)hipGetLastError();
 }

@@ -1770,7 +1770,12 @@ def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tens
     if batch == 0:
         return o
     with _on(q.device):
-        nbytes = int(lib.fq_kv_decode_workspace_bytes(batch, heads, hd)) if split else 0
+        if not split:
+            nbytes = 0
+        elif q_group > 1:
+            nbytes = int(lib.fq_kv_decode_workspace_bytes_gqa(batch, kv_heads, q_group, hd))
+        else:
+            nbytes = int(lib.fq_kv_decode_workspace_bytes(batch, heads, hd))
         stream = _stream(q)
         ws = _kv_split_workspace((q.device.index, stream.value, batch * heads, hd), nbytes, q.device) if nbytes > 0 else None
         if q_group > 1:

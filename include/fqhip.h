@@ -624,8 +624,10 @@ int fq_kv_batch_decode_i4_ex(void* o, const void* q, const void* q_trans, int tr
  * group_size = 1); q and o hold num_kv_heads * q_group query heads, query head h reads cache head h / q_group. The same rows, the same
  * arithmetic: o is bit-identical to fq_kv_batch_decode_split on the replicated cache — from 1 / q_group of the cache memory, and with the
  * q_group workgroups of a KV head re-reading rows the memory-side cache still holds (profiles/r06_gqa_cache.txt). fp16_cache, q_trans,
- * transpose_out, seq_hint, workspace (fq_kv_decode_workspace_bytes(batch, num_kv_heads * q_group, head_dim); may be NULL: no split): as
- * fq_kv_batch_decode_split. */
+ * transpose_out, seq_hint: as fq_kv_batch_decode_split; workspace: fq_kv_decode_workspace_bytes_gqa(batch, num_kv_heads, q_group, head_dim)
+ * bytes (0: this geometry never splits; NULL: no split). At head_dim 128 with q_group 2 or 4 ONE workgroup per (request, KV head) serves its
+ * query heads from one pass over the rows (loaded and unpacked once; the q . k MFMA carries all of them in rows that were idle). */
+int64_t fq_kv_decode_workspace_bytes_gqa(int batch_size, int num_kv_heads, int q_group, int head_dim);
 int fq_kv_batch_decode_gqa(int fp16_cache, void* o, const void* q, const void* q_trans, int transpose_out, const void* kv_data,
                            const void* kv_param, const void* kv_indptr, const void* kv_indices, const void* last_page_offset,
                            int num_layers, int layer_idx, int num_kv_heads, int q_group, int page_size, int head_dim, int batch_size, int seq_hint,

@@ -513,11 +513,14 @@ def test_split_decode_is_bit_stable_over_many_launches(ops):
 
 
 @pytest.mark.parametrize("disable_quant", [False, True])
-@pytest.mark.parametrize("bsz,prompt,kv_heads,group,hd,page", [(3, 37, 2, 4, 128, 16), (1, 300, 8, 4, 128, 64), (5, 20, 4, 2, 64, 16), (40, 70, 2, 4, 128, 32)])
+@pytest.mark.parametrize("bsz,prompt,kv_heads,group,hd,page", [(3, 37, 2, 4, 128, 16), (1, 300, 8, 4, 128, 64), (5, 20, 4, 2, 64, 16), (40, 70, 2, 4, 128, 32),
+                                                               # >= 256 (request, KV head) pairs at head_dim 128: ONE workgroup serves the 4 (2) query heads of a KV head
+                                                               (64, 33, 4, 4, 128, 16), (40, 50, 8, 2, 128, 32), (33, 70, 8, 4, 128, 64)])
 def test_shared_kv_heads_cache_equals_the_replicated_cache(ops, disable_quant, bsz, prompt, kv_heads, group, hd, page):
     """share_kv_heads=True (round 6, extension): the pages hold the KV heads once, query head h reads cache head h // group
     (fq_kv_batch_decode_gqa). Same rows, same arithmetic: the attention output is BIT-identical to the reference-shaped cache's (one copy
-    per query head, kv_cache.py:286-296) — unsplit and split launches, the query transform, the transposed output, both cache dtypes."""
+    per query head, kv_cache.py:286-296) — the query transform, the transposed output, both cache dtypes, a workgroup per query head and (from
+    256 pairs on) one per KV head with its query heads riding in the q . k MFMA's idle rows."""
     import flatquant_amd.deploy.transformers as T
     g = torch.Generator(device="cuda").manual_seed(bsz * 100 + prompt)
     heads = kv_heads * group
@@ -538,8 +541,15 @@ def test_shared_kv_heads_cache_equals_the_replicated_cache(ops, disable_quant, b
             v = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
             a_rep, a_sh = rep.update(k, v, layer, dict(kw)), sh.update(k, v, layer, dict(kw))
             q = torch.randn(bsz, 1, heads, hd, generator=g, device="cuda").half()
+            merged = hd == 128 and group in (2, 4) and bsz * kv_heads >= 256   # one workgroup per KV head: other lanes sum other rows
             for transposed in (False, True):
-                assert torch.equal(a_rep(q, transposed=transposed), a_sh(q, transposed=transposed)), (step, layer, transposed)
+                o_rep, o_sh = a_rep(q, transposed=transposed), a_sh(q, transposed=transposed)
+                if not merged:
+                    assert torch.equal(o_rep, o_sh), (step, layer, transposed)
+                else:   # as the split launch against the unsplit one: the order of fp32 additions differs, nothing else — the fp16 outputs
+                        # differ by at most two units in the last place of the largest (measured: one, 5.7e-4 .. 9.3e-4 of the maximum)
+                    err = (o_rep.float() - o_sh.float()).abs().amax() / o_rep.float().abs().amax()
+                    assert torch.isfinite(o_sh).all() and err.item() <= 2.5e-3, (step, layer, transposed, err.item())
     # the rows themselves: cache head j of the shared pages == every one of its `group` copies in the replicated pages
     assert torch.equal(rep.pages[:sh.pages.shape[0]].reshape(-1, 2, 2, kv_heads, group, *rep.pages.shape[4:])[:, :, :, :, 0], sh.pages.reshape(-1, 2, 2, kv_heads, *sh.pages.shape[4:]))
     # no split workspace (split=False) and the plain entry without a query transform
@@ -547,4 +557,47 @@ def test_shared_kv_heads_cache_equals_the_replicated_cache(ops, disable_quant, b
     q2 = torch.randn(bsz, heads, hd, generator=g, device="cuda").half()
     ar = (specs_r["kv_data"], specs_r["kv_param"], specs_r["kv_indptr"], specs_r["kv_indices"], specs_r["last_page_offset"])
     as_ = (specs_s["kv_data"], specs_s["kv_param"], specs_s["kv_indptr"], specs_s["kv_indices"], specs_s["last_page_offset"])
-    assert torch.equal(ops.kv_batch_decode(q2, *ar, 1, split=False), ops.kv_batch_decode(q2, *as_, 1, split=False))
+    o_r, o_s = ops.kv_batch_decode(q2, *ar, 1, split=False), ops.kv_batch_decode(q2, *as_, 1, split=False)
+    if hd == 128 and group in (2, 4) and bsz * kv_heads >= 256:
+        assert ((o_r.float() - o_s.float()).abs().amax() / o_r.float().abs().amax()).item() <= 2.5e-3
+    else:
+        assert torch.equal(o_r, o_s)
+
+
+def test_merged_query_heads_match_dense_attention(ops):
+    """the workgroup-per-KV-head launch (64 requests x 4 KV heads x 4 query heads each, shared cache) against dense fp32 attention on the
+    de-quantised rows — independent of the per-query-head kernel"""
+    import flatquant_amd.deploy.transformers as T
+    g = torch.Generator(device="cuda").manual_seed(9)
+    bsz, prompt, kv_heads, group, hd = 64, 45, 4, 4, 128
+    cache = T.MultiLayerPagedKVCache4Bit(bsz, 16, 64, "cuda", 1, kv_heads * group, hd, trans="matmul", group_size=group, share_kv_heads=True)
+    tk = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half()
+    tk_inv_t = torch.linalg.inv(tk.float()).T.contiguous().half()
+    kw = {"trans_matrix_k": tk, "trans_matrix_k_inv_t": tk_inv_t}
+
+    def deq32(q8, par):
+        n = torch.stack((q8 & 15, q8 >> 4), dim=-1).reshape(*q8.shape[:-1], -1).float()
+        par = par.reshape(*q8.shape[:-1], 2).float()
+        return n * par[..., 0:1] - par[..., 1:2]
+
+    ks, vs = [], []
+    k = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+    v = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+    cache.update(k, v, 0, dict(kw))
+    kq, kp, vq, vp = T.transform_quantize_kv(k, v, tk)
+    ks.append(deq32(kq, kp)), vs.append(deq32(vq, vp))
+    for step in range(2):
+        k = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+        v = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+        attend = cache.update(k, v, 0, dict(kw))
+        kq, kp, vq, vp = T.transform_quantize_kv(k, v, tk)
+        ks.append(deq32(kq, kp)), vs.append(deq32(vq, vp))
+        q = torch.randn(bsz, 1, kv_heads * group, hd, generator=g, device="cuda").half()
+        o = attend(q)
+        K = torch.cat(ks, dim=1).float().repeat_interleave(group, dim=2)
+        V = torch.cat(vs, dim=1).float().repeat_interleave(group, dim=2)
+        qt = torch.matmul(q.reshape(bsz, -1, hd).half(), tk_inv_t).float()
+        x = torch.einsum("bhd,bshd->bhs", qt, K) / hd ** 0.5
+        ref = torch.einsum("bhs,bshd->bhd", torch.softmax(x, dim=-1), V)
+        err = (o.reshape(bsz, -1, hd).float() - ref).abs().amax(-1) / ref.abs().amax(-1)
+        assert err.max().item() <= 3e-3
