@@ -73,11 +73,11 @@ def main_lone():
     for name, N, K in (("o_proj", 4096, 4096), ("down", 4096, 14336)):
         nb = max(NB, int(400e6 // (N * K // 2)))
         imgs = [ops.int4_to_frag(torch.randint(0, 256, (N, K // 2), generator=gen, device="cuda", dtype=torch.uint8)) for _ in range(nb)]
-        ws = torch.rand(N, generator=gen, device="cuda").half() * 0.01
+        wss = [torch.rand(N, generator=gen, device="cuda").half() * 0.01 for _ in range(nb)]   # (a layer's own scales: cold, like its weights)
         for M in (1, 8, 16):
             x = torch.randint(0, 256, (M, K // 2), generator=gen, device="cuda", dtype=torch.uint8)
             sx = torch.rand(M, generator=gen, device="cuda").half() * 0.01
-            t = graph_time(lambda i: ops.int4_skinny_linear(x, sx, imgs[i % nb], ws, None, N), warm=nb)
+            t = graph_time(lambda i: ops.int4_skinny_linear(x, sx, imgs[i % nb], wss[i % nb], None, N), warm=nb)
             print(f"[{TAG}] {name:8s} M={M:2d}: {t:6.2f} us ({N * K / 2 / 1e6 / t:5.2f} TB/s of weights)", flush=True)
 
 
