@@ -60,7 +60,10 @@ int fq_launch_kv_append(void* kv_data, void* kv_param, const int* indptr, const 
                         hipStream_t stream, bool f16_cache = false);
 int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, const f16* qt,
-                        int transpose_out, hipStream_t stream, bool f16_cache = false, float* ws = nullptr, int splits = 1, int qgroup = 1);
+                        int transpose_out, hipStream_t stream, bool f16_cache = false, float* ws = nullptr, int splits = 1, int qgroup = 1,
+                        const f16* k_new = nullptr, const f16* v_new = nullptr, const void* t_image = nullptr, int src_heads = 1);
+int64_t fq_kv_timage_bytes(int hd);
+int fq_launch_kv_timage(const f16* T, int hd, void* img, hipStream_t stream);
 int fq_kv_decode_splits(int batch, int num_heads, int seq_hint);
 int fq_kv_decode_wg_heads(int batch, int num_q_heads, int q_group, int head_dim);
 int64_t fq_kv_decode_ws_bytes_gqa(int batch, int num_q_heads, int q_group, int head_dim);
@@ -1223,6 +1226,41 @@ int fq_kv_batch_decode_gqa(int fp16_cache, void* o, const void* q, const void* q
     rc = fq_launch_kv_decode((f16*)o, (const f16*)q, (void*)kv_data, (void*)kv_param, (const int*)kv_indptr, (const int*)kv_indices,
                              (const int*)last_page_offset, num_layers, layer_idx, q_heads, page_size, head_dim, batch_size,
                              (const f16*)q_trans, transpose_out != 0, (hipStream_t)stream, fp16_cache != 0, (float*)workspace, splits, q_group);
+    return check_launch(rc, what);
+}
+
+int64_t fq_kv_transform_image_bytes(int head_dim) { return fq_kv_timage_bytes(head_dim); }
+
+int fq_kv_transform_image_f16(const void* trans, int head_dim, void* image, void* stream) {
+    if (head_dim != 64 && head_dim != 128) return fail(FQ_EUNSUPPORTED, "fq_kv_transform_image_f16: head_dim=%d must be 64 or 128", head_dim);
+    if (!trans || !image) return fail(FQ_EINVAL, "fq_kv_transform_image_f16: NULL pointer");
+    FQ_NEED_ALIGN16("fq_kv_transform_image_f16", trans, image);
+    return check_launch(fq_launch_kv_timage((const f16*)trans, head_dim, image, (hipStream_t)stream), "fq_kv_transform_image_f16");
+}
+
+int fq_kv_decode_append_i4(void* o, const void* q, const void* q_trans, int transpose_out, const void* k_new, const void* v_new,
+                           const void* k_trans_image, int src_heads, const void* kv_data, const void* kv_param, const void* kv_indptr,
+                           const void* kv_indices, const void* last_page_offset, int num_layers, int layer_idx, int num_kv_heads, int q_group,
+                           int page_size, int head_dim, int batch_size, int seq_hint, void* workspace, int64_t workspace_bytes, void* stream) {
+    const char* what = "fq_kv_decode_append_i4";
+    int rc = kv_geometry_ok(what, num_layers, layer_idx, num_kv_heads, page_size, head_dim, batch_size);
+    if (rc != FQ_OK) return rc;
+    if (q_group < 1 || q_group > 64) return fail(FQ_EINVAL, "%s: q_group=%d out of [1, 64]", what, q_group);
+    if (head_dim != 128 || page_size % 16) return fail(FQ_EUNSUPPORTED, "%s: head_dim=%d, page_size=%d: needs head_dim 128 and page_size %% 16 == 0 (use fq_kv_quant_append_i4 + the decode launch)", what, head_dim, page_size);
+    if (src_heads < 1 || num_kv_heads % src_heads || num_kv_heads / src_heads > 4)
+        return fail(FQ_EINVAL, "%s: num_kv_heads=%d must be src_heads=%d x a group of at most 4", what, num_kv_heads, src_heads);
+    if (!o || !q || !k_new || !v_new || !kv_data || !kv_param || !kv_indptr || !kv_indices || !last_page_offset)
+        return fail(FQ_EINVAL, "%s: NULL pointer", what);
+    FQ_NEED_ALIGN16(what, kv_data, q_trans, workspace, k_new, v_new, k_trans_image);
+    const int q_heads = num_kv_heads * q_group;
+    const int64_t need = fq_kv_decode_ws_bytes_gqa(batch_size, q_heads, q_group, head_dim);
+    const int splits = (workspace && need > 0) ? fq_kv_decode_splits(batch_size, fq_kv_decode_wg_heads(batch_size, q_heads, q_group, head_dim), seq_hint) : 1;
+    if (splits > 1 && workspace_bytes < need)
+        return fail(FQ_EINVAL, "%s: workspace of %lld bytes, fq_kv_decode_workspace_bytes_gqa says %lld", what, (long long)workspace_bytes, (long long)need);
+    rc = fq_launch_kv_decode((f16*)o, (const f16*)q, (void*)kv_data, (void*)kv_param, (const int*)kv_indptr, (const int*)kv_indices,
+                             (const int*)last_page_offset, num_layers, layer_idx, q_heads, page_size, head_dim, batch_size,
+                             (const f16*)q_trans, transpose_out != 0, (hipStream_t)stream, false, (float*)workspace, splits, q_group,
+                             (const f16*)k_new, (const f16*)v_new, k_trans_image, src_heads);
     return check_launch(rc, what);
 }
 

@@ -30,9 +30,24 @@
 //     64 requests x 2048 tokens x 32 heads: 180.7 -> 102.7 us (0.39 -> 0.69 of 8 TB/s; FETCH_SIZE 571 MB for 570 MB of rows, 136 VALU
 //     instructions per 16-row step where the scalar kernel had ~300), 8 x 8192: 108 -> 46 us (0.77), 128 x 4096: 0.74, one request x 2048:
 //     20.8 -> 8.6 us (profiles/r05_kvdecode_timing.txt, r05_kvdecode_pmc.txt).
-#include "fq_common.hpp"
+#include "fq_kv_common.hpp"
 
 namespace {
+
+// (round 6, third session) THE STEP'S OWN ROW INSIDE THE DECODE LAUNCH. A decode step appends one token per request and then attends over the
+// cache including it (kv_cache.py:283-359): until now two launches — fq_kv_quant_append_i4 (K transform + K / V INT4 quantisation + scatter,
+// 5 - 11 us of dependent round trips for 64 bytes per head) and the attention, which cannot start before the first has finished. With `k` set the
+// decode launch does the first one itself: the workgroup whose rows include the request's LAST row (length - 1: the new token; the host has
+// already advanced the lengths, as for fq_kv_quant_append_i4) transforms and quantises the new K / V row of its cache head in its prologue — the
+// arithmetic of fq_kv_quant_kernel to the bit: the same MFMA on the same fragment image of the transform, the same extrema, (scale, zero) and
+// kv_q8 — keeps the 64 + 64 bytes and the two parameters in LDS, hands them to the lanes of that row in the tail steps of the row loop INSTEAD of
+// what the cache holds there, and (one workgroup per cache head) writes them to the cache for the steps to come. No workgroup waits for another.
+struct KvNew {
+    const f16* k;        // [batch, src_heads, head_dim] fp16, the new token's keys (nullptr: nothing to append — the plain decode launch)
+    const f16* v;        // ... values
+    const uint4* timg;   // the K transform as the fragment image fq_kv_transform_image_f16 wrote (32 KB at head_dim 128), or nullptr: no transform
+    int src_heads;       // heads of k / v: cache head c is a copy of source head c / (cache heads / src_heads) (kv_cache.py:286-296)
+};
 
 struct PagedKv {
     uint8_t* data;
@@ -184,13 +199,14 @@ __device__ __forceinline__ float* kv_states(float* ws, size_t pairs) { return ws
 // nibbles unpacked once, the q . k MFMA that had one useful A row of sixteen carries all QG queries (A row m = query m % QG), and only the
 // per-head softmax state and the p . v accumulation are QG-fold. head_dim 128 only (the 16 x 16 x 32 shape's D rows). QG = 1: every
 // workgroup one query head (qgroup: how many of them share a cache head; 1 = the reference's replicated cache).
-template <int HD, int NW, bool UNI, bool F16, bool SPLIT, int QG = 1>
+template <int HD, int NW, bool UNI, bool F16, bool SPLIT, int QG = 1, bool APPEND = false>
 __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restrict__ o, const f16* __restrict__ q, PagedKv p,
-                                                               const f16* __restrict__ qt, int transpose_out, float* ws, int qgroup) {
+                                                               const f16* __restrict__ qt, int transpose_out, float* ws, int qgroup, KvNew nw) {
     constexpr int QL = HD / 32;        // lanes per cached row: 4 for head_dim 128, 2 for 64
     constexpr int RPW = 64 / QL;       // rows per wave and step: the N of the MFMA (16 / 32)
     constexpr int NS = NW * RPW;       // partial softmax states per workgroup
     static_assert(QL == 4 || QL == 2, "head_dim 128 (16x16x32) or 64 (32x32x16)");
+    static_assert(!APPEND || (HD == 128 && !F16 && UNI), "the step's own row inside the launch: INT4 cache, head_dim 128, rows that never straddle a page");
     extern __shared__ __attribute__((aligned(16))) unsigned char kv_smem[];
     float (*s_o)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(kv_smem);
     float* s_m = reinterpret_cast<float*>(kv_smem + sizeof(float) * NS * (HD + 1));
@@ -260,6 +276,107 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
     }
     uint32_t ebits = 0x4C004C00u;   // (16.0, 16.0): kept in a VGPR
     asm volatile("" : "+v"(ebits));
+
+    // APPEND: the new row (see KvNew). s_new (behind every other LDS array): [0..15] the K row's dwords, [16..31] the V row's, [32] / [33] the
+    // (scale, zero) pairs, [36..] the per-wave extrema of the prologue.
+    constexpr size_t NEW_OFF = (sizeof(float) * ((size_t)NS * (HD + 1 + 2) + QG * HD + NS + NW + (size_t)(NW * 64 / HD) * (HD + 2)) + 15) & ~(size_t)15;
+    uint32_t* s_new = reinterpret_cast<uint32_t*>(kv_smem + NEW_OFF);
+    const int64_t last_row = seq_len - 1;
+    bool own = false;    // (workgroup-uniform) this workgroup's rows include last_row
+    if constexpr (APPEND) {
+        if (nw.k != nullptr && seq_len > 0) {
+            const int wsteps = SPLIT ? (int)gridDim.z * NW : NW;                    // waves that share the pair's rows, 16 rows a step each
+            own = !SPLIT || (int)(((last_row / RPW) % wsteps) / NW) == (int)blockIdx.z;
+        }
+        if (own) {
+            using namespace fqkv;
+            unsigned short* s_ext = reinterpret_cast<unsigned short*>(s_new + 36);   // [k, v][wave 0..3][max, min]
+            const int cgroup = p.num_heads / nw.src_heads, shead = chead / cgroup;
+            const f16* krow = nw.k + ((size_t)b * nw.src_heads + shead) * HD;
+            const f16* vrow = nw.v + ((size_t)b * nw.src_heads + shead) * HD;
+            const int h = lane >> 5;
+            f16 kv16[2][16];   // [k, v][r]: feature 32 wave + 16 h + r of the (transformed) row — the columns lane (h, .) of fq_kv_quant_kernel's wave ends with
+            if (wave < 4) {
+                if (nw.timg != nullptr) {
+                    f16x8 xf[8], tf[8];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        tf[s] = __builtin_bit_cast(f16x8, nw.timg[(s * 4 + wave) * 64 + lane]);
+                        xf[s] = __builtin_bit_cast(f16x8, reinterpret_cast<const uint4*>(krow)[2 * s + h]);
+                    }
+                    f32x16 a = {0};
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(tf[s], xf[s], a, 0, 0, 0);   // (every B column is the one row)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) kv16[0][r] = (f16)a[r];
+                } else {
+                    const f16x8 k0 = __builtin_bit_cast(f16x8, reinterpret_cast<const uint4*>(krow + wave * 32 + 16 * h)[0]);
+                    const f16x8 k1 = __builtin_bit_cast(f16x8, reinterpret_cast<const uint4*>(krow + wave * 32 + 16 * h)[1]);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) kv16[0][r] = k0[r], kv16[0][8 + r] = k1[r];
+                }
+                const f16x8 v0 = __builtin_bit_cast(f16x8, reinterpret_cast<const uint4*>(vrow + wave * 32 + 16 * h)[0]);
+                const f16x8 v1 = __builtin_bit_cast(f16x8, reinterpret_cast<const uint4*>(vrow + wave * 32 + 16 * h)[1]);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) kv16[1][r] = v0[r], kv16[1][8 + r] = v1[r];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f16x2 pmx = {kv16[t][0], kv16[t][1]}, pmn = pmx;
+#pragma unroll
+                    for (int r = 2; r < 16; r += 2) {
+                        const f16x2 pr = {kv16[t][r], kv16[t][r + 1]};
+                        pmx = fq_pk_max(pmx, pr);
+                        pmn = fq_pk_min(pmn, pr);
+                    }
+                    f16 mx = pmx[0] > pmx[1] ? pmx[0] : pmx[1], mn = pmn[0] < pmn[1] ? pmn[0] : pmn[1];
+                    const f16 omx = xchg32(mx, lane), omn = xchg32(mn, lane);
+                    mx = omx > mx ? omx : mx;
+                    mn = omn < mn ? omn : mn;
+                    if (lane == 0) {
+                        s_ext[(t * 4 + wave) * 2 + 0] = __builtin_bit_cast(unsigned short, mx);
+                        s_ext[(t * 4 + wave) * 2 + 1] = __builtin_bit_cast(unsigned short, mn);
+                    }
+                }
+            }
+            __syncthreads();
+            if (wave < 4) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f16 mx = __builtin_bit_cast(f16, s_ext[(t * 4) * 2]), mn = __builtin_bit_cast(f16, s_ext[(t * 4) * 2 + 1]);
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) {
+                        const f16 a = __builtin_bit_cast(f16, s_ext[(t * 4 + w) * 2]), c = __builtin_bit_cast(f16, s_ext[(t * 4 + w) * 2 + 1]);
+                        mx = a > mx ? a : mx;
+                        mn = c < mn ? c : mn;
+                    }
+                    const KvParams pp = kv_params<false>(mx, mn, (f16)1.0f, (f16)1.0f);   // (kv_cache.py:283-284: the cache's own calls leave lac off)
+                    const float sc = (float)pp.scale, rc = fq_fast_inv(sc);
+                    const uint32_t zero2 = __builtin_bit_cast(uint32_t, f16x2{pp.zero, pp.zero});
+                    uint32_t pr[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pr[j] = __builtin_bit_cast(uint32_t, f16x2{kv16[t][2 * j], kv16[t][2 * j + 1]});
+                    const unsigned w0 = kv_q8<false>(pr[0], pr[1], pr[2], pr[3], rc, sc, zero2);
+                    const unsigned w1 = kv_q8<false>(pr[4], pr[5], pr[6], pr[7], rc, sc, zero2);
+                    if ((lane & 31) == 0) {      // features 32 wave + 16 h .. + 15 = dwords 4 wave + 2 h, + 1
+                        s_new[t * 16 + wave * 4 + 2 * h] = w0;
+                        s_new[t * 16 + wave * 4 + 2 * h + 1] = w1;
+                        if (wave == 0 && h == 0)
+                            s_new[32 + t] = (uint32_t)__builtin_bit_cast(unsigned short, pp.scale) | ((uint32_t)__builtin_bit_cast(unsigned short, pp.zero) << 16);
+                    }
+                }
+            }
+            __syncthreads();
+            // the cache gets the row: the workgroup of the cache head's FIRST query head (a replicated cache: every head its copy)
+            if ((QG > 1 || head % qgroup == 0) && tid < 10) {
+                const size_t page = (size_t)p.indices[pg0 + (int)(last_row / p.page_size)];
+                const size_t entry = (size_t)(last_row % p.page_size);
+                const size_t ke = k_entry(p, page, (size_t)chead, entry), ve = v_entry(p, page, (size_t)chead, entry);
+                if (tid < 4) reinterpret_cast<uint4*>(p.data + ke * (HD / 2))[tid] = reinterpret_cast<const uint4*>(s_new)[tid];
+                else if (tid < 8) reinterpret_cast<uint4*>(p.data + ve * (HD / 2))[tid - 4] = reinterpret_cast<const uint4*>(s_new + 16)[tid - 4];
+                else reinterpret_cast<uint32_t*>(p.param)[tid == 8 ? ke : ve] = s_new[32 + (tid - 8)];
+            }
+        }
+    }
 
     float m[QG], d[QG], zacc[QG], acc[QG][32];   // acc[g][8 w + e]: feature 32 part + 8 w + KV_PERM[e] of sum_i p_i s_i (16 + n_i); zacc: sum_i p_i (z_i + 16 s_i)
 #pragma unroll
@@ -457,7 +574,18 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
     for (int j = 0; j < 2 * (NB - 1); ++j) {
         if (j + NB - 1 < 2 * (NB - 1) && base + (int64_t)(j + NB - 1) * STRIDE < seq_len)
             request(base + (int64_t)(j + NB - 1) * STRIDE, buf[(j + NB - 1) % NB]);
-        if (base + (int64_t)j * STRIDE < seq_len) step(base + (int64_t)j * STRIDE, buf[j % NB]);
+        if (base + (int64_t)j * STRIDE < seq_len) {
+            if constexpr (APPEND) {
+                // (the steady-state loop above never reaches the last row: it stops two strides short of the length)
+                if (own && base + (int64_t)j * STRIDE + slot == last_row) {
+                    Rows& r = buf[j % NB];
+                    r.kq[0] = reinterpret_cast<const uint4*>(s_new)[part];
+                    r.vq[0] = reinterpret_cast<const uint4*>(s_new + 16)[part];
+                    r.kpar = s_new[32], r.vpar = s_new[33];
+                }
+            }
+            step(base + (int64_t)j * STRIDE, buf[j % NB]);
+        }
     }
 #pragma unroll
     for (int g = 0; g < QG; ++g) {   // (QG > 1: the heads' states go through the same LDS one after the other)
@@ -651,23 +779,34 @@ int64_t fq_kv_decode_ws_bytes(int batch, int num_heads, int head_dim) {   // for
 
 int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, const f16* qt,
-                        int transpose_out, hipStream_t stream, bool f16_cache, float* ws, int splits, int qgroup) {
+                        int transpose_out, hipStream_t stream, bool f16_cache, float* ws, int splits, int qgroup, const f16* k_new,
+                        const f16* v_new, const void* t_image, int src_heads) {
     // num_heads: QUERY heads (q, o); the cache holds num_heads / qgroup heads (qgroup = 1: the reference's layout)
     if (splits > 16 || qgroup < 1 || num_heads % qgroup) return -1000;   // (the merge of the split launch reads at most 16 states: fq_kv_decode_splits never returns more)
     const PagedKv p = make_kv(kv_data, kv_param, indptr, indices, last, num_layers, layer_idx, num_heads / qgroup, page_size, head_dim, batch);
     const bool split = ws != nullptr && splits > 1;
+    // k_new: the step's own row is quantised and appended by this launch (KvNew): INT4 cache, head_dim 128, page_size % 16 == 0 only
+    KvNew nw = {k_new, v_new, reinterpret_cast<const uint4*>(t_image), src_heads};
+    if (k_new != nullptr && (f16_cache || head_dim != 128 || page_size % 16 || v_new == nullptr || src_heads < 1 || (num_heads / qgroup) % src_heads)) return -1000;
+    const bool append = k_new != nullptr;
     // (round 6) a shared cache with 2 or 4 query heads per KV head at head_dim 128: ONE workgroup per (request, KV head) serves its query heads
     // from one pass over the rows (fq_kv_decode_kernel<.., QG>); every other geometry: a workgroup per query head
     const int wg_heads = fq_kv_decode_wg_heads(batch, num_heads, qgroup, head_dim);
     const int qg = num_heads / wg_heads;
     const dim3 grid((unsigned)batch, (unsigned)wg_heads, split ? (unsigned)splits : 1u);
     const bool wide = (int64_t)batch * wg_heads * (split ? splits : 1) < 512;  // fewer than two workgroups per CU: 8 waves each instead of 4 (measured: 158 -> 113 us at 8 x 8192; no gain from 512 up)
-#define FQ_DEC4(HD_, NW_, UNI_, F16_, SP_, QG_)                                                                        \
+#define FQ_DEC5(HD_, NW_, UNI_, F16_, SP_, QG_, AP_)                                                                   \
     {                                                                                                                 \
         constexpr size_t ns_ = (size_t)(NW_ * (64 / (HD_ / 32))), nch_ = (size_t)NW_ * 64 / HD_;                      \
-        constexpr size_t lds = sizeof(float) * (ns_ * (HD_ + 1 + 2) + QG_ * HD_ + ns_ + NW_ + nch_ + nch_ * (HD_ + 1)); \
-        FQ_RAISE_LDS_CAP((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_, SP_, QG_>), lds);                                 \
-        hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_, SP_, QG_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out, ws, qgroup); \
+        constexpr size_t lds = sizeof(float) * (ns_ * (HD_ + 1 + 2) + QG_ * HD_ + ns_ + NW_ + nch_ + nch_ * (HD_ + 1)) + (AP_ ? 256 : 0); \
+        FQ_RAISE_LDS_CAP((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_, SP_, QG_, AP_>), lds);                            \
+        hipLaunchKernelGGL((fq_kv_decode_kernel<HD_, NW_, UNI_, F16_, SP_, QG_, AP_>), grid, dim3(NW_ * 64), lds, stream, o, q, p, qt, transpose_out, ws, qgroup, nw); \
+    }
+#define FQ_DEC4(HD_, NW_, UNI_, F16_, SP_, QG_)                                                                        \
+    {                                                                                                                 \
+        if constexpr (HD_ == 128 && UNI_ && !F16_) {                                                                  \
+            if (append) FQ_DEC5(HD_, NW_, UNI_, F16_, SP_, QG_, true) else FQ_DEC5(HD_, NW_, UNI_, F16_, SP_, QG_, false) \
+        } else FQ_DEC5(HD_, NW_, UNI_, F16_, SP_, QG_, false)                                                         \
     }
 #define FQ_DEC3(HD_, NW_, UNI_, F16_, SP_)                                                                             \
     {                                                                                                                 \
@@ -700,5 +839,6 @@ int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, con
 #undef FQ_DEC2
 #undef FQ_DEC3
 #undef FQ_DEC4
+#undef FQ_DEC5
     return (int)hipGetLastError();
 }

@@ -82,6 +82,13 @@ def batch_decode_f16(o, q, kv_data, kv_param, kv_indptr, kv_indices, last_page_o
     return batch_decode_i4(o, q, kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, layer_idx)
 
 
+# fuse_append: up to this many (request, cache head) pairs the decode launch quantises and appends the step's own row (every workgroup of a
+# pair's last row runs the quantiser prologue: ~1.5 us each). Measured on a Llama-3-8B layer's captured step (profiles/r06_fused_append.txt):
+# 66.5 -> 61.6 us at one request, 105 -> 99.5 at 16 (512 pairs), 162.6 -> 157.7 at 64 requests on the shared cache (512 pairs); level at 1024 and
+# 2048 pairs; 368 -> 373-379 at 4096 pairs (the prologue in front of every one of eight rounds of workgroups costs more than the launch it saves).
+FUSE_APPEND_MAX_PAIRS = 1024
+
+
 class MultiLayerPagedKVCache4Bit:
     """kv_cache.py:166-392 with the same constructor arguments, page / scale tensors and ``update`` contract: the first call
     per layer stores the (transformed, quantised) prompt keys / values and returns the fp16 key / value states for the prefill
@@ -100,12 +107,16 @@ class MultiLayerPagedKVCache4Bit:
       (NotImplementedError otherwise, :371-372)."""
 
     def __init__(self, batch_size, page_size, max_seq_len, device, n_layers, num_heads, head_dim, disable_quant=False,
-                 trans_dtype=torch.float16, trans="had", group_size=1, share_kv_heads=False):
+                 trans_dtype=torch.float16, trans="had", group_size=1, share_kv_heads=False, fuse_append=True):
         """``share_kv_heads`` (extension, round 6): with grouped-query attention (``group_size`` > 1) the reference's cache holds one copy of
         every KV head per QUERY head (:286-296). With this flag the pages hold the ``num_heads // group_size`` KV heads once and the decode
         launch maps query head h to cache head h // group_size (fq_kv_batch_decode_gqa): the same attention output bit for bit, 1 / group_size
         of the cache memory and of the bytes a decode step reads (a Llama-3-8B layer's step at 64 requests x 2048 tokens:
-        profiles/r06_gqa_cache.txt). The page layout then differs from the reference's in its head count, nothing else."""
+        profiles/r06_gqa_cache.txt). The page layout then differs from the reference's in its head count, nothing else.
+        ``fuse_append`` (round 6, third session): a decode step's K transform + K / V quantisation + append run INSIDE the decode-attention launch
+        of the closure ``update`` returns (ops.kv_decode_append, fq_kv_decode_append_i4: same cache bytes, same output, one launch instead of
+        two) where the geometry allows (INT4 pages, head_dim 128, page_size % 16 == 0). The rows reach the cache when the closure is called;
+        if it is not called before the cache is touched again, they are appended by the usual launch then (``_flush_pending``)."""
         self.page_size, self.batch_size, self.max_seq_len = page_size, batch_size, max_seq_len
         self.device, self.n_layers, self.trans, self.group_size = device, n_layers, trans, group_size
         self.share_kv_heads = bool(share_kv_heads) and group_size > 1
@@ -116,31 +127,53 @@ class MultiLayerPagedKVCache4Bit:
         self.disable_quant = disable_quant
         self.org_head_dim = head_dim
         n_pages = self.page_cnt_from_length(max_seq_len) * batch_size
-        self.pages = torch.empty((n_pages, n_layers, 2, num_heads, page_size, head_dim if disable_quant else head_dim // 2),
+        self._pages = torch.empty((n_pages, n_layers, 2, num_heads, page_size, head_dim if disable_quant else head_dim // 2),
                                  dtype=torch.float16 if disable_quant else torch.uint8, device=device)
-        self.scales = torch.empty((n_pages, n_layers, 2, num_heads, page_size, 2), dtype=torch.float16, device=device)
+        self._scales = torch.empty((n_pages, n_layers, 2, num_heads, page_size, 2), dtype=torch.float16, device=device)
         self._needs_init = [True] * n_layers
+        self.fuse_append = bool(fuse_append)
+        self._pending = None    # a decode step's (k, v, transform, index tensors, layer) not yet appended: the closure's launch will (fuse_append)
         self.length = 0
         self.generation = 0     # bumped when the page / index storage moves: graphs captured over the old pointers are stale (deploy.graphed)
         self._log = None        # deploy.graphed: the (layer_idx, added) host steps of the calls made while it is a list
         self._skip_host = False  # deploy.graphed: update() leaves the host step to replay_host() (capture pass)
+
+    # The page / scale tensors as the reference names them. Reading them from outside first appends a decode step's rows that were left to
+    # the closure's launch (fuse_append): whoever looks at the cache sees every token update() was given, as in the reference.
+    @property
+    def pages(self):
+        self._flush_pending()
+        return self._pages
+
+    @pages.setter
+    def pages(self, t):
+        self._pages = t
+
+    @property
+    def scales(self):
+        self._flush_pending()
+        return self._scales
+
+    @scales.setter
+    def scales(self, t):
+        self._scales = t
 
     def page_cnt_from_length(self, length):
         return (length + self.page_size - 1) // self.page_size
 
     def _ensure_page_cnt_per_batch(self, expected):
         need = expected * self.batch_size
-        have = self.pages.shape[0]
+        have = self._pages.shape[0]
         if need <= have:
             return
         grow = max(need, have * 2) - have
-        self.pages = torch.cat([self.pages, torch.empty((grow, *self.pages.shape[1:]), dtype=self.pages.dtype, device=self.device)])
-        self.scales = torch.cat([self.scales, torch.empty((grow, *self.scales.shape[1:]), dtype=self.scales.dtype, device=self.device)])
+        self._pages = torch.cat([self._pages, torch.empty((grow, *self._pages.shape[1:]), dtype=self._pages.dtype, device=self.device)])
+        self._scales = torch.cat([self._scales, torch.empty((grow, *self._scales.shape[1:]), dtype=self._scales.dtype, device=self.device)])
         self.generation += 1
 
     def would_grow(self, added: int) -> bool:
         """Would appending ``added`` tokens per request re-allocate the pages (and so move every pointer a captured graph holds)?"""
-        return self.page_cnt_from_length(self.length + added) * self.batch_size > self.pages.shape[0]
+        return self.page_cnt_from_length(self.length + added) * self.batch_size > self._pages.shape[0]
 
     @property
     def seen_tokens(self):
@@ -168,8 +201,8 @@ class MultiLayerPagedKVCache4Bit:
             last = seqlens % self.page_size
             last = torch.where((seqlens != 0) & (last == 0), torch.full_like(last, self.page_size), last).to(torch.int32).contiguous()
         return {
-            "kv_data": self.pages,
-            "kv_param": self.scales,
+            "kv_data": self._pages,
+            "kv_param": self._scales,
             "kv_indptr": torch.arange(0, self.batch_size + 1, device=dev, dtype=torch.int32) * page_cnt,
             "kv_indices": ((torch.arange(page_cnt, device=dev, dtype=torch.int32) * self.batch_size).unsqueeze(0)
                            + torch.arange(self.batch_size, device=dev, dtype=torch.int32).unsqueeze(1)).reshape(-1).contiguous(),
@@ -183,10 +216,10 @@ class MultiLayerPagedKVCache4Bit:
         a captured decode step can keep (deploy.graphed)."""
         bsz, dev = self.batch_size, self.device
         st = self.__dict__.get("_st")
-        if st is None or st["pages_ptr"] != self.pages.data_ptr():
-            st = {"pages_ptr": self.pages.data_ptr(), "page_cnt": -1, "ptr": -1,
+        if st is None or st["pages_ptr"] != self._pages.data_ptr():
+            st = {"pages_ptr": self._pages.data_ptr(), "page_cnt": -1, "ptr": -1,
                   "indptr": torch.zeros(bsz + 1, dtype=torch.int32, device=dev),
-                  "indices": torch.zeros(max(1, self.pages.shape[0]), dtype=torch.int32, device=dev),
+                  "indices": torch.zeros(max(1, self._pages.shape[0]), dtype=torch.int32, device=dev),
                   "last": torch.zeros(bsz, dtype=torch.int32, device=dev)}
             self._st = st
             self.generation += 1
@@ -202,7 +235,7 @@ class MultiLayerPagedKVCache4Bit:
         if st["ptr"] != ptr:
             st["last"].fill_(ptr)
             st["ptr"] = ptr
-        return {"kv_data": self.pages, "kv_param": self.scales, "kv_indptr": st["indptr"],
+        return {"kv_data": self._pages, "kv_param": self._scales, "kv_indptr": st["indptr"],
                 "kv_indices": st["indices"][:bsz * page_cnt], "last_page_offset": st["last"]}
 
     def _host_step(self, layer_idx, added, mask=None):
@@ -210,7 +243,7 @@ class MultiLayerPagedKVCache4Bit:
         if layer_idx == 0:
             self._ensure_page_cnt_per_batch(self.page_cnt_from_length(self.length + added))
             self.length += added
-        key = (self.length, self.pages.data_ptr(), None if mask is None else (mask.data_ptr(), ops.ver(mask), tuple(mask.shape)))
+        key = (self.length, self._pages.data_ptr(), None if mask is None else (mask.data_ptr(), ops.ver(mask), tuple(mask.shape)))
         if getattr(self, "_specs_key", None) != key:   # index tensors: once per step, not per layer
             self._specs = self._static_specs() if mask is None else self.get_cache_specs_for_flash_infer(mask)
             self._specs_key = key
@@ -221,7 +254,15 @@ class MultiLayerPagedKVCache4Bit:
         for layer_idx, added in log:
             self._host_step(layer_idx, added)
 
+    def _flush_pending(self):
+        """Append the rows a decode step left to its closure's launch if that closure was never called (the two-launch form's first launch)."""
+        pend, self._pending = self._pending, None
+        if pend is not None:
+            k, v, tk16, args, layer_idx, group = pend
+            ops.kv_quant_append(k, v, tk16, *args, layer_idx, group)
+
     def update(self, key_states, value_states, layer_idx, cache_kwargs=None):
+        self._flush_pending()
         cache_kwargs = cache_kwargs or {}
         mask = cache_kwargs.get("attention_mask")
         b, added, heads, hd = key_states.shape
@@ -243,7 +284,14 @@ class MultiLayerPagedKVCache4Bit:
         if had:                                                         # :265-266 matmul_had_cuda on the keys
             key_states = ops.hadamard(key_states.to(torch.float16).contiguous())
         ragged_init = init and mask is not None
-        if not self.disable_quant and not ragged_init:
+        fused = (self.fuse_append and not init and added == 1 and not self.disable_quant and key_states.dtype == torch.float16
+                 and b * specs["kv_data"].shape[3] <= FUSE_APPEND_MAX_PAIRS
+                 and value_states.dtype == torch.float16 and ops.kv_decode_append_supported(specs["kv_data"], heads))
+        if fused:
+            # the closure's launch quantises and appends these rows itself (ops.kv_decode_append)
+            self._pending = (key_states.contiguous(), value_states.contiguous(), tk16, args, layer_idx, self.group_size)
+            keys_t = None
+        elif not self.disable_quant and not ragged_init:
             # K transform + K / V quantisation + append: one launch (fq_kv_quant_append_i4); every request appends `added`
             # tokens at the end of ITS length (last_page_offset is per request)
             ops.kv_quant_append(key_states.contiguous(), value_states.contiguous(), tk16, *args, layer_idx, self.group_size)
@@ -296,5 +344,11 @@ class MultiLayerPagedKVCache4Bit:
                 q2 = ops.hadamard(q2.contiguous())
             elif tk_inv_t is not None:                                      # :139-140: ... of the learned K transform, in the launch
                 qt = tk_inv_t.to(q.device, torch.float16).contiguous()
+            pend = self._pending
+            if pend is not None and pend[3] is args and pend[4] == layer_idx:      # this step's rows: appended by the decode launch itself
+                self._pending = None
+                return ops.kv_decode_append(q2.contiguous(), pend[0].view(b, heads, hd), pend[1].view(b, heads, hd), pend[2], *args, layer_idx,
+                                            qt, transposed, seq_hint=length_now).unsqueeze(1)
+            self._flush_pending()
             return ops.kv_batch_decode(q2.contiguous(), *args, layer_idx, qt, transposed, seq_hint=length_now).unsqueeze(1)
         return attend

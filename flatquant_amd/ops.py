@@ -333,6 +333,12 @@ def images_ready() -> int:
                 ent[3][0] = True
             else:
                 pending += 1
+    for ent in _KV_TIMG.values():          # (the K-transform images of kv_decode_append: same rule)
+        if not ent[3]["done"]:
+            if ent[2].query():
+                ent[3]["done"] = True
+            else:
+                pending += 1
     return pending
 
 
@@ -1794,6 +1800,102 @@ def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tens
                      _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
                      n_layers, layer_idx, heads, page_size, hd, batch, _stream(q)))
     return o
+
+
+# Fragment images of the K transform for kv_decode_append (fq_kv_transform_image_f16: 32 KB per layer at head_dim 128), by (device, transform):
+# [image, transform, event of the preparing launch, {"done", "streams"}]. Same protocol as the Kronecker images: the entry keeps the transform alive,
+# in-place updates miss (ver), another stream waits for the preparing launch once; under capture only an image known complete (images_ready())
+# or prepared on the capturing stream is shared — otherwise the capture prepares a private one — and whatever a captured launch was handed is pinned.
+_KV_TIMG: "collections.OrderedDict" = CACHES.register("kv_transform_images", collections.OrderedDict())
+_KV_TIMG_PINNED: dict = CACHES.register("kv_transform_images_pinned", {}, pinned=True)
+_KV_TIMG_MAX = 1024
+
+
+def kv_transform_image(trans: torch.Tensor) -> torch.Tensor:
+    """The K transform [head_dim, head_dim] fp16 as the MFMA fragment image kv_decode_append reads (cached per transform tensor)."""
+    _chk(trans, "trans")
+    hd = trans.shape[-1]
+    if trans.dim() != 2 or trans.shape[0] != hd:
+        raise ValueError("trans must be [head_dim, head_dim]")
+    dev = trans.device
+    sh = _stream_handle(dev)
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (dev.index, trans.data_ptr(), ver(trans))
+    ent = _KV_TIMG.get(key)
+    if ent is not None:
+        state = ent[3]
+        if not (state["done"] or sh in state["streams"]):
+            if capturing:
+                ent = None                                  # (no event may be asked or waited for here: a private image inside the capture)
+            elif ent[2].query():
+                state["done"] = True
+            else:
+                torch.cuda.current_stream(dev).wait_event(ent[2])
+                state["streams"].add(sh)
+    if ent is not None:
+        _KV_TIMG.move_to_end(key)
+        img = ent[0]
+    else:
+        nbytes = int(lib.fq_kv_transform_image_bytes(hd))
+        if nbytes <= 0:
+            raise _lib.FqError(_lib.FQ_EUNSUPPORTED, f"kv_transform_image: head_dim={hd} must be 64 or 128")
+        img = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with _on(dev):
+            check(lib.fq_kv_transform_image_f16(_ptr(trans), hd, _ptr(img), _stream(trans)))
+        if not capturing:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            _KV_TIMG[key] = [img, trans, ev, {"done": False, "streams": {sh}}]
+            while len(_KV_TIMG) > _KV_TIMG_MAX:
+                _KV_TIMG.popitem(last=False)
+    if capturing:
+        _KV_TIMG_PINNED.setdefault(id(img), (img, trans))
+    return img
+
+
+def kv_decode_append(q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, trans: Optional[torch.Tensor], kv_data: torch.Tensor,
+                     kv_param: torch.Tensor, kv_indptr: torch.Tensor, kv_indices: torch.Tensor, last_page_offset: torch.Tensor,
+                     layer_idx: int, q_trans: Optional[torch.Tensor] = None, transpose_out: bool = False, seq_hint: int = 0,
+                     split: bool = True) -> torch.Tensor:
+    """kv_quant_append(k_new, v_new, trans, ...) + kv_batch_decode(q, ...) of a decode step as ONE launch (fq_kv_decode_append_i4, round 6): the
+    index tensors already count the new token (as for kv_quant_append), k_new / v_new [batch, kv_heads, head_dim] fp16 are its keys / values
+    (the cache's heads are a multiple of kv_heads: the reference's replicated layout, or the shared one), q [batch, heads, head_dim]. The
+    cache contents and the attention output are bit-identical to the two calls. INT4 cache, head_dim 128, page_size % 16 == 0
+    (``kv_decode_append_supported``)."""
+    _chk(q, "q"), _chk(k_new, "k_new"), _chk(v_new, "v_new"), _chk(kv_data, "kv_data", torch.uint8), _chk(kv_param, "kv_param")
+    n_layers, cache_heads, page_size, hd = _kv_geometry(kv_data)
+    batch = _chk_kv_index(kv_indptr, kv_indices, last_page_offset)
+    if q.dim() != 3 or q.shape[0] != batch or q.shape[2] != hd or q.shape[1] % cache_heads:
+        raise ValueError(f"q must be [{batch}, a multiple of {cache_heads}, {hd}]")
+    if k_new.shape != v_new.shape or k_new.dim() != 3 or k_new.shape[0] != batch or k_new.shape[2] != hd or cache_heads % k_new.shape[1]:
+        raise ValueError(f"k_new / v_new must be [{batch}, a divisor of {cache_heads}, {hd}]")
+    heads, src_heads = q.shape[1], k_new.shape[1]
+    q_group = heads // cache_heads
+    if q_trans is not None:
+        _chk(q_trans, "q_trans")
+        if q_trans.shape != (hd, hd):
+            raise ValueError("q_trans must be [head_dim, head_dim]")
+    img = kv_transform_image(trans) if trans is not None else None
+    o = torch.empty((batch, hd, heads) if transpose_out else (batch, heads, hd), dtype=torch.float16, device=q.device)
+    if batch == 0:
+        return o
+    with _on(q.device):
+        nbytes = int(lib.fq_kv_decode_workspace_bytes_gqa(batch, cache_heads, q_group, hd)) if split else 0
+        stream = _stream(q)
+        ws = _kv_split_workspace((q.device.index, stream.value, batch * heads, hd), nbytes, q.device) if nbytes > 0 else None
+        check(lib.fq_kv_decode_append_i4(_ptr(o), _ptr(q), _ptr(q_trans), 1 if transpose_out else 0, _ptr(k_new), _ptr(v_new), _ptr(img), src_heads,
+                                         _ptr(kv_data), _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
+                                         n_layers, layer_idx, cache_heads, q_group, page_size, hd, batch, int(seq_hint), _ptr(ws),
+                                         nbytes if ws is not None else 0, stream))
+    return o
+
+
+def kv_decode_append_supported(kv_data: torch.Tensor, src_heads: int) -> bool:
+    """Does fq_kv_decode_append_i4 take this cache? (INT4 pages, head_dim 128, a wave's 16 rows never straddle a page, at most 4 copies per head)"""
+    if kv_data.dtype != torch.uint8:
+        return False
+    _, cache_heads, page_size, hd = _kv_geometry(kv_data)
+    return hd == 128 and page_size % 16 == 0 and src_heads > 0 and cache_heads % src_heads == 0 and cache_heads // src_heads <= 4
 
 
 def int4_matmul(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:

@@ -633,6 +633,23 @@ int fq_kv_batch_decode_gqa(int fp16_cache, void* o, const void* q, const void* q
                            int num_layers, int layer_idx, int num_kv_heads, int q_group, int page_size, int head_dim, int batch_size, int seq_hint,
                            void* workspace, int64_t workspace_bytes, void* stream);
 
+/* (round 6, third session) The decode step's append INSIDE the decode launch — deploy/transformers/kv_cache.py:283-359: update() quantises and
+ * appends the step's K / V row (fq_kv_quant_append_i4) and the returned closure attends over the cache including it (batch_decode_i4): two
+ * dependent launches. fq_kv_decode_append_i4 is both: the lengths (kv_indptr / last_page_offset) already count the new token, k_new / v_new
+ * [batch, src_heads, head_dim] fp16 are its keys / values, k_trans_image the K transform as fq_kv_transform_image_f16 wrote it
+ * (fq_kv_transform_image_bytes(head_dim) bytes, once per layer; NULL: keys are not transformed — trans "had" / none). The workgroup that owns a
+ * request's last row quantises the new row with fq_kv_quant_append_i4's arithmetic (lac off, as the cache's own calls), uses it from LDS and
+ * writes it to the cache: the cache contents and o are bit-identical to fq_kv_quant_append_i4 followed by fq_kv_batch_decode_gqa.
+ * The cache holds num_kv_heads heads = src_heads x group (group <= 4: the reference's replicated layout has num_kv_heads = query heads and
+ * q_group = 1; a shared cache num_kv_heads = src_heads). head_dim 128 and page_size % 16 == 0 only (FQ_EUNSUPPORTED otherwise).
+ * Everything else as fq_kv_batch_decode_gqa. */
+int64_t fq_kv_transform_image_bytes(int head_dim);
+int fq_kv_transform_image_f16(const void* trans, int head_dim, void* image, void* stream);
+int fq_kv_decode_append_i4(void* o, const void* q, const void* q_trans, int transpose_out, const void* k_new, const void* v_new,
+                           const void* k_trans_image, int src_heads, const void* kv_data, const void* kv_param, const void* kv_indptr,
+                           const void* kv_indices, const void* last_page_offset, int num_layers, int layer_idx, int num_kv_heads, int q_group,
+                           int page_size, int head_dim, int batch_size, int seq_hint, void* workspace, int64_t workspace_bytes, void* stream);
+
 /*
  * The fp16 configuration of the same cache (MultiLayerPagedKVCache4Bit(disable_quant=True), kv_cache.py:177-190;
  * init_kv_f16 / append_kv_f16 / batch_decode_f16, kv_cache.py:107-137): kv_data [pages, num_layers, 2, num_heads, page_size,

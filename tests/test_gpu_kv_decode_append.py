@@ -1,0 +1,224 @@
+"""The decode step's append inside the decode launch (fq_kv_decode_append_i4, round 6): the launch that quantises and appends the step's own
+K / V row must leave the SAME cache bytes and return the SAME attention output, bit for bit, as fq_kv_quant_append_i4 followed by the decode
+launch (deploy/transformers/kv_cache.py:283-359 is those two steps) — on the replicated and the shared cache, split and unsplit launches, four
+and eight waves, with and without the K transform, ragged lengths, the new row at every place of a wave's 16-row step, on a fresh page, as the
+only row. The two-launch sequence itself is held to the oracle by tests/test_gpu_kvcache.py."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from flatquant_amd import ops as _ops
+    return _ops
+
+
+def _cache(g, bsz, lens, cache_heads, page, hd=128, layers=2):
+    """a cache whose request b holds lens[b] rows (the LAST one is the slot of the new token), pages scattered"""
+    n_pg = [(n + page - 1) // page for n in lens]
+    tot = sum(n_pg)
+    data = torch.randint(0, 256, (tot, layers, 2, cache_heads, page, hd // 2), generator=g, device="cuda", dtype=torch.uint8)
+    param = torch.stack([torch.rand(tot, layers, 2, cache_heads, page, generator=g, device="cuda") * 0.3 + 0.02,
+                         torch.rand(tot, layers, 2, cache_heads, page, generator=g, device="cuda") * 2.0 + 0.1], dim=-1).half()
+    indptr = torch.tensor([0] + list(torch.tensor(n_pg).cumsum(0)), dtype=torch.int32, device="cuda")
+    indices = torch.randperm(tot, generator=g, device="cuda").to(torch.int32)
+    last = torch.tensor([(n - 1) % page + 1 for n in lens], dtype=torch.int32, device="cuda")
+    return data, param, indptr, indices, last
+
+
+CASES = [
+    # bsz, lens, src_heads, copies per source head in the cache, query heads per cache head, page, K transform
+    (1, [2048], 8, 4, 1, 2048, True),          # Llama-3-8B, one request: the split launch (16 workgroups per pair)
+    (1, [2049], 8, 1, 4, 2048, True),          # ... on the shared cache, the new row on a fresh page
+    (2, [700, 333], 2, 2, 1, 16, True),        # split, ragged, small pages
+    (3, [1, 16, 17], 2, 1, 2, 16, True),       # the new row is the only row / the last of a step / the first of the next
+    (4, [31, 32, 33, 48], 4, 1, 1, 16, False),  # no transform (QuaRot keys arrive rotated)
+    (16, [2048] * 16, 8, 4, 1, 2048, True),    # 512 pairs: unsplit, four waves
+    (5, [100, 260, 90, 1000, 515], 8, 4, 1, 32, True),   # 160 pairs: eight waves, unsplit
+    (32, [300 + 7 * i for i in range(32)], 8, 1, 4, 64, True),   # shared cache, 256 (request, KV head) pairs: one workgroup serves 4 query heads
+    (40, [70 + i for i in range(40)], 8, 1, 2, 16, False),       # ... 2 query heads
+    (9, [50 + 3 * i for i in range(9)], 2, 4, 1, 16, True),      # 72 pairs, short rows: split count limited by the length hint
+]
+
+
+@pytest.mark.parametrize("bsz,lens,src_heads,copies,q_group,page,trans", CASES)
+@pytest.mark.parametrize("transpose_out", [False, True])
+def test_decode_append_equals_quant_append_then_decode(ops, bsz, lens, src_heads, copies, q_group, page, trans, transpose_out):
+    g = torch.Generator(device="cuda").manual_seed(bsz * 1000 + lens[0] + src_heads)
+    hd, layer = 128, 1
+    cache_heads, heads = src_heads * copies, src_heads * copies * q_group
+    data, param, indptr, indices, last = _cache(g, bsz, lens, cache_heads, page)
+    k = (torch.randn(bsz, 1, src_heads, hd, generator=g, device="cuda") * 2).half()
+    v = (torch.randn(bsz, 1, src_heads, hd, generator=g, device="cuda") * 2).half()
+    T = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half() if trans else None
+    qt = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half() if trans else None
+    q = (torch.randn(bsz, heads, hd, generator=g, device="cuda") * 0.5).half()
+    hint = max(lens)
+    d1, p1 = data.clone(), param.clone()
+    ops.kv_quant_append(k, v, T, d1, p1, indptr, indices, last, layer, copies)
+    o1 = ops.kv_batch_decode(q, d1, p1, indptr, indices, last, layer, qt, transpose_out, seq_hint=hint)
+    d2, p2 = data.clone(), param.clone()
+    o2 = ops.kv_decode_append(q, k.view(bsz, src_heads, hd), v.view(bsz, src_heads, hd), T, d2, p2, indptr, indices, last, layer, qt, transpose_out,
+                              seq_hint=hint)
+    assert not torch.equal(d1, data)                       # (the step did append something)
+    assert torch.equal(d2, d1)
+    assert torch.equal(p2.view(torch.int16), p1.view(torch.int16))
+    assert torch.equal(o2, o1)
+    assert torch.isfinite(o2.float()).all()
+    # ... and without the split launch's workspace (what a capture that finds none runs)
+    d3, p3 = data.clone(), param.clone()
+    o3 = ops.kv_decode_append(q, k.view(bsz, src_heads, hd), v.view(bsz, src_heads, hd), T, d3, p3, indptr, indices, last, layer, qt, transpose_out,
+                              seq_hint=hint, split=False)
+    o1u = ops.kv_batch_decode(q, d1, p1, indptr, indices, last, layer, qt, transpose_out, seq_hint=hint, split=False)
+    assert torch.equal(d3, d1) and torch.equal(p3.view(torch.int16), p1.view(torch.int16)) and torch.equal(o3, o1u)
+
+
+def test_new_row_at_every_slot_of_a_step_and_repeated_launches(ops):
+    """lengths 1 .. 40 (the new row at each of a wave's 16 slots, in the first / second / third step), the same launch five times: bit-stable"""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    hd, layer, src_heads, copies, page = 128, 0, 2, 2, 16
+    lens = list(range(1, 41))
+    bsz = len(lens)
+    data, param, indptr, indices, last = _cache(g, bsz, lens, src_heads * copies, page)
+    k = (torch.randn(bsz, 1, src_heads, hd, generator=g, device="cuda")).half()
+    v = (torch.randn(bsz, 1, src_heads, hd, generator=g, device="cuda")).half()
+    T = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half()
+    q = (torch.randn(bsz, src_heads * copies, hd, generator=g, device="cuda") * 0.5).half()
+    d1, p1 = data.clone(), param.clone()
+    ops.kv_quant_append(k, v, T, d1, p1, indptr, indices, last, layer, copies)
+    o1 = ops.kv_batch_decode(q, d1, p1, indptr, indices, last, layer, T)
+    for _ in range(5):
+        d2, p2 = data.clone(), param.clone()
+        o2 = ops.kv_decode_append(q, k.view(bsz, src_heads, hd), v.view(bsz, src_heads, hd), T, d2, p2, indptr, indices, last, layer, T)
+        assert torch.equal(d2, d1) and torch.equal(p2.view(torch.int16), p1.view(torch.int16)) and torch.equal(o2, o1)
+
+
+def test_zero_rows_and_extreme_values(ops):
+    """an all-zero K / V row (the 1e-5 floor of the scale), a constant row, large magnitudes: same bytes as the two launches"""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    hd, layer, src_heads, page = 128, 1, 4, 16
+    lens = [20, 21, 22, 23]
+    data, param, indptr, indices, last = _cache(g, 4, lens, src_heads, page)
+    k = torch.randn(4, 1, src_heads, hd, generator=g, device="cuda").half()
+    v = torch.randn(4, 1, src_heads, hd, generator=g, device="cuda").half()
+    k[0], v[0] = 0, 0
+    k[1], v[1] = 3.0, -2.5
+    k[2] *= 900
+    v[2] *= 3000
+    T = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half()
+    q = torch.randn(4, src_heads, hd, generator=g, device="cuda").half()
+    for trans in (T, None):
+        d1, p1 = data.clone(), param.clone()
+        ops.kv_quant_append(k, v, trans, d1, p1, indptr, indices, last, layer, 1)
+        o1 = ops.kv_batch_decode(q, d1, p1, indptr, indices, last, layer)
+        d2, p2 = data.clone(), param.clone()
+        o2 = ops.kv_decode_append(q, k.view(4, src_heads, hd), v.view(4, src_heads, hd), trans, d2, p2, indptr, indices, last, layer)
+        assert torch.equal(d2, d1) and torch.equal(p2.view(torch.int16), p1.view(torch.int16))
+        assert torch.equal(o2.view(torch.int16), o1.view(torch.int16))
+
+
+def test_unsupported_geometries_are_refused(ops):
+    from flatquant_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(1)
+    data, param, indptr, indices, last = _cache(g, 1, [20], 2, 8)           # page_size 8: a wave's 16 rows straddle pages
+    assert not ops.kv_decode_append_supported(data, 2)
+    k = torch.randn(1, 2, 128, generator=g, device="cuda").half()
+    with pytest.raises(_lib.FqError):
+        ops.kv_decode_append(torch.randn(1, 2, 128, generator=g, device="cuda").half(), k, k, None, data, param, indptr, indices, last, 0)
+    data64 = torch.zeros(2, 1, 2, 2, 16, 32, dtype=torch.uint8, device="cuda")   # head_dim 64
+    assert not ops.kv_decode_append_supported(data64, 2)
+    assert not ops.kv_decode_append_supported(torch.zeros(2, 1, 2, 2, 16, 128, dtype=torch.float16, device="cuda"), 2)   # the fp16 configuration
+    ok, _, _, _, _ = _cache(g, 1, [20], 8, 16)
+    assert ops.kv_decode_append_supported(ok, 2) and not ops.kv_decode_append_supported(ok, 1) and not ops.kv_decode_append_supported(ok, 3)
+
+
+@pytest.mark.parametrize("trans", ["matmul", "had", "none"])
+@pytest.mark.parametrize("share", [False, True])
+def test_cache_class_fused_append_equals_the_two_launches(ops, trans, share):
+    """MultiLayerPagedKVCache4Bit(fuse_append=True) against fuse_append=False over a prefill and six decode steps of two layers: the same
+    attention outputs and the same pages, bit for bit; a closure that is never called leaves its rows to the next update (flush)."""
+    import flatquant_amd.deploy.transformers as dt
+    g = torch.Generator(device="cuda").manual_seed(3)
+    bsz, prompt, kv_heads, group, hd, page, layers = 3, 45, 2, 4, 128, 16, 2
+    heads = kv_heads * group
+    tk = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half()
+    kw = {"trans_matrix_k": tk, "trans_matrix_k_inv_t": tk}
+    caches = [dt.MultiLayerPagedKVCache4Bit(bsz, page, prompt + 8, torch.device("cuda"), layers, heads, hd, trans=trans, group_size=group,
+                                            share_kv_heads=share, fuse_append=f) for f in (True, False)]
+    for c in caches:                # (the rows beyond a request's length are whatever torch.empty found: make them comparable)
+        c.pages.zero_(), c.scales.zero_()
+    for li in range(layers):
+        k0 = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+        v0 = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+        for c in caches:
+            c.update(k0, v0, li, dict(kw))
+    for step in range(6):
+        for li in range(layers):
+            k1 = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+            v1 = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+            q1 = torch.randn(bsz, 1, heads, hd, generator=g, device="cuda").half()
+            outs = []
+            for c in caches:
+                attend = c.update(k1, v1, li, dict(kw))
+                if step == 3 and li == 0:
+                    outs.append(None)              # the closure is dropped: the rows must still reach the cache (flushed by the next update)
+                else:
+                    outs.append(attend(q1, transposed=(step % 2 == 1)))
+            if outs[0] is not None:
+                assert torch.equal(outs[0], outs[1]), (step, li)
+                assert torch.isfinite(outs[0].float()).all()
+    assert caches[0].length == caches[1].length == prompt + 6
+    used = caches[0].page_cnt_from_length(caches[0].length) * bsz
+    assert torch.equal(caches[0].pages[:used], caches[1].pages[:used])
+    assert torch.equal(caches[0].scales[:used].view(torch.int16), caches[1].scales[:used].view(torch.int16))
+
+
+def test_fused_append_inside_a_captured_step(ops):
+    """the fused launch under stream capture (deploy.GraphedDecode's case): replays append one row per step like the eager calls"""
+    import flatquant_amd.deploy.transformers as dt
+    g = torch.Generator(device="cuda").manual_seed(4)
+    bsz, prompt, kv_heads, group, hd, page = 2, 30, 8, 4, 128, 2048
+    heads = kv_heads * group
+    tk = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half()
+    kw = {"trans_matrix_k": tk, "trans_matrix_k_inv_t": tk}
+    caches = [dt.MultiLayerPagedKVCache4Bit(bsz, page, 64, torch.device("cuda"), 1, heads, hd, trans="matmul", group_size=group, fuse_append=f)
+              for f in (True, False)]
+    for c in caches:
+        c.pages.zero_(), c.scales.zero_()
+    k0 = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+    v0 = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+    for c in caches:
+        c.update(k0, v0, 0, dict(kw))
+    k1 = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+    v1 = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+    q1 = torch.randn(bsz, 1, heads, hd, generator=g, device="cuda").half()
+
+    def step(c):
+        return c.update(k1, v1, 0, dict(kw))(q1)
+
+    ref = [step(caches[1]).clone() for _ in range(4)]          # eager, two launches: steps 1 .. 4
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        o = step(caches[0])                                     # warm-up on the capture stream (workspace, image): step 1
+        assert torch.equal(o, ref[0])
+        torch.cuda.synchronize()
+        ops.images_ready()
+        caches[0]._host_step(0, 1)                              # step 2's host side, eagerly: inside the capture the in-place fill of the index
+        caches[0]._skip_host = True                             # tensors would become a node of the graph and be replayed (deploy.graphed does the same)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            out = step(caches[0])                               # captured: step 2 (not executed)
+        caches[0]._skip_host = False
+    torch.cuda.synchronize()
+    for i in (1, 2, 3):                                         # replays: steps 2, 3, 4 — the host side advances the index tensors in place
+        if i > 1:
+            caches[0]._host_step(0, 1)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref[i]), i
+    used = caches[0].page_cnt_from_length(caches[0].length) * bsz
+    assert caches[0].length == caches[1].length
+    assert torch.equal(caches[0].pages[:used], caches[1].pages[:used])

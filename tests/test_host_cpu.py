@@ -584,13 +584,16 @@ def test_hot_kernels_keep_their_occupancy_budget():
         "fq_block_kernel<4,1,0,0,1>": (3, 0),             # o_proj transform, 32 heads
         "fq_block_kernel<4,2,1,0,1>": (2, 0),             # ... 64 heads
         "fq_block_any_kernel<4,2,0,f16>": (1, 0),         # ... 40 heads (masked kernel)
-        "fq_kv_decode_kernel<128,4,1,0,0,1>": (4, 0),     # INT4 paged decode attention (MFMA q . k, round 5)
-        "fq_kv_decode_kernel<128,8,1,0,0,1>": (4, 0),
-        "fq_kv_decode_kernel<128,8,1,0,1,1>": (4, 0),     # ... a request's rows split over several workgroups
-        "fq_kv_decode_kernel<128,4,0,0,0,1>": (4, 0),     # ... pages a wave's rows can straddle
-        "fq_kv_decode_kernel<128,4,1,1,0,1>": (3, 0),     # ... the fp16 configuration of the cache
-        "fq_kv_decode_kernel<128,4,1,0,0,4>": (2, 0),     # (round 6) ... four query heads of a shared KV head per workgroup: four softmax states per lane
-        "fq_kv_decode_kernel<128,8,1,0,1,4>": (2, 0),
+        "fq_kv_decode_kernel<128,4,1,0,0,1,0>": (4, 0),     # INT4 paged decode attention (MFMA q . k, round 5)
+        "fq_kv_decode_kernel<128,8,1,0,0,1,0>": (4, 0),
+        "fq_kv_decode_kernel<128,8,1,0,1,1,0>": (4, 0),     # ... a request's rows split over several workgroups
+        "fq_kv_decode_kernel<128,4,0,0,0,1,0>": (4, 0),     # ... pages a wave's rows can straddle
+        "fq_kv_decode_kernel<128,4,1,1,0,1,0>": (3, 0),     # ... the fp16 configuration of the cache
+        "fq_kv_decode_kernel<128,4,1,0,0,4,0>": (2, 0),     # (round 6) ... four query heads of a shared KV head per workgroup: four softmax states per lane
+        "fq_kv_decode_kernel<128,8,1,0,1,4,0>": (2, 0),
+        "fq_kv_decode_kernel<128,4,1,0,0,1,1>": (4, 0),   # (round 6, third session) ... that quantise and append the step's own K / V row (fq_kv_decode_append_i4): prologue only, same budget
+        "fq_kv_decode_kernel<128,8,1,0,1,1,1>": (4, 0),
+        "fq_kv_decode_kernel<128,4,1,0,0,4,1>": (2, 0),
         "fq_rowquant_wave_kernel<33,8,0,f16>": (4, 0),    # deploy Quantizer at 4096
         "fq_rowquant_wave_kernel<2,8,0,bf16>": (2, 0),    # ActivationQuantizer on bf16 rows of 4096
         "fq_had_pow2_kernel<8,1,1,1>": (3, 0),            # Hadamard 4096 + Quantizer
