@@ -254,6 +254,25 @@ class MultiLayerPagedKVCache4Bit:
         for layer_idx, added in log:
             self._host_step(layer_idx, added)
 
+    def _as_f16(self, t):
+        """``t`` as a contiguous fp16 tensor on the cache's device — itself when it already is one; otherwise ONE converted copy per source tensor
+        (keyed by its storage and version): a model that keeps trans_matrix_k in fp32 (modeling_llama.py:185-186 registers fp32 buffers) would
+        otherwise pay a conversion launch per layer and step, and the fragment image of the fused append (ops.kv_transform_image, keyed by the
+        tensor it is given) would be rebuilt every step."""
+        if t is None:
+            return None
+        dev = torch.device(self.device)
+        if t.dtype == torch.float16 and t.is_contiguous() and t.device.type == dev.type and (dev.index is None or t.device.index == dev.index):
+            return t
+        memo = self.__dict__.setdefault("_f16_memo", {})
+        key = (t.data_ptr(), ops.ver(t), t.dtype, tuple(t.shape), ops.cache_epoch())     # (ops.invalidate_caches() after a write through .data)
+        ent = memo.get(key)
+        if ent is None:
+            if len(memo) >= 4 * max(1, self.n_layers):
+                memo.clear()
+            ent = memo[key] = (t.to(device=self.device, dtype=torch.float16).contiguous(), t)    # (the source is kept alive: its address cannot be recycled under the key)
+        return ent[0]
+
     def _flush_pending(self):
         """Append the rows a decode step left to its closure's launch if that closure was never called (the two-launch form's first launch)."""
         pend, self._pending = self._pending, None
@@ -277,7 +296,7 @@ class MultiLayerPagedKVCache4Bit:
             self._host_step(layer_idx, added, mask)
         specs = self._specs
         args = (specs["kv_data"], specs["kv_param"], specs["kv_indptr"], specs["kv_indices"], specs["last_page_offset"])
-        tk16 = None if tk is None else tk.to(device=key_states.device, dtype=torch.float16).contiguous()
+        tk16 = self._as_f16(tk)
         had = self.trans == "had"
         orig_k, orig_v = key_states, value_states
         init = self._needs_init[layer_idx]
@@ -343,7 +362,7 @@ class MultiLayerPagedKVCache4Bit:
             if had:                                                         # :134-138: the query side of the rotation
                 q2 = ops.hadamard(q2.contiguous())
             elif tk_inv_t is not None:                                      # :139-140: ... of the learned K transform, in the launch
-                qt = tk_inv_t.to(q.device, torch.float16).contiguous()
+                qt = self._as_f16(tk_inv_t)
             pend = self._pending
             if pend is not None and pend[3] is args and pend[4] == layer_idx:      # this step's rows: appended by the decode launch itself
                 self._pending = None

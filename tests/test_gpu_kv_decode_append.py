@@ -222,3 +222,29 @@ def test_fused_append_inside_a_captured_step(ops):
     used = caches[0].page_cnt_from_length(caches[0].length) * bsz
     assert caches[0].length == caches[1].length
     assert torch.equal(caches[0].pages[:used], caches[1].pages[:used])
+
+
+def test_fp32_transform_matrices_are_converted_once(ops):
+    """modeling_llama.py:185-186 registers trans_matrix_k as an fp32 buffer: the cache converts it once per source tensor (not per step), the fused
+    append builds ONE fragment image for it, and the outputs equal those of the fp16 matrices"""
+    import flatquant_amd.deploy.transformers as dt
+    g = torch.Generator(device="cuda").manual_seed(8)
+    bsz, prompt, kv_heads, group, hd, page = 2, 20, 2, 2, 128, 16
+    heads = kv_heads * group
+    tk32 = torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5
+    tk16 = tk32.half()
+    caches = [dt.MultiLayerPagedKVCache4Bit(bsz, page, 64, torch.device("cuda"), 1, heads, hd, trans="matmul", group_size=group) for _ in range(2)]
+    kws = [{"trans_matrix_k": tk32, "trans_matrix_k_inv_t": tk32}, {"trans_matrix_k": tk16, "trans_matrix_k_inv_t": tk16}]
+    k0 = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+    v0 = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+    for c, kw in zip(caches, kws):
+        c.update(k0, v0, 0, dict(kw))
+    n0 = ops.cache_stats()["kv_transform_images"]["entries"]
+    for _ in range(5):
+        k1 = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+        v1 = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+        q1 = torch.randn(bsz, 1, heads, hd, generator=g, device="cuda").half()
+        o = [c.update(k1, v1, 0, dict(kw))(q1) for c, kw in zip(caches, kws)]
+        assert torch.equal(o[0], o[1])
+    assert len(caches[0]._f16_memo) == 1 and "_f16_memo" not in caches[1].__dict__
+    assert ops.cache_stats()["kv_transform_images"]["entries"] - n0 <= 2       # one image per distinct fp16 matrix, not one per step
