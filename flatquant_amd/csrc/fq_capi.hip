@@ -61,7 +61,7 @@ int fq_launch_kv_append(void* kv_data, void* kv_param, const int* indptr, const 
 int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, const f16* qt,
                         int transpose_out, hipStream_t stream, bool f16_cache = false, float* ws = nullptr, int splits = 1, int qgroup = 1,
-                        const f16* k_new = nullptr, const f16* v_new = nullptr, const void* t_image = nullptr, int src_heads = 1);
+                        const f16* k_new = nullptr, const f16* v_new = nullptr, const void* t_image = nullptr, int src_heads = 1, int copies = 1);
 int64_t fq_kv_timage_bytes(int hd);
 int fq_launch_kv_timage(const f16* T, int hd, void* img, hipStream_t stream);
 int fq_kv_decode_splits(int batch, int num_heads, int seq_hint);
@@ -1241,7 +1241,7 @@ int fq_kv_transform_image_f16(const void* trans, int head_dim, void* image, void
 int fq_kv_decode_append_i4(void* o, const void* q, const void* q_trans, int transpose_out, const void* k_new, const void* v_new,
                            const void* k_trans_image, int src_heads, const void* kv_data, const void* kv_param, const void* kv_indptr,
                            const void* kv_indices, const void* last_page_offset, int num_layers, int layer_idx, int num_kv_heads, int q_group,
-                           int page_size, int head_dim, int batch_size, int seq_hint, void* workspace, int64_t workspace_bytes, void* stream) {
+                           int page_size, int head_dim, int batch_size, int seq_hint, int read_one_copy, void* workspace, int64_t workspace_bytes, void* stream) {
     const char* what = "fq_kv_decode_append_i4";
     int rc = kv_geometry_ok(what, num_layers, layer_idx, num_kv_heads, page_size, head_dim, batch_size);
     if (rc != FQ_OK) return rc;
@@ -1253,14 +1253,40 @@ int fq_kv_decode_append_i4(void* o, const void* q, const void* q_trans, int tran
         return fail(FQ_EINVAL, "%s: NULL pointer", what);
     FQ_NEED_ALIGN16(what, kv_data, q_trans, workspace, k_new, v_new, k_trans_image);
     const int q_heads = num_kv_heads * q_group;
-    const int64_t need = fq_kv_decode_ws_bytes_gqa(batch_size, q_heads, q_group, head_dim);
-    const int splits = (workspace && need > 0) ? fq_kv_decode_splits(batch_size, fq_kv_decode_wg_heads(batch_size, q_heads, q_group, head_dim), seq_hint) : 1;
+    // read_one_copy: the num_kv_heads / src_heads cache heads of a source head hold identical rows (this function and fq_kv_quant_append_i4 write
+    // them so): the launch reads the first copy for the whole group of query heads (and still writes the new row to every copy)
+    const int copies = (read_one_copy && q_group == 1) ? num_kv_heads / src_heads : 1;
+    const int share = q_group * copies;          // query heads that share one set of rows
+    const int64_t need = fq_kv_decode_ws_bytes_gqa(batch_size, q_heads, share, head_dim);
+    const int splits = (workspace && need > 0) ? fq_kv_decode_splits(batch_size, fq_kv_decode_wg_heads(batch_size, q_heads, share, head_dim), seq_hint) : 1;
     if (splits > 1 && workspace_bytes < need)
         return fail(FQ_EINVAL, "%s: workspace of %lld bytes, fq_kv_decode_workspace_bytes_gqa says %lld", what, (long long)workspace_bytes, (long long)need);
     rc = fq_launch_kv_decode((f16*)o, (const f16*)q, (void*)kv_data, (void*)kv_param, (const int*)kv_indptr, (const int*)kv_indices,
                              (const int*)last_page_offset, num_layers, layer_idx, q_heads, page_size, head_dim, batch_size,
-                             (const f16*)q_trans, transpose_out != 0, (hipStream_t)stream, false, (float*)workspace, splits, q_group,
-                             (const f16*)k_new, (const f16*)v_new, k_trans_image, src_heads);
+                             (const f16*)q_trans, transpose_out != 0, (hipStream_t)stream, false, (float*)workspace, splits, share,
+                             (const f16*)k_new, (const f16*)v_new, k_trans_image, src_heads, copies);
+    return check_launch(rc, what);
+}
+
+int fq_kv_batch_decode_copies(int fp16_cache, void* o, const void* q, const void* q_trans, int transpose_out, const void* kv_data,
+                              const void* kv_param, const void* kv_indptr, const void* kv_indices, const void* last_page_offset,
+                              int num_layers, int layer_idx, int num_heads, int copies, int page_size, int head_dim, int batch_size, int seq_hint,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+    const char* what = "fq_kv_batch_decode_copies";
+    int rc = kv_geometry_ok(what, num_layers, layer_idx, num_heads, page_size, head_dim, batch_size);
+    if (rc != FQ_OK) return rc;
+    if (copies < 1 || copies > 4 || num_heads % copies) return fail(FQ_EINVAL, "%s: copies=%d must be 1..4 and divide num_heads=%d", what, copies, num_heads);
+    if (!o || !q || !kv_data || (!fp16_cache && !kv_param) || !kv_indptr || !kv_indices || !last_page_offset)
+        return fail(FQ_EINVAL, "%s: NULL pointer", what);
+    FQ_NEED_ALIGN16(what, kv_data, q_trans, workspace);
+    const int64_t need = fq_kv_decode_ws_bytes_gqa(batch_size, num_heads, copies, head_dim);
+    const int splits = (workspace && need > 0) ? fq_kv_decode_splits(batch_size, fq_kv_decode_wg_heads(batch_size, num_heads, copies, head_dim), seq_hint) : 1;
+    if (splits > 1 && workspace_bytes < need)
+        return fail(FQ_EINVAL, "%s: workspace of %lld bytes, fq_kv_decode_workspace_bytes_gqa(batch, num_heads / copies, copies, head_dim) says %lld", what, (long long)workspace_bytes, (long long)need);
+    rc = fq_launch_kv_decode((f16*)o, (const f16*)q, (void*)kv_data, (void*)kv_param, (const int*)kv_indptr, (const int*)kv_indices,
+                             (const int*)last_page_offset, num_layers, layer_idx, num_heads, page_size, head_dim, batch_size,
+                             (const f16*)q_trans, transpose_out != 0, (hipStream_t)stream, fp16_cache != 0, (float*)workspace, splits, copies,
+                             nullptr, nullptr, nullptr, 1, copies);
     return check_launch(rc, what);
 }
 

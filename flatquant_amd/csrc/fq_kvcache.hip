@@ -56,6 +56,8 @@ struct PagedKv {
     const int* indices;
     const int* last_page_offset;
     int num_layers, layer_idx, num_heads, page_size, head_dim, batch_size;
+    int copies;            // decode only: cache heads c * copies .. c * copies + copies - 1 hold IDENTICAL rows (the reference's replicated layout,
+                           // kv_cache.py:286-296) and the launch reads the first of them for all of the group's query heads; 1: every head its own rows
 };
 
 __device__ __forceinline__ size_t k_entry(const PagedKv& p, size_t page, size_t head, size_t entry) {
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
     // workgroups of a KV head re-read rows the memory-side cache still holds.
     static_assert(QG == 1 || (HD == 128 && (QG == 2 || QG == 4)), "several query heads per workgroup: head_dim 128, groups of 2 or 4");
     const int b = blockIdx.x, head = QG > 1 ? (int)blockIdx.y * QG : (int)blockIdx.y;        // (QG > 1: the FIRST query head of this workgroup)
-    const int QH = QG > 1 ? (int)gridDim.y * QG : (int)gridDim.y, chead = QG > 1 ? (int)blockIdx.y : head / qgroup;
+    const int QH = QG > 1 ? (int)gridDim.y * QG : (int)gridDim.y, chead = (QG > 1 ? (int)blockIdx.y : head / qgroup) * p.copies;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int part = lane / RPW, slot = lane % RPW;
     const float sm_scale = 1.44269504088896340736f / __builtin_sqrtf((float)HD);  // log2(e) / sqrt(head_dim): exp2 below
@@ -367,13 +369,14 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
             }
             __syncthreads();
             // the cache gets the row: the workgroup of the cache head's FIRST query head (a replicated cache: every head its copy)
-            if ((QG > 1 || head % qgroup == 0) && tid < 10) {
+            if ((QG > 1 || head % qgroup == 0) && tid < 10 * p.copies) {     // (p.copies > 1: this workgroup reads the group's first copy and writes them all)
+                const int cpy = tid / 10, t = tid - cpy * 10;
                 const size_t page = (size_t)p.indices[pg0 + (int)(last_row / p.page_size)];
                 const size_t entry = (size_t)(last_row % p.page_size);
-                const size_t ke = k_entry(p, page, (size_t)chead, entry), ve = v_entry(p, page, (size_t)chead, entry);
-                if (tid < 4) reinterpret_cast<uint4*>(p.data + ke * (HD / 2))[tid] = reinterpret_cast<const uint4*>(s_new)[tid];
-                else if (tid < 8) reinterpret_cast<uint4*>(p.data + ve * (HD / 2))[tid - 4] = reinterpret_cast<const uint4*>(s_new + 16)[tid - 4];
-                else reinterpret_cast<uint32_t*>(p.param)[tid == 8 ? ke : ve] = s_new[32 + (tid - 8)];
+                const size_t ke = k_entry(p, page, (size_t)(chead + cpy), entry), ve = v_entry(p, page, (size_t)(chead + cpy), entry);
+                if (t < 4) reinterpret_cast<uint4*>(p.data + ke * (HD / 2))[t] = reinterpret_cast<const uint4*>(s_new)[t];
+                else if (t < 8) reinterpret_cast<uint4*>(p.data + ve * (HD / 2))[t - 4] = reinterpret_cast<const uint4*>(s_new + 16)[t - 4];
+                else reinterpret_cast<uint32_t*>(p.param)[t == 8 ? ke : ve] = s_new[32 + (t - 8)];
             }
         }
     }
@@ -719,6 +722,7 @@ static PagedKv make_kv(void* kv_data, void* kv_param, const int* indptr, const i
     p.page_size = page_size;
     p.head_dim = head_dim;
     p.batch_size = batch;
+    p.copies = 1;
     return p;
 }
 
@@ -780,14 +784,17 @@ int64_t fq_kv_decode_ws_bytes(int batch, int num_heads, int head_dim) {   // for
 int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
                         int num_layers, int layer_idx, int num_heads, int page_size, int head_dim, int batch, const f16* qt,
                         int transpose_out, hipStream_t stream, bool f16_cache, float* ws, int splits, int qgroup, const f16* k_new,
-                        const f16* v_new, const void* t_image, int src_heads) {
-    // num_heads: QUERY heads (q, o); the cache holds num_heads / qgroup heads (qgroup = 1: the reference's layout)
-    if (splits > 16 || qgroup < 1 || num_heads % qgroup) return -1000;   // (the merge of the split launch reads at most 16 states: fq_kv_decode_splits never returns more)
-    const PagedKv p = make_kv(kv_data, kv_param, indptr, indices, last, num_layers, layer_idx, num_heads / qgroup, page_size, head_dim, batch);
+                        const f16* v_new, const void* t_image, int src_heads, int copies) {
+    // num_heads: QUERY heads (q, o); qgroup of them share one set of rows; the cache holds (num_heads / qgroup) * copies heads: copies = 1 and
+    // qgroup = 1 the reference's layout read head by head, copies = 1 and qgroup = g a cache that holds the KV heads once, copies = qgroup = g the
+    // reference's layout (g identical copies per KV head) read ONE copy per group
+    if (splits > 16 || qgroup < 1 || num_heads % qgroup || copies < 1 || copies > 4) return -1000;   // (the merge of the split launch reads at most 16 states: fq_kv_decode_splits never returns more)
+    PagedKv p = make_kv(kv_data, kv_param, indptr, indices, last, num_layers, layer_idx, num_heads / qgroup * copies, page_size, head_dim, batch);
+    p.copies = copies;
     const bool split = ws != nullptr && splits > 1;
     // k_new: the step's own row is quantised and appended by this launch (KvNew): INT4 cache, head_dim 128, page_size % 16 == 0 only
     KvNew nw = {k_new, v_new, reinterpret_cast<const uint4*>(t_image), src_heads};
-    if (k_new != nullptr && (f16_cache || head_dim != 128 || page_size % 16 || v_new == nullptr || src_heads < 1 || (num_heads / qgroup) % src_heads)) return -1000;
+    if (k_new != nullptr && (f16_cache || head_dim != 128 || page_size % 16 || v_new == nullptr || src_heads < 1 || (num_heads / qgroup * copies) % src_heads)) return -1000;
     const bool append = k_new != nullptr;
     // (round 6) a shared cache with 2 or 4 query heads per KV head at head_dim 128: ONE workgroup per (request, KV head) serves its query heads
     // from one pass over the rows (fq_kv_decode_kernel<.., QG>); every other geometry: a workgroup per query head

@@ -82,7 +82,12 @@ def batch_decode_f16(o, q, kv_data, kv_param, kv_indptr, kv_indices, last_page_o
     return batch_decode_i4(o, q, kv_data, kv_param, kv_indptr, kv_indices, last_page_offset, layer_idx)
 
 
-# fuse_append: up to this many (request, cache head) pairs the decode launch quantises and appends the step's own row (every workgroup of a
+def n_q_is_cache_heads(kv_data, src_heads, group):
+    """the pages hold src_heads x group heads (the replicated layout: one cache head per query head)"""
+    return kv_data.shape[3] == src_heads * group
+
+
+# fuse_append: up to this many workgroups — (request, cache head) pairs, or (request, KV head) pairs where one workgroup serves a group — the decode launch quantises and appends the step's own row (every workgroup of a
 # pair's last row runs the quantiser prologue: ~1.5 us each). Measured on a Llama-3-8B layer's captured step (profiles/r06_fused_append.txt):
 # 66.5 -> 61.6 us at one request, 105 -> 99.5 at 16 (512 pairs), 162.6 -> 157.7 at 64 requests on the shared cache (512 pairs); level at 1024 and
 # 2048 pairs; 368 -> 373-379 at 4096 pairs (the prologue in front of every one of eight rounds of workgroups costs more than the launch it saves).
@@ -107,12 +112,18 @@ class MultiLayerPagedKVCache4Bit:
       (NotImplementedError otherwise, :371-372)."""
 
     def __init__(self, batch_size, page_size, max_seq_len, device, n_layers, num_heads, head_dim, disable_quant=False,
-                 trans_dtype=torch.float16, trans="had", group_size=1, share_kv_heads=False, fuse_append=True):
+                 trans_dtype=torch.float16, trans="had", group_size=1, share_kv_heads=False, fuse_append=True,
+                 read_one_copy=True):
         """``share_kv_heads`` (extension, round 6): with grouped-query attention (``group_size`` > 1) the reference's cache holds one copy of
         every KV head per QUERY head (:286-296). With this flag the pages hold the ``num_heads // group_size`` KV heads once and the decode
         launch maps query head h to cache head h // group_size (fq_kv_batch_decode_gqa): the same attention output bit for bit, 1 / group_size
         of the cache memory and of the bytes a decode step reads (a Llama-3-8B layer's step at 64 requests x 2048 tokens:
         profiles/r06_gqa_cache.txt). The page layout then differs from the reference's in its head count, nothing else.
+        ``read_one_copy`` (round 6, third session): on the reference's replicated layout (``group_size`` > 1, not shared) the decode launch reads
+        ONE of a KV head's ``group_size`` identical copies for the whole group of query heads (ops.kv_batch_decode(kv_copies=...)): every copy
+        is still written as the reference writes it, the values read are the same (the output bit-identical below 256 (request, KV head) pairs, up to
+        the order of fp32 additions above), a decode step reads 1 / group_size of the rows. Set it False
+        if something other than this class's ``update`` fills the pages with copies that differ.
         ``fuse_append`` (round 6, third session): a decode step's K transform + K / V quantisation + append run INSIDE the decode-attention launch
         of the closure ``update`` returns (ops.kv_decode_append, fq_kv_decode_append_i4: same cache bytes, same output, one launch instead of
         two) where the geometry allows (INT4 pages, head_dim 128, page_size % 16 == 0). The rows reach the cache when the closure is called;
@@ -132,6 +143,7 @@ class MultiLayerPagedKVCache4Bit:
         self._scales = torch.empty((n_pages, n_layers, 2, num_heads, page_size, 2), dtype=torch.float16, device=device)
         self._needs_init = [True] * n_layers
         self.fuse_append = bool(fuse_append)
+        self.read_one_copy = bool(read_one_copy)
         self._pending = None    # a decode step's (k, v, transform, index tensors, layer) not yet appended: the closure's launch will (fuse_append)
         self.length = 0
         self.generation = 0     # bumped when the page / index storage moves: graphs captured over the old pointers are stale (deploy.graphed)
@@ -303,8 +315,13 @@ class MultiLayerPagedKVCache4Bit:
         if had:                                                         # :265-266 matmul_had_cuda on the keys
             key_states = ops.hadamard(key_states.to(torch.float16).contiguous())
         ragged_init = init and mask is not None
+        # the reference's replicated layout: group_size identical copies per KV head, one of them read (read_one_copy)
+        copies = self.group_size if (self.read_one_copy and 1 < self.group_size <= 4 and n_q_is_cache_heads(specs["kv_data"], heads, self.group_size)) else 1
+        wgs = b * specs["kv_data"].shape[3]                 # workgroups of the decode launch: one per (request, cache head) ...
+        if copies in (2, 4) and hd == 128 and wgs // copies >= 256:
+            wgs //= copies                                  # ... or per (request, KV head) where one workgroup serves the group (fq_kv_decode_wg_heads)
         fused = (self.fuse_append and not init and added == 1 and not self.disable_quant and key_states.dtype == torch.float16
-                 and b * specs["kv_data"].shape[3] <= FUSE_APPEND_MAX_PAIRS
+                 and wgs <= FUSE_APPEND_MAX_PAIRS
                  and value_states.dtype == torch.float16 and ops.kv_decode_append_supported(specs["kv_data"], heads))
         if fused:
             # the closure's launch quantises and appends these rows itself (ops.kv_decode_append)
@@ -367,7 +384,7 @@ class MultiLayerPagedKVCache4Bit:
             if pend is not None and pend[3] is args and pend[4] == layer_idx:      # this step's rows: appended by the decode launch itself
                 self._pending = None
                 return ops.kv_decode_append(q2.contiguous(), pend[0].view(b, heads, hd), pend[1].view(b, heads, hd), pend[2], *args, layer_idx,
-                                            qt, transposed, seq_hint=length_now).unsqueeze(1)
+                                            qt, transposed, seq_hint=length_now, read_one_copy=copies > 1).unsqueeze(1)
             self._flush_pending()
-            return ops.kv_batch_decode(q2.contiguous(), *args, layer_idx, qt, transposed, seq_hint=length_now).unsqueeze(1)
+            return ops.kv_batch_decode(q2.contiguous(), *args, layer_idx, qt, transposed, seq_hint=length_now, kv_copies=copies).unsqueeze(1)
         return attend

@@ -1753,12 +1753,16 @@ def _kv_split_workspace(key, nbytes: int, device) -> Optional[torch.Tensor]:
 
 def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tensor, kv_indptr: torch.Tensor,
                     kv_indices: torch.Tensor, last_page_offset: torch.Tensor, layer_idx: int,
-                    q_trans: Optional[torch.Tensor] = None, transpose_out: bool = False, seq_hint: int = 0, split: bool = True) -> torch.Tensor:
+                    q_trans: Optional[torch.Tensor] = None, transpose_out: bool = False, seq_hint: int = 0, split: bool = True,
+                    kv_copies: int = 1) -> torch.Tensor:
     """batch_decode_i4 (kv_cache.py:98-105): q [batch, heads, head_dim] fp16 -> o of the same shape, attention over each
     request's cached rows (fq_kv_batch_decode_i4[_ex]). ``q_trans`` [head_dim, head_dim]: the query is multiplied by it
     inside the launch; ``transpose_out``: o comes back as [batch, head_dim, heads]. With at most 128 (request, head) pairs the rows
     of a request are split over several workgroups (fq_kv_batch_decode_split, round 5; ``seq_hint``: the longest request, 0 = unknown;
-    ``split=False``: never) — same results up to the order of fp32 additions."""
+    ``split=False``: never) — same results up to the order of fp32 additions. ``kv_copies`` = g > 1 (round 6): the cache is the reference's
+    REPLICATED layout whose g consecutive heads per KV head hold identical rows (kv_cache.py:286-296; the appends of this package write them so)
+    and the launch reads one copy per group (fq_kv_batch_decode_copies): the same values from 1 / g of the bytes (the same output bit for bit
+    below 256 (request, KV head) pairs; from there one workgroup serves a group: another order of the fp32 additions, as with split launches)."""
     _chk(q, "q"), _chk(kv_data, "kv_data", kv_data.dtype), _chk(kv_param, "kv_param")
     n_layers, kv_heads, page_size, hd = _kv_geometry(kv_data)
     batch = _chk_kv_index(kv_indptr, kv_indices, last_page_offset)
@@ -1768,6 +1772,8 @@ def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tens
         raise ValueError(f"q must be [{batch}, a multiple of {kv_heads}, {hd}]")
     heads = q.shape[1]
     q_group = heads // kv_heads
+    if kv_copies > 1 and (q_group != 1 or kv_heads % kv_copies or kv_copies > 4):
+        raise ValueError(f"kv_copies={kv_copies}: needs a replicated cache (query heads == cache heads == {kv_heads}) in groups of at most 4")
     if q_trans is not None:
         _chk(q_trans, "q_trans")
         if q_trans.shape != (hd, hd):
@@ -1776,6 +1782,15 @@ def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tens
     if batch == 0:
         return o
     with _on(q.device):
+        if kv_copies > 1:
+            nbytes = int(lib.fq_kv_decode_workspace_bytes_gqa(batch, heads // kv_copies, kv_copies, hd)) if split else 0
+            stream = _stream(q)
+            ws = _kv_split_workspace((q.device.index, stream.value, batch * heads, hd), nbytes, q.device) if nbytes > 0 else None
+            check(lib.fq_kv_batch_decode_copies(1 if f16_cache else 0, _ptr(o), _ptr(q), _ptr(q_trans), 1 if transpose_out else 0, _ptr(kv_data),
+                                                _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
+                                                n_layers, layer_idx, heads, kv_copies, page_size, hd, batch, int(seq_hint), _ptr(ws),
+                                                nbytes if ws is not None else 0, stream))
+            return o
         if not split:
             nbytes = 0
         elif q_group > 1:
@@ -1856,12 +1871,13 @@ def kv_transform_image(trans: torch.Tensor) -> torch.Tensor:
 def kv_decode_append(q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, trans: Optional[torch.Tensor], kv_data: torch.Tensor,
                      kv_param: torch.Tensor, kv_indptr: torch.Tensor, kv_indices: torch.Tensor, last_page_offset: torch.Tensor,
                      layer_idx: int, q_trans: Optional[torch.Tensor] = None, transpose_out: bool = False, seq_hint: int = 0,
-                     split: bool = True) -> torch.Tensor:
+                     split: bool = True, read_one_copy: bool = False) -> torch.Tensor:
     """kv_quant_append(k_new, v_new, trans, ...) + kv_batch_decode(q, ...) of a decode step as ONE launch (fq_kv_decode_append_i4, round 6): the
     index tensors already count the new token (as for kv_quant_append), k_new / v_new [batch, kv_heads, head_dim] fp16 are its keys / values
     (the cache's heads are a multiple of kv_heads: the reference's replicated layout, or the shared one), q [batch, heads, head_dim]. The
     cache contents and the attention output are bit-identical to the two calls. INT4 cache, head_dim 128, page_size % 16 == 0
-    (``kv_decode_append_supported``)."""
+    (``kv_decode_append_supported``). ``read_one_copy``: on the replicated layout (cache heads = query heads = kv_heads x copies) the launch
+    reads the first copy of every group (as kv_batch_decode(kv_copies=...)) and writes the new row to all of them."""
     _chk(q, "q"), _chk(k_new, "k_new"), _chk(v_new, "v_new"), _chk(kv_data, "kv_data", torch.uint8), _chk(kv_param, "kv_param")
     n_layers, cache_heads, page_size, hd = _kv_geometry(kv_data)
     batch = _chk_kv_index(kv_indptr, kv_indices, last_page_offset)
@@ -1880,12 +1896,14 @@ def kv_decode_append(q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, 
     if batch == 0:
         return o
     with _on(q.device):
-        nbytes = int(lib.fq_kv_decode_workspace_bytes_gqa(batch, cache_heads, q_group, hd)) if split else 0
+        one = bool(read_one_copy) and q_group == 1 and cache_heads // src_heads > 1
+        share = cache_heads // src_heads if one else q_group           # query heads that share one set of rows
+        nbytes = int(lib.fq_kv_decode_workspace_bytes_gqa(batch, heads // share, share, hd)) if split else 0
         stream = _stream(q)
         ws = _kv_split_workspace((q.device.index, stream.value, batch * heads, hd), nbytes, q.device) if nbytes > 0 else None
         check(lib.fq_kv_decode_append_i4(_ptr(o), _ptr(q), _ptr(q_trans), 1 if transpose_out else 0, _ptr(k_new), _ptr(v_new), _ptr(img), src_heads,
                                          _ptr(kv_data), _ptr(kv_param), _ptr(kv_indptr), _ptr(kv_indices), _ptr(last_page_offset),
-                                         n_layers, layer_idx, cache_heads, q_group, page_size, hd, batch, int(seq_hint), _ptr(ws),
+                                         n_layers, layer_idx, cache_heads, q_group, page_size, hd, batch, int(seq_hint), 1 if one else 0, _ptr(ws),
                                          nbytes if ws is not None else 0, stream))
     return o
 

@@ -648,7 +648,21 @@ int fq_kv_transform_image_f16(const void* trans, int head_dim, void* image, void
 int fq_kv_decode_append_i4(void* o, const void* q, const void* q_trans, int transpose_out, const void* k_new, const void* v_new,
                            const void* k_trans_image, int src_heads, const void* kv_data, const void* kv_param, const void* kv_indptr,
                            const void* kv_indices, const void* last_page_offset, int num_layers, int layer_idx, int num_kv_heads, int q_group,
-                           int page_size, int head_dim, int batch_size, int seq_hint, void* workspace, int64_t workspace_bytes, void* stream);
+                           int page_size, int head_dim, int batch_size, int seq_hint, int read_one_copy, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The reference's replicated layout READ ONE COPY PER GROUP (round 6, third session). kv_cache.py:286-296 stores every KV head once per query head
+ * of its group: `copies` consecutive cache heads with identical rows (fq_kv_quant_append_i4 / fq_kv_append_* with group_size = copies write them
+ * so). fq_kv_batch_decode_copies computes the attention of fq_kv_batch_decode_split on such a cache — num_heads query heads = cache heads — but
+ * reads the rows of cache head (h / copies) * copies for query head h: the same values from 1 / copies of the bytes — o bit for bit where the
+ * launch geometry is the same; from 256 (request, group) pairs on one workgroup serves the group's query heads from one pass over the rows (as
+ * fq_kv_batch_decode_gqa): another order of the fp32 additions, as with split launches.
+ * The caller asserts the copies ARE identical; a cache filled any other way must use fq_kv_batch_decode_split.
+ * workspace: fq_kv_decode_workspace_bytes_gqa(batch, num_heads / copies, copies, head_dim). fq_kv_decode_append_i4(read_one_copy != 0) is the
+ * same reading for the launch that also appends (it writes the new row to every copy). */
+int fq_kv_batch_decode_copies(int fp16_cache, void* o, const void* q, const void* q_trans, int transpose_out, const void* kv_data,
+                              const void* kv_param, const void* kv_indptr, const void* kv_indices, const void* last_page_offset,
+                              int num_layers, int layer_idx, int num_heads, int copies, int page_size, int head_dim, int batch_size, int seq_hint,
+                              void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * The fp16 configuration of the same cache (MultiLayerPagedKVCache4Bit(disable_quant=True), kv_cache.py:177-190;

@@ -248,3 +248,89 @@ def test_fp32_transform_matrices_are_converted_once(ops):
         assert torch.equal(o[0], o[1])
     assert len(caches[0]._f16_memo) == 1 and "_f16_memo" not in caches[1].__dict__
     assert ops.cache_stats()["kv_transform_images"]["entries"] - n0 <= 2       # one image per distinct fp16 matrix, not one per step
+
+
+def _replicated(g, bsz, lens, kv_heads, copies, page, f16=False, hd=128, layers=2):
+    """a cache in the reference's replicated layout: cache head c is a copy of KV head c // copies (kv_cache.py:286-296)"""
+    data, param, indptr, indices, last = _cache(g, bsz, lens, kv_heads, page, hd, layers)
+    if f16:
+        data = torch.randn(data.shape[:-1] + (hd,), generator=g, device="cuda").half()
+    return data.repeat_interleave(copies, dim=3).contiguous(), param.repeat_interleave(copies, dim=3).contiguous(), indptr, indices, last
+
+
+@pytest.mark.parametrize("f16", [False, True])
+@pytest.mark.parametrize("bsz,lens,kv_heads,copies,page", [(1, [2048], 8, 4, 2048), (2, [700, 333], 2, 2, 16), (16, [500 + i for i in range(16)], 8, 4, 64),
+                                                           (32, [300 + 7 * i for i in range(32)], 8, 4, 64), (130, [40 + i for i in range(130)], 2, 2, 16),
+                                                           (3, [1, 16, 17], 4, 3, 16)])
+def test_replicated_cache_read_one_copy_is_bit_identical(ops, f16, bsz, lens, kv_heads, copies, page):
+    """ops.kv_batch_decode(kv_copies=g) on a cache whose g copies per KV head are identical == the launch that reads every head's own copy:
+    bit for bit where the launch geometry is the same (split launches, a workgroup per query head); from 256 (request, KV head) pairs on ONE
+    workgroup serves the group (other wave count, other order of the fp32 additions — as for split launches): 1e-3 of the output's maximum.
+    INT4 and fp16 pages."""
+    g = torch.Generator(device="cuda").manual_seed(bsz + kv_heads)
+    hd, layer = 128, 1
+    data, param, indptr, indices, last = _replicated(g, bsz, lens, kv_heads, copies, page, f16)
+    heads = kv_heads * copies
+    q = (torch.randn(bsz, heads, hd, generator=g, device="cuda") * 0.5).half()
+    qt = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half()
+    for tr in (False, True):
+        o1 = ops.kv_batch_decode(q, data, param, indptr, indices, last, layer, qt, tr, seq_hint=max(lens))
+        o2 = ops.kv_batch_decode(q, data, param, indptr, indices, last, layer, qt, tr, seq_hint=max(lens), kv_copies=copies)
+        if copies in (2, 4) and bsz * kv_heads >= 256:
+            assert ((o1.float() - o2.float()).abs().amax() / o1.float().abs().amax()).item() <= 1e-3
+        else:
+            assert torch.equal(o1, o2)
+    with pytest.raises(ValueError):
+        ops.kv_batch_decode(q[:, :kv_heads].contiguous(), data, param, indptr, indices, last, layer, kv_copies=copies)   # q must carry one head per cache head
+
+
+@pytest.mark.parametrize("bsz,lens,kv_heads,copies,page", [(1, [2048], 8, 4, 2048), (4, [31, 32, 33, 48], 2, 2, 16), (16, [900 + i for i in range(16)], 8, 4, 64),
+                                                           (64, [100 + i for i in range(64)], 8, 4, 32)])
+def test_decode_append_read_one_copy_writes_every_copy(ops, bsz, lens, kv_heads, copies, page):
+    """cache bytes and parameters of EVERY copy bit for bit; the output bit for bit unless one workgroup serves the group (see above)"""
+    g = torch.Generator(device="cuda").manual_seed(bsz * 7 + kv_heads)
+    hd, layer = 128, 0
+    data, param, indptr, indices, last = _replicated(g, bsz, lens, kv_heads, copies, page)
+    heads = kv_heads * copies
+    k = (torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda") * 2).half()
+    v = (torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda") * 2).half()
+    T = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half()
+    q = (torch.randn(bsz, heads, hd, generator=g, device="cuda") * 0.5).half()
+    d1, p1 = data.clone(), param.clone()
+    ops.kv_quant_append(k, v, T, d1, p1, indptr, indices, last, layer, copies)
+    o1 = ops.kv_batch_decode(q, d1, p1, indptr, indices, last, layer, T, seq_hint=max(lens))
+    d2, p2 = data.clone(), param.clone()
+    o2 = ops.kv_decode_append(q, k.view(bsz, kv_heads, hd), v.view(bsz, kv_heads, hd), T, d2, p2, indptr, indices, last, layer, T, seq_hint=max(lens),
+                              read_one_copy=True)
+    assert torch.equal(d2, d1) and torch.equal(p2.view(torch.int16), p1.view(torch.int16))
+    if bsz * kv_heads >= 256:
+        assert ((o1.float() - o2.float()).abs().amax() / o1.float().abs().amax()).item() <= 1e-3
+    else:
+        assert torch.equal(o2, o1)
+
+
+@pytest.mark.parametrize("disable_quant", [False, True])
+def test_cache_class_read_one_copy_equals_reading_every_copy(ops, disable_quant):
+    import flatquant_amd.deploy.transformers as dt
+    g = torch.Generator(device="cuda").manual_seed(6)
+    bsz, prompt, kv_heads, group, hd, page = 40, 37, 8, 4, 128, 16          # 320 (request, KV head) pairs: one workgroup per group
+    heads = kv_heads * group
+    tk = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half()
+    kw = {"trans_matrix_k": tk, "trans_matrix_k_inv_t": tk}
+    caches = [dt.MultiLayerPagedKVCache4Bit(bsz, page, prompt + 8, torch.device("cuda"), 1, heads, hd, trans="matmul", group_size=group,
+                                            disable_quant=disable_quant, read_one_copy=r, fuse_append=r) for r in (True, False)]
+    for c in caches:
+        c.pages.zero_(), c.scales.zero_()
+    k0 = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+    v0 = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+    for c in caches:
+        c.update(k0, v0, 0, dict(kw))
+    for step in range(4):
+        k1 = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+        v1 = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+        q1 = torch.randn(bsz, 1, heads, hd, generator=g, device="cuda").half()
+        o = [c.update(k1, v1, 0, dict(kw))(q1) for c in caches]
+        assert ((o[0].float() - o[1].float()).abs().amax() / o[1].float().abs().amax()).item() <= 1e-3, step      # (320 pairs: one workgroup per group)
+    used = caches[0].page_cnt_from_length(caches[0].length) * bsz
+    assert torch.equal(caches[0].pages[:used], caches[1].pages[:used])
+    assert torch.equal(caches[0].scales[:used].view(torch.int16), caches[1].scales[:used].view(torch.int16))

@@ -28,6 +28,7 @@ def main():
                                                           "layer's INT4 weights are 109 MB and stay in the 256 MB Infinity Cache from one replay to the next; with L >= 4 "
                                                           "(436 MB; fp16: 1.7 GB) every replay streams them from HBM, as a 32-layer model's step does")
     ap.add_argument("--no-fuse-append", action="store_true", help="K transform + K / V quantise + append as a launch of its own in front of the attention (rounds 1-6) instead of inside it")
+    ap.add_argument("--no-one-copy", action="store_true", help="the replicated cache read head by head (every query head its own copy of the rows: rounds 1-6) instead of one copy per KV head")
     ap.add_argument("--single", action="store_true", help="one launch per projection (rounds 1-4) instead of the multi-problem launches")
     ap.add_argument("--fp16", action="store_true", help="also time the same step in fp16 (nn.Linear, rms_norm, SiLU.mul, the fp16 configuration of the paged cache) "
                                                         "— the baseline of the reference's decode table, README.md:300-310")
@@ -69,7 +70,7 @@ def main():
     layers = [make_layer() for _ in range(L)]
     qkv_t, ug_t, o_t, down_t, q_l, k_l, v_l, o_l, up_l, gate_l, down_l = layers[0]
     tk = (torch.randn(hd, hd, generator=g, device=dev) / hd ** 0.5).half()
-    cache = dt.MultiLayerPagedKVCache4Bit(a.bsz, 2048, a.cache + 8, dev, L, heads, hd, trans="matmul", group_size=heads // kv_heads, share_kv_heads=a.share_kv, fuse_append=not a.no_fuse_append)
+    cache = dt.MultiLayerPagedKVCache4Bit(a.bsz, 2048, a.cache + 8, dev, L, heads, hd, trans="matmul", group_size=heads // kv_heads, share_kv_heads=a.share_kv, fuse_append=not a.no_fuse_append, read_one_copy=not a.no_one_copy)
     kw = {"trans_matrix_k": tk, "trans_matrix_k_inv_t": tk}
     for li in range(L):
         cache.update(torch.randn(a.bsz, a.cache, kv_heads, hd, generator=g, device=dev).half(),
@@ -183,7 +184,7 @@ def main():
             f16 = [(mk(hidden, hidden), mk(hidden, kv_heads * hd), mk(hidden, kv_heads * hd), mk(hidden, hidden),
                     mk(hidden, ffn), mk(hidden, ffn), mk(ffn, hidden)) for _ in range(L)]
         w1 = torch.ones(hidden, device=dev, dtype=torch.float16)
-        cache16 = dt.MultiLayerPagedKVCache4Bit(a.bsz, 2048, a.cache + 8, dev, L, heads, hd, disable_quant=True, trans="none", group_size=heads // kv_heads, share_kv_heads=a.share_kv)
+        cache16 = dt.MultiLayerPagedKVCache4Bit(a.bsz, 2048, a.cache + 8, dev, L, heads, hd, disable_quant=True, trans="none", group_size=heads // kv_heads, share_kv_heads=a.share_kv, read_one_copy=not a.no_one_copy)
         for li in range(L):
             cache16.update(torch.randn(a.bsz, a.cache, kv_heads, hd, generator=g, device=dev).half(),
                            torch.randn(a.bsz, a.cache, kv_heads, hd, generator=g, device=dev).half(), li, {})
