@@ -31,6 +31,7 @@
 //     instructions per 16-row step where the scalar kernel had ~300), 8 x 8192: 108 -> 46 us (0.77), 128 x 4096: 0.74, one request x 2048:
 //     20.8 -> 8.6 us (profiles/r05_kvdecode_timing.txt, r05_kvdecode_pmc.txt).
 #include "fq_kv_common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
     // workgroups of a KV head re-read rows the memory-side cache still holds.
     static_assert(QG == 1 || (HD == 128 && (QG == 2 || QG == 4)), "several query heads per workgroup: head_dim 128, groups of 2 or 4");
     const int b = blockIdx.x, head = QG > 1 ? (int)blockIdx.y * QG : (int)blockIdx.y;        // (QG > 1: the FIRST query head of this workgroup)
-    const int QH = QG > 1 ? (int)gridDim.y * QG : (int)gridDim.y, chead = (QG > 1 ? (int)blockIdx.y : head / qgroup) * p.copies;
+    const int QH = QG > 1 ? (int)gridDim.y * QG : (int)gridDim.y, chead = (head / qgroup) * p.copies;       // (QG > 1: the workgroup's QG query heads lie inside one group: QG divides qgroup)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int part = lane / RPW, slot = lane % RPW;
     const float sm_scale = 1.44269504088896340736f / __builtin_sqrtf((float)HD);  // log2(e) / sqrt(head_dim): exp2 below
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
             }
             __syncthreads();
             // the cache gets the row: the workgroup of the cache head's FIRST query head (a replicated cache: every head its copy)
-            if ((QG > 1 || head % qgroup == 0) && tid < 10 * p.copies) {     // (p.copies > 1: this workgroup reads the group's first copy and writes them all)
+            if (head % qgroup == 0 && tid < 10 * p.copies) {     // (p.copies > 1: this workgroup reads the group's first copy and writes them all)
                 const int cpy = tid / 10, t = tid - cpy * 10;
                 const size_t page = (size_t)p.indices[pg0 + (int)(last_row / p.page_size)];
                 const size_t entry = (size_t)(last_row % p.page_size);
@@ -456,8 +457,14 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
             r.vpar = *vpar_;
         }
     };
-    auto step = [&](int64_t base, const Rows& r) {
-        const bool valid = base + slot < seq_len;
+    // (third session of round 6) ALLV: every row of the step lies inside the sequence — true for every step of the steady-state loop (it stops two
+    // strides short of the length) — so the selects that mask rows beyond it fold away: ~17 of the ~290 VALU instructions of a four-head step.
+    auto step = [&](int64_t base, const Rows& r, auto allv) {
+#ifndef KV_ALLV
+#define KV_ALLV 1
+#endif
+        constexpr bool ALLV = KV_ALLV && decltype(allv)::value;
+        const bool valid = ALLV || base + slot < seq_len;
         float x[QG], vs = 1.0f, vz = 0.0f;
         if constexpr (F16) {
             f16x8 kb[4];
@@ -512,6 +519,13 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
             pr[g] = valid ? __builtin_amdgcn_exp2f(x[g] - m[g]) : 0.0f;
             d[g] += pr[g];
         }
+        if constexpr (F16 && ALLV) {
+            // gfx940+ VALU-trans-use hazard: the result of v_exp_f32 may not be read by the NEXT VALU instruction. The compiler pads its own
+            // instructions but not an asm statement's (cdna_hip_programming.md 5.7), and here — no select between the exponential and the
+            // v_fma_mix_f32 asm that multiplies by it any more — the first FMA of a step read a stale p: six NaNs in 4096 outputs at 2048 rows.
+#pragma unroll
+            for (int g = 0; g < QG; ++g) asm volatile("s_nop 1" : "+v"(pr[g]));
+        }
         if constexpr (F16) {
             // (a masked row's VALUES are whatever the page holds, maybe NaN: they must not meet p = 0 in an FMA)
 #pragma unroll
@@ -564,7 +578,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 request(base + (int64_t)(i + NB - 1) * STRIDE, buf[(i + NB - 1) % NB]);
-                step(base + (int64_t)i * STRIDE, buf[i]);
+                step(base + (int64_t)i * STRIDE, buf[i], std::true_type{});
             }
         }
     } else {
@@ -587,7 +601,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
                     r.kpar = s_new[32], r.vpar = s_new[33];
                 }
             }
-            step(base + (int64_t)j * STRIDE, buf[j % NB]);
+            step(base + (int64_t)j * STRIDE, buf[j % NB], std::false_type{});
         }
     }
 #pragma unroll
@@ -766,8 +780,12 @@ int fq_kv_decode_splits(int batch, int num_heads, int seq_hint) {
 #ifndef KV_MERGE_MIN_PAIRS
 #define KV_MERGE_MIN_PAIRS 256
 #endif
+#ifndef KV_MERGE_QG
+#define KV_MERGE_QG 0      // (measurement knob) 2: a group of four as TWO workgroups of two query heads (152 VGPRs: three waves per SIMD instead of two)
+#endif
 int fq_kv_decode_wg_heads(int batch, int num_q_heads, int q_group, int head_dim) {
     const bool merge = KV_MERGE_HEADS && head_dim == 128 && (q_group == 2 || q_group == 4) && (int64_t)batch * (num_q_heads / q_group) >= KV_MERGE_MIN_PAIRS;
+    if (KV_MERGE_QG == 2 && merge && q_group == 4) return num_q_heads / 2;
     return merge ? num_q_heads / q_group : num_q_heads;
 }
 int64_t fq_kv_decode_ws_bytes_gqa(int batch, int num_q_heads, int q_group, int head_dim) {

@@ -526,6 +526,34 @@ def test_fused_decode_launch_does_not_read_requested_registers_before_a_wait(tmp
     assert r.returncode == 0, r.stdout
 
 
+def test_no_transcendental_result_is_read_by_the_next_instruction_of_an_asm_block(tmp_path):
+    """gfx940+ VALU-trans-use hazard: the result of v_exp / v_rcp / v_rsq ... may not be read by the VALU instruction right behind it. hipcc pads
+    the hazard for the instructions it schedules, NOT for the inside of an asm statement: fq_kv_decode_kernel's fp16 path once fed a v_exp_f32
+    straight into the inline-asm v_fma_mix_f32 of its p . v loop (six NaNs in 4096 outputs on the GPU; third session of round 6). The ISA of
+    the decode-attention file must hold no such pair (tools/check_trans_use.py; the whole library was walked once by hand: clean)."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asm = str(tmp_path / "kvc.s")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm",
+                    "-amdgpu-kernarg-preload-count=16", "-S", "--cuda-device-only", "-o", asm,
+                    os.path.join(root, "flatquant_amd", "csrc", "fq_kvcache.hip")], check=True, capture_output=True, timeout=900)
+    text = open(asm).read()
+    assert "fq_kv_decode_kernel" in text and "v_exp_f32" in text and "v_fma_mix_f32" in text
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_trans_use.py"), asm], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    # the checker itself: a hand-made violation is found, an s_nop in between clears it
+    bad = tmp_path / "bad.s"
+    bad.write_text("_Zk:\n\tv_exp_f32_e32 v3, v2\n\tv_fma_mix_f32 v5, v1, v3, v5 op_sel_hi:[1,0,0]\n\ts_endpgm\n")
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "check_trans_use.py"), str(bad)], capture_output=True).returncode == 1
+    bad.write_text("_Zk:\n\tv_exp_f32_e32 v3, v2\n\ts_nop 0\n\tv_fma_mix_f32 v5, v1, v3, v5 op_sel_hi:[1,0,0]\n\ts_endpgm\n")
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "check_trans_use.py"), str(bad)], capture_output=True).returncode == 0
+
+
 def test_hot_kernels_keep_their_occupancy_budget():
     """The compiler's per-kernel resource reports (flatquant_amd/csrc/build/*.res, written by the Makefile's
     -Rpass-analysis=kernel-resource-usage) against the occupancy each hot kernel was tuned at. A source change that makes the

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch ONE op of the library N times (for rocprofv3 --pmc / --kernel-trace runs): tools/run_op.py <op> [n]
-  ops: kron112 (112x128 packed), kron128x224, kron64x128, kron64x112, kron32x64g (grouped, 131072 rows), kron64fq (fake-quant output), hadq14336, kvk / kvv (KV-cache quantisers), kvdec / kvdec16 (paged decode attention, INT4 / fp16 pages)
+  ops: kron112 (112x128 packed), kron128x224, kron64x128, kron64x112, kron32x64g (grouped, 131072 rows), kron64fq (fake-quant output), hadq14336, kvk / kvv (KV-cache quantisers), kvdec / kvdec16 / kvdec4 (paged decode attention, INT4 / fp16 pages / INT4 with one copy per group of four read)
        gemmbf6 / gemmi8 (Linear4bit 16384 x 4096 x 4096), (Hadamard 28x512 + Quantizer), rowq4096 / rowq14336 (deploy Quantizer), block32, block64"""
 import os
 import sys
@@ -75,7 +75,7 @@ elif op in ("gemmbf6", "gemmi8"):   # Linear4bit 16384 x 4096 x 4096: the FP6 ma
         fn = lambda i: ops.bf6_linear(xb, sx, wb, sw, None, Mg, Ng, Kg)
     else:
         fn = lambda i: ops.int4_linear(xq, sx, wq, sw, None)
-elif op in ("kvdec", "kvdec16"):   # paged decode attention: 64 requests x 2048 cached tokens x 32 heads x 128, INT4 / fp16 pages (570 MB / 2.1 GB per launch)
+elif op in ("kvdec", "kvdec16", "kvdec4"):   # paged decode attention: 64 requests x 2048 cached tokens x 32 heads x 128, INT4 / fp16 pages (570 MB / 2.1 GB per launch)
     bsz, seq, heads, hd, page = 64, 2048, 32, 128, 2048
     f16c = op == "kvdec16"
     data = (torch.randn(bsz, 1, 2, heads, page, hd, generator=g, device=dev).half() if f16c
@@ -85,7 +85,7 @@ elif op in ("kvdec", "kvdec16"):   # paged decode attention: 64 requests x 2048 
     indices = torch.arange(bsz, device=dev, dtype=torch.int32)
     last = torch.full((bsz,), seq, device=dev, dtype=torch.int32)
     qd = torch.randn(bsz, heads, hd, generator=g, device=dev).half()
-    fn = lambda i: ops.kv_batch_decode(qd, data, par, indptr, indices, last, 0)
+    fn = (lambda i: ops.kv_batch_decode(qd, data, par, indptr, indices, last, 0, kv_copies=4)) if op == "kvdec4" else (lambda i: ops.kv_batch_decode(qd, data, par, indptr, indices, last, 0))   # kvdec4: one copy per group of four read, one workgroup per group
 elif op.startswith("block"):
     H = int(op[5:])
     xs = [act(16384, 128 * H).reshape(16384, 128, H) for _ in range(2)]
