@@ -94,7 +94,7 @@ def pmc_traffic():
     """(HBM bytes per launch of the dominant kernel, source file) from the COMMITTED rocprofv3 PMC run of this same command
     (tools/prof.sh: separate --pmc passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled per the gfx950 correction) — a
     counter pass cannot run inside a timed bench process, so the line names the file the number is read from."""
-    for name in ("r06b_kron64_pmc.json", "r06_kron64_pmc.json", "r05_kron64_pmc.json", "r04_kron64_pmc.json", "r03_kron64_pmc.json", "r02_kron64_pmc.json", "r01_kron64_pmc.json"):
+    for name in ("r06c_kron64_pmc.json", "r06b_kron64_pmc.json", "r06_kron64_pmc.json", "r05_kron64_pmc.json", "r04_kron64_pmc.json", "r03_kron64_pmc.json", "r02_kron64_pmc.json", "r01_kron64_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 return json.load(fh)["hbm_bytes_per_launch"], "profiles/" + name

@@ -389,6 +389,30 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
 #pragma unroll
         for (int j = 0; j < 32; ++j) acc[g][j] = 0.0f;
     }
+    // (round 6, third session) PVM — p . v ON THE MATRIX PIPE where one workgroup serves four query heads. That launch is VALU-bound (302 VALU
+    // instructions per 16-row wave-step, the pipe ~88 % busy at 2.9 TB/s: profiles/r06_read_one_copy.txt): 128 of them are the fp32 FMAs of
+    // p . v for four heads — 8192 multiply-adds per step, the work of ONE MFMA. The contraction runs over ROWS, which sit in different lanes,
+    // so the rows' unpacked values (exact fp16 16 + n) go through LDS as eight [16 rows][16 features] tiles and come back TRANSPOSED
+    // (ds_read_b64_tr_b16 at byte 8 * lane of a tile = the B fragment of v_mfma_f32_16x16x16_f16: lane (G, n) gets rows 4G .. 4G + 3 of
+    // column n; tools/microbench/tr_probe.hip), the four heads' weights p_i s_i 2^8 (fp16: the one rounding this form adds) go the same way
+    // as a [16 rows][16] tile whose columns 4 .. 15 stay zero (the A fragment: lane (G, m) gets rows 4G .. 4G + 3 of head m), and eight
+    // MFMAs accumulate O[head][feature] — 32 accumulator registers instead of 128. All rows of a wave feed one accumulator, so the softmax
+    // reference m[g] is WAVE-uniform here (a bound KV_MARGIN above the largest score seen when it last moved — a wave reduction then, rare),
+    // the denominators stay per lane. The zero-point sum uses the ROUNDED weights, so the 16-offset cancels exactly as before.
+#ifndef KV_PV_MFMA
+#define KV_PV_MFMA 1
+#endif
+    constexpr bool PVM = KV_PV_MFMA && QG == 4 && !F16 && UNI && !SPLIT;
+    typedef __fp16 h4 __attribute__((__vector_size__(8)));
+    typedef __attribute__((address_space(3))) h4 lds_h4;
+    f32x4 oacc[PVM ? 8 : 1];
+    unsigned char* pv_vt = kv_smem + (size_t)wave * 4096;                       // (the tiles alias s_o, which is free until the states are written)
+    unsigned char* pv_pt = kv_smem + (size_t)NW * 4096 + (size_t)wave * 512;
+    if constexpr (PVM) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) oacc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        reinterpret_cast<uint2*>(pv_pt)[lane] = make_uint2(0u, 0u);             // (wave-private: LDS operations of a wave execute in order)
+    }
 
     const size_t page_stride = (size_t)p.num_layers * 2 * p.num_heads * p.page_size;
     const size_t k_off = ((size_t)p.layer_idx * 2 * p.num_heads + chead) * p.page_size, kv_off = (size_t)p.num_heads * p.page_size;
@@ -504,6 +528,41 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
         // that last raised it: exact maxima move in most steps of a 2048-token request (16 row lanes per wave, each a new maximum
         // with probability 1 / t) and every move rescales 34 registers in all lanes; a bound 2^8 above moves once or twice per
         // request. p = exp2(x - m) stays <= 1, the merge takes m as it is.
+        if constexpr (PVM) {
+            f16x4 ah;
+#pragma unroll
+            for (int g = 0; g < QG; ++g) {
+                if (__builtin_amdgcn_ballot_w64(x[g] > m[g]) != 0) {   // (wave-uniform m: everybody moves, to a bound above the wave's largest score)
+                    const float m_new = fq_wave_max(x[g]) + KV_MARGIN;
+                    const float alpha = __builtin_amdgcn_exp2f(m[g] - m_new);
+                    d[g] *= alpha;
+                    zacc[g] *= alpha;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) oacc[t][g] *= alpha;       // (D row g of every tile: head g — meaningful in lanes 0 .. 15)
+                    m[g] = m_new;
+                }
+                const float pg = valid ? __builtin_amdgcn_exp2f(x[g] - m[g]) : 0.0f;
+                d[g] += pg;
+                const f16 a16 = (f16)((valid ? pg * vs : 0.0f) * 256.0f);   // 2^KV_MARGIN: a row at the reference maximum weighs ~s
+                ah[g] = a16;
+                zacc[g] += __builtin_fmaf((float)a16 * 0.00390625f, KV_OFF, valid ? pg * vz : 0.0f);
+            }
+            if (part == 0) *reinterpret_cast<f16x4*>(pv_pt + slot * 32) = ah;       // row `slot`, heads 0 .. 3 (columns 4 .. 15 stay zero)
+            const uint32_t vw[4] = {r.vq[0].x, r.vq[0].y, r.vq[0].z, r.vq[0].w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {      // dword w's eight values (feature order KV_PERM) -> tile 2 part + w / 2, row `slot`, columns 8 (w % 2) ..
+                uint32_t u[4];
+                kv_unpack8(vw[w], ebits, u);
+                *reinterpret_cast<u32x4*>(pv_vt + (2 * part + (w >> 1)) * 512 + slot * 32 + (w & 1) * 16) = u32x4{u[0], u[1], u[2], u[3]};
+            }
+            const f16x4 pa = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4*)(pv_pt + 8 * lane)));
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const f16x4 vb = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4*)(pv_vt + t * 512 + 8 * lane)));
+                oacc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(pa, vb, oacc[t], 0, 0, 0);
+            }
+            return;
+        }
         float pr[QG];
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
@@ -603,6 +662,49 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
             }
             step(base + (int64_t)j * STRIDE, buf[j % NB], std::false_type{});
         }
+    }
+    if constexpr (PVM) {
+        // one state per wave and head: m (uniform), the denominators and zero-point sums of the rows' part-0 lanes, O in lanes 0 .. 15
+        float dt[QG], zt[QG];
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            dt[g] = fq_wave_sum(part == 0 ? d[g] : 0.0f);
+            zt[g] = fq_wave_sum(part == 0 ? zacc[g] : 0.0f);
+        }
+        __syncthreads();                                         // every wave is done with its tiles: the states below take their place
+        float* st_m = reinterpret_cast<float*>(kv_smem);         // [NW][4]
+        float* st_d = st_m + NW * 4;                             // [NW][4]
+        float (*st_o)[HD] = reinterpret_cast<float (*)[HD]>(st_d + NW * 4);   // [NW * 4][HD]
+        if (lane == 0) {
+#pragma unroll
+            for (int g = 0; g < QG; ++g) st_m[wave * 4 + g] = m[g], st_d[wave * 4 + g] = dt[g];
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int f = 32 * (t >> 1) + 8 * (2 * (t & 1) + (lane >> 3)) + KV_PERM[lane & 7];   // column `lane` of tile t (see the tile writes)
+#pragma unroll
+                for (int g = 0; g < QG; ++g) st_o[wave * 4 + g][f] = oacc[t][g] * 0.00390625f - zt[g];
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < QG * HD; idx += NW * 64) {
+            const int g = idx / HD, f = idx - g * HD;
+            float mm = st_m[g];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) mm = fmaxf(mm, st_m[w * 4 + g]);
+            float oo = 0.0f, dd = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float mw = st_m[w * 4 + g];
+                const float wt = mw == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(mw - mm);
+                oo = __builtin_fmaf(st_o[w * 4 + g][f], wt, oo);
+                dd = __builtin_fmaf(st_d[w * 4 + g], wt, dd);
+            }
+            const size_t oi = transpose_out ? ((size_t)b * HD + f) * QH + head + g : ((size_t)b * QH + head + g) * HD + f;
+            o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;
+        }
+        return;
     }
 #pragma unroll
     for (int g = 0; g < QG; ++g) {   // (QG > 1: the heads' states go through the same LDS one after the other)
@@ -778,7 +880,7 @@ int fq_kv_decode_splits(int batch, int num_heads, int seq_hint) {
 // Merged where it pays (measured, profiles/r06_gqa_cache.txt: a Llama-3-8B step 178 -> 161 us at 64 requests, 293 -> 261 at 128, but 65 -> 79 at
 // one request and 102 -> 111 at sixteen: a quarter of the workgroups, each with four times the p . v arithmetic): from one merged workgroup per CU on.
 #ifndef KV_MERGE_MIN_PAIRS
-#define KV_MERGE_MIN_PAIRS 256
+#define KV_MERGE_MIN_PAIRS 192   // (third session, with p . v of the merged launch on the matrix pipe: 24 requests x 8 KV heads 107.9 -> 98.6 us per step merged, 16 x 8 94.7 -> 105; r06c55)
 #endif
 #ifndef KV_MERGE_QG
 #define KV_MERGE_QG 0      // (measurement knob) 2: a group of four as TWO workgroups of two query heads (152 VGPRs: three waves per SIMD instead of two)
