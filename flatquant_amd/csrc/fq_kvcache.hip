@@ -402,7 +402,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
 #ifndef KV_PV_MFMA
 #define KV_PV_MFMA 1
 #endif
-    constexpr bool PVM = KV_PV_MFMA && QG == 4 && !F16 && UNI && !SPLIT;
+    constexpr bool PVM = KV_PV_MFMA && QG == 4 && !F16 && UNI;
     typedef __fp16 h4 __attribute__((__vector_size__(8)));
     typedef __attribute__((address_space(3))) h4 lds_h4;
     f32x4 oacc[PVM ? 8 : 1];
@@ -701,8 +701,54 @@ __global__ __launch_bounds__(NW * 64, 2) void fq_kv_decode_kernel(f16* __restric
                 oo = __builtin_fmaf(st_o[w * 4 + g][f], wt, oo);
                 dd = __builtin_fmaf(st_d[w * 4 + g], wt, dd);
             }
-            const size_t oi = transpose_out ? ((size_t)b * HD + f) * QH + head + g : ((size_t)b * QH + head + g) * HD + f;
-            o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;
+            if constexpr (!SPLIT) {
+                const size_t oi = transpose_out ? ((size_t)b * HD + f) * QH + head + g : ((size_t)b * QH + head + g) * HD + f;
+                o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;
+            } else {      // the workgroup's state of head g for the pair's last arriver (agent-scope stores: see the hand-over of the lane-state form below)
+                float* mine = kv_states(ws, (size_t)gridDim.x * QH) + (((size_t)b * QH + head + g) * gridDim.z + blockIdx.z) * (HD + 2);
+                if (f == 0) {
+                    __hip_atomic_store(mine, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(mine + 1, dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __hip_atomic_store(mine + 2 + f, oo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if constexpr (SPLIT) {
+            // the same hand-over as below, for the four heads at once: states in memory (vmcnt), then one arrival per head; the last arriver of a head merges
+            const int S = (int)gridDim.z;
+            unsigned* s_lastv = reinterpret_cast<unsigned*>(&st_o[NW * 4][0]);      // [4], behind the states
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid < QG)
+                s_lastv[tid] = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(ws) + (size_t)b * QH + head + tid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(S - 1);
+            __syncthreads();
+            for (int idx = tid; idx < QG * HD; idx += NW * 64) {
+                const int g = idx / HD, f = idx - g * HD;
+                if (!s_lastv[g]) continue;
+                const float* all = kv_states(ws, (size_t)gridDim.x * QH) + ((size_t)b * QH + head + g) * S * (HD + 2);
+                auto ld = [](const float* ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+                float mz[16], dz[16], oz[16];
+#pragma unroll
+                for (int z = 0; z < 16; ++z) {
+                    const float* st_z = all + (size_t)(z < S ? z : 0) * (HD + 2);
+                    mz[z] = ld(st_z), dz[z] = ld(st_z + 1), oz[z] = ld(st_z + 2 + f);
+                }
+                float mm = -INFINITY;
+#pragma unroll
+                for (int z = 0; z < 16; ++z) mm = z < S ? fmaxf(mm, mz[z]) : mm;
+                float dd = 0.0f, oo = 0.0f;
+#pragma unroll
+                for (int z = 0; z < 16; ++z) {
+                    const float wt = (z >= S || mz[z] == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(mz[z] - mm);
+                    dd += dz[z] * wt;
+                    oo += oz[z] * wt;
+                }
+                const size_t oi = transpose_out ? ((size_t)b * HD + f) * QH + head + g : ((size_t)b * QH + head + g) * HD + f;
+                o[oi] = dd > 0.0f ? (f16)(oo / dd) : (f16)0.0f;
+            }
+            __syncthreads();
+            if (tid < QG && s_lastv[tid])
+                __hip_atomic_store(reinterpret_cast<unsigned*>(ws) + (size_t)b * QH + head + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
@@ -880,7 +926,7 @@ int fq_kv_decode_splits(int batch, int num_heads, int seq_hint) {
 // Merged where it pays (measured, profiles/r06_gqa_cache.txt: a Llama-3-8B step 178 -> 161 us at 64 requests, 293 -> 261 at 128, but 65 -> 79 at
 // one request and 102 -> 111 at sixteen: a quarter of the workgroups, each with four times the p . v arithmetic): from one merged workgroup per CU on.
 #ifndef KV_MERGE_MIN_PAIRS
-#define KV_MERGE_MIN_PAIRS 192   // (third session, with p . v of the merged launch on the matrix pipe: 24 requests x 8 KV heads 107.9 -> 98.6 us per step merged, 16 x 8 94.7 -> 105; r06c55)
+#define KV_MERGE_MIN_PAIRS 128   // (third session, with p . v of the merged launch on the matrix pipe — split launches included: 24 requests x 8 KV heads 107.9 -> 98.6 us per step merged, 16 x 8 (two workgroups per pair) 95.0 -> 90.3, 8 x 8 75.8 -> 76.9: r06c55, r06c57)
 #endif
 #ifndef KV_MERGE_QG
 #define KV_MERGE_QG 0      // (measurement knob) 2: a group of four as TWO workgroups of two query heads (152 VGPRs: three waves per SIMD instead of two)
