@@ -1136,8 +1136,8 @@ int fq_kv_quant_append_i4(const void* k, const void* v, const void* trans, int64
     if (rc != FQ_OK) return rc;
     if (flags & ~FQ_KV_LAC) return fail(FQ_EINVAL, "fq_kv_quant_append_i4: unknown flags 0x%x", flags);
     if (tokens < 0 || src_heads <= 0 || tokens % batch_size) return fail(FQ_EINVAL, "fq_kv_quant_append_i4: tokens=%lld must be a multiple of batch_size=%d", (long long)tokens, batch_size);
-    if (group_size < 1 || group_size > 4 || src_heads * group_size != num_heads)
-        return fail(FQ_EINVAL, "fq_kv_quant_append_i4: num_heads=%d must be src_heads=%d x group_size=%d (<= 4)", num_heads, src_heads, group_size);
+    if (group_size < 1 || group_size > 8 || src_heads * group_size != num_heads)
+        return fail(FQ_EINVAL, "fq_kv_quant_append_i4: num_heads=%d must be src_heads=%d x group_size=%d (<= 8)", num_heads, src_heads, group_size);
     if (tokens == 0) return FQ_OK;
     if (!k || !v || !kv_data || !kv_param || !kv_indptr || !kv_indices || !last_page_offset)
         return fail(FQ_EINVAL, "fq_kv_quant_append_i4: NULL pointer");
@@ -1247,8 +1247,8 @@ int fq_kv_decode_append_i4(void* o, const void* q, const void* q_trans, int tran
     if (rc != FQ_OK) return rc;
     if (q_group < 1 || q_group > 64) return fail(FQ_EINVAL, "%s: q_group=%d out of [1, 64]", what, q_group);
     if (head_dim != 128 || page_size % 16) return fail(FQ_EUNSUPPORTED, "%s: head_dim=%d, page_size=%d: needs head_dim 128 and page_size %% 16 == 0 (use fq_kv_quant_append_i4 + the decode launch)", what, head_dim, page_size);
-    if (src_heads < 1 || num_kv_heads % src_heads || num_kv_heads / src_heads > 4)
-        return fail(FQ_EINVAL, "%s: num_kv_heads=%d must be src_heads=%d x a group of at most 4", what, num_kv_heads, src_heads);
+    if (src_heads < 1 || num_kv_heads % src_heads || num_kv_heads / src_heads > 8)
+        return fail(FQ_EINVAL, "%s: num_kv_heads=%d must be src_heads=%d x a group of at most 8", what, num_kv_heads, src_heads);
     if (!o || !q || !k_new || !v_new || !kv_data || !kv_param || !kv_indptr || !kv_indices || !last_page_offset)
         return fail(FQ_EINVAL, "%s: NULL pointer", what);
     FQ_NEED_ALIGN16(what, kv_data, q_trans, workspace, k_new, v_new, k_trans_image);
@@ -1275,7 +1275,7 @@ int fq_kv_batch_decode_copies(int fp16_cache, void* o, const void* q, const void
     const char* what = "fq_kv_batch_decode_copies";
     int rc = kv_geometry_ok(what, num_layers, layer_idx, num_heads, page_size, head_dim, batch_size);
     if (rc != FQ_OK) return rc;
-    if (copies < 1 || copies > 4 || num_heads % copies) return fail(FQ_EINVAL, "%s: copies=%d must be 1..4 and divide num_heads=%d", what, copies, num_heads);
+    if (copies < 1 || copies > 8 || num_heads % copies) return fail(FQ_EINVAL, "%s: copies=%d must be 1..8 and divide num_heads=%d", what, copies, num_heads);
     if (!o || !q || !kv_data || (!fp16_cache && !kv_param) || !kv_indptr || !kv_indices || !last_page_offset)
         return fail(FQ_EINVAL, "%s: NULL pointer", what);
     FQ_NEED_ALIGN16(what, kv_data, q_trans, workspace);

@@ -932,8 +932,10 @@ int fq_kv_decode_splits(int batch, int num_heads, int seq_hint) {
 #define KV_MERGE_QG 0      // (measurement knob) 2: a group of four as TWO workgroups of two query heads (152 VGPRs: three waves per SIMD instead of two)
 #endif
 int fq_kv_decode_wg_heads(int batch, int num_q_heads, int q_group, int head_dim) {
-    const bool merge = KV_MERGE_HEADS && head_dim == 128 && (q_group == 2 || q_group == 4) && (int64_t)batch * (num_q_heads / q_group) >= KV_MERGE_MIN_PAIRS;
+    // (a group of EIGHT — Llama-2/3-70B — runs as two workgroups of four query heads: the kernel only needs its QG heads to lie inside one group)
+    const bool merge = KV_MERGE_HEADS && head_dim == 128 && (q_group == 2 || q_group == 4 || q_group == 8) && (int64_t)batch * (num_q_heads / q_group) >= KV_MERGE_MIN_PAIRS;
     if (KV_MERGE_QG == 2 && merge && q_group == 4) return num_q_heads / 2;
+    if (merge && q_group == 8) return num_q_heads / 4;
     return merge ? num_q_heads / q_group : num_q_heads;
 }
 int64_t fq_kv_decode_ws_bytes_gqa(int batch, int num_q_heads, int q_group, int head_dim) {
@@ -954,7 +956,7 @@ int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, con
     // num_heads: QUERY heads (q, o); qgroup of them share one set of rows; the cache holds (num_heads / qgroup) * copies heads: copies = 1 and
     // qgroup = 1 the reference's layout read head by head, copies = 1 and qgroup = g a cache that holds the KV heads once, copies = qgroup = g the
     // reference's layout (g identical copies per KV head) read ONE copy per group
-    if (splits > 16 || qgroup < 1 || num_heads % qgroup || copies < 1 || copies > 4) return -1000;   // (the merge of the split launch reads at most 16 states: fq_kv_decode_splits never returns more)
+    if (splits > 16 || qgroup < 1 || num_heads % qgroup || copies < 1 || copies > 8) return -1000;   // (the merge of the split launch reads at most 16 states: fq_kv_decode_splits never returns more)
     PagedKv p = make_kv(kv_data, kv_param, indptr, indices, last, num_layers, layer_idx, num_heads / qgroup * copies, page_size, head_dim, batch);
     p.copies = copies;
     const bool split = ws != nullptr && splits > 1;

@@ -116,11 +116,11 @@ __global__ __launch_bounds__(256) void fq_kv_quant_kernel(KvIO io, const f16* __
     for (int64_t tile = (int64_t)blockIdx.x * 4 + (tid >> 6); tile < n_tiles; tile += tstep) {
         const int64_t row = tile * 32 + c;
         const bool ok = row < rows;
-        uint8_t* qdst[4];
-        unsigned* pdst[4];
+        uint8_t* qdst[8];      // (up to eight copies per source head: Llama-2/3-70B have 64 query heads on 8 KV heads)
+        unsigned* pdst[8];
         const int ndst = dn.n;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < 8; ++g) {
             qdst[g] = dn.q + (size_t)g * io.page_size * (HD / 2);
             pdst[g] = dn.p + (size_t)g * io.page_size;
         }
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void fq_kv_quant_kernel(KvIO io, const f16* __
             const unsigned w1 = kv_q8<LAC>(pr[4], pr[5], pr[6], pr[7], rc, sc, zero2);
             if (ok) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                for (int g = 0; g < 8; ++g) {
                     if (g >= ndst) break;
                     if (TRANS && do_trans) {
                         *reinterpret_cast<uint2*>(qdst[g] + nt * 16 + 8 * h) = make_uint2(w0, w1);
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void fq_kv_quant_kernel(KvIO io, const f16* __
         if (ok && h == 0) {
             const unsigned short s16 = __builtin_bit_cast(unsigned short, p.scale), z16 = __builtin_bit_cast(unsigned short, p.zero);
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 8; ++g)
                 if (g < ndst) *pdst[g] = (unsigned)s16 | ((unsigned)z16 << 16);
         }
     }
@@ -306,7 +306,7 @@ int fq_launch_kv_quant_append(const f16* k, const f16* v, const f16* T, int64_t 
                               bool lac, void* kv_data, void* kv_param, const int* indptr, const int* indices, const int* last,
                               int num_layers, int layer_idx, int num_heads, int page_size, int added, int group, int n_cu,
                               hipStream_t stream) {
-    if (group < 1 || group > 4 || src_heads * group != num_heads || added < 1) return -1000;
+    if (group < 1 || group > 8 || src_heads * group != num_heads || added < 1) return -1000;
     KvIO io = {};
     io.x[0] = k;
     io.x[1] = v;

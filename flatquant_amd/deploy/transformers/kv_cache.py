@@ -316,10 +316,10 @@ class MultiLayerPagedKVCache4Bit:
             key_states = ops.hadamard(key_states.to(torch.float16).contiguous())
         ragged_init = init and mask is not None
         # the reference's replicated layout: group_size identical copies per KV head, one of them read (read_one_copy)
-        copies = self.group_size if (self.read_one_copy and 1 < self.group_size <= 4 and n_q_is_cache_heads(specs["kv_data"], heads, self.group_size)) else 1
+        copies = self.group_size if (self.read_one_copy and 1 < self.group_size <= 8 and n_q_is_cache_heads(specs["kv_data"], heads, self.group_size)) else 1
         wgs = b * specs["kv_data"].shape[3]                 # workgroups of the decode launch: one per (request, cache head) ...
-        if copies in (2, 4) and hd == 128 and wgs // copies >= 128:     # (KV_MERGE_MIN_PAIRS of fq_kvcache.hip)
-            wgs //= copies                                  # ... or per (request, KV head) where one workgroup serves the group (fq_kv_decode_wg_heads)
+        if copies in (2, 4, 8) and hd == 128 and wgs // copies >= 128:     # (KV_MERGE_MIN_PAIRS of fq_kvcache.hip)
+            wgs //= min(copies, 4)                          # ... or per (request, KV head) where one workgroup serves the group — up to four heads (fq_kv_decode_wg_heads)
         fused = (self.fuse_append and not init and added == 1 and not self.disable_quant and key_states.dtype == torch.float16
                  and wgs <= FUSE_APPEND_MAX_PAIRS
                  and value_states.dtype == torch.float16 and ops.kv_decode_append_supported(specs["kv_data"], heads))

@@ -1772,8 +1772,8 @@ def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tens
         raise ValueError(f"q must be [{batch}, a multiple of {kv_heads}, {hd}]")
     heads = q.shape[1]
     q_group = heads // kv_heads
-    if kv_copies > 1 and (q_group != 1 or kv_heads % kv_copies or kv_copies > 4):
-        raise ValueError(f"kv_copies={kv_copies}: needs a replicated cache (query heads == cache heads == {kv_heads}) in groups of at most 4")
+    if kv_copies > 1 and (q_group != 1 or kv_heads % kv_copies or kv_copies > 8):
+        raise ValueError(f"kv_copies={kv_copies}: needs a replicated cache (query heads == cache heads == {kv_heads}) in groups of at most 8")
     if q_trans is not None:
         _chk(q_trans, "q_trans")
         if q_trans.shape != (hd, hd):
@@ -1909,11 +1909,11 @@ def kv_decode_append(q: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor, 
 
 
 def kv_decode_append_supported(kv_data: torch.Tensor, src_heads: int) -> bool:
-    """Does fq_kv_decode_append_i4 take this cache? (INT4 pages, head_dim 128, a wave's 16 rows never straddle a page, at most 4 copies per head)"""
+    """Does fq_kv_decode_append_i4 take this cache? (INT4 pages, head_dim 128, a wave's 16 rows never straddle a page, at most 8 copies per head)"""
     if kv_data.dtype != torch.uint8:
         return False
     _, cache_heads, page_size, hd = _kv_geometry(kv_data)
-    return hd == 128 and page_size % 16 == 0 and src_heads > 0 and cache_heads % src_heads == 0 and cache_heads // src_heads <= 4
+    return hd == 128 and page_size % 16 == 0 and src_heads > 0 and cache_heads % src_heads == 0 and cache_heads // src_heads <= 8
 
 
 def int4_matmul(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:

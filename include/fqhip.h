@@ -600,7 +600,7 @@ int fq_kv_append_i4(void* kv_data, void* kv_param, const void* kv_indptr, const 
  * launch instead of two quantiser launches and the append: k, v [tokens, src_heads, head_dim] fp16 with
  * tokens = batch_size * added (every request appends the same number of tokens, request-major, at the END of its
  * current length, as fq_kv_append_i4 with seqlen_indptr = added * arange); num_heads = src_heads * group_size cache heads,
- * group_size <= 4. clip = {k_max, k_min, v_max, v_min} (sigmoid-ed; used with FQ_KV_LAC) or NULL. Same bits in the cache
+ * group_size <= 8. clip = {k_max, k_min, v_max, v_min} (sigmoid-ed; used with FQ_KV_LAC) or NULL. Same bits in the cache
  * as fq_kv_quant_f16 x 2 + fq_kv_append_i4.
  */
 int fq_kv_quant_append_i4(const void* k, const void* v, const void* trans, int64_t tokens, int src_heads, int head_dim,
@@ -640,7 +640,7 @@ int fq_kv_batch_decode_gqa(int fp16_cache, void* o, const void* q, const void* q
  * (fq_kv_transform_image_bytes(head_dim) bytes, once per layer; NULL: keys are not transformed — trans "had" / none). The workgroup that owns a
  * request's last row quantises the new row with fq_kv_quant_append_i4's arithmetic (lac off, as the cache's own calls), uses it from LDS and
  * writes it to the cache: the cache contents and o are bit-identical to fq_kv_quant_append_i4 followed by fq_kv_batch_decode_gqa.
- * The cache holds num_kv_heads heads = src_heads x group (group <= 4: the reference's replicated layout has num_kv_heads = query heads and
+ * The cache holds num_kv_heads heads = src_heads x group (group <= 8: the reference's replicated layout has num_kv_heads = query heads and
  * q_group = 1; a shared cache num_kv_heads = src_heads). head_dim 128 and page_size % 16 == 0 only (FQ_EUNSUPPORTED otherwise).
  * Everything else as fq_kv_batch_decode_gqa. */
 int64_t fq_kv_transform_image_bytes(int head_dim);

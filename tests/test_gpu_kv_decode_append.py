@@ -40,6 +40,8 @@ CASES = [
     (32, [300 + 7 * i for i in range(32)], 8, 1, 4, 64, True),   # shared cache, 256 (request, KV head) pairs: one workgroup serves 4 query heads
     (40, [70 + i for i in range(40)], 8, 1, 2, 16, False),       # ... 2 query heads
     (9, [50 + 3 * i for i in range(9)], 2, 4, 1, 16, True),      # 72 pairs, short rows: split count limited by the length hint
+    (2, [600, 90], 8, 8, 1, 32, True),                           # groups of EIGHT copies (Llama-2/3-70B: 64 query heads on 8 KV heads)
+    (20, [200 + i for i in range(20)], 8, 1, 8, 64, True),       # ... on the shared cache: 160 (request, KV head) pairs, two workgroups of four heads per group
 ]
 
 
@@ -131,7 +133,9 @@ def test_unsupported_geometries_are_refused(ops):
     assert not ops.kv_decode_append_supported(data64, 2)
     assert not ops.kv_decode_append_supported(torch.zeros(2, 1, 2, 2, 16, 128, dtype=torch.float16, device="cuda"), 2)   # the fp16 configuration
     ok, _, _, _, _ = _cache(g, 1, [20], 8, 16)
-    assert ops.kv_decode_append_supported(ok, 2) and not ops.kv_decode_append_supported(ok, 1) and not ops.kv_decode_append_supported(ok, 3)
+    assert ops.kv_decode_append_supported(ok, 2) and ops.kv_decode_append_supported(ok, 1) and not ops.kv_decode_append_supported(ok, 3)   # (8 = 1 x 8 copies: supported since groups of eight are)
+    big, _, _, _, _ = _cache(g, 1, [20], 16, 16)
+    assert not ops.kv_decode_append_supported(big, 1)                                                      # sixteen copies are not
 
 
 @pytest.mark.parametrize("trans", ["matmul", "had", "none"])
@@ -261,7 +265,7 @@ def _replicated(g, bsz, lens, kv_heads, copies, page, f16=False, hd=128, layers=
 @pytest.mark.parametrize("f16", [False, True])
 @pytest.mark.parametrize("bsz,lens,kv_heads,copies,page", [(1, [2048], 8, 4, 2048), (2, [700, 333], 2, 2, 16), (16, [500 + i for i in range(16)], 8, 4, 64),
                                                            (32, [300 + 7 * i for i in range(32)], 8, 4, 64), (130, [40 + i for i in range(130)], 2, 2, 16),
-                                                           (3, [1, 16, 17], 4, 3, 16)])
+                                                           (3, [1, 16, 17], 4, 3, 16), (2, [900, 333], 8, 8, 64), (17, [150 + 9 * i for i in range(17)], 8, 8, 32)])
 def test_replicated_cache_read_one_copy_is_bit_identical(ops, f16, bsz, lens, kv_heads, copies, page):
     """ops.kv_batch_decode(kv_copies=g) on a cache whose g copies per KV head are identical == the launch that reads every head's own copy:
     bit for bit where the launch geometry is the same (split launches, a workgroup per query head); from 128 (request, KV head) pairs on ONE
@@ -276,7 +280,7 @@ def test_replicated_cache_read_one_copy_is_bit_identical(ops, f16, bsz, lens, kv
     for tr in (False, True):
         o1 = ops.kv_batch_decode(q, data, param, indptr, indices, last, layer, qt, tr, seq_hint=max(lens))
         o2 = ops.kv_batch_decode(q, data, param, indptr, indices, last, layer, qt, tr, seq_hint=max(lens), kv_copies=copies)
-        if copies in (2, 4) and bsz * kv_heads >= 128:
+        if copies in (2, 4, 8) and bsz * kv_heads >= 128:
             assert ((o1.float() - o2.float()).abs().amax() / o1.float().abs().amax()).item() <= 1e-3
         else:
             assert torch.equal(o1, o2)
@@ -285,7 +289,7 @@ def test_replicated_cache_read_one_copy_is_bit_identical(ops, f16, bsz, lens, kv
 
 
 @pytest.mark.parametrize("bsz,lens,kv_heads,copies,page", [(1, [2048], 8, 4, 2048), (4, [31, 32, 33, 48], 2, 2, 16), (16, [900 + i for i in range(16)], 8, 4, 64),
-                                                           (64, [100 + i for i in range(64)], 8, 4, 32)])
+                                                           (64, [100 + i for i in range(64)], 8, 4, 32), (3, [70, 300, 33], 8, 8, 16), (16, [260 + i for i in range(16)], 8, 8, 32)])
 def test_decode_append_read_one_copy_writes_every_copy(ops, bsz, lens, kv_heads, copies, page):
     """cache bytes and parameters of EVERY copy bit for bit; the output bit for bit unless one workgroup serves the group (see above)"""
     g = torch.Generator(device="cuda").manual_seed(bsz * 7 + kv_heads)
@@ -331,6 +335,34 @@ def test_cache_class_read_one_copy_equals_reading_every_copy(ops, disable_quant)
         q1 = torch.randn(bsz, 1, heads, hd, generator=g, device="cuda").half()
         o = [c.update(k1, v1, 0, dict(kw))(q1) for c in caches]
         assert ((o[0].float() - o[1].float()).abs().amax() / o[1].float().abs().amax()).item() <= 1e-3, step      # (320 pairs: one workgroup per group)
+    used = caches[0].page_cnt_from_length(caches[0].length) * bsz
+    assert torch.equal(caches[0].pages[:used], caches[1].pages[:used])
+    assert torch.equal(caches[0].scales[:used].view(torch.int16), caches[1].scales[:used].view(torch.int16))
+
+
+def test_cache_class_groups_of_eight(ops):
+    """64 query heads on 8 KV heads (Llama-2/3-70B): the replicated layout (eight copies written, one read, fused append) against the two-launch,
+    every-copy reading — same pages, outputs within the fp32-order tolerance; the shared cache agrees with both"""
+    import flatquant_amd.deploy.transformers as dt
+    g = torch.Generator(device="cuda").manual_seed(11)
+    bsz, prompt, kv_heads, group, hd, page = 3, 50, 8, 8, 128, 16
+    heads = kv_heads * group
+    tk = (torch.randn(hd, hd, generator=g, device="cuda") / hd ** 0.5).half()
+    kw = {"trans_matrix_k": tk, "trans_matrix_k_inv_t": tk}
+    mk = lambda **k: dt.MultiLayerPagedKVCache4Bit(bsz, page, prompt + 8, torch.device("cuda"), 1, heads, hd, trans="matmul", group_size=group, **k)
+    caches = [mk(), mk(read_one_copy=False, fuse_append=False), mk(share_kv_heads=True)]
+    for c in caches:
+        c.pages.zero_(), c.scales.zero_()
+    k0 = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+    v0 = torch.randn(bsz, prompt, kv_heads, hd, generator=g, device="cuda").half()
+    for c in caches:
+        c.update(k0, v0, 0, dict(kw))
+    for step in range(3):
+        k1 = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+        v1 = torch.randn(bsz, 1, kv_heads, hd, generator=g, device="cuda").half()
+        q1 = torch.randn(bsz, 1, heads, hd, generator=g, device="cuda").half()
+        o = [c.update(k1, v1, 0, dict(kw))(q1) for c in caches]
+        assert torch.equal(o[0], o[1]) and torch.equal(o[0], o[2]), step          # (24 (request, KV head) pairs: a workgroup per query head everywhere)
     used = caches[0].page_cnt_from_length(caches[0].length) * bsz
     assert torch.equal(caches[0].pages[:used], caches[1].pages[:used])
     assert torch.equal(caches[0].scales[:used].view(torch.int16), caches[1].scales[:used].view(torch.int16))

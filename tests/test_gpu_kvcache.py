@@ -137,7 +137,7 @@ def test_errors(ops):
 
 
 @pytest.mark.parametrize("hd,kv_heads,group,added,lac", [(128, 2, 2, 21, False), (128, 8, 4, 1, False), (64, 3, 1, 5, True),
-                                                        (128, 1, 3, 1, True)])
+                                                        (128, 1, 3, 1, True), (128, 8, 8, 1, False), (128, 2, 8, 9, True)])   # (groups of 8: Llama-2/3-70B)
 def test_fused_quantise_and_append_equals_the_three_launches(ops, hd, kv_heads, group, added, lac):
     """fq_kv_quant_append_i4 == fq_kv_quant_f16 (keys, with the transform) + fq_kv_quant_f16 (values) + fq_kv_append_i4
     with the GQA repeat: identical cache bytes and parameters."""
