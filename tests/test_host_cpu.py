@@ -617,11 +617,12 @@ def test_hot_kernels_keep_their_occupancy_budget():
         "fq_kv_decode_kernel<128,8,1,0,1,1,0>": (4, 0),     # ... a request's rows split over several workgroups
         "fq_kv_decode_kernel<128,4,0,0,0,1,0>": (4, 0),     # ... pages a wave's rows can straddle
         "fq_kv_decode_kernel<128,4,1,1,0,1,0>": (3, 0),     # ... the fp16 configuration of the cache
-        "fq_kv_decode_kernel<128,4,1,0,0,4,0>": (2, 0),     # (round 6) ... four query heads of a shared KV head per workgroup: four softmax states per lane
-        "fq_kv_decode_kernel<128,8,1,0,1,4,0>": (2, 0),
+        "fq_kv_decode_kernel<128,4,1,0,0,4,0>": (4, 6),     # (round 6) ... four query heads of a KV head per workgroup; third session: p . v on the matrix pipe, held to 128 VGPRs
+        "fq_kv_decode_kernel<128,8,1,0,1,4,0>": (4, 6),     # (four waves per SIMD; the few spilled registers live outside the row loop: checked in the ISA)
+        "fq_kv_decode_kernel<128,8,1,0,0,4,0>": (4, 6),     # ... the eight-wave form, up to 1024 workgroups
         "fq_kv_decode_kernel<128,4,1,0,0,1,1>": (4, 0),   # (round 6, third session) ... that quantise and append the step's own K / V row (fq_kv_decode_append_i4): prologue only, same budget
         "fq_kv_decode_kernel<128,8,1,0,1,1,1>": (4, 0),
-        "fq_kv_decode_kernel<128,4,1,0,0,4,1>": (2, 0),
+        "fq_kv_decode_kernel<128,4,1,0,0,4,1>": (4, 6),
         "fq_rowquant_wave_kernel<33,8,0,f16>": (4, 0),    # deploy Quantizer at 4096
         "fq_rowquant_wave_kernel<2,8,0,bf16>": (2, 0),    # ActivationQuantizer on bf16 rows of 4096
         "fq_had_pow2_kernel<8,1,1,1>": (3, 0),            # Hadamard 4096 + Quantizer
@@ -644,6 +645,9 @@ def test_hot_kernels_keep_their_occupancy_budget():
                "fq_kron_fast_kernel<6,6,11,8,1,0,-1,0,bf16,0,0>", "fq_kron_fast_kernel<6,6,11,8,1,0,1,0,f16,0,0>",
                "fq_kron_fast_kernel<6,6,11,8,1,0,33,0,f16,0,0>", "fq_kron_trio_kernel<4,1,1>", "fq_kron_wave_kernel<2,2,4,16,0,f16,1>",
                "fq_kron_duo_kernel<4>"}
+    # (third session of round 6) the merged decode-attention launch with p . v on the matrix pipe is HELD to 128 VGPRs for four waves per SIMD
+    # (KV_PVM_OCC4): two to six registers of its prologue / merge spill, none inside the row loop (checked in the ISA; measured a gain)
+    allowed |= {f"fq_kv_decode_kernel<128,{nw},1,0,{sp},4,{ap}>" for nw in (4, 8) for sp in (0, 1) for ap in (0, 1)}
     spilling = {k for k, r in res.items() if r.get("vgpr_spill", 0) > 0}
     assert spilling <= allowed, sorted(spilling - allowed)
 
