@@ -560,6 +560,8 @@ __global__ __launch_bounds__(NW * 64, (KV_PVM_OCC4 && KV_PV_MFMA && QG == 4 && !
             for (int w = 0; w < 4; ++w) {      // dword w's eight values (feature order KV_PERM) -> tile 2 part + w / 2, row `slot`, columns 8 (w % 2) ..
                 uint32_t u[4];
                 kv_unpack8(vw[w], ebits, u);
+// (the strided 16-byte writes conflict two ways; swapping the halves of rows 4..7 / 12..15 — un-swizzled by the readers' own addresses — took
+                //  SQ_LDS_BANK_CONFLICT from 2.69 M to 0.59 M per launch and the launch from 33.8 to 34.2 us: LDS is not what the step waits for. Not kept: r06c64)
                 *reinterpret_cast<u32x4*>(pv_vt + (2 * part + (w >> 1)) * 512 + slot * 32 + (w & 1) * 16) = u32x4{u[0], u[1], u[2], u[3]};
             }
             const f16x4 pa = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4*)(pv_pt + 8 * lane)));
