@@ -84,6 +84,8 @@ SYMBOLS = {
     "fq_int4_to_frag": (_i, [_vp, _i, _i, _vp, _vp]),
     "fq_int4_skinny_gemm_i32": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "fq_int4_skinny_linear_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
+    "fq_int4_skinny_split_workspace_bytes": (_i64, [_i64, _i, _i]),
+    "fq_int4_skinny_linear_split_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _i64, _vp]),
     "fq_int4_skinny_linear_multi_f16": (_i, [_i, _vpp, _vpp, _vpp, _vpp, _vpp, _i64, _ip, _i, _vpp, _vp]),
     "fq_kron64_linear_multi_f16": (_i, [_vp, _i, _f, _vp, _vp, _i64, _i, _fp, _fp, _i, _vpp, _vpp, _vpp, _ip, _vpp, _vp, _i64, _vp]),
     "fq_bf6_blob_bytes": (_i64, [_i64, _i]),

@@ -47,6 +47,9 @@ int64_t fq_i4_frag_bytes(int N, int K);
 int fq_launch_i4_to_frag(const uint8_t* W, int N, int K, void* img, int n_cu, hipStream_t stream);
 int fq_launch_gemm_i4_skinny_multi(int n, const uint8_t* const* X, const void* const* wimg, int64_t M, const int* N, int K, f16* const* y,
                                    const f16* const* srow, const f16* const* scol, const f16* const* bias, hipStream_t stream);
+int64_t fq_gemm_i4_skinny_split_ws_bytes(int64_t M, int N, int K);
+int fq_launch_gemm_i4_skinny_split(const uint8_t* X, const void* wimg, int64_t M, int N, int K, f16* y, const f16* srow, const f16* scol,
+                                   const f16* bias, int* kws, hipStream_t stream);
 int fq_launch_gemm_i4_skinny(const uint8_t* X, const void* wimg, int64_t M, int N, int K, int32_t* c, f16* y, const f16* srow,
                              const f16* scol, const f16* bias, hipStream_t stream);
 int64_t fq_bf6_blob_bytes(int64_t rows, int K);  // fq_gemm_bf6.hip (exported as is)
@@ -775,6 +778,27 @@ int fq_int4_skinny_linear_f16(const void* x, const void* x_scale, const void* w_
                                             (const f16*)w_scale, (const f16*)bias, (hipStream_t)stream);
     if (rc == -1000) return fail(FQ_EUNSUPPORTED, "fq_int4_skinny_linear_f16: M=%lld K=%d (M <= 128, K %% 64 == 0)", (long long)M, K);
     return check_launch(rc, "fq_int4_skinny_linear_f16");
+}
+
+int64_t fq_int4_skinny_split_workspace_bytes(int64_t M, int N, int K) {
+    if (M < 0 || N <= 0 || K <= 0) return -1;
+    return fq_gemm_i4_skinny_split_ws_bytes(M, N, K);
+}
+
+int fq_int4_skinny_linear_split_f16(const void* x, const void* x_scale, const void* w_image, const void* w_scale, const void* bias, int64_t M, int N,
+                                    int K, void* y, void* workspace, int64_t workspace_bytes, void* stream) {
+    const char* what = "fq_int4_skinny_linear_split_f16";
+    if (M < 0 || N <= 0 || K <= 0) return fail(FQ_EINVAL, "%s: bad sizes", what);
+    if (M == 0) return FQ_OK;
+    if (!x || !w_image || !y || !x_scale || !w_scale) return fail(FQ_EINVAL, "%s: NULL pointer", what);
+    FQ_NEED_ALIGN16(what, workspace);
+    const int64_t need = fq_gemm_i4_skinny_split_ws_bytes(M, N, K);
+    if (workspace && need > 0 && workspace_bytes < need)
+        return fail(FQ_EINVAL, "%s: workspace of %lld bytes, fq_int4_skinny_split_workspace_bytes says %lld", what, (long long)workspace_bytes, (long long)need);
+    const int rc = fq_launch_gemm_i4_skinny_split((const uint8_t*)x, w_image, M, N, K, (f16*)y, (const f16*)x_scale, (const f16*)w_scale, (const f16*)bias,
+                                                  need > 0 ? (int*)workspace : nullptr, (hipStream_t)stream);
+    if (rc == -1000) return fail(FQ_EUNSUPPORTED, "%s: M=%lld K=%d (M <= 128, K %% 64 == 0)", what, (long long)M, K);
+    return check_launch(rc, what);
 }
 
 int fq_int4_skinny_linear_multi_f16(int n, const void* const* x, const void* const* x_scale, const void* const* w_image,

@@ -284,10 +284,16 @@ struct SkinnyProblems {
     int n;
 };
 
-template <int MT, bool MULTI, int U = 1>
+// KSP (round 6, third session): THE K RANGE OF A FEATURE TILE OVER gridDim.y WORKGROUPS. A lone 4096-wide projection is 128 feature tiles — half the
+// CUs — and at 33 .. 128 rows its workgroups are busy with the int8 MFMAs and the nibble unpacking of two to four token tiles (down_proj, K = 14336:
+// 14.6 us at 64 rows, 26.3 at 128: 2.0 / 1.1 TB/s of weights). With KSP every tile's 64-k blobs are split over 2 (4) workgroups; a workgroup leaves
+// its int32 partial tile in `kws` (agent-scope stores, as the split decode attention's states), takes a ticket on the tile's counter, and the LAST to
+// arrive adds the others' partials to its own and runs the epilogue. Integer sums: the result is the unsplit launch's bit for bit, whatever the order.
+// kws: [tiles] counters (left at zero), then [gridDim.y][tiles][MT * 1024] partial sums.
+template <int MT, bool MULTI, int U = 1, bool KSP = false>
 __global__ __launch_bounds__(SK_WAVES * 64) void fq_gemm_i4_skinny_kernel(const uint8_t* __restrict__ X_,
                                                                          const uint4* __restrict__ Wimg_, int M, int N_,
-                                                                         int Kb, GemmOut out_, SkinnyProblems pr) {
+                                                                         int Kb, GemmOut out_, SkinnyProblems pr, int* __restrict__ kws = nullptr) {
     __shared__ int tile[MT][32][33];  // [token tile][token][feature], +1 padding
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -334,21 +340,47 @@ __global__ __launch_bounds__(SK_WAVES * 64) void fq_gemm_i4_skinny_kernel(const 
     // 448 workgroups, the q/k/v and up/gate groups); a 4096-wide projection alone is 128 workgroups with ONE 1 KB load per wave in
     // flight, 2 MB on the whole chip: latency-bound at 1.9-3.3 TB/s — there U = 2 (measured with the knob on every launch, per-dispatch
     // durations: 7.56 -> 5.8 us on the N = 4096 launches, slower on N = 1024 and 14336: profiles/r05_skinny_prefetch.txt).
-    int kb = wave;
-    for (; kb + (U - 1) * SK_WAVES < KB; kb += U * SK_WAVES) {
+    int kb = wave, kb_end = KB;
+    if constexpr (KSP) {       // this workgroup's share of the tile's blobs
+        const int per = (KB + (int)gridDim.y - 1) / (int)gridDim.y;
+        kb = (int)blockIdx.y * per + wave;
+        kb_end = ((int)blockIdx.y + 1) * per < KB ? ((int)blockIdx.y + 1) * per : KB;
+    }
+    const int KB_ = kb_end;
+    for (; kb + (U - 1) * SK_WAVES < KB_; kb += U * SK_WAVES) {
         u32x4 a_[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) a_[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)(kb + u * SK_WAVES) * 64));
 #pragma unroll
         for (int u = 0; u < U; ++u) block(kb + u * SK_WAVES, a_[u]);
     }
-    for (; kb < KB; kb += SK_WAVES) block(kb, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)kb * 64)));
+    for (; kb < KB_; kb += SK_WAVES) block(kb, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)kb * 64)));
     // lane (h, c) of tile mt: token 32 mt + c, features 16 h + r
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) atomicAdd(&tile[mt][c][16 * h + r], acc[mt][r]);
     __syncthreads();
+    if constexpr (KSP) {
+        const int S = (int)gridDim.y, tiles = (int)gridDim.x;
+        int* part = kws + tiles + ((size_t)blockIdx.y * tiles + rt) * (MT * 1024);
+        for (int i = tid; i < MT * 1024; i += SK_WAVES * 64)
+            __hip_atomic_store(part + i, tile[i >> 10][(i >> 5) & 31][i & 31], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __shared__ unsigned s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partial tile has reached memory (gfx9 counts stores in vmcnt) ...
+        __syncthreads();
+        if (tid == 0) s_last = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(kws) + rt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(S - 1);   // ... before it is counted
+        __syncthreads();
+        if (!s_last) return;
+        for (int i = tid; i < MT * 1024; i += SK_WAVES * 64) {
+            int v = 0;
+            for (int z = 0; z < S; ++z)
+                if (z != (int)blockIdx.y) v += __hip_atomic_load(kws + tiles + ((size_t)z * tiles + rt) * (MT * 1024) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tile[i >> 10][(i >> 5) & 31][i & 31] += v;
+        }
+        if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(kws) + rt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch finds the counter as this one did
+        // (each thread adds into and then reads its OWN elements: the element loop below walks the same indices)
+    }
     for (int i = tid; i < MT * 32 * 32; i += SK_WAVES * 64) {
         const int mt = i >> 10, tok = (i >> 5) & 31, nl = i & 31;
         const int m = mt * 32 + tok, n = rt * 32 + nl;
@@ -419,6 +451,48 @@ int fq_launch_gemm_i4_skinny(const uint8_t* X, const void* wimg, int64_t M, int 
     else if (M <= 32) hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<1, false>), grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o, none);
     else if (M <= 64) hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<2, false>), grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o, none);
     else hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<4, false>), grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o, none);
+    return (int)hipGetLastError();
+}
+
+// How many workgroups share a feature tile's K range (1: the launch is not split), and the workspace the split launch needs. Split where the
+// unsplit launch leaves CUs idle (at most 128 feature tiles) AND either its workgroups are busy with more than one token tile (33 rows or more) or the K
+// range is long; at least two rounds of blobs per workgroup of a split (measured: profiles/r06_skinny_ksplit.txt).
+int fq_gemm_i4_skinny_splits(int64_t M, int N, int K) {
+    const int tiles = (N + 31) / 32, KB = K / 64;
+    if (M < 1 || M > 128 || tiles > 128 || (K & 63)) return 1;
+    // up to 32 rows (one token tile: the launch is latency-, not arithmetic-bound) only a long K range pays for the hand-over: measured on a 4096-wide
+    // projection (r06c69) K = 14336: 8.5 -> 8.8 us at one row, 11.2 -> 9.4 at 16, 15.8 -> 11.3 at 32; K = 28672: 16.6 -> 13.3 at one row, 30.6 -> 18.5 at 32
+    if (M < 33 && (K < 8192 || (M < 9 && K < 16384))) return 1;
+    int s = tiles <= 64 ? 4 : 2;
+    while (s > 1 && KB / s < 2 * SK_WAVES) s >>= 1;
+    return s;
+}
+int64_t fq_gemm_i4_skinny_split_ws_bytes(int64_t M, int N, int K) {
+    const int s = fq_gemm_i4_skinny_splits(M, N, K);
+    if (s <= 1) return 0;
+    const int64_t tiles = (N + 31) / 32, mt = M <= 32 ? 1 : M <= 64 ? 2 : 4;
+    return (((tiles + 3) & ~(int64_t)3) + (int64_t)s * tiles * mt * 1024) * 4 + 64;
+}
+// fq_launch_gemm_i4_skinny with the K range of every feature tile split over fq_gemm_i4_skinny_splits workgroups (kws: zeroed counters in front,
+// fq_gemm_i4_skinny_split_ws_bytes bytes); kws == nullptr or a geometry that is not split: the plain launch. Same results bit for bit.
+int fq_launch_gemm_i4_skinny_split(const uint8_t* X, const void* wimg, int64_t M, int N, int K, f16* y, const f16* srow, const f16* scol,
+                                   const f16* bias, int* kws, hipStream_t stream) {
+    const int s = kws != nullptr ? fq_gemm_i4_skinny_splits(M, N, K) : 1;
+    if (s <= 1) return fq_launch_gemm_i4_skinny(X, wimg, M, N, K, nullptr, y, srow, scol, bias, stream);
+    GemmOut o;
+    o.c = nullptr;
+    o.y = y;
+    o.srow = srow;
+    o.scol = scol;
+    o.bias = bias;
+    const int tiles = (N + 31) / 32;
+    const dim3 grid((unsigned)tiles, (unsigned)s);
+    const uint4* img = reinterpret_cast<const uint4*>(wimg);
+    const SkinnyProblems none = {};
+    int* ws = kws;      // counters [tiles] (the partial sums start at the next multiple of four ints: see the bytes function; the kernel uses `tiles` ints)
+    if (M <= 32) hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<1, false, 2, true>), grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o, none, ws);
+    else if (M <= 64) hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<2, false, 1, true>), grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o, none, ws);
+    else hipLaunchKernelGGL((fq_gemm_i4_skinny_kernel<4, false, 1, true>), grid, dim3(SK_WAVES * 64), 0, stream, X, img, (int)M, N, K / 2, o, none, ws);
     return (int)hipGetLastError();
 }
 

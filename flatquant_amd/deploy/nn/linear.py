@@ -178,6 +178,8 @@ class Linear4bit(torch.nn.Module):
                 if plan is None:
                     ws16, b16 = self._scales16()
                     plan = st.add(q, ops.skinny_linear_fresh_plan(q, dimg, ws16, b16, self.out_features, lead + (self.out_features,)), (w,))
+                if rows >= 33 or self.in_features >= 8192:   # (a captured step of this size takes the split launch: its zeroed workspace must exist ON THIS STREAM before the capture)
+                    ops.skinny_split_workspace(rows, self.out_features, self.in_features, q.device)
                 return plan.run_linear(q, scales_x)
             if dimg is not None:
                 ws16, b16 = self._scales16()

@@ -1412,9 +1412,27 @@ def int4_skinny_matmul(x: torch.Tensor, w_image: torch.Tensor, N: int) -> torch.
     return c
 
 
+_SKINNY_WS_BYTES: dict = {}      # (M tile count, N, K) -> fq_int4_skinny_split_workspace_bytes: a pure function
+
+
+def skinny_split_workspace(M: int, N: int, K: int, device, stream=None):
+    """-> (zeroed workspace | None, bytes) of the split weight-streaming launch for this geometry on the current stream (None: the geometry is
+    not split, or the call is inside a stream capture that no eager call on this stream preceded — the plain launch runs then). The eager
+    module path calls this too, so that a capture that follows its warm-up finds the workspace (deploy.nn.Linear4bit)."""
+    key = ((M + 31) // 32, N, K)
+    nbytes = _SKINNY_WS_BYTES.get(key)
+    if nbytes is None:
+        nbytes = _SKINNY_WS_BYTES[key] = int(lib.fq_int4_skinny_split_workspace_bytes(M, N, K))
+    if nbytes <= 0:
+        return None, 0
+    if stream is None:
+        stream = ctypes.c_void_p(_stream_handle(device))
+    return _kv_split_workspace(("skinny", device.index, stream.value, nbytes), nbytes, device), nbytes
+
+
 def int4_skinny_linear(x: torch.Tensor, x_scale: torch.Tensor, w_image: torch.Tensor, w_scale: torch.Tensor,
-                       bias: Optional[torch.Tensor], N: int) -> torch.Tensor:
-    """int4_linear for M <= 128 rows against a weight image (fq_int4_skinny_linear_f16), bit-identical."""
+                       bias: Optional[torch.Tensor], N: int, split: bool = True) -> torch.Tensor:
+    """int4_linear for M <= 128 rows against a weight image (fq_int4_skinny_linear_f16), bit-identical. ``split=False``: never the split launch."""
     _chk(x, "x", torch.uint8), _chk(x_scale, "x_scale"), _chk(w_scale, "w_scale")
     M, K = x.shape[0], x.shape[1] * 2
     if x_scale.numel() != M or w_scale.numel() != N:
@@ -1424,8 +1442,16 @@ def int4_skinny_linear(x: torch.Tensor, x_scale: torch.Tensor, w_image: torch.Te
     y = torch.empty((M, N), dtype=torch.float16, device=x.device)
     if M:
         with _on(x.device):
-            check(lib.fq_int4_skinny_linear_f16(_ptr(x), _ptr(x_scale), _ptr(w_image), _ptr(w_scale), _ptr(bias), M, N, K,
-                                                _ptr(y), _stream(x)))
+            # (round 6) a lone narrow projection of 33 .. 128 rows: the K range of its feature tiles over 2 - 4 workgroups (fq_int4_skinny_linear_split_f16),
+            # in a zeroed workspace kept per (device, stream, bytes) under the split-decode workspaces' protocol (never created inside a capture)
+            stream = _stream(x)
+            ws, nbytes = skinny_split_workspace(M, N, K, x.device, stream) if split else (None, 0)
+            if ws is not None:
+                check(lib.fq_int4_skinny_linear_split_f16(_ptr(x), _ptr(x_scale), _ptr(w_image), _ptr(w_scale), _ptr(bias), M, N, K,
+                                                          _ptr(y), _ptr(ws), nbytes, stream))
+            else:
+                check(lib.fq_int4_skinny_linear_f16(_ptr(x), _ptr(x_scale), _ptr(w_image), _ptr(w_scale), _ptr(bias), M, N, K,
+                                                    _ptr(y), stream))
     return y
 
 

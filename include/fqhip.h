@@ -368,6 +368,16 @@ int fq_int4_to_frag(const void* w, int N, int K, void* image, void* stream);
 int fq_int4_skinny_gemm_i32(const void* x, const void* w_image, int64_t M, int N, int K, void* c, void* stream);
 int fq_int4_skinny_linear_f16(const void* x, const void* x_scale, const void* w_image, const void* w_scale,
                               const void* bias, int64_t M, int N, int K, void* y, void* stream);
+
+/* (round 6, third session) fq_int4_skinny_linear_f16 with the K range of every 32-feature tile split over 2 (4) workgroups where the unsplit launch
+ * leaves CUs idle (at most 128 feature tiles) and either is busy with more than one token tile (33 .. 128 rows) or has a long K range (K >= 8192 from
+ * 9 rows, K >= 16384 from one): the workgroups of a tile leave int32 partial
+ * sums in `workspace`, the last to arrive adds them and runs sym_dequant + bias. Integer sums: y is bit-identical to the unsplit launch.
+ * workspace: fq_int4_skinny_split_workspace_bytes(M, N, K) bytes (0: this geometry is not split — the plain launch runs), 16-byte aligned, ZEROED
+ * once by the caller before its first use (the launch leaves its counters at zero), used by one launch at a time in stream order. NULL: never split. */
+int64_t fq_int4_skinny_split_workspace_bytes(int64_t M, int N, int K);
+int fq_int4_skinny_linear_split_f16(const void* x, const void* x_scale, const void* w_image, const void* w_scale, const void* bias, int64_t M, int N,
+                                    int K, void* y, void* workspace, int64_t workspace_bytes, void* stream);
 /*
  * (round 5) Up to FOUR decode-sized Linear4bit problems that share M (<= 128) and K — q / k / v, or up / gate, of one decoder layer
  * (deploy/nn/linear.py:40-54 runs once per projection; modeling_llama.py:66-78, 268-280), each with its own packed activations,

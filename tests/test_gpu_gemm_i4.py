@@ -203,3 +203,36 @@ def test_module_takes_the_skinny_path_for_decode_batches(ops):
     ref = ops.int4_linear(p.quantized_x.reshape(-1, 256), p.scales_x.reshape(-1), lin.weight,
                           lin.weight_scales.reshape(-1).half(), lin.bias.half()).view(4, 1, 384)
     assert torch.equal(y, ref)
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(33, 4096, 4096, False), (64, 4096, 14336, True), (100, 4096, 4096, True), (128, 4096, 14336, False),
+                                        (64, 1024, 4096, True), (128, 1000, 8192, False), (40, 2048, 2048, False), (64, 4096, 1024, True),
+                                        (16, 4096, 14336, True), (32, 4096, 14336, False), (1, 4096, 28672, False), (8, 4096, 14336, True), (9, 2048, 8192, False)])
+def test_skinny_linear_with_the_k_range_split_over_workgroups(ops, M, N, K, bias):
+    """fq_int4_skinny_linear_split_f16 (round 6): a lone narrow projection of 33 .. 128 rows with every feature tile's K range over 2 - 4
+    workgroups (int32 partial tiles in a workspace, the last arriver sums and de-quantises) — bit for bit the unsplit launch and the tile
+    kernel; repeated launches (the counters return to zero), geometries that are not split (too few blobs per workgroup) take the plain launch."""
+    from flatquant_amd._lib import lib
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randint(0, 256, (M, K // 2), generator=g, device="cuda", dtype=torch.uint8)
+    w = torch.randint(0, 256, (N, K // 2), generator=g, device="cuda", dtype=torch.uint8)
+    sx = (torch.rand(M, generator=g, device="cuda") * 0.1 + 0.01).half()
+    sw = (torch.rand(N, generator=g, device="cuda") * 0.1 + 0.01).half()
+    b = torch.randn(N, generator=g, device="cuda").half() if bias else None
+    img = ops.int4_to_frag(w)
+    want = ops.int4_skinny_linear(x, sx, img, sw, b, N, split=False)
+    assert torch.equal(want, ops.int4_linear(x, sx, w, sw, b))
+    nbytes = int(lib.fq_int4_skinny_split_workspace_bytes(M, N, K))
+    assert (nbytes > 0) == ((N + 31) // 32 <= 128 and K // 64 >= 64 and (M >= 33 or (K >= 8192 and (M >= 9 or K >= 16384))))   # (two rounds of blobs per workgroup; few rows: a long K only)
+    for _ in range(3):
+        got = ops.int4_skinny_linear(x, sx, img, sw, b, N)
+        assert torch.equal(got, want)
+    # rows that are not split, and the workspace contract
+    assert int(lib.fq_int4_skinny_split_workspace_bytes(8, N, 4096)) == 0 and int(lib.fq_int4_skinny_split_workspace_bytes(M, 8192, K)) == 0
+    if nbytes > 0:
+        from flatquant_amd import _lib
+        y = torch.empty(M, N, dtype=torch.float16, device="cuda")
+        small = torch.zeros(256, dtype=torch.uint8, device="cuda")
+        rc = lib.fq_int4_skinny_linear_split_f16(x.data_ptr(), sx.data_ptr(), img.data_ptr(), sw.data_ptr(), None, M, N, K, y.data_ptr(),
+                                                 small.data_ptr(), 256, None)
+        assert rc == _lib.FQ_EINVAL                                             # a workspace that is too small is refused, not overrun
