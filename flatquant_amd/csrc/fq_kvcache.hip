@@ -209,6 +209,10 @@ __device__ __forceinline__ float* kv_states(float* ws, size_t pairs) { return ws
 #define KV_PVM_OCC4 1      // the matrix-pipe form of the merged launch held to 128 VGPRs (four waves per SIMD; two registers spill) and run on eight-wave workgroups up to 1024 of them:
                            // the launch 36.2 -> 33.8 us at 64 requests, the step 140.1 -> 135.8 (r06c61); 0: 134 VGPRs, four-wave workgroups from 512 on
 #endif
+#ifndef KV_PVM_WIDE_MAX
+#define KV_PVM_WIDE_MAX 512    // the merged matrix-pipe launch runs eight-wave workgroups up to this many of them (two per CU); beyond, four-wave workgroups, four per CU:
+                               // the step at 80 / 96 / 128 requests 164.5 / 172.0 / 210.8 -> 159.4 / 168.1 / 206.5 us against a bound of 1024 (r06c75)
+#endif
 template <int HD, int NW, bool UNI, bool F16, bool SPLIT, int QG = 1, bool APPEND = false>
 __global__ __launch_bounds__(NW * 64, (KV_PVM_OCC4 && KV_PV_MFMA && QG == 4 && !F16 && UNI) ? 4 : 2) void fq_kv_decode_kernel(f16* __restrict__ o, const f16* __restrict__ q, PagedKv p,
                                                                const f16* __restrict__ qt, int transpose_out, float* ws, int qgroup, KvNew nw) {
@@ -978,7 +982,7 @@ int fq_launch_kv_decode(f16* o, const f16* q, void* kv_data, void* kv_param, con
     const int wg_heads = fq_kv_decode_wg_heads(batch, num_heads, qgroup, head_dim);
     const int qg = num_heads / wg_heads;
     const dim3 grid((unsigned)batch, (unsigned)wg_heads, split ? (unsigned)splits : 1u);
-    const bool wide = (int64_t)batch * wg_heads * (split ? splits : 1) < ((KV_PVM_OCC4 && qg == 4 && !f16_cache) ? 1025 : 512);  // fewer than two workgroups per CU: 8 waves each instead of 4 (measured: 158 -> 113 us at 8 x 8192; no gain from 512 up)
+    const bool wide = (int64_t)batch * wg_heads * (split ? splits : 1) < ((KV_PVM_OCC4 && qg == 4 && !f16_cache) ? KV_PVM_WIDE_MAX + 1 : 512);  // fewer than two workgroups per CU: 8 waves each instead of 4 (measured: 158 -> 113 us at 8 x 8192; no gain from 512 up)
 #define FQ_DEC5(HD_, NW_, UNI_, F16_, SP_, QG_, AP_)                                                                   \
     {                                                                                                                 \
         constexpr size_t ns_ = (size_t)(NW_ * (64 / (HD_ / 32))), nch_ = (size_t)NW_ * 64 / HD_;                      \
