@@ -926,7 +926,10 @@ int fq_launch_kv_append(void* kv_data, void* kv_param, const int* indptr, const 
 int fq_kv_decode_splits(int batch, int num_heads, int seq_hint) {
     const int64_t pairs = (int64_t)batch * num_heads;
     if (pairs <= 0 || pairs > 128) return 1;
-    int s = (int)(256 / pairs);   // one 8-wave workgroup per CU
+#ifndef KV_SPLIT_WGS
+#define KV_SPLIT_WGS 256
+#endif
+    int s = (int)(KV_SPLIT_WGS / pairs);   // one 8-wave workgroup per CU
     if (s > 16) s = 16;
     if (seq_hint > 0) {
         const int by_len = seq_hint / 256;
