@@ -243,6 +243,36 @@ __global__ __launch_bounds__(NW * 64, (KV_PVM_OCC4 && KV_PV_MFMA && QG == 4 && !
     // trans_matrix_k_inv_t)), fp32 accumulation — every thread sums HD / NCHQ terms of one output feature (one thread per feature
     // walked all HD terms in a dependent chain: microseconds in front of every workgroup, and a split launch has many), the NCHQ
     // partial sums meet in LDS (s_o is free until the states are written)
+#ifndef KV_QT_ONCE
+#define KV_QT_ONCE 1    // QG > 1: the query transform of the workgroup's heads in ONE pass over qt (0: a pass and two barriers per head, rounds 5-6)
+#endif
+    if (QG > 1 && KV_QT_ONCE && qt != nullptr) {
+        // (third session) the same sums in the same order for every head — qt is read once instead of QG times and the heads share one barrier pair
+        constexpr int NCHQ = NW * 64 / HD, CHQ = HD / NCHQ;
+        static_assert(QG * NCHQ <= NS, "partial sums of all heads fit the scratch rows");
+        const int j = tid % HD, c = tid / HD;
+        const f16* qrow0 = q + ((size_t)b * QH + head) * HD;
+        float a[QG];
+#pragma unroll
+        for (int g = 0; g < QG; ++g) a[g] = 0.0f;
+#pragma unroll 8
+        for (int i = c * CHQ; i < (c + 1) * CHQ; ++i) {
+            const float t = (float)qt[i * HD + j];
+#pragma unroll
+            for (int g = 0; g < QG; ++g) a[g] = __builtin_fmaf((float)qrow0[(size_t)g * HD + i], t, a[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < QG; ++g) s_o[g * NCHQ + c][j] = a[g];
+        __syncthreads();
+        for (int idx = tid; idx < QG * HD; idx += NW * 64) {
+            const int g = idx / HD, f = idx - g * HD;
+            float t = 0.0f;
+#pragma unroll
+            for (int cc = 0; cc < NCHQ; ++cc) t += s_o[g * NCHQ + cc][f];
+            s_q[g * HD + f] = (float)(f16)t;
+        }
+        __syncthreads();
+    } else {
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
         const f16* qrow = q + ((size_t)b * QH + head + g) * HD;
@@ -264,6 +294,7 @@ __global__ __launch_bounds__(NW * 64, (KV_PVM_OCC4 && KV_PV_MFMA && QG == 4 && !
             for (int j = tid; j < HD; j += NW * 64) s_q[g * HD + j] = (float)qrow[j];
         }
         __syncthreads();
+    }
     }
     // the A operand of K-step w: features 32 part + 8 w + feat(e) — INT4: the order kv_unpack8 leaves the nibbles in
     auto feat = [](int e) { return F16 ? e : KV_PERM[e]; };
