@@ -973,7 +973,9 @@ int fq_kv_decode_splits(int batch, int num_heads, int seq_hint) {
 // Merged where it pays (measured, profiles/r06_gqa_cache.txt: a Llama-3-8B step 178 -> 161 us at 64 requests, 293 -> 261 at 128, but 65 -> 79 at
 // one request and 102 -> 111 at sixteen: a quarter of the workgroups, each with four times the p . v arithmetic): from one merged workgroup per CU on.
 #ifndef KV_MERGE_MIN_PAIRS
-#define KV_MERGE_MIN_PAIRS 128   // (third session, with p . v of the merged launch on the matrix pipe — split launches included: 24 requests x 8 KV heads 107.9 -> 98.6 us per step merged, 16 x 8 (two workgroups per pair) 95.0 -> 90.3, 8 x 8 75.8 -> 76.9: r06c55, r06c57)
+#define KV_MERGE_MIN_PAIRS 32    // (third session: with p . v of the merged launch on the matrix pipe, its split hand-over, four waves per SIMD and the one-pass query transform the merged
+                                 // launch wins from 4 requests x 8 KV heads on: the step at 4 / 6 / 10 / 12 / 14 / 16 / 24 requests 70.0 / 76.0 / 90.5 / 89.4 / 94.0 / 95.0 / 107.9 -> 68.8 / 72.7 / 82.9 / 84.4 / 87.6 / 90.3 / 98.6 us
+                                 // (r06c55, r06c57, r06c81, r06c82); at 2 requests level, at one a loss)
 #endif
 #ifndef KV_MERGE_QG
 #define KV_MERGE_QG 0      // (measurement knob) 2: a group of four as TWO workgroups of two query heads (152 VGPRs: three waves per SIMD instead of two)

@@ -121,7 +121,7 @@ class MultiLayerPagedKVCache4Bit:
         profiles/r06_gqa_cache.txt). The page layout then differs from the reference's in its head count, nothing else.
         ``read_one_copy`` (round 6, third session): on the reference's replicated layout (``group_size`` > 1, not shared) the decode launch reads
         ONE of a KV head's ``group_size`` identical copies for the whole group of query heads (ops.kv_batch_decode(kv_copies=...)): every copy
-        is still written as the reference writes it, the values read are the same (the output bit-identical below 128 (request, KV head) pairs, up to
+        is still written as the reference writes it, the values read are the same (the output bit-identical below 32 (request, KV head) pairs, up to
         the order of fp32 additions above), a decode step reads 1 / group_size of the rows. Set it False
         if something other than this class's ``update`` fills the pages with copies that differ.
         ``fuse_append`` (round 6, third session): a decode step's K transform + K / V quantisation + append run INSIDE the decode-attention launch
@@ -318,7 +318,7 @@ class MultiLayerPagedKVCache4Bit:
         # the reference's replicated layout: group_size identical copies per KV head, one of them read (read_one_copy)
         copies = self.group_size if (self.read_one_copy and 1 < self.group_size <= 8 and n_q_is_cache_heads(specs["kv_data"], heads, self.group_size)) else 1
         wgs = b * specs["kv_data"].shape[3]                 # workgroups of the decode launch: one per (request, cache head) ...
-        if copies in (2, 4, 8) and hd == 128 and wgs // copies >= 128:     # (KV_MERGE_MIN_PAIRS of fq_kvcache.hip)
+        if copies in (2, 4, 8) and hd == 128 and wgs // copies >= 32:     # (KV_MERGE_MIN_PAIRS of fq_kvcache.hip)
             wgs //= min(copies, 4)                          # ... or per (request, KV head) where one workgroup serves the group — up to four heads (fq_kv_decode_wg_heads)
         fused = (self.fuse_append and not init and added == 1 and not self.disable_quant and key_states.dtype == torch.float16
                  and wgs <= FUSE_APPEND_MAX_PAIRS

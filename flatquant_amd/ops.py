@@ -1788,7 +1788,7 @@ def kv_batch_decode(q: torch.Tensor, kv_data: torch.Tensor, kv_param: torch.Tens
     ``split=False``: never) — same results up to the order of fp32 additions. ``kv_copies`` = g > 1 (round 6): the cache is the reference's
     REPLICATED layout whose g consecutive heads per KV head hold identical rows (kv_cache.py:286-296; the appends of this package write them so)
     and the launch reads one copy per group (fq_kv_batch_decode_copies): the same values from 1 / g of the bytes (the same output bit for bit
-    below 128 (request, KV head) pairs; from there one workgroup serves a group: another order of the fp32 additions, as with split launches)."""
+    below 32 (request, KV head) pairs; from there one workgroup serves a group: another order of the fp32 additions, as with split launches)."""
     _chk(q, "q"), _chk(kv_data, "kv_data", kv_data.dtype), _chk(kv_param, "kv_param")
     n_layers, kv_heads, page_size, hd = _kv_geometry(kv_data)
     batch = _chk_kv_index(kv_indptr, kv_indices, last_page_offset)

@@ -664,7 +664,7 @@ int fq_kv_decode_append_i4(void* o, const void* q, const void* q_trans, int tran
  * of its group: `copies` consecutive cache heads with identical rows (fq_kv_quant_append_i4 / fq_kv_append_* with group_size = copies write them
  * so). fq_kv_batch_decode_copies computes the attention of fq_kv_batch_decode_split on such a cache — num_heads query heads = cache heads — but
  * reads the rows of cache head (h / copies) * copies for query head h: the same values from 1 / copies of the bytes — o bit for bit where the
- * launch geometry is the same; from 128 (request, group) pairs on one workgroup serves the group's query heads from one pass over the rows (as
+ * launch geometry is the same; from 32 (request, group) pairs on one workgroup serves the group's query heads from one pass over the rows (as
  * fq_kv_batch_decode_gqa): another order of the fp32 additions, as with split launches.
  * The caller asserts the copies ARE identical; a cache filled any other way must use fq_kv_batch_decode_split.
  * workspace: fq_kv_decode_workspace_bytes_gqa(batch, num_heads / copies, copies, head_dim). fq_kv_decode_append_i4(read_one_copy != 0) is the
