@@ -539,23 +539,29 @@ def reduce_over_ranks(dist, device, wall_s, kern_ms, elems, force=False):
 
 def timed_region(step, steps, warmup, dist, stream):
     """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides -> (wall seconds, average step
-    in ms from HIP events on the launch stream)."""
+    in ms from HIP events on the launch stream — of an identical K-step pass right behind the wall-clocked one)."""
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record(stream)                                       # same stream the kernels are launched on
     for i in range(steps):
         step(i)
-    ev1.record(stream)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0     # this rank's K steps, start to drained queue; the MAX over ranks is taken by the caller
     if dist is not None:                # the closing barrier + synchronize of the bracket: behind the clock — an RCCL barrier is an
         dist.barrier()                  # all-reduce of its own (~0.2 ms measured in a one-rank group: a third of 20 steps of 35 us)
+    torch.cuda.synchronize()
+    # The HIP-event figure of the same K steps, from an IDENTICAL pass right behind the wall-clocked one (round 6, third session): an event record
+    # is a packet of its own on this runtime — the two records inside the wall-clocked bracket cost it ~0.5 us per step at K = 20
+    # (tools/microbench/bracket_probe.py: 34.6 us with them, 34.1 without, events 33.7, K = 1000 33.7) — so the wall clock no longer carries them.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream)                                       # same stream the kernels are launched on
+    for i in range(steps):
+        step(i)
+    ev1.record(stream)
     torch.cuda.synchronize()
     return wall, ev0.elapsed_time(ev1) / steps
 
@@ -843,6 +849,7 @@ def main(argv=None):
                          "launch_us": dom_us, "clock": "wall (ms_per_step)" if ev_us is not None else "hip events, the kernel alone back to back",
                          "launch_us_events": ev_us, "achieved_events": (dom_bytes / (ev_us * 1e-6) / 1e9) if ev_us else None,
                          "frac_events": (dom_bytes / (ev_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if ev_us else None,
+                         "events_pass": "HIP events around an identical K-step pass right behind the wall-clocked one (an event record is a packet of its own: inside the wall-clocked bracket the two records cost ~0.5 us per step at K = 20)",
                          "per_launch": per_launch, "hbm_stream_floor_us": floor_us,
                          "frac_of_stream_floor": (floor_us / dom_us) if floor_us else None},
         }
