@@ -368,3 +368,38 @@ def test_cache_class_groups_of_eight(ops):
     used = caches[0].page_cnt_from_length(caches[0].length) * bsz
     assert torch.equal(caches[0].pages[:used], caches[1].pages[:used])
     assert torch.equal(caches[0].scales[:used].view(torch.int16), caches[1].scales[:used].view(torch.int16))
+
+
+def test_matrix_pipe_pv_against_fp64_dense_attention(ops):
+    """the merged launch with p . v on the matrix pipe (fp16 weights p_i s_i) against an fp64 softmax attention over the de-quantised cache: within
+    1e-3 of each output row's largest magnitude (measured 5.2 - 5.6e-4, of which 4.9e-4 is the fp16 output's half ulp: profiles/r06_pv_mfma.txt) —
+    flat and peaked score distributions, ragged lengths, 4 waves and 8 waves per workgroup"""
+    for bsz, qscale in ((40, 0.05), (40, 0.6), (70, 0.2)):
+        g = torch.Generator(device="cuda").manual_seed(bsz)
+        kv, copies, hd, page = 8, 4, 128, 64
+        lens = [200 + 37 * (b % 7) for b in range(bsz)]
+        data, param, indptr, indices, last = _replicated(g, bsz, lens, kv, copies, page)
+        q = (torch.randn(bsz, kv * copies, hd, generator=g, device="cuda") * qscale).half()
+        o = ops.kv_batch_decode(q, data, param, indptr, indices, last, 1, kv_copies=copies, seq_hint=max(lens)).double()
+        # dense reference for a few requests
+        n_pg = [(n + page - 1) // page for n in lens]
+        starts = [0]
+        for c in n_pg:
+            starts.append(starts[-1] + c)
+        worst = 0.0
+        for b in (0, 3, bsz - 1):
+            pages = indices[starts[b]:starts[b + 1]].long()
+            n = lens[b]
+            for h in (0, 5, 17, 31):
+                ch = (h // copies) * copies
+                kq = data[pages, 1, 0, ch].reshape(-1, hd // 2)[:n].to(torch.int32)
+                vq = data[pages, 1, 1, ch].reshape(-1, hd // 2)[:n].to(torch.int32)
+                kn = torch.stack([kq & 15, kq >> 4], -1).reshape(n, hd).double()
+                vn = torch.stack([vq & 15, vq >> 4], -1).reshape(n, hd).double()
+                kp = param[pages, 1, 0, ch].reshape(-1, 2)[:n].double()
+                vp = param[pages, 1, 1, ch].reshape(-1, 2)[:n].double()
+                K = kn * kp[:, :1] - kp[:, 1:]
+                V = vn * vp[:, :1] - vp[:, 1:]
+                ref = torch.softmax((K @ q[b, h].double()) / hd ** 0.5, 0) @ V
+                worst = max(worst, ((o[b, h] - ref).abs().max() / ref.abs().max()).item())
+        assert worst <= 1e-3, (bsz, qscale, worst)
